@@ -1,0 +1,150 @@
+// oracle/ref_enc_driver.cpp -- TEST INFRASTRUCTURE ONLY.
+//
+// A small command-line driver over the *reference's own* public encoder API
+// (codec/api/wels/codec_api.h:272 ISVCEncoder, :545 WelsCreateSVCEncoder).  It links against
+// oracle/_ref/libref_openh264.so (the reference compiled as-is by oracle/Makefile) and plays
+// the role h264enc + welsenc.cfg/layer2.cfg play in the reference tree
+// (codec/console/enc/src/welsenc.cpp), without needing those cfg files on the GPU box.
+//
+// Every option below maps 1:1 onto an SEncParamExt field (codec_app_def.h:540-598); defaults
+// are GetDefaultParams() (param_svc.h:132 FillDefault) unless stated.
+//
+//   ref_enc -i in.yuv -w W -h H -o out.264 [-frames N] [-fps F]
+//           [-rc M] [-qp Q] [-bitrate BPS] [-iper N] [-numtl N] [-complexity C]
+//           [-slcmd M] [-slcnum N] [-slcmbnum N] [-threads N] [-loadbalancing 0/1]
+//           [-deblock IDC] [-aq 0/1] [-bgd 0/1] [-scene 0/1] [-ltr 0/1] [-denoise 0/1]
+//           [-frameskip 0/1] [-cabac 0/1] [-spsid S] [-usage U] [-base] [-quiet]
+//
+// Prints "frames=<n> bytes=<n> enc_seconds=<s> fps=<f>" (timed strictly around EncodeFrame,
+// like welsenc.cpp:957-960).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <chrono>
+#include "codec_api.h"
+
+static bool arg_eq (const char* a, const char* b) { return std::strcmp (a, b) == 0; }
+
+int main (int argc, char** argv) {
+  std::string in, out;
+  int w = 0, h = 0, frames = -1, quiet = 0, use_base = 0;
+  float fps = 30.0f;
+  int rc = -1, qp = 24, bitrate = 5000000, iper = 0, numtl = 1, complexity = 0;
+  int slcmd = 0, slcnum = 1, slcmbnum = 0, threads = 1, loadbal = 0, deblock = 0;
+  int aq = 0, bgd = 0, scene = 0, ltr = 0, denoise = 0, frameskip = 0, cabac = 0, spsid = 1, usage = 0;
+  for (int i = 1; i < argc; ++i) {
+    const char* a = argv[i];
+    auto next = [&] () -> const char* { if (i + 1 >= argc) { std::fprintf (stderr, "missing value for %s\n", a); std::exit (2); } return argv[++i]; };
+    if (arg_eq (a, "-i")) in = next();
+    else if (arg_eq (a, "-o")) out = next();
+    else if (arg_eq (a, "-w")) w = std::atoi (next());
+    else if (arg_eq (a, "-h")) h = std::atoi (next());
+    else if (arg_eq (a, "-frames")) frames = std::atoi (next());
+    else if (arg_eq (a, "-fps")) fps = (float)std::atof (next());
+    else if (arg_eq (a, "-rc")) rc = std::atoi (next());
+    else if (arg_eq (a, "-qp")) qp = std::atoi (next());
+    else if (arg_eq (a, "-bitrate")) bitrate = std::atoi (next());
+    else if (arg_eq (a, "-iper")) iper = std::atoi (next());
+    else if (arg_eq (a, "-numtl")) numtl = std::atoi (next());
+    else if (arg_eq (a, "-complexity")) complexity = std::atoi (next());
+    else if (arg_eq (a, "-slcmd")) slcmd = std::atoi (next());
+    else if (arg_eq (a, "-slcnum")) slcnum = std::atoi (next());
+    else if (arg_eq (a, "-slcmbnum")) slcmbnum = std::atoi (next());
+    else if (arg_eq (a, "-threads")) threads = std::atoi (next());
+    else if (arg_eq (a, "-loadbalancing")) loadbal = std::atoi (next());
+    else if (arg_eq (a, "-deblock")) deblock = std::atoi (next());
+    else if (arg_eq (a, "-aq")) aq = std::atoi (next());
+    else if (arg_eq (a, "-bgd")) bgd = std::atoi (next());
+    else if (arg_eq (a, "-scene")) scene = std::atoi (next());
+    else if (arg_eq (a, "-ltr")) ltr = std::atoi (next());
+    else if (arg_eq (a, "-denoise")) denoise = std::atoi (next());
+    else if (arg_eq (a, "-frameskip")) frameskip = std::atoi (next());
+    else if (arg_eq (a, "-cabac")) cabac = std::atoi (next());
+    else if (arg_eq (a, "-spsid")) spsid = std::atoi (next());
+    else if (arg_eq (a, "-usage")) usage = std::atoi (next());
+    else if (arg_eq (a, "-base")) use_base = 1;
+    else if (arg_eq (a, "-quiet")) quiet = 1;
+    else { std::fprintf (stderr, "unknown option %s\n", a); return 2; }
+  }
+  if (in.empty() || w <= 0 || h <= 0) { std::fprintf (stderr, "need -i -w -h\n"); return 2; }
+
+  ISVCEncoder* enc = NULL;
+  if (WelsCreateSVCEncoder (&enc) || !enc) { std::fprintf (stderr, "WelsCreateSVCEncoder failed\n"); return 1; }
+  int trace = quiet ? WELS_LOG_QUIET : WELS_LOG_ERROR;
+  enc->SetOption (ENCODER_OPTION_TRACE_LEVEL, &trace);
+
+  int ret;
+  if (use_base) {            // the fixture used by test/api/BaseEncoderTest.cpp:8-24 (SEncParamBase)
+    SEncParamBase b; std::memset (&b, 0, sizeof (b));
+    b.iUsageType = (EUsageType)usage; b.iPicWidth = w; b.iPicHeight = h;
+    b.iTargetBitrate = bitrate; b.iRCMode = (RC_MODES)rc; b.fMaxFrameRate = fps;
+    ret = enc->Initialize (&b);
+  } else {
+    SEncParamExt p; enc->GetDefaultParams (&p);
+    p.iUsageType = (EUsageType)usage;
+    p.iPicWidth = w; p.iPicHeight = h;
+    p.iTargetBitrate = bitrate; p.iRCMode = (RC_MODES)rc; p.fMaxFrameRate = fps;
+    p.iTemporalLayerNum = numtl; p.iSpatialLayerNum = 1;
+    p.iComplexityMode = (ECOMPLEXITY_MODE)complexity;
+    p.uiIntraPeriod = (unsigned)iper;
+    p.eSpsPpsIdStrategy = (EParameterSetStrategy)spsid;
+    p.iEntropyCodingModeFlag = cabac;
+    p.bEnableFrameSkip = frameskip != 0;
+    p.iMultipleThreadIdc = (unsigned short)threads;
+    p.bUseLoadBalancing = loadbal != 0;
+    p.iLoopFilterDisableIdc = deblock;
+    p.bEnableDenoise = denoise != 0;
+    p.bEnableBackgroundDetection = bgd != 0;
+    p.bEnableAdaptiveQuant = aq != 0;
+    p.bEnableSceneChangeDetect = scene != 0;
+    p.bEnableLongTermReference = ltr != 0;
+    p.iMaxQp = 51; p.iMinQp = 0;
+    SSpatialLayerConfig& l = p.sSpatialLayers[0];
+    l.iVideoWidth = w; l.iVideoHeight = h; l.fFrameRate = fps;
+    l.iSpatialBitrate = bitrate; l.iDLayerQp = qp;
+    l.uiProfileIdc = PRO_BASELINE;               // layer2.cfg ProfileIdc 66
+    l.sSliceArgument.uiSliceMode = (SliceModeEnum)slcmd;
+    l.sSliceArgument.uiSliceNum = (unsigned)slcnum;
+    if (slcmbnum > 0) for (int k = 0; k < MAX_SLICES_NUM_TMP; ++k) l.sSliceArgument.uiSliceMbNum[k] = (unsigned)slcmbnum;
+    ret = enc->InitializeExt (&p);
+  }
+  if (ret) { std::fprintf (stderr, "Initialize failed: %d\n", ret); return 1; }
+
+  FILE* fi = std::fopen (in.c_str(), "rb");
+  if (!fi) { std::fprintf (stderr, "cannot open %s\n", in.c_str()); return 1; }
+  FILE* fo = out.empty() ? NULL : std::fopen (out.c_str(), "wb");
+  const size_t fsz = (size_t)w * h * 3 / 2;
+  std::vector<unsigned char> buf (fsz);
+  SSourcePicture pic; std::memset (&pic, 0, sizeof (pic));
+  pic.iColorFormat = videoFormatI420; pic.iPicWidth = w; pic.iPicHeight = h;
+  pic.iStride[0] = w; pic.iStride[1] = pic.iStride[2] = w >> 1;
+  pic.pData[0] = buf.data(); pic.pData[1] = buf.data() + (size_t)w * h; pic.pData[2] = pic.pData[1] + (size_t) (w >> 1) * (h >> 1);
+  SFrameBSInfo info;
+  long long total = 0; int n = 0; double secs = 0.0;
+  while ((frames < 0 || n < frames) && std::fread (buf.data(), 1, fsz, fi) == fsz) {
+    std::memset (&info, 0, sizeof (info));
+    pic.uiTimeStamp = (long long) (n * (1000.0 / fps) + 0.5);
+    auto t0 = std::chrono::steady_clock::now();
+    ret = enc->EncodeFrame (&pic, &info);
+    auto t1 = std::chrono::steady_clock::now();
+    secs += std::chrono::duration<double> (t1 - t0).count();
+    if (ret) { std::fprintf (stderr, "EncodeFrame failed: %d\n", ret); return 1; }
+    if (info.eFrameType != videoFrameTypeSkip) {
+      for (int li = 0; li < info.iLayerNum; ++li) {
+        const SLayerBSInfo& L = info.sLayerInfo[li];
+        int sz = 0; for (int k = 0; k < L.iNalCount; ++k) sz += L.pNalLengthInByte[k];
+        if (fo) std::fwrite (L.pBsBuf, 1, sz, fo);
+        total += sz;
+      }
+    }
+    ++n;
+  }
+  if (fo) std::fclose (fo);
+  std::fclose (fi);
+  enc->Uninitialize();
+  WelsDestroySVCEncoder (enc);
+  std::printf ("frames=%d bytes=%lld enc_seconds=%.6f fps=%.3f\n", n, total, secs, secs > 0 ? n / secs : 0.0);
+  return 0;
+}
