@@ -1,0 +1,130 @@
+/* welship.h -- C ABI of libwelship.so, the MI355X-native macroblock engine behind the OpenH264
+ * encoder API.
+ *
+ * Three layers, each one the drop-in counterpart of a reference interface (paths relative to the
+ * cisco/openh264 tree):
+ *
+ *  (1) SESSION  -- mirrors ISVCEncoder (codec/api/wels/codec_api.h:272-343; C vtable :477-493):
+ *      WelsHipCreateEncoder/Destroy  <->  WelsCreateSVCEncoder / WelsDestroySVCEncoder (:545,:552)
+ *      WelsHipInitializeExt          <->  ISVCEncoder::InitializeExt (const SEncParamExt*)   (:286)
+ *      WelsHipGetDefaultParams       <->  ISVCEncoder::GetDefaultParams                      (:293)
+ *      WelsHipEncodeFrame            <->  ISVCEncoder::EncodeFrame (SSourcePicture*, SFrameBSInfo*) (:307)
+ *      WelsHipForceIntraFrame        <->  ISVCEncoder::ForceIntraFrame                       (:323)
+ *      WelsHipUninitialize           <->  ISVCEncoder::Uninitialize                          (:298)
+ *      Same call order, same ownership rules (input planes are caller-owned for the duration of the
+ *      call; output buffers are encoder-owned and valid until the next call on the same object),
+ *      return 0 = cmResultSuccess, 1 = cmInitParaError, 2 = cmUnknownReason, 4 = cmUnsupportedData
+ *      (codec_def.h:80-87).
+ *
+ *  (2) FRAME-LEVEL HOOKS on device-resident pictures -- what the patched reference would reach
+ *      through its dispatch table instead of the per-MB loops:
+ *      WelsHipSliceMdIntra / WelsHipSliceMdInter  <->  WelsISliceMdEnc / WelsMdInterMbLoop
+ *                      (codec/encoder/core/src/svc_encode_slice.cpp:534-599, :1807-1899)
+ *      WelsHipDeblockingFilterFrame  <->  pfDeblocking.pfDeblockingFilterSlice / DeblockingFilterFrameAvcbase
+ *                      (codec/encoder/core/inc/wels_func_ptr_def.h:86-101, deblocking.cpp:656-691)
+ *      WelsHipExpandPicture          <->  pfExpandLumaPicture / pfExpandChromaPicture
+ *                      (wels_func_ptr_def.h, codec/common/src/expand_pic.cpp:271-350)
+ *
+ *  (3) LEAF PRIMITIVES, batched over arrays of blocks -- same per-block semantics as the entries of
+ *      SWelsFuncPtrList (codec/encoder/core/inc/wels_func_ptr_def.h:58-296) and SMcFunc
+ *      (codec/common/inc/mc.h:40-53); see the WelsHipPrim* declarations below.
+ *
+ * No PyTorch types appear here: plain pointers and sizes only.  Pointers named d_* are DEVICE
+ * (HBM) addresses, everything else is host memory.  The library needs an MI355X (gfx950); every
+ * entry point that touches the device returns WELSHIP_ERR_NO_DEVICE when none is usable -- there
+ * is no CPU fallback.
+ */
+#ifndef WELSHIP_H_
+#define WELSHIP_H_
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WELSHIP_OK 0
+#define WELSHIP_ERR_INIT_PARA 1      /* cmInitParaError   */
+#define WELSHIP_ERR_UNKNOWN 2        /* cmUnknownReason   */
+#define WELSHIP_ERR_UNSUPPORTED 4    /* cmUnsupportedData */
+#define WELSHIP_ERR_NO_DEVICE 100
+#define WELSHIP_ERR_VLC_OVERFLOW 101
+
+/* ---- (1) session API ---------------------------------------------------------------------- */
+
+/* Subset of SEncParamExt (codec_app_def.h:540-598) this engine honours; field names kept. */
+typedef struct WelsHipEncParam {
+  int32_t iUsageType;               /* 0 = CAMERA_VIDEO_REAL_TIME (only value supported)            */
+  int32_t iPicWidth, iPicHeight;
+  int32_t iTargetBitrate;           /* bps; only feeds level selection while iRCMode == -1          */
+  int32_t iRCMode;                  /* -1 = RC_OFF_MODE (constant QP) is the only supported mode    */
+  float   fMaxFrameRate;
+  int32_t iTemporalLayerNum;        /* 1                                                            */
+  int32_t iSpatialLayerNum;         /* 1                                                            */
+  int32_t iComplexityMode;          /* 0 LOW (SAD / fast I4x4), 1 MEDIUM, 2 HIGH (SATD / full I4x4)  */
+  uint32_t uiIntraPeriod;           /* 0 = first frame only, N = IDR every N frames                  */
+  int32_t eSpsPpsIdStrategy;        /* 0 CONSTANT_ID, 1 INCREASING_ID                                */
+  int32_t iEntropyCodingModeFlag;   /* 0 = CAVLC (CABAC is host work that is not implemented yet)    */
+  int32_t iLoopFilterDisableIdc;    /* 0, 1, 2                                                       */
+  int32_t iLoopFilterAlphaC0Offset, iLoopFilterBetaOffset;
+  int32_t bEnableFrameCroppingFlag;
+  int32_t iDLayerQp;                /* sSpatialLayers[0].iDLayerQp                                   */
+  int32_t uiSliceMode;              /* 0 SM_SINGLE_SLICE, 1 SM_FIXEDSLCNUM_SLICE                     */
+  int32_t uiSliceNum;
+  int32_t bEnableAdaptiveQuant, bEnableBackgroundDetection, bEnableSceneChangeDetect,
+          bEnableLongTermReference, bEnableDenoise, bEnableFrameSkip;   /* must all be 0 for now    */
+  int32_t iDevice;                  /* HIP device ordinal                                            */
+  int32_t reserved[7];
+} WelsHipEncParam;
+
+/* SSourcePicture (codec_app_def.h:659-671), I420 only */
+typedef struct WelsHipSourcePicture {
+  int32_t iColorFormat;             /* 23 = videoFormatI420 */
+  int32_t iStride[4];
+  const uint8_t* pData[4];
+  int32_t iPicWidth, iPicHeight;
+  int64_t uiTimeStamp;
+} WelsHipSourcePicture;
+
+/* SLayerBSInfo / SFrameBSInfo (codec_app_def.h:621-657) */
+#define WELSHIP_MAX_LAYER_NUM_OF_FRAME 128
+#define WELSHIP_NON_VIDEO_CODING_LAYER 0
+#define WELSHIP_VIDEO_CODING_LAYER 1
+enum { WelsHipFrameTypeInvalid = 0, WelsHipFrameTypeIDR = 1, WelsHipFrameTypeI = 2, WelsHipFrameTypeP = 3, WelsHipFrameTypeSkip = 4 };
+typedef struct WelsHipLayerBSInfo {
+  uint8_t uiTemporalId, uiSpatialId, uiQualityId;
+  int32_t eFrameType;
+  uint8_t uiLayerType;
+  int32_t iSubSeqId;
+  int32_t iNalCount;
+  int32_t* pNalLengthInByte;
+  uint8_t* pBsBuf;
+} WelsHipLayerBSInfo;
+typedef struct WelsHipFrameBSInfo {
+  int32_t iLayerNum;
+  WelsHipLayerBSInfo sLayerInfo[4];
+  int32_t eFrameType;
+  int32_t iFrameSizeInBytes;
+  int64_t uiTimeStamp;
+} WelsHipFrameBSInfo;
+
+typedef struct WelsHipEncoder WelsHipEncoder;
+
+int  WelsHipCreateEncoder (WelsHipEncoder** ppEncoder);
+void WelsHipDestroyEncoder (WelsHipEncoder* pEncoder);
+int  WelsHipGetDefaultParams (WelsHipEncoder* pEncoder, WelsHipEncParam* pParam);
+int  WelsHipInitializeExt (WelsHipEncoder* pEncoder, const WelsHipEncParam* pParam);
+int  WelsHipUninitialize (WelsHipEncoder* pEncoder);
+int  WelsHipEncodeFrame (WelsHipEncoder* pEncoder, const WelsHipSourcePicture* kpSrcPic, WelsHipFrameBSInfo* pBsInfo);
+int  WelsHipForceIntraFrame (WelsHipEncoder* pEncoder, int bIDR);
+/* Test/diagnostic hook (the reference's -drec / DumpDependencyRec, encoder_ext.cpp:3909-3915):
+ * copies the last reconstructed (deblocked) frame, cropped to iPicWidth x iPicHeight, as I420. */
+int  WelsHipGetReconFrame (WelsHipEncoder* pEncoder, uint8_t* pDstI420, size_t uiDstBytes);
+/* Name of the device backend in use ("hip:gfx950 ..."). */
+const char* WelsHipBackendName (WelsHipEncoder* pEncoder);
+const char* WelsHipGetLastError (void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* WELSHIP_H_ */

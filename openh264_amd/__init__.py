@@ -1,0 +1,191 @@
+"""openh264_amd -- Python binding (ctypes) over libwelship.so, the MI355X-native macroblock engine
+behind the OpenH264 encoder API.
+
+`Encoder` mirrors the reference's ISVCEncoder (codec/api/wels/codec_api.h:272-343): same method
+names, argument meaning and error behaviour (0 = cmResultSuccess, non-zero = CM_RETURN error), so
+the parity tests read like test/api/BaseEncoderTest.cpp.  The product library is HIP-only: loading
+works anywhere libamdhip64 is installed, but any call that needs the device fails loudly when no
+MI355X is present -- there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "libwelship.so")
+
+videoFormatI420 = 23
+RC_OFF_MODE = -1
+(LOW_COMPLEXITY, MEDIUM_COMPLEXITY, HIGH_COMPLEXITY) = (0, 1, 2)
+(SM_SINGLE_SLICE, SM_FIXEDSLCNUM_SLICE) = (0, 1)
+(CONSTANT_ID, INCREASING_ID) = (0, 1)
+(videoFrameTypeInvalid, videoFrameTypeIDR, videoFrameTypeI, videoFrameTypeP, videoFrameTypeSkip) = range(5)
+cmResultSuccess, cmInitParaError, cmUnknownReason, cmUnsupportedData = 0, 1, 2, 4
+ERR_NO_DEVICE, ERR_VLC_OVERFLOW = 100, 101
+
+
+class SEncParamExt(C.Structure):
+    """WelsHipEncParam (include/welship.h) -- the honoured subset of SEncParamExt, same field names."""
+    _fields_ = [
+        ("iUsageType", C.c_int32), ("iPicWidth", C.c_int32), ("iPicHeight", C.c_int32),
+        ("iTargetBitrate", C.c_int32), ("iRCMode", C.c_int32), ("fMaxFrameRate", C.c_float),
+        ("iTemporalLayerNum", C.c_int32), ("iSpatialLayerNum", C.c_int32), ("iComplexityMode", C.c_int32),
+        ("uiIntraPeriod", C.c_uint32), ("eSpsPpsIdStrategy", C.c_int32), ("iEntropyCodingModeFlag", C.c_int32),
+        ("iLoopFilterDisableIdc", C.c_int32), ("iLoopFilterAlphaC0Offset", C.c_int32), ("iLoopFilterBetaOffset", C.c_int32),
+        ("bEnableFrameCroppingFlag", C.c_int32), ("iDLayerQp", C.c_int32), ("uiSliceMode", C.c_int32), ("uiSliceNum", C.c_int32),
+        ("bEnableAdaptiveQuant", C.c_int32), ("bEnableBackgroundDetection", C.c_int32), ("bEnableSceneChangeDetect", C.c_int32),
+        ("bEnableLongTermReference", C.c_int32), ("bEnableDenoise", C.c_int32), ("bEnableFrameSkip", C.c_int32),
+        ("iDevice", C.c_int32), ("reserved", C.c_int32 * 7),
+    ]
+
+
+class SSourcePicture(C.Structure):
+    _fields_ = [("iColorFormat", C.c_int32), ("iStride", C.c_int32 * 4), ("pData", C.c_void_p * 4),
+                ("iPicWidth", C.c_int32), ("iPicHeight", C.c_int32), ("uiTimeStamp", C.c_int64)]
+
+
+class SLayerBSInfo(C.Structure):
+    _fields_ = [("uiTemporalId", C.c_uint8), ("uiSpatialId", C.c_uint8), ("uiQualityId", C.c_uint8),
+                ("eFrameType", C.c_int32), ("uiLayerType", C.c_uint8), ("iSubSeqId", C.c_int32),
+                ("iNalCount", C.c_int32), ("pNalLengthInByte", C.POINTER(C.c_int32)), ("pBsBuf", C.POINTER(C.c_uint8))]
+
+
+class SFrameBSInfo(C.Structure):
+    _fields_ = [("iLayerNum", C.c_int32), ("sLayerInfo", SLayerBSInfo * 4), ("eFrameType", C.c_int32),
+                ("iFrameSizeInBytes", C.c_int32), ("uiTimeStamp", C.c_int64)]
+
+
+class WelsHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("welship error %d: %s" % (code, msg))
+        self.code = code
+
+
+_libs = {}
+
+
+def load_library(path=None):
+    """Load libwelship.so (or, in the CPU-only test tier, the emulation test build given by `path`)."""
+    path = path or os.environ.get("WELSHIP_LIB") or DEFAULT_LIB
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
+        raise ImportError("%s not found -- run `python -c 'import __graft_entry__ as g; g.build()'` first" % path)
+    lib = C.CDLL(path)
+    lib.WelsHipCreateEncoder.argtypes = [C.POINTER(C.c_void_p)]
+    lib.WelsHipDestroyEncoder.argtypes = [C.c_void_p]
+    lib.WelsHipDestroyEncoder.restype = None
+    lib.WelsHipGetDefaultParams.argtypes = [C.c_void_p, C.POINTER(SEncParamExt)]
+    lib.WelsHipInitializeExt.argtypes = [C.c_void_p, C.POINTER(SEncParamExt)]
+    lib.WelsHipUninitialize.argtypes = [C.c_void_p]
+    lib.WelsHipEncodeFrame.argtypes = [C.c_void_p, C.POINTER(SSourcePicture), C.POINTER(SFrameBSInfo)]
+    lib.WelsHipForceIntraFrame.argtypes = [C.c_void_p, C.c_int]
+    lib.WelsHipGetReconFrame.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.WelsHipBackendName.argtypes = [C.c_void_p]
+    lib.WelsHipBackendName.restype = C.c_char_p
+    lib.WelsHipGetLastError.restype = C.c_char_p
+    _libs[path] = lib
+    return lib
+
+
+class Encoder:
+    """Mirror of ISVCEncoder for the hot path (create = WelsCreateSVCEncoder)."""
+
+    def __init__(self, lib_path=None):
+        self._lib = load_library(lib_path)
+        h = C.c_void_p()
+        rc = self._lib.WelsHipCreateEncoder(C.byref(h))
+        if rc:
+            raise WelsHipError(rc, "WelsHipCreateEncoder")
+        self._h = h
+        self._w = self._h_pix = 0
+
+    def _err(self):
+        return (self._lib.WelsHipGetLastError() or b"").decode()
+
+    def GetDefaultParams(self):
+        p = SEncParamExt()
+        self._lib.WelsHipGetDefaultParams(self._h, C.byref(p))
+        return p
+
+    def InitializeExt(self, param):
+        rc = self._lib.WelsHipInitializeExt(self._h, C.byref(param))
+        if rc == 0:
+            self._w, self._h_pix = param.iPicWidth, param.iPicHeight
+        return rc
+
+    def Uninitialize(self):
+        return self._lib.WelsHipUninitialize(self._h)
+
+    def ForceIntraFrame(self, idr=True):
+        return self._lib.WelsHipForceIntraFrame(self._h, 1 if idr else 0)
+
+    def EncodeFrame(self, yuv, timestamp=0):
+        """yuv: bytes-like I420 frame of iPicWidth x iPicHeight.  Returns (rc, frame_type, bytes, nal_lengths)."""
+        w, h = self._w, self._h_pix
+        buf = (C.c_uint8 * len(yuv)).from_buffer_copy(yuv) if not isinstance(yuv, C.Array) else yuv
+        base = C.addressof(buf)
+        pic = SSourcePicture()
+        pic.iColorFormat = videoFormatI420
+        pic.iStride[0], pic.iStride[1], pic.iStride[2] = w, w // 2, w // 2
+        pic.pData[0], pic.pData[1], pic.pData[2] = base, base + w * h, base + w * h + (w // 2) * (h // 2)
+        pic.iPicWidth, pic.iPicHeight, pic.uiTimeStamp = w, h, timestamp
+        info = SFrameBSInfo()
+        rc = self._lib.WelsHipEncodeFrame(self._h, C.byref(pic), C.byref(info))
+        if rc:
+            return rc, videoFrameTypeInvalid, b"", []
+        out = bytearray()
+        nals = []
+        for li in range(info.iLayerNum):
+            L = info.sLayerInfo[li]
+            n = sum(L.pNalLengthInByte[k] for k in range(L.iNalCount))
+            nals += [L.pNalLengthInByte[k] for k in range(L.iNalCount)]
+            out += C.string_at(L.pBsBuf, n)
+        return 0, info.eFrameType, bytes(out), nals
+
+    def GetReconFrame(self):
+        n = self._w * self._h_pix * 3 // 2
+        buf = (C.c_uint8 * n)()
+        rc = self._lib.WelsHipGetReconFrame(self._h, buf, n)
+        if rc:
+            raise WelsHipError(rc, self._err())
+        return bytes(buf)
+
+    def backend_name(self):
+        return (self._lib.WelsHipBackendName(self._h) or b"").decode()
+
+    def last_error(self):
+        return self._err()
+
+    def close(self):
+        if self._h:
+            self._lib.WelsHipDestroyEncoder(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def encode_sequence(yuv_bytes, width, height, lib_path=None, **params):
+    """Convenience: encode a whole I420 sequence; returns (bitstream bytes, last recon frame)."""
+    enc = Encoder(lib_path)
+    p = enc.GetDefaultParams()
+    p.iPicWidth, p.iPicHeight = width, height
+    for k, v in params.items():
+        setattr(p, k, v)
+    rc = enc.InitializeExt(p)
+    if rc:
+        raise WelsHipError(rc, enc.last_error())
+    fsz = width * height * 3 // 2
+    out = bytearray()
+    for i in range(len(yuv_bytes) // fsz):
+        rc, _, bs, _ = enc.EncodeFrame(yuv_bytes[i * fsz:(i + 1) * fsz], timestamp=i * 33)
+        if rc:
+            raise WelsHipError(rc, enc.last_error())
+        out += bs
+    recon = enc.GetReconFrame()
+    enc.Uninitialize()
+    enc.close()
+    return bytes(out), recon

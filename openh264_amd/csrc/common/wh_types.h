@@ -1,0 +1,107 @@
+// wh_types.h -- data layout shared by the HIP kernels, the host encoder and the C ABI.
+//
+// Everything here is plain C so that it can be included from .hip, .cpp and (mirrored) ctypes.
+// Names follow the H.264 / OpenH264 domain: macroblock (MB), slice, picture, level, nzc.
+#pragma once
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+// ---- macroblock types (our own compact enum; the reference uses bit flags,
+//      codec/common/inc/wels_common_defs.h:275-300) -------------------------------------------
+enum {
+  WH_MB_I4x4   = 0,
+  WH_MB_I16x16 = 1,
+  WH_MB_P16x16 = 2,
+  WH_MB_P16x8  = 3,
+  WH_MB_P8x16  = 4,
+  WH_MB_P8x8   = 5,
+  WH_MB_PSKIP  = 6,
+  WH_MB_NONE   = 255
+};
+#define WH_IS_INTRA(t) ((t) <= WH_MB_I16x16)
+#define WH_IS_INTER(t) ((t) >= WH_MB_P16x16 && (t) <= WH_MB_PSKIP)
+
+enum { WH_SLICE_P = 0, WH_SLICE_I = 2 };
+
+// ---- what the device hands to the host entropy coder for one MB --------------------------------
+// 960 bytes = 144 B side info + 816 B coefficient levels; the same split the reference keeps in
+// SMB + SMbCache + SDCTCoeff (svc_enc_macroblock.h:49-78, mb_cache.h:62-70,106-109).
+typedef struct WhMbRecord {
+  uint8_t  mb_type;          // WH_MB_*
+  uint8_t  cbp;              // coded_block_pattern: luma bits 0..3, chroma (0/1/2) << 4
+  uint8_t  luma_qp;          // QP this MB was quantised with
+  uint8_t  chroma_qp;
+  uint8_t  i16_mode;         // Intra16x16PredMode 0..3 (V,H,DC,Plane)
+  uint8_t  chroma_mode;      // intra_chroma_pred_mode 0..3 (DC,H,V,Plane)
+  uint16_t i4_prev_flags;    // bit b = prev_intra4x4_pred_mode_flag of luma4x4BlkIdx b
+  int8_t   i4_rem[16];       // rem_intra4x4_pred_mode per luma4x4BlkIdx
+  uint8_t  sub_type[4];      // sub_mb_type per 8x8 (0:8x8 1:8x4 2:4x8 3:4x4)
+  int8_t   ref_idx[4];
+  int16_t  mvd[16][2];       // mvd_l0 per 4x4 block in raster order (x,y), quarter-pel
+  uint8_t  nzc[24];          // total_coeff: luma raster 0..15, Cb raster 16..19, Cr raster 20..23
+  int32_t  cost;             // mode-decision cost of the chosen mode (for rate control)
+  uint8_t  pad[20];
+  // coefficient levels in zig-zag order:
+  int16_t  luma[16][16];     // per luma4x4BlkIdx; I16x16: entries 0..14 = AC, [15] = 0
+  int16_t  luma_dc[16];      // Intra16x16 DC levels
+  int16_t  chroma_ac[8][16]; // Cb blkIdx 0..3, Cr 4..7; entries 0..14 = AC
+  int16_t  chroma_dc[2][4];
+} WhMbRecord;
+
+// ---- per-MB state that lives in HBM across MBs / pictures (neighbour + next-frame context) ----
+typedef struct WhMbState {
+  uint8_t  mb_type;
+  uint8_t  luma_qp;          // QP seen by the deblocking filter (after the "last coded QP" rule)
+  uint8_t  chroma_qp;
+  uint8_t  cbp;
+  uint16_t slice_idc;
+  uint8_t  skip_flag;
+  uint8_t  pad0;
+  int8_t   i4_mode[16];      // Intra4x4PredMode per 4x4 block, raster; 2 (DC) for non-I4x4 MBs
+  uint8_t  nzc[24];          // as in WhMbRecord
+  int16_t  mv[16][2];        // raster 4x4, quarter-pel
+  int8_t   ref_idx[4];
+  int32_t  sad_cost[4];      // pSadCost (md.cpp:826-910 PredictSad)
+  int16_t  p16mv[2];         // sP16x16Mv
+  int32_t  skip_sad;         // pMbSkipSad of the picture
+  uint8_t  pad1[4];
+} WhMbState;                 // 144 bytes
+
+// ---- one picture being encoded (one frame of one session) ---------------------------------------
+typedef struct WhPicJob {
+  const uint8_t* src[3];     // source planes, dims = mb_w*16 x mb_h*16 (host pads), own strides
+  uint8_t*       rec[3];     // reconstructed planes (point at pixel (0,0) inside the padded alloc)
+  const uint8_t* ref[3];     // reference planes (border-expanded) or NULL for I pictures
+  WhMbRecord*    records;    // mb_w*mb_h
+  WhMbState*     mbs;        // mb_w*mb_h, this picture
+  const WhMbState* ref_mbs;  // previous picture's states (P pictures)
+  int32_t        qp;         // picture QP (constant-QP mode) -- per-MB delta via qp_delta
+  int32_t        slice_type; // WH_SLICE_I / WH_SLICE_P
+  const int8_t*  qp_delta;   // optional per-MB QP offsets (adaptive quant) or NULL
+  int32_t        ref_is_p;   // reference picture was a P picture (co-located MV candidates)
+  int32_t        pad;
+} WhPicJob;
+
+#define WH_MAX_SLICES 36
+
+// ---- parameters common to every picture of a launch --------------------------------------------
+typedef struct WhSeqParams {
+  int32_t mb_w, mb_h;
+  int32_t src_stride_y, src_stride_c;
+  int32_t rec_stride_y, rec_stride_c;   // strides of rec[] and ref[] planes
+  int32_t complexity;                   // 0 = LOW (SAD costs, VAA-gated fast I4x4), >=1 = SATD / full
+  int32_t chroma_qp_offset;
+  int32_t num_slices;                   // slices are contiguous MB ranges
+  int32_t slice_first_mb[WH_MAX_SLICES + 1];
+  int32_t deblock_idc;                  // 0: all edges, 1: off, 2: not across slice boundaries
+  int32_t alpha_offset, beta_offset;
+  int32_t mv_range;                     // iMvRange
+  int32_t pad[3];
+} WhSeqParams;
+
+#ifdef __cplusplus
+}
+#endif

@@ -1,0 +1,34 @@
+// backend.h -- the narrow interface between the host-side encoder and the device that runs the
+// macroblock kernels.  The product implements it with HIP on gfx950 (hip/hip_backend.hip); the
+// CPU-only test build implements it with the wave-emulation of the same kernel sources
+// (tests/emu/emu_backend.cpp) so that host logic can be tested without a GPU.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+#include "../common/wh_types.h"
+
+namespace wh {
+
+class Backend {
+ public:
+  virtual ~Backend() {}
+  virtual const char* name() const = 0;
+  // device memory
+  virtual void* alloc (size_t bytes) = 0;
+  virtual void free (void* p) = 0;
+  virtual void upload (void* dst, const void* src, size_t bytes) = 0;
+  virtual void download (void* dst, const void* src, size_t bytes) = 0;
+  virtual void fill (void* dst, int value, size_t bytes) = 0;
+  // frame-level kernels over `n` pictures that share the sequence parameters P.
+  // `jobs` is a DEVICE array of WhPicJob.  All calls are asynchronous on the backend's stream.
+  virtual void run_intra (const WhSeqParams& P, const WhPicJob* jobs, int n) = 0;     // I pictures: MD + recon
+  virtual void run_inter (const WhSeqParams& P, const WhPicJob* jobs, int n) = 0;     // P pictures: ME + MD + recon
+  virtual void run_deblock (const WhSeqParams& P, const WhPicJob* jobs, int n) = 0;   // in-loop filter on rec[]
+  virtual void run_expand (const WhSeqParams& P, const WhPicJob* jobs, int n) = 0;    // replicate rec[] borders (32/16 px)
+  virtual void sync() = 0;
+};
+
+// Implemented by the HIP library only; returns NULL (and sets *err) when no MI355X is usable.
+Backend* create_hip_backend (int device, const char** err);
+
+}  // namespace wh

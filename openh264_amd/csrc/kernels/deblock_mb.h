@@ -1,0 +1,183 @@
+// deblock_mb.h -- in-loop deblocking of one macroblock by one wavefront (H.264 8.7).
+//
+// Reference behaviour restated:
+//   codec/encoder/core/src/deblocking.cpp:599-626  DeblockingBSCalc_c (+ :126-230 bS inside / at MB edges)
+//   codec/encoder/core/src/deblocking.cpp:357-440  DeblockingInterMb   (edge order, edge QP averaging)
+//   codec/encoder/core/src/deblocking.cpp:442-554  DeblockingIntraMb   (bS 4 on MB edges, 3 inside)
+//   codec/common/src/deblocking_common.cpp:5-181   DeblockLuma{Lt4,Eq4}_c, DeblockChroma{Lt4,Eq4}_c
+// MBs are processed on the same 2:1 diagonals as mode decision: MB (x,y) filters its left edge into
+// MB (x-1,y) and its top edge into MB (x,y-1), after (x+1,y-1) has finished its own left edge.
+#pragma once
+#include "prims.h"
+
+// LDS tile: luma pixel (x,y), x,y in [-4,15] at y[(y+4)*24 + x+4]; chroma (x,y) in [-2,7] -> c[p][(y+2)*12 + x+2]
+typedef struct WhDbLds {
+  uint8_t y[20 * 24];
+  uint8_t c[2][10 * 12];
+  uint8_t bs[2][4][4];       // [dir 0=vertical edges,1=horizontal][edge][segment]
+} WhDbLds;
+#define WH_DY(S, x, yy) ((S).y[((yy) + 4) * 24 + (x) + 4])
+#define WH_DC(S, p, x, yy) ((S).c[p][((yy) + 2) * 12 + (x) + 2])
+
+// one line of a luma edge: pix points at q0, step = distance between p/q samples
+WH_FN void wh_db_luma_line (uint8_t* q, int step, int bs, int alpha, int beta, int idx_a) {
+  if (bs == 0) return;
+  const int p0 = q[-step], p1 = q[-2 * step], p2 = q[-3 * step];
+  const int q0 = q[0], q1 = q[step], q2 = q[2 * step];
+  const int d = wh_abs (p0 - q0);
+  if (!(d < alpha && wh_abs (p1 - p0) < beta && wh_abs (q1 - q0) < beta)) return;
+  const bool ap = wh_abs (p2 - p0) < beta, aq = wh_abs (q2 - q0) < beta;
+  if (bs < 4) {
+    const int tc0 = kWhTc0[idx_a * 3 + bs - 1];
+    int tc = tc0;
+    if (ap) { q[-2 * step] = (uint8_t) (p1 + wh_clip3 ((p2 + ((p0 + q0 + 1) >> 1) - (p1 * 2)) >> 1, -tc0, tc0)); tc++; }
+    if (aq) { q[step] = (uint8_t) (q1 + wh_clip3 ((q2 + ((p0 + q0 + 1) >> 1) - (q1 * 2)) >> 1, -tc0, tc0)); tc++; }
+    const int delta = wh_clip3 ((((q0 - p0) * 4) + (p1 - q1) + 4) >> 3, -tc, tc);
+    q[-step] = wh_clip255 (p0 + delta);
+    q[0] = wh_clip255 (q0 - delta);
+  } else {
+    if (d < ((alpha >> 2) + 2)) {
+      if (ap) {
+        const int p3 = q[-4 * step];
+        q[-step] = (uint8_t) ((p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3);
+        q[-2 * step] = (uint8_t) ((p2 + p1 + p0 + q0 + 2) >> 2);
+        q[-3 * step] = (uint8_t) ((2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3);
+      } else {
+        q[-step] = (uint8_t) ((2 * p1 + p0 + q1 + 2) >> 2);
+      }
+      if (aq) {
+        const int q3 = q[3 * step];
+        q[0] = (uint8_t) ((p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3);
+        q[step] = (uint8_t) ((p0 + q0 + q1 + q2 + 2) >> 2);
+        q[2 * step] = (uint8_t) ((2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3);
+      } else {
+        q[0] = (uint8_t) ((2 * q1 + q0 + p1 + 2) >> 2);
+      }
+    } else {
+      q[-step] = (uint8_t) ((2 * p1 + p0 + q1 + 2) >> 2);
+      q[0] = (uint8_t) ((2 * q1 + q0 + p1 + 2) >> 2);
+    }
+  }
+}
+WH_FN void wh_db_chroma_line (uint8_t* q, int step, int bs, int alpha, int beta, int idx_a) {
+  if (bs == 0) return;
+  const int p0 = q[-step], p1 = q[-2 * step], q0 = q[0], q1 = q[step];
+  if (!(wh_abs (p0 - q0) < alpha && wh_abs (p1 - p0) < beta && wh_abs (q1 - q0) < beta)) return;
+  if (bs < 4) {
+    const int tc = kWhTc0[idx_a * 3 + bs - 1] + 1;
+    const int delta = wh_clip3 ((((q0 - p0) * 4) + (p1 - q1) + 4) >> 3, -tc, tc);
+    q[-step] = wh_clip255 (p0 + delta);
+    q[0] = wh_clip255 (q0 - delta);
+  } else {
+    q[-step] = (uint8_t) ((2 * p1 + p0 + q1 + 2) >> 2);
+    q[0] = (uint8_t) ((2 * q1 + q0 + p1 + 2) >> 2);
+  }
+}
+
+WH_FN bool wh_mv_far (const int16_t* a, const int16_t* b) {
+  return wh_abs (a[0] - b[0]) >= 4 || wh_abs (a[1] - b[1]) >= 4;
+}
+
+WH_FN void wh_deblock_mb_body (WhDbLds& S, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby) {
+  const int w = P.mb_w, xy = mby * w + mbx;
+  const WhMbState* M = &J.mbs[xy];
+  const int fidc = (P.deblock_idc != 0);        // 1: do not filter across slice boundaries
+  const bool left_ok = mbx > 0 && (!fidc || M->slice_idc == M[-1].slice_idc);
+  const bool top_ok = mby > 0 && (!fidc || M->slice_idc == M[-w].slice_idc);
+  const int type = M->mb_type;
+  const bool intra = WH_IS_INTRA (type);
+
+  // ---- boundary strengths ----
+  WV_LANES_BEGIN (lane)
+  if (lane < 32) {
+    const int dir = lane >> 4, e = (lane >> 2) & 3, s = lane & 3;
+    // block on the q side (inside this MB) and on the p side, raster 4x4 indices
+    const int bq = dir == 0 ? s * 4 + e : e * 4 + s;
+    int bs = 0;
+    if (e == 0) {
+      const bool ok = dir == 0 ? left_ok : top_ok;
+      if (ok) {
+        const WhMbState* N = dir == 0 ? M - 1 : M - w;
+        const int bp = dir == 0 ? s * 4 + 3 : 12 + s;
+        if (intra || WH_IS_INTRA (N->mb_type)) bs = 4;
+        else if (M->nzc[bq] | N->nzc[bp]) bs = 2;
+        else bs = (M->ref_idx[(bq >> 3) * 2 + ((bq & 3) >> 1)] != N->ref_idx[(bp >> 3) * 2 + ((bp & 3) >> 1)]) || wh_mv_far (M->mv[bq], N->mv[bp]);
+      }
+    } else if (intra) {
+      bs = 3;
+    } else if (type != WH_MB_PSKIP) {
+      const int bp = dir == 0 ? bq - 1 : bq - 4;
+      if (M->nzc[bq] | M->nzc[bp]) bs = 2;
+      else if (type != WH_MB_P16x16) bs = wh_mv_far (M->mv[bq], M->mv[bp]);
+    }
+    S.bs[dir][e][s] = (uint8_t)bs;
+  }
+  WV_LANES_END
+
+  // ---- load tile ----
+  WV_LANES_BEGIN (lane)
+  {
+    // luma: 20 rows x 20 cols (x,y in -4..15) = 5 words per row, 100 words
+    for (int i = lane; i < 100; i += 64) {
+      const int row = i / 5 - 4, x = (i % 5) * 4 - 4;
+      const uint8_t* r = J.rec[0] + (ptrdiff_t) (mby * 16 + row) * P.rec_stride_y + mbx * 16 + x;
+      * (uint32_t*)&S.y[(row + 4) * 24 + x + 4] = * (const uint32_t*)r;
+    }
+    // chroma: 10 rows x (2 + 8) cols per plane: load x = -2..9 as 6 halfwords -> use bytes
+    for (int i = lane; i < 200; i += 64) {
+      const int pl = i / 100, k = i % 100, row = k / 10 - 2, x = k % 10 - 2;
+      WH_DC (S, pl, x, row) = J.rec[1 + pl][(ptrdiff_t) (mby * 8 + row) * P.rec_stride_c + mbx * 8 + x];
+    }
+  }
+  WV_LANES_END
+
+  const int qp = M->luma_qp, qpc = M->chroma_qp;
+  // ---- vertical edges (dir 0) then horizontal edges (dir 1) ----
+  for (int dir = 0; dir < 2; ++dir) {
+    for (int e = 0; e < 4; ++e) {
+      if (e == 0 && !(dir == 0 ? left_ok : top_ok)) continue;
+      int eq = qp, eqc = qpc;
+      if (e == 0) {
+        const WhMbState* N = dir == 0 ? M - 1 : M - w;
+        eq = (qp + N->luma_qp + 1) >> 1;
+        eqc = (qpc + N->chroma_qp + 1) >> 1;
+      }
+      const int ia = wh_clip3 (eq + P.alpha_offset, 0, 51), ib = wh_clip3 (eq + P.beta_offset, 0, 51);
+      const int alpha = kWhAlpha[ia], beta = kWhBeta[ib];
+      const int iac = wh_clip3 (eqc + P.alpha_offset, 0, 51), ibc = wh_clip3 (eqc + P.beta_offset, 0, 51);
+      const int alphac = kWhAlpha[iac], betac = kWhBeta[ibc];
+      WV_LANES_BEGIN (lane)
+      if (lane < 16) {
+        if (alpha | beta) {
+          const int bs = S.bs[dir][e][lane >> 2];
+          uint8_t* q = dir == 0 ? &WH_DY (S, e * 4, lane) : &WH_DY (S, lane, e * 4);
+          wh_db_luma_line (q, dir == 0 ? 1 : 24, bs, alpha, beta, ia);
+        }
+      } else if (lane < 32 && (e & 1) == 0) {
+        if (alphac | betac) {
+          const int pl = (lane - 16) >> 3, k = lane & 7;
+          const int bs = S.bs[dir][e][k >> 1];
+          uint8_t* q = dir == 0 ? &WH_DC (S, pl, e * 2, k) : &WH_DC (S, pl, k, e * 2);
+          wh_db_chroma_line (q, dir == 0 ? 1 : 12, bs, alphac, betac, iac);
+        }
+      }
+      WV_LANES_END
+    }
+  }
+
+  // ---- store back rows/cols -3..15 (luma), -1..7 (chroma; only p0 changes) ----
+  WV_LANES_BEGIN (lane)
+  {
+    for (int i = lane; i < 19 * 19; i += 64) {
+      const int row = i / 19 - 3, x = i % 19 - 3;
+      if ((row >= 0 || top_ok) && (x >= 0 || left_ok) && !(row < 0 && x < 0))
+        J.rec[0][(ptrdiff_t) (mby * 16 + row) * P.rec_stride_y + mbx * 16 + x] = WH_DY (S, x, row);
+    }
+    for (int i = lane; i < 2 * 81; i += 64) {
+      const int pl = i / 81, k = i % 81, row = k / 9 - 1, x = k % 9 - 1;
+      if ((row >= 0 || top_ok) && (x >= 0 || left_ok) && !(row < 0 && x < 0))
+        J.rec[1 + pl][(ptrdiff_t) (mby * 8 + row) * P.rec_stride_c + mbx * 8 + x] = WH_DC (S, pl, x, row);
+    }
+  }
+  WV_LANES_END
+}

@@ -1,0 +1,89 @@
+// frame_kernels.h -- per-macroblock kernel bodies (one wavefront = one MB) and the 2:1 diagonal
+// scheduling helpers.  The __global__ wrappers live in hip/launch.hip; the CPU-side test build
+// (tests/emu) calls the same bodies in raster order.
+//
+// Restructures (does not port) the reference's MB loops:
+//   svc_encode_slice.cpp:534-599   WelsISliceMdEnc   (I slices)
+//   svc_encode_slice.cpp:1807-1899 WelsMdInterMbLoop (P slices, see inter_mb.h)
+#pragma once
+#include "intra_mb.h"
+
+static_assert (sizeof (WhMbRecord) == 960, "WhMbRecord must be 960 bytes");
+static_assert (sizeof (WhMbState) == 144, "WhMbState must be 144 bytes");
+
+// Store the MB's reconstruction, entropy record and neighbour state to HBM.
+WH_FN void wh_store_mb (WhMbLds& S, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, int mb_type, int cbp,
+                        int qp, int qpc, int i16_mode, int chroma_mode, int cost, int slice_idc) {
+  const int xy = mby * P.mb_w + mbx;
+  WhMbRecord* R = &J.records[xy];
+  WhMbState* M = &J.mbs[xy];
+  WV_LANES_BEGIN (lane)
+  {
+    const int row = lane >> 2, seg = lane & 3;
+    uint8_t* d = J.rec[0] + (size_t) (mby * 16 + row) * P.rec_stride_y + mbx * 16 + seg * 4;
+    * (uint32_t*)d = * (const uint32_t*)&WH_RY (S, seg * 4, row);
+  }
+  if (lane < 32) {
+    const int pl = lane >> 4, row = (lane >> 1) & 7, half = lane & 1;
+    uint8_t* d = J.rec[1 + pl] + (size_t) (mby * 8 + row) * P.rec_stride_c + mbx * 8 + half * 4;
+    * (uint32_t*)d = * (const uint32_t*)&WH_RC (S, pl, half * 4, row);
+  }
+  // coefficient levels: 4 luma + 2 chroma-AC int16 quads per lane
+  {
+    const uint64_t* s = (const uint64_t*)S.lv_luma;
+    uint64_t* d = (uint64_t*)&R->luma[0][0];
+    d[lane] = s[lane];
+  }
+  if (lane < 32) {
+    const uint64_t* s = (const uint64_t*)S.lv_cac;
+    uint64_t* d = (uint64_t*)&R->chroma_ac[0][0];
+    d[lane] = s[lane];
+  } else if (lane < 48) {
+    R->luma_dc[lane - 32] = (mb_type == WH_MB_I16x16) ? S.lv_dc[lane - 32] : (int16_t)0;
+  } else if (lane < 56) {
+    R->chroma_dc[0][lane - 48] = S.lv_cdc[lane - 48];
+  }
+  if (lane < 24) { R->nzc[lane] = S.nzc[lane]; M->nzc[lane] = S.nzc[lane]; }
+  if (lane < 16) {
+    R->i4_rem[lane] = (mb_type == WH_MB_I4x4) ? S.i4_rem[lane] : (int8_t)0;
+    M->i4_mode[lane] = (mb_type == WH_MB_I4x4) ? S.i4m[((lane >> 2) + 1) * 5 + (lane & 3) + 1] : (int8_t)2;
+  }
+  if (lane == 0) {
+    R->mb_type = (uint8_t)mb_type; R->cbp = (uint8_t)cbp; R->luma_qp = (uint8_t)qp; R->chroma_qp = (uint8_t)qpc;
+    R->i16_mode = (uint8_t)i16_mode; R->chroma_mode = (uint8_t)chroma_mode;
+    R->i4_prev_flags = (mb_type == WH_MB_I4x4) ? S.i4_prev : (uint16_t)0;
+    R->cost = cost;
+    M->mb_type = (uint8_t)mb_type; M->luma_qp = (uint8_t)qp; M->chroma_qp = (uint8_t)qpc; M->cbp = (uint8_t)cbp;
+    M->slice_idc = (uint16_t)slice_idc; M->skip_flag = 0;
+  }
+  WV_LANES_END
+}
+
+// One intra macroblock (I slice).
+WH_FN void wh_intra_mb_body (WhMbLds& S, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby) {
+  const int xy = mby * P.mb_w + mbx;
+  const int avail = wh_mb_avail (P, mbx, mby);
+  const int qp = wh_clip3 (J.qp, 0, 51);
+  const int qpc = kWhChromaQp[wh_clip3 (qp + P.chroma_qp_offset, 0, 51)];
+  wh_load_mb_tile (S, P, J, mbx, mby);
+  WhIntraResult r;
+  wh_intra_md_enc (S, P, J, mbx, mby, avail, qp, qpc, &r);
+  // intra MBs carry no motion: clear mv/ref so that later P pictures / deblocking see zeros
+  WV_LANES_BEGIN (lane)
+  if (lane < 16) { J.mbs[xy].mv[lane][0] = 0; J.mbs[xy].mv[lane][1] = 0; J.records[xy].mvd[lane][0] = 0; J.records[xy].mvd[lane][1] = 0; }
+  if (lane < 4) { J.mbs[xy].ref_idx[lane] = -1; J.records[xy].ref_idx[lane] = -1; J.records[xy].sub_type[lane] = 0; J.mbs[xy].sad_cost[lane] = 0; }
+  WV_LANES_END
+  wh_store_mb (S, P, J, mbx, mby, r.mb_type, r.cbp, qp, qpc, r.i16_mode_std, r.chroma_mode_std, r.cost_luma, wh_slice_of_mb (P, xy));
+}
+
+// ---- 2:1 diagonal ("wavefront") scheduling -----------------------------------------------------
+// MB (x,y) depends on (x-1,y), (x,y-1), (x+1,y-1)  =>  all MBs with  x + 2*y == d  are independent.
+// d runs 0 .. (mb_w - 1) + 2 * (mb_h - 1).  For diagonal d, the k-th MB is  y = y0 + k, x = d - 2*y.
+WH_FN int wh_diag_count (int mb_w, int mb_h, int d, int* y0) {
+  int ylo = (d - (mb_w - 1) + 1) >> 1;   // ceil((d - (mb_w-1)) / 2)
+  if (ylo < 0) ylo = 0;
+  int yhi = d >> 1;
+  if (yhi > mb_h - 1) yhi = mb_h - 1;
+  *y0 = ylo;
+  return yhi >= ylo ? yhi - ylo + 1 : 0;
+}

@@ -1,0 +1,435 @@
+// intra_mb.h -- mode decision + reconstruction of one intra macroblock by one wavefront.
+//
+// Reference behaviour restated (codec/encoder/core/src):
+//   svc_base_layer_md.cpp:956-962   WelsMdIntraMb
+//   svc_base_layer_md.cpp:365-417   WelsMdI16x16            (generic loop: the C build has no Combined3)
+//   svc_base_layer_md.cpp:418-546   WelsMdI4x4              (complexity >= MEDIUM)
+//   svc_base_layer_md.cpp:548-865   WelsMdI4x4Fast          (complexity LOW, gated by md.cpp:435-475,497-503)
+//   svc_base_layer_md.cpp:867-930   WelsMdIntraChroma
+//   svc_base_layer_md.cpp:2023-2039 WelsMdIntraSecondaryModesEnc
+//   get_intra_predictor.cpp:79-613, common/src/intra_pred_common.cpp:47-77  (predictors)
+#pragma once
+#include "mb_common.h"
+
+// ---- neighbour availability (svc_encode_slice.cpp:138-174 UpdateMbNeighbor: same slice only) ----
+#define WH_AV_LEFT 1
+#define WH_AV_TOP 2
+#define WH_AV_TOPLEFT 4
+#define WH_AV_TOPRIGHT 8
+
+WH_FN int wh_slice_of_mb (const WhSeqParams& P, int mbxy) {
+  int s = 0;
+  for (int i = 1; i < P.num_slices; ++i) s += (mbxy >= P.slice_first_mb[i]);
+  return s;
+}
+WH_FN int wh_mb_avail (const WhSeqParams& P, int mbx, int mby) {
+  const int w = P.mb_w, xy = mby * w + mbx;
+  const int sl = wh_slice_of_mb (P, xy);
+  int av = 0;
+  if (mbx > 0 && wh_slice_of_mb (P, xy - 1) == sl) av |= WH_AV_LEFT;
+  if (mby > 0) {
+    if (wh_slice_of_mb (P, xy - w) == sl) av |= WH_AV_TOP;
+    if (mbx > 0 && wh_slice_of_mb (P, xy - w - 1) == sl) av |= WH_AV_TOPLEFT;
+    if (mbx < w - 1 && wh_slice_of_mb (P, xy - w + 1) == sl) av |= WH_AV_TOPRIGHT;
+  }
+  return av;
+}
+
+// ---- load source MB + reconstructed neighbours into the LDS tile ---------------------------------
+WH_FN void wh_load_mb_tile (WhMbLds& S, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby) {
+  WV_LANES_BEGIN (lane)
+  {
+    const int row = lane >> 2, seg = lane & 3;
+    const uint8_t* s = J.src[0] + (size_t) (mby * 16 + row) * P.src_stride_y + mbx * 16 + seg * 4;
+    * (uint32_t*)&S.enc_y[row * 16 + seg * 4] = * (const uint32_t*)s;
+  }
+  if (lane < 32) {
+    const int pl = lane >> 4, row = (lane >> 1) & 7, half = lane & 1;
+    const uint8_t* s = J.src[1 + pl] + (size_t) (mby * 8 + row) * P.src_stride_c + mbx * 8 + half * 4;
+    * (uint32_t*)&S.enc_c[pl * 64 + row * 8 + half * 4] = * (const uint32_t*)s;
+  }
+  // reconstructed neighbours (garbage where unavailable -- never consumed then)
+  if (lane < 7) {                        // luma row -1, x = -4 .. 23 in 4-byte words
+    const int x = lane * 4 - 4;
+    const uint8_t* r = J.rec[0] + (ptrdiff_t) (mby * 16 - 1) * P.rec_stride_y + mbx * 16 + x;
+    * (uint32_t*)&S.rec_y[0 * 32 + x + 8] = * (const uint32_t*)r;
+  } else if (lane >= 16 && lane < 32) {  // luma column -1
+    const int y = lane - 16;
+    WH_RY (S, -1, y) = J.rec[0][(ptrdiff_t) (mby * 16 + y) * P.rec_stride_y + mbx * 16 - 1];
+  } else if (lane >= 32 && lane < 38) {  // chroma rows -1: 3 words per plane, x = -4..7
+    const int pl = (lane - 32) / 3, x = ((lane - 32) % 3) * 4 - 4;
+    const uint8_t* r = J.rec[1 + pl] + (ptrdiff_t) (mby * 8 - 1) * P.rec_stride_c + mbx * 8 + x;
+    * (uint32_t*)&S.rec_c[pl][0 * 16 + x + 4] = * (const uint32_t*)r;
+  } else if (lane >= 48) {               // chroma columns -1
+    const int pl = (lane - 48) >> 3, y = lane & 7;
+    WH_RC (S, pl, -1, y) = J.rec[1 + pl][(ptrdiff_t) (mby * 8 + y) * P.rec_stride_c + mbx * 8 - 1];
+  }
+  WV_LANES_END
+}
+
+// ---- Intra16x16 predictors into S.pred_y (mode numbering = the reference's I16_PRED_*) ----------
+enum { WH_I16_V = 0, WH_I16_H = 1, WH_I16_DC = 2, WH_I16_P = 3, WH_I16_DC_L = 4, WH_I16_DC_T = 5, WH_I16_DC_128 = 6 };
+
+WH_FN void wh_pred_i16 (WhMbLds& S, int mode, int sum_t, int sum_l, int pl_b, int pl_c, int pl_a) {
+  WV_LANES_BEGIN (lane)
+  const int row = lane >> 2, x0 = (lane & 3) * 4;
+  for (int k = 0; k < 4; ++k) {
+    const int x = x0 + k;
+    int v;
+    switch (mode) {
+    case WH_I16_V: v = WH_RY (S, x, -1); break;
+    case WH_I16_H: v = WH_RY (S, -1, row); break;
+    case WH_I16_DC: v = (sum_t + sum_l + 16) >> 5; break;
+    case WH_I16_DC_L: v = (sum_l + 8) >> 4; break;
+    case WH_I16_DC_T: v = (sum_t + 8) >> 4; break;
+    case WH_I16_P: v = wh_clip255 ((pl_a + pl_b * (x - 7) + pl_c * (row - 7) + 16) >> 5); break;
+    default: v = 128; break;
+    }
+    S.pred_y[row * 16 + x] = (uint8_t)v;
+  }
+  WV_LANES_END
+}
+
+// chroma predictors into S.pred_c (numbering = the reference's C_PRED_*)
+enum { WH_C_DC = 0, WH_C_H = 1, WH_C_V = 2, WH_C_P = 3, WH_C_DC_L = 4, WH_C_DC_T = 5, WH_C_DC_128 = 6 };
+
+WH_FN void wh_pred_chroma (WhMbLds& S, int mode, const int* st /*[pl][2] top sums*/, const int* sl /*[pl][2] left sums*/,
+                           const int* pb, const int* pc, const int* pa) {
+  WV_LANES_BEGIN (lane)
+  if (lane < 32) {
+    const int pl = lane >> 4, row = (lane >> 1) & 7, x0 = (lane & 1) * 4;
+    const int t0 = st[pl * 2], t1 = st[pl * 2 + 1], l0 = sl[pl * 2], l1 = sl[pl * 2 + 1];
+    for (int k = 0; k < 4; ++k) {
+      const int x = x0 + k;
+      int v;
+      switch (mode) {
+      case WH_C_V: v = WH_RC (S, pl, x, -1); break;
+      case WH_C_H: v = WH_RC (S, pl, -1, row); break;
+      case WH_C_DC:
+        if (row < 4) v = (x < 4) ? ((t0 + l0 + 4) >> 3) : ((t1 + 2) >> 2);
+        else         v = (x < 4) ? ((l1 + 2) >> 2) : ((t1 + l1 + 4) >> 3);
+        break;
+      case WH_C_DC_L: v = (row < 4) ? ((l0 + 2) >> 2) : ((l1 + 2) >> 2); break;
+      case WH_C_DC_T: v = (x < 4) ? ((t0 + 2) >> 2) : ((t1 + 2) >> 2); break;
+      case WH_C_P: v = wh_clip255 ((pa[pl] + pb[pl] * (x - 3) + pc[pl] * (row - 3) + 16) >> 5); break;
+      default: v = 128; break;
+      }
+      S.pred_c[pl * 64 + row * 8 + x] = (uint8_t)v;
+    }
+  }
+  WV_LANES_END
+}
+
+// ---- one row (4 pixels) of an Intra4x4 prediction, standard mode numbering 0..8 ------------------
+// E[0..12]: L3 L2 L1 L0 TL T0..T7   (so p[-1,j] = E[3-j], p[i,-1] = E[5+i], TL = E[4])
+#define WH_F3(a, b, c) (((a) + 2 * (b) + (c) + 2) >> 2)
+#define WH_F2(a, b) (((a) + (b) + 1) >> 1)
+WH_FN int wh_pred4_px (int mode, int x, int y, const uint8_t* E, int dcval) {
+  switch (mode) {
+  case 0: return E[5 + x];                                   // V
+  case 1: return E[3 - y];                                   // H
+  case 2: return dcval;                                      // DC family
+  case 3:                                                    // DDL
+    if (x == 3 && y == 3) return (E[5 + 6] + 3 * E[5 + 7] + 2) >> 2;
+    return WH_F3 (E[5 + x + y], E[5 + x + y + 1], E[5 + x + y + 2]);
+  case 4:                                                    // DDR
+    return WH_F3 (E[4 + x - y - 1], E[4 + x - y], E[4 + x - y + 1]);
+  case 5: {                                                  // VR
+    const int z = 2 * x - y, i = x - (y >> 1);
+    if (z >= 0) return (z & 1) ? WH_F3 (E[5 + i - 2], E[5 + i - 1], E[5 + i]) : WH_F2 (E[5 + i - 1], E[5 + i]);
+    if (z == -1) return WH_F3 (E[3], E[4], E[5]);
+    return WH_F3 (E[3 - (y - 1)], E[3 - (y - 2)], E[3 - (y - 3)]);
+  }
+  case 6: {                                                  // HD
+    const int z = 2 * y - x, j = y - (x >> 1);
+    if (z >= 0) return (z & 1) ? WH_F3 (E[3 - (j - 2)], E[3 - (j - 1)], E[3 - j]) : WH_F2 (E[3 - (j - 1)], E[3 - j]);
+    if (z == -1) return WH_F3 (E[3], E[4], E[5]);
+    return WH_F3 (E[5 + x - 1], E[5 + x - 2], E[5 + x - 3]);
+  }
+  case 7: {                                                  // VL
+    const int i = x + (y >> 1);
+    return (y & 1) ? WH_F3 (E[5 + i], E[5 + i + 1], E[5 + i + 2]) : WH_F2 (E[5 + i], E[5 + i + 1]);
+  }
+  default: {                                                 // HU
+    const int z = x + 2 * y, j = y + (x >> 1);
+    if (z > 5) return E[0];
+    if (z == 5) return (E[1] + 3 * E[0] + 2) >> 2;
+    return (z & 1) ? WH_F3 (E[3 - j], E[3 - (j + 1)], E[3 - (j + 2)]) : WH_F2 (E[3 - j], E[3 - (j + 1)]);
+  }
+  }
+}
+
+// ---- the intra MB ---------------------------------------------------------------------------------
+// Leaves: S.lv_*, S.nzc, S.i4_rem/i4_prev, the rec tile.  Returns through *o.
+typedef struct WhIntraResult {
+  int mb_type, cbp, i16_mode_std, chroma_mode_std, cost_luma, cost_chroma;
+} WhIntraResult;
+
+WH_FN void wh_intra_md_enc (WhMbLds& S, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, int avail, int qp, int qpc,
+                            WhIntraResult* o) {
+  const int lambda = kWhLambda[qp];
+  const int use_satd = P.complexity > 0;
+  const int av3 = avail & 7;
+  const bool has_l = (avail & WH_AV_LEFT) != 0, has_t = (avail & WH_AV_TOP) != 0;
+
+  // ---------------- I16x16 mode decision ----------------
+  int sum_t = 0, sum_l = 0, pl_a = 0, pl_b = 0, pl_c = 0;
+  if (has_t) WV_SUM (sum_t, lane, (lane < 16 ? WH_RY (S, lane, -1) : 0));
+  if (has_l) WV_SUM (sum_l, lane, (lane < 16 ? WH_RY (S, -1, lane) : 0));
+  if (av3 == 7) {
+    int h, v;
+    WV_SUM (h, lane, (lane < 8 ? (lane + 1) * (WH_RY (S, 8 + lane, -1) - WH_RY (S, 6 - lane, -1)) : 0));
+    WV_SUM (v, lane, (lane < 8 ? (lane + 1) * (WH_RY (S, -1, 8 + lane) - WH_RY (S, -1, 6 - lane)) : 0));
+    pl_a = (WH_RY (S, -1, 15) + WH_RY (S, 15, -1)) << 4;
+    pl_b = (5 * h + 32) >> 6;
+    pl_c = (5 * v + 32) >> 6;
+  }
+  int cand[4], ncand;
+  if (has_l && has_t) { cand[0] = WH_I16_V; cand[1] = WH_I16_H; cand[2] = WH_I16_DC; cand[3] = WH_I16_P; ncand = (av3 == 7) ? 4 : 3; }
+  else if (has_l) { cand[0] = WH_I16_DC_L; cand[1] = WH_I16_H; ncand = 2; }
+  else if (has_t) { cand[0] = WH_I16_DC_T; cand[1] = WH_I16_V; ncand = 2; }
+  else { cand[0] = WH_I16_DC_128; ncand = 1; }
+  int best_mode = cand[0], best_cost = 0x7fffffff, last_mode = -1;
+  for (int i = 0; i < ncand; ++i) {
+    const int m = cand[i];
+    wh_pred_i16 (S, m, sum_t, sum_l, pl_b, pl_c, pl_a);
+    last_mode = m;
+    // lambda * BsSizeUE (g_kiMapModeI16x16[mode]):  V -> 1 bit, H/DC* -> 3, Plane -> 5
+    const int bits = (m == WH_I16_V) ? 1 : (m == WH_I16_P) ? 5 : 3;
+    const int c = wh_cost_luma16 (S, use_satd) + lambda * bits;
+    if (c < best_cost) { best_cost = c; best_mode = m; }
+  }
+  int cost_luma = best_cost;
+  int mb_type = WH_MB_I16x16;
+
+  // ---------------- I4x4 (fine partition) ----------------
+  bool try_i4 = true;
+  if (!use_satd) {
+    // MdIntraAnalysisVaaInfo (md.cpp:435-475,497-503): variance of the sixteen 4x4 means >= 150
+    WV_LANES_BEGIN (lane)
+    const int b = lane >> 2, r = lane & 3;
+    const uint8_t* e = &S.enc_y[((b >> 2) * 4 + r) * 16 + (b & 3) * 4];
+    S.part[lane] = e[0] + e[1] + e[2] + e[3];
+    WV_LANES_END
+    int sum_avg, sum_sqr;
+    WV_SUM (sum_avg, lane, (lane < 16 ? ((S.part[lane * 4] + S.part[lane * 4 + 1] + S.part[lane * 4 + 2] + S.part[lane * 4 + 3]) >> 4) : 0));
+    WV_SUM (sum_sqr, lane, (lane < 16 ? (((S.part[lane * 4] + S.part[lane * 4 + 1] + S.part[lane * 4 + 2] + S.part[lane * 4 + 3]) >> 4) *
+                                          ((S.part[lane * 4] + S.part[lane * 4 + 1] + S.part[lane * 4 + 2] + S.part[lane * 4 + 3]) >> 4)) : 0));
+    try_i4 = (sum_sqr - ((sum_avg * sum_avg) >> 4)) >= 150;
+  }
+  int cbp = 0;
+  if (try_i4) {
+    // neighbour Intra4x4PredMode cache (md.cpp:51-130 FillNeighborCacheIntra)
+    WV_LANES_BEGIN (lane)
+    if (lane < 25) {
+      const int cx = lane % 5, cy = lane / 5;
+      int8_t m = -1;
+      if (cy == 0 && cx > 0) {
+        if (has_t) {
+          const WhMbState* n = &J.mbs[(mby - 1) * P.mb_w + mbx];
+          m = (n->mb_type == WH_MB_I4x4) ? n->i4_mode[12 + cx - 1] : (int8_t)2;
+        }
+      } else if (cx == 0 && cy > 0) {
+        if (has_l) {
+          const WhMbState* n = &J.mbs[mby * P.mb_w + mbx - 1];
+          m = (n->mb_type == WH_MB_I4x4) ? n->i4_mode[(cy - 1) * 4 + 3] : (int8_t)2;
+        }
+      }
+      S.i4m[lane] = m;
+    }
+    WV_LANES_END
+    const int lam4 = lambda << 2;
+    int cost4 = 0;
+    uint16_t prev_flags = 0;
+    bool completed = true;
+    for (int b = 0; b < 16; ++b) {
+      const int bx = wh_blk_x (b), by = wh_blk_y (b);
+      // sample availability of this 4x4 block (the reference tabulates it: g_kiNeighborIntraToI4x4)
+      const bool a_l = bx > 0 || has_l;
+      const bool a_t = by > 0 || has_t;
+      bool a_tl, a_tr;
+      if (bx > 0 && by > 0) a_tl = true;
+      else if (bx > 0) a_tl = has_t;
+      else if (by > 0) a_tl = has_l;
+      else a_tl = (avail & WH_AV_TOPLEFT) != 0;
+      if (by == 0) a_tr = (bx < 3) ? has_t : ((avail & WH_AV_TOPRIGHT) != 0);
+      else a_tr = ((0x5744 >> b) & 1) != 0;   // blocks whose top-right 4x4 is already reconstructed inside this MB
+      // predicted mode
+      const int m_left = S.i4m[(by + 1) * 5 + bx], m_top = S.i4m[by * 5 + bx + 1];
+      const int pred_mode = (m_left == -1 || m_top == -1) ? 2 : wh_min (m_left, m_top);
+      // candidate predictions: lane (mode m = lane>>2, row r = lane&3), standard numbering
+      WV_LANES_BEGIN (lane)
+      if (lane < 36) {
+        const int m = lane >> 2, r = lane & 3;
+        uint8_t E[13];
+        for (int k = 0; k < 4; ++k) E[3 - k] = WH_RY (S, bx * 4 - 1, by * 4 + k);
+        E[4] = WH_RY (S, bx * 4 - 1, by * 4 - 1);
+        for (int k = 0; k < 8; ++k) E[5 + k] = WH_RY (S, bx * 4 + k, by * 4 - 1);
+        int dcv;
+        if (a_l && a_t) dcv = (E[0] + E[1] + E[2] + E[3] + E[5] + E[6] + E[7] + E[8] + 4) >> 3;
+        else if (a_l) dcv = (E[0] + E[1] + E[2] + E[3] + 2) >> 2;
+        else if (a_t) dcv = (E[5] + E[6] + E[7] + E[8] + 2) >> 2;
+        else dcv = 128;
+        uint8_t px[4];
+        for (int x = 0; x < 4; ++x) px[x] = (uint8_t)wh_pred4_px (m, x, r, E, dcv);
+        uint8_t* pd = &S.pred4[m * 16 + r * 4];
+        pd[0] = px[0]; pd[1] = px[1]; pd[2] = px[2]; pd[3] = px[3];
+        const uint8_t* e = &S.enc_y[(by * 4 + r) * 16 + bx * 4];
+        if (!use_satd) {
+          S.part[lane] = wh_abs (e[0] - px[0]) + wh_abs (e[1] - px[1]) + wh_abs (e[2] - px[2]) + wh_abs (e[3] - px[3]);
+        } else {
+          int o0, o1, o2, o3;
+          wh_had4 (e[0] - px[0], e[1] - px[1], e[2] - px[2], e[3] - px[3], &o0, &o1, &o2, &o3);
+          int16_t* t = &S.tmp[m * 16 + r * 4];
+          t[0] = (int16_t)o0; t[1] = (int16_t)o1; t[2] = (int16_t)o2; t[3] = (int16_t)o3;
+        }
+      }
+      WV_LANES_END
+      if (use_satd) {
+        WV_LANES_BEGIN (lane)
+        if (lane < 36) {
+          const int m = lane >> 2, c = lane & 3;
+          const int16_t* t = &S.tmp[m * 16 + c];
+          int o0, o1, o2, o3;
+          wh_had4 (t[0], t[4], t[8], t[12], &o0, &o1, &o2, &o3);
+          S.part[lane] = wh_abs (o0) + wh_abs (o1) + wh_abs (o2) + wh_abs (o3);
+        }
+        WV_LANES_END
+      }
+      // cost of standard mode m incl. the mode-signalling term lambda[pred_mode == m]
+#define WH_C4(m) ((use_satd ? ((S.part[(m) * 4] + S.part[(m) * 4 + 1] + S.part[(m) * 4 + 2] + S.part[(m) * 4 + 3] + 1) >> 1) \
+                            : (S.part[(m) * 4] + S.part[(m) * 4 + 1] + S.part[(m) * 4 + 2] + S.part[(m) * 4 + 3])) + ((pred_mode == (m)) ? lambda : lam4))
+      // candidate order of the reference (g_kiIntra4AvailMode rows), standard numbering
+      int list[9], n = 0;
+      if (a_l && a_t) {
+        list[n++] = 2; list[n++] = 1; list[n++] = 0; list[n++] = 8;
+        if (a_tr) { list[n++] = 3; list[n++] = 7; }
+        if (a_tl) { list[n++] = 4; list[n++] = 5; list[n++] = 6; }
+      } else if (a_l) { list[n++] = 2; list[n++] = 1; list[n++] = 8; }
+      else if (a_t) { list[n++] = 2; list[n++] = 0; if (a_tr) { list[n++] = 3; list[n++] = 7; } }
+      else { list[n++] = 2; }
+      int bmode, bcost;
+      if (!use_satd && (n == 9 || n == 7)) {
+        // WelsMdI4x4Fast decision tree (svc_base_layer_md.cpp:598-826)
+        bmode = 2; bcost = WH_C4 (2);
+        const int c_h = WH_C4 (1);
+        if (c_h < bcost) { bmode = 1; bcost = c_h; }
+        const int c_v = WH_C4 (0);
+        if (c_v < bcost) { bmode = 0; bcost = c_v; }
+        if (c_v < c_h) {
+          if (n == 9) {
+            bool fake = true;
+            const int c_vr = WH_C4 (5);
+            if (c_vr < bcost) { bmode = 5; bcost = c_vr; }
+            if (c_vr < c_v) fake = false;
+            const int c_vl = WH_C4 (7);
+            if (c_vl < bcost) { bmode = 7; bcost = c_vl; }
+            if (c_vl < c_v) fake = false;
+            if (!fake) {
+              if (c_vr < c_vl) { const int c = WH_C4 (4); if (c < bcost) { bmode = 4; bcost = c; } }
+              else { const int c = WH_C4 (3); if (c < bcost) { bmode = 3; bcost = c; } }
+            }
+          } else {
+            const int c_ddr = WH_C4 (4);
+            if (c_ddr < bcost) { bmode = 4; bcost = c_ddr; }
+            const int c_vr = WH_C4 (5);
+            if (c_vr < bcost) { bmode = 5; bcost = c_vr; }
+          }
+        } else {
+          bool fake = true;
+          const int c_hd = WH_C4 (6);
+          if (c_hd < bcost) { bmode = 6; bcost = c_hd; }
+          if (c_hd < c_h) fake = false;
+          const int c_hu = WH_C4 (8);
+          if (c_hu < bcost) { bmode = 8; bcost = c_hu; }
+          if (c_hu < c_h) fake = false;
+          if (!fake) {
+            if (c_hd < c_hu) { const int c = WH_C4 (4); if (c < bcost) { bmode = 4; bcost = c; } }
+            else if (n == 9) { const int c = WH_C4 (3); if (c < bcost) { bmode = 3; bcost = c; } }
+          }
+        }
+      } else {
+        bmode = list[0]; bcost = 0x7fffffff;
+        for (int i = 0; i < n; ++i) {
+          const int c = WH_C4 (list[i]);
+          if (c < bcost) { bcost = c; bmode = list[i]; }
+        }
+      }
+#undef WH_C4
+      cost4 += bcost;
+      if (cost4 >= cost_luma) { completed = false; break; }
+      if (pred_mode == bmode) prev_flags |= (uint16_t) (1u << b);
+      const int rem = (bmode < pred_mode) ? bmode : bmode - 1;
+      WV_LANES_BEGIN (lane)
+      if (lane == 0) {
+        S.i4m[(by + 1) * 5 + bx + 1] = (int8_t)bmode;
+        S.i4_rem[b] = (int8_t) ((pred_mode == bmode) ? 0 : rem);
+      }
+      WV_LANES_END
+      const int nz = wh_encrec_i4 (S, b, bmode, qp);
+      if (nz > 0) cbp |= 1 << (b >> 2);
+      WV_LANES_BEGIN (lane)
+      if (lane == 0) S.nzc[by * 4 + bx] = (uint8_t)nz;
+      WV_LANES_END
+    }
+    if (completed) cost4 += (lambda << 4) + (lambda << 3);
+    if (completed && cost4 < cost_luma) {
+      mb_type = WH_MB_I4x4;
+      cost_luma = cost4;
+      WV_LANES_BEGIN (lane)
+      if (lane == 0) S.i4_prev = prev_flags;
+      WV_LANES_END
+    }
+  }
+  if (mb_type == WH_MB_I16x16) {
+    if (last_mode != best_mode) wh_pred_i16 (S, best_mode, sum_t, sum_l, pl_b, pl_c, pl_a);
+    cbp = wh_encrec_i16 (S, qp);
+  }
+
+  // ---------------- chroma ----------------
+  int st[4] = {0, 0, 0, 0}, sl[4] = {0, 0, 0, 0}, cpa[2] = {0, 0}, cpb[2] = {0, 0}, cpc[2] = {0, 0};
+  for (int pl = 0; pl < 2; ++pl) {
+    if (has_t) {
+      WV_SUM (st[pl * 2], lane, (lane < 4 ? WH_RC (S, pl, lane, -1) : 0));
+      WV_SUM (st[pl * 2 + 1], lane, (lane < 4 ? WH_RC (S, pl, 4 + lane, -1) : 0));
+    }
+    if (has_l) {
+      WV_SUM (sl[pl * 2], lane, (lane < 4 ? WH_RC (S, pl, -1, lane) : 0));
+      WV_SUM (sl[pl * 2 + 1], lane, (lane < 4 ? WH_RC (S, pl, -1, 4 + lane) : 0));
+    }
+    if (av3 == 7) {
+      int h, v;
+      WV_SUM (h, lane, (lane < 4 ? (lane + 1) * (WH_RC (S, pl, 4 + lane, -1) - WH_RC (S, pl, 2 - lane, -1)) : 0));
+      WV_SUM (v, lane, (lane < 4 ? (lane + 1) * (WH_RC (S, pl, -1, 4 + lane) - WH_RC (S, pl, -1, 2 - lane)) : 0));
+      cpa[pl] = (WH_RC (S, pl, -1, 7) + WH_RC (S, pl, 7, -1)) << 4;
+      cpb[pl] = (17 * h + 16) >> 5;
+      cpc[pl] = (17 * v + 16) >> 5;
+    }
+  }
+  int ccand[4], nc;
+  if (has_l && has_t) { ccand[0] = WH_C_V; ccand[1] = WH_C_H; ccand[2] = WH_C_DC; ccand[3] = WH_C_P; nc = (av3 == 7) ? 4 : 3; }
+  else if (has_l) { ccand[0] = WH_C_DC_L; ccand[1] = WH_C_H; nc = 2; }
+  else if (has_t) { ccand[0] = WH_C_DC_T; ccand[1] = WH_C_V; nc = 2; }
+  else { ccand[0] = WH_C_DC_128; nc = 1; }
+  int cbest = ccand[0], cbest_cost = 0x7fffffff, clast = -1;
+  for (int i = 0; i < nc; ++i) {
+    const int m = ccand[i];
+    wh_pred_chroma (S, m, st, sl, cpb, cpc, cpa);
+    clast = m;
+    // lambda * BsSizeUE (g_kiMapModeIntraChroma[mode]): DC* -> 1 bit, H/V -> 3, Plane -> 5
+    const int bits = (m == WH_C_H || m == WH_C_V) ? 3 : (m == WH_C_P) ? 5 : 1;
+    const int c = wh_cost_chroma (S, use_satd) + lambda * bits;
+    if (c < cbest_cost) { cbest_cost = c; cbest = m; }
+  }
+  if (clast != cbest) wh_pred_chroma (S, cbest, st, sl, cpb, cpc, cpa);
+  const int cbp_c = wh_encrec_chroma (S, qpc, 1);
+  wh_idct_chroma (S);
+
+  o->mb_type = mb_type;
+  o->cbp = cbp | (cbp_c << 4);
+  o->i16_mode_std = (best_mode <= 3) ? best_mode : 2;
+  o->chroma_mode_std = (cbest <= 3) ? cbest : 0;
+  o->cost_luma = cost_luma;
+  o->cost_chroma = cbest_cost;
+  (void)J; (void)mbx; (void)mby;
+}

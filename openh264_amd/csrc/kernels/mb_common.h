@@ -1,0 +1,514 @@
+// mb_common.h -- LDS tile of one macroblock wave + residual coding pipelines shared by the
+// intra and inter MB kernels.
+//
+// Reference behaviour restated here (all under codec/encoder/core/src unless noted):
+//   svc_encode_mb.cpp:54-137   WelsEncRecI16x16Y      -> wh_encrec_i16
+//   svc_encode_mb.cpp:139-178  WelsEncRecI4x4Y        -> wh_encrec_i4
+//   svc_encode_mb.cpp:244-312  WelsEncRecUV           -> wh_encrec_chroma
+//   encode_mb_aux.cpp / decode_mb_aux.cpp primitives  -> prims.h
+#pragma once
+#include "prims.h"
+
+// ---- the per-wave LDS tile ----------------------------------------------------------------------
+// rec_y : reconstructed luma incl. one row above and one column left:  pixel (x,y), x in [-8,23],
+//         y in [-1,15]  at  rec_y[(y+1)*32 + x + 8]
+// rec_c : same for Cb/Cr: pixel (x,y), x in [-4,11], y in [-1,7] at rec_c[p][(y+1)*16 + x + 4]
+typedef struct WhMbLds {
+  uint8_t  enc_y[256];
+  uint8_t  enc_c[128];        // Cb 8x8 then Cr 8x8, stride 8
+  uint8_t  rec_y[17 * 32];
+  uint8_t  rec_c[2][9 * 16];
+  uint8_t  pred_y[256];       // stride 16
+  uint8_t  pred_c[128];       // Cb then Cr, stride 8
+  uint8_t  pred4[9 * 16];     // candidate 4x4 predictions, [mode][y*4+x]
+  int16_t  res[384];          // residual coefficients: luma blk*16 (luma4x4BlkIdx order), Cb 256.., Cr 320..
+  int16_t  tmp[576];          // transform scratch
+  int32_t  part[64];          // reduction partials
+  int32_t  part2[64];
+  int16_t  dc[16];
+  int16_t  cdc[8];
+  int16_t  amax[16];
+  int8_t   i4m[25];           // neighbour Intra4x4PredMode cache: [(by+1)*5 + bx+1]
+  uint8_t  nzc[24];
+  int16_t  lv_luma[256];      // zig-zag levels per luma4x4BlkIdx
+  int16_t  lv_dc[16];
+  int16_t  lv_cac[128];       // chroma AC levels Cb 0..3, Cr 4..7
+  int16_t  lv_cdc[8];
+  int8_t   i4_rem[16];
+  uint16_t i4_prev;
+  // inter-prediction scratch (P slices)
+  uint8_t  refwin[1];         // placeholder, the inter kernel uses its own tile type
+} WhMbLds;
+
+#define WH_RY(S, x, y) ((S).rec_y[((y) + 1) * 32 + (x) + 8])
+#define WH_RC(S, p, x, y) ((S).rec_c[p][((y) + 1) * 16 + (x) + 4])
+
+// position class (0/1/2) helpers for quant tables
+WH_FN int wh_mf (int qp, int pos) { return kWhQuantMF[qp * 3 + WH_POSCLASS (pos)]; }
+WH_FN int wh_ff_intra (int qp, int pos) { return kWhQuantFF[(qp + 6) * 3 + WH_POSCLASS (pos)]; }
+WH_FN int wh_ff_inter (int qp, int pos) { return kWhQuantFF[qp * 3 + WH_POSCLASS (pos)]; }
+WH_FN int wh_dq (int qp, int pos) { return kWhDequant[qp * 3 + WH_POSCLASS (pos)]; }
+
+// ---- forward DCT of N 4x4 blocks: res[blk*16 + r*4 + c] = T(enc - pred) -------------------------
+// `nblk` blocks; block b covers enc rows/cols given by (ex[b],ey[b]) through the callbacks below.
+// Implemented for the three tile shapes we need.
+//
+// luma 16x16: block index = luma4x4BlkIdx, enc = S.enc_y (stride 16), pred = S.pred_y (stride 16)
+WH_FN void wh_dct_luma16 (WhMbLds& S) {
+  WV_LANES_BEGIN (lane)
+  const int b = lane >> 2, r = lane & 3;
+  const int px = wh_blk_x (b) * 4, py = wh_blk_y (b) * 4 + r;
+  const uint8_t* e = &S.enc_y[py * 16 + px];
+  const uint8_t* p = &S.pred_y[py * 16 + px];
+  int16_t o0, o1, o2, o3;
+  wh_fdct4 (e[0] - p[0], e[1] - p[1], e[2] - p[2], e[3] - p[3], &o0, &o1, &o2, &o3);
+  int16_t* t = &S.tmp[b * 16 + r * 4];
+  t[0] = o0; t[1] = o1; t[2] = o2; t[3] = o3;
+  WV_LANES_END
+  WV_LANES_BEGIN (lane)
+  const int b = lane >> 2, c = lane & 3;
+  const int16_t* t = &S.tmp[b * 16 + c];
+  int16_t o0, o1, o2, o3;
+  wh_fdct4 (t[0], t[4], t[8], t[12], &o0, &o1, &o2, &o3);
+  int16_t* o = &S.res[b * 16 + c];
+  o[0] = o0; o[4] = o1; o[8] = o2; o[12] = o3;
+  WV_LANES_END
+}
+
+// chroma: 8 blocks (Cb 0..3, Cr 4..7 raster 2x2), enc = S.enc_c, pred = S.pred_c, out res[256 + blk*16]
+WH_FN void wh_dct_chroma (WhMbLds& S) {
+  WV_LANES_BEGIN (lane)
+  if (lane < 32) {
+    const int b = lane >> 2, r = lane & 3;
+    const int pl = b >> 2, bb = b & 3;
+    const int px = (bb & 1) * 4, py = (bb >> 1) * 4 + r;
+    const uint8_t* e = &S.enc_c[pl * 64 + py * 8 + px];
+    const uint8_t* p = &S.pred_c[pl * 64 + py * 8 + px];
+    int16_t o0, o1, o2, o3;
+    wh_fdct4 (e[0] - p[0], e[1] - p[1], e[2] - p[2], e[3] - p[3], &o0, &o1, &o2, &o3);
+    int16_t* t = &S.tmp[b * 16 + r * 4];
+    t[0] = o0; t[1] = o1; t[2] = o2; t[3] = o3;
+  }
+  WV_LANES_END
+  WV_LANES_BEGIN (lane)
+  if (lane < 32) {
+    const int b = lane >> 2, c = lane & 3;
+    const int16_t* t = &S.tmp[b * 16 + c];
+    int16_t o0, o1, o2, o3;
+    wh_fdct4 (t[0], t[4], t[8], t[12], &o0, &o1, &o2, &o3);
+    int16_t* o = &S.res[256 + b * 16 + c];
+    o[0] = o0; o[4] = o1; o[8] = o2; o[12] = o3;
+  }
+  WV_LANES_END
+}
+
+// ---- inverse transform + reconstruction of the 16 luma blocks from S.res into the rec tile ------
+// rec = clip(pred + idct(res)); pred = S.pred_y
+WH_FN void wh_idct_luma16 (WhMbLds& S) {
+  WV_LANES_BEGIN (lane)
+  const int b = lane >> 2, r = lane & 3;
+  const int16_t* c = &S.res[b * 16 + r * 4];
+  int16_t t0, t1, t2, t3;
+  wh_idct4_h (c[0], c[1], c[2], c[3], &t0, &t1, &t2, &t3);
+  int16_t* t = &S.tmp[b * 16 + r * 4];
+  t[0] = t0; t[1] = t1; t[2] = t2; t[3] = t3;
+  WV_LANES_END
+  WV_LANES_BEGIN (lane)
+  const int b = lane >> 2, c = lane & 3;
+  const int16_t* t = &S.tmp[b * 16 + c];
+  int r0, r1, r2, r3;
+  wh_idct4_v (t[0], t[4], t[8], t[12], &r0, &r1, &r2, &r3);
+  const int px = wh_blk_x (b) * 4 + c, py = wh_blk_y (b) * 4;
+  WH_RY (S, px, py + 0) = wh_clip255 (S.pred_y[(py + 0) * 16 + px] + r0);
+  WH_RY (S, px, py + 1) = wh_clip255 (S.pred_y[(py + 1) * 16 + px] + r1);
+  WH_RY (S, px, py + 2) = wh_clip255 (S.pred_y[(py + 2) * 16 + px] + r2);
+  WH_RY (S, px, py + 3) = wh_clip255 (S.pred_y[(py + 3) * 16 + px] + r3);
+  WV_LANES_END
+}
+
+WH_FN void wh_idct_chroma (WhMbLds& S) {
+  WV_LANES_BEGIN (lane)
+  if (lane < 32) {
+    const int b = lane >> 2, r = lane & 3;
+    const int16_t* c = &S.res[256 + b * 16 + r * 4];
+    int16_t t0, t1, t2, t3;
+    wh_idct4_h (c[0], c[1], c[2], c[3], &t0, &t1, &t2, &t3);
+    int16_t* t = &S.tmp[b * 16 + r * 4];
+    t[0] = t0; t[1] = t1; t[2] = t2; t[3] = t3;
+  }
+  WV_LANES_END
+  WV_LANES_BEGIN (lane)
+  if (lane < 32) {
+    const int b = lane >> 2, c = lane & 3;
+    const int pl = b >> 2, bb = b & 3;
+    const int16_t* t = &S.tmp[b * 16 + c];
+    int r0, r1, r2, r3;
+    wh_idct4_v (t[0], t[4], t[8], t[12], &r0, &r1, &r2, &r3);
+    const int px = (bb & 1) * 4 + c, py = (bb >> 1) * 4;
+    const uint8_t* p = &S.pred_c[pl * 64];
+    WH_RC (S, pl, px, py + 0) = wh_clip255 (p[(py + 0) * 8 + px] + r0);
+    WH_RC (S, pl, px, py + 1) = wh_clip255 (p[(py + 1) * 8 + px] + r1);
+    WH_RC (S, pl, px, py + 2) = wh_clip255 (p[(py + 2) * 8 + px] + r2);
+    WH_RC (S, pl, px, py + 3) = wh_clip255 (p[(py + 3) * 8 + px] + r3);
+  }
+  WV_LANES_END
+}
+
+// ---- cost functions over the full MB tiles -------------------------------------------------------
+// SAD / SATD of enc_y vs pred_y (sad_common.cpp:44-80, sample.cpp:47-156); SATD rounds per 4x4.
+WH_FN int wh_cost_luma16 (WhMbLds& S, int use_satd) {
+  int cost;
+  if (!use_satd) {
+    WV_SUM (cost, lane, (wh_abs (S.enc_y[lane * 4 + 0] - S.pred_y[lane * 4 + 0]) + wh_abs (S.enc_y[lane * 4 + 1] - S.pred_y[lane * 4 + 1]) +
+                          wh_abs (S.enc_y[lane * 4 + 2] - S.pred_y[lane * 4 + 2]) + wh_abs (S.enc_y[lane * 4 + 3] - S.pred_y[lane * 4 + 3])));
+    return cost;
+  }
+  WV_LANES_BEGIN (lane)
+  const int b = lane >> 2, r = lane & 3;                     // raster 4x4 block here
+  const int px = (b & 3) * 4, py = (b >> 2) * 4 + r;
+  const uint8_t* e = &S.enc_y[py * 16 + px];
+  const uint8_t* p = &S.pred_y[py * 16 + px];
+  int o0, o1, o2, o3;
+  wh_had4 (e[0] - p[0], e[1] - p[1], e[2] - p[2], e[3] - p[3], &o0, &o1, &o2, &o3);
+  int16_t* t = &S.tmp[b * 16 + r * 4];
+  t[0] = (int16_t)o0; t[1] = (int16_t)o1; t[2] = (int16_t)o2; t[3] = (int16_t)o3;
+  WV_LANES_END
+  WV_LANES_BEGIN (lane)
+  const int b = lane >> 2, c = lane & 3;
+  const int16_t* t = &S.tmp[b * 16 + c];
+  int o0, o1, o2, o3;
+  wh_had4 (t[0], t[4], t[8], t[12], &o0, &o1, &o2, &o3);
+  S.part[lane] = wh_abs (o0) + wh_abs (o1) + wh_abs (o2) + wh_abs (o3);
+  WV_LANES_END
+  WV_SUM (cost, lane, (lane < 16 ? ((S.part[lane * 4] + S.part[lane * 4 + 1] + S.part[lane * 4 + 2] + S.part[lane * 4 + 3] + 1) >> 1) : 0));
+  return cost;
+}
+
+// chroma 8x8 Cb + Cr cost (enc_c vs pred_c)
+WH_FN int wh_cost_chroma (WhMbLds& S, int use_satd) {
+  int cost;
+  if (!use_satd) {
+    WV_SUM (cost, lane, (lane < 32 ? (wh_abs (S.enc_c[lane * 4 + 0] - S.pred_c[lane * 4 + 0]) + wh_abs (S.enc_c[lane * 4 + 1] - S.pred_c[lane * 4 + 1]) +
+                                        wh_abs (S.enc_c[lane * 4 + 2] - S.pred_c[lane * 4 + 2]) + wh_abs (S.enc_c[lane * 4 + 3] - S.pred_c[lane * 4 + 3])) : 0));
+    return cost;
+  }
+  WV_LANES_BEGIN (lane)
+  if (lane < 32) {
+    const int b = lane >> 2, r = lane & 3;
+    const int pl = b >> 2, bb = b & 3;
+    const int px = (bb & 1) * 4, py = (bb >> 1) * 4 + r;
+    const uint8_t* e = &S.enc_c[pl * 64 + py * 8 + px];
+    const uint8_t* p = &S.pred_c[pl * 64 + py * 8 + px];
+    int o0, o1, o2, o3;
+    wh_had4 (e[0] - p[0], e[1] - p[1], e[2] - p[2], e[3] - p[3], &o0, &o1, &o2, &o3);
+    int16_t* t = &S.tmp[b * 16 + r * 4];
+    t[0] = (int16_t)o0; t[1] = (int16_t)o1; t[2] = (int16_t)o2; t[3] = (int16_t)o3;
+  }
+  WV_LANES_END
+  WV_LANES_BEGIN (lane)
+  if (lane < 32) {
+    const int b = lane >> 2, c = lane & 3;
+    const int16_t* t = &S.tmp[b * 16 + c];
+    int o0, o1, o2, o3;
+    wh_had4 (t[0], t[4], t[8], t[12], &o0, &o1, &o2, &o3);
+    S.part[lane] = wh_abs (o0) + wh_abs (o1) + wh_abs (o2) + wh_abs (o3);
+  }
+  WV_LANES_END
+  WV_SUM (cost, lane, (lane < 8 ? ((S.part[lane * 4] + S.part[lane * 4 + 1] + S.part[lane * 4 + 2] + S.part[lane * 4 + 3] + 1) >> 1) : 0));
+  return cost;
+}
+
+// ---- Intra16x16 luma residual pipeline (svc_encode_mb.cpp:54-137) -------------------------------
+// in : enc_y, pred_y       out: lv_dc, lv_luma (AC), nzc[0..15], rec tile;  returns cbp luma (0 / 15)
+WH_FN int wh_encrec_i16 (WhMbLds& S, int qp) {
+  wh_dct_luma16 (S);
+  // DC gather + 4x4 Hadamard (encode_mb_aux.cpp:280-311 WelsHadamardT4Dc_c): rows first
+  WV_LANES_BEGIN (lane)
+  if (lane < 4) {                       // raster row `lane` of block DCs
+    int d[4];
+    for (int x = 0; x < 4; ++x) {
+      const int by = lane, bx = x;      // raster block (bx,by) -> luma4x4BlkIdx
+      const int b = (bx & 1) | ((by & 1) << 1) | ((bx & 2) << 1) | ((by & 2) << 2);
+      d[x] = S.res[b * 16];
+    }
+    const int s0 = d[0] + d[3], s3 = d[0] - d[3], s1 = d[1] + d[2], s2 = d[1] - d[2];
+    int32_t* p = &S.part[lane * 4];
+    p[0] = s0 + s1; p[2] = s0 - s1; p[1] = s3 + s2; p[3] = s3 - s2;
+  }
+  WV_LANES_END
+  WV_LANES_BEGIN (lane)
+  if (lane < 4) {                       // column `lane`
+    const int32_t* p = &S.part[lane];
+    const int s0 = p[0] + p[12], s3 = p[0] - p[12], s1 = p[4] + p[8], s2 = p[4] - p[8];
+    const int ff = wh_ff_intra (qp, 0) << 1, mf = wh_mf (qp, 0) >> 1;   // pfQuantizationDc4x4 (aDctT4Dc, pFF[0]<<1, pMF[0]>>1)
+    S.dc[lane]      = wh_quant1 ((int16_t)wh_clip3 ((s0 + s1 + 1) >> 1, -32768, 32767), ff, mf);
+    S.dc[lane + 8]  = wh_quant1 ((int16_t)wh_clip3 ((s0 - s1 + 1) >> 1, -32768, 32767), ff, mf);
+    S.dc[lane + 4]  = wh_quant1 ((int16_t)wh_clip3 ((s3 + s2 + 1) >> 1, -32768, 32767), ff, mf);
+    S.dc[lane + 12] = wh_quant1 ((int16_t)wh_clip3 ((s3 - s2 + 1) >> 1, -32768, 32767), ff, mf);
+  }
+  WV_LANES_END
+  // AC quant (WelsQuantFour4x4_c, intra FF) + scans + counts
+  WV_LANES_BEGIN (lane)
+  for (int k = 0; k < 4; ++k) {
+    const int i = lane * 4 + k, pos = i & 15;
+    S.res[i] = wh_quant1 (S.res[i], wh_ff_intra (qp, pos), wh_mf (qp, pos));
+  }
+  if (lane < 16) S.lv_dc[lane] = S.dc[wh_zigzag (lane)];
+  WV_LANES_END
+  int nz_ac, nz_dc;
+  WV_LANES_BEGIN (lane)
+  {                                     // 4 zig-zag AC levels per lane: block lane>>2, k = (lane&3)*4..+3
+    const int b = lane >> 2;
+    int cnt = 0;
+    for (int q = 0; q < 4; ++q) {
+      const int k = (lane & 3) * 4 + q;
+      const int16_t v = (k < 15) ? S.res[b * 16 + wh_zigzag (k + 1)] : (int16_t)0;
+      S.lv_luma[b * 16 + k] = v;
+      cnt += (v != 0);
+    }
+    S.part[lane] = cnt;
+  }
+  WV_LANES_END
+  WV_LANES_BEGIN (lane)
+  if (lane < 16) {
+    const int n = S.part[lane * 4] + S.part[lane * 4 + 1] + S.part[lane * 4 + 2] + S.part[lane * 4 + 3];
+    S.nzc[wh_blk_y (lane) * 4 + wh_blk_x (lane)] = (uint8_t)n;
+    S.part2[lane] = n;
+  }
+  WV_LANES_END
+  WV_SUM (nz_ac, lane, (lane < 16 ? S.part2[lane] : 0));
+  WV_SUM (nz_dc, lane, (lane < 16 ? (S.lv_dc[lane] != 0) : 0));
+  // DC dequant (decode_mb_aux.cpp:40-125)
+  if (nz_dc > 0) {
+    if (qp < 12) {
+      // WelsIHadamard4x4Dc then WelsDequantLumaDc4x4
+      WV_LANES_BEGIN (lane)
+      if (lane < 4) {                   // row pass, in place (int16)
+        int16_t* p = &S.dc[lane * 4];
+        const int16_t t0 = (int16_t) (p[0] + p[2]), t1 = (int16_t) (p[0] - p[2]);
+        const int16_t t2 = (int16_t) (p[1] - p[3]), t3 = (int16_t) (p[1] + p[3]);
+        p[0] = (int16_t) (t0 + t3); p[1] = (int16_t) (t1 + t2); p[2] = (int16_t) (t1 - t2); p[3] = (int16_t) (t0 - t3);
+      }
+      WV_LANES_END
+      WV_LANES_BEGIN (lane)
+      if (lane < 4) {
+        int16_t* p = &S.dc[lane];
+        const int16_t t0 = (int16_t) (p[0] + p[8]), t1 = (int16_t) (p[0] - p[8]);
+        const int16_t t2 = (int16_t) (p[4] - p[12]), t3 = (int16_t) (p[4] + p[12]);
+        const int dqv = kWhDequant[(qp % 6) * 3 + 0];
+        const int qf0 = qp / 6, qf1 = 2 - qf0, qf0s = 1 << (1 - qf0);
+        p[0]  = (int16_t) (((int16_t) (t0 + t3) * dqv + qf0s) >> qf1);
+        p[4]  = (int16_t) (((int16_t) (t1 + t2) * dqv + qf0s) >> qf1);
+        p[8]  = (int16_t) (((int16_t) (t1 - t2) * dqv + qf0s) >> qf1);
+        p[12] = (int16_t) (((int16_t) (t0 - t3) * dqv + qf0s) >> qf1);
+      }
+      WV_LANES_END
+    } else {
+      // WelsDequantIHadamard4x4_c (pRes, g_kuiDequantCoeff[qp][0] >> 2)
+      WV_LANES_BEGIN (lane)
+      if (lane < 4) {
+        int16_t* p = &S.dc[lane * 4];
+        const int16_t t0 = (int16_t) (p[0] + p[2]), t1 = (int16_t) (p[0] - p[2]);
+        const int16_t t2 = (int16_t) (p[1] - p[3]), t3 = (int16_t) (p[1] + p[3]);
+        p[0] = (int16_t) (t0 + t3); p[1] = (int16_t) (t1 + t2); p[2] = (int16_t) (t1 - t2); p[3] = (int16_t) (t0 - t3);
+      }
+      WV_LANES_END
+      WV_LANES_BEGIN (lane)
+      if (lane < 4) {
+        int16_t* p = &S.dc[lane];
+        const int16_t t0 = (int16_t) (p[0] + p[8]), t1 = (int16_t) (p[0] - p[8]);
+        const int16_t t2 = (int16_t) (p[4] - p[12]), t3 = (int16_t) (p[4] + p[12]);
+        const int mfq = wh_dq (qp, 0) >> 2;
+        p[0]  = (int16_t) ((t0 + t3) * mfq);
+        p[4]  = (int16_t) ((t1 + t2) * mfq);
+        p[8]  = (int16_t) ((t1 - t2) * mfq);
+        p[12] = (int16_t) ((t0 - t3) * mfq);
+      }
+      WV_LANES_END
+    }
+  }
+  // AC dequant (WelsDequantFour4x4_c, int16 wrap) and DC insertion; when no AC survived the
+  // quantised AC values are all zero already, so the generic inverse transform reproduces both the
+  // DC-only (WelsIDctRecI16x16Dc_c) and the copy-prediction special cases of the reference.
+  WV_LANES_BEGIN (lane)
+  for (int k = 0; k < 4; ++k) {
+    const int i = lane * 4 + k, pos = i & 15;
+    if (pos == 0) {
+      const int b = i >> 4;
+      S.res[i] = S.dc[wh_blk_y (b) * 4 + wh_blk_x (b)];
+    } else {
+      S.res[i] = (int16_t) (S.res[i] * wh_dq (qp, pos));
+    }
+  }
+  WV_LANES_END
+  wh_idct_luma16 (S);
+  return nz_ac > 0 ? 15 : 0;
+}
+
+// ---- Intra4x4 residual pipeline of one block (svc_encode_mb.cpp:139-178) ------------------------
+// pred = S.pred4[mode_slot*16..], writes lv_luma[b], nzc, rec tile; returns nzc of the block
+WH_FN int wh_encrec_i4 (WhMbLds& S, int b, int pred_slot, int qp) {
+  const int bx = wh_blk_x (b) * 4, by = wh_blk_y (b) * 4;
+  WV_LANES_BEGIN (lane)
+  if (lane < 4) {
+    const uint8_t* e = &S.enc_y[(by + lane) * 16 + bx];
+    const uint8_t* p = &S.pred4[pred_slot * 16 + lane * 4];
+    int16_t o0, o1, o2, o3;
+    wh_fdct4 (e[0] - p[0], e[1] - p[1], e[2] - p[2], e[3] - p[3], &o0, &o1, &o2, &o3);
+    int16_t* t = &S.tmp[lane * 4];
+    t[0] = o0; t[1] = o1; t[2] = o2; t[3] = o3;
+  }
+  WV_LANES_END
+  WV_LANES_BEGIN (lane)
+  if (lane < 4) {
+    const int16_t* t = &S.tmp[lane];
+    int16_t o[4];
+    wh_fdct4 (t[0], t[4], t[8], t[12], &o[0], &o[1], &o[2], &o[3]);
+    for (int k = 0; k < 4; ++k) {
+      const int pos = k * 4 + lane;
+      S.res[b * 16 + pos] = wh_quant1 (o[k], wh_ff_intra (qp, pos), wh_mf (qp, pos));
+    }
+  }
+  WV_LANES_END
+  int nz;
+  WV_LANES_BEGIN (lane)
+  if (lane < 16) S.lv_luma[b * 16 + lane] = S.res[b * 16 + wh_zigzag (lane)];
+  WV_LANES_END
+  WV_SUM (nz, lane, (lane < 16 ? (S.res[b * 16 + lane] != 0) : 0));
+  if (nz > 0) {
+    WV_LANES_BEGIN (lane)
+    if (lane < 4) {                     // dequant (WelsDequant4x4_c, int16 wrap) + horizontal inverse
+      const int16_t* c = &S.res[b * 16 + lane * 4];
+      int16_t t0, t1, t2, t3;
+      wh_idct4_h ((int16_t) (c[0] * wh_dq (qp, lane * 4 + 0)), (int16_t) (c[1] * wh_dq (qp, lane * 4 + 1)),
+                  (int16_t) (c[2] * wh_dq (qp, lane * 4 + 2)), (int16_t) (c[3] * wh_dq (qp, lane * 4 + 3)), &t0, &t1, &t2, &t3);
+      int16_t* t = &S.tmp[lane * 4];
+      t[0] = t0; t[1] = t1; t[2] = t2; t[3] = t3;
+    }
+    WV_LANES_END
+    WV_LANES_BEGIN (lane)
+    if (lane < 4) {
+      const int16_t* t = &S.tmp[lane];
+      int r0, r1, r2, r3;
+      wh_idct4_v (t[0], t[4], t[8], t[12], &r0, &r1, &r2, &r3);
+      const uint8_t* p = &S.pred4[pred_slot * 16 + lane];
+      WH_RY (S, bx + lane, by + 0) = wh_clip255 (p[0] + r0);
+      WH_RY (S, bx + lane, by + 1) = wh_clip255 (p[4] + r1);
+      WH_RY (S, bx + lane, by + 2) = wh_clip255 (p[8] + r2);
+      WH_RY (S, bx + lane, by + 3) = wh_clip255 (p[12] + r3);
+    }
+    WV_LANES_END
+  } else {
+    WV_LANES_BEGIN (lane)
+    if (lane < 16) WH_RY (S, bx + (lane & 3), by + (lane >> 2)) = S.pred4[pred_slot * 16 + lane];
+    WV_LANES_END
+  }
+  return nz;
+}
+
+// ---- chroma residual pipeline for both planes (svc_encode_mb.cpp:244-312 WelsEncRecUV) -----------
+// in: enc_c, pred_c.  out: lv_cdc, lv_cac, nzc[16..23], rec tile.  Returns chroma cbp (0,1,2).
+WH_FN int wh_encrec_chroma (WhMbLds& S, int qpc, int is_intra) {
+  wh_dct_chroma (S);
+  const int ffrow = is_intra ? qpc + 6 : qpc;
+  // 2x2 DC Hadamard + quant per plane (encode_mb_aux.cpp:247-277 WelsHadamardQuant2x2_c)
+  WV_LANES_BEGIN (lane)
+  if (lane < 2) {
+    int16_t* r = &S.res[256 + lane * 64];
+    const int16_t s0 = (int16_t) (r[0] + r[32]), s1 = (int16_t) (r[0] - r[32]);
+    const int16_t s2 = (int16_t) (r[16] + r[48]), s3 = (int16_t) (r[16] - r[48]);
+    r[0] = 0; r[16] = 0; r[32] = 0; r[48] = 0;
+    const int ff = kWhQuantFF[ffrow * 3 + 0] << 1, mf = kWhQuantMF[qpc * 3 + 0] >> 1;
+    int16_t* d = &S.cdc[lane * 4];
+    d[0] = wh_quant1 ((int16_t) (s0 + s2), ff, mf);
+    d[1] = wh_quant1 ((int16_t) (s0 - s2), ff, mf);
+    d[2] = wh_quant1 ((int16_t) (s1 + s3), ff, mf);
+    d[3] = wh_quant1 ((int16_t) (s1 - s3), ff, mf);
+    for (int k = 0; k < 4; ++k) S.lv_cdc[lane * 4 + k] = d[k];
+  }
+  WV_LANES_END
+  // AC quant with per-block max (WelsQuantFour4x4Max_c)
+  WV_LANES_BEGIN (lane)
+  if (lane < 32) {
+    int16_t mx = 0;
+    for (int k = 0; k < 4; ++k) {
+      const int i = lane * 4 + k, pos = i & 15;
+      int16_t a;
+      S.res[256 + i] = wh_quant1_abs (S.res[256 + i], kWhQuantFF[ffrow * 3 + WH_POSCLASS (pos)], wh_mf (qpc, pos), &a);
+      if (mx < a) mx = a;
+    }
+    S.part[lane] = mx;
+  }
+  WV_LANES_END
+  WV_LANES_BEGIN (lane)
+  if (lane < 8) {
+    int mx = wh_max (wh_max (S.part[lane * 4], S.part[lane * 4 + 1]), wh_max (S.part[lane * 4 + 2], S.part[lane * 4 + 3]));
+    S.amax[lane] = (int16_t)mx;
+  }
+  WV_LANES_END
+  // scans (WelsScan4x4Ac_c) -- zero blocks give zero levels either way
+  WV_LANES_BEGIN (lane)
+  if (lane < 32) {
+    const int b = lane >> 2;
+    for (int q = 0; q < 4; ++q) {
+      const int k = (lane & 3) * 4 + q;
+      S.lv_cac[b * 16 + k] = (k < 15) ? S.res[256 + b * 16 + wh_zigzag (k + 1)] : (int16_t)0;
+    }
+  }
+  WV_LANES_END
+  int cbp_c = 0;
+  for (int pl = 0; pl < 2; ++pl) {
+    // JVT-O079 style decision (inter only); intra keeps every non-zero block
+    int ctr = 0;
+    for (int j = 0; j < 4; ++j) {
+      const int mx = S.amax[pl * 4 + j];
+      if (mx != 0) {
+        if (!is_intra) {
+          if (mx > 1) ctr += 9;
+          else if (ctr < 7) ctr += wh_single_ctr (&S.lv_cac[(pl * 4 + j) * 16]);
+        } else {
+          ctr = 0x7fffffff;
+        }
+      }
+    }
+    int nzdc;
+    WV_SUM (nzdc, lane, (lane < 4 ? (S.cdc[pl * 4 + lane] != 0) : 0));
+    if (ctr < 7) {
+      WV_LANES_BEGIN (lane)
+      S.res[256 + pl * 64 + lane] = 0;
+      if (lane < 4) S.nzc[16 + pl * 4 + lane] = 0;
+      WV_LANES_END
+    } else {
+      WV_LANES_BEGIN (lane)
+      if (lane < 4) {
+        int n = 0;
+        for (int k = 0; k < 16; ++k) n += (S.lv_cac[(pl * 4 + lane) * 16 + k] != 0);
+        S.nzc[16 + pl * 4 + lane] = (uint8_t)n;
+      }
+      {
+        const int i = lane, pos = i & 15;
+        S.res[256 + pl * 64 + i] = (int16_t) (S.res[256 + pl * 64 + i] * wh_dq (qpc, pos));
+      }
+      WV_LANES_END
+      cbp_c = 2;
+    }
+    if (nzdc > 0) {
+      // WelsDequantIHadamard2x2Dc (decode_mb_aux.cpp:127-137)
+      WV_LANES_BEGIN (lane)
+      if (lane == 0) {
+        int16_t* d = &S.cdc[pl * 4];
+        const int16_t su = (int16_t) (d[0] + d[2]), du = (int16_t) (d[0] - d[2]);
+        const int16_t sd = (int16_t) (d[1] + d[3]), dd = (int16_t) (d[1] - d[3]);
+        const int mf = wh_dq (qpc, 0);
+        int16_t* r = &S.res[256 + pl * 64];
+        r[0]  = (int16_t) (((su + sd) * mf) >> 1);
+        r[16] = (int16_t) (((su - sd) * mf) >> 1);
+        r[32] = (int16_t) (((du + dd) * mf) >> 1);
+        r[48] = (int16_t) (((du - dd) * mf) >> 1);
+      }
+      WV_LANES_END
+      if (cbp_c != 2) cbp_c = 1;
+    }
+  }
+  return cbp_c;
+}

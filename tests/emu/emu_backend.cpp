@@ -1,0 +1,56 @@
+// emu_backend.cpp -- TEST INFRASTRUCTURE ONLY (never part of libwelship.so).
+//
+// Compiles the very same macroblock kernel sources (openh264_amd/csrc/kernels/*.h) with -DWH_EMU,
+// where a "wavefront" is a 64-iteration loop (kernels/wave.h), and runs them in the same 2:1
+// diagonal order the HIP launcher uses.  It exists so that the CPU-only test tier can exercise the
+// host side (headers, CAVLC, NAL packing, session logic) and the kernel *logic* against the
+// reference bitstream without a GPU.  The product library has no such path and refuses to work
+// without an MI355X.
+#include <stdlib.h>
+#include <string.h>
+#include "../../openh264_amd/csrc/host/backend.h"
+#include "../../openh264_amd/csrc/kernels/frame_kernels.h"
+#include "../../openh264_amd/csrc/kernels/deblock_mb.h"
+#include "../../openh264_amd/csrc/kernels/inter_mb.h"
+#include "../../openh264_amd/csrc/kernels/expand_pic.h"
+
+namespace wh {
+
+class EmuBackend : public Backend {
+ public:
+  const char* name() const override { return "emu:wave64-on-cpu (test build)"; }
+  void* alloc (size_t bytes) override { return ::malloc (bytes ? bytes : 1); }
+  void free (void* p) override { ::free (p); }
+  void upload (void* dst, const void* src, size_t bytes) override { memcpy (dst, src, bytes); }
+  void download (void* dst, const void* src, size_t bytes) override { memcpy (dst, src, bytes); }
+  void fill (void* dst, int value, size_t bytes) override { memset (dst, value, bytes); }
+  template <class F> static void for_diagonals (const WhSeqParams& P, int n, F f) {
+    const int nd = (P.mb_w - 1) + 2 * (P.mb_h - 1) + 1;
+    for (int d = 0; d < nd; ++d) {
+      int y0;
+      const int cnt = wh_diag_count (P.mb_w, P.mb_h, d, &y0);
+      for (int j = 0; j < n; ++j)
+        for (int k = 0; k < cnt; ++k) { const int y = y0 + k, x = d - 2 * y; f (j, x, y); }
+    }
+  }
+  void run_intra (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
+    for_diagonals (P, n, [&] (int j, int x, int y) { WhMbLds S; wh_intra_mb_body (S, P, jobs[j], x, y); });
+  }
+  void run_inter (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
+    for_diagonals (P, n, [&] (int j, int x, int y) { WhInterLds S; wh_inter_mb_body (S, P, jobs[j], x, y); });
+  }
+  void run_deblock (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
+    for_diagonals (P, n, [&] (int j, int x, int y) { WhDbLds S; wh_deblock_mb_body (S, P, jobs[j], x, y); });
+  }
+  void run_expand (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
+    for (int j = 0; j < n; ++j) {
+      const int nb = wh_expand_num_blocks (P);
+      for (int b = 0; b < nb; ++b) wh_expand_body (P, jobs[j], b);
+    }
+  }
+  void sync() override {}
+};
+
+Backend* create_default_backend (int, const char**) { return new EmuBackend(); }
+
+}  // namespace wh
