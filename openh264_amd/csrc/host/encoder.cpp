@@ -167,6 +167,7 @@ int WelsHipInitializeExt (WelsHipEncoder* e, const WelsHipEncParam* p) {
 
   const size_t ysz = (size_t)s.src_stride_y * e->mb_h * 16, csz = (size_t)s.src_stride_c * e->mb_h * 8;
   e->h_src.assign (ysz + 2 * csz, 0);
+  memset (e->h_src.data() + ysz, 0x80, 2 * csz);   // CWelsPreProcess::Padding: luma 0, chroma 0x80
   e->d_src = (uint8_t*)e->be->alloc (ysz + 2 * csz);
   const int rec_h = e->mb_h * 16 + 64;
   const size_t rec_y = (size_t)s.rec_stride_y * rec_h, rec_c = (size_t)s.rec_stride_c * (rec_h / 2);
@@ -203,8 +204,8 @@ int WelsHipForceIntraFrame (WelsHipEncoder* e, int bIDR) {
 const char* WelsHipBackendName (WelsHipEncoder* e) { return (e && e->be) ? e->be->name() : "none"; }
 
 static void stage_source (WelsHipEncoder* e, const WelsHipSourcePicture* src) {
-  // WelsMoveMemoryWrapper + Padding (wels_preprocess.cpp:1395-1450): even dims only; the rows/cols that
-  // exist only because of MB alignment read as zero in the reference (fresh picture buffers), so do ours.
+  // WelsMoveMemoryWrapper + Padding (wels_preprocess.cpp:1250-1275,1395-1450): even dims only; the rows/cols
+  // that exist only because of MB alignment are luma 0 / chroma 0x80 (h_src is pre-filled that way).
   const WhSeqParams& s = e->seq;
   const int w = e->prm.iPicWidth & ~1, h = e->prm.iPicHeight & ~1;
   uint8_t* y = e->h_src.data();

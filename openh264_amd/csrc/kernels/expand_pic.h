@@ -8,7 +8,7 @@
 #pragma once
 #include "prims.h"
 
-WH_FN int wh_expand_num_blocks (const WhSeqParams& P) {
+WH_HDFN int wh_expand_num_blocks (const WhSeqParams& P) {
   return (P.mb_h * 16 + 64) + 2 * (P.mb_h * 8 + 32);
 }
 

@@ -79,7 +79,7 @@ WH_FN void wh_intra_mb_body (WhMbLds& S, const WhSeqParams& P, const WhPicJob& J
 // ---- 2:1 diagonal ("wavefront") scheduling -----------------------------------------------------
 // MB (x,y) depends on (x-1,y), (x,y-1), (x+1,y-1)  =>  all MBs with  x + 2*y == d  are independent.
 // d runs 0 .. (mb_w - 1) + 2 * (mb_h - 1).  For diagonal d, the k-th MB is  y = y0 + k, x = d - 2*y.
-WH_FN int wh_diag_count (int mb_w, int mb_h, int d, int* y0) {
+WH_HDFN int wh_diag_count (int mb_w, int mb_h, int d, int* y0) {
   int ylo = (d - (mb_w - 1) + 1) >> 1;   // ceil((d - (mb_w-1)) / 2)
   if (ylo < 0) ylo = 0;
   int yhi = d >> 1;

@@ -17,6 +17,7 @@
 #if defined(WH_EMU)
 // -------------------------------------------------------------------------------- CPU emulation
 #define WH_FN static inline
+#define WH_HDFN static inline
 #define WH_CONST static const
 #define WV_LANES_BEGIN(lane) for (int lane = 0; lane < 64; ++lane) {
 #define WV_LANES_END }
@@ -35,6 +36,7 @@
 // -------------------------------------------------------------------------------- gfx950 device
 #include <hip/hip_runtime.h>
 #define WH_FN static __device__ __forceinline__
+#define WH_HDFN static __host__ __device__ __forceinline__
 #define WH_CONST static __device__ const
 #define WV_LANES_BEGIN(lane) { const int lane = (int)(threadIdx.x & 63);
 #define WV_LANES_END } __syncthreads();
