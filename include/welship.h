@@ -124,6 +124,27 @@ int  WelsHipGetReconFrame (WelsHipEncoder* pEncoder, uint8_t* pDstI420, size_t u
 const char* WelsHipBackendName (WelsHipEncoder* pEncoder);
 const char* WelsHipGetLastError (void);
 
+/* ---- (1b) session group: N independent sessions with identical parameters advancing in lock
+ * step, one batched launch set per frame step.  This is the multi-session form of the call stack
+ * above (the reference runs N ISVCEncoder objects on N threads); it exists because one
+ * picture exposes at most mb_w/2 independent macroblocks while an MI355X wants thousands. ------- */
+typedef struct WelsHipEncoderGroup WelsHipEncoderGroup;
+int  WelsHipGroupCreate (WelsHipEncoderGroup** ppGroup, const WelsHipEncParam* pParam, int iSessions,
+                         int iSourceRingSlots, int iHostEntropyThreads);
+void WelsHipGroupDestroy (WelsHipEncoderGroup* pGroup);
+/* one EncodeFrame for every session: kpSrcPics[iSessions] -> pBsInfos[iSessions] */
+int  WelsHipGroupEncodeFrames (WelsHipEncoderGroup* pGroup, const WelsHipSourcePicture* kpSrcPics, WelsHipFrameBSInfo* pBsInfos);
+/* the same, split into its phases (sources may be made resident in HBM ahead of time) */
+int  WelsHipGroupUploadSource (WelsHipEncoderGroup* pGroup, int iSession, int iSlot, const WelsHipSourcePicture* kpSrcPic);
+int  WelsHipGroupBegin (WelsHipEncoderGroup* pGroup, int iSlot);
+int  WelsHipGroupRunDevice (WelsHipEncoderGroup* pGroup, int bWait);
+int  WelsHipGroupFinish (WelsHipEncoderGroup* pGroup, WelsHipFrameBSInfo* pBsInfos);
+int  WelsHipGroupStepDeviceOnly (WelsHipEncoderGroup* pGroup, int iSlot);
+int  WelsHipGroupGetReconFrame (WelsHipEncoderGroup* pGroup, int iSession, uint8_t* pDstI420, size_t uiDstBytes);
+const char* WelsHipGroupBackendName (WelsHipEncoderGroup* pGroup);
+/* hot-path timing with HIP events on the launch stream; pOutMs[4] = total, MD, deblock, expand */
+int  WelsHipGroupBench (WelsHipEncoderGroup* pGroup, int iSteps, int iWarmup, double* pOutMs);
+
 #ifdef __cplusplus
 }
 #endif

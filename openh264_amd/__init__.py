@@ -189,3 +189,93 @@ def encode_sequence(yuv_bytes, width, height, lib_path=None, **params):
     enc.Uninitialize()
     enc.close()
     return bytes(out), recon
+
+
+class EncoderGroup:
+    """N independent sessions advancing in lock step (WelsHipGroup* in include/welship.h)."""
+
+    def __init__(self, param, sessions, ring_slots=1, host_threads=1, lib_path=None):
+        self._lib = lib = load_library(lib_path)
+        if not hasattr(lib, "_group_ready"):
+            lib.WelsHipGroupCreate.argtypes = [C.POINTER(C.c_void_p), C.POINTER(SEncParamExt), C.c_int, C.c_int, C.c_int]
+            lib.WelsHipGroupDestroy.argtypes = [C.c_void_p]
+            lib.WelsHipGroupDestroy.restype = None
+            lib.WelsHipGroupUploadSource.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(SSourcePicture)]
+            lib.WelsHipGroupBegin.argtypes = [C.c_void_p, C.c_int]
+            lib.WelsHipGroupRunDevice.argtypes = [C.c_void_p, C.c_int]
+            lib.WelsHipGroupFinish.argtypes = [C.c_void_p, C.POINTER(SFrameBSInfo)]
+            lib.WelsHipGroupStepDeviceOnly.argtypes = [C.c_void_p, C.c_int]
+            lib.WelsHipGroupGetReconFrame.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+            lib.WelsHipGroupBackendName.argtypes = [C.c_void_p]
+            lib.WelsHipGroupBackendName.restype = C.c_char_p
+            lib.WelsHipGroupBench.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
+            lib._group_ready = True
+        h = C.c_void_p()
+        rc = lib.WelsHipGroupCreate(C.byref(h), C.byref(param), sessions, ring_slots, host_threads)
+        if rc:
+            raise WelsHipError(rc, (lib.WelsHipGetLastError() or b"").decode())
+        self._h, self.n, self.w, self.h = h, sessions, param.iPicWidth, param.iPicHeight
+        self._keep = []
+
+    def upload(self, session, slot, yuv):
+        w, h = self.w, self.h
+        buf = (C.c_uint8 * len(yuv)).from_buffer_copy(yuv)
+        base = C.addressof(buf)
+        pic = SSourcePicture()
+        pic.iColorFormat = videoFormatI420
+        pic.iStride[0], pic.iStride[1], pic.iStride[2] = w, w // 2, w // 2
+        pic.pData[0], pic.pData[1], pic.pData[2] = base, base + w * h, base + w * h + (w // 2) * (h // 2)
+        pic.iPicWidth, pic.iPicHeight = w, h
+        rc = self._lib.WelsHipGroupUploadSource(self._h, session, slot, C.byref(pic))
+        if rc:
+            raise WelsHipError(rc, "upload")
+
+    def step(self, slot=0):
+        """One full frame step for all sessions; returns the list of per-session bitstreams."""
+        lib = self._lib
+        rc = lib.WelsHipGroupBegin(self._h, slot)
+        if rc == 0:
+            rc = lib.WelsHipGroupRunDevice(self._h, 0)
+        infos = (SFrameBSInfo * self.n)()
+        if rc == 0:
+            rc = lib.WelsHipGroupFinish(self._h, infos)
+        if rc:
+            raise WelsHipError(rc, (lib.WelsHipGetLastError() or b"").decode())
+        out = []
+        for info in infos:
+            b = bytearray()
+            for li in range(info.iLayerNum):
+                L = info.sLayerInfo[li]
+                b += C.string_at(L.pBsBuf, sum(L.pNalLengthInByte[k] for k in range(L.iNalCount)))
+            out.append(bytes(b))
+        return out
+
+    def bench(self, steps, warmup):
+        """Device-only hot path: returns dict(total_ms, md_ms, deblock_ms, expand_ms) from HIP events."""
+        out = (C.c_double * 4)()
+        rc = self._lib.WelsHipGroupBench(self._h, steps, warmup, out)
+        if rc:
+            raise WelsHipError(rc, (self._lib.WelsHipGetLastError() or b"").decode())
+        return dict(total_ms=out[0], md_ms=out[1], deblock_ms=out[2], expand_ms=out[3])
+
+    def recon(self, session):
+        n = self.w * self.h * 3 // 2
+        buf = (C.c_uint8 * n)()
+        rc = self._lib.WelsHipGroupGetReconFrame(self._h, session, buf, n)
+        if rc:
+            raise WelsHipError(rc, "recon")
+        return bytes(buf)
+
+    def backend_name(self):
+        return (self._lib.WelsHipGroupBackendName(self._h) or b"").decode()
+
+    def close(self):
+        if self._h:
+            self._lib.WelsHipGroupDestroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -75,6 +75,10 @@ class HipBackend : public wh::Backend {
     HIP_CHECK (hipGetLastError());
   }
   void sync() override { HIP_CHECK (hipStreamSynchronize (stream_)); }
+  void* event_create() override { hipEvent_t e; HIP_CHECK (hipEventCreate (&e)); return (void*)e; }
+  void event_destroy (void* ev) override { HIP_CHECK (hipEventDestroy ((hipEvent_t)ev)); }
+  void event_record (void* ev) override { HIP_CHECK (hipEventRecord ((hipEvent_t)ev, stream_)); }
+  float event_elapsed_ms (void* a, void* b) override { float ms = 0.f; HIP_CHECK (hipEventSynchronize ((hipEvent_t)b)); HIP_CHECK (hipEventElapsedTime (&ms, (hipEvent_t)a, (hipEvent_t)b)); return ms; }
   hipStream_t stream() const { return stream_; }
  private:
   int dev_;

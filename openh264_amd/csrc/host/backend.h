@@ -26,6 +26,11 @@ class Backend {
   virtual void run_deblock (const WhSeqParams& P, const WhPicJob* jobs, int n) = 0;   // in-loop filter on rec[]
   virtual void run_expand (const WhSeqParams& P, const WhPicJob* jobs, int n) = 0;    // replicate rec[] borders (32/16 px)
   virtual void sync() = 0;
+  // timing on the stream the kernels are launched on (HIP events)
+  virtual void* event_create() = 0;
+  virtual void event_destroy (void* ev) = 0;
+  virtual void event_record (void* ev) = 0;
+  virtual float event_elapsed_ms (void* a, void* b) = 0;   // waits for b
 };
 
 // Implemented by the HIP library only; returns NULL (and sets *err) when no MI355X is usable.

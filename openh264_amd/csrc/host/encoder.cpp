@@ -1,11 +1,17 @@
-// encoder.cpp -- the host-side encoder session (mirror of ISVCEncoder for the hot path).
+// encoder.cpp -- the host-side encoder: session (mirror of ISVCEncoder) and session group.
 //
 // What stays on the host here is what north_star keeps on the host in the reference as well:
 // parameter handling, frame-type decision, SPS/PPS/slice headers, CAVLC and NAL packing
 // (codec/encoder/plus/src/welsEncoderExt.cpp:175-500, codec/encoder/core/src/encoder_ext.cpp:3441-3960
 // WelsEncoderEncodeExt).  Everything per-macroblock runs on the device through wh::Backend.
+//
+// A *group* is N independent sessions with identical parameters that advance in lock step: one
+// batched launch set per frame step covers all N pictures, which is how a single MI355X is filled
+// (independent sessions / simulcast layers / all-IDR frames have no mutual dependency).
 #include <string.h>
+#include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 #include "../../../include/welship.h"
 #include "backend.h"
@@ -24,64 +30,294 @@ namespace {
 inline int align_up (int v, int a) { return (v + a - 1) / a * a; }
 
 struct DevPicture {            // one padded reconstruction buffer + its MB state
-  uint8_t* base = nullptr;     // allocation
+  uint8_t* base = nullptr;
   uint8_t* plane[3] = {nullptr, nullptr, nullptr};   // pixel (0,0)
   WhMbState* mbs = nullptr;
   bool is_p = false;
 };
+
+// Stream state + device buffers of one session.  The backend is shared (owned by the caller).
+struct SessionCore {
+  wh::Backend* be = nullptr;
+  WelsHipEncParam prm;
+  WhSeqParams seq;
+  int mb_w = 0, mb_h = 0, num_mb = 0;
+  int ring = 1;                       // number of source slots resident in HBM
+  std::vector<uint8_t*> d_src;        // [ring] Y | U | V, MB-aligned dims, tight strides
+  DevPicture pic[2];
+  int cur = 0;
+  WhMbRecord* d_records = nullptr;
+  size_t rec_alloc_bytes = 0, src_bytes = 0, ysz = 0, csz = 0;
+  std::vector<uint8_t> h_src;
+  std::vector<WhMbRecord> h_records;
+  std::vector<uint8_t> bs;
+  std::vector<int32_t> nal_len;
+  int frame_index = 0, frame_num = 0, idr_pic_id = 0;
+  int sps_counter = 0, pps_counter = 0, sps_id_in_bs = 0, pps_id_in_bs = 0;
+  bool force_idr = false, have_recon = false, cur_idr = true;
+  int level_idc = 0;
+  bool level_1b = false;
+  int n_param_nals = 0;
+  size_t vcl_start = 0;
+
+  static int validate (const WelsHipEncParam* p) {
+    // same spirit as ParamValidationExt (encoder_ext.cpp:403-680)
+    if (p->iPicWidth < 16 || p->iPicHeight < 16 || p->iPicWidth > 4096 || p->iPicHeight > 2304) { set_err ("invalid picture size"); return WELSHIP_ERR_INIT_PARA; }
+    if (p->fMaxFrameRate <= 0.f) { set_err ("invalid frame rate"); return WELSHIP_ERR_INIT_PARA; }
+    if (p->iDLayerQp < 0 || p->iDLayerQp > 51) { set_err ("invalid QP"); return WELSHIP_ERR_INIT_PARA; }
+    if (p->iComplexityMode < 0 || p->iComplexityMode > 2) { set_err ("invalid complexity mode"); return WELSHIP_ERR_INIT_PARA; }
+    if (p->iUsageType != 0) { set_err ("only CAMERA_VIDEO_REAL_TIME is supported"); return WELSHIP_ERR_UNSUPPORTED; }
+    if (p->iRCMode != -1) { set_err ("only RC_OFF_MODE (-1) is supported"); return WELSHIP_ERR_UNSUPPORTED; }
+    if (p->iTemporalLayerNum != 1 || p->iSpatialLayerNum != 1) { set_err ("only one temporal and one spatial layer supported"); return WELSHIP_ERR_UNSUPPORTED; }
+    if (p->iEntropyCodingModeFlag != 0) { set_err ("CABAC is not implemented"); return WELSHIP_ERR_UNSUPPORTED; }
+    if (p->bEnableAdaptiveQuant || p->bEnableBackgroundDetection || p->bEnableSceneChangeDetect || p->bEnableLongTermReference ||
+        p->bEnableDenoise || p->bEnableFrameSkip) { set_err ("AQ/BGD/scene-change/LTR/denoise/frame-skip are not supported"); return WELSHIP_ERR_UNSUPPORTED; }
+    if (p->uiSliceMode != 0 && p->uiSliceMode != 1) { set_err ("slice mode must be 0 or 1"); return WELSHIP_ERR_UNSUPPORTED; }
+    if (p->iLoopFilterDisableIdc < 0 || p->iLoopFilterDisableIdc > 2) { set_err ("deblocking idc must be 0..2"); return WELSHIP_ERR_UNSUPPORTED; }
+    if (p->eSpsPpsIdStrategy != 0 && p->eSpsPpsIdStrategy != 1) { set_err ("SpsPpsIdStrategy must be 0 or 1"); return WELSHIP_ERR_UNSUPPORTED; }
+    return WELSHIP_OK;
+  }
+
+  int compute_slices() {
+    WhSeqParams& s = seq;
+    const int n = prm.uiSliceMode == 0 ? 1 : prm.uiSliceNum;
+    if (n < 1 || n > WH_MAX_SLICES) return -1;
+    s.num_slices = n;
+    if (n == 1) { s.slice_first_mb[0] = 0; s.slice_first_mb[1] = num_mb; return 0; }
+    // SM_FIXEDSLCNUM_SLICE: whole MB rows per slice (svc_enc_slice_segment.cpp GomValidCheckSliceMbNum /
+    // AssignMbMapMultipleSlices for pictures of at least one row per slice)
+    if (n > mb_h) return -1;
+    int first = 0;
+    for (int i = 0; i < n; ++i) {
+      s.slice_first_mb[i] = first;
+      int r = mb_h / n;
+      if (i == n - 1) r = mb_h - (mb_h / n) * (n - 1);
+      first += r * mb_w;
+    }
+    s.slice_first_mb[n] = num_mb;
+    return 0;
+  }
+
+  int init (wh::Backend* backend, const WelsHipEncParam* p, int ring_slots) {
+    be = backend; prm = *p; ring = ring_slots < 1 ? 1 : ring_slots;
+    mb_w = (p->iPicWidth + 15) >> 4; mb_h = (p->iPicHeight + 15) >> 4; num_mb = mb_w * mb_h;
+    WhSeqParams& s = seq;
+    memset (&s, 0, sizeof (s));
+    s.mb_w = mb_w; s.mb_h = mb_h;
+    s.src_stride_y = mb_w * 16; s.src_stride_c = mb_w * 8;
+    s.rec_stride_y = align_up (mb_w * 16 + 64, 64); s.rec_stride_c = s.rec_stride_y / 2;
+    s.complexity = p->iComplexityMode;
+    s.chroma_qp_offset = 0;
+    s.deblock_idc = p->iLoopFilterDisableIdc;
+    s.alpha_offset = p->iLoopFilterAlphaC0Offset; s.beta_offset = p->iLoopFilterBetaOffset;
+    s.mv_range = 64;
+    if (compute_slices()) { set_err ("invalid slice number"); return WELSHIP_ERR_INIT_PARA; }
+    ysz = (size_t)s.src_stride_y * mb_h * 16; csz = (size_t)s.src_stride_c * mb_h * 8; src_bytes = ysz + 2 * csz;
+    h_src.assign (src_bytes, 0);
+    memset (h_src.data() + ysz, 0x80, 2 * csz);     // CWelsPreProcess::Padding: luma 0, chroma 0x80
+    d_src.resize (ring);
+    for (int i = 0; i < ring; ++i) d_src[i] = (uint8_t*)be->alloc (src_bytes);
+    const int rec_h = mb_h * 16 + 64;
+    const size_t rec_y = (size_t)s.rec_stride_y * rec_h, rec_c = (size_t)s.rec_stride_c * (rec_h / 2);
+    rec_alloc_bytes = rec_y + 2 * rec_c;
+    for (int i = 0; i < 2; ++i) {
+      DevPicture& d = pic[i];
+      d.base = (uint8_t*)be->alloc (rec_alloc_bytes);
+      be->fill (d.base, 0, rec_alloc_bytes);
+      d.plane[0] = d.base + (size_t)32 * s.rec_stride_y + 32;
+      d.plane[1] = d.base + rec_y + (size_t)16 * s.rec_stride_c + 16;
+      d.plane[2] = d.base + rec_y + rec_c + (size_t)16 * s.rec_stride_c + 16;
+      d.mbs = (WhMbState*)be->alloc (sizeof (WhMbState) * num_mb);
+      be->fill (d.mbs, 0, sizeof (WhMbState) * num_mb);
+    }
+    d_records = (WhMbRecord*)be->alloc (sizeof (WhMbRecord) * num_mb);
+    h_records.resize (num_mb);
+    // level (au_set.cpp:530-545): the reference feeds iSpatialBitrate even with RC off
+    level_idc = wh::select_level_idc (mb_w, mb_h, 1, p->fMaxFrameRate, p->iTargetBitrate, &level_1b);
+    return WELSHIP_OK;
+  }
+
+  void release() {
+    if (!be) return;
+    for (uint8_t* p : d_src) if (p) be->free (p);
+    d_src.clear();
+    for (int i = 0; i < 2; ++i) { if (pic[i].base) be->free (pic[i].base); if (pic[i].mbs) be->free (pic[i].mbs); pic[i] = DevPicture(); }
+    if (d_records) be->free (d_records);
+    d_records = nullptr;
+    be = nullptr;
+  }
+
+  // WelsMoveMemoryWrapper + Padding (wels_preprocess.cpp:1250-1275,1395-1450): even dims only; the rows/cols
+  // that exist only because of MB alignment are luma 0 / chroma 0x80 (h_src is pre-filled that way).
+  void upload_source (int slot, const WelsHipSourcePicture* src) {
+    const WhSeqParams& s = seq;
+    const int w = prm.iPicWidth & ~1, h = prm.iPicHeight & ~1;
+    uint8_t* y = h_src.data();
+    uint8_t* u = y + ysz;
+    uint8_t* v = u + csz;
+    for (int r = 0; r < h; ++r) memcpy (y + (size_t)r * s.src_stride_y, src->pData[0] + (size_t)r * src->iStride[0], w);
+    for (int r = 0; r < h / 2; ++r) {
+      memcpy (u + (size_t)r * s.src_stride_c, src->pData[1] + (size_t)r * src->iStride[1], w / 2);
+      memcpy (v + (size_t)r * s.src_stride_c, src->pData[2] + (size_t)r * src->iStride[2], w / 2);
+    }
+    be->upload (d_src[slot], h_src.data(), src_bytes);
+    be->sync();                       // h_src is reused by the next upload
+  }
+
+  // Decide the frame type (encoder_ext.cpp DecideFrameType: IDR at index 0 / intra period / on request) and
+  // describe the picture to the device.
+  void begin_frame (int slot, WhPicJob* job) {
+    bool idr = force_idr || frame_index == 0;
+    if (!idr && prm.uiIntraPeriod > 0 && (uint32_t)frame_index >= prm.uiIntraPeriod) idr = true;
+    if (idr) { frame_index = 0; frame_num = 0; force_idr = false; }
+    cur_idr = idr;
+    DevPicture& c = pic[cur];
+    DevPicture& r = pic[cur ^ 1];
+    memset (job, 0, sizeof (*job));
+    job->src[0] = d_src[slot]; job->src[1] = d_src[slot] + ysz; job->src[2] = d_src[slot] + ysz + csz;
+    for (int i = 0; i < 3; ++i) { job->rec[i] = c.plane[i]; job->ref[i] = idr ? nullptr : r.plane[i]; }
+    job->records = d_records;
+    job->mbs = c.mbs;
+    job->ref_mbs = idr ? nullptr : r.mbs;
+    job->qp = prm.iDLayerQp;
+    job->slice_type = idr ? WH_SLICE_I : WH_SLICE_P;
+    job->qp_delta = nullptr;
+    job->ref_is_p = r.is_p ? 1 : 0;
+  }
+
+  // Entropy-code the downloaded records into `bs` and advance the stream state.
+  int finish_frame (WelsHipFrameBSInfo* out, int64_t ts) {
+    const WhSeqParams& s = seq;
+    const bool idr = cur_idr;
+    const int qp = prm.iDLayerQp;
+    pic[cur].is_p = !idr;
+    have_recon = true;
+    bs.clear();
+    nal_len.clear();
+    n_param_nals = 0;
+    std::vector<uint8_t> rbsp;
+    if (idr) {
+      if (prm.eSpsPpsIdStrategy == 1) {          // INCREASING_ID (paraset_strategy.cpp:334-372)
+        sps_id_in_bs = sps_counter % 32; pps_id_in_bs = pps_counter % 57;
+        ++sps_counter; ++pps_counter;
+      } else { sps_id_in_bs = 0; pps_id_in_bs = 0; }
+      idr_pic_id = (idr_pic_id < 65535) ? idr_pic_id + 1 : 0;   // WriteSsvcParaset (encoder_ext.cpp:3122-3136)
+      wh::SpsParams sp;
+      sp.sps_id = sps_id_in_bs; sp.level_idc = level_idc; sp.constraint_set3 = level_1b;
+      sp.width = prm.iPicWidth; sp.height = prm.iPicHeight; sp.mb_w = mb_w; sp.mb_h = mb_h;
+      sp.num_ref_frames = 1; sp.gaps_in_frame_num = false; sp.frame_cropping = prm.bEnableFrameCroppingFlag != 0;
+      wh::write_sps_rbsp (rbsp, sp);
+      nal_len.push_back (wh::append_nal (bs, 3, 7, rbsp));
+      wh::PpsParams pp;
+      pp.pps_id = pps_id_in_bs; pp.sps_id = sps_id_in_bs;
+      rbsp.clear();
+      wh::write_pps_rbsp (rbsp, pp);
+      nal_len.push_back (wh::append_nal (bs, 3, 8, rbsp));
+      n_param_nals = 2;
+    }
+    vcl_start = bs.size();
+    rbsp.reserve (1 << 16);
+    for (int si = 0; si < s.num_slices; ++si) {
+      rbsp.clear();
+      wh::BitWriter bw (&rbsp);
+      wh::SliceHeaderParams sh;
+      sh.first_mb = s.slice_first_mb[si];
+      sh.slice_type = idr ? 2 : 0;
+      sh.pps_id = pps_id_in_bs;
+      sh.frame_num = frame_num;
+      sh.idr = idr;
+      sh.idr_pic_id = idr_pic_id;
+      sh.nal_ref_idc = 3;
+      sh.slice_qp = qp;
+      sh.disable_deblocking_idc = s.deblock_idc;
+      sh.alpha_offset = s.alpha_offset; sh.beta_offset = s.beta_offset;
+      wh::write_slice_header (bw, sh);
+      wh::SliceEntropyState st;
+      st.slice_type = idr ? WH_SLICE_I : WH_SLICE_P;
+      st.last_qp = qp;
+      for (int xy = s.slice_first_mb[si]; xy < s.slice_first_mb[si + 1]; ++xy) {
+        const int mbx = xy % mb_w, mby = xy / mb_w;
+        int avail = 0;
+        if (mbx > 0 && xy - 1 >= s.slice_first_mb[si]) avail |= wh::WH_AVAIL_LEFT;
+        if (mby > 0 && xy - mb_w >= s.slice_first_mb[si]) avail |= wh::WH_AVAIL_TOP;
+        int dbqp = qp;
+        const int rc = wh::write_mb_cavlc (bw, st, h_records.data(), mb_w, mbx, mby, avail, &dbqp);
+        if (rc == -1) { set_err ("CAVLC level escape overflow (re-encode at higher QP not implemented)"); return WELSHIP_ERR_VLC_OVERFLOW; }
+        if (rc) { set_err ("bad macroblock record"); return WELSHIP_ERR_UNKNOWN; }
+      }
+      wh::write_slice_end (bw, st);
+      nal_len.push_back (wh::append_nal (bs, 3, idr ? 5 : 1, rbsp));
+    }
+    if (out) {
+      memset (out, 0, sizeof (*out));
+      int li = 0;
+      if (n_param_nals) {
+        WelsHipLayerBSInfo& L = out->sLayerInfo[li++];
+        L.uiLayerType = WELSHIP_NON_VIDEO_CODING_LAYER; L.eFrameType = WelsHipFrameTypeIDR;
+        L.iNalCount = n_param_nals; L.pNalLengthInByte = nal_len.data(); L.pBsBuf = bs.data();
+      }
+      WelsHipLayerBSInfo& V = out->sLayerInfo[li++];
+      V.uiLayerType = WELSHIP_VIDEO_CODING_LAYER; V.eFrameType = idr ? WelsHipFrameTypeIDR : WelsHipFrameTypeP;
+      V.iNalCount = s.num_slices; V.pNalLengthInByte = nal_len.data() + n_param_nals; V.pBsBuf = bs.data() + vcl_start;
+      out->iLayerNum = li;
+      out->eFrameType = idr ? WelsHipFrameTypeIDR : WelsHipFrameTypeP;
+      out->iFrameSizeInBytes = (int32_t)bs.size();
+      out->uiTimeStamp = ts;
+    }
+    ++frame_index;
+    frame_num = (frame_num + 1) & 0x7fff;
+    cur ^= 1;
+    return WELSHIP_OK;
+  }
+
+  int copy_recon (uint8_t* dst, size_t bytes) {
+    if (!have_recon || !dst) return WELSHIP_ERR_INIT_PARA;
+    const int w = prm.iPicWidth, h = prm.iPicHeight;
+    if (bytes < (size_t)w * h * 3 / 2) return WELSHIP_ERR_INIT_PARA;
+    const WhSeqParams& s = seq;
+    std::vector<uint8_t> tmp (rec_alloc_bytes);
+    const DevPicture& p = pic[cur ^ 1];     // the picture encoded last
+    be->download (tmp.data(), p.base, rec_alloc_bytes);
+    be->sync();
+    const uint8_t* y = tmp.data() + (p.plane[0] - p.base);
+    const uint8_t* u = tmp.data() + (p.plane[1] - p.base);
+    const uint8_t* v = tmp.data() + (p.plane[2] - p.base);
+    for (int r = 0; r < h; ++r) memcpy (dst + (size_t)r * w, y + (size_t)r * s.rec_stride_y, w);
+    uint8_t* du = dst + (size_t)w * h;
+    uint8_t* dv = du + (size_t) (w / 2) * (h / 2);
+    for (int r = 0; r < h / 2; ++r) {
+      memcpy (du + (size_t)r * (w / 2), u + (size_t)r * s.rec_stride_c, w / 2);
+      memcpy (dv + (size_t)r * (w / 2), v + (size_t)r * s.rec_stride_c, w / 2);
+    }
+    return WELSHIP_OK;
+  }
+};
+
+// Run the device part of one frame step for `n` pictures described by the device array d_jobs.
+void run_device_step (wh::Backend* be, const WhSeqParams& s, const WhPicJob* d_jobs, int n, bool idr, bool need_ref) {
+  if (idr) be->run_intra (s, d_jobs, n);
+  else be->run_inter (s, d_jobs, n);
+  if (s.deblock_idc != 1) be->run_deblock (s, d_jobs, n);
+  if (need_ref) be->run_expand (s, d_jobs, n);
+}
 
 }  // namespace
 
 struct WelsHipEncoder {
   wh::Backend* be = nullptr;
   bool inited = false;
-  WelsHipEncParam prm;
-  WhSeqParams seq;
-  int mb_w = 0, mb_h = 0, num_mb = 0;
-  // device buffers
-  uint8_t* d_src = nullptr;          // Y | U | V, MB-aligned dims, tight strides
-  DevPicture pic[2];
-  int cur = 0;
-  WhMbRecord* d_records = nullptr;
+  SessionCore core;
   WhPicJob* d_job = nullptr;
-  size_t rec_alloc_bytes = 0;
-  // host staging
-  std::vector<uint8_t> h_src;
-  std::vector<WhMbRecord> h_records;
-  std::vector<uint8_t> bs;           // output bitstream of the current frame
-  std::vector<int32_t> nal_len;
-  // stream state
-  int frame_index = 0;               // frames since the last IDR
-  int frame_num = 0;
-  int idr_pic_id = 0;
-  int sps_counter = 0, pps_counter = 0;   // INCREASING_ID strategy
-  int sps_id_in_bs = 0, pps_id_in_bs = 0;
-  bool force_idr = false;
-  int level_idc = 0;
-  bool level_1b = false;
-  bool have_recon = false;
 };
 
-static int compute_slices (WelsHipEncoder* e) {
-  WhSeqParams& s = e->seq;
-  const int n = e->prm.uiSliceMode == 0 ? 1 : e->prm.uiSliceNum;
-  if (n < 1 || n > WH_MAX_SLICES) return -1;
-  s.num_slices = n;
-  if (n == 1) { s.slice_first_mb[0] = 0; s.slice_first_mb[1] = e->num_mb; return 0; }
-  // SM_FIXEDSLCNUM_SLICE (svc_enc_slice_segment.cpp:118-190 AssignMbMapMultipleSlices + CheckFixedSliceNumMultiSliceSetting):
-  // whole MB rows per slice, rows split as evenly as the reference does.
-  const int rows = e->mb_h;
-  if (n > rows) return -1;
-  int first = 0;
-  for (int i = 0; i < n; ++i) {
-    s.slice_first_mb[i] = first;
-    int r = rows / n;
-    if (i == n - 1) r = rows - (rows / n) * (n - 1);
-    first += r * e->mb_w;
-  }
-  s.slice_first_mb[n] = e->num_mb;
-  return 0;
-}
+struct WelsHipEncoderGroup {
+  wh::Backend* be = nullptr;
+  std::vector<std::unique_ptr<SessionCore>> sess;
+  WhPicJob* d_jobs = nullptr;
+  std::vector<WhPicJob> h_jobs;
+  int host_threads = 1;
+  bool step_idr = true;
+};
 
 extern "C" {
 
@@ -90,7 +326,6 @@ const char* WelsHipGetLastError (void) { return g_last_error.c_str(); }
 int WelsHipCreateEncoder (WelsHipEncoder** pp) {
   if (!pp) return WELSHIP_ERR_INIT_PARA;
   *pp = new WelsHipEncoder();
-  memset (& (*pp)->prm, 0, sizeof (WelsHipEncParam));
   return WELSHIP_OK;
 }
 
@@ -98,11 +333,9 @@ int WelsHipUninitialize (WelsHipEncoder* e) {
   if (!e) return WELSHIP_ERR_INIT_PARA;
   if (e->be) {
     e->be->sync();
-    if (e->d_src) e->be->free (e->d_src);
-    for (int i = 0; i < 2; ++i) { if (e->pic[i].base) e->be->free (e->pic[i].base); if (e->pic[i].mbs) e->be->free (e->pic[i].mbs); e->pic[i] = DevPicture(); }
-    if (e->d_records) e->be->free (e->d_records);
+    e->core.release();
     if (e->d_job) e->be->free (e->d_job);
-    e->d_src = nullptr; e->d_records = nullptr; e->d_job = nullptr;
+    e->d_job = nullptr;
     delete e->be;
     e->be = nullptr;
   }
@@ -117,7 +350,8 @@ void WelsHipDestroyEncoder (WelsHipEncoder* e) {
 }
 
 int WelsHipGetDefaultParams (WelsHipEncoder* e, WelsHipEncParam* p) {
-  if (!e || !p) return WELSHIP_ERR_INIT_PARA;
+  if (!p) return WELSHIP_ERR_INIT_PARA;
+  (void)e;
   // the defaults of SWelsSvcCodingParam::FillDefault (param_svc.h:132-211) restricted to what we support
   memset (p, 0, sizeof (*p));
   p->iUsageType = 0; p->iRCMode = -1; p->fMaxFrameRate = 60.f;   // MAX_FRAME_RATE
@@ -131,65 +365,15 @@ int WelsHipGetDefaultParams (WelsHipEncoder* e, WelsHipEncParam* p) {
 int WelsHipInitializeExt (WelsHipEncoder* e, const WelsHipEncParam* p) {
   if (!e || !p) return WELSHIP_ERR_INIT_PARA;
   if (e->inited) WelsHipUninitialize (e);
-  // ---- validation: same spirit as ParamValidationExt (encoder_ext.cpp:403-680) ----
-  if (p->iPicWidth < 16 || p->iPicHeight < 16 || p->iPicWidth > 4096 || p->iPicHeight > 2304) { set_err ("invalid picture size"); return WELSHIP_ERR_INIT_PARA; }
-  if (p->fMaxFrameRate <= 0.f) { set_err ("invalid frame rate"); return WELSHIP_ERR_INIT_PARA; }
-  if (p->iDLayerQp < 0 || p->iDLayerQp > 51) { set_err ("invalid QP"); return WELSHIP_ERR_INIT_PARA; }
-  if (p->iUsageType != 0) { set_err ("only CAMERA_VIDEO_REAL_TIME is supported"); return WELSHIP_ERR_UNSUPPORTED; }
-  if (p->iRCMode != -1) { set_err ("only RC_OFF_MODE (-1) is supported"); return WELSHIP_ERR_UNSUPPORTED; }
-  if (p->iTemporalLayerNum != 1 || p->iSpatialLayerNum != 1) { set_err ("only one temporal and one spatial layer supported"); return WELSHIP_ERR_UNSUPPORTED; }
-  if (p->iEntropyCodingModeFlag != 0) { set_err ("CABAC is not implemented"); return WELSHIP_ERR_UNSUPPORTED; }
-  if (p->bEnableAdaptiveQuant || p->bEnableBackgroundDetection || p->bEnableSceneChangeDetect || p->bEnableLongTermReference ||
-      p->bEnableDenoise || p->bEnableFrameSkip) { set_err ("AQ/BGD/scene-change/LTR/denoise/frame-skip are not supported"); return WELSHIP_ERR_UNSUPPORTED; }
-  if (p->uiSliceMode != 0 && p->uiSliceMode != 1) { set_err ("slice mode must be 0 or 1"); return WELSHIP_ERR_UNSUPPORTED; }
-  if (p->iLoopFilterDisableIdc < 0 || p->iLoopFilterDisableIdc > 2) { set_err ("deblocking idc must be 0..2"); return WELSHIP_ERR_UNSUPPORTED; }
-  if (p->eSpsPpsIdStrategy != 0 && p->eSpsPpsIdStrategy != 1) { set_err ("SpsPpsIdStrategy must be 0 or 1"); return WELSHIP_ERR_UNSUPPORTED; }
-  if (p->iComplexityMode < 0 || p->iComplexityMode > 2) { set_err ("invalid complexity mode"); return WELSHIP_ERR_INIT_PARA; }
-
+  int rc = SessionCore::validate (p);
+  if (rc) return rc;
   const char* berr = nullptr;
   e->be = wh::create_default_backend (p->iDevice, &berr);
   if (!e->be) { set_err (std::string ("no usable device backend: ") + (berr ? berr : "?")); return WELSHIP_ERR_NO_DEVICE; }
-  e->prm = *p;
-  e->mb_w = (p->iPicWidth + 15) >> 4;
-  e->mb_h = (p->iPicHeight + 15) >> 4;
-  e->num_mb = e->mb_w * e->mb_h;
-  WhSeqParams& s = e->seq;
-  memset (&s, 0, sizeof (s));
-  s.mb_w = e->mb_w; s.mb_h = e->mb_h;
-  s.src_stride_y = e->mb_w * 16; s.src_stride_c = e->mb_w * 8;
-  s.rec_stride_y = align_up (e->mb_w * 16 + 64, 64); s.rec_stride_c = s.rec_stride_y / 2;
-  s.complexity = p->iComplexityMode;
-  s.chroma_qp_offset = 0;
-  s.deblock_idc = p->iLoopFilterDisableIdc;
-  s.alpha_offset = p->iLoopFilterAlphaC0Offset; s.beta_offset = p->iLoopFilterBetaOffset;
-  s.mv_range = 64;
-  if (compute_slices (e)) { set_err ("invalid slice number"); delete e->be; e->be = nullptr; return WELSHIP_ERR_INIT_PARA; }
-
-  const size_t ysz = (size_t)s.src_stride_y * e->mb_h * 16, csz = (size_t)s.src_stride_c * e->mb_h * 8;
-  e->h_src.assign (ysz + 2 * csz, 0);
-  memset (e->h_src.data() + ysz, 0x80, 2 * csz);   // CWelsPreProcess::Padding: luma 0, chroma 0x80
-  e->d_src = (uint8_t*)e->be->alloc (ysz + 2 * csz);
-  const int rec_h = e->mb_h * 16 + 64;
-  const size_t rec_y = (size_t)s.rec_stride_y * rec_h, rec_c = (size_t)s.rec_stride_c * (rec_h / 2);
-  e->rec_alloc_bytes = rec_y + 2 * rec_c;
-  for (int i = 0; i < 2; ++i) {
-    DevPicture& d = e->pic[i];
-    d.base = (uint8_t*)e->be->alloc (e->rec_alloc_bytes);
-    e->be->fill (d.base, 0, e->rec_alloc_bytes);
-    d.plane[0] = d.base + (size_t)32 * s.rec_stride_y + 32;
-    d.plane[1] = d.base + rec_y + (size_t)16 * s.rec_stride_c + 16;
-    d.plane[2] = d.base + rec_y + rec_c + (size_t)16 * s.rec_stride_c + 16;
-    d.mbs = (WhMbState*)e->be->alloc (sizeof (WhMbState) * e->num_mb);
-    e->be->fill (d.mbs, 0, sizeof (WhMbState) * e->num_mb);
-  }
-  e->d_records = (WhMbRecord*)e->be->alloc (sizeof (WhMbRecord) * e->num_mb);
+  e->core = SessionCore();
+  rc = e->core.init (e->be, p, 1);
+  if (rc) { e->core.release(); delete e->be; e->be = nullptr; return rc; }
   e->d_job = (WhPicJob*)e->be->alloc (sizeof (WhPicJob));
-  e->h_records.resize (e->num_mb);
-  e->cur = 0;
-  e->frame_index = 0; e->frame_num = 0; e->idr_pic_id = 0; e->sps_counter = 0; e->pps_counter = 0;
-  e->force_idr = false; e->have_recon = false;
-  // level (au_set.cpp:530-545): the reference feeds iSpatialBitrate even with RC off
-  e->level_idc = wh::select_level_idc (e->mb_w, e->mb_h, 1, p->fMaxFrameRate, p->iTargetBitrate, &e->level_1b);
   e->inited = true;
   return WELSHIP_OK;
 }
@@ -197,166 +381,179 @@ int WelsHipInitializeExt (WelsHipEncoder* e, const WelsHipEncParam* p) {
 int WelsHipForceIntraFrame (WelsHipEncoder* e, int bIDR) {
   if (!e || !e->inited) return WELSHIP_ERR_INIT_PARA;
   (void)bIDR;
-  e->force_idr = true;
+  e->core.force_idr = true;
   return WELSHIP_OK;
 }
 
 const char* WelsHipBackendName (WelsHipEncoder* e) { return (e && e->be) ? e->be->name() : "none"; }
 
-static void stage_source (WelsHipEncoder* e, const WelsHipSourcePicture* src) {
-  // WelsMoveMemoryWrapper + Padding (wels_preprocess.cpp:1250-1275,1395-1450): even dims only; the rows/cols
-  // that exist only because of MB alignment are luma 0 / chroma 0x80 (h_src is pre-filled that way).
-  const WhSeqParams& s = e->seq;
-  const int w = e->prm.iPicWidth & ~1, h = e->prm.iPicHeight & ~1;
-  uint8_t* y = e->h_src.data();
-  uint8_t* u = y + (size_t)s.src_stride_y * e->mb_h * 16;
-  uint8_t* v = u + (size_t)s.src_stride_c * e->mb_h * 8;
-  for (int r = 0; r < h; ++r) memcpy (y + (size_t)r * s.src_stride_y, src->pData[0] + (size_t)r * src->iStride[0], w);
-  for (int r = 0; r < h / 2; ++r) {
-    memcpy (u + (size_t)r * s.src_stride_c, src->pData[1] + (size_t)r * src->iStride[1], w / 2);
-    memcpy (v + (size_t)r * s.src_stride_c, src->pData[2] + (size_t)r * src->iStride[2], w / 2);
-  }
-}
-
 int WelsHipEncodeFrame (WelsHipEncoder* e, const WelsHipSourcePicture* src, WelsHipFrameBSInfo* out) {
   if (!e || !e->inited || !src || !out) return WELSHIP_ERR_INIT_PARA;
+  SessionCore& c = e->core;
   if (src->iColorFormat != 23) { set_err ("only videoFormatI420 input"); return WELSHIP_ERR_UNSUPPORTED; }
-  if (src->iPicWidth != e->prm.iPicWidth || src->iPicHeight != e->prm.iPicHeight) { set_err ("source size differs from the initialised size"); return WELSHIP_ERR_INIT_PARA; }
-  const WhSeqParams& s = e->seq;
-  // ---- frame type (encoder_ext.cpp DecideFrameType: IDR at index 0 / intra period / on request) ----
-  bool idr = e->force_idr || e->frame_index == 0;
-  if (!idr && e->prm.uiIntraPeriod > 0 && (uint32_t)e->frame_index >= e->prm.uiIntraPeriod) idr = true;
-  if (idr) { e->frame_index = 0; e->frame_num = 0; e->force_idr = false; }
-  const int qp = e->prm.iDLayerQp;
-
-  // ---- device work ----
-  stage_source (e, src);
-  const size_t ysz = (size_t)s.src_stride_y * e->mb_h * 16, csz = (size_t)s.src_stride_c * e->mb_h * 8;
-  e->be->upload (e->d_src, e->h_src.data(), ysz + 2 * csz);
-  DevPicture& cur = e->pic[e->cur];
-  DevPicture& ref = e->pic[e->cur ^ 1];
+  if (src->iPicWidth != c.prm.iPicWidth || src->iPicHeight != c.prm.iPicHeight) { set_err ("source size differs from the initialised size"); return WELSHIP_ERR_INIT_PARA; }
+  c.upload_source (0, src);
   WhPicJob job;
-  memset (&job, 0, sizeof (job));
-  job.src[0] = e->d_src; job.src[1] = e->d_src + ysz; job.src[2] = e->d_src + ysz + csz;
-  for (int i = 0; i < 3; ++i) { job.rec[i] = cur.plane[i]; job.ref[i] = idr ? nullptr : ref.plane[i]; }
-  job.records = e->d_records;
-  job.mbs = cur.mbs;
-  job.ref_mbs = idr ? nullptr : ref.mbs;
-  job.qp = qp;
-  job.slice_type = idr ? WH_SLICE_I : WH_SLICE_P;
-  job.qp_delta = nullptr;
-  job.ref_is_p = ref.is_p ? 1 : 0;
+  c.begin_frame (0, &job);
   e->be->upload (e->d_job, &job, sizeof (job));
-  if (idr) e->be->run_intra (s, e->d_job, 1);
-  else e->be->run_inter (s, e->d_job, 1);
-  e->be->download (e->h_records.data(), e->d_records, sizeof (WhMbRecord) * e->num_mb);
-  if (s.deblock_idc != 1) e->be->run_deblock (s, e->d_job, 1);
-  if (e->prm.uiIntraPeriod != 1) e->be->run_expand (s, e->d_job, 1);
+  run_device_step (e->be, c.seq, e->d_job, 1, c.cur_idr, c.prm.uiIntraPeriod != 1);
+  e->be->download (c.h_records.data(), c.d_records, sizeof (WhMbRecord) * c.num_mb);
   e->be->sync();
-  cur.is_p = !idr;
-  e->have_recon = true;
-
-  // ---- bitstream ----
-  e->bs.clear();
-  e->nal_len.clear();
-  int n_param_nals = 0;
-  if (idr) {
-    if (e->prm.eSpsPpsIdStrategy == 1) {          // INCREASING_ID (paraset_strategy.cpp:334-372)
-      e->sps_id_in_bs = e->sps_counter % 32; e->pps_id_in_bs = e->pps_counter % 57;
-      ++e->sps_counter; ++e->pps_counter;
-    } else { e->sps_id_in_bs = 0; e->pps_id_in_bs = 0; }
-    e->idr_pic_id = (e->idr_pic_id < 65535) ? e->idr_pic_id + 1 : 0;   // WriteSsvcParaset (encoder_ext.cpp:3122-3136)
-    wh::SpsParams sp;
-    sp.sps_id = e->sps_id_in_bs; sp.level_idc = e->level_idc; sp.constraint_set3 = e->level_1b;
-    sp.width = e->prm.iPicWidth; sp.height = e->prm.iPicHeight; sp.mb_w = e->mb_w; sp.mb_h = e->mb_h;
-    sp.num_ref_frames = 1; sp.gaps_in_frame_num = false; sp.frame_cropping = e->prm.bEnableFrameCroppingFlag != 0;
-    std::vector<uint8_t> rbsp;
-    wh::write_sps_rbsp (rbsp, sp);
-    e->nal_len.push_back (wh::append_nal (e->bs, 3, 7, rbsp));
-    wh::PpsParams pp;
-    pp.pps_id = e->pps_id_in_bs; pp.sps_id = e->sps_id_in_bs;
-    rbsp.clear();
-    wh::write_pps_rbsp (rbsp, pp);
-    e->nal_len.push_back (wh::append_nal (e->bs, 3, 8, rbsp));
-    n_param_nals = 2;
-  }
-  const size_t vcl_start = e->bs.size();
-  std::vector<uint8_t> rbsp;
-  rbsp.reserve (1 << 16);
-  for (int si = 0; si < s.num_slices; ++si) {
-    rbsp.clear();
-    wh::BitWriter bw (&rbsp);
-    wh::SliceHeaderParams sh;
-    sh.first_mb = s.slice_first_mb[si];
-    sh.slice_type = idr ? 2 : 0;
-    sh.pps_id = e->pps_id_in_bs;
-    sh.frame_num = e->frame_num;
-    sh.idr = idr;
-    sh.idr_pic_id = e->idr_pic_id;
-    sh.nal_ref_idc = 3;
-    sh.slice_qp = qp;
-    sh.disable_deblocking_idc = s.deblock_idc;
-    sh.alpha_offset = s.alpha_offset; sh.beta_offset = s.beta_offset;
-    wh::write_slice_header (bw, sh);
-    wh::SliceEntropyState st;
-    st.slice_type = idr ? WH_SLICE_I : WH_SLICE_P;
-    st.last_qp = qp;
-    for (int xy = s.slice_first_mb[si]; xy < s.slice_first_mb[si + 1]; ++xy) {
-      const int mbx = xy % e->mb_w, mby = xy / e->mb_w;
-      int avail = 0;
-      if (mbx > 0 && xy - 1 >= s.slice_first_mb[si]) avail |= wh::WH_AVAIL_LEFT;
-      if (mby > 0 && xy - e->mb_w >= s.slice_first_mb[si]) avail |= wh::WH_AVAIL_TOP;
-      int dbqp = qp;
-      const int rc = wh::write_mb_cavlc (bw, st, e->h_records.data(), e->mb_w, mbx, mby, avail, &dbqp);
-      if (rc == -1) { set_err ("CAVLC level escape overflow (re-encode at higher QP not implemented)"); return WELSHIP_ERR_VLC_OVERFLOW; }
-      if (rc) { set_err ("bad macroblock record"); return WELSHIP_ERR_UNKNOWN; }
-    }
-    wh::write_slice_end (bw, st);
-    e->nal_len.push_back (wh::append_nal (e->bs, 3, idr ? 5 : 1, rbsp));
-  }
-
-  // ---- SFrameBSInfo ----
-  memset (out, 0, sizeof (*out));
-  int li = 0;
-  if (n_param_nals) {
-    WelsHipLayerBSInfo& L = out->sLayerInfo[li++];
-    L.uiLayerType = WELSHIP_NON_VIDEO_CODING_LAYER; L.eFrameType = WelsHipFrameTypeIDR;
-    L.iNalCount = n_param_nals; L.pNalLengthInByte = e->nal_len.data(); L.pBsBuf = e->bs.data();
-  }
-  WelsHipLayerBSInfo& V = out->sLayerInfo[li++];
-  V.uiLayerType = WELSHIP_VIDEO_CODING_LAYER; V.eFrameType = idr ? WelsHipFrameTypeIDR : WelsHipFrameTypeP;
-  V.iNalCount = s.num_slices; V.pNalLengthInByte = e->nal_len.data() + n_param_nals; V.pBsBuf = e->bs.data() + vcl_start;
-  out->iLayerNum = li;
-  out->eFrameType = idr ? WelsHipFrameTypeIDR : WelsHipFrameTypeP;
-  out->iFrameSizeInBytes = (int32_t)e->bs.size();
-  out->uiTimeStamp = src->uiTimeStamp;
-
-  // ---- advance ----
-  ++e->frame_index;
-  e->frame_num = (e->frame_num + 1) & 0x7fff;
-  e->cur ^= 1;
-  return WELSHIP_OK;
+  return c.finish_frame (out, src->uiTimeStamp);
 }
 
 int WelsHipGetReconFrame (WelsHipEncoder* e, uint8_t* dst, size_t bytes) {
-  if (!e || !e->inited || !e->have_recon || !dst) return WELSHIP_ERR_INIT_PARA;
-  const int w = e->prm.iPicWidth, h = e->prm.iPicHeight;
-  if (bytes < (size_t)w * h * 3 / 2) return WELSHIP_ERR_INIT_PARA;
-  const WhSeqParams& s = e->seq;
-  std::vector<uint8_t> tmp (e->rec_alloc_bytes);
-  const DevPicture& p = e->pic[e->cur ^ 1];     // the picture encoded last
-  e->be->download (tmp.data(), p.base, e->rec_alloc_bytes);
-  e->be->sync();
-  const uint8_t* y = tmp.data() + (p.plane[0] - p.base);
-  const uint8_t* u = tmp.data() + (p.plane[1] - p.base);
-  const uint8_t* v = tmp.data() + (p.plane[2] - p.base);
-  for (int r = 0; r < h; ++r) memcpy (dst + (size_t)r * w, y + (size_t)r * s.rec_stride_y, w);
-  uint8_t* du = dst + (size_t)w * h;
-  uint8_t* dv = du + (size_t) (w / 2) * (h / 2);
-  for (int r = 0; r < h / 2; ++r) {
-    memcpy (du + (size_t)r * (w / 2), u + (size_t)r * s.rec_stride_c, w / 2);
-    memcpy (dv + (size_t)r * (w / 2), v + (size_t)r * s.rec_stride_c, w / 2);
+  if (!e || !e->inited) return WELSHIP_ERR_INIT_PARA;
+  return e->core.copy_recon (dst, bytes);
+}
+
+// ---------------------------------------------------------------------------------- session group
+int WelsHipGroupCreate (WelsHipEncoderGroup** pp, const WelsHipEncParam* p, int n_sessions, int ring_slots, int host_threads) {
+  if (!pp || !p || n_sessions < 1 || n_sessions > 4096) return WELSHIP_ERR_INIT_PARA;
+  int rc = SessionCore::validate (p);
+  if (rc) return rc;
+  const char* berr = nullptr;
+  wh::Backend* be = wh::create_default_backend (p->iDevice, &berr);
+  if (!be) { set_err (std::string ("no usable device backend: ") + (berr ? berr : "?")); return WELSHIP_ERR_NO_DEVICE; }
+  WelsHipEncoderGroup* g = new WelsHipEncoderGroup();
+  g->be = be;
+  g->host_threads = host_threads < 1 ? 1 : host_threads;
+  for (int i = 0; i < n_sessions; ++i) {
+    g->sess.emplace_back (new SessionCore());
+    rc = g->sess.back()->init (be, p, ring_slots);
+    if (rc) { for (auto& s : g->sess) s->release(); delete be; delete g; return rc; }
   }
+  g->d_jobs = (WhPicJob*)be->alloc (sizeof (WhPicJob) * n_sessions);
+  g->h_jobs.resize (n_sessions);
+  *pp = g;
+  return WELSHIP_OK;
+}
+
+void WelsHipGroupDestroy (WelsHipEncoderGroup* g) {
+  if (!g) return;
+  g->be->sync();
+  for (auto& s : g->sess) s->release();
+  g->be->free (g->d_jobs);
+  delete g->be;
+  delete g;
+}
+
+int WelsHipGroupUploadSource (WelsHipEncoderGroup* g, int session, int slot, const WelsHipSourcePicture* src) {
+  if (!g || session < 0 || session >= (int)g->sess.size() || !src) return WELSHIP_ERR_INIT_PARA;
+  SessionCore& c = *g->sess[session];
+  if (slot < 0 || slot >= c.ring) return WELSHIP_ERR_INIT_PARA;
+  if (src->iPicWidth != c.prm.iPicWidth || src->iPicHeight != c.prm.iPicHeight) return WELSHIP_ERR_INIT_PARA;
+  c.upload_source (slot, src);
+  return WELSHIP_OK;
+}
+
+int WelsHipGroupBegin (WelsHipEncoderGroup* g, int slot) {
+  if (!g) return WELSHIP_ERR_INIT_PARA;
+  const int n = (int)g->sess.size();
+  for (int i = 0; i < n; ++i) g->sess[i]->begin_frame (slot % g->sess[i]->ring, &g->h_jobs[i]);
+  g->step_idr = g->sess[0]->cur_idr;
+  for (int i = 1; i < n; ++i) if (g->sess[i]->cur_idr != g->step_idr) { set_err ("sessions of a group must share the frame type"); return WELSHIP_ERR_UNKNOWN; }
+  g->be->upload (g->d_jobs, g->h_jobs.data(), sizeof (WhPicJob) * n);
+  return WELSHIP_OK;
+}
+
+int WelsHipGroupRunDevice (WelsHipEncoderGroup* g, int wait) {
+  if (!g) return WELSHIP_ERR_INIT_PARA;
+  SessionCore& c0 = *g->sess[0];
+  run_device_step (g->be, c0.seq, g->d_jobs, (int)g->sess.size(), g->step_idr, c0.prm.uiIntraPeriod != 1);
+  if (wait) g->be->sync();
+  return WELSHIP_OK;
+}
+
+int WelsHipGroupFinish (WelsHipEncoderGroup* g, WelsHipFrameBSInfo* outs) {
+  if (!g) return WELSHIP_ERR_INIT_PARA;
+  const int n = (int)g->sess.size();
+  for (int i = 0; i < n; ++i) {
+    SessionCore& c = *g->sess[i];
+    g->be->download (c.h_records.data(), c.d_records, sizeof (WhMbRecord) * c.num_mb);
+  }
+  g->be->sync();
+  std::vector<int> rcs (n, 0);
+  const int T = g->host_threads < n ? g->host_threads : n;
+  auto work = [&] (int t) { for (int i = t; i < n; i += T) rcs[i] = g->sess[i]->finish_frame (outs ? &outs[i] : nullptr, 0); };
+  if (T <= 1) work (0);
+  else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t) th.emplace_back (work, t);
+    for (auto& x : th) x.join();
+  }
+  for (int i = 0; i < n; ++i) if (rcs[i]) return rcs[i];
+  return WELSHIP_OK;
+}
+
+int WelsHipGroupEncodeFrames (WelsHipEncoderGroup* g, const WelsHipSourcePicture* srcs, WelsHipFrameBSInfo* outs) {
+  if (!g || !srcs) return WELSHIP_ERR_INIT_PARA;
+  const int n = (int)g->sess.size();
+  for (int i = 0; i < n; ++i) { int rc = WelsHipGroupUploadSource (g, i, 0, &srcs[i]); if (rc) return rc; }
+  int rc = WelsHipGroupBegin (g, 0);
+  if (rc) return rc;
+  WelsHipGroupRunDevice (g, 0);
+  return WelsHipGroupFinish (g, outs);
+}
+
+int WelsHipGroupGetReconFrame (WelsHipEncoderGroup* g, int session, uint8_t* dst, size_t bytes) {
+  if (!g || session < 0 || session >= (int)g->sess.size()) return WELSHIP_ERR_INIT_PARA;
+  return g->sess[session]->copy_recon (dst, bytes);
+}
+
+const char* WelsHipGroupBackendName (WelsHipEncoderGroup* g) { return g ? g->be->name() : "none"; }
+
+// Advance every session by one frame step on the device only (no D2H, no entropy coding): what the
+// hot-path benchmark times.  Stream state (frame type, reference swap) advances exactly as in Finish.
+int WelsHipGroupStepDeviceOnly (WelsHipEncoderGroup* g, int slot) {
+  int rc = WelsHipGroupBegin (g, slot);
+  if (rc) return rc;
+  WelsHipGroupRunDevice (g, 0);
+  for (auto& s : g->sess) {
+    s->pic[s->cur].is_p = !s->cur_idr; s->have_recon = true;
+    ++s->frame_index; s->frame_num = (s->frame_num + 1) & 0x7fff; s->cur ^= 1;
+  }
+  return WELSHIP_OK;
+}
+
+// Hot-path benchmark: `warmup` untimed + `steps` timed device-only frame steps, source slot cycling
+// ping-pong over the resident ring.  out_ms[0] = total (HIP events on the launch stream),
+// out_ms[1..3] = mode-decision / deblocking / border-expansion passes summed over the timed steps.
+int WelsHipGroupBench (WelsHipEncoderGroup* g, int steps, int warmup, double* out_ms) {
+  if (!g || steps < 1 || !out_ms) return WELSHIP_ERR_INIT_PARA;
+  wh::Backend* be = g->be;
+  const int ring = g->sess[0]->ring;
+  const int n = (int)g->sess.size();
+  auto slot_of = [&] (int i) { if (ring == 1) return 0; const int period = 2 * (ring - 1); const int k = i % period; return k < ring ? k : period - k; };
+  int fi = 0;
+  for (int i = 0; i < warmup; ++i) { int rc = WelsHipGroupStepDeviceOnly (g, slot_of (fi++)); if (rc) return rc; }
+  be->sync();
+  std::vector<void*> ev ((size_t)steps * 4 + 1);
+  for (auto& e : ev) e = be->event_create();
+  const WhSeqParams& s = g->sess[0]->seq;
+  const bool need_ref = g->sess[0]->prm.uiIntraPeriod != 1;
+  for (int i = 0; i < steps; ++i) {
+    int rc = WelsHipGroupBegin (g, slot_of (fi++));
+    if (rc) return rc;
+    be->event_record (ev[i * 4 + 0]);
+    if (g->step_idr) be->run_intra (s, g->d_jobs, n); else be->run_inter (s, g->d_jobs, n);
+    be->event_record (ev[i * 4 + 1]);
+    if (s.deblock_idc != 1) be->run_deblock (s, g->d_jobs, n);
+    be->event_record (ev[i * 4 + 2]);
+    if (need_ref) be->run_expand (s, g->d_jobs, n);
+    be->event_record (ev[i * 4 + 3]);
+    for (auto& c : g->sess) { c->pic[c->cur].is_p = !c->cur_idr; c->have_recon = true; ++c->frame_index; c->frame_num = (c->frame_num + 1) & 0x7fff; c->cur ^= 1; }
+  }
+  be->event_record (ev[(size_t)steps * 4]);
+  be->sync();
+  out_ms[0] = be->event_elapsed_ms (ev[0], ev[(size_t)steps * 4]);
+  out_ms[1] = out_ms[2] = out_ms[3] = 0.0;
+  for (int i = 0; i < steps; ++i) {
+    out_ms[1] += be->event_elapsed_ms (ev[i * 4 + 0], ev[i * 4 + 1]);
+    out_ms[2] += be->event_elapsed_ms (ev[i * 4 + 1], ev[i * 4 + 2]);
+    out_ms[3] += be->event_elapsed_ms (ev[i * 4 + 2], ev[i * 4 + 3]);
+  }
+  for (auto& e : ev) be->event_destroy (e);
   return WELSHIP_OK;
 }
 

@@ -8,6 +8,7 @@
 // without an MI355X.
 #include <stdlib.h>
 #include <string.h>
+#include <chrono>
 #include "../../openh264_amd/csrc/host/backend.h"
 #include "../../openh264_amd/csrc/kernels/frame_kernels.h"
 #include "../../openh264_amd/csrc/kernels/deblock_mb.h"
@@ -49,6 +50,10 @@ class EmuBackend : public Backend {
     }
   }
   void sync() override {}
+  void* event_create() override { return new double (0.0); }
+  void event_destroy (void* ev) override { delete (double*)ev; }
+  void event_record (void* ev) override { * (double*)ev = std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now().time_since_epoch()).count(); }
+  float event_elapsed_ms (void* a, void* b) override { return (float) (* (double*)b - * (double*)a); }
 };
 
 Backend* create_default_backend (int, const char**) { return new EmuBackend(); }
