@@ -83,6 +83,7 @@ typedef struct WhPicJob {
   const int8_t*  qp_delta;   // optional per-MB QP offsets (adaptive quant) or NULL
   int32_t        ref_is_p;   // reference picture was a P picture (co-located MV candidates)
   int32_t        pad;
+  const uint8_t* prev_src_y; // luma of the previous source picture (VAA 8x8 SADs, LOW complexity P pictures)
 } WhPicJob;
 
 #define WH_MAX_SLICES 36

@@ -46,6 +46,7 @@ struct SessionCore {
   std::vector<uint8_t*> d_src;        // [ring] Y | U | V, MB-aligned dims, tight strides
   DevPicture pic[2];
   int cur = 0;
+  int last_slot = 0;                  // source slot of the previous frame (VAA reference)
   WhMbRecord* d_records = nullptr;
   size_t rec_alloc_bytes = 0, src_bytes = 0, ysz = 0, csz = 0;
   std::vector<uint8_t> h_src;
@@ -122,11 +123,11 @@ struct SessionCore {
     rec_alloc_bytes = rec_y + 2 * rec_c;
     for (int i = 0; i < 2; ++i) {
       DevPicture& d = pic[i];
-      d.base = (uint8_t*)be->alloc (rec_alloc_bytes);
-      be->fill (d.base, 0, rec_alloc_bytes);
-      d.plane[0] = d.base + (size_t)32 * s.rec_stride_y + 32;
-      d.plane[1] = d.base + rec_y + (size_t)16 * s.rec_stride_c + 16;
-      d.plane[2] = d.base + rec_y + rec_c + (size_t)16 * s.rec_stride_c + 16;
+      d.base = (uint8_t*)be->alloc (rec_alloc_bytes + 128);     // 64 guard bytes either side (aligned window loads)
+      be->fill (d.base, 0, rec_alloc_bytes + 128);
+      d.plane[0] = d.base + 64 + (size_t)32 * s.rec_stride_y + 32;
+      d.plane[1] = d.base + 64 + rec_y + (size_t)16 * s.rec_stride_c + 16;
+      d.plane[2] = d.base + 64 + rec_y + rec_c + (size_t)16 * s.rec_stride_c + 16;
       d.mbs = (WhMbState*)be->alloc (sizeof (WhMbState) * num_mb);
       be->fill (d.mbs, 0, sizeof (WhMbState) * num_mb);
     }
@@ -183,6 +184,8 @@ struct SessionCore {
     job->slice_type = idr ? WH_SLICE_I : WH_SLICE_P;
     job->qp_delta = nullptr;
     job->ref_is_p = r.is_p ? 1 : 0;
+    job->prev_src_y = d_src[last_slot];
+    last_slot = slot;
   }
 
   // Entropy-code the downloaded records into `bs` and advance the stream state.
@@ -231,6 +234,7 @@ struct SessionCore {
       sh.slice_qp = qp;
       sh.disable_deblocking_idc = s.deblock_idc;
       sh.alpha_offset = s.alpha_offset; sh.beta_offset = s.beta_offset;
+      sh.num_ref_idx_override = !idr; sh.num_ref_idx_active = 1;
       wh::write_slice_header (bw, sh);
       wh::SliceEntropyState st;
       st.slice_type = idr ? WH_SLICE_I : WH_SLICE_P;
@@ -275,9 +279,9 @@ struct SessionCore {
     const int w = prm.iPicWidth, h = prm.iPicHeight;
     if (bytes < (size_t)w * h * 3 / 2) return WELSHIP_ERR_INIT_PARA;
     const WhSeqParams& s = seq;
-    std::vector<uint8_t> tmp (rec_alloc_bytes);
+    std::vector<uint8_t> tmp (rec_alloc_bytes + 128);
     const DevPicture& p = pic[cur ^ 1];     // the picture encoded last
-    be->download (tmp.data(), p.base, rec_alloc_bytes);
+    be->download (tmp.data(), p.base, rec_alloc_bytes + 128);
     be->sync();
     const uint8_t* y = tmp.data() + (p.plane[0] - p.base);
     const uint8_t* u = tmp.data() + (p.plane[1] - p.base);
@@ -371,7 +375,7 @@ int WelsHipInitializeExt (WelsHipEncoder* e, const WelsHipEncParam* p) {
   e->be = wh::create_default_backend (p->iDevice, &berr);
   if (!e->be) { set_err (std::string ("no usable device backend: ") + (berr ? berr : "?")); return WELSHIP_ERR_NO_DEVICE; }
   e->core = SessionCore();
-  rc = e->core.init (e->be, p, 1);
+  rc = e->core.init (e->be, p, 2);
   if (rc) { e->core.release(); delete e->be; e->be = nullptr; return rc; }
   e->d_job = (WhPicJob*)e->be->alloc (sizeof (WhPicJob));
   e->inited = true;
@@ -392,9 +396,10 @@ int WelsHipEncodeFrame (WelsHipEncoder* e, const WelsHipSourcePicture* src, Wels
   SessionCore& c = e->core;
   if (src->iColorFormat != 23) { set_err ("only videoFormatI420 input"); return WELSHIP_ERR_UNSUPPORTED; }
   if (src->iPicWidth != c.prm.iPicWidth || src->iPicHeight != c.prm.iPicHeight) { set_err ("source size differs from the initialised size"); return WELSHIP_ERR_INIT_PARA; }
-  c.upload_source (0, src);
+  const int slot = c.last_slot ^ 1;
+  c.upload_source (slot, src);
   WhPicJob job;
-  c.begin_frame (0, &job);
+  c.begin_frame (slot, &job);
   e->be->upload (e->d_job, &job, sizeof (job));
   run_device_step (e->be, c.seq, e->d_job, 1, c.cur_idr, c.prm.uiIntraPeriod != 1);
   e->be->download (c.h_records.data(), c.d_records, sizeof (WhMbRecord) * c.num_mb);

@@ -165,8 +165,10 @@ typedef struct WhIntraResult {
   int mb_type, cbp, i16_mode_std, chroma_mode_std, cost_luma, cost_chroma;
 } WhIntraResult;
 
-WH_FN void wh_intra_md_enc (WhMbLds& S, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, int avail, int qp, int qpc,
-                            WhIntraResult* o) {
+// `inter_cost`: in P slices the I16x16 cost must beat the best inter cost so far, otherwise nothing is
+// encoded and false is returned (WelsMdFirstIntraMode); I slices pass INT_MAX.
+WH_FN bool wh_intra_md_enc_p (WhMbLds& S, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, int avail, int qp, int qpc,
+                              int inter_cost, WhIntraResult* o) {
   const int lambda = kWhLambda[qp];
   const int use_satd = P.complexity > 0;
   const int av3 = avail & 7;
@@ -199,6 +201,7 @@ WH_FN void wh_intra_md_enc (WhMbLds& S, const WhSeqParams& P, const WhPicJob& J,
     const int c = wh_cost_luma16 (S, use_satd) + lambda * bits;
     if (c < best_cost) { best_cost = c; best_mode = m; }
   }
+  if (!(best_cost < inter_cost)) return false;
   int cost_luma = best_cost;
   int mb_type = WH_MB_I16x16;
 
@@ -431,5 +434,10 @@ WH_FN void wh_intra_md_enc (WhMbLds& S, const WhSeqParams& P, const WhPicJob& J,
   o->chroma_mode_std = (cbest <= 3) ? cbest : 0;
   o->cost_luma = cost_luma;
   o->cost_chroma = cbest_cost;
-  (void)J; (void)mbx; (void)mby;
+  (void)mbx; (void)mby;
+  return true;
+}
+WH_FN void wh_intra_md_enc (WhMbLds& S, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, int avail, int qp, int qpc,
+                            WhIntraResult* o) {
+  (void)wh_intra_md_enc_p (S, P, J, mbx, mby, avail, qp, qpc, 0x7fffffff, o);
 }
