@@ -81,20 +81,16 @@ struct SessionCore {
 
   int compute_slices() {
     WhSeqParams& s = seq;
-    const int n = prm.uiSliceMode == 0 ? 1 : prm.uiSliceNum;
-    if (n < 1 || n > WH_MAX_SLICES) return -1;
+    int n = prm.uiSliceMode == 0 ? 1 : prm.uiSliceNum;
+    if (n < 1) return -1;
+    // SliceArgumentValidationFixedSliceMode (encoder_ext.cpp:178-255): small pictures fall back to one slice,
+    // the slice count is capped, and with RC off every slice gets num_mb / n macroblocks (NOT row aligned),
+    // the last one the remainder (CheckFixedSliceNumMultiSliceSetting, svc_enc_slice_segment.cpp:125-150).
+    if (n <= 1 || num_mb <= 48) n = 1;
+    if (n > 35) n = 35;
+    if (n > 1 && num_mb / n <= 0) n = 1;
     s.num_slices = n;
-    if (n == 1) { s.slice_first_mb[0] = 0; s.slice_first_mb[1] = num_mb; return 0; }
-    // SM_FIXEDSLCNUM_SLICE: whole MB rows per slice (svc_enc_slice_segment.cpp GomValidCheckSliceMbNum /
-    // AssignMbMapMultipleSlices for pictures of at least one row per slice)
-    if (n > mb_h) return -1;
-    int first = 0;
-    for (int i = 0; i < n; ++i) {
-      s.slice_first_mb[i] = first;
-      int r = mb_h / n;
-      if (i == n - 1) r = mb_h - (mb_h / n) * (n - 1);
-      first += r * mb_w;
-    }
+    for (int i = 0; i < n; ++i) s.slice_first_mb[i] = i * (num_mb / n);
     s.slice_first_mb[n] = num_mb;
     return 0;
   }

@@ -11,11 +11,13 @@ inline int blk_raster (int b) { return (((b >> 1) & 1) | ((b >> 2) & 2)) * 4 + (
 
 // residual_block_cavlc (7.3.5.3.2 / 9.2).  lv[0..end_idx] zig-zag levels; nc: 0..16, or 17 for ChromaDCLevel.
 // Returns -1 when a level needs an escape longer than Baseline allows (set_mb_syn_cavlc.cpp:181-184).
-int write_block (BitWriter& bw, const int16_t* lv, int end_idx, int nc) {
+int write_block (BitWriter& bw, const int16_t* lv, int end_idx, int nc, bool has_coeff = true) {
+  // has_coeff mirrors iCalRunLevelFlag: a block whose total_coeff (nzc) is 0 is written as empty without looking at
+  // its level buffer, which may be stale after the encoder's zeroing heuristics (svc_encode_mb.cpp:283-287)
   int16_t level[16];
   uint8_t run[16];
   int total = 0, total_zeros = 0;
-  int i = end_idx;
+  int i = has_coeff ? end_idx : -1;
   while (i >= 0 && lv[i] == 0) --i;
   while (i >= 0) {
     int zeros = 0;
@@ -94,14 +96,14 @@ int write_residual (BitWriter& bw, const WhMbRecord& r, const NzcCtx& n) {
     if (cbp_l) {
       for (int b = 0; b < 16; ++b) {
         const int rr = blk_raster (b);
-        if (write_block (bw, r.luma[b], 14, nc_of (n.luma_a (rr), n.luma_b (rr)))) return -1;
+        if (write_block (bw, r.luma[b], 14, nc_of (n.luma_a (rr), n.luma_b (rr)), r.nzc[rr] > 0)) return -1;
       }
     }
   } else {
     for (int b = 0; b < 16; ++b) {
       if (!(cbp_l & (1 << (b >> 2)))) continue;
       const int rr = blk_raster (b);
-      if (write_block (bw, r.luma[b], 15, nc_of (n.luma_a (rr), n.luma_b (rr)))) return -1;
+      if (write_block (bw, r.luma[b], 15, nc_of (n.luma_a (rr), n.luma_b (rr)), r.nzc[rr] > 0)) return -1;
     }
   }
   if (cbp_c) {
@@ -110,7 +112,7 @@ int write_residual (BitWriter& bw, const WhMbRecord& r, const NzcCtx& n) {
     if (cbp_c & 2) {
       for (int p = 0; p < 2; ++p)
         for (int c = 0; c < 4; ++c)
-          if (write_block (bw, r.chroma_ac[p * 4 + c], 14, nc_of (n.chroma_a (p, c), n.chroma_b (p, c)))) return -1;
+          if (write_block (bw, r.chroma_ac[p * 4 + c], 14, nc_of (n.chroma_a (p, c), n.chroma_b (p, c)), r.nzc[16 + p * 4 + c] > 0)) return -1;
     }
   }
   return 0;
