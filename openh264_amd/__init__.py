@@ -21,6 +21,7 @@ RC_OFF_MODE = -1
 (videoFrameTypeInvalid, videoFrameTypeIDR, videoFrameTypeI, videoFrameTypeP, videoFrameTypeSkip) = range(5)
 cmResultSuccess, cmInitParaError, cmUnknownReason, cmUnsupportedData = 0, 1, 2, 4
 ERR_NO_DEVICE, ERR_VLC_OVERFLOW = 100, 101
+HAS_INTER_PATH = True
 
 
 class SEncParamExt(C.Structure):

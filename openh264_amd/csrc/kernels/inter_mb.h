@@ -558,7 +558,8 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, const WhSeqParams& P, const WhPicJob
       if (ok) {
         b_skip = true;
         cost_luma = md_using_sad ? sad_l : wh_satd_tile (S, 0, 0, 16, 16, S.skip_y, 16);
-        if (md_using_sad) sad_cost0 = sad_l;
+        // pSadCost[0] is only refreshed when bMdUsingSad; otherwise the SMB entry keeps the previous frame's value
+        sad_cost0 = md_using_sad ? sad_l : J.ref_mbs[xy].sad_cost[0];
         cost_skip_mb = sad_mb;
         p16x = skx; p16y = sky;
       }

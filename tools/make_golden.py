@@ -27,6 +27,15 @@ CASES = {
     "i_1280x720_qp24": (1280, 720, 2, ["-iper", "1", "-qp", "24"], dict(uiIntraPeriod=1, iDLayerQp=24)),
     "i_1920x1080_qp24": (1920, 1080, 1, ["-iper", "1", "-qp", "24"], dict(uiIntraPeriod=1, iDLayerQp=24)),
     "i_640x368_qp24_constid": (640, 368, 3, ["-iper", "1", "-qp", "24", "-spsid", "0"], dict(uiIntraPeriod=1, iDLayerQp=24, eSpsPpsIdStrategy=0)),
+    # P pictures (IDR + P...), diamond ME + fractional refinement + skip/intra/inter decisions
+    "p_176x144_qp24": (176, 144, 8, ["-iper", "0", "-qp", "24"], dict(uiIntraPeriod=0, iDLayerQp=24)),
+    "p_320x192_qp28_c1": (320, 192, 6, ["-iper", "0", "-qp", "28", "-complexity", "1"], dict(uiIntraPeriod=0, iDLayerQp=28, iComplexityMode=1)),
+    "p_320x192_qp20_c2_iper4": (320, 192, 9, ["-iper", "4", "-qp", "20", "-complexity", "2"], dict(uiIntraPeriod=4, iDLayerQp=20, iComplexityMode=2)),
+    "p_640x368_qp24_4slices": (640, 368, 5, ["-iper", "0", "-qp", "24", "-slcmd", "1", "-slcnum", "4"], dict(uiIntraPeriod=0, iDLayerQp=24, uiSliceMode=1, uiSliceNum=4)),
+    "p_640x368_qp32_3slices_idc2": (640, 368, 4, ["-iper", "0", "-qp", "32", "-slcmd", "1", "-slcnum", "3", "-deblock", "2"], dict(uiIntraPeriod=0, iDLayerQp=32, uiSliceMode=1, uiSliceNum=3, iLoopFilterDisableIdc=2)),
+    "p_152x100_qp24_crop": (152, 100, 6, ["-iper", "0", "-qp", "24"], dict(uiIntraPeriod=0, iDLayerQp=24)),
+    "p_1280x720_qp24": (1280, 720, 3, ["-iper", "0", "-qp", "24"], dict(uiIntraPeriod=0, iDLayerQp=24)),
+    "p_1920x1080_qp24_4slices": (1920, 1080, 3, ["-iper", "0", "-qp", "24", "-slcmd", "1", "-slcnum", "4"], dict(uiIntraPeriod=0, iDLayerQp=24, uiSliceMode=1, uiSliceNum=4)),
 }
 COMMON = ["-rc", "-1", "-fps", "30", "-quiet"]
 
