@@ -145,6 +145,43 @@ const char* WelsHipGroupBackendName (WelsHipEncoderGroup* pGroup);
 /* hot-path timing with HIP events on the launch stream; pOutMs[4] = total, MD, deblock, expand */
 int  WelsHipGroupBench (WelsHipEncoderGroup* pGroup, int iSteps, int iWarmup, double* pOutMs);
 
+/* ---- (3) leaf primitives, batched.  One call = n independent invocations of the reference entry
+ * named in the comment.  p*Plane are HOST buffers of `bytes` bytes; block i starts at
+ * plane + pOff[i] with the given stride (exactly the (pointer, stride) pairs the reference passes).
+ * iBlock: BLOCK_16x16..BLOCK_4x8 = 0..6 (codec/encoder/core/inc/wels_const.h:139-148). -------- */
+/* pfSampleSad[iBlock] / pfSampleSatd[iBlock] / pfSample4Sad[iBlock] (wels_func_ptr_def.h:162-177) */
+int WelsHipPrimSampleSad (int iBlock, int n, const uint8_t* pPlane1, size_t bytes1, int32_t iStride1, const int32_t* pOff1,
+                          const uint8_t* pPlane2, size_t bytes2, int32_t iStride2, const int32_t* pOff2, int32_t* pSad);
+int WelsHipPrimSampleSatd (int iBlock, int n, const uint8_t* pPlane1, size_t bytes1, int32_t iStride1, const int32_t* pOff1,
+                           const uint8_t* pPlane2, size_t bytes2, int32_t iStride2, const int32_t* pOff2, int32_t* pSatd);
+int WelsHipPrimSample4Sad (int iBlock, int n, const uint8_t* pPlane1, size_t bytes1, int32_t iStride1, const int32_t* pOff1,
+                           const uint8_t* pPlane2, size_t bytes2, int32_t iStride2, const int32_t* pOff2, int32_t* pSad4 /*[n][4] up,down,left,right*/);
+/* pfDctT4 (PDctFunc): pDct[n][16] = T(pix1 - pix2) */
+int WelsHipPrimDctT4 (int n, const uint8_t* pPlane1, size_t bytes1, int32_t iStride1, const int32_t* pOff1,
+                      const uint8_t* pPlane2, size_t bytes2, int32_t iStride2, const int32_t* pOff2, int16_t* pDct);
+/* pfQuantizationFour4x4Max (per 4x4) + pfScan4x4 + pfScan4x4Ac + pfCalculateSingleCtr4x4 + pfGetNoneZeroCount */
+int WelsHipPrimQuant4x4 (int n, int16_t* pDctInOut /*[n][16]*/, const uint8_t* pQp, int bIntra, int16_t* pMax, int16_t* pScanDcAc,
+                         int16_t* pScanAc, int32_t* pSingleCtr, int32_t* pNzc);
+/* pfDequantization4x4 + pfIDctT4: pRec[n][16] = clip(pPred + idct(levels * dequant)) */
+int WelsHipPrimDequantIDctRec (int n, const int16_t* pLevelsRaster, const uint8_t* pQp, const uint8_t* pPred, uint8_t* pRec, int16_t* pDequant);
+/* pfGetLumaI4x4Pred: pMode = Intra4x4PredMode 0..8, pAvail bit0 left / bit1 top selects the DC flavour */
+int WelsHipPrimIntraPred4x4 (int n, const uint8_t* pPlane, size_t bytes, int32_t iStride, const int32_t* pOff, const uint8_t* pMode,
+                             const uint8_t* pAvail, uint8_t* pPred /*[n][16]*/);
+/* pfGetLumaI16x16Pred[pMode16] + pfGetChromaPred[pModeChroma] (reference mode numbering incl. DC_L/DC_T/DC_128);
+ * Cr samples are read 16 columns to the right of the Cb block in pPlaneC */
+int WelsHipPrimIntraPredMb (int n, const uint8_t* pPlaneY, size_t bytesY, int32_t iStrideY, const int32_t* pOffY,
+                            const uint8_t* pPlaneC, size_t bytesC, int32_t iStrideC, const int32_t* pOffC,
+                            const uint8_t* pMode16, const uint8_t* pModeChroma, uint8_t* pPred16 /*[n][256]*/, uint8_t* pPredChroma /*[n][128]*/);
+/* sMcFuncs.pMcLumaFunc / pMcChromaFunc: pOff addresses the integer sample position, pMv[n][2] supplies the fraction */
+int WelsHipPrimMc (int n, const uint8_t* pPlane, size_t bytes, int32_t iStride, const int32_t* pOff, const int16_t* pMv, int iWidth,
+                   int iHeight, int bChroma, uint8_t* pDst /*[n][h][w]*/);
+/* pfLumaDeblocking{LT4,EQ4}{Ver,Hor} / pfChromaDeblocking*: edges at plane + pOff[e] (first q0 sample), bS per 4 (luma) or
+ * 2 (chroma) lines in pBs4[e][4], alpha/beta/tc0 looked up at pIndexA[e] (slice offsets 0) */
+int WelsHipPrimDeblockEdges (int nEdges, uint8_t* pPlaneInOut, size_t bytes, int32_t iStride, const int32_t* pOff, int bVerticalEdge,
+                             int bChroma, const uint8_t* pBs4, const uint8_t* pIndexA);
+/* VAACalcSad_c of codec/processing (per macroblock): four 8x8 SADs against the previous source picture */
+int WelsHipPrimVaaSad8x8 (int nMb, const uint8_t* pCur, const uint8_t* pRef, size_t bytes, int32_t iStride, const int32_t* pOff, int32_t* pSad8x8);
+
 #ifdef __cplusplus
 }
 #endif

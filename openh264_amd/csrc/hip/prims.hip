@@ -1,0 +1,261 @@
+// prims.hip -- layer (3) of the C ABI: the leaf primitives of SWelsFuncPtrList / SMcFunc, batched over
+// arrays of blocks.  Same per-block semantics as the reference's function-pointer entries
+// (codec/encoder/core/inc/wels_func_ptr_def.h:58-296, codec/common/inc/mc.h:40-53); each kernel calls
+// the very device functions the fused macroblock kernels use (kernels/prims.h, intra_mb.h, inter_mb.h,
+// deblock_mb.h), so the parity tests of this layer pin the arithmetic of the hot path itself.
+// Buffers are HOST pointers; the library stages them through HBM (this layer exists for parity
+// testing and integration bring-up -- throughput comes from the frame-level kernels).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <vector>
+#include "../../../include/welship.h"
+#include "../kernels/frame_kernels.h"
+#include "../kernels/inter_mb.h"
+#include "../kernels/deblock_mb.h"
+
+namespace {
+
+struct Dev {          // RAII device copy of a host array
+  void* p = nullptr; size_t n = 0;
+  Dev (const void* h, size_t bytes) : n (bytes) { if (hipMalloc (&p, bytes ? bytes : 1) != hipSuccess) p = nullptr; else if (h && bytes) (void)hipMemcpy (p, h, bytes, hipMemcpyHostToDevice); }
+  ~Dev() { if (p) (void)hipFree (p); }
+  template <class T> T* as() const { return (T*)p; }
+  void back (void* h) const { (void)hipMemcpy (h, p, n, hipMemcpyDeviceToHost); }
+};
+bool have_gpu() { int c = 0; return hipGetDeviceCount (&c) == hipSuccess && c > 0; }
+#define NEED_GPU() do { if (!have_gpu()) return WELSHIP_ERR_NO_DEVICE; } while (0)
+inline int grid (int n) { return (n + 255) / 256; }
+
+__device__ const int kBw[7] = {16, 16, 8, 8, 4, 8, 4};
+__device__ const int kBh[7] = {16, 8, 16, 8, 4, 4, 8};
+
+__device__ int dev_sad (int blk, const uint8_t* a, int sa, const uint8_t* b, int sb) {
+  int s = 0;
+  for (int y = 0; y < kBh[blk]; ++y) for (int x = 0; x < kBw[blk]; ++x) s += wh_abs (a[y * sa + x] - b[y * sb + x]);
+  return s;
+}
+__device__ int dev_satd4 (const uint8_t* a, int sa, const uint8_t* b, int sb) {
+  int m[16], s = 0;
+  for (int y = 0; y < 4; ++y) wh_had4 (a[y * sa] - b[y * sb], a[y * sa + 1] - b[y * sb + 1], a[y * sa + 2] - b[y * sb + 2], a[y * sa + 3] - b[y * sb + 3], &m[y * 4], &m[y * 4 + 1], &m[y * 4 + 2], &m[y * 4 + 3]);
+  for (int x = 0; x < 4; ++x) { int o0, o1, o2, o3; wh_had4 (m[x], m[4 + x], m[8 + x], m[12 + x], &o0, &o1, &o2, &o3); s += wh_abs (o0) + wh_abs (o1) + wh_abs (o2) + wh_abs (o3); }
+  return (s + 1) >> 1;
+}
+__global__ void k_sad (int blk, int n, const uint8_t* p1, int s1, const int* o1, const uint8_t* p2, int s2, const int* o2, int* out, int mode) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t* a = p1 + o1[i];
+  const uint8_t* b = p2 + o2[i];
+  if (mode == 0) out[i] = dev_sad (blk, a, s1, b, s2);
+  else if (mode == 1) { int s = 0; for (int y = 0; y < kBh[blk]; y += 4) for (int x = 0; x < kBw[blk]; x += 4) s += dev_satd4 (a + y * s1 + x, s1, b + y * s2 + x, s2); out[i] = s; }
+  else { out[i * 4] = dev_sad (blk, a, s1, b - s2, s2); out[i * 4 + 1] = dev_sad (blk, a, s1, b + s2, s2); out[i * 4 + 2] = dev_sad (blk, a, s1, b - 1, s2); out[i * 4 + 3] = dev_sad (blk, a, s1, b + 1, s2); }
+}
+
+__global__ void k_dct (int n, const uint8_t* p1, int s1, const int* o1, const uint8_t* p2, int s2, const int* o2, int16_t* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t* a = p1 + o1[i];
+  const uint8_t* b = p2 + o2[i];
+  int16_t t[16];
+  for (int y = 0; y < 4; ++y) wh_fdct4 (a[y * s1] - b[y * s2], a[y * s1 + 1] - b[y * s2 + 1], a[y * s1 + 2] - b[y * s2 + 2], a[y * s1 + 3] - b[y * s2 + 3], &t[y * 4], &t[y * 4 + 1], &t[y * 4 + 2], &t[y * 4 + 3]);
+  int16_t* d = out + i * 16;
+  for (int x = 0; x < 4; ++x) wh_fdct4 (t[x], t[4 + x], t[8 + x], t[12 + x], &d[x], &d[4 + x], &d[8 + x], &d[12 + x]);
+}
+// quant (mode 0: pfQuantization4x4, 1: ...Four4x4Max per block), then scan / score / count on the result
+__global__ void k_quant (int n, int16_t* io, const uint8_t* qp, int intra, int16_t* maxv, int16_t* zz, int16_t* zz_ac, int* ctr, int* nzc) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int16_t* d = io + i * 16;
+  const int q = qp[i];
+  int16_t mx = 0;
+  for (int k = 0; k < 16; ++k) { int16_t a; d[k] = wh_quant1_abs (d[k], kWhQuantFF[(q + (intra ? 6 : 0)) * 3 + WH_POSCLASS (k)], wh_mf (q, k), &a); if (mx < a) mx = a; }
+  maxv[i] = mx;
+  int16_t lv[16];
+  int cnt = 0;
+  for (int k = 0; k < 16; ++k) { lv[k] = d[wh_zigzag (k)]; zz[i * 16 + k] = lv[k]; zz_ac[i * 16 + k] = k < 15 ? d[wh_zigzag (k + 1)] : (int16_t)0; cnt += lv[k] != 0; }
+  ctr[i] = wh_single_ctr (lv);
+  nzc[i] = cnt;
+}
+__global__ void k_dequant_idct (int n, const int16_t* coef, const uint8_t* qp, const uint8_t* pred, uint8_t* rec, int16_t* deq) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int16_t c[16], t[16];
+  for (int k = 0; k < 16; ++k) { c[k] = (int16_t) (coef[i * 16 + k] * wh_dq (qp[i], k)); deq[i * 16 + k] = c[k]; }
+  for (int y = 0; y < 4; ++y) wh_idct4_h (c[y * 4], c[y * 4 + 1], c[y * 4 + 2], c[y * 4 + 3], &t[y * 4], &t[y * 4 + 1], &t[y * 4 + 2], &t[y * 4 + 3]);
+  for (int x = 0; x < 4; ++x) {
+    int r0, r1, r2, r3;
+    wh_idct4_v (t[x], t[4 + x], t[8 + x], t[12 + x], &r0, &r1, &r2, &r3);
+    const uint8_t* p = pred + i * 16;
+    uint8_t* o = rec + i * 16;
+    o[x] = wh_clip255 (p[x] + r0); o[4 + x] = wh_clip255 (p[4 + x] + r1); o[8 + x] = wh_clip255 (p[8 + x] + r2); o[12 + x] = wh_clip255 (p[12 + x] + r3);
+  }
+}
+// Intra4x4: standard modes 0..8 plus the DC flavours selected by `avail` (bit0 left, bit1 top)
+__global__ void k_pred4 (int n, const uint8_t* plane, int st, const int* off, const uint8_t* mode, const uint8_t* avail, uint8_t* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t* ref = plane + off[i];
+  uint8_t E[13];
+  for (int k = 0; k < 4; ++k) E[3 - k] = ref[k * st - 1];
+  E[4] = ref[-st - 1];
+  for (int k = 0; k < 8; ++k) E[5 + k] = ref[-st + k];
+  const bool l = avail[i] & 1, t = avail[i] & 2;
+  int dc = 128;
+  if (l && t) dc = (E[0] + E[1] + E[2] + E[3] + E[5] + E[6] + E[7] + E[8] + 4) >> 3;
+  else if (l) dc = (E[0] + E[1] + E[2] + E[3] + 2) >> 2;
+  else if (t) dc = (E[5] + E[6] + E[7] + E[8] + 2) >> 2;
+  for (int y = 0; y < 4; ++y) for (int x = 0; x < 4; ++x) out[i * 16 + y * 4 + x] = (uint8_t)wh_pred4_px (mode[i], x, y, E, dc);
+}
+// Intra16x16 / chroma 8x8 predictors through the macroblock tile code path (one wave per block)
+__global__ __launch_bounds__ (64) void k_pred_mb (const uint8_t* plane_y, int st_y, const int* off_y, const uint8_t* plane_c, int st_c, const int* off_c,
+                                                const uint8_t* mode16, const uint8_t* modec, uint8_t* out16, uint8_t* outc) {
+  __shared__ WhMbLds S;
+  const int i = blockIdx.x;
+  const uint8_t* ry = plane_y + off_y[i];
+  const uint8_t* rc = plane_c + off_c[i];          // Cb; Cr taken from the same plane 16 columns to the right
+  WV_LANES_BEGIN (lane)
+  if (lane < 17) WH_RY (S, lane - 1, -1) = ry[-st_y + lane - 1];
+  else if (lane < 33) WH_RY (S, -1, lane - 17) = ry[(lane - 17) * st_y - 1];
+  else if (lane < 42) { WH_RC (S, 0, lane - 34, -1) = rc[-st_c + lane - 34]; WH_RC (S, 1, lane - 34, -1) = rc[-st_c + 16 + lane - 34]; }
+  else if (lane < 50) { WH_RC (S, 0, -1, lane - 42) = rc[(lane - 42) * st_c - 1]; WH_RC (S, 1, -1, lane - 42) = rc[(lane - 42) * st_c + 16 - 1]; }
+  WV_LANES_END
+  int sum_t, sum_l, h, v;
+  WV_SUM (sum_t, lane, (lane < 16 ? WH_RY (S, lane, -1) : 0));
+  WV_SUM (sum_l, lane, (lane < 16 ? WH_RY (S, -1, lane) : 0));
+  WV_SUM (h, lane, (lane < 8 ? (lane + 1) * (WH_RY (S, 8 + lane, -1) - WH_RY (S, 6 - lane, -1)) : 0));
+  WV_SUM (v, lane, (lane < 8 ? (lane + 1) * (WH_RY (S, -1, 8 + lane) - WH_RY (S, -1, 6 - lane)) : 0));
+  const int a = (WH_RY (S, -1, 15) + WH_RY (S, 15, -1)) << 4, b = (5 * h + 32) >> 6, c = (5 * v + 32) >> 6;
+  wh_pred_i16 (S, mode16[i], sum_t, sum_l, b, c, a);
+  int st[4], sl[4], pa[2], pb[2], pc[2];
+  for (int pl = 0; pl < 2; ++pl) {
+    WV_SUM (st[pl * 2], lane, (lane < 4 ? WH_RC (S, pl, lane, -1) : 0));
+    WV_SUM (st[pl * 2 + 1], lane, (lane < 4 ? WH_RC (S, pl, 4 + lane, -1) : 0));
+    WV_SUM (sl[pl * 2], lane, (lane < 4 ? WH_RC (S, pl, -1, lane) : 0));
+    WV_SUM (sl[pl * 2 + 1], lane, (lane < 4 ? WH_RC (S, pl, -1, 4 + lane) : 0));
+    int hh, vv;
+    WV_SUM (hh, lane, (lane < 4 ? (lane + 1) * (WH_RC (S, pl, 4 + lane, -1) - WH_RC (S, pl, 2 - lane, -1)) : 0));
+    WV_SUM (vv, lane, (lane < 4 ? (lane + 1) * (WH_RC (S, pl, -1, 4 + lane) - WH_RC (S, pl, -1, 2 - lane)) : 0));
+    pa[pl] = (WH_RC (S, pl, -1, 7) + WH_RC (S, pl, 7, -1)) << 4; pb[pl] = (17 * hh + 16) >> 5; pc[pl] = (17 * vv + 16) >> 5;
+  }
+  wh_pred_chroma (S, modec[i], st, sl, pb, pc, pa);
+  WV_LANES_BEGIN (lane)
+  for (int k = 0; k < 4; ++k) out16[i * 256 + lane * 4 + k] = S.pred_y[lane * 4 + k];
+  for (int k = 0; k < 2; ++k) outc[i * 128 + lane * 2 + k] = S.pred_c[lane * 2 + k];
+  WV_LANES_END
+}
+__global__ void k_mc (int n, const uint8_t* plane, int st, const int* off, const int16_t* mv, int w, int h, int chroma, uint8_t* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t* src = plane + off[i];
+  const int mvx = mv[i * 2], mvy = mv[i * 2 + 1];
+  for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x)
+    out[(size_t)i * w * h + y * w + x] = chroma ? (uint8_t)wh_mc_chroma_px (src + y * st + x, st, mvx & 7, mvy & 7) : (uint8_t)wh_mc_luma_px (src + y * st + x, st, mvx & 3, mvy & 3);
+}
+// edge filters: one thread per line; bs per line (0..4), filter parameters from the edge QP index
+__global__ void k_deblock (int n_edges, uint8_t* plane, int st, const int* off, int horizontal, int chroma, const uint8_t* bs, const uint8_t* qp_index) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lines = chroma ? 8 : 16;
+  if (i >= n_edges * lines) return;
+  const int e = i / lines, l = i % lines;
+  uint8_t* q = plane + off[e] + (horizontal ? l * st : l);
+  const int ia = qp_index[e];
+  const int b = bs[e * 4 + (chroma ? l >> 1 : l >> 2)];
+  if (!(kWhAlpha[ia] | kWhBeta[ia])) return;
+  if (chroma) wh_db_chroma_line (q, horizontal ? 1 : st, b, kWhAlpha[ia], kWhBeta[ia], ia);
+  else wh_db_luma_line (q, horizontal ? 1 : st, b, kWhAlpha[ia], kWhBeta[ia], ia);
+}
+__global__ void k_vaa (int n, const uint8_t* cur, const uint8_t* ref, int st, const int* off, int* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * 4) return;
+  const int m = i >> 2, k = i & 3;
+  const uint8_t* c = cur + off[m] + (k >> 1) * 8 * st + (k & 1) * 8;
+  const uint8_t* r = ref + off[m] + (k >> 1) * 8 * st + (k & 1) * 8;
+  int s = 0;
+  for (int y = 0; y < 8; ++y) for (int x = 0; x < 8; ++x) s += wh_abs (c[y * st + x] - r[y * st + x]);
+  out[i] = s;
+}
+
+}  // namespace
+
+extern "C" {
+
+static int sad_like (int mode, int blk, int n, const uint8_t* p1, size_t b1, int s1, const int32_t* o1, const uint8_t* p2, size_t b2, int s2, const int32_t* o2, int32_t* out) {
+  NEED_GPU();
+  if (blk < 0 || blk > 6 || n <= 0) return WELSHIP_ERR_INIT_PARA;
+  Dev d1 (p1, b1), d2 (p2, b2), do1 (o1, n * 4), do2 (o2, n * 4), dout (nullptr, (size_t)n * 4 * (mode == 2 ? 4 : 1));
+  hipLaunchKernelGGL (k_sad, dim3 (grid (n)), dim3 (256), 0, 0, blk, n, d1.as<uint8_t>(), s1, do1.as<int>(), d2.as<uint8_t>(), s2, do2.as<int>(), dout.as<int>(), mode);
+  if (hipDeviceSynchronize() != hipSuccess) return WELSHIP_ERR_UNKNOWN;
+  dout.back (out);
+  return WELSHIP_OK;
+}
+int WelsHipPrimSampleSad (int iBlock, int n, const uint8_t* p1, size_t b1, int32_t s1, const int32_t* o1, const uint8_t* p2, size_t b2, int32_t s2, const int32_t* o2, int32_t* pSad) { return sad_like (0, iBlock, n, p1, b1, s1, o1, p2, b2, s2, o2, pSad); }
+int WelsHipPrimSampleSatd (int iBlock, int n, const uint8_t* p1, size_t b1, int32_t s1, const int32_t* o1, const uint8_t* p2, size_t b2, int32_t s2, const int32_t* o2, int32_t* pSatd) { return sad_like (1, iBlock, n, p1, b1, s1, o1, p2, b2, s2, o2, pSatd); }
+int WelsHipPrimSample4Sad (int iBlock, int n, const uint8_t* p1, size_t b1, int32_t s1, const int32_t* o1, const uint8_t* p2, size_t b2, int32_t s2, const int32_t* o2, int32_t* pSad4) { return sad_like (2, iBlock, n, p1, b1, s1, o1, p2, b2, s2, o2, pSad4); }
+
+int WelsHipPrimDctT4 (int n, const uint8_t* p1, size_t b1, int32_t s1, const int32_t* o1, const uint8_t* p2, size_t b2, int32_t s2, const int32_t* o2, int16_t* pDct) {
+  NEED_GPU();
+  Dev d1 (p1, b1), d2 (p2, b2), do1 (o1, n * 4), do2 (o2, n * 4), dout (nullptr, (size_t)n * 32);
+  hipLaunchKernelGGL (k_dct, dim3 (grid (n)), dim3 (256), 0, 0, n, d1.as<uint8_t>(), s1, do1.as<int>(), d2.as<uint8_t>(), s2, do2.as<int>(), dout.as<int16_t>());
+  if (hipDeviceSynchronize() != hipSuccess) return WELSHIP_ERR_UNKNOWN;
+  dout.back (pDct);
+  return WELSHIP_OK;
+}
+int WelsHipPrimQuant4x4 (int n, int16_t* pDctInOut, const uint8_t* pQp, int bIntra, int16_t* pMax, int16_t* pScanDcAc, int16_t* pScanAc, int32_t* pSingleCtr, int32_t* pNzc) {
+  NEED_GPU();
+  Dev dio (pDctInOut, (size_t)n * 32), dqp (pQp, n), dmx (nullptr, (size_t)n * 2), dzz (nullptr, (size_t)n * 32), dza (nullptr, (size_t)n * 32), dct (nullptr, (size_t)n * 4), dnz (nullptr, (size_t)n * 4);
+  hipLaunchKernelGGL (k_quant, dim3 (grid (n)), dim3 (256), 0, 0, n, dio.as<int16_t>(), dqp.as<uint8_t>(), bIntra, dmx.as<int16_t>(), dzz.as<int16_t>(), dza.as<int16_t>(), dct.as<int>(), dnz.as<int>());
+  if (hipDeviceSynchronize() != hipSuccess) return WELSHIP_ERR_UNKNOWN;
+  dio.back (pDctInOut); dmx.back (pMax); dzz.back (pScanDcAc); dza.back (pScanAc); dct.back (pSingleCtr); dnz.back (pNzc);
+  return WELSHIP_OK;
+}
+int WelsHipPrimDequantIDctRec (int n, const int16_t* pLevelsRaster, const uint8_t* pQp, const uint8_t* pPred, uint8_t* pRec, int16_t* pDequant) {
+  NEED_GPU();
+  Dev dc (pLevelsRaster, (size_t)n * 32), dqp (pQp, n), dp (pPred, (size_t)n * 16), dr (nullptr, (size_t)n * 16), dd (nullptr, (size_t)n * 32);
+  hipLaunchKernelGGL (k_dequant_idct, dim3 (grid (n)), dim3 (256), 0, 0, n, dc.as<int16_t>(), dqp.as<uint8_t>(), dp.as<uint8_t>(), dr.as<uint8_t>(), dd.as<int16_t>());
+  if (hipDeviceSynchronize() != hipSuccess) return WELSHIP_ERR_UNKNOWN;
+  dr.back (pRec); dd.back (pDequant);
+  return WELSHIP_OK;
+}
+int WelsHipPrimIntraPred4x4 (int n, const uint8_t* pPlane, size_t bytes, int32_t iStride, const int32_t* pOff, const uint8_t* pMode, const uint8_t* pAvail, uint8_t* pPred) {
+  NEED_GPU();
+  Dev dp (pPlane, bytes), dof (pOff, n * 4), dm (pMode, n), da (pAvail, n), dout (nullptr, (size_t)n * 16);
+  hipLaunchKernelGGL (k_pred4, dim3 (grid (n)), dim3 (256), 0, 0, n, dp.as<uint8_t>(), iStride, dof.as<int>(), dm.as<uint8_t>(), da.as<uint8_t>(), dout.as<uint8_t>());
+  if (hipDeviceSynchronize() != hipSuccess) return WELSHIP_ERR_UNKNOWN;
+  dout.back (pPred);
+  return WELSHIP_OK;
+}
+int WelsHipPrimIntraPredMb (int n, const uint8_t* pPlaneY, size_t bytesY, int32_t iStrideY, const int32_t* pOffY, const uint8_t* pPlaneC, size_t bytesC, int32_t iStrideC, const int32_t* pOffC,
+                            const uint8_t* pMode16, const uint8_t* pModeChroma, uint8_t* pPred16, uint8_t* pPredChroma) {
+  NEED_GPU();
+  Dev dy (pPlaneY, bytesY), doy (pOffY, n * 4), dc (pPlaneC, bytesC), doc (pOffC, n * 4), dm (pMode16, n), dmc (pModeChroma, n), o16 (nullptr, (size_t)n * 256), oc (nullptr, (size_t)n * 128);
+  hipLaunchKernelGGL (k_pred_mb, dim3 (n), dim3 (64), 0, 0, dy.as<uint8_t>(), iStrideY, doy.as<int>(), dc.as<uint8_t>(), iStrideC, doc.as<int>(), dm.as<uint8_t>(), dmc.as<uint8_t>(), o16.as<uint8_t>(), oc.as<uint8_t>());
+  if (hipDeviceSynchronize() != hipSuccess) return WELSHIP_ERR_UNKNOWN;
+  o16.back (pPred16); oc.back (pPredChroma);
+  return WELSHIP_OK;
+}
+int WelsHipPrimMc (int n, const uint8_t* pPlane, size_t bytes, int32_t iStride, const int32_t* pOff, const int16_t* pMv, int iWidth, int iHeight, int bChroma, uint8_t* pDst) {
+  NEED_GPU();
+  Dev dp (pPlane, bytes), dof (pOff, n * 4), dmv (pMv, (size_t)n * 4), dout (nullptr, (size_t)n * iWidth * iHeight);
+  hipLaunchKernelGGL (k_mc, dim3 (grid (n)), dim3 (256), 0, 0, n, dp.as<uint8_t>(), iStride, dof.as<int>(), dmv.as<int16_t>(), iWidth, iHeight, bChroma, dout.as<uint8_t>());
+  if (hipDeviceSynchronize() != hipSuccess) return WELSHIP_ERR_UNKNOWN;
+  dout.back (pDst);
+  return WELSHIP_OK;
+}
+int WelsHipPrimDeblockEdges (int nEdges, uint8_t* pPlaneInOut, size_t bytes, int32_t iStride, const int32_t* pOff, int bVerticalEdge, int bChroma, const uint8_t* pBs4, const uint8_t* pIndexA) {
+  NEED_GPU();
+  Dev dp (pPlaneInOut, bytes), dof (pOff, nEdges * 4), dbs (pBs4, (size_t)nEdges * 4), dia (pIndexA, nEdges);
+  const int lines = nEdges * (bChroma ? 8 : 16);
+  hipLaunchKernelGGL (k_deblock, dim3 (grid (lines)), dim3 (256), 0, 0, nEdges, dp.as<uint8_t>(), iStride, dof.as<int>(), bVerticalEdge, bChroma, dbs.as<uint8_t>(), dia.as<uint8_t>());
+  if (hipDeviceSynchronize() != hipSuccess) return WELSHIP_ERR_UNKNOWN;
+  dp.back (pPlaneInOut);
+  return WELSHIP_OK;
+}
+int WelsHipPrimVaaSad8x8 (int nMb, const uint8_t* pCur, const uint8_t* pRef, size_t bytes, int32_t iStride, const int32_t* pOff, int32_t* pSad8x8) {
+  NEED_GPU();
+  Dev dc (pCur, bytes), dr (pRef, bytes), dof (pOff, nMb * 4), dout (nullptr, (size_t)nMb * 16);
+  hipLaunchKernelGGL (k_vaa, dim3 (grid (nMb * 4)), dim3 (256), 0, 0, nMb, dc.as<uint8_t>(), dr.as<uint8_t>(), iStride, dof.as<int>(), dout.as<int>());
+  if (hipDeviceSynchronize() != hipSuccess) return WELSHIP_ERR_UNKNOWN;
+  dout.back (pSad8x8);
+  return WELSHIP_OK;
+}
+
+}  // extern "C"
