@@ -101,6 +101,7 @@ typedef struct WhSeqParams {
   int32_t alpha_offset, beta_offset;
   int32_t mv_range;                     // iMvRange
   int32_t pad[3];
+  unsigned long long* prof;             // optional device array of 32 cycle counters (phase profiling), or NULL
 } WhSeqParams;
 
 #ifdef __cplusplus

@@ -467,6 +467,7 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, const WhSeqParams& P, const WhPicJob
   const int use_satd = P.complexity > 0;        // pfMdCost == SATD, pfCalculateSatd == CalculateSatdCost
   const bool md_using_sad = !use_satd;          // bMdUsingSad (svc_encode_slice.cpp:699)
   const int slice_idc = wh_slice_of_mb (P, xy);
+  WH_PROF_DECL (P);
   wh_load_mb_tile (M, P, J, mbx, mby);
 
   // ---- neighbour cache (FillNeighborCacheInterWithoutBGD) ----
@@ -506,6 +507,7 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, const WhSeqParams& P, const WhPicJob
   C.minx = wh_max (- ((mbx + 1) << 4) + 3, -P.mv_range); C.miny = wh_max (- ((mby + 1) << 4) + 3, -P.mv_range);
   C.maxx = wh_min (((P.mb_w - mbx) << 4) - 3, P.mv_range); C.maxy = wh_min (((P.mb_h - mby) << 4) - 3, P.mv_range);
 
+  WH_PROF_MARK (P, 0);   // tile + neighbour cache
   int mb_type = WH_MB_P16x16, cbp = 0, cost_luma = 0, cost_skip_mb = 0, sad_cost0 = 0;
   int p16x = 0, p16y = 0;                       // sP16x16Mv
   int skx = 0, sky = 0;
@@ -566,6 +568,7 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, const WhSeqParams& P, const WhPicJob
     }
   }
   if (b_skip && keep_skip) { mb_type = WH_MB_PSKIP; done = true; }
+  WH_PROF_MARK (P, 1);   // P_Skip test
 
   WhMe me16;
   if (!done && !b_skip) {
@@ -604,6 +607,7 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, const WhSeqParams& P, const WhPicJob
     me16.sad_pred = sad_pred;
   }
 
+  WH_PROF_MARK (P, 2);   // P16x16 motion search
   // ---- secondary modes (WelsMdInterSecondaryModesEnc) ----
   bool intra = false;
   WhIntraResult ir;
@@ -612,6 +616,7 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, const WhSeqParams& P, const WhPicJob
     if (wh_intra_md_enc_p (M, P, J, mbx, mby, avail, qp, qpc, cost_luma, &ir)) { intra = true; done = true; }
   }
   if (!done && b_skip) { mb_type = WH_MB_PSKIP; done = true; }
+  WH_PROF_MARK (P, 3);   // I16x16 test (+ intra encode when intra wins)
 
   int sub_type[4] = {0, 0, 0, 0};
   if (!done) {
@@ -697,6 +702,7 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, const WhSeqParams& P, const WhPicJob
       }
     }
 
+    WH_PROF_MARK (P, 4);   // fine partitions
     // ---- refinement (WelsMdInterMbRefinement) ----
     const int satd_in_md = use_satd;     // bSatdInMdFlag: pfMeCost == pfMdCost == SATD
     int best_sad = 0, best_satd = 0;
@@ -757,6 +763,7 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, const WhSeqParams& P, const WhPicJob
     sad_cost0 = best_sad;
     cost_luma = md_using_sad ? best_sad : best_satd;
 
+    WH_PROF_MARK (P, 5);   // fractional refinement + chroma MC
     // ---- encode (WelsMdInterEncode) ----
     wh_dct_luma16 (M);
     cbp = wh_enc_inter_y (M, qp);
@@ -773,6 +780,7 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, const WhSeqParams& P, const WhPicJob
     }
   }
 
+  WH_PROF_MARK (P, 6);   // residual coding
   // ---- store ----
   const bool is_skip = mb_type == WH_MB_PSKIP;
   if (intra) {
@@ -814,4 +822,5 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, const WhSeqParams& P, const WhPicJob
   }
   WV_LANES_END
   wh_store_mb (M, P, J, mbx, mby, mb_type, cbp, qp, qpc, 0, 0, cost_luma, slice_idc);
+  WH_PROF_MARK (P, 7);   // store
 }

@@ -39,19 +39,31 @@
 #define WH_HDFN static __host__ __device__ __forceinline__
 #define WH_CONST static __device__ const
 #define WV_LANES_BEGIN(lane) { const int lane = (int)(threadIdx.x & 63);
-#define WV_LANES_END } __syncthreads();
-#define WV_SYNC() __syncthreads()
+// A workgroup is ONE wavefront and a wavefront's LDS instructions execute in issue order, so the hand-off between
+// lane blocks needs no s_waitcnt / s_barrier: only the compiler must not move LDS accesses across it.
+#define WV_SYNC() do { __builtin_amdgcn_fence (__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                       __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#define WV_LANES_END } WV_SYNC();
 
+// 64-lane reductions on the DPP network (no LDS traffic): quad -> half row -> row, then the four row results are
+// combined on the scalar unit.  Results are wave-uniform (SGPR).
+#define WH_DPP(v, ctrl) __builtin_amdgcn_update_dpp (0, (v), (ctrl), 0xF, 0xF, true)
 WH_FN int wh_wave_sum_i32 (int v) {
-  // 64-lane butterfly; result made uniform (SGPR) with readfirstlane
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor (v, m, 64);
-  return __builtin_amdgcn_readfirstlane (v);
+  v += WH_DPP (v, 0xB1);     // quad_perm [1,0,3,2]
+  v += WH_DPP (v, 0x4E);     // quad_perm [2,3,0,1]
+  v += WH_DPP (v, 0x141);    // row_half_mirror
+  v += WH_DPP (v, 0x140);    // row_mirror
+  return __builtin_amdgcn_readlane (v, 0) + __builtin_amdgcn_readlane (v, 16) + __builtin_amdgcn_readlane (v, 32) + __builtin_amdgcn_readlane (v, 48);
 }
 WH_FN int wh_wave_min_i32 (int v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) { int o = __shfl_xor (v, m, 64); v = o < v ? o : v; }
-  return __builtin_amdgcn_readfirstlane (v);
+  int o;
+  o = WH_DPP (v, 0xB1); v = o < v ? o : v;
+  o = WH_DPP (v, 0x4E); v = o < v ? o : v;
+  o = WH_DPP (v, 0x141); v = o < v ? o : v;
+  o = WH_DPP (v, 0x140); v = o < v ? o : v;
+  const int a = __builtin_amdgcn_readlane (v, 0), b = __builtin_amdgcn_readlane (v, 16), c = __builtin_amdgcn_readlane (v, 32), d = __builtin_amdgcn_readlane (v, 48);
+  const int ab = a < b ? a : b, cd = c < d ? c : d;
+  return ab < cd ? ab : cd;
 }
 #define WV_SUM(dst, lane, expr)                                   \
   do { const int lane = (int)(threadIdx.x & 63); int _v = (int)(expr); (dst) = wh_wave_sum_i32 (_v); } while (0)
@@ -64,6 +76,17 @@ WH_FN int wh_wave_min_i32 (int v) {
        (dst_key) = _m; (dst_lane) = _b ? (int)__builtin_ctzll (_b) : -1; } while (0)
 #define WV_ANY(dst, lane, expr)                                   \
   do { const int lane = (int)(threadIdx.x & 63); (dst) = __ballot ((expr)) != 0ULL; } while (0)
+#endif
+
+// ---- optional in-kernel phase profiling (WhSeqParams.prof != NULL): cycles since the previous mark are added
+// to counter `id` (64 banks x 32 counters, banked by block id to keep the atomics uncontended) by lane 0.  Costs one uniform branch when disabled.
+#if defined(WH_EMU)
+#define WH_PROF_DECL(P) ((void)0)
+#define WH_PROF_MARK(P, id) ((void)0)
+#else
+#define WH_PROF_DECL(P) unsigned long long _wh_t0 = (P).prof ? (unsigned long long)__builtin_readcyclecounter() : 0ULL
+#define WH_PROF_MARK(P, id) do { if ((P).prof) { const unsigned long long _t = (unsigned long long)__builtin_readcyclecounter(); \
+  if ((threadIdx.x & 63) == 0) { unsigned long long* _p = (P).prof + ((blockIdx.x + blockIdx.y * 7u) & 63u) * 32u; atomicAdd (&_p[id], _t - _wh_t0); atomicAdd (&_p[16 + (id)], 1ULL); } _wh_t0 = _t; } } while (0)
 #endif
 
 // ---- small integer helpers (host + device) -----------------------------------------------------

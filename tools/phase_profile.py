@@ -1,0 +1,24 @@
+"""In-kernel phase profile of the P-frame MB kernel (cycle counters, see WH_PROF_MARK)."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import openh264_amd as oh
+from openh264_amd.utils.synth import synth_sequence
+w, h, S = 1920, 1080, int(sys.argv[1]) if len(sys.argv) > 1 else 16
+e = oh.Encoder(); p = e.GetDefaultParams(); e.close()
+p.iPicWidth, p.iPicHeight, p.iDLayerQp, p.fMaxFrameRate, p.iTargetBitrate, p.uiIntraPeriod, p.uiSliceMode, p.uiSliceNum = w, h, 24, 30.0, 5000000, 0, 1, 4
+g = oh.EncoderGroup(p, S, ring_slots=4)
+fr = synth_sequence(w, h, 4); fsz = w * h * 3 // 2
+for s in range(S):
+    for k in range(4): g.upload(s, k, fr[k * fsz:(k + 1) * fsz])
+g.bench(1, 0)
+lib = g._lib
+lib.WelsHipGroupProfile.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_ulonglong)]
+lib.WelsHipGroupProfile(g._h, 1, None)
+print(g.bench(3, 0))
+out = (C.c_ulonglong * 32)()
+lib.WelsHipGroupProfile(g._h, 1, out)
+names = ["tile+cache", "pskip test", "p16x16 ME", "i16 test", "fine partitions", "refine+chromaMC", "residual", "store"]
+tot = sum(out[i] for i in range(8))
+for i, n in enumerate(names):
+    print("%-18s %6.2f%%  avg %8.0f cycles  hits %d" % (n, 100.0 * out[i] / max(tot, 1), out[i] / max(out[16 + i], 1), out[16 + i]))
+print("total cycles/MB %.0f" % (tot / max(out[16 + 7], 1)))
