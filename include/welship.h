@@ -144,6 +144,8 @@ int  WelsHipGroupGetReconFrame (WelsHipEncoderGroup* pGroup, int iSession, uint8
 const char* WelsHipGroupBackendName (WelsHipEncoderGroup* pGroup);
 /* hot-path timing with HIP events on the launch stream; pOutMs[4] = total, MD, deblock, expand */
 int  WelsHipGroupBench (WelsHipEncoderGroup* pGroup, int iSteps, int iWarmup, double* pOutMs);
+/* developer aid: WhMbRecord[] (openh264_amd/csrc/common/wh_types.h) of the last encoded frame */
+int  WelsHipDebugGetMbRecords (WelsHipEncoder* pEncoder, void* pDst, size_t uiBytes);
 /* developer aid: per-phase cycle counters accumulated inside the MB kernels (16 sums + 16 counts) */
 int  WelsHipGroupProfile (WelsHipEncoderGroup* pGroup, int bEnable, unsigned long long* pOut32);
 

@@ -11,6 +11,7 @@
 #include "../../../include/welship.h"
 #include "../kernels/frame_kernels.h"
 #include "../kernels/inter_mb.h"
+#include "../kernels/mc_px.h"
 #include "../kernels/deblock_mb.h"
 
 namespace {
@@ -48,6 +49,60 @@ __global__ void k_sad (int blk, int n, const uint8_t* p1, int s1, const int* o1,
   if (mode == 0) out[i] = dev_sad (blk, a, s1, b, s2);
   else if (mode == 1) { int s = 0; for (int y = 0; y < kBh[blk]; y += 4) for (int x = 0; x < kBw[blk]; x += 4) s += dev_satd4 (a + y * s1 + x, s1, b + y * s2 + x, s2); out[i] = s; }
   else { out[i * 4] = dev_sad (blk, a, s1, b - s2, s2); out[i * 4 + 1] = dev_sad (blk, a, s1, b + s2, s2); out[i * 4 + 2] = dev_sad (blk, a, s1, b - 1, s2); out[i * 4 + 3] = dev_sad (blk, a, s1, b + 1, s2); }
+}
+
+// Wave-level variants for the partition sizes the macroblock kernel handles (16x16, 16x8, 8x16, 8x8): one wavefront
+// per block, through the very lane primitives of kernels/inter_mb.h (register SATD on DPP, packed-byte SAD, 4-samples-
+// per-lane interpolation from an LDS window) -- so the oracle comparison of this layer pins the hot path's arithmetic.
+__global__ __launch_bounds__ (64) void k_sad_wave (int blk, const uint8_t* p1, int s1, const int* o1, const uint8_t* p2, size_t b2, int s2, const int* o2, int* out, int mode) {
+  __shared__ WhInterLds S;
+  const int i = blockIdx.x, bw = kBw[blk], bh = kBh[blk];
+  const uint8_t* a = p1 + o1[i];
+  const long base = (long)o2[i] - 8 * s2 - 8;                 // window origin = block position - (8,8)
+  WV_LANES_BEGIN (lane)
+  for (int k = lane; k < bw * bh; k += 64) S.m.enc_y[(k / bw) * 16 + k % bw] = a[(k / bw) * s1 + k % bw];
+  for (int k = lane; k < 40 * 64; k += 64) {
+    long ad = base + (long) (k >> 6) * s2 + (k & 63);
+    ad = ad < 0 ? 0 : (ad > (long)b2 - 1 ? (long)b2 - 1 : ad);
+    S.win[k] = p2[ad];
+  }
+  WV_LANES_END
+  const int wo = 8 * WH_WIN_STRIDE + 8;
+  if (mode == 0) {
+    const int s = wh_sad_win (S, 0, 0, bw, bh, wo);
+    if (threadIdx.x == 0) out[i] = s;
+  } else if (mode == 1) {
+    const int nq = (bw >> 2) * (bh >> 2) * 4;
+    int s;
+    WV_SATD_ROWS (s, lane, lane < nq, wh_enc4 (S, lane < nq ? wh_tl_col (lane, bw) : 0, lane < nq ? wh_tl_row (lane, bw) : 0),
+                  wh_ld4u (S.win, wo + (lane < nq ? wh_tl_row (lane, bw) * WH_WIN_STRIDE + wh_tl_col (lane, bw) : 0)));
+    if (threadIdx.x == 0) out[i] = s;
+  } else {
+    const int s0 = wh_sad_win (S, 0, 0, bw, bh, wo - WH_WIN_STRIDE), s1v = wh_sad_win (S, 0, 0, bw, bh, wo + WH_WIN_STRIDE);
+    const int s2v = wh_sad_win (S, 0, 0, bw, bh, wo - 1), s3 = wh_sad_win (S, 0, 0, bw, bh, wo + 1);
+    if (threadIdx.x == 0) { out[i * 4] = s0; out[i * 4 + 1] = s1v; out[i * 4 + 2] = s2v; out[i * 4 + 3] = s3; }
+  }
+}
+__global__ __launch_bounds__ (64) void k_mc_wave (const uint8_t* plane, size_t bytes, int st, const int* off, const int16_t* mv, int w, int h, uint8_t* out) {
+  __shared__ WhInterLds S;
+  const int i = blockIdx.x;
+  const long base = (long)off[i] - 8 * st - 8;
+  WV_LANES_BEGIN (lane)
+  for (int k = lane; k < 40 * 64; k += 64) {
+    long ad = base + (long) (k >> 6) * st + (k & 63);
+    ad = ad < 0 ? 0 : (ad > (long)bytes - 1 ? (long)bytes - 1 : ad);
+    S.win[k] = plane[ad];
+  }
+  WV_LANES_END
+  const int fx = mv[i * 2] & 3, fy = mv[i * 2 + 1] & 3, wo = 8 * WH_WIN_STRIDE + 8;
+  WV_LANES_BEGIN (lane)
+  if (lane < (w * h) >> 2) {
+    const int r = wh_sl_row (lane, w), c = wh_sl_col (lane, w);
+    const uint32_t v = wh_mc4 (S.win, wo + r * WH_WIN_STRIDE + c, fx, fy);
+    uint8_t* d = out + (size_t)i * w * h + r * w + c;
+    d[0] = (uint8_t)v; d[1] = (uint8_t) (v >> 8); d[2] = (uint8_t) (v >> 16); d[3] = (uint8_t) (v >> 24);
+  }
+  WV_LANES_END
 }
 
 __global__ void k_dct (int n, const uint8_t* p1, int s1, const int* o1, const uint8_t* p2, int s2, const int* o2, int16_t* out) {
@@ -182,7 +237,8 @@ static int sad_like (int mode, int blk, int n, const uint8_t* p1, size_t b1, int
   NEED_GPU();
   if (blk < 0 || blk > 6 || n <= 0) return WELSHIP_ERR_INIT_PARA;
   Dev d1 (p1, b1), d2 (p2, b2), do1 (o1, n * 4), do2 (o2, n * 4), dout (nullptr, (size_t)n * 4 * (mode == 2 ? 4 : 1));
-  hipLaunchKernelGGL (k_sad, dim3 (grid (n)), dim3 (256), 0, 0, blk, n, d1.as<uint8_t>(), s1, do1.as<int>(), d2.as<uint8_t>(), s2, do2.as<int>(), dout.as<int>(), mode);
+  if (blk <= 3) hipLaunchKernelGGL (k_sad_wave, dim3 (n), dim3 (64), 0, 0, blk, d1.as<uint8_t>(), s1, do1.as<int>(), d2.as<uint8_t>(), b2, s2, do2.as<int>(), dout.as<int>(), mode);
+  else hipLaunchKernelGGL (k_sad, dim3 (grid (n)), dim3 (256), 0, 0, blk, n, d1.as<uint8_t>(), s1, do1.as<int>(), d2.as<uint8_t>(), s2, do2.as<int>(), dout.as<int>(), mode);
   if (hipDeviceSynchronize() != hipSuccess) return WELSHIP_ERR_UNKNOWN;
   dout.back (out);
   return WELSHIP_OK;
@@ -235,7 +291,10 @@ int WelsHipPrimIntraPredMb (int n, const uint8_t* pPlaneY, size_t bytesY, int32_
 int WelsHipPrimMc (int n, const uint8_t* pPlane, size_t bytes, int32_t iStride, const int32_t* pOff, const int16_t* pMv, int iWidth, int iHeight, int bChroma, uint8_t* pDst) {
   NEED_GPU();
   Dev dp (pPlane, bytes), dof (pOff, n * 4), dmv (pMv, (size_t)n * 4), dout (nullptr, (size_t)n * iWidth * iHeight);
-  hipLaunchKernelGGL (k_mc, dim3 (grid (n)), dim3 (256), 0, 0, n, dp.as<uint8_t>(), iStride, dof.as<int>(), dmv.as<int16_t>(), iWidth, iHeight, bChroma, dout.as<uint8_t>());
+  if (!bChroma && (iWidth == 16 || iWidth == 8) && (iHeight == 16 || iHeight == 8))
+    hipLaunchKernelGGL (k_mc_wave, dim3 (n), dim3 (64), 0, 0, dp.as<uint8_t>(), bytes, iStride, dof.as<int>(), dmv.as<int16_t>(), iWidth, iHeight, dout.as<uint8_t>());
+  else
+    hipLaunchKernelGGL (k_mc, dim3 (grid (n)), dim3 (256), 0, 0, n, dp.as<uint8_t>(), iStride, dof.as<int>(), dmv.as<int16_t>(), iWidth, iHeight, bChroma, dout.as<uint8_t>());
   if (hipDeviceSynchronize() != hipSuccess) return WELSHIP_ERR_UNKNOWN;
   dout.back (pDst);
   return WELSHIP_OK;

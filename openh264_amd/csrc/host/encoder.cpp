@@ -408,6 +408,15 @@ int WelsHipGetReconFrame (WelsHipEncoder* e, uint8_t* dst, size_t bytes) {
   return e->core.copy_recon (dst, bytes);
 }
 
+// Developer aid: the MB records (WhMbRecord[mb_w*mb_h], csrc/common/wh_types.h) of the last encoded frame.
+int WelsHipDebugGetMbRecords (WelsHipEncoder* e, void* dst, size_t bytes) {
+  if (!e || !e->inited || !dst) return WELSHIP_ERR_INIT_PARA;
+  const size_t n = sizeof (WhMbRecord) * e->core.h_records.size();
+  if (bytes < n) return WELSHIP_ERR_INIT_PARA;
+  memcpy (dst, e->core.h_records.data(), n);
+  return WELSHIP_OK;
+}
+
 // ---------------------------------------------------------------------------------- session group
 int WelsHipGroupCreate (WelsHipEncoderGroup** pp, const WelsHipEncParam* p, int n_sessions, int ring_slots, int host_threads) {
   if (!pp || !p || n_sessions < 1 || n_sessions > 4096) return WELSHIP_ERR_INIT_PARA;

@@ -22,23 +22,44 @@
 #pragma once
 #include "frame_kernels.h"
 
+// Performance shape (MI355X): the wave pays HBM latency twice per macroblock -- one batch of loads for the source
+// tile, the neighbour pixels and the neighbour / co-located MB states, and one batch for the reference search
+// windows (luma 64x64, chroma 2 x 32x32) centred on the 16x16 motion vector predictor.  Everything after that
+// (candidate SADs, diamond search, fractional refinement, motion compensation, residual coding) runs from LDS and
+// registers; a window is re-fetched only when a search start or a prediction block falls outside it.
+
 #define WH_REF_NOT_AVAIL (-2)
 #define WH_REF_NOT_IN_LIST (-1)
 #define WH_WIN_STRIDE 64
-#define WH_WIN_ROWS 56
+#define WH_WIN_ROWS 64
 #define WH_WIN_MARGIN 19          // diamond (16) + quarter/half-pel taps (3)
+#define WH_CWIN_STRIDE 32
+#define WH_CWIN_ROWS 32
+
+// slots of S.me[]: one motion search result per partition
+#define WH_SLOT_16x16 0
+#define WH_SLOT_8x8 1             // 1..4
+#define WH_SLOT_16x8 5            // 5,6
+#define WH_SLOT_8x16 7            // 7,8
 
 typedef struct WhInterLds {
   WhMbLds m;
-  uint8_t win[WH_WIN_ROWS * WH_WIN_STRIDE];   // reference search window (luma), see wh_win_load
-  uint8_t cand[256];                          // candidate luma prediction, stride 16
-  uint8_t skip_y[256];                        // P_Skip prediction
+  uint8_t win[WH_WIN_ROWS * WH_WIN_STRIDE + 16];            // reference search window (luma), see wh_win_load_luma
+  uint8_t cwin[2][WH_CWIN_ROWS * WH_CWIN_STRIDE + 16];      // chroma windows (Cb, Cr)
+  uint8_t prev_y[256];                                      // co-located luma of the previous source picture (VAA SADs)
+  uint8_t skip_y[256];                                      // P_Skip prediction
   uint8_t skip_c[128];
-  int16_t mvc[30][2];                         // motion vector cache, 5 rows x 6 cols (row 0 / col 0 = neighbours)
-  int8_t  refc[32];                           // reference index cache
-  int16_t mvp_out[16][2];                     // predictor used for the mvd of each 4x4 (raster)
+  uint32_t nb[5][36];                                       // WhMbState copies: top-left, top, top-right, left, co-located (reference picture)
+  int16_t co_mv[2][2];                                      // sP16x16Mv of the reference picture's MBs to the right / below
+  int16_t mvcl[5][2];                                       // 16x16 search candidates
+  int16_t mvc[30][2];                                       // motion vector cache, 5 rows x 6 cols (row 0 / col 0 = neighbours)
+  int8_t  refc[32];                                         // reference index cache
+  int16_t mvp_out[16][2];                                   // predictor used for the mvd of each 4x4 (raster)
   int16_t mv_out[16][2];
+  int32_t me[9][8];                                         // per slot: mvx, mvy, sad_cost, satd_cost, satd_raw
 } WhInterLds;
+
+typedef struct WhWin { int x0, y0, cx0, cy0; } WhWin;       // picture coordinates of element (0,0) of win / cwin
 
 // ---- mvd cost: lambda * bits(se(mvd))  (md.cpp:797-824, svc_enc_golomb.h BsSizeSE) --------------
 WH_FN int wh_se_bits (int v) {
@@ -50,136 +71,198 @@ WH_FN int wh_se_bits (int v) {
 }
 WH_FN int wh_mvd_cost (int lambda, int dx, int dy) { return (int) (uint16_t) (lambda * wh_se_bits (dx)) + (int) (uint16_t) (lambda * wh_se_bits (dy)); }
 
-// ---- H.264 luma sample interpolation from a byte tile (stride st), integer position p, frac (fx,fy) ----
+// ---- H.264 luma sample interpolation (8.4.2.2.1; mc.cpp:100-347), four horizontally adjacent samples per lane ----
+// `w` is the LDS window, `o` the byte offset of the integer sample G of the first of the four.
 WH_FN int wh_tap6 (int a, int b, int c, int d, int e, int f) { return a - 5 * b + 20 * c + 20 * d - 5 * e + f; }
-WH_FN int wh_mc_b (const uint8_t* p) { return wh_clip255 ((wh_tap6 (p[-2], p[-1], p[0], p[1], p[2], p[3]) + 16) >> 5); }
-WH_FN int wh_mc_h (const uint8_t* p, int st) { return wh_clip255 ((wh_tap6 (p[-2 * st], p[-st], p[0], p[st], p[2 * st], p[3 * st]) + 16) >> 5); }
-WH_FN int wh_mc_j (const uint8_t* p, int st) {
-  int v[6];
-  for (int k = 0; k < 6; ++k) { const uint8_t* r = p + (k - 2) * st; v[k] = wh_tap6 (r[-2], r[-1], r[0], r[1], r[2], r[3]); }
-  return wh_clip255 ((wh_tap6 (v[0], v[1], v[2], v[3], v[4], v[5]) + 512) >> 10);
+#define WH_BYTE(v, k) ((int) (((v) >> (8 * (k))) & 255u))
+WH_FN uint32_t wh_pack4 (int a, int b, int c, int d) { return (uint32_t)a | ((uint32_t)b << 8) | ((uint32_t)c << 16) | ((uint32_t)d << 24); }
+// unclipped horizontal 6-tap sums of the four samples at o (needs bytes o-2 .. o+6)
+WH_FN void wh_htaps4 (const uint8_t* w, int o, int* t0, int* t1, int* t2, int* t3) {
+  const uint32_t a = wh_ld4u (w, o - 2), b = wh_ld4u (w, o + 2), c = wh_ld4u (w, o + 6);
+  const int q0 = WH_BYTE (a, 0), q1 = WH_BYTE (a, 1), q2 = WH_BYTE (a, 2), q3 = WH_BYTE (a, 3);
+  const int q4 = WH_BYTE (b, 0), q5 = WH_BYTE (b, 1), q6 = WH_BYTE (b, 2), q7 = WH_BYTE (b, 3), q8 = WH_BYTE (c, 0);
+  *t0 = wh_tap6 (q0, q1, q2, q3, q4, q5); *t1 = wh_tap6 (q1, q2, q3, q4, q5, q6);
+  *t2 = wh_tap6 (q2, q3, q4, q5, q6, q7); *t3 = wh_tap6 (q3, q4, q5, q6, q7, q8);
 }
-WH_FN int wh_mc_luma_px (const uint8_t* p, int st, int fx, int fy) {
+WH_FN uint32_t wh_mc_b4 (const uint8_t* w, int o) {          // half-sample b (between G and its right neighbour)
+  int t0, t1, t2, t3;
+  wh_htaps4 (w, o, &t0, &t1, &t2, &t3);
+  return wh_pack4 (wh_clip255 ((t0 + 16) >> 5), wh_clip255 ((t1 + 16) >> 5), wh_clip255 ((t2 + 16) >> 5), wh_clip255 ((t3 + 16) >> 5));
+}
+WH_FN uint32_t wh_mc_h4 (const uint8_t* w, int o) {          // half-sample h (between G and the sample below)
+  const uint32_t r0 = wh_ld4u (w, o - 2 * WH_WIN_STRIDE), r1 = wh_ld4u (w, o - WH_WIN_STRIDE), r2 = wh_ld4u (w, o);
+  const uint32_t r3 = wh_ld4u (w, o + WH_WIN_STRIDE), r4 = wh_ld4u (w, o + 2 * WH_WIN_STRIDE), r5 = wh_ld4u (w, o + 3 * WH_WIN_STRIDE);
+  int v[4];
+  for (int k = 0; k < 4; ++k)
+    v[k] = wh_clip255 ((wh_tap6 (WH_BYTE (r0, k), WH_BYTE (r1, k), WH_BYTE (r2, k), WH_BYTE (r3, k), WH_BYTE (r4, k), WH_BYTE (r5, k)) + 16) >> 5);
+  return wh_pack4 (v[0], v[1], v[2], v[3]);
+}
+WH_FN uint32_t wh_mc_j4 (const uint8_t* w, int o) {          // centre half-sample j
+  int t[6][4];
+  for (int k = 0; k < 6; ++k) wh_htaps4 (w, o + (k - 2) * WH_WIN_STRIDE, &t[k][0], &t[k][1], &t[k][2], &t[k][3]);
+  int v[4];
+  for (int x = 0; x < 4; ++x) v[x] = wh_clip255 ((wh_tap6 (t[0][x], t[1][x], t[2][x], t[3][x], t[4][x], t[5][x]) + 512) >> 10);
+  return wh_pack4 (v[0], v[1], v[2], v[3]);
+}
+WH_FN uint32_t wh_mc4 (const uint8_t* w, int o, int fx, int fy) {
   switch (fy * 4 + fx) {
-  case 0: return p[0];
-  case 1: return (p[0] + wh_mc_b (p) + 1) >> 1;
-  case 2: return wh_mc_b (p);
-  case 3: return (p[1] + wh_mc_b (p) + 1) >> 1;
-  case 4: return (p[0] + wh_mc_h (p, st) + 1) >> 1;
-  case 5: return (wh_mc_b (p) + wh_mc_h (p, st) + 1) >> 1;
-  case 6: return (wh_mc_b (p) + wh_mc_j (p, st) + 1) >> 1;
-  case 7: return (wh_mc_b (p) + wh_mc_h (p + 1, st) + 1) >> 1;
-  case 8: return wh_mc_h (p, st);
-  case 9: return (wh_mc_h (p, st) + wh_mc_j (p, st) + 1) >> 1;
-  case 10: return wh_mc_j (p, st);
-  case 11: return (wh_mc_j (p, st) + wh_mc_h (p + 1, st) + 1) >> 1;
-  case 12: return (p[st] + wh_mc_h (p, st) + 1) >> 1;
-  case 13: return (wh_mc_h (p, st) + wh_mc_b (p + st) + 1) >> 1;
-  case 14: return (wh_mc_j (p, st) + wh_mc_b (p + st) + 1) >> 1;
-  default: return (wh_mc_h (p + 1, st) + wh_mc_b (p + st) + 1) >> 1;
+  case 0: return wh_ld4u (w, o);
+  case 1: return wh_avg4 (wh_ld4u (w, o), wh_mc_b4 (w, o));
+  case 2: return wh_mc_b4 (w, o);
+  case 3: return wh_avg4 (wh_ld4u (w, o + 1), wh_mc_b4 (w, o));
+  case 4: return wh_avg4 (wh_ld4u (w, o), wh_mc_h4 (w, o));
+  case 5: return wh_avg4 (wh_mc_b4 (w, o), wh_mc_h4 (w, o));
+  case 6: return wh_avg4 (wh_mc_b4 (w, o), wh_mc_j4 (w, o));
+  case 7: return wh_avg4 (wh_mc_b4 (w, o), wh_mc_h4 (w, o + 1));
+  case 8: return wh_mc_h4 (w, o);
+  case 9: return wh_avg4 (wh_mc_h4 (w, o), wh_mc_j4 (w, o));
+  case 10: return wh_mc_j4 (w, o);
+  case 11: return wh_avg4 (wh_mc_j4 (w, o), wh_mc_h4 (w, o + 1));
+  case 12: return wh_avg4 (wh_ld4u (w, o + WH_WIN_STRIDE), wh_mc_h4 (w, o));
+  case 13: return wh_avg4 (wh_mc_h4 (w, o), wh_mc_b4 (w, o + WH_WIN_STRIDE));
+  case 14: return wh_avg4 (wh_mc_j4 (w, o), wh_mc_b4 (w, o + WH_WIN_STRIDE));
+  default: return wh_avg4 (wh_mc_h4 (w, o + 1), wh_mc_b4 (w, o + WH_WIN_STRIDE));
   }
 }
 // chroma (mc.cpp:349-378): bilinear with eighth-sample weights
-WH_FN int wh_mc_chroma_px (const uint8_t* p, int st, int dx, int dy) {
-  return ((8 - dx) * (8 - dy) * p[0] + dx * (8 - dy) * p[1] + (8 - dx) * dy * p[st] + dx * dy * p[st + 1] + 32) >> 6;
+WH_FN int wh_mc_chroma_w (int a, int b, int c, int d, int dx, int dy) {
+  return ((8 - dx) * (8 - dy) * a + dx * (8 - dy) * b + (8 - dx) * dy * c + dx * dy * d + 32) >> 6;
 }
 
-// ---- reference window ---------------------------------------------------------------------------
-// Loads luma pixels [px-19, px+bw+19) x [py-19, py+bh+19) of the reference picture (picture
-// coordinates) into S.win.  Returns the picture coordinates of window element (0,0) in *ox,*oy
-// (ox is aligned down to 4 for word loads).
-WH_FN void wh_win_load (WhInterLds& S, const WhSeqParams& P, const WhPicJob& J, int px, int py, int bw, int bh, int* ox, int* oy) {
-  const int x0 = (px - WH_WIN_MARGIN) & ~3, y0 = py - WH_WIN_MARGIN;
-  const int words = ((px + bw + WH_WIN_MARGIN) - x0 + 3) >> 2;       // <= 16
-  const int rows = bh + 2 * WH_WIN_MARGIN;                            // <= 54
+// ---- reference windows ----------------------------------------------------------------------------
+// Loads are clamped to the border-expanded picture (32 luma / 16 chroma pixels each side); window cells beyond that
+// can only be touched by motion vectors outside the legal range, i.e. never.
+WH_FN void wh_win_fetch_luma (int lane, const WhSeqParams& P, const WhPicJob& J, int x0, int y0, uint32_t* v /*[16]*/) {
+  const int wd = lane & 15, r0 = lane >> 4;
+  const int x = wh_clip3 (x0 + wd * 4, -32, P.mb_w * 16 + 28);
+  const WH_G uint8_t* ref = (const WH_G uint8_t*)J.ref[0];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int y = wh_clip3 (y0 + r0 + 4 * k, -32, P.mb_h * 16 + 31);
+    v[k] = * (const WH_G uint32_t*) (ref + (ptrdiff_t)y * P.rec_stride_y + x);
+  }
+}
+WH_FN void wh_win_commit_luma (WhInterLds& S, int lane, const uint32_t* v) {
+  const int wd = lane & 15, r0 = lane >> 4;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) * (uint32_t*)&S.win[(r0 + 4 * k) * WH_WIN_STRIDE + wd * 4] = v[k];
+}
+WH_FN void wh_win_load_luma (WhInterLds& S, const WhSeqParams& P, const WhPicJob& J, WhWin& W, int x0, int y0) {
+  W.x0 = x0; W.y0 = y0;
   WV_LANES_BEGIN (lane)
-  for (int i = lane; i < rows * 16; i += 64) {
-    const int r = i >> 4, wd = i & 15;
-    if (wd < words) {
-      const uint8_t* s = J.ref[0] + (ptrdiff_t) (y0 + r) * P.rec_stride_y + x0 + wd * 4;
-      * (uint32_t*)&S.win[r * WH_WIN_STRIDE + wd * 4] = * (const uint32_t*)s;
-    }
+  uint32_t v[16];
+  wh_win_fetch_luma (lane, P, J, x0, y0, v);
+  wh_win_commit_luma (S, lane, v);
+  WV_LANES_END
+}
+// first load of a macroblock: luma + both chroma windows in one batch.  (cx,cy) = luma picture position of the
+// 16x16 block displaced by the integer search centre.
+WH_FN void wh_win_load_all (WhInterLds& S, const WhSeqParams& P, const WhPicJob& J, WhWin& W, int cx, int cy) {
+  W.x0 = (cx - 24) & ~3; W.y0 = cy - 24;
+  W.cx0 = ((cx >> 1) - 12) & ~3; W.cy0 = (cy >> 1) - 12;
+  WV_LANES_BEGIN (lane)
+  uint32_t v[16], c[8];
+  wh_win_fetch_luma (lane, P, J, W.x0, W.y0, v);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int i = lane + 64 * k, pl = i >> 8, row = (i >> 3) & 31, wd = i & 7;
+    const int x = wh_clip3 (W.cx0 + wd * 4, -16, P.mb_w * 8 + 12), y = wh_clip3 (W.cy0 + row, -16, P.mb_h * 8 + 15);
+    c[k] = * (const WH_G uint32_t*) ((const WH_G uint8_t*)J.ref[1 + pl] + (ptrdiff_t)y * P.rec_stride_c + x);
+  }
+  wh_win_commit_luma (S, lane, v);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int i = lane + 64 * k, pl = i >> 8, row = (i >> 3) & 31, wd = i & 7;
+    * (uint32_t*)&S.cwin[pl][row * WH_CWIN_STRIDE + wd * 4] = c[k];
   }
   WV_LANES_END
-  *ox = x0; *oy = y0;
+}
+WH_FN bool wh_win_covers (const WhWin& W, int x0, int y0, int x1, int y1) {
+  return x0 >= W.x0 && y0 >= W.y0 && x1 <= W.x0 + WH_WIN_STRIDE && y1 <= W.y0 + WH_WIN_ROWS;
+}
+// make sure luma [x0,x1) x [y0,y1) is inside the window (extent <= 57 x 64)
+WH_FN void wh_win_ensure (WhInterLds& S, const WhSeqParams& P, const WhPicJob& J, WhWin& W, int x0, int y0, int x1, int y1) {
+  if (wh_win_covers (W, x0, y0, x1, y1)) return;
+  wh_win_load_luma (S, P, J, W, (((x0 + x1) >> 1) - 32) & ~3, ((y0 + y1) >> 1) - 32);
 }
 
-// SAD of a bw x bh block of enc (at ex,ey inside the MB) against a byte tile; lanes = bw*bh/4
-WH_FN int wh_sad_tile (const WhInterLds& S, int ex, int ey, int bw, int bh, const uint8_t* t, int st) {
+// ---- lane geometry -----------------------------------------------------------------------------------
+// SAD layout: lane = (row, 4-pixel segment) of a bw x bh block, lanes [0, bw*bh/4)
+WH_FN int wh_sl_row (int lane, int bw) { return bw == 16 ? lane >> 2 : lane >> 1; }
+WH_FN int wh_sl_col (int lane, int bw) { return bw == 16 ? (lane & 3) * 4 : (lane & 1) * 4; }
+// SATD layout: lane quad = one 4x4 block (raster inside the partition), lane & 3 = row of the block
+WH_FN int wh_tl_row (int lane, int bw) { const int b = lane >> 2; return (bw == 16 ? b >> 2 : b >> 1) * 4 + (lane & 3); }
+WH_FN int wh_tl_col (int lane, int bw) { const int b = lane >> 2; return (bw == 16 ? b & 3 : b & 1) * 4; }
+WH_FN uint32_t wh_enc4 (const WhInterLds& S, int x, int y) { return * (const uint32_t*)&S.m.enc_y[y * 16 + x]; }
+
+// SAD of the bw x bh block at (ex,ey) of the source MB against the window at offset wo
+WH_FN int wh_sad_win (const WhInterLds& S, int ex, int ey, int bw, int bh, int wo) {
   int s;
-  const int per_row = bw >> 2, n = per_row * bh;
-  WV_SUM (s, lane, (lane < n ? (wh_abs (S.m.enc_y[(ey + lane / per_row) * 16 + ex + (lane % per_row) * 4 + 0] - t[(lane / per_row) * st + (lane % per_row) * 4 + 0]) +
-                                 wh_abs (S.m.enc_y[(ey + lane / per_row) * 16 + ex + (lane % per_row) * 4 + 1] - t[(lane / per_row) * st + (lane % per_row) * 4 + 1]) +
-                                 wh_abs (S.m.enc_y[(ey + lane / per_row) * 16 + ex + (lane % per_row) * 4 + 2] - t[(lane / per_row) * st + (lane % per_row) * 4 + 2]) +
-                                 wh_abs (S.m.enc_y[(ey + lane / per_row) * 16 + ex + (lane % per_row) * 4 + 3] - t[(lane / per_row) * st + (lane % per_row) * 4 + 3])) : 0));
+  const int n = (bw * bh) >> 2;
+  WV_SUM (s, lane, (lane < n ? wh_sad4 (wh_enc4 (S, ex + wh_sl_col (lane, bw), ey + wh_sl_row (lane, bw)),
+                                        wh_ld4u (S.win, wo + wh_sl_row (lane, bw) * WH_WIN_STRIDE + wh_sl_col (lane, bw))) : 0));
+  return s;
+}
+// same against the reference picture in HBM (search candidates far away from the window)
+WH_FN int wh_sad_global (const WhInterLds& S, const WhSeqParams& P, const WhPicJob& J, int ex, int ey, int bw, int bh, int px, int py) {
+  int s;
+  const int n = (bw * bh) >> 2;
+  const WH_G uint8_t* ref = (const WH_G uint8_t*)J.ref[0];
+  WV_SUM (s, lane, (lane < n ? ([&] () { const WH_G uint8_t* t = ref + (ptrdiff_t) (py + wh_sl_row (lane, bw)) * P.rec_stride_y + px + wh_sl_col (lane, bw);
+                                          return wh_sad4 (wh_enc4 (S, ex + wh_sl_col (lane, bw), ey + wh_sl_row (lane, bw)), wh_pack4 (t[0], t[1], t[2], t[3])); }) () : 0));
+  return s;
+}
+// SAD of the whole source MB against a 16x16 byte tile in LDS (stride 16)
+WH_FN int wh_sad_mb_tile (const WhInterLds& S, const uint8_t* t) {
+  int s;
+  WV_SUM (s, lane, wh_sad4 (* (const uint32_t*)&S.m.enc_y[lane * 4], * (const uint32_t*)&t[lane * 4]));
+  return s;
+}
+WH_FN int wh_sad_chroma_tile (const WhInterLds& S, const uint8_t* t) {
+  int s;
+  WV_SUM (s, lane, (lane < 32 ? wh_sad4 (* (const uint32_t*)&S.m.enc_c[lane * 4], * (const uint32_t*)&t[lane * 4]) : 0));
   return s;
 }
 
-// SATD (4x4 Hadamard, rounded per 4x4) of a bw x bh block of enc against a tile with stride st
-WH_FN int wh_satd_tile (WhInterLds& S, int ex, int ey, int bw, int bh, const uint8_t* t, int st) {
-  const int nb = (bw >> 2) * (bh >> 2), bpr = bw >> 2;      // 4x4 blocks
-  WV_LANES_BEGIN (lane)
-  if (lane < nb * 4) {
-    const int b = lane >> 2, r = lane & 3;
-    const int bx = (b % bpr) * 4, by = (b / bpr) * 4 + r;
-    const uint8_t* e = &S.m.enc_y[(ey + by) * 16 + ex + bx];
-    const uint8_t* p = &t[by * st + bx];
-    int o0, o1, o2, o3;
-    wh_had4 (e[0] - p[0], e[1] - p[1], e[2] - p[2], e[3] - p[3], &o0, &o1, &o2, &o3);
-    int16_t* q = &S.m.tmp[b * 16 + r * 4];
-    q[0] = (int16_t)o0; q[1] = (int16_t)o1; q[2] = (int16_t)o2; q[3] = (int16_t)o3;
-  }
-  WV_LANES_END
-  WV_LANES_BEGIN (lane)
-  if (lane < nb * 4) {
-    const int b = lane >> 2, c = lane & 3;
-    const int16_t* q = &S.m.tmp[b * 16 + c];
-    int o0, o1, o2, o3;
-    wh_had4 (q[0], q[4], q[8], q[12], &o0, &o1, &o2, &o3);
-    S.m.part[lane] = wh_abs (o0) + wh_abs (o1) + wh_abs (o2) + wh_abs (o3);
-  }
-  WV_LANES_END
-  int s;
-  WV_SUM (s, lane, (lane < nb ? ((S.m.part[lane * 4] + S.m.part[lane * 4 + 1] + S.m.part[lane * 4 + 2] + S.m.part[lane * 4 + 3] + 1) >> 1) : 0));
-  return s;
-}
-
-// Build the luma prediction of a bw x bh block for quarter-pel mv (relative to block position
-// bpx,bpy in picture coords) from the window into dst (stride dst_st).
-WH_FN void wh_mc_luma_from_win (WhInterLds& S, int ox, int oy, int bpx, int bpy, int mvx, int mvy, int bw, int bh, uint8_t* dst, int dst_st) {
-  const int ix = bpx + (mvx >> 2) - ox, iy = bpy + (mvy >> 2) - oy, fx = mvx & 3, fy = mvy & 3;
-  const int per_row = bw >> 2, n = per_row * bh;
+// ---- motion compensation into LDS tiles -----------------------------------------------------------
+// luma: bw x bh block at MB offset (bx,by), quarter-pel mv; dst stride 16, dst addressed like the MB
+WH_FN void wh_mc_luma_to (WhInterLds& S, const WhSeqParams& P, const WhPicJob& J, WhWin& W, int mbx, int mby, int bx, int by, int bw, int bh,
+                          int mvx, int mvy, uint8_t* dst) {
+  const int ipx = mbx * 16 + bx + (mvx >> 2), ipy = mby * 16 + by + (mvy >> 2), fx = mvx & 3, fy = mvy & 3;
+  wh_win_ensure (S, P, J, W, ipx - 2, ipy - 2, ipx + bw + 7, ipy + bh + 3);
+  const int wo = (ipy - W.y0) * WH_WIN_STRIDE + ipx - W.x0, n = (bw * bh) >> 2;
   WV_LANES_BEGIN (lane)
   if (lane < n) {
-    const int r = lane / per_row, c = (lane % per_row) * 4;
-    const uint8_t* p = &S.win[(iy + r) * WH_WIN_STRIDE + ix + c];
-    for (int k = 0; k < 4; ++k) dst[r * dst_st + c + k] = (uint8_t)wh_mc_luma_px (p + k, WH_WIN_STRIDE, fx, fy);
+    const int r = wh_sl_row (lane, bw), c = wh_sl_col (lane, bw);
+    * (uint32_t*)&dst[(by + r) * 16 + bx + c] = wh_mc4 (S.win, wo + r * WH_WIN_STRIDE + c, fx, fy);
   }
   WV_LANES_END
 }
-
-// Luma prediction straight from the reference picture in HBM (P_Skip test: one-off position).
-WH_FN void wh_mc_luma_from_ref (const WhSeqParams& P, const WhPicJob& J, int bpx, int bpy, int mvx, int mvy, uint8_t* dst) {
-  const int fx = mvx & 3, fy = mvy & 3;
-  const uint8_t* base = J.ref[0] + (ptrdiff_t) (bpy + (mvy >> 2)) * P.rec_stride_y + bpx + (mvx >> 2);
-  WV_LANES_BEGIN (lane)
-  const int r = lane >> 2, c = (lane & 3) * 4;
-  const uint8_t* p = base + (ptrdiff_t)r * P.rec_stride_y + c;
-  for (int k = 0; k < 4; ++k) dst[r * 16 + c + k] = (uint8_t)wh_mc_luma_px (p + k, P.rec_stride_y, fx, fy);
-  WV_LANES_END
-}
-
-// Chroma prediction of a cw x ch block (both planes) at chroma block position (cx,cy) inside the MB.
-WH_FN void wh_mc_chroma (const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, int cx, int cy, int cw, int ch, int mvx, int mvy, uint8_t* dst /*Cb at 0, Cr at 64, stride 8*/) {
+// chroma: cw x ch block (both planes) at chroma offset (cx,cy) inside the MB; dst: Cb at 0, Cr at 64, stride 8
+WH_FN void wh_mc_chroma_to (WhInterLds& S, const WhSeqParams& P, const WhPicJob& J, const WhWin& W, int mbx, int mby, int cx, int cy, int cw, int ch,
+                            int mvx, int mvy, uint8_t* dst) {
   const int dx = mvx & 7, dy = mvy & 7;
-  const int n = cw * ch;
-  WV_LANES_BEGIN (lane)
-  for (int i = lane; i < 2 * n; i += 64) {
-    const int pl = i / n, k = i % n, x = cx + k % cw, y = cy + k / cw;
-    const uint8_t* p = J.ref[1 + pl] + (ptrdiff_t) (mby * 8 + y + (mvy >> 3)) * P.rec_stride_c + mbx * 8 + x + (mvx >> 3);
-    dst[pl * 64 + y * 8 + x] = (uint8_t)wh_mc_chroma_px (p, P.rec_stride_c, dx, dy);
+  const int ipx = mbx * 8 + cx + (mvx >> 3), ipy = mby * 8 + cy + (mvy >> 3);
+  const int n = cw * ch, sh = cw == 8 ? 3 : 2;
+  const bool in_win = ipx >= W.cx0 && ipy >= W.cy0 && ipx + cw + 1 <= W.cx0 + WH_CWIN_STRIDE && ipy + ch + 1 <= W.cy0 + WH_CWIN_ROWS;
+  if (in_win) {
+    const int wo = (ipy - W.cy0) * WH_CWIN_STRIDE + ipx - W.cx0;
+    WV_LANES_BEGIN (lane)
+    for (int i = lane; i < 2 * n; i += 64) {
+      const int pl = i >= n, k = i - pl * n, x = k & (cw - 1), y = k >> sh;
+      const uint8_t* p = &S.cwin[pl][wo + y * WH_CWIN_STRIDE + x];
+      dst[pl * 64 + (cy + y) * 8 + cx + x] = (uint8_t)wh_mc_chroma_w (p[0], p[1], p[WH_CWIN_STRIDE], p[WH_CWIN_STRIDE + 1], dx, dy);
+    }
+    WV_LANES_END
+  } else {
+    WV_LANES_BEGIN (lane)
+    for (int i = lane; i < 2 * n; i += 64) {
+      const int pl = i >= n, k = i - pl * n, x = k & (cw - 1), y = k >> sh;
+      const WH_G uint8_t* p = (const WH_G uint8_t*)J.ref[1 + pl] + (ptrdiff_t) (ipy + y) * P.rec_stride_c + ipx + x;
+      dst[pl * 64 + (cy + y) * 8 + cx + x] = (uint8_t)wh_mc_chroma_w (p[0], p[1], p[P.rec_stride_c], p[P.rec_stride_c + 1], dx, dy);
+    }
+    WV_LANES_END
   }
-  WV_LANES_END
 }
 
 // ---- motion vector prediction on the 5x6 cache ----------------------------------------------------
@@ -221,10 +304,24 @@ WH_FN void wh_pred_skip_mv (const WhInterLds& S, int* mx, int* my) {
 WH_FN void wh_cache_set (WhInterLds& S, int bx, int by, int w, int h, int ref, int mx, int my) {
   WV_LANES_BEGIN (lane)
   if (lane < w * h) {
-    const int i = wh_cidx (bx + lane % w, by + lane / w);
+    const int i = wh_cidx (bx + (lane & (w - 1)), by + (w == 4 ? lane >> 2 : lane >> 1));
     S.refc[i] = (int8_t)ref; S.mvc[i][0] = (int16_t)mx; S.mvc[i][1] = (int16_t)my;
   }
   WV_LANES_END
+}
+
+// ---- partition slots ----------------------------------------------------------------------------------
+WH_FN void wh_slot_geom (int slot, int* bx, int* by, int* bw, int* bh) {
+  if (slot == 0) { *bx = 0; *by = 0; *bw = 16; *bh = 16; }
+  else if (slot < WH_SLOT_16x8) { const int i = slot - WH_SLOT_8x8; *bx = (i & 1) * 8; *by = (i >> 1) * 8; *bw = 8; *bh = 8; }
+  else if (slot < WH_SLOT_8x16) { const int i = slot - WH_SLOT_16x8; *bx = 0; *by = i * 8; *bw = 16; *bh = 8; }
+  else { const int i = slot - WH_SLOT_8x16; *bx = i * 8; *by = 0; *bw = 8; *bh = 16; }
+}
+WH_FN void wh_slot_pred (const WhInterLds& S, int slot, int* mx, int* my) {
+  if (slot == 0) wh_pred_mv (S, 0, 0, 4, 0, mx, my);
+  else if (slot < WH_SLOT_16x8) { const int i = slot - WH_SLOT_8x8; wh_pred_mv (S, (i & 1) * 2, (i >> 1) * 2, 2, 0, mx, my); }
+  else if (slot < WH_SLOT_8x16) wh_pred_16x8 (S, slot - WH_SLOT_16x8, 0, mx, my);
+  else wh_pred_8x16 (S, slot - WH_SLOT_8x16, 0, mx, my);
 }
 
 // ---- one motion search (WelsMotionEstimateSearch) -------------------------------------------------
@@ -235,7 +332,6 @@ typedef struct WhMe {
   int mvx, mvy;              // result (quarter-pel)
   int sad_cost, satd_cost;   // uiSadCost / uiSatdCost
   int satd_raw;              // uSadPredISatd.uiSatd (complexity >= MEDIUM)
-  int ox, oy;                // window origin of the last load
 } WhMe;
 
 typedef struct WhMeCtx {
@@ -243,46 +339,51 @@ typedef struct WhMeCtx {
   int minx, miny, maxx, maxy;        // sMvStartMin / sMvStartMax (integer pel)
 } WhMeCtx;
 
-WH_FN int wh_sad_ref_global (const WhInterLds& S, const WhSeqParams& P, const WhPicJob& J, const WhMe& me, const WhMeCtx& C, int imx, int imy) {
-  const uint8_t* base = J.ref[0] + (ptrdiff_t) (C.mby * 16 + me.by + imy) * P.rec_stride_y + C.mbx * 16 + me.bx + imx;
-  return wh_sad_tile (S, me.bx, me.by, me.bw, me.bh, base, P.rec_stride_y);
+// SAD of the block against the reference at integer displacement (imx,imy): from the window when it is inside
+WH_FN int wh_cand_sad (const WhInterLds& S, const WhSeqParams& P, const WhPicJob& J, const WhWin& W, const WhMeCtx& C, const WhMe& me, int imx, int imy) {
+  const int px = C.mbx * 16 + me.bx + imx, py = C.mby * 16 + me.by + imy;
+  if (wh_win_covers (W, px, py, px + me.bw + 3, py + me.bh))
+    return wh_sad_win (S, me.bx, me.by, me.bw, me.bh, (py - W.y0) * WH_WIN_STRIDE + px - W.x0);
+  return wh_sad_global (S, P, J, me.bx, me.by, me.bw, me.bh, px, py);
 }
 
-WH_FN void wh_motion_search (WhInterLds& S, const WhSeqParams& P, const WhPicJob& J, const WhMeCtx& C, WhMe& me,
-                             const int16_t (*mvc_list)[2], int n_mvc) {
-  // initial point (svc_motion_estimate.cpp:222-284)
+WH_FN void wh_motion_search (WhInterLds& S, const WhSeqParams& P, const WhPicJob& J, WhWin& W, const WhMeCtx& C, WhMe& me, int n_mvc) {
+  // initial point (svc_motion_estimate.cpp:222-284); candidates beyond the predictor: S.mvcl[0..n_mvc)
   int bmx = wh_clip3 ((2 + me.mvpx) >> 2, C.minx, C.maxx), bmy = wh_clip3 ((2 + me.mvpy) >> 2, C.miny, C.maxy);
-  int best = wh_sad_ref_global (S, P, J, me, C, bmx, bmy) + wh_mvd_cost (C.lambda, bmx * 4 - me.mvpx, bmy * 4 - me.mvpy);
+  int best = wh_cand_sad (S, P, J, W, C, me, bmx, bmy) + wh_mvd_cost (C.lambda, bmx * 4 - me.mvpx, bmy * 4 - me.mvpy);
   for (int i = 0; i < n_mvc; ++i) {
-    const int cx = wh_clip3 ((2 + mvc_list[i][0]) >> 2, C.minx, C.maxx), cy = wh_clip3 ((2 + mvc_list[i][1]) >> 2, C.miny, C.maxy);
+    const int cx = wh_clip3 ((2 + S.mvcl[i][0]) >> 2, C.minx, C.maxx), cy = wh_clip3 ((2 + S.mvcl[i][1]) >> 2, C.miny, C.maxy);
     if (cx != bmx || cy != bmy) {
-      const int c = wh_sad_ref_global (S, P, J, me, C, cx, cy) + wh_mvd_cost (C.lambda, cx * 4 - me.mvpx, cy * 4 - me.mvpy);
+      const int c = wh_cand_sad (S, P, J, W, C, me, cx, cy) + wh_mvd_cost (C.lambda, cx * 4 - me.mvpx, cy * 4 - me.mvpy);
       if (c < best) { best = c; bmx = cx; bmy = cy; }
     }
   }
-  // the window serves the diamond search and the later fractional refinement
-  wh_win_load (S, P, J, C.mbx * 16 + me.bx + bmx, C.mby * 16 + me.by + bmy, me.bw, me.bh, &me.ox, &me.oy);
-  if (!(best < me.sad_pred)) {
+  const bool diamond = !(best < me.sad_pred);
+  if (diamond || C.use_satd) {
+    const int sx = C.mbx * 16 + me.bx + bmx, sy = C.mby * 16 + me.by + bmy;
+    wh_win_ensure (S, P, J, W, sx - WH_WIN_MARGIN, sy - WH_WIN_MARGIN, sx + me.bw + WH_WIN_MARGIN, sy + me.bh + WH_WIN_MARGIN);
+  }
+  if (diamond) {
     // WelsDiamondSearch (svc_motion_estimate.cpp:335-379)
     int dx = bmx * 4 - me.mvpx, dy = bmy * 4 - me.mvpy;
-    int px = C.mbx * 16 + me.bx + bmx - me.ox, py = C.mby * 16 + me.by + bmy - me.oy;     // position inside the window
+    int wo = (C.mby * 16 + me.by + bmy - W.y0) * WH_WIN_STRIDE + C.mbx * 16 + me.bx + bmx - W.x0;     // window offset of the current centre
+    const int n = (me.bw * me.bh) >> 2;
     for (int it = 0; it < 16; ++it) {
       const int cmx = (dx + me.mvpx) >> 2, cmy = (dy + me.mvpy) >> 2;
-      if (!(cmx >= C.minx && cmx < C.maxx && cmy >= C.miny && cmy < C.maxy)) continue;
-      const uint8_t* t = &S.win[py * WH_WIN_STRIDE + px];
+      if (!(cmx >= C.minx && cmx < C.maxx && cmy >= C.miny && cmy < C.maxy)) break;   // CheckMvInRange fails: nothing changes any more
       // four SADs: up, down, left, right -- two packed 16-bit partial sums per reduction
       int pud, plr;
-      const int per_row = me.bw >> 2, n = per_row * me.bh;
-      WV_SUM (pud, lane, (lane < n ? ([&] () { const int r = lane / per_row, c = (lane % per_row) * 4; const uint8_t* e = &S.m.enc_y[(me.by + r) * 16 + me.bx + c];
-                                                const uint8_t* u = t + (r - 1) * WH_WIN_STRIDE + c; const uint8_t* d = t + (r + 1) * WH_WIN_STRIDE + c;
-                                                int su = 0, sd = 0; for (int k = 0; k < 4; ++k) { su += wh_abs (e[k] - u[k]); sd += wh_abs (e[k] - d[k]); } return su | (sd << 16); }) () : 0));
-      WV_SUM (plr, lane, (lane < n ? ([&] () { const int r = lane / per_row, c = (lane % per_row) * 4; const uint8_t* e = &S.m.enc_y[(me.by + r) * 16 + me.bx + c];
-                                                const uint8_t* l = t + r * WH_WIN_STRIDE + c - 1; const uint8_t* rr = t + r * WH_WIN_STRIDE + c + 1;
-                                                int sl = 0, sr = 0; for (int k = 0; k < 4; ++k) { sl += wh_abs (e[k] - l[k]); sr += wh_abs (e[k] - rr[k]); } return sl | (sr << 16); }) () : 0));
+      WV_SUM2 (pud, plr, lane,
+               (lane < n ? ([&] () { const int r = wh_sl_row (lane, me.bw), c = wh_sl_col (lane, me.bw);
+                                     const uint32_t e = wh_enc4 (S, me.bx + c, me.by + r); const int o = wo + r * WH_WIN_STRIDE + c;
+                                     return wh_sad4 (e, wh_ld4u (S.win, o - WH_WIN_STRIDE)) | (wh_sad4 (e, wh_ld4u (S.win, o + WH_WIN_STRIDE)) << 16); }) () : 0),
+               (lane < n ? ([&] () { const int r = wh_sl_row (lane, me.bw), c = wh_sl_col (lane, me.bw);
+                                     const uint32_t e = wh_enc4 (S, me.bx + c, me.by + r); const int o = wo + r * WH_WIN_STRIDE + c;
+                                     return wh_sad4 (e, wh_ld4u (S.win, o - 1)) | (wh_sad4 (e, wh_ld4u (S.win, o + 1)) << 16); }) () : 0));
       const int c0 = (pud & 0xffff) + wh_mvd_cost (C.lambda, dx, dy - 4);
-      const int c1 = ((unsigned)pud >> 16) + wh_mvd_cost (C.lambda, dx, dy + 4);
+      const int c1 = (int) ((unsigned)pud >> 16) + wh_mvd_cost (C.lambda, dx, dy + 4);
       const int c2 = (plr & 0xffff) + wh_mvd_cost (C.lambda, dx - 4, dy);
-      const int c3 = ((unsigned)plr >> 16) + wh_mvd_cost (C.lambda, dx + 4, dy);
+      const int c3 = (int) ((unsigned)plr >> 16) + wh_mvd_cost (C.lambda, dx + 4, dy);
       const int in_cost = best;
       int ix = 0, iy = 0;
       if (c0 < best) { best = c0; ix = 0; iy = 1; }
@@ -291,103 +392,140 @@ WH_FN void wh_motion_search (WhInterLds& S, const WhSeqParams& P, const WhPicJob
       if (c3 < best) { best = c3; ix = -1; iy = 0; }
       if (best == in_cost) break;
       dx -= ix * 4; dy -= iy * 4;
-      px -= ix; py -= iy;
+      wo -= ix + iy * WH_WIN_STRIDE;
     }
     bmx = (dx + me.mvpx) >> 2; bmy = (dy + me.mvpy) >> 2;
   }
   me.mvx = bmx * 4; me.mvy = bmy * 4;
   me.sad_cost = best; me.satd_cost = best; me.satd_raw = 0;
   if (C.use_satd) {   // CalculateSatdCost (complexity >= MEDIUM)
-    const uint8_t* t = &S.win[(C.mby * 16 + me.by + bmy - me.oy) * WH_WIN_STRIDE + C.mbx * 16 + me.bx + bmx - me.ox];
-    me.satd_raw = wh_satd_tile (S, me.bx, me.by, me.bw, me.bh, t, WH_WIN_STRIDE);
+    const int wo = (C.mby * 16 + me.by + bmy - W.y0) * WH_WIN_STRIDE + C.mbx * 16 + me.bx + bmx - W.x0;
+    const int nq = (me.bw >> 2) * (me.bh >> 2) * 4;
+    WV_SATD_ROWS (me.satd_raw, lane, lane < nq,
+                  wh_enc4 (S, me.bx + (lane < nq ? wh_tl_col (lane, me.bw) : 0), me.by + (lane < nq ? wh_tl_row (lane, me.bw) : 0)),
+                  wh_ld4u (S.win, wo + (lane < nq ? wh_tl_row (lane, me.bw) * WH_WIN_STRIDE + wh_tl_col (lane, me.bw) : 0)));
     me.satd_cost = me.satd_raw + wh_mvd_cost (C.lambda, me.mvx - me.mvpx, me.mvy - me.mvpy);
   }
 }
 
+WH_FN void wh_me_store (WhInterLds& S, int slot, const WhMe& me) {
+  WV_LANES_BEGIN (lane)
+  if (lane == 0) { int32_t* q = S.me[slot]; q[0] = me.mvx; q[1] = me.mvy; q[2] = me.sad_cost; q[3] = me.satd_cost; q[4] = me.satd_raw; }
+  WV_LANES_END
+}
+WH_FN void wh_me_fetch (const WhInterLds& S, int slot, WhMe& me) {
+  const int32_t* q = S.me[slot];
+  me.mvx = q[0]; me.mvy = q[1]; me.sad_cost = q[2]; me.satd_cost = q[3]; me.satd_raw = q[4];
+}
+
 // ---- fractional refinement (MeRefineFracPixel): returns through me.mvx/mvy/satd_cost, writes the
 // final luma prediction of the block into S.m.pred_y -------------------------------------------------
-WH_FN void wh_refine_frac (WhInterLds& S, const WhSeqParams& P, const WhPicJob& J, const WhMeCtx& C, WhMe& me, int satd_in_md) {
+WH_FN void wh_refine_frac (WhInterLds& S, const WhSeqParams& P, const WhPicJob& J, WhWin& W, const WhMeCtx& C, WhMe& me, int satd_in_md) {
   const int bpx = C.mbx * 16 + me.bx, bpy = C.mby * 16 + me.by;
-  // (re)load the window around the integer result: the other partitions' searches have reused S.win
-  wh_win_load (S, P, J, bpx + (me.mvx >> 2), bpy + (me.mvy >> 2), me.bw, me.bh, &me.ox, &me.oy);
-  uint8_t* dst = &S.m.pred_y[me.by * 16 + me.bx];
-  int best;
-  if (satd_in_md) best = me.satd_raw + wh_mvd_cost (C.lambda, me.mvx - me.mvpx, me.mvy - me.mvpy);   // uiSatd of the integer search
-  else {
-    wh_mc_luma_from_win (S, me.ox, me.oy, bpx, bpy, me.mvx, me.mvy, me.bw, me.bh, S.cand, 16);
-    best = wh_satd_tile (S, me.bx, me.by, me.bw, me.bh, S.cand, 16) + wh_mvd_cost (C.lambda, me.mvx - me.mvpx, me.mvy - me.mvpy);
-  }
-  int bmx = me.mvx, bmy = me.mvy;
-  // half-pel candidates: top, bottom, left, right
-  const int hdx[4] = {0, 0, -2, 2}, hdy[4] = {-2, 2, 0, 0};
-  int hbest = -1;
-  for (int k = 0; k < 4; ++k) {
-    const int cx = me.mvx + hdx[k], cy = me.mvy + hdy[k];
-    wh_mc_luma_from_win (S, me.ox, me.oy, bpx, bpy, cx, cy, me.bw, me.bh, S.cand, 16);
-    const int c = wh_satd_tile (S, me.bx, me.by, me.bw, me.bh, S.cand, 16) + wh_mvd_cost (C.lambda, cx - me.mvpx, cy - me.mvpy);
-    if (c < best) { best = c; hbest = k; }
-  }
-  const int hx = hbest < 0 ? me.mvx : me.mvx + hdx[hbest], hy = hbest < 0 ? me.mvy : me.mvy + hdy[hbest];
-  bmx = hx; bmy = hy;
-  // quarter-pel candidates around the best half/integer position: top, bottom, left, right
-  const int qdx[4] = {0, 0, -1, 1}, qdy[4] = {-1, 1, 0, 0};
-  for (int k = 0; k < 4; ++k) {
-    const int cx = hx + qdx[k], cy = hy + qdy[k];
-    wh_mc_luma_from_win (S, me.ox, me.oy, bpx, bpy, cx, cy, me.bw, me.bh, S.cand, 16);
-    const int c = wh_satd_tile (S, me.bx, me.by, me.bw, me.bh, S.cand, 16) + wh_mvd_cost (C.lambda, cx - me.mvpx, cy - me.mvpy);
+  const int ipx = bpx + (me.mvx >> 2), ipy = bpy + (me.mvy >> 2);          // me.mv is integer-pel here
+  wh_win_ensure (S, P, J, W, ipx - 4, ipy - 4, ipx + me.bw + 8, ipy + me.bh + 5);
+  const int wo = (ipy - W.y0) * WH_WIN_STRIDE + ipx - W.x0;
+  const int nq = (me.bw >> 2) * (me.bh >> 2) * 4;
+  int best = 0x7fffffff, bmx = me.mvx, bmy = me.mvy, basex = me.mvx, basey = me.mvy;
+  // k = -1: the integer position; 0..3: half-pel top, bottom, left, right; 4..7: quarter-pel around the best so far
+  for (int k = -1; k < 8; ++k) {
+    if (k == 4) { basex = bmx; basey = bmy; }
+    int cx = basex, cy = basey;
+    if (k >= 0) {
+      const int step = k < 4 ? 2 : 1, kk = k & 3;
+      cx += kk == 2 ? -step : kk == 3 ? step : 0;
+      cy += kk == 0 ? -step : kk == 1 ? step : 0;
+    } else if (satd_in_md) {
+      best = me.satd_raw + wh_mvd_cost (C.lambda, me.mvx - me.mvpx, me.mvy - me.mvpy);   // uiSatd of the integer search
+      continue;
+    }
+    const int o = wo + ((cy >> 2) - (me.mvy >> 2)) * WH_WIN_STRIDE + (cx >> 2) - (me.mvx >> 2), fx = cx & 3, fy = cy & 3;
+    int c;
+    WV_SATD_ROWS (c, lane, lane < nq,
+                  wh_enc4 (S, me.bx + (lane < nq ? wh_tl_col (lane, me.bw) : 0), me.by + (lane < nq ? wh_tl_row (lane, me.bw) : 0)),
+                  wh_mc4 (S.win, o + (lane < nq ? wh_tl_row (lane, me.bw) * WH_WIN_STRIDE + wh_tl_col (lane, me.bw) : 0), fx, fy));
+    c += wh_mvd_cost (C.lambda, cx - me.mvpx, cy - me.mvpy);
     if (c < best) { best = c; bmx = cx; bmy = cy; }
   }
-  me.mvx = bmx; me.mvy = bmy; me.satd_cost = best;
-  wh_mc_luma_from_win (S, me.ox, me.oy, bpx, bpy, bmx, bmy, me.bw, me.bh, dst, 16);
+  me.satd_cost = best;
+  {
+    const int o = wo + ((bmy >> 2) - (me.mvy >> 2)) * WH_WIN_STRIDE + (bmx >> 2) - (me.mvx >> 2), fx = bmx & 3, fy = bmy & 3;
+    const int n = (me.bw * me.bh) >> 2;
+    WV_LANES_BEGIN (lane)
+    if (lane < n) {
+      const int r = wh_sl_row (lane, me.bw), c = wh_sl_col (lane, me.bw);
+      * (uint32_t*)&S.m.pred_y[(me.by + r) * 16 + me.bx + c] = wh_mc4 (S.win, o + r * WH_WIN_STRIDE + c, fx, fy);
+    }
+    WV_LANES_END
+  }
+  me.mvx = bmx; me.mvy = bmy;
 }
 
 // ---- inter luma residual (WelsEncInterY) on S.m.res after wh_dct_luma16; returns cbp luma -----------
-WH_FN int wh_enc_inter_y (WhMbLds& S, int qp) {
-  // quant with per-block max (inter rounding)
+// JVT-O079 single-coefficient score of a block from the 16-bit mask of its non-zero zig-zag positions
+// (encode_mb_aux.cpp:417-436 WelsGetNoneZeroCount-style run table {3,2,2,1,1,1,0...}); equals wh_single_ctr.
+WH_FN int wh_single_ctr_mask (unsigned m) {
+  int ctr = 0, run = 0;
+  for (int k = 0; k < 16; ++k) {
+    if ((m >> k) & 1u) { ctr += (run == 0) ? 3 : (run <= 2) ? 2 : (run <= 5) ? 1 : 0; run = 0; }
+    else ++run;
+  }
+  return ctr;
+}
+// quantise S.res[base + 0 .. 16*nblk) (inter rounding) into `dst`; S.part[blk] = max |level| of the block,
+// S.part2[blk] = mask of non-zero zig-zag positions (`skip_dc`: position 0 is not part of the scan)
+WH_FN void wh_quant_blocks (WhMbLds& S, int base, int nblk, int qp, int16_t* dst, int skip_dc) {
   WV_LANES_BEGIN (lane)
-  {
+  if (lane < nblk * 4) {
     int16_t mx = 0;
     for (int k = 0; k < 4; ++k) {
       const int i = lane * 4 + k, pos = i & 15;
       int16_t a;
-      S.res[i] = wh_quant1_abs (S.res[i], wh_ff_inter (qp, pos), wh_mf (qp, pos), &a);
+      dst[i] = wh_quant1_abs (S.res[base + i], wh_ff_inter (qp, pos), wh_mf (qp, pos), &a);
       if (mx < a) mx = a;
     }
-    S.part[lane] = mx;
+    S.tmp[512 + lane] = mx;
   }
   WV_LANES_END
   WV_LANES_BEGIN (lane)
-  if (lane < 16) S.amax[lane] = (int16_t)wh_max (wh_max (S.part[lane * 4], S.part[lane * 4 + 1]), wh_max (S.part[lane * 4 + 2], S.part[lane * 4 + 3]));
-  {
-    const int b = lane >> 2;
-    for (int q = 0; q < 4; ++q) { const int k = (lane & 3) * 4 + q; S.lv_luma[b * 16 + k] = S.res[b * 16 + wh_zigzag (k)]; }
+  if (lane < nblk) {
+    S.part[lane] = wh_max (wh_max (S.tmp[512 + lane * 4], S.tmp[512 + lane * 4 + 1]), wh_max (S.tmp[512 + lane * 4 + 2], S.tmp[512 + lane * 4 + 3]));
+    unsigned m = 0;
+    for (int k = skip_dc; k < 16; ++k) m |= (unsigned) (dst[lane * 16 + wh_zigzag (k)] != 0) << (k - skip_dc);
+    S.part2[lane] = (int32_t)m;
   }
   WV_LANES_END
-  int ctr8[4], ctr_mb = 0;
-  for (int i = 0; i < 4; ++i) {
-    ctr8[i] = 0;
-    for (int j = 0; j < 4; ++j) {
-      const int mx = S.amax[i * 4 + j];
-      if (mx != 0) {
-        if (mx > 1) ctr8[i] += 9;
-        else if (ctr8[i] < 6) ctr8[i] += wh_single_ctr (&S.lv_luma[(i * 4 + j) * 16]);
-      }
-    }
-    ctr_mb += ctr8[i];
-  }
+}
+
+WH_FN int wh_enc_inter_y (WhMbLds& S, int qp) {
+  wh_quant_blocks (S, 0, 16, qp, S.res, 0);
+  // per 8x8: score = sum over its four 4x4 blocks (9 when a level exceeds 1, else the run score); the reference stops
+  // adding once an 8x8 reaches 6, which cannot change the two threshold tests below
+  int s0, s1, s2, s3;
+#define WH_BSCORE(l) (S.part[l] > 1 ? 9 : S.part[l] == 1 ? wh_single_ctr_mask ((unsigned)S.part2[l]) : 0)
+  WV_SUM2 (s0, s1, lane, (lane < 4 ? WH_BSCORE (lane) : 0), (lane >= 4 && lane < 8 ? WH_BSCORE (lane) : 0));
+  WV_SUM2 (s2, s3, lane, (lane >= 8 && lane < 12 ? WH_BSCORE (lane) : 0), (lane >= 12 && lane < 16 ? WH_BSCORE (lane) : 0));
+#undef WH_BSCORE
   int cbp = 0;
-  if (ctr_mb >= 6) for (int i = 0; i < 4; ++i) if (ctr8[i] >= 4) cbp |= 1 << i;
+  if (s0 + s1 + s2 + s3 >= 6) cbp = (s0 >= 4 ? 1 : 0) | (s1 >= 4 ? 2 : 0) | (s2 >= 4 ? 4 : 0) | (s3 >= 4 ? 8 : 0);
+  WV_LANES_BEGIN (lane)
+  {
+    const int b = lane >> 2, on = (cbp >> (b >> 2)) & 1;
+    for (int q = 0; q < 4; ++q) { const int k = (lane & 3) * 4 + q; S.lv_luma[b * 16 + k] = S.res[b * 16 + wh_zigzag (k)]; }
+    if (lane < 16) {
+      int n = 0;
+      if ((cbp >> (lane >> 2)) & 1) { unsigned m = (unsigned)S.part2[lane]; while (m) { n += (int) (m & 1u); m >>= 1; } }
+      S.nzc[wh_blk_y (lane) * 4 + wh_blk_x (lane)] = (uint8_t)n;
+    }
+    (void)on;
+  }
+  WV_LANES_END
   WV_LANES_BEGIN (lane)
   {
     const int b = lane >> 2, on = (cbp >> (b >> 2)) & 1;
     for (int k = 0; k < 4; ++k) {
       const int i = lane * 4 + k, pos = i & 15;
       S.res[i] = on ? (int16_t) (S.res[i] * wh_dq (qp, pos)) : (int16_t)0;
-    }
-    if (lane < 16) {
-      int n = 0;
-      if ((cbp >> (lane >> 2)) & 1) for (int k = 0; k < 16; ++k) n += (S.lv_luma[lane * 16 + k] != 0);
-      S.nzc[wh_blk_y (lane) * 4 + wh_blk_x (lane)] = (uint8_t)n;
     }
   }
   WV_LANES_END
@@ -396,30 +534,10 @@ WH_FN int wh_enc_inter_y (WhMbLds& S, int qp) {
 
 // quant-to-zero tests of the P_Skip path (WelsTryPYskip / WelsTryPUVskip); operate on copies in S.tmp
 WH_FN bool wh_try_py_skip (WhMbLds& S, int qp) {
-  WV_LANES_BEGIN (lane)
-  {
-    int16_t mx = 0;
-    for (int k = 0; k < 4; ++k) {
-      const int i = lane * 4 + k, pos = i & 15;
-      int16_t a;
-      S.tmp[i] = wh_quant1_abs (S.res[i], wh_ff_inter (qp, pos), wh_mf (qp, pos), &a);
-      if (mx < a) mx = a;
-    }
-    S.part[lane] = mx;
-  }
-  WV_LANES_END
-  int ctr = 0;
-  for (int b = 0; b < 16; ++b) {
-    const int mx = wh_max (wh_max (S.part[b * 4], S.part[b * 4 + 1]), wh_max (S.part[b * 4 + 2], S.part[b * 4 + 3]));
-    if (mx > 1) return false;
-    if (mx == 1) {
-      int16_t lv[16];
-      for (int k = 0; k < 16; ++k) lv[k] = S.tmp[b * 16 + wh_zigzag (k)];
-      ctr += wh_single_ctr (lv);
-    }
-    if (ctr >= 6) return false;
-  }
-  return true;
+  wh_quant_blocks (S, 0, 16, qp, S.tmp, 0);
+  int big, ctr;
+  WV_SUM2 (big, ctr, lane, (lane < 16 ? (S.part[lane] > 1) : 0), (lane < 16 && S.part[lane] == 1 ? wh_single_ctr_mask ((unsigned)S.part2[lane]) : 0));
+  return big == 0 && ctr < 6;
 }
 WH_FN bool wh_try_puv_skip (WhMbLds& S, int pl, int qpc) {
   const int16_t* r = &S.res[256 + pl * 64];
@@ -429,54 +547,67 @@ WH_FN bool wh_try_puv_skip (WhMbLds& S, int pl, int qpc) {
   const int16_t s0 = (int16_t) (r[0] + r[32]), s1 = (int16_t) (r[0] - r[32]), s2 = (int16_t) (r[16] + r[48]), s3 = (int16_t) (r[16] - r[48]);
   const int16_t d0 = (int16_t) (s0 + s2), d1 = (int16_t) (s0 - s2), d2 = (int16_t) (s1 + s3), d3 = (int16_t) (s1 - s3);
   if (wh_abs (d0) > thr || wh_abs (d1) > thr || wh_abs (d2) > thr || wh_abs (d3) > thr) return false;
-  WV_LANES_BEGIN (lane)
-  if (lane < 16) {
-    int16_t mx = 0;
-    for (int k = 0; k < 4; ++k) {
-      const int i = lane * 4 + k, pos = i & 15;
-      int16_t a;
-      S.tmp[i] = wh_quant1_abs (r[i], wh_ff_inter (qpc, pos), wh_mf (qpc, pos), &a);
-      if (mx < a) mx = a;
-    }
-    S.part[lane] = mx;
-  }
-  WV_LANES_END
-  int ctr = 0;
-  for (int b = 0; b < 4; ++b) {
-    const int mx = wh_max (wh_max (S.part[b * 4], S.part[b * 4 + 1]), wh_max (S.part[b * 4 + 2], S.part[b * 4 + 3]));
-    if (mx > 1) return false;
-    if (mx == 1) {
-      int16_t lv[16];
-      for (int k = 0; k < 15; ++k) lv[k] = S.tmp[b * 16 + wh_zigzag (k + 1)];
-      lv[15] = 0;
-      ctr += wh_single_ctr (lv);
-    }
-    if (ctr >= 7) return false;
-  }
-  return true;
+  wh_quant_blocks (S, 256 + pl * 64, 4, qpc, S.tmp, 1);
+  int big, ctr;
+  WV_SUM2 (big, ctr, lane, (lane < 4 ? (S.part[lane] > 1) : 0), (lane < 4 && S.part[lane] == 1 ? wh_single_ctr_mask ((unsigned)S.part2[lane]) : 0));
+  return big == 0 && ctr < 7;
 }
 
 // ---- the P macroblock -----------------------------------------------------------------------------
 WH_FN void wh_inter_mb_body (WhInterLds& S, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby) {
   WhMbLds& M = S.m;
   const int w = P.mb_w, xy = mby * w + mbx;
-  const int avail = wh_mb_avail (P, mbx, mby);
+  const int slice_idc = wh_slice_of_mb (P, xy);
+  const int avail = wh_mb_avail_in_slice (P, mbx, mby, P.slice_first_mb[slice_idc]);
   const int qp = wh_clip3 (J.qp, 0, 51);
   const int qpc = kWhChromaQp[wh_clip3 (qp + P.chroma_qp_offset, 0, 51)];
   const int lambda = kWhLambda[qp];
   const int use_satd = P.complexity > 0;        // pfMdCost == SATD, pfCalculateSatd == CalculateSatdCost
   const bool md_using_sad = !use_satd;          // bMdUsingSad (svc_encode_slice.cpp:699)
-  const int slice_idc = wh_slice_of_mb (P, xy);
+  const bool ref_is_p = J.ref_is_p != 0;
   WH_PROF_DECL (P);
-  wh_load_mb_tile (M, P, J, mbx, mby);
+
+  // ---- batch 1: source tile, neighbour pixels, previous source tile, neighbour + co-located MB states ----
+  WV_LANES_BEGIN (lane)
+  {
+    WhTileRegs tr;
+    wh_tile_fetch (lane, P, J, mbx, mby, &tr);
+    uint32_t pv = 0, st[3] = {0, 0, 0}, cm = 0;
+    if (md_using_sad)
+      pv = * (const WH_G uint32_t*) ((const WH_G uint8_t*)J.prev_src_y + (size_t) (mby * 16 + (lane >> 2)) * P.src_stride_y + mbx * 16 + (lane & 3) * 4);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int i = lane + 64 * k, n = i / 36, wd = i - n * 36;           // state n (0 TL, 1 T, 2 TR, 3 L, 4 co-located), dword wd
+      if (i < 180) {
+        const bool ok = n == 0 ? (avail & WH_AV_TOPLEFT) != 0 : n == 1 ? (avail & WH_AV_TOP) != 0 : n == 2 ? (avail & WH_AV_TOPRIGHT) != 0 :
+                        n == 3 ? (avail & WH_AV_LEFT) != 0 : ref_is_p;
+        const int off = n == 0 ? -w - 1 : n == 1 ? -w : n == 2 ? -w + 1 : n == 3 ? -1 : 0;
+        const WH_G WhMbState* base = n == 4 ? (const WH_G WhMbState*)J.ref_mbs : (const WH_G WhMbState*)J.mbs;
+        if (ok) st[k] = ((const WH_G uint32_t*) (base + xy + off))[wd];
+      }
+    }
+    if (ref_is_p && lane < 2) {
+      const bool ok = lane == 0 ? mbx < P.mb_w - 1 : mby < P.mb_h - 1;
+      const WH_G WhMbState* o = (const WH_G WhMbState*)J.ref_mbs + xy + (lane == 0 ? 1 : w);
+      if (ok) cm = * (const WH_G uint32_t*)&o->p16mv[0];
+    }
+    wh_tile_commit (M, lane, &tr);
+    * (uint32_t*)&S.prev_y[lane * 4] = pv;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { const int i = lane + 64 * k; if (i < 180) S.nb[0][i] = st[k]; }
+    if (lane < 2) * (uint32_t*)&S.co_mv[lane][0] = cm;
+  }
+  WV_LANES_END
 
   // ---- neighbour cache (FillNeighborCacheInterWithoutBGD) ----
-  const WhMbState* Lm = (avail & WH_AV_LEFT) ? &J.mbs[xy - 1] : nullptr;
-  const WhMbState* Tm = (avail & WH_AV_TOP) ? &J.mbs[xy - w] : nullptr;
-  const WhMbState* TLm = (avail & WH_AV_TOPLEFT) ? &J.mbs[xy - w - 1] : nullptr;
-  const WhMbState* TRm = (avail & WH_AV_TOPRIGHT) ? &J.mbs[xy - w + 1] : nullptr;
-  const bool l_inter = Lm && WH_IS_INTER (Lm->mb_type), t_inter = Tm && WH_IS_INTER (Tm->mb_type);
-  const bool tl_inter = TLm && WH_IS_INTER (TLm->mb_type), tr_inter = TRm && WH_IS_INTER (TRm->mb_type);
+  const WhMbState* TLm = (avail & WH_AV_TOPLEFT) ? (const WhMbState*)S.nb[0] : nullptr;
+  const WhMbState* Tm = (avail & WH_AV_TOP) ? (const WhMbState*)S.nb[1] : nullptr;
+  const WhMbState* TRm = (avail & WH_AV_TOPRIGHT) ? (const WhMbState*)S.nb[2] : nullptr;
+  const WhMbState* Lm = (avail & WH_AV_LEFT) ? (const WhMbState*)S.nb[3] : nullptr;
+  const WhMbState* Co = (const WhMbState*)S.nb[4];
+  const int tl_type = TLm ? TLm->mb_type : WH_MB_NONE, t_type = Tm ? Tm->mb_type : WH_MB_NONE;
+  const int tr_type = TRm ? TRm->mb_type : WH_MB_NONE, l_type = Lm ? Lm->mb_type : WH_MB_NONE;
+  const bool l_inter = WH_IS_INTER (l_type), t_inter = WH_IS_INTER (t_type), tl_inter = WH_IS_INTER (tl_type), tr_inter = WH_IS_INTER (tr_type);
   WV_LANES_BEGIN (lane)
   if (lane < 30) {
     const int r = lane / 6, c = lane % 6;
@@ -490,32 +621,29 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, const WhSeqParams& P, const WhPicJob
   }
   WV_LANES_END
   // neighbour SAD / skip context, order of the reference's caches: [0] top-left, [1] top, [2] top-right, [3] left
-  int sadc[4], skc[4], sadsk[4];
-  {
-    const WhMbState* nb[4] = {TLm, Tm, TRm, Lm};
-    const bool ni[4] = {tl_inter, t_inter, tr_inter, l_inter};
-    for (int k = 0; k < 4; ++k) {
-      sadc[k] = ni[k] ? nb[k]->sad_cost[0] : 0;
-      skc[k] = (ni[k] && nb[k]->mb_type == WH_MB_PSKIP) ? 1 : 0;
-      sadsk[k] = skc[k] ? nb[k]->skip_sad : 0;
-    }
-  }
-  const bool ref_is_p = J.ref_is_p != 0;
-  const int ref_mb_type = ref_is_p ? J.ref_mbs[xy].mb_type : WH_MB_NONE;
+  const int sadc0 = tl_inter ? TLm->sad_cost[0] : 0, sadc1 = t_inter ? Tm->sad_cost[0] : 0, sadc2 = tr_inter ? TRm->sad_cost[0] : 0, sadc3 = l_inter ? Lm->sad_cost[0] : 0;
+  const bool tl_sk = tl_type == WH_MB_PSKIP, t_sk = t_type == WH_MB_PSKIP, tr_sk = tr_type == WH_MB_PSKIP, l_sk = l_type == WH_MB_PSKIP;
+  const int sadsk0 = tl_sk ? TLm->skip_sad : 0, sadsk1 = t_sk ? Tm->skip_sad : 0, sadsk2 = tr_sk ? TRm->skip_sad : 0, sadsk3 = l_sk ? Lm->skip_sad : 0;
+  const int ref_mb_type = ref_is_p ? Co->mb_type : WH_MB_NONE;
   WhMeCtx C;
   C.mbx = mbx; C.mby = mby; C.lambda = lambda; C.use_satd = use_satd;
   C.minx = wh_max (- ((mbx + 1) << 4) + 3, -P.mv_range); C.miny = wh_max (- ((mby + 1) << 4) + 3, -P.mv_range);
   C.maxx = wh_min (((P.mb_w - mbx) << 4) - 3, P.mv_range); C.maxy = wh_min (((P.mb_h - mby) << 4) - 3, P.mv_range);
 
-  WH_PROF_MARK (P, 0);   // tile + neighbour cache
+  // ---- batch 2: reference windows centred on the 16x16 predictor (= the search's initial point) ----
+  WhMe me16;
+  me16.bx = 0; me16.by = 0; me16.bw = 16; me16.bh = 16;
+  wh_pred_mv (S, 0, 0, 4, 0, &me16.mvpx, &me16.mvpy);
+  WhWin W;
+  wh_win_load_all (S, P, J, W, mbx * 16 + wh_clip3 ((2 + me16.mvpx) >> 2, C.minx, C.maxx), mby * 16 + wh_clip3 ((2 + me16.mvpy) >> 2, C.miny, C.maxy));
+
+  WH_PROF_MARK (P, 0);   // loads + neighbour cache
   int mb_type = WH_MB_P16x16, cbp = 0, cost_luma = 0, cost_skip_mb = 0, sad_cost0 = 0;
   int p16x = 0, p16y = 0;                       // sP16x16Mv
   int skx = 0, sky = 0;
   bool done = false;
 
   // ---- P_Skip test (WelsMdInterJudgePskip / WelsMdPSkipEnc) ----
-  const bool l_sk = Lm && Lm->mb_type == WH_MB_PSKIP, t_sk = Tm && Tm->mb_type == WH_MB_PSKIP;
-  const bool tl_sk = TLm && TLm->mb_type == WH_MB_PSKIP, tr_sk = TRm && TRm->mb_type == WH_MB_PSKIP;
   const bool try_skip = l_sk || t_sk || tl_sk || tr_sk;
   const bool keep_skip = l_sk && t_sk && tr_sk;
   bool b_skip = false;
@@ -525,31 +653,29 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, const WhSeqParams& P, const WhPicJob
     {
       const int rb = S.refc[1], ra = S.refc[6];
       int rc = S.refc[5];
-      const int sb = skc[1] ? sadsk[1] : 0, sa = skc[3] ? sadsk[3] : 0;
-      int sc = skc[2] ? sadsk[2] : 0, skip_c = skc[2];
-      if (rc == WH_REF_NOT_AVAIL) { rc = S.refc[0]; sc = skc[0] ? sadsk[0] : 0; skip_c = skc[0]; }
+      const int sb = sadsk1, sa = sadsk3;
+      int sc = sadsk2, skip_c = tr_sk;
+      if (rc == WH_REF_NOT_AVAIL) { rc = S.refc[0]; sc = sadsk0; skip_c = tl_sk; }
       if (rb == WH_REF_NOT_AVAIL && rc == WH_REF_NOT_AVAIL && ra != WH_REF_NOT_AVAIL) sad_pred_skip = sa;
       else {
-        const int cnt = ((0 == ra) && skc[3]) | (((0 == rb) && skc[1]) << 1) | (((0 == rc) && skip_c) << 2);
+        const int cnt = ((0 == ra) && l_sk) | (((0 == rb) && t_sk) << 1) | (((0 == rc) && skip_c) << 2);
         sad_pred_skip = cnt == 1 ? sa : cnt == 2 ? sb : cnt == 4 ? sc : wh_median3 (sa, sb, sc);
       }
     }
     wh_pred_skip_mv (S, &skx, &sky);
     const int nx = (mbx << 4) + (skx >> 2), ny = (mby << 4) + (sky >> 2);
     if (!(nx < -29 || nx > (P.mb_w << 4) + 12 || ny < -29 || ny > (P.mb_h << 4) + 12)) {
-      wh_mc_luma_from_ref (P, J, mbx * 16, mby * 16, skx, sky, S.skip_y);
-      wh_mc_chroma (P, J, mbx, mby, 0, 0, 8, 8, skx, sky, S.skip_c);
-      const int sad_l = wh_sad_tile (S, 0, 0, 16, 16, S.skip_y, 16);
-      int sad_c;
-      WV_SUM (sad_c, lane, (lane < 32 ? (wh_abs (M.enc_c[lane * 4] - S.skip_c[lane * 4]) + wh_abs (M.enc_c[lane * 4 + 1] - S.skip_c[lane * 4 + 1]) +
-                                          wh_abs (M.enc_c[lane * 4 + 2] - S.skip_c[lane * 4 + 2]) + wh_abs (M.enc_c[lane * 4 + 3] - S.skip_c[lane * 4 + 3])) : 0));
+      wh_mc_luma_to (S, P, J, W, mbx, mby, 0, 0, 16, 16, skx, sky, S.skip_y);
+      wh_mc_chroma_to (S, P, J, W, mbx, mby, 0, 0, 8, 8, skx, sky, S.skip_c);
+      const int sad_l = wh_sad_mb_tile (S, S.skip_y);
+      const int sad_c = wh_sad_chroma_tile (S, S.skip_c);
       const int sad_mb = sad_l + sad_c;
-      bool ok = sad_mb == 0 || sad_mb < sad_pred_skip || (ref_is_p && ref_mb_type == WH_MB_PSKIP && sad_mb < J.ref_mbs[xy].skip_sad);
+      bool ok = sad_mb == 0 || sad_mb < sad_pred_skip || (ref_is_p && ref_mb_type == WH_MB_PSKIP && sad_mb < Co->skip_sad);
       if (!ok) {
         // residual would quantise to nothing?  (WelsDctMb + WelsTryPYskip + WelsTryPUVskip)
         WV_LANES_BEGIN (lane)
-        for (int k = 0; k < 4; ++k) M.pred_y[lane * 4 + k] = S.skip_y[lane * 4 + k];
-        if (lane < 32) for (int k = 0; k < 4; ++k) M.pred_c[lane * 4 + k] = S.skip_c[lane * 4 + k];
+        * (uint32_t*)&M.pred_y[lane * 4] = * (const uint32_t*)&S.skip_y[lane * 4];
+        if (lane < 32) * (uint32_t*)&M.pred_c[lane * 4] = * (const uint32_t*)&S.skip_c[lane * 4];
         WV_LANES_END
         wh_dct_luma16 (M);
         if (wh_try_py_skip (M, qp)) {
@@ -559,9 +685,10 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, const WhSeqParams& P, const WhPicJob
       }
       if (ok) {
         b_skip = true;
-        cost_luma = md_using_sad ? sad_l : wh_satd_tile (S, 0, 0, 16, 16, S.skip_y, 16);
+        if (md_using_sad) cost_luma = sad_l;
+        else WV_SATD_ROWS (cost_luma, lane, true, wh_enc4 (S, wh_tl_col (lane, 16), wh_tl_row (lane, 16)), * (const uint32_t*)&S.skip_y[wh_tl_row (lane, 16) * 16 + wh_tl_col (lane, 16)]);
         // pSadCost[0] is only refreshed when bMdUsingSad; otherwise the SMB entry keeps the previous frame's value
-        sad_cost0 = md_using_sad ? sad_l : J.ref_mbs[xy].sad_cost[0];
+        sad_cost0 = md_using_sad ? sad_l : Co->sad_cost[0];
         cost_skip_mb = sad_mb;
         p16x = skx; p16y = sky;
       }
@@ -570,41 +697,42 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, const WhSeqParams& P, const WhPicJob
   if (b_skip && keep_skip) { mb_type = WH_MB_PSKIP; done = true; }
   WH_PROF_MARK (P, 1);   // P_Skip test
 
-  WhMe me16;
+  int sad_pred16 = 0;
   if (!done && !b_skip) {
     // PredictSad (md.cpp:826-870)
     int sad_pred;
     {
       const int rb = S.refc[1], ra = S.refc[6];
-      int rc = S.refc[5], sc = sadc[2];
-      if (rc == WH_REF_NOT_AVAIL) { rc = S.refc[0]; sc = sadc[0]; }
-      if (rb == WH_REF_NOT_AVAIL && rc == WH_REF_NOT_AVAIL && ra != WH_REF_NOT_AVAIL) sad_pred = sadc[3];
+      int rc = S.refc[5], sc = sadc2;
+      if (rc == WH_REF_NOT_AVAIL) { rc = S.refc[0]; sc = sadc0; }
+      if (rb == WH_REF_NOT_AVAIL && rc == WH_REF_NOT_AVAIL && ra != WH_REF_NOT_AVAIL) sad_pred = sadc3;
       else {
         const int cnt = (0 == ra) | ((0 == rb) << 1) | ((0 == rc) << 2);
-        sad_pred = cnt == 1 ? sadc[3] : cnt == 2 ? sadc[1] : cnt == 4 ? sc : wh_median3 (sadc[3], sadc[1], sc);
+        sad_pred = cnt == 1 ? sadc3 : cnt == 2 ? sadc1 : cnt == 4 ? sc : wh_median3 (sadc3, sadc1, sc);
       }
       const int v = sad_pred << 6;
       sad_pred = ((v - (v >> 3) + (v >> 5)) + 32) >> 6;
     }
     // ---- P16x16 (WelsMdP16x16): candidates = base (0), left/top P16x16 mv, co-located right/below of the ref ----
-    int16_t mvcl[5][2];
-    int nm = 0;
-    mvcl[nm][0] = 0; mvcl[nm][1] = 0; ++nm;
-    if (Lm) { mvcl[nm][0] = Lm->p16mv[0]; mvcl[nm][1] = Lm->p16mv[1]; ++nm; }
-    if (Tm) { mvcl[nm][0] = Tm->p16mv[0]; mvcl[nm][1] = Tm->p16mv[1]; ++nm; }
-    if (ref_is_p) {
-      if (mbx < P.mb_w - 1) { mvcl[nm][0] = J.ref_mbs[xy + 1].p16mv[0]; mvcl[nm][1] = J.ref_mbs[xy + 1].p16mv[1]; ++nm; }
-      if (mby < P.mb_h - 1) { mvcl[nm][0] = J.ref_mbs[xy + w].p16mv[0]; mvcl[nm][1] = J.ref_mbs[xy + w].p16mv[1]; ++nm; }
+    int nm = 1;
+    const bool c_l = Lm != nullptr, c_t = Tm != nullptr, c_r = ref_is_p && mbx < P.mb_w - 1, c_b = ref_is_p && mby < P.mb_h - 1;
+    const int i_l = 1, i_t = i_l + (c_l ? 1 : 0), i_r = i_t + (c_t ? 1 : 0), i_b = i_r + (c_r ? 1 : 0);
+    nm = i_b + (c_b ? 1 : 0);
+    WV_LANES_BEGIN (lane)
+    if (lane == 0) {
+      S.mvcl[0][0] = 0; S.mvcl[0][1] = 0;
+      if (c_l) { S.mvcl[i_l][0] = Lm->p16mv[0]; S.mvcl[i_l][1] = Lm->p16mv[1]; }
+      if (c_t) { S.mvcl[i_t][0] = Tm->p16mv[0]; S.mvcl[i_t][1] = Tm->p16mv[1]; }
+      if (c_r) { S.mvcl[i_r][0] = S.co_mv[0][0]; S.mvcl[i_r][1] = S.co_mv[0][1]; }
+      if (c_b) { S.mvcl[i_b][0] = S.co_mv[1][0]; S.mvcl[i_b][1] = S.co_mv[1][1]; }
     }
-    me16.bx = 0; me16.by = 0; me16.bw = 16; me16.bh = 16; me16.sad_pred = sad_pred;
-    wh_pred_mv (S, 0, 0, 4, 0, &me16.mvpx, &me16.mvpy);
-    wh_motion_search (S, P, J, C, me16, mvcl, nm);
+    WV_LANES_END
+    me16.sad_pred = sad_pred;
+    wh_motion_search (S, P, J, W, C, me16, nm);
     p16x = me16.mvx; p16y = me16.mvy;
     cost_luma = me16.satd_cost;
     mb_type = WH_MB_P16x16;
-
-    // remember sad_pred for the partitions below
-    me16.sad_pred = sad_pred;
+    sad_pred16 = sad_pred;
   }
 
   WH_PROF_MARK (P, 2);   // P16x16 motion search
@@ -618,147 +746,93 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, const WhSeqParams& P, const WhPicJob
   if (!done && b_skip) { mb_type = WH_MB_PSKIP; done = true; }
   WH_PROF_MARK (P, 3);   // I16x16 test (+ intra encode when intra wins)
 
-  int sub_type[4] = {0, 0, 0, 0};
   if (!done) {
-    // ---- fine partitions ----
-    WhMe me8[4], me168[2], me816[2];
-    const int zero_mvc[1][2] = {{0, 0}};
-    const int16_t zmv[1][2] = {{0, 0}};
-    (void)zero_mvc;
-    auto do_p8x8 = [&] () {
-      int c = 0;
-      for (int i = 0; i < 4; ++i) {
-        WhMe& m = me8[i];
-        m.bx = (i & 1) * 8; m.by = (i >> 1) * 8; m.bw = 8; m.bh = 8; m.sad_pred = me16.sad_pred >> 2;
-        wh_pred_mv (S, (i & 1) * 2, (i >> 1) * 2, 2, 0, &m.mvpx, &m.mvpy);
-        wh_motion_search (S, P, J, C, m, zmv, 1);
-        wh_cache_set (S, (i & 1) * 2, (i >> 1) * 2, 2, 2, 0, m.mvx, m.mvy);
-        c += m.satd_cost;
-      }
-      return c;
-    };
-    auto do_p16x8 = [&] () {
-      int c = 0;
-      for (int i = 0; i < 2; ++i) {
-        WhMe& m = me168[i];
-        m.bx = 0; m.by = i * 8; m.bw = 16; m.bh = 8; m.sad_pred = me16.sad_pred >> 1;
-        wh_pred_16x8 (S, i, 0, &m.mvpx, &m.mvpy);
-        wh_motion_search (S, P, J, C, m, zmv, 1);
-        wh_cache_set (S, 0, i * 2, 4, 2, 0, m.mvx, m.mvy);
-        c += m.satd_cost;
-      }
-      return c;
-    };
-    auto do_p8x16 = [&] () {
-      int c = 0;
-      for (int i = 0; i < 2; ++i) {
-        WhMe& m = me816[i];
-        m.bx = i * 8; m.by = 0; m.bw = 8; m.bh = 16; m.sad_pred = me16.sad_pred >> 1;
-        wh_pred_8x16 (S, i, 0, &m.mvpx, &m.mvpy);
-        wh_motion_search (S, P, J, C, m, zmv, 1);
-        wh_cache_set (S, i * 2, 0, 2, 4, 0, m.mvx, m.mvy);
-        c += m.satd_cost;
-      }
-      return c;
-    };
-    int best_cost = cost_luma;
+    // ---- fine partitions: groups of searches (8x8 x4, 16x8 x2, 8x16 x2), results kept in S.me[slot] ----
+    wh_me_store (S, WH_SLOT_16x16, me16);
+    int order0 = -1, order1 = -1, order2 = -1;      // group ids: 0 = 8x8, 1 = 16x8, 2 = 8x16
+    bool chain = false;                             // later groups only run when the first one beat the 16x16 cost
     if (!use_satd) {
       // WelsMdInterFinePartitionVaa: partition set chosen from the sign pattern of the four 8x8 SADs
       // between this source MB and the previous source frame (VAACalcSad_c + MdInterAnalysisVaaInfo_c)
-      int s8[4];
-      for (int k = 0; k < 4; ++k) {
-        const int ex = (k & 1) * 8, ey = (k >> 1) * 8;
-        const uint8_t* pv = J.prev_src_y + (size_t) (mby * 16 + ey) * P.src_stride_y + mbx * 16 + ex;
-        s8[k] = wh_sad_tile (S, ex, ey, 8, 8, pv, P.src_stride_y);
-      }
+      int p01, p23;
+      WV_SUM2 (p01, p23, lane,
+               (lane < 32 ? (wh_sad4 (* (const uint32_t*)&M.enc_y[lane * 4], * (const uint32_t*)&S.prev_y[lane * 4]) << ((lane & 2) ? 16 : 0)) : 0),
+               (lane >= 32 ? (wh_sad4 (* (const uint32_t*)&M.enc_y[lane * 4], * (const uint32_t*)&S.prev_y[lane * 4]) << ((lane & 2) ? 16 : 0)) : 0));
+      const int s8_0 = p01 & 0xffff, s8_1 = (int) ((unsigned)p01 >> 16), s8_2 = p23 & 0xffff, s8_3 = (int) ((unsigned)p23 >> 16);
       int sign = 15;
       {
-        const int avg = (s8[0] + s8[1] + s8[2] + s8[3]) >> 2;
-        int var = 0;
-        for (int k = 0; k < 4; ++k) { const int d = (s8[k] >> 6) - (avg >> 6); var += d * d; }
-        if (var >= 20) sign = ((s8[0] > avg) << 3) | ((s8[1] > avg) << 2) | ((s8[2] > avg) << 1) | (s8[3] > avg);
+        const int avg = (s8_0 + s8_1 + s8_2 + s8_3) >> 2;
+        const int d0 = (s8_0 >> 6) - (avg >> 6), d1 = (s8_1 >> 6) - (avg >> 6), d2 = (s8_2 >> 6) - (avg >> 6), d3 = (s8_3 >> 6) - (avg >> 6);
+        if (d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3 >= 20) sign = ((s8_0 > avg) << 3) | ((s8_1 > avg) << 2) | ((s8_2 > avg) << 1) | (s8_3 > avg);
       }
-      if (sign != 15) {
-        if (sign == 3 || sign == 12) { const int c = do_p16x8(); if (c < best_cost) { best_cost = c; mb_type = WH_MB_P16x8; } }
-        else if (sign == 5 || sign == 10) { const int c = do_p8x16(); if (c < best_cost) { best_cost = c; mb_type = WH_MB_P8x16; } }
-        else if (sign == 6 || sign == 9) { const int c = do_p8x8(); if (c < best_cost) { best_cost = c; mb_type = WH_MB_P8x8; } }
-        else {
-          const int c8 = do_p8x8();
-          if (c8 < best_cost) {
-            best_cost = c8; mb_type = WH_MB_P8x8;
-            const int c1 = do_p16x8(); if (c1 <= best_cost) { best_cost = c1; mb_type = WH_MB_P16x8; }
-            const int c2 = do_p8x16(); if (c2 <= best_cost) { best_cost = c2; mb_type = WH_MB_P8x16; }
-          }
-        }
-        cost_luma = best_cost;
-      }
+      if (sign == 3 || sign == 12) order0 = 1;
+      else if (sign == 5 || sign == 10) order0 = 2;
+      else if (sign == 6 || sign == 9) order0 = 0;
+      else if (sign != 15) { order0 = 0; order1 = 1; order2 = 2; chain = true; }
     } else {
-      // WelsMdInterFinePartition
-      int c = do_p8x8();
-      if (c < best_cost) {
-        mb_type = WH_MB_P8x8;
-        const int c1 = do_p16x8(); if (c1 <= c) { c = c1; mb_type = WH_MB_P16x8; }
-        const int c2 = do_p8x16(); if (c2 <= c) { c = c2; mb_type = WH_MB_P8x16; }
+      order0 = 0; order1 = 1; order2 = 2; chain = true;     // WelsMdInterFinePartition
+    }
+    int best_cost = cost_luma;
+    for (int oi = 0; oi < 3; ++oi) {
+      const int g = oi == 0 ? order0 : oi == 1 ? order1 : order2;
+      if (g < 0) break;
+      const int first = g == 0 ? WH_SLOT_8x8 : g == 1 ? WH_SLOT_16x8 : WH_SLOT_8x16, cnt = g == 0 ? 4 : 2;
+      int c = 0;
+      for (int i = 0; i < cnt; ++i) {
+        WhMe m;
+        wh_slot_geom (first + i, &m.bx, &m.by, &m.bw, &m.bh);
+        m.sad_pred = g == 0 ? sad_pred16 >> 2 : sad_pred16 >> 1;
+        wh_slot_pred (S, first + i, &m.mvpx, &m.mvpy);
+        WV_LANES_BEGIN (lane)
+        if (lane == 0) { S.mvcl[0][0] = 0; S.mvcl[0][1] = 0; }
+        WV_LANES_END
+        wh_motion_search (S, P, J, W, C, m, 1);
+        wh_cache_set (S, m.bx >> 2, m.by >> 2, m.bw >> 2, m.bh >> 2, 0, m.mvx, m.mvy);
+        wh_me_store (S, first + i, m);
+        c += m.satd_cost;
       }
+      if (oi == 0) {
+        if (c < best_cost) { best_cost = c; mb_type = g == 0 ? WH_MB_P8x8 : g == 1 ? WH_MB_P16x8 : WH_MB_P8x16; }
+        else if (chain) break;
+      } else if (c <= best_cost) { best_cost = c; mb_type = g == 1 ? WH_MB_P16x8 : WH_MB_P8x16; }
     }
 
     WH_PROF_MARK (P, 4);   // fine partitions
     // ---- refinement (WelsMdInterMbRefinement) ----
     const int satd_in_md = use_satd;     // bSatdInMdFlag: pfMeCost == pfMdCost == SATD
     int best_sad = 0, best_satd = 0;
-    auto put_mv = [&] (int bx4, int by4, int w4, int h4, int mvx, int mvy, int px, int py) {
-      WV_LANES_BEGIN (lane)
-      if (lane < w4 * h4) {
-        const int r = (by4 + lane / w4) * 4 + bx4 + lane % w4;
-        S.mv_out[r][0] = (int16_t)mvx; S.mv_out[r][1] = (int16_t)mvy; S.mvp_out[r][0] = (int16_t)px; S.mvp_out[r][1] = (int16_t)py;
-      }
-      WV_LANES_END
-    };
-    if (mb_type == WH_MB_P16x16) {
-      wh_refine_frac (S, P, J, C, me16, satd_in_md);
-      wh_cache_set (S, 0, 0, 4, 4, 0, me16.mvx, me16.mvy);
-      put_mv (0, 0, 4, 4, me16.mvx, me16.mvy, me16.mvpx, me16.mvpy);
-      best_sad = me16.sad_cost; best_satd = me16.satd_cost;
-      wh_mc_chroma (P, J, mbx, mby, 0, 0, 8, 8, me16.mvx, me16.mvy, M.pred_c);
-      // iCostSkipMb of a 16x16 MB = SAD of its final prediction (luma + chroma)
-      const int sl = wh_sad_tile (S, 0, 0, 16, 16, M.pred_y, 16);
-      int sc;
-      WV_SUM (sc, lane, (lane < 32 ? (wh_abs (M.enc_c[lane * 4] - M.pred_c[lane * 4]) + wh_abs (M.enc_c[lane * 4 + 1] - M.pred_c[lane * 4 + 1]) +
-                                       wh_abs (M.enc_c[lane * 4 + 2] - M.pred_c[lane * 4 + 2]) + wh_abs (M.enc_c[lane * 4 + 3] - M.pred_c[lane * 4 + 3])) : 0));
-      cost_skip_mb = sl + sc;
-    } else if (mb_type == WH_MB_P16x8) {
-      for (int i = 0; i < 2; ++i) {
-        WhMe& m = me168[i];
-        wh_pred_16x8 (S, i, 0, &m.mvpx, &m.mvpy);
-        wh_refine_frac (S, P, J, C, m, satd_in_md);
-        wh_cache_set (S, 0, i * 2, 4, 2, 0, m.mvx, m.mvy);
-        put_mv (0, i * 2, 4, 2, m.mvx, m.mvy, m.mvpx, m.mvpy);
-        best_sad += m.sad_cost; best_satd += m.satd_cost;
-        wh_mc_chroma (P, J, mbx, mby, 0, i * 4, 8, 4, m.mvx, m.mvy, M.pred_c);
-      }
-    } else if (mb_type == WH_MB_P8x16) {
-      for (int i = 0; i < 2; ++i) {
-        WhMe& m = me816[i];
-        wh_pred_8x16 (S, i, 0, &m.mvpx, &m.mvpy);
-        wh_refine_frac (S, P, J, C, m, satd_in_md);
-        wh_cache_set (S, i * 2, 0, 2, 4, 0, m.mvx, m.mvy);
-        put_mv (i * 2, 0, 2, 4, m.mvx, m.mvy, m.mvpx, m.mvpy);
-        best_sad += m.sad_cost; best_satd += m.satd_cost;
-        wh_mc_chroma (P, J, mbx, mby, i * 4, 0, 4, 8, m.mvx, m.mvy, M.pred_c);
-      }
-    } else {   // P8x8, all sub types 8x8
+    if (mb_type == WH_MB_P8x8) {
       WV_LANES_BEGIN (lane)
       if (lane == 0) { S.refc[9] = WH_REF_NOT_AVAIL; S.refc[21] = WH_REF_NOT_AVAIL; }
       WV_LANES_END
-      for (int i = 0; i < 4; ++i) {
-        WhMe& m = me8[i];
-        wh_pred_mv (S, (i & 1) * 2, (i >> 1) * 2, 2, 0, &m.mvpx, &m.mvpy);
-        wh_refine_frac (S, P, J, C, m, satd_in_md);
-        wh_cache_set (S, (i & 1) * 2, (i >> 1) * 2, 2, 2, 0, m.mvx, m.mvy);
-        put_mv ((i & 1) * 2, (i >> 1) * 2, 2, 2, m.mvx, m.mvy, m.mvpx, m.mvpy);
+    }
+    {
+      const int first = mb_type == WH_MB_P16x16 ? WH_SLOT_16x16 : mb_type == WH_MB_P16x8 ? WH_SLOT_16x8 : mb_type == WH_MB_P8x16 ? WH_SLOT_8x16 : WH_SLOT_8x8;
+      const int cnt = mb_type == WH_MB_P16x16 ? 1 : mb_type == WH_MB_P8x8 ? 4 : 2;
+      for (int i = 0; i < cnt; ++i) {
+        WhMe m;
+        wh_slot_geom (first + i, &m.bx, &m.by, &m.bw, &m.bh);
+        wh_me_fetch (S, first + i, m);
+        wh_slot_pred (S, first + i, &m.mvpx, &m.mvpy);
+        wh_refine_frac (S, P, J, W, C, m, satd_in_md);
+        wh_cache_set (S, m.bx >> 2, m.by >> 2, m.bw >> 2, m.bh >> 2, 0, m.mvx, m.mvy);
+        {
+          const int bx4 = m.bx >> 2, by4 = m.by >> 2, w4 = m.bw >> 2, h4 = m.bh >> 2;
+          WV_LANES_BEGIN (lane)
+          if (lane < w4 * h4) {
+            const int r = (by4 + (w4 == 4 ? lane >> 2 : lane >> 1)) * 4 + bx4 + (lane & (w4 - 1));
+            S.mv_out[r][0] = (int16_t)m.mvx; S.mv_out[r][1] = (int16_t)m.mvy; S.mvp_out[r][0] = (int16_t)m.mvpx; S.mvp_out[r][1] = (int16_t)m.mvpy;
+          }
+          WV_LANES_END
+        }
         best_sad += m.sad_cost; best_satd += m.satd_cost;
-        wh_mc_chroma (P, J, mbx, mby, (i & 1) * 4, (i >> 1) * 4, 4, 4, m.mvx, m.mvy, M.pred_c);
+        wh_mc_chroma_to (S, P, J, W, mbx, mby, m.bx >> 1, m.by >> 1, m.bw >> 1, m.bh >> 1, m.mvx, m.mvy, M.pred_c);
+        if (mb_type == WH_MB_P16x16) { me16.mvx = m.mvx; me16.mvy = m.mvy; }
       }
+    }
+    if (mb_type == WH_MB_P16x16) {
+      // iCostSkipMb of a 16x16 MB = SAD of its final prediction (luma + chroma)
+      cost_skip_mb = wh_sad_mb_tile (S, M.pred_y) + wh_sad_chroma_tile (S, M.pred_c);
     }
     sad_cost0 = best_sad;
     cost_luma = md_using_sad ? best_sad : best_satd;
@@ -783,11 +857,13 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, const WhSeqParams& P, const WhPicJob
   WH_PROF_MARK (P, 6);   // residual coding
   // ---- store ----
   const bool is_skip = mb_type == WH_MB_PSKIP;
+  WH_G WhMbState* Ms = (WH_G WhMbState*)J.mbs + xy;
+  WH_G WhMbRecord* Rs = (WH_G WhMbRecord*)J.records + xy;
   if (intra) {
     WV_LANES_BEGIN (lane)
-    if (lane < 16) { J.mbs[xy].mv[lane][0] = 0; J.mbs[xy].mv[lane][1] = 0; J.records[xy].mvd[lane][0] = 0; J.records[xy].mvd[lane][1] = 0; }
-    if (lane < 4) { J.mbs[xy].ref_idx[lane] = -1; J.records[xy].ref_idx[lane] = -1; J.records[xy].sub_type[lane] = 0; }
-    if (lane == 0) { J.mbs[xy].sad_cost[0] = 0; J.mbs[xy].p16mv[0] = (int16_t)p16x; J.mbs[xy].p16mv[1] = (int16_t)p16y; J.mbs[xy].skip_sad = 0; }
+    if (lane < 16) { Ms->mv[lane][0] = 0; Ms->mv[lane][1] = 0; Rs->mvd[lane][0] = 0; Rs->mvd[lane][1] = 0; }
+    if (lane < 4) { Ms->ref_idx[lane] = -1; Rs->ref_idx[lane] = -1; Rs->sub_type[lane] = 0; }
+    if (lane == 0) { Ms->sad_cost[0] = 0; Ms->p16mv[0] = (int16_t)p16x; Ms->p16mv[1] = (int16_t)p16y; Ms->skip_sad = 0; }
     WV_LANES_END
     wh_store_mb (M, P, J, mbx, mby, ir.mb_type, ir.cbp, qp, qpc, ir.i16_mode_std, ir.chroma_mode_std, ir.cost_luma, slice_idc);
     return;
@@ -797,11 +873,11 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, const WhSeqParams& P, const WhPicJob
     WV_LANES_BEGIN (lane)
     {
       const int row = lane >> 2, seg = lane & 3;
-      for (int k = 0; k < 4; ++k) WH_RY (M, seg * 4 + k, row) = S.skip_y[row * 16 + seg * 4 + k];
+      * (uint32_t*)&WH_RY (M, seg * 4, row) = * (const uint32_t*)&S.skip_y[row * 16 + seg * 4];
     }
     if (lane < 32) {
       const int pl = lane >> 4, row = (lane >> 1) & 7, half = lane & 1;
-      for (int k = 0; k < 4; ++k) WH_RC (M, pl, half * 4 + k, row) = S.skip_c[pl * 64 + row * 8 + half * 4 + k];
+      * (uint32_t*)&WH_RC (M, pl, half * 4, row) = * (const uint32_t*)&S.skip_c[pl * 64 + row * 8 + half * 4];
     }
     if (lane < 24) M.nzc[lane] = 0;
     WV_LANES_END
@@ -810,15 +886,15 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, const WhSeqParams& P, const WhPicJob
   WV_LANES_BEGIN (lane)
   if (lane < 16) {
     const int mvx = is_skip ? skx : S.mv_out[lane][0], mvy = is_skip ? sky : S.mv_out[lane][1];
-    J.mbs[xy].mv[lane][0] = (int16_t)mvx; J.mbs[xy].mv[lane][1] = (int16_t)mvy;
-    J.records[xy].mvd[lane][0] = is_skip ? (int16_t)0 : (int16_t) (mvx - S.mvp_out[lane][0]);
-    J.records[xy].mvd[lane][1] = is_skip ? (int16_t)0 : (int16_t) (mvy - S.mvp_out[lane][1]);
-    if (!(cbp & 15) || is_skip) { for (int k = 0; k < 16; ++k) M.lv_luma[lane * 16 + k] = 0; }
+    Ms->mv[lane][0] = (int16_t)mvx; Ms->mv[lane][1] = (int16_t)mvy;
+    Rs->mvd[lane][0] = is_skip ? (int16_t)0 : (int16_t) (mvx - S.mvp_out[lane][0]);
+    Rs->mvd[lane][1] = is_skip ? (int16_t)0 : (int16_t) (mvy - S.mvp_out[lane][1]);
   }
-  if (lane < 4) { J.mbs[xy].ref_idx[lane] = 0; J.records[xy].ref_idx[lane] = 0; J.records[xy].sub_type[lane] = (uint8_t)sub_type[lane]; }
+  if (!(cbp & 15) || is_skip) { uint64_t* z = (uint64_t*)M.lv_luma; z[lane] = 0; }
+  if (lane < 4) { Ms->ref_idx[lane] = 0; Rs->ref_idx[lane] = 0; Rs->sub_type[lane] = 0; }
   if (lane == 0) {
-    J.mbs[xy].sad_cost[0] = sad_cost0; J.mbs[xy].p16mv[0] = (int16_t)p16x; J.mbs[xy].p16mv[1] = (int16_t)p16y;
-    J.mbs[xy].skip_sad = is_skip ? cost_skip_mb : 0;
+    Ms->sad_cost[0] = sad_cost0; Ms->p16mv[0] = (int16_t)p16x; Ms->p16mv[1] = (int16_t)p16y;
+    Ms->skip_sad = is_skip ? cost_skip_mb : 0;
   }
   WV_LANES_END
   wh_store_mb (M, P, J, mbx, mby, mb_type, cbp, qp, qpc, 0, 0, cost_luma, slice_idc);

@@ -22,48 +22,78 @@ WH_FN int wh_slice_of_mb (const WhSeqParams& P, int mbxy) {
   for (int i = 1; i < P.num_slices; ++i) s += (mbxy >= P.slice_first_mb[i]);
   return s;
 }
-WH_FN int wh_mb_avail (const WhSeqParams& P, int mbx, int mby) {
+// every neighbour has a smaller MB address, so "same slice" == "not before the first MB of this slice"
+WH_FN int wh_mb_avail_in_slice (const WhSeqParams& P, int mbx, int mby, int slice_first) {
   const int w = P.mb_w, xy = mby * w + mbx;
-  const int sl = wh_slice_of_mb (P, xy);
   int av = 0;
-  if (mbx > 0 && wh_slice_of_mb (P, xy - 1) == sl) av |= WH_AV_LEFT;
+  if (mbx > 0 && xy - 1 >= slice_first) av |= WH_AV_LEFT;
   if (mby > 0) {
-    if (wh_slice_of_mb (P, xy - w) == sl) av |= WH_AV_TOP;
-    if (mbx > 0 && wh_slice_of_mb (P, xy - w - 1) == sl) av |= WH_AV_TOPLEFT;
-    if (mbx < w - 1 && wh_slice_of_mb (P, xy - w + 1) == sl) av |= WH_AV_TOPRIGHT;
+    if (xy - w >= slice_first) av |= WH_AV_TOP;
+    if (mbx > 0 && xy - w - 1 >= slice_first) av |= WH_AV_TOPLEFT;
+    if (mbx < w - 1 && xy - w + 1 >= slice_first) av |= WH_AV_TOPRIGHT;
   }
   return av;
 }
+WH_FN int wh_mb_avail (const WhSeqParams& P, int mbx, int mby) {
+  return wh_mb_avail_in_slice (P, mbx, mby, P.slice_first_mb[wh_slice_of_mb (P, mby * P.mb_w + mbx)]);
+}
 
 // ---- load source MB + reconstructed neighbours into the LDS tile ---------------------------------
-WH_FN void wh_load_mb_tile (WhMbLds& S, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby) {
-  WV_LANES_BEGIN (lane)
+// Split into a fetch half (global loads into registers) and a commit half (LDS stores) so that a caller can put
+// further loads between the two and pay the HBM latency once.
+typedef struct WhTileRegs { uint32_t y, c, nb; } WhTileRegs;
+
+WH_FN void wh_tile_fetch (int lane, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, WhTileRegs* r) {
   {
     const int row = lane >> 2, seg = lane & 3;
-    const uint8_t* s = J.src[0] + (size_t) (mby * 16 + row) * P.src_stride_y + mbx * 16 + seg * 4;
-    * (uint32_t*)&S.enc_y[row * 16 + seg * 4] = * (const uint32_t*)s;
+    r->y = * (const WH_G uint32_t*) ((const WH_G uint8_t*)J.src[0] + (size_t) (mby * 16 + row) * P.src_stride_y + mbx * 16 + seg * 4);
   }
+  r->c = 0; r->nb = 0;
   if (lane < 32) {
     const int pl = lane >> 4, row = (lane >> 1) & 7, half = lane & 1;
-    const uint8_t* s = J.src[1 + pl] + (size_t) (mby * 8 + row) * P.src_stride_c + mbx * 8 + half * 4;
-    * (uint32_t*)&S.enc_c[pl * 64 + row * 8 + half * 4] = * (const uint32_t*)s;
+    r->c = * (const WH_G uint32_t*) ((const WH_G uint8_t*)J.src[1 + pl] + (size_t) (mby * 8 + row) * P.src_stride_c + mbx * 8 + half * 4);
   }
   // reconstructed neighbours (garbage where unavailable -- never consumed then)
   if (lane < 7) {                        // luma row -1, x = -4 .. 23 in 4-byte words
     const int x = lane * 4 - 4;
-    const uint8_t* r = J.rec[0] + (ptrdiff_t) (mby * 16 - 1) * P.rec_stride_y + mbx * 16 + x;
-    * (uint32_t*)&S.rec_y[0 * 32 + x + 8] = * (const uint32_t*)r;
+    r->nb = * (const WH_G uint32_t*) ((const WH_G uint8_t*)J.rec[0] + (ptrdiff_t) (mby * 16 - 1) * P.rec_stride_y + mbx * 16 + x);
   } else if (lane >= 16 && lane < 32) {  // luma column -1
     const int y = lane - 16;
-    WH_RY (S, -1, y) = J.rec[0][(ptrdiff_t) (mby * 16 + y) * P.rec_stride_y + mbx * 16 - 1];
+    r->nb = ((const WH_G uint8_t*)J.rec[0])[(ptrdiff_t) (mby * 16 + y) * P.rec_stride_y + mbx * 16 - 1];
   } else if (lane >= 32 && lane < 38) {  // chroma rows -1: 3 words per plane, x = -4..7
     const int pl = (lane - 32) / 3, x = ((lane - 32) % 3) * 4 - 4;
-    const uint8_t* r = J.rec[1 + pl] + (ptrdiff_t) (mby * 8 - 1) * P.rec_stride_c + mbx * 8 + x;
-    * (uint32_t*)&S.rec_c[pl][0 * 16 + x + 4] = * (const uint32_t*)r;
+    r->nb = * (const WH_G uint32_t*) ((const WH_G uint8_t*)J.rec[1 + pl] + (ptrdiff_t) (mby * 8 - 1) * P.rec_stride_c + mbx * 8 + x);
   } else if (lane >= 48) {               // chroma columns -1
     const int pl = (lane - 48) >> 3, y = lane & 7;
-    WH_RC (S, pl, -1, y) = J.rec[1 + pl][(ptrdiff_t) (mby * 8 + y) * P.rec_stride_c + mbx * 8 - 1];
+    r->nb = ((const WH_G uint8_t*)J.rec[1 + pl])[(ptrdiff_t) (mby * 8 + y) * P.rec_stride_c + mbx * 8 - 1];
   }
+}
+WH_FN void wh_tile_commit (WhMbLds& S, int lane, const WhTileRegs* r) {
+  {
+    const int row = lane >> 2, seg = lane & 3;
+    * (uint32_t*)&S.enc_y[row * 16 + seg * 4] = r->y;
+  }
+  if (lane < 32) {
+    const int pl = lane >> 4, row = (lane >> 1) & 7, half = lane & 1;
+    * (uint32_t*)&S.enc_c[pl * 64 + row * 8 + half * 4] = r->c;
+  }
+  if (lane < 7) {
+    * (uint32_t*)&S.rec_y[0 * 32 + lane * 4 - 4 + 8] = r->nb;
+  } else if (lane >= 16 && lane < 32) {
+    WH_RY (S, -1, lane - 16) = (uint8_t)r->nb;
+  } else if (lane >= 32 && lane < 38) {
+    const int pl = (lane - 32) / 3, x = ((lane - 32) % 3) * 4 - 4;
+    * (uint32_t*)&S.rec_c[pl][0 * 16 + x + 4] = r->nb;
+  } else if (lane >= 48) {
+    const int pl = (lane - 48) >> 3, y = lane & 7;
+    WH_RC (S, pl, -1, y) = (uint8_t)r->nb;
+  }
+}
+WH_FN void wh_load_mb_tile (WhMbLds& S, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby) {
+  WV_LANES_BEGIN (lane)
+  WhTileRegs r;
+  wh_tile_fetch (lane, P, J, mbx, mby, &r);
+  wh_tile_commit (S, lane, &r);
   WV_LANES_END
 }
 

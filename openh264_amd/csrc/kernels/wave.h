@@ -31,6 +31,44 @@
        (dst_key) = _bk; (dst_lane) = _bl; } while (0)
 #define WV_ANY(dst, lane, expr)                                   \
   do { int _a = 0; for (int lane = 0; lane < 64; ++lane) _a |= ((expr) ? 1 : 0); (dst) = _a; } while (0)
+// two sums in one pass
+#define WV_SUM2(dst_a, dst_b, lane, expr_a, expr_b)               \
+  do { int _sa = 0, _sb = 0; for (int lane = 0; lane < 64; ++lane) { _sa += (int)(expr_a); _sb += (int)(expr_b); } (dst_a) = _sa; (dst_b) = _sb; } while (0)
+// SATD over 4x4 blocks held one per lane quad: lane 4q+r supplies row r of block q as four packed source bytes
+// (enc4) and four packed prediction bytes (pred4); `active` must be uniform per quad.
+// dst = sum over active blocks of (sum|Hadamard4x4(enc - pred)| + 1) >> 1   (sample.cpp:47-96 WelsSampleSatd4x4_c)
+#define WV_SATD_ROWS(dst, lane, active, enc4, pred4)              \
+  do { int _h[64][4]; bool _a[64];                                \
+       for (int lane = 0; lane < 64; ++lane) { _a[lane] = (active); const uint32_t _e = (enc4), _p = (pred4); \
+         const int _d0 = (int)(_e & 255) - (int)(_p & 255), _d1 = (int)((_e >> 8) & 255) - (int)((_p >> 8) & 255); \
+         const int _d2 = (int)((_e >> 16) & 255) - (int)((_p >> 16) & 255), _d3 = (int)(_e >> 24) - (int)(_p >> 24); \
+         const int _s0 = _d0 + _d2, _s1 = _d1 + _d3, _s2 = _d0 - _d2, _s3 = _d1 - _d3; \
+         _h[lane][0] = _s0 + _s1; _h[lane][1] = _s2 + _s3; _h[lane][2] = _s2 - _s3; _h[lane][3] = _s0 - _s1; } \
+       int _t = 0;                                                \
+       for (int _q = 0; _q < 16; ++_q) if (_a[_q * 4]) { int _s = 0; \
+         for (int _c = 0; _c < 4; ++_c) { const int _x0 = _h[_q * 4][_c], _x1 = _h[_q * 4 + 1][_c], _x2 = _h[_q * 4 + 2][_c], _x3 = _h[_q * 4 + 3][_c]; \
+           const int _u0 = _x0 + _x2, _u1 = _x1 + _x3, _u2 = _x0 - _x2, _u3 = _x1 - _x3; \
+           _s += abs (_u0 + _u1) + abs (_u2 + _u3) + abs (_u2 - _u3) + abs (_u0 - _u1); } \
+         _t += (_s + 1) >> 1; }                                    \
+       (dst) = _t; } while (0)
+// pointers into device global memory (explicit address space on the GPU so that loads are global_*, not flat_*)
+#define WH_G
+#include <string.h>
+#include <stdlib.h>
+// four bytes at any byte offset of a 4-byte aligned LDS array
+WH_FN uint32_t wh_ld4u (const uint8_t* base, int off) { uint32_t v; memcpy (&v, base + off, 4); return v; }
+// sum of absolute differences of four packed bytes
+WH_FN int wh_sad4 (uint32_t a, uint32_t b) {
+  int s = 0;
+  for (int k = 0; k < 4; ++k) { const int d = (int) ((a >> (8 * k)) & 255) - (int) ((b >> (8 * k)) & 255); s += d < 0 ? -d : d; }
+  return s;
+}
+// per-byte (a + b + 1) >> 1
+WH_FN uint32_t wh_avg4 (uint32_t a, uint32_t b) {
+  uint32_t r = 0;
+  for (int k = 0; k < 4; ++k) r |= ((((a >> (8 * k)) & 255) + ((b >> (8 * k)) & 255) + 1) >> 1) << (8 * k);
+  return r;
+}
 
 #else
 // -------------------------------------------------------------------------------- gfx950 device
@@ -76,6 +114,39 @@ WH_FN int wh_wave_min_i32 (int v) {
        (dst_key) = _m; (dst_lane) = _b ? (int)__builtin_ctzll (_b) : -1; } while (0)
 #define WV_ANY(dst, lane, expr)                                   \
   do { const int lane = (int)(threadIdx.x & 63); (dst) = __ballot ((expr)) != 0ULL; } while (0)
+#define WV_SUM2(dst_a, dst_b, lane, expr_a, expr_b)               \
+  do { const int lane = (int)(threadIdx.x & 63); int _va = (int)(expr_a), _vb = (int)(expr_b); \
+       _va += WH_DPP (_va, 0xB1); _vb += WH_DPP (_vb, 0xB1); _va += WH_DPP (_va, 0x4E); _vb += WH_DPP (_vb, 0x4E); \
+       _va += WH_DPP (_va, 0x141); _vb += WH_DPP (_vb, 0x141); _va += WH_DPP (_va, 0x140); _vb += WH_DPP (_vb, 0x140); \
+       (dst_a) = __builtin_amdgcn_readlane (_va, 0) + __builtin_amdgcn_readlane (_va, 16) + __builtin_amdgcn_readlane (_va, 32) + __builtin_amdgcn_readlane (_va, 48); \
+       (dst_b) = __builtin_amdgcn_readlane (_vb, 0) + __builtin_amdgcn_readlane (_vb, 16) + __builtin_amdgcn_readlane (_vb, 32) + __builtin_amdgcn_readlane (_vb, 48); } while (0)
+// SATD over lane quads, entirely in registers: horizontal Hadamard inside the lane, vertical butterflies across the
+// quad on DPP quad_perm, then the usual wave sum (see the WH_EMU twin above for the contract).
+WH_FN int wh_satd_rows (int lane, bool active, uint32_t e, uint32_t p) {
+  const int d0 = (int) (e & 255) - (int) (p & 255), d1 = (int) ((e >> 8) & 255) - (int) ((p >> 8) & 255);
+  const int d2 = (int) ((e >> 16) & 255) - (int) ((p >> 16) & 255), d3 = (int) (e >> 24) - (int) (p >> 24);
+  const int s0 = d0 + d2, s1 = d1 + d3, s2 = d0 - d2, s3 = d1 - d3;
+  int a0 = s0 + s1, a1 = s2 + s3, a2 = s2 - s3, a3 = s0 - s1;
+  const bool hi2 = (lane & 2) != 0, hi1 = (lane & 1) != 0;
+  int o;
+#define WH_VBF(v) o = WH_DPP (v, 0x4E); v = hi2 ? o - v : v + o; o = WH_DPP (v, 0xB1); v = hi1 ? o - v : v + o;
+  WH_VBF (a0) WH_VBF (a1) WH_VBF (a2) WH_VBF (a3)
+#undef WH_VBF
+  int s = __builtin_abs (a0) + __builtin_abs (a1) + __builtin_abs (a2) + __builtin_abs (a3);
+  s += WH_DPP (s, 0xB1);
+  s += WH_DPP (s, 0x4E);
+  s = (active && (lane & 3) == 0) ? (s + 1) >> 1 : 0;
+  return wh_wave_sum_i32 (s);
+}
+#define WV_SATD_ROWS(dst, lane, active, enc4, pred4)              \
+  do { const int lane = (int)(threadIdx.x & 63); (dst) = wh_satd_rows (lane, (active), (enc4), (pred4)); } while (0)
+#define WH_G __attribute__ ((address_space (1)))
+WH_FN uint32_t wh_ld4u (const uint8_t* base, int off) {
+  const uint32_t* w = (const uint32_t*)base + (off >> 2);
+  return __builtin_amdgcn_alignbyte (w[1], w[0], (uint32_t)off & 3u);
+}
+WH_FN int wh_sad4 (uint32_t a, uint32_t b) { return (int)__builtin_amdgcn_sad_u8 (a, b, 0u); }
+WH_FN uint32_t wh_avg4 (uint32_t a, uint32_t b) { return __builtin_amdgcn_lerp (a, b, 0x01010101u); }
 #endif
 
 // ---- optional in-kernel phase profiling (WhSeqParams.prof != NULL): cycles since the previous mark are added
