@@ -142,11 +142,11 @@ def main():
 
     if rank == 0:
         pics = a.sessions * a.steps * world
-        nd = (((w + 15) // 16) - 1) + 2 * (((h + 15) // 16) - 1) + 1          # launches per pass (2:1 diagonals)
+        nd = 1                                                                # one launch per pass: a workgroup walks a whole slice
         md_launch_ms = ev["md_ms"] / (a.steps * nd)
         b_md = BYTES_I_MB_MD if workload == "intra" else BYTES_P_MB_MD
         b_path = BYTES_I_MB_PATH if workload == "intra" else BYTES_P_MB_PATH
-        bytes_per_launch = b_md * mbs * a.sessions / nd                     # average MBs per diagonal launch x bytes/MB
+        bytes_per_launch = b_md * mbs * a.sessions / nd                     # every MB of every picture in the batch x bytes/MB
         achieved = bytes_per_launch / (md_launch_ms * 1e-3) / 1e9
         line = {
             "metric": "1080p frames/sec/GPU at QP=24 CBP; encoder_binary_comparison SHA1 pass",
@@ -157,7 +157,7 @@ def main():
                        ("%dx%d P-frames, diamond ME range 16, 4 slices/frame, QP %d, LOW complexity" % (w, h, a.qp)),
                        "pictures_in_flight_per_gpu": a.sessions, "hot_path": "device MD/recon + deblock + border expand; sources resident in HBM, MB records left in HBM; host CAVLC excluded",
                        "parallelism": "sessions sharded over %d GPU(s), no collective" % world},
-            "roofline": {"bound": "hbm", "kernel": "k_intra_diag" if workload == "intra" else "k_inter_diag",
+            "roofline": {"bound": "hbm", "kernel": "k_intra_slice" if workload == "intra" else "k_inter_slice",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "bytes_per_mb": b_md, "avg_launch_ms": md_launch_ms, "launches_per_step": nd,
                          "path_achieved_GBs": b_path * mbs * a.sessions * a.steps / (ev["total_ms"] * 1e-3) / 1e9,

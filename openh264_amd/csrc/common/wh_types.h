@@ -101,7 +101,9 @@ typedef struct WhSeqParams {
   int32_t alpha_offset, beta_offset;
   int32_t mv_range;                     // iMvRange
   int32_t pad[3];
-  unsigned long long* prof;             // optional device array of 32 cycle counters (phase profiling), or NULL
+  unsigned long long* prof;             // optional device array of 64 x 32 cycle counters (phase profiling), or NULL
+  const uint16_t* mb_order;             // device table: [0, num_mb) MB addresses in dependency order per slice (each slice's
+                                        // range is [slice_first_mb[s], slice_first_mb[s+1])), [num_mb, 2*num_mb) whole-picture order
 } WhSeqParams;
 
 #ifdef __cplusplus

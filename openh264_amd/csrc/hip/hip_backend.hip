@@ -8,7 +8,9 @@
 // in-kernel spinning, so a launch can never hang the device.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string>
+#include <algorithm>
 #include "../host/backend.h"
 #include "../kernels/frame_kernels.h"
 #include "../kernels/deblock_mb.h"
@@ -17,24 +19,65 @@
 
 namespace {
 
-__global__ __launch_bounds__ (64) void k_intra_diag (WhSeqParams P, const WhPicJob* jobs, int d, int y0) {
-  __shared__ WhMbLds S;
-  const WhPicJob J = jobs[blockIdx.y];
-  const int y = y0 + (int)blockIdx.x, x = d - 2 * y;
-  wh_intra_mb_body (S, P, J, x, y);
+// ---- in-kernel scheduling ------------------------------------------------------------------------------------
+// One workgroup = one slice (mode decision) or one picture (deblocking) = up to 12/16 wavefronts on ONE compute unit.
+// Each wavefront repeatedly takes the next macroblock of the slice's dependency order (an LDS ticket counter), waits
+// until the two MBs that gate its neighbourhood are flagged done in LDS, processes the MB, and flags it.  Data passes
+// between wavefronts through HBM-backed global memory, which is coherent inside a workgroup (same CU, shared vector
+// L1), so the hand-off costs a workgroup-scope release/acquire (s_waitcnt) instead of a kernel boundary.  Tickets are
+// handed out in a topological order, so the lowest outstanding ticket can always run: no deadlock; the spin is
+// bounded anyway and reports through P.prof-independent error word `err` (host checks it after the step).
+#define WH_SPIN_LIMIT (1u << 16)       // x ~200 cycles: ~5 ms of waiting for ONE macroblock means the scheduler is broken
+
+// returns false when the wait timed out (err[0] counts, err[1..3] = block x, block y, awaited index of the first one)
+__device__ __forceinline__ bool wh_wait_done (const uint32_t* done, int idx, uint32_t* err) {
+  if (idx < 0) return true;
+  uint32_t spins = 0;
+  while (!((__hip_atomic_load (&done[idx >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> (idx & 31)) & 1u)) {
+    __builtin_amdgcn_s_sleep (2);
+    if (++spins > WH_SPIN_LIMIT) {
+      if ((threadIdx.x & 63) == 0 && atomicAdd (err, 1u) == 0) { err[1] = blockIdx.x; err[2] = blockIdx.y; err[3] = (uint32_t)idx; }
+      return false;
+    }
+  }
+  return true;
 }
-__global__ __launch_bounds__ (64) void k_inter_diag (WhSeqParams P, const WhPicJob* jobs, int d, int y0) {
-  __shared__ WhInterLds S;
-  const WhPicJob J = jobs[blockIdx.y];
-  const int y = y0 + (int)blockIdx.x, x = d - 2 * y;
-  wh_inter_mb_body (S, P, J, x, y);
+
+#define WH_DEFINE_MB_KERNEL(NAME, LDS_T, BODY, MAX_THREADS, WHOLE_PICTURE)                                               \
+__global__ __launch_bounds__ (MAX_THREADS) void NAME (WhSeqParams P, const WhPicJob* jobs, uint32_t* err) {             \
+  extern __shared__ __align__ (16) uint8_t smem[];                                                                      \
+  const int nw = (int)blockDim.x >> 6, lane = (int)threadIdx.x & 63;                                                    \
+  const int wave = __builtin_amdgcn_readfirstlane ((int)threadIdx.x >> 6);   /* wave-uniform: keeps S's address scalar */   \
+  LDS_T& S = ((LDS_T*)smem)[wave];                                                                                      \
+  uint32_t* sched = (uint32_t*) (smem + (size_t)nw * sizeof (LDS_T));       /* [0] ticket counter, [1..] done bits */    \
+  const int num_mb = P.mb_w * P.mb_h;                                                                                   \
+  const int first = WHOLE_PICTURE ? 0 : P.slice_first_mb[blockIdx.x];                                                   \
+  const int n = WHOLE_PICTURE ? num_mb : P.slice_first_mb[blockIdx.x + 1] - first;                                      \
+  const uint16_t* order = P.mb_order + (WHOLE_PICTURE ? num_mb : first);                                                \
+  for (int i = (int)threadIdx.x; i < 1 + ((n + 31) >> 5); i += (int)blockDim.x) sched[i] = 0;                          \
+  __syncthreads();                                                                                                      \
+  const WhPicJob& J = jobs[blockIdx.y];      /* read where needed (scalar cache), not held in 30 SGPRs */                \
+  for (int guard = 0; guard <= n; ++guard) {      /* a wave can never need more than n + 1 tickets */                   \
+    int t = 0;                                                                                                          \
+    if (lane == 0) t = (int)atomicAdd (&sched[0], 1u);                                                                  \
+    t = __builtin_amdgcn_readfirstlane (t);                                                                             \
+    if (t >= n) break;                                                                                                  \
+    const int xy = order[t];                                                                                            \
+    int dep_a, dep_b;                                                                                                   \
+    wh_mb_deps (P.mb_w, xy, first, &dep_a, &dep_b);                                                                     \
+    if (!wh_wait_done (sched + 1, dep_a < 0 ? -1 : dep_a - first, err)) break;     /* give up: the host aborts on err */   \
+    if (!wh_wait_done (sched + 1, dep_b < 0 ? -1 : dep_b - first, err)) break;                                          \
+    __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "workgroup");                                                             \
+    BODY (S, P, J, xy % P.mb_w, xy / P.mb_w);                                                                           \
+    __builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");                                                             \
+    if (lane == 0) atomicOr (&sched[1 + ((xy - first) >> 5)], 1u << ((xy - first) & 31));                               \
+  }                                                                                                                     \
 }
-__global__ __launch_bounds__ (64) void k_deblock_diag (WhSeqParams P, const WhPicJob* jobs, int d, int y0) {
-  __shared__ WhDbLds S;
-  const WhPicJob J = jobs[blockIdx.y];
-  const int y = y0 + (int)blockIdx.x, x = d - 2 * y;
-  wh_deblock_mb_body (S, P, J, x, y);
-}
+
+WH_DEFINE_MB_KERNEL (k_intra_slice, WhMbLds, wh_intra_mb_body, 512, 0)
+WH_DEFINE_MB_KERNEL (k_inter_slice, WhInterLds, wh_inter_mb_body, 512, 0)
+WH_DEFINE_MB_KERNEL (k_deblock_pic, WhDbLds, wh_deblock_mb_body, 1024, 1)
+
 __global__ __launch_bounds__ (64) void k_expand (WhSeqParams P, const WhPicJob* jobs) {
   const WhPicJob J = jobs[blockIdx.y];
   wh_expand_body (P, J, (int)blockIdx.x);
@@ -47,6 +90,8 @@ class HipBackend : public wh::Backend {
   HipBackend (int dev, const hipDeviceProp_t& prop) : dev_ (dev) {
     HIP_CHECK (hipSetDevice (dev_));
     HIP_CHECK (hipStreamCreateWithFlags (&stream_, hipStreamNonBlocking));
+    HIP_CHECK (hipMalloc ((void**)&err_, 16));
+    HIP_CHECK (hipMemset (err_, 0, 16));
     name_ = std::string ("hip:") + prop.gcnArchName + " " + prop.name;
   }
   ~HipBackend() override { (void)hipSetDevice (dev_); (void)hipStreamSynchronize (stream_); (void)hipStreamDestroy (stream_); }
@@ -57,24 +102,42 @@ class HipBackend : public wh::Backend {
   void download (void* dst, const void* src, size_t bytes) override { HIP_CHECK (hipMemcpyAsync (dst, src, bytes, hipMemcpyDeviceToHost, stream_)); }
   void fill (void* dst, int value, size_t bytes) override { HIP_CHECK (hipMemsetAsync (dst, value, bytes, stream_)); }
 
-  template <class K> void diagonals (K kernel, const WhSeqParams& P, const WhPicJob* jobs, int n) {
-    const int nd = (P.mb_w - 1) + 2 * (P.mb_h - 1) + 1;
-    for (int d = 0; d < nd; ++d) {
-      int y0;
-      const int cnt = wh_diag_count (P.mb_w, P.mb_h, d, &y0);
-      if (cnt <= 0) continue;
-      hipLaunchKernelGGL (kernel, dim3 (cnt, n), dim3 (64), 0, stream_, P, jobs, d, y0);
+  // waves per workgroup: bounded by the LDS budget (160 KB per CU), the kernel's register budget and by how many MBs
+  // of one slice can be in flight at all (~ min(rows, mb_w / 2))
+  template <class K> void mb_pass (K kernel, size_t lds_per_wave, int max_waves, bool whole_picture, const WhSeqParams& P, const WhPicJob* jobs, int n) {
+    const int num_mb = P.mb_w * P.mb_h;
+    int max_n = whole_picture ? num_mb : 0, max_rows = whole_picture ? P.mb_h : 0;
+    if (!whole_picture) for (int s = 0; s < P.num_slices; ++s) {
+      const int cnt = P.slice_first_mb[s + 1] - P.slice_first_mb[s];
+      if (cnt > max_n) max_n = cnt;
+      const int rows = (P.slice_first_mb[s + 1] - 1) / P.mb_w - P.slice_first_mb[s] / P.mb_w + 1;
+      if (rows > max_rows) max_rows = rows;
     }
+    const size_t sched_bytes = 4 * (size_t) (1 + ((max_n + 31) >> 5));
+    int nw = max_waves;
+    const int par = std::max (1, std::min (max_rows, (P.mb_w + 1) / 2));
+    if (nw > par) nw = par;
+    while (nw > 1 && (size_t)nw * lds_per_wave + sched_bytes > (size_t)160 * 1024) --nw;
+    const size_t lds = (size_t)nw * lds_per_wave + sched_bytes;
+    HIP_CHECK (hipFuncSetAttribute ((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (getenv ("WELSHIP_TRACE")) { fprintf (stderr, "welship: launch grid %d x %d, %d waves, %zu B LDS, max_n %d\n", whole_picture ? 1 : P.num_slices, n, nw, lds, max_n); fflush (stderr); }
+    hipLaunchKernelGGL (kernel, dim3 (whole_picture ? 1 : P.num_slices, n), dim3 (nw * 64), lds, stream_, P, jobs, err_);
     HIP_CHECK (hipGetLastError());
+    if (getenv ("WELSHIP_TRACE")) { HIP_CHECK (hipStreamSynchronize (stream_)); fprintf (stderr, "welship: launch done\n"); fflush (stderr); }
   }
-  void run_intra (const WhSeqParams& P, const WhPicJob* jobs, int n) override { diagonals (k_intra_diag, P, jobs, n); }
-  void run_inter (const WhSeqParams& P, const WhPicJob* jobs, int n) override { diagonals (k_inter_diag, P, jobs, n); }
-  void run_deblock (const WhSeqParams& P, const WhPicJob* jobs, int n) override { diagonals (k_deblock_diag, P, jobs, n); }
+  void run_intra (const WhSeqParams& P, const WhPicJob* jobs, int n) override { mb_pass (k_intra_slice, sizeof (WhMbLds), 8, false, P, jobs, n); }
+  void run_inter (const WhSeqParams& P, const WhPicJob* jobs, int n) override { mb_pass (k_inter_slice, sizeof (WhInterLds), 8, false, P, jobs, n); }
+  void run_deblock (const WhSeqParams& P, const WhPicJob* jobs, int n) override { mb_pass (k_deblock_pic, sizeof (WhDbLds), 16, true, P, jobs, n); }
   void run_expand (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
     hipLaunchKernelGGL (k_expand, dim3 (wh_expand_num_blocks (P), n), dim3 (64), 0, stream_, P, jobs);
     HIP_CHECK (hipGetLastError());
   }
-  void sync() override { HIP_CHECK (hipStreamSynchronize (stream_)); }
+  void sync() override {
+    HIP_CHECK (hipStreamSynchronize (stream_));
+    uint32_t e[4] = {0, 0, 0, 0};
+    HIP_CHECK (hipMemcpy (e, err_, 16, hipMemcpyDeviceToHost));
+    if (e[0]) { fprintf (stderr, "welship: %u in-kernel dependency waits timed out (first: block %u,%u waiting for MB index %u)\n", e[0], e[1], e[2], e[3]); abort(); }
+  }
   void* event_create() override { hipEvent_t e; HIP_CHECK (hipEventCreate (&e)); return (void*)e; }
   void event_destroy (void* ev) override { HIP_CHECK (hipEventDestroy ((hipEvent_t)ev)); }
   void event_record (void* ev) override { HIP_CHECK (hipEventRecord ((hipEvent_t)ev, stream_)); }
@@ -83,6 +146,7 @@ class HipBackend : public wh::Backend {
  private:
   int dev_;
   hipStream_t stream_ = nullptr;
+  uint32_t* err_ = nullptr;
   std::string name_;
 };
 

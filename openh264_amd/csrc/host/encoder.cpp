@@ -15,6 +15,7 @@
 #include <vector>
 #include "../../../include/welship.h"
 #include "backend.h"
+#include "../common/mb_order.h"
 #include "entropy_cavlc.h"
 #include "headers.h"
 
@@ -48,6 +49,7 @@ struct SessionCore {
   int cur = 0;
   int last_slot = 0;                  // source slot of the previous frame (VAA reference)
   WhMbRecord* d_records = nullptr;
+  uint16_t* d_order = nullptr;
   size_t rec_alloc_bytes = 0, src_bytes = 0, ysz = 0, csz = 0;
   std::vector<uint8_t> h_src;
   std::vector<WhMbRecord> h_records;
@@ -129,6 +131,16 @@ struct SessionCore {
     }
     d_records = (WhMbRecord*)be->alloc (sizeof (WhMbRecord) * num_mb);
     h_records.resize (num_mb);
+    {
+      // processing order tables (kernels/frame_kernels.h wh_build_mb_order): per slice, then whole picture
+      std::vector<uint16_t> order ((size_t)num_mb * 2);
+      for (int i = 0; i < s.num_slices; ++i) wh_build_mb_order (mb_w, s.slice_first_mb[i], s.slice_first_mb[i + 1], order.data() + s.slice_first_mb[i]);
+      wh_build_mb_order (mb_w, 0, num_mb, order.data() + num_mb);
+      d_order = (uint16_t*)be->alloc (order.size() * 2);
+      be->upload (d_order, order.data(), order.size() * 2);
+      be->sync();
+      s.mb_order = d_order;
+    }
     // level (au_set.cpp:530-545): the reference feeds iSpatialBitrate even with RC off
     level_idc = wh::select_level_idc (mb_w, mb_h, 1, p->fMaxFrameRate, p->iTargetBitrate, &level_1b);
     return WELSHIP_OK;
@@ -141,6 +153,8 @@ struct SessionCore {
     for (int i = 0; i < 2; ++i) { if (pic[i].base) be->free (pic[i].base); if (pic[i].mbs) be->free (pic[i].mbs); pic[i] = DevPicture(); }
     if (d_records) be->free (d_records);
     d_records = nullptr;
+    if (d_order) be->free (d_order);
+    d_order = nullptr;
     be = nullptr;
   }
 

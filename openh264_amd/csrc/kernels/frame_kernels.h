@@ -76,14 +76,4 @@ WH_FN void wh_intra_mb_body (WhMbLds& S, const WhSeqParams& P, const WhPicJob& J
   wh_store_mb (S, P, J, mbx, mby, r.mb_type, r.cbp, qp, qpc, r.i16_mode_std, r.chroma_mode_std, r.cost_luma, wh_slice_of_mb (P, xy));
 }
 
-// ---- 2:1 diagonal ("wavefront") scheduling -----------------------------------------------------
-// MB (x,y) depends on (x-1,y), (x,y-1), (x+1,y-1)  =>  all MBs with  x + 2*y == d  are independent.
-// d runs 0 .. (mb_w - 1) + 2 * (mb_h - 1).  For diagonal d, the k-th MB is  y = y0 + k, x = d - 2*y.
-WH_HDFN int wh_diag_count (int mb_w, int mb_h, int d, int* y0) {
-  int ylo = (d - (mb_w - 1) + 1) >> 1;   // ceil((d - (mb_w-1)) / 2)
-  if (ylo < 0) ylo = 0;
-  int yhi = d >> 1;
-  if (yhi > mb_h - 1) yhi = mb_h - 1;
-  *y0 = ylo;
-  return yhi >= ylo ? yhi - ylo + 1 : 0;
-}
+#include "../common/mb_order.h"

@@ -555,6 +555,7 @@ WH_FN bool wh_try_puv_skip (WhMbLds& S, int pl, int qpc) {
 
 // ---- the P macroblock -----------------------------------------------------------------------------
 WH_FN void wh_inter_mb_body (WhInterLds& S, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby) {
+  WH_PROF_DECL (P);
   WhMbLds& M = S.m;
   const int w = P.mb_w, xy = mby * w + mbx;
   const int slice_idc = wh_slice_of_mb (P, xy);
@@ -565,8 +566,8 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, const WhSeqParams& P, const WhPicJob
   const int use_satd = P.complexity > 0;        // pfMdCost == SATD, pfCalculateSatd == CalculateSatdCost
   const bool md_using_sad = !use_satd;          // bMdUsingSad (svc_encode_slice.cpp:699)
   const bool ref_is_p = J.ref_is_p != 0;
-  WH_PROF_DECL (P);
 
+  WH_PROF_MARK (P, 8);   // kernel arguments, job descriptor, slice lookup
   // ---- batch 1: source tile, neighbour pixels, previous source tile, neighbour + co-located MB states ----
   WV_LANES_BEGIN (lane)
   {
@@ -599,6 +600,7 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, const WhSeqParams& P, const WhPicJob
   }
   WV_LANES_END
 
+  WH_PROF_MARK (P, 9);   // batch 1 loads
   // ---- neighbour cache (FillNeighborCacheInterWithoutBGD) ----
   const WhMbState* TLm = (avail & WH_AV_TOPLEFT) ? (const WhMbState*)S.nb[0] : nullptr;
   const WhMbState* Tm = (avail & WH_AV_TOP) ? (const WhMbState*)S.nb[1] : nullptr;
@@ -630,6 +632,7 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, const WhSeqParams& P, const WhPicJob
   C.minx = wh_max (- ((mbx + 1) << 4) + 3, -P.mv_range); C.miny = wh_max (- ((mby + 1) << 4) + 3, -P.mv_range);
   C.maxx = wh_min (((P.mb_w - mbx) << 4) - 3, P.mv_range); C.maxy = wh_min (((P.mb_h - mby) << 4) - 3, P.mv_range);
 
+  WH_PROF_MARK (P, 10);  // neighbour cache + context
   // ---- batch 2: reference windows centred on the 16x16 predictor (= the search's initial point) ----
   WhMe me16;
   me16.bx = 0; me16.by = 0; me16.bw = 16; me16.bh = 16;
@@ -637,7 +640,7 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, const WhSeqParams& P, const WhPicJob
   WhWin W;
   wh_win_load_all (S, P, J, W, mbx * 16 + wh_clip3 ((2 + me16.mvpx) >> 2, C.minx, C.maxx), mby * 16 + wh_clip3 ((2 + me16.mvpy) >> 2, C.miny, C.maxy));
 
-  WH_PROF_MARK (P, 0);   // loads + neighbour cache
+  WH_PROF_MARK (P, 0);   // mvp + batch 2 (window) loads
   int mb_type = WH_MB_P16x16, cbp = 0, cost_luma = 0, cost_skip_mb = 0, sad_cost0 = 0;
   int p16x = 0, p16y = 0;                       // sP16x16Mv
   int skx = 0, sky = 0;

@@ -25,23 +25,23 @@ class EmuBackend : public Backend {
   void upload (void* dst, const void* src, size_t bytes) override { memcpy (dst, src, bytes); }
   void download (void* dst, const void* src, size_t bytes) override { memcpy (dst, src, bytes); }
   void fill (void* dst, int value, size_t bytes) override { memset (dst, value, bytes); }
-  template <class F> static void for_diagonals (const WhSeqParams& P, int n, F f) {
-    const int nd = (P.mb_w - 1) + 2 * (P.mb_h - 1) + 1;
-    for (int d = 0; d < nd; ++d) {
-      int y0;
-      const int cnt = wh_diag_count (P.mb_w, P.mb_h, d, &y0);
-      for (int j = 0; j < n; ++j)
-        for (int k = 0; k < cnt; ++k) { const int y = y0 + k, x = d - 2 * y; f (j, x, y); }
+  // same per-slice / per-picture dependency order the device kernels walk (common/mb_order.h), one MB at a time
+  template <class F> static void for_order (const WhSeqParams& P, int n, bool whole_picture, F f) {
+    const int num_mb = P.mb_w * P.mb_h;
+    for (int j = 0; j < n; ++j) {
+      if (whole_picture) { for (int t = 0; t < num_mb; ++t) { const int xy = P.mb_order[num_mb + t]; f (j, xy % P.mb_w, xy / P.mb_w); } continue; }
+      for (int s = 0; s < P.num_slices; ++s)
+        for (int t = P.slice_first_mb[s]; t < P.slice_first_mb[s + 1]; ++t) { const int xy = P.mb_order[t]; f (j, xy % P.mb_w, xy / P.mb_w); }
     }
   }
   void run_intra (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
-    for_diagonals (P, n, [&] (int j, int x, int y) { WhMbLds S; wh_intra_mb_body (S, P, jobs[j], x, y); });
+    for_order (P, n, false, [&] (int j, int x, int y) { WhMbLds S; wh_intra_mb_body (S, P, jobs[j], x, y); });
   }
   void run_inter (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
-    for_diagonals (P, n, [&] (int j, int x, int y) { WhInterLds S; wh_inter_mb_body (S, P, jobs[j], x, y); });
+    for_order (P, n, false, [&] (int j, int x, int y) { WhInterLds S; wh_inter_mb_body (S, P, jobs[j], x, y); });
   }
   void run_deblock (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
-    for_diagonals (P, n, [&] (int j, int x, int y) { WhDbLds S; wh_deblock_mb_body (S, P, jobs[j], x, y); });
+    for_order (P, n, true, [&] (int j, int x, int y) { WhDbLds S; wh_deblock_mb_body (S, P, jobs[j], x, y); });
   }
   void run_expand (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
     for (int j = 0; j < n; ++j) {
