@@ -10,6 +10,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string>
+#include <vector>
 #include <algorithm>
 #include "../host/backend.h"
 #include "../kernels/frame_kernels.h"
@@ -43,7 +44,13 @@ __device__ __forceinline__ bool wh_wait_done (const uint32_t* done, int idx, uin
   return true;
 }
 
-#define WH_DEFINE_MB_KERNEL(NAME, LDS_T, BODY, MAX_THREADS, WHOLE_PICTURE)                                               \
+// where a tile type keeps its profiling accumulators (only the P-frame kernel is instrumented)
+__device__ __forceinline__ WhMbLds& wh_prof_holder (WhInterLds& S) { return S.m; }
+__device__ __forceinline__ WhMbLds& wh_prof_holder (WhMbLds& S) { return S; }
+__device__ __forceinline__ WhMbLds& wh_prof_holder (WhDbLds& S) { return * (WhMbLds*)&S; }     /* never used (PROF = 0) */
+template <class T> __device__ __forceinline__ unsigned long long* wh_prof_lds (T& S) { return wh_prof_holder (S).prof; }
+
+#define WH_DEFINE_MB_KERNEL(NAME, LDS_T, BODY, MAX_THREADS, WHOLE_PICTURE, PROF)                                             \
 __global__ __launch_bounds__ (MAX_THREADS) void NAME (WhSeqParams P, const WhPicJob* jobs, uint32_t* err) {             \
   extern __shared__ __align__ (16) uint8_t smem[];                                                                      \
   const int nw = (int)blockDim.x >> 6, lane = (int)threadIdx.x & 63;                                                    \
@@ -55,7 +62,9 @@ __global__ __launch_bounds__ (MAX_THREADS) void NAME (WhSeqParams P, const WhPic
   const int n = WHOLE_PICTURE ? num_mb : P.slice_first_mb[blockIdx.x + 1] - first;                                      \
   const uint16_t* order = P.mb_order + (WHOLE_PICTURE ? num_mb : first);                                                \
   for (int i = (int)threadIdx.x; i < 1 + ((n + 31) >> 5); i += (int)blockDim.x) sched[i] = 0;                          \
+  if (PROF && P.prof && lane < 32) wh_prof_lds (S)[lane] = 0;                                                           \
   __syncthreads();                                                                                                      \
+  WH_PROF_DECL (P);                                                                                                     \
   const WhPicJob& J = jobs[blockIdx.y];      /* read where needed (scalar cache), not held in 30 SGPRs */                \
   for (int guard = 0; guard <= n; ++guard) {      /* a wave can never need more than n + 1 tickets */                   \
     int t = 0;                                                                                                          \
@@ -63,20 +72,26 @@ __global__ __launch_bounds__ (MAX_THREADS) void NAME (WhSeqParams P, const WhPic
     t = __builtin_amdgcn_readfirstlane (t);                                                                             \
     if (t >= n) break;                                                                                                  \
     const int xy = order[t];                                                                                            \
+    if (PROF) WH_PROF_MARK (P, wh_prof_holder (S), 11);      /* ticket + order lookup */                                 \
+    (void)0;                                                                                          \
     int dep_a, dep_b;                                                                                                   \
     wh_mb_deps (P.mb_w, xy, first, &dep_a, &dep_b);                                                                     \
     if (!wh_wait_done (sched + 1, dep_a < 0 ? -1 : dep_a - first, err)) break;     /* give up: the host aborts on err */   \
     if (!wh_wait_done (sched + 1, dep_b < 0 ? -1 : dep_b - first, err)) break;                                          \
     __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "workgroup");                                                             \
+    if (PROF) WH_PROF_MARK (P, wh_prof_holder (S), 12);      /* dependency wait */                                       \
     BODY (S, P, J, xy % P.mb_w, xy / P.mb_w);                                                                           \
+    if (PROF) WH_PROF_MARK (P, wh_prof_holder (S), 14);      /* the MB itself (sum of the body's own phases) */          \
     __builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");                                                             \
     if (lane == 0) atomicOr (&sched[1 + ((xy - first) >> 5)], 1u << ((xy - first) & 31));                               \
+    if (PROF) WH_PROF_MARK (P, wh_prof_holder (S), 13);      /* store drain (release) + done flag */                     \
   }                                                                                                                     \
+  if (PROF && P.prof && lane < 32) atomicAdd (&P.prof[((blockIdx.x + blockIdx.y * 7u) & 63u) * 32u + lane], wh_prof_lds (S)[lane]); \
 }
 
-WH_DEFINE_MB_KERNEL (k_intra_slice, WhMbLds, wh_intra_mb_body, 512, 0)
-WH_DEFINE_MB_KERNEL (k_inter_slice, WhInterLds, wh_inter_mb_body, 512, 0)
-WH_DEFINE_MB_KERNEL (k_deblock_pic, WhDbLds, wh_deblock_mb_body, 1024, 1)
+WH_DEFINE_MB_KERNEL (k_intra_slice, WhMbLds, wh_intra_mb_body, 512, 0, 0)
+WH_DEFINE_MB_KERNEL (k_inter_slice, WhInterLds, wh_inter_mb_body, 512, 0, 1)
+WH_DEFINE_MB_KERNEL (k_deblock_pic, WhDbLds, wh_deblock_mb_body, 1024, 1, 0)
 
 __global__ __launch_bounds__ (64) void k_expand (WhSeqParams P, const WhPicJob* jobs) {
   const WhPicJob J = jobs[blockIdx.y];
@@ -94,10 +109,31 @@ class HipBackend : public wh::Backend {
     HIP_CHECK (hipMemset (err_, 0, 16));
     name_ = std::string ("hip:") + prop.gcnArchName + " " + prop.name;
   }
-  ~HipBackend() override { (void)hipSetDevice (dev_); (void)hipStreamSynchronize (stream_); (void)hipStreamDestroy (stream_); }
+  ~HipBackend() override {
+    (void)hipSetDevice (dev_); (void)hipStreamSynchronize (stream_); (void)hipStreamDestroy (stream_);
+    for (void* p : slabs_) (void)hipFree (p);
+    (void)hipFree (err_);
+  }
   const char* name() const override { return name_.c_str(); }
-  void* alloc (size_t bytes) override { void* p = nullptr; HIP_CHECK (hipSetDevice (dev_)); HIP_CHECK (hipMalloc (&p, bytes ? bytes : 1)); return p; }
-  void free (void* p) override { HIP_CHECK (hipSetDevice (dev_)); HIP_CHECK (hipFree (p)); }
+  // Device memory comes from a few large slabs (bump allocation, 4 KB granules): many small hipMalloc's end up as
+  // many small page-table fragments, and with dozens of planes touched per macroblock the translation misses cost
+  // more than the data misses.  Slabs are returned when the backend goes away (sessions allocate once, at Initialize).
+  void* alloc (size_t bytes) override {
+    HIP_CHECK (hipSetDevice (dev_));
+    bytes = (bytes + 4095) & ~(size_t)4095;
+    if (bytes == 0) bytes = 4096;
+    if (slabs_.empty() || slab_used_ + bytes > slab_size_) {
+      slab_size_ = std::max (bytes, (size_t)256 << 20);
+      void* p = nullptr;
+      HIP_CHECK (hipMalloc (&p, slab_size_));
+      slabs_.push_back (p);
+      slab_used_ = 0;
+    }
+    void* r = (uint8_t*)slabs_.back() + slab_used_;
+    slab_used_ += bytes;
+    return r;
+  }
+  void free (void*) override {}
   void upload (void* dst, const void* src, size_t bytes) override { HIP_CHECK (hipMemcpyAsync (dst, src, bytes, hipMemcpyHostToDevice, stream_)); }
   void download (void* dst, const void* src, size_t bytes) override { HIP_CHECK (hipMemcpyAsync (dst, src, bytes, hipMemcpyDeviceToHost, stream_)); }
   void fill (void* dst, int value, size_t bytes) override { HIP_CHECK (hipMemsetAsync (dst, value, bytes, stream_)); }
@@ -147,6 +183,8 @@ class HipBackend : public wh::Backend {
   int dev_;
   hipStream_t stream_ = nullptr;
   uint32_t* err_ = nullptr;
+  std::vector<void*> slabs_;
+  size_t slab_size_ = 0, slab_used_ = 0;
   std::string name_;
 };
 

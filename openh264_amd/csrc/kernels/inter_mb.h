@@ -567,7 +567,7 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, const WhSeqParams& P, const WhPicJob
   const bool md_using_sad = !use_satd;          // bMdUsingSad (svc_encode_slice.cpp:699)
   const bool ref_is_p = J.ref_is_p != 0;
 
-  WH_PROF_MARK (P, 8);   // kernel arguments, job descriptor, slice lookup
+  WH_PROF_MARK (P, M, 8);   // kernel arguments, job descriptor, slice lookup
   // ---- batch 1: source tile, neighbour pixels, previous source tile, neighbour + co-located MB states ----
   WV_LANES_BEGIN (lane)
   {
@@ -600,7 +600,7 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, const WhSeqParams& P, const WhPicJob
   }
   WV_LANES_END
 
-  WH_PROF_MARK (P, 9);   // batch 1 loads
+  WH_PROF_MARK (P, M, 9);   // batch 1 loads
   // ---- neighbour cache (FillNeighborCacheInterWithoutBGD) ----
   const WhMbState* TLm = (avail & WH_AV_TOPLEFT) ? (const WhMbState*)S.nb[0] : nullptr;
   const WhMbState* Tm = (avail & WH_AV_TOP) ? (const WhMbState*)S.nb[1] : nullptr;
@@ -632,7 +632,7 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, const WhSeqParams& P, const WhPicJob
   C.minx = wh_max (- ((mbx + 1) << 4) + 3, -P.mv_range); C.miny = wh_max (- ((mby + 1) << 4) + 3, -P.mv_range);
   C.maxx = wh_min (((P.mb_w - mbx) << 4) - 3, P.mv_range); C.maxy = wh_min (((P.mb_h - mby) << 4) - 3, P.mv_range);
 
-  WH_PROF_MARK (P, 10);  // neighbour cache + context
+  WH_PROF_MARK (P, M, 10);  // neighbour cache + context
   // ---- batch 2: reference windows centred on the 16x16 predictor (= the search's initial point) ----
   WhMe me16;
   me16.bx = 0; me16.by = 0; me16.bw = 16; me16.bh = 16;
@@ -640,7 +640,7 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, const WhSeqParams& P, const WhPicJob
   WhWin W;
   wh_win_load_all (S, P, J, W, mbx * 16 + wh_clip3 ((2 + me16.mvpx) >> 2, C.minx, C.maxx), mby * 16 + wh_clip3 ((2 + me16.mvpy) >> 2, C.miny, C.maxy));
 
-  WH_PROF_MARK (P, 0);   // mvp + batch 2 (window) loads
+  WH_PROF_MARK (P, M, 0);   // mvp + batch 2 (window) loads
   int mb_type = WH_MB_P16x16, cbp = 0, cost_luma = 0, cost_skip_mb = 0, sad_cost0 = 0;
   int p16x = 0, p16y = 0;                       // sP16x16Mv
   int skx = 0, sky = 0;
@@ -698,7 +698,7 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, const WhSeqParams& P, const WhPicJob
     }
   }
   if (b_skip && keep_skip) { mb_type = WH_MB_PSKIP; done = true; }
-  WH_PROF_MARK (P, 1);   // P_Skip test
+  WH_PROF_MARK (P, M, 1);   // P_Skip test
 
   int sad_pred16 = 0;
   if (!done && !b_skip) {
@@ -738,7 +738,7 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, const WhSeqParams& P, const WhPicJob
     sad_pred16 = sad_pred;
   }
 
-  WH_PROF_MARK (P, 2);   // P16x16 motion search
+  WH_PROF_MARK (P, M, 2);   // P16x16 motion search
   // ---- secondary modes (WelsMdInterSecondaryModesEnc) ----
   bool intra = false;
   WhIntraResult ir;
@@ -747,7 +747,7 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, const WhSeqParams& P, const WhPicJob
     if (wh_intra_md_enc_p (M, P, J, mbx, mby, avail, qp, qpc, cost_luma, &ir)) { intra = true; done = true; }
   }
   if (!done && b_skip) { mb_type = WH_MB_PSKIP; done = true; }
-  WH_PROF_MARK (P, 3);   // I16x16 test (+ intra encode when intra wins)
+  WH_PROF_MARK (P, M, 3);   // I16x16 test (+ intra encode when intra wins)
 
   if (!done) {
     // ---- fine partitions: groups of searches (8x8 x4, 16x8 x2, 8x16 x2), results kept in S.me[slot] ----
@@ -800,7 +800,7 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, const WhSeqParams& P, const WhPicJob
       } else if (c <= best_cost) { best_cost = c; mb_type = g == 1 ? WH_MB_P16x8 : WH_MB_P8x16; }
     }
 
-    WH_PROF_MARK (P, 4);   // fine partitions
+    WH_PROF_MARK (P, M, 4);   // fine partitions
     // ---- refinement (WelsMdInterMbRefinement) ----
     const int satd_in_md = use_satd;     // bSatdInMdFlag: pfMeCost == pfMdCost == SATD
     int best_sad = 0, best_satd = 0;
@@ -840,7 +840,7 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, const WhSeqParams& P, const WhPicJob
     sad_cost0 = best_sad;
     cost_luma = md_using_sad ? best_sad : best_satd;
 
-    WH_PROF_MARK (P, 5);   // fractional refinement + chroma MC
+    WH_PROF_MARK (P, M, 5);   // fractional refinement + chroma MC
     // ---- encode (WelsMdInterEncode) ----
     wh_dct_luma16 (M);
     cbp = wh_enc_inter_y (M, qp);
@@ -857,7 +857,7 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, const WhSeqParams& P, const WhPicJob
     }
   }
 
-  WH_PROF_MARK (P, 6);   // residual coding
+  WH_PROF_MARK (P, M, 6);   // residual coding
   // ---- store ----
   const bool is_skip = mb_type == WH_MB_PSKIP;
   WH_G WhMbState* Ms = (WH_G WhMbState*)J.mbs + xy;
@@ -901,5 +901,5 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, const WhSeqParams& P, const WhPicJob
   }
   WV_LANES_END
   wh_store_mb (M, P, J, mbx, mby, mb_type, cbp, qp, qpc, 0, 0, cost_luma, slice_idc);
-  WH_PROF_MARK (P, 7);   // store
+  WH_PROF_MARK (P, M, 7);   // store
 }

@@ -36,8 +36,8 @@ typedef struct WhMbLds {
   int16_t  lv_cdc[8];
   int8_t   i4_rem[16];
   uint16_t i4_prev;
-  // inter-prediction scratch (P slices)
-  uint8_t  refwin[1];         // placeholder, the inter kernel uses its own tile type
+  uint8_t  pad_[2];
+  unsigned long long prof[32]; // phase-profiling accumulators of this wave (WH_PROF_MARK)
 } WhMbLds;
 
 #define WH_RY(S, x, y) ((S).rec_y[((y) + 1) * 32 + (x) + 8])

@@ -149,15 +149,17 @@ WH_FN int wh_sad4 (uint32_t a, uint32_t b) { return (int)__builtin_amdgcn_sad_u8
 WH_FN uint32_t wh_avg4 (uint32_t a, uint32_t b) { return __builtin_amdgcn_lerp (a, b, 0x01010101u); }
 #endif
 
-// ---- optional in-kernel phase profiling (WhSeqParams.prof != NULL): cycles since the previous mark are added
-// to counter `id` (64 banks x 32 counters, banked by block id to keep the atomics uncontended) by lane 0.  Costs one uniform branch when disabled.
+// ---- optional in-kernel phase profiling (WhSeqParams.prof != NULL) ----------------------------------------------
+// Cycles since the previous mark are accumulated per wave in LDS (`L`.prof[id], count in prof[16 + id]) by lane 0 and
+// flushed to the global counters once, when the wave leaves the kernel -- no memory traffic inside the MB loop, so the
+// measurement does not perturb the s_waitcnt's it is measuring.  Costs one uniform branch when disabled.
 #if defined(WH_EMU)
 #define WH_PROF_DECL(P) ((void)0)
-#define WH_PROF_MARK(P, id) ((void)0)
+#define WH_PROF_MARK(P, L, id) ((void)0)
 #else
 #define WH_PROF_DECL(P) unsigned long long _wh_t0 = (P).prof ? (unsigned long long)__builtin_readcyclecounter() : 0ULL
-#define WH_PROF_MARK(P, id) do { if ((P).prof) { const unsigned long long _t = (unsigned long long)__builtin_readcyclecounter(); \
-  if ((threadIdx.x & 63) == 0) { unsigned long long* _p = (P).prof + ((blockIdx.x + blockIdx.y * 7u) & 63u) * 32u; atomicAdd (&_p[id], _t - _wh_t0); atomicAdd (&_p[16 + (id)], 1ULL); } _wh_t0 = _t; } } while (0)
+#define WH_PROF_MARK(P, L, id) do { if ((P).prof) { const unsigned long long _t = (unsigned long long)__builtin_readcyclecounter(); \
+  if ((threadIdx.x & 63) == 0) { (L).prof[id] += _t - _wh_t0; (L).prof[16 + (id)] += 1ULL; } _wh_t0 = _t; } } while (0)
 #endif
 
 // ---- small integer helpers (host + device) -----------------------------------------------------
