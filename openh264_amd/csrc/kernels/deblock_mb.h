@@ -10,14 +10,15 @@
 #pragma once
 #include "prims.h"
 
-// LDS tile: luma pixel (x,y), x,y in [-4,15] at y[(y+4)*24 + x+4]; chroma (x,y) in [-2,7] -> c[p][(y+2)*12 + x+2]
+// LDS tile: luma pixel (x,y), x,y in [-4,15] at y[(y+4)*24 + x+4]; chroma (x,y), x in [-4,7], y in [-2,7] -> c[p][(y+2)*12 + x+4]
 typedef struct WhDbLds {
   uint8_t y[20 * 24];
   uint8_t c[2][10 * 12];
   uint8_t bs[2][4][4];       // [dir 0=vertical edges,1=horizontal][edge][segment]
+  uint32_t st[3 * 36];       // WhMbState copies (36 words each): this MB, left, top
 } WhDbLds;
 #define WH_DY(S, x, yy) ((S).y[((yy) + 4) * 24 + (x) + 4])
-#define WH_DC(S, p, x, yy) ((S).c[p][((yy) + 2) * 12 + (x) + 2])
+#define WH_DC(S, p, x, yy) ((S).c[p][((yy) + 2) * 12 + (x) + 4])
 
 // one line of a luma edge: pix points at q0, step = distance between p/q samples
 WH_FN void wh_db_luma_line (uint8_t* q, int step, int bs, int alpha, int beta, int idx_a) {
@@ -80,14 +81,45 @@ WH_FN bool wh_mv_far (const int16_t* a, const int16_t* b) {
 
 WH_FN void wh_deblock_mb_body (WhDbLds& S, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby) {
   const int w = P.mb_w, xy = mby * w + mbx;
-  const WhMbState* M = &J.mbs[xy];
+  // ---- one batch of loads: the three MB states and the pixel tile (4-byte words) ----
+  WV_LANES_BEGIN (lane)
+  {
+    const WH_G WhMbState* Mg = (const WH_G WhMbState*)J.mbs + xy;
+    const WH_G uint8_t* ry = (const WH_G uint8_t*)J.rec[0] + (ptrdiff_t) (mby * 16) * P.rec_stride_y + mbx * 16;
+    uint32_t sv[2] = {0, 0}, yv[2] = {0, 0}, cv = 0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int i = lane + 64 * k, n = i / 36, wd = i - n * 36;
+      if (i < 108 && (n == 0 || (n == 1 ? mbx > 0 : mby > 0))) sv[k] = ((const WH_G uint32_t*) (Mg - (n == 1 ? 1 : n == 2 ? w : 0)))[wd];
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int i = lane + 64 * k, row = i / 5 - 4, x = (i % 5) * 4 - 4;      // luma: 20 rows x 5 words
+      if (i < 100) yv[k] = * (const WH_G uint32_t*) (ry + (ptrdiff_t)row * P.rec_stride_y + x);
+    }
+    if (lane < 60) {                                                          // chroma: 2 planes x 10 rows x 3 words
+      const int pl = lane / 30, k = lane % 30, row = k / 3 - 2, x = (k % 3) * 4 - 4;
+      cv = * (const WH_G uint32_t*) ((const WH_G uint8_t*)J.rec[1 + pl] + (ptrdiff_t) (mby * 8 + row) * P.rec_stride_c + mbx * 8 + x);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) { const int i = lane + 64 * k; if (i < 108) S.st[i] = sv[k]; }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) { const int i = lane + 64 * k; if (i < 100) * (uint32_t*)&S.y[(i / 5) * 24 + (i % 5) * 4] = yv[k]; }
+    if (lane < 60) { const int pl = lane / 30, k = lane % 30; * (uint32_t*)&S.c[pl][(k / 3) * 12 + (k % 3) * 4] = cv; }
+  }
+  WV_LANES_END
+
+  const WhMbState* M = (const WhMbState*)&S.st[0];
+  const WhMbState* Nl = (const WhMbState*)&S.st[36];
+  const WhMbState* Nt = (const WhMbState*)&S.st[72];
   const int fidc = (P.deblock_idc != 0);        // 1: do not filter across slice boundaries
-  const bool left_ok = mbx > 0 && (!fidc || M->slice_idc == M[-1].slice_idc);
-  const bool top_ok = mby > 0 && (!fidc || M->slice_idc == M[-w].slice_idc);
+  const bool left_ok = mbx > 0 && (!fidc || M->slice_idc == Nl->slice_idc);
+  const bool top_ok = mby > 0 && (!fidc || M->slice_idc == Nt->slice_idc);
   const int type = M->mb_type;
   const bool intra = WH_IS_INTRA (type);
 
   // ---- boundary strengths ----
+  int any_bs;
   WV_LANES_BEGIN (lane)
   if (lane < 32) {
     const int dir = lane >> 4, e = (lane >> 2) & 3, s = lane & 3;
@@ -97,7 +129,7 @@ WH_FN void wh_deblock_mb_body (WhDbLds& S, const WhSeqParams& P, const WhPicJob&
     if (e == 0) {
       const bool ok = dir == 0 ? left_ok : top_ok;
       if (ok) {
-        const WhMbState* N = dir == 0 ? M - 1 : M - w;
+        const WhMbState* N = dir == 0 ? Nl : Nt;
         const int bp = dir == 0 ? s * 4 + 3 : 12 + s;
         if (intra || WH_IS_INTRA (N->mb_type)) bs = 4;
         else if (M->nzc[bq] | N->nzc[bp]) bs = 2;
@@ -113,23 +145,8 @@ WH_FN void wh_deblock_mb_body (WhDbLds& S, const WhSeqParams& P, const WhPicJob&
     S.bs[dir][e][s] = (uint8_t)bs;
   }
   WV_LANES_END
-
-  // ---- load tile ----
-  WV_LANES_BEGIN (lane)
-  {
-    // luma: 20 rows x 20 cols (x,y in -4..15) = 5 words per row, 100 words
-    for (int i = lane; i < 100; i += 64) {
-      const int row = i / 5 - 4, x = (i % 5) * 4 - 4;
-      const uint8_t* r = J.rec[0] + (ptrdiff_t) (mby * 16 + row) * P.rec_stride_y + mbx * 16 + x;
-      * (uint32_t*)&S.y[(row + 4) * 24 + x + 4] = * (const uint32_t*)r;
-    }
-    // chroma: 10 rows x (2 + 8) cols per plane: load x = -2..9 as 6 halfwords -> use bytes
-    for (int i = lane; i < 200; i += 64) {
-      const int pl = i / 100, k = i % 100, row = k / 10 - 2, x = k % 10 - 2;
-      WH_DC (S, pl, x, row) = J.rec[1 + pl][(ptrdiff_t) (mby * 8 + row) * P.rec_stride_c + mbx * 8 + x];
-    }
-  }
-  WV_LANES_END
+  WV_ANY (any_bs, lane, (lane < 32 && S.bs[lane >> 4][(lane >> 2) & 3][lane & 3] != 0));
+  if (!any_bs) return;                          // nothing to filter: the picture keeps this MB's pixels as they are
 
   const int qp = M->luma_qp, qpc = M->chroma_qp;
   // ---- vertical edges (dir 0) then horizontal edges (dir 1) ----
@@ -138,7 +155,7 @@ WH_FN void wh_deblock_mb_body (WhDbLds& S, const WhSeqParams& P, const WhPicJob&
       if (e == 0 && !(dir == 0 ? left_ok : top_ok)) continue;
       int eq = qp, eqc = qpc;
       if (e == 0) {
-        const WhMbState* N = dir == 0 ? M - 1 : M - w;
+        const WhMbState* N = dir == 0 ? Nl : Nt;
         eq = (qp + N->luma_qp + 1) >> 1;
         eqc = (qpc + N->chroma_qp + 1) >> 1;
       }
@@ -165,18 +182,20 @@ WH_FN void wh_deblock_mb_body (WhDbLds& S, const WhSeqParams& P, const WhPicJob&
     }
   }
 
-  // ---- store back rows/cols -3..15 (luma), -1..7 (chroma; only p0 changes) ----
+  // ---- store back rows -3..15 (luma) / -1..7 (chroma) as words; the left words only when the left edge was filtered,
+  //      the rows above only when the top edge was, never the corner (it belongs to neither neighbour filtered here) ----
   WV_LANES_BEGIN (lane)
   {
-    for (int i = lane; i < 19 * 19; i += 64) {
-      const int row = i / 19 - 3, x = i % 19 - 3;
+    WH_G uint8_t* ry = (WH_G uint8_t*)J.rec[0] + (ptrdiff_t) (mby * 16) * P.rec_stride_y + mbx * 16;
+    for (int i = lane; i < 19 * 5; i += 64) {
+      const int row = i / 5 - 3, x = (i % 5) * 4 - 4;
       if ((row >= 0 || top_ok) && (x >= 0 || left_ok) && !(row < 0 && x < 0))
-        J.rec[0][(ptrdiff_t) (mby * 16 + row) * P.rec_stride_y + mbx * 16 + x] = WH_DY (S, x, row);
+        * (WH_G uint32_t*) (ry + (ptrdiff_t)row * P.rec_stride_y + x) = * (const uint32_t*)&WH_DY (S, x, row);
     }
-    for (int i = lane; i < 2 * 81; i += 64) {
-      const int pl = i / 81, k = i % 81, row = k / 9 - 1, x = k % 9 - 1;
+    if (lane < 54) {
+      const int pl = lane / 27, k = lane % 27, row = k / 3 - 1, x = (k % 3) * 4 - 4;
       if ((row >= 0 || top_ok) && (x >= 0 || left_ok) && !(row < 0 && x < 0))
-        J.rec[1 + pl][(ptrdiff_t) (mby * 8 + row) * P.rec_stride_c + mbx * 8 + x] = WH_DC (S, pl, x, row);
+        * (WH_G uint32_t*) ((WH_G uint8_t*)J.rec[1 + pl] + (ptrdiff_t) (mby * 8 + row) * P.rec_stride_c + mbx * 8 + x) = * (const uint32_t*)&WH_DC (S, pl, x, row);
     }
   }
   WV_LANES_END

@@ -49,7 +49,7 @@ typedef struct WhInterLds {
   uint8_t prev_y[256];                                      // co-located luma of the previous source picture (VAA SADs)
   uint8_t skip_y[256];                                      // P_Skip prediction
   uint8_t skip_c[128];
-  uint32_t nb[5][36];                                       // WhMbState copies: top-left, top, top-right, left, co-located (reference picture)
+  uint32_t nb[5 * 36];                                      // WhMbState copies: top-left, top, top-right, left, co-located (reference picture)
   int16_t co_mv[2][2];                                      // sP16x16Mv of the reference picture's MBs to the right / below
   int16_t mvcl[5][2];                                       // 16x16 search candidates
   int16_t mvc[30][2];                                       // motion vector cache, 5 rows x 6 cols (row 0 / col 0 = neighbours)
@@ -595,18 +595,18 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, const WhSeqParams& P, const WhPicJob
     wh_tile_commit (M, lane, &tr);
     * (uint32_t*)&S.prev_y[lane * 4] = pv;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { const int i = lane + 64 * k; if (i < 180) S.nb[0][i] = st[k]; }
+    for (int k = 0; k < 3; ++k) { const int i = lane + 64 * k; if (i < 180) S.nb[i] = st[k]; }
     if (lane < 2) * (uint32_t*)&S.co_mv[lane][0] = cm;
   }
   WV_LANES_END
 
   WH_PROF_MARK (P, M, 9);   // batch 1 loads
   // ---- neighbour cache (FillNeighborCacheInterWithoutBGD) ----
-  const WhMbState* TLm = (avail & WH_AV_TOPLEFT) ? (const WhMbState*)S.nb[0] : nullptr;
-  const WhMbState* Tm = (avail & WH_AV_TOP) ? (const WhMbState*)S.nb[1] : nullptr;
-  const WhMbState* TRm = (avail & WH_AV_TOPRIGHT) ? (const WhMbState*)S.nb[2] : nullptr;
-  const WhMbState* Lm = (avail & WH_AV_LEFT) ? (const WhMbState*)S.nb[3] : nullptr;
-  const WhMbState* Co = (const WhMbState*)S.nb[4];
+  const WhMbState* TLm = (avail & WH_AV_TOPLEFT) ? (const WhMbState*)&S.nb[0] : nullptr;
+  const WhMbState* Tm = (avail & WH_AV_TOP) ? (const WhMbState*)&S.nb[36] : nullptr;
+  const WhMbState* TRm = (avail & WH_AV_TOPRIGHT) ? (const WhMbState*)&S.nb[72] : nullptr;
+  const WhMbState* Lm = (avail & WH_AV_LEFT) ? (const WhMbState*)&S.nb[108] : nullptr;
+  const WhMbState* Co = (const WhMbState*)&S.nb[144];
   const int tl_type = TLm ? TLm->mb_type : WH_MB_NONE, t_type = Tm ? Tm->mb_type : WH_MB_NONE;
   const int tr_type = TRm ? TRm->mb_type : WH_MB_NONE, l_type = Lm ? Lm->mb_type : WH_MB_NONE;
   const bool l_inter = WH_IS_INTER (l_type), t_inter = WH_IS_INTER (t_type), tl_inter = WH_IS_INTER (tl_type), tr_inter = WH_IS_INTER (tr_type);
