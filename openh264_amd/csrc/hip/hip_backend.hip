@@ -90,7 +90,57 @@ __global__ __launch_bounds__ (MAX_THREADS) void NAME (WhSeqParams P, const WhPic
 }
 
 WH_DEFINE_MB_KERNEL (k_intra_slice, WhMbLds, wh_intra_mb_body, 512, 0, 0)
-WH_DEFINE_MB_KERNEL (k_inter_slice, WhInterLds, wh_inter_mb_body, 512, 0, 1)
+
+// P pictures: same scheduling, plus a one-MB look-ahead: a wave takes the ticket of its NEXT macroblock before it
+// starts the current one, so that the body can fetch the next MB's cold inputs (straight from HBM) underneath its own
+// arithmetic.  Holding one extra ticket keeps the no-deadlock argument: the lowest unfinished ticket is always being
+// processed, never merely held.
+__global__ __launch_bounds__ (512) void k_inter_slice (WhSeqParams P, const WhPicJob* jobs, uint32_t* err) {
+  extern __shared__ __align__ (16) uint8_t smem[];
+  const int nw = (int)blockDim.x >> 6, lane = (int)threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane ((int)threadIdx.x >> 6);
+  WhInterLds& S = ((WhInterLds*)smem)[wave];
+  uint32_t* sched = (uint32_t*) (smem + (size_t)nw * sizeof (WhInterLds));
+  const int first = P.slice_first_mb[blockIdx.x], n = P.slice_first_mb[blockIdx.x + 1] - first;
+  const uint16_t* order = P.mb_order + first;
+  for (int i = (int)threadIdx.x; i < 1 + ((n + 31) >> 5); i += (int)blockDim.x) sched[i] = 0;
+  if (P.prof && lane < 32) S.m.prof[lane] = 0;
+  __syncthreads();
+  WH_PROF_DECL (P);
+  const WhPicJob& J = jobs[blockIdx.y];
+  WhInterCtx X;
+  X.slice_idc = (int)blockIdx.x; X.slice_first = first;
+  int t = 0;
+  if (lane == 0) t = (int)atomicAdd (&sched[0], 1u);
+  t = __builtin_amdgcn_readfirstlane (t);
+  if (t < n) {
+    int xy = order[t];
+    wh_inter_cold_fetch (S, lane, P, J, xy % P.mb_w, xy / P.mb_w);
+    for (int guard = 0; guard <= n; ++guard) {
+      int tn = 0;
+      if (lane == 0) tn = (int)atomicAdd (&sched[0], 1u);
+      tn = __builtin_amdgcn_readfirstlane (tn);
+      const int xyn = tn < n ? (int)order[tn] : 0;
+      WH_PROF_MARK (P, S.m, 11);
+      int dep_a, dep_b;
+      wh_mb_deps (P.mb_w, xy, first, &dep_a, &dep_b);
+      if (!wh_wait_done (sched + 1, dep_a < 0 ? -1 : dep_a - first, err)) break;
+      if (!wh_wait_done (sched + 1, dep_b < 0 ? -1 : dep_b - first, err)) break;
+      __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "workgroup");
+      WH_PROF_MARK (P, S.m, 12);
+      WV_ASYNC_WAIT();                      /* this MB's cold inputs have landed in S.cold_* */
+      X.next_valid = tn < n; X.next_mbx = xyn % P.mb_w; X.next_mby = xyn / P.mb_w;
+      wh_inter_mb_body (S, P, J, xy % P.mb_w, xy / P.mb_w, X);
+      WH_PROF_MARK (P, S.m, 14);
+      __builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) atomicOr (&sched[1 + ((xy - first) >> 5)], 1u << ((xy - first) & 31));
+      WH_PROF_MARK (P, S.m, 13);
+      if (tn >= n) break;
+      xy = xyn;
+    }
+  }
+  if (P.prof && lane < 32) atomicAdd (&P.prof[((blockIdx.x + blockIdx.y * 7u) & 63u) * 32u + lane], S.m.prof[lane]);
+}
 WH_DEFINE_MB_KERNEL (k_deblock_pic, WhDbLds, wh_deblock_mb_body, 1024, 1, 0)
 
 __global__ __launch_bounds__ (64) void k_expand (WhSeqParams P, const WhPicJob* jobs) {

@@ -57,6 +57,7 @@ typedef struct WhInterLds {
   int16_t mvp_out[16][2];                                   // predictor used for the mvd of each 4x4 (raster)
   int16_t mv_out[16][2];
   int32_t me[9][8];                                         // per slot: mvx, mvy, sad_cost, satd_cost, satd_raw
+  uint32_t cold_y[64], cold_c[64], cold_pv[64], cold_co[64]; // staging of the next MB's cold inputs (wh_inter_cold_fetch)
 } WhInterLds;
 
 typedef struct WhWin { int x0, y0, cx0, cy0; } WhWin;       // picture coordinates of element (0,0) of win / cwin
@@ -553,13 +554,41 @@ WH_FN bool wh_try_puv_skip (WhMbLds& S, int pl, int qpc) {
   return big == 0 && ctr < 7;
 }
 
+// ---- "cold" inputs of a P macroblock: data no kernel writes while the picture is being coded (source samples,
+// previous source picture, the reference picture's MB states).  They come straight from HBM, so a wave starts their
+// copy into the LDS staging words S.cold_* for its NEXT macroblock while it is still busy with the current one
+// (LDS-DMA: no registers held), and moves them into place when that MB starts.
+WH_FN void wh_inter_cold_fetch (WhInterLds& S, int lane, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby) {
+  const int w = P.mb_w, xy = mby * w + mbx;
+  wh_ld_async4 ((const WH_G uint8_t*)J.src[0] + (size_t) (mby * 16 + (lane >> 2)) * P.src_stride_y + mbx * 16 + (lane & 3) * 4, S.cold_y, lane);
+  if (lane < 32) {
+    const int pl = lane >> 4, row = (lane >> 1) & 7, half = lane & 1;
+    wh_ld_async4 ((const WH_G uint8_t*)J.src[1 + pl] + (size_t) (mby * 8 + row) * P.src_stride_c + mbx * 8 + half * 4, S.cold_c, lane);
+  }
+  if (P.complexity == 0)     // VAA 8x8 SADs (LOW complexity only)
+    wh_ld_async4 ((const WH_G uint8_t*)J.prev_src_y + (size_t) (mby * 16 + (lane >> 2)) * P.src_stride_y + mbx * 16 + (lane & 3) * 4, S.cold_pv, lane);
+  if (J.ref_is_p) {
+    if (lane < 36) wh_ld_async4 ((const WH_G uint32_t*) ((const WH_G WhMbState*)J.ref_mbs + xy) + lane, S.cold_co, lane);
+    else if (lane < 38) {
+      const bool ok = lane == 36 ? mbx < P.mb_w - 1 : mby < P.mb_h - 1;
+      const WH_G WhMbState* o = (const WH_G WhMbState*)J.ref_mbs + xy + (lane == 36 ? 1 : w);
+      if (ok) wh_ld_async4 (&o->p16mv[0], S.cold_co, lane);
+    }
+  }
+}
+
+typedef struct WhInterCtx {
+  int slice_idc, slice_first;        // slice of this MB and its first MB address
+  int next_valid, next_mbx, next_mby;   // the MB this wave processes next (its cold inputs are fetched during this one)
+} WhInterCtx;
+
 // ---- the P macroblock -----------------------------------------------------------------------------
-WH_FN void wh_inter_mb_body (WhInterLds& S, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby) {
+WH_FN void wh_inter_mb_body (WhInterLds& S, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, const WhInterCtx& X) {
   WH_PROF_DECL (P);
   WhMbLds& M = S.m;
   const int w = P.mb_w, xy = mby * w + mbx;
-  const int slice_idc = wh_slice_of_mb (P, xy);
-  const int avail = wh_mb_avail_in_slice (P, mbx, mby, P.slice_first_mb[slice_idc]);
+  const int slice_idc = X.slice_idc;
+  const int avail = wh_mb_avail_in_slice (P, mbx, mby, X.slice_first);
   const int qp = wh_clip3 (J.qp, 0, 51);
   const int qpc = kWhChromaQp[wh_clip3 (qp + P.chroma_qp_offset, 0, 51)];
   const int lambda = kWhLambda[qp];
@@ -568,35 +597,29 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, const WhSeqParams& P, const WhPicJob
   const bool ref_is_p = J.ref_is_p != 0;
 
   WH_PROF_MARK (P, M, 8);   // kernel arguments, job descriptor, slice lookup
-  // ---- batch 1: source tile, neighbour pixels, previous source tile, neighbour + co-located MB states ----
+  // ---- batch 1: commit the cold inputs fetched earlier; load neighbour pixels + neighbour MB states (L2-warm: the
+  //      neighbours were coded by waves of this very workgroup) ----
   WV_LANES_BEGIN (lane)
   {
     WhTileRegs tr;
-    wh_tile_fetch (lane, P, J, mbx, mby, &tr);
-    uint32_t pv = 0, st[3] = {0, 0, 0}, cm = 0;
-    if (md_using_sad)
-      pv = * (const WH_G uint32_t*) ((const WH_G uint8_t*)J.prev_src_y + (size_t) (mby * 16 + (lane >> 2)) * P.src_stride_y + mbx * 16 + (lane & 3) * 4);
+    wh_tile_fetch_nb (lane, P, J, mbx, mby, &tr);
+    uint32_t st[3] = {0, 0, 0};
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      const int i = lane + 64 * k, n = i / 36, wd = i - n * 36;           // state n (0 TL, 1 T, 2 TR, 3 L, 4 co-located), dword wd
-      if (i < 180) {
-        const bool ok = n == 0 ? (avail & WH_AV_TOPLEFT) != 0 : n == 1 ? (avail & WH_AV_TOP) != 0 : n == 2 ? (avail & WH_AV_TOPRIGHT) != 0 :
-                        n == 3 ? (avail & WH_AV_LEFT) != 0 : ref_is_p;
-        const int off = n == 0 ? -w - 1 : n == 1 ? -w : n == 2 ? -w + 1 : n == 3 ? -1 : 0;
-        const WH_G WhMbState* base = n == 4 ? (const WH_G WhMbState*)J.ref_mbs : (const WH_G WhMbState*)J.mbs;
-        if (ok) st[k] = ((const WH_G uint32_t*) (base + xy + off))[wd];
+      const int i = lane + 64 * k, n = i / 36, wd = i - n * 36;           // state n (0 TL, 1 T, 2 TR, 3 L), dword wd
+      if (i < 144) {
+        const bool ok = n == 0 ? (avail & WH_AV_TOPLEFT) != 0 : n == 1 ? (avail & WH_AV_TOP) != 0 : n == 2 ? (avail & WH_AV_TOPRIGHT) != 0 : (avail & WH_AV_LEFT) != 0;
+        const int off = n == 0 ? -w - 1 : n == 1 ? -w : n == 2 ? -w + 1 : -1;
+        if (ok) st[k] = ((const WH_G uint32_t*) ((const WH_G WhMbState*)J.mbs + xy + off))[wd];
       }
     }
-    if (ref_is_p && lane < 2) {
-      const bool ok = lane == 0 ? mbx < P.mb_w - 1 : mby < P.mb_h - 1;
-      const WH_G WhMbState* o = (const WH_G WhMbState*)J.ref_mbs + xy + (lane == 0 ? 1 : w);
-      if (ok) cm = * (const WH_G uint32_t*)&o->p16mv[0];
-    }
+    tr.y = S.cold_y[lane]; tr.c = S.cold_c[lane];
     wh_tile_commit (M, lane, &tr);
-    * (uint32_t*)&S.prev_y[lane * 4] = pv;
+    * (uint32_t*)&S.prev_y[lane * 4] = S.cold_pv[lane];
+    if (lane < 36) S.nb[144 + lane] = S.cold_co[lane];
+    else if (lane < 38) * (uint32_t*)&S.co_mv[lane - 36][0] = S.cold_co[lane];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { const int i = lane + 64 * k; if (i < 180) S.nb[i] = st[k]; }
-    if (lane < 2) * (uint32_t*)&S.co_mv[lane][0] = cm;
+    for (int k = 0; k < 3; ++k) { const int i = lane + 64 * k; if (i < 144) S.nb[i] = st[k]; }
   }
   WV_LANES_END
 
@@ -640,6 +663,12 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, const WhSeqParams& P, const WhPicJob
   WhWin W;
   wh_win_load_all (S, P, J, W, mbx * 16 + wh_clip3 ((2 + me16.mvpx) >> 2, C.minx, C.maxx), mby * 16 + wh_clip3 ((2 + me16.mvpy) >> 2, C.miny, C.maxy));
 
+  // ---- cold inputs of this wave's next MB: in flight while the rest of this MB runs ----
+  if (X.next_valid) {
+    WV_LANES_BEGIN (lane)
+    wh_inter_cold_fetch (S, lane, P, J, X.next_mbx, X.next_mby);
+    WV_LANES_END
+  }
   WH_PROF_MARK (P, M, 0);   // mvp + batch 2 (window) loads
   int mb_type = WH_MB_P16x16, cbp = 0, cost_luma = 0, cost_skip_mb = 0, sad_cost0 = 0;
   int p16x = 0, p16y = 0;                       // sP16x16Mv

@@ -43,17 +43,22 @@ WH_FN int wh_mb_avail (const WhSeqParams& P, int mbx, int mby) {
 // further loads between the two and pay the HBM latency once.
 typedef struct WhTileRegs { uint32_t y, c, nb; } WhTileRegs;
 
-WH_FN void wh_tile_fetch (int lane, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, WhTileRegs* r) {
+// source samples of the MB (never written on the device: may be fetched long before the MB is processed)
+WH_FN void wh_tile_fetch_src (int lane, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, WhTileRegs* r) {
   {
     const int row = lane >> 2, seg = lane & 3;
     r->y = * (const WH_G uint32_t*) ((const WH_G uint8_t*)J.src[0] + (size_t) (mby * 16 + row) * P.src_stride_y + mbx * 16 + seg * 4);
   }
-  r->c = 0; r->nb = 0;
+  r->c = 0;
   if (lane < 32) {
     const int pl = lane >> 4, row = (lane >> 1) & 7, half = lane & 1;
     r->c = * (const WH_G uint32_t*) ((const WH_G uint8_t*)J.src[1 + pl] + (size_t) (mby * 8 + row) * P.src_stride_c + mbx * 8 + half * 4);
   }
-  // reconstructed neighbours (garbage where unavailable -- never consumed then)
+}
+// reconstructed neighbour samples (written by the neighbour MBs: only after they are done)
+WH_FN void wh_tile_fetch_nb (int lane, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, WhTileRegs* r) {
+  r->nb = 0;
+  // garbage where unavailable -- never consumed then
   if (lane < 7) {                        // luma row -1, x = -4 .. 23 in 4-byte words
     const int x = lane * 4 - 4;
     r->nb = * (const WH_G uint32_t*) ((const WH_G uint8_t*)J.rec[0] + (ptrdiff_t) (mby * 16 - 1) * P.rec_stride_y + mbx * 16 + x);
@@ -67,6 +72,10 @@ WH_FN void wh_tile_fetch (int lane, const WhSeqParams& P, const WhPicJob& J, int
     const int pl = (lane - 48) >> 3, y = lane & 7;
     r->nb = ((const WH_G uint8_t*)J.rec[1 + pl])[(ptrdiff_t) (mby * 8 + y) * P.rec_stride_c + mbx * 8 - 1];
   }
+}
+WH_FN void wh_tile_fetch (int lane, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, WhTileRegs* r) {
+  wh_tile_fetch_src (lane, P, J, mbx, mby, r);
+  wh_tile_fetch_nb (lane, P, J, mbx, mby, r);
 }
 WH_FN void wh_tile_commit (WhMbLds& S, int lane, const WhTileRegs* r) {
   {

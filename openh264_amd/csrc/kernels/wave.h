@@ -55,6 +55,10 @@
 #define WH_G
 #include <string.h>
 #include <stdlib.h>
+// asynchronous copy of one 4-byte word per lane from global memory to LDS word `lane` of `lds_base` (GPU: LDS-DMA,
+// no register holds the data; complete after WV_ASYNC_WAIT)
+WH_FN void wh_ld_async4 (const void* src, uint32_t* lds_base, int lane) { memcpy (&lds_base[lane], src, 4); }
+#define WV_ASYNC_WAIT() ((void)0)
 // four bytes at any byte offset of a 4-byte aligned LDS array
 WH_FN uint32_t wh_ld4u (const uint8_t* base, int off) { uint32_t v; memcpy (&v, base + off, 4); return v; }
 // sum of absolute differences of four packed bytes
@@ -145,6 +149,10 @@ WH_FN uint32_t wh_ld4u (const uint8_t* base, int off) {
   const uint32_t* w = (const uint32_t*)base + (off >> 2);
   return __builtin_amdgcn_alignbyte (w[1], w[0], (uint32_t)off & 3u);
 }
+WH_FN void wh_ld_async4 (const WH_G void* src, uint32_t* lds_base, int /*lane*/) {
+  __builtin_amdgcn_global_load_lds ((const WH_G uint32_t*)src, (__attribute__ ((address_space (3))) uint32_t*)lds_base, 4, 0, 0);
+}
+#define WV_ASYNC_WAIT() asm volatile ("s_waitcnt vmcnt(0)" ::: "memory")
 WH_FN int wh_sad4 (uint32_t a, uint32_t b) { return (int)__builtin_amdgcn_sad_u8 (a, b, 0u); }
 WH_FN uint32_t wh_avg4 (uint32_t a, uint32_t b) { return __builtin_amdgcn_lerp (a, b, 0x01010101u); }
 #endif

@@ -38,7 +38,14 @@ class EmuBackend : public Backend {
     for_order (P, n, false, [&] (int j, int x, int y) { WhMbLds S; wh_intra_mb_body (S, P, jobs[j], x, y); });
   }
   void run_inter (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
-    for_order (P, n, false, [&] (int j, int x, int y) { WhInterLds S; wh_inter_mb_body (S, P, jobs[j], x, y); });
+    for_order (P, n, false, [&] (int j, int x, int y) {
+      WhInterLds S;
+      for (int lane = 0; lane < 64; ++lane) wh_inter_cold_fetch (S, lane, P, jobs[j], x, y);
+      WhInterCtx X;
+      X.slice_idc = wh_slice_of_mb (P, y * P.mb_w + x); X.slice_first = P.slice_first_mb[X.slice_idc];
+      X.next_valid = 0; X.next_mbx = X.next_mby = 0;
+      wh_inter_mb_body (S, P, jobs[j], x, y, X);
+    });
   }
   void run_deblock (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
     for_order (P, n, true, [&] (int j, int x, int y) { WhDbLds S; wh_deblock_mb_body (S, P, jobs[j], x, y); });
