@@ -419,47 +419,145 @@ WH_FN void wh_me_fetch (const WhInterLds& S, int slot, WhMe& me) {
   me.mvx = q[0]; me.mvy = q[1]; me.sad_cost = q[2]; me.satd_cost = q[3]; me.satd_raw = q[4];
 }
 
-// ---- fractional refinement (MeRefineFracPixel): returns through me.mvx/mvy/satd_cost, writes the
-// final luma prediction of the block into S.m.pred_y -------------------------------------------------
+// ---- fractional refinement (MeRefineFracPixel / MeRefineQuarPixel, md.cpp:575-769) -------------------------------
+// The search always starts from an integer position, so the candidate set is fixed: the four half-sample neighbours
+// (top, bottom, left, right: two h-type and two b-type samples), then the four quarter-sample neighbours of the best
+// of those five -- each quarter candidate is the average of two samples of which at least one is already known.
+// Everything below is per lane: four horizontally adjacent samples packed in a word, `o` = window offset of the
+// lane's integer samples G.
+
+// vertical half samples above (hu, between rows -1 and 0) and below (hd) G
+WH_FN void wh_rf_h_pair (const uint8_t* w, int o, uint32_t* hu, uint32_t* hd) {
+  uint32_t r[7];
+  for (int k = 0; k < 7; ++k) r[k] = wh_ld4u (w, o + (k - 3) * WH_WIN_STRIDE);
+  int u[4], d[4];
+  for (int k = 0; k < 4; ++k) {
+    u[k] = wh_clip255 ((wh_tap6 (WH_BYTE (r[0], k), WH_BYTE (r[1], k), WH_BYTE (r[2], k), WH_BYTE (r[3], k), WH_BYTE (r[4], k), WH_BYTE (r[5], k)) + 16) >> 5);
+    d[k] = wh_clip255 ((wh_tap6 (WH_BYTE (r[1], k), WH_BYTE (r[2], k), WH_BYTE (r[3], k), WH_BYTE (r[4], k), WH_BYTE (r[5], k), WH_BYTE (r[6], k)) + 16) >> 5);
+  }
+  *hu = wh_pack4 (u[0], u[1], u[2], u[3]); *hd = wh_pack4 (d[0], d[1], d[2], d[3]);
+}
+// unclipped horizontal 6-tap sums at the five positions x-1 .. x+3 of the row at o (bytes o-3 .. o+6)
+WH_FN void wh_htaps5 (const uint8_t* w, int o, int* t /*[5]*/) {
+  const uint32_t a = wh_ld4u (w, o - 3), b = wh_ld4u (w, o + 1), c = wh_ld4u (w, o + 5);
+  int q[10];
+  for (int k = 0; k < 4; ++k) { q[k] = WH_BYTE (a, k); q[4 + k] = WH_BYTE (b, k); }
+  q[8] = WH_BYTE (c, 0); q[9] = WH_BYTE (c, 1);
+  for (int k = 0; k < 5; ++k) t[k] = wh_tap6 (q[k], q[k + 1], q[k + 2], q[k + 3], q[k + 4], q[k + 5]);
+}
+// horizontal half samples left (bl, between x-1 and x) and right (br) of G
+WH_FN void wh_rf_b_pair (const uint8_t* w, int o, uint32_t* bl, uint32_t* br) {
+  int t[5];
+  wh_htaps5 (w, o, t);
+  int v[5];
+  for (int k = 0; k < 5; ++k) v[k] = wh_clip255 ((t[k] + 16) >> 5);
+  *bl = wh_pack4 (v[0], v[1], v[2], v[3]); *br = wh_pack4 (v[1], v[2], v[3], v[4]);
+}
+// centre half samples j at (o-1, o): the two that flank a vertical half sample h4 (o)
+WH_FN void wh_rf_j_pair_h (const uint8_t* w, int o, uint32_t* jl, uint32_t* jr) {
+  int t[6][5];
+  for (int k = 0; k < 6; ++k) wh_htaps5 (w, o + (k - 2) * WH_WIN_STRIDE, t[k]);
+  int v[5];
+  for (int x = 0; x < 5; ++x) v[x] = wh_clip255 ((wh_tap6 (t[0][x], t[1][x], t[2][x], t[3][x], t[4][x], t[5][x]) + 512) >> 10);
+  *jl = wh_pack4 (v[0], v[1], v[2], v[3]); *jr = wh_pack4 (v[1], v[2], v[3], v[4]);
+}
+// centre half samples j at (o - stride, o): the two that flank a horizontal half sample b4 (o)
+WH_FN void wh_rf_j_pair_v (const uint8_t* w, int o, uint32_t* ju, uint32_t* jd) {
+  int t[7][4];
+  for (int k = 0; k < 7; ++k) wh_htaps4 (w, o + (k - 3) * WH_WIN_STRIDE, &t[k][0], &t[k][1], &t[k][2], &t[k][3]);
+  int u[4], d[4];
+  for (int x = 0; x < 4; ++x) {
+    u[x] = wh_clip255 ((wh_tap6 (t[0][x], t[1][x], t[2][x], t[3][x], t[4][x], t[5][x]) + 512) >> 10);
+    d[x] = wh_clip255 ((wh_tap6 (t[1][x], t[2][x], t[3][x], t[4][x], t[5][x], t[6][x]) + 512) >> 10);
+  }
+  *ju = wh_pack4 (u[0], u[1], u[2], u[3]); *jd = wh_pack4 (d[0], d[1], d[2], d[3]);
+}
+// half-sample candidate k (0 top, 1 bottom, 2 left, 3 right) of the integer position at o
+WH_FN uint32_t wh_rf_half (const uint8_t* w, int o, int k) {
+  uint32_t a, b;
+  if (k < 2) { wh_rf_h_pair (w, o, &a, &b); return k == 0 ? a : b; }
+  wh_rf_b_pair (w, o, &a, &b);
+  return k == 2 ? a : b;
+}
+// quarter-sample candidate k (0 top, 1 bottom, 2 left, 3 right) around the half-stage winner hb
+// (-1: the integer position itself, 0..3: half candidate hb)
+WH_FN uint32_t wh_rf_quarter (const uint8_t* w, int o, int hb, int k) {
+  const uint32_t G = wh_ld4u (w, o);
+  uint32_t a, b;
+  switch (hb) {
+  case -1: return wh_avg4 (G, wh_rf_half (w, o, k));
+  case 0:                                                    // hu, the h sample of the row above (at o - stride)
+    wh_rf_h_pair (w, o, &a, &b);
+    if (k == 0) return wh_avg4 (wh_ld4u (w, o - WH_WIN_STRIDE), a);
+    if (k == 1) return wh_avg4 (G, a);
+    { uint32_t jl, jr; wh_rf_j_pair_h (w, o - WH_WIN_STRIDE, &jl, &jr); return wh_avg4 (k == 2 ? jl : jr, a); }
+  case 1:                                                    // hd
+    wh_rf_h_pair (w, o, &a, &b);
+    if (k == 0) return wh_avg4 (G, b);
+    if (k == 1) return wh_avg4 (wh_ld4u (w, o + WH_WIN_STRIDE), b);
+    { uint32_t jl, jr; wh_rf_j_pair_h (w, o, &jl, &jr); return wh_avg4 (k == 2 ? jl : jr, b); }
+  case 2:                                                    // bl, the b sample of the column to the left (at o - 1)
+    wh_rf_b_pair (w, o, &a, &b);
+    if (k == 2) return wh_avg4 (wh_ld4u (w, o - 1), a);
+    if (k == 3) return wh_avg4 (G, a);
+    { uint32_t ju, jd; wh_rf_j_pair_v (w, o - 1, &ju, &jd); return wh_avg4 (k == 0 ? ju : jd, a); }
+  default:                                                   // br
+    wh_rf_b_pair (w, o, &a, &b);
+    if (k == 2) return wh_avg4 (G, b);
+    if (k == 3) return wh_avg4 (wh_ld4u (w, o + 1), b);
+    { uint32_t ju, jd; wh_rf_j_pair_v (w, o, &ju, &jd); return wh_avg4 (k == 0 ? ju : jd, b); }
+  }
+}
+
+// Returns through me.mvx/mvy/satd_cost, writes the final luma prediction of the block into S.m.pred_y.
 WH_FN void wh_refine_frac (WhInterLds& S, const WhSeqParams& P, const WhPicJob& J, WhWin& W, const WhMeCtx& C, WhMe& me, int satd_in_md) {
   const int bpx = C.mbx * 16 + me.bx, bpy = C.mby * 16 + me.by;
   const int ipx = bpx + (me.mvx >> 2), ipy = bpy + (me.mvy >> 2);          // me.mv is integer-pel here
   wh_win_ensure (S, P, J, W, ipx - 4, ipy - 4, ipx + me.bw + 8, ipy + me.bh + 5);
   const int wo = (ipy - W.y0) * WH_WIN_STRIDE + ipx - W.x0;
-  const int nq = (me.bw >> 2) * (me.bh >> 2) * 4;
-  int best = 0x7fffffff, bmx = me.mvx, bmy = me.mvy, basex = me.mvx, basey = me.mvy;
-  // k = -1: the integer position; 0..3: half-pel top, bottom, left, right; 4..7: quarter-pel around the best so far
-  for (int k = -1; k < 8; ++k) {
-    if (k == 4) { basex = bmx; basey = bmy; }
-    int cx = basex, cy = basey;
-    if (k >= 0) {
-      const int step = k < 4 ? 2 : 1, kk = k & 3;
-      cx += kk == 2 ? -step : kk == 3 ? step : 0;
-      cy += kk == 0 ? -step : kk == 1 ? step : 0;
-    } else if (satd_in_md) {
-      best = me.satd_raw + wh_mvd_cost (C.lambda, me.mvx - me.mvpx, me.mvy - me.mvpy);   // uiSatd of the integer search
-      continue;
-    }
-    const int o = wo + ((cy >> 2) - (me.mvy >> 2)) * WH_WIN_STRIDE + (cx >> 2) - (me.mvx >> 2), fx = cx & 3, fy = cy & 3;
-    int c;
-    WV_SATD_ROWS (c, lane, lane < nq,
-                  wh_enc4 (S, me.bx + (lane < nq ? wh_tl_col (lane, me.bw) : 0), me.by + (lane < nq ? wh_tl_row (lane, me.bw) : 0)),
-                  wh_mc4 (S.win, o + (lane < nq ? wh_tl_row (lane, me.bw) * WH_WIN_STRIDE + wh_tl_col (lane, me.bw) : 0), fx, fy));
-    c += wh_mvd_cost (C.lambda, cx - me.mvpx, cy - me.mvpy);
-    if (c < best) { best = c; bmx = cx; bmy = cy; }
-  }
+  const int nq = (me.bw >> 2) * (me.bh >> 2) * 4, bw = me.bw, ex = me.bx, ey = me.by;
+#define WH_RF_ACT (lane < nq)
+#define WH_RF_ENC wh_enc4 (S, ex + (lane < nq ? wh_tl_col (lane, bw) : 0), ey + (lane < nq ? wh_tl_row (lane, bw) : 0))
+#define WH_RF_O (wo + (lane < nq ? wh_tl_row (lane, bw) * WH_WIN_STRIDE + wh_tl_col (lane, bw) : 0))
+  const int dmx = me.mvx - me.mvpx, dmy = me.mvy - me.mvpy;
+  // integer position + the four half-sample candidates (independent of each other: the SATDs overlap)
+  int c_int, c0, c1, c2, c3;
+  if (satd_in_md) c_int = me.satd_raw;                                      // uiSatd of the integer search
+  else WV_SATD_ROWS (c_int, lane, WH_RF_ACT, WH_RF_ENC, wh_ld4u (S.win, WH_RF_O));
+  WV_SATD_ROWS (c0, lane, WH_RF_ACT, WH_RF_ENC, wh_rf_half (S.win, WH_RF_O, 0));
+  WV_SATD_ROWS (c1, lane, WH_RF_ACT, WH_RF_ENC, wh_rf_half (S.win, WH_RF_O, 1));
+  WV_SATD_ROWS (c2, lane, WH_RF_ACT, WH_RF_ENC, wh_rf_half (S.win, WH_RF_O, 2));
+  WV_SATD_ROWS (c3, lane, WH_RF_ACT, WH_RF_ENC, wh_rf_half (S.win, WH_RF_O, 3));
+  int best = c_int + wh_mvd_cost (C.lambda, dmx, dmy), hb = -1;
+  c0 += wh_mvd_cost (C.lambda, dmx, dmy - 2); if (c0 < best) { best = c0; hb = 0; }
+  c1 += wh_mvd_cost (C.lambda, dmx, dmy + 2); if (c1 < best) { best = c1; hb = 1; }
+  c2 += wh_mvd_cost (C.lambda, dmx - 2, dmy); if (c2 < best) { best = c2; hb = 2; }
+  c3 += wh_mvd_cost (C.lambda, dmx + 2, dmy); if (c3 < best) { best = c3; hb = 3; }
+  const int hx = hb == 2 ? -2 : hb == 3 ? 2 : 0, hy = hb == 0 ? -2 : hb == 1 ? 2 : 0;    // winner of the half stage, relative
+  // quarter-sample candidates around it
+  WV_SATD_ROWS (c0, lane, WH_RF_ACT, WH_RF_ENC, wh_rf_quarter (S.win, WH_RF_O, hb, 0));
+  WV_SATD_ROWS (c1, lane, WH_RF_ACT, WH_RF_ENC, wh_rf_quarter (S.win, WH_RF_O, hb, 1));
+  WV_SATD_ROWS (c2, lane, WH_RF_ACT, WH_RF_ENC, wh_rf_quarter (S.win, WH_RF_O, hb, 2));
+  WV_SATD_ROWS (c3, lane, WH_RF_ACT, WH_RF_ENC, wh_rf_quarter (S.win, WH_RF_O, hb, 3));
+  int qb = -1;
+  c0 += wh_mvd_cost (C.lambda, dmx + hx, dmy + hy - 1); if (c0 < best) { best = c0; qb = 0; }
+  c1 += wh_mvd_cost (C.lambda, dmx + hx, dmy + hy + 1); if (c1 < best) { best = c1; qb = 1; }
+  c2 += wh_mvd_cost (C.lambda, dmx + hx - 1, dmy + hy); if (c2 < best) { best = c2; qb = 2; }
+  c3 += wh_mvd_cost (C.lambda, dmx + hx + 1, dmy + hy); if (c3 < best) { best = c3; qb = 3; }
+  const int qx = qb == 2 ? -1 : qb == 3 ? 1 : 0, qy = qb == 0 ? -1 : qb == 1 ? 1 : 0;
   me.satd_cost = best;
-  {
-    const int o = wo + ((bmy >> 2) - (me.mvy >> 2)) * WH_WIN_STRIDE + (bmx >> 2) - (me.mvx >> 2), fx = bmx & 3, fy = bmy & 3;
-    const int n = (me.bw * me.bh) >> 2;
-    WV_LANES_BEGIN (lane)
-    if (lane < n) {
-      const int r = wh_sl_row (lane, me.bw), c = wh_sl_col (lane, me.bw);
-      * (uint32_t*)&S.m.pred_y[(me.by + r) * 16 + me.bx + c] = wh_mc4 (S.win, o + r * WH_WIN_STRIDE + c, fx, fy);
-    }
-    WV_LANES_END
+  // the winner's samples become the prediction
+  WV_LANES_BEGIN (lane)
+  if (lane < nq) {
+    const int o = WH_RF_O;
+    const uint32_t v = qb >= 0 ? wh_rf_quarter (S.win, o, hb, qb) : hb >= 0 ? wh_rf_half (S.win, o, hb) : wh_ld4u (S.win, o);
+    * (uint32_t*)&S.m.pred_y[(ey + wh_tl_row (lane, bw)) * 16 + ex + wh_tl_col (lane, bw)] = v;
   }
-  me.mvx = bmx; me.mvy = bmy;
+  WV_LANES_END
+#undef WH_RF_ACT
+#undef WH_RF_ENC
+#undef WH_RF_O
+  me.mvx += hx + qx; me.mvy += hy + qy;
 }
 
 // ---- inter luma residual (WelsEncInterY) on S.m.res after wh_dct_luma16; returns cbp luma -----------
