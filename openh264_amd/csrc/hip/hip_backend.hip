@@ -48,7 +48,7 @@ __device__ __forceinline__ bool wh_wait_done (const uint32_t* done, int idx, uin
 __device__ __forceinline__ WhMbLds& wh_prof_holder (WhInterLds& S) { return S.m; }
 __device__ __forceinline__ WhMbLds& wh_prof_holder (WhMbLds& S) { return S; }
 __device__ __forceinline__ WhMbLds& wh_prof_holder (WhDbLds& S) { return * (WhMbLds*)&S; }     /* never used (PROF = 0) */
-template <class T> __device__ __forceinline__ unsigned long long* wh_prof_lds (T& S) { return wh_prof_holder (S).prof; }
+template <class T> __device__ __forceinline__ uint32_t* wh_prof_lds (T& S) { return wh_prof_holder (S).prof; }
 
 #define WH_DEFINE_MB_KERNEL(NAME, LDS_T, BODY, MAX_THREADS, WHOLE_PICTURE, PROF)                                             \
 __global__ __launch_bounds__ (MAX_THREADS) void NAME (WhSeqParams P, const WhPicJob* jobs, uint32_t* err) {             \
@@ -86,7 +86,7 @@ __global__ __launch_bounds__ (MAX_THREADS) void NAME (WhSeqParams P, const WhPic
     if (lane == 0) atomicOr (&sched[1 + ((xy - first) >> 5)], 1u << ((xy - first) & 31));                               \
     if (PROF) WH_PROF_MARK (P, wh_prof_holder (S), 13);      /* store drain (release) + done flag */                     \
   }                                                                                                                     \
-  if (PROF && P.prof && lane < 32) atomicAdd (&P.prof[((blockIdx.x + blockIdx.y * 7u) & 63u) * 32u + lane], wh_prof_lds (S)[lane]); \
+  if (PROF && P.prof && lane < 32) atomicAdd (&P.prof[((blockIdx.x + blockIdx.y * 7u) & 63u) * 32u + lane], (unsigned long long)wh_prof_lds (S)[lane]); \
 }
 
 WH_DEFINE_MB_KERNEL (k_intra_slice, WhMbLds, wh_intra_mb_body, 512, 0, 0)
@@ -95,7 +95,8 @@ WH_DEFINE_MB_KERNEL (k_intra_slice, WhMbLds, wh_intra_mb_body, 512, 0, 0)
 // starts the current one, so that the body can fetch the next MB's cold inputs (straight from HBM) underneath its own
 // arithmetic.  Holding one extra ticket keeps the no-deadlock argument: the lowest unfinished ticket is always being
 // processed, never merely held.
-__global__ __launch_bounds__ (512) void k_inter_slice (WhSeqParams P, const WhPicJob* jobs, uint32_t* err) {
+template <int MAXT, int WPE>
+__global__ __launch_bounds__ (MAXT) __attribute__ ((amdgpu_waves_per_eu (WPE, WPE))) void k_inter_slice (WhSeqParams P, const WhPicJob* jobs, uint32_t* err) {
   extern __shared__ __align__ (16) uint8_t smem[];
   const int nw = (int)blockDim.x >> 6, lane = (int)threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane ((int)threadIdx.x >> 6);
@@ -139,7 +140,7 @@ __global__ __launch_bounds__ (512) void k_inter_slice (WhSeqParams P, const WhPi
       xy = xyn;
     }
   }
-  if (P.prof && lane < 32) atomicAdd (&P.prof[((blockIdx.x + blockIdx.y * 7u) & 63u) * 32u + lane], S.m.prof[lane]);
+  if (P.prof && lane < 32) atomicAdd (&P.prof[((blockIdx.x + blockIdx.y * 7u) & 63u) * 32u + lane], (unsigned long long)S.m.prof[lane]);
 }
 WH_DEFINE_MB_KERNEL (k_deblock_pic, WhDbLds, wh_deblock_mb_body, 1024, 1, 0)
 
@@ -212,7 +213,14 @@ class HipBackend : public wh::Backend {
     if (getenv ("WELSHIP_TRACE")) { HIP_CHECK (hipStreamSynchronize (stream_)); fprintf (stderr, "welship: launch done\n"); fflush (stderr); }
   }
   void run_intra (const WhSeqParams& P, const WhPicJob* jobs, int n) override { mb_pass (k_intra_slice, sizeof (WhMbLds), 8, false, P, jobs, n); }
-  void run_inter (const WhSeqParams& P, const WhPicJob* jobs, int n) override { mb_pass (k_inter_slice, sizeof (WhInterLds), 8, false, P, jobs, n); }
+  // P pictures: 8 waves per workgroup with the full register file (2 waves/SIMD), or -- WELSHIP_P_WAVES=6 / 12 -- variants
+  // compiled for 3 waves/SIMD: 6-wave workgroups (two slices share a CU) or 12-wave workgroups
+  void run_inter (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
+    static const int waves = getenv ("WELSHIP_P_WAVES") ? atoi (getenv ("WELSHIP_P_WAVES")) : 8;
+    if (waves == 6) mb_pass (k_inter_slice<384, 3>, sizeof (WhInterLds), 6, false, P, jobs, n);
+    else if (waves == 12) mb_pass (k_inter_slice<768, 3>, sizeof (WhInterLds), 12, false, P, jobs, n);
+    else mb_pass (k_inter_slice<512, 2>, sizeof (WhInterLds), 8, false, P, jobs, n);
+  }
   void run_deblock (const WhSeqParams& P, const WhPicJob* jobs, int n) override { mb_pass (k_deblock_pic, sizeof (WhDbLds), 16, true, P, jobs, n); }
   void run_expand (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
     hipLaunchKernelGGL (k_expand, dim3 (wh_expand_num_blocks (P), n), dim3 (64), 0, stream_, P, jobs);

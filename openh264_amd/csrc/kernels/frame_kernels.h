@@ -41,7 +41,7 @@ WH_FN void wh_store_mb (WhMbLds& S, const WhSeqParams& P, const WhPicJob& J, int
   } else if (lane < 48) {
     R->luma_dc[lane - 32] = (mb_type == WH_MB_I16x16) ? S.lv_dc[lane - 32] : (int16_t)0;
   } else if (lane < 56) {
-    R->chroma_dc[0][lane - 48] = S.lv_cdc[lane - 48];
+    (&R->chroma_dc[0][0])[lane - 48] = S.lv_cdc[lane - 48];
   }
   if (lane < 24) { R->nzc[lane] = S.nzc[lane]; M->nzc[lane] = S.nzc[lane]; }
   if (lane < 16) {

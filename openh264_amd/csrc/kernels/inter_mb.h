@@ -31,12 +31,12 @@
 #define WH_REF_NOT_AVAIL (-2)
 #define WH_REF_NOT_IN_LIST (-1)
 #define WH_WIN_STRIDE 64
-#define WH_WIN_ROWS 64
+#define WH_WIN_ROWS 60
 #define WH_WIN_MARGIN 19          // diamond (16) + quarter/half-pel taps (3)
 #define WH_CWIN_STRIDE 32
 #define WH_CWIN_ROWS 32
 
-// slots of S.me[]: one motion search result per partition
+// partition slots: one motion search result each (WhMeTab)
 #define WH_SLOT_16x16 0
 #define WH_SLOT_8x8 1             // 1..4
 #define WH_SLOT_16x8 5            // 5,6
@@ -51,13 +51,9 @@ typedef struct WhInterLds {
   uint8_t skip_c[128];
   uint32_t nb[5 * 36];                                      // WhMbState copies: top-left, top, top-right, left, co-located (reference picture)
   int16_t co_mv[2][2];                                      // sP16x16Mv of the reference picture's MBs to the right / below
-  int16_t mvcl[5][2];                                       // 16x16 search candidates
-  int16_t mvc[30][2];                                       // motion vector cache, 5 rows x 6 cols (row 0 / col 0 = neighbours)
-  int8_t  refc[32];                                         // reference index cache
   int16_t mvp_out[16][2];                                   // predictor used for the mvd of each 4x4 (raster)
   int16_t mv_out[16][2];
-  int32_t me[9][8];                                         // per slot: mvx, mvy, sad_cost, satd_cost, satd_raw
-  uint32_t cold_y[64], cold_c[64], cold_pv[64], cold_co[64]; // staging of the next MB's cold inputs (wh_inter_cold_fetch)
+  uint32_t cold_y[64], cold_c[32], cold_pv[64], cold_co[40]; // staging of the next MB's cold inputs (wh_inter_cold_fetch)
 } WhInterLds;
 
 typedef struct WhWin { int x0, y0, cx0, cy0; } WhWin;       // picture coordinates of element (0,0) of win / cwin
@@ -133,12 +129,13 @@ WH_FN int wh_mc_chroma_w (int a, int b, int c, int d, int dx, int dy) {
 // ---- reference windows ----------------------------------------------------------------------------
 // Loads are clamped to the border-expanded picture (32 luma / 16 chroma pixels each side); window cells beyond that
 // can only be touched by motion vectors outside the legal range, i.e. never.
-WH_FN void wh_win_fetch_luma (int lane, const WhSeqParams& P, const WhPicJob& J, int x0, int y0, uint32_t* v /*[16]*/) {
+#define WH_WIN_LOADS (WH_WIN_ROWS / 4)      // words per lane: 4 rows of 16 words per load instruction
+WH_FN void wh_win_fetch_luma (int lane, const WhSeqParams& P, const WhPicJob& J, int x0, int y0, uint32_t* v /*[WH_WIN_LOADS]*/) {
   const int wd = lane & 15, r0 = lane >> 4;
   const int x = wh_clip3 (x0 + wd * 4, -32, P.mb_w * 16 + 28);
   const WH_G uint8_t* ref = (const WH_G uint8_t*)J.ref[0];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
+  for (int k = 0; k < WH_WIN_LOADS; ++k) {
     const int y = wh_clip3 (y0 + r0 + 4 * k, -32, P.mb_h * 16 + 31);
     v[k] = * (const WH_G uint32_t*) (ref + (ptrdiff_t)y * P.rec_stride_y + x);
   }
@@ -146,12 +143,12 @@ WH_FN void wh_win_fetch_luma (int lane, const WhSeqParams& P, const WhPicJob& J,
 WH_FN void wh_win_commit_luma (WhInterLds& S, int lane, const uint32_t* v) {
   const int wd = lane & 15, r0 = lane >> 4;
 #pragma unroll
-  for (int k = 0; k < 16; ++k) * (uint32_t*)&S.win[(r0 + 4 * k) * WH_WIN_STRIDE + wd * 4] = v[k];
+  for (int k = 0; k < WH_WIN_LOADS; ++k) * (uint32_t*)&S.win[(r0 + 4 * k) * WH_WIN_STRIDE + wd * 4] = v[k];
 }
 WH_FN void wh_win_load_luma (WhInterLds& S, const WhSeqParams& P, const WhPicJob& J, WhWin& W, int x0, int y0) {
   W.x0 = x0; W.y0 = y0;
   WV_LANES_BEGIN (lane)
-  uint32_t v[16];
+  uint32_t v[WH_WIN_LOADS];
   wh_win_fetch_luma (lane, P, J, x0, y0, v);
   wh_win_commit_luma (S, lane, v);
   WV_LANES_END
@@ -159,10 +156,10 @@ WH_FN void wh_win_load_luma (WhInterLds& S, const WhSeqParams& P, const WhPicJob
 // first load of a macroblock: luma + both chroma windows in one batch.  (cx,cy) = luma picture position of the
 // 16x16 block displaced by the integer search centre.
 WH_FN void wh_win_load_all (WhInterLds& S, const WhSeqParams& P, const WhPicJob& J, WhWin& W, int cx, int cy) {
-  W.x0 = (cx - 24) & ~3; W.y0 = cy - 24;
+  W.x0 = (cx - 24) & ~3; W.y0 = cy - (WH_WIN_ROWS - 16) / 2;
   W.cx0 = ((cx >> 1) - 12) & ~3; W.cy0 = (cy >> 1) - 12;
   WV_LANES_BEGIN (lane)
-  uint32_t v[16], c[8];
+  uint32_t v[WH_WIN_LOADS], c[8];
   wh_win_fetch_luma (lane, P, J, W.x0, W.y0, v);
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
@@ -181,10 +178,10 @@ WH_FN void wh_win_load_all (WhInterLds& S, const WhSeqParams& P, const WhPicJob&
 WH_FN bool wh_win_covers (const WhWin& W, int x0, int y0, int x1, int y1) {
   return x0 >= W.x0 && y0 >= W.y0 && x1 <= W.x0 + WH_WIN_STRIDE && y1 <= W.y0 + WH_WIN_ROWS;
 }
-// make sure luma [x0,x1) x [y0,y1) is inside the window (extent <= 57 x 64)
+// make sure luma [x0,x1) x [y0,y1) is inside the window (extent <= 57 x WH_WIN_ROWS - 1)
 WH_FN void wh_win_ensure (WhInterLds& S, const WhSeqParams& P, const WhPicJob& J, WhWin& W, int x0, int y0, int x1, int y1) {
   if (wh_win_covers (W, x0, y0, x1, y1)) return;
-  wh_win_load_luma (S, P, J, W, (((x0 + x1) >> 1) - 32) & ~3, ((y0 + y1) >> 1) - 32);
+  wh_win_load_luma (S, P, J, W, (((x0 + x1) >> 1) - 32) & ~3, ((y0 + y1) >> 1) - WH_WIN_ROWS / 2);
 }
 
 // ---- lane geometry -----------------------------------------------------------------------------------
@@ -267,48 +264,51 @@ WH_FN void wh_mc_chroma_to (WhInterLds& S, const WhSeqParams& P, const WhPicJob&
 }
 
 // ---- motion vector prediction on the 5x6 cache ----------------------------------------------------
+// The cache (5 rows x 6 cols of 4x4 blocks, row 0 / col 0 = neighbour MBs) lives in two lane tables: K.mv[i] = packed
+// (mvx & 0xffff) | mvy << 16 and K.ref[i] = reference index of cache cell i = (by + 1) * 6 + bx + 1.
+typedef struct WhMvCache { WvLaneArr mv, ref; } WhMvCache;
+WH_FN int wh_pk_mv (int mx, int my) { return (int) (((unsigned)mx & 0xffffu) | ((unsigned)my << 16)); }
+WH_FN int wh_mvx (int pk) { return (int) (int16_t) (pk & 0xffff); }
+WH_FN int wh_mvy (int pk) { return pk >> 16; }
 WH_FN int wh_cidx (int bx, int by) { return (by + 1) * 6 + bx + 1; }
-WH_FN void wh_pred_mv (const WhInterLds& S, int bx, int by, int w, int ref, int* mx, int* my) {
+WH_FN void wh_pred_mv (const WhMvCache& K, int bx, int by, int w, int ref, int* mx, int* my) {
   const int li = (by + 1) * 6 + bx, ti = by * 6 + bx + 1;
-  const int lref = S.refc[li], tref = S.refc[ti];
+  const int lref = WV_LGET (K.ref, li), tref = WV_LGET (K.ref, ti);
   int di = ti + w;
-  if (S.refc[di] == WH_REF_NOT_AVAIL) di = ti - 1;
-  const int dref = S.refc[di];
-  if (tref == WH_REF_NOT_AVAIL && dref == WH_REF_NOT_AVAIL && lref != WH_REF_NOT_AVAIL) { *mx = S.mvc[li][0]; *my = S.mvc[li][1]; return; }
+  if (WV_LGET (K.ref, di) == WH_REF_NOT_AVAIL) di = ti - 1;
+  const int dref = WV_LGET (K.ref, di);
+  const int lmv = WV_LGET (K.mv, li), tmv = WV_LGET (K.mv, ti), dmv = WV_LGET (K.mv, di);
+  if (tref == WH_REF_NOT_AVAIL && dref == WH_REF_NOT_AVAIL && lref != WH_REF_NOT_AVAIL) { *mx = wh_mvx (lmv); *my = wh_mvy (lmv); return; }
   const int match = (ref == lref) | ((ref == tref) << 1) | ((ref == dref) << 2);
-  if (match == 1) { *mx = S.mvc[li][0]; *my = S.mvc[li][1]; }
-  else if (match == 2) { *mx = S.mvc[ti][0]; *my = S.mvc[ti][1]; }
-  else if (match == 4) { *mx = S.mvc[di][0]; *my = S.mvc[di][1]; }
-  else { *mx = wh_median3 (S.mvc[li][0], S.mvc[ti][0], S.mvc[di][0]); *my = wh_median3 (S.mvc[li][1], S.mvc[ti][1], S.mvc[di][1]); }
+  if (match == 1) { *mx = wh_mvx (lmv); *my = wh_mvy (lmv); }
+  else if (match == 2) { *mx = wh_mvx (tmv); *my = wh_mvy (tmv); }
+  else if (match == 4) { *mx = wh_mvx (dmv); *my = wh_mvy (dmv); }
+  else { *mx = wh_median3 (wh_mvx (lmv), wh_mvx (tmv), wh_mvx (dmv)); *my = wh_median3 (wh_mvy (lmv), wh_mvy (tmv), wh_mvy (dmv)); }
 }
-WH_FN void wh_pred_16x8 (const WhInterLds& S, int part, int ref, int* mx, int* my) {
-  if (part == 0) { if (ref == S.refc[1]) { *mx = S.mvc[1][0]; *my = S.mvc[1][1]; return; } }
-  else { if (ref == S.refc[18]) { *mx = S.mvc[18][0]; *my = S.mvc[18][1]; return; } }
-  wh_pred_mv (S, 0, part * 2, 4, ref, mx, my);
+WH_FN void wh_pred_16x8 (const WhMvCache& K, int part, int ref, int* mx, int* my) {
+  const int i = part == 0 ? 1 : 18;
+  if (ref == WV_LGET (K.ref, i)) { const int v = WV_LGET (K.mv, i); *mx = wh_mvx (v); *my = wh_mvy (v); return; }
+  wh_pred_mv (K, 0, part * 2, 4, ref, mx, my);
 }
-WH_FN void wh_pred_8x16 (const WhInterLds& S, int part, int ref, int* mx, int* my) {
-  if (part == 0) { if (ref == S.refc[6]) { *mx = S.mvc[6][0]; *my = S.mvc[6][1]; return; } }
-  else {
-    int idx = 5;
-    if (S.refc[5] == WH_REF_NOT_AVAIL) idx = 2;
-    if (ref == S.refc[idx]) { *mx = S.mvc[idx][0]; *my = S.mvc[idx][1]; return; }
-  }
-  wh_pred_mv (S, part * 2, 0, 2, ref, mx, my);
+WH_FN void wh_pred_8x16 (const WhMvCache& K, int part, int ref, int* mx, int* my) {
+  int idx = 6;
+  if (part != 0) { idx = 5; if (WV_LGET (K.ref, 5) == WH_REF_NOT_AVAIL) idx = 2; }
+  if (ref == WV_LGET (K.ref, idx)) { const int v = WV_LGET (K.mv, idx); *mx = wh_mvx (v); *my = wh_mvy (v); return; }
+  wh_pred_mv (K, part * 2, 0, 2, ref, mx, my);
 }
-WH_FN void wh_pred_skip_mv (const WhInterLds& S, int* mx, int* my) {
-  const int lref = S.refc[6], tref = S.refc[1];
-  if (lref == WH_REF_NOT_AVAIL || tref == WH_REF_NOT_AVAIL || (lref == 0 && S.mvc[6][0] == 0 && S.mvc[6][1] == 0) ||
-      (tref == 0 && S.mvc[1][0] == 0 && S.mvc[1][1] == 0)) { *mx = 0; *my = 0; return; }
-  wh_pred_mv (S, 0, 0, 4, 0, mx, my);
+WH_FN void wh_pred_skip_mv (const WhMvCache& K, int* mx, int* my) {
+  const int lref = WV_LGET (K.ref, 6), tref = WV_LGET (K.ref, 1);
+  if (lref == WH_REF_NOT_AVAIL || tref == WH_REF_NOT_AVAIL || (lref == 0 && WV_LGET (K.mv, 6) == 0) || (tref == 0 && WV_LGET (K.mv, 1) == 0)) { *mx = 0; *my = 0; return; }
+  wh_pred_mv (K, 0, 0, 4, 0, mx, my);
 }
 // write mv/ref into the cache rectangle (bx,by,w,h in 4x4 units)
-WH_FN void wh_cache_set (WhInterLds& S, int bx, int by, int w, int h, int ref, int mx, int my) {
-  WV_LANES_BEGIN (lane)
-  if (lane < w * h) {
-    const int i = wh_cidx (bx + (lane & (w - 1)), by + (w == 4 ? lane >> 2 : lane >> 1));
-    S.refc[i] = (int8_t)ref; S.mvc[i][0] = (int16_t)mx; S.mvc[i][1] = (int16_t)my;
-  }
-  WV_LANES_END
+WH_FN bool wh_cache_in_rect (int cell, int bx, int by, int w, int h) {
+  const int r = cell / 6 - 1, c = cell % 6 - 1;
+  return cell < 30 && r >= by && r < by + h && c >= bx && c < bx + w;
+}
+WH_FN void wh_cache_set (WhMvCache& K, int bx, int by, int w, int h, int ref, int mx, int my) {
+  WV_LSET_IF (K.ref, lane, wh_cache_in_rect (lane, bx, by, w, h), ref);
+  WV_LSET_IF (K.mv, lane, wh_cache_in_rect (lane, bx, by, w, h), wh_pk_mv (mx, my));
 }
 
 // ---- partition slots ----------------------------------------------------------------------------------
@@ -318,11 +318,11 @@ WH_FN void wh_slot_geom (int slot, int* bx, int* by, int* bw, int* bh) {
   else if (slot < WH_SLOT_8x16) { const int i = slot - WH_SLOT_16x8; *bx = 0; *by = i * 8; *bw = 16; *bh = 8; }
   else { const int i = slot - WH_SLOT_8x16; *bx = i * 8; *by = 0; *bw = 8; *bh = 16; }
 }
-WH_FN void wh_slot_pred (const WhInterLds& S, int slot, int* mx, int* my) {
-  if (slot == 0) wh_pred_mv (S, 0, 0, 4, 0, mx, my);
-  else if (slot < WH_SLOT_16x8) { const int i = slot - WH_SLOT_8x8; wh_pred_mv (S, (i & 1) * 2, (i >> 1) * 2, 2, 0, mx, my); }
-  else if (slot < WH_SLOT_8x16) wh_pred_16x8 (S, slot - WH_SLOT_16x8, 0, mx, my);
-  else wh_pred_8x16 (S, slot - WH_SLOT_8x16, 0, mx, my);
+WH_FN void wh_slot_pred (const WhMvCache& K, int slot, int* mx, int* my) {
+  if (slot == 0) wh_pred_mv (K, 0, 0, 4, 0, mx, my);
+  else if (slot < WH_SLOT_16x8) { const int i = slot - WH_SLOT_8x8; wh_pred_mv (K, (i & 1) * 2, (i >> 1) * 2, 2, 0, mx, my); }
+  else if (slot < WH_SLOT_8x16) wh_pred_16x8 (K, slot - WH_SLOT_16x8, 0, mx, my);
+  else wh_pred_8x16 (K, slot - WH_SLOT_8x16, 0, mx, my);
 }
 
 // ---- one motion search (WelsMotionEstimateSearch) -------------------------------------------------
@@ -348,12 +348,13 @@ WH_FN int wh_cand_sad (const WhInterLds& S, const WhSeqParams& P, const WhPicJob
   return wh_sad_global (S, P, J, me.bx, me.by, me.bw, me.bh, px, py);
 }
 
-WH_FN void wh_motion_search (WhInterLds& S, const WhSeqParams& P, const WhPicJob& J, WhWin& W, const WhMeCtx& C, WhMe& me, int n_mvc) {
-  // initial point (svc_motion_estimate.cpp:222-284); candidates beyond the predictor: S.mvcl[0..n_mvc)
+WH_FN void wh_motion_search (WhInterLds& S, const WhSeqParams& P, const WhPicJob& J, WhWin& W, const WhMeCtx& C, WhMe& me, const WvLaneArr& mvcl, int n_mvc) {
+  // initial point (svc_motion_estimate.cpp:222-284); candidates beyond the predictor: packed mvcl[0..n_mvc)
   int bmx = wh_clip3 ((2 + me.mvpx) >> 2, C.minx, C.maxx), bmy = wh_clip3 ((2 + me.mvpy) >> 2, C.miny, C.maxy);
   int best = wh_cand_sad (S, P, J, W, C, me, bmx, bmy) + wh_mvd_cost (C.lambda, bmx * 4 - me.mvpx, bmy * 4 - me.mvpy);
   for (int i = 0; i < n_mvc; ++i) {
-    const int cx = wh_clip3 ((2 + S.mvcl[i][0]) >> 2, C.minx, C.maxx), cy = wh_clip3 ((2 + S.mvcl[i][1]) >> 2, C.miny, C.maxy);
+    const int cand = WV_LGET (mvcl, i);
+    const int cx = wh_clip3 ((2 + wh_mvx (cand)) >> 2, C.minx, C.maxx), cy = wh_clip3 ((2 + wh_mvy (cand)) >> 2, C.miny, C.maxy);
     if (cx != bmx || cy != bmy) {
       const int c = wh_cand_sad (S, P, J, W, C, me, cx, cy) + wh_mvd_cost (C.lambda, cx * 4 - me.mvpx, cy * 4 - me.mvpy);
       if (c < best) { best = c; bmx = cx; bmy = cy; }
@@ -409,14 +410,14 @@ WH_FN void wh_motion_search (WhInterLds& S, const WhSeqParams& P, const WhPicJob
   }
 }
 
-WH_FN void wh_me_store (WhInterLds& S, int slot, const WhMe& me) {
-  WV_LANES_BEGIN (lane)
-  if (lane == 0) { int32_t* q = S.me[slot]; q[0] = me.mvx; q[1] = me.mvy; q[2] = me.sad_cost; q[3] = me.satd_cost; q[4] = me.satd_raw; }
-  WV_LANES_END
+// search results per partition slot, one lane table per field
+typedef struct WhMeTab { WvLaneArr mv, sad, satd, raw; } WhMeTab;
+WH_FN void wh_me_store (WhMeTab& T, int slot, const WhMe& me) {
+  WV_LSET (T.mv, slot, wh_pk_mv (me.mvx, me.mvy)); WV_LSET (T.sad, slot, me.sad_cost); WV_LSET (T.satd, slot, me.satd_cost); WV_LSET (T.raw, slot, me.satd_raw);
 }
-WH_FN void wh_me_fetch (const WhInterLds& S, int slot, WhMe& me) {
-  const int32_t* q = S.me[slot];
-  me.mvx = q[0]; me.mvy = q[1]; me.sad_cost = q[2]; me.satd_cost = q[3]; me.satd_raw = q[4];
+WH_FN void wh_me_fetch (const WhMeTab& T, int slot, WhMe& me) {
+  const int v = WV_LGET (T.mv, slot);
+  me.mvx = wh_mvx (v); me.mvy = wh_mvy (v); me.sad_cost = WV_LGET (T.sad, slot); me.satd_cost = WV_LGET (T.satd, slot); me.satd_raw = WV_LGET (T.raw, slot);
 }
 
 // ---- fractional refinement (MeRefineFracPixel / MeRefineQuarPixel, md.cpp:575-769) -------------------------------
@@ -561,43 +562,8 @@ WH_FN void wh_refine_frac (WhInterLds& S, const WhSeqParams& P, const WhPicJob& 
 }
 
 // ---- inter luma residual (WelsEncInterY) on S.m.res after wh_dct_luma16; returns cbp luma -----------
-// JVT-O079 single-coefficient score of a block from the 16-bit mask of its non-zero zig-zag positions
-// (encode_mb_aux.cpp:417-436 WelsGetNoneZeroCount-style run table {3,2,2,1,1,1,0...}); equals wh_single_ctr.
-WH_FN int wh_single_ctr_mask (unsigned m) {
-  int ctr = 0, run = 0;
-  for (int k = 0; k < 16; ++k) {
-    if ((m >> k) & 1u) { ctr += (run == 0) ? 3 : (run <= 2) ? 2 : (run <= 5) ? 1 : 0; run = 0; }
-    else ++run;
-  }
-  return ctr;
-}
-// quantise S.res[base + 0 .. 16*nblk) (inter rounding) into `dst`; S.part[blk] = max |level| of the block,
-// S.part2[blk] = mask of non-zero zig-zag positions (`skip_dc`: position 0 is not part of the scan)
-WH_FN void wh_quant_blocks (WhMbLds& S, int base, int nblk, int qp, int16_t* dst, int skip_dc) {
-  WV_LANES_BEGIN (lane)
-  if (lane < nblk * 4) {
-    int16_t mx = 0;
-    for (int k = 0; k < 4; ++k) {
-      const int i = lane * 4 + k, pos = i & 15;
-      int16_t a;
-      dst[i] = wh_quant1_abs (S.res[base + i], wh_ff_inter (qp, pos), wh_mf (qp, pos), &a);
-      if (mx < a) mx = a;
-    }
-    S.tmp[512 + lane] = mx;
-  }
-  WV_LANES_END
-  WV_LANES_BEGIN (lane)
-  if (lane < nblk) {
-    S.part[lane] = wh_max (wh_max (S.tmp[512 + lane * 4], S.tmp[512 + lane * 4 + 1]), wh_max (S.tmp[512 + lane * 4 + 2], S.tmp[512 + lane * 4 + 3]));
-    unsigned m = 0;
-    for (int k = skip_dc; k < 16; ++k) m |= (unsigned) (dst[lane * 16 + wh_zigzag (k)] != 0) << (k - skip_dc);
-    S.part2[lane] = (int32_t)m;
-  }
-  WV_LANES_END
-}
-
 WH_FN int wh_enc_inter_y (WhMbLds& S, int qp) {
-  wh_quant_blocks (S, 0, 16, qp, S.res, 0);
+  wh_quant_blocks (S, 0, 16, qp, qp, S.res, 0);
   // per 8x8: score = sum over its four 4x4 blocks (9 when a level exceeds 1, else the run score); the reference stops
   // adding once an 8x8 reaches 6, which cannot change the two threshold tests below
   int s0, s1, s2, s3;
@@ -633,7 +599,7 @@ WH_FN int wh_enc_inter_y (WhMbLds& S, int qp) {
 
 // quant-to-zero tests of the P_Skip path (WelsTryPYskip / WelsTryPUVskip); operate on copies in S.tmp
 WH_FN bool wh_try_py_skip (WhMbLds& S, int qp) {
-  wh_quant_blocks (S, 0, 16, qp, S.tmp, 0);
+  wh_quant_blocks (S, 0, 16, qp, qp, S.tmp, 0);
   int big, ctr;
   WV_SUM2 (big, ctr, lane, (lane < 16 ? (S.part[lane] > 1) : 0), (lane < 16 && S.part[lane] == 1 ? wh_single_ctr_mask ((unsigned)S.part2[lane]) : 0));
   return big == 0 && ctr < 6;
@@ -646,7 +612,7 @@ WH_FN bool wh_try_puv_skip (WhMbLds& S, int pl, int qpc) {
   const int16_t s0 = (int16_t) (r[0] + r[32]), s1 = (int16_t) (r[0] - r[32]), s2 = (int16_t) (r[16] + r[48]), s3 = (int16_t) (r[16] - r[48]);
   const int16_t d0 = (int16_t) (s0 + s2), d1 = (int16_t) (s0 - s2), d2 = (int16_t) (s1 + s3), d3 = (int16_t) (s1 - s3);
   if (wh_abs (d0) > thr || wh_abs (d1) > thr || wh_abs (d2) > thr || wh_abs (d3) > thr) return false;
-  wh_quant_blocks (S, 256 + pl * 64, 4, qpc, S.tmp, 1);
+  wh_quant_blocks (S, 256 + pl * 64, 4, qpc, qpc, S.tmp, 1);
   int big, ctr;
   WV_SUM2 (big, ctr, lane, (lane < 4 ? (S.part[lane] > 1) : 0), (lane < 4 && S.part[lane] == 1 ? wh_single_ctr_mask ((unsigned)S.part2[lane]) : 0));
   return big == 0 && ctr < 7;
@@ -711,10 +677,10 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, const WhSeqParams& P, const WhPicJob
         if (ok) st[k] = ((const WH_G uint32_t*) ((const WH_G WhMbState*)J.mbs + xy + off))[wd];
       }
     }
-    tr.y = S.cold_y[lane]; tr.c = S.cold_c[lane];
+    tr.y = S.cold_y[lane]; tr.c = lane < 32 ? S.cold_c[lane] : 0u;
     wh_tile_commit (M, lane, &tr);
     * (uint32_t*)&S.prev_y[lane * 4] = S.cold_pv[lane];
-    if (lane < 36) S.nb[144 + lane] = S.cold_co[lane];
+    if (lane < 36) S.nb[144 + lane] = ref_is_p ? S.cold_co[lane] : 0u;      // no co-located state after an IDR: reads as zeros
     else if (lane < 38) * (uint32_t*)&S.co_mv[lane - 36][0] = S.cold_co[lane];
 #pragma unroll
     for (int k = 0; k < 3; ++k) { const int i = lane + 64 * k; if (i < 144) S.nb[i] = st[k]; }
@@ -731,18 +697,32 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, const WhSeqParams& P, const WhPicJob
   const int tl_type = TLm ? TLm->mb_type : WH_MB_NONE, t_type = Tm ? Tm->mb_type : WH_MB_NONE;
   const int tr_type = TRm ? TRm->mb_type : WH_MB_NONE, l_type = Lm ? Lm->mb_type : WH_MB_NONE;
   const bool l_inter = WH_IS_INTER (l_type), t_inter = WH_IS_INTER (t_type), tl_inter = WH_IS_INTER (tl_type), tr_inter = WH_IS_INTER (tr_type);
-  WV_LANES_BEGIN (lane)
-  if (lane < 30) {
-    const int r = lane / 6, c = lane % 6;
-    int ref = WH_REF_NOT_AVAIL, mx = 0, my = 0;
-    if (r == 0 && c == 0) { ref = TLm ? WH_REF_NOT_IN_LIST : WH_REF_NOT_AVAIL; if (tl_inter) { ref = TLm->ref_idx[3]; mx = TLm->mv[15][0]; my = TLm->mv[15][1]; } }
-    else if (r == 0 && c == 5) { ref = TRm ? WH_REF_NOT_IN_LIST : WH_REF_NOT_AVAIL; if (tr_inter) { ref = TRm->ref_idx[2]; mx = TRm->mv[12][0]; my = TRm->mv[12][1]; } }
-    else if (r == 0) { ref = Tm ? WH_REF_NOT_IN_LIST : WH_REF_NOT_AVAIL; if (t_inter) { ref = Tm->ref_idx[2 + ((c - 1) >> 1)]; mx = Tm->mv[12 + c - 1][0]; my = Tm->mv[12 + c - 1][1]; } }
-    else if (c == 0) { ref = Lm ? WH_REF_NOT_IN_LIST : WH_REF_NOT_AVAIL; if (l_inter) { ref = Lm->ref_idx[((r - 1) >> 1) * 2 + 1]; mx = Lm->mv[(r - 1) * 4 + 3][0]; my = Lm->mv[(r - 1) * 4 + 3][1]; } }
-    else { ref = WH_REF_NOT_AVAIL; }          // inside the MB: not coded yet (the reference pre-marks 9,11,17,21,23)
-    S.refc[lane] = (int8_t)ref; S.mvc[lane][0] = (int16_t)mx; S.mvc[lane][1] = (int16_t)my;
-  }
-  WV_LANES_END
+  WhMvCache K;
+  WhMeTab T;
+  WvLaneArr mvcl;
+#if defined(WH_EMU)
+  memset (&K, 0, sizeof (K)); memset (&T, 0, sizeof (T)); memset (&mvcl, 0, sizeof (mvcl));
+#else
+  K.mv = 0; K.ref = 0; T.mv = 0; T.sad = 0; T.satd = 0; T.raw = 0; mvcl = 0;
+#endif
+  // cell (r,c) of the 5x6 cache: row 0 / col 0 come from the neighbour MB states, the rest is this MB (not coded yet;
+  // the reference pre-marks 9,11,17,21,23 the same way)
+#define WH_CACHE_REF(lane) ([&] () { const int r = (lane) / 6, c = (lane) % 6; \
+    if (r == 0 && c == 0) return tl_inter ? (int)TLm->ref_idx[3] : TLm ? WH_REF_NOT_IN_LIST : WH_REF_NOT_AVAIL; \
+    if (r == 0 && c == 5) return tr_inter ? (int)TRm->ref_idx[2] : TRm ? WH_REF_NOT_IN_LIST : WH_REF_NOT_AVAIL; \
+    if (r == 0) return t_inter ? (int)Tm->ref_idx[2 + ((c - 1) >> 1)] : Tm ? WH_REF_NOT_IN_LIST : WH_REF_NOT_AVAIL; \
+    if (c == 0) return l_inter ? (int)Lm->ref_idx[((r - 1) >> 1) * 2 + 1] : Lm ? WH_REF_NOT_IN_LIST : WH_REF_NOT_AVAIL; \
+    return WH_REF_NOT_AVAIL; }) ()
+#define WH_CACHE_MV(lane) ([&] () { const int r = (lane) / 6, c = (lane) % 6; \
+    if (r == 0 && c == 0) return tl_inter ? wh_pk_mv (TLm->mv[15][0], TLm->mv[15][1]) : 0; \
+    if (r == 0 && c == 5) return tr_inter ? wh_pk_mv (TRm->mv[12][0], TRm->mv[12][1]) : 0; \
+    if (r == 0) return t_inter ? wh_pk_mv (Tm->mv[12 + c - 1][0], Tm->mv[12 + c - 1][1]) : 0; \
+    if (c == 0) return l_inter ? wh_pk_mv (Lm->mv[(r - 1) * 4 + 3][0], Lm->mv[(r - 1) * 4 + 3][1]) : 0; \
+    return 0; }) ()
+  WV_LSET_IF (K.ref, lane, lane < 30, WH_CACHE_REF (lane));
+  WV_LSET_IF (K.mv, lane, lane < 30, WH_CACHE_MV (lane));
+#undef WH_CACHE_REF
+#undef WH_CACHE_MV
   // neighbour SAD / skip context, order of the reference's caches: [0] top-left, [1] top, [2] top-right, [3] left
   const int sadc0 = tl_inter ? TLm->sad_cost[0] : 0, sadc1 = t_inter ? Tm->sad_cost[0] : 0, sadc2 = tr_inter ? TRm->sad_cost[0] : 0, sadc3 = l_inter ? Lm->sad_cost[0] : 0;
   const bool tl_sk = tl_type == WH_MB_PSKIP, t_sk = t_type == WH_MB_PSKIP, tr_sk = tr_type == WH_MB_PSKIP, l_sk = l_type == WH_MB_PSKIP;
@@ -757,7 +737,7 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, const WhSeqParams& P, const WhPicJob
   // ---- batch 2: reference windows centred on the 16x16 predictor (= the search's initial point) ----
   WhMe me16;
   me16.bx = 0; me16.by = 0; me16.bw = 16; me16.bh = 16;
-  wh_pred_mv (S, 0, 0, 4, 0, &me16.mvpx, &me16.mvpy);
+  wh_pred_mv (K, 0, 0, 4, 0, &me16.mvpx, &me16.mvpy);
   WhWin W;
   wh_win_load_all (S, P, J, W, mbx * 16 + wh_clip3 ((2 + me16.mvpx) >> 2, C.minx, C.maxx), mby * 16 + wh_clip3 ((2 + me16.mvpy) >> 2, C.miny, C.maxy));
 
@@ -781,18 +761,18 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, const WhSeqParams& P, const WhPicJob
     // PredictSadSkip (md.cpp:872-910)
     int sad_pred_skip;
     {
-      const int rb = S.refc[1], ra = S.refc[6];
-      int rc = S.refc[5];
+      const int rb = WV_LGET (K.ref, 1), ra = WV_LGET (K.ref, 6);
+      int rc = WV_LGET (K.ref, 5);
       const int sb = sadsk1, sa = sadsk3;
       int sc = sadsk2, skip_c = tr_sk;
-      if (rc == WH_REF_NOT_AVAIL) { rc = S.refc[0]; sc = sadsk0; skip_c = tl_sk; }
+      if (rc == WH_REF_NOT_AVAIL) { rc = WV_LGET (K.ref, 0); sc = sadsk0; skip_c = tl_sk; }
       if (rb == WH_REF_NOT_AVAIL && rc == WH_REF_NOT_AVAIL && ra != WH_REF_NOT_AVAIL) sad_pred_skip = sa;
       else {
         const int cnt = ((0 == ra) && l_sk) | (((0 == rb) && t_sk) << 1) | (((0 == rc) && skip_c) << 2);
         sad_pred_skip = cnt == 1 ? sa : cnt == 2 ? sb : cnt == 4 ? sc : wh_median3 (sa, sb, sc);
       }
     }
-    wh_pred_skip_mv (S, &skx, &sky);
+    wh_pred_skip_mv (K, &skx, &sky);
     const int nx = (mbx << 4) + (skx >> 2), ny = (mby << 4) + (sky >> 2);
     if (!(nx < -29 || nx > (P.mb_w << 4) + 12 || ny < -29 || ny > (P.mb_h << 4) + 12)) {
       wh_mc_luma_to (S, P, J, W, mbx, mby, 0, 0, 16, 16, skx, sky, S.skip_y);
@@ -832,9 +812,9 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, const WhSeqParams& P, const WhPicJob
     // PredictSad (md.cpp:826-870)
     int sad_pred;
     {
-      const int rb = S.refc[1], ra = S.refc[6];
-      int rc = S.refc[5], sc = sadc2;
-      if (rc == WH_REF_NOT_AVAIL) { rc = S.refc[0]; sc = sadc0; }
+      const int rb = WV_LGET (K.ref, 1), ra = WV_LGET (K.ref, 6);
+      int rc = WV_LGET (K.ref, 5), sc = sadc2;
+      if (rc == WH_REF_NOT_AVAIL) { rc = WV_LGET (K.ref, 0); sc = sadc0; }
       if (rb == WH_REF_NOT_AVAIL && rc == WH_REF_NOT_AVAIL && ra != WH_REF_NOT_AVAIL) sad_pred = sadc3;
       else {
         const int cnt = (0 == ra) | ((0 == rb) << 1) | ((0 == rc) << 2);
@@ -848,17 +828,13 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, const WhSeqParams& P, const WhPicJob
     const bool c_l = Lm != nullptr, c_t = Tm != nullptr, c_r = ref_is_p && mbx < P.mb_w - 1, c_b = ref_is_p && mby < P.mb_h - 1;
     const int i_l = 1, i_t = i_l + (c_l ? 1 : 0), i_r = i_t + (c_t ? 1 : 0), i_b = i_r + (c_r ? 1 : 0);
     nm = i_b + (c_b ? 1 : 0);
-    WV_LANES_BEGIN (lane)
-    if (lane == 0) {
-      S.mvcl[0][0] = 0; S.mvcl[0][1] = 0;
-      if (c_l) { S.mvcl[i_l][0] = Lm->p16mv[0]; S.mvcl[i_l][1] = Lm->p16mv[1]; }
-      if (c_t) { S.mvcl[i_t][0] = Tm->p16mv[0]; S.mvcl[i_t][1] = Tm->p16mv[1]; }
-      if (c_r) { S.mvcl[i_r][0] = S.co_mv[0][0]; S.mvcl[i_r][1] = S.co_mv[0][1]; }
-      if (c_b) { S.mvcl[i_b][0] = S.co_mv[1][0]; S.mvcl[i_b][1] = S.co_mv[1][1]; }
-    }
-    WV_LANES_END
+    WV_LSET (mvcl, 0, 0);
+    if (c_l) WV_LSET (mvcl, i_l, wh_pk_mv (Lm->p16mv[0], Lm->p16mv[1]));
+    if (c_t) WV_LSET (mvcl, i_t, wh_pk_mv (Tm->p16mv[0], Tm->p16mv[1]));
+    if (c_r) WV_LSET (mvcl, i_r, wh_pk_mv (S.co_mv[0][0], S.co_mv[0][1]));
+    if (c_b) WV_LSET (mvcl, i_b, wh_pk_mv (S.co_mv[1][0], S.co_mv[1][1]));
     me16.sad_pred = sad_pred;
-    wh_motion_search (S, P, J, W, C, me16, nm);
+    wh_motion_search (S, P, J, W, C, me16, mvcl, nm);
     p16x = me16.mvx; p16y = me16.mvy;
     cost_luma = me16.satd_cost;
     mb_type = WH_MB_P16x16;
@@ -877,8 +853,9 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, const WhSeqParams& P, const WhPicJob
   WH_PROF_MARK (P, M, 3);   // I16x16 test (+ intra encode when intra wins)
 
   if (!done) {
-    // ---- fine partitions: groups of searches (8x8 x4, 16x8 x2, 8x16 x2), results kept in S.me[slot] ----
-    wh_me_store (S, WH_SLOT_16x16, me16);
+    // ---- fine partitions: groups of searches (8x8 x4, 16x8 x2, 8x16 x2), results kept per slot in T ----
+    wh_me_store (T, WH_SLOT_16x16, me16);
+    WV_LSET (mvcl, 0, 0);
     int order0 = -1, order1 = -1, order2 = -1;      // group ids: 0 = 8x8, 1 = 16x8, 2 = 8x16
     bool chain = false;                             // later groups only run when the first one beat the 16x16 cost
     if (!use_satd) {
@@ -912,13 +889,10 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, const WhSeqParams& P, const WhPicJob
         WhMe m;
         wh_slot_geom (first + i, &m.bx, &m.by, &m.bw, &m.bh);
         m.sad_pred = g == 0 ? sad_pred16 >> 2 : sad_pred16 >> 1;
-        wh_slot_pred (S, first + i, &m.mvpx, &m.mvpy);
-        WV_LANES_BEGIN (lane)
-        if (lane == 0) { S.mvcl[0][0] = 0; S.mvcl[0][1] = 0; }
-        WV_LANES_END
-        wh_motion_search (S, P, J, W, C, m, 1);
-        wh_cache_set (S, m.bx >> 2, m.by >> 2, m.bw >> 2, m.bh >> 2, 0, m.mvx, m.mvy);
-        wh_me_store (S, first + i, m);
+        wh_slot_pred (K, first + i, &m.mvpx, &m.mvpy);
+        wh_motion_search (S, P, J, W, C, m, mvcl, 1);
+        wh_cache_set (K, m.bx >> 2, m.by >> 2, m.bw >> 2, m.bh >> 2, 0, m.mvx, m.mvy);
+        wh_me_store (T, first + i, m);
         c += m.satd_cost;
       }
       if (oi == 0) {
@@ -932,9 +906,7 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, const WhSeqParams& P, const WhPicJob
     const int satd_in_md = use_satd;     // bSatdInMdFlag: pfMeCost == pfMdCost == SATD
     int best_sad = 0, best_satd = 0;
     if (mb_type == WH_MB_P8x8) {
-      WV_LANES_BEGIN (lane)
-      if (lane == 0) { S.refc[9] = WH_REF_NOT_AVAIL; S.refc[21] = WH_REF_NOT_AVAIL; }
-      WV_LANES_END
+      WV_LSET (K.ref, 9, WH_REF_NOT_AVAIL); WV_LSET (K.ref, 21, WH_REF_NOT_AVAIL);
     }
     {
       const int first = mb_type == WH_MB_P16x16 ? WH_SLOT_16x16 : mb_type == WH_MB_P16x8 ? WH_SLOT_16x8 : mb_type == WH_MB_P8x16 ? WH_SLOT_8x16 : WH_SLOT_8x8;
@@ -942,10 +914,10 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, const WhSeqParams& P, const WhPicJob
       for (int i = 0; i < cnt; ++i) {
         WhMe m;
         wh_slot_geom (first + i, &m.bx, &m.by, &m.bw, &m.bh);
-        wh_me_fetch (S, first + i, m);
-        wh_slot_pred (S, first + i, &m.mvpx, &m.mvpy);
+        wh_me_fetch (T, first + i, m);
+        wh_slot_pred (K, first + i, &m.mvpx, &m.mvpy);
         wh_refine_frac (S, P, J, W, C, m, satd_in_md);
-        wh_cache_set (S, m.bx >> 2, m.by >> 2, m.bw >> 2, m.bh >> 2, 0, m.mvx, m.mvy);
+        wh_cache_set (K, m.bx >> 2, m.by >> 2, m.bw >> 2, m.bh >> 2, 0, m.mvx, m.mvy);
         {
           const int bx4 = m.bx >> 2, by4 = m.by >> 2, w4 = m.bw >> 2, h4 = m.bh >> 2;
           WV_LANES_BEGIN (lane)
@@ -979,7 +951,7 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, const WhSeqParams& P, const WhPicJob
     if (mb_type == WH_MB_P16x16 && cbp == 0) {
       // PredSkipMv against the neighbour cache (row 0 / col 0 are untouched by the partition updates)
       int sx, sy;
-      wh_pred_skip_mv (S, &sx, &sy);
+      wh_pred_skip_mv (K, &sx, &sy);
       if (sx == me16.mvx && sy == me16.mvy) { mb_type = WH_MB_PSKIP; skx = sx; sky = sy; }
     }
   }

@@ -129,6 +129,24 @@ WH_FN void wh_pred_i16 (WhMbLds& S, int mode, int sum_t, int sum_l, int pl_b, in
   WV_LANES_END
 }
 
+// four adjacent samples (x0 .. x0+3 of row y) of an Intra16x16 prediction, packed -- for costing a mode without
+// materialising it in LDS
+WH_FN uint32_t wh_pred_i16_4 (const WhMbLds& S, int mode, int x0, int y, int sum_t, int sum_l, int pl_b, int pl_c, int pl_a) {
+  switch (mode) {
+  case WH_I16_V: return * (const uint32_t*)&S.rec_y[0 * 32 + x0 + 8];
+  case WH_I16_H: return 0x01010101u * (uint32_t)WH_RY (S, -1, y);
+  case WH_I16_DC: return 0x01010101u * (uint32_t) ((sum_t + sum_l + 16) >> 5);
+  case WH_I16_DC_L: return 0x01010101u * (uint32_t) ((sum_l + 8) >> 4);
+  case WH_I16_DC_T: return 0x01010101u * (uint32_t) ((sum_t + 8) >> 4);
+  case WH_I16_P: {
+    const int base = pl_a + pl_c * (y - 7) + 16;
+    return (uint32_t)wh_clip255 ((base + pl_b * (x0 - 7)) >> 5) | ((uint32_t)wh_clip255 ((base + pl_b * (x0 - 6)) >> 5) << 8) |
+           ((uint32_t)wh_clip255 ((base + pl_b * (x0 - 5)) >> 5) << 16) | ((uint32_t)wh_clip255 ((base + pl_b * (x0 - 4)) >> 5) << 24);
+  }
+  default: return 0x80808080u;
+  }
+}
+
 // chroma predictors into S.pred_c (numbering = the reference's C_PRED_*)
 enum { WH_C_DC = 0, WH_C_H = 1, WH_C_V = 2, WH_C_P = 3, WH_C_DC_L = 4, WH_C_DC_T = 5, WH_C_DC_128 = 6 };
 
@@ -230,14 +248,35 @@ WH_FN bool wh_intra_md_enc_p (WhMbLds& S, const WhSeqParams& P, const WhPicJob& 
   else if (has_l) { cand[0] = WH_I16_DC_L; cand[1] = WH_I16_H; ncand = 2; }
   else if (has_t) { cand[0] = WH_I16_DC_T; cand[1] = WH_I16_V; ncand = 2; }
   else { cand[0] = WH_I16_DC_128; ncand = 1; }
+  // cost of every candidate in one pass, straight from the neighbour samples (no prediction is written to LDS yet);
+  // lambda * BsSizeUE (g_kiMapModeI16x16[mode]):  V -> 1 bit, H/DC* -> 3, Plane -> 5
+  int cst[4] = {0, 0, 0, 0};
+  const int m0 = cand[0], m1 = ncand > 1 ? cand[1] : cand[0], m2 = ncand > 2 ? cand[2] : cand[0], m3 = ncand > 3 ? cand[3] : cand[0];
+  if (!use_satd) {
+    int p01, p23;
+#define WH_I16_SAD(m) wh_sad4 (* (const uint32_t*)&S.enc_y[lane * 4], wh_pred_i16_4 (S, (m), (lane & 3) * 4, lane >> 2, sum_t, sum_l, pl_b, pl_c, pl_a))
+    WV_SUM2 (p01, p23, lane, (WH_I16_SAD (m0) | (ncand > 1 ? WH_I16_SAD (m1) << 16 : 0)), ((ncand > 2 ? WH_I16_SAD (m2) : 0) | (ncand > 3 ? WH_I16_SAD (m3) << 16 : 0)));
+#undef WH_I16_SAD
+    cst[0] = p01 & 0xffff; cst[1] = (int) ((unsigned)p01 >> 16); cst[2] = p23 & 0xffff; cst[3] = (int) ((unsigned)p23 >> 16);
+  } else {
+    // SATD layout: lane quad = raster 4x4 block, lane & 3 = row inside it
+#define WH_I16_X0 (((lane >> 2) & 3) * 4)
+#define WH_I16_Y ((lane >> 4) * 4 + (lane & 3))
+#define WH_I16_SATD(dst, m) WV_SATD_ROWS (dst, lane, true, * (const uint32_t*)&S.enc_y[WH_I16_Y * 16 + WH_I16_X0], \
+                                          wh_pred_i16_4 (S, (m), WH_I16_X0, WH_I16_Y, sum_t, sum_l, pl_b, pl_c, pl_a))
+    WH_I16_SATD (cst[0], m0);
+    if (ncand > 1) WH_I16_SATD (cst[1], m1);
+    if (ncand > 2) WH_I16_SATD (cst[2], m2);
+    if (ncand > 3) WH_I16_SATD (cst[3], m3);
+#undef WH_I16_SATD
+#undef WH_I16_X0
+#undef WH_I16_Y
+  }
   int best_mode = cand[0], best_cost = 0x7fffffff, last_mode = -1;
   for (int i = 0; i < ncand; ++i) {
     const int m = cand[i];
-    wh_pred_i16 (S, m, sum_t, sum_l, pl_b, pl_c, pl_a);
-    last_mode = m;
-    // lambda * BsSizeUE (g_kiMapModeI16x16[mode]):  V -> 1 bit, H/DC* -> 3, Plane -> 5
     const int bits = (m == WH_I16_V) ? 1 : (m == WH_I16_P) ? 5 : 3;
-    const int c = wh_cost_luma16 (S, use_satd) + lambda * bits;
+    const int c = cst[i] + lambda * bits;
     if (c < best_cost) { best_cost = c; best_mode = m; }
   }
   if (!(best_cost < inter_cost)) return false;

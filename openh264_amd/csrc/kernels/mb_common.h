@@ -30,14 +30,14 @@ typedef struct WhMbLds {
   int16_t  amax[16];
   int8_t   i4m[25];           // neighbour Intra4x4PredMode cache: [(by+1)*5 + bx+1]
   uint8_t  nzc[24];
-  int16_t  lv_luma[256];      // zig-zag levels per luma4x4BlkIdx
+  alignas (8) int16_t lv_luma[256];   // zig-zag levels per luma4x4BlkIdx (copied out as 8-byte words)
   int16_t  lv_dc[16];
-  int16_t  lv_cac[128];       // chroma AC levels Cb 0..3, Cr 4..7
+  alignas (8) int16_t lv_cac[128];    // chroma AC levels Cb 0..3, Cr 4..7
   int16_t  lv_cdc[8];
   int8_t   i4_rem[16];
   uint16_t i4_prev;
   uint8_t  pad_[2];
-  unsigned long long prof[32]; // phase-profiling accumulators of this wave (WH_PROF_MARK)
+  uint32_t prof[32];          // phase-profiling accumulators of this wave (WH_PROF_MARK)
 } WhMbLds;
 
 #define WH_RY(S, x, y) ((S).rec_y[((y) + 1) * 32 + (x) + 8])
@@ -406,8 +406,43 @@ WH_FN int wh_encrec_i4 (WhMbLds& S, int b, int pred_slot, int qp) {
   return nz;
 }
 
+// JVT-O079 single-coefficient score of a block from the 16-bit mask of its non-zero zig-zag positions
+// (encode_mb_aux.cpp:417-436 WelsGetNoneZeroCount-style run table {3,2,2,1,1,1,0...}); equals wh_single_ctr.
+WH_FN int wh_single_ctr_mask (unsigned m) {
+  int ctr = 0, run = 0;
+  for (int k = 0; k < 16; ++k) {
+    if ((m >> k) & 1u) { ctr += (run == 0) ? 3 : (run <= 2) ? 2 : (run <= 5) ? 1 : 0; run = 0; }
+    else ++run;
+  }
+  return ctr;
+}
+// quantise S.res[base + 0 .. 16*nblk) into `dst` (rounding offsets of table row `ffrow`: qp for inter, qp + 6 for intra); S.part[blk] = max |level| of the block,
+// S.part2[blk] = mask of non-zero zig-zag positions (`skip_dc`: position 0 is not part of the scan)
+WH_FN void wh_quant_blocks (WhMbLds& S, int base, int nblk, int qp, int ffrow, int16_t* dst, int skip_dc) {
+  WV_LANES_BEGIN (lane)
+  if (lane < nblk * 4) {
+    int16_t mx = 0;
+    for (int k = 0; k < 4; ++k) {
+      const int i = lane * 4 + k, pos = i & 15;
+      int16_t a;
+      dst[i] = wh_quant1_abs (S.res[base + i], kWhQuantFF[ffrow * 3 + WH_POSCLASS (pos)], wh_mf (qp, pos), &a);
+      if (mx < a) mx = a;
+    }
+    S.tmp[512 + lane] = mx;
+  }
+  WV_LANES_END
+  WV_LANES_BEGIN (lane)
+  if (lane < nblk) {
+    S.part[lane] = wh_max (wh_max (S.tmp[512 + lane * 4], S.tmp[512 + lane * 4 + 1]), wh_max (S.tmp[512 + lane * 4 + 2], S.tmp[512 + lane * 4 + 3]));
+    unsigned m = 0;
+    for (int k = skip_dc; k < 16; ++k) m |= (unsigned) (dst[lane * 16 + wh_zigzag (k)] != 0) << (k - skip_dc);
+    S.part2[lane] = (int32_t)m;
+  }
+  WV_LANES_END
+}
+
 // ---- chroma residual pipeline for both planes (svc_encode_mb.cpp:244-312 WelsEncRecUV) -----------
-// in: enc_c, pred_c.  out: lv_cdc, lv_cac, nzc[16..23], rec tile.  Returns chroma cbp (0,1,2).
+// in: enc_c, pred_c.  out: lv_cdc, lv_cac, nzc[16..23], S.res[256..383] ready for wh_idct_chroma.  Returns chroma cbp (0,1,2).
 WH_FN int wh_encrec_chroma (WhMbLds& S, int qpc, int is_intra) {
   wh_dct_chroma (S);
   const int ffrow = is_intra ? qpc + 6 : qpc;
@@ -427,88 +462,53 @@ WH_FN int wh_encrec_chroma (WhMbLds& S, int qpc, int is_intra) {
     for (int k = 0; k < 4; ++k) S.lv_cdc[lane * 4 + k] = d[k];
   }
   WV_LANES_END
-  // AC quant with per-block max (WelsQuantFour4x4Max_c)
+  // AC quant with per-block max and non-zero mask (WelsQuantFour4x4Max_c)
+  wh_quant_blocks (S, 256, 8, qpc, ffrow, &S.res[256], 1);
+  // keep a plane's AC when its JVT-O079 score reaches 7 (inter; the reference stops adding at 7, which cannot change
+  // the test) -- intra keeps every plane that has a non-zero level
+  int sc0, sc1, nzdc0, nzdc1;
+#define WH_CSCORE(l) (is_intra ? (S.part[l] != 0 ? 7 : 0) : (S.part[l] > 1 ? 9 : S.part[l] == 1 ? wh_single_ctr_mask ((unsigned)S.part2[l]) : 0))
+  WV_SUM2 (sc0, sc1, lane, (lane < 4 ? WH_CSCORE (lane) : 0), (lane >= 4 && lane < 8 ? WH_CSCORE (lane) : 0));
+#undef WH_CSCORE
+  WV_SUM2 (nzdc0, nzdc1, lane, (lane < 4 ? (S.cdc[lane] != 0) : 0), (lane >= 4 && lane < 8 ? (S.cdc[lane] != 0) : 0));
+  const int keep0 = sc0 >= 7, keep1 = sc1 >= 7;
   WV_LANES_BEGIN (lane)
-  if (lane < 32) {
-    int16_t mx = 0;
-    for (int k = 0; k < 4; ++k) {
-      const int i = lane * 4 + k, pos = i & 15;
-      int16_t a;
-      S.res[256 + i] = wh_quant1_abs (S.res[256 + i], kWhQuantFF[ffrow * 3 + WH_POSCLASS (pos)], wh_mf (qpc, pos), &a);
-      if (mx < a) mx = a;
+  {
+    if (lane < 32) {                      // scans (WelsScan4x4Ac_c) -- a dropped plane leaves stale levels behind, nzc = 0 says so
+      const int b = lane >> 2;
+      for (int q = 0; q < 4; ++q) {
+        const int k = (lane & 3) * 4 + q;
+        S.lv_cac[b * 16 + k] = (k < 15) ? S.res[256 + b * 16 + wh_zigzag (k + 1)] : (int16_t)0;
+      }
     }
-    S.part[lane] = mx;
+    if (lane < 8) {
+      int n = 0;
+      if (lane < 4 ? keep0 : keep1) { unsigned m = (unsigned)S.part2[lane]; while (m) { n += (int) (m & 1u); m >>= 1; } }
+      S.nzc[16 + lane] = (uint8_t)n;
+    }
   }
   WV_LANES_END
   WV_LANES_BEGIN (lane)
-  if (lane < 8) {
-    int mx = wh_max (wh_max (S.part[lane * 4], S.part[lane * 4 + 1]), wh_max (S.part[lane * 4 + 2], S.part[lane * 4 + 3]));
-    S.amax[lane] = (int16_t)mx;
+  for (int h = 0; h < 2; ++h) {           // dequant (or clear) the 128 AC coefficients, two per lane
+    const int i = lane + 64 * h, keep = h == 0 ? keep0 : keep1;
+    S.res[256 + i] = keep ? (int16_t) (S.res[256 + i] * wh_dq (qpc, i & 15)) : (int16_t)0;
   }
   WV_LANES_END
-  // scans (WelsScan4x4Ac_c) -- zero blocks give zero levels either way
-  WV_LANES_BEGIN (lane)
-  if (lane < 32) {
-    const int b = lane >> 2;
-    for (int q = 0; q < 4; ++q) {
-      const int k = (lane & 3) * 4 + q;
-      S.lv_cac[b * 16 + k] = (k < 15) ? S.res[256 + b * 16 + wh_zigzag (k + 1)] : (int16_t)0;
+  if (nzdc0 > 0 || nzdc1 > 0) {
+    // WelsDequantIHadamard2x2Dc (decode_mb_aux.cpp:127-137)
+    WV_LANES_BEGIN (lane)
+    if (lane < 2 && (lane == 0 ? nzdc0 : nzdc1) > 0) {
+      int16_t* d = &S.cdc[lane * 4];
+      const int16_t su = (int16_t) (d[0] + d[2]), du = (int16_t) (d[0] - d[2]);
+      const int16_t sd = (int16_t) (d[1] + d[3]), dd = (int16_t) (d[1] - d[3]);
+      const int mf = wh_dq (qpc, 0);
+      int16_t* r = &S.res[256 + lane * 64];
+      r[0]  = (int16_t) (((su + sd) * mf) >> 1);
+      r[16] = (int16_t) (((su - sd) * mf) >> 1);
+      r[32] = (int16_t) (((du + dd) * mf) >> 1);
+      r[48] = (int16_t) (((du - dd) * mf) >> 1);
     }
+    WV_LANES_END
   }
-  WV_LANES_END
-  int cbp_c = 0;
-  for (int pl = 0; pl < 2; ++pl) {
-    // JVT-O079 style decision (inter only); intra keeps every non-zero block
-    int ctr = 0;
-    for (int j = 0; j < 4; ++j) {
-      const int mx = S.amax[pl * 4 + j];
-      if (mx != 0) {
-        if (!is_intra) {
-          if (mx > 1) ctr += 9;
-          else if (ctr < 7) ctr += wh_single_ctr (&S.lv_cac[(pl * 4 + j) * 16]);
-        } else {
-          ctr = 0x7fffffff;
-        }
-      }
-    }
-    int nzdc;
-    WV_SUM (nzdc, lane, (lane < 4 ? (S.cdc[pl * 4 + lane] != 0) : 0));
-    if (ctr < 7) {
-      WV_LANES_BEGIN (lane)
-      S.res[256 + pl * 64 + lane] = 0;
-      if (lane < 4) S.nzc[16 + pl * 4 + lane] = 0;
-      WV_LANES_END
-    } else {
-      WV_LANES_BEGIN (lane)
-      if (lane < 4) {
-        int n = 0;
-        for (int k = 0; k < 16; ++k) n += (S.lv_cac[(pl * 4 + lane) * 16 + k] != 0);
-        S.nzc[16 + pl * 4 + lane] = (uint8_t)n;
-      }
-      {
-        const int i = lane, pos = i & 15;
-        S.res[256 + pl * 64 + i] = (int16_t) (S.res[256 + pl * 64 + i] * wh_dq (qpc, pos));
-      }
-      WV_LANES_END
-      cbp_c = 2;
-    }
-    if (nzdc > 0) {
-      // WelsDequantIHadamard2x2Dc (decode_mb_aux.cpp:127-137)
-      WV_LANES_BEGIN (lane)
-      if (lane == 0) {
-        int16_t* d = &S.cdc[pl * 4];
-        const int16_t su = (int16_t) (d[0] + d[2]), du = (int16_t) (d[0] - d[2]);
-        const int16_t sd = (int16_t) (d[1] + d[3]), dd = (int16_t) (d[1] - d[3]);
-        const int mf = wh_dq (qpc, 0);
-        int16_t* r = &S.res[256 + pl * 64];
-        r[0]  = (int16_t) (((su + sd) * mf) >> 1);
-        r[16] = (int16_t) (((su - sd) * mf) >> 1);
-        r[32] = (int16_t) (((du + dd) * mf) >> 1);
-        r[48] = (int16_t) (((du - dd) * mf) >> 1);
-      }
-      WV_LANES_END
-      if (cbp_c != 2) cbp_c = 1;
-    }
-  }
-  return cbp_c;
+  return (keep0 || keep1) ? 2 : (nzdc0 > 0 || nzdc1 > 0) ? 1 : 0;
 }

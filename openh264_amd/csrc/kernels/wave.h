@@ -55,6 +55,12 @@
 #define WH_G
 #include <string.h>
 #include <stdlib.h>
+// A small wave-uniform table kept in ONE vector register: lane i holds entry i.  Uniform code reads entry i with
+// v_readlane (a few cycles) instead of an LDS round trip (~100 cycles); lane-parallel code updates many entries at once.
+typedef struct WvLaneArr { int v[64]; } WvLaneArr;
+#define WV_LGET(a, i) ((a).v[i])
+#define WV_LSET(a, i, val) ((a).v[i] = (val))
+#define WV_LSET_IF(a, lane, cond, val) do { for (int lane = 0; lane < 64; ++lane) if (cond) (a).v[lane] = (val); } while (0)
 // asynchronous copy of one 4-byte word per lane from global memory to LDS word `lane` of `lds_base` (GPU: LDS-DMA,
 // no register holds the data; complete after WV_ASYNC_WAIT)
 WH_FN void wh_ld_async4 (const void* src, uint32_t* lds_base, int lane) { memcpy (&lds_base[lane], src, 4); }
@@ -144,6 +150,10 @@ WH_FN int wh_satd_rows (int lane, bool active, uint32_t e, uint32_t p) {
 }
 #define WV_SATD_ROWS(dst, lane, active, enc4, pred4)              \
   do { const int lane = (int)(threadIdx.x & 63); (dst) = wh_satd_rows (lane, (active), (enc4), (pred4)); } while (0)
+typedef int WvLaneArr;
+#define WV_LGET(a, i) __builtin_amdgcn_readlane ((a), (i))
+#define WV_LSET(a, i, val) do { if ((int)(threadIdx.x & 63) == (i)) (a) = (val); } while (0)
+#define WV_LSET_IF(a, lane, cond, val) do { const int lane = (int)(threadIdx.x & 63); if (cond) (a) = (val); } while (0)
 #define WH_G __attribute__ ((address_space (1)))
 WH_FN uint32_t wh_ld4u (const uint8_t* base, int off) {
   const uint32_t* w = (const uint32_t*)base + (off >> 2);
@@ -167,7 +177,7 @@ WH_FN uint32_t wh_avg4 (uint32_t a, uint32_t b) { return __builtin_amdgcn_lerp (
 #else
 #define WH_PROF_DECL(P) unsigned long long _wh_t0 = (P).prof ? (unsigned long long)__builtin_readcyclecounter() : 0ULL
 #define WH_PROF_MARK(P, L, id) do { if ((P).prof) { const unsigned long long _t = (unsigned long long)__builtin_readcyclecounter(); \
-  if ((threadIdx.x & 63) == 0) { (L).prof[id] += _t - _wh_t0; (L).prof[16 + (id)] += 1ULL; } _wh_t0 = _t; } } while (0)
+  if ((threadIdx.x & 63) == 0) { (L).prof[id] += (uint32_t) (_t - _wh_t0); (L).prof[16 + (id)] += 1u; } _wh_t0 = _t; } } while (0)
 #endif
 
 // ---- small integer helpers (host + device) -----------------------------------------------------

@@ -25,6 +25,8 @@ class EmuBackend : public Backend {
   void upload (void* dst, const void* src, size_t bytes) override { memcpy (dst, src, bytes); }
   void download (void* dst, const void* src, size_t bytes) override { memcpy (dst, src, bytes); }
   void fill (void* dst, int value, size_t bytes) override { memset (dst, value, bytes); }
+  // LDS is not initialised on the GPU: poison the emulated tile so that a kernel relying on stale contents fails here
+  static void poison (void* p, size_t n) { memset (p, 0xA5, n); }
   // same per-slice / per-picture dependency order the device kernels walk (common/mb_order.h), one MB at a time
   template <class F> static void for_order (const WhSeqParams& P, int n, bool whole_picture, F f) {
     const int num_mb = P.mb_w * P.mb_h;
@@ -35,11 +37,12 @@ class EmuBackend : public Backend {
     }
   }
   void run_intra (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
-    for_order (P, n, false, [&] (int j, int x, int y) { WhMbLds S; wh_intra_mb_body (S, P, jobs[j], x, y); });
+    for_order (P, n, false, [&] (int j, int x, int y) { WhMbLds S; poison (&S, sizeof (S)); wh_intra_mb_body (S, P, jobs[j], x, y); });
   }
   void run_inter (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
     for_order (P, n, false, [&] (int j, int x, int y) {
       WhInterLds S;
+      poison (&S, sizeof (S));
       for (int lane = 0; lane < 64; ++lane) wh_inter_cold_fetch (S, lane, P, jobs[j], x, y);
       WhInterCtx X;
       X.slice_idc = wh_slice_of_mb (P, y * P.mb_w + x); X.slice_first = P.slice_first_mb[X.slice_idc];
@@ -48,7 +51,7 @@ class EmuBackend : public Backend {
     });
   }
   void run_deblock (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
-    for_order (P, n, true, [&] (int j, int x, int y) { WhDbLds S; wh_deblock_mb_body (S, P, jobs[j], x, y); });
+    for_order (P, n, true, [&] (int j, int x, int y) { WhDbLds S; poison (&S, sizeof (S)); wh_deblock_mb_body (S, P, jobs[j], x, y); });
   }
   void run_expand (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
     for (int j = 0; j < n; ++j) {
