@@ -34,7 +34,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--sessions", type=int, default=int(os.environ.get("WELSHIP_BENCH_SESSIONS", "32")), help="independent pictures per GPU per step")
+    ap.add_argument("--sessions", type=int, default=int(os.environ.get("WELSHIP_BENCH_SESSIONS", "64")), help="independent pictures per GPU per step")
+    ap.add_argument("--queues", type=int, default=int(os.environ.get("WELSHIP_QUEUES", "1")), help="device queues the sessions are spread over (kernels of different queues overlap)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--qp", type=int, default=24)
@@ -82,6 +83,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    os.environ["WELSHIP_QUEUES"] = str(a.queues)
     import openh264_amd as oh
     from openh264_amd.utils.synth import synth_sequence
 
@@ -155,7 +157,7 @@ def main():
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": ("%dx%d all-IDR (intra MD + DCT/quant + deblock), QP %d, LOW complexity" % (w, h, a.qp)) if workload == "intra" else
                        ("%dx%d P-frames, diamond ME range 16, 4 slices/frame, QP %d, LOW complexity" % (w, h, a.qp)),
-                       "pictures_in_flight_per_gpu": a.sessions, "hot_path": "device MD/recon + deblock + border expand; sources resident in HBM, MB records left in HBM; host CAVLC excluded",
+                       "pictures_in_flight_per_gpu": a.sessions, "device_queues": a.queues, "hot_path": "device MD/recon + deblock + border expand; sources resident in HBM, MB records left in HBM; host CAVLC excluded",
                        "parallelism": "sessions sharded over %d GPU(s), no collective" % world},
             "roofline": {"bound": "hbm", "kernel": "k_intra_slice" if workload == "intra" else "k_inter_slice",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,

@@ -84,6 +84,9 @@ typedef struct WhPicJob {
   int32_t        ref_is_p;   // reference picture was a P picture (co-located MV candidates)
   int32_t        pad;
   const uint8_t* prev_src_y; // luma of the previous source picture (VAA 8x8 SADs, LOW complexity P pictures)
+  uint32_t*      db_flags;   // one word per MB: == db_gen once the MB is deblocked (hand-off between the slices' workgroups)
+  uint32_t       db_gen;     // generation of this picture (never 0, changes every frame: the flags need no clearing)
+  uint32_t       pad2;
 } WhPicJob;
 
 #define WH_MAX_SLICES 36

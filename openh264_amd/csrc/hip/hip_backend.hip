@@ -144,6 +144,69 @@ __global__ __launch_bounds__ (MAXT) __attribute__ ((amdgpu_waves_per_eu (WPE, WP
 }
 WH_DEFINE_MB_KERNEL (k_deblock_pic, WhDbLds, wh_deblock_mb_body, 1024, 1, 0)
 
+// Deblocking with one workgroup per slice.  The filter crosses slice boundaries (disable_deblocking_filter_idc 0), so
+// the MBs along a slice's upper seam wait for MBs of the previous slice -- another workgroup, in general on another
+// XCD: the producer publishes with an agent-scope release + a flag word in HBM (J.db_flags[mb] = J.db_gen), the
+// consumer polls the flag (relaxed, agent scope) and then takes an agent-scope acquire before it loads the pixels
+// (MI355X_MICROARCH.md, inter-workgroup visibility).  Only MBs that a later slice can depend on publish.  The
+// workgroups of one picture have consecutive block ids and slice s-1 never waits for slice s, so the chain cannot
+// deadlock while the earlier workgroup is scheduled; the spin is bounded regardless.
+#define WH_SEAM_SPIN_LIMIT (1u << 20)
+__global__ __launch_bounds__ (1024) void k_deblock_slices (WhSeqParams P, const WhPicJob* jobs, uint32_t* err) {
+  extern __shared__ __align__ (16) uint8_t smem[];
+  const int nw = (int)blockDim.x >> 6, lane = (int)threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane ((int)threadIdx.x >> 6);
+  WhDbLds& S = ((WhDbLds*)smem)[wave];
+  uint32_t* sched = (uint32_t*) (smem + (size_t)nw * sizeof (WhDbLds));
+  const int w = P.mb_w, num_mb = P.mb_w * P.mb_h;
+  const int first = P.slice_first_mb[blockIdx.x], last = P.slice_first_mb[blockIdx.x + 1], n = last - first;
+  const uint16_t* order = P.mb_order + first;
+  for (int i = (int)threadIdx.x; i < 1 + ((n + 31) >> 5); i += (int)blockDim.x) sched[i] = 0;
+  __syncthreads();
+  const WhPicJob& J = jobs[blockIdx.y];
+  uint32_t* flags = J.db_flags;
+  const uint32_t gen = J.db_gen;
+  const bool cross = P.deblock_idc == 0;        // idc 2: nothing is filtered (or needed) across slices
+  for (int guard = 0; guard <= n; ++guard) {
+    int t = 0;
+    if (lane == 0) t = (int)atomicAdd (&sched[0], 1u);
+    t = __builtin_amdgcn_readfirstlane (t);
+    if (t >= n) break;
+    const int xy = order[t];
+    int dep_a, dep_b;                           // picture-wide dependencies: left, top-right (top at the right edge)
+    wh_mb_deps (w, xy, 0, &dep_a, &dep_b);
+    bool remote = false, ok = true;
+    for (int k = 0; k < 2 && ok; ++k) {
+      const int dep = k == 0 ? dep_a : dep_b;
+      if (dep < 0) continue;
+      if (dep >= first) ok = wh_wait_done (sched + 1, dep - first, err);
+      else if (cross) {
+        uint32_t spins = 0;
+        while (__hip_atomic_load (&flags[dep], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gen) {
+          __builtin_amdgcn_s_sleep (8);
+          if (++spins > WH_SEAM_SPIN_LIMIT) { if (lane == 0 && atomicAdd (err, 1u) == 0) { err[1] = blockIdx.x; err[2] = blockIdx.y; err[3] = 0x80000000u | (uint32_t)dep; } ok = false; break; }
+        }
+        remote = true;
+      }
+    }
+    if (!ok) break;
+    if (remote) __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "agent");
+    else __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "workgroup");
+    wh_deblock_mb_body (S, P, J, xy % w, xy / w);
+    // MBs a later slice may wait for: its left neighbour (xy + 1), top (xy + w) or top-right consumer (xy + w - 1)
+    const bool publish = cross && xy + w + 1 >= last && last < num_mb;
+    if (publish) {
+      asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_fence (__ATOMIC_RELEASE, "agent");
+      asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_store (&flags[xy], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      __builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");
+    }
+    if (lane == 0) atomicOr (&sched[1 + ((xy - first) >> 5)], 1u << ((xy - first) & 31));
+  }
+}
+
 __global__ __launch_bounds__ (64) void k_expand (WhSeqParams P, const WhPicJob* jobs) {
   const WhPicJob J = jobs[blockIdx.y];
   wh_expand_body (P, J, (int)blockIdx.x);
@@ -156,12 +219,14 @@ class HipBackend : public wh::Backend {
   HipBackend (int dev, const hipDeviceProp_t& prop) : dev_ (dev) {
     HIP_CHECK (hipSetDevice (dev_));
     HIP_CHECK (hipStreamCreateWithFlags (&stream_, hipStreamNonBlocking));
+    streams_.push_back (stream_);
     HIP_CHECK (hipMalloc ((void**)&err_, 16));
     HIP_CHECK (hipMemset (err_, 0, 16));
     name_ = std::string ("hip:") + prop.gcnArchName + " " + prop.name;
   }
   ~HipBackend() override {
-    (void)hipSetDevice (dev_); (void)hipStreamSynchronize (stream_); (void)hipStreamDestroy (stream_);
+    (void)hipSetDevice (dev_);
+    for (hipStream_t st : streams_) { (void)hipStreamSynchronize (st); (void)hipStreamDestroy (st); }
     for (void* p : slabs_) (void)hipFree (p);
     (void)hipFree (err_);
   }
@@ -221,13 +286,22 @@ class HipBackend : public wh::Backend {
     else if (waves == 12) mb_pass (k_inter_slice<768, 3>, sizeof (WhInterLds), 12, false, P, jobs, n);
     else mb_pass (k_inter_slice<512, 2>, sizeof (WhInterLds), 8, false, P, jobs, n);
   }
-  void run_deblock (const WhSeqParams& P, const WhPicJob* jobs, int n) override { mb_pass (k_deblock_pic, sizeof (WhDbLds), 16, true, P, jobs, n); }
+  void run_deblock (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
+    static const bool whole = getenv ("WELSHIP_DEBLOCK_WHOLE_PICTURE") != nullptr;     // the single-workgroup variant, for comparison
+    if (P.num_slices > 1 && !whole) mb_pass (k_deblock_slices, sizeof (WhDbLds), 16, false, P, jobs, n);
+    else mb_pass (k_deblock_pic, sizeof (WhDbLds), 16, true, P, jobs, n);
+  }
   void run_expand (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
     hipLaunchKernelGGL (k_expand, dim3 (wh_expand_num_blocks (P), n), dim3 (64), 0, stream_, P, jobs);
     HIP_CHECK (hipGetLastError());
   }
+  void select_queue (int k) override {
+    HIP_CHECK (hipSetDevice (dev_));
+    while ((int)streams_.size() <= k) { hipStream_t st; HIP_CHECK (hipStreamCreateWithFlags (&st, hipStreamNonBlocking)); streams_.push_back (st); }
+    stream_ = streams_[k < 0 ? 0 : k];
+  }
   void sync() override {
-    HIP_CHECK (hipStreamSynchronize (stream_));
+    for (hipStream_t st : streams_) HIP_CHECK (hipStreamSynchronize (st));
     uint32_t e[4] = {0, 0, 0, 0};
     HIP_CHECK (hipMemcpy (e, err_, 16, hipMemcpyDeviceToHost));
     if (e[0]) { fprintf (stderr, "welship: %u in-kernel dependency waits timed out (first: block %u,%u waiting for MB index %u)\n", e[0], e[1], e[2], e[3]); abort(); }
@@ -239,7 +313,8 @@ class HipBackend : public wh::Backend {
   hipStream_t stream() const { return stream_; }
  private:
   int dev_;
-  hipStream_t stream_ = nullptr;
+  hipStream_t stream_ = nullptr;          // the selected queue
+  std::vector<hipStream_t> streams_;
   uint32_t* err_ = nullptr;
   std::vector<void*> slabs_;
   size_t slab_size_ = 0, slab_used_ = 0;

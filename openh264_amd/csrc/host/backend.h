@@ -25,6 +25,9 @@ class Backend {
   virtual void run_inter (const WhSeqParams& P, const WhPicJob* jobs, int n) = 0;     // P pictures: ME + MD + recon
   virtual void run_deblock (const WhSeqParams& P, const WhPicJob* jobs, int n) = 0;   // in-loop filter on rec[]
   virtual void run_expand (const WhSeqParams& P, const WhPicJob* jobs, int n) = 0;    // replicate rec[] borders (32/16 px)
+  // Independent in-order queues (HIP streams): everything issued after select_queue (k) goes to queue k; work on
+  // different queues may overlap on the device.  sync() waits for all of them.
+  virtual void select_queue (int k) = 0;
   virtual void sync() = 0;
   // timing on the stream the kernels are launched on (HIP events)
   virtual void* event_create() = 0;

@@ -13,6 +13,8 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <algorithm>
+#include <stdlib.h>
 #include "../../../include/welship.h"
 #include "backend.h"
 #include "../common/mb_order.h"
@@ -50,6 +52,8 @@ struct SessionCore {
   int last_slot = 0;                  // source slot of the previous frame (VAA reference)
   WhMbRecord* d_records = nullptr;
   uint16_t* d_order = nullptr;
+  uint32_t* d_dbflags = nullptr;
+  uint32_t db_gen = 0;
   size_t rec_alloc_bytes = 0, src_bytes = 0, ysz = 0, csz = 0;
   std::vector<uint8_t> h_src;
   std::vector<WhMbRecord> h_records;
@@ -141,6 +145,8 @@ struct SessionCore {
       be->sync();
       s.mb_order = d_order;
     }
+    d_dbflags = (uint32_t*)be->alloc (sizeof (uint32_t) * num_mb);
+    be->fill (d_dbflags, 0, sizeof (uint32_t) * num_mb);
     // level (au_set.cpp:530-545): the reference feeds iSpatialBitrate even with RC off
     level_idc = wh::select_level_idc (mb_w, mb_h, 1, p->fMaxFrameRate, p->iTargetBitrate, &level_1b);
     return WELSHIP_OK;
@@ -155,6 +161,8 @@ struct SessionCore {
     d_records = nullptr;
     if (d_order) be->free (d_order);
     d_order = nullptr;
+    if (d_dbflags) be->free (d_dbflags);
+    d_dbflags = nullptr;
     be = nullptr;
   }
 
@@ -196,6 +204,9 @@ struct SessionCore {
     job->ref_is_p = r.is_p ? 1 : 0;
     job->prev_src_y = d_src[last_slot];
     last_slot = slot;
+    job->db_flags = d_dbflags;
+    if (++db_gen == 0) db_gen = 1;
+    job->db_gen = db_gen;
   }
 
   // Entropy-code the downloaded records into `bs` and advance the stream state.
@@ -327,6 +338,9 @@ struct WelsHipEncoder {
 struct WelsHipEncoderGroup {
   wh::Backend* be = nullptr;
   std::vector<std::unique_ptr<SessionCore>> sess;
+  int queues = 1;                               // sessions are split into `queues` contiguous chunks, one device queue each
+  int chunk_first (int q) const { return (int) ((long long)sess.size() * q / queues); }
+  int chunk_of (int session) const { int q = 0; while (q + 1 < queues && chunk_first (q + 1) <= session) ++q; return q; }
   WhPicJob* d_jobs = nullptr;
   std::vector<WhPicJob> h_jobs;
   int host_threads = 1;
@@ -449,6 +463,7 @@ int WelsHipGroupCreate (WelsHipEncoderGroup** pp, const WelsHipEncParam* p, int 
   }
   g->d_jobs = (WhPicJob*)be->alloc (sizeof (WhPicJob) * n_sessions);
   g->h_jobs.resize (n_sessions);
+  if (const char* q = getenv ("WELSHIP_QUEUES")) g->queues = std::max (1, std::min (atoi (q), n_sessions));
   *pp = g;
   return WELSHIP_OK;
 }
@@ -467,6 +482,7 @@ int WelsHipGroupUploadSource (WelsHipEncoderGroup* g, int session, int slot, con
   SessionCore& c = *g->sess[session];
   if (slot < 0 || slot >= c.ring) return WELSHIP_ERR_INIT_PARA;
   if (src->iPicWidth != c.prm.iPicWidth || src->iPicHeight != c.prm.iPicHeight) return WELSHIP_ERR_INIT_PARA;
+  g->be->select_queue (g->chunk_of (session));
   c.upload_source (slot, src);
   return WELSHIP_OK;
 }
@@ -477,14 +493,22 @@ int WelsHipGroupBegin (WelsHipEncoderGroup* g, int slot) {
   for (int i = 0; i < n; ++i) g->sess[i]->begin_frame (slot % g->sess[i]->ring, &g->h_jobs[i]);
   g->step_idr = g->sess[0]->cur_idr;
   for (int i = 1; i < n; ++i) if (g->sess[i]->cur_idr != g->step_idr) { set_err ("sessions of a group must share the frame type"); return WELSHIP_ERR_UNKNOWN; }
-  g->be->upload (g->d_jobs, g->h_jobs.data(), sizeof (WhPicJob) * n);
+  for (int q = 0; q < g->queues; ++q) {
+    const int a = g->chunk_first (q), b = g->chunk_first (q + 1);
+    g->be->select_queue (q);
+    g->be->upload (g->d_jobs + a, g->h_jobs.data() + a, sizeof (WhPicJob) * (b - a));
+  }
   return WELSHIP_OK;
 }
 
 int WelsHipGroupRunDevice (WelsHipEncoderGroup* g, int wait) {
   if (!g) return WELSHIP_ERR_INIT_PARA;
   SessionCore& c0 = *g->sess[0];
-  run_device_step (g->be, c0.seq, g->d_jobs, (int)g->sess.size(), g->step_idr, c0.prm.uiIntraPeriod != 1);
+  for (int q = 0; q < g->queues; ++q) {
+    const int a = g->chunk_first (q), b = g->chunk_first (q + 1);
+    g->be->select_queue (q);
+    run_device_step (g->be, c0.seq, g->d_jobs + a, b - a, g->step_idr, c0.prm.uiIntraPeriod != 1);
+  }
   if (wait) g->be->sync();
   return WELSHIP_OK;
 }
@@ -494,6 +518,7 @@ int WelsHipGroupFinish (WelsHipEncoderGroup* g, WelsHipFrameBSInfo* outs) {
   const int n = (int)g->sess.size();
   for (int i = 0; i < n; ++i) {
     SessionCore& c = *g->sess[i];
+    g->be->select_queue (g->chunk_of (i));
     g->be->download (c.h_records.data(), c.d_records, sizeof (WhMbRecord) * c.num_mb);
   }
   g->be->sync();
@@ -541,8 +566,9 @@ int WelsHipGroupStepDeviceOnly (WelsHipEncoderGroup* g, int slot) {
 }
 
 // Hot-path benchmark: `warmup` untimed + `steps` timed device-only frame steps, source slot cycling
-// ping-pong over the resident ring.  out_ms[0] = total (HIP events on the launch stream),
-// out_ms[1..3] = mode-decision / deblocking / border-expansion passes summed over the timed steps.
+// ping-pong over the resident ring.  out_ms[0] = total, out_ms[1..3] = mode-decision / deblocking / border-expansion
+// passes summed over the timed steps -- HIP events on device queue 0 (with several queues: that queue's own kernels,
+// which then overlap the other queues' work; the wall-clock around the call is the throughput measure).
 int WelsHipGroupBench (WelsHipEncoderGroup* g, int steps, int warmup, double* out_ms) {
   if (!g || steps < 1 || !out_ms) return WELSHIP_ERR_INIT_PARA;
   wh::Backend* be = g->be;
@@ -559,15 +585,20 @@ int WelsHipGroupBench (WelsHipEncoderGroup* g, int steps, int warmup, double* ou
   for (int i = 0; i < steps; ++i) {
     int rc = WelsHipGroupBegin (g, slot_of (fi++));
     if (rc) return rc;
-    be->event_record (ev[i * 4 + 0]);
-    if (g->step_idr) be->run_intra (s, g->d_jobs, n); else be->run_inter (s, g->d_jobs, n);
-    be->event_record (ev[i * 4 + 1]);
-    if (s.deblock_idc != 1) be->run_deblock (s, g->d_jobs, n);
-    be->event_record (ev[i * 4 + 2]);
-    if (need_ref) be->run_expand (s, g->d_jobs, n);
-    be->event_record (ev[i * 4 + 3]);
+    for (int q = g->queues - 1; q >= 0; --q) {      // queue 0 last: it carries the events
+      const int a = g->chunk_first (q), cnt = g->chunk_first (q + 1) - a;
+      be->select_queue (q);
+      if (q == 0) be->event_record (ev[i * 4 + 0]);
+      if (g->step_idr) be->run_intra (s, g->d_jobs + a, cnt); else be->run_inter (s, g->d_jobs + a, cnt);
+      if (q == 0) be->event_record (ev[i * 4 + 1]);
+      if (s.deblock_idc != 1) be->run_deblock (s, g->d_jobs + a, cnt);
+      if (q == 0) be->event_record (ev[i * 4 + 2]);
+      if (need_ref) be->run_expand (s, g->d_jobs + a, cnt);
+      if (q == 0) be->event_record (ev[i * 4 + 3]);
+    }
     for (auto& c : g->sess) { c->pic[c->cur].is_p = !c->cur_idr; c->have_recon = true; ++c->frame_index; c->frame_num = (c->frame_num + 1) & 0x7fff; c->cur ^= 1; }
   }
+  be->select_queue (0);
   be->event_record (ev[(size_t)steps * 4]);
   be->sync();
   out_ms[0] = be->event_elapsed_ms (ev[0], ev[(size_t)steps * 4]);

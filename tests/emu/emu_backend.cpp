@@ -59,6 +59,7 @@ class EmuBackend : public Backend {
       for (int b = 0; b < nb; ++b) wh_expand_body (P, jobs[j], b);
     }
   }
+  void select_queue (int) override {}
   void sync() override {}
   void* event_create() override { return new double (0.0); }
   void event_destroy (void* ev) override { delete (double*)ev; }
