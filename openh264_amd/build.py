@@ -28,12 +28,9 @@ def build_hip(force=False, verbose=True):
     deps = [CSRC, os.path.join(ROOT, "include")]
     if not force and not _newer(LIB, deps):
         return LIB
-    # -ashr-pk-insts: hipcc (ROCm 7.2) selects gfx950's v_ashr_pk_u8_i32 for "clip255 (x >> n)" pairs and then ORs further
-    # bytes into the upper half of its result as if that half were zero; on the MI355X it is not, which corrupts packed
-    # pixels (found by tests/test_prims_gpu.py::test_motion_compensation).  The feature is switched off for device code.
+    # NB: no v_ashr_pk_u8_i32 may appear in the device code (see wh_clip255 in csrc/kernels/wave.h): checked below.
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-function",
-           "-Wno-unused-variable", "-Xclang", "-target-feature", "-Xclang", "-ashr-pk-insts",
-           "-o", LIB] + HIP_SRCS + HOST_SRCS
+           "-Wno-unused-variable", "-o", LIB] + HIP_SRCS + HOST_SRCS
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd, cwd=ROOT)

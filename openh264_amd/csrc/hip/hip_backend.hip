@@ -50,6 +50,10 @@ __device__ __forceinline__ WhMbLds& wh_prof_holder (WhMbLds& S) { return S; }
 __device__ __forceinline__ WhMbLds& wh_prof_holder (WhDbLds& S) { return * (WhMbLds*)&S; }     /* never used (PROF = 0) */
 template <class T> __device__ __forceinline__ uint32_t* wh_prof_lds (T& S) { return wh_prof_holder (S).prof; }
 
+__device__ __forceinline__ void wh_copy_job (WhPicJob* dst, const WhPicJob* src) {
+  if (threadIdx.x < sizeof (WhPicJob) / 4) ((uint32_t*)dst)[threadIdx.x] = ((const uint32_t*)src)[threadIdx.x];
+}
+
 #define WH_DEFINE_MB_KERNEL(NAME, LDS_T, BODY, MAX_THREADS, WHOLE_PICTURE, PROF)                                             \
 __global__ __launch_bounds__ (MAX_THREADS) void NAME (WhSeqParams P, const WhPicJob* jobs, uint32_t* err) {             \
   extern __shared__ __align__ (16) uint8_t smem[];                                                                      \
@@ -63,9 +67,11 @@ __global__ __launch_bounds__ (MAX_THREADS) void NAME (WhSeqParams P, const WhPic
   const uint16_t* order = P.mb_order + (WHOLE_PICTURE ? num_mb : first);                                                \
   for (int i = (int)threadIdx.x; i < 1 + ((n + 31) >> 5); i += (int)blockDim.x) sched[i] = 0;                          \
   if (PROF && P.prof && lane < 32) wh_prof_lds (S)[lane] = 0;                                                           \
+  __shared__ WhPicJob Jl;                   /* the job descriptor, read from LDS (lgkmcnt) wherever it is needed */        \
+  wh_copy_job (&Jl, &jobs[blockIdx.y]);                                                                                 \
   __syncthreads();                                                                                                      \
   WH_PROF_DECL (P);                                                                                                     \
-  const WhPicJob& J = jobs[blockIdx.y];      /* read where needed (scalar cache), not held in 30 SGPRs */                \
+  const WhPicJob& J = Jl;                                                                                               \
   for (int guard = 0; guard <= n; ++guard) {      /* a wave can never need more than n + 1 tickets */                   \
     int t = 0;                                                                                                          \
     if (lane == 0) t = (int)atomicAdd (&sched[0], 1u);                                                                  \
@@ -95,28 +101,40 @@ WH_DEFINE_MB_KERNEL (k_intra_slice, WhMbLds, wh_intra_mb_body, 512, 0, 0)
 // starts the current one, so that the body can fetch the next MB's cold inputs (straight from HBM) underneath its own
 // arithmetic.  Holding one extra ticket keeps the no-deadlock argument: the lowest unfinished ticket is always being
 // processed, never merely held.
-template <int MAXT, int WPE>
-__global__ __launch_bounds__ (MAXT) __attribute__ ((amdgpu_waves_per_eu (WPE, WPE))) void k_inter_slice (WhSeqParams P, const WhPicJob* jobs, uint32_t* err) {
+// LDS for the optional window staging exists only in the kernel variant that uses it
+template <int N, bool ON> struct WhWinStageLds { static __device__ __forceinline__ WhWinStage* get (int wave) { __shared__ WhWinStage st[N]; return &st[wave]; } };
+template <int N> struct WhWinStageLds<N, false> { static __device__ __forceinline__ WhWinStage* get (int) { return nullptr; } };
+
+template <int MAXT, bool WINPF>
+__global__ __launch_bounds__ (MAXT) void k_inter_slice (WhSeqParams P, const WhPicJob* jobs, uint32_t* err) {
   extern __shared__ __align__ (16) uint8_t smem[];
   const int nw = (int)blockDim.x >> 6, lane = (int)threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane ((int)threadIdx.x >> 6);
   WhInterLds& S = ((WhInterLds*)smem)[wave];
+  __shared__ WhInterStage stage[MAXT / 64];          // separate LDS objects: see WhInterStage
+  WhInterStage& G = stage[wave];
   uint32_t* sched = (uint32_t*) (smem + (size_t)nw * sizeof (WhInterLds));
   const int first = P.slice_first_mb[blockIdx.x], n = P.slice_first_mb[blockIdx.x + 1] - first;
   const uint16_t* order = P.mb_order + first;
   for (int i = (int)threadIdx.x; i < 1 + ((n + 31) >> 5); i += (int)blockDim.x) sched[i] = 0;
   if (P.prof && lane < 32) S.m.prof[lane] = 0;
+  __shared__ WhPicJob Jl;
+  wh_copy_job (&Jl, &jobs[blockIdx.y]);
   __syncthreads();
   WH_PROF_DECL (P);
-  const WhPicJob& J = jobs[blockIdx.y];
+  const WhPicJob& J = Jl;
   WhInterCtx X;
+  WhWinPf pf;
+  pf.valid = 0;
+  X.pf = &pf;
+  X.win_stage = WhWinStageLds<MAXT / 64, WINPF>::get (wave);
   X.slice_idc = (int)blockIdx.x; X.slice_first = first;
   int t = 0;
   if (lane == 0) t = (int)atomicAdd (&sched[0], 1u);
   t = __builtin_amdgcn_readfirstlane (t);
   if (t < n) {
     int xy = order[t];
-    wh_inter_cold_fetch (S, lane, P, J, xy % P.mb_w, xy / P.mb_w);
+    wh_inter_cold_fetch (G, lane, P, J, xy % P.mb_w, xy / P.mb_w);
     for (int guard = 0; guard <= n; ++guard) {
       int tn = 0;
       if (lane == 0) tn = (int)atomicAdd (&sched[0], 1u);
@@ -131,7 +149,7 @@ __global__ __launch_bounds__ (MAXT) __attribute__ ((amdgpu_waves_per_eu (WPE, WP
       WH_PROF_MARK (P, S.m, 12);
       WV_ASYNC_WAIT();                      /* this MB's cold inputs have landed in S.cold_* */
       X.next_valid = tn < n; X.next_mbx = xyn % P.mb_w; X.next_mby = xyn / P.mb_w;
-      wh_inter_mb_body (S, P, J, xy % P.mb_w, xy / P.mb_w, X);
+      wh_inter_mb_body (S, G, P, J, xy % P.mb_w, xy / P.mb_w, X);
       WH_PROF_MARK (P, S.m, 14);
       __builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");
       if (lane == 0) atomicOr (&sched[1 + ((xy - first) >> 5)], 1u << ((xy - first) & 31));
@@ -162,8 +180,10 @@ __global__ __launch_bounds__ (1024) void k_deblock_slices (WhSeqParams P, const 
   const int first = P.slice_first_mb[blockIdx.x], last = P.slice_first_mb[blockIdx.x + 1], n = last - first;
   const uint16_t* order = P.mb_order + first;
   for (int i = (int)threadIdx.x; i < 1 + ((n + 31) >> 5); i += (int)blockDim.x) sched[i] = 0;
+  __shared__ WhPicJob Jl;
+  wh_copy_job (&Jl, &jobs[blockIdx.y]);
   __syncthreads();
-  const WhPicJob& J = jobs[blockIdx.y];
+  const WhPicJob& J = Jl;
   uint32_t* flags = J.db_flags;
   const uint32_t gen = J.db_gen;
   const bool cross = P.deblock_idc == 0;        // idc 2: nothing is filtered (or needed) across slices
@@ -216,7 +236,7 @@ __global__ __launch_bounds__ (64) void k_expand (WhSeqParams P, const WhPicJob* 
 
 class HipBackend : public wh::Backend {
  public:
-  HipBackend (int dev, const hipDeviceProp_t& prop) : dev_ (dev) {
+  HipBackend (int dev, const hipDeviceProp_t& prop) : dev_ (dev), cus_ (prop.multiProcessorCount) {
     HIP_CHECK (hipSetDevice (dev_));
     HIP_CHECK (hipStreamCreateWithFlags (&stream_, hipStreamNonBlocking));
     streams_.push_back (stream_);
@@ -256,7 +276,8 @@ class HipBackend : public wh::Backend {
 
   // waves per workgroup: bounded by the LDS budget (160 KB per CU), the kernel's register budget and by how many MBs
   // of one slice can be in flight at all (~ min(rows, mb_w / 2))
-  template <class K> void mb_pass (K kernel, size_t lds_per_wave, int max_waves, bool whole_picture, const WhSeqParams& P, const WhPicJob* jobs, int n) {
+  // `static_lds`: LDS the kernel declares statically (counts against the 160 KB of a CU as well)
+  template <class K> void mb_pass (K kernel, size_t lds_per_wave, int max_waves, bool whole_picture, const WhSeqParams& P, const WhPicJob* jobs, int n, size_t static_lds = 0) {
     const int num_mb = P.mb_w * P.mb_h;
     int max_n = whole_picture ? num_mb : 0, max_rows = whole_picture ? P.mb_h : 0;
     if (!whole_picture) for (int s = 0; s < P.num_slices; ++s) {
@@ -269,7 +290,7 @@ class HipBackend : public wh::Backend {
     int nw = max_waves;
     const int par = std::max (1, std::min (max_rows, (P.mb_w + 1) / 2));
     if (nw > par) nw = par;
-    while (nw > 1 && (size_t)nw * lds_per_wave + sched_bytes > (size_t)160 * 1024) --nw;
+    while (nw > 1 && (size_t)nw * lds_per_wave + sched_bytes + static_lds > (size_t)160 * 1024) --nw;
     const size_t lds = (size_t)nw * lds_per_wave + sched_bytes;
     HIP_CHECK (hipFuncSetAttribute ((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (getenv ("WELSHIP_TRACE")) { fprintf (stderr, "welship: launch grid %d x %d, %d waves, %zu B LDS, max_n %d\n", whole_picture ? 1 : P.num_slices, n, nw, lds, max_n); fflush (stderr); }
@@ -278,13 +299,17 @@ class HipBackend : public wh::Backend {
     if (getenv ("WELSHIP_TRACE")) { HIP_CHECK (hipStreamSynchronize (stream_)); fprintf (stderr, "welship: launch done\n"); fflush (stderr); }
   }
   void run_intra (const WhSeqParams& P, const WhPicJob* jobs, int n) override { mb_pass (k_intra_slice, sizeof (WhMbLds), 8, false, P, jobs, n); }
-  // P pictures: 8 waves per workgroup with the full register file (2 waves/SIMD), or -- WELSHIP_P_WAVES=6 / 12 -- variants
-  // compiled for 3 waves/SIMD: 6-wave workgroups (two slices share a CU) or 12-wave workgroups
+  // P pictures.  The wave count per workgroup (= per slice) trades waiting on neighbours against latency hiding:
+  //   * plenty of workgroups (>= 2 per CU): 6 waves each, two slices share a CU (12 waves / CU, little waiting);
+  //   * otherwise 12 waves per workgroup.
+  // WELSHIP_P_WAVES overrides; 8 selects the variant that also stages the next MB's search windows (it needs 19 KB of LDS
+  // per wave, so 8 waves fill a CU).
   void run_inter (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
-    static const int waves = getenv ("WELSHIP_P_WAVES") ? atoi (getenv ("WELSHIP_P_WAVES")) : 8;
-    if (waves == 6) mb_pass (k_inter_slice<384, 3>, sizeof (WhInterLds), 6, false, P, jobs, n);
-    else if (waves == 12) mb_pass (k_inter_slice<768, 3>, sizeof (WhInterLds), 12, false, P, jobs, n);
-    else mb_pass (k_inter_slice<512, 2>, sizeof (WhInterLds), 8, false, P, jobs, n);
+    static const int forced = getenv ("WELSHIP_P_WAVES") ? atoi (getenv ("WELSHIP_P_WAVES")) : 0;
+    const int waves = forced ? forced : (P.num_slices * n >= 2 * cus_ ? 6 : 12);
+    if (waves == 8) mb_pass (k_inter_slice<512, true>, sizeof (WhInterLds), 8, false, P, jobs, n, 8 * (sizeof (WhInterStage) + sizeof (WhWinStage)) + sizeof (WhPicJob));
+    else if (waves <= 6) mb_pass (k_inter_slice<384, false>, sizeof (WhInterLds), 6, false, P, jobs, n, 6 * sizeof (WhInterStage) + sizeof (WhPicJob));
+    else mb_pass (k_inter_slice<768, false>, sizeof (WhInterLds), 12, false, P, jobs, n, 12 * sizeof (WhInterStage) + sizeof (WhPicJob));
   }
   void run_deblock (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
     static const bool whole = getenv ("WELSHIP_DEBLOCK_WHOLE_PICTURE") != nullptr;     // the single-workgroup variant, for comparison
@@ -313,6 +338,7 @@ class HipBackend : public wh::Backend {
   hipStream_t stream() const { return stream_; }
  private:
   int dev_;
+  int cus_;
   hipStream_t stream_ = nullptr;          // the selected queue
   std::vector<hipStream_t> streams_;
   uint32_t* err_ = nullptr;

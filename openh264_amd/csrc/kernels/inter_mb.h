@@ -42,10 +42,10 @@
 #define WH_SLOT_16x8 5            // 5,6
 #define WH_SLOT_8x16 7            // 7,8
 
-typedef struct WhInterLds {
+typedef struct alignas (16) WhInterLds {
   WhMbLds m;
-  uint8_t win[WH_WIN_ROWS * WH_WIN_STRIDE + 16];            // reference search window (luma), see wh_win_load_luma
-  uint8_t cwin[2][WH_CWIN_ROWS * WH_CWIN_STRIDE + 16];      // chroma windows (Cb, Cr)
+  alignas (16) uint8_t win[WH_WIN_ROWS * WH_WIN_STRIDE + 16];            // reference search window (luma), see wh_win_load_luma
+  alignas (16) uint8_t cwin[2][WH_CWIN_ROWS * WH_CWIN_STRIDE + 16];      // chroma windows (Cb, Cr)
   uint8_t prev_y[256];                                      // co-located luma of the previous source picture (VAA SADs)
   uint8_t skip_y[256];                                      // P_Skip prediction
   uint8_t skip_c[128];
@@ -53,8 +53,20 @@ typedef struct WhInterLds {
   int16_t co_mv[2][2];                                      // sP16x16Mv of the reference picture's MBs to the right / below
   int16_t mvp_out[16][2];                                   // predictor used for the mvd of each 4x4 (raster)
   int16_t mv_out[16][2];
-  uint32_t cold_y[64], cold_c[32], cold_pv[64], cold_co[40]; // staging of the next MB's cold inputs (wh_inter_cold_fetch)
 } WhInterLds;
+
+// Staging area of a wave for its NEXT macroblock, filled by LDS-DMA while the current MB is processed.  It is a separate
+// LDS object (a different __shared__ variable on the GPU) on purpose: the compiler then knows that the tile's LDS reads
+// cannot alias an in-flight DMA and does not wait for it.
+typedef struct alignas (16) WhInterStage {
+  uint32_t cold_y[64], cold_c[32], cold_pv[64], cold_co[40];            // cold inputs (wh_inter_cold_fetch)
+} WhInterStage;
+// optional second staging area: the next MB's search windows (costs 6 KB of LDS per wave; used when the workgroup
+// geometry leaves room for it)
+typedef struct alignas (16) WhWinStage {
+  alignas (16) uint8_t pf_win[WH_WIN_ROWS * WH_WIN_STRIDE + 16];         // search windows (wh_win_prefetch)
+  alignas (16) uint8_t pf_cwin[2][WH_CWIN_ROWS * WH_CWIN_STRIDE + 16];
+} WhWinStage;
 
 typedef struct WhWin { int x0, y0, cx0, cy0; } WhWin;       // picture coordinates of element (0,0) of win / cwin
 
@@ -127,52 +139,45 @@ WH_FN int wh_mc_chroma_w (int a, int b, int c, int d, int dx, int dy) {
 }
 
 // ---- reference windows ----------------------------------------------------------------------------
-// Loads are clamped to the border-expanded picture (32 luma / 16 chroma pixels each side); window cells beyond that
-// can only be touched by motion vectors outside the legal range, i.e. never.
-#define WH_WIN_LOADS (WH_WIN_ROWS / 4)      // words per lane: 4 rows of 16 words per load instruction
-WH_FN void wh_win_fetch_luma (int lane, const WhSeqParams& P, const WhPicJob& J, int x0, int y0, uint32_t* v /*[WH_WIN_LOADS]*/) {
-  const int wd = lane & 15, r0 = lane >> 4;
-  const int x = wh_clip3 (x0 + wd * 4, -32, P.mb_w * 16 + 28);
-  const WH_G uint8_t* ref = (const WH_G uint8_t*)J.ref[0];
-#pragma unroll
-  for (int k = 0; k < WH_WIN_LOADS; ++k) {
-    const int y = wh_clip3 (y0 + r0 + 4 * k, -32, P.mb_h * 16 + 31);
-    v[k] = * (const WH_G uint32_t*) (ref + (ptrdiff_t)y * P.rec_stride_y + x);
-  }
+// A window is a WH_WIN_STRIDE x WH_WIN_ROWS block of the border-expanded reference luma (plus 32 x 32 of each chroma
+// plane) at a 4-pixel aligned origin.  Origins are clamped so that the whole window lies inside the expanded picture
+// (32 luma / 16 chroma pixels each side): loads need no per-lane clamping and move 16 bytes per lane.
+#define WH_WIN_LOADS ((WH_WIN_ROWS + 15) / 16)     // 16-byte loads per lane: 16 rows of 4 x 16 bytes per instruction
+WH_FN void wh_win_place (const WhSeqParams& P, WhWin& W, int cx, int cy) {      // (cx,cy): luma position the 16x16 block is centred on
+  W.x0 = wh_clip3 ((cx - 24) & ~3, -32, P.mb_w * 16 + 32 - WH_WIN_STRIDE);
+  W.y0 = wh_clip3 (cy - (WH_WIN_ROWS - 16) / 2, -32, P.mb_h * 16 + 32 - WH_WIN_ROWS);
+  W.cx0 = wh_clip3 (((cx >> 1) - 12) & ~3, -16, P.mb_w * 8 + 16 - WH_CWIN_STRIDE);
+  W.cy0 = wh_clip3 ((cy >> 1) - 12, -16, P.mb_h * 8 + 16 - WH_CWIN_ROWS);
 }
-WH_FN void wh_win_commit_luma (WhInterLds& S, int lane, const uint32_t* v) {
-  const int wd = lane & 15, r0 = lane >> 4;
-#pragma unroll
-  for (int k = 0; k < WH_WIN_LOADS; ++k) * (uint32_t*)&S.win[(r0 + 4 * k) * WH_WIN_STRIDE + wd * 4] = v[k];
+WH_FN const WH_G uint8_t* wh_win_src_luma (int lane, int k, const WhSeqParams& P, const WhPicJob& J, const WhWin& W) {
+  return (const WH_G uint8_t*)J.ref[0] + (ptrdiff_t) (W.y0 + 16 * k + (lane >> 2)) * P.rec_stride_y + W.x0 + (lane & 3) * 16;
 }
-WH_FN void wh_win_load_luma (WhInterLds& S, const WhSeqParams& P, const WhPicJob& J, WhWin& W, int x0, int y0) {
-  W.x0 = x0; W.y0 = y0;
+WH_FN const WH_G uint8_t* wh_win_src_chroma (int lane, int pl, const WhSeqParams& P, const WhPicJob& J, const WhWin& W) {
+  return (const WH_G uint8_t*)J.ref[1 + pl] + (ptrdiff_t) (W.cy0 + (lane >> 1)) * P.rec_stride_c + W.cx0 + (lane & 1) * 16;
+}
+WH_FN bool wh_win_row_ok (int lane, int k) { return 16 * k + (lane >> 2) < WH_WIN_ROWS; }
+WH_FN void wh_win_load_luma (WhInterLds& S, const WhSeqParams& P, const WhPicJob& J, WhWin& W) {
   WV_LANES_BEGIN (lane)
-  uint32_t v[WH_WIN_LOADS];
-  wh_win_fetch_luma (lane, P, J, x0, y0, v);
-  wh_win_commit_luma (S, lane, v);
+  WhU4 v[WH_WIN_LOADS];
+#pragma unroll
+  for (int k = 0; k < WH_WIN_LOADS; ++k) if (wh_win_row_ok (lane, k)) memcpy (&v[k], (const void*)wh_win_src_luma (lane, k, P, J, W), 16);
+#pragma unroll
+  for (int k = 0; k < WH_WIN_LOADS; ++k) if (wh_win_row_ok (lane, k)) * (WhU4*)&S.win[(16 * k) * WH_WIN_STRIDE + lane * 16] = v[k];
   WV_LANES_END
 }
-// first load of a macroblock: luma + both chroma windows in one batch.  (cx,cy) = luma picture position of the
-// 16x16 block displaced by the integer search centre.
+// first load of a macroblock: luma + both chroma windows in one batch
 WH_FN void wh_win_load_all (WhInterLds& S, const WhSeqParams& P, const WhPicJob& J, WhWin& W, int cx, int cy) {
-  W.x0 = (cx - 24) & ~3; W.y0 = cy - (WH_WIN_ROWS - 16) / 2;
-  W.cx0 = ((cx >> 1) - 12) & ~3; W.cy0 = (cy >> 1) - 12;
+  wh_win_place (P, W, cx, cy);
   WV_LANES_BEGIN (lane)
-  uint32_t v[WH_WIN_LOADS], c[8];
-  wh_win_fetch_luma (lane, P, J, W.x0, W.y0, v);
+  WhU4 v[WH_WIN_LOADS], c[2];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int i = lane + 64 * k, pl = i >> 8, row = (i >> 3) & 31, wd = i & 7;
-    const int x = wh_clip3 (W.cx0 + wd * 4, -16, P.mb_w * 8 + 12), y = wh_clip3 (W.cy0 + row, -16, P.mb_h * 8 + 15);
-    c[k] = * (const WH_G uint32_t*) ((const WH_G uint8_t*)J.ref[1 + pl] + (ptrdiff_t)y * P.rec_stride_c + x);
-  }
-  wh_win_commit_luma (S, lane, v);
+  for (int k = 0; k < WH_WIN_LOADS; ++k) if (wh_win_row_ok (lane, k)) memcpy (&v[k], (const void*)wh_win_src_luma (lane, k, P, J, W), 16);
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int i = lane + 64 * k, pl = i >> 8, row = (i >> 3) & 31, wd = i & 7;
-    * (uint32_t*)&S.cwin[pl][row * WH_CWIN_STRIDE + wd * 4] = c[k];
-  }
+  for (int pl = 0; pl < 2; ++pl) memcpy (&c[pl], (const void*)wh_win_src_chroma (lane, pl, P, J, W), 16);
+#pragma unroll
+  for (int k = 0; k < WH_WIN_LOADS; ++k) if (wh_win_row_ok (lane, k)) * (WhU4*)&S.win[(16 * k) * WH_WIN_STRIDE + lane * 16] = v[k];
+#pragma unroll
+  for (int pl = 0; pl < 2; ++pl) * (WhU4*)&S.cwin[pl][lane * 16] = c[pl];
   WV_LANES_END
 }
 WH_FN bool wh_win_covers (const WhWin& W, int x0, int y0, int x1, int y1) {
@@ -181,7 +186,37 @@ WH_FN bool wh_win_covers (const WhWin& W, int x0, int y0, int x1, int y1) {
 // make sure luma [x0,x1) x [y0,y1) is inside the window (extent <= 57 x WH_WIN_ROWS - 1)
 WH_FN void wh_win_ensure (WhInterLds& S, const WhSeqParams& P, const WhPicJob& J, WhWin& W, int x0, int y0, int x1, int y1) {
   if (wh_win_covers (W, x0, y0, x1, y1)) return;
-  wh_win_load_luma (S, P, J, W, (((x0 + x1) >> 1) - 32) & ~3, ((y0 + y1) >> 1) - WH_WIN_ROWS / 2);
+  W.x0 = wh_clip3 ((((x0 + x1) >> 1) - 32) & ~3, -32, P.mb_w * 16 + 32 - WH_WIN_STRIDE);
+  W.y0 = wh_clip3 (((y0 + y1) >> 1) - WH_WIN_ROWS / 2, -32, P.mb_h * 16 + 32 - WH_WIN_ROWS);
+  wh_win_load_luma (S, P, J, W);
+}
+
+// Speculative fetch of the NEXT macroblock's windows (LDS-DMA into the staging buffers) around the position the 16x16
+// block would have with this MB's integer predictor; adopted by the next MB when it covers what that MB needs first.
+typedef struct WhWinPf { int valid; WhWin w; } WhWinPf;
+WH_FN void wh_win_prefetch (WhWinStage& G, const WhSeqParams& P, const WhPicJob& J, WhWinPf& F, int cx, int cy) {
+  F.valid = 1;
+  wh_win_place (P, F.w, cx, cy);
+  WV_LANES_BEGIN (lane)
+  {
+#pragma unroll
+    for (int k = 0; k < WH_WIN_LOADS; ++k) if (wh_win_row_ok (lane, k)) wh_ld_async16 (wh_win_src_luma (lane, k, P, J, F.w), &G.pf_win[(16 * k) * WH_WIN_STRIDE], lane);
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) wh_ld_async16 (wh_win_src_chroma (lane, pl, P, J, F.w), G.pf_cwin[pl], lane);
+  }
+  WV_LANES_END
+}
+// move the staged windows into place (LDS to LDS)
+WH_FN void wh_win_adopt (WhInterLds& S, const WhWinStage& G, WhWin& W, const WhWinPf& F) {
+  W = F.w;
+  WV_LANES_BEGIN (lane)
+  {
+#pragma unroll
+    for (int k = 0; k < WH_WIN_LOADS; ++k) if (wh_win_row_ok (lane, k)) * (WhU4*)&S.win[(16 * k) * WH_WIN_STRIDE + lane * 16] = * (const WhU4*)&G.pf_win[(16 * k) * WH_WIN_STRIDE + lane * 16];
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) * (WhU4*)&S.cwin[pl][lane * 16] = * (const WhU4*)&G.pf_cwin[pl][lane * 16];
+  }
+  WV_LANES_END
 }
 
 // ---- lane geometry -----------------------------------------------------------------------------------
@@ -523,12 +558,13 @@ WH_FN void wh_refine_frac (WhInterLds& S, const WhSeqParams& P, const WhPicJob& 
   const int dmx = me.mvx - me.mvpx, dmy = me.mvy - me.mvpy;
   // integer position + the four half-sample candidates (independent of each other: the SATDs overlap)
   int c_int, c0, c1, c2, c3;
+  WV_DECLARE_LANE (lane);                   // one lane id for all candidates: they share most of their window loads
   if (satd_in_md) c_int = me.satd_raw;                                      // uiSatd of the integer search
-  else WV_SATD_ROWS (c_int, lane, WH_RF_ACT, WH_RF_ENC, wh_ld4u (S.win, WH_RF_O));
-  WV_SATD_ROWS (c0, lane, WH_RF_ACT, WH_RF_ENC, wh_rf_half (S.win, WH_RF_O, 0));
-  WV_SATD_ROWS (c1, lane, WH_RF_ACT, WH_RF_ENC, wh_rf_half (S.win, WH_RF_O, 1));
-  WV_SATD_ROWS (c2, lane, WH_RF_ACT, WH_RF_ENC, wh_rf_half (S.win, WH_RF_O, 2));
-  WV_SATD_ROWS (c3, lane, WH_RF_ACT, WH_RF_ENC, wh_rf_half (S.win, WH_RF_O, 3));
+  else WV_SATD_ROWS_SHARED (c_int, lane, WH_RF_ACT, WH_RF_ENC, wh_ld4u (S.win, WH_RF_O));
+  WV_SATD_ROWS_SHARED (c0, lane, WH_RF_ACT, WH_RF_ENC, wh_rf_half (S.win, WH_RF_O, 0));
+  WV_SATD_ROWS_SHARED (c1, lane, WH_RF_ACT, WH_RF_ENC, wh_rf_half (S.win, WH_RF_O, 1));
+  WV_SATD_ROWS_SHARED (c2, lane, WH_RF_ACT, WH_RF_ENC, wh_rf_half (S.win, WH_RF_O, 2));
+  WV_SATD_ROWS_SHARED (c3, lane, WH_RF_ACT, WH_RF_ENC, wh_rf_half (S.win, WH_RF_O, 3));
   int best = c_int + wh_mvd_cost (C.lambda, dmx, dmy), hb = -1;
   c0 += wh_mvd_cost (C.lambda, dmx, dmy - 2); if (c0 < best) { best = c0; hb = 0; }
   c1 += wh_mvd_cost (C.lambda, dmx, dmy + 2); if (c1 < best) { best = c1; hb = 1; }
@@ -536,10 +572,10 @@ WH_FN void wh_refine_frac (WhInterLds& S, const WhSeqParams& P, const WhPicJob& 
   c3 += wh_mvd_cost (C.lambda, dmx + 2, dmy); if (c3 < best) { best = c3; hb = 3; }
   const int hx = hb == 2 ? -2 : hb == 3 ? 2 : 0, hy = hb == 0 ? -2 : hb == 1 ? 2 : 0;    // winner of the half stage, relative
   // quarter-sample candidates around it
-  WV_SATD_ROWS (c0, lane, WH_RF_ACT, WH_RF_ENC, wh_rf_quarter (S.win, WH_RF_O, hb, 0));
-  WV_SATD_ROWS (c1, lane, WH_RF_ACT, WH_RF_ENC, wh_rf_quarter (S.win, WH_RF_O, hb, 1));
-  WV_SATD_ROWS (c2, lane, WH_RF_ACT, WH_RF_ENC, wh_rf_quarter (S.win, WH_RF_O, hb, 2));
-  WV_SATD_ROWS (c3, lane, WH_RF_ACT, WH_RF_ENC, wh_rf_quarter (S.win, WH_RF_O, hb, 3));
+  WV_SATD_ROWS_SHARED (c0, lane, WH_RF_ACT, WH_RF_ENC, wh_rf_quarter (S.win, WH_RF_O, hb, 0));
+  WV_SATD_ROWS_SHARED (c1, lane, WH_RF_ACT, WH_RF_ENC, wh_rf_quarter (S.win, WH_RF_O, hb, 1));
+  WV_SATD_ROWS_SHARED (c2, lane, WH_RF_ACT, WH_RF_ENC, wh_rf_quarter (S.win, WH_RF_O, hb, 2));
+  WV_SATD_ROWS_SHARED (c3, lane, WH_RF_ACT, WH_RF_ENC, wh_rf_quarter (S.win, WH_RF_O, hb, 3));
   int qb = -1;
   c0 += wh_mvd_cost (C.lambda, dmx + hx, dmy + hy - 1); if (c0 < best) { best = c0; qb = 0; }
   c1 += wh_mvd_cost (C.lambda, dmx + hx, dmy + hy + 1); if (c1 < best) { best = c1; qb = 1; }
@@ -622,21 +658,21 @@ WH_FN bool wh_try_puv_skip (WhMbLds& S, int pl, int qpc) {
 // previous source picture, the reference picture's MB states).  They come straight from HBM, so a wave starts their
 // copy into the LDS staging words S.cold_* for its NEXT macroblock while it is still busy with the current one
 // (LDS-DMA: no registers held), and moves them into place when that MB starts.
-WH_FN void wh_inter_cold_fetch (WhInterLds& S, int lane, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby) {
+WH_FN void wh_inter_cold_fetch (WhInterStage& G, int lane, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby) {
   const int w = P.mb_w, xy = mby * w + mbx;
-  wh_ld_async4 ((const WH_G uint8_t*)J.src[0] + (size_t) (mby * 16 + (lane >> 2)) * P.src_stride_y + mbx * 16 + (lane & 3) * 4, S.cold_y, lane);
+  wh_ld_async4 ((const WH_G uint8_t*)J.src[0] + (size_t) (mby * 16 + (lane >> 2)) * P.src_stride_y + mbx * 16 + (lane & 3) * 4, G.cold_y, lane);
   if (lane < 32) {
     const int pl = lane >> 4, row = (lane >> 1) & 7, half = lane & 1;
-    wh_ld_async4 ((const WH_G uint8_t*)J.src[1 + pl] + (size_t) (mby * 8 + row) * P.src_stride_c + mbx * 8 + half * 4, S.cold_c, lane);
+    wh_ld_async4 ((const WH_G uint8_t*)J.src[1 + pl] + (size_t) (mby * 8 + row) * P.src_stride_c + mbx * 8 + half * 4, G.cold_c, lane);
   }
   if (P.complexity == 0)     // VAA 8x8 SADs (LOW complexity only)
-    wh_ld_async4 ((const WH_G uint8_t*)J.prev_src_y + (size_t) (mby * 16 + (lane >> 2)) * P.src_stride_y + mbx * 16 + (lane & 3) * 4, S.cold_pv, lane);
+    wh_ld_async4 ((const WH_G uint8_t*)J.prev_src_y + (size_t) (mby * 16 + (lane >> 2)) * P.src_stride_y + mbx * 16 + (lane & 3) * 4, G.cold_pv, lane);
   if (J.ref_is_p) {
-    if (lane < 36) wh_ld_async4 ((const WH_G uint32_t*) ((const WH_G WhMbState*)J.ref_mbs + xy) + lane, S.cold_co, lane);
+    if (lane < 36) wh_ld_async4 ((const WH_G uint32_t*) ((const WH_G WhMbState*)J.ref_mbs + xy) + lane, G.cold_co, lane);
     else if (lane < 38) {
       const bool ok = lane == 36 ? mbx < P.mb_w - 1 : mby < P.mb_h - 1;
       const WH_G WhMbState* o = (const WH_G WhMbState*)J.ref_mbs + xy + (lane == 36 ? 1 : w);
-      if (ok) wh_ld_async4 (&o->p16mv[0], S.cold_co, lane);
+      if (ok) wh_ld_async4 (&o->p16mv[0], G.cold_co, lane);
     }
   }
 }
@@ -644,10 +680,12 @@ WH_FN void wh_inter_cold_fetch (WhInterLds& S, int lane, const WhSeqParams& P, c
 typedef struct WhInterCtx {
   int slice_idc, slice_first;        // slice of this MB and its first MB address
   int next_valid, next_mbx, next_mby;   // the MB this wave processes next (its cold inputs are fetched during this one)
+  WhWinPf* pf;                          // in: windows staged for this MB (or not); out: what was staged for the next one
+  WhWinStage* win_stage;                // where windows are staged, or NULL: no window prefetch
 } WhInterCtx;
 
 // ---- the P macroblock -----------------------------------------------------------------------------
-WH_FN void wh_inter_mb_body (WhInterLds& S, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, const WhInterCtx& X) {
+WH_FN void wh_inter_mb_body (WhInterLds& S, WhInterStage& G, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, const WhInterCtx& X) {
   WH_PROF_DECL (P);
   WhMbLds& M = S.m;
   const int w = P.mb_w, xy = mby * w + mbx;
@@ -677,11 +715,11 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, const WhSeqParams& P, const WhPicJob
         if (ok) st[k] = ((const WH_G uint32_t*) ((const WH_G WhMbState*)J.mbs + xy + off))[wd];
       }
     }
-    tr.y = S.cold_y[lane]; tr.c = lane < 32 ? S.cold_c[lane] : 0u;
+    tr.y = G.cold_y[lane]; tr.c = lane < 32 ? G.cold_c[lane] : 0u;
     wh_tile_commit (M, lane, &tr);
-    * (uint32_t*)&S.prev_y[lane * 4] = S.cold_pv[lane];
-    if (lane < 36) S.nb[144 + lane] = ref_is_p ? S.cold_co[lane] : 0u;      // no co-located state after an IDR: reads as zeros
-    else if (lane < 38) * (uint32_t*)&S.co_mv[lane - 36][0] = S.cold_co[lane];
+    * (uint32_t*)&S.prev_y[lane * 4] = G.cold_pv[lane];
+    if (lane < 36) S.nb[144 + lane] = ref_is_p ? G.cold_co[lane] : 0u;      // no co-located state after an IDR: reads as zeros
+    else if (lane < 38) * (uint32_t*)&S.co_mv[lane - 36][0] = G.cold_co[lane];
 #pragma unroll
     for (int k = 0; k < 3; ++k) { const int i = lane + 64 * k; if (i < 144) S.nb[i] = st[k]; }
   }
@@ -739,13 +777,23 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, const WhSeqParams& P, const WhPicJob
   me16.bx = 0; me16.by = 0; me16.bw = 16; me16.bh = 16;
   wh_pred_mv (K, 0, 0, 4, 0, &me16.mvpx, &me16.mvpy);
   WhWin W;
-  wh_win_load_all (S, P, J, W, mbx * 16 + wh_clip3 ((2 + me16.mvpx) >> 2, C.minx, C.maxx), mby * 16 + wh_clip3 ((2 + me16.mvpy) >> 2, C.miny, C.maxy));
-
-  // ---- cold inputs of this wave's next MB: in flight while the rest of this MB runs ----
-  if (X.next_valid) {
-    WV_LANES_BEGIN (lane)
-    wh_inter_cold_fetch (S, lane, P, J, X.next_mbx, X.next_mby);
-    WV_LANES_END
+  {
+    const int icx = wh_clip3 ((2 + me16.mvpx) >> 2, C.minx, C.maxx), icy = wh_clip3 ((2 + me16.mvpy) >> 2, C.miny, C.maxy);
+    const int cx = mbx * 16 + icx, cy = mby * 16 + icy;
+    if (X.pf->valid && wh_win_covers (X.pf->w, cx - WH_WIN_MARGIN, cy - WH_WIN_MARGIN, cx + 16 + WH_WIN_MARGIN, cy + 16 + WH_WIN_MARGIN))
+    { wh_win_adopt (S, *X.win_stage, W, *X.pf);            // staged during the previous MB
+      WH_PROF_MARK (P, M, 15); }
+    else
+      wh_win_load_all (S, P, J, W, cx, cy);
+    // ---- the next MB of this wave: cold inputs + windows (around where this MB's predictor points), in flight while
+    //      the rest of this MB runs ----
+    X.pf->valid = 0;
+    if (X.next_valid) {
+      WV_LANES_BEGIN (lane)
+      wh_inter_cold_fetch (G, lane, P, J, X.next_mbx, X.next_mby);
+      WV_LANES_END
+      if (X.win_stage) wh_win_prefetch (*X.win_stage, P, J, *X.pf, X.next_mbx * 16 + icx, X.next_mby * 16 + icy);
+    }
   }
   WH_PROF_MARK (P, M, 0);   // mvp + batch 2 (window) loads
   int mb_type = WH_MB_P16x16, cbp = 0, cost_luma = 0, cost_skip_mb = 0, sad_cost0 = 0;

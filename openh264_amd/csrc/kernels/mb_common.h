@@ -44,10 +44,15 @@ typedef struct WhMbLds {
 #define WH_RC(S, p, x, y) ((S).rec_c[p][((y) + 1) * 16 + (x) + 4])
 
 // position class (0/1/2) helpers for quant tables
-WH_FN int wh_mf (int qp, int pos) { return kWhQuantMF[qp * 3 + WH_POSCLASS (pos)]; }
-WH_FN int wh_ff_intra (int qp, int pos) { return kWhQuantFF[(qp + 6) * 3 + WH_POSCLASS (pos)]; }
-WH_FN int wh_ff_inter (int qp, int pos) { return kWhQuantFF[qp * 3 + WH_POSCLASS (pos)]; }
-WH_FN int wh_dq (int qp, int pos) { return kWhDequant[qp * 3 + WH_POSCLASS (pos)]; }
+// The table row is wave-uniform (QP) and only the position class varies per lane: three uniform loads (scalar cache,
+// lgkmcnt) + selects instead of a per-lane gather from global memory (vmcnt, which would also serialise behind any
+// LDS-DMA prefetch in flight).
+WH_FN int wh_sel3 (int a, int b, int d, int pos) { const int c = WH_POSCLASS (pos); return c == 0 ? a : c == 1 ? b : d; }
+WH_FN int wh_mf (int qp, int pos) { return wh_sel3 (kWhQuantMF[qp * 3], kWhQuantMF[qp * 3 + 1], kWhQuantMF[qp * 3 + 2], pos); }
+WH_FN int wh_ff_row (int ffrow, int pos) { return wh_sel3 (kWhQuantFF[ffrow * 3], kWhQuantFF[ffrow * 3 + 1], kWhQuantFF[ffrow * 3 + 2], pos); }
+WH_FN int wh_ff_intra (int qp, int pos) { return wh_ff_row (qp + 6, pos); }
+WH_FN int wh_ff_inter (int qp, int pos) { return wh_ff_row (qp, pos); }
+WH_FN int wh_dq (int qp, int pos) { return wh_sel3 (kWhDequant[qp * 3], kWhDequant[qp * 3 + 1], kWhDequant[qp * 3 + 2], pos); }
 
 // ---- forward DCT of N 4x4 blocks: res[blk*16 + r*4 + c] = T(enc - pred) -------------------------
 // `nblk` blocks; block b covers enc rows/cols given by (ex[b],ey[b]) through the callbacks below.
@@ -425,7 +430,7 @@ WH_FN void wh_quant_blocks (WhMbLds& S, int base, int nblk, int qp, int ffrow, i
     for (int k = 0; k < 4; ++k) {
       const int i = lane * 4 + k, pos = i & 15;
       int16_t a;
-      dst[i] = wh_quant1_abs (S.res[base + i], kWhQuantFF[ffrow * 3 + WH_POSCLASS (pos)], wh_mf (qp, pos), &a);
+      dst[i] = wh_quant1_abs (S.res[base + i], wh_ff_row (ffrow, pos), wh_mf (qp, pos), &a);
       if (mx < a) mx = a;
     }
     S.tmp[512 + lane] = mx;

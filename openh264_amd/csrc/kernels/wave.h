@@ -51,6 +51,10 @@
            _s += abs (_u0 + _u1) + abs (_u2 + _u3) + abs (_u2 - _u3) + abs (_u0 - _u1); } \
          _t += (_s + 1) >> 1; }                                    \
        (dst) = _t; } while (0)
+// Variants for several reductions in a row whose per-lane operands overlap: WV_DECLARE_LANE names ONE lane id for all of
+// them so that the compiler can share the common loads (each plain macro re-materialises its own opaque lane id).
+#define WV_DECLARE_LANE(lane) ((void)0)
+#define WV_SATD_ROWS_SHARED(dst, lane, active, enc4, pred4) WV_SATD_ROWS (dst, lane, active, enc4, pred4)
 // pointers into device global memory (explicit address space on the GPU so that loads are global_*, not flat_*)
 #define WH_G
 #include <string.h>
@@ -64,6 +68,8 @@ typedef struct WvLaneArr { int v[64]; } WvLaneArr;
 // asynchronous copy of one 4-byte word per lane from global memory to LDS word `lane` of `lds_base` (GPU: LDS-DMA,
 // no register holds the data; complete after WV_ASYNC_WAIT)
 WH_FN void wh_ld_async4 (const void* src, uint32_t* lds_base, int lane) { memcpy (&lds_base[lane], src, 4); }
+// same with 16 bytes per lane (lds_base 16-byte aligned, lane i fills bytes [16 i, 16 i + 16))
+WH_FN void wh_ld_async16 (const void* src, void* lds_base, int lane) { memcpy ((uint8_t*)lds_base + 16 * lane, src, 16); }
 #define WV_ASYNC_WAIT() ((void)0)
 // four bytes at any byte offset of a 4-byte aligned LDS array
 WH_FN uint32_t wh_ld4u (const uint8_t* base, int off) { uint32_t v; memcpy (&v, base + off, 4); return v; }
@@ -86,7 +92,10 @@ WH_FN uint32_t wh_avg4 (uint32_t a, uint32_t b) {
 #define WH_FN static __device__ __forceinline__
 #define WH_HDFN static __host__ __device__ __forceinline__
 #define WH_CONST static __device__ const
-#define WV_LANES_BEGIN(lane) { const int lane = (int)(threadIdx.x & 63);
+// The lane id is re-materialised as an opaque value in every lane block: otherwise the compiler hoists all per-lane
+// address arithmetic out of the per-macroblock loop, keeps it live across the whole body and spills it to scratch.
+WH_FN int wh_lane_id() { int l = (int)(threadIdx.x & 63); asm volatile ("" : "+v"(l)); return l; }
+#define WV_LANES_BEGIN(lane) { const int lane = wh_lane_id();
 // A workgroup is ONE wavefront and a wavefront's LDS instructions execute in issue order, so the hand-off between
 // lane blocks needs no s_waitcnt / s_barrier: only the compiler must not move LDS accesses across it.
 #define WV_SYNC() do { __builtin_amdgcn_fence (__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
@@ -114,7 +123,7 @@ WH_FN int wh_wave_min_i32 (int v) {
   return ab < cd ? ab : cd;
 }
 #define WV_SUM(dst, lane, expr)                                   \
-  do { const int lane = (int)(threadIdx.x & 63); int _v = (int)(expr); (dst) = wh_wave_sum_i32 (_v); } while (0)
+  do { const int lane = wh_lane_id(); int _v = (int)(expr); (dst) = wh_wave_sum_i32 (_v); } while (0)
 #define WV_ARGMIN(dst_key, dst_lane, lane, valid, key)            \
   do { const int lane = (int)(threadIdx.x & 63);                  \
        const bool _ok = (valid);                                  \
@@ -125,7 +134,7 @@ WH_FN int wh_wave_min_i32 (int v) {
 #define WV_ANY(dst, lane, expr)                                   \
   do { const int lane = (int)(threadIdx.x & 63); (dst) = __ballot ((expr)) != 0ULL; } while (0)
 #define WV_SUM2(dst_a, dst_b, lane, expr_a, expr_b)               \
-  do { const int lane = (int)(threadIdx.x & 63); int _va = (int)(expr_a), _vb = (int)(expr_b); \
+  do { const int lane = wh_lane_id(); int _va = (int)(expr_a), _vb = (int)(expr_b); \
        _va += WH_DPP (_va, 0xB1); _vb += WH_DPP (_vb, 0xB1); _va += WH_DPP (_va, 0x4E); _vb += WH_DPP (_vb, 0x4E); \
        _va += WH_DPP (_va, 0x141); _vb += WH_DPP (_vb, 0x141); _va += WH_DPP (_va, 0x140); _vb += WH_DPP (_vb, 0x140); \
        (dst_a) = __builtin_amdgcn_readlane (_va, 0) + __builtin_amdgcn_readlane (_va, 16) + __builtin_amdgcn_readlane (_va, 32) + __builtin_amdgcn_readlane (_va, 48); \
@@ -149,11 +158,13 @@ WH_FN int wh_satd_rows (int lane, bool active, uint32_t e, uint32_t p) {
   return wh_wave_sum_i32 (s);
 }
 #define WV_SATD_ROWS(dst, lane, active, enc4, pred4)              \
-  do { const int lane = (int)(threadIdx.x & 63); (dst) = wh_satd_rows (lane, (active), (enc4), (pred4)); } while (0)
+  do { const int lane = wh_lane_id(); (dst) = wh_satd_rows (lane, (active), (enc4), (pred4)); } while (0)
+#define WV_DECLARE_LANE(lane) const int lane = wh_lane_id()
+#define WV_SATD_ROWS_SHARED(dst, lane, active, enc4, pred4) do { (dst) = wh_satd_rows (lane, (active), (enc4), (pred4)); } while (0)
 typedef int WvLaneArr;
 #define WV_LGET(a, i) __builtin_amdgcn_readlane ((a), (i))
 #define WV_LSET(a, i, val) do { if ((int)(threadIdx.x & 63) == (i)) (a) = (val); } while (0)
-#define WV_LSET_IF(a, lane, cond, val) do { const int lane = (int)(threadIdx.x & 63); if (cond) (a) = (val); } while (0)
+#define WV_LSET_IF(a, lane, cond, val) do { const int lane = wh_lane_id(); if (cond) (a) = (val); } while (0)
 #define WH_G __attribute__ ((address_space (1)))
 WH_FN uint32_t wh_ld4u (const uint8_t* base, int off) {
   const uint32_t* w = (const uint32_t*)base + (off >> 2);
@@ -161,6 +172,9 @@ WH_FN uint32_t wh_ld4u (const uint8_t* base, int off) {
 }
 WH_FN void wh_ld_async4 (const WH_G void* src, uint32_t* lds_base, int /*lane*/) {
   __builtin_amdgcn_global_load_lds ((const WH_G uint32_t*)src, (__attribute__ ((address_space (3))) uint32_t*)lds_base, 4, 0, 0);
+}
+WH_FN void wh_ld_async16 (const WH_G void* src, void* lds_base, int /*lane*/) {
+  __builtin_amdgcn_global_load_lds ((const WH_G uint32_t*)src, (__attribute__ ((address_space (3))) uint32_t*)lds_base, 16, 0, 0);
 }
 #define WV_ASYNC_WAIT() asm volatile ("s_waitcnt vmcnt(0)" ::: "memory")
 WH_FN int wh_sad4 (uint32_t a, uint32_t b) { return (int)__builtin_amdgcn_sad_u8 (a, b, 0u); }
@@ -180,12 +194,22 @@ WH_FN uint32_t wh_avg4 (uint32_t a, uint32_t b) { return __builtin_amdgcn_lerp (
   if ((threadIdx.x & 63) == 0) { (L).prof[id] += (uint32_t) (_t - _wh_t0); (L).prof[16 + (id)] += 1u; } _wh_t0 = _t; } } while (0)
 #endif
 
+// 16 bytes moved as one unit (global_load_dwordx4 / ds_read_b128)
+typedef struct alignas (16) WhU4 { uint32_t x, y, z, w; } WhU4;
+
 // ---- small integer helpers (host + device) -----------------------------------------------------
 WH_FN int wh_abs (int a) { return a < 0 ? -a : a; }
 WH_FN int wh_min (int a, int b) { return a < b ? a : b; }
 WH_FN int wh_max (int a, int b) { return a > b ? a : b; }
 WH_FN int wh_clip3 (int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+#if defined(WH_EMU)
 WH_FN uint8_t wh_clip255 (int v) { return (uint8_t) (v < 0 ? 0 : (v > 255 ? 255 : v)); }
+#else
+// The clamp is an explicit v_med3_i32: hipcc (ROCm 7.2) would otherwise fuse "clip255 (x >> n)" pairs into gfx950's
+// v_ashr_pk_u8_i32 and OR further bytes into the upper half of its result as if that half were zero -- on the MI355X it
+// is not, which corrupts packed pixels (first seen in tests/test_prims_gpu.py::test_motion_compensation).
+WH_FN uint8_t wh_clip255 (int v) { int r; asm ("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(v), "v"(255)); return (uint8_t)r; }
+#endif
 WH_FN int wh_median3 (int a, int b, int c) {
   int mn = wh_min (a, wh_min (b, c)), mx = wh_max (a, wh_max (b, c));
   return a + b + c - mn - mx;

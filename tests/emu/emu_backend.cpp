@@ -40,15 +40,27 @@ class EmuBackend : public Backend {
     for_order (P, n, false, [&] (int j, int x, int y) { WhMbLds S; poison (&S, sizeof (S)); wh_intra_mb_body (S, P, jobs[j], x, y); });
   }
   void run_inter (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
-    for_order (P, n, false, [&] (int j, int x, int y) {
-      WhInterLds S;
-      poison (&S, sizeof (S));
-      for (int lane = 0; lane < 64; ++lane) wh_inter_cold_fetch (S, lane, P, jobs[j], x, y);
-      WhInterCtx X;
-      X.slice_idc = wh_slice_of_mb (P, y * P.mb_w + x); X.slice_first = P.slice_first_mb[X.slice_idc];
-      X.next_valid = 0; X.next_mbx = X.next_mby = 0;
-      wh_inter_mb_body (S, P, jobs[j], x, y, X);
-    });
+    // one emulated wavefront walks each slice in order, with the same one-MB look-ahead as the device scheduler: the
+    // next MB's cold inputs and search windows are staged in the LDS tile while the current MB is processed
+    for (int j = 0; j < n; ++j)
+      for (int s = 0; s < P.num_slices; ++s) {
+        WhInterLds S;
+        WhInterStage G;
+        WhWinStage GW;
+        poison (&S, sizeof (S)); poison (&G, sizeof (G)); poison (&GW, sizeof (GW));
+        WhWinPf pf; pf.valid = 0;
+        const int first = P.slice_first_mb[s], last = P.slice_first_mb[s + 1];
+        { const int xy = P.mb_order[first]; for (int lane = 0; lane < 64; ++lane) wh_inter_cold_fetch (G, lane, P, jobs[j], xy % P.mb_w, xy / P.mb_w); }
+        for (int t = first; t < last; ++t) {
+          const int xy = P.mb_order[t], xyn = t + 1 < last ? P.mb_order[t + 1] : 0;
+          WhInterCtx X;
+          X.slice_idc = s; X.slice_first = first;
+          X.next_valid = t + 1 < last; X.next_mbx = xyn % P.mb_w; X.next_mby = xyn / P.mb_w; X.pf = &pf;
+          X.win_stage = ((s + j) & 1) ? &GW : nullptr;      // exercise both variants (with / without window staging), one per slice
+          wh_inter_mb_body (S, G, P, jobs[j], xy % P.mb_w, xy / P.mb_w, X);
+          poison (&S, sizeof (S));            // nothing but the staging area survives from one macroblock to the next
+        }
+      }
   }
   void run_deblock (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
     for_order (P, n, true, [&] (int j, int x, int y) { WhDbLds S; poison (&S, sizeof (S)); wh_deblock_mb_body (S, P, jobs[j], x, y); });

@@ -26,3 +26,18 @@ def test_no_device_is_loud(hip_lib):
     off = (C.c_int32 * 1)(0)
     rc = lib.WelsHipPrimSampleSad(0, 1, buf, C.c_size_t(1024), 32, off, buf, C.c_size_t(1024), 32, off, out)
     assert rc == 100      # WELSHIP_ERR_NO_DEVICE
+
+
+def test_device_code_avoids_ashr_pk(tmp_path):
+    """hipcc (ROCm 7.2) mis-uses gfx950's v_ashr_pk_u8_i32 (see wh_clip255 in csrc/kernels/wave.h): the device code of the
+    macroblock kernels must not contain it."""
+    import shutil
+    import subprocess
+    if not shutil.which("hipcc"):
+        pytest.skip("hipcc not available")
+    for unit in ("hip_backend", "prims"):
+        out = tmp_path / (unit + ".s")
+        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-Wno-unused-function",
+                               "-Wno-unused-variable", "-Wno-unused-command-line-argument", "-o", str(out),
+                               os.path.join(ROOT, "openh264_amd", "csrc", "hip", unit + ".hip")])
+        assert "v_ashr_pk" not in out.read_text()

@@ -87,13 +87,13 @@ def main():
              "#pragma once\n#include <stdint.h>\n\n#ifndef WH_TABLE\n#define WH_TABLE static const\n#endif\n")
     o.append("// Position class of coefficient i (raster 4x4): 0=(even,even) 1=mixed 2=(odd,odd)\n"
              "#define WH_POSCLASS(i) ((((i) >> 2) & 1) + ((i) & 1))\n")
-    o.append("// forward quant multiplier, >>16 form, [qp][class]\nWH_TABLE int16_t kWhQuantMF[52 * 3] = {\n" + fmt(mf3, 12, 6) + "\n};")
-    o.append("// forward quant rounding offset: inter rows 0..51, intra = row qp+6 [qp][class]\nWH_TABLE int16_t kWhQuantFF[58 * 3] = {\n" + fmt(ff3, 12, 4) + "\n};")
-    o.append("// dequant scale LevelScale(qp%6)<<(qp/6) [qp][class]\nWH_TABLE uint16_t kWhDequant[52 * 3] = {\n" + fmt(dq3, 12, 5) + "\n};")
-    o.append("// QPc as a function of qPI (Table 8-15)\nWH_TABLE uint8_t kWhChromaQp[52] = {\n" + fmt(cqp, 26, 2) + "\n};")
-    o.append("// mode-decision lambda per QP\nWH_TABLE uint8_t kWhLambda[52] = {\n" + fmt(lam, 26, 2) + "\n};")
-    o.append("// deblocking alpha'/beta' (Table 8-16), tC0 for bS 1..3 (Table 8-17)\nWH_TABLE uint8_t kWhAlpha[52] = {\n" + fmt(alpha, 26, 3) + "\n};")
-    o.append("WH_TABLE uint8_t kWhBeta[52] = {\n" + fmt(beta, 26, 2) + "\n};")
+    o.append("// forward quant multiplier, >>16 form, [qp][class]\nWH_TABLE int32_t kWhQuantMF[52 * 3] = {\n" + fmt(mf3, 12, 6) + "\n};")
+    o.append("// forward quant rounding offset: inter rows 0..51, intra = row qp+6 [qp][class]\nWH_TABLE int32_t kWhQuantFF[58 * 3] = {\n" + fmt(ff3, 12, 4) + "\n};")
+    o.append("// dequant scale LevelScale(qp%6)<<(qp/6) [qp][class]\nWH_TABLE int32_t kWhDequant[52 * 3] = {\n" + fmt(dq3, 12, 5) + "\n};")
+    o.append("// QPc as a function of qPI (Table 8-15)\nWH_TABLE int32_t kWhChromaQp[52] = {\n" + fmt(cqp, 26, 2) + "\n};")
+    o.append("// mode-decision lambda per QP\nWH_TABLE int32_t kWhLambda[52] = {\n" + fmt(lam, 26, 2) + "\n};")
+    o.append("// deblocking alpha'/beta' (Table 8-16), tC0 for bS 1..3 (Table 8-17)\nWH_TABLE int32_t kWhAlpha[52] = {\n" + fmt(alpha, 26, 3) + "\n};")
+    o.append("WH_TABLE int32_t kWhBeta[52] = {\n" + fmt(beta, 26, 2) + "\n};")
     o.append("WH_TABLE uint8_t kWhTc0[52 * 3] = {\n" + fmt([v for t in tc0 for v in t], 24, 2) + "\n};")
     o.append("// me(v) codeNum for coded_block_pattern (Table 9-4), indexed by cbp\nWH_TABLE uint8_t kWhCbpCodeIntra[48] = {\n" + fmt(code_intra, 16, 2) + "\n};")
     o.append("WH_TABLE uint8_t kWhCbpCodeInter[48] = {\n" + fmt(code_inter, 16, 2) + "\n};")

@@ -18,8 +18,8 @@ print(g.bench(3, 0))
 out = (C.c_ulonglong * 32)()
 lib.WelsHipGroupProfile(g._h, 1, out)
 names = {11: "ticket+order", 12: "dependency wait", 8: "args+job+slice", 9: "batch-1 loads", 10: "nb cache+ctx", 0: "mvp+window loads", 1: "pskip test", 2: "p16x16 ME", 3: "i16 test",
-         4: "fine partitions", 5: "refine+chromaMC", 6: "residual", 7: "store", 13: "release+flag", 14: "(body total)"}
-tot = sum(out[i] for i in range(16) if i != 14)
+         4: "fine partitions", 5: "refine+chromaMC", 6: "residual", 7: "store", 13: "release+flag", 14: "(body total)", 15: "window adopted"}
+tot = sum(out[i] for i in range(16) if i not in (14,))
 for i, n in names.items():
     print("%-18s %6.2f%%  avg %8.0f cycles  hits %d" % (n, 100.0 * out[i] / max(tot, 1), out[i] / max(out[16 + i], 1), out[16 + i]))
 print("total cycles/MB %.0f" % (tot / max(out[16 + 7], 1)))
