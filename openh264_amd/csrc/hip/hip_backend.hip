@@ -28,7 +28,8 @@ namespace {
 // L1), so the hand-off costs a workgroup-scope release/acquire (s_waitcnt) instead of a kernel boundary.  Tickets are
 // handed out in a topological order, so the lowest outstanding ticket can always run: no deadlock; the spin is
 // bounded anyway and reports through P.prof-independent error word `err` (host checks it after the step).
-#define WH_SPIN_LIMIT (1u << 16)       // x ~200 cycles: ~5 ms of waiting for ONE macroblock means the scheduler is broken
+#define WH_SPIN_LIMIT (1u << 23)       // x ~200 cycles: close to a second.  A wait can legitimately be long when the head of the
+                                       // chain waits for another workgroup (deblocking seams) that is not resident yet
 
 // returns false when the wait timed out (err[0] counts, err[1..3] = block x, block y, awaited index of the first one)
 __device__ __forceinline__ bool wh_wait_done (const uint32_t* done, int idx, uint32_t* err) {
@@ -95,7 +96,7 @@ __global__ __launch_bounds__ (MAX_THREADS) void NAME (WhSeqParams P, const WhPic
   if (PROF && P.prof && lane < 32) atomicAdd (&P.prof[((blockIdx.x + blockIdx.y * 7u) & 63u) * 32u + lane], (unsigned long long)wh_prof_lds (S)[lane]); \
 }
 
-WH_DEFINE_MB_KERNEL (k_intra_slice, WhMbLds, wh_intra_mb_body, 512, 0, 0)
+WH_DEFINE_MB_KERNEL (k_intra_slice, WhMbLds, wh_intra_mb_body, 1024, 0, 0)
 
 // P pictures: same scheduling, plus a one-MB look-ahead: a wave takes the ticket of its NEXT macroblock before it
 // starts the current one, so that the body can fetch the next MB's cold inputs (straight from HBM) underneath its own
@@ -160,7 +161,6 @@ __global__ __launch_bounds__ (MAXT) void k_inter_slice (WhSeqParams P, const WhP
   }
   if (P.prof && lane < 32) atomicAdd (&P.prof[((blockIdx.x + blockIdx.y * 7u) & 63u) * 32u + lane], (unsigned long long)S.m.prof[lane]);
 }
-WH_DEFINE_MB_KERNEL (k_deblock_pic, WhDbLds, wh_deblock_mb_body, 1024, 1, 0)
 
 // Deblocking with one workgroup per slice.  The filter crosses slice boundaries (disable_deblocking_filter_idc 0), so
 // the MBs along a slice's upper seam wait for MBs of the previous slice -- another workgroup, in general on another
@@ -169,7 +169,7 @@ WH_DEFINE_MB_KERNEL (k_deblock_pic, WhDbLds, wh_deblock_mb_body, 1024, 1, 0)
 // (MI355X_MICROARCH.md, inter-workgroup visibility).  Only MBs that a later slice can depend on publish.  The
 // workgroups of one picture have consecutive block ids and slice s-1 never waits for slice s, so the chain cannot
 // deadlock while the earlier workgroup is scheduled; the spin is bounded regardless.
-#define WH_SEAM_SPIN_LIMIT (1u << 20)
+#define WH_SEAM_SPIN_LIMIT (1u << 22)
 __global__ __launch_bounds__ (1024) void k_deblock_slices (WhSeqParams P, const WhPicJob* jobs, uint32_t* err) {
   extern __shared__ __align__ (16) uint8_t smem[];
   const int nw = (int)blockDim.x >> 6, lane = (int)threadIdx.x & 63;
@@ -187,12 +187,19 @@ __global__ __launch_bounds__ (1024) void k_deblock_slices (WhSeqParams P, const 
   uint32_t* flags = J.db_flags;
   const uint32_t gen = J.db_gen;
   const bool cross = P.deblock_idc == 0;        // idc 2: nothing is filtered (or needed) across slices
+  __shared__ WhDbStage stage[16];                 // separate LDS object (see WhInterStage)
+  WhDbStage& G = stage[wave];
+  int t = 0;
+  if (lane == 0) t = (int)atomicAdd (&sched[0], 1u);
+  t = __builtin_amdgcn_readfirstlane (t);
+  if (t >= n) return;
+  int xy = order[t];
+  wh_deblock_cold_fetch (G, lane, P, J, xy % w, xy / w);
   for (int guard = 0; guard <= n; ++guard) {
-    int t = 0;
-    if (lane == 0) t = (int)atomicAdd (&sched[0], 1u);
-    t = __builtin_amdgcn_readfirstlane (t);
-    if (t >= n) break;
-    const int xy = order[t];
+    int tn = 0;                                 // look-ahead: this wave's next MB (its inputs are staged during this one)
+    if (lane == 0) tn = (int)atomicAdd (&sched[0], 1u);
+    tn = __builtin_amdgcn_readfirstlane (tn);
+    const int xyn = tn < n ? (int)order[tn] : 0;
     int dep_a, dep_b;                           // picture-wide dependencies: left, top-right (top at the right edge)
     wh_mb_deps (w, xy, 0, &dep_a, &dep_b);
     bool remote = false, ok = true;
@@ -212,7 +219,8 @@ __global__ __launch_bounds__ (1024) void k_deblock_slices (WhSeqParams P, const 
     if (!ok) break;
     if (remote) __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "agent");
     else __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "workgroup");
-    wh_deblock_mb_body (S, P, J, xy % w, xy / w);
+    WV_ASYNC_WAIT();                            // this MB's staged inputs have landed
+    wh_deblock_mb_body (S, G, P, J, xy % w, xy / w, tn < n, xyn % w, xyn / w);
     // MBs a later slice may wait for: its left neighbour (xy + 1), top (xy + w) or top-right consumer (xy + w - 1)
     const bool publish = cross && xy + w + 1 >= last && last < num_mb;
     if (publish) {
@@ -224,6 +232,8 @@ __global__ __launch_bounds__ (1024) void k_deblock_slices (WhSeqParams P, const 
       __builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");
     }
     if (lane == 0) atomicOr (&sched[1 + ((xy - first) >> 5)], 1u << ((xy - first) & 31));
+    if (tn >= n) break;
+    xy = xyn;
   }
 }
 
@@ -298,7 +308,7 @@ class HipBackend : public wh::Backend {
     HIP_CHECK (hipGetLastError());
     if (getenv ("WELSHIP_TRACE")) { HIP_CHECK (hipStreamSynchronize (stream_)); fprintf (stderr, "welship: launch done\n"); fflush (stderr); }
   }
-  void run_intra (const WhSeqParams& P, const WhPicJob* jobs, int n) override { mb_pass (k_intra_slice, sizeof (WhMbLds), 8, false, P, jobs, n); }
+  void run_intra (const WhSeqParams& P, const WhPicJob* jobs, int n) override { mb_pass (k_intra_slice, sizeof (WhMbLds), 16, false, P, jobs, n, sizeof (WhPicJob)); }
   // P pictures.  The wave count per workgroup (= per slice) trades waiting on neighbours against latency hiding:
   //   * plenty of workgroups (>= 2 per CU): 6 waves each, two slices share a CU (12 waves / CU, little waiting);
   //   * otherwise 12 waves per workgroup.
@@ -312,9 +322,7 @@ class HipBackend : public wh::Backend {
     else mb_pass (k_inter_slice<768, false>, sizeof (WhInterLds), 12, false, P, jobs, n, 12 * sizeof (WhInterStage) + sizeof (WhPicJob));
   }
   void run_deblock (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
-    static const bool whole = getenv ("WELSHIP_DEBLOCK_WHOLE_PICTURE") != nullptr;     // the single-workgroup variant, for comparison
-    if (P.num_slices > 1 && !whole) mb_pass (k_deblock_slices, sizeof (WhDbLds), 16, false, P, jobs, n);
-    else mb_pass (k_deblock_pic, sizeof (WhDbLds), 16, true, P, jobs, n);
+    mb_pass (k_deblock_slices, sizeof (WhDbLds), 16, false, P, jobs, n, 16 * sizeof (WhDbStage) + sizeof (WhPicJob));
   }
   void run_expand (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
     hipLaunchKernelGGL (k_expand, dim3 (wh_expand_num_blocks (P), n), dim3 (64), 0, stream_, P, jobs);

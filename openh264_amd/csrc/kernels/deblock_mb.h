@@ -79,35 +79,59 @@ WH_FN bool wh_mv_far (const int16_t* a, const int16_t* b) {
   return wh_abs (a[0] - b[0]) >= 4 || wh_abs (a[1] - b[1]) >= 4;
 }
 
-WH_FN void wh_deblock_mb_body (WhDbLds& S, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby) {
+// Staging area of a wave for its NEXT macroblock (LDS-DMA, a separate LDS object like WhInterStage): what no wave of this
+// kernel writes before that MB is filtered -- the three MB states and the MB's own 16x16 / 8x8 samples.
+typedef struct alignas (16) WhDbStage { uint32_t st[128]; uint32_t y[64]; uint32_t c[32]; } WhDbStage;
+
+WH_FN void wh_deblock_cold_fetch (WhDbStage& G, int lane, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby) {
   const int w = P.mb_w, xy = mby * w + mbx;
-  // ---- one batch of loads: the three MB states and the pixel tile (4-byte words) ----
+  const WH_G WhMbState* Mg = (const WH_G WhMbState*)J.mbs + xy;
+  for (int k = 0; k < 2; ++k) {
+    const int i = lane + 64 * k, n = i / 36, wd = i - n * 36;       // state n: this MB, left, top
+    if (i < 108 && (n == 0 || (n == 1 ? mbx > 0 : mby > 0))) wh_ld_async4 ((const WH_G uint32_t*) (Mg - (n == 1 ? 1 : n == 2 ? w : 0)) + wd, &G.st[64 * k], lane);
+  }
+  wh_ld_async4 ((const WH_G uint8_t*)J.rec[0] + (ptrdiff_t) (mby * 16 + (lane >> 2)) * P.rec_stride_y + mbx * 16 + (lane & 3) * 4, G.y, lane);
+  if (lane < 32) {
+    const int pl = lane >> 4, row = (lane >> 1) & 7, half = lane & 1;
+    wh_ld_async4 ((const WH_G uint8_t*)J.rec[1 + pl] + (ptrdiff_t) (mby * 8 + row) * P.rec_stride_c + mbx * 8 + half * 4, G.c, lane);
+  }
+}
+
+// `G` holds this MB's staged inputs (wh_deblock_cold_fetch, landed); when next_valid the staging area is refilled for
+// (next_mbx, next_mby) as soon as it has been emptied.
+WH_FN void wh_deblock_mb_body (WhDbLds& S, WhDbStage& G, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, int next_valid, int next_mbx, int next_mby) {
+  // ---- the neighbours' strips (only now final: the caller has waited for them) + the staged inputs into the tile ----
   WV_LANES_BEGIN (lane)
   {
-    const WH_G WhMbState* Mg = (const WH_G WhMbState*)J.mbs + xy;
-    const WH_G uint8_t* ry = (const WH_G uint8_t*)J.rec[0] + (ptrdiff_t) (mby * 16) * P.rec_stride_y + mbx * 16;
-    uint32_t sv[2] = {0, 0}, yv[2] = {0, 0}, cv = 0;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int i = lane + 64 * k, n = i / 36, wd = i - n * 36;
-      if (i < 108 && (n == 0 || (n == 1 ? mbx > 0 : mby > 0))) sv[k] = ((const WH_G uint32_t*) (Mg - (n == 1 ? 1 : n == 2 ? w : 0)))[wd];
+    uint32_t v;
+    if (lane < 20) {                            // luma rows -4..-1, words x = -4..15
+      const int row = lane / 5 - 4, x = (lane % 5) * 4 - 4;
+      v = * (const WH_G uint32_t*) ((const WH_G uint8_t*)J.rec[0] + (ptrdiff_t) (mby * 16 + row) * P.rec_stride_y + mbx * 16 + x);
+    } else if (lane < 36) {                     // luma rows 0..15, word x = -4
+      v = * (const WH_G uint32_t*) ((const WH_G uint8_t*)J.rec[0] + (ptrdiff_t) (mby * 16 + lane - 20) * P.rec_stride_y + mbx * 16 - 4);
+    } else if (lane < 48) {                     // chroma rows -2..-1, words x = -4..7
+      const int k = lane - 36, pl = k / 6, row = (k % 6) / 3 - 2, x = (k % 3) * 4 - 4;
+      v = * (const WH_G uint32_t*) ((const WH_G uint8_t*)J.rec[1 + pl] + (ptrdiff_t) (mby * 8 + row) * P.rec_stride_c + mbx * 8 + x);
+    } else {                                    // chroma rows 0..7, word x = -4
+      const int k = lane - 48, pl = k >> 3, row = k & 7;
+      v = * (const WH_G uint32_t*) ((const WH_G uint8_t*)J.rec[1 + pl] + (ptrdiff_t) (mby * 8 + row) * P.rec_stride_c + mbx * 8 - 4);
     }
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int i = lane + 64 * k, row = i / 5 - 4, x = (i % 5) * 4 - 4;      // luma: 20 rows x 5 words
-      if (i < 100) yv[k] = * (const WH_G uint32_t*) (ry + (ptrdiff_t)row * P.rec_stride_y + x);
-    }
-    if (lane < 60) {                                                          // chroma: 2 planes x 10 rows x 3 words
-      const int pl = lane / 30, k = lane % 30, row = k / 3 - 2, x = (k % 3) * 4 - 4;
-      cv = * (const WH_G uint32_t*) ((const WH_G uint8_t*)J.rec[1 + pl] + (ptrdiff_t) (mby * 8 + row) * P.rec_stride_c + mbx * 8 + x);
-    }
-#pragma unroll
-    for (int k = 0; k < 2; ++k) { const int i = lane + 64 * k; if (i < 108) S.st[i] = sv[k]; }
-#pragma unroll
-    for (int k = 0; k < 2; ++k) { const int i = lane + 64 * k; if (i < 100) * (uint32_t*)&S.y[(i / 5) * 24 + (i % 5) * 4] = yv[k]; }
-    if (lane < 60) { const int pl = lane / 30, k = lane % 30; * (uint32_t*)&S.c[pl][(k / 3) * 12 + (k % 3) * 4] = cv; }
+    S.st[lane] = G.st[lane];
+    if (lane < 44) S.st[64 + lane] = G.st[64 + lane];
+    * (uint32_t*)&S.y[((lane >> 2) + 4) * 24 + (lane & 3) * 4 + 4] = G.y[lane];
+    if (lane < 32) { const int pl = lane >> 4, row = (lane >> 1) & 7, half = lane & 1; * (uint32_t*)&S.c[pl][(row + 2) * 12 + half * 4 + 4] = G.c[lane]; }
+    if (lane < 20) * (uint32_t*)&S.y[(lane / 5) * 24 + (lane % 5) * 4] = v;
+    else if (lane < 36) * (uint32_t*)&S.y[(lane - 20 + 4) * 24] = v;
+    else if (lane < 48) { const int k = lane - 36; * (uint32_t*)&S.c[k / 6][((k % 6) / 3) * 12 + (k % 3) * 4] = v; }
+    else { const int k = lane - 48; * (uint32_t*)&S.c[k >> 3][((k & 7) + 2) * 12] = v; }
   }
   WV_LANES_END
+  if (next_valid) {
+    WV_LANES_BEGIN (lane)
+    wh_deblock_cold_fetch (G, lane, P, J, next_mbx, next_mby);
+    WV_LANES_END
+  }
+  const int w = P.mb_w;
 
   const WhMbState* M = (const WhMbState*)&S.st[0];
   const WhMbState* Nl = (const WhMbState*)&S.st[36];

@@ -63,7 +63,20 @@ class EmuBackend : public Backend {
       }
   }
   void run_deblock (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
-    for_order (P, n, true, [&] (int j, int x, int y) { WhDbLds S; poison (&S, sizeof (S)); wh_deblock_mb_body (S, P, jobs[j], x, y); });
+    // one emulated wavefront per picture, with the device scheduler's one-MB look-ahead
+    const int num_mb = P.mb_w * P.mb_h;
+    for (int j = 0; j < n; ++j) {
+      WhDbLds S;
+      WhDbStage G;
+      poison (&S, sizeof (S)); poison (&G, sizeof (G));
+      const uint16_t* order = P.mb_order + num_mb;
+      for (int lane = 0; lane < 64; ++lane) wh_deblock_cold_fetch (G, lane, P, jobs[j], order[0] % P.mb_w, order[0] / P.mb_w);
+      for (int t = 0; t < num_mb; ++t) {
+        const int xy = order[t], xyn = t + 1 < num_mb ? order[t + 1] : 0;
+        wh_deblock_mb_body (S, G, P, jobs[j], xy % P.mb_w, xy / P.mb_w, t + 1 < num_mb, xyn % P.mb_w, xyn / P.mb_w);
+        poison (&S, sizeof (S));
+      }
+    }
   }
   void run_expand (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
     for (int j = 0; j < n; ++j) {
