@@ -4,8 +4,9 @@
     python bench.py --gpus N --steps K --warmup W
 
 A *step* is one pass of the hot path (mode decision + reconstruction, in-loop deblocking, border
-expansion) over one batch: `--sessions` independent 1080p pictures per GPU, sources already
-resident in HBM, MB records left in HBM.  value = pictures processed by all ranks / time.
+expansion) over one batch: `--sessions` independent 1080p pictures per GPU (default 128 = two slice
+workgroups per CU), sources already resident in HBM, MB records left in HBM.
+value = pictures processed by all ranks / time.
 Multi-GPU: one process per GPU, sessions sharded over ranks, no data-path collective ("weak").
 Extra objects on the JSON line: `roofline` (dominant kernel, HIP events on the launch stream) and
 `cpu_baseline` (the reference itself, oracle/_ref, timed on this box's host cores, rank 0, N=1).
@@ -34,7 +35,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--sessions", type=int, default=int(os.environ.get("WELSHIP_BENCH_SESSIONS", "64")), help="independent pictures per GPU per step")
+    ap.add_argument("--sessions", type=int, default=int(os.environ.get("WELSHIP_BENCH_SESSIONS", "128")), help="independent pictures per GPU per step")
     ap.add_argument("--queues", type=int, default=int(os.environ.get("WELSHIP_QUEUES", "1")), help="device queues the sessions are spread over (kernels of different queues overlap)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -43,6 +44,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--e2e", action="store_true", help="also time the full encode incl. D2H + host CAVLC")
     ap.add_argument("--host-threads", type=int, default=8)
+    ap.add_argument("--deblock-idc", type=int, default=0, help="disable_deblocking_filter_idc (0: filter across slice boundaries, the reference default)")
     return ap.parse_args()
 
 
@@ -102,6 +104,7 @@ def main():
     e.close()
     p.iPicWidth, p.iPicHeight, p.iDLayerQp, p.fMaxFrameRate, p.iTargetBitrate = w, h, a.qp, 30.0, 5000000
     p.iDevice = local
+    p.iLoopFilterDisableIdc = a.deblock_idc
     if workload == "intra":
         p.uiIntraPeriod = 1
     else:
@@ -150,6 +153,13 @@ def main():
         b_path = BYTES_I_MB_PATH if workload == "intra" else BYTES_P_MB_PATH
         bytes_per_launch = b_md * mbs * a.sessions / nd                     # every MB of every picture in the batch x bytes/MB
         achieved = bytes_per_launch / (md_launch_ms * 1e-3) / 1e9
+        traffic = None
+        try:        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this very command
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            if tj.get("workload") == workload and tj.get("sessions") == a.sessions and (w, h) == (tj.get("width"), tj.get("height")):
+                traffic = tj["hbm_bytes_per_launch"]
+        except Exception:
+            pass
         line = {
             "metric": "1080p frames/sec/GPU at QP=24 CBP; encoder_binary_comparison SHA1 pass",
             "value": pics / dt, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -160,7 +170,7 @@ def main():
                        "pictures_in_flight_per_gpu": a.sessions, "device_queues": a.queues, "hot_path": "device MD/recon + deblock + border expand; sources resident in HBM, MB records left in HBM; host CAVLC excluded",
                        "parallelism": "sessions sharded over %d GPU(s), no collective" % world},
             "roofline": {"bound": "hbm", "kernel": "k_intra_slice" if workload == "intra" else "k_inter_slice",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "bytes_per_mb": b_md, "avg_launch_ms": md_launch_ms, "launches_per_step": nd,
                          "path_achieved_GBs": b_path * mbs * a.sessions * a.steps / (ev["total_ms"] * 1e-3) / 1e9,
                          "events_ms": ev},
