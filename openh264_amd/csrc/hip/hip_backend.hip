@@ -114,6 +114,7 @@ __global__ __launch_bounds__ (MAXT) void k_inter_slice (WhSeqParams P, const WhP
   WhInterLds& S = ((WhInterLds*)smem)[wave];
   __shared__ WhInterStage stage[MAXT / 64];          // separate LDS objects: see WhInterStage
   WhInterStage& G = stage[wave];
+  __shared__ WhWinLds winbuf[MAXT / 64];
   uint32_t* sched = (uint32_t*) (smem + (size_t)nw * sizeof (WhInterLds));
   const int first = P.slice_first_mb[blockIdx.x], n = P.slice_first_mb[blockIdx.x + 1] - first;
   const uint16_t* order = P.mb_order + first;
@@ -129,6 +130,7 @@ __global__ __launch_bounds__ (MAXT) void k_inter_slice (WhSeqParams P, const WhP
   pf.valid = 0;
   X.pf = &pf;
   X.win_stage = WhWinStageLds<MAXT / 64, WINPF>::get (wave);
+  X.win = &winbuf[wave];
   X.slice_idc = (int)blockIdx.x; X.slice_first = first;
   int t = 0;
   if (lane == 0) t = (int)atomicAdd (&sched[0], 1u);
@@ -317,9 +319,9 @@ class HipBackend : public wh::Backend {
   void run_inter (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
     static const int forced = getenv ("WELSHIP_P_WAVES") ? atoi (getenv ("WELSHIP_P_WAVES")) : 0;
     const int waves = forced ? forced : (P.num_slices * n >= 2 * cus_ ? 6 : 12);
-    if (waves == 8) mb_pass (k_inter_slice<512, true>, sizeof (WhInterLds), 8, false, P, jobs, n, 8 * (sizeof (WhInterStage) + sizeof (WhWinStage)) + sizeof (WhPicJob));
-    else if (waves <= 6) mb_pass (k_inter_slice<384, false>, sizeof (WhInterLds), 6, false, P, jobs, n, 6 * sizeof (WhInterStage) + sizeof (WhPicJob));
-    else mb_pass (k_inter_slice<768, false>, sizeof (WhInterLds), 12, false, P, jobs, n, 12 * sizeof (WhInterStage) + sizeof (WhPicJob));
+    if (waves == 8) mb_pass (k_inter_slice<512, true>, sizeof (WhInterLds), 8, false, P, jobs, n, 8 * (sizeof (WhInterStage) + sizeof (WhWinStage) + sizeof (WhWinLds)) + sizeof (WhPicJob));
+    else if (waves <= 6) mb_pass (k_inter_slice<384, false>, sizeof (WhInterLds), 6, false, P, jobs, n, 6 * (sizeof (WhInterStage) + sizeof (WhWinLds)) + sizeof (WhPicJob));
+    else mb_pass (k_inter_slice<768, false>, sizeof (WhInterLds), 12, false, P, jobs, n, 12 * (sizeof (WhInterStage) + sizeof (WhWinLds)) + sizeof (WhPicJob));
   }
   void run_deblock (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
     mb_pass (k_deblock_slices, sizeof (WhDbLds), 16, false, P, jobs, n, 16 * sizeof (WhDbStage) + sizeof (WhPicJob));

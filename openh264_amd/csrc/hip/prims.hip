@@ -56,6 +56,8 @@ __global__ void k_sad (int blk, int n, const uint8_t* p1, int s1, const int* o1,
 // per-lane interpolation from an LDS window) -- so the oracle comparison of this layer pins the hot path's arithmetic.
 __global__ __launch_bounds__ (64) void k_sad_wave (int blk, const uint8_t* p1, int s1, const int* o1, const uint8_t* p2, size_t b2, int s2, const int* o2, int* out, int mode) {
   __shared__ WhInterLds S;
+  __shared__ WhWinLds WB;
+  WhWin W; W.x0 = W.y0 = W.cx0 = W.cy0 = 0; W.b = &WB;
   const int i = blockIdx.x, bw = kBw[blk], bh = kBh[blk];
   const uint8_t* a = p1 + o1[i];
   const long base = (long)o2[i] - 8 * s2 - 8;                 // window origin = block position - (8,8)
@@ -64,41 +66,42 @@ __global__ __launch_bounds__ (64) void k_sad_wave (int blk, const uint8_t* p1, i
   for (int k = lane; k < 40 * 64; k += 64) {
     long ad = base + (long) (k >> 6) * s2 + (k & 63);
     ad = ad < 0 ? 0 : (ad > (long)b2 - 1 ? (long)b2 - 1 : ad);
-    S.win[k] = p2[ad];
+    WB.win[k] = p2[ad];
   }
   WV_LANES_END
   const int wo = 8 * WH_WIN_STRIDE + 8;
   if (mode == 0) {
-    const int s = wh_sad_win (S, 0, 0, bw, bh, wo);
+    const int s = wh_sad_win (S, W, 0, 0, bw, bh, wo);
     if (threadIdx.x == 0) out[i] = s;
   } else if (mode == 1) {
     const int nq = (bw >> 2) * (bh >> 2) * 4;
     int s;
     WV_SATD_ROWS (s, lane, lane < nq, wh_enc4 (S, lane < nq ? wh_tl_col (lane, bw) : 0, lane < nq ? wh_tl_row (lane, bw) : 0),
-                  wh_ld4u (S.win, wo + (lane < nq ? wh_tl_row (lane, bw) * WH_WIN_STRIDE + wh_tl_col (lane, bw) : 0)));
+                  wh_ld4u (WB.win, wo + (lane < nq ? wh_tl_row (lane, bw) * WH_WIN_STRIDE + wh_tl_col (lane, bw) : 0)));
     if (threadIdx.x == 0) out[i] = s;
   } else {
-    const int s0 = wh_sad_win (S, 0, 0, bw, bh, wo - WH_WIN_STRIDE), s1v = wh_sad_win (S, 0, 0, bw, bh, wo + WH_WIN_STRIDE);
-    const int s2v = wh_sad_win (S, 0, 0, bw, bh, wo - 1), s3 = wh_sad_win (S, 0, 0, bw, bh, wo + 1);
+    const int s0 = wh_sad_win (S, W, 0, 0, bw, bh, wo - WH_WIN_STRIDE), s1v = wh_sad_win (S, W, 0, 0, bw, bh, wo + WH_WIN_STRIDE);
+    const int s2v = wh_sad_win (S, W, 0, 0, bw, bh, wo - 1), s3 = wh_sad_win (S, W, 0, 0, bw, bh, wo + 1);
     if (threadIdx.x == 0) { out[i * 4] = s0; out[i * 4 + 1] = s1v; out[i * 4 + 2] = s2v; out[i * 4 + 3] = s3; }
   }
 }
 __global__ __launch_bounds__ (64) void k_mc_wave (const uint8_t* plane, size_t bytes, int st, const int* off, const int16_t* mv, int w, int h, uint8_t* out) {
-  __shared__ WhInterLds S;
+  __shared__ WhWinLds WB;
+  WhWin W; W.x0 = W.y0 = W.cx0 = W.cy0 = 0; W.b = &WB;
   const int i = blockIdx.x;
   const long base = (long)off[i] - 8 * st - 8;
   WV_LANES_BEGIN (lane)
   for (int k = lane; k < 40 * 64; k += 64) {
     long ad = base + (long) (k >> 6) * st + (k & 63);
     ad = ad < 0 ? 0 : (ad > (long)bytes - 1 ? (long)bytes - 1 : ad);
-    S.win[k] = plane[ad];
+    WB.win[k] = plane[ad];
   }
   WV_LANES_END
   const int fx = mv[i * 2] & 3, fy = mv[i * 2 + 1] & 3, wo = 8 * WH_WIN_STRIDE + 8;
   WV_LANES_BEGIN (lane)
   if (lane < (w * h) >> 2) {
     const int r = wh_sl_row (lane, w), c = wh_sl_col (lane, w);
-    const uint32_t v = wh_mc4 (S.win, wo + r * WH_WIN_STRIDE + c, fx, fy);
+    const uint32_t v = wh_mc4 (WB.win, wo + r * WH_WIN_STRIDE + c, fx, fy);
     uint8_t* d = out + (size_t)i * w * h + r * w + c;
     d[0] = (uint8_t)v; d[1] = (uint8_t) (v >> 8); d[2] = (uint8_t) (v >> 16); d[3] = (uint8_t) (v >> 24);
   }

@@ -42,10 +42,15 @@
 #define WH_SLOT_16x8 5            // 5,6
 #define WH_SLOT_8x16 7            // 7,8
 
+// The reference search windows of a wave: a separate LDS object (its own __shared__ variable on the GPU) because they are
+// filled by LDS-DMA -- the compiler then knows that reads of the MB tile cannot alias a window load still in flight.
+typedef struct alignas (16) WhWinLds {
+  alignas (16) uint8_t win[WH_WIN_ROWS * WH_WIN_STRIDE + 16];            // luma, see wh_win_load_luma
+  alignas (16) uint8_t cwin[2][WH_CWIN_ROWS * WH_CWIN_STRIDE + 16];      // chroma (Cb, Cr)
+} WhWinLds;
+
 typedef struct alignas (16) WhInterLds {
   WhMbLds m;
-  alignas (16) uint8_t win[WH_WIN_ROWS * WH_WIN_STRIDE + 16];            // reference search window (luma), see wh_win_load_luma
-  alignas (16) uint8_t cwin[2][WH_CWIN_ROWS * WH_CWIN_STRIDE + 16];      // chroma windows (Cb, Cr)
   uint8_t prev_y[256];                                      // co-located luma of the previous source picture (VAA SADs)
   uint8_t skip_y[256];                                      // P_Skip prediction
   uint8_t skip_c[128];
@@ -68,7 +73,7 @@ typedef struct alignas (16) WhWinStage {
   alignas (16) uint8_t pf_cwin[2][WH_CWIN_ROWS * WH_CWIN_STRIDE + 16];
 } WhWinStage;
 
-typedef struct WhWin { int x0, y0, cx0, cy0; } WhWin;       // picture coordinates of element (0,0) of win / cwin
+typedef struct WhWin { int x0, y0, cx0, cy0; WhWinLds* b; } WhWin;     // picture coordinates of element (0,0) of win / cwin + where they live
 
 // ---- mvd cost: lambda * bits(se(mvd))  (md.cpp:797-824, svc_enc_golomb.h BsSizeSE) --------------
 WH_FN int wh_se_bits (int v) {
@@ -143,7 +148,7 @@ WH_FN int wh_mc_chroma_w (int a, int b, int c, int d, int dx, int dy) {
 // plane) at a 4-pixel aligned origin.  Origins are clamped so that the whole window lies inside the expanded picture
 // (32 luma / 16 chroma pixels each side): loads need no per-lane clamping and move 16 bytes per lane.
 #define WH_WIN_LOADS ((WH_WIN_ROWS + 15) / 16)     // 16-byte loads per lane: 16 rows of 4 x 16 bytes per instruction
-WH_FN void wh_win_place (const WhSeqParams& P, WhWin& W, int cx, int cy) {      // (cx,cy): luma position the 16x16 block is centred on
+WH_FN void wh_win_place (const WhSeqParams& P, WhWin& W, int cx, int cy) {      // leaves W.b alone      // (cx,cy): luma position the 16x16 block is centred on
   W.x0 = wh_clip3 ((cx - 24) & ~3, -32, P.mb_w * 16 + 32 - WH_WIN_STRIDE);
   W.y0 = wh_clip3 (cy - (WH_WIN_ROWS - 16) / 2, -32, P.mb_h * 16 + 32 - WH_WIN_ROWS);
   W.cx0 = wh_clip3 (((cx >> 1) - 12) & ~3, -16, P.mb_w * 8 + 16 - WH_CWIN_STRIDE);
@@ -156,28 +161,29 @@ WH_FN const WH_G uint8_t* wh_win_src_chroma (int lane, int pl, const WhSeqParams
   return (const WH_G uint8_t*)J.ref[1 + pl] + (ptrdiff_t) (W.cy0 + (lane >> 1)) * P.rec_stride_c + W.cx0 + (lane & 1) * 16;
 }
 WH_FN bool wh_win_row_ok (int lane, int k) { return 16 * k + (lane >> 2) < WH_WIN_ROWS; }
-WH_FN void wh_win_load_luma (WhInterLds& S, const WhSeqParams& P, const WhPicJob& J, WhWin& W) {
+// Window loads are LDS-DMA (16 bytes per lane, no register holds the data).  wh_win_issue_* only starts them; the data
+// may be used after WV_ASYNC_WAIT().
+WH_FN void wh_win_issue_luma (const WhSeqParams& P, const WhPicJob& J, WhWin& W) {
   WV_LANES_BEGIN (lane)
-  WhU4 v[WH_WIN_LOADS];
 #pragma unroll
-  for (int k = 0; k < WH_WIN_LOADS; ++k) if (wh_win_row_ok (lane, k)) memcpy (&v[k], (const void*)wh_win_src_luma (lane, k, P, J, W), 16);
-#pragma unroll
-  for (int k = 0; k < WH_WIN_LOADS; ++k) if (wh_win_row_ok (lane, k)) * (WhU4*)&S.win[(16 * k) * WH_WIN_STRIDE + lane * 16] = v[k];
+  for (int k = 0; k < WH_WIN_LOADS; ++k) if (wh_win_row_ok (lane, k)) wh_ld_async16 (wh_win_src_luma (lane, k, P, J, W), &W.b->win[(16 * k) * WH_WIN_STRIDE], lane);
   WV_LANES_END
 }
-// first load of a macroblock: luma + both chroma windows in one batch
-WH_FN void wh_win_load_all (WhInterLds& S, const WhSeqParams& P, const WhPicJob& J, WhWin& W, int cx, int cy) {
+WH_FN void wh_win_load_luma (WhInterLds& S, const WhSeqParams& P, const WhPicJob& J, WhWin& W) {
+  (void)S;
+  wh_win_issue_luma (P, J, W);
+  WV_ASYNC_WAIT();
+}
+// first load of a macroblock: luma + both chroma windows in one batch (issue only)
+WH_FN void wh_win_issue_all (const WhSeqParams& P, const WhPicJob& J, WhWin& W, int cx, int cy) {
   wh_win_place (P, W, cx, cy);
   WV_LANES_BEGIN (lane)
-  WhU4 v[WH_WIN_LOADS], c[2];
+  {
 #pragma unroll
-  for (int k = 0; k < WH_WIN_LOADS; ++k) if (wh_win_row_ok (lane, k)) memcpy (&v[k], (const void*)wh_win_src_luma (lane, k, P, J, W), 16);
+    for (int k = 0; k < WH_WIN_LOADS; ++k) if (wh_win_row_ok (lane, k)) wh_ld_async16 (wh_win_src_luma (lane, k, P, J, W), &W.b->win[(16 * k) * WH_WIN_STRIDE], lane);
 #pragma unroll
-  for (int pl = 0; pl < 2; ++pl) memcpy (&c[pl], (const void*)wh_win_src_chroma (lane, pl, P, J, W), 16);
-#pragma unroll
-  for (int k = 0; k < WH_WIN_LOADS; ++k) if (wh_win_row_ok (lane, k)) * (WhU4*)&S.win[(16 * k) * WH_WIN_STRIDE + lane * 16] = v[k];
-#pragma unroll
-  for (int pl = 0; pl < 2; ++pl) * (WhU4*)&S.cwin[pl][lane * 16] = c[pl];
+    for (int pl = 0; pl < 2; ++pl) wh_ld_async16 (wh_win_src_chroma (lane, pl, P, J, W), W.b->cwin[pl], lane);
+  }
   WV_LANES_END
 }
 WH_FN bool wh_win_covers (const WhWin& W, int x0, int y0, int x1, int y1) {
@@ -208,13 +214,14 @@ WH_FN void wh_win_prefetch (WhWinStage& G, const WhSeqParams& P, const WhPicJob&
 }
 // move the staged windows into place (LDS to LDS)
 WH_FN void wh_win_adopt (WhInterLds& S, const WhWinStage& G, WhWin& W, const WhWinPf& F) {
-  W = F.w;
+  (void)S;
+  W.x0 = F.w.x0; W.y0 = F.w.y0; W.cx0 = F.w.cx0; W.cy0 = F.w.cy0;
   WV_LANES_BEGIN (lane)
   {
 #pragma unroll
-    for (int k = 0; k < WH_WIN_LOADS; ++k) if (wh_win_row_ok (lane, k)) * (WhU4*)&S.win[(16 * k) * WH_WIN_STRIDE + lane * 16] = * (const WhU4*)&G.pf_win[(16 * k) * WH_WIN_STRIDE + lane * 16];
+    for (int k = 0; k < WH_WIN_LOADS; ++k) if (wh_win_row_ok (lane, k)) * (WhU4*)&W.b->win[(16 * k) * WH_WIN_STRIDE + lane * 16] = * (const WhU4*)&G.pf_win[(16 * k) * WH_WIN_STRIDE + lane * 16];
 #pragma unroll
-    for (int pl = 0; pl < 2; ++pl) * (WhU4*)&S.cwin[pl][lane * 16] = * (const WhU4*)&G.pf_cwin[pl][lane * 16];
+    for (int pl = 0; pl < 2; ++pl) * (WhU4*)&W.b->cwin[pl][lane * 16] = * (const WhU4*)&G.pf_cwin[pl][lane * 16];
   }
   WV_LANES_END
 }
@@ -229,11 +236,11 @@ WH_FN int wh_tl_col (int lane, int bw) { const int b = lane >> 2; return (bw == 
 WH_FN uint32_t wh_enc4 (const WhInterLds& S, int x, int y) { return * (const uint32_t*)&S.m.enc_y[y * 16 + x]; }
 
 // SAD of the bw x bh block at (ex,ey) of the source MB against the window at offset wo
-WH_FN int wh_sad_win (const WhInterLds& S, int ex, int ey, int bw, int bh, int wo) {
+WH_FN int wh_sad_win (const WhInterLds& S, const WhWin& W, int ex, int ey, int bw, int bh, int wo) {
   int s;
   const int n = (bw * bh) >> 2;
   WV_SUM (s, lane, (lane < n ? wh_sad4 (wh_enc4 (S, ex + wh_sl_col (lane, bw), ey + wh_sl_row (lane, bw)),
-                                        wh_ld4u (S.win, wo + wh_sl_row (lane, bw) * WH_WIN_STRIDE + wh_sl_col (lane, bw))) : 0));
+                                        wh_ld4u (W.b->win, wo + wh_sl_row (lane, bw) * WH_WIN_STRIDE + wh_sl_col (lane, bw))) : 0));
   return s;
 }
 // same against the reference picture in HBM (search candidates far away from the window)
@@ -267,7 +274,7 @@ WH_FN void wh_mc_luma_to (WhInterLds& S, const WhSeqParams& P, const WhPicJob& J
   WV_LANES_BEGIN (lane)
   if (lane < n) {
     const int r = wh_sl_row (lane, bw), c = wh_sl_col (lane, bw);
-    * (uint32_t*)&dst[(by + r) * 16 + bx + c] = wh_mc4 (S.win, wo + r * WH_WIN_STRIDE + c, fx, fy);
+    * (uint32_t*)&dst[(by + r) * 16 + bx + c] = wh_mc4 (W.b->win, wo + r * WH_WIN_STRIDE + c, fx, fy);
   }
   WV_LANES_END
 }
@@ -283,7 +290,7 @@ WH_FN void wh_mc_chroma_to (WhInterLds& S, const WhSeqParams& P, const WhPicJob&
     WV_LANES_BEGIN (lane)
     for (int i = lane; i < 2 * n; i += 64) {
       const int pl = i >= n, k = i - pl * n, x = k & (cw - 1), y = k >> sh;
-      const uint8_t* p = &S.cwin[pl][wo + y * WH_CWIN_STRIDE + x];
+      const uint8_t* p = &W.b->cwin[pl][wo + y * WH_CWIN_STRIDE + x];
       dst[pl * 64 + (cy + y) * 8 + cx + x] = (uint8_t)wh_mc_chroma_w (p[0], p[1], p[WH_CWIN_STRIDE], p[WH_CWIN_STRIDE + 1], dx, dy);
     }
     WV_LANES_END
@@ -379,7 +386,7 @@ typedef struct WhMeCtx {
 WH_FN int wh_cand_sad (const WhInterLds& S, const WhSeqParams& P, const WhPicJob& J, const WhWin& W, const WhMeCtx& C, const WhMe& me, int imx, int imy) {
   const int px = C.mbx * 16 + me.bx + imx, py = C.mby * 16 + me.by + imy;
   if (wh_win_covers (W, px, py, px + me.bw + 3, py + me.bh))
-    return wh_sad_win (S, me.bx, me.by, me.bw, me.bh, (py - W.y0) * WH_WIN_STRIDE + px - W.x0);
+    return wh_sad_win (S, W, me.bx, me.by, me.bw, me.bh, (py - W.y0) * WH_WIN_STRIDE + px - W.x0);
   return wh_sad_global (S, P, J, me.bx, me.by, me.bw, me.bh, px, py);
 }
 
@@ -413,10 +420,10 @@ WH_FN void wh_motion_search (WhInterLds& S, const WhSeqParams& P, const WhPicJob
       WV_SUM2 (pud, plr, lane,
                (lane < n ? ([&] () { const int r = wh_sl_row (lane, me.bw), c = wh_sl_col (lane, me.bw);
                                      const uint32_t e = wh_enc4 (S, me.bx + c, me.by + r); const int o = wo + r * WH_WIN_STRIDE + c;
-                                     return wh_sad4 (e, wh_ld4u (S.win, o - WH_WIN_STRIDE)) | (wh_sad4 (e, wh_ld4u (S.win, o + WH_WIN_STRIDE)) << 16); }) () : 0),
+                                     return wh_sad4 (e, wh_ld4u (W.b->win, o - WH_WIN_STRIDE)) | (wh_sad4 (e, wh_ld4u (W.b->win, o + WH_WIN_STRIDE)) << 16); }) () : 0),
                (lane < n ? ([&] () { const int r = wh_sl_row (lane, me.bw), c = wh_sl_col (lane, me.bw);
                                      const uint32_t e = wh_enc4 (S, me.bx + c, me.by + r); const int o = wo + r * WH_WIN_STRIDE + c;
-                                     return wh_sad4 (e, wh_ld4u (S.win, o - 1)) | (wh_sad4 (e, wh_ld4u (S.win, o + 1)) << 16); }) () : 0));
+                                     return wh_sad4 (e, wh_ld4u (W.b->win, o - 1)) | (wh_sad4 (e, wh_ld4u (W.b->win, o + 1)) << 16); }) () : 0));
       const int c0 = (pud & 0xffff) + wh_mvd_cost (C.lambda, dx, dy - 4);
       const int c1 = (int) ((unsigned)pud >> 16) + wh_mvd_cost (C.lambda, dx, dy + 4);
       const int c2 = (plr & 0xffff) + wh_mvd_cost (C.lambda, dx - 4, dy);
@@ -440,7 +447,7 @@ WH_FN void wh_motion_search (WhInterLds& S, const WhSeqParams& P, const WhPicJob
     const int nq = (me.bw >> 2) * (me.bh >> 2) * 4;
     WV_SATD_ROWS (me.satd_raw, lane, lane < nq,
                   wh_enc4 (S, me.bx + (lane < nq ? wh_tl_col (lane, me.bw) : 0), me.by + (lane < nq ? wh_tl_row (lane, me.bw) : 0)),
-                  wh_ld4u (S.win, wo + (lane < nq ? wh_tl_row (lane, me.bw) * WH_WIN_STRIDE + wh_tl_col (lane, me.bw) : 0)));
+                  wh_ld4u (W.b->win, wo + (lane < nq ? wh_tl_row (lane, me.bw) * WH_WIN_STRIDE + wh_tl_col (lane, me.bw) : 0)));
     me.satd_cost = me.satd_raw + wh_mvd_cost (C.lambda, me.mvx - me.mvpx, me.mvy - me.mvpy);
   }
 }
@@ -560,11 +567,11 @@ WH_FN void wh_refine_frac (WhInterLds& S, const WhSeqParams& P, const WhPicJob& 
   int c_int, c0, c1, c2, c3;
   WV_DECLARE_LANE (lane);                   // one lane id for all candidates: they share most of their window loads
   if (satd_in_md) c_int = me.satd_raw;                                      // uiSatd of the integer search
-  else WV_SATD_ROWS_SHARED (c_int, lane, WH_RF_ACT, WH_RF_ENC, wh_ld4u (S.win, WH_RF_O));
-  WV_SATD_ROWS_SHARED (c0, lane, WH_RF_ACT, WH_RF_ENC, wh_rf_half (S.win, WH_RF_O, 0));
-  WV_SATD_ROWS_SHARED (c1, lane, WH_RF_ACT, WH_RF_ENC, wh_rf_half (S.win, WH_RF_O, 1));
-  WV_SATD_ROWS_SHARED (c2, lane, WH_RF_ACT, WH_RF_ENC, wh_rf_half (S.win, WH_RF_O, 2));
-  WV_SATD_ROWS_SHARED (c3, lane, WH_RF_ACT, WH_RF_ENC, wh_rf_half (S.win, WH_RF_O, 3));
+  else WV_SATD_ROWS_SHARED (c_int, lane, WH_RF_ACT, WH_RF_ENC, wh_ld4u (W.b->win, WH_RF_O));
+  WV_SATD_ROWS_SHARED (c0, lane, WH_RF_ACT, WH_RF_ENC, wh_rf_half (W.b->win, WH_RF_O, 0));
+  WV_SATD_ROWS_SHARED (c1, lane, WH_RF_ACT, WH_RF_ENC, wh_rf_half (W.b->win, WH_RF_O, 1));
+  WV_SATD_ROWS_SHARED (c2, lane, WH_RF_ACT, WH_RF_ENC, wh_rf_half (W.b->win, WH_RF_O, 2));
+  WV_SATD_ROWS_SHARED (c3, lane, WH_RF_ACT, WH_RF_ENC, wh_rf_half (W.b->win, WH_RF_O, 3));
   int best = c_int + wh_mvd_cost (C.lambda, dmx, dmy), hb = -1;
   c0 += wh_mvd_cost (C.lambda, dmx, dmy - 2); if (c0 < best) { best = c0; hb = 0; }
   c1 += wh_mvd_cost (C.lambda, dmx, dmy + 2); if (c1 < best) { best = c1; hb = 1; }
@@ -572,10 +579,10 @@ WH_FN void wh_refine_frac (WhInterLds& S, const WhSeqParams& P, const WhPicJob& 
   c3 += wh_mvd_cost (C.lambda, dmx + 2, dmy); if (c3 < best) { best = c3; hb = 3; }
   const int hx = hb == 2 ? -2 : hb == 3 ? 2 : 0, hy = hb == 0 ? -2 : hb == 1 ? 2 : 0;    // winner of the half stage, relative
   // quarter-sample candidates around it
-  WV_SATD_ROWS_SHARED (c0, lane, WH_RF_ACT, WH_RF_ENC, wh_rf_quarter (S.win, WH_RF_O, hb, 0));
-  WV_SATD_ROWS_SHARED (c1, lane, WH_RF_ACT, WH_RF_ENC, wh_rf_quarter (S.win, WH_RF_O, hb, 1));
-  WV_SATD_ROWS_SHARED (c2, lane, WH_RF_ACT, WH_RF_ENC, wh_rf_quarter (S.win, WH_RF_O, hb, 2));
-  WV_SATD_ROWS_SHARED (c3, lane, WH_RF_ACT, WH_RF_ENC, wh_rf_quarter (S.win, WH_RF_O, hb, 3));
+  WV_SATD_ROWS_SHARED (c0, lane, WH_RF_ACT, WH_RF_ENC, wh_rf_quarter (W.b->win, WH_RF_O, hb, 0));
+  WV_SATD_ROWS_SHARED (c1, lane, WH_RF_ACT, WH_RF_ENC, wh_rf_quarter (W.b->win, WH_RF_O, hb, 1));
+  WV_SATD_ROWS_SHARED (c2, lane, WH_RF_ACT, WH_RF_ENC, wh_rf_quarter (W.b->win, WH_RF_O, hb, 2));
+  WV_SATD_ROWS_SHARED (c3, lane, WH_RF_ACT, WH_RF_ENC, wh_rf_quarter (W.b->win, WH_RF_O, hb, 3));
   int qb = -1;
   c0 += wh_mvd_cost (C.lambda, dmx + hx, dmy + hy - 1); if (c0 < best) { best = c0; qb = 0; }
   c1 += wh_mvd_cost (C.lambda, dmx + hx, dmy + hy + 1); if (c1 < best) { best = c1; qb = 1; }
@@ -587,7 +594,7 @@ WH_FN void wh_refine_frac (WhInterLds& S, const WhSeqParams& P, const WhPicJob& 
   WV_LANES_BEGIN (lane)
   if (lane < nq) {
     const int o = WH_RF_O;
-    const uint32_t v = qb >= 0 ? wh_rf_quarter (S.win, o, hb, qb) : hb >= 0 ? wh_rf_half (S.win, o, hb) : wh_ld4u (S.win, o);
+    const uint32_t v = qb >= 0 ? wh_rf_quarter (W.b->win, o, hb, qb) : hb >= 0 ? wh_rf_half (W.b->win, o, hb) : wh_ld4u (W.b->win, o);
     * (uint32_t*)&S.m.pred_y[(ey + wh_tl_row (lane, bw)) * 16 + ex + wh_tl_col (lane, bw)] = v;
   }
   WV_LANES_END
@@ -682,6 +689,7 @@ typedef struct WhInterCtx {
   int next_valid, next_mbx, next_mby;   // the MB this wave processes next (its cold inputs are fetched during this one)
   WhWinPf* pf;                          // in: windows staged for this MB (or not); out: what was staged for the next one
   WhWinStage* win_stage;                // where windows are staged, or NULL: no window prefetch
+  WhWinLds* win;                        // this wave's search windows
 } WhInterCtx;
 
 // ---- the P macroblock -----------------------------------------------------------------------------
@@ -777,14 +785,17 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, WhInterStage& G, const WhSeqParams& 
   me16.bx = 0; me16.by = 0; me16.bw = 16; me16.bh = 16;
   wh_pred_mv (K, 0, 0, 4, 0, &me16.mvpx, &me16.mvpy);
   WhWin W;
+  W.b = X.win;
+  WhI16Cost i16c;
   {
     const int icx = wh_clip3 ((2 + me16.mvpx) >> 2, C.minx, C.maxx), icy = wh_clip3 ((2 + me16.mvpy) >> 2, C.miny, C.maxy);
     const int cx = mbx * 16 + icx, cy = mby * 16 + icy;
-    if (X.pf->valid && wh_win_covers (X.pf->w, cx - WH_WIN_MARGIN, cy - WH_WIN_MARGIN, cx + 16 + WH_WIN_MARGIN, cy + 16 + WH_WIN_MARGIN))
-    { wh_win_adopt (S, *X.win_stage, W, *X.pf);            // staged during the previous MB
-      WH_PROF_MARK (P, M, 15); }
-    else
-      wh_win_load_all (S, P, J, W, cx, cy);
+    const bool adopt = X.pf->valid && wh_win_covers (X.pf->w, cx - WH_WIN_MARGIN, cy - WH_WIN_MARGIN, cx + 16 + WH_WIN_MARGIN, cy + 16 + WH_WIN_MARGIN);
+    if (adopt) { wh_win_adopt (S, *X.win_stage, W, *X.pf); WH_PROF_MARK (P, M, 15); }     // staged during the previous MB
+    else wh_win_issue_all (P, J, W, cx, cy);
+    // the Intra16x16 mode costs need no reference samples: computed while the window loads are in flight
+    wh_i16_costs (M, avail, use_satd, lambda, &i16c);
+    if (!adopt) WV_ASYNC_WAIT();
     // ---- the next MB of this wave: cold inputs + windows (around where this MB's predictor points), in flight while
     //      the rest of this MB runs ----
     X.pf->valid = 0;
@@ -895,7 +906,7 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, WhInterStage& G, const WhSeqParams& 
   WhIntraResult ir;
   if (!done) {
     // WelsMdFirstIntraMode: I16x16 cost vs the inter/skip cost so far
-    if (wh_intra_md_enc_p (M, P, J, mbx, mby, avail, qp, qpc, cost_luma, &ir)) { intra = true; done = true; }
+    if (wh_intra_md_enc_p (M, P, J, mbx, mby, avail, qp, qpc, cost_luma, &ir, &i16c)) { intra = true; done = true; }
   }
   if (!done && b_skip) { mb_type = WH_MB_PSKIP; done = true; }
   WH_PROF_MARK (P, M, 3);   // I16x16 test (+ intra encode when intra wins)

@@ -224,10 +224,10 @@ typedef struct WhIntraResult {
 
 // `inter_cost`: in P slices the I16x16 cost must beat the best inter cost so far, otherwise nothing is
 // encoded and false is returned (WelsMdFirstIntraMode); I slices pass INT_MAX.
-WH_FN bool wh_intra_md_enc_p (WhMbLds& S, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, int avail, int qp, int qpc,
-                              int inter_cost, WhIntraResult* o) {
-  const int lambda = kWhLambda[qp];
-  const int use_satd = P.complexity > 0;
+// Intra16x16 mode costs of the MB (neighbour sums, plane parameters, best mode): needs only the tile, so a caller can
+// compute it early (the P kernel does, underneath its window loads).
+typedef struct WhI16Cost { int sum_t, sum_l, pl_a, pl_b, pl_c, best_mode, best_cost; } WhI16Cost;
+WH_FN void wh_i16_costs (WhMbLds& S, int avail, int use_satd, int lambda, WhI16Cost* k) {
   const int av3 = avail & 7;
   const bool has_l = (avail & WH_AV_LEFT) != 0, has_t = (avail & WH_AV_TOP) != 0;
 
@@ -279,6 +279,20 @@ WH_FN bool wh_intra_md_enc_p (WhMbLds& S, const WhSeqParams& P, const WhPicJob& 
     const int c = cst[i] + lambda * bits;
     if (c < best_cost) { best_cost = c; best_mode = m; }
   }
+  k->sum_t = sum_t; k->sum_l = sum_l; k->pl_a = pl_a; k->pl_b = pl_b; k->pl_c = pl_c; k->best_mode = best_mode; k->best_cost = best_cost;
+  (void)last_mode;
+}
+
+WH_FN bool wh_intra_md_enc_p (WhMbLds& S, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, int avail, int qp, int qpc,
+                              int inter_cost, WhIntraResult* o, const WhI16Cost* pre = nullptr) {
+  const int lambda = kWhLambda[qp];
+  const int use_satd = P.complexity > 0;
+  const bool has_l = (avail & WH_AV_LEFT) != 0, has_t = (avail & WH_AV_TOP) != 0;
+  WhI16Cost own;
+  if (!pre) { wh_i16_costs (S, avail, use_satd, lambda, &own); pre = &own; }
+  const int sum_t = pre->sum_t, sum_l = pre->sum_l, pl_a = pre->pl_a, pl_b = pre->pl_b, pl_c = pre->pl_c;
+  const int best_mode = pre->best_mode, best_cost = pre->best_cost, last_mode = -1;
+  const int av3 = avail & 7;
   if (!(best_cost < inter_cost)) return false;
   int cost_luma = best_cost;
   int mb_type = WH_MB_I16x16;

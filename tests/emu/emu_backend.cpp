@@ -47,7 +47,8 @@ class EmuBackend : public Backend {
         WhInterLds S;
         WhInterStage G;
         WhWinStage GW;
-        poison (&S, sizeof (S)); poison (&G, sizeof (G)); poison (&GW, sizeof (GW));
+        WhWinLds WB;
+        poison (&S, sizeof (S)); poison (&G, sizeof (G)); poison (&GW, sizeof (GW)); poison (&WB, sizeof (WB));
         WhWinPf pf; pf.valid = 0;
         const int first = P.slice_first_mb[s], last = P.slice_first_mb[s + 1];
         { const int xy = P.mb_order[first]; for (int lane = 0; lane < 64; ++lane) wh_inter_cold_fetch (G, lane, P, jobs[j], xy % P.mb_w, xy / P.mb_w); }
@@ -56,9 +57,10 @@ class EmuBackend : public Backend {
           WhInterCtx X;
           X.slice_idc = s; X.slice_first = first;
           X.next_valid = t + 1 < last; X.next_mbx = xyn % P.mb_w; X.next_mby = xyn / P.mb_w; X.pf = &pf;
+          X.win = &WB;
           X.win_stage = ((s + j) & 1) ? &GW : nullptr;      // exercise both variants (with / without window staging), one per slice
           wh_inter_mb_body (S, G, P, jobs[j], xy % P.mb_w, xy / P.mb_w, X);
-          poison (&S, sizeof (S));            // nothing but the staging area survives from one macroblock to the next
+          poison (&S, sizeof (S)); poison (&WB, sizeof (WB));      // nothing but the staging areas survives from one macroblock to the next
         }
       }
   }
