@@ -836,8 +836,9 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, WhInterStage& G, const WhSeqParams& 
     if (!(nx < -29 || nx > (P.mb_w << 4) + 12 || ny < -29 || ny > (P.mb_h << 4) + 12)) {
       wh_mc_luma_to (S, P, J, W, mbx, mby, 0, 0, 16, 16, skx, sky, S.skip_y);
       wh_mc_chroma_to (S, P, J, W, mbx, mby, 0, 0, 8, 8, skx, sky, S.skip_c);
-      const int sad_l = wh_sad_mb_tile (S, S.skip_y);
-      const int sad_c = wh_sad_chroma_tile (S, S.skip_c);
+      int sad_l, sad_c;                       // luma and chroma SAD of the skip prediction in one reduction
+      WV_SUM2 (sad_l, sad_c, lane, wh_sad4 (* (const uint32_t*)&S.m.enc_y[lane * 4], * (const uint32_t*)&S.skip_y[lane * 4]),
+               (lane < 32 ? wh_sad4 (* (const uint32_t*)&S.m.enc_c[lane * 4], * (const uint32_t*)&S.skip_c[lane * 4]) : 0));
       const int sad_mb = sad_l + sad_c;
       bool ok = sad_mb == 0 || sad_mb < sad_pred_skip || (ref_is_p && ref_mb_type == WH_MB_PSKIP && sad_mb < Co->skip_sad);
       if (!ok) {
@@ -993,7 +994,10 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, WhInterStage& G, const WhSeqParams& 
     }
     if (mb_type == WH_MB_P16x16) {
       // iCostSkipMb of a 16x16 MB = SAD of its final prediction (luma + chroma)
-      cost_skip_mb = wh_sad_mb_tile (S, M.pred_y) + wh_sad_chroma_tile (S, M.pred_c);
+      int sl, sc;
+      WV_SUM2 (sl, sc, lane, wh_sad4 (* (const uint32_t*)&M.enc_y[lane * 4], * (const uint32_t*)&M.pred_y[lane * 4]),
+               (lane < 32 ? wh_sad4 (* (const uint32_t*)&M.enc_c[lane * 4], * (const uint32_t*)&M.pred_c[lane * 4]) : 0));
+      cost_skip_mb = sl + sc;
     }
     sad_cost0 = best_sad;
     cost_luma = md_using_sad ? best_sad : best_satd;
