@@ -177,7 +177,11 @@ __global__ __launch_bounds__ (1024) void k_deblock_slices (WhSeqParams P, const 
   const int nw = (int)blockDim.x >> 6, lane = (int)threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane ((int)threadIdx.x >> 6);
   WhDbLds& S = ((WhDbLds*)smem)[wave];
-  uint32_t* sched = (uint32_t*) (smem + (size_t)nw * sizeof (WhDbLds));
+  WhDbXchg E;                                 // strip exchange between the waves (deblock_mb.h), indexed by absolute MB row
+  E.top = (uint32_t*) (smem + (size_t)nw * sizeof (WhDbLds));
+  E.left = E.top + (size_t)P.mb_w * 24;
+  E.first_row = 0;
+  uint32_t* sched = E.left + (size_t)P.mb_h * 32;
   const int w = P.mb_w, num_mb = P.mb_w * P.mb_h;
   const int first = P.slice_first_mb[blockIdx.x], last = P.slice_first_mb[blockIdx.x + 1], n = last - first;
   const uint16_t* order = P.mb_order + first;
@@ -222,7 +226,7 @@ __global__ __launch_bounds__ (1024) void k_deblock_slices (WhSeqParams P, const 
     if (remote) __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "agent");
     else __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "workgroup");
     WV_ASYNC_WAIT();                            // this MB's staged inputs have landed
-    wh_deblock_mb_body (S, G, P, J, xy % w, xy / w, tn < n, xyn % w, xyn / w);
+    wh_deblock_mb_body (S, G, E, first, P, J, xy % w, xy / w, tn < n, xyn % w, xyn / w);
     // MBs a later slice may wait for: its left neighbour (xy + 1), top (xy + w) or top-right consumer (xy + w - 1)
     const bool publish = cross && xy + w + 1 >= last && last < num_mb;
     if (publish) {
@@ -289,7 +293,7 @@ class HipBackend : public wh::Backend {
   // waves per workgroup: bounded by the LDS budget (160 KB per CU), the kernel's register budget and by how many MBs
   // of one slice can be in flight at all (~ min(rows, mb_w / 2))
   // `static_lds`: LDS the kernel declares statically (counts against the 160 KB of a CU as well)
-  template <class K> void mb_pass (K kernel, size_t lds_per_wave, int max_waves, bool whole_picture, const WhSeqParams& P, const WhPicJob* jobs, int n, size_t static_lds = 0) {
+  template <class K> void mb_pass (K kernel, size_t lds_per_wave, int max_waves, bool whole_picture, const WhSeqParams& P, const WhPicJob* jobs, int n, size_t static_lds = 0, size_t extra_dyn = 0) {
     const int num_mb = P.mb_w * P.mb_h;
     int max_n = whole_picture ? num_mb : 0, max_rows = whole_picture ? P.mb_h : 0;
     if (!whole_picture) for (int s = 0; s < P.num_slices; ++s) {
@@ -298,7 +302,7 @@ class HipBackend : public wh::Backend {
       const int rows = (P.slice_first_mb[s + 1] - 1) / P.mb_w - P.slice_first_mb[s] / P.mb_w + 1;
       if (rows > max_rows) max_rows = rows;
     }
-    const size_t sched_bytes = 4 * (size_t) (1 + ((max_n + 31) >> 5));
+    const size_t sched_bytes = 4 * (size_t) (1 + ((max_n + 31) >> 5)) + extra_dyn;
     int nw = max_waves;
     const int par = std::max (1, std::min (max_rows, (P.mb_w + 1) / 2));
     if (nw > par) nw = par;
@@ -324,7 +328,7 @@ class HipBackend : public wh::Backend {
     else mb_pass (k_inter_slice<768, false>, sizeof (WhInterLds), 12, false, P, jobs, n, 12 * (sizeof (WhInterStage) + sizeof (WhWinLds)) + sizeof (WhPicJob));
   }
   void run_deblock (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
-    mb_pass (k_deblock_slices, sizeof (WhDbLds), 16, false, P, jobs, n, 16 * sizeof (WhDbStage) + sizeof (WhPicJob));
+    mb_pass (k_deblock_slices, sizeof (WhDbLds), 16, false, P, jobs, n, 16 * sizeof (WhDbStage) + sizeof (WhPicJob), 4 * wh_db_xchg_words (P.mb_w, P.mb_h));
   }
   void run_expand (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
     hipLaunchKernelGGL (k_expand, dim3 (wh_expand_num_blocks (P), n), dim3 (64), 0, stream_, P, jobs);

@@ -97,33 +97,74 @@ WH_FN void wh_deblock_cold_fetch (WhDbStage& G, int lane, const WhSeqParams& P, 
   }
 }
 
+// this MB's bottom rows / right columns for the MBs below / to the right; with `left_mod` also the three columns of the
+// left MB that the left-edge filter may have changed, inside that MB's bottom rows (they are the top strip of the MB
+// below it)
+WH_FN void wh_db_publish (WhDbLds& S, uint32_t* etop, uint32_t* eleft, bool left_mod) {
+  WV_LANES_BEGIN (lane)
+  if (lane < 16) etop[lane] = * (const uint32_t*)&S.y[((lane >> 2) + 12 + 4) * 24 + (lane & 3) * 4 + 4];
+  else if (lane < 32) eleft[lane - 16] = * (const uint32_t*)&S.y[(lane - 16 + 4) * 24 + 12 + 4];
+  else if (lane < 40) { const int k = lane - 32; etop[16 + k] = * (const uint32_t*)&S.c[k >> 2][(((k >> 1) & 1) + 6 + 2) * 12 + (k & 1) * 4 + 4]; }
+  else if (lane < 56) { const int k = lane - 40; eleft[16 + k] = * (const uint32_t*)&S.c[k >> 3][((k & 7) + 2) * 12 + 4 + 4]; }
+  else if (left_mod) {
+    const int k = lane - 56;                    // 0..3: luma rows 12..15, 4..7: chroma rows 6..7 of both planes
+    if (k < 4) (etop - 24)[k * 4 + 3] = * (const uint32_t*)&S.y[(k + 12 + 4) * 24];
+    else { const int c = k - 4; (etop - 24)[16 + c * 2 + 1] = * (const uint32_t*)&S.c[c >> 1][((c & 1) + 6 + 2) * 12]; }
+  }
+  WV_LANES_END
+}
+
+// ---- exchange of border strips between the wavefronts of a workgroup ------------------------------------------
+// The four rows / columns of samples that a MB shares with the MB below / to its right are handed over through LDS
+// instead of through the picture in HBM: a sample just written by a neighbour wave would otherwise be read back through
+// a partially written cache line (an HBM fill) on the critical path of every macroblock, and the producer would have to
+// drain its stores before it may flag completion.  One entry per MB column holds rows 12..15 (luma) / 6..7 (chroma) of
+// the most recently filtered MB of that column, one entry per MB row its columns 12..15 / 4..7.
+//   top[col]  : 24 words = luma r(4) x w(4), then per plane r(2) x w(2)
+//   left[row] : 32 words = luma row(16), then per plane row(8)
+typedef struct WhDbXchg { uint32_t* top; uint32_t* left; int first_row; } WhDbXchg;
+WH_HDFN size_t wh_db_xchg_words (int mb_w, int rows) { return (size_t)mb_w * 24 + (size_t)rows * 32; }
+
 // `G` holds this MB's staged inputs (wh_deblock_cold_fetch, landed); when next_valid the staging area is refilled for
-// (next_mbx, next_mby) as soon as it has been emptied.
-WH_FN void wh_deblock_mb_body (WhDbLds& S, WhDbStage& G, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, int next_valid, int next_mbx, int next_mby) {
+// (next_mbx, next_mby) as soon as it has been emptied.  `first` = first MB address of the workgroup's slice: neighbours
+// at or after it exchange strips through `E`, earlier ones (another workgroup) through the picture in HBM.
+WH_FN void wh_deblock_mb_body (WhDbLds& S, WhDbStage& G, const WhDbXchg& E, int first, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby,
+                               int next_valid, int next_mbx, int next_mby) {
+  const int w = P.mb_w, xy = mby * w + mbx;
+  const bool top_lds = mby > 0 && xy - w >= first, left_lds = mbx > 0 && xy - 1 >= first;
+  uint32_t* etop = E.top + mbx * 24;
+  uint32_t* eleft = E.left + (mby - E.first_row) * 32;
   // ---- the neighbours' strips (only now final: the caller has waited for them) + the staged inputs into the tile ----
   WV_LANES_BEGIN (lane)
   {
-    uint32_t v;
-    if (lane < 20) {                            // luma rows -4..-1, words x = -4..15
-      const int row = lane / 5 - 4, x = (lane % 5) * 4 - 4;
-      v = * (const WH_G uint32_t*) ((const WH_G uint8_t*)J.rec[0] + (ptrdiff_t) (mby * 16 + row) * P.rec_stride_y + mbx * 16 + x);
-    } else if (lane < 36) {                     // luma rows 0..15, word x = -4
-      v = * (const WH_G uint32_t*) ((const WH_G uint8_t*)J.rec[0] + (ptrdiff_t) (mby * 16 + lane - 20) * P.rec_stride_y + mbx * 16 - 4);
-    } else if (lane < 48) {                     // chroma rows -2..-1, words x = -4..7
-      const int k = lane - 36, pl = k / 6, row = (k % 6) / 3 - 2, x = (k % 3) * 4 - 4;
-      v = * (const WH_G uint32_t*) ((const WH_G uint8_t*)J.rec[1 + pl] + (ptrdiff_t) (mby * 8 + row) * P.rec_stride_c + mbx * 8 + x);
-    } else {                                    // chroma rows 0..7, word x = -4
-      const int k = lane - 48, pl = k >> 3, row = k & 7;
-      v = * (const WH_G uint32_t*) ((const WH_G uint8_t*)J.rec[1 + pl] + (ptrdiff_t) (mby * 8 + row) * P.rec_stride_c + mbx * 8 - 4);
+    uint32_t v = 0;
+    // lanes 0..15: luma rows -4..-1, words x = 0..12; 16..31: luma rows 0..15, word x = -4;
+    // 32..39: chroma rows -2..-1, words x = 0,4 per plane; 40..55: chroma rows 0..7, word x = -4 per plane
+    if (lane < 16) {
+      const int r = lane >> 2, wd = lane & 3;
+      if (top_lds) v = etop[lane];
+      else if (mby > 0) v = * (const WH_G uint32_t*) ((const WH_G uint8_t*)J.rec[0] + (ptrdiff_t) (mby * 16 + r - 4) * P.rec_stride_y + mbx * 16 + wd * 4);
+    } else if (lane < 32) {
+      const int row = lane - 16;
+      if (left_lds) v = eleft[row];
+      else if (mbx > 0) v = * (const WH_G uint32_t*) ((const WH_G uint8_t*)J.rec[0] + (ptrdiff_t) (mby * 16 + row) * P.rec_stride_y + mbx * 16 - 4);
+    } else if (lane < 40) {
+      const int k = lane - 32, pl = k >> 2, r = (k >> 1) & 1, wd = k & 1;
+      if (top_lds) v = etop[16 + k];
+      else if (mby > 0) v = * (const WH_G uint32_t*) ((const WH_G uint8_t*)J.rec[1 + pl] + (ptrdiff_t) (mby * 8 + r - 2) * P.rec_stride_c + mbx * 8 + wd * 4);
+    } else if (lane < 56) {
+      const int k = lane - 40, pl = k >> 3, row = k & 7;
+      if (left_lds) v = eleft[16 + k];
+      else if (mbx > 0) v = * (const WH_G uint32_t*) ((const WH_G uint8_t*)J.rec[1 + pl] + (ptrdiff_t) (mby * 8 + row) * P.rec_stride_c + mbx * 8 - 4);
     }
     S.st[lane] = G.st[lane];
     if (lane < 44) S.st[64 + lane] = G.st[64 + lane];
     * (uint32_t*)&S.y[((lane >> 2) + 4) * 24 + (lane & 3) * 4 + 4] = G.y[lane];
     if (lane < 32) { const int pl = lane >> 4, row = (lane >> 1) & 7, half = lane & 1; * (uint32_t*)&S.c[pl][(row + 2) * 12 + half * 4 + 4] = G.c[lane]; }
-    if (lane < 20) * (uint32_t*)&S.y[(lane / 5) * 24 + (lane % 5) * 4] = v;
-    else if (lane < 36) * (uint32_t*)&S.y[(lane - 20 + 4) * 24] = v;
-    else if (lane < 48) { const int k = lane - 36; * (uint32_t*)&S.c[k / 6][((k % 6) / 3) * 12 + (k % 3) * 4] = v; }
-    else { const int k = lane - 48; * (uint32_t*)&S.c[k >> 3][((k & 7) + 2) * 12] = v; }
+    if (lane < 16) * (uint32_t*)&S.y[(lane >> 2) * 24 + (lane & 3) * 4 + 4] = v;
+    else if (lane < 32) * (uint32_t*)&S.y[(lane - 16 + 4) * 24] = v;
+    else if (lane < 40) { const int k = lane - 32; * (uint32_t*)&S.c[k >> 2][((k >> 1) & 1) * 12 + (k & 1) * 4 + 4] = v; }
+    else if (lane < 56) { const int k = lane - 40; * (uint32_t*)&S.c[k >> 3][((k & 7) + 2) * 12] = v; }
   }
   WV_LANES_END
   if (next_valid) {
@@ -131,7 +172,6 @@ WH_FN void wh_deblock_mb_body (WhDbLds& S, WhDbStage& G, const WhSeqParams& P, c
     wh_deblock_cold_fetch (G, lane, P, J, next_mbx, next_mby);
     WV_LANES_END
   }
-  const int w = P.mb_w;
 
   const WhMbState* M = (const WhMbState*)&S.st[0];
   const WhMbState* Nl = (const WhMbState*)&S.st[36];
@@ -170,7 +210,7 @@ WH_FN void wh_deblock_mb_body (WhDbLds& S, WhDbStage& G, const WhSeqParams& P, c
   }
   WV_LANES_END
   WV_ANY (any_bs, lane, (lane < 32 && S.bs[lane >> 4][(lane >> 2) & 3][lane & 3] != 0));
-  if (!any_bs) return;                          // nothing to filter: the picture keeps this MB's pixels as they are
+  if (!any_bs) { wh_db_publish (S, etop, eleft, false); return; }    // nothing to filter: the picture keeps this MB's pixels as they are
 
   const int qp = M->luma_qp, qpc = M->chroma_qp;
   // ---- vertical edges (dir 0) then horizontal edges (dir 1) ----
@@ -223,4 +263,5 @@ WH_FN void wh_deblock_mb_body (WhDbLds& S, WhDbStage& G, const WhSeqParams& P, c
     }
   }
   WV_LANES_END
+  wh_db_publish (S, etop, eleft, left_ok && left_lds);
 }

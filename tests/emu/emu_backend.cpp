@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <chrono>
+#include <vector>
 #include "../../openh264_amd/csrc/host/backend.h"
 #include "../../openh264_amd/csrc/kernels/frame_kernels.h"
 #include "../../openh264_amd/csrc/kernels/deblock_mb.h"
@@ -65,20 +66,26 @@ class EmuBackend : public Backend {
       }
   }
   void run_deblock (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
-    // one emulated wavefront per picture, with the device scheduler's one-MB look-ahead
-    const int num_mb = P.mb_w * P.mb_h;
-    for (int j = 0; j < n; ++j) {
-      WhDbLds S;
-      WhDbStage G;
-      poison (&S, sizeof (S)); poison (&G, sizeof (G));
-      const uint16_t* order = P.mb_order + num_mb;
-      for (int lane = 0; lane < 64; ++lane) wh_deblock_cold_fetch (G, lane, P, jobs[j], order[0] % P.mb_w, order[0] / P.mb_w);
-      for (int t = 0; t < num_mb; ++t) {
-        const int xy = order[t], xyn = t + 1 < num_mb ? order[t + 1] : 0;
-        wh_deblock_mb_body (S, G, P, jobs[j], xy % P.mb_w, xy / P.mb_w, t + 1 < num_mb, xyn % P.mb_w, xyn / P.mb_w);
-        poison (&S, sizeof (S));
+    // one emulated wavefront per slice (slice s after slice s-1, which satisfies the seam dependencies), with the device
+    // scheduler's one-MB look-ahead and its strip exchange: neighbours inside the slice through the exchange buffers,
+    // neighbours in the previous slice through the picture
+    for (int j = 0; j < n; ++j)
+      for (int s = 0; s < P.num_slices; ++s) {
+        WhDbLds S;
+        WhDbStage G;
+        std::vector<uint32_t> xb (wh_db_xchg_words (P.mb_w, P.mb_h), 0xA5A5A5A5u);
+        WhDbXchg E;
+        E.top = xb.data(); E.left = xb.data() + (size_t)P.mb_w * 24; E.first_row = 0;
+        poison (&S, sizeof (S)); poison (&G, sizeof (G));
+        const int first = P.slice_first_mb[s], last = P.slice_first_mb[s + 1];
+        const uint16_t* order = P.mb_order;
+        for (int lane = 0; lane < 64; ++lane) wh_deblock_cold_fetch (G, lane, P, jobs[j], order[first] % P.mb_w, order[first] / P.mb_w);
+        for (int t = first; t < last; ++t) {
+          const int xy = order[t], xyn = t + 1 < last ? order[t + 1] : 0;
+          wh_deblock_mb_body (S, G, E, first, P, jobs[j], xy % P.mb_w, xy / P.mb_w, t + 1 < last, xyn % P.mb_w, xyn / P.mb_w);
+          poison (&S, sizeof (S));
+        }
       }
-    }
   }
   void run_expand (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
     for (int j = 0; j < n; ++j) {
