@@ -36,7 +36,7 @@ __device__ __forceinline__ bool wh_wait_done (const uint32_t* done, int idx, uin
   if (idx < 0) return true;
   uint32_t spins = 0;
   while (!((__hip_atomic_load (&done[idx >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> (idx & 31)) & 1u)) {
-    __builtin_amdgcn_s_sleep (2);
+    __builtin_amdgcn_s_sleep (4);
     if (++spins > WH_SPIN_LIMIT) {
       if ((threadIdx.x & 63) == 0 && atomicAdd (err, 1u) == 0) { err[1] = blockIdx.x; err[2] = blockIdx.y; err[3] = (uint32_t)idx; }
       return false;
