@@ -226,7 +226,7 @@ __global__ __launch_bounds__ (1024) void k_deblock_slices (WhSeqParams P, const 
     if (remote) __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "agent");
     else __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "workgroup");
     WV_ASYNC_WAIT();                            // this MB's staged inputs have landed
-    wh_deblock_mb_body (S, G, E, first, P, J, xy % w, xy / w, tn < n, xyn % w, xyn / w);
+    const bool drain = wh_deblock_mb_body (S, G, E, first, last, P, J, xy % w, xy / w, tn < n, xyn % w, xyn / w);
     // MBs a later slice may wait for: its left neighbour (xy + 1), top (xy + w) or top-right consumer (xy + w - 1)
     const bool publish = cross && xy + w + 1 >= last && last < num_mb;
     if (publish) {
@@ -234,9 +234,12 @@ __global__ __launch_bounds__ (1024) void k_deblock_slices (WhSeqParams P, const 
       __builtin_amdgcn_fence (__ATOMIC_RELEASE, "agent");
       asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
       if (lane == 0) __hip_atomic_store (&flags[xy], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
+    } else if (drain) {
       __builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");
     }
+    // inside the workgroup the hand-off is LDS only (strip exchange + flag, executed in order by the LDS unit): the
+    // wave's global stores need not have completed -- no other MB of the slice writes or reads those samples
+    WV_SYNC();
     if (lane == 0) atomicOr (&sched[1 + ((xy - first) >> 5)], 1u << ((xy - first) & 31));
     if (tn >= n) break;
     xy = xyn;

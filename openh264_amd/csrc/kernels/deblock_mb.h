@@ -126,9 +126,16 @@ typedef struct WhDbXchg { uint32_t* top; uint32_t* left; int first_row; } WhDbXc
 WH_HDFN size_t wh_db_xchg_words (int mb_w, int rows) { return (size_t)mb_w * 24 + (size_t)rows * 32; }
 
 // `G` holds this MB's staged inputs (wh_deblock_cold_fetch, landed); when next_valid the staging area is refilled for
-// (next_mbx, next_mby) as soon as it has been emptied.  `first` = first MB address of the workgroup's slice: neighbours
-// at or after it exchange strips through `E`, earlier ones (another workgroup) through the picture in HBM.
-WH_FN void wh_deblock_mb_body (WhDbLds& S, WhDbStage& G, const WhDbXchg& E, int first, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby,
+// (next_mbx, next_mby) as soon as it has been emptied.  [first, last) = MB addresses of the workgroup's slice: neighbours
+// inside it exchange strips through `E`, the others (another workgroup) through the picture in HBM.
+//
+// Every sample of the picture is written by exactly ONE macroblock of the slice, so a wave never has to wait for its
+// stores before it flags completion: of an MB's 16x16 samples the right four columns belong to the right neighbour and
+// the bottom four rows to the MB below (the corner to the latter) whenever that neighbour is inside the slice -- it
+// receives them through `E`, possibly filters them, and writes them.  Without such a neighbour the MB writes them itself.
+// Returns true when the caller must drain this wave's stores before it flags the MB done inside the workgroup (the MB
+// rewrote samples of another slice's MBs that a later MB of this workgroup reads back from the picture).
+WH_FN bool wh_deblock_mb_body (WhDbLds& S, WhDbStage& G, const WhDbXchg& E, int first, int last, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby,
                                int next_valid, int next_mbx, int next_mby) {
   const int w = P.mb_w, xy = mby * w + mbx;
   const bool top_lds = mby > 0 && xy - w >= first, left_lds = mbx > 0 && xy - 1 >= first;
@@ -210,8 +217,8 @@ WH_FN void wh_deblock_mb_body (WhDbLds& S, WhDbStage& G, const WhDbXchg& E, int 
   }
   WV_LANES_END
   WV_ANY (any_bs, lane, (lane < 32 && S.bs[lane >> 4][(lane >> 2) & 3][lane & 3] != 0));
-  if (!any_bs) { wh_db_publish (S, etop, eleft, false); return; }    // nothing to filter: the picture keeps this MB's pixels as they are
-
+  const bool filtered = any_bs != 0;           // nothing to filter: the MB's own samples stay as mode decision left them
+  if (filtered) {
   const int qp = M->luma_qp, qpc = M->chroma_qp;
   // ---- vertical edges (dir 0) then horizontal edges (dir 1) ----
   for (int dir = 0; dir < 2; ++dir) {
@@ -246,22 +253,32 @@ WH_FN void wh_deblock_mb_body (WhDbLds& S, WhDbStage& G, const WhDbXchg& E, int 
     }
   }
 
-  // ---- store back rows -3..15 (luma) / -1..7 (chroma) as words; the left words only when the left edge was filtered,
-  //      the rows above only when the top edge was, never the corner (it belongs to neither neighbour filtered here) ----
+  }   // filtered
+
+  // ---- write-back (see the ownership rule above) ----
+  const bool right_in = mbx < w - 1 && xy + 1 < last, below_in = xy + w < last;
+  const bool lb_none = xy - 1 + w >= last;        // the left MB has no neighbour below it inside the slice
   WV_LANES_BEGIN (lane)
   {
     WH_G uint8_t* ry = (WH_G uint8_t*)J.rec[0] + (ptrdiff_t) (mby * 16) * P.rec_stride_y + mbx * 16;
-    for (int i = lane; i < 19 * 5; i += 64) {
-      const int row = i / 5 - 3, x = (i % 5) * 4 - 4;
-      if ((row >= 0 || top_ok) && (x >= 0 || left_ok) && !(row < 0 && x < 0))
-        * (WH_G uint32_t*) (ry + (ptrdiff_t)row * P.rec_stride_y + x) = * (const uint32_t*)&WH_DY (S, x, row);
+    for (int i = lane; i < 20 * 5; i += 64) {
+      const int row = i / 5 - 4, x = (i % 5) * 4 - 4;
+      bool wr;
+      if (row < 0) wr = x >= 0 && (top_lds ? true : (filtered && top_ok && row >= -3));
+      else if (x < 0) wr = left_lds ? (row < 12 || lb_none) : (filtered && left_ok);
+      else wr = filtered && (row < 12 || !below_in) && (x < 12 || !right_in);
+      if (wr) * (WH_G uint32_t*) (ry + (ptrdiff_t)row * P.rec_stride_y + x) = * (const uint32_t*)&WH_DY (S, x, row);
     }
-    if (lane < 54) {
-      const int pl = lane / 27, k = lane % 27, row = k / 3 - 1, x = (k % 3) * 4 - 4;
-      if ((row >= 0 || top_ok) && (x >= 0 || left_ok) && !(row < 0 && x < 0))
-        * (WH_G uint32_t*) ((WH_G uint8_t*)J.rec[1 + pl] + (ptrdiff_t) (mby * 8 + row) * P.rec_stride_c + mbx * 8 + x) = * (const uint32_t*)&WH_DC (S, pl, x, row);
+    if (lane < 60) {
+      const int pl = lane / 30, k = lane % 30, row = k / 3 - 2, x = (k % 3) * 4 - 4;
+      bool wr;
+      if (row < 0) wr = x >= 0 && (top_lds ? true : (filtered && top_ok && row >= -1));
+      else if (x < 0) wr = left_lds ? (row < 6 || lb_none) : (filtered && left_ok);
+      else wr = filtered && (row < 6 || !below_in) && (x < 4 || !right_in);
+      if (wr) * (WH_G uint32_t*) ((WH_G uint8_t*)J.rec[1 + pl] + (ptrdiff_t) (mby * 8 + row) * P.rec_stride_c + mbx * 8 + x) = * (const uint32_t*)&WH_DC (S, pl, x, row);
     }
   }
   WV_LANES_END
-  wh_db_publish (S, etop, eleft, left_ok && left_lds);
+  wh_db_publish (S, etop, eleft, filtered && left_ok && left_lds);
+  return filtered && ((left_ok && !left_lds) || (top_ok && !top_lds));
 }

@@ -82,7 +82,7 @@ class EmuBackend : public Backend {
         for (int lane = 0; lane < 64; ++lane) wh_deblock_cold_fetch (G, lane, P, jobs[j], order[first] % P.mb_w, order[first] / P.mb_w);
         for (int t = first; t < last; ++t) {
           const int xy = order[t], xyn = t + 1 < last ? order[t + 1] : 0;
-          wh_deblock_mb_body (S, G, E, first, P, jobs[j], xy % P.mb_w, xy / P.mb_w, t + 1 < last, xyn % P.mb_w, xyn / P.mb_w);
+          (void)wh_deblock_mb_body (S, G, E, first, last, P, jobs[j], xy % P.mb_w, xy / P.mb_w, t + 1 < last, xyn % P.mb_w, xyn / P.mb_w);
           poison (&S, sizeof (S));
         }
       }
