@@ -132,6 +132,10 @@ __global__ __launch_bounds__ (MAXT) void k_inter_slice (WhSeqParams P, const WhP
   X.win_stage = WhWinStageLds<MAXT / 64, WINPF>::get (wave);
   X.win = &winbuf[wave];
   X.slice_idc = (int)blockIdx.x; X.slice_first = first;
+  // WELSHIP look-ahead (lookahead != 0): a wave takes the ticket of its NEXT macroblock before it starts the current one,
+  // so that the body can fetch the next MB's cold inputs underneath its own arithmetic.  Without it the wave takes a
+  // ticket only when it is free and starts that MB's cold loads before it waits for the neighbours.
+  const bool lookahead = P.pad[0] != 0;
   int t = 0;
   if (lane == 0) t = (int)atomicAdd (&sched[0], 1u);
   t = __builtin_amdgcn_readfirstlane (t);
@@ -139,10 +143,12 @@ __global__ __launch_bounds__ (MAXT) void k_inter_slice (WhSeqParams P, const WhP
     int xy = order[t];
     wh_inter_cold_fetch (G, lane, P, J, xy % P.mb_w, xy / P.mb_w);
     for (int guard = 0; guard <= n; ++guard) {
-      int tn = 0;
-      if (lane == 0) tn = (int)atomicAdd (&sched[0], 1u);
-      tn = __builtin_amdgcn_readfirstlane (tn);
-      const int xyn = tn < n ? (int)order[tn] : 0;
+      int tn = n;
+      if (lookahead) {
+        if (lane == 0) tn = (int)atomicAdd (&sched[0], 1u);
+        tn = __builtin_amdgcn_readfirstlane (tn);
+      }
+      int xyn = tn < n ? (int)order[tn] : 0;
       WH_PROF_MARK (P, S.m, 11);
       int dep_a, dep_b;
       wh_mb_deps (P.mb_w, xy, first, &dep_a, &dep_b);
@@ -157,6 +163,13 @@ __global__ __launch_bounds__ (MAXT) void k_inter_slice (WhSeqParams P, const WhP
       __builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");
       if (lane == 0) atomicOr (&sched[1 + ((xy - first) >> 5)], 1u << ((xy - first) & 31));
       WH_PROF_MARK (P, S.m, 13);
+      if (!lookahead) {
+        if (lane == 0) tn = (int)atomicAdd (&sched[0], 1u);
+        tn = __builtin_amdgcn_readfirstlane (tn);
+        if (tn >= n) break;
+        xyn = order[tn];
+        wh_inter_cold_fetch (G, lane, P, J, xyn % P.mb_w, xyn / P.mb_w);     /* in flight while the wave waits for the neighbours */
+      }
       if (tn >= n) break;
       xy = xyn;
     }
@@ -195,17 +208,15 @@ __global__ __launch_bounds__ (1024) void k_deblock_slices (WhSeqParams P, const 
   const bool cross = P.deblock_idc == 0;        // idc 2: nothing is filtered (or needed) across slices
   __shared__ WhDbStage stage[16];                 // separate LDS object (see WhInterStage)
   WhDbStage& G = stage[wave];
-  int t = 0;
-  if (lane == 0) t = (int)atomicAdd (&sched[0], 1u);
-  t = __builtin_amdgcn_readfirstlane (t);
-  if (t >= n) return;
-  int xy = order[t];
-  wh_deblock_cold_fetch (G, lane, P, J, xy % w, xy / w);
   for (int guard = 0; guard <= n; ++guard) {
-    int tn = 0;                                 // look-ahead: this wave's next MB (its inputs are staged during this one)
-    if (lane == 0) tn = (int)atomicAdd (&sched[0], 1u);
-    tn = __builtin_amdgcn_readfirstlane (tn);
-    const int xyn = tn < n ? (int)order[tn] : 0;
+    // a wave takes a ticket only when it is free (a held ticket could be the one the whole dependency chain is waiting
+    // for), starts the loads of that MB's own inputs at once and waits for the neighbours while they are in flight
+    int t = 0;
+    if (lane == 0) t = (int)atomicAdd (&sched[0], 1u);
+    t = __builtin_amdgcn_readfirstlane (t);
+    if (t >= n) break;
+    const int xy = order[t];
+    wh_deblock_cold_fetch (G, lane, P, J, xy % w, xy / w);
     int dep_a, dep_b;                           // picture-wide dependencies: left, top-right (top at the right edge)
     wh_mb_deps (w, xy, 0, &dep_a, &dep_b);
     bool remote = false, ok = true;
@@ -226,7 +237,7 @@ __global__ __launch_bounds__ (1024) void k_deblock_slices (WhSeqParams P, const 
     if (remote) __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "agent");
     else __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "workgroup");
     WV_ASYNC_WAIT();                            // this MB's staged inputs have landed
-    const bool drain = wh_deblock_mb_body (S, G, E, first, last, P, J, xy % w, xy / w, tn < n, xyn % w, xyn / w);
+    const bool drain = wh_deblock_mb_body (S, G, E, first, last, P, J, xy % w, xy / w, 0, 0, 0);
     // MBs a later slice may wait for: its left neighbour (xy + 1), top (xy + w) or top-right consumer (xy + w - 1)
     const bool publish = cross && xy + w + 1 >= last && last < num_mb;
     if (publish) {
@@ -241,8 +252,6 @@ __global__ __launch_bounds__ (1024) void k_deblock_slices (WhSeqParams P, const 
     // wave's global stores need not have completed -- no other MB of the slice writes or reads those samples
     WV_SYNC();
     if (lane == 0) atomicOr (&sched[1 + ((xy - first) >> 5)], 1u << ((xy - first) & 31));
-    if (tn >= n) break;
-    xy = xyn;
   }
 }
 
@@ -326,12 +335,16 @@ class HipBackend : public wh::Backend {
   void run_inter (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
     static const int forced = getenv ("WELSHIP_P_WAVES") ? atoi (getenv ("WELSHIP_P_WAVES")) : 0;
     const int waves = forced ? forced : (P.num_slices * n >= 2 * cus_ ? 6 : 12);
-    if (waves == 8) mb_pass (k_inter_slice<512, true>, sizeof (WhInterLds), 8, false, P, jobs, n, 8 * (sizeof (WhInterStage) + sizeof (WhWinStage) + sizeof (WhWinLds)) + sizeof (WhPicJob));
-    else if (waves <= 6) mb_pass (k_inter_slice<384, false>, sizeof (WhInterLds), 6, false, P, jobs, n, 6 * (sizeof (WhInterStage) + sizeof (WhWinLds)) + sizeof (WhPicJob));
-    else mb_pass (k_inter_slice<768, false>, sizeof (WhInterLds), 12, false, P, jobs, n, 12 * (sizeof (WhInterStage) + sizeof (WhWinLds)) + sizeof (WhPicJob));
+    static const int lookahead = getenv ("WELSHIP_P_LOOKAHEAD") ? atoi (getenv ("WELSHIP_P_LOOKAHEAD")) : 0;    // measured: holding a ticket ahead costs more than it hides
+    WhSeqParams Q = P;
+    Q.pad[0] = lookahead;
+    if (waves == 8) mb_pass (k_inter_slice<512, true>, sizeof (WhInterLds), 8, false, Q, jobs, n, 8 * (sizeof (WhInterStage) + sizeof (WhWinStage) + sizeof (WhWinLds)) + sizeof (WhPicJob));
+    else if (waves <= 6) mb_pass (k_inter_slice<384, false>, sizeof (WhInterLds), 6, false, Q, jobs, n, 6 * (sizeof (WhInterStage) + sizeof (WhWinLds)) + sizeof (WhPicJob));
+    else mb_pass (k_inter_slice<768, false>, sizeof (WhInterLds), 12, false, Q, jobs, n, 12 * (sizeof (WhInterStage) + sizeof (WhWinLds)) + sizeof (WhPicJob));
   }
   void run_deblock (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
-    mb_pass (k_deblock_slices, sizeof (WhDbLds), 16, false, P, jobs, n, 16 * sizeof (WhDbStage) + sizeof (WhPicJob), 4 * wh_db_xchg_words (P.mb_w, P.mb_h));
+    static const int db_waves = getenv ("WELSHIP_DB_WAVES") ? atoi (getenv ("WELSHIP_DB_WAVES")) : 16;
+    mb_pass (k_deblock_slices, sizeof (WhDbLds), db_waves, false, P, jobs, n, 16 * sizeof (WhDbStage) + sizeof (WhPicJob), 4 * wh_db_xchg_words (P.mb_w, P.mb_h));
   }
   void run_expand (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
     hipLaunchKernelGGL (k_expand, dim3 (wh_expand_num_blocks (P), n), dim3 (64), 0, stream_, P, jobs);
