@@ -35,7 +35,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--sessions", type=int, default=int(os.environ.get("WELSHIP_BENCH_SESSIONS", "128")), help="independent pictures per GPU per step")
+    ap.add_argument("--sessions", type=int, default=int(os.environ.get("WELSHIP_BENCH_SESSIONS", "0")),
+                    help="independent pictures per GPU per step (default: 128 for the P workload = two slice workgroups per CU, 256 for all-IDR = one picture workgroup per CU)")
     ap.add_argument("--queues", type=int, default=int(os.environ.get("WELSHIP_QUEUES", "1")), help="device queues the sessions are spread over (kernels of different queues overlap)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -92,6 +93,8 @@ def main():
     workload = a.workload
     if workload == "auto":
         workload = "p" if getattr(oh, "HAS_INTER_PATH", False) else "intra"
+    if a.sessions <= 0:
+        a.sessions = 128 if workload == "p" else 256
     w, h = a.width, a.height
     mbs = ((w + 15) // 16) * ((h + 15) // 16)
     ring = 1 if workload == "intra" else 8

@@ -98,3 +98,29 @@ def test_product_library_fails_loudly_without_gpu(hip_lib):
     p.iPicWidth, p.iPicHeight = 64, 64
     assert enc.InitializeExt(p) == oh.ERR_NO_DEVICE
     assert "no usable device" in enc.last_error()
+
+
+def _live_4k(lib_path, ref_tools, tmp_path):
+    """Largest supported picture (4096x2304, 36864 MBs, 4 slices, IDR + P) against oracle/_ref run live."""
+    if not ref_tools:
+        pytest.skip("oracle/_ref not built")
+    w, h = 4096, 2304
+    yuv = synth_sequence(w, h, 2)
+    bs, recon = oh.encode_sequence(yuv, w, h, lib_path=lib_path, iDLayerQp=28, uiIntraPeriod=0, fMaxFrameRate=30.0,
+                                   iTargetBitrate=5000000, uiSliceMode=1, uiSliceNum=4)
+    fi, fo, fd = str(tmp_path / "in.yuv"), str(tmp_path / "ref.264"), str(tmp_path / "dec.yuv")
+    open(fi, "wb").write(yuv)
+    subprocess.check_call([ref_tools["enc"], "-i", fi, "-w", str(w), "-h", str(h), "-o", fo, "-rc", "-1", "-qp", "28", "-fps", "30",
+                           "-iper", "0", "-slcmd", "1", "-slcnum", "4", "-quiet"], stdout=subprocess.DEVNULL)
+    assert open(fo, "rb").read() == bs
+    subprocess.check_call([ref_tools["dec"], fo, fd], stdout=subprocess.DEVNULL)
+    assert open(fd, "rb").read()[-w * h * 3 // 2:] == recon
+
+
+def test_emu_4k(emu_lib, ref_tools, tmp_path):
+    _live_4k(emu_lib, ref_tools, tmp_path)
+
+
+@pytest.mark.gpu
+def test_hip_4k(hip_lib, ref_tools, tmp_path):
+    _live_4k(hip_lib, ref_tools, tmp_path)
