@@ -17,10 +17,10 @@ WH_FN void wh_expand_body (const WhSeqParams& P, const WhPicJob& J, int blk) {
   int pl, row, w, h, pad, stride;
   if (blk < lh) { pl = 0; row = blk - 32; w = P.mb_w * 16; h = P.mb_h * 16; pad = 32; stride = P.rec_stride_y; }
   else { const int b = blk - lh; pl = 1 + b / ch; row = b % ch - 16; w = P.mb_w * 8; h = P.mb_h * 8; pad = 16; stride = P.rec_stride_c; }
-  uint8_t* base = J.rec[pl];
+  WH_G uint8_t* base = (WH_G uint8_t*)J.rec[pl];
   const int sy = row < 0 ? 0 : (row >= h ? h - 1 : row);
-  const uint8_t* srow = base + (ptrdiff_t)sy * stride;
-  uint8_t* drow = base + (ptrdiff_t)row * stride;
+  const WH_G uint8_t* srow = base + (ptrdiff_t)sy * stride;
+  WH_G uint8_t* drow = base + (ptrdiff_t)row * stride;
   WV_LANES_BEGIN (lane)
   if (row >= 0 && row < h) {
     if (lane < pad) drow[-pad + lane] = srow[0];

@@ -15,33 +15,35 @@ static_assert (sizeof (WhMbState) == 144, "WhMbState must be 144 bytes");
 WH_FN void wh_store_mb (WhMbLds& S, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, int mb_type, int cbp,
                         int qp, int qpc, int i16_mode, int chroma_mode, int cost, int slice_idc) {
   const int xy = mby * P.mb_w + mbx;
-  WhMbRecord* R = &J.records[xy];
-  WhMbState* M = &J.mbs[xy];
+  // explicit global address space: generic (flat) stores would also count against lgkmcnt and make every later LDS read
+  // of the wave wait for them
+  WH_G WhMbRecord* R = (WH_G WhMbRecord*)J.records + xy;
+  WH_G WhMbState* M = (WH_G WhMbState*)J.mbs + xy;
   WV_LANES_BEGIN (lane)
   {
     const int row = lane >> 2, seg = lane & 3;
-    uint8_t* d = J.rec[0] + (size_t) (mby * 16 + row) * P.rec_stride_y + mbx * 16 + seg * 4;
-    * (uint32_t*)d = * (const uint32_t*)&WH_RY (S, seg * 4, row);
+    WH_G uint8_t* d = (WH_G uint8_t*)J.rec[0] + (size_t) (mby * 16 + row) * P.rec_stride_y + mbx * 16 + seg * 4;
+    * (WH_G uint32_t*)d = * (const uint32_t*)&WH_RY (S, seg * 4, row);
   }
   if (lane < 32) {
     const int pl = lane >> 4, row = (lane >> 1) & 7, half = lane & 1;
-    uint8_t* d = J.rec[1 + pl] + (size_t) (mby * 8 + row) * P.rec_stride_c + mbx * 8 + half * 4;
-    * (uint32_t*)d = * (const uint32_t*)&WH_RC (S, pl, half * 4, row);
+    WH_G uint8_t* d = (WH_G uint8_t*)J.rec[1 + pl] + (size_t) (mby * 8 + row) * P.rec_stride_c + mbx * 8 + half * 4;
+    * (WH_G uint32_t*)d = * (const uint32_t*)&WH_RC (S, pl, half * 4, row);
   }
   // coefficient levels: 4 luma + 2 chroma-AC int16 quads per lane
   {
     const uint64_t* s = (const uint64_t*)S.lv_luma;
-    uint64_t* d = (uint64_t*)&R->luma[0][0];
+    WH_G uint64_t* d = (WH_G uint64_t*)&R->luma[0][0];
     d[lane] = s[lane];
   }
   if (lane < 32) {
     const uint64_t* s = (const uint64_t*)S.lv_cac;
-    uint64_t* d = (uint64_t*)&R->chroma_ac[0][0];
+    WH_G uint64_t* d = (WH_G uint64_t*)&R->chroma_ac[0][0];
     d[lane] = s[lane];
   } else if (lane < 48) {
     R->luma_dc[lane - 32] = (mb_type == WH_MB_I16x16) ? S.lv_dc[lane - 32] : (int16_t)0;
   } else if (lane < 56) {
-    (&R->chroma_dc[0][0])[lane - 48] = S.lv_cdc[lane - 48];
+    ((WH_G int16_t*)&R->chroma_dc[0][0])[lane - 48] = S.lv_cdc[lane - 48];
   }
   if (lane < 24) { R->nzc[lane] = S.nzc[lane]; M->nzc[lane] = S.nzc[lane]; }
   if (lane < 16) {
@@ -70,8 +72,10 @@ WH_FN void wh_intra_mb_body (WhMbLds& S, const WhSeqParams& P, const WhPicJob& J
   wh_intra_md_enc (S, P, J, mbx, mby, avail, qp, qpc, &r);
   // intra MBs carry no motion: clear mv/ref so that later P pictures / deblocking see zeros
   WV_LANES_BEGIN (lane)
-  if (lane < 16) { J.mbs[xy].mv[lane][0] = 0; J.mbs[xy].mv[lane][1] = 0; J.records[xy].mvd[lane][0] = 0; J.records[xy].mvd[lane][1] = 0; }
-  if (lane < 4) { J.mbs[xy].ref_idx[lane] = -1; J.records[xy].ref_idx[lane] = -1; J.records[xy].sub_type[lane] = 0; J.mbs[xy].sad_cost[lane] = 0; }
+  WH_G WhMbState* Ms = (WH_G WhMbState*)J.mbs + xy;
+  WH_G WhMbRecord* Rs = (WH_G WhMbRecord*)J.records + xy;
+  if (lane < 16) { Ms->mv[lane][0] = 0; Ms->mv[lane][1] = 0; Rs->mvd[lane][0] = 0; Rs->mvd[lane][1] = 0; }
+  if (lane < 4) { Ms->ref_idx[lane] = -1; Rs->ref_idx[lane] = -1; Rs->sub_type[lane] = 0; Ms->sad_cost[lane] = 0; }
   WV_LANES_END
   wh_store_mb (S, P, J, mbx, mby, r.mb_type, r.cbp, qp, qpc, r.i16_mode_std, r.chroma_mode_std, r.cost_luma, wh_slice_of_mb (P, xy));
 }

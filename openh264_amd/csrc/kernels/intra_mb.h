@@ -321,12 +321,12 @@ WH_FN bool wh_intra_md_enc_p (WhMbLds& S, const WhSeqParams& P, const WhPicJob& 
       int8_t m = -1;
       if (cy == 0 && cx > 0) {
         if (has_t) {
-          const WhMbState* n = &J.mbs[(mby - 1) * P.mb_w + mbx];
+          const WH_G WhMbState* n = (const WH_G WhMbState*)J.mbs + (mby - 1) * P.mb_w + mbx;
           m = (n->mb_type == WH_MB_I4x4) ? n->i4_mode[12 + cx - 1] : (int8_t)2;
         }
       } else if (cx == 0 && cy > 0) {
         if (has_l) {
-          const WhMbState* n = &J.mbs[mby * P.mb_w + mbx - 1];
+          const WH_G WhMbState* n = (const WH_G WhMbState*)J.mbs + mby * P.mb_w + mbx - 1;
           m = (n->mb_type == WH_MB_I4x4) ? n->i4_mode[(cy - 1) * 4 + 3] : (int8_t)2;
         }
       }
