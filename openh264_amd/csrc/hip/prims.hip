@@ -152,15 +152,17 @@ __global__ void k_pred4 (int n, const uint8_t* plane, int st, const int* off, co
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint8_t* ref = plane + off[i];
-  uint8_t E[13];
-  for (int k = 0; k < 4; ++k) E[3 - k] = ref[k * st - 1];
-  E[4] = ref[-st - 1];
-  for (int k = 0; k < 8; ++k) E[5 + k] = ref[-st + k];
+  uint8_t Eb[16] = {0};
+  for (int k = 0; k < 4; ++k) Eb[3 - k] = ref[k * st - 1];
+  Eb[4] = ref[-st - 1];
+  for (int k = 0; k < 8; ++k) Eb[5 + k] = ref[-st + k];
+  WhE13 E;
+  for (int k = 0; k < 4; ++k) E.w[k] = (uint32_t)Eb[4 * k] | ((uint32_t)Eb[4 * k + 1] << 8) | ((uint32_t)Eb[4 * k + 2] << 16) | ((uint32_t)Eb[4 * k + 3] << 24);
   const bool l = avail[i] & 1, t = avail[i] & 2;
   int dc = 128;
-  if (l && t) dc = (E[0] + E[1] + E[2] + E[3] + E[5] + E[6] + E[7] + E[8] + 4) >> 3;
-  else if (l) dc = (E[0] + E[1] + E[2] + E[3] + 2) >> 2;
-  else if (t) dc = (E[5] + E[6] + E[7] + E[8] + 2) >> 2;
+  if (l && t) dc = (Eb[0] + Eb[1] + Eb[2] + Eb[3] + Eb[5] + Eb[6] + Eb[7] + Eb[8] + 4) >> 3;
+  else if (l) dc = (Eb[0] + Eb[1] + Eb[2] + Eb[3] + 2) >> 2;
+  else if (t) dc = (Eb[5] + Eb[6] + Eb[7] + Eb[8] + 2) >> 2;
   for (int y = 0; y < 4; ++y) for (int x = 0; x < 4; ++x) out[i * 16 + y * 4 + x] = (uint8_t)wh_pred4_px (mode[i], x, y, E, dc);
 }
 // Intra16x16 / chroma 8x8 predictors through the macroblock tile code path (one wave per block)

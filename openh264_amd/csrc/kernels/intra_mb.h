@@ -178,42 +178,50 @@ WH_FN void wh_pred_chroma (WhMbLds& S, int mode, const int* st /*[pl][2] top sum
 }
 
 // ---- one row (4 pixels) of an Intra4x4 prediction, standard mode numbering 0..8 ------------------
-// E[0..12]: L3 L2 L1 L0 TL T0..T7   (so p[-1,j] = E[3-j], p[i,-1] = E[5+i], TL = E[4])
+// E (0..12): L3 L2 L1 L0 TL T0..T7   (so p[-1,j] = E (3-j), p[i,-1] = E (5+i), TL = E (4)), packed four per word: the
+// index varies per lane (mode, position), and a byte array would end up in scratch memory
+typedef struct WhE13 { uint32_t w[4]; } WhE13;
+WH_FN int wh_e13 (const WhE13& E, int i) {
+  const uint32_t v = i < 4 ? E.w[0] : i < 8 ? E.w[1] : i < 12 ? E.w[2] : E.w[3];
+  return (int) ((v >> (8 * (i & 3))) & 255u);
+}
 #define WH_F3(a, b, c) (((a) + 2 * (b) + (c) + 2) >> 2)
 #define WH_F2(a, b) (((a) + (b) + 1) >> 1)
-WH_FN int wh_pred4_px (int mode, int x, int y, const uint8_t* E, int dcval) {
+WH_FN int wh_pred4_px (int mode, int x, int y, const WhE13& EE, int dcval) {
+#define E(i) wh_e13 (EE, (i))
   switch (mode) {
-  case 0: return E[5 + x];                                   // V
-  case 1: return E[3 - y];                                   // H
+  case 0: return E (5 + x);                                   // V
+  case 1: return E (3 - y);                                   // H
   case 2: return dcval;                                      // DC family
   case 3:                                                    // DDL
-    if (x == 3 && y == 3) return (E[5 + 6] + 3 * E[5 + 7] + 2) >> 2;
-    return WH_F3 (E[5 + x + y], E[5 + x + y + 1], E[5 + x + y + 2]);
+    if (x == 3 && y == 3) return (E (5 + 6) + 3 * E (5 + 7) + 2) >> 2;
+    return WH_F3 (E (5 + x + y), E (5 + x + y + 1), E (5 + x + y + 2));
   case 4:                                                    // DDR
-    return WH_F3 (E[4 + x - y - 1], E[4 + x - y], E[4 + x - y + 1]);
+    return WH_F3 (E (4 + x - y - 1), E (4 + x - y), E (4 + x - y + 1));
   case 5: {                                                  // VR
     const int z = 2 * x - y, i = x - (y >> 1);
-    if (z >= 0) return (z & 1) ? WH_F3 (E[5 + i - 2], E[5 + i - 1], E[5 + i]) : WH_F2 (E[5 + i - 1], E[5 + i]);
-    if (z == -1) return WH_F3 (E[3], E[4], E[5]);
-    return WH_F3 (E[3 - (y - 1)], E[3 - (y - 2)], E[3 - (y - 3)]);
+    if (z >= 0) return (z & 1) ? WH_F3 (E (5 + i - 2), E (5 + i - 1), E (5 + i)) : WH_F2 (E (5 + i - 1), E (5 + i));
+    if (z == -1) return WH_F3 (E (3), E (4), E (5));
+    return WH_F3 (E (3 - (y - 1)), E (3 - (y - 2)), E (3 - (y - 3)));
   }
   case 6: {                                                  // HD
     const int z = 2 * y - x, j = y - (x >> 1);
-    if (z >= 0) return (z & 1) ? WH_F3 (E[3 - (j - 2)], E[3 - (j - 1)], E[3 - j]) : WH_F2 (E[3 - (j - 1)], E[3 - j]);
-    if (z == -1) return WH_F3 (E[3], E[4], E[5]);
-    return WH_F3 (E[5 + x - 1], E[5 + x - 2], E[5 + x - 3]);
+    if (z >= 0) return (z & 1) ? WH_F3 (E (3 - (j - 2)), E (3 - (j - 1)), E (3 - j)) : WH_F2 (E (3 - (j - 1)), E (3 - j));
+    if (z == -1) return WH_F3 (E (3), E (4), E (5));
+    return WH_F3 (E (5 + x - 1), E (5 + x - 2), E (5 + x - 3));
   }
   case 7: {                                                  // VL
     const int i = x + (y >> 1);
-    return (y & 1) ? WH_F3 (E[5 + i], E[5 + i + 1], E[5 + i + 2]) : WH_F2 (E[5 + i], E[5 + i + 1]);
+    return (y & 1) ? WH_F3 (E (5 + i), E (5 + i + 1), E (5 + i + 2)) : WH_F2 (E (5 + i), E (5 + i + 1));
   }
   default: {                                                 // HU
     const int z = x + 2 * y, j = y + (x >> 1);
-    if (z > 5) return E[0];
-    if (z == 5) return (E[1] + 3 * E[0] + 2) >> 2;
-    return (z & 1) ? WH_F3 (E[3 - j], E[3 - (j + 1)], E[3 - (j + 2)]) : WH_F2 (E[3 - j], E[3 - (j + 1)]);
+    if (z > 5) return E (0);
+    if (z == 5) return (E (1) + 3 * E (0) + 2) >> 2;
+    return (z & 1) ? WH_F3 (E (3 - j), E (3 - (j + 1)), E (3 - (j + 2))) : WH_F2 (E (3 - j), E (3 - (j + 1)));
   }
   }
+#undef E
 }
 
 // ---- the intra MB ---------------------------------------------------------------------------------
@@ -356,14 +364,20 @@ WH_FN bool wh_intra_md_enc_p (WhMbLds& S, const WhSeqParams& P, const WhPicJob& 
       WV_LANES_BEGIN (lane)
       if (lane < 36) {
         const int m = lane >> 2, r = lane & 3;
-        uint8_t E[13];
-        for (int k = 0; k < 4; ++k) E[3 - k] = WH_RY (S, bx * 4 - 1, by * 4 + k);
-        E[4] = WH_RY (S, bx * 4 - 1, by * 4 - 1);
-        for (int k = 0; k < 8; ++k) E[5 + k] = WH_RY (S, bx * 4 + k, by * 4 - 1);
+        WhE13 E;
+        {
+          const uint32_t t0 = * (const uint32_t*)&WH_RY (S, bx * 4, by * 4 - 1), t1 = * (const uint32_t*)&WH_RY (S, bx * 4 + 4, by * 4 - 1);
+          E.w[0] = (uint32_t)WH_RY (S, bx * 4 - 1, by * 4 + 3) | ((uint32_t)WH_RY (S, bx * 4 - 1, by * 4 + 2) << 8) |
+                   ((uint32_t)WH_RY (S, bx * 4 - 1, by * 4 + 1) << 16) | ((uint32_t)WH_RY (S, bx * 4 - 1, by * 4) << 24);
+          E.w[1] = (uint32_t)WH_RY (S, bx * 4 - 1, by * 4 - 1) | (t0 << 8);
+          E.w[2] = (t0 >> 24) | (t1 << 8);
+          E.w[3] = t1 >> 24;
+        }
+        const int sum_l4 = wh_e13 (E, 0) + wh_e13 (E, 1) + wh_e13 (E, 2) + wh_e13 (E, 3), sum_t4 = wh_e13 (E, 5) + wh_e13 (E, 6) + wh_e13 (E, 7) + wh_e13 (E, 8);
         int dcv;
-        if (a_l && a_t) dcv = (E[0] + E[1] + E[2] + E[3] + E[5] + E[6] + E[7] + E[8] + 4) >> 3;
-        else if (a_l) dcv = (E[0] + E[1] + E[2] + E[3] + 2) >> 2;
-        else if (a_t) dcv = (E[5] + E[6] + E[7] + E[8] + 2) >> 2;
+        if (a_l && a_t) dcv = (sum_l4 + sum_t4 + 4) >> 3;
+        else if (a_l) dcv = (sum_l4 + 2) >> 2;
+        else if (a_t) dcv = (sum_t4 + 2) >> 2;
         else dcv = 128;
         uint8_t px[4];
         for (int x = 0; x < 4; ++x) px[x] = (uint8_t)wh_pred4_px (m, x, r, E, dcv);
@@ -395,14 +409,18 @@ WH_FN bool wh_intra_md_enc_p (WhMbLds& S, const WhSeqParams& P, const WhPicJob& 
 #define WH_C4(m) ((use_satd ? ((S.part[(m) * 4] + S.part[(m) * 4 + 1] + S.part[(m) * 4 + 2] + S.part[(m) * 4 + 3] + 1) >> 1) \
                             : (S.part[(m) * 4] + S.part[(m) * 4 + 1] + S.part[(m) * 4 + 2] + S.part[(m) * 4 + 3])) + ((pred_mode == (m)) ? lambda : lam4))
       // candidate order of the reference (g_kiIntra4AvailMode rows), standard numbering
-      int list[9], n = 0;
+      // (the list is packed four bits per entry: an int array indexed at run time would live in scratch memory)
+      unsigned long long list = 0;
+      int n = 0;
+#define WH_PUSH(m) do { list |= (unsigned long long) (m) << (4 * n); ++n; } while (0)
+#define WH_LIST(i) ((int) ((list >> (4 * (i))) & 15ULL))
       if (a_l && a_t) {
-        list[n++] = 2; list[n++] = 1; list[n++] = 0; list[n++] = 8;
-        if (a_tr) { list[n++] = 3; list[n++] = 7; }
-        if (a_tl) { list[n++] = 4; list[n++] = 5; list[n++] = 6; }
-      } else if (a_l) { list[n++] = 2; list[n++] = 1; list[n++] = 8; }
-      else if (a_t) { list[n++] = 2; list[n++] = 0; if (a_tr) { list[n++] = 3; list[n++] = 7; } }
-      else { list[n++] = 2; }
+        WH_PUSH (2); WH_PUSH (1); WH_PUSH (0); WH_PUSH (8);
+        if (a_tr) { WH_PUSH (3); WH_PUSH (7); }
+        if (a_tl) { WH_PUSH (4); WH_PUSH (5); WH_PUSH (6); }
+      } else if (a_l) { WH_PUSH (2); WH_PUSH (1); WH_PUSH (8); }
+      else if (a_t) { WH_PUSH (2); WH_PUSH (0); if (a_tr) { WH_PUSH (3); WH_PUSH (7); } }
+      else { WH_PUSH (2); }
       int bmode, bcost;
       if (!use_satd && (n == 9 || n == 7)) {
         // WelsMdI4x4Fast decision tree (svc_base_layer_md.cpp:598-826)
@@ -444,13 +462,15 @@ WH_FN bool wh_intra_md_enc_p (WhMbLds& S, const WhSeqParams& P, const WhPicJob& 
           }
         }
       } else {
-        bmode = list[0]; bcost = 0x7fffffff;
+        bmode = WH_LIST (0); bcost = 0x7fffffff;
         for (int i = 0; i < n; ++i) {
-          const int c = WH_C4 (list[i]);
-          if (c < bcost) { bcost = c; bmode = list[i]; }
+          const int c = WH_C4 (WH_LIST (i));
+          if (c < bcost) { bcost = c; bmode = WH_LIST (i); }
         }
       }
 #undef WH_C4
+#undef WH_PUSH
+#undef WH_LIST
       cost4 += bcost;
       if (cost4 >= cost_luma) { completed = false; break; }
       if (pred_mode == bmode) prev_flags |= (uint16_t) (1u << b);
