@@ -155,7 +155,9 @@ WH_FN void wh_pred_chroma (WhMbLds& S, int mode, const int* st /*[pl][2] top sum
   WV_LANES_BEGIN (lane)
   if (lane < 32) {
     const int pl = lane >> 4, row = (lane >> 1) & 7, x0 = (lane & 1) * 4;
-    const int t0 = st[pl * 2], t1 = st[pl * 2 + 1], l0 = sl[pl * 2], l1 = sl[pl * 2 + 1];
+    // (selects, not st[pl * 2]: a local array indexed by a per-lane value is very slow)
+    const int t0 = pl ? st[2] : st[0], t1 = pl ? st[3] : st[1], l0 = pl ? sl[2] : sl[0], l1 = pl ? sl[3] : sl[1];
+    const int ppa = pl ? pa[1] : pa[0], ppb = pl ? pb[1] : pb[0], ppc = pl ? pc[1] : pc[0];
     for (int k = 0; k < 4; ++k) {
       const int x = x0 + k;
       int v;
@@ -168,7 +170,7 @@ WH_FN void wh_pred_chroma (WhMbLds& S, int mode, const int* st /*[pl][2] top sum
         break;
       case WH_C_DC_L: v = (row < 4) ? ((l0 + 2) >> 2) : ((l1 + 2) >> 2); break;
       case WH_C_DC_T: v = (x < 4) ? ((t0 + 2) >> 2) : ((t1 + 2) >> 2); break;
-      case WH_C_P: v = wh_clip255 ((pa[pl] + pb[pl] * (x - 3) + pc[pl] * (row - 3) + 16) >> 5); break;
+      case WH_C_P: v = wh_clip255 ((ppa + ppb * (x - 3) + ppc * (row - 3) + 16) >> 5); break;
       default: v = 128; break;
       }
       S.pred_c[pl * 64 + row * 8 + x] = (uint8_t)v;
@@ -251,42 +253,42 @@ WH_FN void wh_i16_costs (WhMbLds& S, int avail, int use_satd, int lambda, WhI16C
     pl_b = (5 * h + 32) >> 6;
     pl_c = (5 * v + 32) >> 6;
   }
-  int cand[4], ncand;
-  if (has_l && has_t) { cand[0] = WH_I16_V; cand[1] = WH_I16_H; cand[2] = WH_I16_DC; cand[3] = WH_I16_P; ncand = (av3 == 7) ? 4 : 3; }
-  else if (has_l) { cand[0] = WH_I16_DC_L; cand[1] = WH_I16_H; ncand = 2; }
-  else if (has_t) { cand[0] = WH_I16_DC_T; cand[1] = WH_I16_V; ncand = 2; }
-  else { cand[0] = WH_I16_DC_128; ncand = 1; }
+  // candidate modes in the reference's order (scalars, not an array: nothing here is indexed at run time)
+  int m0, m1, m2, m3, ncand;
+  if (has_l && has_t) { m0 = WH_I16_V; m1 = WH_I16_H; m2 = WH_I16_DC; m3 = WH_I16_P; ncand = (av3 == 7) ? 4 : 3; }
+  else if (has_l) { m0 = WH_I16_DC_L; m1 = WH_I16_H; m2 = m0; m3 = m0; ncand = 2; }
+  else if (has_t) { m0 = WH_I16_DC_T; m1 = WH_I16_V; m2 = m0; m3 = m0; ncand = 2; }
+  else { m0 = WH_I16_DC_128; m1 = m0; m2 = m0; m3 = m0; ncand = 1; }
   // cost of every candidate in one pass, straight from the neighbour samples (no prediction is written to LDS yet);
   // lambda * BsSizeUE (g_kiMapModeI16x16[mode]):  V -> 1 bit, H/DC* -> 3, Plane -> 5
-  int cst[4] = {0, 0, 0, 0};
-  const int m0 = cand[0], m1 = ncand > 1 ? cand[1] : cand[0], m2 = ncand > 2 ? cand[2] : cand[0], m3 = ncand > 3 ? cand[3] : cand[0];
+  int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
   if (!use_satd) {
     int p01, p23;
 #define WH_I16_SAD(m) wh_sad4 (* (const uint32_t*)&S.enc_y[lane * 4], wh_pred_i16_4 (S, (m), (lane & 3) * 4, lane >> 2, sum_t, sum_l, pl_b, pl_c, pl_a))
     WV_SUM2 (p01, p23, lane, (WH_I16_SAD (m0) | (ncand > 1 ? WH_I16_SAD (m1) << 16 : 0)), ((ncand > 2 ? WH_I16_SAD (m2) : 0) | (ncand > 3 ? WH_I16_SAD (m3) << 16 : 0)));
 #undef WH_I16_SAD
-    cst[0] = p01 & 0xffff; cst[1] = (int) ((unsigned)p01 >> 16); cst[2] = p23 & 0xffff; cst[3] = (int) ((unsigned)p23 >> 16);
+    c0 = p01 & 0xffff; c1 = (int) ((unsigned)p01 >> 16); c2 = p23 & 0xffff; c3 = (int) ((unsigned)p23 >> 16);
   } else {
     // SATD layout: lane quad = raster 4x4 block, lane & 3 = row inside it
 #define WH_I16_X0 (((lane >> 2) & 3) * 4)
 #define WH_I16_Y ((lane >> 4) * 4 + (lane & 3))
 #define WH_I16_SATD(dst, m) WV_SATD_ROWS (dst, lane, true, * (const uint32_t*)&S.enc_y[WH_I16_Y * 16 + WH_I16_X0], \
                                           wh_pred_i16_4 (S, (m), WH_I16_X0, WH_I16_Y, sum_t, sum_l, pl_b, pl_c, pl_a))
-    WH_I16_SATD (cst[0], m0);
-    if (ncand > 1) WH_I16_SATD (cst[1], m1);
-    if (ncand > 2) WH_I16_SATD (cst[2], m2);
-    if (ncand > 3) WH_I16_SATD (cst[3], m3);
+    WH_I16_SATD (c0, m0);
+    if (ncand > 1) WH_I16_SATD (c1, m1);
+    if (ncand > 2) WH_I16_SATD (c2, m2);
+    if (ncand > 3) WH_I16_SATD (c3, m3);
 #undef WH_I16_SATD
 #undef WH_I16_X0
 #undef WH_I16_Y
   }
-  int best_mode = cand[0], best_cost = 0x7fffffff, last_mode = -1;
-  for (int i = 0; i < ncand; ++i) {
-    const int m = cand[i];
-    const int bits = (m == WH_I16_V) ? 1 : (m == WH_I16_P) ? 5 : 3;
-    const int c = cst[i] + lambda * bits;
-    if (c < best_cost) { best_cost = c; best_mode = m; }
-  }
+  int best_mode = m0, best_cost = 0x7fffffff, last_mode = -1;
+#define WH_I16_TRY(m, c) do { const int _c = (c) + lambda * (((m) == WH_I16_V) ? 1 : ((m) == WH_I16_P) ? 5 : 3); if (_c < best_cost) { best_cost = _c; best_mode = (m); } } while (0)
+  WH_I16_TRY (m0, c0);
+  if (ncand > 1) WH_I16_TRY (m1, c1);
+  if (ncand > 2) WH_I16_TRY (m2, c2);
+  if (ncand > 3) WH_I16_TRY (m3, c3);
+#undef WH_I16_TRY
   k->sum_t = sum_t; k->sum_l = sum_l; k->pl_a = pl_a; k->pl_b = pl_b; k->pl_c = pl_c; k->best_mode = best_mode; k->best_cost = best_cost;
   (void)last_mode;
 }
@@ -521,14 +523,14 @@ WH_FN bool wh_intra_md_enc_p (WhMbLds& S, const WhSeqParams& P, const WhPicJob& 
       cpc[pl] = (17 * v + 16) >> 5;
     }
   }
-  int ccand[4], nc;
-  if (has_l && has_t) { ccand[0] = WH_C_V; ccand[1] = WH_C_H; ccand[2] = WH_C_DC; ccand[3] = WH_C_P; nc = (av3 == 7) ? 4 : 3; }
-  else if (has_l) { ccand[0] = WH_C_DC_L; ccand[1] = WH_C_H; nc = 2; }
-  else if (has_t) { ccand[0] = WH_C_DC_T; ccand[1] = WH_C_V; nc = 2; }
-  else { ccand[0] = WH_C_DC_128; nc = 1; }
-  int cbest = ccand[0], cbest_cost = 0x7fffffff, clast = -1;
+  int q0, q1, q2, q3, nc;
+  if (has_l && has_t) { q0 = WH_C_V; q1 = WH_C_H; q2 = WH_C_DC; q3 = WH_C_P; nc = (av3 == 7) ? 4 : 3; }
+  else if (has_l) { q0 = WH_C_DC_L; q1 = WH_C_H; q2 = q0; q3 = q0; nc = 2; }
+  else if (has_t) { q0 = WH_C_DC_T; q1 = WH_C_V; q2 = q0; q3 = q0; nc = 2; }
+  else { q0 = WH_C_DC_128; q1 = q0; q2 = q0; q3 = q0; nc = 1; }
+  int cbest = q0, cbest_cost = 0x7fffffff, clast = -1;
   for (int i = 0; i < nc; ++i) {
-    const int m = ccand[i];
+    const int m = i == 0 ? q0 : i == 1 ? q1 : i == 2 ? q2 : q3;
     wh_pred_chroma (S, m, st, sl, cpb, cpc, cpa);
     clast = m;
     // lambda * BsSizeUE (g_kiMapModeIntraChroma[mode]): DC* -> 1 bit, H/V -> 3, Plane -> 5
