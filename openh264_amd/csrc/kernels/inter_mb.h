@@ -107,14 +107,17 @@ WH_FN uint32_t wh_mc_h4 (const uint8_t* w, int o) {          // half-sample h (b
   const uint32_t r0 = wh_ld4u (w, o - 2 * WH_WIN_STRIDE), r1 = wh_ld4u (w, o - WH_WIN_STRIDE), r2 = wh_ld4u (w, o);
   const uint32_t r3 = wh_ld4u (w, o + WH_WIN_STRIDE), r4 = wh_ld4u (w, o + 2 * WH_WIN_STRIDE), r5 = wh_ld4u (w, o + 3 * WH_WIN_STRIDE);
   int v[4];
+#pragma unroll
   for (int k = 0; k < 4; ++k)
     v[k] = wh_clip255 ((wh_tap6 (WH_BYTE (r0, k), WH_BYTE (r1, k), WH_BYTE (r2, k), WH_BYTE (r3, k), WH_BYTE (r4, k), WH_BYTE (r5, k)) + 16) >> 5);
   return wh_pack4 (v[0], v[1], v[2], v[3]);
 }
 WH_FN uint32_t wh_mc_j4 (const uint8_t* w, int o) {          // centre half-sample j
   int t[6][4];
+#pragma unroll
   for (int k = 0; k < 6; ++k) wh_htaps4 (w, o + (k - 2) * WH_WIN_STRIDE, &t[k][0], &t[k][1], &t[k][2], &t[k][3]);
   int v[4];
+#pragma unroll
   for (int x = 0; x < 4; ++x) v[x] = wh_clip255 ((wh_tap6 (t[0][x], t[1][x], t[2][x], t[3][x], t[4][x], t[5][x]) + 512) >> 10);
   return wh_pack4 (v[0], v[1], v[2], v[3]);
 }
@@ -472,8 +475,10 @@ WH_FN void wh_me_fetch (const WhMeTab& T, int slot, WhMe& me) {
 // vertical half samples above (hu, between rows -1 and 0) and below (hd) G
 WH_FN void wh_rf_h_pair (const uint8_t* w, int o, uint32_t* hu, uint32_t* hd) {
   uint32_t r[7];
+#pragma unroll
   for (int k = 0; k < 7; ++k) r[k] = wh_ld4u (w, o + (k - 3) * WH_WIN_STRIDE);
   int u[4], d[4];
+#pragma unroll
   for (int k = 0; k < 4; ++k) {
     u[k] = wh_clip255 ((wh_tap6 (WH_BYTE (r[0], k), WH_BYTE (r[1], k), WH_BYTE (r[2], k), WH_BYTE (r[3], k), WH_BYTE (r[4], k), WH_BYTE (r[5], k)) + 16) >> 5);
     d[k] = wh_clip255 ((wh_tap6 (WH_BYTE (r[1], k), WH_BYTE (r[2], k), WH_BYTE (r[3], k), WH_BYTE (r[4], k), WH_BYTE (r[5], k), WH_BYTE (r[6], k)) + 16) >> 5);
@@ -484,8 +489,10 @@ WH_FN void wh_rf_h_pair (const uint8_t* w, int o, uint32_t* hu, uint32_t* hd) {
 WH_FN void wh_htaps5 (const uint8_t* w, int o, int* t /*[5]*/) {
   const uint32_t a = wh_ld4u (w, o - 3), b = wh_ld4u (w, o + 1), c = wh_ld4u (w, o + 5);
   int q[10];
+#pragma unroll
   for (int k = 0; k < 4; ++k) { q[k] = WH_BYTE (a, k); q[4 + k] = WH_BYTE (b, k); }
   q[8] = WH_BYTE (c, 0); q[9] = WH_BYTE (c, 1);
+#pragma unroll
   for (int k = 0; k < 5; ++k) t[k] = wh_tap6 (q[k], q[k + 1], q[k + 2], q[k + 3], q[k + 4], q[k + 5]);
 }
 // horizontal half samples left (bl, between x-1 and x) and right (br) of G
@@ -493,22 +500,27 @@ WH_FN void wh_rf_b_pair (const uint8_t* w, int o, uint32_t* bl, uint32_t* br) {
   int t[5];
   wh_htaps5 (w, o, t);
   int v[5];
+#pragma unroll
   for (int k = 0; k < 5; ++k) v[k] = wh_clip255 ((t[k] + 16) >> 5);
   *bl = wh_pack4 (v[0], v[1], v[2], v[3]); *br = wh_pack4 (v[1], v[2], v[3], v[4]);
 }
 // centre half samples j at (o-1, o): the two that flank a vertical half sample h4 (o)
 WH_FN void wh_rf_j_pair_h (const uint8_t* w, int o, uint32_t* jl, uint32_t* jr) {
   int t[6][5];
+#pragma unroll
   for (int k = 0; k < 6; ++k) wh_htaps5 (w, o + (k - 2) * WH_WIN_STRIDE, t[k]);
   int v[5];
+#pragma unroll
   for (int x = 0; x < 5; ++x) v[x] = wh_clip255 ((wh_tap6 (t[0][x], t[1][x], t[2][x], t[3][x], t[4][x], t[5][x]) + 512) >> 10);
   *jl = wh_pack4 (v[0], v[1], v[2], v[3]); *jr = wh_pack4 (v[1], v[2], v[3], v[4]);
 }
 // centre half samples j at (o - stride, o): the two that flank a horizontal half sample b4 (o)
 WH_FN void wh_rf_j_pair_v (const uint8_t* w, int o, uint32_t* ju, uint32_t* jd) {
   int t[7][4];
+#pragma unroll
   for (int k = 0; k < 7; ++k) wh_htaps4 (w, o + (k - 3) * WH_WIN_STRIDE, &t[k][0], &t[k][1], &t[k][2], &t[k][3]);
   int u[4], d[4];
+#pragma unroll
   for (int x = 0; x < 4; ++x) {
     u[x] = wh_clip255 ((wh_tap6 (t[0][x], t[1][x], t[2][x], t[3][x], t[4][x], t[5][x]) + 512) >> 10);
     d[x] = wh_clip255 ((wh_tap6 (t[1][x], t[2][x], t[3][x], t[4][x], t[5][x], t[6][x]) + 512) >> 10);
