@@ -634,7 +634,7 @@ WH_FN int wh_enc_inter_y (WhMbLds& S, int qp) {
     for (int q = 0; q < 4; ++q) { const int k = (lane & 3) * 4 + q; S.lv_luma[b * 16 + k] = S.res[b * 16 + wh_zigzag (k)]; }
     if (lane < 16) {
       int n = 0;
-      if ((cbp >> (lane >> 2)) & 1) { unsigned m = (unsigned)S.part2[lane]; while (m) { n += (int) (m & 1u); m >>= 1; } }
+      if ((cbp >> (lane >> 2)) & 1) n = __builtin_popcount ((unsigned)S.part2[lane]);
       S.nzc[wh_blk_y (lane) * 4 + wh_blk_x (lane)] = (uint8_t)n;
     }
     (void)on;

@@ -488,7 +488,7 @@ WH_FN int wh_encrec_chroma (WhMbLds& S, int qpc, int is_intra) {
     }
     if (lane < 8) {
       int n = 0;
-      if (lane < 4 ? keep0 : keep1) { unsigned m = (unsigned)S.part2[lane]; while (m) { n += (int) (m & 1u); m >>= 1; } }
+      if (lane < 4 ? keep0 : keep1) n = __builtin_popcount ((unsigned)S.part2[lane]);
       S.nzc[16 + lane] = (uint8_t)n;
     }
   }
