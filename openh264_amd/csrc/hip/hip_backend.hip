@@ -1,11 +1,11 @@
 // hip_backend.hip -- gfx950 launchers for the macroblock kernels + the wh::Backend implementation.
 //
-// Launch geometry: one workgroup = one wavefront (64 lanes) = one macroblock.  A frame-level pass
-// walks the 2:1 diagonals of the MB grid (frame_kernels.h); each diagonal is one launch whose grid
-// is (MBs on the diagonal) x (pictures in the batch), so independent pictures (all-IDR streams,
-// simulcast layers, concurrent sessions) fill the 256 CUs while a single picture only offers
-// <= mb_w/2 parallel MBs.  Kernel boundaries provide the inter-MB ordering and visibility; no
-// in-kernel spinning, so a launch can never hang the device.
+// Launch geometry: one wavefront (64 lanes) processes one macroblock at a time; one workgroup = the wavefronts that
+// work on ONE slice of ONE picture (6 or 12 for mode decision, 16 for deblocking); one launch per pass covers every
+// slice of every picture of the batch (grid = slices x pictures), so independent pictures (concurrent sessions,
+// simulcast layers, all-IDR streams) fill the 256 CUs.  Inside a workgroup the macroblock order and the hand-off
+// between neighbouring macroblocks are resolved in the kernel (LDS ticket counter + done flags, see below); between
+// the slices of a picture the deblocking kernel synchronises through agent-scope flags in HBM.  Every spin is bounded.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>

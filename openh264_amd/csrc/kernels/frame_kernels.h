@@ -1,6 +1,6 @@
-// frame_kernels.h -- per-macroblock kernel bodies (one wavefront = one MB) and the 2:1 diagonal
-// scheduling helpers.  The __global__ wrappers live in hip/launch.hip; the CPU-side test build
-// (tests/emu) calls the same bodies in raster order.
+// frame_kernels.h -- per-macroblock kernel bodies of I pictures (one wavefront = one MB) and the store of a
+// macroblock's results.  The __global__ wrappers and the in-kernel scheduling live in hip/hip_backend.hip; the CPU-side
+// test build (tests/emu) calls the same bodies in the same dependency order (common/mb_order.h).
 //
 // Restructures (does not port) the reference's MB loops:
 //   svc_encode_slice.cpp:534-599   WelsISliceMdEnc   (I slices)

@@ -3,11 +3,12 @@
 // One 64-lane wavefront owns one 16x16 macroblock.  Kernel bodies are written as a sequence of
 //   * "lane blocks"   WV_LANES_BEGIN(lane) ... WV_LANES_END   -- per-lane (vector) work
 //   * uniform code    between lane blocks                      -- wave-uniform scalars & branches
-// All cross-lane traffic goes through the wave's LDS tile (struct passed as `S`) or through the
-// WV_SUM / WV_MIN reductions.  A lane block never keeps per-lane state alive across its END; that
-// discipline is what lets the very same source be compiled
-//   * by hipcc for gfx950 (lane = threadIdx.x, END = workgroup barrier on a 1-wave workgroup,
-//     reductions = DPP/ds_swizzle butterflies), and
+// All cross-lane traffic goes through the wave's LDS tile (struct passed as `S`), through the DPP reductions
+// (WV_SUM, WV_SUM2, WV_SATD_ROWS, WV_ARGMIN) or through lane tables (WvLaneArr: a wave-uniform table in one VGPR).
+// A lane block never keeps per-lane state alive across its END; that discipline is what lets the very same source be
+// compiled
+//   * by hipcc for gfx950 (lane = threadIdx.x & 63, END = a wavefront-scope fence: a wavefront's LDS instructions
+//     execute in order, so no s_waitcnt / s_barrier is needed), and
 //   * by g++ with -DWH_EMU for the CPU-side test build (lane = loop variable), which the
 //     `-m "not gpu"` tests use to exercise the host entropy coder without a GPU.  The emulation
 //     build is test infrastructure: the product library never contains or calls it.
