@@ -355,11 +355,15 @@ class HipBackend : public wh::Backend {
     while ((int)streams_.size() <= k) { hipStream_t st; HIP_CHECK (hipStreamCreateWithFlags (&st, hipStreamNonBlocking)); streams_.push_back (st); }
     stream_ = streams_[k < 0 ? 0 : k];
   }
-  void sync() override {
+  int sync() override {
     for (hipStream_t st : streams_) HIP_CHECK (hipStreamSynchronize (st));
     uint32_t e[4] = {0, 0, 0, 0};
     HIP_CHECK (hipMemcpy (e, err_, 16, hipMemcpyDeviceToHost));
-    if (e[0]) { fprintf (stderr, "welship: %u in-kernel dependency waits timed out (first: block %u,%u waiting for MB index %u)\n", e[0], e[1], e[2], e[3]); abort(); }
+    if (e[0]) {
+      fprintf (stderr, "welship: %u in-kernel dependency waits timed out (first: block %u,%u waiting for MB index %u)\n", e[0], e[1], e[2], e[3]);
+      HIP_CHECK (hipMemset (err_, 0, 16));
+    }
+    return (int)e[0];
   }
   void* event_create() override { hipEvent_t e; HIP_CHECK (hipEventCreate (&e)); return (void*)e; }
   void event_destroy (void* ev) override { HIP_CHECK (hipEventDestroy ((hipEvent_t)ev)); }

@@ -26,9 +26,10 @@ class Backend {
   virtual void run_deblock (const WhSeqParams& P, const WhPicJob* jobs, int n) = 0;   // in-loop filter on rec[]
   virtual void run_expand (const WhSeqParams& P, const WhPicJob* jobs, int n) = 0;    // replicate rec[] borders (32/16 px)
   // Independent in-order queues (HIP streams): everything issued after select_queue (k) goes to queue k; work on
-  // different queues may overlap on the device.  sync() waits for all of them.
+  // different queues may overlap on the device.  sync() waits for all of them and returns 0, or the number of
+  // in-kernel dependency waits that timed out since the last sync (the pictures of that step are then invalid).
   virtual void select_queue (int k) = 0;
-  virtual void sync() = 0;
+  virtual int sync() = 0;
   // timing on the stream the kernels are launched on (HIP events)
   virtual void* event_create() = 0;
   virtual void event_destroy (void* ev) = 0;

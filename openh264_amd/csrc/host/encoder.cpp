@@ -427,7 +427,7 @@ int WelsHipEncodeFrame (WelsHipEncoder* e, const WelsHipSourcePicture* src, Wels
   e->be->upload (e->d_job, &job, sizeof (job));
   run_device_step (e->be, c.seq, e->d_job, 1, c.cur_idr, c.prm.uiIntraPeriod != 1);
   e->be->download (c.h_records.data(), c.d_records, sizeof (WhMbRecord) * c.num_mb);
-  e->be->sync();
+  if (e->be->sync()) { set_err ("device scheduler timed out; the picture was not encoded"); return WELSHIP_ERR_UNKNOWN; }
   return c.finish_frame (out, src->uiTimeStamp);
 }
 
@@ -509,7 +509,7 @@ int WelsHipGroupRunDevice (WelsHipEncoderGroup* g, int wait) {
     g->be->select_queue (q);
     run_device_step (g->be, c0.seq, g->d_jobs + a, b - a, g->step_idr, c0.prm.uiIntraPeriod != 1);
   }
-  if (wait) g->be->sync();
+  if (wait && g->be->sync()) { set_err ("device scheduler timed out"); return WELSHIP_ERR_UNKNOWN; }
   return WELSHIP_OK;
 }
 
@@ -521,7 +521,7 @@ int WelsHipGroupFinish (WelsHipEncoderGroup* g, WelsHipFrameBSInfo* outs) {
     g->be->select_queue (g->chunk_of (i));
     g->be->download (c.h_records.data(), c.d_records, sizeof (WhMbRecord) * c.num_mb);
   }
-  g->be->sync();
+  if (g->be->sync()) { set_err ("device scheduler timed out; the step was not encoded"); return WELSHIP_ERR_UNKNOWN; }
   std::vector<int> rcs (n, 0);
   const int T = g->host_threads < n ? g->host_threads : n;
   auto work = [&] (int t) { for (int i = t; i < n; i += T) rcs[i] = g->sess[i]->finish_frame (outs ? &outs[i] : nullptr, 0); };
@@ -577,7 +577,7 @@ int WelsHipGroupBench (WelsHipEncoderGroup* g, int steps, int warmup, double* ou
   auto slot_of = [&] (int i) { if (ring == 1) return 0; const int period = 2 * (ring - 1); const int k = i % period; return k < ring ? k : period - k; };
   int fi = 0;
   for (int i = 0; i < warmup; ++i) { int rc = WelsHipGroupStepDeviceOnly (g, slot_of (fi++)); if (rc) return rc; }
-  be->sync();
+  if (be->sync()) { set_err ("device scheduler timed out during warm-up"); return WELSHIP_ERR_UNKNOWN; }
   std::vector<void*> ev ((size_t)steps * 4 + 1);
   for (auto& e : ev) e = be->event_create();
   const WhSeqParams& s = g->sess[0]->seq;
@@ -600,7 +600,7 @@ int WelsHipGroupBench (WelsHipEncoderGroup* g, int steps, int warmup, double* ou
   }
   be->select_queue (0);
   be->event_record (ev[(size_t)steps * 4]);
-  be->sync();
+  const int timed_out = be->sync();
   out_ms[0] = be->event_elapsed_ms (ev[0], ev[(size_t)steps * 4]);
   out_ms[1] = out_ms[2] = out_ms[3] = 0.0;
   for (int i = 0; i < steps; ++i) {
@@ -609,6 +609,7 @@ int WelsHipGroupBench (WelsHipEncoderGroup* g, int steps, int warmup, double* ou
     out_ms[3] += be->event_elapsed_ms (ev[i * 4 + 2], ev[i * 4 + 3]);
   }
   for (auto& e : ev) be->event_destroy (e);
+  if (timed_out) { set_err ("device scheduler timed out during the benchmark; the timings are invalid"); return WELSHIP_ERR_UNKNOWN; }
   return WELSHIP_OK;
 }
 

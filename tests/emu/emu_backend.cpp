@@ -94,7 +94,7 @@ class EmuBackend : public Backend {
     }
   }
   void select_queue (int) override {}
-  void sync() override {}
+  int sync() override { return 0; }
   void* event_create() override { return new double (0.0); }
   void event_destroy (void* ev) override { delete (double*)ev; }
   void event_record (void* ev) override { * (double*)ev = std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now().time_since_epoch()).count(); }
