@@ -46,9 +46,10 @@ extern "C" {
 #define WELSHIP_OK 0
 #define WELSHIP_ERR_INIT_PARA 1      /* cmInitParaError   */
 #define WELSHIP_ERR_UNKNOWN 2        /* cmUnknownReason   */
+#define WELSHIP_ERR_MEMORY 3         /* cmMallocMemeError: also what the reference returns when a frame overflows its bitstream buffer */
 #define WELSHIP_ERR_UNSUPPORTED 4    /* cmUnsupportedData */
 #define WELSHIP_ERR_NO_DEVICE 100
-#define WELSHIP_ERR_VLC_OVERFLOW 101
+#define WELSHIP_ERR_VLC_OVERFLOW 101 /* internal: a macroblock must be re-encoded at QP+2 (handled inside EncodeFrame / GroupFinish) */
 
 /* ---- (1) session API ---------------------------------------------------------------------- */
 
@@ -146,6 +147,9 @@ const char* WelsHipGroupBackendName (WelsHipEncoderGroup* pGroup);
 int  WelsHipGroupBench (WelsHipEncoderGroup* pGroup, int iSteps, int iWarmup, double* pOutMs);
 /* developer aid: WhMbRecord[] (openh264_amd/csrc/common/wh_types.h) of the last encoded frame */
 int  WelsHipDebugGetMbRecords (WelsHipEncoder* pEncoder, void* pDst, size_t uiBytes);
+/* developer aid: number of picture re-encodes caused by CAVLC level overflows since InitializeExt (the reference's
+ * TRY_REENCODING loop, codec/encoder/core/src/svc_encode_slice.cpp:572-576,1863-1867), or -1 */
+int  WelsHipDebugGetOverflowReencodes (WelsHipEncoder* pEncoder);
 /* developer aid: per-phase cycle counters accumulated inside the MB kernels (16 sums + 16 counts) */
 int  WelsHipGroupProfile (WelsHipEncoderGroup* pGroup, int bEnable, unsigned long long* pOut32);
 

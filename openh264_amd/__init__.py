@@ -154,6 +154,11 @@ class Encoder:
     def backend_name(self):
         return (self._lib.WelsHipBackendName(self._h) or b"").decode()
 
+    def overflow_reencodes(self):
+        """Pictures re-encoded after a CAVLC level overflow since InitializeExt (developer statistic)."""
+        self._lib.WelsHipDebugGetOverflowReencodes.argtypes = [C.c_void_p]
+        return self._lib.WelsHipDebugGetOverflowReencodes(self._h)
+
     def last_error(self):
         return self._err()
 
@@ -169,8 +174,9 @@ class Encoder:
             pass
 
 
-def encode_sequence(yuv_bytes, width, height, lib_path=None, **params):
-    """Convenience: encode a whole I420 sequence; returns (bitstream bytes, last recon frame)."""
+def encode_sequence(yuv_bytes, width, height, lib_path=None, stats=None, **params):
+    """Convenience: encode a whole I420 sequence; returns (bitstream bytes, last recon frame).
+    `stats`: optional dict that receives developer statistics (overflow_reencodes)."""
     enc = Encoder(lib_path)
     p = enc.GetDefaultParams()
     p.iPicWidth, p.iPicHeight = width, height
@@ -187,6 +193,8 @@ def encode_sequence(yuv_bytes, width, height, lib_path=None, **params):
             raise WelsHipError(rc, enc.last_error())
         out += bs
     recon = enc.GetReconFrame()
+    if stats is not None:
+        stats["overflow_reencodes"] = enc.overflow_reencodes()
     enc.Uninitialize()
     enc.close()
     return bytes(out), recon

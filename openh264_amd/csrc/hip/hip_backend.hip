@@ -260,6 +260,12 @@ __global__ __launch_bounds__ (64) void k_expand (WhSeqParams P, const WhPicJob* 
   wh_expand_body (P, J, (int)blockIdx.x);
 }
 
+// QP_Y chain for the deblocking filter of pictures with a per-MB QP map: one wavefront per (slice, picture).
+__global__ __launch_bounds__ (64) void k_qp_chain (WhSeqParams P, const WhPicJob* jobs) {
+  const WhPicJob J = jobs[blockIdx.y];
+  wh_qp_chain_slice (P, J, P.slice_first_mb[blockIdx.x], P.slice_first_mb[blockIdx.x + 1]);
+}
+
 #define HIP_CHECK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { fprintf (stderr, "welship: HIP error %s at %s:%d\n", hipGetErrorString (_e), __FILE__, __LINE__); abort(); } } while (0)
 
 class HipBackend : public wh::Backend {
@@ -345,6 +351,10 @@ class HipBackend : public wh::Backend {
   void run_deblock (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
     static const int db_waves = getenv ("WELSHIP_DB_WAVES") ? atoi (getenv ("WELSHIP_DB_WAVES")) : 16;
     mb_pass (k_deblock_slices, sizeof (WhDbLds), db_waves, false, P, jobs, n, 16 * sizeof (WhDbStage) + sizeof (WhPicJob), 4 * wh_db_xchg_words (P.mb_w, P.mb_h));
+  }
+  void run_qp_chain (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
+    hipLaunchKernelGGL (k_qp_chain, dim3 (P.num_slices, n), dim3 (64), 0, stream_, P, jobs);
+    HIP_CHECK (hipGetLastError());
   }
   void run_expand (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
     hipLaunchKernelGGL (k_expand, dim3 (wh_expand_num_blocks (P), n), dim3 (64), 0, stream_, P, jobs);

@@ -66,6 +66,15 @@ struct SessionCore {
   bool level_1b = false;
   int n_param_nals = 0;
   size_t vcl_start = 0;
+  // per-MB QP offsets of the picture being encoded: all zero (and not passed to the device) unless a macroblock had to
+  // be re-encoded after a CAVLC level overflow (svc_encode_slice.cpp:572-576,1863-1867)
+  int8_t* d_qp_delta = nullptr;
+  std::vector<int8_t> h_qp_delta;
+  bool qp_map_in_use = false;
+  int overflow_mb = -1;               // set by finish_frame when it returns WELSHIP_ERR_VLC_OVERFLOW
+  int overflow_qp = 0;                // uiLumaQp of that macroblock when the overflow was detected
+  int overflow_reencodes = 0;         // statistics
+  WhPicJob cur_job;                   // what begin_frame described (re-issued by retry_after_overflow)
 
   static int validate (const WelsHipEncParam* p) {
     // same spirit as ParamValidationExt (encoder_ext.cpp:403-680)
@@ -115,6 +124,9 @@ struct SessionCore {
     s.alpha_offset = p->iLoopFilterAlphaC0Offset; s.beta_offset = p->iLoopFilterBetaOffset;
     s.mv_range = 64;
     if (compute_slices()) { set_err ("invalid slice number"); return WELSHIP_ERR_INIT_PARA; }
+    // InitDqLayers (encoder_ext.cpp:1109-1117): with a single slice (requested, or after the fall-back above)
+    // "filter all but slice edges" is signalled and run as idc 0
+    if (s.num_slices == 1 && s.deblock_idc == 2) s.deblock_idc = 0;
     ysz = (size_t)s.src_stride_y * mb_h * 16; csz = (size_t)s.src_stride_c * mb_h * 8; src_bytes = ysz + 2 * csz;
     h_src.assign (src_bytes, 0);
     memset (h_src.data() + ysz, 0x80, 2 * csz);     // CWelsPreProcess::Padding: luma 0, chroma 0x80
@@ -163,6 +175,8 @@ struct SessionCore {
     d_order = nullptr;
     if (d_dbflags) be->free (d_dbflags);
     d_dbflags = nullptr;
+    if (d_qp_delta) be->free (d_qp_delta);
+    d_qp_delta = nullptr;
     be = nullptr;
   }
 
@@ -207,6 +221,32 @@ struct SessionCore {
     job->db_flags = d_dbflags;
     if (++db_gen == 0) db_gen = 1;
     job->db_gen = db_gen;
+    if (qp_map_in_use) { std::fill (h_qp_delta.begin(), h_qp_delta.end(), (int8_t)0); qp_map_in_use = false; }
+    cur_job = *job;
+  }
+
+  // The macroblock `overflow_mb` cannot be written in Baseline CAVLC at its QP: raise its QP by DELTA_QP (rc.h:77) as
+  // UpdateQpForOverflow does and describe the picture again, now with the QP map.  Every other macroblock keeps its
+  // QP, so the device reproduces everything up to that macroblock and continues from the re-encoded one exactly like
+  // the reference's TRY_REENCODING loop.  Fails once the macroblock's QP has reached 50, as the reference does.
+  int retry_after_overflow (WhPicJob* job) {
+    if (overflow_mb < 0 || overflow_mb >= num_mb) return WELSHIP_ERR_UNKNOWN;
+    if (h_qp_delta.empty()) h_qp_delta.assign (num_mb, 0);
+    if (!d_qp_delta) d_qp_delta = (int8_t*)be->alloc (num_mb);
+    // `pCurMb->uiLumaQp < 50` (svc_encode_slice.cpp:572,1863); beyond that the reference gives up on the frame with
+    // cmMallocMemeError (welsEncoderExt.cpp:415-420)
+    if (overflow_qp >= 50) { set_err ("bitstream overflow that raising the macroblock QP cannot resolve (reference: cmMallocMemeError)"); return WELSHIP_ERR_MEMORY; }
+    // uiLumaQp += DELTA_QP: on top of the QP the macroblock had when the overflow was seen -- for a macroblock without
+    // coded residual that is the QP it inherited from the previous one (svc_set_mb_syn_cavlc.cpp:299), not its own
+    h_qp_delta[overflow_mb] = (int8_t) (overflow_qp + 2 - prm.iDLayerQp);
+    qp_map_in_use = true;
+    ++overflow_reencodes;
+    be->upload (d_qp_delta, h_qp_delta.data(), num_mb);
+    if (++db_gen == 0) db_gen = 1;
+    cur_job.db_gen = db_gen;
+    cur_job.qp_delta = d_qp_delta;
+    *job = cur_job;
+    return WELSHIP_OK;
   }
 
   // Entropy-code the downloaded records into `bs` and advance the stream state.
@@ -214,11 +254,26 @@ struct SessionCore {
     const WhSeqParams& s = seq;
     const bool idr = cur_idr;
     const int qp = prm.iDLayerQp;
+    const int saved_ids[5] = {sps_counter, pps_counter, sps_id_in_bs, pps_id_in_bs, idr_pic_id};
+    overflow_mb = -1;
     pic[cur].is_p = !idr;
     have_recon = true;
     bs.clear();
     nal_len.clear();
+    std::vector<long> nal_rbsp_len;
     n_param_nals = 0;
+    const long bs_capacity = 128 + 32 + 2 * 16 + (((3L * mb_w * 16 * mb_h * 16) >> 1) + 800 + 3) / 4 * 4;   // iCountBsLen, see below
+    // WelsEncodeNal (nal_encap.cpp:120-131) refuses a NAL unless 1.5x its size still fits into what is left of the frame's
+    // output buffer (same iCountBsLen bytes); the reference then fails the frame with cmMallocMemeError.
+    auto nal_fits = [&] (const std::vector<uint8_t>& payload) {
+      const long need = 4 + (long)payload.size() + 1;
+      return bs_capacity - (long)bs.size() >= need + (need >> 1);
+    };
+    auto fail_frame = [&] () {
+      sps_counter = saved_ids[0]; pps_counter = saved_ids[1]; sps_id_in_bs = saved_ids[2]; pps_id_in_bs = saved_ids[3]; idr_pic_id = saved_ids[4];
+      set_err ("frame does not fit the bitstream buffer of the reference encoder (cmMallocMemeError there as well)");
+      return WELSHIP_ERR_MEMORY;
+    };
     std::vector<uint8_t> rbsp;
     if (idr) {
       if (prm.eSpsPpsIdStrategy == 1) {          // INCREASING_ID (paraset_strategy.cpp:334-372)
@@ -231,16 +286,27 @@ struct SessionCore {
       sp.width = prm.iPicWidth; sp.height = prm.iPicHeight; sp.mb_w = mb_w; sp.mb_h = mb_h;
       sp.num_ref_frames = 1; sp.gaps_in_frame_num = false; sp.frame_cropping = prm.bEnableFrameCroppingFlag != 0;
       wh::write_sps_rbsp (rbsp, sp);
+      if (!nal_fits (rbsp)) return fail_frame();
       nal_len.push_back (wh::append_nal (bs, 3, 7, rbsp));
+      nal_rbsp_len.push_back ((long)rbsp.size());
       wh::PpsParams pp;
       pp.pps_id = pps_id_in_bs; pp.sps_id = sps_id_in_bs;
       rbsp.clear();
       wh::write_pps_rbsp (rbsp, pp);
+      if (!nal_fits (rbsp)) return fail_frame();
       nal_len.push_back (wh::append_nal (bs, 3, 8, rbsp));
+      nal_rbsp_len.push_back ((long)rbsp.size());
       n_param_nals = 2;
     }
     vcl_start = bs.size();
     rbsp.reserve (1 << 16);
+    // The reference writes every NAL payload of a frame into one buffer of iCountBsLen bytes (RequestMemorySvc,
+    // encoder_ext.cpp:1576-1613: SEI 128 + SPS 32 + PPS 2x16 + picture bytes + 800, 4-aligned) and re-encodes a
+    // macroblock at QP+2 when, after writing it, fewer than 800 bytes are left (CheckBitstreamBuffer,
+    // svc_set_mb_syn_cavlc.cpp:248-257) -- reproduced here so that streams near the raw picture size stay identical.
+    // Its writer flushes 32 bits at a time (golomb_common.h:78-92), hence the 4-byte granularity of the position.
+    long frame_pos = 0;
+    for (size_t i = 0; i < nal_len.size(); ++i) frame_pos += nal_rbsp_len[i];
     for (int si = 0; si < s.num_slices; ++si) {
       rbsp.clear();
       wh::BitWriter bw (&rbsp);
@@ -267,11 +333,21 @@ struct SessionCore {
         if (mby > 0 && xy - mb_w >= s.slice_first_mb[si]) avail |= wh::WH_AVAIL_TOP;
         int dbqp = qp;
         const int rc = wh::write_mb_cavlc (bw, st, h_records.data(), mb_w, mbx, mby, avail, &dbqp);
-        if (rc == -1) { set_err ("CAVLC level escape overflow (re-encode at higher QP not implemented)"); return WELSHIP_ERR_VLC_OVERFLOW; }
+        const bool coded = h_records[xy].mb_type != WH_MB_PSKIP;
+        const bool no_room = coded && bs_capacity - (frame_pos + 4 * (long) (bw.bits() / 32)) - 1 < 800;
+        if (rc == -1 || (rc == 0 && no_room)) {   // the caller re-encodes the picture with this macroblock's QP raised (retry_after_overflow)
+          sps_counter = saved_ids[0]; pps_counter = saved_ids[1]; sps_id_in_bs = saved_ids[2]; pps_id_in_bs = saved_ids[3]; idr_pic_id = saved_ids[4];
+          overflow_mb = xy;
+          overflow_qp = dbqp;
+          set_err ("CAVLC overflow");
+          return WELSHIP_ERR_VLC_OVERFLOW;
+        }
         if (rc) { set_err ("bad macroblock record"); return WELSHIP_ERR_UNKNOWN; }
       }
       wh::write_slice_end (bw, st);
+      if (!nal_fits (rbsp)) return fail_frame();
       nal_len.push_back (wh::append_nal (bs, 3, idr ? 5 : 1, rbsp));
+      frame_pos += (long)rbsp.size();
     }
     if (out) {
       memset (out, 0, sizeof (*out));
@@ -319,11 +395,25 @@ struct SessionCore {
 };
 
 // Run the device part of one frame step for `n` pictures described by the device array d_jobs.
-void run_device_step (wh::Backend* be, const WhSeqParams& s, const WhPicJob* d_jobs, int n, bool idr, bool need_ref) {
+void run_device_step (wh::Backend* be, const WhSeqParams& s, const WhPicJob* d_jobs, int n, bool idr, bool need_ref, bool qp_map = false) {
   if (idr) be->run_intra (s, d_jobs, n);
   else be->run_inter (s, d_jobs, n);
+  if (qp_map && s.deblock_idc != 1) be->run_qp_chain (s, d_jobs, n);
   if (s.deblock_idc != 1) be->run_deblock (s, d_jobs, n);
   if (need_ref) be->run_expand (s, d_jobs, n);
+}
+
+// One round of the overflow loop for the picture session `c` is working on: raise the QP of the offending macroblock,
+// run the picture again on the device (d_job: a device WhPicJob slot that belongs to this session) and fetch the records.
+int reencode_after_overflow (wh::Backend* be, SessionCore& c, WhPicJob* d_job) {
+  WhPicJob job;
+  const int rc = c.retry_after_overflow (&job);
+  if (rc) return rc;
+  be->upload (d_job, &job, sizeof (job));
+  run_device_step (be, c.seq, d_job, 1, c.cur_idr, c.prm.uiIntraPeriod != 1, true);
+  be->download (c.h_records.data(), c.d_records, sizeof (WhMbRecord) * c.num_mb);
+  if (be->sync()) { set_err ("device scheduler timed out; the picture was not encoded"); return WELSHIP_ERR_UNKNOWN; }
+  return WELSHIP_OK;
 }
 
 }  // namespace
@@ -428,7 +518,13 @@ int WelsHipEncodeFrame (WelsHipEncoder* e, const WelsHipSourcePicture* src, Wels
   run_device_step (e->be, c.seq, e->d_job, 1, c.cur_idr, c.prm.uiIntraPeriod != 1);
   e->be->download (c.h_records.data(), c.d_records, sizeof (WhMbRecord) * c.num_mb);
   if (e->be->sync()) { set_err ("device scheduler timed out; the picture was not encoded"); return WELSHIP_ERR_UNKNOWN; }
-  return c.finish_frame (out, src->uiTimeStamp);
+  int rc = c.finish_frame (out, src->uiTimeStamp);
+  while (rc == WELSHIP_ERR_VLC_OVERFLOW) {
+    rc = reencode_after_overflow (e->be, c, e->d_job);
+    if (rc) return rc;
+    rc = c.finish_frame (out, src->uiTimeStamp);
+  }
+  return rc;
 }
 
 int WelsHipGetReconFrame (WelsHipEncoder* e, uint8_t* dst, size_t bytes) {
@@ -443,6 +539,11 @@ int WelsHipDebugGetMbRecords (WelsHipEncoder* e, void* dst, size_t bytes) {
   if (bytes < n) return WELSHIP_ERR_INIT_PARA;
   memcpy (dst, e->core.h_records.data(), n);
   return WELSHIP_OK;
+}
+
+int WelsHipDebugGetOverflowReencodes (WelsHipEncoder* e) {
+  if (!e || !e->inited) return -1;
+  return e->core.overflow_reencodes;
 }
 
 // ---------------------------------------------------------------------------------- session group
@@ -530,6 +631,16 @@ int WelsHipGroupFinish (WelsHipEncoderGroup* g, WelsHipFrameBSInfo* outs) {
     std::vector<std::thread> th;
     for (int t = 0; t < T; ++t) th.emplace_back (work, t);
     for (auto& x : th) x.join();
+  }
+  // sessions whose picture hit a CAVLC level overflow are re-encoded one at a time (rare: very low QP on extreme content)
+  for (int i = 0; i < n; ++i) {
+    SessionCore& c = *g->sess[i];
+    while (rcs[i] == WELSHIP_ERR_VLC_OVERFLOW) {
+      g->be->select_queue (g->chunk_of (i));
+      rcs[i] = reencode_after_overflow (g->be, c, g->d_jobs + i);
+      if (rcs[i]) break;
+      rcs[i] = c.finish_frame (outs ? &outs[i] : nullptr, 0);
+    }
   }
   for (int i = 0; i < n; ++i) if (rcs[i]) return rcs[i];
   return WELSHIP_OK;

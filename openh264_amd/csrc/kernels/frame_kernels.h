@@ -61,11 +61,50 @@ WH_FN void wh_store_mb (WhMbLds& S, const WhSeqParams& P, const WhPicJob& J, int
   WV_LANES_END
 }
 
+// QP of one macroblock: the picture QP, plus the per-MB offset when the host supplies a map (WelsRcMbInitDisable,
+// ratectl.cpp, and UpdateQpForOverflow, svc_encode_slice.cpp:526-529: the re-encode after a CAVLC level overflow).
+WH_FN int wh_mb_qp (const WhPicJob& J, int xy) {
+  return wh_clip3 (J.qp + (J.qp_delta ? (int) ((const WH_G int8_t*)J.qp_delta)[xy] : 0), 0, 51);
+}
+
+// QP_Y as the decoder derives it, for the deblocking filter: a macroblock that codes no mb_qp_delta (P_Skip, or
+// cbp == 0 and not Intra16x16) inherits the QP of the previous macroblock of its slice, the first one the slice QP
+// (svc_set_mb_syn_cavlc.cpp:232-247,288-300: uiLumaQp = uiLastMbQp).  With one QP per picture that is the identity, so
+// this pass only runs for pictures with a per-MB QP map.  One wavefront per slice: 64 states per step are loaded
+// lane-parallel, the chain itself is a wave-uniform scan over the lane table.
+WH_FN void wh_qp_chain_slice (const WhSeqParams& P, const WhPicJob& J, int first, int last) {
+  int carry = wh_clip3 (J.qp, 0, 51);
+  for (int base = first; base < last; base += 64) {
+    WvLaneArr w, o;
+#ifdef WH_EMU
+    memset (&w, 0, sizeof (w)); memset (&o, 0, sizeof (o));
+#else
+    w = 0; o = 0;
+#endif
+    WV_LSET_IF (w, lane, base + lane < last, (int) * (const WH_G uint32_t*) ((const WH_G WhMbState*)J.mbs + base + lane));
+    const int n = last - base < 64 ? last - base : 64;
+    for (int i = 0; i < n; ++i) {
+      const uint32_t v = (uint32_t)WV_LGET (w, i);            // bytes: mb_type, luma_qp, chroma_qp, cbp
+      const int type = (int) (v & 0xff), cbp = (int) (v >> 24);
+      if (! (type == WH_MB_PSKIP || (cbp == 0 && type != WH_MB_I16x16))) carry = (int) ((v >> 8) & 0xff);
+      WV_LSET (o, i, carry);
+    }
+    WV_LANES_BEGIN (lane)
+    if (base + lane < last) {
+      WH_G WhMbState* M = (WH_G WhMbState*)J.mbs + base + lane;
+      const int q = WV_LOWN (o, lane);
+      M->luma_qp = (uint8_t)q;
+      M->chroma_qp = (uint8_t)kWhChromaQp[wh_clip3 (q + P.chroma_qp_offset, 0, 51)];
+    }
+    WV_LANES_END
+  }
+}
+
 // One intra macroblock (I slice).
 WH_FN void wh_intra_mb_body (WhMbLds& S, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby) {
   const int xy = mby * P.mb_w + mbx;
   const int avail = wh_mb_avail (P, mbx, mby);
-  const int qp = wh_clip3 (J.qp, 0, 51);
+  const int qp = wh_mb_qp (J, xy);
   const int qpc = kWhChromaQp[wh_clip3 (qp + P.chroma_qp_offset, 0, 51)];
   wh_load_mb_tile (S, P, J, mbx, mby);
   WhIntraResult r;

@@ -711,7 +711,7 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, WhInterStage& G, const WhSeqParams& 
   const int w = P.mb_w, xy = mby * w + mbx;
   const int slice_idc = X.slice_idc;
   const int avail = wh_mb_avail_in_slice (P, mbx, mby, X.slice_first);
-  const int qp = wh_clip3 (J.qp, 0, 51);
+  const int qp = wh_mb_qp (J, xy);
   const int qpc = kWhChromaQp[wh_clip3 (qp + P.chroma_qp_offset, 0, 51)];
   const int lambda = kWhLambda[qp];
   const int use_satd = P.complexity > 0;        // pfMdCost == SATD, pfCalculateSatd == CalculateSatdCost

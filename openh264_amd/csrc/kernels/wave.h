@@ -65,6 +65,7 @@
 typedef struct WvLaneArr { int v[64]; } WvLaneArr;
 #define WV_LGET(a, i) ((a).v[i])
 #define WV_LSET(a, i, val) ((a).v[i] = (val))
+#define WV_LOWN(a, lane) ((a).v[lane])                      // inside a lane block: this lane's own entry
 #define WV_LSET_IF(a, lane, cond, val) do { for (int lane = 0; lane < 64; ++lane) if (cond) (a).v[lane] = (val); } while (0)
 // asynchronous copy of one 4-byte word per lane from global memory to LDS word `lane` of `lds_base` (GPU: LDS-DMA,
 // no register holds the data; complete after WV_ASYNC_WAIT)
@@ -165,6 +166,7 @@ WH_FN int wh_satd_rows (int lane, bool active, uint32_t e, uint32_t p) {
 typedef int WvLaneArr;
 #define WV_LGET(a, i) __builtin_amdgcn_readlane ((a), (i))
 #define WV_LSET(a, i, val) do { if ((int)(threadIdx.x & 63) == (i)) (a) = (val); } while (0)
+#define WV_LOWN(a, lane) (a)
 #define WV_LSET_IF(a, lane, cond, val) do { const int lane = wh_lane_id(); if (cond) (a) = (val); } while (0)
 #define WH_G __attribute__ ((address_space (1)))
 WH_FN uint32_t wh_ld4u (const uint8_t* base, int off) {

@@ -58,3 +58,23 @@ def synth_sequence(width, height, frames, seed=0x1234):
         v = (128 + ((cy + n) * 32 // max(h // 2, 1)) - 16).astype(np.uint8)
         out += y.tobytes() + u.tobytes() + v.tobytes()
     return bytes(out)
+
+
+def checker_sequence(width, height, frames, period=3):
+    """Saturated 0/255 checkerboards that drift by (3, 1) pixels per frame, chroma likewise: residuals with the
+    largest levels the transform can produce (CAVLC level-escape overflow at very low QP, clipping paths)."""
+    w, h = width, height
+    yy, xx = np.mgrid[0:h, 0:w]
+    out = bytearray()
+    for n in range(frames):
+        y = ((((xx + n * 3) // period + (yy + n) // period) & 1) * 255).astype(np.uint8)
+        c = ((((xx[:h // 2, :w // 2] + n) // period) & 1) * 255).astype(np.uint8)
+        out += y.tobytes() + c.tobytes() + (255 - c).tobytes()
+    return bytes(out)
+
+
+def make_sequence(content, width, height, frames):
+    """`content`: "synth" (default generator) or "checker<period>"."""
+    if content.startswith("checker"):
+        return checker_sequence(width, height, frames, int(content[7:] or 3))
+    return synth_sequence(width, height, frames)

@@ -87,6 +87,10 @@ class EmuBackend : public Backend {
         }
       }
   }
+  void run_qp_chain (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
+    for (int j = 0; j < n; ++j)
+      for (int s = 0; s < P.num_slices; ++s) wh_qp_chain_slice (P, jobs[j], P.slice_first_mb[s], P.slice_first_mb[s + 1]);
+  }
   void run_expand (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
     for (int j = 0; j < n; ++j) {
       const int nb = wh_expand_num_blocks (P);

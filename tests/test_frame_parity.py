@@ -16,7 +16,7 @@ import subprocess
 import pytest
 
 import openh264_amd as oh
-from openh264_amd.utils.synth import synth_sequence
+from openh264_amd.utils.synth import make_sequence, synth_sequence
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = json.load(open(os.path.join(ROOT, "tests", "golden", "golden.json")))
@@ -26,13 +26,16 @@ LARGE = [k for k in GOLDEN if k not in SMALL]
 
 def run_case(name, lib_path, ref_tools, tmp_path):
     g = GOLDEN[name]
-    yuv = synth_sequence(g["w"], g["h"], g["frames"])
+    yuv = make_sequence(g.get("content", "synth"), g["w"], g["h"], g["frames"])
     assert hashlib.sha1(yuv).hexdigest() == g["input_sha1"], "synthetic generator changed"
     params = dict(fMaxFrameRate=30.0, iTargetBitrate=5000000)
     params.update(g["params"])
-    bs, recon = oh.encode_sequence(yuv, g["w"], g["h"], lib_path=lib_path, **params)
+    stats = {}
+    bs, recon = oh.encode_sequence(yuv, g["w"], g["h"], lib_path=lib_path, stats=stats, **params)
     assert len(bs) == g["bytes"]
     assert hashlib.sha1(bs).hexdigest() == g["sha1"]
+    if name.endswith("_overflow"):      # the case must really go through the re-encode loop
+        assert stats["overflow_reencodes"] > 0
     if ref_tools:
         fi, fo, fd = str(tmp_path / "in.yuv"), str(tmp_path / "ref.264"), str(tmp_path / "dec.yuv")
         open(fi, "wb").write(yuv)
@@ -134,7 +137,7 @@ def test_hip_wave_variants(waves, hip_lib):
     import sys
     name = "p_640x368_qp24_4slices"
     g = GOLDEN[name]
-    code = ("import hashlib, sys; sys.path.insert(0, %r); import openh264_amd as oh; from openh264_amd.utils.synth import synth_sequence;"
+    code = ("import hashlib, sys; sys.path.insert(0, %r); import openh264_amd as oh; from openh264_amd.utils.synth import make_sequence, synth_sequence;"
             "yuv = synth_sequence(%d, %d, %d); bs, _ = oh.encode_sequence(yuv, %d, %d, lib_path=%r, fMaxFrameRate=30.0, iTargetBitrate=5000000, **%r);"
             "print(hashlib.sha1(bs).hexdigest())") % (ROOT, g["w"], g["h"], g["frames"], g["w"], g["h"], hip_lib, g["params"])
     env = dict(os.environ, WELSHIP_P_WAVES=waves, WELSHIP_P_LOOKAHEAD="1" if waves == "8" else "0")

@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""Randomised bitstream parity: kernel sources (CPU wave-emulation build, or libwelship.so with --hip) against
+oracle/_ref/ref_enc run live, over random picture sizes, QPs, slice counts, complexity modes, deblocking modes
+and content classes.  Test infrastructure: prints one line per case and a summary; exit code 1 on any mismatch.
+
+    python tools/fuzz_parity.py --cases 200 --seed 1            # CPU emulation
+    python tools/fuzz_parity.py --cases 40 --hip                # on an MI355X box
+"""
+import argparse
+import hashlib
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import openh264_amd as oh                                  # noqa: E402
+from openh264_amd import build as B                        # noqa: E402
+from openh264_amd.utils.synth import synth_sequence        # noqa: E402
+
+
+def content(kind, w, h, frames, rng):
+    """I420 bytes of one of several content classes (all integer, seeded)."""
+    if kind == "synth":
+        return synth_sequence(w, h, frames, seed=int(rng.integers(1, 1 << 30)))
+    out = bytearray()
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = rng.integers(0, 256, (h, w)).astype(np.int32)
+    if kind == "noise":                                    # uncorrelated noise, new every frame
+        for _ in range(frames):
+            out += rng.integers(0, 256, h * w, dtype=np.uint8).tobytes()
+            out += rng.integers(0, 256, h * w // 2, dtype=np.uint8).tobytes()
+        return bytes(out)
+    if kind == "flat":                                     # constant planes with a few outliers (skip-heavy)
+        y0 = np.full((h, w), int(rng.integers(0, 256)), np.int32)
+        for n in range(frames):
+            y = y0.copy()
+            for _ in range(3):
+                py, px = int(rng.integers(0, h)), int(rng.integers(0, w))
+                y[py:py + 5, px:px + 7] = int(rng.integers(0, 256))
+            out += y.astype(np.uint8).tobytes()
+            out += np.full(h * w // 4, int(rng.integers(0, 256)), np.uint8).tobytes() * 2
+        return bytes(out)
+    if kind == "extreme":                                  # saturated checker patterns: clipping paths, large levels
+        p = int(rng.integers(1, 9))
+        for n in range(frames):
+            y = ((((xx + n * 3) // p + (yy + n) // p) & 1) * 255).astype(np.uint8)
+            c = ((((xx[:h // 2, :w // 2] + n) // p) & 1) * 255).astype(np.uint8)
+            out += y.tobytes() + c.tobytes() + (255 - c).tobytes()
+        return bytes(out)
+    if kind == "fastmotion":                               # large global motion (beyond the search range) + texture
+        acc = np.zeros_like(base)
+        for d in range(4):
+            acc += np.roll(base, d, axis=1) + np.roll(base, d, axis=0)
+        tex = (acc >> 3)
+        dx, dy = int(rng.integers(-40, 41)), int(rng.integers(-24, 25))
+        for n in range(frames):
+            y = np.roll(np.roll(tex, dy * n, axis=0), dx * n, axis=1)
+            out += np.clip(y, 0, 255).astype(np.uint8).tobytes()
+            cu = np.roll(tex[::2, ::2], dx * n // 2, axis=1)
+            out += np.clip(cu, 0, 255).astype(np.uint8).tobytes()
+            out += np.clip(255 - cu, 0, 255).astype(np.uint8).tobytes()
+        return bytes(out)
+    if kind == "subpel":                                   # smooth gradients moving by fractions of a pixel
+        fx, fy = rng.integers(1, 8, 2)
+        for n in range(frames):
+            y = (128 + 100 * np.sin((xx * 4 + n * fx) / 37.0) * np.cos((yy * 4 + n * fy) / 29.0)).astype(np.int32)
+            y += rng.integers(-2, 3, (h, w))
+            out += np.clip(y, 0, 255).astype(np.uint8).tobytes()
+            c = (128 + 60 * np.sin((xx[:h // 2, :w // 2] * 8 + n * fx) / 41.0)).astype(np.int32)
+            out += np.clip(c, 0, 255).astype(np.uint8).tobytes()
+            out += np.clip(255 - c, 0, 255).astype(np.uint8).tobytes()
+        return bytes(out)
+    raise ValueError(kind)
+
+
+KINDS = ["synth", "noise", "flat", "extreme", "fastmotion", "subpel"]
+
+
+def one_case(rng, lib, enc_tool, tmp, max_mbs, run=True):
+    while True:
+        w = int(rng.integers(8, 41)) * 2 if rng.random() < 0.5 else int(rng.integers(1, 26)) * 16
+        h = int(rng.integers(8, 41)) * 2 if rng.random() < 0.5 else int(rng.integers(1, 20)) * 16
+        if w < 16 or h < 16:
+            continue
+        mbs = ((w + 15) // 16) * ((h + 15) // 16)
+        if mbs <= max_mbs:
+            break
+    mb_h = (h + 15) // 16
+    frames = int(rng.integers(2, 7))
+    qp = int(rng.choice([0, 1, 5, 10, 12, 18, 24, 26, 30, 36, 40, 45, 51, int(rng.integers(0, 52))]))
+    iper = int(rng.choice([0, 0, 0, 1, 2, 3]))
+    cplx = int(rng.choice([0, 0, 1, 2]))
+    idc = int(rng.choice([0, 0, 1, 2]))
+    nsl = int(rng.integers(1, min(4, mb_h) + 1))
+    kind = str(rng.choice(KINDS))
+    yuv = content(kind, w, h, frames, rng)
+    params = dict(fMaxFrameRate=30.0, iTargetBitrate=5000000, iDLayerQp=qp, uiIntraPeriod=iper, iComplexityMode=cplx,
+                  iLoopFilterDisableIdc=idc)
+    flags = ["-rc", "-1", "-qp", str(qp), "-fps", "30", "-iper", str(iper), "-complexity", str(cplx), "-deblock", str(idc), "-quiet"]
+    if nsl > 1:
+        params.update(uiSliceMode=1, uiSliceNum=nsl)
+        flags += ["-slcmd", "1", "-slcnum", str(nsl)]
+    desc = "%dx%d f%d qp%d iper%d c%d idc%d sl%d %s" % (w, h, frames, qp, iper, cplx, idc, nsl, kind)
+    if not run:                                            # --only: just keep the random stream in step
+        return desc, "ok"
+    fi, fo = os.path.join(tmp, "in.yuv"), os.path.join(tmp, "ref.264")
+    open(fi, "wb").write(yuv)
+    r = subprocess.run([enc_tool, "-i", fi, "-w", str(w), "-h", str(h), "-o", fo] + flags, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    ref_failed = r.returncode != 0
+    ref = b"" if ref_failed else open(fo, "rb").read()
+    try:
+        bs, _ = oh.encode_sequence(yuv, w, h, lib_path=lib, **params)
+    except oh.WelsHipError as e:
+        # the reference gives up with cmMallocMemeError (3) when a frame overflows its bitstream buffer even at QP 50
+        if ref_failed and e.code == 3 and "EncodeFrame failed: 3" in r.stderr.decode():
+            return desc, "ok (both refuse the frame: bitstream buffer overflow)"
+        return desc, "ERROR %s" % e
+    if ref_failed:
+        return desc, "MISMATCH reference failed (%s), ours encoded %d B" % (r.stderr.decode().strip().splitlines()[-1], len(bs))
+    open(os.path.join(tmp, "ours.264"), "wb").write(bs)
+    if bs == ref:
+        return desc, "ok"
+    n = min(len(bs), len(ref))
+    first = next((i for i in range(n) if bs[i] != ref[i]), n)
+    return desc, "MISMATCH ours %d B ref %d B first diff at %d" % (len(bs), len(ref), first)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=100)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--max-mbs", type=int, default=400)
+    ap.add_argument("--hip", action="store_true")
+    ap.add_argument("--only", type=int, default=-1, help="run just this case index of the seed (same random stream)")
+    ap.add_argument("--keep", default=None, help="directory that keeps in.yuv / ref.264 / ours.264 of the last case run")
+    a = ap.parse_args()
+    enc_tool = os.path.join(ROOT, "oracle", "_ref", "ref_enc")
+    if not os.path.exists(enc_tool):
+        sys.exit("oracle/_ref/ref_enc not built (python -c 'import __graft_entry__ as g; g.build()')")
+    lib = B.build_hip() if a.hip else B.build_emu()
+    rng = np.random.default_rng(a.seed)
+    bad = 0
+    with tempfile.TemporaryDirectory() as tmpdir:
+        tmp = a.keep or tmpdir
+        os.makedirs(tmp, exist_ok=True)
+        for i in range(a.cases if a.only < 0 else a.only + 1):
+            desc, res = one_case(rng, lib, enc_tool, tmp, a.max_mbs, run=(a.only < 0 or i == a.only))
+            if a.only >= 0 and i != a.only:
+                continue
+            if not res.startswith("ok"):
+                bad += 1
+            print("%4d %-50s %s" % (i, desc, res), flush=True)
+    print("%d cases, %d failed" % (a.cases if a.only < 0 else 1, bad))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

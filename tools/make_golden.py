@@ -14,9 +14,9 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from openh264_amd.utils.synth import synth_sequence  # noqa: E402
+from openh264_amd.utils.synth import make_sequence  # noqa: E402
 
-# name -> (w, h, frames, ref_enc flags, WelsHipEncParam overrides)
+# name -> (w, h, frames, ref_enc flags, WelsHipEncParam overrides[, content])   content: see utils/synth.py make_sequence
 CASES = {
     "smoke_160x96_iper1_qp24": (160, 96, 3, ["-iper", "1", "-qp", "24"], dict(uiIntraPeriod=1, iDLayerQp=24)),
     "i_176x144_qp24": (176, 144, 4, ["-iper", "1", "-qp", "24"], dict(uiIntraPeriod=1, iDLayerQp=24)),
@@ -36,6 +36,13 @@ CASES = {
     "p_152x100_qp24_crop": (152, 100, 6, ["-iper", "0", "-qp", "24"], dict(uiIntraPeriod=0, iDLayerQp=24)),
     "p_1280x720_qp24": (1280, 720, 3, ["-iper", "0", "-qp", "24"], dict(uiIntraPeriod=0, iDLayerQp=24)),
     "p_1920x1080_qp24_4slices": (1920, 1080, 3, ["-iper", "0", "-qp", "24", "-slcmd", "1", "-slcnum", "4"], dict(uiIntraPeriod=0, iDLayerQp=24, uiSliceMode=1, uiSliceNum=4)),
+    # one slice after the small-picture fall-back: deblocking idc 2 is signalled as 0 (encoder_ext.cpp:1109-1117)
+    "p_36x60_qp24_3slices_idc2_small": (36, 60, 4, ["-iper", "0", "-qp", "24", "-slcmd", "1", "-slcnum", "3", "-deblock", "2"], dict(uiIntraPeriod=0, iDLayerQp=24, uiSliceMode=1, uiSliceNum=3, iLoopFilterDisableIdc=2)),
+    # CAVLC level-escape overflow -> macroblock re-encoded at QP+2 (svc_encode_slice.cpp:572-576,1863-1867)
+    # (finer checkerboards at these QPs make the reference itself fail with cmMallocMemeError: its slice buffer overflows)
+    "i_76x80_qp3_checker_overflow": (76, 80, 3, ["-iper", "1", "-qp", "3"], dict(uiIntraPeriod=1, iDLayerQp=3), "checker5"),
+    "p_144x96_qp1_checker_2slices_overflow": (144, 96, 4, ["-iper", "0", "-qp", "1", "-slcmd", "1", "-slcnum", "2"], dict(uiIntraPeriod=0, iDLayerQp=1, uiSliceMode=1, uiSliceNum=2), "checker8"),
+    "p_64x64_qp3_checker_idc1_overflow": (64, 64, 4, ["-iper", "0", "-qp", "3", "-deblock", "1"], dict(uiIntraPeriod=0, iDLayerQp=3, iLoopFilterDisableIdc=1), "checker5"),
 }
 COMMON = ["-rc", "-1", "-fps", "30", "-quiet"]
 
@@ -44,8 +51,10 @@ def main():
     enc = os.path.join(ROOT, "oracle", "_ref", "ref_enc")
     dec = os.path.join(ROOT, "oracle", "_ref", "ref_dec")
     out = {}
-    for name, (w, h, n, flags, params) in CASES.items():
-        yuv = synth_sequence(w, h, n)
+    for name, case in CASES.items():
+        w, h, n, flags, params = case[:5]
+        content = case[5] if len(case) > 5 else "synth"
+        yuv = make_sequence(content, w, h, n)
         with tempfile.TemporaryDirectory() as td:
             fi, fo, fd = os.path.join(td, "in.yuv"), os.path.join(td, "o.264"), os.path.join(td, "d.yuv")
             open(fi, "wb").write(yuv)
@@ -53,7 +62,7 @@ def main():
             bs = open(fo, "rb").read()
             subprocess.check_call([dec, fo, fd], stdout=subprocess.DEVNULL)
             rec = open(fd, "rb").read()
-        out[name] = {"w": w, "h": h, "frames": n, "ref_flags": flags + COMMON, "params": params,
+        out[name] = {"w": w, "h": h, "frames": n, "ref_flags": flags + COMMON, "params": params, "content": content,
                      "input_sha1": hashlib.sha1(yuv).hexdigest(), "bytes": len(bs), "sha1": hashlib.sha1(bs).hexdigest(),
                      "recon_sha1": hashlib.sha1(rec).hexdigest()}
         print(name, len(bs), out[name]["sha1"])
