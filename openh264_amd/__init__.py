@@ -174,9 +174,10 @@ class Encoder:
             pass
 
 
-def encode_sequence(yuv_bytes, width, height, lib_path=None, stats=None, **params):
+def encode_sequence(yuv_bytes, width, height, lib_path=None, stats=None, force_idr_at=-1, **params):
     """Convenience: encode a whole I420 sequence; returns (bitstream bytes, last recon frame).
-    `stats`: optional dict that receives developer statistics (overflow_reencodes)."""
+    `stats`: optional dict that receives developer statistics (overflow_reencodes);
+    `force_idr_at`: ForceIntraFrame(true) is called before that frame index."""
     enc = Encoder(lib_path)
     p = enc.GetDefaultParams()
     p.iPicWidth, p.iPicHeight = width, height
@@ -188,6 +189,8 @@ def encode_sequence(yuv_bytes, width, height, lib_path=None, stats=None, **param
     fsz = width * height * 3 // 2
     out = bytearray()
     for i in range(len(yuv_bytes) // fsz):
+        if i == force_idr_at:
+            enc.ForceIntraFrame(True)
         rc, _, bs, _ = enc.EncodeFrame(yuv_bytes[i * fsz:(i + 1) * fsz], timestamp=i * 33)
         if rc:
             raise WelsHipError(rc, enc.last_error())

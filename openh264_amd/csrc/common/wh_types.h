@@ -78,9 +78,10 @@ typedef struct WhPicJob {
   WhMbRecord*    records;    // mb_w*mb_h
   WhMbState*     mbs;        // mb_w*mb_h, this picture
   const WhMbState* ref_mbs;  // previous picture's states (P pictures)
-  int32_t        qp;         // picture QP (constant-QP mode) -- per-MB delta via qp_delta
+  int32_t        qp;         // picture QP (constant-QP mode) -- per-MB offsets via mb_ctl
   int32_t        slice_type; // WH_SLICE_I / WH_SLICE_P
-  const int8_t*  qp_delta;   // optional per-MB QP offsets (adaptive quant) or NULL
+  const uint16_t* mb_ctl;    // optional per-MB control words or NULL: bits 0-7 signed QP offset, bits 8-13 the cbp the
+                             // previous encoding pass of this MB left behind (re-encode after a CAVLC overflow)
   int32_t        ref_is_p;   // reference picture was a P picture (co-located MV candidates)
   int32_t        pad;
   const uint8_t* prev_src_y; // luma of the previous source picture (VAA 8x8 SADs, LOW complexity P pictures)

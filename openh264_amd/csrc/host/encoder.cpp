@@ -68,8 +68,8 @@ struct SessionCore {
   size_t vcl_start = 0;
   // per-MB QP offsets of the picture being encoded: all zero (and not passed to the device) unless a macroblock had to
   // be re-encoded after a CAVLC level overflow (svc_encode_slice.cpp:572-576,1863-1867)
-  int8_t* d_qp_delta = nullptr;
-  std::vector<int8_t> h_qp_delta;
+  uint16_t* d_mb_ctl = nullptr;       // WhPicJob::mb_ctl: QP offset | cbp of the previous pass << 8
+  std::vector<uint16_t> h_mb_ctl;
   bool qp_map_in_use = false;
   int overflow_mb = -1;               // set by finish_frame when it returns WELSHIP_ERR_VLC_OVERFLOW
   int overflow_qp = 0;                // uiLumaQp of that macroblock when the overflow was detected
@@ -90,6 +90,9 @@ struct SessionCore {
         p->bEnableDenoise || p->bEnableFrameSkip) { set_err ("AQ/BGD/scene-change/LTR/denoise/frame-skip are not supported"); return WELSHIP_ERR_UNSUPPORTED; }
     if (p->uiSliceMode != 0 && p->uiSliceMode != 1) { set_err ("slice mode must be 0 or 1"); return WELSHIP_ERR_UNSUPPORTED; }
     if (p->iLoopFilterDisableIdc < 0 || p->iLoopFilterDisableIdc > 2) { set_err ("deblocking idc must be 0..2"); return WELSHIP_ERR_UNSUPPORTED; }
+    if (p->iLoopFilterAlphaC0Offset < -6 || p->iLoopFilterAlphaC0Offset > 6 || p->iLoopFilterBetaOffset < -6 || p->iLoopFilterBetaOffset > 6) {
+      set_err ("deblocking alpha/beta offsets must be -6..6"); return WELSHIP_ERR_INIT_PARA;     // ParamValidation, encoder_ext.cpp:316-323
+    }
     if (p->eSpsPpsIdStrategy != 0 && p->eSpsPpsIdStrategy != 1) { set_err ("SpsPpsIdStrategy must be 0 or 1"); return WELSHIP_ERR_UNSUPPORTED; }
     return WELSHIP_OK;
   }
@@ -121,7 +124,8 @@ struct SessionCore {
     s.complexity = p->iComplexityMode;
     s.chroma_qp_offset = 0;
     s.deblock_idc = p->iLoopFilterDisableIdc;
-    s.alpha_offset = p->iLoopFilterAlphaC0Offset; s.beta_offset = p->iLoopFilterBetaOffset;
+    // the API values are slice_alpha_c0_offset_div2 / slice_beta_offset_div2 (InitDqLayers, encoder_ext.cpp:1104-1105)
+    s.alpha_offset = p->iLoopFilterAlphaC0Offset * 2; s.beta_offset = p->iLoopFilterBetaOffset * 2;
     s.mv_range = 64;
     if (compute_slices()) { set_err ("invalid slice number"); return WELSHIP_ERR_INIT_PARA; }
     // InitDqLayers (encoder_ext.cpp:1109-1117): with a single slice (requested, or after the fall-back above)
@@ -175,8 +179,8 @@ struct SessionCore {
     d_order = nullptr;
     if (d_dbflags) be->free (d_dbflags);
     d_dbflags = nullptr;
-    if (d_qp_delta) be->free (d_qp_delta);
-    d_qp_delta = nullptr;
+    if (d_mb_ctl) be->free (d_mb_ctl);
+    d_mb_ctl = nullptr;
     be = nullptr;
   }
 
@@ -214,14 +218,14 @@ struct SessionCore {
     job->ref_mbs = idr ? nullptr : r.mbs;
     job->qp = prm.iDLayerQp;
     job->slice_type = idr ? WH_SLICE_I : WH_SLICE_P;
-    job->qp_delta = nullptr;
+    job->mb_ctl = nullptr;
     job->ref_is_p = r.is_p ? 1 : 0;
     job->prev_src_y = d_src[last_slot];
     last_slot = slot;
     job->db_flags = d_dbflags;
     if (++db_gen == 0) db_gen = 1;
     job->db_gen = db_gen;
-    if (qp_map_in_use) { std::fill (h_qp_delta.begin(), h_qp_delta.end(), (int8_t)0); qp_map_in_use = false; }
+    if (qp_map_in_use) { std::fill (h_mb_ctl.begin(), h_mb_ctl.end(), (uint16_t)0); qp_map_in_use = false; }
     cur_job = *job;
   }
 
@@ -231,20 +235,21 @@ struct SessionCore {
   // the reference's TRY_REENCODING loop.  Fails once the macroblock's QP has reached 50, as the reference does.
   int retry_after_overflow (WhPicJob* job) {
     if (overflow_mb < 0 || overflow_mb >= num_mb) return WELSHIP_ERR_UNKNOWN;
-    if (h_qp_delta.empty()) h_qp_delta.assign (num_mb, 0);
-    if (!d_qp_delta) d_qp_delta = (int8_t*)be->alloc (num_mb);
+    if (h_mb_ctl.empty()) h_mb_ctl.assign (num_mb, 0);
+    if (!d_mb_ctl) d_mb_ctl = (uint16_t*)be->alloc (sizeof (uint16_t) * num_mb);
     // `pCurMb->uiLumaQp < 50` (svc_encode_slice.cpp:572,1863); beyond that the reference gives up on the frame with
     // cmMallocMemeError (welsEncoderExt.cpp:415-420)
     if (overflow_qp >= 50) { set_err ("bitstream overflow that raising the macroblock QP cannot resolve (reference: cmMallocMemeError)"); return WELSHIP_ERR_MEMORY; }
     // uiLumaQp += DELTA_QP: on top of the QP the macroblock had when the overflow was seen -- for a macroblock without
     // coded residual that is the QP it inherited from the previous one (svc_set_mb_syn_cavlc.cpp:299), not its own
-    h_qp_delta[overflow_mb] = (int8_t) (overflow_qp + 2 - prm.iDLayerQp);
+    // ... and uiCbp is not cleared between the passes either (kernels/frame_kernels.h wh_mb_stale_cbp)
+    h_mb_ctl[overflow_mb] = (uint16_t) ((uint8_t) (int8_t) (overflow_qp + 2 - prm.iDLayerQp) | ((h_records[overflow_mb].cbp & 0x3f) << 8));
     qp_map_in_use = true;
     ++overflow_reencodes;
-    be->upload (d_qp_delta, h_qp_delta.data(), num_mb);
+    be->upload (d_mb_ctl, h_mb_ctl.data(), sizeof (uint16_t) * num_mb);
     if (++db_gen == 0) db_gen = 1;
     cur_job.db_gen = db_gen;
-    cur_job.qp_delta = d_qp_delta;
+    cur_job.mb_ctl = d_mb_ctl;
     *job = cur_job;
     return WELSHIP_OK;
   }

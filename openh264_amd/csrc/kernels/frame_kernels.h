@@ -63,9 +63,12 @@ WH_FN void wh_store_mb (WhMbLds& S, const WhSeqParams& P, const WhPicJob& J, int
 
 // QP of one macroblock: the picture QP, plus the per-MB offset when the host supplies a map (WelsRcMbInitDisable,
 // ratectl.cpp, and UpdateQpForOverflow, svc_encode_slice.cpp:526-529: the re-encode after a CAVLC level overflow).
-WH_FN int wh_mb_qp (const WhPicJob& J, int xy) {
-  return wh_clip3 (J.qp + (J.qp_delta ? (int) ((const WH_G int8_t*)J.qp_delta)[xy] : 0), 0, 51);
-}
+WH_FN int wh_mb_ctl (const WhPicJob& J, int xy) { return J.mb_ctl ? (int) ((const WH_G uint16_t*)J.mb_ctl)[xy] : 0; }
+WH_FN int wh_mb_qp (const WhPicJob& J, int ctl) { return wh_clip3 (J.qp + (int) (int8_t) (ctl & 0xff), 0, 51); }
+// The reference clears uiCbp once per macroblock (WelsMdIntraInit, svc_base_layer_md.cpp:310), not per encoding pass:
+// when a macroblock is encoded again after an overflow, an Intra4x4 result ORs its luma bits onto whatever the previous
+// pass left (svc_encode_mb.cpp:173) and the chroma bits only ever grow (svc_encode_mb.cpp:299-306).
+WH_FN int wh_mb_stale_cbp (int ctl) { return (ctl >> 8) & 0x3f; }
 
 // QP_Y as the decoder derives it, for the deblocking filter: a macroblock that codes no mb_qp_delta (P_Skip, or
 // cbp == 0 and not Intra16x16) inherits the QP of the previous macroblock of its slice, the first one the slice QP
@@ -104,11 +107,12 @@ WH_FN void wh_qp_chain_slice (const WhSeqParams& P, const WhPicJob& J, int first
 WH_FN void wh_intra_mb_body (WhMbLds& S, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby) {
   const int xy = mby * P.mb_w + mbx;
   const int avail = wh_mb_avail (P, mbx, mby);
-  const int qp = wh_mb_qp (J, xy);
+  const int ctl = wh_mb_ctl (J, xy);
+  const int qp = wh_mb_qp (J, ctl);
   const int qpc = kWhChromaQp[wh_clip3 (qp + P.chroma_qp_offset, 0, 51)];
   wh_load_mb_tile (S, P, J, mbx, mby);
   WhIntraResult r;
-  wh_intra_md_enc (S, P, J, mbx, mby, avail, qp, qpc, &r);
+  wh_intra_md_enc (S, P, J, mbx, mby, avail, qp, qpc, &r, wh_mb_stale_cbp (ctl));
   // intra MBs carry no motion: clear mv/ref so that later P pictures / deblocking see zeros
   WV_LANES_BEGIN (lane)
   WH_G WhMbState* Ms = (WH_G WhMbState*)J.mbs + xy;

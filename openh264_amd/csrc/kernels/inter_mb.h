@@ -711,7 +711,8 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, WhInterStage& G, const WhSeqParams& 
   const int w = P.mb_w, xy = mby * w + mbx;
   const int slice_idc = X.slice_idc;
   const int avail = wh_mb_avail_in_slice (P, mbx, mby, X.slice_first);
-  const int qp = wh_mb_qp (J, xy);
+  const int ctl = wh_mb_ctl (J, xy);
+  const int qp = wh_mb_qp (J, ctl);
   const int qpc = kWhChromaQp[wh_clip3 (qp + P.chroma_qp_offset, 0, 51)];
   const int lambda = kWhLambda[qp];
   const int use_satd = P.complexity > 0;        // pfMdCost == SATD, pfCalculateSatd == CalculateSatdCost
@@ -828,7 +829,9 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, WhInterStage& G, const WhSeqParams& 
   const bool try_skip = l_sk || t_sk || tl_sk || tr_sk;
   const bool keep_skip = l_sk && t_sk && tr_sk;
   bool b_skip = false;
+  int stale_cbp = wh_mb_stale_cbp (ctl);
   if ((ref_is_p && ref_mb_type == WH_MB_PSKIP) || try_skip) {
+    stale_cbp = 0;          // WelsMdPSkipEnc clears uiCbp whenever the skip test runs (svc_base_layer_md.cpp:1376)
     // PredictSadSkip (md.cpp:872-910)
     int sad_pred_skip;
     {
@@ -919,7 +922,7 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, WhInterStage& G, const WhSeqParams& 
   WhIntraResult ir;
   if (!done) {
     // WelsMdFirstIntraMode: I16x16 cost vs the inter/skip cost so far
-    if (wh_intra_md_enc_p (M, P, J, mbx, mby, avail, qp, qpc, cost_luma, &ir, &i16c)) { intra = true; done = true; }
+    if (wh_intra_md_enc_p (M, P, J, mbx, mby, avail, qp, qpc, cost_luma, &ir, &i16c, stale_cbp)) { intra = true; done = true; }
   }
   if (!done && b_skip) { mb_type = WH_MB_PSKIP; done = true; }
   WH_PROF_MARK (P, M, 3);   // I16x16 test (+ intra encode when intra wins)

@@ -294,7 +294,7 @@ WH_FN void wh_i16_costs (WhMbLds& S, int avail, int use_satd, int lambda, WhI16C
 }
 
 WH_FN bool wh_intra_md_enc_p (WhMbLds& S, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, int avail, int qp, int qpc,
-                              int inter_cost, WhIntraResult* o, const WhI16Cost* pre = nullptr) {
+                              int inter_cost, WhIntraResult* o, const WhI16Cost* pre = nullptr, int stale_cbp = 0) {
   const int lambda = kWhLambda[qp];
   const int use_satd = P.complexity > 0;
   const bool has_l = (avail & WH_AV_LEFT) != 0, has_t = (avail & WH_AV_TOP) != 0;
@@ -539,8 +539,13 @@ WH_FN bool wh_intra_md_enc_p (WhMbLds& S, const WhSeqParams& P, const WhPicJob& 
     if (c < cbest_cost) { cbest_cost = c; cbest = m; }
   }
   if (clast != cbest) wh_pred_chroma (S, cbest, st, sl, cpb, cpc, cpa);
-  const int cbp_c = wh_encrec_chroma (S, qpc, 1);
+  int cbp_c = wh_encrec_chroma (S, qpc, 1);
   wh_idct_chroma (S);
+  if (mb_type == WH_MB_I4x4 && stale_cbp) {      // see wh_mb_stale_cbp: only Intra4x4 keeps what an earlier pass left
+    cbp |= stale_cbp & 15;
+    const int c0 = stale_cbp >> 4;
+    if (cbp_c != 2) cbp_c = (c0 == 2) ? 2 : (cbp_c | c0);
+  }
 
   o->mb_type = mb_type;
   o->cbp = cbp | (cbp_c << 4);
@@ -552,6 +557,6 @@ WH_FN bool wh_intra_md_enc_p (WhMbLds& S, const WhSeqParams& P, const WhPicJob& 
   return true;
 }
 WH_FN void wh_intra_md_enc (WhMbLds& S, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, int avail, int qp, int qpc,
-                            WhIntraResult* o) {
-  (void)wh_intra_md_enc_p (S, P, J, mbx, mby, avail, qp, qpc, 0x7fffffff, o);
+                            WhIntraResult* o, int stale_cbp = 0) {
+  (void)wh_intra_md_enc_p (S, P, J, mbx, mby, avail, qp, qpc, 0x7fffffff, o, nullptr, stale_cbp);
 }

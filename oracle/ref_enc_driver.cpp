@@ -34,6 +34,7 @@ int main (int argc, char** argv) {
   int rc = -1, qp = 24, bitrate = 5000000, iper = 0, numtl = 1, complexity = 0;
   int slcmd = 0, slcnum = 1, slcmbnum = 0, threads = 1, loadbal = 0, deblock = 0;
   int aq = 0, bgd = 0, scene = 0, ltr = 0, denoise = 0, frameskip = 0, cabac = 0, spsid = 1, usage = 0;
+  int alpha = 0, beta = 0, crop = 1, forceidr = -1;
   for (int i = 1; i < argc; ++i) {
     const char* a = argv[i];
     auto next = [&] () -> const char* { if (i + 1 >= argc) { std::fprintf (stderr, "missing value for %s\n", a); std::exit (2); } return argv[++i]; };
@@ -65,6 +66,10 @@ int main (int argc, char** argv) {
     else if (arg_eq (a, "-spsid")) spsid = std::atoi (next());
     else if (arg_eq (a, "-usage")) usage = std::atoi (next());
     else if (arg_eq (a, "-base")) use_base = 1;
+    else if (arg_eq (a, "-alpha")) alpha = std::atoi (next());
+    else if (arg_eq (a, "-beta")) beta = std::atoi (next());
+    else if (arg_eq (a, "-crop")) crop = std::atoi (next());
+    else if (arg_eq (a, "-forceidr")) forceidr = std::atoi (next());     // ForceIntraFrame(true) before frame N
     else if (arg_eq (a, "-quiet")) quiet = 1;
     else { std::fprintf (stderr, "unknown option %s\n", a); return 2; }
   }
@@ -95,6 +100,8 @@ int main (int argc, char** argv) {
     p.iMultipleThreadIdc = (unsigned short)threads;
     p.bUseLoadBalancing = loadbal != 0;
     p.iLoopFilterDisableIdc = deblock;
+    p.iLoopFilterAlphaC0Offset = alpha; p.iLoopFilterBetaOffset = beta;
+    p.bEnableFrameCroppingFlag = crop != 0;
     p.bEnableDenoise = denoise != 0;
     p.bEnableBackgroundDetection = bgd != 0;
     p.bEnableAdaptiveQuant = aq != 0;
@@ -126,6 +133,7 @@ int main (int argc, char** argv) {
   while ((frames < 0 || n < frames) && std::fread (buf.data(), 1, fsz, fi) == fsz) {
     std::memset (&info, 0, sizeof (info));
     pic.uiTimeStamp = (long long) (n * (1000.0 / fps) + 0.5);
+    if (n == forceidr) enc->ForceIntraFrame (true);
     auto t0 = std::chrono::steady_clock::now();
     ret = enc->EncodeFrame (&pic, &info);
     auto t1 = std::chrono::steady_clock::now();

@@ -97,14 +97,20 @@ def one_case(rng, lib, enc_tool, tmp, max_mbs, run=True):
     idc = int(rng.choice([0, 0, 1, 2]))
     nsl = int(rng.integers(1, min(4, mb_h) + 1))
     kind = str(rng.choice(KINDS))
+    alpha, beta = (int(x) for x in rng.choice([0, 0, 0, -6, -3, 2, 6], 2))
+    crop = int(rng.random() < 0.85)
+    spsid = int(rng.random() < 0.7)
+    fidr = int(rng.integers(1, frames)) if rng.random() < 0.2 else -1
     yuv = content(kind, w, h, frames, rng)
     params = dict(fMaxFrameRate=30.0, iTargetBitrate=5000000, iDLayerQp=qp, uiIntraPeriod=iper, iComplexityMode=cplx,
-                  iLoopFilterDisableIdc=idc)
-    flags = ["-rc", "-1", "-qp", str(qp), "-fps", "30", "-iper", str(iper), "-complexity", str(cplx), "-deblock", str(idc), "-quiet"]
+                  iLoopFilterDisableIdc=idc, iLoopFilterAlphaC0Offset=alpha, iLoopFilterBetaOffset=beta,
+                  bEnableFrameCroppingFlag=crop, eSpsPpsIdStrategy=spsid)
+    flags = ["-rc", "-1", "-qp", str(qp), "-fps", "30", "-iper", str(iper), "-complexity", str(cplx), "-deblock", str(idc),
+             "-alpha", str(alpha), "-beta", str(beta), "-crop", str(crop), "-spsid", str(spsid), "-forceidr", str(fidr), "-quiet"]
     if nsl > 1:
         params.update(uiSliceMode=1, uiSliceNum=nsl)
         flags += ["-slcmd", "1", "-slcnum", str(nsl)]
-    desc = "%dx%d f%d qp%d iper%d c%d idc%d sl%d %s" % (w, h, frames, qp, iper, cplx, idc, nsl, kind)
+    desc = "%dx%d f%d qp%d iper%d c%d idc%d a%d b%d crop%d id%d fi%d sl%d %s" % (w, h, frames, qp, iper, cplx, idc, alpha, beta, crop, spsid, fidr, nsl, kind)
     if not run:                                            # --only: just keep the random stream in step
         return desc, "ok"
     fi, fo = os.path.join(tmp, "in.yuv"), os.path.join(tmp, "ref.264")
@@ -113,7 +119,7 @@ def one_case(rng, lib, enc_tool, tmp, max_mbs, run=True):
     ref_failed = r.returncode != 0
     ref = b"" if ref_failed else open(fo, "rb").read()
     try:
-        bs, _ = oh.encode_sequence(yuv, w, h, lib_path=lib, **params)
+        bs, _ = oh.encode_sequence(yuv, w, h, lib_path=lib, force_idr_at=fidr, **params)
     except oh.WelsHipError as e:
         # the reference gives up with cmMallocMemeError (3) when a frame overflows its bitstream buffer even at QP 50
         if ref_failed and e.code == 3 and "EncodeFrame failed: 3" in r.stderr.decode():
@@ -153,7 +159,7 @@ def main():
                 continue
             if not res.startswith("ok"):
                 bad += 1
-            print("%4d %-50s %s" % (i, desc, res), flush=True)
+            print("%4d %-72s %s" % (i, desc, res), flush=True)
     print("%d cases, %d failed" % (a.cases if a.only < 0 else 1, bad))
     sys.exit(1 if bad else 0)
 
