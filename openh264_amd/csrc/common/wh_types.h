@@ -43,7 +43,8 @@ typedef struct WhMbRecord {
   int16_t  mvd[16][2];       // mvd_l0 per 4x4 block in raster order (x,y), quarter-pel
   uint8_t  nzc[24];          // total_coeff: luma raster 0..15, Cb raster 16..19, Cr raster 20..23
   int32_t  cost;             // mode-decision cost of the chosen mode (for rate control)
-  uint8_t  pad[20];
+  int16_t  mv_tr[2];         // inter MBs: final motion vector of the top-right 4x4 block (see WhMbCtl::cell12_mv)
+  uint8_t  pad[16];
   // coefficient levels in zig-zag order:
   int16_t  luma[16][16];     // per luma4x4BlkIdx; I16x16: entries 0..14 = AC, [15] = 0
   int16_t  luma_dc[16];      // Intra16x16 DC levels
@@ -70,6 +71,18 @@ typedef struct WhMbState {
   uint8_t  pad1[4];
 } WhMbState;                 // 144 bytes
 
+// ---- optional per-MB control word (WhPicJob::mb_ctl) ---------------------------------------------
+// All zero for a macroblock that is encoded for the first time.  The reference re-encodes a macroblock at QP+2 after a
+// CAVLC overflow WITHOUT re-initialising its per-MB state (TRY_REENCODING, svc_encode_slice.cpp:564-576,1845-1867), so
+// three things leak from the previous pass into the next one and are reproduced through this word:
+typedef struct WhMbCtl {
+  int8_t   qp_delta;         // QP of this pass minus the picture QP
+  uint8_t  stale_cbp;        // uiCbp left by the previous pass (only cleared in WelsMdIntraInit: an Intra4x4 result ORs onto it)
+  uint8_t  cell12_valid;     // a previous pass ended as P8x16: update_P8x16_motion_info (mv_pred.cpp:235-276) then wrote the
+  uint8_t  pad;              //   second partition's vector over MV-cache cell 12 (left neighbour, 2nd 4x4 row) with ref 0,
+  int16_t  cell12_mv[2];     //   which the 16x8 lower-partition predictor reads as its top-left neighbour
+} WhMbCtl;
+
 // ---- one picture being encoded (one frame of one session) ---------------------------------------
 typedef struct WhPicJob {
   const uint8_t* src[3];     // source planes, dims = mb_w*16 x mb_h*16 (host pads), own strides
@@ -80,8 +93,7 @@ typedef struct WhPicJob {
   const WhMbState* ref_mbs;  // previous picture's states (P pictures)
   int32_t        qp;         // picture QP (constant-QP mode) -- per-MB offsets via mb_ctl
   int32_t        slice_type; // WH_SLICE_I / WH_SLICE_P
-  const uint16_t* mb_ctl;    // optional per-MB control words or NULL: bits 0-7 signed QP offset, bits 8-13 the cbp the
-                             // previous encoding pass of this MB left behind (re-encode after a CAVLC overflow)
+  const WhMbCtl* mb_ctl;     // optional per-MB control words (QP offsets, re-encode state) or NULL
   int32_t        ref_is_p;   // reference picture was a P picture (co-located MV candidates)
   int32_t        pad;
   const uint8_t* prev_src_y; // luma of the previous source picture (VAA 8x8 SADs, LOW complexity P pictures)

@@ -68,8 +68,8 @@ struct SessionCore {
   size_t vcl_start = 0;
   // per-MB QP offsets of the picture being encoded: all zero (and not passed to the device) unless a macroblock had to
   // be re-encoded after a CAVLC level overflow (svc_encode_slice.cpp:572-576,1863-1867)
-  uint16_t* d_mb_ctl = nullptr;       // WhPicJob::mb_ctl: QP offset | cbp of the previous pass << 8
-  std::vector<uint16_t> h_mb_ctl;
+  WhMbCtl* d_mb_ctl = nullptr;        // WhPicJob::mb_ctl
+  std::vector<WhMbCtl> h_mb_ctl;
   bool qp_map_in_use = false;
   int overflow_mb = -1;               // set by finish_frame when it returns WELSHIP_ERR_VLC_OVERFLOW
   int overflow_qp = 0;                // uiLumaQp of that macroblock when the overflow was detected
@@ -225,7 +225,7 @@ struct SessionCore {
     job->db_flags = d_dbflags;
     if (++db_gen == 0) db_gen = 1;
     job->db_gen = db_gen;
-    if (qp_map_in_use) { std::fill (h_mb_ctl.begin(), h_mb_ctl.end(), (uint16_t)0); qp_map_in_use = false; }
+    if (qp_map_in_use) { memset (h_mb_ctl.data(), 0, sizeof (WhMbCtl) * h_mb_ctl.size()); qp_map_in_use = false; }
     cur_job = *job;
   }
 
@@ -235,18 +235,22 @@ struct SessionCore {
   // the reference's TRY_REENCODING loop.  Fails once the macroblock's QP has reached 50, as the reference does.
   int retry_after_overflow (WhPicJob* job) {
     if (overflow_mb < 0 || overflow_mb >= num_mb) return WELSHIP_ERR_UNKNOWN;
-    if (h_mb_ctl.empty()) h_mb_ctl.assign (num_mb, 0);
-    if (!d_mb_ctl) d_mb_ctl = (uint16_t*)be->alloc (sizeof (uint16_t) * num_mb);
+    if (h_mb_ctl.empty()) { h_mb_ctl.resize (num_mb); memset (h_mb_ctl.data(), 0, sizeof (WhMbCtl) * num_mb); }
+    if (!d_mb_ctl) d_mb_ctl = (WhMbCtl*)be->alloc (sizeof (WhMbCtl) * num_mb);
     // `pCurMb->uiLumaQp < 50` (svc_encode_slice.cpp:572,1863); beyond that the reference gives up on the frame with
     // cmMallocMemeError (welsEncoderExt.cpp:415-420)
     if (overflow_qp >= 50) { set_err ("bitstream overflow that raising the macroblock QP cannot resolve (reference: cmMallocMemeError)"); return WELSHIP_ERR_MEMORY; }
     // uiLumaQp += DELTA_QP: on top of the QP the macroblock had when the overflow was seen -- for a macroblock without
     // coded residual that is the QP it inherited from the previous one (svc_set_mb_syn_cavlc.cpp:299), not its own
-    // ... and uiCbp is not cleared between the passes either (kernels/frame_kernels.h wh_mb_stale_cbp)
-    h_mb_ctl[overflow_mb] = (uint16_t) ((uint8_t) (int8_t) (overflow_qp + 2 - prm.iDLayerQp) | ((h_records[overflow_mb].cbp & 0x3f) << 8));
+    // ... and neither uiCbp nor the MV cache are re-initialised between the passes (WhMbCtl, common/wh_types.h)
+    WhMbCtl& ctl = h_mb_ctl[overflow_mb];
+    const WhMbRecord& rec = h_records[overflow_mb];
+    ctl.qp_delta = (int8_t) (overflow_qp + 2 - prm.iDLayerQp);
+    ctl.stale_cbp = rec.cbp & 0x3f;
+    if (rec.mb_type == WH_MB_P8x16) { ctl.cell12_valid = 1; ctl.cell12_mv[0] = rec.mv_tr[0]; ctl.cell12_mv[1] = rec.mv_tr[1]; }
     qp_map_in_use = true;
     ++overflow_reencodes;
-    be->upload (d_mb_ctl, h_mb_ctl.data(), sizeof (uint16_t) * num_mb);
+    be->upload (d_mb_ctl, h_mb_ctl.data(), sizeof (WhMbCtl) * num_mb);
     if (++db_gen == 0) db_gen = 1;
     cur_job.db_gen = db_gen;
     cur_job.mb_ctl = d_mb_ctl;

@@ -10,6 +10,7 @@
 
 static_assert (sizeof (WhMbRecord) == 960, "WhMbRecord must be 960 bytes");
 static_assert (sizeof (WhMbState) == 144, "WhMbState must be 144 bytes");
+static_assert (sizeof (WhMbCtl) == 8, "WhMbCtl must be 8 bytes");
 
 // Store the MB's reconstruction, entropy record and neighbour state to HBM.
 WH_FN void wh_store_mb (WhMbLds& S, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, int mb_type, int cbp,
@@ -63,12 +64,15 @@ WH_FN void wh_store_mb (WhMbLds& S, const WhSeqParams& P, const WhPicJob& J, int
 
 // QP of one macroblock: the picture QP, plus the per-MB offset when the host supplies a map (WelsRcMbInitDisable,
 // ratectl.cpp, and UpdateQpForOverflow, svc_encode_slice.cpp:526-529: the re-encode after a CAVLC level overflow).
-WH_FN int wh_mb_ctl (const WhPicJob& J, int xy) { return J.mb_ctl ? (int) ((const WH_G uint16_t*)J.mb_ctl)[xy] : 0; }
-WH_FN int wh_mb_qp (const WhPicJob& J, int ctl) { return wh_clip3 (J.qp + (int) (int8_t) (ctl & 0xff), 0, 51); }
-// The reference clears uiCbp once per macroblock (WelsMdIntraInit, svc_base_layer_md.cpp:310), not per encoding pass:
-// when a macroblock is encoded again after an overflow, an Intra4x4 result ORs its luma bits onto whatever the previous
-// pass left (svc_encode_mb.cpp:173) and the chroma bits only ever grow (svc_encode_mb.cpp:299-306).
-WH_FN int wh_mb_stale_cbp (int ctl) { return (ctl >> 8) & 0x3f; }
+WH_FN WhMbCtl wh_mb_ctl (const WhPicJob& J, int xy) {
+  WhMbCtl c;
+  uint64_t w = 0;
+  if (J.mb_ctl) w = * (const WH_G uint64_t*) ((const WH_G WhMbCtl*)J.mb_ctl + xy);
+  c.qp_delta = (int8_t) (w & 0xff); c.stale_cbp = (uint8_t) ((w >> 8) & 0x3f); c.cell12_valid = (uint8_t) ((w >> 16) & 1); c.pad = 0;
+  c.cell12_mv[0] = (int16_t) (w >> 32); c.cell12_mv[1] = (int16_t) (w >> 48);
+  return c;
+}
+WH_FN int wh_mb_qp (const WhPicJob& J, const WhMbCtl& c) { return wh_clip3 (J.qp + (int)c.qp_delta, 0, 51); }
 
 // QP_Y as the decoder derives it, for the deblocking filter: a macroblock that codes no mb_qp_delta (P_Skip, or
 // cbp == 0 and not Intra16x16) inherits the QP of the previous macroblock of its slice, the first one the slice QP
@@ -107,12 +111,12 @@ WH_FN void wh_qp_chain_slice (const WhSeqParams& P, const WhPicJob& J, int first
 WH_FN void wh_intra_mb_body (WhMbLds& S, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby) {
   const int xy = mby * P.mb_w + mbx;
   const int avail = wh_mb_avail (P, mbx, mby);
-  const int ctl = wh_mb_ctl (J, xy);
+  const WhMbCtl ctl = wh_mb_ctl (J, xy);
   const int qp = wh_mb_qp (J, ctl);
   const int qpc = kWhChromaQp[wh_clip3 (qp + P.chroma_qp_offset, 0, 51)];
   wh_load_mb_tile (S, P, J, mbx, mby);
   WhIntraResult r;
-  wh_intra_md_enc (S, P, J, mbx, mby, avail, qp, qpc, &r, wh_mb_stale_cbp (ctl));
+  wh_intra_md_enc (S, P, J, mbx, mby, avail, qp, qpc, &r, ctl.stale_cbp);
   // intra MBs carry no motion: clear mv/ref so that later P pictures / deblocking see zeros
   WV_LANES_BEGIN (lane)
   WH_G WhMbState* Ms = (WH_G WhMbState*)J.mbs + xy;

@@ -711,7 +711,7 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, WhInterStage& G, const WhSeqParams& 
   const int w = P.mb_w, xy = mby * w + mbx;
   const int slice_idc = X.slice_idc;
   const int avail = wh_mb_avail_in_slice (P, mbx, mby, X.slice_first);
-  const int ctl = wh_mb_ctl (J, xy);
+  const WhMbCtl ctl = wh_mb_ctl (J, xy);
   const int qp = wh_mb_qp (J, ctl);
   const int qpc = kWhChromaQp[wh_clip3 (qp + P.chroma_qp_offset, 0, 51)];
   const int lambda = kWhLambda[qp];
@@ -780,6 +780,10 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, WhInterStage& G, const WhSeqParams& 
     return 0; }) ()
   WV_LSET_IF (K.ref, lane, lane < 30, WH_CACHE_REF (lane));
   WV_LSET_IF (K.mv, lane, lane < 30, WH_CACHE_MV (lane));
+  if (ctl.cell12_valid) {       // re-encode pass after one that ended as P8x16 (WhMbCtl)
+    WV_LSET (K.ref, 12, 0);
+    WV_LSET (K.mv, 12, wh_pk_mv (ctl.cell12_mv[0], ctl.cell12_mv[1]));
+  }
 #undef WH_CACHE_REF
 #undef WH_CACHE_MV
   // neighbour SAD / skip context, order of the reference's caches: [0] top-left, [1] top, [2] top-right, [3] left
@@ -829,9 +833,8 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, WhInterStage& G, const WhSeqParams& 
   const bool try_skip = l_sk || t_sk || tl_sk || tr_sk;
   const bool keep_skip = l_sk && t_sk && tr_sk;
   bool b_skip = false;
-  int stale_cbp = wh_mb_stale_cbp (ctl);
+  const int stale_cbp = ctl.stale_cbp;
   if ((ref_is_p && ref_mb_type == WH_MB_PSKIP) || try_skip) {
-    stale_cbp = 0;          // WelsMdPSkipEnc clears uiCbp whenever the skip test runs (svc_base_layer_md.cpp:1376)
     // PredictSadSkip (md.cpp:872-910)
     int sad_pred_skip;
     {
@@ -1042,6 +1045,7 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, WhInterStage& G, const WhSeqParams& 
   if (intra) {
     WV_LANES_BEGIN (lane)
     if (lane < 16) { Ms->mv[lane][0] = 0; Ms->mv[lane][1] = 0; Rs->mvd[lane][0] = 0; Rs->mvd[lane][1] = 0; }
+    if (lane < 2) Rs->mv_tr[lane] = 0;
     if (lane < 4) { Ms->ref_idx[lane] = -1; Rs->ref_idx[lane] = -1; Rs->sub_type[lane] = 0; }
     if (lane == 0) { Ms->sad_cost[0] = 0; Ms->p16mv[0] = (int16_t)p16x; Ms->p16mv[1] = (int16_t)p16y; Ms->skip_sad = 0; }
     WV_LANES_END
@@ -1069,6 +1073,7 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, WhInterStage& G, const WhSeqParams& 
     Ms->mv[lane][0] = (int16_t)mvx; Ms->mv[lane][1] = (int16_t)mvy;
     Rs->mvd[lane][0] = is_skip ? (int16_t)0 : (int16_t) (mvx - S.mvp_out[lane][0]);
     Rs->mvd[lane][1] = is_skip ? (int16_t)0 : (int16_t) (mvy - S.mvp_out[lane][1]);
+    if (lane == 3) { Rs->mv_tr[0] = (int16_t)mvx; Rs->mv_tr[1] = (int16_t)mvy; }
   }
   if (!(cbp & 15) || is_skip) { uint64_t* z = (uint64_t*)M.lv_luma; z[lane] = 0; }
   if (lane < 4) { Ms->ref_idx[lane] = 0; Rs->ref_idx[lane] = 0; Rs->sub_type[lane] = 0; }

@@ -541,7 +541,7 @@ WH_FN bool wh_intra_md_enc_p (WhMbLds& S, const WhSeqParams& P, const WhPicJob& 
   if (clast != cbest) wh_pred_chroma (S, cbest, st, sl, cpb, cpc, cpa);
   int cbp_c = wh_encrec_chroma (S, qpc, 1);
   wh_idct_chroma (S);
-  if (mb_type == WH_MB_I4x4 && stale_cbp) {      // see wh_mb_stale_cbp: only Intra4x4 keeps what an earlier pass left
+  if (mb_type == WH_MB_I4x4 && stale_cbp) {      // WhMbCtl::stale_cbp: only Intra4x4 keeps what an earlier pass left
     cbp |= stale_cbp & 15;
     const int c0 = stale_cbp >> 4;
     if (cbp_c != 2) cbp_c = (c0 == 2) ? 2 : (cbp_c | c0);

@@ -1,0 +1,29 @@
+"""Randomised bitstream parity against oracle/_ref run live (tools/fuzz_parity.py): random picture sizes, QPs (0..51),
+slice counts, complexity modes, deblocking modes/offsets, cropping, parameter-set id strategy, forced IDRs and six
+content classes, including streams that hit the reference's CAVLC-overflow re-encode loop and its buffer limits."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra, ref_tools):
+    if not ref_tools:
+        pytest.skip("oracle/_ref not built")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "--cases", "24", "--seed", "7"] + extra,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500)
+    out = r.stdout.decode()
+    assert r.returncode == 0, out[-4000:]
+    assert "24 cases, 0 failed" in out
+
+
+def test_fuzz_emu(emu_lib, ref_tools):
+    _run([], ref_tools)
+
+
+@pytest.mark.gpu
+def test_fuzz_hip(hip_lib, ref_tools):
+    _run(["--hip"], ref_tools)
