@@ -97,7 +97,7 @@ def main():
         a.sessions = 128 if workload == "p" else 256
     w, h = a.width, a.height
     mbs = ((w + 15) // 16) * ((h + 15) // 16)
-    ring = 1 if workload == "intra" else 8
+    ring = 2 if workload == "intra" else 8          # the library keeps at least two source slots per session
     n_unique = 4 if workload == "intra" else ring
     frames = synth_sequence(w, h, n_unique)
     fsz = w * h * 3 // 2
@@ -145,7 +145,7 @@ def main():
     if a.e2e and rank == 0:
         t1 = time.perf_counter()
         for i in range(a.steps):
-            g.step(0 if ring == 1 else i % ring)
+            g.step(i % ring)
         e2e = a.sessions * a.steps / (time.perf_counter() - t1)
 
     if rank == 0:

@@ -135,7 +135,9 @@ int  WelsHipGroupCreate (WelsHipEncoderGroup** ppGroup, const WelsHipEncParam* p
 void WelsHipGroupDestroy (WelsHipEncoderGroup* pGroup);
 /* one EncodeFrame for every session: kpSrcPics[iSessions] -> pBsInfos[iSessions] */
 int  WelsHipGroupEncodeFrames (WelsHipEncoderGroup* pGroup, const WelsHipSourcePicture* kpSrcPics, WelsHipFrameBSInfo* pBsInfos);
-/* the same, split into its phases (sources may be made resident in HBM ahead of time) */
+/* the same, split into its phases (sources may be made resident in HBM ahead of time).  iSlot selects one of the
+ * iSourceRingSlots (at least 2) resident source pictures per session; a P picture must not use the slot of the picture
+ * before it, whose source LOW complexity mode still reads (cmInitParaError otherwise). */
 int  WelsHipGroupUploadSource (WelsHipEncoderGroup* pGroup, int iSession, int iSlot, const WelsHipSourcePicture* kpSrcPic);
 int  WelsHipGroupBegin (WelsHipEncoderGroup* pGroup, int iSlot);
 int  WelsHipGroupRunDevice (WelsHipEncoderGroup* pGroup, int bWait);

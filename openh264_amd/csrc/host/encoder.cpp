@@ -114,7 +114,7 @@ struct SessionCore {
   }
 
   int init (wh::Backend* backend, const WelsHipEncParam* p, int ring_slots) {
-    be = backend; prm = *p; ring = ring_slots < 1 ? 1 : ring_slots;
+    be = backend; prm = *p; ring = ring_slots < 2 ? 2 : ring_slots;     // the previous source stays resident (VAA SADs)
     mb_w = (p->iPicWidth + 15) >> 4; mb_h = (p->iPicHeight + 15) >> 4; num_mb = mb_w * mb_h;
     WhSeqParams& s = seq;
     memset (&s, 0, sizeof (s));
@@ -203,9 +203,14 @@ struct SessionCore {
 
   // Decide the frame type (encoder_ext.cpp DecideFrameType: IDR at index 0 / intra period / on request) and
   // describe the picture to the device.
-  void begin_frame (int slot, WhPicJob* job) {
+  int begin_frame (int slot, WhPicJob* job) {
     bool idr = force_idr || frame_index == 0;
     if (!idr && prm.uiIntraPeriod > 0 && (uint32_t)frame_index >= prm.uiIntraPeriod) idr = true;
+    // LOW complexity P pictures read the previous SOURCE picture (VAA 8x8 SADs): it must still be resident
+    if (!idr && seq.complexity == 0 && slot == last_slot) {
+      set_err ("the previous source picture was overwritten: use at least two source slots and alternate them");
+      return WELSHIP_ERR_INIT_PARA;
+    }
     if (idr) { frame_index = 0; frame_num = 0; force_idr = false; }
     cur_idr = idr;
     DevPicture& c = pic[cur];
@@ -227,6 +232,7 @@ struct SessionCore {
     job->db_gen = db_gen;
     if (qp_map_in_use) { memset (h_mb_ctl.data(), 0, sizeof (WhMbCtl) * h_mb_ctl.size()); qp_map_in_use = false; }
     cur_job = *job;
+    return WELSHIP_OK;
   }
 
   // The macroblock `overflow_mb` cannot be written in Baseline CAVLC at its QP: raise its QP by DELTA_QP (rc.h:77) as
@@ -600,7 +606,7 @@ int WelsHipGroupUploadSource (WelsHipEncoderGroup* g, int session, int slot, con
 int WelsHipGroupBegin (WelsHipEncoderGroup* g, int slot) {
   if (!g) return WELSHIP_ERR_INIT_PARA;
   const int n = (int)g->sess.size();
-  for (int i = 0; i < n; ++i) g->sess[i]->begin_frame (slot % g->sess[i]->ring, &g->h_jobs[i]);
+  for (int i = 0; i < n; ++i) { const int rc = g->sess[i]->begin_frame (slot % g->sess[i]->ring, &g->h_jobs[i]); if (rc) return rc; }
   g->step_idr = g->sess[0]->cur_idr;
   for (int i = 1; i < n; ++i) if (g->sess[i]->cur_idr != g->step_idr) { set_err ("sessions of a group must share the frame type"); return WELSHIP_ERR_UNKNOWN; }
   for (int q = 0; q < g->queues; ++q) {
@@ -658,8 +664,9 @@ int WelsHipGroupFinish (WelsHipEncoderGroup* g, WelsHipFrameBSInfo* outs) {
 int WelsHipGroupEncodeFrames (WelsHipEncoderGroup* g, const WelsHipSourcePicture* srcs, WelsHipFrameBSInfo* outs) {
   if (!g || !srcs) return WELSHIP_ERR_INIT_PARA;
   const int n = (int)g->sess.size();
-  for (int i = 0; i < n; ++i) { int rc = WelsHipGroupUploadSource (g, i, 0, &srcs[i]); if (rc) return rc; }
-  int rc = WelsHipGroupBegin (g, 0);
+  const int slot = (g->sess[0]->last_slot + 1) % g->sess[0]->ring;    // never the slot of the previous picture
+  for (int i = 0; i < n; ++i) { int rc = WelsHipGroupUploadSource (g, i, slot, &srcs[i]); if (rc) return rc; }
+  int rc = WelsHipGroupBegin (g, slot);
   if (rc) return rc;
   WelsHipGroupRunDevice (g, 0);
   return WelsHipGroupFinish (g, outs);

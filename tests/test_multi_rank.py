@@ -85,3 +85,34 @@ def test_group_equals_single_session(emu_lib):
     for s in (0, SESSIONS - 1):
         bs, _ = oh.encode_sequence(b"".join(inputs[s]), W, H, lib_path=emu_lib, iDLayerQp=26, uiIntraPeriod=0, fMaxFrameRate=30.0, iTargetBitrate=500000)
         assert hashlib.sha1(bs).hexdigest() == digs[s]
+
+
+def test_group_reencodes_overflowing_sessions(emu_lib):
+    """Sessions of a group whose picture hits a CAVLC overflow are re-encoded individually (WelsHipGroupFinish) and
+    still match the single-session result; their neighbours in the group are unaffected."""
+    import openh264_amd as oh
+    from openh264_amd.utils.synth import make_sequence
+    w, h, frames, qp = 64, 64, 3, 3
+    fsz = w * h * 3 // 2
+    seqs = [make_sequence(c, w, h, frames) for c in ("synth", "checker5", "synth", "checker8")]
+    e = oh.Encoder(emu_lib)
+    p = e.GetDefaultParams()
+    e.close()
+    p.iPicWidth, p.iPicHeight, p.iDLayerQp, p.uiIntraPeriod, p.fMaxFrameRate, p.iTargetBitrate = w, h, qp, 0, 30.0, 5000000
+    g = oh.EncoderGroup(p, len(seqs), ring_slots=2, host_threads=2, lib_path=emu_lib)
+    got = [bytearray() for _ in seqs]
+    for f in range(frames):
+        for s, yuv in enumerate(seqs):
+            g.upload(s, f & 1, yuv[f * fsz:(f + 1) * fsz])
+        for s, bs in enumerate(g.step(f & 1)):
+            got[s] += bs
+    # LOW complexity P pictures need the previous source picture: re-using its slot is refused, not silently different
+    g.upload(0, (frames - 1) & 1, seqs[0][:fsz])
+    with pytest.raises(oh.WelsHipError):
+        g.step((frames - 1) & 1)
+    g.close()
+    for s, yuv in enumerate(seqs):
+        st = {}
+        bs, _ = oh.encode_sequence(yuv, w, h, lib_path=emu_lib, stats=st, iDLayerQp=qp, uiIntraPeriod=0, fMaxFrameRate=30.0, iTargetBitrate=5000000)
+        assert bytes(got[s]) == bs
+        assert (st["overflow_reencodes"] > 0) == (s in (1, 3))
