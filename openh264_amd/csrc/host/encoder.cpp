@@ -50,6 +50,7 @@ struct SessionCore {
   DevPicture pic[2];
   int cur = 0;
   int last_slot = 0;                  // source slot of the previous frame (VAA reference)
+  bool prev_src_dirty = false;        // that slot received a new upload since the frame was begun
   WhMbRecord* d_records = nullptr;
   uint16_t* d_order = nullptr;
   uint32_t* d_dbflags = nullptr;
@@ -197,6 +198,7 @@ struct SessionCore {
       memcpy (u + (size_t)r * s.src_stride_c, src->pData[1] + (size_t)r * src->iStride[1], w / 2);
       memcpy (v + (size_t)r * s.src_stride_c, src->pData[2] + (size_t)r * src->iStride[2], w / 2);
     }
+    if (slot == last_slot) prev_src_dirty = true;
     be->upload (d_src[slot], h_src.data(), src_bytes);
     be->sync();                       // h_src is reused by the next upload
   }
@@ -207,10 +209,11 @@ struct SessionCore {
     bool idr = force_idr || frame_index == 0;
     if (!idr && prm.uiIntraPeriod > 0 && (uint32_t)frame_index >= prm.uiIntraPeriod) idr = true;
     // LOW complexity P pictures read the previous SOURCE picture (VAA 8x8 SADs): it must still be resident
-    if (!idr && seq.complexity == 0 && slot == last_slot) {
+    if (!idr && seq.complexity == 0 && prev_src_dirty) {
       set_err ("the previous source picture was overwritten: use at least two source slots and alternate them");
       return WELSHIP_ERR_INIT_PARA;
     }
+    prev_src_dirty = false;
     if (idr) { frame_index = 0; frame_num = 0; force_idr = false; }
     cur_idr = idr;
     DevPicture& c = pic[cur];

@@ -116,3 +116,28 @@ def test_group_reencodes_overflowing_sessions(emu_lib):
         bs, _ = oh.encode_sequence(yuv, w, h, lib_path=emu_lib, stats=st, iDLayerQp=qp, uiIntraPeriod=0, fMaxFrameRate=30.0, iTargetBitrate=5000000)
         assert bytes(got[s]) == bs
         assert (st["overflow_reencodes"] > 0) == (s in (1, 3))
+
+
+def test_group_bench_path_on_emulation(emu_lib):
+    """The device-only benchmark entry point (bench.py's timed region) with resident sources: repeated calls, then a full
+    step -- the same call pattern as bench.py, here on the CPU emulation so that it cannot break unnoticed."""
+    import openh264_amd as oh
+    from openh264_amd.utils.synth import synth_sequence
+    w, h, ring = 64, 48, 4
+    fsz = w * h * 3 // 2
+    yuv = synth_sequence(w, h, ring)
+    e = oh.Encoder(emu_lib)
+    p = e.GetDefaultParams()
+    e.close()
+    p.iPicWidth, p.iPicHeight, p.iDLayerQp, p.uiIntraPeriod, p.fMaxFrameRate, p.iTargetBitrate = w, h, 24, 0, 30.0, 5000000
+    g = oh.EncoderGroup(p, 3, ring_slots=ring, host_threads=1, lib_path=emu_lib)
+    for s in range(3):
+        for k in range(ring):
+            g.upload(s, k, yuv[k * fsz:(k + 1) * fsz])
+    g.bench(1, 0)
+    g.bench(2, 1)
+    ev = g.bench(3, 0)
+    assert ev["total_ms"] >= 0.0
+    for i in range(3):
+        assert all(len(bs) > 0 for bs in g.step(i % ring))
+    g.close()

@@ -7,7 +7,7 @@ o=gpurun_out/final; mkdir -p $o
 timeout 200 python -m pytest tests -m gpu -q > $o/pytest_gpu.txt 2>&1; tail -2 $o/pytest_gpu.txt
 timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $o/smoke.txt 2>&1; tail -1 $o/smoke.txt
 timeout 300 python bench.py --e2e > $o/bench_default.json 2> $o/bench_default.err; tail -c 600 $o/bench_default.json
-for s in 8 64; do timeout 120 python bench.py --sessions $s --no-cpu-baseline > $o/bench_s$s.json 2>/dev/null; done
+for s in 8 64 256; do timeout 120 python bench.py --sessions $s --no-cpu-baseline > $o/bench_s$s.json 2>/dev/null; done
 timeout 120 python bench.py --workload intra --sessions 64 --steps 3 --warmup 1 --no-cpu-baseline > $o/bench_intra_s64.json 2>/dev/null
 timeout 200 rocprofv3 --kernel-trace --stats -d $o/prof -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline > $o/prof_bench.json 2> $o/prof.err; echo "rocprof rc=$?"
 timeout 120 python tools/phase_profile.py 128 > $o/phase_p128.txt 2>&1
