@@ -72,8 +72,11 @@ typedef struct WelsHipEncParam {
   int32_t iDLayerQp;                /* sSpatialLayers[0].iDLayerQp                                   */
   int32_t uiSliceMode;              /* 0 SM_SINGLE_SLICE, 1 SM_FIXEDSLCNUM_SLICE                     */
   int32_t uiSliceNum;
+  /* bEnableSceneChangeDetect: implemented (IDR on a LARGE_CHANGED_SCENE, encoder.cpp:377-391).  bEnableAdaptiveQuant is
+   * accepted and ignored like the reference does (encoder_ext.cpp:300-301); bEnableFrameSkip only acts under rate
+   * control.  bEnableBackgroundDetection, bEnableLongTermReference and bEnableDenoise must be 0 (cmUnsupportedData). */
   int32_t bEnableAdaptiveQuant, bEnableBackgroundDetection, bEnableSceneChangeDetect,
-          bEnableLongTermReference, bEnableDenoise, bEnableFrameSkip;   /* must all be 0 for now    */
+          bEnableLongTermReference, bEnableDenoise, bEnableFrameSkip;
   int32_t iDevice;                  /* HIP device ordinal                                            */
   int32_t reserved[7];
 } WelsHipEncParam;

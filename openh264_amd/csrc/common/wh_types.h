@@ -100,6 +100,7 @@ typedef struct WhPicJob {
   uint32_t*      db_flags;   // one word per MB: == db_gen once the MB is deblocked (hand-off between the slices' workgroups)
   uint32_t       db_gen;     // generation of this picture (never 0, changes every frame: the flags need no clearing)
   uint32_t       pad2;
+  uint32_t*      scene_count; // scene-change statistic (kernels/scene_pic.h): zeroed by the host, incremented by the kernel
 } WhPicJob;
 
 #define WH_MAX_SLICES 36
@@ -116,7 +117,8 @@ typedef struct WhSeqParams {
   int32_t deblock_idc;                  // 0: all edges, 1: off, 2: not across slice boundaries
   int32_t alpha_offset, beta_offset;
   int32_t mv_range;                     // iMvRange
-  int32_t pad[3];
+  int32_t pad[1];
+  int32_t blk8_w, blk8_h;               // picture size in whole 8x8 luma blocks (scene-change statistic)
   unsigned long long* prof;             // optional device array of 64 x 32 cycle counters (phase profiling), or NULL
   const uint16_t* mb_order;             // device table: [0, num_mb) MB addresses in dependency order per slice (each slice's
                                         // range is [slice_first_mb[s], slice_first_mb[s+1])), [num_mb, 2*num_mb) whole-picture order

@@ -17,6 +17,7 @@
 #include "../kernels/deblock_mb.h"
 #include "../kernels/inter_mb.h"
 #include "../kernels/expand_pic.h"
+#include "../kernels/scene_pic.h"
 
 namespace {
 
@@ -260,6 +261,12 @@ __global__ __launch_bounds__ (64) void k_expand (WhSeqParams P, const WhPicJob* 
   wh_expand_body (P, J, (int)blockIdx.x);
 }
 
+// Scene-change statistic: one wavefront per 16x16 region of the source picture.
+__global__ __launch_bounds__ (64) void k_scene (WhSeqParams P, const WhPicJob* jobs) {
+  const WhPicJob J = jobs[blockIdx.y];
+  wh_scene_mb_body (P, J, (int) (blockIdx.x % (unsigned)P.mb_w), (int) (blockIdx.x / (unsigned)P.mb_w));
+}
+
 // QP_Y chain for the deblocking filter of pictures with a per-MB QP map: one wavefront per (slice, picture).
 __global__ __launch_bounds__ (64) void k_qp_chain (WhSeqParams P, const WhPicJob* jobs) {
   const WhPicJob J = jobs[blockIdx.y];
@@ -351,6 +358,10 @@ class HipBackend : public wh::Backend {
   void run_deblock (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
     static const int db_waves = getenv ("WELSHIP_DB_WAVES") ? atoi (getenv ("WELSHIP_DB_WAVES")) : 16;
     mb_pass (k_deblock_slices, sizeof (WhDbLds), db_waves, false, P, jobs, n, 16 * sizeof (WhDbStage) + sizeof (WhPicJob), 4 * wh_db_xchg_words (P.mb_w, P.mb_h));
+  }
+  void run_scene (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
+    hipLaunchKernelGGL (k_scene, dim3 (P.mb_w * P.mb_h, n), dim3 (64), 0, stream_, P, jobs);
+    HIP_CHECK (hipGetLastError());
   }
   void run_qp_chain (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
     hipLaunchKernelGGL (k_qp_chain, dim3 (P.num_slices, n), dim3 (64), 0, stream_, P, jobs);

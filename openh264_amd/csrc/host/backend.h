@@ -23,6 +23,7 @@ class Backend {
   // `jobs` is a DEVICE array of WhPicJob.  All calls are asynchronous on the backend's stream.
   virtual void run_intra (const WhSeqParams& P, const WhPicJob* jobs, int n) = 0;     // I pictures: MD + recon
   virtual void run_inter (const WhSeqParams& P, const WhPicJob* jobs, int n) = 0;     // P pictures: ME + MD + recon
+  virtual void run_scene (const WhSeqParams& P, const WhPicJob* jobs, int n) = 0;     // source pictures: scene-change statistic
   virtual void run_qp_chain (const WhSeqParams& P, const WhPicJob* jobs, int n) = 0;  // pictures with a QP map: QP_Y chain for the filter
   virtual void run_deblock (const WhSeqParams& P, const WhPicJob* jobs, int n) = 0;   // in-loop filter on rec[]
   virtual void run_expand (const WhSeqParams& P, const WhPicJob* jobs, int n) = 0;    // replicate rec[] borders (32/16 px)

@@ -75,6 +75,9 @@ struct SessionCore {
   int overflow_mb = -1;               // set by finish_frame when it returns WELSHIP_ERR_VLC_OVERFLOW
   int overflow_qp = 0;                // uiLumaQp of that macroblock when the overflow was detected
   int overflow_reencodes = 0;         // statistics
+  uint32_t* d_scene = nullptr;        // scene-change statistic of the current source picture (WhPicJob::scene_count)
+  uint32_t h_scene = 0;
+  bool scene_idr = false;             // LARGE_CHANGED_SCENE seen for the picture about to be encoded
   WhPicJob cur_job;                   // what begin_frame described (re-issued by retry_after_overflow)
 
   static int validate (const WelsHipEncParam* p) {
@@ -87,8 +90,12 @@ struct SessionCore {
     if (p->iRCMode != -1) { set_err ("only RC_OFF_MODE (-1) is supported"); return WELSHIP_ERR_UNSUPPORTED; }
     if (p->iTemporalLayerNum != 1 || p->iSpatialLayerNum != 1) { set_err ("only one temporal and one spatial layer supported"); return WELSHIP_ERR_UNSUPPORTED; }
     if (p->iEntropyCodingModeFlag != 0) { set_err ("CABAC is not implemented"); return WELSHIP_ERR_UNSUPPORTED; }
-    if (p->bEnableAdaptiveQuant || p->bEnableBackgroundDetection || p->bEnableSceneChangeDetect || p->bEnableLongTermReference ||
-        p->bEnableDenoise || p->bEnableFrameSkip) { set_err ("AQ/BGD/scene-change/LTR/denoise/frame-skip are not supported"); return WELSHIP_ERR_UNSUPPORTED; }
+    // bEnableAdaptiveQuant is accepted and ignored exactly like the reference does ("turn off adaptive quant now",
+    // ParamValidation, encoder_ext.cpp:300-301); bEnableFrameSkip only acts under rate control (RC is off here);
+    // bEnableSceneChangeDetect is implemented (kernels/scene_pic.h + SessionCore::detect_scene_change)
+    if (p->bEnableBackgroundDetection || p->bEnableLongTermReference || p->bEnableDenoise) {
+      set_err ("background detection / LTR / denoise are not supported"); return WELSHIP_ERR_UNSUPPORTED;
+    }
     if (p->uiSliceMode != 0 && p->uiSliceMode != 1) { set_err ("slice mode must be 0 or 1"); return WELSHIP_ERR_UNSUPPORTED; }
     if (p->iLoopFilterDisableIdc < 0 || p->iLoopFilterDisableIdc > 2) { set_err ("deblocking idc must be 0..2"); return WELSHIP_ERR_UNSUPPORTED; }
     if (p->iLoopFilterAlphaC0Offset < -6 || p->iLoopFilterAlphaC0Offset > 6 || p->iLoopFilterBetaOffset < -6 || p->iLoopFilterBetaOffset > 6) {
@@ -128,6 +135,7 @@ struct SessionCore {
     // the API values are slice_alpha_c0_offset_div2 / slice_beta_offset_div2 (InitDqLayers, encoder_ext.cpp:1104-1105)
     s.alpha_offset = p->iLoopFilterAlphaC0Offset * 2; s.beta_offset = p->iLoopFilterBetaOffset * 2;
     s.mv_range = 64;
+    s.blk8_w = mb_w * 2; s.blk8_h = mb_h * 2;      // the reference analyses its MB-aligned, zero-padded copy of the source
     if (compute_slices()) { set_err ("invalid slice number"); return WELSHIP_ERR_INIT_PARA; }
     // InitDqLayers (encoder_ext.cpp:1109-1117): with a single slice (requested, or after the fall-back above)
     // "filter all but slice edges" is signalled and run as idc 0
@@ -162,6 +170,7 @@ struct SessionCore {
       be->sync();
       s.mb_order = d_order;
     }
+    d_scene = (uint32_t*)be->alloc (64);
     d_dbflags = (uint32_t*)be->alloc (sizeof (uint32_t) * num_mb);
     be->fill (d_dbflags, 0, sizeof (uint32_t) * num_mb);
     // level (au_set.cpp:530-545): the reference feeds iSpatialBitrate even with RC off
@@ -182,6 +191,8 @@ struct SessionCore {
     d_dbflags = nullptr;
     if (d_mb_ctl) be->free (d_mb_ctl);
     d_mb_ctl = nullptr;
+    if (d_scene) be->free (d_scene);
+    d_scene = nullptr;
     be = nullptr;
   }
 
@@ -205,9 +216,30 @@ struct SessionCore {
 
   // Decide the frame type (encoder_ext.cpp DecideFrameType: IDR at index 0 / intra period / on request) and
   // describe the picture to the device.
+  // IDR for a reason other than a scene change: first picture, request, intra period (encoder.cpp:377-391)
+  bool idr_without_scene_change() const {
+    return force_idr || frame_index == 0 || (prm.uiIntraPeriod > 0 && (uint32_t)frame_index >= prm.uiIntraPeriod);
+  }
+  // The scene-change verdict can only turn the picture into an IDR if nothing else does already and the reference's
+  // iFrameIndex -- still the count BEFORE this picture at decision time (InitFrameCoding increments it afterwards,
+  // encoder.cpp:281-284) -- has reached 2 * VGOP_SIZE = 16 ("avoid too frequent I frame coding", encoder.cpp:379-382).
+  bool scene_check_needed() const { return prm.bEnableSceneChangeDetect && !idr_without_scene_change() && frame_index - 1 >= 16; }
+  // Describe the statistic pass for the source picture in `slot` (it is compared with the previous source picture).
+  void scene_job (int slot, WhPicJob* job) {
+    memset (job, 0, sizeof (*job));
+    job->src[0] = d_src[slot];
+    job->prev_src_y = d_src[last_slot];
+    job->scene_count = d_scene;
+  }
+  // CSceneChangeDetection::Process (SceneChangeDetection.h:215-241) + GetSceneChangeFlag: LARGE_CHANGED_SCENE only
+  void scene_verdict (uint32_t motion_blocks) {
+    const int n8 = seq.blk8_w * seq.blk8_h;
+    const int thr_large = static_cast<int32_t> (0.85f * n8 + 0.5f + 1e-6);
+    scene_idr = (int)motion_blocks >= thr_large;
+  }
   int begin_frame (int slot, WhPicJob* job) {
-    bool idr = force_idr || frame_index == 0;
-    if (!idr && prm.uiIntraPeriod > 0 && (uint32_t)frame_index >= prm.uiIntraPeriod) idr = true;
+    bool idr = idr_without_scene_change() || scene_idr;
+    scene_idr = false;
     // LOW complexity P pictures read the previous SOURCE picture (VAA 8x8 SADs): it must still be resident
     if (!idr && seq.complexity == 0 && prev_src_dirty) {
       set_err ("the previous source picture was overwritten: use at least two source slots and alternate them");
@@ -452,7 +484,10 @@ struct WelsHipEncoderGroup {
   WhPicJob* d_jobs = nullptr;
   std::vector<WhPicJob> h_jobs;
   int host_threads = 1;
-  bool step_idr = true;
+  bool step_idr = true;                         // every session codes an IDR this step (all-P otherwise, unless mixed)
+  bool mixed = false;                           // sessions disagree (scene changes, forced IDRs): each queue chunk of
+  std::vector<int> order;                       //   d_jobs holds its P pictures first, then its IDR pictures;
+  std::vector<int> chunk_p;                     //   order[k] = session of job slot k, chunk_p[q] = P pictures of chunk q
 };
 
 extern "C" {
@@ -531,7 +566,16 @@ int WelsHipEncodeFrame (WelsHipEncoder* e, const WelsHipSourcePicture* src, Wels
   const int slot = c.last_slot ^ 1;
   c.upload_source (slot, src);
   WhPicJob job;
-  c.begin_frame (slot, &job);
+  if (c.scene_check_needed()) {      // the statistic decides the frame type, so it is read back before the picture is begun
+    c.scene_job (slot, &job);
+    e->be->upload (e->d_job, &job, sizeof (job));
+    e->be->fill (c.d_scene, 0, 4);
+    e->be->run_scene (c.seq, e->d_job, 1);
+    e->be->download (&c.h_scene, c.d_scene, 4);
+    if (e->be->sync()) { set_err ("device error in the scene-change pass"); return WELSHIP_ERR_UNKNOWN; }
+    c.scene_verdict (c.h_scene);
+  }
+  { const int brc = c.begin_frame (slot, &job); if (brc) return brc; }
   e->be->upload (e->d_job, &job, sizeof (job));
   run_device_step (e->be, c.seq, e->d_job, 1, c.cur_idr, c.prm.uiIntraPeriod != 1);
   e->be->download (c.h_records.data(), c.d_records, sizeof (WhMbRecord) * c.num_mb);
@@ -609,11 +653,39 @@ int WelsHipGroupUploadSource (WelsHipEncoderGroup* g, int session, int slot, con
 int WelsHipGroupBegin (WelsHipEncoderGroup* g, int slot) {
   if (!g) return WELSHIP_ERR_INIT_PARA;
   const int n = (int)g->sess.size();
-  for (int i = 0; i < n; ++i) { const int rc = g->sess[i]->begin_frame (slot % g->sess[i]->ring, &g->h_jobs[i]); if (rc) return rc; }
+  // scene-change statistic for the sessions whose frame type it can still change: one launch, read back before the
+  // pictures are begun
+  {
+    std::vector<int> need;
+    for (int i = 0; i < n; ++i) if (g->sess[i]->scene_check_needed()) need.push_back (i);
+    if (!need.empty()) {
+      g->be->select_queue (0);
+      for (size_t k = 0; k < need.size(); ++k) {
+        SessionCore& c = *g->sess[need[k]];
+        c.scene_job (slot % c.ring, &g->h_jobs[k]);
+        g->be->fill (c.d_scene, 0, 4);
+      }
+      g->be->upload (g->d_jobs, g->h_jobs.data(), sizeof (WhPicJob) * need.size());
+      g->be->run_scene (g->sess[0]->seq, g->d_jobs, (int)need.size());
+      for (int i : need) g->be->download (&g->sess[i]->h_scene, g->sess[i]->d_scene, 4);
+      if (g->be->sync()) { set_err ("device error in the scene-change pass"); return WELSHIP_ERR_UNKNOWN; }
+      for (int i : need) g->sess[i]->scene_verdict (g->sess[i]->h_scene);
+    }
+  }
+  std::vector<WhPicJob> jobs (n);
+  for (int i = 0; i < n; ++i) { const int rc = g->sess[i]->begin_frame (slot % g->sess[i]->ring, &jobs[i]); if (rc) return rc; }
   g->step_idr = g->sess[0]->cur_idr;
-  for (int i = 1; i < n; ++i) if (g->sess[i]->cur_idr != g->step_idr) { set_err ("sessions of a group must share the frame type"); return WELSHIP_ERR_UNKNOWN; }
+  g->mixed = false;
+  for (int i = 1; i < n; ++i) if (g->sess[i]->cur_idr != g->step_idr) g->mixed = true;
+  g->order.resize (n);
+  g->chunk_p.assign (g->queues, 0);
   for (int q = 0; q < g->queues; ++q) {
     const int a = g->chunk_first (q), b = g->chunk_first (q + 1);
+    int k = a;
+    for (int i = a; i < b; ++i) if (!g->sess[i]->cur_idr) g->order[k++] = i;
+    g->chunk_p[q] = k - a;
+    for (int i = a; i < b; ++i) if (g->sess[i]->cur_idr) g->order[k++] = i;
+    for (int j = a; j < b; ++j) g->h_jobs[j] = jobs[g->order[j]];
     g->be->select_queue (q);
     g->be->upload (g->d_jobs + a, g->h_jobs.data() + a, sizeof (WhPicJob) * (b - a));
   }
@@ -626,7 +698,12 @@ int WelsHipGroupRunDevice (WelsHipEncoderGroup* g, int wait) {
   for (int q = 0; q < g->queues; ++q) {
     const int a = g->chunk_first (q), b = g->chunk_first (q + 1);
     g->be->select_queue (q);
-    run_device_step (g->be, c0.seq, g->d_jobs + a, b - a, g->step_idr, c0.prm.uiIntraPeriod != 1);
+    const int np = g->chunk_p[q], ni = (b - a) - np;
+    const WhSeqParams& s = c0.seq;
+    if (np) g->be->run_inter (s, g->d_jobs + a, np);
+    if (ni) g->be->run_intra (s, g->d_jobs + a + np, ni);
+    if (s.deblock_idc != 1) g->be->run_deblock (s, g->d_jobs + a, b - a);
+    if (c0.prm.uiIntraPeriod != 1) g->be->run_expand (s, g->d_jobs + a, b - a);
   }
   if (wait && g->be->sync()) { set_err ("device scheduler timed out"); return WELSHIP_ERR_UNKNOWN; }
   return WELSHIP_OK;
@@ -715,6 +792,7 @@ int WelsHipGroupBench (WelsHipEncoderGroup* g, int steps, int warmup, double* ou
   for (int i = 0; i < steps; ++i) {
     int rc = WelsHipGroupBegin (g, slot_of (fi++));
     if (rc) return rc;
+    if (g->mixed) { set_err ("the benchmark entry point needs every session on the same frame type"); return WELSHIP_ERR_UNKNOWN; }
     for (int q = g->queues - 1; q >= 0; --q) {      // queue 0 last: it carries the events
       const int a = g->chunk_first (q), cnt = g->chunk_first (q + 1) - a;
       be->select_queue (q);

@@ -66,6 +66,7 @@ typedef struct WvLaneArr { int v[64]; } WvLaneArr;
 #define WV_LGET(a, i) ((a).v[i])
 #define WV_LSET(a, i, val) ((a).v[i] = (val))
 #define WV_LOWN(a, lane) ((a).v[lane])                      // inside a lane block: this lane's own entry
+WH_FN void wh_atomic_add_u32 (uint32_t* p, uint32_t v) { *p += v; }     // device-scope atomic on the GPU
 #define WV_LSET_IF(a, lane, cond, val) do { for (int lane = 0; lane < 64; ++lane) if (cond) (a).v[lane] = (val); } while (0)
 // asynchronous copy of one 4-byte word per lane from global memory to LDS word `lane` of `lds_base` (GPU: LDS-DMA,
 // no register holds the data; complete after WV_ASYNC_WAIT)
@@ -169,6 +170,7 @@ typedef int WvLaneArr;
 #define WV_LOWN(a, lane) (a)
 #define WV_LSET_IF(a, lane, cond, val) do { const int lane = wh_lane_id(); if (cond) (a) = (val); } while (0)
 #define WH_G __attribute__ ((address_space (1)))
+WH_FN void wh_atomic_add_u32 (WH_G uint32_t* p, uint32_t v) { __hip_atomic_fetch_add (p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 WH_FN uint32_t wh_ld4u (const uint8_t* base, int off) {
   const uint32_t* w = (const uint32_t*)base + (off >> 2);
   return __builtin_amdgcn_alignbyte (w[1], w[0], (uint32_t)off & 3u);

@@ -15,6 +15,7 @@
 #include "../../openh264_amd/csrc/kernels/deblock_mb.h"
 #include "../../openh264_amd/csrc/kernels/inter_mb.h"
 #include "../../openh264_amd/csrc/kernels/expand_pic.h"
+#include "../../openh264_amd/csrc/kernels/scene_pic.h"
 
 namespace wh {
 
@@ -86,6 +87,11 @@ class EmuBackend : public Backend {
           poison (&S, sizeof (S));
         }
       }
+  }
+  void run_scene (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
+    for (int j = 0; j < n; ++j)
+      for (int y = 0; y < P.mb_h; ++y)
+        for (int x = 0; x < P.mb_w; ++x) wh_scene_mb_body (P, jobs[j], x, y);
   }
   void run_qp_chain (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
     for (int j = 0; j < n; ++j)

@@ -36,6 +36,8 @@ def run_case(name, lib_path, ref_tools, tmp_path):
     assert hashlib.sha1(bs).hexdigest() == g["sha1"]
     if name.endswith("_overflow"):      # the case must really go through the re-encode loop
         assert stats["overflow_reencodes"] > 0
+    if name.endswith("_scene"):         # ... and this one must contain the IDR the scene-change detector inserts
+        assert bs.count(b"\x00\x00\x00\x01\x65") == 2
     if ref_tools:
         fi, fo, fd = str(tmp_path / "in.yuv"), str(tmp_path / "ref.264"), str(tmp_path / "dec.yuv")
         open(fi, "wb").write(yuv)

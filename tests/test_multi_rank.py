@@ -141,3 +141,34 @@ def test_group_bench_path_on_emulation(emu_lib):
     for i in range(3):
         assert all(len(bs) > 0 for bs in g.step(i % ring))
     g.close()
+
+
+def test_group_with_mixed_frame_types(emu_lib):
+    """Scene changes (and forced IDRs) make sessions of a group disagree on the frame type: the P and IDR pictures of a
+    step then go to their own launches, and every session still matches its single-session stream."""
+    import openh264_amd as oh
+    from openh264_amd.utils.synth import synth_sequence
+    w, h, frames = 64, 48, 20
+    fsz = w * h * 3 // 2
+    still = synth_sequence(w, h, 1) * frames                      # no motion: never a scene change
+    seqs = [synth_sequence(w, h, frames), still, synth_sequence(w, h, frames, seed=77)]
+    e = oh.Encoder(emu_lib)
+    p = e.GetDefaultParams()
+    e.close()
+    p.iPicWidth, p.iPicHeight, p.iDLayerQp, p.uiIntraPeriod, p.fMaxFrameRate, p.iTargetBitrate = w, h, 30, 0, 30.0, 5000000
+    p.bEnableSceneChangeDetect = 1
+    g = oh.EncoderGroup(p, len(seqs), ring_slots=2, host_threads=2, lib_path=emu_lib)
+    got = [bytearray() for _ in seqs]
+    for f in range(frames):
+        for s, yuv in enumerate(seqs):
+            g.upload(s, f & 1, yuv[f * fsz:(f + 1) * fsz])
+        for s, bs in enumerate(g.step(f & 1)):
+            got[s] += bs
+    g.close()
+    idrs = []
+    for s, yuv in enumerate(seqs):
+        bs, _ = oh.encode_sequence(yuv, w, h, lib_path=emu_lib, iDLayerQp=30, uiIntraPeriod=0, fMaxFrameRate=30.0,
+                                   iTargetBitrate=5000000, bEnableSceneChangeDetect=1)
+        assert bytes(got[s]) == bs
+        idrs.append(bs.count(b"\x00\x00\x00\x01\x65"))
+    assert idrs[1] == 1 and max(idrs) == 2        # the step with the scene change really was mixed

@@ -91,6 +91,12 @@ def one_case(rng, lib, enc_tool, tmp, max_mbs, run=True):
             break
     mb_h = (h + 15) // 16
     frames = int(rng.integers(2, 7))
+    scene = int(rng.random() < 0.5)
+    cut = -1
+    if scene and mbs <= 150 and rng.random() < 0.3:        # long enough for the scene-change detector to be allowed to act
+        frames = int(rng.integers(18, 30))
+        cut = int(rng.integers(10, frames)) if rng.random() < 0.7 else -1
+    aq, fskip = int(rng.random() < 0.3), int(rng.random() < 0.3)   # accepted and without effect, as in the reference
     qp = int(rng.choice([0, 1, 5, 10, 12, 18, 24, 26, 30, 36, 40, 45, 51, int(rng.integers(0, 52))]))
     iper = int(rng.choice([0, 0, 0, 1, 2, 3]))
     cplx = int(rng.choice([0, 0, 1, 2]))
@@ -102,15 +108,21 @@ def one_case(rng, lib, enc_tool, tmp, max_mbs, run=True):
     spsid = int(rng.random() < 0.7)
     fidr = int(rng.integers(1, frames)) if rng.random() < 0.2 else -1
     yuv = content(kind, w, h, frames, rng)
+    if cut > 0:                                            # abrupt change of content at frame `cut`
+        other = content(str(rng.choice(KINDS)), w, h, frames, rng)
+        fsz = w * h * 3 // 2
+        yuv = yuv[:cut * fsz] + other[cut * fsz:]
     params = dict(fMaxFrameRate=30.0, iTargetBitrate=5000000, iDLayerQp=qp, uiIntraPeriod=iper, iComplexityMode=cplx,
                   iLoopFilterDisableIdc=idc, iLoopFilterAlphaC0Offset=alpha, iLoopFilterBetaOffset=beta,
-                  bEnableFrameCroppingFlag=crop, eSpsPpsIdStrategy=spsid)
+                  bEnableFrameCroppingFlag=crop, eSpsPpsIdStrategy=spsid, bEnableSceneChangeDetect=scene,
+                  bEnableAdaptiveQuant=aq, bEnableFrameSkip=fskip)
     flags = ["-rc", "-1", "-qp", str(qp), "-fps", "30", "-iper", str(iper), "-complexity", str(cplx), "-deblock", str(idc),
-             "-alpha", str(alpha), "-beta", str(beta), "-crop", str(crop), "-spsid", str(spsid), "-forceidr", str(fidr), "-quiet"]
+             "-alpha", str(alpha), "-beta", str(beta), "-crop", str(crop), "-spsid", str(spsid), "-forceidr", str(fidr),
+             "-scene", str(scene), "-aq", str(aq), "-frameskip", str(fskip), "-quiet"]
     if nsl > 1:
         params.update(uiSliceMode=1, uiSliceNum=nsl)
         flags += ["-slcmd", "1", "-slcnum", str(nsl)]
-    desc = "%dx%d f%d qp%d iper%d c%d idc%d a%d b%d crop%d id%d fi%d sl%d %s" % (w, h, frames, qp, iper, cplx, idc, alpha, beta, crop, spsid, fidr, nsl, kind)
+    desc = "%dx%d f%d qp%d iper%d c%d idc%d a%d b%d crop%d id%d fi%d sc%d/%d sl%d %s" % (w, h, frames, qp, iper, cplx, idc, alpha, beta, crop, spsid, fidr, scene, cut, nsl, kind)
     if not run:                                            # --only: just keep the random stream in step
         return desc, "ok"
     fi, fo = os.path.join(tmp, "in.yuv"), os.path.join(tmp, "ref.264")
@@ -159,7 +171,7 @@ def main():
                 continue
             if not res.startswith("ok"):
                 bad += 1
-            print("%4d %-72s %s" % (i, desc, res), flush=True)
+            print("%4d %-80s %s" % (i, desc, res), flush=True)
     print("%d cases, %d failed" % (a.cases if a.only < 0 else 1, bad))
     sys.exit(1 if bad else 0)
 

@@ -43,6 +43,9 @@ CASES = {
     "i_76x80_qp3_checker_overflow": (76, 80, 3, ["-iper", "1", "-qp", "3"], dict(uiIntraPeriod=1, iDLayerQp=3), "checker5"),
     "p_144x96_qp1_checker_2slices_overflow": (144, 96, 4, ["-iper", "0", "-qp", "1", "-slcmd", "1", "-slcnum", "2"], dict(uiIntraPeriod=0, iDLayerQp=1, uiSliceMode=1, uiSliceNum=2), "checker8"),
     "p_64x64_qp3_checker_idc1_overflow": (64, 64, 4, ["-iper", "0", "-qp", "3", "-deblock", "1"], dict(uiIntraPeriod=0, iDLayerQp=3, iLoopFilterDisableIdc=1), "checker5"),
+    # scene-change detection (on by default in the reference): first possible 17 pictures after an IDR; the synthetic
+    # motion exceeds the 85 % moving-blocks threshold, so picture 17 becomes an IDR
+    "p_176x144_qp28_20f_scene": (176, 144, 20, ["-iper", "0", "-qp", "28", "-scene", "1"], dict(uiIntraPeriod=0, iDLayerQp=28, bEnableSceneChangeDetect=1)),
 }
 COMMON = ["-rc", "-1", "-fps", "30", "-quiet"]
 
