@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--workload", default="auto", choices=["auto", "intra", "p"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--e2e", action="store_true", help="also time the full encode incl. D2H + host CAVLC")
-    ap.add_argument("--host-threads", type=int, default=8)
+    ap.add_argument("--host-threads", type=int, default=min(32, os.cpu_count() or 8))
     ap.add_argument("--deblock-idc", type=int, default=0, help="disable_deblocking_filter_idc (0: filter across slice boundaries, the reference default)")
     return ap.parse_args()
 

@@ -312,6 +312,8 @@ class HipBackend : public wh::Backend {
   }
   void free (void*) override {}
   void upload (void* dst, const void* src, size_t bytes) override { HIP_CHECK (hipMemcpyAsync (dst, src, bytes, hipMemcpyHostToDevice, stream_)); }
+  void pin_host (void* p, size_t bytes) override { if (hipHostRegister (p, bytes, hipHostRegisterDefault) != hipSuccess) (void)hipGetLastError(); }
+  void unpin_host (void* p) override { if (hipHostUnregister (p) != hipSuccess) (void)hipGetLastError(); }
   void download (void* dst, const void* src, size_t bytes) override { HIP_CHECK (hipMemcpyAsync (dst, src, bytes, hipMemcpyDeviceToHost, stream_)); }
   void fill (void* dst, int value, size_t bytes) override { HIP_CHECK (hipMemsetAsync (dst, value, bytes, stream_)); }
 

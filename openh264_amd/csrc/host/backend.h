@@ -19,6 +19,9 @@ class Backend {
   virtual void upload (void* dst, const void* src, size_t bytes) = 0;
   virtual void download (void* dst, const void* src, size_t bytes) = 0;
   virtual void fill (void* dst, int value, size_t bytes) = 0;
+  // page-lock a host buffer that is the target of many downloads (best effort; no-op where it does not apply)
+  virtual void pin_host (void* p, size_t bytes) { (void)p; (void)bytes; }
+  virtual void unpin_host (void* p) { (void)p; }
   // frame-level kernels over `n` pictures that share the sequence parameters P.
   // `jobs` is a DEVICE array of WhPicJob.  All calls are asynchronous on the backend's stream.
   virtual void run_intra (const WhSeqParams& P, const WhPicJob* jobs, int n) = 0;     // I pictures: MD + recon

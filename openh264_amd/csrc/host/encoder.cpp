@@ -160,6 +160,7 @@ struct SessionCore {
     }
     d_records = (WhMbRecord*)be->alloc (sizeof (WhMbRecord) * num_mb);
     h_records.resize (num_mb);
+    be->pin_host (h_records.data(), sizeof (WhMbRecord) * num_mb);     // D2H target of every frame
     {
       // processing order tables (kernels/frame_kernels.h wh_build_mb_order): per slice, then whole picture
       std::vector<uint16_t> order ((size_t)num_mb * 2);
@@ -185,6 +186,7 @@ struct SessionCore {
     for (int i = 0; i < 2; ++i) { if (pic[i].base) be->free (pic[i].base); if (pic[i].mbs) be->free (pic[i].mbs); pic[i] = DevPicture(); }
     if (d_records) be->free (d_records);
     d_records = nullptr;
+    if (!h_records.empty()) be->unpin_host (h_records.data());
     if (d_order) be->free (d_order);
     d_order = nullptr;
     if (d_dbflags) be->free (d_dbflags);
