@@ -155,8 +155,9 @@ int  WelsHipDebugGetMbRecords (WelsHipEncoder* pEncoder, void* pDst, size_t uiBy
 /* developer aid: number of picture re-encodes caused by CAVLC level overflows since InitializeExt (the reference's
  * TRY_REENCODING loop, codec/encoder/core/src/svc_encode_slice.cpp:572-576,1863-1867), or -1 */
 int  WelsHipDebugGetOverflowReencodes (WelsHipEncoder* pEncoder);
-/* developer aid: per-phase cycle counters accumulated inside the MB kernels (16 sums + 16 counts) */
-int  WelsHipGroupProfile (WelsHipEncoderGroup* pGroup, int bEnable, unsigned long long* pOut32);
+/* developer aid: per-phase cycle counters accumulated inside the MB kernels; pOut64 receives 16 sums + 16 counts of the
+ * mode-decision kernel followed by 16 sums + 16 counts of the deblocking kernel */
+int  WelsHipGroupProfile (WelsHipEncoderGroup* pGroup, int bEnable, unsigned long long* pOut64);
 
 /* ---- (3) leaf primitives, batched.  One call = n independent invocations of the reference entry
  * named in the comment.  p*Plane are HOST buffers of `bytes` bytes; block i starts at

@@ -209,6 +209,8 @@ __global__ __launch_bounds__ (1024) void k_deblock_slices (WhSeqParams P, const 
   const bool cross = P.deblock_idc == 0;        // idc 2: nothing is filtered (or needed) across slices
   __shared__ WhDbStage stage[16];                 // separate LDS object (see WhInterStage)
   WhDbStage& G = stage[wave];
+  if (P.prof && lane < 32) S.prof[lane] = 0;
+  WH_PROF_DECL (P);
   for (int guard = 0; guard <= n; ++guard) {
     // a wave takes a ticket only when it is free (a held ticket could be the one the whole dependency chain is waiting
     // for), starts the loads of that MB's own inputs at once and waits for the neighbours while they are in flight
@@ -217,7 +219,9 @@ __global__ __launch_bounds__ (1024) void k_deblock_slices (WhSeqParams P, const 
     t = __builtin_amdgcn_readfirstlane (t);
     if (t >= n) break;
     const int xy = order[t];
+    WH_PROF_MARK (P, S, 0);   // ticket + order
     wh_deblock_cold_fetch (G, lane, P, J, xy % w, xy / w);
+    WH_PROF_MARK (P, S, 1);   // own inputs requested
     int dep_a, dep_b;                           // picture-wide dependencies: left, top-right (top at the right edge)
     wh_mb_deps (w, xy, 0, &dep_a, &dep_b);
     bool remote = false, ok = true;
@@ -237,8 +241,11 @@ __global__ __launch_bounds__ (1024) void k_deblock_slices (WhSeqParams P, const 
     if (!ok) break;
     if (remote) __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "agent");
     else __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "workgroup");
+    WH_PROF_MARK (P, S, remote ? 3 : 2);        // neighbours done: 2 = inside the workgroup, 3 = incl. a wait across the seam
     WV_ASYNC_WAIT();                            // this MB's staged inputs have landed
+    WH_PROF_MARK (P, S, 4);   // own inputs landed
     const bool drain = wh_deblock_mb_body (S, G, E, first, last, P, J, xy % w, xy / w, 0, 0, 0);
+    WH_PROF_MARK (P, S, 11);  // (body total: ids 5..8)
     // MBs a later slice may wait for: its left neighbour (xy + 1), top (xy + w) or top-right consumer (xy + w - 1)
     const bool publish = cross && xy + w + 1 >= last && last < num_mb;
     if (publish) {
@@ -253,7 +260,11 @@ __global__ __launch_bounds__ (1024) void k_deblock_slices (WhSeqParams P, const 
     // wave's global stores need not have completed -- no other MB of the slice writes or reads those samples
     WV_SYNC();
     if (lane == 0) atomicOr (&sched[1 + ((xy - first) >> 5)], 1u << ((xy - first) & 31));
+    WH_PROF_MARK (P, S, 9);   // publish / release + done flag
   }
+  WH_PROF_MARK (P, S, 10);    // idle tail: no ticket left, the slice is still being finished by other waves
+  // second half of the profile buffer (the first belongs to the mode-decision kernels)
+  if (P.prof && lane < 32) atomicAdd (&P.prof[2048u + ((blockIdx.x + blockIdx.y * 7u) & 63u) * 32u + lane], (unsigned long long)S.prof[lane]);
 }
 
 __global__ __launch_bounds__ (64) void k_expand (WhSeqParams P, const WhPicJob* jobs) {

@@ -825,16 +825,17 @@ int WelsHipGroupBench (WelsHipEncoderGroup* g, int steps, int warmup, double* ou
 
 // Developer aid: in-kernel phase profiling.  Enable -> subsequent steps accumulate cycle counters; Read copies the
 // 32 counters (16 cycle sums + 16 hit counts) and clears them.
-int WelsHipGroupProfile (WelsHipEncoderGroup* g, int enable, unsigned long long* out32) {
+int WelsHipGroupProfile (WelsHipEncoderGroup* g, int enable, unsigned long long* out64) {
   if (!g) return WELSHIP_ERR_INIT_PARA;
   wh::Backend* be = g->be;
   unsigned long long*& prof = g->sess[0]->seq.prof;
-  const size_t bytes = 64 * 32 * 8;      // 64 banks (WH_PROF_MARK)
+  const size_t bytes = 2 * 64 * 32 * 8;  // two kernels (mode decision, deblocking) x 64 banks (WH_PROF_MARK)
   if (enable && !prof) { prof = (unsigned long long*)be->alloc (bytes); be->fill (prof, 0, bytes); be->sync(); }
-  if (out32 && prof) {
-    std::vector<unsigned long long> h (64 * 32);
+  if (out64 && prof) {
+    std::vector<unsigned long long> h (2 * 64 * 32);
     be->download (h.data(), prof, bytes); be->sync(); be->fill (prof, 0, bytes); be->sync();
-    for (int i = 0; i < 32; ++i) { out32[i] = 0; for (int b = 0; b < 64; ++b) out32[i] += h[(size_t)b * 32 + i]; }
+    for (int k = 0; k < 2; ++k)
+      for (int i = 0; i < 32; ++i) { out64[k * 32 + i] = 0; for (int b = 0; b < 64; ++b) out64[k * 32 + i] += h[(size_t)k * 2048 + (size_t)b * 32 + i]; }
   }
   if (!enable && prof) { be->free (prof); prof = nullptr; }
   return WELSHIP_OK;

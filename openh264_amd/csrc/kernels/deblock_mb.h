@@ -16,6 +16,7 @@ typedef struct WhDbLds {
   uint8_t c[2][10 * 12];
   uint8_t bs[2][4][4];       // [dir 0=vertical edges,1=horizontal][edge][segment]
   uint32_t st[3 * 36];       // WhMbState copies (36 words each): this MB, left, top
+  uint32_t prof[32];         // phase-profiling accumulators of this wave (WH_PROF_MARK)
 } WhDbLds;
 #define WH_DY(S, x, yy) ((S).y[((yy) + 4) * 24 + (x) + 4])
 #define WH_DC(S, p, x, yy) ((S).c[p][((yy) + 2) * 12 + (x) + 4])
@@ -137,6 +138,7 @@ WH_HDFN size_t wh_db_xchg_words (int mb_w, int rows) { return (size_t)mb_w * 24 
 // rewrote samples of another slice's MBs that a later MB of this workgroup reads back from the picture).
 WH_FN bool wh_deblock_mb_body (WhDbLds& S, WhDbStage& G, const WhDbXchg& E, int first, int last, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby,
                                int next_valid, int next_mbx, int next_mby) {
+  WH_PROF_DECL (P);
   const int w = P.mb_w, xy = mby * w + mbx;
   const bool top_lds = mby > 0 && xy - w >= first, left_lds = mbx > 0 && xy - 1 >= first;
   uint32_t* etop = E.top + mbx * 24;
@@ -189,6 +191,7 @@ WH_FN bool wh_deblock_mb_body (WhDbLds& S, WhDbStage& G, const WhDbXchg& E, int 
   const int type = M->mb_type;
   const bool intra = WH_IS_INTRA (type);
 
+  WH_PROF_MARK (P, S, 5);   // neighbour strips + staged inputs assembled in the tile
   // ---- boundary strengths ----
   int any_bs;
   WV_LANES_BEGIN (lane)
@@ -220,6 +223,7 @@ WH_FN bool wh_deblock_mb_body (WhDbLds& S, WhDbStage& G, const WhDbXchg& E, int 
   const bool filtered = any_bs != 0;           // nothing to filter: the MB's own samples stay as mode decision left them
   if (filtered) {
   const int qp = M->luma_qp, qpc = M->chroma_qp;
+  WH_PROF_MARK (P, S, 6);   // boundary strengths
   // ---- vertical edges (dir 0) then horizontal edges (dir 1) ----
   for (int dir = 0; dir < 2; ++dir) {
     for (int e = 0; e < 4; ++e) {
@@ -255,6 +259,7 @@ WH_FN bool wh_deblock_mb_body (WhDbLds& S, WhDbStage& G, const WhDbXchg& E, int 
 
   }   // filtered
 
+  WH_PROF_MARK (P, S, 7);   // edge filters
   // ---- write-back (see the ownership rule above) ----
   const bool right_in = mbx < w - 1 && xy + 1 < last, below_in = xy + w < last;
   const bool lb_none = xy - 1 + w >= last;        // the left MB has no neighbour below it inside the slice
@@ -280,5 +285,6 @@ WH_FN bool wh_deblock_mb_body (WhDbLds& S, WhDbStage& G, const WhDbXchg& E, int 
   }
   WV_LANES_END
   wh_db_publish (S, etop, eleft, filtered && left_ok && left_lds);
+  WH_PROF_MARK (P, S, 8);   // write-back + strip exchange
   return filtered && ((left_ok && !left_lds) || (top_ok && !top_lds));
 }

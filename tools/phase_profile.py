@@ -15,7 +15,7 @@ lib = g._lib
 lib.WelsHipGroupProfile.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_ulonglong)]
 lib.WelsHipGroupProfile(g._h, 1, None)
 print(g.bench(3, 0))
-out = (C.c_ulonglong * 32)()
+out = (C.c_ulonglong * 64)()
 lib.WelsHipGroupProfile(g._h, 1, out)
 names = {11: "ticket+order", 12: "dependency wait", 8: "args+job+slice", 9: "batch-1 loads", 10: "nb cache+ctx", 0: "mvp+window loads", 1: "pskip test", 2: "p16x16 ME", 3: "i16 test",
          4: "fine partitions", 5: "refine+chromaMC", 6: "residual", 7: "store", 13: "release+flag", 14: "(body total)", 15: "window adopted"}
@@ -23,3 +23,12 @@ tot = sum(out[i] for i in range(16) if i not in (14,))
 for i, n in names.items():
     print("%-18s %6.2f%%  avg %8.0f cycles  hits %d" % (n, 100.0 * out[i] / max(tot, 1), out[i] / max(out[16 + i], 1), out[16 + i]))
 print("total cycles/MB %.0f" % (tot / max(out[16 + 7], 1)))
+
+db = {0: "ticket+order", 1: "request own inputs", 2: "wait neighbours (in WG)", 3: "wait neighbours (seam)", 4: "own inputs landed", 5: "strips+tile", 6: "boundary strengths",
+      7: "edge filters", 8: "write-back+exchange", 9: "publish+flag", 10: "idle tail (per wave)", 11: "(body total)"}
+d = out[32:]
+tot = sum(d[i] for i in range(16) if i not in (11,))
+print("deblocking kernel:")
+for i, n in db.items():
+    print("%-26s %6.2f%%  avg %8.0f cycles  hits %d" % (n, 100.0 * d[i] / max(tot, 1), d[i] / max(d[16 + i], 1), d[16 + i]))
+print("total wave cycles per MB %.0f" % (tot / max(d[16 + 9], 1)))
