@@ -70,7 +70,7 @@ typedef struct WelsHipEncParam {
   int32_t iLoopFilterAlphaC0Offset, iLoopFilterBetaOffset;
   int32_t bEnableFrameCroppingFlag;
   int32_t iDLayerQp;                /* sSpatialLayers[0].iDLayerQp                                   */
-  int32_t uiSliceMode;              /* 0 SM_SINGLE_SLICE, 1 SM_FIXEDSLCNUM_SLICE                     */
+  int32_t uiSliceMode;              /* 0 SM_SINGLE_SLICE, 1 SM_FIXEDSLCNUM_SLICE, 2 SM_RASTER_SLICE  */
   int32_t uiSliceNum;
   /* bEnableSceneChangeDetect: implemented (IDR on a LARGE_CHANGED_SCENE, encoder.cpp:377-391).  bEnableAdaptiveQuant is
    * accepted and ignored like the reference does (encoder_ext.cpp:300-301); bEnableFrameSkip only acts under rate
@@ -79,6 +79,8 @@ typedef struct WelsHipEncParam {
           bEnableLongTermReference, bEnableDenoise, bEnableFrameSkip;
   int32_t iDevice;                  /* HIP device ordinal                                            */
   int32_t reserved[7];
+  uint32_t uiSliceMbNum[35];        /* SM_RASTER_SLICE: macroblocks per slice (sSliceArgument.uiSliceMbNum, MAX_SLICES_NUM
+                                       entries); uiSliceMbNum[0] == 0 = one slice per macroblock row                  */
 } WelsHipEncParam;
 
 /* SSourcePicture (codec_app_def.h:659-671), I420 only */

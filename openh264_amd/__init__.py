@@ -35,7 +35,7 @@ class SEncParamExt(C.Structure):
         ("bEnableFrameCroppingFlag", C.c_int32), ("iDLayerQp", C.c_int32), ("uiSliceMode", C.c_int32), ("uiSliceNum", C.c_int32),
         ("bEnableAdaptiveQuant", C.c_int32), ("bEnableBackgroundDetection", C.c_int32), ("bEnableSceneChangeDetect", C.c_int32),
         ("bEnableLongTermReference", C.c_int32), ("bEnableDenoise", C.c_int32), ("bEnableFrameSkip", C.c_int32),
-        ("iDevice", C.c_int32), ("reserved", C.c_int32 * 7),
+        ("iDevice", C.c_int32), ("reserved", C.c_int32 * 7), ("uiSliceMbNum", C.c_uint32 * 35),
     ]
 
 
@@ -182,7 +182,12 @@ def encode_sequence(yuv_bytes, width, height, lib_path=None, stats=None, force_i
     p = enc.GetDefaultParams()
     p.iPicWidth, p.iPicHeight = width, height
     for k, v in params.items():
-        setattr(p, k, v)
+        if isinstance(v, (list, tuple)):          # array fields (uiSliceMbNum)
+            arr = getattr(p, k)
+            for i, x in enumerate(v):
+                arr[i] = x
+        else:
+            setattr(p, k, v)
     rc = enc.InitializeExt(p)
     if rc:
         raise WelsHipError(rc, enc.last_error())

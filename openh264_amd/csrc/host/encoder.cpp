@@ -96,7 +96,7 @@ struct SessionCore {
     if (p->bEnableBackgroundDetection || p->bEnableLongTermReference || p->bEnableDenoise) {
       set_err ("background detection / LTR / denoise are not supported"); return WELSHIP_ERR_UNSUPPORTED;
     }
-    if (p->uiSliceMode != 0 && p->uiSliceMode != 1) { set_err ("slice mode must be 0 or 1"); return WELSHIP_ERR_UNSUPPORTED; }
+    if (p->uiSliceMode < 0 || p->uiSliceMode > 2) { set_err ("slice mode must be 0 (single), 1 (fixed number) or 2 (raster)"); return WELSHIP_ERR_UNSUPPORTED; }
     if (p->iLoopFilterDisableIdc < 0 || p->iLoopFilterDisableIdc > 2) { set_err ("deblocking idc must be 0..2"); return WELSHIP_ERR_UNSUPPORTED; }
     if (p->iLoopFilterAlphaC0Offset < -6 || p->iLoopFilterAlphaC0Offset > 6 || p->iLoopFilterBetaOffset < -6 || p->iLoopFilterBetaOffset > 6) {
       set_err ("deblocking alpha/beta offsets must be -6..6"); return WELSHIP_ERR_INIT_PARA;     // ParamValidation, encoder_ext.cpp:316-323
@@ -105,8 +105,10 @@ struct SessionCore {
     return WELSHIP_OK;
   }
 
+  bool single_slice_mode = true;      // the reference's uiSliceMode ended up as SM_SINGLE_SLICE (requested or fall-back)
   int compute_slices() {
     WhSeqParams& s = seq;
+    if (prm.uiSliceMode == 2) return compute_raster_slices();
     int n = prm.uiSliceMode == 0 ? 1 : prm.uiSliceNum;
     if (n < 1) return -1;
     // SliceArgumentValidationFixedSliceMode (encoder_ext.cpp:178-255): small pictures fall back to one slice,
@@ -116,7 +118,42 @@ struct SessionCore {
     if (n > 35) n = 35;
     if (n > 1 && num_mb / n <= 0) n = 1;
     s.num_slices = n;
+    single_slice_mode = n == 1;
     for (int i = 0; i < n; ++i) s.slice_first_mb[i] = i * (num_mb / n);
+    s.slice_first_mb[n] = num_mb;
+    return 0;
+  }
+
+  // SM_RASTER_SLICE (ParamValidationExt, encoder_ext.cpp:560-612 + CheckRasterMultiSliceSetting,
+  // svc_enc_slice_segment.cpp:166-215): uiSliceMbNum[] macroblocks per slice; entry 0 == 0 means one slice per row.
+  int compute_raster_slices() {
+    WhSeqParams& s = seq;
+    const int max_slices = 35;                              // MAX_SLICES_NUM
+    int cnt[36];
+    int n = 0;
+    single_slice_mode = false;
+    if (prm.uiSliceMbNum[0] == 0) {                         // row slices: stays SM_RASTER_SLICE even for one row
+      if (mb_h > max_slices) return -1;
+      n = mb_h;
+      for (int i = 0; i < n; ++i) cnt[i] = mb_w;
+    } else {
+      int total = 0;
+      while (n < max_slices && prm.uiSliceMbNum[n] > 0) {
+        cnt[n] = (int)prm.uiSliceMbNum[n];
+        total += cnt[n];
+        ++n;
+        if (total >= num_mb) break;
+      }
+      if (total > num_mb) cnt[n - 1] -= total - num_mb;     // the last one is cut ...
+      else if (total < num_mb) {                             // ... or a slice with the rest is appended
+        if (n >= max_slices) return -1;
+        cnt[n++] = num_mb - total;
+      }
+      if (n == 1 || num_mb <= 48) { n = 1; cnt[0] = num_mb; single_slice_mode = true; }   // turned into SM_SINGLE_SLICE
+    }
+    s.num_slices = n;
+    int first = 0;
+    for (int i = 0; i < n; ++i) { s.slice_first_mb[i] = first; first += cnt[i]; }
     s.slice_first_mb[n] = num_mb;
     return 0;
   }
@@ -139,7 +176,7 @@ struct SessionCore {
     if (compute_slices()) { set_err ("invalid slice number"); return WELSHIP_ERR_INIT_PARA; }
     // InitDqLayers (encoder_ext.cpp:1109-1117): with a single slice (requested, or after the fall-back above)
     // "filter all but slice edges" is signalled and run as idc 0
-    if (s.num_slices == 1 && s.deblock_idc == 2) s.deblock_idc = 0;
+    if (single_slice_mode && s.deblock_idc == 2) s.deblock_idc = 0;
     ysz = (size_t)s.src_stride_y * mb_h * 16; csz = (size_t)s.src_stride_c * mb_h * 8; src_bytes = ysz + 2 * csz;
     h_src.assign (src_bytes, 0);
     memset (h_src.data() + ysz, 0x80, 2 * csz);     // CWelsPreProcess::Padding: luma 0, chroma 0x80
@@ -739,7 +776,12 @@ int WelsHipGroupFinish (WelsHipEncoderGroup* g, WelsHipFrameBSInfo* outs) {
       rcs[i] = c.finish_frame (outs ? &outs[i] : nullptr, 0);
     }
   }
-  for (int i = 0; i < n; ++i) if (rcs[i]) return rcs[i];
+  for (int i = 0; i < n; ++i) if (rcs[i]) {
+    // the detailed message was recorded on the worker thread that coded the session; leave one the caller can read
+    set_err ("session " + std::to_string (i) + (rcs[i] == WELSHIP_ERR_MEMORY ? ": frame does not fit the reference encoder's bitstream buffer (cmMallocMemeError)"
+                                                                             : ": entropy coding of the frame failed"));
+    return rcs[i];
+  }
   return WELSHIP_OK;
 }
 

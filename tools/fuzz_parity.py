@@ -7,6 +7,7 @@ and content classes.  Test infrastructure: prints one line per case and a summar
     python tools/fuzz_parity.py --cases 40 --hip                # on an MI355X box
 """
 import argparse
+import ctypes as C
 import hashlib
 import os
 import subprocess
@@ -119,7 +120,17 @@ def one_case(rng, lib, enc_tool, tmp, max_mbs, run=True):
     flags = ["-rc", "-1", "-qp", str(qp), "-fps", "30", "-iper", str(iper), "-complexity", str(cplx), "-deblock", str(idc),
              "-alpha", str(alpha), "-beta", str(beta), "-crop", str(crop), "-spsid", str(spsid), "-forceidr", str(fidr),
              "-scene", str(scene), "-aq", str(aq), "-frameskip", str(fskip), "-quiet"]
-    if nsl > 1:
+    raster = -1
+    if rng.random() < 0.2:                                 # SM_RASTER_SLICE: N macroblocks per slice, 0 = one slice per row
+        raster = int(rng.choice([0, 0, int(rng.integers(1, mbs + 8)), int(rng.integers(max(1, mbs // 36), max(2, mbs // 2) + 1))]))
+        if raster == 0 and mb_h > 35 or raster > 0 and (mbs + raster - 1) // raster > 35 + 1:
+            raster = -1
+    if raster >= 0:
+        arr = (C.c_uint32 * 35)(*([raster] * 35))
+        params.update(uiSliceMode=2, uiSliceMbNum=arr)
+        flags += ["-slcmd", "2", "-slcmbnum", str(raster)]
+        nsl = 100 + raster
+    elif nsl > 1:
         params.update(uiSliceMode=1, uiSliceNum=nsl)
         flags += ["-slcmd", "1", "-slcnum", str(nsl)]
     desc = "%dx%d f%d qp%d iper%d c%d idc%d a%d b%d crop%d id%d fi%d sc%d/%d sl%d %s" % (w, h, frames, qp, iper, cplx, idc, alpha, beta, crop, spsid, fidr, scene, cut, nsl, kind)
@@ -136,6 +147,8 @@ def one_case(rng, lib, enc_tool, tmp, max_mbs, run=True):
         # the reference gives up with cmMallocMemeError (3) when a frame overflows its bitstream buffer even at QP 50
         if ref_failed and e.code == 3 and "EncodeFrame failed: 3" in r.stderr.decode():
             return desc, "ok (both refuse the frame: bitstream buffer overflow)"
+        if ref_failed and e.code in (1, 4) and "Initialize failed" in r.stderr.decode():
+            return desc, "ok (both reject the parameters)"
         return desc, "ERROR %s" % e
     if ref_failed:
         return desc, "MISMATCH reference failed (%s), ours encoded %d B" % (r.stderr.decode().strip().splitlines()[-1], len(bs))

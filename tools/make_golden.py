@@ -46,6 +46,9 @@ CASES = {
     # scene-change detection (on by default in the reference): first possible 17 pictures after an IDR; the synthetic
     # motion exceeds the 85 % moving-blocks threshold, so picture 17 becomes an IDR
     "p_176x144_qp28_20f_scene": (176, 144, 20, ["-iper", "0", "-qp", "28", "-scene", "1"], dict(uiIntraPeriod=0, iDLayerQp=28, bEnableSceneChangeDetect=1)),
+    # SM_RASTER_SLICE: 37 macroblocks per slice (7 slices, the last one cut) and one slice per macroblock row (12 slices)
+    "p_320x192_qp26_raster37": (320, 192, 4, ["-iper", "0", "-qp", "26", "-slcmd", "2", "-slcmbnum", "37"], dict(uiIntraPeriod=0, iDLayerQp=26, uiSliceMode=2, uiSliceMbNum=[37] * 35)),
+    "p_320x192_qp26_c1_rowslices_idc2": (320, 192, 4, ["-iper", "0", "-qp", "26", "-complexity", "1", "-slcmd", "2", "-deblock", "2"], dict(uiIntraPeriod=0, iDLayerQp=26, iComplexityMode=1, uiSliceMode=2, iLoopFilterDisableIdc=2)),
 }
 COMMON = ["-rc", "-1", "-fps", "30", "-quiet"]
 
