@@ -1,0 +1,110 @@
+"""The drop-in boundary at application level: the reference's own console front-end (codec/console/enc/src/welsenc.cpp,
+compiled unmodified by oracle/Makefile) linked against this engine through the ISVCEncoder adapter
+(oracle/dropin/welship_isvc.cpp) must write the same bitstream as the same front-end on the reference encoder.
+The configuration files are written here (key names per welsenc.cpp ParseConfig / ParseLayerConfig)."""
+import os
+import subprocess
+
+import pytest
+
+from openh264_amd.utils.synth import make_sequence
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REFDIR = os.path.join(ROOT, "oracle", "_ref")
+
+MAIN_CFG = """UsageType 0
+SimulcastAVC 0
+SourceWidth {w}
+SourceHeight {h}
+InputFile {yuv}
+OutputFile {out}
+MaxFrameRate 30
+FramesToBeEncoded -1
+TemporalLayerNum 1
+IntraPeriod {iper}
+SpsPpsIDStrategy 1
+EnableFrameCropping 1
+EntropyCodingModeFlag 0
+MaxNalSize 0
+ComplexityMode {cplx}
+LoopFilterDisableIDC {idc}
+LoopFilterAlphaC0Offset 0
+LoopFilterBetaOffset 0
+MultipleThreadIdc 1
+UseLoadBalancing 0
+RCMode -1
+TargetBitrate 5000
+MaxOverallBitrate 0
+EnableFrameSkip 0
+MaxQp 51
+MinQp 0
+EnableDenoise 0
+EnableSceneChangeDetection {scene}
+EnableBackgroundDetection 0
+EnableAdaptiveQuantization 1
+EnableLongTermReference 0
+LtrMarkPeriod 30
+PrefixNALAddingCtrl 0
+NumLayers 1
+LayerCfg {layer}
+"""
+
+LAYER_CFG = """FrameWidth {w}
+FrameHeight {h}
+FrameRateOut 30
+ReconFile {rec}
+ProfileIdc 66
+InitialQP {qp}
+SpatialBitrate 5000
+MaxSpatialBitrate 0
+SliceMode {slcmode}
+SliceSize 1500
+SliceNum {slcnum}
+SlicesAssign0 {assign}
+SlicesAssign1 {assign}
+SlicesAssign2 {assign}
+SlicesAssign3 {assign}
+SlicesAssign4 {assign}
+SlicesAssign5 {assign}
+SlicesAssign6 {assign}
+SlicesAssign7 {assign}
+"""
+
+CASES = {
+    "p_176x144_qp24": dict(w=176, h=144, frames=6, qp=24, iper=0, cplx=0, idc=0, scene=0, slcmode=0, slcnum=1, assign=0),
+    "p_320x192_4slices_c1": dict(w=320, h=192, frames=4, qp=28, iper=0, cplx=1, idc=0, scene=0, slcmode=1, slcnum=4, assign=0),
+    "p_152x100_crop_raster20_idc2": dict(w=152, h=100, frames=5, qp=30, iper=3, cplx=2, idc=2, scene=0, slcmode=2, slcnum=1, assign=20),
+    "p_176x144_scene_20f": dict(w=176, h=144, frames=20, qp=28, iper=0, cplx=0, idc=0, scene=1, slcmode=0, slcnum=1, assign=0),
+}
+
+
+def run_cli(exe, c, tmp, tag, env=None):
+    # relative file names, run inside tmp: the console keeps file names in short fixed-size buffers
+    out, main, layer, rec = tag + ".264", tag + ".cfg", tag + "_layer.cfg", tag + "_rec.yuv"
+    open(str(tmp / layer), "w").write(LAYER_CFG.format(rec=rec, **c))
+    open(str(tmp / main), "w").write(MAIN_CFG.format(yuv="in.yuv", out=out, layer=layer, **c))
+    r = subprocess.run([exe, main], cwd=str(tmp), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout.decode()[-2000:]
+    return open(str(tmp / out), "rb").read(), (open(str(tmp / rec), "rb").read() if os.path.exists(str(tmp / rec)) else None)
+
+
+def check_case(name, engine_lib, tmp_path):
+    ref_cli, our_cli = os.path.join(REFDIR, "h264enc_ref"), os.path.join(REFDIR, "h264enc_welship")
+    if not (os.path.exists(ref_cli) and os.path.exists(our_cli)):
+        pytest.skip("oracle/_ref console builds not present")
+    c = CASES[name]
+    open(str(tmp_path / "in.yuv"), "wb").write(make_sequence("synth", c["w"], c["h"], c["frames"]))
+    ref, _ = run_cli(ref_cli, c, tmp_path, "ref")     # (the reference only dumps reconstructions when built with ENABLE_FRAME_DUMP)
+    env = dict(os.environ, WELSHIP_LIB=engine_lib)
+    ours, our_rec = run_cli(our_cli, c, tmp_path, "ours", env=env)
+    assert len(ref) > 100
+    assert ours == ref
+    # ENCODER_OPTION_DUMP_FILE through the adapter: every reconstructed picture equals what the reference decoder outputs
+    subprocess.check_call([os.path.join(REFDIR, "ref_dec"), "ours.264", "dec.yuv"], cwd=str(tmp_path), stdout=subprocess.DEVNULL)
+    dec = open(str(tmp_path / "dec.yuv"), "rb").read()
+    assert len(dec) == c["w"] * c["h"] * 3 // 2 * c["frames"] and our_rec == dec
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_reference_cli_on_this_engine(name, emu_lib, tmp_path):
+    check_case(name, emu_lib, tmp_path)
