@@ -98,6 +98,11 @@ def one_case(rng, lib, enc_tool, tmp, max_mbs, run=True):
         frames = int(rng.integers(18, 30))
         cut = int(rng.integers(10, frames)) if rng.random() < 0.7 else -1
     aq, fskip = int(rng.random() < 0.3), int(rng.random() < 0.3)   # accepted and without effect, as in the reference
+    # frame rate and bitrate only feed the level selection here; drawn from a side stream so that the picture / slice /
+    # content draws of a (seed, index) pair stay what they were when the GPU tier was last run on them
+    rng2 = np.random.default_rng([w, h, frames, mbs])
+    fps = float(rng2.choice([30, 30, 5, 12.5, 15, 25, 60]))
+    bitrate = int(rng2.choice([5000000, 5000000, 64000, 300000, 1200000, 20000000, 80000000]))
     qp = int(rng.choice([0, 1, 5, 10, 12, 18, 24, 26, 30, 36, 40, 45, 51, int(rng.integers(0, 52))]))
     iper = int(rng.choice([0, 0, 0, 1, 2, 3]))
     cplx = int(rng.choice([0, 0, 1, 2]))
@@ -113,11 +118,11 @@ def one_case(rng, lib, enc_tool, tmp, max_mbs, run=True):
         other = content(str(rng.choice(KINDS)), w, h, frames, rng)
         fsz = w * h * 3 // 2
         yuv = yuv[:cut * fsz] + other[cut * fsz:]
-    params = dict(fMaxFrameRate=30.0, iTargetBitrate=5000000, iDLayerQp=qp, uiIntraPeriod=iper, iComplexityMode=cplx,
+    params = dict(fMaxFrameRate=fps, iTargetBitrate=bitrate, iDLayerQp=qp, uiIntraPeriod=iper, iComplexityMode=cplx,
                   iLoopFilterDisableIdc=idc, iLoopFilterAlphaC0Offset=alpha, iLoopFilterBetaOffset=beta,
                   bEnableFrameCroppingFlag=crop, eSpsPpsIdStrategy=spsid, bEnableSceneChangeDetect=scene,
                   bEnableAdaptiveQuant=aq, bEnableFrameSkip=fskip)
-    flags = ["-rc", "-1", "-qp", str(qp), "-fps", "30", "-iper", str(iper), "-complexity", str(cplx), "-deblock", str(idc),
+    flags = ["-rc", "-1", "-qp", str(qp), "-fps", str(fps), "-bitrate", str(bitrate), "-iper", str(iper), "-complexity", str(cplx), "-deblock", str(idc),
              "-alpha", str(alpha), "-beta", str(beta), "-crop", str(crop), "-spsid", str(spsid), "-forceidr", str(fidr),
              "-scene", str(scene), "-aq", str(aq), "-frameskip", str(fskip), "-quiet"]
     raster = -1
@@ -133,7 +138,7 @@ def one_case(rng, lib, enc_tool, tmp, max_mbs, run=True):
     elif nsl > 1:
         params.update(uiSliceMode=1, uiSliceNum=nsl)
         flags += ["-slcmd", "1", "-slcnum", str(nsl)]
-    desc = "%dx%d f%d qp%d iper%d c%d idc%d a%d b%d crop%d id%d fi%d sc%d/%d sl%d %s" % (w, h, frames, qp, iper, cplx, idc, alpha, beta, crop, spsid, fidr, scene, cut, nsl, kind)
+    desc = "%dx%d f%d@%g/%dk qp%d iper%d c%d idc%d a%d b%d crop%d id%d fi%d sc%d/%d sl%d %s" % (w, h, frames, fps, bitrate // 1000, qp, iper, cplx, idc, alpha, beta, crop, spsid, fidr, scene, cut, nsl, kind)
     if not run:                                            # --only: just keep the random stream in step
         return desc, "ok"
     fi, fo = os.path.join(tmp, "in.yuv"), os.path.join(tmp, "ref.264")
@@ -184,7 +189,7 @@ def main():
                 continue
             if not res.startswith("ok"):
                 bad += 1
-            print("%4d %-80s %s" % (i, desc, res), flush=True)
+            print("%4d %-92s %s" % (i, desc, res), flush=True)
     print("%d cases, %d failed" % (a.cases if a.only < 0 else 1, bad))
     sys.exit(1 if bad else 0)
 
