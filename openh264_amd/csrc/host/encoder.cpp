@@ -589,8 +589,9 @@ int WelsHipInitializeExt (WelsHipEncoder* e, const WelsHipEncParam* p) {
 }
 
 int WelsHipForceIntraFrame (WelsHipEncoder* e, int bIDR) {
+  // CWelsH264SVCEncoder::ForceIntraFrame (welsEncoderExt.cpp:487-500): bIDR == false is "nothing to do", success
+  if (!bIDR) return WELSHIP_OK;
   if (!e || !e->inited) return WELSHIP_ERR_INIT_PARA;
-  (void)bIDR;
   e->core.force_idr = true;
   return WELSHIP_OK;
 }

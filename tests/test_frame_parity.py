@@ -145,3 +145,36 @@ def test_hip_wave_variants(waves, hip_lib):
     env = dict(os.environ, WELSHIP_P_WAVES=waves, WELSHIP_P_LOOKAHEAD="1" if waves == "8" else "0")
     out = subprocess.check_output([sys.executable, "-c", code], env=env).decode().split()[-1]
     assert out == g["sha1"]
+
+
+def test_session_lifecycle(emu_lib):
+    """Uninitialize + InitializeExt on the same object behaves like a fresh object (no state leaks between sessions);
+    ForceIntraFrame(false) is a successful no-op as in the reference (welsEncoderExt.cpp:487-500)."""
+    def run(enc, w, h, n, qp, force_at=-1, idr=True, **kw):
+        p = enc.GetDefaultParams()
+        p.iPicWidth, p.iPicHeight, p.iDLayerQp, p.fMaxFrameRate, p.iTargetBitrate = w, h, qp, 30.0, 5000000
+        for k, v in kw.items():
+            setattr(p, k, v)
+        assert enc.InitializeExt(p) == 0, enc.last_error()
+        yuv, fsz, out = synth_sequence(w, h, n), w * h * 3 // 2, b""
+        for f in range(n):
+            if f == force_at:
+                assert enc.ForceIntraFrame(idr) == 0
+            rc, _, bs, _ = enc.EncodeFrame(yuv[f * fsz:(f + 1) * fsz], timestamp=f * 33)
+            assert rc == 0
+            out += bs
+        return out
+    e = oh.Encoder(emu_lib)
+    a1 = run(e, 176, 144, 4, 24)
+    e.Uninitialize()
+    a2 = run(e, 320, 192, 3, 30, uiSliceMode=1, uiSliceNum=3)
+    a3 = run(e, 176, 144, 4, 24)                   # re-initialised without Uninitialize
+    a4 = run(e, 176, 144, 4, 24, force_at=2, idr=False)
+    a5 = run(e, 176, 144, 4, 24, force_at=2, idr=True)
+    e.Uninitialize()
+    e.close()
+    f = oh.Encoder(emu_lib)
+    b2 = run(f, 320, 192, 3, 30, uiSliceMode=1, uiSliceNum=3)
+    f.close()
+    assert a1 == a3 == a4 and a2 == b2
+    assert a5 != a1 and a5.count(b"\x00\x00\x00\x01\x65") == 2
