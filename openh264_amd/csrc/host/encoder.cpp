@@ -108,8 +108,10 @@ struct SessionCore {
   bool single_slice_mode = true;      // the reference's uiSliceMode ended up as SM_SINGLE_SLICE (requested or fall-back)
   int compute_slices() {
     WhSeqParams& s = seq;
-    if (prm.uiSliceMode == 2) return compute_raster_slices();
-    int n = prm.uiSliceMode == 0 ? 1 : prm.uiSliceNum;
+    // "only have one MB, set to single_slice" (ParamValidationExt, encoder_ext.cpp:541-544) comes before everything else
+    const bool one_mb = prm.iPicWidth <= 16 && prm.iPicHeight <= 16;
+    if (prm.uiSliceMode == 2 && !one_mb) return compute_raster_slices();
+    int n = (prm.uiSliceMode == 0 || one_mb) ? 1 : prm.uiSliceNum;
     if (n < 1) return -1;
     // SliceArgumentValidationFixedSliceMode (encoder_ext.cpp:178-255): small pictures fall back to one slice,
     // the slice count is capped, and with RC off every slice gets num_mb / n macroblocks (NOT row aligned),
