@@ -81,10 +81,12 @@ def content(kind, w, h, frames, rng):
 KINDS = ["synth", "noise", "flat", "extreme", "fastmotion", "subpel"]
 
 
-def one_case(rng, lib, enc_tool, tmp, max_mbs, run=True):
+def one_case(rng, lib, enc_tool, tmp, max_mbs, run=True, big=False):
     while True:
         w = int(rng.integers(8, 41)) * 2 if rng.random() < 0.5 else int(rng.integers(1, 26)) * 16
         h = int(rng.integers(8, 41)) * 2 if rng.random() < 0.5 else int(rng.integers(1, 20)) * 16
+        if big:                                            # up to 1920x1088 / 4096x2304-class pictures
+            w, h = int(rng.integers(40, 961)) * 2, int(rng.integers(30, 545)) * 2
         if w < 16 or h < 16:
             continue
         mbs = ((w + 15) // 16) * ((h + 15) // 16)
@@ -171,6 +173,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--max-mbs", type=int, default=400)
     ap.add_argument("--hip", action="store_true")
+    ap.add_argument("--big", action="store_true", help="picture sizes up to 1920x1088 (use with --max-mbs 8200)")
     ap.add_argument("--only", type=int, default=-1, help="run just this case index of the seed (same random stream)")
     ap.add_argument("--keep", default=None, help="directory that keeps in.yuv / ref.264 / ours.264 of the last case run")
     a = ap.parse_args()
@@ -184,7 +187,7 @@ def main():
         tmp = a.keep or tmpdir
         os.makedirs(tmp, exist_ok=True)
         for i in range(a.cases if a.only < 0 else a.only + 1):
-            desc, res = one_case(rng, lib, enc_tool, tmp, a.max_mbs, run=(a.only < 0 or i == a.only))
+            desc, res = one_case(rng, lib, enc_tool, tmp, a.max_mbs, run=(a.only < 0 or i == a.only), big=a.big)
             if a.only >= 0 and i != a.only:
                 continue
             if not res.startswith("ok"):
