@@ -37,17 +37,19 @@ def build_hip(force=False, verbose=True):
     return LIB
 
 
-def build_emu(force=False, verbose=False):
-    """g++ -DWH_EMU test build of the same kernel sources (tests only, never shipped/loaded by the product)."""
+def build_emu(force=False, verbose=False, defines=(), tag=""):
+    """g++ -DWH_EMU test build of the same kernel sources (tests only, never shipped/loaded by the product).
+    `defines` + `tag`: a second test build with candidate code paths switched on (e.g. WH_DB_FAST_LINES)."""
+    out = EMU_LIB if not tag else EMU_LIB.replace(".so", "_" + tag + ".so")
     deps = [CSRC, os.path.join(ROOT, "tests", "emu", "emu_backend.cpp")]
-    if not force and not _newer(EMU_LIB, deps):
-        return EMU_LIB
-    cmd = ["g++", "-O2", "-std=c++17", "-DWH_EMU", "-fPIC", "-shared", "-Wno-unused-function", "-Wno-unused-variable",
-           "-o", EMU_LIB, os.path.join(ROOT, "tests", "emu", "emu_backend.cpp")] + HOST_SRCS
+    if not force and not _newer(out, deps):
+        return out
+    cmd = ["g++", "-O2", "-std=c++17", "-DWH_EMU"] + ["-D" + d for d in defines] + ["-fPIC", "-shared", "-Wno-unused-function", "-Wno-unused-variable",
+           "-o", out, os.path.join(ROOT, "tests", "emu", "emu_backend.cpp")] + HOST_SRCS
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd, cwd=ROOT)
-    return EMU_LIB
+    return out
 
 
 def build_oracle(verbose=True):

@@ -76,6 +76,74 @@ WH_FN void wh_db_chroma_line (uint8_t* q, int step, int bs, int alpha, int beta,
   }
 }
 
+#ifdef WH_DB_FAST_LINES
+// ---- candidate for the next round (NOT part of the default build, not measured yet) --------------------------------
+// The eight luma edges of a MB are strictly ordered, so what counts is the instruction count and the latency of one
+// edge.  Compared with wh_db_luma_line above: tc0 comes from one wave-uniform 32-bit load (kWhTc0Packed) instead of a
+// per-lane byte gather from global memory inside the dependent chain; the samples of a vertical-edge line are two
+// aligned LDS words instead of up to fourteen byte accesses; the bS < 4 filter is select-only; the bS 4 arithmetic is
+// skipped for the whole edge unless some line needs it (`any4`, wave-uniform -- only intra MBs have bS 4).
+// Bit-exact with the default path (tests/test_frame_parity.py::test_emu_fast_deblock_candidate).
+WH_FN void wh_db_luma_px (int bs, int alpha, int beta, int tc3, bool any4, int p3, int& p2, int& p1, int& p0, int& q0, int& q1, int& q2, int q3) {
+  const int d = wh_abs (p0 - q0);
+  const bool on = bs != 0 && d < alpha && wh_abs (p1 - p0) < beta && wh_abs (q1 - q0) < beta;
+  const bool ap = wh_abs (p2 - p0) < beta, aq = wh_abs (q2 - q0) < beta;
+  const int bsn = bs < 1 ? 1 : bs > 3 ? 3 : bs;
+  const int tc0 = (tc3 >> ((bsn - 1) * 8)) & 255;
+  const int tc = tc0 + (ap ? 1 : 0) + (aq ? 1 : 0);
+  const int avg = (p0 + q0 + 1) >> 1;
+  int rp2 = p2, rq2 = q2;
+  int rp1 = ap ? p1 + wh_clip3 ((p2 + avg - (p1 * 2)) >> 1, -tc0, tc0) : p1;
+  int rq1 = aq ? q1 + wh_clip3 ((q2 + avg - (q1 * 2)) >> 1, -tc0, tc0) : q1;
+  const int delta = wh_clip3 ((((q0 - p0) * 4) + (p1 - q1) + 4) >> 3, -tc, tc);
+  int rp0 = wh_clip255 (p0 + delta), rq0 = wh_clip255 (q0 - delta);
+  if (any4) {
+    const bool s4 = bs == 4, strong = d < ((alpha >> 2) + 2);
+    const int wp0 = (2 * p1 + p0 + q1 + 2) >> 2, wq0 = (2 * q1 + q0 + p1 + 2) >> 2;
+    const bool sp = strong && ap, sq = strong && aq;
+    const int s_p0 = sp ? (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3 : wp0;
+    const int s_p1 = sp ? (p2 + p1 + p0 + q0 + 2) >> 2 : p1;
+    const int s_p2 = sp ? (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3 : p2;
+    const int s_q0 = sq ? (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3 : wq0;
+    const int s_q1 = sq ? (p0 + q0 + q1 + q2 + 2) >> 2 : q1;
+    const int s_q2 = sq ? (2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3 : q2;
+    rp0 = s4 ? s_p0 : rp0; rp1 = s4 ? s_p1 : rp1; rp2 = s4 ? s_p2 : rp2;
+    rq0 = s4 ? s_q0 : rq0; rq1 = s4 ? s_q1 : rq1; rq2 = s4 ? s_q2 : rq2;
+  }
+  if (on) { p2 = rp2; p1 = rp1; p0 = rp0; q0 = rq0; q1 = rq1; q2 = rq2; }
+}
+// one line of a vertical luma edge: w points at the aligned word holding p3..p0, w[1] holds q0..q3
+WH_FN void wh_db_luma_line_v (uint32_t* w, int bs, int alpha, int beta, int tc3, bool any4) {
+  const uint32_t pw = w[0], qw = w[1];
+  int p3 = (int) (pw & 255), p2 = (int) ((pw >> 8) & 255), p1 = (int) ((pw >> 16) & 255), p0 = (int) (pw >> 24);
+  int q0 = (int) (qw & 255), q1 = (int) ((qw >> 8) & 255), q2 = (int) ((qw >> 16) & 255), q3 = (int) (qw >> 24);
+  wh_db_luma_px (bs, alpha, beta, tc3, any4, p3, p2, p1, p0, q0, q1, q2, q3);
+  w[0] = (uint32_t)p3 | ((uint32_t)p2 << 8) | ((uint32_t)p1 << 16) | ((uint32_t)p0 << 24);
+  w[1] = (uint32_t)q0 | ((uint32_t)q1 << 8) | ((uint32_t)q2 << 16) | ((uint32_t)q3 << 24);
+}
+// one line of a horizontal luma edge: q points at q0, samples are `step` bytes apart (byte accesses, all loads first)
+WH_FN void wh_db_luma_line_h (uint8_t* q, int step, int bs, int alpha, int beta, int tc3, bool any4) {
+  int p2 = q[-3 * step], p1 = q[-2 * step], p0 = q[-step], q0 = q[0], q1 = q[step], q2 = q[2 * step];
+  const int p3 = any4 ? q[-4 * step] : 0, q3 = any4 ? q[3 * step] : 0;
+  const int o2 = p2, o1 = p1, r1 = q1, r2 = q2;
+  wh_db_luma_px (bs, alpha, beta, tc3, any4, p3, p2, p1, p0, q0, q1, q2, q3);
+  q[-step] = (uint8_t)p0; q[0] = (uint8_t)q0;
+  if (p1 != o1) q[-2 * step] = (uint8_t)p1;
+  if (q1 != r1) q[step] = (uint8_t)q1;
+  if (any4) { if (p2 != o2) q[-3 * step] = (uint8_t)p2; if (q2 != r2) q[2 * step] = (uint8_t)q2; }
+}
+WH_FN void wh_db_chroma_line_fast (uint8_t* q, int step, int bs, int alpha, int beta, int tc3) {
+  const int p0 = q[-step], p1 = q[-2 * step], q0 = q[0], q1 = q[step];
+  const bool on = bs != 0 && wh_abs (p0 - q0) < alpha && wh_abs (p1 - p0) < beta && wh_abs (q1 - q0) < beta;
+  const int bsn = bs < 1 ? 1 : bs > 3 ? 3 : bs;
+  const int tc = ((tc3 >> ((bsn - 1) * 8)) & 255) + 1;
+  const int delta = wh_clip3 ((((q0 - p0) * 4) + (p1 - q1) + 4) >> 3, -tc, tc);
+  const int np0 = bs < 4 ? wh_clip255 (p0 + delta) : (2 * p1 + p0 + q1 + 2) >> 2;
+  const int nq0 = bs < 4 ? wh_clip255 (q0 - delta) : (2 * q1 + q0 + p1 + 2) >> 2;
+  if (on) { q[-step] = (uint8_t)np0; q[0] = (uint8_t)nq0; }
+}
+#endif  // WH_DB_FAST_LINES
+
 WH_FN bool wh_mv_far (const int16_t* a, const int16_t* b) {
   return wh_abs (a[0] - b[0]) >= 4 || wh_abs (a[1] - b[1]) >= 4;
 }
@@ -238,6 +306,28 @@ WH_FN bool wh_deblock_mb_body (WhDbLds& S, WhDbStage& G, const WhDbXchg& E, int 
       const int alpha = kWhAlpha[ia], beta = kWhBeta[ib];
       const int iac = wh_clip3 (eqc + P.alpha_offset, 0, 51), ibc = wh_clip3 (eqc + P.beta_offset, 0, 51);
       const int alphac = kWhAlpha[iac], betac = kWhBeta[ibc];
+#ifdef WH_DB_FAST_LINES
+      const uint32_t bsw = * (const uint32_t*)&S.bs[dir][e][0];     // the four segment strengths of this edge
+      if (bsw == 0) continue;                                        // nothing to filter on this edge (wave-uniform)
+      const bool any4 = (bsw & 0x04040404u) != 0;
+      const int tc3 = kWhTc0Packed[ia], tc3c = kWhTc0Packed[iac];
+      WV_LANES_BEGIN (lane)
+      if (lane < 16) {
+        if (alpha | beta) {
+          const int bs = S.bs[dir][e][lane >> 2];
+          if (dir == 0) wh_db_luma_line_v ((uint32_t*)&S.y[(lane + 4) * 24 + e * 4], bs, alpha, beta, tc3, any4);
+          else wh_db_luma_line_h (&WH_DY (S, lane, e * 4), 24, bs, alpha, beta, tc3, any4);
+        }
+      } else if (lane < 32 && (e & 1) == 0) {
+        if (alphac | betac) {
+          const int pl = (lane - 16) >> 3, k = lane & 7;
+          const int bs = S.bs[dir][e][k >> 1];
+          uint8_t* q = dir == 0 ? &WH_DC (S, pl, e * 2, k) : &WH_DC (S, pl, k, e * 2);
+          wh_db_chroma_line_fast (q, dir == 0 ? 1 : 12, bs, alphac, betac, tc3c);
+        }
+      }
+      WV_LANES_END
+#else
       WV_LANES_BEGIN (lane)
       if (lane < 16) {
         if (alpha | beta) {
@@ -254,6 +344,7 @@ WH_FN bool wh_deblock_mb_body (WhDbLds& S, WhDbStage& G, const WhDbXchg& E, int 
         }
       }
       WV_LANES_END
+#endif
     }
   }
 

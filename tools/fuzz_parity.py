@@ -173,6 +173,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--max-mbs", type=int, default=400)
     ap.add_argument("--hip", action="store_true")
+    ap.add_argument("--emu-define", action="append", default=[], help="extra -D for the emulation build (candidate code paths)")
     ap.add_argument("--big", action="store_true", help="picture sizes up to 1920x1088 (use with --max-mbs 8200)")
     ap.add_argument("--only", type=int, default=-1, help="run just this case index of the seed (same random stream)")
     ap.add_argument("--keep", default=None, help="directory that keeps in.yuv / ref.264 / ours.264 of the last case run")
@@ -180,7 +181,7 @@ def main():
     enc_tool = os.path.join(ROOT, "oracle", "_ref", "ref_enc")
     if not os.path.exists(enc_tool):
         sys.exit("oracle/_ref/ref_enc not built (python -c 'import __graft_entry__ as g; g.build()')")
-    lib = B.build_hip() if a.hip else B.build_emu()
+    lib = B.build_hip() if a.hip else B.build_emu(defines=tuple(a.emu_define), tag="_".join(d.lower() for d in a.emu_define))
     rng = np.random.default_rng(a.seed)
     bad = 0
     with tempfile.TemporaryDirectory() as tmpdir:

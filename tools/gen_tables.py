@@ -95,6 +95,7 @@ def main():
     o.append("// deblocking alpha'/beta' (Table 8-16), tC0 for bS 1..3 (Table 8-17)\nWH_TABLE int32_t kWhAlpha[52] = {\n" + fmt(alpha, 26, 3) + "\n};")
     o.append("WH_TABLE int32_t kWhBeta[52] = {\n" + fmt(beta, 26, 2) + "\n};")
     o.append("WH_TABLE uint8_t kWhTc0[52 * 3] = {\n" + fmt([v for t in tc0 for v in t], 24, 2) + "\n};")
+    o.append("// the same, one 32-bit word per indexA: tc0 for bS 1 | bS 2 << 8 | bS 3 << 16 (a wave-uniform scalar load)\nWH_TABLE int32_t kWhTc0Packed[52] = {\n" + fmt([t[0] | (t[1] << 8) | (t[2] << 16) for t in tc0], 13, 8) + "\n};")
     o.append("// me(v) codeNum for coded_block_pattern (Table 9-4), indexed by cbp\nWH_TABLE uint8_t kWhCbpCodeIntra[48] = {\n" + fmt(code_intra, 16, 2) + "\n};")
     o.append("WH_TABLE uint8_t kWhCbpCodeInter[48] = {\n" + fmt(code_inter, 16, 2) + "\n};")
     # VLC tables: pack as (len<<8)|code in uint16
