@@ -126,6 +126,21 @@ int  WelsHipForceIntraFrame (WelsHipEncoder* pEncoder, int bIDR);
 /* Test/diagnostic hook (the reference's -drec / DumpDependencyRec, encoder_ext.cpp:3909-3915):
  * copies the last reconstructed (deblocked) frame, cropped to iPicWidth x iPicHeight, as I420. */
 int  WelsHipGetReconFrame (WelsHipEncoder* pEncoder, uint8_t* pDstI420, size_t uiDstBytes);
+/* ISVCEncoder::SetOption / GetOption (codec_api.h:329-337) for the options that mean something without rate control;
+ * eOptionId takes the ENCODER_OPTION values of codec_app_def.h:106-146.  Implemented: ENCODER_OPTION_DATAFORMAT (0, int:
+ * only videoFormatI420), ENCODER_OPTION_IDR_INTERVAL (1, int; <= -1 means 0), ENCODER_OPTION_FRAME_RATE (4, float; get
+ * and set, no effect on the stream while RC is off), ENCODER_OPTION_COMPLEXITY (int, effective from the next picture),
+ * ENCODER_OPTION_TRACE_LEVEL / TRACE_CALLBACK / TRACE_CALLBACK_CONTEXT (accepted, ignored).  Others: cmUnsupportedData
+ * -- except that the reference's SetOption returns cmInitParaError for ids it does not know. */
+#define WELSHIP_OPTION_DATAFORMAT 0
+#define WELSHIP_OPTION_IDR_INTERVAL 1
+#define WELSHIP_OPTION_FRAME_RATE 4
+#define WELSHIP_OPTION_COMPLEXITY 15
+#define WELSHIP_OPTION_TRACE_LEVEL 21
+#define WELSHIP_OPTION_TRACE_CALLBACK 22
+#define WELSHIP_OPTION_TRACE_CALLBACK_CONTEXT 23
+int  WelsHipSetOption (WelsHipEncoder* pEncoder, int eOptionId, void* pOption);
+int  WelsHipGetOption (WelsHipEncoder* pEncoder, int eOptionId, void* pOption);
 /* Name of the device backend in use ("hip:gfx950 ..."). */
 const char* WelsHipBackendName (WelsHipEncoder* pEncoder);
 const char* WelsHipGetLastError (void);

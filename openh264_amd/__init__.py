@@ -24,6 +24,9 @@ ERR_NO_DEVICE, ERR_VLC_OVERFLOW = 100, 101
 HAS_INTER_PATH = True
 
 
+OPTION_DATAFORMAT, OPTION_IDR_INTERVAL, OPTION_FRAME_RATE, OPTION_COMPLEXITY = 0, 1, 4, 15     # ENCODER_OPTION ids
+
+
 class SEncParamExt(C.Structure):
     """WelsHipEncParam (include/welship.h) -- the honoured subset of SEncParamExt, same field names."""
     _fields_ = [
@@ -117,6 +120,18 @@ class Encoder:
     def Uninitialize(self):
         return self._lib.WelsHipUninitialize(self._h)
 
+    def SetOption(self, option_id, value):
+        """ISVCEncoder::SetOption for the int / float options of include/welship.h (ENCODER_OPTION ids)."""
+        v = C.c_float(value) if option_id == OPTION_FRAME_RATE else C.c_int32(int(value))
+        self._lib.WelsHipSetOption.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        return self._lib.WelsHipSetOption(self._h, option_id, C.byref(v))
+
+    def GetOption(self, option_id):
+        v = C.c_float(0) if option_id == OPTION_FRAME_RATE else C.c_int32(0)
+        self._lib.WelsHipGetOption.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        rc = self._lib.WelsHipGetOption(self._h, option_id, C.byref(v))
+        return rc, v.value
+
     def ForceIntraFrame(self, idr=True):
         return self._lib.WelsHipForceIntraFrame(self._h, 1 if idr else 0)
 
@@ -174,10 +189,11 @@ class Encoder:
             pass
 
 
-def encode_sequence(yuv_bytes, width, height, lib_path=None, stats=None, force_idr_at=-1, **params):
+def encode_sequence(yuv_bytes, width, height, lib_path=None, stats=None, force_idr_at=-1, options_at=(), **params):
     """Convenience: encode a whole I420 sequence; returns (bitstream bytes, last recon frame).
     `stats`: optional dict that receives developer statistics (overflow_reencodes);
-    `force_idr_at`: ForceIntraFrame(true) is called before that frame index."""
+    `force_idr_at`: ForceIntraFrame(true) is called before that frame index;
+    `options_at`: (frame index, option id, value) triples -> SetOption before that frame."""
     enc = Encoder(lib_path)
     p = enc.GetDefaultParams()
     p.iPicWidth, p.iPicHeight = width, height
@@ -196,6 +212,9 @@ def encode_sequence(yuv_bytes, width, height, lib_path=None, stats=None, force_i
     for i in range(len(yuv_bytes) // fsz):
         if i == force_idr_at:
             enc.ForceIntraFrame(True)
+        for f, oid, val in options_at:
+            if f == i and enc.SetOption(oid, val):
+                raise WelsHipError(1, "SetOption(%d)" % oid)
         rc, _, bs, _ = enc.EncodeFrame(yuv_bytes[i * fsz:(i + 1) * fsz], timestamp=i * 33)
         if rc:
             raise WelsHipError(rc, enc.last_error())

@@ -598,6 +598,53 @@ int WelsHipForceIntraFrame (WelsHipEncoder* e, int bIDR) {
   return WELSHIP_OK;
 }
 
+// CWelsH264SVCEncoder::SetOption / GetOption (welsEncoderExt.cpp:690-1200,1203-1310), the options that act without RC
+int WelsHipSetOption (WelsHipEncoder* e, int id, void* opt) {
+  if (!e || !e->inited || !opt) return WELSHIP_ERR_INIT_PARA;
+  SessionCore& c = e->core;
+  switch (id) {
+  case WELSHIP_OPTION_DATAFORMAT:
+    if (* (int32_t*)opt == 0) return WELSHIP_ERR_INIT_PARA;
+    if (* (int32_t*)opt != 23) { set_err ("only videoFormatI420 input"); return WELSHIP_ERR_UNSUPPORTED; }
+    return WELSHIP_OK;
+  case WELSHIP_OPTION_IDR_INTERVAL: {        // :716-731: <= -1 means 0; takes effect at the next frame-type decision
+    int32_t v = * (int32_t*)opt;
+    if (v <= -1) v = 0;
+    c.prm.uiIntraPeriod = (uint32_t)v;
+    return WELSHIP_OK;
+  }
+  case WELSHIP_OPTION_FRAME_RATE: {          // :846-858: clipped to [MIN_FRAME_RATE 1, MAX_FRAME_RATE 60]; nothing reads it while RC is off
+    const float f = * (float*)opt;
+    if (f <= 0) return WELSHIP_ERR_INIT_PARA;
+    c.prm.fMaxFrameRate = f < 1.f ? 1.f : f > 60.f ? 60.f : f;
+    return WELSHIP_OK;
+  }
+  case WELSHIP_OPTION_COMPLEXITY: {          // :1153-1159: stored as is; PreprocessSliceCoding reads it for every picture
+    const int32_t v = * (int32_t*)opt;
+    c.prm.iComplexityMode = v;
+    c.seq.complexity = v;                    // LOW (0) selects the SAD / VAA-gated paths, anything else the SATD paths
+    return WELSHIP_OK;
+  }
+  case WELSHIP_OPTION_TRACE_LEVEL: case WELSHIP_OPTION_TRACE_CALLBACK: case WELSHIP_OPTION_TRACE_CALLBACK_CONTEXT:
+    return WELSHIP_OK;
+  default:
+    set_err ("option not supported by this engine");
+    return WELSHIP_ERR_UNSUPPORTED;
+  }
+}
+
+int WelsHipGetOption (WelsHipEncoder* e, int id, void* opt) {
+  if (!e || !e->inited || !opt) return WELSHIP_ERR_INIT_PARA;
+  const SessionCore& c = e->core;
+  switch (id) {
+  case WELSHIP_OPTION_DATAFORMAT: * (int32_t*)opt = 23; return WELSHIP_OK;
+  case WELSHIP_OPTION_IDR_INTERVAL: * (int32_t*)opt = (int32_t)c.prm.uiIntraPeriod; return WELSHIP_OK;
+  case WELSHIP_OPTION_FRAME_RATE: * (float*)opt = c.prm.fMaxFrameRate; return WELSHIP_OK;
+  case WELSHIP_OPTION_COMPLEXITY: * (int32_t*)opt = c.prm.iComplexityMode; return WELSHIP_OK;
+  default: return WELSHIP_ERR_INIT_PARA;     // the reference's GetOption: unknown id -> cmInitParaError
+  }
+}
+
 const char* WelsHipBackendName (WelsHipEncoder* e) { return (e && e->be) ? e->be->name() : "none"; }
 
 int WelsHipEncodeFrame (WelsHipEncoder* e, const WelsHipSourcePicture* src, WelsHipFrameBSInfo* out) {

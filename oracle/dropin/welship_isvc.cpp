@@ -29,6 +29,8 @@ struct Api {
   int (*EncodeFrame) (WelsHipEncoder*, const WelsHipSourcePicture*, WelsHipFrameBSInfo*) = nullptr;
   int (*ForceIntraFrame) (WelsHipEncoder*, int) = nullptr;
   int (*GetReconFrame) (WelsHipEncoder*, uint8_t*, size_t) = nullptr;
+  int (*SetOption) (WelsHipEncoder*, int, void*) = nullptr;
+  int (*GetOption) (WelsHipEncoder*, int, void*) = nullptr;
   const char* (*GetLastError) (void) = nullptr;
   bool load() {
     if (so) return true;
@@ -39,6 +41,7 @@ struct Api {
     SYM (Create, "WelsHipCreateEncoder") SYM (Destroy, "WelsHipDestroyEncoder") SYM (GetDefaultParams, "WelsHipGetDefaultParams")
     SYM (InitializeExt, "WelsHipInitializeExt") SYM (Uninitialize, "WelsHipUninitialize") SYM (EncodeFrame, "WelsHipEncodeFrame")
     SYM (ForceIntraFrame, "WelsHipForceIntraFrame") SYM (GetLastError, "WelsHipGetLastError") SYM (GetReconFrame, "WelsHipGetReconFrame")
+    SYM (SetOption, "WelsHipSetOption") SYM (GetOption, "WelsHipGetOption")
 #undef SYM
     return true;
   }
@@ -138,9 +141,10 @@ class CWelsHipEncoder : public ISVCEncoder {
       m_dump = d->pFileName;
       return cmResultSuccess;
     }
-    return (id == ENCODER_OPTION_TRACE_LEVEL || id == ENCODER_OPTION_TRACE_CALLBACK || id == ENCODER_OPTION_TRACE_CALLBACK_CONTEXT) ? cmResultSuccess : cmUnsupportedData;
+    if (id == ENCODER_OPTION_TRACE_LEVEL || id == ENCODER_OPTION_TRACE_CALLBACK || id == ENCODER_OPTION_TRACE_CALLBACK_CONTEXT) return cmResultSuccess;
+    return m_p ? g_api.SetOption (m_p, (int)id, pOption) : cmInitExpected;     // the enum values are the C ABI's ids
   }
-  virtual int EXTAPI GetOption (ENCODER_OPTION, void*) { return cmUnsupportedData; }
+  virtual int EXTAPI GetOption (ENCODER_OPTION id, void* pOption) { return m_p ? g_api.GetOption (m_p, (int)id, pOption) : cmInitExpected; }
 
  private:
   WelsHipEncoder* m_p = NULL;

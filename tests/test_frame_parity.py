@@ -187,3 +187,39 @@ def test_emu_fast_deblock_candidate(ref_tools, tmp_path):
     lib = B.build_emu(defines=("WH_DB_FAST_LINES",), tag="wh_db_fast_lines")
     for name in SMALL:
         run_case(name, lib, ref_tools, tmp_path)
+
+
+@pytest.mark.parametrize("case", [
+    ("idr_interval_3_from_frame_4", ["-iper", "0", "-setidr", "4", "3"], [(4, oh.OPTION_IDR_INTERVAL, 3)], {}),
+    ("idr_interval_off_from_frame_2", ["-iper", "2", "-setidr", "2", "-1"], [(2, oh.OPTION_IDR_INTERVAL, -1)], dict(uiIntraPeriod=2)),
+    ("complexity_high_from_frame_5", ["-iper", "0", "-setcplx", "5", "2"], [(5, oh.OPTION_COMPLEXITY, 2)], {}),
+    ("complexity_low_from_frame_3", ["-iper", "0", "-complexity", "1", "-setcplx", "3", "0"], [(3, oh.OPTION_COMPLEXITY, 0)], dict(iComplexityMode=1)),
+], ids=lambda c: c[0])
+def test_set_option_matches_reference(case, emu_lib, ref_tools, tmp_path):
+    """ISVCEncoder::SetOption in mid-stream (IDR interval, complexity) against the reference run live with the same calls."""
+    if not ref_tools:
+        pytest.skip("oracle/_ref not built")
+    _, flags, options, extra = case
+    w, h, n = 176, 144, 12
+    yuv = synth_sequence(w, h, n)
+    fi, fo = str(tmp_path / "in.yuv"), str(tmp_path / "ref.264")
+    open(fi, "wb").write(yuv)
+    subprocess.check_call([ref_tools["enc"], "-i", fi, "-w", str(w), "-h", str(h), "-o", fo, "-rc", "-1", "-qp", "28", "-quiet"] + flags,
+                          stdout=subprocess.DEVNULL)
+    params = dict(iDLayerQp=28, uiIntraPeriod=0, fMaxFrameRate=30.0, iTargetBitrate=5000000)
+    params.update(extra)
+    bs, _ = oh.encode_sequence(yuv, w, h, lib_path=emu_lib, options_at=options, **params)
+    assert bs == open(fo, "rb").read()
+
+
+def test_get_option(emu_lib):
+    enc = oh.Encoder(emu_lib)
+    p = enc.GetDefaultParams()
+    p.iPicWidth, p.iPicHeight, p.uiIntraPeriod, p.iComplexityMode, p.fMaxFrameRate = 64, 64, 12, 1, 25.0
+    assert enc.InitializeExt(p) == 0
+    assert enc.GetOption(oh.OPTION_IDR_INTERVAL) == (0, 12) and enc.GetOption(oh.OPTION_COMPLEXITY) == (0, 1)
+    assert enc.GetOption(oh.OPTION_DATAFORMAT) == (0, 23) and enc.GetOption(oh.OPTION_FRAME_RATE) == (0, 25.0)
+    assert enc.SetOption(oh.OPTION_FRAME_RATE, 100.0) == 0 and enc.GetOption(oh.OPTION_FRAME_RATE) == (0, 60.0)
+    assert enc.SetOption(oh.OPTION_IDR_INTERVAL, -5) == 0 and enc.GetOption(oh.OPTION_IDR_INTERVAL) == (0, 0)
+    assert enc.SetOption(5, 1000) == oh.cmUnsupportedData          # ENCODER_OPTION_BITRATE: rate control is not part of this engine
+    enc.close()
