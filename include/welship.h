@@ -123,6 +123,8 @@ int  WelsHipInitializeExt (WelsHipEncoder* pEncoder, const WelsHipEncParam* pPar
 int  WelsHipUninitialize (WelsHipEncoder* pEncoder);
 int  WelsHipEncodeFrame (WelsHipEncoder* pEncoder, const WelsHipSourcePicture* kpSrcPic, WelsHipFrameBSInfo* pBsInfo);
 int  WelsHipForceIntraFrame (WelsHipEncoder* pEncoder, int bIDR);
+/* ISVCEncoder::EncodeParameterSets (codec_api.h:316): SPS + PPS alone, one non-VCL layer with two NALs */
+int  WelsHipEncodeParameterSets (WelsHipEncoder* pEncoder, WelsHipFrameBSInfo* pBsInfo);
 /* Test/diagnostic hook (the reference's -drec / DumpDependencyRec, encoder_ext.cpp:3909-3915):
  * copies the last reconstructed (deblocked) frame, cropped to iPicWidth x iPicHeight, as I420. */
 int  WelsHipGetReconFrame (WelsHipEncoder* pEncoder, uint8_t* pDstI420, size_t uiDstBytes);

@@ -132,6 +132,16 @@ class Encoder:
         rc = self._lib.WelsHipGetOption(self._h, option_id, C.byref(v))
         return rc, v.value
 
+    def EncodeParameterSets(self):
+        """ISVCEncoder::EncodeParameterSets: returns (rc, bytes of SPS + PPS)."""
+        info = SFrameBSInfo()
+        self._lib.WelsHipEncodeParameterSets.argtypes = [C.c_void_p, C.POINTER(SFrameBSInfo)]
+        rc = self._lib.WelsHipEncodeParameterSets(self._h, C.byref(info))
+        if rc:
+            return rc, b""
+        L = info.sLayerInfo[0]
+        return 0, C.string_at(L.pBsBuf, sum(L.pNalLengthInByte[k] for k in range(L.iNalCount)))
+
     def ForceIntraFrame(self, idr=True):
         return self._lib.WelsHipForceIntraFrame(self._h, 1 if idr else 0)
 
@@ -189,7 +199,7 @@ class Encoder:
             pass
 
 
-def encode_sequence(yuv_bytes, width, height, lib_path=None, stats=None, force_idr_at=-1, options_at=(), **params):
+def encode_sequence(yuv_bytes, width, height, lib_path=None, stats=None, force_idr_at=-1, options_at=(), param_sets_at=-1, **params):
     """Convenience: encode a whole I420 sequence; returns (bitstream bytes, last recon frame).
     `stats`: optional dict that receives developer statistics (overflow_reencodes);
     `force_idr_at`: ForceIntraFrame(true) is called before that frame index;
@@ -212,6 +222,11 @@ def encode_sequence(yuv_bytes, width, height, lib_path=None, stats=None, force_i
     for i in range(len(yuv_bytes) // fsz):
         if i == force_idr_at:
             enc.ForceIntraFrame(True)
+        if i == param_sets_at:
+            rc, ps = enc.EncodeParameterSets()
+            if rc:
+                raise WelsHipError(rc, "EncodeParameterSets")
+            out += ps
         for f, oid, val in options_at:
             if f == i and enc.SetOption(oid, val):
                 raise WelsHipError(1, "SetOption(%d)" % oid)

@@ -462,6 +462,36 @@ struct SessionCore {
     return WELSHIP_OK;
   }
 
+  // WelsEncoderEncodeParameterSets (encoder_ext.cpp:3074-3108): SPS + PPS on their own, through the same id strategy as
+  // the parameter sets of an IDR (WelsWriteParameterSets :2867-2960) -- with INCREASING_ID every call takes the next ids
+  // and the slices that follow refer to them.
+  int encode_parameter_sets (WelsHipFrameBSInfo* out) {
+    if (prm.eSpsPpsIdStrategy == 1) {
+      sps_id_in_bs = sps_counter % 32; pps_id_in_bs = pps_counter % 57;
+      ++sps_counter; ++pps_counter;
+    } else { sps_id_in_bs = 0; pps_id_in_bs = 0; }
+    bs.clear();
+    nal_len.clear();
+    std::vector<uint8_t> rbsp;
+    wh::SpsParams sp;
+    sp.sps_id = sps_id_in_bs; sp.level_idc = level_idc; sp.constraint_set3 = level_1b;
+    sp.width = prm.iPicWidth; sp.height = prm.iPicHeight; sp.mb_w = mb_w; sp.mb_h = mb_h;
+    sp.num_ref_frames = 1; sp.gaps_in_frame_num = false; sp.frame_cropping = prm.bEnableFrameCroppingFlag != 0;
+    wh::write_sps_rbsp (rbsp, sp);
+    nal_len.push_back (wh::append_nal (bs, 3, 7, rbsp));
+    wh::PpsParams pp;
+    pp.pps_id = pps_id_in_bs; pp.sps_id = sps_id_in_bs;
+    rbsp.clear();
+    wh::write_pps_rbsp (rbsp, pp);
+    nal_len.push_back (wh::append_nal (bs, 3, 8, rbsp));
+    memset (out, 0, sizeof (*out));
+    WelsHipLayerBSInfo& L = out->sLayerInfo[0];
+    L.uiLayerType = WELSHIP_NON_VIDEO_CODING_LAYER; L.eFrameType = WelsHipFrameTypeInvalid;
+    L.iNalCount = 2; L.pNalLengthInByte = nal_len.data(); L.pBsBuf = bs.data();
+    out->iLayerNum = 1; out->eFrameType = WelsHipFrameTypeInvalid; out->iFrameSizeInBytes = (int32_t)bs.size();
+    return WELSHIP_OK;
+  }
+
   int copy_recon (uint8_t* dst, size_t bytes) {
     if (!have_recon || !dst) return WELSHIP_ERR_INIT_PARA;
     const int w = prm.iPicWidth, h = prm.iPicHeight;
@@ -596,6 +626,11 @@ int WelsHipForceIntraFrame (WelsHipEncoder* e, int bIDR) {
   if (!e || !e->inited) return WELSHIP_ERR_INIT_PARA;
   e->core.force_idr = true;
   return WELSHIP_OK;
+}
+
+int WelsHipEncodeParameterSets (WelsHipEncoder* e, WelsHipFrameBSInfo* out) {
+  if (!e || !e->inited || !out) return WELSHIP_ERR_INIT_PARA;
+  return e->core.encode_parameter_sets (out);
 }
 
 // CWelsH264SVCEncoder::SetOption / GetOption (welsEncoderExt.cpp:690-1200,1203-1310), the options that act without RC

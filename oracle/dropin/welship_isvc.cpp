@@ -30,6 +30,7 @@ struct Api {
   int (*ForceIntraFrame) (WelsHipEncoder*, int) = nullptr;
   int (*GetReconFrame) (WelsHipEncoder*, uint8_t*, size_t) = nullptr;
   int (*SetOption) (WelsHipEncoder*, int, void*) = nullptr;
+  int (*EncodeParameterSets) (WelsHipEncoder*, WelsHipFrameBSInfo*) = nullptr;
   int (*GetOption) (WelsHipEncoder*, int, void*) = nullptr;
   const char* (*GetLastError) (void) = nullptr;
   bool load() {
@@ -41,7 +42,7 @@ struct Api {
     SYM (Create, "WelsHipCreateEncoder") SYM (Destroy, "WelsHipDestroyEncoder") SYM (GetDefaultParams, "WelsHipGetDefaultParams")
     SYM (InitializeExt, "WelsHipInitializeExt") SYM (Uninitialize, "WelsHipUninitialize") SYM (EncodeFrame, "WelsHipEncodeFrame")
     SYM (ForceIntraFrame, "WelsHipForceIntraFrame") SYM (GetLastError, "WelsHipGetLastError") SYM (GetReconFrame, "WelsHipGetReconFrame")
-    SYM (SetOption, "WelsHipSetOption") SYM (GetOption, "WelsHipGetOption")
+    SYM (SetOption, "WelsHipSetOption") SYM (GetOption, "WelsHipGetOption") SYM (EncodeParameterSets, "WelsHipEncodeParameterSets")
 #undef SYM
     return true;
   }
@@ -132,7 +133,18 @@ class CWelsHipEncoder : public ISVCEncoder {
     ++m_frames;
     return cmResultSuccess;
   }
-  virtual int EXTAPI EncodeParameterSets (SFrameBSInfo*) { return cmUnsupportedData; }
+  virtual int EXTAPI EncodeParameterSets (SFrameBSInfo* o) {
+    if (!o || !m_p) return cmInitParaError;
+    WelsHipFrameBSInfo b;
+    const int rc = g_api.EncodeParameterSets (m_p, &b);
+    if (rc) return rc;
+    memset (o, 0, sizeof (*o));
+    o->iLayerNum = 1; o->eFrameType = videoFrameTypeInvalid; o->iFrameSizeInBytes = b.iFrameSizeInBytes;
+    o->sLayerInfo[0].uiLayerType = NON_VIDEO_CODING_LAYER; o->sLayerInfo[0].eFrameType = videoFrameTypeInvalid;
+    o->sLayerInfo[0].iNalCount = b.sLayerInfo[0].iNalCount; o->sLayerInfo[0].pNalLengthInByte = b.sLayerInfo[0].pNalLengthInByte;
+    o->sLayerInfo[0].pBsBuf = b.sLayerInfo[0].pBsBuf;
+    return cmResultSuccess;
+  }
   virtual int EXTAPI ForceIntraFrame (bool bIdr, int = -1) { return m_p ? g_api.ForceIntraFrame (m_p, bIdr ? 1 : 0) : cmInitParaError; }
   virtual int EXTAPI SetOption (ENCODER_OPTION id, void* pOption) {
     if (id == ENCODER_OPTION_DUMP_FILE && pOption) {

@@ -35,7 +35,7 @@ int main (int argc, char** argv) {
   int slcmd = 0, slcnum = 1, slcmbnum = 0, threads = 1, loadbal = 0, deblock = 0;
   int aq = 0, bgd = 0, scene = 0, ltr = 0, denoise = 0, frameskip = 0, cabac = 0, spsid = 1, usage = 0;
   int alpha = 0, beta = 0, crop = 1, forceidr = -1;
-  int setidr_at = -1, setidr_val = 0, setcplx_at = -1, setcplx_val = 0;
+  int setidr_at = -1, setidr_val = 0, setcplx_at = -1, setcplx_val = 0, paramsets_at = -1;
   for (int i = 1; i < argc; ++i) {
     const char* a = argv[i];
     auto next = [&] () -> const char* { if (i + 1 >= argc) { std::fprintf (stderr, "missing value for %s\n", a); std::exit (2); } return argv[++i]; };
@@ -73,6 +73,7 @@ int main (int argc, char** argv) {
     else if (arg_eq (a, "-forceidr")) forceidr = std::atoi (next());     // ForceIntraFrame(true) before frame N
     else if (arg_eq (a, "-setidr")) { setidr_at = std::atoi (next()); setidr_val = std::atoi (next()); }      // SetOption (ENCODER_OPTION_IDR_INTERVAL) before frame N
     else if (arg_eq (a, "-setcplx")) { setcplx_at = std::atoi (next()); setcplx_val = std::atoi (next()); }   // SetOption (ENCODER_OPTION_COMPLEXITY) before frame N
+    else if (arg_eq (a, "-paramsets")) paramsets_at = std::atoi (next());       // EncodeParameterSets before frame N, output appended
     else if (arg_eq (a, "-quiet")) quiet = 1;
     else { std::fprintf (stderr, "unknown option %s\n", a); return 2; }
   }
@@ -139,6 +140,16 @@ int main (int argc, char** argv) {
     if (n == forceidr) enc->ForceIntraFrame (true);
     if (n == setidr_at) enc->SetOption (ENCODER_OPTION_IDR_INTERVAL, &setidr_val);
     if (n == setcplx_at) enc->SetOption (ENCODER_OPTION_COMPLEXITY, &setcplx_val);
+    if (n == paramsets_at) {
+      SFrameBSInfo ps; std::memset (&ps, 0, sizeof (ps));
+      if (enc->EncodeParameterSets (&ps)) { std::fprintf (stderr, "EncodeParameterSets failed\n"); return 1; }
+      for (int li = 0; li < ps.iLayerNum; ++li) {
+        const SLayerBSInfo& L = ps.sLayerInfo[li];
+        int sz = 0; for (int k = 0; k < L.iNalCount; ++k) sz += L.pNalLengthInByte[k];
+        if (fo) std::fwrite (L.pBsBuf, 1, sz, fo);
+        total += sz;
+      }
+    }
     auto t0 = std::chrono::steady_clock::now();
     ret = enc->EncodeFrame (&pic, &info);
     auto t1 = std::chrono::steady_clock::now();

@@ -223,3 +223,19 @@ def test_get_option(emu_lib):
     assert enc.SetOption(oh.OPTION_IDR_INTERVAL, -5) == 0 and enc.GetOption(oh.OPTION_IDR_INTERVAL) == (0, 0)
     assert enc.SetOption(5, 1000) == oh.cmUnsupportedData          # ENCODER_OPTION_BITRATE: rate control is not part of this engine
     enc.close()
+
+
+@pytest.mark.parametrize("at,iper,spsid", [(0, 0, 1), (3, 0, 1), (3, 2, 1), (5, 0, 0)])
+def test_encode_parameter_sets_matches_reference(at, iper, spsid, emu_lib, ref_tools, tmp_path):
+    """ISVCEncoder::EncodeParameterSets in mid-stream: SPS + PPS through the id strategy, later slices refer to the new ids."""
+    if not ref_tools:
+        pytest.skip("oracle/_ref not built")
+    w, h, n = 176, 144, 8
+    yuv = synth_sequence(w, h, n)
+    fi, fo = str(tmp_path / "in.yuv"), str(tmp_path / "ref.264")
+    open(fi, "wb").write(yuv)
+    subprocess.check_call([ref_tools["enc"], "-i", fi, "-w", str(w), "-h", str(h), "-o", fo, "-rc", "-1", "-qp", "28", "-quiet",
+                           "-iper", str(iper), "-spsid", str(spsid), "-paramsets", str(at)], stdout=subprocess.DEVNULL)
+    bs, _ = oh.encode_sequence(yuv, w, h, lib_path=emu_lib, param_sets_at=at, iDLayerQp=28, uiIntraPeriod=iper, fMaxFrameRate=30.0,
+                               iTargetBitrate=5000000, eSpsPpsIdStrategy=spsid)
+    assert bs == open(fo, "rb").read()
