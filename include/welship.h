@@ -10,20 +10,26 @@
  *      WelsHipGetDefaultParams       <->  ISVCEncoder::GetDefaultParams                      (:293)
  *      WelsHipEncodeFrame            <->  ISVCEncoder::EncodeFrame (SSourcePicture*, SFrameBSInfo*) (:307)
  *      WelsHipForceIntraFrame        <->  ISVCEncoder::ForceIntraFrame                       (:323)
+ *      WelsHipEncodeParameterSets    <->  ISVCEncoder::EncodeParameterSets                   (:316)
+ *      WelsHipSetOption / GetOption  <->  ISVCEncoder::SetOption / GetOption                 (:329,:337)
  *      WelsHipUninitialize           <->  ISVCEncoder::Uninitialize                          (:298)
  *      Same call order, same ownership rules (input planes are caller-owned for the duration of the
  *      call; output buffers are encoder-owned and valid until the next call on the same object),
- *      return 0 = cmResultSuccess, 1 = cmInitParaError, 2 = cmUnknownReason, 4 = cmUnsupportedData
- *      (codec_def.h:80-87).
+ *      return 0 = cmResultSuccess, 1 = cmInitParaError, 2 = cmUnknownReason, 3 = cmMallocMemeError,
+ *      4 = cmUnsupportedData (codec_def.h:80-87).  oracle/dropin/welship_isvc.cpp is the ISVCEncoder
+ *      class over these functions; the reference's console front-end runs on it unmodified.
  *
- *  (2) FRAME-LEVEL HOOKS on device-resident pictures -- what the patched reference would reach
- *      through its dispatch table instead of the per-MB loops:
- *      WelsHipSliceMdIntra / WelsHipSliceMdInter  <->  WelsISliceMdEnc / WelsMdInterMbLoop
+ *  (2) FRAME-LEVEL PHASES on device-resident pictures, batched over N sessions (WelsHipGroup*) -- what
+ *      the patched reference reaches through its dispatch table instead of its per-MB loops:
+ *      UploadSource -> Begin (frame type, incl. the scene-change pass) -> RunDevice -> Finish, where
+ *      RunDevice is, per picture batch,
+ *        mode decision + reconstruction   <->  WelsISliceMdEnc / WelsMdInterMbLoop
  *                      (codec/encoder/core/src/svc_encode_slice.cpp:534-599, :1807-1899)
- *      WelsHipDeblockingFilterFrame  <->  pfDeblocking.pfDeblockingFilterSlice / DeblockingFilterFrameAvcbase
+ *        in-loop deblocking               <->  pfDeblocking.pfDeblockingFilterSlice / DeblockingFilterFrameAvcbase
  *                      (codec/encoder/core/inc/wels_func_ptr_def.h:86-101, deblocking.cpp:656-691)
- *      WelsHipExpandPicture          <->  pfExpandLumaPicture / pfExpandChromaPicture
+ *        border expansion                 <->  pfExpandLumaPicture / pfExpandChromaPicture
  *                      (wels_func_ptr_def.h, codec/common/src/expand_pic.cpp:271-350)
+ *      and Finish is the host's pfWelsSpatialWriteMbSyn loop over the downloaded MB records.
  *
  *  (3) LEAF PRIMITIVES, batched over arrays of blocks -- same per-block semantics as the entries of
  *      SWelsFuncPtrList (codec/encoder/core/inc/wels_func_ptr_def.h:58-296) and SMcFunc
