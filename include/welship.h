@@ -70,7 +70,7 @@ typedef struct WelsHipEncParam {
   int32_t iSpatialLayerNum;         /* 1                                                            */
   int32_t iComplexityMode;          /* 0 LOW (SAD / fast I4x4), 1 MEDIUM, 2 HIGH (SATD / full I4x4)  */
   uint32_t uiIntraPeriod;           /* 0 = first frame only, N = IDR every N frames                  */
-  int32_t eSpsPpsIdStrategy;        /* 0 CONSTANT_ID, 1 INCREASING_ID                                */
+  int32_t eSpsPpsIdStrategy;        /* 0 CONSTANT_ID, 1 INCREASING_ID, 2 SPS_LISTING, 3 SPS_LISTING_AND_PPS_INCREASING */
   int32_t iEntropyCodingModeFlag;   /* 0 = CAVLC (CABAC is host work that is not implemented yet)    */
   int32_t iLoopFilterDisableIdc;    /* 0, 1, 2                                                       */
   int32_t iLoopFilterAlphaC0Offset, iLoopFilterBetaOffset;

@@ -101,7 +101,10 @@ struct SessionCore {
     if (p->iLoopFilterAlphaC0Offset < -6 || p->iLoopFilterAlphaC0Offset > 6 || p->iLoopFilterBetaOffset < -6 || p->iLoopFilterBetaOffset > 6) {
       set_err ("deblocking alpha/beta offsets must be -6..6"); return WELSHIP_ERR_INIT_PARA;     // ParamValidation, encoder_ext.cpp:316-323
     }
-    if (p->eSpsPpsIdStrategy != 0 && p->eSpsPpsIdStrategy != 1) { set_err ("SpsPpsIdStrategy must be 0 or 1"); return WELSHIP_ERR_UNSUPPORTED; }
+    // CONSTANT_ID 0, INCREASING_ID 1; SPS_LISTING 2 and SPS_LISTING_AND_PPS_INCREASING 3 keep finding the session's one SPS /
+    // PPS in their lists while the parameters never change (they cannot here), i.e. they write what CONSTANT_ID writes
+    // (checked against the reference over 70 IDRs, forced IDRs and EncodeParameterSets); SPS_PPS_LISTING 6 is not implemented
+    if (p->eSpsPpsIdStrategy < 0 || p->eSpsPpsIdStrategy > 3) { set_err ("SpsPpsIdStrategy must be 0..3"); return WELSHIP_ERR_UNSUPPORTED; }
     return WELSHIP_OK;
   }
 
@@ -353,7 +356,10 @@ struct SessionCore {
     nal_len.clear();
     std::vector<long> nal_rbsp_len;
     n_param_nals = 0;
-    const long bs_capacity = 128 + 32 + 2 * 16 + (((3L * mb_w * 16 * mb_h * 16) >> 1) + 800 + 3) / 4 * 4;   // iCountBsLen, see below
+    // iCountBsLen (see below): SEI 128 + SPS slots x 32 + PPS slots x 16 + the picture part; the id strategies that keep
+    // lists reserve 32 SPS slots and one PPS slot (paraset_strategy.cpp:404-413), the others 1 and 2 (:203-211)
+    const long paraset_bytes = (prm.eSpsPpsIdStrategy >= 2) ? 32 * 32 + 1 * 16 : 1 * 32 + 2 * 16;
+    const long bs_capacity = 128 + paraset_bytes + (((3L * mb_w * 16 * mb_h * 16) >> 1) + 800 + 3) / 4 * 4;
     // WelsEncodeNal (nal_encap.cpp:120-131) refuses a NAL unless 1.5x its size still fits into what is left of the frame's
     // output buffer (same iCountBsLen bytes); the reference then fails the frame with cmMallocMemeError.
     auto nal_fits = [&] (const std::vector<uint8_t>& payload) {

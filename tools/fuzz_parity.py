@@ -114,6 +114,8 @@ def one_case(rng, lib, enc_tool, tmp, max_mbs, run=True, big=False):
     alpha, beta = (int(x) for x in rng.choice([0, 0, 0, -6, -3, 2, 6], 2))
     crop = int(rng.random() < 0.85)
     spsid = int(rng.random() < 0.7)
+    if spsid == 0 and (w + h) % 3 == 0:                    # SPS_LISTING / SPS_LISTING_AND_PPS_INCREASING behave like CONSTANT_ID here
+        spsid = 2 + (w // 2) % 2
     fidr = int(rng.integers(1, frames)) if rng.random() < 0.2 else -1
     yuv = content(kind, w, h, frames, rng)
     if cut > 0:                                            # abrupt change of content at frame `cut`
