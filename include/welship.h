@@ -84,7 +84,11 @@ typedef struct WelsHipEncParam {
   int32_t bEnableAdaptiveQuant, bEnableBackgroundDetection, bEnableSceneChangeDetect,
           bEnableLongTermReference, bEnableDenoise, bEnableFrameSkip;
   int32_t iDevice;                  /* HIP device ordinal                                            */
-  int32_t reserved[7];
+  int32_t iMultipleThreadIdc;       /* as in SEncParamExt (0 auto, 1 off, >1 threads); 0 is read as 1 -- see below.  This engine
+                                       has no host slice threads; the field only reproduces what the reference does to the
+                                       STREAM when it runs slice threads: deblocking across slice edges is switched off
+                                       (idc 0 -> 2) because slices are filtered concurrently (encoder_ext.cpp:2051-2055)   */
+  int32_t reserved[6];
   uint32_t uiSliceMbNum[35];        /* SM_RASTER_SLICE: macroblocks per slice (sSliceArgument.uiSliceMbNum, MAX_SLICES_NUM
                                        entries); uiSliceMbNum[0] == 0 = one slice per macroblock row                  */
 } WelsHipEncParam;

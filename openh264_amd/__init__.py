@@ -38,7 +38,7 @@ class SEncParamExt(C.Structure):
         ("bEnableFrameCroppingFlag", C.c_int32), ("iDLayerQp", C.c_int32), ("uiSliceMode", C.c_int32), ("uiSliceNum", C.c_int32),
         ("bEnableAdaptiveQuant", C.c_int32), ("bEnableBackgroundDetection", C.c_int32), ("bEnableSceneChangeDetect", C.c_int32),
         ("bEnableLongTermReference", C.c_int32), ("bEnableDenoise", C.c_int32), ("bEnableFrameSkip", C.c_int32),
-        ("iDevice", C.c_int32), ("reserved", C.c_int32 * 7), ("uiSliceMbNum", C.c_uint32 * 35),
+        ("iDevice", C.c_int32), ("iMultipleThreadIdc", C.c_int32), ("reserved", C.c_int32 * 6), ("uiSliceMbNum", C.c_uint32 * 35),
     ]
 
 

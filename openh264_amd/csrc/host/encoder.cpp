@@ -109,6 +109,7 @@ struct SessionCore {
   }
 
   bool single_slice_mode = true;      // the reference's uiSliceMode ended up as SM_SINGLE_SLICE (requested or fall-back)
+  int hdr_deblock_idc = 0;            // disable_deblocking_filter_idc written to the slice headers (seq.deblock_idc drives the device)
   int compute_slices() {
     WhSeqParams& s = seq;
     // "only have one MB, set to single_slice" (ParamValidationExt, encoder_ext.cpp:541-544) comes before everything else
@@ -181,7 +182,22 @@ struct SessionCore {
     if (compute_slices()) { set_err ("invalid slice number"); return WELSHIP_ERR_INIT_PARA; }
     // InitDqLayers (encoder_ext.cpp:1109-1117): with a single slice (requested, or after the fall-back above)
     // "filter all but slice edges" is signalled and run as idc 0
+    // slice threads in the reference: iMultipleThreadIdc = min (threads, slice count); with more than one, idc 0 becomes 2
+    // (WelsEncoderApplyLTR ... InitSliceSettings, encoder_ext.cpp:2051-2055).  "auto" (0) depends on the machine the
+    // reference runs on and is read as 1 here.
+    {
+      const int threads = p->iMultipleThreadIdc <= 0 ? 1 : p->iMultipleThreadIdc;
+      const int max_slices = single_slice_mode ? 1 : s.num_slices;
+      if (std::min (threads, max_slices) != 1 && s.deblock_idc == 0) s.deblock_idc = 2;
+    }
     if (single_slice_mode && s.deblock_idc == 2) s.deblock_idc = 0;
+    hdr_deblock_idc = s.deblock_idc;
+    // A reference quirk reproduced for byte parity: asked for slice threads (iMultipleThreadIdc != 1) it moves the
+    // deblocking of idc 1/2 pictures into its slice tasks (bDeblockingParallelFlag, encoder_ext.cpp:459-464,1107-1121,
+    // 2773-2783,3870-3879) -- but when the slice count then limits it to one thread after all (a raster-mode picture with
+    // a single slice: one macroblock row in row-slice mode) no slice task exists and the picture is never filtered,
+    // although its slice header still says idc 2.
+    if (p->iMultipleThreadIdc != 1 && !single_slice_mode && s.num_slices == 1 && s.deblock_idc == 2) s.deblock_idc = 1;
     ysz = (size_t)s.src_stride_y * mb_h * 16; csz = (size_t)s.src_stride_c * mb_h * 8; src_bytes = ysz + 2 * csz;
     h_src.assign (src_bytes, 0);
     memset (h_src.data() + ysz, 0x80, 2 * csz);     // CWelsPreProcess::Padding: luma 0, chroma 0x80
@@ -416,7 +432,7 @@ struct SessionCore {
       sh.idr_pic_id = idr_pic_id;
       sh.nal_ref_idc = 3;
       sh.slice_qp = qp;
-      sh.disable_deblocking_idc = s.deblock_idc;
+      sh.disable_deblocking_idc = hdr_deblock_idc;
       sh.alpha_offset = s.alpha_offset; sh.beta_offset = s.beta_offset;
       sh.num_ref_idx_override = !idr; sh.num_ref_idx_active = 1;
       wh::write_slice_header (bw, sh);
@@ -607,6 +623,7 @@ int WelsHipGetDefaultParams (WelsHipEncoder* e, WelsHipEncParam* p) {
   p->uiIntraPeriod = 0; p->eSpsPpsIdStrategy = 1; p->iEntropyCodingModeFlag = 0;
   p->iLoopFilterDisableIdc = 0; p->bEnableFrameCroppingFlag = 1; p->iDLayerQp = 26;   // SVC_QUALITY_BASE_QP
   p->uiSliceMode = 0; p->uiSliceNum = 1;
+  p->iMultipleThreadIdc = 1;
   return WELSHIP_OK;
 }
 

@@ -82,6 +82,7 @@ class CWelsHipEncoder : public ISVCEncoder {
     q.bEnableAdaptiveQuant = p->bEnableAdaptiveQuant; q.bEnableBackgroundDetection = p->bEnableBackgroundDetection;
     q.bEnableSceneChangeDetect = p->bEnableSceneChangeDetect; q.bEnableLongTermReference = p->bEnableLongTermReference;
     q.bEnableDenoise = p->bEnableDenoise; q.bEnableFrameSkip = p->bEnableFrameSkip;
+    q.iMultipleThreadIdc = p->iMultipleThreadIdc;
     const int rc = g_api.InitializeExt (m_p, &q);
     if (rc) fprintf (stderr, "welship_isvc: InitializeExt: %s\n", g_api.GetLastError());
     m_w = p->iPicWidth; m_h = p->iPicHeight; m_frames = 0;

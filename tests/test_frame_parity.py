@@ -239,3 +239,25 @@ def test_encode_parameter_sets_matches_reference(at, iper, spsid, emu_lib, ref_t
     bs, _ = oh.encode_sequence(yuv, w, h, lib_path=emu_lib, param_sets_at=at, iDLayerQp=28, uiIntraPeriod=iper, fMaxFrameRate=30.0,
                                iTargetBitrate=5000000, eSpsPpsIdStrategy=spsid)
     assert bs == open(fo, "rb").read()
+
+
+@pytest.mark.parametrize("threads,flags,extra", [
+    (4, ["-slcmd", "1", "-slcnum", "4"], dict(uiSliceMode=1, uiSliceNum=4)),
+    (2, ["-slcmd", "1", "-slcnum", "3", "-deblock", "1"], dict(uiSliceMode=1, uiSliceNum=3, iLoopFilterDisableIdc=1)),
+    (3, ["-slcmd", "2", "-slcmbnum", "50"], dict(uiSliceMode=2, uiSliceMbNum=[50] * 35)),
+    (4, [], {}),
+])
+def test_matches_the_multithreaded_reference(threads, flags, extra, emu_lib, ref_tools, tmp_path):
+    """iMultipleThreadIdc: this engine has no slice threads, but reproduces what the reference's slice threads do to the
+    stream (deblocking across slice edges off) -- compared with the reference really running its slice threads."""
+    if not ref_tools:
+        pytest.skip("oracle/_ref not built")
+    w, h, n = 320, 192, 4
+    yuv = synth_sequence(w, h, n)
+    fi, fo = str(tmp_path / "in.yuv"), str(tmp_path / "ref.264")
+    open(fi, "wb").write(yuv)
+    subprocess.check_call([ref_tools["enc"], "-i", fi, "-w", str(w), "-h", str(h), "-o", fo, "-rc", "-1", "-qp", "28", "-quiet", "-iper", "0",
+                           "-threads", str(threads), "-loadbalancing", "0"] + flags, stdout=subprocess.DEVNULL)
+    bs, _ = oh.encode_sequence(yuv, w, h, lib_path=emu_lib, iDLayerQp=28, uiIntraPeriod=0, fMaxFrameRate=30.0, iTargetBitrate=5000000,
+                               iMultipleThreadIdc=threads, **extra)
+    assert bs == open(fo, "rb").read()

@@ -117,6 +117,12 @@ def one_case(rng, lib, enc_tool, tmp, max_mbs, run=True, big=False):
     if spsid == 0 and (w + h) % 3 == 0:                    # SPS_LISTING / SPS_LISTING_AND_PPS_INCREASING behave like CONSTANT_ID here
         spsid = 2 + (w // 2) % 2
     fidr = int(rng.integers(1, frames)) if rng.random() < 0.2 else -1
+    # slice threads of the reference (stream effect: idc 0 -> 2); side stream again, see above
+    threads = int(rng2.choice([1, 1, 1, 2, 4]))
+    # (the threaded reference writes every slice into a buffer of its own: near the raw picture size its overflow
+    #  behaviour differs from the single-threaded one that is modelled here, so those cases stay single-threaded)
+    if threads > 1 and qp < (32 if (kind in ("noise", "extreme", "fastmotion") or cut > 0) else 16):
+        threads = 1
     yuv = content(kind, w, h, frames, rng)
     if cut > 0:                                            # abrupt change of content at frame `cut`
         other = content(str(rng.choice(KINDS)), w, h, frames, rng)
@@ -125,10 +131,10 @@ def one_case(rng, lib, enc_tool, tmp, max_mbs, run=True, big=False):
     params = dict(fMaxFrameRate=fps, iTargetBitrate=bitrate, iDLayerQp=qp, uiIntraPeriod=iper, iComplexityMode=cplx,
                   iLoopFilterDisableIdc=idc, iLoopFilterAlphaC0Offset=alpha, iLoopFilterBetaOffset=beta,
                   bEnableFrameCroppingFlag=crop, eSpsPpsIdStrategy=spsid, bEnableSceneChangeDetect=scene,
-                  bEnableAdaptiveQuant=aq, bEnableFrameSkip=fskip)
+                  bEnableAdaptiveQuant=aq, bEnableFrameSkip=fskip, iMultipleThreadIdc=threads)
     flags = ["-rc", "-1", "-qp", str(qp), "-fps", str(fps), "-bitrate", str(bitrate), "-iper", str(iper), "-complexity", str(cplx), "-deblock", str(idc),
              "-alpha", str(alpha), "-beta", str(beta), "-crop", str(crop), "-spsid", str(spsid), "-forceidr", str(fidr),
-             "-scene", str(scene), "-aq", str(aq), "-frameskip", str(fskip), "-quiet"]
+             "-scene", str(scene), "-aq", str(aq), "-frameskip", str(fskip), "-threads", str(threads), "-loadbalancing", "0", "-quiet"]
     raster = -1
     if rng.random() < 0.2:                                 # SM_RASTER_SLICE: N macroblocks per slice, 0 = one slice per row
         raster = int(rng.choice([0, 0, int(rng.integers(1, mbs + 8)), int(rng.integers(max(1, mbs // 36), max(2, mbs // 2) + 1))]))
@@ -142,7 +148,7 @@ def one_case(rng, lib, enc_tool, tmp, max_mbs, run=True, big=False):
     elif nsl > 1:
         params.update(uiSliceMode=1, uiSliceNum=nsl)
         flags += ["-slcmd", "1", "-slcnum", str(nsl)]
-    desc = "%dx%d f%d@%g/%dk qp%d iper%d c%d idc%d a%d b%d crop%d id%d fi%d sc%d/%d sl%d %s" % (w, h, frames, fps, bitrate // 1000, qp, iper, cplx, idc, alpha, beta, crop, spsid, fidr, scene, cut, nsl, kind)
+    desc = "%dx%d f%d@%g/%dk t%d qp%d iper%d c%d idc%d a%d b%d crop%d id%d fi%d sc%d/%d sl%d %s" % (w, h, frames, fps, bitrate // 1000, threads, qp, iper, cplx, idc, alpha, beta, crop, spsid, fidr, scene, cut, nsl, kind)
     if not run:                                            # --only: just keep the random stream in step
         return desc, "ok"
     fi, fo = os.path.join(tmp, "in.yuv"), os.path.join(tmp, "ref.264")
