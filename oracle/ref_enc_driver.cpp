@@ -36,6 +36,7 @@ int main (int argc, char** argv) {
   int aq = 0, bgd = 0, scene = 0, ltr = 0, denoise = 0, frameskip = 0, cabac = 0, spsid = 1, usage = 0;
   int alpha = 0, beta = 0, crop = 1, forceidr = -1;
   int setidr_at = -1, setidr_val = 0, setcplx_at = -1, setcplx_val = 0, paramsets_at = -1;
+  int low_w = 0, low_h = 0;            // -simulcast WxH: an extra, lower spatial layer, simulcast AVC (the input is the higher one)
   for (int i = 1; i < argc; ++i) {
     const char* a = argv[i];
     auto next = [&] () -> const char* { if (i + 1 >= argc) { std::fprintf (stderr, "missing value for %s\n", a); std::exit (2); } return argv[++i]; };
@@ -73,6 +74,7 @@ int main (int argc, char** argv) {
     else if (arg_eq (a, "-forceidr")) forceidr = std::atoi (next());     // ForceIntraFrame(true) before frame N
     else if (arg_eq (a, "-setidr")) { setidr_at = std::atoi (next()); setidr_val = std::atoi (next()); }      // SetOption (ENCODER_OPTION_IDR_INTERVAL) before frame N
     else if (arg_eq (a, "-setcplx")) { setcplx_at = std::atoi (next()); setcplx_val = std::atoi (next()); }   // SetOption (ENCODER_OPTION_COMPLEXITY) before frame N
+    else if (arg_eq (a, "-simulcast")) { low_w = std::atoi (next()); low_h = std::atoi (next()); }
     else if (arg_eq (a, "-paramsets")) paramsets_at = std::atoi (next());       // EncodeParameterSets before frame N, output appended
     else if (arg_eq (a, "-quiet")) quiet = 1;
     else { std::fprintf (stderr, "unknown option %s\n", a); return 2; }
@@ -119,6 +121,12 @@ int main (int argc, char** argv) {
     l.sSliceArgument.uiSliceMode = (SliceModeEnum)slcmd;
     l.sSliceArgument.uiSliceNum = (unsigned)slcnum;
     if (slcmbnum > 0) for (int k = 0; k < MAX_SLICES_NUM_TMP; ++k) l.sSliceArgument.uiSliceMbNum[k] = (unsigned)slcmbnum;
+    if (low_w > 0) {                   // layer 0 = the lower resolution, layer 1 = the input resolution
+      p.iSpatialLayerNum = 2; p.bSimulcastAVC = true;
+      p.sSpatialLayers[1] = l;
+      p.sSpatialLayers[0] = l;
+      p.sSpatialLayers[0].iVideoWidth = low_w; p.sSpatialLayers[0].iVideoHeight = low_h;
+    }
     ret = enc->InitializeExt (&p);
   }
   if (ret) { std::fprintf (stderr, "Initialize failed: %d\n", ret); return 1; }
@@ -161,6 +169,7 @@ int main (int argc, char** argv) {
         int sz = 0; for (int k = 0; k < L.iNalCount; ++k) sz += L.pNalLengthInByte[k];
         if (fo) std::fwrite (L.pBsBuf, 1, sz, fo);
         total += sz;
+        if (low_w > 0 && !quiet) std::fprintf (stderr, "frame %d layer %d: type %d spatial %d nals %d bytes %d\n", n, li, (int)L.uiLayerType, (int)L.uiSpatialId, L.iNalCount, sz);
       }
     }
     ++n;
