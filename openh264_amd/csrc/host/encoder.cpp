@@ -472,6 +472,7 @@ struct SessionCore {
       }
       WelsHipLayerBSInfo& V = out->sLayerInfo[li++];
       V.uiLayerType = WELSHIP_VIDEO_CODING_LAYER; V.eFrameType = idr ? WelsHipFrameTypeIDR : WelsHipFrameTypeP;
+      V.iSubSeqId = idr ? 0 : 3;                  // GetSubSequenceId (encoder_ext.cpp:3110-3124): IDR 0, P of temporal layer 0 -> 3
       V.iNalCount = s.num_slices; V.pNalLengthInByte = nal_len.data() + n_param_nals; V.pBsBuf = bs.data() + vcl_start;
       out->iLayerNum = li;
       out->eFrameType = idr ? WelsHipFrameTypeIDR : WelsHipFrameTypeP;

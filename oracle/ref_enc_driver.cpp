@@ -36,6 +36,7 @@ int main (int argc, char** argv) {
   int aq = 0, bgd = 0, scene = 0, ltr = 0, denoise = 0, frameskip = 0, cabac = 0, spsid = 1, usage = 0;
   int alpha = 0, beta = 0, crop = 1, forceidr = -1;
   int setidr_at = -1, setidr_val = 0, setcplx_at = -1, setcplx_val = 0, paramsets_at = -1;
+  std::string infofile;                // -dumpinfo FILE: the SFrameBSInfo metadata of every frame, one line per layer
   int low_w = 0, low_h = 0;            // -simulcast WxH: an extra, lower spatial layer, simulcast AVC (the input is the higher one)
   for (int i = 1; i < argc; ++i) {
     const char* a = argv[i];
@@ -74,6 +75,7 @@ int main (int argc, char** argv) {
     else if (arg_eq (a, "-forceidr")) forceidr = std::atoi (next());     // ForceIntraFrame(true) before frame N
     else if (arg_eq (a, "-setidr")) { setidr_at = std::atoi (next()); setidr_val = std::atoi (next()); }      // SetOption (ENCODER_OPTION_IDR_INTERVAL) before frame N
     else if (arg_eq (a, "-setcplx")) { setcplx_at = std::atoi (next()); setcplx_val = std::atoi (next()); }   // SetOption (ENCODER_OPTION_COMPLEXITY) before frame N
+    else if (arg_eq (a, "-dumpinfo")) infofile = next();
     else if (arg_eq (a, "-simulcast")) { low_w = std::atoi (next()); low_h = std::atoi (next()); }
     else if (arg_eq (a, "-paramsets")) paramsets_at = std::atoi (next());       // EncodeParameterSets before frame N, output appended
     else if (arg_eq (a, "-quiet")) quiet = 1;
@@ -163,6 +165,17 @@ int main (int argc, char** argv) {
     auto t1 = std::chrono::steady_clock::now();
     secs += std::chrono::duration<double> (t1 - t0).count();
     if (ret) { std::fprintf (stderr, "EncodeFrame failed: %d\n", ret); return 1; }
+    if (!infofile.empty()) {
+      FILE* fm = std::fopen (infofile.c_str(), n == 0 ? "w" : "a");
+      std::fprintf (fm, "frame %d type %d layers %d size %d ts %lld\n", n, (int)info.eFrameType, info.iLayerNum, info.iFrameSizeInBytes, (long long)info.uiTimeStamp);
+      for (int li = 0; li < info.iLayerNum; ++li) {
+        const SLayerBSInfo& L = info.sLayerInfo[li];
+        std::fprintf (fm, "  layer %d ltype %d ftype %d tid %d sid %d qid %d subseq %d nals", li, (int)L.uiLayerType, (int)L.eFrameType, (int)L.uiTemporalId, (int)L.uiSpatialId, (int)L.uiQualityId, L.iSubSeqId);
+        for (int k = 0; k < L.iNalCount; ++k) std::fprintf (fm, " %d", L.pNalLengthInByte[k]);
+        std::fprintf (fm, "\n");
+      }
+      std::fclose (fm);
+    }
     if (info.eFrameType != videoFrameTypeSkip) {
       for (int li = 0; li < info.iLayerNum; ++li) {
         const SLayerBSInfo& L = info.sLayerInfo[li];

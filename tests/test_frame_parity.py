@@ -261,3 +261,39 @@ def test_matches_the_multithreaded_reference(threads, flags, extra, emu_lib, ref
     bs, _ = oh.encode_sequence(yuv, w, h, lib_path=emu_lib, iDLayerQp=28, uiIntraPeriod=0, fMaxFrameRate=30.0, iTargetBitrate=5000000,
                                iMultipleThreadIdc=threads, **extra)
     assert bs == open(fo, "rb").read()
+
+
+def test_frame_info_metadata_matches_reference(emu_lib, ref_tools, tmp_path):
+    """SFrameBSInfo as an application sees it (frame and layer types, NAL counts and lengths, ids, sub-sequence id, size,
+    time stamp) against the reference's, frame by frame (ref_enc -dumpinfo)."""
+    import ctypes as C
+    if not ref_tools:
+        pytest.skip("oracle/_ref not built")
+    w, h, n = 176, 144, 7
+    yuv = synth_sequence(w, h, n)
+    fi, fm = str(tmp_path / "in.yuv"), str(tmp_path / "info.txt")
+    open(fi, "wb").write(yuv)
+    subprocess.check_call([ref_tools["enc"], "-i", fi, "-w", str(w), "-h", str(h), "-o", str(tmp_path / "r.264"), "-rc", "-1", "-qp", "28",
+                           "-iper", "3", "-slcmd", "1", "-slcnum", "2", "-dumpinfo", fm, "-quiet"], stdout=subprocess.DEVNULL)
+    enc = oh.Encoder(emu_lib)
+    p = enc.GetDefaultParams()
+    p.iPicWidth, p.iPicHeight, p.iDLayerQp, p.uiIntraPeriod, p.fMaxFrameRate, p.iTargetBitrate, p.uiSliceMode, p.uiSliceNum = w, h, 28, 3, 30.0, 5000000, 1, 2
+    assert enc.InitializeExt(p) == 0
+    fsz, out = w * h * 3 // 2, ""
+    for f in range(n):
+        buf = (C.c_uint8 * fsz).from_buffer_copy(yuv[f * fsz:(f + 1) * fsz])
+        base = C.addressof(buf)
+        pic = oh.SSourcePicture()
+        pic.iColorFormat = 23
+        pic.iStride[0], pic.iStride[1], pic.iStride[2] = w, w // 2, w // 2
+        pic.pData[0], pic.pData[1], pic.pData[2] = base, base + w * h, base + w * h + (w // 2) * (h // 2)
+        pic.iPicWidth, pic.iPicHeight, pic.uiTimeStamp = w, h, int(f * (1000.0 / 30) + 0.5)
+        info = oh.SFrameBSInfo()
+        assert enc._lib.WelsHipEncodeFrame(enc._h, C.byref(pic), C.byref(info)) == 0
+        out += "frame %d type %d layers %d size %d ts %d\n" % (f, info.eFrameType, info.iLayerNum, info.iFrameSizeInBytes, info.uiTimeStamp)
+        for li in range(info.iLayerNum):
+            L = info.sLayerInfo[li]
+            out += "  layer %d ltype %d ftype %d tid %d sid %d qid %d subseq %d nals" % (li, L.uiLayerType, L.eFrameType, L.uiTemporalId, L.uiSpatialId, L.uiQualityId, L.iSubSeqId)
+            out += "".join(" %d" % L.pNalLengthInByte[k] for k in range(L.iNalCount)) + "\n"
+    enc.close()
+    assert out == open(fm).read()
