@@ -23,8 +23,24 @@ from openh264_amd import build as B                        # noqa: E402
 from openh264_amd.utils.synth import synth_sequence        # noqa: E402
 
 
+def rng2_odd(w, h):
+    """Every ninth size or so becomes odd in one or both dimensions (decided from the size itself: no draw)."""
+    k = (w * 7 + h * 13) % 19
+    if w < 18 or h < 18 or k > 2:
+        return None
+    return ((1, 0), (0, 1), (1, 1))[k]
+
+
 def content(kind, w, h, frames, rng):
     """I420 bytes of one of several content classes (all integer, seeded)."""
+    if kind == "oddsize":                                  # smooth-ish noise, any picture size
+        fsz = w * h * 3 // 2
+        out = bytearray()
+        base = rng.integers(0, 256, fsz, dtype=np.uint8).astype(np.int32)
+        for n in range(frames):
+            v = (base * 3 + np.roll(base, 1) + np.roll(base, w) * 2 + np.roll(base, 3 * n + 1) * 2 + 4) >> 3
+            out += np.clip(v + rng.integers(-3, 4, fsz), 0, 255).astype(np.uint8).tobytes()
+        return bytes(out)
     if kind == "synth":
         return synth_sequence(w, h, frames, seed=int(rng.integers(1, 1 << 30)))
     out = bytearray()
@@ -111,6 +127,10 @@ def one_case(rng, lib, enc_tool, tmp, max_mbs, run=True, big=False):
     idc = int(rng.choice([0, 0, 1, 2]))
     nsl = int(rng.integers(1, min(4, mb_h) + 1))
     kind = str(rng.choice(KINDS))
+    odd = rng2_odd(w, h)
+    if odd:                                                # odd picture sizes (the input layout is the console's: planes of
+        w, h = w - odd[0], h - odd[1]                      # w*h and (w>>1)*(h>>1) bytes inside frames of w*h*3/2 bytes)
+        kind = "oddsize"
     alpha, beta = (int(x) for x in rng.choice([0, 0, 0, -6, -3, 2, 6], 2))
     crop = int(rng.random() < 0.85)
     spsid = int(rng.random() < 0.7)
