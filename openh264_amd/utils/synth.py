@@ -73,8 +73,28 @@ def checker_sequence(width, height, frames, period=3):
     return bytes(out)
 
 
+def pan_sequence(width, height, frames, dx):
+    """A smooth texture moving `dx` samples per picture to the right (wrapping): the true motion sits at the edge of
+    the integer search range, which levels 1 / 1b narrow to 63 samples."""
+    rng = np.random.default_rng(width * 131 + height * 7 + dx)
+    base = rng.integers(0, 256, (height, width)).astype(np.int32)
+    acc = np.zeros_like(base)
+    for d in range(4):
+        acc += np.roll(base, d, axis=1) + np.roll(base, d, axis=0)
+    tex = (acc >> 3).astype(np.uint8)
+    out = bytearray()
+    for n in range(frames):
+        out += np.roll(tex, dx * n, axis=1).tobytes()
+        cu = np.roll(tex[::2, ::2], dx * n // 2, axis=1)
+        out += cu.tobytes()
+        out += (255 - cu).tobytes()
+    return bytes(out)
+
+
 def make_sequence(content, width, height, frames):
-    """`content`: "synth" (default generator) or "checker<period>"."""
+    """`content`: "synth" (default generator), "checker<period>" or "pan<dx>"."""
     if content.startswith("checker"):
         return checker_sequence(width, height, frames, int(content[7:] or 3))
+    if content.startswith("pan"):
+        return pan_sequence(width, height, frames, int(content[3:] or 64))
     return synth_sequence(width, height, frames)

@@ -20,6 +20,32 @@ def _run(extra, ref_tools):
     assert "24 cases, 0 failed" in out
 
 
+# single cases that once differed, kept as regressions: (seed, case, what it was)
+REGRESSIONS = [
+    (176, 393, "level 1 stream: integer search range 63 (GetMvMvdRange), MV at the range edge"),
+]
+
+
+def _run_one(seed, case, extra, ref_tools):
+    if not ref_tools:
+        pytest.skip("oracle/_ref not built")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "--seed", str(seed), "--only", str(case)] + extra,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = r.stdout.decode()
+    assert r.returncode == 0 and "1 cases, 0 failed" in out, out[-4000:]
+
+
+@pytest.mark.parametrize("seed,case,what", REGRESSIONS)
+def test_fuzz_regression_emu(seed, case, what, emu_lib, ref_tools):
+    _run_one(seed, case, [], ref_tools)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,case,what", REGRESSIONS)
+def test_fuzz_regression_hip(seed, case, what, hip_lib, ref_tools):
+    _run_one(seed, case, ["--hip"], ref_tools)
+
+
 def test_fuzz_emu(emu_lib, ref_tools):
     _run([], ref_tools)
 

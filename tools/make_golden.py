@@ -47,6 +47,10 @@ CASES = {
     # motion exceeds the 85 % moving-blocks threshold, so picture 17 becomes an IDR
     "p_176x144_qp28_20f_scene": (176, 144, 20, ["-iper", "0", "-qp", "28", "-scene", "1"], dict(uiIntraPeriod=0, iDLayerQp=28, bEnableSceneChangeDetect=1)),
     # SM_RASTER_SLICE: 37 macroblocks per slice (7 slices, the last one cut) and one slice per macroblock row (12 slices)
+    # a level 1 stream (99 MBs at 7.5 pictures/s, 64 kb/s): level_idc 10 and the 63-sample integer search range that goes
+    # with it (GetMvMvdRange); the range edge itself is pinned by tests/test_fuzz_parity.py::REGRESSIONS
+    "p_176x144_qp30_c2_pan64_level1": (176, 144, 5, ["-iper", "0", "-qp", "30", "-complexity", "2", "-fps", "7.5", "-bitrate", "64000"],
+                                       dict(uiIntraPeriod=0, iDLayerQp=30, iComplexityMode=2, fMaxFrameRate=7.5, iTargetBitrate=64000), "pan64"),
     "p_320x192_qp26_raster37": (320, 192, 4, ["-iper", "0", "-qp", "26", "-slcmd", "2", "-slcmbnum", "37"], dict(uiIntraPeriod=0, iDLayerQp=26, uiSliceMode=2, uiSliceMbNum=[37] * 35)),
     "p_320x192_qp26_c1_rowslices_idc2": (320, 192, 4, ["-iper", "0", "-qp", "26", "-complexity", "1", "-slcmd", "2", "-deblock", "2"], dict(uiIntraPeriod=0, iDLayerQp=26, iComplexityMode=1, uiSliceMode=2, iLoopFilterDisableIdc=2)),
 }
@@ -64,11 +68,11 @@ def main():
         with tempfile.TemporaryDirectory() as td:
             fi, fo, fd = os.path.join(td, "in.yuv"), os.path.join(td, "o.264"), os.path.join(td, "d.yuv")
             open(fi, "wb").write(yuv)
-            subprocess.check_call([enc, "-i", fi, "-w", str(w), "-h", str(h), "-o", fo] + flags + COMMON, stdout=subprocess.DEVNULL)
+            subprocess.check_call([enc, "-i", fi, "-w", str(w), "-h", str(h), "-o", fo] + COMMON + flags, stdout=subprocess.DEVNULL)
             bs = open(fo, "rb").read()
             subprocess.check_call([dec, fo, fd], stdout=subprocess.DEVNULL)
             rec = open(fd, "rb").read()
-        out[name] = {"w": w, "h": h, "frames": n, "ref_flags": flags + COMMON, "params": params, "content": content,
+        out[name] = {"w": w, "h": h, "frames": n, "ref_flags": COMMON + flags, "params": params, "content": content,
                      "input_sha1": hashlib.sha1(yuv).hexdigest(), "bytes": len(bs), "sha1": hashlib.sha1(bs).hexdigest(),
                      "recon_sha1": hashlib.sha1(rec).hexdigest()}
         print(name, len(bs), out[name]["sha1"])
