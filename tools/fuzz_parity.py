@@ -94,6 +94,7 @@ def content(kind, w, h, frames, rng):
     raise ValueError(kind)
 
 
+LEVEL1 = False
 KINDS = ["synth", "noise", "flat", "extreme", "fastmotion", "subpel"]
 
 
@@ -121,6 +122,9 @@ def one_case(rng, lib, enc_tool, tmp, max_mbs, run=True, big=False):
     rng2 = np.random.default_rng([w, h, frames, mbs])
     fps = float(rng2.choice([30, 30, 5, 12.5, 15, 25, 60]))
     bitrate = int(rng2.choice([5000000, 5000000, 64000, 300000, 1200000, 20000000, 80000000]))
+    if LEVEL1 and mbs <= 99:                               # --level1: level 1 / 1b streams (search range 63)
+        fps = float(rng2.choice([f for f in (1, 5, 7.5, 12.5, 15) if mbs * f <= 1485]))
+        bitrate = int(rng2.choice([64000, 76000, 100000, 150000]))
     qp = int(rng.choice([0, 1, 5, 10, 12, 18, 24, 26, 30, 36, 40, 45, 51, int(rng.integers(0, 52))]))
     iper = int(rng.choice([0, 0, 0, 1, 2, 3]))
     cplx = int(rng.choice([0, 0, 1, 2]))
@@ -203,9 +207,12 @@ def main():
     ap.add_argument("--hip", action="store_true")
     ap.add_argument("--emu-define", action="append", default=[], help="extra -D for the emulation build (candidate code paths)")
     ap.add_argument("--big", action="store_true", help="picture sizes up to 1920x1088 (use with --max-mbs 8200)")
+    ap.add_argument("--level1", action="store_true", help="pictures of at most 99 MBs get a frame rate / bitrate that selects level 1 or 1b")
     ap.add_argument("--only", type=int, default=-1, help="run just this case index of the seed (same random stream)")
     ap.add_argument("--keep", default=None, help="directory that keeps in.yuv / ref.264 / ours.264 of the last case run")
     a = ap.parse_args()
+    global LEVEL1
+    LEVEL1 = a.level1
     enc_tool = os.path.join(ROOT, "oracle", "_ref", "ref_enc")
     if not os.path.exists(enc_tool):
         sys.exit("oracle/_ref/ref_enc not built (python -c 'import __graft_entry__ as g; g.build()')")
