@@ -184,6 +184,9 @@ int  WelsHipDebugGetMbRecords (WelsHipEncoder* pEncoder, void* pDst, size_t uiBy
 /* developer aid: number of picture re-encodes caused by CAVLC level overflows since InitializeExt (the reference's
  * TRY_REENCODING loop, codec/encoder/core/src/svc_encode_slice.cpp:572-576,1863-1867), or -1 */
 int  WelsHipDebugGetOverflowReencodes (WelsHipEncoder* pEncoder);
+/* developer aid: the device's macroblock processing order of the MB range [iFirstMb, iLastMb) of a picture iMbWidth wide
+ * (openh264_amd/csrc/common/mb_order.h; iBand = rows per band, 0 = the default single band); pOut: iLastMb - iFirstMb entries */
+int  WelsHipDebugBuildMbOrder (int iMbWidth, int iFirstMb, int iLastMb, int iBand, uint16_t* pOut);
 /* developer aid: per-phase cycle counters accumulated inside the MB kernels; pOut64 receives 16 sums + 16 counts of the
  * mode-decision kernel followed by 16 sums + 16 counts of the deblocking kernel */
 int  WelsHipGroupProfile (WelsHipEncoderGroup* pGroup, int bEnable, unsigned long long* pOut64);

@@ -222,7 +222,9 @@ struct SessionCore {
     {
       // processing order tables (kernels/frame_kernels.h wh_build_mb_order): per slice, then whole picture
       std::vector<uint16_t> order ((size_t)num_mb * 2);
-      for (int i = 0; i < s.num_slices; ++i) wh_build_mb_order (mb_w, s.slice_first_mb[i], s.slice_first_mb[i + 1], order.data() + s.slice_first_mb[i]);
+      const char* band_env = getenv ("WELSHIP_MB_BAND");      // experiment knob: rows per band of the per-slice order (0 = one band)
+      const int band = band_env ? atoi (band_env) : 0;
+      for (int i = 0; i < s.num_slices; ++i) wh_build_mb_order (mb_w, s.slice_first_mb[i], s.slice_first_mb[i + 1], order.data() + s.slice_first_mb[i], band);
       wh_build_mb_order (mb_w, 0, num_mb, order.data() + num_mb);
       d_order = (uint16_t*)be->alloc (order.size() * 2);
       be->upload (d_order, order.data(), order.size() * 2);
@@ -757,6 +759,12 @@ int WelsHipDebugGetMbRecords (WelsHipEncoder* e, void* dst, size_t bytes) {
 int WelsHipDebugGetOverflowReencodes (WelsHipEncoder* e) {
   if (!e || !e->inited) return -1;
   return e->core.overflow_reencodes;
+}
+
+int WelsHipDebugBuildMbOrder (int mb_w, int first, int last, int band, uint16_t* out) {
+  if (mb_w <= 0 || first < 0 || last <= first || !out) return WELSHIP_ERR_INIT_PARA;
+  wh_build_mb_order (mb_w, first, last, out, band);
+  return WELSHIP_OK;
 }
 
 // ---------------------------------------------------------------------------------- session group

@@ -147,6 +147,42 @@ def test_hip_wave_variants(waves, hip_lib):
     assert out == g["sha1"]
 
 
+def _band_order_case(band, lib):
+    import sys
+    name = "p_640x368_qp24_4slices"
+    g = GOLDEN[name]
+    code = ("import hashlib, sys; sys.path.insert(0, %r); import openh264_amd as oh; from openh264_amd.utils.synth import synth_sequence;"
+            "yuv = synth_sequence(%d, %d, %d); bs, _ = oh.encode_sequence(yuv, %d, %d, lib_path=%r, fMaxFrameRate=30.0, iTargetBitrate=5000000, **%r);"
+            "print(hashlib.sha1(bs).hexdigest())") % (ROOT, g["w"], g["h"], g["frames"], g["w"], g["h"], lib, g["params"])
+    out = subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, WELSHIP_MB_BAND=band)).decode().split()[-1]
+    assert out == g["sha1"]
+
+
+@pytest.mark.parametrize("band", ["1", "3", "6"])
+def test_emu_band_order(band, emu_lib):
+    """WELSHIP_MB_BAND changes the processing order of a slice's macroblocks (common/mb_order.h), never the result: the
+    emulation runs the list sequentially, so an order that is not topological would read unfinished neighbours."""
+    _band_order_case(band, emu_lib)
+
+
+def test_band_order_is_topological():
+    import ctypes
+    import numpy as np
+    lib = ctypes.CDLL(oh.build.build_emu())
+    fn = lib.WelsHipDebugBuildMbOrder
+    fn.argtypes = [ctypes.c_int] * 4 + [ctypes.c_void_p]
+    for mb_w, first, last, band in [(40, 0, 920, 6), (40, 13, 700, 3), (7, 0, 49, 2), (120, 240, 2280, 6), (5, 3, 4, 1)]:
+        out = np.zeros(last - first, np.uint16)
+        assert fn(mb_w, first, last, band, out.ctypes.data) == 0
+        assert sorted(out.tolist()) == list(range(first, last))
+        pos = {xy: i for i, xy in enumerate(out.tolist())}
+        for xy in range(first, last):
+            x = xy % mb_w
+            for dep in ([xy - 1] if x > 0 else []) + [xy - mb_w] + ([xy - mb_w + 1] if x < mb_w - 1 else []) + ([xy - mb_w - 1] if x > 0 else []):
+                if dep >= first:
+                    assert pos[dep] < pos[xy]
+
+
 def test_session_lifecycle(emu_lib):
     """Uninitialize + InitializeExt on the same object behaves like a fresh object (no state leaks between sessions);
     ForceIntraFrame(false) is a successful no-op as in the reference (welsEncoderExt.cpp:487-500)."""

@@ -18,6 +18,9 @@ run() { echo "== $*" >> $x; ( env "$@" timeout 60 python bench.py --no-cpu-basel
 run WELSHIP_QUEUES=2 WELSHIP_P_WAVES=6
 run WELSHIP_QUEUES=4 WELSHIP_P_WAVES=6
 run WELSHIP_P_LOOKAHEAD=1
+run WELSHIP_MB_BAND=6
+run WELSHIP_MB_BAND=8
+run WELSHIP_MB_BAND=12 WELSHIP_P_WAVES=12
 echo "== --sessions 192" >> $x; timeout 60 python bench.py --no-cpu-baseline --sessions 192 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['value'],1), 'frames/s', d['roofline'].get('events_ms'))" >> $x 2>&1
 echo "== --deblock-idc 2" >> $x; timeout 60 python bench.py --no-cpu-baseline --deblock-idc 2 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['value'],1), 'frames/s', d['roofline'].get('events_ms'))" >> $x 2>&1
 cat $x
