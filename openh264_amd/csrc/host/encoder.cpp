@@ -674,6 +674,12 @@ int WelsHipSetOption (WelsHipEncoder* e, int id, void* opt) {
   case WELSHIP_OPTION_IDR_INTERVAL: {        // :716-731: <= -1 means 0; takes effect at the next frame-type decision
     int32_t v = * (int32_t*)opt;
     if (v <= -1) v = 0;
+    // an all-IDR session does not expand the borders of its reconstructions (nothing refers to them); leaving that
+    // mode, the last picture becomes a reference after all
+    if (c.prm.uiIntraPeriod == 1 && v != 1 && c.have_recon) {
+      e->be->run_expand (c.seq, e->d_job, 1);
+      if (e->be->sync()) { set_err ("device scheduler timed out"); return WELSHIP_ERR_UNKNOWN; }
+    }
     c.prm.uiIntraPeriod = (uint32_t)v;
     return WELSHIP_OK;
   }

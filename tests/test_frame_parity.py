@@ -228,6 +228,7 @@ def test_emu_fast_deblock_candidate(ref_tools, tmp_path):
 @pytest.mark.parametrize("case", [
     ("idr_interval_3_from_frame_4", ["-iper", "0", "-setidr", "4", "3"], [(4, oh.OPTION_IDR_INTERVAL, 3)], {}),
     ("idr_interval_off_from_frame_2", ["-iper", "2", "-setidr", "2", "-1"], [(2, oh.OPTION_IDR_INTERVAL, -1)], dict(uiIntraPeriod=2)),
+    ("leave_all_idr_mode_at_frame_3", ["-iper", "1", "-setidr", "3", "4"], [(3, oh.OPTION_IDR_INTERVAL, 4)], dict(uiIntraPeriod=1)),
     ("complexity_high_from_frame_5", ["-iper", "0", "-setcplx", "5", "2"], [(5, oh.OPTION_COMPLEXITY, 2)], {}),
     ("complexity_low_from_frame_3", ["-iper", "0", "-complexity", "1", "-setcplx", "3", "0"], [(3, oh.OPTION_COMPLEXITY, 0)], dict(iComplexityMode=1)),
 ], ids=lambda c: c[0])

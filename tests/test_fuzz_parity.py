@@ -22,11 +22,13 @@ def _run(extra, ref_tools):
 
 # single cases that once differed, kept as regressions: (seed, case, what it was)
 REGRESSIONS = [
-    (176, 393, "level 1 stream: integer search range 63 (GetMvMvdRange), MV at the range edge"),
+    (176, 393, [], "level 1 stream: integer search range 63 (GetMvMvdRange), MV at the range edge"),
+    (611, 9, ["--options"], "IDR interval 1 -> 2 in mid-stream: the last all-IDR picture becomes a reference (border expansion)"),
 ]
 
 
 def _run_one(seed, case, extra, ref_tools):
+    extra = list(extra)
     if not ref_tools:
         pytest.skip("oracle/_ref not built")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "--seed", str(seed), "--only", str(case)] + extra,
@@ -35,15 +37,15 @@ def _run_one(seed, case, extra, ref_tools):
     assert r.returncode == 0 and "1 cases, 0 failed" in out, out[-4000:]
 
 
-@pytest.mark.parametrize("seed,case,what", REGRESSIONS)
-def test_fuzz_regression_emu(seed, case, what, emu_lib, ref_tools):
-    _run_one(seed, case, [], ref_tools)
+@pytest.mark.parametrize("seed,case,flags,what", REGRESSIONS)
+def test_fuzz_regression_emu(seed, case, flags, what, emu_lib, ref_tools):
+    _run_one(seed, case, flags, ref_tools)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed,case,what", REGRESSIONS)
-def test_fuzz_regression_hip(seed, case, what, hip_lib, ref_tools):
-    _run_one(seed, case, ["--hip"], ref_tools)
+@pytest.mark.parametrize("seed,case,flags,what", REGRESSIONS)
+def test_fuzz_regression_hip(seed, case, flags, what, hip_lib, ref_tools):
+    _run_one(seed, case, flags + ["--hip"], ref_tools)
 
 
 def test_fuzz_emu(emu_lib, ref_tools):

@@ -95,6 +95,7 @@ def content(kind, w, h, frames, rng):
 
 
 LEVEL1 = False
+OPTIONS = False
 KINDS = ["synth", "noise", "flat", "extreme", "fastmotion", "subpel"]
 
 
@@ -172,7 +173,21 @@ def one_case(rng, lib, enc_tool, tmp, max_mbs, run=True, big=False):
     elif nsl > 1:
         params.update(uiSliceMode=1, uiSliceNum=nsl)
         flags += ["-slcmd", "1", "-slcnum", str(nsl)]
+    options, psets = [], -1
+    if OPTIONS and frames > 2:                             # --options: SetOption / EncodeParameterSets calls in mid-stream
+        rng3 = np.random.default_rng([w, h, frames, qp, 77])
+        if rng3.random() < 0.5:
+            at, v = int(rng3.integers(1, frames)), int(rng3.choice([-1, 0, 1, 2, 3, 5]))
+            options.append((at, oh.OPTION_IDR_INTERVAL, v)); flags += ["-setidr", str(at), str(v)]
+        if rng3.random() < 0.5:
+            at, v = int(rng3.integers(1, frames)), int(rng3.integers(0, 3))
+            options.append((at, oh.OPTION_COMPLEXITY, v)); flags += ["-setcplx", str(at), str(v)]
+        if rng3.random() < 0.3:
+            psets = int(rng3.integers(0, frames))
+            flags += ["-paramsets", str(psets)]
     desc = "%dx%d f%d@%g/%dk t%d qp%d iper%d c%d idc%d a%d b%d crop%d id%d fi%d sc%d/%d sl%d %s" % (w, h, frames, fps, bitrate // 1000, threads, qp, iper, cplx, idc, alpha, beta, crop, spsid, fidr, scene, cut, nsl, kind)
+    if options or psets >= 0:
+        desc += " opt%s ps%d" % ([(a, o, v) for a, o, v in options], psets)
     if not run:                                            # --only: just keep the random stream in step
         return desc, "ok"
     fi, fo = os.path.join(tmp, "in.yuv"), os.path.join(tmp, "ref.264")
@@ -181,7 +196,7 @@ def one_case(rng, lib, enc_tool, tmp, max_mbs, run=True, big=False):
     ref_failed = r.returncode != 0
     ref = b"" if ref_failed else open(fo, "rb").read()
     try:
-        bs, _ = oh.encode_sequence(yuv, w, h, lib_path=lib, force_idr_at=fidr, **params)
+        bs, _ = oh.encode_sequence(yuv, w, h, lib_path=lib, force_idr_at=fidr, options_at=options, param_sets_at=psets, **params)
     except oh.WelsHipError as e:
         # the reference gives up with cmMallocMemeError (3) when a frame overflows its bitstream buffer even at QP 50
         if ref_failed and e.code == 3 and "EncodeFrame failed: 3" in r.stderr.decode():
@@ -208,11 +223,12 @@ def main():
     ap.add_argument("--emu-define", action="append", default=[], help="extra -D for the emulation build (candidate code paths)")
     ap.add_argument("--big", action="store_true", help="picture sizes up to 1920x1088 (use with --max-mbs 8200)")
     ap.add_argument("--level1", action="store_true", help="pictures of at most 99 MBs get a frame rate / bitrate that selects level 1 or 1b")
+    ap.add_argument("--options", action="store_true", help="add SetOption (IDR interval, complexity) and EncodeParameterSets calls in mid-stream")
     ap.add_argument("--only", type=int, default=-1, help="run just this case index of the seed (same random stream)")
     ap.add_argument("--keep", default=None, help="directory that keeps in.yuv / ref.264 / ours.264 of the last case run")
     a = ap.parse_args()
-    global LEVEL1
-    LEVEL1 = a.level1
+    global LEVEL1, OPTIONS
+    LEVEL1, OPTIONS = a.level1, a.options
     enc_tool = os.path.join(ROOT, "oracle", "_ref", "ref_enc")
     if not os.path.exists(enc_tool):
         sys.exit("oracle/_ref/ref_enc not built (python -c 'import __graft_entry__ as g; g.build()')")
