@@ -237,8 +237,9 @@ struct SessionCore {
     // level (au_set.cpp:530-545): the reference feeds iSpatialBitrate even with RC off
     level_idc = wh::select_level_idc (mb_w, mb_h, 1, p->fMaxFrameRate, p->iTargetBitrate, &level_1b);
     // GetMvMvdRange (encoder_ext.cpp:1508-1532): min (|MinVmv| >> 2, MaxVmv >> 2, 64) of the level just chosen --
-    // levels 1 and 1b allow +63.75 at most, so the integer search stays within 63 samples there
-    if (level_idc == 10 || level_1b) s.mv_range = 63;
+    // level 1 allows +63.75 at most, so the integer search stays within 63 samples there (level 1b as well, but a
+    // Baseline stream carries 1b as level 1.1 + constraint_set3 and the reference looks up 1.1: au_set.cpp:530-534)
+    if (level_idc == 10) s.mv_range = 63;
     return WELSHIP_OK;
   }
 

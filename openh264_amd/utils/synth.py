@@ -75,7 +75,7 @@ def checker_sequence(width, height, frames, period=3):
 
 def pan_sequence(width, height, frames, dx):
     """A smooth texture moving `dx` samples per picture to the right (wrapping): the true motion sits at the edge of
-    the integer search range, which levels 1 / 1b narrow to 63 samples."""
+    the integer search range, which level 1 narrows to 63 samples."""
     rng = np.random.default_rng(width * 131 + height * 7 + dx)
     base = rng.integers(0, 256, (height, width)).astype(np.int32)
     acc = np.zeros_like(base)

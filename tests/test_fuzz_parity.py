@@ -23,6 +23,7 @@ def _run(extra, ref_tools):
 # single cases that once differed, kept as regressions: (seed, case, what it was)
 REGRESSIONS = [
     (176, 393, [], "level 1 stream: integer search range 63 (GetMvMvdRange), MV at the range edge"),
+    (9203, 3525, ["--level1", "--max-mbs", "99"], "level 1b Baseline stream is looked up as level 1.1: search range 64"),
     (611, 9, ["--options"], "IDR interval 1 -> 2 in mid-stream: the last all-IDR picture becomes a reference (border expansion)"),
 ]
 

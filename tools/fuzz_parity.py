@@ -123,7 +123,7 @@ def one_case(rng, lib, enc_tool, tmp, max_mbs, run=True, big=False):
     rng2 = np.random.default_rng([w, h, frames, mbs])
     fps = float(rng2.choice([30, 30, 5, 12.5, 15, 25, 60]))
     bitrate = int(rng2.choice([5000000, 5000000, 64000, 300000, 1200000, 20000000, 80000000]))
-    if LEVEL1 and mbs <= 99:                               # --level1: level 1 / 1b streams (search range 63)
+    if LEVEL1 and mbs <= 99:                               # --level1: level 1 / 1b streams (search range 63 at level 1)
         fps = float(rng2.choice([f for f in (1, 5, 7.5, 12.5, 15) if mbs * f <= 1485]))
         bitrate = int(rng2.choice([64000, 76000, 100000, 150000]))
     qp = int(rng.choice([0, 1, 5, 10, 12, 18, 24, 26, 30, 36, 40, 45, 51, int(rng.integers(0, 52))]))
