@@ -35,7 +35,8 @@ int main (int argc, char** argv) {
   int slcmd = 0, slcnum = 1, slcmbnum = 0, threads = 1, loadbal = 0, deblock = 0;
   int aq = 0, bgd = 0, scene = 0, ltr = 0, denoise = 0, frameskip = 0, cabac = 0, spsid = 1, usage = 0;
   int alpha = 0, beta = 0, crop = 1, forceidr = -1;
-  int setidr_at = -1, setidr_val = 0, setcplx_at = -1, setcplx_val = 0, paramsets_at = -1;
+  int setidr_at = -1, setidr_val = 0, setcplx_at = -1, setcplx_val = 0, paramsets_at = -1, setfps_at = -1;
+  float setfps_val = 30.f;
   std::string infofile;                // -dumpinfo FILE: the SFrameBSInfo metadata of every frame, one line per layer
   int low_w = 0, low_h = 0;            // -simulcast WxH: an extra, lower spatial layer, simulcast AVC (the input is the higher one)
   for (int i = 1; i < argc; ++i) {
@@ -75,6 +76,7 @@ int main (int argc, char** argv) {
     else if (arg_eq (a, "-forceidr")) forceidr = std::atoi (next());     // ForceIntraFrame(true) before frame N
     else if (arg_eq (a, "-setidr")) { setidr_at = std::atoi (next()); setidr_val = std::atoi (next()); }      // SetOption (ENCODER_OPTION_IDR_INTERVAL) before frame N
     else if (arg_eq (a, "-setcplx")) { setcplx_at = std::atoi (next()); setcplx_val = std::atoi (next()); }   // SetOption (ENCODER_OPTION_COMPLEXITY) before frame N
+    else if (arg_eq (a, "-setfps")) { setfps_at = std::atoi (next()); setfps_val = (float)std::atof (next()); }  // SetOption (ENCODER_OPTION_FRAME_RATE) before frame N
     else if (arg_eq (a, "-dumpinfo")) infofile = next();
     else if (arg_eq (a, "-simulcast")) { low_w = std::atoi (next()); low_h = std::atoi (next()); }
     else if (arg_eq (a, "-paramsets")) paramsets_at = std::atoi (next());       // EncodeParameterSets before frame N, output appended
@@ -150,6 +152,7 @@ int main (int argc, char** argv) {
     if (n == forceidr) enc->ForceIntraFrame (true);
     if (n == setidr_at) enc->SetOption (ENCODER_OPTION_IDR_INTERVAL, &setidr_val);
     if (n == setcplx_at) enc->SetOption (ENCODER_OPTION_COMPLEXITY, &setcplx_val);
+    if (n == setfps_at) enc->SetOption (ENCODER_OPTION_FRAME_RATE, &setfps_val);
     if (n == paramsets_at) {
       SFrameBSInfo ps; std::memset (&ps, 0, sizeof (ps));
       if (enc->EncodeParameterSets (&ps)) { std::fprintf (stderr, "EncodeParameterSets failed\n"); return 1; }

@@ -183,6 +183,9 @@ def one_case(rng, lib, enc_tool, tmp, max_mbs, run=True, big=False):
             at, v = int(rng3.integers(1, frames)), int(rng3.integers(0, 3))
             options.append((at, oh.OPTION_COMPLEXITY, v)); flags += ["-setcplx", str(at), str(v)]
         if rng3.random() < 0.3:
+            at, v = int(rng3.integers(1, frames)), float(rng3.choice([1, 5, 7.5, 15, 30, 60, 100]))
+            options.append((at, oh.OPTION_FRAME_RATE, v)); flags += ["-setfps", str(at), str(v)]
+        if rng3.random() < 0.3:
             psets = int(rng3.integers(0, frames))
             flags += ["-paramsets", str(psets)]
     desc = "%dx%d f%d@%g/%dk t%d qp%d iper%d c%d idc%d a%d b%d crop%d id%d fi%d sc%d/%d sl%d %s" % (w, h, frames, fps, bitrate // 1000, threads, qp, iper, cplx, idc, alpha, beta, crop, spsid, fidr, scene, cut, nsl, kind)
