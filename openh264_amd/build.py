@@ -23,18 +23,21 @@ def _newer(target, deps):
     return False
 
 
-def build_hip(force=False, verbose=True):
-    """hipcc --offload-arch=gfx950 (cross-compiles without a GPU)."""
+def build_hip(force=False, verbose=True, defines=(), tag=""):
+    """hipcc --offload-arch=gfx950 (cross-compiles without a GPU).
+    `defines` + `tag`: a second library (libwelship_<tag>.so) with candidate code paths switched on, for A/B runs on the
+    device through WELSHIP_LIB / tools/fuzz_parity.py --lib; the product library is always the plain build."""
+    out = LIB if not tag else LIB.replace(".so", "_" + tag + ".so")
     deps = [CSRC, os.path.join(ROOT, "include")]
-    if not force and not _newer(LIB, deps):
-        return LIB
+    if not force and not _newer(out, deps):
+        return out
     # NB: no v_ashr_pk_u8_i32 may appear in the device code (see wh_clip255 in csrc/kernels/wave.h): checked below.
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-function",
-           "-Wno-unused-variable", "-o", LIB] + HIP_SRCS + HOST_SRCS
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17"] + ["-D" + d for d in defines] + ["-fPIC", "-shared", "-Wno-unused-function",
+           "-Wno-unused-variable", "-o", out] + HIP_SRCS + HOST_SRCS
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd, cwd=ROOT)
-    return LIB
+    return out
 
 
 def build_emu(force=False, verbose=False, defines=(), tag=""):

@@ -227,6 +227,7 @@ def main():
     ap.add_argument("--big", action="store_true", help="picture sizes up to 1920x1088 (use with --max-mbs 8200)")
     ap.add_argument("--level1", action="store_true", help="pictures of at most 99 MBs get a frame rate / bitrate that selects level 1 or 1b")
     ap.add_argument("--options", action="store_true", help="add SetOption (IDR interval, complexity) and EncodeParameterSets calls in mid-stream")
+    ap.add_argument("--lib", default=None, help="use this shared library (e.g. a candidate build from build_hip(defines=...))")
     ap.add_argument("--only", type=int, default=-1, help="run just this case index of the seed (same random stream)")
     ap.add_argument("--keep", default=None, help="directory that keeps in.yuv / ref.264 / ours.264 of the last case run")
     a = ap.parse_args()
@@ -235,7 +236,7 @@ def main():
     enc_tool = os.path.join(ROOT, "oracle", "_ref", "ref_enc")
     if not os.path.exists(enc_tool):
         sys.exit("oracle/_ref/ref_enc not built (python -c 'import __graft_entry__ as g; g.build()')")
-    lib = B.build_hip() if a.hip else B.build_emu(defines=tuple(a.emu_define), tag="_".join(d.lower() for d in a.emu_define))
+    lib = a.lib if a.lib else B.build_hip() if a.hip else B.build_emu(defines=tuple(a.emu_define), tag="_".join(d.lower() for d in a.emu_define))
     rng = np.random.default_rng(a.seed)
     bad = 0
     with tempfile.TemporaryDirectory() as tmpdir:
