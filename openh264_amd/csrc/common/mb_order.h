@@ -41,3 +41,39 @@ WH_ORDER_FN void wh_mb_deps (int mb_w, int xy, int first, int* dep_a, int* dep_b
   const int tr = mbx < mb_w - 1 ? xy - mb_w + 1 : xy - mb_w;
   *dep_b = tr >= first ? tr : -1;
 }
+
+// ---- deblocking bands -----------------------------------------------------------------------------------
+// The deblocking kernel gives every workgroup a band: a run of MB rows of one slice, at most `max_rows` of them.  Bands hand
+// over to each other through the picture (write-through stores) + flag words (hip_backend.hip); every band edge costs a few
+// microseconds per macroblock along it, so a slice stays one band unless it is much taller than a workgroup has wavefronts
+// (measured on MI355X, 128 four-slice 1080p pictures: 4 bands per picture 3.4 ms, 5 of 14 rows 5.1 ms, 9 of 8 rows 3.7 ms).
+// out: 3 * n + 1 words (see WhSeqParams::db_bands); returns n, or -1 when `cap` words are not enough.
+// `by_slice` = false (experiment knob, only with idc 0): bands ignore the slice structure and always start at a row.
+WH_ORDER_FN int wh_build_db_bands (int mb_w, int mb_h, int num_slices, const int32_t* slice_first, int deblock_idc, int max_rows,
+                                   int32_t* out, int cap, bool by_slice = true) {
+  const int num_mb = mb_w * mb_h;
+  int n = 0;
+  // pass 1: count, pass 2: fill (the three sections depend on n)
+  for (int pass = 0; pass < 2; ++pass) {
+    const int total = n;
+    n = 0;
+    const bool whole = deblock_idc == 0 && !by_slice;
+    const int ns = whole ? 1 : num_slices;
+    for (int s = 0; s < ns; ++s) {
+      const int first = whole ? 0 : slice_first[s], last = whole ? num_mb : slice_first[s + 1];
+      const int r0 = first / mb_w, r1 = (last - 1) / mb_w, span = r1 - r0 + 1;
+      const int parts = (span + max_rows - 1) / max_rows, rows = (span + parts - 1) / parts;
+      for (int j = 0; j < parts; ++j) {
+        int a = (r0 + j * rows) * mb_w, b = (r0 + (j + 1) * rows) * mb_w;
+        if (a < first) a = first;
+        if (b > last) b = last;
+        if (a >= b) continue;
+        if (pass == 1) { out[n] = a; out[total + 1 + n] = first; out[2 * total + 1 + n] = last; }
+        ++n;
+      }
+    }
+    if (pass == 0 && 3 * n + 1 > cap) return -1;
+    if (pass == 1) out[n] = num_mb;
+  }
+  return n;
+}

@@ -104,6 +104,7 @@ typedef struct WhPicJob {
 } WhPicJob;
 
 #define WH_MAX_SLICES 36
+#define WH_DB_BAND_ROWS 24          // a deblocking band (one workgroup) never spans more MB rows than this
 
 // ---- parameters common to every picture of a launch --------------------------------------------
 typedef struct WhSeqParams {
@@ -121,7 +122,15 @@ typedef struct WhSeqParams {
   int32_t blk8_w, blk8_h;               // picture size in whole 8x8 luma blocks (scene-change statistic)
   unsigned long long* prof;             // optional device array of 64 x 32 cycle counters (phase profiling), or NULL
   const uint16_t* mb_order;             // device table: [0, num_mb) MB addresses in dependency order per slice (each slice's
-                                        // range is [slice_first_mb[s], slice_first_mb[s+1])), [num_mb, 2*num_mb) whole-picture order
+                                        // range is [slice_first_mb[s], slice_first_mb[s+1])), [num_mb, 2*num_mb) whole-picture order,
+                                        // [2*num_mb, 3*num_mb) per deblocking band (each band's range is [db_bands[b], db_bands[b+1]))
+  // Deblocking bands: the MB ranges the deblocking workgroups own (rows of one slice, at most WH_DB_BAND_ROWS of them: a
+  // slice is a band unless it is taller, e.g. a single-slice picture is cut into several).  Device table of
+  // 3 * db_num_bands + 1 words: [0, n] first MB of band b (and the end of the last), [n+1, 2n] first MB of the slice band b
+  // lies in, [2n+1, 3n] end of that slice.
+  int32_t db_num_bands, db_max_mbs;     // db_max_mbs / db_max_rows: the largest band (host-side launch geometry)
+  const int32_t* db_bands;
+  int32_t db_max_rows, pad3;
 } WhSeqParams;
 
 #ifdef __cplusplus

@@ -12,6 +12,8 @@
 #include <string>
 #include <vector>
 #include <algorithm>
+#include <map>
+#include <unordered_map>
 #include "../host/backend.h"
 #include "../kernels/frame_kernels.h"
 #include "../kernels/deblock_mb.h"
@@ -178,13 +180,16 @@ __global__ __launch_bounds__ (MAXT) void k_inter_slice (WhSeqParams P, const WhP
   if (P.prof && lane < 32) atomicAdd (&P.prof[((blockIdx.x + blockIdx.y * 7u) & 63u) * 32u + lane], (unsigned long long)S.m.prof[lane]);
 }
 
-// Deblocking with one workgroup per slice.  The filter crosses slice boundaries (disable_deblocking_filter_idc 0), so
-// the MBs along a slice's upper seam wait for MBs of the previous slice -- another workgroup, in general on another
-// XCD: the producer publishes with an agent-scope release + a flag word in HBM (J.db_flags[mb] = J.db_gen), the
-// consumer polls the flag (relaxed, agent scope) and then takes an agent-scope acquire before it loads the pixels
-// (MI355X_MICROARCH.md, inter-workgroup visibility).  Only MBs that a later slice can depend on publish.  The
-// workgroups of one picture have consecutive block ids and slice s-1 never waits for slice s, so the chain cannot
-// deadlock while the earlier workgroup is scheduled; the spin is bounded regardless.
+// Deblocking with one workgroup per BAND (WhSeqParams::db_bands: whole rows of one slice -- of the picture when the filter
+// crosses slice boundaries, disable_deblocking_filter_idc 0 -- and never more rows than the workgroup has wavefronts, so
+// a 2:1 diagonal of the band is filtered in one round).  The MBs along a band's upper edge wait for MBs of the band above
+// -- another workgroup, in general on another XCD.  The producer writes the samples a later band reads with write-through
+// stores (sc0 sc1), waits for them (vmcnt) and sets a flag word in HBM (J.db_flags[mb] = J.db_gen); the consumer polls the
+// flag and loads those samples past its caches (sc0 sc1) -- MI355X_MICROARCH.md, inter-workgroup visibility, "sc0 sc1 stores
+// and loads both sides".  No agent-scope fences: a release would write back every dirty line of the XCD's L2 and an acquire
+// empty the CU's L1 for all its waves, once per macroblock of every band edge (measured: 3 ms of a 5.4 ms pass).  Only MBs
+// that a later band can depend on publish.  The workgroups of one picture have consecutive block ids and band b-1 never waits for band b, so the chain
+// cannot deadlock while the earlier workgroup is scheduled; the spin is bounded regardless.
 #define WH_SEAM_SPIN_LIMIT (1u << 22)
 __global__ __launch_bounds__ (1024) void k_deblock_slices (WhSeqParams P, const WhPicJob* jobs, uint32_t* err) {
   extern __shared__ __align__ (16) uint8_t smem[];
@@ -197,8 +202,12 @@ __global__ __launch_bounds__ (1024) void k_deblock_slices (WhSeqParams P, const 
   E.first_row = 0;
   uint32_t* sched = E.left + (size_t)P.mb_h * 32;
   const int w = P.mb_w, num_mb = P.mb_w * P.mb_h;
-  const int first = P.slice_first_mb[blockIdx.x], last = P.slice_first_mb[blockIdx.x + 1], n = last - first;
-  const uint16_t* order = P.mb_order + first;
+  const int nb = P.db_num_bands;
+  const int first = P.db_bands[blockIdx.x], last = P.db_bands[blockIdx.x + 1], n = last - first;
+  // idc 2: nothing is filtered (or needed) across slices -- only the bands of this band's own slice matter
+  const bool cross = P.deblock_idc == 0;
+  const int sfirst = cross ? 0 : P.db_bands[nb + 1 + blockIdx.x], slast = cross ? num_mb : P.db_bands[2 * nb + 1 + blockIdx.x];
+  const uint16_t* order = P.mb_order + 2 * num_mb + first;
   for (int i = (int)threadIdx.x; i < 1 + ((n + 31) >> 5); i += (int)blockDim.x) sched[i] = 0;
   __shared__ WhPicJob Jl;
   wh_copy_job (&Jl, &jobs[blockIdx.y]);
@@ -206,7 +215,6 @@ __global__ __launch_bounds__ (1024) void k_deblock_slices (WhSeqParams P, const 
   const WhPicJob& J = Jl;
   uint32_t* flags = J.db_flags;
   const uint32_t gen = J.db_gen;
-  const bool cross = P.deblock_idc == 0;        // idc 2: nothing is filtered (or needed) across slices
   __shared__ WhDbStage stage[16];                 // separate LDS object (see WhInterStage)
   WhDbStage& G = stage[wave];
   if (P.prof && lane < 32) S.prof[lane] = 0;
@@ -229,9 +237,9 @@ __global__ __launch_bounds__ (1024) void k_deblock_slices (WhSeqParams P, const 
       const int dep = k == 0 ? dep_a : dep_b;
       if (dep < 0) continue;
       if (dep >= first) ok = wh_wait_done (sched + 1, dep - first, err);
-      else if (cross) {
+      else if (dep >= sfirst) {
         uint32_t spins = 0;
-        while (__hip_atomic_load (&flags[dep], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gen) {
+        while (__hip_atomic_load (&flags[dep], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != gen) {
           __builtin_amdgcn_s_sleep (8);
           if (++spins > WH_SEAM_SPIN_LIMIT) { if (lane == 0 && atomicAdd (err, 1u) == 0) { err[1] = blockIdx.x; err[2] = blockIdx.y; err[3] = 0x80000000u | (uint32_t)dep; } ok = false; break; }
         }
@@ -239,20 +247,20 @@ __global__ __launch_bounds__ (1024) void k_deblock_slices (WhSeqParams P, const 
       }
     }
     if (!ok) break;
-    if (remote) __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "agent");
-    else __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "workgroup");
+    // no agent-scope acquire: what comes from another band is loaded past the caches (wh_ld_xwg32 in the body)
+    __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "workgroup");
     WH_PROF_MARK (P, S, remote ? 3 : 2);        // neighbours done: 2 = inside the workgroup, 3 = incl. a wait across the seam
     WV_ASYNC_WAIT();                            // this MB's staged inputs have landed
     WH_PROF_MARK (P, S, 4);   // own inputs landed
-    const bool drain = wh_deblock_mb_body (S, G, E, first, last, P, J, xy % w, xy / w, 0, 0, 0);
+    // MBs a later band may wait for: its left neighbour (xy + 1), top (xy + w) or top-right consumer (xy + w - 1).  Their
+    // stores are write-through (no agent-scope release: buffer_wbl2 would write back every dirty line of the XCD's L2 for
+    // each of them); the flag follows once the stores have left the wave
+    const bool publish = xy + w + 1 >= last && last < slast;
+    const bool drain = wh_deblock_mb_body (S, G, E, first, last, P, J, xy % w, xy / w, 0, 0, 0, publish);
     WH_PROF_MARK (P, S, 11);  // (body total: ids 5..8)
-    // MBs a later slice may wait for: its left neighbour (xy + 1), top (xy + w) or top-right consumer (xy + w - 1)
-    const bool publish = cross && xy + w + 1 >= last && last < num_mb;
     if (publish) {
       asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_fence (__ATOMIC_RELEASE, "agent");
-      asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0) __hip_atomic_store (&flags[xy], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane == 0) __hip_atomic_store (&flags[xy], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     } else if (drain) {
       __builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");
     }
@@ -284,57 +292,92 @@ __global__ __launch_bounds__ (64) void k_qp_chain (WhSeqParams P, const WhPicJob
   wh_qp_chain_slice (P, J, P.slice_first_mb[blockIdx.x], P.slice_first_mb[blockIdx.x + 1]);
 }
 
-#define HIP_CHECK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { fprintf (stderr, "welship: HIP error %s at %s:%d\n", hipGetErrorString (_e), __FILE__, __LINE__); abort(); } } while (0)
+// A drop-in library must never take the host application down: a failing HIP call is recorded (first one wins), the
+// operation becomes a no-op, and sync() -- which every caller checks -- reports it.  alloc() returns NULL.
+#define HIP_TRY(x) do { hipError_t _e = (x); if (_e != hipSuccess) note_error (_e, #x, __LINE__); } while (0)
 
 class HipBackend : public wh::Backend {
  public:
   HipBackend (int dev, const hipDeviceProp_t& prop) : dev_ (dev), cus_ (prop.multiProcessorCount) {
-    HIP_CHECK (hipSetDevice (dev_));
-    HIP_CHECK (hipStreamCreateWithFlags (&stream_, hipStreamNonBlocking));
+    HIP_TRY (hipSetDevice (dev_));
+    HIP_TRY (hipStreamCreateWithFlags (&stream_, hipStreamNonBlocking));
     streams_.push_back (stream_);
-    HIP_CHECK (hipMalloc ((void**)&err_, 16));
-    HIP_CHECK (hipMemset (err_, 0, 16));
+    HIP_TRY (hipMalloc ((void**)&err_, 16));
+    if (err_) HIP_TRY (hipMemset (err_, 0, 16));
     name_ = std::string ("hip:") + prop.gcnArchName + " " + prop.name;
   }
   ~HipBackend() override {
     (void)hipSetDevice (dev_);
-    for (hipStream_t st : streams_) { (void)hipStreamSynchronize (st); (void)hipStreamDestroy (st); }
-    for (void* p : slabs_) (void)hipFree (p);
-    (void)hipFree (err_);
+    for (hipStream_t st : streams_) if (st) { (void)hipStreamSynchronize (st); (void)hipStreamDestroy (st); }
+    for (auto& sl : slabs_) (void)hipFree (sl.base);
+    if (err_) (void)hipFree (err_);
   }
+  bool usable() const { return hip_err_ == hipSuccess && stream_ && err_; }
   const char* name() const override { return name_.c_str(); }
-  // Device memory comes from a few large slabs (bump allocation, 4 KB granules): many small hipMalloc's end up as
-  // many small page-table fragments, and with dozens of planes touched per macroblock the translation misses cost
-  // more than the data misses.  Slabs are returned when the backend goes away (sessions allocate once, at Initialize).
+  // Device memory comes from a few large slabs (4 KB granules): many small hipMalloc's end up as many small page-table
+  // fragments, and with dozens of planes touched per macroblock the translation misses cost more than the data misses.
+  // Inside the slabs: first fit over an address-ordered free list with coalescing, else bump allocation; a new slab is
+  // sized by what has been asked for so far (16 MB .. 256 MB), so one small session does not pin a quarter of a GB.
   void* alloc (size_t bytes) override {
-    HIP_CHECK (hipSetDevice (dev_));
+    if (hipSetDevice (dev_) != hipSuccess) return nullptr;
     bytes = (bytes + 4095) & ~(size_t)4095;
     if (bytes == 0) bytes = 4096;
-    if (slabs_.empty() || slab_used_ + bytes > slab_size_) {
-      slab_size_ = std::max (bytes, (size_t)256 << 20);
-      void* p = nullptr;
-      HIP_CHECK (hipMalloc (&p, slab_size_));
-      slabs_.push_back (p);
-      slab_used_ = 0;
+    for (auto it = free_.begin(); it != free_.end(); ++it) if (it->second >= bytes) {
+      uint8_t* p = (uint8_t*)it->first;
+      const size_t rest = it->second - bytes;
+      free_.erase (it);
+      if (rest) free_[(uintptr_t) (p + bytes)] = rest;
+      live_[(uintptr_t)p] = bytes;
+      return p;
     }
-    void* r = (uint8_t*)slabs_.back() + slab_used_;
-    slab_used_ += bytes;
+    if (slabs_.empty() || slabs_.back().used + bytes > slabs_.back().size) {
+      size_t want = std::min (std::max (total_asked_, (size_t)16 << 20), (size_t)256 << 20);
+      want = std::max (want, bytes);
+      void* p = nullptr;
+      if (hipMalloc (&p, want) != hipSuccess) {
+        (void)hipGetLastError();
+        if (want == bytes || hipMalloc (&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }     // out of device memory: the caller fails its call
+        want = bytes;
+      }
+      if (!slabs_.empty() && slabs_.back().size > slabs_.back().used)       // the tail of the previous slab stays usable
+        free_[(uintptr_t) (slabs_.back().base + slabs_.back().used)] = slabs_.back().size - slabs_.back().used;
+      if (!slabs_.empty()) slabs_.back().used = slabs_.back().size;
+      slabs_.push_back (Slab {(uint8_t*)p, want, 0});
+    }
+    Slab& sl = slabs_.back();
+    void* r = sl.base + sl.used;
+    sl.used += bytes;
+    total_asked_ += bytes;
+    live_[(uintptr_t)r] = bytes;
     return r;
   }
-  void free (void*) override {}
-  void upload (void* dst, const void* src, size_t bytes) override { HIP_CHECK (hipMemcpyAsync (dst, src, bytes, hipMemcpyHostToDevice, stream_)); }
+  void free (void* p) override {
+    if (!p) return;
+    auto it = live_.find ((uintptr_t)p);
+    if (it == live_.end()) return;
+    uintptr_t a = it->first;
+    size_t n = it->second;
+    live_.erase (it);
+    auto nx = free_.lower_bound (a);
+    if (nx != free_.end() && a + n == nx->first && same_slab (a, nx->first)) { n += nx->second; nx = free_.erase (nx); }
+    if (nx != free_.begin()) { auto pv = std::prev (nx); if (pv->first + pv->second == a && same_slab (pv->first, a)) { pv->second += n; return; } }
+    free_[a] = n;
+  }
+  void upload (void* dst, const void* src, size_t bytes) override { if (dst && usable()) HIP_TRY (hipMemcpyAsync (dst, src, bytes, hipMemcpyHostToDevice, stream_)); else if (!dst) note_null(); }
   void pin_host (void* p, size_t bytes) override { if (hipHostRegister (p, bytes, hipHostRegisterDefault) != hipSuccess) (void)hipGetLastError(); }
   void unpin_host (void* p) override { if (hipHostUnregister (p) != hipSuccess) (void)hipGetLastError(); }
-  void download (void* dst, const void* src, size_t bytes) override { HIP_CHECK (hipMemcpyAsync (dst, src, bytes, hipMemcpyDeviceToHost, stream_)); }
-  void fill (void* dst, int value, size_t bytes) override { HIP_CHECK (hipMemsetAsync (dst, value, bytes, stream_)); }
+  void download (void* dst, const void* src, size_t bytes) override { if (src && usable()) HIP_TRY (hipMemcpyAsync (dst, src, bytes, hipMemcpyDeviceToHost, stream_)); else if (!src) note_null(); }
+  void fill (void* dst, int value, size_t bytes) override { if (dst && usable()) HIP_TRY (hipMemsetAsync (dst, value, bytes, stream_)); else if (!dst) note_null(); }
 
   // waves per workgroup: bounded by the LDS budget (160 KB per CU), the kernel's register budget and by how many MBs
   // of one slice can be in flight at all (~ min(rows, mb_w / 2))
   // `static_lds`: LDS the kernel declares statically (counts against the 160 KB of a CU as well)
-  template <class K> void mb_pass (K kernel, size_t lds_per_wave, int max_waves, bool whole_picture, const WhSeqParams& P, const WhPicJob* jobs, int n, size_t static_lds = 0, size_t extra_dyn = 0) {
+  // `bands` > 0: the grid's x dimension are that many deblocking bands (at most WH_DB_BAND_ROWS rows each) instead of the slices
+  template <class K> void mb_pass (K kernel, size_t lds_per_wave, int max_waves, bool whole_picture, const WhSeqParams& P, const WhPicJob* jobs, int n, size_t static_lds = 0, size_t extra_dyn = 0, int bands = 0) {
     const int num_mb = P.mb_w * P.mb_h;
     int max_n = whole_picture ? num_mb : 0, max_rows = whole_picture ? P.mb_h : 0;
-    if (!whole_picture) for (int s = 0; s < P.num_slices; ++s) {
+    if (bands > 0) { max_rows = P.db_max_rows; max_n = P.db_max_mbs; }
+    else if (!whole_picture) for (int s = 0; s < P.num_slices; ++s) {
       const int cnt = P.slice_first_mb[s + 1] - P.slice_first_mb[s];
       if (cnt > max_n) max_n = cnt;
       const int rows = (P.slice_first_mb[s + 1] - 1) / P.mb_w - P.slice_first_mb[s] / P.mb_w + 1;
@@ -346,11 +389,11 @@ class HipBackend : public wh::Backend {
     if (nw > par) nw = par;
     while (nw > 1 && (size_t)nw * lds_per_wave + sched_bytes + static_lds > (size_t)160 * 1024) --nw;
     const size_t lds = (size_t)nw * lds_per_wave + sched_bytes;
-    HIP_CHECK (hipFuncSetAttribute ((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY (hipFuncSetAttribute ((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (getenv ("WELSHIP_TRACE")) { fprintf (stderr, "welship: launch grid %d x %d, %d waves, %zu B LDS, max_n %d\n", whole_picture ? 1 : P.num_slices, n, nw, lds, max_n); fflush (stderr); }
-    hipLaunchKernelGGL (kernel, dim3 (whole_picture ? 1 : P.num_slices, n), dim3 (nw * 64), lds, stream_, P, jobs, err_);
-    HIP_CHECK (hipGetLastError());
-    if (getenv ("WELSHIP_TRACE")) { HIP_CHECK (hipStreamSynchronize (stream_)); fprintf (stderr, "welship: launch done\n"); fflush (stderr); }
+    hipLaunchKernelGGL (kernel, dim3 (bands > 0 ? bands : whole_picture ? 1 : P.num_slices, n), dim3 (nw * 64), lds, stream_, P, jobs, err_);
+    HIP_TRY (hipGetLastError());
+    if (getenv ("WELSHIP_TRACE")) { HIP_TRY (hipStreamSynchronize (stream_)); fprintf (stderr, "welship: launch done\n"); fflush (stderr); }
   }
   void run_intra (const WhSeqParams& P, const WhPicJob* jobs, int n) override { mb_pass (k_intra_slice, sizeof (WhMbLds), 16, false, P, jobs, n, sizeof (WhPicJob)); }
   // P pictures.  The wave count per workgroup (= per slice) trades waiting on neighbours against latency hiding:
@@ -370,39 +413,42 @@ class HipBackend : public wh::Backend {
   }
   void run_deblock (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
     static const int db_waves = getenv ("WELSHIP_DB_WAVES") ? atoi (getenv ("WELSHIP_DB_WAVES")) : 16;
-    mb_pass (k_deblock_slices, sizeof (WhDbLds), db_waves, false, P, jobs, n, 16 * sizeof (WhDbStage) + sizeof (WhPicJob), 4 * wh_db_xchg_words (P.mb_w, P.mb_h));
+    mb_pass (k_deblock_slices, sizeof (WhDbLds), db_waves, false, P, jobs, n, 16 * sizeof (WhDbStage) + sizeof (WhPicJob), 4 * wh_db_xchg_words (P.mb_w, P.mb_h), P.db_num_bands);
   }
   void run_scene (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
     hipLaunchKernelGGL (k_scene, dim3 (P.mb_w * P.mb_h, n), dim3 (64), 0, stream_, P, jobs);
-    HIP_CHECK (hipGetLastError());
+    HIP_TRY (hipGetLastError());
   }
   void run_qp_chain (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
     hipLaunchKernelGGL (k_qp_chain, dim3 (P.num_slices, n), dim3 (64), 0, stream_, P, jobs);
-    HIP_CHECK (hipGetLastError());
+    HIP_TRY (hipGetLastError());
   }
   void run_expand (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
     hipLaunchKernelGGL (k_expand, dim3 (wh_expand_num_blocks (P), n), dim3 (64), 0, stream_, P, jobs);
-    HIP_CHECK (hipGetLastError());
+    HIP_TRY (hipGetLastError());
   }
   void select_queue (int k) override {
-    HIP_CHECK (hipSetDevice (dev_));
-    while ((int)streams_.size() <= k) { hipStream_t st; HIP_CHECK (hipStreamCreateWithFlags (&st, hipStreamNonBlocking)); streams_.push_back (st); }
+    HIP_TRY (hipSetDevice (dev_));
+    while ((int)streams_.size() <= k) { hipStream_t st; HIP_TRY (hipStreamCreateWithFlags (&st, hipStreamNonBlocking)); streams_.push_back (st); }
     stream_ = streams_[k < 0 ? 0 : k];
   }
+  // 0, the number of in-kernel dependency waits that timed out, or -1 after a HIP error (sticky: the backend is unusable)
   int sync() override {
-    for (hipStream_t st : streams_) HIP_CHECK (hipStreamSynchronize (st));
+    for (hipStream_t st : streams_) if (st) HIP_TRY (hipStreamSynchronize (st));
+    if (!usable()) return -1;
     uint32_t e[4] = {0, 0, 0, 0};
-    HIP_CHECK (hipMemcpy (e, err_, 16, hipMemcpyDeviceToHost));
+    HIP_TRY (hipMemcpy (e, err_, 16, hipMemcpyDeviceToHost));
+    if (!usable()) return -1;
     if (e[0]) {
       fprintf (stderr, "welship: %u in-kernel dependency waits timed out (first: block %u,%u waiting for MB index %u)\n", e[0], e[1], e[2], e[3]);
-      HIP_CHECK (hipMemset (err_, 0, 16));
+      HIP_TRY (hipMemset (err_, 0, 16));
     }
     return (int)e[0];
   }
-  void* event_create() override { hipEvent_t e; HIP_CHECK (hipEventCreate (&e)); return (void*)e; }
-  void event_destroy (void* ev) override { HIP_CHECK (hipEventDestroy ((hipEvent_t)ev)); }
-  void event_record (void* ev) override { HIP_CHECK (hipEventRecord ((hipEvent_t)ev, stream_)); }
-  float event_elapsed_ms (void* a, void* b) override { float ms = 0.f; HIP_CHECK (hipEventSynchronize ((hipEvent_t)b)); HIP_CHECK (hipEventElapsedTime (&ms, (hipEvent_t)a, (hipEvent_t)b)); return ms; }
+  void* event_create() override { hipEvent_t e = nullptr; HIP_TRY (hipEventCreate (&e)); return (void*)e; }
+  void event_destroy (void* ev) override { if (ev) HIP_TRY (hipEventDestroy ((hipEvent_t)ev)); }
+  void event_record (void* ev) override { if (ev) HIP_TRY (hipEventRecord ((hipEvent_t)ev, stream_)); }
+  float event_elapsed_ms (void* a, void* b) override { float ms = 0.f; if (!a || !b) return ms; HIP_TRY (hipEventSynchronize ((hipEvent_t)b)); HIP_TRY (hipEventElapsedTime (&ms, (hipEvent_t)a, (hipEvent_t)b)); return ms; }
   hipStream_t stream() const { return stream_; }
  private:
   int dev_;
@@ -410,9 +456,24 @@ class HipBackend : public wh::Backend {
   hipStream_t stream_ = nullptr;          // the selected queue
   std::vector<hipStream_t> streams_;
   uint32_t* err_ = nullptr;
-  std::vector<void*> slabs_;
-  size_t slab_size_ = 0, slab_used_ = 0;
+  struct Slab { uint8_t* base; size_t size, used; };
+  std::vector<Slab> slabs_;
+  std::map<uintptr_t, size_t> free_;                     // address -> bytes, coalesced
+  std::unordered_map<uintptr_t, size_t> live_;           // what alloc() handed out
+  size_t total_asked_ = 0;
+  hipError_t hip_err_ = hipSuccess;
   std::string name_;
+  bool same_slab (uintptr_t a, uintptr_t b) const {
+    for (const Slab& sl : slabs_) { const uintptr_t lo = (uintptr_t)sl.base, hi = lo + sl.size; if (a >= lo && a < hi) return b >= lo && b < hi; }
+    return false;
+  }
+  void note_error (hipError_t e, const char* what, int line) {
+    (void)hipGetLastError();
+    if (hip_err_ != hipSuccess) return;
+    hip_err_ = e;
+    fprintf (stderr, "welship: HIP error %s in %s (hip_backend.hip:%d); the session reports failure\n", hipGetErrorString (e), what, line);
+  }
+  void note_null() { if (hip_err_ == hipSuccess) { hip_err_ = hipErrorOutOfMemory; fprintf (stderr, "welship: device memory exhausted; the session reports failure\n"); } }
 };
 
 }  // namespace
@@ -426,7 +487,9 @@ Backend* create_hip_backend (int device, const char** err) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties (&prop, device) != hipSuccess) { if (err) *err = "hipGetDeviceProperties failed"; return nullptr; }
   if (std::string (prop.gcnArchName).find ("gfx950") == std::string::npos) { if (err) *err = "device is not gfx950 (this library is built for MI355X only)"; return nullptr; }
-  return new HipBackend (device, prop);
+  HipBackend* be = new HipBackend (device, prop);
+  if (!be->usable()) { delete be; if (err) *err = "HIP stream / memory set-up failed on the device"; return nullptr; }
+  return be;
 }
 Backend* create_default_backend (int device, const char** err) { return create_hip_backend (device, err); }
 

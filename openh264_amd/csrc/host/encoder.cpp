@@ -53,6 +53,7 @@ struct SessionCore {
   bool prev_src_dirty = false;        // that slot received a new upload since the frame was begun
   WhMbRecord* d_records = nullptr;
   uint16_t* d_order = nullptr;
+  int32_t* d_bands = nullptr;
   uint32_t* d_dbflags = nullptr;
   uint32_t db_gen = 0;
   size_t rec_alloc_bytes = 0, src_bytes = 0, ysz = 0, csz = 0;
@@ -201,39 +202,60 @@ struct SessionCore {
     ysz = (size_t)s.src_stride_y * mb_h * 16; csz = (size_t)s.src_stride_c * mb_h * 8; src_bytes = ysz + 2 * csz;
     h_src.assign (src_bytes, 0);
     memset (h_src.data() + ysz, 0x80, 2 * csz);     // CWelsPreProcess::Padding: luma 0, chroma 0x80
-    d_src.resize (ring);
-    for (int i = 0; i < ring; ++i) d_src[i] = (uint8_t*)be->alloc (src_bytes);
+    // ---- device memory: everything is allocated first; a failure releases what was taken and fails the call ----
+    bool oom = false;
+    auto A = [&] (size_t n) { void* p = be->alloc (n); if (!p) oom = true; return p; };
+    d_src.assign (ring, nullptr);
+    for (int i = 0; i < ring; ++i) d_src[i] = (uint8_t*)A (src_bytes);
     const int rec_h = mb_h * 16 + 64;
     const size_t rec_y = (size_t)s.rec_stride_y * rec_h, rec_c = (size_t)s.rec_stride_c * (rec_h / 2);
     rec_alloc_bytes = rec_y + 2 * rec_c;
     for (int i = 0; i < 2; ++i) {
+      pic[i].base = (uint8_t*)A (rec_alloc_bytes + 128);     // 64 guard bytes either side (aligned window loads)
+      pic[i].mbs = (WhMbState*)A (sizeof (WhMbState) * num_mb);
+    }
+    d_records = (WhMbRecord*)A (sizeof (WhMbRecord) * num_mb);
+    // processing order tables (common/mb_order.h): per slice, whole picture, per deblocking band
+    std::vector<uint16_t> order ((size_t)num_mb * 3);
+    const char* band_env = getenv ("WELSHIP_MB_BAND");      // experiment knob: rows per band of the per-slice order (0 = one band)
+    const int band = band_env ? atoi (band_env) : 0;
+    for (int i = 0; i < s.num_slices; ++i) wh_build_mb_order (mb_w, s.slice_first_mb[i], s.slice_first_mb[i + 1], order.data() + s.slice_first_mb[i], band);
+    wh_build_mb_order (mb_w, 0, num_mb, order.data() + num_mb);
+    // deblocking bands: after the slice fall-backs above, i.e. for the idc the device really runs
+    std::vector<int32_t> bands (3 * (size_t) (mb_h + s.num_slices) + 1);
+    const char* brows_env = getenv ("WELSHIP_DB_BAND_ROWS");     // experiment knobs: rows per deblocking band (default WH_DB_BAND_ROWS),
+    const int brows = brows_env && atoi (brows_env) > 0 ? atoi (brows_env) : WH_DB_BAND_ROWS;   // bands confined to slices also with idc 0
+    const bool by_slice = !(getenv ("WELSHIP_DB_BY_SLICE") && atoi (getenv ("WELSHIP_DB_BY_SLICE")) == 0);
+    const int nb = wh_build_db_bands (mb_w, mb_h, s.num_slices, s.slice_first_mb, s.deblock_idc, brows, bands.data(), (int)bands.size(), by_slice);
+    if (nb < 1) { set_err ("deblocking band table"); release(); return WELSHIP_ERR_UNKNOWN; }
+    for (int b = 0; b < nb; ++b) wh_build_mb_order (mb_w, bands[b], bands[b + 1], order.data() + 2 * (size_t)num_mb + bands[b]);
+    d_order = (uint16_t*)A (order.size() * 2);
+    d_bands = (int32_t*)A (sizeof (int32_t) * (3 * (size_t)nb + 1));
+    d_scene = (uint32_t*)A (64);
+    d_dbflags = (uint32_t*)A (sizeof (uint32_t) * num_mb);
+    if (oom) { set_err ("out of device memory"); release(); return WELSHIP_ERR_MEMORY; }
+    for (int i = 0; i < 2; ++i) {
       DevPicture& d = pic[i];
-      d.base = (uint8_t*)be->alloc (rec_alloc_bytes + 128);     // 64 guard bytes either side (aligned window loads)
       be->fill (d.base, 0, rec_alloc_bytes + 128);
       d.plane[0] = d.base + 64 + (size_t)32 * s.rec_stride_y + 32;
       d.plane[1] = d.base + 64 + rec_y + (size_t)16 * s.rec_stride_c + 16;
       d.plane[2] = d.base + 64 + rec_y + rec_c + (size_t)16 * s.rec_stride_c + 16;
-      d.mbs = (WhMbState*)be->alloc (sizeof (WhMbState) * num_mb);
       be->fill (d.mbs, 0, sizeof (WhMbState) * num_mb);
     }
-    d_records = (WhMbRecord*)be->alloc (sizeof (WhMbRecord) * num_mb);
     h_records.resize (num_mb);
     be->pin_host (h_records.data(), sizeof (WhMbRecord) * num_mb);     // D2H target of every frame
-    {
-      // processing order tables (kernels/frame_kernels.h wh_build_mb_order): per slice, then whole picture
-      std::vector<uint16_t> order ((size_t)num_mb * 2);
-      const char* band_env = getenv ("WELSHIP_MB_BAND");      // experiment knob: rows per band of the per-slice order (0 = one band)
-      const int band = band_env ? atoi (band_env) : 0;
-      for (int i = 0; i < s.num_slices; ++i) wh_build_mb_order (mb_w, s.slice_first_mb[i], s.slice_first_mb[i + 1], order.data() + s.slice_first_mb[i], band);
-      wh_build_mb_order (mb_w, 0, num_mb, order.data() + num_mb);
-      d_order = (uint16_t*)be->alloc (order.size() * 2);
-      be->upload (d_order, order.data(), order.size() * 2);
-      be->sync();
-      s.mb_order = d_order;
-    }
-    d_scene = (uint32_t*)be->alloc (64);
-    d_dbflags = (uint32_t*)be->alloc (sizeof (uint32_t) * num_mb);
+    be->upload (d_order, order.data(), order.size() * 2);
+    be->upload (d_bands, bands.data(), sizeof (int32_t) * (3 * (size_t)nb + 1));
     be->fill (d_dbflags, 0, sizeof (uint32_t) * num_mb);
+    if (be->sync()) { set_err ("device error while setting up the session"); release(); return WELSHIP_ERR_UNKNOWN; }
+    s.mb_order = d_order;
+    s.db_num_bands = nb;
+    s.db_bands = d_bands;
+    s.db_max_mbs = 0; s.db_max_rows = 0;
+    for (int b = 0; b < nb; ++b) {
+      s.db_max_mbs = std::max (s.db_max_mbs, bands[b + 1] - bands[b]);
+      s.db_max_rows = std::max (s.db_max_rows, (bands[b + 1] - 1) / mb_w - bands[b] / mb_w + 1);
+    }
     // level (au_set.cpp:530-545): the reference feeds iSpatialBitrate even with RC off
     level_idc = wh::select_level_idc (mb_w, mb_h, 1, p->fMaxFrameRate, p->iTargetBitrate, &level_1b);
     // GetMvMvdRange (encoder_ext.cpp:1508-1532): min (|MinVmv| >> 2, MaxVmv >> 2, 64) of the level just chosen --
@@ -253,6 +275,8 @@ struct SessionCore {
     if (!h_records.empty()) be->unpin_host (h_records.data());
     if (d_order) be->free (d_order);
     d_order = nullptr;
+    if (d_bands) be->free (d_bands);
+    d_bands = nullptr;
     if (d_dbflags) be->free (d_dbflags);
     d_dbflags = nullptr;
     if (d_mb_ctl) be->free (d_mb_ctl);
@@ -344,6 +368,7 @@ struct SessionCore {
     if (overflow_mb < 0 || overflow_mb >= num_mb) return WELSHIP_ERR_UNKNOWN;
     if (h_mb_ctl.empty()) { h_mb_ctl.resize (num_mb); memset (h_mb_ctl.data(), 0, sizeof (WhMbCtl) * num_mb); }
     if (!d_mb_ctl) d_mb_ctl = (WhMbCtl*)be->alloc (sizeof (WhMbCtl) * num_mb);
+    if (!d_mb_ctl) { set_err ("out of device memory"); return WELSHIP_ERR_MEMORY; }
     // `pCurMb->uiLumaQp < 50` (svc_encode_slice.cpp:572,1863); beyond that the reference gives up on the frame with
     // cmMallocMemeError (welsEncoderExt.cpp:415-420)
     if (overflow_qp >= 50) { set_err ("bitstream overflow that raising the macroblock QP cannot resolve (reference: cmMallocMemeError)"); return WELSHIP_ERR_MEMORY; }
@@ -646,6 +671,7 @@ int WelsHipInitializeExt (WelsHipEncoder* e, const WelsHipEncParam* p) {
   rc = e->core.init (e->be, p, 2);
   if (rc) { e->core.release(); delete e->be; e->be = nullptr; return rc; }
   e->d_job = (WhPicJob*)e->be->alloc (sizeof (WhPicJob));
+  if (!e->d_job) { set_err ("out of device memory"); e->core.release(); delete e->be; e->be = nullptr; return WELSHIP_ERR_MEMORY; }
   e->inited = true;
   return WELSHIP_OK;
 }
@@ -791,6 +817,7 @@ int WelsHipGroupCreate (WelsHipEncoderGroup** pp, const WelsHipEncParam* p, int 
     if (rc) { for (auto& s : g->sess) s->release(); delete be; delete g; return rc; }
   }
   g->d_jobs = (WhPicJob*)be->alloc (sizeof (WhPicJob) * n_sessions);
+  if (!g->d_jobs) { set_err ("out of device memory"); for (auto& s : g->sess) s->release(); delete be; delete g; return WELSHIP_ERR_MEMORY; }
   g->h_jobs.resize (n_sessions);
   if (const char* q = getenv ("WELSHIP_QUEUES")) g->queues = std::max (1, std::min (atoi (q), n_sessions));
   *pp = g;

@@ -204,8 +204,10 @@ WH_HDFN size_t wh_db_xchg_words (int mb_w, int rows) { return (size_t)mb_w * 24 
 // receives them through `E`, possibly filters them, and writes them.  Without such a neighbour the MB writes them itself.
 // Returns true when the caller must drain this wave's stores before it flags the MB done inside the workgroup (the MB
 // rewrote samples of another slice's MBs that a later MB of this workgroup reads back from the picture).
+// `xwg`: a later band (another workgroup) reads samples this MB writes: its stores go through to memory (wh_st_xwg32); strips
+// that come from the picture instead of `E` were written that way by the band above and are loaded past the caches.
 WH_FN bool wh_deblock_mb_body (WhDbLds& S, WhDbStage& G, const WhDbXchg& E, int first, int last, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby,
-                               int next_valid, int next_mbx, int next_mby) {
+                               int next_valid, int next_mbx, int next_mby, bool xwg) {
   WH_PROF_DECL (P);
   const int w = P.mb_w, xy = mby * w + mbx;
   const bool top_lds = mby > 0 && xy - w >= first, left_lds = mbx > 0 && xy - 1 >= first;
@@ -220,19 +222,19 @@ WH_FN bool wh_deblock_mb_body (WhDbLds& S, WhDbStage& G, const WhDbXchg& E, int 
     if (lane < 16) {
       const int r = lane >> 2, wd = lane & 3;
       if (top_lds) v = etop[lane];
-      else if (mby > 0) v = * (const WH_G uint32_t*) ((const WH_G uint8_t*)J.rec[0] + (ptrdiff_t) (mby * 16 + r - 4) * P.rec_stride_y + mbx * 16 + wd * 4);
+      else if (mby > 0) v = wh_ld_xwg32 ((const WH_G uint32_t*) ((const WH_G uint8_t*)J.rec[0] + (ptrdiff_t) (mby * 16 + r - 4) * P.rec_stride_y + mbx * 16 + wd * 4));
     } else if (lane < 32) {
       const int row = lane - 16;
       if (left_lds) v = eleft[row];
-      else if (mbx > 0) v = * (const WH_G uint32_t*) ((const WH_G uint8_t*)J.rec[0] + (ptrdiff_t) (mby * 16 + row) * P.rec_stride_y + mbx * 16 - 4);
+      else if (mbx > 0) v = wh_ld_xwg32 ((const WH_G uint32_t*) ((const WH_G uint8_t*)J.rec[0] + (ptrdiff_t) (mby * 16 + row) * P.rec_stride_y + mbx * 16 - 4));
     } else if (lane < 40) {
       const int k = lane - 32, pl = k >> 2, r = (k >> 1) & 1, wd = k & 1;
       if (top_lds) v = etop[16 + k];
-      else if (mby > 0) v = * (const WH_G uint32_t*) ((const WH_G uint8_t*)J.rec[1 + pl] + (ptrdiff_t) (mby * 8 + r - 2) * P.rec_stride_c + mbx * 8 + wd * 4);
+      else if (mby > 0) v = wh_ld_xwg32 ((const WH_G uint32_t*) ((const WH_G uint8_t*)J.rec[1 + pl] + (ptrdiff_t) (mby * 8 + r - 2) * P.rec_stride_c + mbx * 8 + wd * 4));
     } else if (lane < 56) {
       const int k = lane - 40, pl = k >> 3, row = k & 7;
       if (left_lds) v = eleft[16 + k];
-      else if (mbx > 0) v = * (const WH_G uint32_t*) ((const WH_G uint8_t*)J.rec[1 + pl] + (ptrdiff_t) (mby * 8 + row) * P.rec_stride_c + mbx * 8 - 4);
+      else if (mbx > 0) v = wh_ld_xwg32 ((const WH_G uint32_t*) ((const WH_G uint8_t*)J.rec[1 + pl] + (ptrdiff_t) (mby * 8 + row) * P.rec_stride_c + mbx * 8 - 4));
     }
     S.st[lane] = G.st[lane];
     if (lane < 44) S.st[64 + lane] = G.st[64 + lane];
@@ -363,7 +365,11 @@ WH_FN bool wh_deblock_mb_body (WhDbLds& S, WhDbStage& G, const WhDbXchg& E, int 
       if (row < 0) wr = x >= 0 && (top_lds ? true : (filtered && top_ok && row >= -3));
       else if (x < 0) wr = left_lds ? (row < 12 || lb_none) : (filtered && left_ok);
       else wr = filtered && (row < 12 || !below_in) && (x < 12 || !right_in);
-      if (wr) * (WH_G uint32_t*) (ry + (ptrdiff_t)row * P.rec_stride_y + x) = * (const uint32_t*)&WH_DY (S, x, row);
+      if (wr) {
+        WH_G uint32_t* d = (WH_G uint32_t*) (ry + (ptrdiff_t)row * P.rec_stride_y + x);
+        const uint32_t v = * (const uint32_t*)&WH_DY (S, x, row);
+        if (xwg) wh_st_xwg32 (d, v); else *d = v;
+      }
     }
     if (lane < 60) {
       const int pl = lane / 30, k = lane % 30, row = k / 3 - 2, x = (k % 3) * 4 - 4;
@@ -371,7 +377,11 @@ WH_FN bool wh_deblock_mb_body (WhDbLds& S, WhDbStage& G, const WhDbXchg& E, int 
       if (row < 0) wr = x >= 0 && (top_lds ? true : (filtered && top_ok && row >= -1));
       else if (x < 0) wr = left_lds ? (row < 6 || lb_none) : (filtered && left_ok);
       else wr = filtered && (row < 6 || !below_in) && (x < 4 || !right_in);
-      if (wr) * (WH_G uint32_t*) ((WH_G uint8_t*)J.rec[1 + pl] + (ptrdiff_t) (mby * 8 + row) * P.rec_stride_c + mbx * 8 + x) = * (const uint32_t*)&WH_DC (S, pl, x, row);
+      if (wr) {
+        WH_G uint32_t* d = (WH_G uint32_t*) ((WH_G uint8_t*)J.rec[1 + pl] + (ptrdiff_t) (mby * 8 + row) * P.rec_stride_c + mbx * 8 + x);
+        const uint32_t v = * (const uint32_t*)&WH_DC (S, pl, x, row);
+        if (xwg) wh_st_xwg32 (d, v); else *d = v;
+      }
     }
   }
   WV_LANES_END

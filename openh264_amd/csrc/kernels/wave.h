@@ -74,6 +74,10 @@ WH_FN void wh_ld_async4 (const void* src, uint32_t* lds_base, int lane) { memcpy
 // same with 16 bytes per lane (lds_base 16-byte aligned, lane i fills bytes [16 i, 16 i + 16))
 WH_FN void wh_ld_async16 (const void* src, void* lds_base, int lane) { memcpy ((uint8_t*)lds_base + 16 * lane, src, 16); }
 #define WV_ASYNC_WAIT() ((void)0)
+// One word to / from global memory that ANOTHER workgroup (any XCD) produces / consumes inside the same launch: on the GPU
+// a write-through store and a cache-bypassing load (sc0 sc1) -- see the device twins below.
+WH_FN void wh_st_xwg32 (uint32_t* p, uint32_t v) { *p = v; }
+WH_FN uint32_t wh_ld_xwg32 (const uint32_t* p) { return *p; }
 // four bytes at any byte offset of a 4-byte aligned LDS array
 WH_FN uint32_t wh_ld4u (const uint8_t* base, int off) { uint32_t v; memcpy (&v, base + off, 4); return v; }
 // sum of absolute differences of four packed bytes
@@ -182,6 +186,13 @@ WH_FN void wh_ld_async16 (const WH_G void* src, void* lds_base, int /*lane*/) {
   __builtin_amdgcn_global_load_lds ((const WH_G uint32_t*)src, (__attribute__ ((address_space (3))) uint32_t*)lds_base, 16, 0, 0);
 }
 #define WV_ASYNC_WAIT() asm volatile ("s_waitcnt vmcnt(0)" ::: "memory")
+// Cross-workgroup payload inside one launch (deblocking bands): `global_store_dword ... sc0 sc1` writes through the XCD's
+// L2 and `global_load_dword ... sc0 sc1` bypasses L1 and any stale L2 line, so producer and consumer need no agent-scope
+// release (buffer_wbl2: writes back EVERY dirty line of the XCD's L2) / acquire (buffer_inv: empties the CU's L1 for all
+// its waves) around the hand-off -- only the producer's s_waitcnt vmcnt(0) before its flag store
+// (MI355X_MICROARCH.md, inter-workgroup visibility: "sc0 sc1 stores and loads both sides").
+WH_FN void wh_st_xwg32 (WH_G uint32_t* p, uint32_t v) { __hip_atomic_store (p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+WH_FN uint32_t wh_ld_xwg32 (const WH_G uint32_t* p) { return __hip_atomic_load (p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 WH_FN int wh_sad4 (uint32_t a, uint32_t b) { return (int)__builtin_amdgcn_sad_u8 (a, b, 0u); }
 WH_FN uint32_t wh_avg4 (uint32_t a, uint32_t b) { return __builtin_amdgcn_lerp (a, b, 0x01010101u); }
 #endif

@@ -67,23 +67,23 @@ class EmuBackend : public Backend {
       }
   }
   void run_deblock (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
-    // one emulated wavefront per slice (slice s after slice s-1, which satisfies the seam dependencies), with the device
-    // scheduler's one-MB look-ahead and its strip exchange: neighbours inside the slice through the exchange buffers,
-    // neighbours in the previous slice through the picture
+    // one emulated wavefront per band (band b after band b-1, which satisfies the seam dependencies), with the device
+    // scheduler's one-MB look-ahead and its strip exchange: neighbours inside the band through the exchange buffers,
+    // neighbours in the previous band through the picture
     for (int j = 0; j < n; ++j)
-      for (int s = 0; s < P.num_slices; ++s) {
+      for (int s = 0; s < P.db_num_bands; ++s) {
         WhDbLds S;
         WhDbStage G;
         std::vector<uint32_t> xb (wh_db_xchg_words (P.mb_w, P.mb_h), 0xA5A5A5A5u);
         WhDbXchg E;
         E.top = xb.data(); E.left = xb.data() + (size_t)P.mb_w * 24; E.first_row = 0;
         poison (&S, sizeof (S)); poison (&G, sizeof (G));
-        const int first = P.slice_first_mb[s], last = P.slice_first_mb[s + 1];
-        const uint16_t* order = P.mb_order;
+        const int first = P.db_bands[s], last = P.db_bands[s + 1];
+        const uint16_t* order = P.mb_order + 2 * P.mb_w * P.mb_h;
         for (int lane = 0; lane < 64; ++lane) wh_deblock_cold_fetch (G, lane, P, jobs[j], order[first] % P.mb_w, order[first] / P.mb_w);
         for (int t = first; t < last; ++t) {
           const int xy = order[t], xyn = t + 1 < last ? order[t + 1] : 0;
-          (void)wh_deblock_mb_body (S, G, E, first, last, P, jobs[j], xy % P.mb_w, xy / P.mb_w, t + 1 < last, xyn % P.mb_w, xyn / P.mb_w);
+          (void)wh_deblock_mb_body (S, G, E, first, last, P, jobs[j], xy % P.mb_w, xy / P.mb_w, t + 1 < last, xyn % P.mb_w, xyn / P.mb_w, true);
           poison (&S, sizeof (S));
         }
       }
