@@ -1,15 +1,25 @@
 #!/usr/bin/env python3
-"""bench.py -- hot-path throughput of the MI355X macroblock engine ("Measurement").
+"""bench.py -- throughput of the MI355X macroblock engine on BASELINE.json's metric ("Measurement").
 
     python bench.py --gpus N --steps K --warmup W
 
-A *step* is one pass of the hot path (mode decision + reconstruction, in-loop deblocking, border
-expansion) over one batch: `--sessions` independent 1080p pictures per GPU (default 128 = two slice
-workgroups per CU), sources already resident in HBM, MB records left in HBM.
-value = pictures processed by all ranks / time.
-Multi-GPU: one process per GPU, sessions sharded over ranks, no data-path collective ("weak").
-Extra objects on the JSON line: `roofline` (dominant kernel, HIP events on the launch stream) and
-`cpu_baseline` (the reference itself, oracle/_ref, timed on this box's host cores, rank 0, N=1).
+A *step* is one pass of the hot path (mode decision + reconstruction, in-loop deblocking, border expansion) over one
+batch: `--sessions` independent 1080p pictures per GPU (default 128 = two slice workgroups per CU), every session with its
+own content, sources already resident in HBM, MB records left in HBM.  value = pictures processed by all ranks / time.
+
+With --gpus N > 1 and no torchrun environment the script launches the N ranks itself (one process per GPU, sessions
+sharded over ranks, no data-path collective: "weak" scaling); under torchrun it is one of the ranks.
+
+The JSON line (last line of stdout, rank 0) carries, besides the contract's keys:
+  roofline       dominant kernel, algorithmic bytes per launch / HIP-event launch time (events on the launch stream)
+  verified       the reconstructions the timed steps left behind (sessions 0 and N-1) equal the reference decoder's output of
+                 the reference encoder's stream for the same frame order (oracle/_ref, run live) -- the run fails otherwise
+  e2e            complete EncodeFrame rate incl. source upload, D2H of the MB records and host CAVLC (the PCIe/host-inclusive
+                 figure; never `value`)
+  latency        per-frame wall time of complete EncodeFrame calls with 1 and 8 sessions on the GPU
+  res_clip       the same hot-path step on the reference's own 1080p clip (res/VID_1920x1080_cavlc_temporal_direct.264 decoded)
+  intra_720p     BASELINE config 2: all-IDR 1280x720 on the reference's 720p clip, hot path, with its own roofline fraction
+  cpu_baseline   the reference itself (oracle/_ref, C fallback, no asm) on this box's host cores: 1 thread and 4 slice threads
 """
 import argparse
 import json
@@ -28,53 +38,224 @@ BYTES_I_MB_PATH = 2496
 BYTES_I_MB_MD = 384 + 384 + 960  # the mode-decision/reconstruction kernel's share (dominant kernel)
 BYTES_P_MB_PATH = 2912
 BYTES_P_MB_MD = 384 + 384 + 384 + 960 + 32
+REF_DIR = os.path.join(ROOT, "oracle", "_ref")
+RES_DIR = os.path.join(REF_DIR, "res")
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--sessions", type=int, default=int(os.environ.get("WELSHIP_BENCH_SESSIONS", "0")),
-                    help="independent pictures per GPU per step (default: 128 for the P workload = two slice workgroups per CU, 256 for all-IDR = one picture workgroup per CU)")
-    ap.add_argument("--queues", type=int, default=int(os.environ.get("WELSHIP_QUEUES", "1")), help="device queues the sessions are spread over (kernels of different queues overlap)")
+                    help="independent pictures per GPU per step (default: 128 for the P workload = two slice workgroups per CU, 256 for all-IDR)")
+    ap.add_argument("--queues", type=int, default=int(os.environ.get("WELSHIP_QUEUES", "1")), help="device queues the sessions are spread over")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--qp", type=int, default=24)
-    ap.add_argument("--workload", default="auto", choices=["auto", "intra", "p"])
+    ap.add_argument("--workload", default="p", choices=["intra", "p"])
+    ap.add_argument("--content", default="synthetic", choices=["synthetic", "res"], help="res: the reference's own clip of that size (oracle/_ref/res)")
+    ap.add_argument("--quick", action="store_true", help="only the headline leg (no e2e / latency / res clip / intra / cpu baseline / verification)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--e2e", action="store_true", help="also time the full encode incl. D2H + host CAVLC")
+    ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the e2e, latency, res-clip and intra legs")
     ap.add_argument("--host-threads", type=int, default=min(32, os.cpu_count() or 8))
     ap.add_argument("--deblock-idc", type=int, default=0, help="disable_deblocking_filter_idc (0: filter across slice boundaries, the reference default)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.quick:
+        a.no_cpu_baseline = a.no_verify = a.no_extra = True
+    return a
 
 
-def cpu_baseline(width, height, qp, workload, frames_src):
-    """Time the reference (oracle/_ref/ref_enc, C fallback, 1 thread) on a bounded sample of the same workload."""
-    enc = os.path.join(ROOT, "oracle", "_ref", "ref_enc")
-    if not os.path.exists(enc):
+# ---------------------------------------------------------------------------------------------------------- inputs
+def decode_res_clip(name):
+    """The reference's clip decoded by the reference decoder (oracle/_ref/ref_dec), or None when the oracle is not built."""
+    dec, src = os.path.join(REF_DIR, "ref_dec"), os.path.join(RES_DIR, name)
+    if not (os.path.exists(dec) and os.path.exists(src)):
         return None
-    fsz = width * height * 3 // 2
-    n_unique = len(frames_src) // fsz
-    n = 96 if width * height > 1280 * 720 else 200          # ~ 5-10 s of single-core work
     with tempfile.TemporaryDirectory() as td:
-        fi = os.path.join(td, "in.yuv")
-        with open(fi, "wb") as f:
-            period = max(1, 2 * (n_unique - 1))
-            for i in range(n):
-                k = i % period if n_unique > 1 else 0
-                k = k if k < n_unique else period - k
-                f.write(frames_src[k * fsz:(k + 1) * fsz])
-        flags = ["-rc", "-1", "-qp", str(qp), "-fps", "30", "-quiet", "-threads", "1"]
-        flags += ["-iper", "1"] if workload == "intra" else ["-iper", "0", "-slcmd", "1", "-slcnum", "4"]
-        out = subprocess.check_output([enc, "-i", fi, "-w", str(width), "-h", str(height)] + flags).decode()
-    kv = dict(t.split("=") for t in out.split())
-    return {"value": float(kv["fps"]), "unit": "frames/s", "cores": 1, "kind": "reference",
-            "sample": "%d frames %dx%d, oracle/_ref (reference C fallback, no asm), 1 thread, timed around EncodeFrame" % (n, width, height)}
+        out = os.path.join(td, "clip.yuv")
+        subprocess.check_call([dec, src, out], stdout=subprocess.DEVNULL)
+        return open(out, "rb").read()
+
+
+def slot_of(i, ring):
+    """Source slot of the i-th step of a WelsHipGroupBench call (ping-pong over the resident ring)."""
+    if ring == 1:
+        return 0
+    period = 2 * (ring - 1)
+    k = i % period
+    return k if k < ring else period - k
+
+
+class Content:
+    """Which frame sits in which resident slot of which session: session s, slot j -> frame (first(s) + j) of the clip."""
+
+    def __init__(self, frames, fsz, ring, consecutive):
+        self.frames, self.fsz, self.ring = frames, fsz, ring
+        self.n = len(frames) // fsz
+        self.consecutive = consecutive              # real clip: `ring` consecutive frames from a per-session offset
+
+    def frame(self, s, slot):
+        if self.consecutive:
+            k = (s * 5) % max(1, self.n - self.ring + 1) + slot
+        else:
+            k = (slot + s) % self.n                 # synthetic: every session starts at a different phase of the motion
+        return self.frames[k * self.fsz:(k + 1) * self.fsz]
+
+
+def cpu_info():
+    model = "?"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
+    return {"model": model, "logical_cores": os.cpu_count()}
+
+
+# ------------------------------------------------------------------------------------------------- reference legs
+def ref_encode(yuv, w, h, flags, want_fps=False):
+    enc = os.path.join(REF_DIR, "ref_enc")
+    with tempfile.TemporaryDirectory() as td:
+        fi, fo = os.path.join(td, "in.yuv"), os.path.join(td, "out.264")
+        open(fi, "wb").write(yuv)
+        out = subprocess.check_output([enc, "-i", fi, "-w", str(w), "-h", str(h), "-o", fo, "-rc", "-1", "-fps", "30"] + flags).decode()
+        bs = open(fo, "rb").read()
+    if want_fps:
+        kv = dict(t.split("=") for t in out.split())
+        return bs, float(kv["fps"])
+    return bs
+
+
+def ref_decode_last_frame(bs, w, h):
+    dec = os.path.join(REF_DIR, "ref_dec")
+    with tempfile.TemporaryDirectory() as td:
+        fi, fo = os.path.join(td, "in.264"), os.path.join(td, "out.yuv")
+        open(fi, "wb").write(bs)
+        subprocess.check_call([dec, fi, fo], stdout=subprocess.DEVNULL)
+        fsz = w * h * 3 // 2
+        with open(fo, "rb") as f:
+            f.seek(-fsz, 2)
+            return f.read()
+
+
+def p_flags(qp, idc):
+    return ["-iper", "0", "-qp", str(qp), "-slcmd", "1", "-slcnum", "4", "-deblock", str(idc)]
+
+
+def cpu_baseline(w, h, qp, workload, content, idc):
+    """Time the reference (oracle/_ref/ref_enc, C fallback) on a bounded sample of the same workload: 1 thread, and 4 slice
+    threads with -loadbalancing 0 and deblocking idc 2 (what the threaded reference needs for a deterministic stream)."""
+    if not os.path.exists(os.path.join(REF_DIR, "ref_enc")):
+        return None
+    n = 96 if w * h > 1280 * 720 else 200
+    ring = content.ring
+    yuv = b"".join(content.frame(0, slot_of(i, ring)) for i in range(n))
+    base = ["-iper", "1"] if workload == "intra" else p_flags(qp, idc)
+    _, fps1 = ref_encode(yuv, w, h, base + ["-quiet", "-threads", "1"], True)
+    out = {"value": fps1, "unit": "frames/s", "cores": 1, "kind": "reference", "host": cpu_info(),
+           "sample": "%d frames %dx%d of session 0's frame order, oracle/_ref (reference C fallback, no asm: no nasm in the image), timed around EncodeFrame" % (n, w, h)}
+    if workload == "p":
+        flags4 = ["-iper", "0", "-qp", str(qp), "-slcmd", "1", "-slcnum", "4", "-deblock", "2", "-quiet", "-threads", "4", "-loadbalancing", "0"]
+        _, fps4 = ref_encode(yuv, w, h, flags4, True)
+        out["threads4"] = {"value": fps4, "unit": "frames/s", "cores": 4, "flags": "-threads 4 -loadbalancing 0 -deblock 2"}
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------- GPU legs
+def make_group(oh, a, local, w, h, workload, sessions, ring, content, idc=None):
+    e = oh.Encoder()
+    p = e.GetDefaultParams()
+    e.close()
+    p.iPicWidth, p.iPicHeight, p.iDLayerQp, p.fMaxFrameRate, p.iTargetBitrate = w, h, a.qp, 30.0, 5000000
+    p.iDevice = local
+    p.iLoopFilterDisableIdc = a.deblock_idc if idc is None else idc
+    if workload == "intra":
+        p.uiIntraPeriod = 1
+    else:
+        p.uiIntraPeriod = 0
+        p.uiSliceMode, p.uiSliceNum = 1, 4
+    g = oh.EncoderGroup(p, sessions, ring_slots=ring, host_threads=a.host_threads)
+    if content is not None:
+        for s in range(sessions):
+            for slot in range(ring):
+                g.upload(s, slot, content.frame(s, slot))
+    return g
+
+
+def hot_path_leg(oh, a, local, w, h, workload, sessions, ring, content, steps, warmup, barrier=None, verify_sessions=()):
+    """IDR (P workload) + warmup + `steps` timed device-only steps.  Returns (wall seconds of the timed steps, event dict,
+    verification result or None)."""
+    g = make_group(oh, a, local, w, h, workload, sessions, ring, content)
+    order = []                                       # source slots in coding order (the reference is fed the same frames)
+    if workload == "p":
+        g.bench(1, 0)                                # the IDR that starts every stream is not part of the timed P steps
+        order.append(slot_of(0, ring))
+    if barrier:
+        barrier()
+    if warmup > 0:
+        g.bench(warmup, 0)
+        order += [slot_of(i, ring) for i in range(warmup)]
+    if barrier:
+        barrier()
+    t0 = time.perf_counter()
+    ev = g.bench(steps, 0)
+    if barrier:
+        barrier()
+    dt = time.perf_counter() - t0
+    order += [slot_of(i, ring) for i in range(steps)]
+    verified = None
+    if verify_sessions:
+        verified = {}
+        for s in verify_sessions:
+            yuv = b"".join(content.frame(s, k) for k in order)
+            flags = (["-iper", "1", "-qp", str(a.qp)] if workload == "intra" else p_flags(a.qp, a.deblock_idc)) + ["-quiet", "-threads", "1"]
+            ref = ref_decode_last_frame(ref_encode(yuv, w, h, flags), w, h)
+            verified[s] = g.recon(s) == ref
+    g.close()
+    return dt, ev, verified
+
+
+def e2e_leg(oh, a, local, w, h, sessions, ring, content, frames, check=False):
+    """Complete EncodeFrame calls (source upload + device + D2H + host CAVLC) for `sessions` concurrent streams."""
+    g = make_group(oh, a, local, w, h, "p", sessions, ring, None)
+    pics = [g.make_pictures([content.frame(s, k) for s in range(sessions)]) for k in range(ring)]
+    order = [0, 1 % ring] + [slot_of(i + 2, ring) for i in range(frames)]
+    bs0 = bytearray()
+    bs0 += g.encode_frames(pics[order[0]], want_bytes=True)[0]       # IDR
+    bs0 += g.encode_frames(pics[order[1]], want_bytes=True)[0]       # first P: page-locking and first-touch effects stay out of the timing
+    t0 = time.perf_counter()
+    nbytes = 0
+    for i in range(frames):
+        out = g.encode_frames(pics[order[i + 2]], want_bytes=check)
+        if check:
+            bs0 += out[0]
+            nbytes += sum(len(b) for b in out)
+        else:
+            nbytes += out
+    dt = time.perf_counter() - t0
+    g.close()
+    match = None
+    if check:      # session 0's bitstream against the reference encoder on the same frames
+        import hashlib
+        ref = ref_encode(b"".join(content.frame(0, k) for k in order), w, h, p_flags(a.qp, a.deblock_idc) + ["-quiet", "-threads", "1"])
+        match = {"match": bytes(bs0) == ref, "sha1": hashlib.sha1(bytes(bs0)).hexdigest(), "reference_sha1": hashlib.sha1(ref).hexdigest(), "frames": len(order)}
+    return dt, nbytes, match
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # one process per GPU; this process only launches them and relays rank 0's line
+        port = 29500 + (os.getpid() % 2000)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        raise SystemExit(subprocess.call(cmd, env=env))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -90,105 +271,132 @@ def main():
     import openh264_amd as oh
     from openh264_amd.utils.synth import synth_sequence
 
-    workload = a.workload
-    if workload == "auto":
-        workload = "p" if getattr(oh, "HAS_INTER_PATH", False) else "intra"
-    if a.sessions <= 0:
-        a.sessions = 128 if workload == "p" else 256
-    w, h = a.width, a.height
-    mbs = ((w + 15) // 16) * ((h + 15) // 16)
-    ring = 2 if workload == "intra" else 8          # the library keeps at least two source slots per session
-    n_unique = 4 if workload == "intra" else ring
-    frames = synth_sequence(w, h, n_unique)
-    fsz = w * h * 3 // 2
-
-    e = oh.Encoder()
-    p = e.GetDefaultParams()
-    e.close()
-    p.iPicWidth, p.iPicHeight, p.iDLayerQp, p.fMaxFrameRate, p.iTargetBitrate = w, h, a.qp, 30.0, 5000000
-    p.iDevice = local
-    p.iLoopFilterDisableIdc = a.deblock_idc
-    if workload == "intra":
-        p.uiIntraPeriod = 1
-    else:
-        p.uiIntraPeriod = 0
-        p.uiSliceMode, p.uiSliceNum = 1, 4
-    g = oh.EncoderGroup(p, a.sessions, ring_slots=ring, host_threads=a.host_threads)
-    for s in range(a.sessions):
-        for slot in range(ring):
-            k = (s + slot) % n_unique if workload == "intra" else slot
-            g.upload(s, slot, frames[k * fsz:(k + 1) * fsz])
-    if workload == "p":
-        g.bench(1, 0)          # the IDR that starts every stream is not part of the timed P-frame steps
-
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    barrier()
-    if a.warmup > 0:
-        g.bench(a.warmup, 0)
-    barrier()
-    t0 = time.perf_counter()
-    ev = g.bench(a.steps, 0)
-    torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
+    workload = a.workload
+    if a.sessions <= 0:
+        a.sessions = 128 if workload == "p" else 256
+    w, h = a.width, a.height
+    mbs = ((w + 15) // 16) * ((h + 15) // 16)
+    fsz = w * h * 3 // 2
+    ring = 2 if workload == "intra" else 8          # the library keeps at least two source slots per session
+    have_ref = os.path.exists(os.path.join(REF_DIR, "ref_enc")) and os.path.exists(os.path.join(REF_DIR, "ref_dec"))
+    if a.content == "res":
+        clip = decode_res_clip("VID_%dx%d_cavlc_temporal_direct.264" % (w, h))
+        if clip is None:
+            raise SystemExit("--content res needs oracle/_ref (ref_dec + res/)")
+        content = Content(clip, fsz, ring, True)
+        data = "res/VID_%dx%d_cavlc_temporal_direct.264 decoded by the reference decoder, %d consecutive frames per session" % (w, h, ring)
+    else:
+        content = Content(synth_sequence(w, h, 4 if workload == "intra" else ring), fsz, ring, False)
+        data = "synthetic"
+
+    verify_sessions = () if (a.no_verify or not have_ref or rank != 0) else tuple(sorted({0, a.sessions - 1}))
+    dt, ev, verified = hot_path_leg(oh, a, local, w, h, workload, a.sessions, ring, content, a.steps, a.warmup, barrier, verify_sessions)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    if rank != 0:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
-    e2e = None
-    if a.e2e and rank == 0:
-        t1 = time.perf_counter()
-        for i in range(a.steps):
-            g.step(i % ring)
-        e2e = a.sessions * a.steps / (time.perf_counter() - t1)
-
-    if rank == 0:
-        pics = a.sessions * a.steps * world
-        nd = 1                                                                # one launch per pass: a workgroup walks a whole slice
-        md_launch_ms = ev["md_ms"] / (a.steps * nd)
+    def roofline(workload, mbs, sessions, steps, ev):
         b_md = BYTES_I_MB_MD if workload == "intra" else BYTES_P_MB_MD
         b_path = BYTES_I_MB_PATH if workload == "intra" else BYTES_P_MB_PATH
-        bytes_per_launch = b_md * mbs * a.sessions / nd                     # every MB of every picture in the batch x bytes/MB
-        achieved = bytes_per_launch / (md_launch_ms * 1e-3) / 1e9
-        traffic = None
-        try:        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this very command
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            if tj.get("workload") == workload and tj.get("sessions") == a.sessions and (w, h) == (tj.get("width"), tj.get("height")):
-                traffic = tj["hbm_bytes_per_launch"]
-        except Exception:
-            pass
-        line = {
-            "metric": "1080p frames/sec/GPU at QP=24 CBP; encoder_binary_comparison SHA1 pass",
-            "value": pics / dt, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8", "data": "synthetic",
-            "config": {"workload": ("%dx%d all-IDR (intra MD + DCT/quant + deblock), QP %d, LOW complexity" % (w, h, a.qp)) if workload == "intra" else
-                       ("%dx%d P-frames, diamond ME range 16, 4 slices/frame, QP %d, LOW complexity" % (w, h, a.qp)),
-                       "pictures_in_flight_per_gpu": a.sessions, "device_queues": a.queues, "hot_path": "device MD/recon + deblock + border expand; sources resident in HBM, MB records left in HBM; host CAVLC excluded",
-                       "parallelism": "sessions sharded over %d GPU(s), no collective" % world},
-            "roofline": {"bound": "hbm", "kernel": "k_intra_slice" if workload == "intra" else "k_inter_slice",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "bytes_per_mb": b_md, "avg_launch_ms": md_launch_ms, "launches_per_step": nd,
-                         "path_achieved_GBs": b_path * mbs * a.sessions * a.steps / (ev["total_ms"] * 1e-3) / 1e9,
-                         "events_ms": ev},
-        }
-        if e2e is not None:
-            line["e2e_frames_per_s_incl_d2h_and_host_cavlc"] = e2e
-            line["host_entropy_threads"] = a.host_threads
-        if world == 1 and not a.no_cpu_baseline:
-            cb = cpu_baseline(w, h, a.qp, workload, frames)
-            if cb:
-                line["cpu_baseline"] = cb
-        print(json.dumps(line))
-    g.close()
+        md_launch_ms = ev["md_ms"] / steps                                   # one launch per pass and step
+        achieved = b_md * mbs * sessions / (md_launch_ms * 1e-3) / 1e9       # every MB of every picture in the batch x bytes/MB
+        return {"bound": "hbm", "kernel": "k_intra_slice" if workload == "intra" else "k_inter_slice",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "bytes_per_mb": b_md, "avg_launch_ms": md_launch_ms, "launches_per_step": 1,
+                "path_achieved_GBs": b_path * mbs * sessions * steps / (ev["total_ms"] * 1e-3) / 1e9,
+                "path_frac": b_path * mbs * sessions * steps / (ev["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "events_ms": ev}
+
+    rf = roofline(workload, mbs, a.sessions, a.steps, ev)
+    rf["traffic"] = None
+    try:        # HBM bytes per launch of the dominant kernel: from the committed rocprofv3 --pmc passes of this very command (not measured in this run)
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+        if tj.get("workload") == workload and tj.get("sessions") == a.sessions and (w, h) == (tj.get("width"), tj.get("height")):
+            rf["traffic"] = tj["hbm_bytes_per_launch"]
+            rf["traffic_source"] = "profiles/r02_pmc_traffic.json (separate rocprofv3 --pmc passes of this command; not measured in this run)"
+    except Exception:
+        pass
+    pics = a.sessions * a.steps * world
+    line = {
+        "metric": json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"],
+        "metric_scope": "value = device hot path (MD + reconstruction + deblocking + border expansion), entropy coding on the host excluded; "
+                        "`verified` = the timed steps' reconstruction equals the reference's, `e2e` = complete EncodeFrame rate with a bitstream SHA1 check",
+        "value": pics / dt, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u8", "data": data,
+        "config": {"workload": ("%dx%d all-IDR (intra MD + DCT/quant + deblock), QP %d, LOW complexity" % (w, h, a.qp)) if workload == "intra" else
+                   ("%dx%d P-frames, diamond ME range 16, 4 slices/frame, QP %d, LOW complexity" % (w, h, a.qp)),
+                   "pictures_in_flight_per_gpu": a.sessions, "device_queues": a.queues,
+                   "hot_path": "device MD/recon + deblock + border expand; sources resident in HBM, MB records left in HBM; host CAVLC excluded (see e2e)",
+                   "note": "throughput needs >= 64 concurrent pictures per GPU; see latency for 1 and 8 sessions",
+                   "parallelism": "sessions sharded over %d GPU(s), no collective" % world},
+        "roofline": rf,
+    }
+    if verified is not None:
+        line["verified"] = all(verified.values())
+        line["verified_detail"] = {"sessions": sorted(verified), "frames_each": 1 + a.warmup + a.steps if workload == "p" else a.warmup + a.steps,
+                                   "against": "oracle/_ref: reference encoder + reference decoder on the same frame order, last reconstruction compared byte for byte"}
+
+    if not a.no_extra and world == 1:
+        # complete EncodeFrame calls: upload + device + D2H + host CAVLC
+        n_e2e = 12
+        de, nbytes, match = e2e_leg(oh, a, local, w, h, a.sessions, ring, content, n_e2e, bool(verify_sessions))
+        line["e2e"] = {"frames_per_s": a.sessions * n_e2e / de, "sessions": a.sessions, "frames_each": n_e2e, "host_entropy_threads": a.host_threads,
+                       "host": cpu_info(), "includes": "source upload (H2D), device passes, D2H of the MB records, host CAVLC + NAL packing",
+                       "bitstream_MB_per_s": nbytes / de / 1e6, "bitstream_vs_reference": match}
+        lat = {}
+        for ns in (1, 8):
+            dl, _, _ = e2e_leg(oh, a, local, w, h, ns, ring, content, 20)
+            lat["sessions_%d" % ns] = {"ms_per_frame": dl / 20 * 1e3, "frames_per_s": ns * 20 / dl}
+        line["latency"] = lat
+        # the same step on the reference's own 1080p clip
+        if a.content == "synthetic" and (w, h) == (1920, 1080) and workload == "p":
+            clip = decode_res_clip("VID_1920x1080_cavlc_temporal_direct.264")
+            if clip is not None:
+                c2 = Content(clip, fsz, ring, True)
+                st = max(10, min(a.steps, 50))
+                d2, ev2, ver2 = hot_path_leg(oh, a, local, w, h, "p", a.sessions, ring, c2, st, 2, None, (0,) if verify_sessions else ())
+                r2 = roofline("p", mbs, a.sessions, st, ev2)
+                line["res_clip"] = {"data": "res/VID_1920x1080_cavlc_temporal_direct.264 decoded, %d consecutive frames per session, sessions start 5 frames apart" % ring,
+                                    "value": a.sessions * st / d2, "unit": "frames/s", "steps": st, "roofline_frac": r2["frac"], "events_ms": ev2,
+                                    "verified": (all(ver2.values()) if ver2 is not None else None)}
+        # BASELINE config 2: 720p all-IDR on the reference's 720p clip
+        if workload == "p":
+            clip = decode_res_clip("VID_1280x720_cavlc_temporal_direct.264")
+            if clip is not None:
+                w2, h2 = 1280, 720
+                c3 = Content(clip[: w2 * h2 * 3 // 2 * 16], w2 * h2 * 3 // 2, 2, True)
+                st, ns = 20, 256
+                d3, ev3, ver3 = hot_path_leg(oh, a, local, w2, h2, "intra", ns, 2, c3, st, 2, None, (0,) if verify_sessions else ())
+                r3 = roofline("intra", ((w2 + 15) // 16) * ((h2 + 15) // 16), ns, st, ev3)
+                line["intra_720p"] = {"data": "res/VID_1280x720_cavlc_temporal_direct.264 decoded (BASELINE config 2's stand-in clip)", "value": ns * st / d3, "unit": "frames/s",
+                                      "sessions": ns, "steps": st, "roofline": {k: r3[k] for k in ("kernel", "achieved", "frac", "avg_launch_ms", "bytes_per_mb")},
+                                      "verified": (all(ver3.values()) if ver3 is not None else None)}
+    if world == 1 and not a.no_cpu_baseline:
+        cb = cpu_baseline(w, h, a.qp, workload, content, a.deblock_idc)
+        if cb:
+            line["cpu_baseline"] = cb
+    print(json.dumps(line))
+    sys.stdout.flush()
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
+    if line.get("e2e", {}).get("bitstream_vs_reference") and not line["e2e"]["bitstream_vs_reference"]["match"]:
+        raise SystemExit("bench.py: the e2e bitstream of session 0 differs from the reference encoder's")
+    if verified is not None and not all(verified.values()):
+        raise SystemExit("bench.py: the timed steps' reconstruction differs from the reference (sessions %s)" % [s for s, ok in verified.items() if not ok])
 
 
 if __name__ == "__main__":

@@ -260,6 +260,7 @@ class EncoderGroup:
             lib.WelsHipGroupBackendName.argtypes = [C.c_void_p]
             lib.WelsHipGroupBackendName.restype = C.c_char_p
             lib.WelsHipGroupBench.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
+            lib.WelsHipGroupEncodeFrames.argtypes = [C.c_void_p, C.POINTER(SSourcePicture), C.POINTER(SFrameBSInfo)]
             lib._group_ready = True
         h = C.c_void_p()
         rc = lib.WelsHipGroupCreate(C.byref(h), C.byref(param), sessions, ring_slots, host_threads)
@@ -292,6 +293,41 @@ class EncoderGroup:
             rc = lib.WelsHipGroupFinish(self._h, infos)
         if rc:
             raise WelsHipError(rc, (lib.WelsHipGetLastError() or b"").decode())
+        out = []
+        for info in infos:
+            b = bytearray()
+            for li in range(info.iLayerNum):
+                L = info.sLayerInfo[li]
+                b += C.string_at(L.pBsBuf, sum(L.pNalLengthInByte[k] for k in range(L.iNalCount)))
+            out.append(bytes(b))
+        return out
+
+    def make_pictures(self, yuvs):
+        """Host-resident source pictures for encode_frames: one I420 frame (bytes) per session.  Returns an opaque object
+        that keeps the buffers alive."""
+        w, h = self.w, self.h
+        pics = (SSourcePicture * self.n)()
+        keep = []
+        for i, yuv in enumerate(yuvs):
+            buf = (C.c_uint8 * len(yuv)).from_buffer_copy(yuv)
+            keep.append(buf)
+            base = C.addressof(buf)
+            pic = pics[i]
+            pic.iColorFormat = videoFormatI420
+            pic.iStride[0], pic.iStride[1], pic.iStride[2] = w, w // 2, w // 2
+            pic.pData[0], pic.pData[1], pic.pData[2] = base, base + w * h, base + w * h + (w // 2) * (h // 2)
+            pic.iPicWidth, pic.iPicHeight = w, h
+        return (pics, keep)
+
+    def encode_frames(self, pictures, want_bytes=False):
+        """WelsHipGroupEncodeFrames: one complete EncodeFrame for every session -- source upload, device passes, D2H of the
+        MB records, host entropy coding.  Returns the total number of bitstream bytes (or the per-session bitstreams)."""
+        infos = (SFrameBSInfo * self.n)()
+        rc = self._lib.WelsHipGroupEncodeFrames(self._h, pictures[0], infos)
+        if rc:
+            raise WelsHipError(rc, (self._lib.WelsHipGetLastError() or b"").decode())
+        if not want_bytes:
+            return sum(info.iFrameSizeInBytes for info in infos)
         out = []
         for info in infos:
             b = bytearray()

@@ -1,4 +1,5 @@
-"""In-kernel phase profile of the P-frame MB kernel (cycle counters, see WH_PROF_MARK)."""
+"""In-kernel phase profile of the P-frame MB kernel (cycle counters, see WH_PROF_MARK).
+usage: phase_profile.py [sessions] [synthetic|res]   (res: the reference's 1080p clip from oracle/_ref/res, as in bench.py)"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import openh264_amd as oh
@@ -6,10 +7,18 @@ from openh264_amd.utils.synth import synth_sequence
 w, h, S = 1920, 1080, int(sys.argv[1]) if len(sys.argv) > 1 else 16
 e = oh.Encoder(); p = e.GetDefaultParams(); e.close()
 p.iPicWidth, p.iPicHeight, p.iDLayerQp, p.fMaxFrameRate, p.iTargetBitrate, p.uiIntraPeriod, p.uiSliceMode, p.uiSliceNum = w, h, 24, 30.0, 5000000, 0, 1, 4
-g = oh.EncoderGroup(p, S, ring_slots=4)
-fr = synth_sequence(w, h, 4); fsz = w * h * 3 // 2
+R = 8
+g = oh.EncoderGroup(p, S, ring_slots=R)
+fsz = w * h * 3 // 2
+if len(sys.argv) > 2 and sys.argv[2] == "res":
+    import bench
+    clip = bench.decode_res_clip("VID_1920x1080_cavlc_temporal_direct.264")
+    c = bench.Content(clip, fsz, R, True)
+else:
+    import bench
+    c = bench.Content(synth_sequence(w, h, R), fsz, R, False)
 for s in range(S):
-    for k in range(4): g.upload(s, k, fr[k * fsz:(k + 1) * fsz])
+    for k in range(R): g.upload(s, k, c.frame(s, k))
 g.bench(1, 0)
 lib = g._lib
 lib.WelsHipGroupProfile.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_ulonglong)]
