@@ -101,6 +101,15 @@ typedef struct WhPicJob {
   uint32_t       db_gen;     // generation of this picture (never 0, changes every frame: the flags need no clearing)
   uint32_t       pad2;
   uint32_t*      scene_count; // scene-change statistic (kernels/scene_pic.h): zeroed by the host, incremented by the kernel
+  // ---- what the reference keeps per LAYER rather than per picture, and what its pre-processing hands to mode decision ----
+  int32_t*       sad_cost0;   // pSadCost[0] of every MB (the layer's SMB array, encoder_ext.cpp:900,1675): persists from picture to
+                              //   picture whatever the reference picture is; P pictures read and rewrite it, I pictures leave it alone
+  const int32_t* vaa_sad8x8;  // the host's VAACalcSad result [mb][4] (pVaa->sVaaCalcInfo.pSad8x8), or NULL: computed from prev_src_y
+  const int8_t*  bgd_flags;   // pVaa->pVaaBackgroundMbFlag [mb], or NULL: background detection off
+  int32_t        mvc_shift;   // sScaleShift (svc_encode_slice.cpp:1652-1655): temporal-layer scaling of the co-located MV candidates
+  int32_t        mb_begin;    // only MBs in [mb_begin, mb_end) are coded by this launch (GOM-synchronous rate control); the ones
+  int32_t        mb_end;      //   before mb_begin count as done; mb_end == 0 means the whole picture
+  int32_t        pad4;
 } WhPicJob;
 
 #define WH_MAX_SLICES 36

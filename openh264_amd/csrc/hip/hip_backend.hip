@@ -83,7 +83,10 @@ __global__ __launch_bounds__ (MAX_THREADS) void NAME (WhSeqParams P, const WhPic
     if (t >= n) break;                                                                                                  \
     const int xy = order[t];                                                                                            \
     if (PROF) WH_PROF_MARK (P, wh_prof_holder (S), 11);      /* ticket + order lookup */                                 \
-    (void)0;                                                                                          \
+    if (J.mb_end > 0) {                   /* GOM-synchronous coding: only [mb_begin, mb_end) in this launch */           \
+      if (xy < J.mb_begin) { if (lane == 0) atomicOr (&sched[1 + ((xy - first) >> 5)], 1u << ((xy - first) & 31)); continue; } \
+      if (xy >= J.mb_end) continue;                                                                                     \
+    }                                                                                                                   \
     int dep_a, dep_b;                                                                                                   \
     wh_mb_deps (P.mb_w, xy, first, &dep_a, &dep_b);                                                                     \
     if (!wh_wait_done (sched + 1, dep_a < 0 ? -1 : dep_a - first, err)) break;     /* give up: the host aborts on err */   \
@@ -101,16 +104,18 @@ __global__ __launch_bounds__ (MAX_THREADS) void NAME (WhSeqParams P, const WhPic
 
 WH_DEFINE_MB_KERNEL (k_intra_slice, WhMbLds, wh_intra_mb_body, 1024, 0, 0)
 
-// P pictures: same scheduling, plus a one-MB look-ahead: a wave takes the ticket of its NEXT macroblock before it
-// starts the current one, so that the body can fetch the next MB's cold inputs (straight from HBM) underneath its own
-// arithmetic.  Holding one extra ticket keeps the no-deadlock argument: the lowest unfinished ticket is always being
-// processed, never merely held.
-// LDS for the optional window staging exists only in the kernel variant that uses it
-template <int N, bool ON> struct WhWinStageLds { static __device__ __forceinline__ WhWinStage* get (int wave) { __shared__ WhWinStage st[N]; return &st[wave]; } };
-template <int N> struct WhWinStageLds<N, false> { static __device__ __forceinline__ WhWinStage* get (int) { return nullptr; } };
-
-template <int MAXT, bool WINPF>
-__global__ __launch_bounds__ (MAXT) void k_inter_slice (WhSeqParams P, const WhPicJob* jobs, uint32_t* err) {
+// ---- P pictures: a pool of wavefronts shared by several slices ------------------------------------------------------
+// A workgroup owns up to WH_MD_MAX_SLOTS slices (of any pictures of the batch) and as many wavefronts as fit one CU.  A
+// free wave takes the next macroblock of the slice with the most macroblocks left, so when one slice of the group is cheap
+// (skipped background) or finished, all waves of the CU work on the expensive one: slices cost up to 2-3x their mean on
+// real content, and with a fixed six waves per slice the CU idled for half of the launch.  Which slices share a workgroup
+// is a table (`groups`): k_md_assign sorts the slices by what they cost in the previous picture of their session and deals
+// them out in snake order, heavy with light.  Inside a slice nothing changes: tickets in dependency order (LDS counter),
+// done bits in LDS, data through the workgroup-coherent L1/L2.
+#define WH_MD_MAX_SLOTS 4
+template <int MAXT>
+__global__ __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPicJob* jobs, uint32_t* err, const uint16_t* groups, int slots,
+                                                       int sched_words, int total_slices, uint32_t* slice_cost) {
   extern __shared__ __align__ (16) uint8_t smem[];
   const int nw = (int)blockDim.x >> 6, lane = (int)threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane ((int)threadIdx.x >> 6);
@@ -118,66 +123,132 @@ __global__ __launch_bounds__ (MAXT) void k_inter_slice (WhSeqParams P, const WhP
   __shared__ WhInterStage stage[MAXT / 64];          // separate LDS objects: see WhInterStage
   WhInterStage& G = stage[wave];
   __shared__ WhWinLds winbuf[MAXT / 64];
-  uint32_t* sched = (uint32_t*) (smem + (size_t)nw * sizeof (WhInterLds));
-  const int first = P.slice_first_mb[blockIdx.x], n = P.slice_first_mb[blockIdx.x + 1] - first;
-  const uint16_t* order = P.mb_order + first;
-  for (int i = (int)threadIdx.x; i < 1 + ((n + 31) >> 5); i += (int)blockDim.x) sched[i] = 0;
+  uint32_t* sched = (uint32_t*) (smem + (size_t)nw * sizeof (WhInterLds));     // per slot: [0] ticket counter, [1..] done bits
+  __shared__ WhPicJob Jl[WH_MD_MAX_SLOTS];
+  __shared__ int slot_first[WH_MD_MAX_SLOTS], slot_n[WH_MD_MAX_SLOTS], slot_idc[WH_MD_MAX_SLOTS], slot_id[WH_MD_MAX_SLOTS];
+  for (int i = (int)threadIdx.x; i < slots * sched_words; i += (int)blockDim.x) sched[i] = 0;
   if (P.prof && lane < 32) S.m.prof[lane] = 0;
-  __shared__ WhPicJob Jl;
-  wh_copy_job (&Jl, &jobs[blockIdx.y]);
+  for (int sl = 0; sl < slots; ++sl) {
+    const int k = groups ? (int)groups[blockIdx.x * slots + sl] : (int)blockIdx.x * slots + sl;       // flattened slice id: picture * num_slices + slice
+    const bool on = k < total_slices;
+    const int pic = on ? k / P.num_slices : 0, idc = on ? k % P.num_slices : 0;
+    if (threadIdx.x == 0) {
+      slot_first[sl] = P.slice_first_mb[idc]; slot_n[sl] = on ? P.slice_first_mb[idc + 1] - P.slice_first_mb[idc] : 0;
+      slot_idc[sl] = idc; slot_id[sl] = on ? k : -1;
+    }
+    wh_copy_job (&Jl[sl], &jobs[pic]);
+  }
   __syncthreads();
   WH_PROF_DECL (P);
-  const WhPicJob& J = Jl;
   WhInterCtx X;
   WhWinPf pf;
   pf.valid = 0;
   X.pf = &pf;
-  X.win_stage = WhWinStageLds<MAXT / 64, WINPF>::get (wave);
+  X.win_stage = nullptr;
   X.win = &winbuf[wave];
-  X.slice_idc = (int)blockIdx.x; X.slice_first = first;
-  // WELSHIP look-ahead (lookahead != 0): a wave takes the ticket of its NEXT macroblock before it starts the current one,
-  // so that the body can fetch the next MB's cold inputs underneath its own arithmetic.  Without it the wave takes a
-  // ticket only when it is free and starts that MB's cold loads before it waits for the neighbours.
-  const bool lookahead = P.pad[0] != 0;
-  int t = 0;
-  if (lane == 0) t = (int)atomicAdd (&sched[0], 1u);
-  t = __builtin_amdgcn_readfirstlane (t);
-  if (t < n) {
-    int xy = order[t];
-    wh_inter_cold_fetch (G, lane, P, J, xy % P.mb_w, xy / P.mb_w);
-    for (int guard = 0; guard <= n; ++guard) {
-      int tn = n;
-      if (lookahead) {
-        if (lane == 0) tn = (int)atomicAdd (&sched[0], 1u);
-        tn = __builtin_amdgcn_readfirstlane (tn);
+  X.next_valid = 0; X.next_mbx = 0; X.next_mby = 0;
+  uint32_t gone = 0;                      // slots this wave knows to be out of tickets (wave-uniform)
+  uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;     // cycles / 64 this wave spent on each slot's macroblocks
+  int slot = -1, t = 0, xy = 0;
+  // claim(): the next macroblock for this wave, or slot = -1 when the workgroup's slices are used up
+#define WH_CLAIM()                                                                                                             \
+  for (slot = -1;;) {                                                                                                          \
+    int best = -1, brem = 0;                                                                                                   \
+    for (int sl = 0; sl < slots; ++sl) if (!((gone >> sl) & 1u)) {                                                             \
+      const int rem = slot_n[sl] - (int)__hip_atomic_load (&sched[sl * sched_words], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+      if (rem <= 0) gone |= 1u << sl; else if (rem > brem) { brem = rem; best = sl; }                                          \
+    }                                                                                                                          \
+    best = __builtin_amdgcn_readfirstlane (best);                                                                              \
+    if (best < 0) break;                                                                                                       \
+    int tt = 0;                                                                                                                \
+    if (lane == 0) tt = (int)atomicAdd (&sched[best * sched_words], 1u);                                                       \
+    tt = __builtin_amdgcn_readfirstlane (tt);                                                                                  \
+    if (tt >= slot_n[best]) { gone |= 1u << best; continue; }                                                                  \
+    const int first_ = slot_first[best];                                                                                       \
+    const int xy_ = (int)P.mb_order[first_ + tt];                                                                              \
+    const int mb_end_ = Jl[best].mb_end;                                                                                       \
+    if (mb_end_ > 0) {                    /* GOM-synchronous coding: only [mb_begin, mb_end) in this launch */                 \
+      if (xy_ < Jl[best].mb_begin) { if (lane == 0) atomicOr (&sched[best * sched_words + 1 + ((xy_ - first_) >> 5)], 1u << ((xy_ - first_) & 31)); continue; } \
+      if (xy_ >= mb_end_) continue;                                                                                            \
+    }                                                                                                                          \
+    slot = best; t = tt; xy = xy_;                                                                                             \
+    break;                                                                                                                     \
+  }
+  WH_CLAIM()
+  if (slot >= 0) wh_inter_cold_fetch (G, lane, P, Jl[slot], xy % P.mb_w, xy / P.mb_w);
+  while (slot >= 0) {
+    const WhPicJob& J = Jl[slot];
+    const int first = slot_first[slot];
+    uint32_t* sc = sched + slot * sched_words;
+    WH_PROF_MARK (P, S.m, 11);
+    int dep_a, dep_b;
+    wh_mb_deps (P.mb_w, xy, first, &dep_a, &dep_b);
+    if (!wh_wait_done (sc + 1, dep_a < 0 ? -1 : dep_a - first, err)) break;
+    if (!wh_wait_done (sc + 1, dep_b < 0 ? -1 : dep_b - first, err)) break;
+    __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "workgroup");
+    WH_PROF_MARK (P, S.m, 12);
+    const uint32_t tc0 = (uint32_t)__builtin_readcyclecounter();
+    WV_ASYNC_WAIT();                      /* this MB's cold inputs have landed in the staging area */
+    X.slice_idc = slot_idc[slot]; X.slice_first = first;
+    wh_inter_mb_body (S, G, P, J, xy % P.mb_w, xy / P.mb_w, X);
+    WH_PROF_MARK (P, S.m, 14);
+    __builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) atomicOr (&sc[1 + ((xy - first) >> 5)], 1u << ((xy - first) & 31));
+    WH_PROF_MARK (P, S.m, 13);
+    const uint32_t dc = ((uint32_t)__builtin_readcyclecounter() - tc0) >> 6;
+    c0 += slot == 0 ? dc : 0u; c1 += slot == 1 ? dc : 0u; c2 += slot == 2 ? dc : 0u; c3 += slot == 3 ? dc : 0u;
+    WH_CLAIM()
+    if (slot >= 0) wh_inter_cold_fetch (G, lane, P, Jl[slot], xy % P.mb_w, xy / P.mb_w);     /* in flight while the wave waits for the neighbours */
+  }
+#undef WH_CLAIM
+  if (slice_cost && lane == 0) {
+    if (slot_id[0] >= 0 && c0) atomicAdd (&slice_cost[slot_id[0]], c0);
+    if (slots > 1 && slot_id[1] >= 0 && c1) atomicAdd (&slice_cost[slot_id[1]], c1);
+    if (slots > 2 && slot_id[2] >= 0 && c2) atomicAdd (&slice_cost[slot_id[2]], c2);
+    if (slots > 3 && slot_id[3] >= 0 && c3) atomicAdd (&slice_cost[slot_id[3]], c3);
+  }
+  if (P.prof && lane < 32) atomicAdd (&P.prof[((blockIdx.x * 7u) & 63u) * 32u + lane], (unsigned long long)S.m.prof[lane]);
+}
+
+// Deal the slices of a batch out to the mode-decision workgroups: sorted by the cost they had in the previous picture
+// (slice_cost, accumulated by k_inter_pool; cleared here for the coming launch), then in snake order over the groups, so
+// that every group gets a heavy and a light share.  One workgroup; n <= 4096 slices.
+__global__ __launch_bounds__ (1024) void k_md_assign (uint32_t* slice_cost, uint16_t* groups, int n, int n_groups, int slots) {
+  __shared__ uint32_t key[4096];
+  __shared__ uint16_t val[4096];
+  int m = 1;
+  while (m < n) m <<= 1;
+  for (int i = (int)threadIdx.x; i < m; i += (int)blockDim.x) { key[i] = i < n ? slice_cost[i] : 0u; val[i] = (uint16_t) (i < n ? i : 0xffff); }
+  __syncthreads();
+  for (int i = (int)threadIdx.x; i < n; i += (int)blockDim.x) slice_cost[i] = 0;
+  // bitonic sort, descending by key; entries beyond n carry key 0 and id 0xffff and end up at the tail (ties: any order)
+  for (int k = 2; k <= m; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = (int)threadIdx.x; i < m; i += (int)blockDim.x) {
+        const int l = i ^ j;
+        if (l > i) {
+          const bool up = (i & k) == 0;         // this stretch sorts descending when `up`
+          const uint32_t a = key[i], b = key[l];
+          const bool sw = up ? (a < b || (a == b && val[i] == 0xffff && val[l] != 0xffff)) : (a > b);
+          if (sw) { key[i] = b; key[l] = a; const uint16_t t = val[i]; val[i] = val[l]; val[l] = t; }
+        }
       }
-      int xyn = tn < n ? (int)order[tn] : 0;
-      WH_PROF_MARK (P, S.m, 11);
-      int dep_a, dep_b;
-      wh_mb_deps (P.mb_w, xy, first, &dep_a, &dep_b);
-      if (!wh_wait_done (sched + 1, dep_a < 0 ? -1 : dep_a - first, err)) break;
-      if (!wh_wait_done (sched + 1, dep_b < 0 ? -1 : dep_b - first, err)) break;
-      __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "workgroup");
-      WH_PROF_MARK (P, S.m, 12);
-      WV_ASYNC_WAIT();                      /* this MB's cold inputs have landed in S.cold_* */
-      X.next_valid = tn < n; X.next_mbx = xyn % P.mb_w; X.next_mby = xyn / P.mb_w;
-      wh_inter_mb_body (S, G, P, J, xy % P.mb_w, xy / P.mb_w, X);
-      WH_PROF_MARK (P, S.m, 14);
-      __builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");
-      if (lane == 0) atomicOr (&sched[1 + ((xy - first) >> 5)], 1u << ((xy - first) & 31));
-      WH_PROF_MARK (P, S.m, 13);
-      if (!lookahead) {
-        if (lane == 0) tn = (int)atomicAdd (&sched[0], 1u);
-        tn = __builtin_amdgcn_readfirstlane (tn);
-        if (tn >= n) break;
-        xyn = order[tn];
-        wh_inter_cold_fetch (G, lane, P, J, xyn % P.mb_w, xyn / P.mb_w);     /* in flight while the wave waits for the neighbours */
-      }
-      if (tn >= n) break;
-      xy = xyn;
+      __syncthreads();
+    }
+  // real slices first (a zero-cost slice could sit behind padding): compact is not needed because padding only exists
+  // beyond n and sorts to the very end or among equal (zero) keys -- handle that by scanning for the p-th real entry
+  for (int g = (int)threadIdx.x; g < n_groups * slots; g += (int)blockDim.x) groups[g] = 0xffff;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int p = 0;
+    for (int i = 0; i < m; ++i) {
+      if (val[i] == 0xffff) continue;
+      const int r = p / n_groups, c = p % n_groups;
+      const int g = (r & 1) ? n_groups - 1 - c : c;
+      if (r < slots) groups[g * slots + r] = val[i];
+      ++p;
     }
   }
-  if (P.prof && lane < 32) atomicAdd (&P.prof[((blockIdx.x + blockIdx.y * 7u) & 63u) * 32u + lane], (unsigned long long)S.m.prof[lane]);
 }
 
 // Deblocking with one workgroup per BAND (WhSeqParams::db_bands: whole rows of one slice -- of the picture when the filter
@@ -396,20 +467,54 @@ class HipBackend : public wh::Backend {
     if (getenv ("WELSHIP_TRACE")) { HIP_TRY (hipStreamSynchronize (stream_)); fprintf (stderr, "welship: launch done\n"); fflush (stderr); }
   }
   void run_intra (const WhSeqParams& P, const WhPicJob* jobs, int n) override { mb_pass (k_intra_slice, sizeof (WhMbLds), 16, false, P, jobs, n, sizeof (WhPicJob)); }
-  // P pictures.  The wave count per workgroup (= per slice) trades waiting on neighbours against latency hiding:
-  //   * plenty of workgroups (>= 2 per CU): 6 waves each, two slices share a CU (12 waves / CU, little waiting);
-  //   * otherwise 12 waves per workgroup.
-  // WELSHIP_P_WAVES overrides; 8 selects the variant that also stages the next MB's search windows (it needs 19 KB of LDS
-  // per wave, so 8 waves fill a CU).
+  // P pictures: one workgroup per CU-load of slices.  Few slices (latency regime): one slice per workgroup, 12 waves.  Enough
+  // slices to fill the chip twice: groups of 2..4 slices share a 12-wave workgroup (k_inter_pool), dealt out by k_md_assign.
+  // WELSHIP_MD_SLOTS = 1..4 forces the group size, WELSHIP_P_WAVES the wave count, WELSHIP_MD_ASSIGN=0 the plain order.
   void run_inter (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
-    static const int forced = getenv ("WELSHIP_P_WAVES") ? atoi (getenv ("WELSHIP_P_WAVES")) : 0;
-    const int waves = forced ? forced : (P.num_slices * n >= 2 * cus_ ? 6 : 12);
-    static const int lookahead = getenv ("WELSHIP_P_LOOKAHEAD") ? atoi (getenv ("WELSHIP_P_LOOKAHEAD")) : 0;    // measured: holding a ticket ahead costs more than it hides
-    WhSeqParams Q = P;
-    Q.pad[0] = lookahead;
-    if (waves == 8) mb_pass (k_inter_slice<512, true>, sizeof (WhInterLds), 8, false, Q, jobs, n, 8 * (sizeof (WhInterStage) + sizeof (WhWinStage) + sizeof (WhWinLds)) + sizeof (WhPicJob));
-    else if (waves <= 6) mb_pass (k_inter_slice<384, false>, sizeof (WhInterLds), 6, false, Q, jobs, n, 6 * (sizeof (WhInterStage) + sizeof (WhWinLds)) + sizeof (WhPicJob));
-    else mb_pass (k_inter_slice<768, false>, sizeof (WhInterLds), 12, false, Q, jobs, n, 12 * (sizeof (WhInterStage) + sizeof (WhWinLds)) + sizeof (WhPicJob));
+    static const int forced_waves = getenv ("WELSHIP_P_WAVES") ? atoi (getenv ("WELSHIP_P_WAVES")) : 0;
+    static const int forced_slots = getenv ("WELSHIP_MD_SLOTS") ? atoi (getenv ("WELSHIP_MD_SLOTS")) : 0;
+    static const int use_assign = getenv ("WELSHIP_MD_ASSIGN") ? atoi (getenv ("WELSHIP_MD_ASSIGN")) : 1;
+    const int total = P.num_slices * n;
+    int slots = forced_slots > 0 ? std::min (forced_slots, WH_MD_MAX_SLOTS) : std::max (1, std::min (WH_MD_MAX_SLOTS, total / cus_));
+    const int groups = (total + slots - 1) / slots;
+    int max_n = 0, max_rows = 0;
+    for (int s = 0; s < P.num_slices; ++s) {
+      max_n = std::max (max_n, P.slice_first_mb[s + 1] - P.slice_first_mb[s]);
+      max_rows = std::max (max_rows, (P.slice_first_mb[s + 1] - 1) / P.mb_w - P.slice_first_mb[s] / P.mb_w + 1);
+    }
+    const int sched_words = 1 + ((max_n + 31) >> 5);
+    int nw = forced_waves > 0 ? forced_waves : 12;
+    nw = std::min (nw, 12);
+    const int par = std::max (1, std::min (max_rows, (P.mb_w + 1) / 2)) * slots;       // macroblocks that can be in flight at all
+    nw = std::min (nw, par);
+    const size_t per_wave = sizeof (WhInterLds) + sizeof (WhInterStage) + sizeof (WhWinLds);
+    const size_t fixed = WH_MD_MAX_SLOTS * (sizeof (WhPicJob) + 16) + 4 * (size_t)slots * sched_words;
+    while (nw > 1 && (size_t)nw * per_wave + fixed > (size_t)160 * 1024) --nw;
+    const size_t lds = (size_t)nw * sizeof (WhInterLds) + 4 * (size_t)slots * sched_words;
+    uint16_t* grp = nullptr;
+    uint32_t* cost = nullptr;
+    if (slots > 1 && use_assign && total <= 4096) {
+      if ((size_t)total > md_cap_) {
+        if (md_cost_) { free (md_cost_); free (md_groups_); }
+        md_cap_ = (size_t)total;
+        md_cost_ = (uint32_t*)alloc (4 * md_cap_);
+        md_groups_ = (uint16_t*)alloc (2 * (md_cap_ + WH_MD_MAX_SLOTS));
+        if (md_cost_) HIP_TRY (hipMemsetAsync (md_cost_, 0, 4 * md_cap_, stream_));
+      }
+      if (md_cost_ && md_groups_) {
+        grp = md_groups_; cost = md_cost_;
+        hipLaunchKernelGGL (k_md_assign, dim3 (1), dim3 (1024), 0, stream_, cost, grp, total, groups, slots);
+        HIP_TRY (hipGetLastError());
+      }
+    }
+    auto launch = [&] (auto kernel) {
+      HIP_TRY (hipFuncSetAttribute ((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      if (getenv ("WELSHIP_TRACE")) { fprintf (stderr, "welship: MD launch %d groups x %d slots, %d waves, %zu B dynamic LDS\n", groups, slots, nw, lds); fflush (stderr); }
+      hipLaunchKernelGGL (kernel, dim3 (groups), dim3 (nw * 64), lds, stream_, P, jobs, err_, (const uint16_t*)grp, slots, sched_words, total, cost);
+      HIP_TRY (hipGetLastError());
+      if (getenv ("WELSHIP_TRACE")) { HIP_TRY (hipStreamSynchronize (stream_)); fprintf (stderr, "welship: launch done\n"); fflush (stderr); }
+    };
+    if (nw <= 6) launch (k_inter_pool<384>); else launch (k_inter_pool<768>);
   }
   void run_deblock (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
     static const int db_waves = getenv ("WELSHIP_DB_WAVES") ? atoi (getenv ("WELSHIP_DB_WAVES")) : 16;
@@ -463,6 +568,9 @@ class HipBackend : public wh::Backend {
   size_t total_asked_ = 0;
   hipError_t hip_err_ = hipSuccess;
   std::string name_;
+  uint32_t* md_cost_ = nullptr;          // per slice of a batch: cost of its previous picture (k_inter_pool -> k_md_assign)
+  uint16_t* md_groups_ = nullptr;
+  size_t md_cap_ = 0;
   bool same_slab (uintptr_t a, uintptr_t b) const {
     for (const Slab& sl : slabs_) { const uintptr_t lo = (uintptr_t)sl.base, hi = lo + sl.size; if (a >= lo && a < hi) return b >= lo && b < hi; }
     return false;

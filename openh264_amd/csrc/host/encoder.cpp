@@ -1038,3 +1038,236 @@ int WelsHipGroupProfile (WelsHipEncoderGroup* g, int enable, unsigned long long*
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------- explicit frame API (include/welship.h 2b)
+// What the SWelsFuncPtrList hooks of the patched reference call: the reference owns the stream (frame types, reference
+// lists, rate control, entropy coding); this side owns device twins of its pictures and runs the per-macroblock passes.
+struct WelsHipFrameCtx {
+  wh::Backend* be = nullptr;
+  int w = 0, h = 0, mb_w = 0, mb_h = 0, num_mb = 0;
+  WhSeqParams seq;
+  std::vector<DevPicture> pics;
+  size_t rec_alloc_bytes = 0, rec_y = 0, rec_c = 0, ysz = 0, csz = 0, src_bytes = 0;
+  uint8_t* d_src = nullptr;
+  std::vector<uint8_t> h_src;
+  WhMbRecord* d_records = nullptr;
+  std::vector<WhMbRecord> h_records;
+  uint16_t* d_order = nullptr;
+  int32_t* d_bands = nullptr;
+  uint32_t* d_dbflags = nullptr;
+  uint32_t db_gen = 0;
+  WhMbCtl* d_mb_ctl = nullptr;
+  std::vector<WhMbCtl> h_mb_ctl;
+  int32_t* d_sad_cost0 = nullptr;        // the layer's pSadCost[0] array (persists across pictures)
+  int32_t* d_vaa = nullptr;
+  int8_t* d_bgd = nullptr;
+  WhPicJob* d_job = nullptr;
+  // slice / deblocking layout the tables on the device were built for
+  std::vector<int32_t> cur_slices;
+  int cur_idc = -1;
+
+  void release() {
+    if (!be) return;
+    be->sync();
+    for (auto& p : pics) { if (p.base) be->free (p.base); if (p.mbs) be->free (p.mbs); }
+    pics.clear();
+    void* ptrs[] = {d_src, d_records, d_order, d_bands, d_dbflags, d_mb_ctl, d_sad_cost0, d_vaa, d_bgd, d_job};
+    for (void* p : ptrs) if (p) be->free (p);
+    if (!h_records.empty()) be->unpin_host (h_records.data());
+    delete be;
+    be = nullptr;
+  }
+
+  // (re)build the processing-order and deblocking-band tables when the slice layout or the filter mode changes
+  int set_layout (int n, const int32_t* first, int idc) {
+    if ((int)cur_slices.size() == n + 1 && cur_idc == idc && memcmp (cur_slices.data(), first, sizeof (int32_t) * (n + 1)) == 0) return WELSHIP_OK;
+    if (n < 1 || n > WH_MAX_SLICES || first[0] != 0 || first[n] != num_mb) { set_err ("invalid slice layout"); return WELSHIP_ERR_INIT_PARA; }
+    for (int i = 0; i < n; ++i) if (first[i + 1] <= first[i]) { set_err ("invalid slice layout"); return WELSHIP_ERR_INIT_PARA; }
+    WhSeqParams& s = seq;
+    s.num_slices = n;
+    for (int i = 0; i <= n; ++i) s.slice_first_mb[i] = first[i];
+    s.deblock_idc = idc;
+    std::vector<uint16_t> order ((size_t)num_mb * 3);
+    for (int i = 0; i < n; ++i) wh_build_mb_order (mb_w, first[i], first[i + 1], order.data() + first[i]);
+    wh_build_mb_order (mb_w, 0, num_mb, order.data() + num_mb);
+    std::vector<int32_t> bands (3 * (size_t) (mb_h + n) + 1);
+    const int nb = wh_build_db_bands (mb_w, mb_h, n, first, idc, WH_DB_BAND_ROWS, bands.data(), (int)bands.size());
+    if (nb < 1) { set_err ("deblocking band table"); return WELSHIP_ERR_UNKNOWN; }
+    for (int b = 0; b < nb; ++b) wh_build_mb_order (mb_w, bands[b], bands[b + 1], order.data() + 2 * (size_t)num_mb + bands[b]);
+    be->sync();                                   // nothing in flight may still read the old tables
+    be->upload (d_order, order.data(), order.size() * 2);
+    be->upload (d_bands, bands.data(), sizeof (int32_t) * (3 * (size_t)nb + 1));
+    if (be->sync()) { set_err ("device error"); return WELSHIP_ERR_UNKNOWN; }
+    s.mb_order = d_order;
+    s.db_num_bands = nb; s.db_bands = d_bands;
+    s.db_max_mbs = 0; s.db_max_rows = 0;
+    for (int b = 0; b < nb; ++b) {
+      s.db_max_mbs = std::max (s.db_max_mbs, bands[b + 1] - bands[b]);
+      s.db_max_rows = std::max (s.db_max_rows, (bands[b + 1] - 1) / mb_w - bands[b] / mb_w + 1);
+    }
+    cur_slices.assign (first, first + n + 1);
+    cur_idc = idc;
+    return WELSHIP_OK;
+  }
+};
+
+extern "C" {
+
+int WelsHipFrameCtxCreate (WelsHipFrameCtx** pp, const WelsHipFrameCfg* cfg) {
+  if (!pp || !cfg) return WELSHIP_ERR_INIT_PARA;
+  if (cfg->iPicWidth < 16 || cfg->iPicHeight < 16 || cfg->iPicWidth > 4096 || cfg->iPicHeight > 2304 || cfg->iNumPictures < 2 || cfg->iNumPictures > 64) {
+    set_err ("invalid frame context configuration"); return WELSHIP_ERR_INIT_PARA;
+  }
+  const char* berr = nullptr;
+  wh::Backend* be = wh::create_default_backend (cfg->iDevice, &berr);
+  if (!be) { set_err (std::string ("no usable device backend: ") + (berr ? berr : "?")); return WELSHIP_ERR_NO_DEVICE; }
+  WelsHipFrameCtx* c = new WelsHipFrameCtx();
+  c->be = be;
+  c->w = cfg->iPicWidth; c->h = cfg->iPicHeight;
+  c->mb_w = (c->w + 15) >> 4; c->mb_h = (c->h + 15) >> 4; c->num_mb = c->mb_w * c->mb_h;
+  WhSeqParams& s = c->seq;
+  memset (&s, 0, sizeof (s));
+  s.mb_w = c->mb_w; s.mb_h = c->mb_h;
+  s.src_stride_y = c->mb_w * 16; s.src_stride_c = c->mb_w * 8;
+  s.rec_stride_y = align_up (c->mb_w * 16 + 64, 64); s.rec_stride_c = s.rec_stride_y / 2;
+  s.blk8_w = c->mb_w * 2; s.blk8_h = c->mb_h * 2;
+  c->ysz = (size_t)s.src_stride_y * c->mb_h * 16; c->csz = (size_t)s.src_stride_c * c->mb_h * 8; c->src_bytes = c->ysz + 2 * c->csz;
+  const int rec_h = c->mb_h * 16 + 64;
+  c->rec_y = (size_t)s.rec_stride_y * rec_h; c->rec_c = (size_t)s.rec_stride_c * (rec_h / 2);
+  c->rec_alloc_bytes = c->rec_y + 2 * c->rec_c;
+  bool oom = false;
+  auto A = [&] (size_t n) { void* p = be->alloc (n); if (!p) oom = true; return p; };
+  c->pics.resize (cfg->iNumPictures);
+  for (auto& d : c->pics) { d.base = (uint8_t*)A (c->rec_alloc_bytes + 128); d.mbs = (WhMbState*)A (sizeof (WhMbState) * c->num_mb); }
+  c->d_src = (uint8_t*)A (c->src_bytes);
+  c->d_records = (WhMbRecord*)A (sizeof (WhMbRecord) * c->num_mb);
+  c->d_order = (uint16_t*)A ((size_t)c->num_mb * 3 * 2);
+  c->d_bands = (int32_t*)A (sizeof (int32_t) * (3 * (size_t) (c->mb_h + WH_MAX_SLICES) + 1));
+  c->d_dbflags = (uint32_t*)A (sizeof (uint32_t) * c->num_mb);
+  c->d_mb_ctl = (WhMbCtl*)A (sizeof (WhMbCtl) * c->num_mb);
+  c->d_sad_cost0 = (int32_t*)A (sizeof (int32_t) * c->num_mb);
+  c->d_vaa = (int32_t*)A (sizeof (int32_t) * 4 * c->num_mb);
+  c->d_bgd = (int8_t*)A ((size_t)c->num_mb + 64);
+  c->d_job = (WhPicJob*)A (sizeof (WhPicJob));
+  if (oom) { set_err ("out of device memory"); c->release(); delete c; return WELSHIP_ERR_MEMORY; }
+  for (auto& d : c->pics) {
+    be->fill (d.base, 0, c->rec_alloc_bytes + 128);
+    d.plane[0] = d.base + 64 + (size_t)32 * s.rec_stride_y + 32;
+    d.plane[1] = d.base + 64 + c->rec_y + (size_t)16 * s.rec_stride_c + 16;
+    d.plane[2] = d.base + 64 + c->rec_y + c->rec_c + (size_t)16 * s.rec_stride_c + 16;
+    be->fill (d.mbs, 0, sizeof (WhMbState) * c->num_mb);
+  }
+  be->fill (c->d_dbflags, 0, sizeof (uint32_t) * c->num_mb);
+  be->fill (c->d_sad_cost0, 0, sizeof (int32_t) * c->num_mb);      // WelsMallocz (encoder_ext.cpp:1675-1677)
+  be->fill (c->d_records, 0, sizeof (WhMbRecord) * c->num_mb);
+  c->h_src.assign (c->src_bytes, 0);
+  c->h_records.resize (c->num_mb);
+  c->h_mb_ctl.resize (c->num_mb);
+  be->pin_host (c->h_records.data(), sizeof (WhMbRecord) * c->num_mb);
+  if (be->sync()) { set_err ("device error while setting up the frame context"); c->release(); delete c; return WELSHIP_ERR_UNKNOWN; }
+  *pp = c;
+  return WELSHIP_OK;
+}
+
+void WelsHipFrameCtxDestroy (WelsHipFrameCtx* c) {
+  if (!c) return;
+  c->release();
+  delete c;
+}
+
+int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void** pp_records) {
+  if (!c || !c->be || !j || !pp_records) return WELSHIP_ERR_INIT_PARA;
+  const int np = (int)c->pics.size();
+  const bool is_p = j->eSliceType == 0;
+  if (j->iCurPic < 0 || j->iCurPic >= np || (is_p && (j->iRefPic < 0 || j->iRefPic >= np || j->iRefPic == j->iCurPic)) || (!is_p && j->eSliceType != 2)) {
+    set_err ("invalid picture indices / slice type"); return WELSHIP_ERR_INIT_PARA;
+  }
+  if (j->iQp < 0 || j->iQp > 51 || !j->pSrc[0] || !j->pSrc[1] || !j->pSrc[2]) { set_err ("invalid job"); return WELSHIP_ERR_INIT_PARA; }
+  if (is_p && j->iComplexityMode == 0 && !j->pVaaSad8x8) { set_err ("LOW complexity P pictures need the VAA 8x8 SADs of the pre-processing"); return WELSHIP_ERR_INIT_PARA; }
+  const bool ranged = j->iMbEnd > 0;
+  if (ranged && (j->iMbBegin < 0 || j->iMbBegin >= j->iMbEnd || j->iMbEnd > c->num_mb)) { set_err ("invalid MB range"); return WELSHIP_ERR_INIT_PARA; }
+  const bool first_part = !ranged || j->iMbBegin == 0, last_part = !ranged || j->iMbEnd == c->num_mb;
+  int rc = c->set_layout (j->iNumSlices, j->pSliceFirstMb, j->iDeblockIdc);
+  if (rc) return rc;
+  wh::Backend* be = c->be;
+  WhSeqParams& s = c->seq;
+  s.deblock_idc = j->bDeblock ? j->iDeblockIdc : 1;       // an unfiltered picture (highest temporal layer) keeps the tables of the filtered ones
+  s.complexity = j->iComplexityMode;
+  s.chroma_qp_offset = j->iChromaQpIndexOffset;
+  s.alpha_offset = j->iAlphaOffset; s.beta_offset = j->iBetaOffset;
+  s.mv_range = j->iMvRange;
+  if (first_part) {
+    // source picture: the MB-aligned area of pEncPic (CWelsPreProcess pads it), tight strides on the device
+    uint8_t* y = c->h_src.data();
+    uint8_t* u = y + c->ysz;
+    uint8_t* v = u + c->csz;
+    for (int r = 0; r < c->mb_h * 16; ++r) memcpy (y + (size_t)r * s.src_stride_y, j->pSrc[0] + (size_t)r * j->iSrcStride[0], (size_t)c->mb_w * 16);
+    for (int r = 0; r < c->mb_h * 8; ++r) {
+      memcpy (u + (size_t)r * s.src_stride_c, j->pSrc[1] + (size_t)r * j->iSrcStride[1], (size_t)c->mb_w * 8);
+      memcpy (v + (size_t)r * s.src_stride_c, j->pSrc[2] + (size_t)r * j->iSrcStride[2], (size_t)c->mb_w * 8);
+    }
+    be->upload (c->d_src, c->h_src.data(), c->src_bytes);
+    if (is_p && j->pVaaSad8x8) be->upload (c->d_vaa, j->pVaaSad8x8, sizeof (int32_t) * 4 * c->num_mb);
+    if (is_p && j->pBgdFlags) be->upload (c->d_bgd, j->pBgdFlags, (size_t)c->num_mb);
+    if (++c->db_gen == 0) c->db_gen = 1;
+  }
+  bool qp_map = false;
+  if (j->pMbQp) {
+    for (int i = 0; i < c->num_mb; ++i) { memset (&c->h_mb_ctl[i], 0, sizeof (WhMbCtl)); c->h_mb_ctl[i].qp_delta = (int8_t) ((int)j->pMbQp[i] - j->iQp); if (c->h_mb_ctl[i].qp_delta) qp_map = true; }
+    be->upload (c->d_mb_ctl, c->h_mb_ctl.data(), sizeof (WhMbCtl) * c->num_mb);
+    qp_map = true;
+  }
+  DevPicture& cur = c->pics[j->iCurPic];
+  WhPicJob job;
+  memset (&job, 0, sizeof (job));
+  job.src[0] = c->d_src; job.src[1] = c->d_src + c->ysz; job.src[2] = c->d_src + c->ysz + c->csz;
+  for (int i = 0; i < 3; ++i) { job.rec[i] = cur.plane[i]; job.ref[i] = is_p ? c->pics[j->iRefPic].plane[i] : nullptr; }
+  job.records = c->d_records;
+  job.mbs = cur.mbs;
+  job.ref_mbs = is_p ? c->pics[j->iRefPic].mbs : nullptr;
+  job.qp = j->iQp;
+  job.slice_type = is_p ? WH_SLICE_P : WH_SLICE_I;
+  job.mb_ctl = j->pMbQp ? c->d_mb_ctl : nullptr;
+  job.ref_is_p = is_p && c->pics[j->iRefPic].is_p ? 1 : 0;
+  job.prev_src_y = nullptr;
+  job.db_flags = c->d_dbflags;
+  job.db_gen = c->db_gen;
+  job.sad_cost0 = c->d_sad_cost0;
+  job.vaa_sad8x8 = is_p && j->pVaaSad8x8 ? c->d_vaa : nullptr;
+  job.bgd_flags = is_p && j->pBgdFlags ? c->d_bgd : nullptr;
+  job.mvc_shift = j->iMvcShift;
+  job.mb_begin = ranged ? j->iMbBegin : 0; job.mb_end = ranged ? j->iMbEnd : 0;
+  be->upload (c->d_job, &job, sizeof (job));
+  if (is_p) be->run_inter (s, c->d_job, 1); else be->run_intra (s, c->d_job, 1);
+  if (last_part) {
+    if (ranged) { job.mb_begin = 0; job.mb_end = 0; be->sync(); be->upload (c->d_job, &job, sizeof (job)); }
+    if (qp_map && s.deblock_idc != 1) be->run_qp_chain (s, c->d_job, 1);
+    if (s.deblock_idc != 1) be->run_deblock (s, c->d_job, 1);
+    if (j->bExpand) be->run_expand (s, c->d_job, 1);
+    cur.is_p = is_p;
+  }
+  be->download (c->h_records.data(), c->d_records, sizeof (WhMbRecord) * c->num_mb);
+  if (be->sync()) { set_err ("device scheduler timed out or device error; the picture was not encoded"); return WELSHIP_ERR_UNKNOWN; }
+  *pp_records = c->h_records.data();
+  return WELSHIP_OK;
+}
+
+int WelsHipFrameGetPicture (WelsHipFrameCtx* c, int pic, uint8_t* const dst[3], const int32_t stride[3]) {
+  if (!c || !c->be || pic < 0 || pic >= (int)c->pics.size() || !dst || !stride) return WELSHIP_ERR_INIT_PARA;
+  const WhSeqParams& s = c->seq;
+  std::vector<uint8_t> tmp (c->rec_alloc_bytes + 128);
+  const DevPicture& p = c->pics[pic];
+  c->be->download (tmp.data(), p.base, c->rec_alloc_bytes + 128);
+  if (c->be->sync()) return WELSHIP_ERR_UNKNOWN;
+  const uint8_t* y = tmp.data() + (p.plane[0] - p.base);
+  const uint8_t* u = tmp.data() + (p.plane[1] - p.base);
+  const uint8_t* v = tmp.data() + (p.plane[2] - p.base);
+  for (int r = 0; r < c->mb_h * 16; ++r) memcpy (dst[0] + (size_t)r * stride[0], y + (size_t)r * s.rec_stride_y, (size_t)c->mb_w * 16);
+  for (int r = 0; r < c->mb_h * 8; ++r) {
+    memcpy (dst[1] + (size_t)r * stride[1], u + (size_t)r * s.rec_stride_c, (size_t)c->mb_w * 8);
+    memcpy (dst[2] + (size_t)r * stride[2], v + (size_t)r * s.rec_stride_c, (size_t)c->mb_w * 8);
+  }
+  return WELSHIP_OK;
+}
+
+}  // extern "C"

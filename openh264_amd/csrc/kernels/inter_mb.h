@@ -684,7 +684,7 @@ WH_FN void wh_inter_cold_fetch (WhInterStage& G, int lane, const WhSeqParams& P,
     const int pl = lane >> 4, row = (lane >> 1) & 7, half = lane & 1;
     wh_ld_async4 ((const WH_G uint8_t*)J.src[1 + pl] + (size_t) (mby * 8 + row) * P.src_stride_c + mbx * 8 + half * 4, G.cold_c, lane);
   }
-  if (P.complexity == 0)     // VAA 8x8 SADs (LOW complexity only)
+  if (P.complexity == 0 && !J.vaa_sad8x8)     // VAA 8x8 SADs (LOW complexity only), unless the host supplies them
     wh_ld_async4 ((const WH_G uint8_t*)J.prev_src_y + (size_t) (mby * 16 + (lane >> 2)) * P.src_stride_y + mbx * 16 + (lane & 3) * 4, G.cold_pv, lane);
   if (J.ref_is_p) {
     if (lane < 36) wh_ld_async4 ((const WH_G uint32_t*) ((const WH_G WhMbState*)J.ref_mbs + xy) + lane, G.cold_co, lane);
@@ -694,6 +694,10 @@ WH_FN void wh_inter_cold_fetch (WhInterStage& G, int lane, const WhSeqParams& P,
       if (ok) wh_ld_async4 (&o->p16mv[0], G.cold_co, lane);
     }
   }
+  // pSadCost[0] of the layer's SMB array (cold_co word 38); the host's four VAA SADs take the place of the previous source
+  // picture's first words (cold_pv 0..3 -> S.prev_y, read back by wh_inter_mb_body)
+  if (lane == 38 && J.sad_cost0) wh_ld_async4 ((const WH_G int32_t*)J.sad_cost0 + xy, G.cold_co, lane);
+  if (lane < 4 && J.vaa_sad8x8) wh_ld_async4 ((const WH_G int32_t*)J.vaa_sad8x8 + xy * 4 + lane, G.cold_pv, lane);
 }
 
 typedef struct WhInterCtx {
@@ -741,6 +745,7 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, WhInterStage& G, const WhSeqParams& 
     * (uint32_t*)&S.prev_y[lane * 4] = G.cold_pv[lane];
     if (lane < 36) S.nb[144 + lane] = ref_is_p ? G.cold_co[lane] : 0u;      // no co-located state after an IDR: reads as zeros
     else if (lane < 38) * (uint32_t*)&S.co_mv[lane - 36][0] = G.cold_co[lane];
+    else if (lane == 38) S.nb[144 + 35] = G.cold_co[38];     // rides in the padding word of the co-located state copy (WhMbState::pad1)
 #pragma unroll
     for (int k = 0; k < 3; ++k) { const int i = lane + 64 * k; if (i < 144) S.nb[i] = st[k]; }
   }
@@ -876,7 +881,7 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, WhInterStage& G, const WhSeqParams& 
         if (md_using_sad) cost_luma = sad_l;
         else WV_SATD_ROWS (cost_luma, lane, true, wh_enc4 (S, wh_tl_col (lane, 16), wh_tl_row (lane, 16)), * (const uint32_t*)&S.skip_y[wh_tl_row (lane, 16) * 16 + wh_tl_col (lane, 16)]);
         // pSadCost[0] is only refreshed when bMdUsingSad; otherwise the SMB entry keeps the previous frame's value
-        sad_cost0 = md_using_sad ? sad_l : Co->sad_cost[0];
+        sad_cost0 = md_using_sad ? sad_l : (J.sad_cost0 ? (int)S.nb[144 + 35] : Co->sad_cost[0]);
         cost_skip_mb = sad_mb;
         p16x = skx; p16y = sky;
       }
@@ -909,8 +914,9 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, WhInterStage& G, const WhSeqParams& 
     WV_LSET (mvcl, 0, 0);
     if (c_l) WV_LSET (mvcl, i_l, wh_pk_mv (Lm->p16mv[0], Lm->p16mv[1]));
     if (c_t) WV_LSET (mvcl, i_t, wh_pk_mv (Tm->p16mv[0], Tm->p16mv[1]));
-    if (c_r) WV_LSET (mvcl, i_r, wh_pk_mv (S.co_mv[0][0], S.co_mv[0][1]));
-    if (c_b) WV_LSET (mvcl, i_b, wh_pk_mv (S.co_mv[1][0], S.co_mv[1][1]));
+    const int msh = J.mvc_shift;       // temporal layers: the reference picture's vectors span 2^shift picture intervals
+    if (c_r) WV_LSET (mvcl, i_r, wh_pk_mv (S.co_mv[0][0] >> msh, S.co_mv[0][1] >> msh));
+    if (c_b) WV_LSET (mvcl, i_b, wh_pk_mv (S.co_mv[1][0] >> msh, S.co_mv[1][1] >> msh));
     me16.sad_pred = sad_pred;
     wh_motion_search (S, P, J, W, C, me16, mvcl, nm);
     p16x = me16.mvx; p16y = me16.mvy;
@@ -939,11 +945,15 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, WhInterStage& G, const WhSeqParams& 
     if (!use_satd) {
       // WelsMdInterFinePartitionVaa: partition set chosen from the sign pattern of the four 8x8 SADs
       // between this source MB and the previous source frame (VAACalcSad_c + MdInterAnalysisVaaInfo_c)
-      int p01, p23;
-      WV_SUM2 (p01, p23, lane,
-               (lane < 32 ? (wh_sad4 (* (const uint32_t*)&M.enc_y[lane * 4], * (const uint32_t*)&S.prev_y[lane * 4]) << ((lane & 2) ? 16 : 0)) : 0),
-               (lane >= 32 ? (wh_sad4 (* (const uint32_t*)&M.enc_y[lane * 4], * (const uint32_t*)&S.prev_y[lane * 4]) << ((lane & 2) ? 16 : 0)) : 0));
-      const int s8_0 = p01 & 0xffff, s8_1 = (int) ((unsigned)p01 >> 16), s8_2 = p23 & 0xffff, s8_3 = (int) ((unsigned)p23 >> 16);
+      int s8_0, s8_1, s8_2, s8_3;
+      if (J.vaa_sad8x8) { const int32_t* v8 = (const int32_t*)S.prev_y; s8_0 = v8[0]; s8_1 = v8[1]; s8_2 = v8[2]; s8_3 = v8[3]; }      // the pre-processing's own result
+      else {
+        int p01, p23;
+        WV_SUM2 (p01, p23, lane,
+                 (lane < 32 ? (wh_sad4 (* (const uint32_t*)&M.enc_y[lane * 4], * (const uint32_t*)&S.prev_y[lane * 4]) << ((lane & 2) ? 16 : 0)) : 0),
+                 (lane >= 32 ? (wh_sad4 (* (const uint32_t*)&M.enc_y[lane * 4], * (const uint32_t*)&S.prev_y[lane * 4]) << ((lane & 2) ? 16 : 0)) : 0));
+        s8_0 = p01 & 0xffff; s8_1 = (int) ((unsigned)p01 >> 16); s8_2 = p23 & 0xffff; s8_3 = (int) ((unsigned)p23 >> 16);
+      }
       int sign = 15;
       {
         const int avg = (s8_0 + s8_1 + s8_2 + s8_3) >> 2;
@@ -1047,7 +1057,7 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, WhInterStage& G, const WhSeqParams& 
     if (lane < 16) { Ms->mv[lane][0] = 0; Ms->mv[lane][1] = 0; Rs->mvd[lane][0] = 0; Rs->mvd[lane][1] = 0; }
     if (lane < 2) Rs->mv_tr[lane] = 0;
     if (lane < 4) { Ms->ref_idx[lane] = -1; Rs->ref_idx[lane] = -1; Rs->sub_type[lane] = 0; }
-    if (lane == 0) { Ms->sad_cost[0] = 0; Ms->p16mv[0] = (int16_t)p16x; Ms->p16mv[1] = (int16_t)p16y; Ms->skip_sad = 0; }
+    if (lane == 0) { Ms->sad_cost[0] = 0; Ms->p16mv[0] = (int16_t)p16x; Ms->p16mv[1] = (int16_t)p16y; Ms->skip_sad = 0; if (J.sad_cost0) ((WH_G int32_t*)J.sad_cost0)[xy] = 0; }
     WV_LANES_END
     wh_store_mb (M, P, J, mbx, mby, ir.mb_type, ir.cbp, qp, qpc, ir.i16_mode_std, ir.chroma_mode_std, ir.cost_luma, slice_idc);
     return;
@@ -1080,6 +1090,7 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, WhInterStage& G, const WhSeqParams& 
   if (lane == 0) {
     Ms->sad_cost[0] = sad_cost0; Ms->p16mv[0] = (int16_t)p16x; Ms->p16mv[1] = (int16_t)p16y;
     Ms->skip_sad = is_skip ? cost_skip_mb : 0;
+    if (J.sad_cost0) ((WH_G int32_t*)J.sad_cost0)[xy] = sad_cost0;
   }
   WV_LANES_END
   wh_store_mb (M, P, J, mbx, mby, mb_type, cbp, qp, qpc, 0, 0, cost_luma, slice_idc);

@@ -22,7 +22,7 @@ typedef struct WhMbLds {
   uint8_t  pred_c[128];       // Cb then Cr, stride 8
   uint8_t  pred4[9 * 16];     // candidate 4x4 predictions, [mode][y*4+x]
   int16_t  res[384];          // residual coefficients: luma blk*16 (luma4x4BlkIdx order), Cb 256.., Cr 320..
-  int16_t  tmp[576];          // transform scratch
+  int16_t  tmp[320];          // transform scratch: [0,256) coefficients, [256,320) per-lane maxima of wh_quant_blocks
   int32_t  part[64];          // reduction partials
   int32_t  part2[64];
   int16_t  dc[16];
@@ -433,12 +433,12 @@ WH_FN void wh_quant_blocks (WhMbLds& S, int base, int nblk, int qp, int ffrow, i
       dst[i] = wh_quant1_abs (S.res[base + i], wh_ff_row (ffrow, pos), wh_mf (qp, pos), &a);
       if (mx < a) mx = a;
     }
-    S.tmp[512 + lane] = mx;
+    S.tmp[256 + lane] = mx;
   }
   WV_LANES_END
   WV_LANES_BEGIN (lane)
   if (lane < nblk) {
-    S.part[lane] = wh_max (wh_max (S.tmp[512 + lane * 4], S.tmp[512 + lane * 4 + 1]), wh_max (S.tmp[512 + lane * 4 + 2], S.tmp[512 + lane * 4 + 3]));
+    S.part[lane] = wh_max (wh_max (S.tmp[256 + lane * 4], S.tmp[256 + lane * 4 + 1]), wh_max (S.tmp[256 + lane * 4 + 2], S.tmp[256 + lane * 4 + 3]));
     unsigned m = 0;
     for (int k = skip_dc; k < 16; ++k) m |= (unsigned) (dst[lane * 16 + wh_zigzag (k)] != 0) << (k - skip_dc);
     S.part2[lane] = (int32_t)m;

@@ -39,7 +39,10 @@ class EmuBackend : public Backend {
     }
   }
   void run_intra (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
-    for_order (P, n, false, [&] (int j, int x, int y) { WhMbLds S; poison (&S, sizeof (S)); wh_intra_mb_body (S, P, jobs[j], x, y); });
+    for_order (P, n, false, [&] (int j, int x, int y) {
+      const int xy = y * P.mb_w + x;
+      if (jobs[j].mb_end > 0 && (xy < jobs[j].mb_begin || xy >= jobs[j].mb_end)) return;      // GOM-synchronous coding: only this range
+      WhMbLds S; poison (&S, sizeof (S)); wh_intra_mb_body (S, P, jobs[j], x, y); });
   }
   void run_inter (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
     // one emulated wavefront walks each slice in order, with the same one-MB look-ahead as the device scheduler: the
@@ -53,9 +56,14 @@ class EmuBackend : public Backend {
         poison (&S, sizeof (S)); poison (&G, sizeof (G)); poison (&GW, sizeof (GW)); poison (&WB, sizeof (WB));
         WhWinPf pf; pf.valid = 0;
         const int first = P.slice_first_mb[s], last = P.slice_first_mb[s + 1];
-        { const int xy = P.mb_order[first]; for (int lane = 0; lane < 64; ++lane) wh_inter_cold_fetch (G, lane, P, jobs[j], xy % P.mb_w, xy / P.mb_w); }
-        for (int t = first; t < last; ++t) {
-          const int xy = P.mb_order[t], xyn = t + 1 < last ? P.mb_order[t + 1] : 0;
+        // the MBs of the range this launch codes (all of the slice unless the job restricts it), in dependency order
+        std::vector<int> todo;
+        for (int t = first; t < last; ++t) { const int xy = P.mb_order[t]; if (jobs[j].mb_end > 0 && (xy < jobs[j].mb_begin || xy >= jobs[j].mb_end)) continue; todo.push_back (xy); }
+        if (todo.empty()) continue;
+        { const int xy = todo[0]; for (int lane = 0; lane < 64; ++lane) wh_inter_cold_fetch (G, lane, P, jobs[j], xy % P.mb_w, xy / P.mb_w); }
+        for (size_t ti = 0; ti < todo.size(); ++ti) {
+          const int t = (int)ti, last = (int)todo.size();
+          const int xy = todo[ti], xyn = ti + 1 < todo.size() ? todo[ti + 1] : 0;
           WhInterCtx X;
           X.slice_idc = s; X.slice_first = first;
           X.next_valid = t + 1 < last; X.next_mbx = xyn % P.mb_w; X.next_mby = xyn / P.mb_w; X.pf = &pf;
