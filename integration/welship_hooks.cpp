@@ -1,0 +1,298 @@
+// welship_hooks.cpp -- the reference-side binding of libwelship.so at the SWelsFuncPtrList dispatch surface.
+//
+// This file is compiled INTO a patched copy of the reference encoder (integration/openh264_hip.patch, HAVE_HIP), against
+// the reference's own headers, exactly like an x86/NEON back end would be: it is the code an OpenH264 maintainer adds.  It is
+// not part of libwelship.so and it contains no mode decision: it converts between the reference's structures and the C ABI of
+// include/welship.h (2b, the explicit frame API) and keeps the reference's frame layer, reference-list management, pre-
+// processing, rate control and entropy coder in charge.
+//
+//   WelsHipInstall (pFuncList, pParam)       end of InitFunctionPointers (codec/encoder/core/src/encoder.cpp:157-232): decides
+//                                            whether this session can run on the device and fills the three hook pointers
+//   pfHipFrameMd (pCtx)                      after PreprocessSliceCoding (encoder_ext.cpp:3652): the whole picture on the
+//                                            device -- WelsISliceMdEnc / WelsMdInterMbLoop (svc_encode_slice.cpp:534-599,
+//                                            1807-1899) for every slice, PerformDeblockingFilter (deblocking.cpp:744-762),
+//                                            border expansion (ref_list_mgr_svc.cpp:375)
+//   pfHipCodeSlice (pCtx, pSlice)            in WelsCodeOneSlice (svc_encode_slice.cpp:1642) instead of g_pWelsSliceCoding[][]:
+//                                            the host loop that is left -- pfWelsRcMbInit, neighbour caches,
+//                                            pfWelsSpatialWriteMbSyn, pfWelsRcMbInfoUpdate per macroblock
+//   pfHipRelease (state)                     WelsUninitEncoderExt (encoder_ext.cpp:2239)
+//
+// What runs on the device (see WelsHipSupported below): camera video, one spatial layer (or simulcast AVC layers, each with
+// its own context), CAVLC, slice modes with a frame-constant QP (rate control off, or on with more than one slice, or I
+// pictures in bitrate mode: WelsRcMbInitGom with bEnableGomQp == false, ratectl.cpp:1199-1204,1239-1262), any number of
+// temporal layers, LTR, denoising, scene-change detection, frame skipping.  Everything else keeps the reference's C path --
+// the hooks stay NULL, as they would on a CPU without the needed SIMD level.
+#if defined(HAVE_HIP)
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <map>
+#include <vector>
+
+#include "encoder_context.h"
+#include "svc_enc_slice_segment.h"
+#include "svc_encode_slice.h"
+#include "svc_base_layer_md.h"
+#include "svc_set_mb_syn.h"
+#include "svc_enc_golomb.h"
+#include "rc.h"
+#include "wels_preprocess.h"
+#include <dlfcn.h>
+#include "welship.h"
+#include "wh_types.h"          // WhMbRecord: the engine's per-macroblock record (openh264_amd/csrc/common)
+
+namespace WelsEnc {
+
+namespace {
+
+// libwelship.so is bound at run time ($WELSHIP_LIB, else the name the loader finds): a build of the reference with HAVE_HIP
+// still runs -- on its C path -- on a machine without the library or without an MI355X.
+struct HipApi {
+  int (*FrameCtxCreate) (WelsHipFrameCtx**, const WelsHipFrameCfg*);
+  void (*FrameCtxDestroy) (WelsHipFrameCtx*);
+  int (*FrameEncode) (WelsHipFrameCtx*, const WelsHipFrameJob*, const void**);
+  int (*FrameGetPicture) (WelsHipFrameCtx*, int, uint8_t* const*, const int32_t*);
+  const char* (*GetLastError) (void);
+  bool ok;
+};
+HipApi g_api = { NULL, NULL, NULL, NULL, NULL, false };
+bool LoadApi() {
+  if (g_api.ok) return true;
+  const char* path = getenv ("WELSHIP_LIB");
+  void* h = dlopen (path && *path ? path : "libwelship.so", RTLD_NOW | RTLD_LOCAL);
+  if (!h) return false;
+  g_api.FrameCtxCreate = (int (*) (WelsHipFrameCtx**, const WelsHipFrameCfg*))dlsym (h, "WelsHipFrameCtxCreate");
+  g_api.FrameCtxDestroy = (void (*) (WelsHipFrameCtx*))dlsym (h, "WelsHipFrameCtxDestroy");
+  g_api.FrameEncode = (int (*) (WelsHipFrameCtx*, const WelsHipFrameJob*, const void**))dlsym (h, "WelsHipFrameEncode");
+  g_api.FrameGetPicture = (int (*) (WelsHipFrameCtx*, int, uint8_t* const*, const int32_t*))dlsym (h, "WelsHipFrameGetPicture");
+  g_api.GetLastError = (const char* (*) (void))dlsym (h, "WelsHipGetLastError");
+  g_api.ok = g_api.FrameCtxCreate && g_api.FrameCtxDestroy && g_api.FrameEncode && g_api.FrameGetPicture && g_api.GetLastError;
+  return g_api.ok;
+}
+
+struct HipLayer {                       // one spatial layer = one device context
+  WelsHipFrameCtx* ctx = NULL;
+  std::map<const SPicture*, int> twin;   // reference SPicture -> device picture index
+  int num_pictures = 0;
+  const WhMbRecord* records = NULL;      // of the picture being coded (valid from pfHipFrameMd to the end of its slices)
+};
+
+struct HipState {
+  HipLayer layer[MAX_DEPENDENCY_LAYER];
+  int device = 0;
+  bool failed = false;                  // a device call failed: the session reports errors from then on
+  bool trace = false;
+};
+
+int TwinOf (HipLayer& L, const SPicture* p) {
+  std::map<const SPicture*, int>::iterator it = L.twin.find (p);
+  if (it != L.twin.end()) return it->second;
+  const int idx = (int)L.twin.size();
+  if (idx >= L.num_pictures) return -1;
+  L.twin[p] = idx;
+  return idx;
+}
+
+// Frame-constant QP?  (ratectl.cpp:1199-1204: GOM-level QP only for single-slice pictures, and not for I pictures in bitrate mode)
+bool FrameConstantQp (const sWelsEncCtx* pCtx) {
+  const SWelsSvcCodingParam* p = pCtx->pSvcParam;
+  if (p->iRCMode == RC_OFF_MODE) return true;
+  return !pCtx->pWelsSvcRc[pCtx->uiDependencyId].bEnableGomQp;
+}
+
+int32_t HipFrameMd (sWelsEncCtx* pCtx) {
+  SWelsFuncPtrList* pFunc = pCtx->pFuncList;
+  HipState* st = (HipState*)pFunc->pHipState;
+  if (st == NULL || st->failed) return ENC_RETURN_UNEXPECTED;
+  SDqLayer* pCurLayer = pCtx->pCurDqLayer;
+  const int did = pCtx->uiDependencyId;
+  HipLayer& L = st->layer[did];
+  const SWelsSvcCodingParam* pParam = pCtx->pSvcParam;
+  const int mbw = pCurLayer->iMbWidth, mbh = pCurLayer->iMbHeight, num_mb = mbw * mbh;
+  if (L.ctx == NULL) {
+    WelsHipFrameCfg cfg;
+    memset (&cfg, 0, sizeof (cfg));
+    cfg.iDevice = st->device;
+    cfg.iPicWidth = mbw * 16; cfg.iPicHeight = mbh * 16;
+    cfg.iNumPictures = pParam->iNumRefFrame + 2;          // RequestMemorySvc allocates 1 + iNumRefFrame pictures per layer
+    L.num_pictures = cfg.iNumPictures;
+    const int rc = g_api.FrameCtxCreate (&L.ctx, &cfg);
+    if (rc) { fprintf (stderr, "welship hooks: no device context (%d: %s)\n", rc, g_api.GetLastError()); st->failed = true; return ENC_RETURN_UNEXPECTED; }
+  }
+  if (!FrameConstantQp (pCtx)) {
+    // cannot happen for a session WelsHipSupported accepted, unless the parameters were changed in mid-stream
+    fprintf (stderr, "welship hooks: GOM-level QP requested in a session that was installed for frame-constant QP\n");
+    st->failed = true;
+    return ENC_RETURN_UNSUPPORTED_PARA;
+  }
+  WelsHipFrameJob job;
+  memset (&job, 0, sizeof (job));
+  const bool is_p = pCtx->eSliceType == P_SLICE;
+  job.iCurPic = TwinOf (L, pCtx->pDecPic);
+  job.iRefPic = is_p ? TwinOf (L, pCurLayer->pRefPic) : -1;
+  if (job.iCurPic < 0 || (is_p && job.iRefPic < 0)) { fprintf (stderr, "welship hooks: more reference pictures than device twins\n"); st->failed = true; return ENC_RETURN_UNEXPECTED; }
+  job.eSliceType = is_p ? 0 : 2;
+  job.iQp = pCtx->iGlobalQp;
+  job.iChromaQpIndexOffset = pCurLayer->sLayerInfo.pPpsP->uiChromaQpIndexOffset;
+  job.iComplexityMode = pParam->iComplexityMode;
+  job.iMvRange = pCtx->iMvRange;
+  // pSlice->sScaleShift (svc_encode_slice.cpp:1652-1655), the same for every slice of the picture
+  job.iMvcShift = (is_p && pCtx->uiTemporalId) ? (int) (pCtx->uiTemporalId - pCtx->pRefPic->uiTemporalId) : 0;
+  std::vector<int32_t> first;
+  const int nslices = GetCurrentSliceNum (pCurLayer);
+  for (int i = 0; i < nslices; ++i) first.push_back (pCurLayer->pFirstMbIdxOfSlice[i]);
+  first.push_back (num_mb);
+  job.iNumSlices = nslices;
+  job.pSliceFirstMb = &first[0];
+  job.iDeblockIdc = pCurLayer->iLoopFilterDisableIdc;
+  job.iAlphaOffset = pCurLayer->iLoopFilterAlphaC0Offset;
+  job.iBetaOffset = pCurLayer->iLoopFilterBetaOffset;
+  // the condition WelsEncoderEncodeExt evaluates after the slices are coded (encoder_ext.cpp:3870-3880); its inputs are known now
+  const int iHighestTid = pParam->sDependencyLayers[did].iHighestTemporalId;
+  job.bDeblock = (!pCurLayer->bDeblockingParallelFlag) && pCtx->eNalPriority != NRI_PRI_LOWEST && (iHighestTid == 0 || pCtx->uiTemporalId < iHighestTid)
+                 && pCurLayer->iLoopFilterDisableIdc != 1;
+  job.bExpand = pCtx->eNalPriority != NRI_PRI_LOWEST;        // UpdateRefList -> ExpandReferencingPicture (encoder_ext.cpp:3891-3899)
+  for (int i = 0; i < 3; ++i) { job.pSrc[i] = pCurLayer->pEncData[i]; job.iSrcStride[i] = pCurLayer->iEncStride[i]; }
+  job.pVaaSad8x8 = (is_p && pCtx->pVaa && pCtx->pVaa->sVaaCalcInfo.pSad8x8) ? &pCtx->pVaa->sVaaCalcInfo.pSad8x8[0][0] : NULL;
+  job.pBgdFlags = NULL;
+  const void* rec = NULL;
+  const int rc = g_api.FrameEncode (L.ctx, &job, &rec);
+  if (rc) { fprintf (stderr, "welship hooks: WelsHipFrameEncode failed (%d: %s)\n", rc, g_api.GetLastError()); st->failed = true; return ENC_RETURN_UNEXPECTED; }
+  L.records = (const WhMbRecord*)rec;
+  // the host's copy of the reconstruction (PSNR, reconstruction dumps, pre-processing that looks at the reference picture)
+  uint8_t* dst[3] = { pCtx->pDecPic->pData[0], pCtx->pDecPic->pData[1], pCtx->pDecPic->pData[2] };
+  const int32_t ds[3] = { pCtx->pDecPic->iLineSize[0], pCtx->pDecPic->iLineSize[1], pCtx->pDecPic->iLineSize[2] };
+  if (g_api.FrameGetPicture (L.ctx, job.iCurPic, dst, ds)) { st->failed = true; return ENC_RETURN_UNEXPECTED; }
+  if (st->trace) fprintf (stderr, "welship hooks: did %d %c picture qp %d slices %d cur %d ref %d deblock %d expand %d\n", did, is_p ? 'P' : 'I', job.iQp, nslices, job.iCurPic, job.iRefPic, job.bDeblock, job.bExpand);
+  return ENC_RETURN_SUCCESS;
+}
+
+static const Mb_Type kMbType[7] = { MB_TYPE_INTRA4x4, MB_TYPE_INTRA16x16, MB_TYPE_16x16, MB_TYPE_16x8, MB_TYPE_8x16, MB_TYPE_8x8, MB_TYPE_SKIP };
+
+// One macroblock record -> SMB + the parts of SMbCache the entropy writer reads (svc_set_mb_syn_cavlc.cpp:60-330).
+void LoadRecord (const WhMbRecord& R, SMB* pMb, SMbCache* pMbCache) {
+  pMb->uiMbType = kMbType[R.mb_type <= 6 ? R.mb_type : 6];
+  pMb->uiCbp = R.cbp;
+  for (int i = 0; i < 4; ++i) { pMb->uiSubMbType[i] = SUB_MB_TYPE_8x8; pMb->pRefIndex[i] = R.ref_idx[i]; }
+  // the writer codes sMv - sMbMvp (WelsSpatialWriteMbPred); the device hands over that difference, so the predictor is zero
+  for (int i = 0; i < 16; ++i) {
+    pMb->sMv[i].iMvX = R.mvd[i][0]; pMb->sMv[i].iMvY = R.mvd[i][1];
+    pMbCache->sMbMvp[i].iMvX = 0; pMbCache->sMbMvp[i].iMvY = 0;
+  }
+  // total_coeff: luma raster 0..15; chroma as the reference lays it out -- Cb 16,17,20,21 and Cr 18,19,22,23
+  for (int i = 0; i < 16; ++i) pMb->pNonZeroCount[i] = (int8_t)R.nzc[i];
+  static const int kC[8] = { 16, 17, 20, 21, 18, 19, 22, 23 };
+  for (int i = 0; i < 8; ++i) pMb->pNonZeroCount[kC[i]] = (int8_t)R.nzc[16 + i];
+  pMbCache->uiLumaI16x16Mode = R.i16_mode;
+  pMbCache->uiChmaI8x8Mode = R.chroma_mode;
+  if (R.mb_type == WH_MB_I4x4) {
+    // luma4x4BlkIdx order on both sides (pPrevIntra4x4PredModeFlag / pRemIntra4x4PredModeFlag are written in coding order)
+    for (int i = 0; i < 16; ++i) { pMbCache->pPrevIntra4x4PredModeFlag[i] = ((R.i4_prev_flags >> i) & 1) != 0; pMbCache->pRemIntra4x4PredModeFlag[i] = R.i4_rem[i]; }
+  }
+  // SDCTCoeff (mb_cache.h:62-70) and the record's coefficient part have the same layout
+  memcpy (pMbCache->pDct, &R.luma[0][0], sizeof (SDCTCoeff));
+}
+
+int32_t HipCodeSlice (sWelsEncCtx* pCtx, SSlice* pSlice) {
+  SWelsFuncPtrList* pFunc = pCtx->pFuncList;
+  HipState* st = (HipState*)pFunc->pHipState;
+  HipLayer& L = st->layer[pCtx->uiDependencyId];
+  if (st->failed || L.records == NULL) return ENC_RETURN_UNEXPECTED;
+  SDqLayer* pCurLayer = pCtx->pCurDqLayer;
+  SMbCache* pMbCache = &pSlice->sMbCacheInfo;
+  SMB* pMbList = pCurLayer->sMbDataP;
+  const int32_t kiSliceFirstMbXY = pSlice->sSliceHeaderExt.sSliceHeader.iFirstMbInSlice;
+  const int32_t kiTotalNumMb = pCurLayer->iMbWidth * pCurLayer->iMbHeight;
+  const int32_t kiSliceIdx = pSlice->iSliceIdx;
+  const bool is_p = pCtx->eSliceType == P_SLICE;
+  int32_t iNextMbIdx = kiSliceFirstMbXY, iNumMbCoded = 0;
+  static_assert (sizeof (SDCTCoeff) == 816, "SDCTCoeff layout");
+  if (is_p) pSlice->iMbSkipRun = 0;
+  for (;;) {
+    const int32_t iCurMbIdx = iNextMbIdx;
+    SMB* pCurMb = &pMbList[iCurMbIdx];
+    const WhMbRecord& R = L.records[iCurMbIdx];
+    // QP of the macroblock: what the device was given (frame constant), through the reference's own RC entry point
+    pFunc->pfRc.pfWelsRcMbInit (pCtx, pCurMb, pSlice);
+    if (pCurMb->uiLumaQp != R.luma_qp) { fprintf (stderr, "welship hooks: QP mismatch at MB %d (%d vs %d)\n", iCurMbIdx, pCurMb->uiLumaQp, R.luma_qp); st->failed = true; return ENC_RETURN_UNEXPECTED; }
+    // neighbour caches the entropy writer reads (non-zero counts): the reference's own init functions
+    WelsMdIntraInit (pCtx, pCurMb, pMbCache, kiSliceFirstMbXY);
+    if (is_p) WelsMdInterInit (pCtx, pSlice, pCurMb, kiSliceFirstMbXY);
+    LoadRecord (R, pCurMb, pMbCache);
+    UpdateNonZeroCountCache (pCurMb, pMbCache);
+    const int32_t iEncReturn = pFunc->pfWelsSpatialWriteMbSyn (pCtx, pSlice, pCurMb);
+    if (iEncReturn == ENC_RETURN_VLCOVERFLOWFOUND) {
+      // the reference re-encodes the macroblock at QP + 2 (TRY_REENCODING); with the picture already coded on the device that
+      // is a second pass over the picture, which the session API implements and this binding does not yet
+      fprintf (stderr, "welship hooks: CAVLC overflow at MB %d -- re-encoding is not implemented in the dispatch-table binding\n", iCurMbIdx);
+      st->failed = true;
+      return ENC_RETURN_UNEXPECTED;
+    }
+    if (ENC_RETURN_SUCCESS != iEncReturn) return iEncReturn;
+    pCurMb->uiSliceIdc = kiSliceIdx;
+    pFunc->pfRc.pfWelsRcMbInfoUpdate (pCtx, pCurMb, R.cost, pSlice);
+    ++iNumMbCoded;
+    iNextMbIdx = WelsGetNextMbOfSlice (pCurLayer, iCurMbIdx);
+    if (iNextMbIdx == -1 || iNextMbIdx >= kiTotalNumMb || iNumMbCoded >= kiTotalNumMb) break;
+  }
+  if (is_p && pSlice->iMbSkipRun) BsWriteUE (pSlice->pSliceBsa, pSlice->iMbSkipRun);
+  return ENC_RETURN_SUCCESS;
+}
+
+void HipRelease (void* p) {
+  HipState* st = (HipState*)p;
+  if (st == NULL) return;
+  for (int i = 0; i < MAX_DEPENDENCY_LAYER; ++i) if (st->layer[i].ctx) g_api.FrameCtxDestroy (st->layer[i].ctx);
+  delete st;
+}
+
+// Which sessions run on the device.  `why` receives the reason when the answer is no.
+bool WelsHipSupported (const SWelsSvcCodingParam* p, const char** why) {
+#define NO(msg) do { *why = msg; return false; } while (0)
+  if (p->iUsageType != CAMERA_VIDEO_REAL_TIME) NO ("screen content (feature / scroll search) stays on the C path");
+  if (p->iEntropyCodingModeFlag != 0) NO ("CABAC: the host writer needs mvd / cbp contexts the records do not carry yet");
+  if (p->iSpatialLayerNum != 1 && !p->bSimulcastAVC) NO ("spatial layers with inter-layer prediction");
+  if (p->iSpatialLayerNum != 1) NO ("more than one spatial layer");      // lifted per layer by the simulcast session
+  if (p->iMultipleThreadIdc != 1) NO ("slice threads: the host loop is single-threaded in this binding");
+  if (p->bEnableBackgroundDetection) NO ("background detection: the BGD skip branch (svc_mode_decision.cpp:216-283) is not on the device yet");
+  // bEnableAdaptiveQuant: ParamValidation switches it off for every session (encoder_ext.cpp:300-301), nothing to check
+  for (int i = 0; i < p->iSpatialLayerNum; ++i) {
+    const SSliceArgument& sa = p->sSpatialLayers[i].sSliceArgument;
+    if (sa.uiSliceMode == SM_SIZELIMITED_SLICE) NO ("size-limited slices feed the bitstream position back into mode decision");
+    if (p->iRCMode != RC_OFF_MODE && sa.uiSliceMode == SM_SINGLE_SLICE) NO ("rate control with one slice per picture sets the QP per group of macroblocks from the bits written so far");
+  }
+  return true;
+#undef NO
+}
+
+}  // namespace
+
+// The installer: what an `#if defined(X86_ASM)` block is for the SIMD variants (encoder.cpp:157-232).
+void WelsHipInstall (SWelsFuncPtrList* pFuncList, SWelsSvcCodingParam* pParam) {
+  pFuncList->pfHipFrameMd = NULL;
+  pFuncList->pfHipCodeSlice = NULL;
+  pFuncList->pfHipRelease = NULL;
+  pFuncList->pHipState = NULL;
+  const char* off = getenv ("WELS_HIP");
+  if (off && atoi (off) == 0) return;
+  const char* why = "";
+  if (!WelsHipSupported (pParam, &why)) {
+    if (getenv ("WELS_HIP_TRACE")) fprintf (stderr, "welship hooks: not installed (%s)\n", why);
+    return;
+  }
+  if (!LoadApi()) {
+    if (getenv ("WELS_HIP_TRACE")) fprintf (stderr, "welship hooks: not installed (libwelship.so not loadable: %s)\n", dlerror() ? dlerror() : "missing symbols");
+    return;
+  }
+  HipState* st = new HipState();
+  st->device = getenv ("WELS_HIP_DEVICE") ? atoi (getenv ("WELS_HIP_DEVICE")) : 0;
+  st->trace = getenv ("WELS_HIP_TRACE") != NULL;
+  pFuncList->pHipState = st;
+  pFuncList->pfHipFrameMd = HipFrameMd;
+  pFuncList->pfHipCodeSlice = HipCodeSlice;
+  pFuncList->pfHipRelease = HipRelease;
+  if (st->trace) fprintf (stderr, "welship hooks: installed\n");
+}
+
+}  // namespace WelsEnc
+#endif  // HAVE_HIP

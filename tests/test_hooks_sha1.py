@@ -1,0 +1,115 @@
+"""The metric's own parity gate: rows of the reference's checked-in bitstream-regression table
+(test/encoder_binary_comparison/SHA1Table/BA_MW_D.264_AllCases_SHA1_Table.csv) run through the reference's own console
+encoder with this repository's engine installed behind SWelsFuncPtrList (integration/openh264_hip.patch +
+integration/welship_hooks.cpp -> oracle/_ref/h264enc_hiphooks), exactly the way
+test/encoder_binary_comparison/Scripts/run_BinarySHA1Comparison.sh:165-241 runs them: welsenc.cfg + layer2.cfg copied as
+layer0..3.cfg, the row's options on the command line, SHA1 of the bitstream against the table's first column.
+
+Rows the dispatch-table binding takes to the device: every option combination of the table (rate-control mode 1 and 3,
+1 and 3 temporal layers, LTR, denoising, scene-change detection, frame skipping) with a fixed number of slices
+(-slcmd 1, 4 or 7 slices).  Single-slice rows (GOM-level QP), size-limited slices and background detection keep the
+reference's C path -- the hooks report that, and the test checks that they are NOT counted as device rows.
+
+CPU tier: the wave emulation of the kernel sources (tests/emu); GPU tier (-m gpu): libwelship.so on the MI355X.
+"""
+import csv
+import hashlib
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.path.join(ROOT, "oracle", "_ref")
+RES = os.path.join(REF, "res")
+TABLE = os.path.join(RES, "BA_MW_D.264_AllCases_SHA1_Table.csv")
+H264ENC = os.path.join(REF, "h264enc_hiphooks")
+pytestmark = pytest.mark.skipif(not (os.path.exists(TABLE) and os.path.exists(H264ENC)), reason="oracle/_ref (hooked reference + table) not built")
+
+
+def _rows():
+    rows = list(csv.reader(open(TABLE)))
+    hdr = [h.strip() for h in rows[0]]
+    out = []
+    for r in rows[1:]:
+        vals = [v.strip() for v in r]
+        d = dict(zip(hdr, vals))
+        out.append((vals[0], vals[1], hdr[2:], vals[2:], d))
+    return out
+
+
+def _device_rows():
+    """Rows the binding installs the hooks for: -slcmd 1 (fixed slice number) and no background detection."""
+    return [r for r in _rows() if r[4]["-slcmd 0"] == "1" and r[4]["bgd"] == "0"]
+
+
+@pytest.fixture(scope="module")
+def workdir(tmp_path_factory, ref_tools):
+    if not ref_tools:
+        pytest.skip("oracle/_ref not built")
+    d = tmp_path_factory.mktemp("sha1table")
+    subprocess.check_call([ref_tools["dec"], os.path.join(RES, "BA_MW_D.264"), str(d / "BA_MW_D.264.yuv")], stdout=subprocess.DEVNULL)
+    for k in range(4):
+        (d / ("layer%d.cfg" % k)).write_bytes(open(os.path.join(RES, "layer2.cfg"), "rb").read())
+    (d / "welsenc.cfg").write_bytes(open(os.path.join(RES, "welsenc.cfg"), "rb").read())
+    return d
+
+
+def _run_row(workdir, lib, row, tag):
+    sha, yuv_sha, keys, vals, _ = row
+    opts = []
+    for k, v in zip(keys, vals):
+        opts += k.split() + [v]
+    opts = [o if o != "bgd" else "-bgd" for o in opts]       # the table's header spells this one column without its dash
+    out = str(workdir / ("t_%s.264" % tag))
+    env = dict(os.environ, WELSHIP_LIB=lib, WELS_HIP_TRACE="1")
+    p = subprocess.run([H264ENC, "welsenc.cfg", "-lconfig", "0", "layer0.cfg", "-lconfig", "1", "layer1.cfg", "-lconfig", "2", "layer2.cfg",
+                        "-lconfig", "3", "layer3.cfg", "-bf", out, "-org", str(workdir / "BA_MW_D.264.yuv")] + opts,
+                       cwd=str(workdir), env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    err = p.stderr.decode(errors="replace")
+    assert p.returncode == 0, err[-2000:]
+    pictures = err.count("welship hooks: did")
+    return hashlib.sha1(open(out, "rb").read()).hexdigest(), pictures, err
+
+
+def _check(workdir, lib, rows):
+    bad = []
+    for i, row in enumerate(rows):
+        got, pictures, err = _run_row(workdir, lib, row, str(i))
+        if got != row[0] or pictures < 40:          # 50 frames per case; rate control may skip a few
+            bad.append((row[4], row[0], got, pictures))
+    assert not bad, "%d of %d rows differ, first: %s" % (len(bad), len(rows), bad[0])
+
+
+def test_table_shape():
+    rows = _rows()
+    assert len(rows) == 2304
+    dev = _device_rows()
+    assert len(dev) == 512
+    assert len({r[0] for r in dev}) >= 8            # distinct streams among them
+    assert all(r[1] == "afd7a9765961ca241bb4bdf344b31397bec7465a" for r in rows)
+
+
+def _sample(rows, n):
+    """An even sample that keeps every option of the table represented (the row order cycles through them)."""
+    step = max(1, len(rows) // n)
+    return [rows[(i * step + (i % 7)) % len(rows)] for i in range(n)]
+
+
+def test_sha1_table_rows_on_emulation(workdir, emu_lib):
+    _check(workdir, emu_lib, _sample(_device_rows(), 40))
+
+
+def test_unsupported_rows_stay_on_the_c_path(workdir, emu_lib):
+    """Single-slice rows under rate control need the QP of every group of macroblocks from the bits written so far: the hooks
+    decline, the reference codes the stream itself and still matches the table."""
+    rows = [r for r in _rows() if r[4]["-slcmd 0"] == "0"][:2] + [r for r in _rows() if r[4]["-slcmd 0"] == "1" and r[4]["bgd"] == "1"][:2]
+    for i, row in enumerate(rows):
+        got, pictures, err = _run_row(workdir, emu_lib, row, "c%d" % i)
+        assert "not installed" in err and pictures == 0
+        assert got == row[0]
+
+
+@pytest.mark.gpu
+def test_sha1_table_rows_on_the_mi355x(workdir, hip_lib):
+    _check(workdir, hip_lib, _sample(_device_rows(), 48))
