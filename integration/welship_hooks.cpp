@@ -154,7 +154,7 @@ int32_t HipFrameMd (sWelsEncCtx* pCtx) {
   job.bExpand = pCtx->eNalPriority != NRI_PRI_LOWEST;        // UpdateRefList -> ExpandReferencingPicture (encoder_ext.cpp:3891-3899)
   for (int i = 0; i < 3; ++i) { job.pSrc[i] = pCurLayer->pEncData[i]; job.iSrcStride[i] = pCurLayer->iEncStride[i]; }
   job.pVaaSad8x8 = (is_p && pCtx->pVaa && pCtx->pVaa->sVaaCalcInfo.pSad8x8) ? &pCtx->pVaa->sVaaCalcInfo.pSad8x8[0][0] : NULL;
-  job.pBgdFlags = NULL;
+  job.pBgdFlags = (is_p && pParam->bEnableBackgroundDetection && pCtx->pVaa) ? pCtx->pVaa->pVaaBackgroundMbFlag : NULL;
   const void* rec = NULL;
   const int rc = g_api.FrameEncode (L.ctx, &job, &rec);
   if (rc) { fprintf (stderr, "welship hooks: WelsHipFrameEncode failed (%d: %s)\n", rc, g_api.GetLastError()); st->failed = true; return ENC_RETURN_UNEXPECTED; }
@@ -230,6 +230,15 @@ int32_t HipCodeSlice (sWelsEncCtx* pCtx, SSlice* pSlice) {
     }
     if (ENC_RETURN_SUCCESS != iEncReturn) return iEncReturn;
     pCurMb->uiSliceIdc = kiSliceIdx;
+    if (R.bgd_skip) {
+      // VaaBackgroundMbDataUpdate (svc_base_layer_md.cpp:1341-1350): a background macroblock's source samples are replaced by the
+      // reference's, which the pre-processing of the following pictures sees
+      SVAAFrameInfo* pVaa = pCtx->pVaa;
+      const int32_t kiOffsetY = (pCurMb->iMbY * pVaa->iPicStride + pCurMb->iMbX) << 4, kiOffsetUV = (pCurMb->iMbY * pVaa->iPicStrideUV + pCurMb->iMbX) << 3;
+      pFunc->pfCopy16x16Aligned (pVaa->pCurY + kiOffsetY, pVaa->iPicStride, pVaa->pRefY + kiOffsetY, pVaa->iPicStride);
+      pFunc->pfCopy8x8Aligned (pVaa->pCurU + kiOffsetUV, pVaa->iPicStrideUV, pVaa->pRefU + kiOffsetUV, pVaa->iPicStrideUV);
+      pFunc->pfCopy8x8Aligned (pVaa->pCurV + kiOffsetUV, pVaa->iPicStrideUV, pVaa->pRefV + kiOffsetUV, pVaa->iPicStrideUV);
+    }
     pFunc->pfRc.pfWelsRcMbInfoUpdate (pCtx, pCurMb, R.cost, pSlice);
     ++iNumMbCoded;
     iNextMbIdx = WelsGetNextMbOfSlice (pCurLayer, iCurMbIdx);
@@ -254,7 +263,6 @@ bool WelsHipSupported (const SWelsSvcCodingParam* p, const char** why) {
   if (p->iSpatialLayerNum != 1 && !p->bSimulcastAVC) NO ("spatial layers with inter-layer prediction");
   if (p->iSpatialLayerNum != 1) NO ("more than one spatial layer");      // lifted per layer by the simulcast session
   if (p->iMultipleThreadIdc != 1) NO ("slice threads: the host loop is single-threaded in this binding");
-  if (p->bEnableBackgroundDetection) NO ("background detection: the BGD skip branch (svc_mode_decision.cpp:216-283) is not on the device yet");
   // bEnableAdaptiveQuant: ParamValidation switches it off for every session (encoder_ext.cpp:300-301), nothing to check
   for (int i = 0; i < p->iSpatialLayerNum; ++i) {
     const SSliceArgument& sa = p->sSpatialLayers[i].sSliceArgument;

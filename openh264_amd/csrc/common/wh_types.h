@@ -23,6 +23,7 @@ enum {
 };
 #define WH_IS_INTRA(t) ((t) <= WH_MB_I16x16)
 #define WH_IS_INTER(t) ((t) >= WH_MB_P16x16 && (t) <= WH_MB_PSKIP)
+#define WH_REFTYPE_BACKGROUND 64      /* WhMbState::ref_type of an MB_TYPE_BACKGROUND macroblock (coded as P_Skip) */
 
 enum { WH_SLICE_P = 0, WH_SLICE_I = 2 };
 
@@ -44,7 +45,8 @@ typedef struct WhMbRecord {
   uint8_t  nzc[24];          // total_coeff: luma raster 0..15, Cb raster 16..19, Cr raster 20..23
   int32_t  cost;             // mode-decision cost of the chosen mode (for rate control)
   int16_t  mv_tr[2];         // inter MBs: final motion vector of the top-right 4x4 block (see WhMbCtl::cell12_mv)
-  uint8_t  pad[16];
+  uint8_t  bgd_skip;         // P_Skip decided by background detection (MB_TYPE_BACKGROUND): the host mirrors VaaBackgroundMbDataUpdate
+  uint8_t  pad[15];
   // coefficient levels in zig-zag order:
   int16_t  luma[16][16];     // per luma4x4BlkIdx; I16x16: entries 0..14 = AC, [15] = 0
   int16_t  luma_dc[16];      // Intra16x16 DC levels
@@ -59,8 +61,9 @@ typedef struct WhMbState {
   uint8_t  chroma_qp;
   uint8_t  cbp;
   uint16_t slice_idc;
-  uint8_t  skip_flag;
-  uint8_t  pad0;
+  uint8_t  ref_type;         // uiRefMbType of the picture (picture.h:81): WH_MB_* + 1 as P pictures leave it (WH_REFTYPE_BACKGROUND for a
+                             //   background-skip MB), 0 = never written; I pictures do not touch it (WelsMdInterSaveSadAndRefMbType)
+  uint8_t  ref_qp;           // pRefMbQp of the picture (WelsMdUpdateBGDInfo, svc_mode_decision.cpp:267-282)
   int8_t   i4_mode[16];      // Intra4x4PredMode per 4x4 block, raster; 2 (DC) for non-I4x4 MBs
   uint8_t  nzc[24];          // as in WhMbRecord
   int16_t  mv[16][2];        // raster 4x4, quarter-pel

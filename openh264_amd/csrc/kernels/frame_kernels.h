@@ -57,7 +57,13 @@ WH_FN void wh_store_mb (WhMbLds& S, const WhSeqParams& P, const WhPicJob& J, int
     R->i4_prev_flags = (mb_type == WH_MB_I4x4) ? S.i4_prev : (uint16_t)0;
     R->cost = cost;
     M->mb_type = (uint8_t)mb_type; M->luma_qp = (uint8_t)qp; M->chroma_qp = (uint8_t)qpc; M->cbp = (uint8_t)cbp;
-    M->slice_idc = (uint16_t)slice_idc; M->skip_flag = 0;
+    M->slice_idc = (uint16_t)slice_idc;
+    R->bgd_skip = 0;
+    // uiRefMbType / pRefMbQp of the picture (read when it is a reference): P pictures store the type, I pictures leave the
+    // previous contents of the picture buffer alone (WelsMdInterSaveSadAndRefMbType is a P-slice step); both store the QP
+    // (WelsMdUpdateBGDInfo; wh_inter_mb_body overrides it for unchanged collocated macroblocks)
+    if (J.slice_type == WH_SLICE_P) M->ref_type = (uint8_t) (mb_type + 1);
+    M->ref_qp = (uint8_t)qp;
   }
   WV_LANES_END
 }

@@ -686,9 +686,9 @@ WH_FN void wh_inter_cold_fetch (WhInterStage& G, int lane, const WhSeqParams& P,
   }
   if (P.complexity == 0 && !J.vaa_sad8x8)     // VAA 8x8 SADs (LOW complexity only), unless the host supplies them
     wh_ld_async4 ((const WH_G uint8_t*)J.prev_src_y + (size_t) (mby * 16 + (lane >> 2)) * P.src_stride_y + mbx * 16 + (lane & 3) * 4, G.cold_pv, lane);
+  if (lane < 36 && J.ref_mbs) wh_ld_async4 ((const WH_G uint32_t*) ((const WH_G WhMbState*)J.ref_mbs + xy) + lane, G.cold_co, lane);
   if (J.ref_is_p) {
-    if (lane < 36) wh_ld_async4 ((const WH_G uint32_t*) ((const WH_G WhMbState*)J.ref_mbs + xy) + lane, G.cold_co, lane);
-    else if (lane < 38) {
+    if (lane >= 36 && lane < 38) {
       const bool ok = lane == 36 ? mbx < P.mb_w - 1 : mby < P.mb_h - 1;
       const WH_G WhMbState* o = (const WH_G WhMbState*)J.ref_mbs + xy + (lane == 36 ? 1 : w);
       if (ok) wh_ld_async4 (&o->p16mv[0], G.cold_co, lane);
@@ -743,7 +743,7 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, WhInterStage& G, const WhSeqParams& 
     tr.y = G.cold_y[lane]; tr.c = lane < 32 ? G.cold_c[lane] : 0u;
     wh_tile_commit (M, lane, &tr);
     * (uint32_t*)&S.prev_y[lane * 4] = G.cold_pv[lane];
-    if (lane < 36) S.nb[144 + lane] = ref_is_p ? G.cold_co[lane] : 0u;      // no co-located state after an IDR: reads as zeros
+    if (lane < 36) S.nb[144 + lane] = J.ref_mbs ? G.cold_co[lane] : 0u;     // the reference picture's state of this MB (an I picture's has no motion / SAD)
     else if (lane < 38) * (uint32_t*)&S.co_mv[lane - 36][0] = G.cold_co[lane];
     else if (lane == 38) S.nb[144 + 35] = G.cold_co[38];     // rides in the padding word of the co-located state copy (WhMbState::pad1)
 #pragma unroll
@@ -794,8 +794,27 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, WhInterStage& G, const WhSeqParams& 
   // neighbour SAD / skip context, order of the reference's caches: [0] top-left, [1] top, [2] top-right, [3] left
   const int sadc0 = tl_inter ? TLm->sad_cost[0] : 0, sadc1 = t_inter ? Tm->sad_cost[0] : 0, sadc2 = tr_inter ? TRm->sad_cost[0] : 0, sadc3 = l_inter ? Lm->sad_cost[0] : 0;
   const bool tl_sk = tl_type == WH_MB_PSKIP, t_sk = t_type == WH_MB_PSKIP, tr_sk = tr_type == WH_MB_PSKIP, l_sk = l_type == WH_MB_PSKIP;
-  const int sadsk0 = tl_sk ? TLm->skip_sad : 0, sadsk1 = t_sk ? Tm->skip_sad : 0, sadsk2 = tr_sk ? TRm->skip_sad : 0, sadsk3 = l_sk ? Lm->skip_sad : 0;
+  // background detection (pVaaBackgroundMbFlag): this MB's flag and its neighbours'; entry k of the lane table: 0 this MB,
+  // 1 left, 2 top, 3 top-right, 4 top-left (only read for neighbours that exist)
+  const bool bgd = J.bgd_flags != nullptr;
+  WvLaneArr bgf;
+#if defined(WH_EMU)
+  memset (&bgf, 0, sizeof (bgf));
+#else
+  bgf = 0;
+#endif
+  if (bgd) {
+    WV_LSET_IF (bgf, lane, lane < 5, ([&] () { const int off = lane == 0 ? 0 : lane == 1 ? -1 : lane == 2 ? -w : lane == 3 ? -w + 1 : -w - 1;
+                                              return xy + off >= 0 ? (int) ((const WH_G int8_t*)J.bgd_flags)[xy + off] : 0; }) ());
+  }
+  const bool bg_cur = bgd && WV_LGET (bgf, 0) != 0, bg_l = bgd && WV_LGET (bgf, 1) != 0, bg_t = bgd && WV_LGET (bgf, 2) != 0;
+  const bool bg_tr = bgd && WV_LGET (bgf, 3) != 0, bg_tl = bgd && WV_LGET (bgf, 4) != 0;
+  // skip context of PredictSadSkip: with background detection a skipped neighbour only counts when it is not background
+  // (FillNeighborCacheInterWithBGD, md.cpp:253-372)
+  const bool tl_skc = tl_sk && !bg_tl, t_skc = t_sk && !bg_t, tr_skc = tr_sk && !bg_tr, l_skc = l_sk && !bg_l;
+  const int sadsk0 = tl_skc ? TLm->skip_sad : 0, sadsk1 = t_skc ? Tm->skip_sad : 0, sadsk2 = tr_skc ? TRm->skip_sad : 0, sadsk3 = l_skc ? Lm->skip_sad : 0;
   const int ref_mb_type = ref_is_p ? Co->mb_type : WH_MB_NONE;
+  const bool ref_mb_bg = Co->ref_type == WH_REFTYPE_BACKGROUND;         // a background skip is not MB_TYPE_SKIP where the reference asks for exactly that
   WhMeCtx C;
   C.mbx = mbx; C.mby = mby; C.lambda = lambda; C.use_satd = use_satd;
   C.minx = wh_max (- ((mbx + 1) << 4) + 3, -P.mv_range); C.miny = wh_max (- ((mby + 1) << 4) + 3, -P.mv_range);
@@ -834,26 +853,78 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, WhInterStage& G, const WhSeqParams& 
   int skx = 0, sky = 0;
   bool done = false;
 
-  // ---- P_Skip test (WelsMdInterJudgePskip / WelsMdPSkipEnc) ----
+  // PredictSadSkip (md.cpp:872-910)
+  auto predict_sad_skip = [&] () {
+    const int rb = WV_LGET (K.ref, 1), ra = WV_LGET (K.ref, 6);
+    int rc = WV_LGET (K.ref, 5);
+    const int sb = sadsk1, sa = sadsk3;
+    int sc = sadsk2, skip_c = tr_skc;
+    if (rc == WH_REF_NOT_AVAIL) { rc = WV_LGET (K.ref, 0); sc = sadsk0; skip_c = tl_skc; }
+    if (rb == WH_REF_NOT_AVAIL && rc == WH_REF_NOT_AVAIL && ra != WH_REF_NOT_AVAIL) return sa;
+    const int cnt = ((0 == ra) && l_skc) | (((0 == rb) && t_skc) << 1) | (((0 == rc) && skip_c) << 2);
+    return cnt == 1 ? sa : cnt == 2 ? sb : cnt == 4 ? sc : wh_median3 (sa, sb, sc);
+  };
   const bool try_skip = l_sk || t_sk || tl_sk || tr_sk;
-  const bool keep_skip = l_sk && t_sk && tr_sk;
+  bool keep_skip = l_sk && t_sk && tr_sk;
   bool b_skip = false;
   const int stale_cbp = ctl.stale_cbp;
-  if ((ref_is_p && ref_mb_type == WH_MB_PSKIP) || try_skip) {
-    // PredictSadSkip (md.cpp:872-910)
-    int sad_pred_skip;
-    {
-      const int rb = WV_LGET (K.ref, 1), ra = WV_LGET (K.ref, 6);
-      int rc = WV_LGET (K.ref, 5);
-      const int sb = sadsk1, sa = sadsk3;
-      int sc = sadsk2, skip_c = tr_sk;
-      if (rc == WH_REF_NOT_AVAIL) { rc = WV_LGET (K.ref, 0); sc = sadsk0; skip_c = tl_sk; }
-      if (rb == WH_REF_NOT_AVAIL && rc == WH_REF_NOT_AVAIL && ra != WH_REF_NOT_AVAIL) sad_pred_skip = sa;
-      else {
-        const int cnt = ((0 == ra) && l_sk) | (((0 == rb) && t_sk) << 1) | (((0 == rc) && skip_c) << 2);
-        sad_pred_skip = cnt == 1 ? sa : cnt == 2 ? sb : cnt == 4 ? sc : wh_median3 (sa, sb, sc);
+  bool bg_coded = false, bg_skip = false, collocated = false;      // bCollocatedPredFlag (WelsMdUpdateBGDInfo)
+
+  // ---- background detection (WelsMdInterJudgeBGDPskip, svc_mode_decision.cpp:216-260) ----
+  if (bgd) {
+    keep_skip = keep_skip && !bg_l && !bg_t && !bg_tr;
+    const int ref_type_raw = (int)Co->ref_type - 1;                // uiRefMbType as the reference picture's buffer holds it (0: never written)
+    const bool ref_intra = Co->ref_type != 0 && Co->ref_type != WH_REFTYPE_BACKGROUND && WH_IS_INTRA (ref_type_raw);
+    const int ref_qp = Co->ref_qp;
+    if (bg_cur && !ref_intra && (ref_qp - qp <= 3 /* DELTA_QP_BGD_THD */ || ref_qp <= 26)) {
+      // CheckChromaCost: chroma of the co-located block against the source
+      wh_mc_chroma_to (S, P, J, W, mbx, mby, 0, 0, 8, 8, 0, 0, S.skip_c);
+      int cb, cr;
+      WV_SUM2 (cb, cr, lane, (lane < 16 ? wh_sad4 (* (const uint32_t*)&M.enc_c[lane * 4], * (const uint32_t*)&S.skip_c[lane * 4]) : 0),
+               (lane >= 16 && lane < 32 ? wh_sad4 (* (const uint32_t*)&M.enc_c[lane * 4], * (const uint32_t*)&S.skip_c[lane * 4]) : 0));
+      const bool too_large = cb > 640 || cr > 640;                 // KNOWN_CHROMA_TOO_LARGE
+      const int chroma_sad = cb + cr, pred_skip = predict_sad_skip();
+      const bool cannot = (pred_skip > 128 && chroma_sad >= pred_skip) ||       // SMALLEST_INVISIBLE; IsCostLessEqualSkipCost
+                          (ref_is_p && ref_mb_type == WH_MB_PSKIP && !ref_mb_bg && Co->skip_sad > 128 && chroma_sad >= Co->skip_sad);
+      if (!cannot && !too_large) {
+        // WelsMdBackgroundMbEnc (svc_base_layer_md.cpp:1352-1421): prediction = the co-located block (luma always with a zero
+        // vector); P_Skip when the skip predictor is zero too, else P16x16 with a zero vector and the usual residual
+        int sx, sy;
+        wh_pred_skip_mv (K, &sx, &sy);
+        bg_coded = true; bg_skip = sx == 0 && sy == 0; collocated = true;
+        wh_mc_luma_to (S, P, J, W, mbx, mby, 0, 0, 16, 16, 0, 0, bg_skip ? S.skip_y : M.pred_y);
+        if (!bg_skip) {
+          WV_LANES_BEGIN (lane)
+          if (lane < 32) * (uint32_t*)&M.pred_c[lane * 4] = * (const uint32_t*)&S.skip_c[lane * 4];
+          WV_LANES_END
+        }
+        const uint8_t* pl = bg_skip ? S.skip_y : M.pred_y;
+        int sad;
+        WV_SUM (sad, lane, wh_sad4 (* (const uint32_t*)&M.enc_y[lane * 4], * (const uint32_t*)&pl[lane * 4]));
+        sad_cost0 = sad;
+        p16x = 0; p16y = 0;
+        if (bg_skip) { b_skip = true; mb_type = WH_MB_PSKIP; skx = 0; sky = 0; cost_luma = 0; cost_skip_mb = 0; done = true; }
+        else {
+          mb_type = WH_MB_P16x16;
+          if (md_using_sad) cost_luma = sad;
+          else WV_SATD_ROWS (cost_luma, lane, true, wh_enc4 (S, wh_tl_col (lane, 16), wh_tl_row (lane, 16)), * (const uint32_t*)&M.pred_y[wh_tl_row (lane, 16) * 16 + wh_tl_col (lane, 16)]);
+          WV_LANES_BEGIN (lane)
+          if (lane < 16) { S.mv_out[lane][0] = 0; S.mv_out[lane][1] = 0; S.mvp_out[lane][0] = (int16_t)me16.mvpx; S.mvp_out[lane][1] = (int16_t)me16.mvpy; }
+          WV_LANES_END
+          wh_dct_luma16 (M);
+          cbp = wh_enc_inter_y (M, qp);
+          cbp |= wh_encrec_chroma (M, qpc, 0) << 4;
+          wh_idct_luma16 (M);
+          wh_idct_chroma (M);
+          done = true;
+        }
       }
     }
+  }
+
+  // ---- P_Skip test (WelsMdInterJudgePskip / WelsMdPSkipEnc) ----
+  if (!done && ((ref_is_p && ref_mb_type == WH_MB_PSKIP) || try_skip)) {
+    const int sad_pred_skip = predict_sad_skip();
     wh_pred_skip_mv (K, &skx, &sky);
     const int nx = (mbx << 4) + (skx >> 2), ny = (mby << 4) + (sky >> 2);
     if (!(nx < -29 || nx > (P.mb_w << 4) + 12 || ny < -29 || ny > (P.mb_h << 4) + 12)) {
@@ -863,7 +934,7 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, WhInterStage& G, const WhSeqParams& 
       WV_SUM2 (sad_l, sad_c, lane, wh_sad4 (* (const uint32_t*)&S.m.enc_y[lane * 4], * (const uint32_t*)&S.skip_y[lane * 4]),
                (lane < 32 ? wh_sad4 (* (const uint32_t*)&S.m.enc_c[lane * 4], * (const uint32_t*)&S.skip_c[lane * 4]) : 0));
       const int sad_mb = sad_l + sad_c;
-      bool ok = sad_mb == 0 || sad_mb < sad_pred_skip || (ref_is_p && ref_mb_type == WH_MB_PSKIP && sad_mb < Co->skip_sad);
+      bool ok = sad_mb == 0 || sad_mb < sad_pred_skip || (ref_is_p && ref_mb_type == WH_MB_PSKIP && !ref_mb_bg && sad_mb < Co->skip_sad);
       if (!ok) {
         // residual would quantise to nothing?  (WelsDctMb + WelsTryPYskip + WelsTryPUVskip)
         WV_LANES_BEGIN (lane)
@@ -1094,5 +1165,16 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, WhInterStage& G, const WhSeqParams& 
   }
   WV_LANES_END
   wh_store_mb (M, P, J, mbx, mby, mb_type, cbp, qp, qpc, 0, 0, cost_luma, slice_idc);
+  // what the picture keeps for the time it is a reference (WelsMdInterSaveSadAndRefMbType, WelsMdUpdateBGDInfo): a background
+  // skip keeps its own type; an unchanged collocated MB (no residual, zero vector, P reference) inherits the reference's QP
+  if (is_skip && !bg_coded) collocated = skx == 0 && sky == 0;          // WelsMdInterUpdatePskip / WelsMdInterDoubleCheckPskip
+  if (bg_skip || (cbp == 0 && ref_is_p && collocated)) {
+    WV_LANES_BEGIN (lane)
+    if (lane == 0) {
+      if (bg_skip) { Ms->ref_type = WH_REFTYPE_BACKGROUND; Rs->bgd_skip = 1; }
+      if (cbp == 0 && ref_is_p && collocated) Ms->ref_qp = Co->ref_qp;
+    }
+    WV_LANES_END
+  }
   WH_PROF_MARK (P, M, 7);   // store
 }

@@ -6,8 +6,8 @@ test/encoder_binary_comparison/Scripts/run_BinarySHA1Comparison.sh:165-241 runs 
 layer0..3.cfg, the row's options on the command line, SHA1 of the bitstream against the table's first column.
 
 Rows the dispatch-table binding takes to the device: every option combination of the table (rate-control mode 1 and 3,
-1 and 3 temporal layers, LTR, denoising, scene-change detection, frame skipping) with a fixed number of slices
-(-slcmd 1, 4 or 7 slices).  Single-slice rows (GOM-level QP), size-limited slices and background detection keep the
+1 and 3 temporal layers, LTR, denoising, scene-change detection, background detection, frame skipping) with a fixed
+number of slices (-slcmd 1, 4 or 7 slices).  Single-slice rows (GOM-level QP) and size-limited slices keep the
 reference's C path -- the hooks report that, and the test checks that they are NOT counted as device rows.
 
 CPU tier: the wave emulation of the kernel sources (tests/emu); GPU tier (-m gpu): libwelship.so on the MI355X.
@@ -39,8 +39,8 @@ def _rows():
 
 
 def _device_rows():
-    """Rows the binding installs the hooks for: -slcmd 1 (fixed slice number) and no background detection."""
-    return [r for r in _rows() if r[4]["-slcmd 0"] == "1" and r[4]["bgd"] == "0"]
+    """Rows the binding installs the hooks for: -slcmd 1 (fixed slice number: 4 or 7 slices, frame-constant QP)."""
+    return [r for r in _rows() if r[4]["-slcmd 0"] == "1"]
 
 
 @pytest.fixture(scope="module")
@@ -85,7 +85,7 @@ def test_table_shape():
     rows = _rows()
     assert len(rows) == 2304
     dev = _device_rows()
-    assert len(dev) == 512
+    assert len(dev) == 1024
     assert len({r[0] for r in dev}) >= 8            # distinct streams among them
     assert all(r[1] == "afd7a9765961ca241bb4bdf344b31397bec7465a" for r in rows)
 
@@ -103,7 +103,7 @@ def test_sha1_table_rows_on_emulation(workdir, emu_lib):
 def test_unsupported_rows_stay_on_the_c_path(workdir, emu_lib):
     """Single-slice rows under rate control need the QP of every group of macroblocks from the bits written so far: the hooks
     decline, the reference codes the stream itself and still matches the table."""
-    rows = [r for r in _rows() if r[4]["-slcmd 0"] == "0"][:2] + [r for r in _rows() if r[4]["-slcmd 0"] == "1" and r[4]["bgd"] == "1"][:2]
+    rows = [r for r in _rows() if r[4]["-slcmd 0"] == "0"][:2] + [r for r in _rows() if r[4]["-slcmd 0"] == "3"][:2]
     for i, row in enumerate(rows):
         got, pictures, err = _run_row(workdir, emu_lib, row, "c%d" % i)
         assert "not installed" in err and pictures == 0
