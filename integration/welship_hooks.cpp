@@ -17,10 +17,13 @@
 //                                            pfWelsSpatialWriteMbSyn, pfWelsRcMbInfoUpdate per macroblock
 //   pfHipRelease (state)                     WelsUninitEncoderExt (encoder_ext.cpp:2239)
 //
-// What runs on the device (see WelsHipSupported below): camera video, one spatial layer (or simulcast AVC layers, each with
-// its own context), CAVLC, slice modes with a frame-constant QP (rate control off, or on with more than one slice, or I
-// pictures in bitrate mode: WelsRcMbInitGom with bEnableGomQp == false, ratectl.cpp:1199-1204,1239-1262), any number of
-// temporal layers, LTR, denoising, scene-change detection, frame skipping.  Everything else keeps the reference's C path --
+// What runs on the device (see WelsHipSupported below): camera video, one spatial layer, CAVLC, any number of temporal layers,
+// LTR, denoising, scene-change and background detection, frame skipping, all rate-control modes.  With a frame-constant QP
+// (rate control off, or on with more than one slice, or I pictures in bitrate mode: WelsRcMbInitGom with bEnableGomQp ==
+// false, ratectl.cpp:1199-1204,1239-1262) a picture is one device call; with GOM-level QP (one slice per picture) the QP of a
+// group of macroblocks depends on the bits the groups before it produced, so the picture is coded group by group from inside
+// the slice loop -- a latency chain of one device call per group, bit-exact but not the throughput path.  Everything else
+// (screen content, CABAC, size-limited slices, SVC inter-layer prediction, slice threads) keeps the reference's C path --
 // the hooks stay NULL, as they would on a CPU without the needed SIMD level.
 #if defined(HAVE_HIP)
 #include <stdio.h>
@@ -75,6 +78,13 @@ struct HipLayer {                       // one spatial layer = one device contex
   std::map<const SPicture*, int> twin;   // reference SPicture -> device picture index
   int num_pictures = 0;
   const WhMbRecord* records = NULL;      // of the picture being coded (valid from pfHipFrameMd to the end of its slices)
+  // GOM-level rate control (one slice per picture, QP per group of macroblocks from the bits written so far): the picture is
+  // coded group by group from inside the slice loop -- the job is only prepared by pfHipFrameMd
+  bool gom = false;
+  WelsHipFrameJob job;
+  std::vector<int32_t> first;
+  std::vector<uint8_t> mb_qp;
+  int coded_upto = 0;
 };
 
 struct HipState {
@@ -119,13 +129,8 @@ int32_t HipFrameMd (sWelsEncCtx* pCtx) {
     const int rc = g_api.FrameCtxCreate (&L.ctx, &cfg);
     if (rc) { fprintf (stderr, "welship hooks: no device context (%d: %s)\n", rc, g_api.GetLastError()); st->failed = true; return ENC_RETURN_UNEXPECTED; }
   }
-  if (!FrameConstantQp (pCtx)) {
-    // cannot happen for a session WelsHipSupported accepted, unless the parameters were changed in mid-stream
-    fprintf (stderr, "welship hooks: GOM-level QP requested in a session that was installed for frame-constant QP\n");
-    st->failed = true;
-    return ENC_RETURN_UNSUPPORTED_PARA;
-  }
-  WelsHipFrameJob job;
+  L.gom = !FrameConstantQp (pCtx);
+  WelsHipFrameJob& job = L.job;
   memset (&job, 0, sizeof (job));
   const bool is_p = pCtx->eSliceType == P_SLICE;
   job.iCurPic = TwinOf (L, pCtx->pDecPic);
@@ -138,7 +143,8 @@ int32_t HipFrameMd (sWelsEncCtx* pCtx) {
   job.iMvRange = pCtx->iMvRange;
   // pSlice->sScaleShift (svc_encode_slice.cpp:1652-1655), the same for every slice of the picture
   job.iMvcShift = (is_p && pCtx->uiTemporalId) ? (int) (pCtx->uiTemporalId - pCtx->pRefPic->uiTemporalId) : 0;
-  std::vector<int32_t> first;
+  std::vector<int32_t>& first = L.first;
+  first.clear();
   const int nslices = GetCurrentSliceNum (pCurLayer);
   for (int i = 0; i < nslices; ++i) first.push_back (pCurLayer->pFirstMbIdxOfSlice[i]);
   first.push_back (num_mb);
@@ -155,6 +161,15 @@ int32_t HipFrameMd (sWelsEncCtx* pCtx) {
   for (int i = 0; i < 3; ++i) { job.pSrc[i] = pCurLayer->pEncData[i]; job.iSrcStride[i] = pCurLayer->iEncStride[i]; }
   job.pVaaSad8x8 = (is_p && pCtx->pVaa && pCtx->pVaa->sVaaCalcInfo.pSad8x8) ? &pCtx->pVaa->sVaaCalcInfo.pSad8x8[0][0] : NULL;
   job.pBgdFlags = (is_p && pParam->bEnableBackgroundDetection && pCtx->pVaa) ? pCtx->pVaa->pVaaBackgroundMbFlag : NULL;
+  if (L.gom) {
+    if (nslices != 1) { fprintf (stderr, "welship hooks: GOM-level QP with %d slices\n", nslices); st->failed = true; return ENC_RETURN_UNEXPECTED; }
+    L.mb_qp.assign (num_mb, (uint8_t)pCtx->iGlobalQp);
+    L.coded_upto = 0;
+    L.records = NULL;
+    if (st->trace) fprintf (stderr, "welship hooks: did %d %c picture GOM-level QP (%d MBs per group) cur %d ref %d deblock %d expand %d\n", did, is_p ? 'P' : 'I',
+                            pCtx->pWelsSvcRc[did].iNumberMbGom, job.iCurPic, job.iRefPic, job.bDeblock, job.bExpand);
+    return ENC_RETURN_SUCCESS;
+  }
   const void* rec = NULL;
   const int rc = g_api.FrameEncode (L.ctx, &job, &rec);
   if (rc) { fprintf (stderr, "welship hooks: WelsHipFrameEncode failed (%d: %s)\n", rc, g_api.GetLastError()); st->failed = true; return ENC_RETURN_UNEXPECTED; }
@@ -197,7 +212,7 @@ int32_t HipCodeSlice (sWelsEncCtx* pCtx, SSlice* pSlice) {
   SWelsFuncPtrList* pFunc = pCtx->pFuncList;
   HipState* st = (HipState*)pFunc->pHipState;
   HipLayer& L = st->layer[pCtx->uiDependencyId];
-  if (st->failed || L.records == NULL) return ENC_RETURN_UNEXPECTED;
+  if (st->failed || (L.records == NULL && !L.gom)) return ENC_RETURN_UNEXPECTED;
   SDqLayer* pCurLayer = pCtx->pCurDqLayer;
   SMbCache* pMbCache = &pSlice->sMbCacheInfo;
   SMB* pMbList = pCurLayer->sMbDataP;
@@ -211,9 +226,30 @@ int32_t HipCodeSlice (sWelsEncCtx* pCtx, SSlice* pSlice) {
   for (;;) {
     const int32_t iCurMbIdx = iNextMbIdx;
     SMB* pCurMb = &pMbList[iCurMbIdx];
-    const WhMbRecord& R = L.records[iCurMbIdx];
-    // QP of the macroblock: what the device was given (frame constant), through the reference's own RC entry point
+    // QP of the macroblock through the reference's own RC entry point (frame constant, or the group's: WelsRcMbInitGom)
     pFunc->pfRc.pfWelsRcMbInit (pCtx, pCurMb, pSlice);
+    if (L.gom && iCurMbIdx >= L.coded_upto) {
+      // first macroblock of a group: RcCalculateGomQp has just set the group's QP from the bits of the groups before it
+      // (ratectl.cpp:1239-1262); the device now codes exactly this group, the loop below entropy-codes it, and so on
+      const int nGom = pCtx->pWelsSvcRc[pCtx->uiDependencyId].iNumberMbGom;
+      int end = (iCurMbIdx / nGom + 1) * nGom;
+      if (end > kiTotalNumMb) end = kiTotalNumMb;
+      for (int i = iCurMbIdx; i < end; ++i) L.mb_qp[i] = pCurMb->uiLumaQp;
+      L.job.pMbQp = &L.mb_qp[0];
+      L.job.pSliceFirstMb = &L.first[0];
+      L.job.iMbBegin = iCurMbIdx; L.job.iMbEnd = end;
+      const void* rec = NULL;
+      const int rc = g_api.FrameEncode (L.ctx, &L.job, &rec);
+      if (rc) { fprintf (stderr, "welship hooks: WelsHipFrameEncode (MBs %d..%d) failed (%d: %s)\n", iCurMbIdx, end, rc, g_api.GetLastError()); st->failed = true; return ENC_RETURN_UNEXPECTED; }
+      L.records = (const WhMbRecord*)rec;
+      L.coded_upto = end;
+      if (end == kiTotalNumMb) {       // the picture is complete (filtered, borders expanded): the host's copy of the reconstruction
+        uint8_t* dst[3] = { pCtx->pDecPic->pData[0], pCtx->pDecPic->pData[1], pCtx->pDecPic->pData[2] };
+        const int32_t ds[3] = { pCtx->pDecPic->iLineSize[0], pCtx->pDecPic->iLineSize[1], pCtx->pDecPic->iLineSize[2] };
+        if (g_api.FrameGetPicture (L.ctx, L.job.iCurPic, dst, ds)) { st->failed = true; return ENC_RETURN_UNEXPECTED; }
+      }
+    }
+    const WhMbRecord& R = L.records[iCurMbIdx];
     if (pCurMb->uiLumaQp != R.luma_qp) { fprintf (stderr, "welship hooks: QP mismatch at MB %d (%d vs %d)\n", iCurMbIdx, pCurMb->uiLumaQp, R.luma_qp); st->failed = true; return ENC_RETURN_UNEXPECTED; }
     // neighbour caches the entropy writer reads (non-zero counts): the reference's own init functions
     WelsMdIntraInit (pCtx, pCurMb, pMbCache, kiSliceFirstMbXY);
@@ -230,6 +266,9 @@ int32_t HipCodeSlice (sWelsEncCtx* pCtx, SSlice* pSlice) {
     }
     if (ENC_RETURN_SUCCESS != iEncReturn) return iEncReturn;
     pCurMb->uiSliceIdc = kiSliceIdx;
+    // uiRefMbType of the picture (WelsMdInterSaveSadAndRefMbType): besides the device's mode decision, the host's complexity
+    // analysis of the NEXT picture reads it (wels_preprocess.cpp:830-930: background MBs whose reference MB is intra)
+    if (is_p) pCurLayer->pDecPic->uiRefMbType[iCurMbIdx] = R.bgd_skip ? (Mb_Type)MB_TYPE_BACKGROUND : pCurMb->uiMbType;
     if (R.bgd_skip) {
       // VaaBackgroundMbDataUpdate (svc_base_layer_md.cpp:1341-1350): a background macroblock's source samples are replaced by the
       // reference's, which the pre-processing of the following pictures sees
@@ -267,7 +306,6 @@ bool WelsHipSupported (const SWelsSvcCodingParam* p, const char** why) {
   for (int i = 0; i < p->iSpatialLayerNum; ++i) {
     const SSliceArgument& sa = p->sSpatialLayers[i].sSliceArgument;
     if (sa.uiSliceMode == SM_SIZELIMITED_SLICE) NO ("size-limited slices feed the bitstream position back into mode decision");
-    if (p->iRCMode != RC_OFF_MODE && sa.uiSliceMode == SM_SINGLE_SLICE) NO ("rate control with one slice per picture sets the QP per group of macroblocks from the bits written so far");
   }
   return true;
 #undef NO

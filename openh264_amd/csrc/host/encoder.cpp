@@ -1241,12 +1241,13 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
   if (is_p) be->run_inter (s, c->d_job, 1); else be->run_intra (s, c->d_job, 1);
   if (last_part) {
     if (ranged) { job.mb_begin = 0; job.mb_end = 0; be->sync(); be->upload (c->d_job, &job, sizeof (job)); }
-    if (qp_map && s.deblock_idc != 1) be->run_qp_chain (s, c->d_job, 1);
+    if (qp_map) be->run_qp_chain (s, c->d_job, 1);           // QP_Y for the filter and pRefMbQp of decided skips
     if (s.deblock_idc != 1) be->run_deblock (s, c->d_job, 1);
     if (j->bExpand) be->run_expand (s, c->d_job, 1);
     cur.is_p = is_p;
   }
-  be->download (c->h_records.data(), c->d_records, sizeof (WhMbRecord) * c->num_mb);
+  if (ranged) be->download (c->h_records.data() + j->iMbBegin, c->d_records + j->iMbBegin, sizeof (WhMbRecord) * (size_t) (j->iMbEnd - j->iMbBegin));
+  else be->download (c->h_records.data(), c->d_records, sizeof (WhMbRecord) * c->num_mb);
   if (be->sync()) { set_err ("device scheduler timed out or device error; the picture was not encoded"); return WELSHIP_ERR_UNKNOWN; }
   *pp_records = c->h_records.data();
   return WELSHIP_OK;

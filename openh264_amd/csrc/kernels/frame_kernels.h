@@ -108,6 +108,7 @@ WH_FN void wh_qp_chain_slice (const WhSeqParams& P, const WhPicJob& J, int first
       const int q = WV_LOWN (o, lane);
       M->luma_qp = (uint8_t)q;
       M->chroma_qp = (uint8_t)kWhChromaQp[wh_clip3 (q + P.chroma_qp_offset, 0, 51)];
+      if (M->ref_qp == 0xff) M->ref_qp = (uint8_t)q;          // pRefMbQp of a skip decided in mode decision: the last coded QP (inter_mb.h)
     }
     WV_LANES_END
   }

@@ -1165,16 +1165,26 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, WhInterStage& G, const WhSeqParams& 
   }
   WV_LANES_END
   wh_store_mb (M, P, J, mbx, mby, mb_type, cbp, qp, qpc, 0, 0, cost_luma, slice_idc);
-  // what the picture keeps for the time it is a reference (WelsMdInterSaveSadAndRefMbType, WelsMdUpdateBGDInfo): a background
-  // skip keeps its own type; an unchanged collocated MB (no residual, zero vector, P reference) inherits the reference's QP
-  if (is_skip && !bg_coded) collocated = skx == 0 && sky == 0;          // WelsMdInterUpdatePskip / WelsMdInterDoubleCheckPskip
-  if (bg_skip || (cbp == 0 && ref_is_p && collocated)) {
-    WV_LANES_BEGIN (lane)
-    if (lane == 0) {
-      if (bg_skip) { Ms->ref_type = WH_REFTYPE_BACKGROUND; Rs->bgd_skip = 1; }
-      if (cbp == 0 && ref_is_p && collocated) Ms->ref_qp = Co->ref_qp;
+  // what the picture keeps for the time it is a reference (WelsMdInterSaveSadAndRefMbType, WelsMdUpdateBGDInfo, both run
+  // before the entropy writer): a background skip keeps its own type; pRefMbQp = uiLumaQp unless the MB is an unchanged
+  // collocated one (no residual, zero vector, P reference), which inherits the reference's entry.  uiLumaQp at that point is
+  // the MB's rate-control QP, except for a skip decided in mode decision (WelsMdInterDecidedPskip, WelsMdBackgroundMbEnc):
+  // there it already is the slice's last coded QP -- with a per-MB QP map that is only known in coding order, so the MB
+  // leaves a marker that wh_qp_chain_slice resolves.
+  const bool decided_skip = is_skip && b_skip;                          // not the P16x16 that WelsMdInterDoubleCheckPskip renames
+  if (!bg_coded) collocated = decided_skip ? (skx == 0 && sky == 0) : ((is_skip || mb_type == WH_MB_P16x16) && cbp == 0 && me16.mvx == 0 && me16.mvy == 0);
+  {
+    const bool inherit = cbp == 0 && ref_is_p && collocated;
+    const bool last_qp = !inherit && decided_skip && J.mb_ctl != nullptr;
+    if (bg_skip || inherit || last_qp) {
+      WV_LANES_BEGIN (lane)
+      if (lane == 0) {
+        if (bg_skip) { Ms->ref_type = WH_REFTYPE_BACKGROUND; Rs->bgd_skip = 1; }
+        if (inherit) Ms->ref_qp = Co->ref_qp;
+        else if (last_qp) Ms->ref_qp = 0xff;                              // WH_REFQP_FROM_CHAIN
+      }
+      WV_LANES_END
     }
-    WV_LANES_END
   }
   WH_PROF_MARK (P, M, 7);   // store
 }

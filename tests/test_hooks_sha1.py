@@ -6,9 +6,12 @@ test/encoder_binary_comparison/Scripts/run_BinarySHA1Comparison.sh:165-241 runs 
 layer0..3.cfg, the row's options on the command line, SHA1 of the bitstream against the table's first column.
 
 Rows the dispatch-table binding takes to the device: every option combination of the table (rate-control mode 1 and 3,
-1 and 3 temporal layers, LTR, denoising, scene-change detection, background detection, frame skipping) with a fixed
-number of slices (-slcmd 1, 4 or 7 slices).  Single-slice rows (GOM-level QP) and size-limited slices keep the
-reference's C path -- the hooks report that, and the test checks that they are NOT counted as device rows.
+1 and 3 temporal layers, LTR, denoising, scene-change detection, background detection, frame skipping) in slice modes
+0, 1 and 2 -- 1792 of the 2304 rows.  Size-limited slices (-slcmd 3) keep the reference's C path --
+the hooks report that, and the test checks that those rows are NOT counted as device rows.
+
+Also here: the reference's API-level golden hashes (test/api/encoder_test.cpp:104-115) and its stock testbin/welsenc.cfg
+through the same binding.
 
 CPU tier: the wave emulation of the kernel sources (tests/emu); GPU tier (-m gpu): libwelship.so on the MI355X.
 """
@@ -39,8 +42,10 @@ def _rows():
 
 
 def _device_rows():
-    """Rows the binding installs the hooks for: -slcmd 1 (fixed slice number: 4 or 7 slices, frame-constant QP)."""
-    return [r for r in _rows() if r[4]["-slcmd 0"] == "1"]
+    """Rows the binding installs the hooks for: everything but size-limited slices (-slcmd 3).  -slcmd 1 (4 or 7 slices) has a
+    frame-constant QP; -slcmd 0 and -slcmd 2 (one slice of 960 MBs = the whole QCIF picture) run GOM-level rate control,
+    which the binding codes group by group."""
+    return [r for r in _rows() if r[4]["-slcmd 0"] in ("0", "1", "2")]
 
 
 @pytest.fixture(scope="module")
@@ -85,7 +90,7 @@ def test_table_shape():
     rows = _rows()
     assert len(rows) == 2304
     dev = _device_rows()
-    assert len(dev) == 1024
+    assert len(dev) == 1792
     assert len({r[0] for r in dev}) >= 8            # distinct streams among them
     assert all(r[1] == "afd7a9765961ca241bb4bdf344b31397bec7465a" for r in rows)
 
@@ -101,9 +106,9 @@ def test_sha1_table_rows_on_emulation(workdir, emu_lib):
 
 
 def test_unsupported_rows_stay_on_the_c_path(workdir, emu_lib):
-    """Single-slice rows under rate control need the QP of every group of macroblocks from the bits written so far: the hooks
-    decline, the reference codes the stream itself and still matches the table."""
-    rows = [r for r in _rows() if r[4]["-slcmd 0"] == "0"][:2] + [r for r in _rows() if r[4]["-slcmd 0"] == "3"][:2]
+    """Size-limited slices feed the bitstream position back into mode decision macroblock by macroblock: the hooks decline, the
+    reference codes the stream itself and still matches the table."""
+    rows = [r for r in _rows() if r[4]["-slcmd 0"] == "3"][:3]
     for i, row in enumerate(rows):
         got, pictures, err = _run_row(workdir, emu_lib, row, "c%d" % i)
         assert "not installed" in err and pictures == 0
@@ -113,3 +118,56 @@ def test_unsupported_rows_stay_on_the_c_path(workdir, emu_lib):
 @pytest.mark.gpu
 def test_sha1_table_rows_on_the_mi355x(workdir, hip_lib):
     _check(workdir, hip_lib, _sample(_device_rows(), 48))
+
+
+# ---- the API-level golden hashes and the stock configuration through the binding ---------------------------------------------
+API_GOLDEN = [  # test/api/encoder_test.cpp:104-115 (SEncParamBase: RC quality mode, 5 Mbps, one slice -> GOM-level QP)
+    ("CiscoVT2people_160x96_6fps.yuv", 160, 96, 6.0, "08ade1853e4e49d50be675393780e75519586143"),
+    ("CiscoVT2people_320x192_12fps.yuv", 320, 192, 12.0, "672a52fb6b6e6d52b5b3f3480d13d44e88481fb9"),
+    ("Static_152_100.yuv", 152, 100, 6.0, "e60f12e3c24500d4306d812b0811d3c21855dd1c"),
+]
+
+
+def _api_hash(lib, tmp_path, name, w, h, fps):
+    out = str(tmp_path / "o.264")
+    env = dict(os.environ, WELSHIP_LIB=lib, WELS_HIP_TRACE="1")
+    p = subprocess.run([os.path.join(REF, "ref_enc_hip"), "-i", os.path.join(RES, name), "-w", str(w), "-h", str(h), "-o", out, "-base", "-rc", "0",
+                        "-fps", str(fps), "-quiet"], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    err = p.stderr.decode(errors="replace")
+    assert p.returncode == 0, err[-2000:]
+    assert "welship hooks: installed" in err and err.count("welship hooks: did") >= 5
+    return hashlib.sha1(open(out, "rb").read()).hexdigest()
+
+
+@pytest.mark.parametrize("name,w,h,fps,sha", API_GOLDEN)
+def test_api_golden_hash_through_the_hooks_on_emulation(emu_lib, tmp_path, name, w, h, fps, sha):
+    assert _api_hash(emu_lib, tmp_path, name, w, h, fps) == sha
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,w,h,fps,sha", API_GOLDEN)
+def test_api_golden_hash_through_the_hooks_on_the_mi355x(hip_lib, tmp_path, name, w, h, fps, sha):
+    assert _api_hash(hip_lib, tmp_path, name, w, h, fps) == sha
+
+
+def _stock_cfg(lib, tmp_path):
+    """testbin/welsenc.cfg as it is (RCMode 0, two temporal layers, LTR, background and scene-change detection, adaptive
+    quantisation on): the stock front-end on the reference and on the reference with the hooks must write the same file."""
+    cfg = open(os.path.join(RES, "welsenc.cfg")).read().replace("../res/CiscoVT2people_320x192_12fps.yuv", os.path.join(RES, "CiscoVT2people_320x192_12fps.yuv"))
+    (tmp_path / "welsenc.cfg").write_text(cfg)
+    (tmp_path / "layer2.cfg").write_bytes(open(os.path.join(RES, "layer2.cfg"), "rb").read())
+    subprocess.check_call([os.path.join(REF, "h264enc_ref"), "welsenc.cfg", "-bf", "ref.264"], cwd=str(tmp_path), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    env = dict(os.environ, WELSHIP_LIB=lib, WELS_HIP_TRACE="1")
+    p = subprocess.run([H264ENC, "welsenc.cfg", "-bf", "hip.264"], cwd=str(tmp_path), env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    err = p.stderr.decode(errors="replace")
+    assert p.returncode == 0 and "welship hooks: installed" in err and err.count("welship hooks: did") >= 5, err[-2000:]
+    assert (tmp_path / "ref.264").read_bytes() == (tmp_path / "hip.264").read_bytes()
+
+
+def test_stock_welsenc_cfg_on_emulation(emu_lib, tmp_path):
+    _stock_cfg(emu_lib, tmp_path)
+
+
+@pytest.mark.gpu
+def test_stock_welsenc_cfg_on_the_mi355x(hip_lib, tmp_path):
+    _stock_cfg(hip_lib, tmp_path)

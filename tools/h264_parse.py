@@ -194,8 +194,19 @@ def parse_stream(data, out=sys.stdout, levels=True):
             if hdr >> 5:
                 if typ == 5:
                     b.u(2)
-                elif b.u(1):
-                    raise ValueError("MMCO not handled")
+                elif b.u(1):                   # adaptive_ref_pic_marking_mode_flag: memory_management_control_operations
+                    while True:
+                        op = b.ue()
+                        if op == 0:
+                            break
+                        if op in (1, 3):
+                            b.ue()
+                        if op == 2:
+                            b.ue()
+                        if op in (3, 6):
+                            b.ue()
+                        if op == 4:
+                            b.ue()
             qp = 26 + b.se()
             idc = b.ue()
             if idc != 1:
