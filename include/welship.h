@@ -226,7 +226,13 @@ typedef struct WelsHipFrameJob {
   const uint8_t* pMbQp;             /* per-MB luma QP (host, [mb]) or NULL: iQp for every MB (GOM-level rate control uses it)  */
   int32_t iMbBegin, iMbEnd;         /* code only this MB range now (GOM-synchronous rate control); 0,0 = the whole picture.     */
                                     /* Deblocking / expansion run with the call whose range ends the picture.                  */
-  int32_t reserved[6];
+  const int16_t* pIlHint;           /* highest spatial layer of a multi-layer session: per MB {sMvBase x, y, bit 0 = the layer below  */
+                                    /* is intra there, 0} as SetMvBaseEnhancelayer / GetRefMb derive them (svc_mode_decision.cpp:     */
+                                    /* 108-150), or NULL                                                                               */
+  int32_t* pSadCost;                /* pSadCost[0] of every MB (pEncCtx->pSadCostMb, encoder_ext.cpp:900,1675 -- ONE array for all the    */
+                                    /* spatial layers of a session): copied to the device before the picture and back after it, or NULL:  */
+                                    /* the context keeps its own (single-layer sessions)                                                 */
+  int32_t reserved[2];
 } WelsHipFrameJob;
 int  WelsHipFrameCtxCreate (WelsHipFrameCtx** ppCtx, const WelsHipFrameCfg* pCfg);
 void WelsHipFrameCtxDestroy (WelsHipFrameCtx* pCtx);
@@ -235,6 +241,9 @@ void WelsHipFrameCtxDestroy (WelsHipFrameCtx* pCtx);
 int  WelsHipFrameEncode (WelsHipFrameCtx* pCtx, const WelsHipFrameJob* pJob, const void** ppRecords);
 /* The (deblocked) reconstruction of device picture iPic, coded size, into the caller's planes (the host's SPicture). */
 int  WelsHipFrameGetPicture (WelsHipFrameCtx* pCtx, int iPic, uint8_t* const pDst[3], const int32_t iDstStride[3]);
+/* The per-MB states of device picture iPic (WhMbState[mb_w * mb_h], wh_types.h: types, motion vectors, reference indices):
+ * what a higher spatial layer's mode decision reads from this layer's SMB array. */
+int  WelsHipFrameGetMbStates (WelsHipFrameCtx* pCtx, int iPic, void* pDst, size_t uiBytes);
 
 /* ---- (3) leaf primitives, batched.  One call = n independent invocations of the reference entry
  * named in the comment.  p*Plane are HOST buffers of `bytes` bytes; block i starts at

@@ -55,10 +55,11 @@ struct HipApi {
   void (*FrameCtxDestroy) (WelsHipFrameCtx*);
   int (*FrameEncode) (WelsHipFrameCtx*, const WelsHipFrameJob*, const void**);
   int (*FrameGetPicture) (WelsHipFrameCtx*, int, uint8_t* const*, const int32_t*);
+  int (*FrameGetMbStates) (WelsHipFrameCtx*, int, void*, size_t);
   const char* (*GetLastError) (void);
   bool ok;
 };
-HipApi g_api = { NULL, NULL, NULL, NULL, NULL, false };
+HipApi g_api = { NULL, NULL, NULL, NULL, NULL, NULL, false };
 bool LoadApi() {
   if (g_api.ok) return true;
   const char* path = getenv ("WELSHIP_LIB");
@@ -68,8 +69,9 @@ bool LoadApi() {
   g_api.FrameCtxDestroy = (void (*) (WelsHipFrameCtx*))dlsym (h, "WelsHipFrameCtxDestroy");
   g_api.FrameEncode = (int (*) (WelsHipFrameCtx*, const WelsHipFrameJob*, const void**))dlsym (h, "WelsHipFrameEncode");
   g_api.FrameGetPicture = (int (*) (WelsHipFrameCtx*, int, uint8_t* const*, const int32_t*))dlsym (h, "WelsHipFrameGetPicture");
+  g_api.FrameGetMbStates = (int (*) (WelsHipFrameCtx*, int, void*, size_t))dlsym (h, "WelsHipFrameGetMbStates");
   g_api.GetLastError = (const char* (*) (void))dlsym (h, "WelsHipGetLastError");
-  g_api.ok = g_api.FrameCtxCreate && g_api.FrameCtxDestroy && g_api.FrameEncode && g_api.FrameGetPicture && g_api.GetLastError;
+  g_api.ok = g_api.FrameCtxCreate && g_api.FrameCtxDestroy && g_api.FrameEncode && g_api.FrameGetPicture && g_api.FrameGetMbStates && g_api.GetLastError;
   return g_api.ok;
 }
 
@@ -85,6 +87,8 @@ struct HipLayer {                       // one spatial layer = one device contex
   std::vector<int32_t> first;
   std::vector<uint8_t> mb_qp;
   int coded_upto = 0;
+  std::vector<int16_t> il_hint;          // highest layer of a multi-layer session: hints from the layer below
+  std::vector<WhMbState> states;         // lower layers of a multi-layer session: the device's motion data, for the layer above
 };
 
 struct HipState {
@@ -92,6 +96,7 @@ struct HipState {
   int device = 0;
   bool failed = false;                  // a device call failed: the session reports errors from then on
   bool trace = false;
+  bool layer_devices = false;           // one GPU per simulcast layer
 };
 
 int TwinOf (HipLayer& L, const SPicture* p) {
@@ -122,7 +127,7 @@ int32_t HipFrameMd (sWelsEncCtx* pCtx) {
   if (L.ctx == NULL) {
     WelsHipFrameCfg cfg;
     memset (&cfg, 0, sizeof (cfg));
-    cfg.iDevice = st->device;
+    cfg.iDevice = st->device + (st->layer_devices ? did : 0);
     cfg.iPicWidth = mbw * 16; cfg.iPicHeight = mbh * 16;
     cfg.iNumPictures = pParam->iNumRefFrame + 2;          // RequestMemorySvc allocates 1 + iNumRefFrame pictures per layer
     L.num_pictures = cfg.iNumPictures;
@@ -161,6 +166,29 @@ int32_t HipFrameMd (sWelsEncCtx* pCtx) {
   for (int i = 0; i < 3; ++i) { job.pSrc[i] = pCurLayer->pEncData[i]; job.iSrcStride[i] = pCurLayer->iEncStride[i]; }
   job.pVaaSad8x8 = (is_p && pCtx->pVaa && pCtx->pVaa->sVaaCalcInfo.pSad8x8) ? &pCtx->pVaa->sVaaCalcInfo.pSad8x8[0][0] : NULL;
   job.pBgdFlags = (is_p && pParam->bEnableBackgroundDetection && pCtx->pVaa) ? pCtx->pVaa->pVaaBackgroundMbFlag : NULL;
+  // WelsCodePSlice (svc_encode_slice.cpp:722-741): the highest spatial layer of a multi-layer session decides its P macroblocks
+  // with WelsMdInterMbEnhancelayer -- the type and one vector of the co-located macroblock of the layer coded just before it
+  // (GetRefMb / SetMvBaseEnhancelayer, svc_mode_decision.cpp:108-150), simulcast AVC included
+  // pSadCost[0] lives in ONE array for all spatial layers (pEncCtx->pSadCostMb): the host's copy travels with every picture
+  job.pSadCost = pParam->iSpatialLayerNum > 1 ? pCtx->pSadCostMb : NULL;
+  job.pIlHint = NULL;
+  if (is_p && pCurLayer->bBaseLayerAvailableFlag && pParam->iSpatialLayerNum == did + 1 && pCurLayer->pRefLayer) {
+    const SDqLayer* kpRefLayer = pCurLayer->pRefLayer;
+    L.il_hint.assign ((size_t)num_mb * 4, 0);
+    for (int y = 0; y < mbh; ++y)
+      for (int x = 0; x < mbw; ++x) {
+        const SMB* kpRefMb = &kpRefLayer->sMbDataP[ (y >> 1) * kpRefLayer->iMbWidth + (x >> 1)];
+        int16_t* h = &L.il_hint[ (size_t) (y * mbw + x) * 4];
+        if (IS_SVC_INTRA (kpRefMb->uiMbType)) h[2] = 1;
+        else {
+          const int32_t iRefMbPartIdx = ((y & 0x01) << 1) + (x & 0x01);
+          const int32_t iScan4RefPartIdx = g_kuiMbCountScan4Idx[ (iRefMbPartIdx << 2)];
+          h[0] = (int16_t) (kpRefMb->sMv[iScan4RefPartIdx].iMvX * (1 << 1));
+          h[1] = (int16_t) (kpRefMb->sMv[iScan4RefPartIdx].iMvY * (1 << 1));
+        }
+      }
+    job.pIlHint = &L.il_hint[0];
+  }
   if (L.gom) {
     if (nslices != 1) { fprintf (stderr, "welship hooks: GOM-level QP with %d slices\n", nslices); st->failed = true; return ENC_RETURN_UNEXPECTED; }
     L.mb_qp.assign (num_mb, (uint8_t)pCtx->iGlobalQp);
@@ -174,6 +202,11 @@ int32_t HipFrameMd (sWelsEncCtx* pCtx) {
   const int rc = g_api.FrameEncode (L.ctx, &job, &rec);
   if (rc) { fprintf (stderr, "welship hooks: WelsHipFrameEncode failed (%d: %s)\n", rc, g_api.GetLastError()); st->failed = true; return ENC_RETURN_UNEXPECTED; }
   L.records = (const WhMbRecord*)rec;
+  L.states.clear();
+  if (pParam->iSpatialLayerNum > did + 1) {      // a higher layer will read this layer's motion (see pIlHint above)
+    L.states.resize (num_mb);
+    if (g_api.FrameGetMbStates (L.ctx, job.iCurPic, &L.states[0], sizeof (WhMbState) * num_mb)) { st->failed = true; return ENC_RETURN_UNEXPECTED; }
+  }
   // the host's copy of the reconstruction (PSNR, reconstruction dumps, pre-processing that looks at the reference picture)
   uint8_t* dst[3] = { pCtx->pDecPic->pData[0], pCtx->pDecPic->pData[1], pCtx->pDecPic->pData[2] };
   const int32_t ds[3] = { pCtx->pDecPic->iLineSize[0], pCtx->pDecPic->iLineSize[1], pCtx->pDecPic->iLineSize[2] };
@@ -247,6 +280,11 @@ int32_t HipCodeSlice (sWelsEncCtx* pCtx, SSlice* pSlice) {
         uint8_t* dst[3] = { pCtx->pDecPic->pData[0], pCtx->pDecPic->pData[1], pCtx->pDecPic->pData[2] };
         const int32_t ds[3] = { pCtx->pDecPic->iLineSize[0], pCtx->pDecPic->iLineSize[1], pCtx->pDecPic->iLineSize[2] };
         if (g_api.FrameGetPicture (L.ctx, L.job.iCurPic, dst, ds)) { st->failed = true; return ENC_RETURN_UNEXPECTED; }
+        L.states.clear();
+        if (pCtx->pSvcParam->iSpatialLayerNum > pCtx->uiDependencyId + 1) {
+          L.states.resize (kiTotalNumMb);
+          if (g_api.FrameGetMbStates (L.ctx, L.job.iCurPic, &L.states[0], sizeof (WhMbState) * kiTotalNumMb)) { st->failed = true; return ENC_RETURN_UNEXPECTED; }
+        }
       }
     }
     const WhMbRecord& R = L.records[iCurMbIdx];
@@ -284,6 +322,15 @@ int32_t HipCodeSlice (sWelsEncCtx* pCtx, SSlice* pSlice) {
     if (iNextMbIdx == -1 || iNextMbIdx >= kiTotalNumMb || iNumMbCoded >= kiTotalNumMb) break;
   }
   if (is_p && pSlice->iMbSkipRun) BsWriteUE (pSlice->pSliceBsa, pSlice->iMbSkipRun);
+  // for the layer above: this slice's real motion vectors in the SMB array (the writer above was fed vector differences)
+  if (!L.states.empty()) {
+    int32_t iMb = kiSliceFirstMbXY;
+    for (int32_t n = 0; n < iNumMbCoded && iMb >= 0 && iMb < kiTotalNumMb; ++n) {
+      const WhMbState& S = L.states[iMb];
+      for (int i = 0; i < 16; ++i) { pMbList[iMb].sMv[i].iMvX = S.mv[i][0]; pMbList[iMb].sMv[i].iMvY = S.mv[i][1]; }
+      iMb = WelsGetNextMbOfSlice (pCurLayer, iMb);
+    }
+  }
   return ENC_RETURN_SUCCESS;
 }
 
@@ -299,8 +346,9 @@ bool WelsHipSupported (const SWelsSvcCodingParam* p, const char** why) {
 #define NO(msg) do { *why = msg; return false; } while (0)
   if (p->iUsageType != CAMERA_VIDEO_REAL_TIME) NO ("screen content (feature / scroll search) stays on the C path");
   if (p->iEntropyCodingModeFlag != 0) NO ("CABAC: the host writer needs mvd / cbp contexts the records do not carry yet");
+  // simulcast AVC layers are independent streams (no inter-layer prediction): one device context per layer, optionally one
+  // GPU per layer (WELS_HIP_LAYER_DEVICES=1: layer d runs on device WELS_HIP_DEVICE + d)
   if (p->iSpatialLayerNum != 1 && !p->bSimulcastAVC) NO ("spatial layers with inter-layer prediction");
-  if (p->iSpatialLayerNum != 1) NO ("more than one spatial layer");      // lifted per layer by the simulcast session
   if (p->iMultipleThreadIdc != 1) NO ("slice threads: the host loop is single-threaded in this binding");
   // bEnableAdaptiveQuant: ParamValidation switches it off for every session (encoder_ext.cpp:300-301), nothing to check
   for (int i = 0; i < p->iSpatialLayerNum; ++i) {
@@ -333,6 +381,7 @@ void WelsHipInstall (SWelsFuncPtrList* pFuncList, SWelsSvcCodingParam* pParam) {
   HipState* st = new HipState();
   st->device = getenv ("WELS_HIP_DEVICE") ? atoi (getenv ("WELS_HIP_DEVICE")) : 0;
   st->trace = getenv ("WELS_HIP_TRACE") != NULL;
+  st->layer_devices = getenv ("WELS_HIP_LAYER_DEVICES") != NULL && atoi (getenv ("WELS_HIP_LAYER_DEVICES")) != 0;
   pFuncList->pHipState = st;
   pFuncList->pfHipFrameMd = HipFrameMd;
   pFuncList->pfHipCodeSlice = HipCodeSlice;

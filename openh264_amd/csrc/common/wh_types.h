@@ -113,6 +113,8 @@ typedef struct WhPicJob {
   int32_t        mb_begin;    // only MBs in [mb_begin, mb_end) are coded by this launch (GOM-synchronous rate control); the ones
   int32_t        mb_end;      //   before mb_begin count as done; mb_end == 0 means the whole picture
   int32_t        pad4;
+  const int16_t* il_hint;     // highest spatial layer of a multi-layer session: what WelsMdInterMbEnhancelayer takes from the layer
+                              //   below (svc_mode_decision.cpp:108-150), per MB {sMvBase x, y, flags (bit 0: that MB is intra), 0}; or NULL
 } WhPicJob;
 
 #define WH_MAX_SLICES 36
@@ -133,7 +135,7 @@ typedef struct WhSeqParams {
   int32_t pad[1];
   int32_t blk8_w, blk8_h;               // picture size in whole 8x8 luma blocks (scene-change statistic)
   unsigned long long* prof;             // optional device array of 64 x 32 cycle counters (phase profiling), or NULL
-  const uint16_t* mb_order;             // device table: [0, num_mb) MB addresses in dependency order per slice (each slice's
+  const uint32_t* mb_order;             // device table (32-bit entries: a wave-uniform look-up is then a scalar load): [0, num_mb) MB addresses in dependency order per slice (each slice's
                                         // range is [slice_first_mb[s], slice_first_mb[s+1])), [num_mb, 2*num_mb) whole-picture order,
                                         // [2*num_mb, 3*num_mb) per deblocking band (each band's range is [db_bands[b], db_bands[b+1]))
   // Deblocking bands: the MB ranges the deblocking workgroups own (rows of one slice, at most WH_DB_BAND_ROWS of them: a

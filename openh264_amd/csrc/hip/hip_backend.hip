@@ -68,7 +68,7 @@ __global__ __launch_bounds__ (MAX_THREADS) void NAME (WhSeqParams P, const WhPic
   const int num_mb = P.mb_w * P.mb_h;                                                                                   \
   const int first = WHOLE_PICTURE ? 0 : P.slice_first_mb[blockIdx.x];                                                   \
   const int n = WHOLE_PICTURE ? num_mb : P.slice_first_mb[blockIdx.x + 1] - first;                                      \
-  const uint16_t* order = P.mb_order + (WHOLE_PICTURE ? num_mb : first);                                                \
+  const uint32_t* order = P.mb_order + (WHOLE_PICTURE ? num_mb : first);                                                \
   for (int i = (int)threadIdx.x; i < 1 + ((n + 31) >> 5); i += (int)blockDim.x) sched[i] = 0;                          \
   if (PROF && P.prof && lane < 32) wh_prof_lds (S)[lane] = 0;                                                           \
   __shared__ WhPicJob Jl;                   /* the job descriptor, read from LDS (lgkmcnt) wherever it is needed */        \
@@ -278,7 +278,7 @@ __global__ __launch_bounds__ (1024) void k_deblock_slices (WhSeqParams P, const 
   // idc 2: nothing is filtered (or needed) across slices -- only the bands of this band's own slice matter
   const bool cross = P.deblock_idc == 0;
   const int sfirst = cross ? 0 : P.db_bands[nb + 1 + blockIdx.x], slast = cross ? num_mb : P.db_bands[2 * nb + 1 + blockIdx.x];
-  const uint16_t* order = P.mb_order + 2 * num_mb + first;
+  const uint32_t* order = P.mb_order + 2 * num_mb + first;
   for (int i = (int)threadIdx.x; i < 1 + ((n + 31) >> 5); i += (int)blockDim.x) sched[i] = 0;
   __shared__ WhPicJob Jl;
   wh_copy_job (&Jl, &jobs[blockIdx.y]);

@@ -52,7 +52,7 @@ struct SessionCore {
   int last_slot = 0;                  // source slot of the previous frame (VAA reference)
   bool prev_src_dirty = false;        // that slot received a new upload since the frame was begun
   WhMbRecord* d_records = nullptr;
-  uint16_t* d_order = nullptr;
+  uint32_t* d_order = nullptr;
   int32_t* d_bands = nullptr;
   uint32_t* d_dbflags = nullptr;
   uint32_t db_gen = 0;
@@ -229,7 +229,8 @@ struct SessionCore {
     const int nb = wh_build_db_bands (mb_w, mb_h, s.num_slices, s.slice_first_mb, s.deblock_idc, brows, bands.data(), (int)bands.size(), by_slice);
     if (nb < 1) { set_err ("deblocking band table"); release(); return WELSHIP_ERR_UNKNOWN; }
     for (int b = 0; b < nb; ++b) wh_build_mb_order (mb_w, bands[b], bands[b + 1], order.data() + 2 * (size_t)num_mb + bands[b]);
-    d_order = (uint16_t*)A (order.size() * 2);
+    std::vector<uint32_t> order32 (order.begin(), order.end());      // 32-bit on the device (scalar loads)
+    d_order = (uint32_t*)A (order32.size() * 4);
     d_bands = (int32_t*)A (sizeof (int32_t) * (3 * (size_t)nb + 1));
     d_scene = (uint32_t*)A (64);
     d_dbflags = (uint32_t*)A (sizeof (uint32_t) * num_mb);
@@ -244,7 +245,7 @@ struct SessionCore {
     }
     h_records.resize (num_mb);
     be->pin_host (h_records.data(), sizeof (WhMbRecord) * num_mb);     // D2H target of every frame
-    be->upload (d_order, order.data(), order.size() * 2);
+    be->upload (d_order, order32.data(), order32.size() * 4);
     be->upload (d_bands, bands.data(), sizeof (int32_t) * (3 * (size_t)nb + 1));
     be->fill (d_dbflags, 0, sizeof (uint32_t) * num_mb);
     if (be->sync()) { set_err ("device error while setting up the session"); release(); return WELSHIP_ERR_UNKNOWN; }
@@ -1052,7 +1053,7 @@ struct WelsHipFrameCtx {
   std::vector<uint8_t> h_src;
   WhMbRecord* d_records = nullptr;
   std::vector<WhMbRecord> h_records;
-  uint16_t* d_order = nullptr;
+  uint32_t* d_order = nullptr;
   int32_t* d_bands = nullptr;
   uint32_t* d_dbflags = nullptr;
   uint32_t db_gen = 0;
@@ -1061,6 +1062,7 @@ struct WelsHipFrameCtx {
   int32_t* d_sad_cost0 = nullptr;        // the layer's pSadCost[0] array (persists across pictures)
   int32_t* d_vaa = nullptr;
   int8_t* d_bgd = nullptr;
+  int16_t* d_il = nullptr;
   WhPicJob* d_job = nullptr;
   // slice / deblocking layout the tables on the device were built for
   std::vector<int32_t> cur_slices;
@@ -1071,7 +1073,7 @@ struct WelsHipFrameCtx {
     be->sync();
     for (auto& p : pics) { if (p.base) be->free (p.base); if (p.mbs) be->free (p.mbs); }
     pics.clear();
-    void* ptrs[] = {d_src, d_records, d_order, d_bands, d_dbflags, d_mb_ctl, d_sad_cost0, d_vaa, d_bgd, d_job};
+    void* ptrs[] = {d_src, d_records, d_order, d_bands, d_dbflags, d_mb_ctl, d_sad_cost0, d_vaa, d_bgd, d_il, d_job};
     for (void* p : ptrs) if (p) be->free (p);
     if (!h_records.empty()) be->unpin_host (h_records.data());
     delete be;
@@ -1095,7 +1097,8 @@ struct WelsHipFrameCtx {
     if (nb < 1) { set_err ("deblocking band table"); return WELSHIP_ERR_UNKNOWN; }
     for (int b = 0; b < nb; ++b) wh_build_mb_order (mb_w, bands[b], bands[b + 1], order.data() + 2 * (size_t)num_mb + bands[b]);
     be->sync();                                   // nothing in flight may still read the old tables
-    be->upload (d_order, order.data(), order.size() * 2);
+    std::vector<uint32_t> order32 (order.begin(), order.end());
+    be->upload (d_order, order32.data(), order32.size() * 4);
     be->upload (d_bands, bands.data(), sizeof (int32_t) * (3 * (size_t)nb + 1));
     if (be->sync()) { set_err ("device error"); return WELSHIP_ERR_UNKNOWN; }
     s.mb_order = d_order;
@@ -1141,13 +1144,14 @@ int WelsHipFrameCtxCreate (WelsHipFrameCtx** pp, const WelsHipFrameCfg* cfg) {
   for (auto& d : c->pics) { d.base = (uint8_t*)A (c->rec_alloc_bytes + 128); d.mbs = (WhMbState*)A (sizeof (WhMbState) * c->num_mb); }
   c->d_src = (uint8_t*)A (c->src_bytes);
   c->d_records = (WhMbRecord*)A (sizeof (WhMbRecord) * c->num_mb);
-  c->d_order = (uint16_t*)A ((size_t)c->num_mb * 3 * 2);
+  c->d_order = (uint32_t*)A ((size_t)c->num_mb * 3 * 4);
   c->d_bands = (int32_t*)A (sizeof (int32_t) * (3 * (size_t) (c->mb_h + WH_MAX_SLICES) + 1));
   c->d_dbflags = (uint32_t*)A (sizeof (uint32_t) * c->num_mb);
   c->d_mb_ctl = (WhMbCtl*)A (sizeof (WhMbCtl) * c->num_mb);
   c->d_sad_cost0 = (int32_t*)A (sizeof (int32_t) * c->num_mb);
   c->d_vaa = (int32_t*)A (sizeof (int32_t) * 4 * c->num_mb);
   c->d_bgd = (int8_t*)A ((size_t)c->num_mb + 64);
+  c->d_il = (int16_t*)A (sizeof (int16_t) * 4 * c->num_mb);
   c->d_job = (WhPicJob*)A (sizeof (WhPicJob));
   if (oom) { set_err ("out of device memory"); c->release(); delete c; return WELSHIP_ERR_MEMORY; }
   for (auto& d : c->pics) {
@@ -1209,6 +1213,8 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
     be->upload (c->d_src, c->h_src.data(), c->src_bytes);
     if (is_p && j->pVaaSad8x8) be->upload (c->d_vaa, j->pVaaSad8x8, sizeof (int32_t) * 4 * c->num_mb);
     if (is_p && j->pBgdFlags) be->upload (c->d_bgd, j->pBgdFlags, (size_t)c->num_mb);
+    if (is_p && j->pIlHint) be->upload (c->d_il, j->pIlHint, sizeof (int16_t) * 4 * c->num_mb);
+    if (j->pSadCost) be->upload (c->d_sad_cost0, j->pSadCost, sizeof (int32_t) * c->num_mb);
     if (++c->db_gen == 0) c->db_gen = 1;
   }
   bool qp_map = false;
@@ -1236,6 +1242,7 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
   job.vaa_sad8x8 = is_p && j->pVaaSad8x8 ? c->d_vaa : nullptr;
   job.bgd_flags = is_p && j->pBgdFlags ? c->d_bgd : nullptr;
   job.mvc_shift = j->iMvcShift;
+  job.il_hint = is_p && j->pIlHint ? c->d_il : nullptr;
   job.mb_begin = ranged ? j->iMbBegin : 0; job.mb_end = ranged ? j->iMbEnd : 0;
   be->upload (c->d_job, &job, sizeof (job));
   if (is_p) be->run_inter (s, c->d_job, 1); else be->run_intra (s, c->d_job, 1);
@@ -1246,11 +1253,18 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
     if (j->bExpand) be->run_expand (s, c->d_job, 1);
     cur.is_p = is_p;
   }
+  if (j->pSadCost && last_part) be->download (j->pSadCost, c->d_sad_cost0, sizeof (int32_t) * c->num_mb);
   if (ranged) be->download (c->h_records.data() + j->iMbBegin, c->d_records + j->iMbBegin, sizeof (WhMbRecord) * (size_t) (j->iMbEnd - j->iMbBegin));
   else be->download (c->h_records.data(), c->d_records, sizeof (WhMbRecord) * c->num_mb);
   if (be->sync()) { set_err ("device scheduler timed out or device error; the picture was not encoded"); return WELSHIP_ERR_UNKNOWN; }
   *pp_records = c->h_records.data();
   return WELSHIP_OK;
+}
+
+int WelsHipFrameGetMbStates (WelsHipFrameCtx* c, int pic, void* dst, size_t bytes) {
+  if (!c || !c->be || pic < 0 || pic >= (int)c->pics.size() || !dst || bytes < sizeof (WhMbState) * c->num_mb) return WELSHIP_ERR_INIT_PARA;
+  c->be->download (dst, c->pics[pic].mbs, sizeof (WhMbState) * c->num_mb);
+  return c->be->sync() ? WELSHIP_ERR_UNKNOWN : WELSHIP_OK;
 }
 
 int WelsHipFrameGetPicture (WelsHipFrameCtx* c, int pic, uint8_t* const dst[3], const int32_t stride[3]) {

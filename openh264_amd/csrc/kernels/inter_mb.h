@@ -807,6 +807,20 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, WhInterStage& G, const WhSeqParams& 
     WV_LSET_IF (bgf, lane, lane < 5, ([&] () { const int off = lane == 0 ? 0 : lane == 1 ? -1 : lane == 2 ? -w : lane == 3 ? -w + 1 : -w - 1;
                                               return xy + off >= 0 ? (int) ((const WH_G int8_t*)J.bgd_flags)[xy + off] : 0; }) ());
   }
+  // inter-layer hints of the highest spatial layer (WelsMdInterMbEnhancelayer): base vector candidate and "base MB is intra"
+  int il_mv = 0;
+  bool il_intra = false;
+  if (J.il_hint) {
+    WvLaneArr ilh;
+#if defined(WH_EMU)
+    memset (&ilh, 0, sizeof (ilh));
+#else
+    ilh = 0;
+#endif
+    WV_LSET_IF (ilh, lane, lane < 3, (int) ((const WH_G int16_t*)J.il_hint)[xy * 4 + lane]);
+    il_mv = wh_pk_mv (WV_LGET (ilh, 0), WV_LGET (ilh, 1));
+    il_intra = (WV_LGET (ilh, 2) & 1) != 0;
+  }
   const bool bg_cur = bgd && WV_LGET (bgf, 0) != 0, bg_l = bgd && WV_LGET (bgf, 1) != 0, bg_t = bgd && WV_LGET (bgf, 2) != 0;
   const bool bg_tr = bgd && WV_LGET (bgf, 3) != 0, bg_tl = bgd && WV_LGET (bgf, 4) != 0;
   // skip context of PredictSadSkip: with background detection a skipped neighbour only counts when it is not background
@@ -962,7 +976,7 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, WhInterStage& G, const WhSeqParams& 
   WH_PROF_MARK (P, M, 1);   // P_Skip test
 
   int sad_pred16 = 0;
-  if (!done && !b_skip) {
+  if (!done && !b_skip && !il_intra) {
     // PredictSad (md.cpp:826-870)
     int sad_pred;
     {
@@ -982,7 +996,7 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, WhInterStage& G, const WhSeqParams& 
     const bool c_l = Lm != nullptr, c_t = Tm != nullptr, c_r = ref_is_p && mbx < P.mb_w - 1, c_b = ref_is_p && mby < P.mb_h - 1;
     const int i_l = 1, i_t = i_l + (c_l ? 1 : 0), i_r = i_t + (c_t ? 1 : 0), i_b = i_r + (c_r ? 1 : 0);
     nm = i_b + (c_b ? 1 : 0);
-    WV_LSET (mvcl, 0, 0);
+    WV_LSET (mvcl, 0, il_mv);                   // sMvBase: zero, or twice the base layer's vector (SetMvBaseEnhancelayer)
     if (c_l) WV_LSET (mvcl, i_l, wh_pk_mv (Lm->p16mv[0], Lm->p16mv[1]));
     if (c_t) WV_LSET (mvcl, i_t, wh_pk_mv (Tm->p16mv[0], Tm->p16mv[1]));
     const int msh = J.mvc_shift;       // temporal layers: the reference picture's vectors span 2^shift picture intervals
@@ -1000,6 +1014,12 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, WhInterStage& G, const WhSeqParams& 
   // ---- secondary modes (WelsMdInterSecondaryModesEnc) ----
   bool intra = false;
   WhIntraResult ir;
+  if (!done && il_intra) {
+    // WelsMdSpatialelInterMbIlfmdNoilp, base-layer MB intra (svc_mode_decision.cpp:88-100): no motion search at all -- a skip
+    // that is at least as cheap as Intra16x16 stays, anything else becomes intra (I16x16 against I4x4 as in an I slice)
+    if (b_skip && cost_luma <= i16c.best_cost) { mb_type = WH_MB_PSKIP; done = true; }
+    else { (void)wh_intra_md_enc_p (M, P, J, mbx, mby, avail, qp, qpc, 0x7fffffff, &ir, &i16c, stale_cbp); intra = true; done = true; }
+  }
   if (!done) {
     // WelsMdFirstIntraMode: I16x16 cost vs the inter/skip cost so far
     if (wh_intra_md_enc_p (M, P, J, mbx, mby, avail, qp, qpc, cost_luma, &ir, &i16c, stale_cbp)) { intra = true; done = true; }
@@ -1010,7 +1030,7 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, WhInterStage& G, const WhSeqParams& 
   if (!done) {
     // ---- fine partitions: groups of searches (8x8 x4, 16x8 x2, 8x16 x2), results kept per slot in T ----
     wh_me_store (T, WH_SLOT_16x16, me16);
-    WV_LSET (mvcl, 0, 0);
+    WV_LSET (mvcl, 0, il_mv);
     int order0 = -1, order1 = -1, order2 = -1;      // group ids: 0 = 8x8, 1 = 16x8, 2 = 8x16
     bool chain = false;                             // later groups only run when the first one beat the 16x16 cost
     if (!use_satd) {

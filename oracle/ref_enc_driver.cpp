@@ -38,7 +38,8 @@ int main (int argc, char** argv) {
   int setidr_at = -1, setidr_val = 0, setcplx_at = -1, setcplx_val = 0, paramsets_at = -1, setfps_at = -1;
   float setfps_val = 30.f;
   std::string infofile;                // -dumpinfo FILE: the SFrameBSInfo metadata of every frame, one line per layer
-  int low_w = 0, low_h = 0;            // -simulcast WxH: an extra, lower spatial layer, simulcast AVC (the input is the higher one)
+  int low_w = 0, low_h = 0;            // -simulcast W H: an extra, lower spatial layer, simulcast AVC (the input is the highest one);
+  int lows[3][2] = {{0, 0}, {0, 0}, {0, 0}}, nlow = 0;     // may be given up to three times, lowest resolution first
   for (int i = 1; i < argc; ++i) {
     const char* a = argv[i];
     auto next = [&] () -> const char* { if (i + 1 >= argc) { std::fprintf (stderr, "missing value for %s\n", a); std::exit (2); } return argv[++i]; };
@@ -78,7 +79,7 @@ int main (int argc, char** argv) {
     else if (arg_eq (a, "-setcplx")) { setcplx_at = std::atoi (next()); setcplx_val = std::atoi (next()); }   // SetOption (ENCODER_OPTION_COMPLEXITY) before frame N
     else if (arg_eq (a, "-setfps")) { setfps_at = std::atoi (next()); setfps_val = (float)std::atof (next()); }  // SetOption (ENCODER_OPTION_FRAME_RATE) before frame N
     else if (arg_eq (a, "-dumpinfo")) infofile = next();
-    else if (arg_eq (a, "-simulcast")) { low_w = std::atoi (next()); low_h = std::atoi (next()); }
+    else if (arg_eq (a, "-simulcast")) { low_w = std::atoi (next()); low_h = std::atoi (next()); if (nlow < 3) { lows[nlow][0] = low_w; lows[nlow][1] = low_h; ++nlow; } }
     else if (arg_eq (a, "-paramsets")) paramsets_at = std::atoi (next());       // EncodeParameterSets before frame N, output appended
     else if (arg_eq (a, "-quiet")) quiet = 1;
     else { std::fprintf (stderr, "unknown option %s\n", a); return 2; }
@@ -125,11 +126,12 @@ int main (int argc, char** argv) {
     l.sSliceArgument.uiSliceMode = (SliceModeEnum)slcmd;
     l.sSliceArgument.uiSliceNum = (unsigned)slcnum;
     if (slcmbnum > 0) for (int k = 0; k < MAX_SLICES_NUM_TMP; ++k) l.sSliceArgument.uiSliceMbNum[k] = (unsigned)slcmbnum;
-    if (low_w > 0) {                   // layer 0 = the lower resolution, layer 1 = the input resolution
-      p.iSpatialLayerNum = 2; p.bSimulcastAVC = true;
-      p.sSpatialLayers[1] = l;
-      p.sSpatialLayers[0] = l;
-      p.sSpatialLayers[0].iVideoWidth = low_w; p.sSpatialLayers[0].iVideoHeight = low_h;
+    if (nlow > 0) {                    // layers 0 .. nlow-1 = the lower resolutions (lowest first), layer nlow = the input resolution
+      p.iSpatialLayerNum = nlow + 1; p.bSimulcastAVC = true;
+      const SSpatialLayerConfig top = l;
+      p.sSpatialLayers[nlow] = top;
+      for (int k = 0; k < nlow; ++k) { p.sSpatialLayers[k] = top; p.sSpatialLayers[k].iVideoWidth = lows[k][0]; p.sSpatialLayers[k].iVideoHeight = lows[k][1]; }
+      p.iTargetBitrate = bitrate * (nlow + 1);       // every layer gets `bitrate`; the total must cover their sum
     }
     ret = enc->InitializeExt (&p);
   }

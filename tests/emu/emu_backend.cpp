@@ -87,7 +87,7 @@ class EmuBackend : public Backend {
         E.top = xb.data(); E.left = xb.data() + (size_t)P.mb_w * 24; E.first_row = 0;
         poison (&S, sizeof (S)); poison (&G, sizeof (G));
         const int first = P.db_bands[s], last = P.db_bands[s + 1];
-        const uint16_t* order = P.mb_order + 2 * P.mb_w * P.mb_h;
+        const uint32_t* order = P.mb_order + 2 * P.mb_w * P.mb_h;
         for (int lane = 0; lane < 64; ++lane) wh_deblock_cold_fetch (G, lane, P, jobs[j], order[first] % P.mb_w, order[first] / P.mb_w);
         for (int t = first; t < last; ++t) {
           const int xy = order[t], xyn = t + 1 < last ? order[t + 1] : 0;

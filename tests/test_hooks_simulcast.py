@@ -1,0 +1,67 @@
+"""BASELINE config 4 through the dispatch-table binding: a 4-layer spatial simulcast (1920x1080 / 1280x720 / 640x360 / 320x180) from
+one 1080p input -- the reference's own frame layer downsamples (codec/processing, C downsampler) and codes the four layers one
+after the other; every layer's macroblock work runs on the device in its own context (optionally its own GPU:
+WELS_HIP_LAYER_DEVICES=1), and the highest layer takes the inter-layer mode-decision hints of WelsMdInterMbEnhancelayer
+(svc_mode_decision.cpp:108-150) from the layer below.  The access units must equal the unpatched reference's byte for byte.
+
+Also covered here: 2- and 3-layer sessions with rate control, several slices, temporal layers and background detection."""
+import os
+import subprocess
+
+import pytest
+
+from openh264_amd.utils.synth import synth_sequence
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.path.join(ROOT, "oracle", "_ref")
+RES = os.path.join(REF, "res")
+pytestmark = pytest.mark.skipif(not os.path.exists(os.path.join(REF, "ref_enc_hip")), reason="oracle/_ref (hooked reference) not built")
+
+CONFIG4 = ["-simulcast", "320", "180", "-simulcast", "640", "360", "-simulcast", "1280", "720"]
+
+
+def _both(lib, tmp_path, yuv, w, h, flags, min_pictures):
+    fi = str(tmp_path / "in.yuv")
+    open(fi, "wb").write(yuv)
+    base = ["-i", fi, "-w", str(w), "-h", str(h), "-fps", "30", "-quiet"] + flags
+    subprocess.check_call([os.path.join(REF, "ref_enc"), "-o", str(tmp_path / "ref.264")] + base, stdout=subprocess.DEVNULL)
+    env = dict(os.environ, WELSHIP_LIB=lib, WELS_HIP_TRACE="1")
+    p = subprocess.run([os.path.join(REF, "ref_enc_hip"), "-o", str(tmp_path / "hip.264")] + base, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    err = p.stderr.decode(errors="replace")
+    assert p.returncode == 0, err[-2000:]
+    assert "welship hooks: installed" in err and err.count("welship hooks: did") >= min_pictures, err[-2000:]
+    assert (tmp_path / "ref.264").read_bytes() == (tmp_path / "hip.264").read_bytes()
+
+
+SMALL = [
+    (["-rc", "1", "-bitrate", "800000", "-simulcast", "160", "96", "-simulcast", "320", "192", "-slcmd", "1", "-slcnum", "2"], 18),
+    (["-rc", "0", "-bitrate", "800000", "-simulcast", "106", "62", "-simulcast", "212", "122", "-simulcast", "426", "246", "-bgd", "1", "-numtl", "2"], 24),
+    (["-rc", "3", "-bitrate", "500000", "-simulcast", "320", "184", "-complexity", "2", "-scene", "1"], 12),
+    (["-rc", "-1", "-qp", "28", "-simulcast", "160", "96", "-simulcast", "320", "184", "-complexity", "1", "-slcmd", "1", "-slcnum", "3"], 18),
+]
+
+
+@pytest.mark.parametrize("flags,pictures", SMALL)
+def test_simulcast_sessions_on_emulation(emu_lib, tmp_path, flags, pictures):
+    _both(emu_lib, tmp_path, synth_sequence(640, 368, 6), 640, 368, flags, pictures)
+
+
+def test_config4_four_layers_on_emulation(emu_lib, tmp_path):
+    _both(emu_lib, tmp_path, synth_sequence(1920, 1080, 3), 1920, 1080, ["-rc", "-1", "-qp", "24"] + CONFIG4, 12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags,pictures", SMALL)
+def test_simulcast_sessions_on_the_mi355x(hip_lib, tmp_path, flags, pictures):
+    _both(hip_lib, tmp_path, synth_sequence(640, 368, 6), 640, 368, flags, pictures)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rc", [["-rc", "-1", "-qp", "24"], ["-rc", "1", "-bitrate", "3000000", "-slcmd", "1", "-slcnum", "4"]])
+def test_config4_four_layers_of_the_1080p_clip_on_the_mi355x(hip_lib, ref_tools, tmp_path, rc):
+    if not ref_tools:
+        pytest.skip("oracle/_ref not built")
+    out = str(tmp_path / "clip.yuv")
+    subprocess.check_call([ref_tools["dec"], os.path.join(RES, "VID_1920x1080_cavlc_temporal_direct.264"), out], stdout=subprocess.DEVNULL)
+    yuv = open(out, "rb").read()[: 1920 * 1080 * 3 // 2 * 12]
+    _both(hip_lib, tmp_path, yuv, 1920, 1080, rc + CONFIG4, 48)
