@@ -282,6 +282,21 @@ int WelsHipPrimDeblockEdges (int nEdges, uint8_t* pPlaneInOut, size_t bytes, int
 /* VAACalcSad_c of codec/processing (per macroblock): four 8x8 SADs against the previous source picture */
 int WelsHipPrimVaaSad8x8 (int nMb, const uint8_t* pCur, const uint8_t* pRef, size_t bytes, int32_t iStride, const int32_t* pOff, int32_t* pSad8x8);
 
+/* ---- (3b) spatial down-sampling of source planes (simulcast layers; codec/processing/src/downsample): the entries of
+ * SDownsampleFuncs as the C build fills them (downsample.cpp:73-93): pfHalfAverageWidthx32/x16 = DyadicBilinearDownsampler_c,
+ * pfQuarterDownsampler, pfOneThirdDownsampler, pfGeneralRatioLuma = GeneralBilinearFastDownsampler_c, pfGeneralRatioChroma =
+ * GeneralBilinearAccurateDownsampler_c (downsamplefuncs.cpp:47-245).  Host planes; the source plane must have one readable
+ * row below its last one (the reference's planes are padded), destination samples outside iDstWidth x iDstHeight are untouched. */
+#define WELSHIP_DS_HALF 0
+#define WELSHIP_DS_QUARTER 1
+#define WELSHIP_DS_ONE_THIRD 2
+#define WELSHIP_DS_GENERAL_FAST 3
+#define WELSHIP_DS_GENERAL_ACCURATE 4
+int WelsHipPrimDownsample (int mode, uint8_t* pDst, int32_t iDstStride, int32_t iDstWidth, int32_t iDstHeight,
+                           const uint8_t* pSrc, int32_t iSrcStride, int32_t iSrcWidth, int32_t iSrcHeight);
+/* one launch over nPlanes HBM-resident planes, timed with HIP events: pOut[0] = ms per launch, pOut[1] = algorithmic bytes per launch */
+int WelsHipDownsampleBench (int iDevice, int mode, int nPlanes, int iSrcWidth, int iSrcHeight, int iDstWidth, int iDstHeight, int iIters, double* pOut);
+
 #ifdef __cplusplus
 }
 #endif

@@ -170,9 +170,9 @@ int32_t HipFrameMd (sWelsEncCtx* pCtx) {
   // with WelsMdInterMbEnhancelayer -- the type and one vector of the co-located macroblock of the layer coded just before it
   // (GetRefMb / SetMvBaseEnhancelayer, svc_mode_decision.cpp:108-150), simulcast AVC included
   // pSadCost[0] lives in ONE array for all spatial layers (pEncCtx->pSadCostMb): the host's copy travels with every picture
-  job.pSadCost = pParam->iSpatialLayerNum > 1 ? pCtx->pSadCostMb : NULL;
+  job.pSadCost = (pParam->iSpatialLayerNum > 1 && !getenv ("WELS_HIP_NO_SADCOST")) ? pCtx->pSadCostMb : NULL;
   job.pIlHint = NULL;
-  if (is_p && pCurLayer->bBaseLayerAvailableFlag && pParam->iSpatialLayerNum == did + 1 && pCurLayer->pRefLayer) {
+  if (is_p && pCurLayer->bBaseLayerAvailableFlag && pParam->iSpatialLayerNum == did + 1 && pCurLayer->pRefLayer && !getenv ("WELS_HIP_NO_ILHINT")) {
     const SDqLayer* kpRefLayer = pCurLayer->pRefLayer;
     L.il_hint.assign ((size_t)num_mb * 4, 0);
     for (int y = 0; y < mbh; ++y)
@@ -202,6 +202,12 @@ int32_t HipFrameMd (sWelsEncCtx* pCtx) {
   const int rc = g_api.FrameEncode (L.ctx, &job, &rec);
   if (rc) { fprintf (stderr, "welship hooks: WelsHipFrameEncode failed (%d: %s)\n", rc, g_api.GetLastError()); st->failed = true; return ENC_RETURN_UNEXPECTED; }
   L.records = (const WhMbRecord*)rec;
+  if (const char* dump = getenv ("WELS_HIP_DUMP_RECORDS")) {        // developer aid: the raw macroblock records of every picture
+    static int s_pic = 0;
+    char name[512];
+    snprintf (name, sizeof name, "%s_%03d_d%d.rec", dump, s_pic++, did);
+    if (FILE* f = fopen (name, "wb")) { fwrite (rec, sizeof (WhMbRecord), num_mb, f); fclose (f); }
+  }
   L.states.clear();
   if (pParam->iSpatialLayerNum > did + 1) {      // a higher layer will read this layer's motion (see pIlHint above)
     L.states.resize (num_mb);
@@ -211,7 +217,7 @@ int32_t HipFrameMd (sWelsEncCtx* pCtx) {
   uint8_t* dst[3] = { pCtx->pDecPic->pData[0], pCtx->pDecPic->pData[1], pCtx->pDecPic->pData[2] };
   const int32_t ds[3] = { pCtx->pDecPic->iLineSize[0], pCtx->pDecPic->iLineSize[1], pCtx->pDecPic->iLineSize[2] };
   if (g_api.FrameGetPicture (L.ctx, job.iCurPic, dst, ds)) { st->failed = true; return ENC_RETURN_UNEXPECTED; }
-  if (st->trace) fprintf (stderr, "welship hooks: did %d %c picture qp %d slices %d cur %d ref %d deblock %d expand %d\n", did, is_p ? 'P' : 'I', job.iQp, nslices, job.iCurPic, job.iRefPic, job.bDeblock, job.bExpand);
+  if (st->trace) fprintf (stderr, "welship hooks: did %d %c picture qp %d slices %d cur %d ref %d deblock %d expand %d mvrange %d complexity %d\n", did, is_p ? 'P' : 'I', job.iQp, nslices, job.iCurPic, job.iRefPic, job.bDeblock, job.bExpand, job.iMvRange, job.iComplexityMode);
   return ENC_RETURN_SUCCESS;
 }
 

@@ -113,6 +113,8 @@ typedef struct WhPicJob {
   int32_t        mb_begin;    // only MBs in [mb_begin, mb_end) are coded by this launch (GOM-synchronous rate control); the ones
   int32_t        mb_end;      //   before mb_begin count as done; mb_end == 0 means the whole picture
   int32_t        pad4;
+  uint8_t*       compact;     // packed records of this picture (common/compact.h), written by the compaction pass, or NULL
+  uint32_t*      compact_off; // num_mb + 1 byte offsets into `compact`
   const int16_t* il_hint;     // highest spatial layer of a multi-layer session: what WelsMdInterMbEnhancelayer takes from the layer
                               //   below (svc_mode_decision.cpp:108-150), per MB {sMvBase x, y, flags (bit 0: that MB is intra), 0}; or NULL
 } WhPicJob;

@@ -20,6 +20,7 @@
 #include "../kernels/inter_mb.h"
 #include "../kernels/expand_pic.h"
 #include "../kernels/scene_pic.h"
+#include "../common/compact.h"
 
 namespace {
 
@@ -346,6 +347,81 @@ __global__ __launch_bounds__ (1024) void k_deblock_slices (WhSeqParams P, const 
   if (P.prof && lane < 32) atomicAdd (&P.prof[2048u + ((blockIdx.x + blockIdx.y * 7u) & 63u) * 32u + lane], (unsigned long long)S.prof[lane]);
 }
 
+
+// ---- record compaction (common/compact.h): one workgroup per picture ------------------------------------------------
+// Pass 1: one wavefront per MB tests its 25 coefficient blocks (+ chroma DC) for non-zero levels (ballot over four
+// lane-parallel loads), gates them by type / cbp, and leaves mask and size in LDS.  Pass 2: exclusive scan of the sizes.
+// Pass 3: one wavefront per MB copies header, side info and the selected blocks to their place.  Reads the records once from
+// L2/HBM (they were written by the previous launch), writes ~1/6 of them.
+#define WH_CP_MAX_MB 9216          /* 4096 x 2304 / 256 would be 36864: larger pictures keep the full-record path */
+__global__ __launch_bounds__ (1024) void k_compact (WhSeqParams P, const WhPicJob* jobs) {
+  __shared__ uint16_t s_size[WH_CP_MAX_MB];
+  __shared__ uint32_t s_mask[WH_CP_MAX_MB];
+  __shared__ uint32_t s_part[1024];
+  const WhPicJob J = jobs[blockIdx.x];
+  const int num_mb = P.mb_w * P.mb_h, lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6, nw = (int)blockDim.x >> 6;
+  const WH_G WhMbRecord* recs = (const WH_G WhMbRecord*)J.records;
+  for (int xy = wave; xy < num_mb; xy += nw) {
+    const WH_G uint32_t* r = (const WH_G uint32_t*)&recs[xy];
+    const uint32_t h0 = r[0];                                        // mb_type, cbp, luma_qp, chroma_qp
+    const int mb_type = (int) (h0 & 0xff), cbp = (int) ((h0 >> 8) & 0xff);
+    uint32_t mask = 0;
+    if (mb_type != WH_MB_PSKIP) {
+      const WH_G uint32_t* c = r + 36;                               // 204 coefficient dwords: 25 blocks of 8 + chroma DC (4)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int d = lane + 64 * k;
+        const unsigned long long b = __ballot (d < 204 && c[d] != 0u);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) if ((b >> (8 * g)) & 0xffull) { const int blk = 8 * k + g; mask |= 1u << (blk < 25 ? blk : 25); }
+      }
+      mask &= wh_compact_allowed (mb_type, cbp);
+    }
+    if (lane == 0) { s_mask[xy] = mask; s_size[xy] = (uint16_t)wh_compact_size (mb_type, mask); }
+  }
+  __syncthreads();
+  // exclusive scan: thread t owns the MBs [t * per, (t + 1) * per)
+  const int per = (num_mb + (int)blockDim.x - 1) / (int)blockDim.x, t = (int)threadIdx.x;
+  uint32_t sum = 0;
+  for (int i = t * per; i < (t + 1) * per && i < num_mb; ++i) sum += s_size[i];
+  s_part[t] = sum;
+  __syncthreads();
+  for (int d = 1; d < (int)blockDim.x; d <<= 1) {
+    const uint32_t v = t >= d ? s_part[t - d] : 0u;
+    __syncthreads();
+    s_part[t] += v;
+    __syncthreads();
+  }
+  uint32_t run = t ? s_part[t - 1] : 0u;
+  for (int i = t * per; i < (t + 1) * per && i < num_mb; ++i) { J.compact_off[i] = run; run += s_size[i]; }
+  if (t == (int)blockDim.x - 1) J.compact_off[num_mb] = s_part[t];
+  __syncthreads();
+  for (int xy = wave; xy < num_mb; xy += nw) {
+    const WH_G uint32_t* r = (const WH_G uint32_t*)&recs[xy];
+    WH_G uint32_t* o = (WH_G uint32_t*) ((WH_G uint8_t*)J.compact + J.compact_off[xy]);
+    const uint32_t mask = s_mask[xy];
+    const uint32_t h0 = r[0];
+    if ((h0 & 0xff) == WH_MB_PSKIP) {
+      if (lane < 2) o[lane] = r[lane];
+      else if (lane == 2) o[2] = r[30];                              // cost (byte 120)
+      else if (lane == 3) o[3] = ((const WH_G uint8_t*)r)[WH_COMPACT_SIDE - 16];      // bgd_skip
+      continue;
+    }
+    if (lane == 0) o[0] = mask;
+    if (lane < 36) o[1 + lane] = r[lane];
+    const WH_G uint32_t* c = r + 36;
+    WH_G uint32_t* q = o + 37;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int d = lane + 64 * k;
+      if (d < 204) {
+        const int blk = d >> 3 < 25 ? d >> 3 : 25;
+        if ((mask >> blk) & 1u) q[8 * __builtin_popcount (mask & ((1u << blk) - 1u)) + (d - 8 * blk)] = c[d];
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__ (64) void k_expand (WhSeqParams P, const WhPicJob* jobs) {
   const WhPicJob J = jobs[blockIdx.y];
   wh_expand_body (P, J, (int)blockIdx.x);
@@ -530,6 +606,10 @@ class HipBackend : public wh::Backend {
   }
   void run_expand (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
     hipLaunchKernelGGL (k_expand, dim3 (wh_expand_num_blocks (P), n), dim3 (64), 0, stream_, P, jobs);
+    HIP_TRY (hipGetLastError());
+  }
+  void run_compact (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
+    hipLaunchKernelGGL (k_compact, dim3 (n), dim3 (1024), 0, stream_, P, jobs);
     HIP_TRY (hipGetLastError());
   }
   void select_queue (int k) override {

@@ -245,6 +245,7 @@ struct SessionCore {
     }
     h_records.resize (num_mb);
     be->pin_host (h_records.data(), sizeof (WhMbRecord) * num_mb);     // D2H target of every frame
+    be->pin_host (h_src.data(), src_bytes);                            // H2D source of every frame
     be->upload (d_order, order32.data(), order32.size() * 4);
     be->upload (d_bands, bands.data(), sizeof (int32_t) * (3 * (size_t)nb + 1));
     be->fill (d_dbflags, 0, sizeof (uint32_t) * num_mb);
@@ -274,6 +275,7 @@ struct SessionCore {
     if (d_records) be->free (d_records);
     d_records = nullptr;
     if (!h_records.empty()) be->unpin_host (h_records.data());
+    if (!h_src.empty()) be->unpin_host (h_src.data());
     if (d_order) be->free (d_order);
     d_order = nullptr;
     if (d_bands) be->free (d_bands);
@@ -289,7 +291,11 @@ struct SessionCore {
 
   // WelsMoveMemoryWrapper + Padding (wels_preprocess.cpp:1250-1275,1395-1450): even dims only; the rows/cols
   // that exist only because of MB alignment are luma 0 / chroma 0x80 (h_src is pre-filled that way).
-  void upload_source (int slot, const WelsHipSourcePicture* src) {
+  // Two halves so that a group can do the host copies of all its sessions on several threads and then queue the transfers
+  // without waiting for any of them: stage_source touches only this session's page-locked staging buffer, issue_upload
+  // only queues the DMA (the kernels that read the picture are behind it on the same queue).
+  bool upload_pending = false;        // the staging buffer may still be read by a queued transfer
+  void stage_source (const WelsHipSourcePicture* src) {
     const WhSeqParams& s = seq;
     const int w = prm.iPicWidth & ~1, h = prm.iPicHeight & ~1;
     uint8_t* y = h_src.data();
@@ -300,9 +306,16 @@ struct SessionCore {
       memcpy (u + (size_t)r * s.src_stride_c, src->pData[1] + (size_t)r * src->iStride[1], w / 2);
       memcpy (v + (size_t)r * s.src_stride_c, src->pData[2] + (size_t)r * src->iStride[2], w / 2);
     }
+  }
+  void issue_upload (int slot) {
     if (slot == last_slot) prev_src_dirty = true;
     be->upload (d_src[slot], h_src.data(), src_bytes);
-    be->sync();                       // h_src is reused by the next upload
+    upload_pending = true;
+  }
+  void upload_source (int slot, const WelsHipSourcePicture* src) {
+    if (upload_pending) { be->sync(); upload_pending = false; }      // the previous transfer out of the staging buffer
+    stage_source (src);
+    issue_upload (slot);
   }
 
   // Decide the frame type (encoder_ext.cpp DecideFrameType: IDR at index 0 / intra period / on request) and
@@ -767,6 +780,7 @@ int WelsHipEncodeFrame (WelsHipEncoder* e, const WelsHipSourcePicture* src, Wels
   run_device_step (e->be, c.seq, e->d_job, 1, c.cur_idr, c.prm.uiIntraPeriod != 1);
   e->be->download (c.h_records.data(), c.d_records, sizeof (WhMbRecord) * c.num_mb);
   if (e->be->sync()) { set_err ("device scheduler timed out; the picture was not encoded"); return WELSHIP_ERR_UNKNOWN; }
+  c.upload_pending = false;
   int rc = c.finish_frame (out, src->uiTimeStamp);
   while (rc == WELSHIP_ERR_VLC_OVERFLOW) {
     rc = reencode_after_overflow (e->be, c, e->d_job);
@@ -912,6 +926,7 @@ int WelsHipGroupFinish (WelsHipEncoderGroup* g, WelsHipFrameBSInfo* outs) {
     g->be->download (c.h_records.data(), c.d_records, sizeof (WhMbRecord) * c.num_mb);
   }
   if (g->be->sync()) { set_err ("device scheduler timed out; the step was not encoded"); return WELSHIP_ERR_UNKNOWN; }
+  for (auto& c : g->sess) c->upload_pending = false;
   std::vector<int> rcs (n, 0);
   const int T = g->host_threads < n ? g->host_threads : n;
   auto work = [&] (int t) { for (int i = t; i < n; i += T) rcs[i] = g->sess[i]->finish_frame (outs ? &outs[i] : nullptr, 0); };
@@ -944,7 +959,25 @@ int WelsHipGroupEncodeFrames (WelsHipEncoderGroup* g, const WelsHipSourcePicture
   if (!g || !srcs) return WELSHIP_ERR_INIT_PARA;
   const int n = (int)g->sess.size();
   const int slot = (g->sess[0]->last_slot + 1) % g->sess[0]->ring;    // never the slot of the previous picture
-  for (int i = 0; i < n; ++i) { int rc = WelsHipGroupUploadSource (g, i, slot, &srcs[i]); if (rc) return rc; }
+  for (int i = 0; i < n; ++i) {
+    const SessionCore& c = *g->sess[i];
+    if (srcs[i].iPicWidth != c.prm.iPicWidth || srcs[i].iPicHeight != c.prm.iPicHeight) return WELSHIP_ERR_INIT_PARA;
+  }
+  // host copies into the sessions' page-locked staging buffers on the entropy threads, then all transfers queued at once
+  bool pending = false;
+  for (int i = 0; i < n; ++i) pending = pending || g->sess[i]->upload_pending;
+  if (pending) { g->be->sync(); for (auto& c : g->sess) c->upload_pending = false; }
+  {
+    const int T = g->host_threads < n ? g->host_threads : n;
+    auto work = [&] (int t) { for (int i = t; i < n; i += T) g->sess[i]->stage_source (&srcs[i]); };
+    if (T <= 1) work (0);
+    else {
+      std::vector<std::thread> th;
+      for (int t = 0; t < T; ++t) th.emplace_back (work, t);
+      for (auto& x : th) x.join();
+    }
+  }
+  for (int i = 0; i < n; ++i) { g->be->select_queue (g->chunk_of (i)); g->sess[i]->issue_upload (slot % g->sess[i]->ring); }
   int rc = WelsHipGroupBegin (g, slot);
   if (rc) return rc;
   WelsHipGroupRunDevice (g, 0);

@@ -743,9 +743,11 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, WhInterStage& G, const WhSeqParams& 
     tr.y = G.cold_y[lane]; tr.c = lane < 32 ? G.cold_c[lane] : 0u;
     wh_tile_commit (M, lane, &tr);
     * (uint32_t*)&S.prev_y[lane * 4] = G.cold_pv[lane];
-    if (lane < 36) S.nb[144 + lane] = J.ref_mbs ? G.cold_co[lane] : 0u;     // the reference picture's state of this MB (an I picture's has no motion / SAD)
+    // the reference picture's state of this MB (an I picture's has no motion / SAD).  Its padding word (WhMbState::pad1, word
+    // 35) carries the layer's pSadCost[0] of this MB instead -- written by the SAME lane: two lanes storing to one LDS word in
+    // one instruction have no defined winner on the GPU
+    if (lane < 36) S.nb[144 + lane] = (lane == 35 && J.sad_cost0) ? G.cold_co[38] : J.ref_mbs ? G.cold_co[lane] : 0u;
     else if (lane < 38) * (uint32_t*)&S.co_mv[lane - 36][0] = G.cold_co[lane];
-    else if (lane == 38) S.nb[144 + 35] = G.cold_co[38];     // rides in the padding word of the co-located state copy (WhMbState::pad1)
 #pragma unroll
     for (int k = 0; k < 3; ++k) { const int i = lane + 64 * k; if (i < 144) S.nb[i] = st[k]; }
   }

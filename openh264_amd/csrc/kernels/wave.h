@@ -20,7 +20,13 @@
 #define WH_FN static inline
 #define WH_HDFN static inline
 #define WH_CONST static const
+// -DWH_EMU_REVERSE walks the lanes from 63 down: a lane block whose result depends on the order of its lanes (two lanes storing
+// to the same LDS word) has no defined outcome on the GPU, and shows up as a difference between the two test builds
+#if defined(WH_EMU_REVERSE)
+#define WV_LANES_BEGIN(lane) for (int lane = 63; lane >= 0; --lane) {
+#else
 #define WV_LANES_BEGIN(lane) for (int lane = 0; lane < 64; ++lane) {
+#endif
 #define WV_LANES_END }
 #define WV_SYNC() ((void)0)
 #define WV_SUM(dst, lane, expr)                                   \

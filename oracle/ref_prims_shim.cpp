@@ -22,6 +22,14 @@ using namespace WelsEnc;
 namespace WelsVP {   // codec/processing/src/vaacalc/vaacalculation.h:85
 void VAACalcSad_c (const uint8_t* pCurData, const uint8_t* pRefData, int32_t iPicWidth, int32_t iPicHeight, int32_t iPicStride,
                    int32_t* pFrameSad, int32_t* pSad8x8);
+// codec/processing/src/downsample/downsample.h:100-121 (the C fallbacks of SDownsampleFuncs)
+void DyadicBilinearDownsampler_c (uint8_t* pDst, const int32_t kiDstStride, uint8_t* pSrc, const int32_t kiSrcStride, const int32_t kiSrcWidth, const int32_t kiSrcHeight);
+void DyadicBilinearQuarterDownsampler_c (uint8_t* pDst, const int32_t kiDstStride, uint8_t* pSrc, const int32_t kiSrcStride, const int32_t kiSrcWidth, const int32_t kiSrcHeight);
+void DyadicBilinearOneThirdDownsampler_c (uint8_t* pDst, const int32_t kiDstStride, uint8_t* pSrc, const int32_t kiSrcStride, const int32_t kiSrcWidth, const int32_t kiDstHeight);
+void GeneralBilinearFastDownsampler_c (uint8_t* pDst, const int32_t kiDstStride, const int32_t kiDstWidth, const int32_t kiDstHeight,
+                                       uint8_t* pSrc, const int32_t kiSrcStride, const int32_t kiSrcWidth, const int32_t kiSrcHeight);
+void GeneralBilinearAccurateDownsampler_c (uint8_t* pDst, const int32_t kiDstStride, const int32_t kiDstWidth, const int32_t kiDstHeight,
+                                           uint8_t* pSrc, const int32_t kiSrcStride, const int32_t kiSrcWidth, const int32_t kiSrcHeight);
 }
 
 namespace {
@@ -101,6 +109,17 @@ void ref_deblock_chroma_eq4 (uint8_t* pix, int32_t stride, int horizontal, int a
 void ref_vaa_sad8x8 (const uint8_t* cur, const uint8_t* ref, int32_t stride, int32_t* sad4) {
   int32_t frame_sad = 0;
   WelsVP::VAACalcSad_c (cur, ref, 16, 16, stride, &frame_sad, sad4);
+}
+
+// mode numbering of include/welship.h (WELSHIP_DS_*): 0 half, 1 quarter, 2 one third, 3 general fast, 4 general accurate
+void ref_downsample (int mode, uint8_t* dst, int32_t dst_stride, int32_t dst_w, int32_t dst_h, uint8_t* src, int32_t src_stride, int32_t src_w, int32_t src_h) {
+  switch (mode) {
+  case 0: WelsVP::DyadicBilinearDownsampler_c (dst, dst_stride, src, src_stride, src_w, src_h); break;
+  case 1: WelsVP::DyadicBilinearQuarterDownsampler_c (dst, dst_stride, src, src_stride, src_w, src_h); break;
+  case 2: WelsVP::DyadicBilinearOneThirdDownsampler_c (dst, dst_stride, src, src_stride, src_w, dst_h); break;
+  case 3: WelsVP::GeneralBilinearFastDownsampler_c (dst, dst_stride, dst_w, dst_h, src, src_stride, src_w, src_h); break;
+  default: WelsVP::GeneralBilinearAccurateDownsampler_c (dst, dst_stride, dst_w, dst_h, src, src_stride, src_w, src_h); break;
+  }
 }
 
 }  // extern "C"

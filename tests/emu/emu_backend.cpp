@@ -16,6 +16,7 @@
 #include "../../openh264_amd/csrc/kernels/inter_mb.h"
 #include "../../openh264_amd/csrc/kernels/expand_pic.h"
 #include "../../openh264_amd/csrc/kernels/scene_pic.h"
+#include "../../openh264_amd/csrc/common/compact.h"
 
 namespace wh {
 
@@ -109,6 +110,13 @@ class EmuBackend : public Backend {
     for (int j = 0; j < n; ++j) {
       const int nb = wh_expand_num_blocks (P);
       for (int b = 0; b < nb; ++b) wh_expand_body (P, jobs[j], b);
+    }
+  }
+  void run_compact (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
+    for (int j = 0; j < n; ++j) {
+      uint32_t off = 0;
+      for (int xy = 0; xy < P.mb_w * P.mb_h; ++xy) { jobs[j].compact_off[xy] = off; off += wh_compact_pack (&jobs[j].records[xy], jobs[j].compact + off); }
+      jobs[j].compact_off[P.mb_w * P.mb_h] = off;
     }
   }
   void select_queue (int) override {}

@@ -35,7 +35,7 @@ def test_device_code_avoids_ashr_pk(tmp_path):
     import subprocess
     if not shutil.which("hipcc"):
         pytest.skip("hipcc not available")
-    for unit in ("hip_backend", "prims"):
+    for unit in ("hip_backend", "prims", "downsample"):
         out = tmp_path / (unit + ".s")
         subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-Wno-unused-function",
                                "-Wno-unused-variable", "-Wno-unused-command-line-argument", "-o", str(out),

@@ -46,6 +46,15 @@ def test_simulcast_sessions_on_emulation(emu_lib, tmp_path, flags, pictures):
     _both(emu_lib, tmp_path, synth_sequence(640, 368, 6), 640, 368, flags, pictures)
 
 
+@pytest.mark.parametrize("flags,pictures", SMALL[2:])
+def test_simulcast_sessions_on_the_reverse_lane_emulation(tmp_path, flags, pictures):
+    """The complexity > 0 sessions once more on the test build that walks the lanes of a lane block backwards
+    (tests/test_frame_parity.py::test_emu_reverse_lane_order): the stale-pSadCost path they exercise is where two lanes once
+    stored to one LDS word, which only the MI355X noticed."""
+    from openh264_amd import build as B
+    _both(B.build_emu(defines=("WH_EMU_REVERSE",), tag="wh_emu_reverse"), tmp_path, synth_sequence(640, 368, 6), 640, 368, flags, pictures)
+
+
 def test_config4_four_layers_on_emulation(emu_lib, tmp_path):
     _both(emu_lib, tmp_path, synth_sequence(1920, 1080, 3), 1920, 1080, ["-rc", "-1", "-qp", "24"] + CONFIG4, 12)
 
