@@ -40,7 +40,6 @@ WH_CP_FN uint32_t wh_compact_size (int mb_type, uint32_t mask) {
   return 4u + WH_COMPACT_SIDE + 32u * (uint32_t)__builtin_popcount (mask & 0x1ffffffu) + ((mask >> 25) & 1u) * 16u;
 }
 
-#if !defined(__HIP_DEVICE_COMPILE__)
 // host side: one packed MB -> a full record
 static inline void wh_compact_expand (const uint8_t* p, uint32_t size, WhMbRecord* R) {
   memset (R, 0, sizeof (*R));
@@ -81,4 +80,3 @@ static inline uint32_t wh_compact_pack (const WhMbRecord* R, uint8_t* out) {
   if ((mask >> 25) & 1u) { memcpy (q, c + 400, 16); q += 16; }
   return (uint32_t) (q - out);
 }
-#endif

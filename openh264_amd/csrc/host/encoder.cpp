@@ -20,6 +20,7 @@
 #include "../common/mb_order.h"
 #include "entropy_cavlc.h"
 #include "headers.h"
+#include "../common/compact.h"
 
 namespace wh {
 Backend* create_default_backend (int device, const char** err);   // provided by the HIP lib or the test build
@@ -52,6 +53,12 @@ struct SessionCore {
   int last_slot = 0;                  // source slot of the previous frame (VAA reference)
   bool prev_src_dirty = false;        // that slot received a new upload since the frame was begun
   WhMbRecord* d_records = nullptr;
+  // packed records (common/compact.h): what a session GROUP copies back instead of the full records
+  uint8_t* d_compact = nullptr;
+  uint32_t* d_compact_off = nullptr;
+  std::vector<uint8_t> h_compact;
+  std::vector<uint32_t> h_compact_off;
+  bool use_compact = false;
   uint32_t* d_order = nullptr;
   int32_t* d_bands = nullptr;
   uint32_t* d_dbflags = nullptr;
@@ -267,6 +274,26 @@ struct SessionCore {
     return WELSHIP_OK;
   }
 
+  // Groups copy the records back packed (common/compact.h); pictures larger than the packer's workgroup handles keep the
+  // full records, as does WELSHIP_COMPACT=0.
+  int enable_compact() {
+    if (num_mb > 9216) return WELSHIP_OK;
+    if (const char* e = getenv ("WELSHIP_COMPACT")) if (atoi (e) == 0) return WELSHIP_OK;
+    d_compact = (uint8_t*)be->alloc ((size_t)num_mb * WH_COMPACT_MAX_BYTES);
+    d_compact_off = (uint32_t*)be->alloc (sizeof (uint32_t) * ((size_t)num_mb + 1));
+    if (!d_compact || !d_compact_off) { set_err ("out of device memory"); return WELSHIP_ERR_MEMORY; }
+    h_compact.resize ((size_t)num_mb * WH_COMPACT_MAX_BYTES);
+    h_compact_off.resize ((size_t)num_mb + 1);
+    be->pin_host (h_compact.data(), h_compact.size());
+    be->pin_host (h_compact_off.data(), sizeof (uint32_t) * h_compact_off.size());
+    use_compact = true;
+    return WELSHIP_OK;
+  }
+  // packed stream (already on the host) -> h_records
+  void expand_compact() {
+    for (int xy = 0; xy < num_mb; ++xy) wh_compact_expand (h_compact.data() + h_compact_off[xy], h_compact_off[xy + 1] - h_compact_off[xy], &h_records[xy]);
+  }
+
   void release() {
     if (!be) return;
     for (uint8_t* p : d_src) if (p) be->free (p);
@@ -274,6 +301,10 @@ struct SessionCore {
     for (int i = 0; i < 2; ++i) { if (pic[i].base) be->free (pic[i].base); if (pic[i].mbs) be->free (pic[i].mbs); pic[i] = DevPicture(); }
     if (d_records) be->free (d_records);
     d_records = nullptr;
+    if (d_compact) be->free (d_compact);
+    if (d_compact_off) be->free (d_compact_off);
+    d_compact = nullptr; d_compact_off = nullptr;
+    if (!h_compact.empty()) { be->unpin_host (h_compact.data()); be->unpin_host (h_compact_off.data()); }
     if (!h_records.empty()) be->unpin_host (h_records.data());
     if (!h_src.empty()) be->unpin_host (h_src.data());
     if (d_order) be->free (d_order);
@@ -358,6 +389,8 @@ struct SessionCore {
     job->src[0] = d_src[slot]; job->src[1] = d_src[slot] + ysz; job->src[2] = d_src[slot] + ysz + csz;
     for (int i = 0; i < 3; ++i) { job->rec[i] = c.plane[i]; job->ref[i] = idr ? nullptr : r.plane[i]; }
     job->records = d_records;
+    job->compact = use_compact ? d_compact : nullptr;
+    job->compact_off = use_compact ? d_compact_off : nullptr;
     job->mbs = c.mbs;
     job->ref_mbs = idr ? nullptr : r.mbs;
     job->qp = prm.iDLayerQp;
@@ -829,6 +862,7 @@ int WelsHipGroupCreate (WelsHipEncoderGroup** pp, const WelsHipEncParam* p, int 
   for (int i = 0; i < n_sessions; ++i) {
     g->sess.emplace_back (new SessionCore());
     rc = g->sess.back()->init (be, p, ring_slots);
+    if (!rc) rc = g->sess.back()->enable_compact();
     if (rc) { for (auto& s : g->sess) s->release(); delete be; delete g; return rc; }
   }
   g->d_jobs = (WhPicJob*)be->alloc (sizeof (WhPicJob) * n_sessions);
@@ -910,6 +944,7 @@ int WelsHipGroupRunDevice (WelsHipEncoderGroup* g, int wait) {
     const WhSeqParams& s = c0.seq;
     if (np) g->be->run_inter (s, g->d_jobs + a, np);
     if (ni) g->be->run_intra (s, g->d_jobs + a + np, ni);
+    if (c0.use_compact) g->be->run_compact (s, g->d_jobs + a, b - a);
     if (s.deblock_idc != 1) g->be->run_deblock (s, g->d_jobs + a, b - a);
     if (c0.prm.uiIntraPeriod != 1) g->be->run_expand (s, g->d_jobs + a, b - a);
   }
@@ -920,16 +955,28 @@ int WelsHipGroupRunDevice (WelsHipEncoderGroup* g, int wait) {
 int WelsHipGroupFinish (WelsHipEncoderGroup* g, WelsHipFrameBSInfo* outs) {
   if (!g) return WELSHIP_ERR_INIT_PARA;
   const int n = (int)g->sess.size();
+  const bool packed = g->sess[0]->use_compact;
   for (int i = 0; i < n; ++i) {
     SessionCore& c = *g->sess[i];
     g->be->select_queue (g->chunk_of (i));
-    g->be->download (c.h_records.data(), c.d_records, sizeof (WhMbRecord) * c.num_mb);
+    if (packed) g->be->download (c.h_compact_off.data(), c.d_compact_off, sizeof (uint32_t) * ((size_t)c.num_mb + 1));
+    else g->be->download (c.h_records.data(), c.d_records, sizeof (WhMbRecord) * c.num_mb);
   }
   if (g->be->sync()) { set_err ("device scheduler timed out; the step was not encoded"); return WELSHIP_ERR_UNKNOWN; }
+  if (packed) {        // the sizes are known now: the packed records themselves
+    for (int i = 0; i < n; ++i) {
+      SessionCore& c = *g->sess[i];
+      const size_t bytes = c.h_compact_off[c.num_mb];
+      if (bytes > c.h_compact.size()) { set_err ("corrupt record offsets"); return WELSHIP_ERR_UNKNOWN; }
+      g->be->select_queue (g->chunk_of (i));
+      g->be->download (c.h_compact.data(), c.d_compact, bytes);
+    }
+    if (g->be->sync()) { set_err ("device error while copying the records"); return WELSHIP_ERR_UNKNOWN; }
+  }
   for (auto& c : g->sess) c->upload_pending = false;
   std::vector<int> rcs (n, 0);
   const int T = g->host_threads < n ? g->host_threads : n;
-  auto work = [&] (int t) { for (int i = t; i < n; i += T) rcs[i] = g->sess[i]->finish_frame (outs ? &outs[i] : nullptr, 0); };
+  auto work = [&] (int t) { for (int i = t; i < n; i += T) { if (packed) g->sess[i]->expand_compact(); rcs[i] = g->sess[i]->finish_frame (outs ? &outs[i] : nullptr, 0); } };
   if (T <= 1) work (0);
   else {
     std::vector<std::thread> th;

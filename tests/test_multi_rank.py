@@ -87,6 +87,18 @@ def test_group_equals_single_session(emu_lib):
         assert hashlib.sha1(bs).hexdigest() == digs[s]
 
 
+@pytest.mark.gpu
+def test_hip_group_equals_single_session(hip_lib):
+    """The same on the MI355X: the group path copies the macroblock records back packed (k_compact, common/compact.h), the
+    single session copies them whole -- both must give the stream of the ISVCEncoder-style object."""
+    import openh264_amd as oh
+    inputs = _inputs()
+    digs = __import__("openh264_amd.parallel", fromlist=["x"]).encode_sessions_sharded(_make_group_factory(hip_lib), inputs, FRAMES)
+    for s in range(SESSIONS):
+        bs, _ = oh.encode_sequence(b"".join(inputs[s]), W, H, lib_path=hip_lib, iDLayerQp=26, uiIntraPeriod=0, fMaxFrameRate=30.0, iTargetBitrate=500000)
+        assert hashlib.sha1(bs).hexdigest() == digs[s]
+
+
 def test_group_reencodes_overflowing_sessions(emu_lib):
     """Sessions of a group whose picture hits a CAVLC overflow are re-encoded individually (WelsHipGroupFinish) and
     still match the single-session result; their neighbours in the group are unaffected."""
