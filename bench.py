@@ -60,6 +60,7 @@ def parse():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the e2e, latency, res-clip and intra legs")
     ap.add_argument("--host-threads", type=int, default=min(32, os.cpu_count() or 8))
+    ap.add_argument("--e2e-groups", type=int, default=4, help="independent session groups of the overlapped end-to-end leg (sessions/2 each)")
     ap.add_argument("--deblock-idc", type=int, default=0, help="disable_deblocking_filter_idc (0: filter across slice boundaries, the reference default)")
     a = ap.parse_args()
     if a.quick:
@@ -95,13 +96,18 @@ class Content:
         self.frames, self.fsz, self.ring = frames, fsz, ring
         self.n = len(frames) // fsz
         self.consecutive = consecutive              # real clip: `ring` consecutive frames from a per-session offset
+        self._cache = {}
 
     def frame(self, s, slot):
         if self.consecutive:
             k = (s * 5) % max(1, self.n - self.ring + 1) + slot
+        elif self.n >= 2 * self.ring:
+            k = (s * 3) % (self.n - self.ring + 1) + slot       # synthetic: every session a different, continuous stretch of the motion
         else:
-            k = (slot + s) % self.n                 # synthetic: every session starts at a different phase of the motion
-        return self.frames[k * self.fsz:(k + 1) * self.fsz]
+            k = (slot + s) % self.n
+        if k not in self._cache:
+            self._cache[k] = self.frames[k * self.fsz:(k + 1) * self.fsz]
+        return self._cache[k]
 
 
 def cpu_info():
@@ -246,6 +252,60 @@ def e2e_leg(oh, a, local, w, h, sessions, ring, content, frames, check=False):
     return dt, nbytes, match
 
 
+def e2e_groups_leg(oh, a, local, w, h, groups, per_group, ring, content, frames, check=False):
+    """The same complete EncodeFrame calls from `groups` independent session groups, each driven by its own host thread on its
+    own device queue: while one group's records are copied back and entropy-coded on the host, the other groups' kernels and
+    source uploads keep the device busy.  No call of one group depends on another (sessions are independent)."""
+    import threading
+    gs = [make_group(oh, a, local, w, h, "p", per_group, ring, None) for _ in range(groups)]
+    pics = [[g.make_pictures([content.frame(gi * per_group + s, k) for s in range(per_group)]) for k in range(ring)] for gi, g in enumerate(gs)]
+    order = [0, 1 % ring] + [slot_of(i + 2, ring) for i in range(frames)]
+    bs0 = bytearray()
+    nbytes = [0] * groups
+    errs = []
+    gate = threading.Barrier(groups + 1)
+
+    def worker(gi):
+        try:
+            g = gs[gi]
+            first = [g.encode_frames(pics[gi][order[0]], want_bytes=True)[0], g.encode_frames(pics[gi][order[1]], want_bytes=True)[0]]
+            if gi == 0:
+                bs0.extend(first[0] + first[1])
+            gate.wait()
+            for i in range(frames):
+                out = g.encode_frames(pics[gi][order[i + 2]], want_bytes=(check and gi == 0))
+                if check and gi == 0:
+                    bs0.extend(out[0])
+                    nbytes[gi] += sum(len(b) for b in out)
+                else:
+                    nbytes[gi] += out
+        except Exception as e:          # noqa: BLE001 -- reported by the caller
+            errs.append(repr(e))
+            try:
+                gate.abort()
+            except Exception:
+                pass
+
+    th = [threading.Thread(target=worker, args=(gi,)) for gi in range(groups)]
+    for t in th:
+        t.start()
+    gate.wait()
+    t0 = time.perf_counter()
+    for t in th:
+        t.join()
+    dt = time.perf_counter() - t0
+    for g in gs:
+        g.close()
+    if errs:
+        raise SystemExit("bench.py: e2e groups leg failed: %s" % errs[0])
+    match = None
+    if check:
+        import hashlib
+        ref = ref_encode(b"".join(content.frame(0, k) for k in order), w, h, p_flags(a.qp, a.deblock_idc) + ["-quiet", "-threads", "1"])
+        match = {"match": bytes(bs0) == ref, "sha1": hashlib.sha1(bytes(bs0)).hexdigest(), "reference_sha1": hashlib.sha1(ref).hexdigest(), "frames": len(order)}
+    return dt, sum(nbytes), match
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -292,7 +352,7 @@ def main():
         content = Content(clip, fsz, ring, True)
         data = "res/VID_%dx%d_cavlc_temporal_direct.264 decoded by the reference decoder, %d consecutive frames per session" % (w, h, ring)
     else:
-        content = Content(synth_sequence(w, h, 4 if workload == "intra" else ring), fsz, ring, False)
+        content = Content(synth_sequence(w, h, 4 if workload == "intra" else 2 * ring), fsz, ring, False)
         data = "synthetic"
 
     verify_sessions = () if (a.no_verify or not have_ref or rank != 0) else tuple(sorted({0, a.sessions - 1}))
@@ -312,7 +372,7 @@ def main():
         b_path = BYTES_I_MB_PATH if workload == "intra" else BYTES_P_MB_PATH
         md_launch_ms = ev["md_ms"] / steps                                   # one launch per pass and step
         achieved = b_md * mbs * sessions / (md_launch_ms * 1e-3) / 1e9       # every MB of every picture in the batch x bytes/MB
-        return {"bound": "hbm", "kernel": "k_intra_slice" if workload == "intra" else "k_inter_slice",
+        return {"bound": "hbm", "kernel": "k_intra_slice" if workload == "intra" else "k_inter_pool",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "bytes_per_mb": b_md, "avg_launch_ms": md_launch_ms, "launches_per_step": 1,
                 "path_achieved_GBs": b_path * mbs * sessions * steps / (ev["total_ms"] * 1e-3) / 1e9,
@@ -356,6 +416,14 @@ def main():
         line["e2e"] = {"frames_per_s": a.sessions * n_e2e / de, "sessions": a.sessions, "frames_each": n_e2e, "host_entropy_threads": a.host_threads,
                        "host": cpu_info(), "includes": "source upload (H2D), device passes, D2H of the MB records, host CAVLC + NAL packing",
                        "bitstream_MB_per_s": nbytes / de / 1e6, "bitstream_vs_reference": match}
+        # the same with the sessions split over independent groups, one host thread and one device queue each
+        ng, per = a.e2e_groups, max(1, a.sessions // 2)
+        if ng > 1:
+            n2 = 16
+            dg, nb2, m2 = e2e_groups_leg(oh, a, local, w, h, ng, per, ring, content, n2, bool(verify_sessions))
+            line["e2e_overlapped"] = {"frames_per_s": ng * per * n2 / dg, "groups": ng, "sessions_per_group": per, "frames_each": n2,
+                                      "host_entropy_threads_per_group": a.host_threads, "bitstream_MB_per_s": nb2 / dg / 1e6, "bitstream_vs_reference": m2,
+                                      "how": "independent session groups, one host thread + one device queue each: a group's D2H and CAVLC run under the other groups' kernels"}
         lat = {}
         for ns in (1, 8):
             dl, _, _ = e2e_leg(oh, a, local, w, h, ns, ring, content, 20)
@@ -393,8 +461,9 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    if line.get("e2e", {}).get("bitstream_vs_reference") and not line["e2e"]["bitstream_vs_reference"]["match"]:
-        raise SystemExit("bench.py: the e2e bitstream of session 0 differs from the reference encoder's")
+    for leg in ("e2e", "e2e_overlapped"):
+        if line.get(leg, {}).get("bitstream_vs_reference") and not line[leg]["bitstream_vs_reference"]["match"]:
+            raise SystemExit("bench.py: the %s bitstream of session 0 differs from the reference encoder's" % leg)
     if verified is not None and not all(verified.values()):
         raise SystemExit("bench.py: the timed steps' reconstruction differs from the reference (sessions %s)" % [s for s, ok in verified.items() if not ok])
 

@@ -69,7 +69,9 @@ class CWelsHipEncoder : public ISVCEncoder {
     WelsHipEncParam q;
     g_api.GetDefaultParams (m_p, &q);
     q.iUsageType = p->iUsageType; q.iPicWidth = p->iPicWidth; q.iPicHeight = p->iPicHeight;
-    q.iTargetBitrate = p->iTargetBitrate; q.iRCMode = p->iRCMode; q.fMaxFrameRate = p->fMaxFrameRate;
+    // the stream's level follows the layer's bitrate (au_set.cpp:526 reads sSpatialLayers[].iSpatialBitrate)
+    q.iTargetBitrate = p->sSpatialLayers[0].iSpatialBitrate > 0 ? p->sSpatialLayers[0].iSpatialBitrate : p->iTargetBitrate;
+    q.iRCMode = p->iRCMode; q.fMaxFrameRate = p->fMaxFrameRate;
     q.iTemporalLayerNum = p->iTemporalLayerNum; q.iSpatialLayerNum = p->iSpatialLayerNum;
     q.iComplexityMode = p->iComplexityMode; q.uiIntraPeriod = p->uiIntraPeriod;
     q.eSpsPpsIdStrategy = p->eSpsPpsIdStrategy; q.iEntropyCodingModeFlag = p->iEntropyCodingModeFlag;
@@ -121,6 +123,8 @@ class CWelsHipEncoder : public ISVCEncoder {
     o->iFrameSizeInBytes = b.iFrameSizeInBytes; o->uiTimeStamp = b.uiTimeStamp;
     for (int i = 0; i < b.iLayerNum; ++i) {         // same ownership rule: the buffers stay valid until the next EncodeFrame
       o->sLayerInfo[i].uiLayerType = b.sLayerInfo[i].uiLayerType; o->sLayerInfo[i].eFrameType = (EVideoFrameType)b.sLayerInfo[i].eFrameType;
+      o->sLayerInfo[i].uiTemporalId = b.sLayerInfo[i].uiTemporalId; o->sLayerInfo[i].uiSpatialId = b.sLayerInfo[i].uiSpatialId;
+      o->sLayerInfo[i].uiQualityId = b.sLayerInfo[i].uiQualityId; o->sLayerInfo[i].iSubSeqId = b.sLayerInfo[i].iSubSeqId;
       o->sLayerInfo[i].iNalCount = b.sLayerInfo[i].iNalCount; o->sLayerInfo[i].pNalLengthInByte = b.sLayerInfo[i].pNalLengthInByte;
       o->sLayerInfo[i].pBsBuf = b.sLayerInfo[i].pBsBuf;
     }

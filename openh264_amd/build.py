@@ -31,7 +31,7 @@ def build_hip(force=False, verbose=True, defines=(), tag=""):
     deps = [CSRC, os.path.join(ROOT, "include")]
     if not force and not _newer(out, deps):
         return out
-    # NB: no v_ashr_pk_u8_i32 may appear in the device code (see wh_clip255 in csrc/kernels/wave.h): checked below.
+    # NB: no v_ashr_pk_u8_i32 may appear in the device code (see wh_clip255 in csrc/kernels/wave.h): tests/test_abi.py checks the listing.
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17"] + ["-D" + d for d in defines] + ["-fPIC", "-shared", "-Wno-unused-function",
            "-Wno-unused-variable", "-o", out] + HIP_SRCS + HOST_SRCS
     if verbose:

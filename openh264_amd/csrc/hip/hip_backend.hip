@@ -141,6 +141,7 @@ __global__ __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPi
   }
   __syncthreads();
   WH_PROF_DECL (P);
+  const unsigned long long wall0 = P.prof ? wall_clock64() : 0ULL;     // 100 MHz; wave lifetimes against the launch's span (WelsHipGroupProfile)
   WhInterCtx X;
   WhWinPf pf;
   pf.valid = 0;
@@ -209,6 +210,12 @@ __global__ __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPi
     if (slots > 3 && slot_id[3] >= 0 && c3) atomicAdd (&slice_cost[slot_id[3]], c3);
   }
   if (P.prof && lane < 32) atomicAdd (&P.prof[((blockIdx.x * 7u) & 63u) * 32u + lane], (unsigned long long)S.m.prof[lane]);
+  if (P.prof && lane == 0) {
+    const unsigned long long wall1 = wall_clock64();
+    atomicMax (&P.prof[4096], ~wall0); atomicMax (&P.prof[4097], wall1);
+    atomicAdd (&P.prof[4098], wall1 - wall0); atomicAdd (&P.prof[4099], 1ULL);
+    atomicMax (&P.prof[4104 + (blockIdx.x & 255u)], wall1);             // when each workgroup's last wave left
+  }
 }
 
 // Deal the slices of a batch out to the mode-decision workgroups: sorted by the cost they had in the previous picture
@@ -619,6 +626,7 @@ class HipBackend : public wh::Backend {
   }
   // 0, the number of in-kernel dependency waits that timed out, or -1 after a HIP error (sticky: the backend is unusable)
   int sync() override {
+    HIP_TRY (hipSetDevice (dev_));          // callers may be host threads that never selected a device
     for (hipStream_t st : streams_) if (st) HIP_TRY (hipStreamSynchronize (st));
     if (!usable()) return -1;
     uint32_t e[4] = {0, 0, 0, 0};

@@ -372,14 +372,20 @@ struct SessionCore {
     const int thr_large = static_cast<int32_t> (0.85f * n8 + 0.5f + 1e-6);
     scene_idr = (int)motion_blocks >= thr_large;
   }
-  int begin_frame (int slot, WhPicJob* job) {
-    bool idr = idr_without_scene_change() || scene_idr;
-    scene_idr = false;
+  // what begin_frame would refuse, without changing anything (a group checks all its sessions before it begins any)
+  int begin_frame_check() {
+    const bool idr = idr_without_scene_change() || scene_idr;
     // LOW complexity P pictures read the previous SOURCE picture (VAA 8x8 SADs): it must still be resident
     if (!idr && seq.complexity == 0 && prev_src_dirty) {
       set_err ("the previous source picture was overwritten: use at least two source slots and alternate them");
       return WELSHIP_ERR_INIT_PARA;
     }
+    return WELSHIP_OK;
+  }
+  int begin_frame (int slot, WhPicJob* job) {
+    if (const int rc = begin_frame_check()) return rc;
+    bool idr = idr_without_scene_change() || scene_idr;
+    scene_idr = false;
     prev_src_dirty = false;
     if (idr) { frame_index = 0; frame_num = 0; force_idr = false; }
     cur_idr = idr;
@@ -533,7 +539,11 @@ struct SessionCore {
           set_err ("CAVLC overflow");
           return WELSHIP_ERR_VLC_OVERFLOW;
         }
-        if (rc) { set_err ("bad macroblock record"); return WELSHIP_ERR_UNKNOWN; }
+        if (rc) {
+          sps_counter = saved_ids[0]; pps_counter = saved_ids[1]; sps_id_in_bs = saved_ids[2]; pps_id_in_bs = saved_ids[3]; idr_pic_id = saved_ids[4];
+          set_err ("bad macroblock record");
+          return WELSHIP_ERR_UNKNOWN;
+        }
       }
       wh::write_slice_end (bw, st);
       if (!nal_fits (rbsp)) return fail_frame();
@@ -915,6 +925,7 @@ int WelsHipGroupBegin (WelsHipEncoderGroup* g, int slot) {
     }
   }
   std::vector<WhPicJob> jobs (n);
+  for (int i = 0; i < n; ++i) { const int rc = g->sess[i]->begin_frame_check(); if (rc) return rc; }   // nothing begun yet: the group stays in step
   for (int i = 0; i < n; ++i) { const int rc = g->sess[i]->begin_frame (slot % g->sess[i]->ring, &jobs[i]); if (rc) return rc; }
   g->step_idr = g->sess[0]->cur_idr;
   g->mixed = false;
@@ -1068,10 +1079,11 @@ int WelsHipGroupBench (WelsHipEncoderGroup* g, int steps, int warmup, double* ou
   for (auto& e : ev) e = be->event_create();
   const WhSeqParams& s = g->sess[0]->seq;
   const bool need_ref = g->sess[0]->prm.uiIntraPeriod != 1;
+  auto drop_events = [&] { for (auto& e : ev) be->event_destroy (e); };
   for (int i = 0; i < steps; ++i) {
     int rc = WelsHipGroupBegin (g, slot_of (fi++));
-    if (rc) return rc;
-    if (g->mixed) { set_err ("the benchmark entry point needs every session on the same frame type"); return WELSHIP_ERR_UNKNOWN; }
+    if (rc) { be->sync(); drop_events(); return rc; }
+    if (g->mixed) { be->sync(); drop_events(); set_err ("the benchmark entry point needs every session on the same frame type"); return WELSHIP_ERR_UNKNOWN; }
     for (int q = g->queues - 1; q >= 0; --q) {      // queue 0 last: it carries the events
       const int a = g->chunk_first (q), cnt = g->chunk_first (q + 1) - a;
       be->select_queue (q);
@@ -1095,7 +1107,7 @@ int WelsHipGroupBench (WelsHipEncoderGroup* g, int steps, int warmup, double* ou
     out_ms[2] += be->event_elapsed_ms (ev[i * 4 + 1], ev[i * 4 + 2]);
     out_ms[3] += be->event_elapsed_ms (ev[i * 4 + 2], ev[i * 4 + 3]);
   }
-  for (auto& e : ev) be->event_destroy (e);
+  drop_events();
   if (timed_out) { set_err ("device scheduler timed out during the benchmark; the timings are invalid"); return WELSHIP_ERR_UNKNOWN; }
   return WELSHIP_OK;
 }
@@ -1106,13 +1118,24 @@ int WelsHipGroupProfile (WelsHipEncoderGroup* g, int enable, unsigned long long*
   if (!g) return WELSHIP_ERR_INIT_PARA;
   wh::Backend* be = g->be;
   unsigned long long*& prof = g->sess[0]->seq.prof;
-  const size_t bytes = 2 * 64 * 32 * 8;  // two kernels (mode decision, deblocking) x 64 banks (WH_PROF_MARK)
+  const size_t bytes = 2 * 64 * 32 * 8 + 64 + 256 * 8;  // two kernels (mode decision, deblocking) x 64 banks (WH_PROF_MARK) + the wave-lifetime words of k_inter_pool
   if (enable && !prof) { prof = (unsigned long long*)be->alloc (bytes); be->fill (prof, 0, bytes); be->sync(); }
   if (out64 && prof) {
-    std::vector<unsigned long long> h (2 * 64 * 32);
+    std::vector<unsigned long long> h (2 * 64 * 32 + 8 + 256);
     be->download (h.data(), prof, bytes); be->sync(); be->fill (prof, 0, bytes); be->sync();
     for (int k = 0; k < 2; ++k)
       for (int i = 0; i < 32; ++i) { out64[k * 32 + i] = 0; for (int b = 0; b < 64; ++b) out64[k * 32 + i] += h[(size_t)k * 2048 + (size_t)b * 32 + i]; }
+    // mode-decision launches since the last read, in 100 MHz ticks (spare slots of the deblocking half): [44] first wave's start to
+    // the last wave's end, [45] sum of the wave lifetimes, [46] waves
+    out64[44] = h[4097] ? h[4097] - ~h[4096] : 0; out64[45] = h[4098]; out64[46] = h[4099];
+    if (getenv ("WELSHIP_PROF_GROUPS") && h[4097]) {     // when the workgroups of the (last) mode-decision launch ended, in % of the span
+      std::vector<double> e;
+      for (int i = 0; i < 256; ++i) if (h[4104 + i]) e.push_back (100.0 * (double) (h[4104 + i] - ~h[4096]) / (double)out64[44]);
+      std::sort (e.begin(), e.end());
+      fprintf (stderr, "welship: MD workgroup end times (%% of span), %zu groups:", e.size());
+      for (size_t i = 0; i < e.size(); i += std::max<size_t> (1, e.size() / 16)) fprintf (stderr, " %.0f", e[i]);
+      fprintf (stderr, " %.0f\n", e.empty() ? 0.0 : e.back());
+    }
   }
   if (!enable && prof) { be->free (prof); prof = nullptr; }
   return WELSHIP_OK;

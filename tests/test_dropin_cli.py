@@ -1,6 +1,6 @@
 """The drop-in boundary at application level: the reference's own console front-end (codec/console/enc/src/welsenc.cpp,
 compiled unmodified by oracle/Makefile) linked against this engine through the ISVCEncoder adapter
-(oracle/dropin/welship_isvc.cpp) must write the same bitstream as the same front-end on the reference encoder.
+(integration/welship_isvc.cpp) must write the same bitstream as the same front-end on the reference encoder.
 The configuration files are written here (key names per welsenc.cpp ParseConfig / ParseLayerConfig)."""
 import os
 import subprocess

@@ -77,6 +77,44 @@ def test_two_ranks_match_single_process(emu_lib):
     assert got == single
 
 
+def _groups_in_threads(lib):
+    """Two session groups driven by two host threads at the same time (bench.py's overlapped end-to-end leg): each group has
+    its own backend / device queue, nothing is shared -- the streams must be those of the groups run one after the other."""
+    import threading
+    from openh264_amd.parallel import encode_sessions_sharded
+    inputs = _inputs()
+    want = encode_sessions_sharded(_make_group_factory(lib), inputs, FRAMES)
+    make = _make_group_factory(lib)
+    parts = [inputs[:2], inputs[2:]]
+    got = [None, None]
+
+    def run(k):
+        g = make(len(parts[k]))
+        pics = [g.make_pictures([parts[k][s][f] for s in range(len(parts[k]))]) for f in range(FRAMES)]
+        streams = [bytearray() for _ in parts[k]]
+        for f in range(FRAMES):
+            for s, bs in enumerate(g.encode_frames(pics[f], want_bytes=True)):
+                streams[s] += bs
+        got[k] = [hashlib.sha1(bytes(b)).hexdigest() for b in streams]
+        g.close()
+
+    th = [threading.Thread(target=run, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert got[0] + got[1] == want
+
+
+def test_groups_in_threads(emu_lib):
+    _groups_in_threads(emu_lib)
+
+
+@pytest.mark.gpu
+def test_hip_groups_in_threads(hip_lib):
+    _groups_in_threads(hip_lib)
+
+
 def test_group_equals_single_session(emu_lib):
     """A session inside a group produces the same bitstream as the ISVCEncoder-style object."""
     import openh264_amd as oh

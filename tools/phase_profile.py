@@ -16,15 +16,20 @@ if len(sys.argv) > 2 and sys.argv[2] == "res":
     c = bench.Content(clip, fsz, R, True)
 else:
     import bench
-    c = bench.Content(synth_sequence(w, h, R), fsz, R, False)
+    c = bench.Content(synth_sequence(w, h, 2 * R), fsz, R, False)
 for s in range(S):
     for k in range(R): g.upload(s, k, c.frame(s, k))
 g.bench(1, 0)
 lib = g._lib
 lib.WelsHipGroupProfile.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_ulonglong)]
 lib.WelsHipGroupProfile(g._h, 1, None)
-print(g.bench(3, 0))
 out = (C.c_ulonglong * 64)()
+one = g.bench(1, 0)
+lib.WelsHipGroupProfile(g._h, 1, out)           # one step: the wave lifetimes of a single mode-decision launch
+if out[46]:
+    print("one step %s: MD waves alive %.1f%% of the launch's span (first start to last end %.3f ms, %d waves, mean lifetime %.3f ms)"
+          % (one, 100.0 * out[45] / (out[46] * max(out[44], 1)), out[44] / 1e5, out[46], out[45] / out[46] / 1e5))
+print(g.bench(3, 0))
 lib.WelsHipGroupProfile(g._h, 1, out)
 names = {11: "ticket+order", 12: "dependency wait", 8: "args+job+slice", 9: "batch-1 loads", 10: "nb cache+ctx", 0: "mvp+window loads", 1: "pskip test", 2: "p16x16 ME", 3: "i16 test",
          4: "fine partitions", 5: "refine+chromaMC", 6: "residual", 7: "store", 13: "release+flag", 14: "(body total)", 15: "window adopted"}
