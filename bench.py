@@ -60,7 +60,8 @@ def parse():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the e2e, latency, res-clip and intra legs")
     ap.add_argument("--host-threads", type=int, default=min(32, os.cpu_count() or 8))
-    ap.add_argument("--e2e-groups", type=int, default=4, help="independent session groups of the overlapped end-to-end leg (sessions/2 each)")
+    ap.add_argument("--e2e-groups", type=int, default=3, help="independent session groups of the overlapped end-to-end leg (sessions/2 each)")
+    ap.add_argument("--e2e-group-sessions", type=int, default=0, help="sessions per group of that leg (default: sessions / 2)")
     ap.add_argument("--deblock-idc", type=int, default=0, help="disable_deblocking_filter_idc (0: filter across slice boundaries, the reference default)")
     a = ap.parse_args()
     if a.quick:
@@ -417,9 +418,9 @@ def main():
                        "host": cpu_info(), "includes": "source upload (H2D), device passes, D2H of the MB records, host CAVLC + NAL packing",
                        "bitstream_MB_per_s": nbytes / de / 1e6, "bitstream_vs_reference": match}
         # the same with the sessions split over independent groups, one host thread and one device queue each
-        ng, per = a.e2e_groups, max(1, a.sessions // 2)
+        ng, per = a.e2e_groups, (a.e2e_group_sessions if a.e2e_group_sessions > 0 else max(1, a.sessions // 2))
         if ng > 1:
-            n2 = 16
+            n2 = 30
             dg, nb2, m2 = e2e_groups_leg(oh, a, local, w, h, ng, per, ring, content, n2, bool(verify_sessions))
             line["e2e_overlapped"] = {"frames_per_s": ng * per * n2 / dg, "groups": ng, "sessions_per_group": per, "frames_each": n2,
                                       "host_entropy_threads_per_group": a.host_threads, "bitstream_MB_per_s": nb2 / dg / 1e6, "bitstream_vs_reference": m2,

@@ -30,6 +30,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <map>
+#include <mutex>
 #include <vector>
 
 #include "encoder_context.h"
@@ -61,6 +62,8 @@ struct HipApi {
 };
 HipApi g_api = { NULL, NULL, NULL, NULL, NULL, NULL, false };
 bool LoadApi() {
+  static std::mutex mu;                  // several encoders of one process may be initialised at once
+  std::lock_guard<std::mutex> lock (mu);
   if (g_api.ok) return true;
   const char* path = getenv ("WELSHIP_LIB");
   void* h = dlopen (path && *path ? path : "libwelship.so", RTLD_NOW | RTLD_LOCAL);

@@ -15,7 +15,7 @@
 #include <string>
 #include <vector>
 #include "codec_api.h"
-#include "../../include/welship.h"
+#include "../include/welship.h"
 
 namespace {
 

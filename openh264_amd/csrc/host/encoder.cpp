@@ -1156,6 +1156,7 @@ struct WelsHipFrameCtx {
   std::vector<uint8_t> h_src;
   WhMbRecord* d_records = nullptr;
   std::vector<WhMbRecord> h_records;
+  std::vector<uint8_t> h_pic;
   uint32_t* d_order = nullptr;
   int32_t* d_bands = nullptr;
   uint32_t* d_dbflags = nullptr;
@@ -1179,6 +1180,8 @@ struct WelsHipFrameCtx {
     void* ptrs[] = {d_src, d_records, d_order, d_bands, d_dbflags, d_mb_ctl, d_sad_cost0, d_vaa, d_bgd, d_il, d_job};
     for (void* p : ptrs) if (p) be->free (p);
     if (!h_records.empty()) be->unpin_host (h_records.data());
+    if (!h_src.empty()) be->unpin_host (h_src.data());
+    if (!h_pic.empty()) be->unpin_host (h_pic.data());
     delete be;
     be = nullptr;
   }
@@ -1271,6 +1274,9 @@ int WelsHipFrameCtxCreate (WelsHipFrameCtx** pp, const WelsHipFrameCfg* cfg) {
   c->h_records.resize (c->num_mb);
   c->h_mb_ctl.resize (c->num_mb);
   be->pin_host (c->h_records.data(), sizeof (WhMbRecord) * c->num_mb);
+  be->pin_host (c->h_src.data(), c->h_src.size());
+  c->h_pic.resize (c->rec_alloc_bytes + 128);                 // D2H target of FrameGetPicture
+  be->pin_host (c->h_pic.data(), c->h_pic.size());
   if (be->sync()) { set_err ("device error while setting up the frame context"); c->release(); delete c; return WELSHIP_ERR_UNKNOWN; }
   *pp = c;
   return WELSHIP_OK;
@@ -1373,7 +1379,7 @@ int WelsHipFrameGetMbStates (WelsHipFrameCtx* c, int pic, void* dst, size_t byte
 int WelsHipFrameGetPicture (WelsHipFrameCtx* c, int pic, uint8_t* const dst[3], const int32_t stride[3]) {
   if (!c || !c->be || pic < 0 || pic >= (int)c->pics.size() || !dst || !stride) return WELSHIP_ERR_INIT_PARA;
   const WhSeqParams& s = c->seq;
-  std::vector<uint8_t> tmp (c->rec_alloc_bytes + 128);
+  std::vector<uint8_t>& tmp = c->h_pic;
   const DevPicture& p = c->pics[pic];
   c->be->download (tmp.data(), p.base, c->rec_alloc_bytes + 128);
   if (c->be->sync()) return WELSHIP_ERR_UNKNOWN;

@@ -23,11 +23,13 @@
 #include <string>
 #include <vector>
 #include <chrono>
+#include <thread>
 #include "codec_api.h"
 
 static bool arg_eq (const char* a, const char* b) { return std::strcmp (a, b) == 0; }
 
-int main (int argc, char** argv) {
+// one encoder instance; `instance` >= 0: one of several running in this process at once (-parallel N), output file out.<instance>
+static int run (int argc, char** argv, int instance) {
   std::string in, out;
   int w = 0, h = 0, frames = -1, quiet = 0, use_base = 0;
   float fps = 30.0f;
@@ -85,6 +87,7 @@ int main (int argc, char** argv) {
     else { std::fprintf (stderr, "unknown option %s\n", a); return 2; }
   }
   if (in.empty() || w <= 0 || h <= 0) { std::fprintf (stderr, "need -i -w -h\n"); return 2; }
+  if (instance >= 0 && !out.empty()) out += "." + std::to_string (instance);
 
   ISVCEncoder* enc = NULL;
   if (WelsCreateSVCEncoder (&enc) || !enc) { std::fprintf (stderr, "WelsCreateSVCEncoder failed\n"); return 1; }
@@ -199,3 +202,26 @@ int main (int argc, char** argv) {
   std::printf ("frames=%d bytes=%lld enc_seconds=%.6f fps=%.3f\n", n, total, secs, secs > 0 ? n / secs : 0.0);
   return 0;
 }
+
+// -parallel N (first argument pair): N encoder instances on N threads of this one process, all with the remaining options --
+// what a media server hosting several sessions does.  Prints every instance's line and the aggregate.
+int main (int argc, char** argv) {
+  if (argc > 2 && arg_eq (argv[1], "-parallel")) {
+    const int n = std::atoi (argv[2]);
+    std::vector<char*> args;
+    args.push_back (argv[0]);
+    for (int i = 3; i < argc; ++i) args.push_back (argv[i]);
+    std::vector<int> rcs ((size_t)n, 0);
+    std::vector<std::thread> th;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int k = 0; k < n; ++k) th.emplace_back ([&, k] { rcs[(size_t)k] = run ((int)args.size(), args.data(), k); });
+    for (auto& t : th) t.join();
+    const double wall = std::chrono::duration<double> (std::chrono::steady_clock::now() - t0).count();
+    int bad = 0;
+    for (int r : rcs) bad += r != 0;
+    std::printf ("parallel=%d wall_seconds=%.6f failed=%d\n", n, wall, bad);
+    return bad ? 1 : 0;
+  }
+  return run (argc, argv, -1);
+}
+

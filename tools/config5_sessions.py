@@ -1,0 +1,45 @@
+"""BASELINE config 5's per-GPU share: N concurrent 720p30 sessions with rate control on and raster slices (N-MB slices), each one
+an ISVCEncoder instance of the reference with this engine installed behind SWelsFuncPtrList (oracle/_ref/ref_enc_hip -parallel N:
+N instances on N threads of one process, integration/welship_hooks.cpp) -- against the same instances on the reference's C path
+(WELS_HIP=0).  One process per GPU hosting its sessions is the deployment: kernels of different sessions then share the device
+(different processes would be time-sliced).  Prints one JSON line.
+
+usage: config5_sessions.py [sessions=8] [frames=60]   (needs oracle/_ref incl. res/; the GPU leg needs an MI355X)"""
+import hashlib, json, os, re, subprocess, sys, tempfile, time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.path.join(ROOT, "oracle", "_ref")
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+FRAMES = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+LIB = os.environ.get("WELSHIP_LIB") or os.path.join(ROOT, "openh264_amd", "libwelship.so")
+W, H = 1280, 720
+
+
+def run(tmp, yuv, hip):
+    env = dict(os.environ, WELSHIP_LIB=LIB, WELS_HIP="1" if hip else "0", WELS_HIP_TRACE="1")
+    out = os.path.join(tmp, "s_%d.264" % hip)
+    cmd = [os.path.join(REF, "ref_enc_hip"), "-parallel", str(N), "-i", yuv, "-w", str(W), "-h", str(H), "-o", out, "-frames", str(FRAMES),
+           "-fps", "30", "-rc", "1", "-bitrate", "1500000", "-slcmd", "2", "-slcmbnum", "900", "-threads", "1", "-iper", "0", "-quiet"]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr[-2000:]
+    enc_fps = [float(x) for x in re.findall(rb" fps=([0-9.]+)", p.stdout)]
+    wall = float(re.search(rb"wall_seconds=([0-9.]+)", p.stdout).group(1))
+    pictures = p.stderr.count(b"welship hooks: did")
+    sha = [hashlib.sha1(open("%s.%d" % (out, i), "rb").read()).hexdigest() for i in range(N)]
+    return {"wall_s_incl_init": wall, "sum_of_session_encode_fps": sum(enc_fps), "min_session_fps": min(enc_fps), "max_session_fps": max(enc_fps),
+            "device_pictures": pictures}, sha
+
+
+def main():
+    with tempfile.TemporaryDirectory() as tmp:
+        yuv = os.path.join(tmp, "clip.yuv")
+        subprocess.check_call([os.path.join(REF, "ref_dec"), os.path.join(REF, "res", "VID_1280x720_cavlc_temporal_direct.264"), yuv], stdout=subprocess.DEVNULL)
+        nfr = os.path.getsize(yuv) // (W * H * 3 // 2)
+        c_leg, c_sha = run(tmp, yuv, False)
+        h_leg, h_sha = run(tmp, yuv, True)
+        print(json.dumps({"config": "%d concurrent sessions, %dx%d, %d frames each (clip has %d), RC bitrate mode 1.5 Mbps, raster slices of 900 MBs, one process, one thread per session" % (N, W, H, FRAMES, nfr),
+                          "reference_c_path": c_leg, "hooks_on_device": h_leg, "same_bitstreams": c_sha == h_sha, "lib": os.path.basename(LIB)}))
+
+
+if __name__ == "__main__":
+    main()
