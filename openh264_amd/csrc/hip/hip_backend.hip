@@ -114,6 +114,9 @@ WH_DEFINE_MB_KERNEL (k_intra_slice, WhMbLds, wh_intra_mb_body, 1024, 0, 0)
 // them out in snake order, heavy with light.  Inside a slice nothing changes: tickets in dependency order (LDS counter),
 // done bits in LDS, data through the workgroup-coherent L1/L2.
 #define WH_MD_MAX_SLOTS 4
+#ifndef WH_SPEC_WINDOWS
+#define WH_SPEC_WINDOWS 1          /* fetch a macroblock's search windows with its cold inputs, around the slice's last vector */
+#endif
 template <int MAXT>
 __global__ __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPicJob* jobs, uint32_t* err, const uint16_t* groups, int slots,
                                                        int sched_words, int total_slices, uint32_t* slice_cost) {
@@ -127,6 +130,7 @@ __global__ __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPi
   uint32_t* sched = (uint32_t*) (smem + (size_t)nw * sizeof (WhInterLds));     // per slot: [0] ticket counter, [1..] done bits
   __shared__ WhPicJob Jl[WH_MD_MAX_SLOTS];
   __shared__ int slot_first[WH_MD_MAX_SLOTS], slot_n[WH_MD_MAX_SLOTS], slot_idc[WH_MD_MAX_SLOTS], slot_id[WH_MD_MAX_SLOTS];
+  __shared__ int slot_mv[WH_MD_MAX_SLOTS];         // most recent final 16x16 vector of each slot's slice: the window guess (wh_win_speculate)
   for (int i = (int)threadIdx.x; i < slots * sched_words; i += (int)blockDim.x) sched[i] = 0;
   if (P.prof && lane < 32) S.m.prof[lane] = 0;
   for (int sl = 0; sl < slots; ++sl) {
@@ -135,7 +139,7 @@ __global__ __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPi
     const int pic = on ? k / P.num_slices : 0, idc = on ? k % P.num_slices : 0;
     if (threadIdx.x == 0) {
       slot_first[sl] = P.slice_first_mb[idc]; slot_n[sl] = on ? P.slice_first_mb[idc + 1] - P.slice_first_mb[idc] : 0;
-      slot_idc[sl] = idc; slot_id[sl] = on ? k : -1;
+      slot_idc[sl] = idc; slot_id[sl] = on ? k : -1; slot_mv[sl] = 0;
     }
     wh_copy_job (&Jl[sl], &jobs[pic]);
   }
@@ -143,12 +147,10 @@ __global__ __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPi
   WH_PROF_DECL (P);
   const unsigned long long wall0 = P.prof ? wall_clock64() : 0ULL;     // 100 MHz; wave lifetimes against the launch's span (WelsHipGroupProfile)
   WhInterCtx X;
-  WhWinPf pf;
-  pf.valid = 0;
-  X.pf = &pf;
-  X.win_stage = nullptr;
   X.win = &winbuf[wave];
-  X.next_valid = 0; X.next_mbx = 0; X.next_mby = 0;
+  X.spec_valid = 0;
+  X.spec.b = X.win;
+  X.last_mv = nullptr;
   uint32_t gone = 0;                      // slots this wave knows to be out of tickets (wave-uniform)
   uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;     // cycles / 64 this wave spent on each slot's macroblocks
   int slot = -1, t = 0, xy = 0;
@@ -176,8 +178,15 @@ __global__ __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPi
     slot = best; t = tt; xy = xy_;                                                                                             \
     break;                                                                                                                     \
   }
+  const bool speculate = WH_SPEC_WINDOWS != 0;
+#define WH_FETCH_AHEAD()                                                                                                       \
+  if (slot >= 0) {                                                                                                             \
+    wh_inter_cold_fetch (G, lane, P, Jl[slot], xy % P.mb_w, xy / P.mb_w);   /* in flight while the wave waits for the neighbours */ \
+    X.spec_valid = 0;                                                                                                          \
+    if (speculate) { wh_win_speculate (P, Jl[slot], X.spec, xy % P.mb_w, xy / P.mb_w, slot_mv[slot]); X.spec_valid = 1; }      \
+  }
   WH_CLAIM()
-  if (slot >= 0) wh_inter_cold_fetch (G, lane, P, Jl[slot], xy % P.mb_w, xy / P.mb_w);
+  WH_FETCH_AHEAD()
   while (slot >= 0) {
     const WhPicJob& J = Jl[slot];
     const int first = slot_first[slot];
@@ -191,7 +200,7 @@ __global__ __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPi
     WH_PROF_MARK (P, S.m, 12);
     const uint32_t tc0 = (uint32_t)__builtin_readcyclecounter();
     WV_ASYNC_WAIT();                      /* this MB's cold inputs have landed in the staging area */
-    X.slice_idc = slot_idc[slot]; X.slice_first = first;
+    X.slice_idc = slot_idc[slot]; X.slice_first = first; X.last_mv = &slot_mv[slot];
     wh_inter_mb_body (S, G, P, J, xy % P.mb_w, xy / P.mb_w, X);
     WH_PROF_MARK (P, S.m, 14);
     __builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");
@@ -200,9 +209,10 @@ __global__ __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPi
     const uint32_t dc = ((uint32_t)__builtin_readcyclecounter() - tc0) >> 6;
     c0 += slot == 0 ? dc : 0u; c1 += slot == 1 ? dc : 0u; c2 += slot == 2 ? dc : 0u; c3 += slot == 3 ? dc : 0u;
     WH_CLAIM()
-    if (slot >= 0) wh_inter_cold_fetch (G, lane, P, Jl[slot], xy % P.mb_w, xy / P.mb_w);     /* in flight while the wave waits for the neighbours */
+    WH_FETCH_AHEAD()
   }
 #undef WH_CLAIM
+#undef WH_FETCH_AHEAD
   if (slice_cost && lane == 0) {
     if (slot_id[0] >= 0 && c0) atomicAdd (&slice_cost[slot_id[0]], c0);
     if (slots > 1 && slot_id[1] >= 0 && c1) atomicAdd (&slice_cost[slot_id[1]], c1);

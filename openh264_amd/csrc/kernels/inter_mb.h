@@ -51,7 +51,6 @@ typedef struct alignas (16) WhWinLds {
 
 typedef struct alignas (16) WhInterLds {
   WhMbLds m;
-  uint8_t prev_y[256];                                      // co-located luma of the previous source picture (VAA SADs)
   uint8_t skip_y[256];                                      // P_Skip prediction
   uint8_t skip_c[128];
   uint32_t nb[5 * 36];                                      // WhMbState copies: top-left, top, top-right, left, co-located (reference picture)
@@ -66,13 +65,6 @@ typedef struct alignas (16) WhInterLds {
 typedef struct alignas (16) WhInterStage {
   uint32_t cold_y[64], cold_c[32], cold_pv[64], cold_co[40];            // cold inputs (wh_inter_cold_fetch)
 } WhInterStage;
-// optional second staging area: the next MB's search windows (costs 6 KB of LDS per wave; used when the workgroup
-// geometry leaves room for it)
-typedef struct alignas (16) WhWinStage {
-  alignas (16) uint8_t pf_win[WH_WIN_ROWS * WH_WIN_STRIDE + 16];         // search windows (wh_win_prefetch)
-  alignas (16) uint8_t pf_cwin[2][WH_CWIN_ROWS * WH_CWIN_STRIDE + 16];
-} WhWinStage;
-
 typedef struct WhWin { int x0, y0, cx0, cy0; WhWinLds* b; } WhWin;     // picture coordinates of element (0,0) of win / cwin + where they live
 
 // ---- mvd cost: lambda * bits(se(mvd))  (md.cpp:797-824, svc_enc_golomb.h BsSizeSE) --------------
@@ -200,33 +192,14 @@ WH_FN void wh_win_ensure (WhInterLds& S, const WhSeqParams& P, const WhPicJob& J
   wh_win_load_luma (S, P, J, W);
 }
 
-// Speculative fetch of the NEXT macroblock's windows (LDS-DMA into the staging buffers) around the position the 16x16
-// block would have with this MB's integer predictor; adopted by the next MB when it covers what that MB needs first.
-typedef struct WhWinPf { int valid; WhWin w; } WhWinPf;
-WH_FN void wh_win_prefetch (WhWinStage& G, const WhSeqParams& P, const WhPicJob& J, WhWinPf& F, int cx, int cy) {
-  F.valid = 1;
-  wh_win_place (P, F.w, cx, cy);
-  WV_LANES_BEGIN (lane)
-  {
-#pragma unroll
-    for (int k = 0; k < WH_WIN_LOADS; ++k) if (wh_win_row_ok (lane, k)) wh_ld_async16 (wh_win_src_luma (lane, k, P, J, F.w), &G.pf_win[(16 * k) * WH_WIN_STRIDE], lane);
-#pragma unroll
-    for (int pl = 0; pl < 2; ++pl) wh_ld_async16 (wh_win_src_chroma (lane, pl, P, J, F.w), G.pf_cwin[pl], lane);
-  }
-  WV_LANES_END
-}
-// move the staged windows into place (LDS to LDS)
-WH_FN void wh_win_adopt (WhInterLds& S, const WhWinStage& G, WhWin& W, const WhWinPf& F) {
-  (void)S;
-  W.x0 = F.w.x0; W.y0 = F.w.y0; W.cx0 = F.w.cx0; W.cy0 = F.w.cy0;
-  WV_LANES_BEGIN (lane)
-  {
-#pragma unroll
-    for (int k = 0; k < WH_WIN_LOADS; ++k) if (wh_win_row_ok (lane, k)) * (WhU4*)&W.b->win[(16 * k) * WH_WIN_STRIDE + lane * 16] = * (const WhU4*)&G.pf_win[(16 * k) * WH_WIN_STRIDE + lane * 16];
-#pragma unroll
-    for (int pl = 0; pl < 2; ++pl) * (WhU4*)&W.b->cwin[pl][lane * 16] = * (const WhU4*)&G.pf_cwin[pl][lane * 16];
-  }
-  WV_LANES_END
+// Speculative fetch of a macroblock's windows, issued together with its cold inputs as soon as the wave holds the ticket --
+// before the neighbours are final, so before the motion vector predictor is known.  The guess is the most recent final
+// 16x16 vector of the slice (camera motion and smooth motion fields make it a good one); the macroblock adopts the window when
+// it covers what the search around the real predictor needs, otherwise it loads its own (exactly the round-1 behaviour).
+// Either way every sample the macroblock reads is the reference picture's: the guess changes timing, never a result.
+WH_FN void wh_win_speculate (const WhSeqParams& P, const WhPicJob& J, WhWin& W, int mbx, int mby, int guess_mv) {
+  const int gx = wh_clip3 ((2 + (int) (int16_t) (guess_mv & 0xffff)) >> 2, -P.mv_range, P.mv_range), gy = wh_clip3 ((2 + (guess_mv >> 16)) >> 2, -P.mv_range, P.mv_range);
+  wh_win_issue_all (P, J, W, mbx * 16 + gx, mby * 16 + gy);
 }
 
 // ---- lane geometry -----------------------------------------------------------------------------------
@@ -695,17 +668,17 @@ WH_FN void wh_inter_cold_fetch (WhInterStage& G, int lane, const WhSeqParams& P,
     }
   }
   // pSadCost[0] of the layer's SMB array (cold_co word 38); the host's four VAA SADs take the place of the previous source
-  // picture's first words (cold_pv 0..3 -> S.prev_y, read back by wh_inter_mb_body)
+  // picture's first words (cold_pv 0..3, read by wh_inter_mb_body straight from the staging area)
   if (lane == 38 && J.sad_cost0) wh_ld_async4 ((const WH_G int32_t*)J.sad_cost0 + xy, G.cold_co, lane);
   if (lane < 4 && J.vaa_sad8x8) wh_ld_async4 ((const WH_G int32_t*)J.vaa_sad8x8 + xy * 4 + lane, G.cold_pv, lane);
 }
 
 typedef struct WhInterCtx {
   int slice_idc, slice_first;        // slice of this MB and its first MB address
-  int next_valid, next_mbx, next_mby;   // the MB this wave processes next (its cold inputs are fetched during this one)
-  WhWinPf* pf;                          // in: windows staged for this MB (or not); out: what was staged for the next one
-  WhWinStage* win_stage;                // where windows are staged, or NULL: no window prefetch
   WhWinLds* win;                        // this wave's search windows
+  int spec_valid;                       // windows were fetched speculatively (wh_win_speculate) ...
+  WhWin spec;                           // ... at this placement
+  int* last_mv;                         // out (may be NULL): the slice's most recent final 16x16 vector, packed -- the next guess
 } WhInterCtx;
 
 // ---- the P macroblock -----------------------------------------------------------------------------
@@ -742,7 +715,6 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, WhInterStage& G, const WhSeqParams& 
     }
     tr.y = G.cold_y[lane]; tr.c = lane < 32 ? G.cold_c[lane] : 0u;
     wh_tile_commit (M, lane, &tr);
-    * (uint32_t*)&S.prev_y[lane * 4] = G.cold_pv[lane];
     // the reference picture's state of this MB (an I picture's has no motion / SAD).  Its padding word (WhMbState::pad1, word
     // 35) carries the layer's pSadCost[0] of this MB instead -- written by the SAME lane: two lanes storing to one LDS word in
     // one instruction have no defined winner on the GPU
@@ -847,21 +819,15 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, WhInterStage& G, const WhSeqParams& 
   {
     const int icx = wh_clip3 ((2 + me16.mvpx) >> 2, C.minx, C.maxx), icy = wh_clip3 ((2 + me16.mvpy) >> 2, C.miny, C.maxy);
     const int cx = mbx * 16 + icx, cy = mby * 16 + icy;
-    const bool adopt = X.pf->valid && wh_win_covers (X.pf->w, cx - WH_WIN_MARGIN, cy - WH_WIN_MARGIN, cx + 16 + WH_WIN_MARGIN, cy + 16 + WH_WIN_MARGIN);
-    if (adopt) { wh_win_adopt (S, *X.win_stage, W, *X.pf); WH_PROF_MARK (P, M, 15); }     // staged during the previous MB
-    else wh_win_issue_all (P, J, W, cx, cy);
+    const bool adopt = X.spec_valid && wh_win_covers (X.spec, cx - WH_WIN_MARGIN, cy - WH_WIN_MARGIN, cx + 16 + WH_WIN_MARGIN, cy + 16 + WH_WIN_MARGIN);
+    if (adopt) { W.x0 = X.spec.x0; W.y0 = X.spec.y0; W.cx0 = X.spec.cx0; W.cy0 = X.spec.cy0; WH_PROF_MARK (P, M, 15); }     // fetched while the wave waited for its neighbours
+    else {
+      if (X.spec_valid) WV_ASYNC_WAIT();       // (landed long ago: the batch-1 loads were issued after it)
+      wh_win_issue_all (P, J, W, cx, cy);
+    }
     // the Intra16x16 mode costs need no reference samples: computed while the window loads are in flight
     wh_i16_costs (M, avail, use_satd, lambda, &i16c);
-    if (!adopt) WV_ASYNC_WAIT();
-    // ---- the next MB of this wave: cold inputs + windows (around where this MB's predictor points), in flight while
-    //      the rest of this MB runs ----
-    X.pf->valid = 0;
-    if (X.next_valid) {
-      WV_LANES_BEGIN (lane)
-      wh_inter_cold_fetch (G, lane, P, J, X.next_mbx, X.next_mby);
-      WV_LANES_END
-      if (X.win_stage) wh_win_prefetch (*X.win_stage, P, J, *X.pf, X.next_mbx * 16 + icx, X.next_mby * 16 + icy);
-    }
+    WV_ASYNC_WAIT();
   }
   WH_PROF_MARK (P, M, 0);   // mvp + batch 2 (window) loads
   int mb_type = WH_MB_P16x16, cbp = 0, cost_luma = 0, cost_skip_mb = 0, sad_cost0 = 0;
@@ -1039,12 +1005,12 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, WhInterStage& G, const WhSeqParams& 
       // WelsMdInterFinePartitionVaa: partition set chosen from the sign pattern of the four 8x8 SADs
       // between this source MB and the previous source frame (VAACalcSad_c + MdInterAnalysisVaaInfo_c)
       int s8_0, s8_1, s8_2, s8_3;
-      if (J.vaa_sad8x8) { const int32_t* v8 = (const int32_t*)S.prev_y; s8_0 = v8[0]; s8_1 = v8[1]; s8_2 = v8[2]; s8_3 = v8[3]; }      // the pre-processing's own result
+      if (J.vaa_sad8x8) { const int32_t* v8 = (const int32_t*)G.cold_pv; s8_0 = v8[0]; s8_1 = v8[1]; s8_2 = v8[2]; s8_3 = v8[3]; }      // the pre-processing's own result
       else {
         int p01, p23;
         WV_SUM2 (p01, p23, lane,
-                 (lane < 32 ? (wh_sad4 (* (const uint32_t*)&M.enc_y[lane * 4], * (const uint32_t*)&S.prev_y[lane * 4]) << ((lane & 2) ? 16 : 0)) : 0),
-                 (lane >= 32 ? (wh_sad4 (* (const uint32_t*)&M.enc_y[lane * 4], * (const uint32_t*)&S.prev_y[lane * 4]) << ((lane & 2) ? 16 : 0)) : 0));
+                 (lane < 32 ? (wh_sad4 (* (const uint32_t*)&M.enc_y[lane * 4], G.cold_pv[lane]) << ((lane & 2) ? 16 : 0)) : 0),
+                 (lane >= 32 ? (wh_sad4 (* (const uint32_t*)&M.enc_y[lane * 4], G.cold_pv[lane]) << ((lane & 2) ? 16 : 0)) : 0));
         s8_0 = p01 & 0xffff; s8_1 = (int) ((unsigned)p01 >> 16); s8_2 = p23 & 0xffff; s8_3 = (int) ((unsigned)p23 >> 16);
       }
       int sign = 15;
@@ -1187,6 +1153,12 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, WhInterStage& G, const WhSeqParams& 
   }
   WV_LANES_END
   wh_store_mb (M, P, J, mbx, mby, mb_type, cbp, qp, qpc, 0, 0, cost_luma, slice_idc);
+  if (X.last_mv) {           // the next window guess of this slice (a race between waves is harmless: any recent vector will do)
+    const int fin = is_skip ? wh_pk_mv (skx, sky) : wh_pk_mv (p16x, p16y);
+    WV_LANES_BEGIN (lane)
+    if (lane == 0) *X.last_mv = fin;
+    WV_LANES_END
+  }
   // what the picture keeps for the time it is a reference (WelsMdInterSaveSadAndRefMbType, WelsMdUpdateBGDInfo, both run
   // before the entropy writer): a background skip keeps its own type; pRefMbQp = uiLumaQp unless the MB is an unchanged
   // collocated one (no residual, zero vector, P reference), which inherits the reference's entry.  uiLumaQp at that point is

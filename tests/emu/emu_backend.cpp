@@ -46,32 +46,30 @@ class EmuBackend : public Backend {
       WhMbLds S; poison (&S, sizeof (S)); wh_intra_mb_body (S, P, jobs[j], x, y); });
   }
   void run_inter (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
-    // one emulated wavefront walks each slice in order, with the same one-MB look-ahead as the device scheduler: the
-    // next MB's cold inputs and search windows are staged in the LDS tile while the current MB is processed
+    // one emulated wavefront walks each slice in order like a wave of the device scheduler: a macroblock's cold inputs and
+    // its speculative search windows (around the slice's last final vector) are fetched before its body runs
     for (int j = 0; j < n; ++j)
       for (int s = 0; s < P.num_slices; ++s) {
         WhInterLds S;
         WhInterStage G;
-        WhWinStage GW;
         WhWinLds WB;
-        poison (&S, sizeof (S)); poison (&G, sizeof (G)); poison (&GW, sizeof (GW)); poison (&WB, sizeof (WB));
-        WhWinPf pf; pf.valid = 0;
+        poison (&S, sizeof (S)); poison (&G, sizeof (G)); poison (&WB, sizeof (WB));
         const int first = P.slice_first_mb[s], last = P.slice_first_mb[s + 1];
-        // the MBs of the range this launch codes (all of the slice unless the job restricts it), in dependency order
-        std::vector<int> todo;
-        for (int t = first; t < last; ++t) { const int xy = P.mb_order[t]; if (jobs[j].mb_end > 0 && (xy < jobs[j].mb_begin || xy >= jobs[j].mb_end)) continue; todo.push_back (xy); }
-        if (todo.empty()) continue;
-        { const int xy = todo[0]; for (int lane = 0; lane < 64; ++lane) wh_inter_cold_fetch (G, lane, P, jobs[j], xy % P.mb_w, xy / P.mb_w); }
-        for (size_t ti = 0; ti < todo.size(); ++ti) {
-          const int t = (int)ti, last = (int)todo.size();
-          const int xy = todo[ti], xyn = ti + 1 < todo.size() ? todo[ti + 1] : 0;
+        int last_mv = 0;
+        for (int t = first; t < last; ++t) {
+          const int xy = P.mb_order[t];
+          if (jobs[j].mb_end > 0 && (xy < jobs[j].mb_begin || xy >= jobs[j].mb_end)) continue;      // GOM-synchronous coding: only this range
+          const int mbx = xy % P.mb_w, mby = xy / P.mb_w;
+          for (int lane = 0; lane < 64; ++lane) wh_inter_cold_fetch (G, lane, P, jobs[j], mbx, mby);
           WhInterCtx X;
           X.slice_idc = s; X.slice_first = first;
-          X.next_valid = t + 1 < last; X.next_mbx = xyn % P.mb_w; X.next_mby = xyn / P.mb_w; X.pf = &pf;
           X.win = &WB;
-          X.win_stage = ((s + j) & 1) ? &GW : nullptr;      // exercise both variants (with / without window staging), one per slice
-          wh_inter_mb_body (S, G, P, jobs[j], xy % P.mb_w, xy / P.mb_w, X);
-          poison (&S, sizeof (S)); poison (&WB, sizeof (WB));      // nothing but the staging areas survives from one macroblock to the next
+          X.spec.b = &WB;
+          X.spec_valid = ((t + s + j) % 5) != 0;            // exercise both paths: most macroblocks speculate, every fifth does not
+          if (X.spec_valid) wh_win_speculate (P, jobs[j], X.spec, mbx, mby, last_mv);
+          X.last_mv = &last_mv;
+          wh_inter_mb_body (S, G, P, jobs[j], mbx, mby, X);
+          poison (&S, sizeof (S)); poison (&WB, sizeof (WB)); poison (&G, sizeof (G));      // nothing survives from one macroblock to the next
         }
       }
   }
