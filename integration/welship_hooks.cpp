@@ -29,6 +29,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <chrono>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -100,6 +101,16 @@ struct HipState {
   bool failed = false;                  // a device call failed: the session reports errors from then on
   bool trace = false;
   bool layer_devices = false;           // one GPU per simulcast layer
+  // WELS_HIP_TRACE=2: where a picture's time goes (seconds, summed): device call incl. transfers, reconstruction copy-back,
+  // entropy coding from the records
+  bool timing = false;
+  double t_encode = 0.0, t_getpic = 0.0, t_code = 0.0;
+  int pictures = 0;
+};
+struct Stopwatch {
+  double* acc; std::chrono::steady_clock::time_point t0;
+  explicit Stopwatch (double* a) : acc (a), t0 (std::chrono::steady_clock::now()) {}
+  ~Stopwatch() { if (acc) *acc += std::chrono::duration<double> (std::chrono::steady_clock::now() - t0).count(); }
 };
 
 int TwinOf (HipLayer& L, const SPicture* p) {
@@ -202,7 +213,9 @@ int32_t HipFrameMd (sWelsEncCtx* pCtx) {
     return ENC_RETURN_SUCCESS;
   }
   const void* rec = NULL;
-  const int rc = g_api.FrameEncode (L.ctx, &job, &rec);
+  int rc;
+  { Stopwatch sw (st->timing ? &st->t_encode : NULL); rc = g_api.FrameEncode (L.ctx, &job, &rec); }
+  ++st->pictures;
   if (rc) { fprintf (stderr, "welship hooks: WelsHipFrameEncode failed (%d: %s)\n", rc, g_api.GetLastError()); st->failed = true; return ENC_RETURN_UNEXPECTED; }
   L.records = (const WhMbRecord*)rec;
   if (const char* dump = getenv ("WELS_HIP_DUMP_RECORDS")) {        // developer aid: the raw macroblock records of every picture
@@ -219,7 +232,7 @@ int32_t HipFrameMd (sWelsEncCtx* pCtx) {
   // the host's copy of the reconstruction (PSNR, reconstruction dumps, pre-processing that looks at the reference picture)
   uint8_t* dst[3] = { pCtx->pDecPic->pData[0], pCtx->pDecPic->pData[1], pCtx->pDecPic->pData[2] };
   const int32_t ds[3] = { pCtx->pDecPic->iLineSize[0], pCtx->pDecPic->iLineSize[1], pCtx->pDecPic->iLineSize[2] };
-  if (g_api.FrameGetPicture (L.ctx, job.iCurPic, dst, ds)) { st->failed = true; return ENC_RETURN_UNEXPECTED; }
+  { Stopwatch sw (st->timing ? &st->t_getpic : NULL); if (g_api.FrameGetPicture (L.ctx, job.iCurPic, dst, ds)) { st->failed = true; return ENC_RETURN_UNEXPECTED; } }
   if (st->trace) fprintf (stderr, "welship hooks: did %d %c picture qp %d slices %d cur %d ref %d deblock %d expand %d mvrange %d complexity %d\n", did, is_p ? 'P' : 'I', job.iQp, nslices, job.iCurPic, job.iRefPic, job.bDeblock, job.bExpand, job.iMvRange, job.iComplexityMode);
   return ENC_RETURN_SUCCESS;
 }
@@ -255,6 +268,7 @@ int32_t HipCodeSlice (sWelsEncCtx* pCtx, SSlice* pSlice) {
   HipState* st = (HipState*)pFunc->pHipState;
   HipLayer& L = st->layer[pCtx->uiDependencyId];
   if (st->failed || (L.records == NULL && !L.gom)) return ENC_RETURN_UNEXPECTED;
+  Stopwatch sw_code (st->timing ? &st->t_code : NULL);
   SDqLayer* pCurLayer = pCtx->pCurDqLayer;
   SMbCache* pMbCache = &pSlice->sMbCacheInfo;
   SMB* pMbList = pCurLayer->sMbDataP;
@@ -346,6 +360,8 @@ int32_t HipCodeSlice (sWelsEncCtx* pCtx, SSlice* pSlice) {
 void HipRelease (void* p) {
   HipState* st = (HipState*)p;
   if (st == NULL) return;
+  if (st->timing && st->pictures) fprintf (stderr, "welship hooks: %d pictures; per picture: device call %.3f ms, reconstruction copy-back %.3f ms, slice coding from the records %.3f ms\n",
+                                           st->pictures, 1e3 * st->t_encode / st->pictures, 1e3 * st->t_getpic / st->pictures, 1e3 * st->t_code / st->pictures);
   for (int i = 0; i < MAX_DEPENDENCY_LAYER; ++i) if (st->layer[i].ctx) g_api.FrameCtxDestroy (st->layer[i].ctx);
   delete st;
 }
@@ -390,6 +406,7 @@ void WelsHipInstall (SWelsFuncPtrList* pFuncList, SWelsSvcCodingParam* pParam) {
   HipState* st = new HipState();
   st->device = getenv ("WELS_HIP_DEVICE") ? atoi (getenv ("WELS_HIP_DEVICE")) : 0;
   st->trace = getenv ("WELS_HIP_TRACE") != NULL;
+  st->timing = st->trace && atoi (getenv ("WELS_HIP_TRACE")) >= 2;
   st->layer_devices = getenv ("WELS_HIP_LAYER_DEVICES") != NULL && atoi (getenv ("WELS_HIP_LAYER_DEVICES")) != 0;
   pFuncList->pHipState = st;
   pFuncList->pfHipFrameMd = HipFrameMd;

@@ -439,9 +439,13 @@ __global__ __launch_bounds__ (1024) void k_compact (WhSeqParams P, const WhPicJo
   }
 }
 
-__global__ __launch_bounds__ (64) void k_expand (WhSeqParams P, const WhPicJob* jobs) {
-  const WhPicJob J = jobs[blockIdx.y];
-  wh_expand_body (P, J, (int)blockIdx.x);
+__global__ __launch_bounds__ (256) void k_expand (WhSeqParams P, const WhPicJob* jobs) {
+  const WhPicJob* J = &jobs[blockIdx.y];
+  WH_G uint8_t* r0 = (WH_G uint8_t*)J->rec[0];
+  WH_G uint8_t* r1 = (WH_G uint8_t*)J->rec[1];
+  WH_G uint8_t* r2 = (WH_G uint8_t*)J->rec[2];
+  const int total = wh_expand_items (P);
+  for (int idx = (int) (blockIdx.x * blockDim.x + threadIdx.x); idx < total; idx += (int) (gridDim.x * blockDim.x)) wh_expand_item (P, r0, r1, r2, idx);
 }
 
 // Scene-change statistic: one wavefront per 16x16 region of the source picture.
@@ -622,7 +626,8 @@ class HipBackend : public wh::Backend {
     HIP_TRY (hipGetLastError());
   }
   void run_expand (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
-    hipLaunchKernelGGL (k_expand, dim3 (wh_expand_num_blocks (P), n), dim3 (64), 0, stream_, P, jobs);
+    const int blocks = std::max (1, std::min (64, (wh_expand_items (P) + 1023) / 1024));        // ~4 items per thread, at most 64 workgroups per picture
+    hipLaunchKernelGGL (k_expand, dim3 (blocks, n), dim3 (256), 0, stream_, P, jobs);
     HIP_TRY (hipGetLastError());
   }
   void run_compact (const WhSeqParams& P, const WhPicJob* jobs, int n) override {

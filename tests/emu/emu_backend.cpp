@@ -106,8 +106,8 @@ class EmuBackend : public Backend {
   }
   void run_expand (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
     for (int j = 0; j < n; ++j) {
-      const int nb = wh_expand_num_blocks (P);
-      for (int b = 0; b < nb; ++b) wh_expand_body (P, jobs[j], b);
+      const int total = wh_expand_items (P);
+      for (int i = 0; i < total; ++i) wh_expand_item (P, (uint8_t*)jobs[j].rec[0], (uint8_t*)jobs[j].rec[1], (uint8_t*)jobs[j].rec[2], i);
     }
   }
   void run_compact (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
