@@ -42,7 +42,7 @@ def build_hip(force=False, verbose=True, defines=(), tag=""):
 
 def build_emu(force=False, verbose=False, defines=(), tag=""):
     """g++ -DWH_EMU test build of the same kernel sources (tests only, never shipped/loaded by the product).
-    `defines` + `tag`: a second test build with candidate code paths switched on (e.g. WH_DB_FAST_LINES)."""
+    `defines` + `tag`: a second test build with candidate code paths switched on (e.g. WH_DB_PER_EDGE)."""
     out = EMU_LIB if not tag else EMU_LIB.replace(".so", "_" + tag + ".so")
     deps = [CSRC, os.path.join(ROOT, "tests", "emu", "emu_backend.cpp")]
     if not force and not _newer(out, deps):

@@ -216,11 +216,12 @@ def test_session_lifecycle(emu_lib):
     assert a5 != a1 and a5.count(b"\x00\x00\x00\x01\x65") == 2
 
 
-def test_emu_fast_deblock_candidate(ref_tools, tmp_path):
-    """kernels/deblock_mb.h carries a faster edge filter behind WH_DB_FAST_LINES (not in the default build: it has not been
-    measured on the device yet).  It has to stay bit-exact: the small golden cases with every deblocking variant."""
+def test_emu_deblock_per_edge(ref_tools, tmp_path):
+    """kernels/deblock_mb.h filters a line's edges in registers, one pass per direction; the plain restatement (every edge a
+    lane block of its own, byte accesses to the LDS tile) is kept behind WH_DB_PER_EDGE for A/B builds.  Both have to be
+    bit-exact: the small golden cases with every deblocking variant."""
     from openh264_amd import build as B
-    lib = B.build_emu(defines=("WH_DB_FAST_LINES",), tag="wh_db_fast_lines")
+    lib = B.build_emu(defines=("WH_DB_PER_EDGE",), tag="wh_db_per_edge")
     for name in SMALL:
         run_case(name, lib, ref_tools, tmp_path)
 

@@ -24,7 +24,7 @@ run WELSHIP_MB_BAND=12 WELSHIP_P_WAVES=12
 echo "== --sessions 192" >> $x; timeout 60 python bench.py --no-cpu-baseline --sessions 192 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['value'],1), 'frames/s', d['roofline'].get('events_ms'))" >> $x 2>&1
 echo "== --deblock-idc 2" >> $x; timeout 60 python bench.py --no-cpu-baseline --deblock-idc 2 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['value'],1), 'frames/s', d['roofline'].get('events_ms'))" >> $x 2>&1
 # candidate deblocking edge filters: second library, parity on the device, then the same bench
-cand=$(python -c "from openh264_amd import build as B; print(B.build_hip(verbose=False, defines=('WH_DB_FAST_LINES',), tag='wh_db_fast_lines'))")
+cand=$(python -c "from openh264_amd import build as B; print(B.build_hip(verbose=False, defines=('WH_DB_PER_EDGE',), tag='wh_db_per_edge'))")
 echo "== candidate $cand: parity" >> $x; timeout 600 python tools/fuzz_parity.py --lib $cand --cases 40 --seed 7 2>&1 | tail -1 >> $x
 run WELSHIP_LIB=$cand
 cat $x
