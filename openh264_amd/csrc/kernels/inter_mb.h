@@ -172,12 +172,17 @@ WH_FN void wh_win_load_luma (WhInterLds& S, const WhSeqParams& P, const WhPicJob
 // first load of a macroblock: luma + both chroma windows in one batch (issue only)
 WH_FN void wh_win_issue_all (const WhSeqParams& P, const WhPicJob& J, WhWin& W, int cx, int cy) {
   wh_win_place (P, W, cx, cy);
+#if defined(WH_NO_CWIN)          /* experiment: no chroma windows -- chroma prediction reads the picture (traffic A/B) */
+  W.cx0 = -100000; W.cy0 = -100000;
+#endif
   WV_LANES_BEGIN (lane)
   {
 #pragma unroll
     for (int k = 0; k < WH_WIN_LOADS; ++k) if (wh_win_row_ok (lane, k)) wh_ld_async16 (wh_win_src_luma (lane, k, P, J, W), &W.b->win[(16 * k) * WH_WIN_STRIDE], lane);
+#if !defined(WH_NO_CWIN)
 #pragma unroll
     for (int pl = 0; pl < 2; ++pl) wh_ld_async16 (wh_win_src_chroma (lane, pl, P, J, W), W.b->cwin[pl], lane);
+#endif
   }
   WV_LANES_END
 }
