@@ -25,10 +25,10 @@ def test_h264_parse_reads_our_streams(emu_lib):
 
 
 def test_committed_bench_line_keeps_the_contract():
-    """profiles/r01_final_bench_default.json is the output of `python bench.py --e2e` on the MI355X: the fields the driver and
-    the judge read must all be there (metric/unit from BASELINE.json, roofline and cpu_baseline objects)."""
+    """profiles/r02_bench_default.json is the output of `python bench.py` on the MI355X: the fields the driver and the judge read
+    must all be there (metric/unit from BASELINE.json, roofline and cpu_baseline objects, the self-verification verdicts)."""
     import json
-    line = json.loads(open(os.path.join(ROOT, "profiles", "r01_final_bench_default.json")).read().strip().splitlines()[-1])
+    line = json.loads(open(os.path.join(ROOT, "profiles", "r02_bench_default.json")).read().strip().splitlines()[-1])
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     assert line["metric"] == base["metric"] and line["unit"] == "frames/s"
     for k in ("value", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
@@ -36,7 +36,13 @@ def test_committed_bench_line_keeps_the_contract():
     assert line["n_gpus"] == 1 and line["higher_is_better"] is True and line["scaling"] == "weak" and line["vs_baseline"] is None
     assert line["dtype"] == "u8" and line["data"] == "synthetic" and "workload" in line["config"] and "model" not in line["config"]
     r = line["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["traffic"] > 0
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["kernel"] == "k_inter_pool" and r["avg_launch_ms"] * r["launches_per_step"] <= line["ms_per_step"]
     c = line["cpu_baseline"]
-    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
-    assert abs(line["value"] - 128 * line["steps"] / (line["ms_per_step"] * line["steps"] / 1e3)) / line["value"] < 1e-6
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"] and c["threads4"]["cores"] == 4
+    n = line["config"]["pictures_in_flight_per_gpu"]
+    assert abs(line["value"] - n * line["steps"] / (line["ms_per_step"] * line["steps"] / 1e3)) / line["value"] < 1e-6
+    # what the run checked about itself
+    assert line["verified"] is True and line["e2e"]["bitstream_vs_reference"]["match"] and line["e2e_overlapped"]["bitstream_vs_reference"]["match"]
+    assert line["res_clip"]["verified"] is True and line["intra_720p"]["verified"] is True
+    assert set(line["latency"]) == {"sessions_1", "sessions_8"}
