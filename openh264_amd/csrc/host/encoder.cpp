@@ -9,7 +9,10 @@
 // batched launch set per frame step covers all N pictures, which is how a single MI355X is filled
 // (independent sessions / simulcast layers / all-IDR frames have no mutual dependency).
 #include <string.h>
+#include <chrono>
+#include <condition_variable>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -1146,7 +1149,51 @@ int WelsHipGroupProfile (WelsHipEncoderGroup* g, int enable, unsigned long long*
 // ---------------------------------------------------------------------------------- explicit frame API (include/welship.h 2b)
 // What the SWelsFuncPtrList hooks of the patched reference call: the reference owns the stream (frame types, reference
 // lists, rate control, entropy coding); this side owns device twins of its pictures and runs the per-macroblock passes.
+//
+// All frame contexts of a process that live on the same device share one backend (allocator + queue) and BATCH their
+// pictures: a thread that submits a picture while nobody is launching becomes the leader, takes everything that is pending
+// (pictures other sessions' threads submitted while the previous batch was on the device, or within a short gathering
+// window), issues ONE launch set per group of pictures with identical sequence parameters, waits for the device and wakes
+// the others.  Several sessions with rate control therefore cost the device one latency chain per batch instead of one per
+// session; a single session is a batch of one.  Pictures with GOM-level QP (MB ranges) run on their own.
+namespace {
+
+struct FrameLayout {           // processing-order / deblocking-band tables on the device, shared by the contexts that use them
+  int mb_w = 0, mb_h = 0, idc = -1;
+  std::vector<int32_t> slices;
+  uint32_t* d_order = nullptr;
+  int32_t* d_bands = nullptr;
+  int nb = 0, max_mbs = 0, max_rows = 0;
+};
+
+struct FrameItem;
+struct FrameShared {
+  std::mutex mu;
+  std::condition_variable cv;
+  wh::Backend* be = nullptr;
+  int device = 0, users = 0;
+  std::vector<std::unique_ptr<FrameLayout>> layouts;
+  std::vector<FrameItem*> pending;
+  bool leader_active = false;
+  FrameItem* next_leader = nullptr;
+  WhPicJob* d_jobs = nullptr;
+  int jobs_cap = 0;
+  std::vector<WhPicJob> h_jobs;
+  // how long a leader waits for the other threads that have been submitting pictures lately.  Sessions that once end up in
+  // different batches stay out of phase for good (each waits for the other's batch); one wait of about a picture's host
+  // work merges them, after which they submit together and nobody waits
+  int gather_us = 2000;
+  std::vector<WelsHipFrameCtx*> ctxs;
+  long batches = 0, batched_pictures = 0;
+};
+
+std::mutex g_frame_registry_mu;
+std::vector<FrameShared*> g_frame_shared;
+
+}  // namespace
+
 struct WelsHipFrameCtx {
+  FrameShared* sh = nullptr;
   wh::Backend* be = nullptr;
   int w = 0, h = 0, mb_w = 0, mb_h = 0, num_mb = 0;
   WhSeqParams seq;
@@ -1157,8 +1204,9 @@ struct WelsHipFrameCtx {
   WhMbRecord* d_records = nullptr;
   std::vector<WhMbRecord> h_records;
   std::vector<uint8_t> h_pic;
-  uint32_t* d_order = nullptr;
-  int32_t* d_bands = nullptr;
+  int h_pic_of = -1;                     // the device picture h_pic holds (copied back with the batch), or -1
+  std::thread::id last_tid;              // who submitted this context's last picture, and when (FrameShared::gather_us)
+  std::chrono::steady_clock::time_point last_submit;
   uint32_t* d_dbflags = nullptr;
   uint32_t db_gen = 0;
   WhMbCtl* d_mb_ctl = nullptr;
@@ -1168,57 +1216,133 @@ struct WelsHipFrameCtx {
   int8_t* d_bgd = nullptr;
   int16_t* d_il = nullptr;
   WhPicJob* d_job = nullptr;
-  // slice / deblocking layout the tables on the device were built for
-  std::vector<int32_t> cur_slices;
-  int cur_idc = -1;
+  FrameLayout* layout = nullptr;
 
-  void release() {
+  // caller holds sh->mu
+  void release_locked() {
     if (!be) return;
     be->sync();
     for (auto& p : pics) { if (p.base) be->free (p.base); if (p.mbs) be->free (p.mbs); }
     pics.clear();
-    void* ptrs[] = {d_src, d_records, d_order, d_bands, d_dbflags, d_mb_ctl, d_sad_cost0, d_vaa, d_bgd, d_il, d_job};
+    void* ptrs[] = {d_src, d_records, d_dbflags, d_mb_ctl, d_sad_cost0, d_vaa, d_bgd, d_il, d_job};
     for (void* p : ptrs) if (p) be->free (p);
     if (!h_records.empty()) be->unpin_host (h_records.data());
     if (!h_src.empty()) be->unpin_host (h_src.data());
     if (!h_pic.empty()) be->unpin_host (h_pic.data());
-    delete be;
     be = nullptr;
   }
 
-  // (re)build the processing-order and deblocking-band tables when the slice layout or the filter mode changes
+  // (re)select the processing-order and deblocking-band tables for this slice layout / filter mode; caller holds sh->mu
   int set_layout (int n, const int32_t* first, int idc) {
-    if ((int)cur_slices.size() == n + 1 && cur_idc == idc && memcmp (cur_slices.data(), first, sizeof (int32_t) * (n + 1)) == 0) return WELSHIP_OK;
+    if (layout && layout->idc == idc && (int)layout->slices.size() == n + 1 && memcmp (layout->slices.data(), first, sizeof (int32_t) * (n + 1)) == 0) return WELSHIP_OK;
     if (n < 1 || n > WH_MAX_SLICES || first[0] != 0 || first[n] != num_mb) { set_err ("invalid slice layout"); return WELSHIP_ERR_INIT_PARA; }
     for (int i = 0; i < n; ++i) if (first[i + 1] <= first[i]) { set_err ("invalid slice layout"); return WELSHIP_ERR_INIT_PARA; }
+    FrameLayout* L = nullptr;
+    for (auto& up : sh->layouts)
+      if (up->mb_w == mb_w && up->mb_h == mb_h && up->idc == idc && (int)up->slices.size() == n + 1 && memcmp (up->slices.data(), first, sizeof (int32_t) * (n + 1)) == 0) { L = up.get(); break; }
+    if (!L) {
+      std::unique_ptr<FrameLayout> up (new FrameLayout());
+      up->mb_w = mb_w; up->mb_h = mb_h; up->idc = idc; up->slices.assign (first, first + n + 1);
+      std::vector<uint16_t> order ((size_t)num_mb * 3);
+      for (int i = 0; i < n; ++i) wh_build_mb_order (mb_w, first[i], first[i + 1], order.data() + first[i]);
+      wh_build_mb_order (mb_w, 0, num_mb, order.data() + num_mb);
+      std::vector<int32_t> bands (3 * (size_t) (mb_h + n) + 1);
+      const int nb = wh_build_db_bands (mb_w, mb_h, n, first, idc, WH_DB_BAND_ROWS, bands.data(), (int)bands.size());
+      if (nb < 1) { set_err ("deblocking band table"); return WELSHIP_ERR_UNKNOWN; }
+      for (int b = 0; b < nb; ++b) wh_build_mb_order (mb_w, bands[b], bands[b + 1], order.data() + 2 * (size_t)num_mb + bands[b]);
+      up->d_order = (uint32_t*)be->alloc ((size_t)num_mb * 3 * 4);
+      up->d_bands = (int32_t*)be->alloc (sizeof (int32_t) * (3 * (size_t)nb + 1));
+      if (!up->d_order || !up->d_bands) { set_err ("out of device memory"); return WELSHIP_ERR_MEMORY; }
+      std::vector<uint32_t> order32 (order.begin(), order.end());
+      be->upload (up->d_order, order32.data(), order32.size() * 4);
+      be->upload (up->d_bands, bands.data(), sizeof (int32_t) * (3 * (size_t)nb + 1));
+      if (be->sync()) { set_err ("device error"); return WELSHIP_ERR_UNKNOWN; }
+      up->nb = nb;
+      for (int b = 0; b < nb; ++b) {
+        up->max_mbs = std::max (up->max_mbs, bands[b + 1] - bands[b]);
+        up->max_rows = std::max (up->max_rows, (bands[b + 1] - 1) / mb_w - bands[b] / mb_w + 1);
+      }
+      L = up.get();
+      sh->layouts.push_back (std::move (up));       // tables live as long as the shared device (a handful per resolution)
+    }
+    layout = L;
     WhSeqParams& s = seq;
     s.num_slices = n;
-    for (int i = 0; i <= n; ++i) s.slice_first_mb[i] = first[i];
-    s.deblock_idc = idc;
-    std::vector<uint16_t> order ((size_t)num_mb * 3);
-    for (int i = 0; i < n; ++i) wh_build_mb_order (mb_w, first[i], first[i + 1], order.data() + first[i]);
-    wh_build_mb_order (mb_w, 0, num_mb, order.data() + num_mb);
-    std::vector<int32_t> bands (3 * (size_t) (mb_h + n) + 1);
-    const int nb = wh_build_db_bands (mb_w, mb_h, n, first, idc, WH_DB_BAND_ROWS, bands.data(), (int)bands.size());
-    if (nb < 1) { set_err ("deblocking band table"); return WELSHIP_ERR_UNKNOWN; }
-    for (int b = 0; b < nb; ++b) wh_build_mb_order (mb_w, bands[b], bands[b + 1], order.data() + 2 * (size_t)num_mb + bands[b]);
-    be->sync();                                   // nothing in flight may still read the old tables
-    std::vector<uint32_t> order32 (order.begin(), order.end());
-    be->upload (d_order, order32.data(), order32.size() * 4);
-    be->upload (d_bands, bands.data(), sizeof (int32_t) * (3 * (size_t)nb + 1));
-    if (be->sync()) { set_err ("device error"); return WELSHIP_ERR_UNKNOWN; }
-    s.mb_order = d_order;
-    s.db_num_bands = nb; s.db_bands = d_bands;
-    s.db_max_mbs = 0; s.db_max_rows = 0;
-    for (int b = 0; b < nb; ++b) {
-      s.db_max_mbs = std::max (s.db_max_mbs, bands[b + 1] - bands[b]);
-      s.db_max_rows = std::max (s.db_max_rows, (bands[b + 1] - 1) / mb_w - bands[b] / mb_w + 1);
-    }
-    cur_slices.assign (first, first + n + 1);
-    cur_idc = idc;
+    for (int i = 0; i < WH_MAX_SLICES + 1; ++i) s.slice_first_mb[i] = i <= n ? first[i] : 0;
+    s.mb_order = L->d_order;
+    s.db_num_bands = L->nb; s.db_bands = L->d_bands; s.db_max_mbs = L->max_mbs; s.db_max_rows = L->max_rows;
     return WELSHIP_OK;
   }
 };
+
+namespace {
+
+struct FrameItem {             // one submitted picture, owned by the submitting thread's stack frame
+  WelsHipFrameCtx* c = nullptr;
+  WhSeqParams seq;
+  WhPicJob job;
+  bool is_p = false, qp_map = false, expand = false;
+  int cur_pic = 0;
+  int32_t* sad_dst = nullptr;
+  bool done = false;
+  int rc = 0;
+};
+
+// the leader's work: everything in `batch` on the device, grouped by identical sequence parameters.  Called with sh->mu
+// held; releases it while the device works.
+void frame_run_batch (FrameShared* sh, std::unique_lock<std::mutex>& lock, std::vector<FrameItem*>& batch) {
+  wh::Backend* be = sh->be;
+  const int n = (int)batch.size();
+  if (n > sh->jobs_cap) {
+    if (sh->d_jobs) be->free (sh->d_jobs);
+    sh->jobs_cap = std::max (16, 2 * n);
+    sh->d_jobs = (WhPicJob*)be->alloc (sizeof (WhPicJob) * sh->jobs_cap);
+  }
+  int rc_all = sh->d_jobs ? WELSHIP_OK : WELSHIP_ERR_MEMORY;
+  if (rc_all == WELSHIP_OK) {
+    // groups of identical WhSeqParams and picture type, each a contiguous stretch of the job array
+    std::vector<FrameItem*> order;
+    std::vector<int> group_first;
+    std::vector<bool> taken (n, false);
+    for (int i = 0; i < n; ++i) if (!taken[i]) {
+      group_first.push_back ((int)order.size());
+      for (int k = i; k < n; ++k)
+        if (!taken[k] && batch[k]->is_p == batch[i]->is_p && batch[k]->qp_map == batch[i]->qp_map && batch[k]->expand == batch[i]->expand &&
+            memcmp (&batch[k]->seq, &batch[i]->seq, sizeof (WhSeqParams)) == 0) { taken[k] = true; order.push_back (batch[k]); }
+    }
+    group_first.push_back (n);
+    sh->h_jobs.resize (n);
+    for (int i = 0; i < n; ++i) sh->h_jobs[i] = order[i]->job;
+    be->upload (sh->d_jobs, sh->h_jobs.data(), sizeof (WhPicJob) * n);
+    for (size_t g = 0; g + 1 < group_first.size(); ++g) {
+      const int a = group_first[g], cnt = group_first[g + 1] - a;
+      const FrameItem& it = *order[a];
+      const WhSeqParams& s = it.seq;
+      if (it.is_p) be->run_inter (s, sh->d_jobs + a, cnt); else be->run_intra (s, sh->d_jobs + a, cnt);
+      if (it.qp_map) be->run_qp_chain (s, sh->d_jobs + a, cnt);
+      if (s.deblock_idc != 1) be->run_deblock (s, sh->d_jobs + a, cnt);
+      if (it.expand) be->run_expand (s, sh->d_jobs + a, cnt);
+    }
+    for (FrameItem* it : batch) {
+      WelsHipFrameCtx* c = it->c;
+      be->download (c->h_records.data(), c->d_records, sizeof (WhMbRecord) * c->num_mb);
+      be->download (c->h_pic.data(), c->pics[it->cur_pic].base, c->rec_alloc_bytes + 128);
+      if (it->sad_dst) be->download (it->sad_dst, c->d_sad_cost0, sizeof (int32_t) * c->num_mb);
+    }
+    lock.unlock();               // other sessions stage and queue their next pictures while the device works
+    const int bad = be->sync();
+    lock.lock();
+    if (bad) rc_all = WELSHIP_ERR_UNKNOWN;
+    ++sh->batches; sh->batched_pictures += n;
+  }
+  for (FrameItem* it : batch) {
+    it->rc = rc_all;
+    if (rc_all == WELSHIP_OK) { it->c->pics[it->cur_pic].is_p = it->is_p; it->c->h_pic_of = it->cur_pic; }
+    it->done = true;
+  }
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -1227,10 +1351,25 @@ int WelsHipFrameCtxCreate (WelsHipFrameCtx** pp, const WelsHipFrameCfg* cfg) {
   if (cfg->iPicWidth < 16 || cfg->iPicHeight < 16 || cfg->iPicWidth > 4096 || cfg->iPicHeight > 2304 || cfg->iNumPictures < 2 || cfg->iNumPictures > 64) {
     set_err ("invalid frame context configuration"); return WELSHIP_ERR_INIT_PARA;
   }
-  const char* berr = nullptr;
-  wh::Backend* be = wh::create_default_backend (cfg->iDevice, &berr);
-  if (!be) { set_err (std::string ("no usable device backend: ") + (berr ? berr : "?")); return WELSHIP_ERR_NO_DEVICE; }
+  FrameShared* sh = nullptr;
+  {
+    std::lock_guard<std::mutex> reg (g_frame_registry_mu);
+    for (FrameShared* x : g_frame_shared) if (x->device == cfg->iDevice) sh = x;
+    if (!sh) {
+      const char* berr = nullptr;
+      wh::Backend* be = wh::create_default_backend (cfg->iDevice, &berr);
+      if (!be) { set_err (std::string ("no usable device backend: ") + (berr ? berr : "?")); return WELSHIP_ERR_NO_DEVICE; }
+      sh = new FrameShared();
+      sh->be = be; sh->device = cfg->iDevice;
+      if (const char* e = getenv ("WELSHIP_FRAME_GATHER_US")) sh->gather_us = std::max (0, atoi (e));
+      g_frame_shared.push_back (sh);
+    }
+    ++sh->users;
+  }
+  std::unique_lock<std::mutex> lock (sh->mu);
+  wh::Backend* be = sh->be;
   WelsHipFrameCtx* c = new WelsHipFrameCtx();
+  c->sh = sh;
   c->be = be;
   c->w = cfg->iPicWidth; c->h = cfg->iPicHeight;
   c->mb_w = (c->w + 15) >> 4; c->mb_h = (c->h + 15) >> 4; c->num_mb = c->mb_w * c->mb_h;
@@ -1250,8 +1389,6 @@ int WelsHipFrameCtxCreate (WelsHipFrameCtx** pp, const WelsHipFrameCfg* cfg) {
   for (auto& d : c->pics) { d.base = (uint8_t*)A (c->rec_alloc_bytes + 128); d.mbs = (WhMbState*)A (sizeof (WhMbState) * c->num_mb); }
   c->d_src = (uint8_t*)A (c->src_bytes);
   c->d_records = (WhMbRecord*)A (sizeof (WhMbRecord) * c->num_mb);
-  c->d_order = (uint32_t*)A ((size_t)c->num_mb * 3 * 4);
-  c->d_bands = (int32_t*)A (sizeof (int32_t) * (3 * (size_t) (c->mb_h + WH_MAX_SLICES) + 1));
   c->d_dbflags = (uint32_t*)A (sizeof (uint32_t) * c->num_mb);
   c->d_mb_ctl = (WhMbCtl*)A (sizeof (WhMbCtl) * c->num_mb);
   c->d_sad_cost0 = (int32_t*)A (sizeof (int32_t) * c->num_mb);
@@ -1259,7 +1396,15 @@ int WelsHipFrameCtxCreate (WelsHipFrameCtx** pp, const WelsHipFrameCfg* cfg) {
   c->d_bgd = (int8_t*)A ((size_t)c->num_mb + 64);
   c->d_il = (int16_t*)A (sizeof (int16_t) * 4 * c->num_mb);
   c->d_job = (WhPicJob*)A (sizeof (WhPicJob));
-  if (oom) { set_err ("out of device memory"); c->release(); delete c; return WELSHIP_ERR_MEMORY; }
+  auto fail = [&] (int rc) {
+    c->release_locked();
+    delete c;
+    lock.unlock();
+    std::lock_guard<std::mutex> reg (g_frame_registry_mu);
+    --sh->users;                      // the shared device stays for the next context (its allocator keeps the slabs)
+    return rc;
+  };
+  if (oom) { set_err ("out of device memory"); return fail (WELSHIP_ERR_MEMORY); }
   for (auto& d : c->pics) {
     be->fill (d.base, 0, c->rec_alloc_bytes + 128);
     d.plane[0] = d.base + 64 + (size_t)32 * s.rec_stride_y + 32;
@@ -1275,17 +1420,33 @@ int WelsHipFrameCtxCreate (WelsHipFrameCtx** pp, const WelsHipFrameCfg* cfg) {
   c->h_mb_ctl.resize (c->num_mb);
   be->pin_host (c->h_records.data(), sizeof (WhMbRecord) * c->num_mb);
   be->pin_host (c->h_src.data(), c->h_src.size());
-  c->h_pic.resize (c->rec_alloc_bytes + 128);                 // D2H target of FrameGetPicture
+  c->h_pic.resize (c->rec_alloc_bytes + 128);                 // D2H target of the reconstruction (copied back with every batch)
   be->pin_host (c->h_pic.data(), c->h_pic.size());
-  if (be->sync()) { set_err ("device error while setting up the frame context"); c->release(); delete c; return WELSHIP_ERR_UNKNOWN; }
+  if (be->sync()) { set_err ("device error while setting up the frame context"); return fail (WELSHIP_ERR_UNKNOWN); }
+  sh->ctxs.push_back (c);
   *pp = c;
   return WELSHIP_OK;
 }
 
 void WelsHipFrameCtxDestroy (WelsHipFrameCtx* c) {
   if (!c) return;
-  c->release();
+  FrameShared* sh = c->sh;
+  {
+    std::unique_lock<std::mutex> lock (sh->mu);
+    sh->cv.wait (lock, [&] { return !sh->leader_active; });
+    sh->ctxs.erase (std::remove (sh->ctxs.begin(), sh->ctxs.end(), c), sh->ctxs.end());
+    c->release_locked();
+  }
   delete c;
+  std::lock_guard<std::mutex> reg (g_frame_registry_mu);
+  if (--sh->users == 0) {
+    if (getenv ("WELSHIP_TRACE") && sh->batches) fprintf (stderr, "welship: frame API on device %d: %ld pictures in %ld batches\n", sh->device, sh->batched_pictures, sh->batches);
+    for (auto& L : sh->layouts) { sh->be->free (L->d_order); sh->be->free (L->d_bands); }
+    if (sh->d_jobs) sh->be->free (sh->d_jobs);
+    delete sh->be;
+    g_frame_shared.erase (std::find (g_frame_shared.begin(), g_frame_shared.end(), sh));
+    delete sh;
+  }
 }
 
 int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void** pp_records) {
@@ -1300,9 +1461,31 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
   const bool ranged = j->iMbEnd > 0;
   if (ranged && (j->iMbBegin < 0 || j->iMbBegin >= j->iMbEnd || j->iMbEnd > c->num_mb)) { set_err ("invalid MB range"); return WELSHIP_ERR_INIT_PARA; }
   const bool first_part = !ranged || j->iMbBegin == 0, last_part = !ranged || j->iMbEnd == c->num_mb;
+  FrameShared* sh = c->sh;
+  wh::Backend* be = c->be;
+  // host-side staging into this context's own page-locked buffers: outside the shared lock
+  if (first_part) {
+    // source picture: the MB-aligned area of pEncPic (CWelsPreProcess pads it), tight strides on the device
+    const WhSeqParams& s0 = c->seq;
+    uint8_t* y = c->h_src.data();
+    uint8_t* u = y + c->ysz;
+    uint8_t* v = u + c->csz;
+    for (int r = 0; r < c->mb_h * 16; ++r) memcpy (y + (size_t)r * s0.src_stride_y, j->pSrc[0] + (size_t)r * j->iSrcStride[0], (size_t)c->mb_w * 16);
+    for (int r = 0; r < c->mb_h * 8; ++r) {
+      memcpy (u + (size_t)r * s0.src_stride_c, j->pSrc[1] + (size_t)r * j->iSrcStride[1], (size_t)c->mb_w * 8);
+      memcpy (v + (size_t)r * s0.src_stride_c, j->pSrc[2] + (size_t)r * j->iSrcStride[2], (size_t)c->mb_w * 8);
+    }
+  }
+  bool qp_map = false;
+  if (j->pMbQp) {
+    for (int i = 0; i < c->num_mb; ++i) { memset (&c->h_mb_ctl[i], 0, sizeof (WhMbCtl)); c->h_mb_ctl[i].qp_delta = (int8_t) ((int)j->pMbQp[i] - j->iQp); }
+    qp_map = true;
+  }
+
+  std::unique_lock<std::mutex> lock (sh->mu);
+  if (ranged) sh->cv.wait (lock, [&] { return !sh->leader_active; });        // MB ranges run on their own, with the queue to themselves
   int rc = c->set_layout (j->iNumSlices, j->pSliceFirstMb, j->iDeblockIdc);
   if (rc) return rc;
-  wh::Backend* be = c->be;
   WhSeqParams& s = c->seq;
   s.deblock_idc = j->bDeblock ? j->iDeblockIdc : 1;       // an unfiltered picture (highest temporal layer) keeps the tables of the filtered ones
   s.complexity = j->iComplexityMode;
@@ -1310,28 +1493,15 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
   s.alpha_offset = j->iAlphaOffset; s.beta_offset = j->iBetaOffset;
   s.mv_range = j->iMvRange;
   if (first_part) {
-    // source picture: the MB-aligned area of pEncPic (CWelsPreProcess pads it), tight strides on the device
-    uint8_t* y = c->h_src.data();
-    uint8_t* u = y + c->ysz;
-    uint8_t* v = u + c->csz;
-    for (int r = 0; r < c->mb_h * 16; ++r) memcpy (y + (size_t)r * s.src_stride_y, j->pSrc[0] + (size_t)r * j->iSrcStride[0], (size_t)c->mb_w * 16);
-    for (int r = 0; r < c->mb_h * 8; ++r) {
-      memcpy (u + (size_t)r * s.src_stride_c, j->pSrc[1] + (size_t)r * j->iSrcStride[1], (size_t)c->mb_w * 8);
-      memcpy (v + (size_t)r * s.src_stride_c, j->pSrc[2] + (size_t)r * j->iSrcStride[2], (size_t)c->mb_w * 8);
-    }
     be->upload (c->d_src, c->h_src.data(), c->src_bytes);
     if (is_p && j->pVaaSad8x8) be->upload (c->d_vaa, j->pVaaSad8x8, sizeof (int32_t) * 4 * c->num_mb);
     if (is_p && j->pBgdFlags) be->upload (c->d_bgd, j->pBgdFlags, (size_t)c->num_mb);
     if (is_p && j->pIlHint) be->upload (c->d_il, j->pIlHint, sizeof (int16_t) * 4 * c->num_mb);
     if (j->pSadCost) be->upload (c->d_sad_cost0, j->pSadCost, sizeof (int32_t) * c->num_mb);
     if (++c->db_gen == 0) c->db_gen = 1;
+    c->h_pic_of = -1;
   }
-  bool qp_map = false;
-  if (j->pMbQp) {
-    for (int i = 0; i < c->num_mb; ++i) { memset (&c->h_mb_ctl[i], 0, sizeof (WhMbCtl)); c->h_mb_ctl[i].qp_delta = (int8_t) ((int)j->pMbQp[i] - j->iQp); if (c->h_mb_ctl[i].qp_delta) qp_map = true; }
-    be->upload (c->d_mb_ctl, c->h_mb_ctl.data(), sizeof (WhMbCtl) * c->num_mb);
-    qp_map = true;
-  }
+  if (qp_map) be->upload (c->d_mb_ctl, c->h_mb_ctl.data(), sizeof (WhMbCtl) * c->num_mb);
   DevPicture& cur = c->pics[j->iCurPic];
   WhPicJob job;
   memset (&job, 0, sizeof (job));
@@ -1353,25 +1523,68 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
   job.mvc_shift = j->iMvcShift;
   job.il_hint = is_p && j->pIlHint ? c->d_il : nullptr;
   job.mb_begin = ranged ? j->iMbBegin : 0; job.mb_end = ranged ? j->iMbEnd : 0;
-  be->upload (c->d_job, &job, sizeof (job));
-  if (is_p) be->run_inter (s, c->d_job, 1); else be->run_intra (s, c->d_job, 1);
-  if (last_part) {
-    if (ranged) { job.mb_begin = 0; job.mb_end = 0; be->sync(); be->upload (c->d_job, &job, sizeof (job)); }
-    if (qp_map) be->run_qp_chain (s, c->d_job, 1);           // QP_Y for the filter and pRefMbQp of decided skips
-    if (s.deblock_idc != 1) be->run_deblock (s, c->d_job, 1);
-    if (j->bExpand) be->run_expand (s, c->d_job, 1);
-    cur.is_p = is_p;
+
+  if (ranged) {
+    // GOM-synchronous coding: this MB range now, the picture-wide passes with the last range
+    be->upload (c->d_job, &job, sizeof (job));
+    if (is_p) be->run_inter (s, c->d_job, 1); else be->run_intra (s, c->d_job, 1);
+    if (last_part) {
+      job.mb_begin = 0; job.mb_end = 0; be->sync(); be->upload (c->d_job, &job, sizeof (job));
+      if (qp_map) be->run_qp_chain (s, c->d_job, 1);           // QP_Y for the filter and pRefMbQp of decided skips
+      if (s.deblock_idc != 1) be->run_deblock (s, c->d_job, 1);
+      if (j->bExpand) be->run_expand (s, c->d_job, 1);
+      cur.is_p = is_p;
+      if (j->pSadCost) be->download (j->pSadCost, c->d_sad_cost0, sizeof (int32_t) * c->num_mb);
+    }
+    be->download (c->h_records.data() + j->iMbBegin, c->d_records + j->iMbBegin, sizeof (WhMbRecord) * (size_t) (j->iMbEnd - j->iMbBegin));
+    if (be->sync()) { set_err ("device scheduler timed out or device error; the picture was not encoded"); return WELSHIP_ERR_UNKNOWN; }
+    *pp_records = c->h_records.data();
+    return WELSHIP_OK;
   }
-  if (j->pSadCost && last_part) be->download (j->pSadCost, c->d_sad_cost0, sizeof (int32_t) * c->num_mb);
-  if (ranged) be->download (c->h_records.data() + j->iMbBegin, c->d_records + j->iMbBegin, sizeof (WhMbRecord) * (size_t) (j->iMbEnd - j->iMbBegin));
-  else be->download (c->h_records.data(), c->d_records, sizeof (WhMbRecord) * c->num_mb);
-  if (be->sync()) { set_err ("device scheduler timed out or device error; the picture was not encoded"); return WELSHIP_ERR_UNKNOWN; }
+
+  FrameItem item;
+  item.c = c; item.seq = s; item.job = job; item.is_p = is_p; item.qp_map = qp_map; item.expand = j->bExpand != 0;
+  item.cur_pic = j->iCurPic; item.sad_dst = j->pSadCost;
+  c->last_tid = std::this_thread::get_id();
+  c->last_submit = std::chrono::steady_clock::now();
+  sh->pending.push_back (&item);
+  if (sh->leader_active) sh->cv.notify_all();          // a gathering leader may have been waiting for exactly this picture
+  for (;;) {
+    if (item.done) break;
+    if (!sh->leader_active && (sh->next_leader == nullptr || sh->next_leader == &item)) {
+      // this thread launches: whatever is pending now plus what arrives within the gathering window
+      sh->leader_active = true;
+      sh->next_leader = nullptr;
+      if (sh->gather_us > 0 && sh->ctxs.size() > 1) {
+        // threads that submitted a picture within the last 100 ms (a thread has one picture pending at most; the layers of a
+        // simulcast session come from one thread, one after the other)
+        const auto now = std::chrono::steady_clock::now();
+        std::vector<std::thread::id> tids;
+        for (WelsHipFrameCtx* x : sh->ctxs)
+          if (now - x->last_submit < std::chrono::milliseconds (100) && std::find (tids.begin(), tids.end(), x->last_tid) == tids.end()) tids.push_back (x->last_tid);
+        const size_t expected = tids.size();
+        if (sh->pending.size() < expected)
+          sh->cv.wait_for (lock, std::chrono::microseconds (sh->gather_us), [&] { return sh->pending.size() >= expected; });
+      }
+      std::vector<FrameItem*> batch;
+      batch.swap (sh->pending);
+      frame_run_batch (sh, lock, batch);
+      sh->leader_active = false;
+      if (!sh->pending.empty()) sh->next_leader = sh->pending.front();     // pictures that arrived meanwhile: their first submitter goes next
+      sh->cv.notify_all();
+      continue;
+    }
+    sh->cv.wait (lock);
+  }
+  if (item.rc) { set_err ("device scheduler timed out or device error; the picture was not encoded"); return item.rc; }
   *pp_records = c->h_records.data();
   return WELSHIP_OK;
 }
 
 int WelsHipFrameGetMbStates (WelsHipFrameCtx* c, int pic, void* dst, size_t bytes) {
   if (!c || !c->be || pic < 0 || pic >= (int)c->pics.size() || !dst || bytes < sizeof (WhMbState) * c->num_mb) return WELSHIP_ERR_INIT_PARA;
+  std::unique_lock<std::mutex> lock (c->sh->mu);
+  c->sh->cv.wait (lock, [&] { return !c->sh->leader_active; });
   c->be->download (dst, c->pics[pic].mbs, sizeof (WhMbState) * c->num_mb);
   return c->be->sync() ? WELSHIP_ERR_UNKNOWN : WELSHIP_OK;
 }
@@ -1381,8 +1594,13 @@ int WelsHipFrameGetPicture (WelsHipFrameCtx* c, int pic, uint8_t* const dst[3], 
   const WhSeqParams& s = c->seq;
   std::vector<uint8_t>& tmp = c->h_pic;
   const DevPicture& p = c->pics[pic];
-  c->be->download (tmp.data(), p.base, c->rec_alloc_bytes + 128);
-  if (c->be->sync()) return WELSHIP_ERR_UNKNOWN;
+  if (c->h_pic_of != pic) {              // not the picture that came back with the last batch (GOM-coded pictures, older pictures)
+    std::unique_lock<std::mutex> lock (c->sh->mu);
+    c->sh->cv.wait (lock, [&] { return !c->sh->leader_active; });
+    c->be->download (tmp.data(), p.base, c->rec_alloc_bytes + 128);
+    if (c->be->sync()) return WELSHIP_ERR_UNKNOWN;
+    c->h_pic_of = pic;
+  }
   const uint8_t* y = tmp.data() + (p.plane[0] - p.base);
   const uint8_t* u = tmp.data() + (p.plane[1] - p.base);
   const uint8_t* v = tmp.data() + (p.plane[2] - p.base);
