@@ -171,3 +171,28 @@ def test_stock_welsenc_cfg_on_emulation(emu_lib, tmp_path):
 @pytest.mark.gpu
 def test_stock_welsenc_cfg_on_the_mi355x(hip_lib, tmp_path):
     _stock_cfg(hip_lib, tmp_path)
+
+
+# ---- several encoder instances in one process: their pictures are launched together (FrameShared, csrc/host/encoder.cpp) ------
+def _parallel_sessions(lib, tmp_path, n):
+    yuv = os.path.join(RES, "CiscoVT2people_320x192_12fps.yuv")
+    base = [os.path.join(REF, "ref_enc_hip"), "-parallel", str(n), "-i", yuv, "-w", "320", "-h", "192", "-fps", "12", "-rc", "1", "-bitrate", "300000",
+            "-slcmd", "1", "-slcnum", "3", "-bgd", "1", "-numtl", "2", "-quiet"]
+    subprocess.check_call(base + ["-o", str(tmp_path / "c.264")], env=dict(os.environ, WELS_HIP="0"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    p = subprocess.run(base + ["-o", str(tmp_path / "d.264")], env=dict(os.environ, WELSHIP_LIB=lib, WELS_HIP_TRACE="1"), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    err = p.stderr.decode(errors="replace")
+    assert p.returncode == 0, err[-2000:]
+    assert err.count("welship hooks: installed") == n and err.count("welship hooks: did") >= 5 * n
+    want = (tmp_path / "c.264.0").read_bytes()
+    for k in range(n):
+        assert (tmp_path / ("c.264.%d" % k)).read_bytes() == want
+        assert (tmp_path / ("d.264.%d" % k)).read_bytes() == want, "session %d differs" % k
+
+
+def test_concurrent_sessions_on_emulation(emu_lib, tmp_path):
+    _parallel_sessions(emu_lib, tmp_path, 3)
+
+
+@pytest.mark.gpu
+def test_concurrent_sessions_on_the_mi355x(hip_lib, tmp_path):
+    _parallel_sessions(hip_lib, tmp_path, 6)
