@@ -23,8 +23,9 @@
 // false, ratectl.cpp:1199-1204,1239-1262) a picture is one device call; with GOM-level QP (one slice per picture) the QP of a
 // group of macroblocks depends on the bits the groups before it produced, so the picture is coded group by group from inside
 // the slice loop -- a latency chain of one device call per group, bit-exact but not the throughput path.  Everything else
-// (screen content, CABAC, size-limited slices, SVC inter-layer prediction, slice threads) keeps the reference's C path --
-// the hooks stay NULL, as they would on a CPU without the needed SIMD level.
+// (screen content, CABAC, size-limited slices, SVC inter-layer prediction, slice threads -- and, unless WELS_HIP_GOM=1, the
+// GOM-level-QP sessions, which are correct but slower than the host) keeps the reference's C path -- the hooks stay NULL, as
+// they would on a CPU without the needed SIMD level.
 #if defined(HAVE_HIP)
 #include <stdio.h>
 #include <stdlib.h>
@@ -376,9 +377,21 @@ bool WelsHipSupported (const SWelsSvcCodingParam* p, const char** why) {
   if (p->iSpatialLayerNum != 1 && !p->bSimulcastAVC) NO ("spatial layers with inter-layer prediction");
   if (p->iMultipleThreadIdc != 1) NO ("slice threads: the host loop is single-threaded in this binding");
   // bEnableAdaptiveQuant: ParamValidation switches it off for every session (encoder_ext.cpp:300-301), nothing to check
+  const char* gom = getenv ("WELS_HIP_GOM");
+  const bool gom_ok = gom != NULL && atoi (gom) != 0;
   for (int i = 0; i < p->iSpatialLayerNum; ++i) {
     const SSliceArgument& sa = p->sSpatialLayers[i].sSliceArgument;
     if (sa.uiSliceMode == SM_SIZELIMITED_SLICE) NO ("size-limited slices feed the bitstream position back into mode decision");
+    // Rate control with one slice per picture = GOM-level QP (ratectl.cpp:1199-1204): the QP of a group of macroblocks depends
+    // on the bits of the groups before it, so the picture is one device round trip PER GROUP -- bit-exact, but a latency chain
+    // several times slower than the C path (measured: 720p 22 against 124 frames/s).  Taken only on request (WELS_HIP_GOM=1)
+    // until the bit counting runs on the device too.
+    if (p->iRCMode != RC_OFF_MODE && !gom_ok) {
+      const int mbs = ((p->sSpatialLayers[i].iVideoWidth + 15) >> 4) * ((p->sSpatialLayers[i].iVideoHeight + 15) >> 4);
+      const bool one_slice = sa.uiSliceMode == SM_SINGLE_SLICE || (sa.uiSliceMode == SM_FIXEDSLCNUM_SLICE && sa.uiSliceNum <= 1) ||
+                             (sa.uiSliceMode == SM_RASTER_SLICE && (sa.uiSliceMbNum[0] == 0 || (int)sa.uiSliceMbNum[0] >= mbs));
+      if (one_slice) NO ("rate control with one slice per picture (GOM-level QP) is slower on the device than on the host; WELS_HIP_GOM=1 installs it anyway");
+    }
   }
   return true;
 #undef NO

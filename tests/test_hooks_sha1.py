@@ -67,7 +67,7 @@ def _run_row(workdir, lib, row, tag):
         opts += k.split() + [v]
     opts = [o if o != "bgd" else "-bgd" for o in opts]       # the table's header spells this one column without its dash
     out = str(workdir / ("t_%s.264" % tag))
-    env = dict(os.environ, WELSHIP_LIB=lib, WELS_HIP_TRACE="1")
+    env = dict(os.environ, WELSHIP_LIB=lib, WELS_HIP_TRACE="1", WELS_HIP_GOM="1")      # the one-slice rows use GOM-level QP: opt-in
     p = subprocess.run([H264ENC, "welsenc.cfg", "-lconfig", "0", "layer0.cfg", "-lconfig", "1", "layer1.cfg", "-lconfig", "2", "layer2.cfg",
                         "-lconfig", "3", "layer3.cfg", "-bf", out, "-org", str(workdir / "BA_MW_D.264.yuv")] + opts,
                        cwd=str(workdir), env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
@@ -115,6 +115,20 @@ def test_unsupported_rows_stay_on_the_c_path(workdir, emu_lib):
         assert got == row[0]
 
 
+def test_gom_sessions_are_opt_in(emu_lib, tmp_path):
+    """Rate control with one slice per picture means one device round trip per group of macroblocks: correct (the rows above)
+    but slower than the host, so the installer declines it unless WELS_HIP_GOM=1 -- and says so."""
+    out = str(tmp_path / "o.264")
+    env = dict(os.environ, WELSHIP_LIB=emu_lib, WELS_HIP_TRACE="1")
+    env.pop("WELS_HIP_GOM", None)
+    name, w, h, fps, sha = API_GOLDEN[0]
+    p = subprocess.run([os.path.join(REF, "ref_enc_hip"), "-i", os.path.join(RES, name), "-w", str(w), "-h", str(h), "-o", out, "-base", "-rc", "0",
+                        "-fps", str(fps), "-quiet"], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    err = p.stderr.decode(errors="replace")
+    assert p.returncode == 0 and "not installed" in err and "GOM" in err and "welship hooks: did" not in err
+    assert hashlib.sha1(open(out, "rb").read()).hexdigest() == sha
+
+
 @pytest.mark.gpu
 def test_sha1_table_rows_on_the_mi355x(workdir, hip_lib):
     _check(workdir, hip_lib, _sample(_device_rows(), 48))
@@ -130,7 +144,7 @@ API_GOLDEN = [  # test/api/encoder_test.cpp:104-115 (SEncParamBase: RC quality m
 
 def _api_hash(lib, tmp_path, name, w, h, fps):
     out = str(tmp_path / "o.264")
-    env = dict(os.environ, WELSHIP_LIB=lib, WELS_HIP_TRACE="1")
+    env = dict(os.environ, WELSHIP_LIB=lib, WELS_HIP_TRACE="1", WELS_HIP_GOM="1")
     p = subprocess.run([os.path.join(REF, "ref_enc_hip"), "-i", os.path.join(RES, name), "-w", str(w), "-h", str(h), "-o", out, "-base", "-rc", "0",
                         "-fps", str(fps), "-quiet"], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
     err = p.stderr.decode(errors="replace")
@@ -157,7 +171,7 @@ def _stock_cfg(lib, tmp_path):
     (tmp_path / "welsenc.cfg").write_text(cfg)
     (tmp_path / "layer2.cfg").write_bytes(open(os.path.join(RES, "layer2.cfg"), "rb").read())
     subprocess.check_call([os.path.join(REF, "h264enc_ref"), "welsenc.cfg", "-bf", "ref.264"], cwd=str(tmp_path), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    env = dict(os.environ, WELSHIP_LIB=lib, WELS_HIP_TRACE="1")
+    env = dict(os.environ, WELSHIP_LIB=lib, WELS_HIP_TRACE="1", WELS_HIP_GOM="1")
     p = subprocess.run([H264ENC, "welsenc.cfg", "-bf", "hip.264"], cwd=str(tmp_path), env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
     err = p.stderr.decode(errors="replace")
     assert p.returncode == 0 and "welship hooks: installed" in err and err.count("welship hooks: did") >= 5, err[-2000:]
