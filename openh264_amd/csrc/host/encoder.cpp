@@ -11,6 +11,7 @@
 #include <string.h>
 #include <chrono>
 #include <condition_variable>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -660,8 +661,60 @@ struct WelsHipEncoder {
   WhPicJob* d_job = nullptr;
 };
 
+// The host threads of a session group (staging copies, entropy coding): started once, woken per step -- creating and joining
+// 2 x 32 threads per frame step cost more than a millisecond of every step.
+class WorkerPool {
+ public:
+  explicit WorkerPool (int n) { for (int t = 0; t < n; ++t) th_.emplace_back ([this, t] { loop (t); }); }
+  ~WorkerPool() {
+    { std::lock_guard<std::mutex> l (mu_); stop_ = true; }
+    cv_.notify_all();
+    for (auto& x : th_) x.join();
+  }
+  int size() const { return (int)th_.size(); }
+  // fn (t) for t in [0, size()) on the workers; returns when all are done
+  void run (const std::function<void (int)>& fn) {
+    std::unique_lock<std::mutex> l (mu_);
+    fn_ = &fn; remaining_ = (int)th_.size(); ++gen_;
+    cv_.notify_all();
+    done_.wait (l, [&] { return remaining_ == 0; });
+    fn_ = nullptr;
+  }
+ private:
+  void loop (int t) {
+    unsigned long seen = 0;
+    for (;;) {
+      const std::function<void (int)>* fn;
+      {
+        std::unique_lock<std::mutex> l (mu_);
+        cv_.wait (l, [&] { return stop_ || gen_ != seen; });
+        if (stop_) return;
+        seen = gen_; fn = fn_;
+      }
+      (*fn) (t);
+      std::lock_guard<std::mutex> l (mu_);
+      if (--remaining_ == 0) done_.notify_all();
+    }
+  }
+  std::vector<std::thread> th_;
+  std::mutex mu_;
+  std::condition_variable cv_, done_;
+  const std::function<void (int)>* fn_ = nullptr;
+  unsigned long gen_ = 0;
+  int remaining_ = 0;
+  bool stop_ = false;
+};
+
 struct WelsHipEncoderGroup {
   wh::Backend* be = nullptr;
+  std::unique_ptr<WorkerPool> pool;
+  // fn (t, T): worker t of T; inline when one thread is enough
+  void parallel (int n_items, const std::function<void (int, int)>& fn) {
+    const int T = host_threads < n_items ? host_threads : n_items;
+    if (T <= 1) { fn (0, 1); return; }
+    if (!pool || pool->size() != T) pool.reset (new WorkerPool (T));
+    pool->run ([&] (int t) { fn (t, T); });
+  }
   std::vector<std::unique_ptr<SessionCore>> sess;
   int queues = 1;                               // sessions are split into `queues` contiguous chunks, one device queue each
   int chunk_first (int q) const { return (int) ((long long)sess.size() * q / queues); }
@@ -989,14 +1042,7 @@ int WelsHipGroupFinish (WelsHipEncoderGroup* g, WelsHipFrameBSInfo* outs) {
   }
   for (auto& c : g->sess) c->upload_pending = false;
   std::vector<int> rcs (n, 0);
-  const int T = g->host_threads < n ? g->host_threads : n;
-  auto work = [&] (int t) { for (int i = t; i < n; i += T) { if (packed) g->sess[i]->expand_compact(); rcs[i] = g->sess[i]->finish_frame (outs ? &outs[i] : nullptr, 0); } };
-  if (T <= 1) work (0);
-  else {
-    std::vector<std::thread> th;
-    for (int t = 0; t < T; ++t) th.emplace_back (work, t);
-    for (auto& x : th) x.join();
-  }
+  g->parallel (n, [&] (int t, int T) { for (int i = t; i < n; i += T) { if (packed) g->sess[i]->expand_compact(); rcs[i] = g->sess[i]->finish_frame (outs ? &outs[i] : nullptr, 0); } });
   // sessions whose picture hit a CAVLC level overflow are re-encoded one at a time (rare: very low QP on extreme content)
   for (int i = 0; i < n; ++i) {
     SessionCore& c = *g->sess[i];
@@ -1028,16 +1074,7 @@ int WelsHipGroupEncodeFrames (WelsHipEncoderGroup* g, const WelsHipSourcePicture
   bool pending = false;
   for (int i = 0; i < n; ++i) pending = pending || g->sess[i]->upload_pending;
   if (pending) { g->be->sync(); for (auto& c : g->sess) c->upload_pending = false; }
-  {
-    const int T = g->host_threads < n ? g->host_threads : n;
-    auto work = [&] (int t) { for (int i = t; i < n; i += T) g->sess[i]->stage_source (&srcs[i]); };
-    if (T <= 1) work (0);
-    else {
-      std::vector<std::thread> th;
-      for (int t = 0; t < T; ++t) th.emplace_back (work, t);
-      for (auto& x : th) x.join();
-    }
-  }
+  g->parallel (n, [&] (int t, int T) { for (int i = t; i < n; i += T) g->sess[i]->stage_source (&srcs[i]); });
   for (int i = 0; i < n; ++i) { g->be->select_queue (g->chunk_of (i)); g->sess[i]->issue_upload (slot % g->sess[i]->ring); }
   int rc = WelsHipGroupBegin (g, slot);
   if (rc) return rc;
