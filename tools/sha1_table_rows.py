@@ -1,0 +1,50 @@
+"""Every device row of the reference's bitstream-regression table (test/encoder_binary_comparison/SHA1Table/
+BA_MW_D.264_AllCases_SHA1_Table.csv) through the dispatch-table binding, the way tests/test_hooks_sha1.py runs its sample.
+usage: sha1_table_rows.py [--lib path] [--workers N] [--stride K]      (default library: openh264_amd/libwelship.so)"""
+import argparse, os, pathlib, subprocess, sys, tempfile, time
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
+import test_hooks_sha1 as T
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--lib", default=os.path.join(ROOT, "openh264_amd", "libwelship.so"))
+    ap.add_argument("--workers", type=int, default=8)
+    ap.add_argument("--stride", type=int, default=1)
+    a = ap.parse_args()
+    a.lib = os.path.abspath(a.lib)
+    d = pathlib.Path(tempfile.mkdtemp())
+    subprocess.check_call([os.path.join(T.REF, "ref_dec"), os.path.join(T.RES, "BA_MW_D.264"), str(d / "BA_MW_D.264.yuv")], stdout=subprocess.DEVNULL)
+    for k in range(4):
+        (d / ("layer%d.cfg" % k)).write_bytes(open(os.path.join(T.RES, "layer2.cfg"), "rb").read())
+    (d / "welsenc.cfg").write_bytes(open(os.path.join(T.RES, "welsenc.cfg"), "rb").read())
+    rows = T._device_rows()[::a.stride]
+    t0 = time.time()
+
+    def one(ir):
+        i, r = ir
+        got, pics, err = T._run_row(d, a.lib, r, "w%d" % i)
+        os.remove(str(d / ("t_w%d.264" % i)))
+        return i, got == r[0] and pics >= 40, r[4]["-slcmd 0"], got, pics
+
+    bad, by_mode = [], {}
+    with ThreadPoolExecutor(a.workers) as ex:
+        for i, ok, mode, got, pics in ex.map(one, enumerate(rows)):
+            by_mode.setdefault(mode, [0, 0])
+            by_mode[mode][0] += 1
+            if not ok:
+                by_mode[mode][1] += 1
+                bad.append((i, rows[i][4], got, pics))
+    for mode in sorted(by_mode):
+        print("-slcmd %s : rows %d bad %d" % (mode, by_mode[mode][0], by_mode[mode][1]))
+    print("device rows %d of the table's %d, bad %d, %.1f s, %d workers, library %s" % (len(rows), len(T._rows()), len(bad), time.time() - t0, a.workers, os.path.basename(a.lib)))
+    for b in bad[:10]:
+        print("BAD", b)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
