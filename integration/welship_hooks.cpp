@@ -374,7 +374,7 @@ bool WelsHipSupported (const SWelsSvcCodingParam* p, const char** why) {
   if (p->iEntropyCodingModeFlag != 0) NO ("CABAC: the host writer needs mvd / cbp contexts the records do not carry yet");
   // simulcast AVC layers are independent streams (no inter-layer prediction): one device context per layer, optionally one
   // GPU per layer (WELS_HIP_LAYER_DEVICES=1: layer d runs on device WELS_HIP_DEVICE + d)
-  if (p->iSpatialLayerNum != 1 && !p->bSimulcastAVC) NO ("spatial layers with inter-layer prediction");
+  if (p->iSpatialLayerNum != 1 && !p->bSimulcastAVC) NO ("spatial layers with SVC syntax (tried: not byte-identical yet; simulcast AVC is)");
   if (p->iMultipleThreadIdc != 1) NO ("slice threads: the host loop is single-threaded in this binding");
   // bEnableAdaptiveQuant: ParamValidation switches it off for every session (encoder_ext.cpp:300-301), nothing to check
   const char* gom = getenv ("WELS_HIP_GOM");
