@@ -477,6 +477,7 @@ class HipBackend : public wh::Backend {
   ~HipBackend() override {
     (void)hipSetDevice (dev_);
     for (hipStream_t st : streams_) if (st) { (void)hipStreamSynchronize (st); (void)hipStreamDestroy (st); }
+    for (hipEvent_t ev : wait_ev_) if (ev) (void)hipEventDestroy (ev);
     for (auto& sl : slabs_) (void)hipFree (sl.base);
     if (err_) (void)hipFree (err_);
   }
@@ -590,7 +591,7 @@ class HipBackend : public wh::Backend {
     const size_t lds = (size_t)nw * sizeof (WhInterLds) + 4 * (size_t)slots * sched_words;
     uint16_t* grp = nullptr;
     uint32_t* cost = nullptr;
-    if (slots > 1 && use_assign && total <= 4096) {
+    if (slots > 1 && use_assign && total <= 4096 && stream_ == streams_[0]) {      // the cost / assignment buffers belong to queue 0
       if ((size_t)total > md_cap_) {
         if (md_cost_) { free (md_cost_); free (md_groups_); }
         md_cap_ = (size_t)total;
@@ -634,6 +635,15 @@ class HipBackend : public wh::Backend {
     hipLaunchKernelGGL (k_compact, dim3 (n), dim3 (1024), 0, stream_, P, jobs);
     HIP_TRY (hipGetLastError());
   }
+  void queue_wait (int from) override {
+    if (from < 0 || from >= (int)streams_.size() || streams_[from] == stream_ || !usable()) return;
+    if (wait_ev_.empty()) wait_ev_.assign (16, nullptr);
+    hipEvent_t& ev = wait_ev_[wait_next_++ % wait_ev_.size()];
+    if (!ev) HIP_TRY (hipEventCreateWithFlags (&ev, hipEventDisableTiming));
+    if (!ev) return;
+    HIP_TRY (hipEventRecord (ev, streams_[from]));
+    HIP_TRY (hipStreamWaitEvent (stream_, ev, 0));
+  }
   void select_queue (int k) override {
     HIP_TRY (hipSetDevice (dev_));
     while ((int)streams_.size() <= k) { hipStream_t st; HIP_TRY (hipStreamCreateWithFlags (&st, hipStreamNonBlocking)); streams_.push_back (st); }
@@ -653,6 +663,19 @@ class HipBackend : public wh::Backend {
     }
     return (int)e[0];
   }
+  int sync_queue (int k) override {
+    HIP_TRY (hipSetDevice (dev_));
+    if (k >= 0 && k < (int)streams_.size() && streams_[k]) HIP_TRY (hipStreamSynchronize (streams_[k]));
+    if (!usable()) return -1;
+    uint32_t e[4] = {0, 0, 0, 0};
+    HIP_TRY (hipMemcpy (e, err_, 16, hipMemcpyDeviceToHost));
+    if (!usable()) return -1;
+    if (e[0]) {
+      fprintf (stderr, "welship: %u in-kernel dependency waits timed out (first: block %u,%u waiting for MB index %u)\n", e[0], e[1], e[2], e[3]);
+      HIP_TRY (hipMemset (err_, 0, 16));
+    }
+    return (int)e[0];
+  }
   void* event_create() override { hipEvent_t e = nullptr; HIP_TRY (hipEventCreate (&e)); return (void*)e; }
   void event_destroy (void* ev) override { if (ev) HIP_TRY (hipEventDestroy ((hipEvent_t)ev)); }
   void event_record (void* ev) override { if (ev) HIP_TRY (hipEventRecord ((hipEvent_t)ev, stream_)); }
@@ -661,6 +684,8 @@ class HipBackend : public wh::Backend {
  private:
   int dev_;
   int cus_;
+  std::vector<hipEvent_t> wait_ev_;       // queue_wait: a small ring of events
+  size_t wait_next_ = 0;
   hipStream_t stream_ = nullptr;          // the selected queue
   std::vector<hipStream_t> streams_;
   uint32_t* err_ = nullptr;

@@ -35,7 +35,11 @@ class Backend {
   // different queues may overlap on the device.  sync() waits for all of them and returns 0, or the number of
   // in-kernel dependency waits that timed out since the last sync (the pictures of that step are then invalid).
   virtual void select_queue (int k) = 0;
+  // the selected queue waits (on the device, not the host) for everything issued so far on queue `from`
+  virtual void queue_wait (int from) { (void)from; }
   virtual int sync() = 0;
+  // the same for queue k only (other queues keep running)
+  virtual int sync_queue (int k) { (void)k; return sync(); }
   // timing on the stream the kernels are launched on (HIP events)
   virtual void* event_create() = 0;
   virtual void event_destroy (void* ev) = 0;

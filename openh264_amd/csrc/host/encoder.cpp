@@ -1145,12 +1145,15 @@ int WelsHipGroupProfile (WelsHipEncoderGroup* g, int enable, unsigned long long*
 // What the SWelsFuncPtrList hooks of the patched reference call: the reference owns the stream (frame types, reference
 // lists, rate control, entropy coding); this side owns device twins of its pictures and runs the per-macroblock passes.
 //
-// All frame contexts of a process that live on the same device share one backend (allocator + queue) and BATCH their
-// pictures: a thread that submits a picture while nobody is launching becomes the leader, takes everything that is pending
-// (pictures other sessions' threads submitted while the previous batch was on the device, or within a short gathering
-// window), issues ONE launch set per group of pictures with identical sequence parameters, waits for the device and wakes
-// the others.  Several sessions with rate control therefore cost the device one latency chain per batch instead of one per
-// session; a single session is a batch of one.  Pictures with GOM-level QP (MB ranges) run on their own.
+// All frame contexts of a process that live on the same device share one backend (allocator + queues) and BATCH their
+// pictures.  Pictures with identical sequence parameters and type form a KEY (the 720p P pictures of every session; each
+// layer size of simulcast sessions); every key has a queue of its own.  A thread that submits a picture while nobody is
+// launching for that key becomes its leader, takes everything pending for the key (pictures other sessions' threads
+// submitted while the key's previous batch was on the device, or within a short gathering window), issues ONE launch set,
+// waits for that queue and wakes the others.  Several sessions therefore cost the device one latency chain per batch
+// instead of one per session, and keys never wait for each other (a mixed batch would last as long as its largest
+// pictures: measured, 11 instead of 35 frames/s per simulcast session).  A single session is a batch of one.  Pictures with
+// GOM-level QP (MB ranges) run on their own.
 namespace {
 
 struct FrameLayout {           // processing-order / deblocking-band tables on the device, shared by the contexts that use them
@@ -1162,24 +1165,34 @@ struct FrameLayout {           // processing-order / deblocking-band tables on t
 };
 
 struct FrameItem;
+struct FrameKey {              // pictures that can share a launch: same sequence parameters, type and passes
+  WhSeqParams seq;
+  bool is_p = false, qp_map = false, expand = false;
+  int queue = 0;
+  std::vector<FrameItem*> pending;
+  bool leader_active = false;
+  FrameItem* next_leader = nullptr;
+  WhPicJob* d_jobs = nullptr;
+  int jobs_cap = 0;
+  std::vector<WhPicJob> h_jobs;          // page-locked
+};
 struct FrameShared {
   std::mutex mu;
   std::condition_variable cv;
   wh::Backend* be = nullptr;
   int device = 0, users = 0;
   std::vector<std::unique_ptr<FrameLayout>> layouts;
-  std::vector<FrameItem*> pending;
-  bool leader_active = false;
-  FrameItem* next_leader = nullptr;
-  WhPicJob* d_jobs = nullptr;
-  int jobs_cap = 0;
-  std::vector<WhPicJob> h_jobs;
+  std::vector<std::unique_ptr<FrameKey>> keys;
+  bool any_leader() const { for (auto& k : keys) if (k->leader_active) return true; return false; }
   // how long a leader waits for the other threads that have been submitting pictures lately.  Sessions that once end up in
   // different batches stay out of phase for good (each waits for the other's batch); one wait of about a picture's host
   // work merges them, after which they submit together and nobody waits
   int gather_us = 2000;
   std::vector<WelsHipFrameCtx*> ctxs;
   long batches = 0, batched_pictures = 0;
+  // WELSHIP_TRACE: per batch size, how many batches and how long they took on the device / spent gathering
+  std::vector<long> stat_n; std::vector<double> stat_dev_ms, stat_gather_ms, stat_launch_ms;
+  double stat_submit_ms = 0.0;
 };
 
 std::mutex g_frame_registry_mu;
@@ -1199,9 +1212,14 @@ struct WelsHipFrameCtx {
   WhMbRecord* d_records = nullptr;
   std::vector<WhMbRecord> h_records;
   std::vector<uint8_t> h_pic;
+  // page-locked staging for the small per-picture arrays of the caller (pageable copies block on the queue: with the shared
+  // lock held that stalls every other session): VAA SADs | pSadCost in | inter-layer hints | background flags, and pSadCost out
+  std::vector<uint8_t> h_aux, h_sad_out;
+  size_t aux_vaa = 0, aux_sad = 0, aux_il = 0, aux_bgd = 0;
   int h_pic_of = -1;                     // the device picture h_pic holds (copied back with the batch), or -1
-  std::thread::id last_tid;              // who submitted this context's last picture, and when (FrameShared::gather_us)
+  FrameKey* last_key = nullptr;          // the key of this context's last picture, and when it was submitted (FrameShared::gather_us)
   std::chrono::steady_clock::time_point last_submit;
+  int queue() const { return last_key ? last_key->queue : 0; }
   uint32_t* d_dbflags = nullptr;
   uint32_t db_gen = 0;
   WhMbCtl* d_mb_ctl = nullptr;
@@ -1224,6 +1242,8 @@ struct WelsHipFrameCtx {
     if (!h_records.empty()) be->unpin_host (h_records.data());
     if (!h_src.empty()) be->unpin_host (h_src.data());
     if (!h_pic.empty()) be->unpin_host (h_pic.data());
+    if (!h_aux.empty()) be->unpin_host (h_aux.data());
+    if (!h_sad_out.empty()) be->unpin_host (h_sad_out.data());
     be = nullptr;
   }
 
@@ -1283,50 +1303,45 @@ struct FrameItem {             // one submitted picture, owned by the submitting
   int rc = 0;
 };
 
-// the leader's work: everything in `batch` on the device, grouped by identical sequence parameters.  Called with sh->mu
-// held; releases it while the device works.
-void frame_run_batch (FrameShared* sh, std::unique_lock<std::mutex>& lock, std::vector<FrameItem*>& batch) {
+// the leader's work: the key's pending pictures in one launch set on the key's queue.  Called with sh->mu held; releases it
+// while the device works.
+void frame_run_batch (FrameShared* sh, FrameKey* K, std::unique_lock<std::mutex>& lock, std::vector<FrameItem*>& batch) {
   wh::Backend* be = sh->be;
+  const auto t_launch0 = std::chrono::steady_clock::now();
   const int n = (int)batch.size();
-  if (n > sh->jobs_cap) {
-    if (sh->d_jobs) be->free (sh->d_jobs);
-    sh->jobs_cap = std::max (16, 2 * n);
-    sh->d_jobs = (WhPicJob*)be->alloc (sizeof (WhPicJob) * sh->jobs_cap);
+  be->select_queue (K->queue);
+  if (n > K->jobs_cap) {
+    if (K->d_jobs) be->free (K->d_jobs);
+    if (!K->h_jobs.empty()) be->unpin_host (K->h_jobs.data());
+    K->jobs_cap = std::max (16, 2 * n);
+    K->d_jobs = (WhPicJob*)be->alloc (sizeof (WhPicJob) * K->jobs_cap);
+    K->h_jobs.assign (K->jobs_cap, WhPicJob());
+    be->pin_host (K->h_jobs.data(), sizeof (WhPicJob) * K->jobs_cap);
   }
-  int rc_all = sh->d_jobs ? WELSHIP_OK : WELSHIP_ERR_MEMORY;
+  int rc_all = K->d_jobs ? WELSHIP_OK : WELSHIP_ERR_MEMORY;
   if (rc_all == WELSHIP_OK) {
-    // groups of identical WhSeqParams and picture type, each a contiguous stretch of the job array
-    std::vector<FrameItem*> order;
-    std::vector<int> group_first;
-    std::vector<bool> taken (n, false);
-    for (int i = 0; i < n; ++i) if (!taken[i]) {
-      group_first.push_back ((int)order.size());
-      for (int k = i; k < n; ++k)
-        if (!taken[k] && batch[k]->is_p == batch[i]->is_p && batch[k]->qp_map == batch[i]->qp_map && batch[k]->expand == batch[i]->expand &&
-            memcmp (&batch[k]->seq, &batch[i]->seq, sizeof (WhSeqParams)) == 0) { taken[k] = true; order.push_back (batch[k]); }
-    }
-    group_first.push_back (n);
-    sh->h_jobs.resize (n);
-    for (int i = 0; i < n; ++i) sh->h_jobs[i] = order[i]->job;
-    be->upload (sh->d_jobs, sh->h_jobs.data(), sizeof (WhPicJob) * n);
-    for (size_t g = 0; g + 1 < group_first.size(); ++g) {
-      const int a = group_first[g], cnt = group_first[g + 1] - a;
-      const FrameItem& it = *order[a];
-      const WhSeqParams& s = it.seq;
-      if (it.is_p) be->run_inter (s, sh->d_jobs + a, cnt); else be->run_intra (s, sh->d_jobs + a, cnt);
-      if (it.qp_map) be->run_qp_chain (s, sh->d_jobs + a, cnt);
-      if (s.deblock_idc != 1) be->run_deblock (s, sh->d_jobs + a, cnt);
-      if (it.expand) be->run_expand (s, sh->d_jobs + a, cnt);
-    }
-    for (FrameItem* it : batch) {
-      WelsHipFrameCtx* c = it->c;
+    for (int i = 0; i < n; ++i) K->h_jobs[i] = batch[i]->job;
+    be->upload (K->d_jobs, K->h_jobs.data(), sizeof (WhPicJob) * n);
+    const WhSeqParams& s = K->seq;
+    if (K->is_p) be->run_inter (s, K->d_jobs, n); else be->run_intra (s, K->d_jobs, n);
+    if (K->qp_map) be->run_qp_chain (s, K->d_jobs, n);
+    if (s.deblock_idc != 1) be->run_deblock (s, K->d_jobs, n);
+    if (K->expand) be->run_expand (s, K->d_jobs, n);
+    for (FrameItem* x : batch) {
+      WelsHipFrameCtx* c = x->c;
       be->download (c->h_records.data(), c->d_records, sizeof (WhMbRecord) * c->num_mb);
-      be->download (c->h_pic.data(), c->pics[it->cur_pic].base, c->rec_alloc_bytes + 128);
-      if (it->sad_dst) be->download (it->sad_dst, c->d_sad_cost0, sizeof (int32_t) * c->num_mb);
+      be->download (c->h_pic.data(), c->pics[x->cur_pic].base, c->rec_alloc_bytes + 128);
+      if (x->sad_dst) be->download (c->h_sad_out.data(), c->d_sad_cost0, sizeof (int32_t) * c->num_mb);
     }
+    const double launch_ms = std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now() - t_launch0).count();
+    const int q = K->queue;
     lock.unlock();               // other sessions stage and queue their next pictures while the device works
-    const int bad = be->sync();
+    const auto t_dev0 = std::chrono::steady_clock::now();
+    const int bad = be->sync_queue (q);
+    const double dev_ms = std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now() - t_dev0).count();
     lock.lock();
+    if ((int)sh->stat_n.size() <= n) { sh->stat_n.resize (n + 1, 0); sh->stat_dev_ms.resize (n + 1, 0.0); sh->stat_gather_ms.resize (n + 1, 0.0); sh->stat_launch_ms.resize (n + 1, 0.0); }
+    ++sh->stat_n[n]; sh->stat_dev_ms[n] += dev_ms; sh->stat_launch_ms[n] += launch_ms;
     if (bad) rc_all = WELSHIP_ERR_UNKNOWN;
     ++sh->batches; sh->batched_pictures += n;
   }
@@ -1335,6 +1350,16 @@ void frame_run_batch (FrameShared* sh, std::unique_lock<std::mutex>& lock, std::
     if (rc_all == WELSHIP_OK) { it->c->pics[it->cur_pic].is_p = it->is_p; it->c->h_pic_of = it->cur_pic; }
     it->done = true;
   }
+}
+
+FrameKey* frame_find_key (FrameShared* sh, const WhSeqParams& s, bool is_p, bool qp_map, bool expand) {
+  for (auto& k : sh->keys)
+    if (k->is_p == is_p && k->qp_map == qp_map && k->expand == expand && memcmp (&k->seq, &s, sizeof (WhSeqParams)) == 0) return k.get();
+  std::unique_ptr<FrameKey> k (new FrameKey());
+  k->seq = s; k->is_p = is_p; k->qp_map = qp_map; k->expand = expand;
+  k->queue = (int) (sh->keys.size() % 8);          // keys beyond the eighth share queues (they only serialise, nothing breaks)
+  sh->keys.push_back (std::move (k));
+  return sh->keys.back().get();
 }
 
 }  // namespace
@@ -1417,6 +1442,11 @@ int WelsHipFrameCtxCreate (WelsHipFrameCtx** pp, const WelsHipFrameCfg* cfg) {
   be->pin_host (c->h_src.data(), c->h_src.size());
   c->h_pic.resize (c->rec_alloc_bytes + 128);                 // D2H target of the reconstruction (copied back with every batch)
   be->pin_host (c->h_pic.data(), c->h_pic.size());
+  c->aux_vaa = 0; c->aux_sad = (size_t)16 * c->num_mb; c->aux_il = c->aux_sad + (size_t)4 * c->num_mb; c->aux_bgd = c->aux_il + (size_t)8 * c->num_mb;
+  c->h_aux.assign (c->aux_bgd + (size_t)c->num_mb + 64, 0);
+  c->h_sad_out.assign ((size_t)4 * c->num_mb, 0);
+  be->pin_host (c->h_aux.data(), c->h_aux.size());
+  be->pin_host (c->h_sad_out.data(), c->h_sad_out.size());
   if (be->sync()) { set_err ("device error while setting up the frame context"); return fail (WELSHIP_ERR_UNKNOWN); }
   sh->ctxs.push_back (c);
   *pp = c;
@@ -1428,16 +1458,21 @@ void WelsHipFrameCtxDestroy (WelsHipFrameCtx* c) {
   FrameShared* sh = c->sh;
   {
     std::unique_lock<std::mutex> lock (sh->mu);
-    sh->cv.wait (lock, [&] { return !sh->leader_active; });
     sh->ctxs.erase (std::remove (sh->ctxs.begin(), sh->ctxs.end(), c), sh->ctxs.end());
     c->release_locked();
   }
   delete c;
   std::lock_guard<std::mutex> reg (g_frame_registry_mu);
   if (--sh->users == 0) {
-    if (getenv ("WELSHIP_TRACE") && sh->batches) fprintf (stderr, "welship: frame API on device %d: %ld pictures in %ld batches\n", sh->device, sh->batched_pictures, sh->batches);
+    if ((getenv ("WELSHIP_TRACE") || getenv ("WELSHIP_FRAME_STATS")) && sh->batches) {
+      fprintf (stderr, "welship: frame API on device %d: %ld pictures in %ld batches\n", sh->device, sh->batched_pictures, sh->batches);
+      for (size_t k = 1; k < sh->stat_n.size(); ++k) if (sh->stat_n[k])
+        fprintf (stderr, "welship:   batches of %zu: %ld, issuing %.3f ms, device wait %.3f ms, gathering %.3f ms on average\n", k, sh->stat_n[k],
+                 sh->stat_launch_ms[k] / sh->stat_n[k], sh->stat_dev_ms[k] / sh->stat_n[k], sh->stat_gather_ms[k] / sh->stat_n[k]);
+      fprintf (stderr, "welship:   submitting (uploads under the lock): %.3f ms per picture\n", sh->stat_submit_ms / sh->batched_pictures);
+    }
     for (auto& L : sh->layouts) { sh->be->free (L->d_order); sh->be->free (L->d_bands); }
-    if (sh->d_jobs) sh->be->free (sh->d_jobs);
+    for (auto& K : sh->keys) { if (K->d_jobs) sh->be->free (K->d_jobs); if (!K->h_jobs.empty()) sh->be->unpin_host (K->h_jobs.data()); }
     delete sh->be;
     g_frame_shared.erase (std::find (g_frame_shared.begin(), g_frame_shared.end(), sh));
     delete sh;
@@ -1471,6 +1506,12 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
       memcpy (v + (size_t)r * s0.src_stride_c, j->pSrc[2] + (size_t)r * j->iSrcStride[2], (size_t)c->mb_w * 8);
     }
   }
+  if (first_part) {
+    if (is_p && j->pVaaSad8x8) memcpy (c->h_aux.data() + c->aux_vaa, j->pVaaSad8x8, sizeof (int32_t) * 4 * c->num_mb);
+    if (is_p && j->pBgdFlags) memcpy (c->h_aux.data() + c->aux_bgd, j->pBgdFlags, (size_t)c->num_mb);
+    if (is_p && j->pIlHint) memcpy (c->h_aux.data() + c->aux_il, j->pIlHint, sizeof (int16_t) * 4 * c->num_mb);
+    if (j->pSadCost) memcpy (c->h_aux.data() + c->aux_sad, j->pSadCost, sizeof (int32_t) * c->num_mb);
+  }
   bool qp_map = false;
   if (j->pMbQp) {
     for (int i = 0; i < c->num_mb; ++i) { memset (&c->h_mb_ctl[i], 0, sizeof (WhMbCtl)); c->h_mb_ctl[i].qp_delta = (int8_t) ((int)j->pMbQp[i] - j->iQp); }
@@ -1478,7 +1519,7 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
   }
 
   std::unique_lock<std::mutex> lock (sh->mu);
-  if (ranged) sh->cv.wait (lock, [&] { return !sh->leader_active; });        // MB ranges run on their own, with the queue to themselves
+  const auto t_sub0 = std::chrono::steady_clock::now();
   int rc = c->set_layout (j->iNumSlices, j->pSliceFirstMb, j->iDeblockIdc);
   if (rc) return rc;
   WhSeqParams& s = c->seq;
@@ -1487,12 +1528,16 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
   s.chroma_qp_offset = j->iChromaQpIndexOffset;
   s.alpha_offset = j->iAlphaOffset; s.beta_offset = j->iBetaOffset;
   s.mv_range = j->iMvRange;
+  // the pictures this one can share a launch with, and the queue they use (MB ranges: queue 0, on their own)
+  FrameKey* K = ranged ? nullptr : frame_find_key (sh, s, is_p, qp_map, j->bExpand != 0);
+  const int queue = K ? K->queue : 0;
+  be->select_queue (queue);
   if (first_part) {
     be->upload (c->d_src, c->h_src.data(), c->src_bytes);
-    if (is_p && j->pVaaSad8x8) be->upload (c->d_vaa, j->pVaaSad8x8, sizeof (int32_t) * 4 * c->num_mb);
-    if (is_p && j->pBgdFlags) be->upload (c->d_bgd, j->pBgdFlags, (size_t)c->num_mb);
-    if (is_p && j->pIlHint) be->upload (c->d_il, j->pIlHint, sizeof (int16_t) * 4 * c->num_mb);
-    if (j->pSadCost) be->upload (c->d_sad_cost0, j->pSadCost, sizeof (int32_t) * c->num_mb);
+    if (is_p && j->pVaaSad8x8) be->upload (c->d_vaa, c->h_aux.data() + c->aux_vaa, sizeof (int32_t) * 4 * c->num_mb);
+    if (is_p && j->pBgdFlags) be->upload (c->d_bgd, c->h_aux.data() + c->aux_bgd, (size_t)c->num_mb);
+    if (is_p && j->pIlHint) be->upload (c->d_il, c->h_aux.data() + c->aux_il, sizeof (int16_t) * 4 * c->num_mb);
+    if (j->pSadCost) be->upload (c->d_sad_cost0, c->h_aux.data() + c->aux_sad, sizeof (int32_t) * c->num_mb);
     if (++c->db_gen == 0) c->db_gen = 1;
     c->h_pic_of = -1;
   }
@@ -1524,7 +1569,7 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
     be->upload (c->d_job, &job, sizeof (job));
     if (is_p) be->run_inter (s, c->d_job, 1); else be->run_intra (s, c->d_job, 1);
     if (last_part) {
-      job.mb_begin = 0; job.mb_end = 0; be->sync(); be->upload (c->d_job, &job, sizeof (job));
+      job.mb_begin = 0; job.mb_end = 0; be->sync_queue (queue); be->upload (c->d_job, &job, sizeof (job));
       if (qp_map) be->run_qp_chain (s, c->d_job, 1);           // QP_Y for the filter and pRefMbQp of decided skips
       if (s.deblock_idc != 1) be->run_deblock (s, c->d_job, 1);
       if (j->bExpand) be->run_expand (s, c->d_job, 1);
@@ -1532,7 +1577,7 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
       if (j->pSadCost) be->download (j->pSadCost, c->d_sad_cost0, sizeof (int32_t) * c->num_mb);
     }
     be->download (c->h_records.data() + j->iMbBegin, c->d_records + j->iMbBegin, sizeof (WhMbRecord) * (size_t) (j->iMbEnd - j->iMbBegin));
-    if (be->sync()) { set_err ("device scheduler timed out or device error; the picture was not encoded"); return WELSHIP_ERR_UNKNOWN; }
+    if (be->sync_queue (queue)) { set_err ("device scheduler timed out or device error; the picture was not encoded"); return WELSHIP_ERR_UNKNOWN; }
     *pp_records = c->h_records.data();
     return WELSHIP_OK;
   }
@@ -1540,38 +1585,42 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
   FrameItem item;
   item.c = c; item.seq = s; item.job = job; item.is_p = is_p; item.qp_map = qp_map; item.expand = j->bExpand != 0;
   item.cur_pic = j->iCurPic; item.sad_dst = j->pSadCost;
-  c->last_tid = std::this_thread::get_id();
+  c->last_key = K;
   c->last_submit = std::chrono::steady_clock::now();
-  sh->pending.push_back (&item);
-  if (sh->leader_active) sh->cv.notify_all();          // a gathering leader may have been waiting for exactly this picture
+  sh->stat_submit_ms += std::chrono::duration<double, std::milli> (c->last_submit - t_sub0).count();
+  K->pending.push_back (&item);
+  if (K->leader_active) sh->cv.notify_all();           // a gathering leader may have been waiting for exactly this picture
   for (;;) {
     if (item.done) break;
-    if (!sh->leader_active && (sh->next_leader == nullptr || sh->next_leader == &item)) {
-      // this thread launches: whatever is pending now plus what arrives within the gathering window
-      sh->leader_active = true;
-      sh->next_leader = nullptr;
+    if (!K->leader_active && (K->next_leader == nullptr || K->next_leader == &item)) {
+      // this thread launches for the key: whatever is pending now plus what arrives within the gathering window
+      K->leader_active = true;
+      K->next_leader = nullptr;
+      const auto t_g0 = std::chrono::steady_clock::now();
       if (sh->gather_us > 0 && sh->ctxs.size() > 1) {
-        // threads that submitted a picture within the last 100 ms (a thread has one picture pending at most; the layers of a
-        // simulcast session come from one thread, one after the other)
+        // the contexts whose last picture (within 100 ms) had this key: their next one is probably on its way
         const auto now = std::chrono::steady_clock::now();
-        std::vector<std::thread::id> tids;
-        for (WelsHipFrameCtx* x : sh->ctxs)
-          if (now - x->last_submit < std::chrono::milliseconds (100) && std::find (tids.begin(), tids.end(), x->last_tid) == tids.end()) tids.push_back (x->last_tid);
-        const size_t expected = tids.size();
-        if (sh->pending.size() < expected)
-          sh->cv.wait_for (lock, std::chrono::microseconds (sh->gather_us), [&] { return sh->pending.size() >= expected; });
+        size_t expected = 0;
+        for (WelsHipFrameCtx* x : sh->ctxs) if (x->last_key == K && now - x->last_submit < std::chrono::milliseconds (100)) ++expected;
+        if (K->pending.size() < expected)
+          sh->cv.wait_for (lock, std::chrono::microseconds (sh->gather_us), [&] { return K->pending.size() >= expected; });
       }
       std::vector<FrameItem*> batch;
-      batch.swap (sh->pending);
-      frame_run_batch (sh, lock, batch);
-      sh->leader_active = false;
-      if (!sh->pending.empty()) sh->next_leader = sh->pending.front();     // pictures that arrived meanwhile: their first submitter goes next
+      batch.swap (K->pending);
+      const double gather_ms = std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now() - t_g0).count();
+      const size_t bn = batch.size();
+      frame_run_batch (sh, K, lock, batch);
+      if (bn < sh->stat_gather_ms.size()) sh->stat_gather_ms[bn] += gather_ms;
+      K->leader_active = false;
+      if (!K->pending.empty()) K->next_leader = K->pending.front();        // pictures that arrived meanwhile: their first submitter goes next
       sh->cv.notify_all();
       continue;
     }
     sh->cv.wait (lock);
   }
   if (item.rc) { set_err ("device scheduler timed out or device error; the picture was not encoded"); return item.rc; }
+  lock.unlock();
+  if (j->pSadCost) memcpy (j->pSadCost, c->h_sad_out.data(), sizeof (int32_t) * c->num_mb);
   *pp_records = c->h_records.data();
   return WELSHIP_OK;
 }
@@ -1579,9 +1628,9 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
 int WelsHipFrameGetMbStates (WelsHipFrameCtx* c, int pic, void* dst, size_t bytes) {
   if (!c || !c->be || pic < 0 || pic >= (int)c->pics.size() || !dst || bytes < sizeof (WhMbState) * c->num_mb) return WELSHIP_ERR_INIT_PARA;
   std::unique_lock<std::mutex> lock (c->sh->mu);
-  c->sh->cv.wait (lock, [&] { return !c->sh->leader_active; });
+  c->be->select_queue (c->queue());
   c->be->download (dst, c->pics[pic].mbs, sizeof (WhMbState) * c->num_mb);
-  return c->be->sync() ? WELSHIP_ERR_UNKNOWN : WELSHIP_OK;
+  return c->be->sync_queue (c->queue()) ? WELSHIP_ERR_UNKNOWN : WELSHIP_OK;
 }
 
 int WelsHipFrameGetPicture (WelsHipFrameCtx* c, int pic, uint8_t* const dst[3], const int32_t stride[3]) {
@@ -1591,9 +1640,9 @@ int WelsHipFrameGetPicture (WelsHipFrameCtx* c, int pic, uint8_t* const dst[3], 
   const DevPicture& p = c->pics[pic];
   if (c->h_pic_of != pic) {              // not the picture that came back with the last batch (GOM-coded pictures, older pictures)
     std::unique_lock<std::mutex> lock (c->sh->mu);
-    c->sh->cv.wait (lock, [&] { return !c->sh->leader_active; });
+    c->be->select_queue (c->queue());
     c->be->download (tmp.data(), p.base, c->rec_alloc_bytes + 128);
-    if (c->be->sync()) return WELSHIP_ERR_UNKNOWN;
+    if (c->be->sync_queue (c->queue())) return WELSHIP_ERR_UNKNOWN;
     c->h_pic_of = pic;
   }
   const uint8_t* y = tmp.data() + (p.plane[0] - p.base);

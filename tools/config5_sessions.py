@@ -11,15 +11,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = os.path.join(ROOT, "oracle", "_ref")
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 FRAMES = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+# third argument "simulcast": BASELINE config 4's shape instead -- every session a 1080p input coded as four simulcast AVC layers
+# (1920x1080, 960x540, 480x270, 240x135; four slices each), all layers on this one GPU
+SIMULCAST = len(sys.argv) > 3 and sys.argv[3] == "simulcast"
 LIB = os.environ.get("WELSHIP_LIB") or os.path.join(ROOT, "openh264_amd", "libwelship.so")
-W, H = 1280, 720
+W, H = (1920, 1080) if SIMULCAST else (1280, 720)
 
 
 def run(tmp, yuv, hip):
     env = dict(os.environ, WELSHIP_LIB=LIB, WELS_HIP="1" if hip else "0", WELS_HIP_TRACE="1")
     out = os.path.join(tmp, "s_%d.264" % hip)
     cmd = [os.path.join(REF, "ref_enc_hip"), "-parallel", str(N), "-i", yuv, "-w", str(W), "-h", str(H), "-o", out, "-frames", str(FRAMES),
-           "-fps", "30", "-rc", "1", "-bitrate", "1500000", "-slcmd", "2", "-slcmbnum", "900", "-threads", "1", "-iper", "0", "-quiet"]
+           "-fps", "30", "-rc", "1", "-bitrate", "1500000", "-threads", "1", "-iper", "0", "-quiet"]
+    cmd += (["-slcmd", "1", "-slcnum", "4", "-simulcast", "240", "135", "-simulcast", "480", "270", "-simulcast", "960", "540"] if SIMULCAST
+            else ["-slcmd", "2", "-slcmbnum", "900"])
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert p.returncode == 0, p.stderr[-2000:]
     enc_fps = [float(x) for x in re.findall(rb" fps=([0-9.]+)", p.stdout)]
@@ -33,11 +38,11 @@ def run(tmp, yuv, hip):
 def main():
     with tempfile.TemporaryDirectory() as tmp:
         yuv = os.path.join(tmp, "clip.yuv")
-        subprocess.check_call([os.path.join(REF, "ref_dec"), os.path.join(REF, "res", "VID_1280x720_cavlc_temporal_direct.264"), yuv], stdout=subprocess.DEVNULL)
+        subprocess.check_call([os.path.join(REF, "ref_dec"), os.path.join(REF, "res", "VID_%dx%d_cavlc_temporal_direct.264" % (W, H)), yuv], stdout=subprocess.DEVNULL)
         nfr = os.path.getsize(yuv) // (W * H * 3 // 2)
         c_leg, c_sha = run(tmp, yuv, False)
         h_leg, h_sha = run(tmp, yuv, True)
-        print(json.dumps({"config": "%d concurrent sessions, %dx%d, %d frames each (clip has %d), RC bitrate mode 1.5 Mbps, raster slices of 900 MBs, one process, one thread per session" % (N, W, H, FRAMES, nfr),
+        print(json.dumps({"config": "%d concurrent sessions, %dx%d, %d frames each (clip has %d), RC bitrate mode 1.5 Mbps per layer, %s, one process, one thread per session" % (N, W, H, FRAMES, nfr, "4 simulcast AVC layers of 4 slices" if SIMULCAST else "raster slices of 900 MBs"),
                           "reference_c_path": c_leg, "hooks_on_device": h_leg, "same_bitstreams": c_sha == h_sha, "lib": os.path.basename(LIB)}))
 
 
