@@ -134,15 +134,15 @@ def test_hip_4k(hip_lib, ref_tools, tmp_path):
 @pytest.mark.gpu
 @pytest.mark.parametrize("waves", ["6", "8", "12"])
 def test_hip_wave_variants(waves, hip_lib):
-    """The P kernel exists in three workgroup geometries (6 / 12 waves per slice, 8 with window staging); the backend picks
-    one from the launch size, so each is forced here (the choice is read once per process) and must give the same bits."""
+    """The mode-decision pool runs with 12 waves per workgroup by default (k_inter_pool<768>; 6 and fewer use the <384>
+    instantiation); the count is forced here (read once per process) and must give the same bits."""
     import sys
     name = "p_640x368_qp24_4slices"
     g = GOLDEN[name]
     code = ("import hashlib, sys; sys.path.insert(0, %r); import openh264_amd as oh; from openh264_amd.utils.synth import make_sequence, synth_sequence;"
             "yuv = synth_sequence(%d, %d, %d); bs, _ = oh.encode_sequence(yuv, %d, %d, lib_path=%r, fMaxFrameRate=30.0, iTargetBitrate=5000000, **%r);"
             "print(hashlib.sha1(bs).hexdigest())") % (ROOT, g["w"], g["h"], g["frames"], g["w"], g["h"], hip_lib, g["params"])
-    env = dict(os.environ, WELSHIP_P_WAVES=waves, WELSHIP_P_LOOKAHEAD="1" if waves == "8" else "0")
+    env = dict(os.environ, WELSHIP_P_WAVES=waves)
     out = subprocess.check_output([sys.executable, "-c", code], env=env).decode().split()[-1]
     assert out == g["sha1"]
 
