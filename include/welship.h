@@ -206,6 +206,24 @@ typedef struct WelsHipFrameCfg {
   int32_t iNumPictures;             /* device pictures: the reference pool + the picture being coded (AllocPicture count)      */
   int32_t reserved[4];
 } WelsHipFrameCfg;
+/* Screen content (iUsageType == SCREEN_CONTENT_REAL_TIME), P pictures: what the reference's pre-processing and PreprocessSliceCoding
+ * (encoder_ext.cpp:2700-2765) hand to WelsMdInterJudgeSCDPskip / WelsMdInterFinePartitionVaaOnScreen (svc_mode_decision.cpp:326-667)
+ * and to the cross / feature searches (svc_motion_estimate.cpp:380-1097).  All pointers are host memory of the caller. */
+typedef struct WelsHipScreenInfo {
+  const uint8_t* pBlockStaticIdc;       /* pVaaExt->pVaaBestBlockStaticIdc: EStaticBlockIdc per 8x8 luma block, [2 * mb_h][2 * mb_w]          */
+  const uint8_t* pRefOriChroma[2];      /* pCurDqLayer->pRefOri[0]->pData[1], [2]: chroma of the reference picture's SOURCE, or NULL          */
+  int32_t iRefOriStride;
+  int32_t bScrollDetectFlag, iScrollMvX, iScrollMvY;   /* pVaaExt->sScrollDetectInfo                                                         */
+  uint32_t uiSadCostThreshold16x16, uiSadCostThreshold8x8;   /* pRefPic->pScreenBlockFeatureStorage->uiSadCostThreshold[BLOCK_16x16 / _8x8]  */
+  int32_t bFeatureSearch8x8;            /* pfSearchMethod[BLOCK_8x8] == WelsDiamondCrossFeatureSearch for this picture                       */
+  /* the reference picture's SScreenBlockFeatureStorage as PerformFMEPreprocess built it (svc_motion_estimate.cpp:839-873); read only   */
+  /* with bFeatureSearch8x8                                                                                                              */
+  const uint32_t* pTimesOfFeatureValue; /* [iListSize]                                                                                       */
+  uint16_t* const* pLocationOfFeature;  /* [iListSize] pointers into pLocationPointer                                                        */
+  const uint16_t* pLocationPointer;     /* {x << 2, y << 2} of every 8x8 block position, iLocationEntries entries                            */
+  int32_t iListSize, iLocationEntries;
+  uint32_t* pSliceFMECostDown;          /* out, [iNumSlices]: what the picture adds to each pSlice->uiSliceFMECostDown                       */
+} WelsHipScreenInfo;
 typedef struct WelsHipFrameJob {
   int32_t iCurPic, iRefPic;         /* device picture indices (0 .. iNumPictures-1); iRefPic < 0: I picture                    */
   int32_t eSliceType;               /* 0 = P_SLICE, 2 = I_SLICE (slice_type values of the standard)                            */
@@ -232,7 +250,8 @@ typedef struct WelsHipFrameJob {
   int32_t* pSadCost;                /* pSadCost[0] of every MB (pEncCtx->pSadCostMb, encoder_ext.cpp:900,1675 -- ONE array for all the    */
                                     /* spatial layers of a session): copied to the device before the picture and back after it, or NULL:  */
                                     /* the context keeps its own (single-layer sessions)                                                 */
-  int32_t reserved[2];
+  const WelsHipScreenInfo* pScreen; /* screen-content P pictures, else NULL (I pictures of a screen-content session: iComplexityMode >= 1, */
+                                    /* PreprocessSliceCoding selects the SATD / full-search intra functions for them)                       */
 } WelsHipFrameJob;
 int  WelsHipFrameCtxCreate (WelsHipFrameCtx** ppCtx, const WelsHipFrameCfg* pCfg);
 void WelsHipFrameCtxDestroy (WelsHipFrameCtx* pCtx);

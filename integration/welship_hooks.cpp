@@ -39,6 +39,7 @@
 #include "svc_enc_slice_segment.h"
 #include "svc_encode_slice.h"
 #include "svc_base_layer_md.h"
+#include "svc_motion_estimate.h"
 #include "svc_set_mb_syn.h"
 #include "svc_enc_golomb.h"
 #include "rc.h"
@@ -92,6 +93,8 @@ struct HipLayer {                       // one spatial layer = one device contex
   std::vector<int32_t> first;
   std::vector<uint8_t> mb_qp;
   int coded_upto = 0;
+  WelsHipScreenInfo screen;              // screen content: the pre-processing's results of the picture being coded
+  std::vector<uint32_t> fme_down;        //   and what the device reports back per slice (uiSliceFMECostDown)
   std::vector<int16_t> il_hint;          // highest layer of a multi-layer session: hints from the layer below
   std::vector<WhMbState> states;         // lower layers of a multi-layer session: the device's motion data, for the layer above
 };
@@ -144,7 +147,7 @@ int32_t HipFrameMd (sWelsEncCtx* pCtx) {
     memset (&cfg, 0, sizeof (cfg));
     cfg.iDevice = st->device + (st->layer_devices ? did : 0);
     cfg.iPicWidth = mbw * 16; cfg.iPicHeight = mbh * 16;
-    cfg.iNumPictures = pParam->iNumRefFrame + 2;          // RequestMemorySvc allocates 1 + iNumRefFrame pictures per layer
+    cfg.iNumPictures = WELS_MAX (pParam->iNumRefFrame, pParam->iMaxNumRefFrame) + 2;    // RequestMemorySvc allocates 1 + iMaxNumRefFrame pictures per layer
     L.num_pictures = cfg.iNumPictures;
     const int rc = g_api.FrameCtxCreate (&L.ctx, &cfg);
     if (rc) { fprintf (stderr, "welship hooks: no device context (%d: %s)\n", rc, g_api.GetLastError()); st->failed = true; return ENC_RETURN_UNEXPECTED; }
@@ -204,6 +207,42 @@ int32_t HipFrameMd (sWelsEncCtx* pCtx) {
       }
     job.pIlHint = &L.il_hint[0];
   }
+  job.pScreen = NULL;
+  if (pParam->iUsageType == SCREEN_CONTENT_REAL_TIME) {
+    if (!is_p) {
+      // PreprocessSliceCoding (encoder_ext.cpp:2664-2671): I pictures of a screen-content session always use the SATD costs and the
+      // full Intra4x4 search, whatever the complexity mode
+      if (job.iComplexityMode == 0) job.iComplexityMode = 1;
+    } else {
+      // what the P picture's mode decision and motion estimation take from the pre-processing (scene-change / scroll detection against
+      // the best reference candidate, wels_preprocess.cpp:1087-1240) and from PreprocessSliceCoding (encoder_ext.cpp:2700-2765)
+      WelsHipScreenInfo& scr = L.screen;
+      memset (&scr, 0, sizeof (scr));
+      SVAAFrameInfoExt* pVaaExt = static_cast<SVAAFrameInfoExt*> (pCtx->pVaa);
+      scr.pBlockStaticIdc = pVaaExt->pVaaBestBlockStaticIdc;
+      const SPicture* pRefOri = pCurLayer->pRefOri[0];
+      if (pRefOri != NULL && pRefOri->pData[1] != NULL) {
+        // JudgeStaticSkip / JudgeScrollSkip address the reference's source picture with the CURRENT picture's chroma stride
+        if (pRefOri->iLineSize[1] != pCurLayer->iEncStride[1]) { fprintf (stderr, "welship hooks: source pictures with different strides\n"); st->failed = true; return ENC_RETURN_UNEXPECTED; }
+        scr.pRefOriChroma[0] = pRefOri->pData[1]; scr.pRefOriChroma[1] = pRefOri->pData[2]; scr.iRefOriStride = pRefOri->iLineSize[1];
+      }
+      scr.bScrollDetectFlag = pVaaExt->sScrollDetectInfo.bScrollDetectFlag ? 1 : 0;
+      scr.iScrollMvX = pVaaExt->sScrollDetectInfo.iScrollMvX; scr.iScrollMvY = pVaaExt->sScrollDetectInfo.iScrollMvY;
+      const SScreenBlockFeatureStorage* pSt = pCurLayer->pRefPic->pScreenBlockFeatureStorage;
+      scr.uiSadCostThreshold16x16 = pSt ? pSt->uiSadCostThreshold[BLOCK_16x16] : 0xffffffffu;
+      scr.uiSadCostThreshold8x8 = pSt ? pSt->uiSadCostThreshold[BLOCK_8x8] : 0xffffffffu;
+      scr.bFeatureSearch8x8 = (pSt != NULL && pFunc->pfSearchMethod[BLOCK_8x8] == WelsDiamondCrossFeatureSearch) ? 1 : 0;
+      if (scr.bFeatureSearch8x8) {
+        scr.pTimesOfFeatureValue = pSt->pTimesOfFeatureValue; scr.pLocationOfFeature = pSt->pLocationOfFeature; scr.pLocationPointer = pSt->pLocationPointer;
+        scr.iListSize = pSt->iActualListSize;
+        const SSpatialLayerConfig& lc = pParam->sSpatialLayers[did];
+        scr.iLocationEntries = (lc.iVideoWidth - 8) * (lc.iVideoHeight - 8);      // RequestScreenBlockFeatureStorage (svc_motion_estimate.cpp:692-706)
+      }
+      L.fme_down.assign (nslices, 0u);
+      scr.pSliceFMECostDown = &L.fme_down[0];
+      job.pScreen = &scr;
+    }
+  }
   if (L.gom) {
     if (nslices != 1) { fprintf (stderr, "welship hooks: GOM-level QP with %d slices\n", nslices); st->failed = true; return ENC_RETURN_UNEXPECTED; }
     L.mb_qp.assign (num_mb, (uint8_t)pCtx->iGlobalQp);
@@ -256,6 +295,7 @@ void LoadRecord (const WhMbRecord& R, SMB* pMb, SMbCache* pMbCache) {
   for (int i = 0; i < 8; ++i) pMb->pNonZeroCount[kC[i]] = (int8_t)R.nzc[16 + i];
   pMbCache->uiLumaI16x16Mode = R.i16_mode;
   pMbCache->uiChmaI8x8Mode = R.chroma_mode;
+  pMb->uiChromPredMode = R.chroma_mode;      // WelsMdIntraSecondaryModesEnc / WelsMdFirstIntraMode leave it for the CABAC contexts of the neighbours
   if (R.mb_type == WH_MB_I4x4) {
     // luma4x4BlkIdx order on both sides (pPrevIntra4x4PredModeFlag / pRemIntra4x4PredModeFlag are written in coding order)
     for (int i = 0; i < 16; ++i) { pMbCache->pPrevIntra4x4PredModeFlag[i] = ((R.i4_prev_flags >> i) & 1) != 0; pMbCache->pRemIntra4x4PredModeFlag[i] = R.i4_rem[i]; }
@@ -280,6 +320,9 @@ int32_t HipCodeSlice (sWelsEncCtx* pCtx, SSlice* pSlice) {
   int32_t iNextMbIdx = kiSliceFirstMbXY, iNumMbCoded = 0;
   static_assert (sizeof (SDCTCoeff) == 816, "SDCTCoeff layout");
   if (is_p) pSlice->iMbSkipRun = 0;
+  // CABAC: the slice's arithmetic coder starts here, as in WelsISliceMdEnc / WelsMdInterMbLoop (svc_encode_slice.cpp:550-554,1824-1828);
+  // the writer (WelsSpatialWriteMbSynCabac) derives its contexts from what it wrote for the neighbours (sMvd, iCbpDc, types)
+  if (pCtx->pSvcParam->iEntropyCodingModeFlag) WelsInitSliceCabac (pCtx, pSlice);
   for (;;) {
     const int32_t iCurMbIdx = iNextMbIdx;
     SMB* pCurMb = &pMbList[iCurMbIdx];
@@ -346,6 +389,8 @@ int32_t HipCodeSlice (sWelsEncCtx* pCtx, SSlice* pSlice) {
     if (iNextMbIdx == -1 || iNextMbIdx >= kiTotalNumMb || iNumMbCoded >= kiTotalNumMb) break;
   }
   if (is_p && pSlice->iMbSkipRun) BsWriteUE (pSlice->pSliceBsa, pSlice->iMbSkipRun);
+  // WelsDiamondCrossFeatureSearch's account of what the feature search saved (svc_motion_estimate.cpp:1080-1092), read by UpdateFMESwitch
+  if (is_p && L.job.pScreen != NULL && kiSliceIdx >= 0 && kiSliceIdx < (int32_t)L.fme_down.size()) pSlice->uiSliceFMECostDown += L.fme_down[kiSliceIdx];
   // for the layer above: this slice's real motion vectors in the SMB array (the writer above was fed vector differences)
   if (!L.states.empty()) {
     int32_t iMb = kiSliceFirstMbXY;
@@ -370,8 +415,9 @@ void HipRelease (void* p) {
 // Which sessions run on the device.  `why` receives the reason when the answer is no.
 bool WelsHipSupported (const SWelsSvcCodingParam* p, const char** why) {
 #define NO(msg) do { *why = msg; return false; } while (0)
-  if (p->iUsageType != CAMERA_VIDEO_REAL_TIME) NO ("screen content (feature / scroll search) stays on the C path");
-  if (p->iEntropyCodingModeFlag != 0) NO ("CABAC: the host writer needs mvd / cbp contexts the records do not carry yet");
+  if (p->iUsageType != CAMERA_VIDEO_REAL_TIME && p->iUsageType != SCREEN_CONTENT_REAL_TIME) NO ("usage types beyond camera video and screen content");
+  if (p->iUsageType == SCREEN_CONTENT_REAL_TIME && getenv ("WELS_HIP_SCREEN") && atoi (getenv ("WELS_HIP_SCREEN")) == 0) NO ("screen content switched off (WELS_HIP_SCREEN=0)");
+  if (p->iEntropyCodingModeFlag != 0 && getenv ("WELS_HIP_CABAC") && atoi (getenv ("WELS_HIP_CABAC")) == 0) NO ("CABAC switched off (WELS_HIP_CABAC=0)");
   // simulcast AVC layers are independent streams (no inter-layer prediction): one device context per layer, optionally one
   // GPU per layer (WELS_HIP_LAYER_DEVICES=1: layer d runs on device WELS_HIP_DEVICE + d)
   if (p->iSpatialLayerNum != 1 && !p->bSimulcastAVC) NO ("spatial layers with SVC syntax (tried: not byte-identical yet; simulcast AVC is)");

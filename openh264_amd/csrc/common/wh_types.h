@@ -86,6 +86,27 @@ typedef struct WhMbCtl {
   int16_t  cell12_mv[2];     //   which the 16x8 lower-partition predictor reads as its top-left neighbour
 } WhMbCtl;
 
+// ---- screen-content inputs of one P picture (iUsageType == SCREEN_CONTENT_REAL_TIME) ---------------------------------
+// What the reference's pre-processing (scene-change / scroll detection) and PreprocessSliceCoding (encoder_ext.cpp:2700-2765)
+// hand to mode decision and motion estimation: svc_mode_decision.cpp:293-667, svc_motion_estimate.cpp:380-1097.
+typedef struct WhSccJob {
+  const uint8_t* static_idc;   // pVaaExt->pVaaBestBlockStaticIdc: one EStaticBlockIdc per 8x8 luma block, [2 * mb_h][2 * mb_w]
+                               //   (0 moving, 1 static against the co-located block, 2 static against the scrolled one)
+  const uint8_t* ref_ori_c[2]; // chroma planes of pCurDqLayer->pRefOri[0], the SOURCE picture of the reference (stride = src_stride_c)
+  int32_t scroll_flag;         // sScrollDetectInfo.bScrollDetectFlag
+  int32_t scroll_mvx, scroll_mvy;   // sScrollDetectInfo.iScrollMvX / iScrollMvY (integer samples)
+  uint32_t thr16, thr8;        // uiSadCostThreshold[BLOCK_16x16] / [BLOCK_8x8] of the reference picture's SScreenBlockFeatureStorage
+  int32_t fme;                 // pfSearchMethod[BLOCK_8x8] == WelsDiamondCrossFeatureSearch for this picture
+  const uint32_t* fme_times;   // pTimesOfFeatureValue[fme_list_size]: how many 8x8 blocks of the reference picture have that sample sum
+  const uint32_t* fme_start;   // first entry of that sum in fme_loc (in entries)
+  const uint16_t* fme_loc;     // pLocationPointer: {x << 2, y << 2} of every block, grouped by sum, raster order inside a group
+  int32_t fme_list_size;
+  int32_t pad;
+  uint32_t* chain;             // [num_slices][4]: uiSadCost the slice's SWelsMD keeps in sMe8x8[i] from one macroblock to the next
+                               //   (CheckDirectionalMv compares against it BEFORE the search overwrites it, svc_motion_estimate.cpp:385-402)
+  uint32_t* fme_cost_down;     // [num_slices]: what the picture adds to pSlice->uiSliceFMECostDown
+} WhSccJob;
+
 // ---- one picture being encoded (one frame of one session) ---------------------------------------
 typedef struct WhPicJob {
   const uint8_t* src[3];     // source planes, dims = mb_w*16 x mb_h*16 (host pads), own strides
@@ -117,9 +138,14 @@ typedef struct WhPicJob {
   uint32_t*      compact_off; // num_mb + 1 byte offsets into `compact`
   const int16_t* il_hint;     // highest spatial layer of a multi-layer session: what WelsMdInterMbEnhancelayer takes from the layer
                               //   below (svc_mode_decision.cpp:108-150), per MB {sMvBase x, y, flags (bit 0: that MB is intra), 0}; or NULL
+  const WhSccJob* scc;        // screen-content P pictures (WhSeqParams::flags & WH_SEQ_SCC): device copy of the inputs above; else NULL
 } WhPicJob;
 
 #define WH_MAX_SLICES 36
+#define WH_SEQ_SCC 1                // screen-content mode decision / motion estimation (every picture of the launch has WhPicJob::scc)
+#define WH_SEQ_SERIAL 2             // the macroblocks of a slice run one after the other in raster order: pictures whose scroll vector
+                                    //   is not zero -- the reference's directional-vector test reads state of the previous macroblock
+                                    //   in CODING order (WhSccJob::chain), which the 2:1 dependency order does not respect
 #define WH_DB_BAND_ROWS 24          // a deblocking band (one workgroup) never spans more MB rows than this
 
 // ---- parameters common to every picture of a launch --------------------------------------------
@@ -134,7 +160,7 @@ typedef struct WhSeqParams {
   int32_t deblock_idc;                  // 0: all edges, 1: off, 2: not across slice boundaries
   int32_t alpha_offset, beta_offset;
   int32_t mv_range;                     // iMvRange
-  int32_t pad[1];
+  int32_t flags;                        // WH_SEQ_*
   int32_t blk8_w, blk8_h;               // picture size in whole 8x8 luma blocks (scene-change statistic)
   unsigned long long* prof;             // optional device array of 64 x 32 cycle counters (phase profiling), or NULL
   const uint32_t* mb_order;             // device table (32-bit entries: a wave-uniform look-up is then a scalar load): [0, num_mb) MB addresses in dependency order per slice (each slice's

@@ -117,7 +117,7 @@ WH_DEFINE_MB_KERNEL (k_intra_slice, WhMbLds, wh_intra_mb_body, 1024, 0, 0)
 #ifndef WH_SPEC_WINDOWS
 #define WH_SPEC_WINDOWS 1          /* fetch a macroblock's search windows with its cold inputs, around the slice's last vector */
 #endif
-template <int MAXT>
+template <int MAXT, bool SCC>
 __global__ __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPicJob* jobs, uint32_t* err, const uint16_t* groups, int slots,
                                                        int sched_words, int total_slices, uint32_t* slice_cost) {
   extern __shared__ __align__ (16) uint8_t smem[];
@@ -169,7 +169,7 @@ __global__ __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPi
     tt = __builtin_amdgcn_readfirstlane (tt);                                                                                  \
     if (tt >= slot_n[best]) { gone |= 1u << best; continue; }                                                                  \
     const int first_ = slot_first[best];                                                                                       \
-    const int xy_ = (int)P.mb_order[first_ + tt];                                                                              \
+    const int xy_ = (SCC && (P.flags & WH_SEQ_SERIAL)) ? first_ + tt : (int)P.mb_order[first_ + tt];   /* serial: coding order */ \
     const int mb_end_ = Jl[best].mb_end;                                                                                       \
     if (mb_end_ > 0) {                    /* GOM-synchronous coding: only [mb_begin, mb_end) in this launch */                 \
       if (xy_ < Jl[best].mb_begin) { if (lane == 0) atomicOr (&sched[best * sched_words + 1 + ((xy_ - first_) >> 5)], 1u << ((xy_ - first_) & 31)); continue; } \
@@ -194,6 +194,7 @@ __global__ __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPi
     WH_PROF_MARK (P, S.m, 11);
     int dep_a, dep_b;
     wh_mb_deps (P.mb_w, xy, first, &dep_a, &dep_b);
+    if (SCC && (P.flags & WH_SEQ_SERIAL)) { dep_a = xy > first ? xy - 1 : -1; dep_b = -1; }      // the macroblock before it in coding order (WhSccJob::chain)
     if (!wh_wait_done (sc + 1, dep_a < 0 ? -1 : dep_a - first, err)) break;
     if (!wh_wait_done (sc + 1, dep_b < 0 ? -1 : dep_b - first, err)) break;
     __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "workgroup");
@@ -201,7 +202,7 @@ __global__ __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPi
     const uint32_t tc0 = (uint32_t)__builtin_readcyclecounter();
     WV_ASYNC_WAIT();                      /* this MB's cold inputs have landed in the staging area */
     X.slice_idc = slot_idc[slot]; X.slice_first = first; X.last_mv = &slot_mv[slot];
-    wh_inter_mb_body (S, G, P, J, xy % P.mb_w, xy / P.mb_w, X);
+    wh_inter_mb_body_t<SCC> (S, G, P, J, xy % P.mb_w, xy / P.mb_w, X);
     WH_PROF_MARK (P, S.m, 14);
     __builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");
     if (lane == 0) atomicOr (&sc[1 + ((xy - first) >> 5)], 1u << ((xy - first) & 31));
@@ -583,7 +584,8 @@ class HipBackend : public wh::Backend {
     const int sched_words = 1 + ((max_n + 31) >> 5);
     int nw = forced_waves > 0 ? forced_waves : 12;
     nw = std::min (nw, 12);
-    const int par = std::max (1, std::min (max_rows, (P.mb_w + 1) / 2)) * slots;       // macroblocks that can be in flight at all
+    int par = std::max (1, std::min (max_rows, (P.mb_w + 1) / 2)) * slots;       // macroblocks that can be in flight at all
+    if (P.flags & WH_SEQ_SERIAL) par = 2 * slots;      // one macroblock of a slice at a time; a second wave has the next one's inputs in flight
     nw = std::min (nw, par);
     const size_t per_wave = sizeof (WhInterLds) + sizeof (WhInterStage) + sizeof (WhWinLds);
     const size_t fixed = WH_MD_MAX_SLOTS * (sizeof (WhPicJob) + 16) + 4 * (size_t)slots * sched_words;
@@ -612,7 +614,8 @@ class HipBackend : public wh::Backend {
       HIP_TRY (hipGetLastError());
       if (getenv ("WELSHIP_TRACE")) { HIP_TRY (hipStreamSynchronize (stream_)); fprintf (stderr, "welship: launch done\n"); fflush (stderr); }
     };
-    if (nw <= 6) launch (k_inter_pool<384>); else launch (k_inter_pool<768>);
+    if (P.flags & WH_SEQ_SCC) { if (nw <= 6) launch (k_inter_pool<384, true>); else launch (k_inter_pool<768, true>); }
+    else if (nw <= 6) launch (k_inter_pool<384, false>); else launch (k_inter_pool<768, false>);
   }
   void run_deblock (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
     static const int db_waves = getenv ("WELSHIP_DB_WAVES") ? atoi (getenv ("WELSHIP_DB_WAVES")) : 16;

@@ -1230,6 +1230,20 @@ struct WelsHipFrameCtx {
   int16_t* d_il = nullptr;
   WhPicJob* d_job = nullptr;
   FrameLayout* layout = nullptr;
+  // screen-content P pictures (WelsHipFrameJob::pScreen): device copies of the pre-processing's arrays, the reference's SOURCE chroma,
+  // the reference picture's feature lists, the per-slice cost chain / feature-search statistics (allocated with the first such picture)
+  WhSccJob* d_scc = nullptr;
+  uint8_t* d_scc_idc = nullptr;
+  uint8_t* d_scc_ori = nullptr;
+  uint32_t* d_scc_chain = nullptr;       // [WH_MAX_SLICES][4] chain, then [WH_MAX_SLICES] cost-down sums
+  uint32_t* d_scc_lists = nullptr;       // times[list] | start[list]
+  uint16_t* d_scc_loc = nullptr;
+  size_t scc_list_cap = 0, scc_loc_cap = 0;
+  std::vector<uint8_t> h_scc;            // page-locked staging: idc | source chroma | times | start | locations
+  size_t h_scc_cap = 0;
+  WhSccJob h_scc_job;
+  uint32_t h_scc_down[WH_MAX_SLICES];
+  bool scc_active = false;               // the picture in flight is a screen-content P picture
 
   // caller holds sh->mu
   void release_locked() {
@@ -1237,7 +1251,8 @@ struct WelsHipFrameCtx {
     be->sync();
     for (auto& p : pics) { if (p.base) be->free (p.base); if (p.mbs) be->free (p.mbs); }
     pics.clear();
-    void* ptrs[] = {d_src, d_records, d_dbflags, d_mb_ctl, d_sad_cost0, d_vaa, d_bgd, d_il, d_job};
+    void* ptrs[] = {d_src, d_records, d_dbflags, d_mb_ctl, d_sad_cost0, d_vaa, d_bgd, d_il, d_job, d_scc, d_scc_idc, d_scc_ori, d_scc_chain, d_scc_lists, d_scc_loc};
+    if (!h_scc.empty()) be->unpin_host (h_scc.data());
     for (void* p : ptrs) if (p) be->free (p);
     if (!h_records.empty()) be->unpin_host (h_records.data());
     if (!h_src.empty()) be->unpin_host (h_src.data());
@@ -1332,6 +1347,7 @@ void frame_run_batch (FrameShared* sh, FrameKey* K, std::unique_lock<std::mutex>
       be->download (c->h_records.data(), c->d_records, sizeof (WhMbRecord) * c->num_mb);
       be->download (c->h_pic.data(), c->pics[x->cur_pic].base, c->rec_alloc_bytes + 128);
       if (x->sad_dst) be->download (c->h_sad_out.data(), c->d_sad_cost0, sizeof (int32_t) * c->num_mb);
+      if (c->scc_active) be->download (c->h_scc_down, c->d_scc_chain + 4 * WH_MAX_SLICES, sizeof (uint32_t) * WH_MAX_SLICES);
     }
     const double launch_ms = std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now() - t_launch0).count();
     const int q = K->queue;
@@ -1512,6 +1528,47 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
     if (is_p && j->pIlHint) memcpy (c->h_aux.data() + c->aux_il, j->pIlHint, sizeof (int16_t) * 4 * c->num_mb);
     if (j->pSadCost) memcpy (c->h_aux.data() + c->aux_sad, j->pSadCost, sizeof (int32_t) * c->num_mb);
   }
+  // screen content: stage the pre-processing's arrays (page-locked, own to this context)
+  const WelsHipScreenInfo* scr = is_p ? j->pScreen : nullptr;
+  size_t scc_off_ori = 0, scc_off_times = 0, scc_off_start = 0, scc_off_loc = 0, scc_lists = 0, scc_entries = 0;
+  if (scr) {
+    if (!scr->pBlockStaticIdc) { set_err ("screen-content job without the static-block map"); return WELSHIP_ERR_INIT_PARA; }
+    const bool fme = scr->bFeatureSearch8x8 != 0;
+    if (fme && (!scr->pTimesOfFeatureValue || !scr->pLocationOfFeature || !scr->pLocationPointer || scr->iListSize <= 0 || scr->iLocationEntries < 0)) {
+      set_err ("screen-content job: feature search without the reference picture's feature lists"); return WELSHIP_ERR_INIT_PARA;
+    }
+    scc_lists = fme ? (size_t)scr->iListSize : 0; scc_entries = fme ? (size_t)scr->iLocationEntries : 0;
+    scc_off_ori = (size_t)4 * c->num_mb;
+    scc_off_times = scc_off_ori + 2 * c->csz;
+    scc_off_start = scc_off_times + 4 * scc_lists;
+    scc_off_loc = scc_off_start + 4 * scc_lists;
+    const size_t need = scc_off_loc + 4 * scc_entries + 64;
+    if (first_part) {
+      if (need > c->h_scc_cap) {
+        std::unique_lock<std::mutex> lk (sh->mu);
+        if (!c->h_scc.empty()) be->unpin_host (c->h_scc.data());
+        c->h_scc.assign (need + need / 4, 0);
+        c->h_scc_cap = c->h_scc.size();
+        be->pin_host (c->h_scc.data(), c->h_scc.size());
+      }
+      uint8_t* st = c->h_scc.data();
+      memcpy (st, scr->pBlockStaticIdc, (size_t)4 * c->num_mb);
+      if (scr->pRefOriChroma[0] && scr->pRefOriChroma[1])
+        for (int pl = 0; pl < 2; ++pl)
+          for (int r = 0; r < c->mb_h * 8; ++r)
+            memcpy (st + scc_off_ori + pl * c->csz + (size_t)r * c->seq.src_stride_c, scr->pRefOriChroma[pl] + (size_t)r * scr->iRefOriStride, (size_t)c->mb_w * 8);
+      if (fme) {
+        memcpy (st + scc_off_times, scr->pTimesOfFeatureValue, 4 * scc_lists);
+        uint32_t* start = (uint32_t*) (st + scc_off_start);
+        for (size_t f = 0; f < scc_lists; ++f) {
+          const ptrdiff_t d = scr->pLocationOfFeature[f] ? scr->pLocationOfFeature[f] - scr->pLocationPointer : 0;
+          if (d < 0 || (d & 1) || (size_t) (d >> 1) + scr->pTimesOfFeatureValue[f] > scc_entries) { set_err ("screen-content job: inconsistent feature lists"); return WELSHIP_ERR_INIT_PARA; }
+          start[f] = (uint32_t) (d >> 1);
+        }
+        memcpy (st + scc_off_loc, scr->pLocationPointer, 4 * scc_entries);
+      }
+    }
+  }
   bool qp_map = false;
   if (j->pMbQp) {
     for (int i = 0; i < c->num_mb; ++i) { memset (&c->h_mb_ctl[i], 0, sizeof (WhMbCtl)); c->h_mb_ctl[i].qp_delta = (int8_t) ((int)j->pMbQp[i] - j->iQp); }
@@ -1528,6 +1585,9 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
   s.chroma_qp_offset = j->iChromaQpIndexOffset;
   s.alpha_offset = j->iAlphaOffset; s.beta_offset = j->iBetaOffset;
   s.mv_range = j->iMvRange;
+  // screen content: its own kernel variant; a picture with a scroll vector codes the macroblocks of a slice one after the other
+  // (the directional-vector test of the 8x8 searches reads what the previous macroblock in CODING order left, WhSccJob::chain)
+  s.flags = scr ? (WH_SEQ_SCC | ((scr->bScrollDetectFlag && (scr->iScrollMvX | scr->iScrollMvY)) ? WH_SEQ_SERIAL : 0)) : 0;
   // the pictures this one can share a launch with, and the queue they use (MB ranges: queue 0, on their own)
   FrameKey* K = ranged ? nullptr : frame_find_key (sh, s, is_p, qp_map, j->bExpand != 0);
   const int queue = K ? K->queue : 0;
@@ -1542,6 +1602,39 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
     c->h_pic_of = -1;
   }
   if (qp_map) be->upload (c->d_mb_ctl, c->h_mb_ctl.data(), sizeof (WhMbCtl) * c->num_mb);
+  c->scc_active = scr != nullptr;
+  if (scr) {
+    bool oom = false;
+    auto A = [&] (size_t n) { void* p = be->alloc (n); if (!p) oom = true; return p; };
+    if (!c->d_scc) {
+      c->d_scc = (WhSccJob*)A (sizeof (WhSccJob));
+      c->d_scc_idc = (uint8_t*)A ((size_t)4 * c->num_mb + 64);
+      c->d_scc_ori = (uint8_t*)A (2 * c->csz + 64);
+      c->d_scc_chain = (uint32_t*)A (sizeof (uint32_t) * 5 * WH_MAX_SLICES);
+    }
+    if (scc_lists > c->scc_list_cap) { if (c->d_scc_lists) be->free (c->d_scc_lists); c->d_scc_lists = (uint32_t*)A (8 * scc_lists + 64); c->scc_list_cap = scc_lists; }
+    if (scc_entries > c->scc_loc_cap) { if (c->d_scc_loc) be->free (c->d_scc_loc); c->d_scc_loc = (uint16_t*)A (4 * scc_entries + 64); c->scc_loc_cap = scc_entries; }
+    if (oom) { set_err ("out of device memory"); return WELSHIP_ERR_MEMORY; }
+    if (first_part) {
+      const uint8_t* st = c->h_scc.data();
+      be->upload (c->d_scc_idc, st, (size_t)4 * c->num_mb);
+      if (scr->pRefOriChroma[0] && scr->pRefOriChroma[1]) be->upload (c->d_scc_ori, st + scc_off_ori, 2 * c->csz);
+      if (scc_lists) { be->upload (c->d_scc_lists, st + scc_off_times, 8 * scc_lists); be->upload (c->d_scc_loc, st + scc_off_loc, 4 * scc_entries); }
+      be->fill (c->d_scc_chain, 0, sizeof (uint32_t) * 5 * WH_MAX_SLICES);
+      WhSccJob& z = c->h_scc_job;
+      memset (&z, 0, sizeof (z));
+      z.static_idc = c->d_scc_idc;
+      const bool have_ori = scr->pRefOriChroma[0] && scr->pRefOriChroma[1];
+      z.ref_ori_c[0] = have_ori ? c->d_scc_ori : nullptr; z.ref_ori_c[1] = have_ori ? c->d_scc_ori + c->csz : nullptr;
+      z.scroll_flag = scr->bScrollDetectFlag ? 1 : 0; z.scroll_mvx = scr->iScrollMvX; z.scroll_mvy = scr->iScrollMvY;
+      z.thr16 = scr->uiSadCostThreshold16x16; z.thr8 = scr->uiSadCostThreshold8x8;
+      z.fme = scc_lists ? 1 : 0;
+      z.fme_times = c->d_scc_lists; z.fme_start = c->d_scc_lists ? c->d_scc_lists + scc_lists : nullptr; z.fme_loc = c->d_scc_loc;
+      z.fme_list_size = (int32_t)scc_lists;
+      z.chain = c->d_scc_chain; z.fme_cost_down = c->d_scc_chain + 4 * WH_MAX_SLICES;
+      be->upload (c->d_scc, &z, sizeof (z));
+    }
+  }
   DevPicture& cur = c->pics[j->iCurPic];
   WhPicJob job;
   memset (&job, 0, sizeof (job));
@@ -1562,6 +1655,7 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
   job.bgd_flags = is_p && j->pBgdFlags ? c->d_bgd : nullptr;
   job.mvc_shift = j->iMvcShift;
   job.il_hint = is_p && j->pIlHint ? c->d_il : nullptr;
+  job.scc = scr ? c->d_scc : nullptr;
   job.mb_begin = ranged ? j->iMbBegin : 0; job.mb_end = ranged ? j->iMbEnd : 0;
 
   if (ranged) {
@@ -1575,9 +1669,11 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
       if (j->bExpand) be->run_expand (s, c->d_job, 1);
       cur.is_p = is_p;
       if (j->pSadCost) be->download (j->pSadCost, c->d_sad_cost0, sizeof (int32_t) * c->num_mb);
+      if (scr) be->download (c->h_scc_down, c->d_scc_chain + 4 * WH_MAX_SLICES, sizeof (uint32_t) * WH_MAX_SLICES);
     }
     be->download (c->h_records.data() + j->iMbBegin, c->d_records + j->iMbBegin, sizeof (WhMbRecord) * (size_t) (j->iMbEnd - j->iMbBegin));
     if (be->sync_queue (queue)) { set_err ("device scheduler timed out or device error; the picture was not encoded"); return WELSHIP_ERR_UNKNOWN; }
+    if (scr && last_part && scr->pSliceFMECostDown) memcpy (scr->pSliceFMECostDown, c->h_scc_down, sizeof (uint32_t) * j->iNumSlices);
     *pp_records = c->h_records.data();
     return WELSHIP_OK;
   }
@@ -1621,6 +1717,7 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
   if (item.rc) { set_err ("device scheduler timed out or device error; the picture was not encoded"); return item.rc; }
   lock.unlock();
   if (j->pSadCost) memcpy (j->pSadCost, c->h_sad_out.data(), sizeof (int32_t) * c->num_mb);
+  if (scr && scr->pSliceFMECostDown) memcpy (scr->pSliceFMECostDown, c->h_scc_down, sizeof (uint32_t) * j->iNumSlices);
   *pp_records = c->h_records.data();
   return WELSHIP_OK;
 }

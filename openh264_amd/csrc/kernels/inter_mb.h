@@ -19,6 +19,13 @@
 //   svc_encode_mb.cpp:180-242,325-381 WelsEncInterY / WelsTryPYskip / WelsTryPUVskip
 //   codec/common/src/mc.cpp:100-386  luma 6-tap quarter-pel + chroma bilinear interpolation (= H.264 8.4.2.2)
 //   codec/processing/src/vaacalc/vaacalcfuncs.cpp:254-330 VAACalcSad_c (8x8 SADs vs the previous source frame)
+// Screen content (iUsageType == SCREEN_CONTENT_REAL_TIME; template parameter SCC of the macroblock body):
+//   svc_mode_decision.cpp:293-541    JudgeStaticSkip / JudgeScrollSkip / SvcMdSCDMbEnc / WelsMdInterJudgeSCDPskip
+//   svc_mode_decision.cpp:553-667    TryModeMerge / WelsMdInterFinePartitionVaaOnScreen
+//   svc_motion_estimate.cpp:170-218  WelsMotionEstimateSearchStatic / ...Scrolled
+//   svc_motion_estimate.cpp:385-412  CheckDirectionalMv
+//   svc_motion_estimate.cpp:568-646  LineFullSearch_c / WelsMotionCrossSearch
+//   svc_motion_estimate.cpp:880-1097 SetFeatureSearchIn / FeatureSearchOne / WelsDiamondCrossSearch / WelsDiamondCrossFeatureSearch
 #pragma once
 #include "frame_kernels.h"
 
@@ -233,6 +240,51 @@ WH_FN int wh_sad_global (const WhInterLds& S, const WhSeqParams& P, const WhPicJ
                                           return wh_sad4 (wh_enc4 (S, ex + wh_sl_col (lane, bw), ey + wh_sl_row (lane, bw)), wh_pack4 (t[0], t[1], t[2], t[3])); }) () : 0));
   return s;
 }
+// test-build statistics of the screen-content paths (which of them a test clip reaches at all): WELSHIP_SCC_STATS=1 prints them
+#if defined(WH_EMU)
+#include <stdio.h>
+enum { WH_ST_STATIC_SKIP, WH_ST_SCROLL_SKIP, WH_ST_SCD_P16, WH_ST_CROSS_V, WH_ST_CROSS_H, WH_ST_FME, WH_ST_FME_HIT, WH_ST_DIR_TAKEN, WH_ST_P8X8, WH_ST_MERGE, WH_ST_FIXED, WH_ST_N };
+static long g_wh_scc_stat[WH_ST_N];
+static void wh_scc_stat_dump() {
+  if (!getenv ("WELSHIP_SCC_STATS")) return;
+  static const char* n[WH_ST_N] = {"static_skip", "scroll_skip", "scd_p16x16", "cross_vertical", "cross_horizontal", "feature_search", "feature_hit", "directional_taken", "p8x8", "merged", "fixed_8x8"};
+  for (int i = 0; i < WH_ST_N; ++i) fprintf (stderr, "welship scc stat %s %ld\n", n[i], g_wh_scc_stat[i]);
+}
+struct WhSccStatInit { WhSccStatInit() { atexit (wh_scc_stat_dump); } };
+static WhSccStatInit g_wh_scc_stat_init;
+#define WH_STAT(i) (++g_wh_scc_stat[i])
+#else
+#define WH_STAT(i) ((void)0)
+#endif
+
+// ---- screen content: SADs straight from the reference picture, one candidate per LANE --------------------------------
+// (cross search and feature search look at hundreds of positions far apart: no window can hold them)
+#if defined(WH_EMU)
+WH_FN uint32_t wh_ldg4u (const uint8_t* p) { uint32_t v; memcpy (&v, p, 4); return v; }
+#else
+// four bytes at any byte address of device memory, from the two aligned words around it
+WH_FN uint32_t wh_ldg4u (const WH_G uint8_t* p) {
+  const WH_G uint32_t* w = (const WH_G uint32_t*) ((uintptr_t)p & ~ (uintptr_t)3);
+  return __builtin_amdgcn_alignbyte (w[1], w[0], (uint32_t) (uintptr_t)p & 3u);
+}
+#endif
+// this lane's SAD of the bw x bh source block at (ex,ey) against the block at p (any alignment)
+WH_FN int wh_sad_lane_g (const WhInterLds& S, const WH_G uint8_t* p, int stride, int ex, int ey, int bw, int bh) {
+  int s = 0;
+  for (int r = 0; r < bh; ++r) {
+    const WH_G uint8_t* q = p + (ptrdiff_t)r * stride;
+#if defined(WH_EMU)
+    for (int c = 0; c < bw; c += 4) s += wh_sad4 (wh_enc4 (S, ex + c, ey + r), wh_ldg4u (q + c));
+#else
+    const WH_G uint32_t* w = (const WH_G uint32_t*) ((uintptr_t)q & ~ (uintptr_t)3);
+    const uint32_t sh = (uint32_t) (uintptr_t)q & 3u;
+    uint32_t a = w[0];
+    for (int c = 0; c < bw; c += 4) { const uint32_t b = w[(c >> 2) + 1]; s += wh_sad4 (wh_enc4 (S, ex + c, ey + r), __builtin_amdgcn_alignbyte (b, a, sh)); a = b; }
+#endif
+  }
+  return s;
+}
+
 // SAD of the whole source MB against a 16x16 byte tile in LDS (stride 16)
 WH_FN int wh_sad_mb_tile (const WhInterLds& S, const uint8_t* t) {
   int s;
@@ -371,7 +423,93 @@ WH_FN int wh_cand_sad (const WhInterLds& S, const WhSeqParams& P, const WhPicJob
   return wh_sad_global (S, P, J, me.bx, me.by, me.bw, me.bh, px, py);
 }
 
-WH_FN void wh_motion_search (WhInterLds& S, const WhSeqParams& P, const WhPicJob& J, WhWin& W, const WhMeCtx& C, WhMe& me, const WvLaneArr& mvcl, int n_mvc) {
+// ---- screen content: what the search of one block does beyond the diamond (PreprocessSliceCoding, encoder_ext.cpp:2700-2765) ----
+typedef struct WhSccMe {
+  const WH_G WhSccJob* job;
+  int method;                  // 0 WelsDiamondSearch, 1 WelsDiamondCrossSearch (16x16), 2 WelsDiamondCrossFeatureSearch (8x8 when the switch is on)
+  uint32_t thr;                // uiSadCostThreshold of the block size: the cross / feature searches only run at or above it
+  int dir_on, dmx, dmy;        // CheckDirectionalMv: the picture's scroll vector (pfSetScrollingMv == SetScrollingMvToMd), blocks below 16x16
+  uint32_t chain;              // pMe->uiSadCost as the previous search that used this SWelsME left it (WhSccJob::chain)
+  uint32_t fme_down;           // out: what the feature search took off the cost (pSlice->uiSliceFMECostDown)
+} WhSccMe;
+
+// LineFullSearch_c (svc_motion_estimate.cpp:568-613): every position of the column (or the row) through the CO-LOCATED block
+// inside the search range, one candidate per lane, 64 at a time; the first minimum wins, and it replaces the search result
+// only if it is cheaper.
+WH_FN void wh_line_search (const WhInterLds& S, const WhSeqParams& P, const WhPicJob& J, const WhMeCtx& C, const WhMe& me, bool vertical, int* best, int* bmx, int* bmy) {
+  const int lo = vertical ? C.miny : C.minx, hi = vertical ? C.maxy : C.maxx;
+  const int px = C.mbx * 16 + me.bx, py = C.mby * 16 + me.by;
+  const WH_G uint8_t* ref = (const WH_G uint8_t*)J.ref[0];
+  int lbest = 0x7fffffff, lpos = 0;
+  for (int base = lo; base < hi; base += 64) {
+    int k, l;
+    WV_ARGMIN (k, l, lane, base + lane < hi, ([&] () {
+      const int m = base + lane;
+      const WH_G uint8_t* q = ref + (ptrdiff_t) (py + (vertical ? m : 0)) * P.rec_stride_y + px + (vertical ? 0 : m);
+      return wh_sad_lane_g (S, q, P.rec_stride_y, me.bx, me.by, me.bw, me.bh) +
+             (vertical ? wh_mvd_cost (C.lambda, -me.mvpx, m * 4 - me.mvpy) : wh_mvd_cost (C.lambda, m * 4 - me.mvpx, -me.mvpy)); }) ());
+    if (l >= 0 && k < lbest) { lbest = k; lpos = base + l; }
+  }
+  if (lbest < *best) { *best = lbest; *bmx = vertical ? 0 : lpos; *bmy = vertical ? lpos : 0; }
+}
+
+// MotionEstimateFeatureFullSearch / FeatureSearchOne (svc_motion_estimate.cpp:918-1003): the blocks of the reference picture
+// whose sample sum equals this block's, in raster order.  The reference walks them one by one with a running best cost and
+// stops at the first one below the threshold; as the cost on entry is at or above that threshold, "the first one below the
+// threshold, else the first minimum" is the same result, and that is what 64 candidates at a time compute.
+WH_FN void wh_feature_search (const WhInterLds& S, const WhSeqParams& P, const WhPicJob& J, const WH_G WhSccJob* Z, const WhMeCtx& C, const WhMe& me, uint32_t thr32,
+                              int* best, int* bmx, int* bmy) {
+  int feature;
+  WV_SUM (feature, lane, (lane < 16 ? wh_sad4 (wh_enc4 (S, me.bx + (lane & 1) * 4, me.by + (lane >> 1)), 0u) : 0));
+  if (feature >= Z->fme_list_size) return;
+  const int times = (int)Z->fme_times[feature];
+  const WH_G uint16_t* loc = (const WH_G uint16_t*)Z->fme_loc + 2 * (size_t)Z->fme_start[feature];
+  const WH_G uint8_t* ref = (const WH_G uint8_t*)J.ref[0];
+  const int cpx = C.mbx * 16 + me.bx, cpy = C.mby * 16 + me.by, cqx = cpx * 4, cqy = cpy * 4;
+  const int min_qx = cqx + C.minx * 4, max_qx = cqx + C.maxx * 4, min_qy = cqy + C.miny * 4, max_qy = cqy + C.maxy * 4;
+  const int thr = (int) (thr32 & 0xffffu);          // const uint16_t uiSadCostThresh
+  int b = *best;
+  for (int base = 0; base < times; base += 64) {
+    WvLaneArr cst;
+#if defined(WH_EMU)
+    memset (&cst, 0, sizeof (cst));
+#else
+    cst = 0;
+#endif
+    WV_LSET_IF (cst, lane, true, ([&] () {
+      const int i = base + lane;
+      if (i >= times) return 0x7fffffff;
+      const int qx = (int)loc[2 * i], qy = (int)loc[2 * i + 1];
+      if (qx > max_qx || qx < min_qx || qy > max_qy || qy < min_qy || qx == cqx || qy == cqy) return 0x7fffffff;
+      const int mvdc = wh_mvd_cost (C.lambda, qx - cqx - me.mvpx, qy - cqy - me.mvpy);
+      if (mvdc >= b) return 0x7fffffff;
+      const WH_G uint8_t* q = ref + (ptrdiff_t) (qy >> 2) * P.rec_stride_y + (qx >> 2);
+      return mvdc + wh_sad_lane_g (S, q, P.rec_stride_y, me.bx, me.by, me.bw, me.bh); }) ());
+    int k, l;
+    WV_ARGMIN (k, l, lane, WV_LOWN (cst, lane) < thr, lane);
+    bool stop = false;
+    if (l >= 0) { k = WV_LGET (cst, l); stop = true; }
+    else WV_ARGMIN (k, l, lane, WV_LOWN (cst, lane) != 0x7fffffff, WV_LOWN (cst, lane));
+    if (l >= 0 && k < b) {
+      b = k;
+      *bmx = ((int)loc[2 * (base + l)] >> 2) - cpx; *bmy = ((int)loc[2 * (base + l) + 1] >> 2) - cpy;
+    }
+    if (stop) break;
+  }
+  *best = b;
+}
+
+// SATD of the search result (CalculateSatdCost, complexity >= MEDIUM)
+WH_FN void wh_me_satd (WhInterLds& S, const WhWin& W, const WhMeCtx& C, WhMe& me, int bmx, int bmy) {
+  const int wo = (C.mby * 16 + me.by + bmy - W.y0) * WH_WIN_STRIDE + C.mbx * 16 + me.bx + bmx - W.x0;
+  const int nq = (me.bw >> 2) * (me.bh >> 2) * 4;
+  WV_SATD_ROWS (me.satd_raw, lane, lane < nq,
+                wh_enc4 (S, me.bx + (lane < nq ? wh_tl_col (lane, me.bw) : 0), me.by + (lane < nq ? wh_tl_row (lane, me.bw) : 0)),
+                wh_ld4u (W.b->win, wo + (lane < nq ? wh_tl_row (lane, me.bw) * WH_WIN_STRIDE + wh_tl_col (lane, me.bw) : 0)));
+  me.satd_cost = me.satd_raw + wh_mvd_cost (C.lambda, me.mvx - me.mvpx, me.mvy - me.mvpy);
+}
+
+WH_FN void wh_motion_search (WhInterLds& S, const WhSeqParams& P, const WhPicJob& J, WhWin& W, const WhMeCtx& C, WhMe& me, const WvLaneArr& mvcl, int n_mvc, WhSccMe* Z = nullptr) {
   // initial point (svc_motion_estimate.cpp:222-284); candidates beyond the predictor: packed mvcl[0..n_mvc)
   int bmx = wh_clip3 ((2 + me.mvpx) >> 2, C.minx, C.maxx), bmy = wh_clip3 ((2 + me.mvpy) >> 2, C.miny, C.maxy);
   int best = wh_cand_sad (S, P, J, W, C, me, bmx, bmy) + wh_mvd_cost (C.lambda, bmx * 4 - me.mvpx, bmy * 4 - me.mvpy);
@@ -382,6 +520,11 @@ WH_FN void wh_motion_search (WhInterLds& S, const WhSeqParams& P, const WhPicJob
       const int c = wh_cand_sad (S, P, J, W, C, me, cx, cy) + wh_mvd_cost (C.lambda, cx * 4 - me.mvpx, cy * 4 - me.mvpy);
       if (c < best) { best = c; bmx = cx; bmy = cy; }
     }
+  }
+  if (Z && Z->dir_on && (Z->dmx | Z->dmy) && Z->dmx >= C.minx && Z->dmx < C.maxx && Z->dmy >= C.miny && Z->dmy < C.maxy) {
+    // CheckDirectionalMv: the scroll vector takes over whenever it is cheaper than what this SWelsME held BEFORE this search
+    const int c = wh_cand_sad (S, P, J, W, C, me, Z->dmx, Z->dmy) + wh_mvd_cost (C.lambda, Z->dmx * 4 - me.mvpx, Z->dmy * 4 - me.mvpy);
+    if ((uint32_t)c < Z->chain) { best = c; bmx = Z->dmx; bmy = Z->dmy; WH_STAT (WH_ST_DIR_TAKEN); }
   }
   const bool diamond = !(best < me.sad_pred);
   if (diamond || C.use_satd) {
@@ -420,16 +563,41 @@ WH_FN void wh_motion_search (WhInterLds& S, const WhSeqParams& P, const WhPicJob
       wo -= ix + iy * WH_WIN_STRIDE;
     }
     bmx = (dx + me.mvpx) >> 2; bmy = (dy + me.mvpy) >> 2;
+    if (Z && Z->method >= 1) {
+      // WelsDiamondCrossSearch / WelsDiamondCrossFeatureSearch (svc_motion_estimate.cpp:1055-1094)
+      if ((uint32_t)best >= Z->thr) {
+        WH_STAT (WH_ST_CROSS_V);
+        wh_line_search (S, P, J, C, me, true, &best, &bmx, &bmy);
+        if ((uint32_t)best >= Z->thr) { WH_STAT (WH_ST_CROSS_H); wh_line_search (S, P, J, C, me, false, &best, &bmx, &bmy); }
+      }
+      if (Z->method == 2 && (uint32_t)best >= Z->thr) {
+        const int before = best;
+        WH_STAT (WH_ST_FME);
+        wh_feature_search (S, P, J, Z->job, C, me, Z->thr, &best, &bmx, &bmy);
+        if (best < before) WH_STAT (WH_ST_FME_HIT);
+        Z->fme_down += (uint32_t) (before - best);
+      }
+      if (C.use_satd) {
+        const int sx = C.mbx * 16 + me.bx + bmx, sy = C.mby * 16 + me.by + bmy;
+        wh_win_ensure (S, P, J, W, sx - WH_WIN_MARGIN, sy - WH_WIN_MARGIN, sx + me.bw + WH_WIN_MARGIN, sy + me.bh + WH_WIN_MARGIN);
+      }
+    }
   }
   me.mvx = bmx * 4; me.mvy = bmy * 4;
   me.sad_cost = best; me.satd_cost = best; me.satd_raw = 0;
-  if (C.use_satd) {   // CalculateSatdCost (complexity >= MEDIUM)
-    const int wo = (C.mby * 16 + me.by + bmy - W.y0) * WH_WIN_STRIDE + C.mbx * 16 + me.bx + bmx - W.x0;
-    const int nq = (me.bw >> 2) * (me.bh >> 2) * 4;
-    WV_SATD_ROWS (me.satd_raw, lane, lane < nq,
-                  wh_enc4 (S, me.bx + (lane < nq ? wh_tl_col (lane, me.bw) : 0), me.by + (lane < nq ? wh_tl_row (lane, me.bw) : 0)),
-                  wh_ld4u (W.b->win, wo + (lane < nq ? wh_tl_row (lane, me.bw) * WH_WIN_STRIDE + wh_tl_col (lane, me.bw) : 0)));
-    me.satd_cost = me.satd_raw + wh_mvd_cost (C.lambda, me.mvx - me.mvpx, me.mvy - me.mvpy);
+  if (C.use_satd) wh_me_satd (S, W, C, me, bmx, bmy);
+}
+
+// WelsMotionEstimateSearchStatic / WelsMotionEstimateSearchScrolled (svc_motion_estimate.cpp:186-218): no search at all -- the
+// block takes the given integer vector (zero, or the picture's scroll vector)
+WH_FN void wh_me_fixed (WhInterLds& S, const WhSeqParams& P, const WhPicJob& J, WhWin& W, const WhMeCtx& C, WhMe& me, int imx, int imy) {
+  me.sad_cost = wh_cand_sad (S, P, J, W, C, me, imx, imy) + wh_mvd_cost (C.lambda, imx * 4 - me.mvpx, imy * 4 - me.mvpy);
+  me.mvx = imx * 4; me.mvy = imy * 4;
+  me.satd_cost = me.sad_cost; me.satd_raw = 0;
+  if (C.use_satd) {
+    const int sx = C.mbx * 16 + me.bx + imx, sy = C.mby * 16 + me.by + imy;
+    wh_win_ensure (S, P, J, W, sx - WH_WIN_MARGIN, sy - WH_WIN_MARGIN, sx + me.bw + WH_WIN_MARGIN, sy + me.bh + WH_WIN_MARGIN);
+    wh_me_satd (S, W, C, me, imx, imy);
   }
 }
 
@@ -543,13 +711,16 @@ WH_FN uint32_t wh_rf_quarter (const uint8_t* w, int o, int hb, int k) {
 }
 
 // Returns through me.mvx/mvy/satd_cost, writes the final luma prediction of the block into S.m.pred_y.
-WH_FN void wh_refine_frac (WhInterLds& S, const WhSeqParams& P, const WhPicJob& J, WhWin& W, const WhMeCtx& C, WhMe& me, int satd_in_md) {
+// `sub8`: a 16x8 / 8x16 partition that TryModeMerge made of two 8x8 searches (screen content) keeps BLOCK_8x8 as its block size,
+// so the reference scores every candidate on the partition's first 8x8 only (pfMeCost[pMe->uiBlockSize], md.cpp:602-640) while it
+// interpolates and copies the whole partition.
+WH_FN void wh_refine_frac (WhInterLds& S, const WhSeqParams& P, const WhPicJob& J, WhWin& W, const WhMeCtx& C, WhMe& me, int satd_in_md, int sub8 = 0) {
   const int bpx = C.mbx * 16 + me.bx, bpy = C.mby * 16 + me.by;
   const int ipx = bpx + (me.mvx >> 2), ipy = bpy + (me.mvy >> 2);          // me.mv is integer-pel here
   wh_win_ensure (S, P, J, W, ipx - 4, ipy - 4, ipx + me.bw + 8, ipy + me.bh + 5);
   const int wo = (ipy - W.y0) * WH_WIN_STRIDE + ipx - W.x0;
   const int nq = (me.bw >> 2) * (me.bh >> 2) * 4, bw = me.bw, ex = me.bx, ey = me.by;
-#define WH_RF_ACT (lane < nq)
+#define WH_RF_ACT (lane < nq && (!sub8 || (bw == 16 ? ((lane >> 2) & 3) < 2 : lane < 16)))
 #define WH_RF_ENC wh_enc4 (S, ex + (lane < nq ? wh_tl_col (lane, bw) : 0), ey + (lane < nq ? wh_tl_row (lane, bw) : 0))
 #define WH_RF_O (wo + (lane < nq ? wh_tl_row (lane, bw) * WH_WIN_STRIDE + wh_tl_col (lane, bw) : 0))
   const int dmx = me.mvx - me.mvpx, dmy = me.mvy - me.mvpy;
@@ -687,7 +858,8 @@ typedef struct WhInterCtx {
 } WhInterCtx;
 
 // ---- the P macroblock -----------------------------------------------------------------------------
-WH_FN void wh_inter_mb_body (WhInterLds& S, WhInterStage& G, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, const WhInterCtx& X) {
+template <bool SCC>
+WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, const WhInterCtx& X) {
   WH_PROF_DECL (P);
   WhMbLds& M = S.m;
   const int w = P.mb_w, xy = mby * w + mbx;
@@ -909,6 +1081,74 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, WhInterStage& G, const WhSeqParams& 
     }
   }
 
+  // ---- screen content: static / scrolled P_Skip (WelsMdInterJudgeSCDPskip, svc_mode_decision.cpp:326-541) ----
+  // A macroblock whose four 8x8 blocks the pre-processing found unchanged against the co-located (or the scrolled) block of the
+  // reference's SOURCE picture, and whose chroma is identical there too, is predicted with that integer vector without any search:
+  // P_Skip when the skip predictor happens to be that vector (and the reference MB's QP is close), P16x16 with residual otherwise.
+  const WH_G WhSccJob* Z = nullptr;
+  int idc0 = 0, idc1 = 0, idc2 = 0, idc3 = 0, scroll_on = 0, smx = 0, smy = 0;
+  bool scd_coded = false;
+  if (SCC) {
+    Z = (const WH_G WhSccJob*)J.scc;
+    const WH_G uint8_t* ip = (const WH_G uint8_t*)Z->static_idc + (size_t) (2 * mby) * (2 * w) + 2 * mbx;
+    idc0 = ip[0]; idc1 = ip[1]; idc2 = ip[2 * w]; idc3 = ip[2 * w + 1];
+    const int sflag = Z->scroll_flag;
+    smx = Z->scroll_mvx; smy = Z->scroll_mvy;
+    scroll_on = sflag && (smx | smy);                                // pfSetScrollingMv == SetScrollingMvToMd (encoder_ext.cpp:2707-2713)
+    for (int mode = 0; mode < 2 && !done; ++mode) {                  // STATIC, SCROLLED
+      const int want = mode == 0 ? 1 : 2;                            // COLLOCATED_STATIC / SCROLLED_STATIC
+      if (mode == 1 && !sflag) break;
+      if (!(idc0 == want && idc1 == want && idc2 == want && idc3 == want)) continue;
+      const int ox = mode ? smx : 0, oy = mode ? smy : 0;
+      if (mode == 1 && ((mbx << 4) + ox < 0 || (mbx << 4) + ox > ((P.mb_w - 1) << 4) || (mby << 4) + oy < 0 || (mby << 4) + oy > ((P.mb_h - 1) << 4))) continue;   // CheckBorder
+      if (!Z->ref_ori_c[0]) continue;
+      int cb, cr;
+      {
+        const WH_G uint8_t* o0 = (const WH_G uint8_t*)Z->ref_ori_c[0];
+        const WH_G uint8_t* o1 = (const WH_G uint8_t*)Z->ref_ori_c[1];
+        const ptrdiff_t off = (ptrdiff_t) ((mby << 3) + (oy >> 1)) * P.src_stride_c + (mbx << 3) + (ox >> 1);
+        WV_SUM2 (cb, cr, lane,
+                 (lane < 16 ? wh_sad4 (* (const uint32_t*)&M.enc_c[lane * 4], wh_ldg4u (o0 + off + (ptrdiff_t) ((lane >> 1) & 7) * P.src_stride_c + (lane & 1) * 4)) : 0),
+                 (lane >= 16 && lane < 32 ? wh_sad4 (* (const uint32_t*)&M.enc_c[lane * 4], wh_ldg4u (o1 + off + (ptrdiff_t) ((lane >> 1) & 7) * P.src_stride_c + (lane & 1) * 4)) : 0));
+      }
+      if (cb != 0 || cr != 0) continue;
+      // MdInterSCDPskipProcess + SvcMdSCDMbEnc
+      const int ref_qp = Co->ref_qp;
+      const bool qp_similar = ref_qp - qp <= 5 /* DELTA_QP_SCD_THD */ || ref_qp <= 26;
+      int sx, sy;
+      wh_pred_skip_mv (K, &sx, &sy);
+      const int vx = (int) (int16_t) (ox * 4), vy = (int) (int16_t) (oy * 4);
+      const bool as_skip = qp_similar && sx == vx && sy == vy;
+      uint8_t* dy = as_skip ? S.skip_y : M.pred_y;
+      uint8_t* dc = as_skip ? S.skip_c : M.pred_c;
+      wh_mc_luma_to (S, P, J, W, mbx, mby, 0, 0, 16, 16, vx, vy, dy);
+      wh_mc_chroma_to (S, P, J, W, mbx, mby, 0, 0, 8, 8, vx, vy, dc);
+      int sad;
+      WV_SUM (sad, lane, wh_sad4 (* (const uint32_t*)&M.enc_y[lane * 4], * (const uint32_t*)&dy[lane * 4]));
+      sad_cost0 = sad; cost_skip_mb = sad;                           // iCostSkipMb = pSadCost[0]: luma only
+      p16x = vx; p16y = vy;
+      scd_coded = true;
+      if (as_skip) { b_skip = true; mb_type = WH_MB_PSKIP; skx = vx; sky = vy; cost_luma = 0; collocated = vx == 0 && vy == 0; done = true; WH_STAT (mode ? WH_ST_SCROLL_SKIP : WH_ST_STATIC_SKIP); }
+      else {
+        WH_STAT (WH_ST_SCD_P16);
+        mb_type = WH_MB_P16x16;
+        collocated = false;                                          // bCollocatedPredFlag keeps WelsMdInterInit's false on this path
+        if (md_using_sad) cost_luma = sad;
+        else cost_luma = wh_cand_sad (S, P, J, W, C, me16, 0, 0);    // ... against pRefLuma WITHOUT the vector (svc_mode_decision.cpp:461-463)
+        WV_LANES_BEGIN (lane)
+        if (lane < 16) { S.mv_out[lane][0] = (int16_t)vx; S.mv_out[lane][1] = (int16_t)vy; S.mvp_out[lane][0] = (int16_t)me16.mvpx; S.mvp_out[lane][1] = (int16_t)me16.mvpy; }
+        WV_LANES_END
+        me16.mvx = vx; me16.mvy = vy;
+        wh_dct_luma16 (M);
+        cbp = wh_enc_inter_y (M, qp);
+        cbp |= wh_encrec_chroma (M, qpc, 0) << 4;
+        wh_idct_luma16 (M);
+        wh_idct_chroma (M);
+        done = true;
+      }
+    }
+  }
+
   // ---- P_Skip test (WelsMdInterJudgePskip / WelsMdPSkipEnc) ----
   if (!done && ((ref_is_p && ref_mb_type == WH_MB_PSKIP) || try_skip)) {
     const int sad_pred_skip = predict_sad_skip();
@@ -976,7 +1216,11 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, WhInterStage& G, const WhSeqParams& 
     if (c_r) WV_LSET (mvcl, i_r, wh_pk_mv (S.co_mv[0][0] >> msh, S.co_mv[0][1] >> msh));
     if (c_b) WV_LSET (mvcl, i_b, wh_pk_mv (S.co_mv[1][0] >> msh, S.co_mv[1][1] >> msh));
     me16.sad_pred = sad_pred;
-    wh_motion_search (S, P, J, W, C, me16, mvcl, nm);
+    if (SCC) {
+      WhSccMe z;
+      z.job = Z; z.method = 1; z.thr = Z->thr16; z.dir_on = 0; z.dmx = 0; z.dmy = 0; z.chain = 0; z.fme_down = 0;     // WelsDiamondCrossSearch
+      wh_motion_search (S, P, J, W, C, me16, mvcl, nm, &z);
+    } else wh_motion_search (S, P, J, W, C, me16, mvcl, nm);
     p16x = me16.mvx; p16y = me16.mvy;
     cost_luma = me16.satd_cost;
     mb_type = WH_MB_P16x16;
@@ -1006,7 +1250,70 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, WhInterStage& G, const WhSeqParams& 
     WV_LSET (mvcl, 0, il_mv);
     int order0 = -1, order1 = -1, order2 = -1;      // group ids: 0 = 8x8, 1 = 16x8, 2 = 8x16
     bool chain = false;                             // later groups only run when the first one beat the 16x16 cost
-    if (!use_satd) {
+    bool merged = false;
+    if (SCC) {
+      // WelsMdInterFinePartitionVaaOnScreen: unless the pre-processing's 8x8 SADs are flat, four 8x8 searches -- each by the method
+      // of its block's static idc -- and, when they win, TryModeMerge: equal vectors side by side or on top of each other make it
+      // a 16x8 / 8x16 macroblock whose partitions carry the SUMS of the 8x8 costs
+      const int32_t* v8 = (const int32_t*)G.cold_pv;
+      const int s8_0 = v8[0], s8_1 = v8[1], s8_2 = v8[2], s8_3 = v8[3];
+      const int avg = (s8_0 + s8_1 + s8_2 + s8_3) >> 2;
+      const int d0 = (s8_0 >> 6) - (avg >> 6), d1 = (s8_1 >> 6) - (avg >> 6), d2 = (s8_2 >> 6) - (avg >> 6), d3 = (s8_3 >> 6) - (avg >> 6);
+      if (d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3 >= 20) {             // MdInterAnalysisVaaInfo_c != MBVAASIGN_FLAT
+        WH_G uint32_t* chn = (WH_G uint32_t*)Z->chain + slice_idc * 4;
+        uint32_t down = 0;
+        int c = 0;
+        for (int i = 0; i < 4; ++i) {
+          WhMe m;
+          wh_slot_geom (WH_SLOT_8x8 + i, &m.bx, &m.by, &m.bw, &m.bh);
+          m.sad_pred = sad_pred16 >> 2;
+          wh_slot_pred (K, WH_SLOT_8x8 + i, &m.mvpx, &m.mvpy);
+          const int idc = i == 0 ? idc0 : i == 1 ? idc1 : i == 2 ? idc2 : idc3;
+          if (idc != 0) WH_STAT (WH_ST_FIXED);
+          if (idc == 1) wh_me_fixed (S, P, J, W, C, m, 0, 0);                                          // WelsMotionEstimateSearchStatic
+          else if (idc == 2) wh_me_fixed (S, P, J, W, C, m, scroll_on ? smx : 0, scroll_on ? smy : 0); // ...Scrolled (sDirectionalMv)
+          else {
+            WhSccMe z;
+            z.job = Z; z.method = Z->fme ? 2 : 0; z.thr = Z->thr8; z.dir_on = scroll_on; z.dmx = smx; z.dmy = smy; z.fme_down = 0;
+            z.chain = scroll_on ? wh_ld_wg32 (chn + i) : 0u;
+            wh_motion_search (S, P, J, W, C, m, mvcl, 1, &z);
+            down += z.fme_down;
+          }
+          if (scroll_on) {           // what the next macroblock of the slice finds in sMe8x8[i].uiSadCost (WH_SEQ_SERIAL: coding order)
+            WV_LANES_BEGIN (lane)
+            if (lane == 0) wh_st_wg32 (chn + i, (uint32_t)m.sad_cost);
+            WV_LANES_END
+          }
+          wh_cache_set (K, m.bx >> 2, m.by >> 2, m.bw >> 2, m.bh >> 2, 0, m.mvx, m.mvy);
+          wh_me_store (T, WH_SLOT_8x8 + i, m);
+          c += m.satd_cost;
+        }
+        if (down) {
+          WV_LANES_BEGIN (lane)
+          if (lane == 0) wh_atomic_add_u32 ((WH_G uint32_t*)Z->fme_cost_down + slice_idc, down);
+          WV_LANES_END
+        }
+        if (c < cost_luma) {
+          mb_type = WH_MB_P8x8;
+          WH_STAT (WH_ST_P8X8);
+          const int v0 = WV_LGET (T.mv, WH_SLOT_8x8), v1 = WV_LGET (T.mv, WH_SLOT_8x8 + 1), v2 = WV_LGET (T.mv, WH_SLOT_8x8 + 2), v3 = WV_LGET (T.mv, WH_SLOT_8x8 + 3);
+          const bool same16x8 = v0 == v1 && v2 == v3, same8x16 = v0 == v2 && v1 == v3;
+          if (same16x8 != same8x16) {
+            merged = true;
+            WH_STAT (WH_ST_MERGE);
+            mb_type = same16x8 ? WH_MB_P16x8 : WH_MB_P8x16;
+            const int first = same16x8 ? WH_SLOT_16x8 : WH_SLOT_8x16, step = same16x8 ? 1 : 2;
+            for (int k = 0; k < 2; ++k) {
+              const int a = WH_SLOT_8x8 + (same16x8 ? 2 * k : k), b = a + step;
+              WhMe m;
+              wh_me_fetch (T, a, m);
+              m.sad_cost += WV_LGET (T.sad, b); m.satd_cost += WV_LGET (T.satd, b);     // MergeSub16Me: the first block's fields, the costs summed
+              wh_me_store (T, first + k, m);
+            }
+          }
+        }
+      }
+    } else if (!use_satd) {
       // WelsMdInterFinePartitionVaa: partition set chosen from the sign pattern of the four 8x8 SADs
       // between this source MB and the previous source frame (VAACalcSad_c + MdInterAnalysisVaaInfo_c)
       int s8_0, s8_1, s8_2, s8_3;
@@ -1068,7 +1375,7 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, WhInterStage& G, const WhSeqParams& 
         wh_slot_geom (first + i, &m.bx, &m.by, &m.bw, &m.bh);
         wh_me_fetch (T, first + i, m);
         wh_slot_pred (K, first + i, &m.mvpx, &m.mvpy);
-        wh_refine_frac (S, P, J, W, C, m, satd_in_md);
+        wh_refine_frac (S, P, J, W, C, m, satd_in_md, merged ? 1 : 0);
         wh_cache_set (K, m.bx >> 2, m.by >> 2, m.bw >> 2, m.bh >> 2, 0, m.mvx, m.mvy);
         {
           const int bx4 = m.bx >> 2, by4 = m.by >> 2, w4 = m.bw >> 2, h4 = m.bh >> 2;
@@ -1171,7 +1478,7 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, WhInterStage& G, const WhSeqParams& 
   // there it already is the slice's last coded QP -- with a per-MB QP map that is only known in coding order, so the MB
   // leaves a marker that wh_qp_chain_slice resolves.
   const bool decided_skip = is_skip && b_skip;                          // not the P16x16 that WelsMdInterDoubleCheckPskip renames
-  if (!bg_coded) collocated = decided_skip ? (skx == 0 && sky == 0) : ((is_skip || mb_type == WH_MB_P16x16) && cbp == 0 && me16.mvx == 0 && me16.mvy == 0);
+  if (!bg_coded && !scd_coded) collocated = decided_skip ? (skx == 0 && sky == 0) : ((is_skip || mb_type == WH_MB_P16x16) && cbp == 0 && me16.mvx == 0 && me16.mvy == 0);
   {
     const bool inherit = cbp == 0 && ref_is_p && collocated;
     const bool last_qp = !inherit && decided_skip && J.mb_ctl != nullptr;
@@ -1186,4 +1493,7 @@ WH_FN void wh_inter_mb_body (WhInterLds& S, WhInterStage& G, const WhSeqParams& 
     }
   }
   WH_PROF_MARK (P, M, 7);   // store
+}
+WH_FN void wh_inter_mb_body (WhInterLds& S, WhInterStage& G, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, const WhInterCtx& X) {
+  wh_inter_mb_body_t<false> (S, G, P, J, mbx, mby, X);
 }

@@ -84,6 +84,10 @@ WH_FN void wh_ld_async16 (const void* src, void* lds_base, int lane) { memcpy ((
 // a write-through store and a cache-bypassing load (sc0 sc1) -- see the device twins below.
 WH_FN void wh_st_xwg32 (uint32_t* p, uint32_t v) { *p = v; }
 WH_FN uint32_t wh_ld_xwg32 (const uint32_t* p) { return *p; }
+// One word in global memory that another wavefront of the SAME workgroup wrote earlier in this launch (ordered by the
+// scheduler's done flags): a vector-memory access on the GPU, never a scalar load (the scalar cache is not coherent with stores)
+WH_FN void wh_st_wg32 (uint32_t* p, uint32_t v) { *p = v; }
+WH_FN uint32_t wh_ld_wg32 (const uint32_t* p) { return *p; }
 // four bytes at any byte offset of a 4-byte aligned LDS array
 WH_FN uint32_t wh_ld4u (const uint8_t* base, int off) { uint32_t v; memcpy (&v, base + off, 4); return v; }
 // sum of absolute differences of four packed bytes
@@ -199,6 +203,8 @@ WH_FN void wh_ld_async16 (const WH_G void* src, void* lds_base, int /*lane*/) {
 // (MI355X_MICROARCH.md, inter-workgroup visibility: "sc0 sc1 stores and loads both sides").
 WH_FN void wh_st_xwg32 (WH_G uint32_t* p, uint32_t v) { __hip_atomic_store (p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 WH_FN uint32_t wh_ld_xwg32 (const WH_G uint32_t* p) { return __hip_atomic_load (p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+WH_FN void wh_st_wg32 (WH_G uint32_t* p, uint32_t v) { __hip_atomic_store (p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+WH_FN uint32_t wh_ld_wg32 (const WH_G uint32_t* p) { return __hip_atomic_load (p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 WH_FN int wh_sad4 (uint32_t a, uint32_t b) { return (int)__builtin_amdgcn_sad_u8 (a, b, 0u); }
 WH_FN uint32_t wh_avg4 (uint32_t a, uint32_t b) { return __builtin_amdgcn_lerp (a, b, 0x01010101u); }
 #endif

@@ -13,7 +13,7 @@
 //           [-rc M] [-qp Q] [-bitrate BPS] [-iper N] [-numtl N] [-complexity C]
 //           [-slcmd M] [-slcnum N] [-slcmbnum N] [-threads N] [-loadbalancing 0/1]
 //           [-deblock IDC] [-aq 0/1] [-bgd 0/1] [-scene 0/1] [-ltr 0/1] [-denoise 0/1]
-//           [-frameskip 0/1] [-cabac 0/1] [-spsid S] [-usage U] [-base] [-quiet]
+//           [-frameskip 0/1] [-cabac 0/1] [-spsid S] [-usage U] [-base | -ext [-lossless 0/1]] [-quiet]
 //
 // Prints "frames=<n> bytes=<n> enc_seconds=<s> fps=<f>" (timed strictly around EncodeFrame,
 // like welsenc.cpp:957-960).
@@ -31,7 +31,7 @@ static bool arg_eq (const char* a, const char* b) { return std::strcmp (a, b) ==
 // one encoder instance; `instance` >= 0: one of several running in this process at once (-parallel N), output file out.<instance>
 static int run (int argc, char** argv, int instance) {
   std::string in, out;
-  int w = 0, h = 0, frames = -1, quiet = 0, use_base = 0;
+  int w = 0, h = 0, frames = -1, quiet = 0, use_base = 0, use_ext = 0, lossless = 0, profile = 66;
   float fps = 30.0f;
   int rc = -1, qp = 24, bitrate = 5000000, iper = 0, numtl = 1, complexity = 0;
   int slcmd = 0, slcnum = 1, slcmbnum = 0, threads = 1, loadbal = 0, deblock = 0;
@@ -73,6 +73,9 @@ static int run (int argc, char** argv, int instance) {
     else if (arg_eq (a, "-spsid")) spsid = std::atoi (next());
     else if (arg_eq (a, "-usage")) usage = std::atoi (next());
     else if (arg_eq (a, "-base")) use_base = 1;
+    else if (arg_eq (a, "-ext")) use_ext = 1;
+    else if (arg_eq (a, "-profile")) profile = std::atoi (next());          // uiProfileIdc: 66 baseline (layer2.cfg), 77 main, 100 high (CABAC needs one of the latter)
+    else if (arg_eq (a, "-lossless")) lossless = std::atoi (next());
     else if (arg_eq (a, "-alpha")) alpha = std::atoi (next());
     else if (arg_eq (a, "-beta")) beta = std::atoi (next());
     else if (arg_eq (a, "-crop")) crop = std::atoi (next());
@@ -100,6 +103,20 @@ static int run (int argc, char** argv, int instance) {
     b.iUsageType = (EUsageType)usage; b.iPicWidth = w; b.iPicHeight = h;
     b.iTargetBitrate = bitrate; b.iRCMode = (RC_MODES)rc; b.fMaxFrameRate = fps;
     ret = enc->Initialize (&b);
+  } else if (use_ext) {     // the fixture test/api/BaseEncoderTest.cpp:25-71 uses when SEncParamBase cannot express the case (-denoise, -ltr, -cabac,
+    SEncParamExt p; enc->GetDefaultParams (&p);      // -lossless, a slice mode): GetDefaultParams plus exactly those fields
+    p.iUsageType = (EUsageType)usage; p.fMaxFrameRate = fps; p.iPicWidth = w; p.iPicHeight = h; p.iTargetBitrate = 5000000;
+    p.bEnableDenoise = denoise != 0; p.iSpatialLayerNum = 1; p.bIsLosslessLink = lossless != 0;
+    p.bEnableLongTermReference = ltr != 0; p.iEntropyCodingModeFlag = cabac ? 1 : 0;
+    if (slcmd != SM_SINGLE_SLICE && slcmd != SM_SIZELIMITED_SLICE) p.iMultipleThreadIdc = 2;
+    SSpatialLayerConfig& l = p.sSpatialLayers[0];
+    l.iVideoWidth = w; l.iVideoHeight = h; l.fFrameRate = fps; l.iSpatialBitrate = p.iTargetBitrate;
+    l.sSliceArgument.uiSliceMode = (SliceModeEnum)slcmd;
+    if (slcmd == SM_SIZELIMITED_SLICE) { l.sSliceArgument.uiSliceSizeConstraint = 600; p.uiMaxNalSize = 1500; p.iMultipleThreadIdc = 4; p.bUseLoadBalancing = false; }
+    if (slcmd == SM_FIXEDSLCNUM_SLICE) { l.sSliceArgument.uiSliceNum = 4; p.iMultipleThreadIdc = 4; p.bUseLoadBalancing = false; }
+    if (cabac) l.uiProfileIdc = PRO_MAIN;
+    if (threads != 1) p.iMultipleThreadIdc = (unsigned short)threads;      // (-threads N after -ext overrides the fixture's thread count)
+    ret = enc->InitializeExt (&p);
   } else {
     SEncParamExt p; enc->GetDefaultParams (&p);
     p.iUsageType = (EUsageType)usage;
@@ -125,7 +142,7 @@ static int run (int argc, char** argv, int instance) {
     SSpatialLayerConfig& l = p.sSpatialLayers[0];
     l.iVideoWidth = w; l.iVideoHeight = h; l.fFrameRate = fps;
     l.iSpatialBitrate = bitrate; l.iDLayerQp = qp;
-    l.uiProfileIdc = PRO_BASELINE;               // layer2.cfg ProfileIdc 66
+    l.uiProfileIdc = (EProfileIdc)profile;       // default: layer2.cfg ProfileIdc 66
     l.sSliceArgument.uiSliceMode = (SliceModeEnum)slcmd;
     l.sSliceArgument.uiSliceNum = (unsigned)slcnum;
     if (slcmbnum > 0) for (int k = 0; k < MAX_SLICES_NUM_TMP; ++k) l.sSliceArgument.uiSliceMbNum[k] = (unsigned)slcmbnum;

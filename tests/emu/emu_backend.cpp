@@ -57,7 +57,7 @@ class EmuBackend : public Backend {
         const int first = P.slice_first_mb[s], last = P.slice_first_mb[s + 1];
         int last_mv = 0;
         for (int t = first; t < last; ++t) {
-          const int xy = P.mb_order[t];
+          const int xy = (P.flags & WH_SEQ_SERIAL) ? t : (int)P.mb_order[t];       // coding order for pictures with a scroll vector
           if (jobs[j].mb_end > 0 && (xy < jobs[j].mb_begin || xy >= jobs[j].mb_end)) continue;      // GOM-synchronous coding: only this range
           const int mbx = xy % P.mb_w, mby = xy / P.mb_w;
           for (int lane = 0; lane < 64; ++lane) wh_inter_cold_fetch (G, lane, P, jobs[j], mbx, mby);
@@ -68,7 +68,8 @@ class EmuBackend : public Backend {
           X.spec_valid = ((t + s + j) % 5) != 0;            // exercise both paths: most macroblocks speculate, every fifth does not
           if (X.spec_valid) wh_win_speculate (P, jobs[j], X.spec, mbx, mby, last_mv);
           X.last_mv = &last_mv;
-          wh_inter_mb_body (S, G, P, jobs[j], mbx, mby, X);
+          if (P.flags & WH_SEQ_SCC) wh_inter_mb_body_t<true> (S, G, P, jobs[j], mbx, mby, X);
+          else wh_inter_mb_body (S, G, P, jobs[j], mbx, mby, X);
           poison (&S, sizeof (S)); poison (&WB, sizeof (WB)); poison (&G, sizeof (G));      // nothing survives from one macroblock to the next
         }
       }

@@ -1,12 +1,14 @@
-"""Every device row of the reference's bitstream-regression table (test/encoder_binary_comparison/SHA1Table/
-BA_MW_D.264_AllCases_SHA1_Table.csv) through the dispatch-table binding, the way tests/test_hooks_sha1.py runs its sample.
-usage: sha1_table_rows.py [--lib path] [--workers N] [--stride K]      (default library: openh264_amd/libwelship.so)"""
+"""Every device row of one of the reference's bitstream-regression tables (test/encoder_binary_comparison/SHA1Table/:
+BA_MW_D.264_AllCases_SHA1_Table.csv, camera video; Adobe_PDF_sample_a_1024x768_50Frms.264_AllCases_SHA1_Table.csv, screen
+content) through the dispatch-table binding, the way tests/test_hooks_sha1.py / tests/test_hooks_screen.py run their samples.
+usage: sha1_table_rows.py [--table ba|adobe] [--lib path] [--workers N] [--stride K]      (default library: openh264_amd/libwelship.so)"""
 import argparse, os, pathlib, subprocess, sys, tempfile, time
 from concurrent.futures import ThreadPoolExecutor
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
-import test_hooks_sha1 as T
+import test_hooks_sha1 as T_BA
+import test_hooks_screen as T_ADOBE
 
 
 def main():
@@ -14,10 +16,14 @@ def main():
     ap.add_argument("--lib", default=os.path.join(ROOT, "openh264_amd", "libwelship.so"))
     ap.add_argument("--workers", type=int, default=8)
     ap.add_argument("--stride", type=int, default=1)
+    ap.add_argument("--table", default="ba", choices=("ba", "adobe"))
     a = ap.parse_args()
     a.lib = os.path.abspath(a.lib)
+    T = T_BA if a.table == "ba" else T_ADOBE
+    clip = "BA_MW_D.264" if a.table == "ba" else T_ADOBE.CLIP
+    min_pics = 40 if a.table == "ba" else 1       # the screen table's 450 kbps rows skip most of their 30 frames
     d = pathlib.Path(tempfile.mkdtemp())
-    subprocess.check_call([os.path.join(T.REF, "ref_dec"), os.path.join(T.RES, "BA_MW_D.264"), str(d / "BA_MW_D.264.yuv")], stdout=subprocess.DEVNULL)
+    subprocess.check_call([os.path.join(T.REF, "ref_dec"), os.path.join(T.RES, clip), str(d / (clip + ".yuv"))], stdout=subprocess.DEVNULL)
     for k in range(4):
         (d / ("layer%d.cfg" % k)).write_bytes(open(os.path.join(T.RES, "layer2.cfg"), "rb").read())
     (d / "welsenc.cfg").write_bytes(open(os.path.join(T.RES, "welsenc.cfg"), "rb").read())
@@ -27,12 +33,13 @@ def main():
     def one(ir):
         i, r = ir
         got, pics, err = T._run_row(d, a.lib, r, "w%d" % i)
-        os.remove(str(d / ("t_w%d.264" % i)))
-        return i, got == r[0] and pics >= 40, r[4]["-slcmd 0"], got, pics
+        if a.table == "ba": os.remove(str(d / ("t_w%d.264" % i)))
+        return i, got == r[0] and pics >= min_pics and "welship hooks: installed" in err, r[4]["-slcmd 0"], got, pics
 
-    bad, by_mode = [], {}
+    bad, by_mode, total_pics = [], {}, 0
     with ThreadPoolExecutor(a.workers) as ex:
         for i, ok, mode, got, pics in ex.map(one, enumerate(rows)):
+            total_pics += pics
             by_mode.setdefault(mode, [0, 0])
             by_mode[mode][0] += 1
             if not ok:
@@ -40,7 +47,7 @@ def main():
                 bad.append((i, rows[i][4], got, pics))
     for mode in sorted(by_mode):
         print("-slcmd %s : rows %d bad %d" % (mode, by_mode[mode][0], by_mode[mode][1]))
-    print("device rows %d of the table's %d, bad %d, %.1f s, %d workers, library %s" % (len(rows), len(T._rows()), len(bad), time.time() - t0, a.workers, os.path.basename(a.lib)))
+    print("table %s: device rows %d of the table's %d, bad %d, %d pictures coded on the device, %.1f s, %d workers, library %s" % (os.path.basename(T.TABLE), len(rows), len(T._rows()), len(bad), total_pics, time.time() - t0, a.workers, os.path.basename(a.lib)))
     for b in bad[:10]:
         print("BAD", b)
     return 1 if bad else 0
