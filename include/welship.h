@@ -216,6 +216,7 @@ typedef struct WelsHipScreenInfo {
   int32_t bScrollDetectFlag, iScrollMvX, iScrollMvY;   /* pVaaExt->sScrollDetectInfo                                                         */
   uint32_t uiSadCostThreshold16x16, uiSadCostThreshold8x8;   /* pRefPic->pScreenBlockFeatureStorage->uiSadCostThreshold[BLOCK_16x16 / _8x8]  */
   int32_t bFeatureSearch8x8;            /* pfSearchMethod[BLOCK_8x8] == WelsDiamondCrossFeatureSearch for this picture                       */
+  int32_t bStaticSkipDecision;          /* pfSCDPSkipDecision == WelsMdInterJudgeSCDPskip (encoder.cpp:205-208: off with HIGH complexity)    */
   /* the reference picture's SScreenBlockFeatureStorage as PerformFMEPreprocess built it (svc_motion_estimate.cpp:839-873); read only   */
   /* with bFeatureSearch8x8                                                                                                              */
   const uint32_t* pTimesOfFeatureValue; /* [iListSize]                                                                                       */

@@ -40,6 +40,7 @@
 #include "svc_encode_slice.h"
 #include "svc_base_layer_md.h"
 #include "svc_motion_estimate.h"
+#include "svc_mode_decision.h"
 #include "svc_set_mb_syn.h"
 #include "svc_enc_golomb.h"
 #include "rc.h"
@@ -49,6 +50,9 @@
 #include "wh_types.h"          // WhMbRecord: the engine's per-macroblock record (openh264_amd/csrc/common)
 
 namespace WelsEnc {
+
+// defined in svc_mode_decision.cpp:520-537 (no header declares it): what WelsInitSCDPskipFunc installs for screen content below HIGH complexity
+bool WelsMdInterJudgeSCDPskip (sWelsEncCtx* pEncCtx, SWelsMD* pWelsMd, SSlice* slice, SMB* pCurMb, SMbCache* pMbCache);
 
 namespace {
 
@@ -226,6 +230,7 @@ int32_t HipFrameMd (sWelsEncCtx* pCtx) {
         if (pRefOri->iLineSize[1] != pCurLayer->iEncStride[1]) { fprintf (stderr, "welship hooks: source pictures with different strides\n"); st->failed = true; return ENC_RETURN_UNEXPECTED; }
         scr.pRefOriChroma[0] = pRefOri->pData[1]; scr.pRefOriChroma[1] = pRefOri->pData[2]; scr.iRefOriStride = pRefOri->iLineSize[1];
       }
+      scr.bStaticSkipDecision = pFunc->pfSCDPSkipDecision == WelsMdInterJudgeSCDPskip ? 1 : 0;
       scr.bScrollDetectFlag = pVaaExt->sScrollDetectInfo.bScrollDetectFlag ? 1 : 0;
       scr.iScrollMvX = pVaaExt->sScrollDetectInfo.iScrollMvX; scr.iScrollMvY = pVaaExt->sScrollDetectInfo.iScrollMvY;
       const SScreenBlockFeatureStorage* pSt = pCurLayer->pRefPic->pScreenBlockFeatureStorage;

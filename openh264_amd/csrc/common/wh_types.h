@@ -101,7 +101,8 @@ typedef struct WhSccJob {
   const uint32_t* fme_start;   // first entry of that sum in fme_loc (in entries)
   const uint16_t* fme_loc;     // pLocationPointer: {x << 2, y << 2} of every block, grouped by sum, raster order inside a group
   int32_t fme_list_size;
-  int32_t pad;
+  int32_t scd_on;              // pfSCDPSkipDecision == WelsMdInterJudgeSCDPskip (encoder.cpp:205-208: not with HIGH complexity); when it is off
+                               //   the macroblock never looks at static_idc either -- SetBlockStaticIdcToMd is part of that function
   uint32_t* chain;             // [num_slices][4]: uiSadCost the slice's SWelsMD keeps in sMe8x8[i] from one macroblock to the next
                                //   (CheckDirectionalMv compares against it BEFORE the search overwrites it, svc_motion_estimate.cpp:385-402)
   uint32_t* fme_cost_down;     // [num_slices]: what the picture adds to pSlice->uiSliceFMECostDown
@@ -127,7 +128,7 @@ typedef struct WhPicJob {
   uint32_t*      scene_count; // scene-change statistic (kernels/scene_pic.h): zeroed by the host, incremented by the kernel
   // ---- what the reference keeps per LAYER rather than per picture, and what its pre-processing hands to mode decision ----
   int32_t*       sad_cost0;   // pSadCost[0] of every MB (the layer's SMB array, encoder_ext.cpp:900,1675): persists from picture to
-                              //   picture whatever the reference picture is; P pictures read and rewrite it, I pictures leave it alone
+                              //   picture whatever the reference picture is; P pictures read and rewrite it, intra macroblocks (I pictures too) zero it
   const int32_t* vaa_sad8x8;  // the host's VAACalcSad result [mb][4] (pVaa->sVaaCalcInfo.pSad8x8), or NULL: computed from prev_src_y
   const int8_t*  bgd_flags;   // pVaa->pVaaBackgroundMbFlag [mb], or NULL: background detection off
   int32_t        mvc_shift;   // sScaleShift (svc_encode_slice.cpp:1652-1655): temporal-layer scaling of the co-located MV candidates

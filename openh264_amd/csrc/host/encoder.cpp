@@ -1629,6 +1629,7 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
       z.scroll_flag = scr->bScrollDetectFlag ? 1 : 0; z.scroll_mvx = scr->iScrollMvX; z.scroll_mvy = scr->iScrollMvY;
       z.thr16 = scr->uiSadCostThreshold16x16; z.thr8 = scr->uiSadCostThreshold8x8;
       z.fme = scc_lists ? 1 : 0;
+      z.scd_on = scr->bStaticSkipDecision ? 1 : 0;
       z.fme_times = c->d_scc_lists; z.fme_start = c->d_scc_lists ? c->d_scc_lists + scc_lists : nullptr; z.fme_loc = c->d_scc_loc;
       z.fme_list_size = (int32_t)scc_lists;
       z.chain = c->d_scc_chain; z.fme_cost_down = c->d_scc_chain + 4 * WH_MAX_SLICES;

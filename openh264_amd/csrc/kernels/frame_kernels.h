@@ -130,6 +130,9 @@ WH_FN void wh_intra_mb_body (WhMbLds& S, const WhSeqParams& P, const WhPicJob& J
   WH_G WhMbRecord* Rs = (WH_G WhMbRecord*)J.records + xy;
   if (lane < 16) { Ms->mv[lane][0] = 0; Ms->mv[lane][1] = 0; Rs->mvd[lane][0] = 0; Rs->mvd[lane][1] = 0; }
   if (lane < 4) { Ms->ref_idx[lane] = -1; Rs->ref_idx[lane] = -1; Rs->sub_type[lane] = 0; Ms->sad_cost[lane] = 0; }
+  // pSadCost[0] = 0 (WelsMdIntraSecondaryModesEnc, svc_base_layer_md.cpp:2038) -- in the layer's array too, where a P_Skip of a later
+  // picture that is not costed by SAD (complexity above LOW) finds it (found by tools/fuzz_screen.py: an I picture in mid-stream)
+  if (lane == 0 && J.sad_cost0) ((WH_G int32_t*)J.sad_cost0)[xy] = 0;
   WV_LANES_END
   wh_store_mb (S, P, J, mbx, mby, r.mb_type, r.cbp, qp, qpc, r.i16_mode_std, r.chroma_mode_std, r.cost_luma, wh_slice_of_mb (P, xy));
 }

@@ -1090,12 +1090,15 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
   bool scd_coded = false;
   if (SCC) {
     Z = (const WH_G WhSccJob*)J.scc;
-    const WH_G uint8_t* ip = (const WH_G uint8_t*)Z->static_idc + (size_t) (2 * mby) * (2 * w) + 2 * mbx;
-    idc0 = ip[0]; idc1 = ip[1]; idc2 = ip[2 * w]; idc3 = ip[2 * w + 1];
+    const int scd_on = Z->scd_on;
+    if (scd_on) {                                                    // SetBlockStaticIdcToMd: part of WelsMdInterJudgeSCDPskip; else all four stay NO_STATIC
+      const WH_G uint8_t* ip = (const WH_G uint8_t*)Z->static_idc + (size_t) (2 * mby) * (2 * w) + 2 * mbx;
+      idc0 = ip[0]; idc1 = ip[1]; idc2 = ip[2 * w]; idc3 = ip[2 * w + 1];
+    }
     const int sflag = Z->scroll_flag;
     smx = Z->scroll_mvx; smy = Z->scroll_mvy;
     scroll_on = sflag && (smx | smy);                                // pfSetScrollingMv == SetScrollingMvToMd (encoder_ext.cpp:2707-2713)
-    for (int mode = 0; mode < 2 && !done; ++mode) {                  // STATIC, SCROLLED
+    for (int mode = 0; scd_on && mode < 2 && !done; ++mode) {        // STATIC, SCROLLED
       const int want = mode == 0 ? 1 : 2;                            // COLLOCATED_STATIC / SCROLLED_STATIC
       if (mode == 1 && !sflag) break;
       if (!(idc0 == want && idc1 == want && idc2 == want && idc3 == want)) continue;

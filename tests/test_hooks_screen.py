@@ -168,3 +168,25 @@ def test_screen_api_hash_through_the_hooks_on_the_mi355x(hip_lib, tmp_path, name
     got, err = _api_hash("ref_enc_hip", hip_lib, tmp_path, name, w, h, fps)
     assert "welship hooks: installed" in err and err.count("welship hooks: did") >= 5
     assert got == sha
+
+
+# ---- randomised screen-content sessions (tools/fuzz_screen.py): synthetic scrolling documents, random parameters ------------
+def _fuzz(lib, tmp_path, seeds):
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_screen
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(8) as ex:
+        res = list(ex.map(lambda s: fuzz_screen.run_case(s, lib, str(tmp_path)), seeds))
+    bad = [r for r in res if r[1] == "DIFF"]
+    assert not bad, bad[0]
+    assert sum(r[1] == "ok" for r in res) >= len(res) // 2        # (the rest: parameter sets the reference itself rejects)
+
+
+def test_screen_fuzz_on_emulation(emu_lib, tmp_path):
+    _fuzz(emu_lib, tmp_path, range(0, 16))
+
+
+@pytest.mark.gpu
+def test_screen_fuzz_on_the_mi355x(hip_lib, tmp_path):
+    _fuzz(hip_lib, tmp_path, range(100, 124))
