@@ -17,13 +17,13 @@
 //                                            pfWelsSpatialWriteMbSyn, pfWelsRcMbInfoUpdate per macroblock
 //   pfHipRelease (state)                     WelsUninitEncoderExt (encoder_ext.cpp:2239)
 //
-// What runs on the device (see WelsHipSupported below): camera video, one spatial layer, CAVLC, any number of temporal layers,
+// What runs on the device (see WelsHipSupported below): camera video and screen content, CAVLC and CABAC, slice threads, temporal layers,
 // LTR, denoising, scene-change and background detection, frame skipping, all rate-control modes.  With a frame-constant QP
 // (rate control off, or on with more than one slice, or I pictures in bitrate mode: WelsRcMbInitGom with bEnableGomQp ==
 // false, ratectl.cpp:1199-1204,1239-1262) a picture is one device call; with GOM-level QP (one slice per picture) the QP of a
 // group of macroblocks depends on the bits the groups before it produced, so the picture is coded group by group from inside
 // the slice loop -- a latency chain of one device call per group, bit-exact but not the throughput path.  Everything else
-// (screen content, CABAC, size-limited slices, SVC inter-layer prediction, slice threads -- and, unless WELS_HIP_GOM=1, the
+// (size-limited slices, SVC inter-layer prediction -- and, unless WELS_HIP_GOM=1, the
 // GOM-level-QP sessions, which are correct but slower than the host) keeps the reference's C path -- the hooks stay NULL, as
 // they would on a CPU without the needed SIMD level.
 #if defined(HAVE_HIP)
@@ -41,6 +41,7 @@
 #include "svc_base_layer_md.h"
 #include "svc_motion_estimate.h"
 #include "svc_mode_decision.h"
+#include "deblocking.h"
 #include "svc_set_mb_syn.h"
 #include "svc_enc_golomb.h"
 #include "rc.h"
@@ -184,6 +185,16 @@ int32_t HipFrameMd (sWelsEncCtx* pCtx) {
   const int iHighestTid = pParam->sDependencyLayers[did].iHighestTemporalId;
   job.bDeblock = (!pCurLayer->bDeblockingParallelFlag) && pCtx->eNalPriority != NRI_PRI_LOWEST && (iHighestTid == 0 || pCtx->uiTemporalId < iHighestTid)
                  && pCurLayer->iLoopFilterDisableIdc != 1;
+  // Slice threads (iMultipleThreadIdc > 1): the reference filters slice by slice from inside its slice tasks (wels_task_encoder.cpp:184,
+  // pfDeblockingFilterSlice as PreprocessSliceCoding just set it, encoder_ext.cpp:2773-2783; the filter mode is 2 then: no edge
+  // crosses a slice).  That is the same picture-wide pass on the device; the host's per-slice filter is switched off for this picture.
+  // (No task runs for a picture of a single slice: the reference does not filter it at all then.)
+  if (pCurLayer->bDeblockingParallelFlag && pFunc->pfDeblocking.pfDeblockingFilterSlice == DeblockingFilterSliceAvcbase) {
+    const SliceModeEnum eMode = pParam->sSpatialLayers[did].sSliceArgument.uiSliceMode;
+    const bool tasks = eMode != SM_SINGLE_SLICE && eMode != SM_SIZELIMITED_SLICE && pParam->iMultipleThreadIdc > 1;
+    job.bDeblock = tasks ? 1 : 0;
+    pFunc->pfDeblocking.pfDeblockingFilterSlice = DeblockingFilterSliceAvcbaseNull;
+  }
   job.bExpand = pCtx->eNalPriority != NRI_PRI_LOWEST;        // UpdateRefList -> ExpandReferencingPicture (encoder_ext.cpp:3891-3899)
   for (int i = 0; i < 3; ++i) { job.pSrc[i] = pCurLayer->pEncData[i]; job.iSrcStride[i] = pCurLayer->iEncStride[i]; }
   job.pVaaSad8x8 = (is_p && pCtx->pVaa && pCtx->pVaa->sVaaCalcInfo.pSad8x8) ? &pCtx->pVaa->sVaaCalcInfo.pSad8x8[0][0] : NULL;
@@ -314,7 +325,7 @@ int32_t HipCodeSlice (sWelsEncCtx* pCtx, SSlice* pSlice) {
   HipState* st = (HipState*)pFunc->pHipState;
   HipLayer& L = st->layer[pCtx->uiDependencyId];
   if (st->failed || (L.records == NULL && !L.gom)) return ENC_RETURN_UNEXPECTED;
-  Stopwatch sw_code (st->timing ? &st->t_code : NULL);
+  Stopwatch sw_code (st->timing && pCtx->pSvcParam->iMultipleThreadIdc <= 1 ? &st->t_code : NULL);     // (slice tasks run concurrently: not summed)
   SDqLayer* pCurLayer = pCtx->pCurDqLayer;
   SMbCache* pMbCache = &pSlice->sMbCacheInfo;
   SMB* pMbList = pCurLayer->sMbDataP;
@@ -426,7 +437,8 @@ bool WelsHipSupported (const SWelsSvcCodingParam* p, const char** why) {
   // simulcast AVC layers are independent streams (no inter-layer prediction): one device context per layer, optionally one
   // GPU per layer (WELS_HIP_LAYER_DEVICES=1: layer d runs on device WELS_HIP_DEVICE + d)
   if (p->iSpatialLayerNum != 1 && !p->bSimulcastAVC) NO ("spatial layers with SVC syntax (tried: not byte-identical yet; simulcast AVC is)");
-  if (p->iMultipleThreadIdc != 1) NO ("slice threads: the host loop is single-threaded in this binding");
+  // slice threads: every slice task entropy-codes its slice from the (read-only) records of the picture; see HipFrameMd for the filter
+  if (p->iMultipleThreadIdc != 1 && getenv ("WELS_HIP_THREADS") && atoi (getenv ("WELS_HIP_THREADS")) == 0) NO ("slice threads switched off (WELS_HIP_THREADS=0)");
   // bEnableAdaptiveQuant: ParamValidation switches it off for every session (encoder_ext.cpp:300-301), nothing to check
   const char* gom = getenv ("WELS_HIP_GOM");
   const bool gom_ok = gom != NULL && atoi (gom) != 0;
