@@ -253,7 +253,21 @@ typedef struct WelsHipFrameJob {
                                     /* the context keeps its own (single-layer sessions)                                                 */
   const WelsHipScreenInfo* pScreen; /* screen-content P pictures, else NULL (I pictures of a screen-content session: iComplexityMode >= 1, */
                                     /* PreprocessSliceCoding selects the SATD / full-search intra functions for them)                       */
+  /* TRY_REENCODING (svc_encode_slice.cpp:564-576,1845-1867): the entropy writer could not code a macroblock (CAVLC level overflow,  */
+  /* or the picture's bitstream buffer nearly full) and the reference codes it again with its QP raised by 2.  The caller repeats   */
+  /* the call with bRetry = 1 and the list of ALL macroblocks re-encoded so far in this picture: the device inputs uploaded by the   */
+  /* first call are reused (the host may have modified its copies meanwhile), every other macroblock reproduces itself.              */
+  int32_t bRetry;
+  int32_t iNumReencode;
+  const struct WelsHipMbReencode* pReencode;
 } WelsHipFrameJob;
+typedef struct WelsHipMbReencode {
+  int32_t iMbXY;
+  uint8_t uiLumaQp;                 /* the QP of this pass (UpdateQpForOverflow)                                                       */
+  uint8_t uiStaleCbp;               /* uiCbp the previous pass left (only WelsMdIntraInit clears it, and that is not repeated)         */
+  uint8_t bCell12Valid, pad;        /* the previous pass ended as P8x16: update_P8x16_motion_info wrote its second vector into the     */
+  int16_t iCell12Mv[2];             /* MV cache's left-neighbour cell (mv_pred.cpp:235-276); the vector                                */
+} WelsHipMbReencode;
 int  WelsHipFrameCtxCreate (WelsHipFrameCtx** ppCtx, const WelsHipFrameCfg* pCfg);
 void WelsHipFrameCtxDestroy (WelsHipFrameCtx* pCtx);
 /* Runs the picture (or MB range) on the device and waits; *ppRecords = WhMbRecord[mb_w * mb_h] in host memory, valid until

@@ -102,6 +102,7 @@ struct HipLayer {                       // one spatial layer = one device contex
   std::vector<uint32_t> fme_down;        //   and what the device reports back per slice (uiSliceFMECostDown)
   std::vector<int16_t> il_hint;          // highest layer of a multi-layer session: hints from the layer below
   std::vector<WhMbState> states;         // lower layers of a multi-layer session: the device's motion data, for the layer above
+  std::vector<WelsHipMbReencode> reencode;   // macroblocks of the picture being coded that were coded again at a higher QP (TRY_REENCODING)
 };
 
 struct HipState {
@@ -158,6 +159,7 @@ int32_t HipFrameMd (sWelsEncCtx* pCtx) {
     if (rc) { fprintf (stderr, "welship hooks: no device context (%d: %s)\n", rc, g_api.GetLastError()); st->failed = true; return ENC_RETURN_UNEXPECTED; }
   }
   L.gom = !FrameConstantQp (pCtx);
+  L.reencode.clear();
   WelsHipFrameJob& job = L.job;
   memset (&job, 0, sizeof (job));
   const bool is_p = pCtx->eSliceType == P_SLICE;
@@ -336,12 +338,16 @@ int32_t HipCodeSlice (sWelsEncCtx* pCtx, SSlice* pSlice) {
   int32_t iNextMbIdx = kiSliceFirstMbXY, iNumMbCoded = 0;
   static_assert (sizeof (SDCTCoeff) == 816, "SDCTCoeff layout");
   if (is_p) pSlice->iMbSkipRun = 0;
+  SDynamicSlicingStack sDss;
+  memset (&sDss, 0, sizeof (sDss));
+  const bool kbCavlc = pCtx->pSvcParam->iEntropyCodingModeFlag == 0;
   // CABAC: the slice's arithmetic coder starts here, as in WelsISliceMdEnc / WelsMdInterMbLoop (svc_encode_slice.cpp:550-554,1824-1828);
   // the writer (WelsSpatialWriteMbSynCabac) derives its contexts from what it wrote for the neighbours (sMvd, iCbpDc, types)
   if (pCtx->pSvcParam->iEntropyCodingModeFlag) WelsInitSliceCabac (pCtx, pSlice);
   for (;;) {
     const int32_t iCurMbIdx = iNextMbIdx;
     SMB* pCurMb = &pMbList[iCurMbIdx];
+    if (kbCavlc) pFunc->pfStashMBStatus (&sDss, pSlice, is_p ? pSlice->iMbSkipRun : 0);      // (the position TRY_REENCODING returns to)
     // QP of the macroblock through the reference's own RC entry point (frame constant, or the group's: WelsRcMbInitGom)
     pFunc->pfRc.pfWelsRcMbInit (pCtx, pCurMb, pSlice);
     if (L.gom && iCurMbIdx >= L.coded_upto) {
@@ -370,20 +376,52 @@ int32_t HipCodeSlice (sWelsEncCtx* pCtx, SSlice* pSlice) {
         }
       }
     }
+    bool bInitDone = false;
+TRY_REENCODING:
     const WhMbRecord& R = L.records[iCurMbIdx];
     if (pCurMb->uiLumaQp != R.luma_qp) { fprintf (stderr, "welship hooks: QP mismatch at MB %d (%d vs %d)\n", iCurMbIdx, pCurMb->uiLumaQp, R.luma_qp); st->failed = true; return ENC_RETURN_UNEXPECTED; }
     // neighbour caches the entropy writer reads (non-zero counts): the reference's own init functions
-    WelsMdIntraInit (pCtx, pCurMb, pMbCache, kiSliceFirstMbXY);
-    if (is_p) WelsMdInterInit (pCtx, pSlice, pCurMb, kiSliceFirstMbXY);
+    if (!bInitDone) {        // (not repeated for a re-encoded macroblock, as in the reference: the label comes after them)
+      WelsMdIntraInit (pCtx, pCurMb, pMbCache, kiSliceFirstMbXY);
+      if (is_p) WelsMdInterInit (pCtx, pSlice, pCurMb, kiSliceFirstMbXY);
+      bInitDone = true;
+    }
     LoadRecord (R, pCurMb, pMbCache);
     UpdateNonZeroCountCache (pCurMb, pMbCache);
     const int32_t iEncReturn = pFunc->pfWelsSpatialWriteMbSyn (pCtx, pSlice, pCurMb);
-    if (iEncReturn == ENC_RETURN_VLCOVERFLOWFOUND) {
-      // the reference re-encodes the macroblock at QP + 2 (TRY_REENCODING); with the picture already coded on the device that
-      // is a second pass over the picture, which the session API implements and this binding does not yet
-      fprintf (stderr, "welship hooks: CAVLC overflow at MB %d -- re-encoding is not implemented in the dispatch-table binding\n", iCurMbIdx);
-      st->failed = true;
-      return ENC_RETURN_UNEXPECTED;
+    if (iEncReturn == ENC_RETURN_VLCOVERFLOWFOUND && kbCavlc && pCurMb->uiLumaQp < 50) {
+      // TRY_REENCODING (svc_encode_slice.cpp:564-576,1845-1867): the writer could not code the macroblock (a level beyond what
+      // Baseline CAVLC can express, or the picture's bitstream buffer nearly full); the reference takes the bitstream back to where
+      // the macroblock started and decides it again with its QP raised by 2 -- without re-initialising it, so uiCbp and one cell of the
+      // MV cache carry over (WelsHipMbReencode).  On the device that is the whole picture again with this macroblock's QP changed:
+      // every other macroblock reproduces itself, the ones after it in the slice see its new reconstruction.
+      if (L.gom || pCtx->pSvcParam->iMultipleThreadIdc > 1) {
+        fprintf (stderr, "welship hooks: CAVLC overflow at MB %d -- re-encoding is not implemented for GOM-level QP / slice threads\n", iCurMbIdx);
+        st->failed = true;
+        return ENC_RETURN_UNEXPECTED;
+      }
+      pSlice->iMbSkipRun = pFunc->pfStashPopMBStatus (&sDss, pSlice);
+      const uint8_t kuiChromaQpIndexOffset = pCurLayer->sLayerInfo.pPpsP->uiChromaQpIndexOffset;
+      pCurMb->uiLumaQp += DELTA_QP;                      // UpdateQpForOverflow (svc_encode_slice.cpp:526-530)
+      pCurMb->uiChromaQp = g_kuiChromaQpTable[CLIP3_QP_0_51 (pCurMb->uiLumaQp + kuiChromaQpIndexOffset)];
+      WelsHipMbReencode* e = NULL;
+      for (size_t i = 0; i < L.reencode.size(); ++i) if (L.reencode[i].iMbXY == iCurMbIdx) e = &L.reencode[i];
+      if (e == NULL) { WelsHipMbReencode n; memset (&n, 0, sizeof (n)); n.iMbXY = iCurMbIdx; L.reencode.push_back (n); e = &L.reencode.back(); }
+      e->uiLumaQp = pCurMb->uiLumaQp;
+      e->uiStaleCbp = R.cbp & 0x3f;
+      if (R.mb_type == WH_MB_P8x16) { e->bCell12Valid = 1; e->iCell12Mv[0] = R.mv_tr[0]; e->iCell12Mv[1] = R.mv_tr[1]; }
+      L.job.bRetry = 1; L.job.pReencode = &L.reencode[0]; L.job.iNumReencode = (int32_t)L.reencode.size();
+      L.job.pSliceFirstMb = &L.first[0];
+      const void* rec = NULL;
+      const int rc = g_api.FrameEncode (L.ctx, &L.job, &rec);
+      if (rc) { fprintf (stderr, "welship hooks: WelsHipFrameEncode (re-encoding MB %d at QP %d) failed (%d: %s)\n", iCurMbIdx, pCurMb->uiLumaQp, rc, g_api.GetLastError()); st->failed = true; return ENC_RETURN_UNEXPECTED; }
+      L.records = (const WhMbRecord*)rec;
+      uint8_t* dst[3] = { pCtx->pDecPic->pData[0], pCtx->pDecPic->pData[1], pCtx->pDecPic->pData[2] };
+      const int32_t ds[3] = { pCtx->pDecPic->iLineSize[0], pCtx->pDecPic->iLineSize[1], pCtx->pDecPic->iLineSize[2] };
+      if (g_api.FrameGetPicture (L.ctx, L.job.iCurPic, dst, ds)) { st->failed = true; return ENC_RETURN_UNEXPECTED; }
+      if (!L.states.empty() && g_api.FrameGetMbStates (L.ctx, L.job.iCurPic, &L.states[0], sizeof (WhMbState) * kiTotalNumMb)) { st->failed = true; return ENC_RETURN_UNEXPECTED; }
+      if (st->trace) fprintf (stderr, "welship hooks: MB %d coded again at QP %d (%d re-encoded macroblocks in this picture)\n", iCurMbIdx, pCurMb->uiLumaQp, (int)L.reencode.size());
+      goto TRY_REENCODING;
     }
     if (ENC_RETURN_SUCCESS != iEncReturn) return iEncReturn;
     pCurMb->uiSliceIdc = kiSliceIdx;

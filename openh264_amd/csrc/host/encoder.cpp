@@ -1506,7 +1506,10 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
   if (is_p && j->iComplexityMode == 0 && !j->pVaaSad8x8) { set_err ("LOW complexity P pictures need the VAA 8x8 SADs of the pre-processing"); return WELSHIP_ERR_INIT_PARA; }
   const bool ranged = j->iMbEnd > 0;
   if (ranged && (j->iMbBegin < 0 || j->iMbBegin >= j->iMbEnd || j->iMbEnd > c->num_mb)) { set_err ("invalid MB range"); return WELSHIP_ERR_INIT_PARA; }
-  const bool first_part = !ranged || j->iMbBegin == 0, last_part = !ranged || j->iMbEnd == c->num_mb;
+  const bool retry = j->bRetry != 0;
+  if (retry && (ranged || !j->pReencode || j->iNumReencode < 1)) { set_err ("a retry is a whole-picture call with the list of re-encoded macroblocks"); return WELSHIP_ERR_INIT_PARA; }
+  // (a retry reuses what the first call of the picture uploaded: source, pre-analysis arrays, screen-content inputs)
+  const bool first_part = !retry && (!ranged || j->iMbBegin == 0), last_part = !ranged || j->iMbEnd == c->num_mb;
   FrameShared* sh = c->sh;
   wh::Backend* be = c->be;
   // host-side staging into this context's own page-locked buffers: outside the shared lock
@@ -1574,6 +1577,18 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
     for (int i = 0; i < c->num_mb; ++i) { memset (&c->h_mb_ctl[i], 0, sizeof (WhMbCtl)); c->h_mb_ctl[i].qp_delta = (int8_t) ((int)j->pMbQp[i] - j->iQp); }
     qp_map = true;
   }
+  if (retry) {
+    if (!qp_map) memset (c->h_mb_ctl.data(), 0, sizeof (WhMbCtl) * c->num_mb);
+    for (int i = 0; i < j->iNumReencode; ++i) {
+      const WelsHipMbReencode& r = j->pReencode[i];
+      if (r.iMbXY < 0 || r.iMbXY >= c->num_mb || r.uiLumaQp > 51) { set_err ("invalid re-encode entry"); return WELSHIP_ERR_INIT_PARA; }
+      WhMbCtl& ctl = c->h_mb_ctl[r.iMbXY];
+      ctl.qp_delta = (int8_t) ((int)r.uiLumaQp - j->iQp);
+      ctl.stale_cbp = r.uiStaleCbp & 0x3f;
+      ctl.cell12_valid = r.bCell12Valid ? 1 : 0; ctl.cell12_mv[0] = r.iCell12Mv[0]; ctl.cell12_mv[1] = r.iCell12Mv[1];
+    }
+    qp_map = true;
+  }
 
   std::unique_lock<std::mutex> lock (sh->mu);
   const auto t_sub0 = std::chrono::steady_clock::now();
@@ -1601,6 +1616,7 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
     if (++c->db_gen == 0) c->db_gen = 1;
     c->h_pic_of = -1;
   }
+  if (retry) { if (++c->db_gen == 0) c->db_gen = 1; c->h_pic_of = -1; }
   if (qp_map) be->upload (c->d_mb_ctl, c->h_mb_ctl.data(), sizeof (WhMbCtl) * c->num_mb);
   c->scc_active = scr != nullptr;
   if (scr) {
@@ -1635,6 +1651,7 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
       z.chain = c->d_scc_chain; z.fme_cost_down = c->d_scc_chain + 4 * WH_MAX_SLICES;
       be->upload (c->d_scc, &z, sizeof (z));
     }
+    if (retry) be->fill (c->d_scc_chain, 0, sizeof (uint32_t) * 5 * WH_MAX_SLICES);       // the picture is coded again from its first macroblock
   }
   DevPicture& cur = c->pics[j->iCurPic];
   WhPicJob job;
@@ -1646,7 +1663,7 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
   job.ref_mbs = is_p ? c->pics[j->iRefPic].mbs : nullptr;
   job.qp = j->iQp;
   job.slice_type = is_p ? WH_SLICE_P : WH_SLICE_I;
-  job.mb_ctl = j->pMbQp ? c->d_mb_ctl : nullptr;
+  job.mb_ctl = qp_map ? c->d_mb_ctl : nullptr;
   job.ref_is_p = is_p && c->pics[j->iRefPic].is_p ? 1 : 0;
   job.prev_src_y = nullptr;
   job.db_flags = c->d_dbflags;

@@ -171,13 +171,17 @@ def test_screen_api_hash_through_the_hooks_on_the_mi355x(hip_lib, tmp_path, name
 
 
 # ---- randomised screen-content sessions (tools/fuzz_screen.py): synthetic scrolling documents, random parameters ------------
-def _fuzz(lib, tmp_path, seeds):
+def _fuzz(lib, tmp_path, seeds, usage=1, qp_max=None):
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import fuzz_screen
     from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(8) as ex:
-        res = list(ex.map(lambda s: fuzz_screen.run_case(s, lib, str(tmp_path)), seeds))
+    fuzz_screen.QP_MAX = qp_max
+    try:
+        with ThreadPoolExecutor(8) as ex:
+            res = list(ex.map(lambda s: fuzz_screen.run_case(s, lib, str(tmp_path), usage), seeds))
+    finally:
+        fuzz_screen.QP_MAX = None
     bad = [r for r in res if r[1] == "DIFF"]
     assert not bad, bad[0]
     assert sum(r[1] == "ok" for r in res) >= len(res) // 2        # (the rest: parameter sets the reference itself rejects)
@@ -190,3 +194,16 @@ def test_screen_fuzz_on_emulation(emu_lib, tmp_path):
 @pytest.mark.gpu
 def test_screen_fuzz_on_the_mi355x(hip_lib, tmp_path):
     _fuzz(hip_lib, tmp_path, range(100, 124))
+
+
+# ---- TRY_REENCODING through the binding: constant QP 0..12 on the same noisy synthetic clips makes CAVLC levels overflow; the
+# reference codes such a macroblock again at QP + 2 (svc_encode_slice.cpp:564-576,1845-1867), the hooks repeat the picture on the
+# device with that macroblock's QP raised (WelsHipFrameJob::bRetry).  A third of these cases re-encode macroblocks (tens of passes).
+def test_reencoding_after_cavlc_overflow_on_emulation(emu_lib, tmp_path):
+    _fuzz(emu_lib, tmp_path, range(7000, 7016), usage=0, qp_max=12)
+    _fuzz(emu_lib, tmp_path, range(8000, 8008), usage=1, qp_max=12)
+
+
+@pytest.mark.gpu
+def test_reencoding_after_cavlc_overflow_on_the_mi355x(hip_lib, tmp_path):
+    _fuzz(hip_lib, tmp_path, range(7016, 7032), usage=0, qp_max=12)

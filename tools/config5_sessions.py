@@ -14,8 +14,10 @@ FRAMES = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 # third argument "simulcast": BASELINE config 4's shape instead -- every session a 1080p input coded as four simulcast AVC layers
 # (1920x1080, 960x540, 480x270, 240x135; four slices each), all layers on this one GPU
 SIMULCAST = len(sys.argv) > 3 and sys.argv[3] == "simulcast"
+# third argument "screen": screen-content sessions instead (the SHA1 table's 1024x768 clip, bitrate mode, four slices)
+SCREEN = len(sys.argv) > 3 and sys.argv[3] == "screen"
 LIB = os.environ.get("WELSHIP_LIB") or os.path.join(ROOT, "openh264_amd", "libwelship.so")
-W, H = (1920, 1080) if SIMULCAST else (1280, 720)
+W, H = (1920, 1080) if SIMULCAST else (1024, 768) if SCREEN else (1280, 720)
 
 
 def run(tmp, yuv, hip):
@@ -24,6 +26,7 @@ def run(tmp, yuv, hip):
     cmd = [os.path.join(REF, "ref_enc_hip"), "-parallel", str(N), "-i", yuv, "-w", str(W), "-h", str(H), "-o", out, "-frames", str(FRAMES),
            "-fps", "30", "-rc", "1", "-bitrate", "1500000", "-threads", "1", "-iper", "0", "-quiet"]
     cmd += (["-slcmd", "1", "-slcnum", "4", "-simulcast", "240", "135", "-simulcast", "480", "270", "-simulcast", "960", "540"] if SIMULCAST
+            else ["-usage", "1", "-slcmd", "1", "-slcnum", "4", "-scene", "1", "-denoise", "1", "-frameskip", "1"] if SCREEN
             else ["-slcmd", "2", "-slcmbnum", "900"])
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert p.returncode == 0, p.stderr[-2000:]
@@ -38,11 +41,12 @@ def run(tmp, yuv, hip):
 def main():
     with tempfile.TemporaryDirectory() as tmp:
         yuv = os.path.join(tmp, "clip.yuv")
-        subprocess.check_call([os.path.join(REF, "ref_dec"), os.path.join(REF, "res", "VID_%dx%d_cavlc_temporal_direct.264" % (W, H)), yuv], stdout=subprocess.DEVNULL)
+        clip = "Adobe_PDF_sample_a_1024x768_50Frms.264" if SCREEN else "VID_%dx%d_cavlc_temporal_direct.264" % (W, H)
+        subprocess.check_call([os.path.join(REF, "ref_dec"), os.path.join(REF, "res", clip), yuv], stdout=subprocess.DEVNULL)
         nfr = os.path.getsize(yuv) // (W * H * 3 // 2)
         c_leg, c_sha = run(tmp, yuv, False)
         h_leg, h_sha = run(tmp, yuv, True)
-        print(json.dumps({"config": "%d concurrent sessions, %dx%d, %d frames each (clip has %d), RC bitrate mode 1.5 Mbps per layer, %s, one process, one thread per session" % (N, W, H, FRAMES, nfr, "4 simulcast AVC layers of 4 slices" if SIMULCAST else "raster slices of 900 MBs"),
+        print(json.dumps({"config": "%d concurrent sessions, %dx%d, %d frames each (clip has %d), RC bitrate mode 1.5 Mbps per layer, %s, one process, one thread per session" % (N, W, H, FRAMES, nfr, "4 simulcast AVC layers of 4 slices" if SIMULCAST else "screen content, 4 slices" if SCREEN else "raster slices of 900 MBs"),
                           "reference_c_path": c_leg, "hooks_on_device": h_leg, "same_bitstreams": c_sha == h_sha, "lib": os.path.basename(LIB)}))
 
 

@@ -60,6 +60,9 @@ def make_clip(w, h, n, seed):
     return b"".join(frames)
 
 
+QP_MAX = None       # --qp-max N: constant-QP cases only, QP 0..N (the CAVLC overflow / TRY_REENCODING regime of noisy content)
+
+
 def case_flags(seed, usage=1):
     rnd = random.Random(seed)
     w = rnd.choice([64, 96, 160, 176, 320, 322, 400, 640]) & ~1
@@ -67,8 +70,11 @@ def case_flags(seed, usage=1):
     n = rnd.randint(6, 14)
     flags = ["-usage", str(usage), "-fps", str(rnd.choice([10, 15, 30]))]
     rc = rnd.choice([-1, -1, 1, 0, 3])
+    qp = rnd.randint(10, 40)
+    if QP_MAX is not None:
+        rc, qp = -1, rnd.randint(0, QP_MAX)
     flags += ["-rc", str(rc)]
-    flags += ["-qp", str(rnd.randint(10, 40))] if rc == -1 else ["-bitrate", str(rnd.choice([100000, 400000, 1500000]))]
+    flags += ["-qp", str(qp)] if rc == -1 else ["-bitrate", str(rnd.choice([100000, 400000, 1500000]))]
     sl = rnd.choice([0, 1, 1, 2])
     flags += ["-slcmd", str(sl)]
     if sl == 1:
@@ -114,8 +120,11 @@ def main():
     ap.add_argument("--cases", type=int, default=32)
     ap.add_argument("--workers", type=int, default=8)
     ap.add_argument("--usage", type=int, default=1, help="1 screen content (default), 0 camera video on the same clips (scene-change I pictures in mid-stream)")
+    ap.add_argument("--qp-max", type=int, default=None, help="constant-QP cases only, QP 0..N")
     ap.add_argument("-v", action="store_true")
     a = ap.parse_args()
+    global QP_MAX
+    QP_MAX = a.qp_max
     a.lib = os.path.abspath(a.lib)
     bad = ok = invalid = 0
     with tempfile.TemporaryDirectory() as d, ThreadPoolExecutor(a.workers) as ex:
