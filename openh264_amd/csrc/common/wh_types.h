@@ -140,13 +140,21 @@ typedef struct WhPicJob {
   const int16_t* il_hint;     // highest spatial layer of a multi-layer session: what WelsMdInterMbEnhancelayer takes from the layer
                               //   below (svc_mode_decision.cpp:108-150), per MB {sMvBase x, y, flags (bit 0: that MB is intra), 0}; or NULL
   const WhSccJob* scc;        // screen-content P pictures (WhSeqParams::flags & WH_SEQ_SCC): device copy of the inputs above; else NULL
+  // WH_SEQ_CHAIN pictures: this picture's own processing order (per slice, like WhSeqParams::mb_order's first section) and, per
+  // macroblock, the macroblock it additionally waits for (the previous one of its slice, in coding order, that may search 8x8
+  // blocks), or -1
+  const uint32_t* scc_order;
+  const int32_t* scc_chain_prev;
 } WhPicJob;
 
 #define WH_MAX_SLICES 36
 #define WH_SEQ_SCC 1                // screen-content mode decision / motion estimation (every picture of the launch has WhPicJob::scc)
-#define WH_SEQ_SERIAL 2             // the macroblocks of a slice run one after the other in raster order: pictures whose scroll vector
-                                    //   is not zero -- the reference's directional-vector test reads state of the previous macroblock
-                                    //   in CODING order (WhSccJob::chain), which the 2:1 dependency order does not respect
+#define WH_SEQ_SERIAL 2             // the macroblocks of a slice run one after the other in raster order (fallback of WH_SEQ_CHAIN)
+#define WH_SEQ_CHAIN 4              // pictures whose scroll vector is not zero: the reference's directional-vector test of the 8x8 searches
+                                    //   reads what the previous macroblock in CODING order that searched 8x8 blocks left (WhSccJob::chain).
+                                    //   Only macroblocks whose pre-analysis SADs are not flat can search 8x8 blocks at all (known before the
+                                    //   picture starts): each of them waits for the one before it, everything else keeps the 2:1 dependency
+                                    //   order -- in a processing order built for the picture that respects both (WhPicJob::scc_order)
 #define WH_DB_BAND_ROWS 24          // a deblocking band (one workgroup) never spans more MB rows than this
 
 // ---- parameters common to every picture of a launch --------------------------------------------

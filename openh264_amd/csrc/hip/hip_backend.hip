@@ -169,7 +169,8 @@ __global__ __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPi
     tt = __builtin_amdgcn_readfirstlane (tt);                                                                                  \
     if (tt >= slot_n[best]) { gone |= 1u << best; continue; }                                                                  \
     const int first_ = slot_first[best];                                                                                       \
-    const int xy_ = (SCC && (P.flags & WH_SEQ_SERIAL)) ? first_ + tt : (int)P.mb_order[first_ + tt];   /* serial: coding order */ \
+    const int xy_ = (SCC && (P.flags & WH_SEQ_CHAIN)) ? (int)((const WH_G uint32_t*)Jl[best].scc_order)[first_ + tt]          \
+                  : (SCC && (P.flags & WH_SEQ_SERIAL)) ? first_ + tt : (int)P.mb_order[first_ + tt];   /* serial: coding order */ \
     const int mb_end_ = Jl[best].mb_end;                                                                                       \
     if (mb_end_ > 0) {                    /* GOM-synchronous coding: only [mb_begin, mb_end) in this launch */                 \
       if (xy_ < Jl[best].mb_begin) { if (lane == 0) atomicOr (&sched[best * sched_words + 1 + ((xy_ - first_) >> 5)], 1u << ((xy_ - first_) & 31)); continue; } \
@@ -197,6 +198,10 @@ __global__ __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPi
     if (SCC && (P.flags & WH_SEQ_SERIAL)) { dep_a = xy > first ? xy - 1 : -1; dep_b = -1; }      // the macroblock before it in coding order (WhSccJob::chain)
     if (!wh_wait_done (sc + 1, dep_a < 0 ? -1 : dep_a - first, err)) break;
     if (!wh_wait_done (sc + 1, dep_b < 0 ? -1 : dep_b - first, err)) break;
+    if (SCC && (P.flags & WH_SEQ_CHAIN)) {          // ... and the previous macroblock of the slice that may search 8x8 blocks
+      const int dep_c = ((const WH_G int32_t*)J.scc_chain_prev)[xy];
+      if (!wh_wait_done (sc + 1, dep_c < first ? -1 : dep_c - first, err)) break;
+    }
     __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "workgroup");
     WH_PROF_MARK (P, S.m, 12);
     const uint32_t tc0 = (uint32_t)__builtin_readcyclecounter();
@@ -586,6 +591,7 @@ class HipBackend : public wh::Backend {
     nw = std::min (nw, 12);
     int par = std::max (1, std::min (max_rows, (P.mb_w + 1) / 2)) * slots;       // macroblocks that can be in flight at all
     if (P.flags & WH_SEQ_SERIAL) par = 2 * slots;      // one macroblock of a slice at a time; a second wave has the next one's inputs in flight
+    if (P.flags & WH_SEQ_SCC) nw = std::min (nw, 6);    // the screen-content variant needs 216 VGPRs: six waves per workgroup, no scratch
     nw = std::min (nw, par);
     const size_t per_wave = sizeof (WhInterLds) + sizeof (WhInterStage) + sizeof (WhWinLds);
     const size_t fixed = WH_MD_MAX_SLOTS * (sizeof (WhPicJob) + 16) + 4 * (size_t)slots * sched_words;

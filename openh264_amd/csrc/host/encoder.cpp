@@ -17,6 +17,7 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <queue>
 #include <algorithm>
 #include <stdlib.h>
 #include "../../../include/welship.h"
@@ -1165,16 +1166,26 @@ struct FrameLayout {           // processing-order / deblocking-band tables on t
 };
 
 struct FrameItem;
-struct FrameKey {              // pictures that can share a launch: same sequence parameters, type and passes
-  WhSeqParams seq;
-  bool is_p = false, qp_map = false, expand = false;
+struct FrameLane {             // one launch set in flight: its queue and its job descriptors
   int queue = 0;
-  std::vector<FrameItem*> pending;
-  bool leader_active = false;
-  FrameItem* next_leader = nullptr;
+  bool busy = false;
   WhPicJob* d_jobs = nullptr;
   int jobs_cap = 0;
   std::vector<WhPicJob> h_jobs;          // page-locked
+};
+#define WH_FRAME_LANES 2
+struct FrameKey {              // pictures that can share a launch: same sequence parameters, type and passes
+  WhSeqParams seq;
+  bool is_p = false, qp_map = false, expand = false;
+  int queue = 0;                          // where the pictures' inputs are uploaded
+  std::vector<FrameItem*> pending;
+  // Two launch sets of a key may be on the device at once (each lane a queue of its own): sessions whose host work per picture is
+  // long and uneven (screen content: scroll / scene detection, feature lists) do not arrive within one gathering window, and a
+  // second batch that had to wait for the first one's whole latency chain halved the rate (16 screen sessions: 352 frames/s)
+  FrameLane lane[WH_FRAME_LANES];
+  int gathering = 0;                      // leaders currently collecting their batch
+  FrameItem* next_leader = nullptr;
+  int free_lane() const { for (int i = 0; i < WH_FRAME_LANES; ++i) if (!lane[i].busy) return i; return -1; }
 };
 struct FrameShared {
   std::mutex mu;
@@ -1183,7 +1194,6 @@ struct FrameShared {
   int device = 0, users = 0;
   std::vector<std::unique_ptr<FrameLayout>> layouts;
   std::vector<std::unique_ptr<FrameKey>> keys;
-  bool any_leader() const { for (auto& k : keys) if (k->leader_active) return true; return false; }
   // how long a leader waits for the other threads that have been submitting pictures lately.  Sessions that once end up in
   // different batches stay out of phase for good (each waits for the other's batch); one wait of about a picture's host
   // work merges them, after which they submit together and nobody waits
@@ -1236,13 +1246,16 @@ struct WelsHipFrameCtx {
   uint8_t* d_scc_idc = nullptr;
   uint8_t* d_scc_ori = nullptr;
   uint32_t* d_scc_chain = nullptr;       // [WH_MAX_SLICES][4] chain, then [WH_MAX_SLICES] cost-down sums
+  uint32_t* d_scc_order = nullptr;       // WH_SEQ_CHAIN: the picture's processing order [num_mb] | chain_prev [num_mb]
   uint32_t* d_scc_lists = nullptr;       // times[list] | start[list]
   uint16_t* d_scc_loc = nullptr;
   size_t scc_list_cap = 0, scc_loc_cap = 0;
   std::vector<uint8_t> h_scc;            // page-locked staging: idc | source chroma | times | start | locations
   size_t h_scc_cap = 0;
-  WhSccJob h_scc_job;
-  uint32_t h_scc_down[WH_MAX_SLICES];
+  std::vector<uint8_t> h_scc_small;      // page-locked: the WhSccJob being uploaded | the per-slice statistics coming back (a pageable
+                                         // buffer would make the copy synchronous -- under the shared lock, behind the other sessions' kernels)
+  WhSccJob& scc_job() { return * (WhSccJob*)h_scc_small.data(); }
+  uint32_t* scc_down() { return (uint32_t*) (h_scc_small.data() + 256); }
   bool scc_active = false;               // the picture in flight is a screen-content P picture
 
   // caller holds sh->mu
@@ -1251,8 +1264,9 @@ struct WelsHipFrameCtx {
     be->sync();
     for (auto& p : pics) { if (p.base) be->free (p.base); if (p.mbs) be->free (p.mbs); }
     pics.clear();
-    void* ptrs[] = {d_src, d_records, d_dbflags, d_mb_ctl, d_sad_cost0, d_vaa, d_bgd, d_il, d_job, d_scc, d_scc_idc, d_scc_ori, d_scc_chain, d_scc_lists, d_scc_loc};
+    void* ptrs[] = {d_src, d_records, d_dbflags, d_mb_ctl, d_sad_cost0, d_vaa, d_bgd, d_il, d_job, d_scc, d_scc_idc, d_scc_ori, d_scc_chain, d_scc_lists, d_scc_loc, d_scc_order};
     if (!h_scc.empty()) be->unpin_host (h_scc.data());
+    if (!h_scc_small.empty()) be->unpin_host (h_scc_small.data());
     for (void* p : ptrs) if (p) be->free (p);
     if (!h_records.empty()) be->unpin_host (h_records.data());
     if (!h_src.empty()) be->unpin_host (h_src.data());
@@ -1320,37 +1334,38 @@ struct FrameItem {             // one submitted picture, owned by the submitting
 
 // the leader's work: the key's pending pictures in one launch set on the key's queue.  Called with sh->mu held; releases it
 // while the device works.
-void frame_run_batch (FrameShared* sh, FrameKey* K, std::unique_lock<std::mutex>& lock, std::vector<FrameItem*>& batch) {
+void frame_run_batch (FrameShared* sh, FrameKey* K, FrameLane* L, std::unique_lock<std::mutex>& lock, std::vector<FrameItem*>& batch) {
   wh::Backend* be = sh->be;
   const auto t_launch0 = std::chrono::steady_clock::now();
   const int n = (int)batch.size();
-  be->select_queue (K->queue);
-  if (n > K->jobs_cap) {
-    if (K->d_jobs) be->free (K->d_jobs);
-    if (!K->h_jobs.empty()) be->unpin_host (K->h_jobs.data());
-    K->jobs_cap = std::max (16, 2 * n);
-    K->d_jobs = (WhPicJob*)be->alloc (sizeof (WhPicJob) * K->jobs_cap);
-    K->h_jobs.assign (K->jobs_cap, WhPicJob());
-    be->pin_host (K->h_jobs.data(), sizeof (WhPicJob) * K->jobs_cap);
+  be->select_queue (L->queue);
+  be->queue_wait (K->queue);        // the pictures' inputs were uploaded on the key's queue (which carries nothing else: a lane never waits for the other lane's kernels)
+  if (n > L->jobs_cap) {
+    if (L->d_jobs) be->free (L->d_jobs);
+    if (!L->h_jobs.empty()) be->unpin_host (L->h_jobs.data());
+    L->jobs_cap = std::max (16, 2 * n);
+    L->d_jobs = (WhPicJob*)be->alloc (sizeof (WhPicJob) * L->jobs_cap);
+    L->h_jobs.assign (L->jobs_cap, WhPicJob());
+    be->pin_host (L->h_jobs.data(), sizeof (WhPicJob) * L->jobs_cap);
   }
-  int rc_all = K->d_jobs ? WELSHIP_OK : WELSHIP_ERR_MEMORY;
+  int rc_all = L->d_jobs ? WELSHIP_OK : WELSHIP_ERR_MEMORY;
   if (rc_all == WELSHIP_OK) {
-    for (int i = 0; i < n; ++i) K->h_jobs[i] = batch[i]->job;
-    be->upload (K->d_jobs, K->h_jobs.data(), sizeof (WhPicJob) * n);
+    for (int i = 0; i < n; ++i) L->h_jobs[i] = batch[i]->job;
+    be->upload (L->d_jobs, L->h_jobs.data(), sizeof (WhPicJob) * n);
     const WhSeqParams& s = K->seq;
-    if (K->is_p) be->run_inter (s, K->d_jobs, n); else be->run_intra (s, K->d_jobs, n);
-    if (K->qp_map) be->run_qp_chain (s, K->d_jobs, n);
-    if (s.deblock_idc != 1) be->run_deblock (s, K->d_jobs, n);
-    if (K->expand) be->run_expand (s, K->d_jobs, n);
+    if (K->is_p) be->run_inter (s, L->d_jobs, n); else be->run_intra (s, L->d_jobs, n);
+    if (K->qp_map) be->run_qp_chain (s, L->d_jobs, n);
+    if (s.deblock_idc != 1) be->run_deblock (s, L->d_jobs, n);
+    if (K->expand) be->run_expand (s, L->d_jobs, n);
     for (FrameItem* x : batch) {
       WelsHipFrameCtx* c = x->c;
       be->download (c->h_records.data(), c->d_records, sizeof (WhMbRecord) * c->num_mb);
       be->download (c->h_pic.data(), c->pics[x->cur_pic].base, c->rec_alloc_bytes + 128);
       if (x->sad_dst) be->download (c->h_sad_out.data(), c->d_sad_cost0, sizeof (int32_t) * c->num_mb);
-      if (c->scc_active) be->download (c->h_scc_down, c->d_scc_chain + 4 * WH_MAX_SLICES, sizeof (uint32_t) * WH_MAX_SLICES);
+      if (c->scc_active) be->download (c->scc_down(), c->d_scc_chain + 4 * WH_MAX_SLICES, sizeof (uint32_t) * WH_MAX_SLICES);
     }
     const double launch_ms = std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now() - t_launch0).count();
-    const int q = K->queue;
+    const int q = L->queue;
     lock.unlock();               // other sessions stage and queue their next pictures while the device works
     const auto t_dev0 = std::chrono::steady_clock::now();
     const int bad = be->sync_queue (q);
@@ -1374,6 +1389,7 @@ FrameKey* frame_find_key (FrameShared* sh, const WhSeqParams& s, bool is_p, bool
   std::unique_ptr<FrameKey> k (new FrameKey());
   k->seq = s; k->is_p = is_p; k->qp_map = qp_map; k->expand = expand;
   k->queue = (int) (sh->keys.size() % 8);          // keys beyond the eighth share queues (they only serialise, nothing breaks)
+  for (int i = 0; i < WH_FRAME_LANES; ++i) k->lane[i].queue = k->queue + 8 * (i + 1);      // the key's own queue only carries the uploads
   sh->keys.push_back (std::move (k));
   return sh->keys.back().get();
 }
@@ -1488,7 +1504,7 @@ void WelsHipFrameCtxDestroy (WelsHipFrameCtx* c) {
       fprintf (stderr, "welship:   submitting (uploads under the lock): %.3f ms per picture\n", sh->stat_submit_ms / sh->batched_pictures);
     }
     for (auto& L : sh->layouts) { sh->be->free (L->d_order); sh->be->free (L->d_bands); }
-    for (auto& K : sh->keys) { if (K->d_jobs) sh->be->free (K->d_jobs); if (!K->h_jobs.empty()) sh->be->unpin_host (K->h_jobs.data()); }
+    for (auto& K : sh->keys) for (FrameLane& L : K->lane) { if (L.d_jobs) sh->be->free (L.d_jobs); if (!L.h_jobs.empty()) sh->be->unpin_host (L.h_jobs.data()); }
     delete sh->be;
     g_frame_shared.erase (std::find (g_frame_shared.begin(), g_frame_shared.end(), sh));
     delete sh;
@@ -1533,7 +1549,10 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
   }
   // screen content: stage the pre-processing's arrays (page-locked, own to this context)
   const WelsHipScreenInfo* scr = is_p ? j->pScreen : nullptr;
-  size_t scc_off_ori = 0, scc_off_times = 0, scc_off_start = 0, scc_off_loc = 0, scc_lists = 0, scc_entries = 0;
+  size_t scc_off_ori = 0, scc_off_times = 0, scc_off_start = 0, scc_off_loc = 0, scc_off_order = 0, scc_lists = 0, scc_entries = 0;
+  static const bool scc_serial = getenv ("WELSHIP_SCC_SERIAL") && atoi (getenv ("WELSHIP_SCC_SERIAL")) != 0;       // fallback: plain coding order
+  const bool scc_scroll = scr && scr->bScrollDetectFlag && (scr->iScrollMvX | scr->iScrollMvY);
+  const bool scc_chain = scc_scroll && !scc_serial;
   if (scr) {
     if (!scr->pBlockStaticIdc) { set_err ("screen-content job without the static-block map"); return WELSHIP_ERR_INIT_PARA; }
     const bool fme = scr->bFeatureSearch8x8 != 0;
@@ -1545,7 +1564,8 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
     scc_off_times = scc_off_ori + 2 * c->csz;
     scc_off_start = scc_off_times + 4 * scc_lists;
     scc_off_loc = scc_off_start + 4 * scc_lists;
-    const size_t need = scc_off_loc + 4 * scc_entries + 64;
+    scc_off_order = (scc_off_loc + 4 * scc_entries + 63) & ~ (size_t)63;
+    const size_t need = scc_off_order + 8 * (size_t)c->num_mb + 64;
     if (first_part) {
       if (need > c->h_scc_cap) {
         std::unique_lock<std::mutex> lk (sh->mu);
@@ -1569,6 +1589,56 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
           start[f] = (uint32_t) (d >> 1);
         }
         memcpy (st + scc_off_loc, scr->pLocationPointer, 4 * scc_entries);
+      }
+      if (scc_chain) {
+        // WH_SEQ_CHAIN (wh_types.h): which macroblocks can search 8x8 blocks at all (MdInterAnalysisVaaInfo_c != MBVAASIGN_FLAT on the
+        // pre-analysis' 8x8 SADs, exactly as the kernel evaluates it), the previous such macroblock of each one's slice, and a processing
+        // order that respects those edges and the left / top-right ones: Kahn's algorithm, the ready macroblock that comes first in the
+        // usual 2:1 order goes next
+        if (!j->pVaaSad8x8 || j->iNumSlices < 1 || j->iNumSlices > WH_MAX_SLICES) { set_err ("screen-content job without the pre-analysis SADs"); return WELSHIP_ERR_INIT_PARA; }
+        uint32_t* order = (uint32_t*) (st + scc_off_order);
+        int32_t* prev = (int32_t*) (st + scc_off_order + 4 * (size_t)c->num_mb);
+        std::vector<uint16_t> base (c->num_mb);
+        std::vector<int32_t> rank (c->num_mb), indeg (c->num_mb);
+        std::vector<int32_t> succ ((size_t)4 * c->num_mb, -1);
+        for (int si = 0; si < j->iNumSlices; ++si) {
+          const int first = j->pSliceFirstMb[si], last = j->pSliceFirstMb[si + 1];
+          if (first < 0 || last > c->num_mb || first >= last) { set_err ("invalid slice layout"); return WELSHIP_ERR_INIT_PARA; }
+          wh_build_mb_order (c->mb_w, first, last, base.data() + first);
+          for (int t = first; t < last; ++t) rank[base[t]] = t;
+          int pv = -1;
+          for (int xy = first; xy < last; ++xy) {
+            const int32_t* v = j->pVaaSad8x8 + 4 * (size_t)xy;
+            const int avg = (v[0] + v[1] + v[2] + v[3]) >> 2;
+            const int d0 = (v[0] >> 6) - (avg >> 6), d1 = (v[1] >> 6) - (avg >> 6), d2 = (v[2] >> 6) - (avg >> 6), d3 = (v[3] >> 6) - (avg >> 6);
+            const bool nonflat = d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3 >= 20;
+            prev[xy] = nonflat ? pv : -1;
+            if (nonflat) pv = xy;
+            int da, db;
+            wh_mb_deps (c->mb_w, xy, first, &da, &db);
+            const int deps[3] = {da, db, prev[xy]};
+            indeg[xy] = 0;
+            for (int k = 0; k < 3; ++k) if (deps[k] >= first && !(k == 2 && (deps[k] == da || deps[k] == db))) {
+              ++indeg[xy];
+              int32_t* sl = &succ[(size_t)4 * deps[k]];
+              // a macroblock is the left neighbour of one, the top-right / top of at most two (right picture edge), the chain predecessor of one
+              int q = 0;
+              while (q < 4 && sl[q] >= 0) ++q;
+              if (q == 4) { set_err ("internal: order graph"); return WELSHIP_ERR_UNKNOWN; }
+              sl[q] = xy;
+            }
+          }
+          std::priority_queue<std::pair<int32_t, int32_t>, std::vector<std::pair<int32_t, int32_t>>, std::greater<std::pair<int32_t, int32_t>>> ready;
+          for (int xy = first; xy < last; ++xy) if (indeg[xy] == 0) ready.push ({rank[xy], xy});
+          int t = first;
+          while (!ready.empty()) {
+            const int xy = ready.top().second;
+            ready.pop();
+            order[t++] = (uint32_t)xy;
+            for (int k = 0; k < 4; ++k) { const int n = succ[(size_t)4 * xy + k]; if (n >= 0 && --indeg[n] == 0) ready.push ({rank[n], n}); }
+          }
+          if (t != last) { set_err ("internal: order graph has a cycle"); return WELSHIP_ERR_UNKNOWN; }
+        }
       }
     }
   }
@@ -1602,7 +1672,7 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
   s.mv_range = j->iMvRange;
   // screen content: its own kernel variant; a picture with a scroll vector codes the macroblocks of a slice one after the other
   // (the directional-vector test of the 8x8 searches reads what the previous macroblock in CODING order left, WhSccJob::chain)
-  s.flags = scr ? (WH_SEQ_SCC | ((scr->bScrollDetectFlag && (scr->iScrollMvX | scr->iScrollMvY)) ? WH_SEQ_SERIAL : 0)) : 0;
+  s.flags = scr ? (WH_SEQ_SCC | (scc_chain ? WH_SEQ_CHAIN : scc_scroll ? WH_SEQ_SERIAL : 0)) : 0;
   // the pictures this one can share a launch with, and the queue they use (MB ranges: queue 0, on their own)
   FrameKey* K = ranged ? nullptr : frame_find_key (sh, s, is_p, qp_map, j->bExpand != 0);
   const int queue = K ? K->queue : 0;
@@ -1623,12 +1693,16 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
     bool oom = false;
     auto A = [&] (size_t n) { void* p = be->alloc (n); if (!p) oom = true; return p; };
     if (!c->d_scc) {
+      static_assert (sizeof (WhSccJob) <= 256 && sizeof (uint32_t) * WH_MAX_SLICES <= 256, "staging layout");
+      c->h_scc_small.assign (512, 0);
+      be->pin_host (c->h_scc_small.data(), c->h_scc_small.size());
       c->d_scc = (WhSccJob*)A (sizeof (WhSccJob));
       c->d_scc_idc = (uint8_t*)A ((size_t)4 * c->num_mb + 64);
       c->d_scc_ori = (uint8_t*)A (2 * c->csz + 64);
       c->d_scc_chain = (uint32_t*)A (sizeof (uint32_t) * 5 * WH_MAX_SLICES);
     }
     if (scc_lists > c->scc_list_cap) { if (c->d_scc_lists) be->free (c->d_scc_lists); c->d_scc_lists = (uint32_t*)A (8 * scc_lists + 64); c->scc_list_cap = scc_lists; }
+    if (scc_chain && !c->d_scc_order) c->d_scc_order = (uint32_t*)A (8 * (size_t)c->num_mb + 64);
     if (scc_entries > c->scc_loc_cap) { if (c->d_scc_loc) be->free (c->d_scc_loc); c->d_scc_loc = (uint16_t*)A (4 * scc_entries + 64); c->scc_loc_cap = scc_entries; }
     if (oom) { set_err ("out of device memory"); return WELSHIP_ERR_MEMORY; }
     if (first_part) {
@@ -1636,8 +1710,9 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
       be->upload (c->d_scc_idc, st, (size_t)4 * c->num_mb);
       if (scr->pRefOriChroma[0] && scr->pRefOriChroma[1]) be->upload (c->d_scc_ori, st + scc_off_ori, 2 * c->csz);
       if (scc_lists) { be->upload (c->d_scc_lists, st + scc_off_times, 8 * scc_lists); be->upload (c->d_scc_loc, st + scc_off_loc, 4 * scc_entries); }
+      if (scc_chain) be->upload (c->d_scc_order, st + scc_off_order, 8 * (size_t)c->num_mb);
       be->fill (c->d_scc_chain, 0, sizeof (uint32_t) * 5 * WH_MAX_SLICES);
-      WhSccJob& z = c->h_scc_job;
+      WhSccJob& z = c->scc_job();
       memset (&z, 0, sizeof (z));
       z.static_idc = c->d_scc_idc;
       const bool have_ori = scr->pRefOriChroma[0] && scr->pRefOriChroma[1];
@@ -1674,6 +1749,8 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
   job.mvc_shift = j->iMvcShift;
   job.il_hint = is_p && j->pIlHint ? c->d_il : nullptr;
   job.scc = scr ? c->d_scc : nullptr;
+  job.scc_order = scc_chain ? c->d_scc_order : nullptr;
+  job.scc_chain_prev = scc_chain ? (const int32_t*) (c->d_scc_order + c->num_mb) : nullptr;
   job.mb_begin = ranged ? j->iMbBegin : 0; job.mb_end = ranged ? j->iMbEnd : 0;
 
   if (ranged) {
@@ -1687,11 +1764,11 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
       if (j->bExpand) be->run_expand (s, c->d_job, 1);
       cur.is_p = is_p;
       if (j->pSadCost) be->download (j->pSadCost, c->d_sad_cost0, sizeof (int32_t) * c->num_mb);
-      if (scr) be->download (c->h_scc_down, c->d_scc_chain + 4 * WH_MAX_SLICES, sizeof (uint32_t) * WH_MAX_SLICES);
+      if (scr) be->download (c->scc_down(), c->d_scc_chain + 4 * WH_MAX_SLICES, sizeof (uint32_t) * WH_MAX_SLICES);
     }
     be->download (c->h_records.data() + j->iMbBegin, c->d_records + j->iMbBegin, sizeof (WhMbRecord) * (size_t) (j->iMbEnd - j->iMbBegin));
     if (be->sync_queue (queue)) { set_err ("device scheduler timed out or device error; the picture was not encoded"); return WELSHIP_ERR_UNKNOWN; }
-    if (scr && last_part && scr->pSliceFMECostDown) memcpy (scr->pSliceFMECostDown, c->h_scc_down, sizeof (uint32_t) * j->iNumSlices);
+    if (scr && last_part && scr->pSliceFMECostDown) memcpy (scr->pSliceFMECostDown, c->scc_down(), sizeof (uint32_t) * j->iNumSlices);
     *pp_records = c->h_records.data();
     return WELSHIP_OK;
   }
@@ -1703,12 +1780,15 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
   c->last_submit = std::chrono::steady_clock::now();
   sh->stat_submit_ms += std::chrono::duration<double, std::milli> (c->last_submit - t_sub0).count();
   K->pending.push_back (&item);
-  if (K->leader_active) sh->cv.notify_all();           // a gathering leader may have been waiting for exactly this picture
+  if (K->gathering) sh->cv.notify_all();               // a gathering leader may have been waiting for exactly this picture
   for (;;) {
     if (item.done) break;
-    if (!K->leader_active && (K->next_leader == nullptr || K->next_leader == &item)) {
+    const int li = K->free_lane();
+    if (li >= 0 && K->gathering == 0 && !K->pending.empty() && (K->next_leader == nullptr || K->next_leader == &item)) {
       // this thread launches for the key: whatever is pending now plus what arrives within the gathering window
-      K->leader_active = true;
+      FrameLane* Lk = &K->lane[li];
+      Lk->busy = true;
+      ++K->gathering;
       K->next_leader = nullptr;
       const auto t_g0 = std::chrono::steady_clock::now();
       if (sh->gather_us > 0 && sh->ctxs.size() > 1) {
@@ -1721,12 +1801,14 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
       }
       std::vector<FrameItem*> batch;
       batch.swap (K->pending);
+      K->next_leader = nullptr;                             // (whoever it was is in this batch now)
+      --K->gathering;
       const double gather_ms = std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now() - t_g0).count();
       const size_t bn = batch.size();
-      frame_run_batch (sh, K, lock, batch);
+      frame_run_batch (sh, K, Lk, lock, batch);             // (releases the lock while the device works: the other lane may launch meanwhile)
       if (bn < sh->stat_gather_ms.size()) sh->stat_gather_ms[bn] += gather_ms;
-      K->leader_active = false;
-      if (!K->pending.empty()) K->next_leader = K->pending.front();        // pictures that arrived meanwhile: their first submitter goes next
+      Lk->busy = false;
+      if (!K->pending.empty() && K->gathering == 0 && K->next_leader == nullptr) K->next_leader = K->pending.front();      // pictures that arrived meanwhile: their first submitter goes next
       sh->cv.notify_all();
       continue;
     }
@@ -1735,7 +1817,7 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
   if (item.rc) { set_err ("device scheduler timed out or device error; the picture was not encoded"); return item.rc; }
   lock.unlock();
   if (j->pSadCost) memcpy (j->pSadCost, c->h_sad_out.data(), sizeof (int32_t) * c->num_mb);
-  if (scr && scr->pSliceFMECostDown) memcpy (scr->pSliceFMECostDown, c->h_scc_down, sizeof (uint32_t) * j->iNumSlices);
+  if (scr && scr->pSliceFMECostDown) memcpy (scr->pSliceFMECostDown, c->scc_down(), sizeof (uint32_t) * j->iNumSlices);
   *pp_records = c->h_records.data();
   return WELSHIP_OK;
 }

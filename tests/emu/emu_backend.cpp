@@ -56,8 +56,19 @@ class EmuBackend : public Backend {
         poison (&S, sizeof (S)); poison (&G, sizeof (G)); poison (&WB, sizeof (WB));
         const int first = P.slice_first_mb[s], last = P.slice_first_mb[s + 1];
         int last_mv = 0;
+        std::vector<char> done_mb ((size_t) (last - first), 0);
         for (int t = first; t < last; ++t) {
-          const int xy = (P.flags & WH_SEQ_SERIAL) ? t : (int)P.mb_order[t];       // coding order for pictures with a scroll vector
+          const int xy = (P.flags & WH_SEQ_CHAIN) ? (int)jobs[j].scc_order[t] : (P.flags & WH_SEQ_SERIAL) ? t : (int)P.mb_order[t];
+          if (P.flags & WH_SEQ_CHAIN) {      // the picture's own order must respect everything the device scheduler waits for
+            int da, db;
+            wh_mb_deps (P.mb_w, xy, first, &da, &db);
+            const int dc = jobs[j].scc_chain_prev[xy];
+            if ((da >= first && !done_mb[da - first]) || (db >= first && !done_mb[db - first]) || (dc >= first && !done_mb[dc - first]) || dc >= xy) {
+              fprintf (stderr, "emu: WH_SEQ_CHAIN order is not topological at MB %d (deps %d %d %d)\n", xy, da, db, dc);
+              abort();
+            }
+            done_mb[xy - first] = 1;
+          }
           if (jobs[j].mb_end > 0 && (xy < jobs[j].mb_begin || xy >= jobs[j].mb_end)) continue;      // GOM-synchronous coding: only this range
           const int mbx = xy % P.mb_w, mby = xy / P.mb_w;
           for (int lane = 0; lane < 64; ++lane) wh_inter_cold_fetch (G, lane, P, jobs[j], mbx, mby);

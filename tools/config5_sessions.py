@@ -30,6 +30,8 @@ def run(tmp, yuv, hip):
             else ["-slcmd", "2", "-slcmbnum", "900"])
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert p.returncode == 0, p.stderr[-2000:]
+    if hip and os.environ.get("WELSHIP_FRAME_STATS"):
+        sys.stderr.write("".join(l + "\n" for l in p.stderr.decode(errors="replace").splitlines() if l.startswith("welship:")))
     enc_fps = [float(x) for x in re.findall(rb" fps=([0-9.]+)", p.stdout)]
     wall = float(re.search(rb"wall_seconds=([0-9.]+)", p.stdout).group(1))
     pictures = p.stderr.count(b"welship hooks: did")
