@@ -243,12 +243,13 @@ WH_FN int wh_sad_global (const WhInterLds& S, const WhSeqParams& P, const WhPicJ
 // test-build statistics of the screen-content paths (which of them a test clip reaches at all): WELSHIP_SCC_STATS=1 prints them
 #if defined(WH_EMU)
 #include <stdio.h>
-enum { WH_ST_STATIC_SKIP, WH_ST_SCROLL_SKIP, WH_ST_SCD_P16, WH_ST_CROSS_V, WH_ST_CROSS_H, WH_ST_FME, WH_ST_FME_HIT, WH_ST_DIR_TAKEN, WH_ST_P8X8, WH_ST_MERGE, WH_ST_FIXED, WH_ST_N };
-static long g_wh_scc_stat[WH_ST_N];
+enum { WH_ST_STATIC_SKIP, WH_ST_SCROLL_SKIP, WH_ST_SCD_P16, WH_ST_CROSS_V, WH_ST_CROSS_H, WH_ST_FME, WH_ST_FME_HIT, WH_ST_DIR_TAKEN, WH_ST_P8X8, WH_ST_MERGE, WH_ST_FIXED, WH_ST_N, WH_ST_FME_SADS = WH_ST_N, WH_ST_FME_LISTED, WH_ST_LINE_SADS, WH_ST_ALL };
+static long g_wh_scc_stat[WH_ST_ALL];
 static void wh_scc_stat_dump() {
   if (!getenv ("WELSHIP_SCC_STATS")) return;
   static const char* n[WH_ST_N] = {"static_skip", "scroll_skip", "scd_p16x16", "cross_vertical", "cross_horizontal", "feature_search", "feature_hit", "directional_taken", "p8x8", "merged", "fixed_8x8"};
   for (int i = 0; i < WH_ST_N; ++i) fprintf (stderr, "welship scc stat %s %ld\n", n[i], g_wh_scc_stat[i]);
+  fprintf (stderr, "welship scc work feature_candidates_listed %ld feature_sads %ld line_sads %ld\n", g_wh_scc_stat[WH_ST_FME_LISTED], g_wh_scc_stat[WH_ST_FME_SADS], g_wh_scc_stat[WH_ST_LINE_SADS]);
 }
 struct WhSccStatInit { WhSccStatInit() { atexit (wh_scc_stat_dump); } };
 static WhSccStatInit g_wh_scc_stat_init;
@@ -435,19 +436,41 @@ typedef struct WhSccMe {
 
 // LineFullSearch_c (svc_motion_estimate.cpp:568-613): every position of the column (or the row) through the CO-LOCATED block
 // inside the search range, one candidate per lane, 64 at a time; the first minimum wins, and it replaces the search result
-// only if it is cheaper.
-WH_FN void wh_line_search (const WhInterLds& S, const WhSeqParams& P, const WhPicJob& J, const WhMeCtx& C, const WhMe& me, bool vertical, int* best, int* bmx, int* bmy) {
+// only if it is cheaper.  Row search: neighbouring lanes read overlapping bytes of the same rows (two cache lines per load).
+// Column search: lane l would read rows l .. l + bh - 1 -- 64 different lines per load instruction -- so the 64 + bh - 1 rows of
+// the column a round needs are staged in LDS first (the search window's storage: the window is given up, whoever needs it next
+// reloads it) and every lane takes its rows from there.
+WH_FN void wh_line_search (const WhInterLds& S, const WhSeqParams& P, const WhPicJob& J, WhWin& W, const WhMeCtx& C, const WhMe& me, bool vertical, int* best, int* bmx, int* bmy) {
   const int lo = vertical ? C.miny : C.minx, hi = vertical ? C.maxy : C.maxx;
   const int px = C.mbx * 16 + me.bx, py = C.mby * 16 + me.by;
   const WH_G uint8_t* ref = (const WH_G uint8_t*)J.ref[0];
+  const int bw = me.bw, bh = me.bh, ex = me.bx, ey = me.by;
   int lbest = 0x7fffffff, lpos = 0;
+  if (vertical) { W.x0 = -100000; W.y0 = -100000; }                // (wh_win_covers fails from here on)
   for (int base = lo; base < hi; base += 64) {
     int k, l;
-    WV_ARGMIN (k, l, lane, base + lane < hi, ([&] () {
-      const int m = base + lane;
-      const WH_G uint8_t* q = ref + (ptrdiff_t) (py + (vertical ? m : 0)) * P.rec_stride_y + px + (vertical ? 0 : m);
-      return wh_sad_lane_g (S, q, P.rec_stride_y, me.bx, me.by, me.bw, me.bh) +
-             (vertical ? wh_mvd_cost (C.lambda, -me.mvpx, m * 4 - me.mvpy) : wh_mvd_cost (C.lambda, m * 4 - me.mvpx, -me.mvpy)); }) ());
+    if (vertical) {
+      uint8_t* tile = W.b->win;                                      // rows of 16 bytes
+      const int rows = wh_min (64, hi - base) + bh - 1, words = bw >> 2;
+      WV_LANES_BEGIN (lane)
+      for (int i = lane; i < rows * words; i += 64) {
+        const int r = i / words, c = (i - r * words) * 4;
+        * (uint32_t*)&tile[r * 16 + c] = wh_ldg4u (ref + (ptrdiff_t) (py + base + r) * P.rec_stride_y + px + c);
+      }
+      WV_LANES_END
+      WV_ARGMIN (k, l, lane, base + lane < hi, ([&] () {
+        const int m = base + lane;
+        WH_STAT (WH_ST_LINE_SADS);
+        int s = 0;
+        for (int r = 0; r < bh; ++r)
+          for (int c = 0; c < bw; c += 4) s += wh_sad4 (wh_enc4 (S, ex + c, ey + r), * (const uint32_t*)&tile[(lane + r) * 16 + c]);
+        return s + wh_mvd_cost (C.lambda, -me.mvpx, m * 4 - me.mvpy); }) ());
+    } else {
+      WV_ARGMIN (k, l, lane, base + lane < hi, ([&] () {
+        const int m = base + lane;
+        WH_STAT (WH_ST_LINE_SADS);
+        return wh_sad_lane_g (S, ref + (ptrdiff_t)py * P.rec_stride_y + px + m, P.rec_stride_y, ex, ey, bw, bh) + wh_mvd_cost (C.lambda, m * 4 - me.mvpx, -me.mvpy); }) ());
+    }
     if (l >= 0 && k < lbest) { lbest = k; lpos = base + l; }
   }
   if (lbest < *best) { *best = lbest; *bmx = vertical ? 0 : lpos; *bmy = vertical ? lpos : 0; }
@@ -479,10 +502,12 @@ WH_FN void wh_feature_search (const WhInterLds& S, const WhSeqParams& P, const W
     WV_LSET_IF (cst, lane, true, ([&] () {
       const int i = base + lane;
       if (i >= times) return 0x7fffffff;
+      WH_STAT (WH_ST_FME_LISTED);
       const int qx = (int)loc[2 * i], qy = (int)loc[2 * i + 1];
       if (qx > max_qx || qx < min_qx || qy > max_qy || qy < min_qy || qx == cqx || qy == cqy) return 0x7fffffff;
       const int mvdc = wh_mvd_cost (C.lambda, qx - cqx - me.mvpx, qy - cqy - me.mvpy);
       if (mvdc >= b) return 0x7fffffff;
+      WH_STAT (WH_ST_FME_SADS);
       const WH_G uint8_t* q = ref + (ptrdiff_t) (qy >> 2) * P.rec_stride_y + (qx >> 2);
       return mvdc + wh_sad_lane_g (S, q, P.rec_stride_y, me.bx, me.by, me.bw, me.bh); }) ());
     int k, l;
@@ -567,8 +592,8 @@ WH_FN void wh_motion_search (WhInterLds& S, const WhSeqParams& P, const WhPicJob
       // WelsDiamondCrossSearch / WelsDiamondCrossFeatureSearch (svc_motion_estimate.cpp:1055-1094)
       if ((uint32_t)best >= Z->thr) {
         WH_STAT (WH_ST_CROSS_V);
-        wh_line_search (S, P, J, C, me, true, &best, &bmx, &bmy);
-        if ((uint32_t)best >= Z->thr) { WH_STAT (WH_ST_CROSS_H); wh_line_search (S, P, J, C, me, false, &best, &bmx, &bmy); }
+        wh_line_search (S, P, J, W, C, me, true, &best, &bmx, &bmy);
+        if ((uint32_t)best >= Z->thr) { WH_STAT (WH_ST_CROSS_H); wh_line_search (S, P, J, W, C, me, false, &best, &bmx, &bmy); }
       }
       if (Z->method == 2 && (uint32_t)best >= Z->thr) {
         const int before = best;
