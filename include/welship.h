@@ -258,7 +258,10 @@ typedef struct WelsHipFrameJob {
   /* the call with bRetry = 1 and the list of ALL macroblocks re-encoded so far in this picture: the device inputs uploaded by the   */
   /* first call are reused (the host may have modified its copies meanwhile), every other macroblock reproduces itself.              */
   int32_t bRetry;
+  int32_t bCountBits;               /* WhMbRecord::cavlc_bits of every macroblock: the bits its CAVLC syntax will take, counted on the   */
+                                    /* device (set_mb_syn_cavlc.cpp:84-232, svc_set_mb_syn_cavlc.cpp:58-440), for GOM-level rate control  */
   int32_t iNumReencode;
+  int32_t iNumRefIdxL0Active;       /* P pictures with bCountBits: the slice header's num_ref_idx_l0_active (pEncCtx->iNumRef0)          */
   const struct WelsHipMbReencode* pReencode;
 } WelsHipFrameJob;
 typedef struct WelsHipMbReencode {

@@ -114,6 +114,8 @@ struct HipState {
   // WELS_HIP_TRACE=2: where a picture's time goes (seconds, summed): device call incl. transfers, reconstruction copy-back,
   // entropy coding from the records
   bool timing = false;
+  bool check_bits = false;              // WELS_HIP_CHECK_BITS=1: the device counts every macroblock's CAVLC bits and the slice loop compares them with the writer
+  long bits_checked = 0;
   double t_encode = 0.0, t_getpic = 0.0, t_code = 0.0;
   int pictures = 0;
 };
@@ -224,6 +226,8 @@ int32_t HipFrameMd (sWelsEncCtx* pCtx) {
       }
     job.pIlHint = &L.il_hint[0];
   }
+  job.bCountBits = st->check_bits ? 1 : 0;
+  job.iNumRefIdxL0Active = is_p ? pCtx->iNumRef0 : 0;
   job.pScreen = NULL;
   if (pParam->iUsageType == SCREEN_CONTENT_REAL_TIME) {
     if (!is_p) {
@@ -388,7 +392,22 @@ TRY_REENCODING:
     }
     LoadRecord (R, pCurMb, pMbCache);
     UpdateNonZeroCountCache (pCurMb, pMbCache);
+    const int32_t iBitsBefore = st->check_bits ? pFunc->pfGetBsPosition (pSlice) : 0, iSkipRunBefore = is_p ? pSlice->iMbSkipRun : 0;
+    const int32_t iLastQpBefore = pSlice->uiLastMbQp;
     const int32_t iEncReturn = pFunc->pfWelsSpatialWriteMbSyn (pCtx, pSlice, pCurMb);
+    if (st->check_bits && iEncReturn == ENC_RETURN_SUCCESS) {
+      // what the device counted (kernels/cavlc_bits.h) against what the writer just produced: the count leaves out ue(mb_skip_run) and
+      // se(mb_qp_delta), which depend on the macroblocks before this one in coding order
+      const int32_t iWritten = pFunc->pfGetBsPosition (pSlice) - iBitsBefore;
+      int32_t iCounted = 0;
+      if (R.mb_type != WH_MB_PSKIP) {
+        iCounted = R.cavlc_bits & 0x3fffffff;
+        if (is_p) iCounted += BsSizeUE (iSkipRunBefore);
+        if (R.cavlc_bits & 0x40000000) iCounted += BsSizeSE ((int32_t)R.luma_qp - iLastQpBefore);
+      }
+      if (iCounted != iWritten) { fprintf (stderr, "welship hooks: CAVLC bit count of MB %d (type %d cbp %d): device %d, writer %d\n", iCurMbIdx, R.mb_type, R.cbp, iCounted, iWritten); st->failed = true; return ENC_RETURN_UNEXPECTED; }
+      ++st->bits_checked;
+    }
     if (iEncReturn == ENC_RETURN_VLCOVERFLOWFOUND && kbCavlc && pCurMb->uiLumaQp < 50) {
       // TRY_REENCODING (svc_encode_slice.cpp:564-576,1845-1867): the writer could not code the macroblock (a level beyond what
       // Baseline CAVLC can express, or the picture's bitstream buffer nearly full); the reference takes the bitstream back to where
@@ -460,6 +479,7 @@ TRY_REENCODING:
 void HipRelease (void* p) {
   HipState* st = (HipState*)p;
   if (st == NULL) return;
+  if (st->check_bits && st->trace) fprintf (stderr, "welship hooks: CAVLC bit counts of %ld macroblocks equal the writer's\n", st->bits_checked);
   if (st->timing && st->pictures) fprintf (stderr, "welship hooks: %d pictures; per picture: device call %.3f ms, reconstruction copy-back %.3f ms, slice coding from the records %.3f ms\n",
                                            st->pictures, 1e3 * st->t_encode / st->pictures, 1e3 * st->t_getpic / st->pictures, 1e3 * st->t_code / st->pictures);
   for (int i = 0; i < MAX_DEPENDENCY_LAYER; ++i) if (st->layer[i].ctx) g_api.FrameCtxDestroy (st->layer[i].ctx);
@@ -521,6 +541,7 @@ void WelsHipInstall (SWelsFuncPtrList* pFuncList, SWelsSvcCodingParam* pParam) {
   st->device = getenv ("WELS_HIP_DEVICE") ? atoi (getenv ("WELS_HIP_DEVICE")) : 0;
   st->trace = getenv ("WELS_HIP_TRACE") != NULL;
   st->timing = st->trace && atoi (getenv ("WELS_HIP_TRACE")) >= 2;
+  st->check_bits = getenv ("WELS_HIP_CHECK_BITS") != NULL && atoi (getenv ("WELS_HIP_CHECK_BITS")) != 0 && pParam->iEntropyCodingModeFlag == 0;
   st->layer_devices = getenv ("WELS_HIP_LAYER_DEVICES") != NULL && atoi (getenv ("WELS_HIP_LAYER_DEVICES")) != 0;
   pFuncList->pHipState = st;
   pFuncList->pfHipFrameMd = HipFrameMd;

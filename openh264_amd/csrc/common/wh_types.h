@@ -46,7 +46,10 @@ typedef struct WhMbRecord {
   int32_t  cost;             // mode-decision cost of the chosen mode (for rate control)
   int16_t  mv_tr[2];         // inter MBs: final motion vector of the top-right 4x4 block (see WhMbCtl::cell12_mv)
   uint8_t  bgd_skip;         // P_Skip decided by background detection (MB_TYPE_BACKGROUND): the host mirrors VaaBackgroundMbDataUpdate
-  uint8_t  pad[15];
+  uint8_t  pad0[3];
+  int32_t  cavlc_bits;       // WhPicJob::want_bits: bits of this macroblock's CAVLC syntax without ue(mb_skip_run) and se(mb_qp_delta)
+                             //   (kernels/cavlc_bits.h); | WH_BITS_HAS_QP_DELTA when it codes mb_qp_delta.  Else 0
+  uint8_t  pad[8];
   // coefficient levels in zig-zag order:
   int16_t  luma[16][16];     // per luma4x4BlkIdx; I16x16: entries 0..14 = AC, [15] = 0
   int16_t  luma_dc[16];      // Intra16x16 DC levels
@@ -120,7 +123,8 @@ typedef struct WhPicJob {
   int32_t        slice_type; // WH_SLICE_I / WH_SLICE_P
   const WhMbCtl* mb_ctl;     // optional per-MB control words (QP offsets, re-encode state) or NULL
   int32_t        ref_is_p;   // reference picture was a P picture (co-located MV candidates)
-  int32_t        pad;
+  int32_t        want_bits;  // bit 0: count every macroblock's CAVLC bits (WhMbRecord::cavlc_bits); bit 1: the slice codes ref_idx_l0
+                             //   (num_ref_idx_l0_active_minus1 > 0)
   const uint8_t* prev_src_y; // luma of the previous source picture (VAA 8x8 SADs, LOW complexity P pictures)
   uint32_t*      db_flags;   // one word per MB: == db_gen once the MB is deblocked (hand-off between the slices' workgroups)
   uint32_t       db_gen;     // generation of this picture (never 0, changes every frame: the flags need no clearing)

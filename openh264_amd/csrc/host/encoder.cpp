@@ -1740,6 +1740,7 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
   job.slice_type = is_p ? WH_SLICE_P : WH_SLICE_I;
   job.mb_ctl = qp_map ? c->d_mb_ctl : nullptr;
   job.ref_is_p = is_p && c->pics[j->iRefPic].is_p ? 1 : 0;
+  job.want_bits = j->bCountBits ? (1 | (is_p && j->iNumRefIdxL0Active > 1 ? 2 : 0)) : 0;
   job.prev_src_y = nullptr;
   job.db_flags = c->d_dbflags;
   job.db_gen = c->db_gen;

@@ -7,6 +7,7 @@
 //   svc_encode_slice.cpp:1807-1899 WelsMdInterMbLoop (P slices, see inter_mb.h)
 #pragma once
 #include "intra_mb.h"
+#include "cavlc_bits.h"
 
 static_assert (sizeof (WhMbRecord) == 960, "WhMbRecord must be 960 bytes");
 static_assert (sizeof (WhMbState) == 144, "WhMbState must be 144 bytes");
@@ -14,7 +15,7 @@ static_assert (sizeof (WhMbCtl) == 8, "WhMbCtl must be 8 bytes");
 
 // Store the MB's reconstruction, entropy record and neighbour state to HBM.
 WH_FN void wh_store_mb (WhMbLds& S, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, int mb_type, int cbp,
-                        int qp, int qpc, int i16_mode, int chroma_mode, int cost, int slice_idc) {
+                        int qp, int qpc, int i16_mode, int chroma_mode, int cost, int slice_idc, int cavlc_bits = 0) {
   const int xy = mby * P.mb_w + mbx;
   // explicit global address space: generic (flat) stores would also count against lgkmcnt and make every later LDS read
   // of the wave wait for them
@@ -56,6 +57,7 @@ WH_FN void wh_store_mb (WhMbLds& S, const WhSeqParams& P, const WhPicJob& J, int
     R->i16_mode = (uint8_t)i16_mode; R->chroma_mode = (uint8_t)chroma_mode;
     R->i4_prev_flags = (mb_type == WH_MB_I4x4) ? S.i4_prev : (uint16_t)0;
     R->cost = cost;
+    R->cavlc_bits = cavlc_bits;
     M->mb_type = (uint8_t)mb_type; M->luma_qp = (uint8_t)qp; M->chroma_qp = (uint8_t)qpc; M->cbp = (uint8_t)cbp;
     M->slice_idc = (uint16_t)slice_idc;
     R->bgd_skip = 0;
@@ -134,7 +136,23 @@ WH_FN void wh_intra_mb_body (WhMbLds& S, const WhSeqParams& P, const WhPicJob& J
   // picture that is not costed by SAD (complexity above LOW) finds it (found by tools/fuzz_screen.py: an I picture in mid-stream)
   if (lane == 0 && J.sad_cost0) ((WH_G int32_t*)J.sad_cost0)[xy] = 0;
   WV_LANES_END
-  wh_store_mb (S, P, J, mbx, mby, r.mb_type, r.cbp, qp, qpc, r.i16_mode_std, r.chroma_mode_std, r.cost_luma, wh_slice_of_mb (P, xy));
+  int bits = 0;
+  if (J.want_bits) {
+    // the neighbours' total_coeff counts (coeff_token contexts): into the reduction scratch of the tile, then counted (cavlc_bits.h)
+    const bool al = (avail & WH_AV_LEFT) != 0, at = (avail & WH_AV_TOP) != 0;
+    uint8_t* nl = (uint8_t*)S.part;
+    uint8_t* nt = (uint8_t*)S.part2;
+    WV_LANES_BEGIN (lane)
+    if (lane < 24) {
+      if (al) nl[lane] = ((const WH_G WhMbState*)J.mbs + xy - 1)->nzc[lane];
+      if (at) nt[lane] = ((const WH_G WhMbState*)J.mbs + xy - P.mb_w)->nzc[lane];
+    }
+    WV_LANES_END
+    bits = wh_mb_residual_bits (S, r.mb_type, r.cbp, al ? nl : nullptr, at ? nt : nullptr) +
+           wh_mb_intra_header_bits (S, r.mb_type, r.cbp, r.i16_mode_std, r.chroma_mode_std, false);
+    if (r.cbp > 0 || r.mb_type == WH_MB_I16x16) bits |= WH_BITS_HAS_QP_DELTA;
+  }
+  wh_store_mb (S, P, J, mbx, mby, r.mb_type, r.cbp, qp, qpc, r.i16_mode_std, r.chroma_mode_std, r.cost_luma, wh_slice_of_mb (P, xy), bits);
 }
 
 #include "../common/mb_order.h"

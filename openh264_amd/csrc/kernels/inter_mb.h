@@ -1458,7 +1458,13 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
     if (lane < 4) { Ms->ref_idx[lane] = -1; Rs->ref_idx[lane] = -1; Rs->sub_type[lane] = 0; }
     if (lane == 0) { Ms->sad_cost[0] = 0; Ms->p16mv[0] = (int16_t)p16x; Ms->p16mv[1] = (int16_t)p16y; Ms->skip_sad = 0; if (J.sad_cost0) ((WH_G int32_t*)J.sad_cost0)[xy] = 0; }
     WV_LANES_END
-    wh_store_mb (M, P, J, mbx, mby, ir.mb_type, ir.cbp, qp, qpc, ir.i16_mode_std, ir.chroma_mode_std, ir.cost_luma, slice_idc);
+    int ibits = 0;
+    if (J.want_bits) {
+      ibits = wh_mb_residual_bits (M, ir.mb_type, ir.cbp, Lm ? Lm->nzc : nullptr, Tm ? Tm->nzc : nullptr) +
+              wh_mb_intra_header_bits (M, ir.mb_type, ir.cbp, ir.i16_mode_std, ir.chroma_mode_std, true);
+      if (ir.cbp > 0 || ir.mb_type == WH_MB_I16x16) ibits |= WH_BITS_HAS_QP_DELTA;
+    }
+    wh_store_mb (M, P, J, mbx, mby, ir.mb_type, ir.cbp, qp, qpc, ir.i16_mode_std, ir.chroma_mode_std, ir.cost_luma, slice_idc, ibits);
     return;
   }
   if (is_skip && b_skip) {
@@ -1492,7 +1498,21 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
     if (J.sad_cost0) ((WH_G int32_t*)J.sad_cost0)[xy] = sad_cost0;
   }
   WV_LANES_END
-  wh_store_mb (M, P, J, mbx, mby, mb_type, cbp, qp, qpc, 0, 0, cost_luma, slice_idc);
+  int pbits = 0;
+  if (J.want_bits && !is_skip) {
+    // mb_type (+ four sub_mb_types of P_8x8ref0), the vector differences of the partitions, coded_block_pattern, the residual
+    // (svc_set_mb_syn_cavlc.cpp:58-245; one reference picture: no ref_idx)
+    const int m16 = mb_type == WH_MB_P16x16, m168 = mb_type == WH_MB_P16x8, m816 = mb_type == WH_MB_P8x16;
+    int mvd_bits;
+    WV_SUM (mvd_bits, lane, ((lane == 0 || (m168 && lane == 8) || (m816 && lane == 2) || (!m16 && !m168 && !m816 && (lane == 2 || lane == 8 || lane == 10)))
+                             ? wh_se_bits_c ((int)S.mv_out[lane & 15][0] - (int)S.mvp_out[lane & 15][0]) + wh_se_bits_c ((int)S.mv_out[lane & 15][1] - (int)S.mvp_out[lane & 15][1]) : 0));
+    // (ref_idx_l0 is always 0 here: one bit per partition whenever more than one reference picture is active; P_8x8ref0 carries none)
+    const int ref_bits = (J.want_bits & 2) ? (m16 ? 1 : (m168 || m816) ? 2 : 0) : 0;
+    pbits = (m16 ? 1 : (m168 || m816) ? 3 : 5 + 4) + ref_bits + mvd_bits + wh_ue_bits (kWhCbpCodeInter[cbp]);
+    if (cbp > 0) pbits += wh_mb_residual_bits (M, mb_type, cbp, Lm ? Lm->nzc : nullptr, Tm ? Tm->nzc : nullptr);
+    if (cbp > 0) pbits |= WH_BITS_HAS_QP_DELTA;
+  }
+  wh_store_mb (M, P, J, mbx, mby, mb_type, cbp, qp, qpc, 0, 0, cost_luma, slice_idc, pbits);
   if (X.last_mv) {           // the next window guess of this slice (a race between waves is harmless: any recent vector will do)
     const int fin = is_skip ? wh_pk_mv (skx, sky) : wh_pk_mv (p16x, p16y);
     WV_LANES_BEGIN (lane)

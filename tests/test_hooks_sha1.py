@@ -67,7 +67,7 @@ def _run_row(workdir, lib, row, tag):
         opts += k.split() + [v]
     opts = [o if o != "bgd" else "-bgd" for o in opts]       # the table's header spells this one column without its dash
     out = str(workdir / ("t_%s.264" % tag))
-    env = dict(os.environ, WELSHIP_LIB=lib, WELS_HIP_TRACE="1", WELS_HIP_GOM="1")      # the one-slice rows use GOM-level QP: opt-in
+    env = dict(os.environ, WELSHIP_LIB=lib, WELS_HIP_TRACE="1", WELS_HIP_GOM="1", WELS_HIP_CHECK_BITS="1")      # the one-slice rows use GOM-level QP: opt-in
     p = subprocess.run([H264ENC, "welsenc.cfg", "-lconfig", "0", "layer0.cfg", "-lconfig", "1", "layer1.cfg", "-lconfig", "2", "layer2.cfg",
                         "-lconfig", "3", "layer3.cfg", "-bf", out, "-org", str(workdir / "BA_MW_D.264.yuv")] + opts,
                        cwd=str(workdir), env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
@@ -150,7 +150,7 @@ API_GOLDEN = [  # test/api/encoder_test.cpp:104-115 (SEncParamBase: RC quality m
 
 def _api_hash(lib, tmp_path, name, w, h, fps):
     out = str(tmp_path / "o.264")
-    env = dict(os.environ, WELSHIP_LIB=lib, WELS_HIP_TRACE="1", WELS_HIP_GOM="1")
+    env = dict(os.environ, WELSHIP_LIB=lib, WELS_HIP_TRACE="1", WELS_HIP_GOM="1", WELS_HIP_CHECK_BITS="1")
     p = subprocess.run([os.path.join(REF, "ref_enc_hip"), "-i", os.path.join(RES, name), "-w", str(w), "-h", str(h), "-o", out, "-base", "-rc", "0",
                         "-fps", str(fps), "-quiet"], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
     err = p.stderr.decode(errors="replace")
@@ -177,7 +177,7 @@ def _stock_cfg(lib, tmp_path):
     (tmp_path / "welsenc.cfg").write_text(cfg)
     (tmp_path / "layer2.cfg").write_bytes(open(os.path.join(RES, "layer2.cfg"), "rb").read())
     subprocess.check_call([os.path.join(REF, "h264enc_ref"), "welsenc.cfg", "-bf", "ref.264"], cwd=str(tmp_path), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    env = dict(os.environ, WELSHIP_LIB=lib, WELS_HIP_TRACE="1", WELS_HIP_GOM="1")
+    env = dict(os.environ, WELSHIP_LIB=lib, WELS_HIP_TRACE="1", WELS_HIP_GOM="1", WELS_HIP_CHECK_BITS="1")
     p = subprocess.run([H264ENC, "welsenc.cfg", "-bf", "hip.264"], cwd=str(tmp_path), env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
     err = p.stderr.decode(errors="replace")
     assert p.returncode == 0 and "welship hooks: installed" in err and err.count("welship hooks: did") >= 5, err[-2000:]

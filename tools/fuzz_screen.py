@@ -101,7 +101,7 @@ def run_case(seed, lib, workdir, usage=1):
         p = subprocess.run([os.path.join(REF, "ref_enc"), "-o", a] + base, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         if p.returncode:
             return seed, "invalid", flags
-        env = dict(os.environ, WELSHIP_LIB=lib, WELS_HIP_GOM="1", WELS_HIP_TRACE="1")
+        env = dict(os.environ, WELSHIP_LIB=lib, WELS_HIP_GOM="1", WELS_HIP_CHECK_BITS="1", WELS_HIP_TRACE="1")
         q = subprocess.run([os.path.join(REF, "ref_enc_hip"), "-o", b] + base, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
         err = q.stderr.decode(errors="replace")
         pics = err.count("welship hooks: did")
