@@ -262,8 +262,19 @@ typedef struct WelsHipFrameJob {
                                     /* device (set_mb_syn_cavlc.cpp:84-232, svc_set_mb_syn_cavlc.cpp:58-440), for GOM-level rate control  */
   int32_t iNumReencode;
   int32_t iNumRefIdxL0Active;       /* P pictures with bCountBits: the slice header's num_ref_idx_l0_active (pEncCtx->iNumRef0)          */
+  const struct WelsHipGomRc* pGomRc; /* P pictures of one slice under rate control (GOM-level QP, ratectl.cpp:1239-1278): the whole picture */
+                                    /* in ONE call -- the device counts the bits of every group of macroblocks and runs RcCalculateGomQp /  */
+                                    /* RcGomTargetBits between the groups itself (iQp = the first group's QP, pMbQp / iMbBegin unused);     */
+                                    /* the records carry each macroblock's QP, which the caller's own rate control must arrive at too       */
   const struct WelsHipMbReencode* pReencode;
 } WelsHipFrameJob;
+typedef struct WelsHipGomRc {
+  int32_t iNumberMbGom;             /* pWelsSvcRc->iNumberMbGom: whole macroblock rows (else WELSHIP_ERR_UNSUPPORTED: code the groups one by one) */
+  int32_t iEndMbSlice, iTargetBitsSlice;      /* pSlice->sSlicingOverRc                                                                  */
+  int32_t iMinFrameQp, iMaxFrameQp; /* pWelsSvcRc                                                                                        */
+  int32_t iGomSize;
+  const int32_t* pGomSad;           /* pCurrentFrameGomSad[iGomSize] of the layer RcGomTargetBits reads (RcJudgeBaseUsability)           */
+} WelsHipGomRc;
 typedef struct WelsHipMbReencode {
   int32_t iMbXY;
   uint8_t uiLumaQp;                 /* the QP of this pass (UpdateQpForOverflow)                                                       */

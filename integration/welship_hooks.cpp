@@ -54,6 +54,8 @@ namespace WelsEnc {
 
 // defined in svc_mode_decision.cpp:520-537 (no header declares it): what WelsInitSCDPskipFunc installs for screen content below HIGH complexity
 bool WelsMdInterJudgeSCDPskip (sWelsEncCtx* pEncCtx, SWelsMD* pWelsMd, SSlice* slice, SMB* pCurMb, SMbCache* pMbCache);
+// defined in ratectl.cpp:689-709 (no header declares it): the layer whose per-group SADs RcGomTargetBits reads, or NULL for this layer's own
+SWelsSvcRc* RcJudgeBaseUsability (sWelsEncCtx* pEncCtx);
 
 namespace {
 
@@ -98,6 +100,7 @@ struct HipLayer {                       // one spatial layer = one device contex
   std::vector<int32_t> first;
   std::vector<uint8_t> mb_qp;
   int coded_upto = 0;
+  WelsHipGomRc gomrc;                    // GOM-level rate control inside the kernel (WELS_HIP_GOM=2): the picture's rate-control inputs
   WelsHipScreenInfo screen;              // screen content: the pre-processing's results of the picture being coded
   std::vector<uint32_t> fme_down;        //   and what the device reports back per slice (uiSliceFMECostDown)
   std::vector<int16_t> il_hint;          // highest layer of a multi-layer session: hints from the layer below
@@ -114,6 +117,7 @@ struct HipState {
   // WELS_HIP_TRACE=2: where a picture's time goes (seconds, summed): device call incl. transfers, reconstruction copy-back,
   // entropy coding from the records
   bool timing = false;
+  bool gom_kernel = false;              // WELS_HIP_GOM=2: single-slice rate-controlled P pictures in ONE device call (the QP recursion runs in the kernel)
   bool check_bits = false;              // WELS_HIP_CHECK_BITS=1: the device counts every macroblock's CAVLC bits and the slice loop compares them with the writer
   long bits_checked = 0;
   double t_encode = 0.0, t_getpic = 0.0, t_code = 0.0;
@@ -263,6 +267,27 @@ int32_t HipFrameMd (sWelsEncCtx* pCtx) {
       L.fme_down.assign (nslices, 0u);
       scr.pSliceFMECostDown = &L.fme_down[0];
       job.pScreen = &scr;
+    }
+  }
+  job.pGomRc = NULL;
+  if (L.gom && st->gom_kernel && is_p && job.pScreen == NULL && nslices == 1) {
+    // WELS_HIP_GOM=2: the groups' QP recursion (RcCalculateGomQp / RcGomTargetBits between the groups, from the bits the device counts
+    // itself) runs inside the kernel, so the picture is ONE device call like a constant-QP picture and shares a launch with other
+    // sessions' pictures.  The reference's own rate control still runs in the slice loop, on the real bit positions: every macroblock's QP
+    // is compared there (a difference fails the frame).  Groups must be whole macroblock rows (else group by group as before).
+    const SWelsSvcRc* pRc = &pCtx->pWelsSvcRc[did];
+    const SWelsSvcRc* pRcBase = RcJudgeBaseUsability (pCtx);
+    if (pRcBase == NULL) pRcBase = pRc;
+    if (pRc->iNumberMbGom % mbw == 0 && pRc->iGomSize <= 160 && pRc->bGomRC) {
+      WelsHipGomRc& g = L.gomrc;
+      memset (&g, 0, sizeof (g));
+      // GomRCInitForOneSlice (ratectl.cpp:541-547; WelsCodeOneSlice calls it after this hook) for the picture's only slice
+      g.iNumberMbGom = pRc->iNumberMbGom; g.iEndMbSlice = num_mb - 1;
+      g.iTargetBitsSlice = WELS_DIV_ROUND (static_cast<int64_t> (pRc->iBitsPerMb) * num_mb, INT_MULTIPLY);
+      g.iMinFrameQp = pRc->iMinFrameQp; g.iMaxFrameQp = pRc->iMaxFrameQp;
+      g.iGomSize = pRc->iGomSize; g.pGomSad = pRcBase->pCurrentFrameGomSad;
+      job.pGomRc = &g;
+      L.gom = false;               // (coded by the one call below; HipCodeSlice only entropy-codes and checks the QPs)
     }
   }
   if (L.gom) {
@@ -541,6 +566,7 @@ void WelsHipInstall (SWelsFuncPtrList* pFuncList, SWelsSvcCodingParam* pParam) {
   st->device = getenv ("WELS_HIP_DEVICE") ? atoi (getenv ("WELS_HIP_DEVICE")) : 0;
   st->trace = getenv ("WELS_HIP_TRACE") != NULL;
   st->timing = st->trace && atoi (getenv ("WELS_HIP_TRACE")) >= 2;
+  st->gom_kernel = getenv ("WELS_HIP_GOM") != NULL && atoi (getenv ("WELS_HIP_GOM")) >= 2 && pParam->iEntropyCodingModeFlag == 0;
   st->check_bits = getenv ("WELS_HIP_CHECK_BITS") != NULL && atoi (getenv ("WELS_HIP_CHECK_BITS")) != 0 && pParam->iEntropyCodingModeFlag == 0;
   st->layer_devices = getenv ("WELS_HIP_LAYER_DEVICES") != NULL && atoi (getenv ("WELS_HIP_LAYER_DEVICES")) != 0;
   pFuncList->pHipState = st;

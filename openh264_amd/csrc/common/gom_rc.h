@@ -10,34 +10,12 @@
 // a multiple of 16 (RcInitSequenceParameter, ratectl.cpp:153).
 #pragma once
 #include <stdint.h>
+#include "wh_types.h"
 #if defined(__HIPCC__)
 #define WH_RC_FN static __host__ __device__ inline
 #else
 #define WH_RC_FN static inline
 #endif
-
-#define WH_GOM_MAX 160              /* groups per picture the device state has room for (2304 / 16 rows, one row per group) */
-
-// per-picture inputs (host -> device) and the running state (device), one per picture in flight
-typedef struct WhGomRc {
-  // inputs
-  int32_t n_gom_mb;                 // iNumberMbGom
-  int32_t end_mb;                   // pSOverRc->iEndMbSlice
-  int32_t target_bits;              // pSOverRc->iTargetBitsSlice
-  int32_t min_qp, max_qp;           // pWelsSvcRc->iMinFrameQp / iMaxFrameQp
-  int32_t slice_qp;                 // pSlice->uiLastMbQp at the start of the slice (PicInitQp + slice_qp_delta)
-  int32_t p_slice;                  // ue(mb_skip_run) exists
-  int32_t pad;
-  int32_t gom_sad[WH_GOM_MAX];      // pCurrentFrameGomSad of the layer RcGomTargetBits looks at
-  // state
-  int32_t calc_qp;                  // pSOverRc->iCalculatedQpSlice: the QP of the macroblocks of the current group
-  int32_t frame_bits;               // iFrameBitsSlice
-  int32_t gom_bits;                 // iGomBitsSlice
-  int32_t gom_target;               // iGomTargetBits
-  int32_t index;                    // iComplexityIndexSlice: the current group
-  int32_t skip_run, last_qp;        // the entropy writer's pSlice->iMbSkipRun and uiLastMbQp after the macroblocks counted so far
-  int32_t pad2;
-} WhGomRc;
 
 WH_RC_FN int32_t wh_div_round (int64_t x, int64_t y) { return (int32_t) (y == 0 ? x / (y + 1) : (y / 2 + x) / y); }      // WELS_DIV_ROUND(64)
 

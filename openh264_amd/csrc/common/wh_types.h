@@ -111,6 +111,30 @@ typedef struct WhSccJob {
   uint32_t* fme_cost_down;     // [num_slices]: what the picture adds to pSlice->uiSliceFMECostDown
 } WhSccJob;
 
+// ---- rate control with one slice per picture, QP per group of macroblocks: inputs and running state (common/gom_rc.h) -------
+#define WH_GOM_MAX 160              /* groups per picture the device state has room for (2304 / 16 rows, one row per group) */
+
+// per-picture inputs (host -> device) and the running state (device), one per picture in flight
+typedef struct WhGomRc {
+  // inputs
+  int32_t n_gom_mb;                 // iNumberMbGom
+  int32_t end_mb;                   // pSOverRc->iEndMbSlice
+  int32_t target_bits;              // pSOverRc->iTargetBitsSlice
+  int32_t min_qp, max_qp;           // pWelsSvcRc->iMinFrameQp / iMaxFrameQp
+  int32_t slice_qp;                 // pSlice->uiLastMbQp at the start of the slice (PicInitQp + slice_qp_delta)
+  int32_t p_slice;                  // ue(mb_skip_run) exists
+  int32_t pad;
+  int32_t gom_sad[WH_GOM_MAX];      // pCurrentFrameGomSad of the layer RcGomTargetBits looks at
+  // state
+  int32_t calc_qp;                  // pSOverRc->iCalculatedQpSlice: the QP of the macroblocks of the current group
+  int32_t frame_bits;               // iFrameBitsSlice
+  int32_t gom_bits;                 // iGomBitsSlice
+  int32_t gom_target;               // iGomTargetBits
+  int32_t index;                    // iComplexityIndexSlice: the current group
+  int32_t skip_run, last_qp;        // the entropy writer's pSlice->iMbSkipRun and uiLastMbQp after the macroblocks counted so far
+  int32_t pad2;
+} WhGomRc;
+
 // ---- one picture being encoded (one frame of one session) ---------------------------------------
 typedef struct WhPicJob {
   const uint8_t* src[3];     // source planes, dims = mb_w*16 x mb_h*16 (host pads), own strides
@@ -149,6 +173,9 @@ typedef struct WhPicJob {
   // blocks), or -1
   const uint32_t* scc_order;
   const int32_t* scc_chain_prev;
+  // P pictures coded with GOM-level rate control inside the kernel (also WH_SEQ_CHAIN: the groups are bands of the processing order,
+  // every macroblock of a group additionally waits for the last macroblock of the group before it): inputs + state, or NULL
+  WhGomRc* gom_rc;
 } WhPicJob;
 
 #define WH_MAX_SLICES 36

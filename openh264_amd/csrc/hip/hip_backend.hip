@@ -169,7 +169,7 @@ __global__ __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPi
     tt = __builtin_amdgcn_readfirstlane (tt);                                                                                  \
     if (tt >= slot_n[best]) { gone |= 1u << best; continue; }                                                                  \
     const int first_ = slot_first[best];                                                                                       \
-    const int xy_ = (SCC && (P.flags & WH_SEQ_CHAIN)) ? (int)((const WH_G uint32_t*)Jl[best].scc_order)[first_ + tt]          \
+    const int xy_ = (P.flags & WH_SEQ_CHAIN) ? (int)((const WH_G uint32_t*)Jl[best].scc_order)[first_ + tt]                   \
                   : (SCC && (P.flags & WH_SEQ_SERIAL)) ? first_ + tt : (int)P.mb_order[first_ + tt];   /* serial: coding order */ \
     const int mb_end_ = Jl[best].mb_end;                                                                                       \
     if (mb_end_ > 0) {                    /* GOM-synchronous coding: only [mb_begin, mb_end) in this launch */                 \
@@ -198,7 +198,7 @@ __global__ __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPi
     if (SCC && (P.flags & WH_SEQ_SERIAL)) { dep_a = xy > first ? xy - 1 : -1; dep_b = -1; }      // the macroblock before it in coding order (WhSccJob::chain)
     if (!wh_wait_done (sc + 1, dep_a < 0 ? -1 : dep_a - first, err)) break;
     if (!wh_wait_done (sc + 1, dep_b < 0 ? -1 : dep_b - first, err)) break;
-    if (SCC && (P.flags & WH_SEQ_CHAIN)) {          // ... and the previous macroblock of the slice that may search 8x8 blocks
+    if (P.flags & WH_SEQ_CHAIN) {          // ... and the previous macroblock of the slice that may search 8x8 blocks / the last one of the previous group
       const int dep_c = ((const WH_G int32_t*)J.scc_chain_prev)[xy];
       if (!wh_wait_done (sc + 1, dep_c < first ? -1 : dep_c - first, err)) break;
     }
@@ -208,6 +208,7 @@ __global__ __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPi
     WV_ASYNC_WAIT();                      /* this MB's cold inputs have landed in the staging area */
     X.slice_idc = slot_idc[slot]; X.slice_first = first; X.last_mv = &slot_mv[slot];
     wh_inter_mb_body_t<SCC> (S, G, P, J, xy % P.mb_w, xy / P.mb_w, X);
+    if (J.gom_rc) wh_gom_close_if_last (P, J, xy);       // rate control: the group's last macroblock settles the next group's QP
     WH_PROF_MARK (P, S.m, 14);
     __builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");
     if (lane == 0) atomicOr (&sc[1 + ((xy - first) >> 5)], 1u << ((xy - first) & 31));

@@ -23,6 +23,7 @@
 #include "../../../include/welship.h"
 #include "backend.h"
 #include "../common/mb_order.h"
+#include "../common/gom_rc.h"
 #include "entropy_cavlc.h"
 #include "headers.h"
 #include "../common/compact.h"
@@ -1247,6 +1248,8 @@ struct WelsHipFrameCtx {
   uint8_t* d_scc_ori = nullptr;
   uint32_t* d_scc_chain = nullptr;       // [WH_MAX_SLICES][4] chain, then [WH_MAX_SLICES] cost-down sums
   uint32_t* d_scc_order = nullptr;       // WH_SEQ_CHAIN: the picture's processing order [num_mb] | chain_prev [num_mb]
+  WhGomRc* d_gom_rc = nullptr;           // GOM-level rate control inside the kernel: inputs + state of the picture in flight
+  std::vector<uint8_t> h_gom;            // page-locked staging: WhGomRc | order [num_mb] | dependency [num_mb]
   uint32_t* d_scc_lists = nullptr;       // times[list] | start[list]
   uint16_t* d_scc_loc = nullptr;
   size_t scc_list_cap = 0, scc_loc_cap = 0;
@@ -1264,7 +1267,8 @@ struct WelsHipFrameCtx {
     be->sync();
     for (auto& p : pics) { if (p.base) be->free (p.base); if (p.mbs) be->free (p.mbs); }
     pics.clear();
-    void* ptrs[] = {d_src, d_records, d_dbflags, d_mb_ctl, d_sad_cost0, d_vaa, d_bgd, d_il, d_job, d_scc, d_scc_idc, d_scc_ori, d_scc_chain, d_scc_lists, d_scc_loc, d_scc_order};
+    void* ptrs[] = {d_src, d_records, d_dbflags, d_mb_ctl, d_sad_cost0, d_vaa, d_bgd, d_il, d_job, d_scc, d_scc_idc, d_scc_ori, d_scc_chain, d_scc_lists, d_scc_loc, d_scc_order, d_gom_rc};
+    if (!h_gom.empty()) be->unpin_host (h_gom.data());
     if (!h_scc.empty()) be->unpin_host (h_scc.data());
     if (!h_scc_small.empty()) be->unpin_host (h_scc_small.data());
     for (void* p : ptrs) if (p) be->free (p);
@@ -1642,6 +1646,30 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
       }
     }
   }
+  // GOM-level rate control inside the kernel: the groups become bands of the processing order (2:1 order inside a group), every
+  // macroblock of a group waits for the last macroblock of the group before it, which settles the group's QP (kernels/inter_mb.h)
+  const WelsHipGomRc* gom = j->pGomRc;
+  if (gom) {
+    if (!is_p || ranged || retry || scr || j->pMbQp || j->iNumSlices != 1) { set_err ("GOM-level rate control inside the kernel: a whole single-slice camera-video P picture"); return WELSHIP_ERR_INIT_PARA; }
+    if (gom->iNumberMbGom < 1 || gom->iNumberMbGom % c->mb_w != 0 || gom->iGomSize < 1 || gom->iGomSize > WH_GOM_MAX || !gom->pGomSad || gom->iEndMbSlice != c->num_mb - 1 ||
+        gom->iEndMbSlice / gom->iNumberMbGom >= gom->iGomSize) { set_err ("GOM-level rate control inside the kernel needs groups of whole macroblock rows"); return WELSHIP_ERR_UNSUPPORTED; }
+    if (c->h_gom.empty()) {
+      std::unique_lock<std::mutex> lk (sh->mu);
+      c->h_gom.assign (sizeof (WhGomRc) + 8 * (size_t)c->num_mb + 64, 0);
+      be->pin_host (c->h_gom.data(), c->h_gom.size());
+    }
+    WhGomRc& R = * (WhGomRc*)c->h_gom.data();
+    memset (&R, 0, sizeof (R));
+    R.n_gom_mb = gom->iNumberMbGom; R.end_mb = gom->iEndMbSlice; R.target_bits = gom->iTargetBitsSlice;
+    R.min_qp = gom->iMinFrameQp; R.max_qp = gom->iMaxFrameQp; R.slice_qp = j->iQp; R.p_slice = 1;
+    memcpy (R.gom_sad, gom->pGomSad, sizeof (int32_t) * gom->iGomSize);
+    wh_gom_begin (R, j->iQp);
+    uint32_t* order = (uint32_t*) (c->h_gom.data() + sizeof (WhGomRc));
+    int32_t* dep = (int32_t*) (order + c->num_mb);
+    std::vector<uint16_t> o16 (c->num_mb);
+    wh_build_mb_order (c->mb_w, 0, c->num_mb, o16.data(), gom->iNumberMbGom / c->mb_w);
+    for (int i = 0; i < c->num_mb; ++i) { order[i] = o16[i]; dep[i] = i / gom->iNumberMbGom ? (i / gom->iNumberMbGom) * gom->iNumberMbGom - 1 : -1; }
+  }
   bool qp_map = false;
   if (j->pMbQp) {
     for (int i = 0; i < c->num_mb; ++i) { memset (&c->h_mb_ctl[i], 0, sizeof (WhMbCtl)); c->h_mb_ctl[i].qp_delta = (int8_t) ((int)j->pMbQp[i] - j->iQp); }
@@ -1672,7 +1700,8 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
   s.mv_range = j->iMvRange;
   // screen content: its own kernel variant; a picture with a scroll vector codes the macroblocks of a slice one after the other
   // (the directional-vector test of the 8x8 searches reads what the previous macroblock in CODING order left, WhSccJob::chain)
-  s.flags = scr ? (WH_SEQ_SCC | (scc_chain ? WH_SEQ_CHAIN : scc_scroll ? WH_SEQ_SERIAL : 0)) : 0;
+  s.flags = scr ? (WH_SEQ_SCC | (scc_chain ? WH_SEQ_CHAIN : scc_scroll ? WH_SEQ_SERIAL : 0)) : gom ? WH_SEQ_CHAIN : 0;
+  if (gom) qp_map = true;          // the QP changes from group to group: QP_Y of the macroblocks without mb_qp_delta (run_qp_chain)
   // the pictures this one can share a launch with, and the queue they use (MB ranges: queue 0, on their own)
   FrameKey* K = ranged ? nullptr : frame_find_key (sh, s, is_p, qp_map, j->bExpand != 0);
   const int queue = K ? K->queue : 0;
@@ -1687,7 +1716,12 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
     c->h_pic_of = -1;
   }
   if (retry) { if (++c->db_gen == 0) c->db_gen = 1; c->h_pic_of = -1; }
-  if (qp_map) be->upload (c->d_mb_ctl, c->h_mb_ctl.data(), sizeof (WhMbCtl) * c->num_mb);
+  if (qp_map && !gom) be->upload (c->d_mb_ctl, c->h_mb_ctl.data(), sizeof (WhMbCtl) * c->num_mb);
+  if (gom) {
+    if (!c->d_gom_rc) c->d_gom_rc = (WhGomRc*)be->alloc (sizeof (WhGomRc) + 8 * (size_t)c->num_mb + 64);
+    if (!c->d_gom_rc) { set_err ("out of device memory"); return WELSHIP_ERR_MEMORY; }
+    be->upload (c->d_gom_rc, c->h_gom.data(), sizeof (WhGomRc) + 8 * (size_t)c->num_mb);
+  }
   c->scc_active = scr != nullptr;
   if (scr) {
     bool oom = false;
@@ -1738,7 +1772,7 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
   job.ref_mbs = is_p ? c->pics[j->iRefPic].mbs : nullptr;
   job.qp = j->iQp;
   job.slice_type = is_p ? WH_SLICE_P : WH_SLICE_I;
-  job.mb_ctl = qp_map ? c->d_mb_ctl : nullptr;
+  job.mb_ctl = (qp_map && !gom) ? c->d_mb_ctl : nullptr;
   job.ref_is_p = is_p && c->pics[j->iRefPic].is_p ? 1 : 0;
   job.want_bits = j->bCountBits ? (1 | (is_p && j->iNumRefIdxL0Active > 1 ? 2 : 0)) : 0;
   job.prev_src_y = nullptr;
@@ -1752,6 +1786,12 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
   job.scc = scr ? c->d_scc : nullptr;
   job.scc_order = scc_chain ? c->d_scc_order : nullptr;
   job.scc_chain_prev = scc_chain ? (const int32_t*) (c->d_scc_order + c->num_mb) : nullptr;
+  if (gom) {
+    job.gom_rc = c->d_gom_rc;
+    job.scc_order = (const uint32_t*) ((const uint8_t*)c->d_gom_rc + sizeof (WhGomRc));
+    job.scc_chain_prev = (const int32_t*) (job.scc_order + c->num_mb);
+    job.want_bits |= 1 | (j->iNumRefIdxL0Active > 1 ? 2 : 0);
+  }
   job.mb_begin = ranged ? j->iMbBegin : 0; job.mb_end = ranged ? j->iMbEnd : 0;
 
   if (ranged) {

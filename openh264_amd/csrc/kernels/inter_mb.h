@@ -28,6 +28,7 @@
 //   svc_motion_estimate.cpp:880-1097 SetFeatureSearchIn / FeatureSearchOne / WelsDiamondCrossSearch / WelsDiamondCrossFeatureSearch
 #pragma once
 #include "frame_kernels.h"
+#include "../common/gom_rc.h"
 
 // Performance shape (MI355X): the wave pays HBM latency twice per macroblock -- one batch of loads for the source
 // tile, the neighbour pixels and the neighbour / co-located MB states, and one batch for the reference search
@@ -891,7 +892,9 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
   const int slice_idc = X.slice_idc;
   const int avail = wh_mb_avail_in_slice (P, mbx, mby, X.slice_first);
   const WhMbCtl ctl = wh_mb_ctl (J, xy);
-  const int qp = wh_mb_qp (J, ctl);
+  // GOM-level rate control inside the kernel: the QP of this macroblock's group, settled by the last macroblock of the group before
+  // it (wh_gom_close_if_last) -- which this macroblock has waited for (WhPicJob::scc_chain_prev)
+  const int qp = J.gom_rc ? wh_clip3 ((int)wh_ld_wg32 ((const WH_G uint32_t*)& ((const WH_G WhGomRc*)J.gom_rc)->calc_qp), 0, 51) : wh_mb_qp (J, ctl);
   const int qpc = kWhChromaQp[wh_clip3 (qp + P.chroma_qp_offset, 0, 51)];
   const int lambda = kWhLambda[qp];
   const int use_satd = P.complexity > 0;        // pfMdCost == SATD, pfCalculateSatd == CalculateSatdCost
@@ -1529,7 +1532,7 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
   if (!bg_coded && !scd_coded) collocated = decided_skip ? (skx == 0 && sky == 0) : ((is_skip || mb_type == WH_MB_P16x16) && cbp == 0 && me16.mvx == 0 && me16.mvy == 0);
   {
     const bool inherit = cbp == 0 && ref_is_p && collocated;
-    const bool last_qp = !inherit && decided_skip && J.mb_ctl != nullptr;
+    const bool last_qp = !inherit && decided_skip && (J.mb_ctl != nullptr || J.gom_rc != nullptr);
     if (bg_skip || inherit || last_qp) {
       WV_LANES_BEGIN (lane)
       if (lane == 0) {
@@ -1544,4 +1547,42 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
 }
 WH_FN void wh_inter_mb_body (WhInterLds& S, WhInterStage& G, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, const WhInterCtx& X) {
   wh_inter_mb_body_t<false> (S, G, P, J, mbx, mby, X);
+}
+
+// ---- GOM-level rate control inside the kernel (common/gom_rc.h) ----------------------------------------
+// Called for every macroblock after its body.  The last macroblock of a group (in coding order) only starts when every other
+// macroblock of the group is complete (its left and top neighbours' chains cover the group's rows), so at this point all records
+// of the group are final: walk them in coding order, add the two terms the per-macroblock counts leave out -- ue(mb_skip_run) in
+// front of a coded macroblock, se(mb_qp_delta) of one that codes it (WelsSpatialWriteMbSyn, svc_set_mb_syn_cavlc.cpp:260-322) --
+// and advance the state exactly like WelsRcMbInfoUpdateGom / WelsRcMbInitGom (ratectl.cpp:1239-1278) would macroblock by
+// macroblock.  The macroblocks of the next group wait for this one's done flag and then read the new QP.
+WH_FN void wh_gom_close_if_last (const WhSeqParams& P, const WhPicJob& J, int xy) {
+  WhGomRc& R = * (WhGomRc*)J.gom_rc;
+  const int n = R.n_gom_mb;
+  if ((xy + 1) % n != 0 || xy >= R.end_mb) return;          // not the last of its group, or the slice ends with this group
+  const int a = xy + 1 - n, b = xy + 1;
+  WV_GLOBAL_FENCE();                                       // this wave's own record is among the ones read back
+  const int gom_qp = R.calc_qp, p_slice = R.p_slice;
+  int skip_run = R.skip_run, last_qp = R.last_qp, bits = 0;
+  for (int base = a; base < b; base += 64) {
+    WvLaneArr cb, ty;
+#ifdef WH_EMU
+    memset (&cb, 0, sizeof (cb)); memset (&ty, 0, sizeof (ty));
+#else
+    cb = 0; ty = 0;
+#endif
+    WV_LSET_IF (cb, lane, base + lane < b, ((const WH_G WhMbRecord*)J.records + base + lane)->cavlc_bits);
+    WV_LSET_IF (ty, lane, base + lane < b, (int) ((const WH_G WhMbRecord*)J.records + base + lane)->mb_type);
+    const int cnt = b - base < 64 ? b - base : 64;
+    for (int i = 0; i < cnt; ++i) {
+      if (WV_LGET (ty, i) == WH_MB_PSKIP) { ++skip_run; continue; }
+      const int c = WV_LGET (cb, i);
+      bits += c & 0x3fffffff;
+      if (p_slice) { bits += wh_ue_bits ((unsigned)skip_run); skip_run = 0; }
+      if (c & WH_BITS_HAS_QP_DELTA) { bits += wh_se_bits_c (gom_qp - last_qp); last_qp = gom_qp; }
+    }
+  }
+  wh_gom_next (R, bits);
+  R.skip_run = skip_run; R.last_qp = last_qp;
+  WV_GLOBAL_FENCE();
 }

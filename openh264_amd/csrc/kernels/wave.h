@@ -29,6 +29,7 @@
 #endif
 #define WV_LANES_END }
 #define WV_SYNC() ((void)0)
+#define WV_GLOBAL_FENCE() ((void)0)
 #define WV_SUM(dst, lane, expr)                                   \
   do { int _s = 0; for (int lane = 0; lane < 64; ++lane) _s += (int)(expr); (dst) = _s; } while (0)
 // minimum of (key) over lanes with `valid`, ties -> lowest lane; dst_lane = that lane or -1
@@ -118,6 +119,8 @@ WH_FN int wh_lane_id() { int l = (int)(threadIdx.x & 63); asm volatile ("" : "+v
 #define WV_SYNC() do { __builtin_amdgcn_fence (__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
                        __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 #define WV_LANES_END } WV_SYNC();
+// this wave's global-memory stores are complete and visible to the workgroup (and to its own later loads) before anything after it
+#define WV_GLOBAL_FENCE() __builtin_amdgcn_fence (__ATOMIC_SEQ_CST, "workgroup")
 
 // 64-lane reductions on the DPP network (no LDS traffic): quad -> half row -> row, then the four row results are
 // combined on the scalar unit.  Results are wave-uniform (SGPR).

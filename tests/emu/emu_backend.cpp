@@ -81,6 +81,7 @@ class EmuBackend : public Backend {
           X.last_mv = &last_mv;
           if (P.flags & WH_SEQ_SCC) wh_inter_mb_body_t<true> (S, G, P, jobs[j], mbx, mby, X);
           else wh_inter_mb_body (S, G, P, jobs[j], mbx, mby, X);
+          if (jobs[j].gom_rc) wh_gom_close_if_last (P, jobs[j], xy);
           poison (&S, sizeof (S)); poison (&WB, sizeof (WB)); poison (&G, sizeof (G));      // nothing survives from one macroblock to the next
         }
       }

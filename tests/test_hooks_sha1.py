@@ -60,7 +60,7 @@ def workdir(tmp_path_factory, ref_tools):
     return d
 
 
-def _run_row(workdir, lib, row, tag):
+def _run_row(workdir, lib, row, tag, extra_env=None):
     sha, yuv_sha, keys, vals, _ = row
     opts = []
     for k, v in zip(keys, vals):
@@ -68,6 +68,7 @@ def _run_row(workdir, lib, row, tag):
     opts = [o if o != "bgd" else "-bgd" for o in opts]       # the table's header spells this one column without its dash
     out = str(workdir / ("t_%s.264" % tag))
     env = dict(os.environ, WELSHIP_LIB=lib, WELS_HIP_TRACE="1", WELS_HIP_GOM="1", WELS_HIP_CHECK_BITS="1")      # the one-slice rows use GOM-level QP: opt-in
+    env.update(extra_env or {})
     p = subprocess.run([H264ENC, "welsenc.cfg", "-lconfig", "0", "layer0.cfg", "-lconfig", "1", "layer1.cfg", "-lconfig", "2", "layer2.cfg",
                         "-lconfig", "3", "layer3.cfg", "-bf", out, "-org", str(workdir / "BA_MW_D.264.yuv")] + opts,
                        cwd=str(workdir), env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
@@ -140,6 +141,41 @@ def test_sha1_table_rows_on_the_mi355x(workdir, hip_lib):
     _check(workdir, hip_lib, _sample(_device_rows(), 128))
 
 
+# ---- the one-slice rows with the groups' QP recursion INSIDE the kernel (WELS_HIP_GOM=2) ------------------------
+# The device counts every macroblock's CAVLC bits (kernels/cavlc_bits.h), the last macroblock of a group of macroblocks adds the
+# skip-run / mb_qp_delta terms in coding order and runs RcCalculateGomQp / RcGomTargetBits (common/gom_rc.h), the next group reads
+# its QP -- one device call per P picture.  The reference's own rate control still runs in the slice loop on the real bit
+# positions: the hooks compare every macroblock's QP with the record's (and, with WELS_HIP_CHECK_BITS, every bit count).
+def _gom_rows():
+    return [r for r in _device_rows() if r[4]["-slcmd 0"] in ("0", "2")]
+
+
+def _check_gom_kernel(workdir, lib, rows):
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(ir):
+        i, row = ir
+        got, pictures, err = _run_row(workdir, lib, row, "g%d" % i, {"WELS_HIP_GOM": "2"})
+        os.remove(str(workdir / ("t_g%d.264" % i)))
+        by_group = err.count("GOM-level QP")          # pictures that still went group by group: the I pictures of the quality-mode rows
+        return (row[4], row[0], got, pictures, by_group) if (got != row[0] or pictures < 40 or by_group > pictures // 4) else None
+
+    with ThreadPoolExecutor(8) as ex:
+        bad = [b for b in ex.map(one, enumerate(rows)) if b]
+    assert not bad, "%d of %d rows differ, first: %s" % (len(bad), len(rows), bad[0])
+
+
+def test_gom_rate_control_inside_the_kernel_on_emulation(workdir, emu_lib):
+    rows = _gom_rows()
+    assert len(rows) == 768
+    _check_gom_kernel(workdir, emu_lib, rows[2::8])
+
+
+@pytest.mark.gpu
+def test_gom_rate_control_inside_the_kernel_on_the_mi355x(workdir, hip_lib):
+    _check_gom_kernel(workdir, hip_lib, _gom_rows()[5::16])
+
+
 # ---- the API-level golden hashes and the stock configuration through the binding ---------------------------------------------
 API_GOLDEN = [  # test/api/encoder_test.cpp:104-115 (SEncParamBase: RC quality mode, 5 Mbps, one slice -> GOM-level QP)
     ("CiscoVT2people_160x96_6fps.yuv", 160, 96, 6.0, "08ade1853e4e49d50be675393780e75519586143"),
@@ -148,9 +184,9 @@ API_GOLDEN = [  # test/api/encoder_test.cpp:104-115 (SEncParamBase: RC quality m
 ]
 
 
-def _api_hash(lib, tmp_path, name, w, h, fps):
+def _api_hash(lib, tmp_path, name, w, h, fps, gom="1"):
     out = str(tmp_path / "o.264")
-    env = dict(os.environ, WELSHIP_LIB=lib, WELS_HIP_TRACE="1", WELS_HIP_GOM="1", WELS_HIP_CHECK_BITS="1")
+    env = dict(os.environ, WELSHIP_LIB=lib, WELS_HIP_TRACE="1", WELS_HIP_GOM=gom, WELS_HIP_CHECK_BITS="1")
     p = subprocess.run([os.path.join(REF, "ref_enc_hip"), "-i", os.path.join(RES, name), "-w", str(w), "-h", str(h), "-o", out, "-base", "-rc", "0",
                         "-fps", str(fps), "-quiet"], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
     err = p.stderr.decode(errors="replace")
@@ -168,6 +204,17 @@ def test_api_golden_hash_through_the_hooks_on_emulation(emu_lib, tmp_path, name,
 @pytest.mark.parametrize("name,w,h,fps,sha", API_GOLDEN)
 def test_api_golden_hash_through_the_hooks_on_the_mi355x(hip_lib, tmp_path, name, w, h, fps, sha):
     assert _api_hash(hip_lib, tmp_path, name, w, h, fps) == sha
+
+
+@pytest.mark.parametrize("name,w,h,fps,sha", API_GOLDEN[:2])
+def test_api_golden_hash_gom_inside_the_kernel_on_emulation(emu_lib, tmp_path, name, w, h, fps, sha):
+    assert _api_hash(emu_lib, tmp_path, name, w, h, fps, gom="2") == sha
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,w,h,fps,sha", API_GOLDEN[:2])
+def test_api_golden_hash_gom_inside_the_kernel_on_the_mi355x(hip_lib, tmp_path, name, w, h, fps, sha):
+    assert _api_hash(hip_lib, tmp_path, name, w, h, fps, gom="2") == sha
 
 
 def _stock_cfg(lib, tmp_path):

@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--workers", type=int, default=8)
     ap.add_argument("--stride", type=int, default=1)
     ap.add_argument("--table", default="ba", choices=("ba", "adobe"))
+    ap.add_argument("--gom", type=int, default=1, help="WELS_HIP_GOM: 1 = single-slice rate-controlled pictures group by group, 2 = their QP recursion inside the kernel")
     a = ap.parse_args()
     a.lib = os.path.abspath(a.lib)
     T = T_BA if a.table == "ba" else T_ADOBE
@@ -32,14 +33,15 @@ def main():
 
     def one(ir):
         i, r = ir
-        got, pics, err = T._run_row(d, a.lib, r, "w%d" % i)
+        got, pics, err = T._run_row(d, a.lib, r, "w%d" % i, {"WELS_HIP_GOM": str(a.gom)})
         if a.table == "ba": os.remove(str(d / ("t_w%d.264" % i)))
-        return i, got == r[0] and pics >= min_pics and "welship hooks: installed" in err, r[4]["-slcmd 0"], got, pics
+        return i, got == r[0] and pics >= min_pics and "welship hooks: installed" in err, r[4]["-slcmd 0"], got, pics, err.count("GOM-level QP")
 
-    bad, by_mode, total_pics = [], {}, 0
+    bad, by_mode, total_pics, ranged = [], {}, 0, 0
     with ThreadPoolExecutor(a.workers) as ex:
-        for i, ok, mode, got, pics in ex.map(one, enumerate(rows)):
+        for i, ok, mode, got, pics, rg in ex.map(one, enumerate(rows)):
             total_pics += pics
+            ranged += rg
             by_mode.setdefault(mode, [0, 0])
             by_mode[mode][0] += 1
             if not ok:
@@ -48,6 +50,7 @@ def main():
     for mode in sorted(by_mode):
         print("-slcmd %s : rows %d bad %d" % (mode, by_mode[mode][0], by_mode[mode][1]))
     print("table %s: device rows %d of the table's %d, bad %d, %d pictures coded on the device, %.1f s, %d workers, library %s" % (os.path.basename(T.TABLE), len(rows), len(T._rows()), len(bad), total_pics, time.time() - t0, a.workers, os.path.basename(a.lib)))
+    print("WELS_HIP_GOM=%d: %d pictures were coded group by group (one device call per group of macroblocks)" % (a.gom, ranged))
     for b in bad[:10]:
         print("BAD", b)
     return 1 if bad else 0
