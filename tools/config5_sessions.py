@@ -16,6 +16,8 @@ FRAMES = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 SIMULCAST = len(sys.argv) > 3 and sys.argv[3] == "simulcast"
 # third argument "screen": screen-content sessions instead (the SHA1 table's 1024x768 clip, bitrate mode, four slices)
 SCREEN = len(sys.argv) > 3 and sys.argv[3] == "screen"
+# third argument "gom": the 720p sessions with ONE slice per picture (GOM-level QP; set WELS_HIP_GOM=1 or 2, else the hooks decline)
+GOM = len(sys.argv) > 3 and sys.argv[3] == "gom"
 LIB = os.environ.get("WELSHIP_LIB") or os.path.join(ROOT, "openh264_amd", "libwelship.so")
 W, H = (1920, 1080) if SIMULCAST else (1024, 768) if SCREEN else (1280, 720)
 
@@ -27,6 +29,7 @@ def run(tmp, yuv, hip):
            "-fps", "30", "-rc", "1", "-bitrate", "1500000", "-threads", "1", "-iper", "0", "-quiet"]
     cmd += (["-slcmd", "1", "-slcnum", "4", "-simulcast", "240", "135", "-simulcast", "480", "270", "-simulcast", "960", "540"] if SIMULCAST
             else ["-usage", "1", "-slcmd", "1", "-slcnum", "4", "-scene", "1", "-denoise", "1", "-frameskip", "1"] if SCREEN
+            else ["-slcmd", "0"] if GOM
             else ["-slcmd", "2", "-slcmbnum", "900"])
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert p.returncode == 0, p.stderr[-2000:]
@@ -48,7 +51,7 @@ def main():
         nfr = os.path.getsize(yuv) // (W * H * 3 // 2)
         c_leg, c_sha = run(tmp, yuv, False)
         h_leg, h_sha = run(tmp, yuv, True)
-        print(json.dumps({"config": "%d concurrent sessions, %dx%d, %d frames each (clip has %d), RC bitrate mode 1.5 Mbps per layer, %s, one process, one thread per session" % (N, W, H, FRAMES, nfr, "4 simulcast AVC layers of 4 slices" if SIMULCAST else "screen content, 4 slices" if SCREEN else "raster slices of 900 MBs"),
+        print(json.dumps({"config": "%d concurrent sessions, %dx%d, %d frames each (clip has %d), RC bitrate mode 1.5 Mbps per layer, %s, one process, one thread per session" % (N, W, H, FRAMES, nfr, "4 simulcast AVC layers of 4 slices" if SIMULCAST else "screen content, 4 slices" if SCREEN else "one slice (GOM-level QP, WELS_HIP_GOM=%s)" % os.environ.get("WELS_HIP_GOM", "unset") if GOM else "raster slices of 900 MBs"),
                           "reference_c_path": c_leg, "hooks_on_device": h_leg, "same_bitstreams": c_sha == h_sha, "lib": os.path.basename(LIB)}))
 
 
