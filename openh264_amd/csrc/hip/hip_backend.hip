@@ -114,6 +114,10 @@ WH_DEFINE_MB_KERNEL (k_intra_slice, WhMbLds, wh_intra_mb_body, 1024, 0, 0)
 // them out in snake order, heavy with light.  Inside a slice nothing changes: tickets in dependency order (LDS counter),
 // done bits in LDS, data through the workgroup-coherent L1/L2.
 #define WH_MD_MAX_SLOTS 4
+#ifndef WH_EARLY_CLAIM
+#define WH_EARLY_CLAIM 0           /* claim + fetch the wave's next macroblock when the body's prediction is final (before residual coding): measured, no gain */
+#endif
+template <class F> struct WhEarlyFn { F& f; __device__ __forceinline__ void call() { f(); } };
 #ifndef WH_SPEC_WINDOWS
 #define WH_SPEC_WINDOWS 1          /* fetch a macroblock's search windows with its cold inputs, around the slice's last vector */
 #endif
@@ -153,10 +157,11 @@ __global__ __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPi
   X.last_mv = nullptr;
   uint32_t gone = 0;                      // slots this wave knows to be out of tickets (wave-uniform)
   uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;     // cycles / 64 this wave spent on each slot's macroblocks
-  int slot = -1, t = 0, xy = 0;
-  // claim(): the next macroblock for this wave, or slot = -1 when the workgroup's slices are used up
+  int slot = -1, t = 0, xy = 0;          // the macroblock in hand
+  int nslot = -1, nt = 0, nxy = 0;       // the wave's next one, claimed while the one in hand is still being coded (WH_EARLY_CLAIM)
+  // claim(): the next macroblock for this wave, or nslot = -1 when the workgroup's slices are used up
 #define WH_CLAIM()                                                                                                             \
-  for (slot = -1;;) {                                                                                                          \
+  for (nslot = -1;;) {                                                                                                         \
     int best = -1, brem = 0;                                                                                                   \
     for (int sl = 0; sl < slots; ++sl) if (!((gone >> sl) & 1u)) {                                                             \
       const int rem = slot_n[sl] - (int)__hip_atomic_load (&sched[sl * sched_words], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
@@ -176,18 +181,32 @@ __global__ __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPi
       if (xy_ < Jl[best].mb_begin) { if (lane == 0) atomicOr (&sched[best * sched_words + 1 + ((xy_ - first_) >> 5)], 1u << ((xy_ - first_) & 31)); continue; } \
       if (xy_ >= mb_end_) continue;                                                                                            \
     }                                                                                                                          \
-    slot = best; t = tt; xy = xy_;                                                                                             \
+    nslot = best; nt = tt; nxy = xy_;                                                                                          \
     break;                                                                                                                     \
   }
   const bool speculate = WH_SPEC_WINDOWS != 0;
 #define WH_FETCH_AHEAD()                                                                                                       \
-  if (slot >= 0) {                                                                                                             \
-    wh_inter_cold_fetch (G, lane, P, Jl[slot], xy % P.mb_w, xy / P.mb_w);   /* in flight while the wave waits for the neighbours */ \
+  if (nslot >= 0) {                                                                                                            \
+    wh_inter_cold_fetch (G, lane, P, Jl[nslot], nxy % P.mb_w, nxy / P.mb_w);   /* in flight while the wave codes / waits for the neighbours */ \
     X.spec_valid = 0;                                                                                                          \
-    if (speculate) { wh_win_speculate (P, Jl[slot], X.spec, xy % P.mb_w, xy / P.mb_w, slot_mv[slot]); X.spec_valid = 1; }      \
+    if (speculate) { wh_win_speculate (P, Jl[nslot], X.spec, nxy % P.mb_w, nxy / P.mb_w, slot_mv[nslot]); X.spec_valid = 1; }  \
   }
+  // Called by the macroblock body once its prediction is final (inter_mb.h): from there on it reads neither the staging area nor
+  // the windows, so the next macroblock's fetch runs under the residual coding and the stores of the one in hand.  Claiming a
+  // ticket before the previous one is finished cannot deadlock: a wave works its tickets off in order, and a macroblock only ever
+  // waits for lower tickets of its slice.
+  bool claimed = false;
+  auto early_fn = [&] () {
+#if WH_EARLY_CLAIM
+    WH_CLAIM()
+    WH_FETCH_AHEAD()
+    claimed = true;
+#endif
+  };
+  WhEarlyFn<decltype (early_fn)> early = { early_fn };
   WH_CLAIM()
   WH_FETCH_AHEAD()
+  slot = nslot; t = nt; xy = nxy;
   while (slot >= 0) {
     const WhPicJob& J = Jl[slot];
     const int first = slot_first[slot];
@@ -207,7 +226,8 @@ __global__ __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPi
     const uint32_t tc0 = (uint32_t)__builtin_readcyclecounter();
     WV_ASYNC_WAIT();                      /* this MB's cold inputs have landed in the staging area */
     X.slice_idc = slot_idc[slot]; X.slice_first = first; X.last_mv = &slot_mv[slot];
-    wh_inter_mb_body_t<SCC> (S, G, P, J, xy % P.mb_w, xy / P.mb_w, X);
+    claimed = false;
+    wh_inter_mb_body_t<SCC> (S, G, P, J, xy % P.mb_w, xy / P.mb_w, X, early);
     if (J.gom_rc) wh_gom_close_if_last (P, J, xy);       // rate control: the group's last macroblock settles the next group's QP
     WH_PROF_MARK (P, S.m, 14);
     __builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");
@@ -215,8 +235,11 @@ __global__ __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPi
     WH_PROF_MARK (P, S.m, 13);
     const uint32_t dc = ((uint32_t)__builtin_readcyclecounter() - tc0) >> 6;
     c0 += slot == 0 ? dc : 0u; c1 += slot == 1 ? dc : 0u; c2 += slot == 2 ? dc : 0u; c3 += slot == 3 ? dc : 0u;
-    WH_CLAIM()
-    WH_FETCH_AHEAD()
+    if (!claimed) {
+      WH_CLAIM()
+      WH_FETCH_AHEAD()
+    }
+    slot = nslot; t = nt; xy = nxy;
   }
 #undef WH_CLAIM
 #undef WH_FETCH_AHEAD

@@ -884,8 +884,14 @@ typedef struct WhInterCtx {
 } WhInterCtx;
 
 // ---- the P macroblock -----------------------------------------------------------------------------
-template <bool SCC>
-WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, const WhInterCtx& X) {
+// `early` is called exactly once per macroblock, at the point from which the body reads neither the staging area G nor the
+// search windows any more (the prediction is final: only residual coding and the stores are left).  The device scheduler claims
+// the wave's NEXT macroblock there and starts the LDS-DMA of its cold inputs and speculative windows into those very buffers, so
+// the fetch runs under residual coding + stores instead of being waited for at the top of the next macroblock.  The CPU test
+// build poisons both buffers in the callback: a read after the call would break parity.
+struct WhNoEarly { WH_FN void call() {} };
+template <bool SCC, class Early>
+WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, const WhInterCtx& X, Early& early) {
   WH_PROF_DECL (P);
   WhMbLds& M = S.m;
   const int w = P.mb_w, xy = mby * w + mbx;
@@ -912,11 +918,19 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const int i = lane + 64 * k, n = i / 36, wd = i - n * 36;           // state n (0 TL, 1 T, 2 TR, 3 L), dword wd
+#if WH_FLAT_NB_LOADS
+      // unconditional loads (this MB's own state stands in where there is nothing to read), selects afterwards: see wh_tile_fetch_nb
+      const bool ok = i < 144 && (n == 0 ? (avail & WH_AV_TOPLEFT) != 0 : n == 1 ? (avail & WH_AV_TOP) != 0 : n == 2 ? (avail & WH_AV_TOPRIGHT) != 0 : (avail & WH_AV_LEFT) != 0);
+      const int off = n == 0 ? -w - 1 : n == 1 ? -w : n == 2 ? -w + 1 : -1;
+      const uint32_t v = ((const WH_G uint32_t*) ((const WH_G WhMbState*)J.mbs + xy + (ok ? off : 0)))[ok ? wd : 0];
+      st[k] = ok ? v : 0u;
+#else
       if (i < 144) {
         const bool ok = n == 0 ? (avail & WH_AV_TOPLEFT) != 0 : n == 1 ? (avail & WH_AV_TOP) != 0 : n == 2 ? (avail & WH_AV_TOPRIGHT) != 0 : (avail & WH_AV_LEFT) != 0;
         const int off = n == 0 ? -w - 1 : n == 1 ? -w : n == 2 ? -w + 1 : -1;
         if (ok) st[k] = ((const WH_G uint32_t*) ((const WH_G WhMbState*)J.mbs + xy + off))[wd];
       }
+#endif
     }
     tr.y = G.cold_y[lane]; tr.c = lane < 32 ? G.cold_c[lane] : 0u;
     wh_tile_commit (M, lane, &tr);
@@ -1274,6 +1288,20 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
   }
   if (!done && b_skip) { mb_type = WH_MB_PSKIP; done = true; }
   WH_PROF_MARK (P, M, 3);   // I16x16 test (+ intra encode when intra wins)
+  // the next window guess of this slice: its most recent final 16x16 vector (a race between waves is harmless: any recent vector
+  // will do; it changes timing, never a result)
+  auto publish_guess = [&] (int fin) {
+    if (X.last_mv) {
+      WV_LANES_BEGIN (lane)
+      if (lane == 0) *X.last_mv = fin;
+      WV_LANES_END
+    }
+  };
+  if (done) {               // skip / background / static block / intra: nothing below reads a window or the staging area
+    if (!intra) publish_guess (mb_type == WH_MB_PSKIP ? wh_pk_mv (skx, sky) : wh_pk_mv (p16x, p16y));
+    early.call();
+    WH_PROF_MARK (P, M, 11);   // (the claim + fetch issue of the next macroblock, when the scheduler does it here)
+  }
 
   if (!done) {
     // ---- fine partitions: groups of searches (8x8 x4, 16x8 x2, 8x16 x2), results kept per slot in T ----
@@ -1433,6 +1461,9 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
     cost_luma = md_using_sad ? best_sad : best_satd;
 
     WH_PROF_MARK (P, M, 5);   // fractional refinement + chroma MC
+    publish_guess (wh_pk_mv (p16x, p16y));
+    early.call();
+    WH_PROF_MARK (P, M, 11);
     // ---- encode (WelsMdInterEncode) ----
     wh_dct_luma16 (M);
     cbp = wh_enc_inter_y (M, qp);
@@ -1516,12 +1547,6 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
     if (cbp > 0) pbits |= WH_BITS_HAS_QP_DELTA;
   }
   wh_store_mb (M, P, J, mbx, mby, mb_type, cbp, qp, qpc, 0, 0, cost_luma, slice_idc, pbits);
-  if (X.last_mv) {           // the next window guess of this slice (a race between waves is harmless: any recent vector will do)
-    const int fin = is_skip ? wh_pk_mv (skx, sky) : wh_pk_mv (p16x, p16y);
-    WV_LANES_BEGIN (lane)
-    if (lane == 0) *X.last_mv = fin;
-    WV_LANES_END
-  }
   // what the picture keeps for the time it is a reference (WelsMdInterSaveSadAndRefMbType, WelsMdUpdateBGDInfo, both run
   // before the entropy writer): a background skip keeps its own type; pRefMbQp = uiLumaQp unless the MB is an unchanged
   // collocated one (no residual, zero vector, P reference), which inherits the reference's entry.  uiLumaQp at that point is
@@ -1544,6 +1569,11 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
     }
   }
   WH_PROF_MARK (P, M, 7);   // store
+}
+template <bool SCC>
+WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, const WhInterCtx& X) {
+  WhNoEarly e;
+  wh_inter_mb_body_t<SCC> (S, G, P, J, mbx, mby, X, e);
 }
 WH_FN void wh_inter_mb_body (WhInterLds& S, WhInterStage& G, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, const WhInterCtx& X) {
   wh_inter_mb_body_t<false> (S, G, P, J, mbx, mby, X);

@@ -56,6 +56,25 @@ WH_FN void wh_tile_fetch_src (int lane, const WhSeqParams& P, const WhPicJob& J,
   }
 }
 // reconstructed neighbour samples (written by the neighbour MBs: only after they are done)
+#ifndef WH_FLAT_NB_LOADS
+#define WH_FLAT_NB_LOADS 0         /* candidate (not yet measured on the device): the neighbour loads of a macroblock as ONE batch */
+#endif
+#if WH_FLAT_NB_LOADS
+// One 32-bit load per lane whatever its role, at an address that is valid for every lane, and a select afterwards.  With one
+// load per role inside `if / else if` the compiler merges the results through a phi and waits for each load at the end of its
+// branch: the macroblock then pays one L2 round trip per role (three to four in a row) instead of one.  The column lanes read
+// the aligned word that ENDS with their sample (x = -4 .. -1) and keep its top byte; lanes without a role repeat lane 0's word.
+WH_FN void wh_tile_fetch_nb (int lane, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, WhTileRegs* r) {
+  const bool top_y = lane < 7, col_y = lane >= 16 && lane < 32, top_c = lane >= 32 && lane < 38, col_c = lane >= 48;
+  const bool luma = !(top_c || col_c);                                   // (idle lanes take lane 0's role)
+  const int pl = top_c ? (lane - 32) / 3 : (lane - 48) >> 3;             // chroma plane of the chroma roles
+  const int row = col_y ? mby * 16 + (lane - 16) : col_c ? mby * 8 + (lane & 7) : top_c ? mby * 8 - 1 : mby * 16 - 1;
+  const int x = top_y ? mbx * 16 + lane * 4 - 4 : top_c ? mbx * 8 + ((lane - 32) % 3) * 4 - 4 : luma ? mbx * 16 - 4 : mbx * 8 - 4;
+  const WH_G uint8_t* base = luma ? (const WH_G uint8_t*)J.rec[0] : (pl & 1) ? (const WH_G uint8_t*)J.rec[2] : (const WH_G uint8_t*)J.rec[1];
+  const uint32_t v = * (const WH_G uint32_t*) (base + (ptrdiff_t)row * (luma ? P.rec_stride_y : P.rec_stride_c) + x);
+  r->nb = (col_y || col_c) ? v >> 24 : v;
+}
+#else
 WH_FN void wh_tile_fetch_nb (int lane, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, WhTileRegs* r) {
   r->nb = 0;
   // garbage where unavailable -- never consumed then
@@ -73,6 +92,7 @@ WH_FN void wh_tile_fetch_nb (int lane, const WhSeqParams& P, const WhPicJob& J, 
     r->nb = ((const WH_G uint8_t*)J.rec[1 + pl])[(ptrdiff_t) (mby * 8 + y) * P.rec_stride_c + mbx * 8 - 1];
   }
 }
+#endif
 WH_FN void wh_tile_fetch (int lane, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, WhTileRegs* r) {
   wh_tile_fetch_src (lane, P, J, mbx, mby, r);
   wh_tile_fetch_nb (lane, P, J, mbx, mby, r);
@@ -326,6 +346,19 @@ WH_FN bool wh_intra_md_enc_p (WhMbLds& S, const WhSeqParams& P, const WhPicJob& 
   if (try_i4) {
     // neighbour Intra4x4PredMode cache (md.cpp:51-130 FillNeighborCacheIntra)
     WV_LANES_BEGIN (lane)
+#if WH_FLAT_NB_LOADS
+    {
+      // type + the mode word of the state a lane needs in one batch (a state that exists for every lane: its own MB's when it has
+      // no neighbour to ask), the selects afterwards -- see wh_tile_fetch_nb
+      const int cx = lane % 5, cy = lane / 5;
+      const bool from_t = lane < 25 && cy == 0 && cx > 0 && has_t, from_l = lane < 25 && cx == 0 && cy > 0 && has_l;
+      const WH_G WhMbState* n = (const WH_G WhMbState*)J.mbs + (from_t ? (mby - 1) * P.mb_w + mbx : from_l ? mby * P.mb_w + mbx - 1 : mby * P.mb_w + mbx);
+      const int idx = from_t ? 12 + cx - 1 : from_l ? (cy - 1) * 4 + 3 : 0;
+      const int type = n->mb_type;
+      const int8_t mode = n->i4_mode[idx];
+      if (lane < 25) S.i4m[lane] = (from_t || from_l) ? (type == WH_MB_I4x4 ? mode : (int8_t)2) : (int8_t) - 1;
+    }
+#else
     if (lane < 25) {
       const int cx = lane % 5, cy = lane / 5;
       int8_t m = -1;
@@ -342,6 +375,7 @@ WH_FN bool wh_intra_md_enc_p (WhMbLds& S, const WhSeqParams& P, const WhPicJob& 
       }
       S.i4m[lane] = m;
     }
+#endif
     WV_LANES_END
     const int lam4 = lambda << 2;
     int cost4 = 0;

@@ -79,8 +79,12 @@ class EmuBackend : public Backend {
           X.spec_valid = ((t + s + j) % 5) != 0;            // exercise both paths: most macroblocks speculate, every fifth does not
           if (X.spec_valid) wh_win_speculate (P, jobs[j], X.spec, mbx, mby, last_mv);
           X.last_mv = &last_mv;
-          if (P.flags & WH_SEQ_SCC) wh_inter_mb_body_t<true> (S, G, P, jobs[j], mbx, mby, X);
-          else wh_inter_mb_body (S, G, P, jobs[j], mbx, mby, X);
+          // the device scheduler overwrites the staging area and the windows with the NEXT macroblock's data from the moment the
+          // body calls back: poisoned here, so a read after the call breaks parity
+          struct Early { WhInterStage* g; WhWinLds* wb; int calls; void call() { poison (g, sizeof (*g)); poison (wb, sizeof (*wb)); ++calls; } } early = { &G, &WB, 0 };
+          if (P.flags & WH_SEQ_SCC) wh_inter_mb_body_t<true> (S, G, P, jobs[j], mbx, mby, X, early);
+          else wh_inter_mb_body_t<false> (S, G, P, jobs[j], mbx, mby, X, early);
+          if (early.calls != 1) { fprintf (stderr, "emu: the P macroblock body called back %d times at MB %d\n", early.calls, xy); abort(); }
           if (jobs[j].gom_rc) wh_gom_close_if_last (P, jobs[j], xy);
           poison (&S, sizeof (S)); poison (&WB, sizeof (WB)); poison (&G, sizeof (G));      // nothing survives from one macroblock to the next
         }
