@@ -244,12 +244,14 @@ def e2e_leg(oh, a, local, w, h, sessions, ring, content, frames, check=False):
         else:
             nbytes += out
     dt = time.perf_counter() - t0
+    host = g.host_stats() if hasattr(g, "host_stats") else None
     g.close()
     match = None
     if check:      # session 0's bitstream against the reference encoder on the same frames
         import hashlib
         ref = ref_encode(b"".join(content.frame(0, k) for k in order), w, h, p_flags(a.qp, a.deblock_idc) + ["-quiet", "-threads", "1"])
         match = {"match": bytes(bs0) == ref, "sha1": hashlib.sha1(bytes(bs0)).hexdigest(), "reference_sha1": hashlib.sha1(ref).hexdigest(), "frames": len(order)}
+    e2e_leg.host = host
     return dt, nbytes, match
 
 
@@ -416,7 +418,8 @@ def main():
         de, nbytes, match = e2e_leg(oh, a, local, w, h, a.sessions, ring, content, n_e2e, bool(verify_sessions))
         line["e2e"] = {"frames_per_s": a.sessions * n_e2e / de, "sessions": a.sessions, "frames_each": n_e2e, "host_entropy_threads": a.host_threads,
                        "host": cpu_info(), "includes": "source upload (H2D), device passes, D2H of the MB records, host CAVLC + NAL packing",
-                       "bitstream_MB_per_s": nbytes / de / 1e6, "bitstream_vs_reference": match}
+                       "bitstream_MB_per_s": nbytes / de / 1e6, "bitstream_vs_reference": match,
+                       "host_thread_ms_per_picture": e2e_leg.host}      # WelsHipGroupHostStats: staging copy, entropy coding from the packed records
         # the same with the sessions split over independent groups, one host thread and one device queue each
         ng, per = a.e2e_groups, max(1, a.e2e_group_sessions)
         if ng > 1:

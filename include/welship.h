@@ -179,6 +179,10 @@ int  WelsHipGroupGetReconFrame (WelsHipEncoderGroup* pGroup, int iSession, uint8
 const char* WelsHipGroupBackendName (WelsHipEncoderGroup* pGroup);
 /* hot-path timing with HIP events on the launch stream; pOutMs[4] = total, MD, deblock, expand */
 int  WelsHipGroupBench (WelsHipEncoderGroup* pGroup, int iSteps, int iWarmup, double* pOutMs);
+/* host share of the complete frame steps (EncodeFrames / Finish) so far, thread time per picture: pOut[4] = staging copy of
+ * the source into page-locked memory (ms), entropy coding + NAL packing from the packed records (ms), pictures coded,
+ * packed record bytes copied back per picture */
+int  WelsHipGroupHostStats (WelsHipEncoderGroup* pGroup, double* pOut);
 /* developer aid: WhMbRecord[] (openh264_amd/csrc/common/wh_types.h) of the last encoded frame */
 int  WelsHipDebugGetMbRecords (WelsHipEncoder* pEncoder, void* pDst, size_t uiBytes);
 /* developer aid: number of picture re-encodes caused by CAVLC level overflows since InitializeExt (the reference's

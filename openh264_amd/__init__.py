@@ -261,6 +261,7 @@ class EncoderGroup:
             lib.WelsHipGroupBackendName.restype = C.c_char_p
             lib.WelsHipGroupBench.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
             lib.WelsHipGroupEncodeFrames.argtypes = [C.c_void_p, C.POINTER(SSourcePicture), C.POINTER(SFrameBSInfo)]
+            lib.WelsHipGroupHostStats.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
             lib._group_ready = True
         h = C.c_void_p()
         rc = lib.WelsHipGroupCreate(C.byref(h), C.byref(param), sessions, ring_slots, host_threads)
@@ -344,6 +345,12 @@ class EncoderGroup:
         if rc:
             raise WelsHipError(rc, (self._lib.WelsHipGetLastError() or b"").decode())
         return dict(total_ms=out[0], md_ms=out[1], deblock_ms=out[2], expand_ms=out[3])
+
+    def host_stats(self):
+        """Host share of the complete frame steps so far (thread time per picture)."""
+        out = (C.c_double * 4)()
+        self._lib.WelsHipGroupHostStats(self._h, out)
+        return dict(stage_ms_per_picture=out[0], entropy_ms_per_picture=out[1], pictures=int(out[2]), packed_record_bytes_per_picture=out[3])
 
     def recon(self, session):
         n = self.w * self.h * 3 // 2

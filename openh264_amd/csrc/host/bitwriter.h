@@ -58,15 +58,19 @@ class BitWriter {
 // Append start code + NAL header + escaped RBSP to `bs`; returns the NAL length in bytes.
 inline int append_nal (std::vector<uint8_t>& bs, int nal_ref_idc, int nal_type, const std::vector<uint8_t>& rbsp) {
   const size_t start = bs.size();
-  bs.push_back (0); bs.push_back (0); bs.push_back (0); bs.push_back (1);
-  bs.push_back ((uint8_t) ((nal_ref_idc << 5) | (nal_type & 31)));
+  bs.resize (start + 5 + rbsp.size() + rbsp.size() / 2 + 1);      // worst case: an emulation prevention byte after every second payload byte
+  uint8_t* d = bs.data() + start;
+  d[0] = 0; d[1] = 0; d[2] = 0; d[3] = 1;
+  d[4] = (uint8_t) ((nal_ref_idc << 5) | (nal_type & 31));
+  d += 5;
   int zeros = 0;
-  for (size_t i = 0; i < rbsp.size(); ++i) {
-    const uint8_t b = rbsp[i];
-    if (zeros == 2 && b <= 3) { bs.push_back (3); zeros = 0; }
+  for (const uint8_t* s = rbsp.data(), *e = s + rbsp.size(); s < e; ++s) {
+    const uint8_t b = *s;
+    if (zeros == 2 && b <= 3) { *d++ = 3; zeros = 0; }
     zeros = (b == 0) ? zeros + 1 : 0;
-    bs.push_back (b);
+    *d++ = b;
   }
+  bs.resize ((size_t) (d - bs.data()));
   return (int) (bs.size() - start);
 }
 

@@ -9,13 +9,13 @@
 // batched launch set per frame step covers all N pictures, which is how a single MI355X is filled
 // (independent sessions / simulcast layers / all-IDR frames have no mutual dependency).
 #include <string.h>
-#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
+#include <chrono>
 #include <vector>
 #include <queue>
 #include <algorithm>
@@ -295,10 +295,6 @@ struct SessionCore {
     use_compact = true;
     return WELSHIP_OK;
   }
-  // packed stream (already on the host) -> h_records
-  void expand_compact() {
-    for (int xy = 0; xy < num_mb; ++xy) wh_compact_expand (h_compact.data() + h_compact_off[xy], h_compact_off[xy + 1] - h_compact_off[xy], &h_records[xy]);
-  }
 
   void release() {
     if (!be) return;
@@ -450,7 +446,9 @@ struct SessionCore {
   }
 
   // Entropy-code the downloaded records into `bs` and advance the stream state.
-  int finish_frame (WelsHipFrameBSInfo* out, int64_t ts) {
+  // `packed`: the picture's records are the packed stream in h_compact / h_compact_off (a session group's copy): the writer
+  // reads them in place (entropy_cavlc.h MbView); otherwise the full records in h_records.
+  int finish_frame (WelsHipFrameBSInfo* out, int64_t ts, bool packed = false) {
     const WhSeqParams& s = seq;
     const bool idr = cur_idr;
     const int qp = prm.iDLayerQp;
@@ -535,13 +533,15 @@ struct SessionCore {
         if (mbx > 0 && xy - 1 >= s.slice_first_mb[si]) avail |= wh::WH_AVAIL_LEFT;
         if (mby > 0 && xy - mb_w >= s.slice_first_mb[si]) avail |= wh::WH_AVAIL_TOP;
         int dbqp = qp;
-        const int rc = wh::write_mb_cavlc (bw, st, h_records.data(), mb_w, mbx, mby, avail, &dbqp);
-        const bool coded = h_records[xy].mb_type != WH_MB_PSKIP;
+        const wh::MbView mb = packed ? wh::view_of_packed (h_compact.data(), h_compact_off.data(), mb_w, xy, avail) : wh::view_of_record (h_records.data(), mb_w, xy, avail);
+        const int rc = wh::write_mb_cavlc (bw, st, mb, &dbqp);
+        const bool coded = mb.side->mb_type != WH_MB_PSKIP;
         const bool no_room = coded && bs_capacity - (frame_pos + 4 * (long) (bw.bits() / 32)) - 1 < 800;
         if (rc == -1 || (rc == 0 && no_room)) {   // the caller re-encodes the picture with this macroblock's QP raised (retry_after_overflow)
           sps_counter = saved_ids[0]; pps_counter = saved_ids[1]; sps_id_in_bs = saved_ids[2]; pps_id_in_bs = saved_ids[3]; idr_pic_id = saved_ids[4];
           overflow_mb = xy;
           overflow_qp = dbqp;
+          if (packed) wh_compact_expand (h_compact.data() + h_compact_off[xy], h_compact_off[xy + 1] - h_compact_off[xy], &h_records[xy]);   // retry_after_overflow reads it
           set_err ("CAVLC overflow");
           return WELSHIP_ERR_VLC_OVERFLOW;
         }
@@ -682,6 +682,12 @@ struct WelsHipEncoderGroup {
   WhPicJob* d_jobs = nullptr;
   std::vector<WhPicJob> h_jobs;
   int host_threads = 1;
+  // thread time the host side of the frame steps has taken so far (WelsHipGroupHostStats): [0] staging copies, [1] entropy coding
+  std::mutex stat_mu;
+  double host_ms[2] = {0.0, 0.0};
+  long host_pics[2] = {0, 0};
+  double packed_bytes = 0.0;
+  void note_host_time (int what, double ms, int pics) { std::lock_guard<std::mutex> l (stat_mu); host_ms[what] += ms; host_pics[what] += pics; }
   bool step_idr = true;                         // every session codes an IDR this step (all-P otherwise, unless mixed)
   bool mixed = false;                           // sessions disagree (scene changes, forced IDRs): each queue chunk of
   std::vector<int> order;                       //   d_jobs holds its P pictures first, then its IDR pictures;
@@ -1002,7 +1008,13 @@ int WelsHipGroupFinish (WelsHipEncoderGroup* g, WelsHipFrameBSInfo* outs) {
   }
   for (auto& c : g->sess) c->upload_pending = false;
   std::vector<int> rcs (n, 0);
-  g->parallel (n, [&] (int t, int T) { for (int i = t; i < n; i += T) { if (packed) g->sess[i]->expand_compact(); rcs[i] = g->sess[i]->finish_frame (outs ? &outs[i] : nullptr, 0); } });
+  g->parallel (n, [&] (int t, int T) {
+    const auto t0 = std::chrono::steady_clock::now();
+    int k = 0;
+    for (int i = t; i < n; i += T, ++k) rcs[i] = g->sess[i]->finish_frame (outs ? &outs[i] : nullptr, 0, packed);
+    g->note_host_time (1, std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now() - t0).count(), k);
+  });
+  if (packed) for (auto& c : g->sess) g->packed_bytes += (double)c->h_compact_off[c->num_mb];
   // sessions whose picture hit a CAVLC level overflow are re-encoded one at a time (rare: very low QP on extreme content)
   for (int i = 0; i < n; ++i) {
     SessionCore& c = *g->sess[i];
@@ -1034,7 +1046,12 @@ int WelsHipGroupEncodeFrames (WelsHipEncoderGroup* g, const WelsHipSourcePicture
   bool pending = false;
   for (int i = 0; i < n; ++i) pending = pending || g->sess[i]->upload_pending;
   if (pending) { g->be->sync(); for (auto& c : g->sess) c->upload_pending = false; }
-  g->parallel (n, [&] (int t, int T) { for (int i = t; i < n; i += T) g->sess[i]->stage_source (&srcs[i]); });
+  g->parallel (n, [&] (int t, int T) {
+    const auto t0 = std::chrono::steady_clock::now();
+    int k = 0;
+    for (int i = t; i < n; i += T, ++k) g->sess[i]->stage_source (&srcs[i]);
+    g->note_host_time (0, std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now() - t0).count(), k);
+  });
   for (int i = 0; i < n; ++i) { g->be->select_queue (g->chunk_of (i)); g->sess[i]->issue_upload (slot % g->sess[i]->ring); }
   int rc = WelsHipGroupBegin (g, slot);
   if (rc) return rc;
@@ -1109,6 +1126,17 @@ int WelsHipGroupBench (WelsHipEncoderGroup* g, int steps, int warmup, double* ou
   }
   drop_events();
   if (timed_out) { set_err ("device scheduler timed out during the benchmark; the timings are invalid"); return WELSHIP_ERR_UNKNOWN; }
+  return WELSHIP_OK;
+}
+
+// Host share of the complete frame steps so far: the Amdahl term of the end-to-end rate (bench.py reports it).
+int WelsHipGroupHostStats (WelsHipEncoderGroup* g, double* out4) {
+  if (!g || !out4) return WELSHIP_ERR_INIT_PARA;
+  std::lock_guard<std::mutex> l (g->stat_mu);
+  out4[0] = g->host_pics[0] ? g->host_ms[0] / (double)g->host_pics[0] : 0.0;
+  out4[1] = g->host_pics[1] ? g->host_ms[1] / (double)g->host_pics[1] : 0.0;
+  out4[2] = (double)g->host_pics[1];
+  out4[3] = g->host_pics[1] ? g->packed_bytes / (double)g->host_pics[1] : 0.0;
   return WELSHIP_OK;
 }
 

@@ -1,5 +1,11 @@
 // entropy_cavlc.cpp -- see entropy_cavlc.h
 #include "entropy_cavlc.h"
+#include <stddef.h>
+#include <string.h>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
+#include "../common/compact.h"
 #define WH_TABLE static const
 #include "../common/h264_tables.h"
 
@@ -9,22 +15,46 @@ namespace {
 // luma4x4BlkIdx -> raster index of the 4x4 block inside the MB
 inline int blk_raster (int b) { return (((b >> 1) & 1) | ((b >> 2) & 2)) * 4 + ((b & 1) | ((b >> 1) & 2)); }
 
-// residual_block_cavlc (7.3.5.3.2 / 9.2).  lv[0..end_idx] zig-zag levels; nc: 0..16, or 17 for ChromaDCLevel.
-// Returns -1 when a level needs an escape longer than Baseline allows (set_mb_syn_cavlc.cpp:181-184).
+// Bit i set = lv[i] != 0, for the 16 levels of a block (the callers mask it down to the entries their block type has).
+inline uint32_t nonzero_mask16 (const int16_t* lv) {
+#if defined(__SSE2__)
+  const __m128i z = _mm_setzero_si128();
+  const __m128i a = _mm_loadu_si128 ((const __m128i*)lv), b = _mm_loadu_si128 ((const __m128i*) (lv + 8));
+  return ~(uint32_t)_mm_movemask_epi8 (_mm_packs_epi16 (_mm_cmpeq_epi16 (a, z), _mm_cmpeq_epi16 (b, z))) & 0xffffu;
+#else
+  uint32_t m = 0;
+  for (int i = 0; i < 16; ++i) m |= (uint32_t) (lv[i] != 0) << i;
+  return m;
+#endif
+}
+
+// residual_block_cavlc (7.3.5.3.2 / 9.2).  lv[0..end_idx] zig-zag levels (nullptr: nothing but zeros); nc: 0..16, or 17 for
+// ChromaDCLevel.  Returns -1 when a level needs an escape longer than Baseline allows (set_mb_syn_cavlc.cpp:181-184).
 int write_block (BitWriter& bw, const int16_t* lv, int end_idx, int nc, bool has_coeff = true) {
   // has_coeff mirrors iCalRunLevelFlag: a block whose total_coeff (nzc) is 0 is written as empty without looking at
   // its level buffer, which may be stale after the encoder's zeroing heuristics (svc_encode_mb.cpp:283-287)
+  // Run / level pairs in reverse scan order (CavlcParamCal_c), from the block's non-zero mask instead of a scan per level:
+  // run[k] = zeros between level k and the next lower one, the last one's = its own index.
   int16_t level[16];
   uint8_t run[16];
   int total = 0, total_zeros = 0;
-  int i = has_coeff ? end_idx : -1;
-  while (i >= 0 && lv[i] == 0) --i;
-  while (i >= 0) {
-    int zeros = 0;
-    level[total] = lv[i--];
-    while (i >= 0 && lv[i] == 0) { ++zeros; --i; }
-    total_zeros += zeros;
-    run[total++] = (uint8_t)zeros;
+  if (has_coeff && lv) {
+    uint32_t nz;
+    if (end_idx >= 14) nz = nonzero_mask16 (lv) & ((2u << end_idx) - 1u);          // 15 or 16 levels: a 32-byte block
+    else { nz = 0; for (int i = 0; i <= end_idx; ++i) nz |= (uint32_t) (lv[i] != 0) << i; }
+    if (nz) {
+      int i = 31 - __builtin_clz (nz);
+      total_zeros = i + 1;
+      for (;;) {
+        level[total] = lv[i];
+        nz &= ~(1u << i);
+        if (!nz) { run[total++] = (uint8_t)i; break; }
+        const int j = 31 - __builtin_clz (nz);
+        run[total++] = (uint8_t) (i - j - 1);
+        i = j;
+      }
+      total_zeros -= total;
+    }
   }
   int t1 = 0;
   uint32_t signs = 0;
@@ -80,49 +110,80 @@ inline int nc_of (int na, int nb) {   // WELS_NON_ZERO_COUNT_AVERAGE (macros.h:1
 }
 
 struct NzcCtx {
-  const WhMbRecord* cur; const WhMbRecord* left; const WhMbRecord* top;
+  const uint8_t* cur; const uint8_t* left; const uint8_t* top;       // nzc[24] each; left / top nullptr = not available
   // luma: raster block index r (0..15)
-  int luma_a (int r) const { return (r & 3) ? cur->nzc[r - 1] : (left ? left->nzc[r + 3] : -1); }
-  int luma_b (int r) const { return (r >> 2) ? cur->nzc[r - 4] : (top ? top->nzc[r + 12] : -1); }
+  int luma_a (int r) const { return (r & 3) ? cur[r - 1] : (left ? left[r + 3] : -1); }
+  int luma_b (int r) const { return (r >> 2) ? cur[r - 4] : (top ? top[r + 12] : -1); }
   // chroma plane p (0/1), raster 2x2 index c
-  int chroma_a (int p, int c) const { return (c & 1) ? cur->nzc[16 + p * 4 + c - 1] : (left ? left->nzc[16 + p * 4 + c + 1] : -1); }
-  int chroma_b (int p, int c) const { return (c >> 1) ? cur->nzc[16 + p * 4 + c - 2] : (top ? top->nzc[16 + p * 4 + c + 2] : -1); }
+  int chroma_a (int p, int c) const { return (c & 1) ? cur[16 + p * 4 + c - 1] : (left ? left[16 + p * 4 + c + 1] : -1); }
+  int chroma_b (int p, int c) const { return (c >> 1) ? cur[16 + p * 4 + c - 2] : (top ? top[16 + p * 4 + c + 2] : -1); }
 };
 
-int write_residual (BitWriter& bw, const WhMbRecord& r, const NzcCtx& n) {
+int write_residual (BitWriter& bw, const MbView& mb, const NzcCtx& n) {
+  const WhMbRecord& r = *mb.side;
   const int cbp_l = r.cbp & 15, cbp_c = r.cbp >> 4;
   if (r.mb_type == WH_MB_I16x16) {
-    if (write_block (bw, r.luma_dc, 15, nc_of (n.luma_a (0), n.luma_b (0)))) return -1;
+    if (write_block (bw, mb.block (16), 15, nc_of (n.luma_a (0), n.luma_b (0)))) return -1;
     if (cbp_l) {
       for (int b = 0; b < 16; ++b) {
         const int rr = blk_raster (b);
-        if (write_block (bw, r.luma[b], 14, nc_of (n.luma_a (rr), n.luma_b (rr)), r.nzc[rr] > 0)) return -1;
+        if (write_block (bw, mb.block (b), 14, nc_of (n.luma_a (rr), n.luma_b (rr)), r.nzc[rr] > 0)) return -1;
       }
     }
   } else {
     for (int b = 0; b < 16; ++b) {
       if (!(cbp_l & (1 << (b >> 2)))) continue;
       const int rr = blk_raster (b);
-      if (write_block (bw, r.luma[b], 15, nc_of (n.luma_a (rr), n.luma_b (rr)), r.nzc[rr] > 0)) return -1;
+      if (write_block (bw, mb.block (b), 15, nc_of (n.luma_a (rr), n.luma_b (rr)), r.nzc[rr] > 0)) return -1;
     }
   }
   if (cbp_c) {
-    if (write_block (bw, r.chroma_dc[0], 3, 17)) return -1;
-    if (write_block (bw, r.chroma_dc[1], 3, 17)) return -1;
+    const int16_t* dc = mb.block (25);
+    if (write_block (bw, dc, 3, 17)) return -1;
+    if (write_block (bw, dc ? dc + 4 : nullptr, 3, 17)) return -1;
     if (cbp_c & 2) {
       for (int p = 0; p < 2; ++p)
         for (int c = 0; c < 4; ++c)
-          if (write_block (bw, r.chroma_ac[p * 4 + c], 14, nc_of (n.chroma_a (p, c), n.chroma_b (p, c)), r.nzc[16 + p * 4 + c] > 0)) return -1;
+          if (write_block (bw, mb.block (17 + p * 4 + c), 14, nc_of (n.chroma_a (p, c), n.chroma_b (p, c)), r.nzc[16 + p * 4 + c] > 0)) return -1;
     }
   }
   return 0;
 }
 
+const uint8_t kZeroNzc[24] = {0};       // total_coeff of a packed P_Skip macroblock (its record carries none)
+
 }  // namespace
 
-int write_mb_cavlc (BitWriter& bw, SliceEntropyState& st, const WhMbRecord* recs, int mb_w, int mbx, int mby, int avail,
-                    int* qp_for_deblock) {
-  const WhMbRecord& r = recs[mby * mb_w + mbx];
+MbView view_of_record (const WhMbRecord* recs, int mb_w, int xy, int avail) {
+  MbView v;
+  v.side = &recs[xy];
+  v.blocks = &recs[xy].luma[0][0];
+  if (avail & WH_AVAIL_LEFT) v.nzc_left = recs[xy - 1].nzc;
+  if (avail & WH_AVAIL_TOP) v.nzc_top = recs[xy - mb_w].nzc;
+  return v;
+}
+
+MbView view_of_packed (const uint8_t* packed, const uint32_t* off, int mb_w, int xy, int avail) {
+  // (offsets and sizes are multiples of 4: the side information keeps the alignment its int32 members need)
+  auto nzc_at = [&] (int k) { return off[k + 1] - off[k] == WH_COMPACT_SKIP_BYTES ? kZeroNzc : packed + off[k] + 4 + offsetof (WhMbRecord, nzc); };
+  MbView v;
+  v.packed = true;
+  const uint8_t* p = packed + off[xy];
+  if (off[xy + 1] - off[xy] == WH_COMPACT_SKIP_BYTES) {
+    v.side = (const WhMbRecord*)p;               // P_Skip: the writer reads mb_type and nothing else
+    v.mask = 0;
+  } else {
+    memcpy (&v.mask, p, 4);
+    v.side = (const WhMbRecord*) (p + 4);
+    v.blocks = (const int16_t*) (p + 4 + WH_COMPACT_SIDE);
+  }
+  if (avail & WH_AVAIL_LEFT) v.nzc_left = nzc_at (xy - 1);
+  if (avail & WH_AVAIL_TOP) v.nzc_top = nzc_at (xy - mb_w);
+  return v;
+}
+
+int write_mb_cavlc (BitWriter& bw, SliceEntropyState& st, const MbView& mb, int* qp_for_deblock) {
+  const WhMbRecord& r = *mb.side;
   if (r.mb_type == WH_MB_PSKIP) {
     *qp_for_deblock = st.last_qp;
     ++st.skip_run;
@@ -190,10 +251,8 @@ int write_mb_cavlc (BitWriter& bw, SliceEntropyState& st, const WhMbRecord* recs
     st.last_qp = r.luma_qp;
     *qp_for_deblock = r.luma_qp;
     NzcCtx n;
-    n.cur = &r;
-    n.left = (avail & WH_AVAIL_LEFT) ? &recs[mby * mb_w + mbx - 1] : nullptr;
-    n.top = (avail & WH_AVAIL_TOP) ? &recs[(mby - 1) * mb_w + mbx] : nullptr;
-    if (write_residual (bw, r, n)) return -1;
+    n.cur = r.nzc; n.left = mb.nzc_left; n.top = mb.nzc_top;
+    if (write_residual (bw, mb, n)) return -1;
   } else {
     *qp_for_deblock = st.last_qp;
   }

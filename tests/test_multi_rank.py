@@ -190,6 +190,9 @@ def test_group_bench_path_on_emulation(emu_lib):
     assert ev["total_ms"] >= 0.0
     for i in range(3):
         assert all(len(bs) > 0 for bs in g.step(i % ring))
+    st = g.host_stats()                  # the host share of the three complete steps: entropy coding straight from the packed records
+    assert st["pictures"] == 9 and st["entropy_ms_per_picture"] > 0.0
+    assert 0 < st["packed_record_bytes_per_picture"] < 964 * (w // 16) * (h // 16)
     g.close()
 
 
