@@ -271,6 +271,15 @@ typedef struct WelsHipFrameJob {
                                     /* RcGomTargetBits between the groups itself (iQp = the first group's QP, pMbQp / iMbBegin unused);     */
                                     /* the records carry each macroblock's QP, which the caller's own rate control must arrive at too       */
   const struct WelsHipMbReencode* pReencode;
+  /* Size-limited slices (SM_SIZELIMITED_SLICE, uiSliceSizeConstraint): where a slice ends is only known once the entropy writer has   */
+  /* produced its bytes (DynSlcJudgeSliceBoundaryStepBack, svc_encode_slice.cpp:1741-1790), and the macroblock a new slice begins   */
+  /* with is decided again without its neighbours (WelsMdInterMbLoopOverDynamicSlice :1901-2010, WelsISliceMdEncDynamic :601-680).    */
+  /* iDynSlice = 1 + index of the slice the macroblocks [iMbBegin, iMbEnd) belong to, which begins at iDynSliceFirstMb (<= iMbBegin):  */
+  /* the device codes them AHEAD of the writer, as if the slice went on to iMbEnd; when the writer ends the slice at macroblock b the    */
+  /* caller repeats the call for [b, ...) as the next slice and everything from b on is coded again.  The slice table of such a       */
+  /* picture is one slice (iNumSlices = 1); the picture-wide passes wait for a closing call with iMbBegin = iMbEnd = the number of   */
+  /* macroblocks (nothing is coded by it).  0 = slices as in pSliceFirstMb.                                                          */
+  int32_t iDynSlice, iDynSliceFirstMb;
 } WelsHipFrameJob;
 typedef struct WelsHipGomRc {
   int32_t iNumberMbGom;             /* pWelsSvcRc->iNumberMbGom: whole macroblock rows (else WELSHIP_ERR_UNSUPPORTED: code the groups one by one) */

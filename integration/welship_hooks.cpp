@@ -100,6 +100,12 @@ struct HipLayer {                       // one spatial layer = one device contex
   std::vector<int32_t> first;
   std::vector<uint8_t> mb_qp;
   int coded_upto = 0;
+  // size-limited slices (SM_SIZELIMITED_SLICE): the device codes AHEAD of the entropy writer -- from inside the slice loop, the rest of
+  // the picture as if the slice that begins there never ended; where the writer ends the slice, the next one begins with another call
+  // (WelsHipFrameJob::iDynSlice).  The picture-wide passes follow the picture's last macroblock.
+  bool dyn = false;
+  int dyn_calls = 0;
+  int dyn_est[2] = {0, 0};               // macroblocks per slice lately (I / P pictures): how far ahead of the writer a call codes
   WelsHipGomRc gomrc;                    // GOM-level rate control inside the kernel (WELS_HIP_GOM=2): the picture's rate-control inputs
   WelsHipScreenInfo screen;              // screen content: the pre-processing's results of the picture being coded
   std::vector<uint32_t> fme_down;        //   and what the device reports back per slice (uiSliceFMECostDown)
@@ -290,6 +296,16 @@ int32_t HipFrameMd (sWelsEncCtx* pCtx) {
       L.gom = false;               // (coded by the one call below; HipCodeSlice only entropy-codes and checks the QPs)
     }
   }
+  L.dyn = pParam->sSpatialLayers[did].sSliceArgument.uiSliceMode == SM_SIZELIMITED_SLICE;
+  if (L.dyn) {
+    if (L.gom || nslices != 1 || job.pScreen != NULL) { fprintf (stderr, "welship hooks: size-limited slices with GOM-level QP / %d slices / screen content\n", nslices); st->failed = true; return ENC_RETURN_UNEXPECTED; }
+    L.coded_upto = 0;
+    L.dyn_calls = 0;
+    L.records = NULL;
+    if (st->trace) fprintf (stderr, "welship hooks: did %d %c picture qp %d size-limited slices (%u bytes) cur %d ref %d deblock %d expand %d\n", did, is_p ? 'P' : 'I', job.iQp,
+                            pCurLayer->sSliceEncCtx.uiSliceSizeConstraint, job.iCurPic, job.iRefPic, job.bDeblock, job.bExpand);
+    return ENC_RETURN_SUCCESS;
+  }
   if (L.gom) {
     if (nslices != 1) { fprintf (stderr, "welship hooks: GOM-level QP with %d slices\n", nslices); st->failed = true; return ENC_RETURN_UNEXPECTED; }
     L.mb_qp.assign (num_mb, (uint8_t)pCtx->iGlobalQp);
@@ -355,7 +371,7 @@ int32_t HipCodeSlice (sWelsEncCtx* pCtx, SSlice* pSlice) {
   SWelsFuncPtrList* pFunc = pCtx->pFuncList;
   HipState* st = (HipState*)pFunc->pHipState;
   HipLayer& L = st->layer[pCtx->uiDependencyId];
-  if (st->failed || (L.records == NULL && !L.gom)) return ENC_RETURN_UNEXPECTED;
+  if (st->failed || (L.records == NULL && !L.gom && !L.dyn)) return ENC_RETURN_UNEXPECTED;
   Stopwatch sw_code (st->timing && pCtx->pSvcParam->iMultipleThreadIdc <= 1 ? &st->t_code : NULL);     // (slice tasks run concurrently: not summed)
   SDqLayer* pCurLayer = pCtx->pCurDqLayer;
   SMbCache* pMbCache = &pSlice->sMbCacheInfo;
@@ -373,6 +389,9 @@ int32_t HipCodeSlice (sWelsEncCtx* pCtx, SSlice* pSlice) {
   // CABAC: the slice's arithmetic coder starts here, as in WelsISliceMdEnc / WelsMdInterMbLoop (svc_encode_slice.cpp:550-554,1824-1828);
   // the writer (WelsSpatialWriteMbSynCabac) derives its contexts from what it wrote for the neighbours (sMvd, iCbpDc, types)
   if (pCtx->pSvcParam->iEntropyCodingModeFlag) WelsInitSliceCabac (pCtx, pSlice);
+  SSliceCtx* pSliceCtx = &pCurLayer->sSliceEncCtx;
+  const int32_t kiPartitionId = kiSliceIdx % pCtx->iActiveThreadsNum;
+  if (L.dyn) sDss.iStartPos = BsGetBitsPos (pSlice->pSliceBsa);        // WelsMdInterMbLoopOverDynamicSlice / WelsISliceMdEncDynamic (svc_encode_slice.cpp:1925-1931,620-626), CAVLC
   for (;;) {
     const int32_t iCurMbIdx = iNextMbIdx;
     SMB* pCurMb = &pMbList[iCurMbIdx];
@@ -404,6 +423,25 @@ int32_t HipCodeSlice (sWelsEncCtx* pCtx, SSlice* pSlice) {
           if (g_api.FrameGetMbStates (L.ctx, L.job.iCurPic, &L.states[0], sizeof (WhMbState) * kiTotalNumMb)) { st->failed = true; return ENC_RETURN_UNEXPECTED; }
         }
       }
+    }
+    if (L.dyn && (iCurMbIdx == kiSliceFirstMbXY || iCurMbIdx >= L.coded_upto)) {
+      // The slice begins here (or the device has not coded this far ahead yet): the macroblocks from this one on as macroblocks of
+      // THIS slice -- about one and a half slices' worth (what the last slices of this picture type were long), the rest of the picture
+      // when nothing is known yet.  What an earlier call coded from here on belonged to the slice before (other neighbours for the
+      // macroblocks of the first rows, other predictors after them) and is coded again.
+      const int est = L.dyn_est[is_p ? 1 : 0];
+      int end = est > 0 ? iCurMbIdx + WELS_MAX (est + (est >> 1), 16) : kiTotalNumMb;
+      if (end > kiTotalNumMb || getenv ("WELS_HIP_DYNSLICE_WHOLE")) end = kiTotalNumMb;
+      L.job.pSliceFirstMb = &L.first[0];
+      L.job.iMbBegin = iCurMbIdx; L.job.iMbEnd = end;
+      L.job.iDynSlice = kiSliceIdx + 1; L.job.iDynSliceFirstMb = kiSliceFirstMbXY;
+      const void* rec = NULL;
+      int rc;
+      { Stopwatch sw (st->timing ? &st->t_encode : NULL); rc = g_api.FrameEncode (L.ctx, &L.job, &rec); }
+      if (rc) { fprintf (stderr, "welship hooks: WelsHipFrameEncode (slice %d from MB %d) failed (%d: %s)\n", kiSliceIdx, iCurMbIdx, rc, g_api.GetLastError()); st->failed = true; return ENC_RETURN_UNEXPECTED; }
+      L.records = (const WhMbRecord*)rec;
+      L.coded_upto = end;
+      ++L.dyn_calls;
     }
     bool bInitDone = false;
 TRY_REENCODING:
@@ -439,8 +477,8 @@ TRY_REENCODING:
       // the macroblock started and decides it again with its QP raised by 2 -- without re-initialising it, so uiCbp and one cell of the
       // MV cache carry over (WelsHipMbReencode).  On the device that is the whole picture again with this macroblock's QP changed:
       // every other macroblock reproduces itself, the ones after it in the slice see its new reconstruction.
-      if (L.gom || pCtx->pSvcParam->iMultipleThreadIdc > 1) {
-        fprintf (stderr, "welship hooks: CAVLC overflow at MB %d -- re-encoding is not implemented for GOM-level QP / slice threads\n", iCurMbIdx);
+      if (L.gom || L.dyn || pCtx->pSvcParam->iMultipleThreadIdc > 1) {
+        fprintf (stderr, "welship hooks: CAVLC overflow at MB %d -- re-encoding is not implemented for GOM-level QP / size-limited slices / slice threads\n", iCurMbIdx);
         st->failed = true;
         return ENC_RETURN_UNEXPECTED;
       }
@@ -468,6 +506,19 @@ TRY_REENCODING:
       goto TRY_REENCODING;
     }
     if (ENC_RETURN_SUCCESS != iEncReturn) return iEncReturn;
+    if (L.dyn) {
+      // DYNAMIC_SLICING_ONE_THREAD (svc_encode_slice.cpp:654-663,1982-1992): with this macroblock the slice would exceed its size -- the
+      // bitstream goes back to where the macroblock began, the slice ends before it and the next slice begins WITH it
+      sDss.iCurrentPos = pFunc->pfGetBsPosition (pSlice);
+      if (DynSlcJudgeSliceBoundaryStepBack (pCtx, pSlice, pSliceCtx, pCurMb, &sDss)) {
+        const int32_t iRun = pFunc->pfStashPopMBStatus (&sDss, pSlice);
+        if (is_p) pSlice->iMbSkipRun = iRun;
+        pCurLayer->LastCodedMbIdxOfPartition[kiPartitionId] = iCurMbIdx - 1;
+        ++pCurLayer->NumSliceCodedOfPartition[kiPartitionId];
+        L.dyn_est[is_p ? 1 : 0] = iCurMbIdx - kiSliceFirstMbXY;
+        break;
+      }
+    }
     pCurMb->uiSliceIdc = kiSliceIdx;
     // uiRefMbType of the picture (WelsMdInterSaveSadAndRefMbType): besides the device's mode decision, the host's complexity
     // analysis of the NEXT picture reads it (wels_preprocess.cpp:830-930: background MBs whose reference MB is intra)
@@ -484,7 +535,25 @@ TRY_REENCODING:
     pFunc->pfRc.pfWelsRcMbInfoUpdate (pCtx, pCurMb, R.cost, pSlice);
     ++iNumMbCoded;
     iNextMbIdx = WelsGetNextMbOfSlice (pCurLayer, iCurMbIdx);
-    if (iNextMbIdx == -1 || iNextMbIdx >= kiTotalNumMb || iNumMbCoded >= kiTotalNumMb) break;
+    if (iNextMbIdx == -1 || iNextMbIdx >= kiTotalNumMb || iNumMbCoded >= kiTotalNumMb) {
+      if (L.dyn) {
+        if (!is_p) pSlice->iCountMbNumInSlice = iCurMbIdx - pCurLayer->LastCodedMbIdxOfPartition[kiPartitionId];
+        pCurLayer->LastCodedMbIdxOfPartition[kiPartitionId] = iCurMbIdx;
+        ++pCurLayer->NumSliceCodedOfPartition[kiPartitionId];
+        // the picture's last macroblock is written: the picture-wide passes (filter, borders) and the host's copy of the reconstruction
+        L.job.iMbBegin = kiTotalNumMb; L.job.iMbEnd = kiTotalNumMb;
+        const void* rec = NULL;
+        int rc;
+        { Stopwatch sw (st->timing ? &st->t_encode : NULL); rc = g_api.FrameEncode (L.ctx, &L.job, &rec); }
+        if (rc) { fprintf (stderr, "welship hooks: WelsHipFrameEncode (closing the picture) failed (%d: %s)\n", rc, g_api.GetLastError()); st->failed = true; return ENC_RETURN_UNEXPECTED; }
+        ++st->pictures;
+        uint8_t* dst[3] = { pCtx->pDecPic->pData[0], pCtx->pDecPic->pData[1], pCtx->pDecPic->pData[2] };
+        const int32_t ds[3] = { pCtx->pDecPic->iLineSize[0], pCtx->pDecPic->iLineSize[1], pCtx->pDecPic->iLineSize[2] };
+        { Stopwatch sw (st->timing ? &st->t_getpic : NULL); if (g_api.FrameGetPicture (L.ctx, L.job.iCurPic, dst, ds)) { st->failed = true; return ENC_RETURN_UNEXPECTED; } }
+        if (st->trace) fprintf (stderr, "welship hooks: layer %d picture complete: %d slices, %d device calls\n", (int)pCtx->uiDependencyId, kiSliceIdx + 1, L.dyn_calls);
+      }
+      break;
+    }
   }
   if (is_p && pSlice->iMbSkipRun) BsWriteUE (pSlice->pSliceBsa, pSlice->iMbSkipRun);
   // WelsDiamondCrossFeatureSearch's account of what the feature search saved (svc_motion_estimate.cpp:1080-1092), read by UpdateFMESwitch
@@ -527,7 +596,16 @@ bool WelsHipSupported (const SWelsSvcCodingParam* p, const char** why) {
   const bool gom_ok = gom != NULL && atoi (gom) != 0;
   for (int i = 0; i < p->iSpatialLayerNum; ++i) {
     const SSliceArgument& sa = p->sSpatialLayers[i].sSliceArgument;
-    if (sa.uiSliceMode == SM_SIZELIMITED_SLICE) NO ("size-limited slices feed the bitstream position back into mode decision");
+    if (sa.uiSliceMode == SM_SIZELIMITED_SLICE) {
+      // Size-limited slices feed the bitstream position back into mode decision: a slice ends where the writer says, and the macroblock the
+      // next one begins with is decided again without its neighbours.  The binding codes ahead of the writer and repeats the rest of the
+      // picture from every slice start (HipCodeSlice) -- bit-exact on the CPU test build, not yet run on the MI355X, and several device
+      // calls per picture: taken on request (WELS_HIP_DYNSLICE=1), for what it is implemented for.
+      const char* ds = getenv ("WELS_HIP_DYNSLICE");
+      if (ds == NULL || atoi (ds) == 0) NO ("size-limited slices feed the bitstream position back into mode decision; WELS_HIP_DYNSLICE=1 installs the hooks anyway");
+      if (p->iUsageType != CAMERA_VIDEO_REAL_TIME || p->iEntropyCodingModeFlag != 0 || p->iMultipleThreadIdc != 1 || p->iSpatialLayerNum != 1)
+        NO ("size-limited slices: camera video, CAVLC, one slice thread, one spatial layer only");
+    }
     // Rate control with one slice per picture = GOM-level QP (ratectl.cpp:1199-1204): the QP of a group of macroblocks depends
     // on the bits of the groups before it, so the picture is one device round trip PER GROUP -- bit-exact, but a latency chain
     // several times slower than the C path (measured: 720p 22 against 124 frames/s).  Taken only on request (WELS_HIP_GOM=1)

@@ -152,7 +152,7 @@ typedef struct WhPicJob {
   const uint8_t* prev_src_y; // luma of the previous source picture (VAA 8x8 SADs, LOW complexity P pictures)
   uint32_t*      db_flags;   // one word per MB: == db_gen once the MB is deblocked (hand-off between the slices' workgroups)
   uint32_t       db_gen;     // generation of this picture (never 0, changes every frame: the flags need no clearing)
-  uint32_t       pad2;
+  int32_t        dyn_first;  // size-limited slices (dyn_slice != 0): first macroblock of the slice this launch codes
   uint32_t*      scene_count; // scene-change statistic (kernels/scene_pic.h): zeroed by the host, incremented by the kernel
   // ---- what the reference keeps per LAYER rather than per picture, and what its pre-processing hands to mode decision ----
   int32_t*       sad_cost0;   // pSadCost[0] of every MB (the layer's SMB array, encoder_ext.cpp:900,1675): persists from picture to
@@ -162,7 +162,9 @@ typedef struct WhPicJob {
   int32_t        mvc_shift;   // sScaleShift (svc_encode_slice.cpp:1652-1655): temporal-layer scaling of the co-located MV candidates
   int32_t        mb_begin;    // only MBs in [mb_begin, mb_end) are coded by this launch (GOM-synchronous rate control); the ones
   int32_t        mb_end;      //   before mb_begin count as done; mb_end == 0 means the whole picture
-  int32_t        pad4;
+  int32_t        dyn_slice;   // size-limited slices (SM_SIZELIMITED_SLICE: where a slice ends is only known once its bits are written): 0 = the
+                              //   slices are WhSeqParams::slice_first_mb; else 1 + slice_idc of the ONE slice the macroblocks of this launch belong to,
+                              //   which begins at dyn_first -- neighbours before dyn_first are another slice's (not available)
   uint8_t*       compact;     // packed records of this picture (common/compact.h), written by the compaction pass, or NULL
   uint32_t*      compact_off; // num_mb + 1 byte offsets into `compact`
   const int16_t* il_hint;     // highest spatial layer of a multi-layer session: what WelsMdInterMbEnhancelayer takes from the layer

@@ -225,7 +225,7 @@ __global__ __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPi
     WH_PROF_MARK (P, S.m, 12);
     const uint32_t tc0 = (uint32_t)__builtin_readcyclecounter();
     WV_ASYNC_WAIT();                      /* this MB's cold inputs have landed in the staging area */
-    X.slice_idc = slot_idc[slot]; X.slice_first = first; X.last_mv = &slot_mv[slot];
+    X.slice_idc = J.dyn_slice ? J.dyn_slice - 1 : slot_idc[slot]; X.slice_first = J.dyn_slice ? J.dyn_first : first; X.last_mv = &slot_mv[slot];
     claimed = false;
     wh_inter_mb_body_t<SCC> (S, G, P, J, xy % P.mb_w, xy / P.mb_w, X, early);
     if (J.gom_rc) wh_gom_close_if_last (P, J, xy);       // rate control: the group's last macroblock settles the next group's QP

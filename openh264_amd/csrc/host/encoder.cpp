@@ -1553,11 +1553,17 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
   if (j->iQp < 0 || j->iQp > 51 || !j->pSrc[0] || !j->pSrc[1] || !j->pSrc[2]) { set_err ("invalid job"); return WELSHIP_ERR_INIT_PARA; }
   if (is_p && j->iComplexityMode == 0 && !j->pVaaSad8x8) { set_err ("LOW complexity P pictures need the VAA 8x8 SADs of the pre-processing"); return WELSHIP_ERR_INIT_PARA; }
   const bool ranged = j->iMbEnd > 0;
-  if (ranged && (j->iMbBegin < 0 || j->iMbBegin >= j->iMbEnd || j->iMbEnd > c->num_mb)) { set_err ("invalid MB range"); return WELSHIP_ERR_INIT_PARA; }
+  // size-limited slices: ranges coded ahead of the entropy writer, one slice per call; the picture-wide passes with a closing call
+  const bool dyn = j->iDynSlice > 0;
+  const bool dyn_close = dyn && j->iMbBegin == c->num_mb && j->iMbEnd == c->num_mb;
+  if (dyn && (!ranged || j->iNumSlices != 1 || j->bRetry || j->pGomRc || j->pMbQp || j->pScreen || j->iDynSliceFirstMb < 0 || j->iDynSliceFirstMb > j->iMbBegin)) {
+    set_err ("size-limited slices: MB ranges of a camera-video picture with a frame-constant QP, described as one slice"); return WELSHIP_ERR_INIT_PARA;
+  }
+  if (ranged && !dyn_close && (j->iMbBegin < 0 || j->iMbBegin >= j->iMbEnd || j->iMbEnd > c->num_mb)) { set_err ("invalid MB range"); return WELSHIP_ERR_INIT_PARA; }
   const bool retry = j->bRetry != 0;
   if (retry && (ranged || !j->pReencode || j->iNumReencode < 1)) { set_err ("a retry is a whole-picture call with the list of re-encoded macroblocks"); return WELSHIP_ERR_INIT_PARA; }
   // (a retry reuses what the first call of the picture uploaded: source, pre-analysis arrays, screen-content inputs)
-  const bool first_part = !retry && (!ranged || j->iMbBegin == 0), last_part = !ranged || j->iMbEnd == c->num_mb;
+  const bool first_part = !retry && (!ranged || j->iMbBegin == 0), last_part = !ranged || (dyn ? dyn_close : j->iMbEnd == c->num_mb);
   FrameShared* sh = c->sh;
   wh::Backend* be = c->be;
   // host-side staging into this context's own page-locked buffers: outside the shared lock
@@ -1821,11 +1827,14 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
     job.want_bits |= 1 | (j->iNumRefIdxL0Active > 1 ? 2 : 0);
   }
   job.mb_begin = ranged ? j->iMbBegin : 0; job.mb_end = ranged ? j->iMbEnd : 0;
+  job.dyn_slice = dyn ? j->iDynSlice : 0; job.dyn_first = dyn ? j->iDynSliceFirstMb : 0;
 
   if (ranged) {
     // GOM-synchronous coding: this MB range now, the picture-wide passes with the last range
-    be->upload (c->d_job, &job, sizeof (job));
-    if (is_p) be->run_inter (s, c->d_job, 1); else be->run_intra (s, c->d_job, 1);
+    if (!dyn_close) {
+      be->upload (c->d_job, &job, sizeof (job));
+      if (is_p) be->run_inter (s, c->d_job, 1); else be->run_intra (s, c->d_job, 1);
+    }
     if (last_part) {
       job.mb_begin = 0; job.mb_end = 0; be->sync_queue (queue); be->upload (c->d_job, &job, sizeof (job));
       if (qp_map) be->run_qp_chain (s, c->d_job, 1);           // QP_Y for the filter and pRefMbQp of decided skips
@@ -1835,7 +1844,7 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
       if (j->pSadCost) be->download (j->pSadCost, c->d_sad_cost0, sizeof (int32_t) * c->num_mb);
       if (scr) be->download (c->scc_down(), c->d_scc_chain + 4 * WH_MAX_SLICES, sizeof (uint32_t) * WH_MAX_SLICES);
     }
-    be->download (c->h_records.data() + j->iMbBegin, c->d_records + j->iMbBegin, sizeof (WhMbRecord) * (size_t) (j->iMbEnd - j->iMbBegin));
+    if (!dyn_close) be->download (c->h_records.data() + j->iMbBegin, c->d_records + j->iMbBegin, sizeof (WhMbRecord) * (size_t) (j->iMbEnd - j->iMbBegin));
     if (be->sync_queue (queue)) { set_err ("device scheduler timed out or device error; the picture was not encoded"); return WELSHIP_ERR_UNKNOWN; }
     if (scr && last_part && scr->pSliceFMECostDown) memcpy (scr->pSliceFMECostDown, c->scc_down(), sizeof (uint32_t) * j->iNumSlices);
     *pp_records = c->h_records.data();

@@ -119,7 +119,8 @@ WH_FN void wh_qp_chain_slice (const WhSeqParams& P, const WhPicJob& J, int first
 // One intra macroblock (I slice).
 WH_FN void wh_intra_mb_body (WhMbLds& S, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby) {
   const int xy = mby * P.mb_w + mbx;
-  const int avail = wh_mb_avail (P, mbx, mby);
+  // (size-limited slices: the launch codes ONE slice, which begins at dyn_first -- WhPicJob::dyn_slice)
+  const int avail = J.dyn_slice ? wh_mb_avail_in_slice (P, mbx, mby, J.dyn_first) : wh_mb_avail (P, mbx, mby);
   const WhMbCtl ctl = wh_mb_ctl (J, xy);
   const int qp = wh_mb_qp (J, ctl);
   const int qpc = kWhChromaQp[wh_clip3 (qp + P.chroma_qp_offset, 0, 51)];
@@ -152,7 +153,7 @@ WH_FN void wh_intra_mb_body (WhMbLds& S, const WhSeqParams& P, const WhPicJob& J
            wh_mb_intra_header_bits (S, r.mb_type, r.cbp, r.i16_mode_std, r.chroma_mode_std, false);
     if (r.cbp > 0 || r.mb_type == WH_MB_I16x16) bits |= WH_BITS_HAS_QP_DELTA;
   }
-  wh_store_mb (S, P, J, mbx, mby, r.mb_type, r.cbp, qp, qpc, r.i16_mode_std, r.chroma_mode_std, r.cost_luma, wh_slice_of_mb (P, xy), bits);
+  wh_store_mb (S, P, J, mbx, mby, r.mb_type, r.cbp, qp, qpc, r.i16_mode_std, r.chroma_mode_std, r.cost_luma, J.dyn_slice ? J.dyn_slice - 1 : wh_slice_of_mb (P, xy), bits);
 }
 
 #include "../common/mb_order.h"

@@ -11,7 +11,7 @@
 //
 //   ref_enc -i in.yuv -w W -h H -o out.264 [-frames N] [-fps F]
 //           [-rc M] [-qp Q] [-bitrate BPS] [-iper N] [-numtl N] [-complexity C]
-//           [-slcmd M] [-slcnum N] [-slcmbnum N] [-threads N] [-loadbalancing 0/1]
+//           [-slcmd M] [-slcnum N] [-slcmbnum N] [-slcsize BYTES] [-nalsize BYTES] [-threads N] [-loadbalancing 0/1]
 //           [-deblock IDC] [-aq 0/1] [-bgd 0/1] [-scene 0/1] [-ltr 0/1] [-denoise 0/1]
 //           [-frameskip 0/1] [-cabac 0/1] [-spsid S] [-usage U] [-base | -ext [-lossless 0/1]] [-quiet]
 //
@@ -34,7 +34,7 @@ static int run (int argc, char** argv, int instance) {
   int w = 0, h = 0, frames = -1, quiet = 0, use_base = 0, use_ext = 0, lossless = 0, profile = 66;
   float fps = 30.0f;
   int rc = -1, qp = 24, bitrate = 5000000, iper = 0, numtl = 1, complexity = 0;
-  int slcmd = 0, slcnum = 1, slcmbnum = 0, threads = 1, loadbal = 0, deblock = 0;
+  int slcmd = 0, slcnum = 1, slcmbnum = 0, threads = 1, loadbal = 0, deblock = 0, slcsize = 0, nalsize = 0;
   int aq = 0, bgd = 0, scene = 0, ltr = 0, denoise = 0, frameskip = 0, cabac = 0, spsid = 1, usage = 0;
   int alpha = 0, beta = 0, crop = 1, forceidr = -1;
   int setidr_at = -1, setidr_val = 0, setcplx_at = -1, setcplx_val = 0, paramsets_at = -1, setfps_at = -1;
@@ -60,6 +60,8 @@ static int run (int argc, char** argv, int instance) {
     else if (arg_eq (a, "-slcmd")) slcmd = std::atoi (next());
     else if (arg_eq (a, "-slcnum")) slcnum = std::atoi (next());
     else if (arg_eq (a, "-slcmbnum")) slcmbnum = std::atoi (next());
+    else if (arg_eq (a, "-slcsize")) slcsize = std::atoi (next());       // uiSliceSizeConstraint of -slcmd 3 (size-limited slices)
+    else if (arg_eq (a, "-nalsize")) nalsize = std::atoi (next());       // uiMaxNalSize
     else if (arg_eq (a, "-threads")) threads = std::atoi (next());
     else if (arg_eq (a, "-loadbalancing")) loadbal = std::atoi (next());
     else if (arg_eq (a, "-deblock")) deblock = std::atoi (next());
@@ -146,6 +148,8 @@ static int run (int argc, char** argv, int instance) {
     l.sSliceArgument.uiSliceMode = (SliceModeEnum)slcmd;
     l.sSliceArgument.uiSliceNum = (unsigned)slcnum;
     if (slcmbnum > 0) for (int k = 0; k < MAX_SLICES_NUM_TMP; ++k) l.sSliceArgument.uiSliceMbNum[k] = (unsigned)slcmbnum;
+    if (slcsize > 0) l.sSliceArgument.uiSliceSizeConstraint = (unsigned)slcsize;
+    if (nalsize > 0) p.uiMaxNalSize = (unsigned)nalsize;
     if (nlow > 0) {                    // layers 0 .. nlow-1 = the lower resolutions (lowest first), layer nlow = the input resolution
       p.iSpatialLayerNum = nlow + 1; p.bSimulcastAVC = true;
       const SSpatialLayerConfig top = l;

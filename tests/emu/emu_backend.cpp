@@ -73,7 +73,7 @@ class EmuBackend : public Backend {
           const int mbx = xy % P.mb_w, mby = xy / P.mb_w;
           for (int lane = 0; lane < 64; ++lane) wh_inter_cold_fetch (G, lane, P, jobs[j], mbx, mby);
           WhInterCtx X;
-          X.slice_idc = s; X.slice_first = first;
+          X.slice_idc = jobs[j].dyn_slice ? jobs[j].dyn_slice - 1 : s; X.slice_first = jobs[j].dyn_slice ? jobs[j].dyn_first : first;
           X.win = &WB;
           X.spec.b = &WB;
           X.spec_valid = ((t + s + j) % 5) != 0;            // exercise both paths: most macroblocks speculate, every fifth does not

@@ -1,0 +1,71 @@
+"""Size-limited slices (SM_SIZELIMITED_SLICE) through the dispatch-table binding, on request (WELS_HIP_DYNSLICE=1).
+
+Where such a slice ends is decided by the entropy writer, macroblock by macroblock (DynSlcJudgeSliceBoundaryStepBack,
+codec/encoder/core/src/svc_encode_slice.cpp:1741-1790): when a macroblock would make the slice larger than its limit, the writer
+takes it back, ends the slice before it, and the macroblock is DECIDED AGAIN as the first one of the next slice -- without its
+neighbours (WelsMdInterMbLoopOverDynamicSlice :1901-2010, WelsISliceMdEncDynamic :601-680).  The binding lets the device code ahead
+of the writer (one and a half slices' worth of macroblocks per call, as if the slice never ended) and repeats the call from the
+macroblock a new slice begins with (WelsHipFrameJob::iDynSlice, include/welship.h; integration/welship_hooks.cpp HipCodeSlice).
+
+Checked here on the CPU test build of the kernels (tests/emu): random sessions byte for byte against the unmodified reference
+(tools/fuzz_dynslice.py: 421 .. 3000 bytes per slice, i.e. from slices shorter than a macroblock row -- dozens per picture -- to one
+slice per picture; all rate-control modes, temporal layers, LTR, denoising, background / scene-change detection, the three
+deblocking modes, I pictures in mid-stream).  The reference table's own size-limited rows: tests/test_hooks_sha1.py.
+This path has not run on the MI355X yet (no GPU test): it is opt-in until it has.
+"""
+import os
+import sys
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.path.join(ROOT, "oracle", "_ref")
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+pytestmark = pytest.mark.skipif(not os.path.exists(os.path.join(REF, "ref_enc_hip")), reason="oracle/_ref (hooked reference) not built")
+
+
+def _fuzz(lib, seeds):
+    import fuzz_dynslice
+    from concurrent.futures import ThreadPoolExecutor
+    with tempfile.TemporaryDirectory() as tmp:
+        with ThreadPoolExecutor(8) as ex:
+            res = list(ex.map(lambda s: fuzz_dynslice.one_case(s, lib, tmp), seeds))
+    bad = [(s, m) for s, m, ok in res if not ok]
+    assert not bad, bad[0]
+    ran = [m for _, m, _ in res if m.startswith("ok")]
+    assert len(ran) >= len(seeds) * 3 // 4
+    # the cases really were sessions of many slices: more slices than pictures, and more device calls than pictures
+    slices = sum(int(m.split("device,")[1].split()[0]) for m in ran)
+    pictures = sum(int(m.split("frames,")[1].split()[0]) for m in ran)
+    assert slices > 4 * pictures
+
+
+def test_random_sessions_on_emulation(emu_lib):
+    _fuzz(emu_lib, range(1000, 1016))
+
+
+def test_random_sessions_on_emulation_reverse_lane_order():
+    """The same through the test build that walks the lanes of a lane block from 63 down (tests/test_frame_parity.py)."""
+    from openh264_amd import build as B
+    _fuzz(B.build_emu(defines=("WH_EMU_REVERSE",), tag="wh_emu_reverse"), range(7000, 7008))
+
+
+def test_installer_declines_without_the_switch(emu_lib, tmp_path):
+    """Opt-in: without WELS_HIP_DYNSLICE the session keeps the reference's C path and the installer says why."""
+    import subprocess
+    from openh264_amd.utils.synth import synth_sequence
+    src = str(tmp_path / "c.yuv")
+    open(src, "wb").write(synth_sequence(176, 144, 3))
+    env = dict(os.environ, WELSHIP_LIB=emu_lib, WELS_HIP_TRACE="1")
+    env.pop("WELS_HIP_DYNSLICE", None)
+    p = subprocess.run([os.path.join(REF, "ref_enc_hip"), "-i", src, "-w", "176", "-h", "144", "-o", str(tmp_path / "o.264"), "-quiet", "-slcmd", "3",
+                        "-slcsize", "600", "-threads", "1", "-rc", "-1", "-qp", "26"], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    err = p.stderr.decode(errors="replace")
+    assert p.returncode == 0 and "not installed" in err and "WELS_HIP_DYNSLICE" in err
+    # ... and with several slice threads (one partition of the picture per thread) it declines even when asked
+    env["WELS_HIP_DYNSLICE"] = "1"
+    p = subprocess.run([os.path.join(REF, "ref_enc_hip"), "-i", src, "-w", "176", "-h", "144", "-o", str(tmp_path / "o.264"), "-quiet", "-slcmd", "3",
+                        "-slcsize", "600", "-threads", "2", "-rc", "-1", "-qp", "26"], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    err = p.stderr.decode(errors="replace")
+    assert p.returncode == 0 and "not installed" in err and "one slice thread" in err

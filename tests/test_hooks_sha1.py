@@ -7,8 +7,9 @@ layer0..3.cfg, the row's options on the command line, SHA1 of the bitstream agai
 
 Rows the dispatch-table binding takes to the device: every option combination of the table (rate-control mode 1 and 3,
 1 and 3 temporal layers, LTR, denoising, scene-change detection, background detection, frame skipping) in slice modes
-0, 1 and 2 -- 1792 of the 2304 rows.  Size-limited slices (-slcmd 3) keep the reference's C path --
-the hooks report that, and the test checks that those rows are NOT counted as device rows.
+0, 1 and 2 -- 1792 of the 2304 rows.  Size-limited slices (-slcmd 3) keep the reference's C path by default --
+the hooks report that, and the test checks that those rows are NOT counted as device rows; with WELS_HIP_DYNSLICE=1 the 256
+single-thread rows of that mode run on the device too (CPU tier only so far: the path has not been on the MI355X yet).
 
 Also here: the reference's API-level golden hashes (test/api/encoder_test.cpp:104-115) and its stock testbin/welsenc.cfg
 through the same binding.
@@ -120,6 +121,35 @@ def test_unsupported_rows_stay_on_the_c_path(workdir, emu_lib):
         got, pictures, err = _run_row(workdir, emu_lib, row, "c%d" % i)
         assert "not installed" in err and pictures == 0
         assert got == row[0]
+
+
+def _size_limited_rows():
+    """The table's -slcmd 3 rows that name their thread count (-thread 1).  The other half (-thread 0) takes the machine's core count:
+    on a box with several cores those sessions split every picture into one partition per slice thread, which the binding declines."""
+    return [r for r in _rows() if r[4]["-slcmd 0"] == "3" and r[4]["-thread"] == "1"]
+
+
+def test_size_limited_rows_on_emulation(workdir, emu_lib):
+    """Size-limited slices on request (WELS_HIP_DYNSLICE=1): the device codes ahead of the entropy writer, and where
+    the writer ends a slice (DynSlcJudgeSliceBoundaryStepBack, svc_encode_slice.cpp:1741-1790) the next slice begins with another device
+    call that codes the macroblocks from there on again -- without the neighbours that now belong to the slice before.  Every second
+    of the 256 rows here; all of them: profiles/r02_size_limited_slices_emulation.txt (tools/sha1_table_rows.py --dynslice)."""
+    from concurrent.futures import ThreadPoolExecutor
+    rows = _size_limited_rows()
+    assert len(rows) == 256
+
+    def one(ir):
+        i, row = ir
+        got, pictures, err = _run_row(workdir, emu_lib, row, "d%d" % i, {"WELS_HIP_DYNSLICE": "1"})
+        os.remove(str(workdir / ("t_d%d.264" % i)))
+        multi = sum(1 for l in err.splitlines() if "picture complete" in l and " 1 slices" not in l)
+        return None if (got == row[0] and "welship hooks: installed" in err and err.count("picture complete") >= 40) else (row[4], got), multi
+
+    with ThreadPoolExecutor(8) as ex:
+        res = list(ex.map(one, enumerate(rows[::2])))
+    bad = [b for b, _ in res if b]
+    assert not bad, "%d rows differ, first: %s" % (len(bad), bad[0])
+    assert sum(m for _, m in res) > 100          # pictures of more than one slice really occurred (the IDR pictures at least)
 
 
 def test_gom_sessions_are_opt_in(emu_lib, tmp_path):

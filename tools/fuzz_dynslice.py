@@ -1,0 +1,99 @@
+"""Randomised parity of sessions with size-limited slices (SM_SIZELIMITED_SLICE) through the dispatch-table binding
+(TEST INFRASTRUCTURE).
+
+Camera-like synthetic clips at random sizes, encoded by the unmodified reference (oracle/_ref/ref_enc) and by the reference with
+this engine behind SWelsFuncPtrList (oracle/_ref/ref_enc_hip, WELS_HIP_DYNSLICE=1) with `-slcmd 3` and a random slice size
+(421 .. 3000 bytes: from a few macroblocks per slice -- slices shorter than a macroblock row, dozens of slices per picture -- to
+one slice per picture), random rate-control mode / QP, complexity, temporal layers, LTR, denoising, background and
+scene-change detection, deblocking mode and intra period.  The two bitstreams must be identical and the hooks must have coded
+every picture (several device calls for a picture with several slices).
+
+usage: fuzz_dynslice.py [--lib path] [--seed S] [--cases N] [--workers W] [-v]
+"""
+import argparse
+import os
+import random
+import subprocess
+import sys
+import tempfile
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.path.join(ROOT, "oracle", "_ref")
+sys.path.insert(0, ROOT)
+
+
+def one_case(seed, lib, tmp, verbose=False):
+    from openh264_amd.utils.synth import make_sequence
+    rng = random.Random(seed)
+    w = 16 * rng.randint(4, 40) - rng.choice((0, 0, 0, 2, 8))
+    h = 16 * rng.randint(3, 23) - rng.choice((0, 0, 0, 2, 6))
+    if (w // 16) * (h // 16) > 500:
+        h = max(48, 16 * (500 // max(1, w // 16)))
+    n = rng.randint(4, 10)
+    content = rng.choice(("synth", "synth", "pan", "checker"))
+    yuv = make_sequence(content, w, h, n)
+    rc = rng.choice((-1, -1, 0, 1, 3))
+    flags = ["-slcmd", "3", "-slcsize", str(rng.choice((421, 450, 500, 600, 800, 1200, 1500, 3000))), "-threads", "1",
+             "-rc", str(rc), "-complexity", str(rng.randint(0, 2)), "-numtl", str(rng.choice((1, 1, 2, 3))),
+             "-deblock", str(rng.choice((0, 0, 1, 2))), "-iper", str(rng.choice((0, 0, 3, 5))),
+             "-bgd", str(rng.randint(0, 1)), "-scene", str(rng.randint(0, 1)), "-ltr", str(rng.choice((0, 0, 1))),
+             "-denoise", str(rng.choice((0, 0, 1)))]
+    if rc == -1:
+        flags += ["-qp", str(rng.choice((14, 20, 24, 28, 34, 40)))]
+    else:
+        flags += ["-bitrate", str(rng.choice((150000, 400000, 1000000, 3000000))), "-frameskip", str(rng.randint(0, 1))]
+    if rng.randint(0, 3) == 0:
+        flags += ["-nalsize", str(rng.choice((800, 1000, 1500)))]
+    src = os.path.join(tmp, "c%d.yuv" % seed)
+    open(src, "wb").write(yuv)
+    base = ["-i", src, "-w", str(w), "-h", str(h), "-fps", "30", "-quiet"] + flags
+    outs = []
+    info = ""
+    for exe, env_extra in (("ref_enc", {}), ("ref_enc_hip", {"WELSHIP_LIB": lib, "WELS_HIP_DYNSLICE": "1", "WELS_HIP_TRACE": "1"})):
+        out = os.path.join(tmp, "o%d_%s.264" % (seed, exe))
+        p = subprocess.run([os.path.join(REF, exe)] + base + ["-o", out], env=dict(os.environ, **env_extra), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+        err = p.stderr.decode(errors="replace")
+        if p.returncode != 0:
+            if exe == "ref_enc":          # a parameter combination the reference itself refuses: not a case
+                os.remove(src)
+                return seed, "skipped (reference: %s)" % err.strip().splitlines()[-1][:60] if err.strip() else "skipped", True
+            os.remove(src)
+            return seed, "FAILED rc=%d %s\n%s" % (p.returncode, " ".join(flags), err[-800:]), False
+        outs.append(open(out, "rb").read())
+        os.remove(out)
+        if exe == "ref_enc_hip":
+            done = [l for l in err.splitlines() if "picture complete" in l]
+            slices = sum(int(l.split("complete:")[1].split()[0]) for l in done)
+            calls = sum(int(l.split("slices,")[1].split()[0]) for l in done)
+            info = "%dx%d %d frames, %d pictures on the device, %d slices, %d device calls" % (w, h, n, len(done), slices, calls)
+            if "welship hooks: installed" not in err or not done:
+                os.remove(src)
+                return seed, "NOT ON THE DEVICE %s\n%s" % (" ".join(flags), err[-400:]), False
+    os.remove(src)
+    ok = outs[0] == outs[1]
+    return seed, ("ok   " if ok else "DIFF ") + info + ("" if ok and not verbose else "  " + " ".join(flags)), ok
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--lib", default=None)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--cases", type=int, default=40)
+    ap.add_argument("--workers", type=int, default=8)
+    ap.add_argument("-v", action="store_true")
+    a = ap.parse_args()
+    from openh264_amd import build as B
+    lib = os.path.abspath(a.lib) if a.lib else B.build_emu()
+    bad = 0
+    with tempfile.TemporaryDirectory() as tmp:
+        with ThreadPoolExecutor(a.workers) as ex:
+            for seed, msg, ok in ex.map(lambda s: one_case(s, lib, tmp, a.v), range(a.seed * 1000, a.seed * 1000 + a.cases)):
+                print("%6d %s" % (seed, msg), flush=True)
+                bad += 0 if ok else 1
+    print("%d cases, %d failed (library %s)" % (a.cases, bad, os.path.basename(lib)))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,7 +1,8 @@
 """Every device row of one of the reference's bitstream-regression tables (test/encoder_binary_comparison/SHA1Table/:
 BA_MW_D.264_AllCases_SHA1_Table.csv, camera video; Adobe_PDF_sample_a_1024x768_50Frms.264_AllCases_SHA1_Table.csv, screen
 content) through the dispatch-table binding, the way tests/test_hooks_sha1.py / tests/test_hooks_screen.py run their samples.
-usage: sha1_table_rows.py [--table ba|adobe] [--lib path] [--workers N] [--stride K]      (default library: openh264_amd/libwelship.so)"""
+usage: sha1_table_rows.py [--table ba|adobe] [--lib path] [--workers N] [--stride K] [--dynslice]      (default library: openh264_amd/libwelship.so)
+--dynslice: the camera table's 256 size-limited rows that name one slice thread (-slcmd 3 -thread 1) with WELS_HIP_DYNSLICE=1 instead."""
 import argparse, os, pathlib, subprocess, sys, tempfile, time
 from concurrent.futures import ThreadPoolExecutor
 
@@ -18,6 +19,7 @@ def main():
     ap.add_argument("--stride", type=int, default=1)
     ap.add_argument("--table", default="ba", choices=("ba", "adobe"))
     ap.add_argument("--gom", type=int, default=1, help="WELS_HIP_GOM: 1 = single-slice rate-controlled pictures group by group, 2 = their QP recursion inside the kernel")
+    ap.add_argument("--dynslice", action="store_true")
     a = ap.parse_args()
     a.lib = os.path.abspath(a.lib)
     T = T_BA if a.table == "ba" else T_ADOBE
@@ -28,16 +30,20 @@ def main():
     for k in range(4):
         (d / ("layer%d.cfg" % k)).write_bytes(open(os.path.join(T.RES, "layer2.cfg"), "rb").read())
     (d / "welsenc.cfg").write_bytes(open(os.path.join(T.RES, "welsenc.cfg"), "rb").read())
-    rows = T._device_rows()[::a.stride]
+    rows = (T_BA._size_limited_rows() if a.dynslice else T._device_rows())[::a.stride]
     t0 = time.time()
 
     def one(ir):
         i, r = ir
-        got, pics, err = T._run_row(d, a.lib, r, "w%d" % i, {"WELS_HIP_GOM": str(a.gom)})
+        got, pics, err = T._run_row(d, a.lib, r, "w%d" % i, {"WELS_HIP_GOM": str(a.gom), "WELS_HIP_DYNSLICE": "1" if a.dynslice else "0"})
+        if a.dynslice:
+            done = [l for l in err.splitlines() if "picture complete" in l]
+            dyn[0] += sum(int(l.split("complete:")[1].split()[0]) for l in done); dyn[1] += sum(int(l.split("slices,")[1].split()[0]) for l in done)
         if a.table == "ba": os.remove(str(d / ("t_w%d.264" % i)))
         return i, got == r[0] and pics >= min_pics and "welship hooks: installed" in err, r[4]["-slcmd 0"], got, pics, err.count("GOM-level QP")
 
     bad, by_mode, total_pics, ranged = [], {}, 0, 0
+    dyn = [0, 0]
     with ThreadPoolExecutor(a.workers) as ex:
         for i, ok, mode, got, pics, rg in ex.map(one, enumerate(rows)):
             total_pics += pics
@@ -51,6 +57,7 @@ def main():
         print("-slcmd %s : rows %d bad %d" % (mode, by_mode[mode][0], by_mode[mode][1]))
     print("table %s: device rows %d of the table's %d, bad %d, %d pictures coded on the device, %.1f s, %d workers, library %s" % (os.path.basename(T.TABLE), len(rows), len(T._rows()), len(bad), total_pics, time.time() - t0, a.workers, os.path.basename(a.lib)))
     print("WELS_HIP_GOM=%d: %d pictures were coded group by group (one device call per group of macroblocks)" % (a.gom, ranged))
+    if a.dynslice: print("WELS_HIP_DYNSLICE=1: %d slices, %d device calls that coded macroblocks (+ one closing call per picture)" % (dyn[0], dyn[1]))
     for b in bad[:10]:
         print("BAD", b)
     return 1 if bad else 0
