@@ -391,11 +391,14 @@ int32_t HipCodeSlice (sWelsEncCtx* pCtx, SSlice* pSlice) {
   if (pCtx->pSvcParam->iEntropyCodingModeFlag) WelsInitSliceCabac (pCtx, pSlice);
   SSliceCtx* pSliceCtx = &pCurLayer->sSliceEncCtx;
   const int32_t kiPartitionId = kiSliceIdx % pCtx->iActiveThreadsNum;
-  if (L.dyn) sDss.iStartPos = BsGetBitsPos (pSlice->pSliceBsa);        // WelsMdInterMbLoopOverDynamicSlice / WelsISliceMdEncDynamic (svc_encode_slice.cpp:1925-1931,620-626), CAVLC
+  if (L.dyn) {      // WelsMdInterMbLoopOverDynamicSlice / WelsISliceMdEncDynamic (svc_encode_slice.cpp:1925-1931,620-626)
+    if (kbCavlc) sDss.iStartPos = BsGetBitsPos (pSlice->pSliceBsa);
+    else { sDss.iStartPos = sDss.iCurrentPos = 0; sDss.pRestoreBuffer = pCtx->pDynamicBsBuffer[kiPartitionId]; }
+  }
   for (;;) {
     const int32_t iCurMbIdx = iNextMbIdx;
     SMB* pCurMb = &pMbList[iCurMbIdx];
-    if (kbCavlc) pFunc->pfStashMBStatus (&sDss, pSlice, is_p ? pSlice->iMbSkipRun : 0);      // (the position TRY_REENCODING returns to)
+    if (kbCavlc || L.dyn) pFunc->pfStashMBStatus (&sDss, pSlice, is_p ? pSlice->iMbSkipRun : 0);      // (the position TRY_REENCODING returns to)
     // QP of the macroblock through the reference's own RC entry point (frame constant, or the group's: WelsRcMbInitGom)
     pFunc->pfRc.pfWelsRcMbInit (pCtx, pCurMb, pSlice);
     if (L.gom && iCurMbIdx >= L.coded_upto) {
@@ -603,8 +606,8 @@ bool WelsHipSupported (const SWelsSvcCodingParam* p, const char** why) {
       // calls per picture: taken on request (WELS_HIP_DYNSLICE=1), for what it is implemented for.
       const char* ds = getenv ("WELS_HIP_DYNSLICE");
       if (ds == NULL || atoi (ds) == 0) NO ("size-limited slices feed the bitstream position back into mode decision; WELS_HIP_DYNSLICE=1 installs the hooks anyway");
-      if (p->iUsageType != CAMERA_VIDEO_REAL_TIME || p->iEntropyCodingModeFlag != 0 || p->iMultipleThreadIdc != 1 || p->iSpatialLayerNum != 1)
-        NO ("size-limited slices: camera video, CAVLC, one slice thread, one spatial layer only");
+      if (p->iUsageType != CAMERA_VIDEO_REAL_TIME || p->iMultipleThreadIdc != 1 || p->iSpatialLayerNum != 1)
+        NO ("size-limited slices: camera video, one slice thread, one spatial layer only");
     }
     // Rate control with one slice per picture = GOM-level QP (ratectl.cpp:1199-1204): the QP of a group of macroblocks depends
     // on the bits of the groups before it, so the picture is one device round trip PER GROUP -- bit-exact, but a latency chain

@@ -10,7 +10,7 @@ macroblock a new slice begins with (WelsHipFrameJob::iDynSlice, include/welship.
 Checked here on the CPU test build of the kernels (tests/emu): random sessions byte for byte against the unmodified reference
 (tools/fuzz_dynslice.py: 421 .. 3000 bytes per slice, i.e. from slices shorter than a macroblock row -- dozens per picture -- to one
 slice per picture; all rate-control modes, temporal layers, LTR, denoising, background / scene-change detection, the three
-deblocking modes, I pictures in mid-stream).  The reference table's own size-limited rows: tests/test_hooks_sha1.py.
+deblocking modes, I pictures in mid-stream, CAVLC and CABAC).  The reference table's own size-limited rows: tests/test_hooks_sha1.py.
 This path has not run on the MI355X yet (no GPU test): it is opt-in until it has.
 """
 import os

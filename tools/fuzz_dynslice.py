@@ -5,7 +5,7 @@ Camera-like synthetic clips at random sizes, encoded by the unmodified reference
 this engine behind SWelsFuncPtrList (oracle/_ref/ref_enc_hip, WELS_HIP_DYNSLICE=1) with `-slcmd 3` and a random slice size
 (421 .. 3000 bytes: from a few macroblocks per slice -- slices shorter than a macroblock row, dozens of slices per picture -- to
 one slice per picture), random rate-control mode / QP, complexity, temporal layers, LTR, denoising, background and
-scene-change detection, deblocking mode and intra period.  The two bitstreams must be identical and the hooks must have coded
+scene-change detection, deblocking mode, intra period and entropy coder.  The two bitstreams must be identical and the hooks must have coded
 every picture (several device calls for a picture with several slices).
 
 usage: fuzz_dynslice.py [--lib path] [--seed S] [--cases N] [--workers W] [-v]
@@ -45,6 +45,8 @@ def one_case(seed, lib, tmp, verbose=False):
         flags += ["-bitrate", str(rng.choice((150000, 400000, 1000000, 3000000))), "-frameskip", str(rng.randint(0, 1))]
     if rng.randint(0, 3) == 0:
         flags += ["-nalsize", str(rng.choice((800, 1000, 1500)))]
+    if rng.randint(0, 3) == 0:
+        flags += ["-cabac", "1", "-profile", str(rng.choice((77, 100)))]
     src = os.path.join(tmp, "c%d.yuv" % seed)
     open(src, "wb").write(yuv)
     base = ["-i", src, "-w", str(w), "-h", str(h), "-fps", "30", "-quiet"] + flags
