@@ -277,8 +277,9 @@ typedef struct WelsHipFrameJob {
   /* iDynSlice = 1 + index of the slice the macroblocks [iMbBegin, iMbEnd) belong to, which begins at iDynSliceFirstMb (<= iMbBegin):  */
   /* the device codes them AHEAD of the writer, as if the slice went on to iMbEnd; when the writer ends the slice at macroblock b the    */
   /* caller repeats the call for [b, ...) as the next slice and everything from b on is coded again.  The slice table of such a       */
-  /* picture is one slice (iNumSlices = 1); the picture-wide passes wait for a closing call with iMbBegin = iMbEnd = the number of   */
-  /* macroblocks (nothing is coded by it).  0 = slices as in pSliceFirstMb.                                                          */
+  /* picture are its PARTITIONS (one per slice thread, each sliced on its own; one thread: the whole picture) and a range stays        */
+  /* inside one; calls for different partitions may come from different threads.  The picture-wide passes wait for a closing call     */
+  /* with iMbBegin = iMbEnd = the number of macroblocks (nothing is coded by it).  0 = slices as in pSliceFirstMb.                     */
   int32_t iDynSlice, iDynSliceFirstMb;
 } WelsHipFrameJob;
 typedef struct WelsHipGomRc {

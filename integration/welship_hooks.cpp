@@ -103,9 +103,16 @@ struct HipLayer {                       // one spatial layer = one device contex
   // size-limited slices (SM_SIZELIMITED_SLICE): the device codes AHEAD of the entropy writer -- from inside the slice loop, the rest of
   // the picture as if the slice that begins there never ended; where the writer ends the slice, the next one begins with another call
   // (WelsHipFrameJob::iDynSlice).  The picture-wide passes follow the picture's last macroblock.
+  // With several slice threads the picture is split into one PARTITION per thread (rows of macroblocks), each sliced on its own by its
+  // thread's task (CWelsConstrainedSizeSlicingEncodingTask, wels_task_encoder.cpp:231-325); a partition boundary is a slice boundary.
   bool dyn = false;
-  int dyn_calls = 0;
-  int dyn_est[2] = {0, 0};               // macroblocks per slice lately (I / P pictures): how far ahead of the writer a call codes
+  struct DynPart {
+    int coded_upto = 0;                  // the records of [.., coded_upto) of this partition are valid ...
+    int coded_slice = -1;                //   ... as macroblocks of this slice
+    int est[2] = {0, 0};                 // macroblocks per slice lately (I / P pictures): how far ahead of the writer a call codes
+  } part[MAX_THREADS_NUM];
+  std::mutex dyn_mu;                     // the counters below (slice tasks of a picture run concurrently)
+  int dyn_calls = 0, dyn_slices = 0, dyn_parts_left = 0;
   WelsHipGomRc gomrc;                    // GOM-level rate control inside the kernel (WELS_HIP_GOM=2): the picture's rate-control inputs
   WelsHipScreenInfo screen;              // screen content: the pre-processing's results of the picture being coded
   std::vector<uint32_t> fme_down;        //   and what the device reports back per slice (uiSliceFMECostDown)
@@ -149,6 +156,28 @@ bool FrameConstantQp (const sWelsEncCtx* pCtx) {
   const SWelsSvcCodingParam* p = pCtx->pSvcParam;
   if (p->iRCMode == RC_OFF_MODE) return true;
   return !pCtx->pWelsSvcRc[pCtx->uiDependencyId].bEnableGomQp;
+}
+
+// Size-limited slices: the device codes [iFrom, ...) of partition iPart as macroblocks of slice iSliceIdx, which begins at iSliceFirst --
+// about one and a half slices' worth (what the last slices of this picture type were long in this partition), the rest of the
+// partition when nothing is known yet.  L.job (prepared by HipFrameMd) is read-only here: slice tasks call this concurrently.
+int32_t DynCode (HipState* st, HipLayer& L, int iPart, int iSliceIdx, int iSliceFirst, int iFrom, bool is_p, int iPartEnd) {
+  HipLayer::DynPart& P = L.part[iPart];
+  const int est = P.est[is_p ? 1 : 0];
+  int end = est > 0 ? iFrom + WELS_MAX (est + (est >> 1), 16) : iPartEnd;
+  if (end > iPartEnd || getenv ("WELS_HIP_DYNSLICE_WHOLE")) end = iPartEnd;
+  WelsHipFrameJob jb = L.job;
+  jb.pSliceFirstMb = &L.first[0];
+  jb.iMbBegin = iFrom; jb.iMbEnd = end;
+  jb.iDynSlice = iSliceIdx + 1; jb.iDynSliceFirstMb = iSliceFirst;
+  const void* rec = NULL;
+  const int rc = g_api.FrameEncode (L.ctx, &jb, &rec);
+  if (rc) { fprintf (stderr, "welship hooks: WelsHipFrameEncode (slice %d from MB %d) failed (%d: %s)\n", iSliceIdx, iFrom, rc, g_api.GetLastError()); st->failed = true; return ENC_RETURN_UNEXPECTED; }
+  L.records = (const WhMbRecord*)rec;          // (the context's record array: the same pointer for every call)
+  P.coded_upto = end; P.coded_slice = iSliceIdx;
+  std::lock_guard<std::mutex> lock (L.dyn_mu);
+  ++L.dyn_calls;
+  return ENC_RETURN_SUCCESS;
 }
 
 int32_t HipFrameMd (sWelsEncCtx* pCtx) {
@@ -205,7 +234,7 @@ int32_t HipFrameMd (sWelsEncCtx* pCtx) {
   // (No task runs for a picture of a single slice: the reference does not filter it at all then.)
   if (pCurLayer->bDeblockingParallelFlag && pFunc->pfDeblocking.pfDeblockingFilterSlice == DeblockingFilterSliceAvcbase) {
     const SliceModeEnum eMode = pParam->sSpatialLayers[did].sSliceArgument.uiSliceMode;
-    const bool tasks = eMode != SM_SINGLE_SLICE && eMode != SM_SIZELIMITED_SLICE && pParam->iMultipleThreadIdc > 1;
+    const bool tasks = eMode != SM_SINGLE_SLICE && pParam->iMultipleThreadIdc > 1;      // (size-limited slices: CWelsConstrainedSizeSlicingEncodingTask filters slice by slice too, wels_task_encoder.cpp:301)
     job.bDeblock = tasks ? 1 : 0;
     pFunc->pfDeblocking.pfDeblockingFilterSlice = DeblockingFilterSliceAvcbaseNull;
   }
@@ -298,12 +327,33 @@ int32_t HipFrameMd (sWelsEncCtx* pCtx) {
   }
   L.dyn = pParam->sSpatialLayers[did].sSliceArgument.uiSliceMode == SM_SIZELIMITED_SLICE;
   if (L.dyn) {
-    if (L.gom || nslices != 1 || job.pScreen != NULL) { fprintf (stderr, "welship hooks: size-limited slices with GOM-level QP / %d slices / screen content\n", nslices); st->failed = true; return ENC_RETURN_UNEXPECTED; }
-    L.coded_upto = 0;
-    L.dyn_calls = 0;
+    // (the slice table at this point: one slice per partition, i.e. per slice thread -- pFirstMbIdxOfSlice = the partitions' first macroblocks)
+    const int nparts = pCtx->iActiveThreadsNum;
+    if (L.gom || nslices != nparts || nparts < 1 || nparts > MAX_THREADS_NUM || job.pScreen != NULL) {
+      fprintf (stderr, "welship hooks: size-limited slices with GOM-level QP / %d slices in %d partitions / screen content\n", nslices, nparts); st->failed = true; return ENC_RETURN_UNEXPECTED;
+    }
+    L.dyn_calls = 0; L.dyn_slices = 0; L.dyn_parts_left = 0;
+    if (nparts > 1) {       // the device's slice table: the partitions (FirstMbIdxOfPartition / EndMbIdxOfPartition, svc_enc_slice_segment.cpp)
+      first.clear();
+      for (int q = 0; q < nparts; ++q) first.push_back (pCurLayer->FirstMbIdxOfPartition[q]);
+      first.push_back (num_mb);
+      for (int q = 0; q < nparts; ++q) if (first[q + 1] != pCurLayer->EndMbIdxOfPartition[q] + 1 || first[q + 1] <= first[q]) {
+        fprintf (stderr, "welship hooks: partitions of the picture are not contiguous (%d: %d..%d)\n", q, first[q], pCurLayer->EndMbIdxOfPartition[q]); st->failed = true; return ENC_RETURN_UNEXPECTED;
+      }
+      job.pSliceFirstMb = &first[0];
+    }
+    for (int q = 0; q < nparts; ++q) {
+      L.part[q].coded_upto = 0; L.part[q].coded_slice = -1;
+      // (a partition of a single macroblock is left out by its task, wels_task_encoder.cpp:246-250; one thread: WelsCodeOnePicPartition codes whatever there is)
+      if (nparts == 1 || pCurLayer->EndMbIdxOfPartition[q] > pCurLayer->FirstMbIdxOfPartition[q]) ++L.dyn_parts_left;
+    }
     L.records = NULL;
-    if (st->trace) fprintf (stderr, "welship hooks: did %d %c picture qp %d size-limited slices (%u bytes) cur %d ref %d deblock %d expand %d\n", did, is_p ? 'P' : 'I', job.iQp,
-                            pCurLayer->sSliceEncCtx.uiSliceSizeConstraint, job.iCurPic, job.iRefPic, job.bDeblock, job.bExpand);
+    if (st->trace) fprintf (stderr, "welship hooks: did %d %c picture qp %d size-limited slices (%u bytes, %d partition%s) cur %d ref %d deblock %d expand %d\n", did, is_p ? 'P' : 'I', job.iQp,
+                            pCurLayer->sSliceEncCtx.uiSliceSizeConstraint, nparts, nparts == 1 ? "" : "s", job.iCurPic, job.iRefPic, job.bDeblock, job.bExpand);
+    // The first macroblocks of the picture now (slice 0 begins at macroblock 0 whatever happens): this call also takes the picture's
+    // inputs to the device, before any partition's task asks for its macroblocks.
+    const int rcd = DynCode (st, L, 0, 0, 0, 0, is_p, nparts == 1 ? num_mb : pCurLayer->EndMbIdxOfPartition[0] + 1);
+    if (rcd) return rcd;
     return ENC_RETURN_SUCCESS;
   }
   if (L.gom) {
@@ -391,6 +441,7 @@ int32_t HipCodeSlice (sWelsEncCtx* pCtx, SSlice* pSlice) {
   if (pCtx->pSvcParam->iEntropyCodingModeFlag) WelsInitSliceCabac (pCtx, pSlice);
   SSliceCtx* pSliceCtx = &pCurLayer->sSliceEncCtx;
   const int32_t kiPartitionId = kiSliceIdx % pCtx->iActiveThreadsNum;
+  const int32_t kiDynPartEnd = pCtx->iActiveThreadsNum == 1 ? kiTotalNumMb : pCurLayer->EndMbIdxOfPartition[kiPartitionId] + 1;
   if (L.dyn) {      // WelsMdInterMbLoopOverDynamicSlice / WelsISliceMdEncDynamic (svc_encode_slice.cpp:1925-1931,620-626)
     if (kbCavlc) sDss.iStartPos = BsGetBitsPos (pSlice->pSliceBsa);
     else { sDss.iStartPos = sDss.iCurrentPos = 0; sDss.pRestoreBuffer = pCtx->pDynamicBsBuffer[kiPartitionId]; }
@@ -427,24 +478,12 @@ int32_t HipCodeSlice (sWelsEncCtx* pCtx, SSlice* pSlice) {
         }
       }
     }
-    if (L.dyn && (iCurMbIdx == kiSliceFirstMbXY || iCurMbIdx >= L.coded_upto)) {
-      // The slice begins here (or the device has not coded this far ahead yet): the macroblocks from this one on as macroblocks of
-      // THIS slice -- about one and a half slices' worth (what the last slices of this picture type were long), the rest of the picture
-      // when nothing is known yet.  What an earlier call coded from here on belonged to the slice before (other neighbours for the
-      // macroblocks of the first rows, other predictors after them) and is coded again.
-      const int est = L.dyn_est[is_p ? 1 : 0];
-      int end = est > 0 ? iCurMbIdx + WELS_MAX (est + (est >> 1), 16) : kiTotalNumMb;
-      if (end > kiTotalNumMb || getenv ("WELS_HIP_DYNSLICE_WHOLE")) end = kiTotalNumMb;
-      L.job.pSliceFirstMb = &L.first[0];
-      L.job.iMbBegin = iCurMbIdx; L.job.iMbEnd = end;
-      L.job.iDynSlice = kiSliceIdx + 1; L.job.iDynSliceFirstMb = kiSliceFirstMbXY;
-      const void* rec = NULL;
-      int rc;
-      { Stopwatch sw (st->timing ? &st->t_encode : NULL); rc = g_api.FrameEncode (L.ctx, &L.job, &rec); }
-      if (rc) { fprintf (stderr, "welship hooks: WelsHipFrameEncode (slice %d from MB %d) failed (%d: %s)\n", kiSliceIdx, iCurMbIdx, rc, g_api.GetLastError()); st->failed = true; return ENC_RETURN_UNEXPECTED; }
-      L.records = (const WhMbRecord*)rec;
-      L.coded_upto = end;
-      ++L.dyn_calls;
+    if (L.dyn && (L.part[kiPartitionId].coded_slice != kiSliceIdx || iCurMbIdx >= L.part[kiPartitionId].coded_upto)) {
+      // The slice begins here, or the device has not coded this far ahead yet.  What an earlier call coded from here on belonged to
+      // the slice before (other neighbours for the macroblocks of the first rows, other predictors after them) and is coded again.
+      Stopwatch sw (st->timing && pCtx->iActiveThreadsNum == 1 ? &st->t_encode : NULL);
+      const int rcd = DynCode (st, L, kiPartitionId, kiSliceIdx, kiSliceFirstMbXY, iCurMbIdx, is_p, kiDynPartEnd);
+      if (rcd) return rcd;
     }
     bool bInitDone = false;
 TRY_REENCODING:
@@ -518,7 +557,8 @@ TRY_REENCODING:
         if (is_p) pSlice->iMbSkipRun = iRun;
         pCurLayer->LastCodedMbIdxOfPartition[kiPartitionId] = iCurMbIdx - 1;
         ++pCurLayer->NumSliceCodedOfPartition[kiPartitionId];
-        L.dyn_est[is_p ? 1 : 0] = iCurMbIdx - kiSliceFirstMbXY;
+        L.part[kiPartitionId].est[is_p ? 1 : 0] = iCurMbIdx - kiSliceFirstMbXY;
+        { std::lock_guard<std::mutex> lock (L.dyn_mu); ++L.dyn_slices; }
         break;
       }
     }
@@ -543,17 +583,23 @@ TRY_REENCODING:
         if (!is_p) pSlice->iCountMbNumInSlice = iCurMbIdx - pCurLayer->LastCodedMbIdxOfPartition[kiPartitionId];
         pCurLayer->LastCodedMbIdxOfPartition[kiPartitionId] = iCurMbIdx;
         ++pCurLayer->NumSliceCodedOfPartition[kiPartitionId];
-        // the picture's last macroblock is written: the picture-wide passes (filter, borders) and the host's copy of the reconstruction
-        L.job.iMbBegin = kiTotalNumMb; L.job.iMbEnd = kiTotalNumMb;
-        const void* rec = NULL;
-        int rc;
-        { Stopwatch sw (st->timing ? &st->t_encode : NULL); rc = g_api.FrameEncode (L.ctx, &L.job, &rec); }
-        if (rc) { fprintf (stderr, "welship hooks: WelsHipFrameEncode (closing the picture) failed (%d: %s)\n", rc, g_api.GetLastError()); st->failed = true; return ENC_RETURN_UNEXPECTED; }
-        ++st->pictures;
-        uint8_t* dst[3] = { pCtx->pDecPic->pData[0], pCtx->pDecPic->pData[1], pCtx->pDecPic->pData[2] };
-        const int32_t ds[3] = { pCtx->pDecPic->iLineSize[0], pCtx->pDecPic->iLineSize[1], pCtx->pDecPic->iLineSize[2] };
-        { Stopwatch sw (st->timing ? &st->t_getpic : NULL); if (g_api.FrameGetPicture (L.ctx, L.job.iCurPic, dst, ds)) { st->failed = true; return ENC_RETURN_UNEXPECTED; } }
-        if (st->trace) fprintf (stderr, "welship hooks: layer %d picture complete: %d slices, %d device calls\n", (int)pCtx->uiDependencyId, kiSliceIdx + 1, L.dyn_calls);
+        // the partition's last macroblock is written; with the picture's last partition: the picture-wide passes (filter, borders) and
+        // the host's copy of the reconstruction
+        std::lock_guard<std::mutex> lock (L.dyn_mu);
+        ++L.dyn_slices;
+        if (--L.dyn_parts_left == 0) {
+          WelsHipFrameJob jb = L.job;
+          jb.pSliceFirstMb = &L.first[0];
+          jb.iMbBegin = kiTotalNumMb; jb.iMbEnd = kiTotalNumMb; jb.iDynSlice = kiSliceIdx + 1; jb.iDynSliceFirstMb = kiSliceFirstMbXY;
+          const void* rec = NULL;
+          const int rc = g_api.FrameEncode (L.ctx, &jb, &rec);
+          if (rc) { fprintf (stderr, "welship hooks: WelsHipFrameEncode (closing the picture) failed (%d: %s)\n", rc, g_api.GetLastError()); st->failed = true; return ENC_RETURN_UNEXPECTED; }
+          ++st->pictures;
+          uint8_t* dst[3] = { pCtx->pDecPic->pData[0], pCtx->pDecPic->pData[1], pCtx->pDecPic->pData[2] };
+          const int32_t ds[3] = { pCtx->pDecPic->iLineSize[0], pCtx->pDecPic->iLineSize[1], pCtx->pDecPic->iLineSize[2] };
+          if (g_api.FrameGetPicture (L.ctx, L.job.iCurPic, dst, ds)) { st->failed = true; return ENC_RETURN_UNEXPECTED; }
+          if (st->trace) fprintf (stderr, "welship hooks: layer %d picture complete: %d slices, %d device calls\n", (int)pCtx->uiDependencyId, L.dyn_slices, L.dyn_calls);
+        }
       }
       break;
     }
@@ -606,8 +652,7 @@ bool WelsHipSupported (const SWelsSvcCodingParam* p, const char** why) {
       // calls per picture: taken on request (WELS_HIP_DYNSLICE=1), for what it is implemented for.
       const char* ds = getenv ("WELS_HIP_DYNSLICE");
       if (ds == NULL || atoi (ds) == 0) NO ("size-limited slices feed the bitstream position back into mode decision; WELS_HIP_DYNSLICE=1 installs the hooks anyway");
-      if (p->iUsageType != CAMERA_VIDEO_REAL_TIME || p->iMultipleThreadIdc != 1 || p->iSpatialLayerNum != 1)
-        NO ("size-limited slices: camera video, one slice thread, one spatial layer only");
+      if (p->iUsageType != CAMERA_VIDEO_REAL_TIME || p->iSpatialLayerNum != 1) NO ("size-limited slices: camera video, one spatial layer only");
     }
     // Rate control with one slice per picture = GOM-level QP (ratectl.cpp:1199-1204): the QP of a group of macroblocks depends
     // on the bits of the groups before it, so the picture is one device round trip PER GROUP -- bit-exact, but a latency chain

@@ -1556,8 +1556,13 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
   // size-limited slices: ranges coded ahead of the entropy writer, one slice per call; the picture-wide passes with a closing call
   const bool dyn = j->iDynSlice > 0;
   const bool dyn_close = dyn && j->iMbBegin == c->num_mb && j->iMbEnd == c->num_mb;
-  if (dyn && (!ranged || j->iNumSlices != 1 || j->bRetry || j->pGomRc || j->pMbQp || j->pScreen || j->iDynSliceFirstMb < 0 || j->iDynSliceFirstMb > j->iMbBegin)) {
-    set_err ("size-limited slices: MB ranges of a camera-video picture with a frame-constant QP, described as one slice"); return WELSHIP_ERR_INIT_PARA;
+  if (dyn && (!ranged || j->bRetry || j->pGomRc || j->pMbQp || j->pScreen || j->iDynSliceFirstMb < 0 || j->iDynSliceFirstMb > j->iMbBegin)) {
+    set_err ("size-limited slices: MB ranges of a camera-video picture with a frame-constant QP"); return WELSHIP_ERR_INIT_PARA;
+  }
+  if (dyn && !dyn_close) {      // the slice table of such a picture are its PARTITIONS (one per slice thread; one = the picture): a range stays inside one
+    bool inside = false;
+    for (int i = 0; i < j->iNumSlices && j->pSliceFirstMb; ++i) inside = inside || (j->iDynSliceFirstMb >= j->pSliceFirstMb[i] && j->iMbEnd <= j->pSliceFirstMb[i + 1]);
+    if (!inside) { set_err ("size-limited slices: the MB range crosses a partition of the picture"); return WELSHIP_ERR_INIT_PARA; }
   }
   if (ranged && !dyn_close && (j->iMbBegin < 0 || j->iMbBegin >= j->iMbEnd || j->iMbEnd > c->num_mb)) { set_err ("invalid MB range"); return WELSHIP_ERR_INIT_PARA; }
   const bool retry = j->bRetry != 0;

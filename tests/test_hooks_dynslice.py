@@ -10,7 +10,7 @@ macroblock a new slice begins with (WelsHipFrameJob::iDynSlice, include/welship.
 Checked here on the CPU test build of the kernels (tests/emu): random sessions byte for byte against the unmodified reference
 (tools/fuzz_dynslice.py: 421 .. 3000 bytes per slice, i.e. from slices shorter than a macroblock row -- dozens per picture -- to one
 slice per picture; all rate-control modes, temporal layers, LTR, denoising, background / scene-change detection, the three
-deblocking modes, I pictures in mid-stream, CAVLC and CABAC).  The reference table's own size-limited rows: tests/test_hooks_sha1.py.
+deblocking modes, I pictures in mid-stream, CAVLC and CABAC, one to four slice threads).  The reference table's own size-limited rows: tests/test_hooks_sha1.py.
 This path has not run on the MI355X yet (no GPU test): it is opt-in until it has.
 """
 import os
@@ -63,9 +63,22 @@ def test_installer_declines_without_the_switch(emu_lib, tmp_path):
                         "-slcsize", "600", "-threads", "1", "-rc", "-1", "-qp", "26"], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
     err = p.stderr.decode(errors="replace")
     assert p.returncode == 0 and "not installed" in err and "WELS_HIP_DYNSLICE" in err
-    # ... and with several slice threads (one partition of the picture per thread) it declines even when asked
+    # ... and screen content with size-limited slices stays on the C path even when asked
     env["WELS_HIP_DYNSLICE"] = "1"
     p = subprocess.run([os.path.join(REF, "ref_enc_hip"), "-i", src, "-w", "176", "-h", "144", "-o", str(tmp_path / "o.264"), "-quiet", "-slcmd", "3",
-                        "-slcsize", "600", "-threads", "2", "-rc", "-1", "-qp", "26"], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+                        "-slcsize", "600", "-threads", "1", "-rc", "-1", "-qp", "26", "-usage", "1"], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
     err = p.stderr.decode(errors="replace")
-    assert p.returncode == 0 and "not installed" in err and "one slice thread" in err
+    assert p.returncode == 0 and "not installed" in err and "camera video" in err
+
+
+def test_random_sessions_with_slice_threads_on_emulation(emu_lib):
+    """Several slice threads: the picture is split into one partition per thread, every partition is sliced on its own by its thread's
+    task (CWelsConstrainedSizeSlicingEncodingTask, wels_task_encoder.cpp:231-325) and the tasks call the device concurrently."""
+    import fuzz_dynslice
+    from concurrent.futures import ThreadPoolExecutor
+    with tempfile.TemporaryDirectory() as tmp:
+        with ThreadPoolExecutor(4) as ex:
+            res = list(ex.map(lambda s: fuzz_dynslice.one_case(s, emu_lib, tmp, True, 4), range(5000, 5012)))
+    bad = [(s, m) for s, m, ok in res if not ok]
+    assert not bad, bad[0]
+    assert sum(1 for _, m, _ in res if m.startswith("ok") and "-threads 1 " not in m) >= 6

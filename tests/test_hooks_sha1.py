@@ -9,7 +9,7 @@ Rows the dispatch-table binding takes to the device: every option combination of
 1 and 3 temporal layers, LTR, denoising, scene-change detection, background detection, frame skipping) in slice modes
 0, 1 and 2 -- 1792 of the 2304 rows.  Size-limited slices (-slcmd 3) keep the reference's C path by default --
 the hooks report that, and the test checks that those rows are NOT counted as device rows; with WELS_HIP_DYNSLICE=1 the 256
-single-thread rows of that mode run on the device too (CPU tier only so far: the path has not been on the MI355X yet).
+size-limited rows run on the device too (CPU tier only so far: the path has not been on the MI355X yet).
 
 Also here: the reference's API-level golden hashes (test/api/encoder_test.cpp:104-115) and its stock testbin/welsenc.cfg
 through the same binding.
@@ -123,20 +123,23 @@ def test_unsupported_rows_stay_on_the_c_path(workdir, emu_lib):
         assert got == row[0]
 
 
-def _size_limited_rows():
-    """The table's -slcmd 3 rows that name their thread count (-thread 1).  The other half (-thread 0) takes the machine's core count:
-    on a box with several cores those sessions split every picture into one partition per slice thread, which the binding declines."""
-    return [r for r in _rows() if r[4]["-slcmd 0"] == "3" and r[4]["-thread"] == "1"]
+def _size_limited_rows(threads=("1",)):
+    """The table's -slcmd 3 rows: 256 that name one slice thread (-thread 1) and 256 that take the machine's core count (-thread 0: up to
+    four slice threads, one partition of the picture each -- the table's hashes are those of a machine with at least four cores)."""
+    return [r for r in _rows() if r[4]["-slcmd 0"] == "3" and r[4]["-thread"] in threads]
 
 
 def test_size_limited_rows_on_emulation(workdir, emu_lib):
     """Size-limited slices on request (WELS_HIP_DYNSLICE=1): the device codes ahead of the entropy writer, and where
     the writer ends a slice (DynSlcJudgeSliceBoundaryStepBack, svc_encode_slice.cpp:1741-1790) the next slice begins with another device
     call that codes the macroblocks from there on again -- without the neighbours that now belong to the slice before.  Every second
-    of the 256 rows here; all of them: profiles/r02_size_limited_slices_emulation.txt (tools/sha1_table_rows.py --dynslice)."""
+    of the 256 single-thread rows and every eighth of the others here; all 512: profiles/r02_size_limited_slices_emulation.txt
+    (tools/sha1_table_rows.py --dynslice)."""
     from concurrent.futures import ThreadPoolExecutor
     rows = _size_limited_rows()
     assert len(rows) == 256
+    if (os.cpu_count() or 1) >= 4:          # the -thread 0 rows: four partitions per picture, coded by four slice tasks at once
+        rows = rows + _size_limited_rows(("0",))[::4]
 
     def one(ir):
         i, row = ir

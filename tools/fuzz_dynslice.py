@@ -23,7 +23,7 @@ REF = os.path.join(ROOT, "oracle", "_ref")
 sys.path.insert(0, ROOT)
 
 
-def one_case(seed, lib, tmp, verbose=False):
+def one_case(seed, lib, tmp, verbose=False, max_threads=1):
     from openh264_amd.utils.synth import make_sequence
     rng = random.Random(seed)
     w = 16 * rng.randint(4, 40) - rng.choice((0, 0, 0, 2, 8))
@@ -34,7 +34,8 @@ def one_case(seed, lib, tmp, verbose=False):
     content = rng.choice(("synth", "synth", "pan", "checker"))
     yuv = make_sequence(content, w, h, n)
     rc = rng.choice((-1, -1, 0, 1, 3))
-    flags = ["-slcmd", "3", "-slcsize", str(rng.choice((421, 450, 500, 600, 800, 1200, 1500, 3000))), "-threads", "1",
+    threads = max_threads if max_threads <= 1 else rng.choice((1, 2, 3, 4)[:max_threads])
+    flags = ["-slcmd", "3", "-slcsize", str(rng.choice((421, 450, 500, 600, 800, 1200, 1500, 3000))), "-threads", str(threads), "-loadbalancing", "0",
              "-rc", str(rc), "-complexity", str(rng.randint(0, 2)), "-numtl", str(rng.choice((1, 1, 2, 3))),
              "-deblock", str(rng.choice((0, 0, 1, 2))), "-iper", str(rng.choice((0, 0, 3, 5))),
              "-bgd", str(rng.randint(0, 1)), "-scene", str(rng.randint(0, 1)), "-ltr", str(rng.choice((0, 0, 1))),
@@ -84,13 +85,14 @@ def main():
     ap.add_argument("--cases", type=int, default=40)
     ap.add_argument("--workers", type=int, default=8)
     ap.add_argument("-v", action="store_true")
+    ap.add_argument("--threads", type=int, default=1, help="slice threads up to this many (one partition of the picture per thread)")
     a = ap.parse_args()
     from openh264_amd import build as B
     lib = os.path.abspath(a.lib) if a.lib else B.build_emu()
     bad = 0
     with tempfile.TemporaryDirectory() as tmp:
         with ThreadPoolExecutor(a.workers) as ex:
-            for seed, msg, ok in ex.map(lambda s: one_case(s, lib, tmp, a.v), range(a.seed * 1000, a.seed * 1000 + a.cases)):
+            for seed, msg, ok in ex.map(lambda s: one_case(s, lib, tmp, a.v, a.threads), range(a.seed * 1000, a.seed * 1000 + a.cases)):
                 print("%6d %s" % (seed, msg), flush=True)
                 bad += 0 if ok else 1
     print("%d cases, %d failed (library %s)" % (a.cases, bad, os.path.basename(lib)))
