@@ -281,6 +281,10 @@ typedef struct WelsHipFrameJob {
   /* inside one; calls for different partitions may come from different threads.  The picture-wide passes wait for a closing call     */
   /* with iMbBegin = iMbEnd = the number of macroblocks (nothing is coded by it).  0 = slices as in pSliceFirstMb.                     */
   int32_t iDynSlice, iDynSliceFirstMb;
+  /* A macroblock of an MB range overflowed (TRY_REENCODING above): the call is repeated for the rest of the range, from that macroblock   */
+  /* on, with pReencode / iNumReencode (bRetry stays 0) -- and every later call of the picture, the closing one included, carries the list. */
+  /* bRangeAgain = 1 marks such a repeated call: even when it begins at macroblock 0 the picture's inputs are not uploaded again.           */
+  int32_t bRangeAgain;
 } WelsHipFrameJob;
 typedef struct WelsHipGomRc {
   int32_t iNumberMbGom;             /* pWelsSvcRc->iNumberMbGom: whole macroblock rows (else WELSHIP_ERR_UNSUPPORTED: code the groups one by one) */

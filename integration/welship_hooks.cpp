@@ -170,6 +170,17 @@ int32_t DynCode (HipState* st, HipLayer& L, int iPart, int iSliceIdx, int iSlice
   jb.pSliceFirstMb = &L.first[0];
   jb.iMbBegin = iFrom; jb.iMbEnd = end;
   jb.iDynSlice = iSliceIdx + 1; jb.iDynSliceFirstMb = iSliceFirst;
+  // macroblocks coded again after a CAVLC overflow (TRY_REENCODING in HipCodeSlice): every later call of the picture carries them.  A
+  // macroblock a slice BEGINS with is decided from scratch (pfWelsRcMbInit and the Init functions run again in the reference): what was
+  // noted for it, or for anything behind it, belongs to the slice before
+  std::vector<WelsHipMbReencode> list;
+  {
+    std::lock_guard<std::mutex> lock (L.dyn_mu);
+    if (iFrom == iSliceFirst)
+      for (size_t i = 0; i < L.reencode.size();) { if (L.reencode[i].iMbXY >= iFrom && L.reencode[i].iMbXY < iPartEnd) L.reencode.erase (L.reencode.begin() + i); else ++i; }
+    list = L.reencode;
+  }
+  if (!list.empty()) { jb.pReencode = &list[0]; jb.iNumReencode = (int32_t)list.size(); }
   const void* rec = NULL;
   const int rc = g_api.FrameEncode (L.ctx, &jb, &rec);
   if (rc) { fprintf (stderr, "welship hooks: WelsHipFrameEncode (slice %d from MB %d) failed (%d: %s)\n", iSliceIdx, iFrom, rc, g_api.GetLastError()); st->failed = true; return ENC_RETURN_UNEXPECTED; }
@@ -519,21 +530,42 @@ TRY_REENCODING:
       // the macroblock started and decides it again with its QP raised by 2 -- without re-initialising it, so uiCbp and one cell of the
       // MV cache carry over (WelsHipMbReencode).  On the device that is the whole picture again with this macroblock's QP changed:
       // every other macroblock reproduces itself, the ones after it in the slice see its new reconstruction.
-      if (L.gom || L.dyn || pCtx->pSvcParam->iMultipleThreadIdc > 1) {
-        fprintf (stderr, "welship hooks: CAVLC overflow at MB %d -- re-encoding is not implemented for GOM-level QP / size-limited slices / slice threads\n", iCurMbIdx);
+      if (L.gom || L.job.pGomRc != NULL || (pCtx->pSvcParam->iMultipleThreadIdc > 1 && !L.dyn)) {
+        fprintf (stderr, "welship hooks: CAVLC overflow at MB %d -- re-encoding is not implemented for GOM-level QP / slice threads\n", iCurMbIdx);
         st->failed = true;
         return ENC_RETURN_UNEXPECTED;
       }
-      pSlice->iMbSkipRun = pFunc->pfStashPopMBStatus (&sDss, pSlice);
+      const int32_t iRun = pFunc->pfStashPopMBStatus (&sDss, pSlice);
+      pSlice->iMbSkipRun = iRun;
       const uint8_t kuiChromaQpIndexOffset = pCurLayer->sLayerInfo.pPpsP->uiChromaQpIndexOffset;
       pCurMb->uiLumaQp += DELTA_QP;                      // UpdateQpForOverflow (svc_encode_slice.cpp:526-530)
       pCurMb->uiChromaQp = g_kuiChromaQpTable[CLIP3_QP_0_51 (pCurMb->uiLumaQp + kuiChromaQpIndexOffset)];
-      WelsHipMbReencode* e = NULL;
-      for (size_t i = 0; i < L.reencode.size(); ++i) if (L.reencode[i].iMbXY == iCurMbIdx) e = &L.reencode[i];
-      if (e == NULL) { WelsHipMbReencode n; memset (&n, 0, sizeof (n)); n.iMbXY = iCurMbIdx; L.reencode.push_back (n); e = &L.reencode.back(); }
-      e->uiLumaQp = pCurMb->uiLumaQp;
-      e->uiStaleCbp = R.cbp & 0x3f;
-      if (R.mb_type == WH_MB_P8x16) { e->bCell12Valid = 1; e->iCell12Mv[0] = R.mv_tr[0]; e->iCell12Mv[1] = R.mv_tr[1]; }
+      std::vector<WelsHipMbReencode> list;
+      {
+        std::lock_guard<std::mutex> lock (L.dyn_mu);       // (size-limited slices with slice threads: the partitions' tasks share the list)
+        WelsHipMbReencode* e = NULL;
+        for (size_t i = 0; i < L.reencode.size(); ++i) if (L.reencode[i].iMbXY == iCurMbIdx) e = &L.reencode[i];
+        if (e == NULL) { WelsHipMbReencode n; memset (&n, 0, sizeof (n)); n.iMbXY = iCurMbIdx; L.reencode.push_back (n); e = &L.reencode.back(); }
+        e->uiLumaQp = pCurMb->uiLumaQp;
+        e->uiStaleCbp = R.cbp & 0x3f;
+        if (R.mb_type == WH_MB_P8x16) { e->bCell12Valid = 1; e->iCell12Mv[0] = R.mv_tr[0]; e->iCell12Mv[1] = R.mv_tr[1]; }
+        if (L.dyn) list = L.reencode;
+      }
+      if (L.dyn) {
+        // Size-limited slices: nothing of the picture is filtered yet, so only what the device has coded ahead from this macroblock on is
+        // repeated -- same slice, same range end.
+        WelsHipFrameJob jb = L.job;
+        jb.pSliceFirstMb = &L.first[0];
+        jb.iMbBegin = iCurMbIdx; jb.iMbEnd = L.part[kiPartitionId].coded_upto;
+        jb.iDynSlice = kiSliceIdx + 1; jb.iDynSliceFirstMb = kiSliceFirstMbXY;
+        jb.pReencode = &list[0]; jb.iNumReencode = (int32_t)list.size(); jb.bRangeAgain = 1;
+        const void* rec = NULL;
+        const int rc = g_api.FrameEncode (L.ctx, &jb, &rec);
+        if (rc) { fprintf (stderr, "welship hooks: WelsHipFrameEncode (re-encoding MB %d at QP %d) failed (%d: %s)\n", iCurMbIdx, pCurMb->uiLumaQp, rc, g_api.GetLastError()); st->failed = true; return ENC_RETURN_UNEXPECTED; }
+        L.records = (const WhMbRecord*)rec;
+        if (st->trace) fprintf (stderr, "welship hooks: MB %d coded again at QP %d (%d re-encoded macroblocks in this picture)\n", iCurMbIdx, pCurMb->uiLumaQp, (int)list.size());
+        goto TRY_REENCODING;
+      }
       L.job.bRetry = 1; L.job.pReencode = &L.reencode[0]; L.job.iNumReencode = (int32_t)L.reencode.size();
       L.job.pSliceFirstMb = &L.first[0];
       const void* rec = NULL;
@@ -591,6 +623,7 @@ TRY_REENCODING:
           WelsHipFrameJob jb = L.job;
           jb.pSliceFirstMb = &L.first[0];
           jb.iMbBegin = kiTotalNumMb; jb.iMbEnd = kiTotalNumMb; jb.iDynSlice = kiSliceIdx + 1; jb.iDynSliceFirstMb = kiSliceFirstMbXY;
+          if (!L.reencode.empty()) { jb.pReencode = &L.reencode[0]; jb.iNumReencode = (int32_t)L.reencode.size(); }     // (the QP_Y chain for the filter)
           const void* rec = NULL;
           const int rc = g_api.FrameEncode (L.ctx, &jb, &rec);
           if (rc) { fprintf (stderr, "welship hooks: WelsHipFrameEncode (closing the picture) failed (%d: %s)\n", rc, g_api.GetLastError()); st->failed = true; return ENC_RETURN_UNEXPECTED; }

@@ -1567,8 +1567,11 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
   if (ranged && !dyn_close && (j->iMbBegin < 0 || j->iMbBegin >= j->iMbEnd || j->iMbEnd > c->num_mb)) { set_err ("invalid MB range"); return WELSHIP_ERR_INIT_PARA; }
   const bool retry = j->bRetry != 0;
   if (retry && (ranged || !j->pReencode || j->iNumReencode < 1)) { set_err ("a retry is a whole-picture call with the list of re-encoded macroblocks"); return WELSHIP_ERR_INIT_PARA; }
+  // MB ranges (GOM-synchronous rate control, size-limited slices) repeat only the range from the macroblock that overflowed on: the list of
+  // macroblocks re-encoded so far travels with every later call of the picture (their QP / leaked state, and the QP_Y chain at the end)
+  const bool ranged_reenc = ranged && !retry && j->pReencode && j->iNumReencode > 0;
   // (a retry reuses what the first call of the picture uploaded: source, pre-analysis arrays, screen-content inputs)
-  const bool first_part = !retry && (!ranged || j->iMbBegin == 0), last_part = !ranged || (dyn ? dyn_close : j->iMbEnd == c->num_mb);
+  const bool first_part = !retry && (!ranged || (j->iMbBegin == 0 && !j->bRangeAgain)), last_part = !ranged || (dyn ? dyn_close : j->iMbEnd == c->num_mb);
   FrameShared* sh = c->sh;
   wh::Backend* be = c->be;
   // host-side staging into this context's own page-locked buffers: outside the shared lock
@@ -1709,12 +1712,14 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
     wh_build_mb_order (c->mb_w, 0, c->num_mb, o16.data(), gom->iNumberMbGom / c->mb_w);
     for (int i = 0; i < c->num_mb; ++i) { order[i] = o16[i]; dep[i] = i / gom->iNumberMbGom ? (i / gom->iNumberMbGom) * gom->iNumberMbGom - 1 : -1; }
   }
+  std::unique_lock<std::mutex> lock (sh->mu);
+  // (the per-macroblock control words are built under the lock: the slice tasks of a picture with size-limited slices call concurrently)
   bool qp_map = false;
   if (j->pMbQp) {
     for (int i = 0; i < c->num_mb; ++i) { memset (&c->h_mb_ctl[i], 0, sizeof (WhMbCtl)); c->h_mb_ctl[i].qp_delta = (int8_t) ((int)j->pMbQp[i] - j->iQp); }
     qp_map = true;
   }
-  if (retry) {
+  if (retry || ranged_reenc) {
     if (!qp_map) memset (c->h_mb_ctl.data(), 0, sizeof (WhMbCtl) * c->num_mb);
     for (int i = 0; i < j->iNumReencode; ++i) {
       const WelsHipMbReencode& r = j->pReencode[i];
@@ -1727,7 +1732,6 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
     qp_map = true;
   }
 
-  std::unique_lock<std::mutex> lock (sh->mu);
   const auto t_sub0 = std::chrono::steady_clock::now();
   int rc = c->set_layout (j->iNumSlices, j->pSliceFirstMb, j->iDeblockIdc);
   if (rc) return rc;

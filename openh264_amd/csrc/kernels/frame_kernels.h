@@ -86,21 +86,25 @@ WH_FN int wh_mb_qp (const WhPicJob& J, const WhMbCtl& c) { return wh_clip3 (J.qp
 // cbp == 0 and not Intra16x16) inherits the QP of the previous macroblock of its slice, the first one the slice QP
 // (svc_set_mb_syn_cavlc.cpp:232-247,288-300: uiLumaQp = uiLastMbQp).  With one QP per picture that is the identity, so
 // this pass only runs for pictures with a per-MB QP map.  One wavefront per slice: 64 states per step are loaded
-// lane-parallel, the chain itself is a wave-uniform scan over the lane table.
+// lane-parallel, the chain itself is a wave-uniform scan over the lane table.  Size-limited slices (WhPicJob::dyn_slice): [first, last) is a
+// partition of the picture and the slices inside it are where the states' slice index changes.
 WH_FN void wh_qp_chain_slice (const WhSeqParams& P, const WhPicJob& J, int first, int last) {
   int carry = wh_clip3 (J.qp, 0, 51);
+  int cur_slice = -1;
   for (int base = first; base < last; base += 64) {
-    WvLaneArr w, o;
+    WvLaneArr w, o, sl;
 #ifdef WH_EMU
-    memset (&w, 0, sizeof (w)); memset (&o, 0, sizeof (o));
+    memset (&w, 0, sizeof (w)); memset (&o, 0, sizeof (o)); memset (&sl, 0, sizeof (sl));
 #else
-    w = 0; o = 0;
+    w = 0; o = 0; sl = 0;
 #endif
     WV_LSET_IF (w, lane, base + lane < last, (int) * (const WH_G uint32_t*) ((const WH_G WhMbState*)J.mbs + base + lane));
+    if (J.dyn_slice) WV_LSET_IF (sl, lane, base + lane < last, (int) ((const WH_G WhMbState*)J.mbs + base + lane)->slice_idc);
     const int n = last - base < 64 ? last - base : 64;
     for (int i = 0; i < n; ++i) {
       const uint32_t v = (uint32_t)WV_LGET (w, i);            // bytes: mb_type, luma_qp, chroma_qp, cbp
       const int type = (int) (v & 0xff), cbp = (int) (v >> 24);
+      if (J.dyn_slice) { const int s = WV_LGET (sl, i); if (s != cur_slice) { cur_slice = s; carry = wh_clip3 (J.qp, 0, 51); } }
       if (! (type == WH_MB_PSKIP || (cbp == 0 && type != WH_MB_I16x16))) carry = (int) ((v >> 8) & 0xff);
       WV_LSET (o, i, carry);
     }

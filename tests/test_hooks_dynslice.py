@@ -51,6 +51,21 @@ def test_random_sessions_on_emulation_reverse_lane_order():
     _fuzz(B.build_emu(defines=("WH_EMU_REVERSE",), tag="wh_emu_reverse"), range(7000, 7008))
 
 
+def test_reencoding_after_cavlc_overflow_inside_size_limited_slices(emu_lib):
+    """TRY_REENCODING (svc_encode_slice.cpp:564-576,1845-1867) under size-limited slices: constant QP 0..12 on saturated content makes CAVLC
+    levels overflow; the writer takes the macroblock back and the device codes it -- and what it had coded ahead of it -- again at QP + 2
+    (an MB range repeated with WelsHipFrameJob::pReencode; the QP_Y chain for the filter follows the slices where the states' slice
+    index changes).  One to four slice threads."""
+    import fuzz_dynslice
+    from concurrent.futures import ThreadPoolExecutor
+    with tempfile.TemporaryDirectory() as tmp:
+        with ThreadPoolExecutor(4) as ex:
+            res = list(ex.map(lambda s: fuzz_dynslice.one_case(s, emu_lib, tmp, True, 4, True), range(11012, 11024)))
+    bad = [(s, m) for s, m, ok in res if not ok]
+    assert not bad, bad[0]
+    assert sum(1 for _, m, _ in res if "repeated after a CAVLC overflow" in m) >= 2
+
+
 def test_installer_declines_without_the_switch(emu_lib, tmp_path):
     """Opt-in: without WELS_HIP_DYNSLICE the session keeps the reference's C path and the installer says why."""
     import subprocess

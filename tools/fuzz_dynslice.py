@@ -23,7 +23,7 @@ REF = os.path.join(ROOT, "oracle", "_ref")
 sys.path.insert(0, ROOT)
 
 
-def one_case(seed, lib, tmp, verbose=False, max_threads=1):
+def one_case(seed, lib, tmp, verbose=False, max_threads=1, low_qp=False):
     from openh264_amd.utils.synth import make_sequence
     rng = random.Random(seed)
     w = 16 * rng.randint(4, 40) - rng.choice((0, 0, 0, 2, 8))
@@ -40,7 +40,12 @@ def one_case(seed, lib, tmp, verbose=False, max_threads=1):
              "-deblock", str(rng.choice((0, 0, 1, 2))), "-iper", str(rng.choice((0, 0, 3, 5))),
              "-bgd", str(rng.randint(0, 1)), "-scene", str(rng.randint(0, 1)), "-ltr", str(rng.choice((0, 0, 1))),
              "-denoise", str(rng.choice((0, 0, 1)))]
-    if rc == -1:
+    if low_qp:         # constant QP 0 .. 12 on saturated content: CAVLC level overflows, macroblocks coded again at QP + 2 (TRY_REENCODING)
+        rc = -1
+        flags[flags.index("-rc") + 1] = "-1"
+        yuv = make_sequence(rng.choice(("checker", "checker2", "checker5", "synth")), w, h, n)
+        flags += ["-qp", str(rng.randint(0, 12))]
+    elif rc == -1:
         flags += ["-qp", str(rng.choice((14, 20, 24, 28, 34, 40)))]
     else:
         flags += ["-bitrate", str(rng.choice((150000, 400000, 1000000, 3000000))), "-frameskip", str(rng.randint(0, 1))]
@@ -70,6 +75,9 @@ def one_case(seed, lib, tmp, verbose=False, max_threads=1):
             slices = sum(int(l.split("complete:")[1].split()[0]) for l in done)
             calls = sum(int(l.split("slices,")[1].split()[0]) for l in done)
             info = "%dx%d %d frames, %d pictures on the device, %d slices, %d device calls" % (w, h, n, len(done), slices, calls)
+            again = err.count("coded again at QP")
+            if again:
+                info += ", %d macroblock passes repeated after a CAVLC overflow" % again
             if "welship hooks: installed" not in err or not done:
                 os.remove(src)
                 return seed, "NOT ON THE DEVICE %s\n%s" % (" ".join(flags), err[-400:]), False
@@ -85,6 +93,7 @@ def main():
     ap.add_argument("--cases", type=int, default=40)
     ap.add_argument("--workers", type=int, default=8)
     ap.add_argument("-v", action="store_true")
+    ap.add_argument("--low-qp", action="store_true", help="constant QP 0..12 on saturated content: the re-encode after a CAVLC level overflow inside size-limited slices")
     ap.add_argument("--threads", type=int, default=1, help="slice threads up to this many (one partition of the picture per thread)")
     a = ap.parse_args()
     from openh264_amd import build as B
@@ -92,7 +101,7 @@ def main():
     bad = 0
     with tempfile.TemporaryDirectory() as tmp:
         with ThreadPoolExecutor(a.workers) as ex:
-            for seed, msg, ok in ex.map(lambda s: one_case(s, lib, tmp, a.v, a.threads), range(a.seed * 1000, a.seed * 1000 + a.cases)):
+            for seed, msg, ok in ex.map(lambda s: one_case(s, lib, tmp, a.v, a.threads, a.low_qp), range(a.seed * 1000, a.seed * 1000 + a.cases)):
                 print("%6d %s" % (seed, msg), flush=True)
                 bad += 0 if ok else 1
     print("%d cases, %d failed (library %s)" % (a.cases, bad, os.path.basename(lib)))
