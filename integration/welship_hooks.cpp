@@ -165,6 +165,7 @@ int32_t DynCode (HipState* st, HipLayer& L, int iPart, int iSliceIdx, int iSlice
   HipLayer::DynPart& P = L.part[iPart];
   const int est = P.est[is_p ? 1 : 0];
   int end = est > 0 ? iFrom + WELS_MAX (est + (est >> 1), 16) : iPartEnd;
+  if (iFrom > iSliceFirst && end < iFrom + (iFrom - iSliceFirst)) end = iFrom + (iFrom - iSliceFirst);      // the slice outgrew the estimate: as much again as it has so far
   if (end > iPartEnd || getenv ("WELS_HIP_DYNSLICE_WHOLE")) end = iPartEnd;
   WelsHipFrameJob jb = L.job;
   jb.pSliceFirstMb = &L.first[0];
@@ -340,8 +341,8 @@ int32_t HipFrameMd (sWelsEncCtx* pCtx) {
   if (L.dyn) {
     // (the slice table at this point: one slice per partition, i.e. per slice thread -- pFirstMbIdxOfSlice = the partitions' first macroblocks)
     const int nparts = pCtx->iActiveThreadsNum;
-    if (L.gom || nslices != nparts || nparts < 1 || nparts > MAX_THREADS_NUM || job.pScreen != NULL) {
-      fprintf (stderr, "welship hooks: size-limited slices with GOM-level QP / %d slices in %d partitions / screen content\n", nslices, nparts); st->failed = true; return ENC_RETURN_UNEXPECTED;
+    if (L.gom || nslices != nparts || nparts < 1 || nparts > MAX_THREADS_NUM) {
+      fprintf (stderr, "welship hooks: size-limited slices with GOM-level QP / %d slices in %d partitions\n", nslices, nparts); st->failed = true; return ENC_RETURN_UNEXPECTED;
     }
     L.dyn_calls = 0; L.dyn_slices = 0; L.dyn_parts_left = 0;
     if (nparts > 1) {       // the device's slice table: the partitions (FirstMbIdxOfPartition / EndMbIdxOfPartition, svc_enc_slice_segment.cpp)
@@ -451,6 +452,7 @@ int32_t HipCodeSlice (sWelsEncCtx* pCtx, SSlice* pSlice) {
   // the writer (WelsSpatialWriteMbSynCabac) derives its contexts from what it wrote for the neighbours (sMvd, iCbpDc, types)
   if (pCtx->pSvcParam->iEntropyCodingModeFlag) WelsInitSliceCabac (pCtx, pSlice);
   SSliceCtx* pSliceCtx = &pCurLayer->sSliceEncCtx;
+  uint32_t uiDynFmeDown = 0;
   const int32_t kiPartitionId = kiSliceIdx % pCtx->iActiveThreadsNum;
   const int32_t kiDynPartEnd = pCtx->iActiveThreadsNum == 1 ? kiTotalNumMb : pCurLayer->EndMbIdxOfPartition[kiPartitionId] + 1;
   if (L.dyn) {      // WelsMdInterMbLoopOverDynamicSlice / WelsISliceMdEncDynamic (svc_encode_slice.cpp:1925-1931,620-626)
@@ -608,6 +610,7 @@ TRY_REENCODING:
       pFunc->pfCopy8x8Aligned (pVaa->pCurV + kiOffsetUV, pVaa->iPicStrideUV, pVaa->pRefV + kiOffsetUV, pVaa->iPicStrideUV);
     }
     pFunc->pfRc.pfWelsRcMbInfoUpdate (pCtx, pCurMb, R.cost, pSlice);
+    uiDynFmeDown += R.fme_down;
     ++iNumMbCoded;
     iNextMbIdx = WelsGetNextMbOfSlice (pCurLayer, iCurMbIdx);
     if (iNextMbIdx == -1 || iNextMbIdx >= kiTotalNumMb || iNumMbCoded >= kiTotalNumMb) {
@@ -639,7 +642,8 @@ TRY_REENCODING:
   }
   if (is_p && pSlice->iMbSkipRun) BsWriteUE (pSlice->pSliceBsa, pSlice->iMbSkipRun);
   // WelsDiamondCrossFeatureSearch's account of what the feature search saved (svc_motion_estimate.cpp:1080-1092), read by UpdateFMESwitch
-  if (is_p && L.job.pScreen != NULL && kiSliceIdx >= 0 && kiSliceIdx < (int32_t)L.fme_down.size()) pSlice->uiSliceFMECostDown += L.fme_down[kiSliceIdx];
+  if (is_p && L.job.pScreen != NULL && L.dyn) pSlice->uiSliceFMECostDown += uiDynFmeDown;        // (size-limited slices: summed over the macroblocks this slice really took)
+  else if (is_p && L.job.pScreen != NULL && kiSliceIdx >= 0 && kiSliceIdx < (int32_t)L.fme_down.size()) pSlice->uiSliceFMECostDown += L.fme_down[kiSliceIdx];
   // for the layer above: this slice's real motion vectors in the SMB array (the writer above was fed vector differences)
   if (!L.states.empty()) {
     int32_t iMb = kiSliceFirstMbXY;
@@ -685,7 +689,7 @@ bool WelsHipSupported (const SWelsSvcCodingParam* p, const char** why) {
       // calls per picture: taken on request (WELS_HIP_DYNSLICE=1), for what it is implemented for.
       const char* ds = getenv ("WELS_HIP_DYNSLICE");
       if (ds == NULL || atoi (ds) == 0) NO ("size-limited slices feed the bitstream position back into mode decision; WELS_HIP_DYNSLICE=1 installs the hooks anyway");
-      if (p->iUsageType != CAMERA_VIDEO_REAL_TIME || p->iSpatialLayerNum != 1) NO ("size-limited slices: camera video, one spatial layer only");
+      if (p->iSpatialLayerNum != 1) NO ("size-limited slices: one spatial layer only");
     }
     // Rate control with one slice per picture = GOM-level QP (ratectl.cpp:1199-1204): the QP of a group of macroblocks depends
     // on the bits of the groups before it, so the picture is one device round trip PER GROUP -- bit-exact, but a latency chain

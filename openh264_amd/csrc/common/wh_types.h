@@ -49,7 +49,8 @@ typedef struct WhMbRecord {
   uint8_t  pad0[3];
   int32_t  cavlc_bits;       // WhPicJob::want_bits: bits of this macroblock's CAVLC syntax without ue(mb_skip_run) and se(mb_qp_delta)
                              //   (kernels/cavlc_bits.h); | WH_BITS_HAS_QP_DELTA when it codes mb_qp_delta.  Else 0
-  uint8_t  pad[8];
+  uint32_t fme_down;         // screen content with size-limited slices: what this macroblock adds to pSlice->uiSliceFMECostDown (else 0)
+  uint8_t  pad[4];
   // coefficient levels in zig-zag order:
   int16_t  luma[16][16];     // per luma4x4BlkIdx; I16x16: entries 0..14 = AC, [15] = 0
   int16_t  luma_dc[16];      // Intra16x16 DC levels
@@ -109,6 +110,9 @@ typedef struct WhSccJob {
   uint32_t* chain;             // [num_slices][4]: uiSadCost the slice's SWelsMD keeps in sMe8x8[i] from one macroblock to the next
                                //   (CheckDirectionalMv compares against it BEFORE the search overwrites it, svc_motion_estimate.cpp:385-402)
   uint32_t* fme_cost_down;     // [num_slices]: what the picture adds to pSlice->uiSliceFMECostDown
+  uint32_t* chain_mb;          // size-limited slices (WhPicJob::dyn_slice): the same chain kept PER MACROBLOCK, [mb][4] -- what macroblock mb leaves
+                               //   for the next one of its slice that may search 8x8 blocks (WhPicJob::scc_chain_prev); a slice can then begin,
+                               //   or a range be coded again, at any macroblock.  The cost-down sums travel in the records (WhMbRecord::fme_down)
 } WhSccJob;
 
 // ---- rate control with one slice per picture, QP per group of macroblocks: inputs and running state (common/gom_rc.h) -------

@@ -1276,6 +1276,7 @@ struct WelsHipFrameCtx {
   uint8_t* d_scc_ori = nullptr;
   uint32_t* d_scc_chain = nullptr;       // [WH_MAX_SLICES][4] chain, then [WH_MAX_SLICES] cost-down sums
   uint32_t* d_scc_order = nullptr;       // WH_SEQ_CHAIN: the picture's processing order [num_mb] | chain_prev [num_mb]
+  uint32_t* d_scc_chain_mb = nullptr;    // size-limited slices of such a picture: the chain per macroblock (WhSccJob::chain_mb)
   WhGomRc* d_gom_rc = nullptr;           // GOM-level rate control inside the kernel: inputs + state of the picture in flight
   std::vector<uint8_t> h_gom;            // page-locked staging: WhGomRc | order [num_mb] | dependency [num_mb]
   uint32_t* d_scc_lists = nullptr;       // times[list] | start[list]
@@ -1295,7 +1296,7 @@ struct WelsHipFrameCtx {
     be->sync();
     for (auto& p : pics) { if (p.base) be->free (p.base); if (p.mbs) be->free (p.mbs); }
     pics.clear();
-    void* ptrs[] = {d_src, d_records, d_dbflags, d_mb_ctl, d_sad_cost0, d_vaa, d_bgd, d_il, d_job, d_scc, d_scc_idc, d_scc_ori, d_scc_chain, d_scc_lists, d_scc_loc, d_scc_order, d_gom_rc};
+    void* ptrs[] = {d_src, d_records, d_dbflags, d_mb_ctl, d_sad_cost0, d_vaa, d_bgd, d_il, d_job, d_scc, d_scc_idc, d_scc_ori, d_scc_chain, d_scc_lists, d_scc_loc, d_scc_order, d_scc_chain_mb, d_gom_rc};
     if (!h_gom.empty()) be->unpin_host (h_gom.data());
     if (!h_scc.empty()) be->unpin_host (h_scc.data());
     if (!h_scc_small.empty()) be->unpin_host (h_scc_small.data());
@@ -1556,8 +1557,8 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
   // size-limited slices: ranges coded ahead of the entropy writer, one slice per call; the picture-wide passes with a closing call
   const bool dyn = j->iDynSlice > 0;
   const bool dyn_close = dyn && j->iMbBegin == c->num_mb && j->iMbEnd == c->num_mb;
-  if (dyn && (!ranged || j->bRetry || j->pGomRc || j->pMbQp || j->pScreen || j->iDynSliceFirstMb < 0 || j->iDynSliceFirstMb > j->iMbBegin)) {
-    set_err ("size-limited slices: MB ranges of a camera-video picture with a frame-constant QP"); return WELSHIP_ERR_INIT_PARA;
+  if (dyn && (!ranged || j->bRetry || j->pGomRc || j->pMbQp || j->iDynSliceFirstMb < 0 || j->iDynSliceFirstMb > j->iMbBegin)) {
+    set_err ("size-limited slices: MB ranges of a picture with a frame-constant QP"); return WELSHIP_ERR_INIT_PARA;
   }
   if (dyn && !dyn_close) {      // the slice table of such a picture are its PARTITIONS (one per slice thread; one = the picture): a range stays inside one
     bool inside = false;
@@ -1599,6 +1600,7 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
   static const bool scc_serial = getenv ("WELSHIP_SCC_SERIAL") && atoi (getenv ("WELSHIP_SCC_SERIAL")) != 0;       // fallback: plain coding order
   const bool scc_scroll = scr && scr->bScrollDetectFlag && (scr->iScrollMvX | scr->iScrollMvY);
   const bool scc_chain = scc_scroll && !scc_serial;
+  if (dyn && scc_scroll && scc_serial) { set_err ("size-limited slices of a scrolled screen-content picture need the chained order (WELSHIP_SCC_SERIAL is set)"); return WELSHIP_ERR_UNSUPPORTED; }
   if (scr) {
     if (!scr->pBlockStaticIdc) { set_err ("screen-content job without the static-block map"); return WELSHIP_ERR_INIT_PARA; }
     const bool fme = scr->bFeatureSearch8x8 != 0;
@@ -1780,6 +1782,7 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
     }
     if (scc_lists > c->scc_list_cap) { if (c->d_scc_lists) be->free (c->d_scc_lists); c->d_scc_lists = (uint32_t*)A (8 * scc_lists + 64); c->scc_list_cap = scc_lists; }
     if (scc_chain && !c->d_scc_order) c->d_scc_order = (uint32_t*)A (8 * (size_t)c->num_mb + 64);
+    if (dyn && scc_chain && !c->d_scc_chain_mb) c->d_scc_chain_mb = (uint32_t*)A (16 * (size_t)c->num_mb + 64);
     if (scc_entries > c->scc_loc_cap) { if (c->d_scc_loc) be->free (c->d_scc_loc); c->d_scc_loc = (uint16_t*)A (4 * scc_entries + 64); c->scc_loc_cap = scc_entries; }
     if (oom) { set_err ("out of device memory"); return WELSHIP_ERR_MEMORY; }
     if (first_part) {
@@ -1801,6 +1804,7 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
       z.fme_times = c->d_scc_lists; z.fme_start = c->d_scc_lists ? c->d_scc_lists + scc_lists : nullptr; z.fme_loc = c->d_scc_loc;
       z.fme_list_size = (int32_t)scc_lists;
       z.chain = c->d_scc_chain; z.fme_cost_down = c->d_scc_chain + 4 * WH_MAX_SLICES;
+      z.chain_mb = c->d_scc_chain_mb;
       be->upload (c->d_scc, &z, sizeof (z));
     }
     if (retry) be->fill (c->d_scc_chain, 0, sizeof (uint32_t) * 5 * WH_MAX_SLICES);       // the picture is coded again from its first macroblock

@@ -1129,6 +1129,7 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
   // P_Skip when the skip predictor happens to be that vector (and the reference MB's QP is close), P16x16 with residual otherwise.
   const WH_G WhSccJob* Z = nullptr;
   int idc0 = 0, idc1 = 0, idc2 = 0, idc3 = 0, scroll_on = 0, smx = 0, smy = 0;
+  uint32_t dch0 = 0, dch1 = 0, dch2 = 0, dch3 = 0, fme_down_mb = 0;      // size-limited slices: the incoming chain, this macroblock's cost-down sum
   bool scd_coded = false;
   if (SCC) {
     Z = (const WH_G WhSccJob*)J.scc;
@@ -1140,6 +1141,17 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
     const int sflag = Z->scroll_flag;
     smx = Z->scroll_mvx; smy = Z->scroll_mvy;
     scroll_on = sflag && (smx | smy);                                // pfSetScrollingMv == SetScrollingMvToMd (encoder_ext.cpp:2707-2713)
+    if (J.dyn_slice && scroll_on && J.scc_chain_prev) {
+      // size-limited slices: the chain of the 8x8 searches (below) per macroblock -- take over what the previous macroblock of THIS slice
+      // that may search 8x8 blocks left (nothing when it lies before the slice's first macroblock) and pass it on unchanged unless this
+      // macroblock gets to the 8x8 searches itself
+      const int pv = ((const WH_G int32_t*)J.scc_chain_prev)[xy];
+      WH_G uint32_t* cm = (WH_G uint32_t*)Z->chain_mb;
+      if (pv >= J.dyn_first) { dch0 = wh_ld_wg32 (cm + 4 * pv); dch1 = wh_ld_wg32 (cm + 4 * pv + 1); dch2 = wh_ld_wg32 (cm + 4 * pv + 2); dch3 = wh_ld_wg32 (cm + 4 * pv + 3); }
+      WV_LANES_BEGIN (lane)
+      if (lane == 0) { wh_st_wg32 (cm + 4 * xy, dch0); wh_st_wg32 (cm + 4 * xy + 1, dch1); wh_st_wg32 (cm + 4 * xy + 2, dch2); wh_st_wg32 (cm + 4 * xy + 3, dch3); }
+      WV_LANES_END
+    }
     for (int mode = 0; scd_on && mode < 2 && !done; ++mode) {        // STATIC, SCROLLED
       const int want = mode == 0 ? 1 : 2;                            // COLLOCATED_STATIC / SCROLLED_STATIC
       if (mode == 1 && !sflag) break;
@@ -1334,20 +1346,21 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
           else {
             WhSccMe z;
             z.job = Z; z.method = Z->fme ? 2 : 0; z.thr = Z->thr8; z.dir_on = scroll_on; z.dmx = smx; z.dmy = smy; z.fme_down = 0;
-            z.chain = scroll_on ? wh_ld_wg32 (chn + i) : 0u;
+            z.chain = !scroll_on ? 0u : !J.dyn_slice ? wh_ld_wg32 (chn + i) : i == 0 ? dch0 : i == 1 ? dch1 : i == 2 ? dch2 : dch3;
             wh_motion_search (S, P, J, W, C, m, mvcl, 1, &z);
             down += z.fme_down;
           }
           if (scroll_on) {           // what the next macroblock of the slice finds in sMe8x8[i].uiSadCost (WH_SEQ_SERIAL: coding order)
             WV_LANES_BEGIN (lane)
-            if (lane == 0) wh_st_wg32 (chn + i, (uint32_t)m.sad_cost);
+            if (lane == 0) wh_st_wg32 (J.dyn_slice ? (WH_G uint32_t*)Z->chain_mb + 4 * xy + i : chn + i, (uint32_t)m.sad_cost);
             WV_LANES_END
           }
           wh_cache_set (K, m.bx >> 2, m.by >> 2, m.bw >> 2, m.bh >> 2, 0, m.mvx, m.mvy);
           wh_me_store (T, WH_SLOT_8x8 + i, m);
           c += m.satd_cost;
         }
-        if (down) {
+        fme_down_mb = down;
+        if (down && !J.dyn_slice) {
           WV_LANES_BEGIN (lane)
           if (lane == 0) wh_atomic_add_u32 ((WH_G uint32_t*)Z->fme_cost_down + slice_idc, down);
           WV_LANES_END
@@ -1499,6 +1512,11 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
       if (ir.cbp > 0 || ir.mb_type == WH_MB_I16x16) ibits |= WH_BITS_HAS_QP_DELTA;
     }
     wh_store_mb (M, P, J, mbx, mby, ir.mb_type, ir.cbp, qp, qpc, ir.i16_mode_std, ir.chroma_mode_std, ir.cost_luma, slice_idc, ibits);
+    if (SCC && J.dyn_slice) {
+      WV_LANES_BEGIN (lane)
+      if (lane == 0) Rs->fme_down = 0;
+      WV_LANES_END
+    }
     return;
   }
   if (is_skip && b_skip) {
@@ -1547,6 +1565,11 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
     if (cbp > 0) pbits |= WH_BITS_HAS_QP_DELTA;
   }
   wh_store_mb (M, P, J, mbx, mby, mb_type, cbp, qp, qpc, 0, 0, cost_luma, slice_idc, pbits);
+  if (SCC && J.dyn_slice) {              // (size-limited slices: the host sums the macroblocks the entropy writer really took)
+    WV_LANES_BEGIN (lane)
+    if (lane == 0) ((WH_G WhMbRecord*)J.records + xy)->fme_down = fme_down_mb;
+    WV_LANES_END
+  }
   // what the picture keeps for the time it is a reference (WelsMdInterSaveSadAndRefMbType, WelsMdUpdateBGDInfo, both run
   // before the entropy writer): a background skip keeps its own type; pRefMbQp = uiLumaQp unless the MB is an unchanged
   // collocated one (no residual, zero vector, P reference), which inherits the reference's entry.  uiLumaQp at that point is

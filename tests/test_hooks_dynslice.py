@@ -10,7 +10,7 @@ macroblock a new slice begins with (WelsHipFrameJob::iDynSlice, include/welship.
 Checked here on the CPU test build of the kernels (tests/emu): random sessions byte for byte against the unmodified reference
 (tools/fuzz_dynslice.py: 421 .. 3000 bytes per slice, i.e. from slices shorter than a macroblock row -- dozens per picture -- to one
 slice per picture; all rate-control modes, temporal layers, LTR, denoising, background / scene-change detection, the three
-deblocking modes, I pictures in mid-stream, CAVLC and CABAC, one to four slice threads).  The reference table's own size-limited rows: tests/test_hooks_sha1.py.
+deblocking modes, I pictures in mid-stream, CAVLC and CABAC, one to four slice threads, camera video and screen content).  The reference table's own size-limited rows: tests/test_hooks_sha1.py.
 This path has not run on the MI355X yet (no GPU test): it is opt-in until it has.
 """
 import os
@@ -78,12 +78,26 @@ def test_installer_declines_without_the_switch(emu_lib, tmp_path):
                         "-slcsize", "600", "-threads", "1", "-rc", "-1", "-qp", "26"], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
     err = p.stderr.decode(errors="replace")
     assert p.returncode == 0 and "not installed" in err and "WELS_HIP_DYNSLICE" in err
-    # ... and screen content with size-limited slices stays on the C path even when asked
+    # ... and a simulcast session with size-limited slices stays on the C path even when asked
     env["WELS_HIP_DYNSLICE"] = "1"
     p = subprocess.run([os.path.join(REF, "ref_enc_hip"), "-i", src, "-w", "176", "-h", "144", "-o", str(tmp_path / "o.264"), "-quiet", "-slcmd", "3",
-                        "-slcsize", "600", "-threads", "1", "-rc", "-1", "-qp", "26", "-usage", "1"], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+                        "-slcsize", "600", "-threads", "1", "-rc", "-1", "-qp", "26", "-simulcast", "96", "80"], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
     err = p.stderr.decode(errors="replace")
-    assert p.returncode == 0 and "not installed" in err and "camera video" in err
+    assert p.returncode == 0 and "not installed" in err and "one spatial layer" in err
+
+
+def test_random_screen_content_sessions_on_emulation(emu_lib):
+    """Screen content (-usage 1) under size-limited slices: the chain of the 8x8 searches' costs is kept per macroblock then
+    (WhSccJob::chain_mb: a slice can begin, or a range be coded again, at any macroblock) and the feature search's cost-down sums travel
+    in the records (WhMbRecord::fme_down: the host adds up the macroblocks the writer really took)."""
+    import fuzz_dynslice
+    from concurrent.futures import ThreadPoolExecutor
+    with tempfile.TemporaryDirectory() as tmp:
+        with ThreadPoolExecutor(8) as ex:
+            res = list(ex.map(lambda s: fuzz_dynslice.one_case(s, emu_lib, tmp, True, 4, False, True), range(21000, 21016)))
+    bad = [(s, m) for s, m, ok in res if not ok]
+    assert not bad, bad[0]
+    assert sum(1 for _, m, _ in res if m.startswith("ok")) >= 12
 
 
 def test_random_sessions_with_slice_threads_on_emulation(emu_lib):

@@ -125,6 +125,29 @@ def test_size_limited_rows_stay_on_the_c_path(workdir, emu_lib):
     assert "not installed" in err and pictures == 0 and got == row[0]
 
 
+def _size_limited_rows(threads=("1",)):
+    return [r for r in _rows() if r[4]["-slcmd 0"] == "3" and r[4]["-thread"] in threads]
+
+
+def test_size_limited_rows_on_emulation(workdir, emu_lib):
+    """... unless asked for (WELS_HIP_DYNSLICE=1): the device codes ahead of the entropy writer, the chain of the 8x8 searches
+    is kept per macroblock.  A sample of the 128 single-thread rows (and, on a machine with four cores, of the 128 that take the core
+    count); all 256: profiles/r02_size_limited_slices_emulation.txt (tools/sha1_table_rows.py --table adobe --dynslice)."""
+    from concurrent.futures import ThreadPoolExecutor
+    rows = _size_limited_rows()
+    assert len(rows) == 128
+    rows = rows[::8] + (_size_limited_rows(("0",))[::16] if (os.cpu_count() or 1) >= 4 else [])
+
+    def one(ir):
+        i, row = ir
+        got, pictures, err = _run_row(workdir, emu_lib, row, "d%d" % i, {"WELS_HIP_DYNSLICE": "1"})
+        return None if (got == row[0] and "welship hooks: installed" in err and err.count("picture complete") >= 1) else (row[4], got)
+
+    with ThreadPoolExecutor(8) as ex:
+        bad = [b for b in ex.map(one, enumerate(rows)) if b]
+    assert not bad, "%d rows differ, first: %s" % (len(bad), bad[0])
+
+
 API_GOLDEN_SCREEN = [  # test/api/encoder_test.cpp:146-157 (SEncParamBase, SCREEN_CONTENT_REAL_TIME: RC quality mode, 5 Mbps, one slice)
     ("CiscoVT2people_320x192_12fps.yuv", 320, 192, 12.0, "fd57470eebb9b334e8edcb8b47f7fb5b5868f111"),
     ("CiscoVT2people_160x96_6fps.yuv", 160, 96, 6.0, "5f63e723c3ec82fad186b48fcbcfb54730ce3b26"),

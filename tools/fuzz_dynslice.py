@@ -21,9 +21,10 @@ from concurrent.futures import ThreadPoolExecutor
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = os.path.join(ROOT, "oracle", "_ref")
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
-def one_case(seed, lib, tmp, verbose=False, max_threads=1, low_qp=False):
+def one_case(seed, lib, tmp, verbose=False, max_threads=1, low_qp=False, screen=False):
     from openh264_amd.utils.synth import make_sequence
     rng = random.Random(seed)
     w = 16 * rng.randint(4, 40) - rng.choice((0, 0, 0, 2, 8))
@@ -53,6 +54,15 @@ def one_case(seed, lib, tmp, verbose=False, max_threads=1, low_qp=False):
         flags += ["-nalsize", str(rng.choice((800, 1000, 1500)))]
     if rng.randint(0, 3) == 0:
         flags += ["-cabac", "1", "-profile", str(rng.choice((77, 100)))]
+    if screen:         # screen content (tools/fuzz_screen.py's synthetic documents: still, scrolling, jumping): static / scrolled skips, the
+        import fuzz_screen         # cross and feature searches and the chain of the 8x8 searches' costs, all under size-limited slices
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        w, h = max(64, w & ~1), max(64, h & ~1)
+        n = rng.randint(5, 10)
+        yuv = fuzz_screen.make_clip(w, h, n, seed)
+        flags += ["-usage", "1"]
+        if "-bitrate" in flags:
+            flags[flags.index("-bitrate") + 1] = str(rng.choice((150000, 450000, 2400000)))
     src = os.path.join(tmp, "c%d.yuv" % seed)
     open(src, "wb").write(yuv)
     base = ["-i", src, "-w", str(w), "-h", str(h), "-fps", "30", "-quiet"] + flags
@@ -94,6 +104,7 @@ def main():
     ap.add_argument("--workers", type=int, default=8)
     ap.add_argument("-v", action="store_true")
     ap.add_argument("--low-qp", action="store_true", help="constant QP 0..12 on saturated content: the re-encode after a CAVLC level overflow inside size-limited slices")
+    ap.add_argument("--screen", action="store_true", help="screen-content sessions (-usage 1) on synthetic documents")
     ap.add_argument("--threads", type=int, default=1, help="slice threads up to this many (one partition of the picture per thread)")
     a = ap.parse_args()
     from openh264_amd import build as B
@@ -101,7 +112,7 @@ def main():
     bad = 0
     with tempfile.TemporaryDirectory() as tmp:
         with ThreadPoolExecutor(a.workers) as ex:
-            for seed, msg, ok in ex.map(lambda s: one_case(s, lib, tmp, a.v, a.threads, a.low_qp), range(a.seed * 1000, a.seed * 1000 + a.cases)):
+            for seed, msg, ok in ex.map(lambda s: one_case(s, lib, tmp, a.v, a.threads, a.low_qp, a.screen), range(a.seed * 1000, a.seed * 1000 + a.cases)):
                 print("%6d %s" % (seed, msg), flush=True)
                 bad += 0 if ok else 1
     print("%d cases, %d failed (library %s)" % (a.cases, bad, os.path.basename(lib)))

@@ -2,7 +2,7 @@
 BA_MW_D.264_AllCases_SHA1_Table.csv, camera video; Adobe_PDF_sample_a_1024x768_50Frms.264_AllCases_SHA1_Table.csv, screen
 content) through the dispatch-table binding, the way tests/test_hooks_sha1.py / tests/test_hooks_screen.py run their samples.
 usage: sha1_table_rows.py [--table ba|adobe] [--lib path] [--workers N] [--stride K] [--dynslice]      (default library: openh264_amd/libwelship.so)
---dynslice: the camera table's 512 size-limited rows (-slcmd 3; half of them with as many slice threads as the machine has cores, up to four)
+--dynslice: the table's size-limited rows (-slcmd 3: 512 / 256; half of them with as many slice threads as the machine has cores, up to four)
 with WELS_HIP_DYNSLICE=1 instead."""
 import argparse, os, pathlib, subprocess, sys, tempfile, time
 from concurrent.futures import ThreadPoolExecutor
@@ -31,7 +31,7 @@ def main():
     for k in range(4):
         (d / ("layer%d.cfg" % k)).write_bytes(open(os.path.join(T.RES, "layer2.cfg"), "rb").read())
     (d / "welsenc.cfg").write_bytes(open(os.path.join(T.RES, "welsenc.cfg"), "rb").read())
-    rows = (T_BA._size_limited_rows(("0", "1")) if a.dynslice else T._device_rows())[::a.stride]
+    rows = (T._size_limited_rows(("0", "1")) if a.dynslice else T._device_rows())[::a.stride]
     t0 = time.time()
 
     def one(ir):
