@@ -285,6 +285,10 @@ typedef struct WelsHipFrameJob {
   /* on, with pReencode / iNumReencode (bRetry stays 0) -- and every later call of the picture, the closing one included, carries the list. */
   /* bRangeAgain = 1 marks such a repeated call: even when it begins at macroblock 0 the picture's inputs are not uploaded again.           */
   int32_t bRangeAgain;
+  /* Size-limited slices: the range's first macroblock is decided for the second time in this picture -- the slice begins with the        */
+  /* macroblock the writer took back, or bRangeAgain -- and finds what its first pass left in the layer's pSadCost array                  */
+  /* (WelsMdInterSaveSadAndRefMbType runs before the writer), every other macroblock what the previous picture left.                      */
+  int32_t bDynRedoFirst;
 } WelsHipFrameJob;
 typedef struct WelsHipGomRc {
   int32_t iNumberMbGom;             /* pWelsSvcRc->iNumberMbGom: whole macroblock rows (else WELSHIP_ERR_UNSUPPORTED: code the groups one by one) */

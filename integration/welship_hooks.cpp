@@ -161,7 +161,7 @@ bool FrameConstantQp (const sWelsEncCtx* pCtx) {
 // Size-limited slices: the device codes [iFrom, ...) of partition iPart as macroblocks of slice iSliceIdx, which begins at iSliceFirst --
 // about one and a half slices' worth (what the last slices of this picture type were long in this partition), the rest of the
 // partition when nothing is known yet.  L.job (prepared by HipFrameMd) is read-only here: slice tasks call this concurrently.
-int32_t DynCode (HipState* st, HipLayer& L, int iPart, int iSliceIdx, int iSliceFirst, int iFrom, bool is_p, int iPartEnd) {
+int32_t DynCode (HipState* st, HipLayer& L, int iPart, int iSliceIdx, int iSliceFirst, int iFrom, bool is_p, int iPartFirst, int iPartEnd) {
   HipLayer::DynPart& P = L.part[iPart];
   const int est = P.est[is_p ? 1 : 0];
   int end = est > 0 ? iFrom + WELS_MAX (est + (est >> 1), 16) : iPartEnd;
@@ -171,6 +171,7 @@ int32_t DynCode (HipState* st, HipLayer& L, int iPart, int iSliceIdx, int iSlice
   jb.pSliceFirstMb = &L.first[0];
   jb.iMbBegin = iFrom; jb.iMbEnd = end;
   jb.iDynSlice = iSliceIdx + 1; jb.iDynSliceFirstMb = iSliceFirst;
+  jb.bDynRedoFirst = (iFrom == iSliceFirst && iSliceFirst != iPartFirst) ? 1 : 0;      // a slice inside a partition begins with the macroblock the writer took back
   // macroblocks coded again after a CAVLC overflow (TRY_REENCODING in HipCodeSlice): every later call of the picture carries them.  A
   // macroblock a slice BEGINS with is decided from scratch (pfWelsRcMbInit and the Init functions run again in the reference): what was
   // noted for it, or for anything behind it, belongs to the slice before
@@ -364,7 +365,7 @@ int32_t HipFrameMd (sWelsEncCtx* pCtx) {
                             pCurLayer->sSliceEncCtx.uiSliceSizeConstraint, nparts, nparts == 1 ? "" : "s", job.iCurPic, job.iRefPic, job.bDeblock, job.bExpand);
     // The first macroblocks of the picture now (slice 0 begins at macroblock 0 whatever happens): this call also takes the picture's
     // inputs to the device, before any partition's task asks for its macroblocks.
-    const int rcd = DynCode (st, L, 0, 0, 0, 0, is_p, nparts == 1 ? num_mb : pCurLayer->EndMbIdxOfPartition[0] + 1);
+    const int rcd = DynCode (st, L, 0, 0, 0, 0, is_p, 0, nparts == 1 ? num_mb : pCurLayer->EndMbIdxOfPartition[0] + 1);
     if (rcd) return rcd;
     return ENC_RETURN_SUCCESS;
   }
@@ -455,6 +456,7 @@ int32_t HipCodeSlice (sWelsEncCtx* pCtx, SSlice* pSlice) {
   uint32_t uiDynFmeDown = 0;
   const int32_t kiPartitionId = kiSliceIdx % pCtx->iActiveThreadsNum;
   const int32_t kiDynPartEnd = pCtx->iActiveThreadsNum == 1 ? kiTotalNumMb : pCurLayer->EndMbIdxOfPartition[kiPartitionId] + 1;
+  const int32_t kiDynPartFirst = pCtx->iActiveThreadsNum == 1 ? 0 : pCurLayer->FirstMbIdxOfPartition[kiPartitionId];
   if (L.dyn) {      // WelsMdInterMbLoopOverDynamicSlice / WelsISliceMdEncDynamic (svc_encode_slice.cpp:1925-1931,620-626)
     if (kbCavlc) sDss.iStartPos = BsGetBitsPos (pSlice->pSliceBsa);
     else { sDss.iStartPos = sDss.iCurrentPos = 0; sDss.pRestoreBuffer = pCtx->pDynamicBsBuffer[kiPartitionId]; }
@@ -495,7 +497,7 @@ int32_t HipCodeSlice (sWelsEncCtx* pCtx, SSlice* pSlice) {
       // The slice begins here, or the device has not coded this far ahead yet.  What an earlier call coded from here on belonged to
       // the slice before (other neighbours for the macroblocks of the first rows, other predictors after them) and is coded again.
       Stopwatch sw (st->timing && pCtx->iActiveThreadsNum == 1 ? &st->t_encode : NULL);
-      const int rcd = DynCode (st, L, kiPartitionId, kiSliceIdx, kiSliceFirstMbXY, iCurMbIdx, is_p, kiDynPartEnd);
+      const int rcd = DynCode (st, L, kiPartitionId, kiSliceIdx, kiSliceFirstMbXY, iCurMbIdx, is_p, kiDynPartFirst, kiDynPartEnd);
       if (rcd) return rcd;
     }
     bool bInitDone = false;
@@ -539,6 +541,7 @@ TRY_REENCODING:
       }
       const int32_t iRun = pFunc->pfStashPopMBStatus (&sDss, pSlice);
       pSlice->iMbSkipRun = iRun;
+      uiDynFmeDown += R.fme_down;        // (every pass of the macroblock's searches counts in the reference)
       const uint8_t kuiChromaQpIndexOffset = pCurLayer->sLayerInfo.pPpsP->uiChromaQpIndexOffset;
       pCurMb->uiLumaQp += DELTA_QP;                      // UpdateQpForOverflow (svc_encode_slice.cpp:526-530)
       pCurMb->uiChromaQp = g_kuiChromaQpTable[CLIP3_QP_0_51 (pCurMb->uiLumaQp + kuiChromaQpIndexOffset)];
@@ -560,7 +563,7 @@ TRY_REENCODING:
         jb.pSliceFirstMb = &L.first[0];
         jb.iMbBegin = iCurMbIdx; jb.iMbEnd = L.part[kiPartitionId].coded_upto;
         jb.iDynSlice = kiSliceIdx + 1; jb.iDynSliceFirstMb = kiSliceFirstMbXY;
-        jb.pReencode = &list[0]; jb.iNumReencode = (int32_t)list.size(); jb.bRangeAgain = 1;
+        jb.pReencode = &list[0]; jb.iNumReencode = (int32_t)list.size(); jb.bRangeAgain = 1; jb.bDynRedoFirst = 1;
         const void* rec = NULL;
         const int rc = g_api.FrameEncode (L.ctx, &jb, &rec);
         if (rc) { fprintf (stderr, "welship hooks: WelsHipFrameEncode (re-encoding MB %d at QP %d) failed (%d: %s)\n", iCurMbIdx, pCurMb->uiLumaQp, rc, g_api.GetLastError()); st->failed = true; return ENC_RETURN_UNEXPECTED; }
@@ -587,6 +590,7 @@ TRY_REENCODING:
       // bitstream goes back to where the macroblock began, the slice ends before it and the next slice begins WITH it
       sDss.iCurrentPos = pFunc->pfGetBsPosition (pSlice);
       if (DynSlcJudgeSliceBoundaryStepBack (pCtx, pSlice, pSliceCtx, pCurMb, &sDss)) {
+        uiDynFmeDown += R.fme_down;      // (the reference's feature search has added this macroblock's share to THIS slice before the slice ended in front of it)
         const int32_t iRun = pFunc->pfStashPopMBStatus (&sDss, pSlice);
         if (is_p) pSlice->iMbSkipRun = iRun;
         pCurLayer->LastCodedMbIdxOfPartition[kiPartitionId] = iCurMbIdx - 1;

@@ -182,6 +182,14 @@ typedef struct WhPicJob {
   // P pictures coded with GOM-level rate control inside the kernel (also WH_SEQ_CHAIN: the groups are bands of the processing order,
   // every macroblock of a group additionally waits for the last macroblock of the group before it): inputs + state, or NULL
   WhGomRc* gom_rc;
+  // Size-limited slices code macroblocks AHEAD of the entropy writer and some of them twice (dyn_slice): pSadCost[0] of the layer then has
+  // two copies -- sad_cost0 as the previous picture left it (read: a P_Skip above LOW complexity keeps the macroblock's old entry) and
+  // sad_cost0_out (written; the context swaps the two when the picture is complete).  One macroblock reads the NEW copy: the first one of
+  // a launch that decides it for the second time (dyn_redo: a slice begins with the macroblock the writer took back, or a macroblock is
+  // coded again after a CAVLC overflow) -- the reference's first pass has overwritten its entry by then (WelsMdInterSaveSadAndRefMbType).
+  int32_t*       sad_cost0_out;
+  int32_t        dyn_redo;
+  int32_t        pad5;
 } WhPicJob;
 
 #define WH_MAX_SLICES 36

@@ -1264,6 +1264,7 @@ struct WelsHipFrameCtx {
   WhMbCtl* d_mb_ctl = nullptr;
   std::vector<WhMbCtl> h_mb_ctl;
   int32_t* d_sad_cost0 = nullptr;        // the layer's pSadCost[0] array (persists across pictures)
+  int32_t* d_sad_cost0_new = nullptr;    // size-limited slices: the copy the picture being coded writes (WhPicJob::sad_cost0_out), swapped in when it is complete
   int32_t* d_vaa = nullptr;
   int8_t* d_bgd = nullptr;
   int16_t* d_il = nullptr;
@@ -1296,7 +1297,7 @@ struct WelsHipFrameCtx {
     be->sync();
     for (auto& p : pics) { if (p.base) be->free (p.base); if (p.mbs) be->free (p.mbs); }
     pics.clear();
-    void* ptrs[] = {d_src, d_records, d_dbflags, d_mb_ctl, d_sad_cost0, d_vaa, d_bgd, d_il, d_job, d_scc, d_scc_idc, d_scc_ori, d_scc_chain, d_scc_lists, d_scc_loc, d_scc_order, d_scc_chain_mb, d_gom_rc};
+    void* ptrs[] = {d_src, d_records, d_dbflags, d_mb_ctl, d_sad_cost0, d_vaa, d_bgd, d_il, d_job, d_scc, d_scc_idc, d_scc_ori, d_scc_chain, d_scc_lists, d_scc_loc, d_scc_order, d_scc_chain_mb, d_gom_rc, d_sad_cost0_new};
     if (!h_gom.empty()) be->unpin_host (h_gom.data());
     if (!h_scc.empty()) be->unpin_host (h_scc.data());
     if (!h_scc_small.empty()) be->unpin_host (h_scc_small.data());
@@ -1826,6 +1827,13 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
   job.db_flags = c->d_dbflags;
   job.db_gen = c->db_gen;
   job.sad_cost0 = c->d_sad_cost0;
+  if (dyn) {
+    if (j->pSadCost) { set_err ("size-limited slices: single-layer sessions only"); return WELSHIP_ERR_INIT_PARA; }
+    if (!c->d_sad_cost0_new) { c->d_sad_cost0_new = (int32_t*)be->alloc (sizeof (int32_t) * c->num_mb); if (c->d_sad_cost0_new) be->fill (c->d_sad_cost0_new, 0, sizeof (int32_t) * c->num_mb); }
+    if (!c->d_sad_cost0_new) { set_err ("out of device memory"); return WELSHIP_ERR_MEMORY; }
+    job.sad_cost0_out = c->d_sad_cost0_new;
+    job.dyn_redo = j->bDynRedoFirst ? 1 : 0;
+  }
   job.vaa_sad8x8 = is_p && j->pVaaSad8x8 ? c->d_vaa : nullptr;
   job.bgd_flags = is_p && j->pBgdFlags ? c->d_bgd : nullptr;
   job.mvc_shift = j->iMvcShift;
@@ -1854,6 +1862,7 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
       if (s.deblock_idc != 1) be->run_deblock (s, c->d_job, 1);
       if (j->bExpand) be->run_expand (s, c->d_job, 1);
       cur.is_p = is_p;
+      if (dyn) std::swap (c->d_sad_cost0, c->d_sad_cost0_new);       // every macroblock of the picture has written its entry of the new copy
       if (j->pSadCost) be->download (j->pSadCost, c->d_sad_cost0, sizeof (int32_t) * c->num_mb);
       if (scr) be->download (c->scc_down(), c->d_scc_chain + 4 * WH_MAX_SLICES, sizeof (uint32_t) * WH_MAX_SLICES);
     }

@@ -139,7 +139,7 @@ WH_FN void wh_intra_mb_body (WhMbLds& S, const WhSeqParams& P, const WhPicJob& J
   if (lane < 4) { Ms->ref_idx[lane] = -1; Rs->ref_idx[lane] = -1; Rs->sub_type[lane] = 0; Ms->sad_cost[lane] = 0; }
   // pSadCost[0] = 0 (WelsMdIntraSecondaryModesEnc, svc_base_layer_md.cpp:2038) -- in the layer's array too, where a P_Skip of a later
   // picture that is not costed by SAD (complexity above LOW) finds it (found by tools/fuzz_screen.py: an I picture in mid-stream)
-  if (lane == 0 && J.sad_cost0) ((WH_G int32_t*)J.sad_cost0)[xy] = 0;
+  if (lane == 0 && J.sad_cost0) (J.sad_cost0_out ? (WH_G int32_t*)J.sad_cost0_out : (WH_G int32_t*)J.sad_cost0)[xy] = 0;
   WV_LANES_END
   int bits = 0;
   if (J.want_bits) {

@@ -871,7 +871,7 @@ WH_FN void wh_inter_cold_fetch (WhInterStage& G, int lane, const WhSeqParams& P,
   }
   // pSadCost[0] of the layer's SMB array (cold_co word 38); the host's four VAA SADs take the place of the previous source
   // picture's first words (cold_pv 0..3, read by wh_inter_mb_body straight from the staging area)
-  if (lane == 38 && J.sad_cost0) wh_ld_async4 ((const WH_G int32_t*)J.sad_cost0 + xy, G.cold_co, lane);
+  if (lane == 38 && J.sad_cost0) wh_ld_async4 ((J.sad_cost0_out && J.dyn_redo && xy == J.mb_begin ? (const WH_G int32_t*)J.sad_cost0_out : (const WH_G int32_t*)J.sad_cost0) + xy, G.cold_co, lane);
   if (lane < 4 && J.vaa_sad8x8) wh_ld_async4 ((const WH_G int32_t*)J.vaa_sad8x8 + xy * 4 + lane, G.cold_pv, lane);
 }
 
@@ -1503,7 +1503,7 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
     if (lane < 16) { Ms->mv[lane][0] = 0; Ms->mv[lane][1] = 0; Rs->mvd[lane][0] = 0; Rs->mvd[lane][1] = 0; }
     if (lane < 2) Rs->mv_tr[lane] = 0;
     if (lane < 4) { Ms->ref_idx[lane] = -1; Rs->ref_idx[lane] = -1; Rs->sub_type[lane] = 0; }
-    if (lane == 0) { Ms->sad_cost[0] = 0; Ms->p16mv[0] = (int16_t)p16x; Ms->p16mv[1] = (int16_t)p16y; Ms->skip_sad = 0; if (J.sad_cost0) ((WH_G int32_t*)J.sad_cost0)[xy] = 0; }
+    if (lane == 0) { Ms->sad_cost[0] = 0; Ms->p16mv[0] = (int16_t)p16x; Ms->p16mv[1] = (int16_t)p16y; Ms->skip_sad = 0; if (J.sad_cost0) (J.sad_cost0_out ? (WH_G int32_t*)J.sad_cost0_out : (WH_G int32_t*)J.sad_cost0)[xy] = 0; }
     WV_LANES_END
     int ibits = 0;
     if (J.want_bits) {
@@ -1547,7 +1547,7 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
   if (lane == 0) {
     Ms->sad_cost[0] = sad_cost0; Ms->p16mv[0] = (int16_t)p16x; Ms->p16mv[1] = (int16_t)p16y;
     Ms->skip_sad = is_skip ? cost_skip_mb : 0;
-    if (J.sad_cost0) ((WH_G int32_t*)J.sad_cost0)[xy] = sad_cost0;
+    if (J.sad_cost0) (J.sad_cost0_out ? (WH_G int32_t*)J.sad_cost0_out : (WH_G int32_t*)J.sad_cost0)[xy] = sad_cost0;
   }
   WV_LANES_END
   int pbits = 0;

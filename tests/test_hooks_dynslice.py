@@ -59,7 +59,7 @@ def test_reencoding_after_cavlc_overflow_inside_size_limited_slices(emu_lib):
     import fuzz_dynslice
     from concurrent.futures import ThreadPoolExecutor
     with tempfile.TemporaryDirectory() as tmp:
-        with ThreadPoolExecutor(4) as ex:
+        with ThreadPoolExecutor(3) as ex:
             res = list(ex.map(lambda s: fuzz_dynslice.one_case(s, emu_lib, tmp, True, 4, True), range(11012, 11024)))
     bad = [(s, m) for s, m, ok in res if not ok]
     assert not bad, bad[0]
@@ -93,7 +93,7 @@ def test_random_screen_content_sessions_on_emulation(emu_lib):
     import fuzz_dynslice
     from concurrent.futures import ThreadPoolExecutor
     with tempfile.TemporaryDirectory() as tmp:
-        with ThreadPoolExecutor(8) as ex:
+        with ThreadPoolExecutor(3) as ex:      # (few at a time: with slice threads the reference's own output can depend on the machine's load, see tools/fuzz_dynslice.py)
             res = list(ex.map(lambda s: fuzz_dynslice.one_case(s, emu_lib, tmp, True, 4, False, True), range(21000, 21016)))
     bad = [(s, m) for s, m, ok in res if not ok]
     assert not bad, bad[0]
@@ -106,7 +106,7 @@ def test_random_sessions_with_slice_threads_on_emulation(emu_lib):
     import fuzz_dynslice
     from concurrent.futures import ThreadPoolExecutor
     with tempfile.TemporaryDirectory() as tmp:
-        with ThreadPoolExecutor(4) as ex:
+        with ThreadPoolExecutor(3) as ex:
             res = list(ex.map(lambda s: fuzz_dynslice.one_case(s, emu_lib, tmp, True, 4), range(5000, 5012)))
     bad = [(s, m) for s, m, ok in res if not ok]
     assert not bad, bad[0]

@@ -91,8 +91,21 @@ def one_case(seed, lib, tmp, verbose=False, max_threads=1, low_qp=False, screen=
             if "welship hooks: installed" not in err or not done:
                 os.remove(src)
                 return seed, "NOT ON THE DEVICE %s\n%s" % (" ".join(flags), err[-400:]), False
-    os.remove(src)
     ok = outs[0] == outs[1]
+    if not ok and threads > 1:
+        # With slice threads the unmodified reference is not always deterministic itself (rate control, screen content: its output depends
+        # on how the slice tasks interleave -- seen as two to four different streams of one command line on a loaded machine, from the
+        # reference alone and from the reference with the hooks alike): accept what the reference produces on any of a few more runs -- and say so
+        for k in range(12):
+            out = os.path.join(tmp, "o%d_again.264" % seed)
+            subprocess.run([os.path.join(REF, "ref_enc")] + base + ["-o", out], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            again = open(out, "rb").read()
+            os.remove(out)
+            if again == outs[1]:
+                ok = True
+                info += " (the reference's own output varies between runs of this command: matched on run %d)" % (k + 2)
+                break
+    os.remove(src)
     return seed, ("ok   " if ok else "DIFF ") + info + ("" if ok and not verbose else "  " + " ".join(flags)), ok
 
 
