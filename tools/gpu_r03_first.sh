@@ -13,7 +13,10 @@ timeout 120 python -m pytest tests -m gpu -q -n 4 > $o/pytest_gpu.txt 2>&1; tail
 timeout 40 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $o/smoke.txt 2>&1; tail -1 $o/smoke.txt
 timeout 200 python tools/sha1_table_rows.py --dynslice --workers 16 > $o/size_limited_rows_mi355x.txt 2>&1; tail -4 $o/size_limited_rows_mi355x.txt
 timeout 200 python tools/fuzz_dynslice.py --lib openh264_amd/libwelship.so --cases 60 --seed 7 --workers 16 > $o/fuzz_dynslice_mi355x.txt 2>&1; tail -1 $o/fuzz_dynslice_mi355x.txt
-timeout 200 python tools/fuzz_dynslice.py --lib openh264_amd/libwelship.so --cases 40 --seed 5 --threads 4 --workers 16 > $o/fuzz_dynslice_threads_mi355x.txt 2>&1; tail -1 $o/fuzz_dynslice_threads_mi355x.txt
+timeout 200 python tools/fuzz_dynslice.py --lib openh264_amd/libwelship.so --cases 40 --seed 5 --threads 4 --workers 4 > $o/fuzz_dynslice_threads_mi355x.txt 2>&1; tail -1 $o/fuzz_dynslice_threads_mi355x.txt
+timeout 200 python tools/sha1_table_rows.py --table adobe --dynslice --workers 16 --stride 4 > $o/size_limited_rows_screen_mi355x.txt 2>&1; tail -4 $o/size_limited_rows_screen_mi355x.txt
+timeout 200 python tools/fuzz_dynslice.py --lib openh264_amd/libwelship.so --cases 40 --seed 21 --screen --workers 16 > $o/fuzz_dynslice_screen_mi355x.txt 2>&1; tail -1 $o/fuzz_dynslice_screen_mi355x.txt
+timeout 200 python tools/fuzz_dynslice.py --lib openh264_amd/libwelship.so --cases 24 --seed 11 --low-qp --workers 16 > $o/fuzz_dynslice_lowqp_mi355x.txt 2>&1; tail -1 $o/fuzz_dynslice_lowqp_mi355x.txt
 for tag in "" _flatnb _early; do
   lib=$PWD/openh264_amd/libwelship$tag.so; [ -f $lib ] || continue
   WELSHIP_LIB=$lib timeout 60 python bench.py --quick --steps 60 > $o/bench_quick$tag.json 2> $o/bench_quick$tag.err
