@@ -56,7 +56,7 @@ __device__ __forceinline__ WhMbLds& wh_prof_holder (WhDbLds& S) { return * (WhMb
 template <class T> __device__ __forceinline__ uint32_t* wh_prof_lds (T& S) { return wh_prof_holder (S).prof; }
 
 __device__ __forceinline__ void wh_copy_job (WhPicJob* dst, const WhPicJob* src) {
-  if (threadIdx.x < sizeof (WhPicJob) / 4) ((uint32_t*)dst)[threadIdx.x] = ((const uint32_t*)src)[threadIdx.x];
+  for (unsigned i = threadIdx.x; i < sizeof (WhPicJob) / 4; i += blockDim.x) ((uint32_t*)dst)[i] = ((const uint32_t*)src)[i];      // (a one-wave workgroup has fewer threads than the descriptor has words)
 }
 
 #define WH_DEFINE_MB_KERNEL(NAME, LDS_T, BODY, MAX_THREADS, WHOLE_PICTURE, PROF)                                             \
