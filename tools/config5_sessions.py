@@ -18,18 +18,23 @@ SIMULCAST = len(sys.argv) > 3 and sys.argv[3] == "simulcast"
 SCREEN = len(sys.argv) > 3 and sys.argv[3] == "screen"
 # third argument "gom": the 720p sessions with ONE slice per picture (GOM-level QP; set WELS_HIP_GOM=1 or 2, else the hooks decline)
 GOM = len(sys.argv) > 3 and sys.argv[3] == "gom"
+# third argument "dynslice": the 720p sessions with size-limited slices of 1200 bytes (what an RTP caller asks for; WELS_HIP_DYNSLICE=1 is set here)
+DYNSLICE = len(sys.argv) > 3 and sys.argv[3] == "dynslice"
 LIB = os.environ.get("WELSHIP_LIB") or os.path.join(ROOT, "openh264_amd", "libwelship.so")
 W, H = (1920, 1080) if SIMULCAST else (1024, 768) if SCREEN else (1280, 720)
 
 
 def run(tmp, yuv, hip):
     env = dict(os.environ, WELSHIP_LIB=LIB, WELS_HIP="1" if hip else "0", WELS_HIP_TRACE="1")
+    if DYNSLICE:
+        env["WELS_HIP_DYNSLICE"] = "1"
     out = os.path.join(tmp, "s_%d.264" % hip)
     cmd = [os.path.join(REF, "ref_enc_hip"), "-parallel", str(N), "-i", yuv, "-w", str(W), "-h", str(H), "-o", out, "-frames", str(FRAMES),
            "-fps", "30", "-rc", "1", "-bitrate", "1500000", "-threads", "1", "-iper", "0", "-quiet"]
     cmd += (["-slcmd", "1", "-slcnum", "4", "-simulcast", "240", "135", "-simulcast", "480", "270", "-simulcast", "960", "540"] if SIMULCAST
             else ["-usage", "1", "-slcmd", "1", "-slcnum", "4", "-scene", "1", "-denoise", "1", "-frameskip", "1"] if SCREEN
             else ["-slcmd", "0"] if GOM
+            else ["-slcmd", "3", "-slcsize", "1200"] if DYNSLICE
             else ["-slcmd", "2", "-slcmbnum", "900"])
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert p.returncode == 0, p.stderr[-2000:]
@@ -38,6 +43,9 @@ def run(tmp, yuv, hip):
     enc_fps = [float(x) for x in re.findall(rb" fps=([0-9.]+)", p.stdout)]
     wall = float(re.search(rb"wall_seconds=([0-9.]+)", p.stdout).group(1))
     pictures = p.stderr.count(b"welship hooks: did")
+    if DYNSLICE and hip:
+        done = [l for l in p.stderr.decode(errors="replace").splitlines() if "picture complete" in l]
+        run.dyn = {"slices": sum(int(l.split("complete:")[1].split()[0]) for l in done), "device_calls": sum(int(l.split("slices,")[1].split()[0]) for l in done)}
     sha = [hashlib.sha1(open("%s.%d" % (out, i), "rb").read()).hexdigest() for i in range(N)]
     return {"wall_s_incl_init": wall, "sum_of_session_encode_fps": sum(enc_fps), "min_session_fps": min(enc_fps), "max_session_fps": max(enc_fps),
             "device_pictures": pictures}, sha
@@ -51,7 +59,7 @@ def main():
         nfr = os.path.getsize(yuv) // (W * H * 3 // 2)
         c_leg, c_sha = run(tmp, yuv, False)
         h_leg, h_sha = run(tmp, yuv, True)
-        print(json.dumps({"config": "%d concurrent sessions, %dx%d, %d frames each (clip has %d), RC bitrate mode 1.5 Mbps per layer, %s, one process, one thread per session" % (N, W, H, FRAMES, nfr, "4 simulcast AVC layers of 4 slices" if SIMULCAST else "screen content, 4 slices" if SCREEN else "one slice (GOM-level QP, WELS_HIP_GOM=%s)" % os.environ.get("WELS_HIP_GOM", "unset") if GOM else "raster slices of 900 MBs"),
+        print(json.dumps({"config": "%d concurrent sessions, %dx%d, %d frames each (clip has %d), RC bitrate mode 1.5 Mbps per layer, %s, one process, one thread per session" % (N, W, H, FRAMES, nfr, "4 simulcast AVC layers of 4 slices" if SIMULCAST else "screen content, 4 slices" if SCREEN else "one slice (GOM-level QP, WELS_HIP_GOM=%s)" % os.environ.get("WELS_HIP_GOM", "unset") if GOM else "size-limited slices of 1200 bytes (WELS_HIP_DYNSLICE=1): %s" % getattr(run, "dyn", None) if DYNSLICE else "raster slices of 900 MBs"),
                           "reference_c_path": c_leg, "hooks_on_device": h_leg, "same_bitstreams": c_sha == h_sha, "lib": os.path.basename(LIB)}))
 
 

@@ -17,6 +17,7 @@ timeout 200 python tools/fuzz_dynslice.py --lib openh264_amd/libwelship.so --cas
 timeout 200 python tools/sha1_table_rows.py --table adobe --dynslice --workers 16 --stride 4 > $o/size_limited_rows_screen_mi355x.txt 2>&1; tail -4 $o/size_limited_rows_screen_mi355x.txt
 timeout 200 python tools/fuzz_dynslice.py --lib openh264_amd/libwelship.so --cases 40 --seed 21 --screen --workers 16 > $o/fuzz_dynslice_screen_mi355x.txt 2>&1; tail -1 $o/fuzz_dynslice_screen_mi355x.txt
 timeout 200 python tools/fuzz_dynslice.py --lib openh264_amd/libwelship.so --cases 24 --seed 11 --low-qp --workers 16 > $o/fuzz_dynslice_lowqp_mi355x.txt 2>&1; tail -1 $o/fuzz_dynslice_lowqp_mi355x.txt
+WELSHIP_FRAME_STATS=1 timeout 120 python tools/config5_sessions.py 8 40 dynslice > $o/config5_dynslice_8sessions.json 2> $o/config5_dynslice.err; cut -c1-700 $o/config5_dynslice_8sessions.json
 for tag in "" _flatnb _early; do
   lib=$PWD/openh264_amd/libwelship$tag.so; [ -f $lib ] || continue
   WELSHIP_LIB=$lib timeout 60 python bench.py --quick --steps 60 > $o/bench_quick$tag.json 2> $o/bench_quick$tag.err
