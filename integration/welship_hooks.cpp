@@ -113,6 +113,7 @@ struct HipLayer {                       // one spatial layer = one device contex
   } part[MAX_THREADS_NUM];
   std::mutex dyn_mu;                     // the counters below (slice tasks of a picture run concurrently)
   int dyn_calls = 0, dyn_slices = 0, dyn_parts_left = 0;
+  long dyn_mbs_coded = 0;                // macroblocks the device coded for the picture, the ones coded in vain (ahead of a slice end) included
   WelsHipGomRc gomrc;                    // GOM-level rate control inside the kernel (WELS_HIP_GOM=2): the picture's rate-control inputs
   WelsHipScreenInfo screen;              // screen content: the pre-processing's results of the picture being coded
   std::vector<uint32_t> fme_down;        //   and what the device reports back per slice (uiSliceFMECostDown)
@@ -190,6 +191,7 @@ int32_t DynCode (HipState* st, HipLayer& L, int iPart, int iSliceIdx, int iSlice
   P.coded_upto = end; P.coded_slice = iSliceIdx;
   std::lock_guard<std::mutex> lock (L.dyn_mu);
   ++L.dyn_calls;
+  L.dyn_mbs_coded += end - iFrom;
   return ENC_RETURN_SUCCESS;
 }
 
@@ -345,7 +347,7 @@ int32_t HipFrameMd (sWelsEncCtx* pCtx) {
     if (L.gom || nslices != nparts || nparts < 1 || nparts > MAX_THREADS_NUM) {
       fprintf (stderr, "welship hooks: size-limited slices with GOM-level QP / %d slices in %d partitions\n", nslices, nparts); st->failed = true; return ENC_RETURN_UNEXPECTED;
     }
-    L.dyn_calls = 0; L.dyn_slices = 0; L.dyn_parts_left = 0;
+    L.dyn_calls = 0; L.dyn_slices = 0; L.dyn_parts_left = 0; L.dyn_mbs_coded = 0;
     if (nparts > 1) {       // the device's slice table: the partitions (FirstMbIdxOfPartition / EndMbIdxOfPartition, svc_enc_slice_segment.cpp)
       first.clear();
       for (int q = 0; q < nparts; ++q) first.push_back (pCurLayer->FirstMbIdxOfPartition[q]);
@@ -638,7 +640,7 @@ TRY_REENCODING:
           uint8_t* dst[3] = { pCtx->pDecPic->pData[0], pCtx->pDecPic->pData[1], pCtx->pDecPic->pData[2] };
           const int32_t ds[3] = { pCtx->pDecPic->iLineSize[0], pCtx->pDecPic->iLineSize[1], pCtx->pDecPic->iLineSize[2] };
           if (g_api.FrameGetPicture (L.ctx, L.job.iCurPic, dst, ds)) { st->failed = true; return ENC_RETURN_UNEXPECTED; }
-          if (st->trace) fprintf (stderr, "welship hooks: layer %d picture complete: %d slices, %d device calls\n", (int)pCtx->uiDependencyId, L.dyn_slices, L.dyn_calls);
+          if (st->trace) fprintf (stderr, "welship hooks: layer %d picture complete: %d slices, %d device calls, %ld macroblocks coded for %d\n", (int)pCtx->uiDependencyId, L.dyn_slices, L.dyn_calls, L.dyn_mbs_coded, kiTotalNumMb);
         }
       }
       break;

@@ -40,11 +40,12 @@ def main():
         if a.dynslice:
             done = [l for l in err.splitlines() if "picture complete" in l]
             dyn[0] += sum(int(l.split("complete:")[1].split()[0]) for l in done); dyn[1] += sum(int(l.split("slices,")[1].split()[0]) for l in done)
+            dyn[2] += sum(int(l.split("calls,")[1].split()[0]) for l in done); dyn[3] += sum(int(l.split("coded for")[1].split()[0]) for l in done)
         if a.table == "ba": os.remove(str(d / ("t_w%d.264" % i)))
         return i, got == r[0] and pics >= min_pics and "welship hooks: installed" in err, r[4]["-slcmd 0"], got, pics, err.count("GOM-level QP")
 
     bad, by_mode, total_pics, ranged = [], {}, 0, 0
-    dyn = [0, 0]
+    dyn = [0, 0, 0, 0]
     with ThreadPoolExecutor(a.workers) as ex:
         for i, ok, mode, got, pics, rg in ex.map(one, enumerate(rows)):
             total_pics += pics
@@ -58,7 +59,7 @@ def main():
         print("-slcmd %s : rows %d bad %d" % (mode, by_mode[mode][0], by_mode[mode][1]))
     print("table %s: device rows %d of the table's %d, bad %d, %d pictures coded on the device, %.1f s, %d workers, library %s" % (os.path.basename(T.TABLE), len(rows), len(T._rows()), len(bad), total_pics, time.time() - t0, a.workers, os.path.basename(a.lib)))
     print("WELS_HIP_GOM=%d: %d pictures were coded group by group (one device call per group of macroblocks)" % (a.gom, ranged))
-    if a.dynslice: print("WELS_HIP_DYNSLICE=1: %d slices, %d device calls that coded macroblocks (+ one closing call per picture)" % (dyn[0], dyn[1]))
+    if a.dynslice: print("WELS_HIP_DYNSLICE=1: %d slices, %d device calls that coded macroblocks (+ one closing call per picture); %d macroblocks coded for %d (x%.2f: what coding ahead of the writer costs)" % (dyn[0], dyn[1], dyn[2], dyn[3], dyn[2] / max(1, dyn[3])))
     for b in bad[:10]:
         print("BAD", b)
     return 1 if bad else 0
