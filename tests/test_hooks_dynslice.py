@@ -111,3 +111,28 @@ def test_random_sessions_with_slice_threads_on_emulation(emu_lib):
     bad = [(s, m) for s, m, ok in res if not ok]
     assert not bad, bad[0]
     assert sum(1 for _, m, _ in res if m.startswith("ok") and "-threads 1 " not in m) >= 6
+
+
+# ---- GPU tier, armed by hand until the path has run on the MI355X once (tools/gpu_r03_first.sh does that first thing next round):
+# WELSHIP_TEST_UNVERIFIED=1 python -m pytest tests/test_hooks_dynslice.py -m gpu
+_unverified = pytest.mark.skipif(os.environ.get("WELSHIP_TEST_UNVERIFIED") != "1",
+                                 reason="size-limited slices have not run on the MI355X yet (no GPU budget was left in round 2): set WELSHIP_TEST_UNVERIFIED=1")
+
+
+@pytest.mark.gpu
+@_unverified
+def test_random_sessions_on_the_mi355x(hip_lib):
+    _fuzz(hip_lib, range(1000, 1016))
+
+
+@pytest.mark.gpu
+@_unverified
+def test_random_screen_content_and_low_qp_sessions_on_the_mi355x(hip_lib):
+    import fuzz_dynslice
+    from concurrent.futures import ThreadPoolExecutor
+    with tempfile.TemporaryDirectory() as tmp:
+        with ThreadPoolExecutor(4) as ex:
+            res = list(ex.map(lambda s: fuzz_dynslice.one_case(s, hip_lib, tmp, True, 4, False, True), range(21000, 21012)))
+            res += list(ex.map(lambda s: fuzz_dynslice.one_case(s, hip_lib, tmp, True, 4, True), range(11012, 11020)))
+    bad = [(s, m) for s, m, ok in res if not ok]
+    assert not bad, bad[0]
