@@ -11,6 +11,7 @@ export TMPDIR=/tmp
 o=gpurun_out/r03_first; rm -rf $o; mkdir -p $o
 timeout 120 python -m pytest tests -m gpu -q -n 4 > $o/pytest_gpu.txt 2>&1; tail -3 $o/pytest_gpu.txt
 timeout 40 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $o/smoke.txt 2>&1; tail -1 $o/smoke.txt
+WELSHIP_TEST_UNVERIFIED=1 timeout 120 python -m pytest tests/test_hooks_dynslice.py -m gpu -q > $o/pytest_dynslice_gpu.txt 2>&1; tail -2 $o/pytest_dynslice_gpu.txt
 timeout 200 python tools/sha1_table_rows.py --dynslice --workers 16 > $o/size_limited_rows_mi355x.txt 2>&1; tail -4 $o/size_limited_rows_mi355x.txt
 timeout 200 python tools/fuzz_dynslice.py --lib openh264_amd/libwelship.so --cases 60 --seed 7 --workers 16 > $o/fuzz_dynslice_mi355x.txt 2>&1; tail -1 $o/fuzz_dynslice_mi355x.txt
 timeout 200 python tools/fuzz_dynslice.py --lib openh264_amd/libwelship.so --cases 40 --seed 5 --threads 4 --workers 4 > $o/fuzz_dynslice_threads_mi355x.txt 2>&1; tail -1 $o/fuzz_dynslice_threads_mi355x.txt
