@@ -46,3 +46,18 @@ def test_committed_bench_line_keeps_the_contract():
     assert line["verified"] is True and line["e2e"]["bitstream_vs_reference"]["match"] and line["e2e_overlapped"]["bitstream_vs_reference"]["match"]
     assert line["res_clip"]["verified"] is True and line["intra_720p"]["verified"] is True
     assert set(line["latency"]) == {"sessions_1", "sessions_8"}
+
+
+def test_host_entropy_bench_runs(emu_lib):
+    """tools/host_entropy_bench.py times the host share of a session group's frame step (entropy coding straight from the packed
+    records) on the CPU test build: it must keep running and keep producing the same bytes for the same input."""
+    import subprocess
+    out = []
+    for _ in range(2):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "host_entropy_bench.py"), "--frames", "3", "--sessions", "2", "--width", "320", "--height", "192",
+                            "--lib", emu_lib], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert p.returncode == 0, p.stderr.decode()[-1000:]
+        text = p.stdout.decode()
+        assert "host finish:" in text and "WelsHipGroupHostStats" in text
+        out.append([l for l in text.splitlines() if l.startswith("sha1 of all bitstreams")][0])
+    assert out[0] == out[1]
