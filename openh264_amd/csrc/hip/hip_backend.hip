@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <map>
 #include <unordered_map>
+#include <atomic>
 #include "../host/backend.h"
 #include "../kernels/frame_kernels.h"
 #include "../kernels/deblock_mb.h"
@@ -32,6 +33,8 @@ namespace {
 // L1), so the hand-off costs a workgroup-scope release/acquire (s_waitcnt) instead of a kernel boundary.  Tickets are
 // handed out in a topological order, so the lowest outstanding ticket can always run: no deadlock; the spin is
 // bounded anyway and reports through P.prof-independent error word `err` (host checks it after the step).
+#define WH_NUM_QUEUES 32               /* host queues (HIP streams), all created with the backend */
+#define WH_ERR_WORDS 4                  /* error dwords per queue: count, block x, block y, awaited index */
 #define WH_SPIN_LIMIT (1u << 23)       // x ~200 cycles: close to a second.  A wait can legitimately be long when the head of the
                                        // chain waits for another workgroup (deblocking seams) that is not resident yet
 
@@ -498,10 +501,15 @@ class HipBackend : public wh::Backend {
  public:
   HipBackend (int dev, const hipDeviceProp_t& prop) : dev_ (dev), cus_ (prop.multiProcessorCount) {
     HIP_TRY (hipSetDevice (dev_));
-    HIP_TRY (hipStreamCreateWithFlags (&stream_, hipStreamNonBlocking));
-    streams_.push_back (stream_);
-    HIP_TRY (hipMalloc ((void**)&err_, 16));
-    if (err_) HIP_TRY (hipMemset (err_, 0, 16));
+    // Every queue the host side can ask for exists from here on (frame API: 8 upload queues + 2 x 8 lane queues; session groups: a
+    // handful): streams_ never grows, so a thread may wait on queue k (sync_queue, outside the callers' lock) while another one
+    // selects a queue.  Each queue has an error word of its own (WH_ERR_WORDS dwords): a dependency-wait timeout in one launch set
+    // must fail that set's pictures and nobody else's.
+    streams_.assign (WH_NUM_QUEUES, nullptr);
+    for (int k = 0; k < WH_NUM_QUEUES; ++k) HIP_TRY (hipStreamCreateWithFlags (&streams_[k], hipStreamNonBlocking));
+    stream_ = streams_[0]; cur_ = 0;
+    HIP_TRY (hipMalloc ((void**)&err_, 4 * WH_ERR_WORDS * WH_NUM_QUEUES));
+    if (err_) HIP_TRY (hipMemset (err_, 0, 4 * WH_ERR_WORDS * WH_NUM_QUEUES));
     name_ = std::string ("hip:") + prop.gcnArchName + " " + prop.name;
   }
   ~HipBackend() override {
@@ -511,7 +519,8 @@ class HipBackend : public wh::Backend {
     for (auto& sl : slabs_) (void)hipFree (sl.base);
     if (err_) (void)hipFree (err_);
   }
-  bool usable() const { return hip_err_ == hipSuccess && stream_ && err_; }
+  bool usable() const { return hip_err_.load (std::memory_order_relaxed) == (int)hipSuccess && stream_ && err_; }
+  uint32_t* err_words() const { return err_ + WH_ERR_WORDS * cur_; }         // the selected queue's error word
   const char* name() const override { return name_.c_str(); }
   // Device memory comes from a few large slabs (4 KB granules): many small hipMalloc's end up as many small page-table
   // fragments, and with dozens of planes touched per macroblock the translation misses cost more than the data misses.
@@ -590,7 +599,7 @@ class HipBackend : public wh::Backend {
     const size_t lds = (size_t)nw * lds_per_wave + sched_bytes;
     HIP_TRY (hipFuncSetAttribute ((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (getenv ("WELSHIP_TRACE")) { fprintf (stderr, "welship: launch grid %d x %d, %d waves, %zu B LDS, max_n %d\n", whole_picture ? 1 : P.num_slices, n, nw, lds, max_n); fflush (stderr); }
-    hipLaunchKernelGGL (kernel, dim3 (bands > 0 ? bands : whole_picture ? 1 : P.num_slices, n), dim3 (nw * 64), lds, stream_, P, jobs, err_);
+    hipLaunchKernelGGL (kernel, dim3 (bands > 0 ? bands : whole_picture ? 1 : P.num_slices, n), dim3 (nw * 64), lds, stream_, P, jobs, err_words());
     HIP_TRY (hipGetLastError());
     if (getenv ("WELSHIP_TRACE")) { HIP_TRY (hipStreamSynchronize (stream_)); fprintf (stderr, "welship: launch done\n"); fflush (stderr); }
   }
@@ -640,7 +649,7 @@ class HipBackend : public wh::Backend {
     auto launch = [&] (auto kernel) {
       HIP_TRY (hipFuncSetAttribute ((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       if (getenv ("WELSHIP_TRACE")) { fprintf (stderr, "welship: MD launch %d groups x %d slots, %d waves, %zu B dynamic LDS\n", groups, slots, nw, lds); fflush (stderr); }
-      hipLaunchKernelGGL (kernel, dim3 (groups), dim3 (nw * 64), lds, stream_, P, jobs, err_, (const uint16_t*)grp, slots, sched_words, total, cost);
+      hipLaunchKernelGGL (kernel, dim3 (groups), dim3 (nw * 64), lds, stream_, P, jobs, err_words(), (const uint16_t*)grp, slots, sched_words, total, cost);
       HIP_TRY (hipGetLastError());
       if (getenv ("WELSHIP_TRACE")) { HIP_TRY (hipStreamSynchronize (stream_)); fprintf (stderr, "welship: launch done\n"); fflush (stderr); }
     };
@@ -679,35 +688,24 @@ class HipBackend : public wh::Backend {
   }
   void select_queue (int k) override {
     HIP_TRY (hipSetDevice (dev_));
-    while ((int)streams_.size() <= k) { hipStream_t st; HIP_TRY (hipStreamCreateWithFlags (&st, hipStreamNonBlocking)); streams_.push_back (st); }
-    stream_ = streams_[k < 0 ? 0 : k];
+    cur_ = k < 0 ? 0 : k % WH_NUM_QUEUES;         // (queues beyond the fixed set share: they only serialise, nothing breaks)
+    stream_ = streams_[cur_];
   }
   // 0, the number of in-kernel dependency waits that timed out, or -1 after a HIP error (sticky: the backend is unusable)
   int sync() override {
     HIP_TRY (hipSetDevice (dev_));          // callers may be host threads that never selected a device
     for (hipStream_t st : streams_) if (st) HIP_TRY (hipStreamSynchronize (st));
-    if (!usable()) return -1;
-    uint32_t e[4] = {0, 0, 0, 0};
-    HIP_TRY (hipMemcpy (e, err_, 16, hipMemcpyDeviceToHost));
-    if (!usable()) return -1;
-    if (e[0]) {
-      fprintf (stderr, "welship: %u in-kernel dependency waits timed out (first: block %u,%u waiting for MB index %u)\n", e[0], e[1], e[2], e[3]);
-      HIP_TRY (hipMemset (err_, 0, 16));
-    }
-    return (int)e[0];
+    const int bad = check_err (0, WH_NUM_QUEUES);
+    if (bad > 0) swept_.fetch_add (1, std::memory_order_relaxed);     // may have consumed the verdict of a launch set another thread is waiting for
+    return bad;
   }
+  unsigned errors_swept() const override { return swept_.load (std::memory_order_relaxed); }
+  // queue k only: its stream, its error word (the other queues' launch sets keep running and keep their own verdicts)
   int sync_queue (int k) override {
     HIP_TRY (hipSetDevice (dev_));
-    if (k >= 0 && k < (int)streams_.size() && streams_[k]) HIP_TRY (hipStreamSynchronize (streams_[k]));
-    if (!usable()) return -1;
-    uint32_t e[4] = {0, 0, 0, 0};
-    HIP_TRY (hipMemcpy (e, err_, 16, hipMemcpyDeviceToHost));
-    if (!usable()) return -1;
-    if (e[0]) {
-      fprintf (stderr, "welship: %u in-kernel dependency waits timed out (first: block %u,%u waiting for MB index %u)\n", e[0], e[1], e[2], e[3]);
-      HIP_TRY (hipMemset (err_, 0, 16));
-    }
-    return (int)e[0];
+    k = k < 0 ? 0 : k % WH_NUM_QUEUES;
+    if (streams_[k]) HIP_TRY (hipStreamSynchronize (streams_[k]));
+    return check_err (k, 1);
   }
   void* event_create() override { hipEvent_t e = nullptr; HIP_TRY (hipEventCreate (&e)); return (void*)e; }
   void event_destroy (void* ev) override { if (ev) HIP_TRY (hipEventDestroy ((hipEvent_t)ev)); }
@@ -715,19 +713,38 @@ class HipBackend : public wh::Backend {
   float event_elapsed_ms (void* a, void* b) override { float ms = 0.f; if (!a || !b) return ms; HIP_TRY (hipEventSynchronize ((hipEvent_t)b)); HIP_TRY (hipEventElapsedTime (&ms, (hipEvent_t)a, (hipEvent_t)b)); return ms; }
   hipStream_t stream() const { return stream_; }
  private:
+  // error words of queues [k0, k0 + n): everything on those queues has completed (the callers synchronised them), so the read and
+  // the reset race with no kernel that could write them
+  int check_err (int k0, int n) {
+    if (!usable()) return -1;
+    uint32_t e[WH_ERR_WORDS * WH_NUM_QUEUES];
+    HIP_TRY (hipMemcpy (e, err_ + WH_ERR_WORDS * k0, 4 * WH_ERR_WORDS * n, hipMemcpyDeviceToHost));
+    if (!usable()) return -1;
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+      const uint32_t* w = e + WH_ERR_WORDS * i;
+      if (!w[0]) continue;
+      total += (int)w[0];
+      fprintf (stderr, "welship: queue %d: %u in-kernel dependency waits timed out (first: block %u,%u waiting for MB index %u)\n", k0 + i, w[0], w[1], w[2], w[3]);
+      HIP_TRY (hipMemset (err_ + WH_ERR_WORDS * (k0 + i), 0, 4 * WH_ERR_WORDS));
+    }
+    return total;
+  }
   int dev_;
   int cus_;
   std::vector<hipEvent_t> wait_ev_;       // queue_wait: a small ring of events
   size_t wait_next_ = 0;
-  hipStream_t stream_ = nullptr;          // the selected queue
-  std::vector<hipStream_t> streams_;
+  hipStream_t stream_ = nullptr;          // the selected queue ...
+  int cur_ = 0;                           // ... and its index
+  std::vector<hipStream_t> streams_;      // WH_NUM_QUEUES of them, fixed at construction
   uint32_t* err_ = nullptr;
   struct Slab { uint8_t* base; size_t size, used; };
   std::vector<Slab> slabs_;
   std::map<uintptr_t, size_t> free_;                     // address -> bytes, coalesced
   std::unordered_map<uintptr_t, size_t> live_;           // what alloc() handed out
   size_t total_asked_ = 0;
-  hipError_t hip_err_ = hipSuccess;
+  std::atomic<unsigned> swept_ {0};       // how often sync() found (and reset) error words: see Backend::errors_swept
+  std::atomic<int> hip_err_ {(int)hipSuccess};       // first HIP error (sticky); read by threads that wait outside the callers' lock
   std::string name_;
   uint32_t* md_cost_ = nullptr;          // per slice of a batch: cost of its previous picture (k_inter_pool -> k_md_assign)
   uint16_t* md_groups_ = nullptr;
@@ -738,11 +755,11 @@ class HipBackend : public wh::Backend {
   }
   void note_error (hipError_t e, const char* what, int line) {
     (void)hipGetLastError();
-    if (hip_err_ != hipSuccess) return;
-    hip_err_ = e;
+    int expected = (int)hipSuccess;
+    if (!hip_err_.compare_exchange_strong (expected, (int)e)) return;
     fprintf (stderr, "welship: HIP error %s in %s (hip_backend.hip:%d); the session reports failure\n", hipGetErrorString (e), what, line);
   }
-  void note_null() { if (hip_err_ == hipSuccess) { hip_err_ = hipErrorOutOfMemory; fprintf (stderr, "welship: device memory exhausted; the session reports failure\n"); } }
+  void note_null() { int expected = (int)hipSuccess; if (hip_err_.compare_exchange_strong (expected, (int)hipErrorOutOfMemory)) { fprintf (stderr, "welship: device memory exhausted; the session reports failure\n"); } }
 };
 
 }  // namespace

@@ -40,6 +40,10 @@ class Backend {
   virtual int sync() = 0;
   // the same for queue k only (other queues keep running)
   virtual int sync_queue (int k) { (void)k; return sync(); }
+  // Every queue has its own error word, so sync_queue (k) reports queue k's launch set only.  sync() reads and resets all of them:
+  // a thread that waits for its own queue outside the callers' lock compares this counter before the launch and after the wait, and
+  // fails its pictures when a sync() in between found errors (it may have consumed this queue's verdict).
+  virtual unsigned errors_swept() const { return 0; }
   // timing on the stream the kernels are launched on (HIP events)
   virtual void* event_create() = 0;
   virtual void event_destroy (void* ev) = 0;

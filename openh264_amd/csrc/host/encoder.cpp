@@ -1020,7 +1020,9 @@ int WelsHipGroupFinish (WelsHipEncoderGroup* g, WelsHipFrameBSInfo* outs) {
     SessionCore& c = *g->sess[i];
     while (rcs[i] == WELSHIP_ERR_VLC_OVERFLOW) {
       g->be->select_queue (g->chunk_of (i));
-      rcs[i] = reencode_after_overflow (g->be, c, g->d_jobs + i);
+      int slot = i;                     // the job slots are permuted (P pictures first, g->order): session i's own slot
+      for (int k = 0; k < (int)g->order.size(); ++k) if (g->order[k] == i) { slot = k; break; }
+      rcs[i] = reencode_after_overflow (g->be, c, g->d_jobs + slot);
       if (rcs[i]) break;
       rcs[i] = c.finish_frame (outs ? &outs[i] : nullptr, 0);
     }
@@ -1400,9 +1402,11 @@ void frame_run_batch (FrameShared* sh, FrameKey* K, FrameLane* L, std::unique_lo
     }
     const double launch_ms = std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now() - t_launch0).count();
     const int q = L->queue;
+    const unsigned swept0 = be->errors_swept();
     lock.unlock();               // other sessions stage and queue their next pictures while the device works
     const auto t_dev0 = std::chrono::steady_clock::now();
-    const int bad = be->sync_queue (q);
+    int bad = be->sync_queue (q);
+    if (be->errors_swept() != swept0) bad = 1;       // another thread's sync() found time-outs meanwhile: possibly this launch set's
     const double dev_ms = std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now() - t_dev0).count();
     lock.lock();
     if ((int)sh->stat_n.size() <= n) { sh->stat_n.resize (n + 1, 0); sh->stat_dev_ms.resize (n + 1, 0.0); sh->stat_gather_ms.resize (n + 1, 0.0); sh->stat_launch_ms.resize (n + 1, 0.0); }
@@ -1553,6 +1557,10 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
     set_err ("invalid picture indices / slice type"); return WELSHIP_ERR_INIT_PARA;
   }
   if (j->iQp < 0 || j->iQp > 51 || !j->pSrc[0] || !j->pSrc[1] || !j->pSrc[2]) { set_err ("invalid job"); return WELSHIP_ERR_INIT_PARA; }
+  // (the library never takes the caller down: the slice table and the plane strides are checked before anything reads through them)
+  if (!j->pSliceFirstMb || j->iNumSlices < 1 || j->iNumSlices > WH_MAX_SLICES) { set_err ("invalid slice table"); return WELSHIP_ERR_INIT_PARA; }
+  if (j->iSrcStride[0] < c->mb_w * 16 || j->iSrcStride[1] < c->mb_w * 8 || j->iSrcStride[2] < c->mb_w * 8) { set_err ("source strides below the macroblock-aligned picture width"); return WELSHIP_ERR_INIT_PARA; }
+  if (is_p && j->pScreen && j->pScreen->pRefOriChroma[0] && j->pScreen->pRefOriChroma[1] && j->pScreen->iRefOriStride < c->mb_w * 8) { set_err ("screen-content job: stride of the reference's source chroma"); return WELSHIP_ERR_INIT_PARA; }
   if (is_p && j->iComplexityMode == 0 && !j->pVaaSad8x8) { set_err ("LOW complexity P pictures need the VAA 8x8 SADs of the pre-processing"); return WELSHIP_ERR_INIT_PARA; }
   const bool ranged = j->iMbEnd > 0;
   // size-limited slices: ranges coded ahead of the entropy writer, one slice per call; the picture-wide passes with a closing call
