@@ -16,7 +16,7 @@
  *      Same call order, same ownership rules (input planes are caller-owned for the duration of the
  *      call; output buffers are encoder-owned and valid until the next call on the same object),
  *      return 0 = cmResultSuccess, 1 = cmInitParaError, 2 = cmUnknownReason, 3 = cmMallocMemeError,
- *      4 = cmUnsupportedData (codec_def.h:80-87).  oracle/dropin/welship_isvc.cpp is the ISVCEncoder
+ *      4 = cmUnsupportedData (codec_def.h:80-87).  integration/welship_isvc.cpp is the ISVCEncoder
  *      class over these functions; the reference's console front-end runs on it unmodified.
  *
  *  (2) FRAME-LEVEL PHASES on device-resident pictures, batched over N sessions (WelsHipGroup*) -- what

@@ -22,10 +22,11 @@
 // (rate control off, or on with more than one slice, or I pictures in bitrate mode: WelsRcMbInitGom with bEnableGomQp ==
 // false, ratectl.cpp:1199-1204,1239-1262) a picture is one device call; with GOM-level QP (one slice per picture) the QP of a
 // group of macroblocks depends on the bits the groups before it produced, so the picture is coded group by group from inside
-// the slice loop -- a latency chain of one device call per group, bit-exact but not the throughput path.  Everything else
-// (size-limited slices, SVC inter-layer prediction -- and, unless WELS_HIP_GOM=1, the
-// GOM-level-QP sessions, which are correct but slower than the host) keeps the reference's C path -- the hooks stay NULL, as
-// they would on a CPU without the needed SIMD level.
+// the slice loop -- a latency chain of one device call per group, bit-exact but not the throughput path -- unless the picture is a
+// P picture of a camera session with whole-row groups: then the recursion runs inside the kernel and the picture is one call
+// (WELS_HIP_GOM, default 2).  Size-limited slices: the device codes ahead of the entropy writer (WELS_HIP_DYNSLICE, default on).
+// What keeps the reference's C path: SVC inter-layer prediction (and whatever the switches above take away) -- the hooks stay
+// NULL, as they would on a CPU without the needed SIMD level.
 #if defined(HAVE_HIP)
 #include <stdio.h>
 #include <stdlib.h>
@@ -684,28 +685,29 @@ bool WelsHipSupported (const SWelsSvcCodingParam* p, const char** why) {
   // slice threads: every slice task entropy-codes its slice from the (read-only) records of the picture; see HipFrameMd for the filter
   if (p->iMultipleThreadIdc != 1 && getenv ("WELS_HIP_THREADS") && atoi (getenv ("WELS_HIP_THREADS")) == 0) NO ("slice threads switched off (WELS_HIP_THREADS=0)");
   // bEnableAdaptiveQuant: ParamValidation switches it off for every session (encoder_ext.cpp:300-301), nothing to check
+  // Defaults (round 3, after every one of these paths had run on the MI355X: profiles/r03_*_mi355x.txt): everything the binding
+  // implements is ON.  The switches only take a path away again: WELS_HIP_DYNSLICE=0, WELS_HIP_GOM=0 (see the table in INTEGRATION.md B).
   const char* gom = getenv ("WELS_HIP_GOM");
-  const bool gom_ok = gom != NULL && atoi (gom) != 0;
+  const bool gom_off = gom != NULL && atoi (gom) == 0;
   for (int i = 0; i < p->iSpatialLayerNum; ++i) {
     const SSliceArgument& sa = p->sSpatialLayers[i].sSliceArgument;
     if (sa.uiSliceMode == SM_SIZELIMITED_SLICE) {
       // Size-limited slices feed the bitstream position back into mode decision: a slice ends where the writer says, and the macroblock the
       // next one begins with is decided again without its neighbours.  The binding codes ahead of the writer and repeats the rest of the
-      // picture from every slice start (HipCodeSlice) -- bit-exact on the CPU test build, not yet run on the MI355X, and several device
-      // calls per picture: taken on request (WELS_HIP_DYNSLICE=1), for what it is implemented for.
+      // picture from every slice start (HipCodeSlice): several device calls per picture, bit-exact (both SHA1 tables' -slcmd 3 rows).
       const char* ds = getenv ("WELS_HIP_DYNSLICE");
-      if (ds == NULL || atoi (ds) == 0) NO ("size-limited slices feed the bitstream position back into mode decision; WELS_HIP_DYNSLICE=1 installs the hooks anyway");
+      if (ds != NULL && atoi (ds) == 0) NO ("size-limited slices switched off (WELS_HIP_DYNSLICE=0)");
       if (p->iSpatialLayerNum != 1) NO ("size-limited slices: one spatial layer only");
     }
-    // Rate control with one slice per picture = GOM-level QP (ratectl.cpp:1199-1204): the QP of a group of macroblocks depends
-    // on the bits of the groups before it, so the picture is one device round trip PER GROUP -- bit-exact, but a latency chain
-    // several times slower than the C path (measured: 720p 22 against 124 frames/s).  Taken only on request (WELS_HIP_GOM=1)
-    // until the bit counting runs on the device too.
-    if (p->iRCMode != RC_OFF_MODE && !gom_ok) {
+    // Rate control with one slice per picture = GOM-level QP (ratectl.cpp:1199-1204): the QP of a group of macroblocks depends on the
+    // bits of the groups before it.  P pictures of camera sessions whose groups are whole rows run the recursion inside the kernel (one
+    // device call per picture); the rest (I pictures, screen content, CABAC) one device round trip PER GROUP -- bit-exact, a latency
+    // chain.  WELS_HIP_GOM=0 leaves such sessions to the C path, WELS_HIP_GOM=1 forces the per-group calls everywhere.
+    if (p->iRCMode != RC_OFF_MODE && gom_off) {
       const int mbs = ((p->sSpatialLayers[i].iVideoWidth + 15) >> 4) * ((p->sSpatialLayers[i].iVideoHeight + 15) >> 4);
       const bool one_slice = sa.uiSliceMode == SM_SINGLE_SLICE || (sa.uiSliceMode == SM_FIXEDSLCNUM_SLICE && sa.uiSliceNum <= 1) ||
                              (sa.uiSliceMode == SM_RASTER_SLICE && (sa.uiSliceMbNum[0] == 0 || (int)sa.uiSliceMbNum[0] >= mbs));
-      if (one_slice) NO ("rate control with one slice per picture (GOM-level QP) is slower on the device than on the host; WELS_HIP_GOM=1 installs it anyway");
+      if (one_slice) NO ("rate control with one slice per picture (GOM-level QP) switched off (WELS_HIP_GOM=0)");
     }
   }
   return true;
@@ -735,7 +737,7 @@ void WelsHipInstall (SWelsFuncPtrList* pFuncList, SWelsSvcCodingParam* pParam) {
   st->device = getenv ("WELS_HIP_DEVICE") ? atoi (getenv ("WELS_HIP_DEVICE")) : 0;
   st->trace = getenv ("WELS_HIP_TRACE") != NULL;
   st->timing = st->trace && atoi (getenv ("WELS_HIP_TRACE")) >= 2;
-  st->gom_kernel = getenv ("WELS_HIP_GOM") != NULL && atoi (getenv ("WELS_HIP_GOM")) >= 2 && pParam->iEntropyCodingModeFlag == 0;
+  st->gom_kernel = (getenv ("WELS_HIP_GOM") == NULL || atoi (getenv ("WELS_HIP_GOM")) >= 2) && pParam->iEntropyCodingModeFlag == 0;
   st->check_bits = getenv ("WELS_HIP_CHECK_BITS") != NULL && atoi (getenv ("WELS_HIP_CHECK_BITS")) != 0 && pParam->iEntropyCodingModeFlag == 0;
   st->layer_devices = getenv ("WELS_HIP_LAYER_DEVICES") != NULL && atoi (getenv ("WELS_HIP_LAYER_DEVICES")) != 0;
   pFuncList->pHipState = st;

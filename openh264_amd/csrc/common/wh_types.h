@@ -190,7 +190,27 @@ typedef struct WhPicJob {
   int32_t*       sad_cost0_out;
   int32_t        dyn_redo;
   int32_t        pad5;
+  // Tiled twins of the border-expanded planes (WH_TILE_*, below): what the search windows of the P kernel are fetched from.
+  // [0] luma, [1] Cb and Cr interleaved.  rec_tiles is written by the pass that makes a picture a reference (border expansion,
+  // Backend::run_expand), ref_tiles is the reference picture's; both NULL-free whenever rec / ref are.
+  uint8_t*       rec_tiles[2];
+  const uint8_t* ref_tiles[2];
 } WhPicJob;
+
+// ---- tiled reference pictures ------------------------------------------------------------------------------------------
+// A search window is 64+ columns x 56 rows of the reference at an arbitrary position: in a planar picture every window row is a
+// piece of a different 128-byte line (two when it straddles), so a 3.8 KB window cost the fabric 11-12 KB, and the chroma windows
+// (32-byte rows) fared worse (profiles/r02_pmc_traffic.json: 12.8x the algorithmic bytes).  The reference picture therefore has
+// a second, device-private layout made of 128-byte TILES, one memory line each:
+//   luma    16 samples x 8 rows                        -> a 80 x 56 window touches 5 x 7..8 lines  (4.5-5 KB)
+//   chroma   8 samples x 8 rows, Cb | Cr per row (16 B) -> a 32 x 32 window (both planes) touches 4 x 4..5 lines (2-2.5 KB)
+// covering the whole border-expanded plane (32 / 16 samples each side; strides as in WhSeqParams).  Windows start at tile columns
+// (x0 a multiple of 16 / 8), so every 16-byte piece a lane fetches is one row of one tile.
+#define WH_TILE_BYTES 128
+// byte offset of the 16-byte row piece that holds luma sample (x, y), picture coordinates (x >= -32, y >= -32)
+#define WH_TILE_Y_OFF(stride_y, x, y) ((((size_t) (((y) + 32) >> 3) * (size_t) ((stride_y) >> 4) + (size_t) (((x) + 32) >> 4)) << 7) + (size_t) ((((y) + 32) & 7) << 4))
+// byte offset of the 16-byte row piece (8 Cb then 8 Cr) that holds chroma sample (x, y) (x >= -16, y >= -16)
+#define WH_TILE_C_OFF(stride_c, x, y) ((((size_t) (((y) + 16) >> 3) * (size_t) ((stride_c) >> 3) + (size_t) (((x) + 16) >> 3)) << 7) + (size_t) ((((y) + 16) & 7) << 4))
 
 #define WH_MAX_SLICES 36
 #define WH_SEQ_SCC 1                // screen-content mode decision / motion estimation (every picture of the launch has WhPicJob::scc)
@@ -200,6 +220,8 @@ typedef struct WhPicJob {
                                     //   Only macroblocks whose pre-analysis SADs are not flat can search 8x8 blocks at all (known before the
                                     //   picture starts): each of them waits for the one before it, everything else keeps the 2:1 dependency
                                     //   order -- in a processing order built for the picture that respects both (WhPicJob::scc_order)
+#define WH_SEQ_RANGED 8             // the pictures of the launch code MB ranges (WhPicJob::mb_begin / mb_end, dyn_slice) or carry GOM rate control:
+                                    //   the ticket scheduler runs them (k_inter_pool); everything without a flag may take the row scheduler
 #define WH_DB_BAND_ROWS 24          // a deblocking band (one workgroup) never spans more MB rows than this
 
 // ---- parameters common to every picture of a launch --------------------------------------------

@@ -20,6 +20,7 @@
 #include "../kernels/deblock_mb.h"
 #include "../kernels/inter_mb.h"
 #include "../kernels/expand_pic.h"
+#include "../kernels/tile_pic.h"
 #include "../kernels/scene_pic.h"
 #include "../common/compact.h"
 
@@ -261,6 +262,151 @@ __global__ __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPi
   }
 }
 
+// ---- P pictures, row scheduler: a wave codes the macroblocks of one ROW of a slice, left to right ------------------------
+// The ticket scheduler above hands a free wave the next macroblock of the 2:1 order -- any macroblock of the slice -- so every
+// macroblock fetches its search windows from scratch although they overlap its left neighbour's by four fifths, and the
+// overlap is too far away in time for any cache (profiles/r02_pmc_traffic.json: 12.8x the algorithmic bytes).  Here a wave
+// owns a row of a slice: the left neighbour is the macroblock it has just coded, the only dependency it waits for is the
+// top-right one (the row above, owned by a wave that started that row earlier), and its windows SLIDE -- one tile column of
+// luma and one of chroma per macroblock instead of the whole windows (inter_mb.h wh_win_slide_*).  A free wave takes the
+// next unclaimed row of the slot that has most rows left.  A row can always proceed once the row above is two macroblocks
+// ahead, and rows are claimed top down, so the wave that owns the topmost unfinished row never waits: no deadlock.
+// Used when the launch has enough slices per workgroup that whole rows keep every wave busy (run_inter); pictures coded in
+// ranges, with GOM-level rate control or as screen content keep the ticket scheduler.
+template <int MAXT>
+__global__ __launch_bounds__ (MAXT) void k_inter_rows (WhSeqParams P, const WhPicJob* jobs, uint32_t* err, const uint16_t* groups, int slots,
+                                                       int sched_words, int total_slices, uint32_t* slice_cost) {
+  extern __shared__ __align__ (16) uint8_t smem[];
+  const int nw = (int)blockDim.x >> 6, lane = (int)threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane ((int)threadIdx.x >> 6);
+  WhInterLds& S = ((WhInterLds*)smem)[wave];
+  __shared__ WhInterStage stage[MAXT / 64];
+  WhInterStage& G = stage[wave];
+  __shared__ WhWinLds winbuf[MAXT / 64];
+  uint32_t* sched = (uint32_t*) (smem + (size_t)nw * sizeof (WhInterLds));     // per slot: [0] rows claimed, [1..] done bits
+  __shared__ WhPicJob Jl[WH_MD_MAX_SLOTS];
+  __shared__ int slot_first[WH_MD_MAX_SLOTS], slot_n[WH_MD_MAX_SLOTS], slot_idc[WH_MD_MAX_SLOTS], slot_id[WH_MD_MAX_SLOTS], slot_rows[WH_MD_MAX_SLOTS];
+  __shared__ int slot_mv[WH_MD_MAX_SLOTS];
+  for (int i = (int)threadIdx.x; i < slots * sched_words; i += (int)blockDim.x) sched[i] = 0;
+  if (P.prof && lane < 32) S.m.prof[lane] = 0;
+  const int w = P.mb_w;
+  for (int sl = 0; sl < slots; ++sl) {
+    const int k = groups ? (int)groups[blockIdx.x * slots + sl] : (int)blockIdx.x * slots + sl;
+    const bool on = k < total_slices;
+    const int pic = on ? k / P.num_slices : 0, idc = on ? k % P.num_slices : 0;
+    if (threadIdx.x == 0) {
+      const int first = P.slice_first_mb[idc], n = on ? P.slice_first_mb[idc + 1] - first : 0;
+      slot_first[sl] = first; slot_n[sl] = n;
+      slot_rows[sl] = n > 0 ? (first + n - 1) / w - first / w + 1 : 0;
+      slot_idc[sl] = idc; slot_id[sl] = on ? k : -1; slot_mv[sl] = 0;
+    }
+    wh_copy_job (&Jl[sl], &jobs[pic]);
+  }
+  __syncthreads();
+  WH_PROF_DECL (P);
+  const unsigned long long wall0 = P.prof ? wall_clock64() : 0ULL;
+  WhInterCtx X;
+  X.win = &winbuf[wave];
+  X.spec_valid = 0;
+  X.spec.b = X.win;
+  X.last_mv = nullptr;
+  WhWinSlide SL;
+  SL.on_y = 0; SL.on_c = 0; SL.y = 0u; SL.c0 = 0u; SL.c1 = 0u;
+  uint32_t gone = 0;
+  uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+  int slot = -1, x = 0, y = 0, xe = 0;          // the macroblock in hand: (x, y) of slot `slot`, its row segment ends before xe
+  int nslot = -1, nx = 0, ny = 0, nxe = 0;      // the wave's next one
+  // next(): the right neighbour, or the first macroblock of the next unclaimed row (of the slot with most rows left)
+  auto next_fn = [&] () __attribute__ ((always_inline)) {
+    if (slot >= 0 && x + 1 < xe) { nslot = slot; nx = x + 1; ny = y; nxe = xe; return; }
+    for (nslot = -1;;) {
+      int best = -1, brem = 0;
+      for (int sl = 0; sl < slots; ++sl) if (!((gone >> sl) & 1u)) {
+        const int rem = slot_rows[sl] - (int)__hip_atomic_load (&sched[sl * sched_words], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (rem <= 0) gone |= 1u << sl; else if (rem > brem) { brem = rem; best = sl; }
+      }
+      best = __builtin_amdgcn_readfirstlane (best);
+      if (best < 0) return;
+      int r = 0;
+      if (lane == 0) r = (int)atomicAdd (&sched[best * sched_words], 1u);
+      r = __builtin_amdgcn_readfirstlane (r);
+      if (r >= slot_rows[best]) { gone |= 1u << best; continue; }
+      const int first = slot_first[best], last = first + slot_n[best];
+      nslot = best; ny = first / w + r;
+      nx = r == 0 ? first % w : 0;
+      nxe = last - ny * w < w ? last - ny * w : w;
+      return;
+    }
+  };
+  // Called by the macroblock body once its prediction is final: it reads neither the staging area nor the windows from there on.
+  // Start the next macroblock's cold inputs and windows: slide them when they lie one tile column further (same row, same
+  // guess -- the vector this macroblock has just published), fetch them whole otherwise.
+  auto early_fn = [&] () __attribute__ ((always_inline)) {
+    const bool had = slot >= 0;
+    next_fn();
+    if (nslot < 0) return;
+    const WhPicJob& Jn = Jl[nslot];
+    wh_inter_cold_fetch (G, lane, P, Jn, nx, ny);
+    WhWin N;
+    N.b = X.win;
+    const int guess = slot_mv[nslot];
+    const int gx = wh_clip3 ((2 + (int) (int16_t) (guess & 0xffff)) >> 2, -P.mv_range, P.mv_range), gy = wh_clip3 ((2 + (guess >> 16)) >> 2, -P.mv_range, P.mv_range);
+    wh_win_place (P, N, nx * 16 + gx, ny * 16 + gy);
+    const bool same = had && nslot == slot && ny == y;
+    SL.on_y = same && wh_win_can_slide_y (X.spec, N);
+    SL.on_c = same && wh_win_can_slide_c (X.spec, N);
+    if (SL.on_y | SL.on_c) wh_win_slide_begin (P, Jn, N, SL);
+    if (!SL.on_y) wh_win_issue_luma (P, Jn, N);
+    if (!SL.on_c) wh_win_issue_chroma (P, Jn, N);
+    if (SL.on_y | SL.on_c) wh_win_slide_move (X.win, SL.on_y, SL.on_c);
+    X.spec = N;
+    X.spec_valid = 1;
+  };
+  WhEarlyFn<decltype (early_fn)> early = { early_fn };
+  early_fn();
+  int pslot = -1, pxy = -1;                      // the macroblock this wave coded last
+  while (nslot >= 0) {
+    slot = nslot; x = nx; y = ny; xe = nxe;
+    const WhPicJob& J = Jl[slot];
+    const int first = slot_first[slot], xy = y * w + x;
+    uint32_t* sc = sched + slot * sched_words;
+    WH_PROF_MARK (P, S.m, 11);
+    int dep_a, dep_b;
+    wh_mb_deps (w, xy, first, &dep_a, &dep_b);
+    if (pslot == slot && dep_a == pxy) dep_a = -1;          // the left neighbour is this wave's own previous macroblock
+    if (!wh_wait_done (sc + 1, dep_a < 0 ? -1 : dep_a - first, err)) break;
+    if (!wh_wait_done (sc + 1, dep_b < 0 ? -1 : dep_b - first, err)) break;
+    __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "workgroup");
+    WH_PROF_MARK (P, S.m, 12);
+    const uint32_t tc0 = (uint32_t)__builtin_readcyclecounter();
+    WV_ASYNC_WAIT();                      // cold inputs and whatever was fetched whole have landed ...
+    wh_win_slide_finish (X.win, SL);      // ... and so has the new tile column of windows that slid
+    SL.on_y = 0; SL.on_c = 0;
+    X.slice_idc = slot_idc[slot]; X.slice_first = first; X.last_mv = &slot_mv[slot];
+    wh_inter_mb_body_t<false> (S, G, P, J, x, y, X, early);       // (calls early_fn: nslot .. nxe are the next macroblock from there on)
+    WH_PROF_MARK (P, S.m, 14);
+    __builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) atomicOr (&sc[1 + ((xy - first) >> 5)], 1u << ((xy - first) & 31));
+    WH_PROF_MARK (P, S.m, 13);
+    const uint32_t dc = ((uint32_t)__builtin_readcyclecounter() - tc0) >> 6;
+    c0 += slot == 0 ? dc : 0u; c1 += slot == 1 ? dc : 0u; c2 += slot == 2 ? dc : 0u; c3 += slot == 3 ? dc : 0u;
+    pslot = slot; pxy = xy;
+  }
+  if (slice_cost && lane == 0) {
+    if (slot_id[0] >= 0 && c0) atomicAdd (&slice_cost[slot_id[0]], c0);
+    if (slots > 1 && slot_id[1] >= 0 && c1) atomicAdd (&slice_cost[slot_id[1]], c1);
+    if (slots > 2 && slot_id[2] >= 0 && c2) atomicAdd (&slice_cost[slot_id[2]], c2);
+    if (slots > 3 && slot_id[3] >= 0 && c3) atomicAdd (&slice_cost[slot_id[3]], c3);
+  }
+  if (P.prof && lane < 32) atomicAdd (&P.prof[((blockIdx.x * 7u) & 63u) * 32u + lane], (unsigned long long)S.m.prof[lane]);
+  if (P.prof && lane == 0) {
+    const unsigned long long wall1 = wall_clock64();
+    atomicMax (&P.prof[4096], ~wall0); atomicMax (&P.prof[4097], wall1);
+    atomicAdd (&P.prof[4098], wall1 - wall0); atomicAdd (&P.prof[4099], 1ULL);
+    atomicMax (&P.prof[4104 + (blockIdx.x & 255u)], wall1);
+  }
+}
+
 // Deal the slices of a batch out to the mode-decision workgroups: sorted by the cost they had in the previous picture
 // (slice_cost, accumulated by k_inter_pool; cleared here for the coming launch), then in snake order over the groups, so
 // that every group gets a heavy and a light share.  One workgroup; n <= 4096 slices.
@@ -481,6 +627,15 @@ __global__ __launch_bounds__ (256) void k_expand (WhSeqParams P, const WhPicJob*
   for (int idx = (int) (blockIdx.x * blockDim.x + threadIdx.x); idx < total; idx += (int) (gridDim.x * blockDim.x)) wh_expand_item (P, r0, r1, r2, idx);
 }
 
+// The tiled twin of a picture that has just become a reference (kernels/tile_pic.h): one 16-byte tile row per thread.
+__global__ __launch_bounds__ (256) void k_tile (WhSeqParams P, const WhPicJob* jobs) {
+  __shared__ WhPicJob Jl;
+  wh_copy_job (&Jl, &jobs[blockIdx.y]);
+  __syncthreads();
+  const int idx = (int) (blockIdx.x * blockDim.x + threadIdx.x);
+  if (idx < wh_tile_items (P)) wh_tile_item (P, Jl, idx);
+}
+
 // Scene-change statistic: one wavefront per 16x16 region of the source picture.
 __global__ __launch_bounds__ (64) void k_scene (WhSeqParams P, const WhPicJob* jobs) {
   const WhPicJob J = jobs[blockIdx.y];
@@ -653,7 +808,13 @@ class HipBackend : public wh::Backend {
       HIP_TRY (hipGetLastError());
       if (getenv ("WELSHIP_TRACE")) { HIP_TRY (hipStreamSynchronize (stream_)); fprintf (stderr, "welship: launch done\n"); fflush (stderr); }
     };
+    // row scheduler (k_inter_rows): plain camera pictures, when a workgroup holds enough rows (>= 2 slices) for whole rows to keep its
+    // waves busy; a single slice per workgroup (few pictures in flight: the latency regime) keeps the finer-grained tickets
+    const char* rows_env = getenv ("WELSHIP_MD_ROWS");        // (read per launch: the GPU tests switch it inside one process)
+    const int forced_rows = rows_env ? atoi (rows_env) : -1;
+    const bool rows = P.flags == 0 && (forced_rows >= 0 ? forced_rows != 0 : slots >= 2);
     if (P.flags & WH_SEQ_SCC) { if (nw <= 6) launch (k_inter_pool<384, true>); else launch (k_inter_pool<768, true>); }
+    else if (rows) { if (nw <= 6) launch (k_inter_rows<384>); else launch (k_inter_rows<768>); }
     else if (nw <= 6) launch (k_inter_pool<384, false>); else launch (k_inter_pool<768, false>);
   }
   void run_deblock (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
@@ -671,6 +832,9 @@ class HipBackend : public wh::Backend {
   void run_expand (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
     const int blocks = std::max (1, std::min (64, (wh_expand_items (P) + 1023) / 1024));        // ~4 items per thread, at most 64 workgroups per picture
     hipLaunchKernelGGL (k_expand, dim3 (blocks, n), dim3 (256), 0, stream_, P, jobs);
+    HIP_TRY (hipGetLastError());
+    // ... and, as part of making the picture a reference, its tiled twin (what the next picture's search windows are fetched from)
+    hipLaunchKernelGGL (k_tile, dim3 ((wh_tile_items (P) + 255) / 256, n), dim3 (256), 0, stream_, P, jobs);
     HIP_TRY (hipGetLastError());
   }
   void run_compact (const WhSeqParams& P, const WhPicJob* jobs, int n) override {

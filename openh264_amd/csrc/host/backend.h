@@ -29,7 +29,7 @@ class Backend {
   virtual void run_scene (const WhSeqParams& P, const WhPicJob* jobs, int n) = 0;     // source pictures: scene-change statistic
   virtual void run_qp_chain (const WhSeqParams& P, const WhPicJob* jobs, int n) = 0;  // pictures with a QP map: QP_Y chain for the filter
   virtual void run_deblock (const WhSeqParams& P, const WhPicJob* jobs, int n) = 0;   // in-loop filter on rec[]
-  virtual void run_expand (const WhSeqParams& P, const WhPicJob* jobs, int n) = 0;    // replicate rec[] borders (32/16 px)
+  virtual void run_expand (const WhSeqParams& P, const WhPicJob* jobs, int n) = 0;    // make rec[] a reference: replicate its borders (32/16 px), write its tiled twin rec_tiles[]
   virtual void run_compact (const WhSeqParams& P, const WhPicJob* jobs, int n) = 0;   // pack records[] into compact / compact_off (common/compact.h)
   // Independent in-order queues (HIP streams): everything issued after select_queue (k) goes to queue k; work on
   // different queues may overlap on the device.  sync() waits for all of them and returns 0, or the number of

@@ -39,9 +39,13 @@ namespace {
 
 inline int align_up (int v, int a) { return (v + a - 1) / a * a; }
 
-struct DevPicture {            // one padded reconstruction buffer + its MB state
+struct DevPicture {            // one padded reconstruction buffer + its tiled twin (same allocation) + its MB state
   uint8_t* base = nullptr;
   uint8_t* plane[3] = {nullptr, nullptr, nullptr};   // pixel (0,0)
+  uint8_t* tiles[2] = {nullptr, nullptr};            // WH_TILE_*: luma, Cb|Cr -- written when the picture becomes a reference (run_expand)
+  // the twin lies behind the planar picture: `planar` = bytes of the padded planes incl. the 2 x 64 guard bytes, `rec_y` = luma plane
+  void place_tiles (size_t planar, size_t rec_y) { tiles[0] = base + ((planar + 255) & ~ (size_t)255); tiles[1] = tiles[0] + rec_y; }
+  static size_t alloc_bytes (size_t planar) { return ((planar + 255) & ~ (size_t)255) + (planar - 128); }
   WhMbState* mbs = nullptr;
   bool is_p = false;
 };
@@ -224,7 +228,7 @@ struct SessionCore {
     const size_t rec_y = (size_t)s.rec_stride_y * rec_h, rec_c = (size_t)s.rec_stride_c * (rec_h / 2);
     rec_alloc_bytes = rec_y + 2 * rec_c;
     for (int i = 0; i < 2; ++i) {
-      pic[i].base = (uint8_t*)A (rec_alloc_bytes + 128);     // 64 guard bytes either side (aligned window loads)
+      pic[i].base = (uint8_t*)A (DevPicture::alloc_bytes (rec_alloc_bytes + 128));     // 64 guard bytes either side, then the tiled twin
       pic[i].mbs = (WhMbState*)A (sizeof (WhMbState) * num_mb);
     }
     d_records = (WhMbRecord*)A (sizeof (WhMbRecord) * num_mb);
@@ -250,7 +254,8 @@ struct SessionCore {
     if (oom) { set_err ("out of device memory"); release(); return WELSHIP_ERR_MEMORY; }
     for (int i = 0; i < 2; ++i) {
       DevPicture& d = pic[i];
-      be->fill (d.base, 0, rec_alloc_bytes + 128);
+      be->fill (d.base, 0, DevPicture::alloc_bytes (rec_alloc_bytes + 128));
+      d.place_tiles (rec_alloc_bytes + 128, rec_y);
       d.plane[0] = d.base + 64 + (size_t)32 * s.rec_stride_y + 32;
       d.plane[1] = d.base + 64 + rec_y + (size_t)16 * s.rec_stride_c + 16;
       d.plane[2] = d.base + 64 + rec_y + rec_c + (size_t)16 * s.rec_stride_c + 16;
@@ -396,6 +401,7 @@ struct SessionCore {
     memset (job, 0, sizeof (*job));
     job->src[0] = d_src[slot]; job->src[1] = d_src[slot] + ysz; job->src[2] = d_src[slot] + ysz + csz;
     for (int i = 0; i < 3; ++i) { job->rec[i] = c.plane[i]; job->ref[i] = idr ? nullptr : r.plane[i]; }
+    for (int i = 0; i < 2; ++i) { job->rec_tiles[i] = c.tiles[i]; job->ref_tiles[i] = idr ? nullptr : r.tiles[i]; }
     job->records = d_records;
     job->compact = use_compact ? d_compact : nullptr;
     job->compact_off = use_compact ? d_compact_off : nullptr;
@@ -1476,7 +1482,7 @@ int WelsHipFrameCtxCreate (WelsHipFrameCtx** pp, const WelsHipFrameCfg* cfg) {
   bool oom = false;
   auto A = [&] (size_t n) { void* p = be->alloc (n); if (!p) oom = true; return p; };
   c->pics.resize (cfg->iNumPictures);
-  for (auto& d : c->pics) { d.base = (uint8_t*)A (c->rec_alloc_bytes + 128); d.mbs = (WhMbState*)A (sizeof (WhMbState) * c->num_mb); }
+  for (auto& d : c->pics) { d.base = (uint8_t*)A (DevPicture::alloc_bytes (c->rec_alloc_bytes + 128)); d.mbs = (WhMbState*)A (sizeof (WhMbState) * c->num_mb); }
   c->d_src = (uint8_t*)A (c->src_bytes);
   c->d_records = (WhMbRecord*)A (sizeof (WhMbRecord) * c->num_mb);
   c->d_dbflags = (uint32_t*)A (sizeof (uint32_t) * c->num_mb);
@@ -1496,7 +1502,8 @@ int WelsHipFrameCtxCreate (WelsHipFrameCtx** pp, const WelsHipFrameCfg* cfg) {
   };
   if (oom) { set_err ("out of device memory"); return fail (WELSHIP_ERR_MEMORY); }
   for (auto& d : c->pics) {
-    be->fill (d.base, 0, c->rec_alloc_bytes + 128);
+    be->fill (d.base, 0, DevPicture::alloc_bytes (c->rec_alloc_bytes + 128));
+    d.place_tiles (c->rec_alloc_bytes + 128, c->rec_y);
     d.plane[0] = d.base + 64 + (size_t)32 * s.rec_stride_y + 32;
     d.plane[1] = d.base + 64 + c->rec_y + (size_t)16 * s.rec_stride_c + 16;
     d.plane[2] = d.base + 64 + c->rec_y + c->rec_c + (size_t)16 * s.rec_stride_c + 16;
@@ -1755,6 +1762,7 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
   // screen content: its own kernel variant; a picture with a scroll vector codes the macroblocks of a slice one after the other
   // (the directional-vector test of the 8x8 searches reads what the previous macroblock in CODING order left, WhSccJob::chain)
   s.flags = scr ? (WH_SEQ_SCC | (scc_chain ? WH_SEQ_CHAIN : scc_scroll ? WH_SEQ_SERIAL : 0)) : gom ? WH_SEQ_CHAIN : 0;
+  if (ranged) s.flags |= WH_SEQ_RANGED;
   if (gom) qp_map = true;          // the QP changes from group to group: QP_Y of the macroblocks without mb_qp_delta (run_qp_chain)
   // the pictures this one can share a launch with, and the queue they use (MB ranges: queue 0, on their own)
   FrameKey* K = ranged ? nullptr : frame_find_key (sh, s, is_p, qp_map, j->bExpand != 0);
@@ -1823,6 +1831,7 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
   memset (&job, 0, sizeof (job));
   job.src[0] = c->d_src; job.src[1] = c->d_src + c->ysz; job.src[2] = c->d_src + c->ysz + c->csz;
   for (int i = 0; i < 3; ++i) { job.rec[i] = cur.plane[i]; job.ref[i] = is_p ? c->pics[j->iRefPic].plane[i] : nullptr; }
+  for (int i = 0; i < 2; ++i) { job.rec_tiles[i] = cur.tiles[i]; job.ref_tiles[i] = is_p ? c->pics[j->iRefPic].tiles[i] : nullptr; }
   job.records = c->d_records;
   job.mbs = cur.mbs;
   job.ref_mbs = is_p ? c->pics[j->iRefPic].mbs : nullptr;

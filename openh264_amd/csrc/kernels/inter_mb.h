@@ -38,11 +38,12 @@
 
 #define WH_REF_NOT_AVAIL (-2)
 #define WH_REF_NOT_IN_LIST (-1)
-#define WH_WIN_STRIDE 64
-#define WH_WIN_ROWS 60
+#define WH_WIN_STRIDE 80          // five tile columns (common/wh_types.h WH_TILE_*): 16 + 2 * 19 samples wherever the block sits in its tile column, +
+#define WH_WIN_ROWS 56            // 16 + 2 * 20 rows.  (Rows of 80 bytes also spread the lanes of a block read over all LDS banks; 64 did not.)
 #define WH_WIN_MARGIN 19          // diamond (16) + quarter/half-pel taps (3)
-#define WH_CWIN_STRIDE 32
-#define WH_CWIN_ROWS 32
+#define WH_CWIN_STRIDE 64         // chroma window: 32 samples x 32 rows of BOTH planes, stored as the tiles are -- per row four 16-byte pieces,
+#define WH_CWIN_ROWS 32           //   each 8 Cb samples then the 8 Cr samples at the same position
+#define WH_CWIN_COLS 32
 
 // partition slots: one motion search result each (WhMeTab)
 #define WH_SLOT_16x16 0
@@ -54,7 +55,7 @@
 // filled by LDS-DMA -- the compiler then knows that reads of the MB tile cannot alias a window load still in flight.
 typedef struct alignas (16) WhWinLds {
   alignas (16) uint8_t win[WH_WIN_ROWS * WH_WIN_STRIDE + 16];            // luma, see wh_win_load_luma
-  alignas (16) uint8_t cwin[2][WH_CWIN_ROWS * WH_CWIN_STRIDE + 16];      // chroma (Cb, Cr)
+  alignas (16) uint8_t cwin[WH_CWIN_ROWS * WH_CWIN_STRIDE + 16];         // chroma, Cb and Cr interleaved in 8-sample groups (wh_cwin_off)
 } WhWinLds;
 
 typedef struct alignas (16) WhInterLds {
@@ -147,29 +148,47 @@ WH_FN int wh_mc_chroma_w (int a, int b, int c, int d, int dx, int dy) {
 }
 
 // ---- reference windows ----------------------------------------------------------------------------
-// A window is a WH_WIN_STRIDE x WH_WIN_ROWS block of the border-expanded reference luma (plus 32 x 32 of each chroma
-// plane) at a 4-pixel aligned origin.  Origins are clamped so that the whole window lies inside the expanded picture
-// (32 luma / 16 chroma pixels each side): loads need no per-lane clamping and move 16 bytes per lane.
-#define WH_WIN_LOADS ((WH_WIN_ROWS + 15) / 16)     // 16-byte loads per lane: 16 rows of 4 x 16 bytes per instruction
+// A window is a WH_WIN_STRIDE x WH_WIN_ROWS block of the border-expanded reference luma (plus 32 x 32 of both chroma planes),
+// fetched from the picture's TILED twin (common/wh_types.h): the origin is a tile column (x0 a multiple of 16, chroma 8) and a
+// multiple of four rows, so each 16-byte piece a lane moves is one row of one 128-byte tile and a window costs the fabric the
+// 35-40 lines it is made of instead of one or two lines per row.  Origins are clamped so that the whole window lies inside the
+// expanded picture (32 luma / 16 chroma samples each side): loads need no per-lane clamping.
+#define WH_WIN_PIECES (WH_WIN_ROWS * (WH_WIN_STRIDE / 16))          // 16-byte pieces of the luma window, row-major: piece p = row p / 5, tile column p % 5
+#define WH_WIN_LOADS ((WH_WIN_PIECES + 63) / 64)                     // load instructions per lane
+#define WH_CWIN_PIECES (WH_CWIN_ROWS * (WH_CWIN_STRIDE / 16))
+// a window origin in [lo, hi] that is a multiple of `align` when the range holds one (one tile row fewer to fetch), else the middle
+WH_FN int wh_win_pick (int lo, int hi, int align) { const int a = hi & ~ (align - 1); return a >= lo ? a : (lo + hi) >> 1; }
 WH_FN void wh_win_place (const WhSeqParams& P, WhWin& W, int cx, int cy) {      // leaves W.b alone      // (cx,cy): luma position the 16x16 block is centred on
-  W.x0 = wh_clip3 ((cx - 24) & ~3, -32, P.mb_w * 16 + 32 - WH_WIN_STRIDE);
-  W.y0 = wh_clip3 (cy - (WH_WIN_ROWS - 16) / 2, -32, P.mb_h * 16 + 32 - WH_WIN_ROWS);
-  W.cx0 = wh_clip3 (((cx >> 1) - 12) & ~3, -16, P.mb_w * 8 + 16 - WH_CWIN_STRIDE);
-  W.cy0 = wh_clip3 ((cy >> 1) - 12, -16, P.mb_h * 8 + 16 - WH_CWIN_ROWS);
+  // luma: the block +- WH_WIN_MARGIN must be inside; columns: 24..39 samples either side of the block
+  W.x0 = wh_clip3 ((cx - 24) & ~15, -32, P.mb_w * 16 + 32 - WH_WIN_STRIDE);
+  W.y0 = wh_clip3 (wh_win_pick (cy + 16 + WH_WIN_MARGIN - WH_WIN_ROWS, cy - WH_WIN_MARGIN, 8), -32, P.mb_h * 16 + 32 - WH_WIN_ROWS);
+  // chroma: 8..15 samples either side of the 8x8 block, 10+ rows above and below (whatever lies outside is read from the picture)
+  const int ccx = cx >> 1, ccy = cy >> 1;
+  W.cx0 = wh_clip3 ((ccx - 8) & ~7, -16, P.mb_w * 8 + 16 - WH_CWIN_COLS);
+  W.cy0 = wh_clip3 (wh_win_pick (ccy - 14, ccy - 10, 8), -16, P.mb_h * 8 + 16 - WH_CWIN_ROWS);
 }
-WH_FN const WH_G uint8_t* wh_win_src_luma (int lane, int k, const WhSeqParams& P, const WhPicJob& J, const WhWin& W) {
-  return (const WH_G uint8_t*)J.ref[0] + (ptrdiff_t) (W.y0 + 16 * k + (lane >> 2)) * P.rec_stride_y + W.x0 + (lane & 3) * 16;
+// piece p of the luma window / chroma window in the tiled reference picture
+WH_FN const WH_G uint8_t* wh_win_src_luma (int p, const WhSeqParams& P, const WhPicJob& J, const WhWin& W) {
+  const int r = (p * 205) >> 10, c = p - 5 * r;            // p / 5, p % 5 for p < 1024
+  return (const WH_G uint8_t*)J.ref_tiles[0] + WH_TILE_Y_OFF (P.rec_stride_y, W.x0 + 16 * c, W.y0 + r);
 }
-WH_FN const WH_G uint8_t* wh_win_src_chroma (int lane, int pl, const WhSeqParams& P, const WhPicJob& J, const WhWin& W) {
-  return (const WH_G uint8_t*)J.ref[1 + pl] + (ptrdiff_t) (W.cy0 + (lane >> 1)) * P.rec_stride_c + W.cx0 + (lane & 1) * 16;
+WH_FN const WH_G uint8_t* wh_win_src_chroma (int p, const WhSeqParams& P, const WhPicJob& J, const WhWin& W) {
+  return (const WH_G uint8_t*)J.ref_tiles[1] + WH_TILE_C_OFF (P.rec_stride_c, W.cx0 + 8 * (p & 3), W.cy0 + (p >> 2));
 }
-WH_FN bool wh_win_row_ok (int lane, int k) { return 16 * k + (lane >> 2) < WH_WIN_ROWS; }
+// byte offset of chroma sample (x, y) (window coordinates) of plane pl inside cwin
+WH_FN int wh_cwin_off (int pl, int x, int y) { return y * WH_CWIN_STRIDE + ((x >> 3) << 4) + (pl << 3) + (x & 7); }
 // Window loads are LDS-DMA (16 bytes per lane, no register holds the data).  wh_win_issue_* only starts them; the data
 // may be used after WV_ASYNC_WAIT().
 WH_FN void wh_win_issue_luma (const WhSeqParams& P, const WhPicJob& J, WhWin& W) {
   WV_LANES_BEGIN (lane)
 #pragma unroll
-  for (int k = 0; k < WH_WIN_LOADS; ++k) if (wh_win_row_ok (lane, k)) wh_ld_async16 (wh_win_src_luma (lane, k, P, J, W), &W.b->win[(16 * k) * WH_WIN_STRIDE], lane);
+  for (int k = 0; k < WH_WIN_LOADS; ++k) if (64 * k + lane < WH_WIN_PIECES) wh_ld_async16 (wh_win_src_luma (64 * k + lane, P, J, W), &W.b->win[1024 * k], lane);
+  WV_LANES_END
+}
+WH_FN void wh_win_issue_chroma (const WhSeqParams& P, const WhPicJob& J, WhWin& W) {
+  WV_LANES_BEGIN (lane)
+#pragma unroll
+  for (int k = 0; k < WH_CWIN_PIECES / 64; ++k) wh_ld_async16 (wh_win_src_chroma (64 * k + lane, P, J, W), &W.b->cwin[1024 * k], lane);
   WV_LANES_END
 }
 WH_FN void wh_win_load_luma (WhInterLds& S, const WhSeqParams& P, const WhPicJob& J, WhWin& W) {
@@ -186,10 +205,10 @@ WH_FN void wh_win_issue_all (const WhSeqParams& P, const WhPicJob& J, WhWin& W, 
   WV_LANES_BEGIN (lane)
   {
 #pragma unroll
-    for (int k = 0; k < WH_WIN_LOADS; ++k) if (wh_win_row_ok (lane, k)) wh_ld_async16 (wh_win_src_luma (lane, k, P, J, W), &W.b->win[(16 * k) * WH_WIN_STRIDE], lane);
+    for (int k = 0; k < WH_WIN_LOADS; ++k) if (64 * k + lane < WH_WIN_PIECES) wh_ld_async16 (wh_win_src_luma (64 * k + lane, P, J, W), &W.b->win[1024 * k], lane);
 #if !defined(WH_NO_CWIN)
 #pragma unroll
-    for (int pl = 0; pl < 2; ++pl) wh_ld_async16 (wh_win_src_chroma (lane, pl, P, J, W), W.b->cwin[pl], lane);
+    for (int k = 0; k < WH_CWIN_PIECES / 64; ++k) wh_ld_async16 (wh_win_src_chroma (64 * k + lane, P, J, W), &W.b->cwin[1024 * k], lane);
 #endif
   }
   WV_LANES_END
@@ -197,11 +216,12 @@ WH_FN void wh_win_issue_all (const WhSeqParams& P, const WhPicJob& J, WhWin& W, 
 WH_FN bool wh_win_covers (const WhWin& W, int x0, int y0, int x1, int y1) {
   return x0 >= W.x0 && y0 >= W.y0 && x1 <= W.x0 + WH_WIN_STRIDE && y1 <= W.y0 + WH_WIN_ROWS;
 }
-// make sure luma [x0,x1) x [y0,y1) is inside the window (extent <= 57 x WH_WIN_ROWS - 1)
+// make sure luma [x0,x1) x [y0,y1) is inside the window (extent <= 65 x WH_WIN_ROWS - 3)
 WH_FN void wh_win_ensure (WhInterLds& S, const WhSeqParams& P, const WhPicJob& J, WhWin& W, int x0, int y0, int x1, int y1) {
   if (wh_win_covers (W, x0, y0, x1, y1)) return;
-  W.x0 = wh_clip3 ((((x0 + x1) >> 1) - 32) & ~3, -32, P.mb_w * 16 + 32 - WH_WIN_STRIDE);
-  W.y0 = wh_clip3 (((y0 + y1) >> 1) - WH_WIN_ROWS / 2, -32, P.mb_h * 16 + 32 - WH_WIN_ROWS);
+  // (x1 - 80 <= x0 - 16: a tile column in between always exists)
+  W.x0 = wh_clip3 (wh_win_pick (x1 - WH_WIN_STRIDE, x0, 16), -32, P.mb_w * 16 + 32 - WH_WIN_STRIDE);
+  W.y0 = wh_clip3 (wh_win_pick (y1 - WH_WIN_ROWS, y0, 8), -32, P.mb_h * 16 + 32 - WH_WIN_ROWS);
   wh_win_load_luma (S, P, J, W);
 }
 
@@ -213,6 +233,70 @@ WH_FN void wh_win_ensure (WhInterLds& S, const WhSeqParams& P, const WhPicJob& J
 WH_FN void wh_win_speculate (const WhSeqParams& P, const WhPicJob& J, WhWin& W, int mbx, int mby, int guess_mv) {
   const int gx = wh_clip3 ((2 + (int) (int16_t) (guess_mv & 0xffff)) >> 2, -P.mv_range, P.mv_range), gy = wh_clip3 ((2 + (guess_mv >> 16)) >> 2, -P.mv_range, P.mv_range);
   wh_win_issue_all (P, J, W, mbx * 16 + gx, mby * 16 + gy);
+}
+
+// ---- sliding windows (row scheduler, hip_backend.hip k_inter_rows) ---------------------------------------------------
+// A wave that codes the macroblocks of a row one after the other keeps its windows: when the next macroblock's windows lie
+// exactly one tile column to the right of the ones in LDS (the usual case: the same vector guess, 16 samples further), four
+// fifths of them are already there.  The window is moved left by one tile column inside LDS and only the new column -- 56 tile
+// rows of luma = 7-8 memory lines, 32 of chroma = 4-5 -- comes from the reference picture: through registers, because an
+// LDS-DMA writes one contiguous 16 bytes per lane and a column of a row-major window is not contiguous.
+//   begin: (called where the macroblock in hand stops reading the windows) issue this lane's loads of the new column, move the rest
+//   finish: (before the next macroblock reads them) store the new column
+// Every lane has at most ONE piece of the new luma column (piece p = 64 k + lane is in column p % 5 = (4 k + lane) % 5: exactly
+// one k in 0..4 gives column 4) and two of the new chroma column (lanes with lane % 4 == 3).
+#if defined(WH_EMU)
+typedef struct WhWinSlide { WhV4 y[64], c0[64], c1[64]; int on_y, on_c; } WhWinSlide;       // (the test build keeps every lane's registers)
+#define WH_SL_LANE(f, lane) f[lane]
+#else
+typedef struct WhWinSlide { WhV4 y, c0, c1; int on_y, on_c; } WhWinSlide;
+#define WH_SL_LANE(f, lane) f
+#endif
+WH_FN bool wh_win_can_slide_y (const WhWin& W, const WhWin& N) { return N.y0 == W.y0 && N.x0 == W.x0 + 16; }
+WH_FN bool wh_win_can_slide_c (const WhWin& W, const WhWin& N) { return N.cy0 == W.cy0 && N.cx0 == W.cx0 + 8; }
+WH_FN int wh_win_slide_piece (int lane) { return 64 * ((lane + 1) % 5) + lane; }          // this lane's piece of luma column 4
+// `N`: the placement after the slide (luma and / or chroma origin one tile column further than what LDS holds)
+WH_FN void wh_win_slide_begin (const WhSeqParams& P, const WhPicJob& J, const WhWin& N, WhWinSlide& SL) {
+  WV_LANES_BEGIN (lane)
+  {
+    if (SL.on_y) {
+      const int p = wh_win_slide_piece (lane);
+      if (p < WH_WIN_PIECES) WH_SL_LANE (SL.y, lane) = wh_ldg16v (wh_win_src_luma (p, P, J, N));
+    }
+    if (SL.on_c && (lane & 3) == 3) { WH_SL_LANE (SL.c0, lane) = wh_ldg16v (wh_win_src_chroma (lane, P, J, N)); WH_SL_LANE (SL.c1, lane) = wh_ldg16v (wh_win_src_chroma (64 + lane, P, J, N)); }
+  }
+  WV_LANES_END
+}
+// the pieces that stay: piece p of the new window = piece p + 1 of the old one.  All lanes read before any lane writes (the LDS
+// executes a wave's instructions in order), and a piece is read in the step in which, or before, it is overwritten.
+WH_FN void wh_win_slide_move (WhWinLds* b, int on_y, int on_c) {
+#if defined(WH_EMU)
+  WhV4 t[64];
+#define WH_SLIDE_STEP(arr, idx, cond)                                                                      \
+  { WV_LANES_BEGIN (lane) { const int p = (idx); if (cond) t[lane] = * (const WhV4*)&b->arr[16 * (p + 1)]; } WV_LANES_END  \
+    WV_LANES_BEGIN (lane) { const int p = (idx); if (cond) * (WhV4*)&b->arr[16 * p] = t[lane]; } WV_LANES_END }
+#else
+  const int lane = wh_lane_id();
+#define WH_SLIDE_STEP(arr, idx, cond)                                                                      \
+  { const int p = (idx); const bool mv = (cond); WhV4 v = {0u, 0u, 0u, 0u}; if (mv) v = * (const WhV4*)&b->arr[16 * (p + 1)]; WV_SYNC(); if (mv) * (WhV4*)&b->arr[16 * p] = v; WV_SYNC(); }
+#endif
+  if (on_y) {
+#pragma unroll
+    for (int k = 0; k < WH_WIN_LOADS; ++k) WH_SLIDE_STEP (win, 64 * k + lane, p < WH_WIN_PIECES && (p - 5 * ((p * 205) >> 10)) != 4)
+  }
+  if (on_c) {
+#pragma unroll
+    for (int k = 0; k < WH_CWIN_PIECES / 64; ++k) WH_SLIDE_STEP (cwin, 64 * k + lane, (p & 3) != 3)
+  }
+#undef WH_SLIDE_STEP
+}
+WH_FN void wh_win_slide_finish (WhWinLds* b, const WhWinSlide& SL) {
+  WV_LANES_BEGIN (lane)
+  {
+    if (SL.on_y) { const int p = wh_win_slide_piece (lane); if (p < WH_WIN_PIECES) * (WhV4*)&b->win[16 * p] = WH_SL_LANE (SL.y, lane); }
+    if (SL.on_c && (lane & 3) == 3) { * (WhV4*)&b->cwin[16 * lane] = WH_SL_LANE (SL.c0, lane); * (WhV4*)&b->cwin[16 * (64 + lane)] = WH_SL_LANE (SL.c1, lane); }
+  }
+  WV_LANES_END
 }
 
 // ---- lane geometry -----------------------------------------------------------------------------------
@@ -319,14 +403,15 @@ WH_FN void wh_mc_chroma_to (WhInterLds& S, const WhSeqParams& P, const WhPicJob&
   const int dx = mvx & 7, dy = mvy & 7;
   const int ipx = mbx * 8 + cx + (mvx >> 3), ipy = mby * 8 + cy + (mvy >> 3);
   const int n = cw * ch, sh = cw == 8 ? 3 : 2;
-  const bool in_win = ipx >= W.cx0 && ipy >= W.cy0 && ipx + cw + 1 <= W.cx0 + WH_CWIN_STRIDE && ipy + ch + 1 <= W.cy0 + WH_CWIN_ROWS;
+  const bool in_win = ipx >= W.cx0 && ipy >= W.cy0 && ipx + cw + 1 <= W.cx0 + WH_CWIN_COLS && ipy + ch + 1 <= W.cy0 + WH_CWIN_ROWS;
   if (in_win) {
-    const int wo = (ipy - W.cy0) * WH_CWIN_STRIDE + ipx - W.cx0;
+    const int wx = ipx - W.cx0, wy = ipy - W.cy0;
     WV_LANES_BEGIN (lane)
     for (int i = lane; i < 2 * n; i += 64) {
       const int pl = i >= n, k = i - pl * n, x = k & (cw - 1), y = k >> sh;
-      const uint8_t* p = &W.b->cwin[pl][wo + y * WH_CWIN_STRIDE + x];
-      dst[pl * 64 + (cy + y) * 8 + cx + x] = (uint8_t)wh_mc_chroma_w (p[0], p[1], p[WH_CWIN_STRIDE], p[WH_CWIN_STRIDE + 1], dx, dy);
+      const uint8_t* cw_ = W.b->cwin;
+      const int o0 = wh_cwin_off (pl, wx + x, wy + y), o1 = wh_cwin_off (pl, wx + x + 1, wy + y);
+      dst[pl * 64 + (cy + y) * 8 + cx + x] = (uint8_t)wh_mc_chroma_w (cw_[o0], cw_[o1], cw_[o0 + WH_CWIN_STRIDE], cw_[o1 + WH_CWIN_STRIDE], dx, dy);
     }
     WV_LANES_END
   } else {
@@ -879,7 +964,8 @@ typedef struct WhInterCtx {
   int slice_idc, slice_first;        // slice of this MB and its first MB address
   WhWinLds* win;                        // this wave's search windows
   int spec_valid;                       // windows were fetched speculatively (wh_win_speculate) ...
-  WhWin spec;                           // ... at this placement
+  WhWin spec;                           // ... at this placement.  Out: where the windows really are when the body calls back (`early`):
+                                        //   a search that left them has fetched others -- what a wave that slides its windows starts from
   int* last_mv;                         // out (may be NULL): the slice's most recent final 16x16 vector, packed -- the next guess
 } WhInterCtx;
 
@@ -891,7 +977,7 @@ typedef struct WhInterCtx {
 // build poisons both buffers in the callback: a read after the call would break parity.
 struct WhNoEarly { WH_FN void call() {} };
 template <bool SCC, class Early>
-WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, const WhInterCtx& X, Early& early) {
+WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, WhInterCtx& X, Early& early) {
   WH_PROF_DECL (P);
   WhMbLds& M = S.m;
   const int w = P.mb_w, xy = mby * w + mbx;
@@ -1309,13 +1395,12 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
       WV_LANES_END
     }
   };
-  if (done) {               // skip / background / static block / intra: nothing below reads a window or the staging area
-    if (!intra) publish_guess (mb_type == WH_MB_PSKIP ? wh_pk_mv (skx, sky) : wh_pk_mv (p16x, p16y));
-    early.call();
-    WH_PROF_MARK (P, M, 11);   // (the claim + fetch issue of the next macroblock, when the scheduler does it here)
-  }
+  // (ONE call site of `early` below: the scheduler's callback is large -- inlined once it costs nothing, called from two places it
+  // becomes a function whose captured state lives in scratch memory)
+  const bool searched = !done;      // the macroblock goes through the partition searches, the refinement and residual coding
+  if (done && !intra) publish_guess (mb_type == WH_MB_PSKIP ? wh_pk_mv (skx, sky) : wh_pk_mv (p16x, p16y));     // skip / background / static block
 
-  if (!done) {
+  if (searched) {
     // ---- fine partitions: groups of searches (8x8 x4, 16x8 x2, 8x16 x2), results kept per slot in T ----
     wh_me_store (T, WH_SLOT_16x16, me16);
     WV_LSET (mvcl, 0, il_mv);
@@ -1475,8 +1560,12 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
 
     WH_PROF_MARK (P, M, 5);   // fractional refinement + chroma MC
     publish_guess (wh_pk_mv (p16x, p16y));
-    early.call();
-    WH_PROF_MARK (P, M, 11);
+  }
+  // the prediction is final: nothing below reads a window or the staging area
+  X.spec = W;
+  early.call();
+  WH_PROF_MARK (P, M, 11);   // (the claim + fetch issue of the next macroblock, when the scheduler does it here)
+  if (searched) {
     // ---- encode (WelsMdInterEncode) ----
     wh_dct_luma16 (M);
     cbp = wh_enc_inter_y (M, qp);
@@ -1594,11 +1683,11 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
   WH_PROF_MARK (P, M, 7);   // store
 }
 template <bool SCC>
-WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, const WhInterCtx& X) {
+WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, WhInterCtx& X) {
   WhNoEarly e;
   wh_inter_mb_body_t<SCC> (S, G, P, J, mbx, mby, X, e);
 }
-WH_FN void wh_inter_mb_body (WhInterLds& S, WhInterStage& G, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, const WhInterCtx& X) {
+WH_FN void wh_inter_mb_body (WhInterLds& S, WhInterStage& G, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, WhInterCtx& X) {
   wh_inter_mb_body_t<false> (S, G, P, J, mbx, mby, X);
 }
 

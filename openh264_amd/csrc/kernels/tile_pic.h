@@ -1,0 +1,32 @@
+// tile_pic.h -- the tiled twin of a reference picture (common/wh_types.h, WH_TILE_*): after deblocking and border
+// expansion (the point where the reference encoder calls ExpandReferencingPicture, ref_list_mgr_svc.cpp:375) the whole
+// expanded picture is copied once into 128-byte tiles -- luma 16 x 8, chroma 8 x 8 with Cb | Cr side by side in every row --
+// from which the P kernel fetches its search windows (inter_mb.h, wh_win_*).  Device-private: the planar picture stays what
+// every other pass and the host read.
+//
+// One item = one 16-byte row of one tile, items in tile order: a wavefront reads 8 picture rows x 128 contiguous bytes and
+// writes 1 KB contiguously -- a plain streaming pass (3.4 MB read + written per 1080p picture).
+#pragma once
+#include "prims.h"
+
+WH_HDFN int wh_tile_items_y (const WhSeqParams& P) { return (P.rec_stride_y >> 4) * ((P.mb_h * 16 + 64) >> 3) * 8; }
+WH_HDFN int wh_tile_items_c (const WhSeqParams& P) { return (P.rec_stride_c >> 3) * ((P.mb_h * 8 + 32) >> 3) * 8; }
+WH_HDFN int wh_tile_items (const WhSeqParams& P) { return wh_tile_items_y (P) + wh_tile_items_c (P); }
+
+WH_HDFN void wh_tile_item (const WhSeqParams& P, const WhPicJob& J, int idx) {
+  const int ny = wh_tile_items_y (P);
+  if (idx < ny) {
+    const int tw = P.rec_stride_y >> 4, tile = idx >> 3, row = idx & 7, tx = tile % tw, ty = tile / tw;
+    const WH_G uint8_t* src = (const WH_G uint8_t*)J.rec[0] - (ptrdiff_t)32 * P.rec_stride_y - 32 + (ptrdiff_t) (ty * 8 + row) * P.rec_stride_y + tx * 16;
+    wh_stg16 ((WH_G uint8_t*)J.rec_tiles[0] + (size_t)idx * 16, wh_ldg16 (src));
+    return;
+  }
+  idx -= ny;
+  const int tw = P.rec_stride_c >> 3, tile = idx >> 3, row = idx & 7, tx = tile % tw, ty = tile / tw;
+  const ptrdiff_t off = - (ptrdiff_t)16 * P.rec_stride_c - 16 + (ptrdiff_t) (ty * 8 + row) * P.rec_stride_c + tx * 8;
+  const WH_G uint32_t* cb = (const WH_G uint32_t*) ((const WH_G uint8_t*)J.rec[1] + off);
+  const WH_G uint32_t* cr = (const WH_G uint32_t*) ((const WH_G uint8_t*)J.rec[2] + off);
+  WhU4 v;
+  v.x = cb[0]; v.y = cb[1]; v.z = cr[0]; v.w = cr[1];
+  wh_stg16 ((WH_G uint8_t*)J.rec_tiles[1] + (size_t)idx * 16, v);
+}

@@ -227,6 +227,19 @@ WH_FN uint32_t wh_avg4 (uint32_t a, uint32_t b) { return __builtin_amdgcn_lerp (
 
 // 16 bytes moved as one unit (global_load_dwordx4 / ds_read_b128)
 typedef struct alignas (16) WhU4 { uint32_t x, y, z, w; } WhU4;
+// ... to / from 16-byte aligned device memory
+#if defined(WH_EMU)
+WH_FN WhU4 wh_ldg16 (const void* p) { WhU4 v; memcpy (&v, p, 16); return v; }
+WH_FN void wh_stg16 (void* p, WhU4 v) { memcpy (p, &v, 16); }
+typedef WhU4 WhV4;                   // 16 bytes held in a lane's registers across lane blocks
+WH_FN WhV4 wh_ldg16v (const void* p) { return wh_ldg16 (p); }
+#else
+typedef uint32_t wh_u32x4_t __attribute__ ((ext_vector_type (4)));
+typedef wh_u32x4_t WhV4;             // (a vector VALUE: a struct variable that lives across a fence is kept in scratch memory)
+WH_FN WhV4 wh_ldg16v (const WH_G void* p) { return * (const WH_G wh_u32x4_t*)p; }
+WH_HDFN WhU4 wh_ldg16 (const WH_G void* p) { const wh_u32x4_t t = * (const WH_G wh_u32x4_t*)p; WhU4 v; v.x = t.x; v.y = t.y; v.z = t.z; v.w = t.w; return v; }
+WH_HDFN void wh_stg16 (WH_G void* p, WhU4 v) { wh_u32x4_t t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w; * (WH_G wh_u32x4_t*)p = t; }
+#endif
 
 // ---- small integer helpers (host + device) -----------------------------------------------------
 WH_FN int wh_abs (int a) { return a < 0 ? -a : a; }

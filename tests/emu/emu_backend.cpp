@@ -15,6 +15,7 @@
 #include "../../openh264_amd/csrc/kernels/deblock_mb.h"
 #include "../../openh264_amd/csrc/kernels/inter_mb.h"
 #include "../../openh264_amd/csrc/kernels/expand_pic.h"
+#include "../../openh264_amd/csrc/kernels/tile_pic.h"
 #include "../../openh264_amd/csrc/kernels/scene_pic.h"
 #include "../../openh264_amd/csrc/common/compact.h"
 
@@ -45,9 +46,72 @@ class EmuBackend : public Backend {
       if (jobs[j].mb_end > 0 && (xy < jobs[j].mb_begin || xy >= jobs[j].mb_end)) return;      // GOM-synchronous coding: only this range
       WhMbLds S; poison (&S, sizeof (S)); wh_intra_mb_body (S, P, jobs[j], x, y); });
   }
+  // The row scheduler of the device (hip_backend.hip k_inter_rows): one emulated wavefront codes the rows of a slice one after the
+  // other, left to right, and keeps its windows -- through the very slide functions the device uses (inter_mb.h wh_win_slide_*), started
+  // where the macroblock body calls back.  After the callback the body must not read the staging area or the windows: both are set
+  // aside and poisoned until it returns.  WELSHIP_MD_ROWS=0 (the device's knob) runs these pictures through the ticket order instead.
+  void run_inter_rows (const WhSeqParams& P, const WhPicJob* jobs, int n) {
+    for (int j = 0; j < n; ++j)
+      for (int s = 0; s < P.num_slices; ++s) {
+        WhInterLds S;
+        WhInterStage G, Gk;
+        WhWinLds WB, WBk;
+        poison (&S, sizeof (S)); poison (&G, sizeof (G)); poison (&WB, sizeof (WB));
+        const int first = P.slice_first_mb[s], last = P.slice_first_mb[s + 1], w = P.mb_w;
+        const WhPicJob& J = jobs[j];
+        int last_mv = 0;
+        WhInterCtx X;
+        X.win = &WB; X.spec.b = &WB; X.spec_valid = 0; X.last_mv = &last_mv;
+        WhWinSlide SL;
+        SL.on_y = 0; SL.on_c = 0;
+        int cur = -1;                      // the macroblock in hand
+        struct Early {
+          EmuBackend* self; const WhSeqParams& P; const WhPicJob& J; WhInterStage& G; WhInterStage& Gk; WhWinLds& WB; WhWinLds& WBk; WhInterCtx& X; WhWinSlide& SL;
+          int& cur; int first, last, w; int& last_mv; int calls;
+          void call() {
+            ++calls;
+            const int nxt = cur < 0 ? first : cur + 1;
+            if (nxt < last) {
+              const int nx = nxt % w, ny = nxt / w;
+              for (int lane = 0; lane < 64; ++lane) wh_inter_cold_fetch (G, lane, P, J, nx, ny);
+              WhWin N;
+              N.b = &WB;
+              const int gx = wh_clip3 ((2 + (int) (int16_t) (last_mv & 0xffff)) >> 2, -P.mv_range, P.mv_range), gy = wh_clip3 ((2 + (last_mv >> 16)) >> 2, -P.mv_range, P.mv_range);
+              wh_win_place (P, N, nx * 16 + gx, ny * 16 + gy);
+              const bool same = cur >= 0 && ny == cur / w;
+              SL.on_y = same && wh_win_can_slide_y (X.spec, N);
+              SL.on_c = same && wh_win_can_slide_c (X.spec, N);
+              if (SL.on_y | SL.on_c) wh_win_slide_begin (P, J, N, SL);
+              if (!SL.on_y) { poison (WB.win, sizeof (WB.win)); wh_win_issue_luma (P, J, N); }
+              if (!SL.on_c) { poison (WB.cwin, sizeof (WB.cwin)); wh_win_issue_chroma (P, J, N); }
+              if (SL.on_y | SL.on_c) wh_win_slide_move (&WB, SL.on_y, SL.on_c);
+              X.spec = N; X.spec_valid = 1;
+            }
+            // what the rest of the body must not touch
+            Gk = G; WBk = WB;
+            poison (&G, sizeof (G)); poison (&WB, sizeof (WB));
+          }
+        } early = { this, P, J, G, Gk, WB, WBk, X, SL, cur, first, last, w, last_mv, 0 };
+        early.call();
+        G = Gk; WB = WBk;
+        for (int xy = first; xy < last; ++xy) {
+          cur = xy;
+          wh_win_slide_finish (&WB, SL);
+          SL.on_y = 0; SL.on_c = 0;
+          X.slice_idc = s; X.slice_first = first;
+          early.calls = 0;
+          wh_inter_mb_body_t<false> (S, G, P, J, xy % w, xy / w, X, early);
+          if (early.calls != 1) { fprintf (stderr, "emu: the P macroblock body called back %d times at MB %d\n", early.calls, xy); abort(); }
+          G = Gk; WB = WBk;
+          poison (&S, sizeof (S));
+        }
+      }
+  }
   void run_inter (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
     // one emulated wavefront walks each slice in order like a wave of the device scheduler: a macroblock's cold inputs and
     // its speculative search windows (around the slice's last final vector) are fetched before its body runs
+    static const bool rows_off = getenv ("WELSHIP_MD_ROWS") && atoi (getenv ("WELSHIP_MD_ROWS")) == 0;
+    if (P.flags == 0 && !rows_off) { run_inter_rows (P, jobs, n); return; }
     for (int j = 0; j < n; ++j)
       for (int s = 0; s < P.num_slices; ++s) {
         WhInterLds S;
@@ -125,6 +189,7 @@ class EmuBackend : public Backend {
     for (int j = 0; j < n; ++j) {
       const int total = wh_expand_items (P);
       for (int i = 0; i < total; ++i) wh_expand_item (P, (uint8_t*)jobs[j].rec[0], (uint8_t*)jobs[j].rec[1], (uint8_t*)jobs[j].rec[2], i);
+      for (int i = 0; i < wh_tile_items (P); ++i) wh_tile_item (P, jobs[j], i);       // the tiled twin (kernels/tile_pic.h), as the device's run_expand
     }
   }
   void run_compact (const WhSeqParams& P, const WhPicJob* jobs, int n) override {

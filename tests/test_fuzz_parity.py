@@ -10,11 +10,11 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(extra, ref_tools):
+def _run(extra, ref_tools, seed=7, env=None):
     if not ref_tools:
         pytest.skip("oracle/_ref not built")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "--cases", "24", "--seed", "7"] + extra,
-                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "--cases", "24", "--seed", str(seed)] + extra,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500, env=dict(os.environ, **(env or {})))
     out = r.stdout.decode()
     assert r.returncode == 0, out[-4000:]
     assert "24 cases, 0 failed" in out
@@ -56,3 +56,15 @@ def test_fuzz_emu(emu_lib, ref_tools):
 @pytest.mark.gpu
 def test_fuzz_hip(hip_lib, ref_tools):
     _run(["--hip"], ref_tools)
+
+
+# The two schedulers of the P kernel (hip_backend.hip): tickets in 2:1 order (k_inter_pool) and one wave per row with sliding
+# search windows (k_inter_rows).  The device picks by how many slices a workgroup holds, so single small sessions would only ever
+# see the tickets; the CPU test build runs rows wherever they apply.  WELSHIP_MD_ROWS forces either.
+def test_fuzz_emu_ticket_scheduler(emu_lib, ref_tools):
+    _run([], ref_tools, seed=19, env={"WELSHIP_MD_ROWS": "0"})
+
+
+@pytest.mark.gpu
+def test_fuzz_hip_row_scheduler(hip_lib, ref_tools):
+    _run(["--hip"], ref_tools, seed=23, env={"WELSHIP_MD_ROWS": "1"})

@@ -41,7 +41,7 @@ EXT_GOLDEN = [  # flags after -ext, hash, must the hooks be installed
 
 
 def _enc(exe, lib, src, w, h, fps, flags, out):
-    env = dict(os.environ, WELS_HIP_TRACE="1", WELS_HIP_GOM="1", WELS_HIP_CHECK_BITS="1")
+    env = dict(os.environ, WELS_HIP_TRACE="1", WELS_HIP_CHECK_BITS="1")
     if lib:
         env["WELSHIP_LIB"] = lib
     p = subprocess.run([os.path.join(REF, exe), "-i", src, "-w", str(w), "-h", str(h), "-fps", str(fps), "-o", out, "-quiet"] + flags,

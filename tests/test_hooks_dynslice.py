@@ -66,19 +66,25 @@ def test_reencoding_after_cavlc_overflow_inside_size_limited_slices(emu_lib):
     assert sum(1 for _, m, _ in res if "repeated after a CAVLC overflow" in m) >= 2
 
 
-def test_installer_declines_without_the_switch(emu_lib, tmp_path):
-    """Opt-in: without WELS_HIP_DYNSLICE the session keeps the reference's C path and the installer says why."""
+def test_installer_default_and_switch(emu_lib, tmp_path):
+    """On by default since the path has run on the MI355X (profiles/r03_size_limited_slices_*_mi355x.txt); WELS_HIP_DYNSLICE=0 leaves
+    the session to the reference's C path and the installer says why."""
     import subprocess
     from openh264_amd.utils.synth import synth_sequence
     src = str(tmp_path / "c.yuv")
     open(src, "wb").write(synth_sequence(176, 144, 3))
     env = dict(os.environ, WELSHIP_LIB=emu_lib, WELS_HIP_TRACE="1")
+    cmd = [os.path.join(REF, "ref_enc_hip"), "-i", src, "-w", "176", "-h", "144", "-o", str(tmp_path / "o.264"), "-quiet", "-slcmd", "3",
+           "-slcsize", "600", "-threads", "1", "-rc", "-1", "-qp", "26"]
     env.pop("WELS_HIP_DYNSLICE", None)
-    p = subprocess.run([os.path.join(REF, "ref_enc_hip"), "-i", src, "-w", "176", "-h", "144", "-o", str(tmp_path / "o.264"), "-quiet", "-slcmd", "3",
-                        "-slcsize", "600", "-threads", "1", "-rc", "-1", "-qp", "26"], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    p = subprocess.run(cmd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    err = p.stderr.decode(errors="replace")
+    assert p.returncode == 0 and "welship hooks: installed" in err and "picture complete" in err
+    env["WELS_HIP_DYNSLICE"] = "0"
+    p = subprocess.run(cmd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
     err = p.stderr.decode(errors="replace")
     assert p.returncode == 0 and "not installed" in err and "WELS_HIP_DYNSLICE" in err
-    # ... and a simulcast session with size-limited slices stays on the C path even when asked
+    # ... and a simulcast session with size-limited slices stays on the C path
     env["WELS_HIP_DYNSLICE"] = "1"
     p = subprocess.run([os.path.join(REF, "ref_enc_hip"), "-i", src, "-w", "176", "-h", "144", "-o", str(tmp_path / "o.264"), "-quiet", "-slcmd", "3",
                         "-slcsize", "600", "-threads", "1", "-rc", "-1", "-qp", "26", "-simulcast", "96", "80"], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
@@ -113,20 +119,13 @@ def test_random_sessions_with_slice_threads_on_emulation(emu_lib):
     assert sum(1 for _, m, _ in res if m.startswith("ok") and "-threads 1 " not in m) >= 6
 
 
-# ---- GPU tier, armed by hand until the path has run on the MI355X once (tools/gpu_r03_first.sh does that first thing next round):
-# WELSHIP_TEST_UNVERIFIED=1 python -m pytest tests/test_hooks_dynslice.py -m gpu
-_unverified = pytest.mark.skipif(os.environ.get("WELSHIP_TEST_UNVERIFIED") != "1",
-                                 reason="size-limited slices have not run on the MI355X yet (no GPU budget was left in round 2): set WELSHIP_TEST_UNVERIFIED=1")
-
-
+# ---- GPU tier (first run on the MI355X: round 3, profiles/r03_size_limited_slices_*_mi355x.txt)
 @pytest.mark.gpu
-@_unverified
 def test_random_sessions_on_the_mi355x(hip_lib):
     _fuzz(hip_lib, range(1000, 1016))
 
 
 @pytest.mark.gpu
-@_unverified
 def test_random_screen_content_and_low_qp_sessions_on_the_mi355x(hip_lib):
     import fuzz_dynslice
     from concurrent.futures import ThreadPoolExecutor

@@ -65,7 +65,7 @@ def _run_row(workdir, lib, row, tag, extra_env=None):
         opts += k.split() + [v]
     opts = [o if o != "bgd" else "-bgd" for o in opts]
     out = str(workdir / ("t_%s.264" % tag))
-    env = dict(os.environ, WELSHIP_LIB=lib, WELS_HIP_TRACE="1", WELS_HIP_GOM="1", WELS_HIP_CHECK_BITS="1")
+    env = dict(os.environ, WELSHIP_LIB=lib, WELS_HIP_TRACE="1", WELS_HIP_CHECK_BITS="1")
     env.update(extra_env or {})
     p = subprocess.run([H264ENC, "welsenc.cfg", "-lconfig", "0", "layer0.cfg", "-lconfig", "1", "layer1.cfg", "-lconfig", "2", "layer2.cfg",
                         "-lconfig", "3", "layer3.cfg", "-bf", out, "-org", str(workdir / (CLIP + ".yuv"))] + opts,
@@ -119,9 +119,9 @@ def test_every_screen_content_path_is_reached(workdir, emu_lib):
     assert len(stat) == 11 and all(v > 0 for v in stat.values()), stat
 
 
-def test_size_limited_rows_stay_on_the_c_path(workdir, emu_lib):
+def test_switched_off_size_limited_rows_stay_on_the_c_path(workdir, emu_lib):
     row = [r for r in _rows() if r[4]["-slcmd 0"] == "3"][0]
-    got, pictures, err = _run_row(workdir, emu_lib, row, "c0")
+    got, pictures, err = _run_row(workdir, emu_lib, row, "c0", {"WELS_HIP_DYNSLICE": "0"})
     assert "not installed" in err and pictures == 0 and got == row[0]
 
 
@@ -157,7 +157,7 @@ API_GOLDEN_SCREEN = [  # test/api/encoder_test.cpp:146-157 (SEncParamBase, SCREE
 
 def _api_hash(exe, lib, tmp_path, name, w, h, fps):
     out = str(tmp_path / "o.264")
-    env = dict(os.environ, WELSHIP_LIB=lib or "", WELS_HIP_TRACE="1", WELS_HIP_GOM="1", WELS_HIP_CHECK_BITS="1")
+    env = dict(os.environ, WELSHIP_LIB=lib or "", WELS_HIP_TRACE="1", WELS_HIP_CHECK_BITS="1")
     p = subprocess.run([os.path.join(REF, exe), "-i", os.path.join(RES, name), "-w", str(w), "-h", str(h), "-o", out, "-base", "-usage", "1", "-rc", "0",
                         "-fps", str(fps), "-quiet"], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
     err = p.stderr.decode(errors="replace")

@@ -68,7 +68,7 @@ def _run_row(workdir, lib, row, tag, extra_env=None):
         opts += k.split() + [v]
     opts = [o if o != "bgd" else "-bgd" for o in opts]       # the table's header spells this one column without its dash
     out = str(workdir / ("t_%s.264" % tag))
-    env = dict(os.environ, WELSHIP_LIB=lib, WELS_HIP_TRACE="1", WELS_HIP_GOM="1", WELS_HIP_CHECK_BITS="1")      # the one-slice rows use GOM-level QP: opt-in
+    env = dict(os.environ, WELSHIP_LIB=lib, WELS_HIP_TRACE="1", WELS_HIP_CHECK_BITS="1")      # product defaults: the one-slice rows run their GOM-level QP inside the kernel (P pictures) or group by group
     env.update(extra_env or {})
     p = subprocess.run([H264ENC, "welsenc.cfg", "-lconfig", "0", "layer0.cfg", "-lconfig", "1", "layer1.cfg", "-lconfig", "2", "layer2.cfg",
                         "-lconfig", "3", "layer3.cfg", "-bf", out, "-org", str(workdir / "BA_MW_D.264.yuv")] + opts,
@@ -113,12 +113,11 @@ def test_sha1_table_rows_on_emulation(workdir, emu_lib):
     _check(workdir, emu_lib, _device_rows()[1::4])
 
 
-def test_unsupported_rows_stay_on_the_c_path(workdir, emu_lib):
-    """Size-limited slices feed the bitstream position back into mode decision macroblock by macroblock: the hooks decline, the
-    reference codes the stream itself and still matches the table."""
+def test_switched_off_rows_stay_on_the_c_path(workdir, emu_lib):
+    """With WELS_HIP_DYNSLICE=0 the hooks decline size-limited slices: the reference codes the stream itself and still matches the table."""
     rows = [r for r in _rows() if r[4]["-slcmd 0"] == "3"][:3]
     for i, row in enumerate(rows):
-        got, pictures, err = _run_row(workdir, emu_lib, row, "c%d" % i)
+        got, pictures, err = _run_row(workdir, emu_lib, row, "c%d" % i, {"WELS_HIP_DYNSLICE": "0"})
         assert "not installed" in err and pictures == 0
         assert got == row[0]
 
@@ -155,12 +154,13 @@ def test_size_limited_rows_on_emulation(workdir, emu_lib):
     assert sum(m for _, m in res) > 100          # pictures of more than one slice really occurred (the IDR pictures at least)
 
 
-def test_gom_sessions_are_opt_in(emu_lib, tmp_path):
-    """Rate control with one slice per picture means one device round trip per group of macroblocks: correct (the rows above)
-    but slower than the host, so the installer declines it unless WELS_HIP_GOM=1 -- and says so."""
+def test_gom_sessions_can_be_switched_off(emu_lib, tmp_path):
+    """Rate control with one slice per picture (the reference's DEFAULT parameter set) runs on the device by default -- the groups' QP
+    recursion inside the kernel for P pictures, one call per group otherwise; WELS_HIP_GOM=0 leaves such sessions to the C path and
+    the installer says so."""
     out = str(tmp_path / "o.264")
     env = dict(os.environ, WELSHIP_LIB=emu_lib, WELS_HIP_TRACE="1")
-    env.pop("WELS_HIP_GOM", None)
+    env["WELS_HIP_GOM"] = "0"
     name, w, h, fps, sha = API_GOLDEN[0]
     p = subprocess.run([os.path.join(REF, "ref_enc_hip"), "-i", os.path.join(RES, name), "-w", str(w), "-h", str(h), "-o", out, "-base", "-rc", "0",
                         "-fps", str(fps), "-quiet"], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
@@ -172,6 +172,16 @@ def test_gom_sessions_are_opt_in(emu_lib, tmp_path):
 @pytest.mark.gpu
 def test_sha1_table_rows_on_the_mi355x(workdir, hip_lib):
     _check(workdir, hip_lib, _sample(_device_rows(), 128))
+
+
+@pytest.mark.gpu
+def test_sha1_table_rows_on_the_mi355x_row_scheduler(workdir, hip_lib):
+    """The same through the row scheduler with sliding windows (k_inter_rows), which single QCIF sessions would not select themselves."""
+    os.environ["WELSHIP_MD_ROWS"] = "1"
+    try:
+        _check(workdir, hip_lib, _sample(_device_rows(), 96)[1::2])
+    finally:
+        del os.environ["WELSHIP_MD_ROWS"]
 
 
 # ---- SURVEY 8(f) 3: the one-slice rows with the groups' QP recursion INSIDE the kernel (WELS_HIP_GOM=2) ------------------------
@@ -209,6 +219,24 @@ def test_gom_rate_control_inside_the_kernel_on_the_mi355x(workdir, hip_lib):
     _check_gom_kernel(workdir, hip_lib, _gom_rows()[5::16])
 
 
+def _check_gom_per_group(workdir, lib, rows):
+    """WELS_HIP_GOM=1: every group of macroblocks is a device call of its own (what I pictures, screen content and CABAC sessions
+    always do; forced here for the P pictures too)."""
+    for i, row in enumerate(rows):
+        got, pictures, err = _run_row(workdir, lib, row, "pg%d" % i, {"WELS_HIP_GOM": "1"})
+        os.remove(str(workdir / ("t_pg%d.264" % i)))
+        assert got == row[0] and pictures >= 40 and err.count("GOM-level QP") > pictures // 2, (row[4], got, pictures)
+
+
+def test_gom_rate_control_group_by_group_on_emulation(workdir, emu_lib):
+    _check_gom_per_group(workdir, emu_lib, [r for r in _gom_rows() if r[4]["-slcmd 0"] == "0"][3::64])
+
+
+@pytest.mark.gpu
+def test_gom_rate_control_group_by_group_on_the_mi355x(workdir, hip_lib):
+    _check_gom_per_group(workdir, hip_lib, [r for r in _gom_rows() if r[4]["-slcmd 0"] == "0"][7::64])
+
+
 # ---- the API-level golden hashes and the stock configuration through the binding ---------------------------------------------
 API_GOLDEN = [  # test/api/encoder_test.cpp:104-115 (SEncParamBase: RC quality mode, 5 Mbps, one slice -> GOM-level QP)
     ("CiscoVT2people_160x96_6fps.yuv", 160, 96, 6.0, "08ade1853e4e49d50be675393780e75519586143"),
@@ -217,9 +245,11 @@ API_GOLDEN = [  # test/api/encoder_test.cpp:104-115 (SEncParamBase: RC quality m
 ]
 
 
-def _api_hash(lib, tmp_path, name, w, h, fps, gom="1"):
+def _api_hash(lib, tmp_path, name, w, h, fps, gom=None):
     out = str(tmp_path / "o.264")
-    env = dict(os.environ, WELSHIP_LIB=lib, WELS_HIP_TRACE="1", WELS_HIP_GOM=gom, WELS_HIP_CHECK_BITS="1")
+    env = dict(os.environ, WELSHIP_LIB=lib, WELS_HIP_TRACE="1", WELS_HIP_CHECK_BITS="1")
+    env.pop("WELS_HIP_GOM", None)          # default: the groups' QP recursion inside the kernel for P pictures (= "2")
+    if gom: env["WELS_HIP_GOM"] = gom
     p = subprocess.run([os.path.join(REF, "ref_enc_hip"), "-i", os.path.join(RES, name), "-w", str(w), "-h", str(h), "-o", out, "-base", "-rc", "0",
                         "-fps", str(fps), "-quiet"], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
     err = p.stderr.decode(errors="replace")
@@ -240,14 +270,14 @@ def test_api_golden_hash_through_the_hooks_on_the_mi355x(hip_lib, tmp_path, name
 
 
 @pytest.mark.parametrize("name,w,h,fps,sha", API_GOLDEN[:2])
-def test_api_golden_hash_gom_inside_the_kernel_on_emulation(emu_lib, tmp_path, name, w, h, fps, sha):
-    assert _api_hash(emu_lib, tmp_path, name, w, h, fps, gom="2") == sha
+def test_api_golden_hash_gom_group_by_group_on_emulation(emu_lib, tmp_path, name, w, h, fps, sha):
+    assert _api_hash(emu_lib, tmp_path, name, w, h, fps, gom="1") == sha
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,w,h,fps,sha", API_GOLDEN[:2])
-def test_api_golden_hash_gom_inside_the_kernel_on_the_mi355x(hip_lib, tmp_path, name, w, h, fps, sha):
-    assert _api_hash(hip_lib, tmp_path, name, w, h, fps, gom="2") == sha
+def test_api_golden_hash_gom_group_by_group_on_the_mi355x(hip_lib, tmp_path, name, w, h, fps, sha):
+    assert _api_hash(hip_lib, tmp_path, name, w, h, fps, gom="1") == sha
 
 
 def _stock_cfg(lib, tmp_path):
@@ -257,7 +287,7 @@ def _stock_cfg(lib, tmp_path):
     (tmp_path / "welsenc.cfg").write_text(cfg)
     (tmp_path / "layer2.cfg").write_bytes(open(os.path.join(RES, "layer2.cfg"), "rb").read())
     subprocess.check_call([os.path.join(REF, "h264enc_ref"), "welsenc.cfg", "-bf", "ref.264"], cwd=str(tmp_path), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    env = dict(os.environ, WELSHIP_LIB=lib, WELS_HIP_TRACE="1", WELS_HIP_GOM="1", WELS_HIP_CHECK_BITS="1")
+    env = dict(os.environ, WELSHIP_LIB=lib, WELS_HIP_TRACE="1", WELS_HIP_CHECK_BITS="1")
     p = subprocess.run([H264ENC, "welsenc.cfg", "-bf", "hip.264"], cwd=str(tmp_path), env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
     err = p.stderr.decode(errors="replace")
     assert p.returncode == 0 and "welship hooks: installed" in err and err.count("welship hooks: did") >= 5, err[-2000:]

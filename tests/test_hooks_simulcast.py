@@ -25,7 +25,7 @@ def _both(lib, tmp_path, yuv, w, h, flags, min_pictures):
     open(fi, "wb").write(yuv)
     base = ["-i", fi, "-w", str(w), "-h", str(h), "-fps", "30", "-quiet"] + flags
     subprocess.check_call([os.path.join(REF, "ref_enc"), "-o", str(tmp_path / "ref.264")] + base, stdout=subprocess.DEVNULL)
-    env = dict(os.environ, WELSHIP_LIB=lib, WELS_HIP_TRACE="1", WELS_HIP_GOM="1", WELS_HIP_CHECK_BITS="1")
+    env = dict(os.environ, WELSHIP_LIB=lib, WELS_HIP_TRACE="1", WELS_HIP_CHECK_BITS="1")
     p = subprocess.run([os.path.join(REF, "ref_enc_hip"), "-o", str(tmp_path / "hip.264")] + base, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
     err = p.stderr.decode(errors="replace")
     assert p.returncode == 0, err[-2000:]

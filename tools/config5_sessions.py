@@ -4,7 +4,9 @@ N instances on N threads of one process, integration/welship_hooks.cpp) -- again
 (WELS_HIP=0).  One process per GPU hosting its sessions is the deployment: kernels of different sessions then share the device
 (different processes would be time-sliced).  Prints one JSON line.
 
-usage: config5_sessions.py [sessions=8] [frames=60]   (needs oracle/_ref incl. res/; the GPU leg needs an MI355X)"""
+usage: config5_sessions.py [sessions=8] [frames=60] [mode] [1080p]   (needs oracle/_ref incl. res/; the GPU leg needs an MI355X)
+A fourth argument "1080p" gives BASELINE's sizes as stated: config 5 = 1920x1080 sessions (raster slices of 2040 MBs = 4 slices, 4 Mbit/s),
+config 4 ("simulcast") = 1080p / 720p / 360p / 180p layers instead of the 540 / 270 / 135 ladder."""
 import hashlib, json, os, re, subprocess, sys, tempfile, time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -21,7 +23,9 @@ GOM = len(sys.argv) > 3 and sys.argv[3] == "gom"
 # third argument "dynslice": the 720p sessions with size-limited slices of 1200 bytes (what an RTP caller asks for; WELS_HIP_DYNSLICE=1 is set here)
 DYNSLICE = len(sys.argv) > 3 and sys.argv[3] == "dynslice"
 LIB = os.environ.get("WELSHIP_LIB") or os.path.join(ROOT, "openh264_amd", "libwelship.so")
-W, H = (1920, 1080) if SIMULCAST else (1024, 768) if SCREEN else (1280, 720)
+FULL = len(sys.argv) > 4 and sys.argv[4] == "1080p"
+W, H = (1920, 1080) if (SIMULCAST or (FULL and not SCREEN)) else (1024, 768) if SCREEN else (1280, 720)
+LADDER = ["-simulcast", "320", "180", "-simulcast", "640", "360", "-simulcast", "1280", "720"] if FULL else ["-simulcast", "240", "135", "-simulcast", "480", "270", "-simulcast", "960", "540"]
 
 
 def run(tmp, yuv, hip):
@@ -30,12 +34,12 @@ def run(tmp, yuv, hip):
         env["WELS_HIP_DYNSLICE"] = "1"
     out = os.path.join(tmp, "s_%d.264" % hip)
     cmd = [os.path.join(REF, "ref_enc_hip"), "-parallel", str(N), "-i", yuv, "-w", str(W), "-h", str(H), "-o", out, "-frames", str(FRAMES),
-           "-fps", "30", "-rc", "1", "-bitrate", "1500000", "-threads", "1", "-iper", "0", "-quiet"]
-    cmd += (["-slcmd", "1", "-slcnum", "4", "-simulcast", "240", "135", "-simulcast", "480", "270", "-simulcast", "960", "540"] if SIMULCAST
+           "-fps", "30", "-rc", "1", "-bitrate", "4000000" if FULL and not SIMULCAST else "1500000", "-threads", "1", "-iper", "0", "-quiet"]
+    cmd += (["-slcmd", "1", "-slcnum", "4"] + LADDER if SIMULCAST
             else ["-usage", "1", "-slcmd", "1", "-slcnum", "4", "-scene", "1", "-denoise", "1", "-frameskip", "1"] if SCREEN
             else ["-slcmd", "0"] if GOM
             else ["-slcmd", "3", "-slcsize", "1200"] if DYNSLICE
-            else ["-slcmd", "2", "-slcmbnum", "900"])
+            else ["-slcmd", "2", "-slcmbnum", "2040" if FULL else "900"])
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert p.returncode == 0, p.stderr[-2000:]
     if hip and os.environ.get("WELSHIP_FRAME_STATS"):
@@ -59,7 +63,7 @@ def main():
         nfr = os.path.getsize(yuv) // (W * H * 3 // 2)
         c_leg, c_sha = run(tmp, yuv, False)
         h_leg, h_sha = run(tmp, yuv, True)
-        print(json.dumps({"config": "%d concurrent sessions, %dx%d, %d frames each (clip has %d), RC bitrate mode 1.5 Mbps per layer, %s, one process, one thread per session" % (N, W, H, FRAMES, nfr, "4 simulcast AVC layers of 4 slices" if SIMULCAST else "screen content, 4 slices" if SCREEN else "one slice (GOM-level QP, WELS_HIP_GOM=%s)" % os.environ.get("WELS_HIP_GOM", "unset") if GOM else "size-limited slices of 1200 bytes (WELS_HIP_DYNSLICE=1): %s" % getattr(run, "dyn", None) if DYNSLICE else "raster slices of 900 MBs"),
+        print(json.dumps({"config": "%d concurrent sessions, %dx%d, %d frames each (clip has %d), RC bitrate mode %s Mbps per layer, %s, one process, one thread per session" % (N, W, H, FRAMES, nfr, "4" if FULL and not SIMULCAST else "1.5", ("4 simulcast AVC layers (%s) of 4 slices" % ("1080p/720p/360p/180p" if FULL else "1080p/540p/270p/135p")) if SIMULCAST else "screen content, 4 slices" if SCREEN else "one slice (GOM-level QP, WELS_HIP_GOM=%s)" % os.environ.get("WELS_HIP_GOM", "unset") if GOM else "size-limited slices of 1200 bytes (WELS_HIP_DYNSLICE=1): %s" % getattr(run, "dyn", None) if DYNSLICE else "raster slices of %d MBs" % (2040 if FULL else 900)),
                           "reference_c_path": c_leg, "hooks_on_device": h_leg, "same_bitstreams": c_sha == h_sha, "lib": os.path.basename(LIB)}))
 
 

@@ -1,0 +1,34 @@
+#!/bin/bash
+# Round 3, second run: the tiled reference pictures + the row scheduler with sliding windows (k_inter_rows).
+#   1. GPU tier (now with the size-limited-slice tests armed and the row-scheduler variants)   2. default bench line (verified)
+#   3. A/B rows vs tickets (WELSHIP_MD_ROWS=0), both on tiled windows; on the reference's clip too
+#   4. traffic: FETCH_SIZE / WRITE_SIZE passes of both        5. phase cycles of the row kernel        6. kernel trace
+cd "$(dirname "$0")/.."
+export TMPDIR=/tmp
+o=gpurun_out/r03_b; rm -rf $o; mkdir -p $o
+t0=$(date +%s); lap() { echo "[$(( $(date +%s) - t0 )) s] $*"; }
+timeout 400 python -m pytest tests -m gpu -q -n 4 > $o/pytest_gpu.txt 2>&1; tail -5 $o/pytest_gpu.txt; lap "gpu tier"
+( time timeout 300 python bench.py > $o/bench_default.json 2> $o/bench_default.err ) 2> $o/bench_default.time; python - <<PY
+import json
+d = json.loads(open("$o/bench_default.json").read().strip().splitlines()[-1])
+print("default: value", round(d["value"]), "ms_per_step", d["ms_per_step"], "roofline", d["roofline"], "verified", d.get("verified"))
+for k in ("res_clip", "e2e", "e2e_overlapped", "latency", "intra_720p"):
+    if k in d: print(k, json.dumps(d[k])[:300])
+PY
+lap "bench default"
+for mode in 1 0; do
+  WELSHIP_MD_ROWS=$mode timeout 120 python bench.py --quick --steps 60 > $o/bench_quick_rows$mode.json 2> $o/bench_quick_rows$mode.err
+  WELSHIP_MD_ROWS=$mode timeout 120 python bench.py --quick --steps 40 --content res > $o/bench_quick_res_rows$mode.json 2> $o/bench_quick_res_rows$mode.err
+  for f in bench_quick_rows$mode bench_quick_res_rows$mode; do echo "$f: $(python -c "import json; d=json.loads(open('$o/$f.json').read().strip().splitlines()[-1]); print(round(d['value']), d['roofline']['events_ms'])")"; done
+done
+lap "A/B"
+for mode in 1 0; do
+  for c in FETCH_SIZE WRITE_SIZE; do
+    ( cd /tmp && WELSHIP_MD_ROWS=$mode timeout 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OLDPWD/$o/pmc_rows${mode}_$c -- python $OLDPWD/bench.py --quick --steps 8 --warmup 4 > $OLDPWD/$o/pmc_rows${mode}_$c.log 2>&1 )
+    python tools/pmc_summary.py $o/pmc_rows${mode}_$c | grep -E "inter_|deblock|k_tile|k_expand" | sed "s/^/rows=$mode /"
+  done
+done > $o/pmc_traffic.txt 2>&1; cat $o/pmc_traffic.txt; lap "pmc"
+timeout 200 python tools/phase_profile.py 256 > $o/phase_cycles_rows.txt 2>&1; head -30 $o/phase_cycles_rows.txt
+WELSHIP_MD_ROWS=0 timeout 200 python tools/phase_profile.py 256 > $o/phase_cycles_tickets.txt 2>&1; head -24 $o/phase_cycles_tickets.txt | tail -22; lap "phase cycles"
+( cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$o/trace -- python $OLDPWD/bench.py --quick --steps 8 --warmup 4 > $OLDPWD/$o/trace.log 2>&1 )
+f=$(find $o/trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $o/kernel_stats.csv && head -12 $o/kernel_stats.csv; lap "trace"
