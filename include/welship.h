@@ -364,6 +364,13 @@ int WelsHipPrimVaaSad8x8 (int nMb, const uint8_t* pCur, const uint8_t* pRef, siz
 #define WELSHIP_DS_GENERAL_ACCURATE 4
 int WelsHipPrimDownsample (int mode, uint8_t* pDst, int32_t iDstStride, int32_t iDstWidth, int32_t iDstHeight,
                            const uint8_t* pSrc, int32_t iSrcStride, int32_t iSrcWidth, int32_t iSrcHeight);
+/* One picture, three planes, the method CDownsampling::Process (codec/processing/src/downsample/downsample.cpp:144-277) picks for the
+ * size pair -- the dyadic cascade included -- in one call: what the dispatch-table binding runs in place of
+ * m_pInterfaceVp->Process (METHOD_DOWNSAMPLE, ..) in CWelsPreProcess::DownsamplePadding (wels_preprocess.cpp:625-675; the padding
+ * that follows stays the caller's).  Host planes in, host planes out (I420; chroma planes are (w >> 1) x (h >> 1)); samples outside
+ * iDstWidth x iDstHeight are untouched.  Thread-safe; per device one queue with page-locked staging that is kept between calls. */
+int WelsHipDownsamplePicture (int iDevice, uint8_t* const pDst[3], const int32_t iDstStride[3], int32_t iDstWidth, int32_t iDstHeight,
+                              const uint8_t* const pSrc[3], const int32_t iSrcStride[3], int32_t iSrcWidth, int32_t iSrcHeight);
 /* one launch over nPlanes HBM-resident planes, timed with HIP events: pOut[0] = ms per launch, pOut[1] = algorithmic bytes per launch */
 int WelsHipDownsampleBench (int iDevice, int mode, int nPlanes, int iSrcWidth, int iSrcHeight, int iDstWidth, int iDstHeight, int iIters, double* pOut);
 

@@ -141,7 +141,7 @@ typedef struct WhGomRc {
 
 // ---- one picture being encoded (one frame of one session) ---------------------------------------
 typedef struct WhPicJob {
-  const uint8_t* src[3];     // source planes, dims = mb_w*16 x mb_h*16 (host pads), own strides
+  const uint8_t* src[3];     // source picture, dims = mb_w*16 x mb_h*16 (host pads): src[0] = the macroblock-tiled picture (WH_SRC_*), [1], [2] unused
   uint8_t*       rec[3];     // reconstructed planes (point at pixel (0,0) inside the padded alloc)
   const uint8_t* ref[3];     // reference planes (border-expanded) or NULL for I pictures
   WhMbRecord*    records;    // mb_w*mb_h
@@ -153,7 +153,7 @@ typedef struct WhPicJob {
   int32_t        ref_is_p;   // reference picture was a P picture (co-located MV candidates)
   int32_t        want_bits;  // bit 0: count every macroblock's CAVLC bits (WhMbRecord::cavlc_bits); bit 1: the slice codes ref_idx_l0
                              //   (num_ref_idx_l0_active_minus1 > 0)
-  const uint8_t* prev_src_y; // luma of the previous source picture (VAA 8x8 SADs, LOW complexity P pictures)
+  const uint8_t* prev_src_y; // the previous source picture, macroblock-tiled like src[0] (VAA 8x8 SADs of LOW complexity P pictures, scene change)
   uint32_t*      db_flags;   // one word per MB: == db_gen once the MB is deblocked (hand-off between the slices' workgroups)
   uint32_t       db_gen;     // generation of this picture (never 0, changes every frame: the flags need no clearing)
   int32_t        dyn_first;  // size-limited slices (dyn_slice != 0): first macroblock of the slice this launch codes
@@ -206,6 +206,13 @@ typedef struct WhPicJob {
 //   chroma   8 samples x 8 rows, Cb | Cr per row (16 B) -> a 32 x 32 window (both planes) touches 4 x 4..5 lines (2-2.5 KB)
 // covering the whole border-expanded plane (32 / 16 samples each side; strides as in WhSeqParams).  Windows start at tile columns
 // (x0 a multiple of 16 / 8), so every 16-byte piece a lane fetches is one row of one tile.
+// The SOURCE pictures are kept macroblock by macroblock: 384 bytes per MB -- 16x16 luma row-major, then the 8x8 Cb and the 8x8 Cr block --
+// so that a macroblock's source samples are three consecutive memory lines instead of 32 pieces of 32 different ones (a planar picture
+// gives every MB row of 16 / 8 bytes a line of its own: 6 KB of line traffic per macroblock incl. the previous picture's luma).  The
+// host uploads planar I420 as before; one pass on the device (kernels/tile_pic.h wh_src_tile_item) rearranges it.
+#define WH_SRC_MB_BYTES 384
+#define WH_SRC_Y_OFF(mb_w, mbx, mby, row, x) ((size_t) ((mby) * (mb_w) + (mbx)) * WH_SRC_MB_BYTES + (size_t) ((row) * 16 + (x)))
+#define WH_SRC_C_OFF(mb_w, mbx, mby, pl, row, x) ((size_t) ((mby) * (mb_w) + (mbx)) * WH_SRC_MB_BYTES + (size_t) (256 + (pl) * 64 + (row) * 8 + (x)))
 #define WH_TILE_BYTES 128
 // byte offset of the 16-byte row piece that holds luma sample (x, y), picture coordinates (x >= -32, y >= -32)
 #define WH_TILE_Y_OFF(stride_y, x, y) ((((size_t) (((y) + 32) >> 3) * (size_t) ((stride_y) >> 4) + (size_t) (((x) + 32) >> 4)) << 7) + (size_t) ((((y) + 32) & 7) << 4))
@@ -222,6 +229,7 @@ typedef struct WhPicJob {
                                     //   order -- in a processing order built for the picture that respects both (WhPicJob::scc_order)
 #define WH_SEQ_RANGED 8             // the pictures of the launch code MB ranges (WhPicJob::mb_begin / mb_end, dyn_slice) or carry GOM rate control:
                                     //   the ticket scheduler runs them (k_inter_pool); everything without a flag may take the row scheduler
+#define WH_SEQ_ROWS_SPREAD 16        // (set by the launcher only, never part of a batching key: row scheduler experiment, see k_inter_rows)
 #define WH_DB_BAND_ROWS 24          // a deblocking band (one workgroup) never spans more MB rows than this
 
 // ---- parameters common to every picture of a launch --------------------------------------------

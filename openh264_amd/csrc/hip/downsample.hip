@@ -12,8 +12,12 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <string.h>
+#include <map>
+#include <mutex>
 #include <vector>
 #include "../../../include/welship.h"
+#include "../kernels/downsample_px.h"
 
 namespace {
 
@@ -39,10 +43,7 @@ __global__ __launch_bounds__ (256) void k_ds_half (const DsPlane* planes, int sr
     }
     * (uint2*)d = make_uint2 (o[0], o[1]);
   } else {
-    for (int i = 0; i < 8 && x8 * 8 + i < dst_w; ++i) {
-      const int t1 = (s[2 * i] + s[2 * i + 1] + 1) >> 1, t2 = (s[2 * i + src_stride] + s[2 * i + 1 + src_stride] + 1) >> 1;
-      d[i] = (uint8_t) ((t1 + t2 + 1) >> 1);
-    }
+    for (int i = 0; i < 8 && x8 * 8 + i < dst_w; ++i) d[i] = wh_ds_avg2x2 (s + 2 * i, src_stride);
   }
 }
 
@@ -51,9 +52,7 @@ __global__ __launch_bounds__ (256) void k_ds_step (const DsPlane* planes, int sr
   const DsPlane pl = planes[blockIdx.z];
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
   if (x >= dst_w) return;
-  const uint8_t* s = pl.src + (size_t) (step * y) * src_stride + step * x;
-  const int t1 = (s[0] + s[1] + 1) >> 1, t2 = (s[src_stride] + s[src_stride + 1] + 1) >> 1;
-  pl.dst[(size_t)y * dst_stride + x] = (uint8_t) ((t1 + t2 + 1) >> 1);
+  pl.dst[(size_t)y * dst_stride + x] = wh_ds_avg2x2 (pl.src + (size_t) (step * y) * src_stride + step * x, src_stride);
 }
 
 // any ratio: `accurate` = GeneralBilinearAccurateDownsampler_c, else GeneralBilinearFastDownsampler_c; last column and last
@@ -62,38 +61,11 @@ __global__ __launch_bounds__ (256) void k_ds_general (const DsPlane* planes, int
   const DsPlane pl = planes[blockIdx.z];
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
   if (x >= dst_w) return;
-  const int bw = accurate ? 15 : 16, bh = 15;
-  const int64_t xinv = ((int64_t)1 << (bw - 1)) + (int64_t)x * scalex, yinv = ((int64_t)1 << (bh - 1)) + (int64_t)y * scaley;
-  const int xx = (int) (xinv >> bw), yy = (int) (yinv >> bh);
-  const uint8_t* p = pl.src + (size_t)yy * src_stride + xx;
-  uint8_t out;
-  if (y == dst_h - 1 || x == dst_w - 1) out = p[0];
-  else {
-    const uint32_t fu = (uint32_t) (xinv & ((1 << bw) - 1)), fv = (uint32_t) (yinv & ((1 << bh) - 1));
-    const uint32_t a = p[0], b = p[1], c = p[src_stride], d = p[src_stride + 1];
-    if (accurate) {
-      const int64_t k = 1 << 15;
-      int64_t v = ((k - 1 - fu) * (k - 1 - fv) * a + (int64_t)fu * (k - 1 - fv) * b + (k - 1 - fu) * (int64_t)fv * c + (int64_t)fu * fv * d + ((int64_t)1 << 29)) >> 30;
-      out = (uint8_t) (v < 0 ? 0 : v > 255 ? 255 : v);
-    } else {
-      const uint32_t sw = 1u << 16, sh = 1u << 15;
-      uint32_t v = (((sw - 1 - fu) * (sh - 1 - fv)) >> 16) * a;
-      v += ((fu * (sh - 1 - fv)) >> 16) * b;
-      v += (((sw - 1 - fu) * fv) >> 16) * c;
-      v += ((fu * fv) >> 16) * d;
-      v >>= 14;
-      v += 1;
-      v >>= 1;
-      out = (uint8_t) (v > 255 ? 255 : v);
-    }
-  }
+  const uint8_t out = wh_ds_general (pl.src, src_stride, dst_w, dst_h, x, y, scalex, scaley, accurate);
   pl.dst[(size_t)y * dst_stride + x] = out;
 }
 
-inline int round_scale (int src, int dst, int bits) {        // WELS_ROUND ((float)src / (float)dst * (1 << bits))
-  const float f = (float)src / (float)dst * (float) (1 << bits);
-  return (int) (f + (f >= 0 ? 0.5f : -0.5f));
-}
+inline int round_scale (int src, int dst, int bits) { return wh_ds_round_scale (src, dst, bits); }
 
 int launch (int mode, const DsPlane* d_planes, int n, int src_stride, int src_w, int src_h, int dst_stride, int dst_w, int dst_h, hipStream_t st) {
   switch (mode) {
@@ -144,6 +116,115 @@ int WelsHipPrimDownsample (int mode, uint8_t* pDst, int32_t iDstStride, int32_t 
   if (dp) (void)hipFree (dp);
   return rc;
 }
+
+}  // extern "C"
+
+namespace {
+
+// ---- one picture, all three planes, the method CDownsampling::Process (downsample.cpp:144-277) would pick -------------------
+// What the dispatch-table binding calls from the reference's pre-processing (integration/welship_hooks.cpp, DownsamplePadding,
+// wels_preprocess.cpp:625-675) instead of m_pInterfaceVp->Process (METHOD_DOWNSAMPLE, ..): source planes up, the kernels of the
+// cascade, destination planes back.  Per device one context with a queue, page-locked staging and device buffers that grow to
+// the largest picture seen; calls on one device serialise on its mutex (a call lasts well under a millisecond).
+struct DsContext {
+  std::mutex mu;
+  hipStream_t st = nullptr;
+  uint8_t* h_buf = nullptr; size_t h_cap = 0;       // page-locked: source planes | destination planes
+  uint8_t* d_buf = nullptr; size_t d_cap = 0;       // source | two intermediate pictures | destination
+  DsPlane* d_planes = nullptr;                       // 3 planes per stage, up to 8 stages
+  DsPlane* h_planes = nullptr;
+  bool ok = false;
+};
+std::mutex g_ds_mu;
+std::map<int, DsContext*> g_ds_ctx;
+
+inline size_t al256 (size_t v) { return (v + 255) & ~ (size_t)255; }
+
+}  // namespace
+
+extern "C" int WelsHipDownsamplePicture (int iDevice, uint8_t* const pDst[3], const int32_t iDstStride[3], int32_t iDstWidth, int32_t iDstHeight,
+                                         const uint8_t* const pSrc[3], const int32_t iSrcStride[3], int32_t iSrcWidth, int32_t iSrcHeight) {
+  int cnt = 0;
+  if (hipGetDeviceCount (&cnt) != hipSuccess || cnt <= 0) return WELSHIP_ERR_NO_DEVICE;
+  if (iDevice < 0 || iDevice >= cnt) return WELSHIP_ERR_NO_DEVICE;
+  if (!pDst || !pSrc || !iDstStride || !iSrcStride || iDstWidth < 2 || iDstHeight < 2 || iSrcWidth <= iDstWidth || iSrcHeight <= iDstHeight ||
+      iSrcWidth > 8192 || iSrcHeight > 8192) return WELSHIP_ERR_INIT_PARA;
+  for (int i = 0; i < 3; ++i) if (!pDst[i] || !pSrc[i] || iSrcStride[i] < (i ? iSrcWidth >> 1 : iSrcWidth) || iDstStride[i] < (i ? iDstWidth >> 1 : iDstWidth)) return WELSHIP_ERR_INIT_PARA;
+  DsContext* c = nullptr;
+  {
+    std::lock_guard<std::mutex> reg (g_ds_mu);
+    DsContext*& slot = g_ds_ctx[iDevice];
+    if (!slot) slot = new DsContext();
+    c = slot;
+  }
+  std::lock_guard<std::mutex> lock (c->mu);
+  if (hipSetDevice (iDevice) != hipSuccess) return WELSHIP_ERR_NO_DEVICE;
+  if (!c->ok) {
+    if (hipStreamCreateWithFlags (&c->st, hipStreamNonBlocking) != hipSuccess) return WELSHIP_ERR_UNKNOWN;
+    if (hipMalloc ((void**)&c->d_planes, sizeof (DsPlane) * 24) != hipSuccess || hipHostMalloc ((void**)&c->h_planes, sizeof (DsPlane) * 24) != hipSuccess) return WELSHIP_ERR_MEMORY;
+    c->ok = true;
+  }
+  // the stages CDownsampling::Process would take (kernels/downsample_px.h wh_ds_plan)
+  typedef WhDsStage Stage;
+  WhDsStage plan[8];
+  const int nst = wh_ds_plan (iSrcWidth, iSrcHeight, iDstWidth, iDstHeight, plan);
+  if (nst < 1) return WELSHIP_ERR_INIT_PARA;
+  const std::vector<Stage> stages (plan, plan + nst);
+  // buffers: tight strides (64-byte multiples), one spare row per plane (the general filter's lower tap)
+  auto pitch = [] (int w) { return (w + 63) & ~63; };
+  auto pic_bytes = [&] (int w, int h) { return al256 ((size_t)pitch (w) * (h + 1)) + 2 * al256 ((size_t)pitch (w >> 1) * ((h >> 1) + 1)); };
+  const size_t src_b = pic_bytes (iSrcWidth, iSrcHeight), dst_b = pic_bytes (iDstWidth, iDstHeight), tmp_b = pic_bytes (iSrcWidth >> 1, iSrcHeight >> 1);
+  const size_t need_d = src_b + 2 * tmp_b + dst_b, need_h = src_b + dst_b;
+  if (need_d > c->d_cap) { if (c->d_buf) (void)hipFree (c->d_buf); c->d_buf = nullptr; c->d_cap = 0; if (hipMalloc ((void**)&c->d_buf, need_d) != hipSuccess) return WELSHIP_ERR_MEMORY; c->d_cap = need_d; }
+  if (need_h > c->h_cap) { if (c->h_buf) (void)hipHostFree (c->h_buf); c->h_buf = nullptr; c->h_cap = 0; if (hipHostMalloc ((void**)&c->h_buf, need_h) != hipSuccess) return WELSHIP_ERR_MEMORY; c->h_cap = need_h; }
+  struct Pic { uint8_t* p[3]; int stride[3]; };
+  auto lay = [&] (uint8_t* base, int w, int h) { Pic q; q.stride[0] = pitch (w); q.stride[1] = q.stride[2] = pitch (w >> 1); q.p[0] = base;
+                                               q.p[1] = base + al256 ((size_t)q.stride[0] * (h + 1)); q.p[2] = q.p[1] + al256 ((size_t)q.stride[1] * ((h >> 1) + 1)); return q; };
+  const Pic hs = lay (c->h_buf, iSrcWidth, iSrcHeight), hd = lay (c->h_buf + src_b, iDstWidth, iDstHeight);
+  const Pic ds = lay (c->d_buf, iSrcWidth, iSrcHeight), dd = lay (c->d_buf + src_b + 2 * tmp_b, iDstWidth, iDstHeight);
+  for (int i = 0; i < 3; ++i) {
+    const int w = i ? iSrcWidth >> 1 : iSrcWidth, h = i ? iSrcHeight >> 1 : iSrcHeight;
+    for (int r = 0; r < h; ++r) memcpy (hs.p[i] + (size_t)r * hs.stride[i], pSrc[i] + (size_t)r * iSrcStride[i], (size_t)w);
+    memcpy (hs.p[i] + (size_t)h * hs.stride[i], hs.p[i] + (size_t) (h - 1) * hs.stride[i], (size_t)w);        // (the spare row: never weighted, only addressed)
+  }
+  bool bad = hipMemcpyAsync (c->d_buf, c->h_buf, src_b, hipMemcpyHostToDevice, c->st) != hipSuccess;
+  Pic cur = ds;
+  int rc = WELSHIP_OK;
+  for (size_t k = 0; k < stages.size() && rc == WELSHIP_OK; ++k) {
+    const Stage& g = stages[k];
+    const bool last = k + 1 == stages.size();
+    const Pic out = last ? dd : lay (c->d_buf + src_b + (k & 1) * tmp_b, g.dw, g.dh);
+    for (int i = 0; i < 3; ++i) { c->h_planes[3 * k + i].src = cur.p[i]; c->h_planes[3 * k + i].dst = out.p[i]; }
+    cur = out;
+  }
+  bad = bad || hipMemcpyAsync (c->d_planes, c->h_planes, sizeof (DsPlane) * 3 * stages.size(), hipMemcpyHostToDevice, c->st) != hipSuccess;
+  cur = ds;
+  for (size_t k = 0; k < stages.size() && rc == WELSHIP_OK; ++k) {
+    const Stage& g = stages[k];
+    const bool last = k + 1 == stages.size();
+    const Pic out = last ? dd : lay (c->d_buf + src_b + (k & 1) * tmp_b, g.dw, g.dh);
+    if (g.mode >= 0) {
+      // luma, then both chroma planes in one launch (same geometry)
+      rc = launch (g.mode, c->d_planes + 3 * k, 1, cur.stride[0], g.sw, g.sh, out.stride[0], g.dw, g.dh, c->st);
+      if (rc == WELSHIP_OK) rc = launch (g.mode, c->d_planes + 3 * k + 1, 2, cur.stride[1], g.sw >> 1, g.sh >> 1, out.stride[1], g.dw >> 1, g.dh >> 1, c->st);
+    } else {
+      // pfGeneralRatioLuma = GeneralBilinearFastDownsampler_c, pfGeneralRatioChroma = GeneralBilinearAccurateDownsampler_c (the C table)
+      rc = launch (WELSHIP_DS_GENERAL_FAST, c->d_planes + 3 * k, 1, cur.stride[0], g.sw, g.sh, out.stride[0], g.dw, g.dh, c->st);
+      if (rc == WELSHIP_OK) rc = launch (WELSHIP_DS_GENERAL_ACCURATE, c->d_planes + 3 * k + 1, 2, cur.stride[1], g.sw >> 1, g.sh >> 1, out.stride[1], g.dw >> 1, g.dh >> 1, c->st);
+    }
+    cur = out;
+  }
+  bad = bad || hipMemcpyAsync (c->h_buf + src_b, c->d_buf + src_b + 2 * tmp_b, dst_b, hipMemcpyDeviceToHost, c->st) != hipSuccess;
+  if (hipStreamSynchronize (c->st) != hipSuccess || bad) { (void)hipGetLastError(); return WELSHIP_ERR_UNKNOWN; }
+  if (rc != WELSHIP_OK) return rc;
+  for (int i = 0; i < 3; ++i) {
+    const int w = i ? iDstWidth >> 1 : iDstWidth, h = i ? iDstHeight >> 1 : iDstHeight;
+    for (int r = 0; r < h; ++r) memcpy (pDst[i] + (size_t)r * iDstStride[i], hd.p[i] + (size_t)r * hd.stride[i], (size_t)w);
+  }
+  return WELSHIP_OK;
+}
+
+extern "C" {
 
 // Throughput of one down-sampling launch over `nPlanes` resident planes (HIP events on the launch stream): pOut[0] = average
 // milliseconds per launch, pOut[1] = algorithmic bytes per launch (every source sample the filter touches read once + every

@@ -317,13 +317,20 @@ __global__ __launch_bounds__ (MAXT) void k_inter_rows (WhSeqParams P, const WhPi
   int slot = -1, x = 0, y = 0, xe = 0;          // the macroblock in hand: (x, y) of slot `slot`, its row segment ends before xe
   int nslot = -1, nx = 0, ny = 0, nxe = 0;      // the wave's next one
   // next(): the right neighbour, or the first macroblock of the next unclaimed row (of the slot with most rows left)
+  const bool spread = (P.flags & WH_SEQ_ROWS_SPREAD) != 0;      // (experiment knob WELSHIP_MD_ROWS=2: the slot with most rows left)
+  int brem = 0;
   auto next_fn = [&] () __attribute__ ((always_inline)) {
+    brem = 0;
     if (slot >= 0 && x + 1 < xe) { nslot = slot; nx = x + 1; ny = y; nxe = xe; return; }
     for (nslot = -1;;) {
-      int best = -1, brem = 0;
+      // The waves of a workgroup work ONE slice off at a time (the first slot that has unclaimed rows): its rows then advance as a tight
+      // front, each two macroblocks behind the one above, and finish almost together -- as the 2:1 ticket order would have it.  Spread
+      // over the slots (three waves each: the slot with most rows left first) every slice ends in a tail of its last rows, one
+      // after the other, that leaves most waves idle: measured 18.4 against 14.1 ms per launch (profiles/r03_rows_vs_tickets.txt).
+      int best = -1;
       for (int sl = 0; sl < slots; ++sl) if (!((gone >> sl) & 1u)) {
         const int rem = slot_rows[sl] - (int)__hip_atomic_load (&sched[sl * sched_words], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (rem <= 0) gone |= 1u << sl; else if (rem > brem) { brem = rem; best = sl; }
+        if (rem <= 0) gone |= 1u << sl; else if (best < 0 || (spread && rem > brem)) { brem = rem; best = sl; }
       }
       best = __builtin_amdgcn_readfirstlane (best);
       if (best < 0) return;
@@ -636,6 +643,12 @@ __global__ __launch_bounds__ (256) void k_tile (WhSeqParams P, const WhPicJob* j
   if (idx < wh_tile_items (P)) wh_tile_item (P, Jl, idx);
 }
 
+// A source picture as uploaded -> macroblock tiles (kernels/tile_pic.h wh_src_tile_item): 16 bytes of the tiled picture per thread.
+__global__ __launch_bounds__ (256) void k_src_tile (WhSeqParams P, const uint8_t* planar, uint8_t* tiled) {
+  const int idx = (int) (blockIdx.x * blockDim.x + threadIdx.x);
+  if (idx < wh_src_tile_items (P)) wh_src_tile_item (P, (const WH_G uint8_t*)planar, (WH_G uint8_t*)tiled, idx);
+}
+
 // Scene-change statistic: one wavefront per 16x16 region of the source picture.
 __global__ __launch_bounds__ (64) void k_scene (WhSeqParams P, const WhPicJob* jobs) {
   const WhPicJob J = jobs[blockIdx.y];
@@ -801,18 +814,20 @@ class HipBackend : public wh::Backend {
         HIP_TRY (hipGetLastError());
       }
     }
-    auto launch = [&] (auto kernel) {
-      HIP_TRY (hipFuncSetAttribute ((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      if (getenv ("WELSHIP_TRACE")) { fprintf (stderr, "welship: MD launch %d groups x %d slots, %d waves, %zu B dynamic LDS\n", groups, slots, nw, lds); fflush (stderr); }
-      hipLaunchKernelGGL (kernel, dim3 (groups), dim3 (nw * 64), lds, stream_, P, jobs, err_words(), (const uint16_t*)grp, slots, sched_words, total, cost);
-      HIP_TRY (hipGetLastError());
-      if (getenv ("WELSHIP_TRACE")) { HIP_TRY (hipStreamSynchronize (stream_)); fprintf (stderr, "welship: launch done\n"); fflush (stderr); }
-    };
     // row scheduler (k_inter_rows): plain camera pictures, when a workgroup holds enough rows (>= 2 slices) for whole rows to keep its
     // waves busy; a single slice per workgroup (few pictures in flight: the latency regime) keeps the finer-grained tickets
     const char* rows_env = getenv ("WELSHIP_MD_ROWS");        // (read per launch: the GPU tests switch it inside one process)
     const int forced_rows = rows_env ? atoi (rows_env) : -1;
     const bool rows = P.flags == 0 && (forced_rows >= 0 ? forced_rows != 0 : slots >= 2);
+    WhSeqParams Pr = P;
+    if (rows && forced_rows == 2) Pr.flags |= WH_SEQ_ROWS_SPREAD;
+    auto launch = [&] (auto kernel) {
+      HIP_TRY (hipFuncSetAttribute ((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      if (getenv ("WELSHIP_TRACE")) { fprintf (stderr, "welship: MD launch %d groups x %d slots, %d waves, %zu B dynamic LDS\n", groups, slots, nw, lds); fflush (stderr); }
+      hipLaunchKernelGGL (kernel, dim3 (groups), dim3 (nw * 64), lds, stream_, Pr, jobs, err_words(), (const uint16_t*)grp, slots, sched_words, total, cost);
+      HIP_TRY (hipGetLastError());
+      if (getenv ("WELSHIP_TRACE")) { HIP_TRY (hipStreamSynchronize (stream_)); fprintf (stderr, "welship: launch done\n"); fflush (stderr); }
+    };
     if (P.flags & WH_SEQ_SCC) { if (nw <= 6) launch (k_inter_pool<384, true>); else launch (k_inter_pool<768, true>); }
     else if (rows) { if (nw <= 6) launch (k_inter_rows<384>); else launch (k_inter_rows<768>); }
     else if (nw <= 6) launch (k_inter_pool<384, false>); else launch (k_inter_pool<768, false>);
@@ -835,6 +850,11 @@ class HipBackend : public wh::Backend {
     HIP_TRY (hipGetLastError());
     // ... and, as part of making the picture a reference, its tiled twin (what the next picture's search windows are fetched from)
     hipLaunchKernelGGL (k_tile, dim3 ((wh_tile_items (P) + 255) / 256, n), dim3 (256), 0, stream_, P, jobs);
+    HIP_TRY (hipGetLastError());
+  }
+  void run_src_tile (const WhSeqParams& P, const uint8_t* planar, uint8_t* tiled) override {
+    if (!planar || !tiled) { note_null(); return; }
+    hipLaunchKernelGGL (k_src_tile, dim3 ((wh_src_tile_items (P) + 255) / 256), dim3 (256), 0, stream_, P, planar, tiled);
     HIP_TRY (hipGetLastError());
   }
   void run_compact (const WhSeqParams& P, const WhPicJob* jobs, int n) override {

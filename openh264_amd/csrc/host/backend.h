@@ -19,6 +19,8 @@ class Backend {
   virtual void upload (void* dst, const void* src, size_t bytes) = 0;
   virtual void download (void* dst, const void* src, size_t bytes) = 0;
   virtual void fill (void* dst, int value, size_t bytes) = 0;
+  // source picture as uploaded (planar I420, tight strides of P) -> the macroblock-tiled layout the kernels read (WH_SRC_*), on the selected queue
+  virtual void run_src_tile (const WhSeqParams& P, const uint8_t* planar, uint8_t* tiled) = 0;
   // page-lock a host buffer that is the target of many downloads (best effort; no-op where it does not apply)
   virtual void pin_host (void* p, size_t bytes) { (void)p; (void)bytes; }
   virtual void unpin_host (void* p) { (void)p; }

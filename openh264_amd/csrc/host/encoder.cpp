@@ -57,7 +57,8 @@ struct SessionCore {
   WhSeqParams seq;
   int mb_w = 0, mb_h = 0, num_mb = 0;
   int ring = 1;                       // number of source slots resident in HBM
-  std::vector<uint8_t*> d_src;        // [ring] Y | U | V, MB-aligned dims, tight strides
+  std::vector<uint8_t*> d_src;        // [ring] source pictures, MB-aligned dims, macroblock-tiled (WH_SRC_*)
+  uint8_t* d_src_planar = nullptr;    // where an upload lands (Y | U | V, tight strides) before the device rearranges it into its slot
   DevPicture pic[2];
   int cur = 0;
   int last_slot = 0;                  // source slot of the previous frame (VAA reference)
@@ -224,6 +225,7 @@ struct SessionCore {
     auto A = [&] (size_t n) { void* p = be->alloc (n); if (!p) oom = true; return p; };
     d_src.assign (ring, nullptr);
     for (int i = 0; i < ring; ++i) d_src[i] = (uint8_t*)A (src_bytes);
+    d_src_planar = (uint8_t*)A (src_bytes);
     const int rec_h = mb_h * 16 + 64;
     const size_t rec_y = (size_t)s.rec_stride_y * rec_h, rec_c = (size_t)s.rec_stride_c * (rec_h / 2);
     rec_alloc_bytes = rec_y + 2 * rec_c;
@@ -305,6 +307,8 @@ struct SessionCore {
     if (!be) return;
     for (uint8_t* p : d_src) if (p) be->free (p);
     d_src.clear();
+    if (d_src_planar) be->free (d_src_planar);
+    d_src_planar = nullptr;
     for (int i = 0; i < 2; ++i) { if (pic[i].base) be->free (pic[i].base); if (pic[i].mbs) be->free (pic[i].mbs); pic[i] = DevPicture(); }
     if (d_records) be->free (d_records);
     d_records = nullptr;
@@ -347,7 +351,8 @@ struct SessionCore {
   }
   void issue_upload (int slot) {
     if (slot == last_slot) prev_src_dirty = true;
-    be->upload (d_src[slot], h_src.data(), src_bytes);
+    be->upload (d_src_planar, h_src.data(), src_bytes);        // (same queue: the next upload waits for this pass)
+    be->run_src_tile (seq, d_src_planar, d_src[slot]);
     upload_pending = true;
   }
   void upload_source (int slot, const WelsHipSourcePicture* src) {
@@ -399,7 +404,7 @@ struct SessionCore {
     DevPicture& c = pic[cur];
     DevPicture& r = pic[cur ^ 1];
     memset (job, 0, sizeof (*job));
-    job->src[0] = d_src[slot]; job->src[1] = d_src[slot] + ysz; job->src[2] = d_src[slot] + ysz + csz;
+    job->src[0] = job->src[1] = job->src[2] = d_src[slot];
     for (int i = 0; i < 3; ++i) { job->rec[i] = c.plane[i]; job->ref[i] = idr ? nullptr : r.plane[i]; }
     for (int i = 0; i < 2; ++i) { job->rec_tiles[i] = c.tiles[i]; job->ref_tiles[i] = idr ? nullptr : r.tiles[i]; }
     job->records = d_records;
@@ -1254,7 +1259,8 @@ struct WelsHipFrameCtx {
   WhSeqParams seq;
   std::vector<DevPicture> pics;
   size_t rec_alloc_bytes = 0, rec_y = 0, rec_c = 0, ysz = 0, csz = 0, src_bytes = 0;
-  uint8_t* d_src = nullptr;
+  uint8_t* d_src = nullptr;              // the source picture, macroblock-tiled (WH_SRC_*) ...
+  uint8_t* d_src_planar = nullptr;       // ... and as uploaded
   std::vector<uint8_t> h_src;
   WhMbRecord* d_records = nullptr;
   std::vector<WhMbRecord> h_records;
@@ -1305,7 +1311,7 @@ struct WelsHipFrameCtx {
     be->sync();
     for (auto& p : pics) { if (p.base) be->free (p.base); if (p.mbs) be->free (p.mbs); }
     pics.clear();
-    void* ptrs[] = {d_src, d_records, d_dbflags, d_mb_ctl, d_sad_cost0, d_vaa, d_bgd, d_il, d_job, d_scc, d_scc_idc, d_scc_ori, d_scc_chain, d_scc_lists, d_scc_loc, d_scc_order, d_scc_chain_mb, d_gom_rc, d_sad_cost0_new};
+    void* ptrs[] = {d_src, d_src_planar, d_records, d_dbflags, d_mb_ctl, d_sad_cost0, d_vaa, d_bgd, d_il, d_job, d_scc, d_scc_idc, d_scc_ori, d_scc_chain, d_scc_lists, d_scc_loc, d_scc_order, d_scc_chain_mb, d_gom_rc, d_sad_cost0_new};
     if (!h_gom.empty()) be->unpin_host (h_gom.data());
     if (!h_scc.empty()) be->unpin_host (h_scc.data());
     if (!h_scc_small.empty()) be->unpin_host (h_scc_small.data());
@@ -1484,6 +1490,7 @@ int WelsHipFrameCtxCreate (WelsHipFrameCtx** pp, const WelsHipFrameCfg* cfg) {
   c->pics.resize (cfg->iNumPictures);
   for (auto& d : c->pics) { d.base = (uint8_t*)A (DevPicture::alloc_bytes (c->rec_alloc_bytes + 128)); d.mbs = (WhMbState*)A (sizeof (WhMbState) * c->num_mb); }
   c->d_src = (uint8_t*)A (c->src_bytes);
+  c->d_src_planar = (uint8_t*)A (c->src_bytes);
   c->d_records = (WhMbRecord*)A (sizeof (WhMbRecord) * c->num_mb);
   c->d_dbflags = (uint32_t*)A (sizeof (uint32_t) * c->num_mb);
   c->d_mb_ctl = (WhMbCtl*)A (sizeof (WhMbCtl) * c->num_mb);
@@ -1769,7 +1776,8 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
   const int queue = K ? K->queue : 0;
   be->select_queue (queue);
   if (first_part) {
-    be->upload (c->d_src, c->h_src.data(), c->src_bytes);
+    be->upload (c->d_src_planar, c->h_src.data(), c->src_bytes);
+    be->run_src_tile (s, c->d_src_planar, c->d_src);
     if (is_p && j->pVaaSad8x8) be->upload (c->d_vaa, c->h_aux.data() + c->aux_vaa, sizeof (int32_t) * 4 * c->num_mb);
     if (is_p && j->pBgdFlags) be->upload (c->d_bgd, c->h_aux.data() + c->aux_bgd, (size_t)c->num_mb);
     if (is_p && j->pIlHint) be->upload (c->d_il, c->h_aux.data() + c->aux_il, sizeof (int16_t) * 4 * c->num_mb);
@@ -1829,7 +1837,7 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
   DevPicture& cur = c->pics[j->iCurPic];
   WhPicJob job;
   memset (&job, 0, sizeof (job));
-  job.src[0] = c->d_src; job.src[1] = c->d_src + c->ysz; job.src[2] = c->d_src + c->ysz + c->csz;
+  job.src[0] = job.src[1] = job.src[2] = c->d_src;
   for (int i = 0; i < 3; ++i) { job.rec[i] = cur.plane[i]; job.ref[i] = is_p ? c->pics[j->iRefPic].plane[i] : nullptr; }
   for (int i = 0; i < 2; ++i) { job.rec_tiles[i] = cur.tiles[i]; job.ref_tiles[i] = is_p ? c->pics[j->iRefPic].tiles[i] : nullptr; }
   job.records = c->d_records;

@@ -939,13 +939,11 @@ WH_FN bool wh_try_puv_skip (WhMbLds& S, int pl, int qpc) {
 // (LDS-DMA: no registers held), and moves them into place when that MB starts.
 WH_FN void wh_inter_cold_fetch (WhInterStage& G, int lane, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby) {
   const int w = P.mb_w, xy = mby * w + mbx;
-  wh_ld_async4 ((const WH_G uint8_t*)J.src[0] + (size_t) (mby * 16 + (lane >> 2)) * P.src_stride_y + mbx * 16 + (lane & 3) * 4, G.cold_y, lane);
-  if (lane < 32) {
-    const int pl = lane >> 4, row = (lane >> 1) & 7, half = lane & 1;
-    wh_ld_async4 ((const WH_G uint8_t*)J.src[1 + pl] + (size_t) (mby * 8 + row) * P.src_stride_c + mbx * 8 + half * 4, G.cold_c, lane);
-  }
+  // (macroblock-tiled source pictures, WH_SRC_*: luma = 256 consecutive bytes in lane order, both chroma blocks = the 128 behind them)
+  wh_ld_async4 ((const WH_G uint8_t*)J.src[0] + WH_SRC_Y_OFF (w, mbx, mby, 0, 0) + lane * 4, G.cold_y, lane);
+  if (lane < 32) wh_ld_async4 ((const WH_G uint8_t*)J.src[0] + WH_SRC_C_OFF (w, mbx, mby, 0, 0, 0) + lane * 4, G.cold_c, lane);
   if (P.complexity == 0 && !J.vaa_sad8x8)     // VAA 8x8 SADs (LOW complexity only), unless the host supplies them
-    wh_ld_async4 ((const WH_G uint8_t*)J.prev_src_y + (size_t) (mby * 16 + (lane >> 2)) * P.src_stride_y + mbx * 16 + (lane & 3) * 4, G.cold_pv, lane);
+    wh_ld_async4 ((const WH_G uint8_t*)J.prev_src_y + WH_SRC_Y_OFF (w, mbx, mby, 0, 0) + lane * 4, G.cold_pv, lane);
   if (lane < 36 && J.ref_mbs) wh_ld_async4 ((const WH_G uint32_t*) ((const WH_G WhMbState*)J.ref_mbs + xy) + lane, G.cold_co, lane);
   if (J.ref_is_p) {
     if (lane >= 36 && lane < 38) {

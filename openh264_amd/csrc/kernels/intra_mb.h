@@ -45,15 +45,10 @@ typedef struct WhTileRegs { uint32_t y, c, nb; } WhTileRegs;
 
 // source samples of the MB (never written on the device: may be fetched long before the MB is processed)
 WH_FN void wh_tile_fetch_src (int lane, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, WhTileRegs* r) {
-  {
-    const int row = lane >> 2, seg = lane & 3;
-    r->y = * (const WH_G uint32_t*) ((const WH_G uint8_t*)J.src[0] + (size_t) (mby * 16 + row) * P.src_stride_y + mbx * 16 + seg * 4);
-  }
+  // (macroblock-tiled source picture, WH_SRC_*: lane = (row, 4-sample segment) of the luma block = its byte order; the same for chroma)
+  r->y = * (const WH_G uint32_t*) ((const WH_G uint8_t*)J.src[0] + WH_SRC_Y_OFF (P.mb_w, mbx, mby, 0, 0) + lane * 4);
   r->c = 0;
-  if (lane < 32) {
-    const int pl = lane >> 4, row = (lane >> 1) & 7, half = lane & 1;
-    r->c = * (const WH_G uint32_t*) ((const WH_G uint8_t*)J.src[1 + pl] + (size_t) (mby * 8 + row) * P.src_stride_c + mbx * 8 + half * 4);
-  }
+  if (lane < 32) r->c = * (const WH_G uint32_t*) ((const WH_G uint8_t*)J.src[0] + WH_SRC_C_OFF (P.mb_w, mbx, mby, 0, 0, 0) + lane * 4);
 }
 // reconstructed neighbour samples (written by the neighbour MBs: only after they are done)
 #ifndef WH_FLAT_NB_LOADS

@@ -14,8 +14,9 @@ WH_FN void wh_scene_mb_body (const WhSeqParams& P, const WhPicJob& J, int mbx, i
   WH_G const uint8_t* cur = (WH_G const uint8_t*)J.src[0];
   WH_G const uint8_t* prv = (WH_G const uint8_t*)J.prev_src_y;
   int s0, s1, s2, s3;
-#define WH_SC_SAD(lane) wh_sad4 (* (WH_G const uint32_t*) (cur + (ptrdiff_t) (mby * 16 + ((lane) >> 2)) * P.src_stride_y + mbx * 16 + ((lane) & 3) * 4), \
-                                 * (WH_G const uint32_t*) (prv + (ptrdiff_t) (mby * 16 + ((lane) >> 2)) * P.src_stride_y + mbx * 16 + ((lane) & 3) * 4))
+  // (both pictures macroblock-tiled, WH_SRC_*: lane = (row, 4-sample segment) is the byte order of the luma block)
+#define WH_SC_SAD(lane) wh_sad4 (* (WH_G const uint32_t*) (cur + WH_SRC_Y_OFF (P.mb_w, mbx, mby, 0, 0) + (lane) * 4), \
+                                 * (WH_G const uint32_t*) (prv + WH_SRC_Y_OFF (P.mb_w, mbx, mby, 0, 0) + (lane) * 4))
   // block (by, bx): rows 8*by.., segments 2*bx..  -> lane bit 5 = by, lane bit 1 = bx
   WV_SUM2 (s0, s1, lane, ((lane) & 0x22) == 0x00 ? WH_SC_SAD (lane) : 0, ((lane) & 0x22) == 0x02 ? WH_SC_SAD (lane) : 0);
   WV_SUM2 (s2, s3, lane, ((lane) & 0x22) == 0x20 ? WH_SC_SAD (lane) : 0, ((lane) & 0x22) == 0x22 ? WH_SC_SAD (lane) : 0);

@@ -30,3 +30,20 @@ WH_HDFN void wh_tile_item (const WhSeqParams& P, const WhPicJob& J, int idx) {
   v.x = cb[0]; v.y = cb[1]; v.z = cr[0]; v.w = cr[1];
   wh_stg16 ((WH_G uint8_t*)J.rec_tiles[1] + (size_t)idx * 16, v);
 }
+
+// ---- source pictures: planar I420 (as uploaded: tight strides src_stride_y / src_stride_c) -> macroblock tiles (WH_SRC_*) ------------
+// One item = 16 bytes of the tiled picture: luma row r of MB xy (items 0..15), two rows of its Cb (16..19) or Cr block (20..23).
+WH_HDFN int wh_src_tile_items (const WhSeqParams& P) { return P.mb_w * P.mb_h * 24; }
+WH_HDFN void wh_src_tile_item (const WhSeqParams& P, const WH_G uint8_t* planar, WH_G uint8_t* tiled, int idx) {
+  const int xy = idx / 24, i = idx - xy * 24, mbx = xy % P.mb_w, mby = xy / P.mb_w;
+  const size_t ysz = (size_t)P.src_stride_y * P.mb_h * 16, csz = (size_t)P.src_stride_c * P.mb_h * 8;
+  WhU4 v;
+  if (i < 16) v = wh_ldg16 (planar + (size_t) (mby * 16 + i) * P.src_stride_y + mbx * 16);
+  else {
+    const int pl = (i - 16) >> 2, r = ((i - 16) & 3) * 2;
+    const WH_G uint32_t* a = (const WH_G uint32_t*) (planar + ysz + pl * csz + (size_t) (mby * 8 + r) * P.src_stride_c + mbx * 8);
+    const WH_G uint32_t* b = (const WH_G uint32_t*) ((const WH_G uint8_t*)a + P.src_stride_c);
+    v.x = a[0]; v.y = a[1]; v.z = b[0]; v.w = b[1];
+  }
+  wh_stg16 (tiled + (size_t)idx * 16, v);
+}

@@ -18,6 +18,8 @@
 #include "../../openh264_amd/csrc/kernels/tile_pic.h"
 #include "../../openh264_amd/csrc/kernels/scene_pic.h"
 #include "../../openh264_amd/csrc/common/compact.h"
+#include "../../openh264_amd/csrc/kernels/downsample_px.h"
+#include "../../include/welship.h"
 
 namespace wh {
 
@@ -192,6 +194,9 @@ class EmuBackend : public Backend {
       for (int i = 0; i < wh_tile_items (P); ++i) wh_tile_item (P, jobs[j], i);       // the tiled twin (kernels/tile_pic.h), as the device's run_expand
     }
   }
+  void run_src_tile (const WhSeqParams& P, const uint8_t* planar, uint8_t* tiled) override {
+    for (int i = 0; i < wh_src_tile_items (P); ++i) wh_src_tile_item (P, planar, tiled, i);
+  }
   void run_compact (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
     for (int j = 0; j < n; ++j) {
       uint32_t off = 0;
@@ -210,3 +215,37 @@ class EmuBackend : public Backend {
 Backend* create_default_backend (int, const char**) { return new EmuBackend(); }
 
 }  // namespace wh
+
+// The picture-level down-sampling entry point of the product library (hip/downsample.hip), for the CPU test tier: the same plan
+// (wh_ds_plan) and the same per-sample functions, run as plain loops.
+extern "C" int WelsHipDownsamplePicture (int, uint8_t* const pDst[3], const int32_t iDstStride[3], int32_t iDstWidth, int32_t iDstHeight,
+                                         const uint8_t* const pSrc[3], const int32_t iSrcStride[3], int32_t iSrcWidth, int32_t iSrcHeight) {
+  if (!pDst || !pSrc || !iDstStride || !iSrcStride || iDstWidth < 2 || iDstHeight < 2 || iSrcWidth <= iDstWidth || iSrcHeight <= iDstHeight) return WELSHIP_ERR_INIT_PARA;
+  WhDsStage plan[8];
+  const int nst = wh_ds_plan (iSrcWidth, iSrcHeight, iDstWidth, iDstHeight, plan);
+  if (nst < 1) return WELSHIP_ERR_INIT_PARA;
+  for (int pl = 0; pl < 3; ++pl) {
+    const int sh_ = pl ? 1 : 0;
+    // this plane of the source with one spare row (addressed by the general filter's lower tap, never weighted)
+    int w = iSrcWidth >> sh_, h = iSrcHeight >> sh_, stride = (w + 63) & ~63;
+    std::vector<uint8_t> cur ((size_t)stride * (h + 1) + 64, 0);
+    for (int r = 0; r < h; ++r) memcpy (cur.data() + (size_t)r * stride, pSrc[pl] + (size_t)r * iSrcStride[pl], (size_t)w);
+    memcpy (cur.data() + (size_t)h * stride, cur.data() + (size_t) (h - 1) * stride, (size_t)w);
+    for (int k = 0; k < nst; ++k) {
+      const WhDsStage& g = plan[k];
+      const int dw = g.dw >> sh_, dh = g.dh >> sh_, sw = g.sw >> sh_, sh2 = g.sh >> sh_, ds = (dw + 63) & ~63;
+      std::vector<uint8_t> out ((size_t)ds * (dh + 1) + 64, 0);
+      const int step = g.mode == 0 ? 2 : g.mode == 1 ? 4 : 3;
+      const int accurate = pl ? 1 : 0;
+      const int scx = wh_ds_round_scale (sw, dw, accurate ? 15 : 16), scy = wh_ds_round_scale (sh2, dh, 15);
+      for (int y = 0; y < dh; ++y)
+        for (int x = 0; x < dw; ++x)
+          out[(size_t)y * ds + x] = g.mode >= 0 ? wh_ds_avg2x2 (cur.data() + (size_t) (step * y) * stride + step * x, stride)
+                                                : wh_ds_general (cur.data(), stride, dw, dh, x, y, scx, scy, accurate);
+      memcpy (out.data() + (size_t)dh * ds, out.data() + (size_t) (dh - 1) * ds, (size_t)dw);
+      cur.swap (out); stride = ds; w = dw; h = dh;
+    }
+    for (int r = 0; r < h; ++r) memcpy (pDst[pl] + (size_t)r * iDstStride[pl], cur.data() + (size_t)r * stride, (size_t)w);
+  }
+  return WELSHIP_OK;
+}
