@@ -16,6 +16,8 @@
 //                                            the host loop that is left -- pfWelsRcMbInit, neighbour caches,
 //                                            pfWelsSpatialWriteMbSyn, pfWelsRcMbInfoUpdate per macroblock
 //   pfHipRelease (state)                     WelsUninitEncoderExt (encoder_ext.cpp:2239)
+//   pfHipDownsample (state, dst, src ..)     CWelsPreProcess::DownsamplePadding (wels_preprocess.cpp:625-675): a spatial layer's source picture from
+//                                            the next larger one -- the down-sampling cascade of codec/processing on the device
 //
 // What runs on the device (see WelsHipSupported below): camera video and screen content, CAVLC and CABAC, slice threads, temporal layers,
 // LTR, denoising, scene-change and background detection, frame skipping, all rate-control modes.  With a frame-constant QP
@@ -68,10 +70,11 @@ struct HipApi {
   int (*FrameEncode) (WelsHipFrameCtx*, const WelsHipFrameJob*, const void**);
   int (*FrameGetPicture) (WelsHipFrameCtx*, int, uint8_t* const*, const int32_t*);
   int (*FrameGetMbStates) (WelsHipFrameCtx*, int, void*, size_t);
+  int (*DownsamplePicture) (int, uint8_t* const*, const int32_t*, int32_t, int32_t, const uint8_t* const*, const int32_t*, int32_t, int32_t);      // optional
   const char* (*GetLastError) (void);
   bool ok;
 };
-HipApi g_api = { NULL, NULL, NULL, NULL, NULL, NULL, false };
+HipApi g_api = { NULL, NULL, NULL, NULL, NULL, NULL, NULL, false };
 bool LoadApi() {
   static std::mutex mu;                  // several encoders of one process may be initialised at once
   std::lock_guard<std::mutex> lock (mu);
@@ -85,6 +88,7 @@ bool LoadApi() {
   g_api.FrameGetPicture = (int (*) (WelsHipFrameCtx*, int, uint8_t* const*, const int32_t*))dlsym (h, "WelsHipFrameGetPicture");
   g_api.FrameGetMbStates = (int (*) (WelsHipFrameCtx*, int, void*, size_t))dlsym (h, "WelsHipFrameGetMbStates");
   g_api.GetLastError = (const char* (*) (void))dlsym (h, "WelsHipGetLastError");
+  g_api.DownsamplePicture = (int (*) (int, uint8_t* const*, const int32_t*, int32_t, int32_t, const uint8_t* const*, const int32_t*, int32_t, int32_t))dlsym (h, "WelsHipDownsamplePicture");
   g_api.ok = g_api.FrameCtxCreate && g_api.FrameCtxDestroy && g_api.FrameEncode && g_api.FrameGetPicture && g_api.FrameGetMbStates && g_api.GetLastError;
   return g_api.ok;
 }
@@ -132,6 +136,8 @@ struct HipState {
   // WELS_HIP_TRACE=2: where a picture's time goes (seconds, summed): device call incl. transfers, reconstruction copy-back,
   // entropy coding from the records
   bool timing = false;
+  bool downsample = true;               // WELS_HIP_DOWNSAMPLE=0: the spatial layers are down-sampled by the reference's own C functions
+  long downsampled = 0;
   bool gom_kernel = false;              // WELS_HIP_GOM=2: single-slice rate-controlled P pictures in ONE device call (the QP recursion runs in the kernel)
   bool check_bits = false;              // WELS_HIP_CHECK_BITS=1: the device counts every macroblock's CAVLC bits and the slice loop compares them with the writer
   long bits_checked = 0;
@@ -663,6 +669,25 @@ TRY_REENCODING:
   return ENC_RETURN_SUCCESS;
 }
 
+// CWelsPreProcess::DownsamplePadding (wels_preprocess.cpp:625-675): the step that makes one spatial layer's source picture from the
+// next larger one -- CDownsampling::Process of codec/processing (downsample.cpp:144-277: 2:1 / 4:1 / 3:1 averages, a cascade of halvings,
+// or the general bilinear filters) -- as one call into libwelship.so (include/welship.h 3b).  The padding that follows stays the
+// reference's.  Returns non-zero when the device did not do it: the caller then runs its C functions.
+int32_t HipDownsample (void* p, uint8_t* const pDst[3], const int32_t iDstStride[3], int32_t iDstWidth, int32_t iDstHeight,
+                       const uint8_t* const pSrc[3], const int32_t iSrcStride[3], int32_t iSrcWidth, int32_t iSrcHeight) {
+  HipState* st = (HipState*)p;
+  if (st == NULL || !st->downsample || st->failed || g_api.DownsamplePicture == NULL) return 1;
+  if (iSrcWidth <= iDstWidth || iSrcHeight <= iDstHeight || iDstWidth < 2 || iDstHeight < 2) return 1;       // (RET_INVALIDPARAM of the C path: leave it to it)
+  const int rc = g_api.DownsamplePicture (st->device, pDst, iDstStride, iDstWidth, iDstHeight, pSrc, iSrcStride, iSrcWidth, iSrcHeight);
+  if (rc != 0) {
+    if (st->trace) fprintf (stderr, "welship hooks: down-sampling %dx%d -> %dx%d stays on the host (%d)\n", iSrcWidth, iSrcHeight, iDstWidth, iDstHeight, rc);
+    return 1;
+  }
+  ++st->downsampled;
+  if (st->trace) fprintf (stderr, "welship hooks: down-sampled %dx%d -> %dx%d on the device\n", iSrcWidth, iSrcHeight, iDstWidth, iDstHeight);
+  return 0;
+}
+
 void HipRelease (void* p) {
   HipState* st = (HipState*)p;
   if (st == NULL) return;
@@ -721,6 +746,7 @@ void WelsHipInstall (SWelsFuncPtrList* pFuncList, SWelsSvcCodingParam* pParam) {
   pFuncList->pfHipFrameMd = NULL;
   pFuncList->pfHipCodeSlice = NULL;
   pFuncList->pfHipRelease = NULL;
+  pFuncList->pfHipDownsample = NULL;
   pFuncList->pHipState = NULL;
   const char* off = getenv ("WELS_HIP");
   if (off && atoi (off) == 0) return;
@@ -740,10 +766,12 @@ void WelsHipInstall (SWelsFuncPtrList* pFuncList, SWelsSvcCodingParam* pParam) {
   st->gom_kernel = (getenv ("WELS_HIP_GOM") == NULL || atoi (getenv ("WELS_HIP_GOM")) >= 2) && pParam->iEntropyCodingModeFlag == 0;
   st->check_bits = getenv ("WELS_HIP_CHECK_BITS") != NULL && atoi (getenv ("WELS_HIP_CHECK_BITS")) != 0 && pParam->iEntropyCodingModeFlag == 0;
   st->layer_devices = getenv ("WELS_HIP_LAYER_DEVICES") != NULL && atoi (getenv ("WELS_HIP_LAYER_DEVICES")) != 0;
+  st->downsample = !(getenv ("WELS_HIP_DOWNSAMPLE") != NULL && atoi (getenv ("WELS_HIP_DOWNSAMPLE")) == 0);
   pFuncList->pHipState = st;
   pFuncList->pfHipFrameMd = HipFrameMd;
   pFuncList->pfHipCodeSlice = HipCodeSlice;
   pFuncList->pfHipRelease = HipRelease;
+  pFuncList->pfHipDownsample = HipDownsample;
   if (st->trace) fprintf (stderr, "welship hooks: installed\n");
 }
 

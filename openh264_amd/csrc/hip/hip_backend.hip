@@ -21,6 +21,7 @@
 #include "../kernels/inter_mb.h"
 #include "../kernels/expand_pic.h"
 #include "../kernels/tile_pic.h"
+#include "../kernels/vaa_pic.h"
 #include "../kernels/scene_pic.h"
 #include "../common/compact.h"
 
@@ -262,17 +263,19 @@ __global__ __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPi
   }
 }
 
-// ---- P pictures, row scheduler: a wave codes the macroblocks of one ROW of a slice, left to right ------------------------
+// ---- P pictures, run scheduler: a wave codes a RUN of horizontally adjacent macroblocks, left to right --------------------
 // The ticket scheduler above hands a free wave the next macroblock of the 2:1 order -- any macroblock of the slice -- so every
 // macroblock fetches its search windows from scratch although they overlap its left neighbour's by four fifths, and the
-// overlap is too far away in time for any cache (profiles/r02_pmc_traffic.json: 12.8x the algorithmic bytes).  Here a wave
-// owns a row of a slice: the left neighbour is the macroblock it has just coded, the only dependency it waits for is the
-// top-right one (the row above, owned by a wave that started that row earlier), and its windows SLIDE -- one tile column of
-// luma and one of chroma per macroblock instead of the whole windows (inter_mb.h wh_win_slide_*).  A free wave takes the
-// next unclaimed row of the slot that has most rows left.  A row can always proceed once the row above is two macroblocks
-// ahead, and rows are claimed top down, so the wave that owns the topmost unfinished row never waits: no deadlock.
-// Used when the launch has enough slices per workgroup that whole rows keep every wave busy (run_inter); pictures coded in
-// ranges, with GOM-level rate control or as screen content keep the ticket scheduler.
+// overlap is too far away in time for any cache (profiles/r02_pmc_traffic.json: 12.8x the algorithmic bytes).  Here a ticket
+// is a run of WhSeqParams::run_len macroblocks of one row (common/mb_order.h wh_build_run_order: the 2:1 order of the run grid):
+// inside a run the left neighbour is the macroblock the wave has just coded, and its windows SLIDE -- one tile column of luma
+// and one of chroma per macroblock instead of the whole windows (inter_mb.h wh_win_slide_*).  Dependencies are still waited
+// for macroblock by macroblock (done bits), and everything a run's macroblocks wait for lies in an earlier run of the list, so
+// the lowest outstanding ticket can always proceed: no deadlock.
+// Measured (MI355X, 256 four-slice 1080p pictures, profiles/r03_rows_vs_tickets*.txt): whole ROWS as runs cut the traffic to 2.9x
+// the algorithmic bytes but cost 25 % of the rate -- a workgroup's 68 rows do not divide among 12 waves, the last rows of a slice
+// are a serial tail, and rows two macroblocks apart stall each other; short runs keep the tickets' fine grain and most of the saving.
+// Pictures coded in ranges, with GOM-level rate control or as screen content keep the ticket scheduler.
 template <int MAXT>
 __global__ __launch_bounds__ (MAXT) void k_inter_rows (WhSeqParams P, const WhPicJob* jobs, uint32_t* err, const uint16_t* groups, int slots,
                                                        int sched_words, int total_slices, uint32_t* slice_cost) {
@@ -283,9 +286,9 @@ __global__ __launch_bounds__ (MAXT) void k_inter_rows (WhSeqParams P, const WhPi
   __shared__ WhInterStage stage[MAXT / 64];
   WhInterStage& G = stage[wave];
   __shared__ WhWinLds winbuf[MAXT / 64];
-  uint32_t* sched = (uint32_t*) (smem + (size_t)nw * sizeof (WhInterLds));     // per slot: [0] rows claimed, [1..] done bits
+  uint32_t* sched = (uint32_t*) (smem + (size_t)nw * sizeof (WhInterLds));     // per slot: [0] runs claimed, [1..] done bits
   __shared__ WhPicJob Jl[WH_MD_MAX_SLOTS];
-  __shared__ int slot_first[WH_MD_MAX_SLOTS], slot_n[WH_MD_MAX_SLOTS], slot_idc[WH_MD_MAX_SLOTS], slot_id[WH_MD_MAX_SLOTS], slot_rows[WH_MD_MAX_SLOTS];
+  __shared__ int slot_first[WH_MD_MAX_SLOTS], slot_n[WH_MD_MAX_SLOTS], slot_idc[WH_MD_MAX_SLOTS], slot_id[WH_MD_MAX_SLOTS], slot_runs[WH_MD_MAX_SLOTS];
   __shared__ int slot_mv[WH_MD_MAX_SLOTS];
   for (int i = (int)threadIdx.x; i < slots * sched_words; i += (int)blockDim.x) sched[i] = 0;
   if (P.prof && lane < 32) S.m.prof[lane] = 0;
@@ -297,7 +300,7 @@ __global__ __launch_bounds__ (MAXT) void k_inter_rows (WhSeqParams P, const WhPi
     if (threadIdx.x == 0) {
       const int first = P.slice_first_mb[idc], n = on ? P.slice_first_mb[idc + 1] - first : 0;
       slot_first[sl] = first; slot_n[sl] = n;
-      slot_rows[sl] = n > 0 ? (first + n - 1) / w - first / w + 1 : 0;
+      slot_runs[sl] = on ? (int)P.run_count[idc] : 0;
       slot_idc[sl] = idc; slot_id[sl] = on ? k : -1; slot_mv[sl] = 0;
     }
     wh_copy_job (&Jl[sl], &jobs[pic]);
@@ -317,31 +320,25 @@ __global__ __launch_bounds__ (MAXT) void k_inter_rows (WhSeqParams P, const WhPi
   int slot = -1, x = 0, y = 0, xe = 0;          // the macroblock in hand: (x, y) of slot `slot`, its row segment ends before xe
   int nslot = -1, nx = 0, ny = 0, nxe = 0;      // the wave's next one
   // next(): the right neighbour, or the first macroblock of the next unclaimed row (of the slot with most rows left)
-  const bool spread = (P.flags & WH_SEQ_ROWS_SPREAD) != 0;      // (experiment knob WELSHIP_MD_ROWS=2: the slot with most rows left)
-  int brem = 0;
+  // next(): the right neighbour inside the run, or the first macroblock of the next run (of the slot with most runs left)
+  const uint32_t* run_order = P.mb_order + 3 * (size_t)P.mb_w * P.mb_h;
   auto next_fn = [&] () __attribute__ ((always_inline)) {
-    brem = 0;
     if (slot >= 0 && x + 1 < xe) { nslot = slot; nx = x + 1; ny = y; nxe = xe; return; }
     for (nslot = -1;;) {
-      // The waves of a workgroup work ONE slice off at a time (the first slot that has unclaimed rows): its rows then advance as a tight
-      // front, each two macroblocks behind the one above, and finish almost together -- as the 2:1 ticket order would have it.  Spread
-      // over the slots (three waves each: the slot with most rows left first) every slice ends in a tail of its last rows, one
-      // after the other, that leaves most waves idle: measured 18.4 against 14.1 ms per launch (profiles/r03_rows_vs_tickets.txt).
-      int best = -1;
+      int best = -1, brem = 0;
       for (int sl = 0; sl < slots; ++sl) if (!((gone >> sl) & 1u)) {
-        const int rem = slot_rows[sl] - (int)__hip_atomic_load (&sched[sl * sched_words], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (rem <= 0) gone |= 1u << sl; else if (best < 0 || (spread && rem > brem)) { brem = rem; best = sl; }
+        const int rem = slot_runs[sl] - (int)__hip_atomic_load (&sched[sl * sched_words], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (rem <= 0) gone |= 1u << sl; else if (rem > brem) { brem = rem; best = sl; }
       }
       best = __builtin_amdgcn_readfirstlane (best);
       if (best < 0) return;
       int r = 0;
       if (lane == 0) r = (int)atomicAdd (&sched[best * sched_words], 1u);
       r = __builtin_amdgcn_readfirstlane (r);
-      if (r >= slot_rows[best]) { gone |= 1u << best; continue; }
-      const int first = slot_first[best], last = first + slot_n[best];
-      nslot = best; ny = first / w + r;
-      nx = r == 0 ? first % w : 0;
-      nxe = last - ny * w < w ? last - ny * w : w;
+      if (r >= slot_runs[best]) { gone |= 1u << best; continue; }
+      const uint32_t e = run_order[slot_first[best] + r];
+      const int xy0 = WH_RUN_XY (e);
+      nslot = best; ny = xy0 / w; nx = xy0 - ny * w; nxe = nx + WH_RUN_LEN (e);
       return;
     }
   };
@@ -649,6 +646,12 @@ __global__ __launch_bounds__ (256) void k_src_tile (WhSeqParams P, const uint8_t
   if (idx < wh_src_tile_items (P)) wh_src_tile_item (P, (const WH_G uint8_t*)planar, (WH_G uint8_t*)tiled, idx);
 }
 
+// Pre-analysis statistics (kernels/vaa_pic.h): one thread per macroblock.
+__global__ __launch_bounds__ (64) void k_vaa (int num_mb, const uint8_t* cur, const uint8_t* ref, WhVaaOut o) {
+  const int xy = (int) (blockIdx.x * blockDim.x + threadIdx.x);
+  if (xy < num_mb) wh_vaa_mb ((const WH_G uint8_t*)cur, (const WH_G uint8_t*)ref, xy, o);
+}
+
 // Scene-change statistic: one wavefront per 16x16 region of the source picture.
 __global__ __launch_bounds__ (64) void k_scene (WhSeqParams P, const WhPicJob* jobs) {
   const WhPicJob J = jobs[blockIdx.y];
@@ -814,13 +817,12 @@ class HipBackend : public wh::Backend {
         HIP_TRY (hipGetLastError());
       }
     }
-    // row scheduler (k_inter_rows): plain camera pictures, when a workgroup holds enough rows (>= 2 slices) for whole rows to keep its
-    // waves busy; a single slice per workgroup (few pictures in flight: the latency regime) keeps the finer-grained tickets
+    // run scheduler (k_inter_rows): plain camera pictures, when a workgroup holds several slices (runs of several slices to pick from);
+    // a single slice per workgroup (few pictures in flight: the latency regime) keeps the finest grain, one macroblock per ticket
     const char* rows_env = getenv ("WELSHIP_MD_ROWS");        // (read per launch: the GPU tests switch it inside one process)
     const int forced_rows = rows_env ? atoi (rows_env) : -1;
-    const bool rows = P.flags == 0 && (forced_rows >= 0 ? forced_rows != 0 : slots >= 2);
-    WhSeqParams Pr = P;
-    if (rows && forced_rows == 2) Pr.flags |= WH_SEQ_ROWS_SPREAD;
+    const bool rows = P.flags == 0 && P.run_len > 1 && (forced_rows >= 0 ? forced_rows != 0 : slots >= 2);
+    const WhSeqParams& Pr = P;
     auto launch = [&] (auto kernel) {
       HIP_TRY (hipFuncSetAttribute ((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       if (getenv ("WELSHIP_TRACE")) { fprintf (stderr, "welship: MD launch %d groups x %d slots, %d waves, %zu B dynamic LDS\n", groups, slots, nw, lds); fflush (stderr); }
@@ -855,6 +857,13 @@ class HipBackend : public wh::Backend {
   void run_src_tile (const WhSeqParams& P, const uint8_t* planar, uint8_t* tiled) override {
     if (!planar || !tiled) { note_null(); return; }
     hipLaunchKernelGGL (k_src_tile, dim3 ((wh_src_tile_items (P) + 255) / 256), dim3 (256), 0, stream_, P, planar, tiled);
+    HIP_TRY (hipGetLastError());
+  }
+  void run_vaa (const WhSeqParams& P, const uint8_t* cur, const uint8_t* ref, int32_t* sad8x8, int32_t* sd8x8, uint8_t* mad8x8, int32_t* sum16, int32_t* sqsum16, int32_t* ssd16) override {
+    if (!cur || !ref) { note_null(); return; }
+    const WhVaaOut o = {sad8x8, sd8x8, mad8x8, sum16, sqsum16, ssd16};
+    const int num_mb = P.mb_w * P.mb_h;
+    hipLaunchKernelGGL (k_vaa, dim3 ((num_mb + 63) / 64), dim3 (64), 0, stream_, num_mb, cur, ref, o);
     HIP_TRY (hipGetLastError());
   }
   void run_compact (const WhSeqParams& P, const WhPicJob* jobs, int n) override {

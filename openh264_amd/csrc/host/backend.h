@@ -21,6 +21,9 @@ class Backend {
   virtual void fill (void* dst, int value, size_t bytes) = 0;
   // source picture as uploaded (planar I420, tight strides of P) -> the macroblock-tiled layout the kernels read (WH_SRC_*), on the selected queue
   virtual void run_src_tile (const WhSeqParams& P, const uint8_t* planar, uint8_t* tiled) = 0;
+  // pre-analysis statistics of the tiled source picture `cur` against `ref` (kernels/vaa_pic.h), every macroblock of the MB-aligned picture
+  virtual void run_vaa (const WhSeqParams& P, const uint8_t* cur, const uint8_t* ref, int32_t* sad8x8, int32_t* sd8x8, uint8_t* mad8x8,
+                        int32_t* sum16, int32_t* sqsum16, int32_t* ssd16) = 0;
   // page-lock a host buffer that is the target of many downloads (best effort; no-op where it does not apply)
   virtual void pin_host (void* p, size_t bytes) { (void)p; (void)bytes; }
   virtual void unpin_host (void* p) { (void)p; }

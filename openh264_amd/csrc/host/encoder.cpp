@@ -39,6 +39,22 @@ namespace {
 
 inline int align_up (int v, int a) { return (v + a - 1) / a * a; }
 
+// Macroblocks per run of the P kernel's run scheduler (hip_backend.hip k_inter_rows): a wave codes that many horizontally adjacent
+// macroblocks one after the other and slides its search windows from one to the next.  WELSHIP_MD_RUN overrides (1 = every
+// macroblock fetches its windows whole, >= the picture width = whole rows).
+inline int md_run_len() { const char* e = getenv ("WELSHIP_MD_RUN"); const int v = e ? atoi (e) : 4; return v < 1 ? 1 : v > 1023 ? 1023 : v; }
+// the run section of the order table (entries [3 * num_mb, 4 * num_mb)) + WhSeqParams::run_len / run_count
+inline void build_run_section (WhSeqParams& s, int mb_w, int num_mb, std::vector<uint32_t>& order32) {
+  order32.resize ((size_t)num_mb * 4, 0u);
+  s.run_len = md_run_len();
+  for (int i = 0; i < WH_MAX_SLICES; ++i) s.run_count[i] = 0;
+  for (int i = 0; i < s.num_slices; ++i) {
+    const int n = wh_build_run_order (mb_w, s.slice_first_mb[i], s.slice_first_mb[i + 1], s.run_len, order32.data() + 3 * (size_t)num_mb + s.slice_first_mb[i]);
+    s.run_count[i] = (int16_t) (n > 32767 ? 0 : n);
+    if (n > 32767) s.run_len = 0;           // (cannot happen below 32768 macroblocks per slice; no run section then)
+  }
+}
+
 struct DevPicture {            // one padded reconstruction buffer + its tiled twin (same allocation) + its MB state
   uint8_t* base = nullptr;
   uint8_t* plane[3] = {nullptr, nullptr, nullptr};   // pixel (0,0)
@@ -249,6 +265,7 @@ struct SessionCore {
     if (nb < 1) { set_err ("deblocking band table"); release(); return WELSHIP_ERR_UNKNOWN; }
     for (int b = 0; b < nb; ++b) wh_build_mb_order (mb_w, bands[b], bands[b + 1], order.data() + 2 * (size_t)num_mb + bands[b]);
     std::vector<uint32_t> order32 (order.begin(), order.end());      // 32-bit on the device (scalar loads)
+    build_run_section (s, mb_w, num_mb, order32);
     d_order = (uint32_t*)A (order32.size() * 4);
     d_bands = (int32_t*)A (sizeof (int32_t) * (3 * (size_t)nb + 1));
     d_scene = (uint32_t*)A (64);
@@ -1201,6 +1218,8 @@ namespace {
 
 struct FrameLayout {           // processing-order / deblocking-band tables on the device, shared by the contexts that use them
   int mb_w = 0, mb_h = 0, idc = -1;
+  int run_len = 0;
+  int16_t run_count[WH_MAX_SLICES];
   std::vector<int32_t> slices;
   uint32_t* d_order = nullptr;
   int32_t* d_bands = nullptr;
@@ -1342,10 +1361,19 @@ struct WelsHipFrameCtx {
       const int nb = wh_build_db_bands (mb_w, mb_h, n, first, idc, WH_DB_BAND_ROWS, bands.data(), (int)bands.size());
       if (nb < 1) { set_err ("deblocking band table"); return WELSHIP_ERR_UNKNOWN; }
       for (int b = 0; b < nb; ++b) wh_build_mb_order (mb_w, bands[b], bands[b + 1], order.data() + 2 * (size_t)num_mb + bands[b]);
-      up->d_order = (uint32_t*)be->alloc ((size_t)num_mb * 3 * 4);
+      up->d_order = (uint32_t*)be->alloc ((size_t)num_mb * 4 * 4);
       up->d_bands = (int32_t*)be->alloc (sizeof (int32_t) * (3 * (size_t)nb + 1));
       if (!up->d_order || !up->d_bands) { set_err ("out of device memory"); return WELSHIP_ERR_MEMORY; }
       std::vector<uint32_t> order32 (order.begin(), order.end());
+      {
+        WhSeqParams tmp;
+        memset (&tmp, 0, sizeof (tmp));
+        tmp.num_slices = n;
+        for (int i = 0; i <= n; ++i) tmp.slice_first_mb[i] = first[i];
+        build_run_section (tmp, mb_w, num_mb, order32);
+        up->run_len = tmp.run_len;
+        memcpy (up->run_count, tmp.run_count, sizeof (up->run_count));
+      }
       be->upload (up->d_order, order32.data(), order32.size() * 4);
       be->upload (up->d_bands, bands.data(), sizeof (int32_t) * (3 * (size_t)nb + 1));
       if (be->sync()) { set_err ("device error"); return WELSHIP_ERR_UNKNOWN; }
@@ -1362,6 +1390,8 @@ struct WelsHipFrameCtx {
     s.num_slices = n;
     for (int i = 0; i < WH_MAX_SLICES + 1; ++i) s.slice_first_mb[i] = i <= n ? first[i] : 0;
     s.mb_order = L->d_order;
+    s.run_len = L->run_len;
+    memcpy (s.run_count, L->run_count, sizeof (s.run_count));
     s.db_num_bands = L->nb; s.db_bands = L->d_bands; s.db_max_mbs = L->max_mbs; s.db_max_rows = L->max_rows;
     return WELSHIP_OK;
   }

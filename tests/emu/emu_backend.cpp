@@ -16,6 +16,7 @@
 #include "../../openh264_amd/csrc/kernels/inter_mb.h"
 #include "../../openh264_amd/csrc/kernels/expand_pic.h"
 #include "../../openh264_amd/csrc/kernels/tile_pic.h"
+#include "../../openh264_amd/csrc/kernels/vaa_pic.h"
 #include "../../openh264_amd/csrc/kernels/scene_pic.h"
 #include "../../openh264_amd/csrc/common/compact.h"
 #include "../../openh264_amd/csrc/kernels/downsample_px.h"
@@ -48,39 +49,58 @@ class EmuBackend : public Backend {
       if (jobs[j].mb_end > 0 && (xy < jobs[j].mb_begin || xy >= jobs[j].mb_end)) return;      // GOM-synchronous coding: only this range
       WhMbLds S; poison (&S, sizeof (S)); wh_intra_mb_body (S, P, jobs[j], x, y); });
   }
-  // The row scheduler of the device (hip_backend.hip k_inter_rows): one emulated wavefront codes the rows of a slice one after the
-  // other, left to right, and keeps its windows -- through the very slide functions the device uses (inter_mb.h wh_win_slide_*), started
-  // where the macroblock body calls back.  After the callback the body must not read the staging area or the windows: both are set
-  // aside and poisoned until it returns.  WELSHIP_MD_ROWS=0 (the device's knob) runs these pictures through the ticket order instead.
+  // The run scheduler of the device (hip_backend.hip k_inter_rows): one emulated wavefront takes the runs of a slice in the order of
+  // the run table (common/mb_order.h wh_build_run_order) and codes each run's macroblocks left to right, keeping its windows inside a
+  // run -- through the very slide functions the device uses (inter_mb.h wh_win_slide_*), started where the macroblock body calls back.
+  // After the callback the body must not read the staging area or the windows: both are set aside and poisoned until it returns.  The
+  // table is checked on the way: every macroblock of the slice exactly once, nothing before what it depends on.
+  // WELSHIP_MD_ROWS=0 (the device's knob) runs these pictures through the ticket order instead.
   void run_inter_rows (const WhSeqParams& P, const WhPicJob* jobs, int n) {
+    const int w = P.mb_w, num_mb = P.mb_w * P.mb_h;
     for (int j = 0; j < n; ++j)
       for (int s = 0; s < P.num_slices; ++s) {
         WhInterLds S;
         WhInterStage G, Gk;
         WhWinLds WB, WBk;
         poison (&S, sizeof (S)); poison (&G, sizeof (G)); poison (&WB, sizeof (WB));
-        const int first = P.slice_first_mb[s], last = P.slice_first_mb[s + 1], w = P.mb_w;
+        const int first = P.slice_first_mb[s], last = P.slice_first_mb[s + 1];
+        const uint32_t* runs = P.mb_order + 3 * (size_t)num_mb + first;
+        const int nruns = P.run_count[s];
+        // the macroblocks of the slice in the order the wave codes them
+        std::vector<int> seq;
+        std::vector<char> done_mb ((size_t) (last - first), 0);
+        for (int r = 0; r < nruns; ++r)
+          for (int k = 0; k < WH_RUN_LEN (runs[r]); ++k) {
+            const int xy = WH_RUN_XY (runs[r]) + k;
+            int da, db;
+            wh_mb_deps (w, xy, first, &da, &db);
+            if (xy < first || xy >= last || done_mb[xy - first] || (da >= first && !done_mb[da - first]) || (db >= first && !done_mb[db - first]) || (k && xy % w == 0)) {
+              fprintf (stderr, "emu: run table of slice %d is wrong at run %d MB %d\n", s, r, xy); abort();
+            }
+            done_mb[xy - first] = 1;
+            seq.push_back (xy | (k + 1 < WH_RUN_LEN (runs[r]) ? 0 : 0x40000000));       // bit 30: the run ends with this macroblock
+          }
+        if ((int)seq.size() != last - first) { fprintf (stderr, "emu: run table of slice %d covers %zu of %d macroblocks\n", s, seq.size(), last - first); abort(); }
         const WhPicJob& J = jobs[j];
         int last_mv = 0;
         WhInterCtx X;
         X.win = &WB; X.spec.b = &WB; X.spec_valid = 0; X.last_mv = &last_mv;
         WhWinSlide SL;
         SL.on_y = 0; SL.on_c = 0;
-        int cur = -1;                      // the macroblock in hand
+        int pos = -1;                      // index into seq of the macroblock in hand
         struct Early {
-          EmuBackend* self; const WhSeqParams& P; const WhPicJob& J; WhInterStage& G; WhInterStage& Gk; WhWinLds& WB; WhWinLds& WBk; WhInterCtx& X; WhWinSlide& SL;
-          int& cur; int first, last, w; int& last_mv; int calls;
+          const WhSeqParams& P; const WhPicJob& J; WhInterStage& G; WhInterStage& Gk; WhWinLds& WB; WhWinLds& WBk; WhInterCtx& X; WhWinSlide& SL;
+          int& pos; std::vector<int>& seq; int w; int& last_mv; int calls;
           void call() {
             ++calls;
-            const int nxt = cur < 0 ? first : cur + 1;
-            if (nxt < last) {
-              const int nx = nxt % w, ny = nxt / w;
+            if (pos + 1 < (int)seq.size()) {
+              const int nxy = seq[pos + 1] & 0xfffff, nx = nxy % w, ny = nxy / w;
               for (int lane = 0; lane < 64; ++lane) wh_inter_cold_fetch (G, lane, P, J, nx, ny);
               WhWin N;
               N.b = &WB;
               const int gx = wh_clip3 ((2 + (int) (int16_t) (last_mv & 0xffff)) >> 2, -P.mv_range, P.mv_range), gy = wh_clip3 ((2 + (last_mv >> 16)) >> 2, -P.mv_range, P.mv_range);
               wh_win_place (P, N, nx * 16 + gx, ny * 16 + gy);
-              const bool same = cur >= 0 && ny == cur / w;
+              const bool same = pos >= 0 && !(seq[pos] & 0x40000000);         // the next macroblock continues the run
               SL.on_y = same && wh_win_can_slide_y (X.spec, N);
               SL.on_c = same && wh_win_can_slide_c (X.spec, N);
               if (SL.on_y | SL.on_c) wh_win_slide_begin (P, J, N, SL);
@@ -93,11 +113,11 @@ class EmuBackend : public Backend {
             Gk = G; WBk = WB;
             poison (&G, sizeof (G)); poison (&WB, sizeof (WB));
           }
-        } early = { this, P, J, G, Gk, WB, WBk, X, SL, cur, first, last, w, last_mv, 0 };
+        } early = { P, J, G, Gk, WB, WBk, X, SL, pos, seq, w, last_mv, 0 };
         early.call();
         G = Gk; WB = WBk;
-        for (int xy = first; xy < last; ++xy) {
-          cur = xy;
+        for (pos = 0; pos < (int)seq.size(); ++pos) {
+          const int xy = seq[pos] & 0xfffff;
           wh_win_slide_finish (&WB, SL);
           SL.on_y = 0; SL.on_c = 0;
           X.slice_idc = s; X.slice_first = first;
@@ -113,7 +133,7 @@ class EmuBackend : public Backend {
     // one emulated wavefront walks each slice in order like a wave of the device scheduler: a macroblock's cold inputs and
     // its speculative search windows (around the slice's last final vector) are fetched before its body runs
     static const bool rows_off = getenv ("WELSHIP_MD_ROWS") && atoi (getenv ("WELSHIP_MD_ROWS")) == 0;
-    if (P.flags == 0 && !rows_off) { run_inter_rows (P, jobs, n); return; }
+    if (P.flags == 0 && P.run_len > 1 && !rows_off) { run_inter_rows (P, jobs, n); return; }
     for (int j = 0; j < n; ++j)
       for (int s = 0; s < P.num_slices; ++s) {
         WhInterLds S;
@@ -196,6 +216,10 @@ class EmuBackend : public Backend {
   }
   void run_src_tile (const WhSeqParams& P, const uint8_t* planar, uint8_t* tiled) override {
     for (int i = 0; i < wh_src_tile_items (P); ++i) wh_src_tile_item (P, planar, tiled, i);
+  }
+  void run_vaa (const WhSeqParams& P, const uint8_t* cur, const uint8_t* ref, int32_t* sad8x8, int32_t* sd8x8, uint8_t* mad8x8, int32_t* sum16, int32_t* sqsum16, int32_t* ssd16) override {
+    const WhVaaOut o = {sad8x8, sd8x8, mad8x8, sum16, sqsum16, ssd16};
+    for (int xy = 0; xy < P.mb_w * P.mb_h; ++xy) wh_vaa_mb (cur, ref, xy, o);
   }
   void run_compact (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
     for (int j = 0; j < n; ++j) {

@@ -65,6 +65,17 @@ def test_fuzz_emu_ticket_scheduler(emu_lib, ref_tools):
     _run([], ref_tools, seed=19, env={"WELSHIP_MD_ROWS": "0"})
 
 
+@pytest.mark.parametrize("run_len", ["7", "1000"])
+def test_fuzz_emu_other_run_lengths(emu_lib, ref_tools, run_len):
+    """Runs of 7 macroblocks (not a divisor of most picture widths) and whole rows; the test build checks every run table it walks."""
+    _run([], ref_tools, seed=31, env={"WELSHIP_MD_RUN": run_len})
+
+
 @pytest.mark.gpu
 def test_fuzz_hip_row_scheduler(hip_lib, ref_tools):
     _run(["--hip"], ref_tools, seed=23, env={"WELSHIP_MD_ROWS": "1"})
+
+
+@pytest.mark.gpu
+def test_fuzz_hip_whole_rows(hip_lib, ref_tools):
+    _run(["--hip"], ref_tools, seed=29, env={"WELSHIP_MD_ROWS": "1", "WELSHIP_MD_RUN": "1000"})

@@ -20,16 +20,24 @@ pytestmark = pytest.mark.skipif(not os.path.exists(os.path.join(REF, "ref_enc_hi
 CONFIG4 = ["-simulcast", "320", "180", "-simulcast", "640", "360", "-simulcast", "1280", "720"]
 
 
-def _both(lib, tmp_path, yuv, w, h, flags, min_pictures):
+def _both(lib, tmp_path, yuv, w, h, flags, min_pictures, extra_env=None):
     fi = str(tmp_path / "in.yuv")
     open(fi, "wb").write(yuv)
     base = ["-i", fi, "-w", str(w), "-h", str(h), "-fps", "30", "-quiet"] + flags
     subprocess.check_call([os.path.join(REF, "ref_enc"), "-o", str(tmp_path / "ref.264")] + base, stdout=subprocess.DEVNULL)
     env = dict(os.environ, WELSHIP_LIB=lib, WELS_HIP_TRACE="1", WELS_HIP_CHECK_BITS="1")
+    env.update(extra_env or {})
     p = subprocess.run([os.path.join(REF, "ref_enc_hip"), "-o", str(tmp_path / "hip.264")] + base, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
     err = p.stderr.decode(errors="replace")
     assert p.returncode == 0, err[-2000:]
     assert "welship hooks: installed" in err and err.count("welship hooks: did") >= min_pictures, err[-2000:]
+    # the lower layers' source pictures come from the device's down-sampling cascade (pfHipDownsample in
+    # CWelsPreProcess::DownsamplePadding), not from the reference's C functions -- unless switched off
+    lower = flags.count("-simulcast")
+    if env.get("WELS_HIP_DOWNSAMPLE") == "0":
+        assert "down-sampled" not in err
+    else:
+        assert err.count("down-sampled") >= lower * (min_pictures // (lower + 1)), err[-1500:]
     assert (tmp_path / "ref.264").read_bytes() == (tmp_path / "hip.264").read_bytes()
 
 
@@ -57,6 +65,11 @@ def test_simulcast_sessions_on_the_reverse_lane_emulation(tmp_path, flags, pictu
 
 def test_config4_four_layers_on_emulation(emu_lib, tmp_path):
     _both(emu_lib, tmp_path, synth_sequence(1920, 1080, 3), 1920, 1080, ["-rc", "-1", "-qp", "24"] + CONFIG4, 12)
+
+
+def test_simulcast_with_the_host_downsampler(emu_lib, tmp_path):
+    """WELS_HIP_DOWNSAMPLE=0: the reference's own C down-samplers feed the layers (the pre-round-3 arrangement); same bytes."""
+    _both(emu_lib, tmp_path, synth_sequence(640, 368, 6), 640, 368, SMALL[1][0], SMALL[1][1], {"WELS_HIP_DOWNSAMPLE": "0"})
 
 
 @pytest.mark.gpu
