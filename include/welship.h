@@ -304,6 +304,25 @@ typedef struct WelsHipMbReencode {
   uint8_t bCell12Valid, pad;        /* the previous pass ended as P8x16: update_P8x16_motion_info wrote its second vector into the     */
   int16_t iCell12Mv[2];             /* MV cache's left-neighbour cell (mv_pred.cpp:235-276); the vector                                */
 } WelsHipMbReencode;
+/* Pre-analysis of a source picture against an earlier one: what CWelsPreProcess::VaaCalculation (wels_preprocess.cpp:
+ * 677-711) gets from CVAACalculation::Process (codec/processing/src/vaacalc/vaacalculation.cpp:118-157) -- VAACalcSad_c /
+ * VAACalcSadBgd_c / VAACalcSadSsd_c / VAACalcSadVar_c / VAACalcSadSsdBgd_c (vaacalcfuncs.cpp:37-600), selected by the three flags --
+ * computed on the device.  The CURRENT picture is uploaded by this call and stays resident: the WelsHipFrameEncode of the same
+ * context that follows with the same pSrc[0] does not upload it again; the EARLIER picture is found on the device when it was the
+ * source of an earlier call of this context (keyed by its luma pointer: the reference rotates a fixed set of picture buffers), and is
+ * uploaded otherwise.  Results go to the caller's arrays (those the selected variant writes; macroblocks outside
+ * (iPicWidth >> 4) x (iPicHeight >> 4) are left alone, as the C functions leave them). */
+typedef struct WelsHipVaaJob {
+  const uint8_t* pCur[3]; int32_t iCurStride[3];      /* host planes of the current source picture, MB-aligned area readable    */
+  const uint8_t* pRef[3]; int32_t iRefStride[3];      /* ... of the picture it is compared with                                  */
+  int32_t iPicWidth, iPicHeight;                      /* sRect of the SPixMap the reference passes                               */
+  int32_t bCalcVar, bCalcBgd, bCalcSsd;               /* SVAACalcParam::iCalcVar / iCalcBgd / iCalcSsd                           */
+  int32_t* pSad8x8;                                   /* SVAACalcResult: [mb][4]                                                 */
+  int32_t* pSsd16x16; int32_t* pSum16x16; int32_t* pSumOfSquare16x16;     /* [mb]                                                */
+  int32_t* pSumOfDiff8x8; uint8_t* pMad8x8;           /* [mb][4]                                                                 */
+  int32_t* pFrameSad;
+} WelsHipVaaJob;
+int  WelsHipFrameVaa (WelsHipFrameCtx* pCtx, const WelsHipVaaJob* pJob);
 int  WelsHipFrameCtxCreate (WelsHipFrameCtx** ppCtx, const WelsHipFrameCfg* pCfg);
 void WelsHipFrameCtxDestroy (WelsHipFrameCtx* pCtx);
 /* Runs the picture (or MB range) on the device and waits; *ppRecords = WhMbRecord[mb_w * mb_h] in host memory, valid until

@@ -16,6 +16,8 @@
 //                                            the host loop that is left -- pfWelsRcMbInit, neighbour caches,
 //                                            pfWelsSpatialWriteMbSyn, pfWelsRcMbInfoUpdate per macroblock
 //   pfHipRelease (state)                     WelsUninitEncoderExt (encoder_ext.cpp:2239)
+//   pfHipVaaCalc (pCtx, did, cur, ref ..)    CWelsPreProcess::AnalyzeSpatialPic (wels_preprocess.cpp:263-310): VaaCalculation's statistics of the layer's
+//                                            source picture (8x8 SADs, sums of differences, variances) on the device
 //   pfHipDownsample (state, dst, src ..)     CWelsPreProcess::DownsamplePadding (wels_preprocess.cpp:625-675): a spatial layer's source picture from
 //                                            the next larger one -- the down-sampling cascade of codec/processing on the device
 //
@@ -71,10 +73,11 @@ struct HipApi {
   int (*FrameGetPicture) (WelsHipFrameCtx*, int, uint8_t* const*, const int32_t*);
   int (*FrameGetMbStates) (WelsHipFrameCtx*, int, void*, size_t);
   int (*DownsamplePicture) (int, uint8_t* const*, const int32_t*, int32_t, int32_t, const uint8_t* const*, const int32_t*, int32_t, int32_t);      // optional
+  int (*FrameVaa) (WelsHipFrameCtx*, const WelsHipVaaJob*);                                                                                         // optional
   const char* (*GetLastError) (void);
   bool ok;
 };
-HipApi g_api = { NULL, NULL, NULL, NULL, NULL, NULL, NULL, false };
+HipApi g_api = { NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, false };
 bool LoadApi() {
   static std::mutex mu;                  // several encoders of one process may be initialised at once
   std::lock_guard<std::mutex> lock (mu);
@@ -88,6 +91,7 @@ bool LoadApi() {
   g_api.FrameGetPicture = (int (*) (WelsHipFrameCtx*, int, uint8_t* const*, const int32_t*))dlsym (h, "WelsHipFrameGetPicture");
   g_api.FrameGetMbStates = (int (*) (WelsHipFrameCtx*, int, void*, size_t))dlsym (h, "WelsHipFrameGetMbStates");
   g_api.GetLastError = (const char* (*) (void))dlsym (h, "WelsHipGetLastError");
+  g_api.FrameVaa = (int (*) (WelsHipFrameCtx*, const WelsHipVaaJob*))dlsym (h, "WelsHipFrameVaa");
   g_api.DownsamplePicture = (int (*) (int, uint8_t* const*, const int32_t*, int32_t, int32_t, const uint8_t* const*, const int32_t*, int32_t, int32_t))dlsym (h, "WelsHipDownsamplePicture");
   g_api.ok = g_api.FrameCtxCreate && g_api.FrameCtxDestroy && g_api.FrameEncode && g_api.FrameGetPicture && g_api.FrameGetMbStates && g_api.GetLastError;
   return g_api.ok;
@@ -124,6 +128,9 @@ struct HipLayer {                       // one spatial layer = one device contex
   std::vector<uint32_t> fme_down;        //   and what the device reports back per slice (uiSliceFMECostDown)
   std::vector<int16_t> il_hint;          // highest layer of a multi-layer session: hints from the layer below
   std::vector<WhMbState> states;         // lower layers of a multi-layer session: the device's motion data, for the layer above
+  // WELS_HIP_CHECK_VAA=1: what the device computed for this picture's pre-analysis, compared in HipFrameMd with what the reference's own
+  // C functions then left in pVaa (the hook lets them run as well)
+  struct VaaCopy { bool valid = false; int n = 0, bgd = 0, var = 0, ssd = 0, frame_sad = 0; std::vector<int32_t> sad, sd, sum, sq, ssd16; std::vector<uint8_t> mad; } vaa_copy;
   std::vector<WelsHipMbReencode> reencode;   // macroblocks of the picture being coded that were coded again at a higher QP (TRY_REENCODING)
 };
 
@@ -136,6 +143,9 @@ struct HipState {
   // WELS_HIP_TRACE=2: where a picture's time goes (seconds, summed): device call incl. transfers, reconstruction copy-back,
   // entropy coding from the records
   bool timing = false;
+  bool vaa_check = false;               // WELS_HIP_CHECK_VAA=1
+  bool vaa = true;                      // WELS_HIP_VAA=0: the pre-analysis statistics (VaaCalculation) stay the reference's C functions
+  long vaa_done = 0;
   bool downsample = true;               // WELS_HIP_DOWNSAMPLE=0: the spatial layers are down-sampled by the reference's own C functions
   long downsampled = 0;
   bool gom_kernel = false;              // WELS_HIP_GOM=2: single-slice rate-controlled P pictures in ONE device call (the QP recursion runs in the kernel)
@@ -202,6 +212,67 @@ int32_t DynCode (HipState* st, HipLayer& L, int iPart, int iSliceIdx, int iSlice
   return ENC_RETURN_SUCCESS;
 }
 
+// the device context of spatial layer `did` (created with the layer's first call: pre-analysis or mode decision)
+bool EnsureLayerCtx (HipState* st, sWelsEncCtx* pCtx, int did) {
+  HipLayer& L = st->layer[did];
+  if (L.ctx != NULL) return true;
+  const SWelsSvcCodingParam* pParam = pCtx->pSvcParam;
+  const SDqLayer* pLayer = pCtx->ppDqLayerList[did];
+  WelsHipFrameCfg cfg;
+  memset (&cfg, 0, sizeof (cfg));
+  cfg.iDevice = st->device + (st->layer_devices ? did : 0);
+  cfg.iPicWidth = pLayer->iMbWidth * 16; cfg.iPicHeight = pLayer->iMbHeight * 16;
+  cfg.iNumPictures = WELS_MAX (pParam->iNumRefFrame, pParam->iMaxNumRefFrame) + 2;    // RequestMemorySvc allocates 1 + iMaxNumRefFrame pictures per layer
+  L.num_pictures = cfg.iNumPictures;
+  const int rc = g_api.FrameCtxCreate (&L.ctx, &cfg);
+  if (rc) { fprintf (stderr, "welship hooks: no device context (%d: %s)\n", rc, g_api.GetLastError()); st->failed = true; return false; }
+  return true;
+}
+
+// CWelsPreProcess::VaaCalculation (wels_preprocess.cpp:677-711) for camera video: the statistics of the layer's source picture against
+// the source picture of its reference -- 8x8 SADs (what LOW-complexity mode decision and the rate control's complexity analysis read),
+// and with background detection / the variance request also sums of differences, largest differences, sums and sums of squares
+// (vaacalcfuncs.cpp) -- as one call into libwelship.so.  The current picture stays on the device for HipFrameMd; the other one is there
+// from the picture before.  BackgroundDetection and the complexity analysis that follow read the arrays this fills.  Non-zero: not done.
+int32_t HipVaaCalc (sWelsEncCtx* pCtx, int32_t iDid, SPicture* pCurPic, SPicture* pRefPic, bool bCalculateSQDiff, bool bCalculateVar, bool bCalculateBGD) {
+  HipState* st = (HipState*)pCtx->pFuncList->pHipState;
+  if (st == NULL || !st->vaa || st->failed || g_api.FrameVaa == NULL || pCtx->pVaa == NULL || pCurPic == NULL || pRefPic == NULL) return 1;
+  if (iDid < 0 || iDid >= MAX_DEPENDENCY_LAYER || pCurPic->pData[0] == NULL || pRefPic->pData[0] == NULL || pCurPic->pData[0] == pRefPic->pData[0]) return 1;
+  if (pCurPic->iLineSize[0] != pRefPic->iLineSize[0]) return 1;               // (the C functions take ONE stride for both pictures)
+  if (!EnsureLayerCtx (st, pCtx, iDid)) return 1;
+  SVAACalcResult* pRes = &pCtx->pVaa->sVaaCalcInfo;
+  WelsHipVaaJob job;
+  memset (&job, 0, sizeof (job));
+  for (int i = 0; i < 3; ++i) { job.pCur[i] = pCurPic->pData[i]; job.iCurStride[i] = pCurPic->iLineSize[i]; job.pRef[i] = pRefPic->pData[i]; job.iRefStride[i] = pRefPic->iLineSize[i]; }
+  job.iPicWidth = pCurPic->iWidthInPixel; job.iPicHeight = pCurPic->iHeightInPixel;
+  job.bCalcVar = bCalculateVar ? 1 : 0; job.bCalcBgd = bCalculateBGD ? 1 : 0; job.bCalcSsd = bCalculateSQDiff ? 1 : 0;
+  job.pSad8x8 = pRes->pSad8x8 ? &pRes->pSad8x8[0][0] : NULL;
+  job.pSsd16x16 = pRes->pSsd16x16; job.pSum16x16 = pRes->pSum16x16; job.pSumOfSquare16x16 = pRes->pSumOfSquare16x16;
+  job.pSumOfDiff8x8 = pRes->pSumOfDiff8x8 ? &pRes->pSumOfDiff8x8[0][0] : NULL;
+  job.pMad8x8 = pRes->pMad8x8 ? &pRes->pMad8x8[0][0] : NULL;
+  job.pFrameSad = &pRes->iFrameSad;
+  const int rc = g_api.FrameVaa (st->layer[iDid].ctx, &job);
+  if (rc != 0) {
+    if (st->trace) fprintf (stderr, "welship hooks: pre-analysis of layer %d stays on the host (%d: %s)\n", iDid, rc, g_api.GetLastError());
+    return 1;
+  }
+  pRes->pCurY = pCurPic->pData[0]; pRes->pRefY = pRefPic->pData[0];         // (what VaaCalculation / CVAACalculation::Process leave there)
+  ++st->vaa_done;
+  if (st->vaa_check) {
+    HipLayer::VaaCopy& V = st->layer[iDid].vaa_copy;
+    const int n = (job.iPicWidth >> 4) * (job.iPicHeight >> 4);
+    const bool sd = job.bCalcBgd != 0, sum = job.bCalcSsd || (!job.bCalcBgd && job.bCalcVar), ssd = job.bCalcSsd != 0;
+    V.valid = true; V.n = n; V.bgd = sd; V.var = sum; V.ssd = ssd; V.frame_sad = pRes->iFrameSad;
+    V.sad.assign (job.pSad8x8, job.pSad8x8 + 4 * n);
+    if (sd) { V.sd.assign (job.pSumOfDiff8x8, job.pSumOfDiff8x8 + 4 * n); V.mad.assign (job.pMad8x8, job.pMad8x8 + 4 * n); }
+    if (sum) { V.sum.assign (job.pSum16x16, job.pSum16x16 + n); V.sq.assign (job.pSumOfSquare16x16, job.pSumOfSquare16x16 + n); }
+    if (ssd) V.ssd16.assign (job.pSsd16x16, job.pSsd16x16 + n);
+    return 1;                 // the C functions run as well; HipFrameMd compares
+  }
+  if (st->trace) fprintf (stderr, "welship hooks: pre-analysis statistics of layer %d on the device (bgd %d var %d ssd %d)\n", iDid, job.bCalcBgd, job.bCalcVar, job.bCalcSsd);
+  return 0;
+}
+
 int32_t HipFrameMd (sWelsEncCtx* pCtx) {
   SWelsFuncPtrList* pFunc = pCtx->pFuncList;
   HipState* st = (HipState*)pFunc->pHipState;
@@ -211,15 +282,22 @@ int32_t HipFrameMd (sWelsEncCtx* pCtx) {
   HipLayer& L = st->layer[did];
   const SWelsSvcCodingParam* pParam = pCtx->pSvcParam;
   const int mbw = pCurLayer->iMbWidth, mbh = pCurLayer->iMbHeight, num_mb = mbw * mbh;
-  if (L.ctx == NULL) {
-    WelsHipFrameCfg cfg;
-    memset (&cfg, 0, sizeof (cfg));
-    cfg.iDevice = st->device + (st->layer_devices ? did : 0);
-    cfg.iPicWidth = mbw * 16; cfg.iPicHeight = mbh * 16;
-    cfg.iNumPictures = WELS_MAX (pParam->iNumRefFrame, pParam->iMaxNumRefFrame) + 2;    // RequestMemorySvc allocates 1 + iMaxNumRefFrame pictures per layer
-    L.num_pictures = cfg.iNumPictures;
-    const int rc = g_api.FrameCtxCreate (&L.ctx, &cfg);
-    if (rc) { fprintf (stderr, "welship hooks: no device context (%d: %s)\n", rc, g_api.GetLastError()); st->failed = true; return ENC_RETURN_UNEXPECTED; }
+  if (!EnsureLayerCtx (st, pCtx, did)) return ENC_RETURN_UNEXPECTED;
+  if (L.vaa_copy.valid) {      // WELS_HIP_CHECK_VAA=1: the device's pre-analysis against the reference's own
+    HipLayer::VaaCopy& V = L.vaa_copy;
+    V.valid = false;
+    const SVAACalcResult* pRes = &pCtx->pVaa->sVaaCalcInfo;
+    bool same = V.frame_sad == pRes->iFrameSad && memcmp (&V.sad[0], &pRes->pSad8x8[0][0], sizeof (int32_t) * 4 * V.n) == 0;
+    if (same && V.bgd) same = memcmp (&V.sd[0], &pRes->pSumOfDiff8x8[0][0], sizeof (int32_t) * 4 * V.n) == 0 && memcmp (&V.mad[0], &pRes->pMad8x8[0][0], (size_t)4 * V.n) == 0;
+    if (same && V.var) same = memcmp (&V.sum[0], pRes->pSum16x16, sizeof (int32_t) * V.n) == 0 && memcmp (&V.sq[0], pRes->pSumOfSquare16x16, sizeof (int32_t) * V.n) == 0;
+    if (same && V.ssd) same = memcmp (&V.ssd16[0], pRes->pSsd16x16, sizeof (int32_t) * V.n) == 0;
+    if (!same) {
+      int bad = -1;
+      for (int i = 0; i < 4 * V.n && bad < 0; ++i) if (V.sad[i] != (&pRes->pSad8x8[0][0])[i]) bad = i;
+      fprintf (stderr, "welship hooks: the device's pre-analysis differs from the reference's (layer %d, frame SAD %d vs %d, first 8x8 SAD that differs: %d)\n", did, V.frame_sad, pRes->iFrameSad, bad);
+      st->failed = true; return ENC_RETURN_UNEXPECTED;
+    }
+    if (st->trace) fprintf (stderr, "welship hooks: the device's pre-analysis equals the reference's\n");
   }
   L.gom = !FrameConstantQp (pCtx);
   L.reencode.clear();
@@ -747,6 +825,7 @@ void WelsHipInstall (SWelsFuncPtrList* pFuncList, SWelsSvcCodingParam* pParam) {
   pFuncList->pfHipCodeSlice = NULL;
   pFuncList->pfHipRelease = NULL;
   pFuncList->pfHipDownsample = NULL;
+  pFuncList->pfHipVaaCalc = NULL;
   pFuncList->pHipState = NULL;
   const char* off = getenv ("WELS_HIP");
   if (off && atoi (off) == 0) return;
@@ -767,11 +846,14 @@ void WelsHipInstall (SWelsFuncPtrList* pFuncList, SWelsSvcCodingParam* pParam) {
   st->check_bits = getenv ("WELS_HIP_CHECK_BITS") != NULL && atoi (getenv ("WELS_HIP_CHECK_BITS")) != 0 && pParam->iEntropyCodingModeFlag == 0;
   st->layer_devices = getenv ("WELS_HIP_LAYER_DEVICES") != NULL && atoi (getenv ("WELS_HIP_LAYER_DEVICES")) != 0;
   st->downsample = !(getenv ("WELS_HIP_DOWNSAMPLE") != NULL && atoi (getenv ("WELS_HIP_DOWNSAMPLE")) == 0);
+  st->vaa = !(getenv ("WELS_HIP_VAA") != NULL && atoi (getenv ("WELS_HIP_VAA")) == 0);
+  st->vaa_check = getenv ("WELS_HIP_CHECK_VAA") != NULL && atoi (getenv ("WELS_HIP_CHECK_VAA")) != 0;
   pFuncList->pHipState = st;
   pFuncList->pfHipFrameMd = HipFrameMd;
   pFuncList->pfHipCodeSlice = HipCodeSlice;
   pFuncList->pfHipRelease = HipRelease;
   pFuncList->pfHipDownsample = HipDownsample;
+  pFuncList->pfHipVaaCalc = HipVaaCalc;
   if (st->trace) fprintf (stderr, "welship hooks: installed\n");
 }
 

@@ -366,7 +366,11 @@ __global__ __launch_bounds__ (MAXT) void k_inter_rows (WhSeqParams P, const WhPi
     X.spec = N;
     X.spec_valid = 1;
   };
+#if defined(WH_SLIDE_AT_TOP)      /* experiment: the next macroblock's fetch after the current one is complete (as the ticket scheduler does) */
+  WhNoEarly early;
+#else
   WhEarlyFn<decltype (early_fn)> early = { early_fn };
+#endif
   early_fn();
   int pslot = -1, pxy = -1;                      // the macroblock this wave coded last
   while (nslot >= 0) {
@@ -395,6 +399,9 @@ __global__ __launch_bounds__ (MAXT) void k_inter_rows (WhSeqParams P, const WhPi
     const uint32_t dc = ((uint32_t)__builtin_readcyclecounter() - tc0) >> 6;
     c0 += slot == 0 ? dc : 0u; c1 += slot == 1 ? dc : 0u; c2 += slot == 2 ? dc : 0u; c3 += slot == 3 ? dc : 0u;
     pslot = slot; pxy = xy;
+#if defined(WH_SLIDE_AT_TOP)
+    early_fn();
+#endif
   }
   if (slice_cost && lane == 0) {
     if (slot_id[0] >= 0 && c0) atomicAdd (&slice_cost[slot_id[0]], c0);
@@ -821,7 +828,7 @@ class HipBackend : public wh::Backend {
     // a single slice per workgroup (few pictures in flight: the latency regime) keeps the finest grain, one macroblock per ticket
     const char* rows_env = getenv ("WELSHIP_MD_ROWS");        // (read per launch: the GPU tests switch it inside one process)
     const int forced_rows = rows_env ? atoi (rows_env) : -1;
-    const bool rows = P.flags == 0 && P.run_len > 1 && (forced_rows >= 0 ? forced_rows != 0 : slots >= 2);
+    const bool rows = P.flags == 0 && P.run_len >= 1 && (forced_rows >= 0 ? forced_rows != 0 : (slots >= 2 && P.run_len > 1));
     const WhSeqParams& Pr = P;
     auto launch = [&] (auto kernel) {
       HIP_TRY (hipFuncSetAttribute ((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -1278,8 +1278,44 @@ struct WelsHipFrameCtx {
   WhSeqParams seq;
   std::vector<DevPicture> pics;
   size_t rec_alloc_bytes = 0, rec_y = 0, rec_c = 0, ysz = 0, csz = 0, src_bytes = 0;
-  uint8_t* d_src = nullptr;              // the source picture, macroblock-tiled (WH_SRC_*) ...
-  uint8_t* d_src_planar = nullptr;       // ... and as uploaded
+  uint8_t* d_src = nullptr;              // the source picture being coded, macroblock-tiled (WH_SRC_*): one of src_pool ...
+  uint8_t* d_src_planar = nullptr;       // ... and where an upload lands before the device rearranges it
+  // Source pictures stay on the device for the pre-analysis of later pictures (WelsHipFrameVaa): a small pool keyed by the caller's
+  // luma pointer (the reference rotates a fixed set of SPicture buffers per layer), least recently used slot replaced
+  struct SrcSlot { const void* key = nullptr; uint8_t* d = nullptr; uint64_t stamp = 0, luma_sum = 0; };
+  std::vector<SrcSlot> src_pool;
+  uint64_t src_clock = 0;
+  const void* fresh_key = nullptr;       // the picture WelsHipFrameVaa has just uploaded: the FrameEncode that follows finds it resident
+  uint8_t* d_vaa_out = nullptr;          // pre-analysis results: sad8x8 | sd8x8 | sum16 | sqsum16 | ssd16 | mad8x8 ([mb] each, 48 bytes per MB)
+  std::vector<uint8_t> h_vaa_out;        // page-locked
+  int src_find (const void* key) const { for (size_t i = 0; i < src_pool.size(); ++i) if (src_pool[i].key == key) return (int)i; return -1; }
+  int src_take (const void* key) {       // the slot of `key`, or the least recently used one (its content is then stale: the caller uploads)
+    int k = src_find (key);
+    if (k < 0) { k = 0; for (size_t i = 1; i < src_pool.size(); ++i) if (src_pool[i].stamp < src_pool[k].stamp) k = (int)i; }
+    src_pool[k].key = key; src_pool[k].stamp = ++src_clock;
+    return k;
+  }
+  // A position-weighted 64-bit sum of the MB-aligned luma area of a host picture: what tells whether the copy a pool slot holds is
+  // still what the caller's buffer contains (a buffer's address alone does not: the reference rotates and reuses its pictures)
+  uint64_t luma_checksum (const uint8_t* y, int32_t stride) const {
+    uint64_t s0 = 0, s1 = 0, k = 1;
+    for (int r = 0; r < mb_h * 16; ++r) {
+      const uint8_t* row = y + (size_t)r * stride;
+      for (int i = 0; i < mb_w * 16; i += 16, k += 2) { uint64_t a, b; memcpy (&a, row + i, 8); memcpy (&b, row + i + 8, 8); s0 += a * k; s1 += b * (k + 0x9E3779B97F4A7C15ull); }
+    }
+    return s0 ^ (s1 << 1 | s1 >> 63);
+  }
+  // stage a host picture (MB-aligned area of the caller's planes) into h_src; no device call
+  void stage_planes (const uint8_t* const p[3], const int32_t stride[3]) {
+    uint8_t* y = h_src.data();
+    uint8_t* u = y + ysz;
+    uint8_t* v = u + csz;
+    for (int r = 0; r < mb_h * 16; ++r) memcpy (y + (size_t)r * seq.src_stride_y, p[0] + (size_t)r * stride[0], (size_t)mb_w * 16);
+    for (int r = 0; r < mb_h * 8; ++r) {
+      memcpy (u + (size_t)r * seq.src_stride_c, p[1] + (size_t)r * stride[1], (size_t)mb_w * 8);
+      memcpy (v + (size_t)r * seq.src_stride_c, p[2] + (size_t)r * stride[2], (size_t)mb_w * 8);
+    }
+  }
   std::vector<uint8_t> h_src;
   WhMbRecord* d_records = nullptr;
   std::vector<WhMbRecord> h_records;
@@ -1330,7 +1366,11 @@ struct WelsHipFrameCtx {
     be->sync();
     for (auto& p : pics) { if (p.base) be->free (p.base); if (p.mbs) be->free (p.mbs); }
     pics.clear();
-    void* ptrs[] = {d_src, d_src_planar, d_records, d_dbflags, d_mb_ctl, d_sad_cost0, d_vaa, d_bgd, d_il, d_job, d_scc, d_scc_idc, d_scc_ori, d_scc_chain, d_scc_lists, d_scc_loc, d_scc_order, d_scc_chain_mb, d_gom_rc, d_sad_cost0_new};
+    for (auto& sl : src_pool) if (sl.d) be->free (sl.d);
+    src_pool.clear();
+    d_src = nullptr;
+    if (!h_vaa_out.empty()) be->unpin_host (h_vaa_out.data());
+    void* ptrs[] = {d_vaa_out, d_src_planar, d_records, d_dbflags, d_mb_ctl, d_sad_cost0, d_vaa, d_bgd, d_il, d_job, d_scc, d_scc_idc, d_scc_ori, d_scc_chain, d_scc_lists, d_scc_loc, d_scc_order, d_scc_chain_mb, d_gom_rc, d_sad_cost0_new};
     if (!h_gom.empty()) be->unpin_host (h_gom.data());
     if (!h_scc.empty()) be->unpin_host (h_scc.data());
     if (!h_scc_small.empty()) be->unpin_host (h_scc_small.data());
@@ -1519,7 +1559,9 @@ int WelsHipFrameCtxCreate (WelsHipFrameCtx** pp, const WelsHipFrameCfg* cfg) {
   auto A = [&] (size_t n) { void* p = be->alloc (n); if (!p) oom = true; return p; };
   c->pics.resize (cfg->iNumPictures);
   for (auto& d : c->pics) { d.base = (uint8_t*)A (DevPicture::alloc_bytes (c->rec_alloc_bytes + 128)); d.mbs = (WhMbState*)A (sizeof (WhMbState) * c->num_mb); }
-  c->d_src = (uint8_t*)A (c->src_bytes);
+  c->src_pool.resize (std::min (8, std::max (3, cfg->iNumPictures + 1)));
+  for (auto& sl : c->src_pool) sl.d = (uint8_t*)A (c->src_bytes);
+  c->d_src = c->src_pool[0].d;
   c->d_src_planar = (uint8_t*)A (c->src_bytes);
   c->d_records = (WhMbRecord*)A (sizeof (WhMbRecord) * c->num_mb);
   c->d_dbflags = (uint32_t*)A (sizeof (uint32_t) * c->num_mb);
@@ -1629,18 +1671,10 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
   FrameShared* sh = c->sh;
   wh::Backend* be = c->be;
   // host-side staging into this context's own page-locked buffers: outside the shared lock
-  if (first_part) {
-    // source picture: the MB-aligned area of pEncPic (CWelsPreProcess pads it), tight strides on the device
-    const WhSeqParams& s0 = c->seq;
-    uint8_t* y = c->h_src.data();
-    uint8_t* u = y + c->ysz;
-    uint8_t* v = u + c->csz;
-    for (int r = 0; r < c->mb_h * 16; ++r) memcpy (y + (size_t)r * s0.src_stride_y, j->pSrc[0] + (size_t)r * j->iSrcStride[0], (size_t)c->mb_w * 16);
-    for (int r = 0; r < c->mb_h * 8; ++r) {
-      memcpy (u + (size_t)r * s0.src_stride_c, j->pSrc[1] + (size_t)r * j->iSrcStride[1], (size_t)c->mb_w * 8);
-      memcpy (v + (size_t)r * s0.src_stride_c, j->pSrc[2] + (size_t)r * j->iSrcStride[2], (size_t)c->mb_w * 8);
-    }
-  }
+  // source picture: the MB-aligned area of pEncPic (CWelsPreProcess pads it), tight strides on the device -- unless the pre-analysis
+  // of this very picture has put it there already (WelsHipFrameVaa)
+  const bool src_resident = first_part && c->fresh_key != nullptr && c->fresh_key == (const void*)j->pSrc[0] && c->src_find (c->fresh_key) >= 0;
+  if (first_part && !src_resident) c->stage_planes (j->pSrc, j->iSrcStride);
   if (first_part) {
     if (is_p && j->pVaaSad8x8) memcpy (c->h_aux.data() + c->aux_vaa, j->pVaaSad8x8, sizeof (int32_t) * 4 * c->num_mb);
     if (is_p && j->pBgdFlags) memcpy (c->h_aux.data() + c->aux_bgd, j->pBgdFlags, (size_t)c->num_mb);
@@ -1806,8 +1840,14 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
   const int queue = K ? K->queue : 0;
   be->select_queue (queue);
   if (first_part) {
-    be->upload (c->d_src_planar, c->h_src.data(), c->src_bytes);
-    be->run_src_tile (s, c->d_src_planar, c->d_src);
+    const int slot = c->src_take ((const void*)j->pSrc[0]);
+    c->d_src = c->src_pool[slot].d;
+    c->fresh_key = nullptr;
+    if (!src_resident) {
+      c->src_pool[slot].luma_sum = c->luma_checksum (c->h_src.data(), s.src_stride_y);       // (of the staged copy: what the slot will hold)
+      be->upload (c->d_src_planar, c->h_src.data(), c->src_bytes);
+      be->run_src_tile (s, c->d_src_planar, c->d_src);
+    }
     if (is_p && j->pVaaSad8x8) be->upload (c->d_vaa, c->h_aux.data() + c->aux_vaa, sizeof (int32_t) * 4 * c->num_mb);
     if (is_p && j->pBgdFlags) be->upload (c->d_bgd, c->h_aux.data() + c->aux_bgd, (size_t)c->num_mb);
     if (is_p && j->pIlHint) be->upload (c->d_il, c->h_aux.data() + c->aux_il, sizeof (int16_t) * 4 * c->num_mb);
@@ -1974,6 +2014,78 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
   if (j->pSadCost) memcpy (j->pSadCost, c->h_sad_out.data(), sizeof (int32_t) * c->num_mb);
   if (scr && scr->pSliceFMECostDown) memcpy (scr->pSliceFMECostDown, c->scc_down(), sizeof (uint32_t) * j->iNumSlices);
   *pp_records = c->h_records.data();
+  return WELSHIP_OK;
+}
+
+int WelsHipFrameVaa (WelsHipFrameCtx* c, const WelsHipVaaJob* j) {
+  if (!c || !c->be || !j) return WELSHIP_ERR_INIT_PARA;
+  for (int i = 0; i < 3; ++i) if (!j->pCur[i] || !j->pRef[i] || j->iCurStride[i] < (i ? c->mb_w * 8 : c->mb_w * 16) || j->iRefStride[i] < (i ? c->mb_w * 8 : c->mb_w * 16)) {
+    set_err ("pre-analysis: planes / strides"); return WELSHIP_ERR_INIT_PARA;
+  }
+  // A width that is no multiple of 16: the C functions step from one macroblock row to the next by 16 * stride - width, i.e. every row
+  // starts (width & 15) samples further left than the one above and runs into the previous line's stride padding
+  // (vaacalcfuncs.cpp:262-264,332-333) -- results that depend on bytes outside the picture.  Left to the caller's C path.
+  if (j->iPicWidth & 15) { set_err ("pre-analysis: picture width is no multiple of 16 (the C functions' row step reads the stride padding)"); return WELSHIP_ERR_UNSUPPORTED; }
+  const int vw = j->iPicWidth >> 4, vh = j->iPicHeight >> 4;       // the macroblocks the C functions cover
+  if (vw < 1 || vh < 1 || vw > c->mb_w || vh > c->mb_h || !j->pSad8x8 || !j->pFrameSad) { set_err ("pre-analysis: picture size / result arrays"); return WELSHIP_ERR_INIT_PARA; }
+  // which arrays the selected variant writes (vaacalculation.cpp:118-157)
+  const bool bgd = j->bCalcBgd != 0, ssd = j->bCalcSsd != 0, var = !bgd && !ssd && j->bCalcVar != 0;
+  const bool want_sd = bgd, want_sum = ssd || var, want_ssd = ssd;
+  if ((want_sd && (!j->pSumOfDiff8x8 || !j->pMad8x8)) || (want_sum && (!j->pSum16x16 || !j->pSumOfSquare16x16)) || (want_ssd && !j->pSsd16x16)) {
+    set_err ("pre-analysis: a result array of the selected variant is missing"); return WELSHIP_ERR_INIT_PARA;
+  }
+  FrameShared* sh = c->sh;
+  wh::Backend* be = c->be;
+  const size_t n = (size_t)c->num_mb;
+  const size_t o_sad = 0, o_sd = 16 * n, o_sum = 32 * n, o_sq = 36 * n, o_ssd = 40 * n, o_mad = 44 * n, out_bytes = 48 * n;
+  const int queue = 24 + (int) ((uintptr_t)c / 64 % 8);        // the pre-analysis queues (keys: 0..7 uploads, 8..23 launch sets)
+  std::unique_lock<std::mutex> lock (sh->mu);
+  if (!c->d_vaa_out) {
+    c->d_vaa_out = (uint8_t*)be->alloc (out_bytes);
+    c->h_vaa_out.assign (out_bytes, 0);
+    be->pin_host (c->h_vaa_out.data(), out_bytes);
+    if (!c->d_vaa_out) { set_err ("out of device memory"); return WELSHIP_ERR_MEMORY; }
+  }
+  be->select_queue (queue);
+  // the earlier picture: resident when it was the source of an earlier call AND the caller's buffer still holds what was uploaded then
+  // (its slot is refreshed so that it survives the upload below)
+  const uint64_t ref_sum = c->luma_checksum (j->pRef[0], j->iRefStride[0]);
+  int rslot = c->src_find ((const void*)j->pRef[0]);
+  if (rslot >= 0 && c->src_pool[rslot].luma_sum == ref_sum) c->src_pool[rslot].stamp = ++c->src_clock;
+  else {
+    rslot = c->src_take ((const void*)j->pRef[0]);
+    c->src_pool[rslot].luma_sum = ref_sum;
+    c->stage_planes (j->pRef, j->iRefStride);
+    be->upload (c->d_src_planar, c->h_src.data(), c->src_bytes);
+    be->run_src_tile (c->seq, c->d_src_planar, c->src_pool[rslot].d);
+    if (be->sync_queue (queue)) { set_err ("device error in the pre-analysis"); return WELSHIP_ERR_UNKNOWN; }      // (the staging buffer is used again below)
+  }
+  const int cslot = c->src_take ((const void*)j->pCur[0]);
+  if (cslot == rslot) { set_err ("pre-analysis: a picture against itself"); return WELSHIP_ERR_INIT_PARA; }
+  c->stage_planes (j->pCur, j->iCurStride);
+  c->src_pool[cslot].luma_sum = c->luma_checksum (c->h_src.data(), c->seq.src_stride_y);
+  be->upload (c->d_src_planar, c->h_src.data(), c->src_bytes);
+  be->run_src_tile (c->seq, c->d_src_planar, c->src_pool[cslot].d);
+  uint8_t* o = c->d_vaa_out;
+  be->run_vaa (c->seq, c->src_pool[cslot].d, c->src_pool[rslot].d, (int32_t*) (o + o_sad), want_sd ? (int32_t*) (o + o_sd) : nullptr, want_sd ? o + o_mad : nullptr,
+               want_sum ? (int32_t*) (o + o_sum) : nullptr, want_sum ? (int32_t*) (o + o_sq) : nullptr, want_ssd ? (int32_t*) (o + o_ssd) : nullptr);
+  be->download (c->h_vaa_out.data(), o, out_bytes);
+  lock.unlock();
+  if (be->sync_queue (queue)) { set_err ("device error in the pre-analysis"); return WELSHIP_ERR_UNKNOWN; }
+  c->fresh_key = (const void*)j->pCur[0];
+  // results: the macroblocks the C functions cover, row by row; the frame SAD is their sum
+  const uint8_t* h = c->h_vaa_out.data();
+  long long frame_sad = 0;
+  for (int y = 0; y < vh; ++y) {
+    const size_t a = (size_t)y * c->mb_w, d = (size_t)y * vw;        // device rows are mb_w wide, the caller's arrays (w >> 4)
+    const int32_t* sad = (const int32_t*) (h + o_sad) + 4 * a;
+    memcpy (j->pSad8x8 + 4 * d, sad, sizeof (int32_t) * 4 * vw);
+    for (int i = 0; i < 4 * vw; ++i) frame_sad += sad[i];
+    if (want_sd) { memcpy (j->pSumOfDiff8x8 + 4 * d, (const int32_t*) (h + o_sd) + 4 * a, sizeof (int32_t) * 4 * vw); memcpy (j->pMad8x8 + 4 * d, h + o_mad + 4 * a, (size_t)4 * vw); }
+    if (want_sum) { memcpy (j->pSum16x16 + d, (const int32_t*) (h + o_sum) + a, sizeof (int32_t) * vw); memcpy (j->pSumOfSquare16x16 + d, (const int32_t*) (h + o_sq) + a, sizeof (int32_t) * vw); }
+    if (want_ssd) memcpy (j->pSsd16x16 + d, (const int32_t*) (h + o_ssd) + a, sizeof (int32_t) * vw);
+  }
+  *j->pFrameSad = (int32_t)frame_sad;
   return WELSHIP_OK;
 }
 

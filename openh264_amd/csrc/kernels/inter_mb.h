@@ -276,19 +276,50 @@ WH_FN void wh_win_slide_move (WhWinLds* b, int on_y, int on_c) {
   { WV_LANES_BEGIN (lane) { const int p = (idx); if (cond) t[lane] = * (const WhV4*)&b->arr[16 * (p + 1)]; } WV_LANES_END  \
     WV_LANES_BEGIN (lane) { const int p = (idx); if (cond) * (WhV4*)&b->arr[16 * p] = t[lane]; } WV_LANES_END }
 #else
+  // all reads, one hand-off, all writes: two LDS round trips instead of one per piece (a piece is never read after it was written:
+  // every lane has read everything it needs before the first store of any lane is issued)
   const int lane = wh_lane_id();
-#define WH_SLIDE_STEP(arr, idx, cond)                                                                      \
-  { const int p = (idx); const bool mv = (cond); WhV4 v = {0u, 0u, 0u, 0u}; if (mv) v = * (const WhV4*)&b->arr[16 * (p + 1)]; WV_SYNC(); if (mv) * (WhV4*)&b->arr[16 * p] = v; WV_SYNC(); }
-#endif
+  WhV4 vy[WH_WIN_LOADS], vc[WH_CWIN_PIECES / 64];
   if (on_y) {
 #pragma unroll
-    for (int k = 0; k < WH_WIN_LOADS; ++k) WH_SLIDE_STEP (win, 64 * k + lane, p < WH_WIN_PIECES && (p - 5 * ((p * 205) >> 10)) != 4)
+    for (int k = 0; k < WH_WIN_LOADS; ++k) {
+      const int p = 64 * k + lane;
+      const WhV4 z = {0u, 0u, 0u, 0u};
+      vy[k] = z;
+      if (p < WH_WIN_PIECES && (p - 5 * ((p * 205) >> 10)) != 4) vy[k] = * (const WhV4*)&b->win[16 * (p + 1)];
+    }
   }
   if (on_c) {
 #pragma unroll
-    for (int k = 0; k < WH_CWIN_PIECES / 64; ++k) WH_SLIDE_STEP (cwin, 64 * k + lane, (p & 3) != 3)
+    for (int k = 0; k < WH_CWIN_PIECES / 64; ++k) {
+      const int q = 64 * k + lane;
+      const WhV4 z = {0u, 0u, 0u, 0u};
+      vc[k] = z;
+      if ((q & 3) != 3) vc[k] = * (const WhV4*)&b->cwin[16 * (q + 1)];
+    }
   }
+  WV_SYNC();
+  if (on_y) {
+#pragma unroll
+    for (int k = 0; k < WH_WIN_LOADS; ++k) {
+      const int p = 64 * k + lane;
+      if (p < WH_WIN_PIECES && (p - 5 * ((p * 205) >> 10)) != 4) * (WhV4*)&b->win[16 * p] = vy[k];
+    }
+  }
+  if (on_c) {
+#pragma unroll
+    for (int k = 0; k < WH_CWIN_PIECES / 64; ++k) {
+      const int q = 64 * k + lane;
+      if ((q & 3) != 3) * (WhV4*)&b->cwin[16 * q] = vc[k];
+    }
+  }
+  WV_SYNC();
+#endif
+#if defined(WH_EMU)
+  if (on_y) for (int k = 0; k < WH_WIN_LOADS; ++k) WH_SLIDE_STEP (win, 64 * k + lane, p < WH_WIN_PIECES && (p - 5 * ((p * 205) >> 10)) != 4)
+  if (on_c) for (int k = 0; k < WH_CWIN_PIECES / 64; ++k) WH_SLIDE_STEP (cwin, 64 * k + lane, (p & 3) != 3)
 #undef WH_SLIDE_STEP
+#endif
 }
 WH_FN void wh_win_slide_finish (WhWinLds* b, const WhWinSlide& SL) {
   WV_LANES_BEGIN (lane)
