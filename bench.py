@@ -62,8 +62,13 @@ def parse():
     ap.add_argument("--host-threads", type=int, default=min(32, os.cpu_count() or 8))
     ap.add_argument("--e2e-groups", type=int, default=3, help="independent session groups of the overlapped end-to-end leg (sessions/2 each)")
     ap.add_argument("--e2e-group-sessions", type=int, default=64, help="sessions per group of that leg")
+    ap.add_argument("--cpu-launcher-test", action="store_true",
+                    help="TEST ONLY (tests/test_multi_rank.py): exercise the N-rank launch / barrier / max-over-ranks / JSON logic without a GPU -- "
+                         "gloo instead of RCCL, WELSHIP_LIB must name the CPU test build of the kernels; implies --quick, the line is marked as no measurement")
     ap.add_argument("--deblock-idc", type=int, default=0, help="disable_deblocking_filter_idc (0: filter across slice boundaries, the reference default)")
     a = ap.parse_args()
+    if a.cpu_launcher_test:
+        a.quick = True
     if a.quick:
         a.no_cpu_baseline = a.no_verify = a.no_extra = True
     return a
@@ -323,22 +328,32 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
-    if not torch.cuda.is_available():
+    cpu_test = a.cpu_launcher_test
+    if cpu_test:
+        if "emu" not in os.path.basename(os.environ.get("WELSHIP_LIB", "")):
+            raise SystemExit("--cpu-launcher-test needs WELSHIP_LIB = the CPU test build (tests/emu/libwelship_emu.so)")
+    elif not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    torch.cuda.set_device(local)
+    else:
+        torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if cpu_test:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     os.environ["WELSHIP_QUEUES"] = str(a.queues)
     import openh264_amd as oh
     from openh264_amd.utils.synth import synth_sequence
 
     def barrier():
-        torch.cuda.synchronize()
+        if not cpu_test:
+            torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not cpu_test:
+            torch.cuda.synchronize()
 
     workload = a.workload
     if a.sessions <= 0:
@@ -361,7 +376,7 @@ def main():
     verify_sessions = () if (a.no_verify or not have_ref or rank != 0) else tuple(sorted({0, a.sessions - 1}))
     dt, ev, verified = hot_path_leg(oh, a, local, w, h, workload, a.sessions, ring, content, a.steps, a.warmup, barrier, verify_sessions)
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if cpu_test else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     if rank != 0:
@@ -370,12 +385,26 @@ def main():
             dist.destroy_process_group()
         return
 
+    def md_run_len():
+        try:
+            return max(1, int(os.environ.get("WELSHIP_MD_RUN", "1")))
+        except ValueError:
+            return 1
+
+    def md_kernel(sessions):
+        """Which mode-decision kernel the library launches for this batch (hip_backend.hip run_inter): tickets of one macroblock
+        (k_inter_pool) unless runs are asked for (WELSHIP_MD_RUN > 1) and a workgroup holds at least two slices."""
+        forced = os.environ.get("WELSHIP_MD_ROWS")
+        slots = max(1, min(4, sessions * 4 // 256))
+        rows = (forced != "0") if forced is not None else (slots >= 2 and md_run_len() > 1)
+        return "k_inter_rows (runs of %d macroblocks)" % md_run_len() if rows else "k_inter_pool"
+
     def roofline(workload, mbs, sessions, steps, ev):
         b_md = BYTES_I_MB_MD if workload == "intra" else BYTES_P_MB_MD
         b_path = BYTES_I_MB_PATH if workload == "intra" else BYTES_P_MB_PATH
         md_launch_ms = ev["md_ms"] / steps                                   # one launch per pass and step
         achieved = b_md * mbs * sessions / (md_launch_ms * 1e-3) / 1e9       # every MB of every picture in the batch x bytes/MB
-        return {"bound": "hbm", "kernel": "k_intra_slice" if workload == "intra" else "k_inter_pool",
+        return {"bound": "hbm", "kernel": "k_intra_slice" if workload == "intra" else md_kernel(sessions),
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "bytes_per_mb": b_md, "avg_launch_ms": md_launch_ms, "launches_per_step": 1,
                 "path_achieved_GBs": b_path * mbs * sessions * steps / (ev["total_ms"] * 1e-3) / 1e9,
@@ -385,10 +414,14 @@ def main():
     rf = roofline(workload, mbs, a.sessions, a.steps, ev)
     rf["traffic"] = None
     try:        # HBM bytes per launch of the dominant kernel: from the committed rocprofv3 --pmc passes of this very command (not measured in this run)
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
         if tj.get("workload") == workload and tj.get("sessions") == a.sessions and (w, h) == (tj.get("width"), tj.get("height")):
-            rf["traffic"] = tj["hbm_bytes_per_launch"]
-            rf["traffic_source"] = "profiles/r02_pmc_traffic.json (separate rocprofv3 --pmc passes of this command; not measured in this run)"
+            want = "tickets" if rf["kernel"] == "k_inter_pool" else "runs of 4" if md_run_len() == 4 else "whole rows" if md_run_len() >= (w + 15) // 16 else None
+            for name, v in tj["schedulers"].items():
+                if want and name.startswith(want):
+                    rf["traffic"] = v["hbm_bytes_per_launch"]
+                    rf["traffic_over_algorithmic"] = v["times_algorithmic"]
+                    rf["traffic_source"] = "profiles/r03_pmc_traffic.json, '%s' (separate rocprofv3 --pmc passes of this command; not measured in this run)" % name
     except Exception:
         pass
     pics = a.sessions * a.steps * world
@@ -398,7 +431,7 @@ def main():
                         "`verified` = the timed steps' reconstruction equals the reference's, `e2e` = complete EncodeFrame rate with a bitstream SHA1 check",
         "value": pics / dt, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u8", "data": data,
+        "dtype": "u8", "data": data if not cpu_test else data + " -- LAUNCHER TEST on the CPU test build of the kernels: not a measurement",
         "config": {"workload": ("%dx%d all-IDR (intra MD + DCT/quant + deblock), QP %d, LOW complexity" % (w, h, a.qp)) if workload == "intra" else
                    ("%dx%d P-frames, diamond ME range 16, 4 slices/frame, QP %d, LOW complexity" % (w, h, a.qp)),
                    "pictures_in_flight_per_gpu": a.sessions, "device_queues": a.queues,
@@ -456,6 +489,24 @@ def main():
                 line["intra_720p"] = {"data": "res/VID_1280x720_cavlc_temporal_direct.264 decoded (BASELINE config 2's stand-in clip)", "value": ns * st / d3, "unit": "frames/s",
                                       "sessions": ns, "steps": st, "roofline": {k: r3[k] for k in ("kernel", "achieved", "frac", "avg_launch_ms", "bytes_per_mb")},
                                       "verified": (all(ver3.values()) if ver3 is not None else None)}
+        # BASELINE configs 4 and 5 at the sizes BASELINE.json states, through the dispatch-table binding (the reference's own frame layer,
+        # rate control and entropy coder; oracle/_ref/ref_enc_hip -parallel N = N ISVCEncoder objects on N threads of one process), next to
+        # the same sessions on the reference's C path on as many host cores.  One GPU's share: config 4 = one 1080p input coded as
+        # 1080p / 720p / 360p / 180p simulcast AVC layers (all four layers on this GPU; one layer per GPU is WELS_HIP_LAYER_DEVICES=1),
+        # config 5 = 8 of the 64 concurrent 1080p sessions (rate control in bitrate mode, raster slices of 2040 macroblocks).
+        if workload == "p" and os.path.exists(os.path.join(REF_DIR, "ref_enc_hip")):
+            for key, args in (("config4_simulcast_1080p_720p_360p_180p", ["1", "30", "simulcast", "1080p"]), ("config4_8_sessions", ["8", "30", "simulcast", "1080p"]),
+                              ("config5_8_sessions_1080p_rc_raster_slices", ["8", "30", "plain", "1080p"])):
+                try:
+                    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "config5_sessions.py")] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240,
+                                       env=dict(os.environ, WELS_HIP_DEVICE=str(local)))
+                    j = json.loads(r.stdout.decode().strip().splitlines()[-1])
+                    line[key] = {"config": j["config"], "same_bitstreams": j["same_bitstreams"],
+                                 "device_frames_per_s": j["hooks_on_device"]["sum_of_session_encode_fps"], "device_slowest_session_fps": j["hooks_on_device"]["min_session_fps"],
+                                 "c_path_frames_per_s": j["reference_c_path"]["sum_of_session_encode_fps"], "c_path_cores": int(args[0]),
+                                 "note": "frames/s = sum over the sessions of frames / time inside EncodeFrame; every layer of a simulcast frame counts as part of ONE frame"}
+                except Exception as e:
+                    line[key] = {"error": str(e)[:200]}
     if world == 1 and not a.no_cpu_baseline:
         cb = cpu_baseline(w, h, a.qp, workload, content, a.deblock_idc)
         if cb:

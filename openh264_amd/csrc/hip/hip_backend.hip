@@ -193,6 +193,7 @@ __global__ __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPi
 #define WH_FETCH_AHEAD()                                                                                                       \
   if (nslot >= 0) {                                                                                                            \
     wh_inter_cold_fetch (G, lane, P, Jl[nslot], nxy % P.mb_w, nxy / P.mb_w);   /* in flight while the wave codes / waits for the neighbours */ \
+    WH_PROF_SUB (P, S.m, 2);         /* detail: cold inputs issued */                                                          \
     X.spec_valid = 0;                                                                                                          \
     if (speculate) { wh_win_speculate (P, Jl[nslot], X.spec, nxy % P.mb_w, nxy / P.mb_w, slot_mv[nslot]); X.spec_valid = 1; }  \
   }
@@ -242,6 +243,7 @@ __global__ __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPi
     c0 += slot == 0 ? dc : 0u; c1 += slot == 1 ? dc : 0u; c2 += slot == 2 ? dc : 0u; c3 += slot == 3 ? dc : 0u;
     if (!claimed) {
       WH_CLAIM()
+      WH_PROF_SUB (P, S.m, 0);       /* detail: slot scan + ticket + order look-up */
       WH_FETCH_AHEAD()
     }
     slot = nslot; t = nt; xy = nxy;
@@ -356,7 +358,11 @@ __global__ __launch_bounds__ (MAXT) void k_inter_rows (WhSeqParams P, const WhPi
     const int guess = slot_mv[nslot];
     const int gx = wh_clip3 ((2 + (int) (int16_t) (guess & 0xffff)) >> 2, -P.mv_range, P.mv_range), gy = wh_clip3 ((2 + (guess >> 16)) >> 2, -P.mv_range, P.mv_range);
     wh_win_place (P, N, nx * 16 + gx, ny * 16 + gy);
+#if defined(WH_NO_SLIDE)           /* experiment: the run scheduler without sliding (every macroblock fetches whole windows) */
+    const bool same = false;
+#else
     const bool same = had && nslot == slot && ny == y;
+#endif
     SL.on_y = same && wh_win_can_slide_y (X.spec, N);
     SL.on_c = same && wh_win_can_slide_c (X.spec, N);
     if (SL.on_y | SL.on_c) wh_win_slide_begin (P, Jn, N, SL);

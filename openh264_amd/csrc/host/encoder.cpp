@@ -40,9 +40,11 @@ namespace {
 inline int align_up (int v, int a) { return (v + a - 1) / a * a; }
 
 // Macroblocks per run of the P kernel's run scheduler (hip_backend.hip k_inter_rows): a wave codes that many horizontally adjacent
-// macroblocks one after the other and slides its search windows from one to the next.  WELSHIP_MD_RUN overrides (1 = every
-// macroblock fetches its windows whole, >= the picture width = whole rows).
-inline int md_run_len() { const char* e = getenv ("WELSHIP_MD_RUN"); const int v = e ? atoi (e) : 4; return v < 1 ? 1 : v > 1023 ? 1023 : v; }
+// macroblocks one after the other and slides its search windows from one to the next.  WELSHIP_MD_RUN sets it (>= the picture width =
+// whole rows).  Default 1: one macroblock per ticket (k_inter_pool), every macroblock fetches its windows whole -- the fastest on the
+// MI355X today (profiles/r03_run_length_sweep.txt: 13.2 k frames/s against 12.8 k / 12.2 k / 10.5 k with runs of 2 / 4 / whole rows),
+// at 6.1 x the algorithmic bytes against 4.5 x / 3.0 x for runs of 4 / whole rows (profiles/r03_pmc_traffic.json).
+inline int md_run_len() { const char* e = getenv ("WELSHIP_MD_RUN"); const int v = e ? atoi (e) : 1; return v < 1 ? 1 : v > 1023 ? 1023 : v; }
 // the run section of the order table (entries [3 * num_mb, 4 * num_mb)) + WhSeqParams::run_len / run_count
 inline void build_run_section (WhSeqParams& s, int mb_w, int num_mb, std::vector<uint32_t>& order32) {
   order32.resize ((size_t)num_mb * 4, 0u);

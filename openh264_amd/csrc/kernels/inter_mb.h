@@ -1047,6 +1047,7 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
       }
 #endif
     }
+    WH_PROF_SUB (P, M, 3);       /* detail: neighbour loads issued */
     tr.y = G.cold_y[lane]; tr.c = lane < 32 ? G.cold_c[lane] : 0u;
     wh_tile_commit (M, lane, &tr);
     // the reference picture's state of this MB (an I picture's has no motion / SAD).  Its padding word (WhMbState::pad1, word
@@ -1328,12 +1329,15 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
     const int nx = (mbx << 4) + (skx >> 2), ny = (mby << 4) + (sky >> 2);
     if (!(nx < -29 || nx > (P.mb_w << 4) + 12 || ny < -29 || ny > (P.mb_h << 4) + 12)) {
       wh_mc_luma_to (S, P, J, W, mbx, mby, 0, 0, 16, 16, skx, sky, S.skip_y);
+      WH_PROF_SUB (P, M, 4);     /* detail: P_Skip luma prediction */
       wh_mc_chroma_to (S, P, J, W, mbx, mby, 0, 0, 8, 8, skx, sky, S.skip_c);
+      WH_PROF_SUB (P, M, 5);     /* detail: P_Skip chroma prediction */
       int sad_l, sad_c;                       // luma and chroma SAD of the skip prediction in one reduction
       WV_SUM2 (sad_l, sad_c, lane, wh_sad4 (* (const uint32_t*)&S.m.enc_y[lane * 4], * (const uint32_t*)&S.skip_y[lane * 4]),
                (lane < 32 ? wh_sad4 (* (const uint32_t*)&S.m.enc_c[lane * 4], * (const uint32_t*)&S.skip_c[lane * 4]) : 0));
       const int sad_mb = sad_l + sad_c;
       bool ok = sad_mb == 0 || sad_mb < sad_pred_skip || (ref_is_p && ref_mb_type == WH_MB_PSKIP && !ref_mb_bg && sad_mb < Co->skip_sad);
+      WH_PROF_SUB (P, M, 6);     /* detail: P_Skip SADs + decision */
       if (!ok) {
         // residual would quantise to nothing?  (WelsDctMb + WelsTryPYskip + WelsTryPUVskip)
         WV_LANES_BEGIN (lane)

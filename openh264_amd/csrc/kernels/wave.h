@@ -219,10 +219,20 @@ WH_FN uint32_t wh_avg4 (uint32_t a, uint32_t b) { return __builtin_amdgcn_lerp (
 #if defined(WH_EMU)
 #define WH_PROF_DECL(P) ((void)0)
 #define WH_PROF_MARK(P, L, id) ((void)0)
+#define WH_PROF_SUB(P, L, id) ((void)0)
 #else
 #define WH_PROF_DECL(P) unsigned long long _wh_t0 = (P).prof ? (unsigned long long)__builtin_readcyclecounter() : 0ULL
-#define WH_PROF_MARK(P, L, id) do { if ((P).prof) { const unsigned long long _t = (unsigned long long)__builtin_readcyclecounter(); \
+#define WH_PROF_MARK_RAW(P, L, id) do { if ((P).prof) { const unsigned long long _t = (unsigned long long)__builtin_readcyclecounter(); \
   if ((threadIdx.x & 63) == 0) { (L).prof[id] += (uint32_t) (_t - _wh_t0); (L).prof[16 + (id)] += 1u; } _wh_t0 = _t; } } while (0)
+#if defined(WH_PROF_DETAIL)
+// Detail build of the P kernel's profile (tools/phase_profile.py --detail): the search .. store phases (2..7) are merged into id 7 and
+// 0 / 8 / 10 into id 10, which frees ids for sub-phases of the claim, the neighbour loads and the P_Skip test (WH_PROF_SUB)
+#define WH_PROF_MARK(P, L, id) WH_PROF_MARK_RAW (P, L, ((id) >= 2 && (id) <= 7) ? 7 : ((id) == 0 || (id) == 8 || (id) == 10) ? 10 : (id))
+#define WH_PROF_SUB(P, L, id) WH_PROF_MARK_RAW (P, L, id)
+#else
+#define WH_PROF_MARK(P, L, id) WH_PROF_MARK_RAW (P, L, id)
+#define WH_PROF_SUB(P, L, id) ((void)0)
+#endif
 #endif
 
 // 16 bytes moved as one unit (global_load_dwordx4 / ds_read_b128)

@@ -58,22 +58,18 @@ def test_fuzz_hip(hip_lib, ref_tools):
     _run(["--hip"], ref_tools)
 
 
-# The two schedulers of the P kernel (hip_backend.hip): tickets in 2:1 order (k_inter_pool) and one wave per row with sliding
-# search windows (k_inter_rows).  The device picks by how many slices a workgroup holds, so single small sessions would only ever
-# see the tickets; the CPU test build runs rows wherever they apply.  WELSHIP_MD_ROWS forces either.
-def test_fuzz_emu_ticket_scheduler(emu_lib, ref_tools):
-    _run([], ref_tools, seed=19, env={"WELSHIP_MD_ROWS": "0"})
-
-
-@pytest.mark.parametrize("run_len", ["7", "1000"])
-def test_fuzz_emu_other_run_lengths(emu_lib, ref_tools, run_len):
-    """Runs of 7 macroblocks (not a divisor of most picture widths) and whole rows; the test build checks every run table it walks."""
+# The two schedulers of the P kernel (hip_backend.hip): tickets of one macroblock in 2:1 order (k_inter_pool, the default) and runs of
+# WELSHIP_MD_RUN horizontally adjacent macroblocks with sliding search windows (k_inter_rows).  On the device runs also need several
+# slices per workgroup, which single small sessions never have: WELSHIP_MD_ROWS=1 forces the run scheduler there.
+@pytest.mark.parametrize("run_len", ["4", "7", "1000"])
+def test_fuzz_emu_run_scheduler(emu_lib, ref_tools, run_len):
+    """Runs of 4, of 7 macroblocks (not a divisor of most picture widths) and whole rows; the test build checks every run table it walks."""
     _run([], ref_tools, seed=31, env={"WELSHIP_MD_RUN": run_len})
 
 
 @pytest.mark.gpu
 def test_fuzz_hip_row_scheduler(hip_lib, ref_tools):
-    _run(["--hip"], ref_tools, seed=23, env={"WELSHIP_MD_ROWS": "1"})
+    _run(["--hip"], ref_tools, seed=23, env={"WELSHIP_MD_ROWS": "1", "WELSHIP_MD_RUN": "4"})
 
 
 @pytest.mark.gpu

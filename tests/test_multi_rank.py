@@ -225,3 +225,22 @@ def test_group_with_mixed_frame_types(emu_lib):
         assert bytes(got[s]) == bs
         idrs.append(bs.count(b"\x00\x00\x00\x01\x65"))
     assert idrs[1] == 1 and max(idrs) == 2        # the step with the scene change really was mixed
+
+
+def test_bench_line_from_two_ranks_on_the_cpu_test_build(emu_lib):
+    """bench.py --gpus 2 end to end without a GPU: the launcher (torch.distributed.run, one process per rank), the barriers, the
+    max-over-ranks time and the ONE JSON line of rank 0 with its roofline object -- gloo in place of RCCL and the CPU test build of the
+    kernels in place of libwelship.so (bench.py --cpu-launcher-test; the line says it is no measurement).  What the driver's 2 / 4 / 8
+    GPU runs execute, minus the device."""
+    import json
+    import subprocess
+    env = dict(os.environ, WELSHIP_LIB=emu_lib)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--sessions", "3", "--width", "176",
+                        "--height", "144", "--cpu-launcher-test"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["unit"] == "frames/s"
+    assert d["value"] > 0 and abs(d["value"] - 2 * 3 * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 1e-6        # all ranks' pictures / the slowest rank's time
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["frac"] > 0 and "not a measurement" in d["data"]

@@ -31,7 +31,12 @@ if out[46]:
           % (one, 100.0 * out[45] / (out[46] * max(out[44], 1)), out[44] / 1e5, out[46], out[45] / out[46] / 1e5))
 print(g.bench(3, 0))
 lib.WelsHipGroupProfile(g._h, 1, out)
-names = {11: "ticket+order", 12: "dependency wait", 8: "args+job+slice", 9: "batch-1 loads", 10: "nb cache+ctx", 0: "mvp+window loads", 1: "pskip test", 2: "p16x16 ME", 3: "i16 test",
+if os.environ.get("WELSHIP_PROF_DETAIL"):      # library built with -DWH_PROF_DETAIL (wave.h): sub-phases instead of the search .. store phases
+    names = {0: "claim: slots+ticket+order", 2: "claim: cold inputs issued", 11: "claim: windows issued (+body callback)", 12: "dependency wait",
+             3: "batch-1: loads issued", 9: "batch-1: wait + commit", 10: "args, nb cache, mvp+window wait", 4: "pskip: luma prediction", 5: "pskip: chroma prediction",
+             6: "pskip: SADs + decision", 1: "pskip: DCT / quant test + rest", 7: "search .. store (merged)", 13: "release+flag", 14: "(body total)", 15: "window adopted"}
+else:
+  names = {11: "ticket+order", 12: "dependency wait", 8: "args+job+slice", 9: "batch-1 loads", 10: "nb cache+ctx", 0: "mvp+window loads", 1: "pskip test", 2: "p16x16 ME", 3: "i16 test",
          4: "fine partitions", 5: "refine+chromaMC", 6: "residual", 7: "store", 13: "release+flag", 14: "(body total)", 15: "window adopted"}
 tot = sum(out[i] for i in range(16) if i not in (14,))
 for i, n in names.items():
