@@ -260,6 +260,40 @@ def e2e_leg(oh, a, local, w, h, sessions, ring, content, frames, check=False):
     return dt, nbytes, match
 
 
+def e2e_pipelined_leg(oh, a, local, w, h, sessions, ring, content, frames, check=False):
+    """The same complete EncodeFrame work as e2e_leg through WelsHipGroupEncodeFramesPipelined: one group, the call that submits step k
+    (staging copy, H2D, kernels) entropy-codes step k - 1 while the device works.  Timed from the first timed submission to the flush
+    that returns the last step's streams: `frames` steps submitted and `frames` steps finished inside the region."""
+    g = make_group(oh, a, local, w, h, "p", sessions, ring, None)
+    g.set_pipelined()
+    pics = [g.make_pictures([content.frame(s, k) for s in range(sessions)]) for k in range(ring)]
+    order = [0, 1 % ring] + [slot_of(i + 2, ring) for i in range(frames)]
+    bs0 = bytearray()
+    assert g.encode_frames_pipelined(pics[order[0]]) is None
+    bs0 += g.encode_frames_pipelined(pics[order[1]], want_bytes=True)[0]      # the IDR's streams
+    bs0 += g.encode_frames_pipelined(None, want_bytes=True)[0]                # the first P picture's: the pipeline is empty again
+    t0 = time.perf_counter()
+    nbytes = 0
+    for i in range(frames + 1):
+        out = g.encode_frames_pipelined(pics[order[i + 2]] if i < frames else None, want_bytes=check)
+        if out is None:
+            continue
+        if check:
+            bs0 += out[0]
+            nbytes += sum(len(b) for b in out)
+        else:
+            nbytes += out
+    dt = time.perf_counter() - t0
+    host = g.host_stats()
+    g.close()
+    match = None
+    if check:
+        import hashlib
+        ref = ref_encode(b"".join(content.frame(0, k) for k in order), w, h, p_flags(a.qp, a.deblock_idc) + ["-quiet", "-threads", "1"])
+        match = {"match": bytes(bs0) == ref, "sha1": hashlib.sha1(bytes(bs0)).hexdigest(), "reference_sha1": hashlib.sha1(ref).hexdigest(), "frames": len(order)}
+    return dt, nbytes, match, host
+
+
 def e2e_groups_leg(oh, a, local, w, h, groups, per_group, ring, content, frames, check=False):
     """The same complete EncodeFrame calls from `groups` independent session groups, each driven by its own host thread on its
     own device queue: while one group's records are copied back and entropy-coded on the host, the other groups' kernels and
@@ -461,6 +495,12 @@ def main():
             line["e2e_overlapped"] = {"frames_per_s": ng * per * n2 / dg, "groups": ng, "sessions_per_group": per, "frames_each": n2,
                                       "host_entropy_threads_per_group": a.host_threads, "bitstream_MB_per_s": nb2 / dg / 1e6, "bitstream_vs_reference": m2,
                                       "how": "independent session groups, one host thread + one device queue each: a group's D2H and CAVLC run under the other groups' kernels"}
+        # one group as a two-stage pipeline: the host entropy-codes step k - 1 while the device codes step k
+        n3 = 30
+        dp, nb3, m3, host3 = e2e_pipelined_leg(oh, a, local, w, h, a.sessions, ring, content, n3, bool(verify_sessions))
+        line["e2e_pipelined"] = {"frames_per_s": a.sessions * n3 / dp, "sessions": a.sessions, "frames_each": n3, "host_entropy_threads": a.host_threads,
+                                 "bitstream_MB_per_s": nb3 / dp / 1e6, "bitstream_vs_reference": m3, "host_thread_ms_per_picture": host3,
+                                 "how": "WelsHipGroupEncodeFramesPipelined: staging copy + H2D + kernels of step k queued, then D2H + CAVLC of step k - 1 under them"}
         lat = {}
         for ns in (1, 8):
             dl, _, _ = e2e_leg(oh, a, local, w, h, ns, ring, content, 20)
@@ -516,7 +556,7 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    for leg in ("e2e", "e2e_overlapped"):
+    for leg in ("e2e", "e2e_overlapped", "e2e_pipelined"):
         if line.get(leg, {}).get("bitstream_vs_reference") and not line[leg]["bitstream_vs_reference"]["match"]:
             raise SystemExit("bench.py: the %s bitstream of session 0 differs from the reference encoder's" % leg)
     if verified is not None and not all(verified.values()):

@@ -262,6 +262,8 @@ class EncoderGroup:
             lib.WelsHipGroupBench.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
             lib.WelsHipGroupEncodeFrames.argtypes = [C.c_void_p, C.POINTER(SSourcePicture), C.POINTER(SFrameBSInfo)]
             lib.WelsHipGroupHostStats.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+            lib.WelsHipGroupSetPipelined.argtypes = [C.c_void_p, C.c_int]
+            lib.WelsHipGroupEncodeFramesPipelined.argtypes = [C.c_void_p, C.POINTER(SSourcePicture), C.POINTER(SFrameBSInfo), C.POINTER(C.c_int)]
             lib._group_ready = True
         h = C.c_void_p()
         rc = lib.WelsHipGroupCreate(C.byref(h), C.byref(param), sessions, ring_slots, host_threads)
@@ -327,6 +329,33 @@ class EncoderGroup:
         rc = self._lib.WelsHipGroupEncodeFrames(self._h, pictures[0], infos)
         if rc:
             raise WelsHipError(rc, (self._lib.WelsHipGetLastError() or b"").decode())
+        if not want_bytes:
+            return sum(info.iFrameSizeInBytes for info in infos)
+        out = []
+        for info in infos:
+            b = bytearray()
+            for li in range(info.iLayerNum):
+                L = info.sLayerInfo[li]
+                b += C.string_at(L.pBsBuf, sum(L.pNalLengthInByte[k] for k in range(L.iNalCount)))
+            out.append(bytes(b))
+        return out
+
+    def set_pipelined(self):
+        """WelsHipGroupSetPipelined: encode_frames_pipelined from now on (before the first picture)."""
+        rc = self._lib.WelsHipGroupSetPipelined(self._h, 1)
+        if rc:
+            raise WelsHipError(rc, (self._lib.WelsHipGetLastError() or b"").decode())
+
+    def encode_frames_pipelined(self, pictures, want_bytes=False):
+        """WelsHipGroupEncodeFramesPipelined: submits `pictures` (None: nothing, only finish) and finishes the step submitted by the
+        previous call.  Returns None when no step was finished, else what encode_frames returns -- for that EARLIER step."""
+        infos = (SFrameBSInfo * self.n)()
+        done = C.c_int(0)
+        rc = self._lib.WelsHipGroupEncodeFramesPipelined(self._h, pictures[0] if pictures is not None else None, infos, C.byref(done))
+        if rc:
+            raise WelsHipError(rc, (self._lib.WelsHipGetLastError() or b"").decode())
+        if not done.value:
+            return None
         if not want_bytes:
             return sum(info.iFrameSizeInBytes for info in infos)
         out = []

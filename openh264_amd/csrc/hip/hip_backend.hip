@@ -805,7 +805,7 @@ class HipBackend : public wh::Backend {
     }
     const int sched_words = 1 + ((max_n + 31) >> 5);
     int nw = forced_waves > 0 ? forced_waves : 12;
-    nw = std::min (nw, 12);
+    nw = std::min (nw, 12);              // (12 x 13.4 KB of LDS per wave is the CU's 160 KB; a 1024-thread build fits 128 VGPRs without scratch but not the LDS)
     int par = std::max (1, std::min (max_rows, (P.mb_w + 1) / 2)) * slots;       // macroblocks that can be in flight at all
     if (P.flags & WH_SEQ_SERIAL) par = 2 * slots;      // one macroblock of a slice at a time; a second wave has the next one's inputs in flight
     if (P.flags & WH_SEQ_SCC) nw = std::min (nw, 6);    // the screen-content variant needs 216 VGPRs: six waves per workgroup, no scratch
@@ -906,6 +906,7 @@ class HipBackend : public wh::Backend {
     return bad;
   }
   unsigned errors_swept() const override { return swept_.load (std::memory_order_relaxed); }
+  int peek_queue_errors (int k) override { HIP_TRY (hipSetDevice (dev_)); return check_err (k < 0 ? 0 : k % WH_NUM_QUEUES, 1); }
   // queue k only: its stream, its error word (the other queues' launch sets keep running and keep their own verdicts)
   int sync_queue (int k) override {
     HIP_TRY (hipSetDevice (dev_));

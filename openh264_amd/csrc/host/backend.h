@@ -49,6 +49,9 @@ class Backend {
   // a thread that waits for its own queue outside the callers' lock compares this counter before the launch and after the wait, and
   // fails its pictures when a sync() in between found errors (it may have consumed this queue's verdict).
   virtual unsigned errors_swept() const { return 0; }
+  // the dependency-wait time-outs queue k's kernels have reported so far, WITHOUT waiting for the queue (a pipelined caller checks the
+  // launch set it is about to read results of while the next one is already running on the same queue)
+  virtual int peek_queue_errors (int k) { (void)k; return 0; }
   // timing on the stream the kernels are launched on (HIP events)
   virtual void* event_create() = 0;
   virtual void event_destroy (void* ev) = 0;

@@ -77,8 +77,11 @@ struct SessionCore {
   int ring = 1;                       // number of source slots resident in HBM
   std::vector<uint8_t*> d_src;        // [ring] source pictures, MB-aligned dims, macroblock-tiled (WH_SRC_*)
   uint8_t* d_src_planar = nullptr;    // where an upload lands (Y | U | V, tight strides) before the device rearranges it into its slot
-  DevPicture pic[2];
+  DevPicture pic[3];                  // reconstruction pictures: two (current / reference); a pipelined group adds a third (see Pending)
+  int nbuf = 2;
   int cur = 0;
+  int ref_of (int c) const { return (c + nbuf - 1) % nbuf; }
+  int next_of (int c) const { return (c + 1) % nbuf; }
   int last_slot = 0;                  // source slot of the previous frame (VAA reference)
   bool prev_src_dirty = false;        // that slot received a new upload since the frame was begun
   WhMbRecord* d_records = nullptr;
@@ -116,6 +119,25 @@ struct SessionCore {
   uint32_t h_scene = 0;
   bool scene_idr = false;             // LARGE_CHANGED_SCENE seen for the picture about to be encoded
   WhPicJob cur_job;                   // what begin_frame described (re-issued by retry_after_overflow)
+  // ---- pipelined session groups (WelsHipGroupEncodeFramesPipelined): the device codes picture k while the host entropy-codes picture
+  // k - 1.  The stream state advances when a picture is SUBMITTED; what its entropy coding needs later is kept here.  Second set of
+  // packed-record buffers and of the staging buffer (picture k's records / source are written while k - 1's are still being read), third
+  // reconstruction picture (a picture whose entropy coding hits a CAVLC overflow is coded again on the device after its successor has
+  // already been: its reference must still exist).
+  struct Pending { bool valid = false, idr = false; int frame_num = 0, buf = 0; WhPicJob job; };
+  Pending pend, fin;                  // the picture submitted last; the one being finished (a copy the next submission cannot overwrite)
+  bool pipelined = false;
+  uint8_t* d_compact1 = nullptr;
+  uint32_t* d_compact_off1 = nullptr;
+  std::vector<uint8_t> h_compact1;
+  std::vector<uint32_t> h_compact_off1;
+  std::vector<uint8_t> h_src1;
+  int pbuf = 0;                       // which set the picture being submitted uses
+  uint8_t* dcompact (int b) const { return b ? d_compact1 : d_compact; }
+  uint32_t* dcompact_off (int b) const { return b ? d_compact_off1 : d_compact_off; }
+  std::vector<uint8_t>& hcompact (int b) { return b ? h_compact1 : h_compact; }
+  std::vector<uint32_t>& hcompact_off (int b) { return b ? h_compact_off1 : h_compact_off; }
+  std::vector<uint8_t>& hsrc (int b) { return b ? h_src1 : h_src; }
 
   static int validate (const WelsHipEncParam* p) {
     // same spirit as ParamValidationExt (encoder_ext.cpp:403-680)
@@ -322,13 +344,48 @@ struct SessionCore {
     return WELSHIP_OK;
   }
 
+  // third reconstruction picture, second record / staging buffers (needs the packed records); before the first picture
+  int enable_pipeline() {
+    if (pipelined) return WELSHIP_OK;
+    if (!use_compact || frame_index != 0 || have_recon) { set_err ("pipelined groups need packed records and must be switched on before the first picture"); return WELSHIP_ERR_UNSUPPORTED; }
+    if (prm.bEnableSceneChangeDetect) { set_err ("pipelined groups: scene-change detection reads a device statistic back before every picture"); return WELSHIP_ERR_UNSUPPORTED; }
+    const size_t rec_y = (size_t)seq.rec_stride_y * (mb_h * 16 + 64), rec_c = (size_t)seq.rec_stride_c * ((mb_h * 16 + 64) / 2);
+    DevPicture& d = pic[2];
+    d.base = (uint8_t*)be->alloc (DevPicture::alloc_bytes (rec_alloc_bytes + 128));
+    d.mbs = (WhMbState*)be->alloc (sizeof (WhMbState) * num_mb);
+    d_compact1 = (uint8_t*)be->alloc ((size_t)num_mb * WH_COMPACT_MAX_BYTES);
+    d_compact_off1 = (uint32_t*)be->alloc (sizeof (uint32_t) * ((size_t)num_mb + 1));
+    if (!d.base || !d.mbs || !d_compact1 || !d_compact_off1) { set_err ("out of device memory"); return WELSHIP_ERR_MEMORY; }
+    be->fill (d.base, 0, DevPicture::alloc_bytes (rec_alloc_bytes + 128));
+    d.place_tiles (rec_alloc_bytes + 128, rec_y);
+    d.plane[0] = d.base + 64 + (size_t)32 * seq.rec_stride_y + 32;
+    d.plane[1] = d.base + 64 + rec_y + (size_t)16 * seq.rec_stride_c + 16;
+    d.plane[2] = d.base + 64 + rec_y + rec_c + (size_t)16 * seq.rec_stride_c + 16;
+    be->fill (d.mbs, 0, sizeof (WhMbState) * num_mb);
+    h_compact1.resize ((size_t)num_mb * WH_COMPACT_MAX_BYTES);
+    h_compact_off1.resize ((size_t)num_mb + 1);
+    be->pin_host (h_compact1.data(), h_compact1.size());
+    be->pin_host (h_compact_off1.data(), sizeof (uint32_t) * h_compact_off1.size());
+    h_src1 = h_src;                     // (keeps the padding values of the MB-alignment area)
+    be->pin_host (h_src1.data(), src_bytes);
+    nbuf = 3;
+    pipelined = true;
+    return WELSHIP_OK;
+  }
+
   void release() {
     if (!be) return;
+    if (pipelined) {
+      be->unpin_host (h_compact1.data()); be->unpin_host (h_compact_off1.data()); be->unpin_host (h_src1.data());
+      if (d_compact1) be->free (d_compact1);
+      if (d_compact_off1) be->free (d_compact_off1);
+      d_compact1 = nullptr; d_compact_off1 = nullptr; pipelined = false; nbuf = 2;
+    }
     for (uint8_t* p : d_src) if (p) be->free (p);
     d_src.clear();
     if (d_src_planar) be->free (d_src_planar);
     d_src_planar = nullptr;
-    for (int i = 0; i < 2; ++i) { if (pic[i].base) be->free (pic[i].base); if (pic[i].mbs) be->free (pic[i].mbs); pic[i] = DevPicture(); }
+    for (int i = 0; i < 3; ++i) { if (pic[i].base) be->free (pic[i].base); if (pic[i].mbs) be->free (pic[i].mbs); pic[i] = DevPicture(); }
     if (d_records) be->free (d_records);
     d_records = nullptr;
     if (d_compact) be->free (d_compact);
@@ -356,10 +413,10 @@ struct SessionCore {
   // without waiting for any of them: stage_source touches only this session's page-locked staging buffer, issue_upload
   // only queues the DMA (the kernels that read the picture are behind it on the same queue).
   bool upload_pending = false;        // the staging buffer may still be read by a queued transfer
-  void stage_source (const WelsHipSourcePicture* src) {
+  void stage_source (const WelsHipSourcePicture* src, int buf = 0) {
     const WhSeqParams& s = seq;
     const int w = prm.iPicWidth & ~1, h = prm.iPicHeight & ~1;
-    uint8_t* y = h_src.data();
+    uint8_t* y = hsrc (buf).data();
     uint8_t* u = y + ysz;
     uint8_t* v = u + csz;
     for (int r = 0; r < h; ++r) memcpy (y + (size_t)r * s.src_stride_y, src->pData[0] + (size_t)r * src->iStride[0], w);
@@ -368,9 +425,9 @@ struct SessionCore {
       memcpy (v + (size_t)r * s.src_stride_c, src->pData[2] + (size_t)r * src->iStride[2], w / 2);
     }
   }
-  void issue_upload (int slot) {
+  void issue_upload (int slot, int buf = 0) {
     if (slot == last_slot) prev_src_dirty = true;
-    be->upload (d_src_planar, h_src.data(), src_bytes);        // (same queue: the next upload waits for this pass)
+    be->upload (d_src_planar, hsrc (buf).data(), src_bytes);   // (same queue: the next upload waits for this pass)
     be->run_src_tile (seq, d_src_planar, d_src[slot]);
     upload_pending = true;
   }
@@ -421,14 +478,14 @@ struct SessionCore {
     if (idr) { frame_index = 0; frame_num = 0; force_idr = false; }
     cur_idr = idr;
     DevPicture& c = pic[cur];
-    DevPicture& r = pic[cur ^ 1];
+    DevPicture& r = pic[ref_of (cur)];
     memset (job, 0, sizeof (*job));
     job->src[0] = job->src[1] = job->src[2] = d_src[slot];
     for (int i = 0; i < 3; ++i) { job->rec[i] = c.plane[i]; job->ref[i] = idr ? nullptr : r.plane[i]; }
     for (int i = 0; i < 2; ++i) { job->rec_tiles[i] = c.tiles[i]; job->ref_tiles[i] = idr ? nullptr : r.tiles[i]; }
     job->records = d_records;
-    job->compact = use_compact ? d_compact : nullptr;
-    job->compact_off = use_compact ? d_compact_off : nullptr;
+    job->compact = use_compact ? dcompact (pbuf) : nullptr;
+    job->compact_off = use_compact ? dcompact_off (pbuf) : nullptr;
     job->mbs = c.mbs;
     job->ref_mbs = idr ? nullptr : r.mbs;
     job->qp = prm.iDLayerQp;
@@ -479,13 +536,36 @@ struct SessionCore {
   // `packed`: the picture's records are the packed stream in h_compact / h_compact_off (a session group's copy): the writer
   // reads them in place (entropy_cavlc.h MbView); otherwise the full records in h_records.
   int finish_frame (WelsHipFrameBSInfo* out, int64_t ts, bool packed = false) {
+    pic[cur].is_p = !cur_idr;
+    have_recon = true;
+    const int rc = entropy_frame (out, ts, packed, cur_idr, frame_num, h_compact.data(), h_compact_off.data());
+    if (rc) return rc;
+    ++frame_index;
+    frame_num = (frame_num + 1) & 0x7fff;
+    cur = next_of (cur);
+    return WELSHIP_OK;
+  }
+  // Pipelined groups: the picture has been handed to the device; the stream state moves on at once (the next picture is begun while
+  // this one is still being coded), what the entropy coder will need is kept in `pend`.
+  void submit_advance() {
+    pend.valid = true; pend.idr = cur_idr; pend.frame_num = frame_num; pend.buf = pbuf; pend.job = cur_job;
+    pic[cur].is_p = !cur_idr;
+    have_recon = true;
+    ++frame_index;
+    frame_num = (frame_num + 1) & 0x7fff;
+    cur = next_of (cur);
+    pbuf ^= 1;
+  }
+  int finish_pending (WelsHipFrameBSInfo* out) {
+    return entropy_frame (out, 0, true, fin.idr, fin.frame_num, hcompact (fin.buf).data(), hcompact_off (fin.buf).data());
+  }
+  // Entropy-code one picture: `idr` / `frame_num_` of that picture, its packed records in hc / hoff (or the full records in h_records).
+  // Changes nothing of the stream state but the parameter-set ids of an IDR picture (restored on failure).
+  int entropy_frame (WelsHipFrameBSInfo* out, int64_t ts, bool packed, bool idr, int frame_num_, const uint8_t* hc, const uint32_t* hoff) {
     const WhSeqParams& s = seq;
-    const bool idr = cur_idr;
     const int qp = prm.iDLayerQp;
     const int saved_ids[5] = {sps_counter, pps_counter, sps_id_in_bs, pps_id_in_bs, idr_pic_id};
     overflow_mb = -1;
-    pic[cur].is_p = !idr;
-    have_recon = true;
     bs.clear();
     nal_len.clear();
     std::vector<long> nal_rbsp_len;
@@ -545,7 +625,7 @@ struct SessionCore {
       sh.first_mb = s.slice_first_mb[si];
       sh.slice_type = idr ? 2 : 0;
       sh.pps_id = pps_id_in_bs;
-      sh.frame_num = frame_num;
+      sh.frame_num = frame_num_;
       sh.idr = idr;
       sh.idr_pic_id = idr_pic_id;
       sh.nal_ref_idc = 3;
@@ -563,7 +643,7 @@ struct SessionCore {
         if (mbx > 0 && xy - 1 >= s.slice_first_mb[si]) avail |= wh::WH_AVAIL_LEFT;
         if (mby > 0 && xy - mb_w >= s.slice_first_mb[si]) avail |= wh::WH_AVAIL_TOP;
         int dbqp = qp;
-        const wh::MbView mb = packed ? wh::view_of_packed (h_compact.data(), h_compact_off.data(), mb_w, xy, avail) : wh::view_of_record (h_records.data(), mb_w, xy, avail);
+        const wh::MbView mb = packed ? wh::view_of_packed (hc, hoff, mb_w, xy, avail) : wh::view_of_record (h_records.data(), mb_w, xy, avail);
         const int rc = wh::write_mb_cavlc (bw, st, mb, &dbqp);
         const bool coded = mb.side->mb_type != WH_MB_PSKIP;
         const bool no_room = coded && bs_capacity - (frame_pos + 4 * (long) (bw.bits() / 32)) - 1 < 800;
@@ -571,7 +651,7 @@ struct SessionCore {
           sps_counter = saved_ids[0]; pps_counter = saved_ids[1]; sps_id_in_bs = saved_ids[2]; pps_id_in_bs = saved_ids[3]; idr_pic_id = saved_ids[4];
           overflow_mb = xy;
           overflow_qp = dbqp;
-          if (packed) wh_compact_expand (h_compact.data() + h_compact_off[xy], h_compact_off[xy + 1] - h_compact_off[xy], &h_records[xy]);   // retry_after_overflow reads it
+          if (packed) wh_compact_expand (hc + hoff[xy], hoff[xy + 1] - hoff[xy], &h_records[xy]);   // retry_after_overflow reads it
           set_err ("CAVLC overflow");
           return WELSHIP_ERR_VLC_OVERFLOW;
         }
@@ -603,9 +683,6 @@ struct SessionCore {
       out->iFrameSizeInBytes = (int32_t)bs.size();
       out->uiTimeStamp = ts;
     }
-    ++frame_index;
-    frame_num = (frame_num + 1) & 0x7fff;
-    cur ^= 1;
     return WELSHIP_OK;
   }
 
@@ -645,7 +722,7 @@ struct SessionCore {
     if (bytes < (size_t)w * h * 3 / 2) return WELSHIP_ERR_INIT_PARA;
     const WhSeqParams& s = seq;
     std::vector<uint8_t> tmp (rec_alloc_bytes + 128);
-    const DevPicture& p = pic[cur ^ 1];     // the picture encoded last
+    const DevPicture& p = pic[ref_of (cur)];     // the picture encoded last
     be->download (tmp.data(), p.base, rec_alloc_bytes + 128);
     be->sync();
     const uint8_t* y = tmp.data() + (p.plane[0] - p.base);
@@ -712,6 +789,15 @@ struct WelsHipEncoderGroup {
   WhPicJob* d_jobs = nullptr;
   std::vector<WhPicJob> h_jobs;
   int host_threads = 1;
+  // pipelined mode (WelsHipGroupSetPipelined / WelsHipGroupEncodeFramesPipelined): second job array (the device may still read step
+  // k - 1's descriptors when step k's are uploaded), page-locked host copies, one spare descriptor for re-runs
+  bool pipelined = false;
+  WhPicJob* d_jobs1 = nullptr;
+  WhPicJob* d_job_aux = nullptr;
+  std::vector<WhPicJob> h_jobs_p[2];
+  long step_no = 0;
+  bool pending = false;               // a submitted step whose pictures have not been entropy-coded yet
+  int pending_slot = 0;
   // thread time the host side of the frame steps has taken so far (WelsHipGroupHostStats): [0] staging copies, [1] entropy coding
   std::mutex stat_mu;
   double host_ms[2] = {0.0, 0.0};
@@ -939,6 +1025,11 @@ void WelsHipGroupDestroy (WelsHipEncoderGroup* g) {
   if (!g) return;
   g->be->sync();
   for (auto& s : g->sess) s->release();
+  if (g->pipelined) {
+    for (int b = 0; b < 2; ++b) if (!g->h_jobs_p[b].empty()) g->be->unpin_host (g->h_jobs_p[b].data());
+    if (g->d_jobs1) g->be->free (g->d_jobs1);
+    if (g->d_job_aux) g->be->free (g->d_job_aux);
+  }
   g->be->free (g->d_jobs);
   delete g->be;
   delete g;
@@ -1068,6 +1159,7 @@ int WelsHipGroupFinish (WelsHipEncoderGroup* g, WelsHipFrameBSInfo* outs) {
 
 int WelsHipGroupEncodeFrames (WelsHipEncoderGroup* g, const WelsHipSourcePicture* srcs, WelsHipFrameBSInfo* outs) {
   if (!g || !srcs) return WELSHIP_ERR_INIT_PARA;
+  if (g->pending) { set_err ("a pipelined step is pending: finish it first (WelsHipGroupEncodeFramesPipelined with no pictures)"); return WELSHIP_ERR_INIT_PARA; }
   const int n = (int)g->sess.size();
   const int slot = (g->sess[0]->last_slot + 1) % g->sess[0]->ring;    // never the slot of the previous picture
   for (int i = 0; i < n; ++i) {
@@ -1091,6 +1183,158 @@ int WelsHipGroupEncodeFrames (WelsHipEncoderGroup* g, const WelsHipSourcePicture
   return WelsHipGroupFinish (g, outs);
 }
 
+// ---- pipelined frame steps: the device codes step k while the host entropy-codes step k - 1 --------------------------------------
+// WelsHipGroupEncodeFrames is a chain per step: staging copy -> H2D -> kernels -> D2H -> CAVLC, each waiting for the one before; the
+// device idles during the transfers and the host work, the host during the kernels (profiles/r03_e2e_copy_kernel_overlap.txt: copies
+// and kernels never overlap).  Here a call SUBMITS step k -- staging, H2D on an upload queue, kernels on the compute queue behind it --
+// and then FINISHES step k - 1 while the device works: D2H of its packed records on a third queue, entropy coding on the host threads.
+// The stream state of every session advances at submission (SessionCore::submit_advance); a picture's bitstream comes back one call
+// late.  Second buffer sets keep step k's data apart from step k - 1's (records, staging, job descriptors), and every session has a
+// third reconstruction picture: when the entropy coder finds a CAVLC overflow in step k - 1 (TRY_REENCODING, rare), that picture is
+// coded again on the device (its reference, step k - 2, still exists) and then its already submitted successor once more.
+// Queues: 0 = kernels, WH_PIPE_UPQ = uploads, WH_PIPE_DLQ = downloads.
+#define WH_PIPE_UPQ 30
+#define WH_PIPE_DLQ 31
+int WelsHipGroupSetPipelined (WelsHipEncoderGroup* g, int on) {
+  if (!g) return WELSHIP_ERR_INIT_PARA;
+  if (!on) { if (g->pending) { set_err ("a submitted step is still pending: flush first"); return WELSHIP_ERR_INIT_PARA; } return WELSHIP_OK; }
+  if (g->pipelined) return WELSHIP_OK;
+  if (g->queues != 1) { set_err ("pipelined groups use one compute queue (WELSHIP_QUEUES=1)"); return WELSHIP_ERR_UNSUPPORTED; }
+  const int n = (int)g->sess.size();
+  for (auto& c : g->sess) { const int rc = c->enable_pipeline(); if (rc) return rc; }
+  g->d_jobs1 = (WhPicJob*)g->be->alloc (sizeof (WhPicJob) * n);
+  g->d_job_aux = (WhPicJob*)g->be->alloc (sizeof (WhPicJob));
+  if (!g->d_jobs1 || !g->d_job_aux) { set_err ("out of device memory"); return WELSHIP_ERR_MEMORY; }
+  for (int b = 0; b < 2; ++b) { g->h_jobs_p[b].assign (n, WhPicJob()); g->be->pin_host (g->h_jobs_p[b].data(), sizeof (WhPicJob) * n); }
+  if (g->be->sync()) { set_err ("device error while setting up the pipelined group"); return WELSHIP_ERR_UNKNOWN; }
+  g->pipelined = true;
+  return WELSHIP_OK;
+}
+
+// srcs != NULL: submit a step with these source pictures.  Then, if a step was pending before this call, finish it: its bitstreams go
+// to outs[] and *pFinished = 1.  srcs == NULL: only finish what is pending (the end of the streams).
+int WelsHipGroupEncodeFramesPipelined (WelsHipEncoderGroup* g, const WelsHipSourcePicture* srcs, WelsHipFrameBSInfo* outs, int* pFinished) {
+  if (!g || !g->pipelined) { set_err ("not a pipelined group (WelsHipGroupSetPipelined)"); return WELSHIP_ERR_INIT_PARA; }
+  if (pFinished) *pFinished = 0;
+  wh::Backend* be = g->be;
+  const int n = (int)g->sess.size();
+  SessionCore& c0 = *g->sess[0];
+  const bool had_pending = g->pending;
+  bool submitted = false;
+  if (had_pending) for (auto& c : g->sess) c->fin = c->pend;
+  if (srcs) {
+    const int slot = (c0.last_slot + 1) % c0.ring;
+    const int sb = (int) (g->step_no & 1);
+    for (int i = 0; i < n; ++i) if (srcs[i].iPicWidth != g->sess[i]->prm.iPicWidth || srcs[i].iPicHeight != g->sess[i]->prm.iPicHeight) return WELSHIP_ERR_INIT_PARA;
+    if (be->sync_queue (WH_PIPE_UPQ)) { set_err ("device error on the upload queue"); return WELSHIP_ERR_UNKNOWN; }     // staging set sb is free again (step k - 2's transfers)
+    g->parallel (n, [&] (int t, int T) {
+      const auto t0 = std::chrono::steady_clock::now();
+      int k = 0;
+      for (int i = t; i < n; i += T, ++k) g->sess[i]->stage_source (&srcs[i], sb);
+      g->note_host_time (0, std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now() - t0).count(), k);
+    });
+    be->select_queue (WH_PIPE_UPQ);
+    // the slot written now: with two slots it is the one the kernels still running (step k - 1) read as "previous source picture" (LOW_COMPLEXITY)
+    if (c0.ring < 3 && c0.seq.complexity == 0) be->queue_wait (0);
+    for (int i = 0; i < n; ++i) { g->sess[i]->issue_upload (slot % g->sess[i]->ring, sb); g->sess[i]->upload_pending = false; }
+    // describe the pictures (P pictures first, then IDR pictures, as WelsHipGroupBegin orders them)
+    std::vector<WhPicJob> jobs (n);
+    for (int i = 0; i < n; ++i) { const int rc = g->sess[i]->begin_frame_check(); if (rc) return rc; }
+    for (int i = 0; i < n; ++i) { const int rc = g->sess[i]->begin_frame (slot % g->sess[i]->ring, &jobs[i]); if (rc) return rc; }
+    g->order.resize (n);
+    int k = 0;
+    for (int i = 0; i < n; ++i) if (!g->sess[i]->cur_idr) g->order[k++] = i;
+    const int np = k;
+    for (int i = 0; i < n; ++i) if (g->sess[i]->cur_idr) g->order[k++] = i;
+    std::vector<WhPicJob>& hj = g->h_jobs_p[sb];
+    for (int j = 0; j < n; ++j) hj[j] = jobs[g->order[j]];
+    WhPicJob* dj = sb ? g->d_jobs1 : g->d_jobs;
+    be->select_queue (0);
+    be->queue_wait (WH_PIPE_UPQ);                       // the kernels wait (on the device) for this step's sources
+    be->upload (dj, hj.data(), sizeof (WhPicJob) * n);
+    const WhSeqParams& s = c0.seq;
+    if (np) be->run_inter (s, dj, np);
+    if (n - np) be->run_intra (s, dj + np, n - np);
+    be->run_compact (s, dj, n);
+    if (s.deblock_idc != 1) be->run_deblock (s, dj, n);
+    if (c0.prm.uiIntraPeriod != 1) be->run_expand (s, dj, n);
+    for (auto& c : g->sess) c->submit_advance();
+    ++g->step_no;
+    submitted = true;
+  }
+  // ---- finish the step that was pending before this call ----
+  if (had_pending) {
+    be->select_queue (WH_PIPE_DLQ);        // (waits, on the device, for that step's kernels: queue_wait at its submission)
+    for (int i = 0; i < n; ++i) {
+      SessionCore& c = *g->sess[i];
+      be->download (c.hcompact_off (c.fin.buf).data(), c.dcompact_off (c.fin.buf), sizeof (uint32_t) * ((size_t)c.num_mb + 1));
+    }
+    if (be->sync_queue (WH_PIPE_DLQ) || be->peek_queue_errors (0)) { set_err ("device scheduler timed out; the step was not encoded"); return WELSHIP_ERR_UNKNOWN; }
+    for (int i = 0; i < n; ++i) {
+      SessionCore& c = *g->sess[i];
+      const size_t bytes = c.hcompact_off (c.fin.buf)[c.num_mb];
+      if (bytes > c.hcompact (c.fin.buf).size()) { set_err ("corrupt record offsets"); return WELSHIP_ERR_UNKNOWN; }
+      be->download (c.hcompact (c.fin.buf).data(), c.dcompact (c.fin.buf), bytes);
+      g->packed_bytes += (double)bytes;
+    }
+    if (be->sync_queue (WH_PIPE_DLQ)) { set_err ("device error while copying the records"); return WELSHIP_ERR_UNKNOWN; }
+    std::vector<int> rcs (n, 0);
+    g->parallel (n, [&] (int t, int T) {
+      const auto t0 = std::chrono::steady_clock::now();
+      int k = 0;
+      for (int i = t; i < n; i += T, ++k) rcs[i] = g->sess[i]->finish_pending (outs ? &outs[i] : nullptr);
+      g->note_host_time (1, std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now() - t0).count(), k);
+    });
+    // CAVLC overflow (rare): that picture again with the macroblock's QP raised, then the picture submitted after it -- it predicted from
+    // the reconstruction that has just been replaced.  Everything the device has queued is waited for first.
+    for (int i = 0; i < n; ++i) {
+      if (rcs[i] != WELSHIP_ERR_VLC_OVERFLOW) continue;
+      SessionCore& c = *g->sess[i];
+      if (be->sync()) { set_err ("device scheduler timed out"); return WELSHIP_ERR_UNKNOWN; }
+      be->select_queue (0);
+      const bool need_ref = c.prm.uiIntraPeriod != 1;
+      while (rcs[i] == WELSHIP_ERR_VLC_OVERFLOW) {
+        WhPicJob job;
+        std::swap (c.cur_job, c.fin.job);                 // retry_after_overflow edits "the picture being coded"
+        rcs[i] = c.retry_after_overflow (&job);
+        std::swap (c.cur_job, c.fin.job);
+        if (rcs[i]) break;
+        be->upload (g->d_job_aux, &job, sizeof (job));
+        run_device_step (be, c.seq, g->d_job_aux, 1, c.fin.idr, need_ref, true);
+        be->download (c.h_records.data(), c.d_records, sizeof (WhMbRecord) * c.num_mb);
+        if (be->sync()) { set_err ("device scheduler timed out; the picture was not encoded"); rcs[i] = WELSHIP_ERR_UNKNOWN; break; }
+        rcs[i] = c.entropy_frame (outs ? &outs[i] : nullptr, 0, false, c.fin.idr, c.fin.frame_num, nullptr, nullptr);
+      }
+      memset (c.h_mb_ctl.data(), 0, sizeof (WhMbCtl) * c.h_mb_ctl.size());   // the QP map belonged to that picture only
+      c.qp_map_in_use = false;
+      if (rcs[i] == WELSHIP_OK && submitted) {
+        if (++c.db_gen == 0) c.db_gen = 1;
+        c.cur_job.db_gen = c.db_gen;
+        c.pend.job = c.cur_job;
+        be->upload (g->d_job_aux, &c.cur_job, sizeof (WhPicJob));
+        if (c.cur_idr) be->run_intra (c.seq, g->d_job_aux, 1); else be->run_inter (c.seq, g->d_job_aux, 1);
+        be->run_compact (c.seq, g->d_job_aux, 1);
+        if (c.seq.deblock_idc != 1) be->run_deblock (c.seq, g->d_job_aux, 1);
+        if (need_ref) be->run_expand (c.seq, g->d_job_aux, 1);
+        if (be->sync()) { set_err ("device scheduler timed out; the picture was not encoded"); rcs[i] = WELSHIP_ERR_UNKNOWN; }
+      }
+    }
+    for (int i = 0; i < n; ++i) if (rcs[i]) {
+      set_err ("session " + std::to_string (i) + (rcs[i] == WELSHIP_ERR_MEMORY ? ": frame does not fit the reference encoder's bitstream buffer (cmMallocMemeError)"
+                                                                               : ": entropy coding of the frame failed"));
+      return rcs[i];
+    }
+    if (pFinished) *pFinished = 1;
+  }
+  g->pending = submitted;
+  if (submitted) {                 // the download queue will wait for this step's kernels
+    be->select_queue (WH_PIPE_DLQ);
+    be->queue_wait (0);
+    be->select_queue (0);
+  }
+  return WELSHIP_OK;
+}
+
 int WelsHipGroupGetReconFrame (WelsHipEncoderGroup* g, int session, uint8_t* dst, size_t bytes) {
   if (!g || session < 0 || session >= (int)g->sess.size()) return WELSHIP_ERR_INIT_PARA;
   return g->sess[session]->copy_recon (dst, bytes);
@@ -1106,7 +1350,7 @@ int WelsHipGroupStepDeviceOnly (WelsHipEncoderGroup* g, int slot) {
   WelsHipGroupRunDevice (g, 0);
   for (auto& s : g->sess) {
     s->pic[s->cur].is_p = !s->cur_idr; s->have_recon = true;
-    ++s->frame_index; s->frame_num = (s->frame_num + 1) & 0x7fff; s->cur ^= 1;
+    ++s->frame_index; s->frame_num = (s->frame_num + 1) & 0x7fff; s->cur = s->next_of (s->cur);
   }
   return WELSHIP_OK;
 }
@@ -1144,7 +1388,7 @@ int WelsHipGroupBench (WelsHipEncoderGroup* g, int steps, int warmup, double* ou
       if (need_ref) be->run_expand (s, g->d_jobs + a, cnt);
       if (q == 0) be->event_record (ev[i * 4 + 3]);
     }
-    for (auto& c : g->sess) { c->pic[c->cur].is_p = !c->cur_idr; c->have_recon = true; ++c->frame_index; c->frame_num = (c->frame_num + 1) & 0x7fff; c->cur ^= 1; }
+    for (auto& c : g->sess) { c->pic[c->cur].is_p = !c->cur_idr; c->have_recon = true; ++c->frame_index; c->frame_num = (c->frame_num + 1) & 0x7fff; c->cur = c->next_of (c->cur); }
   }
   be->select_queue (0);
   be->event_record (ev[(size_t)steps * 4]);

@@ -244,3 +244,83 @@ def test_bench_line_from_two_ranks_on_the_cpu_test_build(emu_lib):
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["unit"] == "frames/s"
     assert d["value"] > 0 and abs(d["value"] - 2 * 3 * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 1e-6        # all ranks' pictures / the slowest rank's time
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["frac"] > 0 and "not a measurement" in d["data"]
+
+
+# ---- pipelined groups: WelsHipGroupEncodeFramesPipelined returns step k - 1's streams while the device codes step k -------------
+def _pipelined_vs_synchronous(lib, w, h, frames, qp, contents, ring, intra_period=0, threads=2):
+    import openh264_amd as oh
+    from openh264_amd.utils.synth import make_sequence
+    fsz = w * h * 3 // 2
+    seqs = [make_sequence(c, w, h, frames) for c in contents]
+    e = oh.Encoder(lib)
+    p = e.GetDefaultParams()
+    e.close()
+    p.iPicWidth, p.iPicHeight, p.iDLayerQp, p.uiIntraPeriod, p.fMaxFrameRate, p.iTargetBitrate = w, h, qp, intra_period, 30.0, 5000000
+    p.bEnableSceneChangeDetect = False
+    out = {}
+    for mode in ("sync", "pipe"):
+        g = oh.EncoderGroup(p, len(seqs), ring_slots=ring, host_threads=threads, lib_path=lib)
+        if mode == "pipe":
+            g.set_pipelined()
+        got = [bytearray() for _ in seqs]
+        steps = 0
+        for f in range(frames):
+            pics = g.make_pictures([s[f * fsz:(f + 1) * fsz] for s in seqs])
+            res = g.encode_frames(pics, want_bytes=True) if mode == "sync" else g.encode_frames_pipelined(pics, want_bytes=True)
+            if mode == "pipe":
+                assert (res is None) == (f == 0)          # one call late
+            if res is not None:
+                steps += 1
+                for s, bs in enumerate(res):
+                    got[s] += bs
+        if mode == "pipe":
+            res = g.encode_frames_pipelined(None, want_bytes=True)
+            steps += 1
+            for s, bs in enumerate(res):
+                got[s] += bs
+            assert g.encode_frames_pipelined(None) is None    # nothing pending any more
+        assert steps == frames
+        out[mode] = ([bytes(b) for b in got], g.recon(0))
+        g.close()
+    assert out["pipe"][0] == out["sync"][0]
+    assert out["pipe"][1] == out["sync"][1]
+    return seqs, out["pipe"][0]
+
+
+@pytest.mark.parametrize("ring", [2, 3])
+def test_pipelined_group_matches_the_synchronous_one(emu_lib, ring):
+    _pipelined_vs_synchronous(emu_lib, 64, 48, 6, 26, ("synth", "checker5", "synth"), ring, intra_period=4)
+
+
+def test_pipelined_group_reencodes_after_cavlc_overflow(emu_lib):
+    """QP 3 on checkerboards: pictures in the middle and at the end of the stream overflow the CAVLC level range, when their successor
+    is already on the device: the picture is coded again, then the successor (it predicted from the replaced reconstruction)."""
+    import openh264_amd as oh
+    seqs, got = _pipelined_vs_synchronous(emu_lib, 64, 64, 4, 3, ("synth", "checker5", "synth", "checker8"), 3)
+    for s in (1, 3):
+        st = {}
+        bs, _ = oh.encode_sequence(seqs[s], 64, 64, lib_path=emu_lib, stats=st, iDLayerQp=3, uiIntraPeriod=0, fMaxFrameRate=30.0, iTargetBitrate=5000000)
+        assert st["overflow_reencodes"] > 0 and bs == got[s]
+
+
+def test_pipelined_group_refuses_what_it_cannot_do(emu_lib):
+    import openh264_amd as oh
+    e = oh.Encoder(emu_lib)
+    p = e.GetDefaultParams()
+    e.close()
+    p.iPicWidth, p.iPicHeight, p.iDLayerQp, p.fMaxFrameRate, p.iTargetBitrate = 64, 48, 26, 30.0, 500000
+    p.bEnableSceneChangeDetect = True
+    g = oh.EncoderGroup(p, 2, ring_slots=3, host_threads=1, lib_path=emu_lib)
+    with pytest.raises(oh.WelsHipError):
+        g.set_pipelined()
+    g.close()
+
+
+@pytest.mark.gpu
+def test_hip_pipelined_group_matches_the_synchronous_one(hip_lib):
+    _pipelined_vs_synchronous(hip_lib, 320, 192, 8, 26, ("synth", "checker5", "synth", "pan7"), 3, intra_period=5, threads=4)
+
+
+@pytest.mark.gpu
+def test_hip_pipelined_group_reencodes_after_cavlc_overflow(hip_lib):
+    _pipelined_vs_synchronous(hip_lib, 64, 64, 4, 3, ("synth", "checker5", "synth", "checker8"), 3)
