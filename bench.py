@@ -262,8 +262,9 @@ def e2e_leg(oh, a, local, w, h, sessions, ring, content, frames, check=False):
 
 def e2e_pipelined_leg(oh, a, local, w, h, sessions, ring, content, frames, check=False):
     """The same complete EncodeFrame work as e2e_leg through WelsHipGroupEncodeFramesPipelined: one group, the call that submits step k
-    (staging copy, H2D, kernels) entropy-codes step k - 1 while the device works.  Timed from the first timed submission to the flush
-    that returns the last step's streams: `frames` steps submitted and `frames` steps finished inside the region."""
+    (staging copy, H2D, kernels) entropy-codes step k - 1 meanwhile.  Timed from the first timed submission to the flush that returns
+    the last step's streams: `frames` steps submitted and `frames` steps finished inside the region.  Also returns the rate over the
+    second half of the region (the first P pictures after the IDR carry more residual than the later ones)."""
     g = make_group(oh, a, local, w, h, "p", sessions, ring, None)
     g.set_pipelined()
     pics = [g.make_pictures([content.frame(s, k) for s in range(sessions)]) for k in range(ring)]
@@ -274,8 +275,10 @@ def e2e_pipelined_leg(oh, a, local, w, h, sessions, ring, content, frames, check
     bs0 += g.encode_frames_pipelined(None, want_bytes=True)[0]                # the first P picture's: the pipeline is empty again
     t0 = time.perf_counter()
     nbytes = 0
+    stamps = []
     for i in range(frames + 1):
         out = g.encode_frames_pipelined(pics[order[i + 2]] if i < frames else None, want_bytes=check)
+        stamps.append(time.perf_counter())
         if out is None:
             continue
         if check:
@@ -284,6 +287,8 @@ def e2e_pipelined_leg(oh, a, local, w, h, sessions, ring, content, frames, check
         else:
             nbytes += out
     dt = time.perf_counter() - t0
+    half = frames // 2
+    steady = sessions * (frames - half) / (stamps[frames] - stamps[half]) if frames >= 4 else None      # steps half+1 .. frames finished in that time
     host = g.host_stats()
     g.close()
     match = None
@@ -291,6 +296,7 @@ def e2e_pipelined_leg(oh, a, local, w, h, sessions, ring, content, frames, check
         import hashlib
         ref = ref_encode(b"".join(content.frame(0, k) for k in order), w, h, p_flags(a.qp, a.deblock_idc) + ["-quiet", "-threads", "1"])
         match = {"match": bytes(bs0) == ref, "sha1": hashlib.sha1(bytes(bs0)).hexdigest(), "reference_sha1": hashlib.sha1(ref).hexdigest(), "frames": len(order)}
+    e2e_pipelined_leg.steady = steady
     return dt, nbytes, match, host
 
 
@@ -496,9 +502,10 @@ def main():
                                       "host_entropy_threads_per_group": a.host_threads, "bitstream_MB_per_s": nb2 / dg / 1e6, "bitstream_vs_reference": m2,
                                       "how": "independent session groups, one host thread + one device queue each: a group's D2H and CAVLC run under the other groups' kernels"}
         # one group as a two-stage pipeline: the host entropy-codes step k - 1 while the device codes step k
-        n3 = 30
+        n3 = 60
         dp, nb3, m3, host3 = e2e_pipelined_leg(oh, a, local, w, h, a.sessions, ring, content, n3, bool(verify_sessions))
-        line["e2e_pipelined"] = {"frames_per_s": a.sessions * n3 / dp, "sessions": a.sessions, "frames_each": n3, "host_entropy_threads": a.host_threads,
+        line["e2e_pipelined"] = {"frames_per_s": a.sessions * n3 / dp, "frames_per_s_second_half": e2e_pipelined_leg.steady,
+                                 "sessions": a.sessions, "frames_each": n3, "host_entropy_threads": a.host_threads,
                                  "bitstream_MB_per_s": nb3 / dp / 1e6, "bitstream_vs_reference": m3, "host_thread_ms_per_picture": host3,
                                  "how": "WelsHipGroupEncodeFramesPipelined: staging copy + H2D + kernels of step k queued, then D2H + CAVLC of step k - 1 under them"}
         lat = {}

@@ -141,7 +141,7 @@ typedef struct WhGomRc {
 
 // ---- one picture being encoded (one frame of one session) ---------------------------------------
 typedef struct WhPicJob {
-  const uint8_t* src[3];     // source picture, dims = mb_w*16 x mb_h*16 (host pads): src[0] = the macroblock-tiled picture (WH_SRC_*), [1], [2] unused
+  const uint8_t* src[3];     // source picture, dims = mb_w*16 x mb_h*16 (host pads): src[0] = the macroblock-tiled picture (WH_SRC_*); [1] = NULL or the planar picture as uploaded, for run_src_tile_jobs; [2] unused
   uint8_t*       rec[3];     // reconstructed planes (point at pixel (0,0) inside the padded alloc)
   const uint8_t* ref[3];     // reference planes (border-expanded) or NULL for I pictures
   WhMbRecord*    records;    // mb_w*mb_h

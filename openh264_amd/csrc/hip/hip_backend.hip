@@ -659,6 +659,12 @@ __global__ __launch_bounds__ (256) void k_src_tile (WhSeqParams P, const uint8_t
   if (idx < wh_src_tile_items (P)) wh_src_tile_item (P, (const WH_G uint8_t*)planar, (WH_G uint8_t*)tiled, idx);
 }
 
+__global__ __launch_bounds__ (256) void k_src_tile_jobs (WhSeqParams P, const WhPicJob* jobs) {
+  const int idx = (int) (blockIdx.x * blockDim.x + threadIdx.x);
+  const WhPicJob& J = jobs[blockIdx.y];
+  if (idx < wh_src_tile_items (P) && J.src[1]) wh_src_tile_item (P, (const WH_G uint8_t*)J.src[1], (WH_G uint8_t*)J.src[0], idx);
+}
+
 // Pre-analysis statistics (kernels/vaa_pic.h): one thread per macroblock.
 __global__ __launch_bounds__ (64) void k_vaa (int num_mb, const uint8_t* cur, const uint8_t* ref, WhVaaOut o) {
   const int xy = (int) (blockIdx.x * blockDim.x + threadIdx.x);
@@ -690,7 +696,14 @@ class HipBackend : public wh::Backend {
     // selects a queue.  Each queue has an error word of its own (WH_ERR_WORDS dwords): a dependency-wait timeout in one launch set
     // must fail that set's pictures and nobody else's.
     streams_.assign (WH_NUM_QUEUES, nullptr);
-    for (int k = 0; k < WH_NUM_QUEUES; ++k) HIP_TRY (hipStreamCreateWithFlags (&streams_[k], hipStreamNonBlocking));
+    // WELSHIP_STREAM_PRIO=1 (experiment knob): the last two queues (a pipelined group's transfer queues) with the highest priority
+    const bool prio = getenv ("WELSHIP_STREAM_PRIO") && atoi (getenv ("WELSHIP_STREAM_PRIO")) != 0;
+    int plo = 0, phi = 0;
+    if (prio) HIP_TRY (hipDeviceGetStreamPriorityRange (&plo, &phi));
+    for (int k = 0; k < WH_NUM_QUEUES; ++k) {
+      if (prio && k >= WH_NUM_QUEUES - 2) HIP_TRY (hipStreamCreateWithPriority (&streams_[k], hipStreamNonBlocking, phi));
+      else HIP_TRY (hipStreamCreateWithFlags (&streams_[k], hipStreamNonBlocking));
+    }
     stream_ = streams_[0]; cur_ = 0;
     HIP_TRY (hipMalloc ((void**)&err_, 4 * WH_ERR_WORDS * WH_NUM_QUEUES));
     if (err_) HIP_TRY (hipMemset (err_, 0, 4 * WH_ERR_WORDS * WH_NUM_QUEUES));
@@ -872,6 +885,21 @@ class HipBackend : public wh::Backend {
     hipLaunchKernelGGL (k_src_tile, dim3 ((wh_src_tile_items (P) + 255) / 256), dim3 (256), 0, stream_, P, planar, tiled);
     HIP_TRY (hipGetLastError());
   }
+  void run_src_tile_jobs (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
+    if (!jobs || n <= 0) { note_null(); return; }
+    hipLaunchKernelGGL (k_src_tile_jobs, dim3 ((wh_src_tile_items (P) + 255) / 256, n), dim3 (256), 0, stream_, P, jobs);
+    HIP_TRY (hipGetLastError());
+  }
+  void upload_on (int q, void* dst, const void* src, size_t bytes) override {
+    HIP_TRY (hipSetDevice (dev_));
+    HIP_TRY (hipMemcpyAsync (dst, src, bytes, hipMemcpyHostToDevice, streams_[(q < 0 ? 0 : q) % WH_NUM_QUEUES]));
+  }
+  void download_on (int q, void* dst, const void* src, size_t bytes) override {
+    HIP_TRY (hipSetDevice (dev_));
+    HIP_TRY (hipMemcpyAsync (dst, src, bytes, hipMemcpyDeviceToHost, streams_[(q < 0 ? 0 : q) % WH_NUM_QUEUES]));
+  }
+  void event_record_on (int q, void* ev) override { if (ev) { HIP_TRY (hipSetDevice (dev_)); HIP_TRY (hipEventRecord ((hipEvent_t)ev, streams_[(q < 0 ? 0 : q) % WH_NUM_QUEUES])); } }
+  void event_wait (void* ev) override { if (ev) { HIP_TRY (hipSetDevice (dev_)); HIP_TRY (hipEventSynchronize ((hipEvent_t)ev)); } }
   void run_vaa (const WhSeqParams& P, const uint8_t* cur, const uint8_t* ref, int32_t* sad8x8, int32_t* sd8x8, uint8_t* mad8x8, int32_t* sum16, int32_t* sqsum16, int32_t* ssd16) override {
     if (!cur || !ref) { note_null(); return; }
     const WhVaaOut o = {sad8x8, sd8x8, mad8x8, sum16, sqsum16, ssd16};
@@ -906,13 +934,13 @@ class HipBackend : public wh::Backend {
     return bad;
   }
   unsigned errors_swept() const override { return swept_.load (std::memory_order_relaxed); }
-  int peek_queue_errors (int k) override { HIP_TRY (hipSetDevice (dev_)); return check_err (k < 0 ? 0 : k % WH_NUM_QUEUES, 1); }
+  int peek_queue_errors (int k, int via) override { HIP_TRY (hipSetDevice (dev_)); return check_err (k < 0 ? 0 : k % WH_NUM_QUEUES, 1, streams_[(via < 0 ? 0 : via) % WH_NUM_QUEUES]); }
   // queue k only: its stream, its error word (the other queues' launch sets keep running and keep their own verdicts)
   int sync_queue (int k) override {
     HIP_TRY (hipSetDevice (dev_));
     k = k < 0 ? 0 : k % WH_NUM_QUEUES;
     if (streams_[k]) HIP_TRY (hipStreamSynchronize (streams_[k]));
-    return check_err (k, 1);
+    return check_err (k, 1, streams_[k]);
   }
   void* event_create() override { hipEvent_t e = nullptr; HIP_TRY (hipEventCreate (&e)); return (void*)e; }
   void event_destroy (void* ev) override { if (ev) HIP_TRY (hipEventDestroy ((hipEvent_t)ev)); }
@@ -922,9 +950,14 @@ class HipBackend : public wh::Backend {
  private:
   // error words of queues [k0, k0 + n): everything on those queues has completed (the callers synchronised them), so the read and
   // the reset race with no kernel that could write them
-  int check_err (int k0, int n) {
+  // via: the words are read through that queue (a copy on the null stream may wait for other queues' kernels)
+  int check_err (int k0, int n, hipStream_t via = nullptr) {
     if (!usable()) return -1;
     uint32_t e[WH_ERR_WORDS * WH_NUM_QUEUES];
+    if (via) {
+      HIP_TRY (hipMemcpyAsync (e, err_ + WH_ERR_WORDS * k0, 4 * WH_ERR_WORDS * n, hipMemcpyDeviceToHost, via));
+      HIP_TRY (hipStreamSynchronize (via));
+    } else
     HIP_TRY (hipMemcpy (e, err_ + WH_ERR_WORDS * k0, 4 * WH_ERR_WORDS * n, hipMemcpyDeviceToHost));
     if (!usable()) return -1;
     int total = 0;

@@ -50,8 +50,16 @@ class Backend {
   // fails its pictures when a sync() in between found errors (it may have consumed this queue's verdict).
   virtual unsigned errors_swept() const { return 0; }
   // the dependency-wait time-outs queue k's kernels have reported so far, WITHOUT waiting for the queue (a pipelined caller checks the
-  // launch set it is about to read results of while the next one is already running on the same queue)
-  virtual int peek_queue_errors (int k) { (void)k; return 0; }
+  // launch set it is about to read results of while the next one is already running on the same queue); read through queue `via`
+  virtual int peek_queue_errors (int k, int via) { (void)k; (void)via; return 0; }
+  // ---- calls that name their queue and leave the selected one alone: safe from several host threads at once (a pipelined group stages
+  // and uploads the next step's pictures on worker threads while another thread downloads and entropy-codes the previous step's) ----
+  virtual void upload_on (int q, void* dst, const void* src, size_t bytes) = 0;
+  virtual void download_on (int q, void* dst, const void* src, size_t bytes) = 0;
+  virtual void event_record_on (int q, void* ev) = 0;
+  virtual void event_wait (void* ev) = 0;                    // the host waits for the event
+  // the pictures' planar sources (jobs[i].src[1], as uploaded) -> their macroblock-tiled form (jobs[i].src[0]): run_src_tile for a batch, on the selected queue
+  virtual void run_src_tile_jobs (const WhSeqParams& P, const WhPicJob* jobs, int n) = 0;
   // timing on the stream the kernels are launched on (HIP events)
   virtual void* event_create() = 0;
   virtual void event_destroy (void* ev) = 0;

@@ -128,16 +128,20 @@ struct SessionCore {
   Pending pend, fin;                  // the picture submitted last; the one being finished (a copy the next submission cannot overwrite)
   bool pipelined = false;
   uint8_t* d_compact1 = nullptr;
-  uint32_t* d_compact_off1 = nullptr;
   std::vector<uint8_t> h_compact1;
-  std::vector<uint32_t> h_compact_off1;
   std::vector<uint8_t> h_src1;
   int pbuf = 0;                       // which set the picture being submitted uses
   uint8_t* dcompact (int b) const { return b ? d_compact1 : d_compact; }
-  uint32_t* dcompact_off (int b) const { return b ? d_compact_off1 : d_compact_off; }
+  uint32_t* dcompact_off (int b) const { return x_doff[b] ? x_doff[b] : d_compact_off; }
   std::vector<uint8_t>& hcompact (int b) { return b ? h_compact1 : h_compact; }
-  std::vector<uint32_t>& hcompact_off (int b) { return b ? h_compact_off1 : h_compact_off; }
+  uint32_t* hcompact_off (int b) { return x_hoff[b] ? x_hoff[b] : h_compact_off.data(); }
   std::vector<uint8_t>& hsrc (int b) { return b ? h_src1 : h_src; }
+  uint8_t* planar (int b) const { return b ? d_src_planar1 : d_src_planar; }
+  // pipelined groups: the offset tables of all sessions are slices of one device / one page-locked host array per buffer set (one copy
+  // brings all of them), owned by the group
+  uint32_t* x_doff[2] = {nullptr, nullptr};
+  uint32_t* x_hoff[2] = {nullptr, nullptr};
+  uint8_t* d_src_planar1 = nullptr;   // second upload target (the batch tiling pass of step k reads the first while step k + 1 is uploaded)
 
   static int validate (const WelsHipEncParam* p) {
     // same spirit as ParamValidationExt (encoder_ext.cpp:403-680)
@@ -345,7 +349,7 @@ struct SessionCore {
   }
 
   // third reconstruction picture, second record / staging buffers (needs the packed records); before the first picture
-  int enable_pipeline() {
+  int enable_pipeline (uint32_t* const doff[2], uint32_t* const hoff[2]) {
     if (pipelined) return WELSHIP_OK;
     if (!use_compact || frame_index != 0 || have_recon) { set_err ("pipelined groups need packed records and must be switched on before the first picture"); return WELSHIP_ERR_UNSUPPORTED; }
     if (prm.bEnableSceneChangeDetect) { set_err ("pipelined groups: scene-change detection reads a device statistic back before every picture"); return WELSHIP_ERR_UNSUPPORTED; }
@@ -354,8 +358,9 @@ struct SessionCore {
     d.base = (uint8_t*)be->alloc (DevPicture::alloc_bytes (rec_alloc_bytes + 128));
     d.mbs = (WhMbState*)be->alloc (sizeof (WhMbState) * num_mb);
     d_compact1 = (uint8_t*)be->alloc ((size_t)num_mb * WH_COMPACT_MAX_BYTES);
-    d_compact_off1 = (uint32_t*)be->alloc (sizeof (uint32_t) * ((size_t)num_mb + 1));
-    if (!d.base || !d.mbs || !d_compact1 || !d_compact_off1) { set_err ("out of device memory"); return WELSHIP_ERR_MEMORY; }
+    d_src_planar1 = (uint8_t*)be->alloc (src_bytes);
+    for (int b = 0; b < 2; ++b) { x_doff[b] = doff[b]; x_hoff[b] = hoff[b]; }
+    if (!d.base || !d.mbs || !d_compact1 || !d_src_planar1) { set_err ("out of device memory"); return WELSHIP_ERR_MEMORY; }
     be->fill (d.base, 0, DevPicture::alloc_bytes (rec_alloc_bytes + 128));
     d.place_tiles (rec_alloc_bytes + 128, rec_y);
     d.plane[0] = d.base + 64 + (size_t)32 * seq.rec_stride_y + 32;
@@ -363,9 +368,7 @@ struct SessionCore {
     d.plane[2] = d.base + 64 + rec_y + rec_c + (size_t)16 * seq.rec_stride_c + 16;
     be->fill (d.mbs, 0, sizeof (WhMbState) * num_mb);
     h_compact1.resize ((size_t)num_mb * WH_COMPACT_MAX_BYTES);
-    h_compact_off1.resize ((size_t)num_mb + 1);
     be->pin_host (h_compact1.data(), h_compact1.size());
-    be->pin_host (h_compact_off1.data(), sizeof (uint32_t) * h_compact_off1.size());
     h_src1 = h_src;                     // (keeps the padding values of the MB-alignment area)
     be->pin_host (h_src1.data(), src_bytes);
     nbuf = 3;
@@ -376,10 +379,11 @@ struct SessionCore {
   void release() {
     if (!be) return;
     if (pipelined) {
-      be->unpin_host (h_compact1.data()); be->unpin_host (h_compact_off1.data()); be->unpin_host (h_src1.data());
+      be->unpin_host (h_compact1.data()); be->unpin_host (h_src1.data());
       if (d_compact1) be->free (d_compact1);
-      if (d_compact_off1) be->free (d_compact_off1);
-      d_compact1 = nullptr; d_compact_off1 = nullptr; pipelined = false; nbuf = 2;
+      if (d_src_planar1) be->free (d_src_planar1);
+      d_compact1 = nullptr; d_src_planar1 = nullptr; pipelined = false; nbuf = 2;
+      for (int b = 0; b < 2; ++b) { x_doff[b] = nullptr; x_hoff[b] = nullptr; }
     }
     for (uint8_t* p : d_src) if (p) be->free (p);
     d_src.clear();
@@ -430,6 +434,12 @@ struct SessionCore {
     be->upload (d_src_planar, hsrc (buf).data(), src_bytes);   // (same queue: the next upload waits for this pass)
     be->run_src_tile (seq, d_src_planar, d_src[slot]);
     upload_pending = true;
+  }
+  // pipelined groups, on a worker thread: staging copy, then the transfer into upload target `buf` on queue q (nothing else: the batch
+  // tiling pass runs on the compute queue, so the upload queue holds copy-engine work only and runs under the previous step's kernels)
+  void stage_and_upload (const WelsHipSourcePicture* src, int buf, int q) {
+    stage_source (src, buf);
+    be->upload_on (q, planar (buf), hsrc (buf).data(), src_bytes);
   }
   void upload_source (int slot, const WelsHipSourcePicture* src) {
     if (upload_pending) { be->sync(); upload_pending = false; }      // the previous transfer out of the staging buffer
@@ -557,7 +567,7 @@ struct SessionCore {
     pbuf ^= 1;
   }
   int finish_pending (WelsHipFrameBSInfo* out) {
-    return entropy_frame (out, 0, true, fin.idr, fin.frame_num, hcompact (fin.buf).data(), hcompact_off (fin.buf).data());
+    return entropy_frame (out, 0, true, fin.idr, fin.frame_num, hcompact (fin.buf).data(), hcompact_off (fin.buf));
   }
   // Entropy-code one picture: `idr` / `frame_num_` of that picture, its packed records in hc / hoff (or the full records in h_records).
   // Changes nothing of the stream state but the parameter-set ids of an IDR picture (restored on failure).
@@ -797,7 +807,9 @@ struct WelsHipEncoderGroup {
   std::vector<WhPicJob> h_jobs_p[2];
   long step_no = 0;
   bool pending = false;               // a submitted step whose pictures have not been entropy-coded yet
-  int pending_slot = 0;
+  uint32_t* d_off_all[2] = {nullptr, nullptr};      // the sessions' record offset tables, one array per buffer set
+  std::vector<uint32_t> h_off_all[2];
+  std::vector<void*> dl_ev;           // one event per session: its records have arrived
   // thread time the host side of the frame steps has taken so far (WelsHipGroupHostStats): [0] staging copies, [1] entropy coding
   std::mutex stat_mu;
   double host_ms[2] = {0.0, 0.0};
@@ -1027,6 +1039,8 @@ void WelsHipGroupDestroy (WelsHipEncoderGroup* g) {
   for (auto& s : g->sess) s->release();
   if (g->pipelined) {
     for (int b = 0; b < 2; ++b) if (!g->h_jobs_p[b].empty()) g->be->unpin_host (g->h_jobs_p[b].data());
+    for (int b = 0; b < 2; ++b) { if (!g->h_off_all[b].empty()) g->be->unpin_host (g->h_off_all[b].data()); if (g->d_off_all[b]) g->be->free (g->d_off_all[b]); }
+    for (void* e : g->dl_ev) g->be->event_destroy (e);
     if (g->d_jobs1) g->be->free (g->d_jobs1);
     if (g->d_job_aux) g->be->free (g->d_job_aux);
   }
@@ -1193,98 +1207,170 @@ int WelsHipGroupEncodeFrames (WelsHipEncoderGroup* g, const WelsHipSourcePicture
 // third reconstruction picture: when the entropy coder finds a CAVLC overflow in step k - 1 (TRY_REENCODING, rare), that picture is
 // coded again on the device (its reference, step k - 2, still exists) and then its already submitted successor once more.
 // Queues: 0 = kernels, WH_PIPE_UPQ = uploads, WH_PIPE_DLQ = downloads.
-#define WH_PIPE_UPQ 30
-#define WH_PIPE_DLQ 31
+static int pipe_queue (int which) {            // WELSHIP_PIPE_QUEUES=upload,download (experiment knob; default 1,2)
+  static int q[2] = {-1, -1};
+  if (q[0] < 0) {
+    int a = 1, b = 2;          // (measured: queues 30 and 31 share a hardware queue with queue 0 -- their copies waited for its kernels; profiles/r03_pipelined_group.txt)
+    if (const char* e = getenv ("WELSHIP_PIPE_QUEUES")) sscanf (e, "%d,%d", &a, &b);
+    q[1] = b; q[0] = a;
+  }
+  return q[which];
+}
+#define WH_PIPE_UPQ pipe_queue (0)
+#define WH_PIPE_DLQ pipe_queue (1)
 int WelsHipGroupSetPipelined (WelsHipEncoderGroup* g, int on) {
   if (!g) return WELSHIP_ERR_INIT_PARA;
   if (!on) { if (g->pending) { set_err ("a submitted step is still pending: flush first"); return WELSHIP_ERR_INIT_PARA; } return WELSHIP_OK; }
   if (g->pipelined) return WELSHIP_OK;
   if (g->queues != 1) { set_err ("pipelined groups use one compute queue (WELSHIP_QUEUES=1)"); return WELSHIP_ERR_UNSUPPORTED; }
   const int n = (int)g->sess.size();
-  for (auto& c : g->sess) { const int rc = c->enable_pipeline(); if (rc) return rc; }
+  const size_t off_words = (size_t)g->sess[0]->num_mb + 1;
+  uint32_t* doff[2];
+  for (int b = 0; b < 2; ++b) {
+    g->d_off_all[b] = (uint32_t*)g->be->alloc (sizeof (uint32_t) * off_words * n);
+    g->h_off_all[b].assign (off_words * n, 0);
+    g->be->pin_host (g->h_off_all[b].data(), sizeof (uint32_t) * off_words * n);
+    if (!g->d_off_all[b]) { set_err ("out of device memory"); return WELSHIP_ERR_MEMORY; }
+  }
+  for (int i = 0; i < n; ++i) {
+    uint32_t* hoff[2];
+    for (int b = 0; b < 2; ++b) { doff[b] = g->d_off_all[b] + off_words * i; hoff[b] = g->h_off_all[b].data() + off_words * i; }
+    const int rc = g->sess[i]->enable_pipeline (doff, hoff);
+    if (rc) return rc;
+  }
   g->d_jobs1 = (WhPicJob*)g->be->alloc (sizeof (WhPicJob) * n);
   g->d_job_aux = (WhPicJob*)g->be->alloc (sizeof (WhPicJob));
   if (!g->d_jobs1 || !g->d_job_aux) { set_err ("out of device memory"); return WELSHIP_ERR_MEMORY; }
   for (int b = 0; b < 2; ++b) { g->h_jobs_p[b].assign (n, WhPicJob()); g->be->pin_host (g->h_jobs_p[b].data(), sizeof (WhPicJob) * n); }
+  g->dl_ev.assign (n, nullptr);
+  for (int i = 0; i < n; ++i) g->dl_ev[i] = g->be->event_create();
   if (g->be->sync()) { set_err ("device error while setting up the pipelined group"); return WELSHIP_ERR_UNKNOWN; }
   g->pipelined = true;
   return WELSHIP_OK;
 }
 
-// srcs != NULL: submit a step with these source pictures.  Then, if a step was pending before this call, finish it: its bitstreams go
-// to outs[] and *pFinished = 1.  srcs == NULL: only finish what is pending (the end of the streams).
+namespace {
+// The submitting half of a pipelined call (the calling thread): staging copies and H2D transfers on the worker threads, then the jobs
+// and the kernels.  Nothing here waits for the device beyond the upload queue's work of two steps ago.
+int pipe_submit (WelsHipEncoderGroup* g, const WelsHipSourcePicture* srcs, double* tm, const std::function<double()>& now) {
+  wh::Backend* be = g->be;
+  const int n = (int)g->sess.size();
+  SessionCore& c0 = *g->sess[0];
+  const int slot = (c0.last_slot + 1) % c0.ring;
+  const int sb = (int) (g->step_no & 1);
+  for (int i = 0; i < n; ++i) if (srcs[i].iPicWidth != g->sess[i]->prm.iPicWidth || srcs[i].iPicHeight != g->sess[i]->prm.iPicHeight) return WELSHIP_ERR_INIT_PARA;
+  for (int i = 0; i < n; ++i) { const int rc = g->sess[i]->begin_frame_check(); if (rc) return rc; }      // nothing queued yet: the group stays in step
+  if (be->sync_queue (WH_PIPE_UPQ)) { set_err ("device error on the upload queue"); return WELSHIP_ERR_UNKNOWN; }     // staging set sb is free again (step k - 2's transfers)
+  tm[0] = now();
+  g->parallel (n, [&] (int t, int T) {
+    const auto t0 = std::chrono::steady_clock::now();
+    int k = 0;
+    for (int i = t; i < n; i += T, ++k) g->sess[i]->stage_and_upload (&srcs[i], sb, WH_PIPE_UPQ);
+    g->note_host_time (0, std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now() - t0).count(), k);
+  });
+  tm[1] = now();
+  // describe the pictures (P pictures first, then IDR pictures, as WelsHipGroupBegin orders them)
+  std::vector<WhPicJob> jobs (n);
+  for (int i = 0; i < n; ++i) {
+    SessionCore& c = *g->sess[i];
+    if (slot % c.ring == c.last_slot) c.prev_src_dirty = true;
+    const int rc = c.begin_frame (slot % c.ring, &jobs[i]);
+    if (rc) return rc;
+    jobs[i].src[1] = c.planar (sb);                     // tiled into src[0] by the batch pass below
+  }
+  g->order.resize (n);
+  int k = 0;
+  for (int i = 0; i < n; ++i) if (!g->sess[i]->cur_idr) g->order[k++] = i;
+  const int np = k;
+  for (int i = 0; i < n; ++i) if (g->sess[i]->cur_idr) g->order[k++] = i;
+  std::vector<WhPicJob>& hj = g->h_jobs_p[sb];
+  for (int j = 0; j < n; ++j) hj[j] = jobs[g->order[j]];
+  WhPicJob* dj = sb ? g->d_jobs1 : g->d_jobs;
+  be->select_queue (0);
+  be->queue_wait (WH_PIPE_UPQ);                         // the kernels wait (on the device) for this step's sources
+  be->upload (dj, hj.data(), sizeof (WhPicJob) * n);
+  const WhSeqParams& s = c0.seq;
+  be->run_src_tile_jobs (s, dj, n);
+  if (np) be->run_inter (s, dj, np);
+  if (n - np) be->run_intra (s, dj + np, n - np);
+  be->run_compact (s, dj, n);
+  if (s.deblock_idc != 1) be->run_deblock (s, dj, n);
+  if (c0.prm.uiIntraPeriod != 1) be->run_expand (s, dj, n);
+  for (auto& c : g->sess) c->submit_advance();
+  ++g->step_no;
+  tm[2] = now();
+  return WELSHIP_OK;
+}
+
+// The finishing half (its own thread while the other half submits): the offset tables of all sessions in one copy, then every session's
+// packed records, an event behind each; the entropy threads start on a session as soon as its records have arrived.  Touches only what
+// SessionCore::entropy_frame touches (parameter-set ids, bitstream buffers) and `fin` -- nothing the submitting half uses.
+int pipe_finish (WelsHipEncoderGroup* g, WelsHipFrameBSInfo* outs, std::vector<int>& rcs, double* tm, const std::function<double()>& now) {
+  wh::Backend* be = g->be;
+  const int n = (int)g->sess.size();
+  const int fb = g->sess[0]->fin.buf;                   // (the sessions advance in lock step)
+  const size_t off_words = (size_t)g->sess[0]->num_mb + 1;
+  be->download_on (WH_PIPE_DLQ, g->h_off_all[fb].data(), g->d_off_all[fb], sizeof (uint32_t) * off_words * n);   // (the queue waits for that step's kernels: queue_wait at its submission)
+  if (be->sync_queue (WH_PIPE_DLQ) || be->peek_queue_errors (0, WH_PIPE_DLQ)) { set_err ("device scheduler timed out; the step was not encoded"); return WELSHIP_ERR_UNKNOWN; }
+  tm[3] = now();
+  for (int i = 0; i < n; ++i) {
+    SessionCore& c = *g->sess[i];
+    const size_t bytes = c.hcompact_off (fb)[c.num_mb];
+    if (bytes > c.hcompact (fb).size()) { set_err ("corrupt record offsets"); return WELSHIP_ERR_UNKNOWN; }
+    be->download_on (WH_PIPE_DLQ, c.hcompact (fb).data(), c.dcompact (fb), bytes);
+    be->event_record_on (WH_PIPE_DLQ, g->dl_ev[i]);
+    g->packed_bytes += (double)bytes;
+  }
+  tm[4] = now();
+  // thread t takes sessions t, t + T, ...: in the order their records arrive
+  g->parallel (n, [&] (int t, int T) {
+    double busy = 0.0;
+    int k = 0;
+    for (int i = t; i < n; i += T, ++k) {
+      be->event_wait (g->dl_ev[i]);
+      const auto t0 = std::chrono::steady_clock::now();
+      rcs[i] = g->sess[i]->finish_pending (outs ? &outs[i] : nullptr);
+      busy += std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now() - t0).count();
+    }
+    g->note_host_time (1, busy, k);
+  });
+  tm[5] = now();
+  return WELSHIP_OK;
+}
+}  // namespace
+
+// srcs != NULL: submit a step with these source pictures.  If a step was pending before this call, it is finished meanwhile: its
+// bitstreams go to outs[] and *pFinished = 1.  srcs == NULL: only finish what is pending (the end of the streams).
 int WelsHipGroupEncodeFramesPipelined (WelsHipEncoderGroup* g, const WelsHipSourcePicture* srcs, WelsHipFrameBSInfo* outs, int* pFinished) {
   if (!g || !g->pipelined) { set_err ("not a pipelined group (WelsHipGroupSetPipelined)"); return WELSHIP_ERR_INIT_PARA; }
   if (pFinished) *pFinished = 0;
   wh::Backend* be = g->be;
   const int n = (int)g->sess.size();
-  SessionCore& c0 = *g->sess[0];
   const bool had_pending = g->pending;
-  bool submitted = false;
+  // WELSHIP_PIPE_TRACE=1: where the host spends a call (ms since its start), on stderr
+  static const bool trace = getenv ("WELSHIP_PIPE_TRACE") && atoi (getenv ("WELSHIP_PIPE_TRACE")) != 0;
+  const auto tc0 = std::chrono::steady_clock::now();
+  const std::function<double()> now = [&] () { return std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now() - tc0).count(); };
+  double tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (had_pending) for (auto& c : g->sess) c->fin = c->pend;
-  if (srcs) {
-    const int slot = (c0.last_slot + 1) % c0.ring;
-    const int sb = (int) (g->step_no & 1);
-    for (int i = 0; i < n; ++i) if (srcs[i].iPicWidth != g->sess[i]->prm.iPicWidth || srcs[i].iPicHeight != g->sess[i]->prm.iPicHeight) return WELSHIP_ERR_INIT_PARA;
-    if (be->sync_queue (WH_PIPE_UPQ)) { set_err ("device error on the upload queue"); return WELSHIP_ERR_UNKNOWN; }     // staging set sb is free again (step k - 2's transfers)
-    g->parallel (n, [&] (int t, int T) {
-      const auto t0 = std::chrono::steady_clock::now();
-      int k = 0;
-      for (int i = t; i < n; i += T, ++k) g->sess[i]->stage_source (&srcs[i], sb);
-      g->note_host_time (0, std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now() - t0).count(), k);
-    });
-    be->select_queue (WH_PIPE_UPQ);
-    // the slot written now: with two slots it is the one the kernels still running (step k - 1) read as "previous source picture" (LOW_COMPLEXITY)
-    if (c0.ring < 3 && c0.seq.complexity == 0) be->queue_wait (0);
-    for (int i = 0; i < n; ++i) { g->sess[i]->issue_upload (slot % g->sess[i]->ring, sb); g->sess[i]->upload_pending = false; }
-    // describe the pictures (P pictures first, then IDR pictures, as WelsHipGroupBegin orders them)
-    std::vector<WhPicJob> jobs (n);
-    for (int i = 0; i < n; ++i) { const int rc = g->sess[i]->begin_frame_check(); if (rc) return rc; }
-    for (int i = 0; i < n; ++i) { const int rc = g->sess[i]->begin_frame (slot % g->sess[i]->ring, &jobs[i]); if (rc) return rc; }
-    g->order.resize (n);
-    int k = 0;
-    for (int i = 0; i < n; ++i) if (!g->sess[i]->cur_idr) g->order[k++] = i;
-    const int np = k;
-    for (int i = 0; i < n; ++i) if (g->sess[i]->cur_idr) g->order[k++] = i;
-    std::vector<WhPicJob>& hj = g->h_jobs_p[sb];
-    for (int j = 0; j < n; ++j) hj[j] = jobs[g->order[j]];
-    WhPicJob* dj = sb ? g->d_jobs1 : g->d_jobs;
-    be->select_queue (0);
-    be->queue_wait (WH_PIPE_UPQ);                       // the kernels wait (on the device) for this step's sources
-    be->upload (dj, hj.data(), sizeof (WhPicJob) * n);
-    const WhSeqParams& s = c0.seq;
-    if (np) be->run_inter (s, dj, np);
-    if (n - np) be->run_intra (s, dj + np, n - np);
-    be->run_compact (s, dj, n);
-    if (s.deblock_idc != 1) be->run_deblock (s, dj, n);
-    if (c0.prm.uiIntraPeriod != 1) be->run_expand (s, dj, n);
-    for (auto& c : g->sess) c->submit_advance();
-    ++g->step_no;
-    submitted = true;
-  }
-  // ---- finish the step that was pending before this call ----
+  std::vector<int> rcs (n, 0);
+  int frc = WELSHIP_OK, src_rc = WELSHIP_OK;
+  std::string ferr;
+  std::thread fth;
   if (had_pending) {
-    be->select_queue (WH_PIPE_DLQ);        // (waits, on the device, for that step's kernels: queue_wait at its submission)
-    for (int i = 0; i < n; ++i) {
-      SessionCore& c = *g->sess[i];
-      be->download (c.hcompact_off (c.fin.buf).data(), c.dcompact_off (c.fin.buf), sizeof (uint32_t) * ((size_t)c.num_mb + 1));
-    }
-    if (be->sync_queue (WH_PIPE_DLQ) || be->peek_queue_errors (0)) { set_err ("device scheduler timed out; the step was not encoded"); return WELSHIP_ERR_UNKNOWN; }
-    for (int i = 0; i < n; ++i) {
-      SessionCore& c = *g->sess[i];
-      const size_t bytes = c.hcompact_off (c.fin.buf)[c.num_mb];
-      if (bytes > c.hcompact (c.fin.buf).size()) { set_err ("corrupt record offsets"); return WELSHIP_ERR_UNKNOWN; }
-      be->download (c.hcompact (c.fin.buf).data(), c.dcompact (c.fin.buf), bytes);
-      g->packed_bytes += (double)bytes;
-    }
-    if (be->sync_queue (WH_PIPE_DLQ)) { set_err ("device error while copying the records"); return WELSHIP_ERR_UNKNOWN; }
-    std::vector<int> rcs (n, 0);
-    g->parallel (n, [&] (int t, int T) {
-      const auto t0 = std::chrono::steady_clock::now();
-      int k = 0;
-      for (int i = t; i < n; i += T, ++k) rcs[i] = g->sess[i]->finish_pending (outs ? &outs[i] : nullptr);
-      g->note_host_time (1, std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now() - t0).count(), k);
-    });
+    if (srcs) fth = std::thread ([&] { frc = pipe_finish (g, outs, rcs, tm, now); if (frc) ferr = g_last_error; });
+    else frc = pipe_finish (g, outs, rcs, tm, now);
+  }
+  const bool submitted = srcs != nullptr && (src_rc = pipe_submit (g, srcs, tm, now)) == WELSHIP_OK;
+  if (fth.joinable()) { fth.join(); if (frc) set_err (ferr); }
+  if (trace) fprintf (stderr, "welship pipe: submit half: upload queue free %.2f, staged + H2D queued %.2f, kernels queued %.2f | finish half: step k-1 done on the device %.2f, copies queued %.2f, entropy-coded %.2f ms\n",
+                      tm[0], tm[1], tm[2], tm[3], tm[4], tm[5]);
+  if (srcs && src_rc) {             // nothing of this step was queued (the checks come first) unless the device itself failed
+    g->pending = false;
+    return src_rc;
+  }
+  if (frc) { g->pending = submitted; return frc; }
+  if (had_pending) {
     // CAVLC overflow (rare): that picture again with the macroblock's QP raised, then the picture submitted after it -- it predicted from
     // the reconstruction that has just been replaced.  Everything the device has queued is waited for first.
     for (int i = 0; i < n; ++i) {
@@ -1299,13 +1385,14 @@ int WelsHipGroupEncodeFramesPipelined (WelsHipEncoderGroup* g, const WelsHipSour
         rcs[i] = c.retry_after_overflow (&job);
         std::swap (c.cur_job, c.fin.job);
         if (rcs[i]) break;
+        job.src[1] = nullptr;
         be->upload (g->d_job_aux, &job, sizeof (job));
         run_device_step (be, c.seq, g->d_job_aux, 1, c.fin.idr, need_ref, true);
         be->download (c.h_records.data(), c.d_records, sizeof (WhMbRecord) * c.num_mb);
         if (be->sync()) { set_err ("device scheduler timed out; the picture was not encoded"); rcs[i] = WELSHIP_ERR_UNKNOWN; break; }
         rcs[i] = c.entropy_frame (outs ? &outs[i] : nullptr, 0, false, c.fin.idr, c.fin.frame_num, nullptr, nullptr);
       }
-      memset (c.h_mb_ctl.data(), 0, sizeof (WhMbCtl) * c.h_mb_ctl.size());   // the QP map belonged to that picture only
+      if (!c.h_mb_ctl.empty()) memset (c.h_mb_ctl.data(), 0, sizeof (WhMbCtl) * c.h_mb_ctl.size());   // the QP map belonged to that picture only
       c.qp_map_in_use = false;
       if (rcs[i] == WELSHIP_OK && submitted) {
         if (++c.db_gen == 0) c.db_gen = 1;
@@ -1322,6 +1409,7 @@ int WelsHipGroupEncodeFramesPipelined (WelsHipEncoderGroup* g, const WelsHipSour
     for (int i = 0; i < n; ++i) if (rcs[i]) {
       set_err ("session " + std::to_string (i) + (rcs[i] == WELSHIP_ERR_MEMORY ? ": frame does not fit the reference encoder's bitstream buffer (cmMallocMemeError)"
                                                                                : ": entropy coding of the frame failed"));
+      g->pending = submitted;
       return rcs[i];
     }
     if (pFinished) *pFinished = 1;
@@ -1579,7 +1667,9 @@ struct WelsHipFrameCtx {
   WhMbCtl* d_mb_ctl = nullptr;
   std::vector<WhMbCtl> h_mb_ctl;
   int32_t* d_sad_cost0 = nullptr;        // the layer's pSadCost[0] array (persists across pictures)
-  int32_t* d_sad_cost0_new = nullptr;    // size-limited slices: the copy the picture being coded writes (WhPicJob::sad_cost0_out), swapped in when it is complete
+  int32_t* d_sad_cost0_new = nullptr;    // the copy the picture being coded writes (WhPicJob::sad_cost0_out): size-limited slices swap it in when the picture
+                                         // is complete, whole-picture calls when the NEXT picture begins (a bRetry pass reads the previous picture's again)
+  bool sad_swap_pending = false;
   int32_t* d_vaa = nullptr;
   int8_t* d_bgd = nullptr;
   int16_t* d_il = nullptr;
@@ -1725,7 +1815,7 @@ void frame_run_batch (FrameShared* sh, FrameKey* K, FrameLane* L, std::unique_lo
       WelsHipFrameCtx* c = x->c;
       be->download (c->h_records.data(), c->d_records, sizeof (WhMbRecord) * c->num_mb);
       be->download (c->h_pic.data(), c->pics[x->cur_pic].base, c->rec_alloc_bytes + 128);
-      if (x->sad_dst) be->download (c->h_sad_out.data(), c->d_sad_cost0, sizeof (int32_t) * c->num_mb);
+      if (x->sad_dst) be->download (c->h_sad_out.data(), x->job.sad_cost0_out ? x->job.sad_cost0_out : x->job.sad_cost0, sizeof (int32_t) * c->num_mb);
       if (c->scc_active) be->download (c->scc_down(), c->d_scc_chain + 4 * WH_MAX_SLICES, sizeof (uint32_t) * WH_MAX_SLICES);
     }
     const double launch_ms = std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now() - t_launch0).count();
@@ -2097,6 +2187,7 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
     if (is_p && j->pVaaSad8x8) be->upload (c->d_vaa, c->h_aux.data() + c->aux_vaa, sizeof (int32_t) * 4 * c->num_mb);
     if (is_p && j->pBgdFlags) be->upload (c->d_bgd, c->h_aux.data() + c->aux_bgd, (size_t)c->num_mb);
     if (is_p && j->pIlHint) be->upload (c->d_il, c->h_aux.data() + c->aux_il, sizeof (int16_t) * 4 * c->num_mb);
+    if (c->sad_swap_pending) { std::swap (c->d_sad_cost0, c->d_sad_cost0_new); c->sad_swap_pending = false; }     // the previous picture's array is final now
     if (j->pSadCost) be->upload (c->d_sad_cost0, c->h_aux.data() + c->aux_sad, sizeof (int32_t) * c->num_mb);
     if (++c->db_gen == 0) c->db_gen = 1;
     c->h_pic_of = -1;
@@ -2174,6 +2265,14 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
     if (!c->d_sad_cost0_new) { set_err ("out of device memory"); return WELSHIP_ERR_MEMORY; }
     job.sad_cost0_out = c->d_sad_cost0_new;
     job.dyn_redo = j->bDynRedoFirst ? 1 : 0;
+  } else if (!ranged) {
+    // whole-picture calls: every macroblock writes its entry of the second copy, and a repeat of the picture after a CAVLC overflow (bRetry)
+    // starts from the previous picture's entries again, as the reference's TRY_REENCODING does macroblock by macroblock -- not from what
+    // the abandoned pass left (a macroblock that was coded in that pass and is a P_Skip above LOW complexity now keeps the OLD entry)
+    if (!c->d_sad_cost0_new) { c->d_sad_cost0_new = (int32_t*)be->alloc (sizeof (int32_t) * c->num_mb); if (c->d_sad_cost0_new) be->fill (c->d_sad_cost0_new, 0, sizeof (int32_t) * c->num_mb); }
+    if (!c->d_sad_cost0_new) { set_err ("out of device memory"); return WELSHIP_ERR_MEMORY; }
+    job.sad_cost0_out = c->d_sad_cost0_new;
+    c->sad_swap_pending = true;
   }
   job.vaa_sad8x8 = is_p && j->pVaaSad8x8 ? c->d_vaa : nullptr;
   job.bgd_flags = is_p && j->pBgdFlags ? c->d_bgd : nullptr;

@@ -230,6 +230,13 @@ class EmuBackend : public Backend {
   }
   void select_queue (int) override {}
   int sync() override { return 0; }
+  void upload_on (int, void* dst, const void* src, size_t bytes) override { memcpy (dst, src, bytes); }
+  void download_on (int, void* dst, const void* src, size_t bytes) override { memcpy (dst, src, bytes); }
+  void event_record_on (int, void* ev) override { event_record (ev); }
+  void event_wait (void*) override {}
+  void run_src_tile_jobs (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
+    for (int i = 0; i < n; ++i) if (jobs[i].src[1]) run_src_tile (P, jobs[i].src[1], (uint8_t*)jobs[i].src[0]);
+  }
   void* event_create() override { return new double (0.0); }
   void event_destroy (void* ev) override { delete (double*)ev; }
   void event_record (void* ev) override { * (double*)ev = std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now().time_since_epoch()).count(); }
