@@ -861,7 +861,7 @@ class HipBackend : public wh::Backend {
     else if (nw <= 6) launch (k_inter_pool<384, false>); else launch (k_inter_pool<768, false>);
   }
   void run_deblock (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
-    static const int db_waves = getenv ("WELSHIP_DB_WAVES") ? atoi (getenv ("WELSHIP_DB_WAVES")) : 16;
+    static const int db_waves = getenv ("WELSHIP_DB_WAVES") ? atoi (getenv ("WELSHIP_DB_WAVES")) : 12;    // 73 VGPRs: two 12-wave workgroups per CU, one of 16 (measured 3.85 against 4.79 ms per step of 256 pictures; 8: 4.3, 6: 5.1)
     mb_pass (k_deblock_slices, sizeof (WhDbLds), db_waves, false, P, jobs, n, 16 * sizeof (WhDbStage) + sizeof (WhPicJob), 4 * wh_db_xchg_words (P.mb_w, P.mb_h), P.db_num_bands);
   }
   void run_scene (const WhSeqParams& P, const WhPicJob* jobs, int n) override {

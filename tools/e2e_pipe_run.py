@@ -17,7 +17,7 @@ def main():
     w, h, ring = 1920, 1080, 8
     fsz = w * h * 3 // 2
     from openh264_amd.utils.synth import synth_sequence
-    content = B.Content(synth_sequence(w, h, ring), fsz, ring, False)
+    content = B.Content(synth_sequence(w, h, 2 * ring), fsz, ring, False)      # as bench.py builds it
     t0 = time.perf_counter()
     dt, nbytes, _, host = B.e2e_pipelined_leg(oh, A, 0, w, h, sessions, ring, content, frames, False)
     print("pipelined: %.0f frames/s (%d sessions x %d frames in %.1f ms; second half %.0f frames/s; whole leg %.1f s)" % (
