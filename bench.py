@@ -268,21 +268,31 @@ def e2e_pipelined_leg(oh, a, local, w, h, sessions, ring, content, frames, check
     # (its two halves run at the same time, each on its own team of host threads: staging copies | entropy coding)
     e2e_pipelined_leg.threads = int(os.environ.get("WELSHIP_PIPE_THREADS", "0")) or max(4, a.host_threads // 2)
     g = make_group(oh, a, local, w, h, "p", sessions, ring, None, host_threads=e2e_pipelined_leg.threads)
-    g.set_pipelined()
+    ahead = e2e_pipelined_leg.ahead = max(1, min(3, int(os.environ.get("WELSHIP_PIPE_AHEAD", "2"))))
+    g.set_pipelined(ahead)
     pics = [g.make_pictures([content.frame(s, k) for s in range(sessions)]) for k in range(ring)]
     order = [0, 1 % ring] + [slot_of(i + 2, ring) for i in range(frames)]
     bs0 = bytearray()
-    assert g.encode_frames_pipelined(pics[order[0]]) is None
-    bs0 += g.encode_frames_pipelined(pics[order[1]], want_bytes=True)[0]      # the IDR's streams
-    bs0 += g.encode_frames_pipelined(None, want_bytes=True)[0]                # the first P picture's: the pipeline is empty again
+    for k in (0, 1):                                                          # the IDR and the first P picture, then the pipeline is emptied again
+        out = g.encode_frames_pipelined(pics[order[k]], want_bytes=True)
+        if out is not None:
+            bs0 += out[0]
+    while True:
+        out = g.encode_frames_pipelined(None, want_bytes=True)
+        if out is None:
+            break
+        bs0 += out[0]
     t0 = time.perf_counter()
     nbytes = 0
     stamps = []
-    for i in range(frames + 1):
+    i = done = 0
+    while done < frames:
         out = g.encode_frames_pipelined(pics[order[i + 2]] if i < frames else None, want_bytes=check)
-        stamps.append(time.perf_counter())
+        i += 1
         if out is None:
             continue
+        done += 1
+        stamps.append(time.perf_counter())          # step `done` finished
         if check:
             bs0 += out[0]
             nbytes += sum(len(b) for b in out)
@@ -290,7 +300,7 @@ def e2e_pipelined_leg(oh, a, local, w, h, sessions, ring, content, frames, check
             nbytes += out
     dt = time.perf_counter() - t0
     half = frames // 2
-    steady = sessions * (frames - half) / (stamps[frames] - stamps[half]) if frames >= 4 else None      # steps half+1 .. frames finished in that time
+    steady = sessions * (frames - half) / (stamps[frames - 1] - stamps[half - 1]) if frames >= 4 else None      # steps half+1 .. frames finished in that time
     host = g.host_stats()
     g.close()
     match = None
@@ -507,7 +517,7 @@ def main():
         n3 = 60
         dp, nb3, m3, host3 = e2e_pipelined_leg(oh, a, local, w, h, a.sessions, ring, content, n3, bool(verify_sessions))
         line["e2e_pipelined"] = {"frames_per_s": a.sessions * n3 / dp, "frames_per_s_second_half": e2e_pipelined_leg.steady,
-                                 "sessions": a.sessions, "frames_each": n3, "host_threads_per_half": e2e_pipelined_leg.threads,
+                                 "sessions": a.sessions, "frames_each": n3, "host_threads_per_half": e2e_pipelined_leg.threads, "steps_ahead": e2e_pipelined_leg.ahead,
                                  "bitstream_MB_per_s": nb3 / dp / 1e6, "bitstream_vs_reference": m3, "host_thread_ms_per_picture": host3,
                                  "how": "WelsHipGroupEncodeFramesPipelined: staging copy + H2D + kernels of step k queued, then D2H + CAVLC of step k - 1 under them"}
         lat = {}

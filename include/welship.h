@@ -167,13 +167,15 @@ int  WelsHipGroupCreate (WelsHipEncoderGroup** ppGroup, const WelsHipEncParam* p
 void WelsHipGroupDestroy (WelsHipEncoderGroup* pGroup);
 /* one EncodeFrame for every session: kpSrcPics[iSessions] -> pBsInfos[iSessions] */
 int  WelsHipGroupEncodeFrames (WelsHipEncoderGroup* pGroup, const WelsHipSourcePicture* kpSrcPics, WelsHipFrameBSInfo* pBsInfos);
-/* The same step as a two-stage software pipeline: the call SUBMITS kpSrcPics (staging copy, H2D, kernels: all queued) and then FINISHES
- * the step submitted by the previous call while the device works (D2H of its records, CAVLC + NAL packing on the host threads), so the
- * bitstreams come back one call late: *pbFinished = 1 when pBsInfos[] holds that earlier step's output.  kpSrcPics = NULL only finishes
- * (end of the streams).  The streams are byte-identical to WelsHipGroupEncodeFrames' (ISVCEncoder::EncodeFrame per session,
- * codec/api/wels/codec_api.h:343); scene-change detection is not available in this mode (it needs a device statistic before every
- * picture's type is decided).  WelsHipGroupSetPipelined before the first picture. */
-int  WelsHipGroupSetPipelined (WelsHipEncoderGroup* pGroup, int bOn);
+/* The same step as a software pipeline: the call SUBMITS kpSrcPics (staging copies and H2D on worker threads, then the kernels: all
+ * queued) and meanwhile FINISHES the oldest pending step on a second thread (D2H of its packed records, CAVLC + NAL packing), so the
+ * bitstreams come back iStepsAhead calls late: *pbFinished = 1 when pBsInfos[] holds that earlier step's output.  kpSrcPics = NULL only
+ * finishes the oldest pending step (end of the streams: call until *pbFinished stays 0).  The streams are byte-identical to
+ * WelsHipGroupEncodeFrames' (ISVCEncoder::EncodeFrame per session, codec/api/wels/codec_api.h:343), a CAVLC overflow found late
+ * included: that picture and the ones submitted after it are coded again.  Scene-change detection is not available in this mode (it
+ * needs a device statistic before every picture's type is decided).  WelsHipGroupSetPipelined (iStepsAhead = 1..3) before the first
+ * picture: every step ahead costs each session one more reconstruction picture, record buffer and staging buffer. */
+int  WelsHipGroupSetPipelined (WelsHipEncoderGroup* pGroup, int iStepsAhead);
 int  WelsHipGroupEncodeFramesPipelined (WelsHipEncoderGroup* pGroup, const WelsHipSourcePicture* kpSrcPics, WelsHipFrameBSInfo* pBsInfos, int* pbFinished);
 /* the same, split into its phases (sources may be made resident in HBM ahead of time).  iSlot selects one of the
  * iSourceRingSlots (at least 2) resident source pictures per session; a P picture must not use the slot of the picture

@@ -340,15 +340,16 @@ class EncoderGroup:
             out.append(bytes(b))
         return out
 
-    def set_pipelined(self):
-        """WelsHipGroupSetPipelined: encode_frames_pipelined from now on (before the first picture)."""
-        rc = self._lib.WelsHipGroupSetPipelined(self._h, 1)
+    def set_pipelined(self, steps_ahead=1):
+        """WelsHipGroupSetPipelined: encode_frames_pipelined from now on (before the first picture); the device runs up to
+        `steps_ahead` frame steps ahead of the entropy coder."""
+        rc = self._lib.WelsHipGroupSetPipelined(self._h, steps_ahead)
         if rc:
             raise WelsHipError(rc, (self._lib.WelsHipGetLastError() or b"").decode())
 
     def encode_frames_pipelined(self, pictures, want_bytes=False):
-        """WelsHipGroupEncodeFramesPipelined: submits `pictures` (None: nothing, only finish) and finishes the step submitted by the
-        previous call.  Returns None when no step was finished, else what encode_frames returns -- for that EARLIER step."""
+        """WelsHipGroupEncodeFramesPipelined: submits `pictures` (None: nothing, only finish) and finishes the oldest pending step once
+        `steps_ahead` are pending.  Returns None when no step was finished, else what encode_frames returns -- for that EARLIER step."""
         infos = (SFrameBSInfo * self.n)()
         done = C.c_int(0)
         rc = self._lib.WelsHipGroupEncodeFramesPipelined(self._h, pictures[0] if pictures is not None else None, infos, C.byref(done))

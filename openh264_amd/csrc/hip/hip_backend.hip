@@ -899,6 +899,7 @@ class HipBackend : public wh::Backend {
     HIP_TRY (hipMemcpyAsync (dst, src, bytes, hipMemcpyDeviceToHost, streams_[(q < 0 ? 0 : q) % WH_NUM_QUEUES]));
   }
   void event_record_on (int q, void* ev) override { if (ev) { HIP_TRY (hipSetDevice (dev_)); HIP_TRY (hipEventRecord ((hipEvent_t)ev, streams_[(q < 0 ? 0 : q) % WH_NUM_QUEUES])); } }
+  void queue_wait_event (int q, void* ev) override { if (ev) { HIP_TRY (hipSetDevice (dev_)); HIP_TRY (hipStreamWaitEvent (streams_[(q < 0 ? 0 : q) % WH_NUM_QUEUES], (hipEvent_t)ev, 0)); } }
   void event_wait (void* ev) override { if (ev) { HIP_TRY (hipSetDevice (dev_)); HIP_TRY (hipEventSynchronize ((hipEvent_t)ev)); } }
   void run_vaa (const WhSeqParams& P, const uint8_t* cur, const uint8_t* ref, int32_t* sad8x8, int32_t* sd8x8, uint8_t* mad8x8, int32_t* sum16, int32_t* sqsum16, int32_t* ssd16) override {
     if (!cur || !ref) { note_null(); return; }

@@ -58,6 +58,7 @@ class Backend {
   virtual void download_on (int q, void* dst, const void* src, size_t bytes) = 0;
   virtual void event_record_on (int q, void* ev) = 0;
   virtual void event_wait (void* ev) = 0;                    // the host waits for the event
+  virtual void queue_wait_event (int q, void* ev) = 0;       // queue q waits (on the device) for the event
   // the pictures' planar sources (jobs[i].src[1], as uploaded) -> their macroblock-tiled form (jobs[i].src[0]): run_src_tile for a batch, on the selected queue
   virtual void run_src_tile_jobs (const WhSeqParams& P, const WhPicJob* jobs, int n) = 0;
   // timing on the stream the kernels are launched on (HIP events)

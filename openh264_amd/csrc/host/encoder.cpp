@@ -13,6 +13,7 @@
 #include <functional>
 #include <memory>
 #include <mutex>
+#include <deque>
 #include <string>
 #include <thread>
 #include <chrono>
@@ -32,6 +33,7 @@ namespace wh {
 Backend* create_default_backend (int device, const char** err);   // provided by the HIP lib or the test build
 }
 
+#define WH_PIPE_MAX_AHEAD 3            // pipelined groups: the device runs at most this many frame steps ahead of the entropy coder
 static thread_local std::string g_last_error;
 static void set_err (const std::string& s) { g_last_error = s; }
 
@@ -77,7 +79,7 @@ struct SessionCore {
   int ring = 1;                       // number of source slots resident in HBM
   std::vector<uint8_t*> d_src;        // [ring] source pictures, MB-aligned dims, macroblock-tiled (WH_SRC_*)
   uint8_t* d_src_planar = nullptr;    // where an upload lands (Y | U | V, tight strides) before the device rearranges it into its slot
-  DevPicture pic[3];                  // reconstruction pictures: two (current / reference); a pipelined group adds a third (see Pending)
+  DevPicture pic[WH_PIPE_MAX_AHEAD + 2];   // reconstruction pictures: two (current / reference); a pipelined group adds one per step it runs ahead (see Pending)
   int nbuf = 2;
   int cur = 0;
   int ref_of (int c) const { return (c + nbuf - 1) % nbuf; }
@@ -125,23 +127,25 @@ struct SessionCore {
   // reconstruction picture (a picture whose entropy coding hits a CAVLC overflow is coded again on the device after its successor has
   // already been: its reference must still exist).
   struct Pending { bool valid = false, idr = false; int frame_num = 0, buf = 0; WhPicJob job; };
-  Pending pend, fin;                  // the picture submitted last; the one being finished (a copy the next submission cannot overwrite)
+  std::deque<Pending> pendq;          // submitted, not yet entropy-coded: oldest first
+  Pending fin;                        // the one being finished (taken off the queue)
+  int depth = 1;                      // buffer sets = steps in flight at most (1 + the steps the device runs ahead)
   bool pipelined = false;
-  uint8_t* d_compact1 = nullptr;
-  std::vector<uint8_t> h_compact1;
-  std::vector<uint8_t> h_src1;
+  uint8_t* d_compact_n[WH_PIPE_MAX_AHEAD] = {};        // buffer sets 1 .. (set 0: the members every group has)
+  std::vector<uint8_t> h_compact_n[WH_PIPE_MAX_AHEAD];
+  std::vector<uint8_t> h_src_n[WH_PIPE_MAX_AHEAD];
+  uint8_t* d_planar_n[WH_PIPE_MAX_AHEAD] = {};         // upload targets (the batch tiling pass of step k reads one while later steps are uploaded)
   int pbuf = 0;                       // which set the picture being submitted uses
-  uint8_t* dcompact (int b) const { return b ? d_compact1 : d_compact; }
+  uint8_t* dcompact (int b) const { return b ? d_compact_n[b - 1] : d_compact; }
   uint32_t* dcompact_off (int b) const { return x_doff[b] ? x_doff[b] : d_compact_off; }
-  std::vector<uint8_t>& hcompact (int b) { return b ? h_compact1 : h_compact; }
+  std::vector<uint8_t>& hcompact (int b) { return b ? h_compact_n[b - 1] : h_compact; }
   uint32_t* hcompact_off (int b) { return x_hoff[b] ? x_hoff[b] : h_compact_off.data(); }
-  std::vector<uint8_t>& hsrc (int b) { return b ? h_src1 : h_src; }
-  uint8_t* planar (int b) const { return b ? d_src_planar1 : d_src_planar; }
+  std::vector<uint8_t>& hsrc (int b) { return b ? h_src_n[b - 1] : h_src; }
+  uint8_t* planar (int b) const { return b ? d_planar_n[b - 1] : d_src_planar; }
   // pipelined groups: the offset tables of all sessions are slices of one device / one page-locked host array per buffer set (one copy
   // brings all of them), owned by the group
-  uint32_t* x_doff[2] = {nullptr, nullptr};
-  uint32_t* x_hoff[2] = {nullptr, nullptr};
-  uint8_t* d_src_planar1 = nullptr;   // second upload target (the batch tiling pass of step k reads the first while step k + 1 is uploaded)
+  uint32_t* x_doff[WH_PIPE_MAX_AHEAD + 1] = {};
+  uint32_t* x_hoff[WH_PIPE_MAX_AHEAD + 1] = {};
 
   static int validate (const WelsHipEncParam* p) {
     // same spirit as ParamValidationExt (encoder_ext.cpp:403-680)
@@ -348,30 +352,34 @@ struct SessionCore {
     return WELSHIP_OK;
   }
 
-  // third reconstruction picture, second record / staging buffers (needs the packed records); before the first picture
-  int enable_pipeline (uint32_t* const doff[2], uint32_t* const hoff[2]) {
+  // `ahead` more reconstruction pictures and record / staging / upload buffer sets (needs the packed records); before the first picture
+  int enable_pipeline (int ahead, uint32_t* const* doff, uint32_t* const* hoff) {
     if (pipelined) return WELSHIP_OK;
+    if (ahead < 1 || ahead > WH_PIPE_MAX_AHEAD) return WELSHIP_ERR_INIT_PARA;
     if (!use_compact || frame_index != 0 || have_recon) { set_err ("pipelined groups need packed records and must be switched on before the first picture"); return WELSHIP_ERR_UNSUPPORTED; }
     if (prm.bEnableSceneChangeDetect) { set_err ("pipelined groups: scene-change detection reads a device statistic back before every picture"); return WELSHIP_ERR_UNSUPPORTED; }
     const size_t rec_y = (size_t)seq.rec_stride_y * (mb_h * 16 + 64), rec_c = (size_t)seq.rec_stride_c * ((mb_h * 16 + 64) / 2);
-    DevPicture& d = pic[2];
-    d.base = (uint8_t*)be->alloc (DevPicture::alloc_bytes (rec_alloc_bytes + 128));
-    d.mbs = (WhMbState*)be->alloc (sizeof (WhMbState) * num_mb);
-    d_compact1 = (uint8_t*)be->alloc ((size_t)num_mb * WH_COMPACT_MAX_BYTES);
-    d_src_planar1 = (uint8_t*)be->alloc (src_bytes);
-    for (int b = 0; b < 2; ++b) { x_doff[b] = doff[b]; x_hoff[b] = hoff[b]; }
-    if (!d.base || !d.mbs || !d_compact1 || !d_src_planar1) { set_err ("out of device memory"); return WELSHIP_ERR_MEMORY; }
-    be->fill (d.base, 0, DevPicture::alloc_bytes (rec_alloc_bytes + 128));
-    d.place_tiles (rec_alloc_bytes + 128, rec_y);
-    d.plane[0] = d.base + 64 + (size_t)32 * seq.rec_stride_y + 32;
-    d.plane[1] = d.base + 64 + rec_y + (size_t)16 * seq.rec_stride_c + 16;
-    d.plane[2] = d.base + 64 + rec_y + rec_c + (size_t)16 * seq.rec_stride_c + 16;
-    be->fill (d.mbs, 0, sizeof (WhMbState) * num_mb);
-    h_compact1.resize ((size_t)num_mb * WH_COMPACT_MAX_BYTES);
-    be->pin_host (h_compact1.data(), h_compact1.size());
-    h_src1 = h_src;                     // (keeps the padding values of the MB-alignment area)
-    be->pin_host (h_src1.data(), src_bytes);
-    nbuf = 3;
+    for (int k = 0; k < ahead; ++k) {
+      DevPicture& d = pic[2 + k];
+      d.base = (uint8_t*)be->alloc (DevPicture::alloc_bytes (rec_alloc_bytes + 128));
+      d.mbs = (WhMbState*)be->alloc (sizeof (WhMbState) * num_mb);
+      d_compact_n[k] = (uint8_t*)be->alloc ((size_t)num_mb * WH_COMPACT_MAX_BYTES);
+      d_planar_n[k] = (uint8_t*)be->alloc (src_bytes);
+      if (!d.base || !d.mbs || !d_compact_n[k] || !d_planar_n[k]) { set_err ("out of device memory"); return WELSHIP_ERR_MEMORY; }
+      be->fill (d.base, 0, DevPicture::alloc_bytes (rec_alloc_bytes + 128));
+      d.place_tiles (rec_alloc_bytes + 128, rec_y);
+      d.plane[0] = d.base + 64 + (size_t)32 * seq.rec_stride_y + 32;
+      d.plane[1] = d.base + 64 + rec_y + (size_t)16 * seq.rec_stride_c + 16;
+      d.plane[2] = d.base + 64 + rec_y + rec_c + (size_t)16 * seq.rec_stride_c + 16;
+      be->fill (d.mbs, 0, sizeof (WhMbState) * num_mb);
+      h_compact_n[k].resize ((size_t)num_mb * WH_COMPACT_MAX_BYTES);
+      be->pin_host (h_compact_n[k].data(), h_compact_n[k].size());
+      h_src_n[k] = h_src;                     // (keeps the padding values of the MB-alignment area)
+      be->pin_host (h_src_n[k].data(), src_bytes);
+    }
+    for (int b2 = 0; b2 <= ahead; ++b2) { x_doff[b2] = doff[b2]; x_hoff[b2] = hoff[b2]; }
+    nbuf = 2 + ahead;
+    depth = 1 + ahead;
     pipelined = true;
     return WELSHIP_OK;
   }
@@ -379,17 +387,21 @@ struct SessionCore {
   void release() {
     if (!be) return;
     if (pipelined) {
-      be->unpin_host (h_compact1.data()); be->unpin_host (h_src1.data());
-      if (d_compact1) be->free (d_compact1);
-      if (d_src_planar1) be->free (d_src_planar1);
-      d_compact1 = nullptr; d_src_planar1 = nullptr; pipelined = false; nbuf = 2;
-      for (int b = 0; b < 2; ++b) { x_doff[b] = nullptr; x_hoff[b] = nullptr; }
+      for (int k = 0; k < WH_PIPE_MAX_AHEAD; ++k) {
+        if (!h_compact_n[k].empty()) be->unpin_host (h_compact_n[k].data());
+        if (!h_src_n[k].empty()) be->unpin_host (h_src_n[k].data());
+        if (d_compact_n[k]) be->free (d_compact_n[k]);
+        if (d_planar_n[k]) be->free (d_planar_n[k]);
+        d_compact_n[k] = nullptr; d_planar_n[k] = nullptr;
+      }
+      pipelined = false; nbuf = 2; depth = 1;
+      for (int b = 0; b <= WH_PIPE_MAX_AHEAD; ++b) { x_doff[b] = nullptr; x_hoff[b] = nullptr; }
     }
     for (uint8_t* p : d_src) if (p) be->free (p);
     d_src.clear();
     if (d_src_planar) be->free (d_src_planar);
     d_src_planar = nullptr;
-    for (int i = 0; i < 3; ++i) { if (pic[i].base) be->free (pic[i].base); if (pic[i].mbs) be->free (pic[i].mbs); pic[i] = DevPicture(); }
+    for (int i = 0; i < WH_PIPE_MAX_AHEAD + 2; ++i) { if (pic[i].base) be->free (pic[i].base); if (pic[i].mbs) be->free (pic[i].mbs); pic[i] = DevPicture(); }
     if (d_records) be->free (d_records);
     d_records = nullptr;
     if (d_compact) be->free (d_compact);
@@ -556,15 +568,17 @@ struct SessionCore {
     return WELSHIP_OK;
   }
   // Pipelined groups: the picture has been handed to the device; the stream state moves on at once (the next picture is begun while
-  // this one is still being coded), what the entropy coder will need is kept in `pend`.
+  // this one is still being coded), what the entropy coder will need is queued in `pendq`.
   void submit_advance() {
+    Pending pend;
     pend.valid = true; pend.idr = cur_idr; pend.frame_num = frame_num; pend.buf = pbuf; pend.job = cur_job;
+    pendq.push_back (pend);
     pic[cur].is_p = !cur_idr;
     have_recon = true;
     ++frame_index;
     frame_num = (frame_num + 1) & 0x7fff;
     cur = next_of (cur);
-    pbuf ^= 1;
+    pbuf = (pbuf + 1) % depth;
   }
   int finish_pending (WelsHipFrameBSInfo* out) {
     return entropy_frame (out, 0, true, fin.idr, fin.frame_num, hcompact (fin.buf).data(), hcompact_off (fin.buf));
@@ -802,14 +816,17 @@ struct WelsHipEncoderGroup {
   // pipelined mode (WelsHipGroupSetPipelined / WelsHipGroupEncodeFramesPipelined): second job array (the device may still read step
   // k - 1's descriptors when step k's are uploaded), page-locked host copies, one spare descriptor for re-runs
   bool pipelined = false;
-  WhPicJob* d_jobs1 = nullptr;
+  int depth = 1;                      // buffer sets: 1 + the steps the device may run ahead of the entropy coder
+  WhPicJob* d_jobs_n[WH_PIPE_MAX_AHEAD + 1] = {};   // per buffer set ([0] = d_jobs)
   WhPicJob* d_job_aux = nullptr;
-  std::vector<WhPicJob> h_jobs_p[2];
+  std::vector<WhPicJob> h_jobs_p[WH_PIPE_MAX_AHEAD + 1];
   long step_no = 0;
-  bool pending = false;               // a submitted step whose pictures have not been entropy-coded yet
-  uint32_t* d_off_all[2] = {nullptr, nullptr};      // the sessions' record offset tables, one array per buffer set
-  std::vector<uint32_t> h_off_all[2];
+  int pending = 0;                    // submitted steps whose pictures have not been entropy-coded yet
+  uint32_t* d_off_all[WH_PIPE_MAX_AHEAD + 1] = {};  // the sessions' record offset tables, one array per buffer set
+  std::vector<uint32_t> h_off_all[WH_PIPE_MAX_AHEAD + 1];
   std::vector<void*> dl_ev;           // one event per session: its records have arrived
+  void* step_ev[WH_PIPE_MAX_AHEAD + 1] = {};        // per buffer set: the kernels of the step that uses it have run
+  void* up_ev[2][WH_PIPE_MAX_AHEAD + 1] = {};       // per upload queue and buffer set: the transfers out of its staging buffers are done
   // thread time the host side of the frame steps has taken so far (WelsHipGroupHostStats): [0] staging copies, [1] entropy coding
   std::mutex stat_mu;
   double host_ms[2] = {0.0, 0.0};
@@ -1038,10 +1055,14 @@ void WelsHipGroupDestroy (WelsHipEncoderGroup* g) {
   g->be->sync();
   for (auto& s : g->sess) s->release();
   if (g->pipelined) {
-    for (int b = 0; b < 2; ++b) if (!g->h_jobs_p[b].empty()) g->be->unpin_host (g->h_jobs_p[b].data());
-    for (int b = 0; b < 2; ++b) { if (!g->h_off_all[b].empty()) g->be->unpin_host (g->h_off_all[b].data()); if (g->d_off_all[b]) g->be->free (g->d_off_all[b]); }
+    for (int b = 0; b <= WH_PIPE_MAX_AHEAD; ++b) {
+      if (!g->h_jobs_p[b].empty()) g->be->unpin_host (g->h_jobs_p[b].data());
+      if (!g->h_off_all[b].empty()) g->be->unpin_host (g->h_off_all[b].data());
+      if (g->d_off_all[b]) g->be->free (g->d_off_all[b]);
+      if (b && g->d_jobs_n[b]) g->be->free (g->d_jobs_n[b]);
+      g->be->event_destroy (g->step_ev[b]); g->be->event_destroy (g->up_ev[0][b]); g->be->event_destroy (g->up_ev[1][b]);
+    }
     for (void* e : g->dl_ev) g->be->event_destroy (e);
-    if (g->d_jobs1) g->be->free (g->d_jobs1);
     if (g->d_job_aux) g->be->free (g->d_job_aux);
   }
   g->be->free (g->d_jobs);
@@ -1173,7 +1194,7 @@ int WelsHipGroupFinish (WelsHipEncoderGroup* g, WelsHipFrameBSInfo* outs) {
 
 int WelsHipGroupEncodeFrames (WelsHipEncoderGroup* g, const WelsHipSourcePicture* srcs, WelsHipFrameBSInfo* outs) {
   if (!g || !srcs) return WELSHIP_ERR_INIT_PARA;
-  if (g->pending) { set_err ("a pipelined step is pending: finish it first (WelsHipGroupEncodeFramesPipelined with no pictures)"); return WELSHIP_ERR_INIT_PARA; }
+  if (g->pending > 0) { set_err ("a pipelined step is pending: finish it first (WelsHipGroupEncodeFramesPipelined with no pictures)"); return WELSHIP_ERR_INIT_PARA; }
   const int n = (int)g->sess.size();
   const int slot = (g->sess[0]->last_slot + 1) % g->sess[0]->ring;    // never the slot of the previous picture
   for (int i = 0; i < n; ++i) {
@@ -1207,67 +1228,75 @@ int WelsHipGroupEncodeFrames (WelsHipEncoderGroup* g, const WelsHipSourcePicture
 // third reconstruction picture: when the entropy coder finds a CAVLC overflow in step k - 1 (TRY_REENCODING, rare), that picture is
 // coded again on the device (its reference, step k - 2, still exists) and then its already submitted successor once more.
 // Queues: 0 = kernels, WH_PIPE_UPQ = uploads, WH_PIPE_DLQ = downloads.
-static int pipe_queue (int which) {            // WELSHIP_PIPE_QUEUES=upload,download (experiment knob; default 1,2)
-  static int q[2] = {-1, -1};
-  if (q[0] < 0) {
-    int a = 1, b = 2;          // (measured: queues 30 and 31 share a hardware queue with queue 0 -- their copies waited for its kernels; profiles/r03_pipelined_group.txt)
-    if (const char* e = getenv ("WELSHIP_PIPE_QUEUES")) sscanf (e, "%d,%d", &a, &b);
-    q[1] = b; q[0] = a;
+static int pipe_queue (int which) {            // WELSHIP_PIPE_QUEUES=upload,download[,second upload] (experiment knob; default 1,2, no second one)
+  static int q[3] = {-2, -2, -2};
+  if (q[0] == -2) {
+    int a = 1, b = 2, c = -1;      // (measured: queues 30 and 31 share a hardware queue with queue 0 -- their copies waited for its kernels; profiles/r03_pipelined_group.txt)
+    if (const char* e = getenv ("WELSHIP_PIPE_QUEUES")) sscanf (e, "%d,%d,%d", &a, &b, &c);
+    q[2] = c; q[1] = b; q[0] = a;
   }
   return q[which];
 }
 #define WH_PIPE_UPQ pipe_queue (0)
 #define WH_PIPE_DLQ pipe_queue (1)
-int WelsHipGroupSetPipelined (WelsHipEncoderGroup* g, int on) {
+#define WH_PIPE_UPQ2 pipe_queue (2)
+int WelsHipGroupSetPipelined (WelsHipEncoderGroup* g, int ahead) {
   if (!g) return WELSHIP_ERR_INIT_PARA;
-  if (!on) { if (g->pending) { set_err ("a submitted step is still pending: flush first"); return WELSHIP_ERR_INIT_PARA; } return WELSHIP_OK; }
+  if (ahead <= 0) { if (g->pending) { set_err ("submitted steps are still pending: flush first"); return WELSHIP_ERR_INIT_PARA; } return WELSHIP_OK; }
   if (g->pipelined) return WELSHIP_OK;
+  if (ahead > WH_PIPE_MAX_AHEAD) { set_err ("pipelined groups: at most 3 steps ahead"); return WELSHIP_ERR_INIT_PARA; }
   if (g->queues != 1) { set_err ("pipelined groups use one compute queue (WELSHIP_QUEUES=1)"); return WELSHIP_ERR_UNSUPPORTED; }
-  const int n = (int)g->sess.size();
+  const int n = (int)g->sess.size(), depth = 1 + ahead;
   const size_t off_words = (size_t)g->sess[0]->num_mb + 1;
-  uint32_t* doff[2];
-  for (int b = 0; b < 2; ++b) {
+  for (int b = 0; b < depth; ++b) {
     g->d_off_all[b] = (uint32_t*)g->be->alloc (sizeof (uint32_t) * off_words * n);
     g->h_off_all[b].assign (off_words * n, 0);
     g->be->pin_host (g->h_off_all[b].data(), sizeof (uint32_t) * off_words * n);
-    if (!g->d_off_all[b]) { set_err ("out of device memory"); return WELSHIP_ERR_MEMORY; }
+    g->d_jobs_n[b] = b ? (WhPicJob*)g->be->alloc (sizeof (WhPicJob) * n) : g->d_jobs;
+    if (!g->d_off_all[b] || !g->d_jobs_n[b]) { set_err ("out of device memory"); return WELSHIP_ERR_MEMORY; }
+    g->h_jobs_p[b].assign (n, WhPicJob());
+    g->be->pin_host (g->h_jobs_p[b].data(), sizeof (WhPicJob) * n);
+    g->step_ev[b] = g->be->event_create(); g->up_ev[0][b] = g->be->event_create(); g->up_ev[1][b] = g->be->event_create();
   }
   for (int i = 0; i < n; ++i) {
-    uint32_t* hoff[2];
-    for (int b = 0; b < 2; ++b) { doff[b] = g->d_off_all[b] + off_words * i; hoff[b] = g->h_off_all[b].data() + off_words * i; }
-    const int rc = g->sess[i]->enable_pipeline (doff, hoff);
+    uint32_t* doff[WH_PIPE_MAX_AHEAD + 1];
+    uint32_t* hoff[WH_PIPE_MAX_AHEAD + 1];
+    for (int b = 0; b < depth; ++b) { doff[b] = g->d_off_all[b] + off_words * i; hoff[b] = g->h_off_all[b].data() + off_words * i; }
+    const int rc = g->sess[i]->enable_pipeline (ahead, doff, hoff);
     if (rc) return rc;
   }
-  g->d_jobs1 = (WhPicJob*)g->be->alloc (sizeof (WhPicJob) * n);
   g->d_job_aux = (WhPicJob*)g->be->alloc (sizeof (WhPicJob));
-  if (!g->d_jobs1 || !g->d_job_aux) { set_err ("out of device memory"); return WELSHIP_ERR_MEMORY; }
-  for (int b = 0; b < 2; ++b) { g->h_jobs_p[b].assign (n, WhPicJob()); g->be->pin_host (g->h_jobs_p[b].data(), sizeof (WhPicJob) * n); }
+  if (!g->d_job_aux) { set_err ("out of device memory"); return WELSHIP_ERR_MEMORY; }
   g->dl_ev.assign (n, nullptr);
   for (int i = 0; i < n; ++i) g->dl_ev[i] = g->be->event_create();
   if (g->be->sync()) { set_err ("device error while setting up the pipelined group"); return WELSHIP_ERR_UNKNOWN; }
+  g->depth = depth;
   g->pipelined = true;
   return WELSHIP_OK;
 }
 
 namespace {
 // The submitting half of a pipelined call (the calling thread): staging copies and H2D transfers on the worker threads, then the jobs
-// and the kernels.  Nothing here waits for the device beyond the upload queue's work of two steps ago.
+// and the kernels.  Nothing here waits for the device beyond the transfers out of the staging set it is about to refill (`depth` steps ago).
 int pipe_submit (WelsHipEncoderGroup* g, const WelsHipSourcePicture* srcs, double* tm, const std::function<double()>& now) {
   wh::Backend* be = g->be;
   const int n = (int)g->sess.size();
   SessionCore& c0 = *g->sess[0];
   const int slot = (c0.last_slot + 1) % c0.ring;
-  const int sb = (int) (g->step_no & 1);
+  const int sb = (int) (g->step_no % g->depth);
+  const int upq[2] = {WH_PIPE_UPQ, WH_PIPE_UPQ2 >= 0 ? WH_PIPE_UPQ2 : WH_PIPE_UPQ};
   for (int i = 0; i < n; ++i) if (srcs[i].iPicWidth != g->sess[i]->prm.iPicWidth || srcs[i].iPicHeight != g->sess[i]->prm.iPicHeight) return WELSHIP_ERR_INIT_PARA;
   for (int i = 0; i < n; ++i) { const int rc = g->sess[i]->begin_frame_check(); if (rc) return rc; }      // nothing queued yet: the group stays in step
-  if (be->sync_queue (WH_PIPE_UPQ)) { set_err ("device error on the upload queue"); return WELSHIP_ERR_UNKNOWN; }     // staging set sb is free again (step k - 2's transfers)
+  if (g->step_no >= g->depth) { be->event_wait (g->up_ev[0][sb]); if (upq[1] != upq[0]) be->event_wait (g->up_ev[1][sb]); }     // staging set sb is free again
   tm[0] = now();
   g->parallel (n, [&] (int t, int T) {
     const auto t0 = std::chrono::steady_clock::now();
     int k = 0;
-    for (int i = t; i < n; i += T, ++k) g->sess[i]->stage_and_upload (&srcs[i], sb, WH_PIPE_UPQ);
+    for (int i = t; i < n; i += T, ++k) g->sess[i]->stage_and_upload (&srcs[i], sb, upq[i & 1]);
     g->note_host_time (0, std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now() - t0).count(), k);
   });
+  be->event_record_on (upq[0], g->up_ev[0][sb]);
+  if (upq[1] != upq[0]) be->event_record_on (upq[1], g->up_ev[1][sb]);
   tm[1] = now();
   // describe the pictures (P pictures first, then IDR pictures, as WelsHipGroupBegin orders them)
   std::vector<WhPicJob> jobs (n);
@@ -1285,9 +1314,10 @@ int pipe_submit (WelsHipEncoderGroup* g, const WelsHipSourcePicture* srcs, doubl
   for (int i = 0; i < n; ++i) if (g->sess[i]->cur_idr) g->order[k++] = i;
   std::vector<WhPicJob>& hj = g->h_jobs_p[sb];
   for (int j = 0; j < n; ++j) hj[j] = jobs[g->order[j]];
-  WhPicJob* dj = sb ? g->d_jobs1 : g->d_jobs;
+  WhPicJob* dj = g->d_jobs_n[sb];
   be->select_queue (0);
-  be->queue_wait (WH_PIPE_UPQ);                         // the kernels wait (on the device) for this step's sources
+  be->queue_wait_event (0, g->up_ev[0][sb]);            // the kernels wait (on the device) for this step's sources
+  if (upq[1] != upq[0]) be->queue_wait_event (0, g->up_ev[1][sb]);
   be->upload (dj, hj.data(), sizeof (WhPicJob) * n);
   const WhSeqParams& s = c0.seq;
   be->run_src_tile_jobs (s, dj, n);
@@ -1296,6 +1326,7 @@ int pipe_submit (WelsHipEncoderGroup* g, const WelsHipSourcePicture* srcs, doubl
   be->run_compact (s, dj, n);
   if (s.deblock_idc != 1) be->run_deblock (s, dj, n);
   if (c0.prm.uiIntraPeriod != 1) be->run_expand (s, dj, n);
+  be->event_record (g->step_ev[sb]);                    // what the download queue will wait for before it copies this step's records
   for (auto& c : g->sess) c->submit_advance();
   ++g->step_no;
   tm[2] = now();
@@ -1310,7 +1341,8 @@ int pipe_finish (WelsHipEncoderGroup* g, WelsHipFrameBSInfo* outs, std::vector<i
   const int n = (int)g->sess.size();
   const int fb = g->sess[0]->fin.buf;                   // (the sessions advance in lock step)
   const size_t off_words = (size_t)g->sess[0]->num_mb + 1;
-  be->download_on (WH_PIPE_DLQ, g->h_off_all[fb].data(), g->d_off_all[fb], sizeof (uint32_t) * off_words * n);   // (the queue waits for that step's kernels: queue_wait at its submission)
+  be->queue_wait_event (WH_PIPE_DLQ, g->step_ev[fb]);   // that step's kernels, not the later steps'
+  be->download_on (WH_PIPE_DLQ, g->h_off_all[fb].data(), g->d_off_all[fb], sizeof (uint32_t) * off_words * n);
   if (be->sync_queue (WH_PIPE_DLQ) || be->peek_queue_errors (0, WH_PIPE_DLQ)) { set_err ("device scheduler timed out; the step was not encoded"); return WELSHIP_ERR_UNKNOWN; }
   tm[3] = now();
   for (int i = 0; i < n; ++i) {
@@ -1337,42 +1369,57 @@ int pipe_finish (WelsHipEncoderGroup* g, WelsHipFrameBSInfo* outs, std::vector<i
   tm[5] = now();
   return WELSHIP_OK;
 }
+
+// One picture of session c again on the device, alone, with everything waited for: `job` as it was submitted (a fresh filter generation)
+int pipe_rerun (WelsHipEncoderGroup* g, SessionCore& c, WhPicJob* job, bool idr) {
+  wh::Backend* be = g->be;
+  if (++c.db_gen == 0) c.db_gen = 1;
+  job->db_gen = c.db_gen;
+  job->src[1] = nullptr;                               // (the source is tiled already)
+  be->upload (g->d_job_aux, job, sizeof (WhPicJob));
+  if (idr) be->run_intra (c.seq, g->d_job_aux, 1); else be->run_inter (c.seq, g->d_job_aux, 1);
+  be->run_compact (c.seq, g->d_job_aux, 1);
+  if (c.seq.deblock_idc != 1) be->run_deblock (c.seq, g->d_job_aux, 1);
+  if (c.prm.uiIntraPeriod != 1) be->run_expand (c.seq, g->d_job_aux, 1);
+  if (be->sync()) { set_err ("device scheduler timed out; the picture was not encoded"); return WELSHIP_ERR_UNKNOWN; }
+  return WELSHIP_OK;
+}
 }  // namespace
 
-// srcs != NULL: submit a step with these source pictures.  If a step was pending before this call, it is finished meanwhile: its
-// bitstreams go to outs[] and *pFinished = 1.  srcs == NULL: only finish what is pending (the end of the streams).
+// srcs != NULL: submit a step with these source pictures.  When as many steps are pending as the group may run ahead, the oldest one is
+// finished meanwhile: its bitstreams go to outs[] and *pFinished = 1.  srcs == NULL: finish the oldest pending step (the end of the
+// streams: call until *pFinished stays 0).
 int WelsHipGroupEncodeFramesPipelined (WelsHipEncoderGroup* g, const WelsHipSourcePicture* srcs, WelsHipFrameBSInfo* outs, int* pFinished) {
   if (!g || !g->pipelined) { set_err ("not a pipelined group (WelsHipGroupSetPipelined)"); return WELSHIP_ERR_INIT_PARA; }
   if (pFinished) *pFinished = 0;
   wh::Backend* be = g->be;
   const int n = (int)g->sess.size();
-  const bool had_pending = g->pending;
+  const bool finish = srcs ? g->pending >= g->depth - 1 : g->pending > 0;
   // WELSHIP_PIPE_TRACE=1: where the host spends a call (ms since its start), on stderr
   static const bool trace = getenv ("WELSHIP_PIPE_TRACE") && atoi (getenv ("WELSHIP_PIPE_TRACE")) != 0;
   const auto tc0 = std::chrono::steady_clock::now();
   const std::function<double()> now = [&] () { return std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now() - tc0).count(); };
   double tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (had_pending) for (auto& c : g->sess) c->fin = c->pend;
+  if (finish) for (auto& c : g->sess) { c->fin = c->pendq.front(); c->pendq.pop_front(); }
   std::vector<int> rcs (n, 0);
   int frc = WELSHIP_OK, src_rc = WELSHIP_OK;
   std::string ferr;
   std::thread fth;
-  if (had_pending) {
+  if (finish) {
     if (srcs) fth = std::thread ([&] { frc = pipe_finish (g, outs, rcs, tm, now); if (frc) ferr = g_last_error; });
     else frc = pipe_finish (g, outs, rcs, tm, now);
+    --g->pending;
   }
   const bool submitted = srcs != nullptr && (src_rc = pipe_submit (g, srcs, tm, now)) == WELSHIP_OK;
   if (fth.joinable()) { fth.join(); if (frc) set_err (ferr); }
-  if (trace) fprintf (stderr, "welship pipe: submit half: upload queue free %.2f, staged + H2D queued %.2f, kernels queued %.2f | finish half: step k-1 done on the device %.2f, copies queued %.2f, entropy-coded %.2f ms\n",
+  if (submitted) ++g->pending;
+  if (trace) fprintf (stderr, "welship pipe: submit half: staging set free %.2f, staged + H2D queued %.2f, kernels queued %.2f | finish half: that step done on the device %.2f, copies queued %.2f, entropy-coded %.2f ms\n",
                       tm[0], tm[1], tm[2], tm[3], tm[4], tm[5]);
-  if (srcs && src_rc) {             // nothing of this step was queued (the checks come first) unless the device itself failed
-    g->pending = false;
-    return src_rc;
-  }
-  if (frc) { g->pending = submitted; return frc; }
-  if (had_pending) {
-    // CAVLC overflow (rare): that picture again with the macroblock's QP raised, then the picture submitted after it -- it predicted from
-    // the reconstruction that has just been replaced.  Everything the device has queued is waited for first.
+  if (srcs && src_rc) return src_rc;      // nothing of this step was queued (the checks come first) unless the device itself failed
+  if (frc) return frc;
+  if (finish) {
+    // CAVLC overflow (rare): that picture again with the macroblock's QP raised, then the pictures submitted after it, oldest first -- each
+    // predicted from a reconstruction that has just been replaced.  Everything the device has queued is waited for first.
     for (int i = 0; i < n; ++i) {
       if (rcs[i] != WELSHIP_ERR_VLC_OVERFLOW) continue;
       SessionCore& c = *g->sess[i];
@@ -1394,31 +1441,15 @@ int WelsHipGroupEncodeFramesPipelined (WelsHipEncoderGroup* g, const WelsHipSour
       }
       if (!c.h_mb_ctl.empty()) memset (c.h_mb_ctl.data(), 0, sizeof (WhMbCtl) * c.h_mb_ctl.size());   // the QP map belonged to that picture only
       c.qp_map_in_use = false;
-      if (rcs[i] == WELSHIP_OK && submitted) {
-        if (++c.db_gen == 0) c.db_gen = 1;
-        c.cur_job.db_gen = c.db_gen;
-        c.pend.job = c.cur_job;
-        be->upload (g->d_job_aux, &c.cur_job, sizeof (WhPicJob));
-        if (c.cur_idr) be->run_intra (c.seq, g->d_job_aux, 1); else be->run_inter (c.seq, g->d_job_aux, 1);
-        be->run_compact (c.seq, g->d_job_aux, 1);
-        if (c.seq.deblock_idc != 1) be->run_deblock (c.seq, g->d_job_aux, 1);
-        if (need_ref) be->run_expand (c.seq, g->d_job_aux, 1);
-        if (be->sync()) { set_err ("device scheduler timed out; the picture was not encoded"); rcs[i] = WELSHIP_ERR_UNKNOWN; }
-      }
+      for (size_t k = 0; k < c.pendq.size() && rcs[i] == WELSHIP_OK; ++k) rcs[i] = pipe_rerun (g, c, &c.pendq[k].job, c.pendq[k].idr);
+      if (!c.pendq.empty()) c.cur_job = c.pendq.back().job;
     }
     for (int i = 0; i < n; ++i) if (rcs[i]) {
       set_err ("session " + std::to_string (i) + (rcs[i] == WELSHIP_ERR_MEMORY ? ": frame does not fit the reference encoder's bitstream buffer (cmMallocMemeError)"
                                                                                : ": entropy coding of the frame failed"));
-      g->pending = submitted;
       return rcs[i];
     }
     if (pFinished) *pFinished = 1;
-  }
-  g->pending = submitted;
-  if (submitted) {                 // the download queue will wait for this step's kernels
-    be->select_queue (WH_PIPE_DLQ);
-    be->queue_wait (0);
-    be->select_queue (0);
   }
   return WELSHIP_OK;
 }

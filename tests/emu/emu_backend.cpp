@@ -234,6 +234,7 @@ class EmuBackend : public Backend {
   void download_on (int, void* dst, const void* src, size_t bytes) override { memcpy (dst, src, bytes); }
   void event_record_on (int, void* ev) override { event_record (ev); }
   void event_wait (void*) override {}
+  void queue_wait_event (int, void*) override {}
   void run_src_tile_jobs (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
     for (int i = 0; i < n; ++i) if (jobs[i].src[1]) run_src_tile (P, jobs[i].src[1], (uint8_t*)jobs[i].src[0]);
   }

@@ -247,7 +247,7 @@ def test_bench_line_from_two_ranks_on_the_cpu_test_build(emu_lib):
 
 
 # ---- pipelined groups: WelsHipGroupEncodeFramesPipelined returns step k - 1's streams while the device codes step k -------------
-def _pipelined_vs_synchronous(lib, w, h, frames, qp, contents, ring, intra_period=0, threads=2):
+def _pipelined_vs_synchronous(lib, w, h, frames, qp, contents, ring, intra_period=0, threads=2, ahead=1):
     import openh264_amd as oh
     from openh264_amd.utils.synth import make_sequence
     fsz = w * h * 3 // 2
@@ -261,24 +261,25 @@ def _pipelined_vs_synchronous(lib, w, h, frames, qp, contents, ring, intra_perio
     for mode in ("sync", "pipe"):
         g = oh.EncoderGroup(p, len(seqs), ring_slots=ring, host_threads=threads, lib_path=lib)
         if mode == "pipe":
-            g.set_pipelined()
+            g.set_pipelined(ahead)
         got = [bytearray() for _ in seqs]
         steps = 0
         for f in range(frames):
             pics = g.make_pictures([s[f * fsz:(f + 1) * fsz] for s in seqs])
             res = g.encode_frames(pics, want_bytes=True) if mode == "sync" else g.encode_frames_pipelined(pics, want_bytes=True)
             if mode == "pipe":
-                assert (res is None) == (f == 0)          # one call late
+                assert (res is None) == (f < ahead)       # `ahead` calls late
             if res is not None:
                 steps += 1
                 for s, bs in enumerate(res):
                     got[s] += bs
-        if mode == "pipe":
+        while mode == "pipe":
             res = g.encode_frames_pipelined(None, want_bytes=True)
+            if res is None:                                   # nothing pending any more
+                break
             steps += 1
             for s, bs in enumerate(res):
                 got[s] += bs
-            assert g.encode_frames_pipelined(None) is None    # nothing pending any more
         assert steps == frames
         out[mode] = ([bytes(b) for b in got], g.recon(0))
         g.close()
@@ -287,16 +288,17 @@ def _pipelined_vs_synchronous(lib, w, h, frames, qp, contents, ring, intra_perio
     return seqs, out["pipe"][0]
 
 
-@pytest.mark.parametrize("ring", [2, 3])
-def test_pipelined_group_matches_the_synchronous_one(emu_lib, ring):
-    _pipelined_vs_synchronous(emu_lib, 64, 48, 6, 26, ("synth", "checker5", "synth"), ring, intra_period=4)
+@pytest.mark.parametrize("ring,ahead", [(2, 1), (3, 1), (3, 2), (2, 3)])
+def test_pipelined_group_matches_the_synchronous_one(emu_lib, ring, ahead):
+    _pipelined_vs_synchronous(emu_lib, 64, 48, 7, 26, ("synth", "checker5", "synth"), ring, intra_period=4, ahead=ahead)
 
 
-def test_pipelined_group_reencodes_after_cavlc_overflow(emu_lib):
+@pytest.mark.parametrize("ahead", [1, 2])
+def test_pipelined_group_reencodes_after_cavlc_overflow(emu_lib, ahead):
     """QP 3 on checkerboards: pictures in the middle and at the end of the stream overflow the CAVLC level range, when their successor
     is already on the device: the picture is coded again, then the successor (it predicted from the replaced reconstruction)."""
     import openh264_amd as oh
-    seqs, got = _pipelined_vs_synchronous(emu_lib, 64, 64, 4, 3, ("synth", "checker5", "synth", "checker8"), 3)
+    seqs, got = _pipelined_vs_synchronous(emu_lib, 64, 64, 4, 3, ("synth", "checker5", "synth", "checker8"), 3, ahead=ahead)
     for s in (1, 3):
         st = {}
         bs, _ = oh.encode_sequence(seqs[s], 64, 64, lib_path=emu_lib, stats=st, iDLayerQp=3, uiIntraPeriod=0, fMaxFrameRate=30.0, iTargetBitrate=5000000)
@@ -317,10 +319,12 @@ def test_pipelined_group_refuses_what_it_cannot_do(emu_lib):
 
 
 @pytest.mark.gpu
-def test_hip_pipelined_group_matches_the_synchronous_one(hip_lib):
-    _pipelined_vs_synchronous(hip_lib, 320, 192, 8, 26, ("synth", "checker5", "synth", "pan7"), 3, intra_period=5, threads=4)
+@pytest.mark.parametrize("ahead", [1, 2])
+def test_hip_pipelined_group_matches_the_synchronous_one(hip_lib, ahead):
+    _pipelined_vs_synchronous(hip_lib, 320, 192, 8, 26, ("synth", "checker5", "synth", "pan7"), 3, intra_period=5, threads=4, ahead=ahead)
 
 
 @pytest.mark.gpu
-def test_hip_pipelined_group_reencodes_after_cavlc_overflow(hip_lib):
-    _pipelined_vs_synchronous(hip_lib, 64, 64, 4, 3, ("synth", "checker5", "synth", "checker8"), 3)
+@pytest.mark.parametrize("ahead", [1, 2])
+def test_hip_pipelined_group_reencodes_after_cavlc_overflow(hip_lib, ahead):
+    _pipelined_vs_synchronous(hip_lib, 64, 64, 4, 3, ("synth", "checker5", "synth", "checker8"), 3, ahead=ahead)
