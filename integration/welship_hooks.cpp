@@ -38,6 +38,7 @@
 #include <chrono>
 #include <map>
 #include <mutex>
+#include <atomic>
 #include <vector>
 
 #include "encoder_context.h"
@@ -137,7 +138,7 @@ struct HipLayer {                       // one spatial layer = one device contex
 struct HipState {
   HipLayer layer[MAX_DEPENDENCY_LAYER];
   int device = 0;
-  bool failed = false;                  // a device call failed: the session reports errors from then on
+  std::atomic<bool> failed {false};     // a device call failed: the session reports errors from then on (slice tasks set it concurrently)
   bool trace = false;
   bool layer_devices = false;           // one GPU per simulcast layer
   // WELS_HIP_TRACE=2: where a picture's time goes (seconds, summed): device call incl. transfers, reconstruction copy-back,
@@ -150,7 +151,7 @@ struct HipState {
   long downsampled = 0;
   bool gom_kernel = false;              // WELS_HIP_GOM=2: single-slice rate-controlled P pictures in ONE device call (the QP recursion runs in the kernel)
   bool check_bits = false;              // WELS_HIP_CHECK_BITS=1: the device counts every macroblock's CAVLC bits and the slice loop compares them with the writer
-  long bits_checked = 0;
+  std::atomic<long> bits_checked {0};
   double t_encode = 0.0, t_getpic = 0.0, t_code = 0.0;
   int pictures = 0;
 };
@@ -769,7 +770,7 @@ int32_t HipDownsample (void* p, uint8_t* const pDst[3], const int32_t iDstStride
 void HipRelease (void* p) {
   HipState* st = (HipState*)p;
   if (st == NULL) return;
-  if (st->check_bits && st->trace) fprintf (stderr, "welship hooks: CAVLC bit counts of %ld macroblocks equal the writer's\n", st->bits_checked);
+  if (st->check_bits && st->trace) fprintf (stderr, "welship hooks: CAVLC bit counts of %ld macroblocks equal the writer's\n", st->bits_checked.load());
   if (st->timing && st->pictures) fprintf (stderr, "welship hooks: %d pictures; per picture: device call %.3f ms, reconstruction copy-back %.3f ms, slice coding from the records %.3f ms\n",
                                            st->pictures, 1e3 * st->t_encode / st->pictures, 1e3 * st->t_getpic / st->pictures, 1e3 * st->t_code / st->pictures);
   for (int i = 0; i < MAX_DEPENDENCY_LAYER; ++i) if (st->layer[i].ctx) g_api.FrameCtxDestroy (st->layer[i].ctx);

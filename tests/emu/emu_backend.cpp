@@ -244,7 +244,11 @@ class EmuBackend : public Backend {
   float event_elapsed_ms (void* a, void* b) override { return (float) (* (double*)b - * (double*)a); }
 };
 
-Backend* create_default_backend (int, const char**) { return new EmuBackend(); }
+// WELSHIP_TRACE_DEVICES=1: which device index every backend is asked for (tests of the layer -> device and rank -> device mappings)
+Backend* create_default_backend (int device, const char**) {
+  if (getenv ("WELSHIP_TRACE_DEVICES")) { fprintf (stderr, "welship emu: backend for device %d\n", device); fflush (stderr); }
+  return new EmuBackend();
+}
 
 }  // namespace wh
 

@@ -39,6 +39,7 @@ def _both(lib, tmp_path, yuv, w, h, flags, min_pictures, extra_env=None):
     else:
         assert err.count("down-sampled") >= lower * (min_pictures // (lower + 1)), err[-1500:]
     assert (tmp_path / "ref.264").read_bytes() == (tmp_path / "hip.264").read_bytes()
+    return err
 
 
 SMALL = [
@@ -87,3 +88,17 @@ def test_config4_four_layers_of_the_1080p_clip_on_the_mi355x(hip_lib, ref_tools,
     subprocess.check_call([ref_tools["dec"], os.path.join(RES, "VID_1920x1080_cavlc_temporal_direct.264"), out], stdout=subprocess.DEVNULL)
     yuv = open(out, "rb").read()[: 1920 * 1080 * 3 // 2 * 12]
     _both(hip_lib, tmp_path, yuv, 1920, 1080, rc + CONFIG4, 48)
+
+
+def test_one_device_per_simulcast_layer(emu_lib, tmp_path):
+    """WELS_HIP_LAYER_DEVICES=1: spatial layer d gets a device context on GPU WELS_HIP_DEVICE + d, a backend of its own each (no GPU in
+    the CPU tier: the test build of the kernels reports which device index every backend was asked for); without the switch all layers
+    share device WELS_HIP_DEVICE.  Same access units either way."""
+    import re
+    flags, pictures = SMALL[1]                         # three lower layers + the full-size one
+    for layer_devices, want in (("1", [2, 3, 4, 5]), ("0", [2])):
+        err = _both(emu_lib, tmp_path, synth_sequence(640, 368, 6), 640, 368, flags, pictures,
+                    {"WELS_HIP_DEVICE": "2", "WELS_HIP_LAYER_DEVICES": layer_devices, "WELSHIP_TRACE_DEVICES": "1"})
+        got = sorted(set(int(x) for x in re.findall(r"welship emu: backend for device (\d+)", err)))
+        # (the picture-level down-sampling entry point keeps its own per-device state and is not a backend)
+        assert got == want, (layer_devices, got)
