@@ -52,7 +52,7 @@ WH_FN void wh_tile_fetch_src (int lane, const WhSeqParams& P, const WhPicJob& J,
 }
 // reconstructed neighbour samples (written by the neighbour MBs: only after they are done)
 #ifndef WH_FLAT_NB_LOADS
-#define WH_FLAT_NB_LOADS 0         /* candidate (not yet measured on the device): the neighbour loads of a macroblock as ONE batch */
+#define WH_FLAT_NB_LOADS 1         /* the neighbour loads of a macroblock as ONE batch (measured on the MI355X, round 3: MD launch 13.65 -> 13.18 ms; 0 = one load per role) */
 #endif
 #if WH_FLAT_NB_LOADS
 // One 32-bit load per lane whatever its role, at an address that is valid for every lane, and a select afterwards.  With one
