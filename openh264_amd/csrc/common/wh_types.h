@@ -227,8 +227,10 @@ typedef struct WhPicJob {
                                     //   Only macroblocks whose pre-analysis SADs are not flat can search 8x8 blocks at all (known before the
                                     //   picture starts): each of them waits for the one before it, everything else keeps the 2:1 dependency
                                     //   order -- in a processing order built for the picture that respects both (WhPicJob::scc_order)
+#define WH_SEQ_DB_WHOLE 16          // deblocking launch only (set by the backend on its copy): ONE band = the whole picture, in the picture's own 2:1 order (mb_order's second section)
 #define WH_SEQ_RANGED 8             // the pictures of the launch code MB ranges (WhPicJob::mb_begin / mb_end, dyn_slice) or carry GOM rate control:
                                     //   the ticket scheduler runs them (k_inter_pool); everything without a flag may take the row scheduler
+#define WH_DB_WHOLE_TABLE(P) ((P).db_bands + 3 * (size_t)(P).db_num_bands + 1)
 #define WH_DB_BAND_ROWS 24          // a deblocking band (one workgroup) never spans more MB rows than this
 
 // ---- parameters common to every picture of a launch --------------------------------------------
@@ -254,7 +256,8 @@ typedef struct WhSeqParams {
   // Deblocking bands: the MB ranges the deblocking workgroups own (rows of one slice, at most WH_DB_BAND_ROWS of them: a
   // slice is a band unless it is taller, e.g. a single-slice picture is cut into several).  Device table of
   // 3 * db_num_bands + 1 words: [0, n] first MB of band b (and the end of the last), [n+1, 2n] first MB of the slice band b
-  // lies in, [2n+1, 3n] end of that slice.
+  // lies in, [2n+1, 3n] end of that slice; then four more words: the same table for ONE band that is the whole picture (WH_DB_WHOLE_TABLE) --
+  // what a launch takes when it has about as many pictures as the device has CUs and the filter crosses slice edges anyway (idc 0).
   int32_t db_num_bands, db_max_mbs;     // db_max_mbs / db_max_rows: the largest band (host-side launch geometry)
   const int32_t* db_bands;
   int32_t db_max_rows;

@@ -492,7 +492,7 @@ __global__ __launch_bounds__ (1024) void k_deblock_slices (WhSeqParams P, const 
   // idc 2: nothing is filtered (or needed) across slices -- only the bands of this band's own slice matter
   const bool cross = P.deblock_idc == 0;
   const int sfirst = cross ? 0 : P.db_bands[nb + 1 + blockIdx.x], slast = cross ? num_mb : P.db_bands[2 * nb + 1 + blockIdx.x];
-  const uint32_t* order = P.mb_order + 2 * num_mb + first;
+  const uint32_t* order = (P.flags & WH_SEQ_DB_WHOLE) ? P.mb_order + num_mb : P.mb_order + 2 * num_mb + first;
   for (int i = (int)threadIdx.x; i < 1 + ((n + 31) >> 5); i += (int)blockDim.x) sched[i] = 0;
   __shared__ WhPicJob Jl;
   wh_copy_job (&Jl, &jobs[blockIdx.y]);
@@ -862,6 +862,17 @@ class HipBackend : public wh::Backend {
   }
   void run_deblock (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
     static const int db_waves = getenv ("WELSHIP_DB_WAVES") ? atoi (getenv ("WELSHIP_DB_WAVES")) : 12;    // 73 VGPRs: two 12-wave workgroups per CU, one of 16 (measured 3.85 against 4.79 ms per step of 256 pictures; 8: 4.3, 6: 5.1)
+    // Enough pictures to give every CU one (and a filter that crosses slice edges anyway): ONE band per picture, 16 waves -- no seams between
+    // workgroups at all (measured, 256 four-slice 1080p pictures: 3.17 against 3.88 ms per step; profiles/r03_deblock_bands.txt).
+    // WELSHIP_DB_WHOLE = 0 / 1 forces the choice (read per launch: the tests switch it).
+    const char* we = getenv ("WELSHIP_DB_WHOLE");
+    const bool whole = P.deblock_idc == 0 && P.db_bands && (P.flags & WH_SEQ_DB_WHOLE) == 0 && (we ? atoi (we) != 0 : 4 * n >= 3 * cus_);
+    if (whole) {
+      WhSeqParams W = P;
+      W.flags |= WH_SEQ_DB_WHOLE; W.db_num_bands = 1; W.db_bands = WH_DB_WHOLE_TABLE (P); W.db_max_rows = P.mb_h; W.db_max_mbs = P.mb_w * P.mb_h;
+      mb_pass (k_deblock_slices, sizeof (WhDbLds), 16, false, W, jobs, n, 16 * sizeof (WhDbStage) + sizeof (WhPicJob), 4 * wh_db_xchg_words (P.mb_w, P.mb_h), 1);
+      return;
+    }
     mb_pass (k_deblock_slices, sizeof (WhDbLds), db_waves, false, P, jobs, n, 16 * sizeof (WhDbStage) + sizeof (WhPicJob), 4 * wh_db_xchg_words (P.mb_w, P.mb_h), P.db_num_bands);
   }
   void run_scene (const WhSeqParams& P, const WhPicJob* jobs, int n) override {

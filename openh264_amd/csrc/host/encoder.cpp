@@ -299,7 +299,7 @@ struct SessionCore {
     std::vector<uint32_t> order32 (order.begin(), order.end());      // 32-bit on the device (scalar loads)
     build_run_section (s, mb_w, num_mb, order32);
     d_order = (uint32_t*)A (order32.size() * 4);
-    d_bands = (int32_t*)A (sizeof (int32_t) * (3 * (size_t)nb + 1));
+    d_bands = (int32_t*)A (sizeof (int32_t) * (3 * (size_t)nb + 1 + 4));      // + the one-band table of the whole picture
     d_scene = (uint32_t*)A (64);
     d_dbflags = (uint32_t*)A (sizeof (uint32_t) * num_mb);
     if (oom) { set_err ("out of device memory"); release(); return WELSHIP_ERR_MEMORY; }
@@ -316,7 +316,8 @@ struct SessionCore {
     be->pin_host (h_records.data(), sizeof (WhMbRecord) * num_mb);     // D2H target of every frame
     be->pin_host (h_src.data(), src_bytes);                            // H2D source of every frame
     be->upload (d_order, order32.data(), order32.size() * 4);
-    be->upload (d_bands, bands.data(), sizeof (int32_t) * (3 * (size_t)nb + 1));
+    { const int32_t whole[4] = {0, num_mb, 0, num_mb}; bands.resize (3 * (size_t)nb + 1); bands.insert (bands.end(), whole, whole + 4); }
+    be->upload (d_bands, bands.data(), sizeof (int32_t) * (3 * (size_t)nb + 1 + 4));
     be->fill (d_dbflags, 0, sizeof (uint32_t) * num_mb);
     if (be->sync()) { set_err ("device error while setting up the session"); release(); return WELSHIP_ERR_UNKNOWN; }
     s.mb_order = d_order;
@@ -1769,7 +1770,7 @@ struct WelsHipFrameCtx {
       if (nb < 1) { set_err ("deblocking band table"); return WELSHIP_ERR_UNKNOWN; }
       for (int b = 0; b < nb; ++b) wh_build_mb_order (mb_w, bands[b], bands[b + 1], order.data() + 2 * (size_t)num_mb + bands[b]);
       up->d_order = (uint32_t*)be->alloc ((size_t)num_mb * 4 * 4);
-      up->d_bands = (int32_t*)be->alloc (sizeof (int32_t) * (3 * (size_t)nb + 1));
+      up->d_bands = (int32_t*)be->alloc (sizeof (int32_t) * (3 * (size_t)nb + 1 + 4));
       if (!up->d_order || !up->d_bands) { set_err ("out of device memory"); return WELSHIP_ERR_MEMORY; }
       std::vector<uint32_t> order32 (order.begin(), order.end());
       {
@@ -1782,7 +1783,8 @@ struct WelsHipFrameCtx {
         memcpy (up->run_count, tmp.run_count, sizeof (up->run_count));
       }
       be->upload (up->d_order, order32.data(), order32.size() * 4);
-      be->upload (up->d_bands, bands.data(), sizeof (int32_t) * (3 * (size_t)nb + 1));
+      { const int32_t whole[4] = {0, num_mb, 0, num_mb}; bands.resize (3 * (size_t)nb + 1); bands.insert (bands.end(), whole, whole + 4); }
+      be->upload (up->d_bands, bands.data(), sizeof (int32_t) * (3 * (size_t)nb + 1 + 4));
       if (be->sync()) { set_err ("device error"); return WELSHIP_ERR_UNKNOWN; }
       up->nb = nb;
       for (int b = 0; b < nb; ++b) {

@@ -180,16 +180,21 @@ class EmuBackend : public Backend {
     // one emulated wavefront per band (band b after band b-1, which satisfies the seam dependencies), with the device
     // scheduler's one-MB look-ahead and its strip exchange: neighbours inside the band through the exchange buffers,
     // neighbours in the previous band through the picture
+    // WELSHIP_DB_WHOLE=1: the one-band table of the whole picture (what the device takes for large batches, hip_backend.hip run_deblock)
+    const char* we = getenv ("WELSHIP_DB_WHOLE");
+    const bool whole = P.deblock_idc == 0 && P.db_bands && we && atoi (we) != 0;
+    const int32_t* bands = whole ? WH_DB_WHOLE_TABLE (P) : P.db_bands;
+    const int nbands = whole ? 1 : P.db_num_bands;
     for (int j = 0; j < n; ++j)
-      for (int s = 0; s < P.db_num_bands; ++s) {
+      for (int s = 0; s < nbands; ++s) {
         WhDbLds S;
         WhDbStage G;
         std::vector<uint32_t> xb (wh_db_xchg_words (P.mb_w, P.mb_h), 0xA5A5A5A5u);
         WhDbXchg E;
         E.top = xb.data(); E.left = xb.data() + (size_t)P.mb_w * 24; E.first_row = 0;
         poison (&S, sizeof (S)); poison (&G, sizeof (G));
-        const int first = P.db_bands[s], last = P.db_bands[s + 1];
-        const uint32_t* order = P.mb_order + 2 * P.mb_w * P.mb_h;
+        const int first = bands[s], last = bands[s + 1];
+        const uint32_t* order = whole ? P.mb_order + P.mb_w * P.mb_h : P.mb_order + 2 * P.mb_w * P.mb_h;
         for (int lane = 0; lane < 64; ++lane) wh_deblock_cold_fetch (G, lane, P, jobs[j], order[first] % P.mb_w, order[first] / P.mb_w);
         for (int t = first; t < last; ++t) {
           const int xy = order[t], xyn = t + 1 < last ? order[t + 1] : 0;

@@ -345,3 +345,22 @@ def test_frame_info_metadata_matches_reference(emu_lib, ref_tools, tmp_path):
             out += "".join(" %d" % L.pNalLengthInByte[k] for k in range(L.iNalCount)) + "\n"
     enc.close()
     assert out == open(fm).read()
+
+
+def _whole_picture_band(lib, ref_tools, tmp_path, monkeypatch):
+    """Large batches deblock a picture as ONE band (no seams between workgroups; hip_backend.hip run_deblock, WH_DB_WHOLE_TABLE)
+    when the filter crosses slice edges anyway; WELSHIP_DB_WHOLE=1 forces that choice for a single picture: the multi-slice cases again."""
+    monkeypatch.setenv("WELSHIP_DB_WHOLE", "1")
+    names = [k for k in SMALL if GOLDEN[k]["params"].get("uiSliceNum", 1) > 1 or GOLDEN[k]["params"].get("uiSliceMode", 0) != 0]
+    assert names
+    for name in names[:6]:
+        run_case(name, lib, ref_tools, tmp_path)
+
+
+def test_emu_whole_picture_deblocking_band(emu_lib, ref_tools, tmp_path, monkeypatch):
+    _whole_picture_band(emu_lib, ref_tools, tmp_path, monkeypatch)
+
+
+@pytest.mark.gpu
+def test_hip_whole_picture_deblocking_band(hip_lib, ref_tools, tmp_path, monkeypatch):
+    _whole_picture_band(hip_lib, ref_tools, tmp_path, monkeypatch)
