@@ -123,6 +123,32 @@ WH_DEFINE_MB_KERNEL (k_intra_slice, WhMbLds, wh_intra_mb_body, 1024, 0, 0)
 #define WH_EARLY_CLAIM 0           /* claim + fetch the wave's next macroblock when the body's prediction is final (before residual coding): measured, no gain */
 #endif
 template <class F> struct WhEarlyFn { F& f; __device__ __forceinline__ void call() { f(); } };
+// Candidate, measured and switched off: the job descriptor of the slot a wave works on as wave-uniform REGISTER values -- every lane
+// reads one dword of the LDS copy (two loads, one wait), v_readlane hands each dword out as a scalar -- instead of one LDS read per
+// field where the body needs it (some thirty per macroblock, eight in a row in the claim path, each with a wait in front of its first
+// use).  134 VGPRs, no scratch (it needs the selects of intra_mb.h wh_tile_fetch_nb_planes to stay out of memory), bit-exact -- and
+// 3.7 % SLOWER on the MI355X (MD launch 13.70 against 13.20 ms, same box): a wave changes slots with almost every macroblock, and 74
+// v_readlane plus the scalar spills they cause cost more than the LDS round trips, which other waves hide.
+#ifndef WH_JOB_REGS
+#define WH_JOB_REGS 0
+#endif
+template <int I, int N> struct WhLaneWords {      // d[I .. N) = lanes I .. of (t0, t1): constant indices only, so that d never exists in memory
+  static __device__ __forceinline__ void get (uint32_t* d, uint32_t t0, uint32_t t1) {
+    d[I] = (uint32_t)__builtin_amdgcn_readlane ((int) (I < 64 ? t0 : t1), I & 63);
+    WhLaneWords<I + 1, N>::get (d, t0, t1);
+  }
+};
+template <int N> struct WhLaneWords<N, N> { static __device__ __forceinline__ void get (uint32_t*, uint32_t, uint32_t) {} };
+__device__ __forceinline__ void wh_job_to_regs (WhPicJob& R, const WhPicJob& L, int lane) {
+  constexpr int N = (int) (sizeof (WhPicJob) / 4);
+  static_assert (sizeof (WhPicJob) % 4 == 0 && N <= 128, "WhPicJob: whole dwords, at most two per lane");
+  const uint32_t* s = (const uint32_t*)&L;
+  const uint32_t t0 = s[lane < N ? lane : 0];
+  const uint32_t t1 = N > 64 ? s[64 + lane < N ? 64 + lane : 0] : 0u;
+  uint32_t d[N];
+  WhLaneWords<0, N>::get (d, t0, t1);
+  __builtin_memcpy (&R, d, sizeof (R));
+}
 #ifndef WH_SPEC_WINDOWS
 #define WH_SPEC_WINDOWS 1          /* fetch a macroblock's search windows with its cold inputs, around the slice's last vector */
 #endif
@@ -164,6 +190,15 @@ __global__ __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPi
   uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;     // cycles / 64 this wave spent on each slot's macroblocks
   int slot = -1, t = 0, xy = 0;          // the macroblock in hand
   int nslot = -1, nt = 0, nxy = 0;       // the wave's next one, claimed while the one in hand is still being coded (WH_EARLY_CLAIM)
+#if WH_JOB_REGS && !WH_EARLY_CLAIM
+  WhPicJob Jr;                           // the job of slot jr_slot in registers (wh_job_to_regs): reloaded only when the wave changes slots
+  int jr_slot = -1;
+#define WH_JOB_OF(sl) Jr
+#define WH_JOB_LOAD(sl) if ((sl) >= 0 && (sl) != jr_slot) { wh_job_to_regs (Jr, Jl[sl], lane); jr_slot = (sl); }
+#else
+#define WH_JOB_OF(sl) Jl[sl]
+#define WH_JOB_LOAD(sl)
+#endif
   // claim(): the next macroblock for this wave, or nslot = -1 when the workgroup's slices are used up
 #define WH_CLAIM()                                                                                                             \
   for (nslot = -1;;) {                                                                                                         \
@@ -191,11 +226,12 @@ __global__ __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPi
   }
   const bool speculate = WH_SPEC_WINDOWS != 0;
 #define WH_FETCH_AHEAD()                                                                                                       \
+  WH_JOB_LOAD (nslot)                                                                                                          \
   if (nslot >= 0) {                                                                                                            \
-    wh_inter_cold_fetch (G, lane, P, Jl[nslot], nxy % P.mb_w, nxy / P.mb_w);   /* in flight while the wave codes / waits for the neighbours */ \
+    wh_inter_cold_fetch (G, lane, P, WH_JOB_OF (nslot), nxy % P.mb_w, nxy / P.mb_w);   /* in flight while the wave codes / waits for the neighbours */ \
     WH_PROF_SUB (P, S.m, 2);         /* detail: cold inputs issued */                                                          \
     X.spec_valid = 0;                                                                                                          \
-    if (speculate) { wh_win_speculate (P, Jl[nslot], X.spec, nxy % P.mb_w, nxy / P.mb_w, slot_mv[nslot]); X.spec_valid = 1; }  \
+    if (speculate) { wh_win_speculate (P, WH_JOB_OF (nslot), X.spec, nxy % P.mb_w, nxy / P.mb_w, slot_mv[nslot]); X.spec_valid = 1; }  \
   }
   // Called by the macroblock body once its prediction is final (inter_mb.h): from there on it reads neither the staging area nor
   // the windows, so the next macroblock's fetch runs under the residual coding and the stores of the one in hand.  Claiming a
@@ -214,7 +250,7 @@ __global__ __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPi
   WH_FETCH_AHEAD()
   slot = nslot; t = nt; xy = nxy;
   while (slot >= 0) {
-    const WhPicJob& J = Jl[slot];
+    const WhPicJob& J = WH_JOB_OF (slot);       // (registers: loaded by the fetch-ahead of this very macroblock)
     const int first = slot_first[slot];
     uint32_t* sc = sched + slot * sched_words;
     WH_PROF_MARK (P, S.m, 11);
@@ -250,6 +286,8 @@ __global__ __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPi
   }
 #undef WH_CLAIM
 #undef WH_FETCH_AHEAD
+#undef WH_JOB_OF
+#undef WH_JOB_LOAD
   if (slice_cost && lane == 0) {
     if (slot_id[0] >= 0 && c0) atomicAdd (&slice_cost[slot_id[0]], c0);
     if (slots > 1 && slot_id[1] >= 0 && c1) atomicAdd (&slice_cost[slot_id[1]], c1);

@@ -29,7 +29,7 @@ WH_FN void wh_store_mb (WhMbLds& S, const WhSeqParams& P, const WhPicJob& J, int
   }
   if (lane < 32) {
     const int pl = lane >> 4, row = (lane >> 1) & 7, half = lane & 1;
-    WH_G uint8_t* d = (WH_G uint8_t*)J.rec[1 + pl] + (size_t) (mby * 8 + row) * P.rec_stride_c + mbx * 8 + half * 4;
+    WH_G uint8_t* d = (WH_G uint8_t*) (pl ? J.rec[2] : J.rec[1]) + (size_t) (mby * 8 + row) * P.rec_stride_c + mbx * 8 + half * 4;     // (a select, not an index: the job may live in registers)
     * (WH_G uint32_t*)d = * (const uint32_t*)&WH_RC (S, pl, half * 4, row);
   }
   // coefficient levels: 4 luma + 2 chroma-AC int16 quads per lane

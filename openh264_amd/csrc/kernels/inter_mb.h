@@ -449,7 +449,7 @@ WH_FN void wh_mc_chroma_to (WhInterLds& S, const WhSeqParams& P, const WhPicJob&
     WV_LANES_BEGIN (lane)
     for (int i = lane; i < 2 * n; i += 64) {
       const int pl = i >= n, k = i - pl * n, x = k & (cw - 1), y = k >> sh;
-      const WH_G uint8_t* p = (const WH_G uint8_t*)J.ref[1 + pl] + (ptrdiff_t) (ipy + y) * P.rec_stride_c + ipx + x;
+      const WH_G uint8_t* p = (const WH_G uint8_t*) (pl ? J.ref[2] : J.ref[1]) + (ptrdiff_t) (ipy + y) * P.rec_stride_c + ipx + x;
       dst[pl * 64 + (cy + y) * 8 + cx + x] = (uint8_t)wh_mc_chroma_w (p[0], p[1], p[P.rec_stride_c], p[P.rec_stride_c + 1], dx, dy);
     }
     WV_LANES_END

@@ -59,15 +59,20 @@ WH_FN void wh_tile_fetch_src (int lane, const WhSeqParams& P, const WhPicJob& J,
 // load per role inside `if / else if` the compiler merges the results through a phi and waits for each load at the end of its
 // branch: the macroblock then pays one L2 round trip per role (three to four in a row) instead of one.  The column lanes read
 // the aligned word that ENDS with their sample (x = -4 .. -1) and keep its top byte; lanes without a role repeat lane 0's word.
-WH_FN void wh_tile_fetch_nb (int lane, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, WhTileRegs* r) {
+// (the three planes as VALUES: a select between loads of job fields would be folded into one load at a selected offset, which
+// keeps a job descriptor that lives in registers -- hip_backend.hip wh_job_to_regs -- from staying there)
+WH_FN void wh_tile_fetch_nb_planes (int lane, const WhSeqParams& P, const WH_G uint8_t* rec0, const WH_G uint8_t* rec1, const WH_G uint8_t* rec2, int mbx, int mby, WhTileRegs* r) {
   const bool top_y = lane < 7, col_y = lane >= 16 && lane < 32, top_c = lane >= 32 && lane < 38, col_c = lane >= 48;
   const bool luma = !(top_c || col_c);                                   // (idle lanes take lane 0's role)
   const int pl = top_c ? (lane - 32) / 3 : (lane - 48) >> 3;             // chroma plane of the chroma roles
   const int row = col_y ? mby * 16 + (lane - 16) : col_c ? mby * 8 + (lane & 7) : top_c ? mby * 8 - 1 : mby * 16 - 1;
   const int x = top_y ? mbx * 16 + lane * 4 - 4 : top_c ? mbx * 8 + ((lane - 32) % 3) * 4 - 4 : luma ? mbx * 16 - 4 : mbx * 8 - 4;
-  const WH_G uint8_t* base = luma ? (const WH_G uint8_t*)J.rec[0] : (pl & 1) ? (const WH_G uint8_t*)J.rec[2] : (const WH_G uint8_t*)J.rec[1];
+  const WH_G uint8_t* base = luma ? rec0 : (pl & 1) ? rec2 : rec1;
   const uint32_t v = * (const WH_G uint32_t*) (base + (ptrdiff_t)row * (luma ? P.rec_stride_y : P.rec_stride_c) + x);
   r->nb = (col_y || col_c) ? v >> 24 : v;
+}
+WH_FN void wh_tile_fetch_nb (int lane, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, WhTileRegs* r) {
+  wh_tile_fetch_nb_planes (lane, P, (const WH_G uint8_t*)J.rec[0], (const WH_G uint8_t*)J.rec[1], (const WH_G uint8_t*)J.rec[2], mbx, mby, r);
 }
 #else
 WH_FN void wh_tile_fetch_nb (int lane, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, WhTileRegs* r) {
@@ -81,10 +86,10 @@ WH_FN void wh_tile_fetch_nb (int lane, const WhSeqParams& P, const WhPicJob& J, 
     r->nb = ((const WH_G uint8_t*)J.rec[0])[(ptrdiff_t) (mby * 16 + y) * P.rec_stride_y + mbx * 16 - 1];
   } else if (lane >= 32 && lane < 38) {  // chroma rows -1: 3 words per plane, x = -4..7
     const int pl = (lane - 32) / 3, x = ((lane - 32) % 3) * 4 - 4;
-    r->nb = * (const WH_G uint32_t*) ((const WH_G uint8_t*)J.rec[1 + pl] + (ptrdiff_t) (mby * 8 - 1) * P.rec_stride_c + mbx * 8 + x);
+    r->nb = * (const WH_G uint32_t*) ((const WH_G uint8_t*) (pl ? J.rec[2] : J.rec[1]) + (ptrdiff_t) (mby * 8 - 1) * P.rec_stride_c + mbx * 8 + x);
   } else if (lane >= 48) {               // chroma columns -1
     const int pl = (lane - 48) >> 3, y = lane & 7;
-    r->nb = ((const WH_G uint8_t*)J.rec[1 + pl])[(ptrdiff_t) (mby * 8 + y) * P.rec_stride_c + mbx * 8 - 1];
+    r->nb = ((const WH_G uint8_t*) (pl ? J.rec[2] : J.rec[1]))[(ptrdiff_t) (mby * 8 + y) * P.rec_stride_c + mbx * 8 - 1];
   }
 }
 #endif

@@ -29,7 +29,7 @@ LADDER = ["-simulcast", "320", "180", "-simulcast", "640", "360", "-simulcast", 
 
 
 def run(tmp, yuv, hip):
-    env = dict(os.environ, WELSHIP_LIB=LIB, WELS_HIP="1" if hip else "0", WELS_HIP_TRACE="1")
+    env = dict(os.environ, WELSHIP_LIB=LIB, WELS_HIP="1" if hip else "0", WELS_HIP_TRACE=os.environ.get("WELS_HIP_TRACE", "1"))
     if DYNSLICE:
         env["WELS_HIP_DYNSLICE"] = "1"
     out = os.path.join(tmp, "s_%d.264" % hip)
@@ -42,6 +42,8 @@ def run(tmp, yuv, hip):
             else ["-slcmd", "2", "-slcmbnum", "2040" if FULL else "900"])
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert p.returncode == 0, p.stderr[-2000:]
+    if hip and os.environ.get("WELS_HIP_TRACE") == "2":       # where a picture's time went, per session
+        sys.stderr.write("".join(l + "\n" for l in p.stderr.decode(errors="replace").splitlines() if "per picture" in l))
     if hip and os.environ.get("WELSHIP_FRAME_STATS"):
         sys.stderr.write("".join(l + "\n" for l in p.stderr.decode(errors="replace").splitlines() if l.startswith("welship:")))
     enc_fps = [float(x) for x in re.findall(rb" fps=([0-9.]+)", p.stdout)]
