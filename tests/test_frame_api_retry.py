@@ -1,0 +1,120 @@
+"""The frame API's whole-picture repeat after a CAVLC overflow (WelsHipFrameJob::bRetry, include/welship.h 2b) and the layer's pSadCost[0]
+array: the repeat must see the array as the PREVIOUS picture left it, not what the abandoned pass wrote (the reference's
+TRY_REENCODING repeats one macroblock at a time and never sees a later macroblock's entry of the same picture).  Pinned case: a P picture
+whose macroblocks are coded with residual in the first pass and become P_Skip in the repeat (their QP raised far enough): above LOW
+complexity a P_Skip keeps the macroblock's OLD entry (svc_base_layer_md.cpp WelsMdInterSaveSadAndRefMbType: pSadCost[0] is only refreshed
+when bMdUsingSad), so after the repeat those entries must be the sentinels the test put there before the picture."""
+import ctypes as C
+import random
+
+import pytest
+
+import openh264_amd as oh
+
+WH_MB_PSKIP = 6
+REC_BYTES = 960
+
+
+class FrameCfg(C.Structure):
+    _fields_ = [("iDevice", C.c_int32), ("iPicWidth", C.c_int32), ("iPicHeight", C.c_int32), ("iNumPictures", C.c_int32), ("reserved", C.c_int32 * 4)]
+
+
+class MbReencode(C.Structure):
+    _fields_ = [("iMbXY", C.c_int32), ("uiLumaQp", C.c_uint8), ("uiStaleCbp", C.c_uint8), ("bCell12Valid", C.c_uint8), ("pad", C.c_uint8), ("iCell12Mv", C.c_int16 * 2)]
+
+
+class FrameJob(C.Structure):          # WelsHipFrameJob, field for field
+    _fields_ = [("iCurPic", C.c_int32), ("iRefPic", C.c_int32), ("eSliceType", C.c_int32), ("iQp", C.c_int32), ("iChromaQpIndexOffset", C.c_int32),
+                ("iComplexityMode", C.c_int32), ("iMvRange", C.c_int32), ("iMvcShift", C.c_int32), ("iNumSlices", C.c_int32),
+                ("pSliceFirstMb", C.POINTER(C.c_int32)),
+                ("iDeblockIdc", C.c_int32), ("iAlphaOffset", C.c_int32), ("iBetaOffset", C.c_int32), ("bDeblock", C.c_int32), ("bExpand", C.c_int32),
+                ("pSrc", C.c_void_p * 3), ("iSrcStride", C.c_int32 * 3),
+                ("pVaaSad8x8", C.c_void_p), ("pBgdFlags", C.c_void_p), ("pMbQp", C.c_void_p),
+                ("iMbBegin", C.c_int32), ("iMbEnd", C.c_int32),
+                ("pIlHint", C.c_void_p), ("pSadCost", C.POINTER(C.c_int32)), ("pScreen", C.c_void_p),
+                ("bRetry", C.c_int32), ("bCountBits", C.c_int32), ("iNumReencode", C.c_int32), ("iNumRefIdxL0Active", C.c_int32),
+                ("pGomRc", C.c_void_p), ("pReencode", C.POINTER(MbReencode)),
+                ("iDynSlice", C.c_int32), ("iDynSliceFirstMb", C.c_int32), ("bRangeAgain", C.c_int32), ("bDynRedoFirst", C.c_int32)]
+
+
+def _retry_sees_the_previous_pictures_sad_costs(lib_path):
+    lib = oh.load_library(lib_path)
+    lib.WelsHipFrameCtxCreate.argtypes = [C.POINTER(C.c_void_p), C.POINTER(FrameCfg)]
+    lib.WelsHipFrameCtxDestroy.argtypes = [C.c_void_p]
+    lib.WelsHipFrameCtxDestroy.restype = None
+    lib.WelsHipFrameEncode.argtypes = [C.c_void_p, C.POINTER(FrameJob), C.POINTER(C.c_void_p)]
+    w, h = 128, 96
+    mbs = (w // 16) * (h // 16)
+    rnd = random.Random(7)
+    # a textured picture, and the same picture with a little noise: zero motion, a residual that QP 24 codes and QP 51 does not
+    f0 = bytearray(w * h * 3 // 2)
+    for y in range(h):
+        for x in range(w):
+            f0[y * w + x] = (96 + 40 * ((x // 8 + y // 8) & 1) + (x * 3 + y * 5) % 17) & 255
+    for i in range(w * h, len(f0)):
+        f0[i] = 128
+    f1 = bytearray(f0)
+    for i in range(w * h):
+        f1[i] = max(0, min(255, f1[i] + rnd.randint(-6, 6)))
+
+    cfg = FrameCfg(0, w, h, 3)
+    ctx = C.c_void_p()
+    assert lib.WelsHipFrameCtxCreate(C.byref(ctx), C.byref(cfg)) == 0, lib.WelsHipGetLastError()
+    first = (C.c_int32 * 2)(0, mbs)
+
+    def job(frame, cur, ref, sad):
+        j = FrameJob()
+        j.iCurPic, j.iRefPic, j.eSliceType, j.iQp, j.iComplexityMode, j.iMvRange = cur, ref, (2 if ref < 0 else 0), 24, 1, 64
+        j.iNumSlices, j.pSliceFirstMb = 1, first
+        j.iDeblockIdc, j.bDeblock, j.bExpand = 0, 1, 1
+        buf = (C.c_uint8 * len(frame)).from_buffer(frame)
+        base = C.addressof(buf)
+        j.pSrc[0], j.pSrc[1], j.pSrc[2] = base, base + w * h, base + w * h + (w // 2) * (h // 2)
+        j.iSrcStride[0], j.iSrcStride[1], j.iSrcStride[2] = w, w // 2, w // 2
+        j.pSadCost = sad
+        j.iNumRefIdxL0Active = 1
+        return j, buf
+
+    def run(j):
+        rec = C.c_void_p()
+        rc = lib.WelsHipFrameEncode(ctx, C.byref(j), C.byref(rec))
+        assert rc == 0, (rc, lib.WelsHipGetLastError())
+        raw = C.string_at(rec, REC_BYTES * mbs)
+        return [(raw[i * REC_BYTES], raw[i * REC_BYTES + 1]) for i in range(mbs)]      # (mb_type, cbp)
+
+    sad = (C.c_int32 * mbs)(*([0] * mbs))
+    j, keep0 = job(f0, 0, -1, sad)
+    run(j)                                                     # the IDR picture (zeroes the entries: intra macroblocks)
+    sentinel = [1000000 + 37 * i for i in range(mbs)]
+    for i in range(mbs):
+        sad[i] = sentinel[i]                                   # "what the previous picture left"
+    j, keep1 = job(f1, 1, 0, sad)
+    r1 = run(j)                                                # first pass
+    after1 = list(sad)
+    coded = [i for i in range(mbs) if r1[i][0] != WH_MB_PSKIP]
+    assert len(coded) >= mbs // 2, r1
+    assert all(after1[i] != sentinel[i] for i in coded)        # a coded macroblock writes its own cost
+    lst = (MbReencode * len(coded))()
+    for k, i in enumerate(coded):
+        lst[k].iMbXY, lst[k].uiLumaQp, lst[k].uiStaleCbp = i, 51, r1[i][1] & 0x3f
+    j.bRetry, j.pReencode, j.iNumReencode = 1, lst, len(coded)  # the repeat: the host's copy of the array now holds the first pass's values
+    r2 = run(j)
+    after2 = list(sad)
+    flipped = [i for i in coded if r2[i][0] == WH_MB_PSKIP]
+    assert len(flipped) >= 4, (r1, r2)                         # the case the gap was about: coded in the abandoned pass, P_Skip in the repeat
+    # a P_Skip decided by the skip test keeps the old entry; one that is a renamed P16x16 (WelsMdInterDoubleCheckPskip: the macroblocks
+    # without skipped neighbours never take the skip test) carries the search's cost at the NEW QP -- never the abandoned pass's value
+    kept = [i for i in flipped if after2[i] == sentinel[i]]
+    assert len(kept) >= 4, (flipped, after1, after2)
+    for i in flipped:
+        assert after2[i] != after1[i], (i, after1[i], after2[i], sentinel[i])
+    lib.WelsHipFrameCtxDestroy(ctx)
+
+
+def test_retry_sees_the_previous_pictures_sad_costs(emu_lib):
+    _retry_sees_the_previous_pictures_sad_costs(emu_lib)
+
+
+@pytest.mark.gpu
+def test_hip_retry_sees_the_previous_pictures_sad_costs(hip_lib):
+    _retry_sees_the_previous_pictures_sad_costs(hip_lib)
