@@ -2340,7 +2340,14 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
       if (scr) be->download (c->scc_down(), c->d_scc_chain + 4 * WH_MAX_SLICES, sizeof (uint32_t) * WH_MAX_SLICES);
     }
     if (!dyn_close) be->download (c->h_records.data() + j->iMbBegin, c->d_records + j->iMbBegin, sizeof (WhMbRecord) * (size_t) (j->iMbEnd - j->iMbBegin));
-    if (be->sync_queue (queue)) { set_err ("device scheduler timed out or device error; the picture was not encoded"); return WELSHIP_ERR_UNKNOWN; }
+    // wait for the range outside the device-wide lock: other sessions (and the other slice threads of this picture) stage and submit
+    // meanwhile -- a picture of ranges is dozens of these round trips (everything above was queued under the lock, in order, on `queue`)
+    const unsigned swept0 = be->errors_swept();
+    lock.unlock();
+    int bad = be->sync_queue (queue);
+    if (be->errors_swept() != swept0) bad = 1;       // another thread's sync() found time-outs meanwhile: possibly this range's
+    lock.lock();
+    if (bad) { set_err ("device scheduler timed out or device error; the picture was not encoded"); return WELSHIP_ERR_UNKNOWN; }
     if (scr && last_part && scr->pSliceFMECostDown) memcpy (scr->pSliceFMECostDown, c->scc_down(), sizeof (uint32_t) * j->iNumSlices);
     *pp_records = c->h_records.data();
     return WELSHIP_OK;
