@@ -733,8 +733,15 @@ class HipBackend : public wh::Backend {
     // handful): streams_ never grows, so a thread may wait on queue k (sync_queue, outside the callers' lock) while another one
     // selects a queue.  Each queue has an error word of its own (WH_ERR_WORDS dwords): a dependency-wait timeout in one launch set
     // must fail that set's pictures and nobody else's.
+    // HIP streams share hardware queues (four by default, GPU_MAX_HW_QUEUES): measured with tools/micro/stream_alias.hip, the n-th stream
+    // a process creates is served by hardware queue 3 - n % 4 -- except the first four, which get one each in creation order -- and work on
+    // two streams of one hardware queue serialises (a copy's barrier packet waits behind the other stream's kernel: profiles/
+    // r03_stream_hardware_queues.txt).  Four throw-away streams take the irregular positions, so that for the queues of this backend
+    // "k % 4 differs" means "different hardware queue" whatever was created before it; the host side chooses the queues of roles that
+    // must overlap accordingly (csrc/host/encoder.cpp: frame_find_key; compute / upload / download of a pipelined group: 0 / 1 / 2).
+    for (int k = 0; k < 4; ++k) HIP_TRY (hipStreamCreateWithFlags (&pad_streams_[k], hipStreamNonBlocking));
     streams_.assign (WH_NUM_QUEUES, nullptr);
-    // WELSHIP_STREAM_PRIO=1 (experiment knob): the last two queues (a pipelined group's transfer queues) with the highest priority
+    // WELSHIP_STREAM_PRIO=1 (experiment knob): the last two queues with the highest priority
     const bool prio = getenv ("WELSHIP_STREAM_PRIO") && atoi (getenv ("WELSHIP_STREAM_PRIO")) != 0;
     int plo = 0, phi = 0;
     if (prio) HIP_TRY (hipDeviceGetStreamPriorityRange (&plo, &phi));
@@ -750,6 +757,7 @@ class HipBackend : public wh::Backend {
   ~HipBackend() override {
     (void)hipSetDevice (dev_);
     for (hipStream_t st : streams_) if (st) { (void)hipStreamSynchronize (st); (void)hipStreamDestroy (st); }
+    for (hipStream_t st : pad_streams_) if (st) (void)hipStreamDestroy (st);
     for (hipEvent_t ev : wait_ev_) if (ev) (void)hipEventDestroy (ev);
     for (auto& sl : slabs_) (void)hipFree (sl.base);
     if (err_) (void)hipFree (err_);
@@ -1027,6 +1035,7 @@ class HipBackend : public wh::Backend {
   hipStream_t stream_ = nullptr;          // the selected queue ...
   int cur_ = 0;                           // ... and its index
   std::vector<hipStream_t> streams_;      // WH_NUM_QUEUES of them, fixed at construction
+  hipStream_t pad_streams_[4] = {nullptr, nullptr, nullptr, nullptr};     // never used (see the constructor)
   uint32_t* err_ = nullptr;
   struct Slab { uint8_t* base; size_t size, used; };
   std::vector<Slab> slabs_;

@@ -1877,8 +1877,15 @@ FrameKey* frame_find_key (FrameShared* sh, const WhSeqParams& s, bool is_p, bool
     if (k->is_p == is_p && k->qp_map == qp_map && k->expand == expand && memcmp (&k->seq, &s, sizeof (WhSeqParams)) == 0) return k.get();
   std::unique_ptr<FrameKey> k (new FrameKey());
   k->seq = s; k->is_p = is_p; k->qp_map = qp_map; k->expand = expand;
-  k->queue = (int) (sh->keys.size() % 8);          // keys beyond the eighth share queues (they only serialise, nothing breaks)
-  for (int i = 0; i < WH_FRAME_LANES; ++i) k->lane[i].queue = k->queue + 8 * (i + 1);      // the key's own queue only carries the uploads
+  // Queues whose numbers differ modulo 4 are served by different hardware queues (hip_backend.hip, constructor; there are four).  A key's
+  // uploads go to hardware queue key % 4, both its launch sets to 3 - key % 4: the kernels of four keys (the layers of a simulcast
+  // session) run beside each other, and a key's uploads never queue behind its own kernels.  Measured against the alternative "uploads /
+  // launch set 1 / launch set 2 / pre-analysis of every key on hardware queues 0 / 1 / 2 / 3" (profiles/r03_stream_hardware_queues.txt):
+  // 8 simulcast sessions 89-92 against 67 frames/s, one-key workloads the same.  Keys beyond the eighth share queues (they only
+  // serialise, nothing breaks).
+  const int kn = (int) (sh->keys.size() % 8);
+  k->queue = kn;                                   // the key's own queue only carries the uploads
+  for (int i = 0; i < WH_FRAME_LANES; ++i) k->lane[i].queue = 8 + 8 * i + 4 * (kn / 4) + (3 - kn % 4);
   sh->keys.push_back (std::move (k));
   return sh->keys.back().get();
 }
@@ -2423,7 +2430,8 @@ int WelsHipFrameVaa (WelsHipFrameCtx* c, const WelsHipVaaJob* j) {
   wh::Backend* be = c->be;
   const size_t n = (size_t)c->num_mb;
   const size_t o_sad = 0, o_sd = 16 * n, o_sum = 32 * n, o_sq = 36 * n, o_ssd = 40 * n, o_mad = 44 * n, out_bytes = 48 * n;
-  const int queue = 24 + (int) ((uintptr_t)c / 64 % 8);        // the pre-analysis queues (keys: 0..7 uploads, 8..23 launch sets)
+  const int vq = (int) ((uintptr_t)c / 64 % 8);
+  const int queue = 24 + 4 * (vq / 4) + (3 - vq % 4);          // the pre-analysis queues (keys: 0..7 uploads, 8..23 launch sets)
   std::unique_lock<std::mutex> lock (sh->mu);
   if (!c->d_vaa_out) {
     c->d_vaa_out = (uint8_t*)be->alloc (out_bytes);
