@@ -1083,6 +1083,8 @@ int WelsHipGroupUploadSource (WelsHipEncoderGroup* g, int session, int slot, con
 
 int WelsHipGroupBegin (WelsHipEncoderGroup* g, int slot) {
   if (!g) return WELSHIP_ERR_INIT_PARA;
+  // (a pipelined group's pictures write their records into the buffer set of their step: the synchronous calls would read the wrong one)
+  if (g->pipelined) { set_err ("pipelined group: frame steps go through WelsHipGroupEncodeFramesPipelined"); return WELSHIP_ERR_INIT_PARA; }
   const int n = (int)g->sess.size();
   // scene-change statistic for the sessions whose frame type it can still change: one launch, read back before the
   // pictures are begun
@@ -1244,8 +1246,8 @@ static int pipe_queue (int which) {            // WELSHIP_PIPE_QUEUES=upload,dow
 int WelsHipGroupSetPipelined (WelsHipEncoderGroup* g, int ahead) {
   if (!g) return WELSHIP_ERR_INIT_PARA;
   if (ahead <= 0) { if (g->pending) { set_err ("submitted steps are still pending: flush first"); return WELSHIP_ERR_INIT_PARA; } return WELSHIP_OK; }
-  if (g->pipelined) return WELSHIP_OK;
   if (ahead > WH_PIPE_MAX_AHEAD) { set_err ("pipelined groups: at most 3 steps ahead"); return WELSHIP_ERR_INIT_PARA; }
+  if (g->pipelined) { if (ahead == g->depth - 1) return WELSHIP_OK; set_err ("the group is pipelined already, with a different number of steps ahead"); return WELSHIP_ERR_INIT_PARA; }
   if (g->queues != 1) { set_err ("pipelined groups use one compute queue (WELSHIP_QUEUES=1)"); return WELSHIP_ERR_UNSUPPORTED; }
   const int n = (int)g->sess.size(), depth = 1 + ahead;
   const size_t off_words = (size_t)g->sess[0]->num_mb + 1;

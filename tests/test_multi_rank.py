@@ -316,6 +316,20 @@ def test_pipelined_group_refuses_what_it_cannot_do(emu_lib):
     with pytest.raises(oh.WelsHipError):
         g.set_pipelined()
     g.close()
+    # ... and a pipelined group takes its frame steps through the pipelined call only (its records live in per-step buffer sets)
+    from openh264_amd.utils.synth import synth_sequence
+    p.bEnableSceneChangeDetect = False
+    g = oh.EncoderGroup(p, 2, ring_slots=3, host_threads=1, lib_path=emu_lib)
+    g.set_pipelined(2)
+    yuv = synth_sequence(64, 48, 1)
+    pics = g.make_pictures([yuv, yuv])
+    with pytest.raises(oh.WelsHipError):
+        g.encode_frames(pics)
+    assert g.encode_frames_pipelined(pics) is None
+    with pytest.raises(oh.WelsHipError):
+        g.set_pipelined(3)                       # (a second call is only accepted with the same number of steps ahead)
+    g.set_pipelined(2)
+    g.close()
 
 
 @pytest.mark.gpu
