@@ -152,7 +152,13 @@ __device__ __forceinline__ void wh_job_to_regs (WhPicJob& R, const WhPicJob& L, 
 #ifndef WH_SPEC_WINDOWS
 #define WH_SPEC_WINDOWS 1          /* fetch a macroblock's search windows with its cold inputs, around the slice's last vector */
 #endif
-template <int MAXT, bool SCC>
+// PLAIN: see inter_mb.h wh_inter_cold_fetch.  The variant has 30 k instructions instead of 44 k (no background-detection, inter-layer, bit-counting,
+// rate-control or QP-map code) and codes a session group's pictures 7.4 % faster (MD launch 13.70 -> 12.69 ms, same box:
+// profiles/r03_p_kernel_candidates_ab.txt); 0 = every launch takes the general kernel.
+#ifndef WH_PLAIN_KERNEL
+#define WH_PLAIN_KERNEL 1
+#endif
+template <int MAXT, bool SCC, bool PLAIN = false>
 __global__ __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPicJob* jobs, uint32_t* err, const uint16_t* groups, int slots,
                                                        int sched_words, int total_slices, uint32_t* slice_cost) {
   extern __shared__ __align__ (16) uint8_t smem[];
@@ -216,7 +222,7 @@ __global__ __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPi
     const int first_ = slot_first[best];                                                                                       \
     const int xy_ = (P.flags & WH_SEQ_CHAIN) ? (int)((const WH_G uint32_t*)Jl[best].scc_order)[first_ + tt]                   \
                   : (SCC && (P.flags & WH_SEQ_SERIAL)) ? first_ + tt : (int)P.mb_order[first_ + tt];   /* serial: coding order */ \
-    const int mb_end_ = Jl[best].mb_end;                                                                                       \
+    const int mb_end_ = PLAIN ? 0 : Jl[best].mb_end;                                                                                       \
     if (mb_end_ > 0) {                    /* GOM-synchronous coding: only [mb_begin, mb_end) in this launch */                 \
       if (xy_ < Jl[best].mb_begin) { if (lane == 0) atomicOr (&sched[best * sched_words + 1 + ((xy_ - first_) >> 5)], 1u << ((xy_ - first_) & 31)); continue; } \
       if (xy_ >= mb_end_) continue;                                                                                            \
@@ -228,7 +234,7 @@ __global__ __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPi
 #define WH_FETCH_AHEAD()                                                                                                       \
   WH_JOB_LOAD (nslot)                                                                                                          \
   if (nslot >= 0) {                                                                                                            \
-    wh_inter_cold_fetch (G, lane, P, WH_JOB_OF (nslot), nxy % P.mb_w, nxy / P.mb_w);   /* in flight while the wave codes / waits for the neighbours */ \
+    wh_inter_cold_fetch<PLAIN> (G, lane, P, WH_JOB_OF (nslot), nxy % P.mb_w, nxy / P.mb_w);   /* in flight while the wave codes / waits for the neighbours */ \
     WH_PROF_SUB (P, S.m, 2);         /* detail: cold inputs issued */                                                          \
     X.spec_valid = 0;                                                                                                          \
     if (speculate) { wh_win_speculate (P, WH_JOB_OF (nslot), X.spec, nxy % P.mb_w, nxy / P.mb_w, slot_mv[nslot]); X.spec_valid = 1; }  \
@@ -267,10 +273,11 @@ __global__ __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPi
     WH_PROF_MARK (P, S.m, 12);
     const uint32_t tc0 = (uint32_t)__builtin_readcyclecounter();
     WV_ASYNC_WAIT();                      /* this MB's cold inputs have landed in the staging area */
-    X.slice_idc = J.dyn_slice ? J.dyn_slice - 1 : slot_idc[slot]; X.slice_first = J.dyn_slice ? J.dyn_first : first; X.last_mv = &slot_mv[slot];
+    const bool dyn_ = !PLAIN && J.dyn_slice;
+    X.slice_idc = dyn_ ? J.dyn_slice - 1 : slot_idc[slot]; X.slice_first = dyn_ ? J.dyn_first : first; X.last_mv = &slot_mv[slot];
     claimed = false;
-    wh_inter_mb_body_t<SCC> (S, G, P, J, xy % P.mb_w, xy / P.mb_w, X, early);
-    if (J.gom_rc) wh_gom_close_if_last (P, J, xy);       // rate control: the group's last macroblock settles the next group's QP
+    wh_inter_mb_body_t<SCC, PLAIN> (S, G, P, J, xy % P.mb_w, xy / P.mb_w, X, early);
+    if (!PLAIN && J.gom_rc) wh_gom_close_if_last (P, J, xy);       // rate control: the group's last macroblock settles the next group's QP
     WH_PROF_MARK (P, S.m, 14);
     __builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");
     if (lane == 0) atomicOr (&sc[1 + ((xy - first) >> 5)], 1u << ((xy - first) & 31));
@@ -850,7 +857,11 @@ class HipBackend : public wh::Backend {
   // P pictures: one workgroup per CU-load of slices.  Few slices (latency regime): one slice per workgroup, 12 waves.  Enough
   // slices to fill the chip twice: groups of 2..4 slices share a 12-wave workgroup (k_inter_pool), dealt out by k_md_assign.
   // WELSHIP_MD_SLOTS = 1..4 forces the group size, WELSHIP_P_WAVES the wave count, WELSHIP_MD_ASSIGN=0 the plain order.
-  void run_inter (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
+  void run_inter (const WhSeqParams& Pin, const WhPicJob* jobs, int n) override {
+    const bool plain = WH_PLAIN_KERNEL && (Pin.flags & WH_SEQ_PLAIN) != 0;
+    WhSeqParams Pm = Pin;
+    Pm.flags &= ~WH_SEQ_PLAIN;
+    const WhSeqParams& P = Pm;
     static const int forced_waves = getenv ("WELSHIP_P_WAVES") ? atoi (getenv ("WELSHIP_P_WAVES")) : 0;
     static const int forced_slots = getenv ("WELSHIP_MD_SLOTS") ? atoi (getenv ("WELSHIP_MD_SLOTS")) : 0;
     static const int use_assign = getenv ("WELSHIP_MD_ASSIGN") ? atoi (getenv ("WELSHIP_MD_ASSIGN")) : 1;
@@ -904,6 +915,7 @@ class HipBackend : public wh::Backend {
     };
     if (P.flags & WH_SEQ_SCC) { if (nw <= 6) launch (k_inter_pool<384, true>); else launch (k_inter_pool<768, true>); }
     else if (rows) { if (nw <= 6) launch (k_inter_rows<384>); else launch (k_inter_rows<768>); }
+    else if (WH_PLAIN_KERNEL && plain && P.flags == 0) { if (nw <= 6) launch (k_inter_pool<384, false, WH_PLAIN_KERNEL != 0>); else launch (k_inter_pool<768, false, WH_PLAIN_KERNEL != 0>); }
     else if (nw <= 6) launch (k_inter_pool<384, false>); else launch (k_inter_pool<768, false>);
   }
   void run_deblock (const WhSeqParams& P, const WhPicJob* jobs, int n) override {

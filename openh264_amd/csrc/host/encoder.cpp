@@ -764,6 +764,10 @@ struct SessionCore {
   }
 };
 
+// The sequence parameters of a session group's ordinary step, with the promise that its P pictures carry none of the optional per-picture
+// inputs (SessionCore::begin_frame sets none; the re-run after a CAVLC overflow, which brings a QP map, goes through run_device_step).
+static WhSeqParams plain_seq (const WhSeqParams& s) { WhSeqParams q = s; if (q.flags == 0) q.flags |= WH_SEQ_PLAIN; return q; }
+
 // Run the device part of one frame step for `n` pictures described by the device array d_jobs.
 void run_device_step (wh::Backend* be, const WhSeqParams& s, const WhPicJob* d_jobs, int n, bool idr, bool need_ref, bool qp_map = false) {
   if (idr) be->run_intra (s, d_jobs, n);
@@ -1134,7 +1138,7 @@ int WelsHipGroupRunDevice (WelsHipEncoderGroup* g, int wait) {
     g->be->select_queue (q);
     const int np = g->chunk_p[q], ni = (b - a) - np;
     const WhSeqParams& s = c0.seq;
-    if (np) g->be->run_inter (s, g->d_jobs + a, np);
+    if (np) g->be->run_inter (plain_seq (s), g->d_jobs + a, np);
     if (ni) g->be->run_intra (s, g->d_jobs + a + np, ni);
     if (c0.use_compact) g->be->run_compact (s, g->d_jobs + a, b - a);
     if (s.deblock_idc != 1) g->be->run_deblock (s, g->d_jobs + a, b - a);
@@ -1324,7 +1328,7 @@ int pipe_submit (WelsHipEncoderGroup* g, const WelsHipSourcePicture* srcs, doubl
   be->upload (dj, hj.data(), sizeof (WhPicJob) * n);
   const WhSeqParams& s = c0.seq;
   be->run_src_tile_jobs (s, dj, n);
-  if (np) be->run_inter (s, dj, np);
+  if (np) be->run_inter (plain_seq (s), dj, np);
   if (n - np) be->run_intra (s, dj + np, n - np);
   be->run_compact (s, dj, n);
   if (s.deblock_idc != 1) be->run_deblock (s, dj, n);
@@ -1503,7 +1507,7 @@ int WelsHipGroupBench (WelsHipEncoderGroup* g, int steps, int warmup, double* ou
       const int a = g->chunk_first (q), cnt = g->chunk_first (q + 1) - a;
       be->select_queue (q);
       if (q == 0) be->event_record (ev[i * 4 + 0]);
-      if (g->step_idr) be->run_intra (s, g->d_jobs + a, cnt); else be->run_inter (s, g->d_jobs + a, cnt);
+      if (g->step_idr) be->run_intra (s, g->d_jobs + a, cnt); else be->run_inter (plain_seq (s), g->d_jobs + a, cnt);
       if (q == 0) be->event_record (ev[i * 4 + 1]);
       if (s.deblock_idc != 1) be->run_deblock (s, g->d_jobs + a, cnt);
       if (q == 0) be->event_record (ev[i * 4 + 2]);

@@ -129,7 +129,23 @@ class EmuBackend : public Backend {
         }
       }
   }
-  void run_inter (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
+  void run_inter (const WhSeqParams& Pin, const WhPicJob* jobs, int n) override {
+    // WH_SEQ_PLAIN (a session group's step): the body variant that never looks at the optional per-picture inputs (as hip_backend.hip takes it;
+    // -DWH_PLAIN_KERNEL=0: the general body) -- and a check that the promise holds
+#ifndef WH_PLAIN_KERNEL
+#define WH_PLAIN_KERNEL 1
+#endif
+    const bool plain = WH_PLAIN_KERNEL && (Pin.flags & WH_SEQ_PLAIN) != 0;
+    WhSeqParams Pm = Pin;
+    Pm.flags &= ~WH_SEQ_PLAIN;
+    const WhSeqParams& P = Pm;
+    if (Pin.flags & WH_SEQ_PLAIN)
+      for (int j = 0; j < n; ++j) {
+        const WhPicJob& q = jobs[j];
+        if (P.flags || q.vaa_sad8x8 || q.sad_cost0 || q.bgd_flags || q.il_hint || q.mb_ctl || q.gom_rc || q.dyn_slice || q.want_bits || q.mb_end || q.mvc_shift || q.scc) {
+          fprintf (stderr, "emu: WH_SEQ_PLAIN on a picture with optional inputs\n"); abort();
+        }
+      }
     // one emulated wavefront walks each slice in order like a wave of the device scheduler: a macroblock's cold inputs and
     // its speculative search windows (around the slice's last final vector) are fetched before its body runs
     static const bool rows_off = getenv ("WELSHIP_MD_ROWS") && atoi (getenv ("WELSHIP_MD_ROWS")) == 0;
@@ -157,7 +173,7 @@ class EmuBackend : public Backend {
           }
           if (jobs[j].mb_end > 0 && (xy < jobs[j].mb_begin || xy >= jobs[j].mb_end)) continue;      // GOM-synchronous coding: only this range
           const int mbx = xy % P.mb_w, mby = xy / P.mb_w;
-          for (int lane = 0; lane < 64; ++lane) wh_inter_cold_fetch (G, lane, P, jobs[j], mbx, mby);
+          for (int lane = 0; lane < 64; ++lane) { if (plain) wh_inter_cold_fetch<true> (G, lane, P, jobs[j], mbx, mby); else wh_inter_cold_fetch (G, lane, P, jobs[j], mbx, mby); }
           WhInterCtx X;
           X.slice_idc = jobs[j].dyn_slice ? jobs[j].dyn_slice - 1 : s; X.slice_first = jobs[j].dyn_slice ? jobs[j].dyn_first : first;
           X.win = &WB;
@@ -169,6 +185,7 @@ class EmuBackend : public Backend {
           // body calls back: poisoned here, so a read after the call breaks parity
           struct Early { WhInterStage* g; WhWinLds* wb; int calls; void call() { poison (g, sizeof (*g)); poison (wb, sizeof (*wb)); ++calls; } } early = { &G, &WB, 0 };
           if (P.flags & WH_SEQ_SCC) wh_inter_mb_body_t<true> (S, G, P, jobs[j], mbx, mby, X, early);
+          else if (plain) wh_inter_mb_body_t<false, true> (S, G, P, jobs[j], mbx, mby, X, early);
           else wh_inter_mb_body_t<false> (S, G, P, jobs[j], mbx, mby, X, early);
           if (early.calls != 1) { fprintf (stderr, "emu: the P macroblock body called back %d times at MB %d\n", early.calls, xy); abort(); }
           if (jobs[j].gom_rc) wh_gom_close_if_last (P, jobs[j], xy);

@@ -342,3 +342,33 @@ def test_hip_pipelined_group_matches_the_synchronous_one(hip_lib, ahead):
 @pytest.mark.parametrize("ahead", [1, 2])
 def test_hip_pipelined_group_reencodes_after_cavlc_overflow(hip_lib, ahead):
     _pipelined_vs_synchronous(hip_lib, 64, 64, 4, 3, ("synth", "checker5", "synth", "checker8"), 3, ahead=ahead)
+
+
+def test_plain_p_kernel_variant_on_emulation(emu_lib):
+    """A session group's steps promise the P kernel that their pictures carry no optional per-picture inputs (WH_SEQ_PLAIN, common/wh_types.h)
+    and get a body variant that never looks at them (hip_backend.hip WH_PLAIN_KERNEL; the emulation also checks the promise on every picture).
+    The default test build takes that variant, a build with -DWH_PLAIN_KERNEL=0 the general body: both must give the streams of the
+    single-session encoder (which never takes the variant), synchronous and pipelined."""
+    import openh264_amd as oh
+    from openh264_amd import build as B
+    from openh264_amd.parallel import encode_sessions_sharded
+    general = B.build_emu(defines=("WH_PLAIN_KERNEL=0",), tag="noplain")
+    inputs = _inputs()
+    want = []
+    for s in range(SESSIONS):
+        bs, _ = oh.encode_sequence(b"".join(inputs[s]), W, H, lib_path=emu_lib, iDLayerQp=26, uiIntraPeriod=0, fMaxFrameRate=30.0, iTargetBitrate=500000)
+        want.append(hashlib.sha1(bs).hexdigest())
+    for lib in (emu_lib, general):
+        assert encode_sessions_sharded(_make_group_factory(lib), inputs, FRAMES) == want
+        seqs, got = _pipelined_vs_synchronous(lib, 64, 64, 5, 24, ("synth", "checker5", "pan7"), 3, intra_period=4, ahead=2)
+        for s, yuv in enumerate(seqs):
+            bs, _ = oh.encode_sequence(yuv, 64, 64, lib_path=emu_lib, iDLayerQp=24, uiIntraPeriod=4, fMaxFrameRate=30.0, iTargetBitrate=5000000, bEnableSceneChangeDetect=False)
+            assert bs == got[s]
+
+
+@pytest.mark.gpu
+def test_hip_plain_p_kernel_variant(hip_lib):
+    """The same on the MI355X for the shipped library: session groups (the variant) against the single-session encoder (the general kernel)."""
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "plain_check.py"), hip_lib], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert out.returncode == 0 and b"identical" in out.stdout, out.stdout[-1500:]
