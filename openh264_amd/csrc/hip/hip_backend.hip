@@ -158,9 +158,11 @@ __device__ __forceinline__ void wh_job_to_regs (WhPicJob& R, const WhPicJob& L, 
 #ifndef WH_PLAIN_KERNEL
 #define WH_PLAIN_KERNEL 1
 #endif
-template <int MAXT, bool SCC, bool PLAIN = false>
+// (WH_PLAIN_KERNEL=2, candidate: additionally a variant with LOW complexity known at compile time -- not measured on the device yet)
+template <int MAXT, bool SCC, int VAR = 0>
 __global__ __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPicJob* jobs, uint32_t* err, const uint16_t* groups, int slots,
                                                        int sched_words, int total_slices, uint32_t* slice_cost) {
+  constexpr bool PLAIN = VAR >= 1;
   extern __shared__ __align__ (16) uint8_t smem[];
   const int nw = (int)blockDim.x >> 6, lane = (int)threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane ((int)threadIdx.x >> 6);
@@ -276,7 +278,7 @@ __global__ __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPi
     const bool dyn_ = !PLAIN && J.dyn_slice;
     X.slice_idc = dyn_ ? J.dyn_slice - 1 : slot_idc[slot]; X.slice_first = dyn_ ? J.dyn_first : first; X.last_mv = &slot_mv[slot];
     claimed = false;
-    wh_inter_mb_body_t<SCC, PLAIN> (S, G, P, J, xy % P.mb_w, xy / P.mb_w, X, early);
+    wh_inter_mb_body_t<SCC, VAR> (S, G, P, J, xy % P.mb_w, xy / P.mb_w, X, early);
     if (!PLAIN && J.gom_rc) wh_gom_close_if_last (P, J, xy);       // rate control: the group's last macroblock settles the next group's QP
     WH_PROF_MARK (P, S.m, 14);
     __builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");
@@ -915,7 +917,8 @@ class HipBackend : public wh::Backend {
     };
     if (P.flags & WH_SEQ_SCC) { if (nw <= 6) launch (k_inter_pool<384, true>); else launch (k_inter_pool<768, true>); }
     else if (rows) { if (nw <= 6) launch (k_inter_rows<384>); else launch (k_inter_rows<768>); }
-    else if (WH_PLAIN_KERNEL && plain && P.flags == 0) { if (nw <= 6) launch (k_inter_pool<384, false, WH_PLAIN_KERNEL != 0>); else launch (k_inter_pool<768, false, WH_PLAIN_KERNEL != 0>); }
+    else if (WH_PLAIN_KERNEL == 2 && plain && P.flags == 0 && P.complexity == 0) { if (nw <= 6) launch (k_inter_pool<384, false, WH_PLAIN_KERNEL == 2 ? 2 : 0>); else launch (k_inter_pool<768, false, WH_PLAIN_KERNEL == 2 ? 2 : 0>); }
+    else if (WH_PLAIN_KERNEL && plain && P.flags == 0) { if (nw <= 6) launch (k_inter_pool<384, false, WH_PLAIN_KERNEL ? 1 : 0>); else launch (k_inter_pool<768, false, WH_PLAIN_KERNEL ? 1 : 0>); }
     else if (nw <= 6) launch (k_inter_pool<384, false>); else launch (k_inter_pool<768, false>);
   }
   void run_deblock (const WhSeqParams& P, const WhPicJob* jobs, int n) override {

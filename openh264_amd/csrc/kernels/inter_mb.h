@@ -1009,8 +1009,11 @@ typedef struct WhInterCtx {
 // the fetch runs under residual coding + stores instead of being waited for at the top of the next macroblock.  The CPU test
 // build poisons both buffers in the callback: a read after the call would break parity.
 struct WhNoEarly { WH_FN void call() {} };
-template <bool SCC, bool PLAIN, class Early>
+// VAR: 0 = the general body, 1 = PLAIN (see wh_inter_cold_fetch), 2 = PLAIN and LOW complexity known at compile time (SAD costs: the SATD
+// paths of the search, the refinement and the intra test are not compiled in)
+template <bool SCC, int VAR, class Early>
 WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, WhInterCtx& X, Early& early) {
+  constexpr bool PLAIN = VAR >= 1, LOW = VAR == 2;
   WH_PROF_DECL (P);
   WhMbLds& M = S.m;
   const int w = P.mb_w, xy = mby * w + mbx;
@@ -1024,7 +1027,7 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
   const int qp = (!PLAIN && J.gom_rc) ? wh_clip3 ((int)wh_ld_wg32 ((const WH_G uint32_t*)& ((const WH_G WhGomRc*)J.gom_rc)->calc_qp), 0, 51) : wh_mb_qp (J, ctl);
   const int qpc = kWhChromaQp[wh_clip3 (qp + P.chroma_qp_offset, 0, 51)];
   const int lambda = kWhLambda[qp];
-  const int use_satd = P.complexity > 0;        // pfMdCost == SATD, pfCalculateSatd == CalculateSatdCost
+  const int use_satd = LOW ? 0 : P.complexity > 0;        // pfMdCost == SATD, pfCalculateSatd == CalculateSatdCost
   const bool md_using_sad = !use_satd;          // bMdUsingSad (svc_encode_slice.cpp:699)
   const bool ref_is_p = J.ref_is_p != 0;
 
@@ -1417,11 +1420,11 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
     // WelsMdSpatialelInterMbIlfmdNoilp, base-layer MB intra (svc_mode_decision.cpp:88-100): no motion search at all -- a skip
     // that is at least as cheap as Intra16x16 stays, anything else becomes intra (I16x16 against I4x4 as in an I slice)
     if (b_skip && cost_luma <= i16c.best_cost) { mb_type = WH_MB_PSKIP; done = true; }
-    else { (void)wh_intra_md_enc_p (M, P, J, mbx, mby, avail, qp, qpc, 0x7fffffff, &ir, &i16c, stale_cbp); intra = true; done = true; }
+    else { (void)wh_intra_md_enc_p<LOW ? 0 : -1> (M, P, J, mbx, mby, avail, qp, qpc, 0x7fffffff, &ir, &i16c, stale_cbp); intra = true; done = true; }
   }
   if (!done) {
     // WelsMdFirstIntraMode: I16x16 cost vs the inter/skip cost so far
-    if (wh_intra_md_enc_p (M, P, J, mbx, mby, avail, qp, qpc, cost_luma, &ir, &i16c, stale_cbp)) { intra = true; done = true; }
+    if (wh_intra_md_enc_p<LOW ? 0 : -1> (M, P, J, mbx, mby, avail, qp, qpc, cost_luma, &ir, &i16c, stale_cbp)) { intra = true; done = true; }
   }
   if (!done && b_skip) { mb_type = WH_MB_PSKIP; done = true; }
   WH_PROF_MARK (P, M, 3);   // I16x16 test (+ intra encode when intra wins)
@@ -1723,12 +1726,12 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
 }
 template <bool SCC, class Early>
 WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, WhInterCtx& X, Early& early) {
-  wh_inter_mb_body_t<SCC, false, Early> (S, G, P, J, mbx, mby, X, early);
+  wh_inter_mb_body_t<SCC, 0, Early> (S, G, P, J, mbx, mby, X, early);
 }
 template <bool SCC>
 WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, WhInterCtx& X) {
   WhNoEarly e;
-  wh_inter_mb_body_t<SCC, false, WhNoEarly> (S, G, P, J, mbx, mby, X, e);
+  wh_inter_mb_body_t<SCC, 0, WhNoEarly> (S, G, P, J, mbx, mby, X, e);
 }
 WH_FN void wh_inter_mb_body (WhInterLds& S, WhInterStage& G, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, WhInterCtx& X) {
   wh_inter_mb_body_t<false> (S, G, P, J, mbx, mby, X);

@@ -313,10 +313,12 @@ WH_FN void wh_i16_costs (WhMbLds& S, int avail, int use_satd, int lambda, WhI16C
   (void)last_mode;
 }
 
+// CPLX >= 0: the complexity mode is known at compile time (the P kernel's variant for LOW complexity launches, inter_mb.h)
+template <int CPLX = -1>
 WH_FN bool wh_intra_md_enc_p (WhMbLds& S, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, int avail, int qp, int qpc,
                               int inter_cost, WhIntraResult* o, const WhI16Cost* pre = nullptr, int stale_cbp = 0) {
   const int lambda = kWhLambda[qp];
-  const int use_satd = P.complexity > 0;
+  const int use_satd = CPLX >= 0 ? (CPLX > 0) : (P.complexity > 0);
   const bool has_l = (avail & WH_AV_LEFT) != 0, has_t = (avail & WH_AV_TOP) != 0;
   WhI16Cost own;
   if (!pre) { wh_i16_costs (S, avail, use_satd, lambda, &own); pre = &own; }

@@ -185,7 +185,8 @@ class EmuBackend : public Backend {
           // body calls back: poisoned here, so a read after the call breaks parity
           struct Early { WhInterStage* g; WhWinLds* wb; int calls; void call() { poison (g, sizeof (*g)); poison (wb, sizeof (*wb)); ++calls; } } early = { &G, &WB, 0 };
           if (P.flags & WH_SEQ_SCC) wh_inter_mb_body_t<true> (S, G, P, jobs[j], mbx, mby, X, early);
-          else if (plain) wh_inter_mb_body_t<false, true> (S, G, P, jobs[j], mbx, mby, X, early);
+          else if (plain && WH_PLAIN_KERNEL == 2 && P.complexity == 0) wh_inter_mb_body_t<false, 2> (S, G, P, jobs[j], mbx, mby, X, early);
+          else if (plain) wh_inter_mb_body_t<false, 1> (S, G, P, jobs[j], mbx, mby, X, early);
           else wh_inter_mb_body_t<false> (S, G, P, jobs[j], mbx, mby, X, early);
           if (early.calls != 1) { fprintf (stderr, "emu: the P macroblock body called back %d times at MB %d\n", early.calls, xy); abort(); }
           if (jobs[j].gom_rc) wh_gom_close_if_last (P, jobs[j], xy);
