@@ -229,6 +229,8 @@ typedef struct WhPicJob {
                                     //   order -- in a processing order built for the picture that respects both (WhPicJob::scc_order)
 #define WH_SEQ_PLAIN 32             // a promise of the host, stripped by the backend: every picture of the launch is a plain camera picture without any optional per-picture
                                     //   input (a session group's step) -- the P kernel then runs a variant that never looks at them (hip_backend.hip WH_PLAIN_KERNEL)
+#define WH_SEQ_NO_CTRL 64           // the same kind of promise for the frame API's camera pictures: no inter-layer hints, QP map, GOM rate control, MB ranges or bit
+                                    //   counting (what the pre-processing supplies -- VAA SADs, pSadCost, background flags, vector shift -- may be there); candidate: WH_FRAME_KERNEL
 #define WH_SEQ_DB_WHOLE 16          // deblocking launch only (set by the backend on its copy): ONE band = the whole picture, in the picture's own 2:1 order (mb_order's second section)
 #define WH_SEQ_RANGED 8             // the pictures of the launch code MB ranges (WhPicJob::mb_begin / mb_end, dyn_slice) or carry GOM rate control:
                                     //   the ticket scheduler runs them (k_inter_pool); everything without a flag may take the row scheduler

@@ -158,11 +158,15 @@ __device__ __forceinline__ void wh_job_to_regs (WhPicJob& R, const WhPicJob& L, 
 #ifndef WH_PLAIN_KERNEL
 #define WH_PLAIN_KERNEL 1
 #endif
-// (WH_PLAIN_KERNEL=2, candidate: additionally a variant with LOW complexity known at compile time -- not measured on the device yet)
+// (WH_PLAIN_KERNEL=2, candidate: additionally a variant with LOW complexity known at compile time -- not measured on the device yet;
+//  WH_FRAME_KERNEL=1, candidate: a variant for the frame API's camera pictures without control inputs, WH_SEQ_NO_CTRL -- not measured either)
+#ifndef WH_FRAME_KERNEL
+#define WH_FRAME_KERNEL 0
+#endif
 template <int MAXT, bool SCC, int VAR = 0>
 __global__ __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPicJob* jobs, uint32_t* err, const uint16_t* groups, int slots,
                                                        int sched_words, int total_slices, uint32_t* slice_cost) {
-  constexpr bool PLAIN = VAR >= 1;
+  constexpr bool CTRL = VAR == 0;          // (inter_mb.h wh_inter_cold_fetch)
   extern __shared__ __align__ (16) uint8_t smem[];
   const int nw = (int)blockDim.x >> 6, lane = (int)threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane ((int)threadIdx.x >> 6);
@@ -224,7 +228,7 @@ __global__ __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPi
     const int first_ = slot_first[best];                                                                                       \
     const int xy_ = (P.flags & WH_SEQ_CHAIN) ? (int)((const WH_G uint32_t*)Jl[best].scc_order)[first_ + tt]                   \
                   : (SCC && (P.flags & WH_SEQ_SERIAL)) ? first_ + tt : (int)P.mb_order[first_ + tt];   /* serial: coding order */ \
-    const int mb_end_ = PLAIN ? 0 : Jl[best].mb_end;                                                                                       \
+    const int mb_end_ = CTRL ? Jl[best].mb_end : 0;                                                                                       \
     if (mb_end_ > 0) {                    /* GOM-synchronous coding: only [mb_begin, mb_end) in this launch */                 \
       if (xy_ < Jl[best].mb_begin) { if (lane == 0) atomicOr (&sched[best * sched_words + 1 + ((xy_ - first_) >> 5)], 1u << ((xy_ - first_) & 31)); continue; } \
       if (xy_ >= mb_end_) continue;                                                                                            \
@@ -236,7 +240,7 @@ __global__ __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPi
 #define WH_FETCH_AHEAD()                                                                                                       \
   WH_JOB_LOAD (nslot)                                                                                                          \
   if (nslot >= 0) {                                                                                                            \
-    wh_inter_cold_fetch<PLAIN> (G, lane, P, WH_JOB_OF (nslot), nxy % P.mb_w, nxy / P.mb_w);   /* in flight while the wave codes / waits for the neighbours */ \
+    wh_inter_cold_fetch<VAR> (G, lane, P, WH_JOB_OF (nslot), nxy % P.mb_w, nxy / P.mb_w);   /* in flight while the wave codes / waits for the neighbours */ \
     WH_PROF_SUB (P, S.m, 2);         /* detail: cold inputs issued */                                                          \
     X.spec_valid = 0;                                                                                                          \
     if (speculate) { wh_win_speculate (P, WH_JOB_OF (nslot), X.spec, nxy % P.mb_w, nxy / P.mb_w, slot_mv[nslot]); X.spec_valid = 1; }  \
@@ -275,11 +279,11 @@ __global__ __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPi
     WH_PROF_MARK (P, S.m, 12);
     const uint32_t tc0 = (uint32_t)__builtin_readcyclecounter();
     WV_ASYNC_WAIT();                      /* this MB's cold inputs have landed in the staging area */
-    const bool dyn_ = !PLAIN && J.dyn_slice;
+    const bool dyn_ = CTRL && J.dyn_slice;
     X.slice_idc = dyn_ ? J.dyn_slice - 1 : slot_idc[slot]; X.slice_first = dyn_ ? J.dyn_first : first; X.last_mv = &slot_mv[slot];
     claimed = false;
     wh_inter_mb_body_t<SCC, VAR> (S, G, P, J, xy % P.mb_w, xy / P.mb_w, X, early);
-    if (!PLAIN && J.gom_rc) wh_gom_close_if_last (P, J, xy);       // rate control: the group's last macroblock settles the next group's QP
+    if (CTRL && J.gom_rc) wh_gom_close_if_last (P, J, xy);       // rate control: the group's last macroblock settles the next group's QP
     WH_PROF_MARK (P, S.m, 14);
     __builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");
     if (lane == 0) atomicOr (&sc[1 + ((xy - first) >> 5)], 1u << ((xy - first) & 31));
@@ -860,9 +864,9 @@ class HipBackend : public wh::Backend {
   // slices to fill the chip twice: groups of 2..4 slices share a 12-wave workgroup (k_inter_pool), dealt out by k_md_assign.
   // WELSHIP_MD_SLOTS = 1..4 forces the group size, WELSHIP_P_WAVES the wave count, WELSHIP_MD_ASSIGN=0 the plain order.
   void run_inter (const WhSeqParams& Pin, const WhPicJob* jobs, int n) override {
-    const bool plain = WH_PLAIN_KERNEL && (Pin.flags & WH_SEQ_PLAIN) != 0;
+    const bool plain = WH_PLAIN_KERNEL && (Pin.flags & WH_SEQ_PLAIN) != 0, no_ctrl = WH_FRAME_KERNEL && (Pin.flags & WH_SEQ_NO_CTRL) != 0;
     WhSeqParams Pm = Pin;
-    Pm.flags &= ~WH_SEQ_PLAIN;
+    Pm.flags &= ~ (WH_SEQ_PLAIN | WH_SEQ_NO_CTRL);
     const WhSeqParams& P = Pm;
     static const int forced_waves = getenv ("WELSHIP_P_WAVES") ? atoi (getenv ("WELSHIP_P_WAVES")) : 0;
     static const int forced_slots = getenv ("WELSHIP_MD_SLOTS") ? atoi (getenv ("WELSHIP_MD_SLOTS")) : 0;
@@ -919,6 +923,7 @@ class HipBackend : public wh::Backend {
     else if (rows) { if (nw <= 6) launch (k_inter_rows<384>); else launch (k_inter_rows<768>); }
     else if (WH_PLAIN_KERNEL == 2 && plain && P.flags == 0 && P.complexity == 0) { if (nw <= 6) launch (k_inter_pool<384, false, WH_PLAIN_KERNEL == 2 ? 2 : 0>); else launch (k_inter_pool<768, false, WH_PLAIN_KERNEL == 2 ? 2 : 0>); }
     else if (WH_PLAIN_KERNEL && plain && P.flags == 0) { if (nw <= 6) launch (k_inter_pool<384, false, WH_PLAIN_KERNEL ? 1 : 0>); else launch (k_inter_pool<768, false, WH_PLAIN_KERNEL ? 1 : 0>); }
+    else if (WH_FRAME_KERNEL && no_ctrl && P.flags == 0) { if (nw <= 6) launch (k_inter_pool<384, false, WH_FRAME_KERNEL ? 3 : 0>); else launch (k_inter_pool<768, false, WH_FRAME_KERNEL ? 3 : 0>); }
     else if (nw <= 6) launch (k_inter_pool<384, false>); else launch (k_inter_pool<768, false>);
   }
   void run_deblock (const WhSeqParams& P, const WhPicJob* jobs, int n) override {

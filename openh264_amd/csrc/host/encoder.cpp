@@ -1846,7 +1846,18 @@ void frame_run_batch (FrameShared* sh, FrameKey* K, FrameLane* L, std::unique_lo
     for (int i = 0; i < n; ++i) L->h_jobs[i] = batch[i]->job;
     be->upload (L->d_jobs, L->h_jobs.data(), sizeof (WhPicJob) * n);
     const WhSeqParams& s = K->seq;
-    if (K->is_p) be->run_inter (s, L->d_jobs, n); else be->run_intra (s, L->d_jobs, n);
+    if (K->is_p) {
+      // camera pictures without control inputs (the usual case: rate control with several slices, or off): the promise the P kernel's
+      // frame-API variant needs (WH_SEQ_NO_CTRL, common/wh_types.h)
+      bool no_ctrl = s.flags == 0;
+      for (int i = 0; i < n && no_ctrl; ++i) {
+        const WhPicJob& q = L->h_jobs[i];
+        no_ctrl = !q.il_hint && !q.mb_ctl && !q.gom_rc && !q.dyn_slice && !q.want_bits && !q.mb_end && !q.scc;
+      }
+      WhSeqParams sq = s;
+      if (no_ctrl) sq.flags |= WH_SEQ_NO_CTRL;
+      be->run_inter (sq, L->d_jobs, n);
+    } else be->run_intra (s, L->d_jobs, n);
     if (K->qp_map) be->run_qp_chain (s, L->d_jobs, n);
     if (s.deblock_idc != 1) be->run_deblock (s, L->d_jobs, n);
     if (K->expand) be->run_expand (s, L->d_jobs, n);

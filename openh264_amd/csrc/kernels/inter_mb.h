@@ -971,13 +971,17 @@ WH_FN bool wh_try_puv_skip (WhMbLds& S, int pl, int qpc) {
 // PLAIN (here and in wh_inter_mb_body_t): the picture has none of the optional per-picture inputs -- host VAA SADs, the layer's pSadCost array,
 // background flags, inter-layer hints, a QP map, GOM rate control, MB ranges, bit counting, a temporal-layer vector shift (common/wh_types.h
 // WH_SEQ_PLAIN: the pictures of a session group) -- so none of them is looked at.
-template <bool PLAIN = false>
+// VAR (an integer, shared with wh_inter_mb_body_t): 0 = everything may be there; 1, 2 = PLAIN; 3 = a camera picture of the frame API: the
+// inputs a host's pre-processing supplies (VAA SADs, pSadCost, background flags, the vector shift) may be there, the control inputs (inter-layer
+// hints, QP map, GOM rate control, MB ranges, bit counting) are not (WH_SEQ_NO_CTRL; candidate, -DWH_FRAME_KERNEL=1)
+template <int VAR = 0>
 WH_FN void wh_inter_cold_fetch (WhInterStage& G, int lane, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby) {
+  constexpr bool HOSTIN = VAR == 0 || VAR == 3, CTRL = VAR == 0;
   const int w = P.mb_w, xy = mby * w + mbx;
   // (macroblock-tiled source pictures, WH_SRC_*: luma = 256 consecutive bytes in lane order, both chroma blocks = the 128 behind them)
   wh_ld_async4 ((const WH_G uint8_t*)J.src[0] + WH_SRC_Y_OFF (w, mbx, mby, 0, 0) + lane * 4, G.cold_y, lane);
   if (lane < 32) wh_ld_async4 ((const WH_G uint8_t*)J.src[0] + WH_SRC_C_OFF (w, mbx, mby, 0, 0, 0) + lane * 4, G.cold_c, lane);
-  if (P.complexity == 0 && (PLAIN || !J.vaa_sad8x8))     // VAA 8x8 SADs (LOW complexity only), unless the host supplies them
+  if (P.complexity == 0 && (!HOSTIN || !J.vaa_sad8x8))     // VAA 8x8 SADs (LOW complexity only), unless the host supplies them
     wh_ld_async4 ((const WH_G uint8_t*)J.prev_src_y + WH_SRC_Y_OFF (w, mbx, mby, 0, 0) + lane * 4, G.cold_pv, lane);
   if (lane < 36 && J.ref_mbs) wh_ld_async4 ((const WH_G uint32_t*) ((const WH_G WhMbState*)J.ref_mbs + xy) + lane, G.cold_co, lane);
   if (J.ref_is_p) {
@@ -989,8 +993,8 @@ WH_FN void wh_inter_cold_fetch (WhInterStage& G, int lane, const WhSeqParams& P,
   }
   // pSadCost[0] of the layer's SMB array (cold_co word 38); the host's four VAA SADs take the place of the previous source
   // picture's first words (cold_pv 0..3, read by wh_inter_mb_body straight from the staging area)
-  if (!PLAIN && lane == 38 && J.sad_cost0) wh_ld_async4 ((J.sad_cost0_out && J.dyn_redo && xy == J.mb_begin ? (const WH_G int32_t*)J.sad_cost0_out : (const WH_G int32_t*)J.sad_cost0) + xy, G.cold_co, lane);
-  if (!PLAIN && lane < 4 && J.vaa_sad8x8) wh_ld_async4 ((const WH_G int32_t*)J.vaa_sad8x8 + xy * 4 + lane, G.cold_pv, lane);
+  if (HOSTIN && lane == 38 && J.sad_cost0) wh_ld_async4 ((CTRL && J.sad_cost0_out && J.dyn_redo && xy == J.mb_begin ? (const WH_G int32_t*)J.sad_cost0_out : (const WH_G int32_t*)J.sad_cost0) + xy, G.cold_co, lane);
+  if (HOSTIN && lane < 4 && J.vaa_sad8x8) wh_ld_async4 ((const WH_G int32_t*)J.vaa_sad8x8 + xy * 4 + lane, G.cold_pv, lane);
 }
 
 typedef struct WhInterCtx {
@@ -1010,21 +1014,21 @@ typedef struct WhInterCtx {
 // build poisons both buffers in the callback: a read after the call would break parity.
 struct WhNoEarly { WH_FN void call() {} };
 // VAR: 0 = the general body, 1 = PLAIN (see wh_inter_cold_fetch), 2 = PLAIN and LOW complexity known at compile time (SAD costs: the SATD
-// paths of the search, the refinement and the intra test are not compiled in)
+// paths of the search, the refinement and the intra test are not compiled in), 3 = the frame API's camera pictures without control inputs
 template <bool SCC, int VAR, class Early>
 WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, WhInterCtx& X, Early& early) {
-  constexpr bool PLAIN = VAR >= 1, LOW = VAR == 2;
+  constexpr bool LOW = VAR == 2, HOSTIN = VAR == 0 || VAR == 3, CTRL = VAR == 0;      // (see wh_inter_cold_fetch)
   WH_PROF_DECL (P);
   WhMbLds& M = S.m;
   const int w = P.mb_w, xy = mby * w + mbx;
   const int slice_idc = X.slice_idc;
   const int avail = wh_mb_avail_in_slice (P, mbx, mby, X.slice_first);
   WhMbCtl ctl;
-  if (PLAIN) { ctl.qp_delta = 0; ctl.stale_cbp = 0; ctl.cell12_valid = 0; ctl.pad = 0; ctl.cell12_mv[0] = ctl.cell12_mv[1] = 0; }
+  if (!CTRL) { ctl.qp_delta = 0; ctl.stale_cbp = 0; ctl.cell12_valid = 0; ctl.pad = 0; ctl.cell12_mv[0] = ctl.cell12_mv[1] = 0; }
   else ctl = wh_mb_ctl (J, xy);
   // GOM-level rate control inside the kernel: the QP of this macroblock's group, settled by the last macroblock of the group before
   // it (wh_gom_close_if_last) -- which this macroblock has waited for (WhPicJob::scc_chain_prev)
-  const int qp = (!PLAIN && J.gom_rc) ? wh_clip3 ((int)wh_ld_wg32 ((const WH_G uint32_t*)& ((const WH_G WhGomRc*)J.gom_rc)->calc_qp), 0, 51) : wh_mb_qp (J, ctl);
+  const int qp = (CTRL && J.gom_rc) ? wh_clip3 ((int)wh_ld_wg32 ((const WH_G uint32_t*)& ((const WH_G WhGomRc*)J.gom_rc)->calc_qp), 0, 51) : wh_mb_qp (J, ctl);
   const int qpc = kWhChromaQp[wh_clip3 (qp + P.chroma_qp_offset, 0, 51)];
   const int lambda = kWhLambda[qp];
   const int use_satd = LOW ? 0 : P.complexity > 0;        // pfMdCost == SATD, pfCalculateSatd == CalculateSatdCost
@@ -1062,7 +1066,7 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
     // the reference picture's state of this MB (an I picture's has no motion / SAD).  Its padding word (WhMbState::pad1, word
     // 35) carries the layer's pSadCost[0] of this MB instead -- written by the SAME lane: two lanes storing to one LDS word in
     // one instruction have no defined winner on the GPU
-    if (lane < 36) S.nb[144 + lane] = (!PLAIN && lane == 35 && J.sad_cost0) ? G.cold_co[38] : J.ref_mbs ? G.cold_co[lane] : 0u;
+    if (lane < 36) S.nb[144 + lane] = (HOSTIN && lane == 35 && J.sad_cost0) ? G.cold_co[38] : J.ref_mbs ? G.cold_co[lane] : 0u;
     else if (lane < 38) * (uint32_t*)&S.co_mv[lane - 36][0] = G.cold_co[lane];
 #pragma unroll
     for (int k = 0; k < 3; ++k) { const int i = lane + 64 * k; if (i < 144) S.nb[i] = st[k]; }
@@ -1114,7 +1118,7 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
   const bool tl_sk = tl_type == WH_MB_PSKIP, t_sk = t_type == WH_MB_PSKIP, tr_sk = tr_type == WH_MB_PSKIP, l_sk = l_type == WH_MB_PSKIP;
   // background detection (pVaaBackgroundMbFlag): this MB's flag and its neighbours'; entry k of the lane table: 0 this MB,
   // 1 left, 2 top, 3 top-right, 4 top-left (only read for neighbours that exist)
-  const bool bgd = !PLAIN && J.bgd_flags != nullptr;
+  const bool bgd = HOSTIN && J.bgd_flags != nullptr;
   WvLaneArr bgf;
 #if defined(WH_EMU)
   memset (&bgf, 0, sizeof (bgf));
@@ -1128,7 +1132,7 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
   // inter-layer hints of the highest spatial layer (WelsMdInterMbEnhancelayer): base vector candidate and "base MB is intra"
   int il_mv = 0;
   bool il_intra = false;
-  if (!PLAIN && J.il_hint) {
+  if (CTRL && J.il_hint) {
     WvLaneArr ilh;
 #if defined(WH_EMU)
     memset (&ilh, 0, sizeof (ilh));
@@ -1364,7 +1368,7 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
         if (md_using_sad) cost_luma = sad_l;
         else WV_SATD_ROWS (cost_luma, lane, true, wh_enc4 (S, wh_tl_col (lane, 16), wh_tl_row (lane, 16)), * (const uint32_t*)&S.skip_y[wh_tl_row (lane, 16) * 16 + wh_tl_col (lane, 16)]);
         // pSadCost[0] is only refreshed when bMdUsingSad; otherwise the SMB entry keeps the previous frame's value
-        sad_cost0 = md_using_sad ? sad_l : ((!PLAIN && J.sad_cost0) ? (int)S.nb[144 + 35] : Co->sad_cost[0]);
+        sad_cost0 = md_using_sad ? sad_l : ((HOSTIN && J.sad_cost0) ? (int)S.nb[144 + 35] : Co->sad_cost[0]);
         cost_skip_mb = sad_mb;
         p16x = skx; p16y = sky;
       }
@@ -1397,7 +1401,7 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
     WV_LSET (mvcl, 0, il_mv);                   // sMvBase: zero, or twice the base layer's vector (SetMvBaseEnhancelayer)
     if (c_l) WV_LSET (mvcl, i_l, wh_pk_mv (Lm->p16mv[0], Lm->p16mv[1]));
     if (c_t) WV_LSET (mvcl, i_t, wh_pk_mv (Tm->p16mv[0], Tm->p16mv[1]));
-    const int msh = PLAIN ? 0 : J.mvc_shift;       // temporal layers: the reference picture's vectors span 2^shift picture intervals
+    const int msh = HOSTIN ? J.mvc_shift : 0;       // temporal layers: the reference picture's vectors span 2^shift picture intervals
     if (c_r) WV_LSET (mvcl, i_r, wh_pk_mv (S.co_mv[0][0] >> msh, S.co_mv[0][1] >> msh));
     if (c_b) WV_LSET (mvcl, i_b, wh_pk_mv (S.co_mv[1][0] >> msh, S.co_mv[1][1] >> msh));
     me16.sad_pred = sad_pred;
@@ -1516,7 +1520,7 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
       // WelsMdInterFinePartitionVaa: partition set chosen from the sign pattern of the four 8x8 SADs
       // between this source MB and the previous source frame (VAACalcSad_c + MdInterAnalysisVaaInfo_c)
       int s8_0, s8_1, s8_2, s8_3;
-      if (!PLAIN && J.vaa_sad8x8) { const int32_t* v8 = (const int32_t*)G.cold_pv; s8_0 = v8[0]; s8_1 = v8[1]; s8_2 = v8[2]; s8_3 = v8[3]; }      // the pre-processing's own result
+      if (HOSTIN && J.vaa_sad8x8) { const int32_t* v8 = (const int32_t*)G.cold_pv; s8_0 = v8[0]; s8_1 = v8[1]; s8_2 = v8[2]; s8_3 = v8[3]; }      // the pre-processing's own result
       else {
         int p01, p23;
         WV_SUM2 (p01, p23, lane,
@@ -1634,10 +1638,10 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
     if (lane < 16) { Ms->mv[lane][0] = 0; Ms->mv[lane][1] = 0; Rs->mvd[lane][0] = 0; Rs->mvd[lane][1] = 0; }
     if (lane < 2) Rs->mv_tr[lane] = 0;
     if (lane < 4) { Ms->ref_idx[lane] = -1; Rs->ref_idx[lane] = -1; Rs->sub_type[lane] = 0; }
-    if (lane == 0) { Ms->sad_cost[0] = 0; Ms->p16mv[0] = (int16_t)p16x; Ms->p16mv[1] = (int16_t)p16y; Ms->skip_sad = 0; if (!PLAIN && J.sad_cost0) (J.sad_cost0_out ? (WH_G int32_t*)J.sad_cost0_out : (WH_G int32_t*)J.sad_cost0)[xy] = 0; }
+    if (lane == 0) { Ms->sad_cost[0] = 0; Ms->p16mv[0] = (int16_t)p16x; Ms->p16mv[1] = (int16_t)p16y; Ms->skip_sad = 0; if (HOSTIN && J.sad_cost0) (J.sad_cost0_out ? (WH_G int32_t*)J.sad_cost0_out : (WH_G int32_t*)J.sad_cost0)[xy] = 0; }
     WV_LANES_END
     int ibits = 0;
-    if (!PLAIN && J.want_bits) {
+    if (CTRL && J.want_bits) {
       ibits = wh_mb_residual_bits (M, ir.mb_type, ir.cbp, Lm ? Lm->nzc : nullptr, Tm ? Tm->nzc : nullptr) +
               wh_mb_intra_header_bits (M, ir.mb_type, ir.cbp, ir.i16_mode_std, ir.chroma_mode_std, true);
       if (ir.cbp > 0 || ir.mb_type == WH_MB_I16x16) ibits |= WH_BITS_HAS_QP_DELTA;
@@ -1678,11 +1682,11 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
   if (lane == 0) {
     Ms->sad_cost[0] = sad_cost0; Ms->p16mv[0] = (int16_t)p16x; Ms->p16mv[1] = (int16_t)p16y;
     Ms->skip_sad = is_skip ? cost_skip_mb : 0;
-    if (!PLAIN && J.sad_cost0) (J.sad_cost0_out ? (WH_G int32_t*)J.sad_cost0_out : (WH_G int32_t*)J.sad_cost0)[xy] = sad_cost0;
+    if (HOSTIN && J.sad_cost0) (J.sad_cost0_out ? (WH_G int32_t*)J.sad_cost0_out : (WH_G int32_t*)J.sad_cost0)[xy] = sad_cost0;
   }
   WV_LANES_END
   int pbits = 0;
-  if (!PLAIN && J.want_bits && !is_skip) {
+  if (CTRL && J.want_bits && !is_skip) {
     // mb_type (+ four sub_mb_types of P_8x8ref0), the vector differences of the partitions, coded_block_pattern, the residual
     // (svc_set_mb_syn_cavlc.cpp:58-245; one reference picture: no ref_idx)
     const int m16 = mb_type == WH_MB_P16x16, m168 = mb_type == WH_MB_P16x8, m816 = mb_type == WH_MB_P8x16;
@@ -1711,7 +1715,7 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
   if (!bg_coded && !scd_coded) collocated = decided_skip ? (skx == 0 && sky == 0) : ((is_skip || mb_type == WH_MB_P16x16) && cbp == 0 && me16.mvx == 0 && me16.mvy == 0);
   {
     const bool inherit = cbp == 0 && ref_is_p && collocated;
-    const bool last_qp = !inherit && decided_skip && !PLAIN && (J.mb_ctl != nullptr || J.gom_rc != nullptr);
+    const bool last_qp = !inherit && decided_skip && CTRL && (J.mb_ctl != nullptr || J.gom_rc != nullptr);
     if (bg_skip || inherit || last_qp) {
       WV_LANES_BEGIN (lane)
       if (lane == 0) {

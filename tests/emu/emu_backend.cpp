@@ -135,9 +135,12 @@ class EmuBackend : public Backend {
 #ifndef WH_PLAIN_KERNEL
 #define WH_PLAIN_KERNEL 1
 #endif
-    const bool plain = WH_PLAIN_KERNEL && (Pin.flags & WH_SEQ_PLAIN) != 0;
+#ifndef WH_FRAME_KERNEL
+#define WH_FRAME_KERNEL 0
+#endif
+    const bool plain = WH_PLAIN_KERNEL && (Pin.flags & WH_SEQ_PLAIN) != 0, no_ctrl = WH_FRAME_KERNEL && (Pin.flags & WH_SEQ_NO_CTRL) != 0;
     WhSeqParams Pm = Pin;
-    Pm.flags &= ~WH_SEQ_PLAIN;
+    Pm.flags &= ~ (WH_SEQ_PLAIN | WH_SEQ_NO_CTRL);
     const WhSeqParams& P = Pm;
     if (Pin.flags & WH_SEQ_PLAIN)
       for (int j = 0; j < n; ++j) {
@@ -145,6 +148,11 @@ class EmuBackend : public Backend {
         if (P.flags || q.vaa_sad8x8 || q.sad_cost0 || q.bgd_flags || q.il_hint || q.mb_ctl || q.gom_rc || q.dyn_slice || q.want_bits || q.mb_end || q.mvc_shift || q.scc) {
           fprintf (stderr, "emu: WH_SEQ_PLAIN on a picture with optional inputs\n"); abort();
         }
+      }
+    if (Pin.flags & WH_SEQ_NO_CTRL)
+      for (int j = 0; j < n; ++j) {
+        const WhPicJob& q = jobs[j];
+        if (P.flags || q.il_hint || q.mb_ctl || q.gom_rc || q.dyn_slice || q.want_bits || q.mb_end || q.scc) { fprintf (stderr, "emu: WH_SEQ_NO_CTRL on a picture with control inputs\n"); abort(); }
       }
     // one emulated wavefront walks each slice in order like a wave of the device scheduler: a macroblock's cold inputs and
     // its speculative search windows (around the slice's last final vector) are fetched before its body runs
@@ -173,7 +181,7 @@ class EmuBackend : public Backend {
           }
           if (jobs[j].mb_end > 0 && (xy < jobs[j].mb_begin || xy >= jobs[j].mb_end)) continue;      // GOM-synchronous coding: only this range
           const int mbx = xy % P.mb_w, mby = xy / P.mb_w;
-          for (int lane = 0; lane < 64; ++lane) { if (plain) wh_inter_cold_fetch<true> (G, lane, P, jobs[j], mbx, mby); else wh_inter_cold_fetch (G, lane, P, jobs[j], mbx, mby); }
+          for (int lane = 0; lane < 64; ++lane) { if (plain) wh_inter_cold_fetch<1> (G, lane, P, jobs[j], mbx, mby); else if (no_ctrl) wh_inter_cold_fetch<3> (G, lane, P, jobs[j], mbx, mby); else wh_inter_cold_fetch (G, lane, P, jobs[j], mbx, mby); }
           WhInterCtx X;
           X.slice_idc = jobs[j].dyn_slice ? jobs[j].dyn_slice - 1 : s; X.slice_first = jobs[j].dyn_slice ? jobs[j].dyn_first : first;
           X.win = &WB;
@@ -187,6 +195,7 @@ class EmuBackend : public Backend {
           if (P.flags & WH_SEQ_SCC) wh_inter_mb_body_t<true> (S, G, P, jobs[j], mbx, mby, X, early);
           else if (plain && WH_PLAIN_KERNEL == 2 && P.complexity == 0) wh_inter_mb_body_t<false, 2> (S, G, P, jobs[j], mbx, mby, X, early);
           else if (plain) wh_inter_mb_body_t<false, 1> (S, G, P, jobs[j], mbx, mby, X, early);
+          else if (no_ctrl) wh_inter_mb_body_t<false, 3> (S, G, P, jobs[j], mbx, mby, X, early);
           else wh_inter_mb_body_t<false> (S, G, P, jobs[j], mbx, mby, X, early);
           if (early.calls != 1) { fprintf (stderr, "emu: the P macroblock body called back %d times at MB %d\n", early.calls, xy); abort(); }
           if (jobs[j].gom_rc) wh_gom_close_if_last (P, jobs[j], xy);
