@@ -160,8 +160,10 @@ extern "C" int WelsHipDownsamplePicture (int iDevice, uint8_t* const pDst[3], co
   std::lock_guard<std::mutex> lock (c->mu);
   if (hipSetDevice (iDevice) != hipSuccess) return WELSHIP_ERR_NO_DEVICE;
   if (!c->ok) {
-    if (hipStreamCreateWithFlags (&c->st, hipStreamNonBlocking) != hipSuccess) return WELSHIP_ERR_UNKNOWN;
-    if (hipMalloc ((void**)&c->d_planes, sizeof (DsPlane) * 24) != hipSuccess || hipHostMalloc ((void**)&c->h_planes, sizeof (DsPlane) * 24) != hipSuccess) return WELSHIP_ERR_MEMORY;
+    // (a call that fails here leaves what it got in the context: the next call continues from there instead of creating another stream)
+    if (!c->st && hipStreamCreateWithFlags (&c->st, hipStreamNonBlocking) != hipSuccess) { c->st = nullptr; return WELSHIP_ERR_UNKNOWN; }
+    if (!c->d_planes && hipMalloc ((void**)&c->d_planes, sizeof (DsPlane) * 24) != hipSuccess) { c->d_planes = nullptr; (void)hipGetLastError(); return WELSHIP_ERR_MEMORY; }
+    if (!c->h_planes && hipHostMalloc ((void**)&c->h_planes, sizeof (DsPlane) * 24) != hipSuccess) { c->h_planes = nullptr; (void)hipGetLastError(); return WELSHIP_ERR_MEMORY; }
     c->ok = true;
   }
   // the stages CDownsampling::Process would take (kernels/downsample_px.h wh_ds_plan)

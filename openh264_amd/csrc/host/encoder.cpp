@@ -360,6 +360,14 @@ struct SessionCore {
     if (!use_compact || frame_index != 0 || have_recon) { set_err ("pipelined groups need packed records and must be switched on before the first picture"); return WELSHIP_ERR_UNSUPPORTED; }
     if (prm.bEnableSceneChangeDetect) { set_err ("pipelined groups: scene-change detection reads a device statistic back before every picture"); return WELSHIP_ERR_UNSUPPORTED; }
     const size_t rec_y = (size_t)seq.rec_stride_y * (mb_h * 16 + 64), rec_c = (size_t)seq.rec_stride_c * ((mb_h * 16 + 64) / 2);
+    // The source ring must outlast the steps in flight: when a CAVLC overflow of picture k is found, k+1 .. k+ahead have been tiled into
+    // the ring already, and the repeat of k reads its own slot and (LOW complexity: the VAA SADs) the slot of k-1 -- ahead + 2 slots.
+    while (ring < ahead + 2) {
+      uint8_t* p = (uint8_t*)be->alloc (src_bytes);
+      if (!p) { set_err ("out of device memory"); return WELSHIP_ERR_MEMORY; }
+      d_src.push_back (p);
+      ++ring;
+    }
     for (int k = 0; k < ahead; ++k) {
       DevPicture& d = pic[2 + k];
       d.base = (uint8_t*)be->alloc (DevPicture::alloc_bytes (rec_alloc_bytes + 128));
@@ -821,6 +829,7 @@ struct WelsHipEncoderGroup {
   // pipelined mode (WelsHipGroupSetPipelined / WelsHipGroupEncodeFramesPipelined): second job array (the device may still read step
   // k - 1's descriptors when step k's are uploaded), page-locked host copies, one spare descriptor for re-runs
   bool pipelined = false;
+  bool pipe_failed = false;           // WelsHipGroupSetPipelined failed half way (out of memory): some sessions have their pipeline buffers, the group is unusable
   int depth = 1;                      // buffer sets: 1 + the steps the device may run ahead of the entropy coder
   WhPicJob* d_jobs_n[WH_PIPE_MAX_AHEAD + 1] = {};   // per buffer set ([0] = d_jobs)
   WhPicJob* d_job_aux = nullptr;
@@ -1059,7 +1068,7 @@ void WelsHipGroupDestroy (WelsHipEncoderGroup* g) {
   if (!g) return;
   g->be->sync();
   for (auto& s : g->sess) s->release();
-  if (g->pipelined) {
+  {   // (whether or not WelsHipGroupSetPipelined got through: a call that failed half way leaves some of these behind; everything here is null-safe)
     for (int b = 0; b <= WH_PIPE_MAX_AHEAD; ++b) {
       if (!g->h_jobs_p[b].empty()) g->be->unpin_host (g->h_jobs_p[b].data());
       if (!g->h_off_all[b].empty()) g->be->unpin_host (g->h_off_all[b].data());
@@ -1089,6 +1098,7 @@ int WelsHipGroupBegin (WelsHipEncoderGroup* g, int slot) {
   if (!g) return WELSHIP_ERR_INIT_PARA;
   // (a pipelined group's pictures write their records into the buffer set of their step: the synchronous calls would read the wrong one)
   if (g->pipelined) { set_err ("pipelined group: frame steps go through WelsHipGroupEncodeFramesPipelined"); return WELSHIP_ERR_INIT_PARA; }
+  if (g->pipe_failed) { set_err ("the group could not be made a pipelined one (out of memory) and is in an inconsistent state: destroy it"); return WELSHIP_ERR_INIT_PARA; }
   const int n = (int)g->sess.size();
   // scene-change statistic for the sessions whose frame type it can still change: one launch, read back before the
   // pictures are begun
@@ -1253,6 +1263,9 @@ int WelsHipGroupSetPipelined (WelsHipEncoderGroup* g, int ahead) {
   if (ahead > WH_PIPE_MAX_AHEAD) { set_err ("pipelined groups: at most 3 steps ahead"); return WELSHIP_ERR_INIT_PARA; }
   if (g->pipelined) { if (ahead == g->depth - 1) return WELSHIP_OK; set_err ("the group is pipelined already, with a different number of steps ahead"); return WELSHIP_ERR_INIT_PARA; }
   if (g->queues != 1) { set_err ("pipelined groups use one compute queue (WELSHIP_QUEUES=1)"); return WELSHIP_ERR_UNSUPPORTED; }
+  if (g->pipe_failed) { set_err ("an earlier WelsHipGroupSetPipelined failed half way: destroy the group"); return WELSHIP_ERR_INIT_PARA; }
+  // from here on a failure leaves buffers behind (WelsHipGroupDestroy frees them) and the group unusable
+  struct Guard { WelsHipEncoderGroup* g; bool ok = false; ~Guard() { if (!ok) g->pipe_failed = true; } } guard {g};
   const int n = (int)g->sess.size(), depth = 1 + ahead;
   const size_t off_words = (size_t)g->sess[0]->num_mb + 1;
   for (int b = 0; b < depth; ++b) {
@@ -1279,6 +1292,7 @@ int WelsHipGroupSetPipelined (WelsHipEncoderGroup* g, int ahead) {
   if (g->be->sync()) { set_err ("device error while setting up the pipelined group"); return WELSHIP_ERR_UNKNOWN; }
   g->depth = depth;
   g->pipelined = true;
+  guard.ok = true;
   return WELSHIP_OK;
 }
 
@@ -1407,6 +1421,12 @@ int WelsHipGroupEncodeFramesPipelined (WelsHipEncoderGroup* g, const WelsHipSour
   const auto tc0 = std::chrono::steady_clock::now();
   const std::function<double()> now = [&] () { return std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now() - tc0).count(); };
   double tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  // The cheap checks of the submitting half come before anything is taken off the pending queue: a call that is refused (picture size,
+  // a session that cannot begin a frame) leaves the group exactly as it was -- the oldest step is still pending and can be retrieved.
+  if (srcs) {
+    for (int i = 0; i < n; ++i) if (srcs[i].iPicWidth != g->sess[i]->prm.iPicWidth || srcs[i].iPicHeight != g->sess[i]->prm.iPicHeight) { set_err ("source picture size differs from the session's"); return WELSHIP_ERR_INIT_PARA; }
+    for (int i = 0; i < n; ++i) { const int rc = g->sess[i]->begin_frame_check(); if (rc) return rc; }
+  }
   if (finish) for (auto& c : g->sess) { c->fin = c->pendq.front(); c->pendq.pop_front(); }
   std::vector<int> rcs (n, 0);
   int frc = WELSHIP_OK, src_rc = WELSHIP_OK;
@@ -1422,7 +1442,8 @@ int WelsHipGroupEncodeFramesPipelined (WelsHipEncoderGroup* g, const WelsHipSour
   if (submitted) ++g->pending;
   if (trace) fprintf (stderr, "welship pipe: submit half: staging set free %.2f, staged + H2D queued %.2f, kernels queued %.2f | finish half: that step done on the device %.2f, copies queued %.2f, entropy-coded %.2f ms\n",
                       tm[0], tm[1], tm[2], tm[3], tm[4], tm[5]);
-  if (srcs && src_rc) return src_rc;      // nothing of this step was queued (the checks come first) unless the device itself failed
+  // (a failing submit half after the checks above is a device / memory failure: the finished step's results are still reported first, so
+  // that its bitstreams and a CAVLC overflow are not lost; the submit error follows)
   if (frc) return frc;
   if (finish) {
     // CAVLC overflow (rare): that picture again with the macroblock's QP raised, then the pictures submitted after it, oldest first -- each
@@ -1458,6 +1479,7 @@ int WelsHipGroupEncodeFramesPipelined (WelsHipEncoderGroup* g, const WelsHipSour
     }
     if (pFinished) *pFinished = 1;
   }
+  if (srcs && src_rc) return src_rc;
   return WELSHIP_OK;
 }
 

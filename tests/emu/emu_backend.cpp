@@ -198,6 +198,13 @@ class EmuBackend : public Backend {
           else if (no_ctrl) wh_inter_mb_body_t<false, 3> (S, G, P, jobs[j], mbx, mby, X, early);
           else wh_inter_mb_body_t<false> (S, G, P, jobs[j], mbx, mby, X, early);
           if (early.calls != 1) { fprintf (stderr, "emu: the P macroblock body called back %d times at MB %d\n", early.calls, xy); abort(); }
+          // WELSHIP_EMU_CORRUPT_MB=<xy> (tests/test_hooks_dynslice.py): one level of that macroblock's record is off by one whenever a RANGED
+          // call codes it -- what a lost update between the slice tasks' device calls would look like.  The harness must report it.
+          if (jobs[j].mb_end > 0) if (const char* cm = getenv ("WELSHIP_EMU_CORRUPT_MB")) if (atoi (cm) == xy) {
+            WhMbRecord& R = ((WhMbRecord*)jobs[j].records)[xy];
+            int16_t* lv = &R.luma[0][0];
+            for (int i = 0; i < 16 * 16; ++i) if (lv[i] > 1 || lv[i] < -1) { lv[i] += lv[i] > 0 ? 1 : -1; break; }
+          }
           if (jobs[j].gom_rc) wh_gom_close_if_last (P, jobs[j], xy);
           poison (&S, sizeof (S)); poison (&WB, sizeof (WB)); poison (&G, sizeof (G));      // nothing survives from one macroblock to the next
         }

@@ -1,4 +1,4 @@
-"""Size-limited slices (SM_SIZELIMITED_SLICE) through the dispatch-table binding, on request (WELS_HIP_DYNSLICE=1).
+"""Size-limited slices (SM_SIZELIMITED_SLICE) through the dispatch-table binding (default on; WELS_HIP_DYNSLICE=0 declines them).
 
 Where such a slice ends is decided by the entropy writer, macroblock by macroblock (DynSlcJudgeSliceBoundaryStepBack,
 codec/encoder/core/src/svc_encode_slice.cpp:1741-1790): when a macroblock would make the slice larger than its limit, the writer
@@ -11,7 +11,13 @@ Checked here on the CPU test build of the kernels (tests/emu): random sessions b
 (tools/fuzz_dynslice.py: 421 .. 3000 bytes per slice, i.e. from slices shorter than a macroblock row -- dozens per picture -- to one
 slice per picture; all rate-control modes, temporal layers, LTR, denoising, background / scene-change detection, the three
 deblocking modes, I pictures in mid-stream, CAVLC and CABAC, one to four slice threads, camera video and screen content).  The reference table's own size-limited rows: tests/test_hooks_sha1.py.
-This path has not run on the MI355X yet (no GPU test): it is opt-in until it has.
+The comparison (tools/fuzz_dynslice.py one_case): the unmodified reference runs FIRST, several times when the session has slice threads,
+and the hooked run's stream must be one of the streams it produced; every result line names the set ("reference: 1 stream in 3 runs
+{ef6f29ba}; with the hooks: ef6f29ba").  One class of sessions has a set larger than one -- slice threads with screen content or rate
+control: the reference's own output depends on which pool thread runs which slice task (root cause in one_case; measured in
+profiles/r04_size_limited_slices_screen_threads_reference_varies.txt: seed 21001, the case the round-3 driver run reported as DIFF, is
+such a session -- 4 streams in 60 runs of the unmodified reference, the hooked run's stream one of them).  Every other session must
+match the reference's ONE stream.
 """
 import os
 import sys
@@ -117,6 +123,22 @@ def test_random_sessions_with_slice_threads_on_emulation(emu_lib):
     bad = [(s, m) for s, m, ok in res if not ok]
     assert not bad, bad[0]
     assert sum(1 for _, m, _ in res if m.startswith("ok") and "-threads 1 " not in m) >= 6
+
+
+def test_harness_catches_one_corrupted_macroblock_in_one_slice_threads_range(emu_lib):
+    """The comparison is only worth something if it fails when it should: the test build is told to change ONE coefficient level of ONE
+    macroblock's record whenever a ranged call codes it (tests/emu/emu_backend.cpp, WELSHIP_EMU_CORRUPT_MB) -- in the last slice thread's
+    partition of a constant-QP session with three slice threads.  The unmodified reference gives one stream for such a session, so
+    nothing but an exact match passes; the case must come back as DIFF (or as a failed run: the writer's own checks may notice first)."""
+    import fuzz_dynslice
+    with tempfile.TemporaryDirectory() as tmp:
+        force = {"-threads": "3", "-qp": "10", "-rc": "-1", "-cabac": "0"}
+        seed, msg, ok = fuzz_dynslice.one_case(1005, emu_lib, tmp, True, 4, False, False, force=force)
+        assert ok and msg.startswith("ok") and "reference: 1 stream in 3 runs" in msg, msg
+        w, h = (int(t) for t in msg.split()[1].split("x"))
+        num_mb = ((w + 15) // 16) * ((h + 15) // 16)
+        seed, msg, ok = fuzz_dynslice.one_case(1005, emu_lib, tmp, True, 4, False, False, force=force, env={"WELSHIP_EMU_CORRUPT_MB": str(num_mb - 3)})
+        assert not ok and (msg.startswith("DIFF") or msg.startswith("FAILED")), msg
 
 
 # ---- GPU tier (first run on the MI355X: round 3, profiles/r03_size_limited_slices_*_mi355x.txt)

@@ -293,12 +293,15 @@ def test_pipelined_group_matches_the_synchronous_one(emu_lib, ring, ahead):
     _pipelined_vs_synchronous(emu_lib, 64, 48, 7, 26, ("synth", "checker5", "synth"), ring, intra_period=4, ahead=ahead)
 
 
-@pytest.mark.parametrize("ahead", [1, 2])
-def test_pipelined_group_reencodes_after_cavlc_overflow(emu_lib, ahead):
-    """QP 3 on checkerboards: pictures in the middle and at the end of the stream overflow the CAVLC level range, when their successor
-    is already on the device: the picture is coded again, then the successor (it predicted from the replaced reconstruction)."""
+@pytest.mark.parametrize("ring,ahead,frames", [(3, 1, 4), (3, 2, 4), (2, 2, 7), (2, 3, 8), (3, 3, 8), (5, 2, 6)])
+def test_pipelined_group_reencodes_after_cavlc_overflow(emu_lib, ring, ahead, frames):
+    """QP 3 on checkerboards: pictures in the middle and at the end of the stream overflow the CAVLC level range, when their successors
+    are already on the device: the picture is coded again, then the successors (they predicted from the replaced reconstruction).
+    The repeat reads the picture's source slot and the previous picture's (LOW complexity) while `ahead` later pictures have been tiled
+    into the ring: a ring asked for with fewer than ahead + 2 slots is grown by WelsHipGroupSetPipelined (round-3 advisor finding:
+    ring 2 / ahead 2 and ring 3 / ahead 3 coded the wrong source in the repeat)."""
     import openh264_amd as oh
-    seqs, got = _pipelined_vs_synchronous(emu_lib, 64, 64, 4, 3, ("synth", "checker5", "synth", "checker8"), 3, ahead=ahead)
+    seqs, got = _pipelined_vs_synchronous(emu_lib, 64, 64, frames, 3, ("synth", "checker5", "synth", "checker8"), ring, ahead=ahead)
     for s in (1, 3):
         st = {}
         bs, _ = oh.encode_sequence(seqs[s], 64, 64, lib_path=emu_lib, stats=st, iDLayerQp=3, uiIntraPeriod=0, fMaxFrameRate=30.0, iTargetBitrate=5000000)

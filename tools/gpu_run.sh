@@ -1,0 +1,66 @@
+#!/bin/bash
+# The one script that runs on the GPU box:   gpurun -- 'bash tools/gpu_run.sh <tag> <stage> [<stage> ...]'
+# Every stage writes under gpurun_out/<tag>/ and prints a short summary; what is worth keeping is copied into profiles/ by hand.
+#
+# stages
+#   tier            the GPU tier exactly as the driver runs it (serial, -x) -> pytest_gpu.txt
+#   tier_all        the same without -x (every failure of the tier in one run)
+#   bench           the default bench line -> bench_default.json (+ a digest)
+#   quick           bench.py --quick (the timed configuration only) -> bench_quick.json
+#   stats           rocprofv3 --kernel-trace --stats of `bench.py --quick` -> kernel_stats.csv
+#   pmc             FETCH_SIZE / WRITE_SIZE passes of `bench.py --quick` (separate runs, --kernel-trace only beside --pmc) -> pmc_traffic.txt
+#   phase           in-kernel phase cycles of the P macroblock body (tools/phase_profile.py 256) -> phase_cycles.txt
+#   tables          every device row of both SHA1 tables incl. the size-limited rows -> *_rows.txt
+#   repro:<seeds>   size-limited-slice sessions <seeds> (comma separated; s = screen content, q = low QP: e.g. s21001,q11012,1003) with slice threads,
+#                   RUNS times each (default 6), for every library of LIBS (default: the product library) -> repro.txt
+#   ab:<tagA>,<tagB>   `bench.py --quick` alternating between two candidate libraries openh264_amd/libwelship_<tag>.so ("-" = the product library)
+cd "$(dirname "$0")/.."
+export TMPDIR=/tmp
+tag=${1:?tag}; shift
+o=gpurun_out/$tag; mkdir -p $o
+T0=$SECONDS; lap() { echo "[$((SECONDS - T0)) s] $1"; }
+digest() { python - "$1" <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+r = d["roofline"]
+print("value", round(d["value"]), "ms_per_step", round(d["ms_per_step"], 2), "frac", round(r["frac"], 4), "avg_launch_ms", r.get("avg_launch_ms"), "traffic x", r.get("traffic_over_algorithmic"), "verified", d.get("verified"))
+for k in ("e2e", "e2e_pipelined"):
+    if k in d: print(k, {x: d[k][x] for x in d[k] if x in ("frames_per_s", "frames_per_s_second_half", "steps_ahead")}, d[k].get("bitstream_vs_reference", {}).get("match"))
+for k in d:
+    if k.startswith("config") and k != "config": print(k, d[k].get("device_frames_per_s"), d[k].get("c_path_frames_per_s"), d[k].get("same_bitstreams"))
+print("res_clip", d.get("res_clip", {}).get("value"), "intra_720p", d.get("intra_720p", {}).get("value"), "latency", d.get("latency"), "events_ms", d.get("events_ms"))
+print("cpu_baseline", d.get("cpu_baseline", {}).get("value"))
+PY
+}
+for stage in "$@"; do
+  case $stage in
+  tier)     timeout 1500 python -m pytest tests -m gpu -x -q > $o/pytest_gpu.txt 2>&1; tail -5 $o/pytest_gpu.txt | cut -c1-300; lap "gpu tier (serial, -x, as the driver runs it)";;
+  tier_all) timeout 1500 python -m pytest tests -m gpu -q > $o/pytest_gpu_all.txt 2>&1; tail -15 $o/pytest_gpu_all.txt | cut -c1-300; lap "gpu tier (serial, every failure)";;
+  bench)    timeout 900 python bench.py > $o/bench_default.json 2> $o/bench_default.err; digest $o/bench_default.json; lap "bench default";;
+  quick)    timeout 300 python bench.py --quick > $o/bench_quick.json 2> $o/bench_quick.err; digest $o/bench_quick.json; lap "bench --quick";;
+  stats)    ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$o/stats -- python $OLDPWD/bench.py --quick --steps 6 --warmup 2 > $OLDPWD/$o/prof_bench.json 2> $OLDPWD/$o/prof_bench.err )
+            f=$(find $o/stats -name "*kernel_stats.csv" | head -1); cp $f $o/kernel_stats.csv 2>/dev/null; head -14 $o/kernel_stats.csv | cut -c1-200
+            python -c "import json; d=json.loads(open('$o/prof_bench.json').read().strip().splitlines()[-1]); print('HIP events of the same run: avg MD launch ms', d['roofline']['avg_launch_ms'])"
+            rm -rf $o/stats; lap "kernel stats";;
+  pmc)      for c in FETCH_SIZE WRITE_SIZE; do
+              ( cd /tmp && timeout 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OLDPWD/$o/pmc_$c -- python $OLDPWD/bench.py --quick --steps 8 --warmup 4 > $OLDPWD/$o/pmc_$c.log 2>&1 )
+              python tools/pmc_summary.py $o/pmc_$c | grep -E "inter_|intra_|deblock|k_tile|k_expand|src_tile"
+              rm -rf $o/pmc_$c
+            done > $o/pmc_traffic.txt 2>&1; cat $o/pmc_traffic.txt; lap "pmc";;
+  phase)    timeout 200 python tools/phase_profile.py 256 > $o/phase_cycles.txt 2>&1; head -30 $o/phase_cycles.txt; lap "phase cycles";;
+  tables)   W=${WORKERS:-48}
+            timeout 400 python tools/sha1_table_rows.py --workers $W > $o/camera_table_1792_rows.txt 2>&1; tail -2 $o/camera_table_1792_rows.txt | cut -c1-220
+            timeout 300 python tools/sha1_table_rows.py --table adobe --workers $W > $o/screen_table_896_rows.txt 2>&1; tail -2 $o/screen_table_896_rows.txt | cut -c1-220
+            timeout 300 python tools/sha1_table_rows.py --dynslice --workers $W > $o/camera_table_size_limited_512_rows.txt 2>&1; tail -2 $o/camera_table_size_limited_512_rows.txt | cut -c1-220
+            timeout 300 python tools/sha1_table_rows.py --table adobe --dynslice --workers $W > $o/screen_table_size_limited_256_rows.txt 2>&1; tail -2 $o/screen_table_size_limited_256_rows.txt | cut -c1-220
+            lap "SHA1 tables";;
+  repro:*)  FUZZ_DYNSLICE_KEEP=$o/streams timeout ${REPRO_TIMEOUT:-600} python tools/repro_dynslice.py "${stage#repro:}" > $o/repro.txt 2>&1; grep -E "^==|DIFF|FAILED|VARIES|summary" $o/repro.txt | cut -c1-260 | head -80; lap "repro";;
+  ab:*)     IFS=, read -r A B <<< "${stage#ab:}"
+            for rep in 1 2 3; do for t in $A $B; do
+              lib=openh264_amd/libwelship.so; [ "$t" != "-" ] && lib=openh264_amd/libwelship_$t.so
+              WELSHIP_LIB=$PWD/$lib timeout 200 python bench.py --quick > $o/ab_${t}_$rep.json 2> $o/ab_${t}_$rep.err
+              python -c "import json; d=json.loads(open('$o/ab_${t}_$rep.json').read().strip().splitlines()[-1]); print('$t', $rep, 'value', round(d['value']), 'md_ms', d['roofline']['avg_launch_ms'], 'verified', d.get('verified'))"
+            done; done | tee $o/ab.txt; lap "A/B";;
+  *)        echo "unknown stage $stage";;
+  esac
+done
