@@ -13,12 +13,7 @@
 
 #define WH_BITS_HAS_QP_DELTA 0x40000000      /* flag in the count: the macroblock codes mb_qp_delta (cbp > 0 or Intra16x16) */
 
-WH_FN int wh_ue_bits (unsigned v) {
-  unsigned k = v + 1u;
-  int n = 0;
-  while (k > 1) { k >>= 1; ++n; }
-  return 2 * n + 1;
-}
+WH_FN int wh_ue_bits (unsigned v) { return 2 * (31 - __builtin_clz (v + 1u)) + 1; }       // (v + 1 >= 1 for every code number that occurs)
 WH_FN int wh_se_bits_c (int v) { return wh_ue_bits ((unsigned) (v > 0 ? 2 * v - 1 : -2 * v)); }
 
 // residual_block_cavlc (7.3.5.3.2 / 9.2): lv[0..end_idx] zig-zag levels; nc: 0..16, or 17 for ChromaDCLevel.

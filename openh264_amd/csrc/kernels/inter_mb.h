@@ -77,12 +77,11 @@ typedef struct alignas (16) WhInterStage {
 typedef struct WhWin { int x0, y0, cx0, cy0; WhWinLds* b; } WhWin;     // picture coordinates of element (0,0) of win / cwin + where they live
 
 // ---- mvd cost: lambda * bits(se(mvd))  (md.cpp:797-824, svc_enc_golomb.h BsSizeSE) --------------
+// (branch-free: the count is evaluated on the scalar unit eight times per diamond step, and as a shift loop it was five instructions
+//  and a taken branch per bit of the difference)
 WH_FN int wh_se_bits (int v) {
-  if (v == 0) return 1;
-  unsigned k = (unsigned) (v > 0 ? 2 * v - 1 : -2 * v) + 1u;
-  int n = 0;
-  while (k > 1) { k >>= 1; ++n; }
-  return 2 * n + 1;
+  const unsigned k = v > 0 ? 2u * (unsigned)v : 1u - 2u * (unsigned)v;      // codeNum + 1 of se(v): 2v for v > 0, 1 - 2v otherwise (v = 0: 1)
+  return 2 * (31 - __builtin_clz (k)) + 1;
 }
 WH_FN int wh_mvd_cost (int lambda, int dx, int dy) { return (int) (uint16_t) (lambda * wh_se_bits (dx)) + (int) (uint16_t) (lambda * wh_se_bits (dy)); }
 
@@ -913,10 +912,7 @@ WH_FN int wh_enc_inter_y (WhMbLds& S, int qp) {
   // per 8x8: score = sum over its four 4x4 blocks (9 when a level exceeds 1, else the run score); the reference stops
   // adding once an 8x8 reaches 6, which cannot change the two threshold tests below
   int s0, s1, s2, s3;
-#define WH_BSCORE(l) (S.part[l] > 1 ? 9 : S.part[l] == 1 ? wh_single_ctr_mask ((unsigned)S.part2[l]) : 0)
-  WV_SUM2 (s0, s1, lane, (lane < 4 ? WH_BSCORE (lane) : 0), (lane >= 4 && lane < 8 ? WH_BSCORE (lane) : 0));
-  WV_SUM2 (s2, s3, lane, (lane >= 8 && lane < 12 ? WH_BSCORE (lane) : 0), (lane >= 12 && lane < 16 ? WH_BSCORE (lane) : 0));
-#undef WH_BSCORE
+  WV_QUADSUM4 (s0, s1, s2, s3, lane, (lane < 16 ? WH_Q_SCORE (S.part2[lane]) : 0));          // lanes 0..15 = blocks 0..15 in luma4x4BlkIdx order: a quad is an 8x8
   int cbp = 0;
   if (s0 + s1 + s2 + s3 >= 6) cbp = (s0 >= 4 ? 1 : 0) | (s1 >= 4 ? 2 : 0) | (s2 >= 4 ? 4 : 0) | (s3 >= 4 ? 8 : 0);
   WV_LANES_BEGIN (lane)
@@ -925,7 +921,7 @@ WH_FN int wh_enc_inter_y (WhMbLds& S, int qp) {
     for (int q = 0; q < 4; ++q) { const int k = (lane & 3) * 4 + q; S.lv_luma[b * 16 + k] = S.res[b * 16 + wh_zigzag (k)]; }
     if (lane < 16) {
       int n = 0;
-      if ((cbp >> (lane >> 2)) & 1) n = __builtin_popcount ((unsigned)S.part2[lane]);
+      if ((cbp >> (lane >> 2)) & 1) n = __builtin_popcount (WH_Q_MASK (S.part2[lane]));
       S.nzc[wh_blk_y (lane) * 4 + wh_blk_x (lane)] = (uint8_t)n;
     }
     (void)on;
@@ -947,21 +943,25 @@ WH_FN int wh_enc_inter_y (WhMbLds& S, int qp) {
 WH_FN bool wh_try_py_skip (WhMbLds& S, int qp) {
   wh_quant_blocks (S, 0, 16, qp, qp, S.tmp, 0);
   int big, ctr;
-  WV_SUM2 (big, ctr, lane, (lane < 16 ? (S.part[lane] > 1) : 0), (lane < 16 && S.part[lane] == 1 ? wh_single_ctr_mask ((unsigned)S.part2[lane]) : 0));
+  WV_SUM2 (big, ctr, lane, (lane < 16 ? WH_Q_BIG (S.part2[lane]) : 0), (lane < 16 ? WH_Q_SCORE (S.part2[lane]) : 0));      // (the score only counts when no block is big)
   return big == 0 && ctr < 6;
 }
-WH_FN bool wh_try_puv_skip (WhMbLds& S, int pl, int qpc) {
-  const int16_t* r = &S.res[256 + pl * 64];
+// both chroma planes at once (the reference tests Cb, then Cr: both must pass)
+WH_FN bool wh_try_puv_skip (WhMbLds& S, int qpc) {
   // WelsHadamardQuant2x2Skip_c (encode_mb_aux.cpp:226-245)
   const int ff = wh_ff_inter (qpc, 0) << 1, mf = wh_mf (qpc, 0) >> 1;
   const int16_t thr = (int16_t) (((1 << 16) - 1) / mf - ff);
-  const int16_t s0 = (int16_t) (r[0] + r[32]), s1 = (int16_t) (r[0] - r[32]), s2 = (int16_t) (r[16] + r[48]), s3 = (int16_t) (r[16] - r[48]);
-  const int16_t d0 = (int16_t) (s0 + s2), d1 = (int16_t) (s0 - s2), d2 = (int16_t) (s1 + s3), d3 = (int16_t) (s1 - s3);
-  if (wh_abs (d0) > thr || wh_abs (d1) > thr || wh_abs (d2) > thr || wh_abs (d3) > thr) return false;
-  wh_quant_blocks (S, 256 + pl * 64, 4, qpc, qpc, S.tmp, 1);
-  int big, ctr;
-  WV_SUM2 (big, ctr, lane, (lane < 4 ? (S.part[lane] > 1) : 0), (lane < 4 && S.part[lane] == 1 ? wh_single_ctr_mask ((unsigned)S.part2[lane]) : 0));
-  return big == 0 && ctr < 7;
+  for (int pl = 0; pl < 2; ++pl) {
+    const int16_t* r = &S.res[256 + pl * 64];
+    const int16_t s0 = (int16_t) (r[0] + r[32]), s1 = (int16_t) (r[0] - r[32]), s2 = (int16_t) (r[16] + r[48]), s3 = (int16_t) (r[16] - r[48]);
+    const int16_t d0 = (int16_t) (s0 + s2), d1 = (int16_t) (s0 - s2), d2 = (int16_t) (s1 + s3), d3 = (int16_t) (s1 - s3);
+    if (wh_abs (d0) > thr || wh_abs (d1) > thr || wh_abs (d2) > thr || wh_abs (d3) > thr) return false;
+  }
+  wh_quant_blocks (S, 256, 8, qpc, qpc, S.tmp, 1);
+  int c0, c1, c2, c3;          // per plane (a quad of lanes each): score sum | number of big blocks << 8
+  WV_QUADSUM4 (c0, c1, c2, c3, lane, (lane < 8 ? WH_Q_SCORE (S.part2[lane]) | (WH_Q_BIG (S.part2[lane]) << 8) : 0));
+  (void)c2; (void)c3;
+  return c0 < 7 && c1 < 7;     // (a big block makes the word >= 256)
 }
 
 // ---- "cold" inputs of a P macroblock: data no kernel writes while the picture is being coded (source samples,
@@ -1360,7 +1360,7 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
         wh_dct_luma16 (M);
         if (wh_try_py_skip (M, qp)) {
           wh_dct_chroma (M);
-          if (wh_try_puv_skip (M, 0, qpc) && wh_try_puv_skip (M, 1, qpc)) ok = true;
+          if (wh_try_puv_skip (M, qpc)) ok = true;
         }
       }
       if (ok) {

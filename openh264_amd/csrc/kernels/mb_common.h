@@ -22,7 +22,7 @@ typedef struct WhMbLds {
   uint8_t  pred_c[128];       // Cb then Cr, stride 8
   uint8_t  pred4[9 * 16];     // candidate 4x4 predictions, [mode][y*4+x]
   int16_t  res[384];          // residual coefficients: luma blk*16 (luma4x4BlkIdx order), Cb 256.., Cr 320..
-  int16_t  tmp[320];          // transform scratch: [0,256) coefficients, [256,320) per-lane maxima of wh_quant_blocks
+  int16_t  tmp[320];          // transform scratch: [0,256) coefficients
   int32_t  part[64];          // reduction partials
   int32_t  part2[64];
   int16_t  dc[16];
@@ -413,35 +413,49 @@ WH_FN int wh_encrec_i4 (WhMbLds& S, int b, int pred_slot, int qp) {
 
 // JVT-O079 single-coefficient score of a block from the 16-bit mask of its non-zero zig-zag positions
 // (encode_mb_aux.cpp:417-436 WelsGetNoneZeroCount-style run table {3,2,2,1,1,1,0...}); equals wh_single_ctr.
+// JVT-O079 "single coefficient" score of a block whose levels are all +-1 (WelsGetNoneZeroCount / the run table of svc_encode_mb.cpp:
+// 3 for a coefficient right behind the previous one in zig-zag order, 2 after a run of one or two zeros, 1 after three to five, 0
+// beyond), from the mask of non-zero zig-zag positions.  Bit-parallel: a coefficient scores [run < 1] + [run < 3] + [run < 6], and
+// "run < d" says that one of the d positions below it is occupied -- positions below zero count as occupied (the run before the
+// first coefficient is its index).
 WH_FN int wh_single_ctr_mask (unsigned m) {
-  int ctr = 0, run = 0;
-  for (int k = 0; k < 16; ++k) {
-    if ((m >> k) & 1u) { ctr += (run == 0) ? 3 : (run <= 2) ? 2 : (run <= 5) ? 1 : 0; run = 0; }
-    else ++run;
-  }
-  return ctr;
+  const unsigned R = m << 6, M = R | 63u;
+  const unsigned a1 = M << 1, a3 = a1 | (M << 2) | (M << 3), a6 = a3 | (M << 4) | (M << 5) | (M << 6);
+  return __builtin_popcount (R & a1) + __builtin_popcount (R & a3) + __builtin_popcount (R & a6);
 }
-// quantise S.res[base + 0 .. 16*nblk) into `dst` (rounding offsets of table row `ffrow`: qp for inter, qp + 6 for intra); S.part[blk] = max |level| of the block,
-// S.part2[blk] = mask of non-zero zig-zag positions (`skip_dc`: position 0 is not part of the scan)
+// What wh_quant_blocks leaves per block in S.part2[blk]: the mask of non-zero zig-zag positions, the block's score and two flags
+#define WH_Q_MASK(w) ((unsigned)(w) & 0xffffu)                 /* bit k: zig-zag position k + skip_dc holds a level */
+#define WH_Q_SCORE(w) ((int)(((unsigned)(w) >> 16) & 0xffu))   /* 9 when a level exceeds 1, else the single-coefficient score of the mask */
+#define WH_Q_BIG(w) ((int)(((unsigned)(w) >> 24) & 1u))        /* some |level| > 1 */
+#define WH_Q_ANY(w) ((int)(((unsigned)(w) >> 25) & 1u))        /* some level != 0 */
+// quantise S.res[base + 0 .. 16*nblk) into `dst` (rounding offsets of table row `ffrow`: qp for inter, qp + 6 for intra); S.part2[blk] = the
+// block's WH_Q_* word (`skip_dc`: position 0 is not part of the scan).  Lane 4 b + q quantises the raster positions 4 q .. 4 q + 3 of
+// block b and leaves its share of the mask (its four positions' zig-zag indices) and its largest |level| in S.part; lane b gathers.
 WH_FN void wh_quant_blocks (WhMbLds& S, int base, int nblk, int qp, int ffrow, int16_t* dst, int skip_dc) {
   WV_LANES_BEGIN (lane)
   if (lane < nblk * 4) {
     int16_t mx = 0;
+    unsigned pm = 0;
+    // zig-zag index of raster position p, a nibble each: 0 1 5 6 | 2 4 7 12 | 3 8 11 13 | 9 10 14 15
+    const unsigned inv4 = (unsigned) (0xFEA9DB83C7426510ULL >> (16 * (lane & 3))) & 0xffffu;
     for (int k = 0; k < 4; ++k) {
       const int i = lane * 4 + k, pos = i & 15;
       int16_t a;
       dst[i] = wh_quant1_abs (S.res[base + i], wh_ff_row (ffrow, pos), wh_mf (qp, pos), &a);
       if (mx < a) mx = a;
+      pm |= (unsigned) (a != 0) << ((inv4 >> (4 * k)) & 15u);
     }
-    S.tmp[256 + lane] = mx;
+    S.part[lane] = (int32_t) (pm | ((unsigned) (uint16_t)mx << 16));
   }
   WV_LANES_END
   WV_LANES_BEGIN (lane)
   if (lane < nblk) {
-    S.part[lane] = wh_max (wh_max (S.tmp[256 + lane * 4], S.tmp[256 + lane * 4 + 1]), wh_max (S.tmp[256 + lane * 4 + 2], S.tmp[256 + lane * 4 + 3]));
-    unsigned m = 0;
-    for (int k = skip_dc; k < 16; ++k) m |= (unsigned) (dst[lane * 16 + wh_zigzag (k)] != 0) << (k - skip_dc);
-    S.part2[lane] = (int32_t)m;
+    const unsigned w0 = (unsigned)S.part[lane * 4], w1 = (unsigned)S.part[lane * 4 + 1], w2 = (unsigned)S.part[lane * 4 + 2], w3 = (unsigned)S.part[lane * 4 + 3];
+    const unsigned m = ((w0 | w1 | w2 | w3) & 0xffffu) >> skip_dc;
+    const int mx = wh_max (wh_max ((int) (w0 >> 16), (int) (w1 >> 16)), wh_max ((int) (w2 >> 16), (int) (w3 >> 16)));      // (|level| as uint16: 0 .. 32768)
+    const unsigned big = mx > 1, any = mx != 0;
+    const unsigned score = big ? 9u : (unsigned)wh_single_ctr_mask (m);      // (no level at all: empty mask, score 0)
+    S.part2[lane] = (int32_t) (m | (score << 16) | (big << 24) | (any << 25));
   }
   WV_LANES_END
 }
@@ -472,7 +486,7 @@ WH_FN int wh_encrec_chroma (WhMbLds& S, int qpc, int is_intra) {
   // keep a plane's AC when its JVT-O079 score reaches 7 (inter; the reference stops adding at 7, which cannot change
   // the test) -- intra keeps every plane that has a non-zero level
   int sc0, sc1, nzdc0, nzdc1;
-#define WH_CSCORE(l) (is_intra ? (S.part[l] != 0 ? 7 : 0) : (S.part[l] > 1 ? 9 : S.part[l] == 1 ? wh_single_ctr_mask ((unsigned)S.part2[l]) : 0))
+#define WH_CSCORE(l) (is_intra ? (WH_Q_ANY (S.part2[l]) ? 7 : 0) : WH_Q_SCORE (S.part2[l]))
   WV_SUM2 (sc0, sc1, lane, (lane < 4 ? WH_CSCORE (lane) : 0), (lane >= 4 && lane < 8 ? WH_CSCORE (lane) : 0));
 #undef WH_CSCORE
   WV_SUM2 (nzdc0, nzdc1, lane, (lane < 4 ? (S.cdc[lane] != 0) : 0), (lane >= 4 && lane < 8 ? (S.cdc[lane] != 0) : 0));
@@ -488,7 +502,7 @@ WH_FN int wh_encrec_chroma (WhMbLds& S, int qpc, int is_intra) {
     }
     if (lane < 8) {
       int n = 0;
-      if (lane < 4 ? keep0 : keep1) n = __builtin_popcount ((unsigned)S.part2[lane]);
+      if (lane < 4 ? keep0 : keep1) n = __builtin_popcount (WH_Q_MASK (S.part2[lane]));
       S.nzc[16 + lane] = (uint8_t)n;
     }
   }
