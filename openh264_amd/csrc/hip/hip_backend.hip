@@ -119,54 +119,37 @@ WH_DEFINE_MB_KERNEL (k_intra_slice, WhMbLds, wh_intra_mb_body, 1024, 0, 0)
 // them out in snake order, heavy with light.  Inside a slice nothing changes: tickets in dependency order (LDS counter),
 // done bits in LDS, data through the workgroup-coherent L1/L2.
 #define WH_MD_MAX_SLOTS 4
-#ifndef WH_EARLY_CLAIM
-#define WH_EARLY_CLAIM 0           /* claim + fetch the wave's next macroblock when the body's prediction is final (before residual coding): measured, no gain */
-#endif
-template <class F> struct WhEarlyFn { F& f; __device__ __forceinline__ void call() { f(); } };
-// Candidate, measured and switched off: the job descriptor of the slot a wave works on as wave-uniform REGISTER values -- every lane
-// reads one dword of the LDS copy (two loads, one wait), v_readlane hands each dword out as a scalar -- instead of one LDS read per
-// field where the body needs it (some thirty per macroblock, eight in a row in the claim path, each with a wait in front of its first
-// use).  134 VGPRs, no scratch (it needs the selects of intra_mb.h wh_tile_fetch_nb_planes to stay out of memory), bit-exact -- and
-// 3.7 % SLOWER on the MI355X (MD launch 13.70 against 13.20 ms, same box): a wave changes slots with almost every macroblock, and 74
-// v_readlane plus the scalar spills they cause cost more than the LDS round trips, which other waves hide.
-#ifndef WH_JOB_REGS
-#define WH_JOB_REGS 0
-#endif
-template <int I, int N> struct WhLaneWords {      // d[I .. N) = lanes I .. of (t0, t1): constant indices only, so that d never exists in memory
-  static __device__ __forceinline__ void get (uint32_t* d, uint32_t t0, uint32_t t1) {
-    d[I] = (uint32_t)__builtin_amdgcn_readlane ((int) (I < 64 ? t0 : t1), I & 63);
-    WhLaneWords<I + 1, N>::get (d, t0, t1);
-  }
-};
-template <int N> struct WhLaneWords<N, N> { static __device__ __forceinline__ void get (uint32_t*, uint32_t, uint32_t) {} };
-__device__ __forceinline__ void wh_job_to_regs (WhPicJob& R, const WhPicJob& L, int lane) {
-  constexpr int N = (int) (sizeof (WhPicJob) / 4);
-  static_assert (sizeof (WhPicJob) % 4 == 0 && N <= 128, "WhPicJob: whole dwords, at most two per lane");
-  const uint32_t* s = (const uint32_t*)&L;
-  const uint32_t t0 = s[lane < N ? lane : 0];
-  const uint32_t t1 = N > 64 ? s[64 + lane < N ? 64 + lane : 0] : 0u;
-  uint32_t d[N];
-  WhLaneWords<0, N>::get (d, t0, t1);
-  __builtin_memcpy (&R, d, sizeof (R));
-}
+template <class F> struct WhEarlyFn { F& f; __device__ __forceinline__ void call() { f(); } };      // (the run scheduler's callback from the macroblock body)
 #ifndef WH_SPEC_WINDOWS
 #define WH_SPEC_WINDOWS 1          /* fetch a macroblock's search windows with its cold inputs, around the slice's last vector */
 #endif
-// PLAIN: see inter_mb.h wh_inter_cold_fetch.  The variant has 30 k instructions instead of 44 k (no background-detection, inter-layer, bit-counting,
+// PLAIN: see inter_mb.h wh_inter_cold_fetch.  The variant has a third fewer instructions (no background-detection, inter-layer, bit-counting,
 // rate-control or QP-map code) and codes a session group's pictures 7.4 % faster (MD launch 13.70 -> 12.69 ms, same box:
 // profiles/r03_p_kernel_candidates_ab.txt); 0 = every launch takes the general kernel.
 #ifndef WH_PLAIN_KERNEL
-#define WH_PLAIN_KERNEL 1
+#define WH_PLAIN_KERNEL 2
 #endif
-// (WH_PLAIN_KERNEL=2, candidate: additionally a variant with LOW complexity known at compile time -- not measured on the device yet;
-//  WH_FRAME_KERNEL=1, candidate: a variant for the frame API's camera pictures without control inputs, WH_SEQ_NO_CTRL -- not measured either)
+// 2 (the default since round 4: MD launch 10.76 -> 10.45 ms in a same-box A/B, profiles/r04_ab_claim_path_plain2_chroma.txt): additionally a
+// variant that knows LOW complexity -- the reference's default -- at compile time (no SATD paths in the search, the refinement and the intra test);
+// groups of another complexity take variant 1.  WH_FRAME_KERNEL=1, candidate: a variant for the frame API's camera pictures without
+// control inputs (WH_SEQ_NO_CTRL)
 #ifndef WH_FRAME_KERNEL
 #define WH_FRAME_KERNEL 0
 #endif
+// The claim path (a free wave takes its next macroblock) is pure overhead and was a chain of a dozen dependent LDS / memory round
+// trips (profiles/r04_p1080p_s256_phase_cycles_v1.txt: 6.6 k of a macroblock's 50 k cycles).  What it needs is therefore kept where a
+// wave reaches it without a round trip:
+//   * the slots' constants (first macroblock, macroblock count, slice index) in LANE TABLES -- lane sl of a VGPR holds slot sl's value,
+//     read with v_readlane;
+//   * the tickets left in every slot with ONE LDS access (lane sl reads slot sl's counter);
+//   * the processing order through a 64-entry WINDOW per slot in a VGPR: the entries from the wave's last miss on, one per lane.  A wave's
+//     tickets of one slot are about a dozen apart (the other waves take the ones in between), so a window serves several claims before
+//     the next ticket lies beyond it and one coalesced load refills it;
+//   * the job fields the fetch of the next macroblock's inputs reads, copied out of the LDS descriptor in one go (one wait, not one per field).
 template <int MAXT, bool SCC, int VAR = 0>
 __global__ __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPicJob* jobs, uint32_t* err, const uint16_t* groups, int slots,
                                                        int sched_words, int total_slices, uint32_t* slice_cost) {
-  constexpr bool CTRL = VAR == 0;          // (inter_mb.h wh_inter_cold_fetch)
+  constexpr bool CTRL = VAR == 0, HOSTIN = VAR == 0 || VAR == 3;          // (inter_mb.h wh_inter_cold_fetch)
   extern __shared__ __align__ (16) uint8_t smem[];
   const int nw = (int)blockDim.x >> 6, lane = (int)threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane ((int)threadIdx.x >> 6);
@@ -190,9 +173,12 @@ __global__ __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPi
     }
     wh_copy_job (&Jl[sl], &jobs[pic]);
   }
+  if (threadIdx.x == 0) for (int sl = slots; sl < WH_MD_MAX_SLOTS; ++sl) { slot_first[sl] = 0; slot_n[sl] = 0; slot_idc[sl] = 0; }
   __syncthreads();
   WH_PROF_DECL (P);
   const unsigned long long wall0 = P.prof ? wall_clock64() : 0ULL;     // 100 MHz; wave lifetimes against the launch's span (WelsHipGroupProfile)
+  // lane tables of the slots' constants (lane sl: slot sl)
+  const int tab_first = slot_first[lane & (WH_MD_MAX_SLOTS - 1)], tab_n = slot_n[lane & (WH_MD_MAX_SLOTS - 1)], tab_idc = slot_idc[lane & (WH_MD_MAX_SLOTS - 1)];
   WhInterCtx X;
   X.win = &winbuf[wave];
   X.spec_valid = 0;
@@ -200,70 +186,76 @@ __global__ __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPi
   X.last_mv = nullptr;
   uint32_t gone = 0;                      // slots this wave knows to be out of tickets (wave-uniform)
   uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;     // cycles / 64 this wave spent on each slot's macroblocks
-  int slot = -1, t = 0, xy = 0;          // the macroblock in hand
-  int nslot = -1, nt = 0, nxy = 0;       // the wave's next one, claimed while the one in hand is still being coded (WH_EARLY_CLAIM)
-#if WH_JOB_REGS && !WH_EARLY_CLAIM
-  WhPicJob Jr;                           // the job of slot jr_slot in registers (wh_job_to_regs): reloaded only when the wave changes slots
-  int jr_slot = -1;
-#define WH_JOB_OF(sl) Jr
-#define WH_JOB_LOAD(sl) if ((sl) >= 0 && (sl) != jr_slot) { wh_job_to_regs (Jr, Jl[sl], lane); jr_slot = (sl); }
-#else
-#define WH_JOB_OF(sl) Jl[sl]
-#define WH_JOB_LOAD(sl)
-#endif
+  int slot = -1, xy = 0;                  // the macroblock in hand
+  int nslot = -1, nxy = 0;                // the wave's next one
+  // order windows: ow<k> lane i = entry ob<k> + i of slot k's processing order (tickets); ob<k> = a ticket no claim can be near: empty
+  int ow0 = 0, ow1 = 0, ow2 = 0, ow3 = 0;
+  int ob0 = -0x40000000, ob1 = -0x40000000, ob2 = -0x40000000, ob3 = -0x40000000;
   // claim(): the next macroblock for this wave, or nslot = -1 when the workgroup's slices are used up
 #define WH_CLAIM()                                                                                                             \
   for (nslot = -1;;) {                                                                                                         \
+    int remv = 0;                         /* tickets left in slot `lane` */                                                     \
+    if (lane < slots) remv = tab_n - (int)__hip_atomic_load (&sched[lane * sched_words], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
     int best = -1, brem = 0;                                                                                                   \
-    for (int sl = 0; sl < slots; ++sl) if (!((gone >> sl) & 1u)) {                                                             \
-      const int rem = slot_n[sl] - (int)__hip_atomic_load (&sched[sl * sched_words], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+    _Pragma ("unroll") for (int sl = 0; sl < WH_MD_MAX_SLOTS; ++sl) if (sl < slots && !((gone >> sl) & 1u)) {                  \
+      const int rem = __builtin_amdgcn_readlane (remv, sl);                                                                    \
       if (rem <= 0) gone |= 1u << sl; else if (rem > brem) { brem = rem; best = sl; }                                          \
     }                                                                                                                          \
-    best = __builtin_amdgcn_readfirstlane (best);                                                                              \
     if (best < 0) break;                                                                                                       \
     int tt = 0;                                                                                                                \
     if (lane == 0) tt = (int)atomicAdd (&sched[best * sched_words], 1u);                                                       \
     tt = __builtin_amdgcn_readfirstlane (tt);                                                                                  \
-    if (tt >= slot_n[best]) { gone |= 1u << best; continue; }                                                                  \
-    const int first_ = slot_first[best];                                                                                       \
-    const int xy_ = (P.flags & WH_SEQ_CHAIN) ? (int)((const WH_G uint32_t*)Jl[best].scc_order)[first_ + tt]                   \
-                  : (SCC && (P.flags & WH_SEQ_SERIAL)) ? first_ + tt : (int)P.mb_order[first_ + tt];   /* serial: coding order */ \
-    const int mb_end_ = CTRL ? Jl[best].mb_end : 0;                                                                                       \
+    const int n_ = __builtin_amdgcn_readlane (tab_n, best);                                                                    \
+    if (tt >= n_) { gone |= 1u << best; continue; }                                                                            \
+    const int first_ = __builtin_amdgcn_readlane (tab_first, best);                                                            \
+    int xy_;                                                                                                                   \
+    if (SCC && (P.flags & WH_SEQ_SERIAL)) xy_ = first_ + tt;                    /* serial: coding order */                     \
+    else {                                                                                                                     \
+      int rel = tt - (best == 0 ? ob0 : best == 1 ? ob1 : best == 2 ? ob2 : ob3);                                              \
+      if ((unsigned)rel >= 64u) {           /* beyond the slot's window: the 64 entries from this ticket on */                 \
+        int v_ = 0;                                                                                                            \
+        if (P.flags & WH_SEQ_CHAIN) { const WH_G uint32_t* src_ = (const WH_G uint32_t*)Jl[best].scc_order; if (tt + lane < n_) v_ = (int)src_[first_ + tt + lane]; } \
+        else { const WH_G uint32_t* src_ = (const WH_G uint32_t*)P.mb_order; if (tt + lane < n_) v_ = (int)src_[first_ + tt + lane]; }   \
+        if (best == 0) { ow0 = v_; ob0 = tt; } else if (best == 1) { ow1 = v_; ob1 = tt; } else if (best == 2) { ow2 = v_; ob2 = tt; } else { ow3 = v_; ob3 = tt; } \
+        rel = 0;                                                                                                               \
+      }                                                                                                                        \
+      const int ow_ = best == 0 ? ow0 : best == 1 ? ow1 : best == 2 ? ow2 : ow3;                                               \
+      xy_ = __builtin_amdgcn_readlane (ow_, rel);                                                                              \
+    }                                                                                                                          \
+    const int mb_end_ = CTRL ? Jl[best].mb_end : 0;                                                                            \
     if (mb_end_ > 0) {                    /* GOM-synchronous coding: only [mb_begin, mb_end) in this launch */                 \
       if (xy_ < Jl[best].mb_begin) { if (lane == 0) atomicOr (&sched[best * sched_words + 1 + ((xy_ - first_) >> 5)], 1u << ((xy_ - first_) & 31)); continue; } \
       if (xy_ >= mb_end_) continue;                                                                                            \
     }                                                                                                                          \
-    nslot = best; nt = tt; nxy = xy_;                                                                                          \
+    nslot = best; nxy = xy_;                                                                                                   \
     break;                                                                                                                     \
   }
   const bool speculate = WH_SPEC_WINDOWS != 0;
+  // the next macroblock's cold inputs and speculative windows: in flight while the wave waits for the neighbours.  `Jf`: the fields of
+  // the slot's job descriptor this reads, taken out of LDS together
 #define WH_FETCH_AHEAD()                                                                                                       \
-  WH_JOB_LOAD (nslot)                                                                                                          \
   if (nslot >= 0) {                                                                                                            \
-    wh_inter_cold_fetch<VAR> (G, lane, P, WH_JOB_OF (nslot), nxy % P.mb_w, nxy / P.mb_w);   /* in flight while the wave codes / waits for the neighbours */ \
+    WhPicJob Jf;                                                                                                               \
+    {                                                                                                                          \
+      const WhPicJob& Jn = Jl[nslot];                                                                                          \
+      Jf.src[0] = Jn.src[0]; Jf.prev_src_y = Jn.prev_src_y; Jf.ref_mbs = Jn.ref_mbs; Jf.ref_is_p = Jn.ref_is_p;                \
+      Jf.ref_tiles[0] = Jn.ref_tiles[0]; Jf.ref_tiles[1] = Jn.ref_tiles[1];                                                    \
+      if (HOSTIN) { Jf.vaa_sad8x8 = Jn.vaa_sad8x8; Jf.sad_cost0 = Jn.sad_cost0; }                                              \
+      if (CTRL) { Jf.sad_cost0_out = Jn.sad_cost0_out; Jf.dyn_redo = Jn.dyn_redo; Jf.mb_begin = Jn.mb_begin; }                 \
+    }                                                                                                                          \
+    const int guess_ = slot_mv[nslot];                                                                                         \
+    wh_inter_cold_fetch<VAR> (G, lane, P, Jf, nxy % P.mb_w, nxy / P.mb_w);                                                     \
     WH_PROF_SUB (P, S.m, 2);         /* detail: cold inputs issued */                                                          \
     X.spec_valid = 0;                                                                                                          \
-    if (speculate) { wh_win_speculate (P, WH_JOB_OF (nslot), X.spec, nxy % P.mb_w, nxy / P.mb_w, slot_mv[nslot]); X.spec_valid = 1; }  \
+    if (speculate) { wh_win_speculate (P, Jf, X.spec, nxy % P.mb_w, nxy / P.mb_w, guess_); X.spec_valid = 1; }                  \
   }
-  // Called by the macroblock body once its prediction is final (inter_mb.h): from there on it reads neither the staging area nor
-  // the windows, so the next macroblock's fetch runs under the residual coding and the stores of the one in hand.  Claiming a
-  // ticket before the previous one is finished cannot deadlock: a wave works its tickets off in order, and a macroblock only ever
-  // waits for lower tickets of its slice.
-  bool claimed = false;
-  auto early_fn = [&] () {
-#if WH_EARLY_CLAIM
-    WH_CLAIM()
-    WH_FETCH_AHEAD()
-    claimed = true;
-#endif
-  };
-  WhEarlyFn<decltype (early_fn)> early = { early_fn };
+  WhNoEarly early;                        // (claiming the next macroblock when the body's prediction is final, before residual coding, was measured: no gain)
   WH_CLAIM()
   WH_FETCH_AHEAD()
-  slot = nslot; t = nt; xy = nxy;
+  slot = nslot; xy = nxy;
   while (slot >= 0) {
-    const WhPicJob& J = WH_JOB_OF (slot);       // (registers: loaded by the fetch-ahead of this very macroblock)
-    const int first = slot_first[slot];
+    const WhPicJob& J = Jl[slot];
+    const int first = __builtin_amdgcn_readlane (tab_first, slot);
     uint32_t* sc = sched + slot * sched_words;
     WH_PROF_MARK (P, S.m, 11);
     int dep_a, dep_b;
@@ -280,8 +272,7 @@ __global__ __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPi
     const uint32_t tc0 = (uint32_t)__builtin_readcyclecounter();
     WV_ASYNC_WAIT();                      /* this MB's cold inputs have landed in the staging area */
     const bool dyn_ = CTRL && J.dyn_slice;
-    X.slice_idc = dyn_ ? J.dyn_slice - 1 : slot_idc[slot]; X.slice_first = dyn_ ? J.dyn_first : first; X.last_mv = &slot_mv[slot];
-    claimed = false;
+    X.slice_idc = dyn_ ? J.dyn_slice - 1 : __builtin_amdgcn_readlane (tab_idc, slot); X.slice_first = dyn_ ? J.dyn_first : first; X.last_mv = &slot_mv[slot];
     wh_inter_mb_body_t<SCC, VAR> (S, G, P, J, xy % P.mb_w, xy / P.mb_w, X, early);
     if (CTRL && J.gom_rc) wh_gom_close_if_last (P, J, xy);       // rate control: the group's last macroblock settles the next group's QP
     WH_PROF_MARK (P, S.m, 14);
@@ -290,17 +281,13 @@ __global__ __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPi
     WH_PROF_MARK (P, S.m, 13);
     const uint32_t dc = ((uint32_t)__builtin_readcyclecounter() - tc0) >> 6;
     c0 += slot == 0 ? dc : 0u; c1 += slot == 1 ? dc : 0u; c2 += slot == 2 ? dc : 0u; c3 += slot == 3 ? dc : 0u;
-    if (!claimed) {
-      WH_CLAIM()
-      WH_PROF_SUB (P, S.m, 0);       /* detail: slot scan + ticket + order look-up */
-      WH_FETCH_AHEAD()
-    }
-    slot = nslot; t = nt; xy = nxy;
+    WH_CLAIM()
+    WH_PROF_SUB (P, S.m, 0);       /* detail: slot scan + ticket + order look-up */
+    WH_FETCH_AHEAD()
+    slot = nslot; xy = nxy;
   }
 #undef WH_CLAIM
 #undef WH_FETCH_AHEAD
-#undef WH_JOB_OF
-#undef WH_JOB_LOAD
   if (slice_cost && lane == 0) {
     if (slot_id[0] >= 0 && c0) atomicAdd (&slice_cost[slot_id[0]], c0);
     if (slots > 1 && slot_id[1] >= 0 && c1) atomicAdd (&slice_cost[slot_id[1]], c1);

@@ -435,13 +435,29 @@ WH_FN void wh_mc_chroma_to (WhInterLds& S, const WhSeqParams& P, const WhPicJob&
   const int n = cw * ch, sh = cw == 8 ? 3 : 2;
   const bool in_win = ipx >= W.cx0 && ipy >= W.cy0 && ipx + cw + 1 <= W.cx0 + WH_CWIN_COLS && ipy + ch + 1 <= W.cy0 + WH_CWIN_ROWS;
   if (in_win) {
+    // A lane makes four adjacent samples of one row of one plane: per source row the 8-sample group its first sample lies in and the
+    // first word of the next group (12 bytes of that plane; wh_cwin_off), of which it takes samples s .. s + 3 (A) and s + 1 .. s + 4
+    // (B, their right neighbours).  The weighted sum runs on two samples per register (fields of 16 bits: 64 x 255 + 32 fits).
     const int wx = ipx - W.cx0, wy = ipy - W.cy0;
+    const uint32_t w00 = (uint32_t) ((8 - dx) * (8 - dy)), w10 = (uint32_t) (dx * (8 - dy)), w01 = (uint32_t) ((8 - dx) * dy), w11 = (uint32_t) (dx * dy);
     WV_LANES_BEGIN (lane)
-    for (int i = lane; i < 2 * n; i += 64) {
-      const int pl = i >= n, k = i - pl * n, x = k & (cw - 1), y = k >> sh;
-      const uint8_t* cw_ = W.b->cwin;
-      const int o0 = wh_cwin_off (pl, wx + x, wy + y), o1 = wh_cwin_off (pl, wx + x + 1, wy + y);
-      dst[pl * 64 + (cy + y) * 8 + cx + x] = (uint8_t)wh_mc_chroma_w (cw_[o0], cw_[o1], cw_[o0 + WH_CWIN_STRIDE], cw_[o1 + WH_CWIN_STRIDE], dx, dy);
+    if (lane < (n >> 1)) {                  // n / 4 lanes per plane
+      const int per = n >> 2, pl = lane >= per, k = lane - pl * per;
+      const int x = cw == 8 ? (k & 1) * 4 : 0, y = cw == 8 ? k >> 1 : k;
+      const int p = wx + x, sft = p & 7;
+      const uint32_t* g = (const uint32_t*)&W.b->cwin[(wy + y) * WH_CWIN_STRIDE + ((p >> 3) << 4) + (pl << 3)];
+      uint32_t r[2][2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const uint32_t d0 = g[q * (WH_CWIN_STRIDE / 4)], d1 = g[q * (WH_CWIN_STRIDE / 4) + 1], d2 = g[q * (WH_CWIN_STRIDE / 4) + 4];
+        const int t = sft + 1;
+        r[q][0] = sft < 4 ? wh_funnel4 (d0, d1, sft) : wh_funnel4 (d1, d2, sft - 4);
+        r[q][1] = t < 4 ? wh_funnel4 (d0, d1, t) : t < 8 ? wh_funnel4 (d1, d2, t - 4) : d2;
+      }
+      const uint32_t m = 0x00ff00ffu;
+      const uint32_t lo = w00 * (r[0][0] & m) + w10 * (r[0][1] & m) + w01 * (r[1][0] & m) + w11 * (r[1][1] & m) + 0x00200020u;
+      const uint32_t hi = w00 * ((r[0][0] >> 8) & m) + w10 * ((r[0][1] >> 8) & m) + w01 * ((r[1][0] >> 8) & m) + w11 * ((r[1][1] >> 8) & m) + 0x00200020u;
+      * (uint32_t*)&dst[pl * 64 + (cy + y) * 8 + cx + x] = ((lo >> 6) & m) | (((hi >> 6) & m) << 8);
     }
     WV_LANES_END
   } else {

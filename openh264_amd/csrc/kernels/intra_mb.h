@@ -60,7 +60,7 @@ WH_FN void wh_tile_fetch_src (int lane, const WhSeqParams& P, const WhPicJob& J,
 // branch: the macroblock then pays one L2 round trip per role (three to four in a row) instead of one.  The column lanes read
 // the aligned word that ENDS with their sample (x = -4 .. -1) and keep its top byte; lanes without a role repeat lane 0's word.
 // (the three planes as VALUES: a select between loads of job fields would be folded into one load at a selected offset, which
-// keeps a job descriptor that lives in registers -- hip_backend.hip wh_job_to_regs -- from staying there)
+// keeps a job descriptor that lives in registers from staying there)
 WH_FN void wh_tile_fetch_nb_planes (int lane, const WhSeqParams& P, const WH_G uint8_t* rec0, const WH_G uint8_t* rec1, const WH_G uint8_t* rec2, int mbx, int mby, WhTileRegs* r) {
   const bool top_y = lane < 7, col_y = lane >= 16 && lane < 32, top_c = lane >= 32 && lane < 38, col_c = lane >= 48;
   const bool luma = !(top_c || col_c);                                   // (idle lanes take lane 0's role)

@@ -95,6 +95,8 @@ WH_FN void wh_st_wg32 (uint32_t* p, uint32_t v) { *p = v; }
 WH_FN uint32_t wh_ld_wg32 (const uint32_t* p) { return *p; }
 // four bytes at any byte offset of a 4-byte aligned LDS array
 WH_FN uint32_t wh_ld4u (const uint8_t* base, int off) { uint32_t v; memcpy (&v, base + off, 4); return v; }
+// bytes k .. k + 3 (k = 0 .. 3) of the eight bytes lo | hi << 32
+WH_FN uint32_t wh_funnel4 (uint32_t lo, uint32_t hi, int k) { return k ? (lo >> (8 * k)) | (hi << (32 - 8 * k)) : lo; }
 // sum of absolute differences of four packed bytes
 WH_FN int wh_sad4 (uint32_t a, uint32_t b) {
   int s = 0;
@@ -216,6 +218,7 @@ WH_FN void wh_st_xwg32 (WH_G uint32_t* p, uint32_t v) { __hip_atomic_store (p, v
 WH_FN uint32_t wh_ld_xwg32 (const WH_G uint32_t* p) { return __hip_atomic_load (p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 WH_FN void wh_st_wg32 (WH_G uint32_t* p, uint32_t v) { __hip_atomic_store (p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 WH_FN uint32_t wh_ld_wg32 (const WH_G uint32_t* p) { return __hip_atomic_load (p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+WH_FN uint32_t wh_funnel4 (uint32_t lo, uint32_t hi, int k) { return __builtin_amdgcn_alignbyte (hi, lo, (uint32_t)k); }
 WH_FN int wh_sad4 (uint32_t a, uint32_t b) { return (int)__builtin_amdgcn_sad_u8 (a, b, 0u); }
 WH_FN uint32_t wh_avg4 (uint32_t a, uint32_t b) { return __builtin_amdgcn_lerp (a, b, 0x01010101u); }
 #endif

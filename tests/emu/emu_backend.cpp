@@ -133,7 +133,7 @@ class EmuBackend : public Backend {
     // WH_SEQ_PLAIN (a session group's step): the body variant that never looks at the optional per-picture inputs (as hip_backend.hip takes it;
     // -DWH_PLAIN_KERNEL=0: the general body) -- and a check that the promise holds
 #ifndef WH_PLAIN_KERNEL
-#define WH_PLAIN_KERNEL 1
+#define WH_PLAIN_KERNEL 2
 #endif
 #ifndef WH_FRAME_KERNEL
 #define WH_FRAME_KERNEL 0

@@ -247,7 +247,7 @@ def test_bench_line_from_two_ranks_on_the_cpu_test_build(emu_lib):
 
 
 # ---- pipelined groups: WelsHipGroupEncodeFramesPipelined returns step k - 1's streams while the device codes step k -------------
-def _pipelined_vs_synchronous(lib, w, h, frames, qp, contents, ring, intra_period=0, threads=2, ahead=1):
+def _pipelined_vs_synchronous(lib, w, h, frames, qp, contents, ring, intra_period=0, threads=2, ahead=1, complexity=0):
     import openh264_amd as oh
     from openh264_amd.utils.synth import make_sequence
     fsz = w * h * 3 // 2
@@ -257,6 +257,7 @@ def _pipelined_vs_synchronous(lib, w, h, frames, qp, contents, ring, intra_perio
     e.close()
     p.iPicWidth, p.iPicHeight, p.iDLayerQp, p.uiIntraPeriod, p.fMaxFrameRate, p.iTargetBitrate = w, h, qp, intra_period, 30.0, 5000000
     p.bEnableSceneChangeDetect = False
+    p.iComplexityMode = complexity
     out = {}
     for mode in ("sync", "pipe"):
         g = oh.EncoderGroup(p, len(seqs), ring_slots=ring, host_threads=threads, lib_path=lib)
@@ -366,6 +367,11 @@ def test_plain_p_kernel_variant_on_emulation(emu_lib):
         seqs, got = _pipelined_vs_synchronous(lib, 64, 64, 5, 24, ("synth", "checker5", "pan7"), 3, intra_period=4, ahead=2)
         for s, yuv in enumerate(seqs):
             bs, _ = oh.encode_sequence(yuv, 64, 64, lib_path=emu_lib, iDLayerQp=24, uiIntraPeriod=4, fMaxFrameRate=30.0, iTargetBitrate=5000000, bEnableSceneChangeDetect=False)
+            assert bs == got[s]
+        # (LOW complexity takes the variant that knows it at compile time, WH_PLAIN_KERNEL == 2; any other complexity the plain variant with the SATD paths)
+        seqs, got = _pipelined_vs_synchronous(lib, 64, 64, 5, 24, ("synth", "checker5", "pan7"), 3, intra_period=4, ahead=2, complexity=2)
+        for s, yuv in enumerate(seqs):
+            bs, _ = oh.encode_sequence(yuv, 64, 64, lib_path=emu_lib, iDLayerQp=24, uiIntraPeriod=4, fMaxFrameRate=30.0, iTargetBitrate=5000000, bEnableSceneChangeDetect=False, iComplexityMode=2)
             assert bs == got[s]
 
 

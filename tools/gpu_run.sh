@@ -13,7 +13,8 @@
 #   tables          every device row of both SHA1 tables incl. the size-limited rows -> *_rows.txt
 #   repro:<seeds>   size-limited-slice sessions <seeds> (comma separated; s = screen content, q = low QP: e.g. s21001,q11012,1003) with slice threads,
 #                   RUNS times each (default 6), for every library of LIBS (default: the product library) -> repro.txt
-#   ab:<tagA>,<tagB>   `bench.py --quick` alternating between two candidate libraries openh264_amd/libwelship_<tag>.so ("-" = the product library)
+#   ab:<tagA>,<tagB>[,..]   `bench.py --quick` alternating between candidate libraries openh264_amd/libwelship_<tag>.so ("-" = the product library), three rounds
+#   detail:<tag>    sub-phase cycles of the claim / neighbour-load / P_Skip phases: tools/phase_profile.py with a library built with -DWH_PROF_DETAIL
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 tag=${1:?tag}; shift
@@ -55,12 +56,13 @@ for stage in "$@"; do
             timeout 300 python tools/sha1_table_rows.py --table adobe --dynslice --workers $W > $o/screen_table_size_limited_256_rows.txt 2>&1; tail -2 $o/screen_table_size_limited_256_rows.txt | cut -c1-220
             lap "SHA1 tables";;
   repro:*)  FUZZ_DYNSLICE_KEEP=$o/streams timeout ${REPRO_TIMEOUT:-600} python tools/repro_dynslice.py "${stage#repro:}" > $o/repro.txt 2>&1; grep -E "^==|DIFF|FAILED|VARIES|summary" $o/repro.txt | cut -c1-260 | head -80; lap "repro";;
-  ab:*)     IFS=, read -r A B <<< "${stage#ab:}"
-            for rep in 1 2 3; do for t in $A $B; do
+  ab:*)     LIBTAGS=$(echo "${stage#ab:}" | tr , ' ')
+            for rep in 1 2 3; do for t in $LIBTAGS; do
               lib=openh264_amd/libwelship.so; [ "$t" != "-" ] && lib=openh264_amd/libwelship_$t.so
               WELSHIP_LIB=$PWD/$lib timeout 200 python bench.py --quick > $o/ab_${t}_$rep.json 2> $o/ab_${t}_$rep.err
               python -c "import json; d=json.loads(open('$o/ab_${t}_$rep.json').read().strip().splitlines()[-1]); print('$t', $rep, 'value', round(d['value']), 'md_ms', d['roofline']['avg_launch_ms'], 'verified', d.get('verified'))"
             done; done | tee $o/ab.txt; lap "A/B";;
+  detail:*) WELSHIP_LIB=$PWD/openh264_amd/libwelship_${stage#detail:}.so WELSHIP_PROF_DETAIL=1 timeout 200 python tools/phase_profile.py 256 > $o/phase_cycles_detail.txt 2>&1; head -22 $o/phase_cycles_detail.txt; lap "phase cycles (detail)";;
   *)        echo "unknown stage $stage";;
   esac
 done
