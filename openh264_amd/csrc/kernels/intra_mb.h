@@ -246,6 +246,36 @@ WH_FN int wh_pred4_px (int mode, int x, int y, const WhE13& EE, int dcval) {
 #undef E
 }
 
+// The same nine predictors as a TABLE LOOK-UP (what the macroblock bodies use; wh_pred4_px stays the definition and serves the leaf
+// primitive).  Every predicted sample is one of three functions of the edge samples at an index that only depends on (mode, x, y):
+// with X = E(0), E(0) .. E(12), E(12) (the ends doubled: the two "3 x outer sample" cases of DDL and HU become ordinary 3-tap
+// cases), RAW[a] = X[a], F2[a] = (X[a] + X[a+1] + 1) >> 1, F3[a] = (X[a] + 2 X[a+1] + X[a+2] + 2) >> 2 -- or the DC value.  A lane per
+// index fills the 49-byte table (0..14 RAW, 16..30 F2, 32..46 F3, 48 DC), then lane (mode, row) fetches its four samples with the
+// byte offsets below: nine modes cost one pass without a nine-way divergent switch.  Generated from wh_pred4_px's index arithmetic
+// and checked against it for every (mode, x, y) on random edges (tools/gen_tables.py --i4).
+WH_TABLE uint32_t kWhI4Desc[36] = {     // [mode * 4 + row]: byte x = table offset of sample (x, row)
+  0x09080706u, 0x09080706u, 0x09080706u, 0x09080706u, 0x04040404u, 0x03030303u, 0x02020202u, 0x01010101u, 0x30303030u, 0x30303030u, 0x30303030u, 0x30303030u,
+  0x29282726u, 0x2a292827u, 0x2b2a2928u, 0x2c2b2a29u, 0x27262524u, 0x26252423u, 0x25242322u, 0x24232221u, 0x18171615u, 0x27262524u, 0x17161523u, 0x26252422u,
+  0x26252414u, 0x24142313u, 0x23132212u, 0x22122111u, 0x19181716u, 0x29282726u, 0x1a191817u, 0x2a292827u, 0x21122213u, 0x20112112u, 0x01012011u, 0x01010101u };
+// edge sample X[i] (i = 0 .. 16; beyond 14: E(12) again) of the 4x4 block at (bx, by) in 4-sample units, from the reconstruction tile
+WH_FN int wh_i4_edge (const WhMbLds& S, int bx, int by, int i) {
+  const int e = i < 1 ? 0 : i > 13 ? 12 : i - 1;
+  const int x = e < 5 ? bx * 4 - 1 : bx * 4 + e - 5, y = e < 4 ? by * 4 + 3 - e : by * 4 - 1;
+  return WH_RY (S, x, y);
+}
+// the 49-byte table of one block into `t` (lanes 0 .. 15; lane 15: the DC value for the block's availability)
+WH_FN void wh_i4_fill_table (const WhMbLds& S, uint8_t* t, int lane, int bx, int by, bool a_l, bool a_t) {
+  if (lane < 15) {
+    const int x0 = wh_i4_edge (S, bx, by, lane), x1 = wh_i4_edge (S, bx, by, lane + 1), x2 = wh_i4_edge (S, bx, by, lane + 2);
+    t[lane] = (uint8_t)x0; t[16 + lane] = (uint8_t)WH_F2 (x0, x1); t[32 + lane] = (uint8_t)WH_F3 (x0, x1, x2);
+  } else if (lane == 15) {
+    const uint32_t tw = * (const uint32_t*)&WH_RY (S, bx * 4, by * 4 - 1);
+    const int sum_t4 = (int) ((tw & 255u) + ((tw >> 8) & 255u) + ((tw >> 16) & 255u) + (tw >> 24));
+    const int sum_l4 = WH_RY (S, bx * 4 - 1, by * 4) + WH_RY (S, bx * 4 - 1, by * 4 + 1) + WH_RY (S, bx * 4 - 1, by * 4 + 2) + WH_RY (S, bx * 4 - 1, by * 4 + 3);
+    t[48] = (uint8_t) ((a_l && a_t) ? (sum_l4 + sum_t4 + 4) >> 3 : a_l ? (sum_l4 + 2) >> 2 : a_t ? (sum_t4 + 2) >> 2 : 128);
+  }
+}
+
 // ---- the intra MB ---------------------------------------------------------------------------------
 // Leaves: S.lv_*, S.nzc, S.i4_rem/i4_prev, the rec tile.  Returns through *o.
 typedef struct WhIntraResult {
@@ -346,21 +376,31 @@ WH_FN bool wh_intra_md_enc_p (WhMbLds& S, const WhSeqParams& P, const WhPicJob& 
   }
   int cbp = 0;
   if (try_i4) {
-    // neighbour Intra4x4PredMode cache (md.cpp:51-130 FillNeighborCacheIntra)
-    WV_LANES_BEGIN (lane)
+    // neighbour Intra4x4PredMode cache (md.cpp:51-130 FillNeighborCacheIntra): in the tile (what the store reads) and in a lane table
+    // (what the sixteen blocks' predicted modes are read from: v_readlane instead of an LDS round trip per block)
+    WvLaneArr i4t, dsc;
+#if defined(WH_EMU)
+    memset (&i4t, 0, sizeof (i4t)); memset (&dsc, 0, sizeof (dsc));
+#else
+    i4t = 0; dsc = 0;
+#endif
+    WV_LSET_IF (dsc, lane, lane < 36, (int)kWhI4Desc[lane]);
 #if WH_FLAT_NB_LOADS
-    {
+    WV_LSET_IF (i4t, lane, lane < 25, ([&] () {
       // type + the mode word of the state a lane needs in one batch (a state that exists for every lane: its own MB's when it has
       // no neighbour to ask), the selects afterwards -- see wh_tile_fetch_nb
       const int cx = lane % 5, cy = lane / 5;
-      const bool from_t = lane < 25 && cy == 0 && cx > 0 && has_t, from_l = lane < 25 && cx == 0 && cy > 0 && has_l;
+      const bool from_t = cy == 0 && cx > 0 && has_t, from_l = cx == 0 && cy > 0 && has_l;
       const WH_G WhMbState* n = (const WH_G WhMbState*)J.mbs + (from_t ? (mby - 1) * P.mb_w + mbx : from_l ? mby * P.mb_w + mbx - 1 : mby * P.mb_w + mbx);
       const int idx = from_t ? 12 + cx - 1 : from_l ? (cy - 1) * 4 + 3 : 0;
       const int type = n->mb_type;
       const int8_t mode = n->i4_mode[idx];
-      if (lane < 25) S.i4m[lane] = (from_t || from_l) ? (type == WH_MB_I4x4 ? mode : (int8_t)2) : (int8_t) - 1;
-    }
+      const int8_t v = (from_t || from_l) ? (type == WH_MB_I4x4 ? mode : (int8_t)2) : (int8_t) - 1;
+      S.i4m[lane] = v;
+      return (int)v; }) ());
+    WV_SYNC();
 #else
+    WV_LANES_BEGIN (lane)
     if (lane < 25) {
       const int cx = lane % 5, cy = lane / 5;
       int8_t m = -1;
@@ -377,8 +417,9 @@ WH_FN bool wh_intra_md_enc_p (WhMbLds& S, const WhSeqParams& P, const WhPicJob& 
       }
       S.i4m[lane] = m;
     }
-#endif
     WV_LANES_END
+    WV_LSET_IF (i4t, lane, lane < 25, (int)S.i4m[lane]);
+#endif
     const int lam4 = lambda << 2;
     int cost4 = 0;
     uint16_t prev_flags = 0;
@@ -396,56 +437,44 @@ WH_FN bool wh_intra_md_enc_p (WhMbLds& S, const WhSeqParams& P, const WhPicJob& 
       if (by == 0) a_tr = (bx < 3) ? has_t : ((avail & WH_AV_TOPRIGHT) != 0);
       else a_tr = ((0x5744 >> b) & 1) != 0;   // blocks whose top-right 4x4 is already reconstructed inside this MB
       // predicted mode
-      const int m_left = S.i4m[(by + 1) * 5 + bx], m_top = S.i4m[by * 5 + bx + 1];
+      const int m_left = WV_LGET (i4t, (by + 1) * 5 + bx), m_top = WV_LGET (i4t, by * 5 + bx + 1);
       const int pred_mode = (m_left == -1 || m_top == -1) ? 2 : wh_min (m_left, m_top);
-      // candidate predictions: lane (mode m = lane>>2, row r = lane&3), standard numbering
+      // candidate predictions: the block's filter table (see kWhI4Desc), then lane (mode m = lane >> 2, row r = lane & 3) fetches its
+      // four samples, stores them for the encode step and costs them; the modes' costs are quad sums, read from a lane table
+      uint8_t* const tbl = (uint8_t*)S.part2;
       WV_LANES_BEGIN (lane)
-      if (lane < 36) {
-        const int m = lane >> 2, r = lane & 3;
-        WhE13 E;
-        {
-          const uint32_t t0 = * (const uint32_t*)&WH_RY (S, bx * 4, by * 4 - 1), t1 = * (const uint32_t*)&WH_RY (S, bx * 4 + 4, by * 4 - 1);
-          E.w[0] = (uint32_t)WH_RY (S, bx * 4 - 1, by * 4 + 3) | ((uint32_t)WH_RY (S, bx * 4 - 1, by * 4 + 2) << 8) |
-                   ((uint32_t)WH_RY (S, bx * 4 - 1, by * 4 + 1) << 16) | ((uint32_t)WH_RY (S, bx * 4 - 1, by * 4) << 24);
-          E.w[1] = (uint32_t)WH_RY (S, bx * 4 - 1, by * 4 - 1) | (t0 << 8);
-          E.w[2] = (t0 >> 24) | (t1 << 8);
-          E.w[3] = t1 >> 24;
-        }
-        const int sum_l4 = wh_e13 (E, 0) + wh_e13 (E, 1) + wh_e13 (E, 2) + wh_e13 (E, 3), sum_t4 = wh_e13 (E, 5) + wh_e13 (E, 6) + wh_e13 (E, 7) + wh_e13 (E, 8);
-        int dcv;
-        if (a_l && a_t) dcv = (sum_l4 + sum_t4 + 4) >> 3;
-        else if (a_l) dcv = (sum_l4 + 2) >> 2;
-        else if (a_t) dcv = (sum_t4 + 2) >> 2;
-        else dcv = 128;
-        uint8_t px[4];
-        for (int x = 0; x < 4; ++x) px[x] = (uint8_t)wh_pred4_px (m, x, r, E, dcv);
-        uint8_t* pd = &S.pred4[m * 16 + r * 4];
-        pd[0] = px[0]; pd[1] = px[1]; pd[2] = px[2]; pd[3] = px[3];
-        const uint8_t* e = &S.enc_y[(by * 4 + r) * 16 + bx * 4];
-        if (!use_satd) {
-          S.part[lane] = wh_abs (e[0] - px[0]) + wh_abs (e[1] - px[1]) + wh_abs (e[2] - px[2]) + wh_abs (e[3] - px[3]);
-        } else {
-          int o0, o1, o2, o3;
-          wh_had4 (e[0] - px[0], e[1] - px[1], e[2] - px[2], e[3] - px[3], &o0, &o1, &o2, &o3);
-          int16_t* t = &S.tmp[m * 16 + r * 4];
-          t[0] = (int16_t)o0; t[1] = (int16_t)o1; t[2] = (int16_t)o2; t[3] = (int16_t)o3;
-        }
-      }
+      wh_i4_fill_table (S, tbl, lane, bx, by, a_l, a_t);
       WV_LANES_END
+      WvLaneArr ct;
+#if defined(WH_EMU)
+      memset (&ct, 0, sizeof (ct));
+#else
+      ct = 0;
+#endif
+      WV_QUADSUM_TAB (ct, lane, (lane < 36 ? ([&] () {
+        const int m = lane >> 2, r = lane & 3;
+        const uint32_t d = (uint32_t)WV_LOWN (dsc, lane);
+        const uint32_t px = (uint32_t)tbl[d & 255u] | ((uint32_t)tbl[(d >> 8) & 255u] << 8) | ((uint32_t)tbl[(d >> 16) & 255u] << 16) | ((uint32_t)tbl[d >> 24] << 24);
+        * (uint32_t*)&S.pred4[m * 16 + r * 4] = px;
+        const uint32_t e = * (const uint32_t*)&S.enc_y[(by * 4 + r) * 16 + bx * 4];
+        if (!use_satd) return wh_sad4 (e, px);
+        int o0, o1, o2, o3;
+        wh_had4 ((int) (e & 255u) - (int) (px & 255u), (int) ((e >> 8) & 255u) - (int) ((px >> 8) & 255u), (int) ((e >> 16) & 255u) - (int) ((px >> 16) & 255u),
+                 (int) (e >> 24) - (int) (px >> 24), &o0, &o1, &o2, &o3);
+        int16_t* t = &S.tmp[m * 16 + r * 4];
+        t[0] = (int16_t)o0; t[1] = (int16_t)o1; t[2] = (int16_t)o2; t[3] = (int16_t)o3;
+        return 0; }) () : 0));
+      WV_SYNC();                           // (the lanes' stores above are read by other lanes below and in the encode step)
       if (use_satd) {
-        WV_LANES_BEGIN (lane)
-        if (lane < 36) {
+        WV_QUADSUM_TAB (ct, lane, (lane < 36 ? ([&] () {
           const int m = lane >> 2, c = lane & 3;
           const int16_t* t = &S.tmp[m * 16 + c];
           int o0, o1, o2, o3;
           wh_had4 (t[0], t[4], t[8], t[12], &o0, &o1, &o2, &o3);
-          S.part[lane] = wh_abs (o0) + wh_abs (o1) + wh_abs (o2) + wh_abs (o3);
-        }
-        WV_LANES_END
+          return wh_abs (o0) + wh_abs (o1) + wh_abs (o2) + wh_abs (o3); }) () : 0));
       }
       // cost of standard mode m incl. the mode-signalling term lambda[pred_mode == m]
-#define WH_C4(m) ((use_satd ? ((S.part[(m) * 4] + S.part[(m) * 4 + 1] + S.part[(m) * 4 + 2] + S.part[(m) * 4 + 3] + 1) >> 1) \
-                            : (S.part[(m) * 4] + S.part[(m) * 4 + 1] + S.part[(m) * 4 + 2] + S.part[(m) * 4 + 3])) + ((pred_mode == (m)) ? lambda : lam4))
+#define WH_C4(m) ((use_satd ? ((WV_LGET (ct, (m) * 4) + 1) >> 1) : WV_LGET (ct, (m) * 4)) + ((pred_mode == (m)) ? lambda : lam4))
       // candidate order of the reference (g_kiIntra4AvailMode rows), standard numbering
       // (the list is packed four bits per entry: an int array indexed at run time would live in scratch memory)
       unsigned long long list = 0;
@@ -513,17 +542,10 @@ WH_FN bool wh_intra_md_enc_p (WhMbLds& S, const WhSeqParams& P, const WhPicJob& 
       if (cost4 >= cost_luma) { completed = false; break; }
       if (pred_mode == bmode) prev_flags |= (uint16_t) (1u << b);
       const int rem = (bmode < pred_mode) ? bmode : bmode - 1;
-      WV_LANES_BEGIN (lane)
-      if (lane == 0) {
-        S.i4m[(by + 1) * 5 + bx + 1] = (int8_t)bmode;
-        S.i4_rem[b] = (int8_t) ((pred_mode == bmode) ? 0 : rem);
-      }
-      WV_LANES_END
-      const int nz = wh_encrec_i4 (S, b, bmode, qp);
+      WV_LSET (i4t, (by + 1) * 5 + bx + 1, bmode);
+      // (the block's mode, rem_intra4x4_pred_mode and total_coeff go into the tile inside the encode step's own lane blocks)
+      const int nz = wh_encrec_i4 (S, b, bmode, qp, (int8_t) ((pred_mode == bmode) ? 0 : rem));
       if (nz > 0) cbp |= 1 << (b >> 2);
-      WV_LANES_BEGIN (lane)
-      if (lane == 0) S.nzc[by * 4 + bx] = (uint8_t)nz;
-      WV_LANES_END
     }
     if (completed) cost4 += (lambda << 4) + (lambda << 3);
     if (completed && cost4 < cost_luma) {

@@ -351,8 +351,10 @@ WH_FN int wh_encrec_i16 (WhMbLds& S, int qp) {
 }
 
 // ---- Intra4x4 residual pipeline of one block (svc_encode_mb.cpp:139-178) ------------------------
-// pred = S.pred4[mode_slot*16..], writes lv_luma[b], nzc, rec tile; returns nzc of the block
-WH_FN int wh_encrec_i4 (WhMbLds& S, int b, int pred_slot, int qp) {
+// pred = S.pred4[mode_slot*16..], writes lv_luma[b], nzc, i4m / i4_rem of the block, the rec tile; returns nzc of the block.
+// Four lane blocks: rows of the forward transform | columns + quantisation (the count of non-zero levels is a quad sum of the four
+// lanes' shares, no 64-lane reduction) | zig-zag scan + dequantisation + rows of the inverse | columns of the inverse + reconstruction.
+WH_FN int wh_encrec_i4 (WhMbLds& S, int b, int pred_slot, int qp, int8_t rem) {
   const int bx = wh_blk_x (b) * 4, by = wh_blk_y (b) * 4;
   WV_LANES_BEGIN (lane)
   if (lane < 4) {
@@ -362,26 +364,30 @@ WH_FN int wh_encrec_i4 (WhMbLds& S, int b, int pred_slot, int qp) {
     wh_fdct4 (e[0] - p[0], e[1] - p[1], e[2] - p[2], e[3] - p[3], &o0, &o1, &o2, &o3);
     int16_t* t = &S.tmp[lane * 4];
     t[0] = o0; t[1] = o1; t[2] = o2; t[3] = o3;
+  } else if (lane == 4) {
+    S.i4m[((by >> 2) + 1) * 5 + (bx >> 2) + 1] = (int8_t)pred_slot;
+    S.i4_rem[b] = rem;
   }
   WV_LANES_END
-  WV_LANES_BEGIN (lane)
-  if (lane < 4) {
+  int nz, nz1, nz2, nz3;
+  WV_QUADSUM4 (nz, nz1, nz2, nz3, lane, (lane < 4 ? ([&] () {
     const int16_t* t = &S.tmp[lane];
     int16_t o[4];
     wh_fdct4 (t[0], t[4], t[8], t[12], &o[0], &o[1], &o[2], &o[3]);
+    int cnt = 0;
     for (int k = 0; k < 4; ++k) {
       const int pos = k * 4 + lane;
-      S.res[b * 16 + pos] = wh_quant1 (o[k], wh_ff_intra (qp, pos), wh_mf (qp, pos));
+      const int16_t q = wh_quant1 (o[k], wh_ff_intra (qp, pos), wh_mf (qp, pos));
+      S.res[b * 16 + pos] = q;
+      cnt += q != 0;
     }
-  }
-  WV_LANES_END
-  int nz;
+    return cnt; }) () : 0));
+  (void)nz1; (void)nz2; (void)nz3;
+  WV_SYNC();
   WV_LANES_BEGIN (lane)
   if (lane < 16) S.lv_luma[b * 16 + lane] = S.res[b * 16 + wh_zigzag (lane)];
-  WV_LANES_END
-  WV_SUM (nz, lane, (lane < 16 ? (S.res[b * 16 + lane] != 0) : 0));
+  if (lane == 16) S.nzc[(by >> 2) * 4 + (bx >> 2)] = (uint8_t)nz;
   if (nz > 0) {
-    WV_LANES_BEGIN (lane)
     if (lane < 4) {                     // dequant (WelsDequant4x4_c, int16 wrap) + horizontal inverse
       const int16_t* c = &S.res[b * 16 + lane * 4];
       int16_t t0, t1, t2, t3;
@@ -390,7 +396,12 @@ WH_FN int wh_encrec_i4 (WhMbLds& S, int b, int pred_slot, int qp) {
       int16_t* t = &S.tmp[lane * 4];
       t[0] = t0; t[1] = t1; t[2] = t2; t[3] = t3;
     }
-    WV_LANES_END
+  } else if (lane >= 32 && lane < 48) {
+    const int l = lane - 32;
+    WH_RY (S, bx + (l & 3), by + (l >> 2)) = S.pred4[pred_slot * 16 + l];
+  }
+  WV_LANES_END
+  if (nz > 0) {
     WV_LANES_BEGIN (lane)
     if (lane < 4) {
       const int16_t* t = &S.tmp[lane];
@@ -403,16 +414,10 @@ WH_FN int wh_encrec_i4 (WhMbLds& S, int b, int pred_slot, int qp) {
       WH_RY (S, bx + lane, by + 3) = wh_clip255 (p[12] + r3);
     }
     WV_LANES_END
-  } else {
-    WV_LANES_BEGIN (lane)
-    if (lane < 16) WH_RY (S, bx + (lane & 3), by + (lane >> 2)) = S.pred4[pred_slot * 16 + lane];
-    WV_LANES_END
   }
   return nz;
 }
 
-// JVT-O079 single-coefficient score of a block from the 16-bit mask of its non-zero zig-zag positions
-// (encode_mb_aux.cpp:417-436 WelsGetNoneZeroCount-style run table {3,2,2,1,1,1,0...}); equals wh_single_ctr.
 // JVT-O079 "single coefficient" score of a block whose levels are all +-1 (WelsGetNoneZeroCount / the run table of svc_encode_mb.cpp:
 // 3 for a coefficient right behind the previous one in zig-zag order, 2 after a run of one or two zeros, 1 after three to five, 0
 // beyond), from the mask of non-zero zig-zag positions.  Bit-parallel: a coefficient scores [run < 1] + [run < 3] + [run < 6], and

@@ -42,6 +42,12 @@
 // two sums in one pass
 #define WV_SUM2(dst_a, dst_b, lane, expr_a, expr_b)               \
   do { int _sa = 0, _sb = 0; for (int lane = 0; lane < 64; ++lane) { _sa += (int)(expr_a); _sb += (int)(expr_b); } (dst_a) = _sa; (dst_b) = _sb; } while (0)
+// quad sums as a lane table: every lane of quad q (lanes 4 q .. 4 q + 3) of `tab` holds the sum of expr over that quad -- read
+// with WV_LGET (tab, 4 * q).  `expr` may have side effects on the LDS tile (it is evaluated once per lane, in lane order).
+#define WV_QUADSUM_TAB(tab, lane, expr)                           \
+  do { int _t[64]; for (int lane = 0; lane < 64; ++lane) _t[lane] = (int)(expr); \
+       for (int _q = 0; _q < 16; ++_q) { const int _s = _t[4 * _q] + _t[4 * _q + 1] + _t[4 * _q + 2] + _t[4 * _q + 3]; \
+         for (int _k = 0; _k < 4; ++_k) (tab).v[4 * _q + _k] = _s; } } while (0)
 // four sums at once: d_i = sum of expr over the lanes of quad i (4 i .. 4 i + 3), i = 0..3 -- sixteen lanes, one value each
 #define WV_QUADSUM4(d0, d1, d2, d3, lane, expr)                   \
   do { int _q[4] = {0, 0, 0, 0}; for (int lane = 0; lane < 16; ++lane) _q[lane >> 2] += (int)(expr); \
@@ -165,6 +171,9 @@ WH_FN int wh_wave_min_i32 (int v) {
        _va += WH_DPP (_va, 0x141); _vb += WH_DPP (_vb, 0x141); _va += WH_DPP (_va, 0x140); _vb += WH_DPP (_vb, 0x140); \
        (dst_a) = __builtin_amdgcn_readlane (_va, 0) + __builtin_amdgcn_readlane (_va, 16) + __builtin_amdgcn_readlane (_va, 32) + __builtin_amdgcn_readlane (_va, 48); \
        (dst_b) = __builtin_amdgcn_readlane (_vb, 0) + __builtin_amdgcn_readlane (_vb, 16) + __builtin_amdgcn_readlane (_vb, 32) + __builtin_amdgcn_readlane (_vb, 48); } while (0)
+#define WV_QUADSUM_TAB(tab, lane, expr)                           \
+  do { const int lane = wh_lane_id(); int _v = (int)(expr);       \
+       _v += WH_DPP (_v, 0xB1); _v += WH_DPP (_v, 0x4E); (tab) = _v; } while (0)
 #define WV_QUADSUM4(d0, d1, d2, d3, lane, expr)                   \
   do { const int lane = wh_lane_id(); int _v = (int)(expr);       \
        _v += WH_DPP (_v, 0xB1); _v += WH_DPP (_v, 0x4E);          \
