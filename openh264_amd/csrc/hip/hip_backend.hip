@@ -108,7 +108,7 @@ __global__ __launch_bounds__ (MAX_THREADS) void NAME (WhSeqParams P, const WhPic
   if (PROF && P.prof && lane < 32) atomicAdd (&P.prof[((blockIdx.x + blockIdx.y * 7u) & 63u) * 32u + lane], (unsigned long long)wh_prof_lds (S)[lane]); \
 }
 
-WH_DEFINE_MB_KERNEL (k_intra_slice, WhMbLds, wh_intra_mb_body, 1024, 0, 0)
+WH_DEFINE_MB_KERNEL (k_intra_slice, WhMbLds, wh_intra_mb_body, 1024, 0, 1)
 
 // ---- P pictures: a pool of wavefronts shared by several slices ------------------------------------------------------
 // A workgroup owns up to WH_MD_MAX_SLOTS slices (of any pictures of the batch) and as many wavefronts as fit one CU.  A
@@ -846,7 +846,16 @@ class HipBackend : public wh::Backend {
     HIP_TRY (hipGetLastError());
     if (getenv ("WELSHIP_TRACE")) { HIP_TRY (hipStreamSynchronize (stream_)); fprintf (stderr, "welship: launch done\n"); fflush (stderr); }
   }
-  void run_intra (const WhSeqParams& P, const WhPicJob* jobs, int n) override { mb_pass (k_intra_slice, sizeof (WhMbLds), 16, false, P, jobs, n, sizeof (WhPicJob)); }
+  // I pictures: one workgroup per slice.  Few slices in flight (the latency regime, or an all-intra stream of a few sessions): 16 waves each, every
+  // macroblock the wavefront has ready gets a wave.  Enough slices to give every CU two: 12 waves each -- a slice has at most ~17 macroblocks
+  // ready at a time and a wave that holds a ticket waits for its neighbours, so sixteen waves idled a quarter of their time (32 k of 141 k
+  // cycles per macroblock in the dependency wait).  Measured, IDR step of 256 four-slice 1080p pictures (profiles/r04_intra_waves_per_workgroup.txt):
+  // 16 waves 31.3 ms, 12: 24.4 ms, 8 (four workgroups per CU): 25.7 ms, 6: 30.7 ms.  WELSHIP_I_WAVES forces the count.
+  void run_intra (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
+    static const int forced = getenv ("WELSHIP_I_WAVES") ? atoi (getenv ("WELSHIP_I_WAVES")) : 0;
+    const int waves = forced > 0 ? std::min (forced, 16) : (P.num_slices * n >= 2 * cus_ ? 12 : 16);
+    mb_pass (k_intra_slice, sizeof (WhMbLds), waves, false, P, jobs, n, sizeof (WhPicJob));
+  }
   // P pictures: one workgroup per CU-load of slices.  Few slices (latency regime): one slice per workgroup, 12 waves.  Enough
   // slices to fill the chip twice: groups of 2..4 slices share a 12-wave workgroup (k_inter_pool), dealt out by k_md_assign.
   // WELSHIP_MD_SLOTS = 1..4 forces the group size, WELSHIP_P_WAVES the wave count, WELSHIP_MD_ASSIGN=0 the plain order.

@@ -128,9 +128,12 @@ WH_FN void wh_intra_mb_body (WhMbLds& S, const WhSeqParams& P, const WhPicJob& J
   const WhMbCtl ctl = wh_mb_ctl (J, xy);
   const int qp = wh_mb_qp (J, ctl);
   const int qpc = kWhChromaQp[wh_clip3 (qp + P.chroma_qp_offset, 0, 51)];
+  WH_PROF_DECL (P);
   wh_load_mb_tile (S, P, J, mbx, mby);
+  WH_PROF_MARK (P, S, 9);    // source + neighbour samples
   WhIntraResult r;
   wh_intra_md_enc (S, P, J, mbx, mby, avail, qp, qpc, &r, ctl.stale_cbp);
+  WH_PROF_MARK (P, S, 15);   // (what the decision's own marks leave: its epilogue)
   // intra MBs carry no motion: clear mv/ref so that later P pictures / deblocking see zeros
   WV_LANES_BEGIN (lane)
   WH_G WhMbState* Ms = (WH_G WhMbState*)J.mbs + xy;
@@ -158,6 +161,7 @@ WH_FN void wh_intra_mb_body (WhMbLds& S, const WhSeqParams& P, const WhPicJob& J
     if (r.cbp > 0 || r.mb_type == WH_MB_I16x16) bits |= WH_BITS_HAS_QP_DELTA;
   }
   wh_store_mb (S, P, J, mbx, mby, r.mb_type, r.cbp, qp, qpc, r.i16_mode_std, r.chroma_mode_std, r.cost_luma, J.dyn_slice ? J.dyn_slice - 1 : wh_slice_of_mb (P, xy), bits);
+  WH_PROF_MARK (P, S, 7);    // store
 }
 
 #include "../common/mb_order.h"

@@ -350,8 +350,16 @@ WH_FN bool wh_intra_md_enc_p (WhMbLds& S, const WhSeqParams& P, const WhPicJob& 
   const int lambda = kWhLambda[qp];
   const int use_satd = CPLX >= 0 ? (CPLX > 0) : (P.complexity > 0);
   const bool has_l = (avail & WH_AV_LEFT) != 0, has_t = (avail & WH_AV_TOP) != 0;
+  // phase cycles of an I picture's macroblocks (a P macroblock's intra test is part of the P body's own phases)
+#if defined(WH_EMU)
+#define WH_PROF_MARK_I(id) ((void)0)
+#else
+  unsigned long long _wh_t0 = (P.prof && J.slice_type == WH_SLICE_I) ? (unsigned long long)__builtin_readcyclecounter() : 0ULL;
+#define WH_PROF_MARK_I(id) do { if (J.slice_type == WH_SLICE_I) WH_PROF_MARK_RAW (P, S, id); } while (0)
+#endif
   WhI16Cost own;
   if (!pre) { wh_i16_costs (S, avail, use_satd, lambda, &own); pre = &own; }
+  WH_PROF_MARK_I (2);       // Intra16x16 mode costs
   const int sum_t = pre->sum_t, sum_l = pre->sum_l, pl_a = pre->pl_a, pl_b = pre->pl_b, pl_c = pre->pl_c;
   const int best_mode = pre->best_mode, best_cost = pre->best_cost, last_mode = -1;
   const int av3 = avail & 7;
@@ -424,6 +432,7 @@ WH_FN bool wh_intra_md_enc_p (WhMbLds& S, const WhSeqParams& P, const WhPicJob& 
     int cost4 = 0;
     uint16_t prev_flags = 0;
     bool completed = true;
+    WH_PROF_MARK_I (3);     // texture analysis + neighbour mode cache
     for (int b = 0; b < 16; ++b) {
       const int bx = wh_blk_x (b), by = wh_blk_y (b);
       // sample availability of this 4x4 block (the reference tabulates it: g_kiNeighborIntraToI4x4)
@@ -556,10 +565,12 @@ WH_FN bool wh_intra_md_enc_p (WhMbLds& S, const WhSeqParams& P, const WhPicJob& 
       WV_LANES_END
     }
   }
+  WH_PROF_MARK_I (4);       // the sixteen Intra4x4 blocks
   if (mb_type == WH_MB_I16x16) {
     if (last_mode != best_mode) wh_pred_i16 (S, best_mode, sum_t, sum_l, pl_b, pl_c, pl_a);
     cbp = wh_encrec_i16 (S, qp);
   }
+  WH_PROF_MARK_I (5);       // Intra16x16 encode (when it won)
 
   // ---------------- chroma ----------------
   int st[4] = {0, 0, 0, 0}, sl[4] = {0, 0, 0, 0}, cpa[2] = {0, 0}, cpb[2] = {0, 0}, cpc[2] = {0, 0};
@@ -605,6 +616,8 @@ WH_FN bool wh_intra_md_enc_p (WhMbLds& S, const WhSeqParams& P, const WhPicJob& 
     if (cbp_c != 2) cbp_c = (c0 == 2) ? 2 : (cbp_c | c0);
   }
 
+  WH_PROF_MARK_I (6);       // chroma: mode decision + encode
+#undef WH_PROF_MARK_I
   o->mb_type = mb_type;
   o->cbp = cbp | (cbp_c << 4);
   o->i16_mode_std = (best_mode <= 3) ? best_mode : 2;

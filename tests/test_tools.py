@@ -61,3 +61,14 @@ def test_host_entropy_bench_runs(emu_lib):
         assert "host finish:" in text and "WelsHipGroupHostStats" in text
         out.append([l for l in text.splitlines() if l.startswith("sha1 of all bitstreams")][0])
     assert out[0] == out[1]
+
+
+def test_intra4x4_predictor_table_is_the_generated_one():
+    """kernels/intra_mb.h kWhI4Desc (the nine Intra4x4 predictors as a table look-up) equals what tools/gen_tables.py derives from the
+    predictors' index arithmetic -- which the generator checks against the predictors themselves on random edge samples."""
+    import re
+    import gen_tables
+    src = open(os.path.join(ROOT, "openh264_amd", "csrc", "kernels", "intra_mb.h")).read()
+    body = src.split("kWhI4Desc[36] = {", 1)[1].split("};", 1)[0]
+    words = [int(w, 16) for w in re.findall(r"0x([0-9a-fA-F]{8})u", body)]
+    assert words == gen_tables.i4_table(check=300)

@@ -35,7 +35,82 @@ def fmt(vals, per=16, w=4):
     return "\n".join(lines)
 
 
+# ---- Intra4x4 predictors as a table look-up (kernels/intra_mb.h kWhI4Desc) -------------------------------------------
+# Edge samples E(0..12) = L3 L2 L1 L0 TL T0..T7; X = E(0), E(0) .. E(12), E(12); RAW[a] = X[a], F2[a] = (X[a] + X[a+1] + 1) >> 1,
+# F3[a] = (X[a] + 2 X[a+1] + X[a+2] + 2) >> 2.  i4_desc gives, for a sample of a mode, the table offset (RAW 0.., F2 16.., F3 32.., DC 48);
+# i4_ref is the predictor as kernels/intra_mb.h wh_pred4_px (= the reference's WelsI4x4Luma*Pred_c, get_intra_predictor.cpp) computes it.
+def i4_desc(mode, x, y):
+    RAW, F2, F3 = 0, 16, 32
+    if mode == 0: return RAW + 6 + x
+    if mode == 1: return RAW + 4 - y
+    if mode == 2: return 48
+    if mode == 3: return F3 + 12 if (x == 3 and y == 3) else F3 + 6 + x + y
+    if mode == 4: return F3 + 4 + x - y
+    if mode == 5:
+        z, i = 2 * x - y, x - (y >> 1)
+        if z >= 0: return (F3 + 4 + i) if (z & 1) else (F2 + 5 + i)
+        return F3 + 4 if z == -1 else F3 + 5 - y
+    if mode == 6:
+        z, j = 2 * y - x, y - (x >> 1)
+        if z >= 0: return (F3 + 4 - j) if (z & 1) else (F2 + 4 - j)
+        return F3 + 4 if z == -1 else F3 + 3 + x
+    if mode == 7:
+        i = x + (y >> 1)
+        return (F3 + 6 + i) if (y & 1) else (F2 + 6 + i)
+    z, j = x + 2 * y, y + (x >> 1)
+    if z > 5: return RAW + 1
+    if z == 5: return F3 + 0
+    return (F3 + 2 - j) if (z & 1) else (F2 + 3 - j)
+
+
+def i4_ref(mode, x, y, e, dc):
+    f3 = lambda a, b, c: (a + 2 * b + c + 2) >> 2
+    f2 = lambda a, b: (a + b + 1) >> 1
+    if mode == 0: return e[5 + x]
+    if mode == 1: return e[3 - y]
+    if mode == 2: return dc
+    if mode == 3:
+        return (e[11] + 3 * e[12] + 2) >> 2 if (x == 3 and y == 3) else f3(e[5 + x + y], e[6 + x + y], e[7 + x + y])
+    if mode == 4: return f3(e[4 + x - y - 1], e[4 + x - y], e[4 + x - y + 1])
+    if mode == 5:
+        z, i = 2 * x - y, x - (y >> 1)
+        if z >= 0: return f3(e[5 + i - 2], e[5 + i - 1], e[5 + i]) if z & 1 else f2(e[5 + i - 1], e[5 + i])
+        return f3(e[3], e[4], e[5]) if z == -1 else f3(e[3 - (y - 1)], e[3 - (y - 2)], e[3 - (y - 3)])
+    if mode == 6:
+        z, j = 2 * y - x, y - (x >> 1)
+        if z >= 0: return f3(e[3 - (j - 2)], e[3 - (j - 1)], e[3 - j]) if z & 1 else f2(e[3 - (j - 1)], e[3 - j])
+        return f3(e[3], e[4], e[5]) if z == -1 else f3(e[5 + x - 1], e[5 + x - 2], e[5 + x - 3])
+    if mode == 7:
+        i = x + (y >> 1)
+        return f3(e[5 + i], e[5 + i + 1], e[5 + i + 2]) if y & 1 else f2(e[5 + i], e[5 + i + 1])
+    z, j = x + 2 * y, y + (x >> 1)
+    if z > 5: return e[0]
+    if z == 5: return (e[1] + 3 * e[0] + 2) >> 2
+    return f3(e[3 - j], e[3 - (j + 1)], e[3 - (j + 2)]) if z & 1 else f2(e[3 - j], e[3 - (j + 1)])
+
+
+def i4_table(check=2000):
+    """The 36 words of kWhI4Desc ([mode * 4 + row], byte x = offset of sample (x, row)), checked against i4_ref on random edges."""
+    import random
+    rnd = random.Random(4)
+    for _ in range(check):
+        e = [rnd.randint(0, 255) for _ in range(13)]
+        X = [e[0]] + e + [e[12]] * 3
+        T = [0] * 49
+        for a in range(15):
+            T[a], T[16 + a], T[32 + a] = X[a], (X[a] + X[a + 1] + 1) >> 1, (X[a] + 2 * X[a + 1] + X[a + 2] + 2) >> 2
+        T[48] = rnd.randint(0, 255)
+        for m in range(9):
+            for y in range(4):
+                for x in range(4):
+                    assert T[i4_desc(m, x, y)] == i4_ref(m, x, y, e, T[48]), (m, x, y)
+    return [sum(i4_desc(m, x, r) << (8 * x) for x in range(4)) for m in range(9) for r in range(4)]
+
+
 def main():
+    if "--i4" in sys.argv:
+        print(", ".join("0x%08xu" % w for w in i4_table()))
+        return
     lib = ctypes.CDLL(LIB)
     mf = arr(lib, "_ZN7WelsEnc11g_kiQuantMFE", ctypes.c_int16, 52 * 8)
     ff = arr(lib, "_ZN7WelsEnc16g_kiQuantInterFFE", ctypes.c_int16, 58 * 8)

@@ -1,5 +1,5 @@
 """In-kernel phase profile of the P-frame MB kernel (cycle counters, see WH_PROF_MARK).
-usage: phase_profile.py [sessions] [synthetic|res]   (res: the reference's 1080p clip from oracle/_ref/res, as in bench.py)"""
+usage: phase_profile.py [sessions] [synthetic|res] [intra]   (res: the reference's 1080p clip from oracle/_ref/res, as in bench.py; intra: the IDR step)"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import openh264_amd as oh
@@ -19,9 +19,22 @@ else:
     c = bench.Content(synth_sequence(w, h, 2 * R), fsz, R, False)
 for s in range(S):
     for k in range(R): g.upload(s, k, c.frame(s, k))
-g.bench(1, 0)
 lib = g._lib
 lib.WelsHipGroupProfile.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_ulonglong)]
+if len(sys.argv) > 3 and sys.argv[3] == "intra":      # the IDR step that starts every stream: the I macroblock body's phases
+    lib.WelsHipGroupProfile(g._h, 1, None)
+    out = (C.c_ulonglong * 64)()
+    one = g.bench(1, 0)
+    lib.WelsHipGroupProfile(g._h, 1, out)
+    print("IDR step %s" % (one,))
+    names = {11: "ticket+order", 12: "dependency wait", 9: "tile load", 2: "I16x16 mode costs", 3: "texture analysis + mode cache", 4: "sixteen I4x4 blocks", 5: "I16x16 encode", 6: "chroma decision + encode",
+             15: "decision epilogue", 7: "bits + store", 13: "release+flag", 14: "(body total)"}
+    tot = sum(out[i] for i in range(16) if i not in (14,))
+    for i, n in names.items():
+        print("%-30s %6.2f%%  avg %8.0f cycles  hits %d" % (n, 100.0 * out[i] / max(tot, 1), out[i] / max(out[16 + i], 1), out[16 + i]))
+    print("total cycles/MB %.0f" % (tot / max(out[16 + 7], 1)))
+    sys.exit(0)
+g.bench(1, 0)
 lib.WelsHipGroupProfile(g._h, 1, None)
 out = (C.c_ulonglong * 64)()
 one = g.bench(1, 0)
