@@ -60,8 +60,7 @@ typedef struct alignas (16) WhWinLds {
 
 typedef struct alignas (16) WhInterLds {
   WhMbLds m;
-  uint8_t skip_y[256];                                      // P_Skip prediction
-  uint8_t skip_c[128];
+  // (the P_Skip prediction lives in m.pred_y / m.pred_c: whenever a macroblock makes another prediction it is not a decided skip any more)
   uint32_t nb[5 * 36];                                      // WhMbState copies: top-left, top, top-right, left, co-located (reference picture)
   int16_t co_mv[2][2];                                      // sP16x16Mv of the reference picture's MBs to the right / below
   int16_t mvp_out[16][2];                                   // predictor used for the mvd of each 4x4 (raster)
@@ -830,40 +829,26 @@ WH_FN void wh_rf_j_pair_v (const uint8_t* w, int o, uint32_t* ju, uint32_t* jd) 
   }
   *ju = wh_pack4 (u[0], u[1], u[2], u[3]); *jd = wh_pack4 (d[0], d[1], d[2], d[3]);
 }
-// half-sample candidate k (0 top, 1 bottom, 2 left, 3 right) of the integer position at o
-WH_FN uint32_t wh_rf_half (const uint8_t* w, int o, int k) {
-  uint32_t a, b;
-  if (k < 2) { wh_rf_h_pair (w, o, &a, &b); return k == 0 ? a : b; }
-  wh_rf_b_pair (w, o, &a, &b);
-  return k == 2 ? a : b;
-}
-// quarter-sample candidate k (0 top, 1 bottom, 2 left, 3 right) around the half-stage winner hb
-// (-1: the integer position itself, 0..3: half candidate hb)
-WH_FN uint32_t wh_rf_quarter (const uint8_t* w, int o, int hb, int k) {
-  const uint32_t G = wh_ld4u (w, o);
-  uint32_t a, b;
+// the four quarter-sample candidates (0 top, 1 bottom, 2 left, 3 right) around the half-stage winner hb (-1: the integer position
+// itself, 0..3: half candidate hb), from the stage-1 samples G, hu / hd (vertical half samples above / below), bl / br (horizontal
+// half samples left / right): each is the average of two samples of which at least one is already known; the centre half samples
+// (j) a half-sample winner needs are interpolated once for both of its candidates
+WH_FN void wh_rf_quarters (const uint8_t* w, int o, int hb, uint32_t G, uint32_t hu, uint32_t hd, uint32_t bl, uint32_t br, uint32_t* q) {
+  uint32_t ja, jb;
   switch (hb) {
-  case -1: return wh_avg4 (G, wh_rf_half (w, o, k));
+  case -1: q[0] = wh_avg4 (G, hu); q[1] = wh_avg4 (G, hd); q[2] = wh_avg4 (G, bl); q[3] = wh_avg4 (G, br); break;
   case 0:                                                    // hu, the h sample of the row above (at o - stride)
-    wh_rf_h_pair (w, o, &a, &b);
-    if (k == 0) return wh_avg4 (wh_ld4u (w, o - WH_WIN_STRIDE), a);
-    if (k == 1) return wh_avg4 (G, a);
-    { uint32_t jl, jr; wh_rf_j_pair_h (w, o - WH_WIN_STRIDE, &jl, &jr); return wh_avg4 (k == 2 ? jl : jr, a); }
+    wh_rf_j_pair_h (w, o - WH_WIN_STRIDE, &ja, &jb);
+    q[0] = wh_avg4 (wh_ld4u (w, o - WH_WIN_STRIDE), hu); q[1] = wh_avg4 (G, hu); q[2] = wh_avg4 (ja, hu); q[3] = wh_avg4 (jb, hu); break;
   case 1:                                                    // hd
-    wh_rf_h_pair (w, o, &a, &b);
-    if (k == 0) return wh_avg4 (G, b);
-    if (k == 1) return wh_avg4 (wh_ld4u (w, o + WH_WIN_STRIDE), b);
-    { uint32_t jl, jr; wh_rf_j_pair_h (w, o, &jl, &jr); return wh_avg4 (k == 2 ? jl : jr, b); }
+    wh_rf_j_pair_h (w, o, &ja, &jb);
+    q[0] = wh_avg4 (G, hd); q[1] = wh_avg4 (wh_ld4u (w, o + WH_WIN_STRIDE), hd); q[2] = wh_avg4 (ja, hd); q[3] = wh_avg4 (jb, hd); break;
   case 2:                                                    // bl, the b sample of the column to the left (at o - 1)
-    wh_rf_b_pair (w, o, &a, &b);
-    if (k == 2) return wh_avg4 (wh_ld4u (w, o - 1), a);
-    if (k == 3) return wh_avg4 (G, a);
-    { uint32_t ju, jd; wh_rf_j_pair_v (w, o - 1, &ju, &jd); return wh_avg4 (k == 0 ? ju : jd, a); }
+    wh_rf_j_pair_v (w, o - 1, &ja, &jb);
+    q[0] = wh_avg4 (ja, bl); q[1] = wh_avg4 (jb, bl); q[2] = wh_avg4 (wh_ld4u (w, o - 1), bl); q[3] = wh_avg4 (G, bl); break;
   default:                                                   // br
-    wh_rf_b_pair (w, o, &a, &b);
-    if (k == 2) return wh_avg4 (G, b);
-    if (k == 3) return wh_avg4 (wh_ld4u (w, o + 1), b);
-    { uint32_t ju, jd; wh_rf_j_pair_v (w, o, &ju, &jd); return wh_avg4 (k == 0 ? ju : jd, b); }
+    wh_rf_j_pair_v (w, o, &ja, &jb);
+    q[0] = wh_avg4 (ja, br); q[1] = wh_avg4 (jb, br); q[2] = wh_avg4 (G, br); q[3] = wh_avg4 (wh_ld4u (w, o + 1), br); break;
   }
 }
 
@@ -871,6 +856,8 @@ WH_FN uint32_t wh_rf_quarter (const uint8_t* w, int o, int hb, int k) {
 // `sub8`: a 16x8 / 8x16 partition that TryModeMerge made of two 8x8 searches (screen content) keeps BLOCK_8x8 as its block size,
 // so the reference scores every candidate on the partition's first 8x8 only (pfMeCost[pMe->uiBlockSize], md.cpp:602-640) while it
 // interpolates and copies the whole partition.
+// Every candidate's samples are interpolated ONCE and stay in the lane's registers (lane tables): the stage-1 samples feed the quarter
+// candidates, and the winner's samples become the prediction without being computed again.
 WH_FN void wh_refine_frac (WhInterLds& S, const WhSeqParams& P, const WhPicJob& J, WhWin& W, const WhMeCtx& C, WhMe& me, int satd_in_md, int sub8 = 0) {
   const int bpx = C.mbx * 16 + me.bx, bpy = C.mby * 16 + me.by;
   const int ipx = bpx + (me.mvx >> 2), ipy = bpy + (me.mvy >> 2);          // me.mv is integer-pel here
@@ -881,15 +868,28 @@ WH_FN void wh_refine_frac (WhInterLds& S, const WhSeqParams& P, const WhPicJob& 
 #define WH_RF_ENC wh_enc4 (S, ex + (lane < nq ? wh_tl_col (lane, bw) : 0), ey + (lane < nq ? wh_tl_row (lane, bw) : 0))
 #define WH_RF_O (wo + (lane < nq ? wh_tl_row (lane, bw) * WH_WIN_STRIDE + wh_tl_col (lane, bw) : 0))
   const int dmx = me.mvx - me.mvpx, dmy = me.mvy - me.mvpy;
+  WvLaneArr vG, vhu, vhd, vbl, vbr, vq0, vq1, vq2, vq3;
+#if defined(WH_EMU)
+  memset (&vG, 0, sizeof (vG)); memset (&vhu, 0, sizeof (vhu)); memset (&vhd, 0, sizeof (vhd)); memset (&vbl, 0, sizeof (vbl)); memset (&vbr, 0, sizeof (vbr));
+  memset (&vq0, 0, sizeof (vq0)); memset (&vq1, 0, sizeof (vq1)); memset (&vq2, 0, sizeof (vq2)); memset (&vq3, 0, sizeof (vq3));
+#else
+  vG = 0; vhu = 0; vhd = 0; vbl = 0; vbr = 0; vq0 = 0; vq1 = 0; vq2 = 0; vq3 = 0;
+#endif
   // integer position + the four half-sample candidates (independent of each other: the SATDs overlap)
   int c_int, c0, c1, c2, c3;
-  WV_DECLARE_LANE (lane);                   // one lane id for all candidates: they share most of their window loads
+  WV_DECLARE_LANE (lane);                   // one lane id for everything below: the candidates share most of their window loads
+  WV_LANE_EVAL (lane, {
+    const int o = WH_RF_O;
+    uint32_t a, b;
+    WV_LOWN (vG, lane) = (int)wh_ld4u (W.b->win, o);
+    wh_rf_h_pair (W.b->win, o, &a, &b); WV_LOWN (vhu, lane) = (int)a; WV_LOWN (vhd, lane) = (int)b;
+    wh_rf_b_pair (W.b->win, o, &a, &b); WV_LOWN (vbl, lane) = (int)a; WV_LOWN (vbr, lane) = (int)b; });
   if (satd_in_md) c_int = me.satd_raw;                                      // uiSatd of the integer search
-  else WV_SATD_ROWS_SHARED (c_int, lane, WH_RF_ACT, WH_RF_ENC, wh_ld4u (W.b->win, WH_RF_O));
-  WV_SATD_ROWS_SHARED (c0, lane, WH_RF_ACT, WH_RF_ENC, wh_rf_half (W.b->win, WH_RF_O, 0));
-  WV_SATD_ROWS_SHARED (c1, lane, WH_RF_ACT, WH_RF_ENC, wh_rf_half (W.b->win, WH_RF_O, 1));
-  WV_SATD_ROWS_SHARED (c2, lane, WH_RF_ACT, WH_RF_ENC, wh_rf_half (W.b->win, WH_RF_O, 2));
-  WV_SATD_ROWS_SHARED (c3, lane, WH_RF_ACT, WH_RF_ENC, wh_rf_half (W.b->win, WH_RF_O, 3));
+  else WV_SATD_ROWS_SHARED (c_int, lane, WH_RF_ACT, WH_RF_ENC, (uint32_t)WV_LOWN (vG, lane));
+  WV_SATD_ROWS_SHARED (c0, lane, WH_RF_ACT, WH_RF_ENC, (uint32_t)WV_LOWN (vhu, lane));
+  WV_SATD_ROWS_SHARED (c1, lane, WH_RF_ACT, WH_RF_ENC, (uint32_t)WV_LOWN (vhd, lane));
+  WV_SATD_ROWS_SHARED (c2, lane, WH_RF_ACT, WH_RF_ENC, (uint32_t)WV_LOWN (vbl, lane));
+  WV_SATD_ROWS_SHARED (c3, lane, WH_RF_ACT, WH_RF_ENC, (uint32_t)WV_LOWN (vbr, lane));
   int best = c_int + wh_mvd_cost (C.lambda, dmx, dmy), hb = -1;
   c0 += wh_mvd_cost (C.lambda, dmx, dmy - 2); if (c0 < best) { best = c0; hb = 0; }
   c1 += wh_mvd_cost (C.lambda, dmx, dmy + 2); if (c1 < best) { best = c1; hb = 1; }
@@ -897,10 +897,14 @@ WH_FN void wh_refine_frac (WhInterLds& S, const WhSeqParams& P, const WhPicJob& 
   c3 += wh_mvd_cost (C.lambda, dmx + 2, dmy); if (c3 < best) { best = c3; hb = 3; }
   const int hx = hb == 2 ? -2 : hb == 3 ? 2 : 0, hy = hb == 0 ? -2 : hb == 1 ? 2 : 0;    // winner of the half stage, relative
   // quarter-sample candidates around it
-  WV_SATD_ROWS_SHARED (c0, lane, WH_RF_ACT, WH_RF_ENC, wh_rf_quarter (W.b->win, WH_RF_O, hb, 0));
-  WV_SATD_ROWS_SHARED (c1, lane, WH_RF_ACT, WH_RF_ENC, wh_rf_quarter (W.b->win, WH_RF_O, hb, 1));
-  WV_SATD_ROWS_SHARED (c2, lane, WH_RF_ACT, WH_RF_ENC, wh_rf_quarter (W.b->win, WH_RF_O, hb, 2));
-  WV_SATD_ROWS_SHARED (c3, lane, WH_RF_ACT, WH_RF_ENC, wh_rf_quarter (W.b->win, WH_RF_O, hb, 3));
+  WV_LANE_EVAL (lane, {
+    uint32_t q[4];
+    wh_rf_quarters (W.b->win, WH_RF_O, hb, (uint32_t)WV_LOWN (vG, lane), (uint32_t)WV_LOWN (vhu, lane), (uint32_t)WV_LOWN (vhd, lane), (uint32_t)WV_LOWN (vbl, lane), (uint32_t)WV_LOWN (vbr, lane), q);
+    WV_LOWN (vq0, lane) = (int)q[0]; WV_LOWN (vq1, lane) = (int)q[1]; WV_LOWN (vq2, lane) = (int)q[2]; WV_LOWN (vq3, lane) = (int)q[3]; });
+  WV_SATD_ROWS_SHARED (c0, lane, WH_RF_ACT, WH_RF_ENC, (uint32_t)WV_LOWN (vq0, lane));
+  WV_SATD_ROWS_SHARED (c1, lane, WH_RF_ACT, WH_RF_ENC, (uint32_t)WV_LOWN (vq1, lane));
+  WV_SATD_ROWS_SHARED (c2, lane, WH_RF_ACT, WH_RF_ENC, (uint32_t)WV_LOWN (vq2, lane));
+  WV_SATD_ROWS_SHARED (c3, lane, WH_RF_ACT, WH_RF_ENC, (uint32_t)WV_LOWN (vq3, lane));
   int qb = -1;
   c0 += wh_mvd_cost (C.lambda, dmx + hx, dmy + hy - 1); if (c0 < best) { best = c0; qb = 0; }
   c1 += wh_mvd_cost (C.lambda, dmx + hx, dmy + hy + 1); if (c1 < best) { best = c1; qb = 1; }
@@ -909,13 +913,13 @@ WH_FN void wh_refine_frac (WhInterLds& S, const WhSeqParams& P, const WhPicJob& 
   const int qx = qb == 2 ? -1 : qb == 3 ? 1 : 0, qy = qb == 0 ? -1 : qb == 1 ? 1 : 0;
   me.satd_cost = best;
   // the winner's samples become the prediction
-  WV_LANES_BEGIN (lane)
-  if (lane < nq) {
-    const int o = WH_RF_O;
-    const uint32_t v = qb >= 0 ? wh_rf_quarter (W.b->win, o, hb, qb) : hb >= 0 ? wh_rf_half (W.b->win, o, hb) : wh_ld4u (W.b->win, o);
-    * (uint32_t*)&S.m.pred_y[(ey + wh_tl_row (lane, bw)) * 16 + ex + wh_tl_col (lane, bw)] = v;
-  }
-  WV_LANES_END
+  WV_LANE_EVAL (lane, {
+    if (lane < nq) {
+      const int v = qb >= 0 ? (qb == 0 ? WV_LOWN (vq0, lane) : qb == 1 ? WV_LOWN (vq1, lane) : qb == 2 ? WV_LOWN (vq2, lane) : WV_LOWN (vq3, lane))
+                  : hb >= 0 ? (hb == 0 ? WV_LOWN (vhu, lane) : hb == 1 ? WV_LOWN (vhd, lane) : hb == 2 ? WV_LOWN (vbl, lane) : WV_LOWN (vbr, lane)) : WV_LOWN (vG, lane);
+      * (uint32_t*)&S.m.pred_y[(ey + wh_tl_row (lane, bw)) * 16 + ex + wh_tl_col (lane, bw)] = (uint32_t)v;
+    } });
+  WV_SYNC();
 #undef WH_RF_ACT
 #undef WH_RF_ENC
 #undef WH_RF_O
@@ -1224,10 +1228,10 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
     const int ref_qp = Co->ref_qp;
     if (bg_cur && !ref_intra && (ref_qp - qp <= 3 /* DELTA_QP_BGD_THD */ || ref_qp <= 26)) {
       // CheckChromaCost: chroma of the co-located block against the source
-      wh_mc_chroma_to (S, P, J, W, mbx, mby, 0, 0, 8, 8, 0, 0, S.skip_c);
+      wh_mc_chroma_to (S, P, J, W, mbx, mby, 0, 0, 8, 8, 0, 0, M.pred_c);
       int cb, cr;
-      WV_SUM2 (cb, cr, lane, (lane < 16 ? wh_sad4 (* (const uint32_t*)&M.enc_c[lane * 4], * (const uint32_t*)&S.skip_c[lane * 4]) : 0),
-               (lane >= 16 && lane < 32 ? wh_sad4 (* (const uint32_t*)&M.enc_c[lane * 4], * (const uint32_t*)&S.skip_c[lane * 4]) : 0));
+      WV_SUM2 (cb, cr, lane, (lane < 16 ? wh_sad4 (* (const uint32_t*)&M.enc_c[lane * 4], * (const uint32_t*)&M.pred_c[lane * 4]) : 0),
+               (lane >= 16 && lane < 32 ? wh_sad4 (* (const uint32_t*)&M.enc_c[lane * 4], * (const uint32_t*)&M.pred_c[lane * 4]) : 0));
       const bool too_large = cb > 640 || cr > 640;                 // KNOWN_CHROMA_TOO_LARGE
       const int chroma_sad = cb + cr, pred_skip = predict_sad_skip();
       const bool cannot = (pred_skip > 128 && chroma_sad >= pred_skip) ||       // SMALLEST_INVISIBLE; IsCostLessEqualSkipCost
@@ -1238,13 +1242,8 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
         int sx, sy;
         wh_pred_skip_mv (K, &sx, &sy);
         bg_coded = true; bg_skip = sx == 0 && sy == 0; collocated = true;
-        wh_mc_luma_to (S, P, J, W, mbx, mby, 0, 0, 16, 16, 0, 0, bg_skip ? S.skip_y : M.pred_y);
-        if (!bg_skip) {
-          WV_LANES_BEGIN (lane)
-          if (lane < 32) * (uint32_t*)&M.pred_c[lane * 4] = * (const uint32_t*)&S.skip_c[lane * 4];
-          WV_LANES_END
-        }
-        const uint8_t* pl = bg_skip ? S.skip_y : M.pred_y;
+        wh_mc_luma_to (S, P, J, W, mbx, mby, 0, 0, 16, 16, 0, 0, M.pred_y);
+        const uint8_t* pl = M.pred_y;
         int sad;
         WV_SUM (sad, lane, wh_sad4 (* (const uint32_t*)&M.enc_y[lane * 4], * (const uint32_t*)&pl[lane * 4]));
         sad_cost0 = sad;
@@ -1321,8 +1320,8 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
       wh_pred_skip_mv (K, &sx, &sy);
       const int vx = (int) (int16_t) (ox * 4), vy = (int) (int16_t) (oy * 4);
       const bool as_skip = qp_similar && sx == vx && sy == vy;
-      uint8_t* dy = as_skip ? S.skip_y : M.pred_y;
-      uint8_t* dc = as_skip ? S.skip_c : M.pred_c;
+      uint8_t* dy = M.pred_y;
+      uint8_t* dc = M.pred_c;
       wh_mc_luma_to (S, P, J, W, mbx, mby, 0, 0, 16, 16, vx, vy, dy);
       wh_mc_chroma_to (S, P, J, W, mbx, mby, 0, 0, 8, 8, vx, vy, dc);
       int sad;
@@ -1357,22 +1356,18 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
     wh_pred_skip_mv (K, &skx, &sky);
     const int nx = (mbx << 4) + (skx >> 2), ny = (mby << 4) + (sky >> 2);
     if (!(nx < -29 || nx > (P.mb_w << 4) + 12 || ny < -29 || ny > (P.mb_h << 4) + 12)) {
-      wh_mc_luma_to (S, P, J, W, mbx, mby, 0, 0, 16, 16, skx, sky, S.skip_y);
+      wh_mc_luma_to (S, P, J, W, mbx, mby, 0, 0, 16, 16, skx, sky, M.pred_y);
       WH_PROF_SUB (P, M, 4);     /* detail: P_Skip luma prediction */
-      wh_mc_chroma_to (S, P, J, W, mbx, mby, 0, 0, 8, 8, skx, sky, S.skip_c);
+      wh_mc_chroma_to (S, P, J, W, mbx, mby, 0, 0, 8, 8, skx, sky, M.pred_c);
       WH_PROF_SUB (P, M, 5);     /* detail: P_Skip chroma prediction */
       int sad_l, sad_c;                       // luma and chroma SAD of the skip prediction in one reduction
-      WV_SUM2 (sad_l, sad_c, lane, wh_sad4 (* (const uint32_t*)&S.m.enc_y[lane * 4], * (const uint32_t*)&S.skip_y[lane * 4]),
-               (lane < 32 ? wh_sad4 (* (const uint32_t*)&S.m.enc_c[lane * 4], * (const uint32_t*)&S.skip_c[lane * 4]) : 0));
+      WV_SUM2 (sad_l, sad_c, lane, wh_sad4 (* (const uint32_t*)&S.m.enc_y[lane * 4], * (const uint32_t*)&M.pred_y[lane * 4]),
+               (lane < 32 ? wh_sad4 (* (const uint32_t*)&S.m.enc_c[lane * 4], * (const uint32_t*)&M.pred_c[lane * 4]) : 0));
       const int sad_mb = sad_l + sad_c;
       bool ok = sad_mb == 0 || sad_mb < sad_pred_skip || (ref_is_p && ref_mb_type == WH_MB_PSKIP && !ref_mb_bg && sad_mb < Co->skip_sad);
       WH_PROF_SUB (P, M, 6);     /* detail: P_Skip SADs + decision */
       if (!ok) {
-        // residual would quantise to nothing?  (WelsDctMb + WelsTryPYskip + WelsTryPUVskip)
-        WV_LANES_BEGIN (lane)
-        * (uint32_t*)&M.pred_y[lane * 4] = * (const uint32_t*)&S.skip_y[lane * 4];
-        if (lane < 32) * (uint32_t*)&M.pred_c[lane * 4] = * (const uint32_t*)&S.skip_c[lane * 4];
-        WV_LANES_END
+        // residual would quantise to nothing?  (WelsDctMb + WelsTryPYskip + WelsTryPUVskip; the transform reads the skip prediction where it lies)
         wh_dct_luma16 (M);
         if (wh_try_py_skip (M, qp)) {
           wh_dct_chroma (M);
@@ -1382,7 +1377,7 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
       if (ok) {
         b_skip = true;
         if (md_using_sad) cost_luma = sad_l;
-        else WV_SATD_ROWS (cost_luma, lane, true, wh_enc4 (S, wh_tl_col (lane, 16), wh_tl_row (lane, 16)), * (const uint32_t*)&S.skip_y[wh_tl_row (lane, 16) * 16 + wh_tl_col (lane, 16)]);
+        else WV_SATD_ROWS (cost_luma, lane, true, wh_enc4 (S, wh_tl_col (lane, 16), wh_tl_row (lane, 16)), * (const uint32_t*)&M.pred_y[wh_tl_row (lane, 16) * 16 + wh_tl_col (lane, 16)]);
         // pSadCost[0] is only refreshed when bMdUsingSad; otherwise the SMB entry keeps the previous frame's value
         sad_cost0 = md_using_sad ? sad_l : ((HOSTIN && J.sad_cost0) ? (int)S.nb[144 + 35] : Co->sad_cost[0]);
         cost_skip_mb = sad_mb;
@@ -1675,11 +1670,11 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
     WV_LANES_BEGIN (lane)
     {
       const int row = lane >> 2, seg = lane & 3;
-      * (uint32_t*)&WH_RY (M, seg * 4, row) = * (const uint32_t*)&S.skip_y[row * 16 + seg * 4];
+      * (uint32_t*)&WH_RY (M, seg * 4, row) = * (const uint32_t*)&M.pred_y[row * 16 + seg * 4];
     }
     if (lane < 32) {
       const int pl = lane >> 4, row = (lane >> 1) & 7, half = lane & 1;
-      * (uint32_t*)&WH_RC (M, pl, half * 4, row) = * (const uint32_t*)&S.skip_c[pl * 64 + row * 8 + half * 4];
+      * (uint32_t*)&WH_RC (M, pl, half * 4, row) = * (const uint32_t*)&M.pred_c[pl * 64 + row * 8 + half * 4];
     }
     if (lane < 24) M.nzc[lane] = 0;
     WV_LANES_END

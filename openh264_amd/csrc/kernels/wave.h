@@ -73,6 +73,8 @@
 // them so that the compiler can share the common loads (each plain macro re-materialises its own opaque lane id).
 #define WV_DECLARE_LANE(lane) ((void)0)
 #define WV_SATD_ROWS_SHARED(dst, lane, active, enc4, pred4) WV_SATD_ROWS (dst, lane, active, enc4, pred4)
+// per-lane statements under the shared lane id (results kept in lane tables: WV_LOWN (tab, lane) = ...)
+#define WV_LANE_EVAL(lane, ...) do { for (int lane = 0; lane < 64; ++lane) { __VA_ARGS__; } } while (0)
 // pointers into device global memory (explicit address space on the GPU so that loads are global_*, not flat_*)
 #define WH_G
 #include <string.h>
@@ -200,6 +202,7 @@ WH_FN int wh_satd_rows (int lane, bool active, uint32_t e, uint32_t p) {
   do { const int lane = wh_lane_id(); (dst) = wh_satd_rows (lane, (active), (enc4), (pred4)); } while (0)
 #define WV_DECLARE_LANE(lane) const int lane = wh_lane_id()
 #define WV_SATD_ROWS_SHARED(dst, lane, active, enc4, pred4) do { (dst) = wh_satd_rows (lane, (active), (enc4), (pred4)); } while (0)
+#define WV_LANE_EVAL(lane, ...) do { __VA_ARGS__; } while (0)
 typedef int WvLaneArr;
 #define WV_LGET(a, i) __builtin_amdgcn_readlane ((a), (i))
 #define WV_LSET(a, i, val) do { if ((int)(threadIdx.x & 63) == (i)) (a) = (val); } while (0)

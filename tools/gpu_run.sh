@@ -10,6 +10,7 @@
 #   stats           rocprofv3 --kernel-trace --stats of `bench.py --quick` -> kernel_stats.csv
 #   pmc             FETCH_SIZE / WRITE_SIZE passes of `bench.py --quick` (separate runs, --kernel-trace only beside --pmc) -> pmc_traffic.txt
 #   phase           in-kernel phase cycles of the P macroblock body (tools/phase_profile.py 256) -> phase_cycles.txt
+#   trace1          kernel + copy timeline of ONE 1080p session through the dispatch-table binding (config 5's shape) -> trace1_timeline.txt
 #   iphase          the same for the I macroblock body (the IDR step of 256 pictures) -> phase_cycles_intra.txt
 #   tables          every device row of both SHA1 tables incl. the size-limited rows -> *_rows.txt
 #   repro:<seeds>   size-limited-slice sessions <seeds> (comma separated; s = screen content, q = low QP: e.g. s21001,q11012,1003) with slice threads,
@@ -63,6 +64,8 @@ for stage in "$@"; do
               WELSHIP_LIB=$PWD/$lib timeout 200 python bench.py --quick > $o/ab_${t}_$rep.json 2> $o/ab_${t}_$rep.err
               python -c "import json; d=json.loads(open('$o/ab_${t}_$rep.json').read().strip().splitlines()[-1]); print('$t', $rep, 'value', round(d['value']), 'md_ms', d['roofline']['avg_launch_ms'], 'verified', d.get('verified'))"
             done; done | tee $o/ab.txt; lap "A/B";;
+  trace1)   ( cd /tmp && WELS_HIP_TRACE=2 timeout 200 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $OLDPWD/$o/trace1 -- python $OLDPWD/tools/config5_sessions.py 1 12 x 1080p > $OLDPWD/$o/trace1.log 2>&1 )
+            python tools/trace_timeline.py $o/trace1 2 > $o/trace1_timeline.txt 2>&1; tail -60 $o/trace1_timeline.txt; rm -rf $o/trace1; lap "timeline of one 1080p session through the binding";;
   iphase)   timeout 200 python tools/phase_profile.py 256 synthetic intra > $o/phase_cycles_intra.txt 2>&1; head -16 $o/phase_cycles_intra.txt; lap "phase cycles (IDR step)";;
   detail:*) WELSHIP_LIB=$PWD/openh264_amd/libwelship_${stage#detail:}.so WELSHIP_PROF_DETAIL=1 timeout 200 python tools/phase_profile.py 256 > $o/phase_cycles_detail.txt 2>&1; head -22 $o/phase_cycles_detail.txt; lap "phase cycles (detail)";;
   *)        echo "unknown stage $stage";;
