@@ -299,7 +299,16 @@ typedef struct WelsHipFrameJob {
   /* macroblock the writer took back, or bRangeAgain -- and finds what its first pass left in the layer's pSadCost array                  */
   /* (WelsMdInterSaveSadAndRefMbType runs before the writer), every other macroblock what the previous picture left.                      */
   int32_t bDynRedoFirst;
+  /* Whole-picture calls: hand the records over PACKED, as they crossed PCIe (a skipped macroblock 16 bytes, any other its 144 bytes of side     */
+  /* information plus the 32-byte level blocks that hold a level the entropy coder can read: openh264_amd/csrc/common/compact.h) -- *ppRecords   */
+  /* then points at a WelsHipPackedRecords instead of a WhMbRecord array, and the caller expands a macroblock when it gets to it                  */
+  /* (wh_compact_expand).  About a sixth of the 960-byte records on camera content; MB ranges always come back as full records.                   */
+  int32_t bPackedRecords;
 } WelsHipFrameJob;
+typedef struct WelsHipPackedRecords {
+  const uint8_t* pData;             /* the packed stream of the picture                                                                       */
+  const uint32_t* pOffset;          /* [number of macroblocks + 1] byte offsets into pData; macroblock mb is pOffset[mb + 1] - pOffset[mb] long */
+} WelsHipPackedRecords;
 typedef struct WelsHipGomRc {
   int32_t iNumberMbGom;             /* pWelsSvcRc->iNumberMbGom: whole macroblock rows (else WELSHIP_ERR_UNSUPPORTED: code the groups one by one) */
   int32_t iEndMbSlice, iTargetBitsSlice;      /* pSlice->sSlicingOverRc                                                                  */

@@ -53,6 +53,7 @@
 #include "rc.h"
 #include "wels_preprocess.h"
 #include <dlfcn.h>
+#include "compact.h"
 #include "welship.h"
 #include "wh_types.h"          // WhMbRecord: the engine's per-macroblock record (openh264_amd/csrc/common)
 
@@ -103,6 +104,8 @@ struct HipLayer {                       // one spatial layer = one device contex
   std::map<const SPicture*, int> twin;   // reference SPicture -> device picture index
   int num_pictures = 0;
   const WhMbRecord* records = NULL;      // of the picture being coded (valid from pfHipFrameMd to the end of its slices)
+  const WelsHipPackedRecords* packed = NULL;   // ... or its packed records (whole-picture calls: WelsHipFrameJob::bPackedRecords); a macroblock is
+                                               // expanded into a WhMbRecord of the slice loop's own when the entropy writer gets to it
   // GOM-level rate control (one slice per picture, QP per group of macroblocks from the bits written so far): the picture is
   // coded group by group from inside the slice loop -- the job is only prepared by pfHipFrameMd
   bool gom = false;
@@ -150,6 +153,9 @@ struct HipState {
   bool downsample = true;               // WELS_HIP_DOWNSAMPLE=0: the spatial layers are down-sampled by the reference's own C functions
   long downsampled = 0;
   bool gom_kernel = false;              // WELS_HIP_GOM=2: single-slice rate-controlled P pictures in ONE device call (the QP recursion runs in the kernel)
+  bool packed = true;                   // WELS_HIP_PACKED=0: whole pictures' records come back as full 960-byte records
+  bool eager_recon = false;             // WELS_HIP_EAGER_RECON=1: copy every reconstruction back into pDecPic as soon as the picture is coded (else: pfHipFetchRecon, on demand)
+  long recon_fetched = 0;
   bool check_bits = false;              // WELS_HIP_CHECK_BITS=1: the device counts every macroblock's CAVLC bits and the slice loop compares them with the writer
   std::atomic<long> bits_checked {0};
   double t_encode = 0.0, t_getpic = 0.0, t_code = 0.0;
@@ -160,6 +166,24 @@ struct Stopwatch {
   explicit Stopwatch (double* a) : acc (a), t0 (std::chrono::steady_clock::now()) {}
   ~Stopwatch() { if (acc) *acc += std::chrono::duration<double> (std::chrono::steady_clock::now() - t0).count(); }
 };
+
+// The device's reconstruction of the layer's current picture into pDecPic.  Nothing of the hooked encoder reads pDecPic's samples on the
+// host (mode decision, the in-loop filter and the reference pictures live on the device), so this only runs where the reference is about
+// to: PSNR and the test builds' frame dump (pfHipFetchRecon, called from WelsEncoderEncodeExt), or for every picture with WELS_HIP_EAGER_RECON=1.
+bool FetchRecon (HipState* st, sWelsEncCtx* pCtx, HipLayer& L, int iPic) {
+  uint8_t* dst[3] = { pCtx->pDecPic->pData[0], pCtx->pDecPic->pData[1], pCtx->pDecPic->pData[2] };
+  const int32_t ds[3] = { pCtx->pDecPic->iLineSize[0], pCtx->pDecPic->iLineSize[1], pCtx->pDecPic->iLineSize[2] };
+  Stopwatch sw (st->timing ? &st->t_getpic : NULL);
+  if (g_api.FrameGetPicture (L.ctx, iPic, dst, ds)) { st->failed = true; return false; }
+  ++st->recon_fetched;
+  return true;
+}
+void HipFetchRecon (sWelsEncCtx* pCtx) {
+  HipState* st = (HipState*)pCtx->pFuncList->pHipState;
+  if (st == NULL || st->failed || st->eager_recon) return;
+  HipLayer& L = st->layer[pCtx->uiDependencyId];
+  if (L.ctx != NULL) FetchRecon (st, pCtx, L, L.job.iCurPic);
+}
 
 int TwinOf (HipLayer& L, const SPicture* p) {
   std::map<const SPicture*, int>::iterator it = L.twin.find (p);
@@ -205,7 +229,7 @@ int32_t DynCode (HipState* st, HipLayer& L, int iPart, int iSliceIdx, int iSlice
   const void* rec = NULL;
   const int rc = g_api.FrameEncode (L.ctx, &jb, &rec);
   if (rc) { fprintf (stderr, "welship hooks: WelsHipFrameEncode (slice %d from MB %d) failed (%d: %s)\n", iSliceIdx, iFrom, rc, g_api.GetLastError()); st->failed = true; return ENC_RETURN_UNEXPECTED; }
-  L.records = (const WhMbRecord*)rec;          // (the context's record array: the same pointer for every call)
+  L.records = (const WhMbRecord*)rec; L.packed = NULL;          // (the context's record array: the same pointer for every call)
   P.coded_upto = end; P.coded_slice = iSliceIdx;
   std::lock_guard<std::mutex> lock (L.dyn_mu);
   ++L.dyn_calls;
@@ -448,7 +472,7 @@ int32_t HipFrameMd (sWelsEncCtx* pCtx) {
       // (a partition of a single macroblock is left out by its task, wels_task_encoder.cpp:246-250; one thread: WelsCodeOnePicPartition codes whatever there is)
       if (nparts == 1 || pCurLayer->EndMbIdxOfPartition[q] > pCurLayer->FirstMbIdxOfPartition[q]) ++L.dyn_parts_left;
     }
-    L.records = NULL;
+    L.records = NULL; L.packed = NULL;
     if (st->trace) fprintf (stderr, "welship hooks: did %d %c picture qp %d size-limited slices (%u bytes, %d partition%s) cur %d ref %d deblock %d expand %d\n", did, is_p ? 'P' : 'I', job.iQp,
                             pCurLayer->sSliceEncCtx.uiSliceSizeConstraint, nparts, nparts == 1 ? "" : "s", job.iCurPic, job.iRefPic, job.bDeblock, job.bExpand);
     // The first macroblocks of the picture now (slice 0 begins at macroblock 0 whatever happens): this call also takes the picture's
@@ -461,18 +485,22 @@ int32_t HipFrameMd (sWelsEncCtx* pCtx) {
     if (nslices != 1) { fprintf (stderr, "welship hooks: GOM-level QP with %d slices\n", nslices); st->failed = true; return ENC_RETURN_UNEXPECTED; }
     L.mb_qp.assign (num_mb, (uint8_t)pCtx->iGlobalQp);
     L.coded_upto = 0;
-    L.records = NULL;
+    L.records = NULL; L.packed = NULL;
     if (st->trace) fprintf (stderr, "welship hooks: did %d %c picture GOM-level QP (%d MBs per group) cur %d ref %d deblock %d expand %d\n", did, is_p ? 'P' : 'I',
                             pCtx->pWelsSvcRc[did].iNumberMbGom, job.iCurPic, job.iRefPic, job.bDeblock, job.bExpand);
     return ENC_RETURN_SUCCESS;
   }
   const void* rec = NULL;
   int rc;
+  const char* dump = getenv ("WELS_HIP_DUMP_RECORDS");
+  job.bPackedRecords = (st->packed && dump == NULL) ? 1 : 0;
   { Stopwatch sw (st->timing ? &st->t_encode : NULL); rc = g_api.FrameEncode (L.ctx, &job, &rec); }
   ++st->pictures;
   if (rc) { fprintf (stderr, "welship hooks: WelsHipFrameEncode failed (%d: %s)\n", rc, g_api.GetLastError()); st->failed = true; return ENC_RETURN_UNEXPECTED; }
-  L.records = (const WhMbRecord*)rec;
-  if (const char* dump = getenv ("WELS_HIP_DUMP_RECORDS")) {        // developer aid: the raw macroblock records of every picture
+  if (job.bPackedRecords) { L.packed = (const WelsHipPackedRecords*)rec; L.records = NULL; }
+  else { L.packed = NULL; L.records = (const WhMbRecord*)rec; }
+  job.bPackedRecords = 0;          // (the job is reused by the retry after a CAVLC overflow, which asks for what the slice loop holds then)
+  if (dump) {        // developer aid: the raw macroblock records of every picture
     static int s_pic = 0;
     char name[512];
     snprintf (name, sizeof name, "%s_%03d_d%d.rec", dump, s_pic++, did);
@@ -483,10 +511,7 @@ int32_t HipFrameMd (sWelsEncCtx* pCtx) {
     L.states.resize (num_mb);
     if (g_api.FrameGetMbStates (L.ctx, job.iCurPic, &L.states[0], sizeof (WhMbState) * num_mb)) { st->failed = true; return ENC_RETURN_UNEXPECTED; }
   }
-  // the host's copy of the reconstruction (PSNR, reconstruction dumps, pre-processing that looks at the reference picture)
-  uint8_t* dst[3] = { pCtx->pDecPic->pData[0], pCtx->pDecPic->pData[1], pCtx->pDecPic->pData[2] };
-  const int32_t ds[3] = { pCtx->pDecPic->iLineSize[0], pCtx->pDecPic->iLineSize[1], pCtx->pDecPic->iLineSize[2] };
-  { Stopwatch sw (st->timing ? &st->t_getpic : NULL); if (g_api.FrameGetPicture (L.ctx, job.iCurPic, dst, ds)) { st->failed = true; return ENC_RETURN_UNEXPECTED; } }
+  if (st->eager_recon && !FetchRecon (st, pCtx, L, job.iCurPic)) return ENC_RETURN_UNEXPECTED;
   if (st->trace) fprintf (stderr, "welship hooks: did %d %c picture qp %d slices %d cur %d ref %d deblock %d expand %d mvrange %d complexity %d\n", did, is_p ? 'P' : 'I', job.iQp, nslices, job.iCurPic, job.iRefPic, job.bDeblock, job.bExpand, job.iMvRange, job.iComplexityMode);
   return ENC_RETURN_SUCCESS;
 }
@@ -522,7 +547,8 @@ int32_t HipCodeSlice (sWelsEncCtx* pCtx, SSlice* pSlice) {
   SWelsFuncPtrList* pFunc = pCtx->pFuncList;
   HipState* st = (HipState*)pFunc->pHipState;
   HipLayer& L = st->layer[pCtx->uiDependencyId];
-  if (st->failed || (L.records == NULL && !L.gom && !L.dyn)) return ENC_RETURN_UNEXPECTED;
+  if (st->failed || (L.records == NULL && L.packed == NULL && !L.gom && !L.dyn)) return ENC_RETURN_UNEXPECTED;
+  WhMbRecord sExpanded;              // (packed records: the macroblock in hand)
   Stopwatch sw_code (st->timing && pCtx->pSvcParam->iMultipleThreadIdc <= 1 ? &st->t_code : NULL);     // (slice tasks run concurrently: not summed)
   SDqLayer* pCurLayer = pCtx->pCurDqLayer;
   SMbCache* pMbCache = &pSlice->sMbCacheInfo;
@@ -568,12 +594,10 @@ int32_t HipCodeSlice (sWelsEncCtx* pCtx, SSlice* pSlice) {
       const void* rec = NULL;
       const int rc = g_api.FrameEncode (L.ctx, &L.job, &rec);
       if (rc) { fprintf (stderr, "welship hooks: WelsHipFrameEncode (MBs %d..%d) failed (%d: %s)\n", iCurMbIdx, end, rc, g_api.GetLastError()); st->failed = true; return ENC_RETURN_UNEXPECTED; }
-      L.records = (const WhMbRecord*)rec;
+      L.records = (const WhMbRecord*)rec; L.packed = NULL;
       L.coded_upto = end;
-      if (end == kiTotalNumMb) {       // the picture is complete (filtered, borders expanded): the host's copy of the reconstruction
-        uint8_t* dst[3] = { pCtx->pDecPic->pData[0], pCtx->pDecPic->pData[1], pCtx->pDecPic->pData[2] };
-        const int32_t ds[3] = { pCtx->pDecPic->iLineSize[0], pCtx->pDecPic->iLineSize[1], pCtx->pDecPic->iLineSize[2] };
-        if (g_api.FrameGetPicture (L.ctx, L.job.iCurPic, dst, ds)) { st->failed = true; return ENC_RETURN_UNEXPECTED; }
+      if (end == kiTotalNumMb) {       // the picture is complete (filtered, borders expanded)
+        if (st->eager_recon && !FetchRecon (st, pCtx, L, L.job.iCurPic)) return ENC_RETURN_UNEXPECTED;
         L.states.clear();
         if (pCtx->pSvcParam->iSpatialLayerNum > pCtx->uiDependencyId + 1) {
           L.states.resize (kiTotalNumMb);
@@ -590,7 +614,8 @@ int32_t HipCodeSlice (sWelsEncCtx* pCtx, SSlice* pSlice) {
     }
     bool bInitDone = false;
 TRY_REENCODING:
-    const WhMbRecord& R = L.records[iCurMbIdx];
+    if (L.packed != NULL) wh_compact_expand (L.packed->pData + L.packed->pOffset[iCurMbIdx], L.packed->pOffset[iCurMbIdx + 1] - L.packed->pOffset[iCurMbIdx], &sExpanded);
+    const WhMbRecord& R = L.packed != NULL ? sExpanded : L.records[iCurMbIdx];
     if (pCurMb->uiLumaQp != R.luma_qp) { fprintf (stderr, "welship hooks: QP mismatch at MB %d (%d vs %d)\n", iCurMbIdx, pCurMb->uiLumaQp, R.luma_qp); st->failed = true; return ENC_RETURN_UNEXPECTED; }
     // neighbour caches the entropy writer reads (non-zero counts): the reference's own init functions
     if (!bInitDone) {        // (not repeated for a re-encoded macroblock, as in the reference: the label comes after them)
@@ -655,7 +680,7 @@ TRY_REENCODING:
         const void* rec = NULL;
         const int rc = g_api.FrameEncode (L.ctx, &jb, &rec);
         if (rc) { fprintf (stderr, "welship hooks: WelsHipFrameEncode (re-encoding MB %d at QP %d) failed (%d: %s)\n", iCurMbIdx, pCurMb->uiLumaQp, rc, g_api.GetLastError()); st->failed = true; return ENC_RETURN_UNEXPECTED; }
-        L.records = (const WhMbRecord*)rec;
+        L.records = (const WhMbRecord*)rec; L.packed = NULL;
         if (st->trace) fprintf (stderr, "welship hooks: MB %d coded again at QP %d (%d re-encoded macroblocks in this picture)\n", iCurMbIdx, pCurMb->uiLumaQp, (int)list.size());
         goto TRY_REENCODING;
       }
@@ -664,10 +689,8 @@ TRY_REENCODING:
       const void* rec = NULL;
       const int rc = g_api.FrameEncode (L.ctx, &L.job, &rec);
       if (rc) { fprintf (stderr, "welship hooks: WelsHipFrameEncode (re-encoding MB %d at QP %d) failed (%d: %s)\n", iCurMbIdx, pCurMb->uiLumaQp, rc, g_api.GetLastError()); st->failed = true; return ENC_RETURN_UNEXPECTED; }
-      L.records = (const WhMbRecord*)rec;
-      uint8_t* dst[3] = { pCtx->pDecPic->pData[0], pCtx->pDecPic->pData[1], pCtx->pDecPic->pData[2] };
-      const int32_t ds[3] = { pCtx->pDecPic->iLineSize[0], pCtx->pDecPic->iLineSize[1], pCtx->pDecPic->iLineSize[2] };
-      if (g_api.FrameGetPicture (L.ctx, L.job.iCurPic, dst, ds)) { st->failed = true; return ENC_RETURN_UNEXPECTED; }
+      L.records = (const WhMbRecord*)rec; L.packed = NULL;
+      if (st->eager_recon && !FetchRecon (st, pCtx, L, L.job.iCurPic)) return ENC_RETURN_UNEXPECTED;
       if (!L.states.empty() && g_api.FrameGetMbStates (L.ctx, L.job.iCurPic, &L.states[0], sizeof (WhMbState) * kiTotalNumMb)) { st->failed = true; return ENC_RETURN_UNEXPECTED; }
       if (st->trace) fprintf (stderr, "welship hooks: MB %d coded again at QP %d (%d re-encoded macroblocks in this picture)\n", iCurMbIdx, pCurMb->uiLumaQp, (int)L.reencode.size());
       goto TRY_REENCODING;
@@ -723,9 +746,7 @@ TRY_REENCODING:
           const int rc = g_api.FrameEncode (L.ctx, &jb, &rec);
           if (rc) { fprintf (stderr, "welship hooks: WelsHipFrameEncode (closing the picture) failed (%d: %s)\n", rc, g_api.GetLastError()); st->failed = true; return ENC_RETURN_UNEXPECTED; }
           ++st->pictures;
-          uint8_t* dst[3] = { pCtx->pDecPic->pData[0], pCtx->pDecPic->pData[1], pCtx->pDecPic->pData[2] };
-          const int32_t ds[3] = { pCtx->pDecPic->iLineSize[0], pCtx->pDecPic->iLineSize[1], pCtx->pDecPic->iLineSize[2] };
-          if (g_api.FrameGetPicture (L.ctx, L.job.iCurPic, dst, ds)) { st->failed = true; return ENC_RETURN_UNEXPECTED; }
+          if (st->eager_recon && !FetchRecon (st, pCtx, L, L.job.iCurPic)) return ENC_RETURN_UNEXPECTED;
           if (st->trace) fprintf (stderr, "welship hooks: layer %d picture complete: %d slices, %d device calls, %ld macroblocks coded for %d\n", (int)pCtx->uiDependencyId, L.dyn_slices, L.dyn_calls, L.dyn_mbs_coded, kiTotalNumMb);
         }
       }
@@ -827,6 +848,7 @@ void WelsHipInstall (SWelsFuncPtrList* pFuncList, SWelsSvcCodingParam* pParam) {
   pFuncList->pfHipRelease = NULL;
   pFuncList->pfHipDownsample = NULL;
   pFuncList->pfHipVaaCalc = NULL;
+  pFuncList->pfHipFetchRecon = NULL;
   pFuncList->pHipState = NULL;
   const char* off = getenv ("WELS_HIP");
   if (off && atoi (off) == 0) return;
@@ -844,6 +866,10 @@ void WelsHipInstall (SWelsFuncPtrList* pFuncList, SWelsSvcCodingParam* pParam) {
   st->trace = getenv ("WELS_HIP_TRACE") != NULL;
   st->timing = st->trace && atoi (getenv ("WELS_HIP_TRACE")) >= 2;
   st->gom_kernel = (getenv ("WELS_HIP_GOM") == NULL || atoi (getenv ("WELS_HIP_GOM")) >= 2) && pParam->iEntropyCodingModeFlag == 0;
+  // (screen content: the reference's own pre-processing reads the reconstructed reference picture on the host -- the feature search's hash
+  //  lists, PerformFMEPreprocess, svc_motion_estimate.cpp:700-760 -- so such sessions get every picture back)
+  st->packed = !(getenv ("WELS_HIP_PACKED") != NULL && atoi (getenv ("WELS_HIP_PACKED")) == 0);
+  st->eager_recon = (getenv ("WELS_HIP_EAGER_RECON") != NULL && atoi (getenv ("WELS_HIP_EAGER_RECON")) != 0) || pParam->iUsageType == SCREEN_CONTENT_REAL_TIME;
   st->check_bits = getenv ("WELS_HIP_CHECK_BITS") != NULL && atoi (getenv ("WELS_HIP_CHECK_BITS")) != 0 && pParam->iEntropyCodingModeFlag == 0;
   st->layer_devices = getenv ("WELS_HIP_LAYER_DEVICES") != NULL && atoi (getenv ("WELS_HIP_LAYER_DEVICES")) != 0;
   st->downsample = !(getenv ("WELS_HIP_DOWNSAMPLE") != NULL && atoi (getenv ("WELS_HIP_DOWNSAMPLE")) == 0);
@@ -855,6 +881,7 @@ void WelsHipInstall (SWelsFuncPtrList* pFuncList, SWelsSvcCodingParam* pParam) {
   pFuncList->pfHipRelease = HipRelease;
   pFuncList->pfHipDownsample = HipDownsample;
   pFuncList->pfHipVaaCalc = HipVaaCalc;
+  pFuncList->pfHipFetchRecon = HipFetchRecon;
   if (st->trace) fprintf (stderr, "welship hooks: installed\n");
 }
 

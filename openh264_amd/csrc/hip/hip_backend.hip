@@ -120,9 +120,6 @@ WH_DEFINE_MB_KERNEL (k_intra_slice, WhMbLds, wh_intra_mb_body, 1024, 0, 1)
 // done bits in LDS, data through the workgroup-coherent L1/L2.
 #define WH_MD_MAX_SLOTS 4
 template <class F> struct WhEarlyFn { F& f; __device__ __forceinline__ void call() { f(); } };      // (the run scheduler's callback from the macroblock body)
-#ifndef WH_SPEC_WINDOWS
-#define WH_SPEC_WINDOWS 1          /* fetch a macroblock's search windows with its cold inputs, around the slice's last vector */
-#endif
 // PLAIN: see inter_mb.h wh_inter_cold_fetch.  The variant has a third fewer instructions (no background-detection, inter-layer, bit-counting,
 // rate-control or QP-map code) and codes a session group's pictures 7.4 % faster (MD launch 13.70 -> 12.69 ms, same box:
 // profiles/r03_p_kernel_candidates_ab.txt); 0 = every launch takes the general kernel.
@@ -131,10 +128,12 @@ template <class F> struct WhEarlyFn { F& f; __device__ __forceinline__ void call
 #endif
 // 2 (the default since round 4: MD launch 10.76 -> 10.45 ms in a same-box A/B, profiles/r04_ab_claim_path_plain2_chroma.txt): additionally a
 // variant that knows LOW complexity -- the reference's default -- at compile time (no SATD paths in the search, the refinement and the intra test);
-// groups of another complexity take variant 1.  WH_FRAME_KERNEL=1, candidate: a variant for the frame API's camera pictures without
-// control inputs (WH_SEQ_NO_CTRL)
+// groups of another complexity take variant 1.  WH_FRAME_KERNEL=1 (the default since round 4): a variant for the frame API's camera pictures
+// without control inputs (WH_SEQ_NO_CTRL, promised per launch by the host's frame_run_batch) -- what a session through the dispatch-table binding
+// launches unless it has GOM-level rate control, size-limited slices, a QP map or inter-layer hints: one 1080p session 51.5 -> 63.1 frames/s
+// (the reference's C path: 61.5; profiles/r04_config5_frame_kernel_ab.txt)
 #ifndef WH_FRAME_KERNEL
-#define WH_FRAME_KERNEL 0
+#define WH_FRAME_KERNEL 1
 #endif
 // The claim path (a free wave takes its next macroblock) is pure overhead and was a chain of a dozen dependent LDS / memory round
 // trips (profiles/r04_p1080p_s256_phase_cycles_v1.txt: 6.6 k of a macroblock's 50 k cycles).  What it needs is therefore kept where a
@@ -230,7 +229,7 @@ __global__ __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPi
     nslot = best; nxy = xy_;                                                                                                   \
     break;                                                                                                                     \
   }
-  const bool speculate = WH_SPEC_WINDOWS != 0;
+  const bool speculate = true;            // (a macroblock's search windows are fetched with its cold inputs, around the slice's last vector)
   // the next macroblock's cold inputs and speculative windows: in flight while the wave waits for the neighbours.  `Jf`: the fields of
   // the slot's job descriptor this reads, taken out of LDS together
 #define WH_FETCH_AHEAD()                                                                                                       \
@@ -396,11 +395,7 @@ __global__ __launch_bounds__ (MAXT) void k_inter_rows (WhSeqParams P, const WhPi
     const int guess = slot_mv[nslot];
     const int gx = wh_clip3 ((2 + (int) (int16_t) (guess & 0xffff)) >> 2, -P.mv_range, P.mv_range), gy = wh_clip3 ((2 + (guess >> 16)) >> 2, -P.mv_range, P.mv_range);
     wh_win_place (P, N, nx * 16 + gx, ny * 16 + gy);
-#if defined(WH_NO_SLIDE)           /* experiment: the run scheduler without sliding (every macroblock fetches whole windows) */
-    const bool same = false;
-#else
     const bool same = had && nslot == slot && ny == y;
-#endif
     SL.on_y = same && wh_win_can_slide_y (X.spec, N);
     SL.on_c = same && wh_win_can_slide_c (X.spec, N);
     if (SL.on_y | SL.on_c) wh_win_slide_begin (P, Jn, N, SL);
@@ -410,11 +405,7 @@ __global__ __launch_bounds__ (MAXT) void k_inter_rows (WhSeqParams P, const WhPi
     X.spec = N;
     X.spec_valid = 1;
   };
-#if defined(WH_SLIDE_AT_TOP)      /* experiment: the next macroblock's fetch after the current one is complete (as the ticket scheduler does) */
-  WhNoEarly early;
-#else
   WhEarlyFn<decltype (early_fn)> early = { early_fn };
-#endif
   early_fn();
   int pslot = -1, pxy = -1;                      // the macroblock this wave coded last
   while (nslot >= 0) {
@@ -443,9 +434,6 @@ __global__ __launch_bounds__ (MAXT) void k_inter_rows (WhSeqParams P, const WhPi
     const uint32_t dc = ((uint32_t)__builtin_readcyclecounter() - tc0) >> 6;
     c0 += slot == 0 ? dc : 0u; c1 += slot == 1 ? dc : 0u; c2 += slot == 2 ? dc : 0u; c3 += slot == 3 ? dc : 0u;
     pslot = slot; pxy = xy;
-#if defined(WH_SLIDE_AT_TOP)
-    early_fn();
-#endif
   }
   if (slice_cost && lane == 0) {
     if (slot_id[0] >= 0 && c0) atomicAdd (&slice_cost[slot_id[0]], c0);
@@ -610,6 +598,7 @@ __global__ __launch_bounds__ (1024) void k_compact (WhSeqParams P, const WhPicJo
   __shared__ uint32_t s_mask[WH_CP_MAX_MB];
   __shared__ uint32_t s_part[1024];
   const WhPicJob J = jobs[blockIdx.x];
+  if (!J.compact || !J.compact_off) return;        // (a picture of the batch whose caller takes the full records: uniform for the workgroup)
   const int num_mb = P.mb_w * P.mb_h, lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6, nw = (int)blockDim.x >> 6;
   const WH_G WhMbRecord* recs = (const WH_G WhMbRecord*)J.records;
   for (int xy = wave; xy < num_mb; xy += nw) {
@@ -741,14 +730,7 @@ class HipBackend : public wh::Backend {
     // must overlap accordingly (csrc/host/encoder.cpp: frame_find_key; compute / upload / download of a pipelined group: 0 / 1 / 2).
     for (int k = 0; k < 4; ++k) HIP_TRY (hipStreamCreateWithFlags (&pad_streams_[k], hipStreamNonBlocking));
     streams_.assign (WH_NUM_QUEUES, nullptr);
-    // WELSHIP_STREAM_PRIO=1 (experiment knob): the last two queues with the highest priority
-    const bool prio = getenv ("WELSHIP_STREAM_PRIO") && atoi (getenv ("WELSHIP_STREAM_PRIO")) != 0;
-    int plo = 0, phi = 0;
-    if (prio) HIP_TRY (hipDeviceGetStreamPriorityRange (&plo, &phi));
-    for (int k = 0; k < WH_NUM_QUEUES; ++k) {
-      if (prio && k >= WH_NUM_QUEUES - 2) HIP_TRY (hipStreamCreateWithPriority (&streams_[k], hipStreamNonBlocking, phi));
-      else HIP_TRY (hipStreamCreateWithFlags (&streams_[k], hipStreamNonBlocking));
-    }
+    for (int k = 0; k < WH_NUM_QUEUES; ++k) HIP_TRY (hipStreamCreateWithFlags (&streams_[k], hipStreamNonBlocking));      // (stream priorities were tried: no effect beyond the queue choice)
     stream_ = streams_[0]; cur_ = 0;
     HIP_TRY (hipMalloc ((void**)&err_, 4 * WH_ERR_WORDS * WH_NUM_QUEUES));
     if (err_) HIP_TRY (hipMemset (err_, 0, 4 * WH_ERR_WORDS * WH_NUM_QUEUES));

@@ -1713,6 +1713,14 @@ struct WelsHipFrameCtx {
   std::vector<uint8_t> h_src;
   WhMbRecord* d_records = nullptr;
   std::vector<WhMbRecord> h_records;
+  // packed records of whole-picture calls (WelsHipFrameJob::bPackedRecords; common/compact.h): device stream + offsets, page-locked host copies.
+  // The host copy is brought back in one go up to `compact_est` bytes (a little more than the previous picture's size); the rare rest follows.
+  uint8_t* d_compact = nullptr;
+  uint32_t* d_compact_off = nullptr;
+  std::vector<uint8_t> h_compact;
+  std::vector<uint32_t> h_coff;
+  size_t compact_est = 0, compact_got = 0;
+  WelsHipPackedRecords packed_view = {nullptr, nullptr};
   std::vector<uint8_t> h_pic;
   // page-locked staging for the small per-picture arrays of the caller (pageable copies block on the queue: with the shared
   // lock held that stalls every other session): VAA SADs | pSadCost in | inter-layer hints | background flags, and pSadCost out
@@ -1766,6 +1774,11 @@ struct WelsHipFrameCtx {
     src_pool.clear();
     d_src = nullptr;
     if (!h_vaa_out.empty()) be->unpin_host (h_vaa_out.data());
+    if (!h_compact.empty()) be->unpin_host (h_compact.data());
+    if (!h_coff.empty()) be->unpin_host (h_coff.data());
+    if (d_compact) be->free (d_compact);
+    if (d_compact_off) be->free (d_compact_off);
+    d_compact = nullptr; d_compact_off = nullptr;
     void* ptrs[] = {d_vaa_out, d_src_planar, d_records, d_dbflags, d_mb_ctl, d_sad_cost0, d_vaa, d_bgd, d_il, d_job, d_scc, d_scc_idc, d_scc_ori, d_scc_chain, d_scc_lists, d_scc_loc, d_scc_order, d_scc_chain_mb, d_gom_rc, d_sad_cost0_new};
     if (!h_gom.empty()) be->unpin_host (h_gom.data());
     if (!h_scc.empty()) be->unpin_host (h_scc.data());
@@ -1838,6 +1851,7 @@ namespace {
 
 struct FrameItem {             // one submitted picture, owned by the submitting thread's stack frame
   WelsHipFrameCtx* c = nullptr;
+  bool packed = false;                    // the records come back packed (WelsHipFrameJob::bPackedRecords)
   WhSeqParams seq;
   WhPicJob job;
   bool is_p = false, qp_map = false, expand = false;
@@ -1865,7 +1879,13 @@ void frame_run_batch (FrameShared* sh, FrameKey* K, FrameLane* L, std::unique_lo
   }
   int rc_all = L->d_jobs ? WELSHIP_OK : WELSHIP_ERR_MEMORY;
   if (rc_all == WELSHIP_OK) {
-    for (int i = 0; i < n; ++i) L->h_jobs[i] = batch[i]->job;
+    bool any_packed = false;
+    for (int i = 0; i < n; ++i) {
+      L->h_jobs[i] = batch[i]->job;
+      L->h_jobs[i].compact = batch[i]->packed ? batch[i]->c->d_compact : nullptr;
+      L->h_jobs[i].compact_off = batch[i]->packed ? batch[i]->c->d_compact_off : nullptr;
+      any_packed = any_packed || batch[i]->packed;
+    }
     be->upload (L->d_jobs, L->h_jobs.data(), sizeof (WhPicJob) * n);
     const WhSeqParams& s = K->seq;
     if (K->is_p) {
@@ -1883,10 +1903,17 @@ void frame_run_batch (FrameShared* sh, FrameKey* K, FrameLane* L, std::unique_lo
     if (K->qp_map) be->run_qp_chain (s, L->d_jobs, n);
     if (s.deblock_idc != 1) be->run_deblock (s, L->d_jobs, n);
     if (K->expand) be->run_expand (s, L->d_jobs, n);
+    if (any_packed) be->run_compact (s, L->d_jobs, n);      // (pictures without a packed stream are left alone: WhPicJob::compact == NULL)
     for (FrameItem* x : batch) {
       WelsHipFrameCtx* c = x->c;
+      if (x->packed) {
+        c->compact_got = std::min (c->compact_est, c->h_compact.size());
+        be->download (c->h_coff.data(), c->d_compact_off, sizeof (uint32_t) * (c->num_mb + 1));
+        be->download (c->h_compact.data(), c->d_compact, c->compact_got);
+      } else
       be->download (c->h_records.data(), c->d_records, sizeof (WhMbRecord) * c->num_mb);
-      be->download (c->h_pic.data(), c->pics[x->cur_pic].base, c->rec_alloc_bytes + 128);
+      // (the reconstruction stays on the device: WelsHipFrameGetPicture fetches it when the caller asks -- PSNR, a frame dump; the
+      //  dispatch-table binding's pfHipFetchRecon)
       if (x->sad_dst) be->download (c->h_sad_out.data(), x->job.sad_cost0_out ? x->job.sad_cost0_out : x->job.sad_cost0, sizeof (int32_t) * c->num_mb);
       if (c->scc_active) be->download (c->scc_down(), c->d_scc_chain + 4 * WH_MAX_SLICES, sizeof (uint32_t) * WH_MAX_SLICES);
     }
@@ -1899,6 +1926,21 @@ void frame_run_batch (FrameShared* sh, FrameKey* K, FrameLane* L, std::unique_lo
     if (be->errors_swept() != swept0) bad = 1;       // another thread's sync() found time-outs meanwhile: possibly this launch set's
     const double dev_ms = std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now() - t_dev0).count();
     lock.lock();
+    // a packed stream longer than what was brought back with the batch (a picture much larger than the one before it): the rest now
+    if (!bad && any_packed) {
+      bool more = false;
+      for (FrameItem* x : batch) if (x->packed) {
+        WelsHipFrameCtx* c = x->c;
+        const size_t total = c->h_coff[c->num_mb];
+        if (total > c->h_compact.size()) { bad = 1; continue; }                  // (cannot be: the buffer holds the worst case)
+        if (total > c->compact_got) {
+          if (!more) { be->select_queue (q); more = true; }
+          be->download (c->h_compact.data() + c->compact_got, c->d_compact + c->compact_got, total - c->compact_got);
+        }
+        c->compact_est = std::min (c->h_compact.size(), ((total + total / 4 + 4095) & ~ (size_t)4095) + 65536);
+      }
+      if (more) { lock.unlock(); if (be->sync_queue (q)) bad = 1; lock.lock(); }
+    }
     if ((int)sh->stat_n.size() <= n) { sh->stat_n.resize (n + 1, 0); sh->stat_dev_ms.resize (n + 1, 0.0); sh->stat_gather_ms.resize (n + 1, 0.0); sh->stat_launch_ms.resize (n + 1, 0.0); }
     ++sh->stat_n[n]; sh->stat_dev_ms[n] += dev_ms; sh->stat_launch_ms[n] += launch_ms;
     if (bad) rc_all = WELSHIP_ERR_UNKNOWN;
@@ -1906,7 +1948,7 @@ void frame_run_batch (FrameShared* sh, FrameKey* K, FrameLane* L, std::unique_lo
   }
   for (FrameItem* it : batch) {
     it->rc = rc_all;
-    if (rc_all == WELSHIP_OK) { it->c->pics[it->cur_pic].is_p = it->is_p; it->c->h_pic_of = it->cur_pic; }
+    if (rc_all == WELSHIP_OK) { it->c->pics[it->cur_pic].is_p = it->is_p; it->c->h_pic_of = -1; }
     it->done = true;
   }
 }
@@ -2402,6 +2444,21 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
   FrameItem item;
   item.c = c; item.seq = s; item.job = job; item.is_p = is_p; item.qp_map = qp_map; item.expand = j->bExpand != 0;
   item.cur_pic = j->iCurPic; item.sad_dst = j->pSadCost;
+  // packed records on request (pictures larger than the packer's workgroup handles keep the full records, as does WELSHIP_COMPACT=0)
+  static const bool compact_off_env = getenv ("WELSHIP_COMPACT") && atoi (getenv ("WELSHIP_COMPACT")) == 0;
+  if (j->bPackedRecords && c->num_mb <= 9216 && !compact_off_env) {
+    if (!c->d_compact) {
+      c->d_compact = (uint8_t*)be->alloc ((size_t)c->num_mb * WH_COMPACT_MAX_BYTES);
+      c->d_compact_off = (uint32_t*)be->alloc (sizeof (uint32_t) * ((size_t)c->num_mb + 1));
+      if (!c->d_compact || !c->d_compact_off) { set_err ("out of device memory"); return WELSHIP_ERR_MEMORY; }
+      c->h_compact.resize ((size_t)c->num_mb * WH_COMPACT_MAX_BYTES);
+      c->h_coff.resize ((size_t)c->num_mb + 1);
+      be->pin_host (c->h_compact.data(), c->h_compact.size());
+      be->pin_host (c->h_coff.data(), sizeof (uint32_t) * c->h_coff.size());
+      c->compact_est = c->h_compact.size() / 4;
+    }
+    item.packed = true;
+  }
   c->last_key = K;
   c->last_submit = std::chrono::steady_clock::now();
   sh->stat_submit_ms += std::chrono::duration<double, std::milli> (c->last_submit - t_sub0).count();
@@ -2444,7 +2501,10 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
   lock.unlock();
   if (j->pSadCost) memcpy (j->pSadCost, c->h_sad_out.data(), sizeof (int32_t) * c->num_mb);
   if (scr && scr->pSliceFMECostDown) memcpy (scr->pSliceFMECostDown, c->scc_down(), sizeof (uint32_t) * j->iNumSlices);
-  *pp_records = c->h_records.data();
+  if (item.packed) {
+    c->packed_view.pData = c->h_compact.data(); c->packed_view.pOffset = c->h_coff.data();
+    *pp_records = &c->packed_view;
+  } else *pp_records = c->h_records.data();
   return WELSHIP_OK;
 }
 

@@ -197,17 +197,12 @@ WH_FN void wh_win_load_luma (WhInterLds& S, const WhSeqParams& P, const WhPicJob
 // first load of a macroblock: luma + both chroma windows in one batch (issue only)
 WH_FN void wh_win_issue_all (const WhSeqParams& P, const WhPicJob& J, WhWin& W, int cx, int cy) {
   wh_win_place (P, W, cx, cy);
-#if defined(WH_NO_CWIN)          /* experiment: no chroma windows -- chroma prediction reads the picture (traffic A/B) */
-  W.cx0 = -100000; W.cy0 = -100000;
-#endif
   WV_LANES_BEGIN (lane)
   {
 #pragma unroll
     for (int k = 0; k < WH_WIN_LOADS; ++k) if (64 * k + lane < WH_WIN_PIECES) wh_ld_async16 (wh_win_src_luma (64 * k + lane, P, J, W), &W.b->win[1024 * k], lane);
-#if !defined(WH_NO_CWIN)
 #pragma unroll
     for (int k = 0; k < WH_CWIN_PIECES / 64; ++k) wh_ld_async16 (wh_win_src_chroma (64 * k + lane, P, J, W), &W.b->cwin[1024 * k], lane);
-#endif
   }
   WV_LANES_END
 }
@@ -1066,19 +1061,11 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const int i = lane + 64 * k, n = i / 36, wd = i - n * 36;           // state n (0 TL, 1 T, 2 TR, 3 L), dword wd
-#if WH_FLAT_NB_LOADS
       // unconditional loads (this MB's own state stands in where there is nothing to read), selects afterwards: see wh_tile_fetch_nb
       const bool ok = i < 144 && (n == 0 ? (avail & WH_AV_TOPLEFT) != 0 : n == 1 ? (avail & WH_AV_TOP) != 0 : n == 2 ? (avail & WH_AV_TOPRIGHT) != 0 : (avail & WH_AV_LEFT) != 0);
       const int off = n == 0 ? -w - 1 : n == 1 ? -w : n == 2 ? -w + 1 : -1;
       const uint32_t v = ((const WH_G uint32_t*) ((const WH_G WhMbState*)J.mbs + xy + (ok ? off : 0)))[ok ? wd : 0];
       st[k] = ok ? v : 0u;
-#else
-      if (i < 144) {
-        const bool ok = n == 0 ? (avail & WH_AV_TOPLEFT) != 0 : n == 1 ? (avail & WH_AV_TOP) != 0 : n == 2 ? (avail & WH_AV_TOPRIGHT) != 0 : (avail & WH_AV_LEFT) != 0;
-        const int off = n == 0 ? -w - 1 : n == 1 ? -w : n == 2 ? -w + 1 : -1;
-        if (ok) st[k] = ((const WH_G uint32_t*) ((const WH_G WhMbState*)J.mbs + xy + off))[wd];
-      }
-#endif
     }
     WH_PROF_SUB (P, M, 3);       /* detail: neighbour loads issued */
     tr.y = G.cold_y[lane]; tr.c = lane < 32 ? G.cold_c[lane] : 0u;

@@ -51,10 +51,7 @@ WH_FN void wh_tile_fetch_src (int lane, const WhSeqParams& P, const WhPicJob& J,
   if (lane < 32) r->c = * (const WH_G uint32_t*) ((const WH_G uint8_t*)J.src[0] + WH_SRC_C_OFF (P.mb_w, mbx, mby, 0, 0, 0) + lane * 4);
 }
 // reconstructed neighbour samples (written by the neighbour MBs: only after they are done)
-#ifndef WH_FLAT_NB_LOADS
-#define WH_FLAT_NB_LOADS 1         /* the neighbour loads of a macroblock as ONE batch (measured on the MI355X, round 3: MD launch 13.65 -> 13.18 ms; 0 = one load per role) */
-#endif
-#if WH_FLAT_NB_LOADS
+// (the neighbour loads of a macroblock as ONE batch: measured on the MI355X in round 3, MD launch 13.65 -> 13.18 ms against one load per role)
 // One 32-bit load per lane whatever its role, at an address that is valid for every lane, and a select afterwards.  With one
 // load per role inside `if / else if` the compiler merges the results through a phi and waits for each load at the end of its
 // branch: the macroblock then pays one L2 round trip per role (three to four in a row) instead of one.  The column lanes read
@@ -74,25 +71,6 @@ WH_FN void wh_tile_fetch_nb_planes (int lane, const WhSeqParams& P, const WH_G u
 WH_FN void wh_tile_fetch_nb (int lane, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, WhTileRegs* r) {
   wh_tile_fetch_nb_planes (lane, P, (const WH_G uint8_t*)J.rec[0], (const WH_G uint8_t*)J.rec[1], (const WH_G uint8_t*)J.rec[2], mbx, mby, r);
 }
-#else
-WH_FN void wh_tile_fetch_nb (int lane, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, WhTileRegs* r) {
-  r->nb = 0;
-  // garbage where unavailable -- never consumed then
-  if (lane < 7) {                        // luma row -1, x = -4 .. 23 in 4-byte words
-    const int x = lane * 4 - 4;
-    r->nb = * (const WH_G uint32_t*) ((const WH_G uint8_t*)J.rec[0] + (ptrdiff_t) (mby * 16 - 1) * P.rec_stride_y + mbx * 16 + x);
-  } else if (lane >= 16 && lane < 32) {  // luma column -1
-    const int y = lane - 16;
-    r->nb = ((const WH_G uint8_t*)J.rec[0])[(ptrdiff_t) (mby * 16 + y) * P.rec_stride_y + mbx * 16 - 1];
-  } else if (lane >= 32 && lane < 38) {  // chroma rows -1: 3 words per plane, x = -4..7
-    const int pl = (lane - 32) / 3, x = ((lane - 32) % 3) * 4 - 4;
-    r->nb = * (const WH_G uint32_t*) ((const WH_G uint8_t*) (pl ? J.rec[2] : J.rec[1]) + (ptrdiff_t) (mby * 8 - 1) * P.rec_stride_c + mbx * 8 + x);
-  } else if (lane >= 48) {               // chroma columns -1
-    const int pl = (lane - 48) >> 3, y = lane & 7;
-    r->nb = ((const WH_G uint8_t*) (pl ? J.rec[2] : J.rec[1]))[(ptrdiff_t) (mby * 8 + y) * P.rec_stride_c + mbx * 8 - 1];
-  }
-}
-#endif
 WH_FN void wh_tile_fetch (int lane, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, WhTileRegs* r) {
   wh_tile_fetch_src (lane, P, J, mbx, mby, r);
   wh_tile_fetch_nb (lane, P, J, mbx, mby, r);
@@ -393,7 +371,6 @@ WH_FN bool wh_intra_md_enc_p (WhMbLds& S, const WhSeqParams& P, const WhPicJob& 
     i4t = 0; dsc = 0;
 #endif
     WV_LSET_IF (dsc, lane, lane < 36, (int)kWhI4Desc[lane]);
-#if WH_FLAT_NB_LOADS
     WV_LSET_IF (i4t, lane, lane < 25, ([&] () {
       // type + the mode word of the state a lane needs in one batch (a state that exists for every lane: its own MB's when it has
       // no neighbour to ask), the selects afterwards -- see wh_tile_fetch_nb
@@ -407,27 +384,6 @@ WH_FN bool wh_intra_md_enc_p (WhMbLds& S, const WhSeqParams& P, const WhPicJob& 
       S.i4m[lane] = v;
       return (int)v; }) ());
     WV_SYNC();
-#else
-    WV_LANES_BEGIN (lane)
-    if (lane < 25) {
-      const int cx = lane % 5, cy = lane / 5;
-      int8_t m = -1;
-      if (cy == 0 && cx > 0) {
-        if (has_t) {
-          const WH_G WhMbState* n = (const WH_G WhMbState*)J.mbs + (mby - 1) * P.mb_w + mbx;
-          m = (n->mb_type == WH_MB_I4x4) ? n->i4_mode[12 + cx - 1] : (int8_t)2;
-        }
-      } else if (cx == 0 && cy > 0) {
-        if (has_l) {
-          const WH_G WhMbState* n = (const WH_G WhMbState*)J.mbs + mby * P.mb_w + mbx - 1;
-          m = (n->mb_type == WH_MB_I4x4) ? n->i4_mode[(cy - 1) * 4 + 3] : (int8_t)2;
-        }
-      }
-      S.i4m[lane] = m;
-    }
-    WV_LANES_END
-    WV_LSET_IF (i4t, lane, lane < 25, (int)S.i4m[lane]);
-#endif
     const int lam4 = lambda << 2;
     int cost4 = 0;
     uint16_t prev_flags = 0;

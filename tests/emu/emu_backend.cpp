@@ -136,7 +136,7 @@ class EmuBackend : public Backend {
 #define WH_PLAIN_KERNEL 2
 #endif
 #ifndef WH_FRAME_KERNEL
-#define WH_FRAME_KERNEL 0
+#define WH_FRAME_KERNEL 1
 #endif
     const bool plain = WH_PLAIN_KERNEL && (Pin.flags & WH_SEQ_PLAIN) != 0, no_ctrl = WH_FRAME_KERNEL && (Pin.flags & WH_SEQ_NO_CTRL) != 0;
     WhSeqParams Pm = Pin;
@@ -262,6 +262,7 @@ class EmuBackend : public Backend {
   }
   void run_compact (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
     for (int j = 0; j < n; ++j) {
+      if (!jobs[j].compact || !jobs[j].compact_off) continue;
       uint32_t off = 0;
       for (int xy = 0; xy < P.mb_w * P.mb_h; ++xy) { jobs[j].compact_off[xy] = off; off += wh_compact_pack (&jobs[j].records[xy], jobs[j].compact + off); }
       jobs[j].compact_off[P.mb_w * P.mb_h] = off;
