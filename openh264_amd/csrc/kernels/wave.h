@@ -139,12 +139,18 @@ WH_FN int wh_lane_id() { int l = (int)(threadIdx.x & 63); asm volatile ("" : "+v
 // 64-lane reductions on the DPP network (no LDS traffic): quad -> half row -> row, then the four row results are
 // combined on the scalar unit.  Results are wave-uniform (SGPR).
 #define WH_DPP(v, ctrl) __builtin_amdgcn_update_dpp (0, (v), (ctrl), 0xF, 0xF, true)
+// The four row sums are combined on the DPP network too (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3: gfx9's
+// whole-wave reduction), so the total is ONE v_readlane of lane 63 instead of four reads and three scalar additions -- a macroblock
+// makes some eighty of these reductions.
+#define WH_DPP_ROWS(v, ctrl, rows) __builtin_amdgcn_update_dpp (0, (v), (ctrl), (rows), 0xF, false)
 WH_FN int wh_wave_sum_i32 (int v) {
   v += WH_DPP (v, 0xB1);     // quad_perm [1,0,3,2]
   v += WH_DPP (v, 0x4E);     // quad_perm [2,3,0,1]
   v += WH_DPP (v, 0x141);    // row_half_mirror
   v += WH_DPP (v, 0x140);    // row_mirror
-  return __builtin_amdgcn_readlane (v, 0) + __builtin_amdgcn_readlane (v, 16) + __builtin_amdgcn_readlane (v, 32) + __builtin_amdgcn_readlane (v, 48);
+  v += WH_DPP_ROWS (v, 0x142, 0xA);   // row_bcast:15 -> rows 1, 3
+  v += WH_DPP_ROWS (v, 0x143, 0xC);   // row_bcast:31 -> rows 2, 3
+  return __builtin_amdgcn_readlane (v, 63);
 }
 WH_FN int wh_wave_min_i32 (int v) {
   int o;
@@ -171,8 +177,8 @@ WH_FN int wh_wave_min_i32 (int v) {
   do { const int lane = wh_lane_id(); int _va = (int)(expr_a), _vb = (int)(expr_b); \
        _va += WH_DPP (_va, 0xB1); _vb += WH_DPP (_vb, 0xB1); _va += WH_DPP (_va, 0x4E); _vb += WH_DPP (_vb, 0x4E); \
        _va += WH_DPP (_va, 0x141); _vb += WH_DPP (_vb, 0x141); _va += WH_DPP (_va, 0x140); _vb += WH_DPP (_vb, 0x140); \
-       (dst_a) = __builtin_amdgcn_readlane (_va, 0) + __builtin_amdgcn_readlane (_va, 16) + __builtin_amdgcn_readlane (_va, 32) + __builtin_amdgcn_readlane (_va, 48); \
-       (dst_b) = __builtin_amdgcn_readlane (_vb, 0) + __builtin_amdgcn_readlane (_vb, 16) + __builtin_amdgcn_readlane (_vb, 32) + __builtin_amdgcn_readlane (_vb, 48); } while (0)
+       _va += WH_DPP_ROWS (_va, 0x142, 0xA); _vb += WH_DPP_ROWS (_vb, 0x142, 0xA); _va += WH_DPP_ROWS (_va, 0x143, 0xC); _vb += WH_DPP_ROWS (_vb, 0x143, 0xC); \
+       (dst_a) = __builtin_amdgcn_readlane (_va, 63); (dst_b) = __builtin_amdgcn_readlane (_vb, 63); } while (0)
 #define WV_QUADSUM_TAB(tab, lane, expr)                           \
   do { const int lane = wh_lane_id(); int _v = (int)(expr);       \
        _v += WH_DPP (_v, 0xB1); _v += WH_DPP (_v, 0x4E); (tab) = _v; } while (0)
