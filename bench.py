@@ -551,7 +551,7 @@ def main():
             if clip is not None:
                 w2, h2 = 1280, 720
                 c3 = Content(clip[: w2 * h2 * 3 // 2 * 16], w2 * h2 * 3 // 2, 2, True)
-                st, ns = 20, 256
+                st, ns = 12, 512        # (two single-slice pictures per CU: the intra kernel then runs two 12-wave workgroups on each)
                 d3, ev3, ver3 = hot_path_leg(oh, a, local, w2, h2, "intra", ns, 2, c3, st, 2, None, (0,) if verify_sessions else ())
                 r3 = roofline("intra", ((w2 + 15) // 16) * ((h2 + 15) // 16), ns, st, ev3)
                 line["intra_720p"] = {"data": "res/VID_1280x720_cavlc_temporal_direct.264 decoded (BASELINE config 2's stand-in clip)", "value": ns * st / d3, "unit": "frames/s",

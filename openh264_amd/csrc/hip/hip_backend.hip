@@ -185,8 +185,11 @@ __global__ __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPi
   X.last_mv = nullptr;
   uint32_t gone = 0;                      // slots this wave knows to be out of tickets (wave-uniform)
   uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;     // cycles / 64 this wave spent on each slot's macroblocks
-  int slot = -1, xy = 0;                  // the macroblock in hand
-  int nslot = -1, nxy = 0;                // the wave's next one
+  int slot = -1, xy = 0, mbx = 0, mby = 0;        // the macroblock in hand
+  int nslot = -1, nxy = 0, nmbx = 0, nmby = 0;    // the wave's next one
+  // macroblock address -> (x, y) by a multiplication: ceil (2^32 / mb_w) is exact for addresses below 2^20 and widths below 2^12 (the
+  // generic division by a run-time value is a fourteen-instruction fix-up sequence, three times per macroblock)
+  const uint32_t w_rcp = P.mb_w > 1 ? 0xffffffffu / (uint32_t)P.mb_w + 1u : 0u;       // (a picture one macroblock wide: 2^32 does not fit -- y is the address itself)
   // order windows: ow<k> lane i = entry ob<k> + i of slot k's processing order (tickets); ob<k> = a ticket no claim can be near: empty
   int ow0 = 0, ow1 = 0, ow2 = 0, ow3 = 0;
   int ob0 = -0x40000000, ob1 = -0x40000000, ob2 = -0x40000000, ob3 = -0x40000000;
@@ -227,6 +230,7 @@ __global__ __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPi
       if (xy_ >= mb_end_) continue;                                                                                            \
     }                                                                                                                          \
     nslot = best; nxy = xy_;                                                                                                   \
+    nmby = P.mb_w > 1 ? (int)__umulhi ((uint32_t)xy_, w_rcp) : xy_; nmbx = xy_ - nmby * P.mb_w;                                \
     break;                                                                                                                     \
   }
   const bool speculate = true;            // (a macroblock's search windows are fetched with its cold inputs, around the slice's last vector)
@@ -243,22 +247,22 @@ __global__ __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPi
       if (CTRL) { Jf.sad_cost0_out = Jn.sad_cost0_out; Jf.dyn_redo = Jn.dyn_redo; Jf.mb_begin = Jn.mb_begin; }                 \
     }                                                                                                                          \
     const int guess_ = slot_mv[nslot];                                                                                         \
-    wh_inter_cold_fetch<VAR> (G, lane, P, Jf, nxy % P.mb_w, nxy / P.mb_w);                                                     \
+    wh_inter_cold_fetch<VAR> (G, lane, P, Jf, nmbx, nmby);                                                                     \
     WH_PROF_SUB (P, S.m, 2);         /* detail: cold inputs issued */                                                          \
     X.spec_valid = 0;                                                                                                          \
-    if (speculate) { wh_win_speculate (P, Jf, X.spec, nxy % P.mb_w, nxy / P.mb_w, guess_); X.spec_valid = 1; }                  \
+    if (speculate) { wh_win_speculate (P, Jf, X.spec, nmbx, nmby, guess_); X.spec_valid = 1; }                                  \
   }
   WhNoEarly early;                        // (claiming the next macroblock when the body's prediction is final, before residual coding, was measured: no gain)
   WH_CLAIM()
   WH_FETCH_AHEAD()
-  slot = nslot; xy = nxy;
+  slot = nslot; xy = nxy; mbx = nmbx; mby = nmby;
   while (slot >= 0) {
     const WhPicJob& J = Jl[slot];
     const int first = __builtin_amdgcn_readlane (tab_first, slot);
     uint32_t* sc = sched + slot * sched_words;
     WH_PROF_MARK (P, S.m, 11);
-    int dep_a, dep_b;
-    wh_mb_deps (P.mb_w, xy, first, &dep_a, &dep_b);
+    int dep_a = (mbx > 0 && xy - 1 >= first) ? xy - 1 : -1, dep_b;         // (common/mb_order.h wh_mb_deps, with the column already known)
+    { const int tr = mbx < P.mb_w - 1 ? xy - P.mb_w + 1 : xy - P.mb_w; dep_b = tr >= first ? tr : -1; }
     if (SCC && (P.flags & WH_SEQ_SERIAL)) { dep_a = xy > first ? xy - 1 : -1; dep_b = -1; }      // the macroblock before it in coding order (WhSccJob::chain)
     if (!wh_wait_done (sc + 1, dep_a < 0 ? -1 : dep_a - first, err)) break;
     if (!wh_wait_done (sc + 1, dep_b < 0 ? -1 : dep_b - first, err)) break;
@@ -272,7 +276,7 @@ __global__ __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPi
     WV_ASYNC_WAIT();                      /* this MB's cold inputs have landed in the staging area */
     const bool dyn_ = CTRL && J.dyn_slice;
     X.slice_idc = dyn_ ? J.dyn_slice - 1 : __builtin_amdgcn_readlane (tab_idc, slot); X.slice_first = dyn_ ? J.dyn_first : first; X.last_mv = &slot_mv[slot];
-    wh_inter_mb_body_t<SCC, VAR> (S, G, P, J, xy % P.mb_w, xy / P.mb_w, X, early);
+    wh_inter_mb_body_t<SCC, VAR> (S, G, P, J, mbx, mby, X, early);
     if (CTRL && J.gom_rc) wh_gom_close_if_last (P, J, xy);       // rate control: the group's last macroblock settles the next group's QP
     WH_PROF_MARK (P, S.m, 14);
     __builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");
@@ -283,7 +287,7 @@ __global__ __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPi
     WH_CLAIM()
     WH_PROF_SUB (P, S.m, 0);       /* detail: slot scan + ticket + order look-up */
     WH_FETCH_AHEAD()
-    slot = nslot; xy = nxy;
+    slot = nslot; xy = nxy; mbx = nmbx; mby = nmby;
   }
 #undef WH_CLAIM
 #undef WH_FETCH_AHEAD
@@ -475,19 +479,30 @@ __global__ __launch_bounds__ (1024) void k_md_assign (uint32_t* slice_cost, uint
       }
       __syncthreads();
     }
-  // real slices first (a zero-cost slice could sit behind padding): compact is not needed because padding only exists
-  // beyond n and sorts to the very end or among equal (zero) keys -- handle that by scanning for the p-th real entry
+  // deal the sorted slices out: the p-th REAL entry (padding carries id 0xffff; it sorts behind every real entry of its key, but a
+  // zero-cost slice shares the key) goes to row p / n_groups of the snake.  p = a prefix count over the sorted list: per chunk of 1024
+  // entries a ballot inside each wave, the waves' totals scanned by one thread.
   for (int g = (int)threadIdx.x; g < n_groups * slots; g += (int)blockDim.x) groups[g] = 0xffff;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int p = 0;
-    for (int i = 0; i < m; ++i) {
-      if (val[i] == 0xffff) continue;
+  __shared__ int wtot[17];
+  int carry = 0;
+  const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6, nwv = (int)blockDim.x >> 6;
+  for (int base = 0; base < m; base += (int)blockDim.x) {
+    const int i = base + (int)threadIdx.x;
+    const bool valid = i < m && val[i] != 0xffff;
+    const unsigned long long b = __ballot (valid);
+    const int before = __builtin_popcountll (b & ((1ull << lane) - 1ull));
+    __syncthreads();                                   // (wtot of the previous chunk has been read by everybody)
+    if (lane == 0) wtot[wave] = __builtin_popcountll (b);
+    __syncthreads();
+    if (threadIdx.x == 0) { int acc = 0; for (int w2 = 0; w2 < nwv; ++w2) { const int t = wtot[w2]; wtot[w2] = acc; acc += t; } wtot[16] = acc; }
+    __syncthreads();
+    if (valid) {
+      const int p = carry + wtot[wave] + before;
       const int r = p / n_groups, c = p % n_groups;
       const int g = (r & 1) ? n_groups - 1 - c : c;
       if (r < slots) groups[g * slots + r] = val[i];
-      ++p;
     }
+    carry += wtot[16];
   }
 }
 

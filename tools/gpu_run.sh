@@ -10,8 +10,12 @@
 #   stats           rocprofv3 --kernel-trace --stats of `bench.py --quick` -> kernel_stats.csv
 #   pmc             FETCH_SIZE / WRITE_SIZE passes of `bench.py --quick` (separate runs, --kernel-trace only beside --pmc) -> pmc_traffic.txt
 #   phase           in-kernel phase cycles of the P macroblock body (tools/phase_profile.py 256) -> phase_cycles.txt
+#   iwaves          IDR step of 256 four-slice 1080p pictures with 16 / 12 / 10 / 8 / 6 waves per intra workgroup (WELSHIP_I_WAVES) -> intra_waves.txt
+#   c5trace         config 5's shape (1 and 8 sessions 1080p, rate control, raster slices) through the binding with WELS_HIP_TRACE=2 -> config5_trace.txt
+#   c5ab:<v>,<v>..  the same, device frames/s against the C path, per variant (library tag[:ENV=VALUE...]) -> config5_ab.txt
 #   trace1          kernel + copy timeline of ONE 1080p session through the dispatch-table binding (config 5's shape) -> trace1_timeline.txt
 #   iphase          the same for the I macroblock body (the IDR step of 256 pictures) -> phase_cycles_intra.txt
+#   rphase          the same on the reference's own 1080p clip -> phase_cycles_res_clip.txt
 #   tables          every device row of both SHA1 tables incl. the size-limited rows -> *_rows.txt
 #   repro:<seeds>   size-limited-slice sessions <seeds> (comma separated; s = screen content, q = low QP: e.g. s21001,q11012,1003) with slice threads,
 #                   RUNS times each (default 6), for every library of LIBS (default: the product library) -> repro.txt
@@ -51,6 +55,7 @@ for stage in "$@"; do
               rm -rf $o/pmc_$c
             done > $o/pmc_traffic.txt 2>&1; cat $o/pmc_traffic.txt; lap "pmc";;
   phase)    timeout 200 python tools/phase_profile.py 256 > $o/phase_cycles.txt 2>&1; head -30 $o/phase_cycles.txt; lap "phase cycles";;
+  rphase)   timeout 300 python tools/phase_profile.py 256 res > $o/phase_cycles_res_clip.txt 2>&1; head -20 $o/phase_cycles_res_clip.txt; lap "phase cycles (the reference's 1080p clip)";;
   tables)   W=${WORKERS:-48}
             timeout 400 python tools/sha1_table_rows.py --workers $W > $o/camera_table_1792_rows.txt 2>&1; tail -2 $o/camera_table_1792_rows.txt | cut -c1-220
             timeout 300 python tools/sha1_table_rows.py --table adobe --workers $W > $o/screen_table_896_rows.txt 2>&1; tail -2 $o/screen_table_896_rows.txt | cut -c1-220
@@ -64,6 +69,17 @@ for stage in "$@"; do
               WELSHIP_LIB=$PWD/$lib timeout 200 python bench.py --quick > $o/ab_${t}_$rep.json 2> $o/ab_${t}_$rep.err
               python -c "import json; d=json.loads(open('$o/ab_${t}_$rep.json').read().strip().splitlines()[-1]); print('$t', $rep, 'value', round(d['value']), 'md_ms', d['roofline']['avg_launch_ms'], 'verified', d.get('verified'))"
             done; done | tee $o/ab.txt; lap "A/B";;
+  iwaves)   for w in 16 12 10 8 6 0; do echo "WELSHIP_I_WAVES=$w: $(WELSHIP_I_WAVES=$w timeout 120 python tools/phase_profile.py 256 synthetic intra 2>&1 | grep -E "IDR step|dependency wait|total cycles" | tr '\n' ' ')"; done > $o/intra_waves.txt 2>&1
+            cat $o/intra_waves.txt; lap "IDR step by waves per intra workgroup";;
+  c5trace)  for n in 1 8; do echo "== $n session(s)"; WELS_HIP_TRACE=2 WELSHIP_FRAME_STATS=1 timeout 200 python tools/config5_sessions.py $n 40 x 1080p 2>&1 | cut -c1-600; done > $o/config5_trace.txt 2>&1
+            cat $o/config5_trace.txt; lap "config 5: where the binding path's time goes";;
+  c5ab:*)   # variants: a library tag ("-" = the product library), optionally followed by :ENV=VALUE settings; comma separated
+            for rep in 1 2; do for v in $(echo "${stage#c5ab:}" | tr , ' '); do for n in 1 8; do
+              t=${v%%:*}; lib=openh264_amd/libwelship.so; [ "$t" != "-" ] && lib=openh264_amd/libwelship_$t.so
+              envs=$(echo "${v#*:}" | tr ':' ' '); [ "$envs" = "$v" ] && envs=""
+              r=$(env $envs WELSHIP_LIB=$PWD/$lib timeout 200 python tools/config5_sessions.py $n 40 x 1080p 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['hooks_on_device']['sum_of_session_encode_fps'], d['reference_c_path']['sum_of_session_encode_fps'], d['same_bitstreams'])")
+              echo "$v rep $rep sessions $n: device fps, C path fps, same bitstreams: $r"
+            done; done; done > $o/config5_ab.txt 2>&1; cat $o/config5_ab.txt; lap "config 5 A/B";;
   trace1)   ( cd /tmp && WELS_HIP_TRACE=2 timeout 200 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $OLDPWD/$o/trace1 -- python $OLDPWD/tools/config5_sessions.py 1 12 x 1080p > $OLDPWD/$o/trace1.log 2>&1 )
             python tools/trace_timeline.py $o/trace1 2 > $o/trace1_timeline.txt 2>&1; tail -60 $o/trace1_timeline.txt; rm -rf $o/trace1; lap "timeline of one 1080p session through the binding";;
   iphase)   timeout 200 python tools/phase_profile.py 256 synthetic intra > $o/phase_cycles_intra.txt 2>&1; head -16 $o/phase_cycles_intra.txt; lap "phase cycles (IDR step)";;
