@@ -319,7 +319,7 @@ __global__ __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPi
 // the algorithmic bytes but cost 25 % of the rate -- a workgroup's 68 rows do not divide among 12 waves, the last rows of a slice
 // are a serial tail, and rows two macroblocks apart stall each other; short runs keep the tickets' fine grain and most of the saving.
 // Pictures coded in ranges, with GOM-level rate control or as screen content keep the ticket scheduler.
-template <int MAXT>
+template <int MAXT, int VAR = 0>
 __global__ __launch_bounds__ (MAXT) void k_inter_rows (WhSeqParams P, const WhPicJob* jobs, uint32_t* err, const uint16_t* groups, int slots,
                                                        int sched_words, int total_slices, uint32_t* slice_cost) {
   extern __shared__ __align__ (16) uint8_t smem[];
@@ -393,7 +393,7 @@ __global__ __launch_bounds__ (MAXT) void k_inter_rows (WhSeqParams P, const WhPi
     next_fn();
     if (nslot < 0) return;
     const WhPicJob& Jn = Jl[nslot];
-    wh_inter_cold_fetch (G, lane, P, Jn, nx, ny);
+    wh_inter_cold_fetch<VAR> (G, lane, P, Jn, nx, ny);
     WhWin N;
     N.b = X.win;
     const int guess = slot_mv[nslot];
@@ -430,7 +430,7 @@ __global__ __launch_bounds__ (MAXT) void k_inter_rows (WhSeqParams P, const WhPi
     wh_win_slide_finish (X.win, SL);      // ... and so has the new tile column of windows that slid
     SL.on_y = 0; SL.on_c = 0;
     X.slice_idc = slot_idc[slot]; X.slice_first = first; X.last_mv = &slot_mv[slot];
-    wh_inter_mb_body_t<false> (S, G, P, J, x, y, X, early);       // (calls early_fn: nslot .. nxe are the next macroblock from there on)
+    wh_inter_mb_body_t<false, VAR> (S, G, P, J, x, y, X, early);       // (calls early_fn: nslot .. nxe are the next macroblock from there on)
     WH_PROF_MARK (P, S.m, 14);
     __builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");
     if (lane == 0) atomicOr (&sc[1 + ((xy - first) >> 5)], 1u << ((xy - first) & 31));
@@ -913,6 +913,7 @@ class HipBackend : public wh::Backend {
       if (getenv ("WELSHIP_TRACE")) { HIP_TRY (hipStreamSynchronize (stream_)); fprintf (stderr, "welship: launch done\n"); fflush (stderr); }
     };
     if (P.flags & WH_SEQ_SCC) { if (nw <= 6) launch (k_inter_pool<384, true>); else launch (k_inter_pool<768, true>); }
+    else if (rows && WH_PLAIN_KERNEL == 2 && plain && P.complexity == 0) { if (nw <= 6) launch (k_inter_rows<384, WH_PLAIN_KERNEL == 2 ? 2 : 0>); else launch (k_inter_rows<768, WH_PLAIN_KERNEL == 2 ? 2 : 0>); }
     else if (rows) { if (nw <= 6) launch (k_inter_rows<384>); else launch (k_inter_rows<768>); }
     else if (WH_PLAIN_KERNEL == 2 && plain && P.flags == 0 && P.complexity == 0) { if (nw <= 6) launch (k_inter_pool<384, false, WH_PLAIN_KERNEL == 2 ? 2 : 0>); else launch (k_inter_pool<768, false, WH_PLAIN_KERNEL == 2 ? 2 : 0>); }
     else if (WH_PLAIN_KERNEL && plain && P.flags == 0) { if (nw <= 6) launch (k_inter_pool<384, false, WH_PLAIN_KERNEL ? 1 : 0>); else launch (k_inter_pool<768, false, WH_PLAIN_KERNEL ? 1 : 0>); }
