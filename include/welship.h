@@ -33,7 +33,8 @@
  *
  *  (3) LEAF PRIMITIVES, batched over arrays of blocks -- same per-block semantics as the entries of
  *      SWelsFuncPtrList (codec/encoder/core/inc/wels_func_ptr_def.h:58-296) and SMcFunc
- *      (codec/common/inc/mc.h:40-53); see the WelsHipPrim* declarations below.
+ *      (codec/common/inc/mc.h:40-53); see the WelsHipPrim* declarations below.  The same primitives one call at a time,
+ *      with exactly the reference's typedefs (installable into the table's slots): welship_leaf.h.
  *
  * No PyTorch types appear here: plain pointers and sizes only.  Pointers named d_* are DEVICE
  * (HBM) addresses, everything else is host memory.  The library needs an MI355X (gfx950); every

@@ -21,6 +21,11 @@
 //   pfHipDownsample (state, dst, src ..)     CWelsPreProcess::DownsamplePadding (wels_preprocess.cpp:625-675): a spatial layer's source picture from
 //                                            the next larger one -- the down-sampling cascade of codec/processing on the device
 //
+//   WELS_HIP_LEAVES=1                        instead of all of the above: the reference's own loops stay in charge and every LEAF slot of the table
+//                                            (SAD / SATD, transforms, quantisation, motion compensation, the 28 intra predictors, the edge filters)
+//                                            is pointed at the device-backed export of the same typedef (include/welship_leaf.h) -- InstallLeaves
+//                                            below; a launch per call, for bring-up and parity checking only
+//
 // What runs on the device (see WelsHipSupported below): camera video and screen content, CAVLC and CABAC, slice threads, temporal layers,
 // LTR, denoising, scene-change and background detection, frame skipping, all rate-control modes.  With a frame-constant QP
 // (rate control off, or on with more than one slice, or I pictures in bitrate mode: WelsRcMbInitGom with bEnableGomQp ==
@@ -55,6 +60,8 @@
 #include <dlfcn.h>
 #include "compact.h"
 #include "welship.h"
+#include "welship_leaf.h"
+#include <type_traits>
 #include "wh_types.h"          // WhMbRecord: the engine's per-macroblock record (openh264_amd/csrc/common)
 
 namespace WelsEnc {
@@ -839,6 +846,62 @@ bool WelsHipSupported (const SWelsSvcCodingParam* p, const char** why) {
 #undef NO
 }
 
+// WELS_HIP_LEAVES=1: the leaf slots of the dispatch table point at the device-backed exports of include/welship_leaf.h.  Every export has
+// exactly its slot's typedef (the static_assert in LEAF) and is bound by name from the library the frame hooks use.
+int InstallLeaves (SWelsFuncPtrList* fl, const char** why) {
+  const char* path = getenv ("WELSHIP_LIB");
+  void* h = dlopen (path && *path ? path : "libwelship.so", RTLD_NOW | RTLD_LOCAL);
+  if (!h) { *why = "libwelship.so not loadable"; return 0; }
+  int (*avail) (void) = (int (*) (void))dlsym (h, "WelsHipLeafAvailable");
+  if (!avail) { *why = "libwelship.so without the leaf layer"; return 0; }
+  if (avail() != WELSHIP_OK) { *why = "no usable device"; return 0; }
+  int n = 0, missing = 0;
+#define LEAF(slot, sym) do { \
+    static_assert (std::is_same<decltype (&sym), std::remove_reference<decltype (slot)>::type>::value, #sym ": not the type of its slot"); \
+    void* f_ = dlsym (h, #sym); if (f_) { slot = (decltype (&sym))f_; ++n; } else ++missing; } while (0)
+  SSampleDealingFunc& sd = fl->sSampleDealingFuncs;
+#define LEAF_BLOCK(idx, name) LEAF (sd.pfSampleSad[idx], WelsHipSampleSad##name); LEAF (sd.pfSampleSatd[idx], WelsHipSampleSatd##name); LEAF (sd.pfSample4Sad[idx], WelsHipSampleSadFour##name)
+  LEAF_BLOCK (BLOCK_16x16, 16x16); LEAF_BLOCK (BLOCK_16x8, 16x8); LEAF_BLOCK (BLOCK_8x16, 8x16); LEAF_BLOCK (BLOCK_8x8, 8x8);
+  LEAF_BLOCK (BLOCK_4x4, 4x4); LEAF_BLOCK (BLOCK_8x4, 8x4); LEAF_BLOCK (BLOCK_4x8, 4x8);
+  LEAF (fl->pfDctT4, WelsHipDctT4); LEAF (fl->pfDctFourT4, WelsHipDctFourT4);
+  LEAF (fl->pfQuantization4x4, WelsHipQuant4x4); LEAF (fl->pfQuantizationDc4x4, WelsHipQuant4x4Dc);
+  LEAF (fl->pfQuantizationFour4x4, WelsHipQuantFour4x4); LEAF (fl->pfQuantizationFour4x4Max, WelsHipQuantFour4x4Max);
+  LEAF (fl->pfQuantizationHadamard2x2, WelsHipHadamardQuant2x2); LEAF (fl->pfQuantizationHadamard2x2Skip, WelsHipHadamardQuant2x2Skip);
+  LEAF (fl->pfTransformHadamard4x4Dc, WelsHipHadamardT4Dc);
+  LEAF (fl->pfScan4x4, WelsHipScan4x4DcAc); LEAF (fl->pfScan4x4Ac, WelsHipScan4x4Ac);
+  LEAF (fl->pfCalculateSingleCtr4x4, WelsHipCalculateSingleCtr4x4); LEAF (fl->pfGetNoneZeroCount, WelsHipGetNoneZeroCount);
+  LEAF (fl->pfDequantization4x4, WelsHipDequant4x4); LEAF (fl->pfDequantizationFour4x4, WelsHipDequantFour4x4);
+  LEAF (fl->pfDequantizationIHadamard4x4, WelsHipDequantIHadamard4x4);
+  LEAF (fl->pfIDctT4, WelsHipIDctT4Rec); LEAF (fl->pfIDctFourT4, WelsHipIDctFourT4Rec); LEAF (fl->pfIDctI16x16Dc, WelsHipIDctRecI16x16Dc);
+  LEAF (fl->sMcFuncs.pMcLumaFunc, WelsHipMcLuma); LEAF (fl->sMcFuncs.pMcChromaFunc, WelsHipMcChroma);
+  LEAF (fl->sMcFuncs.pfLumaHalfpelHor, WelsHipMcHorVer20); LEAF (fl->sMcFuncs.pfLumaHalfpelVer, WelsHipMcHorVer02);
+  LEAF (fl->sMcFuncs.pfLumaHalfpelCen, WelsHipMcHorVer22); LEAF (fl->sMcFuncs.pfSampleAveraging, WelsHipPixelAvg);
+  LEAF (fl->pfGetLumaI4x4Pred[I4_PRED_V], WelsHipI4x4LumaPredV); LEAF (fl->pfGetLumaI4x4Pred[I4_PRED_H], WelsHipI4x4LumaPredH);
+  LEAF (fl->pfGetLumaI4x4Pred[I4_PRED_DC], WelsHipI4x4LumaPredDc); LEAF (fl->pfGetLumaI4x4Pred[I4_PRED_DC_L], WelsHipI4x4LumaPredDcLeft);
+  LEAF (fl->pfGetLumaI4x4Pred[I4_PRED_DC_T], WelsHipI4x4LumaPredDcTop); LEAF (fl->pfGetLumaI4x4Pred[I4_PRED_DC_128], WelsHipI4x4LumaPredDcNA);
+  LEAF (fl->pfGetLumaI4x4Pred[I4_PRED_DDL], WelsHipI4x4LumaPredDDL); LEAF (fl->pfGetLumaI4x4Pred[I4_PRED_DDL_TOP], WelsHipI4x4LumaPredDDLTop);
+  LEAF (fl->pfGetLumaI4x4Pred[I4_PRED_DDR], WelsHipI4x4LumaPredDDR); LEAF (fl->pfGetLumaI4x4Pred[I4_PRED_VL], WelsHipI4x4LumaPredVL);
+  LEAF (fl->pfGetLumaI4x4Pred[I4_PRED_VL_TOP], WelsHipI4x4LumaPredVLTop); LEAF (fl->pfGetLumaI4x4Pred[I4_PRED_VR], WelsHipI4x4LumaPredVR);
+  LEAF (fl->pfGetLumaI4x4Pred[I4_PRED_HU], WelsHipI4x4LumaPredHU); LEAF (fl->pfGetLumaI4x4Pred[I4_PRED_HD], WelsHipI4x4LumaPredHD);
+  LEAF (fl->pfGetLumaI16x16Pred[I16_PRED_V], WelsHipI16x16LumaPredV); LEAF (fl->pfGetLumaI16x16Pred[I16_PRED_H], WelsHipI16x16LumaPredH);
+  LEAF (fl->pfGetLumaI16x16Pred[I16_PRED_DC], WelsHipI16x16LumaPredDc); LEAF (fl->pfGetLumaI16x16Pred[I16_PRED_P], WelsHipI16x16LumaPredPlane);
+  LEAF (fl->pfGetLumaI16x16Pred[I16_PRED_DC_L], WelsHipI16x16LumaPredDcLeft); LEAF (fl->pfGetLumaI16x16Pred[I16_PRED_DC_T], WelsHipI16x16LumaPredDcTop);
+  LEAF (fl->pfGetLumaI16x16Pred[I16_PRED_DC_128], WelsHipI16x16LumaPredDcNA);
+  LEAF (fl->pfGetChromaPred[C_PRED_DC], WelsHipIChromaPredDc); LEAF (fl->pfGetChromaPred[C_PRED_H], WelsHipIChromaPredH);
+  LEAF (fl->pfGetChromaPred[C_PRED_V], WelsHipIChromaPredV); LEAF (fl->pfGetChromaPred[C_PRED_P], WelsHipIChromaPredPlane);
+  LEAF (fl->pfGetChromaPred[C_PRED_DC_L], WelsHipIChromaPredDcLeft); LEAF (fl->pfGetChromaPred[C_PRED_DC_T], WelsHipIChromaPredDcTop);
+  LEAF (fl->pfGetChromaPred[C_PRED_DC_128], WelsHipIChromaPredDcNA);
+  DeblockingFunc& db = fl->pfDeblocking;
+  LEAF (db.pfLumaDeblockingLT4Ver, WelsHipDeblockLumaLt4V); LEAF (db.pfLumaDeblockingEQ4Ver, WelsHipDeblockLumaEq4V);
+  LEAF (db.pfLumaDeblockingLT4Hor, WelsHipDeblockLumaLt4H); LEAF (db.pfLumaDeblockingEQ4Hor, WelsHipDeblockLumaEq4H);
+  LEAF (db.pfChromaDeblockingLT4Ver, WelsHipDeblockChromaLt4V); LEAF (db.pfChromaDeblockingEQ4Ver, WelsHipDeblockChromaEq4V);
+  LEAF (db.pfChromaDeblockingLT4Hor, WelsHipDeblockChromaLt4H); LEAF (db.pfChromaDeblockingEQ4Hor, WelsHipDeblockChromaEq4H);
+#undef LEAF_BLOCK
+#undef LEAF
+  if (missing) { *why = "libwelship.so lacks some leaf exports"; return -missing; }
+  return n;
+}
+
 }  // namespace
 
 // The installer: what an `#if defined(X86_ASM)` block is for the SIMD variants (encoder.cpp:157-232).
@@ -853,6 +916,17 @@ void WelsHipInstall (SWelsFuncPtrList* pFuncList, SWelsSvcCodingParam* pParam) {
   const char* off = getenv ("WELS_HIP");
   if (off && atoi (off) == 0) return;
   const char* why = "";
+  if (getenv ("WELS_HIP_LEAVES") && atoi (getenv ("WELS_HIP_LEAVES")) != 0) {
+    // the leaf level instead of the frame level: the slots are written before any encoder thread exists; a partial table is refused
+    // by taking the process down (the slots already written cannot be told from the C ones afterwards)
+    const int n = InstallLeaves (pFuncList, &why);
+    if (n < 0) { fprintf (stderr, "welship hooks: leaf functions: %s (%d missing)\n", why, -n); abort(); }
+    if (getenv ("WELS_HIP_TRACE")) {
+      if (n > 0) fprintf (stderr, "welship hooks: %d leaf functions installed (frame-level hooks off)\n", n);
+      else fprintf (stderr, "welship hooks: leaf functions not installed (%s)\n", why);
+    }
+    return;
+  }
   if (!WelsHipSupported (pParam, &why)) {
     if (getenv ("WELS_HIP_TRACE")) fprintf (stderr, "welship hooks: not installed (%s)\n", why);
     return;

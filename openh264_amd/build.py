@@ -6,7 +6,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "openh264_amd", "csrc")
 HOST_SRCS = [os.path.join(CSRC, "host", f) for f in ("encoder.cpp", "entropy_cavlc.cpp", "headers.cpp")]
-HIP_SRCS = [os.path.join(CSRC, "hip", "hip_backend.hip"), os.path.join(CSRC, "hip", "prims.hip"), os.path.join(CSRC, "hip", "downsample.hip")]
+HIP_SRCS = [os.path.join(CSRC, "hip", "hip_backend.hip"), os.path.join(CSRC, "hip", "prims.hip"), os.path.join(CSRC, "hip", "downsample.hip"),
+            os.path.join(CSRC, "hip", "leaf.hip")]
 LIB = os.path.join(ROOT, "openh264_amd", "libwelship.so")
 EMU_LIB = os.path.join(ROOT, "tests", "emu", "libwelship_emu.so")
 

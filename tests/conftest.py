@@ -14,7 +14,7 @@ def pytest_configure(config):
 # Order of the tiers: cheap, wide evidence first (leaf primitives, frame parity, the reference's own clips and SHA1 tables), the randomised
 # sessions last -- the driver runs the GPU tier with -x, and one late failure of a fuzzer must not blank the primitives' evidence
 # (round 3: 43 of 116 GPU tests never ran behind a failing fuzz case).
-_FILE_ORDER = ["test_abi", "test_prims_gpu", "test_oracle_prims", "test_mb_order", "test_frame_parity", "test_reference_content", "test_downsample_gpu",
+_FILE_ORDER = ["test_abi", "test_prims_gpu", "test_leaf_gpu", "test_oracle_prims", "test_mb_order", "test_frame_parity", "test_reference_content", "test_downsample_gpu",
                "test_vaa", "test_frame_api_retry", "test_hooks_sha1", "test_hooks_screen", "test_hooks_simulcast", "test_hooks_cabac_threads",
                "test_multi_rank", "test_dropin_cli", "test_zz_dropin_gpu", "test_tools", "test_fuzz_parity", "test_hooks_dynslice"]
 

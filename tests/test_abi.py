@@ -1,4 +1,4 @@
-"""The C-ABI library loads without a GPU and exports every symbol include/welship.h declares."""
+"""The C-ABI library loads without a GPU and exports every symbol include/*.h declares."""
 import ctypes as C
 import os
 import re
@@ -9,10 +9,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_exports_match_header(hip_lib):
-    hdr = open(os.path.join(ROOT, "include", "welship.h")).read()
-    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    names = set(re.findall(r"\b(WelsHip[A-Za-z0-9]+)\s*\(", hdr))
-    assert len(names) >= 30
+    names = set()
+    for h in ("welship.h", "welship_leaf.h"):
+        hdr = open(os.path.join(ROOT, "include", h)).read()
+        hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+        names |= set(re.findall(r"\b(WelsHip[A-Za-z0-9]+)\s*\(", hdr))
+    assert len(names) >= 30 + 85
     lib = C.CDLL(hip_lib)
     missing = [n for n in sorted(names) if not hasattr(lib, n)]
     assert not missing, missing
@@ -37,7 +39,7 @@ def test_device_code_avoids_ashr_pk(tmp_path):
     import subprocess
     if not shutil.which("hipcc"):
         pytest.skip("hipcc not available")
-    for unit in ("hip_backend", "prims", "downsample"):
+    for unit in ("hip_backend", "prims", "downsample", "leaf"):
         out = tmp_path / (unit + ".s")
         subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-Wno-unused-function",
                                "-Wno-unused-variable", "-Wno-unused-command-line-argument", "-o", str(out),
