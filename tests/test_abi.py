@@ -45,3 +45,22 @@ def test_device_code_avoids_ashr_pk(tmp_path):
                                "-Wno-unused-variable", "-Wno-unused-command-line-argument", "-o", str(out),
                                os.path.join(ROOT, "openh264_amd", "csrc", "hip", unit + ".hip")])
         assert "v_ashr_pk" not in out.read_text()
+
+
+def test_leaf_installer_declines_without_a_device(hip_lib, tmp_path):
+    """WELS_HIP_LEAVES=1 (integration/welship_hooks.cpp InstallLeaves) on a machine without an MI355X: nothing is installed, the
+    installer says why, the session runs on the reference's C functions.  (With a device: tests/test_leaf_gpu.py.)"""
+    import subprocess
+    from conftest import has_gpu
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_enc_hip")
+    if has_gpu() or not os.path.exists(exe):
+        pytest.skip("needs the hooked reference build and no GPU")
+    from openh264_amd.utils.synth import synth_sequence
+    src = str(tmp_path / "c.yuv")
+    open(src, "wb").write(synth_sequence(64, 48, 2))
+    p = subprocess.run([exe, "-i", src, "-w", "64", "-h", "48", "-o", str(tmp_path / "o.264"), "-quiet", "-rc", "-1", "-qp", "30"],
+                       env=dict(os.environ, WELSHIP_LIB=hip_lib, WELS_HIP_LEAVES="1", WELS_HIP_TRACE="1"), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    err = p.stderr.decode(errors="replace")
+    assert p.returncode == 0 and "leaf functions not installed (no usable device)" in err, err[-1000:]
+    lib = C.CDLL(hip_lib)
+    assert lib.WelsHipLeafAvailable() == 100      # WELSHIP_ERR_NO_DEVICE
