@@ -9,6 +9,8 @@
 #   quick           bench.py --quick (the timed configuration only) -> bench_quick.json
 #   stats           rocprofv3 --kernel-trace --stats of `bench.py --quick` -> kernel_stats.csv
 #   pmc             FETCH_SIZE / WRITE_SIZE passes of `bench.py --quick` (separate runs, --kernel-trace only beside --pmc) -> pmc_traffic.txt
+#   counters:<a>+<b>,<c>   one rocprofv3 --pmc pass per comma-separated group of `bench.py --quick` (counters of a group joined by +) -> counters.txt;
+#                   "counters:list" writes the counter names the box offers (rocprofv3 --list-avail) -> counters_avail.txt
 #   phase           in-kernel phase cycles of the P macroblock body (tools/phase_profile.py 256) -> phase_cycles.txt
 #   iwaves          IDR step of 256 four-slice 1080p pictures with 16 / 12 / 10 / 8 / 6 waves per intra workgroup (WELSHIP_I_WAVES) -> intra_waves.txt
 #   c5trace         config 5's shape (1 and 8 sessions 1080p, rate control, raster slices) through the binding with WELS_HIP_TRACE=2 -> config5_trace.txt
@@ -16,7 +18,8 @@
 #   trace1          kernel + copy timeline of ONE 1080p session through the dispatch-table binding (config 5's shape) -> trace1_timeline.txt
 #   iphase          the same for the I macroblock body (the IDR step of 256 pictures) -> phase_cycles_intra.txt
 #   rphase          the same on the reference's own 1080p clip -> phase_cycles_res_clip.txt
-#   tables          every device row of both SHA1 tables incl. the size-limited rows -> *_rows.txt
+#   tables          every device row of both SHA1 tables incl. the size-limited rows -> *_rows.txt (the tool prints at the end: the timeouts are generous;
+#                   tables:camera / tables:screen / tables:dyn run one part)
 #   repro:<seeds>   size-limited-slice sessions <seeds> (comma separated; s = screen content, q = low QP: e.g. s21001,q11012,1003) with slice threads,
 #                   RUNS times each (default 6), for every library of LIBS (default: the product library) -> repro.txt
 #   ab:<tagA>,<tagB>[,..]   `bench.py --quick` alternating between candidate libraries openh264_amd/libwelship_<tag>.so ("-" = the product library), three rounds
@@ -54,13 +57,19 @@ for stage in "$@"; do
               python tools/pmc_summary.py $o/pmc_$c | grep -E "inter_|intra_|deblock|k_tile|k_expand|src_tile"
               rm -rf $o/pmc_$c
             done > $o/pmc_traffic.txt 2>&1; cat $o/pmc_traffic.txt; lap "pmc";;
+  counters:list) ( cd /tmp && timeout 120 rocprofv3 --list-avail > $OLDPWD/$o/counters_avail.txt 2>&1 ); grep -c . $o/counters_avail.txt; grep -i -o "SQC_ICACHE[A-Z_]*\|SQ_IFETCH[A-Z_]*\|SQ_WAIT_INST[A-Z_]*\|SQ_WAVE_CYCLES\|SQ_BUSY_CYCLES\|SQ_INSTS_[A-Z_]*\|SQ_INST_CYCLES[A-Z_]*\|SQ_ACTIVE_INST[A-Z_]*" $o/counters_avail.txt | sort -u | tr '\n' ' '; lap "counter list";;
+  counters:*) for grp in $(echo "${stage#counters:}" | tr , ' '); do
+              ( cd /tmp && timeout 200 rocprofv3 --kernel-trace --pmc $(echo $grp | tr + ' ') --output-format csv -d $OLDPWD/$o/pmc_$grp -- python $OLDPWD/bench.py --quick --steps 6 --warmup 2 > $OLDPWD/$o/pmc_$grp.log 2>&1 )
+              python tools/pmc_summary.py $o/pmc_$grp | grep -E "inter_|intra_|deblock"
+              rm -rf $o/pmc_$grp
+            done > $o/counters.txt 2>&1; cat $o/counters.txt; lap "counters";;
   phase)    timeout 200 python tools/phase_profile.py 256 > $o/phase_cycles.txt 2>&1; head -30 $o/phase_cycles.txt; lap "phase cycles";;
   rphase)   timeout 300 python tools/phase_profile.py 256 res > $o/phase_cycles_res_clip.txt 2>&1; head -20 $o/phase_cycles_res_clip.txt; lap "phase cycles (the reference's 1080p clip)";;
-  tables)   W=${WORKERS:-48}
-            timeout 400 python tools/sha1_table_rows.py --workers $W > $o/camera_table_1792_rows.txt 2>&1; tail -2 $o/camera_table_1792_rows.txt | cut -c1-220
-            timeout 300 python tools/sha1_table_rows.py --table adobe --workers $W > $o/screen_table_896_rows.txt 2>&1; tail -2 $o/screen_table_896_rows.txt | cut -c1-220
-            timeout 300 python tools/sha1_table_rows.py --dynslice --workers $W > $o/camera_table_size_limited_512_rows.txt 2>&1; tail -2 $o/camera_table_size_limited_512_rows.txt | cut -c1-220
-            timeout 300 python tools/sha1_table_rows.py --table adobe --dynslice --workers $W > $o/screen_table_size_limited_256_rows.txt 2>&1; tail -2 $o/screen_table_size_limited_256_rows.txt | cut -c1-220
+  tables|tables:*)   W=${WORKERS:-48}; part=${stage#tables}; part=${part#:}
+            [ -z "$part" -o "$part" = camera ] && timeout 700 python tools/sha1_table_rows.py --gom ${GOM:-2} --workers $W > $o/camera_table_1792_rows.txt 2>&1; tail -2 $o/camera_table_1792_rows.txt | cut -c1-220
+            [ -z "$part" -o "$part" = screen ] && timeout 600 python tools/sha1_table_rows.py --table adobe --workers $W > $o/screen_table_896_rows.txt 2>&1; tail -2 $o/screen_table_896_rows.txt | cut -c1-220
+            [ -z "$part" -o "$part" = dyn ] && timeout 300 python tools/sha1_table_rows.py --dynslice --workers $W > $o/camera_table_size_limited_512_rows.txt 2>&1; tail -2 $o/camera_table_size_limited_512_rows.txt | cut -c1-220
+            [ -z "$part" -o "$part" = dyn ] && timeout 300 python tools/sha1_table_rows.py --table adobe --dynslice --workers $W > $o/screen_table_size_limited_256_rows.txt 2>&1; tail -2 $o/screen_table_size_limited_256_rows.txt | cut -c1-220
             lap "SHA1 tables";;
   repro:*)  FUZZ_DYNSLICE_KEEP=$o/streams timeout ${REPRO_TIMEOUT:-600} python tools/repro_dynslice.py "${stage#repro:}" > $o/repro.txt 2>&1; grep -E "^==|DIFF|FAILED|VARIES|summary" $o/repro.txt | cut -c1-260 | head -80; lap "repro";;
   ab:*)     LIBTAGS=$(echo "${stage#ab:}" | tr , ' ')
