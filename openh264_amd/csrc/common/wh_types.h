@@ -195,6 +195,11 @@ typedef struct WhPicJob {
   // Backend::run_expand), ref_tiles is the reference picture's; both NULL-free whenever rec / ref are.
   uint8_t*       rec_tiles[2];
   const uint8_t* ref_tiles[2];
+  // Pictures that get deblocked: mode decision leaves the UNFILTERED reconstruction here, macroblock by macroblock (WH_SRC_MB_BYTES each:
+  // 16x16 luma, 8x8 Cb, 8x8 Cr -- three memory lines written whole), instead of in rec[]: the intra predictors of the neighbours and the
+  // deblocking pass read it from here, and the deblocking pass writes every sample of rec[] exactly once, filtered or not.  A planar
+  // picture costs both passes 32 pieces of 32 different lines per macroblock.  NULL: no deblocking pass follows, rec[] is written directly.
+  uint8_t*       rec_blk;
 } WhPicJob;
 
 // ---- tiled reference pictures ------------------------------------------------------------------------------------------

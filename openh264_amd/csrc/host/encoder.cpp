@@ -59,6 +59,10 @@ inline void build_run_section (WhSeqParams& s, int mb_w, int num_mb, std::vector
   }
 }
 
+// WELSHIP_REC_BLOCKS=0: mode decision writes the unfiltered reconstruction into the planar picture and the deblocking pass filters it in place (the
+// layout before round 4; kept as a switch for A/B runs)
+static bool rec_blocks_on() { static const bool on = !(getenv ("WELSHIP_REC_BLOCKS") && atoi (getenv ("WELSHIP_REC_BLOCKS")) == 0); return on; }
+
 struct DevPicture {            // one padded reconstruction buffer + its tiled twin (same allocation) + its MB state
   uint8_t* base = nullptr;
   uint8_t* plane[3] = {nullptr, nullptr, nullptr};   // pixel (0,0)
@@ -87,6 +91,7 @@ struct SessionCore {
   int last_slot = 0;                  // source slot of the previous frame (VAA reference)
   bool prev_src_dirty = false;        // that slot received a new upload since the frame was begun
   WhMbRecord* d_records = nullptr;
+  uint8_t* d_rec_blk = nullptr;       // the unfiltered reconstruction of the picture being coded, macroblock by macroblock (WhPicJob::rec_blk): lives from mode decision to the deblocking pass of the same step
   // packed records (common/compact.h): what a session GROUP copies back instead of the full records
   uint8_t* d_compact = nullptr;
   uint32_t* d_compact_off = nullptr;
@@ -282,6 +287,7 @@ struct SessionCore {
       pic[i].mbs = (WhMbState*)A (sizeof (WhMbState) * num_mb);
     }
     d_records = (WhMbRecord*)A (sizeof (WhMbRecord) * num_mb);
+    d_rec_blk = rec_blocks_on() ? (uint8_t*)A ((size_t)WH_SRC_MB_BYTES * num_mb) : nullptr;
     // processing order tables (common/mb_order.h): per slice, whole picture, per deblocking band
     std::vector<uint16_t> order ((size_t)num_mb * 3);
     const char* band_env = getenv ("WELSHIP_MB_BAND");      // experiment knob: rows per band of the per-slice order (0 = one band)
@@ -413,6 +419,8 @@ struct SessionCore {
     for (int i = 0; i < WH_PIPE_MAX_AHEAD + 2; ++i) { if (pic[i].base) be->free (pic[i].base); if (pic[i].mbs) be->free (pic[i].mbs); pic[i] = DevPicture(); }
     if (d_records) be->free (d_records);
     d_records = nullptr;
+    if (d_rec_blk) be->free (d_rec_blk);
+    d_rec_blk = nullptr;
     if (d_compact) be->free (d_compact);
     if (d_compact_off) be->free (d_compact_off);
     d_compact = nullptr; d_compact_off = nullptr;
@@ -515,6 +523,7 @@ struct SessionCore {
     for (int i = 0; i < 3; ++i) { job->rec[i] = c.plane[i]; job->ref[i] = idr ? nullptr : r.plane[i]; }
     for (int i = 0; i < 2; ++i) { job->rec_tiles[i] = c.tiles[i]; job->ref_tiles[i] = idr ? nullptr : r.tiles[i]; }
     job->records = d_records;
+    job->rec_blk = seq.deblock_idc != 1 ? d_rec_blk : nullptr;
     job->compact = use_compact ? dcompact (pbuf) : nullptr;
     job->compact_off = use_compact ? dcompact_off (pbuf) : nullptr;
     job->mbs = c.mbs;
@@ -1712,6 +1721,7 @@ struct WelsHipFrameCtx {
   }
   std::vector<uint8_t> h_src;
   WhMbRecord* d_records = nullptr;
+  uint8_t* d_rec_blk = nullptr;       // (SessionCore::d_rec_blk)
   std::vector<WhMbRecord> h_records;
   // packed records of whole-picture calls (WelsHipFrameJob::bPackedRecords; common/compact.h): device stream + offsets, page-locked host copies.
   // The host copy is brought back in one go up to `compact_est` bytes (a little more than the previous picture's size); the rare rest follows.
@@ -1779,7 +1789,7 @@ struct WelsHipFrameCtx {
     if (d_compact) be->free (d_compact);
     if (d_compact_off) be->free (d_compact_off);
     d_compact = nullptr; d_compact_off = nullptr;
-    void* ptrs[] = {d_vaa_out, d_src_planar, d_records, d_dbflags, d_mb_ctl, d_sad_cost0, d_vaa, d_bgd, d_il, d_job, d_scc, d_scc_idc, d_scc_ori, d_scc_chain, d_scc_lists, d_scc_loc, d_scc_order, d_scc_chain_mb, d_gom_rc, d_sad_cost0_new};
+    void* ptrs[] = {d_vaa_out, d_src_planar, d_records, d_rec_blk, d_dbflags, d_mb_ctl, d_sad_cost0, d_vaa, d_bgd, d_il, d_job, d_scc, d_scc_idc, d_scc_ori, d_scc_chain, d_scc_lists, d_scc_loc, d_scc_order, d_scc_chain_mb, d_gom_rc, d_sad_cost0_new};
     if (!h_gom.empty()) be->unpin_host (h_gom.data());
     if (!h_scc.empty()) be->unpin_host (h_scc.data());
     if (!h_scc_small.empty()) be->unpin_host (h_scc_small.data());
@@ -2021,6 +2031,7 @@ int WelsHipFrameCtxCreate (WelsHipFrameCtx** pp, const WelsHipFrameCfg* cfg) {
   c->d_src = c->src_pool[0].d;
   c->d_src_planar = (uint8_t*)A (c->src_bytes);
   c->d_records = (WhMbRecord*)A (sizeof (WhMbRecord) * c->num_mb);
+  c->d_rec_blk = rec_blocks_on() ? (uint8_t*)A ((size_t)WH_SRC_MB_BYTES * c->num_mb) : nullptr;
   c->d_dbflags = (uint32_t*)A (sizeof (uint32_t) * c->num_mb);
   c->d_mb_ctl = (WhMbCtl*)A (sizeof (WhMbCtl) * c->num_mb);
   c->d_sad_cost0 = (int32_t*)A (sizeof (int32_t) * c->num_mb);
@@ -2369,6 +2380,7 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
   for (int i = 0; i < 3; ++i) { job.rec[i] = cur.plane[i]; job.ref[i] = is_p ? c->pics[j->iRefPic].plane[i] : nullptr; }
   for (int i = 0; i < 2; ++i) { job.rec_tiles[i] = cur.tiles[i]; job.ref_tiles[i] = is_p ? c->pics[j->iRefPic].tiles[i] : nullptr; }
   job.records = c->d_records;
+  job.rec_blk = s.deblock_idc != 1 ? c->d_rec_blk : nullptr;
   job.mbs = cur.mbs;
   job.ref_mbs = is_p ? c->pics[j->iRefPic].mbs : nullptr;
   job.qp = j->iQp;

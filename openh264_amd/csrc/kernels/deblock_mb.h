@@ -134,6 +134,12 @@ WH_FN void wh_deblock_cold_fetch (WhDbStage& G, int lane, const WhSeqParams& P, 
     const int i = lane + 64 * k, n = i / 36, wd = i - n * 36;       // state n: this MB, left, top
     if (i < 108 && (n == 0 || (n == 1 ? mbx > 0 : mby > 0))) wh_ld_async4 ((const WH_G uint32_t*) (Mg - (n == 1 ? 1 : n == 2 ? w : 0)) + wd, &G.st[64 * k], lane);
   }
+  if (J.rec_blk) {               // the unfiltered samples as mode decision left them: the macroblock's own three lines (WhPicJob::rec_blk), in the staging area's order
+    const WH_G uint8_t* b = (const WH_G uint8_t*)J.rec_blk + (size_t)xy * WH_SRC_MB_BYTES;
+    wh_ld_async4 (b + lane * 4, G.y, lane);
+    if (lane < 32) wh_ld_async4 (b + 256 + lane * 4, G.c, lane);
+    return;
+  }
   wh_ld_async4 ((const WH_G uint8_t*)J.rec[0] + (ptrdiff_t) (mby * 16 + (lane >> 2)) * P.rec_stride_y + mbx * 16 + (lane & 3) * 4, G.y, lane);
   if (lane < 32) {
     const int pl = lane >> 4, row = (lane >> 1) & 7, half = lane & 1;
@@ -386,6 +392,7 @@ WH_FN bool wh_deblock_mb_body (WhDbLds& S, WhDbStage& G, const WhDbXchg& E, int 
   // ---- write-back (see the ownership rule above) ----
   const bool right_in = mbx < w - 1 && xy + 1 < last, below_in = xy + w < last;
   const bool lb_none = xy - 1 + w >= last;        // the left MB has no neighbour below it inside the slice
+  const bool own = filtered || J.rec_blk != nullptr;      // the MB's own samples are written: always when the picture does not hold the unfiltered ones (WhPicJob::rec_blk)
   WV_LANES_BEGIN (lane)
   {
     WH_G uint8_t* ry = (WH_G uint8_t*)J.rec[0] + (ptrdiff_t) (mby * 16) * P.rec_stride_y + mbx * 16;
@@ -394,7 +401,7 @@ WH_FN bool wh_deblock_mb_body (WhDbLds& S, WhDbStage& G, const WhDbXchg& E, int 
       bool wr;
       if (row < 0) wr = x >= 0 && (top_lds ? true : (filtered && top_ok && row >= -3));
       else if (x < 0) wr = left_lds ? (row < 12 || lb_none) : (filtered && left_ok);
-      else wr = filtered && (row < 12 || !below_in) && (x < 12 || !right_in);
+      else wr = own && (row < 12 || !below_in) && (x < 12 || !right_in);
       if (wr) {
         WH_G uint32_t* d = (WH_G uint32_t*) (ry + (ptrdiff_t)row * P.rec_stride_y + x);
         const uint32_t v = * (const uint32_t*)&WH_DY (S, x, row);
@@ -406,7 +413,7 @@ WH_FN bool wh_deblock_mb_body (WhDbLds& S, WhDbStage& G, const WhDbXchg& E, int 
       bool wr;
       if (row < 0) wr = x >= 0 && (top_lds ? true : (filtered && top_ok && row >= -1));
       else if (x < 0) wr = left_lds ? (row < 6 || lb_none) : (filtered && left_ok);
-      else wr = filtered && (row < 6 || !below_in) && (x < 4 || !right_in);
+      else wr = own && (row < 6 || !below_in) && (x < 4 || !right_in);
       if (wr) {
         WH_G uint32_t* d = (WH_G uint32_t*) ((WH_G uint8_t*)J.rec[1 + pl] + (ptrdiff_t) (mby * 8 + row) * P.rec_stride_c + mbx * 8 + x);
         const uint32_t v = * (const uint32_t*)&WH_DC (S, pl, x, row);

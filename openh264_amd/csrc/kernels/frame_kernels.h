@@ -22,15 +22,21 @@ WH_FN void wh_store_mb (WhMbLds& S, const WhSeqParams& P, const WhPicJob& J, int
   WH_G WhMbRecord* R = (WH_G WhMbRecord*)J.records + xy;
   WH_G WhMbState* M = (WH_G WhMbState*)J.mbs + xy;
   WV_LANES_BEGIN (lane)
-  {
-    const int row = lane >> 2, seg = lane & 3;
-    WH_G uint8_t* d = (WH_G uint8_t*)J.rec[0] + (size_t) (mby * 16 + row) * P.rec_stride_y + mbx * 16 + seg * 4;
-    * (WH_G uint32_t*)d = * (const uint32_t*)&WH_RY (S, seg * 4, row);
-  }
-  if (lane < 32) {
-    const int pl = lane >> 4, row = (lane >> 1) & 7, half = lane & 1;
-    WH_G uint8_t* d = (WH_G uint8_t*) (pl ? J.rec[2] : J.rec[1]) + (size_t) (mby * 8 + row) * P.rec_stride_c + mbx * 8 + half * 4;     // (a select, not an index: the job may live in registers)
-    * (WH_G uint32_t*)d = * (const uint32_t*)&WH_RC (S, pl, half * 4, row);
+  if (J.rec_blk) {              // (wave-uniform) the macroblock's own 384 bytes: the lane's luma word is word `lane`, its chroma word 64 + lane
+    WH_G uint32_t* b = (WH_G uint32_t*) ((WH_G uint8_t*)J.rec_blk + (size_t)xy * WH_SRC_MB_BYTES);
+    b[lane] = * (const uint32_t*)&WH_RY (S, (lane & 3) * 4, lane >> 2);
+    if (lane < 32) b[64 + lane] = * (const uint32_t*)&WH_RC (S, lane >> 4, (lane & 1) * 4, (lane >> 1) & 7);
+  } else {
+    {
+      const int row = lane >> 2, seg = lane & 3;
+      WH_G uint8_t* d = (WH_G uint8_t*)J.rec[0] + (size_t) (mby * 16 + row) * P.rec_stride_y + mbx * 16 + seg * 4;
+      * (WH_G uint32_t*)d = * (const uint32_t*)&WH_RY (S, seg * 4, row);
+    }
+    if (lane < 32) {
+      const int pl = lane >> 4, row = (lane >> 1) & 7, half = lane & 1;
+      WH_G uint8_t* d = (WH_G uint8_t*) (pl ? J.rec[2] : J.rec[1]) + (size_t) (mby * 8 + row) * P.rec_stride_c + mbx * 8 + half * 4;     // (a select, not an index: the job may live in registers)
+      * (WH_G uint32_t*)d = * (const uint32_t*)&WH_RC (S, pl, half * 4, row);
+    }
   }
   // coefficient levels: 4 luma + 2 chroma-AC int16 quads per lane
   {

@@ -68,8 +68,29 @@ WH_FN void wh_tile_fetch_nb_planes (int lane, const WhSeqParams& P, const WH_G u
   const uint32_t v = * (const WH_G uint32_t*) (base + (ptrdiff_t)row * (luma ? P.rec_stride_y : P.rec_stride_c) + x);
   r->nb = (col_y || col_c) ? v >> 24 : v;
 }
+// The same roles when the unfiltered reconstruction is kept macroblock by macroblock (WhPicJob::rec_blk): the word is the neighbour block's
+// row 15 / 7 (top roles: the macroblock above-left, above, above-right) or the last word of one of its rows (column roles: the left one).
+// A neighbour outside the picture is replaced by a block that exists (macroblock 0 / the last one): its samples are never used.
+WH_FN void wh_tile_fetch_nb_blk (int lane, const WhSeqParams& P, const WH_G uint8_t* blk, int mbx, int mby, WhTileRegs* r) {
+  const bool top_y = lane < 7, col_y = lane >= 16 && lane < 32, top_c = lane >= 32 && lane < 38, col_c = lane >= 48;
+  const int w = P.mb_w, xy = mby * w + mbx;
+  int nb, off;
+  if (col_y) { nb = xy - 1; off = (lane - 16) * 16 + 12; }
+  else if (col_c) { nb = xy - 1; off = 256 + ((lane - 48) >> 3) * 64 + (lane & 7) * 8 + 4; }
+  else if (top_c) {
+    const int pl = (lane - 32) / 3, k = (lane - 32) - 3 * pl;
+    nb = k == 0 ? xy - w - 1 : xy - w; off = 256 + pl * 64 + 56 + (k == 0 ? 4 : (k - 1) * 4);
+  } else {
+    const int k = top_y ? lane : 0;                                      // (idle lanes take lane 0's role)
+    nb = k == 0 ? xy - w - 1 : k < 5 ? xy - w : xy - w + 1; off = 240 + (k == 0 ? 12 : k < 5 ? (k - 1) * 4 : (k - 5) * 4);
+  }
+  nb = nb < 0 ? 0 : nb;                                                  // (xy - w + 1 <= xy: never beyond the picture)
+  const uint32_t v = * (const WH_G uint32_t*) (blk + (size_t)nb * WH_SRC_MB_BYTES + off);
+  r->nb = (col_y || col_c) ? v >> 24 : v;
+}
 WH_FN void wh_tile_fetch_nb (int lane, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, WhTileRegs* r) {
-  wh_tile_fetch_nb_planes (lane, P, (const WH_G uint8_t*)J.rec[0], (const WH_G uint8_t*)J.rec[1], (const WH_G uint8_t*)J.rec[2], mbx, mby, r);
+  if (J.rec_blk) wh_tile_fetch_nb_blk (lane, P, (const WH_G uint8_t*)J.rec_blk, mbx, mby, r);
+  else wh_tile_fetch_nb_planes (lane, P, (const WH_G uint8_t*)J.rec[0], (const WH_G uint8_t*)J.rec[1], (const WH_G uint8_t*)J.rec[2], mbx, mby, r);
 }
 WH_FN void wh_tile_fetch (int lane, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, WhTileRegs* r) {
   wh_tile_fetch_src (lane, P, J, mbx, mby, r);
