@@ -2141,7 +2141,14 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
   // host-side staging into this context's own page-locked buffers: outside the shared lock
   // source picture: the MB-aligned area of pEncPic (CWelsPreProcess pads it), tight strides on the device -- unless the pre-analysis
   // of this very picture has put it there already (WelsHipFrameVaa)
-  const bool src_resident = first_part && c->fresh_key != nullptr && c->fresh_key == (const void*)j->pSrc[0] && c->src_find (c->fresh_key) >= 0;
+  // (the address alone does not identify the content -- the caller may have refilled the buffer since the pre-analysis call, or dropped that
+  //  picture: the slot's checksum must be the buffer's)
+  bool src_resident = false;
+  if (first_part && c->fresh_key != nullptr && c->fresh_key == (const void*)j->pSrc[0]) {
+    const int k = c->src_find (c->fresh_key);
+    src_resident = k >= 0 && c->src_pool[k].luma_sum == c->luma_checksum (j->pSrc[0], j->iSrcStride[0]);
+  }
+  if (first_part) c->fresh_key = nullptr;           // one pre-analysis call vouches for one encode call
   if (first_part && !src_resident) c->stage_planes (j->pSrc, j->iSrcStride);
   if (first_part) {
     if (is_p && j->pVaaSad8x8) memcpy (c->h_aux.data() + c->aux_vaa, j->pVaaSad8x8, sizeof (int32_t) * 4 * c->num_mb);
@@ -2310,7 +2317,6 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
   if (first_part) {
     const int slot = c->src_take ((const void*)j->pSrc[0]);
     c->d_src = c->src_pool[slot].d;
-    c->fresh_key = nullptr;
     if (!src_resident) {
       c->src_pool[slot].luma_sum = c->luma_checksum (c->h_src.data(), s.src_stride_y);       // (of the staged copy: what the slot will hold)
       be->upload (c->d_src_planar, c->h_src.data(), c->src_bytes);
@@ -2543,6 +2549,29 @@ int WelsHipFrameVaa (WelsHipFrameCtx* c, const WelsHipVaaJob* j) {
   const size_t o_sad = 0, o_sd = 16 * n, o_sum = 32 * n, o_sq = 36 * n, o_ssd = 40 * n, o_mad = 44 * n, out_bytes = 48 * n;
   const int vq = (int) ((uintptr_t)c / 64 % 8);
   const int queue = 24 + 4 * (vq / 4) + (3 - vq % 4);          // the pre-analysis queues (keys: 0..7 uploads, 8..23 launch sets)
+  // Host-side work -- the reference's checksum, staging into this context's own page-locked buffer -- happens OUTSIDE the device-wide lock
+  // (other sessions keep submitting meanwhile); the lock covers queue selection and the enqueues only.  The source pool is the context's own.
+  // The earlier picture is resident when it was the source of an earlier call AND the caller's buffer still holds what was uploaded then
+  // (its slot is refreshed so that it survives the upload below).
+  const uint64_t ref_sum = c->luma_checksum (j->pRef[0], j->iRefStride[0]);
+  int rslot = c->src_find ((const void*)j->pRef[0]);
+  if (rslot >= 0 && c->src_pool[rslot].luma_sum == ref_sum) c->src_pool[rslot].stamp = ++c->src_clock;
+  else {
+    rslot = c->src_take ((const void*)j->pRef[0]);
+    c->src_pool[rslot].luma_sum = ref_sum;
+    c->stage_planes (j->pRef, j->iRefStride);
+    {
+      std::unique_lock<std::mutex> lock (sh->mu);
+      be->select_queue (queue);
+      be->upload (c->d_src_planar, c->h_src.data(), c->src_bytes);
+      be->run_src_tile (c->seq, c->d_src_planar, c->src_pool[rslot].d);
+    }
+    if (be->sync_queue (queue)) { set_err ("device error in the pre-analysis"); return WELSHIP_ERR_UNKNOWN; }      // (the staging buffer is used again below)
+  }
+  const int cslot = c->src_take ((const void*)j->pCur[0]);
+  if (cslot == rslot) { set_err ("pre-analysis: a picture against itself"); return WELSHIP_ERR_INIT_PARA; }
+  c->stage_planes (j->pCur, j->iCurStride);
+  c->src_pool[cslot].luma_sum = c->luma_checksum (c->h_src.data(), c->seq.src_stride_y);
   std::unique_lock<std::mutex> lock (sh->mu);
   if (!c->d_vaa_out) {
     c->d_vaa_out = (uint8_t*)be->alloc (out_bytes);
@@ -2551,23 +2580,6 @@ int WelsHipFrameVaa (WelsHipFrameCtx* c, const WelsHipVaaJob* j) {
     if (!c->d_vaa_out) { set_err ("out of device memory"); return WELSHIP_ERR_MEMORY; }
   }
   be->select_queue (queue);
-  // the earlier picture: resident when it was the source of an earlier call AND the caller's buffer still holds what was uploaded then
-  // (its slot is refreshed so that it survives the upload below)
-  const uint64_t ref_sum = c->luma_checksum (j->pRef[0], j->iRefStride[0]);
-  int rslot = c->src_find ((const void*)j->pRef[0]);
-  if (rslot >= 0 && c->src_pool[rslot].luma_sum == ref_sum) c->src_pool[rslot].stamp = ++c->src_clock;
-  else {
-    rslot = c->src_take ((const void*)j->pRef[0]);
-    c->src_pool[rslot].luma_sum = ref_sum;
-    c->stage_planes (j->pRef, j->iRefStride);
-    be->upload (c->d_src_planar, c->h_src.data(), c->src_bytes);
-    be->run_src_tile (c->seq, c->d_src_planar, c->src_pool[rslot].d);
-    if (be->sync_queue (queue)) { set_err ("device error in the pre-analysis"); return WELSHIP_ERR_UNKNOWN; }      // (the staging buffer is used again below)
-  }
-  const int cslot = c->src_take ((const void*)j->pCur[0]);
-  if (cslot == rslot) { set_err ("pre-analysis: a picture against itself"); return WELSHIP_ERR_INIT_PARA; }
-  c->stage_planes (j->pCur, j->iCurStride);
-  c->src_pool[cslot].luma_sum = c->luma_checksum (c->h_src.data(), c->seq.src_stride_y);
   be->upload (c->d_src_planar, c->h_src.data(), c->src_bytes);
   be->run_src_tile (c->seq, c->d_src_planar, c->src_pool[cslot].d);
   uint8_t* o = c->d_vaa_out;

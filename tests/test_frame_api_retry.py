@@ -34,7 +34,7 @@ class FrameJob(C.Structure):          # WelsHipFrameJob, field for field
                 ("pIlHint", C.c_void_p), ("pSadCost", C.POINTER(C.c_int32)), ("pScreen", C.c_void_p),
                 ("bRetry", C.c_int32), ("bCountBits", C.c_int32), ("iNumReencode", C.c_int32), ("iNumRefIdxL0Active", C.c_int32),
                 ("pGomRc", C.c_void_p), ("pReencode", C.POINTER(MbReencode)),
-                ("iDynSlice", C.c_int32), ("iDynSliceFirstMb", C.c_int32), ("bRangeAgain", C.c_int32), ("bDynRedoFirst", C.c_int32)]
+                ("iDynSlice", C.c_int32), ("iDynSliceFirstMb", C.c_int32), ("bRangeAgain", C.c_int32), ("bDynRedoFirst", C.c_int32), ("bPackedRecords", C.c_int32)]
 
 
 def _retry_sees_the_previous_pictures_sad_costs(lib_path):
