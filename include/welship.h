@@ -332,6 +332,9 @@ typedef struct WelsHipMbReencode {
  * source of an earlier call of this context (keyed by its luma pointer: the reference rotates a fixed set of picture buffers), and is
  * uploaded otherwise.  Results go to the caller's arrays (those the selected variant writes; macroblocks outside
  * (iPicWidth >> 4) x (iPicHeight >> 4) are left alone, as the C functions leave them). */
+/* Widths that are no multiple of 16: the C functions walk such a picture skewed (every macroblock row begins (width & 15) samples further left,
+ * vaacalcfuncs.cpp:46,145-146) -- pCur[0] / pRef[0] must then be readable for 16 * (iPicHeight >> 4) whole lines of iCurStride[0] bytes, and the two
+ * strides must be equal (the C functions take one).  The picture is not left on the device in that case. */
 typedef struct WelsHipVaaJob {
   const uint8_t* pCur[3]; int32_t iCurStride[3];      /* host planes of the current source picture, MB-aligned area readable    */
   const uint8_t* pRef[3]; int32_t iRefStride[3];      /* ... of the picture it is compared with                                  */

@@ -713,6 +713,11 @@ __global__ __launch_bounds__ (64) void k_vaa (int num_mb, const uint8_t* cur, co
   if (xy < num_mb) wh_vaa_mb ((const WH_G uint8_t*)cur, (const WH_G uint8_t*)ref, xy, o);
 }
 
+__global__ __launch_bounds__ (64) void k_vaa_skewed (int vw, int vh, int mb_w, int stride, int width, const uint8_t* cur, const uint8_t* ref, WhVaaOut o) {
+  const int t = (int) (blockIdx.x * blockDim.x + threadIdx.x);
+  if (t < vw * vh) wh_vaa_mb_skewed ((const WH_G uint8_t*)cur, (const WH_G uint8_t*)ref, stride, width, mb_w, t % vw, t / vw, o);
+}
+
 // Scene-change statistic: one wavefront per 16x16 region of the source picture.
 __global__ __launch_bounds__ (64) void k_scene (WhSeqParams P, const WhPicJob* jobs) {
   const WhPicJob J = jobs[blockIdx.y];
@@ -977,6 +982,14 @@ class HipBackend : public wh::Backend {
     const WhVaaOut o = {sad8x8, sd8x8, mad8x8, sum16, sqsum16, ssd16};
     const int num_mb = P.mb_w * P.mb_h;
     hipLaunchKernelGGL (k_vaa, dim3 ((num_mb + 63) / 64), dim3 (64), 0, stream_, num_mb, cur, ref, o);
+    HIP_TRY (hipGetLastError());
+  }
+  void run_vaa_skewed (const WhSeqParams& P, const uint8_t* cur, const uint8_t* ref, int stride, int width, int height, int32_t* sad8x8, int32_t* sd8x8, uint8_t* mad8x8,
+                       int32_t* sum16, int32_t* sqsum16, int32_t* ssd16) override {
+    if (!cur || !ref) { note_null(); return; }
+    const WhVaaOut o = {sad8x8, sd8x8, mad8x8, sum16, sqsum16, ssd16};
+    const int vw = width >> 4, vh = height >> 4;
+    hipLaunchKernelGGL (k_vaa_skewed, dim3 ((vw * vh + 63) / 64), dim3 (64), 0, stream_, vw, vh, P.mb_w, stride, width, cur, ref, o);
     HIP_TRY (hipGetLastError());
   }
   void run_compact (const WhSeqParams& P, const WhPicJob* jobs, int n) override {

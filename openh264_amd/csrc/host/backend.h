@@ -24,6 +24,10 @@ class Backend {
   // pre-analysis statistics of the tiled source picture `cur` against `ref` (kernels/vaa_pic.h), every macroblock of the MB-aligned picture
   virtual void run_vaa (const WhSeqParams& P, const uint8_t* cur, const uint8_t* ref, int32_t* sad8x8, int32_t* sd8x8, uint8_t* mad8x8,
                         int32_t* sum16, int32_t* sqsum16, int32_t* ssd16) = 0;
+  // the same for a picture whose width is no multiple of 16 (kernels/vaa_pic.h wh_vaa_mb_skewed): `cur` / `ref` are the two luma planes as the
+  // caller has them, `stride` bytes per line; the (width >> 4) x (height >> 4) macroblocks the C functions cover
+  virtual void run_vaa_skewed (const WhSeqParams& P, const uint8_t* cur, const uint8_t* ref, int stride, int width, int height, int32_t* sad8x8, int32_t* sd8x8,
+                               uint8_t* mad8x8, int32_t* sum16, int32_t* sqsum16, int32_t* ssd16) = 0;
   // page-lock a host buffer that is the target of many downloads (best effort; no-op where it does not apply)
   virtual void pin_host (void* p, size_t bytes) { (void)p; (void)bytes; }
   virtual void unpin_host (void* p) { (void)p; }

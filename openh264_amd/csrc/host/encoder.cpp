@@ -1722,6 +1722,9 @@ struct WelsHipFrameCtx {
   std::vector<uint8_t> h_src;
   WhMbRecord* d_records = nullptr;
   uint8_t* d_rec_blk = nullptr;       // (SessionCore::d_rec_blk)
+  uint8_t* d_skew = nullptr;          // pre-analysis of a picture whose width is no multiple of 16: the two luma planes at the caller's stride (WelsHipFrameVaa)
+  std::vector<uint8_t> h_skew;
+  size_t skew_bytes = 0;
   std::vector<WhMbRecord> h_records;
   // packed records of whole-picture calls (WelsHipFrameJob::bPackedRecords; common/compact.h): device stream + offsets, page-locked host copies.
   // The host copy is brought back in one go up to `compact_est` bytes (a little more than the previous picture's size); the rare rest follows.
@@ -1784,12 +1787,13 @@ struct WelsHipFrameCtx {
     src_pool.clear();
     d_src = nullptr;
     if (!h_vaa_out.empty()) be->unpin_host (h_vaa_out.data());
+    if (!h_skew.empty()) be->unpin_host (h_skew.data());
     if (!h_compact.empty()) be->unpin_host (h_compact.data());
     if (!h_coff.empty()) be->unpin_host (h_coff.data());
     if (d_compact) be->free (d_compact);
     if (d_compact_off) be->free (d_compact_off);
     d_compact = nullptr; d_compact_off = nullptr;
-    void* ptrs[] = {d_vaa_out, d_src_planar, d_records, d_rec_blk, d_dbflags, d_mb_ctl, d_sad_cost0, d_vaa, d_bgd, d_il, d_job, d_scc, d_scc_idc, d_scc_ori, d_scc_chain, d_scc_lists, d_scc_loc, d_scc_order, d_scc_chain_mb, d_gom_rc, d_sad_cost0_new};
+    void* ptrs[] = {d_vaa_out, d_skew, d_src_planar, d_records, d_rec_blk, d_dbflags, d_mb_ctl, d_sad_cost0, d_vaa, d_bgd, d_il, d_job, d_scc, d_scc_idc, d_scc_ori, d_scc_chain, d_scc_lists, d_scc_loc, d_scc_order, d_scc_chain_mb, d_gom_rc, d_sad_cost0_new};
     if (!h_gom.empty()) be->unpin_host (h_gom.data());
     if (!h_scc.empty()) be->unpin_host (h_scc.data());
     if (!h_scc_small.empty()) be->unpin_host (h_scc_small.data());
@@ -2532,9 +2536,11 @@ int WelsHipFrameVaa (WelsHipFrameCtx* c, const WelsHipVaaJob* j) {
     set_err ("pre-analysis: planes / strides"); return WELSHIP_ERR_INIT_PARA;
   }
   // A width that is no multiple of 16: the C functions step from one macroblock row to the next by 16 * stride - width, i.e. every row
-  // starts (width & 15) samples further left than the one above and runs into the previous line's stride padding
-  // (vaacalcfuncs.cpp:262-264,332-333) -- results that depend on bytes outside the picture.  Left to the caller's C path.
-  if (j->iPicWidth & 15) { set_err ("pre-analysis: picture width is no multiple of 16 (the C functions' row step reads the stride padding)"); return WELSHIP_ERR_UNSUPPORTED; }
+  // starts (width & 15) samples further left than the one above and runs into the previous line's stride padding and samples
+  // (vaacalcfuncs.cpp:46,145-146 ...) -- results that depend on the bytes between the lines.  Such a picture takes the path below that
+  // hands the device the two luma planes as the caller has them, padding included (kernels/vaa_pic.h wh_vaa_mb_skewed).
+  const bool skewed = (j->iPicWidth & 15) != 0;
+  if (skewed && j->iCurStride[0] != j->iRefStride[0]) { set_err ("pre-analysis: a width that is no multiple of 16 needs both pictures at one stride (the C functions take one)"); return WELSHIP_ERR_UNSUPPORTED; }
   const int vw = j->iPicWidth >> 4, vh = j->iPicHeight >> 4;       // the macroblocks the C functions cover
   if (vw < 1 || vh < 1 || vw > c->mb_w || vh > c->mb_h || !j->pSad8x8 || !j->pFrameSad) { set_err ("pre-analysis: picture size / result arrays"); return WELSHIP_ERR_INIT_PARA; }
   // which arrays the selected variant writes (vaacalculation.cpp:118-157)
@@ -2549,6 +2555,39 @@ int WelsHipFrameVaa (WelsHipFrameCtx* c, const WelsHipVaaJob* j) {
   const size_t o_sad = 0, o_sd = 16 * n, o_sum = 32 * n, o_sq = 36 * n, o_ssd = 40 * n, o_mad = 44 * n, out_bytes = 48 * n;
   const int vq = (int) ((uintptr_t)c / 64 % 8);
   const int queue = 24 + 4 * (vq / 4) + (3 - vq % 4);          // the pre-analysis queues (keys: 0..7 uploads, 8..23 launch sets)
+  if (skewed) {
+    const int stride = j->iCurStride[0];
+    const size_t plane = (size_t)vh * 16 * (size_t)stride;            // the lines the walk touches: [0, 16 * vh) of each plane, whole lines
+    if (c->skew_bytes < 2 * plane) {
+      std::unique_lock<std::mutex> lock (sh->mu);
+      if (c->d_skew) be->free (c->d_skew);
+      if (!c->h_skew.empty()) be->unpin_host (c->h_skew.data());
+      c->d_skew = (uint8_t*)be->alloc (2 * plane);
+      c->h_skew.assign (2 * plane, 0);
+      be->pin_host (c->h_skew.data(), 2 * plane);
+      c->skew_bytes = c->d_skew ? 2 * plane : 0;
+      if (!c->d_skew) { set_err ("out of device memory"); return WELSHIP_ERR_MEMORY; }
+    }
+    memcpy (c->h_skew.data(), j->pCur[0], plane);
+    memcpy (c->h_skew.data() + plane, j->pRef[0], plane);
+    {
+      std::unique_lock<std::mutex> lock (sh->mu);
+      if (!c->d_vaa_out) {
+        c->d_vaa_out = (uint8_t*)be->alloc (out_bytes);
+        c->h_vaa_out.assign (out_bytes, 0);
+        be->pin_host (c->h_vaa_out.data(), out_bytes);
+        if (!c->d_vaa_out) { set_err ("out of device memory"); return WELSHIP_ERR_MEMORY; }
+      }
+      be->select_queue (queue);
+      be->upload (c->d_skew, c->h_skew.data(), 2 * plane);
+      uint8_t* o = c->d_vaa_out;
+      be->run_vaa_skewed (c->seq, c->d_skew, c->d_skew + plane, stride, j->iPicWidth, j->iPicHeight, (int32_t*) (o + o_sad), want_sd ? (int32_t*) (o + o_sd) : nullptr,
+                          want_sd ? o + o_mad : nullptr, want_sum ? (int32_t*) (o + o_sum) : nullptr, want_sum ? (int32_t*) (o + o_sq) : nullptr, want_ssd ? (int32_t*) (o + o_ssd) : nullptr);
+      be->download (c->h_vaa_out.data(), o, out_bytes);
+    }
+    if (be->sync_queue (queue)) { set_err ("device error in the pre-analysis"); return WELSHIP_ERR_UNKNOWN; }
+    c->fresh_key = nullptr;              // (the picture itself was not put on the device in the encoder's layout: the encode call uploads it)
+  } else {
   // Host-side work -- the reference's checksum, staging into this context's own page-locked buffer -- happens OUTSIDE the device-wide lock
   // (other sessions keep submitting meanwhile); the lock covers queue selection and the enqueues only.  The source pool is the context's own.
   // The earlier picture is resident when it was the source of an earlier call AND the caller's buffer still holds what was uploaded then
@@ -2589,6 +2628,7 @@ int WelsHipFrameVaa (WelsHipFrameCtx* c, const WelsHipVaaJob* j) {
   lock.unlock();
   if (be->sync_queue (queue)) { set_err ("device error in the pre-analysis"); return WELSHIP_ERR_UNKNOWN; }
   c->fresh_key = (const void*)j->pCur[0];
+  }
   // results: the macroblocks the C functions cover, row by row; the frame SAD is their sum
   const uint8_t* h = c->h_vaa_out.data();
   long long frame_sad = 0;

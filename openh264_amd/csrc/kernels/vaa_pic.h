@@ -23,14 +23,25 @@ typedef struct WhVaaOut {          // device arrays, [num_mb] macroblocks of the
   int32_t* ssd16;                  // [mb]      pSsd16x16
 } WhVaaOut;
 
-WH_HDFN void wh_vaa_mb (const WH_G uint8_t* cur, const WH_G uint8_t* ref, int xy, const WhVaaOut& o) {
-  const WH_G uint8_t* c = cur + (size_t)xy * WH_SRC_MB_BYTES;
-  const WH_G uint8_t* r = ref + (size_t)xy * WH_SRC_MB_BYTES;
+// `c` / `r`: the macroblock's first sample in the two pictures, `pitch` bytes from one of its rows to the next (16 in a tiled picture)
+template <bool ALIGNED>
+WH_HDFN void wh_vaa_mb_at (const WH_G uint8_t* c, const WH_G uint8_t* r, size_t pitch, int xy, const WhVaaOut& o) {
   int sad[4] = {0, 0, 0, 0}, sd[4] = {0, 0, 0, 0}, mad[4] = {0, 0, 0, 0};
   int sum = 0, sqsum = 0, ssd = 0;
   for (int row = 0; row < 16; ++row) {
-    const WhU4 a = wh_ldg16 (c + row * 16), b = wh_ldg16 (r + row * 16);
-    const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+    uint32_t aw[4], bw[4];
+    if (ALIGNED) {
+      const WhU4 a = wh_ldg16 (c + row * pitch), b = wh_ldg16 (r + row * pitch);
+      aw[0] = a.x; aw[1] = a.y; aw[2] = a.z; aw[3] = a.w; bw[0] = b.x; bw[1] = b.y; bw[2] = b.z; bw[3] = b.w;
+    } else {                                   // any byte address
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const WH_G uint8_t* pc = c + row * pitch + 4 * k;
+        const WH_G uint8_t* pr = r + row * pitch + 4 * k;
+        aw[k] = (uint32_t)pc[0] | ((uint32_t)pc[1] << 8) | ((uint32_t)pc[2] << 16) | ((uint32_t)pc[3] << 24);
+        bw[k] = (uint32_t)pr[0] | ((uint32_t)pr[1] << 8) | ((uint32_t)pr[2] << 16) | ((uint32_t)pr[3] << 24);
+      }
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int blk = (row >> 3) * 2 + (k >> 1);
@@ -52,4 +63,16 @@ WH_HDFN void wh_vaa_mb (const WH_G uint8_t* cur, const WH_G uint8_t* ref, int xy
   if (o.sum16) ((WH_G int32_t*)o.sum16)[xy] = sum;
   if (o.sqsum16) ((WH_G int32_t*)o.sqsum16)[xy] = sqsum;
   if (o.ssd16) ((WH_G int32_t*)o.ssd16)[xy] = ssd;
+}
+WH_HDFN void wh_vaa_mb (const WH_G uint8_t* cur, const WH_G uint8_t* ref, int xy, const WhVaaOut& o) {
+  wh_vaa_mb_at<true> (cur + (size_t)xy * WH_SRC_MB_BYTES, ref + (size_t)xy * WH_SRC_MB_BYTES, 16, xy, o);
+}
+// A picture whose width is no multiple of 16, exactly as the C functions walk it: they step from one macroblock row to the next by
+// 16 * stride - width (vaacalcfuncs.cpp:46,145-146 and the same lines of the other four variants), so row i begins (width & 15) * i
+// samples to the LEFT of the picture's column 0 -- in the stride padding of the line before, and further in that line's samples.  The
+// two luma planes are here as the caller has them (`stride` bytes per line, padding bytes included); macroblock (j, i) of the
+// (width >> 4) x (height >> 4) the functions cover; results at the MB-aligned picture's index i * mb_w + j like the tiled walk's.
+WH_HDFN void wh_vaa_mb_skewed (const WH_G uint8_t* cur, const WH_G uint8_t* ref, int stride, int width, int mb_w, int j, int i, const WhVaaOut& o) {
+  const size_t off = (size_t)i * (size_t) (16 * stride - (width & 15)) + (size_t)j * 16;
+  wh_vaa_mb_at<false> (cur + off, ref + off, (size_t)stride, i * mb_w + j, o);
 }

@@ -260,6 +260,11 @@ class EmuBackend : public Backend {
     const WhVaaOut o = {sad8x8, sd8x8, mad8x8, sum16, sqsum16, ssd16};
     for (int xy = 0; xy < P.mb_w * P.mb_h; ++xy) wh_vaa_mb (cur, ref, xy, o);
   }
+  void run_vaa_skewed (const WhSeqParams& P, const uint8_t* cur, const uint8_t* ref, int stride, int width, int height, int32_t* sad8x8, int32_t* sd8x8, uint8_t* mad8x8,
+                       int32_t* sum16, int32_t* sqsum16, int32_t* ssd16) override {
+    const WhVaaOut o = {sad8x8, sd8x8, mad8x8, sum16, sqsum16, ssd16};
+    for (int i = 0; i < (height >> 4); ++i) for (int j = 0; j < (width >> 4); ++j) wh_vaa_mb_skewed (cur, ref, stride, width, P.mb_w, j, i, o);
+  }
   void run_compact (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
     for (int j = 0; j < n; ++j) {
       if (!jobs[j].compact || !jobs[j].compact_off) continue;
