@@ -346,6 +346,18 @@ typedef struct WelsHipVaaJob {
   int32_t* pFrameSad;
 } WelsHipVaaJob;
 int  WelsHipFrameVaa (WelsHipFrameCtx* pCtx, const WelsHipVaaJob* pJob);
+/* Background detection (CBackgroundDetection::Process, codec/processing/src/backgrounddetection/BackgroundDetection.cpp:52-85: what
+ * CWelsPreProcess::BackgroundDetection runs right after VaaCalculation, wels_preprocess.cpp:286-301,713-761) of the picture pair the LAST
+ * WelsHipFrameVaa call of this context analysed with bCalcBgd: the statistics and the two pictures are still on the device.
+ * pBackgroundMbFlag [((iPicWidth + 15) >> 4) per row] receives the flag of every macroblock of the (iPicWidth >> 4) x (iPicHeight >> 4)
+ * the reference covers; the others are left alone.  WELSHIP_ERR_UNSUPPORTED (the caller runs its C function) when the last call was for
+ * another pair, without bCalcBgd, or for a width that is no multiple of 16. */
+typedef struct WelsHipBgdJob {
+  const uint8_t* pCur[3]; const uint8_t* pRef[3];     /* the planes handed to that WelsHipFrameVaa call (identify the pair; not read)    */
+  int32_t iPicWidth, iPicHeight;
+  int8_t* pBackgroundMbFlag;
+} WelsHipBgdJob;
+int  WelsHipFrameBgd (WelsHipFrameCtx* pCtx, const WelsHipBgdJob* pJob);
 int  WelsHipFrameCtxCreate (WelsHipFrameCtx** ppCtx, const WelsHipFrameCfg* pCfg);
 void WelsHipFrameCtxDestroy (WelsHipFrameCtx* pCtx);
 /* Runs the picture (or MB range) on the device and waits; *ppRecords = WhMbRecord[mb_w * mb_h] in host memory, valid until

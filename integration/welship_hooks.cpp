@@ -82,11 +82,12 @@ struct HipApi {
   int (*FrameGetPicture) (WelsHipFrameCtx*, int, uint8_t* const*, const int32_t*);
   int (*FrameGetMbStates) (WelsHipFrameCtx*, int, void*, size_t);
   int (*DownsamplePicture) (int, uint8_t* const*, const int32_t*, int32_t, int32_t, const uint8_t* const*, const int32_t*, int32_t, int32_t);      // optional
-  int (*FrameVaa) (WelsHipFrameCtx*, const WelsHipVaaJob*);                                                                                         // optional
+  int (*FrameVaa) (WelsHipFrameCtx*, const WelsHipVaaJob*);
+  int (*FrameBgd) (WelsHipFrameCtx*, const WelsHipBgdJob*);                                                                                         // optional
   const char* (*GetLastError) (void);
   bool ok;
 };
-HipApi g_api = { NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, false };
+HipApi g_api = { NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, false };
 bool LoadApi() {
   static std::mutex mu;                  // several encoders of one process may be initialised at once
   std::lock_guard<std::mutex> lock (mu);
@@ -101,6 +102,7 @@ bool LoadApi() {
   g_api.FrameGetMbStates = (int (*) (WelsHipFrameCtx*, int, void*, size_t))dlsym (h, "WelsHipFrameGetMbStates");
   g_api.GetLastError = (const char* (*) (void))dlsym (h, "WelsHipGetLastError");
   g_api.FrameVaa = (int (*) (WelsHipFrameCtx*, const WelsHipVaaJob*))dlsym (h, "WelsHipFrameVaa");
+  g_api.FrameBgd = (int (*) (WelsHipFrameCtx*, const WelsHipBgdJob*))dlsym (h, "WelsHipFrameBgd");
   g_api.DownsamplePicture = (int (*) (int, uint8_t* const*, const int32_t*, int32_t, int32_t, const uint8_t* const*, const int32_t*, int32_t, int32_t))dlsym (h, "WelsHipDownsamplePicture");
   g_api.ok = g_api.FrameCtxCreate && g_api.FrameCtxDestroy && g_api.FrameEncode && g_api.FrameGetPicture && g_api.FrameGetMbStates && g_api.GetLastError;
   return g_api.ok;
@@ -141,6 +143,7 @@ struct HipLayer {                       // one spatial layer = one device contex
   std::vector<WhMbState> states;         // lower layers of a multi-layer session: the device's motion data, for the layer above
   // WELS_HIP_CHECK_VAA=1: what the device computed for this picture's pre-analysis, compared in HipFrameMd with what the reference's own
   // C functions then left in pVaa (the hook lets them run as well)
+  std::vector<int8_t> bgd_copy;          // WELS_HIP_CHECK_BGD=1: the device's flags of the picture about to be coded
   struct VaaCopy { bool valid = false; int n = 0, bgd = 0, var = 0, ssd = 0, frame_sad = 0; std::vector<int32_t> sad, sd, sum, sq, ssd16; std::vector<uint8_t> mad; } vaa_copy;
   std::vector<WelsHipMbReencode> reencode;   // macroblocks of the picture being coded that were coded again at a higher QP (TRY_REENCODING)
 };
@@ -155,6 +158,10 @@ struct HipState {
   // entropy coding from the records
   bool timing = false;
   bool vaa_check = false;               // WELS_HIP_CHECK_VAA=1
+  bool bgd = true;                      // background detection on the device (WELS_HIP_BGD=0: the VP library's function)
+  int last_vaa_did = -1;                // the layer HipVaaCalc has just served: HipBgd follows it for the same picture pair
+  long bgd_done = 0;
+  bool bgd_check = false;               // WELS_HIP_CHECK_BGD=1: the VP library's function runs as well and HipFrameMd compares the flags
   bool vaa = true;                      // WELS_HIP_VAA=0: the pre-analysis statistics (VaaCalculation) stay the reference's C functions
   long vaa_done = 0;
   bool downsample = true;               // WELS_HIP_DOWNSAMPLE=0: the spatial layers are down-sampled by the reference's own C functions
@@ -290,6 +297,7 @@ int32_t HipVaaCalc (sWelsEncCtx* pCtx, int32_t iDid, SPicture* pCurPic, SPicture
   }
   pRes->pCurY = pCurPic->pData[0]; pRes->pRefY = pRefPic->pData[0];         // (what VaaCalculation / CVAACalculation::Process leave there)
   ++st->vaa_done;
+  st->last_vaa_did = iDid;
   if (st->vaa_check) {
     HipLayer::VaaCopy& V = st->layer[iDid].vaa_copy;
     const int n = (job.iPicWidth >> 4) * (job.iPicHeight >> 4);
@@ -302,6 +310,37 @@ int32_t HipVaaCalc (sWelsEncCtx* pCtx, int32_t iDid, SPicture* pCurPic, SPicture
     return 1;                 // the C functions run as well; HipFrameMd compares
   }
   if (st->trace) fprintf (stderr, "welship hooks: pre-analysis statistics of layer %d on the device (bgd %d var %d ssd %d)\n", iDid, job.bCalcBgd, job.bCalcVar, job.bCalcSsd);
+  return 0;
+}
+
+// CWelsPreProcess::BackgroundDetection (wels_preprocess.cpp:713-761) of the picture pair HipVaaCalc has just analysed: the in-place pass of
+// BackgroundDetection.cpp:333-374 on the device, from the statistics that are still there.  Non-zero: the VP library's function runs.
+int32_t HipBgd (sWelsEncCtx* pCtx, SVAAFrameInfo* pVaaInfo, SPicture* pCurPic, SPicture* pRefPic) {
+  HipState* st = (HipState*)pCtx->pFuncList->pHipState;
+  if (st == NULL || st->failed || !st->bgd || !g_api.FrameBgd || st->vaa_check) return 1;
+  for (int i = 0; i < MAX_DEPENDENCY_LAYER; ++i) st->layer[i].bgd_copy.clear();
+  const int did = st->last_vaa_did;
+  st->last_vaa_did = -1;
+  if (did < 0 || st->layer[did].ctx == NULL) return 1;       // (the statistics of this call's pictures came from the C functions)
+  WelsHipBgdJob job;
+  memset (&job, 0, sizeof (job));
+  for (int i = 0; i < 3; ++i) { job.pCur[i] = pCurPic->pData[i]; job.pRef[i] = pRefPic->pData[i]; }
+  job.iPicWidth = pCurPic->iWidthInPixel; job.iPicHeight = pCurPic->iHeightInPixel;
+  job.pBackgroundMbFlag = pVaaInfo->pVaaBackgroundMbFlag;
+  if (st->bgd_check) {         // into a copy of the caller's array (entries outside the covered area keep their values in both)
+    const size_t n = (size_t) ((job.iPicWidth + 15) >> 4) * ((job.iPicHeight + 15) >> 4);
+    st->layer[did].bgd_copy.assign (pVaaInfo->pVaaBackgroundMbFlag, pVaaInfo->pVaaBackgroundMbFlag + n);
+    job.pBackgroundMbFlag = st->layer[did].bgd_copy.data();
+  }
+  const int rc = g_api.FrameBgd (st->layer[did].ctx, &job);
+  if (rc != 0) {
+    st->layer[did].bgd_copy.clear();
+    if (st->trace) fprintf (stderr, "welship hooks: background detection of layer %d stays on the host (%d: %s)\n", did, rc, g_api.GetLastError());
+    return 1;
+  }
+  ++st->bgd_done;
+  if (st->bgd_check) return 1;             // the VP library's function runs as well; HipFrameMd compares
+  if (st->trace) fprintf (stderr, "welship hooks: background detection of layer %d on the device\n", did);
   return 0;
 }
 
@@ -330,6 +369,12 @@ int32_t HipFrameMd (sWelsEncCtx* pCtx) {
       st->failed = true; return ENC_RETURN_UNEXPECTED;
     }
     if (st->trace) fprintf (stderr, "welship hooks: the device's pre-analysis equals the reference's\n");
+  }
+  if (!L.bgd_copy.empty()) {   // WELS_HIP_CHECK_BGD=1: the device's background flags against the VP library's
+    const bool same = memcmp (L.bgd_copy.data(), pCtx->pVaa->pVaaBackgroundMbFlag, L.bgd_copy.size()) == 0;
+    L.bgd_copy.clear();
+    if (!same) { fprintf (stderr, "welship hooks: the device's background detection differs from the reference's (layer %d)\n", did); st->failed = true; return ENC_RETURN_UNEXPECTED; }
+    if (st->trace) fprintf (stderr, "welship hooks: the device's background detection equals the reference's\n");
   }
   L.gom = !FrameConstantQp (pCtx);
   L.reencode.clear();
@@ -912,6 +957,7 @@ void WelsHipInstall (SWelsFuncPtrList* pFuncList, SWelsSvcCodingParam* pParam) {
   pFuncList->pfHipDownsample = NULL;
   pFuncList->pfHipVaaCalc = NULL;
   pFuncList->pfHipFetchRecon = NULL;
+  pFuncList->pfHipBgd = NULL;
   pFuncList->pHipState = NULL;
   const char* off = getenv ("WELS_HIP");
   if (off && atoi (off) == 0) return;
@@ -949,6 +995,8 @@ void WelsHipInstall (SWelsFuncPtrList* pFuncList, SWelsSvcCodingParam* pParam) {
   st->downsample = !(getenv ("WELS_HIP_DOWNSAMPLE") != NULL && atoi (getenv ("WELS_HIP_DOWNSAMPLE")) == 0);
   st->vaa = !(getenv ("WELS_HIP_VAA") != NULL && atoi (getenv ("WELS_HIP_VAA")) == 0);
   st->vaa_check = getenv ("WELS_HIP_CHECK_VAA") != NULL && atoi (getenv ("WELS_HIP_CHECK_VAA")) != 0;
+  st->bgd = st->vaa && !(getenv ("WELS_HIP_BGD") != NULL && atoi (getenv ("WELS_HIP_BGD")) == 0);
+  st->bgd_check = getenv ("WELS_HIP_CHECK_BGD") != NULL && atoi (getenv ("WELS_HIP_CHECK_BGD")) != 0;
   pFuncList->pHipState = st;
   pFuncList->pfHipFrameMd = HipFrameMd;
   pFuncList->pfHipCodeSlice = HipCodeSlice;
@@ -956,6 +1004,7 @@ void WelsHipInstall (SWelsFuncPtrList* pFuncList, SWelsSvcCodingParam* pParam) {
   pFuncList->pfHipDownsample = HipDownsample;
   pFuncList->pfHipVaaCalc = HipVaaCalc;
   pFuncList->pfHipFetchRecon = HipFetchRecon;
+  pFuncList->pfHipBgd = HipBgd;
   if (st->trace) fprintf (stderr, "welship hooks: installed\n");
 }
 

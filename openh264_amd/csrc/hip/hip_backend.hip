@@ -22,6 +22,7 @@
 #include "../kernels/expand_pic.h"
 #include "../kernels/tile_pic.h"
 #include "../kernels/vaa_pic.h"
+#include "../kernels/bgd_pic.h"
 #include "../kernels/scene_pic.h"
 #include "../common/compact.h"
 
@@ -718,6 +719,22 @@ __global__ __launch_bounds__ (64) void k_vaa_skewed (int vw, int vh, int mb_w, i
   if (t < vw * vh) wh_vaa_mb_skewed ((const WH_G uint8_t*)cur, (const WH_G uint8_t*)ref, stride, width, mb_w, t % vw, t / vw, o);
 }
 
+// Background detection (kernels/bgd_pic.h): ONE workgroup per picture walks the diagonals of the in-place pass, verdicts in LDS.
+__global__ __launch_bounds__ (256) void k_bgd (WhBgdIn I, int8_t* mbflag) {
+  extern __shared__ __align__ (16) uint8_t bgd_fl[];
+  const int n = I.w * I.h;
+  for (int k = (int)threadIdx.x; k < n; k += (int)blockDim.x) bgd_fl[k] = (uint8_t)wh_bgd_coarse (wh_bgd_ou (I, k % I.w, k / I.w));
+  __syncthreads();
+  const int steps = wh_bgd_steps (I.w, I.h);
+  for (int t = 0; t < steps; ++t) {
+    for (int j = (int)threadIdx.x; j < I.h; j += (int)blockDim.x) {
+      const int i = t - 2 * j;
+      if (i >= 0 && i < I.w) wh_bgd_step (I, bgd_fl, (WH_G int8_t*)mbflag, i, j);
+    }
+    __syncthreads();
+  }
+}
+
 // Scene-change statistic: one wavefront per 16x16 region of the source picture.
 __global__ __launch_bounds__ (64) void k_scene (WhSeqParams P, const WhPicJob* jobs) {
   const WhPicJob J = jobs[blockIdx.y];
@@ -990,6 +1007,15 @@ class HipBackend : public wh::Backend {
     const WhVaaOut o = {sad8x8, sd8x8, mad8x8, sum16, sqsum16, ssd16};
     const int vw = width >> 4, vh = height >> 4;
     hipLaunchKernelGGL (k_vaa_skewed, dim3 ((vw * vh + 63) / 64), dim3 (64), 0, stream_, vw, vh, P.mb_w, stride, width, cur, ref, o);
+    HIP_TRY (hipGetLastError());
+  }
+  void run_bgd (const WhSeqParams& P, const uint8_t* cur, const uint8_t* ref, const int32_t* sad8x8, const int32_t* sd8x8, const uint8_t* mad8x8, int units_w, int units_h,
+                int8_t* flags) override {
+    if (!cur || !ref || !sad8x8 || !sd8x8 || !mad8x8 || !flags) { note_null(); return; }
+    const WhBgdIn in = {sad8x8, sd8x8, mad8x8, cur, ref, units_w, units_h, P.mb_w};
+    const size_t lds = (size_t)units_w * units_h;
+    HIP_TRY (hipFuncSetAttribute ((const void*)k_bgd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL (k_bgd, dim3 (1), dim3 (256), lds, stream_, in, flags);
     HIP_TRY (hipGetLastError());
   }
   void run_compact (const WhSeqParams& P, const WhPicJob* jobs, int n) override {

@@ -28,6 +28,10 @@ class Backend {
   // caller has them, `stride` bytes per line; the (width >> 4) x (height >> 4) macroblocks the C functions cover
   virtual void run_vaa_skewed (const WhSeqParams& P, const uint8_t* cur, const uint8_t* ref, int stride, int width, int height, int32_t* sad8x8, int32_t* sd8x8,
                                uint8_t* mad8x8, int32_t* sum16, int32_t* sqsum16, int32_t* ssd16) = 0;
+  // background detection of the picture the statistics above belong to (kernels/bgd_pic.h): units = (width >> 4) x (height >> 4) macroblocks,
+  // `flags` [row of mb_w][unit] on the device; the statistics arrays are the ones run_vaa wrote
+  virtual void run_bgd (const WhSeqParams& P, const uint8_t* cur, const uint8_t* ref, const int32_t* sad8x8, const int32_t* sd8x8, const uint8_t* mad8x8,
+                        int units_w, int units_h, int8_t* flags) = 0;
   // page-lock a host buffer that is the target of many downloads (best effort; no-op where it does not apply)
   virtual void pin_host (void* p, size_t bytes) { (void)p; (void)bytes; }
   virtual void unpin_host (void* p) { (void)p; }

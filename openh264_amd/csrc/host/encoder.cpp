@@ -1722,6 +1722,10 @@ struct WelsHipFrameCtx {
   std::vector<uint8_t> h_src;
   WhMbRecord* d_records = nullptr;
   uint8_t* d_rec_blk = nullptr;       // (SessionCore::d_rec_blk)
+  // what the last WelsHipFrameVaa call left on the device for WelsHipFrameBgd: the pair's keys and pool slots, whether the background statistics were computed
+  const void* vaa_cur_key = nullptr; const void* vaa_ref_key = nullptr; int vaa_cslot = -1, vaa_rslot = -1, vaa_queue = 0; bool vaa_has_bgd = false;
+  int8_t* d_bgd_calc = nullptr;       // WelsHipFrameBgd's result (one flag per macroblock)
+  std::vector<int8_t> h_bgd_calc;
   uint8_t* d_skew = nullptr;          // pre-analysis of a picture whose width is no multiple of 16: the two luma planes at the caller's stride (WelsHipFrameVaa)
   std::vector<uint8_t> h_skew;
   size_t skew_bytes = 0;
@@ -1788,12 +1792,13 @@ struct WelsHipFrameCtx {
     d_src = nullptr;
     if (!h_vaa_out.empty()) be->unpin_host (h_vaa_out.data());
     if (!h_skew.empty()) be->unpin_host (h_skew.data());
+    if (!h_bgd_calc.empty()) be->unpin_host (h_bgd_calc.data());
     if (!h_compact.empty()) be->unpin_host (h_compact.data());
     if (!h_coff.empty()) be->unpin_host (h_coff.data());
     if (d_compact) be->free (d_compact);
     if (d_compact_off) be->free (d_compact_off);
     d_compact = nullptr; d_compact_off = nullptr;
-    void* ptrs[] = {d_vaa_out, d_skew, d_src_planar, d_records, d_rec_blk, d_dbflags, d_mb_ctl, d_sad_cost0, d_vaa, d_bgd, d_il, d_job, d_scc, d_scc_idc, d_scc_ori, d_scc_chain, d_scc_lists, d_scc_loc, d_scc_order, d_scc_chain_mb, d_gom_rc, d_sad_cost0_new};
+    void* ptrs[] = {d_vaa_out, d_bgd_calc, d_skew, d_src_planar, d_records, d_rec_blk, d_dbflags, d_mb_ctl, d_sad_cost0, d_vaa, d_bgd, d_il, d_job, d_scc, d_scc_idc, d_scc_ori, d_scc_chain, d_scc_lists, d_scc_loc, d_scc_order, d_scc_chain_mb, d_gom_rc, d_sad_cost0_new};
     if (!h_gom.empty()) be->unpin_host (h_gom.data());
     if (!h_scc.empty()) be->unpin_host (h_scc.data());
     if (!h_scc_small.empty()) be->unpin_host (h_scc_small.data());
@@ -2587,6 +2592,7 @@ int WelsHipFrameVaa (WelsHipFrameCtx* c, const WelsHipVaaJob* j) {
     }
     if (be->sync_queue (queue)) { set_err ("device error in the pre-analysis"); return WELSHIP_ERR_UNKNOWN; }
     c->fresh_key = nullptr;              // (the picture itself was not put on the device in the encoder's layout: the encode call uploads it)
+    c->vaa_cur_key = nullptr; c->vaa_has_bgd = false;
   } else {
   // Host-side work -- the reference's checksum, staging into this context's own page-locked buffer -- happens OUTSIDE the device-wide lock
   // (other sessions keep submitting meanwhile); the lock covers queue selection and the enqueues only.  The source pool is the context's own.
@@ -2628,6 +2634,7 @@ int WelsHipFrameVaa (WelsHipFrameCtx* c, const WelsHipVaaJob* j) {
   lock.unlock();
   if (be->sync_queue (queue)) { set_err ("device error in the pre-analysis"); return WELSHIP_ERR_UNKNOWN; }
   c->fresh_key = (const void*)j->pCur[0];
+  c->vaa_cur_key = (const void*)j->pCur[0]; c->vaa_ref_key = (const void*)j->pRef[0]; c->vaa_cslot = cslot; c->vaa_rslot = rslot; c->vaa_queue = queue; c->vaa_has_bgd = want_sd;
   }
   // results: the macroblocks the C functions cover, row by row; the frame SAD is their sum
   const uint8_t* h = c->h_vaa_out.data();
@@ -2642,6 +2649,35 @@ int WelsHipFrameVaa (WelsHipFrameCtx* c, const WelsHipVaaJob* j) {
     if (want_ssd) memcpy (j->pSsd16x16 + d, (const int32_t*) (h + o_ssd) + a, sizeof (int32_t) * vw);
   }
   *j->pFrameSad = (int32_t)frame_sad;
+  return WELSHIP_OK;
+}
+
+int WelsHipFrameBgd (WelsHipFrameCtx* c, const WelsHipBgdJob* j) {
+  if (!c || !c->be || !j || !j->pBackgroundMbFlag) return WELSHIP_ERR_INIT_PARA;
+  const int uw = j->iPicWidth >> 4, uh = j->iPicHeight >> 4;
+  if ((j->iPicWidth & 15) || uw < 1 || uh < 1 || uw > c->mb_w || uh > c->mb_h || (size_t)uw * uh > 65536) { set_err ("background detection: picture size (width a multiple of 16, at most 65536 units)"); return WELSHIP_ERR_UNSUPPORTED; }
+  if (!c->vaa_has_bgd || c->vaa_cur_key == nullptr || c->vaa_cur_key != (const void*)j->pCur[0] || c->vaa_ref_key != (const void*)j->pRef[0] || !c->d_vaa_out ||
+      c->src_find (c->vaa_cur_key) != c->vaa_cslot || c->src_find (c->vaa_ref_key) != c->vaa_rslot) {
+    set_err ("background detection: the statistics of this picture pair are not on the device"); return WELSHIP_ERR_UNSUPPORTED;
+  }
+  wh::Backend* be = c->be;
+  const size_t n = (size_t)c->num_mb;
+  const uint8_t* o = c->d_vaa_out;                  // (WelsHipFrameVaa's layout)
+  {
+    std::unique_lock<std::mutex> lock (c->sh->mu);
+    if (!c->d_bgd_calc) {
+      c->d_bgd_calc = (int8_t*)be->alloc (n);
+      c->h_bgd_calc.assign (n, 0);
+      be->pin_host (c->h_bgd_calc.data(), n);
+      if (!c->d_bgd_calc) { set_err ("out of device memory"); return WELSHIP_ERR_MEMORY; }
+    }
+    be->select_queue (c->vaa_queue);
+    be->run_bgd (c->seq, c->src_pool[c->vaa_cslot].d, c->src_pool[c->vaa_rslot].d, (const int32_t*) (o + 0), (const int32_t*) (o + 16 * n), o + 44 * n, uw, uh, c->d_bgd_calc);
+    be->download (c->h_bgd_calc.data(), c->d_bgd_calc, n);
+  }
+  if (be->sync_queue (c->vaa_queue)) { set_err ("device error in the background detection"); return WELSHIP_ERR_UNKNOWN; }
+  const int row = (j->iPicWidth + 15) >> 4;
+  for (int y = 0; y < uh; ++y) memcpy (j->pBackgroundMbFlag + (size_t)y * row, c->h_bgd_calc.data() + (size_t)y * c->mb_w, (size_t)uw);
   return WELSHIP_OK;
 }
 

@@ -17,6 +17,7 @@
 #include "../../openh264_amd/csrc/kernels/expand_pic.h"
 #include "../../openh264_amd/csrc/kernels/tile_pic.h"
 #include "../../openh264_amd/csrc/kernels/vaa_pic.h"
+#include "../../openh264_amd/csrc/kernels/bgd_pic.h"
 #include "../../openh264_amd/csrc/kernels/scene_pic.h"
 #include "../../openh264_amd/csrc/common/compact.h"
 #include "../../openh264_amd/csrc/kernels/downsample_px.h"
@@ -264,6 +265,15 @@ class EmuBackend : public Backend {
                        int32_t* sum16, int32_t* sqsum16, int32_t* ssd16) override {
     const WhVaaOut o = {sad8x8, sd8x8, mad8x8, sum16, sqsum16, ssd16};
     for (int i = 0; i < (height >> 4); ++i) for (int j = 0; j < (width >> 4); ++j) wh_vaa_mb_skewed (cur, ref, stride, width, P.mb_w, j, i, o);
+  }
+  void run_bgd (const WhSeqParams& P, const uint8_t* cur, const uint8_t* ref, const int32_t* sad8x8, const int32_t* sd8x8, const uint8_t* mad8x8, int units_w, int units_h,
+                int8_t* flags) override {
+    // the device's schedule: the units of one diagonal (i + 2 j) in any order -- here from the bottom up, the opposite of the raster pass
+    const WhBgdIn in = {sad8x8, sd8x8, mad8x8, cur, ref, units_w, units_h, P.mb_w};
+    std::vector<uint8_t> fl ((size_t)units_w * units_h);
+    for (int k = 0; k < units_w * units_h; ++k) fl[k] = (uint8_t)wh_bgd_coarse (wh_bgd_ou (in, k % units_w, k / units_w));
+    for (int t = 0; t < wh_bgd_steps (units_w, units_h); ++t)
+      for (int j = units_h - 1; j >= 0; --j) { const int i = t - 2 * j; if (i >= 0 && i < units_w) wh_bgd_step (in, fl.data(), flags, i, j); }
   }
   void run_compact (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
     for (int j = 0; j < n; ++j) {

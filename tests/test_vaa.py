@@ -145,3 +145,45 @@ def test_hooked_sessions_of_odd_widths_on_emulation(emu_lib, tmp_path):
 @pytest.mark.gpu
 def test_hooked_sessions_of_odd_widths_on_the_mi355x(hip_lib, tmp_path):
     _hooked_sessions_of_odd_widths(hip_lib, tmp_path)
+
+
+def _hooked_background_detection(lib, tmp_path):
+    """CWelsPreProcess::BackgroundDetection on the device (WelsHipFrameBgd, kernels/bgd_pic.h: the in-place raster pass of
+    BackgroundDetection.cpp:333-374 walked diagonal by diagonal), from the statistics the pre-analysis call left there.  WELS_HIP_CHECK_BGD=1
+    makes the hook run the VP library's function as well and compare every macroblock's flag; without it the streams must be the reference's."""
+    import subprocess
+    from openh264_amd.utils.synth import synth_sequence
+    refdir = os.path.join(ROOT, "oracle", "_ref")
+    if not os.path.exists(os.path.join(refdir, "ref_enc_hip")):
+        pytest.skip("oracle/_ref (hooked reference) not built")
+    clips = []
+    src = str(tmp_path / "s.yuv")
+    open(src, "wb").write(synth_sequence(320, 192, 8))
+    clips.append((src, 320, 192))
+    cam = os.path.join(refdir, "res", "CiscoVT2people_320x192_12fps.yuv")
+    if os.path.exists(cam):
+        clips.append((cam, 320, 192))
+    for (src, w, h) in clips:
+        outs = []
+        for exe, env in (("ref_enc", dict(os.environ)), ("ref_enc_hip", dict(os.environ, WELSHIP_LIB=lib, WELS_HIP_TRACE="1", WELS_HIP_CHECK_BGD="1")),
+                         ("ref_enc_hip", dict(os.environ, WELSHIP_LIB=lib, WELS_HIP_TRACE="1"))):
+            out = str(tmp_path / (exe + ".264"))
+            p = subprocess.run([os.path.join(refdir, exe), "-i", src, "-w", str(w), "-h", str(h), "-o", out, "-quiet", "-rc", "1", "-bitrate", "300000", "-bgd", "1",
+                                "-scene", "1", "-frames", "24"], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+            err = p.stderr.decode(errors="replace")
+            assert p.returncode == 0 and "differs" not in err, err[-1500:]
+            if "WELS_HIP_CHECK_BGD" in env:
+                assert err.count("the device's background detection equals the reference's") >= 5, err[-1500:]
+            elif exe == "ref_enc_hip":
+                assert err.count("background detection of layer 0 on the device") >= 5 and "background detection of layer 0 stays" not in err, err[-1500:]
+            outs.append(open(out, "rb").read())
+        assert outs[0] == outs[1] == outs[2] and len(outs[0]) > 500
+
+
+def test_hooked_background_detection_on_emulation(emu_lib, tmp_path):
+    _hooked_background_detection(emu_lib, tmp_path)
+
+
+@pytest.mark.gpu
+def test_hooked_background_detection_on_the_mi355x(hip_lib, tmp_path):
+    _hooked_background_detection(hip_lib, tmp_path)
