@@ -991,6 +991,7 @@ class HipBackend : public wh::Backend {
     HIP_TRY (hipSetDevice (dev_));
     HIP_TRY (hipMemcpyAsync (dst, src, bytes, hipMemcpyDeviceToHost, streams_[(q < 0 ? 0 : q) % WH_NUM_QUEUES]));
   }
+  void err_snapshot (int q, uint32_t* dst) override { if (dst && usable()) { HIP_TRY (hipSetDevice (dev_)); q = (q < 0 ? 0 : q) % WH_NUM_QUEUES; HIP_TRY (hipMemcpyAsync (dst, err_ + WH_ERR_WORDS * q, 4 * WH_ERR_WORDS, hipMemcpyDeviceToHost, streams_[q])); } }
   void event_record_on (int q, void* ev) override { if (ev) { HIP_TRY (hipSetDevice (dev_)); HIP_TRY (hipEventRecord ((hipEvent_t)ev, streams_[(q < 0 ? 0 : q) % WH_NUM_QUEUES])); } }
   void queue_wait_event (int q, void* ev) override { if (ev) { HIP_TRY (hipSetDevice (dev_)); HIP_TRY (hipStreamWaitEvent (streams_[(q < 0 ? 0 : q) % WH_NUM_QUEUES], (hipEvent_t)ev, 0)); } }
   void event_wait (void* ev) override { if (ev) { HIP_TRY (hipSetDevice (dev_)); HIP_TRY (hipEventSynchronize ((hipEvent_t)ev)); } }

@@ -64,6 +64,9 @@ class Backend {
   // and uploads the next step's pictures on worker threads while another thread downloads and entropy-codes the previous step's) ----
   virtual void upload_on (int q, void* dst, const void* src, size_t bytes) = 0;
   virtual void download_on (int q, void* dst, const void* src, size_t bytes) = 0;
+  // queue q's error words as they are once everything queued so far has run, into `dst` (page-locked, 4 words): lets a caller that waits for an event
+  // on q -- not for the whole queue -- see whether the kernels up to here timed out (sync_queue reads and resets the words themselves)
+  virtual void err_snapshot (int q, uint32_t* dst) { (void)q; if (dst) dst[0] = 0; }
   virtual void event_record_on (int q, void* ev) = 0;
   virtual void event_wait (void* ev) = 0;                    // the host waits for the event
   virtual void queue_wait_event (int q, void* ev) = 0;       // queue q waits (on the device) for the event

@@ -1636,6 +1636,8 @@ struct FrameLane {             // one launch set in flight: its queue and its jo
   WhPicJob* d_jobs = nullptr;
   int jobs_cap = 0;
   std::vector<WhPicJob> h_jobs;          // page-locked
+  void* tail_ev = nullptr;               // marks "the records of this launch set are on the host": what the callers wait for (frame_run_batch)
+  std::vector<uint32_t> h_err;           // page-locked: the queue's error words at that point
 };
 #define WH_FRAME_LANES 2
 struct FrameKey {              // pictures that can share a launch: same sequence parameters, type and passes
@@ -1747,6 +1749,9 @@ struct WelsHipFrameCtx {
   FrameKey* last_key = nullptr;          // the key of this context's last picture, and when it was submitted (FrameShared::gather_us)
   std::chrono::steady_clock::time_point last_submit;
   int queue() const { return last_key ? last_key->queue : 0; }
+  int tail_queue = -1;                   // the queue on which this context's last picture is still being deblocked / expanded (frame_run_batch), or -1
+  // whatever touches this context's pictures on another queue comes after that tail (the caller has selected its queue)
+  void join_tail (int on_queue) { if (tail_queue >= 0 && tail_queue != on_queue) be->queue_wait (tail_queue); }
   uint32_t* d_dbflags = nullptr;
   uint32_t db_gen = 0;
   WhMbCtl* d_mb_ctl = nullptr;
@@ -1888,6 +1893,7 @@ void frame_run_batch (FrameShared* sh, FrameKey* K, FrameLane* L, std::unique_lo
   const int n = (int)batch.size();
   be->select_queue (L->queue);
   be->queue_wait (K->queue);        // the pictures' inputs were uploaded on the key's queue (which carries nothing else: a lane never waits for the other lane's kernels)
+  for (FrameItem* x : batch) x->c->join_tail (L->queue);      // a context's previous picture may still be in its deblocking pass on the other lane's queue
   if (n > L->jobs_cap) {
     if (L->d_jobs) be->free (L->d_jobs);
     if (!L->h_jobs.empty()) be->unpin_host (L->h_jobs.data());
@@ -1920,8 +1926,6 @@ void frame_run_batch (FrameShared* sh, FrameKey* K, FrameLane* L, std::unique_lo
       be->run_inter (sq, L->d_jobs, n);
     } else be->run_intra (s, L->d_jobs, n);
     if (K->qp_map) be->run_qp_chain (s, L->d_jobs, n);
-    if (s.deblock_idc != 1) be->run_deblock (s, L->d_jobs, n);
-    if (K->expand) be->run_expand (s, L->d_jobs, n);
     if (any_packed) be->run_compact (s, L->d_jobs, n);      // (pictures without a packed stream are left alone: WhPicJob::compact == NULL)
     for (FrameItem* x : batch) {
       WelsHipFrameCtx* c = x->c;
@@ -1936,12 +1940,29 @@ void frame_run_batch (FrameShared* sh, FrameKey* K, FrameLane* L, std::unique_lo
       if (x->sad_dst) be->download (c->h_sad_out.data(), x->job.sad_cost0_out ? x->job.sad_cost0_out : x->job.sad_cost0, sizeof (int32_t) * c->num_mb);
       if (c->scc_active) be->download (c->scc_down(), c->d_scc_chain + 4 * WH_MAX_SLICES, sizeof (uint32_t) * WH_MAX_SLICES);
     }
-    const double launch_ms = std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now() - t_launch0).count();
+    // What the callers wait for ends HERE: their entropy coders need the records, nothing else.  The deblocking pass, the border expansion and
+    // the tiled twin only matter to whatever touches these pictures next -- the next launch set with one of these contexts, a
+    // reconstruction fetch -- and that is ordered behind them on the device (same queue, or WelsHipFrameCtx::join_tail from another one).
+    // The host's entropy coding of a picture (4-7 ms for 1080p) thus overlaps the 2.5 ms its filtering takes.  A time-out inside the tail
+    // shows up in the next call that synchronises this queue.  WELSHIP_FRAME_TAIL=0: wait for everything, as before round 4.
     const int q = L->queue;
+    static const bool tail_env_off = getenv ("WELSHIP_FRAME_TAIL") && atoi (getenv ("WELSHIP_FRAME_TAIL")) == 0;
+    const bool tail = !tail_env_off && (s.deblock_idc != 1 || K->expand);
+    if (tail) {
+      if (!L->tail_ev) { L->tail_ev = be->event_create(); L->h_err.assign (4, 0u); be->pin_host (L->h_err.data(), 16); }
+      be->err_snapshot (q, L->h_err.data());
+      be->event_record_on (q, L->tail_ev);
+    }
+    if (s.deblock_idc != 1) be->run_deblock (s, L->d_jobs, n);
+    if (K->expand) be->run_expand (s, L->d_jobs, n);
+    for (FrameItem* x : batch) x->c->tail_queue = tail && L->tail_ev ? q : -1;
+    const double launch_ms = std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now() - t_launch0).count();
     const unsigned swept0 = be->errors_swept();
     lock.unlock();               // other sessions stage and queue their next pictures while the device works
     const auto t_dev0 = std::chrono::steady_clock::now();
-    int bad = be->sync_queue (q);
+    int bad = 0;
+    if (tail && L->tail_ev) { be->event_wait (L->tail_ev); bad = L->h_err[0] != 0; }
+    else bad = be->sync_queue (q);
     if (be->errors_swept() != swept0) bad = 1;       // another thread's sync() found time-outs meanwhile: possibly this launch set's
     const double dev_ms = std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now() - t_dev0).count();
     lock.lock();
@@ -2105,7 +2126,7 @@ void WelsHipFrameCtxDestroy (WelsHipFrameCtx* c) {
       fprintf (stderr, "welship:   submitting (uploads under the lock): %.3f ms per picture\n", sh->stat_submit_ms / sh->batched_pictures);
     }
     for (auto& L : sh->layouts) { sh->be->free (L->d_order); sh->be->free (L->d_bands); }
-    for (auto& K : sh->keys) for (FrameLane& L : K->lane) { if (L.d_jobs) sh->be->free (L.d_jobs); if (!L.h_jobs.empty()) sh->be->unpin_host (L.h_jobs.data()); }
+    for (auto& K : sh->keys) for (FrameLane& L : K->lane) { if (L.d_jobs) sh->be->free (L.d_jobs); if (!L.h_jobs.empty()) sh->be->unpin_host (L.h_jobs.data()); if (L.tail_ev) sh->be->event_destroy (L.tail_ev); if (!L.h_err.empty()) sh->be->unpin_host (L.h_err.data()); }
     delete sh->be;
     g_frame_shared.erase (std::find (g_frame_shared.begin(), g_frame_shared.end(), sh));
     delete sh;
@@ -2323,6 +2344,7 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
   FrameKey* K = ranged ? nullptr : frame_find_key (sh, s, is_p, qp_map, j->bExpand != 0);
   const int queue = K ? K->queue : 0;
   be->select_queue (queue);
+  if (ranged) c->join_tail (queue);           // (MB ranges run on this queue; whole pictures join in frame_run_batch, on their lane's)
   if (first_part) {
     const int slot = c->src_take ((const void*)j->pSrc[0]);
     c->d_src = c->src_pool[slot].d;
@@ -2462,6 +2484,7 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
     int bad = be->sync_queue (queue);
     if (be->errors_swept() != swept0) bad = 1;       // another thread's sync() found time-outs meanwhile: possibly this range's
     lock.lock();
+    c->tail_queue = -1;                       // (this queue was waited for: nothing of the context is in flight)
     if (bad) { set_err ("device scheduler timed out or device error; the picture was not encoded"); return WELSHIP_ERR_UNKNOWN; }
     if (scr && last_part && scr->pSliceFMECostDown) memcpy (scr->pSliceFMECostDown, c->scc_down(), sizeof (uint32_t) * j->iNumSlices);
     *pp_records = c->h_records.data();
@@ -2685,6 +2708,7 @@ int WelsHipFrameGetMbStates (WelsHipFrameCtx* c, int pic, void* dst, size_t byte
   if (!c || !c->be || pic < 0 || pic >= (int)c->pics.size() || !dst || bytes < sizeof (WhMbState) * c->num_mb) return WELSHIP_ERR_INIT_PARA;
   std::unique_lock<std::mutex> lock (c->sh->mu);
   c->be->select_queue (c->queue());
+  c->join_tail (c->queue());
   c->be->download (dst, c->pics[pic].mbs, sizeof (WhMbState) * c->num_mb);
   return c->be->sync_queue (c->queue()) ? WELSHIP_ERR_UNKNOWN : WELSHIP_OK;
 }
@@ -2697,6 +2721,7 @@ int WelsHipFrameGetPicture (WelsHipFrameCtx* c, int pic, uint8_t* const dst[3], 
   if (c->h_pic_of != pic) {              // not the picture that came back with the last batch (GOM-coded pictures, older pictures)
     std::unique_lock<std::mutex> lock (c->sh->mu);
     c->be->select_queue (c->queue());
+    c->join_tail (c->queue());
     c->be->download (tmp.data(), p.base, c->rec_alloc_bytes + 128);
     if (c->be->sync_queue (c->queue())) return WELSHIP_ERR_UNKNOWN;
     c->h_pic_of = pic;
