@@ -364,3 +364,20 @@ def test_emu_whole_picture_deblocking_band(emu_lib, ref_tools, tmp_path, monkeyp
 @pytest.mark.gpu
 def test_hip_whole_picture_deblocking_band(hip_lib, ref_tools, tmp_path, monkeypatch):
     _whole_picture_band(hip_lib, ref_tools, tmp_path, monkeypatch)
+
+
+def test_emu_planar_unfiltered_reconstruction_switch(emu_lib, tmp_path):
+    """WELSHIP_REC_BLOCKS=0 (openh264_amd/csrc/host/encoder.cpp: the unfiltered reconstruction goes into the planar picture and is filtered in
+    place -- the layout before WhPicJob::rec_blk, kept for A/B runs): the same golden streams.  The switch is read once per process."""
+    import sys
+    names = [n for n in SMALL if "p_" in n or n.startswith("p")][:3] + [n for n in SMALL if n.startswith("i")][:1]
+    code = ("import sys, json, hashlib; sys.path.insert(0, %r); sys.path.insert(0, %r); import openh264_amd as oh; from openh264_amd.utils.synth import make_sequence\n"
+            "G = json.load(open(%r))\n"
+            "for n in %r:\n"
+            "    g = G[n]; yuv = make_sequence(g.get('content', 'synth'), g['w'], g['h'], g['frames']); p = dict(fMaxFrameRate=30.0, iTargetBitrate=5000000); p.update(g['params'])\n"
+            "    bs, rec = oh.encode_sequence(yuv, g['w'], g['h'], lib_path=%r, **p)\n"
+            "    assert hashlib.sha1(bs).hexdigest() == g['sha1'], n\n"
+            "print('ok', len(%r))\n") % (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden", "golden.json"), names, emu_lib, names)
+    assert len(names) >= 2
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, WELSHIP_REC_BLOCKS="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0 and b"ok" in p.stdout, p.stderr.decode(errors="replace")[-1500:]
