@@ -1961,8 +1961,11 @@ void frame_run_batch (FrameShared* sh, FrameKey* K, FrameLane* L, std::unique_lo
     lock.unlock();               // other sessions stage and queue their next pictures while the device works
     const auto t_dev0 = std::chrono::steady_clock::now();
     int bad = 0;
-    if (tail && L->tail_ev) { be->event_wait (L->tail_ev); bad = L->h_err[0] != 0; }
-    else bad = be->sync_queue (q);
+    if (tail && L->tail_ev) {
+      be->event_wait (L->tail_ev);
+      bad = L->h_err[0] != 0;
+      if (bad) (void)be->sync_queue (q);         // (reports the time-out and clears the queue's error words: the next launch set starts clean)
+    } else bad = be->sync_queue (q);
     if (be->errors_swept() != swept0) bad = 1;       // another thread's sync() found time-outs meanwhile: possibly this launch set's
     const double dev_ms = std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now() - t_dev0).count();
     lock.lock();
