@@ -181,6 +181,17 @@ def test_screen_api_hash_through_the_hooks_on_emulation(emu_lib, tmp_path, name,
 
 
 @pytest.mark.gpu
+def test_size_limited_screen_rows_on_the_mi355x(workdir, hip_lib):
+    """Slice mode 3 with screen content on the device: eight of the table's single-thread rows (one stream from the unmodified reference)."""
+    rows = _size_limited_rows()[5::16]
+    assert len(rows) == 8
+    for i, row in enumerate(rows):
+        got, pictures, err = _run_row(workdir, hip_lib, row, "dg%d" % i)
+        assert "welship hooks: installed" in err and err.count("picture complete") >= 1, err[-1500:]
+        assert got == row[0], (row[4], got)
+
+
+@pytest.mark.gpu
 def test_screen_table_rows_on_the_mi355x(workdir, hip_lib):
     _check(workdir, hip_lib, _sample(_device_rows(), 24))
 

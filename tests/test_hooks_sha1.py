@@ -6,10 +6,10 @@ test/encoder_binary_comparison/Scripts/run_BinarySHA1Comparison.sh:165-241 runs 
 layer0..3.cfg, the row's options on the command line, SHA1 of the bitstream against the table's first column.
 
 Rows the dispatch-table binding takes to the device: every option combination of the table (rate-control mode 1 and 3,
-1 and 3 temporal layers, LTR, denoising, scene-change detection, background detection, frame skipping) in slice modes
-0, 1 and 2 -- 1792 of the 2304 rows.  Size-limited slices (-slcmd 3) keep the reference's C path by default --
-the hooks report that, and the test checks that those rows are NOT counted as device rows; with WELS_HIP_DYNSLICE=1 the 256
-size-limited rows run on the device too (CPU tier only so far: the path has not been on the MI355X yet).
+1 and 3 temporal layers, LTR, denoising, scene-change detection, background detection, frame skipping) in all four slice modes.
+Slice modes 0, 1 and 2 are 1792 of the 2304 rows; the 512 size-limited rows (-slcmd 3) run on the device by default as well
+(WELS_HIP_DYNSLICE=0 hands them back to the reference's C path -- the hooks report that, and a test checks it).  A deterministic
+sample of the size-limited rows (one slice thread) sits here, early in the GPU tier; the randomised sessions are tests/test_hooks_dynslice.py.
 
 Also here: the reference's API-level golden hashes (test/api/encoder_test.cpp:104-115) and its stock testbin/welsenc.cfg
 through the same binding.
@@ -172,6 +172,20 @@ def test_gom_sessions_can_be_switched_off(emu_lib, tmp_path):
 @pytest.mark.gpu
 def test_sha1_table_rows_on_the_mi355x(workdir, hip_lib):
     _check(workdir, hip_lib, _sample(_device_rows(), 128))
+
+
+@pytest.mark.gpu
+def test_size_limited_rows_on_the_mi355x(workdir, hip_lib):
+    """Slice mode 3 on the device (the installer's default): sixteen of the table's single-thread rows -- one slice thread, so the unmodified
+    reference writes ONE stream for them and the table's hash is the only acceptable answer (DynSlcJudgeSliceBoundaryStepBack,
+    svc_encode_slice.cpp:1741-1793; WelsMdInterMbLoopOverDynamicSlice :1901-2010)."""
+    rows = _size_limited_rows()[3::16]
+    assert len(rows) == 16
+    for i, row in enumerate(rows):
+        got, pictures, err = _run_row(workdir, hip_lib, row, "dg%d" % i)
+        os.remove(str(workdir / ("t_dg%d.264" % i)))
+        assert "welship hooks: installed" in err and err.count("picture complete") >= 40, err[-1500:]
+        assert got == row[0], (row[4], got)
 
 
 @pytest.mark.gpu

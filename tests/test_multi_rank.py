@@ -126,15 +126,17 @@ def test_group_equals_single_session(emu_lib):
 
 
 @pytest.mark.gpu
-def test_hip_group_equals_single_session(hip_lib):
+def test_hip_group_equals_single_session(hip_lib, ref_tools, tmp_path):
     """The same on the MI355X: the group path copies the macroblock records back packed (k_compact, common/compact.h), the
-    single session copies them whole -- both must give the stream of the ISVCEncoder-style object."""
+    single session copies them whole -- both must give the stream of the ISVCEncoder-style object, and that stream is oracle/_ref's."""
     import openh264_amd as oh
     inputs = _inputs()
     digs = __import__("openh264_amd.parallel", fromlist=["x"]).encode_sessions_sharded(_make_group_factory(hip_lib), inputs, FRAMES)
     for s in range(SESSIONS):
         bs, _ = oh.encode_sequence(b"".join(inputs[s]), W, H, lib_path=hip_lib, iDLayerQp=26, uiIntraPeriod=0, fMaxFrameRate=30.0, iTargetBitrate=500000)
         assert hashlib.sha1(bs).hexdigest() == digs[s]
+        if ref_tools:
+            assert _reference_stream(ref_tools, tmp_path, b"".join(inputs[s]), W, H, ["-qp", 26, "-iper", 0, "-bitrate", 500000]) == bs
 
 
 def test_group_reencodes_overflowing_sessions(emu_lib):
@@ -375,9 +377,41 @@ def test_plain_p_kernel_variant_on_emulation(emu_lib):
             assert bs == got[s]
 
 
-@pytest.mark.gpu
-def test_hip_plain_p_kernel_variant(hip_lib):
-    """The same on the MI355X for the shipped library: session groups (the variant) against the single-session encoder (the general kernel)."""
+def _reference_stream(ref_tools, tmp_path, yuv, w, h, flags):
+    """The stream of oracle/_ref/ref_enc (the reference compiled by oracle/Makefile) for one input, run live."""
     import subprocess
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "plain_check.py"), hip_lib], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
-    assert out.returncode == 0 and b"identical" in out.stdout, out.stdout[-1500:]
+    fi, fo = str(tmp_path / "in.yuv"), str(tmp_path / "ref.264")
+    open(fi, "wb").write(yuv)
+    subprocess.check_call([ref_tools["enc"], "-i", fi, "-w", str(w), "-h", str(h), "-o", fo, "-rc", "-1", "-fps", "30", "-quiet"] + [str(f) for f in flags],
+                          stdout=subprocess.DEVNULL)
+    return open(fo, "rb").read()
+
+
+def _group_paths_against_the_reference(lib, ref_tools, tmp_path, w, h, frames):
+    """Session groups (the PLAIN body variants of the P kernel, packed records, the pipelined steps) against the reference itself: every
+    stream a group returns -- synchronous, pipelined, LOW and MEDIUM complexity -- must be the one oracle/_ref/ref_enc writes for that input."""
+    from openh264_amd.parallel import encode_sessions_sharded
+    inputs = _inputs()
+    digs = encode_sessions_sharded(_make_group_factory(lib), inputs, FRAMES)
+    for s in range(SESSIONS):
+        ref = _reference_stream(ref_tools, tmp_path, b"".join(inputs[s]), W, H, ["-qp", 26, "-iper", 0, "-bitrate", 500000])
+        assert hashlib.sha1(ref).hexdigest() == digs[s], "group session %d differs from oracle/_ref" % s
+    for complexity in (0, 2):
+        seqs, got = _pipelined_vs_synchronous(lib, w, h, frames, 24, ("synth", "checker5", "synth", "pan7"), 3, intra_period=5, threads=4, ahead=2, complexity=complexity)
+        for s, yuv in enumerate(seqs):
+            ref = _reference_stream(ref_tools, tmp_path, yuv, w, h, ["-qp", 24, "-iper", 5, "-scene", 0, "-complexity", complexity])
+            assert ref == got[s], "pipelined group session %d (complexity %d) differs from oracle/_ref" % (s, complexity)
+
+
+def test_group_paths_against_the_reference_on_emulation(emu_lib, ref_tools, tmp_path):
+    if not ref_tools:
+        pytest.skip("oracle/_ref not built")
+    _group_paths_against_the_reference(emu_lib, ref_tools, tmp_path, 96, 64, 6)
+
+
+@pytest.mark.gpu
+def test_hip_plain_p_kernel_variant(hip_lib, ref_tools, tmp_path):
+    """The same on the MI355X for the shipped library, in process: the kernel the headline is timed on (k_inter_pool, PLAIN variant, which only
+    session groups launch) meets the oracle here, not only inside bench.py."""
+    assert ref_tools, "oracle/_ref must travel to the GPU box (it is the checker)"
+    _group_paths_against_the_reference(hip_lib, ref_tools, tmp_path, 320, 192, 8)

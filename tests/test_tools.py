@@ -72,3 +72,34 @@ def test_intra4x4_predictor_table_is_the_generated_one():
     body = src.split("kWhI4Desc[36] = {", 1)[1].split("};", 1)[0]
     words = [int(w, 16) for w in re.findall(r"0x([0-9a-fA-F]{8})u", body)]
     assert words == gen_tables.i4_table(check=300)
+
+
+def test_every_repo_file_a_test_names_exists():
+    """Round 4 lost eleven GPU tests to a clean-up commit that deleted a helper script a `gpu`-marked test still shelled out to; nothing on the
+    CPU tier noticed.  Every tracked-tree path the test sources name -- os.path.join(ROOT, "tools", "x.py"), "profiles/..." literals, modules
+    imported from tools/ -- must exist (built artefacts under oracle/_ref, tests/emu and gpurun_out are made by build(), not tracked)."""
+    import ast
+    import glob
+    import re
+    missing = []
+    built = ("oracle/_ref", "gpurun_out", "tests/emu/", "build/")
+    tool_modules = {os.path.splitext(f)[0] for f in os.listdir(os.path.join(ROOT, "tools")) if f.endswith(".py")}
+    top = {"tools", "oracle", "profiles", "integration", "include", "tests", "openh264_amd"}
+    for src in sorted(glob.glob(os.path.join(ROOT, "tests", "*.py"))) + [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")]:
+        tree = ast.parse(open(src).read())
+        inserts_tools = 'os.path.join(ROOT, "tools")' in open(src).read()
+        for node in ast.walk(tree):
+            rel = None
+            if isinstance(node, ast.Call) and isinstance(node.func, ast.Attribute) and node.func.attr == "join" and len(node.args) >= 2 \
+                    and isinstance(node.args[0], ast.Name) and node.args[0].id == "ROOT" and all(isinstance(a, ast.Constant) and isinstance(a.value, str) for a in node.args[1:]):
+                rel = "/".join(a.value for a in node.args[1:])
+            elif isinstance(node, ast.Constant) and isinstance(node.value, str) and re.fullmatch(r"(tools|oracle|profiles|integration|include|tests/golden)/[\w./-]+\.\w+", node.value):
+                rel = node.value
+            elif isinstance(node, ast.Import) and inserts_tools:
+                for a in node.names:                      # `import h264_parse` after sys.path.insert(tools)
+                    if a.name not in sys.stdlib_module_names and a.name not in sys.modules and "." not in a.name and a.name not in tool_modules \
+                            and not os.path.exists(os.path.join(ROOT, "tests", a.name + ".py")) and a.name not in ("pytest", "numpy", "torch", "openh264_amd", "conftest"):
+                        missing.append("%s imports %s (not in tools/)" % (os.path.basename(src), a.name))
+            if rel and "*" not in rel and rel.split("/")[0] in top and not rel.startswith(built) and not os.path.exists(os.path.join(ROOT, rel)):
+                missing.append("%s names %s" % (os.path.basename(src), rel))
+    assert not missing, missing
