@@ -14,8 +14,10 @@ The JSON line (last line of stdout, rank 0) carries, besides the contract's keys
   roofline       dominant kernel, algorithmic bytes per launch / HIP-event launch time (events on the launch stream)
   verified       the reconstructions the timed steps left behind (eight sessions spread over 0 .. N-1) equal the reference decoder's output of
                  the reference encoder's stream for the same frame order (oracle/_ref, run live) -- the run fails otherwise
-  e2e            complete EncodeFrame rate incl. source upload, D2H of the MB records and host CAVLC (the PCIe/host-inclusive
-                 figure; never `value`)
+  e2e_pipelined  complete EncodeFrame rate incl. source upload, D2H of the packed MB records and host CAVLC (the PCIe/host-inclusive
+                 figure; never `value`), session 0's bitstream compared with the reference encoder's
+  config4_* / config5_*   BASELINE configs 4 and 5 through the dispatch-table binding next to the reference's C path; with --gpus N > 1:
+                 config5_64_sessions (8 sessions per GPU on every rank) and config4_layer_per_gpu (one simulcast session, its layers spread over the GPUs)
   latency        per-frame wall time of complete EncodeFrame calls with 1 and 8 sessions on the GPU
   res_clip       the same hot-path step on the reference's own 1080p clip (res/VID_1920x1080_cavlc_temporal_direct.264 decoded)
   intra_720p     BASELINE config 2: all-IDR 1280x720 on the reference's 720p clip, hot path, with its own roofline fraction
@@ -60,8 +62,8 @@ def parse():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the e2e, latency, res-clip and intra legs")
     ap.add_argument("--host-threads", type=int, default=min(32, os.cpu_count() or 8))
-    ap.add_argument("--e2e-groups", type=int, default=3, help="independent session groups of the overlapped end-to-end leg (sessions/2 each)")
-    ap.add_argument("--e2e-group-sessions", type=int, default=64, help="sessions per group of that leg")
+    ap.add_argument("--multi-gpu-legs", action="store_true",
+                    help="with --gpus N > 1: also run BASELINE configs 4 and 5 across the ranks (default there unless --quick; the launcher test asks for them explicitly)")
     ap.add_argument("--cpu-launcher-test", action="store_true",
                     help="TEST ONLY (tests/test_multi_rank.py): exercise the N-rank launch / barrier / max-over-ranks / JSON logic without a GPU -- "
                          "gloo instead of RCCL, WELSHIP_LIB must name the CPU test build of the kernels; implies --quick, the line is marked as no measurement")
@@ -321,58 +323,64 @@ def e2e_pipelined_leg(oh, a, local, w, h, sessions, ring, content, frames, check
     return dt, nbytes, match, host
 
 
-def e2e_groups_leg(oh, a, local, w, h, groups, per_group, ring, content, frames, check=False):
-    """The same complete EncodeFrame calls from `groups` independent session groups, each driven by its own host thread on its
-    own device queue: while one group's records are copied back and entropy-coded on the host, the other groups' kernels and
-    source uploads keep the device busy.  No call of one group depends on another (sessions are independent)."""
-    import threading
-    gs = [make_group(oh, a, local, w, h, "p", per_group, ring, None) for _ in range(groups)]
-    pics = [[g.make_pictures([content.frame(gi * per_group + s, k) for s in range(per_group)]) for k in range(ring)] for gi, g in enumerate(gs)]
-    order = [0, 1 % ring] + [slot_of(i + 2, ring) for i in range(frames)]
-    bs0 = bytearray()
-    nbytes = [0] * groups
-    errs = []
-    gate = threading.Barrier(groups + 1)
+def binding_leg(args, local, extra_env=None, timeout=400):
+    """One run of tools/config5_sessions.py (N ISVCEncoder objects of the patched reference in one process, this engine behind SWelsFuncPtrList,
+    next to the same sessions on the reference's C path) -> the digest bench lines carry."""
+    env = dict(os.environ, WELS_HIP_DEVICE=str(local))
+    env.update(extra_env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "config5_sessions.py")] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, env=env)
+    j = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    n = int(args[0])
+    dev, c = j["hooks_on_device"], j["reference_c_path"]
+    return {"config": j["config"], "same_bitstreams": j["same_bitstreams"],
+            "device_frames_per_s": dev["sum_of_session_encode_fps"], "device_slowest_session_fps": dev["min_session_fps"],
+            "device_ms_per_frame_per_session": 1e3 * n / dev["sum_of_session_encode_fps"],
+            "c_path_frames_per_s": c["sum_of_session_encode_fps"], "c_path_cores": n,
+            "note": "frames/s = sum over the sessions of frames / time inside EncodeFrame; every layer of a simulcast frame counts as part of ONE frame"}, r.stderr.decode(errors="replace")
 
-    def worker(gi):
+
+def multi_gpu_legs(rank, world, local, dist, small):
+    """BASELINE configs 5 and 4 over the ranks of one node (no data-path collective: all_gather_object of the per-rank digests only).
+    config5_64_sessions: every rank hosts 8 concurrent 1080p sessions (rate control, raster slices) on its GPU, all ranks at once -- 8 x N sessions
+    per node, 64 on 8 GPUs; the C-path twin of every rank runs at the same time too, so the host's cores are shared by 8 x N reference sessions.
+    config4_layer_per_gpu: ONE simulcast session (1080p input, four AVC layers) on rank 0's process with its layers on GPUs 0 .. min(N, 4) - 1
+    (WELS_HIP_LAYER_DEVICES, integration/welship_hooks.cpp), the other ranks idle at the barrier.
+    small: the launcher test's sizes (2 sessions of 3 frames at 720p / one 2-frame simulcast session) on the CPU test build."""
+    import re
+    out = {}
+    args5 = ["2", "3", "plain"] if small else ["8", "30", "plain", "1080p"]
+    try:
+        mine, _ = binding_leg(args5, local)
+    except Exception as e:          # noqa: BLE001 -- reported in the line
+        mine = {"error": str(e)[:200]}
+    mine["rank"], mine["device"] = rank, local
+    parts = [None] * world
+    dist.all_gather_object(parts, mine)
+    if rank == 0:
+        ok = [p for p in parts if "error" not in p]
+        out["config5_64_sessions" if world == 8 else "config5_%d_sessions" % (int(args5[0]) * world)] = {
+            "n_ranks_seen": len(parts), "sessions_per_gpu": int(args5[0]), "sessions": int(args5[0]) * world,
+            "aggregate_device_frames_per_s": sum(p["device_frames_per_s"] for p in ok), "aggregate_c_path_frames_per_s": sum(p["c_path_frames_per_s"] for p in ok),
+            "per_gpu_device_frames_per_s": [p.get("device_frames_per_s") for p in parts],
+            "per_session_latency_ms": [p.get("device_ms_per_frame_per_session") for p in parts],
+            "same_bitstreams": bool(ok) and len(ok) == len(parts) and all(p["same_bitstreams"] for p in ok), "errors": [p["error"] for p in parts if "error" in p],
+            "config": ok[0]["config"] if ok else None,
+            "note": "all ranks at once; the C-path sessions of all ranks share the host's cores (%d reference sessions on %s logical cores)" % (int(args5[0]) * world, os.cpu_count())}
+    dist.barrier()
+    if rank == 0:
+        n = min(world, 4)
         try:
-            g = gs[gi]
-            first = [g.encode_frames(pics[gi][order[0]], want_bytes=True)[0], g.encode_frames(pics[gi][order[1]], want_bytes=True)[0]]
-            if gi == 0:
-                bs0.extend(first[0] + first[1])
-            gate.wait()
-            for i in range(frames):
-                out = g.encode_frames(pics[gi][order[i + 2]], want_bytes=(check and gi == 0))
-                if check and gi == 0:
-                    bs0.extend(out[0])
-                    nbytes[gi] += sum(len(b) for b in out)
-                else:
-                    nbytes[gi] += out
-        except Exception as e:          # noqa: BLE001 -- reported by the caller
-            errs.append(repr(e))
-            try:
-                gate.abort()
-            except Exception:
-                pass
-
-    th = [threading.Thread(target=worker, args=(gi,)) for gi in range(groups)]
-    for t in th:
-        t.start()
-    gate.wait()
-    t0 = time.perf_counter()
-    for t in th:
-        t.join()
-    dt = time.perf_counter() - t0
-    for g in gs:
-        g.close()
-    if errs:
-        raise SystemExit("bench.py: e2e groups leg failed: %s" % errs[0])
-    match = None
-    if check:
-        import hashlib
-        ref = ref_encode(b"".join(content.frame(0, k) for k in order), w, h, p_flags(a.qp, a.deblock_idc) + ["-quiet", "-threads", "1"])
-        match = {"match": bytes(bs0) == ref, "sha1": hashlib.sha1(bytes(bs0)).hexdigest(), "reference_sha1": hashlib.sha1(ref).hexdigest(), "frames": len(order)}
-    return dt, sum(nbytes), match
+            leg, err = binding_leg(["1", "2", "simulcast"] if small else ["1", "30", "simulcast", "1080p"], 0,
+                                   {"WELS_HIP_LAYER_DEVICES": str(n if n >= 2 else 0), "WELSHIP_TRACE_DEVICES": "1", "WELS_HIP_TRACE": "1"})
+            leg["layer_devices"] = n
+            seen = sorted(set(int(x) for x in re.findall(r"backend for device (\d+)", err)))
+            if seen:
+                leg["devices_seen"] = seen        # (the CPU test build's backend reports the device index it was asked for)
+            out["config4_layer_per_gpu"] = leg
+        except Exception as e:      # noqa: BLE001
+            out["config4_layer_per_gpu"] = {"error": str(e)[:200]}
+    dist.barrier()
+    return out
 
 
 def main():
@@ -440,6 +448,9 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if cpu_test else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    mg = {}
+    if dist is not None and world > 1 and (a.multi_gpu_legs or not a.quick) and os.path.exists(os.path.join(REF_DIR, "ref_enc_hip")):
+        mg = multi_gpu_legs(rank, world, local, dist, cpu_test)
     if rank != 0:
         if dist is not None:
             dist.barrier()
@@ -489,14 +500,14 @@ def main():
     line = {
         "metric": json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"],
         "metric_scope": "value = device hot path (MD + reconstruction + deblocking + border expansion), entropy coding on the host excluded; "
-                        "`verified` = the timed steps' reconstruction equals the reference's, `e2e` = complete EncodeFrame rate with a bitstream SHA1 check",
+                        "`verified` = the timed steps' reconstruction equals the reference's, `e2e_pipelined` = complete EncodeFrame rate with a bitstream SHA1 check",
         "value": pics / dt, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u8", "data": data if not cpu_test else data + " -- LAUNCHER TEST on the CPU test build of the kernels: not a measurement",
         "config": {"workload": ("%dx%d all-IDR (intra MD + DCT/quant + deblock), QP %d, LOW complexity" % (w, h, a.qp)) if workload == "intra" else
                    ("%dx%d P-frames, diamond ME range 16, 4 slices/frame, QP %d, LOW complexity" % (w, h, a.qp)),
                    "pictures_in_flight_per_gpu": a.sessions, "device_queues": a.queues,
-                   "hot_path": "device MD/recon + deblock + border expand; sources resident in HBM, MB records left in HBM; host CAVLC excluded (see e2e)",
+                   "hot_path": "device MD/recon + deblock + border expand; sources resident in HBM, MB records left in HBM; host CAVLC excluded (see e2e_pipelined)",
                    "note": "throughput needs many concurrent pictures per GPU (128 in flight: ~12 % less, 64: ~45 % less); see latency for 1 and 8 sessions",
                    "parallelism": "sessions sharded over %d GPU(s), no collective" % world},
         "roofline": rf,
@@ -507,22 +518,9 @@ def main():
                                    "against": "oracle/_ref: reference encoder + reference decoder on the same frame order, last reconstruction compared byte for byte"}
 
     if not a.no_extra and world == 1:
-        # complete EncodeFrame calls: upload + device + D2H + host CAVLC
-        n_e2e = 12
-        de, nbytes, match = e2e_leg(oh, a, local, w, h, a.sessions, ring, content, n_e2e, bool(verify_sessions))
-        line["e2e"] = {"frames_per_s": a.sessions * n_e2e / de, "sessions": a.sessions, "frames_each": n_e2e, "host_entropy_threads": a.host_threads,
-                       "host": cpu_info(), "includes": "source upload (H2D), device passes, D2H of the MB records, host CAVLC + NAL packing",
-                       "bitstream_MB_per_s": nbytes / de / 1e6, "bitstream_vs_reference": match,
-                       "host_thread_ms_per_picture": e2e_leg.host}      # WelsHipGroupHostStats: staging copy, entropy coding from the packed records
-        # the same with the sessions split over independent groups, one host thread and one device queue each
-        ng, per = a.e2e_groups, max(1, a.e2e_group_sessions)
-        if ng > 1:
-            n2 = 30
-            dg, nb2, m2 = e2e_groups_leg(oh, a, local, w, h, ng, per, ring, content, n2, bool(verify_sessions))
-            line["e2e_overlapped"] = {"frames_per_s": ng * per * n2 / dg, "groups": ng, "sessions_per_group": per, "frames_each": n2,
-                                      "host_entropy_threads_per_group": a.host_threads, "bitstream_MB_per_s": nb2 / dg / 1e6, "bitstream_vs_reference": m2,
-                                      "how": "independent session groups, one host thread + one device queue each: a group's D2H and CAVLC run under the other groups' kernels"}
-        # one group as a two-stage pipeline: the host entropy-codes step k - 1 while the device codes step k
+        # complete EncodeFrame work end to end (source upload, device passes, D2H of the packed records, host CAVLC): one group as a two-stage pipeline,
+        # the host entropy-codes step k - 1 while the device codes step k.  (The synchronous and the several-groups legs of rounds 1-3 are gone:
+        # 4.2 k and 4.1 k frames/s against this leg's 13.4 k, profiles/r04_bench_default_final.json.)
         n3 = 60
         dp, nb3, m3, host3 = e2e_pipelined_leg(oh, a, local, w, h, a.sessions, ring, content, n3, bool(verify_sessions))
         line["e2e_pipelined"] = {"frames_per_s": a.sessions * n3 / dp, "frames_per_s_second_half": e2e_pipelined_leg.steady,
@@ -566,15 +564,10 @@ def main():
             for key, args in (("config4_simulcast_1080p_720p_360p_180p", ["1", "30", "simulcast", "1080p"]), ("config4_8_sessions", ["8", "30", "simulcast", "1080p"]),
                               ("config5_8_sessions_1080p_rc_raster_slices", ["8", "30", "plain", "1080p"])):
                 try:
-                    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "config5_sessions.py")] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240,
-                                       env=dict(os.environ, WELS_HIP_DEVICE=str(local)))
-                    j = json.loads(r.stdout.decode().strip().splitlines()[-1])
-                    line[key] = {"config": j["config"], "same_bitstreams": j["same_bitstreams"],
-                                 "device_frames_per_s": j["hooks_on_device"]["sum_of_session_encode_fps"], "device_slowest_session_fps": j["hooks_on_device"]["min_session_fps"],
-                                 "c_path_frames_per_s": j["reference_c_path"]["sum_of_session_encode_fps"], "c_path_cores": int(args[0]),
-                                 "note": "frames/s = sum over the sessions of frames / time inside EncodeFrame; every layer of a simulcast frame counts as part of ONE frame"}
+                    line[key], _ = binding_leg(args, local, timeout=240)
                 except Exception as e:
                     line[key] = {"error": str(e)[:200]}
+    line.update(mg)
     if world == 1 and not a.no_cpu_baseline:
         cb = cpu_baseline(w, h, a.qp, workload, content, a.deblock_idc)
         if cb:
@@ -584,7 +577,7 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    for leg in ("e2e", "e2e_overlapped", "e2e_pipelined"):
+    for leg in ("e2e_pipelined",):
         if line.get(leg, {}).get("bitstream_vs_reference") and not line[leg]["bitstream_vs_reference"]["match"]:
             raise SystemExit("bench.py: the %s bitstream of session 0 differs from the reference encoder's" % leg)
     if verified is not None and not all(verified.values()):

@@ -241,6 +241,8 @@ typedef struct WelsHipScreenInfo {
   uint32_t* pSliceFMECostDown;          /* out, [iNumSlices]: what the picture adds to each pSlice->uiSliceFMECostDown                       */
 } WelsHipScreenInfo;
 typedef struct WelsHipFrameJob {
+  uint32_t cbSize;                  /* sizeof (WelsHipFrameJob) of the header the caller was compiled with: the library refuses a job of      */
+                                    /* another size (WELSHIP_ERR_INIT_PARA) instead of reading past a shorter struct                         */
   int32_t iCurPic, iRefPic;         /* device picture indices (0 .. iNumPictures-1); iRefPic < 0: I picture                    */
   int32_t eSliceType;               /* 0 = P_SLICE, 2 = I_SLICE (slice_type values of the standard)                            */
   int32_t iQp;                      /* pEncCtx->iGlobalQp: WelsRcMbInitDisable / WelsRcMbInitGom with bEnableGomQp == false    */
@@ -304,8 +306,13 @@ typedef struct WelsHipFrameJob {
   /* information plus the 32-byte level blocks that hold a level the entropy coder can read: openh264_amd/csrc/common/compact.h) -- *ppRecords   */
   /* then points at a WelsHipPackedRecords instead of a WhMbRecord array, and the caller expands a macroblock when it gets to it                  */
   /* (wh_compact_expand).  About a sixth of the 960-byte records on camera content; MB ranges always come back as full records.                   */
+  /* Pictures of more than WELSHIP_PACKED_MAX_MB macroblocks (and a library run with WELSHIP_COMPACT=0) cannot be packed: the library says what  */
+  /* *ppRecords holds through *pbRecordsPacked (1 = a WelsHipPackedRecords, 0 = the WhMbRecord array), which a caller that sets bPackedRecords     */
+  /* MUST supply -- a request without it is refused (WELSHIP_ERR_INIT_PARA), never answered in a format the caller cannot tell.                    */
   int32_t bPackedRecords;
+  int32_t* pbRecordsPacked;
 } WelsHipFrameJob;
+#define WELSHIP_PACKED_MAX_MB 9216
 typedef struct WelsHipPackedRecords {
   const uint8_t* pData;             /* the packed stream of the picture                                                                       */
   const uint32_t* pOffset;          /* [number of macroblocks + 1] byte offsets into pData; macroblock mb is pOffset[mb + 1] - pOffset[mb] long */

@@ -153,7 +153,7 @@ struct HipState {
   int device = 0;
   std::atomic<bool> failed {false};     // a device call failed: the session reports errors from then on (slice tasks set it concurrently)
   bool trace = false;
-  bool layer_devices = false;           // one GPU per simulcast layer
+  int layer_devices = 0;                // WELS_HIP_LAYER_DEVICES: 0 all layers on one GPU; 1 layer d on GPU base + d; n >= 2 layer d on GPU base + d mod n
   // WELS_HIP_TRACE=2: where a picture's time goes (seconds, summed): device call incl. transfers, reconstruction copy-back,
   // entropy coding from the records
   bool timing = false;
@@ -259,7 +259,7 @@ bool EnsureLayerCtx (HipState* st, sWelsEncCtx* pCtx, int did) {
   const SDqLayer* pLayer = pCtx->ppDqLayerList[did];
   WelsHipFrameCfg cfg;
   memset (&cfg, 0, sizeof (cfg));
-  cfg.iDevice = st->device + (st->layer_devices ? did : 0);
+  cfg.iDevice = st->device + (st->layer_devices == 1 ? did : st->layer_devices >= 2 ? did % st->layer_devices : 0);
   cfg.iPicWidth = pLayer->iMbWidth * 16; cfg.iPicHeight = pLayer->iMbHeight * 16;
   cfg.iNumPictures = WELS_MAX (pParam->iNumRefFrame, pParam->iMaxNumRefFrame) + 2;    // RequestMemorySvc allocates 1 + iMaxNumRefFrame pictures per layer
   L.num_pictures = cfg.iNumPictures;
@@ -275,6 +275,7 @@ bool EnsureLayerCtx (HipState* st, sWelsEncCtx* pCtx, int did) {
 // from the picture before.  BackgroundDetection and the complexity analysis that follow read the arrays this fills.  Non-zero: not done.
 int32_t HipVaaCalc (sWelsEncCtx* pCtx, int32_t iDid, SPicture* pCurPic, SPicture* pRefPic, bool bCalculateSQDiff, bool bCalculateVar, bool bCalculateBGD) {
   HipState* st = (HipState*)pCtx->pFuncList->pHipState;
+  if (st != NULL) st->last_vaa_did = -1;        // (set again only when the device really served this call: HipBgd must never address a stale layer)
   if (st == NULL || !st->vaa || st->failed || g_api.FrameVaa == NULL || pCtx->pVaa == NULL || pCurPic == NULL || pRefPic == NULL) return 1;
   if (iDid < 0 || iDid >= MAX_DEPENDENCY_LAYER || pCurPic->pData[0] == NULL || pRefPic->pData[0] == NULL || pCurPic->pData[0] == pRefPic->pData[0]) return 1;
   if (pCurPic->iLineSize[0] != pRefPic->iLineSize[0]) return 1;               // (the C functions take ONE stride for both pictures)
@@ -380,6 +381,7 @@ int32_t HipFrameMd (sWelsEncCtx* pCtx) {
   L.reencode.clear();
   WelsHipFrameJob& job = L.job;
   memset (&job, 0, sizeof (job));
+  job.cbSize = (uint32_t)sizeof (job);
   const bool is_p = pCtx->eSliceType == P_SLICE;
   job.iCurPic = TwinOf (L, pCtx->pDecPic);
   job.iRefPic = is_p ? TwinOf (L, pCurLayer->pRefPic) : -1;
@@ -545,13 +547,15 @@ int32_t HipFrameMd (sWelsEncCtx* pCtx) {
   const void* rec = NULL;
   int rc;
   const char* dump = getenv ("WELS_HIP_DUMP_RECORDS");
-  job.bPackedRecords = (st->packed && dump == NULL) ? 1 : 0;
+  int32_t got_packed = 0;           // what the library really returned (pictures above WELSHIP_PACKED_MAX_MB macroblocks, WELSHIP_COMPACT=0: full records)
+  job.bPackedRecords = (st->packed && dump == NULL && num_mb <= WELSHIP_PACKED_MAX_MB) ? 1 : 0;
+  job.pbRecordsPacked = &got_packed;
   { Stopwatch sw (st->timing ? &st->t_encode : NULL); rc = g_api.FrameEncode (L.ctx, &job, &rec); }
   ++st->pictures;
   if (rc) { fprintf (stderr, "welship hooks: WelsHipFrameEncode failed (%d: %s)\n", rc, g_api.GetLastError()); st->failed = true; return ENC_RETURN_UNEXPECTED; }
-  if (job.bPackedRecords) { L.packed = (const WelsHipPackedRecords*)rec; L.records = NULL; }
+  if (got_packed) { L.packed = (const WelsHipPackedRecords*)rec; L.records = NULL; }
   else { L.packed = NULL; L.records = (const WhMbRecord*)rec; }
-  job.bPackedRecords = 0;          // (the job is reused by the retry after a CAVLC overflow, which asks for what the slice loop holds then)
+  job.bPackedRecords = 0; job.pbRecordsPacked = NULL;          // (the job is reused by the retry after a CAVLC overflow, which asks for what the slice loop holds then)
   if (dump) {        // developer aid: the raw macroblock records of every picture
     static int s_pic = 0;
     char name[512];
@@ -857,7 +861,7 @@ bool WelsHipSupported (const SWelsSvcCodingParam* p, const char** why) {
   if (p->iUsageType == SCREEN_CONTENT_REAL_TIME && getenv ("WELS_HIP_SCREEN") && atoi (getenv ("WELS_HIP_SCREEN")) == 0) NO ("screen content switched off (WELS_HIP_SCREEN=0)");
   if (p->iEntropyCodingModeFlag != 0 && getenv ("WELS_HIP_CABAC") && atoi (getenv ("WELS_HIP_CABAC")) == 0) NO ("CABAC switched off (WELS_HIP_CABAC=0)");
   // simulcast AVC layers are independent streams (no inter-layer prediction): one device context per layer, optionally one
-  // GPU per layer (WELS_HIP_LAYER_DEVICES=1: layer d runs on device WELS_HIP_DEVICE + d)
+  // GPU per layer (WELS_HIP_LAYER_DEVICES=1: layer d runs on device WELS_HIP_DEVICE + d; =n, n >= 2: on device WELS_HIP_DEVICE + d mod n)
   if (p->iSpatialLayerNum != 1 && !p->bSimulcastAVC) NO ("spatial layers with SVC syntax (tried: not byte-identical yet; simulcast AVC is)");
   // slice threads: every slice task entropy-codes its slice from the (read-only) records of the picture; see HipFrameMd for the filter
   if (p->iMultipleThreadIdc != 1 && getenv ("WELS_HIP_THREADS") && atoi (getenv ("WELS_HIP_THREADS")) == 0) NO ("slice threads switched off (WELS_HIP_THREADS=0)");
@@ -991,7 +995,7 @@ void WelsHipInstall (SWelsFuncPtrList* pFuncList, SWelsSvcCodingParam* pParam) {
   st->packed = !(getenv ("WELS_HIP_PACKED") != NULL && atoi (getenv ("WELS_HIP_PACKED")) == 0);
   st->eager_recon = (getenv ("WELS_HIP_EAGER_RECON") != NULL && atoi (getenv ("WELS_HIP_EAGER_RECON")) != 0) || pParam->iUsageType == SCREEN_CONTENT_REAL_TIME;
   st->check_bits = getenv ("WELS_HIP_CHECK_BITS") != NULL && atoi (getenv ("WELS_HIP_CHECK_BITS")) != 0 && pParam->iEntropyCodingModeFlag == 0;
-  st->layer_devices = getenv ("WELS_HIP_LAYER_DEVICES") != NULL && atoi (getenv ("WELS_HIP_LAYER_DEVICES")) != 0;
+  st->layer_devices = getenv ("WELS_HIP_LAYER_DEVICES") != NULL ? WELS_MAX (0, atoi (getenv ("WELS_HIP_LAYER_DEVICES"))) : 0;
   st->downsample = !(getenv ("WELS_HIP_DOWNSAMPLE") != NULL && atoi (getenv ("WELS_HIP_DOWNSAMPLE")) == 0);
   st->vaa = !(getenv ("WELS_HIP_VAA") != NULL && atoi (getenv ("WELS_HIP_VAA")) == 0);
   st->vaa_check = getenv ("WELS_HIP_CHECK_VAA") != NULL && atoi (getenv ("WELS_HIP_CHECK_VAA")) != 0;

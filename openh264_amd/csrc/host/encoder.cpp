@@ -346,7 +346,7 @@ struct SessionCore {
   // Groups copy the records back packed (common/compact.h); pictures larger than the packer's workgroup handles keep the
   // full records, as does WELSHIP_COMPACT=0.
   int enable_compact() {
-    if (num_mb > 9216) return WELSHIP_OK;
+    if (num_mb > WELSHIP_PACKED_MAX_MB) return WELSHIP_OK;
     if (const char* e = getenv ("WELSHIP_COMPACT")) if (atoi (e) == 0) return WELSHIP_OK;
     d_compact = (uint8_t*)be->alloc ((size_t)num_mb * WH_COMPACT_MAX_BYTES);
     d_compact_off = (uint32_t*)be->alloc (sizeof (uint32_t) * ((size_t)num_mb + 1));
@@ -1638,6 +1638,15 @@ struct FrameLane {             // one launch set in flight: its queue and its jo
   std::vector<WhPicJob> h_jobs;          // page-locked
   void* tail_ev = nullptr;               // marks "the records of this launch set are on the host": what the callers wait for (frame_run_batch)
   std::vector<uint32_t> h_err;           // page-locked: the queue's error words at that point
+  // ... and what nobody waits for at once: the launch set's deblocking pass / border expansion ("tail").  Its verdict -- the queue's error words
+  // AFTER the expansion -- lands in one of two slots (launch sets alternate), and every context of the launch set is listed until its next call
+  // has looked at the slot (WelsHipFrameCtx::check_tail): a time-out inside the tail fails the picture's OWN context at its next call, not
+  // whichever launch set synchronises this queue next.
+  void* tail_done_ev[2] = {nullptr, nullptr};
+  std::vector<uint32_t> h_err_tail;      // page-locked, 2 x 4 words
+  unsigned tail_slot = 0;
+  std::vector<WelsHipFrameCtx*> tail_ctxs;      // contexts with an unverified tail on this lane's queue
+  void fail_tails();                     // an error was seen on this queue: every listed context's reference picture is suspect
 };
 #define WH_FRAME_LANES 2
 struct FrameKey {              // pictures that can share a launch: same sequence parameters, type and passes
@@ -1750,8 +1759,28 @@ struct WelsHipFrameCtx {
   std::chrono::steady_clock::time_point last_submit;
   int queue() const { return last_key ? last_key->queue : 0; }
   int tail_queue = -1;                   // the queue on which this context's last picture is still being deblocked / expanded (frame_run_batch), or -1
+  FrameLane* tail_lane = nullptr;        // ... the lane whose verdict slot tail_slot will hold that pass's error words (checked by the next call: check_tail)
+  int tail_slot = 0;
+  bool tail_failed = false;              // the last picture's deblocking / expansion did not complete: its reconstruction cannot be predicted from
   // whatever touches this context's pictures on another queue comes after that tail (the caller has selected its queue)
   void join_tail (int on_queue) { if (tail_queue >= 0 && tail_queue != on_queue) be->queue_wait (tail_queue); }
+  // The verdict of the last picture's deblocking pass / border expansion, at this context's next call (advisor finding, round 4: that pass runs
+  // after the callers were released, and its time-out used to fail whichever launch set synchronised the queue next).  Waits for the pass
+  // (normally long over: the caller has entropy-coded a picture meanwhile), reads the error words copied out behind it.  Called WITHOUT sh->mu.
+  int check_tail() {
+    if (tail_lane) {
+      FrameLane* TL = tail_lane;
+      be->event_wait (TL->tail_done_ev[tail_slot]);
+      std::unique_lock<std::mutex> lock (sh->mu);
+      const uint32_t* e = TL->h_err_tail.data() + 4 * tail_slot;
+      if (tail_lane == TL) {             // (an error seen meanwhile on that queue has cleared the list and set tail_failed already)
+        if (e[0] | e[1] | e[2] | e[3]) { (void)be->sync_queue (TL->queue); TL->fail_tails(); }
+        else { TL->tail_ctxs.erase (std::remove (TL->tail_ctxs.begin(), TL->tail_ctxs.end(), this), TL->tail_ctxs.end()); tail_lane = nullptr; }
+      }
+    }
+    if (tail_failed) { tail_failed = false; return 1; }
+    return 0;
+  }
   uint32_t* d_dbflags = nullptr;
   uint32_t db_gen = 0;
   WhMbCtl* d_mb_ctl = nullptr;
@@ -1885,6 +1914,11 @@ struct FrameItem {             // one submitted picture, owned by the submitting
   int rc = 0;
 };
 
+void FrameLane::fail_tails() {
+  for (WelsHipFrameCtx* x : tail_ctxs) { x->tail_failed = true; x->tail_lane = nullptr; }
+  tail_ctxs.clear();
+}
+
 // the leader's work: the key's pending pictures in one launch set on the key's queue.  Called with sh->mu held; releases it
 // while the device works.
 void frame_run_batch (FrameShared* sh, FrameKey* K, FrameLane* L, std::unique_lock<std::mutex>& lock, std::vector<FrameItem*>& batch) {
@@ -1956,6 +1990,18 @@ void frame_run_batch (FrameShared* sh, FrameKey* K, FrameLane* L, std::unique_lo
     if (s.deblock_idc != 1) be->run_deblock (s, L->d_jobs, n);
     if (K->expand) be->run_expand (s, L->d_jobs, n);
     for (FrameItem* x : batch) x->c->tail_queue = tail && L->tail_ev ? q : -1;
+    if (tail && L->tail_ev) {            // the tail's own verdict, for the contexts' next calls (WelsHipFrameCtx::check_tail)
+      if (L->h_err_tail.empty()) { L->h_err_tail.assign (8, 0u); be->pin_host (L->h_err_tail.data(), 32); for (void*& e : L->tail_done_ev) e = be->event_create(); }
+      const int slot = (int) (++L->tail_slot & 1);
+      be->err_snapshot (q, L->h_err_tail.data() + 4 * slot);
+      be->event_record_on (q, L->tail_done_ev[slot]);
+      for (FrameItem* x : batch) {
+        WelsHipFrameCtx* c = x->c;
+        if (c->tail_lane && c->tail_lane != L) c->tail_lane->tail_ctxs.erase (std::remove (c->tail_lane->tail_ctxs.begin(), c->tail_lane->tail_ctxs.end(), c), c->tail_lane->tail_ctxs.end());
+        if (c->tail_lane != L) L->tail_ctxs.push_back (c);
+        c->tail_lane = L; c->tail_slot = slot;
+      }
+    }
     const double launch_ms = std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now() - t_launch0).count();
     const unsigned swept0 = be->errors_swept();
     lock.unlock();               // other sessions stage and queue their next pictures while the device works
@@ -1983,6 +2029,10 @@ void frame_run_batch (FrameShared* sh, FrameKey* K, FrameLane* L, std::unique_lo
         c->compact_est = std::min (c->h_compact.size(), ((total + total / 4 + 4095) & ~ (size_t)4095) + 65536);
       }
       if (more) { lock.unlock(); if (be->sync_queue (q)) bad = 1; lock.lock(); }
+    }
+    if (bad) {                           // whatever went wrong on this queue: the pictures still in their tails on it cannot be trusted either
+      for (FrameItem* x : batch) { x->c->tail_lane = nullptr; L->tail_ctxs.erase (std::remove (L->tail_ctxs.begin(), L->tail_ctxs.end(), x->c), L->tail_ctxs.end()); }      // (these fail now)
+      L->fail_tails();
     }
     if ((int)sh->stat_n.size() <= n) { sh->stat_n.resize (n + 1, 0); sh->stat_dev_ms.resize (n + 1, 0.0); sh->stat_gather_ms.resize (n + 1, 0.0); sh->stat_launch_ms.resize (n + 1, 0.0); }
     ++sh->stat_n[n]; sh->stat_dev_ms[n] += dev_ms; sh->stat_launch_ms[n] += launch_ms;
@@ -2116,6 +2166,7 @@ void WelsHipFrameCtxDestroy (WelsHipFrameCtx* c) {
   {
     std::unique_lock<std::mutex> lock (sh->mu);
     sh->ctxs.erase (std::remove (sh->ctxs.begin(), sh->ctxs.end(), c), sh->ctxs.end());
+    if (c->tail_lane) c->tail_lane->tail_ctxs.erase (std::remove (c->tail_lane->tail_ctxs.begin(), c->tail_lane->tail_ctxs.end(), c), c->tail_lane->tail_ctxs.end());
     c->release_locked();
   }
   delete c;
@@ -2129,7 +2180,8 @@ void WelsHipFrameCtxDestroy (WelsHipFrameCtx* c) {
       fprintf (stderr, "welship:   submitting (uploads under the lock): %.3f ms per picture\n", sh->stat_submit_ms / sh->batched_pictures);
     }
     for (auto& L : sh->layouts) { sh->be->free (L->d_order); sh->be->free (L->d_bands); }
-    for (auto& K : sh->keys) for (FrameLane& L : K->lane) { if (L.d_jobs) sh->be->free (L.d_jobs); if (!L.h_jobs.empty()) sh->be->unpin_host (L.h_jobs.data()); if (L.tail_ev) sh->be->event_destroy (L.tail_ev); if (!L.h_err.empty()) sh->be->unpin_host (L.h_err.data()); }
+    for (auto& K : sh->keys) for (FrameLane& L : K->lane) { if (L.d_jobs) sh->be->free (L.d_jobs); if (!L.h_jobs.empty()) sh->be->unpin_host (L.h_jobs.data()); if (L.tail_ev) sh->be->event_destroy (L.tail_ev); if (!L.h_err.empty()) sh->be->unpin_host (L.h_err.data());
+      for (void* e : L.tail_done_ev) if (e) sh->be->event_destroy (e); if (!L.h_err_tail.empty()) sh->be->unpin_host (L.h_err_tail.data()); }
     delete sh->be;
     g_frame_shared.erase (std::find (g_frame_shared.begin(), g_frame_shared.end(), sh));
     delete sh;
@@ -2138,6 +2190,9 @@ void WelsHipFrameCtxDestroy (WelsHipFrameCtx* c) {
 
 int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void** pp_records) {
   if (!c || !c->be || !j || !pp_records) return WELSHIP_ERR_INIT_PARA;
+  if (j->cbSize != sizeof (WelsHipFrameJob)) { set_err ("WelsHipFrameJob::cbSize is not this library's sizeof (WelsHipFrameJob): the caller was built against another include/welship.h"); return WELSHIP_ERR_INIT_PARA; }
+  if (j->bPackedRecords && !j->pbRecordsPacked) { set_err ("bPackedRecords without pbRecordsPacked: the caller could not tell which record format it got"); return WELSHIP_ERR_INIT_PARA; }
+  if (j->pbRecordsPacked) *j->pbRecordsPacked = 0;
   const int np = (int)c->pics.size();
   const bool is_p = j->eSliceType == 0;
   if (j->iCurPic < 0 || j->iCurPic >= np || (is_p && (j->iRefPic < 0 || j->iRefPic >= np || j->iRefPic == j->iCurPic)) || (!is_p && j->eSliceType != 2)) {
@@ -2169,6 +2224,7 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
   const bool ranged_reenc = ranged && !retry && j->pReencode && j->iNumReencode > 0;
   // (a retry reuses what the first call of the picture uploaded: source, pre-analysis arrays, screen-content inputs)
   const bool first_part = !retry && (!ranged || (j->iMbBegin == 0 && !j->bRangeAgain)), last_part = !ranged || (dyn ? dyn_close : j->iMbEnd == c->num_mb);
+  if (c->check_tail()) { set_err ("the deblocking pass / border expansion of this context's previous picture timed out or failed on the device: its reconstruction is unusable (code an IDR picture)"); return WELSHIP_ERR_UNKNOWN; }
   FrameShared* sh = c->sh;
   wh::Backend* be = c->be;
   // host-side staging into this context's own page-locked buffers: outside the shared lock
@@ -2347,7 +2403,8 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
   FrameKey* K = ranged ? nullptr : frame_find_key (sh, s, is_p, qp_map, j->bExpand != 0);
   const int queue = K ? K->queue : 0;
   be->select_queue (queue);
-  if (ranged) c->join_tail (queue);           // (MB ranges run on this queue; whole pictures join in frame_run_batch, on their lane's)
+  c->join_tail (queue);                       // the previous picture's tail first: MB ranges run on this queue; a whole picture's uploads wait too (its kernels join
+                                              // again in frame_run_batch on their lane's queue) -- no upload may overtake a pass that could still read what it replaces
   if (first_part) {
     const int slot = c->src_take ((const void*)j->pSrc[0]);
     c->d_src = c->src_pool[slot].d;
@@ -2499,7 +2556,7 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
   item.cur_pic = j->iCurPic; item.sad_dst = j->pSadCost;
   // packed records on request (pictures larger than the packer's workgroup handles keep the full records, as does WELSHIP_COMPACT=0)
   static const bool compact_off_env = getenv ("WELSHIP_COMPACT") && atoi (getenv ("WELSHIP_COMPACT")) == 0;
-  if (j->bPackedRecords && c->num_mb <= 9216 && !compact_off_env) {
+  if (j->bPackedRecords && c->num_mb <= WELSHIP_PACKED_MAX_MB && !compact_off_env) {
     if (!c->d_compact) {
       c->d_compact = (uint8_t*)be->alloc ((size_t)c->num_mb * WH_COMPACT_MAX_BYTES);
       c->d_compact_off = (uint32_t*)be->alloc (sizeof (uint32_t) * ((size_t)c->num_mb + 1));
@@ -2557,6 +2614,7 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
   if (item.packed) {
     c->packed_view.pData = c->h_compact.data(); c->packed_view.pOffset = c->h_coff.data();
     *pp_records = &c->packed_view;
+    *j->pbRecordsPacked = 1;
   } else *pp_records = c->h_records.data();
   return WELSHIP_OK;
 }

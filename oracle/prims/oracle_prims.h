@@ -58,6 +58,14 @@ void    orc_deblock_chroma_eq4 (uint8_t* pix, int32_t stride, int horizontal, in
 /* VAA (codec/processing): four 8x8 SADs of one MB against the previous source picture */
 void    orc_vaa_sad8x8 (const uint8_t* cur, const uint8_t* ref, int32_t stride, int32_t* sad4);
 
+/* batch.c: loops of the functions above over arrays of cases (one call per draw) */
+void    orc_sad_batch (int blk, int n, const uint8_t* p1, int32_t s1, const int32_t* o1, const uint8_t* p2, int32_t s2, const int32_t* o2, int32_t* out);
+void    orc_satd_batch (int blk, int n, const uint8_t* p1, int32_t s1, const int32_t* o1, const uint8_t* p2, int32_t s2, const int32_t* o2, int32_t* out);
+void    orc_sad_four_batch (int blk, int n, const uint8_t* p1, int32_t s1, const int32_t* o1, const uint8_t* p2, int32_t s2, const int32_t* o2, int32_t* out4);
+void    orc_dct4x4_batch (int n, const uint8_t* p1, int32_t s1, const int32_t* o1, const uint8_t* p2, int32_t s2, const int32_t* o2, int16_t* out);
+void    orc_quant_scan_batch (int n, int16_t* io, const uint8_t* qp, int intra, int16_t* mx, int16_t* zz, int16_t* za, int32_t* ctr, int32_t* nz);
+void    orc_dequant_idct_rec_batch (int n, const int16_t* lev, const uint8_t* qp, const uint8_t* pred, uint8_t* rec, int16_t* deq);
+
 #ifdef __cplusplus
 }
 #endif

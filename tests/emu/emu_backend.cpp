@@ -288,6 +288,16 @@ class EmuBackend : public Backend {
   void upload_on (int, void* dst, const void* src, size_t bytes) override { memcpy (dst, src, bytes); }
   void download_on (int, void* dst, const void* src, size_t bytes) override { memcpy (dst, src, bytes); }
   void event_record_on (int, void* ev) override { event_record (ev); }
+  // fault injection for the host logic's tests: WELSHIP_EMU_ERR_SNAPSHOT_AT=k makes the k-th copy of a queue's error words (1-based) report a time-out;
+  // the words stay set until the queue is synchronised, as on the device
+  int snaps_ = 0; uint32_t sticky_err_[64] = {0};
+  void err_snapshot (int q, uint32_t* dst) override {
+    const char* e = getenv ("WELSHIP_EMU_ERR_SNAPSHOT_AT");
+    q = (q < 0 ? 0 : q) % 64;
+    if (e && ++snaps_ == atoi (e)) sticky_err_[q] = 1;
+    if (dst) { dst[0] = sticky_err_[q]; dst[1] = dst[2] = dst[3] = 0; }
+  }
+  int sync_queue (int q) override { q = (q < 0 ? 0 : q) % 64; const int bad = sticky_err_[q] != 0; sticky_err_[q] = 0; return bad; }
   void event_wait (void*) override {}
   void queue_wait_event (int, void*) override {}
   void run_src_tile_jobs (const WhSeqParams& P, const WhPicJob* jobs, int n) override {

@@ -24,7 +24,7 @@ class MbReencode(C.Structure):
 
 
 class FrameJob(C.Structure):          # WelsHipFrameJob, field for field
-    _fields_ = [("iCurPic", C.c_int32), ("iRefPic", C.c_int32), ("eSliceType", C.c_int32), ("iQp", C.c_int32), ("iChromaQpIndexOffset", C.c_int32),
+    _fields_ = [("cbSize", C.c_uint32), ("iCurPic", C.c_int32), ("iRefPic", C.c_int32), ("eSliceType", C.c_int32), ("iQp", C.c_int32), ("iChromaQpIndexOffset", C.c_int32),
                 ("iComplexityMode", C.c_int32), ("iMvRange", C.c_int32), ("iMvcShift", C.c_int32), ("iNumSlices", C.c_int32),
                 ("pSliceFirstMb", C.POINTER(C.c_int32)),
                 ("iDeblockIdc", C.c_int32), ("iAlphaOffset", C.c_int32), ("iBetaOffset", C.c_int32), ("bDeblock", C.c_int32), ("bExpand", C.c_int32),
@@ -34,7 +34,7 @@ class FrameJob(C.Structure):          # WelsHipFrameJob, field for field
                 ("pIlHint", C.c_void_p), ("pSadCost", C.POINTER(C.c_int32)), ("pScreen", C.c_void_p),
                 ("bRetry", C.c_int32), ("bCountBits", C.c_int32), ("iNumReencode", C.c_int32), ("iNumRefIdxL0Active", C.c_int32),
                 ("pGomRc", C.c_void_p), ("pReencode", C.POINTER(MbReencode)),
-                ("iDynSlice", C.c_int32), ("iDynSliceFirstMb", C.c_int32), ("bRangeAgain", C.c_int32), ("bDynRedoFirst", C.c_int32), ("bPackedRecords", C.c_int32)]
+                ("iDynSlice", C.c_int32), ("iDynSliceFirstMb", C.c_int32), ("bRangeAgain", C.c_int32), ("bDynRedoFirst", C.c_int32), ("bPackedRecords", C.c_int32), ("pbRecordsPacked", C.POINTER(C.c_int32))]
 
 
 def _retry_sees_the_previous_pictures_sad_costs(lib_path):
@@ -64,6 +64,7 @@ def _retry_sees_the_previous_pictures_sad_costs(lib_path):
 
     def job(frame, cur, ref, sad):
         j = FrameJob()
+        j.cbSize = C.sizeof(FrameJob)
         j.iCurPic, j.iRefPic, j.eSliceType, j.iQp, j.iComplexityMode, j.iMvRange = cur, ref, (2 if ref < 0 else 0), 24, 1, 64
         j.iNumSlices, j.pSliceFirstMb = 1, first
         j.iDeblockIdc, j.bDeblock, j.bExpand = 0, 1, 1
@@ -118,3 +119,100 @@ def test_retry_sees_the_previous_pictures_sad_costs(emu_lib):
 @pytest.mark.gpu
 def test_hip_retry_sees_the_previous_pictures_sad_costs(hip_lib):
     _retry_sees_the_previous_pictures_sad_costs(hip_lib)
+
+
+# ---- the job's ABI guards (advisor findings, round 4) and the tail's verdict -----------------------------------------------------------
+class PackedRecords(C.Structure):
+    _fields_ = [("pData", C.POINTER(C.c_uint8)), ("pOffset", C.POINTER(C.c_uint32))]
+
+
+def _frame_api(lib_path, w, h):
+    lib = oh.load_library(lib_path)
+    lib.WelsHipFrameCtxCreate.argtypes = [C.POINTER(C.c_void_p), C.POINTER(FrameCfg)]
+    lib.WelsHipFrameCtxDestroy.argtypes = [C.c_void_p]
+    lib.WelsHipFrameCtxDestroy.restype = None
+    lib.WelsHipFrameEncode.argtypes = [C.c_void_p, C.POINTER(FrameJob), C.POINTER(C.c_void_p)]
+    lib.WelsHipGetLastError.restype = C.c_char_p
+    mbs = ((w + 15) // 16) * ((h + 15) // 16)
+    rnd = random.Random(11)
+    frame = bytearray(rnd.getrandbits(8) & 0x3f | 0x40 for _ in range(w * h * 3 // 2))
+    buf = (C.c_uint8 * len(frame)).from_buffer(frame)
+    first = (C.c_int32 * 2)(0, mbs)
+    cfg = FrameCfg(0, w, h, 3)
+    ctx = C.c_void_p()
+    assert lib.WelsHipFrameCtxCreate(C.byref(ctx), C.byref(cfg)) == 0, lib.WelsHipGetLastError()
+
+    def job(cur=0):
+        j = FrameJob()
+        j.cbSize = C.sizeof(FrameJob)
+        j.iCurPic, j.iRefPic, j.eSliceType, j.iQp, j.iComplexityMode, j.iMvRange = cur, -1, 2, 30, 1, 64
+        j.iNumSlices, j.pSliceFirstMb = 1, first
+        j.iDeblockIdc, j.bDeblock, j.bExpand = 0, 1, 1
+        base = C.addressof(buf)
+        j.pSrc[0], j.pSrc[1], j.pSrc[2] = base, base + w * h, base + w * h + (w // 2) * (h // 2)
+        j.iSrcStride[0], j.iSrcStride[1], j.iSrcStride[2] = w, w // 2, w // 2
+        j.iNumRefIdxL0Active = 1
+        return j
+    return lib, ctx, job, mbs, (buf, first, frame)
+
+
+def _job_size_and_record_format(lib_path):
+    lib, ctx, job, mbs, keep = _frame_api(lib_path, 128, 96)
+    rec = C.c_void_p()
+    j = job()
+    j.cbSize = C.sizeof(FrameJob) - 8                      # a caller compiled against an older, shorter header
+    assert lib.WelsHipFrameEncode(ctx, C.byref(j), C.byref(rec)) == oh.cmInitParaError and b"cbSize" in lib.WelsHipGetLastError()
+    j = job()
+    j.bPackedRecords = 1                                   # packed records asked for without a way to learn what came back
+    assert lib.WelsHipFrameEncode(ctx, C.byref(j), C.byref(rec)) == oh.cmInitParaError and b"pbRecordsPacked" in lib.WelsHipGetLastError()
+    got = C.c_int32(-1)
+    j.pbRecordsPacked = C.pointer(got)
+    assert lib.WelsHipFrameEncode(ctx, C.byref(j), C.byref(rec)) == 0, lib.WelsHipGetLastError()
+    assert got.value == 1
+    view = C.cast(rec, C.POINTER(PackedRecords)).contents
+    offs = [view.pOffset[i] for i in range(mbs + 1)]
+    assert offs[0] == 0 and all(16 <= b - a <= REC_BYTES + 16 for a, b in zip(offs, offs[1:]))
+    j = job(1)
+    got2 = C.c_int32(-1)
+    j.pbRecordsPacked = C.pointer(got2)                    # no packing asked for: the flag still says what *ppRecords is
+    assert lib.WelsHipFrameEncode(ctx, C.byref(j), C.byref(rec)) == 0 and got2.value == 0
+    lib.WelsHipFrameCtxDestroy(ctx)
+    # a picture of more macroblocks than the packer takes (WELSHIP_PACKED_MAX_MB = 9216): full records, and the flag says so
+    lib, ctx, job, mbs, keep = _frame_api(lib_path, 2048, 1200)
+    assert mbs > 9216
+    j = job()
+    j.bPackedRecords = 1
+    got = C.c_int32(-1)
+    j.pbRecordsPacked = C.pointer(got)
+    assert lib.WelsHipFrameEncode(ctx, C.byref(j), C.byref(rec)) == 0, lib.WelsHipGetLastError()
+    assert got.value == 0
+    raw = C.string_at(rec, REC_BYTES * mbs)
+    assert all(raw[i * REC_BYTES] in (0, 1, 2, 3, 4) for i in range(0, mbs, 97))       # mb_type of an I picture's macroblocks: a record array, not two pointers
+    lib.WelsHipFrameCtxDestroy(ctx)
+
+
+def test_job_size_and_record_format(emu_lib):
+    _job_size_and_record_format(emu_lib)
+
+
+@pytest.mark.gpu
+def test_hip_job_size_and_record_format(hip_lib):
+    _job_size_and_record_format(hip_lib)
+
+
+def test_a_failed_tail_fails_its_own_context(emu_lib, monkeypatch):
+    """The deblocking pass / border expansion of a picture runs after its caller was released (the entropy coder only needs the records).  When it
+    times out, the picture's OWN context must learn at its next call -- not the next launch set on that queue, and never nobody (the context would
+    predict from a corrupt reconstruction).  The CPU test build's backend reports a time-out in the k-th copy of the error words on request."""
+    monkeypatch.setenv("WELSHIP_EMU_ERR_SNAPSHOT_AT", "2")          # copy 1: behind the first picture's records; copy 2: behind its expansion
+    lib, ctx, job, mbs, keep = _frame_api(emu_lib, 128, 96)
+    lib2, ctx2, job2, mbs2, keep2 = _frame_api(emu_lib, 96, 64)      # another session on the same device (its own key and launch sets)
+    rec = C.c_void_p()
+    assert lib.WelsHipFrameEncode(ctx, C.byref(job(0)), C.byref(rec)) == 0          # the records were fine: the caller is released
+    assert lib.WelsHipFrameEncode(ctx2, C.byref(job2(0)), C.byref(rec)) == 0, lib.WelsHipGetLastError()     # the other session is not blamed
+    rc = lib.WelsHipFrameEncode(ctx, C.byref(job(1)), C.byref(rec))
+    assert rc != 0 and b"previous picture" in lib.WelsHipGetLastError()
+    assert lib.WelsHipFrameEncode(ctx, C.byref(job(1)), C.byref(rec)) == 0, lib.WelsHipGetLastError()       # reported once; an intra picture starts afresh
+    assert lib.WelsHipFrameEncode(ctx2, C.byref(job2(1)), C.byref(rec)) == 0
+    lib.WelsHipFrameCtxDestroy(ctx)
+    lib.WelsHipFrameCtxDestroy(ctx2)

@@ -46,6 +46,7 @@ def _encode_after_refill(lib_path):
 
     def encode(ctx, buf, cur, ref):
         j = FrameJob()
+        j.cbSize = C.sizeof(FrameJob)
         j.iCurPic, j.iRefPic, j.eSliceType, j.iQp, j.iComplexityMode, j.iMvRange = cur, ref, (2 if ref < 0 else 0), 26, 1, 64
         j.iNumSlices, j.pSliceFirstMb = 1, first
         j.iDeblockIdc, j.bDeblock, j.bExpand = 0, 1, 1

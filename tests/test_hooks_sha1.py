@@ -343,3 +343,36 @@ def test_concurrent_sessions_on_emulation(emu_lib, tmp_path):
 @pytest.mark.gpu
 def test_concurrent_sessions_on_the_mi355x(hip_lib, tmp_path):
     _parallel_sessions(hip_lib, tmp_path, 6)
+
+
+# ---- pictures of more macroblocks than the record packer takes (advisor finding, round 4) ----------------------------------------------
+def _large_picture_through_the_hooks(lib, tmp_path):
+    """2048x1200 = 9600 macroblocks, above WELSHIP_PACKED_MAX_MB: the library hands such a picture's records over unpacked and says so
+    (WelsHipFrameJob::pbRecordsPacked); the slice loop must read them as what they are -- the stream is the unmodified reference's."""
+    from openh264_amd.utils.synth import synth_sequence
+    w, h, n = 2048, 1200, 2
+    yuv = str(tmp_path / "in.yuv")
+    open(yuv, "wb").write(synth_sequence(w, h, n))
+    base = ["-i", yuv, "-w", str(w), "-h", str(h), "-rc", "-1", "-qp", "30", "-fps", "30", "-iper", "0", "-slcmd", "1", "-slcnum", "2", "-quiet"]
+    subprocess.check_call([os.path.join(REF, "ref_enc")] + base + ["-o", str(tmp_path / "c.264")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    p = subprocess.run([os.path.join(REF, "ref_enc_hip")] + base + ["-o", str(tmp_path / "d.264")], env=dict(os.environ, WELSHIP_LIB=lib, WELS_HIP_TRACE="1"),
+                       stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    err = p.stderr.decode(errors="replace")
+    assert p.returncode == 0 and "welship hooks: installed" in err and err.count("welship hooks: did") >= n, err[-2000:]
+    assert (tmp_path / "c.264").read_bytes() == (tmp_path / "d.264").read_bytes()
+
+
+def test_large_picture_through_the_hooks_on_emulation(emu_lib, tmp_path):
+    _large_picture_through_the_hooks(emu_lib, tmp_path)
+
+
+@pytest.mark.gpu
+def test_large_picture_through_the_hooks_on_the_mi355x(hip_lib, tmp_path):
+    _large_picture_through_the_hooks(hip_lib, tmp_path)
+
+
+def test_unpacked_records_on_request_on_emulation(emu_lib, workdir):
+    """WELSHIP_COMPACT=0 (the library keeps full records) under hooks that ask for packed ones: the answer's format is reported, not assumed."""
+    row = _device_rows()[5]
+    got, pictures, err = _run_row(workdir, emu_lib, row, "nc", {"WELSHIP_COMPACT": "0"})
+    assert got == row[0] and pictures >= 40

@@ -96,7 +96,7 @@ def test_one_device_per_simulcast_layer(emu_lib, tmp_path):
     share device WELS_HIP_DEVICE.  Same access units either way."""
     import re
     flags, pictures = SMALL[1]                         # three lower layers + the full-size one
-    for layer_devices, want in (("1", [2, 3, 4, 5]), ("0", [2])):
+    for layer_devices, want in (("1", [2, 3, 4, 5]), ("0", [2]), ("2", [2, 3])):      # ("2": two GPUs for the four layers, d mod 2)
         err = _both(emu_lib, tmp_path, synth_sequence(640, 368, 6), 640, 368, flags, pictures,
                     {"WELS_HIP_DEVICE": "2", "WELS_HIP_LAYER_DEVICES": layer_devices, "WELSHIP_TRACE_DEVICES": "1"})
         got = sorted(set(int(x) for x in re.findall(r"welship emu: backend for device (\d+)", err)))

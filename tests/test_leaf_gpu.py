@@ -46,7 +46,7 @@ def test_sad_satd_sad_four(L):
     p1 = rng.integers(0, 256, (64, 96), dtype=np.uint8)
     p2 = rng.integers(0, 256, (64, 160), dtype=np.uint8)
     for blk in range(7):
-        for _ in range(6):
+        for _ in range(300):
             o1 = int(rng.integers(4, 40)) * 96 + int(rng.integers(4, 70))
             o2 = int(rng.integers(4, 40)) * 160 + int(rng.integers(4, 130))
             for kind in ("Sad", "Satd"):
@@ -70,7 +70,7 @@ def test_transform_and_quantisation_slots(L):
     rng = np.random.default_rng(6)
     p1 = rng.integers(0, 256, (32, 64), dtype=np.uint8)
     p2 = rng.integers(0, 256, (32, 48), dtype=np.uint8)
-    for _ in range(8):
+    for _ in range(200):
         o1, o2 = int(rng.integers(0, 20)) * 64 + int(rng.integers(0, 50)), int(rng.integers(0, 20)) * 48 + int(rng.integers(0, 36))
         got, want = np.zeros(64, np.int16), np.zeros(64, np.int16)
         lib.WelsHipDctT4(p16(got), at(p1, o1), 64, at(p2, o2), 48)
@@ -80,7 +80,7 @@ def test_transform_and_quantisation_slots(L):
         for b, (dx, dy) in enumerate(((0, 0), (4, 0), (0, 4), (4, 4))):     # encode_mb_aux.cpp:348-368: left, right, lower left, lower right
             orc.orc_dct4x4(p16(want, b * 16), at(p1, o1 + dy * 64 + dx), 64, at(p2, o2 + dy * 48 + dx), 48)
         assert (got == want).all()
-    for _ in range(12):
+    for _ in range(300):
         d = rng.integers(-32768, 32768, 64).astype(np.int16)
         if _ % 3 == 0:
             d = rng.integers(-600, 600, 64).astype(np.int16)
@@ -118,7 +118,7 @@ def test_transform_and_quantisation_slots(L):
 def test_reconstruction_slots(L):
     lib, orc = L
     rng = np.random.default_rng(7)
-    for _ in range(10):
+    for _ in range(200):
         res = rng.integers(-2000, 2000, 64).astype(np.int16)
         mf = rng.integers(10, 300, 8).astype(np.uint16)
         g = res.copy(); lib.WelsHipDequant4x4(p16(g), mf.ctypes.data_as(C.POINTER(C.c_uint16)))
@@ -156,7 +156,7 @@ def test_motion_compensation_slots(L):
     src = rng.integers(0, 256, (64, 96), dtype=np.uint8)
     for chroma, sizes in ((0, ((16, 16), (16, 8), (8, 16), (8, 8), (8, 4), (4, 8), (4, 4))), (1, ((8, 8), (8, 4), (4, 8), (4, 4), (2, 4), (4, 2), (2, 2)))):
         for (w, h) in sizes:
-            for _ in range(6):
+            for _ in range(100):
                 o = int(rng.integers(8, 36)) * 96 + int(rng.integers(8, 70))
                 mvx, mvy = int(rng.integers(-40, 40)), int(rng.integers(-40, 40))
                 got = np.full((20, 24), 7, np.uint8); want = got.copy()
@@ -194,7 +194,7 @@ def test_intra_predictor_slots(L):
     for fam, tab, n, of in (("WelsHipI4x4LumaPred", i4, 16, orc.orc_pred_i4x4), ("WelsHipI16x16LumaPred", i16, 256, orc.orc_pred_i16x16),
                             ("WelsHipIChromaPred", ic, 64, orc.orc_pred_chroma)):
         for name, mode in tab:
-            for _ in range(4):
+            for _ in range(60):
                 o = int(rng.integers(4, 24)) * 64 + int(rng.integers(4, 40))
                 got, want = np.zeros(n, np.uint8), np.zeros(n, np.uint8)
                 getattr(lib, fam + name)(at(got), at(plane, o), 64)
@@ -205,7 +205,7 @@ def test_intra_predictor_slots(L):
 def test_deblocking_slots(L):
     lib, orc = L
     rng = np.random.default_rng(10)
-    for _ in range(24):
+    for _ in range(400):
         base = rng.integers(60, 200)
         pl = np.clip(base + rng.integers(-14, 15, (40, 48)), 0, 255).astype(np.uint8)
         pl2 = np.clip(base + rng.integers(-14, 15, (40, 48)), 0, 255).astype(np.uint8)

@@ -45,35 +45,76 @@ def planes(rng, n):
     return p1, p2, o1, o2
 
 
+N_PAIRS = 131072          # pairs per block size and function: every one compared (SURVEY 7 minimum slice: 10^6 random pairs over the family)
+
+
+def _sad_family(lib, orc, p1, s1, o1, p2, s2, o2, blocks=range(7)):
+    """Every block size x {SAD, SATD, four-neighbour SAD} for the given (enc, ref) pairs: the device's answers against the oracle's, all of them."""
+    n = len(o1)
+    for blk in blocks:
+        for name, fn, k in (("sad", lib.WelsHipPrimSampleSad, 1), ("satd", lib.WelsHipPrimSampleSatd, 1), ("sad_four", lib.WelsHipPrimSample4Sad, 4)):
+            out, want = np.zeros(n * k, np.int32), np.zeros(n * k, np.int32)
+            assert fn(blk, n, u8(p1), C.c_size_t(p1.size), s1, i32(o1), u8(p2), C.c_size_t(p2.size), s2, i32(o2), i32(out)) == 0
+            getattr(orc, "orc_%s_batch" % name)(blk, n, u8(p1), s1, i32(o1), u8(p2), s2, i32(o2), i32(want))
+            bad = np.nonzero(out != want)[0]
+            assert bad.size == 0, (name, blk, int(bad[0]) // k, int(out[bad[0]]), int(want[bad[0]]))
+
+
 def test_sad_satd_sad4(L):
+    """131072 random pairs per block size and function, 7 x 3 x 131072 = 2.75 M comparisons, every case checked."""
     lib, orc = L
     rng = np.random.default_rng(11)
-    n = 3000
-    p1, p2, o1, o2 = planes(rng, n)
-    for blk in range(7):
-        for name, fn, k in (("sad", lib.WelsHipPrimSampleSad, 1), ("satd", lib.WelsHipPrimSampleSatd, 1), ("sad_four", lib.WelsHipPrimSample4Sad, 4)):
-            out = np.zeros(n * k, np.int32)
-            assert fn(blk, n, u8(p1), C.c_size_t(p1.size), 128, i32(o1), u8(p2), C.c_size_t(p2.size), 160, i32(o2), i32(out)) == 0
-            for i in range(0, n, 7):
-                if k == 1:
-                    assert out[i] == getattr(orc, "orc_" + name)(blk, at(p1, o1[i]), 128, at(p2, o2[i]), 160)
-                else:
-                    r = (C.c_int32 * 4)()
-                    orc.orc_sad_four(blk, at(p1, o1[i]), 128, at(p2, o2[i]), 160, r)
-                    assert list(out[i * 4:i * 4 + 4]) == list(r)
+    p1, p2, o1, o2 = planes(rng, N_PAIRS)
+    # (random u8 pixels: the domain of the reference's own unit tests; a tenth of the pairs with near-equal blocks, where SATD's rounding matters)
+    p2[:, :128] = np.clip(p1.astype(np.int32) + rng.integers(-3, 4, p1.shape), 0, 255).astype(np.uint8)
+    k = N_PAIRS // 10
+    o2[:k] = (o1[:k] // 128) * 160 + o1[:k] % 128         # the same position in both planes: differences of -3 .. 3
+    _sad_family(lib, orc, p1, 128, o1, p2, 160, o2)
+
+
+def test_sad_satd_on_real_enc_ref_pairs(L, ref_tools, tmp_path):
+    """Real (enc, ref) pairs as the motion search meets them, produced by oracle/_ref: enc = a macroblock of source picture k of the reference's own
+    clip, ref = the reference encoder's RECONSTRUCTION of picture k - 1 (its bitstream through its decoder) displaced by a search offset -- every
+    macroblock of every picture at 40 offsets ("real (enc, ref) MB pairs dumped from the oracle")."""
+    import subprocess
+    lib, orc = L
+    assert ref_tools, "oracle/_ref must travel to the GPU box"
+    w, h, frames = 320, 192, 8
+    src = np.fromfile(os.path.join(ROOT, "oracle", "_ref", "res", "CiscoVT2people_320x192_12fps.yuv"), np.uint8)[: w * h * 3 // 2 * frames]
+    fi, fo, fd = str(tmp_path / "in.yuv"), str(tmp_path / "ref.264"), str(tmp_path / "dec.yuv")
+    src.tofile(fi)
+    subprocess.check_call([ref_tools["enc"], "-i", fi, "-w", str(w), "-h", str(h), "-o", fo, "-rc", "-1", "-qp", "30", "-fps", "12", "-iper", "0", "-quiet"], stdout=subprocess.DEVNULL)
+    subprocess.check_call([ref_tools["dec"], fo, fd], stdout=subprocess.DEVNULL)
+    rec = np.fromfile(fd, np.uint8)
+    fsz = w * h * 3 // 2
+    assert rec.size == fsz * frames
+    pad = 32                                              # the reference pictures' border, replicated as ExpandPicture does
+    enc_y = np.concatenate([src[k * fsz:k * fsz + w * h] for k in range(1, frames)]).reshape((frames - 1) * h, w)
+    ref_y = np.concatenate([np.pad(rec[k * fsz:k * fsz + w * h].reshape(h, w), pad, mode="edge") for k in range(frames - 1)])
+    rs, rh = w + 2 * pad, h + 2 * pad
+    rng = np.random.default_rng(17)
+    o1, o2 = [], []
+    for k in range(frames - 1):
+        for my in range(h // 16):
+            for mx in range(w // 16):
+                d = rng.integers(-16, 17, (40, 2))
+                d[0] = 0
+                o1 += [(k * h + my * 16) * w + mx * 16] * 40
+                o2 += [((k * rh + pad + my * 16 + int(dy)) * rs + pad + mx * 16 + int(dx)) for dx, dy in d]
+    o1, o2 = np.array(o1, np.int32), np.array(o2, np.int32)
+    assert len(o1) == 7 * 240 * 40
+    _sad_family(lib, orc, np.ascontiguousarray(enc_y), w, o1, np.ascontiguousarray(ref_y), rs, o2)
 
 
 def test_dct_quant_scan_dequant_idct(L):
     lib, orc = L
     rng = np.random.default_rng(12)
-    n = 4000
+    n = N_PAIRS
     p1, p2, o1, o2 = planes(rng, n)
-    dct = np.zeros((n, 16), np.int16)
+    dct, ref = np.zeros((n, 16), np.int16), np.zeros((n, 16), np.int16)
     assert lib.WelsHipPrimDctT4(n, u8(p1), C.c_size_t(p1.size), 128, i32(o1), u8(p2), C.c_size_t(p2.size), 160, i32(o2), i16(dct)) == 0
-    ref = np.zeros(16, np.int16)
-    for i in range(0, n, 5):
-        orc.orc_dct4x4(i16(ref), at(p1, o1[i]), 128, at(p2, o2[i]), 160)
-        assert (dct[i] == ref).all()
+    orc.orc_dct4x4_batch(n, u8(p1), 128, i32(o1), u8(p2), 160, i32(o2), i16(ref))
+    assert (dct == ref).all()
     for intra in (0, 1):
         x = rng.integers(-32768, 32768, (n, 16)).astype(np.int16)     # EncUT_EncoderMbAux.cpp:440-444 domain
         x[: n // 2] = dct[: n // 2]
@@ -82,27 +123,20 @@ def test_dct_quant_scan_dequant_idct(L):
         mx, zz, za = np.zeros(n, np.int16), np.zeros((n, 16), np.int16), np.zeros((n, 16), np.int16)
         ctr, nz = np.zeros(n, np.int32), np.zeros(n, np.int32)
         assert lib.WelsHipPrimQuant4x4(n, i16(io), u8(qp), intra, i16(mx), i16(zz), i16(za), i32(ctr), i32(nz)) == 0
-        for i in range(0, n, 3):
-            r = x[i].copy()
-            m = orc.orc_quant4x4_max(i16(r), int(qp[i]), intra)
-            assert (io[i] == r).all() and mx[i] == m
-            a, b = np.zeros(16, np.int16), np.zeros(16, np.int16)
-            orc.orc_scan4x4_dcac(i16(a), i16(r)); orc.orc_scan4x4_ac(i16(b), i16(r))
-            assert (zz[i] == a).all() and (za[i] == b).all()
-            assert ctr[i] == orc.orc_single_ctr4x4(i16(a)) and nz[i] == orc.orc_nonzero_count(i16(a))
+        r = x.copy()
+        rmx, rzz, rza = np.zeros(n, np.int16), np.zeros((n, 16), np.int16), np.zeros((n, 16), np.int16)
+        rctr, rnz = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        orc.orc_quant_scan_batch(n, i16(r), u8(qp), intra, i16(rmx), i16(rzz), i16(rza), i32(rctr), i32(rnz))
+        assert (io == r).all() and (mx == rmx).all() and (zz == rzz).all() and (za == rza).all() and (ctr == rctr).all() and (nz == rnz).all()
     lev = rng.integers(-2000, 2000, (n, 16)).astype(np.int16)
     lev[::4] = rng.integers(-32768, 32768, (len(lev[::4]), 16)).astype(np.int16)    # int16 wrap-around cases
     qp = rng.integers(0, 52, n).astype(np.uint8)
     pred = rng.integers(0, 256, (n, 16), dtype=np.uint8)
     rec, deq = np.zeros((n, 16), np.uint8), np.zeros((n, 16), np.int16)
     assert lib.WelsHipPrimDequantIDctRec(n, i16(lev), u8(qp), u8(pred), u8(rec), i16(deq)) == 0
-    for i in range(0, n, 3):
-        d = lev[i].copy()
-        orc.orc_dequant4x4(i16(d), int(qp[i]))
-        assert (deq[i] == d).all()
-        r = np.zeros(16, np.uint8)
-        orc.orc_idct4x4_rec(u8(r), 4, u8(pred[i]), 4, i16(d))
-        assert (rec[i] == r).all()
+    rrec, rdeq = np.zeros((n, 16), np.uint8), np.zeros((n, 16), np.int16)
+    orc.orc_dequant_idct_rec_batch(n, i16(lev), u8(qp), u8(pred), u8(rrec), i16(rdeq))
+    assert (deq == rdeq).all() and (rec == rrec).all()
 
 
 def test_intra_predictors(L):
@@ -143,7 +177,7 @@ def test_motion_compensation(L):
     rng = np.random.default_rng(14)
     pl = rng.integers(0, 256, (96, 128), dtype=np.uint8)
     for (w, h, chroma) in [(16, 16, 0), (16, 8, 0), (8, 16, 0), (8, 8, 0), (4, 4, 0), (8, 8, 1), (4, 4, 1), (2, 2, 1), (8, 4, 1)]:
-        n = 400
+        n = 4000
         off = (rng.integers(8, 60, n) * 128 + rng.integers(8, 90, n)).astype(np.int32)
         mv = rng.integers(-64, 64, (n, 2)).astype(np.int16)
         dst = np.zeros((n, h, w), np.uint8)
