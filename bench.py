@@ -51,7 +51,6 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--sessions", type=int, default=int(os.environ.get("WELSHIP_BENCH_SESSIONS", "0")),
                     help="independent pictures per GPU per step (default: 128 for the P workload = two slice workgroups per CU, 256 for all-IDR)")
-    ap.add_argument("--queues", type=int, default=int(os.environ.get("WELSHIP_QUEUES", "1")), help="device queues the sessions are spread over")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--qp", type=int, default=24)
@@ -412,7 +411,6 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    os.environ["WELSHIP_QUEUES"] = str(a.queues)
     import openh264_amd as oh
     from openh264_amd.utils.synth import synth_sequence
 
@@ -506,7 +504,7 @@ def main():
         "dtype": "u8", "data": data if not cpu_test else data + " -- LAUNCHER TEST on the CPU test build of the kernels: not a measurement",
         "config": {"workload": ("%dx%d all-IDR (intra MD + DCT/quant + deblock), QP %d, LOW complexity" % (w, h, a.qp)) if workload == "intra" else
                    ("%dx%d P-frames, diamond ME range 16, 4 slices/frame, QP %d, LOW complexity" % (w, h, a.qp)),
-                   "pictures_in_flight_per_gpu": a.sessions, "device_queues": a.queues,
+                   "pictures_in_flight_per_gpu": a.sessions,
                    "hot_path": "device MD/recon + deblock + border expand; sources resident in HBM, MB records left in HBM; host CAVLC excluded (see e2e_pipelined)",
                    "note": "throughput needs many concurrent pictures per GPU (128 in flight: ~12 % less, 64: ~45 % less); see latency for 1 and 8 sessions",
                    "parallelism": "sessions sharded over %d GPU(s), no collective" % world},

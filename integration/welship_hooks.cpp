@@ -167,12 +167,12 @@ struct HipState {
   bool downsample = true;               // WELS_HIP_DOWNSAMPLE=0: the spatial layers are down-sampled by the reference's own C functions
   long downsampled = 0;
   bool gom_kernel = false;              // WELS_HIP_GOM=2: single-slice rate-controlled P pictures in ONE device call (the QP recursion runs in the kernel)
-  bool packed = true;                   // WELS_HIP_PACKED=0: whole pictures' records come back as full 960-byte records
-  bool eager_recon = false;             // WELS_HIP_EAGER_RECON=1: copy every reconstruction back into pDecPic as soon as the picture is coded (else: pfHipFetchRecon, on demand)
+  bool packed = true;                   // whole pictures' records come back packed (where the library can: WelsHipFrameJob::pbRecordsPacked says)
+  bool eager_recon = false;             // screen content: copy every reconstruction back into pDecPic as soon as the picture is coded (else: pfHipFetchRecon, on demand)
   long recon_fetched = 0;
   bool check_bits = false;              // WELS_HIP_CHECK_BITS=1: the device counts every macroblock's CAVLC bits and the slice loop compares them with the writer
   std::atomic<long> bits_checked {0};
-  double t_encode = 0.0, t_getpic = 0.0, t_code = 0.0;
+  double t_encode = 0.0, t_getpic = 0.0, t_code = 0.0, t_vaa = 0.0, t_down = 0.0, t_md_prep = 0.0;
   int pictures = 0;
 };
 struct Stopwatch {
@@ -183,7 +183,7 @@ struct Stopwatch {
 
 // The device's reconstruction of the layer's current picture into pDecPic.  Nothing of the hooked encoder reads pDecPic's samples on the
 // host (mode decision, the in-loop filter and the reference pictures live on the device), so this only runs where the reference is about
-// to: PSNR and the test builds' frame dump (pfHipFetchRecon, called from WelsEncoderEncodeExt), or for every picture with WELS_HIP_EAGER_RECON=1.
+// to: PSNR and the test builds' frame dump (pfHipFetchRecon, called from WelsEncoderEncodeExt), or for every picture of a screen-content session.
 bool FetchRecon (HipState* st, sWelsEncCtx* pCtx, HipLayer& L, int iPic) {
   uint8_t* dst[3] = { pCtx->pDecPic->pData[0], pCtx->pDecPic->pData[1], pCtx->pDecPic->pData[2] };
   const int32_t ds[3] = { pCtx->pDecPic->iLineSize[0], pCtx->pDecPic->iLineSize[1], pCtx->pDecPic->iLineSize[2] };
@@ -223,7 +223,7 @@ int32_t DynCode (HipState* st, HipLayer& L, int iPart, int iSliceIdx, int iSlice
   const int est = P.est[is_p ? 1 : 0];
   int end = est > 0 ? iFrom + WELS_MAX (est + (est >> 1), 16) : iPartEnd;
   if (iFrom > iSliceFirst && end < iFrom + (iFrom - iSliceFirst)) end = iFrom + (iFrom - iSliceFirst);      // the slice outgrew the estimate: as much again as it has so far
-  if (end > iPartEnd || getenv ("WELS_HIP_DYNSLICE_WHOLE")) end = iPartEnd;
+  if (end > iPartEnd) end = iPartEnd;
   WelsHipFrameJob jb = L.job;
   jb.pSliceFirstMb = &L.first[0];
   jb.iMbBegin = iFrom; jb.iMbEnd = end;
@@ -291,7 +291,8 @@ int32_t HipVaaCalc (sWelsEncCtx* pCtx, int32_t iDid, SPicture* pCurPic, SPicture
   job.pSumOfDiff8x8 = pRes->pSumOfDiff8x8 ? &pRes->pSumOfDiff8x8[0][0] : NULL;
   job.pMad8x8 = pRes->pMad8x8 ? &pRes->pMad8x8[0][0] : NULL;
   job.pFrameSad = &pRes->iFrameSad;
-  const int rc = g_api.FrameVaa (st->layer[iDid].ctx, &job);
+  int rc;
+  { Stopwatch sw (st->timing ? &st->t_vaa : NULL); rc = g_api.FrameVaa (st->layer[iDid].ctx, &job); }
   if (rc != 0) {
     if (st->trace) fprintf (stderr, "welship hooks: pre-analysis of layer %d stays on the host (%d: %s)\n", iDid, rc, g_api.GetLastError());
     return 1;
@@ -425,9 +426,9 @@ int32_t HipFrameMd (sWelsEncCtx* pCtx) {
   // with WelsMdInterMbEnhancelayer -- the type and one vector of the co-located macroblock of the layer coded just before it
   // (GetRefMb / SetMvBaseEnhancelayer, svc_mode_decision.cpp:108-150), simulcast AVC included
   // pSadCost[0] lives in ONE array for all spatial layers (pEncCtx->pSadCostMb): the host's copy travels with every picture
-  job.pSadCost = (pParam->iSpatialLayerNum > 1 && !getenv ("WELS_HIP_NO_SADCOST")) ? pCtx->pSadCostMb : NULL;
+  job.pSadCost = (pParam->iSpatialLayerNum > 1) ? pCtx->pSadCostMb : NULL;
   job.pIlHint = NULL;
-  if (is_p && pCurLayer->bBaseLayerAvailableFlag && pParam->iSpatialLayerNum == did + 1 && pCurLayer->pRefLayer && !getenv ("WELS_HIP_NO_ILHINT")) {
+  if (is_p && pCurLayer->bBaseLayerAvailableFlag && pParam->iSpatialLayerNum == did + 1 && pCurLayer->pRefLayer) {
     const SDqLayer* kpRefLayer = pCurLayer->pRefLayer;
     L.il_hint.assign ((size_t)num_mb * 4, 0);
     for (int y = 0; y < mbh; ++y)
@@ -546,9 +547,8 @@ int32_t HipFrameMd (sWelsEncCtx* pCtx) {
   }
   const void* rec = NULL;
   int rc;
-  const char* dump = getenv ("WELS_HIP_DUMP_RECORDS");
   int32_t got_packed = 0;           // what the library really returned (pictures above WELSHIP_PACKED_MAX_MB macroblocks, WELSHIP_COMPACT=0: full records)
-  job.bPackedRecords = (st->packed && dump == NULL && num_mb <= WELSHIP_PACKED_MAX_MB) ? 1 : 0;
+  job.bPackedRecords = (st->packed && num_mb <= WELSHIP_PACKED_MAX_MB) ? 1 : 0;
   job.pbRecordsPacked = &got_packed;
   { Stopwatch sw (st->timing ? &st->t_encode : NULL); rc = g_api.FrameEncode (L.ctx, &job, &rec); }
   ++st->pictures;
@@ -556,12 +556,6 @@ int32_t HipFrameMd (sWelsEncCtx* pCtx) {
   if (got_packed) { L.packed = (const WelsHipPackedRecords*)rec; L.records = NULL; }
   else { L.packed = NULL; L.records = (const WhMbRecord*)rec; }
   job.bPackedRecords = 0; job.pbRecordsPacked = NULL;          // (the job is reused by the retry after a CAVLC overflow, which asks for what the slice loop holds then)
-  if (dump) {        // developer aid: the raw macroblock records of every picture
-    static int s_pic = 0;
-    char name[512];
-    snprintf (name, sizeof name, "%s_%03d_d%d.rec", dump, s_pic++, did);
-    if (FILE* f = fopen (name, "wb")) { fwrite (rec, sizeof (WhMbRecord), num_mb, f); fclose (f); }
-  }
   L.states.clear();
   if (pParam->iSpatialLayerNum > did + 1) {      // a higher layer will read this layer's motion (see pIlHint above)
     L.states.resize (num_mb);
@@ -834,7 +828,8 @@ int32_t HipDownsample (void* p, uint8_t* const pDst[3], const int32_t iDstStride
   HipState* st = (HipState*)p;
   if (st == NULL || !st->downsample || st->failed || g_api.DownsamplePicture == NULL) return 1;
   if (iSrcWidth <= iDstWidth || iSrcHeight <= iDstHeight || iDstWidth < 2 || iDstHeight < 2) return 1;       // (RET_INVALIDPARAM of the C path: leave it to it)
-  const int rc = g_api.DownsamplePicture (st->device, pDst, iDstStride, iDstWidth, iDstHeight, pSrc, iSrcStride, iSrcWidth, iSrcHeight);
+  int rc;
+  { Stopwatch sw (st->timing ? &st->t_down : NULL); rc = g_api.DownsamplePicture (st->device, pDst, iDstStride, iDstWidth, iDstHeight, pSrc, iSrcStride, iSrcWidth, iSrcHeight); }
   if (rc != 0) {
     if (st->trace) fprintf (stderr, "welship hooks: down-sampling %dx%d -> %dx%d stays on the host (%d)\n", iSrcWidth, iSrcHeight, iDstWidth, iDstHeight, rc);
     return 1;
@@ -848,8 +843,8 @@ void HipRelease (void* p) {
   HipState* st = (HipState*)p;
   if (st == NULL) return;
   if (st->check_bits && st->trace) fprintf (stderr, "welship hooks: CAVLC bit counts of %ld macroblocks equal the writer's\n", st->bits_checked.load());
-  if (st->timing && st->pictures) fprintf (stderr, "welship hooks: %d pictures; per picture: device call %.3f ms, reconstruction copy-back %.3f ms, slice coding from the records %.3f ms\n",
-                                           st->pictures, 1e3 * st->t_encode / st->pictures, 1e3 * st->t_getpic / st->pictures, 1e3 * st->t_code / st->pictures);
+  if (st->timing && st->pictures) fprintf (stderr, "welship hooks: %d pictures; per picture: device call %.3f ms, reconstruction copy-back %.3f ms, slice coding from the records %.3f ms, pre-analysis call %.3f ms, down-sampling calls %.3f ms\n",
+                                           st->pictures, 1e3 * st->t_encode / st->pictures, 1e3 * st->t_getpic / st->pictures, 1e3 * st->t_code / st->pictures, 1e3 * st->t_vaa / st->pictures, 1e3 * st->t_down / st->pictures);
   for (int i = 0; i < MAX_DEPENDENCY_LAYER; ++i) if (st->layer[i].ctx) g_api.FrameCtxDestroy (st->layer[i].ctx);
   delete st;
 }
@@ -992,8 +987,8 @@ void WelsHipInstall (SWelsFuncPtrList* pFuncList, SWelsSvcCodingParam* pParam) {
   st->gom_kernel = (getenv ("WELS_HIP_GOM") == NULL || atoi (getenv ("WELS_HIP_GOM")) >= 2) && pParam->iEntropyCodingModeFlag == 0;
   // (screen content: the reference's own pre-processing reads the reconstructed reference picture on the host -- the feature search's hash
   //  lists, PerformFMEPreprocess, svc_motion_estimate.cpp:700-760 -- so such sessions get every picture back)
-  st->packed = !(getenv ("WELS_HIP_PACKED") != NULL && atoi (getenv ("WELS_HIP_PACKED")) == 0);
-  st->eager_recon = (getenv ("WELS_HIP_EAGER_RECON") != NULL && atoi (getenv ("WELS_HIP_EAGER_RECON")) != 0) || pParam->iUsageType == SCREEN_CONTENT_REAL_TIME;
+  st->packed = true;
+  st->eager_recon = pParam->iUsageType == SCREEN_CONTENT_REAL_TIME;
   st->check_bits = getenv ("WELS_HIP_CHECK_BITS") != NULL && atoi (getenv ("WELS_HIP_CHECK_BITS")) != 0 && pParam->iEntropyCodingModeFlag == 0;
   st->layer_devices = getenv ("WELS_HIP_LAYER_DEVICES") != NULL ? WELS_MAX (0, atoi (getenv ("WELS_HIP_LAYER_DEVICES"))) : 0;
   st->downsample = !(getenv ("WELS_HIP_DOWNSAMPLE") != NULL && atoi (getenv ("WELS_HIP_DOWNSAMPLE")) == 0);

@@ -877,7 +877,7 @@ class HipBackend : public wh::Backend {
   }
   // P pictures: one workgroup per CU-load of slices.  Few slices (latency regime): one slice per workgroup, 12 waves.  Enough
   // slices to fill the chip twice: groups of 2..4 slices share a 12-wave workgroup (k_inter_pool), dealt out by k_md_assign.
-  // WELSHIP_MD_SLOTS = 1..4 forces the group size, WELSHIP_P_WAVES the wave count, WELSHIP_MD_ASSIGN=0 the plain order.
+  // WELSHIP_MD_SLOTS = 1..4 forces the group size, WELSHIP_P_WAVES the wave count.
   void run_inter (const WhSeqParams& Pin, const WhPicJob* jobs, int n) override {
     const bool plain = WH_PLAIN_KERNEL && (Pin.flags & WH_SEQ_PLAIN) != 0, no_ctrl = WH_FRAME_KERNEL && (Pin.flags & WH_SEQ_NO_CTRL) != 0;
     WhSeqParams Pm = Pin;
@@ -885,7 +885,7 @@ class HipBackend : public wh::Backend {
     const WhSeqParams& P = Pm;
     static const int forced_waves = getenv ("WELSHIP_P_WAVES") ? atoi (getenv ("WELSHIP_P_WAVES")) : 0;
     static const int forced_slots = getenv ("WELSHIP_MD_SLOTS") ? atoi (getenv ("WELSHIP_MD_SLOTS")) : 0;
-    static const int use_assign = getenv ("WELSHIP_MD_ASSIGN") ? atoi (getenv ("WELSHIP_MD_ASSIGN")) : 1;
+    const int use_assign = 1;            // slices dealt out by their previous cost (84 -> 94.5 % of the launch span with live waves on real content)
     const int total = P.num_slices * n;
     int slots = forced_slots > 0 ? std::min (forced_slots, WH_MD_MAX_SLOTS) : std::max (1, std::min (WH_MD_MAX_SLOTS, total / cus_));
     const int groups = (total + slots - 1) / slots;
@@ -943,7 +943,7 @@ class HipBackend : public wh::Backend {
     else if (nw <= 6) launch (k_inter_pool<384, false>); else launch (k_inter_pool<768, false>);
   }
   void run_deblock (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
-    static const int db_waves = getenv ("WELSHIP_DB_WAVES") ? atoi (getenv ("WELSHIP_DB_WAVES")) : 12;    // 73 VGPRs: two 12-wave workgroups per CU, one of 16 (measured 3.85 against 4.79 ms per step of 256 pictures; 8: 4.3, 6: 5.1)
+    const int db_waves = 12;    // 73 VGPRs: two 12-wave workgroups per CU, one of 16 (measured 3.85 against 4.79 ms per step of 256 pictures; 8: 4.3, 6: 5.1)
     // Enough pictures to give every CU one (and a filter that crosses slice edges anyway): ONE band per picture, 16 waves -- no seams between
     // workgroups at all (measured, 256 four-slice 1080p pictures: 3.17 against 3.88 ms per step; profiles/r03_deblock_bands.txt).
     // WELSHIP_DB_WHOLE = 0 / 1 forces the choice (read per launch: the tests switch it).
@@ -1130,6 +1130,10 @@ Backend* create_hip_backend (int device, const char** err) {
   if (!be->usable()) { delete be; if (err) *err = "HIP stream / memory set-up failed on the device"; return nullptr; }
   return be;
 }
-Backend* create_default_backend (int device, const char** err) { return create_hip_backend (device, err); }
+// WELSHIP_TRACE_DEVICES=1: which device index every backend is asked for (the layer -> device and rank -> device mappings: bench.py config4_layer_per_gpu)
+Backend* create_default_backend (int device, const char** err) {
+  if (getenv ("WELSHIP_TRACE_DEVICES")) { fprintf (stderr, "welship: backend for device %d\n", device); fflush (stderr); }
+  return create_hip_backend (device, err);
+}
 
 }  // namespace wh

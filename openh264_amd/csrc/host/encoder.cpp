@@ -59,9 +59,9 @@ inline void build_run_section (WhSeqParams& s, int mb_w, int num_mb, std::vector
   }
 }
 
-// WELSHIP_REC_BLOCKS=0: mode decision writes the unfiltered reconstruction into the planar picture and the deblocking pass filters it in place (the
-// layout before round 4; kept as a switch for A/B runs)
-static bool rec_blocks_on() { static const bool on = !(getenv ("WELSHIP_REC_BLOCKS") && atoi (getenv ("WELSHIP_REC_BLOCKS")) == 0); return on; }
+// (the unfiltered reconstruction lives in macroblock-contiguous blocks, WhPicJob::rec_blk; the planar in-place layout of rounds 1-3 measured
+//  6.07 x against 4.03 x the algorithmic traffic and lost its switch in round 5: profiles/r04_pmc_traffic_unfiltered_recon_in_blocks.txt)
+static bool rec_blocks_on() { return true; }
 
 struct DevPicture {            // one padded reconstruction buffer + its tiled twin (same allocation) + its MB state
   uint8_t* base = nullptr;
@@ -290,15 +290,13 @@ struct SessionCore {
     d_rec_blk = rec_blocks_on() ? (uint8_t*)A ((size_t)WH_SRC_MB_BYTES * num_mb) : nullptr;
     // processing order tables (common/mb_order.h): per slice, whole picture, per deblocking band
     std::vector<uint16_t> order ((size_t)num_mb * 3);
-    const char* band_env = getenv ("WELSHIP_MB_BAND");      // experiment knob: rows per band of the per-slice order (0 = one band)
-    const int band = band_env ? atoi (band_env) : 0;
+    const int band = 0;            // (rows per band of the per-slice order; banded orders measured slower, profiles/HISTORY.md -- one band)
     for (int i = 0; i < s.num_slices; ++i) wh_build_mb_order (mb_w, s.slice_first_mb[i], s.slice_first_mb[i + 1], order.data() + s.slice_first_mb[i], band);
     wh_build_mb_order (mb_w, 0, num_mb, order.data() + num_mb);
     // deblocking bands: after the slice fall-backs above, i.e. for the idc the device really runs
     std::vector<int32_t> bands (3 * (size_t) (mb_h + s.num_slices) + 1);
-    const char* brows_env = getenv ("WELSHIP_DB_BAND_ROWS");     // experiment knobs: rows per deblocking band (default WH_DB_BAND_ROWS),
-    const int brows = brows_env && atoi (brows_env) > 0 ? atoi (brows_env) : WH_DB_BAND_ROWS;   // bands confined to slices also with idc 0
-    const bool by_slice = !(getenv ("WELSHIP_DB_BY_SLICE") && atoi (getenv ("WELSHIP_DB_BY_SLICE")) == 0);
+    const int brows = WH_DB_BAND_ROWS;
+    const bool by_slice = true;           // bands confined to slices also with idc 0 (profiles/r03_deblock_bands.txt)
     const int nb = wh_build_db_bands (mb_w, mb_h, s.num_slices, s.slice_first_mb, s.deblock_idc, brows, bands.data(), (int)bands.size(), by_slice);
     if (nb < 1) { set_err ("deblocking band table"); release(); return WELSHIP_ERR_UNKNOWN; }
     for (int b = 0; b < nb; ++b) wh_build_mb_order (mb_w, bands[b], bands[b + 1], order.data() + 2 * (size_t)num_mb + bands[b]);
@@ -1068,7 +1066,6 @@ int WelsHipGroupCreate (WelsHipEncoderGroup** pp, const WelsHipEncParam* p, int 
   g->d_jobs = (WhPicJob*)be->alloc (sizeof (WhPicJob) * n_sessions);
   if (!g->d_jobs) { set_err ("out of device memory"); for (auto& s : g->sess) s->release(); delete be; delete g; return WELSHIP_ERR_MEMORY; }
   g->h_jobs.resize (n_sessions);
-  if (const char* q = getenv ("WELSHIP_QUEUES")) g->queues = std::max (1, std::min (atoi (q), n_sessions));
   *pp = g;
   return WELSHIP_OK;
 }
@@ -1254,13 +1251,8 @@ int WelsHipGroupEncodeFrames (WelsHipEncoderGroup* g, const WelsHipSourcePicture
 // third reconstruction picture: when the entropy coder finds a CAVLC overflow in step k - 1 (TRY_REENCODING, rare), that picture is
 // coded again on the device (its reference, step k - 2, still exists) and then its already submitted successor once more.
 // Queues: 0 = kernels, WH_PIPE_UPQ = uploads, WH_PIPE_DLQ = downloads.
-static int pipe_queue (int which) {            // WELSHIP_PIPE_QUEUES=upload,download[,second upload] (experiment knob; default 1,2, no second one)
-  static int q[3] = {-2, -2, -2};
-  if (q[0] == -2) {
-    int a = 1, b = 2, c = -1;      // (measured: queues 30 and 31 share a hardware queue with queue 0 -- their copies waited for its kernels; profiles/r03_pipelined_group.txt)
-    if (const char* e = getenv ("WELSHIP_PIPE_QUEUES")) sscanf (e, "%d,%d,%d", &a, &b, &c);
-    q[2] = c; q[1] = b; q[0] = a;
-  }
+static int pipe_queue (int which) {            // upload, download, no second upload queue
+  static const int q[3] = {1, 2, -1};          // (measured: queues 30 and 31 share a hardware queue with queue 0 -- their copies waited for its kernels; profiles/r03_pipelined_group.txt)
   return q[which];
 }
 #define WH_PIPE_UPQ pipe_queue (0)
@@ -1271,7 +1263,7 @@ int WelsHipGroupSetPipelined (WelsHipEncoderGroup* g, int ahead) {
   if (ahead <= 0) { if (g->pending) { set_err ("submitted steps are still pending: flush first"); return WELSHIP_ERR_INIT_PARA; } return WELSHIP_OK; }
   if (ahead > WH_PIPE_MAX_AHEAD) { set_err ("pipelined groups: at most 3 steps ahead"); return WELSHIP_ERR_INIT_PARA; }
   if (g->pipelined) { if (ahead == g->depth - 1) return WELSHIP_OK; set_err ("the group is pipelined already, with a different number of steps ahead"); return WELSHIP_ERR_INIT_PARA; }
-  if (g->queues != 1) { set_err ("pipelined groups use one compute queue (WELSHIP_QUEUES=1)"); return WELSHIP_ERR_UNSUPPORTED; }
+  if (g->queues != 1) { set_err ("pipelined groups use one compute queue"); return WELSHIP_ERR_UNSUPPORTED; }
   if (g->pipe_failed) { set_err ("an earlier WelsHipGroupSetPipelined failed half way: destroy the group"); return WELSHIP_ERR_INIT_PARA; }
   // from here on a failure leaves buffers behind (WelsHipGroupDestroy frees them) and the group unusable
   struct Guard { WelsHipEncoderGroup* g; bool ok = false; ~Guard() { if (!ok) g->pipe_failed = true; } } guard {g};
@@ -1589,14 +1581,6 @@ int WelsHipGroupProfile (WelsHipEncoderGroup* g, int enable, unsigned long long*
     // mode-decision launches since the last read, in 100 MHz ticks (spare slots of the deblocking half): [44] first wave's start to
     // the last wave's end, [45] sum of the wave lifetimes, [46] waves
     out64[44] = h[4097] ? h[4097] - ~h[4096] : 0; out64[45] = h[4098]; out64[46] = h[4099];
-    if (getenv ("WELSHIP_PROF_GROUPS") && h[4097]) {     // when the workgroups of the (last) mode-decision launch ended, in % of the span
-      std::vector<double> e;
-      for (int i = 0; i < 256; ++i) if (h[4104 + i]) e.push_back (100.0 * (double) (h[4104 + i] - ~h[4096]) / (double)out64[44]);
-      std::sort (e.begin(), e.end());
-      fprintf (stderr, "welship: MD workgroup end times (%% of span), %zu groups:", e.size());
-      for (size_t i = 0; i < e.size(); i += std::max<size_t> (1, e.size() / 16)) fprintf (stderr, " %.0f", e[i]);
-      fprintf (stderr, " %.0f\n", e.empty() ? 0.0 : e.back());
-    }
   }
   if (!enable && prof) { be->free (prof); prof = nullptr; }
   return WELSHIP_OK;
@@ -2083,7 +2067,6 @@ int WelsHipFrameCtxCreate (WelsHipFrameCtx** pp, const WelsHipFrameCfg* cfg) {
       if (!be) { set_err (std::string ("no usable device backend: ") + (berr ? berr : "?")); return WELSHIP_ERR_NO_DEVICE; }
       sh = new FrameShared();
       sh->be = be; sh->device = cfg->iDevice;
-      if (const char* e = getenv ("WELSHIP_FRAME_GATHER_US")) sh->gather_us = std::max (0, atoi (e));
       g_frame_shared.push_back (sh);
     }
     ++sh->users;
@@ -2248,10 +2231,9 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
   // screen content: stage the pre-processing's arrays (page-locked, own to this context)
   const WelsHipScreenInfo* scr = is_p ? j->pScreen : nullptr;
   size_t scc_off_ori = 0, scc_off_times = 0, scc_off_start = 0, scc_off_loc = 0, scc_off_order = 0, scc_lists = 0, scc_entries = 0;
-  static const bool scc_serial = getenv ("WELSHIP_SCC_SERIAL") && atoi (getenv ("WELSHIP_SCC_SERIAL")) != 0;       // fallback: plain coding order
+  const bool scc_serial = false;           // (the chained order is the only one: its plain-coding-order fallback lost its switch in round 5)
   const bool scc_scroll = scr && scr->bScrollDetectFlag && (scr->iScrollMvX | scr->iScrollMvY);
   const bool scc_chain = scc_scroll && !scc_serial;
-  if (dyn && scc_scroll && scc_serial) { set_err ("size-limited slices of a scrolled screen-content picture need the chained order (WELSHIP_SCC_SERIAL is set)"); return WELSHIP_ERR_UNSUPPORTED; }
   if (scr) {
     if (!scr->pBlockStaticIdc) { set_err ("screen-content job without the static-block map"); return WELSHIP_ERR_INIT_PARA; }
     const bool fme = scr->bFeatureSearch8x8 != 0;

@@ -238,7 +238,7 @@ def test_bench_line_from_two_ranks_on_the_cpu_test_build(emu_lib):
     import subprocess
     env = dict(os.environ, WELSHIP_LIB=emu_lib)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--sessions", "3", "--width", "176",
-                        "--height", "144", "--cpu-launcher-test"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+                        "--height", "144", "--cpu-launcher-test", "--multi-gpu-legs"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
     lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
     assert len(lines) == 1, lines
@@ -246,6 +246,15 @@ def test_bench_line_from_two_ranks_on_the_cpu_test_build(emu_lib):
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["unit"] == "frames/s"
     assert d["value"] > 0 and abs(d["value"] - 2 * 3 * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 1e-6        # all ranks' pictures / the slowest rank's time
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["frac"] > 0 and "not a measurement" in d["data"]
+    # BASELINE configs 5 and 4 over the ranks (bench.py multi_gpu_legs): every rank hosts its sessions through the dispatch-table binding
+    # at once, rank 0 gathers the digests; one simulcast session with its layers spread over the devices (WELS_HIP_LAYER_DEVICES = number of ranks).
+    if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ref_enc_hip")):
+        c5 = d["config5_4_sessions"]                  # (2 sessions per rank in the launcher test; 8 per GPU = config5_64_sessions on an 8-GPU node)
+        assert c5["n_ranks_seen"] == 2 and c5["sessions"] == 4 and c5["same_bitstreams"] is True and not c5["errors"]
+        assert len(c5["per_gpu_device_frames_per_s"]) == 2 and all(v > 0 for v in c5["per_gpu_device_frames_per_s"])
+        assert abs(c5["aggregate_device_frames_per_s"] - sum(c5["per_gpu_device_frames_per_s"])) < 1e-6 and all(v > 0 for v in c5["per_session_latency_ms"])
+        c4 = d["config4_layer_per_gpu"]
+        assert c4["same_bitstreams"] is True and c4["layer_devices"] == 2 and c4["devices_seen"] == [0, 1] and c4["device_frames_per_s"] > 0
 
 
 # ---- pipelined groups: WelsHipGroupEncodeFramesPipelined returns step k - 1's streams while the device codes step k -------------

@@ -44,6 +44,8 @@ def run(tmp, yuv, hip):
     assert p.returncode == 0, p.stderr[-2000:]
     if hip and os.environ.get("WELS_HIP_TRACE") == "2":       # where a picture's time went, per session
         sys.stderr.write("".join(l + "\n" for l in p.stderr.decode(errors="replace").splitlines() if "per picture" in l))
+    if hip and os.environ.get("WELSHIP_TRACE_DEVICES"):        # which device every backend was opened on (bench.py config4_layer_per_gpu)
+        sys.stderr.write("".join(l + "\n" for l in p.stderr.decode(errors="replace").splitlines() if "backend for device" in l))
     if hip and os.environ.get("WELSHIP_FRAME_STATS"):
         sys.stderr.write("".join(l + "\n" for l in p.stderr.decode(errors="replace").splitlines() if l.startswith("welship:")))
     enc_fps = [float(x) for x in re.findall(rb" fps=([0-9.]+)", p.stdout)]
