@@ -347,7 +347,7 @@ def multi_gpu_legs(rank, world, local, dist, small):
     small: the launcher test's sizes (2 sessions of 3 frames at 720p / one 2-frame simulcast session) on the CPU test build."""
     import re
     out = {}
-    args5 = ["2", "3", "plain"] if small else ["8", "30", "plain", "1080p"]
+    args5 = ["2", "3", "plain"] if small else ["8", "54", "plain", "1080p"]
     try:
         mine, _ = binding_leg(args5, local)
     except Exception as e:          # noqa: BLE001 -- reported in the line
@@ -369,7 +369,7 @@ def multi_gpu_legs(rank, world, local, dist, small):
     if rank == 0:
         n = min(world, 4)
         try:
-            leg, err = binding_leg(["1", "2", "simulcast"] if small else ["1", "30", "simulcast", "1080p"], 0,
+            leg, err = binding_leg(["1", "2", "simulcast"] if small else ["1", "54", "simulcast", "1080p"], 0,
                                    {"WELS_HIP_LAYER_DEVICES": str(n if n >= 2 else 0), "WELSHIP_TRACE_DEVICES": "1", "WELS_HIP_TRACE": "1"})
             leg["layer_devices"] = n
             seen = sorted(set(int(x) for x in re.findall(r"backend for device (\d+)", err)))
@@ -559,8 +559,9 @@ def main():
         # 1080p / 720p / 360p / 180p simulcast AVC layers (all four layers on this GPU; one layer per GPU is WELS_HIP_LAYER_DEVICES=1),
         # config 5 = 8 of the 64 concurrent 1080p sessions (rate control in bitrate mode, raster slices of 2040 macroblocks).
         if workload == "p" and os.path.exists(os.path.join(REF_DIR, "ref_enc_hip")):
-            for key, args in (("config4_simulcast_1080p_720p_360p_180p", ["1", "30", "simulcast", "1080p"]), ("config4_8_sessions", ["8", "30", "simulcast", "1080p"]),
-                              ("config5_8_sessions_1080p_rc_raster_slices", ["8", "30", "plain", "1080p"])):
+            for key, args in (("config4_simulcast_1080p_720p_360p_180p", ["1", "54", "simulcast", "1080p"]), ("config4_8_sessions", ["8", "54", "simulcast", "1080p"]),
+                              ("config5_8_sessions_1080p_rc_raster_slices", ["8", "54", "plain", "1080p"])):      # (the whole 54-frame clip: rounds 2-4 coded its first 30
+                # frames, of which the sessions of the device leg spend about ten falling into step -- a running service is the steady state)
                 try:
                     line[key], _ = binding_leg(args, local, timeout=240)
                 except Exception as e:

@@ -146,8 +146,11 @@ template <class F> struct WhEarlyFn { F& f; __device__ __forceinline__ void call
 //     tickets of one slot are about a dozen apart (the other waves take the ones in between), so a window serves several claims before
 //     the next ticket lies beyond it and one coalesced load refills it;
 //   * the job fields the fetch of the next macroblock's inputs reads, copied out of the LDS descriptor in one go (one wait, not one per field).
+#ifndef WH_MD_ATTR
+#define WH_MD_ATTR          /* (A/B builds: an extra function attribute of the mode-decision kernel, e.g. amdgpu_waves_per_eu) */
+#endif
 template <int MAXT, bool SCC, int VAR = 0>
-__global__ __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPicJob* jobs, uint32_t* err, const uint16_t* groups, int slots,
+__global__ WH_MD_ATTR __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P, const WhPicJob* jobs, uint32_t* err, const uint16_t* groups, int slots,
                                                        int sched_words, int total_slices, uint32_t* slice_cost) {
   constexpr bool CTRL = VAR == 0, HOSTIN = VAR == 0 || VAR == 3;          // (inter_mb.h wh_inter_cold_fetch)
   extern __shared__ __align__ (16) uint8_t smem[];

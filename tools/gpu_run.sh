@@ -7,7 +7,7 @@
 #   tier_all        the same without -x (every failure of the tier in one run)
 #   bench           the default bench line -> bench_default.json (+ a digest)
 #   quick           bench.py --quick (the timed configuration only) -> bench_quick.json
-#   stats           rocprofv3 --kernel-trace --stats of `bench.py --quick` -> kernel_stats.csv
+#   stats           rocprofv3 --kernel-trace --stats of `bench.py --quick --steps 20 --warmup 5` (the driver's run shape) -> kernel_stats.csv
 #   pmc             FETCH_SIZE / WRITE_SIZE passes of `bench.py --quick` (separate runs, --kernel-trace only beside --pmc) -> pmc_traffic.txt
 #   counters:<a>+<b>,<c>   one rocprofv3 --pmc pass per comma-separated group of `bench.py --quick` (counters of a group joined by +) -> counters.txt;
 #                   "counters:list" writes the counter names the box offers (rocprofv3 --list-avail) -> counters_avail.txt
@@ -48,12 +48,12 @@ for stage in "$@"; do
   tier_all) timeout 1500 python -m pytest tests -m gpu -q > $o/pytest_gpu_all.txt 2>&1; tail -15 $o/pytest_gpu_all.txt | cut -c1-300; lap "gpu tier (serial, every failure)";;
   bench)    timeout 900 python bench.py > $o/bench_default.json 2> $o/bench_default.err; digest $o/bench_default.json; lap "bench default";;
   quick)    timeout 300 python bench.py --quick > $o/bench_quick.json 2> $o/bench_quick.err; digest $o/bench_quick.json; lap "bench --quick";;
-  stats)    ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$o/stats -- python $OLDPWD/bench.py --quick --steps 6 --warmup 2 > $OLDPWD/$o/prof_bench.json 2> $OLDPWD/$o/prof_bench.err )
+  stats)    ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$o/stats -- python $OLDPWD/bench.py --quick --steps 20 --warmup 5 > $OLDPWD/$o/prof_bench.json 2> $OLDPWD/$o/prof_bench.err )
             f=$(find $o/stats -name "*kernel_stats.csv" | head -1); cp $f $o/kernel_stats.csv 2>/dev/null; head -14 $o/kernel_stats.csv | cut -c1-200
             python -c "import json; d=json.loads(open('$o/prof_bench.json').read().strip().splitlines()[-1]); print('HIP events of the same run: avg MD launch ms', d['roofline']['avg_launch_ms'])"
             rm -rf $o/stats; lap "kernel stats";;
   pmc)      for c in FETCH_SIZE WRITE_SIZE; do
-              ( cd /tmp && timeout 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OLDPWD/$o/pmc_$c -- python $OLDPWD/bench.py --quick --steps 8 --warmup 4 > $OLDPWD/$o/pmc_$c.log 2>&1 )
+              ( cd /tmp && timeout 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OLDPWD/$o/pmc_$c -- python $OLDPWD/bench.py --quick --steps 20 --warmup 5 > $OLDPWD/$o/pmc_$c.log 2>&1 )
               python tools/pmc_summary.py $o/pmc_$c | grep -E "inter_|intra_|deblock|k_tile|k_expand|src_tile"
               rm -rf $o/pmc_$c
             done > $o/pmc_traffic.txt 2>&1; cat $o/pmc_traffic.txt; lap "pmc";;
