@@ -211,7 +211,9 @@ int TwinOf (HipLayer& L, const SPicture* p) {
 // Frame-constant QP?  (ratectl.cpp:1199-1204: GOM-level QP only for single-slice pictures, and not for I pictures in bitrate mode)
 bool FrameConstantQp (const sWelsEncCtx* pCtx) {
   const SWelsSvcCodingParam* p = pCtx->pSvcParam;
-  if (p->iRCMode == RC_OFF_MODE) return true;
+  // RC_OFF_MODE and RC_BUFFERBASED_MODE install WelsRcMbInitDisable (ratectl.cpp:1495-1516): every macroblock gets iGlobalQp (adaptive quantisation is
+  // switched off by ParamValidation); the other modes run WelsRcMbInitGom, which does the same unless bEnableGomQp (ratectl.cpp:1239-1262)
+  if (p->iRCMode == RC_OFF_MODE || p->iRCMode == RC_BUFFERBASED_MODE) return true;
   return !pCtx->pWelsSvcRc[pCtx->uiDependencyId].bEnableGomQp;
 }
 
@@ -485,7 +487,7 @@ int32_t HipFrameMd (sWelsEncCtx* pCtx) {
     }
   }
   job.pGomRc = NULL;
-  if (L.gom && st->gom_kernel && is_p && job.pScreen == NULL && nslices == 1) {
+  if (L.gom && st->gom_kernel && pParam->iUsageType == CAMERA_VIDEO_REAL_TIME && job.pScreen == NULL && nslices == 1) {      // (I pictures too since round 5)
     // WELS_HIP_GOM=2: the groups' QP recursion (RcCalculateGomQp / RcGomTargetBits between the groups, from the bits the device counts
     // itself) runs inside the kernel, so the picture is ONE device call like a constant-QP picture and shares a launch with other
     // sessions' pictures.  The reference's own rate control still runs in the slice loop, on the real bit positions: every macroblock's QP

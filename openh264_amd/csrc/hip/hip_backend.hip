@@ -75,7 +75,7 @@ __global__ __launch_bounds__ (MAX_THREADS) void NAME (WhSeqParams P, const WhPic
   const int num_mb = P.mb_w * P.mb_h;                                                                                   \
   const int first = WHOLE_PICTURE ? 0 : P.slice_first_mb[blockIdx.x];                                                   \
   const int n = WHOLE_PICTURE ? num_mb : P.slice_first_mb[blockIdx.x + 1] - first;                                      \
-  const uint32_t* order = P.mb_order + (WHOLE_PICTURE ? num_mb : first);                                                \
+  const uint32_t* order0 = P.mb_order + (WHOLE_PICTURE ? num_mb : first);                                               \
   for (int i = (int)threadIdx.x; i < 1 + ((n + 31) >> 5); i += (int)blockDim.x) sched[i] = 0;                          \
   if (PROF && P.prof && lane < 32) wh_prof_lds (S)[lane] = 0;                                                           \
   __shared__ WhPicJob Jl;                   /* the job descriptor, read from LDS (lgkmcnt) wherever it is needed */        \
@@ -83,6 +83,9 @@ __global__ __launch_bounds__ (MAX_THREADS) void NAME (WhSeqParams P, const WhPic
   __syncthreads();                                                                                                      \
   WH_PROF_DECL (P);                                                                                                     \
   const WhPicJob& J = Jl;                                                                                               \
+  /* GOM-level rate control inside the kernel (single-slice pictures): the groups are bands of the picture's OWN order, and a     */ \
+  /* group's first macroblock waits for the last one of the group before it, which settles its QP (WhPicJob::scc_order / _prev)   */ \
+  const uint32_t* order = J.gom_rc ? (const uint32_t*)J.scc_order + first : order0;                                     \
   for (int guard = 0; guard <= n; ++guard) {      /* a wave can never need more than n + 1 tickets */                   \
     int t = 0;                                                                                                          \
     if (lane == 0) t = (int)atomicAdd (&sched[0], 1u);                                                                  \
@@ -98,9 +101,11 @@ __global__ __launch_bounds__ (MAX_THREADS) void NAME (WhSeqParams P, const WhPic
     wh_mb_deps (P.mb_w, xy, first, &dep_a, &dep_b);                                                                     \
     if (!wh_wait_done (sched + 1, dep_a < 0 ? -1 : dep_a - first, err)) break;     /* give up: the host aborts on err */   \
     if (!wh_wait_done (sched + 1, dep_b < 0 ? -1 : dep_b - first, err)) break;                                          \
+    if (J.gom_rc) { const int dep_c = ((const WH_G int32_t*)J.scc_chain_prev)[xy]; if (!wh_wait_done (sched + 1, dep_c < first ? -1 : dep_c - first, err)) break; } \
     __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "workgroup");                                                             \
     if (PROF) WH_PROF_MARK (P, wh_prof_holder (S), 12);      /* dependency wait */                                       \
     BODY (S, P, J, xy % P.mb_w, xy / P.mb_w);                                                                           \
+    if (J.gom_rc) wh_gom_close_if_last (P, J, xy);           /* rate control: the group's last macroblock settles the next group's QP */ \
     if (PROF) WH_PROF_MARK (P, wh_prof_holder (S), 14);      /* the MB itself (sum of the body's own phases) */          \
     __builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");                                                             \
     if (lane == 0) atomicOr (&sched[1 + ((xy - first) >> 5)], 1u << ((xy - first) & 31));                               \
@@ -937,7 +942,7 @@ class HipBackend : public wh::Backend {
       HIP_TRY (hipGetLastError());
       if (getenv ("WELSHIP_TRACE")) { HIP_TRY (hipStreamSynchronize (stream_)); fprintf (stderr, "welship: launch done\n"); fflush (stderr); }
     };
-    if (P.flags & WH_SEQ_SCC) { if (nw <= 6) launch (k_inter_pool<384, true>); else launch (k_inter_pool<768, true>); }
+    if (P.flags & WH_SEQ_SCC) launch (k_inter_pool<384, true>);      // (nw <= 6 above: 249 VGPRs, no scratch; a 12-wave build of this variant spills -- 168 VGPRs + 360 B -- and is not instantiated any more)
     else if (rows && WH_PLAIN_KERNEL == 2 && plain && P.complexity == 0) { if (nw <= 6) launch (k_inter_rows<384, WH_PLAIN_KERNEL == 2 ? 2 : 0>); else launch (k_inter_rows<768, WH_PLAIN_KERNEL == 2 ? 2 : 0>); }
     else if (rows) { if (nw <= 6) launch (k_inter_rows<384>); else launch (k_inter_rows<768>); }
     else if (WH_PLAIN_KERNEL == 2 && plain && P.flags == 0 && P.complexity == 0) { if (nw <= 6) launch (k_inter_pool<384, false, WH_PLAIN_KERNEL == 2 ? 2 : 0>); else launch (k_inter_pool<768, false, WH_PLAIN_KERNEL == 2 ? 2 : 0>); }

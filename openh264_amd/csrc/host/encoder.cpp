@@ -2327,7 +2327,7 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
   // macroblock of a group waits for the last macroblock of the group before it, which settles the group's QP (kernels/inter_mb.h)
   const WelsHipGomRc* gom = j->pGomRc;
   if (gom) {
-    if (!is_p || ranged || retry || scr || j->pMbQp || j->iNumSlices != 1) { set_err ("GOM-level rate control inside the kernel: a whole single-slice camera-video P picture"); return WELSHIP_ERR_INIT_PARA; }
+    if (ranged || retry || scr || j->pMbQp || j->iNumSlices != 1) { set_err ("GOM-level rate control inside the kernel: a whole single-slice camera-video picture"); return WELSHIP_ERR_INIT_PARA; }
     if (gom->iNumberMbGom < 1 || gom->iNumberMbGom % c->mb_w != 0 || gom->iGomSize < 1 || gom->iGomSize > WH_GOM_MAX || !gom->pGomSad || gom->iEndMbSlice != c->num_mb - 1 ||
         gom->iEndMbSlice / gom->iNumberMbGom >= gom->iGomSize) { set_err ("GOM-level rate control inside the kernel needs groups of whole macroblock rows"); return WELSHIP_ERR_UNSUPPORTED; }
     if (c->h_gom.empty()) {
@@ -2338,7 +2338,7 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
     WhGomRc& R = * (WhGomRc*)c->h_gom.data();
     memset (&R, 0, sizeof (R));
     R.n_gom_mb = gom->iNumberMbGom; R.end_mb = gom->iEndMbSlice; R.target_bits = gom->iTargetBitsSlice;
-    R.min_qp = gom->iMinFrameQp; R.max_qp = gom->iMaxFrameQp; R.slice_qp = j->iQp; R.p_slice = 1;
+    R.min_qp = gom->iMinFrameQp; R.max_qp = gom->iMaxFrameQp; R.slice_qp = j->iQp; R.p_slice = is_p ? 1 : 0;
     memcpy (R.gom_sad, gom->pGomSad, sizeof (int32_t) * gom->iGomSize);
     wh_gom_begin (R, j->iQp);
     uint32_t* order = (uint32_t*) (c->h_gom.data() + sizeof (WhGomRc));

@@ -8,6 +8,7 @@
 #pragma once
 #include "intra_mb.h"
 #include "cavlc_bits.h"
+#include "../common/gom_rc.h"
 
 static_assert (sizeof (WhMbRecord) == 960, "WhMbRecord must be 960 bytes");
 static_assert (sizeof (WhMbState) == 144, "WhMbState must be 144 bytes");
@@ -132,7 +133,9 @@ WH_FN void wh_intra_mb_body (WhMbLds& S, const WhSeqParams& P, const WhPicJob& J
   // (size-limited slices: the launch codes ONE slice, which begins at dyn_first -- WhPicJob::dyn_slice)
   const int avail = J.dyn_slice ? wh_mb_avail_in_slice (P, mbx, mby, J.dyn_first) : wh_mb_avail (P, mbx, mby);
   const WhMbCtl ctl = wh_mb_ctl (J, xy);
-  const int qp = wh_mb_qp (J, ctl);
+  // GOM-level rate control inside the kernel (I pictures too since round 5): the QP of this macroblock's group, settled by the last macroblock
+  // of the group before it (wh_gom_close_if_last, inter_mb.h), which the scheduler has waited for (WhPicJob::scc_chain_prev)
+  const int qp = J.gom_rc ? wh_clip3 ((int)wh_ld_wg32 ((const WH_G uint32_t*)& ((const WH_G WhGomRc*)J.gom_rc)->calc_qp), 0, 51) : wh_mb_qp (J, ctl);
   const int qpc = kWhChromaQp[wh_clip3 (qp + P.chroma_qp_offset, 0, 51)];
   WH_PROF_DECL (P);
   wh_load_mb_tile (S, P, J, mbx, mby);

@@ -45,10 +45,33 @@ class EmuBackend : public Backend {
     }
   }
   void run_intra (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
-    for_order (P, n, false, [&] (int j, int x, int y) {
-      const int xy = y * P.mb_w + x;
-      if (jobs[j].mb_end > 0 && (xy < jobs[j].mb_begin || xy >= jobs[j].mb_end)) return;      // GOM-synchronous coding: only this range
-      WhMbLds S; poison (&S, sizeof (S)); wh_intra_mb_body (S, P, jobs[j], x, y); });
+    bool any_gom = false;
+    for (int j = 0; j < n; ++j) any_gom = any_gom || jobs[j].gom_rc != nullptr;
+    if (!any_gom) {
+      for_order (P, n, false, [&] (int j, int x, int y) {
+        const int xy = y * P.mb_w + x;
+        if (jobs[j].mb_end > 0 && (xy < jobs[j].mb_begin || xy >= jobs[j].mb_end)) return;      // GOM-synchronous coding: only this range
+        WhMbLds S; poison (&S, sizeof (S)); wh_intra_mb_body (S, P, jobs[j], x, y); });
+      return;
+    }
+    // GOM-level rate control inside the kernel: the picture's own order (groups as bands), checked against everything the device scheduler waits for
+    const int num_mb = P.mb_w * P.mb_h;
+    for (int j = 0; j < n; ++j) {
+      const WhPicJob& J = jobs[j];
+      if (!J.gom_rc || P.num_slices != 1 || !J.scc_order || !J.scc_chain_prev) { fprintf (stderr, "emu: GOM-level rate control inside the intra kernel needs a single-slice picture with its own order\n"); abort(); }
+      std::vector<char> done_mb ((size_t)num_mb, 0);
+      for (int t = 0; t < num_mb; ++t) {
+        const int xy = (int)J.scc_order[t];
+        int da, db;
+        wh_mb_deps (P.mb_w, xy, 0, &da, &db);
+        const int dc = J.scc_chain_prev[xy];
+        if ((da >= 0 && !done_mb[da]) || (db >= 0 && !done_mb[db]) || (dc >= 0 && !done_mb[dc]) || dc >= xy) { fprintf (stderr, "emu: the I picture's order is not topological at MB %d (deps %d %d %d)\n", xy, da, db, dc); abort(); }
+        done_mb[xy] = 1;
+        WhMbLds S; poison (&S, sizeof (S));
+        wh_intra_mb_body (S, P, J, xy % P.mb_w, xy / P.mb_w);
+        wh_gom_close_if_last (P, J, xy);
+      }
+    }
   }
   // The run scheduler of the device (hip_backend.hip k_inter_rows): one emulated wavefront takes the runs of a slice in the order of
   // the run table (common/mb_order.h wh_build_run_order) and codes each run's macroblocks left to right, keeping its windows inside a

@@ -204,7 +204,8 @@ def test_sha1_table_rows_on_the_mi355x_row_scheduler(workdir, hip_lib):
 # ---- the one-slice rows with the groups' QP recursion INSIDE the kernel (WELS_HIP_GOM=2) ------------------------
 # The device counts every macroblock's CAVLC bits (kernels/cavlc_bits.h), the last macroblock of a group of macroblocks adds the
 # skip-run / mb_qp_delta terms in coding order and runs RcCalculateGomQp / RcGomTargetBits (common/gom_rc.h), the next group reads
-# its QP -- one device call per P picture.  The reference's own rate control still runs in the slice loop on the real bit
+# its QP -- one device call per picture (P pictures since round 2, I pictures since round 5: k_intra_slice walks the picture's own order,
+# waits for the group before and closes its group the same way).  The reference's own rate control still runs in the slice loop on the real bit
 # positions: the hooks compare every macroblock's QP with the record's (and, with WELS_HIP_CHECK_BITS, every bit count).
 def _gom_rows():
     return [r for r in _device_rows() if r[4]["-slcmd 0"] in ("0", "2")]
@@ -217,8 +218,8 @@ def _check_gom_kernel(workdir, lib, rows):
         i, row = ir
         got, pictures, err = _run_row(workdir, lib, row, "g%d" % i, {"WELS_HIP_GOM": "2"})
         os.remove(str(workdir / ("t_g%d.264" % i)))
-        by_group = err.count("GOM-level QP")          # pictures that still went group by group: the I pictures of the quality-mode rows
-        return (row[4], row[0], got, pictures, by_group) if (got != row[0] or pictures < 40 or by_group > pictures // 4) else None
+        by_group = err.count("GOM-level QP")          # pictures that still went group by group: none since round 5 (I pictures run the recursion in the intra kernel)
+        return (row[4], row[0], got, pictures, by_group) if (got != row[0] or pictures < 40 or by_group != 0) else None
 
     with ThreadPoolExecutor(8) as ex:
         bad = [b for b in ex.map(one, enumerate(rows)) if b]
@@ -272,6 +273,8 @@ def _api_hash(lib, tmp_path, name, w, h, fps, gom=None):
     err = p.stderr.decode(errors="replace")
     assert p.returncode == 0, err[-2000:]
     assert "welship hooks: installed" in err and err.count("welship hooks: did") >= 5
+    if gom is None:          # quality-mode rate control gives I pictures a GOM-level QP too: the IDR picture of these sessions is ONE device call as well
+        assert err.count("GOM-level QP") == 0, err[-1500:]
     return hashlib.sha1(open(out, "rb").read()).hexdigest()
 
 
@@ -376,3 +379,35 @@ def test_unpacked_records_on_request_on_emulation(emu_lib, workdir):
     row = _device_rows()[5]
     got, pictures, err = _run_row(workdir, emu_lib, row, "nc", {"WELSHIP_COMPACT": "0"})
     assert got == row[0] and pictures >= 40
+
+
+# ---- I pictures with a GOM-level QP (quality-mode / timestamp rate control, one slice) in ONE device call; buffer-based rate control ------------
+def _intra_gom_sessions(lib, tmp_path):
+    """Rate-control modes that give I pictures a QP per group of macroblocks (RC_QUALITY_MODE 0, RC_TIMESTAMP_MODE 3; bitrate mode switches it off
+    for I slices, ratectl.cpp:1199-1204): since round 5 the intra kernel runs the groups' recursion itself (k_intra_slice: the picture's own order,
+    a group's first macroblock waits for the group before, its last one closes it -- kernels/frame_kernels.h, inter_mb.h wh_gom_close_if_last), so
+    no picture of such a session goes group by group any more; the reference's own rate control still checks every macroblock's QP and bit count.
+    RC_BUFFERBASED_MODE (2) has a frame-constant QP (WelsRcMbInitDisable): any number of slices, plain calls."""
+    from openh264_amd.utils.synth import make_sequence
+    cases = [(320, 192, 9, "pan7", 0, 3, []), (352, 288, 7, "checker8", 0, 0, ["-scene", "1"]), (640, 368, 6, "synth", 3, 4, []), (176, 144, 9, "checker5", 0, 5, ["-complexity", "2"]),
+             (320, 192, 6, "synth", 2, 3, ["-slcmd", "1", "-slcnum", "3"]), (176, 144, 6, "pan7", 2, 0, [])]
+    for k, (w, h, frames, content, rc, iper, extra) in enumerate(cases):
+        yuv = str(tmp_path / "in.yuv")
+        open(yuv, "wb").write(make_sequence(content, w, h, frames))
+        flags = ["-i", yuv, "-w", str(w), "-h", str(h), "-rc", str(rc), "-bitrate", "600000", "-fps", "30", "-iper", str(iper), "-quiet"] + extra
+        subprocess.check_call([os.path.join(REF, "ref_enc")] + flags + ["-o", str(tmp_path / "c.264")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        p = subprocess.run([os.path.join(REF, "ref_enc_hip")] + flags + ["-o", str(tmp_path / "d.264")], env=dict(os.environ, WELSHIP_LIB=lib, WELS_HIP_TRACE="1", WELS_HIP_CHECK_BITS="1"),
+                           stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+        err = p.stderr.decode(errors="replace")
+        assert p.returncode == 0 and "welship hooks: installed" in err, (k, err[-1500:])
+        assert err.count(" I picture") >= (2 if iper else 1) and err.count("GOM-level QP") == 0, (k, err.count(" I picture"), err.count("GOM-level QP"))
+        assert (tmp_path / "c.264").read_bytes() == (tmp_path / "d.264").read_bytes(), k
+
+
+def test_intra_pictures_with_gom_level_qp_on_emulation(emu_lib, tmp_path):
+    _intra_gom_sessions(emu_lib, tmp_path)
+
+
+@pytest.mark.gpu
+def test_intra_pictures_with_gom_level_qp_on_the_mi355x(hip_lib, tmp_path):
+    _intra_gom_sessions(hip_lib, tmp_path)
