@@ -455,26 +455,12 @@ def main():
             dist.destroy_process_group()
         return
 
-    def md_run_len():
-        try:
-            return max(1, int(os.environ.get("WELSHIP_MD_RUN", "1")))
-        except ValueError:
-            return 1
-
-    def md_kernel(sessions):
-        """Which mode-decision kernel the library launches for this batch (hip_backend.hip run_inter): tickets of one macroblock
-        (k_inter_pool) unless runs are asked for (WELSHIP_MD_RUN > 1) and a workgroup holds at least two slices."""
-        forced = os.environ.get("WELSHIP_MD_ROWS")
-        slots = max(1, min(4, sessions * 4 // 256))
-        rows = (forced != "0") if forced is not None else (slots >= 2 and md_run_len() > 1)
-        return "k_inter_rows (runs of %d macroblocks)" % md_run_len() if rows else "k_inter_pool"
-
     def roofline(workload, mbs, sessions, steps, ev):
         b_md = BYTES_I_MB_MD if workload == "intra" else BYTES_P_MB_MD
         b_path = BYTES_I_MB_PATH if workload == "intra" else BYTES_P_MB_PATH
         md_launch_ms = ev["md_ms"] / steps                                   # one launch per pass and step
         achieved = b_md * mbs * sessions / (md_launch_ms * 1e-3) / 1e9       # every MB of every picture in the batch x bytes/MB
-        return {"bound": "hbm", "kernel": "k_intra_slice" if workload == "intra" else md_kernel(sessions),
+        return {"bound": "hbm", "kernel": "k_intra_slice" if workload == "intra" else "k_inter_pool",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "bytes_per_mb": b_md, "avg_launch_ms": md_launch_ms, "launches_per_step": 1,
                 "path_achieved_GBs": b_path * mbs * sessions * steps / (ev["total_ms"] * 1e-3) / 1e9,
@@ -486,7 +472,7 @@ def main():
     try:        # HBM bytes per launch of the dominant kernel: from the committed rocprofv3 --pmc passes of this very command (not measured in this run)
         tj = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")))
         if tj.get("workload") == workload and tj.get("sessions") == a.sessions and (w, h) == (tj.get("width"), tj.get("height")):
-            want = "tickets" if rf["kernel"] == "k_inter_pool" else "runs of 4" if md_run_len() == 4 else "whole rows" if md_run_len() >= (w + 15) // 16 else None
+            want = "tickets" if rf["kernel"] == "k_inter_pool" else None
             for name, v in tj["schedulers"].items():
                 if want and name.startswith(want):
                     rf["traffic"] = v["hbm_bytes_per_launch"]

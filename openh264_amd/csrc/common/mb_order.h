@@ -33,31 +33,6 @@ WH_ORDER_FN void wh_build_mb_order (int mb_w, int first, int last, uint16_t* out
     }
   }
 }
-// ---- runs: `len` horizontally adjacent macroblocks coded one after the other by one wave (k_inter_rows) ----------------
-// The macroblock rows of a range are cut at the multiples of `len`; a run is what such a stretch has in common with the range.
-// Runs are visited sorted by (k + 2 * (y - y_first), y), k = x / len -- the 2:1 order of the run grid: every macroblock a run's
-// macroblocks wait for (left: run k - 1 of the row; top-right: runs k and k + 1 of the row above) lies in an EARLIER run, so
-// waves that take runs from the list in order, and wait macroblock by macroblock, cannot deadlock.  Entry: first MB | count << 20.
-// Returns the number of runs (<= last - first).
-#define WH_RUN_XY(e) ((int) ((e) & 0xfffffu))
-#define WH_RUN_LEN(e) ((int) ((e) >> 20))
-WH_ORDER_FN int wh_build_run_order (int mb_w, int first, int last, int len, uint32_t* out /* up to last - first entries */) {
-  const int y0 = first / mb_w, y1 = (last - 1) / mb_w;
-  if (len < 1) len = 1;
-  const int kw = (mb_w + len - 1) / len;
-  int n = 0;
-  for (int d = 0; d <= (kw - 1) + 2 * (y1 - y0); ++d)
-    for (int y = y0; y <= y1; ++y) {
-      const int k = d - 2 * (y - y0);
-      if (k < 0 || k >= kw) continue;
-      int a = y * mb_w + k * len, b = a + len;
-      if (b > (y + 1) * mb_w) b = (y + 1) * mb_w;
-      if (a < first) a = first;
-      if (b > last) b = last;
-      if (a < b) out[n++] = (uint32_t)a | ((uint32_t) (b - a) << 20);
-    }
-  return n;
-}
 // The (at most two) MBs whose completion implies that every neighbour MB (x,y) reads is complete: the left one and
 // the top-right one (top at the right picture edge); -1 when outside [first, ...).
 WH_ORDER_FN void wh_mb_deps (int mb_w, int xy, int first, int* dep_a, int* dep_b) {

@@ -260,8 +260,6 @@ typedef struct WhSeqParams {
   const uint32_t* mb_order;             // device table (32-bit entries: a wave-uniform look-up is then a scalar load): [0, num_mb) MB addresses in dependency order per slice (each slice's
                                         // range is [slice_first_mb[s], slice_first_mb[s+1])), [num_mb, 2*num_mb) whole-picture order,
                                         // [2*num_mb, 3*num_mb) per deblocking band (each band's range is [db_bands[b], db_bands[b+1]))
-                                        // [3*num_mb, 4*num_mb) per slice: its RUNS of run_len macroblocks in 2:1 run order (common/mb_order.h
-                                        // wh_build_run_order; first MB | count << 20), from entry slice_first_mb[s] on, run_count[s] of them
   // Deblocking bands: the MB ranges the deblocking workgroups own (rows of one slice, at most WH_DB_BAND_ROWS of them: a
   // slice is a band unless it is taller, e.g. a single-slice picture is cut into several).  Device table of
   // 3 * db_num_bands + 1 words: [0, n] first MB of band b (and the end of the last), [n+1, 2n] first MB of the slice band b
@@ -270,8 +268,6 @@ typedef struct WhSeqParams {
   int32_t db_num_bands, db_max_mbs;     // db_max_mbs / db_max_rows: the largest band (host-side launch geometry)
   const int32_t* db_bands;
   int32_t db_max_rows;
-  int32_t run_len;                      // macroblocks per run of the run table (0: the table has no run section)
-  int16_t run_count[WH_MAX_SLICES];     // runs per slice
 } WhSeqParams;
 
 #ifdef __cplusplus

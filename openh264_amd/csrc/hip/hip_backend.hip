@@ -59,7 +59,13 @@ __device__ __forceinline__ bool wh_wait_done (const uint32_t* done, int idx, uin
 __device__ __forceinline__ WhMbLds& wh_prof_holder (WhInterLds& S) { return S.m; }
 __device__ __forceinline__ WhMbLds& wh_prof_holder (WhMbLds& S) { return S; }
 __device__ __forceinline__ WhMbLds& wh_prof_holder (WhDbLds& S) { return * (WhMbLds*)&S; }     /* never used (PROF = 0) */
+#if defined(WH_PROF)
 template <class T> __device__ __forceinline__ uint32_t* wh_prof_lds (T& S) { return wh_prof_holder (S).prof; }
+#define WH_PROF_ON 1
+#else
+template <class T> __device__ __forceinline__ uint32_t* wh_prof_lds (T& S) { return nullptr; }      /* (never dereferenced: WH_PROF_ON = 0) */
+#define WH_PROF_ON 0
+#endif
 
 __device__ __forceinline__ void wh_copy_job (WhPicJob* dst, const WhPicJob* src) {
   for (unsigned i = threadIdx.x; i < sizeof (WhPicJob) / 4; i += blockDim.x) ((uint32_t*)dst)[i] = ((const uint32_t*)src)[i];      // (a one-wave workgroup has fewer threads than the descriptor has words)
@@ -77,7 +83,7 @@ __global__ __launch_bounds__ (MAX_THREADS) void NAME (WhSeqParams P, const WhPic
   const int n = WHOLE_PICTURE ? num_mb : P.slice_first_mb[blockIdx.x + 1] - first;                                      \
   const uint32_t* order0 = P.mb_order + (WHOLE_PICTURE ? num_mb : first);                                               \
   for (int i = (int)threadIdx.x; i < 1 + ((n + 31) >> 5); i += (int)blockDim.x) sched[i] = 0;                          \
-  if (PROF && P.prof && lane < 32) wh_prof_lds (S)[lane] = 0;                                                           \
+  if (WH_PROF_ON && PROF && P.prof && lane < 32) wh_prof_lds (S)[lane] = 0;                                                           \
   __shared__ WhPicJob Jl;                   /* the job descriptor, read from LDS (lgkmcnt) wherever it is needed */        \
   wh_copy_job (&Jl, &jobs[blockIdx.y]);                                                                                 \
   __syncthreads();                                                                                                      \
@@ -111,7 +117,7 @@ __global__ __launch_bounds__ (MAX_THREADS) void NAME (WhSeqParams P, const WhPic
     if (lane == 0) atomicOr (&sched[1 + ((xy - first) >> 5)], 1u << ((xy - first) & 31));                               \
     if (PROF) WH_PROF_MARK (P, wh_prof_holder (S), 13);      /* store drain (release) + done flag */                     \
   }                                                                                                                     \
-  if (PROF && P.prof && lane < 32) atomicAdd (&P.prof[((blockIdx.x + blockIdx.y * 7u) & 63u) * 32u + lane], (unsigned long long)wh_prof_lds (S)[lane]); \
+  if (WH_PROF_ON && PROF && P.prof && lane < 32) atomicAdd (&P.prof[((blockIdx.x + blockIdx.y * 7u) & 63u) * 32u + lane], (unsigned long long)wh_prof_lds (S)[lane]); \
 }
 
 WH_DEFINE_MB_KERNEL (k_intra_slice, WhMbLds, wh_intra_mb_body, 1024, 0, 1)
@@ -151,6 +157,9 @@ template <class F> struct WhEarlyFn { F& f; __device__ __forceinline__ void call
 //     tickets of one slot are about a dozen apart (the other waves take the ones in between), so a window serves several claims before
 //     the next ticket lies beyond it and one coalesced load refills it;
 //   * the job fields the fetch of the next macroblock's inputs reads, copied out of the LDS descriptor in one go (one wait, not one per field).
+#ifndef WH_P_WAVES_DEFAULT
+#define WH_P_WAVES_DEFAULT 14           /* waves per mode-decision workgroup unless WELSHIP_P_WAVES says otherwise */
+#endif
 #ifndef WH_MD_ATTR
 #define WH_MD_ATTR          /* (A/B builds: an extra function attribute of the mode-decision kernel, e.g. amdgpu_waves_per_eu) */
 #endif
@@ -170,7 +179,9 @@ __global__ WH_MD_ATTR __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P,
   __shared__ int slot_first[WH_MD_MAX_SLOTS], slot_n[WH_MD_MAX_SLOTS], slot_idc[WH_MD_MAX_SLOTS], slot_id[WH_MD_MAX_SLOTS];
   __shared__ int slot_mv[WH_MD_MAX_SLOTS];         // most recent final 16x16 vector of each slot's slice: the window guess (wh_win_speculate)
   for (int i = (int)threadIdx.x; i < slots * sched_words; i += (int)blockDim.x) sched[i] = 0;
+#if WH_PROF_ON
   if (P.prof && lane < 32) S.m.prof[lane] = 0;
+#endif
   for (int sl = 0; sl < slots; ++sl) {
     const int k = groups ? (int)groups[blockIdx.x * slots + sl] : (int)blockIdx.x * slots + sl;       // flattened slice id: picture * num_slices + slice
     const bool on = k < total_slices;
@@ -306,7 +317,9 @@ __global__ WH_MD_ATTR __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P,
     if (slots > 2 && slot_id[2] >= 0 && c2) atomicAdd (&slice_cost[slot_id[2]], c2);
     if (slots > 3 && slot_id[3] >= 0 && c3) atomicAdd (&slice_cost[slot_id[3]], c3);
   }
+#if WH_PROF_ON
   if (P.prof && lane < 32) atomicAdd (&P.prof[((blockIdx.x * 7u) & 63u) * 32u + lane], (unsigned long long)S.m.prof[lane]);
+#endif
   if (P.prof && lane == 0) {
     const unsigned long long wall1 = wall_clock64();
     atomicMax (&P.prof[4096], ~wall0); atomicMax (&P.prof[4097], wall1);
@@ -315,153 +328,6 @@ __global__ WH_MD_ATTR __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P,
   }
 }
 
-// ---- P pictures, run scheduler: a wave codes a RUN of horizontally adjacent macroblocks, left to right --------------------
-// The ticket scheduler above hands a free wave the next macroblock of the 2:1 order -- any macroblock of the slice -- so every
-// macroblock fetches its search windows from scratch although they overlap its left neighbour's by four fifths, and the
-// overlap is too far away in time for any cache (profiles/r02_pmc_traffic.json: 12.8x the algorithmic bytes).  Here a ticket
-// is a run of WhSeqParams::run_len macroblocks of one row (common/mb_order.h wh_build_run_order: the 2:1 order of the run grid):
-// inside a run the left neighbour is the macroblock the wave has just coded, and its windows SLIDE -- one tile column of luma
-// and one of chroma per macroblock instead of the whole windows (inter_mb.h wh_win_slide_*).  Dependencies are still waited
-// for macroblock by macroblock (done bits), and everything a run's macroblocks wait for lies in an earlier run of the list, so
-// the lowest outstanding ticket can always proceed: no deadlock.
-// Measured (MI355X, 256 four-slice 1080p pictures, profiles/r03_rows_vs_tickets*.txt): whole ROWS as runs cut the traffic to 2.9x
-// the algorithmic bytes but cost 25 % of the rate -- a workgroup's 68 rows do not divide among 12 waves, the last rows of a slice
-// are a serial tail, and rows two macroblocks apart stall each other; short runs keep the tickets' fine grain and most of the saving.
-// Pictures coded in ranges, with GOM-level rate control or as screen content keep the ticket scheduler.
-template <int MAXT, int VAR = 0>
-__global__ __launch_bounds__ (MAXT) void k_inter_rows (WhSeqParams P, const WhPicJob* jobs, uint32_t* err, const uint16_t* groups, int slots,
-                                                       int sched_words, int total_slices, uint32_t* slice_cost) {
-  extern __shared__ __align__ (16) uint8_t smem[];
-  const int nw = (int)blockDim.x >> 6, lane = (int)threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane ((int)threadIdx.x >> 6);
-  WhInterLds& S = ((WhInterLds*)smem)[wave];
-  __shared__ WhInterStage stage[MAXT / 64];
-  WhInterStage& G = stage[wave];
-  __shared__ WhWinLds winbuf[MAXT / 64];
-  uint32_t* sched = (uint32_t*) (smem + (size_t)nw * sizeof (WhInterLds));     // per slot: [0] runs claimed, [1..] done bits
-  __shared__ WhPicJob Jl[WH_MD_MAX_SLOTS];
-  __shared__ int slot_first[WH_MD_MAX_SLOTS], slot_n[WH_MD_MAX_SLOTS], slot_idc[WH_MD_MAX_SLOTS], slot_id[WH_MD_MAX_SLOTS], slot_runs[WH_MD_MAX_SLOTS];
-  __shared__ int slot_mv[WH_MD_MAX_SLOTS];
-  for (int i = (int)threadIdx.x; i < slots * sched_words; i += (int)blockDim.x) sched[i] = 0;
-  if (P.prof && lane < 32) S.m.prof[lane] = 0;
-  const int w = P.mb_w;
-  for (int sl = 0; sl < slots; ++sl) {
-    const int k = groups ? (int)groups[blockIdx.x * slots + sl] : (int)blockIdx.x * slots + sl;
-    const bool on = k < total_slices;
-    const int pic = on ? k / P.num_slices : 0, idc = on ? k % P.num_slices : 0;
-    if (threadIdx.x == 0) {
-      const int first = P.slice_first_mb[idc], n = on ? P.slice_first_mb[idc + 1] - first : 0;
-      slot_first[sl] = first; slot_n[sl] = n;
-      slot_runs[sl] = on ? (int)P.run_count[idc] : 0;
-      slot_idc[sl] = idc; slot_id[sl] = on ? k : -1; slot_mv[sl] = 0;
-    }
-    wh_copy_job (&Jl[sl], &jobs[pic]);
-  }
-  __syncthreads();
-  WH_PROF_DECL (P);
-  const unsigned long long wall0 = P.prof ? wall_clock64() : 0ULL;
-  WhInterCtx X;
-  X.win = &winbuf[wave];
-  X.spec_valid = 0;
-  X.spec.b = X.win;
-  X.last_mv = nullptr;
-  WhWinSlide SL;
-  SL.on_y = 0; SL.on_c = 0; SL.y = 0u; SL.c0 = 0u; SL.c1 = 0u;
-  uint32_t gone = 0;
-  uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-  int slot = -1, x = 0, y = 0, xe = 0;          // the macroblock in hand: (x, y) of slot `slot`, its row segment ends before xe
-  int nslot = -1, nx = 0, ny = 0, nxe = 0;      // the wave's next one
-  // next(): the right neighbour, or the first macroblock of the next unclaimed row (of the slot with most rows left)
-  // next(): the right neighbour inside the run, or the first macroblock of the next run (of the slot with most runs left)
-  const uint32_t* run_order = P.mb_order + 3 * (size_t)P.mb_w * P.mb_h;
-  auto next_fn = [&] () __attribute__ ((always_inline)) {
-    if (slot >= 0 && x + 1 < xe) { nslot = slot; nx = x + 1; ny = y; nxe = xe; return; }
-    for (nslot = -1;;) {
-      int best = -1, brem = 0;
-      for (int sl = 0; sl < slots; ++sl) if (!((gone >> sl) & 1u)) {
-        const int rem = slot_runs[sl] - (int)__hip_atomic_load (&sched[sl * sched_words], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (rem <= 0) gone |= 1u << sl; else if (rem > brem) { brem = rem; best = sl; }
-      }
-      best = __builtin_amdgcn_readfirstlane (best);
-      if (best < 0) return;
-      int r = 0;
-      if (lane == 0) r = (int)atomicAdd (&sched[best * sched_words], 1u);
-      r = __builtin_amdgcn_readfirstlane (r);
-      if (r >= slot_runs[best]) { gone |= 1u << best; continue; }
-      const uint32_t e = run_order[slot_first[best] + r];
-      const int xy0 = WH_RUN_XY (e);
-      nslot = best; ny = xy0 / w; nx = xy0 - ny * w; nxe = nx + WH_RUN_LEN (e);
-      return;
-    }
-  };
-  // Called by the macroblock body once its prediction is final: it reads neither the staging area nor the windows from there on.
-  // Start the next macroblock's cold inputs and windows: slide them when they lie one tile column further (same row, same
-  // guess -- the vector this macroblock has just published), fetch them whole otherwise.
-  auto early_fn = [&] () __attribute__ ((always_inline)) {
-    const bool had = slot >= 0;
-    next_fn();
-    if (nslot < 0) return;
-    const WhPicJob& Jn = Jl[nslot];
-    wh_inter_cold_fetch<VAR> (G, lane, P, Jn, nx, ny);
-    WhWin N;
-    N.b = X.win;
-    const int guess = slot_mv[nslot];
-    const int gx = wh_clip3 ((2 + (int) (int16_t) (guess & 0xffff)) >> 2, -P.mv_range, P.mv_range), gy = wh_clip3 ((2 + (guess >> 16)) >> 2, -P.mv_range, P.mv_range);
-    wh_win_place (P, N, nx * 16 + gx, ny * 16 + gy);
-    const bool same = had && nslot == slot && ny == y;
-    SL.on_y = same && wh_win_can_slide_y (X.spec, N);
-    SL.on_c = same && wh_win_can_slide_c (X.spec, N);
-    if (SL.on_y | SL.on_c) wh_win_slide_begin (P, Jn, N, SL);
-    if (!SL.on_y) wh_win_issue_luma (P, Jn, N);
-    if (!SL.on_c) wh_win_issue_chroma (P, Jn, N);
-    if (SL.on_y | SL.on_c) wh_win_slide_move (X.win, SL.on_y, SL.on_c);
-    X.spec = N;
-    X.spec_valid = 1;
-  };
-  WhEarlyFn<decltype (early_fn)> early = { early_fn };
-  early_fn();
-  int pslot = -1, pxy = -1;                      // the macroblock this wave coded last
-  while (nslot >= 0) {
-    slot = nslot; x = nx; y = ny; xe = nxe;
-    const WhPicJob& J = Jl[slot];
-    const int first = slot_first[slot], xy = y * w + x;
-    uint32_t* sc = sched + slot * sched_words;
-    WH_PROF_MARK (P, S.m, 11);
-    int dep_a, dep_b;
-    wh_mb_deps (w, xy, first, &dep_a, &dep_b);
-    if (pslot == slot && dep_a == pxy) dep_a = -1;          // the left neighbour is this wave's own previous macroblock
-    if (!wh_wait_done (sc + 1, dep_a < 0 ? -1 : dep_a - first, err)) break;
-    if (!wh_wait_done (sc + 1, dep_b < 0 ? -1 : dep_b - first, err)) break;
-    __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "workgroup");
-    WH_PROF_MARK (P, S.m, 12);
-    const uint32_t tc0 = (uint32_t)__builtin_readcyclecounter();
-    WV_ASYNC_WAIT();                      // cold inputs and whatever was fetched whole have landed ...
-    wh_win_slide_finish (X.win, SL);      // ... and so has the new tile column of windows that slid
-    SL.on_y = 0; SL.on_c = 0;
-    X.slice_idc = slot_idc[slot]; X.slice_first = first; X.last_mv = &slot_mv[slot];
-    wh_inter_mb_body_t<false, VAR> (S, G, P, J, x, y, X, early);       // (calls early_fn: nslot .. nxe are the next macroblock from there on)
-    WH_PROF_MARK (P, S.m, 14);
-    __builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");
-    if (lane == 0) atomicOr (&sc[1 + ((xy - first) >> 5)], 1u << ((xy - first) & 31));
-    WH_PROF_MARK (P, S.m, 13);
-    const uint32_t dc = ((uint32_t)__builtin_readcyclecounter() - tc0) >> 6;
-    c0 += slot == 0 ? dc : 0u; c1 += slot == 1 ? dc : 0u; c2 += slot == 2 ? dc : 0u; c3 += slot == 3 ? dc : 0u;
-    pslot = slot; pxy = xy;
-  }
-  if (slice_cost && lane == 0) {
-    if (slot_id[0] >= 0 && c0) atomicAdd (&slice_cost[slot_id[0]], c0);
-    if (slots > 1 && slot_id[1] >= 0 && c1) atomicAdd (&slice_cost[slot_id[1]], c1);
-    if (slots > 2 && slot_id[2] >= 0 && c2) atomicAdd (&slice_cost[slot_id[2]], c2);
-    if (slots > 3 && slot_id[3] >= 0 && c3) atomicAdd (&slice_cost[slot_id[3]], c3);
-  }
-  if (P.prof && lane < 32) atomicAdd (&P.prof[((blockIdx.x * 7u) & 63u) * 32u + lane], (unsigned long long)S.m.prof[lane]);
-  if (P.prof && lane == 0) {
-    const unsigned long long wall1 = wall_clock64();
-    atomicMax (&P.prof[4096], ~wall0); atomicMax (&P.prof[4097], wall1);
-    atomicAdd (&P.prof[4098], wall1 - wall0); atomicAdd (&P.prof[4099], 1ULL);
-    atomicMax (&P.prof[4104 + (blockIdx.x & 255u)], wall1);
-  }
-}
 
 // Deal the slices of a batch out to the mode-decision workgroups: sorted by the cost they had in the previous picture
 // (slice_cost, accumulated by k_inter_pool; cleared here for the coming launch), then in snake order over the groups, so
@@ -552,7 +418,9 @@ __global__ __launch_bounds__ (1024) void k_deblock_slices (WhSeqParams P, const 
   const uint32_t gen = J.db_gen;
   __shared__ WhDbStage stage[16];                 // separate LDS object (see WhInterStage)
   WhDbStage& G = stage[wave];
+#if WH_PROF_ON
   if (P.prof && lane < 32) S.prof[lane] = 0;
+#endif
   WH_PROF_DECL (P);
   for (int guard = 0; guard <= n; ++guard) {
     // a wave takes a ticket only when it is free (a held ticket could be the one the whole dependency chain is waiting
@@ -607,7 +475,9 @@ __global__ __launch_bounds__ (1024) void k_deblock_slices (WhSeqParams P, const 
   }
   WH_PROF_MARK (P, S, 10);    // idle tail: no ticket left, the slice is still being finished by other waves
   // second half of the profile buffer (the first belongs to the mode-decision kernels)
+#if WH_PROF_ON
   if (P.prof && lane < 32) atomicAdd (&P.prof[2048u + ((blockIdx.x + blockIdx.y * 7u) & 63u) * 32u + lane], (unsigned long long)S.prof[lane]);
+#endif
 }
 
 
@@ -903,8 +773,9 @@ class HipBackend : public wh::Backend {
       max_rows = std::max (max_rows, (P.slice_first_mb[s + 1] - 1) / P.mb_w - P.slice_first_mb[s] / P.mb_w + 1);
     }
     const int sched_words = 1 + ((max_n + 31) >> 5);
-    int nw = forced_waves > 0 ? forced_waves : 12;
-    nw = std::min (nw, 12);              // (12 x 13.4 KB of LDS per wave is the CU's 160 KB; a 1024-thread build fits 128 VGPRs without scratch but not the LDS)
+    int nw = forced_waves > 0 ? forced_waves : WH_P_WAVES_DEFAULT;
+    nw = std::min (nw, 16);              // (the LDS bounds it below: 10.9 KB per wave since round 5 = 14 waves; rounds 1-4: 12.7 KB = 12 waves)
+    if (!(WH_PLAIN_KERNEL == 2 && plain && P.flags == 0 && P.complexity == 0)) nw = std::min (nw, 12);      // (only the session groups' variant is built for more than 768 threads)
     int par = std::max (1, std::min (max_rows, (P.mb_w + 1) / 2)) * slots;       // macroblocks that can be in flight at all
     if (P.flags & WH_SEQ_SERIAL) par = 2 * slots;      // one macroblock of a slice at a time; a second wave has the next one's inputs in flight
     if (P.flags & WH_SEQ_SCC) nw = std::min (nw, 6);    // the screen-content variant needs 216 VGPRs: six waves per workgroup, no scratch
@@ -929,11 +800,6 @@ class HipBackend : public wh::Backend {
         HIP_TRY (hipGetLastError());
       }
     }
-    // run scheduler (k_inter_rows): plain camera pictures, when a workgroup holds several slices (runs of several slices to pick from);
-    // a single slice per workgroup (few pictures in flight: the latency regime) keeps the finest grain, one macroblock per ticket
-    const char* rows_env = getenv ("WELSHIP_MD_ROWS");        // (read per launch: the GPU tests switch it inside one process)
-    const int forced_rows = rows_env ? atoi (rows_env) : -1;
-    const bool rows = P.flags == 0 && P.run_len >= 1 && (forced_rows >= 0 ? forced_rows != 0 : (slots >= 2 && P.run_len > 1));
     const WhSeqParams& Pr = P;
     auto launch = [&] (auto kernel) {
       HIP_TRY (hipFuncSetAttribute ((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -943,9 +809,10 @@ class HipBackend : public wh::Backend {
       if (getenv ("WELSHIP_TRACE")) { HIP_TRY (hipStreamSynchronize (stream_)); fprintf (stderr, "welship: launch done\n"); fflush (stderr); }
     };
     if (P.flags & WH_SEQ_SCC) launch (k_inter_pool<384, true>);      // (nw <= 6 above: 249 VGPRs, no scratch; a 12-wave build of this variant spills -- 168 VGPRs + 360 B -- and is not instantiated any more)
-    else if (rows && WH_PLAIN_KERNEL == 2 && plain && P.complexity == 0) { if (nw <= 6) launch (k_inter_rows<384, WH_PLAIN_KERNEL == 2 ? 2 : 0>); else launch (k_inter_rows<768, WH_PLAIN_KERNEL == 2 ? 2 : 0>); }
-    else if (rows) { if (nw <= 6) launch (k_inter_rows<384>); else launch (k_inter_rows<768>); }
-    else if (WH_PLAIN_KERNEL == 2 && plain && P.flags == 0 && P.complexity == 0) { if (nw <= 6) launch (k_inter_pool<384, false, WH_PLAIN_KERNEL == 2 ? 2 : 0>); else launch (k_inter_pool<768, false, WH_PLAIN_KERNEL == 2 ? 2 : 0>); }
+    else if (WH_PLAIN_KERNEL == 2 && plain && P.flags == 0 && P.complexity == 0) {
+      if (nw <= 6) launch (k_inter_pool<384, false, WH_PLAIN_KERNEL == 2 ? 2 : 0>); else if (nw <= 12) launch (k_inter_pool<768, false, WH_PLAIN_KERNEL == 2 ? 2 : 0>);
+      else if (nw <= 14) launch (k_inter_pool<896, false, WH_PLAIN_KERNEL == 2 ? 2 : 0>); else launch (k_inter_pool<1024, false, WH_PLAIN_KERNEL == 2 ? 2 : 0>);
+    }
     else if (WH_PLAIN_KERNEL && plain && P.flags == 0) { if (nw <= 6) launch (k_inter_pool<384, false, WH_PLAIN_KERNEL ? 1 : 0>); else launch (k_inter_pool<768, false, WH_PLAIN_KERNEL ? 1 : 0>); }
     else if (WH_FRAME_KERNEL && no_ctrl && P.flags == 0) { if (nw <= 6) launch (k_inter_pool<384, false, WH_FRAME_KERNEL ? 3 : 0>); else launch (k_inter_pool<768, false, WH_FRAME_KERNEL ? 3 : 0>); }
     else if (nw <= 6) launch (k_inter_pool<384, false>); else launch (k_inter_pool<768, false>);

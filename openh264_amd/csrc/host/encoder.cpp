@@ -41,24 +41,6 @@ namespace {
 
 inline int align_up (int v, int a) { return (v + a - 1) / a * a; }
 
-// Macroblocks per run of the P kernel's run scheduler (hip_backend.hip k_inter_rows): a wave codes that many horizontally adjacent
-// macroblocks one after the other and slides its search windows from one to the next.  WELSHIP_MD_RUN sets it (>= the picture width =
-// whole rows).  Default 1: one macroblock per ticket (k_inter_pool), every macroblock fetches its windows whole -- the fastest on the
-// MI355X today (profiles/r03_run_length_sweep.txt: 13.2 k frames/s against 12.8 k / 12.2 k / 10.5 k with runs of 2 / 4 / whole rows),
-// at 6.1 x the algorithmic bytes against 4.5 x / 3.0 x for runs of 4 / whole rows (profiles/r03_pmc_traffic.json).
-inline int md_run_len() { const char* e = getenv ("WELSHIP_MD_RUN"); const int v = e ? atoi (e) : 1; return v < 1 ? 1 : v > 1023 ? 1023 : v; }
-// the run section of the order table (entries [3 * num_mb, 4 * num_mb)) + WhSeqParams::run_len / run_count
-inline void build_run_section (WhSeqParams& s, int mb_w, int num_mb, std::vector<uint32_t>& order32) {
-  order32.resize ((size_t)num_mb * 4, 0u);
-  s.run_len = md_run_len();
-  for (int i = 0; i < WH_MAX_SLICES; ++i) s.run_count[i] = 0;
-  for (int i = 0; i < s.num_slices; ++i) {
-    const int n = wh_build_run_order (mb_w, s.slice_first_mb[i], s.slice_first_mb[i + 1], s.run_len, order32.data() + 3 * (size_t)num_mb + s.slice_first_mb[i]);
-    s.run_count[i] = (int16_t) (n > 32767 ? 0 : n);
-    if (n > 32767) s.run_len = 0;           // (cannot happen below 32768 macroblocks per slice; no run section then)
-  }
-}
-
 // (the unfiltered reconstruction lives in macroblock-contiguous blocks, WhPicJob::rec_blk; the planar in-place layout of rounds 1-3 measured
 //  6.07 x against 4.03 x the algorithmic traffic and lost its switch in round 5: profiles/r04_pmc_traffic_unfiltered_recon_in_blocks.txt)
 static bool rec_blocks_on() { return true; }
@@ -301,7 +283,6 @@ struct SessionCore {
     if (nb < 1) { set_err ("deblocking band table"); release(); return WELSHIP_ERR_UNKNOWN; }
     for (int b = 0; b < nb; ++b) wh_build_mb_order (mb_w, bands[b], bands[b + 1], order.data() + 2 * (size_t)num_mb + bands[b]);
     std::vector<uint32_t> order32 (order.begin(), order.end());      // 32-bit on the device (scalar loads)
-    build_run_section (s, mb_w, num_mb, order32);
     d_order = (uint32_t*)A (order32.size() * 4);
     d_bands = (int32_t*)A (sizeof (int32_t) * (3 * (size_t)nb + 1 + 4));      // + the one-band table of the whole picture
     d_scene = (uint32_t*)A (64);
@@ -1605,8 +1586,6 @@ namespace {
 
 struct FrameLayout {           // processing-order / deblocking-band tables on the device, shared by the contexts that use them
   int mb_w = 0, mb_h = 0, idc = -1;
-  int run_len = 0;
-  int16_t run_count[WH_MAX_SLICES];
   std::vector<int32_t> slices;
   uint32_t* d_order = nullptr;
   int32_t* d_bands = nullptr;
@@ -1847,19 +1826,10 @@ struct WelsHipFrameCtx {
       const int nb = wh_build_db_bands (mb_w, mb_h, n, first, idc, WH_DB_BAND_ROWS, bands.data(), (int)bands.size());
       if (nb < 1) { set_err ("deblocking band table"); return WELSHIP_ERR_UNKNOWN; }
       for (int b = 0; b < nb; ++b) wh_build_mb_order (mb_w, bands[b], bands[b + 1], order.data() + 2 * (size_t)num_mb + bands[b]);
-      up->d_order = (uint32_t*)be->alloc ((size_t)num_mb * 4 * 4);
+      up->d_order = (uint32_t*)be->alloc ((size_t)num_mb * 3 * 4);
       up->d_bands = (int32_t*)be->alloc (sizeof (int32_t) * (3 * (size_t)nb + 1 + 4));
       if (!up->d_order || !up->d_bands) { set_err ("out of device memory"); return WELSHIP_ERR_MEMORY; }
       std::vector<uint32_t> order32 (order.begin(), order.end());
-      {
-        WhSeqParams tmp;
-        memset (&tmp, 0, sizeof (tmp));
-        tmp.num_slices = n;
-        for (int i = 0; i <= n; ++i) tmp.slice_first_mb[i] = first[i];
-        build_run_section (tmp, mb_w, num_mb, order32);
-        up->run_len = tmp.run_len;
-        memcpy (up->run_count, tmp.run_count, sizeof (up->run_count));
-      }
       be->upload (up->d_order, order32.data(), order32.size() * 4);
       { const int32_t whole[4] = {0, num_mb, 0, num_mb}; bands.resize (3 * (size_t)nb + 1); bands.insert (bands.end(), whole, whole + 4); }
       be->upload (up->d_bands, bands.data(), sizeof (int32_t) * (3 * (size_t)nb + 1 + 4));
@@ -1877,8 +1847,6 @@ struct WelsHipFrameCtx {
     s.num_slices = n;
     for (int i = 0; i < WH_MAX_SLICES + 1; ++i) s.slice_first_mb[i] = i <= n ? first[i] : 0;
     s.mb_order = L->d_order;
-    s.run_len = L->run_len;
-    memcpy (s.run_count, L->run_count, sizeof (s.run_count));
     s.db_num_bands = L->nb; s.db_bands = L->d_bands; s.db_max_mbs = L->max_mbs; s.db_max_rows = L->max_rows;
     return WELSHIP_OK;
   }

@@ -16,7 +16,9 @@ typedef struct WhDbLds {
   uint8_t c[2][10 * 12];
   uint8_t bs[2][4][4];       // [dir 0=vertical edges,1=horizontal][edge][segment]
   uint32_t st[3 * 36];       // WhMbState copies (36 words each): this MB, left, top
-  uint32_t prof[32];         // phase-profiling accumulators of this wave (WH_PROF_MARK)
+#if defined(WH_PROF)
+  uint32_t prof[32];         // phase-profiling accumulators of this wave (WH_PROF_MARK; profiling build only)
+#endif
 } WhDbLds;
 #define WH_DY(S, x, yy) ((S).y[((yy) + 4) * 24 + (x) + 4])
 #define WH_DC(S, p, x, yy) ((S).c[p][((yy) + 2) * 12 + (x) + 4])

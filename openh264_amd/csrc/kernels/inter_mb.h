@@ -36,13 +36,44 @@
 // (candidate SADs, diamond search, fractional refinement, motion compensation, residual coding) runs from LDS and
 // registers; a window is re-fetched only when a search start or a prediction block falls outside it.
 
+// test-build statistics of the search windows (WELSHIP_WIN_STATS=1 prints them at exit): 0 P macroblocks, 1 reloads (wh_win_ensure misses),
+// 2 speculative windows adopted, 3 first loads after a refused / missing speculation, 4 reloads in the middle of a diamond walk
+#if defined(WH_EMU)
+#include <stdio.h>
+static long g_wh_win_stat[8];
+static void wh_win_stat_dump() {
+  if (!getenv ("WELSHIP_WIN_STATS")) return;
+  fprintf (stderr, "welship window stat: P macroblocks %ld, reloads %ld, adopted %ld, first loads %ld, mid-walk reloads %ld\n", g_wh_win_stat[0], g_wh_win_stat[1], g_wh_win_stat[2], g_wh_win_stat[3], g_wh_win_stat[4]);
+}
+struct WhWinStatInit { WhWinStatInit() { atexit (wh_win_stat_dump); } };
+static WhWinStatInit g_wh_win_stat_init;
+#define WH_STAT_WIN(i) (++g_wh_win_stat[i])
+#else
+#define WH_STAT_WIN(i) ((void)0)
+#endif
+
 #define WH_REF_NOT_AVAIL (-2)
 #define WH_REF_NOT_IN_LIST (-1)
-#define WH_WIN_STRIDE 80          // five tile columns (common/wh_types.h WH_TILE_*): 16 + 2 * 19 samples wherever the block sits in its tile column, +
-#define WH_WIN_ROWS 56            // 16 + 2 * 20 rows.  (Rows of 80 bytes also spread the lanes of a block read over all LDS banks; 64 did not.)
-#define WH_WIN_MARGIN 19          // diamond (16) + quarter/half-pel taps (3)
-#define WH_CWIN_STRIDE 64         // chroma window: 32 samples x 32 rows of BOTH planes, stored as the tiles are -- per row four 16-byte pieces,
-#define WH_CWIN_ROWS 32           //   each 8 Cb samples then the 8 Cr samples at the same position
+// The windows are SMALL and follow the search (round 5; rounds 1-4 held everything a 16-step diamond could ever reach, 56 rows of
+// luma and 32 of chroma: 6.4 KB of a wave's 12.7 KB of LDS, which kept a CU at 12 waves): a search start only demands WH_WIN_START
+// samples of room around its block (wh_win_need), the diamond counts its steps against the room it started with and has the window
+// follow it when that is used up (wh_motion_search), and every other reader states what it reads (wh_win_ensure).  What a window holds
+// never changes a result -- only whether a reload is needed.
+#define WH_WIN_STRIDE 80          // five tile columns (common/wh_types.h WH_TILE_*): 16 + 2 * 19 samples wherever the block sits in its tile column
+#ifndef WH_WIN_ROWS
+#define WH_WIN_ROWS 40            // 16 + 2 * 12 rows.  (Rows of 80 bytes also spread the lanes of a block read over all LDS banks; 64 did not.)
+#endif
+#define WH_WIN_MARGIN_X 19        // what a (re)load leaves around the block it is centred on, horizontally ...
+#ifndef WH_WIN_MARGIN_Y
+#define WH_WIN_MARGIN_Y 11        // ... and vertically (a 16-row block: 38 of the 40 rows)
+#endif
+#ifndef WH_WIN_START
+#define WH_WIN_START 5            // room (samples in every direction) a search start asks for: what the fractional refinement reads around a block that does not move (measured on the reference 1080p clip with the test build: profiles/r05_window_reload_statistics.txt)
+#endif
+#define WH_CWIN_STRIDE 64         // chroma window: 32 samples x 24 rows of BOTH planes, stored as the tiles are -- per row four 16-byte pieces,
+#ifndef WH_CWIN_ROWS
+#define WH_CWIN_ROWS 24           //   each 8 Cb samples then the 8 Cr samples at the same position (a block outside it is read from the picture)
+#endif
 #define WH_CWIN_COLS 32
 
 // partition slots: one motion search result each (WhMeTab)
@@ -154,16 +185,17 @@ WH_FN int wh_mc_chroma_w (int a, int b, int c, int d, int dx, int dy) {
 #define WH_WIN_PIECES (WH_WIN_ROWS * (WH_WIN_STRIDE / 16))          // 16-byte pieces of the luma window, row-major: piece p = row p / 5, tile column p % 5
 #define WH_WIN_LOADS ((WH_WIN_PIECES + 63) / 64)                     // load instructions per lane
 #define WH_CWIN_PIECES (WH_CWIN_ROWS * (WH_CWIN_STRIDE / 16))
+#define WH_CWIN_LOADS ((WH_CWIN_PIECES + 63) / 64)
 // a window origin in [lo, hi] that is a multiple of `align` when the range holds one (one tile row fewer to fetch), else the middle
 WH_FN int wh_win_pick (int lo, int hi, int align) { const int a = hi & ~ (align - 1); return a >= lo ? a : (lo + hi) >> 1; }
 WH_FN void wh_win_place (const WhSeqParams& P, WhWin& W, int cx, int cy) {      // leaves W.b alone      // (cx,cy): luma position the 16x16 block is centred on
-  // luma: the block +- WH_WIN_MARGIN must be inside; columns: 24..39 samples either side of the block
+  // luma: the block +- WH_WIN_MARGIN_X / _Y must be inside; columns: 24..39 samples either side of the block
   W.x0 = wh_clip3 ((cx - 24) & ~15, -32, P.mb_w * 16 + 32 - WH_WIN_STRIDE);
-  W.y0 = wh_clip3 (wh_win_pick (cy + 16 + WH_WIN_MARGIN - WH_WIN_ROWS, cy - WH_WIN_MARGIN, 8), -32, P.mb_h * 16 + 32 - WH_WIN_ROWS);
-  // chroma: 8..15 samples either side of the 8x8 block, 10+ rows above and below (whatever lies outside is read from the picture)
+  W.y0 = wh_clip3 (wh_win_pick (cy + 16 + WH_WIN_MARGIN_Y - WH_WIN_ROWS, cy - WH_WIN_MARGIN_Y, 8), -32, P.mb_h * 16 + 32 - WH_WIN_ROWS);
+  // chroma: 8..15 samples either side of the 8x8 block, 6+ rows above and below (whatever lies outside is read from the picture)
   const int ccx = cx >> 1, ccy = cy >> 1;
   W.cx0 = wh_clip3 ((ccx - 8) & ~7, -16, P.mb_w * 8 + 16 - WH_CWIN_COLS);
-  W.cy0 = wh_clip3 (wh_win_pick (ccy - 14, ccy - 10, 8), -16, P.mb_h * 8 + 16 - WH_CWIN_ROWS);
+  W.cy0 = wh_clip3 (wh_win_pick (ccy - (WH_CWIN_ROWS - 9) / 2 - 2, ccy - (WH_CWIN_ROWS - 9) / 2 + 1, 8), -16, P.mb_h * 8 + 16 - WH_CWIN_ROWS);
 }
 // piece p of the luma window / chroma window in the tiled reference picture
 WH_FN const WH_G uint8_t* wh_win_src_luma (int p, const WhSeqParams& P, const WhPicJob& J, const WhWin& W) {
@@ -186,7 +218,7 @@ WH_FN void wh_win_issue_luma (const WhSeqParams& P, const WhPicJob& J, WhWin& W)
 WH_FN void wh_win_issue_chroma (const WhSeqParams& P, const WhPicJob& J, WhWin& W) {
   WV_LANES_BEGIN (lane)
 #pragma unroll
-  for (int k = 0; k < WH_CWIN_PIECES / 64; ++k) wh_ld_async16 (wh_win_src_chroma (64 * k + lane, P, J, W), &W.b->cwin[1024 * k], lane);
+  for (int k = 0; k < WH_CWIN_LOADS; ++k) if (64 * k + lane < WH_CWIN_PIECES) wh_ld_async16 (wh_win_src_chroma (64 * k + lane, P, J, W), &W.b->cwin[1024 * k], lane);
   WV_LANES_END
 }
 WH_FN void wh_win_load_luma (WhInterLds& S, const WhSeqParams& P, const WhPicJob& J, WhWin& W) {
@@ -202,20 +234,32 @@ WH_FN void wh_win_issue_all (const WhSeqParams& P, const WhPicJob& J, WhWin& W, 
 #pragma unroll
     for (int k = 0; k < WH_WIN_LOADS; ++k) if (64 * k + lane < WH_WIN_PIECES) wh_ld_async16 (wh_win_src_luma (64 * k + lane, P, J, W), &W.b->win[1024 * k], lane);
 #pragma unroll
-    for (int k = 0; k < WH_CWIN_PIECES / 64; ++k) wh_ld_async16 (wh_win_src_chroma (64 * k + lane, P, J, W), &W.b->cwin[1024 * k], lane);
+    for (int k = 0; k < WH_CWIN_LOADS; ++k) if (64 * k + lane < WH_CWIN_PIECES) wh_ld_async16 (wh_win_src_chroma (64 * k + lane, P, J, W), &W.b->cwin[1024 * k], lane);
   }
   WV_LANES_END
 }
 WH_FN bool wh_win_covers (const WhWin& W, int x0, int y0, int x1, int y1) {
   return x0 >= W.x0 && y0 >= W.y0 && x1 <= W.x0 + WH_WIN_STRIDE && y1 <= W.y0 + WH_WIN_ROWS;
 }
-// make sure luma [x0,x1) x [y0,y1) is inside the window (extent <= 65 x WH_WIN_ROWS - 3)
+// make sure luma [x0,x1) x [y0,y1) is inside the window (extent <= 65 x WH_WIN_ROWS)
 WH_FN void wh_win_ensure (WhInterLds& S, const WhSeqParams& P, const WhPicJob& J, WhWin& W, int x0, int y0, int x1, int y1) {
   if (wh_win_covers (W, x0, y0, x1, y1)) return;
   // (x1 - 80 <= x0 - 16: a tile column in between always exists)
   W.x0 = wh_clip3 (wh_win_pick (x1 - WH_WIN_STRIDE, x0, 16), -32, P.mb_w * 16 + 32 - WH_WIN_STRIDE);
   W.y0 = wh_clip3 (wh_win_pick (y1 - WH_WIN_ROWS, y0, 8), -32, P.mb_h * 16 + 32 - WH_WIN_ROWS);
+  WH_STAT_WIN (1);
   wh_win_load_luma (S, P, J, W);
+}
+// Room of the bw x bh block at (px, py): how many samples it can move in EVERY direction with its SAD still read from the window (a
+// 4-byte read at any byte offset takes 3 bytes beyond the block); negative: the block itself is not (wholly) inside
+WH_FN int wh_win_room (const WhWin& W, int px, int py, int bw, int bh) {
+  return wh_min (wh_min (px - W.x0, W.x0 + WH_WIN_STRIDE - (px + bw + 3)), wh_min (py - W.y0, W.y0 + WH_WIN_ROWS - (py + bh)));
+}
+// ... at least `need` of it, else the window is reloaded around the block (WH_WIN_MARGIN_X / _Y either side; the picture's expanded border
+// bounds the window, never the room: a search does not leave the picture by more than the border either)
+WH_FN void wh_win_need (WhInterLds& S, const WhSeqParams& P, const WhPicJob& J, WhWin& W, int px, int py, int bw, int bh, int need) {
+  if (wh_win_room (W, px, py, bw, bh) >= need) return;
+  wh_win_ensure (S, P, J, W, px - WH_WIN_MARGIN_X, py - WH_WIN_MARGIN_Y, px + bw + 3 + WH_WIN_MARGIN_X, py + bh + WH_WIN_MARGIN_Y);
 }
 
 // Speculative fetch of a macroblock's windows, issued together with its cold inputs as soon as the wave holds the ticket --
@@ -226,101 +270,6 @@ WH_FN void wh_win_ensure (WhInterLds& S, const WhSeqParams& P, const WhPicJob& J
 WH_FN void wh_win_speculate (const WhSeqParams& P, const WhPicJob& J, WhWin& W, int mbx, int mby, int guess_mv) {
   const int gx = wh_clip3 ((2 + (int) (int16_t) (guess_mv & 0xffff)) >> 2, -P.mv_range, P.mv_range), gy = wh_clip3 ((2 + (guess_mv >> 16)) >> 2, -P.mv_range, P.mv_range);
   wh_win_issue_all (P, J, W, mbx * 16 + gx, mby * 16 + gy);
-}
-
-// ---- sliding windows (row scheduler, hip_backend.hip k_inter_rows) ---------------------------------------------------
-// A wave that codes the macroblocks of a row one after the other keeps its windows: when the next macroblock's windows lie
-// exactly one tile column to the right of the ones in LDS (the usual case: the same vector guess, 16 samples further), four
-// fifths of them are already there.  The window is moved left by one tile column inside LDS and only the new column -- 56 tile
-// rows of luma = 7-8 memory lines, 32 of chroma = 4-5 -- comes from the reference picture: through registers, because an
-// LDS-DMA writes one contiguous 16 bytes per lane and a column of a row-major window is not contiguous.
-//   begin: (called where the macroblock in hand stops reading the windows) issue this lane's loads of the new column, move the rest
-//   finish: (before the next macroblock reads them) store the new column
-// Every lane has at most ONE piece of the new luma column (piece p = 64 k + lane is in column p % 5 = (4 k + lane) % 5: exactly
-// one k in 0..4 gives column 4) and two of the new chroma column (lanes with lane % 4 == 3).
-#if defined(WH_EMU)
-typedef struct WhWinSlide { WhV4 y[64], c0[64], c1[64]; int on_y, on_c; } WhWinSlide;       // (the test build keeps every lane's registers)
-#define WH_SL_LANE(f, lane) f[lane]
-#else
-typedef struct WhWinSlide { WhV4 y, c0, c1; int on_y, on_c; } WhWinSlide;
-#define WH_SL_LANE(f, lane) f
-#endif
-WH_FN bool wh_win_can_slide_y (const WhWin& W, const WhWin& N) { return N.y0 == W.y0 && N.x0 == W.x0 + 16; }
-WH_FN bool wh_win_can_slide_c (const WhWin& W, const WhWin& N) { return N.cy0 == W.cy0 && N.cx0 == W.cx0 + 8; }
-WH_FN int wh_win_slide_piece (int lane) { return 64 * ((lane + 1) % 5) + lane; }          // this lane's piece of luma column 4
-// `N`: the placement after the slide (luma and / or chroma origin one tile column further than what LDS holds)
-WH_FN void wh_win_slide_begin (const WhSeqParams& P, const WhPicJob& J, const WhWin& N, WhWinSlide& SL) {
-  WV_LANES_BEGIN (lane)
-  {
-    if (SL.on_y) {
-      const int p = wh_win_slide_piece (lane);
-      if (p < WH_WIN_PIECES) WH_SL_LANE (SL.y, lane) = wh_ldg16v (wh_win_src_luma (p, P, J, N));
-    }
-    if (SL.on_c && (lane & 3) == 3) { WH_SL_LANE (SL.c0, lane) = wh_ldg16v (wh_win_src_chroma (lane, P, J, N)); WH_SL_LANE (SL.c1, lane) = wh_ldg16v (wh_win_src_chroma (64 + lane, P, J, N)); }
-  }
-  WV_LANES_END
-}
-// the pieces that stay: piece p of the new window = piece p + 1 of the old one.  All lanes read before any lane writes (the LDS
-// executes a wave's instructions in order), and a piece is read in the step in which, or before, it is overwritten.
-WH_FN void wh_win_slide_move (WhWinLds* b, int on_y, int on_c) {
-#if defined(WH_EMU)
-  WhV4 t[64];
-#define WH_SLIDE_STEP(arr, idx, cond)                                                                      \
-  { WV_LANES_BEGIN (lane) { const int p = (idx); if (cond) t[lane] = * (const WhV4*)&b->arr[16 * (p + 1)]; } WV_LANES_END  \
-    WV_LANES_BEGIN (lane) { const int p = (idx); if (cond) * (WhV4*)&b->arr[16 * p] = t[lane]; } WV_LANES_END }
-#else
-  // all reads, one hand-off, all writes: two LDS round trips instead of one per piece (a piece is never read after it was written:
-  // every lane has read everything it needs before the first store of any lane is issued)
-  const int lane = wh_lane_id();
-  WhV4 vy[WH_WIN_LOADS], vc[WH_CWIN_PIECES / 64];
-  if (on_y) {
-#pragma unroll
-    for (int k = 0; k < WH_WIN_LOADS; ++k) {
-      const int p = 64 * k + lane;
-      const WhV4 z = {0u, 0u, 0u, 0u};
-      vy[k] = z;
-      if (p < WH_WIN_PIECES && (p - 5 * ((p * 205) >> 10)) != 4) vy[k] = * (const WhV4*)&b->win[16 * (p + 1)];
-    }
-  }
-  if (on_c) {
-#pragma unroll
-    for (int k = 0; k < WH_CWIN_PIECES / 64; ++k) {
-      const int q = 64 * k + lane;
-      const WhV4 z = {0u, 0u, 0u, 0u};
-      vc[k] = z;
-      if ((q & 3) != 3) vc[k] = * (const WhV4*)&b->cwin[16 * (q + 1)];
-    }
-  }
-  WV_SYNC();
-  if (on_y) {
-#pragma unroll
-    for (int k = 0; k < WH_WIN_LOADS; ++k) {
-      const int p = 64 * k + lane;
-      if (p < WH_WIN_PIECES && (p - 5 * ((p * 205) >> 10)) != 4) * (WhV4*)&b->win[16 * p] = vy[k];
-    }
-  }
-  if (on_c) {
-#pragma unroll
-    for (int k = 0; k < WH_CWIN_PIECES / 64; ++k) {
-      const int q = 64 * k + lane;
-      if ((q & 3) != 3) * (WhV4*)&b->cwin[16 * q] = vc[k];
-    }
-  }
-  WV_SYNC();
-#endif
-#if defined(WH_EMU)
-  if (on_y) for (int k = 0; k < WH_WIN_LOADS; ++k) WH_SLIDE_STEP (win, 64 * k + lane, p < WH_WIN_PIECES && (p - 5 * ((p * 205) >> 10)) != 4)
-  if (on_c) for (int k = 0; k < WH_CWIN_PIECES / 64; ++k) WH_SLIDE_STEP (cwin, 64 * k + lane, (p & 3) != 3)
-#undef WH_SLIDE_STEP
-#endif
-}
-WH_FN void wh_win_slide_finish (WhWinLds* b, const WhWinSlide& SL) {
-  WV_LANES_BEGIN (lane)
-  {
-    if (SL.on_y) { const int p = wh_win_slide_piece (lane); if (p < WH_WIN_PIECES) * (WhV4*)&b->win[16 * p] = WH_SL_LANE (SL.y, lane); }
-    if (SL.on_c && (lane & 3) == 3) { * (WhV4*)&b->cwin[16 * lane] = WH_SL_LANE (SL.c0, lane); * (WhV4*)&b->cwin[16 * (64 + lane)] = WH_SL_LANE (SL.c1, lane); }
-  }
-  WV_LANES_END
 }
 
 // ---- lane geometry -----------------------------------------------------------------------------------
@@ -678,18 +627,31 @@ WH_FN void wh_motion_search (WhInterLds& S, const WhSeqParams& P, const WhPicJob
     if ((uint32_t)c < Z->chain) { best = c; bmx = Z->dmx; bmy = Z->dmy; WH_STAT (WH_ST_DIR_TAKEN); }
   }
   const bool diamond = !(best < me.sad_pred);
-  if (diamond || C.use_satd) {
-    const int sx = C.mbx * 16 + me.bx + bmx, sy = C.mby * 16 + me.by + bmy;
-    wh_win_ensure (S, P, J, W, sx - WH_WIN_MARGIN, sy - WH_WIN_MARGIN, sx + me.bw + WH_WIN_MARGIN, sy + me.bh + WH_WIN_MARGIN);
-  }
+  const int bpx = C.mbx * 16 + me.bx, bpy = C.mby * 16 + me.by;
+  if (diamond || C.use_satd) wh_win_need (S, P, J, W, bpx + bmx, bpy + bmy, me.bw, me.bh, diamond ? WH_WIN_START : 0);
   if (diamond) {
     // WelsDiamondSearch (svc_motion_estimate.cpp:335-379)
     int dx = bmx * 4 - me.mvpx, dy = bmy * 4 - me.mvpy;
-    int wo = (C.mby * 16 + me.by + bmy - W.y0) * WH_WIN_STRIDE + C.mbx * 16 + me.bx + bmx - W.x0;     // window offset of the current centre
+    int wo = (bpy + bmy - W.y0) * WH_WIN_STRIDE + bpx + bmx - W.x0;     // window offset of the current centre
     const int n = (me.bw * me.bh) >> 2;
+    // Step `it` probes the four neighbours of a centre at most `it` samples away from the start: with `budget` samples of room at the start
+    // the steps below `budget` read inside the window whatever way the walk goes; then the room is looked at again (and the window follows
+    // the walk when it is used up)
+    int budget = wh_win_room (W, bpx + bmx, bpy + bmy, me.bw, me.bh);
     for (int it = 0; it < 16; ++it) {
       const int cmx = (dx + me.mvpx) >> 2, cmy = (dy + me.mvpy) >> 2;
       if (!(cmx >= C.minx && cmx < C.maxx && cmy >= C.miny && cmy < C.maxy)) break;   // CheckMvInRange fails: nothing changes any more
+      if (it >= budget) {
+        if (wh_win_room (W, bpx + cmx, bpy + cmy, me.bw, me.bh) < 1) {
+          WH_STAT_WIN (4);
+          wh_win_need (S, P, J, W, bpx + cmx, bpy + cmy, me.bw, me.bh, WH_WIN_START);
+          wo = (bpy + cmy - W.y0) * WH_WIN_STRIDE + bpx + cmx - W.x0;
+        }
+        budget = it + wh_max (1, wh_win_room (W, bpx + cmx, bpy + cmy, me.bw, me.bh));
+      }
+#if defined(WH_EMU)
+      if (wh_win_room (W, bpx + cmx, bpy + cmy, me.bw, me.bh) < 1 || wo != (bpy + cmy - W.y0) * WH_WIN_STRIDE + bpx + cmx - W.x0) { fprintf (stderr, "emu: diamond step outside the search window\n"); abort(); }
+#endif
       // four SADs: up, down, left, right -- two packed 16-bit partial sums per reduction
       int pud, plr;
       WV_SUM2 (pud, plr, lane,
@@ -728,10 +690,7 @@ WH_FN void wh_motion_search (WhInterLds& S, const WhSeqParams& P, const WhPicJob
         if (best < before) WH_STAT (WH_ST_FME_HIT);
         Z->fme_down += (uint32_t) (before - best);
       }
-      if (C.use_satd) {
-        const int sx = C.mbx * 16 + me.bx + bmx, sy = C.mby * 16 + me.by + bmy;
-        wh_win_ensure (S, P, J, W, sx - WH_WIN_MARGIN, sy - WH_WIN_MARGIN, sx + me.bw + WH_WIN_MARGIN, sy + me.bh + WH_WIN_MARGIN);
-      }
+      if (C.use_satd) wh_win_need (S, P, J, W, bpx + bmx, bpy + bmy, me.bw, me.bh, 0);       // (the line searches gave the window up)
     }
   }
   me.mvx = bmx * 4; me.mvy = bmy * 4;
@@ -746,8 +705,7 @@ WH_FN void wh_me_fixed (WhInterLds& S, const WhSeqParams& P, const WhPicJob& J, 
   me.mvx = imx * 4; me.mvy = imy * 4;
   me.satd_cost = me.sad_cost; me.satd_raw = 0;
   if (C.use_satd) {
-    const int sx = C.mbx * 16 + me.bx + imx, sy = C.mby * 16 + me.by + imy;
-    wh_win_ensure (S, P, J, W, sx - WH_WIN_MARGIN, sy - WH_WIN_MARGIN, sx + me.bw + WH_WIN_MARGIN, sy + me.bh + WH_WIN_MARGIN);
+    wh_win_need (S, P, J, W, C.mbx * 16 + me.bx + imx, C.mby * 16 + me.by + imy, me.bw, me.bh, 0);
     wh_me_satd (S, W, C, me, imx, imy);
   }
 }
@@ -1174,9 +1132,11 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
   {
     const int icx = wh_clip3 ((2 + me16.mvpx) >> 2, C.minx, C.maxx), icy = wh_clip3 ((2 + me16.mvpy) >> 2, C.miny, C.maxy);
     const int cx = mbx * 16 + icx, cy = mby * 16 + icy;
-    const bool adopt = X.spec_valid && wh_win_covers (X.spec, cx - WH_WIN_MARGIN, cy - WH_WIN_MARGIN, cx + 16 + WH_WIN_MARGIN, cy + 16 + WH_WIN_MARGIN);
-    if (adopt) { W.x0 = X.spec.x0; W.y0 = X.spec.y0; W.cx0 = X.spec.cx0; W.cy0 = X.spec.cy0; WH_PROF_MARK (P, M, 15); }     // fetched while the wave waited for its neighbours
+    const bool adopt = X.spec_valid && wh_win_room (X.spec, cx, cy, 16, 16) >= WH_WIN_START;
+    WH_STAT_WIN (0);
+    if (adopt) { W.x0 = X.spec.x0; W.y0 = X.spec.y0; W.cx0 = X.spec.cx0; W.cy0 = X.spec.cy0; WH_STAT_WIN (2); WH_PROF_MARK (P, M, 15); }     // fetched while the wave waited for its neighbours
     else {
+      WH_STAT_WIN (3);
       if (X.spec_valid) WV_ASYNC_WAIT();       // (landed long ago: the batch-1 loads were issued after it)
       wh_win_issue_all (P, J, W, cx, cy);
     }

@@ -350,7 +350,7 @@ WH_FN bool wh_intra_md_enc_p (WhMbLds& S, const WhSeqParams& P, const WhPicJob& 
   const int use_satd = CPLX >= 0 ? (CPLX > 0) : (P.complexity > 0);
   const bool has_l = (avail & WH_AV_LEFT) != 0, has_t = (avail & WH_AV_TOP) != 0;
   // phase cycles of an I picture's macroblocks (a P macroblock's intra test is part of the P body's own phases)
-#if defined(WH_EMU)
+#if defined(WH_EMU) || !defined(WH_PROF)
 #define WH_PROF_MARK_I(id) ((void)0)
 #else
   unsigned long long _wh_t0 = (P.prof && J.slice_type == WH_SLICE_I) ? (unsigned long long)__builtin_readcyclecounter() : 0ULL;

@@ -37,7 +37,9 @@ typedef struct WhMbLds {
   int8_t   i4_rem[16];
   uint16_t i4_prev;
   uint8_t  pad_[2];
-  uint32_t prof[32];          // phase-profiling accumulators of this wave (WH_PROF_MARK)
+#if defined(WH_PROF)
+  uint32_t prof[32];          // phase-profiling accumulators of this wave (WH_PROF_MARK; profiling build only)
+#endif
 } WhMbLds;
 
 #define WH_RY(S, x, y) ((S).rec_y[((y) + 1) * 32 + (x) + 8])

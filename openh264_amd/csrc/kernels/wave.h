@@ -245,7 +245,9 @@ WH_FN uint32_t wh_avg4 (uint32_t a, uint32_t b) { return __builtin_amdgcn_lerp (
 // Cycles since the previous mark are accumulated per wave in LDS (`L`.prof[id], count in prof[16 + id]) by lane 0 and
 // flushed to the global counters once, when the wave leaves the kernel -- no memory traffic inside the MB loop, so the
 // measurement does not perturb the s_waitcnt's it is measuring.  Costs one uniform branch when disabled.
-#if defined(WH_EMU)
+// The accumulators cost every wave 128 bytes of LDS and every mark a branch, so they are compiled in only with -DWH_PROF: the library the
+// profiling tools load (openh264_amd/libwelship_prof.so, tools/phase_profile.py builds it), never the product library.
+#if defined(WH_EMU) || !defined(WH_PROF)
 #define WH_PROF_DECL(P) ((void)0)
 #define WH_PROF_MARK(P, L, id) ((void)0)
 #define WH_PROF_SUB(P, L, id) ((void)0)

@@ -73,86 +73,6 @@ class EmuBackend : public Backend {
       }
     }
   }
-  // The run scheduler of the device (hip_backend.hip k_inter_rows): one emulated wavefront takes the runs of a slice in the order of
-  // the run table (common/mb_order.h wh_build_run_order) and codes each run's macroblocks left to right, keeping its windows inside a
-  // run -- through the very slide functions the device uses (inter_mb.h wh_win_slide_*), started where the macroblock body calls back.
-  // After the callback the body must not read the staging area or the windows: both are set aside and poisoned until it returns.  The
-  // table is checked on the way: every macroblock of the slice exactly once, nothing before what it depends on.
-  // WELSHIP_MD_ROWS=0 (the device's knob) runs these pictures through the ticket order instead.
-  void run_inter_rows (const WhSeqParams& P, const WhPicJob* jobs, int n) {
-    const int w = P.mb_w, num_mb = P.mb_w * P.mb_h;
-    for (int j = 0; j < n; ++j)
-      for (int s = 0; s < P.num_slices; ++s) {
-        WhInterLds S;
-        WhInterStage G, Gk;
-        WhWinLds WB, WBk;
-        poison (&S, sizeof (S)); poison (&G, sizeof (G)); poison (&WB, sizeof (WB));
-        const int first = P.slice_first_mb[s], last = P.slice_first_mb[s + 1];
-        const uint32_t* runs = P.mb_order + 3 * (size_t)num_mb + first;
-        const int nruns = P.run_count[s];
-        // the macroblocks of the slice in the order the wave codes them
-        std::vector<int> seq;
-        std::vector<char> done_mb ((size_t) (last - first), 0);
-        for (int r = 0; r < nruns; ++r)
-          for (int k = 0; k < WH_RUN_LEN (runs[r]); ++k) {
-            const int xy = WH_RUN_XY (runs[r]) + k;
-            int da, db;
-            wh_mb_deps (w, xy, first, &da, &db);
-            if (xy < first || xy >= last || done_mb[xy - first] || (da >= first && !done_mb[da - first]) || (db >= first && !done_mb[db - first]) || (k && xy % w == 0)) {
-              fprintf (stderr, "emu: run table of slice %d is wrong at run %d MB %d\n", s, r, xy); abort();
-            }
-            done_mb[xy - first] = 1;
-            seq.push_back (xy | (k + 1 < WH_RUN_LEN (runs[r]) ? 0 : 0x40000000));       // bit 30: the run ends with this macroblock
-          }
-        if ((int)seq.size() != last - first) { fprintf (stderr, "emu: run table of slice %d covers %zu of %d macroblocks\n", s, seq.size(), last - first); abort(); }
-        const WhPicJob& J = jobs[j];
-        int last_mv = 0;
-        WhInterCtx X;
-        X.win = &WB; X.spec.b = &WB; X.spec_valid = 0; X.last_mv = &last_mv;
-        WhWinSlide SL;
-        SL.on_y = 0; SL.on_c = 0;
-        int pos = -1;                      // index into seq of the macroblock in hand
-        struct Early {
-          const WhSeqParams& P; const WhPicJob& J; WhInterStage& G; WhInterStage& Gk; WhWinLds& WB; WhWinLds& WBk; WhInterCtx& X; WhWinSlide& SL;
-          int& pos; std::vector<int>& seq; int w; int& last_mv; int calls;
-          void call() {
-            ++calls;
-            if (pos + 1 < (int)seq.size()) {
-              const int nxy = seq[pos + 1] & 0xfffff, nx = nxy % w, ny = nxy / w;
-              for (int lane = 0; lane < 64; ++lane) wh_inter_cold_fetch (G, lane, P, J, nx, ny);
-              WhWin N;
-              N.b = &WB;
-              const int gx = wh_clip3 ((2 + (int) (int16_t) (last_mv & 0xffff)) >> 2, -P.mv_range, P.mv_range), gy = wh_clip3 ((2 + (last_mv >> 16)) >> 2, -P.mv_range, P.mv_range);
-              wh_win_place (P, N, nx * 16 + gx, ny * 16 + gy);
-              const bool same = pos >= 0 && !(seq[pos] & 0x40000000);         // the next macroblock continues the run
-              SL.on_y = same && wh_win_can_slide_y (X.spec, N);
-              SL.on_c = same && wh_win_can_slide_c (X.spec, N);
-              if (SL.on_y | SL.on_c) wh_win_slide_begin (P, J, N, SL);
-              if (!SL.on_y) { poison (WB.win, sizeof (WB.win)); wh_win_issue_luma (P, J, N); }
-              if (!SL.on_c) { poison (WB.cwin, sizeof (WB.cwin)); wh_win_issue_chroma (P, J, N); }
-              if (SL.on_y | SL.on_c) wh_win_slide_move (&WB, SL.on_y, SL.on_c);
-              X.spec = N; X.spec_valid = 1;
-            }
-            // what the rest of the body must not touch
-            Gk = G; WBk = WB;
-            poison (&G, sizeof (G)); poison (&WB, sizeof (WB));
-          }
-        } early = { P, J, G, Gk, WB, WBk, X, SL, pos, seq, w, last_mv, 0 };
-        early.call();
-        G = Gk; WB = WBk;
-        for (pos = 0; pos < (int)seq.size(); ++pos) {
-          const int xy = seq[pos] & 0xfffff;
-          wh_win_slide_finish (&WB, SL);
-          SL.on_y = 0; SL.on_c = 0;
-          X.slice_idc = s; X.slice_first = first;
-          early.calls = 0;
-          wh_inter_mb_body_t<false> (S, G, P, J, xy % w, xy / w, X, early);
-          if (early.calls != 1) { fprintf (stderr, "emu: the P macroblock body called back %d times at MB %d\n", early.calls, xy); abort(); }
-          G = Gk; WB = WBk;
-          poison (&S, sizeof (S));
-        }
-      }
-  }
   void run_inter (const WhSeqParams& Pin, const WhPicJob* jobs, int n) override {
     // WH_SEQ_PLAIN (a session group's step): the body variant that never looks at the optional per-picture inputs (as hip_backend.hip takes it;
     // -DWH_PLAIN_KERNEL=0: the general body) -- and a check that the promise holds
@@ -180,8 +100,6 @@ class EmuBackend : public Backend {
       }
     // one emulated wavefront walks each slice in order like a wave of the device scheduler: a macroblock's cold inputs and
     // its speculative search windows (around the slice's last final vector) are fetched before its body runs
-    static const bool rows_off = getenv ("WELSHIP_MD_ROWS") && atoi (getenv ("WELSHIP_MD_ROWS")) == 0;
-    if (P.flags == 0 && P.run_len > 1 && !rows_off) { run_inter_rows (P, jobs, n); return; }
     for (int j = 0; j < n; ++j)
       for (int s = 0; s < P.num_slices; ++s) {
         WhInterLds S;

@@ -22,7 +22,8 @@
 #                   tables:camera / tables:screen / tables:dyn run one part)
 #   repro:<seeds>   size-limited-slice sessions <seeds> (comma separated; s = screen content, q = low QP: e.g. s21001,q11012,1003) with slice threads,
 #                   RUNS times each (default 6), for every library of LIBS (default: the product library) -> repro.txt
-#   ab:<tagA>,<tagB>[,..]   `bench.py --quick` alternating between candidate libraries openh264_amd/libwelship_<tag>.so ("-" = the product library), three rounds
+#   ab:<v>,<v>..    `bench.py --quick` alternating between variants, three rounds; a variant = a library tag (openh264_amd/libwelship_<tag>.so, "-" = the product
+#                   library) optionally followed by :ENV=VALUE settings (e.g. -:WELSHIP_P_WAVES=14); AB_ARGS = further bench.py arguments
 #   detail:<tag>    sub-phase cycles of the claim / neighbour-load / P_Skip phases: tools/phase_profile.py with a library built with -DWH_PROF_DETAIL
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
@@ -72,11 +73,13 @@ for stage in "$@"; do
             [ -z "$part" -o "$part" = dyn ] && timeout 300 python tools/sha1_table_rows.py --table adobe --dynslice --workers $W > $o/screen_table_size_limited_256_rows.txt 2>&1; tail -2 $o/screen_table_size_limited_256_rows.txt | cut -c1-220
             lap "SHA1 tables";;
   repro:*)  FUZZ_DYNSLICE_KEEP=$o/streams timeout ${REPRO_TIMEOUT:-600} python tools/repro_dynslice.py "${stage#repro:}" > $o/repro.txt 2>&1; grep -E "^==|DIFF|FAILED|VARIES|summary" $o/repro.txt | cut -c1-260 | head -80; lap "repro";;
-  ab:*)     LIBTAGS=$(echo "${stage#ab:}" | tr , ' ')
-            for rep in 1 2 3; do for t in $LIBTAGS; do
-              lib=openh264_amd/libwelship.so; [ "$t" != "-" ] && lib=openh264_amd/libwelship_$t.so
-              WELSHIP_LIB=$PWD/$lib timeout 200 python bench.py --quick > $o/ab_${t}_$rep.json 2> $o/ab_${t}_$rep.err
-              python -c "import json; d=json.loads(open('$o/ab_${t}_$rep.json').read().strip().splitlines()[-1]); print('$t', $rep, 'value', round(d['value']), 'md_ms', d['roofline']['avg_launch_ms'], 'verified', d.get('verified'))"
+  ab:*)     # variants: a library tag ("-" = the product library), optionally followed by :ENV=VALUE settings; comma separated
+            for rep in $(seq 1 ${REPS:-3}); do for v in $(echo "${stage#ab:}" | tr , ' '); do
+              t=${v%%:*}; lib=openh264_amd/libwelship.so; [ "$t" != "-" ] && lib=openh264_amd/libwelship_$t.so
+              envs=$(echo "${v#*:}" | tr ':' ' '); [ "$envs" = "$v" ] && envs=""
+              n=$(echo "$v" | tr ':=' '__')
+              env $envs WELSHIP_LIB=$PWD/$lib timeout 200 python bench.py --quick ${AB_ARGS:-} > $o/ab_${n}_$rep.json 2> $o/ab_${n}_$rep.err
+              python -c "import json; d=json.loads(open('$o/ab_${n}_$rep.json').read().strip().splitlines()[-1]); print('$v', $rep, 'value', round(d['value']), 'md_ms', round(d['roofline']['avg_launch_ms'], 3), 'res_clip', round(d.get('res_clip', {}).get('value', 0)), 'verified', d.get('verified'))"
             done; done | tee $o/ab.txt; lap "A/B";;
   iwaves)   for w in 16 12 10 8 6 0; do echo "WELSHIP_I_WAVES=$w: $(WELSHIP_I_WAVES=$w timeout 120 python tools/phase_profile.py 256 synthetic intra 2>&1 | grep -E "IDR step|dependency wait|total cycles" | tr '\n' ' ')"; done > $o/intra_waves.txt 2>&1
             cat $o/intra_waves.txt; lap "IDR step by waves per intra workgroup";;
