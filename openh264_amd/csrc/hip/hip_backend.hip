@@ -131,7 +131,6 @@ WH_DEFINE_MB_KERNEL (k_intra_slice, WhMbLds, wh_intra_mb_body, 1024, 0, 1)
 // them out in snake order, heavy with light.  Inside a slice nothing changes: tickets in dependency order (LDS counter),
 // done bits in LDS, data through the workgroup-coherent L1/L2.
 #define WH_MD_MAX_SLOTS 4
-template <class F> struct WhEarlyFn { F& f; __device__ __forceinline__ void call() { f(); } };      // (the run scheduler's callback from the macroblock body)
 // PLAIN: see inter_mb.h wh_inter_cold_fetch.  The variant has a third fewer instructions (no background-detection, inter-layer, bit-counting,
 // rate-control or QP-map code) and codes a session group's pictures 7.4 % faster (MD launch 13.70 -> 12.69 ms, same box:
 // profiles/r03_p_kernel_candidates_ab.txt); 0 = every launch takes the general kernel.
@@ -158,7 +157,7 @@ template <class F> struct WhEarlyFn { F& f; __device__ __forceinline__ void call
 //     the next ticket lies beyond it and one coalesced load refills it;
 //   * the job fields the fetch of the next macroblock's inputs reads, copied out of the LDS descriptor in one go (one wait, not one per field).
 #ifndef WH_P_WAVES_DEFAULT
-#define WH_P_WAVES_DEFAULT 14           /* waves per mode-decision workgroup unless WELSHIP_P_WAVES says otherwise */
+#define WH_P_WAVES_DEFAULT 16           /* waves per mode-decision workgroup unless WELSHIP_P_WAVES says otherwise */
 #endif
 #ifndef WH_MD_ATTR
 #define WH_MD_ATTR          /* (A/B builds: an extra function attribute of the mode-decision kernel, e.g. amdgpu_waves_per_eu) */
@@ -267,12 +266,12 @@ __global__ WH_MD_ATTR __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P,
       if (CTRL) { Jf.sad_cost0_out = Jn.sad_cost0_out; Jf.dyn_redo = Jn.dyn_redo; Jf.mb_begin = Jn.mb_begin; }                 \
     }                                                                                                                          \
     const int guess_ = slot_mv[nslot];                                                                                         \
-    wh_inter_cold_fetch<VAR> (G, lane, P, Jf, nmbx, nmby);                                                                     \
+    wh_inter_cold_fetch<VAR> (S, G, lane, P, Jf, nmbx, nmby);                                                                     \
     WH_PROF_SUB (P, S.m, 2);         /* detail: cold inputs issued */                                                          \
     X.spec_valid = 0;                                                                                                          \
     if (speculate) { wh_win_speculate (P, Jf, X.spec, nmbx, nmby, guess_); X.spec_valid = 1; }                                  \
   }
-  WhNoEarly early;                        // (claiming the next macroblock when the body's prediction is final, before residual coding, was measured: no gain)
+  // (claiming the next macroblock when the body's prediction is final, before residual coding, was measured in round 3: no gain -- and its inputs now land where the macroblock in hand still reads)
   WH_CLAIM()
   WH_FETCH_AHEAD()
   slot = nslot; xy = nxy; mbx = nmbx; mby = nmby;
@@ -296,7 +295,7 @@ __global__ WH_MD_ATTR __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P,
     WV_ASYNC_WAIT();                      /* this MB's cold inputs have landed in the staging area */
     const bool dyn_ = CTRL && J.dyn_slice;
     X.slice_idc = dyn_ ? J.dyn_slice - 1 : __builtin_amdgcn_readlane (tab_idc, slot); X.slice_first = dyn_ ? J.dyn_first : first; X.last_mv = &slot_mv[slot];
-    wh_inter_mb_body_t<SCC, VAR> (S, G, P, J, mbx, mby, X, early);
+    wh_inter_mb_body_t<SCC, VAR> (S, G, P, J, mbx, mby, X);
     if (CTRL && J.gom_rc) wh_gom_close_if_last (P, J, xy);       // rate control: the group's last macroblock settles the next group's QP
     WH_PROF_MARK (P, S.m, 14);
     __builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");
@@ -774,15 +773,17 @@ class HipBackend : public wh::Backend {
     }
     const int sched_words = 1 + ((max_n + 31) >> 5);
     int nw = forced_waves > 0 ? forced_waves : WH_P_WAVES_DEFAULT;
-    nw = std::min (nw, 16);              // (the LDS bounds it below: 10.9 KB per wave since round 5 = 14 waves; rounds 1-4: 12.7 KB = 12 waves)
-    if (!(WH_PLAIN_KERNEL == 2 && plain && P.flags == 0 && P.complexity == 0)) nw = std::min (nw, 12);      // (only the session groups' variant is built for more than 768 threads)
+    nw = std::min (nw, 16);
     int par = std::max (1, std::min (max_rows, (P.mb_w + 1) / 2)) * slots;       // macroblocks that can be in flight at all
     if (P.flags & WH_SEQ_SERIAL) par = 2 * slots;      // one macroblock of a slice at a time; a second wave has the next one's inputs in flight
     if (P.flags & WH_SEQ_SCC) nw = std::min (nw, 6);    // the screen-content variant needs 216 VGPRs: six waves per workgroup, no scratch
     nw = std::min (nw, par);
-    const size_t per_wave = sizeof (WhInterLds) + sizeof (WhInterStage) + sizeof (WhWinLds);
-    const size_t fixed = WH_MD_MAX_SLOTS * (sizeof (WhPicJob) + 16) + 4 * (size_t)slots * sched_words;
-    while (nw > 1 && (size_t)nw * per_wave + fixed > (size_t)160 * 1024) --nw;
+    // LDS of a workgroup: the waves' tiles (dynamic) + the windows and staging areas of as many waves as the kernel variant is built for
+    // (static arrays: 6 / 12 / 14 / 16) + the job descriptors and the scheduler's words.  10.0 KB per wave since round 5 = 16 waves per CU
+    // (rounds 1-4: 12.7 KB = 12 waves).
+    auto built_for = [] (int w) { return w <= 6 ? 6 : w <= 12 ? 12 : w <= 14 ? 14 : 16; };
+    const size_t fixed = WH_MD_MAX_SLOTS * (sizeof (WhPicJob) + 24) + 4 * (size_t)slots * sched_words;
+    while (nw > 1 && (size_t)nw * sizeof (WhInterLds) + (size_t)built_for (nw) * (sizeof (WhInterStage) + sizeof (WhWinLds)) + fixed > (size_t)160 * 1024) --nw;
     const size_t lds = (size_t)nw * sizeof (WhInterLds) + 4 * (size_t)slots * sched_words;
     uint16_t* grp = nullptr;
     uint32_t* cost = nullptr;
@@ -809,13 +810,13 @@ class HipBackend : public wh::Backend {
       if (getenv ("WELSHIP_TRACE")) { HIP_TRY (hipStreamSynchronize (stream_)); fprintf (stderr, "welship: launch done\n"); fflush (stderr); }
     };
     if (P.flags & WH_SEQ_SCC) launch (k_inter_pool<384, true>);      // (nw <= 6 above: 249 VGPRs, no scratch; a 12-wave build of this variant spills -- 168 VGPRs + 360 B -- and is not instantiated any more)
-    else if (WH_PLAIN_KERNEL == 2 && plain && P.flags == 0 && P.complexity == 0) {
-      if (nw <= 6) launch (k_inter_pool<384, false, WH_PLAIN_KERNEL == 2 ? 2 : 0>); else if (nw <= 12) launch (k_inter_pool<768, false, WH_PLAIN_KERNEL == 2 ? 2 : 0>);
-      else if (nw <= 14) launch (k_inter_pool<896, false, WH_PLAIN_KERNEL == 2 ? 2 : 0>); else launch (k_inter_pool<1024, false, WH_PLAIN_KERNEL == 2 ? 2 : 0>);
-    }
-    else if (WH_PLAIN_KERNEL && plain && P.flags == 0) { if (nw <= 6) launch (k_inter_pool<384, false, WH_PLAIN_KERNEL ? 1 : 0>); else launch (k_inter_pool<768, false, WH_PLAIN_KERNEL ? 1 : 0>); }
-    else if (WH_FRAME_KERNEL && no_ctrl && P.flags == 0) { if (nw <= 6) launch (k_inter_pool<384, false, WH_FRAME_KERNEL ? 3 : 0>); else launch (k_inter_pool<768, false, WH_FRAME_KERNEL ? 3 : 0>); }
-    else if (nw <= 6) launch (k_inter_pool<384, false>); else launch (k_inter_pool<768, false>);
+#define WH_LAUNCH_POOL(VARIANT) do { if (nw <= 6) launch (k_inter_pool<384, false, VARIANT>); else if (nw <= 12) launch (k_inter_pool<768, false, VARIANT>); \
+                                     else if (nw <= 14) launch (k_inter_pool<896, false, VARIANT>); else launch (k_inter_pool<1024, false, VARIANT>); } while (0)
+    else if (WH_PLAIN_KERNEL == 2 && plain && P.flags == 0 && P.complexity == 0) WH_LAUNCH_POOL (WH_PLAIN_KERNEL == 2 ? 2 : 0);
+    else if (WH_PLAIN_KERNEL && plain && P.flags == 0) WH_LAUNCH_POOL (WH_PLAIN_KERNEL ? 1 : 0);
+    else if (WH_FRAME_KERNEL && no_ctrl && P.flags == 0) WH_LAUNCH_POOL (WH_FRAME_KERNEL ? 3 : 0);
+    else WH_LAUNCH_POOL (0);
+#undef WH_LAUNCH_POOL
   }
   void run_deblock (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
     const int db_waves = 12;    // 73 VGPRs: two 12-wave workgroups per CU, one of 16 (measured 3.85 against 4.79 ms per step of 256 pictures; 8: 4.3, 6: 5.1)

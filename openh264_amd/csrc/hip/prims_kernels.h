@@ -39,7 +39,7 @@ __global__ __launch_bounds__ (64) void k_sad_wave (int blk, const uint8_t* p1, i
   const long base = (long)o2[i] - 8 * s2 - 8;                 // window origin = block position - (8,8)
   WV_LANES_BEGIN (lane)
   for (int k = lane; k < bw * bh; k += 64) S.m.enc_y[(k / bw) * 16 + k % bw] = a[(k / bw) * s1 + k % bw];
-  for (int k = lane; k < 40 * 64; k += 64) {              // 40 rows x 64 columns of the plane at the window's row pitch
+  for (int k = lane; k < 32 * 64; k += 64) {              // 32 rows x 64 columns of the plane at the window's row pitch (the block at (8,8) + every tap)
     long ad = base + (long) (k >> 6) * s2 + (k & 63);
     ad = ad < 0 ? 0 : (ad > (long)b2 - 1 ? (long)b2 - 1 : ad);
     WB.win[(k >> 6) * WH_WIN_STRIDE + (k & 63)] = p2[ad];
@@ -67,7 +67,7 @@ __global__ __launch_bounds__ (64) void k_mc_wave (const uint8_t* plane, size_t b
   const int i = blockIdx.x;
   const long base = (long)off[i] - 8 * st - 8;
   WV_LANES_BEGIN (lane)
-  for (int k = lane; k < 40 * 64; k += 64) {
+  for (int k = lane; k < 32 * 64; k += 64) {
     long ad = base + (long) (k >> 6) * st + (k & 63);
     ad = ad < 0 ? 0 : (ad > (long)bytes - 1 ? (long)bytes - 1 : ad);
     WB.win[(k >> 6) * WH_WIN_STRIDE + (k & 63)] = plane[ad];

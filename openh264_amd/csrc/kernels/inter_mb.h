@@ -61,11 +61,11 @@ static WhWinStatInit g_wh_win_stat_init;
 // never changes a result -- only whether a reload is needed.
 #define WH_WIN_STRIDE 80          // five tile columns (common/wh_types.h WH_TILE_*): 16 + 2 * 19 samples wherever the block sits in its tile column
 #ifndef WH_WIN_ROWS
-#define WH_WIN_ROWS 40            // 16 + 2 * 12 rows.  (Rows of 80 bytes also spread the lanes of a block read over all LDS banks; 64 did not.)
+#define WH_WIN_ROWS 38            // 16 + 2 * 11 rows = 190 16-byte pieces: three loads per lane.  (Rows of 80 bytes also spread the lanes of a block read over all LDS banks; 64 did not.)
 #endif
 #define WH_WIN_MARGIN_X 19        // what a (re)load leaves around the block it is centred on, horizontally ...
 #ifndef WH_WIN_MARGIN_Y
-#define WH_WIN_MARGIN_Y 11        // ... and vertically (a 16-row block: 38 of the 40 rows)
+#define WH_WIN_MARGIN_Y 11        // ... and vertically (a 16-row block: all 38 rows)
 #endif
 #ifndef WH_WIN_START
 #define WH_WIN_START 5            // room (samples in every direction) a search start asks for: what the fractional refinement reads around a block that does not move (measured on the reference 1080p clip with the test build: profiles/r05_window_reload_statistics.txt)
@@ -93,16 +93,19 @@ typedef struct alignas (16) WhInterLds {
   WhMbLds m;
   // (the P_Skip prediction lives in m.pred_y / m.pred_c: whenever a macroblock makes another prediction it is not a decided skip any more)
   uint32_t nb[5 * 36];                                      // WhMbState copies: top-left, top, top-right, left, co-located (reference picture)
-  int16_t co_mv[2][2];                                      // sP16x16Mv of the reference picture's MBs to the right / below
+  int16_t co_mv[2][2];                                      // sP16x16Mv of the reference picture's MBs to the right / below (MUST follow nb: wh_inter_cold_fetch)
+  uint32_t sad_cost0_in;                                    // the layer's pSadCost[0] of this macroblock (WhPicJob::sad_cost0), when the host supplies it
   int16_t mvp_out[16][2];                                   // predictor used for the mvd of each 4x4 (raster)
   int16_t mv_out[16][2];
 } WhInterLds;
 
-// Staging area of a wave for its NEXT macroblock, filled by LDS-DMA while the current MB is processed.  It is a separate
-// LDS object (a different __shared__ variable on the GPU) on purpose: the compiler then knows that the tile's LDS reads
-// cannot alias an in-flight DMA and does not wait for it.
+// The "cold" inputs of a wave's NEXT macroblock (wh_inter_cold_fetch) are copied by LDS-DMA straight to where the body reads them -- the source
+// samples into m.enc_y / m.enc_c, the reference picture's macroblock state into nb[144..] / co_mv -- while the wave waits for that macroblock's
+// neighbours: the macroblock in hand is complete by then (rounds 1-4 staged them in 800 bytes of their own and moved them at the top of the
+// body).  Only the previous source picture's luma block keeps a staging area: it is a separate LDS object (a different __shared__ variable on
+// the GPU), which the four words of the host's own 8x8 SADs share when the pre-processing supplies them.
 typedef struct alignas (16) WhInterStage {
-  uint32_t cold_y[64], cold_c[32], cold_pv[64], cold_co[40];            // cold inputs (wh_inter_cold_fetch)
+  uint32_t cold_pv[64];
 } WhInterStage;
 typedef struct WhWin { int x0, y0, cx0, cy0; WhWinLds* b; } WhWin;     // picture coordinates of element (0,0) of win / cwin + where they live
 
@@ -939,8 +942,8 @@ WH_FN bool wh_try_puv_skip (WhMbLds& S, int qpc) {
 
 // ---- "cold" inputs of a P macroblock: data no kernel writes while the picture is being coded (source samples,
 // previous source picture, the reference picture's MB states).  They come straight from HBM, so a wave starts their
-// copy into the LDS staging words S.cold_* for its NEXT macroblock while it is still busy with the current one
-// (LDS-DMA: no registers held), and moves them into place when that MB starts.
+// copy for its NEXT macroblock as soon as the macroblock in hand is complete -- LDS-DMA (no registers held) straight to where the body
+// reads them, under the wait for the next macroblock's neighbours.
 // PLAIN (here and in wh_inter_mb_body_t): the picture has none of the optional per-picture inputs -- host VAA SADs, the layer's pSadCost array,
 // background flags, inter-layer hints, a QP map, GOM rate control, MB ranges, bit counting, a temporal-layer vector shift (common/wh_types.h
 // WH_SEQ_PLAIN: the pictures of a session group) -- so none of them is looked at.
@@ -948,25 +951,26 @@ WH_FN bool wh_try_puv_skip (WhMbLds& S, int qpc) {
 // inputs a host's pre-processing supplies (VAA SADs, pSadCost, background flags, the vector shift) may be there, the control inputs (inter-layer
 // hints, QP map, GOM rate control, MB ranges, bit counting) are not (WH_SEQ_NO_CTRL; candidate, -DWH_FRAME_KERNEL=1)
 template <int VAR = 0>
-WH_FN void wh_inter_cold_fetch (WhInterStage& G, int lane, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby) {
+WH_FN void wh_inter_cold_fetch (WhInterLds& S, WhInterStage& G, int lane, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby) {
   constexpr bool HOSTIN = VAR == 0 || VAR == 3, CTRL = VAR == 0;
   const int w = P.mb_w, xy = mby * w + mbx;
-  // (macroblock-tiled source pictures, WH_SRC_*: luma = 256 consecutive bytes in lane order, both chroma blocks = the 128 behind them)
-  wh_ld_async4 ((const WH_G uint8_t*)J.src[0] + WH_SRC_Y_OFF (w, mbx, mby, 0, 0) + lane * 4, G.cold_y, lane);
-  if (lane < 32) wh_ld_async4 ((const WH_G uint8_t*)J.src[0] + WH_SRC_C_OFF (w, mbx, mby, 0, 0, 0) + lane * 4, G.cold_c, lane);
+  // (macroblock-tiled source pictures, WH_SRC_*: luma = 256 consecutive bytes in lane order, both chroma blocks = the 128 behind them: the very
+  //  order of m.enc_y / m.enc_c)
+  wh_ld_async4 ((const WH_G uint8_t*)J.src[0] + WH_SRC_Y_OFF (w, mbx, mby, 0, 0) + lane * 4, (uint32_t*)S.m.enc_y, lane);
+  if (lane < 32) wh_ld_async4 ((const WH_G uint8_t*)J.src[0] + WH_SRC_C_OFF (w, mbx, mby, 0, 0, 0) + lane * 4, (uint32_t*)S.m.enc_c, lane);
   if (P.complexity == 0 && (!HOSTIN || !J.vaa_sad8x8))     // VAA 8x8 SADs (LOW complexity only), unless the host supplies them
     wh_ld_async4 ((const WH_G uint8_t*)J.prev_src_y + WH_SRC_Y_OFF (w, mbx, mby, 0, 0) + lane * 4, G.cold_pv, lane);
-  if (lane < 36 && J.ref_mbs) wh_ld_async4 ((const WH_G uint32_t*) ((const WH_G WhMbState*)J.ref_mbs + xy) + lane, G.cold_co, lane);
+  // the reference picture's state of this MB (an I picture's has no motion / SAD: zeros), words 144..179 of nb; lanes 36 / 37: co_mv
+  if (lane < 36) { if (J.ref_mbs) wh_ld_async4 ((const WH_G uint32_t*) ((const WH_G WhMbState*)J.ref_mbs + xy) + lane, &S.nb[144], lane); else S.nb[144 + lane] = 0u; }
   if (J.ref_is_p) {
     if (lane >= 36 && lane < 38) {
       const bool ok = lane == 36 ? mbx < P.mb_w - 1 : mby < P.mb_h - 1;
       const WH_G WhMbState* o = (const WH_G WhMbState*)J.ref_mbs + xy + (lane == 36 ? 1 : w);
-      if (ok) wh_ld_async4 (&o->p16mv[0], G.cold_co, lane);
+      if (ok) wh_ld_async4 (&o->p16mv[0], &S.nb[144], lane);
     }
   }
-  // pSadCost[0] of the layer's SMB array (cold_co word 38); the host's four VAA SADs take the place of the previous source
-  // picture's first words (cold_pv 0..3, read by wh_inter_mb_body straight from the staging area)
-  if (HOSTIN && lane == 38 && J.sad_cost0) wh_ld_async4 ((CTRL && J.sad_cost0_out && J.dyn_redo && xy == J.mb_begin ? (const WH_G int32_t*)J.sad_cost0_out : (const WH_G int32_t*)J.sad_cost0) + xy, G.cold_co, lane);
+  // pSadCost[0] of the layer's SMB array; the host's four VAA SADs take the place of the previous source picture's first words (cold_pv 0..3)
+  if (HOSTIN && lane == 0 && J.sad_cost0) wh_ld_async4 ((CTRL && J.sad_cost0_out && J.dyn_redo && xy == J.mb_begin ? (const WH_G int32_t*)J.sad_cost0_out : (const WH_G int32_t*)J.sad_cost0) + xy, &S.sad_cost0_in, lane);
   if (HOSTIN && lane < 4 && J.vaa_sad8x8) wh_ld_async4 ((const WH_G int32_t*)J.vaa_sad8x8 + xy * 4 + lane, G.cold_pv, lane);
 }
 
@@ -974,22 +978,15 @@ typedef struct WhInterCtx {
   int slice_idc, slice_first;        // slice of this MB and its first MB address
   WhWinLds* win;                        // this wave's search windows
   int spec_valid;                       // windows were fetched speculatively (wh_win_speculate) ...
-  WhWin spec;                           // ... at this placement.  Out: where the windows really are when the body calls back (`early`):
-                                        //   a search that left them has fetched others -- what a wave that slides its windows starts from
+  WhWin spec;                           // ... at this placement
   int* last_mv;                         // out (may be NULL): the slice's most recent final 16x16 vector, packed -- the next guess
 } WhInterCtx;
 
 // ---- the P macroblock -----------------------------------------------------------------------------
-// `early` is called exactly once per macroblock, at the point from which the body reads neither the staging area G nor the
-// search windows any more (the prediction is final: only residual coding and the stores are left).  The device scheduler claims
-// the wave's NEXT macroblock there and starts the LDS-DMA of its cold inputs and speculative windows into those very buffers, so
-// the fetch runs under residual coding + stores instead of being waited for at the top of the next macroblock.  The CPU test
-// build poisons both buffers in the callback: a read after the call would break parity.
-struct WhNoEarly { WH_FN void call() {} };
 // VAR: 0 = the general body, 1 = PLAIN (see wh_inter_cold_fetch), 2 = PLAIN and LOW complexity known at compile time (SAD costs: the SATD
 // paths of the search, the refinement and the intra test are not compiled in), 3 = the frame API's camera pictures without control inputs
-template <bool SCC, int VAR, class Early>
-WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, WhInterCtx& X, Early& early) {
+template <bool SCC, int VAR = 0>
+WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, WhInterCtx& X) {
   constexpr bool LOW = VAR == 2, HOSTIN = VAR == 0 || VAR == 3, CTRL = VAR == 0;      // (see wh_inter_cold_fetch)
   WH_PROF_DECL (P);
   WhMbLds& M = S.m;
@@ -1026,13 +1023,7 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
       st[k] = ok ? v : 0u;
     }
     WH_PROF_SUB (P, M, 3);       /* detail: neighbour loads issued */
-    tr.y = G.cold_y[lane]; tr.c = lane < 32 ? G.cold_c[lane] : 0u;
-    wh_tile_commit (M, lane, &tr);
-    // the reference picture's state of this MB (an I picture's has no motion / SAD).  Its padding word (WhMbState::pad1, word
-    // 35) carries the layer's pSadCost[0] of this MB instead -- written by the SAME lane: two lanes storing to one LDS word in
-    // one instruction have no defined winner on the GPU
-    if (lane < 36) S.nb[144 + lane] = (HOSTIN && lane == 35 && J.sad_cost0) ? G.cold_co[38] : J.ref_mbs ? G.cold_co[lane] : 0u;
-    else if (lane < 38) * (uint32_t*)&S.co_mv[lane - 36][0] = G.cold_co[lane];
+    wh_tile_commit_nb (M, lane, &tr);      // (the source samples and the reference picture's state of this MB are in place already: wh_inter_cold_fetch)
 #pragma unroll
     for (int k = 0; k < 3; ++k) { const int i = lane + 64 * k; if (i < 144) S.nb[i] = st[k]; }
   }
@@ -1326,7 +1317,7 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
         if (md_using_sad) cost_luma = sad_l;
         else WV_SATD_ROWS (cost_luma, lane, true, wh_enc4 (S, wh_tl_col (lane, 16), wh_tl_row (lane, 16)), * (const uint32_t*)&M.pred_y[wh_tl_row (lane, 16) * 16 + wh_tl_col (lane, 16)]);
         // pSadCost[0] is only refreshed when bMdUsingSad; otherwise the SMB entry keeps the previous frame's value
-        sad_cost0 = md_using_sad ? sad_l : ((HOSTIN && J.sad_cost0) ? (int)S.nb[144 + 35] : Co->sad_cost[0]);
+        sad_cost0 = md_using_sad ? sad_l : ((HOSTIN && J.sad_cost0) ? (int)S.sad_cost0_in : Co->sad_cost[0]);
         cost_skip_mb = sad_mb;
         p16x = skx; p16y = sky;
       }
@@ -1399,8 +1390,6 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
       WV_LANES_END
     }
   };
-  // (ONE call site of `early` below: the scheduler's callback is large -- inlined once it costs nothing, called from two places it
-  // becomes a function whose captured state lives in scratch memory)
   const bool searched = !done;      // the macroblock goes through the partition searches, the refinement and residual coding
   if (done && !intra) publish_guess (mb_type == WH_MB_PSKIP ? wh_pk_mv (skx, sky) : wh_pk_mv (p16x, p16y));     // skip / background / static block
 
@@ -1565,10 +1554,7 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
     WH_PROF_MARK (P, M, 5);   // fractional refinement + chroma MC
     publish_guess (wh_pk_mv (p16x, p16y));
   }
-  // the prediction is final: nothing below reads a window or the staging area
-  X.spec = W;
-  early.call();
-  WH_PROF_MARK (P, M, 11);   // (the claim + fetch issue of the next macroblock, when the scheduler does it here)
+  // (the prediction is final: nothing below reads a window or the staging area)
   if (searched) {
     // ---- encode (WelsMdInterEncode) ----
     wh_dct_luma16 (M);
@@ -1685,15 +1671,6 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
     }
   }
   WH_PROF_MARK (P, M, 7);   // store
-}
-template <bool SCC, class Early>
-WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, WhInterCtx& X, Early& early) {
-  wh_inter_mb_body_t<SCC, 0, Early> (S, G, P, J, mbx, mby, X, early);
-}
-template <bool SCC>
-WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, WhInterCtx& X) {
-  WhNoEarly e;
-  wh_inter_mb_body_t<SCC, 0, WhNoEarly> (S, G, P, J, mbx, mby, X, e);
 }
 WH_FN void wh_inter_mb_body (WhInterLds& S, WhInterStage& G, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, WhInterCtx& X) {
   wh_inter_mb_body_t<false> (S, G, P, J, mbx, mby, X);

@@ -96,15 +96,8 @@ WH_FN void wh_tile_fetch (int lane, const WhSeqParams& P, const WhPicJob& J, int
   wh_tile_fetch_src (lane, P, J, mbx, mby, r);
   wh_tile_fetch_nb (lane, P, J, mbx, mby, r);
 }
-WH_FN void wh_tile_commit (WhMbLds& S, int lane, const WhTileRegs* r) {
-  {
-    const int row = lane >> 2, seg = lane & 3;
-    * (uint32_t*)&S.enc_y[row * 16 + seg * 4] = r->y;
-  }
-  if (lane < 32) {
-    const int pl = lane >> 4, row = (lane >> 1) & 7, half = lane & 1;
-    * (uint32_t*)&S.enc_c[pl * 64 + row * 8 + half * 4] = r->c;
-  }
+// the neighbour samples only (the P kernel's source samples arrive by LDS-DMA: inter_mb.h wh_inter_cold_fetch)
+WH_FN void wh_tile_commit_nb (WhMbLds& S, int lane, const WhTileRegs* r) {
   if (lane < 7) {
     * (uint32_t*)&S.rec_y[0 * 32 + lane * 4 - 4 + 8] = r->nb;
   } else if (lane >= 16 && lane < 32) {
@@ -116,6 +109,17 @@ WH_FN void wh_tile_commit (WhMbLds& S, int lane, const WhTileRegs* r) {
     const int pl = (lane - 48) >> 3, y = lane & 7;
     WH_RC (S, pl, -1, y) = (uint8_t)r->nb;
   }
+}
+WH_FN void wh_tile_commit (WhMbLds& S, int lane, const WhTileRegs* r) {
+  {
+    const int row = lane >> 2, seg = lane & 3;
+    * (uint32_t*)&S.enc_y[row * 16 + seg * 4] = r->y;           // (= enc_y[4 * lane]: the source blocks are stored in lane order)
+  }
+  if (lane < 32) {
+    const int pl = lane >> 4, row = (lane >> 1) & 7, half = lane & 1;
+    * (uint32_t*)&S.enc_c[pl * 64 + row * 8 + half * 4] = r->c;
+  }
+  wh_tile_commit_nb (S, lane, r);
 }
 WH_FN void wh_load_mb_tile (WhMbLds& S, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby) {
   WV_LANES_BEGIN (lane)

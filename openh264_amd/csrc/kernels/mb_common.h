@@ -22,12 +22,11 @@ typedef struct WhMbLds {
   uint8_t  pred_c[128];       // Cb then Cr, stride 8
   uint8_t  pred4[9 * 16];     // candidate 4x4 predictions, [mode][y*4+x]
   int16_t  res[384];          // residual coefficients: luma blk*16 (luma4x4BlkIdx order), Cb 256.., Cr 320..
-  int16_t  tmp[320];          // transform scratch: [0,256) coefficients
+  int16_t  tmp[256];          // transform scratch: 16 blocks of coefficients
   int32_t  part[64];          // reduction partials
-  int32_t  part2[64];
+  int32_t  part2[16];         // per-block words of wh_quant_blocks; 64 bytes of table (Intra4x4 edge filters, neighbour counts)
   int16_t  dc[16];
   int16_t  cdc[8];
-  int16_t  amax[16];
   int8_t   i4m[25];           // neighbour Intra4x4PredMode cache: [(by+1)*5 + bx+1]
   uint8_t  nzc[24];
   alignas (8) int16_t lv_luma[256];   // zig-zag levels per luma4x4BlkIdx (copied out as 8-byte words)

@@ -123,7 +123,9 @@ class EmuBackend : public Backend {
           }
           if (jobs[j].mb_end > 0 && (xy < jobs[j].mb_begin || xy >= jobs[j].mb_end)) continue;      // GOM-synchronous coding: only this range
           const int mbx = xy % P.mb_w, mby = xy / P.mb_w;
-          for (int lane = 0; lane < 64; ++lane) { if (plain) wh_inter_cold_fetch<1> (G, lane, P, jobs[j], mbx, mby); else if (no_ctrl) wh_inter_cold_fetch<3> (G, lane, P, jobs[j], mbx, mby); else wh_inter_cold_fetch (G, lane, P, jobs[j], mbx, mby); }
+          // the device scheduler copies a macroblock's cold inputs straight into the wave's tile while it waits for the neighbours: the tile holds
+          // nothing else of use by then (poisoned below, after every macroblock)
+          for (int lane = 0; lane < 64; ++lane) { if (plain) wh_inter_cold_fetch<1> (S, G, lane, P, jobs[j], mbx, mby); else if (no_ctrl) wh_inter_cold_fetch<3> (S, G, lane, P, jobs[j], mbx, mby); else wh_inter_cold_fetch (S, G, lane, P, jobs[j], mbx, mby); }
           WhInterCtx X;
           X.slice_idc = jobs[j].dyn_slice ? jobs[j].dyn_slice - 1 : s; X.slice_first = jobs[j].dyn_slice ? jobs[j].dyn_first : first;
           X.win = &WB;
@@ -131,15 +133,11 @@ class EmuBackend : public Backend {
           X.spec_valid = ((t + s + j) % 5) != 0;            // exercise both paths: most macroblocks speculate, every fifth does not
           if (X.spec_valid) wh_win_speculate (P, jobs[j], X.spec, mbx, mby, last_mv);
           X.last_mv = &last_mv;
-          // the device scheduler overwrites the staging area and the windows with the NEXT macroblock's data from the moment the
-          // body calls back: poisoned here, so a read after the call breaks parity
-          struct Early { WhInterStage* g; WhWinLds* wb; int calls; void call() { poison (g, sizeof (*g)); poison (wb, sizeof (*wb)); ++calls; } } early = { &G, &WB, 0 };
-          if (P.flags & WH_SEQ_SCC) wh_inter_mb_body_t<true> (S, G, P, jobs[j], mbx, mby, X, early);
-          else if (plain && WH_PLAIN_KERNEL == 2 && P.complexity == 0) wh_inter_mb_body_t<false, 2> (S, G, P, jobs[j], mbx, mby, X, early);
-          else if (plain) wh_inter_mb_body_t<false, 1> (S, G, P, jobs[j], mbx, mby, X, early);
-          else if (no_ctrl) wh_inter_mb_body_t<false, 3> (S, G, P, jobs[j], mbx, mby, X, early);
-          else wh_inter_mb_body_t<false> (S, G, P, jobs[j], mbx, mby, X, early);
-          if (early.calls != 1) { fprintf (stderr, "emu: the P macroblock body called back %d times at MB %d\n", early.calls, xy); abort(); }
+          if (P.flags & WH_SEQ_SCC) wh_inter_mb_body_t<true> (S, G, P, jobs[j], mbx, mby, X);
+          else if (plain && WH_PLAIN_KERNEL == 2 && P.complexity == 0) wh_inter_mb_body_t<false, 2> (S, G, P, jobs[j], mbx, mby, X);
+          else if (plain) wh_inter_mb_body_t<false, 1> (S, G, P, jobs[j], mbx, mby, X);
+          else if (no_ctrl) wh_inter_mb_body_t<false, 3> (S, G, P, jobs[j], mbx, mby, X);
+          else wh_inter_mb_body_t<false> (S, G, P, jobs[j], mbx, mby, X);
           // WELSHIP_EMU_CORRUPT_MB=<xy> (tests/test_hooks_dynslice.py): one level of that macroblock's record is off by one whenever a RANGED
           // call codes it -- what a lost update between the slice tasks' device calls would look like.  The harness must report it.
           if (jobs[j].mb_end > 0) if (const char* cm = getenv ("WELSHIP_EMU_CORRUPT_MB")) if (atoi (cm) == xy) {

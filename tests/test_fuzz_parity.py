@@ -58,7 +58,7 @@ def test_fuzz_hip(hip_lib, ref_tools):
     _run(["--hip"], ref_tools)
 
 
-# More draws of the same generator: the search windows of a wave are small (kernels/inter_mb.h: 40 rows of luma, 24 of chroma) and follow
+# More draws of the same generator: the search windows of a wave are small (kernels/inter_mb.h: 38 rows of luma, 24 of chroma) and follow
 # the search as it walks (wh_win_need, the diamond's step budget), so the fast-motion and noise classes of other seeds walk other paths
 # through the reloads.  (Rounds 3-4 had a second scheduler here -- runs of macroblocks with sliding windows, k_inter_rows -- which was
 # measured slower at every run length, profiles/r03_run_length_sweep.txt, and was removed in round 5.)
