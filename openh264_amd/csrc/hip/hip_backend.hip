@@ -71,7 +71,7 @@ __device__ __forceinline__ void wh_copy_job (WhPicJob* dst, const WhPicJob* src)
   for (unsigned i = threadIdx.x; i < sizeof (WhPicJob) / 4; i += blockDim.x) ((uint32_t*)dst)[i] = ((const uint32_t*)src)[i];      // (a one-wave workgroup has fewer threads than the descriptor has words)
 }
 
-#define WH_DEFINE_MB_KERNEL(NAME, LDS_T, BODY, MAX_THREADS, WHOLE_PICTURE, PROF)                                             \
+#define WH_DEFINE_MB_KERNEL(NAME, LDS_T, BODY, MAX_THREADS, WHOLE_PICTURE, PROF, GOM)                                             \
 __global__ __launch_bounds__ (MAX_THREADS) void NAME (WhSeqParams P, const WhPicJob* jobs, uint32_t* err) {             \
   extern __shared__ __align__ (16) uint8_t smem[];                                                                      \
   const int nw = (int)blockDim.x >> 6, lane = (int)threadIdx.x & 63;                                                    \
@@ -91,7 +91,7 @@ __global__ __launch_bounds__ (MAX_THREADS) void NAME (WhSeqParams P, const WhPic
   const WhPicJob& J = Jl;                                                                                               \
   /* GOM-level rate control inside the kernel (single-slice pictures): the groups are bands of the picture's OWN order, and a     */ \
   /* group's first macroblock waits for the last one of the group before it, which settles its QP (WhPicJob::scc_order / _prev)   */ \
-  const uint32_t* order = J.gom_rc ? (const uint32_t*)J.scc_order + first : order0;                                     \
+  const uint32_t* order = (GOM && J.gom_rc) ? (const uint32_t*)J.scc_order + first : order0;                                     \
   for (int guard = 0; guard <= n; ++guard) {      /* a wave can never need more than n + 1 tickets */                   \
     int t = 0;                                                                                                          \
     if (lane == 0) t = (int)atomicAdd (&sched[0], 1u);                                                                  \
@@ -107,11 +107,11 @@ __global__ __launch_bounds__ (MAX_THREADS) void NAME (WhSeqParams P, const WhPic
     wh_mb_deps (P.mb_w, xy, first, &dep_a, &dep_b);                                                                     \
     if (!wh_wait_done (sched + 1, dep_a < 0 ? -1 : dep_a - first, err)) break;     /* give up: the host aborts on err */   \
     if (!wh_wait_done (sched + 1, dep_b < 0 ? -1 : dep_b - first, err)) break;                                          \
-    if (J.gom_rc) { const int dep_c = ((const WH_G int32_t*)J.scc_chain_prev)[xy]; if (!wh_wait_done (sched + 1, dep_c < first ? -1 : dep_c - first, err)) break; } \
+    if (GOM && J.gom_rc) { const int dep_c = ((const WH_G int32_t*)J.scc_chain_prev)[xy]; if (!wh_wait_done (sched + 1, dep_c < first ? -1 : dep_c - first, err)) break; } \
     __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "workgroup");                                                             \
     if (PROF) WH_PROF_MARK (P, wh_prof_holder (S), 12);      /* dependency wait */                                       \
     BODY (S, P, J, xy % P.mb_w, xy / P.mb_w);                                                                           \
-    if (J.gom_rc) wh_gom_close_if_last (P, J, xy);           /* rate control: the group's last macroblock settles the next group's QP */ \
+    if (GOM && J.gom_rc) wh_gom_close_if_last (P, J, xy);    /* rate control: the group's last macroblock settles the next group's QP */ \
     if (PROF) WH_PROF_MARK (P, wh_prof_holder (S), 14);      /* the MB itself (sum of the body's own phases) */          \
     __builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");                                                             \
     if (lane == 0) atomicOr (&sched[1 + ((xy - first) >> 5)], 1u << ((xy - first) & 31));                               \
@@ -120,7 +120,8 @@ __global__ __launch_bounds__ (MAX_THREADS) void NAME (WhSeqParams P, const WhPic
   if (WH_PROF_ON && PROF && P.prof && lane < 32) atomicAdd (&P.prof[((blockIdx.x + blockIdx.y * 7u) & 63u) * 32u + lane], (unsigned long long)wh_prof_lds (S)[lane]); \
 }
 
-WH_DEFINE_MB_KERNEL (k_intra_slice, WhMbLds, wh_intra_mb_body, 1024, 0, 1)
+WH_DEFINE_MB_KERNEL (k_intra_slice, WhMbLds, wh_intra_mb_body<false>, 1024, 0, 1, false)
+WH_DEFINE_MB_KERNEL (k_intra_slice_gom, WhMbLds, wh_intra_mb_body<true>, 1024, 0, 1, true)      /* WH_SEQ_CHAIN launches: GOM-level rate control inside the kernel */
 
 // ---- P pictures: a pool of wavefronts shared by several slices ------------------------------------------------------
 // A workgroup owns up to WH_MD_MAX_SLOTS slices (of any pictures of the batch) and as many wavefronts as fit one CU.  A
@@ -750,7 +751,8 @@ class HipBackend : public wh::Backend {
   void run_intra (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
     static const int forced = getenv ("WELSHIP_I_WAVES") ? atoi (getenv ("WELSHIP_I_WAVES")) : 0;
     const int waves = forced > 0 ? std::min (forced, 16) : (P.num_slices * n >= 2 * cus_ ? 12 : 16);
-    mb_pass (k_intra_slice, sizeof (WhMbLds), waves, false, P, jobs, n, sizeof (WhPicJob));
+    if (P.flags & WH_SEQ_CHAIN) mb_pass (k_intra_slice_gom, sizeof (WhMbLds), waves, false, P, jobs, n, sizeof (WhPicJob));
+    else mb_pass (k_intra_slice, sizeof (WhMbLds), waves, false, P, jobs, n, sizeof (WhPicJob));
   }
   // P pictures: one workgroup per CU-load of slices.  Few slices (latency regime): one slice per workgroup, 12 waves.  Enough
   // slices to fill the chip twice: groups of 2..4 slices share a 12-wave workgroup (k_inter_pool), dealt out by k_md_assign.

@@ -127,7 +127,10 @@ WH_FN void wh_qp_chain_slice (const WhSeqParams& P, const WhPicJob& J, int first
   }
 }
 
-// One intra macroblock (I slice).
+// One intra macroblock (I slice).  GOM: the picture may be coded with GOM-level rate control inside the kernel (WH_SEQ_CHAIN launches); a
+// compile-time switch because the all-IDR kernel is register-bound and the rate-control path cost it 40 % when it was a run-time test
+// (IDR step of 512 720p pictures 17.4 -> 24.4 ms, profiles/r05_intra_kernel_gom_split_ab.txt).
+template <bool GOM = true>
 WH_FN void wh_intra_mb_body (WhMbLds& S, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby) {
   const int xy = mby * P.mb_w + mbx;
   // (size-limited slices: the launch codes ONE slice, which begins at dyn_first -- WhPicJob::dyn_slice)
@@ -135,7 +138,7 @@ WH_FN void wh_intra_mb_body (WhMbLds& S, const WhSeqParams& P, const WhPicJob& J
   const WhMbCtl ctl = wh_mb_ctl (J, xy);
   // GOM-level rate control inside the kernel (I pictures too since round 5): the QP of this macroblock's group, settled by the last macroblock
   // of the group before it (wh_gom_close_if_last, inter_mb.h), which the scheduler has waited for (WhPicJob::scc_chain_prev)
-  const int qp = J.gom_rc ? wh_clip3 ((int)wh_ld_wg32 ((const WH_G uint32_t*)& ((const WH_G WhGomRc*)J.gom_rc)->calc_qp), 0, 51) : wh_mb_qp (J, ctl);
+  const int qp = (GOM && J.gom_rc) ? wh_clip3 ((int)wh_ld_wg32 ((const WH_G uint32_t*)& ((const WH_G WhGomRc*)J.gom_rc)->calc_qp), 0, 51) : wh_mb_qp (J, ctl);
   const int qpc = kWhChromaQp[wh_clip3 (qp + P.chroma_qp_offset, 0, 51)];
   WH_PROF_DECL (P);
   wh_load_mb_tile (S, P, J, mbx, mby);

@@ -47,11 +47,13 @@ class EmuBackend : public Backend {
   void run_intra (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
     bool any_gom = false;
     for (int j = 0; j < n; ++j) any_gom = any_gom || jobs[j].gom_rc != nullptr;
+    // the device picks its kernel variant by the launch's flag (hip_backend.hip run_intra: k_intra_slice_gom for WH_SEQ_CHAIN): the flag must say what the jobs hold
+    if (any_gom && !(P.flags & WH_SEQ_CHAIN)) { fprintf (stderr, "emu: an I picture with GOM-level rate control in a launch without WH_SEQ_CHAIN\n"); abort(); }
     if (!any_gom) {
       for_order (P, n, false, [&] (int j, int x, int y) {
         const int xy = y * P.mb_w + x;
         if (jobs[j].mb_end > 0 && (xy < jobs[j].mb_begin || xy >= jobs[j].mb_end)) return;      // GOM-synchronous coding: only this range
-        WhMbLds S; poison (&S, sizeof (S)); wh_intra_mb_body (S, P, jobs[j], x, y); });
+        WhMbLds S; poison (&S, sizeof (S)); wh_intra_mb_body<false> (S, P, jobs[j], x, y); });
       return;
     }
     // GOM-level rate control inside the kernel: the picture's own order (groups as bands), checked against everything the device scheduler waits for
@@ -68,7 +70,7 @@ class EmuBackend : public Backend {
         if ((da >= 0 && !done_mb[da]) || (db >= 0 && !done_mb[db]) || (dc >= 0 && !done_mb[dc]) || dc >= xy) { fprintf (stderr, "emu: the I picture's order is not topological at MB %d (deps %d %d %d)\n", xy, da, db, dc); abort(); }
         done_mb[xy] = 1;
         WhMbLds S; poison (&S, sizeof (S));
-        wh_intra_mb_body (S, P, J, xy % P.mb_w, xy / P.mb_w);
+        wh_intra_mb_body<true> (S, P, J, xy % P.mb_w, xy / P.mb_w);
         wh_gom_close_if_last (P, J, xy);
       }
     }

@@ -2,6 +2,14 @@
 usage: phase_profile.py [sessions] [synthetic|res] [intra]   (res: the reference's 1080p clip from oracle/_ref/res, as in bench.py; intra: the IDR step)"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+# the cycle accumulators are only compiled into the profiling build (-DWH_PROF, kernels/wave.h): openh264_amd/libwelship_prof.so, built here
+# (`python -c "from openh264_amd import build as B; B.build_hip(defines=('WH_PROF',), tag='prof')"`) so that it travels to the GPU box
+if "WELSHIP_LIB" not in os.environ:
+    _prof = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "openh264_amd", "libwelship_prof.so")
+    if not os.path.exists(_prof):
+        from openh264_amd import build as _B
+        _B.build_hip(defines=("WH_PROF",), tag="prof")
+    os.environ["WELSHIP_LIB"] = _prof
 import openh264_amd as oh
 from openh264_amd.utils.synth import synth_sequence
 w, h, S = 1920, 1080, int(sys.argv[1]) if len(sys.argv) > 1 else 16
