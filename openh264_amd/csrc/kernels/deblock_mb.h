@@ -83,13 +83,15 @@ WH_FN void wh_db_chroma_line (uint8_t* q, int step, int bs, int alpha, int beta,
 // bS < 4 filter is select-only; the bS 4 arithmetic is skipped for the whole edge unless some line needs it (`any4`,
 // wave-uniform -- only intra MBs have bS 4).  Bit-exact with wh_db_luma_line / wh_db_chroma_line
 // (tests/test_frame_parity.py::test_emu_deblock_per_edge).
-WH_FN void wh_db_luma_px (int bs, int alpha, int beta, int tc3, bool any4, int p3, int& p2, int& p1, int& p0, int& q0, int& q1, int& q2, int q3) {
+// `chroma`: the line is a chroma line -- the same filter with the p1 / q1 updates and the strong variant switched off and tc = tc0 + 1
+// (DeblockChromaLt4_c / DeblockChromaEq4_c are exactly that subset), so luma and chroma lines share one instruction stream
+WH_FN void wh_db_line_px (bool chroma, int bs, int alpha, int beta, int tc3, bool any4, int p3, int& p2, int& p1, int& p0, int& q0, int& q1, int& q2, int q3) {
   const int d = wh_abs (p0 - q0);
   const bool on = bs != 0 && d < alpha && wh_abs (p1 - p0) < beta && wh_abs (q1 - q0) < beta;
-  const bool ap = wh_abs (p2 - p0) < beta, aq = wh_abs (q2 - q0) < beta;
+  const bool ap = !chroma && wh_abs (p2 - p0) < beta, aq = !chroma && wh_abs (q2 - q0) < beta;
   const int bsn = bs < 1 ? 1 : bs > 3 ? 3 : bs;
   const int tc0 = (tc3 >> ((bsn - 1) * 8)) & 255;
-  const int tc = tc0 + (ap ? 1 : 0) + (aq ? 1 : 0);
+  const int tc = tc0 + (chroma ? 1 : (ap ? 1 : 0) + (aq ? 1 : 0));
   const int avg = (p0 + q0 + 1) >> 1;
   int rp2 = p2, rq2 = q2;
   int rp1 = ap ? p1 + wh_clip3 ((p2 + avg - (p1 * 2)) >> 1, -tc0, tc0) : p1;
@@ -97,7 +99,7 @@ WH_FN void wh_db_luma_px (int bs, int alpha, int beta, int tc3, bool any4, int p
   const int delta = wh_clip3 ((((q0 - p0) * 4) + (p1 - q1) + 4) >> 3, -tc, tc);
   int rp0 = wh_clip255 (p0 + delta), rq0 = wh_clip255 (q0 - delta);
   if (any4) {
-    const bool s4 = bs == 4, strong = d < ((alpha >> 2) + 2);
+    const bool s4 = bs == 4, strong = !chroma && d < ((alpha >> 2) + 2);
     const int wp0 = (2 * p1 + p0 + q1 + 2) >> 2, wq0 = (2 * q1 + q0 + p1 + 2) >> 2;
     const bool sp = strong && ap, sq = strong && aq;
     const int s_p0 = sp ? (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3 : wp0;
@@ -111,14 +113,14 @@ WH_FN void wh_db_luma_px (int bs, int alpha, int beta, int tc3, bool any4, int p
   }
   if (on) { p2 = rp2; p1 = rp1; p0 = rp0; q0 = rq0; q1 = rq1; q2 = rq2; }
 }
+
+// (the two filters by their old names: hip/leaf.hip's per-edge slots)
+WH_FN void wh_db_luma_px (int bs, int alpha, int beta, int tc3, bool any4, int p3, int& p2, int& p1, int& p0, int& q0, int& q1, int& q2, int q3) {
+  wh_db_line_px (false, bs, alpha, beta, tc3, any4, p3, p2, p1, p0, q0, q1, q2, q3);
+}
 WH_FN void wh_db_chroma_px (int bs, int alpha, int beta, int tc3, int p1, int& p0, int& q0, int q1) {
-  const bool on = bs != 0 && wh_abs (p0 - q0) < alpha && wh_abs (p1 - p0) < beta && wh_abs (q1 - q0) < beta;
-  const int bsn = bs < 1 ? 1 : bs > 3 ? 3 : bs;
-  const int tc = ((tc3 >> ((bsn - 1) * 8)) & 255) + 1;
-  const int delta = wh_clip3 ((((q0 - p0) * 4) + (p1 - q1) + 4) >> 3, -tc, tc);
-  const int np0 = bs < 4 ? wh_clip255 (p0 + delta) : (2 * p1 + p0 + q1 + 2) >> 2;
-  const int nq0 = bs < 4 ? wh_clip255 (q0 - delta) : (2 * q1 + q0 + p1 + 2) >> 2;
-  if (on) { p0 = np0; q0 = nq0; }
+  int p2 = 0, q2 = 0, a = p1, b = q1;
+  wh_db_line_px (true, bs, alpha, beta, tc3, bs == 4, 0, p2, a, p0, q0, b, q2, 0);
 }
 
 WH_FN bool wh_mv_far (const int16_t* a, const int16_t* b) {
@@ -297,57 +299,52 @@ WH_FN bool wh_deblock_mb_body (WhDbLds& S, WhDbStage& G, const WhDbXchg& E, int 
     const uint32_t bsw0 = outer_ok ? * (const uint32_t*)&S.bs[dir][0][0] : 0u, bsw1 = * (const uint32_t*)&S.bs[dir][1][0];
     const uint32_t bsw2 = * (const uint32_t*)&S.bs[dir][2][0], bsw3 = * (const uint32_t*)&S.bs[dir][3][0];
     if ((bsw0 | bsw1 | bsw2 | bsw3) == 0) continue;
+    // Lanes 0..15 own a luma line (20 samples: -4 .. 15), lanes 16..31 a chroma line of one plane (its samples -2 .. 7 sit at indices
+    // 2 .. 11, so that its two edges fall on the slots of the first two luma edges: between [3] | [4] and [7] | [8]).  One instruction
+    // stream for both (round 5; the chroma lines used to be a second branch of their own: a third of the pass's vector instructions).
+    // A chroma lane reads a few bytes around its line that are not its own (inside the wave's tile) and never writes them back.
+    const bool act_l0 = bsw0 != 0 && (alpha0 | beta0) != 0, act_l1 = bsw1 != 0 && (alpha1 | beta1) != 0, act_l2 = bsw2 != 0 && (alpha1 | beta1) != 0, act_l3 = bsw3 != 0 && (alpha1 | beta1) != 0;
+    const bool act_c0 = bsw0 != 0 && (alphac0 | betac0) != 0, act_c1 = bsw2 != 0 && (alphac1 | betac1) != 0;
     WV_LANES_BEGIN (lane)
-    if (lane < 16) {
+    if (lane < 32) {
+      const bool ch = lane >= 16;
+      const int pl = (lane - 16) >> 3, k = lane & 7;
+      uint8_t* const Sb = (uint8_t*)&S;
+      const int ybase = (int) ((uint8_t*)&S.y[0] - Sb), cbase = (int) ((uint8_t*)&S.c[0][0] - Sb) + pl * 120;
       int px[20];
       if (dir == 0) {
-        const uint32_t* wr = (const uint32_t*)&S.y[(lane + 4) * 24];
+        const uint32_t* wr = (const uint32_t*) (Sb + (ch ? cbase + (k + 2) * 12 : ybase + (lane + 4) * 24));
 #pragma unroll
-        for (int k = 0; k < 5; ++k) { const uint32_t v = wr[k]; px[4 * k] = (int) (v & 255u); px[4 * k + 1] = (int) ((v >> 8) & 255u); px[4 * k + 2] = (int) ((v >> 16) & 255u); px[4 * k + 3] = (int) (v >> 24); }
+        for (int j = 0; j < 5; ++j) { const uint32_t v = wr[j]; px[4 * j] = (int) (v & 255u); px[4 * j + 1] = (int) ((v >> 8) & 255u); px[4 * j + 2] = (int) ((v >> 16) & 255u); px[4 * j + 3] = (int) (v >> 24); }
       } else {
+        const uint8_t* col = Sb + (ch ? cbase + k + 4 - 2 * 12 : ybase + lane + 4);
+        const int st = ch ? 12 : 24;
 #pragma unroll
-        for (int r = 0; r < 20; ++r) px[r] = S.y[r * 24 + lane + 4];
+        for (int r = 0; r < 20; ++r) px[r] = col[r * st];
       }
-      const int sh = 8 * (lane >> 2);
+      const int sh = ch ? 8 * (k >> 1) : 8 * (lane >> 2);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const uint32_t bsw = e == 0 ? bsw0 : e == 1 ? bsw1 : e == 2 ? bsw2 : bsw3;
-        const int al = e == 0 ? alpha0 : alpha1, be = e == 0 ? beta0 : beta1, tc = e == 0 ? tc30 : tc31;
-        if (bsw != 0 && (al | be) != 0)
-          wh_db_luma_px ((int) ((bsw >> sh) & 255u), al, be, tc, (bsw & 0x04040404u) != 0, px[4 * e], px[4 * e + 1], px[4 * e + 2], px[4 * e + 3],
-                         px[4 * e + 4], px[4 * e + 5], px[4 * e + 6], px[4 * e + 7]);
+        const uint32_t bl = e == 0 ? bsw0 : e == 1 ? bsw1 : e == 2 ? bsw2 : bsw3;
+        const bool al_on = e == 0 ? act_l0 : e == 1 ? act_l1 : e == 2 ? act_l2 : act_l3;
+        const bool ac_on = e == 0 ? act_c0 : e == 1 ? act_c1 : false;
+        if (!(al_on || ac_on)) continue;
+        const uint32_t bc = e == 0 ? bsw0 : bsw2;                     // the chroma line's second edge is the macroblock's edge 2
+        const uint32_t bw = ch ? (ac_on ? bc : 0u) : (al_on ? bl : 0u);
+        const int al = ch ? (e == 0 ? alphac0 : alphac1) : (e == 0 ? alpha0 : alpha1), be = ch ? (e == 0 ? betac0 : betac1) : (e == 0 ? beta0 : beta1);
+        const int tc = ch ? (e == 0 ? tc3c0 : tc3c1) : (e == 0 ? tc30 : tc31);
+        const bool any4 = (((al_on ? bl : 0u) | (ac_on ? bc : 0u)) & 0x04040404u) != 0;
+        wh_db_line_px (ch, (int) ((bw >> sh) & 255u), al, be, tc, any4, px[4 * e], px[4 * e + 1], px[4 * e + 2], px[4 * e + 3], px[4 * e + 4], px[4 * e + 5], px[4 * e + 6], px[4 * e + 7]);
       }
       if (dir == 0) {
-        uint32_t* ww = (uint32_t*)&S.y[(lane + 4) * 24];
+        uint32_t* ww = (uint32_t*) (Sb + (ch ? cbase + (k + 2) * 12 : ybase + (lane + 4) * 24));
 #pragma unroll
-        for (int k = 0; k < 5; ++k) ww[k] = (uint32_t)px[4 * k] | ((uint32_t)px[4 * k + 1] << 8) | ((uint32_t)px[4 * k + 2] << 16) | ((uint32_t)px[4 * k + 3] << 24);
+        for (int j = 0; j < 5; ++j) if (j < 3 || !ch) ww[j] = (uint32_t)px[4 * j] | ((uint32_t)px[4 * j + 1] << 8) | ((uint32_t)px[4 * j + 2] << 16) | ((uint32_t)px[4 * j + 3] << 24);
       } else {
+        uint8_t* col = Sb + (ch ? cbase + k + 4 - 2 * 12 : ybase + lane + 4);
+        const int st = ch ? 12 : 24;
 #pragma unroll
-        for (int r = 1; r < 19; ++r) S.y[r * 24 + lane + 4] = (uint8_t)px[r];
-      }
-    } else if (lane < 32) {
-      const int pl = (lane - 16) >> 3, k = lane & 7;
-      int c[12];
-      if (dir == 0) {
-        const uint32_t* wr = (const uint32_t*)&S.c[pl][(k + 2) * 12];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) { const uint32_t v = wr[j]; c[4 * j] = (int) (v & 255u); c[4 * j + 1] = (int) ((v >> 8) & 255u); c[4 * j + 2] = (int) ((v >> 16) & 255u); c[4 * j + 3] = (int) (v >> 24); }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 10; ++r) c[r + 2] = S.c[pl][r * 12 + k + 4];       // rows -2..7 at c[2..11]: the same indices as the columns -2..7 of a row
-        c[0] = 0; c[1] = 0;
-      }
-      // edge 0 between c[3] and c[4], edge 2 between c[7] and c[8]
-      const int sh = 8 * (k >> 1);
-      if (bsw0 != 0 && (alphac0 | betac0) != 0) wh_db_chroma_px ((int) ((bsw0 >> sh) & 255u), alphac0, betac0, tc3c0, c[2], c[3], c[4], c[5]);
-      if (bsw2 != 0 && (alphac1 | betac1) != 0) wh_db_chroma_px ((int) ((bsw2 >> sh) & 255u), alphac1, betac1, tc3c1, c[6], c[7], c[8], c[9]);
-      if (dir == 0) {
-        uint32_t* ww = (uint32_t*)&S.c[pl][(k + 2) * 12];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) ww[j] = (uint32_t)c[4 * j] | ((uint32_t)c[4 * j + 1] << 8) | ((uint32_t)c[4 * j + 2] << 16) | ((uint32_t)c[4 * j + 3] << 24);
-      } else {
-        S.c[pl][1 * 12 + k + 4] = (uint8_t)c[3]; S.c[pl][2 * 12 + k + 4] = (uint8_t)c[4];
-        S.c[pl][5 * 12 + k + 4] = (uint8_t)c[7]; S.c[pl][6 * 12 + k + 4] = (uint8_t)c[8];
+        for (int r = 1; r < 19; ++r) if (!ch || (r >= 3 && r <= 8)) col[r * st] = (uint8_t)px[r];      // (chroma: rows -1 .. 4 hold everything its two edges can change)
       }
     }
     WV_LANES_END
