@@ -918,9 +918,10 @@ WH_FN int wh_enc_inter_y (WhMbLds& S, int qp) {
 // quant-to-zero tests of the P_Skip path (WelsTryPYskip / WelsTryPUVskip); operate on copies in S.tmp
 WH_FN bool wh_try_py_skip (WhMbLds& S, int qp) {
   wh_quant_blocks (S, 0, 16, qp, qp, S.tmp, 0);
-  int big, ctr;
-  WV_SUM2 (big, ctr, lane, (lane < 16 ? WH_Q_BIG (S.part2[lane]) : 0), (lane < 16 ? WH_Q_SCORE (S.part2[lane]) : 0));      // (the score only counts when no block is big)
-  return big == 0 && ctr < 6;
+  int bc, u1, u2, u3;                  // sixteen lanes: one DPP row.  Score sum (<= 16 x 9) | number of big blocks << 16
+  WV_ROWSUM4 (bc, u1, u2, u3, lane, (lane < 16 ? WH_Q_SCORE (S.part2[lane]) | (WH_Q_BIG (S.part2[lane]) << 16) : 0));      // (the score only counts when no block is big)
+  (void)u1; (void)u2; (void)u3;
+  return bc < 6;
 }
 // both chroma planes at once (the reference tests Cb, then Cr: both must pass)
 WH_FN bool wh_try_puv_skip (WhMbLds& S, int qpc) {

@@ -296,15 +296,22 @@ WH_FN void wh_i16_costs (WhMbLds& S, int avail, int use_satd, int lambda, WhI16C
 
   // ---------------- I16x16 mode decision ----------------
   int sum_t = 0, sum_l = 0, pl_a = 0, pl_b = 0, pl_c = 0;
-  if (has_t) WV_SUM (sum_t, lane, (lane < 16 ? WH_RY (S, lane, -1) : 0));
-  if (has_l) WV_SUM (sum_l, lane, (lane < 16 ? WH_RY (S, -1, lane) : 0));
-  if (av3 == 7) {
+  {
+    // the four sums of the neighbour samples side by side, one per DPP row (one pass instead of four wave sums): row 0 the top
+    // samples, row 1 the left ones, rows 2 / 3 the eight terms of the plane predictor's H / V
     int h, v;
-    WV_SUM (h, lane, (lane < 8 ? (lane + 1) * (WH_RY (S, 8 + lane, -1) - WH_RY (S, 6 - lane, -1)) : 0));
-    WV_SUM (v, lane, (lane < 8 ? (lane + 1) * (WH_RY (S, -1, 8 + lane) - WH_RY (S, -1, 6 - lane)) : 0));
-    pl_a = (WH_RY (S, -1, 15) + WH_RY (S, 15, -1)) << 4;
-    pl_b = (5 * h + 32) >> 6;
-    pl_c = (5 * v + 32) >> 6;
+    const bool plane = av3 == 7;
+    WV_ROWSUM4 (sum_t, sum_l, h, v, lane, ([&] () {
+      const int r = lane >> 4, k = lane & 15, k7 = k & 7;
+      if (r == 0) return has_t ? (int)WH_RY (S, k, -1) : 0;
+      if (r == 1) return has_l ? (int)WH_RY (S, -1, k) : 0;
+      if (!plane || k >= 8) return 0;
+      return r == 2 ? (k7 + 1) * ((int)WH_RY (S, 8 + k7, -1) - (int)WH_RY (S, 6 - k7, -1)) : (k7 + 1) * ((int)WH_RY (S, -1, 8 + k7) - (int)WH_RY (S, -1, 6 - k7)); }) ());
+    if (plane) {
+      pl_a = (WH_RY (S, -1, 15) + WH_RY (S, 15, -1)) << 4;
+      pl_b = (5 * h + 32) >> 6;
+      pl_c = (5 * v + 32) >> 6;
+    }
   }
   // candidate modes in the reference's order (scalars, not an array: nothing here is indexed at run time)
   int m0, m1, m2, m3, ncand;

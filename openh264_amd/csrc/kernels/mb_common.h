@@ -491,11 +491,10 @@ WH_FN int wh_encrec_chroma (WhMbLds& S, int qpc, int is_intra) {
   wh_quant_blocks (S, 256, 8, qpc, ffrow, &S.res[256], 1);
   // keep a plane's AC when its JVT-O079 score reaches 7 (inter; the reference stops adding at 7, which cannot change
   // the test) -- intra keeps every plane that has a non-zero level
-  int sc0, sc1, nzdc0, nzdc1;
+  int sc0, sc1, nzdc0, nzdc1;          // (four quad sums in one pass: lanes 0..7 the blocks' scores per plane, lanes 8..15 the planes' DC levels)
 #define WH_CSCORE(l) (is_intra ? (WH_Q_ANY (S.part2[l]) ? 7 : 0) : WH_Q_SCORE (S.part2[l]))
-  WV_SUM2 (sc0, sc1, lane, (lane < 4 ? WH_CSCORE (lane) : 0), (lane >= 4 && lane < 8 ? WH_CSCORE (lane) : 0));
+  WV_QUADSUM4 (sc0, sc1, nzdc0, nzdc1, lane, (lane < 8 ? WH_CSCORE (lane & 7) : lane < 16 ? (int) (S.cdc[lane & 7] != 0) : 0));
 #undef WH_CSCORE
-  WV_SUM2 (nzdc0, nzdc1, lane, (lane < 4 ? (S.cdc[lane] != 0) : 0), (lane >= 4 && lane < 8 ? (S.cdc[lane] != 0) : 0));
   const int keep0 = sc0 >= 7, keep1 = sc1 >= 7;
   WV_LANES_BEGIN (lane)
   {

@@ -52,6 +52,11 @@
 #define WV_QUADSUM4(d0, d1, d2, d3, lane, expr)                   \
   do { int _q[4] = {0, 0, 0, 0}; for (int lane = 0; lane < 16; ++lane) _q[lane >> 2] += (int)(expr); \
        (d0) = _q[0]; (d1) = _q[1]; (d2) = _q[2]; (d3) = _q[3]; } while (0)
+// four sums at once, one per DPP row: d_i = sum of expr over lanes 16 i .. 16 i + 15 -- several small reductions of a phase placed side by
+// side on the lanes cost one pass over the DPP network (four steps + four reads) instead of one full wave sum each
+#define WV_ROWSUM4(d0, d1, d2, d3, lane, expr)                    \
+  do { int _q[4] = {0, 0, 0, 0}; for (int lane = 0; lane < 64; ++lane) _q[lane >> 4] += (int)(expr); \
+       (d0) = _q[0]; (d1) = _q[1]; (d2) = _q[2]; (d3) = _q[3]; } while (0)
 // SATD over 4x4 blocks held one per lane quad: lane 4q+r supplies row r of block q as four packed source bytes
 // (enc4) and four packed prediction bytes (pred4); `active` must be uniform per quad.
 // dst = sum over active blocks of (sum|Hadamard4x4(enc - pred)| + 1) >> 1   (sample.cpp:47-96 WelsSampleSatd4x4_c)
@@ -186,6 +191,10 @@ WH_FN int wh_wave_min_i32 (int v) {
   do { const int lane = wh_lane_id(); int _v = (int)(expr);       \
        _v += WH_DPP (_v, 0xB1); _v += WH_DPP (_v, 0x4E);          \
        (d0) = __builtin_amdgcn_readlane (_v, 0); (d1) = __builtin_amdgcn_readlane (_v, 4); (d2) = __builtin_amdgcn_readlane (_v, 8); (d3) = __builtin_amdgcn_readlane (_v, 12); } while (0)
+#define WV_ROWSUM4(d0, d1, d2, d3, lane, expr)                    \
+  do { const int lane = wh_lane_id(); int _v = (int)(expr);       \
+       _v += WH_DPP (_v, 0xB1); _v += WH_DPP (_v, 0x4E); _v += WH_DPP (_v, 0x141); _v += WH_DPP (_v, 0x140); \
+       (d0) = __builtin_amdgcn_readlane (_v, 0); (d1) = __builtin_amdgcn_readlane (_v, 16); (d2) = __builtin_amdgcn_readlane (_v, 32); (d3) = __builtin_amdgcn_readlane (_v, 48); } while (0)
 // SATD over lane quads, entirely in registers: horizontal Hadamard inside the lane, vertical butterflies across the
 // quad on DPP quad_perm, then the usual wave sum (see the WH_EMU twin above for the contract).
 WH_FN int wh_satd_rows (int lane, bool active, uint32_t e, uint32_t p) {
