@@ -1698,6 +1698,7 @@ struct WelsHipFrameCtx {
   uint8_t* d_rec_blk = nullptr;       // (SessionCore::d_rec_blk)
   // what the last WelsHipFrameVaa call left on the device for WelsHipFrameBgd: the pair's keys and pool slots, whether the background statistics were computed
   const void* vaa_cur_key = nullptr; const void* vaa_ref_key = nullptr; int vaa_cslot = -1, vaa_rslot = -1, vaa_queue = 0; bool vaa_has_bgd = false;
+  uint64_t vaa_cur_sum = 0, vaa_ref_sum = 0;      // what the two slots held when the statistics were made (SrcSlot::luma_sum): a reused slot fails WelsHipFrameBgd
   int8_t* d_bgd_calc = nullptr;       // WelsHipFrameBgd's result (one flag per macroblock)
   std::vector<int8_t> h_bgd_calc;
   uint8_t* d_skew = nullptr;          // pre-analysis of a picture whose width is no multiple of 16: the two luma planes at the caller's stride (WelsHipFrameVaa)
@@ -2669,6 +2670,7 @@ int WelsHipFrameVaa (WelsHipFrameCtx* c, const WelsHipVaaJob* j) {
   if (be->sync_queue (queue)) { set_err ("device error in the pre-analysis"); return WELSHIP_ERR_UNKNOWN; }
   c->fresh_key = (const void*)j->pCur[0];
   c->vaa_cur_key = (const void*)j->pCur[0]; c->vaa_ref_key = (const void*)j->pRef[0]; c->vaa_cslot = cslot; c->vaa_rslot = rslot; c->vaa_queue = queue; c->vaa_has_bgd = want_sd;
+  c->vaa_cur_sum = c->src_pool[cslot].luma_sum; c->vaa_ref_sum = c->src_pool[rslot].luma_sum;
   }
   // results: the macroblocks the C functions cover, row by row; the frame SAD is their sum
   const uint8_t* h = c->h_vaa_out.data();
@@ -2691,7 +2693,8 @@ int WelsHipFrameBgd (WelsHipFrameCtx* c, const WelsHipBgdJob* j) {
   const int uw = j->iPicWidth >> 4, uh = j->iPicHeight >> 4;
   if ((j->iPicWidth & 15) || uw < 1 || uh < 1 || uw > c->mb_w || uh > c->mb_h || (size_t)uw * uh > 65536) { set_err ("background detection: picture size (width a multiple of 16, at most 65536 units)"); return WELSHIP_ERR_UNSUPPORTED; }
   if (!c->vaa_has_bgd || c->vaa_cur_key == nullptr || c->vaa_cur_key != (const void*)j->pCur[0] || c->vaa_ref_key != (const void*)j->pRef[0] || !c->d_vaa_out ||
-      c->src_find (c->vaa_cur_key) != c->vaa_cslot || c->src_find (c->vaa_ref_key) != c->vaa_rslot) {
+      c->src_find (c->vaa_cur_key) != c->vaa_cslot || c->src_find (c->vaa_ref_key) != c->vaa_rslot ||
+      c->src_pool[c->vaa_cslot].luma_sum != c->vaa_cur_sum || c->src_pool[c->vaa_rslot].luma_sum != c->vaa_ref_sum) {       // (the source ring reuses pointers: the slots' contents must still be this pair's)
     set_err ("background detection: the statistics of this picture pair are not on the device"); return WELSHIP_ERR_UNSUPPORTED;
   }
   wh::Backend* be = c->be;
