@@ -37,13 +37,14 @@
 // registers; a window is re-fetched only when a search start or a prediction block falls outside it.
 
 // test-build statistics of the search windows (WELSHIP_WIN_STATS=1 prints them at exit): 0 P macroblocks, 1 reloads (wh_win_ensure misses),
-// 2 speculative windows adopted, 3 first loads after a refused / missing speculation, 4 reloads in the middle of a diamond walk
+// 2 speculative windows adopted, 3 first loads after a refused / missing speculation, 4 reloads in the middle of a diamond walk,
+// 5 chroma predictions made inside the chroma window, 6 read from the picture
 #if defined(WH_EMU)
 #include <stdio.h>
 static long g_wh_win_stat[8];
 static void wh_win_stat_dump() {
   if (!getenv ("WELSHIP_WIN_STATS")) return;
-  fprintf (stderr, "welship window stat: P macroblocks %ld, reloads %ld, adopted %ld, first loads %ld, mid-walk reloads %ld\n", g_wh_win_stat[0], g_wh_win_stat[1], g_wh_win_stat[2], g_wh_win_stat[3], g_wh_win_stat[4]);
+  fprintf (stderr, "welship window stat: P macroblocks %ld, reloads %ld, adopted %ld, first loads %ld, mid-walk reloads %ld, chroma predictions inside the window %ld / from the picture %ld\n", g_wh_win_stat[0], g_wh_win_stat[1], g_wh_win_stat[2], g_wh_win_stat[3], g_wh_win_stat[4], g_wh_win_stat[5], g_wh_win_stat[6]);
 }
 struct WhWinStatInit { WhWinStatInit() { atexit (wh_win_stat_dump); } };
 static WhWinStatInit g_wh_win_stat_init;
@@ -380,6 +381,7 @@ WH_FN void wh_mc_chroma_to (WhInterLds& S, const WhSeqParams& P, const WhPicJob&
   const int ipx = mbx * 8 + cx + (mvx >> 3), ipy = mby * 8 + cy + (mvy >> 3);
   const int n = cw * ch, sh = cw == 8 ? 3 : 2;
   const bool in_win = ipx >= W.cx0 && ipy >= W.cy0 && ipx + cw + 1 <= W.cx0 + WH_CWIN_COLS && ipy + ch + 1 <= W.cy0 + WH_CWIN_ROWS;
+  if (in_win) WH_STAT_WIN (5); else WH_STAT_WIN (6);
   if (in_win) {
     // A lane makes four adjacent samples of one row of one plane: per source row the 8-sample group its first sample lies in and the
     // first word of the next group (12 bytes of that plane; wh_cwin_off), of which it takes samples s .. s + 3 (A) and s + 1 .. s + 4
