@@ -24,16 +24,17 @@ def _newer(target, deps):
     return False
 
 
-def build_hip(force=False, verbose=True, defines=(), tag=""):
+def build_hip(force=False, verbose=True, defines=(), tag="", flags=()):
     """hipcc --offload-arch=gfx950 (cross-compiles without a GPU).
     `defines` + `tag`: a second library (libwelship_<tag>.so) with candidate code paths switched on, for A/B runs on the
-    device through WELSHIP_LIB / tools/fuzz_parity.py --lib; the product library is always the plain build."""
+    device through WELSHIP_LIB / tools/fuzz_parity.py --lib; the product library is always the plain build.
+    `flags`: further compiler flags of such a candidate (e.g. "-mllvm", "-amdgpu-enable-max-ilp-scheduling-strategy")."""
     out = LIB if not tag else LIB.replace(".so", "_" + tag + ".so")
     deps = [CSRC, os.path.join(ROOT, "include")]
     if not force and not _newer(out, deps):
         return out
     # NB: no v_ashr_pk_u8_i32 may appear in the device code (see wh_clip255 in csrc/kernels/wave.h): tests/test_abi.py checks the listing.
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17"] + ["-D" + d for d in defines] + ["-fPIC", "-shared", "-Wno-unused-function",
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17"] + ["-D" + d for d in defines] + list(flags) + ["-fPIC", "-shared", "-Wno-unused-function",
            "-Wno-unused-variable", "-o", out] + HIP_SRCS + HOST_SRCS
     if verbose:
         print(" ".join(cmd), flush=True)
