@@ -2013,6 +2013,13 @@ FrameKey* frame_find_key (FrameShared* sh, const WhSeqParams& s, bool is_p, bool
   const int kn = (int) (sh->keys.size() % 8);
   k->queue = kn;                                   // the key's own queue only carries the uploads
   for (int i = 0; i < WH_FRAME_LANES; ++i) k->lane[i].queue = 8 + 8 * i + 4 * (kn / 4) + (3 - kn % 4);
+  // The first two keys of a device -- what single-layer sessions have: their I and their P pictures -- get the second launch set on a
+  // hardware queue of its own (stream 16 + (2 - kn % 4) % 4 is served by another one than stream 8 + 3 - kn % 4: profiles/r03_stream_hardware_queues.txt).
+  // A session that misses its batch by a moment is then coded BESIDE the batch instead of behind it, returns a moment after the others and
+  // is back in their batch one picture later; on a shared queue it returned a whole latency chain late, for good (eight 1080p sessions:
+  // 211-470 frames/s from run to run on one queue, 398-444 on two; profiles/r05_frame_api_second_launch_set_queue.txt).  Sessions with
+  // several layers (more keys) keep both launch sets of a key on one queue: their layers' queues would collide (-4 %).
+  if (kn < 2 && sh->keys.size() < 2) k->lane[1].queue = 8 + 8 + (3 - kn % 4 + 3) % 4;
   sh->keys.push_back (std::move (k));
   return sh->keys.back().get();
 }
