@@ -218,6 +218,18 @@ def test_emu_reverse_lane_order(ref_tools, tmp_path):
         run_case(name, lib, ref_tools, tmp_path)
 
 
+def test_emu_tiny_search_windows(ref_tools, tmp_path):
+    """The search windows of a wave follow the search (kernels/inter_mb.h: wh_win_need, the diamond's step budget) and what they hold must
+    never change a result.  A test build with windows that hold little more than the block (30 rows of luma, 12 of chroma) and a search start
+    that asks for one sample of room reloads them all the time -- in mid-walk, before the refinement, for every skip prediction -- and has to
+    write the golden streams too (incl. the 64-sample pan at level 1 and the 720p P picture)."""
+    from openh264_amd import build as B
+    lib = B.build_emu(defines=("WH_WIN_ROWS=30", "WH_WIN_MARGIN_Y=7", "WH_WIN_START=1", "WH_CWIN_ROWS=12"), tag="tiny_windows")
+    for name in SMALL + ["p_1280x720_qp24"]:
+        if name in GOLDEN:
+            run_case(name, lib, ref_tools, tmp_path)
+
+
 @pytest.mark.parametrize("case", [
     ("idr_interval_3_from_frame_4", ["-iper", "0", "-setidr", "4", "3"], [(4, oh.OPTION_IDR_INTERVAL, 3)], {}),
     ("idr_interval_off_from_frame_2", ["-iper", "2", "-setidr", "2", "-1"], [(2, oh.OPTION_IDR_INTERVAL, -1)], dict(uiIntraPeriod=2)),
