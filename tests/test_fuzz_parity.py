@@ -67,6 +67,14 @@ def test_fuzz_emu_more_seeds(emu_lib, ref_tools, seed):
     _run([], ref_tools, seed=seed)
 
 
+def test_fuzz_emu_tiny_windows(ref_tools):
+    """The same generator on the test build whose search windows hold little more than the block (tests/test_frame_parity.py
+    test_emu_tiny_search_windows): every reload path of kernels/inter_mb.h, on random sizes and the fast-motion / noise classes."""
+    from openh264_amd import build as B
+    lib = B.build_emu(defines=("WH_WIN_ROWS=30", "WH_WIN_MARGIN_Y=7", "WH_WIN_START=1", "WH_CWIN_ROWS=12"), tag="tiny_windows")
+    _run(["--lib", lib], ref_tools, seed=43)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", [23, 29])
 def test_fuzz_hip_more_seeds(hip_lib, ref_tools, seed):
