@@ -41,16 +41,24 @@
 // 5 chroma predictions made inside the chroma window, 6 read from the picture
 #if defined(WH_EMU)
 #include <stdio.h>
-static long g_wh_win_stat[8];
+static long g_wh_win_stat[40];
+// 8.. : what the macroblocks became and what their searches cost (WELSHIP_WIN_STATS=1): 8 decided P_Skip, 9 background / static, 10 intra, 11 P16x16, 12 P16x8,
+// 13 P8x16, 14 P8x8, 15 renamed P_Skip (double check); 16 / 17 / 18 searches of 16x16 / 16x8+8x16 / 8x8 blocks, 19 / 20 / 21 their diamond steps,
+// 22 / 23 / 24 refinements of 16x16 / 16x8+8x16 / 8x8 blocks, 25 P_Skip tests, 26 of which went through the transform
 static void wh_win_stat_dump() {
   if (!getenv ("WELSHIP_WIN_STATS")) return;
+  fprintf (stderr, "welship mb stat: skip %ld bg/static %ld intra %ld p16x16 %ld p16x8 %ld p8x16 %ld p8x8 %ld renamed-skip %ld | searches 16x16 %ld 16x8/8x16 %ld 8x8 %ld, diamond steps %ld %ld %ld | refinements %ld %ld %ld | skip tests %ld with transform %ld\n",
+           g_wh_win_stat[8], g_wh_win_stat[9], g_wh_win_stat[10], g_wh_win_stat[11], g_wh_win_stat[12], g_wh_win_stat[13], g_wh_win_stat[14], g_wh_win_stat[15], g_wh_win_stat[16], g_wh_win_stat[17], g_wh_win_stat[18],
+           g_wh_win_stat[19], g_wh_win_stat[20], g_wh_win_stat[21], g_wh_win_stat[22], g_wh_win_stat[23], g_wh_win_stat[24], g_wh_win_stat[25], g_wh_win_stat[26]);
   fprintf (stderr, "welship window stat: P macroblocks %ld, reloads %ld, adopted %ld, first loads %ld, mid-walk reloads %ld, chroma predictions inside the window %ld / from the picture %ld\n", g_wh_win_stat[0], g_wh_win_stat[1], g_wh_win_stat[2], g_wh_win_stat[3], g_wh_win_stat[4], g_wh_win_stat[5], g_wh_win_stat[6]);
 }
 struct WhWinStatInit { WhWinStatInit() { atexit (wh_win_stat_dump); } };
 static WhWinStatInit g_wh_win_stat_init;
 #define WH_STAT_WIN(i) (++g_wh_win_stat[i])
+#define WH_STAT_BLK(base, bw, bh) (++g_wh_win_stat[(base) + ((bw) == 16 && (bh) == 16 ? 0 : (bw) == 8 && (bh) == 8 ? 2 : 1)])
 #else
 #define WH_STAT_WIN(i) ((void)0)
+#define WH_STAT_BLK(base, bw, bh) ((void)0)
 #endif
 
 #define WH_REF_NOT_AVAIL (-2)
@@ -632,6 +640,7 @@ WH_FN void wh_motion_search (WhInterLds& S, const WhSeqParams& P, const WhPicJob
     if ((uint32_t)c < Z->chain) { best = c; bmx = Z->dmx; bmy = Z->dmy; WH_STAT (WH_ST_DIR_TAKEN); }
   }
   const bool diamond = !(best < me.sad_pred);
+  WH_STAT_BLK (16, me.bw, me.bh);
   const int bpx = C.mbx * 16 + me.bx, bpy = C.mby * 16 + me.by;
   if (diamond || C.use_satd) wh_win_need (S, P, J, W, bpx + bmx, bpy + bmy, me.bw, me.bh, diamond ? WH_WIN_START : 0);
   if (diamond) {
@@ -658,6 +667,7 @@ WH_FN void wh_motion_search (WhInterLds& S, const WhSeqParams& P, const WhPicJob
       if (wh_win_room (W, bpx + cmx, bpy + cmy, me.bw, me.bh) < 1 || wo != (bpy + cmy - W.y0) * WH_WIN_STRIDE + bpx + cmx - W.x0) { fprintf (stderr, "emu: diamond step outside the search window\n"); abort(); }
 #endif
       // four SADs: up, down, left, right -- two packed 16-bit partial sums per reduction
+      WH_STAT_BLK (19, me.bw, me.bh);
       int pud, plr;
       WV_SUM2 (pud, plr, lane,
                (lane < n ? ([&] () { const int r = wh_sl_row (lane, me.bw), c = wh_sl_col (lane, me.bw);
@@ -818,6 +828,7 @@ WH_FN void wh_rf_quarters (const uint8_t* w, int o, int hb, uint32_t G, uint32_t
 // candidates, and the winner's samples become the prediction without being computed again.
 WH_FN void wh_refine_frac (WhInterLds& S, const WhSeqParams& P, const WhPicJob& J, WhWin& W, const WhMeCtx& C, WhMe& me, int satd_in_md, int sub8 = 0) {
   const int bpx = C.mbx * 16 + me.bx, bpy = C.mby * 16 + me.by;
+  WH_STAT_BLK (22, me.bw, me.bh);
   const int ipx = bpx + (me.mvx >> 2), ipy = bpy + (me.mvy >> 2);          // me.mv is integer-pel here
   wh_win_ensure (S, P, J, W, ipx - 4, ipy - 4, ipx + me.bw + 8, ipy + me.bh + 5);
   const int wo = (ipy - W.y0) * WH_WIN_STRIDE + ipx - W.x0;
@@ -1307,7 +1318,9 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
       const int sad_mb = sad_l + sad_c;
       bool ok = sad_mb == 0 || sad_mb < sad_pred_skip || (ref_is_p && ref_mb_type == WH_MB_PSKIP && !ref_mb_bg && sad_mb < Co->skip_sad);
       WH_PROF_SUB (P, M, 6);     /* detail: P_Skip SADs + decision */
+      WH_STAT_WIN (25);
       if (!ok) {
+        WH_STAT_WIN (26);
         // residual would quantise to nothing?  (WelsDctMb + WelsTryPYskip + WelsTryPUVskip; the transform reads the skip prediction where it lies)
         wh_dct_luma16 (M);
         if (wh_try_py_skip (M, qp)) {
@@ -1578,6 +1591,7 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
   WH_PROF_MARK (P, M, 6);   // residual coding
   // ---- store ----
   const bool is_skip = mb_type == WH_MB_PSKIP;
+  WH_STAT_WIN (intra ? 10 : (bg_coded || scd_coded) ? 9 : (is_skip && b_skip) ? 8 : is_skip ? 15 : mb_type == WH_MB_P16x16 ? 11 : mb_type == WH_MB_P16x8 ? 12 : mb_type == WH_MB_P8x16 ? 13 : 14);
   WH_G WhMbState* Ms = (WH_G WhMbState*)J.mbs + xy;
   WH_G WhMbRecord* Rs = (WH_G WhMbRecord*)J.records + xy;
   if (intra) {

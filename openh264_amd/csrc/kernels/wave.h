@@ -197,19 +197,33 @@ WH_FN int wh_wave_min_i32 (int v) {
        (d0) = __builtin_amdgcn_readlane (_v, 0); (d1) = __builtin_amdgcn_readlane (_v, 16); (d2) = __builtin_amdgcn_readlane (_v, 32); (d3) = __builtin_amdgcn_readlane (_v, 48); } while (0)
 // SATD over lane quads, entirely in registers: horizontal Hadamard inside the lane, vertical butterflies across the
 // quad on DPP quad_perm, then the usual wave sum (see the WH_EMU twin above for the contract).
-WH_FN int wh_satd_rows (int lane, bool active, uint32_t e, uint32_t p) {
-  const int d0 = (int) (e & 255) - (int) (p & 255), d1 = (int) ((e >> 8) & 255) - (int) ((p >> 8) & 255);
-  const int d2 = (int) ((e >> 16) & 255) - (int) ((p >> 16) & 255), d3 = (int) (e >> 24) - (int) (p >> 24);
-  const int s0 = d0 + d2, s1 = d1 + d3, s2 = d0 - d2, s3 = d1 - d3;
-  int a0 = s0 + s1, a1 = s2 + s3, a2 = s2 - s3, a3 = s0 - s1;
-  const bool hi2 = (lane & 2) != 0, hi1 = (lane & 1) != 0;
-  int o;
-#define WH_VBF(v) o = WH_DPP (v, 0x4E); v = hi2 ? o - v : v + o; o = WH_DPP (v, 0xB1); v = hi1 ? o - v : v + o;
-  WH_VBF (a0) WH_VBF (a1) WH_VBF (a2) WH_VBF (a3)
-#undef WH_VBF
-  int s = __builtin_abs (a0) + __builtin_abs (a1) + __builtin_abs (a2) + __builtin_abs (a3);
+// Two 16-bit values per register (v_pk_*_i16): every intermediate of a 4x4 Hadamard of byte differences fits (|x| <= 16 * 255).
+typedef short wh_s16x2 __attribute__ ((ext_vector_type (2)));
+WH_FN wh_s16x2 wh_as_s16x2 (uint32_t v) { return __builtin_bit_cast (wh_s16x2, v); }
+WH_FN uint32_t wh_as_u32 (wh_s16x2 v) { return __builtin_bit_cast (uint32_t, v); }
+// (x + y, x - y) of a pair: one v_pk_mad_i16 with the halves picked by op_sel
+WH_FN wh_s16x2 wh_pk_sumdiff (wh_s16x2 v) { const wh_s16x2 pm = {1, -1}; return v.yy * pm + v.xx; }
+// The sum of |Hadamard4x4 (e - p)| of this lane's quad in every lane of the quad (round 6: packed 16-bit arithmetic -- 25 vector
+// instructions where the 32-bit version took 55; a P16x16 macroblock makes nine or ten of these passes in its refinement alone).
+// Bytes 0,1 and 2,3 go to the 16-bit halves of two registers (v_perm_b32); the horizontal butterflies are two packed add / sub and two
+// (x + y, x - y) steps; a vertical butterfly stage is partner + sign * own, sign = -1 in the upper lane of the pair: one DPP move and
+// one v_pk_mad_i16 per register; |.| summed by v_sad_u16 against the bias that makes the halves unsigned.
+WH_FN int wh_satd_quad (int lane, uint32_t e, uint32_t p) {
+  const wh_s16x2 d01 = wh_as_s16x2 (__builtin_amdgcn_perm (0u, e, 0x0c010c00u)) - wh_as_s16x2 (__builtin_amdgcn_perm (0u, p, 0x0c010c00u));
+  const wh_s16x2 d23 = wh_as_s16x2 (__builtin_amdgcn_perm (0u, e, 0x0c030c02u)) - wh_as_s16x2 (__builtin_amdgcn_perm (0u, p, 0x0c030c02u));
+  wh_s16x2 a03 = wh_pk_sumdiff (d01 + d23);            // (s0 + s1, s0 - s1)
+  wh_s16x2 a12 = wh_pk_sumdiff (d01 - d23);            // (s2 + s3, s2 - s3)
+  const wh_s16x2 sg2 = wh_as_s16x2 ((lane & 2) ? 0xffffffffu : 0x00010001u), sg1 = wh_as_s16x2 ((lane & 1) ? 0xffffffffu : 0x00010001u);
+  a03 = a03 * sg2 + wh_as_s16x2 ((uint32_t)WH_DPP ((int)wh_as_u32 (a03), 0x4E)); a12 = a12 * sg2 + wh_as_s16x2 ((uint32_t)WH_DPP ((int)wh_as_u32 (a12), 0x4E));
+  a03 = a03 * sg1 + wh_as_s16x2 ((uint32_t)WH_DPP ((int)wh_as_u32 (a03), 0xB1)); a12 = a12 * sg1 + wh_as_s16x2 ((uint32_t)WH_DPP ((int)wh_as_u32 (a12), 0xB1));
+  int s = (int)__builtin_amdgcn_sad_u16 (wh_as_u32 (a03) ^ 0x80008000u, 0x80008000u, 0u);
+  s = (int)__builtin_amdgcn_sad_u16 (wh_as_u32 (a12) ^ 0x80008000u, 0x80008000u, (uint32_t)s);
   s += WH_DPP (s, 0xB1);
   s += WH_DPP (s, 0x4E);
+  return s;
+}
+WH_FN int wh_satd_rows (int lane, bool active, uint32_t e, uint32_t p) {
+  int s = wh_satd_quad (lane, e, p);
   s = (active && (lane & 3) == 0) ? (s + 1) >> 1 : 0;
   return wh_wave_sum_i32 (s);
 }
