@@ -1026,22 +1026,22 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
   {
     WhTileRegs tr;
     wh_tile_fetch_nb (lane, P, J, mbx, mby, &tr);
-    uint32_t st[3] = {0, 0, 0};
+    // The four neighbours' states by LDS-DMA straight into S.nb (round 6; rounds 1-5: three loads per lane into registers, selects, three LDS
+    // stores -- 135 vector instructions of address arithmetic and a division by 36 per load).  Top-left, top and top-right are ONE run of 108
+    // words of the picture's state array, which nb[0..107] mirrors; the left state follows in nb[108..143].  A neighbour that does not exist (or
+    // belongs to another slice) is not copied: its words keep whatever they held and are never read (TLm / Tm / TRm / Lm are null then).
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      const int i = lane + 64 * k, n = i / 36, wd = i - n * 36;           // state n (0 TL, 1 T, 2 TR, 3 L), dword wd
-      // unconditional loads (this MB's own state stands in where there is nothing to read), selects afterwards: see wh_tile_fetch_nb
-      const bool ok = i < 144 && (n == 0 ? (avail & WH_AV_TOPLEFT) != 0 : n == 1 ? (avail & WH_AV_TOP) != 0 : n == 2 ? (avail & WH_AV_TOPRIGHT) != 0 : (avail & WH_AV_LEFT) != 0);
-      const int off = n == 0 ? -w - 1 : n == 1 ? -w : n == 2 ? -w + 1 : -1;
-      const uint32_t v = ((const WH_G uint32_t*) ((const WH_G WhMbState*)J.mbs + xy + (ok ? off : 0)))[ok ? wd : 0];
-      st[k] = ok ? v : 0u;
+      const int d = lane + 64 * k;
+      const bool ok = d < 36 ? (avail & WH_AV_TOPLEFT) != 0 : d < 72 ? (avail & WH_AV_TOP) != 0 : d < 108 ? (avail & WH_AV_TOPRIGHT) != 0 : d < 144 && (avail & WH_AV_LEFT) != 0;
+      const int wofs = d < 108 ? (xy - w - 1) * 36 + d : (xy - 1) * 36 + (d - 108);         // word offset inside the state array (36 words per state)
+      if (ok) wh_ld_async4 ((const WH_G uint32_t*)J.mbs + wofs, &S.nb[64 * k], lane);
     }
     WH_PROF_SUB (P, M, 3);       /* detail: neighbour loads issued */
     wh_tile_commit_nb (M, lane, &tr);      // (the source samples and the reference picture's state of this MB are in place already: wh_inter_cold_fetch)
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { const int i = lane + 64 * k; if (i < 144) S.nb[i] = st[k]; }
   }
   WV_LANES_END
+  WV_ASYNC_WAIT();
 
   WH_PROF_MARK (P, M, 9);   // batch 1 loads
   // ---- neighbour cache (FillNeighborCacheInterWithoutBGD) ----

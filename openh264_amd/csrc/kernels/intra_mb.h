@@ -58,39 +58,46 @@ WH_FN void wh_tile_fetch_src (int lane, const WhSeqParams& P, const WhPicJob& J,
 // the aligned word that ENDS with their sample (x = -4 .. -1) and keep its top byte; lanes without a role repeat lane 0's word.
 // (the three planes as VALUES: a select between loads of job fields would be folded into one load at a selected offset, which
 // keeps a job descriptor that lives in registers from staying there)
-WH_FN void wh_tile_fetch_nb_planes (int lane, const WhSeqParams& P, const WH_G uint8_t* rec0, const WH_G uint8_t* rec1, const WH_G uint8_t* rec2, int mbx, int mby, WhTileRegs* r) {
+// (round 6: both layouts only compute the ADDRESS of the lane's word; the one load follows the uniform choice between them, and the
+//  column lanes' shift waits until the commit.  With a load in each branch the compiler merged the loaded VALUES through a phi and waited
+//  for the load at the end of its branch -- the P kernel then paid that L2 round trip before it had even issued the loads of the
+//  neighbours' states: "batch-1: loads issued" 3.2 k of a macroblock's 47 k cycles, profiles/r06_p1080p_detail_phase_cycles_before.txt)
+WH_FN const WH_G uint8_t* wh_tile_nb_addr_planes (int lane, const WhSeqParams& P, const WH_G uint8_t* rec0, const WH_G uint8_t* rec1, const WH_G uint8_t* rec2, int mbx, int mby) {
   const bool top_y = lane < 7, col_y = lane >= 16 && lane < 32, top_c = lane >= 32 && lane < 38, col_c = lane >= 48;
   const bool luma = !(top_c || col_c);                                   // (idle lanes take lane 0's role)
   const int pl = top_c ? (lane - 32) / 3 : (lane - 48) >> 3;             // chroma plane of the chroma roles
   const int row = col_y ? mby * 16 + (lane - 16) : col_c ? mby * 8 + (lane & 7) : top_c ? mby * 8 - 1 : mby * 16 - 1;
   const int x = top_y ? mbx * 16 + lane * 4 - 4 : top_c ? mbx * 8 + ((lane - 32) % 3) * 4 - 4 : luma ? mbx * 16 - 4 : mbx * 8 - 4;
   const WH_G uint8_t* base = luma ? rec0 : (pl & 1) ? rec2 : rec1;
-  const uint32_t v = * (const WH_G uint32_t*) (base + (ptrdiff_t)row * (luma ? P.rec_stride_y : P.rec_stride_c) + x);
-  r->nb = (col_y || col_c) ? v >> 24 : v;
+  int sy = P.rec_stride_y, sc = P.rec_stride_c;
+  WH_UNIFORM_VALUE (sy); WH_UNIFORM_VALUE (sc);
+  return base + (ptrdiff_t)row * (luma ? sy : sc) + x;
 }
 // The same roles when the unfiltered reconstruction is kept macroblock by macroblock (WhPicJob::rec_blk): the word is the neighbour block's
 // row 15 / 7 (top roles: the macroblock above-left, above, above-right) or the last word of one of its rows (column roles: the left one).
 // A neighbour outside the picture is replaced by a block that exists (macroblock 0 / the last one): its samples are never used.
-WH_FN void wh_tile_fetch_nb_blk (int lane, const WhSeqParams& P, const WH_G uint8_t* blk, int mbx, int mby, WhTileRegs* r) {
+// (selects, no branches: lane roles as `if / else if` become a chain of exec-mask updates)
+WH_FN const WH_G uint8_t* wh_tile_nb_addr_blk (int lane, const WhSeqParams& P, const WH_G uint8_t* blk, int mbx, int mby) {
   const bool top_y = lane < 7, col_y = lane >= 16 && lane < 32, top_c = lane >= 32 && lane < 38, col_c = lane >= 48;
   const int w = P.mb_w, xy = mby * w + mbx;
-  int nb, off;
-  if (col_y) { nb = xy - 1; off = (lane - 16) * 16 + 12; }
-  else if (col_c) { nb = xy - 1; off = 256 + ((lane - 48) >> 3) * 64 + (lane & 7) * 8 + 4; }
-  else if (top_c) {
-    const int pl = (lane - 32) / 3, k = (lane - 32) - 3 * pl;
-    nb = k == 0 ? xy - w - 1 : xy - w; off = 256 + pl * 64 + 56 + (k == 0 ? 4 : (k - 1) * 4);
-  } else {
-    const int k = top_y ? lane : 0;                                      // (idle lanes take lane 0's role)
-    nb = k == 0 ? xy - w - 1 : k < 5 ? xy - w : xy - w + 1; off = 240 + (k == 0 ? 12 : k < 5 ? (k - 1) * 4 : (k - 5) * 4);
-  }
+  const int cpl = lane >= 35 ? 1 : 0, ck = (lane - 32) - 3 * cpl;       // top_c: plane and word (0: above-left, 1 / 2: above)
+  const int k = top_y ? lane : 0;                                        // (idle lanes take lane 0's role)
+  const int nb_top = top_c ? (ck == 0 ? xy - w - 1 : xy - w) : (k == 0 ? xy - w - 1 : k < 5 ? xy - w : xy - w + 1);
+  const int off_top = top_c ? 256 + cpl * 64 + 56 + (ck == 0 ? 4 : (ck - 1) * 4) : 240 + (k == 0 ? 12 : k < 5 ? (k - 1) * 4 : (k - 5) * 4);
+  const int off_col = col_y ? (lane - 16) * 16 + 12 : 256 + ((lane - 48) >> 3) * 64 + (lane & 7) * 8 + 4;
+  int nb = (col_y || col_c) ? xy - 1 : nb_top;
+  const int off = (col_y || col_c) ? off_col : off_top;
   nb = nb < 0 ? 0 : nb;                                                  // (xy - w + 1 <= xy: never beyond the picture)
-  const uint32_t v = * (const WH_G uint32_t*) (blk + (size_t)nb * WH_SRC_MB_BYTES + off);
-  r->nb = (col_y || col_c) ? v >> 24 : v;
+  return blk + (size_t)nb * WH_SRC_MB_BYTES + off;
+}
+// r->nb: the lane's word as loaded; the column roles keep its top byte (wh_tile_commit_nb)
+WH_FN void wh_tile_fetch_nb_planes (int lane, const WhSeqParams& P, const WH_G uint8_t* rec0, const WH_G uint8_t* rec1, const WH_G uint8_t* rec2, int mbx, int mby, WhTileRegs* r) {
+  r->nb = * (const WH_G uint32_t*)wh_tile_nb_addr_planes (lane, P, rec0, rec1, rec2, mbx, mby);
 }
 WH_FN void wh_tile_fetch_nb (int lane, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, WhTileRegs* r) {
-  if (J.rec_blk) wh_tile_fetch_nb_blk (lane, P, (const WH_G uint8_t*)J.rec_blk, mbx, mby, r);
-  else wh_tile_fetch_nb_planes (lane, P, (const WH_G uint8_t*)J.rec[0], (const WH_G uint8_t*)J.rec[1], (const WH_G uint8_t*)J.rec[2], mbx, mby, r);
+  const WH_G uint8_t* a = J.rec_blk ? wh_tile_nb_addr_blk (lane, P, (const WH_G uint8_t*)J.rec_blk, mbx, mby)
+                                    : wh_tile_nb_addr_planes (lane, P, (const WH_G uint8_t*)J.rec[0], (const WH_G uint8_t*)J.rec[1], (const WH_G uint8_t*)J.rec[2], mbx, mby);
+  r->nb = * (const WH_G uint32_t*)a;
 }
 WH_FN void wh_tile_fetch (int lane, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, WhTileRegs* r) {
   wh_tile_fetch_src (lane, P, J, mbx, mby, r);
@@ -101,13 +108,13 @@ WH_FN void wh_tile_commit_nb (WhMbLds& S, int lane, const WhTileRegs* r) {
   if (lane < 7) {
     * (uint32_t*)&S.rec_y[0 * 32 + lane * 4 - 4 + 8] = r->nb;
   } else if (lane >= 16 && lane < 32) {
-    WH_RY (S, -1, lane - 16) = (uint8_t)r->nb;
+    WH_RY (S, -1, lane - 16) = (uint8_t) (r->nb >> 24);
   } else if (lane >= 32 && lane < 38) {
     const int pl = (lane - 32) / 3, x = ((lane - 32) % 3) * 4 - 4;
     * (uint32_t*)&S.rec_c[pl][0 * 16 + x + 4] = r->nb;
   } else if (lane >= 48) {
     const int pl = (lane - 48) >> 3, y = lane & 7;
-    WH_RC (S, pl, -1, y) = (uint8_t)r->nb;
+    WH_RC (S, pl, -1, y) = (uint8_t) (r->nb >> 24);
   }
 }
 WH_FN void wh_tile_commit (WhMbLds& S, int lane, const WhTileRegs* r) {

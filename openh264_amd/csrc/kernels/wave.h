@@ -28,6 +28,7 @@
 #define WV_LANES_BEGIN(lane) for (int lane = 0; lane < 64; ++lane) {
 #endif
 #define WV_LANES_END }
+#define WH_UNIFORM_VALUE(x) ((void)0)
 #define WV_SYNC() ((void)0)
 #define WV_GLOBAL_FENCE() ((void)0)
 #define WV_SUM(dst, lane, expr)                                   \
@@ -132,6 +133,9 @@ WH_FN uint32_t wh_avg4 (uint32_t a, uint32_t b) {
 // The lane id is re-materialised as an opaque value in every lane block: otherwise the compiler hoists all per-lane
 // address arithmetic out of the per-macroblock loop, keeps it live across the whole body and spills it to scratch.
 WH_FN int wh_lane_id() { int l = (int)(threadIdx.x & 63); asm volatile ("" : "+v"(l)); return l; }
+// a wave-uniform value the compiler must take as it is (kept in a scalar register): a select between two LOADED uniforms is otherwise
+// folded into one vector load at a selected address
+#define WH_UNIFORM_VALUE(x) asm volatile ("" : "+s"(x))
 #define WV_LANES_BEGIN(lane) { const int lane = wh_lane_id();
 // A workgroup is ONE wavefront and a wavefront's LDS instructions execute in issue order, so the hand-off between
 // lane blocks needs no s_waitcnt / s_barrier: only the compiler must not move LDS accesses across it.
