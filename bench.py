@@ -166,22 +166,52 @@ def p_flags(qp, idc):
     return ["-iper", "0", "-qp", str(qp), "-slcmd", "1", "-slcnum", "4", "-deblock", str(idc)]
 
 
-def cpu_baseline(w, h, qp, workload, content, idc):
-    """Time the reference (oracle/_ref/ref_enc, C fallback) on a bounded sample of the same workload: 1 thread, and 4 slice
-    threads with -loadbalancing 0 and deblocking idc 2 (what the threaded reference needs for a deterministic stream)."""
+def cpu_baseline(w, h, qp, workload, content, idc, sessions=(0,)):
+    """Time the reference (oracle/_ref/ref_enc) on a bounded sample of the same workload: the frame orders of the sessions whose reconstruction
+    the timed steps verified (up to 8, spread over the batch), one after the other on ONE thread; and session 0's on 4 slice threads with
+    -loadbalancing 0 and deblocking idc 2 (what the threaded reference needs for a deterministic stream).
+    Which reference: oracle/_ref/ref_enc is the C fallback (`-O3`, no asm) -- the image has no nasm, so the SIMD library cannot be built here and,
+    /root/reference not existing on the GPU box, not there either.  oracle/Makefile builds oracle/_ref/ref_enc_asm (the reference with its x86
+    assembly, build/x86-common.mk) wherever nasm is on PATH at build time; when that binary travels with the snapshot it is timed as well and
+    reported as `simd` (kind "reference SSE2/AVX2").  A reported baseline either way, not the optimisation target."""
     if not os.path.exists(os.path.join(REF_DIR, "ref_enc")):
         return None
-    n = 96 if w * h > 1280 * 720 else 200
+    sessions = tuple(sessions) or (0,)
+    n = max(12, (96 if w * h > 1280 * 720 else 200) * 2 // len(sessions)) if len(sessions) > 1 else (96 if w * h > 1280 * 720 else 200)
     ring = content.ring
-    yuv = b"".join(content.frame(0, slot_of(i, ring)) for i in range(n))
     base = ["-iper", "1"] if workload == "intra" else p_flags(qp, idc)
-    _, fps1 = ref_encode(yuv, w, h, base + ["-quiet", "-threads", "1"], True)
-    out = {"value": fps1, "unit": "frames/s", "cores": 1, "kind": "reference", "host": cpu_info(),
-           "sample": "%d frames %dx%d of session 0's frame order, oracle/_ref (reference C fallback, no asm: no nasm in the image), timed around EncodeFrame" % (n, w, h)}
+
+    def run(exe_flags, sess, frames):
+        yuv = b"".join(content.frame(sess, slot_of(i, ring)) for i in range(frames))
+        return ref_encode(yuv, w, h, exe_flags, True)[1]
+    per = [run(base + ["-quiet", "-threads", "1"], s_, n) for s_ in sessions]
+    fps1 = len(per) / sum(1.0 / f for f in per)            # frames / total time over the sessions (equal frame counts)
+    out = {"value": fps1, "unit": "frames/s", "cores": 1, "kind": "reference", "host": cpu_info(), "build": "C fallback, -O3, no asm",
+           "per_session": dict(zip((str(s_) for s_ in sessions), per)),
+           "sample": "%d frames %dx%d of each of %d sessions' frame orders (sessions %s of the batch), oracle/_ref (reference C fallback, no asm), one thread, timed around EncodeFrame"
+                     % (n, w, h, len(sessions), list(sessions))}
     if workload == "p":
         flags4 = ["-iper", "0", "-qp", str(qp), "-slcmd", "1", "-slcnum", "4", "-deblock", "2", "-quiet", "-threads", "4", "-loadbalancing", "0"]
-        _, fps4 = ref_encode(yuv, w, h, flags4, True)
-        out["threads4"] = {"value": fps4, "unit": "frames/s", "cores": 4, "flags": "-threads 4 -loadbalancing 0 -deblock 2"}
+        out["threads4"] = {"value": run(flags4, sessions[0], 96 if w * h > 1280 * 720 else 200), "unit": "frames/s", "cores": 4, "flags": "-threads 4 -loadbalancing 0 -deblock 2"}
+    asm = os.path.join(REF_DIR, "ref_enc_asm")
+    import shutil
+    if os.path.exists(asm):
+        def run_asm(flags, frames):
+            yuv = b"".join(content.frame(sessions[0], slot_of(i, ring)) for i in range(frames))
+            with tempfile.TemporaryDirectory() as td:
+                fi, fo = os.path.join(td, "in.yuv"), os.path.join(td, "out.264")
+                open(fi, "wb").write(yuv)
+                o = subprocess.check_output([asm, "-i", fi, "-w", str(w), "-h", str(h), "-o", fo, "-rc", "-1", "-fps", "30"] + flags).decode()
+            return float(dict(t.split("=") for t in o.split())["fps"])
+        try:
+            out["simd"] = {"value": run_asm(base + ["-quiet", "-threads", "1"], 3 * n), "unit": "frames/s", "cores": 1, "kind": "reference SSE2/AVX2",
+                           "sample": "%d frames of session %d, oracle/_ref/ref_enc_asm (the reference with its x86 assembly)" % (3 * n, sessions[0])}
+        except Exception as e:          # noqa: BLE001
+            out["simd"] = {"available": False, "why": "oracle/_ref/ref_enc_asm failed: %s" % str(e)[:160]}
+    else:
+        out["simd"] = {"available": False, "nasm_on_this_box": shutil.which("nasm") is not None,
+                       "why": "oracle/_ref/ref_enc_asm is not in the snapshot: the build image has no nasm (oracle/Makefile builds it where nasm is on PATH), and "
+                              "/root/reference does not exist on the GPU box, so it cannot be built here either"}
     return out
 
 
@@ -326,9 +356,16 @@ def binding_leg(args, local, extra_env=None, timeout=400):
     """One run of tools/config5_sessions.py (N ISVCEncoder objects of the patched reference in one process, this engine behind SWelsFuncPtrList,
     next to the same sessions on the reference's C path) -> the digest bench lines carry."""
     env = dict(os.environ, WELS_HIP_DEVICE=str(local))
-    env.update(extra_env or {})
+    for k, v in (extra_env or {}).items():
+        if v is None:
+            env.pop(k, None)
+        else:
+            env[k] = v
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "config5_sessions.py")] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, env=env)
-    j = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    lines = r.stdout.decode(errors="replace").strip().splitlines()
+    if r.returncode != 0 or not lines:
+        raise RuntimeError("tools/config5_sessions.py %s: exit code %d, stderr tail: %s" % (" ".join(args), r.returncode, r.stderr.decode(errors="replace")[-400:]))
+    j = json.loads(lines[-1])
     n = int(args[0])
     dev, c = j["hooks_on_device"], j["reference_c_path"]
     return {"config": j["config"], "same_bitstreams": j["same_bitstreams"],
@@ -338,7 +375,7 @@ def binding_leg(args, local, extra_env=None, timeout=400):
             "note": "frames/s = sum over the sessions of frames / time inside EncodeFrame; every layer of a simulcast frame counts as part of ONE frame"}, r.stderr.decode(errors="replace")
 
 
-def multi_gpu_legs(rank, world, local, dist, small):
+def multi_gpu_legs(rank, world, local, dist, small, visible0=None):
     """BASELINE configs 5 and 4 over the ranks of one node (no data-path collective: all_gather_object of the per-rank digests only).
     config5_64_sessions: every rank hosts 8 concurrent 1080p sessions (rate control, raster slices) on its GPU, all ranks at once -- 8 x N sessions
     per node, 64 on 8 GPUs; the C-path twin of every rank runs at the same time too, so the host's cores are shared by 8 x N reference sessions.
@@ -352,7 +389,7 @@ def multi_gpu_legs(rank, world, local, dist, small):
         mine, _ = binding_leg(args5, local)
     except Exception as e:          # noqa: BLE001 -- reported in the line
         mine = {"error": str(e)[:200]}
-    mine["rank"], mine["device"] = rank, local
+    mine["rank"], mine["device"] = rank, os.environ.get("HIP_VISIBLE_DEVICES", str(local))
     parts = [None] * world
     dist.all_gather_object(parts, mine)
     if rank == 0:
@@ -364,13 +401,16 @@ def multi_gpu_legs(rank, world, local, dist, small):
             "per_session_latency_ms": [p.get("device_ms_per_frame_per_session") for p in parts],
             "same_bitstreams": bool(ok) and len(ok) == len(parts) and all(p["same_bitstreams"] for p in ok), "errors": [p["error"] for p in parts if "error" in p],
             "config": ok[0]["config"] if ok else None,
-            "note": "all ranks at once; the C-path sessions of all ranks share the host's cores (%d reference sessions on %s logical cores)" % (int(args5[0]) * world, os.cpu_count())}
+            "c_path_comparable_with_single_gpu_leg": False,
+            "note": "all ranks at once; the C-path sessions of all ranks share the host's cores (%d reference sessions on %s logical cores): the aggregate C-path figure "
+                    "is measured on oversubscribed cores and is NOT comparable with the single-GPU leg's (config5_8_sessions_1080p_rc_raster_slices)" % (int(args5[0]) * world, os.cpu_count())}
     dist.barrier()
     if rank == 0:
         n = min(world, 4)
         try:
             leg, err = binding_leg(["1", "2", "simulcast"] if small else ["1", "54", "simulcast", "1080p"], 0,
-                                   {"WELS_HIP_LAYER_DEVICES": str(n if n >= 2 else 0), "WELSHIP_TRACE_DEVICES": "1", "WELS_HIP_TRACE": "1"})
+                                   {"WELS_HIP_LAYER_DEVICES": str(n if n >= 2 else 0), "WELSHIP_TRACE_DEVICES": "1", "WELS_HIP_TRACE": "1",
+                                    "HIP_VISIBLE_DEVICES": visible0})          # (this one session sees all the node's GPUs again)
             leg["layer_devices"] = n
             seen = sorted(set(int(x) for x in re.findall(r"backend for device (\d+)", err)))
             if seen:
@@ -395,22 +435,33 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    import torch
     cpu_test = a.cpu_launcher_test
+    # One rank = one GPU, pinned BEFORE anything initialises HIP: the rank sees exactly its own device (index 0), whatever the launcher's
+    # HIP_VISIBLE_DEVICES was -- no plumbing left that the first real N-GPU run could trip over (a library or a child process that forgets the
+    # device index lands on the right GPU anyway).  `visible0`: the launcher's own setting, for the one leg that spreads ONE session over
+    # several GPUs (config4_layer_per_gpu).
+    visible0 = os.environ.get("HIP_VISIBLE_DEVICES")
+    dev = local
+    if world > 1 and not cpu_test:
+        ids = [x for x in visible0.split(",") if x != ""] if visible0 else [str(i) for i in range(world)]
+        if local >= len(ids):
+            raise SystemExit("bench.py: rank %d has no GPU (HIP_VISIBLE_DEVICES=%r)" % (local, visible0))
+        os.environ["HIP_VISIBLE_DEVICES"] = ids[local]
+        dev = 0
+    import torch
     if cpu_test:
         if "emu" not in os.path.basename(os.environ.get("WELSHIP_LIB", "")):
             raise SystemExit("--cpu-launcher-test needs WELSHIP_LIB = the CPU test build (tests/emu/libwelship_emu.so)")
     elif not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     else:
-        torch.cuda.set_device(local)
+        torch.cuda.set_device(dev)
     dist = None
     if world > 1:
+        # the harness' barrier and its max-over-ranks of ONE float go over gloo: the path has no exchange step, so no RCCL
+        # communicator is brought up at all
         import torch.distributed as dist
-        if cpu_test:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        dist.init_process_group("gloo")
     import openh264_amd as oh
     from openh264_amd.utils.synth import synth_sequence
 
@@ -441,14 +492,14 @@ def main():
         data = "synthetic"
 
     verify_sessions = () if (a.no_verify or not have_ref or rank != 0) else spread_sessions(a.sessions, 8)
-    dt, ev, verified = hot_path_leg(oh, a, local, w, h, workload, a.sessions, ring, content, a.steps, a.warmup, barrier, verify_sessions)
+    dt, ev, verified = hot_path_leg(oh, a, dev, w, h, workload, a.sessions, ring, content, a.steps, a.warmup, barrier, verify_sessions)
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if cpu_test else "cuda")
+        t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     mg = {}
     if dist is not None and world > 1 and (a.multi_gpu_legs or not a.quick) and os.path.exists(os.path.join(REF_DIR, "ref_enc_hip")):
-        mg = multi_gpu_legs(rank, world, local, dist, cpu_test)
+        mg = multi_gpu_legs(rank, world, dev, dist, cpu_test, visible0)
     if rank != 0:
         if dist is not None:
             dist.barrier()
@@ -506,14 +557,14 @@ def main():
         # the host entropy-codes step k - 1 while the device codes step k.  (The synchronous and the several-groups legs of rounds 1-3 are gone:
         # 4.2 k and 4.1 k frames/s against this leg's 13.4 k, profiles/r04_bench_default_final.json.)
         n3 = 60
-        dp, nb3, m3, host3 = e2e_pipelined_leg(oh, a, local, w, h, a.sessions, ring, content, n3, bool(verify_sessions))
+        dp, nb3, m3, host3 = e2e_pipelined_leg(oh, a, dev, w, h, a.sessions, ring, content, n3, bool(verify_sessions))
         line["e2e_pipelined"] = {"frames_per_s": a.sessions * n3 / dp, "frames_per_s_second_half": e2e_pipelined_leg.steady,
                                  "sessions": a.sessions, "frames_each": n3, "host_threads_per_half": e2e_pipelined_leg.threads, "steps_ahead": e2e_pipelined_leg.ahead,
                                  "bitstream_MB_per_s": nb3 / dp / 1e6, "bitstream_vs_reference": m3, "host_thread_ms_per_picture": host3,
                                  "how": "WelsHipGroupEncodeFramesPipelined: staging copy + H2D + kernels of step k queued, then D2H + CAVLC of step k - 1 under them"}
         lat = {}
         for ns in (1, 8):
-            dl, _, _ = e2e_leg(oh, a, local, w, h, ns, ring, content, 20)
+            dl, _, _ = e2e_leg(oh, a, dev, w, h, ns, ring, content, 20)
             lat["sessions_%d" % ns] = {"ms_per_frame": dl / 20 * 1e3, "frames_per_s": ns * 20 / dl}
         line["latency"] = lat
         # the same step on the reference's own 1080p clip
@@ -522,7 +573,7 @@ def main():
             if clip is not None:
                 c2 = Content(clip, fsz, ring, True)
                 st = max(10, min(a.steps, 50))
-                d2, ev2, ver2 = hot_path_leg(oh, a, local, w, h, "p", a.sessions, ring, c2, st, 2, None, (0,) if verify_sessions else ())
+                d2, ev2, ver2 = hot_path_leg(oh, a, dev, w, h, "p", a.sessions, ring, c2, st, 2, None, (0,) if verify_sessions else ())
                 r2 = roofline("p", mbs, a.sessions, st, ev2)
                 line["res_clip"] = {"data": "res/VID_1920x1080_cavlc_temporal_direct.264 decoded, %d consecutive frames per session, sessions start 5 frames apart" % ring,
                                     "value": a.sessions * st / d2, "unit": "frames/s", "steps": st, "roofline_frac": r2["frac"], "events_ms": ev2,
@@ -534,7 +585,7 @@ def main():
                 w2, h2 = 1280, 720
                 c3 = Content(clip[: w2 * h2 * 3 // 2 * 16], w2 * h2 * 3 // 2, 2, True)
                 st, ns = 12, 512        # (two single-slice pictures per CU: the intra kernel then runs two 12-wave workgroups on each)
-                d3, ev3, ver3 = hot_path_leg(oh, a, local, w2, h2, "intra", ns, 2, c3, st, 2, None, (0,) if verify_sessions else ())
+                d3, ev3, ver3 = hot_path_leg(oh, a, dev, w2, h2, "intra", ns, 2, c3, st, 2, None, (0,) if verify_sessions else ())
                 r3 = roofline("intra", ((w2 + 15) // 16) * ((h2 + 15) // 16), ns, st, ev3)
                 line["intra_720p"] = {"data": "res/VID_1280x720_cavlc_temporal_direct.264 decoded (BASELINE config 2's stand-in clip)", "value": ns * st / d3, "unit": "frames/s",
                                       "sessions": ns, "steps": st, "roofline": {k: r3[k] for k in ("kernel", "achieved", "frac", "avg_launch_ms", "bytes_per_mb")},
@@ -549,12 +600,19 @@ def main():
                               ("config5_8_sessions_1080p_rc_raster_slices", ["8", "54", "plain", "1080p"])):      # (the whole 54-frame clip: rounds 2-4 coded its first 30
                 # frames, of which the sessions of the device leg spend about ten falling into step -- a running service is the steady state)
                 try:
-                    line[key], _ = binding_leg(args, local, timeout=240)
+                    line[key], _ = binding_leg(args, dev, timeout=240)
                 except Exception as e:
                     line[key] = {"error": str(e)[:200]}
+    # what an encoder delivers, next to the contract's `value` (the device hot path): complete EncodeFrame work with a verified bitstream, and the
+    # hot path on the reference's own 1080p content instead of the synthetic pan
+    if "e2e_pipelined" in line:
+        line["value_e2e"] = line["e2e_pipelined"]["frames_per_s"]
+        line["value_e2e_note"] = "frames/s of complete EncodeFrame work (H2D of the sources, device passes, D2H of the packed records, host CAVLC), bitstreams == the reference's; PCIe-bound"
+    if "res_clip" in line:
+        line["value_res_clip"] = line["res_clip"]["value"]
     line.update(mg)
     if world == 1 and not a.no_cpu_baseline:
-        cb = cpu_baseline(w, h, a.qp, workload, content, a.deblock_idc)
+        cb = cpu_baseline(w, h, a.qp, workload, content, a.deblock_idc, verify_sessions or (0,))
         if cb:
             line["cpu_baseline"] = cb
     print(json.dumps(line))

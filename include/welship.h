@@ -241,8 +241,11 @@ typedef struct WelsHipScreenInfo {
   uint32_t* pSliceFMECostDown;          /* out, [iNumSlices]: what the picture adds to each pSlice->uiSliceFMECostDown                       */
 } WelsHipScreenInfo;
 typedef struct WelsHipFrameJob {
-  uint32_t cbSize;                  /* sizeof (WelsHipFrameJob) of the header the caller was compiled with: the library refuses a job of      */
-                                    /* another size (WELSHIP_ERR_INIT_PARA) instead of reading past a shorter struct                         */
+  uint32_t cbSize;                  /* sizeof (WelsHipFrameJob) of the header the caller was compiled with.  New fields are only ever APPENDED, */
+                                    /* and zero means "not used": a caller built against an older header (cbSize from WELSHIP_FRAMEJOB_MIN_SIZE, */
+                                    /* the first layout that carried this field, up to the library's own sizeof) is served with the fields it   */
+                                    /* does not know taken as zero; anything shorter, or longer than the library's struct (a caller newer than  */
+                                    /* the library, whose extra fields it could not honour), is refused with WELSHIP_ERR_INIT_PARA             */
   int32_t iCurPic, iRefPic;         /* device picture indices (0 .. iNumPictures-1); iRefPic < 0: I picture                    */
   int32_t eSliceType;               /* 0 = P_SLICE, 2 = I_SLICE (slice_type values of the standard)                            */
   int32_t iQp;                      /* pEncCtx->iGlobalQp: WelsRcMbInitDisable / WelsRcMbInitGom with bEnableGomQp == false    */
@@ -312,6 +315,7 @@ typedef struct WelsHipFrameJob {
   int32_t bPackedRecords;
   int32_t* pbRecordsPacked;
 } WelsHipFrameJob;
+#define WELSHIP_FRAMEJOB_MIN_SIZE 232u      /* sizeof (WelsHipFrameJob) of the first layout with cbSize (LP64): up to and including pbRecordsPacked */
 #define WELSHIP_PACKED_MAX_MB 9216
 typedef struct WelsHipPackedRecords {
   const uint8_t* pData;             /* the packed stream of the picture                                                                       */

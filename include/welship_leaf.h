@@ -1,5 +1,5 @@
 /* welship_leaf.h -- layer (3c) of the C ABI: the leaf primitives with EXACTLY the reference's function-pointer typedefs, one export
- * per table slot, so that each can be stored into SWelsFuncPtrList / SMcFunc / DeblockingFunc without a cast
+ * per table slot (95 exports; several slots share one, e.g. the three pfSetMemZero* or the two pfCopy16x16*), so that each can be stored into SWelsFuncPtrList / SMcFunc / DeblockingFunc without a cast
  * (codec/encoder/core/inc/wels_func_ptr_def.h:58-188, codec/common/inc/mc.h:40-53; SURVEY.md 8b "signatures a C-ABI replacement must
  * export (leaf level)").  integration/welship_hooks.cpp installs them with WELS_HIP_LEAVES=1 (static_asserts there tie every export
  * to its typedef) and tests/test_leaf_gpu.py runs the unmodified encoder loop on top of them against the reference's C functions.
@@ -127,6 +127,31 @@ void WelsHipDeblockChromaLt4V (uint8_t* pPixCb, uint8_t* pPixCr, int32_t iStride
 void WelsHipDeblockChromaEq4V (uint8_t* pPixCb, uint8_t* pPixCr, int32_t iStride, int32_t iAlpha, int32_t iBeta);
 void WelsHipDeblockChromaLt4H (uint8_t* pPixCb, uint8_t* pPixCr, int32_t iStride, int32_t iAlpha, int32_t iBeta, int8_t* pTc);
 void WelsHipDeblockChromaEq4H (uint8_t* pPixCb, uint8_t* pPixCr, int32_t iStride, int32_t iAlpha, int32_t iBeta);
+
+/* ---- PCopyFunc (wels_func_ptr_def.h:61, slots :238-245: pfCopy16x16Aligned, pfCopy16x16NotAligned, pfCopy8x8Aligned, pfCopy16x8NotAligned,
+ * pfCopy8x16Aligned, pfCopy4x4, pfCopy8x4, pfCopy4x8; copy_mb.cpp:48-111) and PSetMemoryZero (:58, slots :285-287: pfSetMemZeroSize8,
+ * pfSetMemZeroSize64Aligned16, pfSetMemZeroSize64; copy_mb.cpp:38-46) */
+void WelsHipCopy4x4 (uint8_t* pDst, int32_t iStrideD, uint8_t* pSrc, int32_t iStrideS);
+void WelsHipCopy8x4 (uint8_t* pDst, int32_t iStrideD, uint8_t* pSrc, int32_t iStrideS);
+void WelsHipCopy4x8 (uint8_t* pDst, int32_t iStrideD, uint8_t* pSrc, int32_t iStrideS);
+void WelsHipCopy8x8 (uint8_t* pDst, int32_t iStrideD, uint8_t* pSrc, int32_t iStrideS);
+void WelsHipCopy16x8 (uint8_t* pDst, int32_t iStrideD, uint8_t* pSrc, int32_t iStrideS);
+void WelsHipCopy8x16 (uint8_t* pDst, int32_t iStrideD, uint8_t* pSrc, int32_t iStrideS);
+void WelsHipCopy16x16 (uint8_t* pDst, int32_t iStrideD, uint8_t* pSrc, int32_t iStrideS);
+void WelsHipSetMemZero (void* pDst, int32_t iSize);
+
+/* ---- PIntraPred4x4Combined3Func / PIntraPred16x16Combined3Func / PIntraPred8x8Combined3Func (wels_func_ptr_def.h:129-133; slots :166-170
+ * pfIntra4x4Combined3Satd, pfIntra16x16Combined3Satd / Sad, pfIntra8x8Combined3Satd / Sad, from which InitIntraAnalysisVaaInfo / the complexity
+ * mode pick :174-176).  The reference's C build leaves these slots NULL (sample.cpp:363-367); its `_c` functions (sample.cpp:153-331) are what
+ * the exports restate: V / H / DC of a block predicted and costed in one call, the best mode and cost returned. */
+int32_t WelsHipIntra4x4Combined3Satd (uint8_t* pDec, int32_t iDecStride, uint8_t* pEnc, int32_t iEncStride, uint8_t* pDst, int32_t* pBestMode,
+                                     int32_t iLambda2, int32_t iLambda1, int32_t iLambda0);
+int32_t WelsHipIntra16x16Combined3Satd (uint8_t* pDec, int32_t iDecStride, uint8_t* pEnc, int32_t iEncStride, int32_t* pBestMode, int32_t iLambda, uint8_t* pDst);
+int32_t WelsHipIntra16x16Combined3Sad (uint8_t* pDec, int32_t iDecStride, uint8_t* pEnc, int32_t iEncStride, int32_t* pBestMode, int32_t iLambda, uint8_t* pDst);
+int32_t WelsHipIntra8x8Combined3Satd (uint8_t* pDecCb, int32_t iDecStride, uint8_t* pEncCb, int32_t iEncStride, int32_t* pBestMode, int32_t iLambda,
+                                     uint8_t* pDstChroma, uint8_t* pDecCr, uint8_t* pEncCr);
+int32_t WelsHipIntra8x8Combined3Sad (uint8_t* pDecCb, int32_t iDecStride, uint8_t* pEncCb, int32_t iEncStride, int32_t* pBestMode, int32_t iLambda,
+                                    uint8_t* pDstChroma, uint8_t* pDecCr, uint8_t* pEncCr);
 
 #ifdef __cplusplus
 }

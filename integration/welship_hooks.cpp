@@ -40,6 +40,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <stdarg.h>
 #include <chrono>
 #include <map>
 #include <mutex>
@@ -267,6 +268,7 @@ bool EnsureLayerCtx (HipState* st, sWelsEncCtx* pCtx, int did) {
   L.num_pictures = cfg.iNumPictures;
   const int rc = g_api.FrameCtxCreate (&L.ctx, &cfg);
   if (rc) { fprintf (stderr, "welship hooks: no device context (%d: %s)\n", rc, g_api.GetLastError()); st->failed = true; return false; }
+  if (st->trace) fprintf (stderr, "welship hooks: device context of layer %d created (%dx%d, %d pictures)\n", did, cfg.iPicWidth, cfg.iPicHeight, cfg.iNumPictures);
   return true;
 }
 
@@ -847,7 +849,10 @@ void HipRelease (void* p) {
   if (st->check_bits && st->trace) fprintf (stderr, "welship hooks: CAVLC bit counts of %ld macroblocks equal the writer's\n", st->bits_checked.load());
   if (st->timing && st->pictures) fprintf (stderr, "welship hooks: %d pictures; per picture: device call %.3f ms, reconstruction copy-back %.3f ms, slice coding from the records %.3f ms, pre-analysis call %.3f ms, down-sampling calls %.3f ms\n",
                                            st->pictures, 1e3 * st->t_encode / st->pictures, 1e3 * st->t_getpic / st->pictures, 1e3 * st->t_code / st->pictures, 1e3 * st->t_vaa / st->pictures, 1e3 * st->t_down / st->pictures);
-  for (int i = 0; i < MAX_DEPENDENCY_LAYER; ++i) if (st->layer[i].ctx) g_api.FrameCtxDestroy (st->layer[i].ctx);
+  for (int i = 0; i < MAX_DEPENDENCY_LAYER; ++i) if (st->layer[i].ctx) {
+    g_api.FrameCtxDestroy (st->layer[i].ctx);
+    if (st->trace) fprintf (stderr, "welship hooks: device context of layer %d released\n", i);
+  }
   delete st;
 }
 
@@ -942,6 +947,17 @@ int InstallLeaves (SWelsFuncPtrList* fl, const char** why) {
   LEAF (db.pfLumaDeblockingLT4Hor, WelsHipDeblockLumaLt4H); LEAF (db.pfLumaDeblockingEQ4Hor, WelsHipDeblockLumaEq4H);
   LEAF (db.pfChromaDeblockingLT4Ver, WelsHipDeblockChromaLt4V); LEAF (db.pfChromaDeblockingEQ4Ver, WelsHipDeblockChromaEq4V);
   LEAF (db.pfChromaDeblockingLT4Hor, WelsHipDeblockChromaLt4H); LEAF (db.pfChromaDeblockingEQ4Hor, WelsHipDeblockChromaEq4H);
+  LEAF (fl->pfCopy16x16Aligned, WelsHipCopy16x16); LEAF (fl->pfCopy16x16NotAligned, WelsHipCopy16x16); LEAF (fl->pfCopy8x8Aligned, WelsHipCopy8x8);
+  LEAF (fl->pfCopy16x8NotAligned, WelsHipCopy16x8); LEAF (fl->pfCopy8x16Aligned, WelsHipCopy8x16);
+  LEAF (fl->pfCopy4x4, WelsHipCopy4x4); LEAF (fl->pfCopy8x4, WelsHipCopy8x4); LEAF (fl->pfCopy4x8, WelsHipCopy4x8);
+  LEAF (fl->pfSetMemZeroSize8, WelsHipSetMemZero); LEAF (fl->pfSetMemZeroSize64Aligned16, WelsHipSetMemZero); LEAF (fl->pfSetMemZeroSize64, WelsHipSetMemZero);
+  // the Combined3 slots are NULL in the C build (sample.cpp:363-367); with WELS_HIP_LEAVES=2 they are filled as a SIMD build fills them, and
+  // mode decision then takes its combined paths (svc_base_layer_md.cpp:380, :474, :885) -- same decisions, so the same bitstream
+  if (atoi (getenv ("WELS_HIP_LEAVES")) >= 2) {
+    LEAF (sd.pfIntra4x4Combined3Satd, WelsHipIntra4x4Combined3Satd);
+    LEAF (sd.pfIntra16x16Combined3Satd, WelsHipIntra16x16Combined3Satd); LEAF (sd.pfIntra16x16Combined3Sad, WelsHipIntra16x16Combined3Sad);
+    LEAF (sd.pfIntra8x8Combined3Satd, WelsHipIntra8x8Combined3Satd); LEAF (sd.pfIntra8x8Combined3Sad, WelsHipIntra8x8Combined3Sad);
+  }
 #undef LEAF_BLOCK
 #undef LEAF
   if (missing) { *why = "libwelship.so lacks some leaf exports"; return -missing; }
@@ -951,7 +967,19 @@ int InstallLeaves (SWelsFuncPtrList* fl, const char** why) {
 }  // namespace
 
 // The installer: what an `#if defined(X86_ASM)` block is for the SIMD variants (encoder.cpp:157-232).
-void WelsHipInstall (SWelsFuncPtrList* pFuncList, SWelsSvcCodingParam* pParam) {
+// What it decided goes to the encoder's own log (WelsLog, WELS_LOG_INFO: the application's trace callback / ENCODER_OPTION_TRACE_LEVEL decide
+// whether anybody sees it, welsCodecTrace.h:42-62) -- an application can find out whether its encoder runs on the device -- and, with
+// WELS_HIP_TRACE set, to stderr as before.
+static void Report (SLogContext* pLogCtx, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start (ap, fmt);
+  vsnprintf (buf, sizeof (buf), fmt, ap);
+  va_end (ap);
+  if (pLogCtx) WelsLog (pLogCtx, WELS_LOG_INFO, "welship hooks: %s", buf);
+  if (getenv ("WELS_HIP_TRACE")) fprintf (stderr, "welship hooks: %s\n", buf);
+}
+void WelsHipInstall (SWelsFuncPtrList* pFuncList, SWelsSvcCodingParam* pParam, SLogContext* pLogCtx) {
   pFuncList->pfHipFrameMd = NULL;
   pFuncList->pfHipCodeSlice = NULL;
   pFuncList->pfHipRelease = NULL;
@@ -961,25 +989,21 @@ void WelsHipInstall (SWelsFuncPtrList* pFuncList, SWelsSvcCodingParam* pParam) {
   pFuncList->pfHipBgd = NULL;
   pFuncList->pHipState = NULL;
   const char* off = getenv ("WELS_HIP");
-  if (off && atoi (off) == 0) return;
+  if (off && atoi (off) == 0) { Report (pLogCtx, "not installed (WELS_HIP=0)"); return; }
   const char* why = "";
   if (getenv ("WELS_HIP_LEAVES") && atoi (getenv ("WELS_HIP_LEAVES")) != 0) {
     // the leaf level instead of the frame level: the slots are written before any encoder thread exists; a partial table is refused
     // by taking the process down (the slots already written cannot be told from the C ones afterwards)
     const int n = InstallLeaves (pFuncList, &why);
     if (n < 0) { fprintf (stderr, "welship hooks: leaf functions: %s (%d missing)\n", why, -n); abort(); }
-    if (getenv ("WELS_HIP_TRACE")) {
-      if (n > 0) fprintf (stderr, "welship hooks: %d leaf functions installed (frame-level hooks off)\n", n);
-      else fprintf (stderr, "welship hooks: leaf functions not installed (%s)\n", why);
-    }
+    if (n > 0) Report (pLogCtx, "%d leaf functions installed (frame-level hooks off)", n);
+    else Report (pLogCtx, "leaf functions not installed (%s)", why);
     return;
   }
-  if (!WelsHipSupported (pParam, &why)) {
-    if (getenv ("WELS_HIP_TRACE")) fprintf (stderr, "welship hooks: not installed (%s)\n", why);
-    return;
-  }
+  if (!WelsHipSupported (pParam, &why)) { Report (pLogCtx, "not installed (%s)", why); return; }
   if (!LoadApi()) {
-    if (getenv ("WELS_HIP_TRACE")) fprintf (stderr, "welship hooks: not installed (libwelship.so not loadable: %s)\n", dlerror() ? dlerror() : "missing symbols");
+    const char* e = dlerror();
+    Report (pLogCtx, "not installed (libwelship.so not loadable: %s)", e ? e : "missing symbols");
     return;
   }
   HipState* st = new HipState();
@@ -1006,7 +1030,7 @@ void WelsHipInstall (SWelsFuncPtrList* pFuncList, SWelsSvcCodingParam* pParam) {
   pFuncList->pfHipVaaCalc = HipVaaCalc;
   pFuncList->pfHipFetchRecon = HipFetchRecon;
   pFuncList->pfHipBgd = HipBgd;
-  if (st->trace) fprintf (stderr, "welship hooks: installed\n");
+  Report (pLogCtx, "installed (device %d, %d spatial layer(s), %s)", st->device, pParam->iSpatialLayerNum, pParam->iUsageType == SCREEN_CONTENT_REAL_TIME ? "screen content" : "camera video");
 }
 
 }  // namespace WelsEnc

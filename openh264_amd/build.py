@@ -6,8 +6,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "openh264_amd", "csrc")
 HOST_SRCS = [os.path.join(CSRC, "host", f) for f in ("encoder.cpp", "entropy_cavlc.cpp", "headers.cpp")]
-HIP_SRCS = [os.path.join(CSRC, "hip", "hip_backend.hip"), os.path.join(CSRC, "hip", "prims.hip"), os.path.join(CSRC, "hip", "downsample.hip"),
-            os.path.join(CSRC, "hip", "leaf.hip")]
+# (csrc/hip/leaf.hip is the second half of prims.hip's translation unit: the kernels both layers launch are compiled once)
+HIP_SRCS = [os.path.join(CSRC, "hip", "hip_backend.hip"), os.path.join(CSRC, "hip", "prims.hip"), os.path.join(CSRC, "hip", "downsample.hip")]
 LIB = os.path.join(ROOT, "openh264_amd", "libwelship.so")
 EMU_LIB = os.path.join(ROOT, "tests", "emu", "libwelship_emu.so")
 
@@ -24,6 +24,32 @@ def _newer(target, deps):
     return False
 
 
+class _locked:
+    """One builder at a time per output file (pytest -n runs the session fixtures of several workers at once): an exclusive lock on <out>.lock;
+    the compiler writes <out>.tmp.<pid>, which is renamed over <out> only when it is complete -- nobody ever maps a half-written library."""
+    def __init__(self, out):
+        self.out = out
+
+    def __enter__(self):
+        import fcntl
+        self.f = open(self.out + ".lock", "w")
+        fcntl.flock(self.f, fcntl.LOCK_EX)
+        return self.out + ".tmp.%d" % os.getpid()
+
+    def __exit__(self, et, ev, tb):
+        import fcntl
+        tmp = self.out + ".tmp.%d" % os.getpid()
+        try:
+            if et is None and os.path.exists(tmp):
+                os.replace(tmp, self.out)
+            elif os.path.exists(tmp):
+                os.remove(tmp)
+        finally:
+            fcntl.flock(self.f, fcntl.LOCK_UN)
+            self.f.close()
+        return False
+
+
 def build_hip(force=False, verbose=True, defines=(), tag="", flags=()):
     """hipcc --offload-arch=gfx950 (cross-compiles without a GPU).
     `defines` + `tag`: a second library (libwelship_<tag>.so) with candidate code paths switched on, for A/B runs on the
@@ -34,11 +60,14 @@ def build_hip(force=False, verbose=True, defines=(), tag="", flags=()):
     if not force and not _newer(out, deps):
         return out
     # NB: no v_ashr_pk_u8_i32 may appear in the device code (see wh_clip255 in csrc/kernels/wave.h): tests/test_abi.py checks the listing.
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17"] + ["-D" + d for d in defines] + list(flags) + ["-fPIC", "-shared", "-Wno-unused-function",
-           "-Wno-unused-variable", "-o", out] + HIP_SRCS + HOST_SRCS
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd, cwd=ROOT)
+    with _locked(out) as tmp:
+        if not force and not _newer(out, deps):          # (another process built it while this one waited for the lock)
+            return out
+        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17"] + ["-D" + d for d in defines] + list(flags) + ["-fPIC", "-shared", "-Wno-unused-function",
+               "-Wno-unused-variable", "-o", tmp] + HIP_SRCS + HOST_SRCS
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd, cwd=ROOT)
     return out
 
 
@@ -49,11 +78,14 @@ def build_emu(force=False, verbose=False, defines=(), tag=""):
     deps = [CSRC, os.path.join(ROOT, "tests", "emu", "emu_backend.cpp")]
     if not force and not _newer(out, deps):
         return out
-    cmd = ["g++", "-O2", "-std=c++17", "-DWH_EMU"] + ["-D" + d for d in defines] + ["-fPIC", "-shared", "-Wno-unused-function", "-Wno-unused-variable",
-           "-o", out, os.path.join(ROOT, "tests", "emu", "emu_backend.cpp")] + HOST_SRCS
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd, cwd=ROOT)
+    with _locked(out) as tmp:
+        if not force and not _newer(out, deps):
+            return out
+        cmd = ["g++", "-O2", "-std=c++17", "-DWH_EMU"] + ["-D" + d for d in defines] + ["-fPIC", "-shared", "-Wno-unused-function", "-Wno-unused-variable",
+               "-o", tmp, os.path.join(ROOT, "tests", "emu", "emu_backend.cpp")] + HOST_SRCS
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd, cwd=ROOT)
     return out
 
 

@@ -13,10 +13,10 @@
 // context) -- for deblocking, of the whole picture.  Visiting the MBs of a range [first,last) sorted by
 // (x + 2*(y - y_first), y) is a topological order of that graph in which consecutive MBs are independent of each
 // other as far as possible (they lie on one 2:1 diagonal), so waves that take MBs from the list in order rarely wait.
-// `band` > 0 (an experiment knob, WELSHIP_MB_BAND): the rows are taken in bands of that many rows, each band in its own
-// 2:1 diagonal order -- still a topological order (a band only depends on the bands above it); the horizontally adjacent MB
-// then follows `band` list entries later instead of one full-height diagonal later, which shortens the L2 reuse distance
-// of the overlapping reference windows.
+// `band` > 0: the rows are taken in bands of that many rows, each band in its own 2:1 diagonal order -- still a topological order (a band
+// only depends on the bands above it).  Its one user is GOM-level rate control inside the kernel: a group of macroblock rows
+// is a band, so that a group is complete before the next one starts.  (Rounds 1-4 also had it as an experiment knob for the L2 reuse
+// distance of the search windows, WELSHIP_MB_BAND: no gain, removed in round 5.)
 WH_ORDER_FN void wh_build_mb_order (int mb_w, int first, int last, uint16_t* out /* last - first entries */, int band = 0) {
   const int y0 = first / mb_w, y1 = (last - 1) / mb_w;
   if (band <= 0) band = y1 - y0 + 1;

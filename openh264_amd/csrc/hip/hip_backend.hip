@@ -737,12 +737,21 @@ class HipBackend : public wh::Backend {
     if (nw > par) nw = par;
     while (nw > 1 && (size_t)nw * lds_per_wave + sched_bytes + static_lds > (size_t)160 * 1024) --nw;
     const size_t lds = (size_t)nw * lds_per_wave + sched_bytes;
-    HIP_TRY (hipFuncSetAttribute ((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (getenv ("WELSHIP_TRACE")) { fprintf (stderr, "welship: launch grid %d x %d, %d waves, %zu B LDS, max_n %d\n", whole_picture ? 1 : P.num_slices, n, nw, lds, max_n); fflush (stderr); }
+    set_dynamic_lds ((const void*)kernel, lds);
+    if (trace_) { fprintf (stderr, "welship: launch grid %d x %d, %d waves, %zu B LDS, max_n %d\n", whole_picture ? 1 : P.num_slices, n, nw, lds, max_n); fflush (stderr); }
     hipLaunchKernelGGL (kernel, dim3 (bands > 0 ? bands : whole_picture ? 1 : P.num_slices, n), dim3 (nw * 64), lds, stream_, P, jobs, err_words());
     HIP_TRY (hipGetLastError());
-    if (getenv ("WELSHIP_TRACE")) { HIP_TRY (hipStreamSynchronize (stream_)); fprintf (stderr, "welship: launch done\n"); fflush (stderr); }
+    if (trace_) { HIP_TRY (hipStreamSynchronize (stream_)); fprintf (stderr, "welship: launch done\n"); fflush (stderr); }
   }
+  // The dynamic-LDS limit of a kernel is raised once per size it has not had yet, and whether launches are traced is read when the backend is
+  // made -- not a driver call and two getenv per launch (round-5 review: they sit on the latency path of a single session).
+  void set_dynamic_lds (const void* kernel, size_t lds) {
+    for (auto& e : lds_attr_) if (e.first == kernel) { if (lds > e.second) { HIP_TRY (hipFuncSetAttribute (kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); e.second = lds; } return; }
+    HIP_TRY (hipFuncSetAttribute (kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    lds_attr_.push_back ({kernel, lds});
+  }
+  std::vector<std::pair<const void*, size_t>> lds_attr_;
+  const bool trace_ = getenv ("WELSHIP_TRACE") != nullptr;
   // I pictures: one workgroup per slice.  Few slices in flight (the latency regime, or an all-intra stream of a few sessions): 16 waves each, every
   // macroblock the wavefront has ready gets a wave.  Enough slices to give every CU two: 12 waves each -- a slice has at most ~17 macroblocks
   // ready at a time and a wave that holds a ticket waits for its neighbours, so sixteen waves idled a quarter of their time (32 k of 141 k
@@ -805,11 +814,11 @@ class HipBackend : public wh::Backend {
     }
     const WhSeqParams& Pr = P;
     auto launch = [&] (auto kernel) {
-      HIP_TRY (hipFuncSetAttribute ((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      if (getenv ("WELSHIP_TRACE")) { fprintf (stderr, "welship: MD launch %d groups x %d slots, %d waves, %zu B dynamic LDS\n", groups, slots, nw, lds); fflush (stderr); }
+      set_dynamic_lds ((const void*)kernel, lds);
+      if (trace_) { fprintf (stderr, "welship: MD launch %d groups x %d slots, %d waves, %zu B dynamic LDS\n", groups, slots, nw, lds); fflush (stderr); }
       hipLaunchKernelGGL (kernel, dim3 (groups), dim3 (nw * 64), lds, stream_, Pr, jobs, err_words(), (const uint16_t*)grp, slots, sched_words, total, cost);
       HIP_TRY (hipGetLastError());
-      if (getenv ("WELSHIP_TRACE")) { HIP_TRY (hipStreamSynchronize (stream_)); fprintf (stderr, "welship: launch done\n"); fflush (stderr); }
+      if (trace_) { HIP_TRY (hipStreamSynchronize (stream_)); fprintf (stderr, "welship: launch done\n"); fflush (stderr); }
     };
     if (P.flags & WH_SEQ_SCC) launch (k_inter_pool<384, true>);      // (nw <= 6 above: 249 VGPRs, no scratch; a 12-wave build of this variant spills -- 168 VGPRs + 360 B -- and is not instantiated any more)
 #define WH_LAUNCH_POOL(VARIANT) do { if (nw <= 6) launch (k_inter_pool<384, false, VARIANT>); else if (nw <= 12) launch (k_inter_pool<768, false, VARIANT>); \
@@ -893,7 +902,7 @@ class HipBackend : public wh::Backend {
     if (!cur || !ref || !sad8x8 || !sd8x8 || !mad8x8 || !flags) { note_null(); return; }
     const WhBgdIn in = {sad8x8, sd8x8, mad8x8, cur, ref, units_w, units_h, P.mb_w};
     const size_t lds = (size_t)units_w * units_h;
-    HIP_TRY (hipFuncSetAttribute ((const void*)k_bgd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    set_dynamic_lds ((const void*)k_bgd, lds);
     hipLaunchKernelGGL (k_bgd, dim3 (1), dim3 (256), lds, stream_, in, flags);
     HIP_TRY (hipGetLastError());
   }

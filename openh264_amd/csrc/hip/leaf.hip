@@ -19,10 +19,12 @@
 #include "../kernels/mc_px.h"
 #include "../kernels/deblock_mb.h"
 
+// This file is the second half of prims.hip's translation unit (prims.hip includes it at its end): both layers launch the kernels of
+// prims_kernels.h, which are therefore compiled ONCE (rounds 4-5: two translation units, every one of those kernels twice in the code object).
+#ifndef WH_PRIMS_TU
+#error "leaf.hip is compiled as part of prims.hip"
+#endif
 namespace {
-
-inline int grid (int n) { return (n + 255) / 256; }
-#include "prims_kernels.h"
 
 [[noreturn]] void die (const char* what, hipError_t e) {
   fprintf (stderr, "welship leaf primitive: %s failed: %s -- no CPU fallback, aborting\n", what, hipGetErrorString (e));
@@ -361,6 +363,33 @@ void deblock_family (uint8_t* p0, uint8_t* p1, int st, int alpha, int beta, cons
 
 }  // namespace
 
+// pfCopy* (copy_mb.cpp:48-111): w x h samples from one plane to another.  The device moves them (dwords where both rows allow it are not worth a
+// second kernel: these are 16 .. 256 bytes).
+__global__ void k_leaf_copy (const uint8_t* src, int sp, int w, int h, uint8_t* dst) {
+  for (int i = (int)threadIdx.x; i < w * h; i += (int)blockDim.x) { const int y = i / w, x = i - y * w; dst[i] = src[y * sp + x]; }
+}
+void copy_family (uint8_t* dst, int ds, const uint8_t* src, int ss, int w, int h) {
+  Call c;
+  const Rect rs = c.rect (src, ss, 0, 0, w, h);
+  const size_t dout = c.raw (nullptr, (size_t)w * h);
+  c.out (dout, (size_t)w * h);
+  LAUNCH (c, k_leaf_copy, 1, 256, c.dev<uint8_t> (rs.origin), rs.pitch, w, h, c.dev<uint8_t> (dout));
+  for (int y = 0; y < h; ++y) memcpy (dst + (ptrdiff_t)y * ds, c.host<uint8_t> (dout) + y * w, (size_t)w);
+}
+// pfSetMemZero* (copy_mb.cpp:38-46 WelsSetMemZero_c): the zeros come from the device too, a piece of the arena at a time
+__global__ void k_leaf_zero (uint32_t* d, int words) { for (int i = (int)threadIdx.x; i < words; i += (int)blockDim.x) d[i] = 0u; }
+void zero_family (uint8_t* dst, int size) {
+  while (size > 0) {
+    Call c;
+    const int n = size < (int) (kArenaBytes / 2) ? size : (int) (kArenaBytes / 2);
+    const size_t dout = c.raw (dst, (size_t)n);          // (uploaded as it is: only the device's zeros come back)
+    c.out (dout, (size_t)n);
+    LAUNCH (c, k_leaf_zero, 1, 256, c.dev<uint32_t> (dout), (n + 3) / 4);
+    memcpy (dst, c.host<uint8_t> (dout), (size_t)n);
+    dst += n; size -= n;
+  }
+}
+
 extern "C" {
 
 int WelsHipLeafAvailable (void) { int n = 0; return hipGetDeviceCount (&n) == hipSuccess && n > 0 ? WELSHIP_OK : WELSHIP_ERR_NO_DEVICE; }
@@ -433,5 +462,64 @@ void WelsHipDeblockChromaLt4V (uint8_t* pPixCb, uint8_t* pPixCr, int32_t iStride
 void WelsHipDeblockChromaEq4V (uint8_t* pPixCb, uint8_t* pPixCr, int32_t iStride, int32_t iAlpha, int32_t iBeta) { deblock_family (pPixCb, pPixCr, iStride, iAlpha, iBeta, nullptr, 1, 1, 0); }
 void WelsHipDeblockChromaLt4H (uint8_t* pPixCb, uint8_t* pPixCr, int32_t iStride, int32_t iAlpha, int32_t iBeta, int8_t* pTc) { deblock_family (pPixCb, pPixCr, iStride, iAlpha, iBeta, pTc, 1, 0, 1); }
 void WelsHipDeblockChromaEq4H (uint8_t* pPixCb, uint8_t* pPixCr, int32_t iStride, int32_t iAlpha, int32_t iBeta) { deblock_family (pPixCb, pPixCr, iStride, iAlpha, iBeta, nullptr, 1, 1, 1); }
+
+
+// PCopyFunc pfCopy16x16Aligned / pfCopy16x16NotAligned / pfCopy8x8Aligned / pfCopy16x8NotAligned / pfCopy8x16Aligned / pfCopy4x4 / pfCopy8x4 / pfCopy4x8
+// (wels_func_ptr_def.h:238-245; copy_mb.cpp:48-111), PSetMemoryZero pfSetMemZeroSize8 / ..Size64Aligned16 / ..Size64 (:285-287; copy_mb.cpp:38-46)
+#define COPY_SLOT(name, w, h) void WelsHipCopy##name (uint8_t* pDst, int32_t iStrideD, uint8_t* pSrc, int32_t iStrideS) { copy_family (pDst, iStrideD, pSrc, iStrideS, w, h); }
+COPY_SLOT (4x4, 4, 4) COPY_SLOT (8x4, 8, 4) COPY_SLOT (4x8, 4, 8) COPY_SLOT (8x8, 8, 8) COPY_SLOT (16x8, 16, 8) COPY_SLOT (8x16, 8, 16) COPY_SLOT (16x16, 16, 16)
+void WelsHipSetMemZero (void* pDst, int32_t iSize) { zero_family ((uint8_t*)pDst, iSize); }
+
+// PIntraPred*Combined3Func (wels_func_ptr_def.h:129-133, slots :166-176; sample.cpp:153-331): the three cheapest intra modes of a block costed in
+// one call.  NULL in the reference's C build (sample.cpp:363-367: only the SIMD builds fill them); here each is the reference's `_c` text over
+// the device-backed predictors and costs above -- same order of the candidates, same tie-breaking (`<`), same bytes left in the caller's buffers.
+int32_t WelsHipIntra4x4Combined3Satd (uint8_t* pDec, int32_t iDecStride, uint8_t* pEnc, int32_t iEncStride, uint8_t* pDst, int32_t* pBestMode,
+                                     int32_t iLambda2, int32_t iLambda1, int32_t iLambda0) {
+  uint8_t buf[3][16];
+  int32_t best_mode = -1, best = 0x7fffffff, cur;
+  WelsHipI4x4LumaPredDc (buf[2], pDec, iDecStride);
+  cur = WelsHipSampleSatd4x4 (buf[2], 4, pEnc, iEncStride) + iLambda2; if (cur < best) { best_mode = 2; best = cur; }
+  WelsHipI4x4LumaPredH (buf[1], pDec, iDecStride);
+  cur = WelsHipSampleSatd4x4 (buf[1], 4, pEnc, iEncStride) + iLambda1; if (cur < best) { best_mode = 1; best = cur; }
+  WelsHipI4x4LumaPredV (buf[0], pDec, iDecStride);
+  cur = WelsHipSampleSatd4x4 (buf[0], 4, pEnc, iEncStride) + iLambda0; if (cur < best) { best_mode = 0; best = cur; }
+  memcpy (pDst, buf[best_mode], 16);
+  *pBestMode = best_mode;
+  return best;
+}
+static int32_t combined3_16 (bool satd, uint8_t* pDec, int32_t iDecStride, uint8_t* pEnc, int32_t iEncStride, int32_t* pBestMode, int32_t iLambda, uint8_t* pDst) {
+  int32_t best_mode = -1, best = 0x7fffffff, cur;
+  auto cost = [&] () { return satd ? WelsHipSampleSatd16x16 (pDst, 16, pEnc, iEncStride) : WelsHipSampleSad16x16 (pDst, 16, pEnc, iEncStride); };
+  WelsHipI16x16LumaPredV (pDst, pDec, iDecStride);  cur = cost();               if (cur < best) { best_mode = 0; best = cur; }
+  WelsHipI16x16LumaPredH (pDst, pDec, iDecStride);  cur = cost() + iLambda * 2; if (cur < best) { best_mode = 1; best = cur; }
+  WelsHipI16x16LumaPredDc (pDst, pDec, iDecStride); cur = cost() + iLambda * 2; if (cur < best) { best_mode = 2; best = cur; }
+  *pBestMode = best_mode;
+  return best;
+}
+int32_t WelsHipIntra16x16Combined3Satd (uint8_t* pDec, int32_t iDecStride, uint8_t* pEnc, int32_t iEncStride, int32_t* pBestMode, int32_t iLambda, uint8_t* pDst) {
+  return combined3_16 (true, pDec, iDecStride, pEnc, iEncStride, pBestMode, iLambda, pDst);
+}
+int32_t WelsHipIntra16x16Combined3Sad (uint8_t* pDec, int32_t iDecStride, uint8_t* pEnc, int32_t iEncStride, int32_t* pBestMode, int32_t iLambda, uint8_t* pDst) {
+  return combined3_16 (false, pDec, iDecStride, pEnc, iEncStride, pBestMode, iLambda, pDst);
+}
+static int32_t combined3_8 (bool satd, uint8_t* pDecCb, int32_t iDecStride, uint8_t* pEncCb, int32_t iEncStride, int32_t* pBestMode, int32_t iLambda,
+                            uint8_t* pDstChroma, uint8_t* pDecCr, uint8_t* pEncCr) {
+  int32_t best_mode = -1, best = 0x7fffffff, cur;
+  auto cost = [&] () { return satd ? WelsHipSampleSatd8x8 (pDstChroma, 8, pEncCb, iEncStride) + WelsHipSampleSatd8x8 (pDstChroma + 64, 8, pEncCr, iEncStride)
+                                   : WelsHipSampleSad8x8 (pDstChroma, 8, pEncCb, iEncStride) + WelsHipSampleSad8x8 (pDstChroma + 64, 8, pEncCr, iEncStride); };
+  WelsHipIChromaPredV (pDstChroma, pDecCb, iDecStride);  WelsHipIChromaPredV (pDstChroma + 64, pDecCr, iDecStride);  cur = cost() + iLambda * 2; if (cur < best) { best_mode = 2; best = cur; }
+  WelsHipIChromaPredH (pDstChroma, pDecCb, iDecStride);  WelsHipIChromaPredH (pDstChroma + 64, pDecCr, iDecStride);  cur = cost() + iLambda * 2; if (cur < best) { best_mode = 1; best = cur; }
+  WelsHipIChromaPredDc (pDstChroma, pDecCb, iDecStride); WelsHipIChromaPredDc (pDstChroma + 64, pDecCr, iDecStride); cur = cost();               if (cur < best) { best_mode = 0; best = cur; }
+  *pBestMode = best_mode;
+  return best;
+}
+int32_t WelsHipIntra8x8Combined3Satd (uint8_t* pDecCb, int32_t iDecStride, uint8_t* pEncCb, int32_t iEncStride, int32_t* pBestMode, int32_t iLambda,
+                                     uint8_t* pDstChroma, uint8_t* pDecCr, uint8_t* pEncCr) {
+  return combined3_8 (true, pDecCb, iDecStride, pEncCb, iEncStride, pBestMode, iLambda, pDstChroma, pDecCr, pEncCr);
+}
+int32_t WelsHipIntra8x8Combined3Sad (uint8_t* pDecCb, int32_t iDecStride, uint8_t* pEncCb, int32_t iEncStride, int32_t* pBestMode, int32_t iLambda,
+                                    uint8_t* pDstChroma, uint8_t* pDecCr, uint8_t* pEncCr) {
+  return combined3_8 (false, pDecCb, iDecStride, pEncCb, iEncStride, pBestMode, iLambda, pDstChroma, pDecCr, pEncCr);
+}
 
 }  // extern "C"

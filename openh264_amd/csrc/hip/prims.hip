@@ -130,3 +130,7 @@ int WelsHipPrimVaaSad8x8 (int nMb, const uint8_t* pCur, const uint8_t* pRef, siz
 }
 
 }  // extern "C"
+
+// layer (3c): the same kernels behind the reference's own function-pointer typedefs (include/welship_leaf.h)
+#define WH_PRIMS_TU 1
+#include "leaf.hip"

@@ -9,6 +9,7 @@
 // batched launch set per frame step covers all N pictures, which is how a single MI355X is filled
 // (independent sessions / simulcast layers / all-IDR frames have no mutual dependency).
 #include <string.h>
+#include <stddef.h>
 #include <condition_variable>
 #include <functional>
 #include <memory>
@@ -1731,19 +1732,26 @@ struct WelsHipFrameCtx {
   // The verdict of the last picture's deblocking pass / border expansion, at this context's next call (advisor finding, round 4: that pass runs
   // after the callers were released, and its time-out used to fail whichever launch set synchronised the queue next).  Waits for the pass
   // (normally long over: the caller has entropy-coded a picture meanwhile), reads the error words copied out behind it.  Called WITHOUT sh->mu.
-  int check_tail() {
+  // `intra`: the call codes an I picture, which predicts from nothing -- it clears a failure; until then the failure is reported to EVERY call
+  // on this context (slice tasks of a size-limited picture call concurrently: with a flag that the first caller consumed, the others coded
+  // against the bad reference -- advisor finding, round 5).  sh->mu is held throughout except around the wait itself.
+  int check_tail (bool intra) {
+    std::unique_lock<std::mutex> lock (sh->mu);
     if (tail_lane) {
       FrameLane* TL = tail_lane;
-      be->event_wait (TL->tail_done_ev[tail_slot]);
-      std::unique_lock<std::mutex> lock (sh->mu);
-      const uint32_t* e = TL->h_err_tail.data() + 4 * tail_slot;
-      if (tail_lane == TL) {             // (an error seen meanwhile on that queue has cleared the list and set tail_failed already)
+      const int slot = tail_slot;
+      void* ev = TL->tail_done_ev[slot];
+      lock.unlock();
+      be->event_wait (ev);
+      lock.lock();
+      const uint32_t* e = TL->h_err_tail.data() + 4 * slot;
+      if (tail_lane == TL && tail_slot == slot) {      // (an error seen meanwhile on that queue has cleared the list and set tail_failed already; a later tail re-armed the slot)
         if (e[0] | e[1] | e[2] | e[3]) { (void)be->sync_queue (TL->queue); TL->fail_tails(); }
         else { TL->tail_ctxs.erase (std::remove (TL->tail_ctxs.begin(), TL->tail_ctxs.end(), this), TL->tail_ctxs.end()); tail_lane = nullptr; }
       }
     }
-    if (tail_failed) { tail_failed = false; return 1; }
-    return 0;
+    if (tail_failed && intra) tail_failed = false;
+    return tail_failed ? 1 : 0;
   }
   uint32_t* d_dbflags = nullptr;
   uint32_t db_gen = 0;
@@ -2147,9 +2155,16 @@ void WelsHipFrameCtxDestroy (WelsHipFrameCtx* c) {
   }
 }
 
+static_assert (sizeof (WelsHipFrameJob) >= WELSHIP_FRAMEJOB_MIN_SIZE && offsetof (WelsHipFrameJob, pbRecordsPacked) + sizeof (int32_t*) == WELSHIP_FRAMEJOB_MIN_SIZE,
+               "WelsHipFrameJob: fields are only appended behind pbRecordsPacked (include/welship.h, cbSize)");
 int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void** pp_records) {
   if (!c || !c->be || !j || !pp_records) return WELSHIP_ERR_INIT_PARA;
-  if (j->cbSize != sizeof (WelsHipFrameJob)) { set_err ("WelsHipFrameJob::cbSize is not this library's sizeof (WelsHipFrameJob): the caller was built against another include/welship.h"); return WELSHIP_ERR_INIT_PARA; }
+  if (j->cbSize < WELSHIP_FRAMEJOB_MIN_SIZE || j->cbSize > sizeof (WelsHipFrameJob)) {
+    set_err ("WelsHipFrameJob::cbSize is outside [WELSHIP_FRAMEJOB_MIN_SIZE, this library's sizeof (WelsHipFrameJob)]: the caller was built against an include/welship.h this library cannot serve");
+    return WELSHIP_ERR_INIT_PARA;
+  }
+  WelsHipFrameJob older;       // a caller compiled against an older (shorter) header: the fields it does not know are zero = "not used"
+  if (j->cbSize != sizeof (WelsHipFrameJob)) { memset (&older, 0, sizeof (older)); memcpy (&older, j, j->cbSize); older.cbSize = (uint32_t)sizeof (older); j = &older; }
   if (j->bPackedRecords && !j->pbRecordsPacked) { set_err ("bPackedRecords without pbRecordsPacked: the caller could not tell which record format it got"); return WELSHIP_ERR_INIT_PARA; }
   if (j->pbRecordsPacked) *j->pbRecordsPacked = 0;
   const int np = (int)c->pics.size();
@@ -2183,7 +2198,7 @@ int WelsHipFrameEncode (WelsHipFrameCtx* c, const WelsHipFrameJob* j, const void
   const bool ranged_reenc = ranged && !retry && j->pReencode && j->iNumReencode > 0;
   // (a retry reuses what the first call of the picture uploaded: source, pre-analysis arrays, screen-content inputs)
   const bool first_part = !retry && (!ranged || (j->iMbBegin == 0 && !j->bRangeAgain)), last_part = !ranged || (dyn ? dyn_close : j->iMbEnd == c->num_mb);
-  if (c->check_tail()) { set_err ("the deblocking pass / border expansion of this context's previous picture timed out or failed on the device: its reconstruction is unusable (code an IDR picture)"); return WELSHIP_ERR_UNKNOWN; }
+  if (c->check_tail (!is_p)) { set_err ("the deblocking pass / border expansion of this context's previous picture timed out or failed on the device: its reconstruction is unusable (code an IDR picture)"); return WELSHIP_ERR_UNKNOWN; }
   FrameShared* sh = c->sh;
   wh::Backend* be = c->be;
   // host-side staging into this context's own page-locked buffers: outside the shared lock

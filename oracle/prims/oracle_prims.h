@@ -28,6 +28,7 @@ void    orc_hadamard_t4_dc (int16_t* luma_dc, const int16_t* dct256);
 void    orc_quant4x4 (int16_t* dct, int qp, int intra);
 int32_t orc_quant4x4_max (int16_t* dct, int qp, int intra);            /* returns the block's max |level| */
 void    orc_quant4x4_dc (int16_t* dct, int16_t ff, int16_t mf);
+void    orc_quant_rows (int qp, int intra, int16_t* ff8, int16_t* mf8);         /* the table rows the encoder passes to pfQuantization* */
 int32_t orc_hadamard_quant2x2 (int16_t* rs, int16_t ff, int16_t mf, int16_t* dct4, int16_t* block4);
 int32_t orc_hadamard_quant2x2_skip (const int16_t* rs, int16_t ff, int16_t mf);
 void    orc_scan4x4_dcac (int16_t* level, const int16_t* dct);

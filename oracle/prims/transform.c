@@ -58,6 +58,11 @@ int32_t orc_quant4x4_max (int16_t* d, int qp, int intra) {
   }
   return mx;
 }
+/* the rows of g_kiQuantInterFF[qp (+ 6 for intra)] / g_kiQuantMF[qp] (encode_mb_aux.cpp:39-157) as the encoder hands them to the quantiser
+ * slots: eight entries, positions 0..7 of a 4x4 block (the second half of the block repeats them) */
+void orc_quant_rows (int qp, int intra, int16_t* ff8, int16_t* mf8) {
+  for (int i = 0; i < 8; ++i) { ff8[i] = kQuantFF[(qp + (intra ? 6 : 0)) * 3 + pc (i)]; mf8[i] = kQuantMF[qp * 3 + pc (i)]; }
+}
 /* encode_mb_aux.cpp:180-192 WelsQuant4x4Dc_c */
 void orc_quant4x4_dc (int16_t* d, int16_t ff, int16_t mf) { for (int i = 0; i < 16; ++i) d[i] = q1 (d[i], ff, mf); }
 

@@ -39,6 +39,12 @@ static int run (int argc, char** argv, int instance) {
   int alpha = 0, beta = 0, crop = 1, forceidr = -1;
   int setidr_at = -1, setidr_val = 0, setcplx_at = -1, setcplx_val = 0, paramsets_at = -1, setfps_at = -1;
   float setfps_val = 30.f;
+  int trace_level = -1;
+  // re-configuration in mid-stream (welsEncoderExt.cpp:700-1100 SetOption; encoder_ext.cpp:4173 WelsEncoderParamAdjust): each before frame N
+  int setbr_at = -1, setbr_val = 0;                 // -setbr N BPS: ENCODER_OPTION_BITRATE (SPATIAL_LAYER_ALL)
+  int setres_at = -1, setres_w = 0, setres_h = 0;   // -setres N W H: ENCODER_OPTION_SVC_ENCODE_PARAM_EXT with another picture size; the input file holds W x H frames from frame N on
+  int setltr_at = -1, setltr_val = 0;               // -setltr N 0/1: ENCODER_OPTION_LTR
+  int ltrrecover_at = -1, ltrmarkfb_at = -1;        // -ltrrecover N / -ltrmarkfb N: ENCODER_LTR_RECOVERY_REQUEST / ENCODER_LTR_MARKING_FEEDBACK as a receiver would send them
   std::string infofile;                // -dumpinfo FILE: the SFrameBSInfo metadata of every frame, one line per layer
   int low_w = 0, low_h = 0;            // -simulcast W H: an extra, lower spatial layer, simulcast AVC (the input is the highest one);
   int lows[3][2] = {{0, 0}, {0, 0}, {0, 0}}, nlow = 0;     // may be given up to three times, lowest resolution first
@@ -89,6 +95,12 @@ static int run (int argc, char** argv, int instance) {
     else if (arg_eq (a, "-simulcast")) { low_w = std::atoi (next()); low_h = std::atoi (next()); if (nlow < 3) { lows[nlow][0] = low_w; lows[nlow][1] = low_h; ++nlow; } }
     else if (arg_eq (a, "-paramsets")) paramsets_at = std::atoi (next());       // EncodeParameterSets before frame N, output appended
     else if (arg_eq (a, "-quiet")) quiet = 1;
+    else if (arg_eq (a, "-setbr")) { setbr_at = std::atoi (next()); setbr_val = std::atoi (next()); }
+    else if (arg_eq (a, "-setres")) { setres_at = std::atoi (next()); setres_w = std::atoi (next()); setres_h = std::atoi (next()); }
+    else if (arg_eq (a, "-setltr")) { setltr_at = std::atoi (next()); setltr_val = std::atoi (next()); }
+    else if (arg_eq (a, "-ltrrecover")) ltrrecover_at = std::atoi (next());
+    else if (arg_eq (a, "-ltrmarkfb")) ltrmarkfb_at = std::atoi (next());
+    else if (arg_eq (a, "-tracelevel")) trace_level = std::atoi (next());      // ENCODER_OPTION_TRACE_LEVEL (WELS_LOG_INFO = 4): the encoder's own log on stderr
     else { std::fprintf (stderr, "unknown option %s\n", a); return 2; }
   }
   if (in.empty() || w <= 0 || h <= 0) { std::fprintf (stderr, "need -i -w -h\n"); return 2; }
@@ -96,7 +108,7 @@ static int run (int argc, char** argv, int instance) {
 
   ISVCEncoder* enc = NULL;
   if (WelsCreateSVCEncoder (&enc) || !enc) { std::fprintf (stderr, "WelsCreateSVCEncoder failed\n"); return 1; }
-  int trace = quiet ? WELS_LOG_QUIET : WELS_LOG_ERROR;
+  int trace = trace_level >= 0 ? trace_level : quiet ? WELS_LOG_QUIET : WELS_LOG_ERROR;
   enc->SetOption (ENCODER_OPTION_TRACE_LEVEL, &trace);
 
   int ret;
@@ -164,21 +176,45 @@ static int run (int argc, char** argv, int instance) {
   FILE* fi = std::fopen (in.c_str(), "rb");
   if (!fi) { std::fprintf (stderr, "cannot open %s\n", in.c_str()); return 1; }
   FILE* fo = out.empty() ? NULL : std::fopen (out.c_str(), "wb");
-  const size_t fsz = (size_t)w * h * 3 / 2;
+  size_t fsz = (size_t)w * h * 3 / 2;
   std::vector<unsigned char> buf (fsz);
+  int idr_pics = 0, frame_num = 0;     // what a receiver would know: IDR pictures so far, frame_num of the picture before (reference pictures only: one temporal layer assumed)
   SSourcePicture pic; std::memset (&pic, 0, sizeof (pic));
   pic.iColorFormat = videoFormatI420; pic.iPicWidth = w; pic.iPicHeight = h;
   pic.iStride[0] = w; pic.iStride[1] = pic.iStride[2] = w >> 1;
   pic.pData[0] = buf.data(); pic.pData[1] = buf.data() + (size_t)w * h; pic.pData[2] = pic.pData[1] + (size_t) (w >> 1) * (h >> 1);
   SFrameBSInfo info;
   long long total = 0; int n = 0; double secs = 0.0;
-  while ((frames < 0 || n < frames) && std::fread (buf.data(), 1, fsz, fi) == fsz) {
+  while (frames < 0 || n < frames) {
+    if (n == setres_at) {
+      SEncParamExt q; std::memset (&q, 0, sizeof (q));
+      if (enc->GetOption (ENCODER_OPTION_SVC_ENCODE_PARAM_EXT, &q)) { std::fprintf (stderr, "GetOption (SVC_ENCODE_PARAM_EXT) failed\n"); return 1; }
+      w = setres_w; h = setres_h;
+      q.iPicWidth = w; q.iPicHeight = h; q.sSpatialLayers[q.iSpatialLayerNum - 1].iVideoWidth = w; q.sSpatialLayers[q.iSpatialLayerNum - 1].iVideoHeight = h;
+      if (enc->SetOption (ENCODER_OPTION_SVC_ENCODE_PARAM_EXT, &q)) { std::fprintf (stderr, "SetOption (SVC_ENCODE_PARAM_EXT) failed\n"); return 1; }
+      fsz = (size_t)w * h * 3 / 2; buf.resize (fsz);       // the rest of the input file holds frames of the new size
+      pic.iPicWidth = w; pic.iPicHeight = h; pic.iStride[0] = w; pic.iStride[1] = pic.iStride[2] = w >> 1;
+      pic.pData[0] = buf.data(); pic.pData[1] = buf.data() + (size_t)w * h; pic.pData[2] = pic.pData[1] + (size_t) (w >> 1) * (h >> 1);
+    }
+    if (std::fread (buf.data(), 1, fsz, fi) != fsz) break;
     std::memset (&info, 0, sizeof (info));
     pic.uiTimeStamp = (long long) (n * (1000.0 / fps) + 0.5);
     if (n == forceidr) enc->ForceIntraFrame (true);
     if (n == setidr_at) enc->SetOption (ENCODER_OPTION_IDR_INTERVAL, &setidr_val);
     if (n == setcplx_at) enc->SetOption (ENCODER_OPTION_COMPLEXITY, &setcplx_val);
     if (n == setfps_at) enc->SetOption (ENCODER_OPTION_FRAME_RATE, &setfps_val);
+    if (n == setbr_at) { SBitrateInfo b; std::memset (&b, 0, sizeof (b)); b.iLayer = SPATIAL_LAYER_ALL; b.iBitrate = setbr_val; if (enc->SetOption (ENCODER_OPTION_BITRATE, &b)) { std::fprintf (stderr, "SetOption (BITRATE) failed\n"); return 1; } }
+    if (n == setltr_at) { SLTRConfig c; std::memset (&c, 0, sizeof (c)); c.bEnableLongTermReference = setltr_val != 0; c.iLTRRefNum = 2; enc->SetOption (ENCODER_OPTION_LTR, &c); }
+    if (n == ltrrecover_at) {
+      SLTRRecoverRequest r; std::memset (&r, 0, sizeof (r));
+      r.uiFeedbackType = LTR_RECOVERY_REQUEST; r.uiIDRPicId = (unsigned)(idr_pics > 0 ? idr_pics - 1 : 0); r.iLastCorrectFrameNum = frame_num > 1 ? frame_num - 2 : 0; r.iCurrentFrameNum = frame_num > 0 ? frame_num - 1 : 0;
+      enc->SetOption (ENCODER_LTR_RECOVERY_REQUEST, &r);
+    }
+    if (n == ltrmarkfb_at) {
+      SLTRMarkingFeedback f; std::memset (&f, 0, sizeof (f));
+      f.uiFeedbackType = LTR_MARKING_SUCCESS; f.uiIDRPicId = (unsigned)(idr_pics > 0 ? idr_pics - 1 : 0); f.iLTRFrameNum = frame_num > 0 ? frame_num - 1 : 0;
+      enc->SetOption (ENCODER_LTR_MARKING_FEEDBACK, &f);
+    }
     if (n == paramsets_at) {
       SFrameBSInfo ps; std::memset (&ps, 0, sizeof (ps));
       if (enc->EncodeParameterSets (&ps)) { std::fprintf (stderr, "EncodeParameterSets failed\n"); return 1; }
@@ -194,6 +230,8 @@ static int run (int argc, char** argv, int instance) {
     auto t1 = std::chrono::steady_clock::now();
     secs += std::chrono::duration<double> (t1 - t0).count();
     if (ret) { std::fprintf (stderr, "EncodeFrame failed: %d\n", ret); return 1; }
+    if (info.eFrameType == videoFrameTypeIDR) { ++idr_pics; frame_num = 1; }
+    else if (info.eFrameType == videoFrameTypeI || info.eFrameType == videoFrameTypeP) ++frame_num;
     if (!infofile.empty()) {
       FILE* fm = std::fopen (infofile.c_str(), n == 0 ? "w" : "a");
       std::fprintf (fm, "frame %d type %d layers %d size %d ts %lld\n", n, (int)info.eFrameType, info.iLayerNum, info.iFrameSizeInBytes, (long long)info.uiTimeStamp);

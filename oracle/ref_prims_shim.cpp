@@ -17,8 +17,10 @@
 #include "deblocking_common.h"
 #include "svc_encode_mb.h"
 #include "wels_common_defs.h"
+#include "copy_mb.h"
 
 using namespace WelsEnc;
+namespace WelsEnc { void WelsSetMemZero_c (void* pDst, int32_t iSize); }     // codec/encoder/core/inc/encoder.h:122
 namespace WelsVP {   // codec/processing/src/vaacalc/vaacalculation.h:85
 void VAACalcSad_c (const uint8_t* pCurData, const uint8_t* pRefData, int32_t iPicWidth, int32_t iPicHeight, int32_t iPicStride,
                    int32_t* pFrameSad, int32_t* pSad8x8);
@@ -121,5 +123,26 @@ void ref_downsample (int mode, uint8_t* dst, int32_t dst_stride, int32_t dst_w, 
   default: WelsVP::GeneralBilinearAccurateDownsampler_c (dst, dst_stride, dst_w, dst_h, src, src_stride, src_w, src_h); break;
   }
 }
+
+
+// the Combined3 intra costs (sample.cpp:153-331: `_c` functions no C build installs, sample.cpp:363-367), block copies and memory clearing
+// (copy_mb.cpp:38-111) -- the references of the leaf exports of include/welship_leaf.h that round 6 added
+int32_t ref_intra4x4_combined3_satd (uint8_t* dec, int32_t ds, uint8_t* enc, int32_t es, uint8_t* dst, int32_t* mode, int32_t l2, int32_t l1, int32_t l0) {
+  return WelsSampleSatdIntra4x4Combined3_c (dec, ds, enc, es, dst, mode, l2, l1, l0);
+}
+int32_t ref_intra16x16_combined3 (int satd, uint8_t* dec, int32_t ds, uint8_t* enc, int32_t es, int32_t* mode, int32_t lambda, uint8_t* dst) {
+  return satd ? WelsSampleSatdIntra16x16Combined3_c (dec, ds, enc, es, mode, lambda, dst) : WelsSampleSadIntra16x16Combined3_c (dec, ds, enc, es, mode, lambda, dst);
+}
+int32_t ref_intra8x8_combined3 (int satd, uint8_t* dec_cb, int32_t ds, uint8_t* enc_cb, int32_t es, int32_t* mode, int32_t lambda, uint8_t* dst, uint8_t* dec_cr, uint8_t* enc_cr) {
+  return satd ? WelsSampleSatdIntra8x8Combined3_c (dec_cb, ds, enc_cb, es, mode, lambda, dst, dec_cr, enc_cr)
+              : WelsSampleSadIntra8x8Combined3_c (dec_cb, ds, enc_cb, es, mode, lambda, dst, dec_cr, enc_cr);
+}
+void ref_copy (int w, int h, uint8_t* dst, int32_t ds, uint8_t* src, int32_t ss) {
+  PCopyFunc f = w == 4 && h == 4 ? WelsCopy4x4_c : w == 8 && h == 4 ? WelsCopy8x4_c : w == 4 && h == 8 ? WelsCopy4x8_c : w == 8 && h == 8 ? WelsCopy8x8_c
+              : w == 16 && h == 8 ? WelsCopy16x8_c : w == 8 && h == 16 ? WelsCopy8x16_c : WelsCopy16x16_c;
+  f (dst, ds, src, ss);
+}
+void ref_quant_rows (int qp, int intra, int16_t* ff8, int16_t* mf8) { memcpy (ff8, g_kiQuantInterFF[qp + (intra ? 6 : 0)], 16); memcpy (mf8, g_kiQuantMF[qp], 16); }
+void ref_set_mem_zero (void* dst, int32_t size) { WelsSetMemZero_c (dst, size); }
 
 }  // extern "C"

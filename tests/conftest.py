@@ -15,7 +15,7 @@ def pytest_configure(config):
 # sessions last -- the driver runs the GPU tier with -x, and one late failure of a fuzzer must not blank the primitives' evidence
 # (round 3: 43 of 116 GPU tests never ran behind a failing fuzz case).
 _FILE_ORDER = ["test_abi", "test_prims_gpu", "test_leaf_gpu", "test_oracle_prims", "test_mb_order", "test_frame_parity", "test_reference_content", "test_downsample_gpu",
-               "test_vaa", "test_frame_api_retry", "test_hooks_sha1", "test_hooks_screen", "test_hooks_simulcast", "test_hooks_cabac_threads",
+               "test_vaa", "test_frame_api_retry", "test_hooks_sha1", "test_hooks_screen", "test_hooks_simulcast", "test_hooks_cabac_threads", "test_hooks_reconfig",
                "test_multi_rank", "test_dropin_cli", "test_zz_dropin_gpu", "test_tools", "test_fuzz_parity", "test_hooks_dynslice"]
 
 
@@ -24,6 +24,40 @@ def pytest_collection_modifyitems(session, config, items):
         name = os.path.splitext(os.path.basename(str(item.fspath)))[0]
         return _FILE_ORDER.index(name) if name in _FILE_ORDER else len(_FILE_ORDER) - 2
     items.sort(key=key)          # (stable: the order inside a file stays)
+
+
+# WELSHIP_REQUIRE_ORACLE=1 (tools/gpu_run.sh sets it; the GPU tier's documented invocation): the reference build under oracle/_ref is git-ignored and
+# reaches the GPU box only with the snapshot -- a third of the GPU tier is `skipif (oracle/_ref missing)`, so a snapshot without it would pass
+# with those tests silently skipped.  With the variable set a missing piece is an error before the first test runs, and any test that still
+# skips for that reason fails instead.
+_ORACLE_FILES = ["ref_enc", "ref_dec", "ref_enc_hip", "h264enc_ref", "h264enc_hiphooks", "h264enc_welship", "libref_prims.so", "libref_openh264.so",
+                 "libref_openh264_hip.so", "res/BA_MW_D.264", "res/VID_1920x1080_cavlc_temporal_direct.264", "res/welsenc.cfg"]
+
+
+def _require_oracle():
+    return os.environ.get("WELSHIP_REQUIRE_ORACLE", "0") not in ("", "0")
+
+
+def pytest_sessionstart(session):
+    if not _require_oracle():
+        return
+    d = os.path.join(ROOT, "oracle", "_ref")
+    missing = [f for f in _ORACLE_FILES if not os.path.exists(os.path.join(d, f))]
+    if not os.path.exists(os.path.join(ROOT, "oracle", "liboracle_prims.so")):
+        missing.append("../liboracle_prims.so")
+    if missing:
+        pytest.exit("WELSHIP_REQUIRE_ORACLE=1 but oracle/_ref lacks: %s (build it with `make -C oracle` where /root/reference exists; it travels with gpurun)" % ", ".join(missing), returncode=3)
+
+
+@pytest.hookimpl(hookwrapper=True)
+def pytest_runtest_makereport(item, call):
+    outcome = yield
+    rep = outcome.get_result()
+    if _require_oracle() and rep.skipped and not hasattr(rep, "wasxfail"):
+        reason = str(rep.longrepr[2] if isinstance(rep.longrepr, tuple) else rep.longrepr)
+        if "oracle" in reason or "_ref" in reason:
+            rep.outcome = "failed"
+            rep.longrepr = "WELSHIP_REQUIRE_ORACLE=1: this test would have been skipped (%s)" % reason
 
 
 def has_gpu():

@@ -39,7 +39,7 @@ def test_device_code_avoids_ashr_pk(tmp_path):
     import subprocess
     if not shutil.which("hipcc"):
         pytest.skip("hipcc not available")
-    for unit in ("hip_backend", "prims", "downsample", "leaf"):
+    for unit in ("hip_backend", "prims", "downsample"):       # (leaf.hip is the second half of prims.hip's translation unit)
         out = tmp_path / (unit + ".s")
         subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-Wno-unused-function",
                                "-Wno-unused-variable", "-Wno-unused-command-line-argument", "-o", str(out),
@@ -64,3 +64,30 @@ def test_leaf_installer_declines_without_a_device(hip_lib, tmp_path):
     assert p.returncode == 0 and "leaf functions not installed (no usable device)" in err, err[-1000:]
     lib = C.CDLL(hip_lib)
     assert lib.WelsHipLeafAvailable() == 100      # WELSHIP_ERR_NO_DEVICE
+
+
+def test_frame_job_layout_and_versioning(tmp_path):
+    """WelsHipFrameJob (include/welship.h, layer 2b): the ctypes mirror the frame-API tests drive the library with has the header's size and field
+    offsets, and WELSHIP_FRAMEJOB_MIN_SIZE is the size of the layout up to pbRecordsPacked -- fields are only appended behind it (cbSize)."""
+    import shutil
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_frame_api_retry import FrameJob
+    if not shutil.which("gcc"):
+        pytest.skip("gcc not available")
+    fields = [f[0] for f in FrameJob._fields_]
+    src = tmp_path / "probe.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "%s"\nint main (void) {\n  printf ("%%zu %%u\\n", sizeof (WelsHipFrameJob), WELSHIP_FRAMEJOB_MIN_SIZE);\n%s  return 0;\n}\n'
+                   % (os.path.join(ROOT, "include", "welship.h"), "".join('  printf ("%s %%zu\\n", offsetof (WelsHipFrameJob, %s));\n' % (f, f) for f in fields)))
+    exe = tmp_path / "probe"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", str(src), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)]).decode().split("\n")
+    size, min_size = (int(x) for x in out[0].split())
+    assert size == C.sizeof(FrameJob) and min_size <= size
+    for line in out[1:]:
+        if line.strip():
+            name, off = line.split()
+            assert getattr(FrameJob, name).offset == int(off), name
+    assert FrameJob.cbSize.offset == 0
+    assert FrameJob.pbRecordsPacked.offset + C.sizeof(C.c_void_p) == min_size        # the first versioned layout ends with pbRecordsPacked

@@ -132,10 +132,11 @@ def test_hip_4k(hip_lib, ref_tools, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("waves", ["6", "8", "12"])
+@pytest.mark.parametrize("waves", ["6", "8", "12", "14", "16"])
 def test_hip_wave_variants(waves, hip_lib):
-    """The mode-decision pool runs with 12 waves per workgroup by default (k_inter_pool<768>; 6 and fewer use the <384>
-    instantiation); the count is forced here (read once per process) and must give the same bits."""
+    """The mode-decision pool runs with 16 waves per workgroup by default (k_inter_pool<1024>: one workgroup per CU); it is built for
+    6 / 12 / 14 / 16 waves (<384>, <768>, <896>, <1024>: the LDS a launch has decides, csrc/hip/hip_backend.hip WH_LAUNCH_POOL) and every
+    instantiation that ships is selected here once (8 takes <768>).  The count is forced (read once per process) and must give the same bits."""
     import sys
     name = "p_640x368_qp24_4slices"
     g = GOLDEN[name]

@@ -2,7 +2,8 @@
 
 Two checks.  (1) Every export, called with the (pointer, stride) pairs the reference passes, against the oracle's restatement of the
 slot's C function (oracle/prims, pinned against the reference's `_c` functions by tests/test_oracle_prims.py); the quantisers get
-arbitrary FF / MF rows, which the oracle (QP-indexed) has no entry for: their arithmetic is restated in numpy here.
+the rows of the reference's tables (against the oracle's QP-indexed quantisers) and, beyond what any QP produces, arbitrary FF / MF rows
+(against the arithmetic restated in numpy here).
 (2) The slots really are installable: the unmodified encoder loop of the reference, built with the patch, runs with all of them in
 its dispatch table (WELS_HIP_LEAVES=1: integration/welship_hooks.cpp InstallLeaves -- the static_asserts there tie every export to its
 slot's typedef) and must write the bitstream the C functions give, for I and P pictures, CAVLC and CABAC, with the deblocking filter on.
@@ -92,6 +93,15 @@ def test_transform_and_quantisation_slots(L):
         g = d.copy(); lib.WelsHipQuantFour4x4(p16(g), p16(ff), p16(mf)); assert (g == want).all()
         g = d.copy(); mx = np.zeros(4, np.int16); lib.WelsHipQuantFour4x4Max(p16(g), p16(ff), p16(mf), p16(mx))
         assert (g == want).all() and list(mx) == [int(max(0, wabs[b * 16:b * 16 + 16].max())) for b in range(4)]
+        # ... and with the rows the encoder really passes (the tables of encode_mb_aux.cpp:39-157), against the oracle's QP-indexed quantisers
+        qp, intra = int(rng.integers(0, 52)), int(rng.integers(0, 2))
+        tff, tmf = np.zeros(8, np.int16), np.zeros(8, np.int16)
+        orc.orc_quant_rows(qp, intra, p16(tff), p16(tmf))
+        w = d.copy()
+        wmx = [orc.orc_quant4x4_max(p16(w, b * 16), qp, intra) for b in range(4)]
+        g = d.copy(); lib.WelsHipQuant4x4(p16(g), p16(tff), p16(tmf)); assert (g[:16] == w[:16]).all()
+        g = d.copy(); lib.WelsHipQuantFour4x4(p16(g), p16(tff), p16(tmf)); assert (g == w).all()
+        g = d.copy(); mx = np.zeros(4, np.int16); lib.WelsHipQuantFour4x4Max(p16(g), p16(tff), p16(tmf), p16(mx)); assert (g == w).all() and [int(x) for x in mx] == wmx
         g = d.copy(); lib.WelsHipQuant4x4Dc(p16(g), C.c_int16(int(ff[0])), C.c_int16(int(mf[0])))
         w = d.copy(); orc.orc_quant4x4_dc(p16(w), C.c_int16(int(ff[0])), C.c_int16(int(mf[0]))); assert (g == w).all()
         # chroma DC: Hadamard + quantisation / the skip test
@@ -229,23 +239,76 @@ def test_deblocking_slots(L):
             assert (g == w).all() and (g2 == w2).all()
 
 
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "libref_prims.so")), reason="oracle/_ref not built")
+def test_copy_clear_and_combined_intra_cost_slots(L):
+    """pfCopy*, pfSetMemZero* and the five pfIntra*Combined3* slots (round 6) against the reference's own `_c` functions (oracle/_ref/libref_prims.so:
+    copy_mb.cpp:38-111, sample.cpp:153-331).  The Combined3 functions also leave bytes in the caller's buffers -- compared too."""
+    lib, _ = L
+    ref = C.CDLL(os.path.join(REF, "libref_prims.so"))
+    rng = np.random.default_rng(12)
+    for name, w, h in (("4x4", 4, 4), ("8x4", 8, 4), ("4x8", 4, 8), ("8x8", 8, 8), ("16x8", 16, 8), ("8x16", 8, 16), ("16x16", 16, 16)):
+        for _ in range(40):
+            src = rng.integers(0, 256, (40, 64), dtype=np.uint8)
+            got = rng.integers(0, 256, (40, 48), dtype=np.uint8)
+            want = got.copy()
+            so, do = int(rng.integers(0, 20)) * 64 + int(rng.integers(0, 40)), int(rng.integers(0, 20)) * 48 + int(rng.integers(0, 30))
+            getattr(lib, "WelsHipCopy" + name)(at(got, do), 48, at(src, so), 64)
+            ref.ref_copy(w, h, at(want, do), 48, at(src, so), 64)
+            assert (got == want).all(), name
+    for size in (8, 64, 128, 768, 8192, 8192 + 64, 40000):
+        got = rng.integers(1, 256, size + 32, dtype=np.uint8)
+        want = got.copy()
+        lib.WelsHipSetMemZero(C.cast(got.ctypes.data + 16, C.c_void_p), size)
+        ref.ref_set_mem_zero(C.cast(want.ctypes.data + 16, C.c_void_p), size)
+        assert (got == want).all() and not got[16:16 + size].any() and got[:16].all() and got[16 + size:].all(), size
+    lib.WelsHipIntra4x4Combined3Satd.restype = lib.WelsHipIntra16x16Combined3Satd.restype = lib.WelsHipIntra16x16Combined3Sad.restype = C.c_int32
+    lib.WelsHipIntra8x8Combined3Satd.restype = lib.WelsHipIntra8x8Combined3Sad.restype = C.c_int32
+    for case in range(120):
+        flat = case % 3 == 0       # near-flat blocks: equal costs, where the order of the candidates decides
+        dec = (rng.integers(100, 104, (40, 64)) if flat else rng.integers(0, 256, (40, 64))).astype(np.uint8)
+        dec2 = (rng.integers(100, 104, (40, 64)) if flat else rng.integers(0, 256, (40, 64))).astype(np.uint8)
+        enc = (rng.integers(100, 104, (40, 48)) if flat else rng.integers(0, 256, (40, 48))).astype(np.uint8)
+        enc2 = (rng.integers(100, 104, (40, 48)) if flat else rng.integers(0, 256, (40, 48))).astype(np.uint8)
+        o, e = 8 * 64 + 16, 4 * 48 + 8
+        lam = int(rng.integers(0, 40))
+        gm, wm = C.c_int32(-7), C.c_int32(-7)
+        gd, wd = np.full(16, 9, np.uint8), np.full(16, 9, np.uint8)
+        l2, l1, l0 = (int(x) for x in rng.integers(0, 60, 3))
+        g = lib.WelsHipIntra4x4Combined3Satd(at(dec, o), 64, at(enc, e), 48, at(gd), C.byref(gm), l2, l1, l0)
+        w_ = ref.ref_intra4x4_combined3_satd(at(dec, o), 64, at(enc, e), 48, at(wd), C.byref(wm), l2, l1, l0)
+        assert (g, gm.value) == (w_, wm.value) and (gd == wd).all(), ("4x4", case)
+        for satd in (1, 0):
+            gd, wd = np.full(256, 9, np.uint8), np.full(256, 9, np.uint8)
+            f = lib.WelsHipIntra16x16Combined3Satd if satd else lib.WelsHipIntra16x16Combined3Sad
+            g = f(at(dec, o), 64, at(enc, e), 48, C.byref(gm), lam, at(gd))
+            w_ = ref.ref_intra16x16_combined3(satd, at(dec, o), 64, at(enc, e), 48, C.byref(wm), lam, at(wd))
+            assert (g, gm.value) == (w_, wm.value) and (gd == wd).all(), ("16x16", satd, case)
+            gd, wd = np.full(128, 9, np.uint8), np.full(128, 9, np.uint8)
+            f = lib.WelsHipIntra8x8Combined3Satd if satd else lib.WelsHipIntra8x8Combined3Sad
+            g = f(at(dec, o), 64, at(enc, e), 48, C.byref(gm), lam, at(gd), at(dec2, o), at(enc2, e))
+            w_ = ref.ref_intra8x8_combined3(satd, at(dec, o), 64, at(enc, e), 48, C.byref(wm), lam, at(wd), at(dec2, o), at(enc2, e))
+            assert (g, gm.value) == (w_, wm.value) and (gd == wd).all(), ("8x8", satd, case)
+
+
 @pytest.mark.skipif(not os.path.exists(os.path.join(REF, "ref_enc_hip")), reason="oracle/_ref (hooked reference) not built")
+@pytest.mark.parametrize("leaves", ["1", "2"])
 @pytest.mark.parametrize("extra", [["-rc", "-1", "-qp", "28"], ["-rc", "-1", "-qp", "20", "-cabac", "1", "-profile", "77", "-slcmd", "1", "-slcnum", "2"],
                                    ["-rc", "1", "-bitrate", "90000", "-complexity", "2"]])
-def test_reference_encoder_loop_on_the_leaf_slots(hip_lib, tmp_path, extra):
-    """The reference's own macroblock loops with every leaf slot of its dispatch table served by the device: byte-identical stream."""
+def test_reference_encoder_loop_on_the_leaf_slots(hip_lib, tmp_path, extra, leaves):
+    """The reference's own macroblock loops with every leaf slot of its dispatch table served by the device: byte-identical stream.
+    leaves = 2 also fills the five Combined3 slots, which the C build leaves NULL: mode decision then takes its combined paths (same decisions)."""
     from openh264_amd.utils.synth import synth_sequence
     w, h, n = 80, 64, 4
     src = str(tmp_path / "c.yuv")
     open(src, "wb").write(synth_sequence(w, h, n))
     outs = []
-    for exe, env in (("ref_enc", dict(os.environ)), ("ref_enc_hip", dict(os.environ, WELSHIP_LIB=hip_lib, WELS_HIP_LEAVES="1", WELS_HIP_TRACE="1"))):
+    for exe, env in (("ref_enc", dict(os.environ)), ("ref_enc_hip", dict(os.environ, WELSHIP_LIB=hip_lib, WELS_HIP_LEAVES=leaves, WELS_HIP_TRACE="1"))):
         out = str(tmp_path / (exe + ".264"))
         p = subprocess.run([os.path.join(REF, exe), "-i", src, "-w", str(w), "-h", str(h), "-o", out, "-quiet", "-threads", "1", "-deblock", "0"] + extra, env=env,
                            stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=600)
         err = p.stderr.decode(errors="replace")
         assert p.returncode == 0, err[-2000:]
         if exe == "ref_enc_hip":
-            assert "82 leaf functions installed" in err, err[-2000:]
+            assert ("%d leaf functions installed" % (93 if leaves == "1" else 98)) in err, err[-2000:]
         outs.append(open(out, "rb").read())
     assert len(outs[0]) > 200 and outs[0] == outs[1]

@@ -229,32 +229,35 @@ def test_group_with_mixed_frame_types(emu_lib):
     assert idrs[1] == 1 and max(idrs) == 2        # the step with the scene change really was mixed
 
 
-def test_bench_line_from_two_ranks_on_the_cpu_test_build(emu_lib):
-    """bench.py --gpus 2 end to end without a GPU: the launcher (torch.distributed.run, one process per rank), the barriers, the
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_line_from_two_ranks_on_the_cpu_test_build(emu_lib, world):
+    """bench.py --gpus 2 (and --gpus 8: the node the driver's scaling run uses) end to end without a GPU: the launcher (torch.distributed.run, one process per rank), the barriers, the
     max-over-ranks time and the ONE JSON line of rank 0 with its roofline object -- gloo in place of RCCL and the CPU test build of the
     kernels in place of libwelship.so (bench.py --cpu-launcher-test; the line says it is no measurement).  What the driver's 2 / 4 / 8
     GPU runs execute, minus the device."""
     import json
     import subprocess
     env = dict(os.environ, WELSHIP_LIB=emu_lib)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--sessions", "3", "--width", "176",
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1", "--sessions", "3", "--width", "176",
                         "--height", "144", "--cpu-launcher-test", "--multi-gpu-legs"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
     lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["unit"] == "frames/s"
-    assert d["value"] > 0 and abs(d["value"] - 2 * 3 * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 1e-6        # all ranks' pictures / the slowest rank's time
+    assert d["n_gpus"] == world and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["unit"] == "frames/s"
+    assert d["value"] > 0 and abs(d["value"] - world * 3 * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 1e-6        # all ranks' pictures / the slowest rank's time
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["frac"] > 0 and "not a measurement" in d["data"]
     # BASELINE configs 5 and 4 over the ranks (bench.py multi_gpu_legs; SURVEY 8d/8e): every rank hosts its sessions through the dispatch-table binding
     # at once, rank 0 gathers the digests; one simulcast session with its layers spread over the devices (WELS_HIP_LAYER_DEVICES = number of ranks).
     if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ref_enc_hip")):
-        c5 = d["config5_4_sessions"]                  # (2 sessions per rank in the launcher test; 8 per GPU = config5_64_sessions on an 8-GPU node)
-        assert c5["n_ranks_seen"] == 2 and c5["sessions"] == 4 and c5["same_bitstreams"] is True and not c5["errors"]
-        assert len(c5["per_gpu_device_frames_per_s"]) == 2 and all(v > 0 for v in c5["per_gpu_device_frames_per_s"])
+        c5 = d["config5_64_sessions" if world == 8 else "config5_4_sessions"]      # (2 sessions per rank in the launcher test; 8 per GPU on an 8-GPU node: the key is the real run's)
+        assert c5["n_ranks_seen"] == world and c5["sessions"] == 2 * world and c5["same_bitstreams"] is True and not c5["errors"]
+        assert c5["c_path_comparable_with_single_gpu_leg"] is False
+        assert len(c5["per_gpu_device_frames_per_s"]) == world and all(v > 0 for v in c5["per_gpu_device_frames_per_s"])
         assert abs(c5["aggregate_device_frames_per_s"] - sum(c5["per_gpu_device_frames_per_s"])) < 1e-6 and all(v > 0 for v in c5["per_session_latency_ms"])
         c4 = d["config4_layer_per_gpu"]
-        assert c4["same_bitstreams"] is True and c4["layer_devices"] == 2 and c4["devices_seen"] == [0, 1] and c4["device_frames_per_s"] > 0
+        n4 = min(world, 4)
+        assert c4["same_bitstreams"] is True and c4["layer_devices"] == n4 and c4["devices_seen"] == list(range(n4)) and c4["device_frames_per_s"] > 0
 
 
 # ---- pipelined groups: WelsHipGroupEncodeFramesPipelined returns step k - 1's streams while the device codes step k -------------

@@ -188,3 +188,15 @@ def test_vaa_sad(libs):
         so, sr = (C.c_int32 * 4)(), (C.c_int32 * 4)()
         fo(u8p(a), u8p(b), 32, so); fr(u8p(a), u8p(b), 32, sr)
         assert list(so) == list(sr)
+
+
+def test_quantiser_table_rows(libs):
+    """orc_quant_rows: the rows the encoder passes to pfQuantization* (g_kiQuantInterFF[qp (+ 6)] / g_kiQuantMF[qp], encode_mb_aux.cpp:39-157) --
+    what tests/test_leaf_gpu.py feeds the device's quantiser slots."""
+    o, r = libs
+    for qp in range(52):
+        for intra in (0, 1):
+            of, om, rf, rm = (np.zeros(8, np.int16) for _ in range(4))
+            o.orc_quant_rows(qp, intra, i16p(of), i16p(om))
+            r.ref_quant_rows(qp, intra, i16p(rf), i16p(rm))
+            assert (of == rf).all() and (om == rm).all(), (qp, intra)

@@ -45,8 +45,8 @@ PY
 }
 for stage in "$@"; do
   case $stage in
-  tier)     timeout 1500 python -m pytest tests -m gpu -x -q > $o/pytest_gpu.txt 2>&1; tail -5 $o/pytest_gpu.txt | cut -c1-300; lap "gpu tier (serial, -x, as the driver runs it)";;
-  tier_all) timeout 1500 python -m pytest tests -m gpu -q > $o/pytest_gpu_all.txt 2>&1; tail -15 $o/pytest_gpu_all.txt | cut -c1-300; lap "gpu tier (serial, every failure)";;
+  tier)     WELSHIP_REQUIRE_ORACLE=1 timeout 1800 python -m pytest tests -m gpu -x -q > $o/pytest_gpu.txt 2>&1; tail -5 $o/pytest_gpu.txt | cut -c1-300; lap "gpu tier (serial, -x, as the driver runs it)";;
+  tier_all) WELSHIP_REQUIRE_ORACLE=1 timeout 1800 python -m pytest tests -m gpu -q > $o/pytest_gpu_all.txt 2>&1; tail -15 $o/pytest_gpu_all.txt | cut -c1-300; lap "gpu tier (serial, every failure)";;
   bench)    timeout 900 python bench.py > $o/bench_default.json 2> $o/bench_default.err; digest $o/bench_default.json; lap "bench default";;
   quick)    timeout 300 python bench.py --quick > $o/bench_quick.json 2> $o/bench_quick.err; digest $o/bench_quick.json; lap "bench --quick";;
   stats)    ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$o/stats -- python $OLDPWD/bench.py --quick --steps 20 --warmup 5 > $OLDPWD/$o/prof_bench.json 2> $OLDPWD/$o/prof_bench.err )
