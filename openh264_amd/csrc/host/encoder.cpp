@@ -1732,7 +1732,7 @@ struct WelsHipFrameCtx {
   // The verdict of the last picture's deblocking pass / border expansion, at this context's next call (advisor finding, round 4: that pass runs
   // after the callers were released, and its time-out used to fail whichever launch set synchronised the queue next).  Waits for the pass
   // (normally long over: the caller has entropy-coded a picture meanwhile), reads the error words copied out behind it.  Called WITHOUT sh->mu.
-  // `intra`: the call codes an I picture, which predicts from nothing -- it clears a failure; until then the failure is reported to EVERY call
+  // `intra`: the call codes an I picture, which predicts from nothing -- once the failure has been reported, such a call clears it; until then it is reported to EVERY call
   // on this context (slice tasks of a size-limited picture call concurrently: with a flag that the first caller consumed, the others coded
   // against the bad reference -- advisor finding, round 5).  sh->mu is held throughout except around the wait itself.
   int check_tail (bool intra) {
@@ -1750,9 +1750,12 @@ struct WelsHipFrameCtx {
         else { TL->tail_ctxs.erase (std::remove (TL->tail_ctxs.begin(), TL->tail_ctxs.end(), this), TL->tail_ctxs.end()); tail_lane = nullptr; }
       }
     }
-    if (tail_failed && intra) tail_failed = false;
-    return tail_failed ? 1 : 0;
+    if (!tail_failed) return 0;
+    if (intra && tail_reported) { tail_failed = false; tail_reported = false; return 0; }     // the caller has been told and now starts afresh
+    tail_reported = true;
+    return 1;
   }
+  bool tail_reported = false;
   uint32_t* d_dbflags = nullptr;
   uint32_t db_gen = 0;
   WhMbCtl* d_mb_ctl = nullptr;
