@@ -129,6 +129,9 @@ WH_FN int wh_mvd_cost (int lambda, int dx, int dy) { return (int) (uint16_t) (la
 
 // ---- H.264 luma sample interpolation (8.4.2.2.1; mc.cpp:100-347), four horizontally adjacent samples per lane ----
 // `w` is the LDS window, `o` the byte offset of the integer sample G of the first of the four.
+// (Tried in round 6: the shift-and-add form (a + f) + 5 m, m = 4 (c + d) - (b + e), which spares the second stage of the centre half sample its
+//  quarter-rate 32-bit multiplies -- the 16-wave kernel then needed 150 registers and spilled 22 of them to scratch: MD launch 7.2 -> 8.3 ms.
+//  tests/test_abi.py now checks that no mode-decision kernel that ships spills.)
 WH_FN int wh_tap6 (int a, int b, int c, int d, int e, int f) { return a - 5 * b + 20 * c + 20 * d - 5 * e + f; }
 #define WH_BYTE(v, k) ((int) (((v) >> (8 * (k))) & 255u))
 WH_FN uint32_t wh_pack4 (int a, int b, int c, int d) { return (uint32_t)a | ((uint32_t)b << 8) | ((uint32_t)c << 16) | ((uint32_t)d << 24); }
@@ -210,12 +213,20 @@ WH_FN void wh_win_place (const WhSeqParams& P, WhWin& W, int cx, int cy) {      
   W.cy0 = wh_clip3 (wh_win_pick (ccy - (WH_CWIN_ROWS - 9) / 2 - 2, ccy - (WH_CWIN_ROWS - 9) / 2 + 1, 8), -16, P.mb_h * 8 + 16 - WH_CWIN_ROWS);
 }
 // piece p of the luma window / chroma window in the tiled reference picture
+// (WH_TILE_Y_OFF / WH_TILE_C_OFF of common/wh_types.h in 32-bit arithmetic with 24-bit multiplies: a tiled picture is far below 4 GB, a tile row and
+//  the tiles per row far below 2^24 -- the macros' size_t products are 64-bit multiplies, four quarter-rate instructions per piece)
+WH_FN uint32_t wh_tile_y_off32 (int stride_y, int x, int y) {
+  return ((wh_mul_u24 ((uint32_t) ((y + 32) >> 3), (uint32_t) (stride_y >> 4)) + (uint32_t) ((x + 32) >> 4)) << 7) + (uint32_t) (((y + 32) & 7) << 4);
+}
+WH_FN uint32_t wh_tile_c_off32 (int stride_c, int x, int y) {
+  return ((wh_mul_u24 ((uint32_t) ((y + 16) >> 3), (uint32_t) (stride_c >> 3)) + (uint32_t) ((x + 16) >> 3)) << 7) + (uint32_t) (((y + 16) & 7) << 4);
+}
 WH_FN const WH_G uint8_t* wh_win_src_luma (int p, const WhSeqParams& P, const WhPicJob& J, const WhWin& W) {
   const int r = (p * 205) >> 10, c = p - 5 * r;            // p / 5, p % 5 for p < 1024
-  return (const WH_G uint8_t*)J.ref_tiles[0] + WH_TILE_Y_OFF (P.rec_stride_y, W.x0 + 16 * c, W.y0 + r);
+  return (const WH_G uint8_t*)J.ref_tiles[0] + wh_tile_y_off32 (P.rec_stride_y, W.x0 + 16 * c, W.y0 + r);
 }
 WH_FN const WH_G uint8_t* wh_win_src_chroma (int p, const WhSeqParams& P, const WhPicJob& J, const WhWin& W) {
-  return (const WH_G uint8_t*)J.ref_tiles[1] + WH_TILE_C_OFF (P.rec_stride_c, W.cx0 + 8 * (p & 3), W.cy0 + (p >> 2));
+  return (const WH_G uint8_t*)J.ref_tiles[1] + wh_tile_c_off32 (P.rec_stride_c, W.cx0 + 8 * (p & 3), W.cy0 + (p >> 2));
 }
 // byte offset of chroma sample (x, y) (window coordinates) of plane pl inside cwin
 WH_FN int wh_cwin_off (int pl, int x, int y) { return y * WH_CWIN_STRIDE + ((x >> 3) << 4) + (pl << 3) + (x & 7); }

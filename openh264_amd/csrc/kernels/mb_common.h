@@ -247,17 +247,17 @@ WH_FN int wh_encrec_i16 (WhMbLds& S, int qp) {
     const int32_t* p = &S.part[lane];
     const int s0 = p[0] + p[12], s3 = p[0] - p[12], s1 = p[4] + p[8], s2 = p[4] - p[8];
     const int ff = wh_ff_intra (qp, 0) << 1, mf = wh_mf (qp, 0) >> 1;   // pfQuantizationDc4x4 (aDctT4Dc, pFF[0]<<1, pMF[0]>>1)
-    S.dc[lane]      = wh_quant1 ((int16_t)wh_clip3 ((s0 + s1 + 1) >> 1, -32768, 32767), ff, mf);
-    S.dc[lane + 8]  = wh_quant1 ((int16_t)wh_clip3 ((s0 - s1 + 1) >> 1, -32768, 32767), ff, mf);
-    S.dc[lane + 4]  = wh_quant1 ((int16_t)wh_clip3 ((s3 + s2 + 1) >> 1, -32768, 32767), ff, mf);
-    S.dc[lane + 12] = wh_quant1 ((int16_t)wh_clip3 ((s3 - s2 + 1) >> 1, -32768, 32767), ff, mf);
+    S.dc[lane]      = wh_quant1_t ((int16_t)wh_clip3 ((s0 + s1 + 1) >> 1, -32768, 32767), ff, mf);
+    S.dc[lane + 8]  = wh_quant1_t ((int16_t)wh_clip3 ((s0 - s1 + 1) >> 1, -32768, 32767), ff, mf);
+    S.dc[lane + 4]  = wh_quant1_t ((int16_t)wh_clip3 ((s3 + s2 + 1) >> 1, -32768, 32767), ff, mf);
+    S.dc[lane + 12] = wh_quant1_t ((int16_t)wh_clip3 ((s3 - s2 + 1) >> 1, -32768, 32767), ff, mf);
   }
   WV_LANES_END
   // AC quant (WelsQuantFour4x4_c, intra FF) + scans + counts
   WV_LANES_BEGIN (lane)
   for (int k = 0; k < 4; ++k) {
     const int i = lane * 4 + k, pos = i & 15;
-    S.res[i] = wh_quant1 (S.res[i], wh_ff_intra (qp, pos), wh_mf (qp, pos));
+    S.res[i] = wh_quant1_t (S.res[i], wh_ff_intra (qp, pos), wh_mf (qp, pos));
   }
   if (lane < 16) S.lv_dc[lane] = S.dc[wh_zigzag (lane)];
   WV_LANES_END
@@ -378,7 +378,7 @@ WH_FN int wh_encrec_i4 (WhMbLds& S, int b, int pred_slot, int qp, int8_t rem) {
     int cnt = 0;
     for (int k = 0; k < 4; ++k) {
       const int pos = k * 4 + lane;
-      const int16_t q = wh_quant1 (o[k], wh_ff_intra (qp, pos), wh_mf (qp, pos));
+      const int16_t q = wh_quant1_t (o[k], wh_ff_intra (qp, pos), wh_mf (qp, pos));
       S.res[b * 16 + pos] = q;
       cnt += q != 0;
     }
@@ -447,7 +447,7 @@ WH_FN void wh_quant_blocks (WhMbLds& S, int base, int nblk, int qp, int ffrow, i
     for (int k = 0; k < 4; ++k) {
       const int i = lane * 4 + k, pos = i & 15;
       int16_t a;
-      dst[i] = wh_quant1_abs (S.res[base + i], wh_ff_row (ffrow, pos), wh_mf (qp, pos), &a);
+      dst[i] = wh_quant1_abs_t (S.res[base + i], wh_ff_row (ffrow, pos), wh_mf (qp, pos), &a);
       if (mx < a) mx = a;
       pm |= (unsigned) (a != 0) << ((inv4 >> (4 * k)) & 15u);
     }
@@ -480,10 +480,10 @@ WH_FN int wh_encrec_chroma (WhMbLds& S, int qpc, int is_intra) {
     r[0] = 0; r[16] = 0; r[32] = 0; r[48] = 0;
     const int ff = kWhQuantFF[ffrow * 3 + 0] << 1, mf = kWhQuantMF[qpc * 3 + 0] >> 1;
     int16_t* d = &S.cdc[lane * 4];
-    d[0] = wh_quant1 ((int16_t) (s0 + s2), ff, mf);
-    d[1] = wh_quant1 ((int16_t) (s0 - s2), ff, mf);
-    d[2] = wh_quant1 ((int16_t) (s1 + s3), ff, mf);
-    d[3] = wh_quant1 ((int16_t) (s1 - s3), ff, mf);
+    d[0] = wh_quant1_t ((int16_t) (s0 + s2), ff, mf);
+    d[1] = wh_quant1_t ((int16_t) (s0 - s2), ff, mf);
+    d[2] = wh_quant1_t ((int16_t) (s1 + s3), ff, mf);
+    d[3] = wh_quant1_t ((int16_t) (s1 - s3), ff, mf);
     for (int k = 0; k < 4; ++k) S.lv_cdc[lane * 4 + k] = d[k];
   }
   WV_LANES_END

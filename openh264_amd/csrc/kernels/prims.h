@@ -51,6 +51,23 @@ WH_FN int16_t wh_quant1_abs (int16_t x, int ff, int mf, int16_t* absq) {
   return (int16_t) ((sign ^ (int) q) - sign);
 }
 
+// The same two with operands from the encoder's own tables (0 <= ff < 2^15, 0 < mf < 2^14: encode_mb_aux.cpp:39-157; |x| <= 2^15), which is
+// what the fused kernels pass: the product is below 2^31 and both factors below 2^24, so the full-rate 24-bit multiply gives the same bits.
+// (The leaf exports take the CALLER's rows, any int16: they keep the general functions above.)
+WH_FN int16_t wh_quant1_t (int16_t x, int ff, int mf) {
+  const int sign = ((int) x) >> 31;
+  const int a = (sign ^ (int) x) - sign;
+  const int16_t q = (int16_t) (wh_mul_u24 ((uint32_t) (ff + a), (uint32_t)mf) >> 16);
+  return (int16_t) ((sign ^ (int) q) - sign);
+}
+WH_FN int16_t wh_quant1_abs_t (int16_t x, int ff, int mf, int16_t* absq) {
+  const int sign = ((int) x) >> 31;
+  const int a = (sign ^ (int) x) - sign;
+  const int16_t q = (int16_t) (wh_mul_u24 ((uint32_t) (ff + a), (uint32_t)mf) >> 16);
+  *absq = q;
+  return (int16_t) ((sign ^ (int) q) - sign);
+}
+
 // ---- inverse 4-point butterflies (decode_mb_aux.cpp:164-199 WelsIDctT4Rec_c) --------------------
 // horizontal pass: int16 outputs (the reference keeps iTemp[] in int16)
 WH_FN void wh_idct4_h (int16_t c0, int16_t c1, int16_t c2, int16_t c3, int16_t* t0, int16_t* t1, int16_t* t2, int16_t* t3) {

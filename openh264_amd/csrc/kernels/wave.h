@@ -309,6 +309,26 @@ WH_HDFN WhU4 wh_ldg16 (const WH_G void* p) { const wh_u32x4_t t = * (const WH_G 
 WH_HDFN void wh_stg16 (WH_G void* p, WhU4 v) { wh_u32x4_t t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w; * (WH_G wh_u32x4_t*)p = t; }
 #endif
 
+// 16 / 8 bytes to device memory that is only 4-byte aligned (a row piece of a picture at any multiple of four samples): still ONE
+// global_store_dwordx4 / _dwordx2 per lane
+#if defined(WH_EMU)
+WH_FN void wh_stg16_a4 (void* p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) { const uint32_t v[4] = {a, b, c, d}; memcpy (p, v, 16); }
+WH_FN void wh_stg8_a4 (void* p, uint32_t a, uint32_t b) { const uint32_t v[2] = {a, b}; memcpy (p, v, 8); }
+#else
+typedef uint32_t wh_u32x4_a4_t __attribute__ ((ext_vector_type (4), aligned (4)));
+typedef uint32_t wh_u32x2_a4_t __attribute__ ((ext_vector_type (2), aligned (4)));
+WH_FN void wh_stg16_a4 (WH_G void* p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) { const wh_u32x4_a4_t v = {a, b, c, d}; * (WH_G wh_u32x4_a4_t*)p = v; }
+WH_FN void wh_stg8_a4 (WH_G void* p, uint32_t a, uint32_t b) { const wh_u32x2_a4_t v = {a, b}; * (WH_G wh_u32x2_a4_t*)p = v; }
+#endif
+
+// a * b for 0 <= a, b < 2^24 whose product fits 32 bits: v_mul_u32_u24 issues at the full rate, the general 32-bit multiply
+// (v_mul_lo_u32) at a quarter of it -- the quantiser multiplies four coefficients per lane and pass
+#if defined(WH_EMU)
+WH_FN uint32_t wh_mul_u24 (uint32_t a, uint32_t b) { return a * b; }
+#else
+WH_FN uint32_t wh_mul_u24 (uint32_t a, uint32_t b) { return __umul24 (a, b); }
+#endif
+
 // ---- small integer helpers (host + device) -----------------------------------------------------
 WH_FN int wh_abs (int a) { return a < 0 ? -a : a; }
 WH_FN int wh_min (int a, int b) { return a < b ? a : b; }

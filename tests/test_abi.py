@@ -91,3 +91,26 @@ def test_frame_job_layout_and_versioning(tmp_path):
             assert getattr(FrameJob, name).offset == int(off), name
     assert FrameJob.cbSize.offset == 0
     assert FrameJob.pbRecordsPacked.offset + C.sizeof(C.c_void_p) == min_size        # the first versioned layout ends with pbRecordsPacked
+
+
+def test_mode_decision_kernels_do_not_spill(hip_lib):
+    """Every instantiation of the P kernel that a launch can select keeps its registers: no scratch memory, no spilled VGPR (the 16- and 14-wave
+    builds have 128 VGPRs to live in; one innocent-looking change of a helper in round 6 pushed them to 150 and the launch from 7.2 to 8.3 ms).
+    The deblocking, intra and pre-processing kernels likewise.  Read from the notes of the code object inside the built library."""
+    import shutil
+    import subprocess
+    tool = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not os.path.exists(tool) or not shutil.which("bash"):
+        pytest.skip("ROCm LLVM tools not available")
+    out = subprocess.check_output(["bash", os.path.join(ROOT, "tools", "kernel_resources.sh"), hip_lib]).decode()
+    rows = [l for l in out.splitlines() if ".name:" in l]
+    assert len(rows) > 30
+    seen = 0
+    for l in rows:
+        f = l.split()
+        name = f[f.index(".name:") + 1]
+        scratch, spills = int(f[f.index(".private_segment_fixed_size:") + 1]), int(f[f.index(".vgpr_spill_count:") + 1])
+        if any(k in name for k in ("k_inter_pool", "k_intra_slice", "k_deblock_slices", "k_expand", "k_tile", "k_compact", "k_vaa", "k_bgd", "k_ds_")):
+            seen += 1
+            assert scratch == 0 and spills == 0, "%s: %d bytes of scratch, %d spilled VGPRs" % (name, scratch, spills)
+    assert seen >= 20
