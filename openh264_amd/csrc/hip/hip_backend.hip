@@ -566,12 +566,16 @@ __global__ __launch_bounds__ (256) void k_expand (WhSeqParams P, const WhPicJob*
 }
 
 // The tiled twin of a picture that has just become a reference (kernels/tile_pic.h): one 16-byte tile row per thread.
+// A picture that the deblocking pass has written (WhPicJob::rec_blk) only has its border tiles left: the workgroups beyond those leave at once.
 __global__ __launch_bounds__ (256) void k_tile (WhSeqParams P, const WhPicJob* jobs) {
+  const bool border_only = jobs[blockIdx.y].rec_blk != nullptr;
+  const int idx = (int) (blockIdx.x * blockDim.x + threadIdx.x), items = border_only ? wh_tile_border_items (P) : wh_tile_items (P);
+  if ((int) (blockIdx.x * blockDim.x) >= items) return;
   __shared__ WhPicJob Jl;
   wh_copy_job (&Jl, &jobs[blockIdx.y]);
   __syncthreads();
-  const int idx = (int) (blockIdx.x * blockDim.x + threadIdx.x);
-  if (idx < wh_tile_items (P)) wh_tile_item (P, Jl, idx);
+  if (idx >= items) return;
+  if (border_only) wh_tile_border_item (P, Jl, idx); else wh_tile_item (P, Jl, idx);
 }
 
 // A source picture as uploaded -> macroblock tiles (kernels/tile_pic.h wh_src_tile_item): 16 bytes of the tiled picture per thread.

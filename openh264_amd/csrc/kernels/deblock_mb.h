@@ -123,6 +123,15 @@ WH_FN void wh_db_chroma_px (int bs, int alpha, int beta, int tc3, int p1, int& p
   wh_db_line_px (true, bs, alpha, beta, tc3, bs == 4, 0, p2, a, p0, q0, b, q2, 0);
 }
 
+// byte offset of the 16-byte row piece of the picture's tiled twin (common/wh_types.h WH_TILE_*) that holds luma sample (x, y) / chroma sample (x, y),
+// in 32-bit arithmetic (a tiled picture is far below 4 GB)
+WH_FN uint32_t wh_db_tile_y_off (int stride_y, int x, int y) {
+  return ((wh_mul_u24 ((uint32_t) ((y + 32) >> 3), (uint32_t) (stride_y >> 4)) + (uint32_t) ((x + 32) >> 4)) << 7) + (uint32_t) (((y + 32) & 7) << 4);
+}
+WH_FN uint32_t wh_db_tile_c_off (int stride_c, int x, int y) {
+  return ((wh_mul_u24 ((uint32_t) ((y + 16) >> 3), (uint32_t) (stride_c >> 3)) + (uint32_t) ((x + 16) >> 3)) << 7) + (uint32_t) (((y + 16) & 7) << 4);
+}
+
 WH_FN bool wh_mv_far (const int16_t* a, const int16_t* b) {
   return wh_abs (a[0] - b[0]) >= 4 || wh_abs (a[1] - b[1]) >= 4;
 }
@@ -397,19 +406,39 @@ WH_FN bool wh_deblock_mb_body (WhDbLds& S, WhDbStage& G, const WhDbXchg& E, int 
   // 8-sample rows (rows -2 .. -1 from x = 0, rows 0 .. 5 from x = -4): one 16-byte / 8-byte store per row on 32 lanes (round 6).  The general
   // loop below asked every one of 160 words whether it is this macroblock's -- two passes over the lanes with a division by 5 and by 3 each:
   // "write-back + exchange" was 4.0 k of the pass's 19.9 k cycles per macroblock (profiles/r06_phase_cycles_before.txt).
+  // The picture's TILED TWIN (what the next picture's search windows are fetched from, common/wh_types.h WH_TILE_*) gets the same samples here
+  // (round 6): every sample inside the picture is written by exactly one macroblock of this pass, so the tiling pass behind the border expansion
+  // only has the borders left to copy (kernels/tile_pic.h) instead of reading the whole planar picture back and writing it again -- 3.4 MB each way
+  // per 1080p picture, 0.31 ms per step of 256.  A luma row piece is one 16-byte tile row (x = 0 .. 15) or the last word of the left tile's row and
+  // the first three of this one's (x = -4 .. 11); chroma tile rows hold 8 Cb then 8 Cr samples.
+  const bool tiles = J.rec_blk != nullptr && J.rec_tiles[0] != nullptr;
   const bool interior = top_lds && left_lds && own && below_in && right_in && !lb_none && !xwg;
   if (interior) {
     WV_LANES_BEGIN (lane)
     if (lane < 16) {
       const int row = lane - 4, x0 = lane < 4 ? 0 : -4;
       const uint32_t* sp = (const uint32_t*)&WH_DY (S, x0, row);
+      const uint32_t w0 = sp[0], w1 = sp[1], w2 = sp[2], w3 = sp[3];
       WH_G uint8_t* d = (WH_G uint8_t*)J.rec[0] + (ptrdiff_t) (mby * 16 + row) * P.rec_stride_y + mbx * 16 + x0;
-      wh_stg16_a4 (d, sp[0], sp[1], sp[2], sp[3]);
+      wh_stg16_a4 (d, w0, w1, w2, w3);
+      if (tiles) {
+        const uint32_t tb = wh_db_tile_y_off (P.rec_stride_y, mbx * 16, mby * 16 + row);       // this macroblock's tile column
+        WH_G uint8_t* t = (WH_G uint8_t*)J.rec_tiles[0];
+        * (WH_G uint32_t*) (t + (x0 == 0 ? tb : tb - 128u + 12u)) = w0;                         // (the left tile column is the previous tile of the row)
+        wh_stg12_a4 (t + (x0 == 0 ? tb + 4u : tb), w1, w2, w3);
+      }
     } else if (lane < 32) {
       const int pl = (lane - 16) >> 3, k = lane & 7, row = k - 2, x0 = k < 2 ? 0 : -4;
       const uint32_t* sp = (const uint32_t*)&WH_DC (S, pl, x0, row);
+      const uint32_t w0 = sp[0], w1 = sp[1];
       WH_G uint8_t* d = (WH_G uint8_t*)J.rec[1 + pl] + (ptrdiff_t) (mby * 8 + row) * P.rec_stride_c + mbx * 8 + x0;
-      wh_stg8_a4 (d, sp[0], sp[1]);
+      wh_stg8_a4 (d, w0, w1);
+      if (tiles) {
+        const uint32_t tb = wh_db_tile_c_off (P.rec_stride_c, mbx * 8, mby * 8 + row) + (uint32_t)pl * 8u;
+        WH_G uint8_t* t = (WH_G uint8_t*)J.rec_tiles[1];
+        * (WH_G uint32_t*) (t + (x0 == 0 ? tb : tb - 128u + 4u)) = w0;
+        * (WH_G uint32_t*) (t + (x0 == 0 ? tb + 4u : tb)) = w1;
+      }
     }
     WV_LANES_END
   } else {
@@ -426,6 +455,10 @@ WH_FN bool wh_deblock_mb_body (WhDbLds& S, WhDbStage& G, const WhDbXchg& E, int 
         WH_G uint32_t* d = (WH_G uint32_t*) (ry + (ptrdiff_t)row * P.rec_stride_y + x);
         const uint32_t v = * (const uint32_t*)&WH_DY (S, x, row);
         if (xwg) wh_st_xwg32 (d, v); else *d = v;
+        if (tiles) {          // (the same rule as for the planar word: what another band's workgroup -- another XCD's L2 -- may write again goes through to memory)
+          WH_G uint32_t* tp = (WH_G uint32_t*) ((WH_G uint8_t*)J.rec_tiles[0] + wh_db_tile_y_off (P.rec_stride_y, mbx * 16 + x, mby * 16 + row) + (uint32_t) (x & 12));
+          if (xwg) wh_st_xwg32 (tp, v); else *tp = v;
+        }
       }
     }
     if (lane < 60) {
@@ -438,6 +471,10 @@ WH_FN bool wh_deblock_mb_body (WhDbLds& S, WhDbStage& G, const WhDbXchg& E, int 
         WH_G uint32_t* d = (WH_G uint32_t*) ((WH_G uint8_t*)J.rec[1 + pl] + (ptrdiff_t) (mby * 8 + row) * P.rec_stride_c + mbx * 8 + x);
         const uint32_t v = * (const uint32_t*)&WH_DC (S, pl, x, row);
         if (xwg) wh_st_xwg32 (d, v); else *d = v;
+        if (tiles) {
+          WH_G uint32_t* tp = (WH_G uint32_t*) ((WH_G uint8_t*)J.rec_tiles[1] + wh_db_tile_c_off (P.rec_stride_c, mbx * 8 + x, mby * 8 + row) + (uint32_t) (pl * 8 + (x & 4)));
+          if (xwg) wh_st_xwg32 (tp, v); else *tp = v;
+        }
       }
     }
   }

@@ -6,6 +6,7 @@
 //   svc_encode_slice.cpp:534-599   WelsISliceMdEnc   (I slices)
 //   svc_encode_slice.cpp:1807-1899 WelsMdInterMbLoop (P slices, see inter_mb.h)
 #pragma once
+#include <stddef.h>
 #include "intra_mb.h"
 #include "cavlc_bits.h"
 #include "../common/gom_rc.h"
@@ -13,6 +14,12 @@
 static_assert (sizeof (WhMbRecord) == 960, "WhMbRecord must be 960 bytes");
 static_assert (sizeof (WhMbState) == 144, "WhMbState must be 144 bytes");
 static_assert (sizeof (WhMbCtl) == 8, "WhMbCtl must be 8 bytes");
+// (wh_store_mb and the P body write these groups of byte / short fields as one 32-bit word each)
+static_assert (offsetof (WhMbRecord, mb_type) == 0 && offsetof (WhMbRecord, i16_mode) == 4 && offsetof (WhMbRecord, i4_prev_flags) == 6 && offsetof (WhMbRecord, bgd_skip) % 4 == 0 &&
+               offsetof (WhMbRecord, sub_type) % 4 == 0 && offsetof (WhMbRecord, ref_idx) % 4 == 0 && offsetof (WhMbRecord, mvd) % 4 == 0 && offsetof (WhMbRecord, mv_tr) % 4 == 0, "WhMbRecord layout");
+static_assert (offsetof (WhMbState, mb_type) == 0 && offsetof (WhMbState, luma_qp) == 1 && offsetof (WhMbState, chroma_qp) == 2 && offsetof (WhMbState, cbp) == 3 &&
+               offsetof (WhMbState, slice_idc) == 4 && offsetof (WhMbState, ref_type) == 6 && offsetof (WhMbState, ref_qp) == 7 && offsetof (WhMbState, mv) % 4 == 0 &&
+               offsetof (WhMbState, ref_idx) % 4 == 0 && offsetof (WhMbState, p16mv) % 4 == 0, "WhMbState layout");
 
 // Store the MB's reconstruction, entropy record and neighbour state to HBM.
 WH_FN void wh_store_mb (WhMbLds& S, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, int mb_type, int cbp,
@@ -60,19 +67,19 @@ WH_FN void wh_store_mb (WhMbLds& S, const WhSeqParams& P, const WhPicJob& J, int
     M->i4_mode[lane] = (mb_type == WH_MB_I4x4) ? S.i4m[((lane >> 2) + 1) * 5 + (lane & 3) + 1] : (int8_t)2;
   }
   if (lane == 0) {
-    R->mb_type = (uint8_t)mb_type; R->cbp = (uint8_t)cbp; R->luma_qp = (uint8_t)qp; R->chroma_qp = (uint8_t)qpc;
-    R->i16_mode = (uint8_t)i16_mode; R->chroma_mode = (uint8_t)chroma_mode;
-    R->i4_prev_flags = (mb_type == WH_MB_I4x4) ? S.i4_prev : (uint16_t)0;
+    // (the header fields word by word: field by field they were fifteen byte / short stores with an address each)
+    const uint32_t i4p = (mb_type == WH_MB_I4x4) ? (uint32_t)S.i4_prev : 0u;
+    * (WH_G uint32_t*)&R->mb_type = (uint32_t) (mb_type & 255) | ((uint32_t) (cbp & 255) << 8) | ((uint32_t) (qp & 255) << 16) | ((uint32_t) (qpc & 255) << 24);
+    * (WH_G uint32_t*)&R->i16_mode = (uint32_t) (i16_mode & 255) | ((uint32_t) (chroma_mode & 255) << 8) | (i4p << 16);
     R->cost = cost;
     R->cavlc_bits = cavlc_bits;
-    M->mb_type = (uint8_t)mb_type; M->luma_qp = (uint8_t)qp; M->chroma_qp = (uint8_t)qpc; M->cbp = (uint8_t)cbp;
-    M->slice_idc = (uint16_t)slice_idc;
-    R->bgd_skip = 0;
+    * (WH_G uint32_t*)&R->bgd_skip = 0u;                    // bgd_skip + pad0
+    * (WH_G uint32_t*)&M->mb_type = (uint32_t) (mb_type & 255) | ((uint32_t) (qp & 255) << 8) | ((uint32_t) (qpc & 255) << 16) | ((uint32_t) (cbp & 255) << 24);
     // uiRefMbType / pRefMbQp of the picture (read when it is a reference): P pictures store the type, I pictures leave the
     // previous contents of the picture buffer alone (WelsMdInterSaveSadAndRefMbType is a P-slice step); both store the QP
     // (WelsMdUpdateBGDInfo; wh_inter_mb_body overrides it for unchanged collocated macroblocks)
-    if (J.slice_type == WH_SLICE_P) M->ref_type = (uint8_t) (mb_type + 1);
-    M->ref_qp = (uint8_t)qp;
+    if (J.slice_type == WH_SLICE_P) * (WH_G uint32_t*)&M->slice_idc = (uint32_t) (slice_idc & 0xffff) | ((uint32_t) ((mb_type + 1) & 255) << 16) | ((uint32_t) (qp & 255) << 24);
+    else { M->slice_idc = (uint16_t)slice_idc; M->ref_qp = (uint8_t)qp; }
   }
   WV_LANES_END
 }

@@ -1644,15 +1644,16 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
   WV_LANES_BEGIN (lane)
   if (lane < 16) {
     const int mvx = is_skip ? skx : S.mv_out[lane][0], mvy = is_skip ? sky : S.mv_out[lane][1];
-    Ms->mv[lane][0] = (int16_t)mvx; Ms->mv[lane][1] = (int16_t)mvy;
-    Rs->mvd[lane][0] = is_skip ? (int16_t)0 : (int16_t) (mvx - S.mvp_out[lane][0]);
-    Rs->mvd[lane][1] = is_skip ? (int16_t)0 : (int16_t) (mvy - S.mvp_out[lane][1]);
-    if (lane == 3) { Rs->mv_tr[0] = (int16_t)mvx; Rs->mv_tr[1] = (int16_t)mvy; }
+    // (one 32-bit store per pair of 16-bit fields: written field by field each pair was two global_store_short)
+    const uint32_t mv32 = (uint32_t)wh_pk_mv (mvx, mvy);
+    * (WH_G uint32_t*)&Ms->mv[lane][0] = mv32;
+    * (WH_G uint32_t*)&Rs->mvd[lane][0] = is_skip ? 0u : (uint32_t)wh_pk_mv (mvx - S.mvp_out[lane][0], mvy - S.mvp_out[lane][1]);
+    if (lane == 3) * (WH_G uint32_t*)&Rs->mv_tr[0] = mv32;
   }
   if (!(cbp & 15) || is_skip) { uint64_t* z = (uint64_t*)M.lv_luma; z[lane] = 0; }
-  if (lane < 4) { Ms->ref_idx[lane] = 0; Rs->ref_idx[lane] = 0; Rs->sub_type[lane] = 0; }
   if (lane == 0) {
-    Ms->sad_cost[0] = sad_cost0; Ms->p16mv[0] = (int16_t)p16x; Ms->p16mv[1] = (int16_t)p16y;
+    * (WH_G uint32_t*)&Ms->ref_idx[0] = 0u; * (WH_G uint32_t*)&Rs->ref_idx[0] = 0u; * (WH_G uint32_t*)&Rs->sub_type[0] = 0u;      // four bytes each
+    Ms->sad_cost[0] = sad_cost0; * (WH_G uint32_t*)&Ms->p16mv[0] = (uint32_t)wh_pk_mv (p16x, p16y);
     Ms->skip_sad = is_skip ? cost_skip_mb : 0;
     if (HOSTIN && J.sad_cost0) (J.sad_cost0_out ? (WH_G int32_t*)J.sad_cost0_out : (WH_G int32_t*)J.sad_cost0)[xy] = sad_cost0;
   }

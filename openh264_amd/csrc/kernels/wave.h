@@ -314,7 +314,10 @@ WH_HDFN void wh_stg16 (WH_G void* p, WhU4 v) { wh_u32x4_t t; t.x = v.x; t.y = v.
 #if defined(WH_EMU)
 WH_FN void wh_stg16_a4 (void* p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) { const uint32_t v[4] = {a, b, c, d}; memcpy (p, v, 16); }
 WH_FN void wh_stg8_a4 (void* p, uint32_t a, uint32_t b) { const uint32_t v[2] = {a, b}; memcpy (p, v, 8); }
+WH_FN void wh_stg12_a4 (void* p, uint32_t a, uint32_t b, uint32_t c) { const uint32_t v[3] = {a, b, c}; memcpy (p, v, 12); }
 #else
+typedef uint32_t wh_u32x3_a4_t __attribute__ ((ext_vector_type (3), aligned (4)));
+WH_FN void wh_stg12_a4 (WH_G void* p, uint32_t a, uint32_t b, uint32_t c) { const wh_u32x3_a4_t v = {a, b, c}; * (WH_G wh_u32x3_a4_t*)p = v; }
 typedef uint32_t wh_u32x4_a4_t __attribute__ ((ext_vector_type (4), aligned (4)));
 typedef uint32_t wh_u32x2_a4_t __attribute__ ((ext_vector_type (2), aligned (4)));
 WH_FN void wh_stg16_a4 (WH_G void* p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) { const wh_u32x4_a4_t v = {a, b, c, d}; * (WH_G wh_u32x4_a4_t*)p = v; }

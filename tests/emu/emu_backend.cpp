@@ -192,7 +192,8 @@ class EmuBackend : public Backend {
     for (int j = 0; j < n; ++j) {
       const int total = wh_expand_items (P);
       for (int i = 0; i < total; ++i) wh_expand_item (P, (uint8_t*)jobs[j].rec[0], (uint8_t*)jobs[j].rec[1], (uint8_t*)jobs[j].rec[2], i);
-      for (int i = 0; i < wh_tile_items (P); ++i) wh_tile_item (P, jobs[j], i);       // the tiled twin (kernels/tile_pic.h), as the device's run_expand
+      if (jobs[j].rec_blk) { for (int i = 0; i < wh_tile_border_items (P); ++i) wh_tile_border_item (P, jobs[j], i); }     // (the deblocking pass wrote the tiles inside the picture)
+      else for (int i = 0; i < wh_tile_items (P); ++i) wh_tile_item (P, jobs[j], i);       // the tiled twin (kernels/tile_pic.h), as the device's run_expand
     }
   }
   void run_src_tile (const WhSeqParams& P, const uint8_t* planar, uint8_t* tiled) override {
