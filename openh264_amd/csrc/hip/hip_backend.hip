@@ -175,10 +175,29 @@ __global__ WH_MD_ATTR __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P,
   WhInterStage& G = stage[wave];
   __shared__ WhWinLds winbuf[MAXT / 64];
   uint32_t* sched = (uint32_t*) (smem + (size_t)nw * sizeof (WhInterLds));     // per slot: [0] ticket counter, [1..] done bits
+  // The job descriptors of the slots' pictures: a copy in LDS (a uniform field = a ds_read plus a v_readfirstlane).  Measured in round 6 against
+  // reading them where they lie through the CONSTANT address space (one scalar load per field, nothing on the vector pipe: 117 vector instructions
+  // and 65 LDS instructions fewer in the listing): the scalar loads' latency on the dependent paths costs more than the vector instructions saved --
+  // MD launch 7.27 against 7.18 ms, same box, alternating (profiles/r06_ab_job_descriptors_constant_address_space.txt).  -DWH_JOBS_IN_LDS=0 builds that variant.
+#ifndef WH_JOBS_IN_LDS
+#define WH_JOBS_IN_LDS 1
+#endif
+#if WH_JOBS_IN_LDS
   __shared__ WhPicJob Jl[WH_MD_MAX_SLOTS];
+#define WH_JOB_OF_SLOT(sl) Jl[sl]
+#else
+  typedef const __attribute__ ((address_space (4))) WhPicJob WhPicJobC;
+  const WhPicJobC* const jobs_c = (const WhPicJobC*)jobs;
+  __shared__ int slot_pic[WH_MD_MAX_SLOTS];
+#define WH_JOB_OF_SLOT(sl) (* (const WhPicJob*) (jobs_c + __builtin_amdgcn_readlane (tab_pic, (sl))))
+#endif
   __shared__ int slot_first[WH_MD_MAX_SLOTS], slot_n[WH_MD_MAX_SLOTS], slot_idc[WH_MD_MAX_SLOTS], slot_id[WH_MD_MAX_SLOTS];
   __shared__ int slot_mv[WH_MD_MAX_SLOTS];         // most recent final 16x16 vector of each slot's slice: the window guess (wh_win_speculate)
   for (int i = (int)threadIdx.x; i < slots * sched_words; i += (int)blockDim.x) sched[i] = 0;
+  __shared__ uint32_t slot_cost[WH_MD_MAX_SLOTS];
+  __shared__ uint32_t waves_left;
+  if (threadIdx.x < WH_MD_MAX_SLOTS) slot_cost[threadIdx.x] = 0;
+  if (threadIdx.x == 0) waves_left = (uint32_t)nw;
 #if WH_PROF_ON
   if (P.prof && lane < 32) S.m.prof[lane] = 0;
 #endif
@@ -190,21 +209,34 @@ __global__ WH_MD_ATTR __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P,
       slot_first[sl] = P.slice_first_mb[idc]; slot_n[sl] = on ? P.slice_first_mb[idc + 1] - P.slice_first_mb[idc] : 0;
       slot_idc[sl] = idc; slot_id[sl] = on ? k : -1; slot_mv[sl] = 0;
     }
+#if WH_JOBS_IN_LDS
     wh_copy_job (&Jl[sl], &jobs[pic]);
+#else
+    if (threadIdx.x == 0) slot_pic[sl] = pic;
+#endif
   }
-  if (threadIdx.x == 0) for (int sl = slots; sl < WH_MD_MAX_SLOTS; ++sl) { slot_first[sl] = 0; slot_n[sl] = 0; slot_idc[sl] = 0; }
+  if (threadIdx.x == 0) for (int sl = slots; sl < WH_MD_MAX_SLOTS; ++sl) { slot_first[sl] = 0; slot_n[sl] = 0; slot_idc[sl] = 0;
+#if !WH_JOBS_IN_LDS
+    slot_pic[sl] = 0;
+#endif
+  }
   __syncthreads();
   WH_PROF_DECL (P);
   const unsigned long long wall0 = P.prof ? wall_clock64() : 0ULL;     // 100 MHz; wave lifetimes against the launch's span (WelsHipGroupProfile)
   // lane tables of the slots' constants (lane sl: slot sl)
   const int tab_first = slot_first[lane & (WH_MD_MAX_SLOTS - 1)], tab_n = slot_n[lane & (WH_MD_MAX_SLOTS - 1)], tab_idc = slot_idc[lane & (WH_MD_MAX_SLOTS - 1)];
+#if !WH_JOBS_IN_LDS
+  const int tab_pic = slot_pic[lane & (WH_MD_MAX_SLOTS - 1)];
+#endif
   WhInterCtx X;
   X.win = &winbuf[wave];
   X.spec_valid = 0;
   X.spec.b = X.win;
   X.last_mv = nullptr;
   uint32_t gone = 0;                      // slots this wave knows to be out of tickets (wave-uniform)
-  uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;     // cycles / 64 this wave spent on each slot's macroblocks
+  // cycles / 64 the workgroup spent on each slot's macroblocks: summed in LDS (one add per macroblock), handed to slice_cost by the last wave that
+  // leaves.  (Rounds 3-5: four scalar registers per wave, live across the whole body in a kernel that spills scalars.)
+  // (slot_cost / waves_left: declared and cleared before the workgroup's barrier above)
   int slot = -1, xy = 0, mbx = 0, mby = 0;        // the macroblock in hand
   int nslot = -1, nxy = 0, nmbx = 0, nmby = 0;    // the wave's next one
   // macroblock address -> (x, y) by a multiplication: ceil (2^32 / mb_w) is exact for addresses below 2^20 and widths below 2^12 (the
@@ -236,7 +268,7 @@ __global__ WH_MD_ATTR __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P,
       int rel = tt - (best == 0 ? ob0 : best == 1 ? ob1 : best == 2 ? ob2 : ob3);                                              \
       if ((unsigned)rel >= 64u) {           /* beyond the slot's window: the 64 entries from this ticket on */                 \
         int v_ = 0;                                                                                                            \
-        if (P.flags & WH_SEQ_CHAIN) { const WH_G uint32_t* src_ = (const WH_G uint32_t*)Jl[best].scc_order; if (tt + lane < n_) v_ = (int)src_[first_ + tt + lane]; } \
+        if (P.flags & WH_SEQ_CHAIN) { const WH_G uint32_t* src_ = (const WH_G uint32_t*)WH_JOB_OF_SLOT (best).scc_order; if (tt + lane < n_) v_ = (int)src_[first_ + tt + lane]; } \
         else { const WH_G uint32_t* src_ = (const WH_G uint32_t*)P.mb_order; if (tt + lane < n_) v_ = (int)src_[first_ + tt + lane]; }   \
         if (best == 0) { ow0 = v_; ob0 = tt; } else if (best == 1) { ow1 = v_; ob1 = tt; } else if (best == 2) { ow2 = v_; ob2 = tt; } else { ow3 = v_; ob3 = tt; } \
         rel = 0;                                                                                                               \
@@ -244,9 +276,9 @@ __global__ WH_MD_ATTR __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P,
       const int ow_ = best == 0 ? ow0 : best == 1 ? ow1 : best == 2 ? ow2 : ow3;                                               \
       xy_ = __builtin_amdgcn_readlane (ow_, rel);                                                                              \
     }                                                                                                                          \
-    const int mb_end_ = CTRL ? Jl[best].mb_end : 0;                                                                            \
+    const int mb_end_ = CTRL ? WH_JOB_OF_SLOT (best).mb_end : 0;                                                                            \
     if (mb_end_ > 0) {                    /* GOM-synchronous coding: only [mb_begin, mb_end) in this launch */                 \
-      if (xy_ < Jl[best].mb_begin) { if (lane == 0) atomicOr (&sched[best * sched_words + 1 + ((xy_ - first_) >> 5)], 1u << ((xy_ - first_) & 31)); continue; } \
+      if (xy_ < WH_JOB_OF_SLOT (best).mb_begin) { if (lane == 0) atomicOr (&sched[best * sched_words + 1 + ((xy_ - first_) >> 5)], 1u << ((xy_ - first_) & 31)); continue; } \
       if (xy_ >= mb_end_) continue;                                                                                            \
     }                                                                                                                          \
     nslot = best; nxy = xy_;                                                                                                   \
@@ -260,7 +292,7 @@ __global__ WH_MD_ATTR __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P,
   if (nslot >= 0) {                                                                                                            \
     WhPicJob Jf;                                                                                                               \
     {                                                                                                                          \
-      const WhPicJob& Jn = Jl[nslot];                                                                                          \
+      const WhPicJob& Jn = WH_JOB_OF_SLOT (nslot);                                                                                         \
       Jf.src[0] = Jn.src[0]; Jf.prev_src_y = Jn.prev_src_y; Jf.ref_mbs = Jn.ref_mbs; Jf.ref_is_p = Jn.ref_is_p;                \
       Jf.ref_tiles[0] = Jn.ref_tiles[0]; Jf.ref_tiles[1] = Jn.ref_tiles[1];                                                    \
       if (HOSTIN) { Jf.vaa_sad8x8 = Jn.vaa_sad8x8; Jf.sad_cost0 = Jn.sad_cost0; }                                              \
@@ -277,7 +309,7 @@ __global__ WH_MD_ATTR __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P,
   WH_FETCH_AHEAD()
   slot = nslot; xy = nxy; mbx = nmbx; mby = nmby;
   while (slot >= 0) {
-    const WhPicJob& J = Jl[slot];
+    const WhPicJob& J = WH_JOB_OF_SLOT (slot);
     const int first = __builtin_amdgcn_readlane (tab_first, slot);
     uint32_t* sc = sched + slot * sched_words;
     WH_PROF_MARK (P, S.m, 11);
@@ -302,8 +334,7 @@ __global__ WH_MD_ATTR __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P,
     __builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");
     if (lane == 0) atomicOr (&sc[1 + ((xy - first) >> 5)], 1u << ((xy - first) & 31));
     WH_PROF_MARK (P, S.m, 13);
-    const uint32_t dc = ((uint32_t)__builtin_readcyclecounter() - tc0) >> 6;
-    c0 += slot == 0 ? dc : 0u; c1 += slot == 1 ? dc : 0u; c2 += slot == 2 ? dc : 0u; c3 += slot == 3 ? dc : 0u;
+    if (slice_cost && lane == 0) atomicAdd (&slot_cost[slot], ((uint32_t)__builtin_readcyclecounter() - tc0) >> 6);
     WH_CLAIM()
     WH_PROF_SUB (P, S.m, 0);       /* detail: slot scan + ticket + order look-up */
     WH_FETCH_AHEAD()
@@ -311,11 +342,8 @@ __global__ WH_MD_ATTR __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P,
   }
 #undef WH_CLAIM
 #undef WH_FETCH_AHEAD
-  if (slice_cost && lane == 0) {
-    if (slot_id[0] >= 0 && c0) atomicAdd (&slice_cost[slot_id[0]], c0);
-    if (slots > 1 && slot_id[1] >= 0 && c1) atomicAdd (&slice_cost[slot_id[1]], c1);
-    if (slots > 2 && slot_id[2] >= 0 && c2) atomicAdd (&slice_cost[slot_id[2]], c2);
-    if (slots > 3 && slot_id[3] >= 0 && c3) atomicAdd (&slice_cost[slot_id[3]], c3);
+  if (slice_cost && lane == 0 && atomicSub (&waves_left, 1u) == 1u) {        // the workgroup's last wave: every slot's sum is complete
+    for (int sl = 0; sl < slots; ++sl) { const uint32_t c = __hip_atomic_load (&slot_cost[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); if (slot_id[sl] >= 0 && c) atomicAdd (&slice_cost[slot_id[sl]], c); }
   }
 #if WH_PROF_ON
   if (P.prof && lane < 32) atomicAdd (&P.prof[((blockIdx.x * 7u) & 63u) * 32u + lane], (unsigned long long)S.m.prof[lane]);
@@ -797,7 +825,7 @@ class HipBackend : public wh::Backend {
     // (static arrays: 6 / 12 / 14 / 16) + the job descriptors and the scheduler's words.  10.0 KB per wave since round 5 = 16 waves per CU
     // (rounds 1-4: 12.7 KB = 12 waves).
     auto built_for = [] (int w) { return w <= 6 ? 6 : w <= 12 ? 12 : w <= 14 ? 14 : 16; };
-    const size_t fixed = WH_MD_MAX_SLOTS * (sizeof (WhPicJob) + 24) + 4 * (size_t)slots * sched_words;
+    const size_t fixed = WH_MD_MAX_SLOTS * (sizeof (WhPicJob) + 32) + 4 * (size_t)slots * sched_words;
     while (nw > 1 && (size_t)nw * sizeof (WhInterLds) + (size_t)built_for (nw) * (sizeof (WhInterStage) + sizeof (WhWinLds)) + fixed > (size_t)160 * 1024) --nw;
     const size_t lds = (size_t)nw * sizeof (WhInterLds) + 4 * (size_t)slots * sched_words;
     uint16_t* grp = nullptr;
