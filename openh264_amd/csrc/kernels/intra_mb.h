@@ -428,57 +428,22 @@ WH_FN bool wh_intra_md_enc_p (WhMbLds& S, const WhSeqParams& P, const WhPicJob& 
     uint16_t prev_flags = 0;
     bool completed = true;
     WH_PROF_MARK_I (3);     // texture analysis + neighbour mode cache
-    for (int b = 0; b < 16; ++b) {
+    // sample availability of 4x4 block b (the reference tabulates it: g_kiNeighborIntraToI4x4)
+    auto blk_avail = [&] (int b, bool& a_l, bool& a_t, bool& a_tl, bool& a_tr) {
       const int bx = wh_blk_x (b), by = wh_blk_y (b);
-      // sample availability of this 4x4 block (the reference tabulates it: g_kiNeighborIntraToI4x4)
-      const bool a_l = bx > 0 || has_l;
-      const bool a_t = by > 0 || has_t;
-      bool a_tl, a_tr;
+      a_l = bx > 0 || has_l;
+      a_t = by > 0 || has_t;
       if (bx > 0 && by > 0) a_tl = true;
       else if (bx > 0) a_tl = has_t;
       else if (by > 0) a_tl = has_l;
       else a_tl = (avail & WH_AV_TOPLEFT) != 0;
       if (by == 0) a_tr = (bx < 3) ? has_t : ((avail & WH_AV_TOPRIGHT) != 0);
-      else a_tr = ((0x5744 >> b) & 1) != 0;   // blocks whose top-right 4x4 is already reconstructed inside this MB
-      // predicted mode
-      const int m_left = WV_LGET (i4t, (by + 1) * 5 + bx), m_top = WV_LGET (i4t, by * 5 + bx + 1);
-      const int pred_mode = (m_left == -1 || m_top == -1) ? 2 : wh_min (m_left, m_top);
-      // candidate predictions: the block's filter table (see kWhI4Desc), then lane (mode m = lane >> 2, row r = lane & 3) fetches its
-      // four samples, stores them for the encode step and costs them; the modes' costs are quad sums, read from a lane table
-      uint8_t* const tbl = (uint8_t*)S.part2;
-      WV_LANES_BEGIN (lane)
-      wh_i4_fill_table (S, tbl, lane, bx, by, a_l, a_t);
-      WV_LANES_END
-      WvLaneArr ct;
-#if defined(WH_EMU)
-      memset (&ct, 0, sizeof (ct));
-#else
-      ct = 0;
-#endif
-      WV_QUADSUM_TAB (ct, lane, (lane < 36 ? ([&] () {
-        const int m = lane >> 2, r = lane & 3;
-        const uint32_t d = (uint32_t)WV_LOWN (dsc, lane);
-        const uint32_t px = (uint32_t)tbl[d & 255u] | ((uint32_t)tbl[(d >> 8) & 255u] << 8) | ((uint32_t)tbl[(d >> 16) & 255u] << 16) | ((uint32_t)tbl[d >> 24] << 24);
-        * (uint32_t*)&S.pred4[m * 16 + r * 4] = px;
-        const uint32_t e = * (const uint32_t*)&S.enc_y[(by * 4 + r) * 16 + bx * 4];
-        if (!use_satd) return wh_sad4 (e, px);
-        int o0, o1, o2, o3;
-        wh_had4 ((int) (e & 255u) - (int) (px & 255u), (int) ((e >> 8) & 255u) - (int) ((px >> 8) & 255u), (int) ((e >> 16) & 255u) - (int) ((px >> 16) & 255u),
-                 (int) (e >> 24) - (int) (px >> 24), &o0, &o1, &o2, &o3);
-        int16_t* t = &S.tmp[m * 16 + r * 4];
-        t[0] = (int16_t)o0; t[1] = (int16_t)o1; t[2] = (int16_t)o2; t[3] = (int16_t)o3;
-        return 0; }) () : 0));
-      WV_SYNC();                           // (the lanes' stores above are read by other lanes below and in the encode step)
-      if (use_satd) {
-        WV_QUADSUM_TAB (ct, lane, (lane < 36 ? ([&] () {
-          const int m = lane >> 2, c = lane & 3;
-          const int16_t* t = &S.tmp[m * 16 + c];
-          int o0, o1, o2, o3;
-          wh_had4 (t[0], t[4], t[8], t[12], &o0, &o1, &o2, &o3);
-          return wh_abs (o0) + wh_abs (o1) + wh_abs (o2) + wh_abs (o3); }) () : 0));
-      }
+      else a_tr = ((0x5744 >> b) & 1) != 0;   // blocks whose top-right 4x4 is already reconstructed inside this MB (in CODING order: what the decoder has)
+    };
+    // the block's best mode from the cost table `ct` (mode m at lane cbase + m * cstep)
+    auto decide = [&] (const WvLaneArr& ct, int cbase, int cstep, bool a_l, bool a_t, bool a_tl, bool a_tr, int pred_mode, int& bmode, int& bcost) {
       // cost of standard mode m incl. the mode-signalling term lambda[pred_mode == m]
-#define WH_C4(m) ((use_satd ? ((WV_LGET (ct, (m) * 4) + 1) >> 1) : WV_LGET (ct, (m) * 4)) + ((pred_mode == (m)) ? lambda : lam4))
+#define WH_C4(m) ((use_satd ? ((WV_LGET (ct, cbase + (m) * cstep) + 1) >> 1) : WV_LGET (ct, cbase + (m) * cstep)) + ((pred_mode == (m)) ? lambda : lam4))
       // candidate order of the reference (g_kiIntra4AvailMode rows), standard numbering
       // (the list is packed four bits per entry: an int array indexed at run time would live in scratch memory)
       unsigned long long list = 0;
@@ -492,7 +457,6 @@ WH_FN bool wh_intra_md_enc_p (WhMbLds& S, const WhSeqParams& P, const WhPicJob& 
       } else if (a_l) { WH_PUSH (2); WH_PUSH (1); WH_PUSH (8); }
       else if (a_t) { WH_PUSH (2); WH_PUSH (0); if (a_tr) { WH_PUSH (3); WH_PUSH (7); } }
       else { WH_PUSH (2); }
-      int bmode, bcost;
       if (!use_satd && (n == 9 || n == 7)) {
         // WelsMdI4x4Fast decision tree (svc_base_layer_md.cpp:598-826)
         bmode = 2; bcost = WH_C4 (2);
@@ -542,14 +506,133 @@ WH_FN bool wh_intra_md_enc_p (WhMbLds& S, const WhSeqParams& P, const WhPicJob& 
 #undef WH_C4
 #undef WH_PUSH
 #undef WH_LIST
+    };
+    // one block, start to finish (rounds 1-5: all sixteen, in coding order); false = the MB's Intra4x4 attempt is over
+    auto single_block = [&] (int b) -> bool {
+      const int bx = wh_blk_x (b), by = wh_blk_y (b);
+      bool a_l, a_t, a_tl, a_tr;
+      blk_avail (b, a_l, a_t, a_tl, a_tr);
+      // predicted mode
+      const int m_left = WV_LGET (i4t, (by + 1) * 5 + bx), m_top = WV_LGET (i4t, by * 5 + bx + 1);
+      const int pred_mode = (m_left == -1 || m_top == -1) ? 2 : wh_min (m_left, m_top);
+      // candidate predictions: the block's filter table (see kWhI4Desc), then lane (mode m = lane >> 2, row r = lane & 3) fetches its
+      // four samples, stores them for the encode step and costs them; the modes' costs are quad sums, read from a lane table
+      uint8_t* const tbl = (uint8_t*)S.part2;
+      WV_LANES_BEGIN (lane)
+      wh_i4_fill_table (S, tbl, lane, bx, by, a_l, a_t);
+      WV_LANES_END
+      WvLaneArr ct;
+#if defined(WH_EMU)
+      memset (&ct, 0, sizeof (ct));
+#else
+      ct = 0;
+#endif
+      WV_QUADSUM_TAB (ct, lane, (lane < 36 ? ([&] () {
+        const int m = lane >> 2, r = lane & 3;
+        const uint32_t d = (uint32_t)WV_LOWN (dsc, lane);
+        const uint32_t px = (uint32_t)tbl[d & 255u] | ((uint32_t)tbl[(d >> 8) & 255u] << 8) | ((uint32_t)tbl[(d >> 16) & 255u] << 16) | ((uint32_t)tbl[d >> 24] << 24);
+        * (uint32_t*)&S.pred4[m * 16 + r * 4] = px;
+        const uint32_t e = * (const uint32_t*)&S.enc_y[(by * 4 + r) * 16 + bx * 4];
+        if (!use_satd) return wh_sad4 (e, px);
+        int o0, o1, o2, o3;
+        wh_had4 ((int) (e & 255u) - (int) (px & 255u), (int) ((e >> 8) & 255u) - (int) ((px >> 8) & 255u), (int) ((e >> 16) & 255u) - (int) ((px >> 16) & 255u),
+                 (int) (e >> 24) - (int) (px >> 24), &o0, &o1, &o2, &o3);
+        int16_t* t = &S.tmp[m * 16 + r * 4];
+        t[0] = (int16_t)o0; t[1] = (int16_t)o1; t[2] = (int16_t)o2; t[3] = (int16_t)o3;
+        return 0; }) () : 0));
+      WV_SYNC();                           // (the lanes' stores above are read by other lanes below and in the encode step)
+      if (use_satd) {
+        WV_QUADSUM_TAB (ct, lane, (lane < 36 ? ([&] () {
+          const int m = lane >> 2, c = lane & 3;
+          const int16_t* t = &S.tmp[m * 16 + c];
+          int o0, o1, o2, o3;
+          wh_had4 (t[0], t[4], t[8], t[12], &o0, &o1, &o2, &o3);
+          return wh_abs (o0) + wh_abs (o1) + wh_abs (o2) + wh_abs (o3); }) () : 0));
+      }
+      int bmode, bcost;
+      decide (ct, 0, 4, a_l, a_t, a_tl, a_tr, pred_mode, bmode, bcost);
       cost4 += bcost;
-      if (cost4 >= cost_luma) { completed = false; break; }
+      if (cost4 >= cost_luma) { completed = false; return false; }
       if (pred_mode == bmode) prev_flags |= (uint16_t) (1u << b);
       const int rem = (bmode < pred_mode) ? bmode : bmode - 1;
       WV_LSET (i4t, (by + 1) * 5 + bx + 1, bmode);
       // (the block's mode, rem_intra4x4_pred_mode and total_coeff go into the tile inside the encode step's own lane blocks)
       const int nz = wh_encrec_i4 (S, b, bmode, qp, (int8_t) ((pred_mode == bmode) ? 0 : rem));
       if (nz > 0) cbp |= 1 << (b >> 2);
+      return true;
+    };
+    // Two blocks at once, one per half of the wave (round 6; SAD costs, i.e. LOW complexity).  The sixteen blocks of a macroblock are no chain: a
+    // block predicts from its left, upper, upper-left and -- where coding order has it -- upper-right neighbour, so the blocks of one 2:1
+    // diagonal of the 4x4 grid (bx + 2 by) are independent: ten steps, six of them with two blocks -- (2,0)+(0,1), (3,0)+(1,1), (2,1)+(0,2),
+    // (3,1)+(1,2), (2,2)+(0,3), (3,2)+(1,3) -- instead of sixteen.  What coding order decides stays as it is: upper-right availability is the table
+    // above, and the early end of the attempt (svc_base_layer_md.cpp:418-546: the costs are added up in coding order until they reach the
+    // Intra16x16 cost) depends on the blocks' order only through WHEN it happens, never WHETHER: the costs are not negative, so some prefix of
+    // the coding order reaches the limit exactly when the sum of ALL of them does, and an attempt that ends leaves nothing behind that is read
+    // (Intra16x16 then codes every block again).  Lanes 0..31 hold the step's first block, lanes 32..63 the second.
+    auto block_pair = [&] (int bA, int bB) -> bool {
+      const int bxA = wh_blk_x (bA), byA = wh_blk_y (bA), bxB = wh_blk_x (bB), byB = wh_blk_y (bB);
+      bool alA, atA, atlA, atrA, alB, atB, atlB, atrB;
+      blk_avail (bA, alA, atA, atlA, atrA);
+      blk_avail (bB, alB, atB, atlB, atrB);
+      const int mlA = WV_LGET (i4t, (byA + 1) * 5 + bxA), mtA = WV_LGET (i4t, byA * 5 + bxA + 1), mlB = WV_LGET (i4t, (byB + 1) * 5 + bxB), mtB = WV_LGET (i4t, byB * 5 + bxB + 1);
+      const int pmA = (mlA == -1 || mtA == -1) ? 2 : wh_min (mlA, mtA), pmB = (mlB == -1 || mtB == -1) ? 2 : wh_min (mlB, mtB);
+      uint8_t* const tbl2 = (uint8_t*)S.part;                 // two filter tables, 64 bytes apart
+      uint8_t* const predB = (uint8_t*)&S.res[256];           // the second block's nine candidates (the chroma coefficients' place: not in use before the chroma step)
+      WV_LANES_BEGIN (lane)
+      {
+        const int h = lane >> 5;
+        wh_i4_fill_table (S, tbl2 + 64 * h, lane & 31, h ? bxB : bxA, h ? byB : byA, h ? alB : alA, h ? atB : atA);
+      }
+      WV_LANES_END
+      // lane (half h, mode m = (lane & 31) >> 1, rows 2 p and 2 p + 1 with p = lane & 1): fetches, stores and costs two rows; a mode's cost is the sum of its
+      // two lanes.  The descriptor of (mode, row) sits in lane 4 m + row of `dsc`
+      WvLaneArr d0, d1, ct;
+#if defined(WH_EMU)
+      memset (&d0, 0, sizeof (d0)); memset (&d1, 0, sizeof (d1)); memset (&ct, 0, sizeof (ct));
+#else
+      d0 = 0; d1 = 0; ct = 0;
+#endif
+      WV_LSHUF (d0, dsc, lane, ((lane & 31) < 18 ? ((lane & 31) >> 1) * 4 + (lane & 1) * 2 : 0));
+      WV_LSHUF (d1, dsc, lane, ((lane & 31) < 18 ? ((lane & 31) >> 1) * 4 + (lane & 1) * 2 + 1 : 0));
+      WV_PAIRSUM_TAB (ct, lane, ((lane & 31) < 18 ? ([&] () {
+        const int h = lane >> 5, m = (lane & 31) >> 1, r0 = (lane & 1) * 2;
+        const uint8_t* tbl = tbl2 + 64 * h;
+        uint8_t* pr = h ? predB : S.pred4;
+        const int bx = h ? bxB : bxA, by = h ? byB : byA;
+        int c = 0;
+        for (int k = 0; k < 2; ++k) {
+          const uint32_t d = (uint32_t) (k ? WV_LOWN (d1, lane) : WV_LOWN (d0, lane));
+          const uint32_t px = (uint32_t)tbl[d & 255u] | ((uint32_t)tbl[(d >> 8) & 255u] << 8) | ((uint32_t)tbl[(d >> 16) & 255u] << 16) | ((uint32_t)tbl[d >> 24] << 24);
+          * (uint32_t*)&pr[m * 16 + (r0 + k) * 4] = px;
+          c += wh_sad4 (* (const uint32_t*)&S.enc_y[(by * 4 + r0 + k) * 16 + bx * 4], px);
+        }
+        return c; }) () : 0));
+      WV_SYNC();
+      int bmA, bcA, bmB, bcB;
+      decide (ct, 0, 2, alA, atA, atlA, atrA, pmA, bmA, bcA);
+      decide (ct, 32, 2, alB, atB, atlB, atrB, pmB, bmB, bcB);
+      cost4 += bcA + bcB;
+      if (cost4 >= cost_luma) { completed = false; return false; }
+      if (pmA == bmA) prev_flags |= (uint16_t) (1u << bA);
+      if (pmB == bmB) prev_flags |= (uint16_t) (1u << bB);
+      WV_LSET (i4t, (byA + 1) * 5 + bxA + 1, bmA);
+      WV_LSET (i4t, (byB + 1) * 5 + bxB + 1, bmB);
+      const int remA = (pmA == bmA) ? 0 : (bmA < pmA) ? bmA : bmA - 1, remB = (pmB == bmB) ? 0 : (bmB < pmB) ? bmB : bmB - 1;
+      int nzA, nzB;
+      wh_encrec_i4_pair (S, bA, bB, bmA, bmB, qp, (int8_t)remA, (int8_t)remB, predB, &nzA, &nzB);
+      if (nzA > 0) cbp |= 1 << (bA >> 2);
+      if (nzB > 0) cbp |= 1 << (bB >> 2);
+      return true;
+    };
+    if (use_satd) {
+      for (int b = 0; b < 16; ++b) if (!single_block (b)) break;
+    } else {
+      // (the steps' blocks as nibbles, the second one 15 + 1 = none; luma4x4BlkIdx: (2,0) = 4, (0,1) = 2, (3,0) = 5, (1,1) = 3, (2,1) = 6, (0,2) = 8, ...)
+      const unsigned long long first = 0xFEBA763210ULL, second = 0x00DC985400ULL;
+      for (int st = 0; st < 10; ++st) {
+        const int bA = (int) ((first >> (4 * st)) & 15ULL), bB = (int) ((second >> (4 * st)) & 15ULL);
+        if (!(bB ? block_pair (bA, bB) : single_block (bA))) break;
+      }
     }
     if (completed) cost4 += (lambda << 4) + (lambda << 3);
     if (completed && cost4 < cost_luma) {

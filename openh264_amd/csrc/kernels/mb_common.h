@@ -419,6 +419,90 @@ WH_FN int wh_encrec_i4 (WhMbLds& S, int b, int pred_slot, int qp, int8_t rem) {
   return nz;
 }
 
+// The same for TWO blocks at once -- bA on lanes 0..31, bB on lanes 32..63 (intra_mb.h: the blocks of one 2:1 diagonal of the 4x4 grid are independent) --
+// with the lane roles of wh_encrec_i4 inside each half.  predB: the second block's candidate predictions (the first one's are S.pred4); the transform
+// scratch is S.tmp[0..15] for the first block, S.tmp[16..31] for the second.
+WH_FN void wh_encrec_i4_pair (WhMbLds& S, int bA, int bB, int slotA, int slotB, int qp, int8_t remA, int8_t remB, const uint8_t* predB, int* nzA, int* nzB) {
+#define WH_I4P_HALF const int h = lane >> 5, ll = lane & 31, b = h ? bB : bA, slot = h ? slotB : slotA, bx = wh_blk_x (b) * 4, by = wh_blk_y (b) * 4; const uint8_t* pr = h ? predB : S.pred4
+  WV_LANES_BEGIN (lane)
+  {
+    WH_I4P_HALF;
+    if (ll < 4) {
+      const uint8_t* e = &S.enc_y[(by + ll) * 16 + bx];
+      const uint8_t* p = &pr[slot * 16 + ll * 4];
+      int16_t o0, o1, o2, o3;
+      wh_fdct4 (e[0] - p[0], e[1] - p[1], e[2] - p[2], e[3] - p[3], &o0, &o1, &o2, &o3);
+      int16_t* t = &S.tmp[h * 16 + ll * 4];
+      t[0] = o0; t[1] = o1; t[2] = o2; t[3] = o3;
+    } else if (ll == 4) {
+      S.i4m[((by >> 2) + 1) * 5 + (bx >> 2) + 1] = (int8_t)slot;
+      S.i4_rem[b] = h ? remB : remA;
+    }
+  }
+  WV_LANES_END
+  WvLaneArr nzt;
+#if defined(WH_EMU)
+  memset (&nzt, 0, sizeof (nzt));
+#else
+  nzt = 0;
+#endif
+  WV_QUADSUM_TAB (nzt, lane, ((lane & 31) < 4 ? ([&] () {
+    const int h = lane >> 5, ll = lane & 31, b = h ? bB : bA;
+    const int16_t* t = &S.tmp[h * 16 + ll];
+    int16_t o[4];
+    wh_fdct4 (t[0], t[4], t[8], t[12], &o[0], &o[1], &o[2], &o[3]);
+    int cnt = 0;
+    for (int k = 0; k < 4; ++k) {
+      const int pos = k * 4 + ll;
+      const int16_t q = wh_quant1_t (o[k], wh_ff_intra (qp, pos), wh_mf (qp, pos));
+      S.res[b * 16 + pos] = q;
+      cnt += q != 0;
+    }
+    return cnt; }) () : 0));
+  WV_SYNC();
+  const int nz0 = WV_LGET (nzt, 0), nz1 = WV_LGET (nzt, 32);
+  *nzA = nz0; *nzB = nz1;
+  WV_LANES_BEGIN (lane)
+  {
+    WH_I4P_HALF;
+    const int nz = h ? nz1 : nz0;
+    if (ll < 16) S.lv_luma[b * 16 + ll] = S.res[b * 16 + wh_zigzag (ll)];
+    if (ll == 16) S.nzc[(by >> 2) * 4 + (bx >> 2)] = (uint8_t)nz;
+    if (nz > 0) {
+      if (ll < 4) {                     // dequant (WelsDequant4x4_c, int16 wrap) + horizontal inverse
+        const int16_t* c = &S.res[b * 16 + ll * 4];
+        int16_t t0, t1, t2, t3;
+        wh_idct4_h ((int16_t) (c[0] * wh_dq (qp, ll * 4 + 0)), (int16_t) (c[1] * wh_dq (qp, ll * 4 + 1)),
+                    (int16_t) (c[2] * wh_dq (qp, ll * 4 + 2)), (int16_t) (c[3] * wh_dq (qp, ll * 4 + 3)), &t0, &t1, &t2, &t3);
+        int16_t* t = &S.tmp[h * 16 + ll * 4];
+        t[0] = t0; t[1] = t1; t[2] = t2; t[3] = t3;
+      }
+    } else if (ll >= 16) {
+      const int l = ll - 16;
+      WH_RY (S, bx + (l & 3), by + (l >> 2)) = pr[slot * 16 + l];
+    }
+  }
+  WV_LANES_END
+  if (nz0 > 0 || nz1 > 0) {
+    WV_LANES_BEGIN (lane)
+    {
+      WH_I4P_HALF;
+      if (ll < 4 && (h ? nz1 : nz0) > 0) {
+        const int16_t* t = &S.tmp[h * 16 + ll];
+        int r0, r1, r2, r3;
+        wh_idct4_v (t[0], t[4], t[8], t[12], &r0, &r1, &r2, &r3);
+        const uint8_t* p = &pr[slot * 16 + ll];
+        WH_RY (S, bx + ll, by + 0) = wh_clip255 (p[0] + r0);
+        WH_RY (S, bx + ll, by + 1) = wh_clip255 (p[4] + r1);
+        WH_RY (S, bx + ll, by + 2) = wh_clip255 (p[8] + r2);
+        WH_RY (S, bx + ll, by + 3) = wh_clip255 (p[12] + r3);
+      }
+    }
+    WV_LANES_END
+  }
+#undef WH_I4P_HALF
+}
+
 // JVT-O079 "single coefficient" score of a block whose levels are all +-1 (WelsGetNoneZeroCount / the run table of svc_encode_mb.cpp:
 // 3 for a coefficient right behind the previous one in zig-zag order, 2 after a run of one or two zeros, 1 after three to five, 0
 // beyond), from the mask of non-zero zig-zag positions.  Bit-parallel: a coefficient scores [run < 1] + [run < 3] + [run < 6], and

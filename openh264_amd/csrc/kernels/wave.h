@@ -49,6 +49,13 @@
   do { int _t[64]; for (int lane = 0; lane < 64; ++lane) _t[lane] = (int)(expr); \
        for (int _q = 0; _q < 16; ++_q) { const int _s = _t[4 * _q] + _t[4 * _q + 1] + _t[4 * _q + 2] + _t[4 * _q + 3]; \
          for (int _k = 0; _k < 4; ++_k) (tab).v[4 * _q + _k] = _s; } } while (0)
+// pair sums as a lane table: both lanes of pair p (lanes 2 p, 2 p + 1) of `tab` hold the sum of expr over the pair (expr: evaluated once per lane, in lane order)
+#define WV_PAIRSUM_TAB(tab, lane, expr)                           \
+  do { int _t[64]; for (int lane = 0; lane < 64; ++lane) _t[lane] = (int)(expr); \
+       for (int _p = 0; _p < 32; ++_p) { (tab).v[2 * _p] = (tab).v[2 * _p + 1] = _t[2 * _p] + _t[2 * _p + 1]; } } while (0)
+// dst[lane] = src[idx (lane)] for every lane (idx in 0 .. 63): a lane table read at a per-lane index
+#define WV_LSHUF(dst, src, lane, idx)                             \
+  do { WvLaneArr _s = (src); for (int lane = 0; lane < 64; ++lane) (dst).v[lane] = _s.v[(idx) & 63]; } while (0)
 // four sums at once: d_i = sum of expr over the lanes of quad i (4 i .. 4 i + 3), i = 0..3 -- sixteen lanes, one value each
 #define WV_QUADSUM4(d0, d1, d2, d3, lane, expr)                   \
   do { int _q[4] = {0, 0, 0, 0}; for (int lane = 0; lane < 16; ++lane) _q[lane >> 2] += (int)(expr); \
@@ -191,6 +198,11 @@ WH_FN int wh_wave_min_i32 (int v) {
 #define WV_QUADSUM_TAB(tab, lane, expr)                           \
   do { const int lane = wh_lane_id(); int _v = (int)(expr);       \
        _v += WH_DPP (_v, 0xB1); _v += WH_DPP (_v, 0x4E); (tab) = _v; } while (0)
+#define WV_PAIRSUM_TAB(tab, lane, expr)                           \
+  do { const int lane = wh_lane_id(); int _v = (int)(expr);       \
+       _v += WH_DPP (_v, 0xB1); (tab) = _v; } while (0)
+#define WV_LSHUF(dst, src, lane, idx)                             \
+  do { const int lane = wh_lane_id(); (dst) = __builtin_amdgcn_ds_bpermute ((int)(idx) << 2, (src)); } while (0)
 #define WV_QUADSUM4(d0, d1, d2, d3, lane, expr)                   \
   do { const int lane = wh_lane_id(); int _v = (int)(expr);       \
        _v += WH_DPP (_v, 0xB1); _v += WH_DPP (_v, 0x4E);          \
