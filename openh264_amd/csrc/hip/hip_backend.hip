@@ -17,6 +17,7 @@
 #include <atomic>
 #include "../host/backend.h"
 #include "../kernels/frame_kernels.h"
+#include <mutex>
 #include "../kernels/deblock_mb.h"
 #include "../kernels/inter_mb.h"
 #include "../kernels/expand_pic.h"
@@ -38,6 +39,7 @@ namespace {
 // bounded anyway and reports through P.prof-independent error word `err` (host checks it after the step).
 #define WH_NUM_QUEUES 32               /* host queues (HIP streams), all created with the backend */
 #define WH_ERR_WORDS 4                  /* error dwords per queue: count, block x, block y, awaited index */
+#define WH_SEAM_SPIN_LIMIT (1u << 22)   /* waits on flags in device memory (deblocking seams, k_inter_split) */
 #define WH_SPIN_LIMIT (1u << 23)       // x ~200 cycles: close to a second.  A wait can legitimately be long when the head of the
                                        // chain waits for another workgroup (deblocking seams) that is not resident yet
 
@@ -357,6 +359,102 @@ __global__ WH_MD_ATTR __launch_bounds__ (MAXT) void k_inter_pool (WhSeqParams P,
 }
 
 
+// ---- P pictures of a launch with FEW slices: every slice on several compute units (round 6) ----------------------------------
+// One session through the frame API is one picture per launch: four slices = four workgroups of k_inter_pool on four of 256 CUs, and what the caller waits
+// for is a chain of 152 macroblock steps at the latency a macroblock has when sixteen waves share a CU (27 us on the reference's 1080p clip: 4.6 ms per
+// picture, profiles/r06_single_session_timeline.txt).  Here a slice's macroblocks are taken by the waves of `parts` workgroups -- few waves per CU, so a
+// macroblock runs at close to its unloaded latency -- with the scheduler's words (ticket counter, done bits) in device memory instead of LDS and the data
+// that passes between macroblocks (state, unfiltered samples) stored write-through and loaded past the caches (inter_mb.h XWG; the deblocking bands' seams
+// work the same way; tools/micro/xcd_stale.hip: a hop costs about a microsecond and never returns a line an earlier read left in the reader's L2).
+// Tickets are handed out in a topological order over the whole slice, so a resident wave only ever waits for macroblocks that resident waves hold: no
+// assumption on which workgroups are resident, and none on their placement -- blocks b, b + 8, b + 16 ... serve one slice because they share an XCD's L2
+// (speed only).  Not for screen content, chained orders or the control inputs (VAR 0): their extra dependencies stay inside one workgroup.
+__device__ __forceinline__ bool wh_wait_done_x (const uint32_t* done, int idx, uint32_t* err) {
+  if (idx < 0) return true;
+  uint32_t spins = 0;
+  while (!((__hip_atomic_load (&done[idx >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >> (idx & 31)) & 1u)) {
+    __builtin_amdgcn_s_sleep (8);
+    if (++spins > WH_SEAM_SPIN_LIMIT) {
+      if ((threadIdx.x & 63) == 0 && atomicAdd (err, 1u) == 0) { err[1] = blockIdx.x; err[2] = blockIdx.y; err[3] = 0x40000000u | (uint32_t)idx; }
+      return false;
+    }
+  }
+  return true;
+}
+#define WH_SPLIT_WAVES 6
+template <int VAR>
+__global__ __launch_bounds__ (WH_SPLIT_WAVES * 64) void k_inter_split (WhSeqParams P, const WhPicJob* jobs, uint32_t* err, uint32_t* xsched, int sched_words, int parts, int total_slices) {
+  constexpr bool HOSTIN = VAR == 3;
+  extern __shared__ __align__ (16) uint8_t smem[];
+  const int lane = (int)threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane ((int)threadIdx.x >> 6);
+  // blocks g * 8 * parts + part * 8 + r, part = 0 .. parts - 1, serve slice k = g * 8 + r
+  const int per = 8 * parts, g = (int)blockIdx.x / per, rem = (int)blockIdx.x - g * per, k = g * 8 + (rem & 7);
+  if (k >= total_slices) return;
+  WhInterLds& S = ((WhInterLds*)smem)[wave];
+  __shared__ WhInterStage stage[WH_SPLIT_WAVES];
+  __shared__ WhWinLds winbuf[WH_SPLIT_WAVES];
+  __shared__ WhPicJob Jl;
+  __shared__ int slot_mv;
+  WhInterStage& G = stage[wave];
+  const int pic = k / P.num_slices, idc = k - pic * P.num_slices;
+  const int first = P.slice_first_mb[idc], n = P.slice_first_mb[idc + 1] - first;
+  uint32_t* sc = xsched + (size_t)k * sched_words;          // [0] ticket counter, [1 ..] done bits: zeroed by the host before the launch
+  wh_copy_job (&Jl, &jobs[pic]);
+  if (threadIdx.x == 0) slot_mv = 0;
+#if WH_PROF_ON
+  if (P.prof && lane < 32) S.m.prof[lane] = 0;
+#endif
+  __syncthreads();
+  const WhPicJob& J = Jl;
+  const uint32_t* order = P.mb_order + first;
+  WhInterCtx X;
+  X.win = &winbuf[wave];
+  X.spec_valid = 0;
+  X.spec.b = X.win;
+  X.last_mv = &slot_mv;
+  X.slice_idc = idc; X.slice_first = first;
+  const uint32_t w_rcp = P.mb_w > 1 ? 0xffffffffu / (uint32_t)P.mb_w + 1u : 0u;
+  int xy = -1, mbx = 0, mby = 0;
+#define WH_XCLAIM()                                                                                                            \
+  {                                                                                                                            \
+    int tt = 0;                                                                                                                \
+    if (lane == 0) tt = (int)__hip_atomic_fetch_add (&sc[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                  \
+    tt = __builtin_amdgcn_readfirstlane (tt);                                                                                  \
+    xy = -1;                                                                                                                   \
+    if (tt < n) {                                                                                                              \
+      xy = (int)order[tt];                                                                                                     \
+      mby = P.mb_w > 1 ? (int)__umulhi ((uint32_t)xy, w_rcp) : xy; mbx = xy - mby * P.mb_w;                                    \
+      WhPicJob Jf;                                                                                                             \
+      Jf.src[0] = J.src[0]; Jf.prev_src_y = J.prev_src_y; Jf.ref_mbs = J.ref_mbs; Jf.ref_is_p = J.ref_is_p;                    \
+      Jf.ref_tiles[0] = J.ref_tiles[0]; Jf.ref_tiles[1] = J.ref_tiles[1];                                                      \
+      if (HOSTIN) { Jf.vaa_sad8x8 = J.vaa_sad8x8; Jf.sad_cost0 = J.sad_cost0; }                                                \
+      const int guess_ = slot_mv;                                                                                              \
+      wh_inter_cold_fetch<VAR> (S, G, lane, P, Jf, mbx, mby);                                                                  \
+      wh_win_speculate (P, Jf, X.spec, mbx, mby, guess_); X.spec_valid = 1;                                                    \
+    }                                                                                                                          \
+  }
+  WH_XCLAIM()
+  while (xy >= 0) {
+    const int dep_a = (mbx > 0 && xy - 1 >= first) ? xy - 1 : -1;
+    int dep_b;
+    { const int tr = mbx < P.mb_w - 1 ? xy - P.mb_w + 1 : xy - P.mb_w; dep_b = tr >= first ? tr : -1; }
+    if (!wh_wait_done_x (sc + 1, dep_a < 0 ? -1 : dep_a - first, err)) break;
+    if (!wh_wait_done_x (sc + 1, dep_b < 0 ? -1 : dep_b - first, err)) break;
+    __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "workgroup");       // (nothing of the body moves above the waits; the neighbours' data is loaded past the caches)
+    WV_ASYNC_WAIT();
+    wh_inter_mb_body_t<false, VAR, true> (S, G, P, J, mbx, mby, X);
+    // this wave's write-through stores have left it: then the flag
+    asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_or (&sc[1 + ((xy - first) >> 5)], 1u << ((xy - first) & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    WH_XCLAIM()
+  }
+#undef WH_XCLAIM
+#if WH_PROF_ON
+  if (P.prof && lane < 32) atomicAdd (&P.prof[((blockIdx.x * 7u) & 63u) * 32u + lane], (unsigned long long)S.m.prof[lane]);
+#endif
+}
+
 // Deal the slices of a batch out to the mode-decision workgroups: sorted by the cost they had in the previous picture
 // (slice_cost, accumulated by k_inter_pool; cleared here for the coming launch), then in snake order over the groups, so
 // that every group gets a heavy and a light share.  One workgroup; n <= 4096 slices.
@@ -419,7 +517,6 @@ __global__ __launch_bounds__ (1024) void k_md_assign (uint32_t* slice_cost, uint
 // empty the CU's L1 for all its waves, once per macroblock of every band edge (measured: 3 ms of a 5.4 ms pass).  Only MBs
 // that a later band can depend on publish.  The workgroups of one picture have consecutive block ids and band b-1 never waits for band b, so the chain
 // cannot deadlock while the earlier workgroup is scheduled; the spin is bounded regardless.
-#define WH_SEAM_SPIN_LIMIT (1u << 22)
 __global__ __launch_bounds__ (1024) void k_deblock_slices (WhSeqParams P, const WhPicJob* jobs, uint32_t* err) {
   extern __shared__ __align__ (16) uint8_t smem[];
   const int nw = (int)blockDim.x >> 6, lane = (int)threadIdx.x & 63;
@@ -584,6 +681,101 @@ __global__ __launch_bounds__ (1024) void k_compact (WhSeqParams P, const WhPicJo
   }
 }
 
+// The same for launches of a few pictures (round 6): one workgroup per picture packed a 1080p picture's 7.8 MB of records in 0.9 ms -- one CU's rate -- which a
+// single session through the frame API waited for, picture by picture (profiles/r06_single_session_timeline.txt).  A picture is cut into chunks of
+// WH_CP_CHUNK macroblocks, one 256-thread workgroup each, in two launches: k_compact_sizes leaves every macroblock's packed size in its slot of the offset
+// table and the chunk's total in `totals`; k_compact_chunks turns the sizes into offsets (the chunks before it: a sum over at most WH_CP_MAX_CHUNKS words;
+// its own macroblocks: a scan in LDS) and copies.  The masks are computed twice (the records are L2-warm the second time) instead of being kept.
+#define WH_CP_CHUNK 256
+#define WH_CP_MAX_CHUNKS ((WH_CP_MAX_MB + WH_CP_CHUNK - 1) / WH_CP_CHUNK)
+__device__ __forceinline__ uint32_t wh_cp_mask (const WH_G uint32_t* r, int lane, int mb_type, int cbp) {
+  uint32_t mask = 0;
+  if (mb_type != WH_MB_PSKIP) {
+    const WH_G uint32_t* c = r + 36;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int d = lane + 64 * k;
+      const unsigned long long b = __ballot (d < 204 && c[d] != 0u);
+#pragma unroll
+      for (int g = 0; g < 8; ++g) if ((b >> (8 * g)) & 0xffull) { const int blk = 8 * k + g; mask |= 1u << (blk < 25 ? blk : 25); }
+    }
+    mask &= wh_compact_allowed (mb_type, cbp);
+  }
+  return mask;
+}
+__global__ __launch_bounds__ (256) void k_compact_sizes (WhSeqParams P, const WhPicJob* jobs, uint32_t* totals) {
+  __shared__ uint32_t s_sum;
+  const WhPicJob J = jobs[blockIdx.y];
+  if (!J.compact || !J.compact_off) return;
+  const int num_mb = P.mb_w * P.mb_h, lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6, nw = (int)blockDim.x >> 6;
+  const int a = (int)blockIdx.x * WH_CP_CHUNK, b = a + WH_CP_CHUNK < num_mb ? a + WH_CP_CHUNK : num_mb;
+  if (threadIdx.x == 0) s_sum = 0;
+  __syncthreads();
+  const WH_G WhMbRecord* recs = (const WH_G WhMbRecord*)J.records;
+  uint32_t sum = 0;
+  for (int xy = a + wave; xy < b; xy += nw) {
+    const WH_G uint32_t* r = (const WH_G uint32_t*)&recs[xy];
+    const uint32_t h0 = r[0];
+    const int mb_type = (int) (h0 & 0xff), cbp = (int) ((h0 >> 8) & 0xff);
+    const uint32_t size = wh_compact_size (mb_type, wh_cp_mask (r, lane, mb_type, cbp));
+    if (lane == 0) J.compact_off[xy] = size;
+    sum += size;
+  }
+  if (lane == 0) atomicAdd (&s_sum, sum);
+  __syncthreads();
+  if (threadIdx.x == 0) totals[blockIdx.y * WH_CP_MAX_CHUNKS + blockIdx.x] = s_sum;
+}
+__global__ __launch_bounds__ (256) void k_compact_chunks (WhSeqParams P, const WhPicJob* jobs, const uint32_t* totals) {
+  __shared__ uint32_t s_off[WH_CP_CHUNK];
+  const WhPicJob J = jobs[blockIdx.y];
+  if (!J.compact || !J.compact_off) return;
+  const int num_mb = P.mb_w * P.mb_h, lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6, nw = (int)blockDim.x >> 6, t = (int)threadIdx.x;
+  const int a = (int)blockIdx.x * WH_CP_CHUNK, b = a + WH_CP_CHUNK < num_mb ? a + WH_CP_CHUNK : num_mb;
+  uint32_t base = 0;
+  for (int c = 0; c < (int)blockIdx.x; ++c) base += totals[blockIdx.y * WH_CP_MAX_CHUNKS + c];
+  const uint32_t own = a + t < b ? J.compact_off[a + t] : 0u;      // (this macroblock's size, left by k_compact_sizes)
+  s_off[t] = own;
+  __syncthreads();
+  for (int d = 1; d < WH_CP_CHUNK; d <<= 1) {
+    const uint32_t v = t >= d ? s_off[t - d] : 0u;
+    __syncthreads();
+    s_off[t] += v;
+    __syncthreads();
+  }
+  const uint32_t incl = s_off[t];
+  __syncthreads();
+  s_off[t] = base + incl - own;
+  if (a + t < b) J.compact_off[a + t] = base + incl - own;
+  if (a + t == num_mb - 1) J.compact_off[num_mb] = base + incl;
+  __syncthreads();
+  const WH_G WhMbRecord* recs = (const WH_G WhMbRecord*)J.records;
+  for (int xy = a + wave; xy < b; xy += nw) {
+    const WH_G uint32_t* r = (const WH_G uint32_t*)&recs[xy];
+    WH_G uint32_t* o = (WH_G uint32_t*) ((WH_G uint8_t*)J.compact + s_off[xy - a]);
+    const uint32_t h0 = r[0];
+    const int mb_type = (int) (h0 & 0xff), cbp = (int) ((h0 >> 8) & 0xff);
+    if (mb_type == WH_MB_PSKIP) {
+      if (lane < 2) o[lane] = r[lane];
+      else if (lane == 2) o[2] = r[30];
+      else if (lane == 3) o[3] = ((const WH_G uint8_t*)r)[WH_COMPACT_SIDE - 16];
+      continue;
+    }
+    const uint32_t mask = wh_cp_mask (r, lane, mb_type, cbp);
+    if (lane == 0) o[0] = mask;
+    if (lane < 36) o[1 + lane] = r[lane];
+    const WH_G uint32_t* c = r + 36;
+    WH_G uint32_t* q = o + 37;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int d = lane + 64 * k;
+      if (d < 204) {
+        const int blk = d >> 3 < 25 ? d >> 3 : 25;
+        if ((mask >> blk) & 1u) q[8 * __builtin_popcount (mask & ((1u << blk) - 1u)) + (d - 8 * blk)] = c[d];
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__ (256) void k_expand (WhSeqParams P, const WhPicJob* jobs) {
   const WhPicJob* J = &jobs[blockIdx.y];
   WH_G uint8_t* r0 = (WH_G uint8_t*)J->rec[0];
@@ -681,6 +873,7 @@ class HipBackend : public wh::Backend {
     stream_ = streams_[0]; cur_ = 0;
     HIP_TRY (hipMalloc ((void**)&err_, 4 * WH_ERR_WORDS * WH_NUM_QUEUES));
     if (err_) HIP_TRY (hipMemset (err_, 0, 4 * WH_ERR_WORDS * WH_NUM_QUEUES));
+    HIP_TRY (hipMalloc ((void**)&cp_totals_, sizeof (uint32_t) * WH_NUM_QUEUES * WH_CP_MAX_CHUNKS * (size_t) (cus_ / 2 + 1)));
     name_ = std::string ("hip:") + prop.gcnArchName + " " + prop.name;
   }
   ~HipBackend() override {
@@ -690,6 +883,8 @@ class HipBackend : public wh::Backend {
     for (hipEvent_t ev : wait_ev_) if (ev) (void)hipEventDestroy (ev);
     for (auto& sl : slabs_) (void)hipFree (sl.base);
     if (err_) (void)hipFree (err_);
+    if (cp_totals_) (void)hipFree (cp_totals_);
+    for (uint32_t* p : split_sched_) if (p) (void)hipFree (p);
   }
   bool usable() const { return hip_err_.load (std::memory_order_relaxed) == (int)hipSuccess && stream_ && err_; }
   uint32_t* err_words() const { return err_ + WH_ERR_WORDS * cur_; }         // the selected queue's error word
@@ -828,6 +1023,32 @@ class HipBackend : public wh::Backend {
     const size_t fixed = WH_MD_MAX_SLOTS * (sizeof (WhPicJob) + 32) + 4 * (size_t)slots * sched_words;
     while (nw > 1 && (size_t)nw * sizeof (WhInterLds) + (size_t)built_for (nw) * (sizeof (WhInterStage) + sizeof (WhWinLds)) + fixed > (size_t)160 * 1024) --nw;
     const size_t lds = (size_t)nw * sizeof (WhInterLds) + 4 * (size_t)slots * sched_words;
+    // Few slices in the launch (one or a few sessions through the frame API): every slice on `parts` CUs (k_inter_split), as many waves in all as the slice
+    // can have macroblocks in flight (+ a few that hold their next ticket), at most six per CU.  WELSHIP_MD_SPLIT = 0 switches it off, n > 1 forces the parts.
+    {
+      static const int split_env = getenv ("WELSHIP_MD_SPLIT") ? atoi (getenv ("WELSHIP_MD_SPLIT")) : -1;
+      const int variant = (WH_PLAIN_KERNEL == 2 && plain && P.flags == 0 && P.complexity == 0) ? 2 : (WH_PLAIN_KERNEL && plain && P.flags == 0) ? 1 : (WH_FRAME_KERNEL && no_ctrl && P.flags == 0) ? 3 : 0;
+      int parts = split_env == 0 ? 1 : std::min (8, cus_ / std::max (1, total));
+      if (split_env > 1) parts = std::min (split_env, 8);
+      const int par1 = std::max (1, std::min (max_rows, (P.mb_w + 1) / 2));
+      parts = std::min (parts, (par1 + 3 + 3) / 4);            // (no more CUs than waves to fill them with four each)
+      uint32_t* xs = (variant != 0 && parts >= 2 && forced_slots <= 0) ? split_sched ((size_t)total * sched_words) : nullptr;
+      if (xs) {
+        const int xw = std::max (2, std::min (WH_SPLIT_WAVES, (par1 + 3 + parts - 1) / parts));
+        const size_t xlds = (size_t)xw * sizeof (WhInterLds);
+        const int blocks = ((total + 7) / 8) * 8 * parts;
+        HIP_TRY (hipMemsetAsync (xs, 0, 4 * (size_t)total * sched_words, stream_));
+        auto xlaunch = [&] (auto kernel) {
+          set_dynamic_lds ((const void*)kernel, xlds);
+          if (trace_) { fprintf (stderr, "welship: MD launch, %d slices on %d CUs each, %d waves per CU\n", total, parts, xw); fflush (stderr); }
+          hipLaunchKernelGGL (kernel, dim3 (blocks), dim3 (xw * 64), xlds, stream_, P, jobs, err_words(), xs, sched_words, parts, total);
+          HIP_TRY (hipGetLastError());
+          if (trace_) { HIP_TRY (hipStreamSynchronize (stream_)); fprintf (stderr, "welship: launch done\n"); fflush (stderr); }
+        };
+        if (variant == 2) xlaunch (k_inter_split<2>); else if (variant == 1) xlaunch (k_inter_split<1>); else xlaunch (k_inter_split<3>);
+        return;
+      }
+    }
     uint16_t* grp = nullptr;
     uint32_t* cost = nullptr;
     if (slots > 1 && use_assign && total <= 4096 && stream_ == streams_[0]) {      // the cost / assignment buffers belong to queue 0
@@ -939,6 +1160,13 @@ class HipBackend : public wh::Backend {
     HIP_TRY (hipGetLastError());
   }
   void run_compact (const WhSeqParams& P, const WhPicJob* jobs, int n) override {
+    // few pictures: chunks of a picture on as many CUs (k_compact_sizes + k_compact_chunks); a launch that fills the device anyway keeps one workgroup per picture
+    const int num_mb = P.mb_w * P.mb_h, chunks = (num_mb + WH_CP_CHUNK - 1) / WH_CP_CHUNK;
+    uint32_t* tot = 2 * n <= cus_ && chunks > 1 && chunks <= WH_CP_MAX_CHUNKS ? compact_totals (n) : nullptr;
+    if (tot) {
+      hipLaunchKernelGGL (k_compact_sizes, dim3 (chunks, n), dim3 (256), 0, stream_, P, jobs, tot);
+      hipLaunchKernelGGL (k_compact_chunks, dim3 (chunks, n), dim3 (256), 0, stream_, P, jobs, (const uint32_t*)tot);
+    } else
     hipLaunchKernelGGL (k_compact, dim3 (n), dim3 (1024), 0, stream_, P, jobs);
     HIP_TRY (hipGetLastError());
   }
@@ -1001,6 +1229,21 @@ class HipBackend : public wh::Backend {
     }
     return total;
   }
+  // the chunk totals of run_compact's two launches: one array per queue (launch sets of different queues overlap), for up to cus_ / 2 pictures each;
+  // allocated with the backend (run_compact is called from whichever host thread runs a launch set)
+  uint32_t* compact_totals (int n) const { return cp_totals_ && n <= cus_ / 2 + 1 ? cp_totals_ + (size_t)cur_ * WH_CP_MAX_CHUNKS * (size_t) (cus_ / 2 + 1) : nullptr; }
+  uint32_t* cp_totals_ = nullptr;
+  // the scheduler's words of k_inter_split: one array per queue, allocated the first time a queue launches it (any host thread)
+  uint32_t* split_sched (size_t words) {
+    if (words > kSplitWords) return nullptr;
+    std::lock_guard<std::mutex> lk (split_mu_);
+    uint32_t*& p = split_sched_[cur_];
+    if (!p && hipMalloc ((void**)&p, 4 * kSplitWords) != hipSuccess) { (void)hipGetLastError(); p = nullptr; }
+    return p;
+  }
+  static constexpr size_t kSplitWords = (size_t)128 * 1160;         // 128 slices of a 4096 x 2304 picture's macroblocks
+  uint32_t* split_sched_[WH_NUM_QUEUES] = {};
+  std::mutex split_mu_;
   int dev_;
   int cus_;
   std::vector<hipEvent_t> wait_ev_;       // queue_wait: a small ring of events

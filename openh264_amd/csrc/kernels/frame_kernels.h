@@ -22,6 +22,8 @@ static_assert (offsetof (WhMbState, mb_type) == 0 && offsetof (WhMbState, luma_q
                offsetof (WhMbState, ref_idx) % 4 == 0 && offsetof (WhMbState, p16mv) % 4 == 0, "WhMbState layout");
 
 // Store the MB's reconstruction, entropy record and neighbour state to HBM.
+// X: the slice is coded by several workgroups (wave.h wh_st_x): state and unfiltered samples go through to memory; the record is the host's
+template <bool X = false>
 WH_FN void wh_store_mb (WhMbLds& S, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, int mb_type, int cbp,
                         int qp, int qpc, int i16_mode, int chroma_mode, int cost, int slice_idc, int cavlc_bits = 0) {
   const int xy = mby * P.mb_w + mbx;
@@ -32,8 +34,8 @@ WH_FN void wh_store_mb (WhMbLds& S, const WhSeqParams& P, const WhPicJob& J, int
   WV_LANES_BEGIN (lane)
   if (J.rec_blk) {              // (wave-uniform) the macroblock's own 384 bytes: the lane's luma word is word `lane`, its chroma word 64 + lane
     WH_G uint32_t* b = (WH_G uint32_t*) ((WH_G uint8_t*)J.rec_blk + (size_t)xy * WH_SRC_MB_BYTES);
-    b[lane] = * (const uint32_t*)&WH_RY (S, (lane & 3) * 4, lane >> 2);
-    if (lane < 32) b[64 + lane] = * (const uint32_t*)&WH_RC (S, lane >> 4, (lane & 1) * 4, (lane >> 1) & 7);
+    wh_st_x<X> (&b[lane], * (const uint32_t*)&WH_RY (S, (lane & 3) * 4, lane >> 2));
+    if (lane < 32) wh_st_x<X> (&b[64 + lane], * (const uint32_t*)&WH_RC (S, lane >> 4, (lane & 1) * 4, (lane >> 1) & 7));
   } else {
     {
       const int row = lane >> 2, seg = lane & 3;
@@ -61,10 +63,10 @@ WH_FN void wh_store_mb (WhMbLds& S, const WhSeqParams& P, const WhPicJob& J, int
   } else if (lane < 56) {
     ((WH_G int16_t*)&R->chroma_dc[0][0])[lane - 48] = S.lv_cdc[lane - 48];
   }
-  if (lane < 24) { R->nzc[lane] = S.nzc[lane]; M->nzc[lane] = S.nzc[lane]; }
+  if (lane < 24) { R->nzc[lane] = S.nzc[lane]; wh_st_x<X> (&M->nzc[lane], S.nzc[lane]); }
   if (lane < 16) {
     R->i4_rem[lane] = (mb_type == WH_MB_I4x4) ? S.i4_rem[lane] : (int8_t)0;
-    M->i4_mode[lane] = (mb_type == WH_MB_I4x4) ? S.i4m[((lane >> 2) + 1) * 5 + (lane & 3) + 1] : (int8_t)2;
+    wh_st_x<X> (&M->i4_mode[lane], (mb_type == WH_MB_I4x4) ? S.i4m[((lane >> 2) + 1) * 5 + (lane & 3) + 1] : (int8_t)2);
   }
   if (lane == 0) {
     // (the header fields word by word: field by field they were fifteen byte / short stores with an address each)
@@ -74,12 +76,12 @@ WH_FN void wh_store_mb (WhMbLds& S, const WhSeqParams& P, const WhPicJob& J, int
     R->cost = cost;
     R->cavlc_bits = cavlc_bits;
     * (WH_G uint32_t*)&R->bgd_skip = 0u;                    // bgd_skip + pad0
-    * (WH_G uint32_t*)&M->mb_type = (uint32_t) (mb_type & 255) | ((uint32_t) (qp & 255) << 8) | ((uint32_t) (qpc & 255) << 16) | ((uint32_t) (cbp & 255) << 24);
+    wh_st_x<X> ((WH_G uint32_t*)&M->mb_type, (uint32_t) (mb_type & 255) | ((uint32_t) (qp & 255) << 8) | ((uint32_t) (qpc & 255) << 16) | ((uint32_t) (cbp & 255) << 24));
     // uiRefMbType / pRefMbQp of the picture (read when it is a reference): P pictures store the type, I pictures leave the
     // previous contents of the picture buffer alone (WelsMdInterSaveSadAndRefMbType is a P-slice step); both store the QP
     // (WelsMdUpdateBGDInfo; wh_inter_mb_body overrides it for unchanged collocated macroblocks)
-    if (J.slice_type == WH_SLICE_P) * (WH_G uint32_t*)&M->slice_idc = (uint32_t) (slice_idc & 0xffff) | ((uint32_t) ((mb_type + 1) & 255) << 16) | ((uint32_t) (qp & 255) << 24);
-    else { M->slice_idc = (uint16_t)slice_idc; M->ref_qp = (uint8_t)qp; }
+    if (J.slice_type == WH_SLICE_P) wh_st_x<X> ((WH_G uint32_t*)&M->slice_idc, (uint32_t) (slice_idc & 0xffff) | ((uint32_t) ((mb_type + 1) & 255) << 16) | ((uint32_t) (qp & 255) << 24));
+    else { wh_st_x<X> (&M->slice_idc, (uint16_t)slice_idc); wh_st_x<X> (&M->ref_qp, (uint8_t)qp); }
   }
   WV_LANES_END
 }

@@ -866,10 +866,7 @@ WH_FN void wh_refine_frac (WhInterLds& S, const WhSeqParams& P, const WhPicJob& 
     wh_rf_b_pair (W.b->win, o, &a, &b); WV_LOWN (vbl, lane) = (int)a; WV_LOWN (vbr, lane) = (int)b; });
   if (satd_in_md) c_int = me.satd_raw;                                      // uiSatd of the integer search
   else WV_SATD_ROWS_SHARED (c_int, lane, WH_RF_ACT, WH_RF_ENC, (uint32_t)WV_LOWN (vG, lane));
-  WV_SATD_ROWS_SHARED (c0, lane, WH_RF_ACT, WH_RF_ENC, (uint32_t)WV_LOWN (vhu, lane));
-  WV_SATD_ROWS_SHARED (c1, lane, WH_RF_ACT, WH_RF_ENC, (uint32_t)WV_LOWN (vhd, lane));
-  WV_SATD_ROWS_SHARED (c2, lane, WH_RF_ACT, WH_RF_ENC, (uint32_t)WV_LOWN (vbl, lane));
-  WV_SATD_ROWS_SHARED (c3, lane, WH_RF_ACT, WH_RF_ENC, (uint32_t)WV_LOWN (vbr, lane));
+  WV_SATD_ROWS4_SHARED (c0, c1, c2, c3, lane, WH_RF_ACT, WH_RF_ENC, (uint32_t)WV_LOWN (vhu, lane), (uint32_t)WV_LOWN (vhd, lane), (uint32_t)WV_LOWN (vbl, lane), (uint32_t)WV_LOWN (vbr, lane));
   int best = c_int + wh_mvd_cost (C.lambda, dmx, dmy), hb = -1;
   c0 += wh_mvd_cost (C.lambda, dmx, dmy - 2); if (c0 < best) { best = c0; hb = 0; }
   c1 += wh_mvd_cost (C.lambda, dmx, dmy + 2); if (c1 < best) { best = c1; hb = 1; }
@@ -881,10 +878,7 @@ WH_FN void wh_refine_frac (WhInterLds& S, const WhSeqParams& P, const WhPicJob& 
     uint32_t q[4];
     wh_rf_quarters (W.b->win, WH_RF_O, hb, (uint32_t)WV_LOWN (vG, lane), (uint32_t)WV_LOWN (vhu, lane), (uint32_t)WV_LOWN (vhd, lane), (uint32_t)WV_LOWN (vbl, lane), (uint32_t)WV_LOWN (vbr, lane), q);
     WV_LOWN (vq0, lane) = (int)q[0]; WV_LOWN (vq1, lane) = (int)q[1]; WV_LOWN (vq2, lane) = (int)q[2]; WV_LOWN (vq3, lane) = (int)q[3]; });
-  WV_SATD_ROWS_SHARED (c0, lane, WH_RF_ACT, WH_RF_ENC, (uint32_t)WV_LOWN (vq0, lane));
-  WV_SATD_ROWS_SHARED (c1, lane, WH_RF_ACT, WH_RF_ENC, (uint32_t)WV_LOWN (vq1, lane));
-  WV_SATD_ROWS_SHARED (c2, lane, WH_RF_ACT, WH_RF_ENC, (uint32_t)WV_LOWN (vq2, lane));
-  WV_SATD_ROWS_SHARED (c3, lane, WH_RF_ACT, WH_RF_ENC, (uint32_t)WV_LOWN (vq3, lane));
+  WV_SATD_ROWS4_SHARED (c0, c1, c2, c3, lane, WH_RF_ACT, WH_RF_ENC, (uint32_t)WV_LOWN (vq0, lane), (uint32_t)WV_LOWN (vq1, lane), (uint32_t)WV_LOWN (vq2, lane), (uint32_t)WV_LOWN (vq3, lane));
   int qb = -1;
   c0 += wh_mvd_cost (C.lambda, dmx + hx, dmy + hy - 1); if (c0 < best) { best = c0; qb = 0; }
   c1 += wh_mvd_cost (C.lambda, dmx + hx, dmy + hy + 1); if (c1 < best) { best = c1; qb = 1; }
@@ -1010,7 +1004,10 @@ typedef struct WhInterCtx {
 // ---- the P macroblock -----------------------------------------------------------------------------
 // VAR: 0 = the general body, 1 = PLAIN (see wh_inter_cold_fetch), 2 = PLAIN and LOW complexity known at compile time (SAD costs: the SATD
 // paths of the search, the refinement and the intra test are not compiled in), 3 = the frame API's camera pictures without control inputs
-template <bool SCC, int VAR = 0>
+// XWG: the slice is coded by SEVERAL workgroups (hip_backend.hip k_inter_split: a launch of a few pictures spreads every slice over several compute units):
+// the neighbours' states and samples are loaded past the caches and this macroblock's are stored write-through (wave.h wh_ld_x32 / wh_st_x); not with
+// screen content or the control inputs (their chains through the slice stay inside one workgroup)
+template <bool SCC, int VAR = 0, bool XWG = false>
 WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, WhInterCtx& X) {
   constexpr bool LOW = VAR == 2, HOSTIN = VAR == 0 || VAR == 3, CTRL = VAR == 0;      // (see wh_inter_cold_fetch)
   WH_PROF_DECL (P);
@@ -1036,7 +1033,7 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
   WV_LANES_BEGIN (lane)
   {
     WhTileRegs tr;
-    wh_tile_fetch_nb (lane, P, J, mbx, mby, &tr);
+    wh_tile_fetch_nb<XWG> (lane, P, J, mbx, mby, &tr);
     // The four neighbours' states by LDS-DMA straight into S.nb (round 6; rounds 1-5: three loads per lane into registers, selects, three LDS
     // stores -- 135 vector instructions of address arithmetic and a division by 36 per load).  Top-left, top and top-right are ONE run of 108
     // words of the picture's state array, which nb[0..107] mirrors; the left state follows in nb[108..143].  A neighbour that does not exist (or
@@ -1046,7 +1043,7 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
       const int d = lane + 64 * k;
       const bool ok = d < 36 ? (avail & WH_AV_TOPLEFT) != 0 : d < 72 ? (avail & WH_AV_TOP) != 0 : d < 108 ? (avail & WH_AV_TOPRIGHT) != 0 : d < 144 && (avail & WH_AV_LEFT) != 0;
       const int wofs = d < 108 ? (xy - w - 1) * 36 + d : (xy - 1) * 36 + (d - 108);         // word offset inside the state array (36 words per state)
-      if (ok) wh_ld_async4 ((const WH_G uint32_t*)J.mbs + wofs, &S.nb[64 * k], lane);
+      if (ok) wh_ld_async4_x<XWG> ((const WH_G uint32_t*)J.mbs + wofs, &S.nb[64 * k], lane);
     }
     WH_PROF_SUB (P, M, 3);       /* detail: neighbour loads issued */
     wh_tile_commit_nb (M, lane, &tr);      // (the source samples and the reference picture's state of this MB are in place already: wh_inter_cold_fetch)
@@ -1607,10 +1604,10 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
   WH_G WhMbRecord* Rs = (WH_G WhMbRecord*)J.records + xy;
   if (intra) {
     WV_LANES_BEGIN (lane)
-    if (lane < 16) { Ms->mv[lane][0] = 0; Ms->mv[lane][1] = 0; Rs->mvd[lane][0] = 0; Rs->mvd[lane][1] = 0; }
+    if (lane < 16) { wh_st_x<XWG> ((WH_G uint32_t*)&Ms->mv[lane][0], 0u); Rs->mvd[lane][0] = 0; Rs->mvd[lane][1] = 0; }
     if (lane < 2) Rs->mv_tr[lane] = 0;
-    if (lane < 4) { Ms->ref_idx[lane] = -1; Rs->ref_idx[lane] = -1; Rs->sub_type[lane] = 0; }
-    if (lane == 0) { Ms->sad_cost[0] = 0; Ms->p16mv[0] = (int16_t)p16x; Ms->p16mv[1] = (int16_t)p16y; Ms->skip_sad = 0; if (HOSTIN && J.sad_cost0) (J.sad_cost0_out ? (WH_G int32_t*)J.sad_cost0_out : (WH_G int32_t*)J.sad_cost0)[xy] = 0; }
+    if (lane < 4) { wh_st_x<XWG> (&Ms->ref_idx[lane], (int8_t)-1); Rs->ref_idx[lane] = -1; Rs->sub_type[lane] = 0; }
+    if (lane == 0) { wh_st_x<XWG> (&Ms->sad_cost[0], 0); wh_st_x<XWG> ((WH_G uint32_t*)&Ms->p16mv[0], (uint32_t)wh_pk_mv (p16x, p16y)); wh_st_x<XWG> (&Ms->skip_sad, 0); if (HOSTIN && J.sad_cost0) (J.sad_cost0_out ? (WH_G int32_t*)J.sad_cost0_out : (WH_G int32_t*)J.sad_cost0)[xy] = 0; }
     WV_LANES_END
     int ibits = 0;
     if (CTRL && J.want_bits) {
@@ -1618,7 +1615,7 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
               wh_mb_intra_header_bits (M, ir.mb_type, ir.cbp, ir.i16_mode_std, ir.chroma_mode_std, true);
       if (ir.cbp > 0 || ir.mb_type == WH_MB_I16x16) ibits |= WH_BITS_HAS_QP_DELTA;
     }
-    wh_store_mb (M, P, J, mbx, mby, ir.mb_type, ir.cbp, qp, qpc, ir.i16_mode_std, ir.chroma_mode_std, ir.cost_luma, slice_idc, ibits);
+    wh_store_mb<XWG> (M, P, J, mbx, mby, ir.mb_type, ir.cbp, qp, qpc, ir.i16_mode_std, ir.chroma_mode_std, ir.cost_luma, slice_idc, ibits);
     if (SCC && J.dyn_slice) {
       WV_LANES_BEGIN (lane)
       if (lane == 0) Rs->fme_down = 0;
@@ -1646,15 +1643,15 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
     const int mvx = is_skip ? skx : S.mv_out[lane][0], mvy = is_skip ? sky : S.mv_out[lane][1];
     // (one 32-bit store per pair of 16-bit fields: written field by field each pair was two global_store_short)
     const uint32_t mv32 = (uint32_t)wh_pk_mv (mvx, mvy);
-    * (WH_G uint32_t*)&Ms->mv[lane][0] = mv32;
+    wh_st_x<XWG> ((WH_G uint32_t*)&Ms->mv[lane][0], mv32);
     * (WH_G uint32_t*)&Rs->mvd[lane][0] = is_skip ? 0u : (uint32_t)wh_pk_mv (mvx - S.mvp_out[lane][0], mvy - S.mvp_out[lane][1]);
     if (lane == 3) * (WH_G uint32_t*)&Rs->mv_tr[0] = mv32;
   }
   if (!(cbp & 15) || is_skip) { uint64_t* z = (uint64_t*)M.lv_luma; z[lane] = 0; }
   if (lane == 0) {
-    * (WH_G uint32_t*)&Ms->ref_idx[0] = 0u; * (WH_G uint32_t*)&Rs->ref_idx[0] = 0u; * (WH_G uint32_t*)&Rs->sub_type[0] = 0u;      // four bytes each
-    Ms->sad_cost[0] = sad_cost0; * (WH_G uint32_t*)&Ms->p16mv[0] = (uint32_t)wh_pk_mv (p16x, p16y);
-    Ms->skip_sad = is_skip ? cost_skip_mb : 0;
+    wh_st_x<XWG> ((WH_G uint32_t*)&Ms->ref_idx[0], 0u); * (WH_G uint32_t*)&Rs->ref_idx[0] = 0u; * (WH_G uint32_t*)&Rs->sub_type[0] = 0u;      // four bytes each
+    wh_st_x<XWG> (&Ms->sad_cost[0], sad_cost0); wh_st_x<XWG> ((WH_G uint32_t*)&Ms->p16mv[0], (uint32_t)wh_pk_mv (p16x, p16y));
+    wh_st_x<XWG> (&Ms->skip_sad, is_skip ? cost_skip_mb : 0);
     if (HOSTIN && J.sad_cost0) (J.sad_cost0_out ? (WH_G int32_t*)J.sad_cost0_out : (WH_G int32_t*)J.sad_cost0)[xy] = sad_cost0;
   }
   WV_LANES_END
@@ -1672,7 +1669,7 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
     if (cbp > 0) pbits += wh_mb_residual_bits (M, mb_type, cbp, Lm ? Lm->nzc : nullptr, Tm ? Tm->nzc : nullptr);
     if (cbp > 0) pbits |= WH_BITS_HAS_QP_DELTA;
   }
-  wh_store_mb (M, P, J, mbx, mby, mb_type, cbp, qp, qpc, 0, 0, cost_luma, slice_idc, pbits);
+  wh_store_mb<XWG> (M, P, J, mbx, mby, mb_type, cbp, qp, qpc, 0, 0, cost_luma, slice_idc, pbits);
   if (SCC && J.dyn_slice) {              // (size-limited slices: the host sums the macroblocks the entropy writer really took)
     WV_LANES_BEGIN (lane)
     if (lane == 0) ((WH_G WhMbRecord*)J.records + xy)->fme_down = fme_down_mb;
@@ -1692,9 +1689,9 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
     if (bg_skip || inherit || last_qp) {
       WV_LANES_BEGIN (lane)
       if (lane == 0) {
-        if (bg_skip) { Ms->ref_type = WH_REFTYPE_BACKGROUND; Rs->bgd_skip = 1; }
-        if (inherit) Ms->ref_qp = Co->ref_qp;
-        else if (last_qp) Ms->ref_qp = 0xff;                              // WH_REFQP_FROM_CHAIN
+        if (bg_skip) { wh_st_x<XWG> (&Ms->ref_type, (uint8_t)WH_REFTYPE_BACKGROUND); Rs->bgd_skip = 1; }
+        if (inherit) wh_st_x<XWG> (&Ms->ref_qp, (uint8_t)Co->ref_qp);
+        else if (last_qp) wh_st_x<XWG> (&Ms->ref_qp, (uint8_t)0xff);                              // WH_REFQP_FROM_CHAIN
       }
       WV_LANES_END
     }

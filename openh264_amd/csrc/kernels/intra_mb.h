@@ -94,10 +94,12 @@ WH_FN const WH_G uint8_t* wh_tile_nb_addr_blk (int lane, const WhSeqParams& P, c
 WH_FN void wh_tile_fetch_nb_planes (int lane, const WhSeqParams& P, const WH_G uint8_t* rec0, const WH_G uint8_t* rec1, const WH_G uint8_t* rec2, int mbx, int mby, WhTileRegs* r) {
   r->nb = * (const WH_G uint32_t*)wh_tile_nb_addr_planes (lane, P, rec0, rec1, rec2, mbx, mby);
 }
+// (X: the neighbours may have been coded by another workgroup -- wave.h wh_ld_x32)
+template <bool X = false>
 WH_FN void wh_tile_fetch_nb (int lane, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, WhTileRegs* r) {
   const WH_G uint8_t* a = J.rec_blk ? wh_tile_nb_addr_blk (lane, P, (const WH_G uint8_t*)J.rec_blk, mbx, mby)
                                     : wh_tile_nb_addr_planes (lane, P, (const WH_G uint8_t*)J.rec[0], (const WH_G uint8_t*)J.rec[1], (const WH_G uint8_t*)J.rec[2], mbx, mby);
-  r->nb = * (const WH_G uint32_t*)a;
+  r->nb = wh_ld_x32<X> ((const WH_G uint32_t*)a);
 }
 WH_FN void wh_tile_fetch (int lane, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, WhTileRegs* r) {
   wh_tile_fetch_src (lane, P, J, mbx, mby, r);

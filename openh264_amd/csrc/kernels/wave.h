@@ -86,6 +86,9 @@
 // them so that the compiler can share the common loads (each plain macro re-materialises its own opaque lane id).
 #define WV_DECLARE_LANE(lane) ((void)0)
 #define WV_SATD_ROWS_SHARED(dst, lane, active, enc4, pred4) WV_SATD_ROWS (dst, lane, active, enc4, pred4)
+// four candidates against the same source samples in one pass (the device twin shares the reduction over the blocks)
+#define WV_SATD_ROWS4_SHARED(d0, d1, d2, d3, lane, active, enc4, p0, p1, p2, p3) \
+  do { WV_SATD_ROWS (d0, lane, active, enc4, p0); WV_SATD_ROWS (d1, lane, active, enc4, p1); WV_SATD_ROWS (d2, lane, active, enc4, p2); WV_SATD_ROWS (d3, lane, active, enc4, p3); } while (0)
 // per-lane statements under the shared lane id (results kept in lane tables: WV_LOWN (tab, lane) = ...)
 #define WV_LANE_EVAL(lane, ...) do { for (int lane = 0; lane < 64; ++lane) { __VA_ARGS__; } } while (0)
 // pointers into device global memory (explicit address space on the GPU so that loads are global_*, not flat_*)
@@ -114,6 +117,11 @@ WH_FN uint32_t wh_ld_xwg32 (const uint32_t* p) { return *p; }
 // scheduler's done flags): a vector-memory access on the GPU, never a scalar load (the scalar cache is not coherent with stores)
 WH_FN void wh_st_wg32 (uint32_t* p, uint32_t v) { *p = v; }
 WH_FN uint32_t wh_ld_wg32 (const uint32_t* p) { return *p; }
+// A slice coded by SEVERAL workgroups (hip_backend.hip k_inter_split; X = true): whatever a neighbour macroblock reads back -- the macroblock's state and its
+// unfiltered samples -- is stored write-through and loaded past the caches, as wh_st_xwg32 / wh_ld_xwg32 do for the deblocking bands; X = false: plain accesses
+template <bool X, class T> WH_FN void wh_st_x (T* p, T v) { *p = v; }
+template <bool X> WH_FN uint32_t wh_ld_x32 (const uint32_t* p) { return *p; }
+template <bool X> WH_FN void wh_ld_async4_x (const void* src, uint32_t* lds_base, int lane) { memcpy (&lds_base[lane], src, 4); }
 // four bytes at any byte offset of a 4-byte aligned LDS array
 WH_FN uint32_t wh_ld4u (const uint8_t* base, int off) { uint32_t v; memcpy (&v, base + off, 4); return v; }
 // bytes k .. k + 3 (k = 0 .. 3) of the eight bytes lo | hi << 32
@@ -238,6 +246,9 @@ WH_FN int wh_satd_quad (int lane, uint32_t e, uint32_t p) {
   s += WH_DPP (s, 0x4E);
   return s;
 }
+// (Measured in round 6 and not adopted, profiles/r06_ab_satd_reductions_nt_records.txt: the four candidates of a refinement stage reduced in ONE pass -- lane k of
+//  every quad keeps candidate k's block sum, two row rotations, the four rows by v_permlane16_swap / v_permlane32_swap, 15 instructions where four separate
+//  reductions take 40 -- together with a sum over the row's blocks by row_ror instead of the masked quad stages: MD launch 7.13 -> 7.20 ms, same box, alternating.)
 WH_FN int wh_satd_rows (int lane, bool active, uint32_t e, uint32_t p) {
   int s = wh_satd_quad (lane, e, p);
   s = (active && (lane & 3) == 0) ? (s + 1) >> 1 : 0;
@@ -247,6 +258,8 @@ WH_FN int wh_satd_rows (int lane, bool active, uint32_t e, uint32_t p) {
   do { const int lane = wh_lane_id(); (dst) = wh_satd_rows (lane, (active), (enc4), (pred4)); } while (0)
 #define WV_DECLARE_LANE(lane) const int lane = wh_lane_id()
 #define WV_SATD_ROWS_SHARED(dst, lane, active, enc4, pred4) do { (dst) = wh_satd_rows (lane, (active), (enc4), (pred4)); } while (0)
+#define WV_SATD_ROWS4_SHARED(d0, d1, d2, d3, lane, active, enc4, p0, p1, p2, p3) \
+  do { (d0) = wh_satd_rows (lane, (active), (enc4), (p0)); (d1) = wh_satd_rows (lane, (active), (enc4), (p1)); (d2) = wh_satd_rows (lane, (active), (enc4), (p2)); (d3) = wh_satd_rows (lane, (active), (enc4), (p3)); } while (0)
 #define WV_LANE_EVAL(lane, ...) do { __VA_ARGS__; } while (0)
 typedef int WvLaneArr;
 #define WV_LGET(a, i) __builtin_amdgcn_readlane ((a), (i))
@@ -275,6 +288,12 @@ WH_FN void wh_st_xwg32 (WH_G uint32_t* p, uint32_t v) { __hip_atomic_store (p, v
 WH_FN uint32_t wh_ld_xwg32 (const WH_G uint32_t* p) { return __hip_atomic_load (p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 WH_FN void wh_st_wg32 (WH_G uint32_t* p, uint32_t v) { __hip_atomic_store (p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 WH_FN uint32_t wh_ld_wg32 (const WH_G uint32_t* p) { return __hip_atomic_load (p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+template <bool X, class T> WH_FN void wh_st_x (WH_G T* p, T v) { if (X) __hip_atomic_store (p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); else *p = v; }
+template <bool X> WH_FN uint32_t wh_ld_x32 (const WH_G uint32_t* p) { return X ? __hip_atomic_load (p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : *p; }
+template <bool X> WH_FN void wh_ld_async4_x (const WH_G void* src, uint32_t* lds_base, int /*lane*/) {
+  if (X) __builtin_amdgcn_global_load_lds ((const WH_G uint32_t*)src, (__attribute__ ((address_space (3))) uint32_t*)lds_base, 4, 0, 17);      // sc0 sc1
+  else __builtin_amdgcn_global_load_lds ((const WH_G uint32_t*)src, (__attribute__ ((address_space (3))) uint32_t*)lds_base, 4, 0, 0);
+}
 WH_FN uint32_t wh_funnel4 (uint32_t lo, uint32_t hi, int k) { return __builtin_amdgcn_alignbyte (hi, lo, (uint32_t)k); }
 WH_FN int wh_sad4 (uint32_t a, uint32_t b) { return (int)__builtin_amdgcn_sad_u8 (a, b, 0u); }
 WH_FN uint32_t wh_avg4 (uint32_t a, uint32_t b) { return __builtin_amdgcn_lerp (a, b, 0x01010101u); }
