@@ -19,7 +19,7 @@ static_assert (offsetof (WhMbRecord, mb_type) == 0 && offsetof (WhMbRecord, i16_
                offsetof (WhMbRecord, sub_type) % 4 == 0 && offsetof (WhMbRecord, ref_idx) % 4 == 0 && offsetof (WhMbRecord, mvd) % 4 == 0 && offsetof (WhMbRecord, mv_tr) % 4 == 0, "WhMbRecord layout");
 static_assert (offsetof (WhMbState, mb_type) == 0 && offsetof (WhMbState, luma_qp) == 1 && offsetof (WhMbState, chroma_qp) == 2 && offsetof (WhMbState, cbp) == 3 &&
                offsetof (WhMbState, slice_idc) == 4 && offsetof (WhMbState, ref_type) == 6 && offsetof (WhMbState, ref_qp) == 7 && offsetof (WhMbState, mv) % 4 == 0 &&
-               offsetof (WhMbState, ref_idx) % 4 == 0 && offsetof (WhMbState, p16mv) % 4 == 0, "WhMbState layout");
+               offsetof (WhMbState, ref_idx) % 4 == 0 && offsetof (WhMbState, p16mv) % 4 == 0 && offsetof (WhMbState, i4_mode) == 8, "WhMbState layout");
 
 // Store the MB's reconstruction, entropy record and neighbour state to HBM.
 // X: the slice is coded by several workgroups (wave.h wh_st_x): state and unfiltered samples go through to memory; the record is the host's

@@ -1397,11 +1397,11 @@ WH_FN void wh_inter_mb_body_t (WhInterLds& S, WhInterStage& G, const WhSeqParams
     // WelsMdSpatialelInterMbIlfmdNoilp, base-layer MB intra (svc_mode_decision.cpp:88-100): no motion search at all -- a skip
     // that is at least as cheap as Intra16x16 stays, anything else becomes intra (I16x16 against I4x4 as in an I slice)
     if (b_skip && cost_luma <= i16c.best_cost) { mb_type = WH_MB_PSKIP; done = true; }
-    else { (void)wh_intra_md_enc_p<LOW ? 0 : -1> (M, P, J, mbx, mby, avail, qp, qpc, 0x7fffffff, &ir, &i16c, stale_cbp); intra = true; done = true; }
+    else { (void)wh_intra_md_enc_p<LOW ? 0 : -1, XWG> (M, P, J, mbx, mby, avail, qp, qpc, 0x7fffffff, &ir, &i16c, stale_cbp); intra = true; done = true; }
   }
   if (!done) {
     // WelsMdFirstIntraMode: I16x16 cost vs the inter/skip cost so far
-    if (wh_intra_md_enc_p<LOW ? 0 : -1> (M, P, J, mbx, mby, avail, qp, qpc, cost_luma, &ir, &i16c, stale_cbp)) { intra = true; done = true; }
+    if (wh_intra_md_enc_p<LOW ? 0 : -1, XWG> (M, P, J, mbx, mby, avail, qp, qpc, cost_luma, &ir, &i16c, stale_cbp)) { intra = true; done = true; }
   }
   if (!done && b_skip) { mb_type = WH_MB_PSKIP; done = true; }
   WH_PROF_MARK (P, M, 3);   // I16x16 test (+ intra encode when intra wins)

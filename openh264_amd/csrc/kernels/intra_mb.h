@@ -363,7 +363,9 @@ WH_FN void wh_i16_costs (WhMbLds& S, int avail, int use_satd, int lambda, WhI16C
 }
 
 // CPLX >= 0: the complexity mode is known at compile time (the P kernel's variant for LOW complexity launches, inter_mb.h)
-template <int CPLX = -1>
+// X: the slice is coded by several workgroups (hip_backend.hip k_inter_split): the neighbours' states were stored write-through by another compute unit
+// and are loaded past the caches like their samples (wave.h wh_ld_x32)
+template <int CPLX = -1, bool X = false>
 WH_FN bool wh_intra_md_enc_p (WhMbLds& S, const WhSeqParams& P, const WhPicJob& J, int mbx, int mby, int avail, int qp, int qpc,
                               int inter_cost, WhIntraResult* o, const WhI16Cost* pre = nullptr, int stale_cbp = 0) {
   const int lambda = kWhLambda[qp];
@@ -419,8 +421,11 @@ WH_FN bool wh_intra_md_enc_p (WhMbLds& S, const WhSeqParams& P, const WhPicJob& 
       const bool from_t = cy == 0 && cx > 0 && has_t, from_l = cx == 0 && cy > 0 && has_l;
       const WH_G WhMbState* n = (const WH_G WhMbState*)J.mbs + (from_t ? (mby - 1) * P.mb_w + mbx : from_l ? mby * P.mb_w + mbx - 1 : mby * P.mb_w + mbx);
       const int idx = from_t ? 12 + cx - 1 : from_l ? (cy - 1) * 4 + 3 : 0;
-      const int type = n->mb_type;
-      const int8_t mode = n->i4_mode[idx];
+      // (X: a plain load could hit a line this compute unit's L1 holds from before the neighbour -- or this very macroblock's predecessor in the
+      //  picture buffer, read as the lane's placeholder above -- was written: a write-through store does not touch that copy.  Found as one
+      //  mismatching P picture in one of six runs of the GPU tier, round 6.)
+      const int type = X ? (int) (wh_ld_x32<X> ((const WH_G uint32_t*)n) & 0xffu) : (int)n->mb_type;
+      const int8_t mode = X ? (int8_t) ((wh_ld_x32<X> ((const WH_G uint32_t*)n + 2 + (idx >> 2)) >> (8 * (idx & 3))) & 0xffu) : n->i4_mode[idx];
       const int8_t v = (from_t || from_l) ? (type == WH_MB_I4x4 ? mode : (int8_t)2) : (int8_t) - 1;
       S.i4m[lane] = v;
       return (int)v; }) ());

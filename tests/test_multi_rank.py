@@ -298,9 +298,33 @@ def _pipelined_vs_synchronous(lib, w, h, frames, qp, contents, ring, intra_perio
         assert steps == frames
         out[mode] = ([bytes(b) for b in got], g.recon(0))
         g.close()
+    if out["pipe"][0] != out["sync"][0] or out["pipe"][1] != out["sync"][1]:
+        _explain_mismatch(lib, seqs, out, w, h, qp, intra_period, complexity, ahead)
     assert out["pipe"][0] == out["sync"][0]
     assert out["pipe"][1] == out["sync"][1]
     return seqs, out["pipe"][0]
+
+
+def _explain_mismatch(lib, seqs, out, w, h, qp, intra_period, complexity, ahead):
+    """A pipelined group and a synchronous one disagree: say which of them left the single-session encoder's stream (same library), for which
+    session and from which access unit on, and keep the streams (gpurun_out/ travels back from the GPU box)."""
+    import openh264_amd as oh
+    d = os.path.join(ROOT, "gpurun_out", "pipelined_mismatch_ahead%d" % ahead)
+    os.makedirs(d, exist_ok=True)
+    lines = []
+    for s, yuv in enumerate(seqs):
+        want, _ = oh.encode_sequence(yuv, w, h, lib_path=lib, iDLayerQp=qp, uiIntraPeriod=intra_period, fMaxFrameRate=30.0, iTargetBitrate=5000000,
+                                     bEnableSceneChangeDetect=False, iComplexityMode=complexity)
+        for mode in ("sync", "pipe"):
+            got = out[mode][0][s]
+            open(os.path.join(d, "%s_session%d.264" % (mode, s)), "wb").write(got)
+            if got != want:
+                first = next((i for i in range(min(len(got), len(want))) if got[i] != want[i]), min(len(got), len(want)))
+                lines.append("%s session %d: leaves the single-session stream at byte %d of %d (access unit %d)" % (mode, s, first, len(want), want[:first].count(b"\x00\x00\x00\x01")))
+        open(os.path.join(d, "single_session%d.264" % s), "wb").write(want)
+    lines.append("reconstruction of session 0: %s" % ("same" if out["pipe"][1] == out["sync"][1] else "differs"))
+    open(os.path.join(d, "report.txt"), "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines))
 
 
 @pytest.mark.parametrize("ring,ahead", [(2, 1), (3, 1), (3, 2), (2, 3)])
