@@ -372,6 +372,7 @@ def binding_leg(args, local, extra_env=None, timeout=400):
             "device_frames_per_s": dev["sum_of_session_encode_fps"], "device_slowest_session_fps": dev["min_session_fps"],
             "device_ms_per_frame_per_session": 1e3 * n / dev["sum_of_session_encode_fps"],
             "c_path_frames_per_s": c["sum_of_session_encode_fps"], "c_path_cores": n,
+            "pictures_on_device": dev.get("device_pictures"), "pictures_left_to_the_host": dev.get("host_pictures"),
             "note": "frames/s = sum over the sessions of frames / time inside EncodeFrame; every layer of a simulcast frame counts as part of ONE frame"}, r.stderr.decode(errors="replace")
 
 
@@ -596,11 +597,14 @@ def main():
         # 1080p / 720p / 360p / 180p simulcast AVC layers (all four layers on this GPU; one layer per GPU is WELS_HIP_LAYER_DEVICES=1),
         # config 5 = 8 of the 64 concurrent 1080p sessions (rate control in bitrate mode, raster slices of 2040 macroblocks).
         if workload == "p" and os.path.exists(os.path.join(REF_DIR, "ref_enc_hip")):
-            for key, args in (("config4_simulcast_1080p_720p_360p_180p", ["1", "54", "simulcast", "1080p"]), ("config4_8_sessions", ["8", "54", "simulcast", "1080p"]),
-                              ("config5_8_sessions_1080p_rc_raster_slices", ["8", "54", "plain", "1080p"])):      # (the whole 54-frame clip: rounds 2-4 coded its first 30
+            # (config 4 as the binding runs it by default: the 360p and 180p layers -- 920 and 240 macroblocks -- are coded by the session's own thread on the
+            #  reference's path, 1080p and 720p on the device, integration/welship_hooks.cpp pfHipLayerOnDevice; "..._all_layers_on_device" switches that off)
+            for key, args, env in (("config4_simulcast_1080p_720p_360p_180p", ["1", "54", "simulcast", "1080p"], None), ("config4_8_sessions", ["8", "54", "simulcast", "1080p"], None),
+                                   ("config4_8_sessions_all_layers_on_device", ["8", "54", "simulcast", "1080p"], {"WELS_HIP_MIN_LAYER_MBS": "0"}),
+                                   ("config5_8_sessions_1080p_rc_raster_slices", ["8", "54", "plain", "1080p"], None)):      # (the whole 54-frame clip: rounds 2-4 coded its first 30
                 # frames, of which the sessions of the device leg spend about ten falling into step -- a running service is the steady state)
                 try:
-                    line[key], _ = binding_leg(args, dev, timeout=240)
+                    line[key], _ = binding_leg(args, dev, extra_env=env, timeout=240)
                 except Exception as e:
                     line[key] = {"error": str(e)[:200]}
     # what an encoder delivers, next to the contract's `value` (the device hot path): complete EncodeFrame work with a verified bitstream, and the

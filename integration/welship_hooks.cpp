@@ -155,6 +155,12 @@ struct HipState {
   std::atomic<bool> failed {false};     // a device call failed: the session reports errors from then on (slice tasks set it concurrently)
   bool trace = false;
   int layer_devices = 0;                // WELS_HIP_LAYER_DEVICES: 0 all layers on one GPU; 1 layer d on GPU base + d; n >= 2 layer d on GPU base + d mod n
+  // Spatial layers with fewer macroblocks than this stay on the reference's own path (pfHipLayerOnDevice): a session's layers are coded one after the
+  // other, so every layer on the device adds a whole round trip -- a latency chain of ~50 macroblock steps for 320x180, behind whatever
+  // other sessions have queued -- to the frame, and a core codes 240 macroblocks in half a millisecond.  Sessions with ONE spatial layer are never
+  // split this way (the caller chose the device for that size).  WELS_HIP_MIN_LAYER_MBS overrides (0: every layer on the device).
+  int min_layer_mbs = 0;
+  long host_pictures = 0;               // pictures of such layers (the trace's count of device pictures does not include them)
   // WELS_HIP_TRACE=2: where a picture's time goes (seconds, summed): device call incl. transfers, reconstruction copy-back,
   // entropy coding from the records
   bool timing = false;
@@ -181,6 +187,18 @@ struct Stopwatch {
   explicit Stopwatch (double* a) : acc (a), t0 (std::chrono::steady_clock::now()) {}
   ~Stopwatch() { if (acc) *acc += std::chrono::duration<double> (std::chrono::steady_clock::now() - t0).count(); }
 };
+
+// Is spatial layer `did` coded on the device?  (Simulcast layers are independent streams, so the answer may differ from layer to layer; the one
+// coupling -- the highest layer's inter-layer hints from the layer below, HipFrameMd -- reads SMB fields that either path fills in.)
+bool LayerOnDevice (const HipState* st, const sWelsEncCtx* pCtx, int did) {
+  if (st->min_layer_mbs <= 0) return true;
+  const SDqLayer* pLayer = pCtx->ppDqLayerList[did];
+  return pLayer == NULL || pLayer->iMbWidth * pLayer->iMbHeight >= st->min_layer_mbs;
+}
+bool HipLayerOnDevice (sWelsEncCtx* pCtx) {
+  const HipState* st = (const HipState*)pCtx->pFuncList->pHipState;
+  return st == NULL || LayerOnDevice (st, pCtx, pCtx->uiDependencyId);
+}
 
 // The device's reconstruction of the layer's current picture into pDecPic.  Nothing of the hooked encoder reads pDecPic's samples on the
 // host (mode decision, the in-loop filter and the reference pictures live on the device), so this only runs where the reference is about
@@ -283,6 +301,7 @@ int32_t HipVaaCalc (sWelsEncCtx* pCtx, int32_t iDid, SPicture* pCurPic, SPicture
   if (st == NULL || !st->vaa || st->failed || g_api.FrameVaa == NULL || pCtx->pVaa == NULL || pCurPic == NULL || pRefPic == NULL) return 1;
   if (iDid < 0 || iDid >= MAX_DEPENDENCY_LAYER || pCurPic->pData[0] == NULL || pRefPic->pData[0] == NULL || pCurPic->pData[0] == pRefPic->pData[0]) return 1;
   if (pCurPic->iLineSize[0] != pRefPic->iLineSize[0]) return 1;               // (the C functions take ONE stride for both pictures)
+  if (!LayerOnDevice (st, pCtx, iDid)) return 1;                              // (a layer that is coded on the host: its statistics come from there too)
   if (!EnsureLayerCtx (st, pCtx, iDid)) return 1;
   SVAACalcResult* pRes = &pCtx->pVaa->sVaaCalcInfo;
   WelsHipVaaJob job;
@@ -359,6 +378,11 @@ int32_t HipFrameMd (sWelsEncCtx* pCtx) {
   HipLayer& L = st->layer[did];
   const SWelsSvcCodingParam* pParam = pCtx->pSvcParam;
   const int mbw = pCurLayer->iMbWidth, mbh = pCurLayer->iMbHeight, num_mb = mbw * mbh;
+  if (!LayerOnDevice (st, pCtx, did)) {          // the slice loops, the in-loop filter and the reference list run as if no hook were installed
+    ++st->host_pictures;
+    if (st->trace) fprintf (stderr, "welship hooks: picture of layer %d (%d macroblocks) left to the host\n", did, num_mb);
+    return ENC_RETURN_SUCCESS;
+  }
   if (!EnsureLayerCtx (st, pCtx, did)) return ENC_RETURN_UNEXPECTED;
   if (L.vaa_copy.valid) {      // WELS_HIP_CHECK_VAA=1: the device's pre-analysis against the reference's own
     HipLayer::VaaCopy& V = L.vaa_copy;
@@ -849,6 +873,7 @@ void HipRelease (void* p) {
   if (st->check_bits && st->trace) fprintf (stderr, "welship hooks: CAVLC bit counts of %ld macroblocks equal the writer's\n", st->bits_checked.load());
   if (st->timing && st->pictures) fprintf (stderr, "welship hooks: %d pictures; per picture: device call %.3f ms, reconstruction copy-back %.3f ms, slice coding from the records %.3f ms, pre-analysis call %.3f ms, down-sampling calls %.3f ms\n",
                                            st->pictures, 1e3 * st->t_encode / st->pictures, 1e3 * st->t_getpic / st->pictures, 1e3 * st->t_code / st->pictures, 1e3 * st->t_vaa / st->pictures, 1e3 * st->t_down / st->pictures);
+  if (st->trace && st->host_pictures) fprintf (stderr, "welship hooks: %ld pictures of layers below %d macroblocks were coded by the host\n", st->host_pictures, st->min_layer_mbs);
   for (int i = 0; i < MAX_DEPENDENCY_LAYER; ++i) if (st->layer[i].ctx) {
     g_api.FrameCtxDestroy (st->layer[i].ctx);
     if (st->trace) fprintf (stderr, "welship hooks: device context of layer %d released\n", i);
@@ -982,6 +1007,7 @@ static void Report (SLogContext* pLogCtx, const char* fmt, ...) {
 void WelsHipInstall (SWelsFuncPtrList* pFuncList, SWelsSvcCodingParam* pParam, SLogContext* pLogCtx) {
   pFuncList->pfHipFrameMd = NULL;
   pFuncList->pfHipCodeSlice = NULL;
+  pFuncList->pfHipLayerOnDevice = NULL;
   pFuncList->pfHipRelease = NULL;
   pFuncList->pfHipDownsample = NULL;
   pFuncList->pfHipVaaCalc = NULL;
@@ -1017,6 +1043,8 @@ void WelsHipInstall (SWelsFuncPtrList* pFuncList, SWelsSvcCodingParam* pParam, S
   st->eager_recon = pParam->iUsageType == SCREEN_CONTENT_REAL_TIME;
   st->check_bits = getenv ("WELS_HIP_CHECK_BITS") != NULL && atoi (getenv ("WELS_HIP_CHECK_BITS")) != 0 && pParam->iEntropyCodingModeFlag == 0;
   st->layer_devices = getenv ("WELS_HIP_LAYER_DEVICES") != NULL ? WELS_MAX (0, atoi (getenv ("WELS_HIP_LAYER_DEVICES"))) : 0;
+  st->min_layer_mbs = getenv ("WELS_HIP_MIN_LAYER_MBS") != NULL ? WELS_MAX (0, atoi (getenv ("WELS_HIP_MIN_LAYER_MBS")))
+                    : (pParam->iSpatialLayerNum > 1 && st->layer_devices == 0) ? 1000 : 0;      // (640x360 = 920 macroblocks and below; a GPU per layer: the caller placed them)
   st->downsample = !(getenv ("WELS_HIP_DOWNSAMPLE") != NULL && atoi (getenv ("WELS_HIP_DOWNSAMPLE")) == 0);
   st->vaa = !(getenv ("WELS_HIP_VAA") != NULL && atoi (getenv ("WELS_HIP_VAA")) == 0);
   st->vaa_check = getenv ("WELS_HIP_CHECK_VAA") != NULL && atoi (getenv ("WELS_HIP_CHECK_VAA")) != 0;
@@ -1025,6 +1053,7 @@ void WelsHipInstall (SWelsFuncPtrList* pFuncList, SWelsSvcCodingParam* pParam, S
   pFuncList->pHipState = st;
   pFuncList->pfHipFrameMd = HipFrameMd;
   pFuncList->pfHipCodeSlice = HipCodeSlice;
+  pFuncList->pfHipLayerOnDevice = HipLayerOnDevice;
   pFuncList->pfHipRelease = HipRelease;
   pFuncList->pfHipDownsample = HipDownsample;
   pFuncList->pfHipVaaCalc = HipVaaCalc;

@@ -25,8 +25,14 @@ def _both(lib, tmp_path, yuv, w, h, flags, min_pictures, extra_env=None):
     open(fi, "wb").write(yuv)
     base = ["-i", fi, "-w", str(w), "-h", str(h), "-fps", "30", "-quiet"] + flags
     subprocess.check_call([os.path.join(REF, "ref_enc"), "-o", str(tmp_path / "ref.264")] + base, stdout=subprocess.DEVNULL)
-    env = dict(os.environ, WELSHIP_LIB=lib, WELS_HIP_TRACE="1", WELS_HIP_CHECK_BITS="1")
-    env.update(extra_env or {})
+    # (every layer on the device unless a test asks for the binding's default -- layers below 1000 macroblocks of a multi-layer session stay on
+    #  the host, WELS_HIP_MIN_LAYER_MBS -- or for a threshold of its own: the small pictures of this file would all stay there)
+    env = dict(os.environ, WELSHIP_LIB=lib, WELS_HIP_TRACE="1", WELS_HIP_CHECK_BITS="1", WELS_HIP_MIN_LAYER_MBS="0")
+    for k, v in (extra_env or {}).items():
+        if v is None:
+            env.pop(k, None)
+        else:
+            env[k] = v
     p = subprocess.run([os.path.join(REF, "ref_enc_hip"), "-o", str(tmp_path / "hip.264")] + base, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
     err = p.stderr.decode(errors="replace")
     assert p.returncode == 0, err[-2000:]
@@ -68,6 +74,22 @@ def test_config4_four_layers_on_emulation(emu_lib, tmp_path):
     _both(emu_lib, tmp_path, synth_sequence(1920, 1080, 3), 1920, 1080, ["-rc", "-1", "-qp", "24"] + CONFIG4, 12)
 
 
+@pytest.mark.parametrize("flags,pictures", SMALL)
+def test_small_layers_left_to_the_host_on_emulation(emu_lib, tmp_path, flags, pictures):
+    """pfHipLayerOnDevice (round 6): the layers below the threshold are coded by the reference's own path -- slice loops, in-loop filter, reference
+    list as if no hook were installed -- and only the full-size layer goes to the device, which still takes its inter-layer hints from
+    the (host-coded) layer below and shares the one pSadCost array with it.  Same access units."""
+    layers = flags.count("-simulcast") + 1
+    err = _both(emu_lib, tmp_path, synth_sequence(640, 368, 6), 640, 368, flags, pictures // layers, {"WELS_HIP_MIN_LAYER_MBS": "500"})
+    assert err.count("left to the host") == pictures - pictures // layers and err.count("welship hooks: did") == pictures // layers, err[-1500:]
+
+
+def test_config4_with_the_default_layer_split_on_emulation(emu_lib, tmp_path):
+    """The binding's default for config 4: 1080p and 720p on the device, 360p and 180p (920 and 240 macroblocks) on the host."""
+    err = _both(emu_lib, tmp_path, synth_sequence(1920, 1080, 3), 1920, 1080, ["-rc", "-1", "-qp", "24"] + CONFIG4, 6, {"WELS_HIP_MIN_LAYER_MBS": None})
+    assert err.count("left to the host") == 6 and err.count("welship hooks: did") == 6 and "pictures of layers below 1000 macroblocks were coded by the host" in err
+
+
 def test_simulcast_with_the_host_downsampler(emu_lib, tmp_path):
     """WELS_HIP_DOWNSAMPLE=0: the reference's own C down-samplers feed the layers (the pre-round-3 arrangement); same bytes."""
     _both(emu_lib, tmp_path, synth_sequence(640, 368, 6), 640, 368, SMALL[1][0], SMALL[1][1], {"WELS_HIP_DOWNSAMPLE": "0"})
@@ -80,14 +102,25 @@ def test_simulcast_sessions_on_the_mi355x(hip_lib, tmp_path, flags, pictures):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("rc", [["-rc", "-1", "-qp", "24"], ["-rc", "1", "-bitrate", "3000000", "-slcmd", "1", "-slcnum", "4"]])
-def test_config4_four_layers_of_the_1080p_clip_on_the_mi355x(hip_lib, ref_tools, tmp_path, rc):
+def test_config4_four_layers_of_the_1080p_clip_on_the_mi355x(hip_lib, ref_tools, tmp_path, rc, split):
+    """split: the binding's default -- 360p and 180p on the host, 1080p and 720p on the device; else all four layers on the device."""
     if not ref_tools:
         pytest.skip("oracle/_ref not built")
     out = str(tmp_path / "clip.yuv")
     subprocess.check_call([ref_tools["dec"], os.path.join(RES, "VID_1920x1080_cavlc_temporal_direct.264"), out], stdout=subprocess.DEVNULL)
     yuv = open(out, "rb").read()[: 1920 * 1080 * 3 // 2 * 12]
-    _both(hip_lib, tmp_path, yuv, 1920, 1080, rc + CONFIG4, 48)
+    err = _both(hip_lib, tmp_path, yuv, 1920, 1080, rc + CONFIG4, 24 if split else 48, {"WELS_HIP_MIN_LAYER_MBS": None} if split else None)
+    assert err.count("left to the host") == (24 if split else 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags,pictures", SMALL[:2])
+def test_small_layers_left_to_the_host_on_the_mi355x(hip_lib, tmp_path, flags, pictures):
+    layers = flags.count("-simulcast") + 1
+    err = _both(hip_lib, tmp_path, synth_sequence(640, 368, 6), 640, 368, flags, pictures // layers, {"WELS_HIP_MIN_LAYER_MBS": "500"})
+    assert err.count("left to the host") == pictures - pictures // layers
 
 
 def test_one_device_per_simulcast_layer(emu_lib, tmp_path):

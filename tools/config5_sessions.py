@@ -51,12 +51,13 @@ def run(tmp, yuv, hip):
     enc_fps = [float(x) for x in re.findall(rb" fps=([0-9.]+)", p.stdout)]
     wall = float(re.search(rb"wall_seconds=([0-9.]+)", p.stdout).group(1))
     pictures = p.stderr.count(b"welship hooks: did")
+    host_pictures = p.stderr.count(b"left to the host")      # layers below WELS_HIP_MIN_LAYER_MBS macroblocks of a multi-layer session (pfHipLayerOnDevice)
     if DYNSLICE and hip:
         done = [l for l in p.stderr.decode(errors="replace").splitlines() if "picture complete" in l]
         run.dyn = {"slices": sum(int(l.split("complete:")[1].split()[0]) for l in done), "device_calls": sum(int(l.split("slices,")[1].split()[0]) for l in done)}
     sha = [hashlib.sha1(open("%s.%d" % (out, i), "rb").read()).hexdigest() for i in range(N)]
     return {"wall_s_incl_init": wall, "sum_of_session_encode_fps": sum(enc_fps), "min_session_fps": min(enc_fps), "max_session_fps": max(enc_fps),
-            "device_pictures": pictures}, sha
+            "device_pictures": pictures, "host_pictures": host_pictures}, sha
 
 
 def main():

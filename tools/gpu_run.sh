@@ -15,6 +15,7 @@
 #   iwaves          IDR step of 256 four-slice 1080p pictures with 16 / 12 / 10 / 8 / 6 waves per intra workgroup (WELSHIP_I_WAVES) -> intra_waves.txt
 #   c5trace         config 5's shape (1 and 8 sessions 1080p, rate control, raster slices) through the binding with WELS_HIP_TRACE=2 -> config5_trace.txt
 #   c5ab:<v>,<v>..  the same, device frames/s against the C path, per variant (library tag[:ENV=VALUE...]) -> config5_ab.txt
+#   c4ab:<v>,<v>..  config 4's shape (four simulcast layers, 1 and 8 sessions) per variant -> config4_ab.txt
 #   trace1          kernel + copy timeline of ONE 1080p session through the dispatch-table binding (config 5's shape) -> trace1_timeline.txt
 #   iphase          the same for the I macroblock body (the IDR step of 256 pictures) -> phase_cycles_intra.txt
 #   rphase          the same on the reference's own 1080p clip -> phase_cycles_res_clip.txt
@@ -92,6 +93,13 @@ for stage in "$@"; do
               r=$(env $envs WELSHIP_LIB=$PWD/$lib timeout 200 python tools/config5_sessions.py $n 40 x 1080p 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['hooks_on_device']['sum_of_session_encode_fps'], d['reference_c_path']['sum_of_session_encode_fps'], d['same_bitstreams'])")
               echo "$v rep $rep sessions $n: device fps, C path fps, same bitstreams: $r"
             done; done; done > $o/config5_ab.txt 2>&1; cat $o/config5_ab.txt; lap "config 5 A/B";;
+  c4ab:*)   # config 4's shape (four simulcast layers of the 1080p clip, 1 and 8 sessions) per variant, as c5ab
+            for rep in 1 2; do for v in $(echo "${stage#c4ab:}" | tr , ' '); do for n in 1 8; do
+              t=${v%%:*}; lib=openh264_amd/libwelship.so; [ "$t" != "-" ] && lib=openh264_amd/libwelship_$t.so
+              envs=$(echo "${v#*:}" | tr ':' ' '); [ "$envs" = "$v" ] && envs=""
+              r=$(env $envs WELSHIP_LIB=$PWD/$lib timeout 200 python tools/config5_sessions.py $n 54 simulcast 1080p 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['hooks_on_device']['sum_of_session_encode_fps'], d['reference_c_path']['sum_of_session_encode_fps'], d['same_bitstreams'], d['hooks_on_device']['device_pictures'], d['hooks_on_device']['host_pictures'])")
+              echo "$v rep $rep sessions $n: device fps, C path fps, same bitstreams, pictures on the device / left to the host: $r"
+            done; done; done > $o/config4_ab.txt 2>&1; cat $o/config4_ab.txt; lap "config 4 A/B";;
   trace1)   ( cd /tmp && WELS_HIP_TRACE=2 timeout 200 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $OLDPWD/$o/trace1 -- python $OLDPWD/tools/config5_sessions.py 1 12 x 1080p > $OLDPWD/$o/trace1.log 2>&1 )
             python tools/trace_timeline.py $o/trace1 2 > $o/trace1_timeline.txt 2>&1; tail -60 $o/trace1_timeline.txt; rm -rf $o/trace1; lap "timeline of one 1080p session through the binding";;
   iphase)   timeout 200 python tools/phase_profile.py 256 synthetic intra > $o/phase_cycles_intra.txt 2>&1; head -16 $o/phase_cycles_intra.txt; lap "phase cycles (IDR step)";;
