@@ -522,14 +522,14 @@ def main():
     rf = roofline(workload, mbs, a.sessions, a.steps, ev)
     rf["traffic"] = None
     try:        # HBM bytes per launch of the dominant kernel: from the committed rocprofv3 --pmc passes of this very command (not measured in this run)
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")))
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r06_pmc_traffic.json")))
         if tj.get("workload") == workload and tj.get("sessions") == a.sessions and (w, h) == (tj.get("width"), tj.get("height")):
             want = "tickets" if rf["kernel"] == "k_inter_pool" else None
             for name, v in tj["schedulers"].items():
                 if want and name.startswith(want):
                     rf["traffic"] = v["hbm_bytes_per_launch"]
                     rf["traffic_over_algorithmic"] = v["times_algorithmic"]
-                    rf["traffic_source"] = "profiles/r05_pmc_traffic.json, '%s' (separate rocprofv3 --pmc passes of this command; not measured in this run)" % name
+                    rf["traffic_source"] = "profiles/r06_pmc_traffic.json, '%s' (separate rocprofv3 --pmc passes of this command; not measured in this run)" % name
     except Exception:
         pass
     pics = a.sessions * a.steps * world

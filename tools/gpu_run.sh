@@ -25,6 +25,8 @@
 #                   RUNS times each (default 6), for every library of LIBS (default: the product library) -> repro.txt
 #   ab:<v>,<v>..    `bench.py --quick` alternating between variants, three rounds; a variant = a library tag (openh264_amd/libwelship_<tag>.so, "-" = the product
 #                   library) optionally followed by :ENV=VALUE settings (e.g. -:WELSHIP_P_WAVES=14); AB_ARGS = further bench.py arguments
+#   l2              LDS-DMA loads and the L2: tools/micro/lds_dma_l2 under the TCC counters; the P kernel's TCC counters with 32 / 64 / 128 / 256 pictures in flight -> l2_micro.txt, l2_by_sessions.txt
+#   l2ab:<v>,<v>..  the P kernel's TCC counters and FETCH_SIZE / WRITE_SIZE per variant (as ab:) -> l2_ab.txt
 #   detail:<tag>    sub-phase cycles of the claim / neighbour-load / P_Skip phases: tools/phase_profile.py with a library built with -DWH_PROF_DETAIL
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
@@ -104,6 +106,28 @@ for stage in "$@"; do
             python tools/trace_timeline.py $o/trace1 2 > $o/trace1_timeline.txt 2>&1; tail -60 $o/trace1_timeline.txt; rm -rf $o/trace1; lap "timeline of one 1080p session through the binding";;
   iphase)   timeout 200 python tools/phase_profile.py 256 synthetic intra > $o/phase_cycles_intra.txt 2>&1; head -16 $o/phase_cycles_intra.txt; lap "phase cycles (IDR step)";;
   detail:*) WELSHIP_LIB=$PWD/openh264_amd/libwelship_${stage#detail:}.so WELSHIP_PROF_DETAIL=1 timeout 200 python tools/phase_profile.py 256 > $o/phase_cycles_detail.txt 2>&1; head -22 $o/phase_cycles_detail.txt; lap "phase cycles (detail)";;
+  l2)       # does an LDS-DMA load allocate in the L2 (tools/micro/lds_dma_l2.hip), and the P kernel's L2 hit counters by pictures in flight (capacity?)
+            ( cd /tmp && timeout 120 rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum --output-format csv -d $OLDPWD/$o/l2_micro -- $OLDPWD/tools/micro/lds_dma_l2 > $OLDPWD/$o/l2_micro.txt 2>&1 )
+            python tools/pmc_summary.py $o/l2_micro >> $o/l2_micro.txt 2>&1; rm -rf $o/l2_micro
+            ( cd /tmp && timeout 120 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OLDPWD/$o/l2_micro -- $OLDPWD/tools/micro/lds_dma_l2 > /dev/null 2>&1 )
+            python tools/pmc_summary.py $o/l2_micro >> $o/l2_micro.txt 2>&1; rm -rf $o/l2_micro
+            ( cd /tmp && timeout 120 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OLDPWD/$o/l2_micro -- $OLDPWD/tools/micro/lds_dma_l2 > /dev/null 2>&1 )
+            python tools/pmc_summary.py $o/l2_micro >> $o/l2_micro.txt 2>&1; rm -rf $o/l2_micro
+            cat $o/l2_micro.txt
+            for n in 32 64 128 256; do
+              ( cd /tmp && timeout 200 rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum --output-format csv -d $OLDPWD/$o/l2_s$n -- python $OLDPWD/bench.py --quick --steps 6 --warmup 2 --sessions $n > $OLDPWD/$o/l2_s$n.log 2>&1 )
+              echo "== $n pictures in flight"; python tools/pmc_summary.py $o/l2_s$n | grep -E "inter_"; rm -rf $o/l2_s$n
+            done > $o/l2_by_sessions.txt 2>&1; cat $o/l2_by_sessions.txt; lap "L2";;
+  l2ab:*)   # TCC counters of the P kernel per variant (library tag[:ENV=VALUE...], as ab:) -> l2_ab.txt
+            for v in $(echo "${stage#l2ab:}" | tr , ' '); do
+              t=${v%%:*}; lib=openh264_amd/libwelship.so; [ "$t" != "-" ] && lib=openh264_amd/libwelship_$t.so
+              envs=$(echo "${v#*:}" | tr ':' ' '); [ "$envs" = "$v" ] && envs=""
+              n=$(echo "$v" | tr ':=' '__')
+              for grp in "TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum" "FETCH_SIZE" "WRITE_SIZE"; do
+                ( cd /tmp && env $envs WELSHIP_LIB=$OLDPWD/$lib timeout 200 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OLDPWD/$o/l2ab_$n -- python $OLDPWD/bench.py --quick --steps 6 --warmup 2 ${AB_ARGS:-} > $OLDPWD/$o/l2ab_$n.log 2>&1 )
+                echo "== $v"; python tools/pmc_summary.py $o/l2ab_$n | grep -E "inter_"; rm -rf $o/l2ab_$n
+              done
+            done > $o/l2_ab.txt 2>&1; cat $o/l2_ab.txt; lap "L2 counters per variant";;
   *)        echo "unknown stage $stage";;
   esac
 done
