@@ -5,7 +5,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "openh264_amd", "csrc")
-HOST_SRCS = [os.path.join(CSRC, "host", f) for f in ("encoder.cpp", "entropy_cavlc.cpp", "headers.cpp")]
+HOST_SRCS = [os.path.join(CSRC, "host", f) for f in ("encoder.cpp", "frame_api.cpp", "entropy_cavlc.cpp", "headers.cpp")]
 # (csrc/hip/leaf.hip is the second half of prims.hip's translation unit: the kernels both layers launch are compiled once)
 HIP_SRCS = [os.path.join(CSRC, "hip", "hip_backend.hip"), os.path.join(CSRC, "hip", "prims.hip"), os.path.join(CSRC, "hip", "downsample.hip")]
 LIB = os.path.join(ROOT, "openh264_amd", "libwelship.so")
@@ -56,7 +56,7 @@ def build_hip(force=False, verbose=True, defines=(), tag="", flags=()):
     device through WELSHIP_LIB / tools/fuzz_parity.py --lib; the product library is always the plain build.
     `flags`: further compiler flags of such a candidate (e.g. "-mllvm", "-amdgpu-enable-max-ilp-scheduling-strategy")."""
     out = LIB if not tag else LIB.replace(".so", "_" + tag + ".so")
-    deps = [CSRC, os.path.join(ROOT, "include")]
+    deps = [CSRC, os.path.join(ROOT, "include"), os.path.abspath(__file__)]        # (this file: the source lists)
     if not force and not _newer(out, deps):
         return out
     # NB: no v_ashr_pk_u8_i32 may appear in the device code (see wh_clip255 in csrc/kernels/wave.h): tests/test_abi.py checks the listing.
@@ -75,7 +75,7 @@ def build_emu(force=False, verbose=False, defines=(), tag=""):
     """g++ -DWH_EMU test build of the same kernel sources (tests only, never shipped/loaded by the product).
     `defines` + `tag`: a second test build with candidate code paths switched on (e.g. WH_DB_PER_EDGE)."""
     out = EMU_LIB if not tag else EMU_LIB.replace(".so", "_" + tag + ".so")
-    deps = [CSRC, os.path.join(ROOT, "tests", "emu", "emu_backend.cpp")]
+    deps = [CSRC, os.path.join(ROOT, "tests", "emu", "emu_backend.cpp"), os.path.abspath(__file__)]
     if not force and not _newer(out, deps):
         return out
     with _locked(out) as tmp:

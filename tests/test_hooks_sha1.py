@@ -316,7 +316,7 @@ def test_stock_welsenc_cfg_on_the_mi355x(hip_lib, tmp_path):
     _stock_cfg(hip_lib, tmp_path)
 
 
-# ---- several encoder instances in one process: their pictures are launched together (FrameShared, csrc/host/encoder.cpp) ------
+# ---- several encoder instances in one process: their pictures are launched together (FrameShared, csrc/host/frame_api.cpp) ------
 def _parallel_sessions(lib, tmp_path, n):
     yuv = os.path.join(RES, "CiscoVT2people_320x192_12fps.yuv")
     base = [os.path.join(REF, "ref_enc_hip"), "-parallel", str(n), "-i", yuv, "-w", "320", "-h", "192", "-fps", "12", "-rc", "1", "-bitrate", "300000",
