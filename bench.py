@@ -173,7 +173,9 @@ def cpu_baseline(w, h, qp, workload, content, idc, sessions=(0,)):
     Which reference: oracle/_ref/ref_enc is the C fallback (`-O3`, no asm) -- the image has no nasm, so the SIMD library cannot be built here and,
     /root/reference not existing on the GPU box, not there either.  oracle/Makefile builds oracle/_ref/ref_enc_asm (the reference with its x86
     assembly, build/x86-common.mk) wherever nasm is on PATH at build time; when that binary travels with the snapshot it is timed as well and
-    reported as `simd` (kind "reference SSE2/AVX2").  A reported baseline either way, not the optimisation target."""
+    reported as `simd` (kind "reference SSE2/AVX2").  A reported baseline either way, not the optimisation target.
+    (Letting the compiler vectorise the C path for AVX2 -- -O3 -march=x86-64-v3 -- is no stand-in for the assembly: measured in round 6, the same 1080p
+    frames code at 16.8 instead of 20.2 frames/s on the build container's Xeon, identical stream; not built.)"""
     if not os.path.exists(os.path.join(REF_DIR, "ref_enc")):
         return None
     sessions = tuple(sessions) or (0,)
