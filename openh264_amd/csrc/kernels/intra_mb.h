@@ -374,9 +374,15 @@ WH_FN bool wh_intra_md_enc_p (WhMbLds& S, const WhSeqParams& P, const WhPicJob& 
   // phase cycles of an I picture's macroblocks (a P macroblock's intra test is part of the P body's own phases)
 #if defined(WH_EMU) || !defined(WH_PROF)
 #define WH_PROF_MARK_I(id) ((void)0)
+#define WH_PROF_SUB_I(id) ((void)0)
 #else
   unsigned long long _wh_t0 = (P.prof && J.slice_type == WH_SLICE_I) ? (unsigned long long)__builtin_readcyclecounter() : 0ULL;
 #define WH_PROF_MARK_I(id) do { if (J.slice_type == WH_SLICE_I) WH_PROF_MARK_RAW (P, S, id); } while (0)
+#if defined(WH_PROF_I4)          /* sub-phases of the Intra4x4 pair steps (tools/phase_profile.py ... intra with a -DWH_PROF -DWH_PROF_I4 library) */
+#define WH_PROF_SUB_I(id) WH_PROF_MARK_I (id)
+#else
+#define WH_PROF_SUB_I(id) ((void)0)
+#endif
 #endif
   WhI16Cost own;
   if (!pre) { wh_i16_costs (S, avail, use_satd, lambda, &own); pre = &own; }
@@ -615,9 +621,11 @@ WH_FN bool wh_intra_md_enc_p (WhMbLds& S, const WhSeqParams& P, const WhPicJob& 
         }
         return c; }) () : 0));
       WV_SYNC();
+      WH_PROF_SUB_I (0);      /* detail: a pair step's filter tables, candidates and costs */
       int bmA, bcA, bmB, bcB;
       decide (ct, 0, 2, alA, atA, atlA, atrA, pmA, bmA, bcA);
       decide (ct, 32, 2, alB, atB, atlB, atrB, pmB, bmB, bcB);
+      WH_PROF_SUB_I (1);      /* detail: both decision trees */
       cost4 += bcA + bcB;
       if (cost4 >= cost_luma) { completed = false; return false; }
       if (pmA == bmA) prev_flags |= (uint16_t) (1u << bA);
@@ -627,6 +635,7 @@ WH_FN bool wh_intra_md_enc_p (WhMbLds& S, const WhSeqParams& P, const WhPicJob& 
       const int remA = (pmA == bmA) ? 0 : (bmA < pmA) ? bmA : bmA - 1, remB = (pmB == bmB) ? 0 : (bmB < pmB) ? bmB : bmB - 1;
       int nzA, nzB;
       wh_encrec_i4_pair (S, bA, bB, bmA, bmB, qp, (int8_t)remA, (int8_t)remB, predB, &nzA, &nzB);
+      WH_PROF_SUB_I (8);      /* detail: both blocks' transform, quantisation, reconstruction */
       if (nzA > 0) cbp |= 1 << (bA >> 2);
       if (nzB > 0) cbp |= 1 << (bB >> 2);
       return true;
@@ -703,6 +712,7 @@ WH_FN bool wh_intra_md_enc_p (WhMbLds& S, const WhSeqParams& P, const WhPicJob& 
 
   WH_PROF_MARK_I (6);       // chroma: mode decision + encode
 #undef WH_PROF_MARK_I
+#undef WH_PROF_SUB_I
   o->mb_type = mb_type;
   o->cbp = cbp | (cbp_c << 4);
   o->i16_mode_std = (best_mode <= 3) ? best_mode : 2;

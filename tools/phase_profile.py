@@ -37,6 +37,8 @@ if len(sys.argv) > 3 and sys.argv[3] == "intra":      # the IDR step that starts
     print("IDR step %s" % (one,))
     names = {11: "ticket+order", 12: "dependency wait", 9: "tile load", 2: "I16x16 mode costs", 3: "texture analysis + mode cache", 4: "sixteen I4x4 blocks", 5: "I16x16 encode", 6: "chroma decision + encode",
              15: "decision epilogue", 7: "bits + store", 13: "release+flag", 14: "(body total)"}
+    if out[16 + 0]:       # a -DWH_PROF_I4 library: the pair steps' parts are counted on their own, "sixteen I4x4 blocks" keeps the rest (single-block steps, loop)
+        names.update({0: "I4x4 pair: tables + candidates + costs", 1: "I4x4 pair: decision trees", 8: "I4x4 pair: transform .. reconstruction"})
     tot = sum(out[i] for i in range(16) if i not in (14,))
     for i, n in names.items():
         print("%-30s %6.2f%%  avg %8.0f cycles  hits %d" % (n, 100.0 * out[i] / max(tot, 1), out[i] / max(out[16 + i], 1), out[16 + i]))
