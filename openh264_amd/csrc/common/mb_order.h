@@ -77,3 +77,31 @@ WH_ORDER_FN int wh_build_db_bands (int mb_w, int mb_h, int num_slices, const int
   }
   return n;
 }
+
+// ---- deblocking, one band = the whole picture: two macroblocks per wavefront (kernels/deblock_mb.h wh_deblock_pair_body) -----------------
+// A macroblock in the middle of the band [first, last): left, upper, right and lower neighbours (and the left neighbour's lower one) inside it.
+WH_ORDER_FN bool wh_db_mb_interior (int mb_w, int xy, int first, int last) {
+  const int x = xy % mb_w;
+  return x > 0 && x < mb_w - 1 && xy - mb_w >= first && xy - 1 >= first && xy + mb_w < last;
+}
+// The whole-picture order as ITEMS of one or two macroblocks: out[0] = number of items, out[1 + i] = address of the item's (first) macroblock A,
+// bit 31 set when the item is a pair -- A = (x, y) and the next macroblock of its 2:1 diagonal, B = (x - 2, y + 1) = A + mb_w - 2.  Items follow
+// the diagonals, so an item only depends on earlier items.  Pairs are made of interior macroblocks, and only on diagonals of at least `min_len`
+// macroblocks: a shorter diagonal has fewer macroblocks than the workgroup has waves anyway, and a pair takes longer than one macroblock.
+// out: mb_w * mb_h + 1 words.
+#define WH_DB_ITEM_PAIR 0x80000000u
+WH_ORDER_FN int wh_build_db_pair_items (int mb_w, int mb_h, int min_len, uint32_t* out) {
+  const int num_mb = mb_w * mb_h;
+  int n = 0;
+  for (int d = 0; d <= (mb_w - 1) + 2 * (mb_h - 1); ++d) {
+    const int y0 = d - (mb_w - 1) > 0 ? (d - (mb_w - 1) + 1) / 2 : 0, y1 = d / 2 < mb_h - 1 ? d / 2 : mb_h - 1;     // rows with 0 <= d - 2 y < mb_w
+    const int len = y1 - y0 + 1;
+    for (int y = y0; y <= y1; ++y) {
+      const int xy = y * mb_w + d - 2 * y;
+      if (len >= min_len && y < y1 && wh_db_mb_interior (mb_w, xy, 0, num_mb) && wh_db_mb_interior (mb_w, xy + mb_w - 2, 0, num_mb)) { out[1 + n++] = (uint32_t)xy | WH_DB_ITEM_PAIR; ++y; }
+      else out[1 + n++] = (uint32_t)xy;
+    }
+  }
+  out[0] = (uint32_t)n;
+  return n;
+}

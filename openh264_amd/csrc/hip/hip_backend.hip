@@ -606,6 +606,91 @@ __global__ __launch_bounds__ (1024) void k_deblock_slices (WhSeqParams P, const 
 }
 
 
+// Deblocking with one band = the whole picture (large batches, filter across slice edges), TWO macroblocks per wavefront where the processing
+// order pairs them up (round 6; kernels/deblock_mb.h wh_deblock_pair_body, common/mb_order.h wh_build_db_pair_items: the order's fourth section).
+// A ticket is an item of one or two macroblocks of one 2:1 diagonal; an item only depends on earlier items, everything is inside the workgroup
+// (no seams: k_deblock_slices' hand-off between bands does not exist here).  Two tiles and two staging areas per wave.
+__global__ __launch_bounds__ (1024) void k_deblock_pairs (WhSeqParams P, const WhPicJob* jobs, uint32_t* err) {
+  extern __shared__ __align__ (16) uint8_t smem[];
+  const int nw = (int)blockDim.x >> 6, lane = (int)threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane ((int)threadIdx.x >> 6);
+  WhDbLds* S2 = (WhDbLds*)smem + 2 * wave;
+  WhDbLds& S = S2[0];
+  WhDbXchg E;                                 // strip exchange between the waves (deblock_mb.h), indexed by absolute MB row
+  E.top = (uint32_t*) (smem + (size_t)nw * 2 * sizeof (WhDbLds));
+  E.left = E.top + (size_t)P.mb_w * 24;
+  E.first_row = 0;
+  uint32_t* sched = E.left + (size_t)P.mb_h * 32;
+  const int w = P.mb_w, num_mb = P.mb_w * P.mb_h;
+  const uint32_t* items = P.mb_order + 3 * (size_t)num_mb;
+  const int n = (int)items[0];
+  for (int i = (int)threadIdx.x; i < 1 + ((num_mb + 31) >> 5); i += (int)blockDim.x) sched[i] = 0;
+  __shared__ WhPicJob Jl;
+  wh_copy_job (&Jl, &jobs[blockIdx.y]);
+  __syncthreads();
+  const WhPicJob& J = Jl;
+  __shared__ WhDbStage stage[16][2];              // separate LDS object (see WhInterStage)
+  WhDbStage* G2 = stage[wave];
+#if WH_PROF_ON
+  if (P.prof && lane < 32) S.prof[lane] = 0;
+#endif
+  WH_PROF_DECL (P);
+  // an item: its first macroblock (x, y), `kind` = 0 none, 1 one macroblock, 2 the pair with (x - 2, y + 1)
+  int kind = 0, ax = 0, ay = 0;
+#define WH_DB_CLAIM(KIND, X, Y) do {                                                                                     \
+    int t_ = 0;                                                                                                           \
+    if (lane == 0) t_ = (int)atomicAdd (&sched[0], 1u);                                                                   \
+    t_ = __builtin_amdgcn_readfirstlane (t_);                                                                             \
+    if (t_ >= n) KIND = 0;                                                                                                \
+    else { const uint32_t it_ = items[1 + t_]; const int xy_ = (int) (it_ & ~WH_DB_ITEM_PAIR); KIND = (it_ & WH_DB_ITEM_PAIR) ? 2 : 1; Y = xy_ / w; X = xy_ - Y * w; } \
+  } while (0)
+  WH_DB_CLAIM (kind, ax, ay);
+  if (kind) { wh_deblock_cold_fetch (G2[0], lane, P, J, ax, ay); if (kind > 1) wh_deblock_cold_fetch (G2[1], lane, P, J, ax - 2, ay + 1); }
+  WH_PROF_MARK (P, S, 0);     // ticket + order (+ the first item's inputs requested)
+  for (int guard = 0; guard <= n && kind; ++guard) {
+    const bool pair = kind > 1;
+    const int xy = ay * w + ax, xb = xy + w - 2, bx = ax - 2, by = ay + 1;
+    // left and top-right neighbours (top at the right edge) of A; of B: its left one -- its top-right one is A's left
+    int dep_a, dep_b;
+    wh_mb_deps (w, xy, 0, &dep_a, &dep_b);
+    bool ok = wh_wait_done (sched + 1, dep_a, err) && wh_wait_done (sched + 1, dep_b, err);
+    if (ok && pair) ok = wh_wait_done (sched + 1, xb - 1, err);
+    if (!ok) break;
+    __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "workgroup");
+    WH_PROF_MARK (P, S, 2);   // neighbours done
+    WV_ASYNC_WAIT();                            // the staged inputs have landed
+    WH_PROF_MARK (P, S, 4);   // own inputs landed
+    // (Taking the next item here and requesting its inputs as soon as the staging areas are empty -- so that ticket, order look-up and the loads' way
+    //  through the memory system run beside this item's filters -- was measured and lost, as it had with one macroblock per wave: 2.09 -> 2.35 ms per
+    //  step of 256 1080p pictures, profiles/r06_deblock_two_macroblocks_per_wave_ab.txt.  A diagonal of a 1080p picture is about thirty items; sixteen
+    //  items in hand plus sixteen held reach into the next diagonal, whose items then wait for this one's.)
+    if (pair && J.rec_blk) wh_deblock_pair_body (S2, G2, E, P, J, ax, ay, bx, by);
+    else {          // (a pair without WhPicJob::rec_blk -- no launch of this library -- is two macroblocks one after the other)
+      bool drain = wh_deblock_mb_body (S, G2[0], E, 0, num_mb, P, J, ax, ay, 0, 0, 0, false);
+      if (pair) drain |= wh_deblock_mb_body (S2[1], G2[1], E, 0, num_mb, P, J, bx, by, 0, 0, 0, false);
+      if (drain) __builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");
+    }
+    WH_PROF_MARK (P, S, 11);  // (body total: ids 5..8)
+    // the hand-off is LDS only (strip exchange + flags, executed in order by the LDS unit): the wave's global stores need not have completed --
+    // no other macroblock of the picture writes or reads those samples
+    WV_SYNC();
+    if (lane == 0) {
+      atomicOr (&sched[1 + (xy >> 5)], 1u << (xy & 31));
+      if (pair) atomicOr (&sched[1 + (xb >> 5)], 1u << (xb & 31));
+    }
+    WH_PROF_MARK (P, S, 9);   // done flags
+    // a wave takes a ticket only when it is free, starts the loads of that item's own inputs at once and waits for the neighbours while they are in flight
+    WH_DB_CLAIM (kind, ax, ay);
+    if (kind) { wh_deblock_cold_fetch (G2[0], lane, P, J, ax, ay); if (kind > 1) wh_deblock_cold_fetch (G2[1], lane, P, J, ax - 2, ay + 1); }
+    WH_PROF_MARK (P, S, 0);   // ticket + order + own inputs requested
+  }
+#undef WH_DB_CLAIM
+  WH_PROF_MARK (P, S, 10);    // idle tail: no ticket left, the picture is still being finished by other waves
+#if WH_PROF_ON
+  if (P.prof && lane < 32) atomicAdd (&P.prof[2048u + ((blockIdx.x + blockIdx.y * 7u) & 63u) * 32u + lane], (unsigned long long)S.prof[lane]);
+#endif
+}
+
 // ---- record compaction (common/compact.h): one workgroup per picture ------------------------------------------------
 // Pass 1: one wavefront per MB tests its 25 coefficient blocks (+ chroma DC) for non-zero levels (ballot over four
 // lane-parallel loads), gates them by type / cbp, and leaves mask and size in LDS.  Pass 2: exclusive scan of the sizes.
@@ -1092,7 +1177,11 @@ class HipBackend : public wh::Backend {
     if (whole) {
       WhSeqParams W = P;
       W.flags |= WH_SEQ_DB_WHOLE; W.db_num_bands = 1; W.db_bands = WH_DB_WHOLE_TABLE (P); W.db_max_rows = P.mb_h; W.db_max_mbs = P.mb_w * P.mb_h;
-      mb_pass (k_deblock_slices, sizeof (WhDbLds), 16, false, W, jobs, n, 16 * sizeof (WhDbStage) + sizeof (WhPicJob), 4 * wh_db_xchg_words (P.mb_w, P.mb_h), 1);
+      // ... two macroblocks per wavefront where the order pairs them up (k_deblock_pairs).  WELSHIP_DB_PAIRS=0: the one-macroblock kernel (A/B).
+      static const bool pairs = !(getenv ("WELSHIP_DB_PAIRS") && atoi (getenv ("WELSHIP_DB_PAIRS")) == 0);
+      // (sixteen waves: the pass's time goes with 1 / waves -- 12: 2.52, 14: 2.32, 16: 2.13 ms per step of 256 1080p pictures)
+      if (pairs) mb_pass (k_deblock_pairs, 2 * sizeof (WhDbLds), 16, false, W, jobs, n, 32 * sizeof (WhDbStage) + sizeof (WhPicJob), 4 * wh_db_xchg_words (P.mb_w, P.mb_h), 1);
+      else mb_pass (k_deblock_slices, sizeof (WhDbLds), 16, false, W, jobs, n, 16 * sizeof (WhDbStage) + sizeof (WhPicJob), 4 * wh_db_xchg_words (P.mb_w, P.mb_h), 1);
       return;
     }
     mb_pass (k_deblock_slices, sizeof (WhDbLds), db_waves, false, P, jobs, n, 16 * sizeof (WhDbStage) + sizeof (WhPicJob), 4 * wh_db_xchg_words (P.mb_w, P.mb_h), P.db_num_bands);

@@ -247,6 +247,8 @@ struct SessionCore {
     if (nb < 1) { set_err ("deblocking band table"); release(); return WELSHIP_ERR_UNKNOWN; }
     for (int b = 0; b < nb; ++b) wh_build_mb_order (mb_w, bands[b], bands[b + 1], order.data() + 2 * (size_t)num_mb + bands[b]);
     std::vector<uint32_t> order32 (order.begin(), order.end());      // 32-bit on the device (scalar loads)
+    order32.resize ((size_t)num_mb * 4 + 1);                          // + the whole-picture deblocking order as items of one or two macroblocks (common/mb_order.h)
+    wh_build_db_pair_items (mb_w, mb_h, wh::db_pair_min_len(), order32.data() + 3 * (size_t)num_mb);
     d_order = (uint32_t*)A (order32.size() * 4);
     d_bands = (int32_t*)A (sizeof (int32_t) * (3 * (size_t)nb + 1 + 4));      // + the one-band table of the whole picture
     d_scene = (uint32_t*)A (64);
@@ -988,6 +990,12 @@ int WelsHipDebugGetOverflowReencodes (WelsHipEncoder* e) {
 int WelsHipDebugBuildMbOrder (int mb_w, int first, int last, int band, uint16_t* out) {
   if (mb_w <= 0 || first < 0 || last <= first || !out) return WELSHIP_ERR_INIT_PARA;
   wh_build_mb_order (mb_w, first, last, out, band);
+  return WELSHIP_OK;
+}
+
+int WelsHipDebugBuildDbPairItems (int mb_w, int mb_h, int min_len, uint32_t* out) {
+  if (mb_w <= 0 || mb_h <= 0 || !out) return WELSHIP_ERR_INIT_PARA;
+  wh_build_db_pair_items (mb_w, mb_h, min_len, out);
   return WELSHIP_OK;
 }
 

@@ -38,6 +38,10 @@ inline int align_up (int v, int a) { return (v + a - 1) / a * a; }
 // (the unfiltered reconstruction lives in macroblock-contiguous blocks, WhPicJob::rec_blk; the planar in-place layout of rounds 1-3 measured
 //  6.07 x against 4.03 x the algorithmic traffic and lost its switch in round 5: profiles/r04_pmc_traffic_unfiltered_recon_in_blocks.txt)
 inline bool rec_blocks_on() { return true; }
+// Whole-picture deblocking, two macroblocks per wavefront (common/mb_order.h wh_build_db_pair_items): the shortest 2:1 diagonal whose macroblocks
+// are paired up (measured on the MI355X, 256 1080p pictures: 16 and below 2.07-2.10 ms per step, 32: 2.13-2.15; profiles/r06_deblock_two_macroblocks_per_wave_ab.txt).  WELSHIP_DB_PAIR_MIN (read when a session's tables are built; a value above
+// any diagonal's length = no pairs) is the measurement knob.
+inline int db_pair_min_len() { const char* e = getenv ("WELSHIP_DB_PAIR_MIN"); const int v = e ? atoi (e) : 16; return v > 2 ? v : 2; }
 
 struct DevPicture {            // one padded reconstruction buffer + its tiled twin (same allocation) + its MB state
   uint8_t* base = nullptr;

@@ -271,10 +271,12 @@ struct WelsHipFrameCtx {
       const int nb = wh_build_db_bands (mb_w, mb_h, n, first, idc, WH_DB_BAND_ROWS, bands.data(), (int)bands.size());
       if (nb < 1) { set_err ("deblocking band table"); return WELSHIP_ERR_UNKNOWN; }
       for (int b = 0; b < nb; ++b) wh_build_mb_order (mb_w, bands[b], bands[b + 1], order.data() + 2 * (size_t)num_mb + bands[b]);
-      up->d_order = (uint32_t*)be->alloc ((size_t)num_mb * 3 * 4);
+      std::vector<uint32_t> order32 (order.begin(), order.end());
+      order32.resize ((size_t)num_mb * 4 + 1);                        // + the whole-picture deblocking order as items of one or two macroblocks (common/mb_order.h)
+      wh_build_db_pair_items (mb_w, mb_h, wh::db_pair_min_len(), order32.data() + 3 * (size_t)num_mb);
+      up->d_order = (uint32_t*)be->alloc (order32.size() * 4);
       up->d_bands = (int32_t*)be->alloc (sizeof (int32_t) * (3 * (size_t)nb + 1 + 4));
       if (!up->d_order || !up->d_bands) { set_err ("out of device memory"); return WELSHIP_ERR_MEMORY; }
-      std::vector<uint32_t> order32 (order.begin(), order.end());
       be->upload (up->d_order, order32.data(), order32.size() * 4);
       { const int32_t whole[4] = {0, num_mb, 0, num_mb}; bands.resize (3 * (size_t)nb + 1); bands.insert (bands.end(), whole, whole + 4); }
       be->upload (up->d_bands, bands.data(), sizeof (int32_t) * (3 * (size_t)nb + 1 + 4));

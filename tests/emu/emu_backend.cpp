@@ -170,6 +170,24 @@ class EmuBackend : public Backend {
         E.top = xb.data(); E.left = xb.data() + (size_t)P.mb_w * 24; E.first_row = 0;
         poison (&S, sizeof (S)); poison (&G, sizeof (G));
         const int first = bands[s], last = bands[s + 1];
+        if (whole && jobs[j].rec_blk) {
+          // the whole picture in items of one or two macroblocks (common/mb_order.h wh_build_db_pair_items), as the device's k_deblock_pairs
+          const uint32_t* items = P.mb_order + 3 * (size_t)P.mb_w * P.mb_h;
+          WhDbLds S2[2];
+          WhDbStage G2[2];
+          for (uint32_t t = 0; t < items[0]; ++t) {
+            const int xy = (int) (items[1 + t] & ~WH_DB_ITEM_PAIR), xb = xy + P.mb_w - 2;
+            const bool pair = (items[1 + t] & WH_DB_ITEM_PAIR) != 0;
+            poison (S2, sizeof (S2)); poison (G2, sizeof (G2));
+            for (int lane = 0; lane < 64; ++lane) wh_deblock_cold_fetch (G2[0], lane, P, jobs[j], xy % P.mb_w, xy / P.mb_w);
+            if (pair) {
+              if (getenv ("WELSHIP_EMU_DB_STATS")) { static long pairs_seen = 0; if ((++pairs_seen & 1023) == 1) fprintf (stderr, "emu: deblocking pair %ld (MB %d + %d)\n", pairs_seen, xy, xb); }
+              for (int lane = 0; lane < 64; ++lane) wh_deblock_cold_fetch (G2[1], lane, P, jobs[j], xb % P.mb_w, xb / P.mb_w);
+              wh_deblock_pair_body (S2, G2, E, P, jobs[j], xy % P.mb_w, xy / P.mb_w, xb % P.mb_w, xb / P.mb_w);
+            } else (void)wh_deblock_mb_body (S2[0], G2[0], E, first, last, P, jobs[j], xy % P.mb_w, xy / P.mb_w, 0, 0, 0, false);
+          }
+          continue;
+        }
         const uint32_t* order = whole ? P.mb_order + P.mb_w * P.mb_h : P.mb_order + 2 * P.mb_w * P.mb_h;
         for (int lane = 0; lane < 64; ++lane) wh_deblock_cold_fetch (G, lane, P, jobs[j], order[first] % P.mb_w, order[first] / P.mb_w);
         for (int t = first; t < last; ++t) {

@@ -111,7 +111,7 @@ def test_mode_decision_kernels_do_not_spill(hip_lib):
         name = re.search(r"\.name:\s+(\S+)", l).group(1)
         m = re.search(r"\.private_segment_fixed_size:\s+(\d+)", l)        # (the script's name shortening swallows this field of some rows: the spill count is in all)
         scratch, spills = int(m.group(1)) if m else 0, int(re.search(r"\.vgpr_spill_count:\s+(\d+)", l).group(1))
-        if any(k in name for k in ("k_inter_pool", "k_intra_slice", "k_deblock_slices", "k_expand", "k_tile", "k_compact", "k_vaa", "k_bgd", "k_ds_")):
+        if any(k in name for k in ("k_inter_pool", "k_intra_slice", "k_deblock_slices", "k_deblock_pairs", "k_expand", "k_tile", "k_compact", "k_vaa", "k_bgd", "k_ds_")):
             seen += 1
             assert scratch == 0 and spills == 0, "%s: %d bytes of scratch, %d spilled VGPRs" % (name, scratch, spills)
     assert seen >= 20

@@ -166,6 +166,48 @@ def test_band_order_is_topological():
                     assert pos[dep] < pos[xy]
 
 
+def test_deblocking_pair_items_are_a_topological_order_of_independent_pairs():
+    """The whole-picture deblocking order as items of one or two macroblocks (common/mb_order.h wh_build_db_pair_items, what k_deblock_pairs takes
+    tickets for): every macroblock once; an item's macroblocks only depend on macroblocks of earlier items (deblocking dependencies: left, top,
+    top-right -- deblocking.cpp:357-440 filters a macroblock's left and upper edge into its neighbours); a pair is two interior macroblocks of
+    one 2:1 diagonal, on a diagonal of at least the asked length."""
+    import ctypes
+    import numpy as np
+    from openh264_amd import build as whbuild
+    lib = ctypes.CDLL(whbuild.build_emu())
+    fn = lib.WelsHipDebugBuildDbPairItems
+    fn.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p]
+    for mb_w, mb_h, min_len in [(120, 68, 32), (120, 68, 2), (20, 12, 2), (7, 7, 2), (3, 9, 2), (1, 5, 2), (256, 144, 32), (80, 45, 1000)]:
+        out = np.zeros(mb_w * mb_h + 1, np.uint32)
+        assert fn(mb_w, mb_h, min_len, out.ctypes.data) == 0
+        n = int(out[0])
+        item_of, pairs = {}, 0
+        for i in range(n):
+            a, pair = int(out[1 + i]) & 0x7fffffff, int(out[1 + i]) >> 31
+            mbs = [a, a + mb_w - 2] if pair else [a]
+            pairs += pair
+            for xy in mbs:
+                assert 0 <= xy < mb_w * mb_h and xy not in item_of
+                item_of[xy] = i
+            if pair:
+                (ax, ay), (bx, by) = (a % mb_w, a // mb_w), (mbs[1] % mb_w, mbs[1] // mb_w)
+                assert (bx, by) == (ax - 2, ay + 1)
+                d = ax + 2 * ay
+                assert sum(1 for y in range(mb_h) if 0 <= d - 2 * y < mb_w) >= min_len
+                for x, y in ((ax, ay), (bx, by)):
+                    assert 1 <= x <= mb_w - 2 and 1 <= y <= mb_h - 2
+        assert len(item_of) == mb_w * mb_h
+        for xy, i in item_of.items():
+            x = xy % mb_w
+            for dep in ([xy - 1] if x > 0 else []) + [xy - mb_w] + ([xy - mb_w + 1] if x < mb_w - 1 else []):
+                if dep >= 0:
+                    assert item_of[dep] < i
+        if (mb_w, mb_h, min_len) == (120, 68, 32):
+            assert pairs > 2500            # (three quarters of a 1080p picture's 8160 macroblocks go two at a time)
+        if min_len == 1000 or mb_w < 5:
+            assert pairs == 0
+
+
 def test_session_lifecycle(emu_lib):
     """Uninitialize + InitializeExt on the same object behaves like a fresh object (no state leaks between sessions);
     ForceIntraFrame(false) is a successful no-op as in the reference (welsEncoderExt.cpp:487-500)."""
@@ -346,6 +388,9 @@ def _whole_picture_band(lib, ref_tools, tmp_path, monkeypatch):
     """Large batches deblock a picture as ONE band (no seams between workgroups; hip_backend.hip run_deblock, WH_DB_WHOLE_TABLE)
     when the filter crosses slice edges anyway; WELSHIP_DB_WHOLE=1 forces that choice for a single picture: the multi-slice cases again."""
     monkeypatch.setenv("WELSHIP_DB_WHOLE", "1")
+    # ... and there the pass filters TWO macroblocks per wavefront wherever a 2:1 diagonal has enough of them (common/mb_order.h
+    # wh_build_db_pair_items; on the device k_deblock_pairs): these pictures' diagonals are short, so every diagonal pairs up here
+    monkeypatch.setenv("WELSHIP_DB_PAIR_MIN", "2")
     names = [k for k in SMALL if GOLDEN[k]["params"].get("uiSliceNum", 1) > 1 or GOLDEN[k]["params"].get("uiSliceMode", 0) != 0]
     assert names
     for name in names[:6]:
