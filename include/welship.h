@@ -203,7 +203,7 @@ int  WelsHipDebugGetOverflowReencodes (WelsHipEncoder* pEncoder);
  * (openh264_amd/csrc/common/mb_order.h; iBand = rows per band, 0 = the default single band); pOut: iLastMb - iFirstMb entries */
 int  WelsHipDebugBuildMbOrder (int iMbWidth, int iFirstMb, int iLastMb, int iBand, uint16_t* pOut);
 /* developer aid: the whole-picture deblocking order as items of one or two macroblocks (mb_order.h wh_build_db_pair_items: pOut[0] = number of
- * items, pOut[1 + i] = address of the item's first macroblock A, bit 31 set when the item is the pair A, A + iMbWidth - 2 -- two macroblocks of one
+ * items, pOut[1 + i] = the item's first macroblock A as x | y << 12, bit 31 set when the item is the pair A, A + iMbWidth - 2 -- two macroblocks of one
  * 2:1 diagonal that one wavefront filters at once; only on diagonals of at least iMinLen macroblocks); pOut: iMbWidth * iMbHeight + 1 entries */
 int  WelsHipDebugBuildDbPairItems (int iMbWidth, int iMbHeight, int iMinLen, uint32_t* pOut);
 /* developer aid: per-phase cycle counters accumulated inside the MB kernels; pOut64 receives 16 sums + 16 counts of the

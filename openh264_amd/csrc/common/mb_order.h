@@ -84,12 +84,14 @@ WH_ORDER_FN bool wh_db_mb_interior (int mb_w, int xy, int first, int last) {
   const int x = xy % mb_w;
   return x > 0 && x < mb_w - 1 && xy - mb_w >= first && xy - 1 >= first && xy + mb_w < last;
 }
-// The whole-picture order as ITEMS of one or two macroblocks: out[0] = number of items, out[1 + i] = address of the item's (first) macroblock A,
-// bit 31 set when the item is a pair -- A = (x, y) and the next macroblock of its 2:1 diagonal, B = (x - 2, y + 1) = A + mb_w - 2.  Items follow
+// The whole-picture order as ITEMS of one or two macroblocks: out[0] = number of items, out[1 + i] = the item's (first) macroblock A as x | y << 12
+// (WH_DB_ITEM_X / _Y: no division by the picture's width on the claim path), bit 31 set when the item is a pair -- A = (x, y) and the next macroblock of its 2:1 diagonal, B = (x - 2, y + 1) = A + mb_w - 2.  Items follow
 // the diagonals, so an item only depends on earlier items.  Pairs are made of interior macroblocks, and only on diagonals of at least `min_len`
 // macroblocks: a shorter diagonal has fewer macroblocks than the workgroup has waves anyway, and a pair takes longer than one macroblock.
 // out: mb_w * mb_h + 1 words.
 #define WH_DB_ITEM_PAIR 0x80000000u
+#define WH_DB_ITEM_X(it) ((int) ((it) & 0xfffu))
+#define WH_DB_ITEM_Y(it) ((int) (((it) >> 12) & 0xfffu))
 WH_ORDER_FN int wh_build_db_pair_items (int mb_w, int mb_h, int min_len, uint32_t* out) {
   const int num_mb = mb_w * mb_h;
   int n = 0;
@@ -98,8 +100,8 @@ WH_ORDER_FN int wh_build_db_pair_items (int mb_w, int mb_h, int min_len, uint32_
     const int len = y1 - y0 + 1;
     for (int y = y0; y <= y1; ++y) {
       const int xy = y * mb_w + d - 2 * y;
-      if (len >= min_len && y < y1 && wh_db_mb_interior (mb_w, xy, 0, num_mb) && wh_db_mb_interior (mb_w, xy + mb_w - 2, 0, num_mb)) { out[1 + n++] = (uint32_t)xy | WH_DB_ITEM_PAIR; ++y; }
-      else out[1 + n++] = (uint32_t)xy;
+      if (len >= min_len && y < y1 && wh_db_mb_interior (mb_w, xy, 0, num_mb) && wh_db_mb_interior (mb_w, xy + mb_w - 2, 0, num_mb)) { out[1 + n++] = (uint32_t) (d - 2 * y) | ((uint32_t)y << 12) | WH_DB_ITEM_PAIR; ++y; }
+      else out[1 + n++] = (uint32_t) (d - 2 * y) | ((uint32_t)y << 12);
     }
   }
   out[0] = (uint32_t)n;

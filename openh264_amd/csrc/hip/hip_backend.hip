@@ -610,6 +610,10 @@ __global__ __launch_bounds__ (1024) void k_deblock_slices (WhSeqParams P, const 
 // order pairs them up (round 6; kernels/deblock_mb.h wh_deblock_pair_body, common/mb_order.h wh_build_db_pair_items: the order's fourth section).
 // A ticket is an item of one or two macroblocks of one 2:1 diagonal; an item only depends on earlier items, everything is inside the workgroup
 // (no seams: k_deblock_slices' hand-off between bands does not exist here).  Two tiles and two staging areas per wave.
+#ifndef WH_DB_ITEMS_IN_LDS
+#define WH_DB_ITEMS_IN_LDS 1
+#endif
+#define WH_DB_ITEMS_LDS_MAX_MB 9216          /* 36 KB of items at most (1080p: 32 KB) */
 __global__ __launch_bounds__ (1024) void k_deblock_pairs (WhSeqParams P, const WhPicJob* jobs, uint32_t* err) {
   extern __shared__ __align__ (16) uint8_t smem[];
   const int nw = (int)blockDim.x >> 6, lane = (int)threadIdx.x & 63;
@@ -622,9 +626,18 @@ __global__ __launch_bounds__ (1024) void k_deblock_pairs (WhSeqParams P, const W
   E.first_row = 0;
   uint32_t* sched = E.left + (size_t)P.mb_h * 32;
   const int w = P.mb_w, num_mb = P.mb_w * P.mb_h;
-  const uint32_t* items = P.mb_order + 3 * (size_t)num_mb;
-  const int n = (int)items[0];
+  const uint32_t* items_g = P.mb_order + 3 * (size_t)num_mb;
+  const int n = (int)items_g[0];
   for (int i = (int)threadIdx.x; i < 1 + ((num_mb + 31) >> 5); i += (int)blockDim.x) sched[i] = 0;
+  // the item list in LDS when the picture is small enough (WH_DB_ITEMS_LDS_MAX_MB, the launch reserves the room): a wave's claim is then an LDS atomic and
+  // an LDS read instead of an LDS atomic and a round trip to the L2 in front of every item's loads
+#if WH_DB_ITEMS_IN_LDS
+  uint32_t* items_l = sched + 1 + ((num_mb + 31) >> 5);
+  const bool items_in_lds = num_mb <= WH_DB_ITEMS_LDS_MAX_MB;
+  if (items_in_lds) for (int i = (int)threadIdx.x; i <= n; i += (int)blockDim.x) items_l[i] = items_g[i];
+#else
+  const bool items_in_lds = false; uint32_t* items_l = nullptr;
+#endif
   __shared__ WhPicJob Jl;
   wh_copy_job (&Jl, &jobs[blockIdx.y]);
   __syncthreads();
@@ -642,7 +655,10 @@ __global__ __launch_bounds__ (1024) void k_deblock_pairs (WhSeqParams P, const W
     if (lane == 0) t_ = (int)atomicAdd (&sched[0], 1u);                                                                   \
     t_ = __builtin_amdgcn_readfirstlane (t_);                                                                             \
     if (t_ >= n) KIND = 0;                                                                                                \
-    else { const uint32_t it_ = items[1 + t_]; const int xy_ = (int) (it_ & ~WH_DB_ITEM_PAIR); KIND = (it_ & WH_DB_ITEM_PAIR) ? 2 : 1; Y = xy_ / w; X = xy_ - Y * w; } \
+    else { const uint32_t it_ = WH_DB_ITEMS_IN_LDS && items_in_lds ? (uint32_t)__builtin_amdgcn_readfirstlane ((int)items_l[1 + t_]) : items_g[1 + t_]; KIND = (it_ & WH_DB_ITEM_PAIR) ? 2 : 1; X = WH_DB_ITEM_X (it_); Y = WH_DB_ITEM_Y (it_); } \
+    /* (Touching the inputs of the item sixteen tickets further on at this point -- one word per 128-byte line by LDS-DMA into a scrap area, so that they */ \
+    /*  are in the L2 when their wave asks for them -- changes nothing: 2.01 against 2.04 ms per step.  The wait in front of a body is the picture's own  */ \
+    /*  ramps, where a 2:1 diagonal has fewer items than the workgroup has waves, not the loads: profiles/r06_deblock_two_macroblocks_per_wave_ab.txt)     */ \
   } while (0)
   WH_DB_CLAIM (kind, ax, ay);
   if (kind) { wh_deblock_cold_fetch (G2[0], lane, P, J, ax, ay); if (kind > 1) wh_deblock_cold_fetch (G2[1], lane, P, J, ax - 2, ay + 1); }
@@ -1180,7 +1196,8 @@ class HipBackend : public wh::Backend {
       // ... two macroblocks per wavefront where the order pairs them up (k_deblock_pairs).  WELSHIP_DB_PAIRS=0: the one-macroblock kernel (A/B).
       static const bool pairs = !(getenv ("WELSHIP_DB_PAIRS") && atoi (getenv ("WELSHIP_DB_PAIRS")) == 0);
       // (sixteen waves: the pass's time goes with 1 / waves -- 12: 2.52, 14: 2.32, 16: 2.13 ms per step of 256 1080p pictures)
-      if (pairs) mb_pass (k_deblock_pairs, 2 * sizeof (WhDbLds), 16, false, W, jobs, n, 32 * sizeof (WhDbStage) + sizeof (WhPicJob), 4 * wh_db_xchg_words (P.mb_w, P.mb_h), 1);
+      const size_t items_lds = (WH_DB_ITEMS_IN_LDS && P.mb_w * P.mb_h <= WH_DB_ITEMS_LDS_MAX_MB) ? 4 * ((size_t)P.mb_w * P.mb_h + 1) : 0;
+      if (pairs) mb_pass (k_deblock_pairs, 2 * sizeof (WhDbLds), 16, false, W, jobs, n, 32 * sizeof (WhDbStage) + sizeof (WhPicJob), 4 * wh_db_xchg_words (P.mb_w, P.mb_h) + items_lds, 1);
       else mb_pass (k_deblock_slices, sizeof (WhDbLds), 16, false, W, jobs, n, 16 * sizeof (WhDbStage) + sizeof (WhPicJob), 4 * wh_db_xchg_words (P.mb_w, P.mb_h), 1);
       return;
     }

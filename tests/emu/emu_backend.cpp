@@ -176,7 +176,7 @@ class EmuBackend : public Backend {
           WhDbLds S2[2];
           WhDbStage G2[2];
           for (uint32_t t = 0; t < items[0]; ++t) {
-            const int xy = (int) (items[1 + t] & ~WH_DB_ITEM_PAIR), xb = xy + P.mb_w - 2;
+            const int xy = WH_DB_ITEM_Y (items[1 + t]) * P.mb_w + WH_DB_ITEM_X (items[1 + t]), xb = xy + P.mb_w - 2;
             const bool pair = (items[1 + t] & WH_DB_ITEM_PAIR) != 0;
             poison (S2, sizeof (S2)); poison (G2, sizeof (G2));
             for (int lane = 0; lane < 64; ++lane) wh_deblock_cold_fetch (G2[0], lane, P, jobs[j], xy % P.mb_w, xy / P.mb_w);

@@ -183,7 +183,8 @@ def test_deblocking_pair_items_are_a_topological_order_of_independent_pairs():
         n = int(out[0])
         item_of, pairs = {}, 0
         for i in range(n):
-            a, pair = int(out[1 + i]) & 0x7fffffff, int(out[1 + i]) >> 31
+            it = int(out[1 + i])
+            a, pair = ((it >> 12) & 0xfff) * mb_w + (it & 0xfff), it >> 31           # x | y << 12 | pair << 31
             mbs = [a, a + mb_w - 2] if pair else [a]
             pairs += pair
             for xy in mbs:
