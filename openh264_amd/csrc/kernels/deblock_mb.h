@@ -86,9 +86,9 @@ WH_FN void wh_db_chroma_line (uint8_t* q, int step, int bs, int alpha, int beta,
 // `chroma`: the line is a chroma line -- the same filter with the p1 / q1 updates and the strong variant switched off and tc = tc0 + 1
 // (DeblockChromaLt4_c / DeblockChromaEq4_c are exactly that subset), so luma and chroma lines share one instruction stream
 WH_FN void wh_db_line_px (bool chroma, int bs, int alpha, int beta, int tc3, bool any4, int p3, int& p2, int& p1, int& p0, int& q0, int& q1, int& q2, int q3) {
-  const int d = wh_abs (p0 - q0);
-  const bool on = bs != 0 && d < alpha && wh_abs (p1 - p0) < beta && wh_abs (q1 - q0) < beta;
-  const bool ap = !chroma && wh_abs (p2 - p0) < beta, aq = !chroma && wh_abs (q2 - q0) < beta;
+  const int d = wh_absdiff_px (p0, q0);
+  const bool on = bs != 0 && d < alpha && wh_absdiff_px (p1, p0) < beta && wh_absdiff_px (q1, q0) < beta;
+  const bool ap = !chroma && wh_absdiff_px (p2, p0) < beta, aq = !chroma && wh_absdiff_px (q2, q0) < beta;
   const int bsn = bs < 1 ? 1 : bs > 3 ? 3 : bs;
   const int tc0 = (tc3 >> ((bsn - 1) * 8)) & 255;
   const int tc = tc0 + (chroma ? 1 : (ap ? 1 : 0) + (aq ? 1 : 0));

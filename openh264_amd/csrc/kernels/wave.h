@@ -376,6 +376,13 @@ WH_FN uint8_t wh_clip255 (int v) { return (uint8_t) (v < 0 ? 0 : (v > 255 ? 255 
 // is not, which corrupts packed pixels (first seen in tests/test_prims_gpu.py::test_motion_compensation).
 WH_FN uint8_t wh_clip255 (int v) { int r; asm ("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(v), "v"(255)); return (uint8_t)r; }
 #endif
+// |a - b| of two samples (both 0 .. 255): one v_sad_u8 on the GPU (the bytes above the samples are zero and add nothing) instead of the
+// subtract / negate / maximum the compiler makes of wh_abs (a - b)
+#if defined(WH_EMU)
+WH_FN int wh_absdiff_px (int a, int b) { return a < b ? b - a : a - b; }
+#else
+WH_FN int wh_absdiff_px (int a, int b) { return (int)__builtin_amdgcn_sad_u8 ((uint32_t)a, (uint32_t)b, 0u); }
+#endif
 WH_FN int wh_median3 (int a, int b, int c) {
   int mn = wh_min (a, wh_min (b, c)), mx = wh_max (a, wh_max (b, c));
   return a + b + c - mn - mx;
