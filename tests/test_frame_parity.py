@@ -132,6 +132,14 @@ def test_hip_4k(hip_lib, ref_tools, tmp_path):
 
 
 @pytest.mark.gpu
+def test_hip_4k_one_band_two_macroblocks_per_wave(hip_lib, ref_tools, tmp_path, monkeypatch):
+    """The same picture deblocked as ONE band, two macroblocks per wavefront (k_deblock_pairs): 36864 macroblocks are more than the kernel keeps
+    items for in LDS (WH_DB_ITEMS_LDS_MAX_MB), so this is the launch that reads the item list from device memory."""
+    monkeypatch.setenv("WELSHIP_DB_WHOLE", "1")
+    _live_4k(hip_lib, ref_tools, tmp_path)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("waves", ["6", "8", "12", "14", "16"])
 def test_hip_wave_variants(waves, hip_lib):
     """The mode-decision pool runs with 16 waves per workgroup by default (k_inter_pool<1024>: one workgroup per CU); it is built for
