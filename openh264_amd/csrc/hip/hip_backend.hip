@@ -1093,6 +1093,9 @@ class HipBackend : public wh::Backend {
   }
   // P pictures: one workgroup per CU-load of slices.  Few slices (latency regime): one slice per workgroup, 12 waves.  Enough
   // slices to fill the chip twice: groups of 2..4 slices share a 12-wave workgroup (k_inter_pool), dealt out by k_md_assign.
+  // The group size is slices / CUs ROUNDED UP (round 6; rounds 2-5 rounded down): every workgroup then starts at once instead of a second, partly filled round
+  // behind the first -- measured, 1080p pictures of four slices per launch: 80 pictures 7.17 -> 4.47 ms, 96: 7.45 -> 4.49, 160: 7.18 -> 5.60, 224: 10.46 -> 7.12
+  // (profiles/r06_md_slots_rounded_up.txt); 64, 128, 192, 256 pictures are the same either way.
   // WELSHIP_MD_SLOTS = 1..4 forces the group size, WELSHIP_P_WAVES the wave count.
   void run_inter (const WhSeqParams& Pin, const WhPicJob* jobs, int n) override {
     const bool plain = WH_PLAIN_KERNEL && (Pin.flags & WH_SEQ_PLAIN) != 0, no_ctrl = WH_FRAME_KERNEL && (Pin.flags & WH_SEQ_NO_CTRL) != 0;
@@ -1103,7 +1106,7 @@ class HipBackend : public wh::Backend {
     static const int forced_slots = getenv ("WELSHIP_MD_SLOTS") ? atoi (getenv ("WELSHIP_MD_SLOTS")) : 0;
     const int use_assign = 1;            // slices dealt out by their previous cost (84 -> 94.5 % of the launch span with live waves on real content)
     const int total = P.num_slices * n;
-    int slots = forced_slots > 0 ? std::min (forced_slots, WH_MD_MAX_SLOTS) : std::max (1, std::min (WH_MD_MAX_SLOTS, total / cus_));
+    int slots = forced_slots > 0 ? std::min (forced_slots, WH_MD_MAX_SLOTS) : std::max (1, std::min (WH_MD_MAX_SLOTS, (total + cus_ - 1) / cus_));
     const int groups = (total + slots - 1) / slots;
     int max_n = 0, max_rows = 0;
     for (int s = 0; s < P.num_slices; ++s) {
@@ -1187,9 +1190,11 @@ class HipBackend : public wh::Backend {
     const int db_waves = 12;    // 73 VGPRs: two 12-wave workgroups per CU, one of 16 (measured 3.85 against 4.79 ms per step of 256 pictures; 8: 4.3, 6: 5.1)
     // Enough pictures to give every CU one (and a filter that crosses slice edges anyway): ONE band per picture, 16 waves -- no seams between
     // workgroups at all (measured, 256 four-slice 1080p pictures: 3.17 against 3.88 ms per step; profiles/r03_deblock_bands.txt).
+    // With two macroblocks per wavefront (k_deblock_pairs, round 6) one band per picture wins from 96 pictures on (1.92 against 2.10 ms per step; 128: 2.00 against 2.12,
+    // 160: 2.09 against 2.79; 64: 1.80 against 1.59 -- profiles/r06_deblock_two_macroblocks_per_wave_ab.txt): 8 x pictures >= 3 x CUs (rounds 3-5: 4 x).
     // WELSHIP_DB_WHOLE = 0 / 1 forces the choice (read per launch: the tests switch it).
     const char* we = getenv ("WELSHIP_DB_WHOLE");
-    const bool whole = P.deblock_idc == 0 && P.db_bands && (P.flags & WH_SEQ_DB_WHOLE) == 0 && (we ? atoi (we) != 0 : 4 * n >= 3 * cus_);
+    const bool whole = P.deblock_idc == 0 && P.db_bands && (P.flags & WH_SEQ_DB_WHOLE) == 0 && (we ? atoi (we) != 0 : 8 * n >= 3 * cus_);
     if (whole) {
       WhSeqParams W = P;
       W.flags |= WH_SEQ_DB_WHOLE; W.db_num_bands = 1; W.db_bands = WH_DB_WHOLE_TABLE (P); W.db_max_rows = P.mb_h; W.db_max_mbs = P.mb_w * P.mb_h;
