@@ -546,7 +546,7 @@ def main():
                    ("%dx%d P-frames, diamond ME range 16, 4 slices/frame, QP %d, LOW complexity" % (w, h, a.qp)),
                    "pictures_in_flight_per_gpu": a.sessions,
                    "hot_path": "device MD/recon + deblock + border expand; sources resident in HBM, MB records left in HBM; host CAVLC excluded (see e2e_pipelined)",
-                   "note": "throughput needs many concurrent pictures per GPU (128 in flight: ~12 % less, 64: ~45 % less); see latency for 1 and 8 sessions",
+                   "note": "throughput needs many concurrent pictures per GPU (measured in round 6: 224 in flight 23.9 k, 160: 20.5 k, 128: 19.4 k, 96: 14.8 k, 64: 11.4 k frames/s); see latency for 1 and 8 sessions",
                    "parallelism": "sessions sharded over %d GPU(s), no collective" % world},
         "roofline": rf,
     }
