@@ -211,6 +211,39 @@ WH_FN void wh_pred_chroma (WhMbLds& S, int mode, const int* st /*[pl][2] top sum
   WV_LANES_END
 }
 
+// The same predictors for the mode decision, one 4-sample row of a 4x4 block per lane, as a packed word: pl = plane, bb = block (raster in the 8x8), r = row of the
+// block; t0 / t1 / l0 / l1 = the plane's top / left half sums, ppa / ppb / ppc = its plane parameters.
+WH_FN uint32_t wh_pred_chroma4 (const WhMbLds& S, int mode, int pl, int bb, int r, int t0, int t1, int l0, int l1, int ppa, int ppb, int ppc) {
+  const int px = (bb & 1) * 4, py = (bb >> 1) * 4 + r;
+  int v;
+  switch (mode) {
+  case WH_C_V: return wh_ld4u (S.rec_c[pl], 4 + px);
+  case WH_C_H: v = WH_RC (S, pl, -1, py); break;
+  case WH_C_DC: v = bb == 0 ? (t0 + l0 + 4) >> 3 : bb == 1 ? (t1 + 2) >> 2 : bb == 2 ? (l1 + 2) >> 2 : (t1 + l1 + 4) >> 3; break;
+  case WH_C_DC_L: v = ((bb < 2 ? l0 : l1) + 2) >> 2; break;
+  case WH_C_DC_T: v = (((bb & 1) ? t1 : t0) + 2) >> 2; break;
+  case WH_C_P: {
+    const int base = ppa + ppc * (py - 3) + 16 + ppb * (px - 3);
+    return (uint32_t)wh_clip255 (base >> 5) | ((uint32_t)wh_clip255 ((base + ppb) >> 5) << 8) | ((uint32_t)wh_clip255 ((base + 2 * ppb) >> 5) << 16) |
+           ((uint32_t)wh_clip255 ((base + 3 * ppb) >> 5) << 24);
+  }
+  default: v = 128; break;
+  }
+  return (uint32_t)v * 0x01010101u;
+}
+// lane's term of the edge sums of the chroma decision: quads 0..3 the top halves (plane * 2 + half), 4..7 the left halves, 8 / 9 the plane mode's horizontal
+// gradient of Cb / Cr, 10 / 11 the vertical one (get_intra_predictor.cpp:530-570 WelsIChromaPredPlane_c)
+WH_FN int wh_chroma_edge_term (const WhMbLds& S, int lane, bool has_t, bool has_l, bool plane) {
+  const int k = lane >> 2, j = lane & 3;
+  if (k < 4) return has_t ? WH_RC (S, k >> 1, (k & 1) * 4 + j, -1) : 0;
+  if (k < 8) return has_l ? WH_RC (S, (k - 4) >> 1, -1, (k & 1) * 4 + j) : 0;
+  if (k < 12 && plane) {
+    const int pl = k & 1;
+    return k < 10 ? (j + 1) * (WH_RC (S, pl, 4 + j, -1) - WH_RC (S, pl, 2 - j, -1)) : (j + 1) * (WH_RC (S, pl, -1, 4 + j) - WH_RC (S, pl, -1, 2 - j));
+  }
+  return 0;
+}
+
 // ---- one row (4 pixels) of an Intra4x4 prediction, standard mode numbering 0..8 ------------------
 // E (0..12): L3 L2 L1 L0 TL T0..T7   (so p[-1,j] = E (3-j), p[i,-1] = E (5+i), TL = E (4)), packed four per word: the
 // index varies per lane (mode, position), and a byte array would end up in scratch memory
@@ -667,20 +700,16 @@ WH_FN bool wh_intra_md_enc_p (WhMbLds& S, const WhSeqParams& P, const WhPicJob& 
   WH_PROF_MARK_I (5);       // Intra16x16 encode (when it won)
 
   // ---------------- chroma ----------------
-  int st[4] = {0, 0, 0, 0}, sl[4] = {0, 0, 0, 0}, cpa[2] = {0, 0}, cpb[2] = {0, 0}, cpc[2] = {0, 0};
-  for (int pl = 0; pl < 2; ++pl) {
-    if (has_t) {
-      WV_SUM (st[pl * 2], lane, (lane < 4 ? WH_RC (S, pl, lane, -1) : 0));
-      WV_SUM (st[pl * 2 + 1], lane, (lane < 4 ? WH_RC (S, pl, 4 + lane, -1) : 0));
-    }
-    if (has_l) {
-      WV_SUM (sl[pl * 2], lane, (lane < 4 ? WH_RC (S, pl, -1, lane) : 0));
-      WV_SUM (sl[pl * 2 + 1], lane, (lane < 4 ? WH_RC (S, pl, -1, 4 + lane) : 0));
-    }
-    if (av3 == 7) {
-      int h, v;
-      WV_SUM (h, lane, (lane < 4 ? (lane + 1) * (WH_RC (S, pl, 4 + lane, -1) - WH_RC (S, pl, 2 - lane, -1)) : 0));
-      WV_SUM (v, lane, (lane < 4 ? (lane + 1) * (WH_RC (S, pl, -1, 4 + lane) - WH_RC (S, pl, -1, 2 - lane)) : 0));
+  // The twelve edge sums (top / left halves of both planes, the plane mode's gradients) as quad sums of ONE pass, then two candidates per pass side by
+  // side on the halves of the wave: lane = (candidate, 4x4 block, row), predictions and source rows as packed words in registers, only the winner goes to
+  // S.pred_c (round 6; before: a pass over LDS bytes per candidate and a wave sum per edge sum).  Order and strict '<' as WelsMdIntraChroma (md.cpp:391-433).
+  WvLaneArr es;
+  WV_QUADSUM_TAB (es, lane, wh_chroma_edge_term (S, lane, has_t, has_l, av3 == 7));
+  int st[4], sl[4], cpa[2] = {0, 0}, cpb[2] = {0, 0}, cpc[2] = {0, 0};
+  for (int i = 0; i < 4; ++i) { st[i] = WV_LGET (es, 4 * i); sl[i] = WV_LGET (es, 16 + 4 * i); }
+  if (av3 == 7) {
+    for (int pl = 0; pl < 2; ++pl) {
+      const int h = WV_LGET (es, 32 + 4 * pl), v = WV_LGET (es, 40 + 4 * pl);
       cpa[pl] = (WH_RC (S, pl, -1, 7) + WH_RC (S, pl, 7, -1)) << 4;
       cpb[pl] = (17 * h + 16) >> 5;
       cpc[pl] = (17 * v + 16) >> 5;
@@ -691,17 +720,41 @@ WH_FN bool wh_intra_md_enc_p (WhMbLds& S, const WhSeqParams& P, const WhPicJob& 
   else if (has_l) { q0 = WH_C_DC_L; q1 = WH_C_H; q2 = q0; q3 = q0; nc = 2; }
   else if (has_t) { q0 = WH_C_DC_T; q1 = WH_C_V; q2 = q0; q3 = q0; nc = 2; }
   else { q0 = WH_C_DC_128; q1 = q0; q2 = q0; q3 = q0; nc = 1; }
-  int cbest = q0, cbest_cost = 0x7fffffff, clast = -1;
+  WvLaneArr pr0, pr1;
+  WV_DECLARE_LANE (lane);
+  int cc0, cc1 = 0x7fffffff, cc2 = 0x7fffffff, cc3 = 0x7fffffff;
+#define WH_CPOS(lane) const int pl_ = ((lane) >> 4) & 1, bb_ = ((lane) >> 2) & 3, r_ = (lane) & 3
+#define WH_CENC(lane) wh_ld4u (S.enc_c, (((lane) >> 4) & 1) * 64 + (((((lane) >> 2) & 3) >> 1) * 4 + ((lane) & 3)) * 8 + ((((lane) >> 2) & 3) & 1) * 4)
+  WV_LANE_EVAL (lane, WH_CPOS (lane);
+                WV_LOWN (pr0, lane) = (int)wh_pred_chroma4 (S, lane < 32 ? q0 : q1, pl_, bb_, r_, pl_ ? st[2] : st[0], pl_ ? st[3] : st[1], pl_ ? sl[2] : sl[0], pl_ ? sl[3] : sl[1],
+                                                            pl_ ? cpa[1] : cpa[0], pl_ ? cpb[1] : cpb[0], pl_ ? cpc[1] : cpc[0]));
+  if (use_satd) WV_SATD_ROWS_HALVES (cc0, cc1, lane, true, WH_CENC (lane), (uint32_t)WV_LOWN (pr0, lane));
+  else { int d0, d1, d2, d3; WV_ROWSUM4 (d0, d1, d2, d3, lane, wh_sad4 (WH_CENC (lane), (uint32_t)WV_LOWN (pr0, lane))); cc0 = d0 + d1; cc1 = d2 + d3; }
+  if (nc > 2) {
+    WV_LANE_EVAL (lane, WH_CPOS (lane);
+                  WV_LOWN (pr1, lane) = (int)wh_pred_chroma4 (S, lane < 32 ? q2 : q3, pl_, bb_, r_, pl_ ? st[2] : st[0], pl_ ? st[3] : st[1], pl_ ? sl[2] : sl[0], pl_ ? sl[3] : sl[1],
+                                                              pl_ ? cpa[1] : cpa[0], pl_ ? cpb[1] : cpb[0], pl_ ? cpc[1] : cpc[0]));
+    if (use_satd) WV_SATD_ROWS_HALVES (cc2, cc3, lane, true, WH_CENC (lane), (uint32_t)WV_LOWN (pr1, lane));
+    else { int d0, d1, d2, d3; WV_ROWSUM4 (d0, d1, d2, d3, lane, wh_sad4 (WH_CENC (lane), (uint32_t)WV_LOWN (pr1, lane))); cc2 = d0 + d1; cc3 = d2 + d3; }
+  } else {
+    WV_LANE_EVAL (lane, WV_LOWN (pr1, lane) = 0);
+  }
+  int cbest = q0, cbest_cost = 0x7fffffff, cidx = 0;
   for (int i = 0; i < nc; ++i) {
     const int m = i == 0 ? q0 : i == 1 ? q1 : i == 2 ? q2 : q3;
-    wh_pred_chroma (S, m, st, sl, cpb, cpc, cpa);
-    clast = m;
     // lambda * BsSizeUE (g_kiMapModeIntraChroma[mode]): DC* -> 1 bit, H/V -> 3, Plane -> 5
     const int bits = (m == WH_C_H || m == WH_C_V) ? 3 : (m == WH_C_P) ? 5 : 1;
-    const int c = wh_cost_chroma (S, use_satd) + lambda * bits;
-    if (c < cbest_cost) { cbest_cost = c; cbest = m; }
+    const int c = (i == 0 ? cc0 : i == 1 ? cc1 : i == 2 ? cc2 : cc3) + lambda * bits;
+    if (c < cbest_cost) { cbest_cost = c; cbest = m; cidx = i; }
   }
-  if (clast != cbest) wh_pred_chroma (S, cbest, st, sl, cpb, cpc, cpa);
+  WV_LANES_BEGIN (lane)
+  if ((lane >> 5) == (cidx & 1)) {
+    WH_CPOS (lane);
+    * (uint32_t*)&S.pred_c[pl_ * 64 + ((bb_ >> 1) * 4 + r_) * 8 + (bb_ & 1) * 4] = (uint32_t) ((cidx & 2) ? WV_LOWN (pr1, lane) : WV_LOWN (pr0, lane));
+  }
+  WV_LANES_END
+#undef WH_CPOS
+#undef WH_CENC
   int cbp_c = wh_encrec_chroma (S, qpc, 1);
   wh_idct_chroma (S);
   if (mb_type == WH_MB_I4x4 && stale_cbp) {      // WhMbCtl::stale_cbp: only Intra4x4 keeps what an earlier pass left

@@ -82,6 +82,9 @@
            _s += abs (_u0 + _u1) + abs (_u2 + _u3) + abs (_u2 - _u3) + abs (_u0 - _u1); } \
          _t += (_s + 1) >> 1; }                                    \
        (dst) = _t; } while (0)
+// the same with one sum per half of the wave (lanes 0..31 / 32..63): two candidates side by side
+#define WV_SATD_ROWS_HALVES(dA, dB, lane, active, enc4, pred4)    \
+  do { WV_SATD_ROWS (dA, lane, (lane < 32) && (active), enc4, pred4); WV_SATD_ROWS (dB, lane, (lane >= 32) && (active), enc4, pred4); } while (0)
 // Variants for several reductions in a row whose per-lane operands overlap: WV_DECLARE_LANE names ONE lane id for all of
 // them so that the compiler can share the common loads (each plain macro re-materialises its own opaque lane id).
 #define WV_DECLARE_LANE(lane) ((void)0)
@@ -256,6 +259,10 @@ WH_FN int wh_satd_rows (int lane, bool active, uint32_t e, uint32_t p) {
 }
 #define WV_SATD_ROWS(dst, lane, active, enc4, pred4)              \
   do { const int lane = wh_lane_id(); (dst) = wh_satd_rows (lane, (active), (enc4), (pred4)); } while (0)
+#define WV_SATD_ROWS_HALVES(dA, dB, lane, active, enc4, pred4)    \
+  do { const int lane = wh_lane_id(); int _v = wh_satd_quad (lane, (enc4), (pred4)); _v = (active) ? (_v + 1) >> 1 : 0;     /* every lane of a quad holds its block's sum */ \
+       _v += WH_DPP (_v, 0x141); _v += WH_DPP (_v, 0x140);         \
+       (dA) = __builtin_amdgcn_readlane (_v, 0) + __builtin_amdgcn_readlane (_v, 16); (dB) = __builtin_amdgcn_readlane (_v, 32) + __builtin_amdgcn_readlane (_v, 48); } while (0)
 #define WV_DECLARE_LANE(lane) const int lane = wh_lane_id()
 #define WV_SATD_ROWS_SHARED(dst, lane, active, enc4, pred4) do { (dst) = wh_satd_rows (lane, (active), (enc4), (pred4)); } while (0)
 #define WV_SATD_ROWS4_SHARED(d0, d1, d2, d3, lane, active, enc4, p0, p1, p2, p3) \
