@@ -41,16 +41,16 @@ struct SessionCore {
   // packed records (common/compact.h): what a session GROUP copies back instead of the full records
   uint8_t* d_compact = nullptr;
   uint32_t* d_compact_off = nullptr;
-  std::vector<uint8_t> h_compact;
-  std::vector<uint32_t> h_compact_off;
+  WhHostVec<uint8_t> h_compact;
+  WhHostVec<uint32_t> h_compact_off;
   bool use_compact = false;
   uint32_t* d_order = nullptr;
   int32_t* d_bands = nullptr;
   uint32_t* d_dbflags = nullptr;
   uint32_t db_gen = 0;
   size_t rec_alloc_bytes = 0, src_bytes = 0, ysz = 0, csz = 0;
-  std::vector<uint8_t> h_src;
-  std::vector<WhMbRecord> h_records;
+  WhHostVec<uint8_t> h_src;
+  WhHostVec<WhMbRecord> h_records;
   std::vector<uint8_t> bs;
   std::vector<int32_t> nal_len;
   int frame_index = 0, frame_num = 0, idr_pic_id = 0;
@@ -63,7 +63,7 @@ struct SessionCore {
   // per-MB QP offsets of the picture being encoded: all zero (and not passed to the device) unless a macroblock had to
   // be re-encoded after a CAVLC level overflow (svc_encode_slice.cpp:572-576,1863-1867)
   WhMbCtl* d_mb_ctl = nullptr;        // WhPicJob::mb_ctl
-  std::vector<WhMbCtl> h_mb_ctl;
+  WhHostVec<WhMbCtl> h_mb_ctl;
   bool qp_map_in_use = false;
   int overflow_mb = -1;               // set by finish_frame when it returns WELSHIP_ERR_VLC_OVERFLOW
   int overflow_qp = 0;                // uiLumaQp of that macroblock when the overflow was detected
@@ -83,15 +83,15 @@ struct SessionCore {
   int depth = 1;                      // buffer sets = steps in flight at most (1 + the steps the device runs ahead)
   bool pipelined = false;
   uint8_t* d_compact_n[WH_PIPE_MAX_AHEAD] = {};        // buffer sets 1 .. (set 0: the members every group has)
-  std::vector<uint8_t> h_compact_n[WH_PIPE_MAX_AHEAD];
-  std::vector<uint8_t> h_src_n[WH_PIPE_MAX_AHEAD];
+  WhHostVec<uint8_t> h_compact_n[WH_PIPE_MAX_AHEAD];
+  WhHostVec<uint8_t> h_src_n[WH_PIPE_MAX_AHEAD];
   uint8_t* d_planar_n[WH_PIPE_MAX_AHEAD] = {};         // upload targets (the batch tiling pass of step k reads one while later steps are uploaded)
   int pbuf = 0;                       // which set the picture being submitted uses
   uint8_t* dcompact (int b) const { return b ? d_compact_n[b - 1] : d_compact; }
   uint32_t* dcompact_off (int b) const { return x_doff[b] ? x_doff[b] : d_compact_off; }
-  std::vector<uint8_t>& hcompact (int b) { return b ? h_compact_n[b - 1] : h_compact; }
+  WhHostVec<uint8_t>& hcompact (int b) { return b ? h_compact_n[b - 1] : h_compact; }
   uint32_t* hcompact_off (int b) { return x_hoff[b] ? x_hoff[b] : h_compact_off.data(); }
-  std::vector<uint8_t>& hsrc (int b) { return b ? h_src_n[b - 1] : h_src; }
+  WhHostVec<uint8_t>& hsrc (int b) { return b ? h_src_n[b - 1] : h_src; }
   uint8_t* planar (int b) const { return b ? d_planar_n[b - 1] : d_src_planar; }
   // pipelined groups: the offset tables of all sessions are slices of one device / one page-locked host array per buffer set (one copy
   // brings all of them), owned by the group
@@ -240,13 +240,13 @@ struct SessionCore {
     for (int i = 0; i < s.num_slices; ++i) wh_build_mb_order (mb_w, s.slice_first_mb[i], s.slice_first_mb[i + 1], order.data() + s.slice_first_mb[i], band);
     wh_build_mb_order (mb_w, 0, num_mb, order.data() + num_mb);
     // deblocking bands: after the slice fall-backs above, i.e. for the idc the device really runs
-    std::vector<int32_t> bands (3 * (size_t) (mb_h + s.num_slices) + 1);
+    WhHostVec<int32_t> bands (3 * (size_t) (mb_h + s.num_slices) + 1);
     const int brows = WH_DB_BAND_ROWS;
     const bool by_slice = true;           // bands confined to slices also with idc 0 (profiles/r03_deblock_bands.txt)
     const int nb = wh_build_db_bands (mb_w, mb_h, s.num_slices, s.slice_first_mb, s.deblock_idc, brows, bands.data(), (int)bands.size(), by_slice);
     if (nb < 1) { set_err ("deblocking band table"); release(); return WELSHIP_ERR_UNKNOWN; }
     for (int b = 0; b < nb; ++b) wh_build_mb_order (mb_w, bands[b], bands[b + 1], order.data() + 2 * (size_t)num_mb + bands[b]);
-    std::vector<uint32_t> order32 (order.begin(), order.end());      // 32-bit on the device (scalar loads)
+    WhHostVec<uint32_t> order32 (order.begin(), order.end());      // 32-bit on the device (scalar loads)
     order32.resize ((size_t)num_mb * 4 + 1);                          // + the whole-picture deblocking order as items of one or two macroblocks (common/mb_order.h)
     wh_build_db_pair_items (mb_w, mb_h, wh::db_pair_min_len(), order32.data() + 3 * (size_t)num_mb);
     d_order = (uint32_t*)A (order32.size() * 4);
@@ -708,7 +708,7 @@ struct SessionCore {
     const int w = prm.iPicWidth, h = prm.iPicHeight;
     if (bytes < (size_t)w * h * 3 / 2) return WELSHIP_ERR_INIT_PARA;
     const WhSeqParams& s = seq;
-    std::vector<uint8_t> tmp (rec_alloc_bytes + 128);
+    WhHostVec<uint8_t> tmp (rec_alloc_bytes + 128);
     const DevPicture& p = pic[ref_of (cur)];     // the picture encoded last
     be->download (tmp.data(), p.base, rec_alloc_bytes + 128);
     be->sync();
@@ -791,7 +791,7 @@ struct WelsHipEncoderGroup {
   long step_no = 0;
   int pending = 0;                    // submitted steps whose pictures have not been entropy-coded yet
   uint32_t* d_off_all[WH_PIPE_MAX_AHEAD + 1] = {};  // the sessions' record offset tables, one array per buffer set
-  std::vector<uint32_t> h_off_all[WH_PIPE_MAX_AHEAD + 1];
+  WhHostVec<uint32_t> h_off_all[WH_PIPE_MAX_AHEAD + 1];
   std::vector<void*> dl_ev;           // one event per session: its records have arrived
   void* step_ev[WH_PIPE_MAX_AHEAD + 1] = {};        // per buffer set: the kernels of the step that uses it have run
   void* up_ev[2][WH_PIPE_MAX_AHEAD + 1] = {};       // per upload queue and buffer set: the transfers out of its staging buffers are done

@@ -12,6 +12,7 @@
 #include <thread>
 #include <chrono>
 #include <vector>
+#include <new>
 #include <queue>
 #include <algorithm>
 #include <stdlib.h>
@@ -20,6 +21,28 @@
 #include "../common/mb_order.h"
 #include "../common/gom_rc.h"
 #include "entropy_cavlc.h"
+
+// Host buffers that are the source or the destination of a device copy get pages of their own.  The HIP runtime pins the pages of a pageable buffer for a large
+// hipMemcpyAsync -- read-only when the buffer is the copy's SOURCE -- and keeps them pinned until the stream has drained.  Two such buffers that share a page (the tail
+// of one and the head of the next on the brk heap: glibc serves even multi-megabyte vectors from there once a process has freed a few large blocks) then let a
+// device-to-host copy write into a page the device has mapped read-only, and the runtime aborts the process: "Memory access fault by GPU ... Write access to a
+// read-only page" (round 6: seen once in four runs of the GPU tier's first files with one build of the library and never with another -- it only depends on where the
+// heap puts the vectors).  Page-aligned, page-padded blocks cannot share a page with anything.
+template <class T> struct WhPageAlloc {
+  using value_type = T;
+  WhPageAlloc() = default;
+  template <class U> WhPageAlloc (const WhPageAlloc<U>&) {}
+  T* allocate (size_t n) {
+    const size_t bytes = (n * sizeof (T) + 4095) & ~ (size_t)4095;
+    void* p = aligned_alloc (4096, bytes ? bytes : 4096);
+    if (!p) throw std::bad_alloc();
+    return (T*)p;
+  }
+  void deallocate (T* p, size_t) { free (p); }
+  template <class U> bool operator== (const WhPageAlloc<U>&) const { return true; }
+  template <class U> bool operator!= (const WhPageAlloc<U>&) const { return false; }
+};
+template <class T> using WhHostVec = std::vector<T, WhPageAlloc<T>>;
 #include "headers.h"
 #include "../common/compact.h"
 

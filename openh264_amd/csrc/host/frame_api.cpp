@@ -127,30 +127,30 @@ struct WelsHipFrameCtx {
       memcpy (v + (size_t)r * seq.src_stride_c, p[2] + (size_t)r * stride[2], (size_t)mb_w * 8);
     }
   }
-  std::vector<uint8_t> h_src;
+  WhHostVec<uint8_t> h_src;
   WhMbRecord* d_records = nullptr;
   uint8_t* d_rec_blk = nullptr;       // (SessionCore::d_rec_blk)
   // what the last WelsHipFrameVaa call left on the device for WelsHipFrameBgd: the pair's keys and pool slots, whether the background statistics were computed
   const void* vaa_cur_key = nullptr; const void* vaa_ref_key = nullptr; int vaa_cslot = -1, vaa_rslot = -1, vaa_queue = 0; bool vaa_has_bgd = false;
   uint64_t vaa_cur_sum = 0, vaa_ref_sum = 0;      // what the two slots held when the statistics were made (SrcSlot::luma_sum): a reused slot fails WelsHipFrameBgd
   int8_t* d_bgd_calc = nullptr;       // WelsHipFrameBgd's result (one flag per macroblock)
-  std::vector<int8_t> h_bgd_calc;
+  WhHostVec<int8_t> h_bgd_calc;
   uint8_t* d_skew = nullptr;          // pre-analysis of a picture whose width is no multiple of 16: the two luma planes at the caller's stride (WelsHipFrameVaa)
-  std::vector<uint8_t> h_skew;
+  WhHostVec<uint8_t> h_skew;
   size_t skew_bytes = 0;
-  std::vector<WhMbRecord> h_records;
+  WhHostVec<WhMbRecord> h_records;
   // packed records of whole-picture calls (WelsHipFrameJob::bPackedRecords; common/compact.h): device stream + offsets, page-locked host copies.
   // The host copy is brought back in one go up to `compact_est` bytes (a little more than the previous picture's size); the rare rest follows.
   uint8_t* d_compact = nullptr;
   uint32_t* d_compact_off = nullptr;
-  std::vector<uint8_t> h_compact;
-  std::vector<uint32_t> h_coff;
+  WhHostVec<uint8_t> h_compact;
+  WhHostVec<uint32_t> h_coff;
   size_t compact_est = 0, compact_got = 0;
   WelsHipPackedRecords packed_view = {nullptr, nullptr};
-  std::vector<uint8_t> h_pic;
+  WhHostVec<uint8_t> h_pic;
   // page-locked staging for the small per-picture arrays of the caller (pageable copies block on the queue: with the shared
   // lock held that stalls every other session): VAA SADs | pSadCost in | inter-layer hints | background flags, and pSadCost out
-  std::vector<uint8_t> h_aux, h_sad_out;
+  WhHostVec<uint8_t> h_aux, h_sad_out;
   size_t aux_vaa = 0, aux_sad = 0, aux_il = 0, aux_bgd = 0;
   int h_pic_of = -1;                     // the device picture h_pic holds (copied back with the batch), or -1
   FrameKey* last_key = nullptr;          // the key of this context's last picture, and when it was submitted (FrameShared::gather_us)
@@ -192,7 +192,7 @@ struct WelsHipFrameCtx {
   uint32_t* d_dbflags = nullptr;
   uint32_t db_gen = 0;
   WhMbCtl* d_mb_ctl = nullptr;
-  std::vector<WhMbCtl> h_mb_ctl;
+  WhHostVec<WhMbCtl> h_mb_ctl;
   int32_t* d_sad_cost0 = nullptr;        // the layer's pSadCost[0] array (persists across pictures)
   int32_t* d_sad_cost0_new = nullptr;    // the copy the picture being coded writes (WhPicJob::sad_cost0_out): size-limited slices swap it in when the picture
                                          // is complete, whole-picture calls when the NEXT picture begins (a bRetry pass reads the previous picture's again)
@@ -267,11 +267,11 @@ struct WelsHipFrameCtx {
       std::vector<uint16_t> order ((size_t)num_mb * 3);
       for (int i = 0; i < n; ++i) wh_build_mb_order (mb_w, first[i], first[i + 1], order.data() + first[i]);
       wh_build_mb_order (mb_w, 0, num_mb, order.data() + num_mb);
-      std::vector<int32_t> bands (3 * (size_t) (mb_h + n) + 1);
+      WhHostVec<int32_t> bands (3 * (size_t) (mb_h + n) + 1);
       const int nb = wh_build_db_bands (mb_w, mb_h, n, first, idc, WH_DB_BAND_ROWS, bands.data(), (int)bands.size());
       if (nb < 1) { set_err ("deblocking band table"); return WELSHIP_ERR_UNKNOWN; }
       for (int b = 0; b < nb; ++b) wh_build_mb_order (mb_w, bands[b], bands[b + 1], order.data() + 2 * (size_t)num_mb + bands[b]);
-      std::vector<uint32_t> order32 (order.begin(), order.end());
+      WhHostVec<uint32_t> order32 (order.begin(), order.end());
       order32.resize ((size_t)num_mb * 4 + 1);                        // + the whole-picture deblocking order as items of one or two macroblocks (common/mb_order.h)
       wh_build_db_pair_items (mb_w, mb_h, wh::db_pair_min_len(), order32.data() + 3 * (size_t)num_mb);
       up->d_order = (uint32_t*)be->alloc (order32.size() * 4);
@@ -1193,7 +1193,7 @@ int WelsHipFrameGetMbStates (WelsHipFrameCtx* c, int pic, void* dst, size_t byte
 int WelsHipFrameGetPicture (WelsHipFrameCtx* c, int pic, uint8_t* const dst[3], const int32_t stride[3]) {
   if (!c || !c->be || pic < 0 || pic >= (int)c->pics.size() || !dst || !stride) return WELSHIP_ERR_INIT_PARA;
   const WhSeqParams& s = c->seq;
-  std::vector<uint8_t>& tmp = c->h_pic;
+  WhHostVec<uint8_t>& tmp = c->h_pic;
   const DevPicture& p = c->pics[pic];
   if (c->h_pic_of != pic) {              // not the picture that came back with the last batch (GOM-coded pictures, older pictures)
     std::unique_lock<std::mutex> lock (c->sh->mu);

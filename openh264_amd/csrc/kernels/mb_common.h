@@ -48,12 +48,20 @@ typedef struct WhMbLds {
 // The table row is wave-uniform (QP) and only the position class varies per lane: three uniform loads (scalar cache,
 // lgkmcnt) + selects instead of a per-lane gather from global memory (vmcnt, which would also serialise behind any
 // LDS-DMA prefetch in flight).
-WH_FN int wh_sel3 (int a, int b, int d, int pos) { const int c = WH_POSCLASS (pos); return c == 0 ? a : c == 1 ? b : d; }
+// (by the parities of the position's row and column, not by the class number: wherever one of the two is a compile-time constant after unrolling -- a lane's four
+//  coefficients of a row, or of a column -- the lookup is ONE v_cndmask on a compare shared by all of the lane's lookups; by class number it was two compares, two selects
+//  and the class arithmetic per coefficient, more than the quantisation itself: round 6)
+WH_FN int wh_sel3_rc (int a, int b, int d, bool row_odd, bool col_odd) { return row_odd ? (col_odd ? d : b) : (col_odd ? b : a); }
+WH_FN int wh_sel3 (int a, int b, int d, int pos) { return wh_sel3_rc (a, b, d, ((pos >> 2) & 1) != 0, (pos & 1) != 0); }
 WH_FN int wh_mf (int qp, int pos) { return wh_sel3 (kWhQuantMF[qp * 3], kWhQuantMF[qp * 3 + 1], kWhQuantMF[qp * 3 + 2], pos); }
 WH_FN int wh_ff_row (int ffrow, int pos) { return wh_sel3 (kWhQuantFF[ffrow * 3], kWhQuantFF[ffrow * 3 + 1], kWhQuantFF[ffrow * 3 + 2], pos); }
 WH_FN int wh_ff_intra (int qp, int pos) { return wh_ff_row (qp + 6, pos); }
 WH_FN int wh_ff_inter (int qp, int pos) { return wh_ff_row (qp, pos); }
 WH_FN int wh_dq (int qp, int pos) { return wh_sel3 (kWhDequant[qp * 3], kWhDequant[qp * 3 + 1], kWhDequant[qp * 3 + 2], pos); }
+// position (row r, column c) of a 4x4 block with r, c in 0..3 given separately (a caller whose lane index is only known to be < 4 by a guard)
+WH_FN int wh_mf_rc (int qp, int r, int c) { return wh_sel3_rc (kWhQuantMF[qp * 3], kWhQuantMF[qp * 3 + 1], kWhQuantMF[qp * 3 + 2], (r & 1) != 0, (c & 1) != 0); }
+WH_FN int wh_ff_intra_rc (int qp, int r, int c) { return wh_sel3_rc (kWhQuantFF[(qp + 6) * 3], kWhQuantFF[(qp + 6) * 3 + 1], kWhQuantFF[(qp + 6) * 3 + 2], (r & 1) != 0, (c & 1) != 0); }
+WH_FN int wh_dq_rc (int qp, int r, int c) { return wh_sel3_rc (kWhDequant[qp * 3], kWhDequant[qp * 3 + 1], kWhDequant[qp * 3 + 2], (r & 1) != 0, (c & 1) != 0); }
 
 // ---- forward DCT of N 4x4 blocks: res[blk*16 + r*4 + c] = T(enc - pred) -------------------------
 // `nblk` blocks; block b covers enc rows/cols given by (ex[b],ey[b]) through the callbacks below.
@@ -378,7 +386,7 @@ WH_FN int wh_encrec_i4 (WhMbLds& S, int b, int pred_slot, int qp, int8_t rem) {
     int cnt = 0;
     for (int k = 0; k < 4; ++k) {
       const int pos = k * 4 + lane;
-      const int16_t q = wh_quant1_t (o[k], wh_ff_intra (qp, pos), wh_mf (qp, pos));
+      const int16_t q = wh_quant1_t (o[k], wh_ff_intra_rc (qp, k, lane), wh_mf_rc (qp, k, lane));
       S.res[b * 16 + pos] = q;
       cnt += q != 0;
     }
@@ -392,8 +400,8 @@ WH_FN int wh_encrec_i4 (WhMbLds& S, int b, int pred_slot, int qp, int8_t rem) {
     if (lane < 4) {                     // dequant (WelsDequant4x4_c, int16 wrap) + horizontal inverse
       const int16_t* c = &S.res[b * 16 + lane * 4];
       int16_t t0, t1, t2, t3;
-      wh_idct4_h ((int16_t) (c[0] * wh_dq (qp, lane * 4 + 0)), (int16_t) (c[1] * wh_dq (qp, lane * 4 + 1)),
-                  (int16_t) (c[2] * wh_dq (qp, lane * 4 + 2)), (int16_t) (c[3] * wh_dq (qp, lane * 4 + 3)), &t0, &t1, &t2, &t3);
+      wh_idct4_h ((int16_t) (c[0] * wh_dq_rc (qp, lane, 0)), (int16_t) (c[1] * wh_dq_rc (qp, lane, 1)),
+                  (int16_t) (c[2] * wh_dq_rc (qp, lane, 2)), (int16_t) (c[3] * wh_dq_rc (qp, lane, 3)), &t0, &t1, &t2, &t3);
       int16_t* t = &S.tmp[lane * 4];
       t[0] = t0; t[1] = t1; t[2] = t2; t[3] = t3;
     }
@@ -454,7 +462,7 @@ WH_FN void wh_encrec_i4_pair (WhMbLds& S, int bA, int bB, int slotA, int slotB, 
     int cnt = 0;
     for (int k = 0; k < 4; ++k) {
       const int pos = k * 4 + ll;
-      const int16_t q = wh_quant1_t (o[k], wh_ff_intra (qp, pos), wh_mf (qp, pos));
+      const int16_t q = wh_quant1_t (o[k], wh_ff_intra_rc (qp, k, ll), wh_mf_rc (qp, k, ll));
       S.res[b * 16 + pos] = q;
       cnt += q != 0;
     }
@@ -472,8 +480,8 @@ WH_FN void wh_encrec_i4_pair (WhMbLds& S, int bA, int bB, int slotA, int slotB, 
       if (ll < 4) {                     // dequant (WelsDequant4x4_c, int16 wrap) + horizontal inverse
         const int16_t* c = &S.res[b * 16 + ll * 4];
         int16_t t0, t1, t2, t3;
-        wh_idct4_h ((int16_t) (c[0] * wh_dq (qp, ll * 4 + 0)), (int16_t) (c[1] * wh_dq (qp, ll * 4 + 1)),
-                    (int16_t) (c[2] * wh_dq (qp, ll * 4 + 2)), (int16_t) (c[3] * wh_dq (qp, ll * 4 + 3)), &t0, &t1, &t2, &t3);
+        wh_idct4_h ((int16_t) (c[0] * wh_dq_rc (qp, ll, 0)), (int16_t) (c[1] * wh_dq_rc (qp, ll, 1)),
+                    (int16_t) (c[2] * wh_dq_rc (qp, ll, 2)), (int16_t) (c[3] * wh_dq_rc (qp, ll, 3)), &t0, &t1, &t2, &t3);
         int16_t* t = &S.tmp[h * 16 + ll * 4];
         t[0] = t0; t[1] = t1; t[2] = t2; t[3] = t3;
       }
